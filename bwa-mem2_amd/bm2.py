@@ -1,0 +1,253 @@
+"""ctypes binding of libbm2.so (the C ABI declared in include/bm2.h).
+
+Host-side plumbing only: numpy arrays in, numpy arrays out.  There is no CPU fallback --
+if the library or a HIP device is missing every call raises.
+(The package directory is `bwa-mem2_amd/`; put it on sys.path and `import bm2`.)
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbm2.so")
+
+BM2_OK, BM2_ENODEV, BM2_ENOMEM, BM2_EINVAL, BM2_ECAP, BM2_EUNSUP, BM2_EIO = 0, -1, -2, -3, -4, -5, -6
+
+SMEM_DT = np.dtype([("rid", "<u4"), ("m", "<u4"), ("n", "<u4"), ("pad", "<u4"), ("k", "<i8"), ("l", "<i8"), ("s", "<i8")])
+SEQPAIR_DT = np.dtype([(n, "<i4") for n in ("idr", "idq", "id", "len1", "len2", "h0", "seqid", "regid",
+                                             "score", "tle", "gtle", "qle", "gscore", "max_off")])
+REG_DT = np.dtype([("rb", "<i8"), ("re", "<i8"), ("qb", "<i4"), ("qe", "<i4"), ("rid", "<i4"), ("score", "<i4"),
+                   ("truesc", "<i4"), ("w", "<i4"), ("seedcov", "<i4"), ("seedlen0", "<i4"), ("frac_rep", "<f4"),
+                   ("pad", "<i4")])
+assert SMEM_DT.itemsize == 40 and SEQPAIR_DT.itemsize == 56 and REG_DT.itemsize == 56
+
+
+class IndexDesc(C.Structure):
+    _fields_ = [("ref_len", C.c_int64), ("count", C.c_int64 * 5), ("sentinel_index", C.c_int64),
+                ("cp_occ", C.c_void_p), ("sa_ms_byte", C.c_void_p), ("sa_ls_word", C.c_void_p),
+                ("ref_string", C.c_void_p), ("l_pac", C.c_int64), ("n_seqs", C.c_int32),
+                ("ann_offset", C.c_void_p), ("ann_len", C.c_void_p), ("ann_is_alt", C.c_void_p)]
+
+
+class Opt(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("a", "b", "o_del", "e_del", "o_ins", "e_ins", "pen_clip5", "pen_clip3",
+                                         "w", "zdrop", "min_seed_len", "split_width", "max_occ", "max_chain_gap",
+                                         "min_chain_weight", "max_chain_extend")] + \
+               [("max_mem_intv", C.c_int64), ("split_factor", C.c_float), ("mask_level", C.c_float),
+                ("drop_ratio", C.c_float), ("mask_level_redun", C.c_float), ("mat", C.c_int8 * 25),
+                ("pad", C.c_int8 * 3)]
+
+
+class SwParams(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("o_del", "e_del", "o_ins", "e_ins", "zdrop", "end_bonus", "w_match",
+                                         "w_mismatch")] + [("mat", C.c_int8 * 25), ("pad", C.c_int8 * 3)]
+
+
+class Reads(C.Structure):
+    _fields_ = [("n_reads", C.c_int32), ("enc", C.c_void_p), ("off", C.c_void_p), ("len", C.c_void_p)]
+
+
+class Stats(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("n_reads", "n_bases", "n_smem", "n_sa", "n_chain", "n_reg_raw", "n_reg",
+                                         "n_ext", "n_lf", "n_sw_cells", "n_sw_tasks")]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+EXPORTS = ["bm2_index_load", "bm2_index_free", "bm2_opt_init", "bm2_opt_fill_scmat", "bm2_create", "bm2_destroy",
+           "bm2_last_error", "bm2_device_count", "bm2_bsw", "bm2_smem", "bm2_sal", "bm2_seed_chain_extend",
+           "bm2_batch_upload", "bm2_batch_run", "bm2_batch_stats", "bm2_batch_download", "bm2_batch_kernel_ms"]
+
+_lib = None
+
+
+def build():
+    """Compile libbm2.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(_HERE, "csrc")])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libbm2.so is not built (run __graft_entry__.build()); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        L.bm2_last_error.restype = C.c_char_p
+        L.bm2_create.restype = C.c_void_p
+        L.bm2_create.argtypes = [C.c_int, C.c_void_p]
+        L.bm2_destroy.argtypes = [C.c_void_p]
+        L.bm2_index_load.argtypes = [C.c_char_p, C.POINTER(IndexDesc)]
+        L.bm2_index_free.argtypes = [C.POINTER(IndexDesc)]
+        L.bm2_opt_init.argtypes = [C.POINTER(Opt)]
+        L.bm2_opt_fill_scmat.argtypes = [C.POINTER(Opt)]
+        L.bm2_bsw.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
+                              C.POINTER(SwParams)]
+        L.bm2_smem.argtypes = [C.c_void_p, C.POINTER(Reads), C.POINTER(Opt), C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+        L.bm2_sal.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+        L.bm2_seed_chain_extend.argtypes = [C.c_void_p, C.POINTER(Reads), C.POINTER(Opt), C.c_void_p, C.c_int64,
+                                            C.c_void_p, C.POINTER(C.c_int64), C.POINTER(Stats)]
+        L.bm2_batch_upload.argtypes = [C.c_void_p, C.POINTER(Reads)]
+        L.bm2_batch_run.argtypes = [C.c_void_p, C.POINTER(Opt)]
+        L.bm2_batch_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+        L.bm2_batch_download.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_int64)]
+        L.bm2_batch_kernel_ms.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.c_void_p]
+        _lib = L
+    return _lib
+
+
+class Bm2Error(RuntimeError):
+    pass
+
+
+def _chk(rc, what):
+    if rc != BM2_OK:
+        raise Bm2Error("%s failed (%d): %s" % (what, rc, lib().bm2_last_error().decode()))
+
+
+def default_opt(**kw):
+    o = Opt()
+    lib().bm2_opt_init(C.byref(o))
+    for k, v in kw.items():
+        setattr(o, k, v)
+    lib().bm2_opt_fill_scmat(C.byref(o))
+    return o
+
+
+def sw_params(opt, end_bonus):
+    p = SwParams()
+    p.o_del, p.e_del, p.o_ins, p.e_ins, p.zdrop = opt.o_del, opt.e_del, opt.o_ins, opt.e_ins, opt.zdrop
+    p.end_bonus, p.w_match, p.w_mismatch = end_bonus, opt.a, opt.b
+    for i in range(25):
+        p.mat[i] = opt.mat[i]
+    return p
+
+
+def _reads_struct(enc, off, ln):
+    enc = np.ascontiguousarray(enc, np.uint8)
+    off = np.ascontiguousarray(off, np.int64)
+    ln = np.ascontiguousarray(ln, np.int32)
+    r = Reads(len(ln), enc.ctypes.data, off.ctypes.data, ln.ctypes.data)
+    return r, (enc, off, ln)
+
+
+class Context:
+    """One per GPU; mirrors the lifetime of the reference's FMI_search + ref_string (fastmap.cpp:848-888)."""
+
+    def __init__(self, device=0, index_prefix=None):
+        L = lib()
+        self._desc = None
+        self.h = None
+        if index_prefix is not None:
+            self._desc = IndexDesc()
+            _chk(L.bm2_index_load(index_prefix.encode(), C.byref(self._desc)), "bm2_index_load")
+        self.h = L.bm2_create(device, C.byref(self._desc) if self._desc is not None else None)
+        if not self.h:
+            msg = L.bm2_last_error().decode()
+            if self._desc is not None:
+                L.bm2_index_free(C.byref(self._desc))
+            raise Bm2Error("bm2_create failed: " + msg)
+
+    @property
+    def l_pac(self):
+        return self._desc.l_pac if self._desc is not None else 0
+
+    def close(self):
+        if self.h:
+            lib().bm2_destroy(self.h)
+            self.h = None
+        if self._desc is not None:
+            lib().bm2_index_free(C.byref(self._desc))
+            self._desc = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # S1
+    def bsw(self, pairs, ref, qer, w, params):
+        pairs = np.ascontiguousarray(pairs, SEQPAIR_DT)
+        ref = np.ascontiguousarray(ref, np.uint8)
+        qer = np.ascontiguousarray(qer, np.uint8)
+        _chk(lib().bm2_bsw(self.h, pairs.ctypes.data, ref.ctypes.data, len(ref), qer.ctypes.data, len(qer), len(pairs), w,
+                           C.byref(params)), "bm2_bsw")
+        return pairs
+
+    # S2
+    def smem(self, enc, off, ln, opt, cap=None):
+        r, keep = _reads_struct(enc, off, ln)
+        cap = cap or max(1024, 64 * len(keep[2]))
+        while True:
+            out = np.zeros(cap, SMEM_DT)
+            n = C.c_int64(0)
+            rc = lib().bm2_smem(self.h, C.byref(r), C.byref(opt), out.ctypes.data, cap, C.byref(n))
+            if rc == BM2_ECAP:
+                cap = int(n.value)
+                continue
+            _chk(rc, "bm2_smem")
+            return out[:n.value]
+
+    def sal(self, smems, max_occ, cap=None):
+        smems = np.ascontiguousarray(smems, SMEM_DT)
+        cap = cap or int(np.minimum(smems["s"], max_occ).sum()) + 16
+        out = np.zeros(cap, np.int64)
+        n = C.c_int64(0)
+        _chk(lib().bm2_sal(self.h, smems.ctypes.data, len(smems), max_occ, out.ctypes.data, cap, C.byref(n)), "bm2_sal")
+        return out[:n.value]
+
+    # S3
+    def seed_chain_extend(self, enc, off, ln, opt, cap=None):
+        r, keep = _reads_struct(enc, off, ln)
+        nr = len(keep[2])
+        cap = cap or max(1024, 16 * nr)
+        reg_off = np.zeros(nr + 1, np.int64)
+        st = Stats()
+        while True:
+            regs = np.zeros(cap, REG_DT)
+            n = C.c_int64(0)
+            rc = lib().bm2_seed_chain_extend(self.h, C.byref(r), C.byref(opt), regs.ctypes.data, cap, reg_off.ctypes.data,
+                                             C.byref(n), C.byref(st))
+            if rc == BM2_ECAP:
+                cap = int(n.value)
+                continue
+            _chk(rc, "bm2_seed_chain_extend")
+            return regs[:n.value], reg_off, st.as_dict()
+
+    # split S3 (device-resident timing)
+    def batch_upload(self, enc, off, ln):
+        r, keep = _reads_struct(enc, off, ln)
+        _chk(lib().bm2_batch_upload(self.h, C.byref(r)), "bm2_batch_upload")
+        self._n_reads = len(keep[2])
+
+    def batch_run(self, opt):
+        _chk(lib().bm2_batch_run(self.h, C.byref(opt)), "bm2_batch_run")
+
+    def batch_stats(self):
+        st = Stats()
+        _chk(lib().bm2_batch_stats(self.h, C.byref(st)), "bm2_batch_stats")
+        return st.as_dict()
+
+    def batch_download(self, cap=None):
+        nr = self._n_reads
+        cap = cap or max(1024, 16 * nr)
+        reg_off = np.zeros(nr + 1, np.int64)
+        while True:
+            regs = np.zeros(cap, REG_DT)
+            n = C.c_int64(0)
+            rc = lib().bm2_batch_download(self.h, regs.ctypes.data, cap, reg_off.ctypes.data, C.byref(n))
+            if rc == BM2_ECAP:
+                cap = int(n.value)
+                continue
+            _chk(rc, "bm2_batch_download")
+            return regs[:n.value], reg_off
+
+    def batch_kernel_ms(self):
+        ms = (C.c_float * 32)()
+        names = (C.c_char_p * 32)()
+        n = C.c_int32(0)
+        _chk(lib().bm2_batch_kernel_ms(self.h, ms, 32, C.byref(n), names), "bm2_batch_kernel_ms")
+        return [(names[i].decode(), float(ms[i])) for i in range(n.value)]

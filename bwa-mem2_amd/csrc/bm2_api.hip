@@ -1,0 +1,146 @@
+// bm2_api.hip -- C-ABI glue: context lifetime, error reporting, option defaults, the S1 entry point.
+// (S2/S3 entry points live in pipeline.hip.)
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <new>
+#include "bm2_ctx.h"
+
+static thread_local char g_err[512] = "";
+
+void bm2_set_error(const char *fmt, ...) {
+    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap);
+}
+extern "C" const char *bm2_last_error(void) { return g_err; }
+
+int bm2_check(hipError_t e, const char *what) {
+    if (e == hipSuccess) return BM2_OK;
+    bm2_set_error("%s: %s", what, hipGetErrorString(e));
+    return e == hipErrorOutOfMemory ? BM2_ENOMEM : BM2_ENODEV;
+}
+
+int bm2_reserve(DevBuf &b, size_t bytes) {
+    if (bytes <= b.cap) return BM2_OK;
+    if (b.p) { (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
+    size_t want = bytes + bytes / 4 + 256;
+    int rc = bm2_check(hipMalloc(&b.p, want), "hipMalloc");
+    if (rc != BM2_OK) { b.p = nullptr; return BM2_ENOMEM; }
+    b.cap = want;
+    return BM2_OK;
+}
+void bm2_release(DevBuf &b) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
+
+extern "C" int bm2_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// mem_opt_init, bwamem.cpp:107-143
+extern "C" void bm2_opt_fill_scmat(bm2_opt *o) {     // bwa_fill_scmat, bwa.cpp:248-257
+    int k = 0;
+    for (int i = 0; i < 4; ++i) {
+        for (int j = 0; j < 4; ++j) o->mat[k++] = (int8_t)(i == j ? o->a : -o->b);
+        o->mat[k++] = -1;
+    }
+    for (int j = 0; j < 5; ++j) o->mat[k++] = -1;
+}
+extern "C" void bm2_opt_init(bm2_opt *o) {
+    memset(o, 0, sizeof *o);
+    o->a = 1; o->b = 4; o->o_del = o->o_ins = 6; o->e_del = o->e_ins = 1;
+    o->w = 100; o->zdrop = 100; o->pen_clip5 = o->pen_clip3 = 5;
+    o->max_mem_intv = 20; o->min_seed_len = 19; o->split_width = 10; o->max_occ = 500;
+    o->max_chain_gap = 10000; o->mask_level = 0.50f; o->drop_ratio = 0.50f; o->split_factor = 1.5f;
+    o->mask_level_redun = 0.95f; o->min_chain_weight = 0; o->max_chain_extend = 1 << 30;
+    bm2_opt_fill_scmat(o);
+}
+
+template <class T>
+static int upload(void **dst, const T *src, size_t n, hipStream_t s) {
+    size_t bytes = n * sizeof(T);
+    int rc = bm2_check(hipMalloc(dst, bytes ? bytes : 64), "hipMalloc(index)");
+    if (rc) return rc;
+    if (bytes) rc = bm2_check(hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, s), "hipMemcpy(index)");
+    return rc;
+}
+
+void bm2_batch_destroy(bm2_ctx *c);     // pipeline.hip
+
+extern "C" bm2_ctx *bm2_create(int device, const bm2_index_desc *idx) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        bm2_set_error("no HIP device visible: libbm2 has no CPU fallback");
+        return nullptr;
+    }
+    if (device < 0 || device >= ndev) { bm2_set_error("device %d out of range (%d visible)", device, ndev); return nullptr; }
+    if (bm2_check(hipSetDevice(device), "hipSetDevice")) return nullptr;
+    bm2_ctx *c = new (std::nothrow) bm2_ctx();
+    if (!c) return nullptr;
+    c->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount;
+    if (bm2_check(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "hipStreamCreate")) { delete c; return nullptr; }
+    for (int i = 0; i <= BM2_MAX_TIMERS; i++) (void)hipEventCreate(&c->ev[i]);
+    if (idx) {
+        const int64_t nocc = (idx->ref_len >> 6) + 1, nsa = (idx->ref_len >> 3) + 1;
+        int rc = 0;
+        rc = rc ? rc : upload(&c->d_cp_occ, (const CpOcc *)idx->cp_occ, (size_t)nocc, c->stream);
+        rc = rc ? rc : upload(&c->d_sa_ms, idx->sa_ms_byte, (size_t)nsa, c->stream);
+        rc = rc ? rc : upload(&c->d_sa_ls, idx->sa_ls_word, (size_t)nsa, c->stream);
+        rc = rc ? rc : upload(&c->d_ref, idx->ref_string, (size_t)(2 * idx->l_pac), c->stream);
+        rc = rc ? rc : upload(&c->d_ann_off, idx->ann_offset, (size_t)idx->n_seqs, c->stream);
+        rc = rc ? rc : upload(&c->d_ann_len, idx->ann_len, (size_t)idx->n_seqs, c->stream);
+        rc = rc ? rc : upload(&c->d_ann_alt, idx->ann_is_alt, (size_t)idx->n_seqs, c->stream);
+        rc = rc ? rc : bm2_check(hipStreamSynchronize(c->stream), "index upload");
+        if (rc) { bm2_destroy(c); return nullptr; }
+        DevIndex &ix = c->ix;
+        ix.cp_occ = (const CpOcc *)c->d_cp_occ; ix.sa_ms_byte = (const int8_t *)c->d_sa_ms;
+        ix.sa_ls_word = (const uint32_t *)c->d_sa_ls; ix.ref_string = (const uint8_t *)c->d_ref;
+        ix.ann_offset = (const int64_t *)c->d_ann_off; ix.ann_len = (const int32_t *)c->d_ann_len;
+        ix.ann_is_alt = (const int32_t *)c->d_ann_alt;
+        ix.ref_len = idx->ref_len; ix.l_pac = idx->l_pac; ix.sentinel_index = idx->sentinel_index;
+        for (int i = 0; i < 5; i++) ix.count[i] = idx->count[i] + 1;      // FMI_search.cpp:433-436
+        ix.n_seqs = idx->n_seqs;
+        c->has_index = true;
+    }
+    return c;
+}
+
+extern "C" void bm2_destroy(bm2_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    bm2_batch_destroy(c);
+    void *ps[] = { c->d_cp_occ, c->d_sa_ms, c->d_sa_ls, c->d_ref, c->d_ann_off, c->d_ann_len, c->d_ann_alt };
+    for (void *p : ps) if (p) (void)hipFree(p);
+    bm2_release(c->b_pairs); bm2_release(c->b_ref); bm2_release(c->b_qer); bm2_release(c->b_misc);
+    for (int i = 0; i <= BM2_MAX_TIMERS; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+// ---- S1 --------------------------------------------------------------------------------------------------------
+extern "C" int bm2_bsw(bm2_ctx *c, bm2_seqpair_t *pairs, const uint8_t *ref, int64_t ref_bytes, const uint8_t *qer,
+                       int64_t qer_bytes, int32_t n, int32_t w, const bm2_sw_params *p) {
+    if (!c || !pairs || !p || n < 0 || w < 0 || (n > 0 && (!ref || !qer))) { bm2_set_error("bm2_bsw: bad argument"); return BM2_EINVAL; }
+    if (n == 0) return BM2_OK;
+    if (p->e_del <= 0 || p->e_ins <= 0) { bm2_set_error("bm2_bsw: gap extension penalties must be > 0"); return BM2_EINVAL; }
+    int rc = bm2_check(hipSetDevice(c->device), "hipSetDevice");
+    if (rc) return rc;
+    if ((rc = bm2_reserve(c->b_pairs, (size_t)n * sizeof(bm2_seqpair_t)))) return rc;
+    if ((rc = bm2_reserve(c->b_ref, (size_t)ref_bytes + 64))) return rc;
+    if ((rc = bm2_reserve(c->b_qer, (size_t)qer_bytes + 64))) return rc;
+    SwParams P;
+    P.o_del = p->o_del; P.e_del = p->e_del; P.o_ins = p->o_ins; P.e_ins = p->e_ins; P.zdrop = p->zdrop;
+    P.end_bonus = p->end_bonus; P.max_sc = p->w_match;
+    for (int i = 0; i < 25; i++) P.mat[i] = p->mat[i];
+    hipStream_t s = c->stream;
+    rc = bm2_check(hipMemcpyAsync(c->b_pairs.p, pairs, (size_t)n * sizeof(bm2_seqpair_t), hipMemcpyHostToDevice, s), "H2D pairs");
+    if (!rc) rc = bm2_check(hipMemcpyAsync(c->b_ref.p, ref, (size_t)ref_bytes, hipMemcpyHostToDevice, s), "H2D ref");
+    if (!rc) rc = bm2_check(hipMemcpyAsync(c->b_qer.p, qer, (size_t)qer_bytes, hipMemcpyHostToDevice, s), "H2D qer");
+    if (!rc) rc = bm2_launch_bsw_pairs(c, (bm2_seqpair_t *)c->b_pairs.p, (const uint8_t *)c->b_ref.p, (const uint8_t *)c->b_qer.p, n, w, P, nullptr);
+    if (!rc) rc = bm2_check(hipMemcpyAsync(pairs, c->b_pairs.p, (size_t)n * sizeof(bm2_seqpair_t), hipMemcpyDeviceToHost, s), "D2H pairs");
+    if (!rc) rc = bm2_check(hipStreamSynchronize(s), "bm2_bsw sync");
+    return rc;
+}

@@ -1,0 +1,42 @@
+// bm2_ctx.h -- host-side context of libbm2.so (internal).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include "bm2_dev.h"
+
+// growable device buffer (never shrinks; a chunk-sized workspace is reused across batches)
+struct DevBuf {
+    void  *p = nullptr;
+    size_t cap = 0;
+};
+
+#define BM2_MAX_TIMERS 24
+
+struct bm2_ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    bool has_index = false;
+    DevIndex ix{};
+    // device copies of the index arrays (owned)
+    void *d_cp_occ = nullptr, *d_sa_ms = nullptr, *d_sa_ls = nullptr, *d_ref = nullptr;
+    void *d_ann_off = nullptr, *d_ann_len = nullptr, *d_ann_alt = nullptr;
+    // scratch for the S1/S2 entry points
+    DevBuf b_pairs, b_ref, b_qer, b_misc;
+    // batch state of the S3 path (see pipeline.hip)
+    struct Batch *batch = nullptr;
+    // per-kernel timers of the last bm2_batch_run
+    hipEvent_t ev[BM2_MAX_TIMERS + 1];
+    const char *ev_name[BM2_MAX_TIMERS];
+    int n_ev = 0;
+    bool ev_ready = false;
+    int n_cu = 256;
+};
+
+int  bm2_check(hipError_t e, const char *what);            // -> BM2_OK or BM2_ENODEV (+ message)
+void bm2_set_error(const char *fmt, ...);
+int  bm2_reserve(DevBuf &b, size_t bytes);                  // grow-only device allocation
+void bm2_release(DevBuf &b);
+
+struct SwParams;
+int bm2_launch_bsw_pairs(bm2_ctx *c, bm2_seqpair_t *d_pairs, const uint8_t *d_ref, const uint8_t *d_qer, int n, int w,
+                         const SwParams &P, unsigned long long *d_cells);

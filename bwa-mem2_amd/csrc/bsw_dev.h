@@ -1,0 +1,170 @@
+// bsw_dev.h -- banded affine-gap extension DP, one task per 64-lane wavefront.
+//
+// Semantics = ksw_extend2 (ksw.cpp:432-533) = BandedPairWiseSW::scalarBandedSWA (bandedSWA.cpp:116-237),
+// which the reference's int8/int16 SIMD kernels reproduce lane by lane.  The reference vectorises ACROSS
+// tasks (one pair per SIMD lane); here one wavefront owns one task and vectorises ALONG A ROW:
+//
+//   * lane l of a 64-column chunk owns column j = jb + l of target row i;
+//   * H(i-1,j-1) and E(i,j) live in a per-wave LDS ring indexed by (j mod R): the band [beg,end) of
+//     row i is always inside [i-w, i+w+1], so R >= 2w+4 slots never alias live columns (this is what
+//     keeps 10 kb queries inside a few KB of LDS);
+//   * the row recurrence  F(i,j+1) = max(F(i,j) - e_ins, max(M(i,j) - o_ins - e_ins, 0))  takes M, not H
+//     (bandedSWA.cpp:181-199: "separating H and M"), so T(j) = max(M - oe_ins, 0) does not depend on F and
+//     F is a max-plus prefix scan over the chunk: F(jb+l) = max(f0 - l*e, max_{l'<l}(T(l') + l'*e) - (l-1)*e),
+//     done with 6 DPP row_shr/row_bcast steps instead of a serial loop;
+//   * everything the reference decides once per row -- band clamp to [i-w, i+w+1], first-column h1, gscore at
+//     the query end, the m==0 and z-drop exits, max/max_off, the beg/end shrink from the zero pattern of the
+//     stored row -- is wave-uniform scalar code driven by ballots.
+//
+// Integer DP: no MFMA anywhere (nothing here is a dense contraction).
+#pragma once
+#include "bm2_dev.h"
+
+#define DPP_ROW_SHR(n)   (0x110 + (n))
+#define DPP_WAVE_SHR1    0x138
+#define DPP_ROW_BCAST15  0x142
+#define DPP_ROW_BCAST31  0x143
+#define NEG_BIG          (-(1 << 29))
+
+// lane l <- value of lane l-1; lane 0 <- fill
+static __device__ __forceinline__ int wave_shr1(int v, int fill) {
+    return __builtin_amdgcn_update_dpp(fill, v, DPP_WAVE_SHR1, 0xf, 0xf, false);
+}
+
+// inclusive max-scan over the 64 lanes (identity = ident); all lanes must be active
+static __device__ __forceinline__ int wave_scan_max(int v, int ident) {
+    v = imax(v, __builtin_amdgcn_update_dpp(ident, v, DPP_ROW_SHR(1), 0xf, 0xf, false));
+    v = imax(v, __builtin_amdgcn_update_dpp(ident, v, DPP_ROW_SHR(2), 0xf, 0xf, false));
+    v = imax(v, __builtin_amdgcn_update_dpp(ident, v, DPP_ROW_SHR(4), 0xf, 0xf, false));
+    v = imax(v, __builtin_amdgcn_update_dpp(ident, v, DPP_ROW_SHR(8), 0xf, 0xf, false));
+    v = imax(v, __builtin_amdgcn_update_dpp(ident, v, DPP_ROW_BCAST15, 0xa, 0xf, false));
+    v = imax(v, __builtin_amdgcn_update_dpp(ident, v, DPP_ROW_BCAST31, 0xc, 0xf, false));
+    return v;
+}
+
+static __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+struct SwOut { int score, qle, tle, gtle, gscore, max_off; };
+
+// Pair class of the reference's three BSW entry points (bwamem.cpp:1947-1953, 2304-2313)
+static __device__ __forceinline__ int pair_class(int len1, int len2, int h0, int a) {
+    int minval = h0 + imin(len1, len2) * a;
+    if (len1 < 128 && len2 < 128 && minval < 128) return 8;
+    if (len1 < 32768 && len2 < 32768 && minval < 32768) return 16;
+    return 32;
+}
+
+// Band clamp.  Scalar: bandedSWA.cpp:148-156 (signed, double division).  The int8/int16 wrappers compute the
+// same bound in wrapping unsigned lane arithmetic with an integer division (bandedSWA.cpp:635-653, 1333-1353);
+// identical for the default and ont2d scoring, different when len2*a + end_bonus - o < 0.
+static __device__ __forceinline__ int band_clamp(int w, int qlen, const SwParams &P, int cls) {
+    int max_ins, max_del;
+    if (cls == 32) {
+        max_ins = (int)((double)(qlen * P.max_sc + P.end_bonus - P.o_ins) / P.e_ins + 1.);
+        max_del = (int)((double)(qlen * P.max_sc + P.end_bonus - P.o_del) / P.e_del + 1.);
+    } else {
+        unsigned mask = cls == 8 ? 0xffu : 0xffffu;
+        unsigned q = (unsigned)(qlen * P.max_sc) & mask;
+        unsigned ti = (q + ((unsigned)(P.end_bonus - P.o_ins) & mask)) & mask;
+        unsigned td = (q + ((unsigned)(P.end_bonus - P.o_del) & mask)) & mask;
+        max_ins = (int)(ti / (unsigned)P.e_ins) + 1;
+        max_del = (int)(td / (unsigned)P.e_del) + 1;
+    }
+    max_ins = imax(max_ins, 1);
+    w = imin(w, max_ins);
+    max_del = imax(max_del, 1);
+    w = imin(w, max_del);
+    return w;
+}
+
+// One extension on one wavefront.  All arguments wave-uniform.  RH/RE: this wave's LDS rings (RM = R-1, R a
+// power of two >= 2*w+4).  q/t are read with strides qs/ts (-1 walks a left extension backwards through the
+// read and through ref_string, so no reversed copies are ever materialised, cf. bwamem.cpp:2268-2290).
+// `w` must already be clamped.  Returns the number of DP cells computed.
+static __device__ int bsw_extend_wave(const uint8_t *__restrict__ qp, int qs, int qlen,
+                                      const uint8_t *__restrict__ tp, int ts, int tlen,
+                                      int w, int h0, const SwParams &P, int *RH, int *RE, int RM, SwOut &out) {
+    const int lane = threadIdx.x & 63;
+    const int oe_del = P.o_del + P.e_del, oe_ins = P.o_ins + P.e_ins, e_del = P.e_del, e_ins = P.e_ins;
+    const int e1 = h0 > oe_ins ? h0 - oe_ins : 0;                  // first row, bandedSWA.cpp:143-145
+    int beg = 0, end = qlen, maxv = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0;
+    int maxEnd = -1;                                               // columns <= maxEnd have been stored in the ring
+    int cells = 0;
+    int tchunk = 4;
+    for (int i = 0; i < tlen; ++i) {
+        if ((i & 63) == 0) { int ti = i + lane; tchunk = ti < tlen ? (int)tp[(int64_t)ti * ts] : 4; }
+        const int tb = __builtin_amdgcn_readlane(tchunk, i & 63);
+        const int s0 = P.mat[tb * 5 + 0], s1 = P.mat[tb * 5 + 1], s2 = P.mat[tb * 5 + 2], s3 = P.mat[tb * 5 + 3],
+                  s4 = P.mat[tb * 5 + 4];
+        if (beg < i - w) beg = i - w;                               // bandedSWA.cpp:166-168
+        if (end > i + w + 1) end = i + w + 1;
+        if (end > qlen) end = qlen;
+        int h1 = 0;                                                 // H(i, beg-1), :170-173
+        if (beg == 0) { h1 = h0 - (P.o_del + e_del * (i + 1)); if (h1 < 0) h1 = 0; }
+        int fc = 0, m = 0, mj = -1, firstnz = -1, lastnz = -1;
+        cells += imax(end - beg, 0);
+        for (int jb = beg; jb <= end; jb += 64) {
+            const int j = jb + lane;
+            const bool act = j < end, st = j <= end;
+            int Hd = 0, E = 0;
+            if (st) {
+                if (j <= maxEnd) { Hd = RH[j & RM]; E = RE[j & RM]; }
+                else { Hd = j == 0 ? h0 : imax(e1 - (j - 1) * e_ins, 0); }
+            }
+            const int qb = act ? (int)qp[(int64_t)j * qs] : 4;
+            const int sc = qb == 0 ? s0 : qb == 1 ? s1 : qb == 2 ? s2 : qb == 3 ? s3 : s4;
+            const int M = (act && Hd) ? Hd + sc : 0;                // :181-186
+            const int T = imax(M - oe_ins, 0);
+            const int U = T + lane * e_ins;
+            const int Pm = wave_scan_max(U, 0);
+            const int Pprev = wave_shr1(Pm, NEG_BIG);
+            const int F = imax(fc - lane * e_ins, Pprev - (lane - 1) * e_ins);
+            int h = imax(imax(M, E), F);
+            if (!act) h = 0;
+            const int hs = wave_shr1(h, h1);                        // H(i, j-1): what eh[j].h holds for the next row
+            const int en = act ? imax(E - e_del, imax(M - oe_del, 0)) : 0;
+            if (st) { RH[j & RM] = hs; RE[j & RM] = en; }
+            const int nact = imin(64, end - jb);
+            if (nact > 0) {
+                const int cm = __builtin_amdgcn_readlane(wave_scan_max(h, 0), 63);
+                const unsigned long long eq = __ballot(act && h == cm);
+                if (cm >= m) { m = cm; mj = jb + 63 - __builtin_clzll(eq); }   // last column among equal maxima, :188-189
+                h1 = __builtin_amdgcn_readlane(h, nact - 1);
+                fc = imax(fc - 64 * e_ins, __builtin_amdgcn_readlane(Pm, 63) - 63 * e_ins);
+            }
+            const unsigned long long nzb = __ballot(act && (hs | en) != 0);
+            const unsigned long long nze = __ballot(st && (hs | en) != 0);
+            if (firstnz < 0 && nzb) firstnz = jb + __builtin_ctzll(nzb);
+            if (nze) lastnz = jb + 63 - __builtin_clzll(nze);
+        }
+        maxEnd = imax(maxEnd, end);
+        const int jfin = beg < end ? end : beg;
+        if (jfin == qlen) {                                         // :202-205
+            max_ie = gscore > h1 ? max_ie : i;
+            gscore = gscore > h1 ? gscore : h1;
+        }
+        if (m == 0) break;                                          // :206
+        if (m > maxv) {
+            maxv = m; max_i = i; max_j = mj;
+            const int d = mj - i;
+            max_off = imax(max_off, d < 0 ? -d : d);
+        } else if (P.zdrop > 0) {                                   // :210-216
+            if (i - max_i > mj - max_j) {
+                if (maxv - m - ((i - max_i) - (mj - max_j)) * e_del > P.zdrop) break;
+            } else {
+                if (maxv - m - ((mj - max_j) - (i - max_i)) * e_ins > P.zdrop) break;
+            }
+        }
+        const int nb = firstnz >= 0 ? firstnz : end;                // :218-221
+        const int jl = imax(lastnz, nb - 1);
+        beg = nb;
+        end = jl + 2 < qlen ? jl + 2 : qlen;
+        beg = uni(beg); end = uni(end);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    out.score = maxv; out.qle = max_j + 1; out.tle = max_i + 1; out.gtle = max_ie + 1;
+    out.gscore = gscore; out.max_off = max_off;
+    return cells;
+}

@@ -1,0 +1,148 @@
+/* include/bm2.h -- C ABI of the MI355X seed -> chain -> extend library (libbm2.so).
+ *
+ * bwa-mem2 has no plugin/FFI interface; the seams this library replaces are ordinary C++
+ * calls inside libbwa.  Every entry point below names the reference
+ * interface it stands in for (paths relative to the reference's src/).  Plain pointers and
+ * sizes only; no C++ or torch types.  All functions return 0 on success or a negative
+ * BM2_E* code (the reference exit()s or assert()s instead); outputs are caller-allocated
+ * with a capacity and an n_out so the caller can grow and retry (the reference reallocs
+ * inside the callee, e.g. bwamem.cpp:718-739).  One bm2_ctx per GPU, used from one host
+ * thread at a time.  There is NO CPU fallback: without a usable HIP device every call
+ * fails with BM2_ENODEV.
+ */
+#ifndef BM2_H
+#define BM2_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BM2_OK        0
+#define BM2_ENODEV   -1   /* no HIP device / HIP runtime error (message: bm2_last_error) */
+#define BM2_ENOMEM   -2   /* host or device allocation failed */
+#define BM2_EINVAL   -3   /* bad argument */
+#define BM2_ECAP     -4   /* caller-provided output too small; *n_out holds the needed count */
+#define BM2_EUNSUP   -5   /* a path of the reference that is not implemented (stated in DESIGN.md) */
+#define BM2_EIO      -6   /* index file missing / malformed */
+
+typedef struct bm2_ctx bm2_ctx;
+
+/* ---- index ---------------------------------------------------------------------------------
+ * The arrays FMI_search::load_index (FMI_search.cpp:384-494) and main_mem (fastmap.cpp:860-888)
+ * read from <prefix>.bwt.2bit.64 / .0123 / .ann / .alt, as host pointers.  `count` is the
+ * on-disk cumulative count (the +1 of FMI_search.cpp:433-436 is applied inside the library). */
+typedef struct {
+    int64_t ref_len;                /* reference_seq_len = 2*l_pac + 1 */
+    int64_t count[5];
+    int64_t sentinel_index;
+    const void     *cp_occ;         /* (ref_len>>6)+1 CP_OCC blocks of 64 B (FMI_search.h:54-58) */
+    const int8_t   *sa_ms_byte;     /* (ref_len>>3)+1 */
+    const uint32_t *sa_ls_word;     /* (ref_len>>3)+1 */
+    const uint8_t  *ref_string;     /* 2*l_pac bytes, values 0..3 (.0123) */
+    int64_t l_pac;
+    int32_t n_seqs;
+    const int64_t *ann_offset;      /* bntann1_t.offset, .len, .is_alt (bntseq.h:42-49) */
+    const int32_t *ann_len;
+    const int32_t *ann_is_alt;
+} bm2_index_desc;
+
+/* Read the reference's index files into malloc'd host arrays (stands in for
+ * FMI_search::load_index + bwa_idx_load_ele + the .0123 fread).  Free with bm2_index_free. */
+int  bm2_index_load(const char *prefix, bm2_index_desc *out);
+void bm2_index_free(bm2_index_desc *d);
+
+/* ---- options: the fields of mem_opt_t (bwamem.h:76-108) the hot path reads ------------------ */
+typedef struct {
+    int32_t a, b, o_del, e_del, o_ins, e_ins, pen_clip5, pen_clip3, w, zdrop;
+    int32_t min_seed_len, split_width, max_occ, max_chain_gap, min_chain_weight, max_chain_extend;
+    int64_t max_mem_intv;
+    float   split_factor, mask_level, drop_ratio, mask_level_redun;
+    int8_t  mat[25];                /* bwa_fill_scmat (bwa.cpp:248-257) */
+    int8_t  pad[3];
+} bm2_opt;
+void bm2_opt_init(bm2_opt *o);      /* mem_opt_init defaults, bwamem.cpp:107-143 */
+void bm2_opt_fill_scmat(bm2_opt *o);
+
+/* ---- records (byte-compatible with the reference where a reference struct exists) ----------- */
+typedef struct {                    /* SMEM, FMI_search.h:75-83 (40 B) */
+    uint32_t rid, m, n, pad;
+    int64_t  k, l, s;
+} bm2_smem_t;
+
+typedef struct {                    /* SeqPair, bandedSWA.h:90-99 (56 B) */
+    int32_t idr, idq, id, len1, len2, h0;
+    int32_t seqid, regid;
+    int32_t score, tle, gtle, qle, gscore, max_off;
+} bm2_seqpair_t;
+
+typedef struct {                    /* BandedPairWiseSW ctor arguments, bandedSWA.h:118-124 */
+    int32_t o_del, e_del, o_ins, e_ins, zdrop, end_bonus, w_match, w_mismatch;
+    int8_t  mat[25];
+    int8_t  pad[3];
+} bm2_sw_params;
+
+typedef struct {                    /* the fields of mem_alnreg_t (bwamem.h:137-160) that mem_kernel2_core has
+                                     * written when it reaches bwamem.cpp:1152 (before mem_sort_dedup_patch) */
+    int64_t rb, re;
+    int32_t qb, qe, rid, score, truesc, w, seedcov, seedlen0;
+    float   frac_rep;
+    int32_t pad;
+} bm2_reg_t;
+
+typedef struct {                    /* reads of one chunk: 2-bit codes (0..3, 4 = N), as after bwamem.cpp:992-1000 */
+    int32_t n_reads;
+    const uint8_t *enc;             /* concatenated codes */
+    const int64_t *off;             /* [n_reads] start of read i in enc */
+    const int32_t *len;             /* [n_reads] */
+} bm2_reads;
+
+typedef struct {                    /* work counters measured by the kernels themselves */
+    int64_t n_reads, n_bases;
+    int64_t n_smem, n_sa, n_chain, n_reg_raw, n_reg;
+    int64_t n_ext;                  /* backwardExt calls                -> 128 B each */
+    int64_t n_lf;                   /* LF steps in the SA walk          ->  64 B each */
+    int64_t n_sw_cells;             /* DP cells actually computed */
+    int64_t n_sw_tasks;
+} bm2_stats;
+
+/* ---- lifetime ---------------------------------------------------------------------------- */
+bm2_ctx *bm2_create(int device, const bm2_index_desc *idx);     /* uploads the index replica to HBM */
+void     bm2_destroy(bm2_ctx *c);
+const char *bm2_last_error(void);
+int      bm2_device_count(void);
+
+/* ---- S1: BandedPairWiseSW::getScores8 / getScores16 / scalarBandedSWAWrapper (bandedSWA.h:126-135,
+ * 199-211; call sites bwamem.cpp:2476,2544,2613,2692,2757,2828).  Fills score,tle,gtle,qle,gscore,max_off
+ * of every pair; the per-pair band clamp follows the pair's class (int8/int16/scalar), as the reference's
+ * three entry points do.  ref/qer are the flat seqBuf arrays indexed by idr/idq. */
+int bm2_bsw(bm2_ctx *c, bm2_seqpair_t *pairs, const uint8_t *ref, int64_t ref_bytes, const uint8_t *qer,
+            int64_t qer_bytes, int32_t n, int32_t w, const bm2_sw_params *p);
+
+/* ---- S2: mem_collect_smem (bwamem.cpp:626-803) = getSMEMsAllPosOneThread + the pass-2 selection +
+ * getSMEMsOnePosOneThread + bwtSeedStrategyAllPosOneThread + sortSMEMs (FMI_search.h:106-165).
+ * out is sorted by (rid, m, n); rid is the index of the read in `reads`. */
+int bm2_smem(bm2_ctx *c, const bm2_reads *reads, const bm2_opt *opt, bm2_smem_t *out, int64_t cap, int64_t *n_out);
+
+/* ---- S2: FMI_search::get_sa_entries_prefetch (FMI_search.cpp:1257-1375): coordinates of up to max_occ
+ * sampled occurrences of each SMEM, in (SMEM, occurrence) order. */
+int bm2_sal(bm2_ctx *c, const bm2_smem_t *smems, int64_t n, int32_t max_occ, int64_t *coords, int64_t cap,
+            int64_t *n_out);
+
+/* ---- S3: mem_kernel1_core + mem_kernel2_core up to bwamem.cpp:1152 for a whole chunk
+ * (worker_bwt / worker_aln over all 512-read blocks, bwamem.cpp:1175-1214).
+ * regs of read i = regs[reg_off[i] .. reg_off[i+1]); reg_off has n_reads+1 entries. */
+int bm2_seed_chain_extend(bm2_ctx *c, const bm2_reads *reads, const bm2_opt *opt, bm2_reg_t *regs, int64_t cap,
+                          int64_t *reg_off, int64_t *n_out, bm2_stats *stats);
+
+/* ---- the same path split so that a caller can keep inputs resident in HBM and time only the device work */
+int bm2_batch_upload(bm2_ctx *c, const bm2_reads *reads);                 /* H2D (pinned staging) */
+int bm2_batch_run(bm2_ctx *c, const bm2_opt *opt);                         /* device only, returns after sync */
+int bm2_batch_stats(bm2_ctx *c, bm2_stats *stats);
+int bm2_batch_download(bm2_ctx *c, bm2_reg_t *regs, int64_t cap, int64_t *reg_off, int64_t *n_out);
+/* wall time of the last bm2_batch_run measured with hipEvents on the library's stream, per kernel */
+int bm2_batch_kernel_ms(bm2_ctx *c, float *ms, int32_t cap, int32_t *n_out, const char **names);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,63 @@
+"""S1 parity: bm2_bsw (HIP, one task per wavefront) vs the oracle's ksw_extend2 restatement, bit-exact on all six
+outputs (score, qle, tle, gtle, gscore, max_off) -- the fields `xeonbsw -DMAXI` prints (test/main_banded.cpp)."""
+import numpy as np
+import pytest
+
+import bm2
+from helpers import pack_pairs, random_pairs
+from tools import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(ctx, triples, oopt, bopt, w, end_bonus):
+    pairs, ref, qer = pack_pairs(bm2, triples)
+    got = ctx.bsw(pairs, ref, qer, w, bm2.sw_params(bopt, end_bonus))
+    bad = 0
+    for i, (q, t, h0) in enumerate(triples):
+        exp = oracle.ksw_extend(q, t, oopt, w, end_bonus, h0)
+        g = tuple(int(got[i][f]) for f in ("score", "qle", "tle", "gtle", "gscore", "max_off"))
+        if g != exp:
+            bad += 1
+            if bad <= 5:
+                print("pair", i, "len", len(q), len(t), "h0", h0, "got", g, "exp", exp)
+    assert bad == 0, "%d / %d pairs differ" % (bad, len(triples))
+
+
+@pytest.mark.parametrize("w", [100, 200])
+def test_bsw_default_scoring(gpu_ctx_factory, w):
+    ctx = gpu_ctx_factory()
+    tr = random_pairs(11 + w, 3000)
+    _check(ctx, tr, oracle.default_opt(), bm2.default_opt(), w, 5)
+
+
+def test_bsw_small_band_and_tiny(gpu_ctx_factory):
+    ctx = gpu_ctx_factory()
+    tr = random_pairs(5, 1500, max_len=40, h0_max=60)
+    _check(ctx, tr, oracle.default_opt(), bm2.default_opt(), 7, 5)
+    tr = random_pairs(6, 500, max_len=3, h0_max=20)
+    _check(ctx, tr, oracle.default_opt(), bm2.default_opt(), 100, 5)
+
+
+def test_bsw_ont2d_scoring_long(gpu_ctx_factory):
+    ctx = gpu_ctx_factory()
+    kw = dict(a=1, b=1, o_del=1, e_del=1, o_ins=1, e_ins=1, pen_clip5=0, pen_clip3=0)
+    tr = random_pairs(21, 300, max_len=1500, h0_max=400)
+    _check(ctx, tr, oracle.default_opt(**kw), bm2.default_opt(**kw), 100, 0)
+    tr = random_pairs(22, 20, max_len=6000, h0_max=2000, long_tail=False)
+    _check(ctx, tr, oracle.default_opt(**kw), bm2.default_opt(**kw), 200, 0)
+
+
+def test_bsw_intractg_band_wrap(gpu_ctx_factory):
+    # -x intractg (O=16, B=9): pairs with len2*a + L - O < 0 take the wrapping band of the int8/int16 wrappers
+    ctx = gpu_ctx_factory()
+    kw = dict(b=9, o_del=16, o_ins=16)
+    tr = random_pairs(31, 2000, max_len=30, h0_max=100)
+    _check(ctx, tr, oracle.default_opt(**kw), bm2.default_opt(**kw), 100, 5)
+
+
+def test_bsw_empty_batch(gpu_ctx_factory):
+    ctx = gpu_ctx_factory()
+    out = ctx.bsw(np.zeros(0, bm2.SEQPAIR_DT), np.zeros(1, np.uint8), np.zeros(1, np.uint8), 100,
+                  bm2.sw_params(bm2.default_opt(), 5))
+    assert len(out) == 0
