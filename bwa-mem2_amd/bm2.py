@@ -18,6 +18,13 @@ BM2_OK, BM2_ENODEV, BM2_ENOMEM, BM2_EINVAL, BM2_ECAP, BM2_EUNSUP, BM2_EIO = 0, -
 SMEM_DT = np.dtype([("rid", "<u4"), ("m", "<u4"), ("n", "<u4"), ("pad", "<u4"), ("k", "<i8"), ("l", "<i8"), ("s", "<i8")])
 SEQPAIR_DT = np.dtype([(n, "<i4") for n in ("idr", "idq", "id", "len1", "len2", "h0", "seqid", "regid",
                                              "score", "tle", "gtle", "qle", "gscore", "max_off")])
+DEVCHAIN_DT = np.dtype([("pos", "<i8"), ("seed_off", "<i8"), ("n", "<i4"), ("rid", "<i4"), ("w", "<i4"), ("kept", "<i4"),
+                        ("first", "<i4"), ("is_alt", "<i4"), ("read", "<i4"), ("frac_rep", "<f4"), ("rmax0", "<i8"),
+                        ("rmax1", "<i8")])
+DEVSEED_DT = np.dtype([("rbeg", "<i8"), ("qbeg", "<i4"), ("len", "<i4"), ("score", "<i4"), ("aln", "<i4")])
+DEVREG_DT = np.dtype([("rb", "<i8"), ("re", "<i8"), ("qb", "<i4"), ("qe", "<i4"), ("rid", "<i4"), ("score", "<i4"),
+                      ("truesc", "<i4"), ("w", "<i4"), ("seedcov", "<i4"), ("seedlen0", "<i4"), ("frac_rep", "<f4"),
+                      ("chain", "<i4")])
 REG_DT = np.dtype([("rb", "<i8"), ("re", "<i8"), ("qb", "<i4"), ("qe", "<i4"), ("rid", "<i4"), ("score", "<i4"),
                    ("truesc", "<i4"), ("w", "<i4"), ("seedcov", "<i4"), ("seedlen0", "<i4"), ("frac_rep", "<f4"),
                    ("pad", "<i4")])
@@ -59,7 +66,8 @@ class Stats(C.Structure):
 
 EXPORTS = ["bm2_index_load", "bm2_index_free", "bm2_opt_init", "bm2_opt_fill_scmat", "bm2_create", "bm2_destroy",
            "bm2_last_error", "bm2_device_count", "bm2_bsw", "bm2_smem", "bm2_sal", "bm2_seed_chain_extend",
-           "bm2_batch_upload", "bm2_batch_run", "bm2_batch_stats", "bm2_batch_download", "bm2_batch_kernel_ms"]
+           "bm2_batch_upload", "bm2_batch_run", "bm2_batch_stats", "bm2_batch_download", "bm2_batch_kernel_ms",
+           "bm2_batch_fetch"]
 
 _lib = None
 
@@ -94,6 +102,7 @@ def lib():
         L.bm2_batch_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
         L.bm2_batch_download.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_int64)]
         L.bm2_batch_kernel_ms.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.c_void_p]
+        L.bm2_batch_fetch.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
         _lib = L
     return _lib
 
@@ -244,6 +253,17 @@ class Context:
                 continue
             _chk(rc, "bm2_batch_download")
             return regs[:n.value], reg_off
+
+    def batch_fetch(self, what, dtype):
+        n = C.c_int64(0)
+        rc = lib().bm2_batch_fetch(self.h, what.encode(), None, 0, C.byref(n))
+        if rc not in (BM2_OK, BM2_ECAP):
+            _chk(rc, "bm2_batch_fetch")
+        dt = np.dtype(dtype)
+        out = np.zeros(n.value // dt.itemsize, dt)
+        if n.value:
+            _chk(lib().bm2_batch_fetch(self.h, what.encode(), out.ctypes.data, n.value, C.byref(n)), "bm2_batch_fetch")
+        return out
 
     def batch_kernel_ms(self):
         ms = (C.c_float * 32)()

@@ -1,0 +1,440 @@
+// chain.hip -- per-read sequential stages between seeding and extension, one read per lane:
+//   mem_chain_seeds  (bwamem.cpp:806-974)   seeds -> chains through the klib B-tree (exact node-level emulation)
+//   mem_chain_flt    (bwamem.cpp:506-624)   weight, klib introsort by weight, overlap filter
+//   task building of mem_chain2aln_across_reads_V2 (bwamem.cpp:2127-2438): reference window, seed order, regs
+// and, after the extension kernel, the redundant-seed post-filter (bwamem.cpp:2895-2989).
+//
+// These stages are branchy pointer-chasing over a handful of records per read (measured: 1.2 chains, 3 seeds per
+// 150 bp read); they are kept on the device so a chunk never leaves HBM between seeding and extension.  All
+// per-read storage is carved from arrays indexed by the read's SA range [sa_beg, sa_beg+n_sa): a read can never
+// have more seeds, chains or regs than SA coordinates.
+#include "pipeline.h"
+#include "chain_dev.h"
+
+// ---------------------------------------------------------------- bntseq helpers (bntseq.cpp:378-402, bntseq.h:87-90)
+static __device__ __forceinline__ int64_t depos(const DevIndex &ix, int64_t pos, int &is_rev) {
+    is_rev = pos >= ix.l_pac;
+    return is_rev ? (ix.l_pac << 1) - 1 - pos : pos;
+}
+static __device__ int pos2rid(const DevIndex &ix, int64_t pos_f) {
+    int left = 0, mid = 0, right = ix.n_seqs;
+    if (pos_f >= ix.l_pac) return -1;
+    while (left < right) {
+        mid = (left + right) >> 1;
+        if (pos_f >= ix.ann_offset[mid]) {
+            if (mid == ix.n_seqs - 1) break;
+            if (pos_f < ix.ann_offset[mid + 1]) break;
+            left = mid + 1;
+        } else right = mid;
+    }
+    return mid;
+}
+static __device__ int intv2rid(const DevIndex &ix, int64_t rb, int64_t re) {
+    int is_rev;
+    if (rb < ix.l_pac && re > ix.l_pac) return -2;
+    const int rid_b = pos2rid(ix, depos(ix, rb, is_rev));
+    const int rid_e = rb < re ? pos2rid(ix, depos(ix, re - 1, is_rev)) : rid_b;
+    return rid_b == rid_e ? rid_b : -1;
+}
+
+// cal_max_gap, bwamem.cpp:66-76
+static __device__ __forceinline__ int cal_max_gap(const ChainParams &o, int qlen) {
+    const int l_del = (int)((double)(qlen * o.a - o.o_del) / o.e_del + 1.);
+    const int l_ins = (int)((double)(qlen * o.a - o.o_ins) / o.e_ins + 1.);
+    int l = l_del > l_ins ? l_del : l_ins;
+    l = l > 1 ? l : 1;
+    return l < o.w << 1 ? l : o.w << 1;
+}
+
+// ---------------------------------------------------------------- klib B-tree, t = 5 (kbtree.h; kb_init(chn, 512+8), 48-byte keys)
+#define BT_T 5
+struct BTree { BtNode *nodes; int n_nodes, root, n_keys; const WChain *ch; };
+
+static __device__ __forceinline__ int bt_new(BTree &b, int internal) {
+    BtNode &z = b.nodes[b.n_nodes];
+    z.n = 0; z.is_internal = internal;
+    return b.n_nodes++;
+}
+// __kb_getp_aux, kbtree.h:124-138
+static __device__ int bt_getp_aux(const BTree &b, const BtNode &x, int64_t k, int &r) {
+    int begin = 0, end = x.n;
+    if (x.n == 0) return -1;
+    while (begin < end) {
+        const int mid = (begin + end) >> 1;
+        if (b.ch[x.key[mid]].pos < k) begin = mid + 1; else end = mid;
+    }
+    if (begin == x.n) { r = 1; return x.n - 1; }
+    const int64_t kp = b.ch[x.key[begin]].pos;
+    r = (kp < k) - (k < kp);
+    if (r < 0) --begin;
+    return begin;
+}
+// kb_intervalp, lower bound only (kbtree.h:158-175)
+static __device__ int bt_lower(const BTree &b, int64_t k) {
+    int lower = -1, x = b.root, r = 0;
+    while (x >= 0) {
+        const BtNode &nd = b.nodes[x];
+        const int i = bt_getp_aux(b, nd, k, r);
+        if (i >= 0 && r == 0) return nd.key[i];
+        if (i >= 0) lower = nd.key[i];
+        if (!nd.is_internal) return lower;
+        x = nd.ptr[i + 1];
+    }
+    return lower;
+}
+// __kb_split, kbtree.h:179-196
+static __device__ void bt_split(BTree &b, int xi, int i, int yi) {
+    const int zi = bt_new(b, b.nodes[yi].is_internal);
+    BtNode &x = b.nodes[xi], &y = b.nodes[yi], &z = b.nodes[zi];
+    z.n = BT_T - 1;
+    for (int t = 0; t < BT_T - 1; t++) z.key[t] = y.key[BT_T + t];
+    if (y.is_internal) for (int t = 0; t < BT_T; t++) z.ptr[t] = y.ptr[BT_T + t];
+    y.n = BT_T - 1;
+    for (int t = x.n; t > i; t--) x.ptr[t + 1] = x.ptr[t];
+    x.ptr[i + 1] = zi;
+    for (int t = x.n - 1; t >= i; t--) x.key[t + 1] = x.key[t];
+    x.key[i] = y.key[BT_T - 1];
+    ++x.n;
+}
+// kb_putp + __kb_putp_aux, kbtree.h:197-231 (the recursion is a plain descent)
+static __device__ void bt_put(BTree &b, int key) {
+    const int64_t k = b.ch[key].pos;
+    ++b.n_keys;
+    if (b.nodes[b.root].n == 2 * BT_T - 1) {
+        const int s = bt_new(b, 1), r = b.root;
+        b.root = s; b.nodes[s].ptr[0] = r;
+        bt_split(b, s, 0, r);
+    }
+    int xi = b.root, r;
+    for (;;) {
+        BtNode &x = b.nodes[xi];
+        if (!x.is_internal) {
+            const int i = bt_getp_aux(b, x, k, r);
+            for (int t = x.n - 1; t > i; t--) x.key[t + 1] = x.key[t];
+            x.key[i + 1] = key;
+            ++x.n;
+            return;
+        }
+        int i = bt_getp_aux(b, x, k, r) + 1;
+        if (b.nodes[x.ptr[i]].n == 2 * BT_T - 1) {
+            bt_split(b, xi, i, x.ptr[i]);
+            if (k > b.ch[x.key[i]].pos) ++i;
+        }
+        xi = x.ptr[i];
+    }
+}
+// __kb_traverse (in-order), kbtree.h:343-366
+static __device__ int bt_traverse(const BTree &b, int32_t *out) {
+    int n = 0, sp = 0;
+    int stk_node[24], stk_i[24];
+    stk_node[0] = b.root; stk_i[0] = 0;
+    while (sp >= 0) {
+        const BtNode &nd = b.nodes[stk_node[sp]];
+        const int i = stk_i[sp];
+        if (nd.is_internal) {
+            if (i <= nd.n) {
+                if (i > 0 && i <= nd.n) { /* key i-1 is emitted when we come back from child i-1 */ }
+                // descend into child i, after emitting key i-1
+                if (i > 0) out[n++] = nd.key[i - 1];
+                stk_i[sp] = i + 1;
+                ++sp; stk_node[sp] = nd.ptr[i]; stk_i[sp] = 0;
+            } else --sp;
+        } else {
+            for (int t = 0; t < nd.n; t++) out[n++] = nd.key[t];
+            --sp;
+        }
+    }
+    return n;
+}
+
+// ---------------------------------------------------------------- klib introsort (ksort.h:185-236) on an index array
+// lt(a, b) is a strict order on the referenced records; the permutation of equal keys must match klib exactly
+// because mem_flt ties are observable.
+template <class LT>
+static __device__ void k_insertsort(int32_t *s, int32_t *t, LT lt) {
+    for (int32_t *i = s + 1; i < t; ++i)
+        for (int32_t *j = i; j > s && lt(*j, *(j - 1)); --j) { int32_t tmp = *j; *j = *(j - 1); *(j - 1) = tmp; }
+}
+template <class LT>
+static __device__ void k_combsort(int n, int32_t *a, LT lt) {
+    const double shrink = 1.2473309501039786540366528676643;
+    int do_swap, gap = n;
+    do {
+        if (gap > 2) { gap = (int)(gap / shrink); if (gap == 9 || gap == 10) gap = 11; }
+        do_swap = 0;
+        for (int32_t *i = a; i < a + n - gap; ++i) {
+            int32_t *j = i + gap;
+            if (lt(*j, *i)) { int32_t tmp = *i; *i = *j; *j = tmp; do_swap = 1; }
+        }
+    } while (do_swap || gap > 2);
+    if (gap != 1) k_insertsort(a, a + n, lt);
+}
+template <class LT>
+static __device__ void k_introsort(int n, int32_t *a, LT lt) {
+    if (n < 1) return;
+    if (n == 2) { if (lt(a[1], a[0])) { int32_t t = a[0]; a[0] = a[1]; a[1] = t; } return; }
+    int d;
+    for (d = 2; (1 << d) < n; ++d) {}
+    int32_t *stk_l[72], *stk_r[72]; int stk_d[72]; int top = 0;
+    int32_t *s = a, *t = a + (n - 1);
+    d <<= 1;
+    for (;;) {
+        if (s < t) {
+            if (--d == 0) { k_combsort((int)(t - s) + 1, s, lt); t = s; continue; }
+            int32_t *i = s, *j = t, *k = i + ((j - i) >> 1) + 1;
+            if (lt(*k, *i)) { if (lt(*k, *j)) k = j; }
+            else k = lt(*j, *i) ? i : j;
+            const int32_t rp = *k;
+            if (k != t) { int32_t tmp = *k; *k = *t; *t = tmp; }
+            for (;;) {
+                do ++i; while (lt(*i, rp));
+                do --j; while (i <= j && lt(rp, *j));
+                if (j <= i) break;
+                int32_t tmp = *i; *i = *j; *j = tmp;
+            }
+            { int32_t tmp = *i; *i = *t; *t = tmp; }
+            if (i - s > t - i) {
+                if (i - s > 16) { stk_l[top] = s; stk_r[top] = i - 1; stk_d[top] = d; ++top; }
+                s = t - i > 16 ? i + 1 : t;
+            } else {
+                if (t - i > 16) { stk_l[top] = i + 1; stk_r[top] = t; stk_d[top] = d; ++top; }
+                t = i - s > 16 ? i - 1 : s;
+            }
+        } else {
+            if (top == 0) { k_insertsort(a, a + n, lt); return; }
+            --top; s = stk_l[top]; t = stk_r[top]; d = stk_d[top];
+        }
+    }
+}
+
+// ---------------------------------------------------------------- chaining of one read
+// test_and_merge, bwamem.cpp:357-399
+static __device__ int test_and_merge(const ChainParams &o, int64_t l_pac, WChain &c, const WSeed &p, int seed_rid,
+                                     WSeed *seeds, int si) {
+    const int64_t qend = c.last_qbeg + c.last_len, rend = c.last_rbeg + c.last_len;
+    if (seed_rid != c.rid) return 0;
+    if (p.qbeg >= c.first_qbeg && p.qbeg + p.len <= qend && p.rbeg >= c.pos && p.rbeg + p.len <= rend) return 1;
+    if ((c.last_rbeg < l_pac || c.pos < l_pac) && p.rbeg >= l_pac) return 0;
+    const int64_t x = p.qbeg - c.last_qbeg, y = p.rbeg - c.last_rbeg;
+    if (y >= 0 && x - y <= o.w && y - x <= o.w && x - c.last_len < o.max_chain_gap && y - c.last_len < o.max_chain_gap) {
+        seeds[si] = p; seeds[si].next = -1;
+        seeds[c.tail].next = si;
+        c.tail = si; c.n++;
+        c.last_rbeg = p.rbeg; c.last_qbeg = p.qbeg; c.last_len = p.len;
+        return 2;      // merged and consumed the seed slot
+    }
+    return 0;
+}
+
+// mem_chain_weight, bwamem.cpp:429-448
+static __device__ int chain_weight(const WChain &c, const WSeed *seeds) {
+    int64_t end = 0; int w = 0, tmp;
+    for (int si = c.head; si >= 0; si = seeds[si].next) {
+        const WSeed &s = seeds[si];
+        if (s.qbeg >= end) w += s.len;
+        else if (s.qbeg + s.len > end) w += (int)(s.qbeg + s.len - end);
+        end = end > s.qbeg + s.len ? end : s.qbeg + s.len;
+    }
+    tmp = w; w = 0; end = 0;
+    for (int si = c.head; si >= 0; si = seeds[si].next) {
+        const WSeed &s = seeds[si];
+        if (s.rbeg >= end) w += s.len;
+        else if (s.rbeg + s.len > end) w += (int)(s.rbeg + s.len - end);
+        end = end > s.rbeg + s.len ? end : s.rbeg + s.len;
+    }
+    w = w < tmp ? w : tmp;
+    return w < 1 << 30 ? w : (1 << 30) - 1;
+}
+
+__global__ void __launch_bounds__(128)
+k_chain(DevIndex ix, ChainParams o, int n_reads, const int32_t *__restrict__ len, const bm2_smem_t *__restrict__ smems,
+        const int32_t *__restrict__ smem_cnt, const int64_t *__restrict__ smem_off, const int64_t *__restrict__ sa_off,
+        const int64_t *__restrict__ sa_coord, WChain *wchain, WSeed *wseed, BtNode *nodes, int32_t *order,
+        DevChain *chn, DevSeed *seeds_out, int32_t *srt_out, int32_t *reg_seed, int32_t *reg_chain,
+        int32_t *n_chain_out, int32_t *n_reg_out, int32_t *n_chain0_out) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    const int n_sm = smem_cnt[r];
+    n_chain_out[r] = 0; n_reg_out[r] = 0;
+    if (n_chain0_out) n_chain0_out[r] = 0;
+    if (n_sm == 0 || len[r] < o.min_seed_len) return;
+    if (n_sm <= 1) {                                    // the `pos < num_smem - 1` loop bound of mem_chain_seeds (bwamem.cpp:834):
+        const int b0 = (r / BM2_BLOCK_READS) * BM2_BLOCK_READS;      // a 512-read block whose SMEM total is <= 1 yields no chains
+        const int b1 = b0 + BM2_BLOCK_READS < n_reads ? b0 + BM2_BLOCK_READS : n_reads;
+        int tot = 0;
+        for (int t = b0; t < b1 && tot <= 1; t++) tot += smem_cnt[t];
+        if (tot <= 1) return;
+    }
+    const int64_t so = smem_off[r];
+    const int64_t base = sa_off[so];
+    const int n_sa = (int)(sa_off[so + n_sm] - base);
+    if (n_sa == 0) return;
+    WChain *ch = wchain + base;
+    WSeed *sd = wseed + base;
+    int32_t *ord = order + base;
+    BTree bt; bt.nodes = nodes + base; bt.n_nodes = 0;     // <= n_sa/4 + 1 nodes are ever needed bt.n_keys = 0; bt.ch = ch;
+    bt.root = bt_new(bt, 0);
+    int n_ch = 0, n_sd = 0;
+    int b = 0, e = 0, l_rep = 0;
+    for (int i = 0; i < n_sm; i++) {                     // l_rep, bwamem.cpp:849-861
+        const int sb = (int)smems[so + i].m, se = (int)smems[so + i].n + 1;
+        if (smems[so + i].s <= o.max_occ) continue;
+        if (sb > e) { l_rep += e - b; b = sb; e = se; }
+        else e = e > se ? e : se;
+    }
+    l_rep += e - b;
+    for (int i = 0; i < n_sm; i++) {
+        const bm2_smem_t p = smems[so + i];
+        const int slen = (int)(p.n + 1 - p.m);
+        const int64_t o0 = sa_off[so + i] - base;
+        const int cnt = (int)(sa_off[so + i + 1] - sa_off[so + i]);
+        for (int c = 0; c < cnt; c++) {
+            WSeed s; s.rbeg = sa_coord[base + o0 + c]; s.qbeg = (int32_t)p.m; s.len = slen; s.next = -1;
+            const int rid = intv2rid(ix, s.rbeg, s.rbeg + s.len);
+            if (rid < 0) continue;                       // bwamem.cpp:915-919
+            int to_add = 0;
+            if (bt.n_keys) {
+                const int lower = bt_lower(bt, s.rbeg);
+                if (lower < 0) to_add = 1;
+                else {
+                    const int m = test_and_merge(o, ix.l_pac, ch[lower], s, rid, sd, n_sd);
+                    if (m == 2) n_sd++;
+                    else if (m == 0) to_add = 1;
+                }
+            } else to_add = 1;
+            if (to_add) {                                // bwamem.cpp:930-951
+                WChain c2;
+                c2.pos = s.rbeg; c2.last_rbeg = s.rbeg; c2.first_qbeg = s.qbeg; c2.last_qbeg = s.qbeg; c2.last_len = s.len;
+                c2.n = 1; c2.rid = rid; c2.is_alt = ix.ann_is_alt[rid] ? 1 : 0; c2.head = c2.tail = n_sd;
+                c2.w = 0; c2.kept = 0; c2.first = -1;
+                sd[n_sd] = s; n_sd++;
+                ch[n_ch] = c2;
+                bt_put(bt, n_ch);
+                n_ch++;
+            }
+        }
+    }
+    int n = bt_traverse(bt, ord);                        // chains in key order (bwamem.cpp:958-962)
+    if (n_chain0_out) n_chain0_out[r] = n;
+    const float frac_rep = (float)l_rep / len[r];        // bwamem.cpp:965-966
+    // ---- mem_chain_flt, bwamem.cpp:506-624
+    int k = 0;
+    for (int i = 0; i < n; i++) {
+        WChain &c = ch[ord[i]];
+        c.first = -1; c.kept = 0;
+        c.w = chain_weight(c, sd);
+        if (c.w >= o.min_chain_weight) ord[k++] = ord[i];
+    }
+    if (k == 0 && n > 0) k = 1;      // quirk: an empty survivor list still processes the untouched a_[0] (bwamem.cpp:529-546)
+    n = k;
+    if (n > 0) {
+        k_introsort(n, ord, [&](int32_t x, int32_t y) { return ch[x].w > ch[y].w; });     // flt_lt, bwamem.cpp:61
+        // `kept chain list` reuses the tail of the order array's sibling: indices into ord
+        int32_t *kept_list = (int32_t *)(nodes + base);          // the B-tree is no longer needed
+        int n_kept = 0;
+        ch[ord[0]].kept = 3;
+        kept_list[n_kept++] = 0;
+        for (int i = 1; i < n; ++i) {
+            WChain &ci = ch[ord[i]];
+            const int beg_i = ci.first_qbeg, end_i = ci.last_qbeg + ci.last_len;
+            int large_ovlp = 0, kk;
+            for (kk = 0; kk < n_kept; ++kk) {
+                const int j = kept_list[kk];
+                WChain &cj = ch[ord[j]];
+                const int beg_j = cj.first_qbeg, end_j = cj.last_qbeg + cj.last_len;
+                const int b_max = beg_j > beg_i ? beg_j : beg_i;
+                const int e_min = end_j < end_i ? end_j : end_i;
+                if (e_min > b_max && (!cj.is_alt || ci.is_alt)) {
+                    const int li = end_i - beg_i, lj = end_j - beg_j;
+                    const int min_l = li < lj ? li : lj;
+                    if (e_min - b_max >= min_l * o.mask_level && min_l < o.max_chain_gap) {
+                        large_ovlp = 1;
+                        if (cj.first < 0) cj.first = i;
+                        if (ci.w < cj.w * o.drop_ratio && cj.w - ci.w >= o.min_seed_len << 1) break;
+                    }
+                }
+            }
+            if (kk == n_kept) { kept_list[n_kept++] = i; ci.kept = large_ovlp ? 2 : 3; }
+        }
+        for (int i = 0; i < n_kept; ++i) {
+            const WChain &c = ch[ord[kept_list[i]]];
+            if (c.first >= 0) ch[ord[c.first]].kept = 1;
+        }
+        int i2;
+        for (i2 = k = 0; i2 < n; ++i2) {
+            const int kp = ch[ord[i2]].kept;
+            if (kp == 0 || kp == 3) continue;
+            if (++k >= o.max_chain_extend) break;
+        }
+        for (; i2 < n; ++i2) if (ch[ord[i2]].kept < 3) ch[ord[i2]].kept = 0;
+        for (i2 = k = 0; i2 < n; ++i2) if (ch[ord[i2]].kept != 0) ord[k++] = ord[i2];
+        n = k;
+    }
+    // ---- emit kept chains with contiguous seeds
+    DevChain *oc = chn + base;
+    DevSeed *os = seeds_out + base;
+    int n_seed = 0, n_reg = 0;
+    for (int i = 0; i < n; i++) {
+        const WChain &c = ch[ord[i]];
+        DevChain d;
+        d.pos = c.pos; d.seed_off = base + n_seed; d.n = c.n; d.rid = c.rid; d.w = c.w; d.kept = c.kept; d.first = c.first;
+        d.is_alt = c.is_alt; d.read = r; d.frac_rep = frac_rep; d.rmax0 = 0; d.rmax1 = 0;
+        const int s0 = n_seed;
+        for (int si = c.head; si >= 0; si = sd[si].next) {
+            DevSeed s; s.rbeg = sd[si].rbeg; s.qbeg = sd[si].qbeg; s.len = sd[si].len; s.score = sd[si].len; s.aln = -1;
+            os[n_seed++] = s;
+        }
+        // reference window of the chain, bwamem.cpp:2145-2172 (rmax, strand clip, bns_fetch_seq_v2 contig clip)
+        const int l_query = len[r];
+        int64_t rmax0 = ix.l_pac << 1, rmax1 = 0;
+        for (int t = s0; t < n_seed; t++) {
+            const DevSeed &sx = os[t];
+            const int64_t bb = sx.rbeg - (sx.qbeg + cal_max_gap(o, sx.qbeg));
+            const int64_t ee = sx.rbeg + sx.len + ((l_query - sx.qbeg - sx.len) + cal_max_gap(o, l_query - sx.qbeg - sx.len));
+            rmax0 = rmax0 < bb ? rmax0 : bb;
+            rmax1 = rmax1 > ee ? rmax1 : ee;
+        }
+        rmax0 = rmax0 > 0 ? rmax0 : 0;
+        rmax1 = rmax1 < ix.l_pac << 1 ? rmax1 : ix.l_pac << 1;
+        if (rmax0 < ix.l_pac && ix.l_pac < rmax1) {
+            if (os[s0].rbeg < ix.l_pac) rmax1 = ix.l_pac; else rmax0 = ix.l_pac;
+        }
+        {
+            int is_rev;
+            const int rid = pos2rid(ix, depos(ix, os[s0].rbeg, is_rev));
+            int64_t far_beg = ix.ann_offset[rid], far_end = far_beg + ix.ann_len[rid];
+            if (is_rev) { const int64_t tmp = far_beg; far_beg = (ix.l_pac << 1) - far_end; far_end = (ix.l_pac << 1) - tmp; }
+            rmax0 = rmax0 > far_beg ? rmax0 : far_beg;
+            rmax1 = rmax1 < far_end ? rmax1 : far_end;
+        }
+        d.rmax0 = rmax0; d.rmax1 = rmax1;
+        // seeds are extended in descending (score<<32 | index) order, bwamem.cpp:2188-2206; srt keeps the ascending order
+        int32_t *srt = srt_out + base + s0;
+        for (int t = 0; t < c.n; t++) srt[t] = t;
+        if (c.n > 1) {
+            const DevSeed *cs = os + s0;
+            k_introsort(c.n, srt, [&](int32_t x, int32_t y) { return cs[x].score < cs[y].score || (cs[x].score == cs[y].score && x < y); });
+        }
+        for (int kk = c.n - 1; kk >= 0; kk--) {
+            const int reg = n_reg++;
+            os[s0 + srt[kk]].aln = reg;
+            reg_seed[base + reg] = (int32_t)(s0 + srt[kk]);       // seed index relative to the read's base
+            reg_chain[base + reg] = i;                             // chain index relative to the read's base
+        }
+        oc[i] = d;
+    }
+    n_chain_out[r] = n;
+    n_reg_out[r] = n_seed;
+}
+
+int bm2_launch_chain(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_t *len, const bm2_smem_t *smems,
+                     const int32_t *smem_cnt, const int64_t *smem_off, const int64_t *sa_off, const int64_t *sa_coord,
+                     WChain *wchain, WSeed *wseed, BtNode *nodes, int32_t *order, DevChain *chn, DevSeed *seeds_out,
+                     int32_t *srt_out, int32_t *reg_seed, int32_t *reg_chain,
+                     int32_t *n_chain_out, int32_t *n_reg_out, int32_t *n_chain0_out) {
+    if (n_reads <= 0) return BM2_OK;
+    hipLaunchKernelGGL(k_chain, dim3((n_reads + 127) / 128), dim3(128), 0, c->stream, c->ix, o, n_reads, len, smems, smem_cnt,
+                       smem_off, sa_off, sa_coord, wchain, wseed, nodes, order, chn, seeds_out, srt_out, reg_seed, reg_chain,
+                       n_chain_out, n_reg_out, n_chain0_out);
+    return bm2_check(hipGetLastError(), "k_chain launch");
+}

@@ -1,11 +1,401 @@
-// pipeline.hip -- S2/S3 entry points (placeholder until the seeding / chaining kernels land).
-#include "bm2_ctx.h"
-void bm2_batch_destroy(bm2_ctx *c) { (void)c; }
-extern "C" int bm2_smem(bm2_ctx *, const bm2_reads *, const bm2_opt *, bm2_smem_t *, int64_t, int64_t *) { bm2_set_error("bm2_smem: not built yet"); return BM2_EUNSUP; }
-extern "C" int bm2_sal(bm2_ctx *, const bm2_smem_t *, int64_t, int32_t, int64_t *, int64_t, int64_t *) { bm2_set_error("bm2_sal: not built yet"); return BM2_EUNSUP; }
-extern "C" int bm2_seed_chain_extend(bm2_ctx *, const bm2_reads *, const bm2_opt *, bm2_reg_t *, int64_t, int64_t *, int64_t *, bm2_stats *) { return BM2_EUNSUP; }
-extern "C" int bm2_batch_upload(bm2_ctx *, const bm2_reads *) { return BM2_EUNSUP; }
-extern "C" int bm2_batch_run(bm2_ctx *, const bm2_opt *) { return BM2_EUNSUP; }
-extern "C" int bm2_batch_stats(bm2_ctx *, bm2_stats *) { return BM2_EUNSUP; }
-extern "C" int bm2_batch_download(bm2_ctx *, bm2_reg_t *, int64_t, int64_t *, int64_t *) { return BM2_EUNSUP; }
-extern "C" int bm2_batch_kernel_ms(bm2_ctx *, float *, int32_t, int32_t *, const char **) { return BM2_EUNSUP; }
+// pipeline.hip -- host orchestration of the device pipeline and the S2/S3 entry points of include/bm2.h.
+//
+// A chunk of reads stays in HBM from upload to the final regs: k_smem -> scan -> k_sal_expand -> k_sal -> k_chain ->
+// k_slot_base -> k_extend -> k_postfilter -> scan -> k_reg_gather, all on one stream.  The host only reads back three
+// scalars (SMEM count, SA count, reg count) to size the next stage's buffers.
+#include <string.h>
+#include <stdio.h>
+#include <math.h>
+#include <vector>
+#include "pipeline.h"
+#include "chain_dev.h"
+
+// launchers defined in chain.hip / extend.hip
+int bm2_launch_chain(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_t *len, const bm2_smem_t *smems,
+                     const int32_t *smem_cnt, const int64_t *smem_off, const int64_t *sa_off, const int64_t *sa_coord,
+                     WChain *wchain, WSeed *wseed, BtNode *nodes, int32_t *order, DevChain *chn, DevSeed *seeds_out,
+                     int32_t *srt_out, int32_t *reg_seed, int32_t *reg_chain,
+                     int32_t *n_chain_out, int32_t *n_reg_out, int32_t *n_chain0_out);
+int bm2_launch_extend(bm2_ctx *c, const bm2_opt &opt, int64_t n_slots, const uint8_t *enc, const int64_t *off, const int32_t *len,
+                      const int64_t *slot_base, const int32_t *reg_seed, const int32_t *reg_chain, const DevChain *chn,
+                      const DevSeed *seeds, DevReg *regs, unsigned long long *counters);
+int bm2_launch_slot_base(bm2_ctx *c, int n_reads, const int64_t *read_base, const int32_t *n_reg, int64_t *slot_base);
+int bm2_launch_postfilter(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_t *len, const int64_t *read_base,
+                          const int32_t *n_chain, const int32_t *n_reg, const DevChain *chn, const DevSeed *seeds,
+                          int32_t *srt_all, DevReg *regs, int32_t *n_out);
+int bm2_launch_reg_gather(bm2_ctx *c, int n_reads, const int64_t *read_base, const int32_t *n_reg, const DevReg *regs,
+                          const int64_t *out_off, bm2_reg_t *out, int64_t out_cap);
+
+struct Batch {
+    int n_reads = 0, max_len = 0;
+    int64_t n_bases = 0;
+    bool uploaded = false, ran = false;
+    // inputs
+    DevBuf enc, off, len;
+    // seeding
+    DevBuf stage, prevbuf, smem, occ_cnt, smem_cnt, smem_off, counters, sa_off, sa_coord, scan_tmp, read_base;
+    // chaining / extension
+    DevBuf wchain, wseed, nodes, order, chn, seeds, srt, reg_seed, reg_chain, regs, slot_base, n_chain, n_reg, n_chain0, n_out;
+    DevBuf out_off, out_regs, smem_sorted, smem_sorted_off;
+    int64_t n_smem = 0, n_sa = 0, n_out_regs = 0;
+    bm2_stats stats{};
+};
+
+void bm2_batch_destroy(bm2_ctx *c) {
+    if (!c->batch) return;
+    Batch *b = c->batch;
+    DevBuf *all[] = { &b->enc, &b->off, &b->len, &b->stage, &b->prevbuf, &b->smem, &b->occ_cnt, &b->smem_cnt, &b->smem_off,
+                      &b->counters, &b->sa_off, &b->sa_coord, &b->scan_tmp, &b->read_base, &b->wchain, &b->wseed, &b->nodes,
+                      &b->order, &b->chn, &b->seeds, &b->srt, &b->reg_seed, &b->reg_chain, &b->regs, &b->slot_base, &b->n_chain,
+                      &b->n_reg, &b->n_chain0, &b->n_out, &b->out_off, &b->out_regs, &b->smem_sorted, &b->smem_sorted_off };
+    for (DevBuf *d : all) bm2_release(*d);
+    delete b;
+    c->batch = nullptr;
+}
+
+static Batch *get_batch(bm2_ctx *c) {
+    if (!c->batch) c->batch = new Batch();
+    return c->batch;
+}
+
+static void tick(bm2_ctx *c, const char *name) {       // event after the stage `name`
+    if (c->n_ev < BM2_MAX_TIMERS) {
+        c->ev_name[c->n_ev] = name;
+        (void)hipEventRecord(c->ev[c->n_ev + 1], c->stream);
+        c->n_ev++;
+    }
+}
+
+__global__ void k_read_base(int n_reads, const int32_t *__restrict__ smem_cnt, const int64_t *__restrict__ smem_off,
+                            const int64_t *__restrict__ sa_off, int64_t *read_base) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    read_base[r] = smem_cnt[r] > 0 ? sa_off[smem_off[r]] : 0;
+}
+
+extern "C" int bm2_batch_upload(bm2_ctx *c, const bm2_reads *reads) {
+    if (!c || !reads || reads->n_reads < 0) { bm2_set_error("bm2_batch_upload: bad argument"); return BM2_EINVAL; }
+    if (!c->has_index) { bm2_set_error("context was created without an index"); return BM2_EINVAL; }
+    int rc = bm2_check(hipSetDevice(c->device), "hipSetDevice");
+    if (rc) return rc;
+    Batch *b = get_batch(c);
+    const int n = reads->n_reads;
+    int64_t nb = 0; int max_len = 0;
+    for (int i = 0; i < n; i++) {
+        if (reads->len[i] < 0 || reads->off[i] < 0) { bm2_set_error("read %d: negative length/offset", i); return BM2_EINVAL; }
+        if (reads->len[i] >= 32768) { bm2_set_error("read %d is %d bp: the reference path handles reads < 32768 bp (bandedSWA.h:83)", i, reads->len[i]); return BM2_EUNSUP; }
+        int64_t e = reads->off[i] + reads->len[i];
+        if (e > nb) nb = e;
+        if (reads->len[i] > max_len) max_len = reads->len[i];
+    }
+    b->n_reads = n; b->n_bases = nb; b->max_len = max_len; b->ran = false;
+    if ((rc = bm2_reserve(b->enc, (size_t)nb + 64))) return rc;
+    if ((rc = bm2_reserve(b->off, (size_t)(n + 1) * 8))) return rc;
+    if ((rc = bm2_reserve(b->len, (size_t)(n + 1) * 4))) return rc;
+    if (n) {
+        rc = bm2_check(hipMemcpyAsync(b->enc.p, reads->enc, (size_t)nb, hipMemcpyHostToDevice, c->stream), "H2D reads");
+        if (!rc) rc = bm2_check(hipMemcpyAsync(b->off.p, reads->off, (size_t)n * 8, hipMemcpyHostToDevice, c->stream), "H2D off");
+        if (!rc) rc = bm2_check(hipMemcpyAsync(b->len.p, reads->len, (size_t)n * 4, hipMemcpyHostToDevice, c->stream), "H2D len");
+        if (!rc) rc = bm2_check(hipStreamSynchronize(c->stream), "upload sync");
+    }
+    b->uploaded = rc == 0;
+    return rc;
+}
+
+static SeedParams seed_params(const bm2_opt *opt) {
+    SeedParams sp;
+    sp.min_seed_len = opt->min_seed_len;
+    sp.split_len = (int)(opt->min_seed_len * opt->split_factor + .499);      // bwamem.cpp:639
+    sp.split_width = opt->split_width; sp.max_occ = opt->max_occ; sp.max_mem_intv = opt->max_mem_intv;
+    return sp;
+}
+static ChainParams chain_params(const bm2_opt *opt) {
+    ChainParams o;
+    o.a = opt->a; o.o_del = opt->o_del; o.e_del = opt->e_del; o.o_ins = opt->o_ins; o.e_ins = opt->e_ins; o.w = opt->w;
+    o.max_chain_gap = opt->max_chain_gap; o.max_occ = opt->max_occ; o.min_seed_len = opt->min_seed_len;
+    o.min_chain_weight = opt->min_chain_weight; o.max_chain_extend = opt->max_chain_extend;
+    o.pen_clip5 = opt->pen_clip5; o.pen_clip3 = opt->pen_clip3; o.zdrop = opt->zdrop;
+    o.mask_level = opt->mask_level; o.drop_ratio = opt->drop_ratio;
+    return o;
+}
+
+static int check_opt(const bm2_opt *opt) {
+    if (!opt) return BM2_EINVAL;
+    if (opt->e_del <= 0 || opt->e_ins <= 0 || opt->a <= 0 || opt->w <= 0 || opt->max_occ <= 0 || opt->min_seed_len <= 0) {
+        bm2_set_error("bm2: option out of range (a, w, max_occ, min_seed_len, e_del, e_ins must be > 0)");
+        return BM2_EINVAL;
+    }
+    return BM2_OK;
+}
+
+// seeding stages: SMEMs (bump order) + SA coordinates
+static int run_seeding(bm2_ctx *c, Batch *b, const bm2_opt *opt, bool with_sal) {
+    const int n = b->n_reads;
+    int rc;
+    hipStream_t s = c->stream;
+    const SeedParams sp = seed_params(opt);
+    if ((rc = bm2_reserve(b->counters, 16 * 8))) return rc;
+    if ((rc = bm2_reserve(b->smem_cnt, (size_t)(n + 1) * 4))) return rc;
+    if ((rc = bm2_reserve(b->smem_off, (size_t)(n + 1) * 8))) return rc;
+    int grid = (n + 255) / 256;
+    if (grid > c->n_cu * 4) grid = c->n_cu * 4;
+    if (grid < 1) grid = 1;
+    const int64_t nthreads = (int64_t)grid * 256;
+    const int stage_cap = 2 * b->max_len + 64, prev_cap = b->max_len + 2;
+    if ((rc = bm2_reserve(b->stage, (size_t)nthreads * stage_cap * sizeof(StSmem)))) return rc;
+    if ((rc = bm2_reserve(b->prevbuf, (size_t)nthreads * prev_cap * sizeof(StSmem)))) return rc;
+    int64_t cap = b->smem.cap / sizeof(bm2_smem_t);
+    if (cap < (int64_t)n * 16 + 1024) cap = (int64_t)n * 16 + 1024;
+    unsigned long long h_cnt[3];
+    for (int attempt = 0; attempt < 3; attempt++) {
+        if ((rc = bm2_reserve(b->smem, (size_t)cap * sizeof(bm2_smem_t)))) return rc;
+        if ((rc = bm2_reserve(b->occ_cnt, (size_t)(cap + 1) * 4))) return rc;
+        cap = b->smem.cap / sizeof(bm2_smem_t);
+        if ((int64_t)(b->occ_cnt.cap / 4) - 1 < cap) cap = b->occ_cnt.cap / 4 - 1;
+        if ((rc = bm2_check(hipMemsetAsync(b->counters.p, 0, 16 * 8, s), "memset counters"))) return rc;
+        if ((rc = bm2_launch_smem(c, sp, n, (const uint8_t *)b->enc.p, (const int64_t *)b->off.p, (const int32_t *)b->len.p,
+                                  (StSmem *)b->stage.p, (StSmem *)b->prevbuf.p, stage_cap, prev_cap, grid, (bm2_smem_t *)b->smem.p, cap,
+                                  (int32_t *)b->smem_cnt.p, (int64_t *)b->smem_off.p, (int32_t *)b->occ_cnt.p,
+                                  (unsigned long long *)b->counters.p))) return rc;
+        if ((rc = bm2_check(hipMemcpyAsync(h_cnt, b->counters.p, 24, hipMemcpyDeviceToHost, s), "D2H counters"))) return rc;
+        if ((rc = bm2_check(hipStreamSynchronize(s), "k_smem"))) return rc;
+        if (h_cnt[2]) { bm2_set_error("per-read SMEM staging overflow (%d entries)", stage_cap); return BM2_EUNSUP; }
+        if ((int64_t)h_cnt[0] <= cap) break;
+        cap = (int64_t)h_cnt[0] + 1024;
+        if (attempt == 2) { bm2_set_error("SMEM buffer could not be sized"); return BM2_ENOMEM; }
+    }
+    tick(c, "smem");
+    b->n_smem = (int64_t)h_cnt[0];
+    b->stats.n_smem = b->n_smem; b->stats.n_ext = (int64_t)h_cnt[1];
+    if (!with_sal) return BM2_OK;
+    // SA offsets per SMEM (scan of occurrence counts), then the lookups
+    if ((rc = bm2_reserve(b->sa_off, (size_t)(b->n_smem + 2) * 8))) return rc;
+    if ((rc = bm2_scan_i32(c, (const int32_t *)b->occ_cnt.p, b->n_smem, (int64_t *)b->sa_off.p, b->scan_tmp))) return rc;
+    int64_t n_sa = 0;
+    if ((rc = bm2_check(hipMemcpyAsync(&n_sa, (int64_t *)b->sa_off.p + b->n_smem, 8, hipMemcpyDeviceToHost, s), "D2H n_sa"))) return rc;
+    if ((rc = bm2_check(hipStreamSynchronize(s), "scan"))) return rc;
+    b->n_sa = n_sa; b->stats.n_sa = n_sa;
+    if ((rc = bm2_reserve(b->sa_coord, (size_t)(n_sa + 1) * 8))) return rc;
+    if ((rc = bm2_launch_sal_expand(c, (const bm2_smem_t *)b->smem.p, b->n_smem, (const int64_t *)b->sa_off.p, opt->max_occ,
+                                    (int64_t *)b->sa_coord.p))) return rc;
+    if ((rc = bm2_launch_sal(c, n_sa, (int64_t *)b->sa_coord.p, (unsigned long long *)b->counters.p + 4))) return rc;
+    tick(c, "sal");
+    return BM2_OK;
+}
+
+extern "C" int bm2_batch_run(bm2_ctx *c, const bm2_opt *opt) {
+    if (!c || !c->batch || !c->batch->uploaded) { bm2_set_error("bm2_batch_run: no batch uploaded"); return BM2_EINVAL; }
+    int rc = check_opt(opt);
+    if (rc) return rc;
+    if ((rc = bm2_check(hipSetDevice(c->device), "hipSetDevice"))) return rc;
+    Batch *b = c->batch;
+    const int n = b->n_reads;
+    hipStream_t s = c->stream;
+    // mem_flt_chained_seeds (bwamem.cpp:472-504) runs a local SW per short seed when min_l <= 0.05*l_query (reads >~1.1 kb
+    // or -W): that path is not on the device yet -- refuse rather than return chains the reference would have filtered.
+    {
+        const double min_l = opt->min_chain_weight ? 1.1f * opt->min_chain_weight : 5.5f * log((double)(b->max_len > 1 ? b->max_len : 2));
+        if (!(min_l > 0.05f * b->max_len)) {
+            bm2_set_error("reads of %d bp with min_chain_weight=%d need mem_flt_chained_seeds, which is not implemented", b->max_len, opt->min_chain_weight);
+            return BM2_EUNSUP;
+        }
+    }
+    memset(&b->stats, 0, sizeof b->stats);
+    b->stats.n_reads = n; b->stats.n_bases = b->n_bases;
+    c->n_ev = 0; c->ev_ready = false;
+    (void)hipEventRecord(c->ev[0], s);
+    b->n_out_regs = 0;
+    if ((rc = bm2_reserve(b->out_off, (size_t)(n + 2) * 8))) return rc;
+    if (n == 0) { b->ran = true; return bm2_check(hipMemsetAsync(b->out_off.p, 0, 16, s), "memset"); }
+    if ((rc = run_seeding(c, b, opt, true))) return rc;
+    const int64_t n_sa = b->n_sa;
+    const ChainParams cp = chain_params(opt);
+    size_t ns = (size_t)n_sa + 1;
+    if ((rc = bm2_reserve(b->wchain, ns * sizeof(WChain)))) return rc;
+    if ((rc = bm2_reserve(b->wseed, ns * sizeof(WSeed)))) return rc;
+    if ((rc = bm2_reserve(b->nodes, ns * sizeof(BtNode)))) return rc;
+    if ((rc = bm2_reserve(b->order, ns * 4))) return rc;
+    if ((rc = bm2_reserve(b->chn, ns * sizeof(DevChain)))) return rc;
+    if ((rc = bm2_reserve(b->seeds, ns * sizeof(DevSeed)))) return rc;
+    if ((rc = bm2_reserve(b->srt, ns * 4))) return rc;
+    if ((rc = bm2_reserve(b->reg_seed, ns * 4))) return rc;
+    if ((rc = bm2_reserve(b->reg_chain, ns * 4))) return rc;
+    if ((rc = bm2_reserve(b->regs, ns * sizeof(DevReg)))) return rc;
+    if ((rc = bm2_reserve(b->slot_base, ns * 8))) return rc;
+    if ((rc = bm2_reserve(b->read_base, (size_t)(n + 1) * 8))) return rc;
+    if ((rc = bm2_reserve(b->n_chain, (size_t)(n + 1) * 4))) return rc;
+    if ((rc = bm2_reserve(b->n_reg, (size_t)(n + 1) * 4))) return rc;
+    if ((rc = bm2_reserve(b->n_chain0, (size_t)(n + 1) * 4))) return rc;
+    if ((rc = bm2_reserve(b->n_out, (size_t)(n + 1) * 4))) return rc;
+    if ((rc = bm2_check(hipMemsetAsync(b->reg_seed.p, 0xff, ns * 4, s), "memset reg_seed"))) return rc;
+    hipLaunchKernelGGL(k_read_base, dim3((n + 255) / 256), dim3(256), 0, s, n, (const int32_t *)b->smem_cnt.p,
+                       (const int64_t *)b->smem_off.p, (const int64_t *)b->sa_off.p, (int64_t *)b->read_base.p);
+    if ((rc = bm2_launch_chain(c, cp, n, (const int32_t *)b->len.p, (const bm2_smem_t *)b->smem.p, (const int32_t *)b->smem_cnt.p,
+                               (const int64_t *)b->smem_off.p, (const int64_t *)b->sa_off.p, (const int64_t *)b->sa_coord.p,
+                               (WChain *)b->wchain.p, (WSeed *)b->wseed.p, (BtNode *)b->nodes.p, (int32_t *)b->order.p,
+                               (DevChain *)b->chn.p, (DevSeed *)b->seeds.p, (int32_t *)b->srt.p, (int32_t *)b->reg_seed.p,
+                               (int32_t *)b->reg_chain.p, (int32_t *)b->n_chain.p, (int32_t *)b->n_reg.p, (int32_t *)b->n_chain0.p))) return rc;
+    tick(c, "chain");
+    if ((rc = bm2_launch_slot_base(c, n, (const int64_t *)b->read_base.p, (const int32_t *)b->n_reg.p, (int64_t *)b->slot_base.p))) return rc;
+    if ((rc = bm2_launch_extend(c, *opt, n_sa, (const uint8_t *)b->enc.p, (const int64_t *)b->off.p, (const int32_t *)b->len.p,
+                                (const int64_t *)b->slot_base.p, (const int32_t *)b->reg_seed.p, (const int32_t *)b->reg_chain.p,
+                                (const DevChain *)b->chn.p, (const DevSeed *)b->seeds.p, (DevReg *)b->regs.p,
+                                (unsigned long long *)b->counters.p + 5))) return rc;
+    tick(c, "extend");
+    if ((rc = bm2_launch_postfilter(c, cp, n, (const int32_t *)b->len.p, (const int64_t *)b->read_base.p, (const int32_t *)b->n_chain.p,
+                                    (const int32_t *)b->n_reg.p, (const DevChain *)b->chn.p, (const DevSeed *)b->seeds.p,
+                                    (int32_t *)b->srt.p, (DevReg *)b->regs.p, (int32_t *)b->n_out.p))) return rc;
+    if ((rc = bm2_scan_i32(c, (const int32_t *)b->n_out.p, n, (int64_t *)b->out_off.p, b->scan_tmp))) return rc;
+    int64_t n_out = 0;
+    unsigned long long h_cnt[8];
+    if ((rc = bm2_check(hipMemcpyAsync(&n_out, (int64_t *)b->out_off.p + n, 8, hipMemcpyDeviceToHost, s), "D2H n_out"))) return rc;
+    if ((rc = bm2_check(hipMemcpyAsync(h_cnt, b->counters.p, 64, hipMemcpyDeviceToHost, s), "D2H counters"))) return rc;
+    if ((rc = bm2_check(hipStreamSynchronize(s), "postfilter"))) return rc;
+    if ((rc = bm2_reserve(b->out_regs, (size_t)(n_out + 1) * sizeof(bm2_reg_t)))) return rc;
+    if ((rc = bm2_launch_reg_gather(c, n, (const int64_t *)b->read_base.p, (const int32_t *)b->n_reg.p, (const DevReg *)b->regs.p,
+                                    (const int64_t *)b->out_off.p, (bm2_reg_t *)b->out_regs.p, n_out))) return rc;
+    tick(c, "postfilter");
+    if ((rc = bm2_check(hipStreamSynchronize(s), "gather"))) return rc;
+    b->n_out_regs = n_out;
+    b->stats.n_reg = n_out; b->stats.n_lf = (int64_t)h_cnt[4]; b->stats.n_sw_cells = (int64_t)h_cnt[5];
+    b->stats.n_sw_tasks = (int64_t)h_cnt[6];
+    b->ran = true; c->ev_ready = true;
+    return BM2_OK;
+}
+
+extern "C" int bm2_batch_stats(bm2_ctx *c, bm2_stats *st) {
+    if (!c || !c->batch || !c->batch->ran || !st) return BM2_EINVAL;
+    Batch *b = c->batch;
+    // n_chain / n_reg_raw are summed on demand (diagnostic only)
+    std::vector<int32_t> h((size_t)b->n_reads);
+    int64_t nc = 0, nr = 0;
+    if (b->n_reads && b->n_chain.p) {
+        if (hipMemcpy(h.data(), b->n_chain.p, (size_t)b->n_reads * 4, hipMemcpyDeviceToHost) == hipSuccess) for (int32_t v : h) nc += v;
+        if (hipMemcpy(h.data(), b->n_reg.p, (size_t)b->n_reads * 4, hipMemcpyDeviceToHost) == hipSuccess) for (int32_t v : h) nr += v;
+    }
+    b->stats.n_chain = nc; b->stats.n_reg_raw = nr;
+    *st = b->stats;
+    return BM2_OK;
+}
+
+extern "C" int bm2_batch_download(bm2_ctx *c, bm2_reg_t *regs, int64_t cap, int64_t *reg_off, int64_t *n_out) {
+    if (!c || !c->batch || !c->batch->ran || !reg_off || !n_out) { bm2_set_error("bm2_batch_download: nothing to download"); return BM2_EINVAL; }
+    Batch *b = c->batch;
+    *n_out = b->n_out_regs;
+    int rc = bm2_check(hipMemcpy(reg_off, b->out_off.p, (size_t)(b->n_reads + 1) * 8, hipMemcpyDeviceToHost), "D2H reg_off");
+    if (rc) return rc;
+    if (b->n_out_regs > cap) { bm2_set_error("regs capacity %ld < %ld", (long)cap, (long)b->n_out_regs); return BM2_ECAP; }
+    if (b->n_out_regs && !regs) return BM2_EINVAL;
+    if (b->n_out_regs) rc = bm2_check(hipMemcpy(regs, b->out_regs.p, (size_t)b->n_out_regs * sizeof(bm2_reg_t), hipMemcpyDeviceToHost), "D2H regs");
+    return rc;
+}
+
+extern "C" int bm2_batch_kernel_ms(bm2_ctx *c, float *ms, int32_t cap, int32_t *n_out, const char **names) {
+    if (!c || !ms || !n_out) return BM2_EINVAL;
+    if (!c->ev_ready) { *n_out = 0; return BM2_OK; }
+    int n = c->n_ev < cap ? c->n_ev : cap;
+    for (int i = 0; i < n; i++) {
+        float t = 0;
+        (void)hipEventElapsedTime(&t, c->ev[i], c->ev[i + 1]);
+        ms[i] = t;
+        if (names) names[i] = c->ev_name[i];
+    }
+    *n_out = n;
+    return BM2_OK;
+}
+
+extern "C" int bm2_seed_chain_extend(bm2_ctx *c, const bm2_reads *reads, const bm2_opt *opt, bm2_reg_t *regs, int64_t cap,
+                                     int64_t *reg_off, int64_t *n_out, bm2_stats *stats) {
+    int rc = bm2_batch_upload(c, reads);
+    if (!rc) rc = bm2_batch_run(c, opt);
+    if (!rc && stats) rc = bm2_batch_stats(c, stats);
+    if (!rc) rc = bm2_batch_download(c, regs, cap, reg_off, n_out);
+    return rc;
+}
+
+// ---- S2 --------------------------------------------------------------------------------------------------------
+extern "C" int bm2_smem(bm2_ctx *c, const bm2_reads *reads, const bm2_opt *opt, bm2_smem_t *out, int64_t cap, int64_t *n_out) {
+    if (!n_out) return BM2_EINVAL;
+    int rc = check_opt(opt);
+    if (!rc) rc = bm2_batch_upload(c, reads);
+    if (rc) return rc;
+    Batch *b = c->batch;
+    const int n = b->n_reads;
+    c->n_ev = 0; c->ev_ready = false;
+    (void)hipEventRecord(c->ev[0], c->stream);
+    *n_out = 0;
+    if (n == 0) return BM2_OK;
+    if ((rc = run_seeding(c, b, opt, false))) return rc;
+    *n_out = b->n_smem;
+    if (b->n_smem > cap) { bm2_set_error("SMEM capacity %ld < %ld", (long)cap, (long)b->n_smem); return BM2_ECAP; }
+    if (b->n_smem == 0) return BM2_OK;
+    // bump order -> (rid, m, n) order: offsets by a scan over the per-read counts
+    if ((rc = bm2_reserve(b->smem_sorted_off, (size_t)(n + 2) * 8))) return rc;
+    if ((rc = bm2_reserve(b->smem_sorted, (size_t)b->n_smem * sizeof(bm2_smem_t)))) return rc;
+    if ((rc = bm2_scan_i32(c, (const int32_t *)b->smem_cnt.p, n, (int64_t *)b->smem_sorted_off.p, b->scan_tmp))) return rc;
+    if ((rc = bm2_launch_smem_gather(c, n, (const bm2_smem_t *)b->smem.p, (const int64_t *)b->smem_off.p, (const int32_t *)b->smem_cnt.p,
+                                     (const int64_t *)b->smem_sorted_off.p, (bm2_smem_t *)b->smem_sorted.p))) return rc;
+    rc = bm2_check(hipMemcpyAsync(out, b->smem_sorted.p, (size_t)b->n_smem * sizeof(bm2_smem_t), hipMemcpyDeviceToHost, c->stream), "D2H smem");
+    if (!rc) rc = bm2_check(hipStreamSynchronize(c->stream), "bm2_smem sync");
+    return rc;
+}
+
+__global__ void k_occ_cnt(const bm2_smem_t *__restrict__ sm, int64_t n, int32_t max_occ, int32_t *occ) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) occ[i] = (int32_t)(sm[i].s < max_occ ? (sm[i].s < 0 ? 0 : sm[i].s) : max_occ);
+}
+
+extern "C" int bm2_sal(bm2_ctx *c, const bm2_smem_t *smems, int64_t n, int32_t max_occ, int64_t *coords, int64_t cap, int64_t *n_out) {
+    if (!c || n < 0 || max_occ <= 0 || !n_out || (n > 0 && !smems)) { bm2_set_error("bm2_sal: bad argument"); return BM2_EINVAL; }
+    if (!c->has_index) { bm2_set_error("context was created without an index"); return BM2_EINVAL; }
+    int rc = bm2_check(hipSetDevice(c->device), "hipSetDevice");
+    if (rc) return rc;
+    *n_out = 0;
+    if (n == 0) return BM2_OK;
+    Batch *b = get_batch(c);
+    hipStream_t s = c->stream;
+    if ((rc = bm2_reserve(b->smem_sorted, (size_t)n * sizeof(bm2_smem_t)))) return rc;
+    if ((rc = bm2_reserve(b->occ_cnt, (size_t)(n + 1) * 4))) return rc;
+    if ((rc = bm2_reserve(b->sa_off, (size_t)(n + 2) * 8))) return rc;
+    if ((rc = bm2_check(hipMemcpyAsync(b->smem_sorted.p, smems, (size_t)n * sizeof(bm2_smem_t), hipMemcpyHostToDevice, s), "H2D smems"))) return rc;
+    hipLaunchKernelGGL(k_occ_cnt, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const bm2_smem_t *)b->smem_sorted.p, n, max_occ, (int32_t *)b->occ_cnt.p);
+    if ((rc = bm2_scan_i32(c, (const int32_t *)b->occ_cnt.p, n, (int64_t *)b->sa_off.p, b->scan_tmp))) return rc;
+    int64_t n_sa = 0;
+    if ((rc = bm2_check(hipMemcpyAsync(&n_sa, (int64_t *)b->sa_off.p + n, 8, hipMemcpyDeviceToHost, s), "D2H n_sa"))) return rc;
+    if ((rc = bm2_check(hipStreamSynchronize(s), "scan"))) return rc;
+    *n_out = n_sa;
+    if (n_sa > cap) { bm2_set_error("coords capacity %ld < %ld", (long)cap, (long)n_sa); return BM2_ECAP; }
+    if (n_sa == 0) return BM2_OK;
+    if (!coords) return BM2_EINVAL;
+    if ((rc = bm2_reserve(b->sa_coord, (size_t)(n_sa + 1) * 8))) return rc;
+    if ((rc = bm2_launch_sal_expand(c, (const bm2_smem_t *)b->smem_sorted.p, n, (const int64_t *)b->sa_off.p, max_occ, (int64_t *)b->sa_coord.p))) return rc;
+    if ((rc = bm2_launch_sal(c, n_sa, (int64_t *)b->sa_coord.p, nullptr))) return rc;
+    rc = bm2_check(hipMemcpyAsync(coords, b->sa_coord.p, (size_t)n_sa * 8, hipMemcpyDeviceToHost, s), "D2H coords");
+    if (!rc) rc = bm2_check(hipStreamSynchronize(s), "bm2_sal sync");
+    return rc;
+}
+
+// ---- diagnostic: raw device arrays of the last bm2_batch_run (used by the stage-level parity tests) ------------------
+extern "C" int bm2_batch_fetch(bm2_ctx *c, const char *what, void *out, int64_t cap_bytes, int64_t *n_bytes) {
+    if (!c || !c->batch || !what || !n_bytes) return BM2_EINVAL;
+    Batch *b = c->batch;
+    const int n = b->n_reads;
+    const size_t ns = (size_t)b->n_sa;
+    struct { const char *name; DevBuf *buf; size_t bytes; } tab[] = {
+        { "smem", &b->smem, (size_t)b->n_smem * sizeof(bm2_smem_t) }, { "smem_cnt", &b->smem_cnt, (size_t)n * 4 },
+        { "smem_off", &b->smem_off, (size_t)n * 8 }, { "sa_off", &b->sa_off, (size_t)(b->n_smem + 1) * 8 },
+        { "sa_coord", &b->sa_coord, ns * 8 }, { "read_base", &b->read_base, (size_t)n * 8 },
+        { "n_chain", &b->n_chain, (size_t)n * 4 }, { "n_chain0", &b->n_chain0, (size_t)n * 4 }, { "n_reg", &b->n_reg, (size_t)n * 4 },
+        { "n_out", &b->n_out, (size_t)n * 4 }, { "chn", &b->chn, ns * sizeof(DevChain) }, { "seeds", &b->seeds, ns * sizeof(DevSeed) },
+        { "regs_raw", &b->regs, ns * sizeof(DevReg) }, { "reg_seed", &b->reg_seed, ns * 4 },
+    };
+    for (auto &t : tab) if (!strcmp(t.name, what)) {
+        *n_bytes = (int64_t)t.bytes;
+        if ((int64_t)t.bytes > cap_bytes) return BM2_ECAP;
+        if (!t.bytes) return BM2_OK;
+        if (!t.buf->p || !out) return BM2_EINVAL;
+        return bm2_check(hipMemcpy(out, t.buf->p, t.bytes, hipMemcpyDeviceToHost), "bm2_batch_fetch");
+    }
+    bm2_set_error("bm2_batch_fetch: unknown array '%s'", what);
+    return BM2_EINVAL;
+}

@@ -141,6 +141,9 @@ int bm2_batch_stats(bm2_ctx *c, bm2_stats *stats);
 int bm2_batch_download(bm2_ctx *c, bm2_reg_t *regs, int64_t cap, int64_t *reg_off, int64_t *n_out);
 /* wall time of the last bm2_batch_run measured with hipEvents on the library's stream, per kernel */
 int bm2_batch_kernel_ms(bm2_ctx *c, float *ms, int32_t cap, int32_t *n_out, const char **names);
+/* diagnostic: copy a raw device array of the last bm2_batch_run to the host ("smem", "sa_coord", "chn", "seeds",
+ * "regs_raw", ... see pipeline.hip); lets tests pin every stage against the oracle (level ii) */
+int bm2_batch_fetch(bm2_ctx *c, const char *what, void *out, int64_t cap_bytes, int64_t *n_bytes);
 
 #ifdef __cplusplus
 }

@@ -50,3 +50,87 @@ def pack_pairs(bm2, triples):
         refs.append(t); qers.append(q)
         ro += len(t); qo += len(q)
     return pairs, np.concatenate(refs), np.concatenate(qers)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+import os
+import subprocess
+
+
+def load_golden(golden_dir, name):
+    """-> (index_prefix, enc, off, len, dump dict)"""
+    from tools import refio
+    pre = os.path.join(golden_dir, name + ".fa")
+    _, seqs = refio.read_fastq(os.path.join(golden_dir, name + ".reads.txt"))
+    enc, off, ln = refio.pack_reads(seqs)
+    d = dict(np.load(os.path.join(golden_dir, name + ".dump.npz")))
+    return pre, enc, off, ln, d
+
+
+def ref_binary(kind="bwa-mem2"):
+    """Path of the prebuilt reference binary matching this host's ISA (oracle/_ref travels to the GPU box), or None."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    flags = open("/proc/cpuinfo").read()
+    for a in (["avx512bw"] if "avx512bw" in flags else []) + (["avx2"] if "avx2" in flags else []) + ["sse41"]:
+        p = os.path.join(root, "oracle", "_ref", "%s.%s" % (kind, a))
+        if os.path.exists(p):
+            return p
+    return None
+
+
+def build_index(fa_path):
+    exe = ref_binary()
+    if exe is None:
+        return False
+    subprocess.check_call([exe, "index", fa_path], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return True
+
+
+def chain_mask(a):
+    """CHN0 records carry w/kept/first that mem_chain_seeds never initialises; compare only the defined fields."""
+    b = a.copy()
+    b["w"] = 0; b["kept"] = 0; b["first"] = 0
+    return b
+
+
+def gpu_stage_records(ctx, bm2, n_reads):
+    """Re-assemble the device arrays of the last batch_run into the record layout of refdump (CHN1/SEED1/REGRAW)."""
+    from tools import refio
+    base = ctx.batch_fetch("read_base", "<i8")
+    n_chain = ctx.batch_fetch("n_chain", "<i4")
+    n_reg = ctx.batch_fetch("n_reg", "<i4")
+    chn = ctx.batch_fetch("chn", bm2.DEVCHAIN_DT)
+    seeds = ctx.batch_fetch("seeds", bm2.DEVSEED_DT)
+    regs = ctx.batch_fetch("regs_raw", bm2.DEVREG_DT)
+    C, S, R = [], [], []
+    for r in range(n_reads):
+        b = int(base[r])
+        for j in range(int(n_chain[r])):
+            c = chn[b + j]
+            C.append((r, c["n"], c["rid"], c["is_alt"], c["pos"], c["frac_rep"], c["w"], c["kept"], c["first"]))
+            for t in range(int(c["n"])):
+                s = seeds[int(c["seed_off"]) + t]
+                S.append((s["rbeg"], s["qbeg"], s["len"], s["score"], 0))
+        for i in range(int(n_reg[r])):
+            a = regs[b + i]
+            R.append((r, 0, a["rb"], a["re"], a["qb"], a["qe"], a["rid"], a["score"], a["truesc"], 0, 0, 0, 0, a["w"],
+                      a["seedcov"], 0, 0, a["seedlen0"], 0, 0, a["frac_rep"], 0))
+    return (np.array(C, dtype=refio.CHAIN_DT), np.array(S, dtype=refio.SEED_DT), np.array(R, dtype=refio.REG_DT))
+
+
+def regs_to_records(regs, reg_off):
+    from tools import refio
+    out = np.zeros(len(regs), refio.REG_DT)
+    reads = np.repeat(np.arange(len(reg_off) - 1), np.diff(reg_off))
+    out["read"] = reads
+    for f in ("rb", "re", "qb", "qe", "rid", "score", "truesc", "w", "seedcov", "seedlen0", "frac_rep"):
+        out[f] = regs[f]
+    return out
+
+
+def first_diff(a, b):
+    n = min(len(a), len(b))
+    for i in range(n):
+        if a[i] != b[i]:
+            return "first difference at %d:\n  exp %s\n  got %s" % (i, a[i], b[i])
+    return "lengths differ: %d vs %d" % (len(a), len(b))

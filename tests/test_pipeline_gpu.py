@@ -1,0 +1,113 @@
+"""Hot-path parity on the GPU: every stage of libbm2's device pipeline against the reference dumps (golden fixtures)
+and against the oracle on freshly generated inputs.  Bit-exact; calls go through the C ABI (bm2.py is a thin ctypes
+binding)."""
+import os
+
+import numpy as np
+import pytest
+
+import bm2
+from helpers import (build_index, first_diff, gpu_stage_records, load_golden, regs_to_records)
+from tools import oracle, refio, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(exp, got, what):
+    assert len(exp) == len(got) and exp.tobytes() == got.tobytes(), "%s: %s" % (what, first_diff(exp, got))
+
+
+@pytest.mark.parametrize("name", ["g60k", "g20k_l76"])
+def test_golden_all_stages(gpu_ctx_factory, golden_dir, name):
+    pre, enc, off, ln, d = load_golden(golden_dir, name)
+    ctx = gpu_ctx_factory(pre)
+    opt = bm2.default_opt()
+    # S2: SMEMs, sorted (rid, m, n)
+    sm = ctx.smem(enc, off, ln, opt)
+    exp = d["SMEM"]
+    got = np.zeros(len(sm), refio.SMEM_DT)
+    for a, b in (("read", "rid"), ("m", "m"), ("n", "n"), ("k", "k"), ("l", "l"), ("s", "s")):
+        got[a] = sm[b]
+    _same(exp, got, "SMEM")
+    # S2: SA coordinates in (SMEM, occurrence) order
+    co = ctx.sal(sm, opt.max_occ)
+    _same(d["SACOORD"], co, "SACOORD")
+    # S3
+    regs, reg_off, st = ctx.seed_chain_extend(enc, off, ln, opt)
+    C, S, R = gpu_stage_records(ctx, bm2, len(ln))
+    _same(d["CHN1"], C, "CHN1")
+    _same(d["SEED1"], S, "SEED1")
+    _same(d["REGRAW"], R, "REGRAW")
+    _same(d["REGPRG"], regs_to_records(regs, reg_off), "REGPRG")
+    assert st["n_smem"] == len(d["SMEM"]) and st["n_sa"] == len(d["SACOORD"]) and st["n_reg"] == len(d["REGPRG"])
+
+
+def test_empty_and_degenerate_batches(gpu_ctx_factory, golden_dir):
+    pre, enc, off, ln, d = load_golden(golden_dir, "g20k_l76")
+    ctx = gpu_ctx_factory(pre)
+    opt = bm2.default_opt()
+    regs, reg_off, st = ctx.seed_chain_extend(np.zeros(0, np.uint8), np.zeros(0, np.int64), np.zeros(0, np.int32), opt)
+    assert len(regs) == 0 and list(reg_off) == [0]
+    # reads that cannot seed: all N, shorter than min_seed_len, length 1
+    seqs = [np.full(50, 4, np.uint8), np.array([0, 1, 2, 3, 0, 1], np.uint8), np.array([2], np.uint8)]
+    e, o, l = refio.pack_reads(seqs)
+    regs, reg_off, st = ctx.seed_chain_extend(e, o, l, opt)
+    assert len(regs) == 0 and list(reg_off) == [0, 0, 0, 0]
+    assert len(ctx.smem(e, o, l, opt)) == 0
+
+
+def _fresh_case(tmp_path, seed, contigs, n_reads, L, **kw):
+    names, ctg, alts = synth.make_genome(seed, contigs, alt_contigs=1, alt_len=3000, n_repeat_families=6,
+                                         repeat_len=(200, 3000), copies=(3, 40), divergence=(0.0, 0.08))
+    fa = str(tmp_path / "g.fa")
+    synth.write_fasta(fa, names, ctg)
+    if alts:
+        synth.write_alt(fa + ".alt", alts)
+    if not build_index(fa):
+        pytest.skip("oracle/_ref reference binary not present (build it with `make -C oracle ref`)")
+    reads = synth.make_reads_se(seed + 1, ctg, n_reads, L=L, **kw)
+    return fa, refio.pack_reads(reads)
+
+
+@pytest.mark.parametrize("seed,L,n", [(5, 150, 6000), (6, 101, 3000), (7, 250, 2000)])
+def test_fresh_inputs_vs_oracle(gpu_ctx_factory, tmp_path, seed, L, n):
+    fa, (enc, off, ln) = _fresh_case(tmp_path, seed, [300000, 150000, 50000], n, L)
+    ix = oracle.Index(fa)
+    try:
+        exp = ix.run(enc, off, ln)
+    finally:
+        ix.close()
+    ctx = gpu_ctx_factory(fa)
+    regs, reg_off, st = ctx.seed_chain_extend(enc, off, ln, bm2.default_opt())
+    _same(exp["REGPRG"], regs_to_records(regs, reg_off), "REGPRG")
+    c = exp["counters"]
+    assert st["n_ext"] == c["n_ext"] and st["n_lf"] == c["n_lf"] and st["n_sw_cells"] == c["n_sw_cells"]
+    assert st["n_sw_tasks"] == len(exp["PAIR"])
+
+
+def test_non_default_options_vs_oracle(gpu_ctx_factory, tmp_path):
+    fa, (enc, off, ln) = _fresh_case(tmp_path, 9, [120000, 60000], 2500, 150, sub_rate=0.03, indel_frac=0.3)
+    kw = dict(min_seed_len=15, w=30, max_occ=50, zdrop=40, b=3, o_del=4, o_ins=5, e_del=2, e_ins=1, pen_clip5=3, pen_clip3=7,
+              max_mem_intv=0, split_width=5, drop_ratio=0.3, max_chain_gap=500)
+    ix = oracle.Index(fa)
+    try:
+        exp = ix.run(enc, off, ln, oracle.default_opt(**kw))
+    finally:
+        ix.close()
+    ctx = gpu_ctx_factory(fa)
+    regs, reg_off, st = ctx.seed_chain_extend(enc, off, ln, bm2.default_opt(**kw))
+    _same(exp["REGPRG"], regs_to_records(regs, reg_off), "REGPRG")
+
+
+def test_split_api_is_idempotent(gpu_ctx_factory, golden_dir):
+    # upload once, run twice: identical regs (no state leaks between runs of a resident batch)
+    pre, enc, off, ln, d = load_golden(golden_dir, "g60k")
+    ctx = gpu_ctx_factory(pre)
+    opt = bm2.default_opt()
+    ctx.batch_upload(enc, off, ln)
+    ctx.batch_run(opt)
+    r1, o1 = ctx.batch_download()
+    ctx.batch_run(opt)
+    r2, o2 = ctx.batch_download()
+    assert r1.tobytes() == r2.tobytes() and o1.tobytes() == o2.tobytes()
+    assert [n for n, _ in ctx.batch_kernel_ms()] == ["smem", "sal", "chain", "extend", "postfilter"]
