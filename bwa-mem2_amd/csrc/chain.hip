@@ -272,7 +272,7 @@ k_chain(DevIndex ix, ChainParams o, int n_reads, const int32_t *__restrict__ len
     WChain *ch = wchain + base;
     WSeed *sd = wseed + base;
     int32_t *ord = order + base;
-    BTree bt; bt.nodes = nodes + base; bt.n_nodes = 0;     // <= n_sa/4 + 1 nodes are ever needed bt.n_keys = 0; bt.ch = ch;
+    BTree bt; bt.nodes = nodes + base; bt.n_nodes = 0; bt.n_keys = 0; bt.ch = ch;     // <= n_sa/4 + 1 nodes are ever needed
     bt.root = bt_new(bt, 0);
     int n_ch = 0, n_sd = 0;
     int b = 0, e = 0, l_rep = 0;
@@ -295,6 +295,9 @@ k_chain(DevIndex ix, ChainParams o, int n_reads, const int32_t *__restrict__ len
             int to_add = 0;
             if (bt.n_keys) {
                 const int lower = bt_lower(bt, s.rbeg);
+#ifdef BM2_DEBUG_CHAIN
+                if (r == 0) printf("seed rbeg=%ld qbeg=%d len=%d rid=%d lower=%d nkeys=%d root=%d rootn=%d w=%d gap=%d\n", (long)s.rbeg, s.qbeg, s.len, rid, lower, bt.n_keys, bt.root, bt.nodes[bt.root].n, o.w, o.max_chain_gap);
+#endif
                 if (lower < 0) to_add = 1;
                 else {
                     const int m = test_and_merge(o, ix.l_pac, ch[lower], s, rid, sd, n_sd);
