@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""bench.py -- hot-path throughput of libbm2 on MI355X (one process per GPU).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" = one pass of the device pipeline (SMEM seeding -> SA lookup -> chaining -> banded extension -> regs,
+i.e. mem_kernel1_core + mem_kernel2_core up to bwamem.cpp:1152) over one chunk of synthetic 150 bp paired-end reads
+that is already resident in HBM.  Reads shard across GPUs (per-GPU index replica, no collective on the data path;
+torch.distributed is used only for the barrier and the max-over-ranks of the timed region) => weak scaling.
+
+Prints ONE JSON line on rank 0 (see the driver contract in the task statement) with two extra objects:
+  roofline     -- the FM-index seeding kernel against the HBM peak, from ALGORITHMIC bytes (128 B per backwardExt,
+                  SURVEY.md section 8(d)) over its HIP-event-timed launches inside the timed region
+  cpu_baseline -- the compiled reference (oracle/_ref/bwa-mem2.<isa> mem) on this host's cores, bounded sample.
+"""
+import argparse
+import json
+import os
+import re
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "bwa-mem2_amd"))
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def log(*a):
+    print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def ref_binary():
+    flags = open("/proc/cpuinfo").read()
+    for a in (["avx512bw"] if "avx512bw" in flags else []) + (["avx2"] if "avx2" in flags else []) + ["sse41"]:
+        p = os.path.join(ROOT, "oracle", "_ref", "bwa-mem2." + a)
+        if os.path.exists(p):
+            return p, a
+    return None, None
+
+
+def contig_lengths(total_bp):
+    """Human-like spread of contig sizes summing to total_bp (25 primary contigs)."""
+    w = np.array([248, 242, 198, 190, 181, 171, 159, 145, 138, 133, 135, 133, 114, 107, 102, 90, 83, 80, 58, 64, 46,
+                  50, 156, 57, 16], dtype=np.float64)
+    l = np.maximum((w / w.sum() * total_bp).astype(np.int64), 2000)
+    return [int(x) for x in l]
+
+
+def prepare_genome(workdir, mbp, seed):
+    from tools import synth
+    pre = os.path.join(workdir, "genome_%dmbp_s%d.fa" % (mbp, seed))
+    meta = pre + ".contigs.npz"
+    if os.path.exists(pre + ".bwt.2bit.64") and os.path.exists(meta):
+        z = np.load(meta, allow_pickle=True)
+        return pre, [z["c%d" % i] for i in range(int(z["n"]))]
+    exe, isa = ref_binary()
+    if exe is None:
+        raise RuntimeError("oracle/_ref/bwa-mem2.* missing: run __graft_entry__.build() where /root/reference exists")
+    t = time.time()
+    total = int(mbp * 1e6)
+    names, ctg, alts = synth.make_genome(seed, contig_lengths(total), n_repeat_families=max(8, mbp),
+                                         repeat_len=(300, 6000), copies=(5, 200), divergence=(0.01, 0.15),
+                                         n_gaps=8, gap_len=(100, 5000), alt_contigs=3, alt_len=50000)
+    synth.write_fasta(pre, names, ctg)
+    synth.write_alt(pre + ".alt", alts)
+    log("genome %d Mbp generated in %.1fs; indexing with the reference (%s)..." % (mbp, time.time() - t, isa))
+    t = time.time()
+    subprocess.check_call([exe, "index", pre], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    log("index built in %.1fs" % (time.time() - t))
+    np.savez(meta, n=len(ctg), **{"c%d" % i: c for i, c in enumerate(ctg)})
+    return pre, ctg
+
+
+def cpu_baseline(prefix, contigs, n_pairs, read_len, workdir, seed):
+    """Time the compiled reference on a bounded sample of the same workload, all host cores."""
+    from tools import synth
+    exe, isa = ref_binary()
+    if exe is None:
+        return None
+    r1, r2 = synth.make_reads_pe(seed, contigs, n_pairs, L=read_len)
+    f1, f2 = os.path.join(workdir, "cpu_1.fq"), os.path.join(workdir, "cpu_2.fq")
+    synth.write_fastq(f1, r1, suffix="/1")
+    synth.write_fastq(f2, r2, suffix="/2")
+    cores = os.cpu_count() or 1
+    threads = min(cores, 128)
+    t = time.time()
+    p = subprocess.run([exe, "mem", "-t", str(threads), "-K", "100000000", "-o", "/dev/null", prefix, f1, f2],
+                       stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+    wall = time.time() - t
+    if p.returncode != 0:
+        log("reference mem failed:", p.stderr[-500:])
+        return None
+    n_proc, real = 0, 0.0
+    for m in re.finditer(r"Processed (\d+) reads in [\d.]+ CPU sec, ([\d.]+) real sec", p.stderr):
+        n_proc += int(m.group(1)); real += float(m.group(2))
+    kern = re.search(r"Total kernel \(smem\+sal\+bsw\) time avg: ([\d.]+)", p.stderr)
+    kern_s = float(kern.group(1)) if kern else None
+    if n_proc == 0 or real <= 0:
+        return None
+    out = {"value": n_proc / real, "unit": "reads/s", "cores": threads, "kind": "reference",
+           "sample": "%d x %d bp PE reads, same index; bwa-mem2 v2.2.1 %s build, `mem -t %d`; whole `mem` chunk time "
+                     "(seed+chain+extend+pairing+SAM) from its own 'Processed N reads' lines; wall %.1fs"
+                     % (n_proc, read_len, isa, threads, wall)}
+    if kern_s:
+        out["hot_path_value"] = n_proc / kern_s
+        out["hot_path_note"] = "reads / reference's own per-thread-average SMEM+SAL+BSW kernel time (same scope as `value`)"
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--genome-mbp", type=int, default=int(os.environ.get("BM2_BENCH_GENOME_MBP", 128)))
+    ap.add_argument("--reads", type=int, default=int(os.environ.get("BM2_BENCH_READS", 1000000)),
+                    help="reads per GPU per step (both mates counted)")
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--cpu-pairs", type=int, default=int(os.environ.get("BM2_BENCH_CPU_PAIRS", 250000)))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workdir", default=os.environ.get("BM2_BENCH_WORKDIR", "/tmp/bm2_bench"))
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (libbm2 has no CPU fallback)")
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    import bm2
+    from tools import synth
+
+    os.makedirs(a.workdir, exist_ok=True)
+    seed = 20260924
+    if rank == 0:
+        prefix, contigs = prepare_genome(a.workdir, a.genome_mbp, seed)
+    if world > 1:
+        dist.barrier()
+    if rank != 0:
+        prefix, contigs = prepare_genome(a.workdir, a.genome_mbp, seed)
+
+    t = time.time()
+    ctx = bm2.Context(local, prefix)
+    log("rank %d: index replica in HBM after %.1fs" % (rank, time.time() - t))
+    r1, r2 = synth.make_reads_pe(seed + 1000 + rank, contigs, a.reads // 2, L=a.read_len)
+    reads = np.empty((2 * len(r1), a.read_len), np.uint8)
+    reads[0::2] = r1; reads[1::2] = r2                      # mates interleaved, as bseq_read_orig delivers PE chunks
+    n_reads = len(reads)
+    enc = reads.reshape(-1)
+    off = np.arange(n_reads, dtype=np.int64) * a.read_len
+    ln = np.full(n_reads, a.read_len, np.int32)
+    opt = bm2.default_opt()
+    ctx.batch_upload(enc, off, ln)
+
+    for _ in range(a.warmup):
+        ctx.batch_run(opt)
+    kms = {}
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        ctx.batch_run(opt)                                   # returns after the library's stream has drained
+        for name, ms in ctx.batch_kernel_ms():
+            kms[name] = kms.get(name, 0.0) + ms
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    st = ctx.batch_stats()
+
+    if rank == 0:
+        steps = max(a.steps, 1)
+        value = world * n_reads * a.steps / dt
+        stage_ms = {k: v / steps for k, v in kms.items()}
+        fm_bytes = 128.0 * st["n_ext"]                       # two 64-B CP_OCC lines per backwardExt
+        smem_ms = stage_ms.get("smem", 0.0)
+        ach = fm_bytes / (smem_ms * 1e-3) / 1e9 if smem_ms > 0 else 0.0
+        cells = st["n_sw_cells"]
+        ext_ms = stage_ms.get("extend", 0.0)
+        dominant = max(stage_ms, key=stage_ms.get) if stage_ms else None
+        out = {
+            "metric": "aligned reads/s (150bp PE vs GRCh38) at 1/2/4/8 GPU; SAM bit-exact vs ref",
+            "value": value, "unit": "reads/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int32", "data": "synthetic",
+            "config": {"workload": "config 3 shape (SMEM+SAL+chain+banded-SW all on device), %d x %d bp PE reads per GPU "
+                                   "per step, synthetic %d Mbp genome with planted repeats/ALT/N-gaps (a GRCh38-size index "
+                                   "cannot be built inside the bench: the reference's `index` is single-threaded, ~0.5 us/bp); "
+                                   "output = mem_alnreg_t regs at bwamem.cpp:1152 (pairing/SAM formatting not included)"
+                                   % (n_reads, a.read_len, a.genome_mbp),
+                       "reads_per_gpu_per_step": n_reads, "read_len": a.read_len, "genome_mbp": a.genome_mbp,
+                       "parallelism": "reads sharded over %d GPU(s), index replica per GPU, no collectives" % world},
+            "stage_ms_per_step": stage_ms, "dominant_stage": dominant,
+            "work_per_read": {"backwardExt": st["n_ext"] / n_reads, "lf_steps": st["n_lf"] / n_reads,
+                              "sa_lookups": st["n_sa"] / n_reads, "sw_tasks": st["n_sw_tasks"] / n_reads,
+                              "sw_cells": cells / n_reads, "regs": st["n_reg"] / n_reads},
+            "roofline": {"kernel": "k_smem", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": fm_bytes, "avg_launch_ms": smem_ms},
+            "extend_kernel": {"kernel": "k_extend", "gcups": cells / (ext_ms * 1e-3) / 1e9 if ext_ms > 0 else 0.0,
+                              "avg_launch_ms": ext_ms, "cells_per_launch": cells},
+        }
+        if not a.no_cpu_baseline:
+            t = time.time()
+            cb = cpu_baseline(prefix, contigs, a.cpu_pairs, a.read_len, a.workdir, seed + 5)
+            log("cpu baseline took %.1fs" % (time.time() - t))
+            out["cpu_baseline"] = cb
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
