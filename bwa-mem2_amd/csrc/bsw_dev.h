@@ -168,3 +168,133 @@ static __device__ int bsw_extend_wave(const uint8_t *__restrict__ qp, int qs, in
     out.gscore = gscore; out.max_off = max_off;
     return cells;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Register-resident variant for queries of up to 64*NCH - 1 bases (150 bp reads: NCH <= 3).  Lane l owns the fixed
+// columns l, l+64, ... so the H/E row state and the query bases never leave VGPRs: no LDS, no per-row global loads.
+// Same row-uniform control flow as bsw_extend_wave; columns outside [beg, end] simply keep their registers, which
+// reproduces the reference's "stale eh[] entries are seen again when the band regrows" behaviour for free.
+// Every per-row decision is kept in SGPRs (readfirstlane / ballots), so the row loop is straight-line VALU with
+// scalar branches: no exec-mask juggling.
+// Scoring uses the (match, mismatch, ambiguous) structure of bwa_fill_scmat (bwa.cpp:248-257), which is also all the
+// reference's SIMD kernels implement (bandedSWA.cpp:286-290): P.mat[0] / P.mat[1] / P.mat[4].
+template <int NCH>
+static __device__ int bsw_extend_reg(const uint8_t *__restrict__ qp, int qs, int qlen_,
+                                     const uint8_t *__restrict__ tp, int ts, int tlen_,
+                                     int w_, int h0_, const SwParams &P, SwOut &out) {
+    const int lane = threadIdx.x & 63;
+    const int qlen = uni(qlen_), tlen = uni(tlen_), w = uni(w_), h0 = uni(h0_);
+    const int o_del = uni(P.o_del), e_del = uni(P.e_del), e_ins = uni(P.e_ins), zdrop = uni(P.zdrop);
+    const int oe_del = o_del + e_del, oe_ins = uni(P.o_ins) + e_ins;
+    const int sc_match = uni(P.mat[0]), sc_mis = uni(P.mat[1]), sc_amb = uni(P.mat[4]);
+    const int e1 = h0 > oe_ins ? h0 - oe_ins : 0;
+    const int le = lane * e_ins, le1 = le - e_ins;
+    int H[NCH], E[NCH], Q[NCH], X[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+        const int j = c * 64 + lane;
+        const int qv = j < qlen ? (int)qp[(int64_t)j * qs] : 4;
+        Q[c] = qv > 3 ? 5 : qv;                                                     // 5 never equals a target code
+        X[c] = qv > 3 ? sc_amb : sc_mis;                                            // score against a non-matching base
+        H[c] = j == 0 ? h0 : (j <= qlen ? imax(e1 - (j - 1) * e_ins, 0) : 0);      // first row, bandedSWA.cpp:143-145
+        E[c] = 0;
+    }
+    int beg = 0, end = qlen, maxv = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0;
+    int cells = 0;
+    int tchunk = 4;
+    for (int i = 0; i < tlen; ++i) {
+        if ((i & 63) == 0) { const int ti = i + lane; tchunk = ti < tlen ? (int)tp[(int64_t)ti * ts] : 4; }
+        const int tb = __builtin_amdgcn_readlane(tchunk, i & 63);
+        const bool t_amb = tb > 3;
+        const int s_eq = t_amb ? sc_amb : sc_match;
+        beg = beg < i - w ? i - w : beg;
+        end = end > i + w + 1 ? i + w + 1 : end;
+        end = end > qlen ? qlen : end;
+        int h1 = 0;
+        if (beg == 0) { h1 = h0 - (o_del + e_del * (i + 1)); h1 = h1 < 0 ? 0 : h1; }
+        int fc = 0, m = 0, mj = -1, firstnz = -1, lastnz = -1;
+        cells += end > beg ? end - beg : 0;
+        const int cb = beg >> 6, ce = end >> 6;
+        int hcarry = h1;
+        if (beg <= end) {
+#pragma unroll
+            for (int c = 0; c < NCH; c++) {
+                if (c >= cb && c <= ce) {                                           // wave-uniform
+                    const int jb = c * 64;
+                    // lane masks of the band inside this chunk, built on the scalar unit
+                    const int lo = beg > jb ? beg - jb : 0;
+                    const int hi = end - jb < 64 ? end - jb : 64;                   // active lanes [lo, hi)
+                    const int hi2 = end - jb + 1 < 64 ? end - jb + 1 : 64;          // stored lanes  [lo, hi2)
+                    const unsigned long long mlo = (1ULL << lo) - 1ULL;
+                    const unsigned long long mhi = hi >= 64 ? ~0ULL : ((1ULL << hi) - 1ULL);
+                    const unsigned long long mhi2 = hi2 >= 64 ? ~0ULL : ((1ULL << hi2) - 1ULL);
+                    const unsigned long long actm = mhi & ~mlo, stm = mhi2 & ~mlo;
+                    const bool act = __builtin_amdgcn_inverse_ballot_w64(actm);
+                    const bool st = __builtin_amdgcn_inverse_ballot_w64(stm);
+                    const int Hd = H[c], Ec = E[c];
+                    int sc = Q[c] == tb ? s_eq : X[c];
+                    if (t_amb) sc = sc_amb;
+                    const int M = (act && Hd != 0) ? Hd + sc : 0;
+                    const int Pm = wave_scan_max(imax(M - oe_ins, 0) + le, 0);
+                    const int Pprev = wave_shr1(Pm, NEG_BIG);
+                    const int F = imax(fc - le, Pprev - le1);
+                    const int h = act ? imax(imax(M, Ec), F) : 0;
+                    const int hs = wave_shr1(h, hcarry);
+                    const int en = act ? imax(imax(Ec - e_del, M - oe_del), 0) : 0;
+                    H[c] = st ? hs : Hd;
+                    E[c] = st ? en : Ec;
+                    if (actm) {
+                        // row maximum and the LAST column holding it (bandedSWA.cpp:188-189): max over (h << 6 | lane) + 1
+                        const int key = act ? (((h << 6) | lane) + 1) : 0;
+                        const int kmax = __builtin_amdgcn_readlane(wave_scan_max(key, 0), 63) - 1;
+                        const int cm = kmax >> 6;
+                        if (cm >= m) { m = cm; mj = jb + (kmax & 63); }
+                        h1 = __builtin_amdgcn_readlane(h, hi - 1);
+                    }
+                    hcarry = __builtin_amdgcn_readlane(h, 63);
+                    fc = imax(fc - 64 * e_ins, __builtin_amdgcn_readlane(Pm, 63) - 63 * e_ins);
+                    const unsigned long long nz = __ballot((hs | en) != 0);
+                    const unsigned long long nzb = nz & actm, nze = nz & stm;
+                    if (firstnz < 0 && nzb) firstnz = jb + __builtin_ctzll(nzb);
+                    if (nze) lastnz = jb + 63 - __builtin_clzll(nze);
+                }
+            }
+        }
+        const int jfin = beg < end ? end : beg;
+        if (jfin == qlen) {
+            max_ie = gscore > h1 ? max_ie : i;
+            gscore = gscore > h1 ? gscore : h1;
+        }
+        if (m == 0) break;
+        if (m > maxv) {
+            maxv = m; max_i = i; max_j = mj;
+            const int d = mj - i;
+            max_off = imax(max_off, d < 0 ? -d : d);
+        } else if (zdrop > 0) {
+            if (i - max_i > mj - max_j) {
+                if (maxv - m - ((i - max_i) - (mj - max_j)) * e_del > zdrop) break;
+            } else {
+                if (maxv - m - ((mj - max_j) - (i - max_i)) * e_ins > zdrop) break;
+            }
+        }
+        const int nb = firstnz >= 0 ? firstnz : end;
+        const int jl = imax(lastnz, nb - 1);
+        beg = nb;
+        end = jl + 2 < qlen ? jl + 2 : qlen;
+    }
+    out.score = maxv; out.qle = max_j + 1; out.tle = max_i + 1; out.gtle = max_ie + 1;
+    out.gscore = gscore; out.max_off = max_off;
+    return cells;
+}
+
+// dispatch: registers when the query fits 4 chunks, the LDS ring otherwise
+static __device__ __forceinline__ int bsw_extend(const uint8_t *__restrict__ qp, int qs, int qlen,
+                                                 const uint8_t *__restrict__ tp, int ts, int tlen,
+                                                 int w, int h0, const SwParams &P, int *RH, int *RE, int RM, SwOut &out) {
+    const int nch = (qlen >> 6) + 1;
+    if (nch == 1) return bsw_extend_reg<1>(qp, qs, qlen, tp, ts, tlen, w, h0, P, out);
+    if (nch == 2) return bsw_extend_reg<2>(qp, qs, qlen, tp, ts, tlen, w, h0, P, out);
+    if (nch == 3) return bsw_extend_reg<3>(qp, qs, qlen, tp, ts, tlen, w, h0, P, out);
+    if (nch == 4) return bsw_extend_reg<4>(qp, qs, qlen, tp, ts, tlen, w, h0, P, out);
+    return bsw_extend_wave(qp, qs, qlen, tp, ts, tlen, w, h0, P, RH, RE, RM, out);
+}

@@ -27,7 +27,7 @@ static __device__ __forceinline__ int extend_side(const uint8_t *q, int qs, int 
     for (int i = 0; i < MAX_BAND_TRY; i++) {
         const int w = w0 << i;
         const int wc = band_clamp(w, len2, P, cls);
-        cells += bsw_extend_wave(q, qs, len2, t, ts, len1, wc, h0, P, RH, RE, RM, o);
+        cells += bsw_extend(q, qs, len2, t, ts, len1, wc, h0, P, RH, RE, RM, o);
         w_used = w;
         if (o.score == prev || o.max_off < (w >> 1) + (w >> 2) || i + 1 == MAX_BAND_TRY) break;
         prev = o.score;
