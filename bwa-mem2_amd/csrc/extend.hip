@@ -18,8 +18,242 @@ struct ExtParams {
     SwParams left, right;         // end_bonus = pen_clip5 / pen_clip3 (bwamem.cpp:2457-2463)
 };
 
-// one side, with the accept/retry rule of bwamem.cpp:2495-2496: stop when the score did not change, or the best cell
-// stayed within 3/4 of the band, or this was the last try.
+#define LANE_QMAX 160             // longest query the lane-per-task kernel takes; longer tasks go one-per-wavefront
+#define BIN_FALLBACK (LANE_QMAX + 1)
+#define N_BINS (LANE_QMAX + 2)
+
+// geometry of the two extension tasks of a seed (what a SeqPair + its seqBuf slices describe, bwamem.cpp:2229-2418)
+struct TaskGeom { const uint8_t *q, *t; int qs, ts, len2, len1; };
+static __device__ __forceinline__ TaskGeom task_geom(int side, const DevSeed &s, const DevChain &c, const uint8_t *query,
+                                                     int l_query, const uint8_t *ref) {
+    TaskGeom g;
+    if (side == 0) {            // left: query prefix and reference prefix, both walked backwards
+        g.len2 = s.qbeg; g.len1 = (int)(s.rbeg - c.rmax0);
+        g.q = query + s.qbeg - 1; g.qs = -1; g.t = ref + s.rbeg - 1; g.ts = -1;
+    } else {
+        const int qe0 = s.qbeg + s.len;
+        const int64_t re0 = s.rbeg + s.len - c.rmax0;
+        g.len2 = l_query - qe0; g.len1 = (int)(c.rmax1 - c.rmax0 - re0);
+        g.q = query + qe0; g.qs = 1; g.t = ref + c.rmax0 + re0; g.ts = 1;
+    }
+    return g;
+}
+
+// accept/clip decision of one finished side, bwamem.cpp:2497-2505 (left) and :2715-2722 (right)
+static __device__ __forceinline__ void apply_side(int side, DevReg &a, const DevSeed &s, int l_query, const SwOut &o, int h0,
+                                                  int w_used, int pen_clip) {
+    a.score = o.score;
+    if (side == 0) {
+        if (o.gscore <= 0 || o.gscore <= a.score - pen_clip) { a.qb = s.qbeg - o.qle; a.rb = s.rbeg - o.tle; a.truesc = a.score; }
+        else { a.qb = 0; a.rb = s.rbeg - o.gtle; a.truesc = o.gscore; }
+    } else {
+        if (o.gscore <= 0 || o.gscore <= a.score - pen_clip) { a.qe += o.qle; a.re += o.tle; a.truesc += a.score - h0; }
+        else { a.qe = l_query; a.re += o.gtle; a.truesc += o.gscore - h0; }
+    }
+    a.w = imax(a.w, w_used);
+}
+
+// ---- per-seed initialisation (mem_alnreg_t set-up of bwamem.cpp:2212-2223, 2318-2322, 2419-2437) and task binning
+__global__ void __launch_bounds__(256)
+k_reg_init(ExtParams xp, int64_t n_slots, const int32_t *__restrict__ len, const int64_t *__restrict__ slot_base,
+           const int32_t *__restrict__ reg_seed, const int32_t *__restrict__ reg_chain, const DevChain *__restrict__ chn,
+           const DevSeed *__restrict__ seeds, DevReg *regs, uint8_t *bins /* [2][n_slots] */, uint32_t *hist /* [2][N_BINS] */) {
+    __shared__ uint32_t sh[2 * N_BINS];
+    for (int i = threadIdx.x; i < 2 * N_BINS; i += blockDim.x) sh[i] = 0;
+    __syncthreads();
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < n_slots) {
+        const int sidx = reg_seed[g];
+        int bl = 255, br = 255;                              // 255 = no task
+        if (sidx >= 0) {
+            const int64_t base = slot_base[g];
+            const DevChain c = chn[base + reg_chain[g]];
+            const DevSeed s = seeds[base + sidx];
+            const int l_query = len[c.read];
+            DevReg a;
+            a.w = xp.w; a.rid = c.rid; a.frac_rep = c.frac_rep; a.seedlen0 = s.len; a.chain = reg_chain[g]; a.seedcov = 0;
+            a.rb = s.rbeg; a.re = s.rbeg + s.len;
+            if (s.qbeg) { a.score = a.truesc = -1; a.qb = s.qbeg; }
+            else { a.score = a.truesc = s.len * xp.a; a.qb = 0; }
+            a.qe = (s.qbeg + s.len != l_query) ? s.qbeg + s.len : l_query;
+            regs[g] = a;
+            for (int side = 0; side < 2; side++) {
+                const bool has = side == 0 ? s.qbeg != 0 : s.qbeg + s.len != l_query;
+                if (!has) continue;
+                const TaskGeom tg = task_geom(side, s, c, nullptr, l_query, nullptr);
+                const bool lane_ok = tg.len2 <= LANE_QMAX && tg.len1 < 32768 && (l_query + tg.len1 + 1) * xp.a < 32768;
+                const int b = lane_ok ? tg.len2 : BIN_FALLBACK;
+                if (side == 0) bl = b; else br = b;
+                atomicAdd(&sh[side * N_BINS + b], 1u);
+            }
+        }
+        bins[g] = (uint8_t)bl; bins[n_slots + g] = (uint8_t)br;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * N_BINS; i += blockDim.x) if (sh[i]) atomicAdd(&hist[i], sh[i]);
+}
+
+// scatter slot ids into per-side task lists ordered by bin (= query length): a counting sort.  Each block first counts
+// its own tasks per bin in LDS and reserves its ranges with one global atomic per non-empty bin.
+__global__ void __launch_bounds__(256)
+k_task_scatter(int64_t n_slots, const uint8_t *__restrict__ bins, uint32_t *cursor /* [2][N_BINS] start offsets, bumped */,
+               int32_t *taskL, int32_t *taskR) {
+    __shared__ uint32_t cnt[2 * N_BINS], basep[2 * N_BINS];
+    for (int i = threadIdx.x; i < 2 * N_BINS; i += blockDim.x) cnt[i] = 0;
+    __syncthreads();
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int bl = 255, br = 255; uint32_t pl = 0, pr = 0;
+    if (g < n_slots) {
+        bl = bins[g]; br = bins[n_slots + g];
+        if (bl != 255) pl = atomicAdd(&cnt[bl], 1u);
+        if (br != 255) pr = atomicAdd(&cnt[N_BINS + br], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * N_BINS; i += blockDim.x) if (cnt[i]) basep[i] = atomicAdd(&cursor[i], cnt[i]);
+    __syncthreads();
+    if (bl != 255) taskL[basep[bl] + pl] = (int32_t)g;
+    if (br != 255) taskR[basep[N_BINS + br] + pr] = (int32_t)g;
+}
+
+// ---- lane-per-task extension: the inter-task SIMD shape of the reference (one pair per lane, bandedSWA.cpp:436-1113)
+// on 64-wide wavefronts.  Each lane runs the scalar recurrence of ksw_extend2 on its own task; the row state eh[j] =
+// {H(i-1,j-1), E(i,j)} is packed 16+16 bits in LDS, laid out [column][lane] so a wavefront touches 64 consecutive
+// dwords (conflict-free); the query bases sit next to it as [column][lane] bytes.  Tasks arrive sorted by query length,
+// so the lanes of a wavefront walk almost the same loop bounds.  All lanes step the same (i, j); a lane outside its own
+// band or past its own exit is masked off.
+struct LaneOut { int score, qle, tle, gtle, gscore, max_off; };
+
+static __device__ void lane_dp(bool run, int qlen, int tlen, int w, int h0, const uint8_t *tp, int ts, const SwParams &P,
+                               uint32_t *EH, const uint8_t *QL, int lane, LaneOut &out, long long &cells) {
+    const int o_del = P.o_del, e_del = P.e_del, o_ins = P.o_ins, e_ins = P.e_ins, oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
+    const int sc_match = P.mat[0], sc_mis = P.mat[1], sc_amb = P.mat[4];
+    // first row, bandedSWA.cpp:143-145
+    const int e1 = h0 > oe_ins ? h0 - oe_ins : 0;
+    const int maxq = __builtin_amdgcn_readlane(wave_scan_max(run ? qlen : 0, 0), 63);
+    for (int j = 0; j <= maxq; j++)
+        if (run && j <= qlen) EH[j * 64 + lane] = (uint32_t)(j == 0 ? h0 : imax(e1 - (j - 1) * e_ins, 0));
+    int beg = 0, end = qlen, maxv = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0;
+    bool alive = run && tlen > 0;
+    const int maxt = __builtin_amdgcn_readlane(wave_scan_max(alive ? tlen : 0, 0), 63);
+    int t_next = alive ? (int)tp[0] : 4;
+    for (int i = 0; i < maxt; ++i) {
+        if (!__ballot(alive)) break;
+        const int tb = t_next;
+        if (alive && i + 1 < tlen) t_next = (int)tp[(int64_t)(i + 1) * ts];
+        int h1 = 0, f = 0, m = 0, mj = -1, fnz = -1, lnz = -1;
+        if (alive) {
+            if (beg < i - w) beg = i - w;
+            if (end > i + w + 1) end = i + w + 1;
+            if (end > qlen) end = qlen;
+            if (beg == 0) { h1 = h0 - (o_del + e_del * (i + 1)); if (h1 < 0) h1 = 0; }
+            cells += imax(end - beg, 0);
+        }
+        const int s_eq = tb > 3 ? sc_amb : sc_match;
+        const int jlo = (1 << 20) - __builtin_amdgcn_readlane(wave_scan_max(alive ? (1 << 20) - beg : 0, 0), 63);
+        const int jhi = __builtin_amdgcn_readlane(wave_scan_max(alive ? end : 0, 0), 63);
+        for (int j = jlo; j < jhi; ++j) {
+            if (alive && j >= beg && j < end) {
+                const uint32_t p = EH[j * 64 + lane];
+                const int qb = QL[j * 64 + lane];
+                const int e = (int)(p >> 16);
+                int M = (int)(p & 0xffffu);
+                const int sc = (qb == tb && tb < 4) ? s_eq : ((qb > 3 || tb > 3) ? sc_amb : sc_mis);
+                M = M ? M + sc : 0;
+                int h = M > e ? M : e;
+                h = h > f ? h : f;
+                mj = m > h ? mj : j;
+                m = m > h ? m : h;
+                const int en = imax(imax(e - e_del, M - oe_del), 0);
+                f = imax(imax(f - e_ins, M - oe_ins), 0);
+                const uint32_t nw = (uint32_t)h1 | ((uint32_t)en << 16);
+                EH[j * 64 + lane] = nw;
+                if (nw) { lnz = j; if (fnz < 0) fnz = j; }
+                h1 = h;
+            }
+        }
+        if (alive) {
+            EH[end * 64 + lane] = (uint32_t)h1;                       // eh[end] = {h1, 0}, bandedSWA.cpp:201
+            if (h1) lnz = end;
+            const int jfin = beg < end ? end : beg;
+            if (jfin == qlen) { max_ie = gscore > h1 ? max_ie : i; gscore = gscore > h1 ? gscore : h1; }
+            if (m == 0) alive = false;
+            else {
+                if (m > maxv) {
+                    maxv = m; max_i = i; max_j = mj;
+                    const int d = mj - i;
+                    max_off = imax(max_off, d < 0 ? -d : d);
+                } else if (P.zdrop > 0) {
+                    if (i - max_i > mj - max_j) { if (maxv - m - ((i - max_i) - (mj - max_j)) * e_del > P.zdrop) alive = false; }
+                    else { if (maxv - m - ((mj - max_j) - (i - max_i)) * e_ins > P.zdrop) alive = false; }
+                }
+                const int nb = fnz >= 0 ? fnz : end;
+                const int jl = imax(lnz, nb - 1);
+                beg = nb;
+                end = jl + 2 < qlen ? jl + 2 : qlen;
+                if (i + 1 >= tlen) alive = false;
+            }
+        }
+    }
+    if (run) { out.score = maxv; out.qle = max_j + 1; out.tle = max_i + 1; out.gtle = max_ie + 1; out.gscore = gscore; out.max_off = max_off; }
+}
+
+template <int SIDE>
+__global__ void __launch_bounds__(64)
+k_ext_lanes(DevIndex ix, ExtParams xp, const int32_t *__restrict__ tasks, int n_tasks, int qmax,
+            const uint8_t *__restrict__ enc, const int64_t *__restrict__ off, const int32_t *__restrict__ len,
+            const int64_t *__restrict__ slot_base, const int32_t *__restrict__ reg_seed, const int32_t *__restrict__ reg_chain,
+            const DevChain *__restrict__ chn, const DevSeed *__restrict__ seeds, DevReg *regs, unsigned long long *counters) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_l[];
+    uint32_t *EH = lds_l;                                       // [(qmax+1)][64]
+    uint8_t *QL = (uint8_t *)(lds_l + (size_t)(qmax + 1) * 64); // [qmax][64]
+    const int lane = threadIdx.x;
+    const int idx = blockIdx.x * 64 + lane;
+    const bool valid = idx < n_tasks;
+    const SwParams &P = SIDE == 0 ? xp.left : xp.right;
+    int g = 0, l_query = 0, h0 = 0, prev = -1;
+    DevSeed s; DevReg a; TaskGeom tg;
+    tg.len1 = tg.len2 = 0; tg.q = tg.t = ix.ref_string; tg.qs = tg.ts = 1;
+    if (valid) {
+        g = tasks[idx];
+        const int64_t base = slot_base[g];
+        const DevChain c = chn[base + reg_chain[g]];
+        s = seeds[base + reg_seed[g]];
+        a = regs[g];
+        l_query = len[c.read];
+        tg = task_geom(SIDE, s, c, enc + off[c.read], l_query, ix.ref_string);
+        if (SIDE == 0) { h0 = s.len * xp.a; prev = -1; }
+        else { h0 = a.score; prev = a.score; }                  // right h0 = score after the left side, bwamem.cpp:2672-2677
+    }
+    // stage the query bases
+    const int maxq = __builtin_amdgcn_readlane(wave_scan_max(valid ? tg.len2 : 0, 0), 63);
+    for (int j = 0; j < maxq; j++) if (valid && j < tg.len2) QL[j * 64 + lane] = tg.q[(int64_t)j * tg.qs];
+    const int cls = pair_class(tg.len1, tg.len2, h0, P.max_sc);
+    LaneOut o; o.score = h0; o.qle = o.tle = o.gtle = 0; o.gscore = -1; o.max_off = 0;
+    long long cells = 0;
+    bool run = valid;
+    int w_used = xp.w;
+    for (int t = 0; t < MAX_BAND_TRY; t++) {                    // two-try band rule, bwamem.cpp:2495-2496
+        if (!__ballot(run)) break;
+        const int w = xp.w << t;
+        const int wc = band_clamp(w, tg.len2, P, cls);
+        lane_dp(run, tg.len2, tg.len1, wc, h0, tg.t, tg.ts, P, EH, QL, lane, o, cells);
+        if (run) {
+            w_used = w;
+            if (o.score == prev || o.max_off < (w >> 1) + (w >> 2) || t + 1 == MAX_BAND_TRY) run = false;
+            else prev = o.score;
+        }
+    }
+    if (valid) {
+        SwOut so; so.score = o.score; so.qle = o.qle; so.tle = o.tle; so.gtle = o.gtle; so.gscore = o.gscore; so.max_off = o.max_off;
+        apply_side(SIDE, a, s, l_query, so, h0, w_used, SIDE == 0 ? xp.pen_clip5 : xp.pen_clip3);
+        regs[g] = a;
+    }
+    atomicAdd(&counters[0], (unsigned long long)cells);
+    atomicAdd(&counters[1], valid ? 1ULL : 0ULL);
+}
+
+// one side on one wavefront, with the accept/retry rule of bwamem.cpp:2495-2496: stop when the score did not change, or
+// the best cell stayed within 3/4 of the band, or this was the last try.
 static __device__ __forceinline__ int extend_side(const uint8_t *q, int qs, int len2, const uint8_t *t, int ts, int len1, int h0,
                                                   int prev, int w0, const SwParams &P, int *RH, int *RE, int RM, SwOut &o,
                                                   int &w_used, long long &cells) {
@@ -38,11 +272,13 @@ static __device__ __forceinline__ int extend_side(const uint8_t *q, int qs, int 
     return o.score;
 }
 
+// ---- one task per wavefront: long queries, int32-class scores (the scalar fallback of the reference, bwamem.cpp:2472)
+template <int SIDE>
 __global__ void __launch_bounds__(256)
-k_extend(DevIndex ix, ExtParams xp, int64_t n_slots, const uint8_t *__restrict__ enc, const int64_t *__restrict__ off,
-         const int32_t *__restrict__ len, const int64_t *__restrict__ slot_base /* per slot: base of its read */,
-         const int32_t *__restrict__ reg_seed, const int32_t *__restrict__ reg_chain, const DevChain *__restrict__ chn,
-         const DevSeed *__restrict__ seeds, DevReg *regs, int R, unsigned long long *counters /* [0]=cells [1]=tasks */) {
+k_ext_wave(DevIndex ix, ExtParams xp, const int32_t *__restrict__ tasks, int n_tasks,
+           const uint8_t *__restrict__ enc, const int64_t *__restrict__ off, const int32_t *__restrict__ len,
+           const int64_t *__restrict__ slot_base, const int32_t *__restrict__ reg_seed, const int32_t *__restrict__ reg_chain,
+           const DevChain *__restrict__ chn, const DevSeed *__restrict__ seeds, DevReg *regs, int R, unsigned long long *counters) {
     extern __shared__ __attribute__((aligned(16))) int lds[];
     ExtParams *sP = (ExtParams *)lds;
     int *rings = lds + (sizeof(ExtParams) + 3) / 4;
@@ -50,64 +286,41 @@ k_extend(DevIndex ix, ExtParams xp, int64_t n_slots, const uint8_t *__restrict__
     __syncthreads();
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int *RH = rings + (size_t)wv * 2 * R, *RE = RH + R;
-    const int64_t g = (int64_t)blockIdx.x * (blockDim.x >> 6) + wv;
-    if (g >= n_slots) return;
-    const int sidx = reg_seed[g];
-    if (sidx < 0) return;                                   // slot not used by any seed
+    const int idx = blockIdx.x * (blockDim.x >> 6) + wv;
+    if (idx >= n_tasks) return;
+    const int g = tasks[idx];
     const int64_t base = slot_base[g];
     const DevChain c = chn[base + reg_chain[g]];
-    const DevSeed s = seeds[base + sidx];
-    const int r = c.read;
-    const uint8_t *query = enc + off[r];
-    const int l_query = len[r];
-    const uint8_t *ref = ix.ref_string;
-    // mem_alnreg_t initialisation, bwamem.cpp:2212-2223
-    int64_t rb, re; int qb, qe, score = -1, truesc = -1, w = sP->w;
-    long long cells = 0; int tasks = 0;
-    SwOut o;
-    if (s.qbeg) {                                           // left extension, bwamem.cpp:2229-2317 + :2472-2526
-        const int len2 = s.qbeg, len1 = (int)(s.rbeg - c.rmax0), h0 = s.len * sP->a;
-        int w_used;
-        score = extend_side(query + s.qbeg - 1, -1, len2, ref + s.rbeg - 1, -1, len1, h0, -1, sP->w, sP->left, RH, RE, R - 1, o, w_used, cells);
-        tasks++;
-        if (o.gscore <= 0 || o.gscore <= score - sP->pen_clip5) { qb = s.qbeg - o.qle; rb = s.rbeg - o.tle; truesc = score; }
-        else { qb = 0; rb = s.rbeg - o.gtle; truesc = o.gscore; }
-        w = imax(w, w_used);
-    } else {
-        score = truesc = s.len * sP->a; qb = 0; rb = s.rbeg;
-    }
-    if (s.qbeg + s.len != l_query) {                        // right extension, bwamem.cpp:2324-2418 + :2672-2740
-        const int qe0 = s.qbeg + s.len;
-        const int64_t re0 = s.rbeg + s.len - c.rmax0;
-        const int len2 = l_query - qe0, len1 = (int)(c.rmax1 - c.rmax0 - re0), h0 = score;
-        int w_used;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const int sc = extend_side(query + qe0, 1, len2, ref + c.rmax0 + re0, 1, len1, h0, score, sP->w, sP->right, RH, RE, R - 1, o, w_used, cells);
-        tasks++;
-        score = sc;
-        if (o.gscore <= 0 || o.gscore <= score - sP->pen_clip3) { qe = qe0 + o.qle; re = c.rmax0 + re0 + o.tle; truesc += score - h0; }
-        else { qe = l_query; re = c.rmax0 + re0 + o.gtle; truesc += o.gscore - h0; }
-        w = imax(w, w_used);
-    } else {
-        qe = l_query; re = s.rbeg + s.len;
-    }
-    // seedcov over the chain's seeds, bwamem.cpp:2507-2516 (the H0_ guard is always true for real coordinates)
-    int cov = 0;
-    for (int i = lane; i < c.n; i += 64) {
-        const DevSeed t = seeds[c.seed_off + i];
-        if (t.qbeg >= qb && t.qbeg + t.len <= qe && t.rbeg >= rb && t.rbeg + t.len <= re) cov += t.len;
-    }
-    for (int d = 32; d > 0; d >>= 1) cov += __shfl_xor(cov, d);
+    const DevSeed s = seeds[base + reg_seed[g]];
+    DevReg a = regs[g];
+    const int l_query = len[c.read];
+    const TaskGeom tg = task_geom(SIDE, s, c, enc + off[c.read], l_query, ix.ref_string);
+    const int h0 = SIDE == 0 ? s.len * sP->a : a.score;
+    const int prev = SIDE == 0 ? -1 : a.score;
+    SwOut o; int w_used; long long cells = 0;
+    extend_side(tg.q, tg.qs, tg.len2, tg.t, tg.ts, tg.len1, h0, prev, sP->w, SIDE == 0 ? sP->left : sP->right, RH, RE, R - 1, o, w_used, cells);
     if (lane == 0) {
-        DevReg a;
-        a.rb = rb; a.re = re; a.qb = qb; a.qe = qe; a.rid = c.rid; a.score = score; a.truesc = truesc; a.w = w;
-        a.seedcov = cov; a.seedlen0 = s.len; a.frac_rep = c.frac_rep; a.chain = reg_chain[g];
+        apply_side(SIDE, a, s, l_query, o, h0, w_used, SIDE == 0 ? sP->pen_clip5 : sP->pen_clip3);
         regs[g] = a;
         atomicAdd(&counters[0], (unsigned long long)cells);
-        atomicAdd(&counters[1], (unsigned long long)tasks);
+        atomicAdd(&counters[1], 1ULL);
     }
+}
+
+// seedcov over the chain's seeds, bwamem.cpp:2507-2516 (the H0_ guard there is always true for real coordinates)
+__global__ void __launch_bounds__(256)
+k_seedcov(int64_t n_slots, const int64_t *__restrict__ slot_base, const int32_t *__restrict__ reg_seed,
+          const int32_t *__restrict__ reg_chain, const DevChain *__restrict__ chn, const DevSeed *__restrict__ seeds, DevReg *regs) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_slots || reg_seed[g] < 0) return;
+    const DevChain c = chn[slot_base[g] + reg_chain[g]];
+    DevReg a = regs[g];
+    int cov = 0;
+    for (int i = 0; i < c.n; i++) {
+        const DevSeed t = seeds[c.seed_off + i];
+        if (t.qbeg >= a.qb && t.qbeg + t.len <= a.qe && t.rbeg >= a.rb && t.rbeg + t.len <= a.re) cov += t.len;
+    }
+    regs[g].seedcov = cov;
 }
 
 // cal_max_gap, bwamem.cpp:66-76
@@ -212,10 +425,13 @@ k_slot_base(int n_reads, const int64_t *__restrict__ read_base, const int32_t *_
 
 static int ring_size2(int w) { int R = 64; while (R < 2 * w + 4) R <<= 1; return R; }
 
+// Extension stage: init regs + bin tasks by query length, then left side, then right side (which starts from the left
+// score), lane-per-task for short queries and wavefront-per-task for the rest, then seedcov.
 int bm2_launch_extend(bm2_ctx *c, const bm2_opt &opt, int64_t n_slots, const uint8_t *enc, const int64_t *off, const int32_t *len,
                       const int64_t *slot_base, const int32_t *reg_seed, const int32_t *reg_chain, const DevChain *chn,
-                      const DevSeed *seeds, DevReg *regs, unsigned long long *counters) {
+                      const DevSeed *seeds, DevReg *regs, unsigned long long *counters, DevBuf &tmp) {
     if (n_slots <= 0) return BM2_OK;
+    hipStream_t s = c->stream;
     ExtParams xp;
     xp.a = opt.a; xp.w = opt.w; xp.pen_clip5 = opt.pen_clip5; xp.pen_clip3 = opt.pen_clip3;
     SwParams P;
@@ -223,13 +439,64 @@ int bm2_launch_extend(bm2_ctx *c, const bm2_opt &opt, int64_t n_slots, const uin
     for (int i = 0; i < 25; i++) P.mat[i] = opt.mat[i];
     P.end_bonus = opt.pen_clip5; xp.left = P;
     P.end_bonus = opt.pen_clip3; xp.right = P;
+    // scratch: bins[2*n_slots] bytes | hist[2*N_BINS] | cursor[2*N_BINS] | taskL[n_slots] | taskR[n_slots]
+    const size_t o_hist = ((size_t)2 * n_slots + 255) & ~(size_t)255, o_cur = o_hist + 2 * N_BINS * 4;
+    const size_t o_tl = (o_cur + 2 * N_BINS * 4 + 255) & ~(size_t)255, o_tr = o_tl + (size_t)n_slots * 4;
+    int rc = bm2_reserve(tmp, o_tr + (size_t)n_slots * 4 + 256);
+    if (rc) return rc;
+    uint8_t *bins = (uint8_t *)tmp.p;
+    uint32_t *hist = (uint32_t *)((char *)tmp.p + o_hist), *cursor = (uint32_t *)((char *)tmp.p + o_cur);
+    int32_t *taskL = (int32_t *)((char *)tmp.p + o_tl), *taskR = (int32_t *)((char *)tmp.p + o_tr);
+    if ((rc = bm2_check(hipMemsetAsync(hist, 0, 2 * N_BINS * 4, s), "memset hist"))) return rc;
+    const unsigned nb = (unsigned)((n_slots + 255) / 256);
+    hipLaunchKernelGGL(k_reg_init, dim3(nb), dim3(256), 0, s, xp, n_slots, len, slot_base, reg_seed, reg_chain, chn, seeds, regs, bins, hist);
+    uint32_t h_hist[2 * N_BINS], h_start[2 * N_BINS];
+    if ((rc = bm2_check(hipMemcpyAsync(h_hist, hist, sizeof h_hist, hipMemcpyDeviceToHost, s), "D2H hist"))) return rc;
+    if ((rc = bm2_check(hipStreamSynchronize(s), "k_reg_init"))) return rc;
+    for (int side = 0; side < 2; side++) {
+        uint32_t acc = 0;
+        for (int b = 0; b < N_BINS; b++) { h_start[side * N_BINS + b] = acc; acc += h_hist[side * N_BINS + b]; }
+    }
+    if ((rc = bm2_check(hipMemcpyAsync(cursor, h_start, sizeof h_start, hipMemcpyHostToDevice, s), "H2D cursor"))) return rc;
+    hipLaunchKernelGGL(k_task_scatter, dim3(nb), dim3(256), 0, s, n_slots, bins, cursor, taskL, taskR);
+    static const int cls_hi[] = { 16, 32, 48, 64, 80, 96, 112, 128, 144, 160 };
     const int R = ring_size2(opt.w << (MAX_BAND_TRY - 1));
-    const int waves = 4;
-    const size_t lds = ((sizeof(ExtParams) + 3) / 4) * 4 + (size_t)waves * 2 * R * 4;
-    if (lds > 160 * 1024) { bm2_set_error("band width %d needs more LDS than a CU has", opt.w); return BM2_EUNSUP; }
-    hipLaunchKernelGGL(k_extend, dim3((unsigned)((n_slots + waves - 1) / waves)), dim3(waves * 64), lds, c->stream, c->ix, xp,
-                       n_slots, enc, off, len, slot_base, reg_seed, reg_chain, chn, seeds, regs, R, counters);
-    return bm2_check(hipGetLastError(), "k_extend launch");
+    const size_t lds_w = ((sizeof(ExtParams) + 3) / 4) * 4 + (size_t)4 * 2 * R * 4;
+    if (lds_w > 160 * 1024) { bm2_set_error("band width %d needs more LDS than a CU has", opt.w); return BM2_EUNSUP; }
+    for (int side = 0; side < 2; side++) {
+        const int32_t *tasks = side == 0 ? taskL : taskR;
+        const uint32_t *st = h_start + side * N_BINS, *hc = h_hist + side * N_BINS;
+        int lo = 0;
+        for (int k = 0; k < (int)(sizeof cls_hi / sizeof cls_hi[0]); k++) {
+            const int hi = cls_hi[k];                                  // bins (lo, hi]
+            const uint32_t first = st[lo + 1 > N_BINS - 1 ? N_BINS - 1 : lo + 1];
+            uint32_t n = 0;
+            for (int b = lo + 1; b <= hi; b++) n += hc[b];
+            lo = hi;
+            if (!n) continue;
+            const size_t lds = (size_t)(hi + 1) * 64 * 4 + (size_t)hi * 64;
+            if (side == 0)
+                hipLaunchKernelGGL(k_ext_lanes<0>, dim3((n + 63) / 64), dim3(64), lds, s, c->ix, xp, tasks + first, (int)n, hi, enc, off, len,
+                                   slot_base, reg_seed, reg_chain, chn, seeds, regs, counters);
+            else
+                hipLaunchKernelGGL(k_ext_lanes<1>, dim3((n + 63) / 64), dim3(64), lds, s, c->ix, xp, tasks + first, (int)n, hi, enc, off, len,
+                                   slot_base, reg_seed, reg_chain, chn, seeds, regs, counters);
+        }
+        // bin 0 cannot occur (a task has at least one query base); the fallback bin runs one task per wavefront
+        const uint32_t nf = hc[BIN_FALLBACK] + hc[0], ff = st[0];
+        if (hc[0]) {
+            if (side == 0) hipLaunchKernelGGL(k_ext_wave<0>, dim3((hc[0] + 3) / 4), dim3(256), lds_w, s, c->ix, xp, tasks + ff, (int)hc[0], enc, off, len, slot_base, reg_seed, reg_chain, chn, seeds, regs, R, counters);
+            else hipLaunchKernelGGL(k_ext_wave<1>, dim3((hc[0] + 3) / 4), dim3(256), lds_w, s, c->ix, xp, tasks + ff, (int)hc[0], enc, off, len, slot_base, reg_seed, reg_chain, chn, seeds, regs, R, counters);
+        }
+        (void)nf;
+        if (hc[BIN_FALLBACK]) {
+            const uint32_t f2 = st[BIN_FALLBACK], n2 = hc[BIN_FALLBACK];
+            if (side == 0) hipLaunchKernelGGL(k_ext_wave<0>, dim3((n2 + 3) / 4), dim3(256), lds_w, s, c->ix, xp, tasks + f2, (int)n2, enc, off, len, slot_base, reg_seed, reg_chain, chn, seeds, regs, R, counters);
+            else hipLaunchKernelGGL(k_ext_wave<1>, dim3((n2 + 3) / 4), dim3(256), lds_w, s, c->ix, xp, tasks + f2, (int)n2, enc, off, len, slot_base, reg_seed, reg_chain, chn, seeds, regs, R, counters);
+        }
+    }
+    hipLaunchKernelGGL(k_seedcov, dim3(nb), dim3(256), 0, s, n_slots, slot_base, reg_seed, reg_chain, chn, seeds, regs);
+    return bm2_check(hipGetLastError(), "extension launches");
 }
 
 int bm2_launch_slot_base(bm2_ctx *c, int n_reads, const int64_t *read_base, const int32_t *n_reg, int64_t *slot_base) {

@@ -18,7 +18,7 @@ int bm2_launch_chain(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_
                      int32_t *n_chain_out, int32_t *n_reg_out, int32_t *n_chain0_out);
 int bm2_launch_extend(bm2_ctx *c, const bm2_opt &opt, int64_t n_slots, const uint8_t *enc, const int64_t *off, const int32_t *len,
                       const int64_t *slot_base, const int32_t *reg_seed, const int32_t *reg_chain, const DevChain *chn,
-                      const DevSeed *seeds, DevReg *regs, unsigned long long *counters);
+                      const DevSeed *seeds, DevReg *regs, unsigned long long *counters, DevBuf &tmp);
 int bm2_launch_slot_base(bm2_ctx *c, int n_reads, const int64_t *read_base, const int32_t *n_reg, int64_t *slot_base);
 int bm2_launch_postfilter(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_t *len, const int64_t *read_base,
                           const int32_t *n_chain, const int32_t *n_reg, const DevChain *chn, const DevSeed *seeds,
@@ -36,7 +36,7 @@ struct Batch {
     DevBuf stage, prevbuf, smem, occ_cnt, smem_cnt, smem_off, counters, sa_off, sa_coord, scan_tmp, read_base;
     // chaining / extension
     DevBuf wchain, wseed, nodes, order, chn, seeds, srt, reg_seed, reg_chain, regs, slot_base, n_chain, n_reg, n_chain0, n_out;
-    DevBuf out_off, out_regs, smem_sorted, smem_sorted_off;
+    DevBuf out_off, out_regs, smem_sorted, smem_sorted_off, ext_tmp;
     int64_t n_smem = 0, n_sa = 0, n_out_regs = 0;
     bm2_stats stats{};
 };
@@ -47,7 +47,7 @@ void bm2_batch_destroy(bm2_ctx *c) {
     DevBuf *all[] = { &b->enc, &b->off, &b->len, &b->stage, &b->prevbuf, &b->smem, &b->occ_cnt, &b->smem_cnt, &b->smem_off,
                       &b->counters, &b->sa_off, &b->sa_coord, &b->scan_tmp, &b->read_base, &b->wchain, &b->wseed, &b->nodes,
                       &b->order, &b->chn, &b->seeds, &b->srt, &b->reg_seed, &b->reg_chain, &b->regs, &b->slot_base, &b->n_chain,
-                      &b->n_reg, &b->n_chain0, &b->n_out, &b->out_off, &b->out_regs, &b->smem_sorted, &b->smem_sorted_off };
+                      &b->n_reg, &b->n_chain0, &b->n_out, &b->out_off, &b->out_regs, &b->smem_sorted, &b->smem_sorted_off, &b->ext_tmp };
     for (DevBuf *d : all) bm2_release(*d);
     delete b;
     c->batch = nullptr;
@@ -240,7 +240,7 @@ extern "C" int bm2_batch_run(bm2_ctx *c, const bm2_opt *opt) {
     if ((rc = bm2_launch_extend(c, *opt, n_sa, (const uint8_t *)b->enc.p, (const int64_t *)b->off.p, (const int32_t *)b->len.p,
                                 (const int64_t *)b->slot_base.p, (const int32_t *)b->reg_seed.p, (const int32_t *)b->reg_chain.p,
                                 (const DevChain *)b->chn.p, (const DevSeed *)b->seeds.p, (DevReg *)b->regs.p,
-                                (unsigned long long *)b->counters.p + 5))) return rc;
+                                (unsigned long long *)b->counters.p + 5, b->ext_tmp))) return rc;
     tick(c, "extend");
     if ((rc = bm2_launch_postfilter(c, cp, n, (const int32_t *)b->len.p, (const int64_t *)b->read_base.p, (const int32_t *)b->n_chain.p,
                                     (const int32_t *)b->n_reg.p, (const DevChain *)b->chn.p, (const DevSeed *)b->seeds.p,
