@@ -20,7 +20,7 @@ SEQPAIR_DT = np.dtype([(n, "<i4") for n in ("idr", "idq", "id", "len1", "len2", 
                                              "score", "tle", "gtle", "qle", "gscore", "max_off")])
 DEVCHAIN_DT = np.dtype([("pos", "<i8"), ("seed_off", "<i8"), ("n", "<i4"), ("rid", "<i4"), ("w", "<i4"), ("kept", "<i4"),
                         ("first", "<i4"), ("is_alt", "<i4"), ("read", "<i4"), ("frac_rep", "<f4"), ("rmax0", "<i8"),
-                        ("rmax1", "<i8")])
+                        ("rmax1", "<i8"), ("reg0", "<i4"), ("pad", "<i4")])
 DEVSEED_DT = np.dtype([("rbeg", "<i8"), ("qbeg", "<i4"), ("len", "<i4"), ("score", "<i4"), ("aln", "<i4")])
 DEVREG_DT = np.dtype([("rb", "<i8"), ("re", "<i8"), ("qb", "<i4"), ("qe", "<i4"), ("rid", "<i4"), ("score", "<i4"),
                       ("truesc", "<i4"), ("w", "<i4"), ("seedcov", "<i4"), ("seedlen0", "<i4"), ("frac_rep", "<f4"),

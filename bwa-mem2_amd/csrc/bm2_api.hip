@@ -82,6 +82,11 @@ extern "C" bm2_ctx *bm2_create(int device, const bm2_index_desc *idx) {
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount;
     if (bm2_check(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "hipStreamCreate")) { delete c; return nullptr; }
     for (int i = 0; i <= BM2_MAX_TIMERS; i++) (void)hipEventCreate(&c->ev[i]);
+    (void)hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+    for (int i = 0; i < 12; i++) {
+        (void)hipStreamCreateWithFlags(&c->side_stream[i], hipStreamNonBlocking);
+        (void)hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming);
+    }
     if (idx) {
         const int64_t nocc = (idx->ref_len >> 6) + 1, nsa = (idx->ref_len >> 3) + 1;
         int rc = 0;
@@ -116,6 +121,11 @@ extern "C" void bm2_destroy(bm2_ctx *c) {
     for (void *p : ps) if (p) (void)hipFree(p);
     bm2_release(c->b_pairs); bm2_release(c->b_ref); bm2_release(c->b_qer); bm2_release(c->b_misc);
     for (int i = 0; i <= BM2_MAX_TIMERS; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    for (int i = 0; i < 12; i++) {
+        if (c->side_stream[i]) (void)hipStreamDestroy(c->side_stream[i]);
+        if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
+    }
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }

@@ -30,6 +30,9 @@ struct bm2_ctx {
     int n_ev = 0;
     bool ev_ready = false;
     int n_cu = 256;
+    // fork/join of the per-class extension launches (extend.hip)
+    hipStream_t side_stream[12] = {};
+    hipEvent_t ev_fork = nullptr, ev_join[12] = {};
 };
 
 int  bm2_check(hipError_t e, const char *what);            // -> BM2_OK or BM2_ENODEV (+ message)

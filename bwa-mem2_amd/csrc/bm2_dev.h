@@ -51,6 +51,7 @@ struct DevChain {                    // mem_chain_t (bwamem.h:126-133); seeds ar
     int32_t n, rid, w, kept, first, is_alt, read;
     float   frac_rep;
     int64_t rmax0, rmax1;            // reference window of the chain (bwamem.cpp:2145-2172)
+    int32_t reg0, pad;               // index (within the read) of the chain's first reg; regs follow in extension order
 };
 
 // one banded-extension task (what a SeqPair + its seqBuf slices describe, bwamem.cpp:2229-2418)

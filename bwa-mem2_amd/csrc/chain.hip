@@ -383,6 +383,7 @@ k_chain(DevIndex ix, ChainParams o, int n_reads, const int32_t *__restrict__ len
         d.pos = c.pos; d.seed_off = base + n_seed; d.n = c.n; d.rid = c.rid; d.w = c.w; d.kept = c.kept; d.first = c.first;
         d.is_alt = c.is_alt; d.read = r; d.frac_rep = frac_rep; d.rmax0 = 0; d.rmax1 = 0;
         const int s0 = n_seed;
+        d.reg0 = n_reg; d.pad = 0;
         for (int si = c.head; si >= 0; si = sd[si].next) {
             DevSeed s; s.rbeg = sd[si].rbeg; s.qbeg = sd[si].qbeg; s.len = sd[si].len; s.score = sd[si].len; s.aln = -1;
             os[n_seed++] = s;

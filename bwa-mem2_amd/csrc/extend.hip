@@ -57,7 +57,8 @@ static __device__ __forceinline__ void apply_side(int side, DevReg &a, const Dev
 __global__ void __launch_bounds__(256)
 k_reg_init(ExtParams xp, int64_t n_slots, const int32_t *__restrict__ len, const int64_t *__restrict__ slot_base,
            const int32_t *__restrict__ reg_seed, const int32_t *__restrict__ reg_chain, const DevChain *__restrict__ chn,
-           const DevSeed *__restrict__ seeds, DevReg *regs, uint8_t *bins /* [2][n_slots] */, uint32_t *hist /* [2][N_BINS] */) {
+           const DevSeed *__restrict__ seeds, DevReg *regs, uint8_t *bins /* [2][n_slots] */, uint32_t *hist /* [2][N_BINS] */,
+           const int32_t *__restrict__ cursor /* per read: regs below this index were handled by the lazy rounds */) {
     __shared__ uint32_t sh[2 * N_BINS];
     for (int i = threadIdx.x; i < 2 * N_BINS; i += blockDim.x) sh[i] = 0;
     __syncthreads();
@@ -65,7 +66,7 @@ k_reg_init(ExtParams xp, int64_t n_slots, const int32_t *__restrict__ len, const
     if (g < n_slots) {
         const int sidx = reg_seed[g];
         int bl = 255, br = 255;                              // 255 = no task
-        if (sidx >= 0) {
+        if (sidx >= 0 && g - slot_base[g] >= cursor[chn[slot_base[g] + reg_chain[g]].read]) {
             const int64_t base = slot_base[g];
             const DevChain c = chn[base + reg_chain[g]];
             const DevSeed s = seeds[base + sidx];
@@ -97,7 +98,8 @@ k_reg_init(ExtParams xp, int64_t n_slots, const int32_t *__restrict__ len, const
 // its own tasks per bin in LDS and reserves its ranges with one global atomic per non-empty bin.
 __global__ void __launch_bounds__(256)
 k_task_scatter(int64_t n_slots, const uint8_t *__restrict__ bins, uint32_t *cursor /* [2][N_BINS] start offsets, bumped */,
-               int32_t *taskL, int32_t *taskR) {
+               int32_t *taskL, int32_t *taskR, const int64_t *__restrict__ read_base /* round mode: item = read */,
+               const int32_t *__restrict__ cur_slot) {
     __shared__ uint32_t cnt[2 * N_BINS], basep[2 * N_BINS];
     for (int i = threadIdx.x; i < 2 * N_BINS; i += blockDim.x) cnt[i] = 0;
     __syncthreads();
@@ -111,8 +113,9 @@ k_task_scatter(int64_t n_slots, const uint8_t *__restrict__ bins, uint32_t *curs
     __syncthreads();
     for (int i = threadIdx.x; i < 2 * N_BINS; i += blockDim.x) if (cnt[i]) basep[i] = atomicAdd(&cursor[i], cnt[i]);
     __syncthreads();
-    if (bl != 255) taskL[basep[bl] + pl] = (int32_t)g;
-    if (br != 255) taskR[basep[N_BINS + br] + pr] = (int32_t)g;
+    const int32_t slot = read_base ? (int32_t)(read_base[g < n_slots ? g : 0] + cur_slot[g < n_slots ? g : 0]) : (int32_t)g;
+    if (bl != 255) taskL[basep[bl] + pl] = slot;
+    if (br != 255) taskR[basep[N_BINS + br] + pr] = slot;
 }
 
 // ---- lane-per-task extension: the inter-task SIMD shape of the reference (one pair per lane, bandedSWA.cpp:436-1113)
@@ -310,10 +313,11 @@ k_ext_wave(DevIndex ix, ExtParams xp, const int32_t *__restrict__ tasks, int n_t
 // seedcov over the chain's seeds, bwamem.cpp:2507-2516 (the H0_ guard there is always true for real coordinates)
 __global__ void __launch_bounds__(256)
 k_seedcov(int64_t n_slots, const int64_t *__restrict__ slot_base, const int32_t *__restrict__ reg_seed,
-          const int32_t *__restrict__ reg_chain, const DevChain *__restrict__ chn, const DevSeed *__restrict__ seeds, DevReg *regs) {
+          const int32_t *__restrict__ reg_chain, const DevChain *__restrict__ chn, const DevSeed *__restrict__ seeds, DevReg *regs, const int32_t *__restrict__ cursor) {
     const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n_slots || reg_seed[g] < 0) return;
     const DevChain c = chn[slot_base[g] + reg_chain[g]];
+    if (g - slot_base[g] < cursor[c.read]) return;
     DevReg a = regs[g];
     int cov = 0;
     for (int i = 0; i < c.n; i++) {
@@ -332,63 +336,164 @@ static __device__ __forceinline__ int cal_max_gap2(const ChainParams &o, int qle
     return l < o.w << 1 ? l : o.w << 1;
 }
 
+// The per-seed test of the redundant-seed filter, bwamem.cpp:2922-2983: true = the seed's alignment is purged (the
+// original bwa-mem would not have extended it).  `lim` = number of kept regs of the read before this seed.
+static __device__ bool seed_redundant(const ChainParams &o, int l_query, const DevReg *av, int nr, int lim, const DevChain &c,
+                                      const DevSeed *cs, const int32_t *srt2, int k) {
+    const DevSeed s = cs[srt2[k]];
+    int i, v = 0;
+    for (i = 0; i < nr && v < lim; ++i) {
+        const DevReg p = av[i];
+        int64_t rd; int qd, w, max_gap;
+        if (p.qb == -1 && p.qe == -1) continue;
+        if (s.rbeg < p.rb || s.rbeg + s.len > p.re || s.qbeg < p.qb || s.qbeg + s.len > p.qe) { v++; continue; }
+        if (s.len - p.seedlen0 > .1 * l_query) { v++; continue; }
+        qd = s.qbeg - p.qb; rd = s.rbeg - p.rb;
+        max_gap = cal_max_gap2(o, qd < rd ? qd : (int)rd);
+        w = max_gap < p.w ? max_gap : p.w;
+        if (qd - rd < w && rd - qd < w) break;
+        qd = p.qe - (s.qbeg + s.len); rd = p.re - (s.rbeg + s.len);
+        max_gap = cal_max_gap2(o, qd < rd ? qd : (int)rd);
+        w = max_gap < p.w ? max_gap : p.w;
+        if (qd - rd < w && rd - qd < w) break;
+        v++;
+    }
+    if (v < lim) {
+        for (v = k + 1; v < c.n; ++v) {
+            if (srt2[v] < 0) continue;                      // UINT_MAX marker of the reference
+            const DevSeed t = cs[srt2[v]];
+            if (t.len < s.len * .95) continue;
+            if (s.qbeg <= t.qbeg && s.qbeg + s.len - t.qbeg >= s.len >> 2 && t.qbeg - s.qbeg != t.rbeg - s.rbeg) break;
+            if (t.qbeg <= s.qbeg && t.qbeg + t.len - s.qbeg >= s.len >> 2 && s.qbeg - t.qbeg != s.rbeg - t.rbeg) break;
+        }
+        if (v == c.n) return true;
+    }
+    return false;
+}
+
 // Redundant-seed post-filter, bwamem.cpp:2895-2989 (one read per lane): replays the original bwa-mem rule "skip a seed
 // already contained in an earlier alignment unless an overlapping seed lies on another diagonal" and purges those regs.
+// Seeds already decided by the lazy rounds (k_decide_round) get the same verdict again, so replaying them is harmless.
 __global__ void __launch_bounds__(128)
 k_postfilter(ChainParams o, int n_reads, const int32_t *__restrict__ len, const int64_t *__restrict__ read_base,
              const int32_t *__restrict__ n_chain, const int32_t *__restrict__ n_reg, const DevChain *__restrict__ chn,
-             const DevSeed *__restrict__ seeds, int32_t *srt_all, DevReg *regs, int32_t *n_out) {
+             const DevSeed *__restrict__ seeds, int32_t *srt_all, DevReg *regs, int32_t *n_out, const int32_t *__restrict__ cursor) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_reads) return;
     const int nc = n_chain[r], nr = n_reg[r];
     if (nc == 0) { n_out[r] = 0; return; }
+    const int first_idx = cursor[r];
     const int64_t base = read_base[r];
     const int l_query = len[r];
     DevReg *av = regs + base;
     int lim = 0;
-    for (int j = 0; j < nc; j++) {
-        const DevChain c = chn[base + j];
-        const DevSeed *cs = seeds + c.seed_off;
-        int32_t *srt2 = srt_all + c.seed_off;
-        for (int k = c.n - 1; k >= 0; k--) {
-            const DevSeed s = cs[srt2[k]];
-            int i, v = 0;
-            for (i = 0; i < nr && v < lim; ++i) {
-                const DevReg p = av[i];
-                int64_t rd; int qd, w, max_gap;
-                if (p.qb == -1 && p.qe == -1) continue;
-                if (s.rbeg < p.rb || s.rbeg + s.len > p.re || s.qbeg < p.qb || s.qbeg + s.len > p.qe) { v++; continue; }
-                if (s.len - p.seedlen0 > .1 * l_query) { v++; continue; }
-                qd = s.qbeg - p.qb; rd = s.rbeg - p.rb;
-                max_gap = cal_max_gap2(o, qd < rd ? qd : (int)rd);
-                w = max_gap < p.w ? max_gap : p.w;
-                if (qd - rd < w && rd - qd < w) break;
-                qd = p.qe - (s.qbeg + s.len); rd = p.re - (s.rbeg + s.len);
-                max_gap = cal_max_gap2(o, qd < rd ? qd : (int)rd);
-                w = max_gap < p.w ? max_gap : p.w;
-                if (qd - rd < w && rd - qd < w) break;
-                v++;
-            }
-            if (v < lim) {
-                for (v = k + 1; v < c.n; ++v) {
-                    if (srt2[v] < 0) continue;              // UINT_MAX marker of the reference
-                    const DevSeed t = cs[srt2[v]];
-                    if (t.len < s.len * .95) continue;
-                    if (s.qbeg <= t.qbeg && s.qbeg + s.len - t.qbeg >= s.len >> 2 && t.qbeg - s.qbeg != t.rbeg - s.rbeg) break;
-                    if (t.qbeg <= s.qbeg && t.qbeg + t.len - s.qbeg >= s.len >> 2 && s.qbeg - t.qbeg != s.rbeg - t.rbeg) break;
-                }
-                if (v == c.n) {
-                    av[s.aln].qb = -1; av[s.aln].qe = -1;
+    for (int i = 0; i < first_idx && i < nr; i++) if (!(av[i].qb == -1 && av[i].qe == -1)) lim++;
+    if (nr > first_idx) {
+        for (int j = 0; j < nc; j++) {
+            const DevChain c = chn[base + j];
+            if (c.reg0 + c.n <= first_idx) continue;        // every seed of this chain was decided lazily
+            const DevSeed *cs = seeds + c.seed_off;
+            int32_t *srt2 = srt_all + c.seed_off;
+            for (int k = c.n - 1; k >= 0; k--) {
+                const int idx = c.reg0 + (c.n - 1 - k);     // reg index of this seed inside the read
+                if (idx < first_idx) continue;
+                if (seed_redundant(o, l_query, av, nr, lim, c, cs, srt2, k)) {
+                    av[idx].qb = -1; av[idx].qe = -1;
                     srt2[k] = -1;
                     continue;
                 }
+                lim++;
             }
-            lim++;
         }
     }
     int m = 0;
     for (int i = 0; i < nr; i++) if (av[i].qe > av[i].qb) m++;       // bwamem.cpp:1141-1152
     n_out[r] = m;
+}
+
+// Lazy rounds: BEFORE extending, decide whether the next seeds of each read are redundant given the regs kept so far (the
+// order the original bwa-mem extends in).  Each round advances every read over its consecutive redundant seeds (purged,
+// never extended) to the next seed that must be extended; that seed is initialised and binned.  Equivalent to
+// extend-everything-then-purge (bwamem.cpp:2895-2989 exists precisely to reproduce this order), but the purged seeds --
+// about two thirds of all seeds on 150 bp reads -- cost nothing.  cursor[r] = index of the next undecided reg of read r.
+__global__ void __launch_bounds__(128)
+k_advance(ChainParams o, ExtParams xp, int n_reads, const int32_t *__restrict__ len,
+          const int64_t *__restrict__ read_base, const int32_t *__restrict__ n_reg,
+          const int32_t *__restrict__ reg_chain, const DevChain *__restrict__ chn,
+          const DevSeed *__restrict__ seeds, int32_t *srt_all, DevReg *regs, int32_t *cursor, int32_t *cur_slot /* [n_reads] reg idx to extend or -1 */,
+          uint8_t *bins /* [2][n_reads] */, uint32_t *hist /* [2*N_BINS] + [1] pending reads */) {
+    __shared__ uint32_t sh[2 * N_BINS + 1];
+    for (int i = threadIdx.x; i < 2 * N_BINS + 1; i += blockDim.x) sh[i] = 0;
+    __syncthreads();
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n_reads) {
+        int bl = 255, br = 255, pick = -1;
+        const int nr = n_reg[r];
+        int cur = cursor[r];
+        if (cur < nr) {
+            const int64_t base = read_base[r];
+            const int l_query = len[r];
+            DevReg *av = regs + base;
+            int lim = 0;
+            for (int i = 0; i < cur; i++) if (!(av[i].qb == -1 && av[i].qe == -1)) lim++;
+            while (cur < nr) {
+                const int ci = reg_chain[base + cur];
+                const DevChain c = chn[base + ci];
+                const DevSeed *cs = seeds + c.seed_off;
+                int32_t *srt2 = srt_all + c.seed_off;
+                const int k = c.n - 1 - (cur - c.reg0);
+                const DevSeed s = cs[srt2[k]];
+                DevReg a;
+                a.w = xp.w; a.rid = c.rid; a.frac_rep = c.frac_rep; a.seedlen0 = s.len; a.chain = ci; a.seedcov = 0;
+                a.rb = s.rbeg; a.re = s.rbeg + s.len; a.score = a.truesc = -1; a.qb = a.qe = -1;
+                if (lim > 0 && seed_redundant(o, l_query, av, cur, lim, c, cs, srt2, k)) {
+                    srt2[k] = -1;                            // purged: never extended
+                    av[cur] = a;
+                    cur++;
+                    continue;
+                }
+                if (s.qbeg) { a.qb = s.qbeg; }
+                else { a.score = a.truesc = s.len * xp.a; a.qb = 0; }
+                a.qe = (s.qbeg + s.len != l_query) ? s.qbeg + s.len : l_query;
+                for (int side = 0; side < 2; side++) {
+                    const bool has = side == 0 ? s.qbeg != 0 : s.qbeg + s.len != l_query;
+                    if (!has) continue;
+                    const TaskGeom tg = task_geom(side, s, c, nullptr, l_query, nullptr);
+                    const bool lane_ok = tg.len2 <= LANE_QMAX && tg.len1 < 32768 && (l_query + tg.len1 + 1) * xp.a < 32768;
+                    const int b = lane_ok ? tg.len2 : BIN_FALLBACK;
+                    if (side == 0) bl = b; else br = b;
+                    atomicAdd(&sh[side * N_BINS + b], 1u);
+                }
+                av[cur] = a;
+                pick = cur;
+                cur++;
+                break;
+            }
+            cursor[r] = cur;
+            if (cur < nr) atomicAdd(&sh[2 * N_BINS], 1u);    // this read still has undecided seeds
+        }
+        cur_slot[r] = pick;
+        bins[r] = (uint8_t)bl; bins[n_reads + r] = (uint8_t)br;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * N_BINS + 1; i += blockDim.x) if (sh[i]) atomicAdd(&hist[i], sh[i]);
+}
+
+// seedcov for the regs extended in one lazy round (one read per lane)
+__global__ void __launch_bounds__(256)
+k_seedcov_round(int n_reads, const int64_t *__restrict__ read_base, const int32_t *__restrict__ cur_slot,
+                const int32_t *__restrict__ reg_chain, const DevChain *__restrict__ chn, const DevSeed *__restrict__ seeds, DevReg *regs) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads || cur_slot[r] < 0) return;
+    const int64_t base = read_base[r], g = base + cur_slot[r];
+    DevReg a = regs[g];
+    const DevChain c = chn[base + reg_chain[g]];
+    int cov = 0;
+    for (int i = 0; i < c.n; i++) {
+        const DevSeed t = seeds[c.seed_off + i];
+        if (t.qbeg >= a.qb && t.qbeg + t.len <= a.qe && t.rbeg >= a.rb && t.rbeg + t.len <= a.re) cov += t.len;
+    }
+    regs[g].seedcov = cov;
 }
 
 // compact the surviving regs into read order
@@ -425,77 +530,133 @@ k_slot_base(int n_reads, const int64_t *__restrict__ read_base, const int32_t *_
 
 static int ring_size2(int w) { int R = 64; while (R < 2 * w + 4) R <<= 1; return R; }
 
-// Extension stage: init regs + bin tasks by query length, then left side, then right side (which starts from the left
-// score), lane-per-task for short queries and wavefront-per-task for the rest, then seedcov.
-int bm2_launch_extend(bm2_ctx *c, const bm2_opt &opt, int64_t n_slots, const uint8_t *enc, const int64_t *off, const int32_t *len,
+#define LAZY_ROUNDS 6
+#define N_CLS 10
+
+struct ExtLaunch {
+    bm2_ctx *c; hipStream_t s; ExtParams xp; const uint8_t *enc; const int64_t *off; const int32_t *len; const int64_t *slot_base;
+    const int32_t *reg_seed, *reg_chain; const DevChain *chn; const DevSeed *seeds; DevReg *regs; unsigned long long *counters;
+    int R; size_t lds_w;
+};
+
+// Left side, then right side (whose h0 is the left score).  Lane-per-task kernels per query-length class (each class needs
+// a different LDS footprint) plus the wavefront-per-task fallback; the launches of one side run concurrently on the
+// context's side streams, joined by events before the other side starts.
+static int run_sides(const ExtLaunch &L, const uint32_t *h_hist, const uint32_t *h_start, const int32_t *taskL, const int32_t *taskR) {
+    static const int cls_hi[N_CLS] = { 16, 32, 48, 64, 80, 96, 112, 128, 144, 160 };
+    bm2_ctx *c = L.c;
+    for (int side = 0; side < 2; side++) {
+        const int32_t *tasks = side == 0 ? taskL : taskR;
+        const uint32_t *st = h_start + side * N_BINS, *hc = h_hist + side * N_BINS;
+        (void)hipEventRecord(c->ev_fork, L.s);
+        int lo = 0, used = 0;
+        for (int k = 0; k <= N_CLS; k++) {
+            hipStream_t sk = c->side_stream[k];
+            uint32_t n = 0, first = 0; int hi = 0;
+            if (k < N_CLS) {
+                hi = cls_hi[k]; first = st[lo + 1];
+                for (int b = lo + 1; b <= hi; b++) n += hc[b];
+                lo = hi;
+            } else { n = hc[BIN_FALLBACK]; first = st[BIN_FALLBACK]; }
+            if (!n) continue;
+            (void)hipStreamWaitEvent(sk, c->ev_fork, 0);
+            if (k < N_CLS) {
+                const size_t lds = (size_t)(hi + 1) * 64 * 4 + (size_t)hi * 64;
+                if (side == 0)
+                    hipLaunchKernelGGL(k_ext_lanes<0>, dim3((n + 63) / 64), dim3(64), lds, sk, c->ix, L.xp, tasks + first, (int)n, hi, L.enc, L.off, L.len,
+                                       L.slot_base, L.reg_seed, L.reg_chain, L.chn, L.seeds, L.regs, L.counters);
+                else
+                    hipLaunchKernelGGL(k_ext_lanes<1>, dim3((n + 63) / 64), dim3(64), lds, sk, c->ix, L.xp, tasks + first, (int)n, hi, L.enc, L.off, L.len,
+                                       L.slot_base, L.reg_seed, L.reg_chain, L.chn, L.seeds, L.regs, L.counters);
+            } else {
+                if (side == 0) hipLaunchKernelGGL(k_ext_wave<0>, dim3((n + 3) / 4), dim3(256), L.lds_w, sk, c->ix, L.xp, tasks + first, (int)n, L.enc, L.off, L.len, L.slot_base, L.reg_seed, L.reg_chain, L.chn, L.seeds, L.regs, L.R, L.counters);
+                else hipLaunchKernelGGL(k_ext_wave<1>, dim3((n + 3) / 4), dim3(256), L.lds_w, sk, c->ix, L.xp, tasks + first, (int)n, L.enc, L.off, L.len, L.slot_base, L.reg_seed, L.reg_chain, L.chn, L.seeds, L.regs, L.R, L.counters);
+            }
+            (void)hipEventRecord(c->ev_join[k], sk);
+            (void)hipStreamWaitEvent(L.s, c->ev_join[k], 0);
+            used++;
+        }
+        (void)used;
+    }
+    return bm2_check(hipGetLastError(), "extension launches");
+}
+
+// Extension stage: lazy rounds (k_advance + extension of the picked seeds), then -- for reads that still have undecided
+// seeds after LAZY_ROUNDS kept alignments (repeat-rich reads) -- eager extension of the rest, purged by k_postfilter exactly
+// as the reference does for every seed.  cursor[r] tells the post-filter where its replay starts.
+int bm2_launch_extend(bm2_ctx *c, const bm2_opt &opt, const ChainParams &cp, int n_reads, int64_t n_slots, const uint8_t *enc,
+                      const int64_t *off, const int32_t *len, const int64_t *read_base, const int32_t *n_chain, const int32_t *n_reg,
                       const int64_t *slot_base, const int32_t *reg_seed, const int32_t *reg_chain, const DevChain *chn,
-                      const DevSeed *seeds, DevReg *regs, unsigned long long *counters, DevBuf &tmp) {
-    if (n_slots <= 0) return BM2_OK;
+                      const DevSeed *seeds, int32_t *srt_all, DevReg *regs, unsigned long long *counters, DevBuf &tmp, int32_t *cursor) {
     hipStream_t s = c->stream;
-    ExtParams xp;
+    int rc;
+    if ((rc = bm2_check(hipMemsetAsync(cursor, 0, (size_t)(n_reads + 1) * 4, s), "memset cursor"))) return rc;
+    if (n_slots <= 0) return BM2_OK;
+    ExtLaunch L;
+    L.c = c; L.s = s; L.enc = enc; L.off = off; L.len = len; L.slot_base = slot_base; L.reg_seed = reg_seed; L.reg_chain = reg_chain;
+    L.chn = chn; L.seeds = seeds; L.regs = regs; L.counters = counters;
+    ExtParams &xp = L.xp;
     xp.a = opt.a; xp.w = opt.w; xp.pen_clip5 = opt.pen_clip5; xp.pen_clip3 = opt.pen_clip3;
     SwParams P;
     P.o_del = opt.o_del; P.e_del = opt.e_del; P.o_ins = opt.o_ins; P.e_ins = opt.e_ins; P.zdrop = opt.zdrop; P.max_sc = opt.a;
     for (int i = 0; i < 25; i++) P.mat[i] = opt.mat[i];
     P.end_bonus = opt.pen_clip5; xp.left = P;
     P.end_bonus = opt.pen_clip3; xp.right = P;
-    // scratch: bins[2*n_slots] bytes | hist[2*N_BINS] | cursor[2*N_BINS] | taskL[n_slots] | taskR[n_slots]
-    const size_t o_hist = ((size_t)2 * n_slots + 255) & ~(size_t)255, o_cur = o_hist + 2 * N_BINS * 4;
-    const size_t o_tl = (o_cur + 2 * N_BINS * 4 + 255) & ~(size_t)255, o_tr = o_tl + (size_t)n_slots * 4;
-    int rc = bm2_reserve(tmp, o_tr + (size_t)n_slots * 4 + 256);
-    if (rc) return rc;
+    L.R = ring_size2(opt.w << (MAX_BAND_TRY - 1));
+    L.lds_w = ((sizeof(ExtParams) + 3) / 4) * 4 + (size_t)4 * 2 * L.R * 4;
+    if (L.lds_w > 160 * 1024) { bm2_set_error("band width %d needs more LDS than a CU has", opt.w); return BM2_EUNSUP; }
+    // scratch: bins[2*max(n_slots,n_reads)] | hist[2*N_BINS+1] | start[2*N_BINS] | cur_slot[n_reads] | taskL[n_slots] | taskR[n_slots]
+    const size_t n_items = (size_t)(n_slots > n_reads ? n_slots : n_reads);
+    const size_t o_hist = (2 * n_items + 255) & ~(size_t)255, o_cur = o_hist + (2 * N_BINS + 2) * 4;
+    const size_t o_cs = (o_cur + 2 * N_BINS * 4 + 255) & ~(size_t)255;
+    const size_t o_tl = (o_cs + (size_t)n_reads * 4 + 255) & ~(size_t)255, o_tr = o_tl + (size_t)n_slots * 4;
+    if ((rc = bm2_reserve(tmp, o_tr + (size_t)n_slots * 4 + 256))) return rc;
     uint8_t *bins = (uint8_t *)tmp.p;
-    uint32_t *hist = (uint32_t *)((char *)tmp.p + o_hist), *cursor = (uint32_t *)((char *)tmp.p + o_cur);
+    uint32_t *hist = (uint32_t *)((char *)tmp.p + o_hist), *start = (uint32_t *)((char *)tmp.p + o_cur);
+    int32_t *cur_slot = (int32_t *)((char *)tmp.p + o_cs);
     int32_t *taskL = (int32_t *)((char *)tmp.p + o_tl), *taskR = (int32_t *)((char *)tmp.p + o_tr);
-    if ((rc = bm2_check(hipMemsetAsync(hist, 0, 2 * N_BINS * 4, s), "memset hist"))) return rc;
-    const unsigned nb = (unsigned)((n_slots + 255) / 256);
-    hipLaunchKernelGGL(k_reg_init, dim3(nb), dim3(256), 0, s, xp, n_slots, len, slot_base, reg_seed, reg_chain, chn, seeds, regs, bins, hist);
-    uint32_t h_hist[2 * N_BINS], h_start[2 * N_BINS];
-    if ((rc = bm2_check(hipMemcpyAsync(h_hist, hist, sizeof h_hist, hipMemcpyDeviceToHost, s), "D2H hist"))) return rc;
-    if ((rc = bm2_check(hipStreamSynchronize(s), "k_reg_init"))) return rc;
-    for (int side = 0; side < 2; side++) {
-        uint32_t acc = 0;
-        for (int b = 0; b < N_BINS; b++) { h_start[side * N_BINS + b] = acc; acc += h_hist[side * N_BINS + b]; }
+    uint32_t h_hist[2 * N_BINS + 1], h_start[2 * N_BINS];
+    auto prefix = [&]() {
+        for (int side = 0; side < 2; side++) {
+            uint32_t acc = 0;
+            for (int b = 0; b < N_BINS; b++) { h_start[side * N_BINS + b] = acc; acc += h_hist[side * N_BINS + b]; }
+        }
+    };
+    const unsigned nbr = (unsigned)((n_reads + 127) / 128), nbr2 = (unsigned)((n_reads + 255) / 256);
+    uint32_t pending = 1;
+    for (int round = 0; round < LAZY_ROUNDS && pending; round++) {
+        if ((rc = bm2_check(hipMemsetAsync(hist, 0, (2 * N_BINS + 1) * 4, s), "memset hist"))) return rc;
+        hipLaunchKernelGGL(k_advance, dim3(nbr), dim3(128), 0, s, cp, xp, n_reads, len, read_base, n_reg, reg_chain, chn, seeds, srt_all,
+                           regs, cursor, cur_slot, bins, hist);
+        if ((rc = bm2_check(hipMemcpyAsync(h_hist, hist, sizeof h_hist, hipMemcpyDeviceToHost, s), "D2H hist"))) return rc;
+        if ((rc = bm2_check(hipStreamSynchronize(s), "k_advance"))) return rc;
+        pending = h_hist[2 * N_BINS];
+        uint32_t tot = 0;
+        for (int b = 0; b < 2 * N_BINS; b++) tot += h_hist[b];
+        if (tot) {
+            prefix();
+            if ((rc = bm2_check(hipMemcpyAsync(start, h_start, sizeof h_start, hipMemcpyHostToDevice, s), "H2D start"))) return rc;
+            hipLaunchKernelGGL(k_task_scatter, dim3(nbr2), dim3(256), 0, s, (int64_t)n_reads, bins, start, taskL, taskR, read_base, cur_slot);
+            if ((rc = run_sides(L, h_hist, h_start, taskL, taskR))) return rc;
+        }
+        hipLaunchKernelGGL(k_seedcov_round, dim3(nbr2), dim3(256), 0, s, n_reads, read_base, cur_slot, reg_chain, chn, seeds, regs);
     }
-    if ((rc = bm2_check(hipMemcpyAsync(cursor, h_start, sizeof h_start, hipMemcpyHostToDevice, s), "H2D cursor"))) return rc;
-    hipLaunchKernelGGL(k_task_scatter, dim3(nb), dim3(256), 0, s, n_slots, bins, cursor, taskL, taskR);
-    static const int cls_hi[] = { 16, 32, 48, 64, 80, 96, 112, 128, 144, 160 };
-    const int R = ring_size2(opt.w << (MAX_BAND_TRY - 1));
-    const size_t lds_w = ((sizeof(ExtParams) + 3) / 4) * 4 + (size_t)4 * 2 * R * 4;
-    if (lds_w > 160 * 1024) { bm2_set_error("band width %d needs more LDS than a CU has", opt.w); return BM2_EUNSUP; }
-    for (int side = 0; side < 2; side++) {
-        const int32_t *tasks = side == 0 ? taskL : taskR;
-        const uint32_t *st = h_start + side * N_BINS, *hc = h_hist + side * N_BINS;
-        int lo = 0;
-        for (int k = 0; k < (int)(sizeof cls_hi / sizeof cls_hi[0]); k++) {
-            const int hi = cls_hi[k];                                  // bins (lo, hi]
-            const uint32_t first = st[lo + 1 > N_BINS - 1 ? N_BINS - 1 : lo + 1];
-            uint32_t n = 0;
-            for (int b = lo + 1; b <= hi; b++) n += hc[b];
-            lo = hi;
-            if (!n) continue;
-            const size_t lds = (size_t)(hi + 1) * 64 * 4 + (size_t)hi * 64;
-            if (side == 0)
-                hipLaunchKernelGGL(k_ext_lanes<0>, dim3((n + 63) / 64), dim3(64), lds, s, c->ix, xp, tasks + first, (int)n, hi, enc, off, len,
-                                   slot_base, reg_seed, reg_chain, chn, seeds, regs, counters);
-            else
-                hipLaunchKernelGGL(k_ext_lanes<1>, dim3((n + 63) / 64), dim3(64), lds, s, c->ix, xp, tasks + first, (int)n, hi, enc, off, len,
-                                   slot_base, reg_seed, reg_chain, chn, seeds, regs, counters);
+    if (pending) {      // eager remainder: every seed at or beyond its read's cursor
+        if ((rc = bm2_check(hipMemsetAsync(hist, 0, (2 * N_BINS + 1) * 4, s), "memset hist"))) return rc;
+        const unsigned nb = (unsigned)((n_slots + 255) / 256);
+        hipLaunchKernelGGL(k_reg_init, dim3(nb), dim3(256), 0, s, xp, n_slots, len, slot_base, reg_seed, reg_chain, chn, seeds, regs, bins, hist, cursor);
+        if ((rc = bm2_check(hipMemcpyAsync(h_hist, hist, sizeof h_hist, hipMemcpyDeviceToHost, s), "D2H hist"))) return rc;
+        if ((rc = bm2_check(hipStreamSynchronize(s), "k_reg_init"))) return rc;
+        uint32_t tot = 0;
+        for (int b = 0; b < 2 * N_BINS; b++) tot += h_hist[b];
+        if (tot) {
+            prefix();
+            if ((rc = bm2_check(hipMemcpyAsync(start, h_start, sizeof h_start, hipMemcpyHostToDevice, s), "H2D start"))) return rc;
+            hipLaunchKernelGGL(k_task_scatter, dim3(nb), dim3(256), 0, s, n_slots, bins, start, taskL, taskR, (const int64_t *)nullptr, (const int32_t *)nullptr);
+            if ((rc = run_sides(L, h_hist, h_start, taskL, taskR))) return rc;
         }
-        // bin 0 cannot occur (a task has at least one query base); the fallback bin runs one task per wavefront
-        const uint32_t nf = hc[BIN_FALLBACK] + hc[0], ff = st[0];
-        if (hc[0]) {
-            if (side == 0) hipLaunchKernelGGL(k_ext_wave<0>, dim3((hc[0] + 3) / 4), dim3(256), lds_w, s, c->ix, xp, tasks + ff, (int)hc[0], enc, off, len, slot_base, reg_seed, reg_chain, chn, seeds, regs, R, counters);
-            else hipLaunchKernelGGL(k_ext_wave<1>, dim3((hc[0] + 3) / 4), dim3(256), lds_w, s, c->ix, xp, tasks + ff, (int)hc[0], enc, off, len, slot_base, reg_seed, reg_chain, chn, seeds, regs, R, counters);
-        }
-        (void)nf;
-        if (hc[BIN_FALLBACK]) {
-            const uint32_t f2 = st[BIN_FALLBACK], n2 = hc[BIN_FALLBACK];
-            if (side == 0) hipLaunchKernelGGL(k_ext_wave<0>, dim3((n2 + 3) / 4), dim3(256), lds_w, s, c->ix, xp, tasks + f2, (int)n2, enc, off, len, slot_base, reg_seed, reg_chain, chn, seeds, regs, R, counters);
-            else hipLaunchKernelGGL(k_ext_wave<1>, dim3((n2 + 3) / 4), dim3(256), lds_w, s, c->ix, xp, tasks + f2, (int)n2, enc, off, len, slot_base, reg_seed, reg_chain, chn, seeds, regs, R, counters);
-        }
+        hipLaunchKernelGGL(k_seedcov, dim3(nb), dim3(256), 0, s, n_slots, slot_base, reg_seed, reg_chain, chn, seeds, regs, cursor);
     }
-    hipLaunchKernelGGL(k_seedcov, dim3(nb), dim3(256), 0, s, n_slots, slot_base, reg_seed, reg_chain, chn, seeds, regs);
     return bm2_check(hipGetLastError(), "extension launches");
 }
 
@@ -507,10 +668,10 @@ int bm2_launch_slot_base(bm2_ctx *c, int n_reads, const int64_t *read_base, cons
 
 int bm2_launch_postfilter(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_t *len, const int64_t *read_base,
                           const int32_t *n_chain, const int32_t *n_reg, const DevChain *chn, const DevSeed *seeds,
-                          int32_t *srt_all, DevReg *regs, int32_t *n_out) {
+                          int32_t *srt_all, DevReg *regs, int32_t *n_out, const int32_t *cursor) {
     if (n_reads <= 0) return BM2_OK;
     hipLaunchKernelGGL(k_postfilter, dim3((n_reads + 127) / 128), dim3(128), 0, c->stream, o, n_reads, len, read_base, n_chain,
-                       n_reg, chn, seeds, srt_all, regs, n_out);
+                       n_reg, chn, seeds, srt_all, regs, n_out, cursor);
     return bm2_check(hipGetLastError(), "k_postfilter launch");
 }
 

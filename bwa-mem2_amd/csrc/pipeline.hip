@@ -16,13 +16,14 @@ int bm2_launch_chain(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_
                      WChain *wchain, WSeed *wseed, BtNode *nodes, int32_t *order, DevChain *chn, DevSeed *seeds_out,
                      int32_t *srt_out, int32_t *reg_seed, int32_t *reg_chain,
                      int32_t *n_chain_out, int32_t *n_reg_out, int32_t *n_chain0_out);
-int bm2_launch_extend(bm2_ctx *c, const bm2_opt &opt, int64_t n_slots, const uint8_t *enc, const int64_t *off, const int32_t *len,
+int bm2_launch_extend(bm2_ctx *c, const bm2_opt &opt, const ChainParams &cp, int n_reads, int64_t n_slots, const uint8_t *enc,
+                      const int64_t *off, const int32_t *len, const int64_t *read_base, const int32_t *n_chain, const int32_t *n_reg,
                       const int64_t *slot_base, const int32_t *reg_seed, const int32_t *reg_chain, const DevChain *chn,
-                      const DevSeed *seeds, DevReg *regs, unsigned long long *counters, DevBuf &tmp);
+                      const DevSeed *seeds, int32_t *srt_all, DevReg *regs, unsigned long long *counters, DevBuf &tmp, int32_t *cursor);
 int bm2_launch_slot_base(bm2_ctx *c, int n_reads, const int64_t *read_base, const int32_t *n_reg, int64_t *slot_base);
 int bm2_launch_postfilter(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_t *len, const int64_t *read_base,
                           const int32_t *n_chain, const int32_t *n_reg, const DevChain *chn, const DevSeed *seeds,
-                          int32_t *srt_all, DevReg *regs, int32_t *n_out);
+                          int32_t *srt_all, DevReg *regs, int32_t *n_out, const int32_t *cursor);
 int bm2_launch_reg_gather(bm2_ctx *c, int n_reads, const int64_t *read_base, const int32_t *n_reg, const DevReg *regs,
                           const int64_t *out_off, bm2_reg_t *out, int64_t out_cap);
 
@@ -36,7 +37,7 @@ struct Batch {
     DevBuf stage, prevbuf, smem, occ_cnt, smem_cnt, smem_off, counters, sa_off, sa_coord, scan_tmp, read_base;
     // chaining / extension
     DevBuf wchain, wseed, nodes, order, chn, seeds, srt, reg_seed, reg_chain, regs, slot_base, n_chain, n_reg, n_chain0, n_out;
-    DevBuf out_off, out_regs, smem_sorted, smem_sorted_off, ext_tmp;
+    DevBuf out_off, out_regs, smem_sorted, smem_sorted_off, ext_tmp, cursor;
     int64_t n_smem = 0, n_sa = 0, n_out_regs = 0;
     bm2_stats stats{};
 };
@@ -47,7 +48,7 @@ void bm2_batch_destroy(bm2_ctx *c) {
     DevBuf *all[] = { &b->enc, &b->off, &b->len, &b->stage, &b->prevbuf, &b->smem, &b->occ_cnt, &b->smem_cnt, &b->smem_off,
                       &b->counters, &b->sa_off, &b->sa_coord, &b->scan_tmp, &b->read_base, &b->wchain, &b->wseed, &b->nodes,
                       &b->order, &b->chn, &b->seeds, &b->srt, &b->reg_seed, &b->reg_chain, &b->regs, &b->slot_base, &b->n_chain,
-                      &b->n_reg, &b->n_chain0, &b->n_out, &b->out_off, &b->out_regs, &b->smem_sorted, &b->smem_sorted_off, &b->ext_tmp };
+                      &b->n_reg, &b->n_chain0, &b->n_out, &b->out_off, &b->out_regs, &b->smem_sorted, &b->smem_sorted_off, &b->ext_tmp, &b->cursor };
     for (DevBuf *d : all) bm2_release(*d);
     delete b;
     c->batch = nullptr;
@@ -237,14 +238,16 @@ extern "C" int bm2_batch_run(bm2_ctx *c, const bm2_opt *opt) {
                                (int32_t *)b->reg_chain.p, (int32_t *)b->n_chain.p, (int32_t *)b->n_reg.p, (int32_t *)b->n_chain0.p))) return rc;
     tick(c, "chain");
     if ((rc = bm2_launch_slot_base(c, n, (const int64_t *)b->read_base.p, (const int32_t *)b->n_reg.p, (int64_t *)b->slot_base.p))) return rc;
-    if ((rc = bm2_launch_extend(c, *opt, n_sa, (const uint8_t *)b->enc.p, (const int64_t *)b->off.p, (const int32_t *)b->len.p,
+    if ((rc = bm2_reserve(b->cursor, (size_t)(n + 1) * 4))) return rc;
+    if ((rc = bm2_launch_extend(c, *opt, cp, n, n_sa, (const uint8_t *)b->enc.p, (const int64_t *)b->off.p, (const int32_t *)b->len.p,
+                                (const int64_t *)b->read_base.p, (const int32_t *)b->n_chain.p, (const int32_t *)b->n_reg.p,
                                 (const int64_t *)b->slot_base.p, (const int32_t *)b->reg_seed.p, (const int32_t *)b->reg_chain.p,
-                                (const DevChain *)b->chn.p, (const DevSeed *)b->seeds.p, (DevReg *)b->regs.p,
-                                (unsigned long long *)b->counters.p + 5, b->ext_tmp))) return rc;
+                                (const DevChain *)b->chn.p, (const DevSeed *)b->seeds.p, (int32_t *)b->srt.p, (DevReg *)b->regs.p,
+                                (unsigned long long *)b->counters.p + 5, b->ext_tmp, (int32_t *)b->cursor.p))) return rc;
     tick(c, "extend");
     if ((rc = bm2_launch_postfilter(c, cp, n, (const int32_t *)b->len.p, (const int64_t *)b->read_base.p, (const int32_t *)b->n_chain.p,
                                     (const int32_t *)b->n_reg.p, (const DevChain *)b->chn.p, (const DevSeed *)b->seeds.p,
-                                    (int32_t *)b->srt.p, (DevReg *)b->regs.p, (int32_t *)b->n_out.p))) return rc;
+                                    (int32_t *)b->srt.p, (DevReg *)b->regs.p, (int32_t *)b->n_out.p, (const int32_t *)b->cursor.p))) return rc;
     if ((rc = bm2_scan_i32(c, (const int32_t *)b->n_out.p, n, (int64_t *)b->out_off.p, b->scan_tmp))) return rc;
     int64_t n_out = 0;
     unsigned long long h_cnt[8];

@@ -37,7 +37,13 @@ def test_golden_all_stages(gpu_ctx_factory, golden_dir, name):
     C, S, R = gpu_stage_records(ctx, bm2, len(ln))
     _same(d["CHN1"], C, "CHN1")
     _same(d["SEED1"], S, "SEED1")
-    _same(d["REGRAW"], R, "REGRAW")
+    # regs before the purge: the device decides redundancy BEFORE extending (lazy rounds), the reference after; purged
+    # regs therefore agree on the purge marker only, surviving regs on every field
+    exp_raw = d["REGRAW"]
+    assert len(exp_raw) == len(R)
+    purged = (exp_raw["qb"] == -1) & (exp_raw["qe"] == -1)
+    assert ((R["qb"] == -1) & (R["qe"] == -1) == purged).all()
+    _same(exp_raw[~purged], R[~purged], "REGRAW (kept)")
     _same(d["REGPRG"], regs_to_records(regs, reg_off), "REGPRG")
     assert st["n_smem"] == len(d["SMEM"]) and st["n_sa"] == len(d["SACOORD"]) and st["n_reg"] == len(d["REGPRG"])
 
@@ -81,8 +87,9 @@ def test_fresh_inputs_vs_oracle(gpu_ctx_factory, tmp_path, seed, L, n):
     regs, reg_off, st = ctx.seed_chain_extend(enc, off, ln, bm2.default_opt())
     _same(exp["REGPRG"], regs_to_records(regs, reg_off), "REGPRG")
     c = exp["counters"]
-    assert st["n_ext"] == c["n_ext"] and st["n_lf"] == c["n_lf"] and st["n_sw_cells"] == c["n_sw_cells"]
-    assert st["n_sw_tasks"] == len(exp["PAIR"])
+    assert st["n_ext"] == c["n_ext"] and st["n_lf"] == c["n_lf"]
+    # lazy rounds skip the extension of seeds the reference extends and then purges
+    assert 0 < st["n_sw_cells"] <= c["n_sw_cells"] and 0 < st["n_sw_tasks"] <= len(exp["PAIR"])
 
 
 def test_non_default_options_vs_oracle(gpu_ctx_factory, tmp_path):
