@@ -25,6 +25,8 @@ import time
 
 import numpy as np
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # the extension stage forks ~10 concurrent launches per side
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "bwa-mem2_amd"))

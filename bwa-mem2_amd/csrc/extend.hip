@@ -154,6 +154,7 @@ static __device__ void lane_dp(bool run, int qlen, int tlen, int w, int h0, cons
         const int s_eq = tb > 3 ? sc_amb : sc_match;
         const int jlo = (1 << 20) - __builtin_amdgcn_readlane(wave_scan_max(alive ? (1 << 20) - beg : 0, 0), 63);
         const int jhi = __builtin_amdgcn_readlane(wave_scan_max(alive ? end : 0, 0), 63);
+#pragma unroll 2
         for (int j = jlo; j < jhi; ++j) {
             if (alive && j >= beg && j < end) {
                 const uint32_t p = EH[j * 64 + lane];
@@ -549,14 +550,16 @@ static int run_sides(const ExtLaunch &L, const uint32_t *h_hist, const uint32_t 
         const int32_t *tasks = side == 0 ? taskL : taskR;
         const uint32_t *st = h_start + side * N_BINS, *hc = h_hist + side * N_BINS;
         (void)hipEventRecord(c->ev_fork, L.s);
-        int lo = 0, used = 0;
-        for (int k = 0; k <= N_CLS; k++) {
+        int used = 0;
+        for (int kk = 0; kk <= N_CLS; kk++) {                  // longest queries first: their tails overlap the short classes
+            const int k = kk == 0 ? N_CLS : N_CLS - kk;
             hipStream_t sk = c->side_stream[k];
             uint32_t n = 0, first = 0; int hi = 0;
             if (k < N_CLS) {
-                hi = cls_hi[k]; first = st[lo + 1];
+                hi = cls_hi[k];
+                const int lo = k ? cls_hi[k - 1] : 0;
+                first = st[lo + 1];
                 for (int b = lo + 1; b <= hi; b++) n += hc[b];
-                lo = hi;
             } else { n = hc[BIN_FALLBACK]; first = st[BIN_FALLBACK]; }
             if (!n) continue;
             (void)hipStreamWaitEvent(sk, c->ev_fork, 0);
@@ -624,7 +627,7 @@ int bm2_launch_extend(bm2_ctx *c, const bm2_opt &opt, const ChainParams &cp, int
     };
     const unsigned nbr = (unsigned)((n_reads + 127) / 128), nbr2 = (unsigned)((n_reads + 255) / 256);
     uint32_t pending = 1;
-    for (int round = 0; round < LAZY_ROUNDS && pending; round++) {
+    for (int round = 0; round < LAZY_ROUNDS && pending && (round < 1 || pending * 12u >= (uint32_t)n_reads); round++) {
         if ((rc = bm2_check(hipMemsetAsync(hist, 0, (2 * N_BINS + 1) * 4, s), "memset hist"))) return rc;
         hipLaunchKernelGGL(k_advance, dim3(nbr), dim3(128), 0, s, cp, xp, n_reads, len, read_base, n_reg, reg_chain, chn, seeds, srt_all,
                            regs, cursor, cur_slot, bins, hist);
