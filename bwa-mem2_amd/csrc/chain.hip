@@ -29,6 +29,21 @@ static __device__ int pos2rid(const DevIndex &ix, int64_t pos_f) {
     }
     return mid;
 }
+// bns_intv2rid with a one-entry cache: consecutive seeds of a read almost always fall in the same contig and strand, so
+// the two binary searches over the contig table are skipped when [rb, re) lies inside the cached contig's span
+struct RidCache { int64_t lo, hi; int rid; };
+static __device__ int intv2rid(const DevIndex &ix, int64_t rb, int64_t re);
+static __device__ __forceinline__ int intv2rid_cached(const DevIndex &ix, int64_t rb, int64_t re, RidCache &rc) {
+    if (rb >= rc.lo && re <= rc.hi && rb < re) return rc.rid;
+    const int rid = intv2rid(ix, rb, re);
+    if (rid >= 0) {
+        const int64_t o = ix.ann_offset[rid], e = o + ix.ann_len[rid];
+        if (rb >= ix.l_pac) { rc.lo = (ix.l_pac << 1) - e; rc.hi = (ix.l_pac << 1) - o; }
+        else { rc.lo = o; rc.hi = e; }
+        rc.rid = rid;
+    }
+    return rid;
+}
 static __device__ int intv2rid(const DevIndex &ix, int64_t rb, int64_t re) {
     int is_rev;
     if (rb < ix.l_pac && re > ix.l_pac) return -2;
@@ -39,8 +54,11 @@ static __device__ int intv2rid(const DevIndex &ix, int64_t rb, int64_t re) {
 
 // cal_max_gap, bwamem.cpp:66-76
 static __device__ __forceinline__ int cal_max_gap(const ChainParams &o, int qlen) {
-    const int l_del = (int)((double)(qlen * o.a - o.o_del) / o.e_del + 1.);
-    const int l_ins = (int)((double)(qlen * o.a - o.o_ins) / o.e_ins + 1.);
+    // (int)((double)(qlen*a - o)/e + 1.) == (qlen*a - o + e) / e in C integer division (both truncate toward zero, e > 0);
+    // the double division of the reference would cost ~100 instructions per call on the GPU
+    const int nd = qlen * o.a - o.o_del + o.e_del, ni = qlen * o.a - o.o_ins + o.e_ins;
+    const int l_del = o.e_del == 1 ? nd : nd / o.e_del;
+    const int l_ins = o.e_ins == 1 ? ni : ni / o.e_ins;
     int l = l_del > l_ins ? l_del : l_ins;
     l = l > 1 ? l : 1;
     return l < o.w << 1 ? l : o.w << 1;
@@ -61,10 +79,10 @@ static __device__ int bt_getp_aux(const BTree &b, const BtNode &x, int64_t k, in
     if (x.n == 0) return -1;
     while (begin < end) {
         const int mid = (begin + end) >> 1;
-        if (b.ch[x.key[mid]].pos < k) begin = mid + 1; else end = mid;
+        if (x.kpos[mid] < k) begin = mid + 1; else end = mid;
     }
     if (begin == x.n) { r = 1; return x.n - 1; }
-    const int64_t kp = b.ch[x.key[begin]].pos;
+    const int64_t kp = x.kpos[begin];
     r = (kp < k) - (k < kp);
     if (r < 0) --begin;
     return begin;
@@ -87,13 +105,13 @@ static __device__ void bt_split(BTree &b, int xi, int i, int yi) {
     const int zi = bt_new(b, b.nodes[yi].is_internal);
     BtNode &x = b.nodes[xi], &y = b.nodes[yi], &z = b.nodes[zi];
     z.n = BT_T - 1;
-    for (int t = 0; t < BT_T - 1; t++) z.key[t] = y.key[BT_T + t];
+    for (int t = 0; t < BT_T - 1; t++) { z.key[t] = y.key[BT_T + t]; z.kpos[t] = y.kpos[BT_T + t]; }
     if (y.is_internal) for (int t = 0; t < BT_T; t++) z.ptr[t] = y.ptr[BT_T + t];
     y.n = BT_T - 1;
     for (int t = x.n; t > i; t--) x.ptr[t + 1] = x.ptr[t];
     x.ptr[i + 1] = zi;
-    for (int t = x.n - 1; t >= i; t--) x.key[t + 1] = x.key[t];
-    x.key[i] = y.key[BT_T - 1];
+    for (int t = x.n - 1; t >= i; t--) { x.key[t + 1] = x.key[t]; x.kpos[t + 1] = x.kpos[t]; }
+    x.key[i] = y.key[BT_T - 1]; x.kpos[i] = y.kpos[BT_T - 1];
     ++x.n;
 }
 // kb_putp + __kb_putp_aux, kbtree.h:197-231 (the recursion is a plain descent)
@@ -110,15 +128,15 @@ static __device__ void bt_put(BTree &b, int key) {
         BtNode &x = b.nodes[xi];
         if (!x.is_internal) {
             const int i = bt_getp_aux(b, x, k, r);
-            for (int t = x.n - 1; t > i; t--) x.key[t + 1] = x.key[t];
-            x.key[i + 1] = key;
+            for (int t = x.n - 1; t > i; t--) { x.key[t + 1] = x.key[t]; x.kpos[t + 1] = x.kpos[t]; }
+            x.key[i + 1] = key; x.kpos[i + 1] = k;
             ++x.n;
             return;
         }
         int i = bt_getp_aux(b, x, k, r) + 1;
         if (b.nodes[x.ptr[i]].n == 2 * BT_T - 1) {
             bt_split(b, xi, i, x.ptr[i]);
-            if (k > b.ch[x.key[i]].pos) ++i;
+            if (k > x.kpos[i]) ++i;
         }
         xi = x.ptr[i];
     }
@@ -251,9 +269,10 @@ k_chain(DevIndex ix, ChainParams o, int n_reads, const int32_t *__restrict__ len
         const int32_t *__restrict__ smem_cnt, const int64_t *__restrict__ smem_off, const int64_t *__restrict__ sa_off,
         const int64_t *__restrict__ sa_coord, WChain *wchain, WSeed *wseed, BtNode *nodes, int32_t *order,
         DevChain *chn, DevSeed *seeds_out, int32_t *srt_out, int32_t *reg_seed, int32_t *reg_chain,
-        int32_t *n_chain_out, int32_t *n_reg_out, int32_t *n_chain0_out) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_reads) return;
+        int32_t *n_chain_out, int32_t *n_reg_out, int32_t *n_chain0_out, const int32_t *__restrict__ perm) {
+    const int tix = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tix >= n_reads) return;
+    const int r = perm[tix];
     const int n_sm = smem_cnt[r];
     n_chain_out[r] = 0; n_reg_out[r] = 0;
     if (n_chain0_out) n_chain0_out[r] = 0;
@@ -275,6 +294,7 @@ k_chain(DevIndex ix, ChainParams o, int n_reads, const int32_t *__restrict__ len
     BTree bt; bt.nodes = nodes + base; bt.n_nodes = 0; bt.n_keys = 0; bt.ch = ch;     // <= n_sa/4 + 1 nodes are ever needed
     bt.root = bt_new(bt, 0);
     int n_ch = 0, n_sd = 0;
+    RidCache ridc; ridc.lo = 1; ridc.hi = 0; ridc.rid = -1;
     int b = 0, e = 0, l_rep = 0;
     for (int i = 0; i < n_sm; i++) {                     // l_rep, bwamem.cpp:849-861
         const int sb = (int)smems[so + i].m, se = (int)smems[so + i].n + 1;
@@ -290,7 +310,7 @@ k_chain(DevIndex ix, ChainParams o, int n_reads, const int32_t *__restrict__ len
         const int cnt = (int)(sa_off[so + i + 1] - sa_off[so + i]);
         for (int c = 0; c < cnt; c++) {
             WSeed s; s.rbeg = sa_coord[base + o0 + c]; s.qbeg = (int32_t)p.m; s.len = slen; s.next = -1;
-            const int rid = intv2rid(ix, s.rbeg, s.rbeg + s.len);
+            const int rid = intv2rid_cached(ix, s.rbeg, s.rbeg + s.len, ridc);
             if (rid < 0) continue;                       // bwamem.cpp:915-919
             int to_add = 0;
             if (bt.n_keys) {
@@ -435,10 +455,10 @@ int bm2_launch_chain(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_
                      const int32_t *smem_cnt, const int64_t *smem_off, const int64_t *sa_off, const int64_t *sa_coord,
                      WChain *wchain, WSeed *wseed, BtNode *nodes, int32_t *order, DevChain *chn, DevSeed *seeds_out,
                      int32_t *srt_out, int32_t *reg_seed, int32_t *reg_chain,
-                     int32_t *n_chain_out, int32_t *n_reg_out, int32_t *n_chain0_out) {
+                     int32_t *n_chain_out, int32_t *n_reg_out, int32_t *n_chain0_out, const int32_t *perm) {
     if (n_reads <= 0) return BM2_OK;
     hipLaunchKernelGGL(k_chain, dim3((n_reads + 127) / 128), dim3(128), 0, c->stream, c->ix, o, n_reads, len, smems, smem_cnt,
                        smem_off, sa_off, sa_coord, wchain, wseed, nodes, order, chn, seeds_out, srt_out, reg_seed, reg_chain,
-                       n_chain_out, n_reg_out, n_chain0_out);
+                       n_chain_out, n_reg_out, n_chain0_out, perm);
     return bm2_check(hipGetLastError(), "k_chain launch");
 }

@@ -14,9 +14,9 @@ struct WChain {                      // mem_chain_t while it is in the B-tree; f
     int32_t n, rid, is_alt, head, tail, w, kept, first, pad;
 };
 
-struct BtNode {                      // kbnode_t with t = 5: up to 9 keys (chain indices) and 10 children (node indices)
-    int32_t is_internal, n;
-    int32_t key[9];
+struct BtNode {                      // kbnode_t with t = 5: up to 9 keys (chain indices) and 10 children (node indices).
+    int64_t kpos[9];                 // the key's sort field (chain.pos) is kept next to the index so that a search touches the
+    int32_t key[9];                  // node only (one memory round trip per level instead of one per probe)
     int32_t ptr[10];
-    int32_t pad;
+    int32_t is_internal, n, pad;
 };

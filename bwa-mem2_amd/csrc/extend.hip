@@ -330,8 +330,11 @@ k_seedcov(int64_t n_slots, const int64_t *__restrict__ slot_base, const int32_t 
 
 // cal_max_gap, bwamem.cpp:66-76
 static __device__ __forceinline__ int cal_max_gap2(const ChainParams &o, int qlen) {
-    const int l_del = (int)((double)(qlen * o.a - o.o_del) / o.e_del + 1.);
-    const int l_ins = (int)((double)(qlen * o.a - o.o_ins) / o.e_ins + 1.);
+    // (int)((double)(qlen*a - o)/e + 1.) == (qlen*a - o + e) / e in C integer division (both truncate toward zero, e > 0);
+    // the double division of the reference would cost ~100 instructions per call on the GPU
+    const int nd = qlen * o.a - o.o_del + o.e_del, ni = qlen * o.a - o.o_ins + o.e_ins;
+    const int l_del = o.e_del == 1 ? nd : nd / o.e_del;
+    const int l_ins = o.e_ins == 1 ? ni : ni / o.e_ins;
     int l = l_del > l_ins ? l_del : l_ins;
     l = l > 1 ? l : 1;
     return l < o.w << 1 ? l : o.w << 1;
@@ -378,9 +381,11 @@ static __device__ bool seed_redundant(const ChainParams &o, int l_query, const D
 __global__ void __launch_bounds__(128)
 k_postfilter(ChainParams o, int n_reads, const int32_t *__restrict__ len, const int64_t *__restrict__ read_base,
              const int32_t *__restrict__ n_chain, const int32_t *__restrict__ n_reg, const DevChain *__restrict__ chn,
-             const DevSeed *__restrict__ seeds, int32_t *srt_all, DevReg *regs, int32_t *n_out, const int32_t *__restrict__ cursor) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_reads) return;
+             const DevSeed *__restrict__ seeds, int32_t *srt_all, DevReg *regs, int32_t *n_out, const int32_t *__restrict__ cursor,
+             const int32_t *__restrict__ perm) {
+    const int tix = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tix >= n_reads) return;
+    const int r = perm[tix];
     const int nc = n_chain[r], nr = n_reg[r];
     if (nc == 0) { n_out[r] = 0; return; }
     const int first_idx = cursor[r];
@@ -671,10 +676,10 @@ int bm2_launch_slot_base(bm2_ctx *c, int n_reads, const int64_t *read_base, cons
 
 int bm2_launch_postfilter(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_t *len, const int64_t *read_base,
                           const int32_t *n_chain, const int32_t *n_reg, const DevChain *chn, const DevSeed *seeds,
-                          int32_t *srt_all, DevReg *regs, int32_t *n_out, const int32_t *cursor) {
+                          int32_t *srt_all, DevReg *regs, int32_t *n_out, const int32_t *cursor, const int32_t *perm) {
     if (n_reads <= 0) return BM2_OK;
     hipLaunchKernelGGL(k_postfilter, dim3((n_reads + 127) / 128), dim3(128), 0, c->stream, o, n_reads, len, read_base, n_chain,
-                       n_reg, chn, seeds, srt_all, regs, n_out, cursor);
+                       n_reg, chn, seeds, srt_all, regs, n_out, cursor, perm);
     return bm2_check(hipGetLastError(), "k_postfilter launch");
 }
 

@@ -6,6 +6,7 @@
 #include <string.h>
 #include <stdio.h>
 #include <math.h>
+#include <stdlib.h>
 #include <vector>
 #include "pipeline.h"
 #include "chain_dev.h"
@@ -15,7 +16,7 @@ int bm2_launch_chain(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_
                      const int32_t *smem_cnt, const int64_t *smem_off, const int64_t *sa_off, const int64_t *sa_coord,
                      WChain *wchain, WSeed *wseed, BtNode *nodes, int32_t *order, DevChain *chn, DevSeed *seeds_out,
                      int32_t *srt_out, int32_t *reg_seed, int32_t *reg_chain,
-                     int32_t *n_chain_out, int32_t *n_reg_out, int32_t *n_chain0_out);
+                     int32_t *n_chain_out, int32_t *n_reg_out, int32_t *n_chain0_out, const int32_t *perm);
 int bm2_launch_extend(bm2_ctx *c, const bm2_opt &opt, const ChainParams &cp, int n_reads, int64_t n_slots, const uint8_t *enc,
                       const int64_t *off, const int32_t *len, const int64_t *read_base, const int32_t *n_chain, const int32_t *n_reg,
                       const int64_t *slot_base, const int32_t *reg_seed, const int32_t *reg_chain, const DevChain *chn,
@@ -23,7 +24,7 @@ int bm2_launch_extend(bm2_ctx *c, const bm2_opt &opt, const ChainParams &cp, int
 int bm2_launch_slot_base(bm2_ctx *c, int n_reads, const int64_t *read_base, const int32_t *n_reg, int64_t *slot_base);
 int bm2_launch_postfilter(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_t *len, const int64_t *read_base,
                           const int32_t *n_chain, const int32_t *n_reg, const DevChain *chn, const DevSeed *seeds,
-                          int32_t *srt_all, DevReg *regs, int32_t *n_out, const int32_t *cursor);
+                          int32_t *srt_all, DevReg *regs, int32_t *n_out, const int32_t *cursor, const int32_t *perm);
 int bm2_launch_reg_gather(bm2_ctx *c, int n_reads, const int64_t *read_base, const int32_t *n_reg, const DevReg *regs,
                           const int64_t *out_off, bm2_reg_t *out, int64_t out_cap);
 
@@ -37,7 +38,7 @@ struct Batch {
     DevBuf stage, prevbuf, smem, occ_cnt, smem_cnt, smem_off, counters, sa_off, sa_coord, scan_tmp, read_base;
     // chaining / extension
     DevBuf wchain, wseed, nodes, order, chn, seeds, srt, reg_seed, reg_chain, regs, slot_base, n_chain, n_reg, n_chain0, n_out;
-    DevBuf out_off, out_regs, smem_sorted, smem_sorted_off, ext_tmp, cursor;
+    DevBuf out_off, out_regs, smem_sorted, smem_sorted_off, ext_tmp, cursor, n_sa_read, perm, perm_hist;
     int64_t n_smem = 0, n_sa = 0, n_out_regs = 0;
     bm2_stats stats{};
 };
@@ -48,7 +49,7 @@ void bm2_batch_destroy(bm2_ctx *c) {
     DevBuf *all[] = { &b->enc, &b->off, &b->len, &b->stage, &b->prevbuf, &b->smem, &b->occ_cnt, &b->smem_cnt, &b->smem_off,
                       &b->counters, &b->sa_off, &b->sa_coord, &b->scan_tmp, &b->read_base, &b->wchain, &b->wseed, &b->nodes,
                       &b->order, &b->chn, &b->seeds, &b->srt, &b->reg_seed, &b->reg_chain, &b->regs, &b->slot_base, &b->n_chain,
-                      &b->n_reg, &b->n_chain0, &b->n_out, &b->out_off, &b->out_regs, &b->smem_sorted, &b->smem_sorted_off, &b->ext_tmp, &b->cursor };
+                      &b->n_reg, &b->n_chain0, &b->n_out, &b->out_off, &b->out_regs, &b->smem_sorted, &b->smem_sorted_off, &b->ext_tmp, &b->cursor, &b->n_sa_read, &b->perm, &b->perm_hist };
     for (DevBuf *d : all) bm2_release(*d);
     delete b;
     c->batch = nullptr;
@@ -68,10 +69,12 @@ static void tick(bm2_ctx *c, const char *name) {       // event after the stage 
 }
 
 __global__ void k_read_base(int n_reads, const int32_t *__restrict__ smem_cnt, const int64_t *__restrict__ smem_off,
-                            const int64_t *__restrict__ sa_off, int64_t *read_base) {
+                            const int64_t *__restrict__ sa_off, int64_t *read_base, int32_t *n_sa_read) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_reads) return;
-    read_base[r] = smem_cnt[r] > 0 ? sa_off[smem_off[r]] : 0;
+    const int c = smem_cnt[r];
+    read_base[r] = c > 0 ? sa_off[smem_off[r]] : 0;
+    n_sa_read[r] = c > 0 ? (int32_t)(sa_off[smem_off[r] + c] - sa_off[smem_off[r]]) : 0;
 }
 
 extern "C" int bm2_batch_upload(bm2_ctx *c, const bm2_reads *reads) {
@@ -228,14 +231,19 @@ extern "C" int bm2_batch_run(bm2_ctx *c, const bm2_opt *opt) {
     if ((rc = bm2_reserve(b->n_reg, (size_t)(n + 1) * 4))) return rc;
     if ((rc = bm2_reserve(b->n_chain0, (size_t)(n + 1) * 4))) return rc;
     if ((rc = bm2_reserve(b->n_out, (size_t)(n + 1) * 4))) return rc;
+    if ((rc = bm2_reserve(b->n_sa_read, (size_t)(n + 1) * 4))) return rc;
+    if ((rc = bm2_reserve(b->perm, (size_t)(n + 1) * 4))) return rc;
+    if ((rc = bm2_reserve(b->perm_hist, 256))) return rc;
     if ((rc = bm2_check(hipMemsetAsync(b->reg_seed.p, 0xff, ns * 4, s), "memset reg_seed"))) return rc;
     hipLaunchKernelGGL(k_read_base, dim3((n + 255) / 256), dim3(256), 0, s, n, (const int32_t *)b->smem_cnt.p,
-                       (const int64_t *)b->smem_off.p, (const int64_t *)b->sa_off.p, (int64_t *)b->read_base.p);
+                       (const int64_t *)b->smem_off.p, (const int64_t *)b->sa_off.p, (int64_t *)b->read_base.p, (int32_t *)b->n_sa_read.p);
+    static const int perm_mode = getenv("BM2_PERM_MODE") ? atoi(getenv("BM2_PERM_MODE")) : 0;
+    if ((rc = bm2_perm_by_work(c, n, (const int32_t *)b->n_sa_read.p, (int32_t *)b->perm.p, (uint32_t *)b->perm_hist.p, perm_mode))) return rc;
     if ((rc = bm2_launch_chain(c, cp, n, (const int32_t *)b->len.p, (const bm2_smem_t *)b->smem.p, (const int32_t *)b->smem_cnt.p,
                                (const int64_t *)b->smem_off.p, (const int64_t *)b->sa_off.p, (const int64_t *)b->sa_coord.p,
                                (WChain *)b->wchain.p, (WSeed *)b->wseed.p, (BtNode *)b->nodes.p, (int32_t *)b->order.p,
                                (DevChain *)b->chn.p, (DevSeed *)b->seeds.p, (int32_t *)b->srt.p, (int32_t *)b->reg_seed.p,
-                               (int32_t *)b->reg_chain.p, (int32_t *)b->n_chain.p, (int32_t *)b->n_reg.p, (int32_t *)b->n_chain0.p))) return rc;
+                               (int32_t *)b->reg_chain.p, (int32_t *)b->n_chain.p, (int32_t *)b->n_reg.p, (int32_t *)b->n_chain0.p, (const int32_t *)b->perm.p))) return rc;
     tick(c, "chain");
     if ((rc = bm2_launch_slot_base(c, n, (const int64_t *)b->read_base.p, (const int32_t *)b->n_reg.p, (int64_t *)b->slot_base.p))) return rc;
     if ((rc = bm2_reserve(b->cursor, (size_t)(n + 1) * 4))) return rc;
@@ -245,9 +253,10 @@ extern "C" int bm2_batch_run(bm2_ctx *c, const bm2_opt *opt) {
                                 (const DevChain *)b->chn.p, (const DevSeed *)b->seeds.p, (int32_t *)b->srt.p, (DevReg *)b->regs.p,
                                 (unsigned long long *)b->counters.p + 5, b->ext_tmp, (int32_t *)b->cursor.p))) return rc;
     tick(c, "extend");
+    if ((rc = bm2_perm_by_work(c, n, (const int32_t *)b->n_reg.p, (int32_t *)b->perm.p, (uint32_t *)b->perm_hist.p, perm_mode))) return rc;
     if ((rc = bm2_launch_postfilter(c, cp, n, (const int32_t *)b->len.p, (const int64_t *)b->read_base.p, (const int32_t *)b->n_chain.p,
                                     (const int32_t *)b->n_reg.p, (const DevChain *)b->chn.p, (const DevSeed *)b->seeds.p,
-                                    (int32_t *)b->srt.p, (DevReg *)b->regs.p, (int32_t *)b->n_out.p, (const int32_t *)b->cursor.p))) return rc;
+                                    (int32_t *)b->srt.p, (DevReg *)b->regs.p, (int32_t *)b->n_out.p, (const int32_t *)b->cursor.p, (const int32_t *)b->perm.p))) return rc;
     if ((rc = bm2_scan_i32(c, (const int32_t *)b->n_out.p, n, (int64_t *)b->out_off.p, b->scan_tmp))) return rc;
     int64_t n_out = 0;
     unsigned long long h_cnt[8];
@@ -390,7 +399,7 @@ extern "C" int bm2_batch_fetch(bm2_ctx *c, const char *what, void *out, int64_t 
         { "sa_coord", &b->sa_coord, ns * 8 }, { "read_base", &b->read_base, (size_t)n * 8 },
         { "n_chain", &b->n_chain, (size_t)n * 4 }, { "n_chain0", &b->n_chain0, (size_t)n * 4 }, { "n_reg", &b->n_reg, (size_t)n * 4 },
         { "n_out", &b->n_out, (size_t)n * 4 }, { "chn", &b->chn, ns * sizeof(DevChain) }, { "seeds", &b->seeds, ns * sizeof(DevSeed) },
-        { "regs_raw", &b->regs, ns * sizeof(DevReg) }, { "reg_seed", &b->reg_seed, ns * 4 },
+        { "regs_raw", &b->regs, ns * sizeof(DevReg) }, { "reg_seed", &b->reg_seed, ns * 4 }, { "wchain", &b->wchain, ns * sizeof(WChain) },
     };
     for (auto &t : tab) if (!strcmp(t.name, what)) {
         *n_bytes = (int64_t)t.bytes;

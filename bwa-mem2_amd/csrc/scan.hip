@@ -68,3 +68,54 @@ int bm2_scan_i32(bm2_ctx *c, const int32_t *in, int64_t n, int64_t *out, DevBuf 
     hipLaunchKernelGGL(k_scan_final, dim3((unsigned)nb), dim3(256), 0, c->stream, in, n, bsum, total, out);
     return bm2_check(hipGetLastError(), "scan launch");
 }
+
+// ---- permutation of reads by a work key (counting sort into 32 log2 bins): the one-read-per-lane kernels (chaining,
+// post-filter) run as long as the heaviest lane of a wavefront, so lanes are grouped by how much sequential work their
+// read carries.
+#define PERM_BINS 32
+static __device__ __forceinline__ int perm_bin(int v, int heavy_first) {
+    int lg = v <= 0 ? 0 : 1 + (31 - __clz(v));          // 0, 1, 2, 2, 3, 3, 3, 3, 4 ...
+    if (lg > PERM_BINS - 1) lg = PERM_BINS - 1;
+    return heavy_first ? PERM_BINS - 1 - lg : lg;
+}
+__global__ void __launch_bounds__(256) k_perm_hist(int n, const int32_t *__restrict__ key, uint32_t *hist, int hf) {
+    __shared__ uint32_t sh[PERM_BINS];
+    if (threadIdx.x < PERM_BINS) sh[threadIdx.x] = 0;
+    __syncthreads();
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) atomicAdd(&sh[perm_bin(key[i], hf)], 1u);
+    __syncthreads();
+    if (threadIdx.x < PERM_BINS && sh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], sh[threadIdx.x]);
+}
+__global__ void k_perm_prefix(uint32_t *hist) {
+    if (threadIdx.x == 0) { uint32_t acc = 0; for (int b = 0; b < PERM_BINS; b++) { uint32_t c = hist[b]; hist[b] = acc; acc += c; } }
+}
+__global__ void __launch_bounds__(256) k_perm_scatter(int n, const int32_t *__restrict__ key, uint32_t *cursor, int32_t *perm, int hf) {
+    __shared__ uint32_t cnt[PERM_BINS], basep[PERM_BINS];
+    if (threadIdx.x < PERM_BINS) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int b = 0; uint32_t pos = 0;
+    if (i < n) { b = perm_bin(key[i], hf); pos = atomicAdd(&cnt[b], 1u); }
+    __syncthreads();
+    if (threadIdx.x < PERM_BINS && cnt[threadIdx.x]) basep[threadIdx.x] = atomicAdd(&cursor[threadIdx.x], cnt[threadIdx.x]);
+    __syncthreads();
+    if (i < n) perm[basep[b] + pos] = i;
+}
+__global__ void __launch_bounds__(256) k_perm_identity(int n, int32_t *perm) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) perm[i] = i;
+}
+
+int bm2_perm_by_work(bm2_ctx *c, int n, const int32_t *key, int32_t *perm, uint32_t *hist32 /* device, PERM_BINS words */, int mode) {
+    if (n <= 0) return BM2_OK;
+    hipStream_t s = c->stream;
+    if (mode == 0) { hipLaunchKernelGGL(k_perm_identity, dim3((n + 255) / 256), dim3(256), 0, s, n, perm); return bm2_check(hipGetLastError(), "perm"); }
+    int rc = bm2_check(hipMemsetAsync(hist32, 0, PERM_BINS * 4, s), "memset perm hist");
+    if (rc) return rc;
+    const int hf = mode == 1;
+    hipLaunchKernelGGL(k_perm_hist, dim3((n + 255) / 256), dim3(256), 0, s, n, key, hist32, hf);
+    hipLaunchKernelGGL(k_perm_prefix, dim3(1), dim3(64), 0, s, hist32);
+    hipLaunchKernelGGL(k_perm_scatter, dim3((n + 255) / 256), dim3(256), 0, s, n, key, hist32, perm, hf);
+    return bm2_check(hipGetLastError(), "perm launch");
+}
