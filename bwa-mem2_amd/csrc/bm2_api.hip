@@ -67,6 +67,26 @@ static int upload(void **dst, const T *src, size_t n, hipStream_t s) {
 
 void bm2_batch_destroy(bm2_ctx *c);     // pipeline.hip
 
+static int make_streams(bm2_ctx *c) {
+    if (bm2_check(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "hipStreamCreate")) return BM2_ENODEV;
+    for (int i = 0; i <= BM2_MAX_TIMERS; i++) (void)hipEventCreate(&c->ev[i]);
+    (void)hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+    for (int i = 0; i < 12; i++) {
+        (void)hipStreamCreateWithFlags(&c->side_stream[i], hipStreamNonBlocking);
+        (void)hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming);
+    }
+    return BM2_OK;
+}
+static void free_streams(bm2_ctx *c) {
+    for (int i = 0; i <= BM2_MAX_TIMERS; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    for (int i = 0; i < 12; i++) {
+        if (c->side_stream[i]) (void)hipStreamDestroy(c->side_stream[i]);
+        if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
+    }
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+}
+
 extern "C" bm2_ctx *bm2_create(int device, const bm2_index_desc *idx) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
@@ -80,13 +100,7 @@ extern "C" bm2_ctx *bm2_create(int device, const bm2_index_desc *idx) {
     c->device = device;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount;
-    if (bm2_check(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "hipStreamCreate")) { delete c; return nullptr; }
-    for (int i = 0; i <= BM2_MAX_TIMERS; i++) (void)hipEventCreate(&c->ev[i]);
-    (void)hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
-    for (int i = 0; i < 12; i++) {
-        (void)hipStreamCreateWithFlags(&c->side_stream[i], hipStreamNonBlocking);
-        (void)hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming);
-    }
+    if (make_streams(c)) { delete c; return nullptr; }
     if (idx) {
         const int64_t nocc = (idx->ref_len >> 6) + 1, nsa = (idx->ref_len >> 3) + 1;
         int rc = 0;
@@ -108,6 +122,15 @@ extern "C" bm2_ctx *bm2_create(int device, const bm2_index_desc *idx) {
         for (int i = 0; i < 5; i++) ix.count[i] = idx->count[i] + 1;      // FMI_search.cpp:433-436
         ix.n_seqs = idx->n_seqs;
         c->has_index = true;
+        const char *ns = getenv("BM2_N_SUB");
+        const int n_sub = ns ? atoi(ns) : BM2_N_SUB;
+        for (int i = 1; i < n_sub; i++) {               // extra contexts for sub-batch pipelining: same index replica
+            bm2_ctx *k = new (std::nothrow) bm2_ctx();
+            if (!k) break;
+            k->device = c->device; k->n_cu = c->n_cu; k->ix = c->ix; k->has_index = true; k->is_child = true;
+            if (make_streams(k)) { delete k; break; }
+            c->subs.push_back(k);
+        }
     }
     return c;
 }
@@ -116,17 +139,18 @@ extern "C" void bm2_destroy(bm2_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (bm2_ctx *k : c->subs) {
+        if (k->stream) (void)hipStreamSynchronize(k->stream);
+        bm2_batch_destroy(k);
+        free_streams(k);
+        delete k;
+    }
+    c->subs.clear();
     bm2_batch_destroy(c);
     void *ps[] = { c->d_cp_occ, c->d_sa_ms, c->d_sa_ls, c->d_ref, c->d_ann_off, c->d_ann_len, c->d_ann_alt };
     for (void *p : ps) if (p) (void)hipFree(p);
     bm2_release(c->b_pairs); bm2_release(c->b_ref); bm2_release(c->b_qer); bm2_release(c->b_misc);
-    for (int i = 0; i <= BM2_MAX_TIMERS; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
-    for (int i = 0; i < 12; i++) {
-        if (c->side_stream[i]) (void)hipStreamDestroy(c->side_stream[i]);
-        if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
-    }
-    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
+    free_streams(c);
     delete c;
 }
 

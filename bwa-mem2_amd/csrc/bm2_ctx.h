@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stddef.h>
+#include <vector>
 #include "bm2_dev.h"
 
 // growable device buffer (never shrinks; a chunk-sized workspace is reused across batches)
@@ -33,7 +34,13 @@ struct bm2_ctx {
     // fork/join of the per-class extension launches (extend.hip)
     hipStream_t side_stream[12] = {};
     hipEvent_t ev_fork = nullptr, ev_join[12] = {};
+    // sub-batch pipelining (pipeline.hip): extra contexts sharing this one's index replica
+    std::vector<bm2_ctx *> subs;
+    bool is_child = false;
+    int n_parts = 1;
+    std::vector<int> part_first;
 };
+#define BM2_N_SUB 1     // sub-batch pipelining is implemented and parity-tested, but did not pay on one GPU (profiles/)
 
 int  bm2_check(hipError_t e, const char *what);            // -> BM2_OK or BM2_ENODEV (+ message)
 void bm2_set_error(const char *fmt, ...);

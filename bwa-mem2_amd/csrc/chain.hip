@@ -303,21 +303,23 @@ k_chain(DevIndex ix, ChainParams o, int n_reads, const int32_t *__restrict__ len
         else e = e > se ? e : se;
     }
     l_rep += e - b;
-    for (int i = 0; i < n_sm; i++) {
-        const bm2_smem_t p = smems[so + i];
-        const int slen = (int)(p.n + 1 - p.m);
-        const int64_t o0 = sa_off[so + i] - base;
-        const int cnt = (int)(sa_off[so + i + 1] - sa_off[so + i]);
-        for (int c = 0; c < cnt; c++) {
-            WSeed s; s.rbeg = sa_coord[base + o0 + c]; s.qbeg = (int32_t)p.m; s.len = slen; s.next = -1;
+    // one flat loop over the read's seeds (SMEM-major, occurrence-minor -- the order of bwamem.cpp:879-905): the lanes of
+    // a wavefront then run max(seeds per read) iterations instead of the sum over SMEM ranks of the per-rank maxima
+    {
+        int si = -1, left = 0, qbeg = 0, slen = 0;
+        for (int t = 0; t < n_sa; t++) {
+            while (left == 0) {                          // next SMEM with at least one sampled occurrence
+                ++si;
+                left = (int)(sa_off[so + si + 1] - sa_off[so + si]);
+                qbeg = (int)smems[so + si].m; slen = (int)(smems[so + si].n + 1 - smems[so + si].m);
+            }
+            --left;
+            WSeed s; s.rbeg = sa_coord[base + t]; s.qbeg = qbeg; s.len = slen; s.next = -1;
             const int rid = intv2rid_cached(ix, s.rbeg, s.rbeg + s.len, ridc);
             if (rid < 0) continue;                       // bwamem.cpp:915-919
             int to_add = 0;
             if (bt.n_keys) {
                 const int lower = bt_lower(bt, s.rbeg);
-#ifdef BM2_DEBUG_CHAIN
-                if (r == 0) printf("seed rbeg=%ld qbeg=%d len=%d rid=%d lower=%d nkeys=%d root=%d rootn=%d w=%d gap=%d\n", (long)s.rbeg, s.qbeg, s.len, rid, lower, bt.n_keys, bt.root, bt.nodes[bt.root].n, o.w, o.max_chain_gap);
-#endif
                 if (lower < 0) to_add = 1;
                 else {
                     const int m = test_and_merge(o, ix.l_pac, ch[lower], s, rid, sd, n_sd);

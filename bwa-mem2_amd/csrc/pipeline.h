@@ -23,6 +23,8 @@ int bm2_scan_i32(bm2_ctx *c, const int32_t *in, int64_t n, int64_t *out_excl /* 
 
 int bm2_perm_by_work(bm2_ctx *c, int n, const int32_t *key, int32_t *perm, uint32_t *hist32, int mode);
 
+int bm2_partition_by_work(bm2_ctx *c, int n, const int32_t *key, int thr, int32_t *perm, DevBuf &tmp, DevBuf &scan_tmp);
+
 // smem.hip
 int bm2_launch_smem(bm2_ctx *c, const SeedParams &sp, int n_reads, const uint8_t *enc, const int64_t *off, const int32_t *len,
                     StSmem *stage, StSmem *prevbuf, int stage_cap, int prev_cap, int grid, bm2_smem_t *out, int64_t out_cap,

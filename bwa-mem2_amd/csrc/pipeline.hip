@@ -38,7 +38,7 @@ struct Batch {
     DevBuf stage, prevbuf, smem, occ_cnt, smem_cnt, smem_off, counters, sa_off, sa_coord, scan_tmp, read_base;
     // chaining / extension
     DevBuf wchain, wseed, nodes, order, chn, seeds, srt, reg_seed, reg_chain, regs, slot_base, n_chain, n_reg, n_chain0, n_out;
-    DevBuf out_off, out_regs, smem_sorted, smem_sorted_off, ext_tmp, cursor, n_sa_read, perm, perm_hist;
+    DevBuf out_off, out_regs, smem_sorted, smem_sorted_off, ext_tmp, cursor, n_sa_read, perm, perm_hist, part_tmp;
     int64_t n_smem = 0, n_sa = 0, n_out_regs = 0;
     bm2_stats stats{};
 };
@@ -49,7 +49,7 @@ void bm2_batch_destroy(bm2_ctx *c) {
     DevBuf *all[] = { &b->enc, &b->off, &b->len, &b->stage, &b->prevbuf, &b->smem, &b->occ_cnt, &b->smem_cnt, &b->smem_off,
                       &b->counters, &b->sa_off, &b->sa_coord, &b->scan_tmp, &b->read_base, &b->wchain, &b->wseed, &b->nodes,
                       &b->order, &b->chn, &b->seeds, &b->srt, &b->reg_seed, &b->reg_chain, &b->regs, &b->slot_base, &b->n_chain,
-                      &b->n_reg, &b->n_chain0, &b->n_out, &b->out_off, &b->out_regs, &b->smem_sorted, &b->smem_sorted_off, &b->ext_tmp, &b->cursor, &b->n_sa_read, &b->perm, &b->perm_hist };
+                      &b->n_reg, &b->n_chain0, &b->n_out, &b->out_off, &b->out_regs, &b->smem_sorted, &b->smem_sorted_off, &b->ext_tmp, &b->cursor, &b->n_sa_read, &b->perm, &b->perm_hist, &b->part_tmp };
     for (DevBuf *d : all) bm2_release(*d);
     delete b;
     c->batch = nullptr;
@@ -77,7 +77,7 @@ __global__ void k_read_base(int n_reads, const int32_t *__restrict__ smem_cnt, c
     n_sa_read[r] = c > 0 ? (int32_t)(sa_off[smem_off[r] + c] - sa_off[smem_off[r]]) : 0;
 }
 
-extern "C" int bm2_batch_upload(bm2_ctx *c, const bm2_reads *reads) {
+static int batch_upload_one(bm2_ctx *c, const bm2_reads *reads) {
     if (!c || !reads || reads->n_reads < 0) { bm2_set_error("bm2_batch_upload: bad argument"); return BM2_EINVAL; }
     if (!c->has_index) { bm2_set_error("context was created without an index"); return BM2_EINVAL; }
     int rc = bm2_check(hipSetDevice(c->device), "hipSetDevice");
@@ -187,7 +187,7 @@ static int run_seeding(bm2_ctx *c, Batch *b, const bm2_opt *opt, bool with_sal) 
     return BM2_OK;
 }
 
-extern "C" int bm2_batch_run(bm2_ctx *c, const bm2_opt *opt) {
+static int batch_run_one(bm2_ctx *c, const bm2_opt *opt) {
     if (!c || !c->batch || !c->batch->uploaded) { bm2_set_error("bm2_batch_run: no batch uploaded"); return BM2_EINVAL; }
     int rc = check_opt(opt);
     if (rc) return rc;
@@ -237,8 +237,11 @@ extern "C" int bm2_batch_run(bm2_ctx *c, const bm2_opt *opt) {
     if ((rc = bm2_check(hipMemsetAsync(b->reg_seed.p, 0xff, ns * 4, s), "memset reg_seed"))) return rc;
     hipLaunchKernelGGL(k_read_base, dim3((n + 255) / 256), dim3(256), 0, s, n, (const int32_t *)b->smem_cnt.p,
                        (const int64_t *)b->smem_off.p, (const int64_t *)b->sa_off.p, (int64_t *)b->read_base.p, (int32_t *)b->n_sa_read.p);
-    static const int perm_mode = getenv("BM2_PERM_MODE") ? atoi(getenv("BM2_PERM_MODE")) : 0;
-    if ((rc = bm2_perm_by_work(c, n, (const int32_t *)b->n_sa_read.p, (int32_t *)b->perm.p, (uint32_t *)b->perm_hist.p, perm_mode))) return rc;
+    static const int perm_mode = getenv("BM2_PERM_MODE") ? atoi(getenv("BM2_PERM_MODE")) : 3;      // chaining: light reads first, stable
+    static const int perm_mode_pf = getenv("BM2_PERM_MODE_PF") ? atoi(getenv("BM2_PERM_MODE_PF")) : 0;   // post-filter: read order
+    static const int thr_sa = getenv("BM2_HEAVY_SA") ? atoi(getenv("BM2_HEAVY_SA")) : 40;
+    if (perm_mode == 3) { if ((rc = bm2_partition_by_work(c, n, (const int32_t *)b->n_sa_read.p, thr_sa, (int32_t *)b->perm.p, b->part_tmp, b->scan_tmp))) return rc; }
+    else if ((rc = bm2_perm_by_work(c, n, (const int32_t *)b->n_sa_read.p, (int32_t *)b->perm.p, (uint32_t *)b->perm_hist.p, perm_mode))) return rc;
     if ((rc = bm2_launch_chain(c, cp, n, (const int32_t *)b->len.p, (const bm2_smem_t *)b->smem.p, (const int32_t *)b->smem_cnt.p,
                                (const int64_t *)b->smem_off.p, (const int64_t *)b->sa_off.p, (const int64_t *)b->sa_coord.p,
                                (WChain *)b->wchain.p, (WSeed *)b->wseed.p, (BtNode *)b->nodes.p, (int32_t *)b->order.p,
@@ -253,7 +256,9 @@ extern "C" int bm2_batch_run(bm2_ctx *c, const bm2_opt *opt) {
                                 (const DevChain *)b->chn.p, (const DevSeed *)b->seeds.p, (int32_t *)b->srt.p, (DevReg *)b->regs.p,
                                 (unsigned long long *)b->counters.p + 5, b->ext_tmp, (int32_t *)b->cursor.p))) return rc;
     tick(c, "extend");
-    if ((rc = bm2_perm_by_work(c, n, (const int32_t *)b->n_reg.p, (int32_t *)b->perm.p, (uint32_t *)b->perm_hist.p, perm_mode))) return rc;
+    static const int thr_reg = getenv("BM2_HEAVY_REG") ? atoi(getenv("BM2_HEAVY_REG")) : 12;
+    if (perm_mode_pf == 3) { if ((rc = bm2_partition_by_work(c, n, (const int32_t *)b->n_reg.p, thr_reg, (int32_t *)b->perm.p, b->part_tmp, b->scan_tmp))) return rc; }
+    else if ((rc = bm2_perm_by_work(c, n, (const int32_t *)b->n_reg.p, (int32_t *)b->perm.p, (uint32_t *)b->perm_hist.p, perm_mode_pf))) return rc;
     if ((rc = bm2_launch_postfilter(c, cp, n, (const int32_t *)b->len.p, (const int64_t *)b->read_base.p, (const int32_t *)b->n_chain.p,
                                     (const int32_t *)b->n_reg.p, (const DevChain *)b->chn.p, (const DevSeed *)b->seeds.p,
                                     (int32_t *)b->srt.p, (DevReg *)b->regs.p, (int32_t *)b->n_out.p, (const int32_t *)b->cursor.p, (const int32_t *)b->perm.p))) return rc;
@@ -275,7 +280,7 @@ extern "C" int bm2_batch_run(bm2_ctx *c, const bm2_opt *opt) {
     return BM2_OK;
 }
 
-extern "C" int bm2_batch_stats(bm2_ctx *c, bm2_stats *st) {
+static int batch_stats_one(bm2_ctx *c, bm2_stats *st) {
     if (!c || !c->batch || !c->batch->ran || !st) return BM2_EINVAL;
     Batch *b = c->batch;
     // n_chain / n_reg_raw are summed on demand (diagnostic only)
@@ -290,7 +295,7 @@ extern "C" int bm2_batch_stats(bm2_ctx *c, bm2_stats *st) {
     return BM2_OK;
 }
 
-extern "C" int bm2_batch_download(bm2_ctx *c, bm2_reg_t *regs, int64_t cap, int64_t *reg_off, int64_t *n_out) {
+static int batch_download_one(bm2_ctx *c, bm2_reg_t *regs, int64_t cap, int64_t *reg_off, int64_t *n_out) {
     if (!c || !c->batch || !c->batch->ran || !reg_off || !n_out) { bm2_set_error("bm2_batch_download: nothing to download"); return BM2_EINVAL; }
     Batch *b = c->batch;
     *n_out = b->n_out_regs;
@@ -302,7 +307,7 @@ extern "C" int bm2_batch_download(bm2_ctx *c, bm2_reg_t *regs, int64_t cap, int6
     return rc;
 }
 
-extern "C" int bm2_batch_kernel_ms(bm2_ctx *c, float *ms, int32_t cap, int32_t *n_out, const char **names) {
+static int batch_kernel_ms_one(bm2_ctx *c, float *ms, int32_t cap, int32_t *n_out, const char **names) {
     if (!c || !ms || !n_out) return BM2_EINVAL;
     if (!c->ev_ready) { *n_out = 0; return BM2_OK; }
     int n = c->n_ev < cap ? c->n_ev : cap;
@@ -313,6 +318,109 @@ extern "C" int bm2_batch_kernel_ms(bm2_ctx *c, float *ms, int32_t cap, int32_t *
         if (names) names[i] = c->ev_name[i];
     }
     *n_out = n;
+    return BM2_OK;
+}
+
+// ---- sub-batch pipelining ------------------------------------------------------------------------------------------------
+// A chunk is cut into up to BM2_N_SUB parts at multiples of 512 reads (the kt_for block size: the one cross-read rule of
+// the path, bwamem.cpp:834, is per 512-read block, so parts are independent).  Every part has its own streams and
+// workspace and is driven by its own host thread, so the latency-bound stages of one part (chaining, the tails of the
+// extension launches, the host round trips for buffer sizes) overlap the bandwidth- and ALU-bound kernels of the others.
+#include <thread>
+#include <string>
+
+static bm2_ctx *part_ctx(bm2_ctx *c, int i) { return i == 0 ? c : c->subs[i - 1]; }
+
+extern "C" int bm2_batch_upload(bm2_ctx *c, const bm2_reads *reads) {
+    if (!c || !reads || reads->n_reads < 0) { bm2_set_error("bm2_batch_upload: bad argument"); return BM2_EINVAL; }
+    const int n = reads->n_reads;
+    int parts = 1 + (int)c->subs.size();
+    const int blocks = (n + BM2_BLOCK_READS - 1) / BM2_BLOCK_READS;
+    if (blocks < 64 * parts) parts = 1;                    // small chunk: one part
+    c->n_parts = parts;
+    c->part_first.assign(parts + 1, 0);
+    for (int i = 0; i <= parts; i++) {
+        int64_t b = (int64_t)blocks * i / parts * BM2_BLOCK_READS;
+        c->part_first[i] = (int)(b < n ? b : n);
+    }
+    c->part_first[parts] = n;
+    for (int i = 0; i < parts; i++) {
+        const int lo = c->part_first[i], hi = c->part_first[i + 1];
+        bm2_reads r;
+        r.n_reads = hi - lo; r.enc = reads->enc; r.off = reads->off + lo; r.len = reads->len + lo;
+        // offsets stay absolute: the part uploads [0, max end) of enc only if it is part 0; other parts rebase
+        std::vector<int64_t> off2;
+        if (i > 0 && r.n_reads > 0) {
+            int64_t mn = r.off[0];
+            for (int k = 0; k < r.n_reads; k++) if (r.off[k] < mn) mn = r.off[k];
+            off2.resize(r.n_reads);
+            for (int k = 0; k < r.n_reads; k++) off2[k] = r.off[k] - mn;
+            r.enc = reads->enc + mn; r.off = off2.data();
+        }
+        int rc = batch_upload_one(part_ctx(c, i), &r);
+        if (rc) return rc;
+    }
+    return BM2_OK;
+}
+
+extern "C" int bm2_batch_run(bm2_ctx *c, const bm2_opt *opt) {
+    if (!c) return BM2_EINVAL;
+    if (c->n_parts <= 1) return batch_run_one(c, opt);
+    std::vector<int> rcs(c->n_parts, 0);
+    std::vector<std::string> msgs(c->n_parts);
+    std::vector<std::thread> th;
+    for (int i = 0; i < c->n_parts; i++)
+        th.emplace_back([&, i]() { rcs[i] = batch_run_one(part_ctx(c, i), opt); if (rcs[i]) msgs[i] = bm2_last_error(); });
+    for (auto &t : th) t.join();
+    for (int i = 0; i < c->n_parts; i++) if (rcs[i]) { bm2_set_error("part %d: %s", i, msgs[i].c_str()); return rcs[i]; }
+    return BM2_OK;
+}
+
+extern "C" int bm2_batch_stats(bm2_ctx *c, bm2_stats *st) {
+    if (!c || !st) return BM2_EINVAL;
+    memset(st, 0, sizeof *st);
+    for (int i = 0; i < (c->n_parts < 1 ? 1 : c->n_parts); i++) {
+        bm2_stats s1;
+        int rc = batch_stats_one(part_ctx(c, i), &s1);
+        if (rc) return rc;
+        int64_t *a = (int64_t *)st; const int64_t *b = (const int64_t *)&s1;
+        for (size_t k = 0; k < sizeof(bm2_stats) / 8; k++) a[k] += b[k];
+    }
+    return BM2_OK;
+}
+
+extern "C" int bm2_batch_download(bm2_ctx *c, bm2_reg_t *regs, int64_t cap, int64_t *reg_off, int64_t *n_out) {
+    if (!c || !reg_off || !n_out) return BM2_EINVAL;
+    if (c->n_parts <= 1) return batch_download_one(c, regs, cap, reg_off, n_out);
+    int64_t tot = 0;
+    for (int i = 0; i < c->n_parts; i++) { Batch *b = part_ctx(c, i)->batch; if (!b || !b->ran) return BM2_EINVAL; tot += b->n_out_regs; }
+    *n_out = tot;
+    int64_t base = 0; int rc = BM2_OK;
+    for (int i = 0; i < c->n_parts; i++) {
+        bm2_ctx *p = part_ctx(c, i);
+        const int lo = c->part_first[i], hi = c->part_first[i + 1];
+        int64_t n1 = 0;
+        rc = batch_download_one(p, tot <= cap ? regs + base : nullptr, tot <= cap ? cap - base : 0, reg_off + lo, &n1);
+        if (rc && !(rc == BM2_ECAP && tot > cap)) return rc;
+        for (int k = lo; k <= hi; k++) reg_off[k] += base;      // (entry `hi` is rewritten by the next part with the same value)
+        base += n1;
+    }
+    if (tot > cap) { bm2_set_error("regs capacity %ld < %ld", (long)cap, (long)tot); return BM2_ECAP; }
+    return BM2_OK;
+}
+
+// per-stage time of the last run: mean over the parts (their stages overlap each other on the device)
+extern "C" int bm2_batch_kernel_ms(bm2_ctx *c, float *ms, int32_t cap, int32_t *n_out, const char **names) {
+    if (!c || !ms || !n_out) return BM2_EINVAL;
+    int rc = batch_kernel_ms_one(c, ms, cap, n_out, names);
+    if (rc || c->n_parts <= 1) return rc;
+    std::vector<float> t((size_t)cap);
+    for (int i = 1; i < c->n_parts; i++) {
+        int32_t n1 = 0;
+        if ((rc = batch_kernel_ms_one(part_ctx(c, i), t.data(), cap, &n1, nullptr))) return rc;
+        for (int k = 0; k < *n_out && k < n1; k++) ms[k] += t[k];
+    }
+    for (int k = 0; k < *n_out; k++) ms[k] /= c->n_parts;
     return BM2_OK;
 }
 
@@ -329,8 +437,9 @@ extern "C" int bm2_seed_chain_extend(bm2_ctx *c, const bm2_reads *reads, const b
 extern "C" int bm2_smem(bm2_ctx *c, const bm2_reads *reads, const bm2_opt *opt, bm2_smem_t *out, int64_t cap, int64_t *n_out) {
     if (!n_out) return BM2_EINVAL;
     int rc = check_opt(opt);
-    if (!rc) rc = bm2_batch_upload(c, reads);
+    if (!rc) rc = batch_upload_one(c, reads);
     if (rc) return rc;
+    c->n_parts = 1;
     Batch *b = c->batch;
     const int n = b->n_reads;
     c->n_ev = 0; c->ev_ready = false;

@@ -119,3 +119,28 @@ int bm2_perm_by_work(bm2_ctx *c, int n, const int32_t *key, int32_t *perm, uint3
     hipLaunchKernelGGL(k_perm_scatter, dim3((n + 255) / 256), dim3(256), 0, s, n, key, hist32, perm, hf);
     return bm2_check(hipGetLastError(), "perm launch");
 }
+
+// ---- stable two-way partition of reads: light reads (key <= thr) first, in their original order (neighbouring reads own
+// neighbouring memory), heavy reads after them, so that a wavefront of light reads is not held up by one heavy lane
+__global__ void __launch_bounds__(256) k_part_flag(int n, const int32_t *__restrict__ key, int thr, int32_t *flag) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flag[i] = key[i] > thr ? 1 : 0;
+}
+__global__ void __launch_bounds__(256) k_part_scatter(int n, const int32_t *__restrict__ flag, const int64_t *__restrict__ hpos, int32_t *perm) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t n_heavy = hpos[n], h = hpos[i];
+    if (flag[i]) perm[(n - n_heavy) + h] = i;
+    else perm[i - h] = i;
+}
+int bm2_partition_by_work(bm2_ctx *c, int n, const int32_t *key, int thr, int32_t *perm, DevBuf &tmp, DevBuf &scan_tmp) {
+    if (n <= 0) return BM2_OK;
+    int rc = bm2_reserve(tmp, (size_t)(n + 1) * 4 + (size_t)(n + 2) * 8 + 64);
+    if (rc) return rc;
+    int32_t *flag = (int32_t *)tmp.p;
+    int64_t *hpos = (int64_t *)((char *)tmp.p + (((size_t)(n + 1) * 4 + 15) & ~(size_t)15));
+    hipLaunchKernelGGL(k_part_flag, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, key, thr, flag);
+    if ((rc = bm2_scan_i32(c, flag, n, hpos, scan_tmp))) return rc;
+    hipLaunchKernelGGL(k_part_scatter, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, flag, hpos, perm);
+    return bm2_check(hipGetLastError(), "partition launch");
+}

@@ -118,3 +118,31 @@ def test_split_api_is_idempotent(gpu_ctx_factory, golden_dir):
     r2, o2 = ctx.batch_download()
     assert r1.tobytes() == r2.tobytes() and o1.tobytes() == o2.tobytes()
     assert [n for n, _ in ctx.batch_kernel_ms()] == ["smem", "sal", "chain", "extend", "postfilter"]
+
+
+def test_sub_batch_pipelining_matches_single_part(tmp_path):
+    # a chunk big enough to be cut into 4 parts (at multiples of 512 reads), each driven by its own host thread
+    fa, (enc, off, ln) = _fresh_case(tmp_path, 13, [200000, 100000], 140000, 100)
+    os.environ["BM2_N_SUB"] = "1"
+    try:
+        c1 = bm2.Context(0, fa)
+    finally:
+        del os.environ["BM2_N_SUB"]
+    try:
+        r1, o1, s1 = c1.seed_chain_extend(enc, off, ln, bm2.default_opt())
+    finally:
+        c1.close()
+    c4 = bm2.Context(0, fa)
+    try:
+        r4, o4, s4 = c4.seed_chain_extend(enc, off, ln, bm2.default_opt())
+        kms = c4.batch_kernel_ms()
+    finally:
+        c4.close()
+    assert o1.tobytes() == o4.tobytes() and r1.tobytes() == r4.tobytes()
+    assert s1 == s4 and len(kms) == 5
+    ix = oracle.Index(fa)
+    try:
+        exp = ix.run(enc, off, ln)
+    finally:
+        ix.close()
+    _same(exp["REGPRG"], regs_to_records(r4, o4), "REGPRG")
