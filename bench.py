@@ -196,6 +196,14 @@ def main():
         cells = st["n_sw_cells"]
         ext_ms = stage_ms.get("extend", 0.0)
         dominant = max(stage_ms, key=stage_ms.get) if stage_ms else None
+        traffic = None                                       # HBM bytes per k_smem launch from the committed PMC pass, same workload only
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_k_smem_pmc.json")))
+            wl = pm["workload"]
+            if wl["genome_mbp"] == a.genome_mbp and wl["reads_per_gpu_per_step"] == n_reads and wl["read_len"] == a.read_len:
+                traffic = pm["fetch_size_kb_per_launch"] * 1024.0
+        except Exception:
+            pass
         out = {
             "metric": "aligned reads/s (150bp PE vs GRCh38) at 1/2/4/8 GPU; SAM bit-exact vs ref",
             "value": value, "unit": "reads/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -213,7 +221,7 @@ def main():
                               "sa_lookups": st["n_sa"] / n_reads, "sw_tasks": st["n_sw_tasks"] / n_reads,
                               "sw_cells": cells / n_reads, "regs": st["n_reg"] / n_reads},
             "roofline": {"kernel": "k_smem", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": fm_bytes, "avg_launch_ms": smem_ms},
             "extend_kernel": {"kernel": "k_extend", "gcups": cells / (ext_ms * 1e-3) / 1e9 if ext_ms > 0 else 0.0,
                               "avg_launch_ms": ext_ms, "cells_per_launch": cells},

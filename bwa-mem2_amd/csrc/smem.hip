@@ -85,8 +85,7 @@ static __device__ int smem_one_pos(const DevIndex &ix, const uint8_t *q, int len
         if (a >= 4) break;
         Bi cur = { sm.k, sm.l, sm.s };
         Bi nb = forward_ext(ix, cur, a); n_ext++;
-        prev.set(n_prev, sm);
-        n_prev += (nb.s != sm.s);
+        if (nb.s != sm.s) { prev.set(n_prev, sm); n_prev++; }    // (the reference stores unconditionally and bumps the count, :556-559)
         if (nb.s < min_intv) { next_x = j; break; }
         sm.k = nb.k; sm.l = nb.l; sm.s = nb.s; sm.n = j;
     }
