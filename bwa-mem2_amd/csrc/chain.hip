@@ -268,7 +268,7 @@ __global__ void __launch_bounds__(128)
 k_chain(DevIndex ix, ChainParams o, int n_reads, const int32_t *__restrict__ len, const bm2_smem_t *__restrict__ smems,
         const int32_t *__restrict__ smem_cnt, const int64_t *__restrict__ smem_off, const int64_t *__restrict__ sa_off,
         const int64_t *__restrict__ sa_coord, WChain *wchain, WSeed *wseed, BtNode *nodes, int32_t *order,
-        DevChain *chn, DevSeed *seeds_out, int32_t *srt_out, int32_t *reg_seed, int32_t *reg_chain,
+        DevChain *chn, DevSeed *seeds_out, int32_t *seed_owner,
         int32_t *n_chain_out, int32_t *n_reg_out, int32_t *n_chain0_out, const int32_t *__restrict__ perm) {
     const int tix = blockIdx.x * blockDim.x + threadIdx.x;
     if (tix >= n_reads) return;
@@ -398,18 +398,45 @@ k_chain(DevIndex ix, ChainParams o, int n_reads, const int32_t *__restrict__ len
     // ---- emit kept chains with contiguous seeds
     DevChain *oc = chn + base;
     DevSeed *os = seeds_out + base;
-    int n_seed = 0, n_reg = 0;
+    int n_seed = 0;
     for (int i = 0; i < n; i++) {
         const WChain &c = ch[ord[i]];
         DevChain d;
         d.pos = c.pos; d.seed_off = base + n_seed; d.n = c.n; d.rid = c.rid; d.w = c.w; d.kept = c.kept; d.first = c.first;
         d.is_alt = c.is_alt; d.read = r; d.frac_rep = frac_rep; d.rmax0 = 0; d.rmax1 = 0;
         const int s0 = n_seed;
-        d.reg0 = n_reg; d.pad = 0;
         for (int si = c.head; si >= 0; si = sd[si].next) {
             DevSeed s; s.rbeg = sd[si].rbeg; s.qbeg = sd[si].qbeg; s.len = sd[si].len; s.score = sd[si].len; s.aln = -1;
             os[n_seed++] = s;
         }
+        d.reg0 = 0; d.pad = 0;
+        for (int t = s0; t < n_seed; t++) seed_owner[base + t] = r;
+        oc[i] = d;
+    }
+    n_chain_out[r] = n;
+    n_reg_out[r] = 0;              // set by k_chain_finish
+}
+
+// After the (optional) short-seed filter: reference window, extension order and reg slots of every kept chain
+// (the task-building part of mem_chain2aln_across_reads_V2, bwamem.cpp:2127-2223).  One read per lane.
+__global__ void __launch_bounds__(128)
+k_chain_finish(DevIndex ix, ChainParams o, int n_reads, const int32_t *__restrict__ len, const int64_t *__restrict__ read_base,
+               const int32_t *__restrict__ n_chain, DevChain *chn, DevSeed *seeds_out, int32_t *srt_out, int32_t *reg_seed,
+               int32_t *reg_chain, int32_t *n_reg_out) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    const int n = n_chain[r];
+    if (n == 0) { n_reg_out[r] = 0; return; }
+    const int64_t base = read_base[r];
+    DevChain *oc = chn + base;
+    int n_reg = 0;
+    for (int i = 0; i < n; i++) {
+        DevChain d = oc[i];
+        DevSeed *os = seeds_out + base;
+        const int s0 = (int)(d.seed_off - base), n_seed = s0 + d.n;
+        d.reg0 = n_reg;
+        if (d.n == 0) { oc[i] = d; continue; }          // bwamem.cpp:2140 (a chain emptied by the seed filter)
+        struct { int n; } c; c.n = d.n;
         // reference window of the chain, bwamem.cpp:2145-2172 (rmax, strand clip, bns_fetch_seq_v2 contig clip)
         const int l_query = len[r];
         int64_t rmax0 = ix.l_pac << 1, rmax1 = 0;
@@ -449,18 +476,26 @@ k_chain(DevIndex ix, ChainParams o, int n_reads, const int32_t *__restrict__ len
         }
         oc[i] = d;
     }
-    n_chain_out[r] = n;
-    n_reg_out[r] = n_seed;
+    n_reg_out[r] = n_reg;
+}
+
+int bm2_launch_chain_finish(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_t *len, const int64_t *read_base,
+                            const int32_t *n_chain, DevChain *chn, DevSeed *seeds_out, int32_t *srt_out, int32_t *reg_seed,
+                            int32_t *reg_chain, int32_t *n_reg_out) {
+    if (n_reads <= 0) return BM2_OK;
+    hipLaunchKernelGGL(k_chain_finish, dim3((n_reads + 127) / 128), dim3(128), 0, c->stream, c->ix, o, n_reads, len, read_base, n_chain,
+                       chn, seeds_out, srt_out, reg_seed, reg_chain, n_reg_out);
+    return bm2_check(hipGetLastError(), "k_chain_finish launch");
 }
 
 int bm2_launch_chain(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_t *len, const bm2_smem_t *smems,
                      const int32_t *smem_cnt, const int64_t *smem_off, const int64_t *sa_off, const int64_t *sa_coord,
                      WChain *wchain, WSeed *wseed, BtNode *nodes, int32_t *order, DevChain *chn, DevSeed *seeds_out,
-                     int32_t *srt_out, int32_t *reg_seed, int32_t *reg_chain,
+                     int32_t *seed_owner,
                      int32_t *n_chain_out, int32_t *n_reg_out, int32_t *n_chain0_out, const int32_t *perm) {
     if (n_reads <= 0) return BM2_OK;
     hipLaunchKernelGGL(k_chain, dim3((n_reads + 127) / 128), dim3(128), 0, c->stream, c->ix, o, n_reads, len, smems, smem_cnt,
-                       smem_off, sa_off, sa_coord, wchain, wseed, nodes, order, chn, seeds_out, srt_out, reg_seed, reg_chain,
+                       smem_off, sa_off, sa_coord, wchain, wseed, nodes, order, chn, seeds_out, seed_owner,
                        n_chain_out, n_reg_out, n_chain0_out, perm);
     return bm2_check(hipGetLastError(), "k_chain launch");
 }

@@ -15,8 +15,14 @@
 int bm2_launch_chain(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_t *len, const bm2_smem_t *smems,
                      const int32_t *smem_cnt, const int64_t *smem_off, const int64_t *sa_off, const int64_t *sa_coord,
                      WChain *wchain, WSeed *wseed, BtNode *nodes, int32_t *order, DevChain *chn, DevSeed *seeds_out,
-                     int32_t *srt_out, int32_t *reg_seed, int32_t *reg_chain,
+                     int32_t *seed_owner,
                      int32_t *n_chain_out, int32_t *n_reg_out, int32_t *n_chain0_out, const int32_t *perm);
+int bm2_launch_chain_finish(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_t *len, const int64_t *read_base,
+                            const int32_t *n_chain, DevChain *chn, DevSeed *seeds_out, int32_t *srt_out, int32_t *reg_seed,
+                            int32_t *reg_chain, int32_t *n_reg_out);
+int bm2_launch_seed_filter(bm2_ctx *c, const ChainParams &o, const int8_t *d_mat25, int n_reads, int64_t n_slots, const uint8_t *enc,
+                           const int64_t *off, const int32_t *len, const int32_t *min_hsp, const int64_t *read_base, const int32_t *n_chain,
+                           const int32_t *seed_owner, DevChain *chn, DevSeed *seeds, uint8_t *seed_keep);
 int bm2_launch_extend(bm2_ctx *c, const bm2_opt &opt, const ChainParams &cp, int n_reads, int64_t n_slots, const uint8_t *enc,
                       const int64_t *off, const int32_t *len, const int64_t *read_base, const int32_t *n_chain, const int32_t *n_reg,
                       const int64_t *slot_base, const int32_t *reg_seed, const int32_t *reg_chain, const DevChain *chn,
@@ -41,6 +47,8 @@ struct Batch {
     DevBuf out_off, out_regs, smem_sorted, smem_sorted_off, ext_tmp, cursor, n_sa_read, perm, perm_hist, part_tmp;
     int64_t n_smem = 0, n_sa = 0, n_out_regs = 0;
     bm2_stats stats{};
+    std::vector<int32_t> h_len;              // host copy of the read lengths (per-read filter thresholds)
+    DevBuf min_hsp, seed_owner, seed_keep, mat25;
 };
 
 void bm2_batch_destroy(bm2_ctx *c) {
@@ -49,7 +57,7 @@ void bm2_batch_destroy(bm2_ctx *c) {
     DevBuf *all[] = { &b->enc, &b->off, &b->len, &b->stage, &b->prevbuf, &b->smem, &b->occ_cnt, &b->smem_cnt, &b->smem_off,
                       &b->counters, &b->sa_off, &b->sa_coord, &b->scan_tmp, &b->read_base, &b->wchain, &b->wseed, &b->nodes,
                       &b->order, &b->chn, &b->seeds, &b->srt, &b->reg_seed, &b->reg_chain, &b->regs, &b->slot_base, &b->n_chain,
-                      &b->n_reg, &b->n_chain0, &b->n_out, &b->out_off, &b->out_regs, &b->smem_sorted, &b->smem_sorted_off, &b->ext_tmp, &b->cursor, &b->n_sa_read, &b->perm, &b->perm_hist, &b->part_tmp };
+                      &b->n_reg, &b->n_chain0, &b->n_out, &b->out_off, &b->out_regs, &b->smem_sorted, &b->smem_sorted_off, &b->ext_tmp, &b->cursor, &b->n_sa_read, &b->perm, &b->perm_hist, &b->part_tmp, &b->min_hsp, &b->seed_owner, &b->seed_keep, &b->mat25 };
     for (DevBuf *d : all) bm2_release(*d);
     delete b;
     c->batch = nullptr;
@@ -93,6 +101,7 @@ static int batch_upload_one(bm2_ctx *c, const bm2_reads *reads) {
         if (reads->len[i] > max_len) max_len = reads->len[i];
     }
     b->n_reads = n; b->n_bases = nb; b->max_len = max_len; b->ran = false;
+    b->h_len.assign(reads->len, reads->len + n);
     if ((rc = bm2_reserve(b->enc, (size_t)nb + 64))) return rc;
     if ((rc = bm2_reserve(b->off, (size_t)(n + 1) * 8))) return rc;
     if ((rc = bm2_reserve(b->len, (size_t)(n + 1) * 4))) return rc;
@@ -128,6 +137,12 @@ static int check_opt(const bm2_opt *opt) {
     if (opt->e_del <= 0 || opt->e_ins <= 0 || opt->a <= 0 || opt->w <= 0 || opt->max_occ <= 0 || opt->min_seed_len <= 0) {
         bm2_set_error("bm2: option out of range (a, w, max_occ, min_seed_len, e_del, e_ins must be > 0)");
         return BM2_EINVAL;
+    }
+    // the kernels score with (match, mismatch, ambiguous) = (mat[0], mat[1], mat[4]), the structure bwa_fill_scmat builds
+    // (bwa.cpp:248-257) and the only one the reference's SIMD kernels implement (bandedSWA.cpp:286-290)
+    for (int i = 0; i < 5; i++) for (int j = 0; j < 5; j++) {
+        const int want = (i == 4 || j == 4) ? opt->mat[4] : (i == j ? opt->mat[0] : opt->mat[1]);
+        if (opt->mat[i * 5 + j] != want) { bm2_set_error("bm2: scoring matrix is not of the bwa_fill_scmat form"); return BM2_EUNSUP; }
     }
     return BM2_OK;
 }
@@ -195,15 +210,6 @@ static int batch_run_one(bm2_ctx *c, const bm2_opt *opt) {
     Batch *b = c->batch;
     const int n = b->n_reads;
     hipStream_t s = c->stream;
-    // mem_flt_chained_seeds (bwamem.cpp:472-504) runs a local SW per short seed when min_l <= 0.05*l_query (reads >~1.1 kb
-    // or -W): that path is not on the device yet -- refuse rather than return chains the reference would have filtered.
-    {
-        const double min_l = opt->min_chain_weight ? 1.1f * opt->min_chain_weight : 5.5f * log((double)(b->max_len > 1 ? b->max_len : 2));
-        if (!(min_l > 0.05f * b->max_len)) {
-            bm2_set_error("reads of %d bp with min_chain_weight=%d need mem_flt_chained_seeds, which is not implemented", b->max_len, opt->min_chain_weight);
-            return BM2_EUNSUP;
-        }
-    }
     memset(&b->stats, 0, sizeof b->stats);
     b->stats.n_reads = n; b->stats.n_bases = b->n_bases;
     c->n_ev = 0; c->ev_ready = false;
@@ -235,6 +241,28 @@ static int batch_run_one(bm2_ctx *c, const bm2_opt *opt) {
     if ((rc = bm2_reserve(b->perm, (size_t)(n + 1) * 4))) return rc;
     if ((rc = bm2_reserve(b->perm_hist, 256))) return rc;
     if ((rc = bm2_check(hipMemsetAsync(b->reg_seed.p, 0xff, ns * 4, s), "memset reg_seed"))) return rc;
+    if ((rc = bm2_reserve(b->seed_owner, ns * 4))) return rc;
+    if ((rc = bm2_check(hipMemsetAsync(b->seed_owner.p, 0xff, ns * 4, s), "memset seed_owner"))) return rc;
+    // mem_flt_chained_seeds thresholds (bwamem.cpp:484-490), evaluated on the host with the same libm the reference uses:
+    // min_l = W ? 1.1f*W : 5.5f*log(l_query); active when !(min_l > 0.05f*l_query); min_HSP_score = (int)(a*min_l + .499)
+    bool any_flt = false;
+    {
+        std::vector<int32_t> mh((size_t)n);
+        for (int i = 0; i < n; i++) {
+            const int lq = b->h_len[i];
+            const double min_l = opt->min_chain_weight ? 1.1f * opt->min_chain_weight : 5.5f * log((double)lq);
+            if (lq > 0 && !(min_l > 0.05f * lq)) { mh[i] = (int)(opt->a * min_l + .499); if (mh[i] < 0) mh[i] = 0; any_flt = true; }
+            else mh[i] = -1;
+        }
+        if (any_flt) {
+            if ((rc = bm2_reserve(b->min_hsp, (size_t)(n + 1) * 4))) return rc;
+            if ((rc = bm2_reserve(b->seed_keep, ns))) return rc;
+            if ((rc = bm2_reserve(b->mat25, 64))) return rc;
+            if ((rc = bm2_check(hipMemcpyAsync(b->min_hsp.p, mh.data(), (size_t)n * 4, hipMemcpyHostToDevice, s), "H2D min_hsp"))) return rc;
+            if ((rc = bm2_check(hipMemcpyAsync(b->mat25.p, opt->mat, 25, hipMemcpyHostToDevice, s), "H2D mat"))) return rc;
+            if ((rc = bm2_check(hipStreamSynchronize(s), "H2D filter params"))) return rc;     // mh is a local
+        }
+    }
     hipLaunchKernelGGL(k_read_base, dim3((n + 255) / 256), dim3(256), 0, s, n, (const int32_t *)b->smem_cnt.p,
                        (const int64_t *)b->smem_off.p, (const int64_t *)b->sa_off.p, (int64_t *)b->read_base.p, (int32_t *)b->n_sa_read.p);
     static const int perm_mode = getenv("BM2_PERM_MODE") ? atoi(getenv("BM2_PERM_MODE")) : 3;      // chaining: light reads first, stable
@@ -245,8 +273,17 @@ static int batch_run_one(bm2_ctx *c, const bm2_opt *opt) {
     if ((rc = bm2_launch_chain(c, cp, n, (const int32_t *)b->len.p, (const bm2_smem_t *)b->smem.p, (const int32_t *)b->smem_cnt.p,
                                (const int64_t *)b->smem_off.p, (const int64_t *)b->sa_off.p, (const int64_t *)b->sa_coord.p,
                                (WChain *)b->wchain.p, (WSeed *)b->wseed.p, (BtNode *)b->nodes.p, (int32_t *)b->order.p,
-                               (DevChain *)b->chn.p, (DevSeed *)b->seeds.p, (int32_t *)b->srt.p, (int32_t *)b->reg_seed.p,
-                               (int32_t *)b->reg_chain.p, (int32_t *)b->n_chain.p, (int32_t *)b->n_reg.p, (int32_t *)b->n_chain0.p, (const int32_t *)b->perm.p))) return rc;
+                               (DevChain *)b->chn.p, (DevSeed *)b->seeds.p, (int32_t *)b->seed_owner.p,
+                               (int32_t *)b->n_chain.p, (int32_t *)b->n_reg.p, (int32_t *)b->n_chain0.p, (const int32_t *)b->perm.p))) return rc;
+    if (any_flt) {
+        if ((rc = bm2_launch_seed_filter(c, cp, (const int8_t *)b->mat25.p, n, n_sa, (const uint8_t *)b->enc.p, (const int64_t *)b->off.p,
+                                         (const int32_t *)b->len.p, (const int32_t *)b->min_hsp.p, (const int64_t *)b->read_base.p,
+                                         (const int32_t *)b->n_chain.p, (const int32_t *)b->seed_owner.p, (DevChain *)b->chn.p,
+                                         (DevSeed *)b->seeds.p, (uint8_t *)b->seed_keep.p))) return rc;
+    }
+    if ((rc = bm2_launch_chain_finish(c, cp, n, (const int32_t *)b->len.p, (const int64_t *)b->read_base.p, (const int32_t *)b->n_chain.p,
+                                      (DevChain *)b->chn.p, (DevSeed *)b->seeds.p, (int32_t *)b->srt.p, (int32_t *)b->reg_seed.p,
+                                      (int32_t *)b->reg_chain.p, (int32_t *)b->n_reg.p))) return rc;
     tick(c, "chain");
     if ((rc = bm2_launch_slot_base(c, n, (const int64_t *)b->read_base.p, (const int32_t *)b->n_reg.p, (int64_t *)b->slot_base.p))) return rc;
     if ((rc = bm2_reserve(b->cursor, (size_t)(n + 1) * 4))) return rc;

@@ -1,0 +1,128 @@
+// seedsw.hip -- mem_flt_chained_seeds / mem_seed_sw (bwamem.cpp:401-427, 472-504): for reads long enough that
+// 5.5*ln(l) <= 0.05*l (or with -W), every seed shorter than 200 bp is re-scored by a local Smith-Waterman of the seed
+// +-50 bp against the reference and dropped when the score is below min_HSP_score.  The reference calls ksw_align2
+// (Farrar's striped SW, ksw.cpp:234-381) once per seed; only its score is used.  Here: one seed per lane, the DP row
+// {H, E} packed 16+16 bits in LDS laid out [column][lane] (query windows are < 200 columns), plain row-by-row
+// recurrence -- the maximum it finds is the one the striped evaluation finds.
+#include "pipeline.h"
+#include "chain_dev.h"
+
+#define SSW_QMAX 200
+
+static __device__ __forceinline__ int64_t depos2(const DevIndex &ix, int64_t pos, int &is_rev) {
+    is_rev = pos >= ix.l_pac;
+    return is_rev ? (ix.l_pac << 1) - 1 - pos : pos;
+}
+static __device__ int pos2rid2(const DevIndex &ix, int64_t pos_f) {
+    int left = 0, mid = 0, right = ix.n_seqs;
+    if (pos_f >= ix.l_pac) return -1;
+    while (left < right) {
+        mid = (left + right) >> 1;
+        if (pos_f >= ix.ann_offset[mid]) {
+            if (mid == ix.n_seqs - 1) break;
+            if (pos_f < ix.ann_offset[mid + 1]) break;
+            left = mid + 1;
+        } else right = mid;
+    }
+    return mid;
+}
+
+__global__ void __launch_bounds__(64)
+k_seed_sw(DevIndex ix, ChainParams o, const int8_t *__restrict__ mat25, int64_t n_slots, const uint8_t *__restrict__ enc,
+          const int64_t *__restrict__ off, const int32_t *__restrict__ len, const int32_t *__restrict__ min_hsp /* per read, <0 = filter inactive */,
+          const int32_t *__restrict__ seed_owner, DevSeed *seeds, uint8_t *seed_keep) {
+    __shared__ uint32_t HE[SSW_QMAX * 64];
+    __shared__ uint8_t QL[SSW_QMAX * 64];
+    const int lane = threadIdx.x;
+    const int64_t g = (int64_t)blockIdx.x * 64 + lane;
+    int r = -1;
+    if (g < n_slots) r = seed_owner[g];
+    bool run = r >= 0 && min_hsp[r] >= 0;
+    int qlen = 0, tlen = 0;
+    const uint8_t *tp = ix.ref_string;
+    DevSeed s;
+    if (run) {
+        s = seeds[g];
+        const int l_query = len[r];
+        const int64_t l_pac = ix.l_pac;
+        run = false;
+        if (s.len < 200) {                               // MEM_SHORT_LEN
+            int qb = s.qbeg - 50, qe = s.qbeg + s.len + 50;                     // MEM_SHORT_EXT
+            int64_t rb = s.rbeg - 50, re = s.rbeg + s.len + 50;
+            const int64_t mid = (s.rbeg + s.rbeg + s.len) >> 1;
+            qb = qb > 0 ? qb : 0; qe = qe < l_query ? qe : l_query;
+            rb = rb > 0 ? rb : 0; re = re < l_pac << 1 ? re : l_pac << 1;
+            if (rb < l_pac && l_pac < re) { if (mid < l_pac) re = l_pac; else rb = l_pac; }
+            if (!(qe - qb >= 200 || re - rb >= 200)) {
+                int is_rev;
+                const int rid = pos2rid2(ix, depos2(ix, mid, is_rev));           // bns_fetch_seq: clip to the contig of mid
+                int64_t far_beg = ix.ann_offset[rid], far_end = far_beg + ix.ann_len[rid];
+                if (is_rev) { const int64_t tmp = far_beg; far_beg = (l_pac << 1) - far_end; far_end = (l_pac << 1) - tmp; }
+                rb = rb > far_beg ? rb : far_beg;
+                re = re < far_end ? re : far_end;
+                qlen = qe - qb; tlen = (int)(re - rb);
+                tp = ix.ref_string + rb;
+                const uint8_t *qp = enc + off[r] + qb;
+                for (int j = 0; j < qlen; j++) { QL[j * 64 + lane] = qp[j]; HE[j * 64 + lane] = 0; }
+                run = true;
+            }
+        }
+    }
+    // local SW, ksw_i16 recurrence (ksw.cpp:275-291): gaps open from H, everything clamped at 0
+    const int oe_del = o.o_del + o.e_del, oe_ins = o.o_ins + o.e_ins;
+    int maxq = run ? qlen : 0, maxt = run ? tlen : 0;
+    for (int d = 32; d > 0; d >>= 1) { maxq = max(maxq, __shfl_xor(maxq, d)); maxt = max(maxt, __shfl_xor(maxt, d)); }
+    int gmax = 0;
+    for (int i = 0; i < maxt; i++) {
+        const bool rowon = run && i < tlen;
+        const int tb = rowon ? (int)tp[i] : 4;
+        int hdiag = 0, f = 0;
+        for (int j = 0; j < maxq; j++) {
+            if (rowon && j < qlen) {
+                const uint32_t p = HE[j * 64 + lane];
+                const int qb = QL[j * 64 + lane];
+                int e = (int)(p >> 16);
+                int h = hdiag + mat25[tb * 5 + qb];
+                hdiag = (int)(p & 0xffffu);
+                h = h > e ? h : e;
+                h = h > f ? h : f;
+                gmax = gmax > h ? gmax : h;
+                e = max(max(e - o.e_del, h - oe_del), 0);
+                f = max(max(f - o.e_ins, h - oe_ins), 0);
+                HE[j * 64 + lane] = (uint32_t)h | ((uint32_t)e << 16);
+            }
+        }
+    }
+    if (g < n_slots && r >= 0 && min_hsp[r] >= 0) {
+        const int sc = run ? gmax : -1;
+        const bool keep = sc < 0 || sc >= min_hsp[r];            // bwamem.cpp:494-499
+        seed_keep[g] = keep ? 1 : 0;
+        seeds[g].score = sc < 0 ? s.len * o.a : sc;
+    }
+}
+
+// drop the filtered seeds inside every chain of the reads the filter applies to (keeps order), bwamem.cpp:491-501
+__global__ void __launch_bounds__(128)
+k_seed_flt_apply(int n_reads, const int64_t *__restrict__ read_base, const int32_t *__restrict__ n_chain, const int32_t *__restrict__ min_hsp,
+                 DevChain *chn, DevSeed *seeds, const uint8_t *__restrict__ seed_keep) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads || min_hsp[r] < 0) return;
+    const int64_t base = read_base[r];
+    for (int i = 0; i < n_chain[r]; i++) {
+        DevChain c = chn[base + i];
+        int k = 0;
+        for (int j = 0; j < c.n; j++)
+            if (seed_keep[c.seed_off + j]) { if (k != j) seeds[c.seed_off + k] = seeds[c.seed_off + j]; k++; }
+        chn[base + i].n = k;
+    }
+}
+
+int bm2_launch_seed_filter(bm2_ctx *c, const ChainParams &o, const int8_t *d_mat25, int n_reads, int64_t n_slots, const uint8_t *enc,
+                           const int64_t *off, const int32_t *len, const int32_t *min_hsp, const int64_t *read_base, const int32_t *n_chain,
+                           const int32_t *seed_owner, DevChain *chn, DevSeed *seeds, uint8_t *seed_keep) {
+    if (n_slots <= 0) return BM2_OK;
+    hipLaunchKernelGGL(k_seed_sw, dim3((unsigned)((n_slots + 63) / 64)), dim3(64), 0, c->stream, c->ix, o, d_mat25, n_slots, enc, off, len, min_hsp,
+                       seed_owner, seeds, seed_keep);
+    hipLaunchKernelGGL(k_seed_flt_apply, dim3((n_reads + 127) / 128), dim3(128), 0, c->stream, n_reads, read_base, n_chain, min_hsp, chn, seeds, seed_keep);
+    return bm2_check(hipGetLastError(), "seed filter launch");
+}

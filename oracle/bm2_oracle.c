@@ -643,6 +643,83 @@ static int chain_flt(const ora_opt *opt, int n_chn, chain_t *a) {
     return k;
 }
 
+/* ------------------------------------------------------------------ short-seed filter (long reads / -W) */
+
+/* score of ksw_align2(..., KSW_XSTART) = ksw_i16 (ksw.cpp:234-338): local Smith-Waterman, affine gaps opened from H
+ * (not from M as in ksw_extend2), everything clamped at 0 by the unsigned saturating subtractions.  Only the score is
+ * used by the caller; Farrar's striped evaluation order gives the same maximum as this plain row-by-row DP. */
+static int local_sw_score(int qlen, const uint8_t *query, int tlen, const uint8_t *target, const int8_t *mat,
+                          int o_del, int e_del, int o_ins, int e_ins) {
+    int *H = (int *)calloc((size_t)qlen + 1, sizeof(int)), *E = (int *)calloc((size_t)qlen + 1, sizeof(int));
+    int gmax = 0;
+    for (int i = 0; i < tlen; i++) {
+        const int8_t *row = &mat[target[i] * 5];
+        int hdiag = 0, f = 0;
+        for (int j = 0; j < qlen; j++) {
+            int h = hdiag + row[query[j]];
+            int e = E[j], t;
+            hdiag = H[j];
+            h = h > e ? h : e;
+            h = h > f ? h : f;
+            if (h > gmax) gmax = h;
+            H[j] = h;
+            e -= e_del; if (e < 0) e = 0;
+            t = h - (o_del + e_del); if (t < 0) t = 0;
+            E[j] = e > t ? e : t;
+            f -= e_ins; if (f < 0) f = 0;
+            t = h - (o_ins + e_ins); if (t < 0) t = 0;
+            f = f > t ? f : t;
+        }
+    }
+    free(H); free(E);
+    return gmax;
+}
+
+/* mem_seed_sw, bwamem.cpp:401-427 */
+static int seed_sw(const ora_index *ix, const ora_opt *opt, int l_query, const uint8_t *query, const seed_t *s) {
+    int qb, qe;
+    int64_t rb, re, mid, l_pac = ix->l_pac;
+    if (s->len >= 200) return -1;                       /* MEM_SHORT_LEN */
+    qb = s->qbeg; qe = s->qbeg + s->len;
+    rb = s->rbeg; re = s->rbeg + s->len;
+    mid = (rb + re) >> 1;
+    qb -= 50; qb = qb > 0 ? qb : 0;                     /* MEM_SHORT_EXT */
+    qe += 50; qe = qe < l_query ? qe : l_query;
+    rb -= 50; rb = rb > 0 ? rb : 0;
+    re += 50; re = re < l_pac << 1 ? re : l_pac << 1;
+    if (rb < l_pac && l_pac < re) { if (mid < l_pac) re = l_pac; else rb = l_pac; }
+    if (qe - qb >= 200 || re - rb >= 200) return -1;
+    {                                                   /* bns_fetch_seq, bntseq.cpp:454-482: clip to the contig of mid */
+        int is_rev;
+        int rid = pos2rid(ix, depos(ix, mid, &is_rev));
+        int64_t far_beg = ix->ann_offset[rid], far_end = far_beg + ix->ann_len[rid];
+        if (is_rev) { int64_t tmp = far_beg; far_beg = (l_pac << 1) - far_end; far_end = (l_pac << 1) - tmp; }
+        rb = rb > far_beg ? rb : far_beg;
+        re = re < far_end ? re : far_end;
+    }
+    return local_sw_score(qe - qb, query + qb, (int)(re - rb), ix->ref_string + rb, opt->mat, opt->o_del, opt->e_del, opt->o_ins, opt->e_ins);
+}
+
+/* mem_flt_chained_seeds for the chains of one read, bwamem.cpp:472-504 */
+static void flt_chained_seeds(const ora_index *ix, const ora_opt *opt, int l_query, const uint8_t *query, int n_chn, chain_t *a) {
+    double min_l = opt->min_chain_weight ? 1.1f * opt->min_chain_weight : 5.5f * log(l_query);   /* MEM_HSP_COEF, MEM_MINSC_COEF */
+    int min_HSP_score = (int)(opt->a * min_l + .499);
+    if (min_l > 0.05f * l_query) return;                /* MEM_SEEDSW_COEF: short reads skip this */
+    for (int i = 0; i < n_chn; ++i) {
+        chain_t *c = &a[i];
+        int j, k;
+        for (j = k = 0; j < c->n; ++j) {
+            seed_t *s = &c->seeds[j];
+            s->score = seed_sw(ix, opt, l_query, query, s);
+            if (s->score < 0 || s->score >= min_HSP_score) {
+                s->score = s->score < 0 ? s->len * opt->a : s->score;
+                c->seeds[k++] = *s;
+            }
+        }
+        c->n = k;
+    }
+}
+
 /* ------------------------------------------------------------------ banded extension */
 
 int ora_pair_class(int len1, int len2, int h0, int a) {        /* bwamem.cpp:1947-1953, 2304-2313 */
@@ -1008,15 +1085,7 @@ int ora_run(const ora_index *ix, const ora_opt *opt, int32_t n_reads, const uint
                     chain_read(ix, opt, l, len[base + l], sv.a + i, n_sm, res->sa_coord + sa_beg, &ch);
                 put_chain_recs(ch.a, (int)ch.n, base + l, &res->chn0, &res->n_chn0, &m_c0, &res->seed0, &res->n_seed0, &m_s0);
                 ch.n = chain_flt(opt, (int)ch.n, ch.a);
-                /* mem_flt_chained_seeds (bwamem.cpp:472-504) is a no-op unless min_l <= 0.05*l_query (reads >~ 1.1 kb or -W):
-                 * not restated yet -- refuse loudly rather than return wrong chains. */
-                {
-                    double min_l = opt->min_chain_weight ? 1.1f * opt->min_chain_weight : 5.5f * log(len[base + l]);
-                    if (ch.n > 0 && !(min_l > 0.05f * len[base + l])) {
-                        fprintf(stderr, "[bm2_oracle] mem_flt_chained_seeds path (long reads) not restated\n");
-                        return -1;
-                    }
-                }
+                flt_chained_seeds(ix, opt, len[base + l], enc + off[base + l], (int)ch.n, ch.a);
                 put_chain_recs(ch.a, (int)ch.n, base + l, &res->chn1, &res->n_chn1, &m_c1, &res->seed1, &res->n_seed1, &m_s1);
                 reg_v av = {0, 0, 0};
                 chain2aln_read(ix, opt, base + l, enc + off[base + l], len[base + l], ch.a, (int)ch.n, &av, res, &pairs);

@@ -134,3 +134,7 @@ def first_diff(a, b):
         if a[i] != b[i]:
             return "first difference at %d:\n  exp %s\n  got %s" % (i, a[i], b[i])
     return "lengths differ: %d vs %d" % (len(a), len(b))
+
+
+ONT2D = dict(a=1, b=1, o_del=1, e_del=1, o_ins=1, e_ins=1, pen_clip5=0, pen_clip3=0, min_seed_len=14, min_chain_weight=20,
+             split_factor=10.0)      # `-x ont2d`, fastmap.cpp:812-826

@@ -3,7 +3,7 @@
 import numpy as np
 import pytest
 
-from helpers import chain_mask, first_diff, load_golden
+from helpers import ONT2D, chain_mask, first_diff, load_golden
 from tools import oracle
 
 STAGES = ["SMEM", "SACOORD", "SACNT", "CHN0", "SEED0", "CHN1", "SEED1", "REGRAW", "REGPRG"]
@@ -47,3 +47,18 @@ def test_ksw_extend_known_answers():
     t = (q + 1) % 4
     sc, qle, tle, gtle, gscore, max_off = oracle.ksw_extend(q, t, o, 100, 5, 3)
     assert sc == 3 and qle == 0 and tle == 0
+
+
+def test_oracle_long_reads_ont2d(golden_dir):
+    # `-x ont2d`: mem_flt_chained_seeds / mem_seed_sw (local SW per short seed), min_chain_weight, kb-long extensions
+    pre, enc, off, ln, d = load_golden(golden_dir, "g40k_ont")
+    ix = oracle.Index(pre)
+    try:
+        r = ix.run(enc, off, ln, oracle.default_opt(**ONT2D))
+    finally:
+        ix.close()
+    for k in STAGES:
+        exp, got = d[k], r[k]
+        if k == "CHN0":
+            exp, got = chain_mask(exp), chain_mask(got)
+        assert len(exp) == len(got) and exp.tobytes() == got.tobytes(), "%s: %s" % (k, first_diff(exp, got))

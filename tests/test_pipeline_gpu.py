@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import bm2
-from helpers import (build_index, first_diff, gpu_stage_records, load_golden, regs_to_records)
+from helpers import (ONT2D, build_index, first_diff, gpu_stage_records, load_golden, regs_to_records)
 from tools import oracle, refio, synth
 
 pytestmark = pytest.mark.gpu
@@ -146,3 +146,44 @@ def test_sub_batch_pipelining_matches_single_part(tmp_path):
     finally:
         ix.close()
     _same(exp["REGPRG"], regs_to_records(r4, o4), "REGPRG")
+
+
+def test_long_reads_ont2d_golden(gpu_ctx_factory, golden_dir):
+    # config-5 shape: the seed filter (local SW per short seed), chains emptied by it, kb-long int16/int32-class extensions
+    pre, enc, off, ln, d = load_golden(golden_dir, "g40k_ont")
+    ctx = gpu_ctx_factory(pre)
+    opt = bm2.default_opt(**ONT2D)
+    regs, reg_off, st = ctx.seed_chain_extend(enc, off, ln, opt)
+    C, S, R = gpu_stage_records(ctx, bm2, len(ln))
+    _same(d["CHN1"], C, "CHN1")
+    _same(d["SEED1"], S, "SEED1")
+    _same(d["REGPRG"], regs_to_records(regs, reg_off), "REGPRG")
+
+
+def test_long_reads_fresh_vs_oracle(gpu_ctx_factory, tmp_path):
+    names, ctg, alts = synth.make_genome(41, [200000, 90000], alt_contigs=1, alt_len=4000, n_repeat_families=5,
+                                         repeat_len=(300, 4000), copies=(3, 20), divergence=(0.0, 0.08))
+    fa = str(tmp_path / "g.fa")
+    synth.write_fasta(fa, names, ctg)
+    synth.write_alt(fa + ".alt", alts)
+    if not build_index(fa):
+        pytest.skip("oracle/_ref reference binary not present")
+    reads = synth.make_reads_long(42, ctg, 60, mean_len=3000, max_len=9000)
+    enc, off, ln = refio.pack_reads(reads)
+    ix = oracle.Index(fa)
+    try:
+        exp = ix.run(enc, off, ln, oracle.default_opt(**ONT2D))
+    finally:
+        ix.close()
+    ctx = gpu_ctx_factory(fa)
+    regs, reg_off, st = ctx.seed_chain_extend(enc, off, ln, bm2.default_opt(**ONT2D))
+    _same(exp["REGPRG"], regs_to_records(regs, reg_off), "REGPRG")
+
+
+def test_non_bwa_scoring_matrix_is_refused(gpu_ctx_factory, golden_dir):
+    pre, enc, off, ln, d = load_golden(golden_dir, "g20k_l76")
+    ctx = gpu_ctx_factory(pre)
+    opt = bm2.default_opt()
+    opt.mat[7] = -2              # C vs G scored differently from the other mismatches
+    with pytest.raises(bm2.Bm2Error):
+        ctx.seed_chain_extend(enc, off, ln, opt)
