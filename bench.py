@@ -130,32 +130,27 @@ def main():
     ap.add_argument("--workdir", default=os.environ.get("BM2_BENCH_WORKDIR", "/tmp/bm2_bench"))
     a = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", 0))
-    world = int(os.environ.get("WORLD_SIZE", 1))
-    local = int(os.environ.get("LOCAL_RANK", 0))
+    from tools import dist_util, synth
+    rank, world, local = dist_util.env_rank()
     import torch
-    import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (libbm2 has no CPU fallback)")
     torch.cuda.set_device(local)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dist_util.init("nccl", world, torch.device("cuda", local))     # "nccl" is RCCL on ROCm
     import bm2
-    from tools import synth
 
     os.makedirs(a.workdir, exist_ok=True)
     seed = 20260924
     if rank == 0:
         prefix, contigs = prepare_genome(a.workdir, a.genome_mbp, seed)
-    if world > 1:
-        dist.barrier()
+    dist_util.barrier(world)
     if rank != 0:
         prefix, contigs = prepare_genome(a.workdir, a.genome_mbp, seed)
 
     t = time.time()
     ctx = bm2.Context(local, prefix)
     log("rank %d: index replica in HBM after %.1fs" % (rank, time.time() - t))
-    r1, r2 = synth.make_reads_pe(seed + 1000 + rank, contigs, a.reads // 2, L=a.read_len)
+    r1, r2 = synth.make_reads_pe(dist_util.shard_seed(seed, rank), contigs, a.reads // 2, L=a.read_len)
     reads = np.empty((2 * len(r1), a.read_len), np.uint8)
     reads[0::2] = r1; reads[1::2] = r2                      # mates interleaved, as bseq_read_orig delivers PE chunks
     n_reads = len(reads)
@@ -169,21 +164,15 @@ def main():
         ctx.batch_run(opt)
     kms = {}
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    dist_util.barrier(world)
     t0 = time.perf_counter()
     for _ in range(a.steps):
         ctx.batch_run(opt)                                   # returns after the library's stream has drained
         for name, ms in ctx.batch_kernel_ms():
             kms[name] = kms.get(name, 0.0) + ms
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dist_util.barrier(world)
+    dt = dist_util.max_over_ranks(time.perf_counter() - t0, world, "cuda")
     st = ctx.batch_stats()
 
     if rank == 0:
@@ -233,9 +222,7 @@ def main():
             out["cpu_baseline"] = cb
         print(json.dumps(out), flush=True)
     ctx.close()
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    dist_util.finish(world)
 
 
 if __name__ == "__main__":
