@@ -28,7 +28,10 @@ DEVREG_DT = np.dtype([("rb", "<i8"), ("re", "<i8"), ("qb", "<i4"), ("qe", "<i4")
 REG_DT = np.dtype([("rb", "<i8"), ("re", "<i8"), ("qb", "<i4"), ("qe", "<i4"), ("rid", "<i4"), ("score", "<i4"),
                    ("truesc", "<i4"), ("w", "<i4"), ("seedcov", "<i4"), ("seedlen0", "<i4"), ("frac_rep", "<f4"),
                    ("pad", "<i4")])
-assert SMEM_DT.itemsize == 40 and SEQPAIR_DT.itemsize == 56 and REG_DT.itemsize == 56
+ALNREG_DT = np.dtype([("rb", "<i8"), ("re", "<i8")] + [(n, "<i4") for n in ("qb", "qe", "rid", "score", "truesc", "sub", "alt_sc", "csub",
+                      "sub_n", "w", "seedcov", "secondary", "secondary_all", "seedlen0", "n_comp", "is_alt")] +
+                     [("frac_rep", "<f4"), ("pad", "<i4"), ("hash", "<u8")])
+assert SMEM_DT.itemsize == 40 and SEQPAIR_DT.itemsize == 56 and REG_DT.itemsize == 56 and ALNREG_DT.itemsize == 96
 
 
 class IndexDesc(C.Structure):
@@ -67,7 +70,7 @@ class Stats(C.Structure):
 EXPORTS = ["bm2_index_load", "bm2_index_free", "bm2_opt_init", "bm2_opt_fill_scmat", "bm2_create", "bm2_destroy",
            "bm2_last_error", "bm2_device_count", "bm2_bsw", "bm2_smem", "bm2_sal", "bm2_seed_chain_extend",
            "bm2_batch_upload", "bm2_batch_run", "bm2_batch_stats", "bm2_batch_download", "bm2_batch_kernel_ms",
-           "bm2_batch_fetch"]
+           "bm2_batch_fetch", "bm2_finish_regs"]
 
 _lib = None
 
@@ -103,6 +106,8 @@ def lib():
         L.bm2_batch_download.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_int64)]
         L.bm2_batch_kernel_ms.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.c_void_p]
         L.bm2_batch_fetch.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+        L.bm2_finish_regs.argtypes = [C.POINTER(IndexDesc), C.POINTER(Opt), C.POINTER(Reads), C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_int64, C.c_void_p, C.POINTER(C.c_int64)]
         _lib = L
     return _lib
 
@@ -271,3 +276,22 @@ class Context:
         n = C.c_int32(0)
         _chk(lib().bm2_batch_kernel_ms(self.h, ms, 32, C.byref(n), names), "bm2_batch_kernel_ms")
         return [(names[i].decode(), float(ms[i])) for i in range(n.value)]
+
+
+def finish_regs(index_prefix, enc, off, ln, opt, regs, reg_off):
+    """Tail of mem_kernel2_core on the host (no GPU): -> (alnregs ALNREG_DT, out_off)."""
+    L = lib()
+    d = IndexDesc()
+    _chk(L.bm2_index_load(index_prefix.encode(), C.byref(d)), "bm2_index_load")
+    try:
+        r, keep = _reads_struct(enc, off, ln)
+        regs = np.ascontiguousarray(regs, REG_DT)
+        reg_off = np.ascontiguousarray(reg_off, np.int64)
+        out = np.zeros(max(len(regs), 1), ALNREG_DT)
+        out_off = np.zeros(len(keep[2]) + 1, np.int64)
+        n = C.c_int64(0)
+        _chk(L.bm2_finish_regs(C.byref(d), C.byref(opt), C.byref(r), regs.ctypes.data, reg_off.ctypes.data, out.ctypes.data,
+                               len(out), out_off.ctypes.data, C.byref(n)), "bm2_finish_regs")
+        return out[:n.value], out_off
+    finally:
+        L.bm2_index_free(C.byref(d))

@@ -89,6 +89,15 @@ typedef struct {                    /* the fields of mem_alnreg_t (bwamem.h:137-
     int32_t pad;
 } bm2_reg_t;
 
+typedef struct {                    /* mem_alnreg_t (bwamem.h:137-160) without the chain pointer: what mem_kernel2_core returns */
+    int64_t rb, re;
+    int32_t qb, qe, rid, score, truesc, sub, alt_sc, csub, sub_n, w, seedcov, secondary, secondary_all, seedlen0;
+    int32_t n_comp, is_alt;
+    float   frac_rep;
+    int32_t pad;
+    uint64_t hash;
+} bm2_alnreg_t;
+
 typedef struct {                    /* reads of one chunk: 2-bit codes (0..3, 4 = N), as after bwamem.cpp:992-1000 */
     int32_t n_reads;
     const uint8_t *enc;             /* concatenated codes */
@@ -133,6 +142,13 @@ int bm2_sal(bm2_ctx *c, const bm2_smem_t *smems, int64_t n, int32_t max_occ, int
  * regs of read i = regs[reg_off[i] .. reg_off[i+1]); reg_off has n_reads+1 entries. */
 int bm2_seed_chain_extend(bm2_ctx *c, const bm2_reads *reads, const bm2_opt *opt, bm2_reg_t *regs, int64_t cap,
                           int64_t *reg_off, int64_t *n_out, bm2_stats *stats);
+
+/* ---- host side, after the device boundary: the tail of mem_kernel2_core (bwamem.cpp:1154-1169) =
+ * mem_sort_dedup_patch (bwamem.cpp:292-353, with mem_patch_reg :175-225 -> bwa_gen_cigar2 -> ksw_global2) and the ALT
+ * flag.  In: the regs of bm2_seed_chain_extend.  Out: exactly the mem_alnreg_v contents the reference hands to
+ * worker_sam.  Pure host code (no GPU needed); idx must carry ref_string. */
+int bm2_finish_regs(const bm2_index_desc *idx, const bm2_opt *opt, const bm2_reads *reads, const bm2_reg_t *regs,
+                    const int64_t *reg_off, bm2_alnreg_t *out, int64_t cap, int64_t *out_off, int64_t *n_out);
 
 /* ---- the same path split so that a caller can keep inputs resident in HBM and time only the device work */
 int bm2_batch_upload(bm2_ctx *c, const bm2_reads *reads);                 /* H2D (pinned staging) */
