@@ -70,7 +70,7 @@ class Stats(C.Structure):
 EXPORTS = ["bm2_index_load", "bm2_index_free", "bm2_opt_init", "bm2_opt_fill_scmat", "bm2_create", "bm2_destroy",
            "bm2_last_error", "bm2_device_count", "bm2_bsw", "bm2_smem", "bm2_sal", "bm2_seed_chain_extend",
            "bm2_batch_upload", "bm2_batch_run", "bm2_batch_stats", "bm2_batch_download", "bm2_batch_kernel_ms",
-           "bm2_batch_fetch", "bm2_finish_regs"]
+           "bm2_batch_fetch", "bm2_finish_regs", "bm2_index_build"]
 
 _lib = None
 
@@ -108,6 +108,7 @@ def lib():
         L.bm2_batch_fetch.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
         L.bm2_finish_regs.argtypes = [C.POINTER(IndexDesc), C.POINTER(Opt), C.POINTER(Reads), C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_int64, C.c_void_p, C.POINTER(C.c_int64)]
+        L.bm2_index_build.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
         _lib = L
     return _lib
 
@@ -295,3 +296,8 @@ def finish_regs(index_prefix, enc, off, ln, opt, regs, reg_off):
         return out[:n.value], out_off
     finally:
         L.bm2_index_free(C.byref(d))
+
+
+def index_build(fasta, prefix=None, n_threads=0):
+    """Multi-threaded, byte-identical equivalent of `bwa-mem2 index` (host only)."""
+    _chk(lib().bm2_index_build(fasta.encode(), (prefix or fasta).encode(), n_threads), "bm2_index_build")

@@ -1,0 +1,265 @@
+// index_build.cpp -- multi-threaded builder of the reference's on-disk index (the "index loader / on-disk format" row of
+// SURVEY.md section 8(f)).  Produces, for the same FASTA, byte-identical <prefix>.pac/.ann/.amb/.0123/.bwt.2bit.64 to
+// `bwa-mem2 index` (bns_fasta2bntseq bntseq.cpp:249-357, bns_dump :73-105, FMI_search::build_index / build_fm_index
+// FMI_search.cpp:144-382), so either program can load either index.  The FM-index of a text is unique, so only the
+// construction differs: the reference runs single-threaded SA-IS (28N bytes of RAM, ~0.25-0.5 us per base: an hour for a
+// human genome); here suffixes are bucketed by their first 11 bases and every bucket is sorted independently on all host
+// cores with word-wise comparisons on a 2-bit packed text -- what lets a GRCh38-size synthetic genome be indexed inside a
+// benchmark run.  Host code; no GPU involved.
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <atomic>
+#include <string>
+#include <thread>
+#include <vector>
+#include "../../include/bm2.h"
+
+void bm2_set_error(const char *fmt, ...);
+
+namespace {
+
+const int KPRE = 11;                                   // bucket = first 11 bases (4^11 = 4M buckets)
+
+struct Contig { std::string name, anno; int64_t offset; int32_t len, n_ambs; };
+struct Hole { int64_t offset; int32_t len; char amb; };
+
+inline int nt4(int c) {                                 // nst_nt4_table, bntseq.cpp:51-68
+    switch (c) { case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2; case 'T': case 't': return 3; case '-': return 5; default: return 4; }
+}
+
+template <class F> void parallel_for(int nthr, int64_t n, F f) {       // f(tid, begin, end) over contiguous ranges
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthr; t++) {
+        const int64_t b = n * t / nthr, e = n * (t + 1) / nthr;
+        th.emplace_back([=]() { f(t, b, e); });
+    }
+    for (auto &x : th) x.join();
+}
+
+struct Text {
+    int64_t N = 0;                  // 2 * l_pac
+    std::vector<uint8_t> T;         // one base per byte (.0123)
+    std::vector<uint64_t> P;        // 2-bit packed, 32 bases per word, first base in the top bits
+    inline uint64_t get32(int64_t i) const {
+        const int64_t w = i >> 5; const int s = (int)(i & 31) * 2;
+        return s ? (P[w] << s) | (P[w + 1] >> (64 - s)) : P[w];
+    }
+    // suffix i < suffix j (i != j); the end of the text sorts before every base (implicit sentinel, as SA-IS does)
+    inline bool less(int64_t i, int64_t j) const {
+        int64_t off = 0;
+        for (;;) {
+            if (i + off + 32 <= N && j + off + 32 <= N) {
+                const uint64_t a = get32(i + off), b = get32(j + off);
+                if (a != b) return a < b;
+                off += 32;
+            } else {
+                for (;;) {
+                    if (i + off == N) return true;
+                    if (j + off == N) return false;
+                    const uint8_t a = T[i + off], b = T[j + off];
+                    if (a != b) return a < b;
+                    ++off;
+                }
+            }
+        }
+    }
+};
+
+}  // namespace
+
+extern "C" int bm2_index_build(const char *fasta, const char *prefix, int n_threads) {
+    if (!fasta || !prefix) return BM2_EINVAL;
+    if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency();
+    if (n_threads <= 0) n_threads = 1;
+    // ---- 1. FASTA -> contigs, holes, forward bases (N -> lrand48()&3 after srand48(11): bntseq.cpp:284,314-315)
+    FILE *f = fopen(fasta, "rb");
+    if (!f) { bm2_set_error("cannot open %s", fasta); return BM2_EIO; }
+    fseek(f, 0, SEEK_END); const int64_t fsz = ftell(f); fseek(f, 0, SEEK_SET);
+    std::vector<char> buf((size_t)fsz + 1);
+    if (fsz > 0 && (int64_t)fread(buf.data(), 1, (size_t)fsz, f) != fsz) { fclose(f); bm2_set_error("short read on %s", fasta); return BM2_EIO; }
+    fclose(f);
+    if (fsz >= 2 && (uint8_t)buf[0] == 0x1f && (uint8_t)buf[1] == 0x8b) { bm2_set_error("%s is gzip-compressed: give plain FASTA", fasta); return BM2_EUNSUP; }
+    std::vector<Contig> ctg; std::vector<Hole> holes;
+    Text tx;
+    std::vector<uint8_t> &T = tx.T;
+    T.reserve((size_t)fsz * 2 + 64);
+    srand48(11);
+    {
+        int64_t p = 0; int lasts = 0; Hole *q = nullptr;
+        while (p < fsz) {
+            if (buf[p] == '>') {
+                int64_t e = p; while (e < fsz && buf[e] != '\n') e++;
+                std::string hdr(buf.data() + p + 1, buf.data() + e);
+                if (!hdr.empty() && hdr.back() == '\r') hdr.pop_back();
+                size_t sp = hdr.find_first_of(" \t");
+                Contig c; c.name = hdr.substr(0, sp);
+                c.anno = "(null)";
+                if (sp != std::string::npos && sp + 1 < hdr.size()) c.anno = hdr.substr(sp + 1);     // kseq: the rest of the line
+                c.offset = (int64_t)T.size(); c.len = 0; c.n_ambs = 0;
+                ctg.push_back(c); lasts = 0; q = nullptr;
+                p = e + 1;
+            } else {
+                int64_t e = p; while (e < fsz && buf[e] != '\n') e++;
+                if (ctg.empty()) { p = e + 1; continue; }
+                Contig &c = ctg.back();
+                for (int64_t k = p; k < e; k++) {
+                    const int ch = (uint8_t)buf[k];
+                    if (ch == '\r' || ch == ' ' || ch == '\t') continue;
+                    int v = nt4(ch);
+                    if (v >= 4) {                                           // bntseq.cpp:266-282
+                        if (lasts == ch && q) ++q->len;
+                        else { Hole h; h.offset = c.offset + c.len; h.len = 1; h.amb = (char)ch; holes.push_back(h); q = &holes.back(); ++c.n_ambs; }
+                        v = (int)(lrand48() & 3);
+                    }
+                    lasts = ch;
+                    T.push_back((uint8_t)v); c.len++;
+                }
+                p = e + 1;
+            }
+        }
+    }
+    std::vector<char>().swap(buf);
+    const int64_t l_pac = (int64_t)T.size();
+    if (l_pac == 0) { bm2_set_error("%s holds no sequence", fasta); return BM2_EIO; }
+    const std::string pre(prefix);
+    // ---- 2. .pac (forward strand only, bntseq.cpp:331-346), .ann / .amb (bns_dump)
+    {
+        std::vector<uint8_t> pac((size_t)(l_pac >> 2) + 2, 0);
+        for (int64_t i = 0; i < l_pac; i++) pac[i >> 2] |= T[i] << ((~i & 3) << 1);
+        FILE *o = fopen((pre + ".pac").c_str(), "wb");
+        if (!o) { bm2_set_error("cannot write %s.pac", prefix); return BM2_EIO; }
+        fwrite(pac.data(), 1, (size_t)((l_pac >> 2) + ((l_pac & 3) == 0 ? 0 : 1)), o);
+        if (l_pac % 4 == 0) { uint8_t z = 0; fwrite(&z, 1, 1, o); }
+        uint8_t ct = (uint8_t)(l_pac % 4); fwrite(&ct, 1, 1, o);
+        fclose(o);
+        o = fopen((pre + ".ann").c_str(), "w");
+        fprintf(o, "%lld %d %u\n", (long long)l_pac, (int)ctg.size(), 11u);
+        for (auto &c : ctg) {
+            fprintf(o, "%d %s", 0, c.name.c_str());
+            if (!c.anno.empty()) fprintf(o, " %s\n", c.anno.c_str()); else fprintf(o, "\n");
+            fprintf(o, "%lld %d %d\n", (long long)c.offset, c.len, c.n_ambs);
+        }
+        fclose(o);
+        o = fopen((pre + ".amb").c_str(), "w");
+        fprintf(o, "%lld %d %u\n", (long long)l_pac, (int)ctg.size(), (unsigned)holes.size());
+        for (auto &h : holes) fprintf(o, "%lld %d %c\n", (long long)h.offset, h.len, h.amb);
+        fclose(o);
+    }
+    // ---- 3. text = forward + reverse complement (pac2nt, FMI_search.cpp:83-142); .0123
+    const int64_t N = 2 * l_pac;
+    tx.N = N;
+    T.resize((size_t)N);
+    parallel_for(n_threads, l_pac, [&](int, int64_t b, int64_t e) { for (int64_t i = b; i < e; i++) T[N - 1 - i] = 3 - T[i]; });
+    {
+        FILE *o = fopen((pre + ".0123").c_str(), "wb");
+        if (!o || (int64_t)fwrite(T.data(), 1, (size_t)N, o) != N) { if (o) fclose(o); bm2_set_error("cannot write %s.0123", prefix); return BM2_EIO; }
+        fclose(o);
+    }
+    tx.P.assign((size_t)(N >> 5) + 3, 0);
+    parallel_for(n_threads, (N >> 5) + 1, [&](int, int64_t b, int64_t e) {
+        for (int64_t w = b; w < e; w++) {
+            uint64_t v = 0;
+            for (int k = 0; k < 32; k++) { const int64_t i = w * 32 + k; v = (v << 2) | (i < N ? T[i] : 0); }
+            tx.P[w] = v;
+        }
+    });
+    int64_t count[5] = { 0, 0, 0, 0, 0 };
+    {
+        std::vector<std::vector<int64_t>> c4((size_t)n_threads, std::vector<int64_t>(4, 0));
+        parallel_for(n_threads, N, [&](int t, int64_t b, int64_t e) { for (int64_t i = b; i < e; i++) c4[t][T[i]]++; });
+        int64_t c[4] = { 0, 0, 0, 0 };
+        for (auto &v : c4) for (int k = 0; k < 4; k++) c[k] += v[k];
+        count[0] = 0; count[1] = c[0]; count[2] = c[0] + c[1]; count[3] = c[0] + c[1] + c[2]; count[4] = c[0] + c[1] + c[2] + c[3];
+    }
+    // ---- 4. suffix array: SA[0] = N (the empty suffix), then the N suffixes in lexicographic order (FMI_search.cpp:366-368)
+    const int64_t NB = 1LL << (2 * KPRE);
+    auto key_of = [&](int64_t i) -> int64_t {              // first KPRE bases, zero-padded past the end (a short suffix then
+        return (int64_t)(tx.get32(i) >> (64 - 2 * KPRE));  // sorts first inside the bucket it is padded into)
+    };
+    std::vector<int64_t> SA((size_t)N + 2);
+    SA[0] = N;
+    std::vector<int64_t> bstart((size_t)NB + 1, 0);
+    {
+        std::vector<std::vector<uint32_t>> hist((size_t)n_threads);
+        parallel_for(n_threads, N, [&](int t, int64_t b, int64_t e) {
+            hist[t].assign((size_t)NB, 0);
+            for (int64_t i = b; i < e; i++) hist[t][key_of(i)]++;
+        });
+        // offsets: bucket-major, thread-minor => suffixes enter a bucket in text order
+        int64_t acc = 1;
+        for (int64_t b = 0; b < NB; b++) {
+            bstart[b] = acc;
+            for (int t = 0; t < n_threads; t++) { const uint32_t c = hist[t][b]; hist[t][b] = (uint32_t)(acc - bstart[b]); acc += c; }
+        }
+        bstart[NB] = acc;
+        parallel_for(n_threads, N, [&](int t, int64_t b, int64_t e) {
+            std::vector<uint32_t> &h = hist[t];
+            for (int64_t i = b; i < e; i++) { const int64_t k = key_of(i); SA[bstart[k] + h[k]++] = i; }
+        });
+    }
+    {
+        std::atomic<int64_t> next(0);
+        std::vector<std::thread> th;
+        for (int t = 0; t < n_threads; t++)
+            th.emplace_back([&]() {
+                for (;;) {
+                    const int64_t b0 = next.fetch_add(256);
+                    if (b0 >= NB) break;
+                    for (int64_t b = b0; b < b0 + 256 && b < NB; b++) {
+                        const int64_t lo = bstart[b], hi = bstart[b + 1];
+                        if (hi - lo > 1) std::sort(SA.begin() + lo, SA.begin() + hi, [&](int64_t x, int64_t y) { return tx.less(x, y); });
+                    }
+                }
+            });
+        for (auto &x : th) x.join();
+    }
+    // ---- 5. BWT -> CP_OCC blocks, sampled SA (build_fm_index, FMI_search.cpp:144-304)
+    const int64_t ref_seq_len = N + 1;
+    const int64_t n_occ = (ref_seq_len >> 6) + 1, n_sa = (ref_seq_len >> 3) + 1;
+    struct CpOcc { int64_t cp_count[4]; uint64_t bwt[4]; };
+    std::vector<CpOcc> occ((size_t)n_occ);
+    std::vector<int64_t> sent((size_t)n_threads, -1);
+    parallel_for(n_threads, n_occ, [&](int t, int64_t b, int64_t e) {
+        for (int64_t blk = b; blk < e; blk++) {
+            CpOcc c; memset(&c, 0, sizeof c);
+            for (int j = 0; j < 64; j++) {
+                const int64_t i = blk * 64 + j;
+                for (int k = 0; k < 4; k++) c.bwt[k] <<= 1;
+                if (i < ref_seq_len) {
+                    const int64_t s = SA[i];
+                    if (s == 0) sent[t] = i;
+                    else { const int ch = T[s - 1]; c.bwt[ch] += 1; c.cp_count[ch]++; }       // cp_count holds the block's own counts for now
+                }
+            }
+            occ[blk] = c;
+        }
+    });
+    int64_t sentinel_index = -1;
+    for (int64_t v : sent) if (v >= 0) sentinel_index = v;
+    {
+        int64_t run[4] = { 0, 0, 0, 0 };
+        for (int64_t blk = 0; blk < n_occ; blk++)
+            for (int k = 0; k < 4; k++) { const int64_t c = occ[blk].cp_count[k]; occ[blk].cp_count[k] = run[k]; run[k] += c; }
+    }
+    std::vector<int8_t> ms((size_t)n_sa, 0); std::vector<uint32_t> ls((size_t)n_sa, 0);
+    parallel_for(n_threads, n_sa, [&](int, int64_t b, int64_t e) {
+        for (int64_t p = b; p < e; p++) {
+            const int64_t i = p << 3;
+            if (i < ref_seq_len) { ls[p] = (uint32_t)(SA[i] & 0xffffffff); ms[p] = (int8_t)((SA[i] >> 32) & 0xff); }
+        }
+    });
+    {
+        FILE *o = fopen((pre + ".bwt.2bit.64").c_str(), "wb");
+        if (!o) { bm2_set_error("cannot write %s.bwt.2bit.64", prefix); return BM2_EIO; }
+        bool ok = fwrite(&ref_seq_len, 8, 1, o) == 1 && fwrite(count, 8, 5, o) == 5 &&
+                  (int64_t)fwrite(occ.data(), sizeof(CpOcc), (size_t)n_occ, o) == n_occ &&
+                  (int64_t)fwrite(ms.data(), 1, (size_t)n_sa, o) == n_sa && (int64_t)fwrite(ls.data(), 4, (size_t)n_sa, o) == n_sa &&
+                  fwrite(&sentinel_index, 8, 1, o) == 1;
+        fclose(o);
+        if (!ok) { bm2_set_error("short write on %s.bwt.2bit.64", prefix); return BM2_EIO; }
+    }
+    return BM2_OK;
+}

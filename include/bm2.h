@@ -49,6 +49,10 @@ typedef struct {
 /* Read the reference's index files into malloc'd host arrays (stands in for
  * FMI_search::load_index + bwa_idx_load_ele + the .0123 fread).  Free with bm2_index_free. */
 int  bm2_index_load(const char *prefix, bm2_index_desc *out);
+/* Build <prefix>.pac/.ann/.amb/.0123/.bwt.2bit.64 from a plain FASTA, byte-identical to `bwa-mem2 index`
+ * (bns_fasta2bntseq bntseq.cpp:249-357; FMI_search::build_index FMI_search.cpp:306-382) but on n_threads host cores
+ * (n_threads <= 0: all).  The <prefix>.alt list, if any, is the caller's to provide, as with the reference. */
+int  bm2_index_build(const char *fasta, const char *prefix, int n_threads);
 void bm2_index_free(bm2_index_desc *d);
 
 /* ---- options: the fields of mem_opt_t (bwamem.h:76-108) the hot path reads ------------------ */
