@@ -15,6 +15,7 @@
 #include <string>
 #include <thread>
 #include <vector>
+#include <chrono>
 #include "../../include/bm2.h"
 
 void bm2_set_error(const char *fmt, ...);
@@ -72,6 +73,13 @@ struct Text {
 
 extern "C" int bm2_index_build(const char *fasta, const char *prefix, int n_threads) {
     if (!fasta || !prefix) return BM2_EINVAL;
+    const bool verbose = getenv("BM2_VERBOSE") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        auto now = std::chrono::steady_clock::now();
+        if (verbose) fprintf(stderr, "[bm2_index_build] %-28s %.2f s\n", what, std::chrono::duration<double>(now - t_last).count());
+        t_last = now;
+    };
     if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency();
     if (n_threads <= 0) n_threads = 1;
     // ---- 1. FASTA -> contigs, holes, forward bases (N -> lrand48()&3 after srand48(11): bntseq.cpp:284,314-315)
@@ -85,7 +93,11 @@ extern "C" int bm2_index_build(const char *fasta, const char *prefix, int n_thre
     std::vector<Contig> ctg; std::vector<Hole> holes;
     Text tx;
     std::vector<uint8_t> &T = tx.T;
-    T.reserve((size_t)fsz * 2 + 64);
+    T.resize((size_t)fsz + 64);                        // bases <= file size; shrunk below
+    int64_t tw = 0;                                     // write cursor into T
+    uint8_t tbl[256];
+    for (int c = 0; c < 256; c++) tbl[c] = (uint8_t)nt4(c);
+    tbl['\r'] = tbl[' '] = tbl['\t'] = 255;
     srand48(11);
     {
         int64_t p = 0; int lasts = 0; Hole *q = nullptr;
@@ -98,31 +110,37 @@ extern "C" int bm2_index_build(const char *fasta, const char *prefix, int n_thre
                 Contig c; c.name = hdr.substr(0, sp);
                 c.anno = "(null)";
                 if (sp != std::string::npos && sp + 1 < hdr.size()) c.anno = hdr.substr(sp + 1);     // kseq: the rest of the line
-                c.offset = (int64_t)T.size(); c.len = 0; c.n_ambs = 0;
+                c.offset = tw; c.len = 0; c.n_ambs = 0;
                 ctg.push_back(c); lasts = 0; q = nullptr;
                 p = e + 1;
             } else {
                 int64_t e = p; while (e < fsz && buf[e] != '\n') e++;
                 if (ctg.empty()) { p = e + 1; continue; }
                 Contig &c = ctg.back();
+                const int64_t tw0 = tw;
                 for (int64_t k = p; k < e; k++) {
                     const int ch = (uint8_t)buf[k];
-                    if (ch == '\r' || ch == ' ' || ch == '\t') continue;
-                    int v = nt4(ch);
-                    if (v >= 4) {                                           // bntseq.cpp:266-282
+                    int v = tbl[ch];
+                    if (v < 4) { T[tw++] = (uint8_t)v; lasts = ch; continue; }
+                    if (v == 255) continue;
+                    {                                                       // ambiguous base, bntseq.cpp:266-284
+                        const int64_t pos = c.offset + c.len + (tw - tw0);
                         if (lasts == ch && q) ++q->len;
-                        else { Hole h; h.offset = c.offset + c.len; h.len = 1; h.amb = (char)ch; holes.push_back(h); q = &holes.back(); ++c.n_ambs; }
+                        else { Hole h; h.offset = pos; h.len = 1; h.amb = (char)ch; holes.push_back(h); q = &holes.back(); ++c.n_ambs; }
                         v = (int)(lrand48() & 3);
                     }
                     lasts = ch;
-                    T.push_back((uint8_t)v); c.len++;
+                    T[tw++] = (uint8_t)v;
                 }
+                c.len += (int32_t)(tw - tw0);
                 p = e + 1;
             }
         }
     }
     std::vector<char>().swap(buf);
-    const int64_t l_pac = (int64_t)T.size();
+    T.resize((size_t)tw);
+    lap("read + parse FASTA");
+    const int64_t l_pac = tw;
     if (l_pac == 0) { bm2_set_error("%s holds no sequence", fasta); return BM2_EIO; }
     const std::string pre(prefix);
     // ---- 2. .pac (forward strand only, bntseq.cpp:331-346), .ann / .amb (bns_dump)
@@ -148,6 +166,7 @@ extern "C" int bm2_index_build(const char *fasta, const char *prefix, int n_thre
         for (auto &h : holes) fprintf(o, "%lld %d %c\n", (long long)h.offset, h.len, h.amb);
         fclose(o);
     }
+    lap("pac/ann/amb");
     // ---- 3. text = forward + reverse complement (pac2nt, FMI_search.cpp:83-142); .0123
     const int64_t N = 2 * l_pac;
     tx.N = N;
@@ -166,6 +185,7 @@ extern "C" int bm2_index_build(const char *fasta, const char *prefix, int n_thre
             tx.P[w] = v;
         }
     });
+    lap(".0123 + packed text");
     int64_t count[5] = { 0, 0, 0, 0, 0 };
     {
         std::vector<std::vector<int64_t>> c4((size_t)n_threads, std::vector<int64_t>(4, 0));
@@ -183,23 +203,35 @@ extern "C" int bm2_index_build(const char *fasta, const char *prefix, int n_thre
     SA[0] = N;
     std::vector<int64_t> bstart((size_t)NB + 1, 0);
     {
-        std::vector<std::vector<uint32_t>> hist((size_t)n_threads);
-        parallel_for(n_threads, N, [&](int t, int64_t b, int64_t e) {
+        // text chunks: enough for all cores, few enough that the per-chunk histograms (16 MB each) stay cheap to combine
+        const int n_chunks = n_threads < 64 ? n_threads : 64;
+        std::vector<std::vector<uint32_t>> hist((size_t)n_chunks);
+        parallel_for(n_chunks, N, [&](int t, int64_t b, int64_t e) {
             hist[t].assign((size_t)NB, 0);
             for (int64_t i = b; i < e; i++) hist[t][key_of(i)]++;
         });
-        // offsets: bucket-major, thread-minor => suffixes enter a bucket in text order
+        lap("bucket histogram");
+        // offsets: bucket-major, chunk-minor => suffixes enter a bucket in text order
+        std::vector<int64_t> tot((size_t)NB);
+        parallel_for(n_threads, NB, [&](int, int64_t b0, int64_t b1) {
+            for (int64_t b = b0; b < b1; b++) { int64_t c = 0; for (int t = 0; t < n_chunks; t++) c += hist[t][b]; tot[b] = c; }
+        });
         int64_t acc = 1;
-        for (int64_t b = 0; b < NB; b++) {
-            bstart[b] = acc;
-            for (int t = 0; t < n_threads; t++) { const uint32_t c = hist[t][b]; hist[t][b] = (uint32_t)(acc - bstart[b]); acc += c; }
-        }
+        for (int64_t b = 0; b < NB; b++) { bstart[b] = acc; acc += tot[b]; }
         bstart[NB] = acc;
-        parallel_for(n_threads, N, [&](int t, int64_t b, int64_t e) {
+        parallel_for(n_threads, NB, [&](int, int64_t b0, int64_t b1) {
+            for (int64_t b = b0; b < b1; b++) {
+                uint32_t run = 0;
+                for (int t = 0; t < n_chunks; t++) { const uint32_t c = hist[t][b]; hist[t][b] = run; run += c; }
+            }
+        });
+        lap("bucket offsets");
+        parallel_for(n_chunks, N, [&](int t, int64_t b, int64_t e) {
             std::vector<uint32_t> &h = hist[t];
             for (int64_t i = b; i < e; i++) { const int64_t k = key_of(i); SA[bstart[k] + h[k]++] = i; }
         });
     }
+    lap("bucket scatter");
     {
         std::atomic<int64_t> next(0);
         std::vector<std::thread> th;
@@ -216,6 +248,7 @@ extern "C" int bm2_index_build(const char *fasta, const char *prefix, int n_thre
             });
         for (auto &x : th) x.join();
     }
+    lap("bucket sort");
     // ---- 5. BWT -> CP_OCC blocks, sampled SA (build_fm_index, FMI_search.cpp:144-304)
     const int64_t ref_seq_len = N + 1;
     const int64_t n_occ = (ref_seq_len >> 6) + 1, n_sa = (ref_seq_len >> 3) + 1;
@@ -251,6 +284,7 @@ extern "C" int bm2_index_build(const char *fasta, const char *prefix, int n_thre
             if (i < ref_seq_len) { ls[p] = (uint32_t)(SA[i] & 0xffffffff); ms[p] = (int8_t)((SA[i] >> 32) & 0xff); }
         }
     });
+    lap("BWT / Occ / sampled SA");
     {
         FILE *o = fopen((pre + ".bwt.2bit.64").c_str(), "wb");
         if (!o) { bm2_set_error("cannot write %s.bwt.2bit.64", prefix); return BM2_EIO; }
@@ -261,5 +295,6 @@ extern "C" int bm2_index_build(const char *fasta, const char *prefix, int n_thre
         fclose(o);
         if (!ok) { bm2_set_error("short write on %s.bwt.2bit.64", prefix); return BM2_EIO; }
     }
+    lap("write .bwt.2bit.64");
     return BM2_OK;
 }

@@ -157,7 +157,8 @@ static int run_seeding(bm2_ctx *c, Batch *b, const bm2_opt *opt, bool with_sal) 
     if ((rc = bm2_reserve(b->smem_cnt, (size_t)(n + 1) * 4))) return rc;
     if ((rc = bm2_reserve(b->smem_off, (size_t)(n + 1) * 8))) return rc;
     int grid = (n + 255) / 256;
-    if (grid > c->n_cu * 4) grid = c->n_cu * 4;
+    static const int smem_bpc = getenv("BM2_SMEM_BLOCKS_PER_CU") ? atoi(getenv("BM2_SMEM_BLOCKS_PER_CU")) : 4;
+    if (grid > c->n_cu * smem_bpc) grid = c->n_cu * smem_bpc;
     if (grid < 1) grid = 1;
     const int64_t nthreads = (int64_t)grid * 256;
     const int stage_cap = 2 * b->max_len + 64, prev_cap = b->max_len + 2;

@@ -10,6 +10,8 @@
 #include "bm2_ctx.h"
 #include "pipeline.h"
 
+// (forcing 8 waves/SIMD with __launch_bounds__(256, 8) spills 88 B/lane and measured 25 % slower: left at the natural 84 VGPRs)
+
 struct Bi { int64_t k, l, s; };
 
 static __device__ __forceinline__ int64_t pick4(int a, int64_t c0, int64_t c1, int64_t c2, int64_t c3) {
