@@ -26,9 +26,19 @@ int bm2_perm_by_work(bm2_ctx *c, int n, const int32_t *key, int32_t *perm, uint3
 int bm2_partition_by_work(bm2_ctx *c, int n, const int32_t *key, int thr, int32_t *perm, DevBuf &tmp, DevBuf &scan_tmp);
 
 // smem.hip
-int bm2_launch_smem(bm2_ctx *c, const SeedParams &sp, int n_reads, const uint8_t *enc, const int64_t *off, const int32_t *len,
-                    StSmem *stage, StSmem *prevbuf, int stage_cap, int prev_cap, int grid, bm2_smem_t *out, int64_t out_cap,
-                    int32_t *smem_cnt, int64_t *smem_off, int32_t *occ_cnt, unsigned long long *counters);
+struct BHead; struct P2Task;
+struct SeedBufs {                                   // workspace of the seeding task kernels (smem.hip)
+    BHead *heads1, *heads2; uint4 *ents1, *ents2; int64_t slot1_cap, slot2_cap;
+    uint4 *pool; int pool_cap, pool_slots;
+    bm2_smem_t *recs; int64_t rec_cap;
+    P2Task *tasks; int64_t task_cap;
+};
+enum { BM2_SC_SLOT1 = 1, BM2_SC_REC = 3, BM2_SC_TASK = 4, BM2_SC_SLOT2 = 6, BM2_SC_NEXT = 9, BM2_SC_OVF = 10, BM2_SC_POOL = 11 };   // = the SC_* of smem.hip
+int bm2_launch_seeding(bm2_ctx *c, const SeedParams &sp, int n_reads, const uint8_t *enc, const int64_t *off, const int32_t *len,
+                       const SeedBufs &sb, int grid_walk, int grid_bwd, int32_t *smem_cnt, unsigned long long *sc);
+int bm2_launch_smem_finish(bm2_ctx *c, int n_reads, const SeedBufs &sb, const unsigned long long *sc, const int32_t *smem_cnt,
+                           const int64_t *smem_off, int32_t *fill, bm2_smem_t *tmp, int32_t max_occ, bm2_smem_t *out, int32_t *occ_cnt);
+int bm2_seed_sizes(size_t *head, size_t *ent, size_t *task, int *n_sc);      // returns CAPF
 int bm2_launch_sal_expand(bm2_ctx *c, const bm2_smem_t *smems, int64_t n_smem, const int64_t *sa_off, int32_t max_occ, int64_t *pos);
 int bm2_launch_sal(bm2_ctx *c, int64_t n, int64_t *pos_coord, unsigned long long *n_lf);
 int bm2_launch_smem_gather(bm2_ctx *c, int n_reads, const bm2_smem_t *in, const int64_t *in_off, const int32_t *cnt,

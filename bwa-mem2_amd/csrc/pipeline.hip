@@ -49,6 +49,7 @@ struct Batch {
     bm2_stats stats{};
     std::vector<int32_t> h_len;              // host copy of the read lengths (per-read filter thresholds)
     DevBuf min_hsp, seed_owner, seed_keep, mat25;
+    DevBuf heads1, ents1, heads2, ents2, pool, recs, tasks, seedc, fill, smem_tmp;     // seeding task kernels
 };
 
 void bm2_batch_destroy(bm2_ctx *c) {
@@ -57,7 +58,8 @@ void bm2_batch_destroy(bm2_ctx *c) {
     DevBuf *all[] = { &b->enc, &b->off, &b->len, &b->stage, &b->prevbuf, &b->smem, &b->occ_cnt, &b->smem_cnt, &b->smem_off,
                       &b->counters, &b->sa_off, &b->sa_coord, &b->scan_tmp, &b->read_base, &b->wchain, &b->wseed, &b->nodes,
                       &b->order, &b->chn, &b->seeds, &b->srt, &b->reg_seed, &b->reg_chain, &b->regs, &b->slot_base, &b->n_chain,
-                      &b->n_reg, &b->n_chain0, &b->n_out, &b->out_off, &b->out_regs, &b->smem_sorted, &b->smem_sorted_off, &b->ext_tmp, &b->cursor, &b->n_sa_read, &b->perm, &b->perm_hist, &b->part_tmp, &b->min_hsp, &b->seed_owner, &b->seed_keep, &b->mat25 };
+                      &b->n_reg, &b->n_chain0, &b->n_out, &b->out_off, &b->out_regs, &b->smem_sorted, &b->smem_sorted_off, &b->ext_tmp, &b->cursor, &b->n_sa_read, &b->perm, &b->perm_hist, &b->part_tmp, &b->min_hsp, &b->seed_owner, &b->seed_keep, &b->mat25,
+                      &b->heads1, &b->ents1, &b->heads2, &b->ents2, &b->pool, &b->recs, &b->tasks, &b->seedc, &b->fill, &b->smem_tmp };
     for (DevBuf *d : all) bm2_release(*d);
     delete b;
     c->batch = nullptr;
@@ -154,36 +156,87 @@ static int run_seeding(bm2_ctx *c, Batch *b, const bm2_opt *opt, bool with_sal) 
     hipStream_t s = c->stream;
     const SeedParams sp = seed_params(opt);
     if ((rc = bm2_reserve(b->counters, 16 * 8))) return rc;
+    if ((rc = bm2_check(hipMemsetAsync(b->counters.p, 0, 16 * 8, s), "memset counters"))) return rc;
     if ((rc = bm2_reserve(b->smem_cnt, (size_t)(n + 1) * 4))) return rc;
     if ((rc = bm2_reserve(b->smem_off, (size_t)(n + 1) * 8))) return rc;
-    int grid = (n + 255) / 256;
-    static const int smem_bpc = getenv("BM2_SMEM_BLOCKS_PER_CU") ? atoi(getenv("BM2_SMEM_BLOCKS_PER_CU")) : 4;
-    if (grid > c->n_cu * smem_bpc) grid = c->n_cu * smem_bpc;
-    if (grid < 1) grid = 1;
-    const int64_t nthreads = (int64_t)grid * 256;
-    const int stage_cap = 2 * b->max_len + 64, prev_cap = b->max_len + 2;
-    if ((rc = bm2_reserve(b->stage, (size_t)nthreads * stage_cap * sizeof(StSmem)))) return rc;
-    if ((rc = bm2_reserve(b->prevbuf, (size_t)nthreads * prev_cap * sizeof(StSmem)))) return rc;
-    int64_t cap = b->smem.cap / sizeof(bm2_smem_t);
-    if (cap < (int64_t)n * 16 + 1024) cap = (int64_t)n * 16 + 1024;
-    unsigned long long h_cnt[3];
-    for (int attempt = 0; attempt < 3; attempt++) {
-        if ((rc = bm2_reserve(b->smem, (size_t)cap * sizeof(bm2_smem_t)))) return rc;
-        if ((rc = bm2_reserve(b->occ_cnt, (size_t)(cap + 1) * 4))) return rc;
-        cap = b->smem.cap / sizeof(bm2_smem_t);
-        if ((int64_t)(b->occ_cnt.cap / 4) - 1 < cap) cap = b->occ_cnt.cap / 4 - 1;
-        if ((rc = bm2_check(hipMemsetAsync(b->counters.p, 0, 16 * 8, s), "memset counters"))) return rc;
-        if ((rc = bm2_launch_smem(c, sp, n, (const uint8_t *)b->enc.p, (const int64_t *)b->off.p, (const int32_t *)b->len.p,
-                                  (StSmem *)b->stage.p, (StSmem *)b->prevbuf.p, stage_cap, prev_cap, grid, (bm2_smem_t *)b->smem.p, cap,
-                                  (int32_t *)b->smem_cnt.p, (int64_t *)b->smem_off.p, (int32_t *)b->occ_cnt.p,
-                                  (unsigned long long *)b->counters.p))) return rc;
-        if ((rc = bm2_check(hipMemcpyAsync(h_cnt, b->counters.p, 24, hipMemcpyDeviceToHost, s), "D2H counters"))) return rc;
-        if ((rc = bm2_check(hipStreamSynchronize(s), "k_smem"))) return rc;
-        if (h_cnt[2]) { bm2_set_error("per-read SMEM staging overflow (%d entries)", stage_cap); return BM2_EUNSUP; }
-        if ((int64_t)h_cnt[0] <= cap) break;
-        cap = (int64_t)h_cnt[0] + 1024;
-        if (attempt == 2) { bm2_set_error("SMEM buffer could not be sized"); return BM2_ENOMEM; }
+    // task kernels with persistent lanes (smem.hip); workspace sizes are learned: a run that overflows one of them reports
+    // what it needed and is repeated
+    static const int bpc_w = getenv("BM2_WALK_BLOCKS_PER_CU") ? atoi(getenv("BM2_WALK_BLOCKS_PER_CU")) : 4;
+    static const int bpc_b = getenv("BM2_BWD_BLOCKS_PER_CU") ? atoi(getenv("BM2_BWD_BLOCKS_PER_CU")) : 4;
+    const int grid_w = c->n_cu * bpc_w, grid_b = c->n_cu * bpc_b;
+    const int64_t lanes = (int64_t)(grid_w > grid_b ? grid_w : grid_b) * 256;
+    if (opt->split_width > 65534) { bm2_set_error("split_width %d > 65534 is not supported", opt->split_width); return BM2_EUNSUP; }
+    size_t head_sz, ent_sz, task_sz; int n_sc;
+    const int capf = bm2_seed_sizes(&head_sz, &ent_sz, &task_sz, &n_sc);
+    SeedBufs sb;
+    sb.pool_cap = b->max_len + 2 > capf ? b->max_len + 2 - capf : 1;
+    int64_t slot1_cap = (int64_t)(b->heads1.cap / head_sz), slot2_cap = (int64_t)(b->heads2.cap / head_sz);
+    int64_t rec_cap = (int64_t)(b->recs.cap / sizeof(bm2_smem_t)), task_cap = (int64_t)(b->tasks.cap / task_sz);
+    int64_t pool_slots = (int64_t)(b->pool.cap / ((size_t)sb.pool_cap * 16));
+    if (slot1_cap < (int64_t)n * 6 + lanes * 4 + 4096) slot1_cap = (int64_t)n * 6 + lanes * 4 + 4096;
+    if (slot2_cap < (int64_t)n * 6 + lanes * 4 + 4096) slot2_cap = (int64_t)n * 6 + lanes * 4 + 4096;
+    if (rec_cap < (int64_t)n * 24 + lanes * 12 + 4096) rec_cap = (int64_t)n * 24 + lanes * 12 + 4096;      // + the pool tails: 3 kernels x 256 / wave
+    if (task_cap < (int64_t)n * 6 + lanes + 4096) task_cap = (int64_t)n * 6 + lanes + 4096;
+    if (pool_slots < n / 8 + 1024) pool_slots = n / 8 + 1024;
+    if ((rc = bm2_reserve(b->seedc, (size_t)n_sc * 8))) return rc;
+    if ((rc = bm2_reserve(b->fill, (size_t)(n + 1) * 4))) return rc;
+    std::vector<unsigned long long> h_sc((size_t)n_sc);
+    int64_t n_smem_tot = 0;
+    const bool verbose = getenv("BM2_VERBOSE") != nullptr;
+    auto now_ms = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
+    double t0 = now_ms();
+    if (verbose) (void)hipStreamSynchronize(s);
+    for (int attempt = 0; ; attempt++) {
+        if ((rc = bm2_reserve(b->heads1, (size_t)slot1_cap * head_sz))) return rc;
+        if ((rc = bm2_reserve(b->ents1, (size_t)slot1_cap * ent_sz))) return rc;
+        if ((rc = bm2_reserve(b->heads2, (size_t)slot2_cap * head_sz))) return rc;
+        if ((rc = bm2_reserve(b->ents2, (size_t)slot2_cap * ent_sz))) return rc;
+        if ((rc = bm2_reserve(b->recs, (size_t)rec_cap * sizeof(bm2_smem_t)))) return rc;
+        if ((rc = bm2_reserve(b->tasks, (size_t)task_cap * task_sz))) return rc;
+        if ((rc = bm2_reserve(b->pool, (size_t)pool_slots * sb.pool_cap * 16))) return rc;
+        sb.heads1 = (BHead *)b->heads1.p; sb.ents1 = (uint4 *)b->ents1.p; sb.slot1_cap = slot1_cap;
+        sb.heads2 = (BHead *)b->heads2.p; sb.ents2 = (uint4 *)b->ents2.p; sb.slot2_cap = slot2_cap;
+        sb.pool = (uint4 *)b->pool.p; sb.pool_slots = (int)pool_slots;
+        sb.recs = (bm2_smem_t *)b->recs.p; sb.rec_cap = rec_cap; sb.tasks = (P2Task *)b->tasks.p; sb.task_cap = task_cap;
+        if ((rc = bm2_check(hipMemsetAsync(b->seedc.p, 0, (size_t)n_sc * 8, s), "memset seed cursors"))) return rc;
+        if ((rc = bm2_check(hipMemsetAsync(b->smem_cnt.p, 0, (size_t)(n + 1) * 4, s), "memset smem_cnt"))) return rc;
+        if ((rc = bm2_check(hipMemsetAsync(b->fill.p, 0, (size_t)(n + 1) * 4, s), "memset fill"))) return rc;
+        if (verbose) { (void)hipStreamSynchronize(s); fprintf(stderr, "[seeding] reserve+memset %.1f ms\n", now_ms() - t0); t0 = now_ms(); }
+        if ((rc = bm2_launch_seeding(c, sp, n, (const uint8_t *)b->enc.p, (const int64_t *)b->off.p, (const int32_t *)b->len.p, sb,
+                                     grid_w, grid_b, (int32_t *)b->smem_cnt.p, (unsigned long long *)b->seedc.p))) return rc;
+        if ((rc = bm2_scan_i32(c, (const int32_t *)b->smem_cnt.p, n, (int64_t *)b->smem_off.p, b->scan_tmp))) return rc;
+        if ((rc = bm2_check(hipMemcpyAsync(&n_smem_tot, (int64_t *)b->smem_off.p + n, 8, hipMemcpyDeviceToHost, s), "D2H n_smem"))) return rc;
+        if ((rc = bm2_check(hipMemcpyAsync(h_sc.data(), b->seedc.p, (size_t)n_sc * 8, hipMemcpyDeviceToHost, s), "D2H seed cursors"))) return rc;
+        if ((rc = bm2_check(hipStreamSynchronize(s), "seeding kernels"))) return rc;
+        if (verbose) { fprintf(stderr, "[seeding] kernels+scan %.1f ms\n", now_ms() - t0); t0 = now_ms(); }
+        if (!h_sc[BM2_SC_OVF]) break;
+        if (getenv("BM2_VERBOSE"))
+            fprintf(stderr, "[seeding] attempt %d overflowed (flags %llu): slots %llu/%lld + %llu/%lld, records %llu/%lld, tasks %llu/%lld, pool %llu/%lld\n",
+                    attempt, h_sc[BM2_SC_OVF], h_sc[BM2_SC_SLOT1], (long long)slot1_cap, h_sc[BM2_SC_SLOT2], (long long)slot2_cap,
+                    h_sc[BM2_SC_REC], (long long)rec_cap, h_sc[BM2_SC_TASK], (long long)task_cap, h_sc[BM2_SC_POOL], (long long)pool_slots);
+        if (attempt == 5) { bm2_set_error("seeding workspace could not be sized (flags %llu)", h_sc[BM2_SC_OVF]); return BM2_ENOMEM; }
+        auto grow = [](int64_t &cap, int64_t need) { const int64_t want = need + need / 4 + 4096; if (cap < want) cap = want; };
+        grow(slot1_cap, (int64_t)h_sc[BM2_SC_SLOT1]); grow(slot2_cap, (int64_t)h_sc[BM2_SC_SLOT2]);
+        grow(rec_cap, (int64_t)h_sc[BM2_SC_REC]); grow(task_cap, (int64_t)h_sc[BM2_SC_TASK]);
+        grow(pool_slots, (int64_t)h_sc[BM2_SC_POOL]);
     }
+    if (getenv("BM2_SMEM_PROF")) {
+        static const char *nm[5] = { "walk P1", "walk P2", "walk P3", "bwd 1", "bwd 2" };
+        for (int t = 0; t < 5; t++) {
+            const unsigned long long rounds = h_sc[n_sc - 10 + 2 * t], act = h_sc[n_sc - 10 + 2 * t + 1];
+            fprintf(stderr, "[seeding] %-8s wave rounds %10llu, extensions %11llu (%.1f%% of 64 lanes)\n", nm[t], rounds, act,
+                    rounds ? 100.0 * act / (64.0 * rounds) : 0.0);
+        }
+        fprintf(stderr, "[seeding] slots %llu + %llu, records %llu, pass-2 tasks %llu, pool lists %llu\n", h_sc[BM2_SC_SLOT1],
+                h_sc[BM2_SC_SLOT2], h_sc[BM2_SC_REC], h_sc[BM2_SC_TASK], h_sc[BM2_SC_POOL]);
+    }
+    unsigned long long h_cnt[3] = { (unsigned long long)n_smem_tot, h_sc[BM2_SC_NEXT], 0 };
+    if ((rc = bm2_reserve(b->smem, (size_t)(n_smem_tot + 1) * sizeof(bm2_smem_t)))) return rc;
+    if ((rc = bm2_reserve(b->smem_tmp, (size_t)(n_smem_tot + 1) * sizeof(bm2_smem_t)))) return rc;
+    if ((rc = bm2_reserve(b->occ_cnt, (size_t)(n_smem_tot + 2) * 4))) return rc;
+    if ((rc = bm2_launch_smem_finish(c, n, sb, (const unsigned long long *)b->seedc.p, (const int32_t *)b->smem_cnt.p,
+                                     (const int64_t *)b->smem_off.p, (int32_t *)b->fill.p, (bm2_smem_t *)b->smem_tmp.p, sp.max_occ,
+                                     (bm2_smem_t *)b->smem.p, (int32_t *)b->occ_cnt.p))) return rc;
     tick(c, "smem");
     b->n_smem = (int64_t)h_cnt[0];
     b->stats.n_smem = b->n_smem; b->stats.n_ext = (int64_t)h_cnt[1];

@@ -65,161 +65,417 @@ static __device__ __forceinline__ Bi init_bi(const DevIndex &ix, int a) {     //
     return b;
 }
 
-// per-lane scratch arrays live in global memory, interleaved by lane: element i of lane t at [i * stride + t]
-struct LaneVec {
-    StSmem *base; int64_t stride; int cap; int n;
-    __device__ __forceinline__ StSmem get(int i) const { return base[(int64_t)i * stride]; }
-    __device__ __forceinline__ void set(int i, const StSmem &v) { base[(int64_t)i * stride] = v; }
+// ------------------------------------------------------------------------------------------------------------------
+// Seeding as TASK KERNELS.  The order in which mem_collect_smem finds the SMEMs of a read does not matter -- the array is
+// sorted by (rid, m, n) afterwards (bwamem.cpp:785-799) and equal (m, n) are field-identical -- so the work is cut where
+// the data dependences are, not where the reference's loops are:
+//   * the forward walk of getSMEMsOnePosOneThread (FMI_search.cpp:537-575) alone decides the next start position, so
+//     pass 1 is a chain of forward walks per read (k_walk<P1>); each walk leaves its candidate list (prev[]) as a TASK;
+//   * the backward phase (:596-665) of a start position depends only on that list (k_bwd, one task per lane); every
+//     SMEM it emits that is long and rare enough spawns a pass-2 forward walk (bwamem.cpp:695-753: k_walk<P2>, then
+//     k_bwd again);
+//   * pass 3 (bwtSeedStrategyAllPosOneThread, FMI_search.cpp:740-810) is a forward walk with a different stop rule
+//     (k_walk<P3>) and independent of the other two.
+// Every kernel is one CONVERGED LOOP over homogeneous lanes: each trip, every lane issues the two CP_OCC line loads of
+// its pending backwardExt at the same program point, so a wave keeps up to 128 independent HBM lines in flight and the
+// trip counts of different reads/walks never serialise.  Lanes pull work items from a cursor; anything a lane needs
+// from global memory between two extensions is requested one step ahead (next query window, next candidate, next work
+// item, next slot/chunk id -- the atomics return into registers nobody reads for many trips) or the lane YIELDS: it sits
+// out one extension round while the load returns behind the other lanes' CP_OCC loads.  No lane ever stalls the wave.
+#define CAPF 32                   // candidate-list entries stored in a task slot (longer lists continue in the pool)
+
+enum { W_P1 = 1, W_P2 = 2, W_P3 = 3 };
+enum { SC_P1_ITEM = 0, SC_SLOT1, SC_B1_ITEM, SC_REC, SC_TASK, SC_P2_ITEM, SC_SLOT2, SC_B2_ITEM, SC_P3_ITEM, SC_NEXT, SC_OVF_FLAG,
+       SC_POOL, SC_N };           // cursors / counters of the seeding kernels (unsigned long long each)
+enum { OVF_SLOT1 = 1, OVF_SLOT2 = 2, OVF_REC = 4, OVF_TASK = 8, OVF_POOL = 16 };
+
+struct __attribute__((aligned(16))) BHead {       // header of a backward-phase task (32 bytes)
+    int64_t rd_off;               // offset of the read in enc
+    int32_t r, L;
+    uint32_t x_np;                // start position | list length << 16
+    uint32_t mi_pass;             // min_intv (<= 65535) | pass << 16
+    int32_t pool_id;              // continuation of the list beyond CAPF entries, -1 = none
+    int32_t pad;
+};
+struct __attribute__((aligned(16))) P2Task {      // pass-2 forward walk (32 bytes)
+    int64_t rd_off;
+    int32_t r, L, x, s;
+    int64_t pad;
+};
+// Ids (work items, task slots, record / task indices) are handed out from per-wave pools: the lanes that need one at
+// the same point take consecutive ids from the wave's pool with a ballot; a pool is refilled with ONE atomic on the
+// global cursor per BATCH ids (a same-address atomic per lane and id would serialise in L2: ~10 ns each, measured).
+// Pool state lives in LDS (one [pos, end) pair per wave and allocator), because the lanes calling are a divergent subset.
+struct WavePool { volatile int64_t pos, end; };
+template <int BATCH>
+static __device__ __forceinline__ int64_t wave_alloc(WavePool *wp, unsigned long long *cursor) {
+    const unsigned long long mask = __ballot(1);
+    const int lt = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+    const int cnt = __popcll(mask);
+    const int64_t pos = wp->pos, rem = wp->end - pos;
+    if (cnt <= rem) {
+        if (lt == 0) wp->pos = pos + cnt;
+        return pos + lt;
+    }
+    unsigned long long nb = 0;
+    if (lt == 0) nb = atomicAdd(cursor, (unsigned long long)BATCH);
+    const int leader = __ffsll((long long)mask) - 1;
+    const unsigned lo = __builtin_amdgcn_readlane((unsigned)nb, leader), hi = __builtin_amdgcn_readlane((unsigned)(nb >> 32), leader);
+    const int64_t nbase = (int64_t)(((unsigned long long)hi << 32) | lo);
+    if (lt == 0) { wp->pos = nbase + (cnt - rem); wp->end = nbase + BATCH; }
+    return lt < rem ? pos + lt : nbase + (lt - rem);
+}
+#define ITEM_BATCH 64
+#define SLOT_BATCH 256
+#define REC_BATCH 256
+#define TASK_BATCH 64
+
+static __device__ __forceinline__ uint64_t load8(const uint8_t *p) { uint64_t w; __builtin_memcpy(&w, p, 8); return w; }
+
+static __device__ __forceinline__ uint4 pv_pack(int64_t k, int64_t l, int64_t s, int n) {
+    uint4 v;
+    v.x = (uint32_t)k; v.y = (uint32_t)l; v.z = (uint32_t)s;
+    v.w = (uint32_t)((k >> 32) & 31) | (uint32_t)((l >> 32) & 31) << 5 | (uint32_t)((s >> 32) & 31) << 10 | (uint32_t)n << 16;
+    return v;
+}
+static __device__ __forceinline__ void pv_unpack(const uint4 v, int64_t &k, int64_t &l, int64_t &s, int &n) {
+    k = (int64_t)v.x | (int64_t)(v.w & 31) << 32;
+    l = (int64_t)v.y | (int64_t)((v.w >> 5) & 31) << 32;
+    s = (int64_t)v.z | (int64_t)((v.w >> 10) & 31) << 32;
+    n = (int)(v.w >> 16);
+}
+
+// 8-base register window on the query with the next window (in walking direction) prefetched
+struct QWin {
+    uint64_t cur, nxt; int curb, nxtb;
+    __device__ __forceinline__ void start(const uint8_t *q, int pos, int dir) {
+        curb = dir > 0 ? pos : (pos > 7 ? pos - 7 : 0);
+        cur = load8(q + curb);
+        nxtb = dir > 0 ? curb + 8 : (curb > 8 ? curb - 8 : 0);
+        nxt = load8(q + nxtb);
+    }
+    // base `pos`; false = the window was (re)loaded, look again after yielding
+    __device__ __forceinline__ bool get(const uint8_t *q, int pos, int dir, int &base) {
+        unsigned d = (unsigned)(pos - curb);
+        if (d < 8u) { base = (int)((cur >> (8 * d)) & 0xff); return true; }
+        d = (unsigned)(pos - nxtb);
+        if (d < 8u) {
+            cur = nxt; curb = nxtb;
+            nxtb = dir > 0 ? curb + 8 : (curb > 8 ? curb - 8 : 0);
+            nxt = load8(q + nxtb);
+            base = (int)((cur >> (8 * d)) & 0xff);
+            return true;
+        }
+        start(q, pos, dir);
+        return false;
+    }
 };
 
-// one (read, start) step of getSMEMsOnePosOneThread (FMI_search.cpp:514-668); returns next_x
-static __device__ int smem_one_pos(const DevIndex &ix, const uint8_t *q, int len, int x, int64_t min_intv, int min_seed_len,
-                                   LaneVec &out, LaneVec &prev, int64_t &n_ext, int &overflow) {
-    int next_x = x + 1;
-    int a = q[x];
-    if (a >= 4) return next_x;
-    StSmem sm; sm.m = x; sm.n = x;
-    { Bi b = init_bi(ix, a); sm.k = b.k; sm.l = b.l; sm.s = b.s; }
-    int n_prev = 0, j;
-    for (j = x + 1; j < len; j++) {                                     // forward phase :537-575
-        a = q[j];
-        next_x = j + 1;
-        if (a >= 4) break;
-        Bi cur = { sm.k, sm.l, sm.s };
-        Bi nb = forward_ext(ix, cur, a); n_ext++;
-        if (nb.s != sm.s) { prev.set(n_prev, sm); n_prev++; }    // (the reference stores unconditionally and bumps the count, :556-559)
-        if (nb.s < min_intv) { next_x = j; break; }
-        sm.k = nb.k; sm.l = nb.l; sm.s = nb.s; sm.n = j;
-    }
-    if (sm.s >= min_intv) { prev.set(n_prev, sm); n_prev++; }
-    for (int p = 0; p < n_prev / 2; p++) {                              // longest first, :586-592
-        StSmem t = prev.get(p), u = prev.get(n_prev - 1 - p);
-        prev.set(p, u); prev.set(n_prev - 1 - p, t);
-    }
-    for (j = x - 1; j >= 0; j--) {                                      // backward phase :596-655
-        int n_curr = 0, p;
-        int32_t curr_s = -1;
-        a = q[j];
-        if (a > 3) break;
-        bool first_done = false;
-        for (p = 0; p < n_prev; p++) {
-            StSmem s0 = prev.get(p);
-            Bi cur = { s0.k, s0.l, s0.s };
-            Bi nb = backward_ext(ix, cur, a); n_ext++;
-            if (!first_done) {
-                if (nb.s < min_intv && (s0.n - s0.m + 1) >= min_seed_len) {
-                    if (out.n < out.cap) out.set(out.n, s0); else overflow = 1;
-                    out.n++;
-                    first_done = true;
+// ---- forward walks ----------------------------------------------------------------------------------------------
+// MODE W_P1: item = read; chain of start positions, every walk leaves a backward task.  W_P2: item = P2Task, one walk.
+// W_P3: item = read; forward-only seeding, SMEM records written directly.
+enum { F_EXT = 0, F_NEWITEM, F_START, F_NEWPOS, F_CHK, F_END, F_DONE };
+
+template <int MODE>
+__global__ void __launch_bounds__(256)
+k_walk(DevIndex ix, SeedParams sp, int n_reads, const uint8_t *__restrict__ enc, const int64_t *__restrict__ off,
+       const int32_t *__restrict__ len, const P2Task *__restrict__ tasks, int64_t task_cap,
+       BHead *__restrict__ heads, uint4 *__restrict__ ents, int64_t slot_cap, uint4 *__restrict__ pool, int pool_cap, int pool_slots,
+       bm2_smem_t *__restrict__ recs, int64_t rec_cap, int32_t *__restrict__ smem_cnt, unsigned long long *sc) {
+    int64_t n_ext = 0;
+    unsigned ovf = 0;
+    int64_t n_items;
+    if (MODE == W_P2) { n_items = (int64_t)sc[SC_TASK]; if (n_items > task_cap) n_items = task_cap; }
+    else n_items = n_reads;
+    __shared__ WavePool pools[4][2];                           // per wave: [0] work items, [1] task slots or records
+    WavePool *ip = &pools[threadIdx.x >> 6][0], *op = &pools[threadIdx.x >> 6][1];
+    if ((threadIdx.x & 63) == 0) { ip->pos = ip->end = 0; op->pos = op->end = 0; }
+    unsigned long long *item_cur = sc + (MODE == W_P1 ? SC_P1_ITEM : MODE == W_P2 ? SC_P2_ITEM : SC_P3_ITEM);
+    unsigned long long *out_cur = sc + (MODE == W_P1 ? SC_SLOT1 : MODE == W_P2 ? SC_SLOT2 : SC_REC);
+    // work items: it_a = the next item of this lane; its payload is already loaded
+    int64_t it_a = wave_alloc<ITEM_BATCH>(ip, item_cur);
+    int64_t pl_off = 0; int pl_len = 0; P2Task pl_t = {};
+    if (it_a < n_items) { if (MODE == W_P2) pl_t = tasks[it_a]; else { pl_off = off[it_a]; pl_len = len[it_a]; } }
+
+#ifdef BM2_SMEM_PROF
+    unsigned long long prof_rounds = 0, prof_active = 0;
+#endif
+    int state = F_NEWITEM;
+    int32_t r = 0; int64_t rd_off = 0; const uint8_t *q = enc; int L = 0;
+    int x = 0, next_x = 0, j = 0, a = 0, n_prev = 0, pool_id = -1;
+    int64_t min_intv = 1, slot = 0;
+    int64_t smk = 0, sml = 0, sms = 0; int smn = 0;
+    int64_t eik = 0, eil = 0, eis = 0; int ea = 0;
+    QWin w; w.cur = w.nxt = 0; w.curb = w.nxtb = -64;
+
+    auto push = [&](const uint4 v) {                          // prev[n_prev++] = sm
+        if (slot < slot_cap) {
+            if (n_prev < CAPF) ents[slot * CAPF + n_prev] = v;
+            else {
+                if (pool_id < 0) pool_id = (int)atomicAdd(&sc[SC_POOL], 1ULL);      // (a wait; lists this long are rare)
+                if (pool_id < pool_slots && n_prev - CAPF < pool_cap) pool[(int64_t)pool_id * pool_cap + (n_prev - CAPF)] = v;
+                else ovf |= OVF_POOL;
+            }
+        }
+        n_prev++;
+    };
+
+    for (;;) {
+        while (state != F_EXT && state != F_DONE) {            // `break` = yield: sit out one extension round
+            if (state == F_NEWITEM) {
+                if (it_a >= n_items) { state = F_DONE; break; }
+                if (MODE == W_P2) { r = pl_t.r; rd_off = pl_t.rd_off; L = pl_t.L; x = pl_t.x; min_intv = (int64_t)pl_t.s + 1; }
+                else { r = (int32_t)it_a; rd_off = pl_off; L = pl_len; x = 0; min_intv = 1; }
+                it_a = wave_alloc<ITEM_BATCH>(ip, item_cur);
+                if (it_a < n_items) { if (MODE == W_P2) pl_t = tasks[it_a]; else { pl_off = off[it_a]; pl_len = len[it_a]; } }
+                if (MODE == W_P2 && r < 0) break;              // padding of a task chunk: take the next item
+                q = enc + rd_off;
+                if (L <= 0) break;
+                w.start(q, x, 1);
+                state = F_NEWPOS; break;
+            }
+            if (state == F_NEWPOS) {                            // FMI_search.cpp:514-535 / :746-755
+                if (MODE != W_P2 && x >= L) { state = F_NEWITEM; continue; }
+                if (!w.get(q, x, 1, a)) break;
+                next_x = x + 1;
+                if (a >= 4) {
+                    if (MODE == W_P2) state = F_NEWITEM; else x = next_x;
                     continue;
                 }
-                if (nb.s >= min_intv && nb.s != (int64_t)curr_s) {
-                    curr_s = (int32_t)nb.s;
-                    StSmem ns = s0; ns.k = nb.k; ns.l = nb.l; ns.s = nb.s; ns.m = j;
-                    prev.set(n_curr++, ns);
-                    first_done = true;
+                const Bi b = init_bi(ix, a); smk = b.k; sml = b.l; sms = b.s; smn = x;
+                j = x + 1;
+                if (MODE != W_P3) { n_prev = 0; pool_id = -1; slot = wave_alloc<SLOT_BATCH>(op, out_cur); }
+                state = F_CHK;
+            }
+            if (state == F_CHK) {                               // :537-545 / :761-770
+                if (j >= L) state = F_END;
+                else if (!w.get(q, j, 1, a)) break;
+                else {
+                    next_x = j + 1;
+                    if (a < 4) { eik = sml; eil = smk; eis = sms; ea = 3 - a; state = F_EXT; }
+                    else state = F_END;
                 }
-            } else if (nb.s >= min_intv && nb.s != (int64_t)curr_s) {
-                curr_s = (int32_t)nb.s;
-                StSmem ns = s0; ns.k = nb.k; ns.l = nb.l; ns.s = nb.s; ns.m = j;
-                prev.set(n_curr++, ns);
+            }
+            if (state == F_END) {
+                if (MODE == W_P3) { x = next_x; state = F_NEWPOS; continue; }
+                if (sms >= min_intv) push(pv_pack(smk, sml, sms, smn));                      // :576-580
+                if (slot < slot_cap) {
+                    BHead h; h.rd_off = rd_off; h.r = r; h.L = L; h.x_np = (uint32_t)x | (uint32_t)n_prev << 16;
+                    h.mi_pass = (uint32_t)min_intv | (uint32_t)(MODE == W_P1 ? 1 : 2) << 16; h.pool_id = pool_id; h.pad = 0;
+                    heads[slot] = h;
+                } else ovf |= (MODE == W_P1 ? OVF_SLOT1 : OVF_SLOT2);
+                if (MODE == W_P1) { x = next_x; state = F_NEWPOS; } else state = F_NEWITEM;
             }
         }
-        n_prev = n_curr;
-        if (n_curr == 0) break;
-    }
-    if (n_prev != 0) {                                                  // :656-665
-        StSmem s0 = prev.get(0);
-        if ((s0.n - s0.m + 1) >= min_seed_len) {
-            if (out.n < out.cap) out.set(out.n, s0); else overflow = 1;
-            out.n++;
-        }
-    }
-    return next_x;
-}
-
-// bwtSeedStrategyAllPosOneThread for one read (FMI_search.cpp:740-810)
-static __device__ void smem_pass3(const DevIndex &ix, const uint8_t *q, int len, int64_t max_intv, int min_seed_len,
-                                  LaneVec &out, int64_t &n_ext, int &overflow) {
-    int x = 0;
-    while (x < len) {
-        int next_x = x + 1;
-        int a = q[x];
-        if (a < 4) {
-            StSmem sm; sm.m = x; sm.n = x;
-            Bi cur = init_bi(ix, a);
-            for (int j = x + 1; j < len; j++) {
-                next_x = j + 1;
-                a = q[j];
-                if (a >= 4) break;
-                cur = forward_ext(ix, cur, a); n_ext++;
-                sm.n = j;
-                if (cur.s < max_intv && (sm.n - sm.m + 1) >= min_seed_len) {
-                    if (cur.s > 0) {
-                        sm.k = cur.k; sm.l = cur.l; sm.s = cur.s;
-                        if (out.n < out.cap) out.set(out.n, sm); else overflow = 1;
-                        out.n++;
+        if (!__any(state != F_DONE)) break;
+#ifdef BM2_SMEM_PROF
+        if ((threadIdx.x & 63) == 0) prof_rounds++;
+        if (state == F_EXT) prof_active++;
+#endif
+        if (state == F_EXT) {                                   // forward = swapped backward, :546-570
+            const Bi in = { eik, eil, eis };
+            const Bi o = backward_ext(ix, in, ea); n_ext++;
+            if (MODE == W_P3) {                                 // :771-808
+                smk = o.l; sml = o.k; sms = o.s; smn = j;
+                if (sms < sp.max_mem_intv && (smn - x + 1) >= sp.min_seed_len + 1) {
+                    if (sms > 0) {
+                        const int64_t at = wave_alloc<REC_BATCH>(op, out_cur);
+                        if (at < rec_cap) {
+                            bm2_smem_t v; v.rid = (uint32_t)r; v.m = (uint32_t)x; v.n = (uint32_t)smn; v.pad = 0; v.k = smk; v.l = sml; v.s = sms;
+                            recs[at] = v;
+                            atomicAdd(&smem_cnt[r], 1);
+                        } else ovf |= OVF_REC;
                     }
-                    break;
-                }
+                    x = next_x; state = F_NEWPOS;
+                } else { j++; state = F_CHK; }
+            } else {
+                if (o.s != sms) push(pv_pack(smk, sml, sms, smn));
+                if (o.s < min_intv) { next_x = j; state = F_END; }
+                else { smk = o.l; sml = o.k; sms = o.s; smn = j; j++; state = F_CHK; }
             }
         }
-        x = next_x;
+    }
+    // close: the ids left in the wave's pool must not look like work
+    for (int64_t at = op->pos + (threadIdx.x & 63); at < op->end; at += 64) {
+        if (MODE != W_P3) { if (at < slot_cap) { BHead h = {}; h.r = -1; h.pool_id = -1; heads[at] = h; } }
+        else if (at < rec_cap) recs[at].rid = 0xffffffffu;
+    }
+    atomicAdd(&sc[SC_NEXT], (unsigned long long)n_ext);
+    if (ovf) atomicOr(&sc[SC_OVF_FLAG], (unsigned long long)ovf);
+#ifdef BM2_SMEM_PROF
+    atomicAdd(&sc[SC_N + 2 * (MODE - 1)], prof_rounds); atomicAdd(&sc[SC_N + 2 * (MODE - 1) + 1], prof_active);
+#endif
+}
+
+// ---- backward phases --------------------------------------------------------------------------------------------
+// One task = the candidate list of one start position (FMI_search.cpp:586-665).  The list stays where the walk wrote it
+// and is compacted in place: it is read top-down (longest candidate first = the reversal of :586-592), the survivors
+// of a row are written top-down behind the reader, the next candidate is requested while the current one is extended,
+// and the first survivor of a row -- the first candidate of the next row -- never leaves the registers.
+enum { B_EXT = 0, B_NEWITEM, B_FIRST, B_ROWEND, B_ROW, B_FIN, B_DONE };
+
+__global__ void __launch_bounds__(256)
+k_bwd(DevIndex ix, SeedParams sp, int pass, const uint8_t *__restrict__ enc, const BHead *__restrict__ heads,
+      uint4 *__restrict__ ents, int64_t slot_cap, uint4 *__restrict__ pool, int pool_cap, int pool_slots,
+      bm2_smem_t *__restrict__ recs, int64_t rec_cap, P2Task *__restrict__ tasks, int64_t task_cap,
+      int32_t *__restrict__ smem_cnt, unsigned long long *sc) {
+    int64_t n_ext = 0;
+    unsigned ovf = 0;
+    int64_t n_items = (int64_t)sc[pass == 1 ? SC_SLOT1 : SC_SLOT2];
+    if (n_items > slot_cap) n_items = slot_cap;
+    __shared__ WavePool pools[4][3];                           // per wave: [0] work items, [1] records, [2] pass-2 tasks
+    WavePool *ip = &pools[threadIdx.x >> 6][0], *rp = &pools[threadIdx.x >> 6][1], *tp = &pools[threadIdx.x >> 6][2];
+    if ((threadIdx.x & 63) == 0) { ip->pos = ip->end = 0; rp->pos = rp->end = 0; tp->pos = tp->end = 0; }
+    unsigned long long *item_cur = sc + (pass == 1 ? SC_B1_ITEM : SC_B2_ITEM);
+    int64_t it_a = wave_alloc<ITEM_BATCH>(ip, item_cur);
+    BHead pl = {};
+    if (it_a < n_items) pl = heads[it_a];
+
+#ifdef BM2_SMEM_PROF
+    unsigned long long prof_rounds = 0, prof_active = 0;
+#endif
+    int state = B_NEWITEM;
+    int32_t r = 0; const uint8_t *q = enc; int L = 0;
+    int x = 0, j = 0, a = 0, n_prev = 0, top = 0, n_curr = 0, p = 0, m_row = 0; int32_t curr_s = -1; bool first_done = false;
+    int32_t min_intv = 1;                                      // <= 65535 (pass 2: s + 1 with s <= split_width)
+    uint4 *lst = ents; uint4 *lpool = pool;                   // this task's list: entries [0, CAPF) and [CAPF, ...)
+    int64_t ck = 0, cl = 0, cs = 0; int cn = 0;                // the candidate being extended
+    int64_t fk = 0, fl = 0, fs = 0; int fn = 0;                // first survivor of the current row
+    uint4 nxt_raw4 = {};                                       // the candidate after the current one, requested one round ahead
+    int em = 0;                                                // an SMEM to write out: 1 = the candidate, 2 = the first survivor
+    QWin w; w.cur = w.nxt = 0; w.curb = w.nxtb = -64;
+    auto entry = [&](int idx) -> uint4 * { return idx < CAPF ? lst + idx : lpool + (idx - CAPF); };
+
+    for (;;) {
+        while (state != B_EXT && state != B_DONE) {            // `break` = yield
+            if (state == B_NEWITEM) {
+                if (it_a >= n_items) { state = B_DONE; break; }
+                const BHead h = pl;
+                const int64_t slot = it_a;
+                it_a = wave_alloc<ITEM_BATCH>(ip, item_cur);
+                if (it_a < n_items) pl = heads[it_a];
+                n_prev = (int)(h.x_np >> 16);
+                if (h.r < 0 || n_prev == 0) break;             // unused slot / empty list: take the next item
+                r = h.r; L = h.L; x = (int)(h.x_np & 0xffff); min_intv = (int32_t)(h.mi_pass & 0xffff);
+                q = enc + h.rd_off;
+                lst = ents + slot * CAPF;
+                lpool = pool + (int64_t)(h.pool_id >= 0 && h.pool_id < pool_slots ? h.pool_id : 0) * pool_cap;
+                top = n_prev - 1; j = x - 1; m_row = x;
+                nxt_raw4 = *entry(top);
+                if (j >= 0) w.start(q, j, -1);
+                state = B_FIRST; break;
+            }
+            if (state == B_FIRST) {
+                pv_unpack(nxt_raw4, fk, fl, fs, fn);
+                state = B_ROW;
+            }
+            if (state == B_ROWEND) {                            // :650-655
+                n_prev = n_curr;
+                if (n_curr == 0) state = B_FIN;
+                else { m_row = j; j--; state = B_ROW; }
+            }
+            if (state == B_ROW) {                               // :596-606
+                if (j < 0) state = B_FIN;
+                else if (!w.get(q, j, -1, a)) break;
+                else if (a > 3) state = B_FIN;
+                else {
+                    n_curr = 0; curr_s = -1; p = 0; first_done = false;
+                    ck = fk; cl = fl; cs = fs; cn = fn;
+                    if (n_prev > 1) nxt_raw4 = *entry(top - 1);
+                    state = B_EXT;
+                }
+            }
+            if (state == B_FIN) {                               // :656-665
+                if (n_prev != 0 && (fn - m_row + 1) >= sp.min_seed_len) em = 2;
+                state = B_NEWITEM;
+                if (em) break;                                  // write it out below, then look for work
+            }
+        }
+        if (!__any(state != B_DONE || em)) break;
+#ifdef BM2_SMEM_PROF
+        if ((threadIdx.x & 63) == 0) prof_rounds++;
+        if (state == B_EXT) prof_active++;
+#endif
+        if (state == B_EXT) {                                   // :607-649
+            const Bi in = { ck, cl, cs };
+            const Bi o = backward_ext(ix, in, a); n_ext++;
+            if (!first_done && o.s < (int64_t)min_intv && (cn - m_row + 1) >= sp.min_seed_len) {
+                em = 1;
+                first_done = true;
+            } else if (o.s >= (int64_t)min_intv && o.s != (int64_t)curr_s) {
+                curr_s = (int32_t)o.s;
+                if (n_curr == 0) { fk = o.k; fl = o.l; fs = o.s; fn = cn; }
+                else *entry(top - n_curr) = pv_pack(o.k, o.l, o.s, cn);
+                n_curr++;
+                first_done = true;
+            }
+        }
+        if (em) {                                               // one SMEM: record, per-read count, pass-2 task
+            const int64_t ek = em == 1 ? ck : fk, el = em == 1 ? cl : fl, es = em == 1 ? cs : fs;
+            const int en = em == 1 ? cn : fn;
+            em = 0;
+            const int64_t at = wave_alloc<REC_BATCH>(rp, sc + SC_REC);
+            if (at < rec_cap) {
+                bm2_smem_t v; v.rid = (uint32_t)r; v.m = (uint32_t)m_row; v.n = (uint32_t)en; v.pad = 0; v.k = ek; v.l = el; v.s = es;
+                recs[at] = v;
+                atomicAdd(&smem_cnt[r], 1);
+            } else ovf |= OVF_REC;
+            if (pass == 1 && (en + 1 - m_row) >= sp.split_len && es <= (int64_t)sp.split_width) {       // bwamem.cpp:701-703
+                const int64_t ta = wave_alloc<TASK_BATCH>(tp, sc + SC_TASK);
+                if (ta < task_cap) { P2Task t; t.rd_off = (int64_t)(q - enc); t.r = r; t.L = L; t.x = (en + 1 + m_row) >> 1; t.s = (int32_t)es; t.pad = 0; tasks[ta] = t; }
+                else ovf |= OVF_TASK;
+            }
+        }
+        if (state == B_EXT) {                                   // on to the next candidate of the row
+            p++;
+            if (p < n_prev) {
+                pv_unpack(nxt_raw4, ck, cl, cs, cn);
+                if (p + 1 < n_prev) nxt_raw4 = *entry(top - (p + 1));
+            } else state = B_ROWEND;
+        }
+    }
+    for (int64_t at = rp->pos + (threadIdx.x & 63); at < rp->end; at += 64) if (at < rec_cap) recs[at].rid = 0xffffffffu;
+    for (int64_t at = tp->pos + (threadIdx.x & 63); at < tp->end; at += 64) if (at < task_cap) tasks[at].r = -1;
+    atomicAdd(&sc[SC_NEXT], (unsigned long long)n_ext);
+    if (ovf) atomicOr(&sc[SC_OVF_FLAG], (unsigned long long)ovf);
+#ifdef BM2_SMEM_PROF
+    atomicAdd(&sc[SC_N + 6 + 2 * (pass - 1)], prof_rounds); atomicAdd(&sc[SC_N + 6 + 2 * (pass - 1) + 1], prof_active);
+#endif
+}
+
+// records (any order, with padding) -> the reads' segments of `tmp`
+__global__ void __launch_bounds__(256)
+k_rec_scatter(const bm2_smem_t *__restrict__ recs, int64_t rec_cap, const unsigned long long *__restrict__ sc,
+              const int64_t *__restrict__ smem_off, int32_t *__restrict__ fill, bm2_smem_t *__restrict__ tmp) {
+    int64_t n = (int64_t)sc[SC_REC];
+    if (n > rec_cap) n = rec_cap;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const bm2_smem_t v = recs[i];
+        if (v.rid == 0xffffffffu) continue;
+        tmp[smem_off[v.rid] + atomicAdd(&fill[v.rid], 1)] = v;
     }
 }
 
-// All three passes for the reads of a chunk; one read per lane, grid-stride over reads.
+// Order one read's SMEMs by (m, n) (sortSMEMs + ks_introsort(mem_intv1), bwamem.cpp:785-799; equal (m, n) are
+// field-identical, so any order among them gives the same array); `out` is dense and in read order.
 __global__ void __launch_bounds__(256)
-k_smem(DevIndex ix, SeedParams sp, int n_reads, const uint8_t *__restrict__ enc, const int64_t *__restrict__ off,
-       const int32_t *__restrict__ len, StSmem *stage, StSmem *prevbuf, int stage_cap, int prev_cap,
-       bm2_smem_t *out, int64_t out_cap, int32_t *smem_cnt, int64_t *smem_off, int32_t *occ_cnt,
-       unsigned long long *counters /* [0]=n_smem [1]=n_ext [2]=overflow */) {
-    const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
-    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int64_t n_ext = 0;
-    int overflow = 0;
-    for (int64_t r = tid; r < n_reads; r += nthreads) {
-        const uint8_t *q = enc + off[r];
-        const int L = len[r];
-        LaneVec st = { stage + tid, nthreads, stage_cap, 0 };
-        LaneVec pv = { prevbuf + tid, nthreads, prev_cap, 0 };
-        int x = 0;
-        while (x < L) x = smem_one_pos(ix, q, L, x, 1, sp.min_seed_len, st, pv, n_ext, overflow);       // pass 1
-        const int n1 = st.n < st.cap ? st.n : st.cap;
-        for (int i = 0; i < n1; i++) {                                                               // pass 2, bwamem.cpp:695-753
-            StSmem p = st.get(i);
-            const int start = p.m, end = p.n + 1;
-            if (end - start < sp.split_len || p.s > sp.split_width) continue;
-            smem_one_pos(ix, q, L, (end + start) >> 1, p.s + 1, sp.min_seed_len, st, pv, n_ext, overflow);
+k_smem_finish(int n_reads, const bm2_smem_t *__restrict__ tmp, const int32_t *__restrict__ smem_cnt,
+              const int64_t *__restrict__ smem_off, int32_t max_occ, bm2_smem_t *out, int32_t *occ_cnt) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    const int n = smem_cnt[r];
+    const int64_t o = smem_off[r];
+    const bm2_smem_t *row = tmp + o;
+    for (int i = 0; i < n; i++) {
+        const bm2_smem_t v = row[i];
+        int rank = 0;
+        for (int t = 0; t < n; t++) {
+            const uint32_t tm = row[t].m, tn = row[t].n;
+            rank += (tm < v.m || (tm == v.m && (tn < v.n || (tn == v.n && t < i)))) ? 1 : 0;
         }
-        if (sp.max_mem_intv > 0) smem_pass3(ix, q, L, sp.max_mem_intv, sp.min_seed_len + 1, st, n_ext, overflow);   // pass 3
-        int n = st.n < st.cap ? st.n : st.cap;
-        // order (m, n) ascending within the read (sortSMEMs + ks_introsort(mem_intv1), bwamem.cpp:785-799);
-        // equal (m,n) are field-identical, so any stable-or-not sort gives the same array
-        for (int i = 1; i < n; i++) {
-            StSmem v = st.get(i);
-            int j = i - 1;
-            while (j >= 0) {
-                StSmem u = st.get(j);
-                if (u.m < v.m || (u.m == v.m && u.n <= v.n)) break;
-                st.set(j + 1, u);
-                j--;
-            }
-            st.set(j + 1, v);
-        }
-        const int64_t o = (int64_t)atomicAdd(&counters[0], (unsigned long long)n);
-        smem_cnt[r] = n; smem_off[r] = o;
-        for (int i = 0; i < n; i++) {
-            StSmem v = st.get(i);
-            if (o + i < out_cap) {
-                bm2_smem_t w; w.rid = (uint32_t)r; w.m = (uint32_t)v.m; w.n = (uint32_t)v.n; w.pad = 0; w.k = v.k; w.l = v.l; w.s = v.s;
-                out[o + i] = w;
-                occ_cnt[o + i] = (int32_t)(v.s < sp.max_occ ? v.s : sp.max_occ);       // FMI_search.cpp:1280-1290
-            }
-        }
+        out[o + rank] = v;
+        occ_cnt[o + rank] = (int32_t)(v.s < max_occ ? v.s : max_occ);           // FMI_search.cpp:1280-1290
     }
-    atomicAdd(&counters[1], (unsigned long long)n_ext);
-    if (overflow) atomicAdd(&counters[2], 1ULL);
 }
 
 // positions of the sampled occurrences of every SMEM: j = k, k+step, ... (FMI_search.cpp:1280-1290)
@@ -279,12 +535,36 @@ k_smem_gather(int n_reads, const bm2_smem_t *__restrict__ in, const int64_t *__r
     for (int i = 0; i < cnt[r]; i++) out[b + i] = in[a + i];
 }
 
-int bm2_launch_smem(bm2_ctx *c, const SeedParams &sp, int n_reads, const uint8_t *enc, const int64_t *off, const int32_t *len,
-                    StSmem *stage, StSmem *prevbuf, int stage_cap, int prev_cap, int grid, bm2_smem_t *out, int64_t out_cap,
-                    int32_t *smem_cnt, int64_t *smem_off, int32_t *occ_cnt, unsigned long long *counters) {
-    hipLaunchKernelGGL(k_smem, dim3(grid), dim3(256), 0, c->stream, c->ix, sp, n_reads, enc, off, len, stage, prevbuf,
-                       stage_cap, prev_cap, out, out_cap, smem_cnt, smem_off, occ_cnt, counters);
-    return bm2_check(hipGetLastError(), "k_smem launch");
+int bm2_launch_seeding(bm2_ctx *c, const SeedParams &sp, int n_reads, const uint8_t *enc, const int64_t *off, const int32_t *len,
+                       const SeedBufs &sb, int grid_walk, int grid_bwd, int32_t *smem_cnt, unsigned long long *sc) {
+    hipStream_t s = c->stream, s3 = c->side_stream[0];
+    // pass 3 is independent of passes 1 and 2: it runs beside them
+    (void)hipEventRecord(c->ev_fork, s);
+    (void)hipStreamWaitEvent(s3, c->ev_fork, 0);
+    hipLaunchKernelGGL(k_walk<W_P3>, dim3(grid_walk), dim3(256), 0, s3, c->ix, sp, n_reads, enc, off, len, (const P2Task *)nullptr, (int64_t)0,
+                       (BHead *)nullptr, (uint4 *)nullptr, (int64_t)0, (uint4 *)nullptr, 0, 0, sb.recs, sb.rec_cap, smem_cnt, sc);
+    (void)hipEventRecord(c->ev_join[0], s3);
+    hipLaunchKernelGGL(k_walk<W_P1>, dim3(grid_walk), dim3(256), 0, s, c->ix, sp, n_reads, enc, off, len, (const P2Task *)nullptr, (int64_t)0,
+                       sb.heads1, sb.ents1, sb.slot1_cap, sb.pool, sb.pool_cap, sb.pool_slots, sb.recs, sb.rec_cap, smem_cnt, sc);
+    hipLaunchKernelGGL(k_bwd, dim3(grid_bwd), dim3(256), 0, s, c->ix, sp, 1, enc, sb.heads1, sb.ents1, sb.slot1_cap, sb.pool, sb.pool_cap,
+                       sb.pool_slots, sb.recs, sb.rec_cap, sb.tasks, sb.task_cap, smem_cnt, sc);
+    hipLaunchKernelGGL(k_walk<W_P2>, dim3(grid_walk), dim3(256), 0, s, c->ix, sp, n_reads, enc, off, len, sb.tasks, sb.task_cap,
+                       sb.heads2, sb.ents2, sb.slot2_cap, sb.pool, sb.pool_cap, sb.pool_slots, sb.recs, sb.rec_cap, smem_cnt, sc);
+    hipLaunchKernelGGL(k_bwd, dim3(grid_bwd), dim3(256), 0, s, c->ix, sp, 2, enc, sb.heads2, sb.ents2, sb.slot2_cap, sb.pool, sb.pool_cap,
+                       sb.pool_slots, sb.recs, sb.rec_cap, sb.tasks, sb.task_cap, smem_cnt, sc);
+    (void)hipStreamWaitEvent(s, c->ev_join[0], 0);
+    return bm2_check(hipGetLastError(), "seeding launch");
+}
+int bm2_launch_smem_finish(bm2_ctx *c, int n_reads, const SeedBufs &sb, const unsigned long long *sc, const int32_t *smem_cnt,
+                           const int64_t *smem_off, int32_t *fill, bm2_smem_t *tmp, int32_t max_occ, bm2_smem_t *out, int32_t *occ_cnt) {
+    if (n_reads <= 0) return BM2_OK;
+    hipLaunchKernelGGL(k_rec_scatter, dim3(c->n_cu * 8), dim3(256), 0, c->stream, sb.recs, sb.rec_cap, sc, smem_off, fill, tmp);
+    hipLaunchKernelGGL(k_smem_finish, dim3((n_reads + 255) / 256), dim3(256), 0, c->stream, n_reads, tmp, smem_cnt, smem_off, max_occ, out, occ_cnt);
+    return bm2_check(hipGetLastError(), "k_smem_finish launch");
+}
+int bm2_seed_sizes(size_t *head, size_t *ent, size_t *task, int *n_sc) {
+    *head = sizeof(BHead); *ent = (size_t)CAPF * 16; *task = sizeof(P2Task); *n_sc = SC_N + 10;
+    return CAPF;
 }
 int bm2_launch_sal_expand(bm2_ctx *c, const bm2_smem_t *smems, int64_t n_smem, const int64_t *sa_off, int32_t max_occ, int64_t *pos) {
     if (n_smem <= 0) return BM2_OK;
