@@ -87,6 +87,16 @@ static void free_streams(bm2_ctx *c) {
     if (c->stream) (void)hipStreamDestroy(c->stream);
 }
 
+// CP_OCC file layout -> device layout (bm2_dev.h), in place: one entry per lane
+__global__ void __launch_bounds__(256) k_cp_occ_relayout(CpOcc *occ, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const CpOcc e = occ[i];
+    CpOccDev d;
+    for (int b = 0; b < 4; b++) { d.q[b].count = e.cp_count[b]; d.q[b].bwt = e.bwt[b]; }
+    ((CpOccDev *)occ)[i] = d;
+}
+
 extern "C" bm2_ctx *bm2_create(int device, const bm2_index_desc *idx) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
@@ -105,6 +115,10 @@ extern "C" bm2_ctx *bm2_create(int device, const bm2_index_desc *idx) {
         const int64_t nocc = (idx->ref_len >> 6) + 1, nsa = (idx->ref_len >> 3) + 1;
         int rc = 0;
         rc = rc ? rc : upload(&c->d_cp_occ, (const CpOcc *)idx->cp_occ, (size_t)nocc, c->stream);
+        if (!rc) {
+            hipLaunchKernelGGL(k_cp_occ_relayout, dim3((unsigned)((nocc + 255) / 256)), dim3(256), 0, c->stream, (CpOcc *)c->d_cp_occ, nocc);
+            rc = bm2_check(hipGetLastError(), "k_cp_occ_relayout");
+        }
         rc = rc ? rc : upload(&c->d_sa_ms, idx->sa_ms_byte, (size_t)nsa, c->stream);
         rc = rc ? rc : upload(&c->d_sa_ls, idx->sa_ls_word, (size_t)nsa, c->stream);
         rc = rc ? rc : upload(&c->d_ref, idx->ref_string, (size_t)(2 * idx->l_pac), c->stream);
@@ -114,7 +128,7 @@ extern "C" bm2_ctx *bm2_create(int device, const bm2_index_desc *idx) {
         rc = rc ? rc : bm2_check(hipStreamSynchronize(c->stream), "index upload");
         if (rc) { bm2_destroy(c); return nullptr; }
         DevIndex &ix = c->ix;
-        ix.cp_occ = (const CpOcc *)c->d_cp_occ; ix.sa_ms_byte = (const int8_t *)c->d_sa_ms;
+        ix.cp_occ = (const CpOccDev *)c->d_cp_occ; ix.sa_ms_byte = (const int8_t *)c->d_sa_ms;
         ix.sa_ls_word = (const uint32_t *)c->d_sa_ls; ix.ref_string = (const uint8_t *)c->d_ref;
         ix.ann_offset = (const int64_t *)c->d_ann_off; ix.ann_len = (const int32_t *)c->d_ann_len;
         ix.ann_is_alt = (const int32_t *)c->d_ann_alt;

@@ -8,14 +8,20 @@
 #define BM2_BLOCK_READS 512          // BATCH_SIZE of the reference (macro.h:48): the kt_for block (kthread.cpp:53-78)
 #define BM2_H0 (-99)                 // H0_ (macro.h:44)
 
-// CP_OCC (FMI_search.h:54-58): Occ checkpoint per 64 BWT symbols; exactly one 64-byte HBM line.
+// CP_OCC (FMI_search.h:54-58): Occ checkpoint per 64 BWT symbols; exactly one 64-byte HBM line.  This is the layout of
+// the index FILE and of bm2_index_desc; bm2_create re-lays every entry in HBM as CpOccDev.
 struct __attribute__((aligned(64))) CpOcc {
     int64_t  cp_count[4];
     uint64_t bwt[4];                 // bit 63 = first symbol of the block (FMI_search.cpp:234-246)
 };
+// Device layout: the same 64 bytes, interleaved per base -- quarter b = { cp_count[b], bwt[b] } -- so that the four lanes
+// of a quad fetch one entry with ONE coalesced 64-byte request, lane b getting exactly what the rank of base b needs.
+struct __attribute__((aligned(64))) CpOccDev {
+    struct { int64_t count; uint64_t bwt; } q[4];
+};
 
 struct DevIndex {
-    const CpOcc    *cp_occ;
+    const CpOccDev *cp_occ;
     const int8_t   *sa_ms_byte;
     const uint32_t *sa_ls_word;
     const uint8_t  *ref_string;      // .0123: forward then reverse complement, one base per byte

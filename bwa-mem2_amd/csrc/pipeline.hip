@@ -50,6 +50,7 @@ struct Batch {
     std::vector<int32_t> h_len;              // host copy of the read lengths (per-read filter thresholds)
     DevBuf min_hsp, seed_owner, seed_keep, mat25;
     DevBuf heads1, ents1, heads2, ents2, pool, recs, tasks, seedc, fill, smem_tmp;     // seeding task kernels
+    int64_t seed_cap[5] = { 0, 0, 0, 0, 0 };   // learned workspace sizes: slots pass 1/2, records, pass-2 tasks, pool lists
 };
 
 void bm2_batch_destroy(bm2_ctx *c) {
@@ -170,9 +171,10 @@ static int run_seeding(bm2_ctx *c, Batch *b, const bm2_opt *opt, bool with_sal) 
     const int capf = bm2_seed_sizes(&head_sz, &ent_sz, &task_sz, &n_sc);
     SeedBufs sb;
     sb.pool_cap = b->max_len + 2 > capf ? b->max_len + 2 - capf : 1;
-    int64_t slot1_cap = (int64_t)(b->heads1.cap / head_sz), slot2_cap = (int64_t)(b->heads2.cap / head_sz);
-    int64_t rec_cap = (int64_t)(b->recs.cap / sizeof(bm2_smem_t)), task_cap = (int64_t)(b->tasks.cap / task_sz);
-    int64_t pool_slots = (int64_t)(b->pool.cap / ((size_t)sb.pool_cap * 16));
+    // (the learned sizes are kept as counts: deriving them from the buffers' byte capacities would make every buffer chase
+    //  the slack of the others)
+    int64_t &slot1_cap = b->seed_cap[0], &slot2_cap = b->seed_cap[1], &rec_cap = b->seed_cap[2], &task_cap = b->seed_cap[3],
+            &pool_slots = b->seed_cap[4];
     if (slot1_cap < (int64_t)n * 6 + lanes * 4 + 4096) slot1_cap = (int64_t)n * 6 + lanes * 4 + 4096;
     if (slot2_cap < (int64_t)n * 6 + lanes * 4 + 4096) slot2_cap = (int64_t)n * 6 + lanes * 4 + 4096;
     if (rec_cap < (int64_t)n * 24 + lanes * 12 + 4096) rec_cap = (int64_t)n * 24 + lanes * 12 + 4096;      // + the pool tails: 3 kernels x 256 / wave
@@ -210,7 +212,7 @@ static int run_seeding(bm2_ctx *c, Batch *b, const bm2_opt *opt, bool with_sal) 
         if ((rc = bm2_check(hipStreamSynchronize(s), "seeding kernels"))) return rc;
         if (verbose) { fprintf(stderr, "[seeding] kernels+scan %.1f ms\n", now_ms() - t0); t0 = now_ms(); }
         if (!h_sc[BM2_SC_OVF]) break;
-        if (getenv("BM2_VERBOSE"))
+        if (getenv("BM2_VERBOSE") || getenv("BM2_WARN_RETRY"))
             fprintf(stderr, "[seeding] attempt %d overflowed (flags %llu): slots %llu/%lld + %llu/%lld, records %llu/%lld, tasks %llu/%lld, pool %llu/%lld\n",
                     attempt, h_sc[BM2_SC_OVF], h_sc[BM2_SC_SLOT1], (long long)slot1_cap, h_sc[BM2_SC_SLOT2], (long long)slot2_cap,
                     h_sc[BM2_SC_REC], (long long)rec_cap, h_sc[BM2_SC_TASK], (long long)task_cap, h_sc[BM2_SC_POOL], (long long)pool_slots);
@@ -234,6 +236,7 @@ static int run_seeding(bm2_ctx *c, Batch *b, const bm2_opt *opt, bool with_sal) 
     if ((rc = bm2_reserve(b->smem, (size_t)(n_smem_tot + 1) * sizeof(bm2_smem_t)))) return rc;
     if ((rc = bm2_reserve(b->smem_tmp, (size_t)(n_smem_tot + 1) * sizeof(bm2_smem_t)))) return rc;
     if ((rc = bm2_reserve(b->occ_cnt, (size_t)(n_smem_tot + 2) * 4))) return rc;
+    if (verbose) { fprintf(stderr, "[seeding] output reserve %.1f ms (n_smem %lld, caps %zu %zu %zu)\n", now_ms() - t0, (long long)n_smem_tot, b->smem.cap, b->smem_tmp.cap, b->occ_cnt.cap); t0 = now_ms(); }
     if ((rc = bm2_launch_smem_finish(c, n, sb, (const unsigned long long *)b->seedc.p, (const int32_t *)b->smem_cnt.p,
                                      (const int64_t *)b->smem_off.p, (int32_t *)b->fill.p, (bm2_smem_t *)b->smem_tmp.p, sp.max_occ,
                                      (bm2_smem_t *)b->smem.p, (int32_t *)b->occ_cnt.p))) return rc;

@@ -19,41 +19,72 @@ static __device__ __forceinline__ int64_t pick4(int a, int64_t c0, int64_t c1, i
 }
 
 struct Blk { uint64_t w[8]; };   // cp_count[0..3], bwt[0..3]
-static __device__ __forceinline__ Blk load_blk(const CpOcc *p) {
+static __device__ __forceinline__ Blk load_blk(const CpOccDev *p) {              // (whole entry, de-interleaved: k_sal)
     const ulonglong2 *q = (const ulonglong2 *)p;
     ulonglong2 a = q[0], b = q[1], c = q[2], d = q[3];
-    Blk r; r.w[0] = a.x; r.w[1] = a.y; r.w[2] = b.x; r.w[3] = b.y; r.w[4] = c.x; r.w[5] = c.y; r.w[6] = d.x; r.w[7] = d.y;
+    Blk r; r.w[0] = a.x; r.w[4] = a.y; r.w[1] = b.x; r.w[5] = b.y; r.w[2] = c.x; r.w[6] = c.y; r.w[3] = d.x; r.w[7] = d.y;
     return r;
 }
 
-// FMI_search::backwardExt (FMI_search.cpp:1025-1052) with GET_OCC (FMI_search.h:66-73)
-static __device__ __forceinline__ Bi backward_ext(const DevIndex &ix, Bi in, int a) {
-    const int64_t sp = in.k, ep = in.k + in.s;
-    const Blk b1 = load_blk(&ix.cp_occ[sp >> 6]);
-    const Blk b2 = load_blk(&ix.cp_occ[ep >> 6]);
-    const int y1 = (int)(sp & 63), y2 = (int)(ep & 63);
-    const uint64_t m1 = y1 ? (~0ULL << (64 - y1)) : 0ULL, m2 = y2 ? (~0ULL << (64 - y2)) : 0ULL;   // one_hot_mask_array[y]
-    int64_t o1[4], d[4];
-#pragma unroll
-    for (int b = 0; b < 4; b++) {
-        o1[b] = (int64_t)b1.w[b] + __popcll(b1.w[4 + b] & m1);
-        const int64_t o2 = (int64_t)b2.w[b] + __popcll(b2.w[4 + b] & m2);
-        d[b] = o2 - o1[b];
-    }
-    const int64_t sent = (in.k <= ix.sentinel_index && ep > ix.sentinel_index) ? 1 : 0;
-    const int64_t l3 = in.l + sent, l2 = l3 + d[3], l1 = l2 + d[2], l0 = l1 + d[1];
-    Bi out;
-    out.k = pick4(a, ix.count[0] + o1[0], ix.count[1] + o1[1], ix.count[2] + o1[2], ix.count[3] + o1[3]);
-    out.l = pick4(a, l0, l1, l2, l3);
-    out.s = pick4(a, d[0], d[1], d[2], d[3]);
-    return out;
+// quad helpers (DPP quad_perm; every lane of the quad must be active)
+template <int CTRL> static __device__ __forceinline__ int32_t qperm32(int32_t v) {
+    return __builtin_amdgcn_mov_dpp(v, CTRL, 0xf, 0xf, false);
+}
+template <int CTRL> static __device__ __forceinline__ int64_t qperm64(int64_t v) {
+    const int32_t lo = qperm32<CTRL>((int32_t)(uint32_t)v), hi = qperm32<CTRL>((int32_t)(v >> 32));
+    return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+}
+template <int T> static __device__ __forceinline__ int64_t qbcast64(int64_t v) { return qperm64<T | T << 2 | T << 4 | T << 6>(v); }
+template <int T> static __device__ __forceinline__ int32_t qbcast32(int32_t v) { return qperm32<T | T << 2 | T << 4 | T << 6>(v); }
+static __device__ __forceinline__ int64_t qsum64(int64_t v) {                     // sum over the quad, in every lane
+    v += qperm64<0xB1>(v);           // [1,0,3,2]
+    v += qperm64<0x4E>(v);           // [2,3,0,1]
+    return v;
 }
 
-// forward extension = backward extension of the swapped interval by the complement (FMI_search.cpp:546-554)
-static __device__ __forceinline__ Bi forward_ext(const DevIndex &ix, Bi in, int a) {
-    Bi sw = { in.l, in.k, in.s };
-    Bi r = backward_ext(ix, sw, 3 - a);
-    Bi out = { r.l, r.k, r.s };
+// FMI_search::backwardExt (FMI_search.cpp:1025-1052) with GET_OCC (FMI_search.h:66-73), QUAD-COOPERATIVE: the wave
+// must be converged; lanes with want == false take part in the exchange and get garbage back.
+// For each of the four lanes t of a quad in turn, the quad fetches the two CP_OCC entries lane t needs -- lane b loads
+// quarter b -- so that one load instruction touches 16 lines (and 16 pages) per wave, not 64: with one entry per lane
+// the address-translation rate caps the kernel at ~22 G lines/s once the index exceeds ~3 GB; fetched by quads the same
+// hardware delivers ~50 G lines/s (tools/ubench/randline.hip).  Lane b then ranks base b at both ends of the interval,
+// and three quad sums hand lane t what it needs: occ(a, k), the size d[a], and the sizes of the bases above a.
+template <int T>
+static __device__ __forceinline__ void coop_issue(const DevIndex &ix, int64_t k, int64_t s, int want, int sub, ulonglong2 &e1, ulonglong2 &e2) {
+    const int64_t sp = qbcast64<T>(k), ep = sp + qbcast64<T>(s);
+    e1 = make_ulonglong2(0, 0); e2 = e1;
+    if (qbcast32<T>(want)) {         // (a quad whose lane T has nothing pending loads nothing: idle lanes must not all hit one line)
+        e1 = ((const ulonglong2 *)&ix.cp_occ[sp >> 6])[sub];
+        e2 = ((const ulonglong2 *)&ix.cp_occ[ep >> 6])[sub];
+    }
+}
+template <int T>
+static __device__ __forceinline__ void coop_rank(int64_t k, int64_t s, int a, int sub, const ulonglong2 e1, const ulonglong2 e2,
+                                                 int64_t &X, int64_t &Y, int64_t &Z) {
+    const int64_t sp = qbcast64<T>(k), ep = sp + qbcast64<T>(s);
+    const int at = qbcast32<T>(a);
+    const int y1 = (int)(sp & 63), y2 = (int)(ep & 63);
+    const uint64_t m1 = y1 ? (~0ULL << (64 - y1)) : 0ULL, m2 = y2 ? (~0ULL << (64 - y2)) : 0ULL;   // one_hot_mask_array[y]
+    const int64_t o1 = (int64_t)e1.x + __popcll(e1.y & m1);
+    const int64_t d = (int64_t)e2.x + __popcll(e2.y & m2) - o1;
+    const int64_t x = qsum64(sub == at ? o1 : 0), y = qsum64(sub == at ? d : 0), z = qsum64(sub > at ? d : 0);
+    if (sub == T) { X = x; Y = y; Z = z; }
+}
+static __device__ __forceinline__ Bi backward_ext(const DevIndex &ix, Bi in, int a, bool want) {
+    const int sub = (int)(threadIdx.x & 3);
+    const int64_t k = want ? in.k : 0, s = want ? in.s : 0;
+    ulonglong2 e1[4], e2[4];
+    const int w = want ? 1 : 0;
+    coop_issue<0>(ix, k, s, w, sub, e1[0], e2[0]); coop_issue<1>(ix, k, s, w, sub, e1[1], e2[1]);
+    coop_issue<2>(ix, k, s, w, sub, e1[2], e2[2]); coop_issue<3>(ix, k, s, w, sub, e1[3], e2[3]);
+    int64_t X = 0, Y = 0, Z = 0;
+    coop_rank<0>(k, s, a, sub, e1[0], e2[0], X, Y, Z); coop_rank<1>(k, s, a, sub, e1[1], e2[1], X, Y, Z);
+    coop_rank<2>(k, s, a, sub, e1[2], e2[2], X, Y, Z); coop_rank<3>(k, s, a, sub, e1[3], e2[3], X, Y, Z);
+    const int64_t sent = (k <= ix.sentinel_index && k + s > ix.sentinel_index) ? 1 : 0;
+    Bi out;
+    out.k = pick4(a, ix.count[0], ix.count[1], ix.count[2], ix.count[3]) + X;
+    out.l = in.l + sent + Z;
+    out.s = Y;
     return out;
 }
 
@@ -272,9 +303,10 @@ k_walk(DevIndex ix, SeedParams sp, int n_reads, const uint8_t *__restrict__ enc,
         if ((threadIdx.x & 63) == 0) prof_rounds++;
         if (state == F_EXT) prof_active++;
 #endif
+        const Bi ein = { eik, eil, eis };
+        const Bi o = backward_ext(ix, ein, ea, state == F_EXT);   // (all lanes: quad-cooperative)
         if (state == F_EXT) {                                   // forward = swapped backward, :546-570
-            const Bi in = { eik, eil, eis };
-            const Bi o = backward_ext(ix, in, ea); n_ext++;
+            n_ext++;
             if (MODE == W_P3) {                                 // :771-808
                 smk = o.l; sml = o.k; sms = o.s; smn = j;
                 if (sms < sp.max_mem_intv && (smn - x + 1) >= sp.min_seed_len + 1) {
@@ -396,9 +428,10 @@ k_bwd(DevIndex ix, SeedParams sp, int pass, const uint8_t *__restrict__ enc, con
         if ((threadIdx.x & 63) == 0) prof_rounds++;
         if (state == B_EXT) prof_active++;
 #endif
+        const Bi ein = { ck, cl, cs };
+        const Bi o = backward_ext(ix, ein, a, state == B_EXT);    // (all lanes: quad-cooperative)
         if (state == B_EXT) {                                   // :607-649
-            const Bi in = { ck, cl, cs };
-            const Bi o = backward_ext(ix, in, a); n_ext++;
+            n_ext++;
             if (!first_done && o.s < (int64_t)min_intv && (cn - m_row + 1) >= sp.min_seed_len) {
                 em = 1;
                 first_done = true;
