@@ -201,15 +201,110 @@ static __device__ void lane_dp(bool run, int qlen, int tlen, int w, int h0, cons
     if (run) { out.score = maxv; out.qle = max_j + 1; out.tle = max_i + 1; out.gtle = max_ie + 1; out.gscore = gscore; out.max_off = max_off; }
 }
 
-template <int SIDE>
+// The same recurrence with the row packed 8+8 bits: usable when no score of the batch can exceed 255 (l_query * a <= 255,
+// i.e. every short-read run with the default scoring).  Two columns share one LDS dword -- {H[j], E[j], H[j+1], E[j+1]}
+// -- and the query sits 8 bases to a dword, so a cell costs half an LDS read and half an LDS write instead of two reads
+// and a write, and a wave's rows take 2.6x less LDS: 6 instead of 3 wavefronts per CU for 150-base queries.
+static __device__ void lane_dp8(bool run, int qlen, int tlen, int w, int h0, const uint8_t *tp, int ts, const SwParams &P,
+                                uint32_t *EH, const uint32_t *QL, int lane, LaneOut &out, long long &cells) {
+    const int o_del = P.o_del, e_del = P.e_del, o_ins = P.o_ins, e_ins = P.e_ins, oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
+    const int sc_match = P.mat[0], sc_mis = P.mat[1], sc_amb = P.mat[4];
+    const int e1 = h0 > oe_ins ? h0 - oe_ins : 0;                // first row, bandedSWA.cpp:143-145
+    const int maxq = __builtin_amdgcn_readlane(wave_scan_max(run ? qlen : 0, 0), 63);
+    for (int jp = 0; jp <= maxq; jp += 2) {
+        if (run && jp <= qlen) {
+            const uint32_t v0 = (uint32_t)(jp == 0 ? h0 : imax(e1 - (jp - 1) * e_ins, 0));
+            const uint32_t v1 = jp + 1 <= qlen ? (uint32_t)imax(e1 - jp * e_ins, 0) : 0u;
+            EH[(jp >> 1) * 64 + lane] = v0 | v1 << 16;
+        }
+    }
+    int beg = 0, end = qlen, maxv = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0;
+    bool alive = run && tlen > 0;
+    const int maxt = __builtin_amdgcn_readlane(wave_scan_max(alive ? tlen : 0, 0), 63);
+    int t_next = alive ? (int)tp[0] : 4;
+    for (int i = 0; i < maxt; ++i) {
+        if (!__ballot(alive)) break;
+        const int tb = t_next;
+        if (alive && i + 1 < tlen) t_next = (int)tp[(int64_t)(i + 1) * ts];
+        int h1 = 0, f = 0, m = 0, mj = -1, fnz = -1, lnz = -1;
+        if (alive) {
+            if (beg < i - w) beg = i - w;
+            if (end > i + w + 1) end = i + w + 1;
+            if (end > qlen) end = qlen;
+            if (beg == 0) { h1 = h0 - (o_del + e_del * (i + 1)); if (h1 < 0) h1 = 0; }
+            cells += imax(end - beg, 0);
+        }
+        const int s_eq = tb > 3 ? sc_amb : sc_match;
+        const int jlo = (1 << 20) - __builtin_amdgcn_readlane(wave_scan_max(alive ? (1 << 20) - beg : 0, 0), 63);
+        const int jhi = __builtin_amdgcn_readlane(wave_scan_max(alive ? end : 0, 0), 63);
+        uint32_t qw = 0;
+        for (int jp = jlo & ~1; jp < jhi; jp += 2) {
+            if ((jp & 7) == 0 || jp == (jlo & ~1)) qw = QL[(jp >> 3) * 64 + lane] >> (4 * (jp & 7));
+            if (alive && jp + 1 >= beg && jp < end) {
+                uint32_t word = EH[(jp >> 1) * 64 + lane];
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const int j = jp + u;
+                    if (j >= beg && j < end) {
+                        const int qb = (int)((qw >> (4 * u)) & 15u);
+                        const int e = (int)((word >> (16 * u + 8)) & 0xffu);
+                        int M = (int)((word >> (16 * u)) & 0xffu);
+                        const int sc = (qb == tb && tb < 4) ? s_eq : ((qb > 3 || tb > 3) ? sc_amb : sc_mis);
+                        M = M ? M + sc : 0;
+                        int h = M > e ? M : e;
+                        h = h > f ? h : f;
+                        mj = m > h ? mj : j;
+                        m = m > h ? m : h;
+                        const int en = imax(imax(e - e_del, M - oe_del), 0);
+                        f = imax(imax(f - e_ins, M - oe_ins), 0);
+                        const uint32_t nw = (uint32_t)h1 | ((uint32_t)en << 8);
+                        word = (word & ~(0xffffu << (16 * u))) | nw << (16 * u);
+                        if (nw) { lnz = j; if (fnz < 0) fnz = j; }
+                        h1 = h;
+                    }
+                }
+                EH[(jp >> 1) * 64 + lane] = word;
+            }
+            qw >>= 8;
+        }
+        if (alive) {
+            uint32_t word = EH[(end >> 1) * 64 + lane];                // eh[end] = {h1, 0}, bandedSWA.cpp:201
+            word = (word & ~(0xffffu << (16 * (end & 1)))) | (uint32_t)h1 << (16 * (end & 1));
+            EH[(end >> 1) * 64 + lane] = word;
+            if (h1) lnz = end;
+            const int jfin = beg < end ? end : beg;
+            if (jfin == qlen) { max_ie = gscore > h1 ? max_ie : i; gscore = gscore > h1 ? gscore : h1; }
+            if (m == 0) alive = false;
+            else {
+                if (m > maxv) {
+                    maxv = m; max_i = i; max_j = mj;
+                    const int d = mj - i;
+                    max_off = imax(max_off, d < 0 ? -d : d);
+                } else if (P.zdrop > 0) {
+                    if (i - max_i > mj - max_j) { if (maxv - m - ((i - max_i) - (mj - max_j)) * e_del > P.zdrop) alive = false; }
+                    else { if (maxv - m - ((mj - max_j) - (i - max_i)) * e_ins > P.zdrop) alive = false; }
+                }
+                const int nb = fnz >= 0 ? fnz : end;
+                const int jl = imax(lnz, nb - 1);
+                beg = nb;
+                end = jl + 2 < qlen ? jl + 2 : qlen;
+                if (i + 1 >= tlen) alive = false;
+            }
+        }
+    }
+    if (run) { out.score = maxv; out.qle = max_j + 1; out.tle = max_i + 1; out.gtle = max_ie + 1; out.gscore = gscore; out.max_off = max_off; }
+}
+
+template <int SIDE, bool P8>
 __global__ void __launch_bounds__(64)
 k_ext_lanes(DevIndex ix, ExtParams xp, const int32_t *__restrict__ tasks, int n_tasks, int qmax,
             const uint8_t *__restrict__ enc, const int64_t *__restrict__ off, const int32_t *__restrict__ len,
             const int64_t *__restrict__ slot_base, const int32_t *__restrict__ reg_seed, const int32_t *__restrict__ reg_chain,
             const DevChain *__restrict__ chn, const DevSeed *__restrict__ seeds, DevReg *regs, unsigned long long *counters) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_l[];
-    uint32_t *EH = lds_l;                                       // [(qmax+1)][64]
-    uint8_t *QL = (uint8_t *)(lds_l + (size_t)(qmax + 1) * 64); // [qmax][64]
+    uint32_t *EH = lds_l;                                       // [(qmax+1)][64]           (P8: [(qmax+2)/2][64])
+    uint8_t *QL = (uint8_t *)(lds_l + (size_t)(qmax + 1) * 64); // [qmax][64] bytes
+    uint32_t *QL8 = lds_l + (size_t)((qmax + 2) / 2) * 64;      // P8: [(qmax+7)/8][64] dwords, 8 bases of 4 bits each
     const int lane = threadIdx.x;
     const int idx = blockIdx.x * 64 + lane;
     const bool valid = idx < n_tasks;
@@ -230,7 +325,17 @@ k_ext_lanes(DevIndex ix, ExtParams xp, const int32_t *__restrict__ tasks, int n_
     }
     // stage the query bases
     const int maxq = __builtin_amdgcn_readlane(wave_scan_max(valid ? tg.len2 : 0, 0), 63);
-    for (int j = 0; j < maxq; j++) if (valid && j < tg.len2) QL[j * 64 + lane] = tg.q[(int64_t)j * tg.qs];
+    if (!P8) {
+        for (int j = 0; j < maxq; j++) if (valid && j < tg.len2) QL[j * 64 + lane] = tg.q[(int64_t)j * tg.qs];
+    } else {
+        for (int j0 = 0; j0 < maxq; j0 += 8) {
+            if (valid && j0 < tg.len2) {
+                uint32_t wq = 0;
+                for (int u = 0; u < 8 && j0 + u < tg.len2; u++) wq |= (uint32_t)(tg.q[(int64_t)(j0 + u) * tg.qs] & 15) << (4 * u);
+                QL8[(j0 >> 3) * 64 + lane] = wq;
+            }
+        }
+    }
     const int cls = pair_class(tg.len1, tg.len2, h0, P.max_sc);
     LaneOut o; o.score = h0; o.qle = o.tle = o.gtle = 0; o.gscore = -1; o.max_off = 0;
     long long cells = 0;
@@ -240,7 +345,8 @@ k_ext_lanes(DevIndex ix, ExtParams xp, const int32_t *__restrict__ tasks, int n_
         if (!__ballot(run)) break;
         const int w = xp.w << t;
         const int wc = band_clamp(w, tg.len2, P, cls);
-        lane_dp(run, tg.len2, tg.len1, wc, h0, tg.t, tg.ts, P, EH, QL, lane, o, cells);
+        if (P8) lane_dp8(run, tg.len2, tg.len1, wc, h0, tg.t, tg.ts, P, EH, QL8, lane, o, cells);
+        else lane_dp(run, tg.len2, tg.len1, wc, h0, tg.t, tg.ts, P, EH, QL, lane, o, cells);
         if (run) {
             w_used = w;
             if (o.score == prev || o.max_off < (w >> 1) + (w >> 2) || t + 1 == MAX_BAND_TRY) run = false;
@@ -542,7 +648,7 @@ static int ring_size2(int w) { int R = 64; while (R < 2 * w + 4) R <<= 1; return
 struct ExtLaunch {
     bm2_ctx *c; hipStream_t s; ExtParams xp; const uint8_t *enc; const int64_t *off; const int32_t *len; const int64_t *slot_base;
     const int32_t *reg_seed, *reg_chain; const DevChain *chn; const DevSeed *seeds; DevReg *regs; unsigned long long *counters;
-    int R; size_t lds_w;
+    int R; size_t lds_w; bool pack8;
 };
 
 // Left side, then right side (whose h0 is the left score).  Lane-per-task kernels per query-length class (each class needs
@@ -569,13 +675,12 @@ static int run_sides(const ExtLaunch &L, const uint32_t *h_hist, const uint32_t 
             if (!n) continue;
             (void)hipStreamWaitEvent(sk, c->ev_fork, 0);
             if (k < N_CLS) {
-                const size_t lds = (size_t)(hi + 1) * 64 * 4 + (size_t)hi * 64;
-                if (side == 0)
-                    hipLaunchKernelGGL(k_ext_lanes<0>, dim3((n + 63) / 64), dim3(64), lds, sk, c->ix, L.xp, tasks + first, (int)n, hi, L.enc, L.off, L.len,
-                                       L.slot_base, L.reg_seed, L.reg_chain, L.chn, L.seeds, L.regs, L.counters);
-                else
-                    hipLaunchKernelGGL(k_ext_lanes<1>, dim3((n + 63) / 64), dim3(64), lds, sk, c->ix, L.xp, tasks + first, (int)n, hi, L.enc, L.off, L.len,
-                                       L.slot_base, L.reg_seed, L.reg_chain, L.chn, L.seeds, L.regs, L.counters);
+                const size_t lds = L.pack8 ? (size_t)((hi + 2) / 2) * 64 * 4 + (size_t)((hi + 7) / 8) * 64 * 4
+                                           : (size_t)(hi + 1) * 64 * 4 + (size_t)hi * 64;
+                auto kern = side == 0 ? (L.pack8 ? k_ext_lanes<0, true> : k_ext_lanes<0, false>)
+                                      : (L.pack8 ? k_ext_lanes<1, true> : k_ext_lanes<1, false>);
+                hipLaunchKernelGGL(kern, dim3((n + 63) / 64), dim3(64), lds, sk, c->ix, L.xp, tasks + first, (int)n, hi, L.enc, L.off, L.len,
+                                   L.slot_base, L.reg_seed, L.reg_chain, L.chn, L.seeds, L.regs, L.counters);
             } else {
                 if (side == 0) hipLaunchKernelGGL(k_ext_wave<0>, dim3((n + 3) / 4), dim3(256), L.lds_w, sk, c->ix, L.xp, tasks + first, (int)n, L.enc, L.off, L.len, L.slot_base, L.reg_seed, L.reg_chain, L.chn, L.seeds, L.regs, L.R, L.counters);
                 else hipLaunchKernelGGL(k_ext_wave<1>, dim3((n + 3) / 4), dim3(256), L.lds_w, sk, c->ix, L.xp, tasks + first, (int)n, L.enc, L.off, L.len, L.slot_base, L.reg_seed, L.reg_chain, L.chn, L.seeds, L.regs, L.R, L.counters);
@@ -595,7 +700,8 @@ static int run_sides(const ExtLaunch &L, const uint32_t *h_hist, const uint32_t 
 int bm2_launch_extend(bm2_ctx *c, const bm2_opt &opt, const ChainParams &cp, int n_reads, int64_t n_slots, const uint8_t *enc,
                       const int64_t *off, const int32_t *len, const int64_t *read_base, const int32_t *n_chain, const int32_t *n_reg,
                       const int64_t *slot_base, const int32_t *reg_seed, const int32_t *reg_chain, const DevChain *chn,
-                      const DevSeed *seeds, int32_t *srt_all, DevReg *regs, unsigned long long *counters, DevBuf &tmp, int32_t *cursor) {
+                      const DevSeed *seeds, int32_t *srt_all, DevReg *regs, unsigned long long *counters, DevBuf &tmp, int32_t *cursor,
+                      int max_len) {
     hipStream_t s = c->stream;
     int rc;
     if ((rc = bm2_check(hipMemsetAsync(cursor, 0, (size_t)(n_reads + 1) * 4, s), "memset cursor"))) return rc;
@@ -610,6 +716,9 @@ int bm2_launch_extend(bm2_ctx *c, const bm2_opt &opt, const ChainParams &cp, int
     for (int i = 0; i < 25; i++) P.mat[i] = opt.mat[i];
     P.end_bonus = opt.pen_clip5; xp.left = P;
     P.end_bonus = opt.pen_clip3; xp.right = P;
+    // no H / E of the batch can exceed l_query * a (a full-length perfect match): 8-bit rows when that fits
+    static const int no_p8 = getenv("BM2_NO_PACK8") ? atoi(getenv("BM2_NO_PACK8")) : 0;
+    L.pack8 = !no_p8 && (int64_t)max_len * opt.a <= 255 && opt.a > 0;
     L.R = ring_size2(opt.w << (MAX_BAND_TRY - 1));
     L.lds_w = ((sizeof(ExtParams) + 3) / 4) * 4 + (size_t)4 * 2 * L.R * 4;
     if (L.lds_w > 160 * 1024) { bm2_set_error("band width %d needs more LDS than a CU has", opt.w); return BM2_EUNSUP; }

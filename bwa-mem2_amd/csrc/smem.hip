@@ -138,8 +138,9 @@ struct __attribute__((aligned(16))) P2Task {      // pass-2 forward walk (32 byt
 // global cursor per BATCH ids (a same-address atomic per lane and id would serialise in L2: ~10 ns each, measured).
 // Pool state lives in LDS (one [pos, end) pair per wave and allocator), because the lanes calling are a divergent subset.
 struct WavePool { volatile int64_t pos, end; };
+typedef __attribute__((address_space(3))) WavePool LdsPool;       // (explicitly LDS: a generic pointer would make these flat accesses)
 template <int BATCH>
-static __device__ __forceinline__ int64_t wave_alloc(WavePool *wp, unsigned long long *cursor) {
+static __device__ __forceinline__ int64_t wave_alloc(LdsPool *wp, unsigned long long *cursor) {
     const unsigned long long mask = __ballot(1);
     const int lt = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
     const int cnt = __popcll(mask);
@@ -156,6 +157,7 @@ static __device__ __forceinline__ int64_t wave_alloc(WavePool *wp, unsigned long
     if (lt == 0) { wp->pos = nbase + (cnt - rem); wp->end = nbase + BATCH; }
     return lt < rem ? pos + lt : nbase + (lt - rem);
 }
+#define LCAP 12                   // survivors of a backward row kept in LDS per lane (48 KB per 256-thread block)
 #define ITEM_BATCH 64
 #define SLOT_BATCH 256
 #define REC_BATCH 256
@@ -219,7 +221,7 @@ k_walk(DevIndex ix, SeedParams sp, int n_reads, const uint8_t *__restrict__ enc,
     if (MODE == W_P2) { n_items = (int64_t)sc[SC_TASK]; if (n_items > task_cap) n_items = task_cap; }
     else n_items = n_reads;
     __shared__ WavePool pools[4][2];                           // per wave: [0] work items, [1] task slots or records
-    WavePool *ip = &pools[threadIdx.x >> 6][0], *op = &pools[threadIdx.x >> 6][1];
+    LdsPool *ip = (LdsPool *)&pools[threadIdx.x >> 6][0], *op = (LdsPool *)&pools[threadIdx.x >> 6][1];
     if ((threadIdx.x & 63) == 0) { ip->pos = ip->end = 0; op->pos = op->end = 0; }
     unsigned long long *item_cur = sc + (MODE == W_P1 ? SC_P1_ITEM : MODE == W_P2 ? SC_P2_ITEM : SC_P3_ITEM);
     unsigned long long *out_cur = sc + (MODE == W_P1 ? SC_SLOT1 : MODE == W_P2 ? SC_SLOT2 : SC_REC);
@@ -356,7 +358,7 @@ k_bwd(DevIndex ix, SeedParams sp, int pass, const uint8_t *__restrict__ enc, con
     int64_t n_items = (int64_t)sc[pass == 1 ? SC_SLOT1 : SC_SLOT2];
     if (n_items > slot_cap) n_items = slot_cap;
     __shared__ WavePool pools[4][3];                           // per wave: [0] work items, [1] records, [2] pass-2 tasks
-    WavePool *ip = &pools[threadIdx.x >> 6][0], *rp = &pools[threadIdx.x >> 6][1], *tp = &pools[threadIdx.x >> 6][2];
+    LdsPool *ip = (LdsPool *)&pools[threadIdx.x >> 6][0], *rp = (LdsPool *)&pools[threadIdx.x >> 6][1], *tp = (LdsPool *)&pools[threadIdx.x >> 6][2];
     if ((threadIdx.x & 63) == 0) { ip->pos = ip->end = 0; rp->pos = rp->end = 0; tp->pos = tp->end = 0; }
     unsigned long long *item_cur = sc + (pass == 1 ? SC_B1_ITEM : SC_B2_ITEM);
     int64_t it_a = wave_alloc<ITEM_BATCH>(ip, item_cur);
@@ -377,6 +379,18 @@ k_bwd(DevIndex ix, SeedParams sp, int pass, const uint8_t *__restrict__ enc, con
     int em = 0;                                                // an SMEM to write out: 1 = the candidate, 2 = the first survivor
     QWin w; w.cur = w.nxt = 0; w.curb = w.nxtb = -64;
     auto entry = [&](int idx) -> uint4 * { return idx < CAPF ? lst + idx : lpool + (idx - CAPF); };
+    // survivors at depth 1..LCAP below the top of the list live in LDS ([depth][lane]); deeper ones go back to the slot
+    __shared__ uint4 surv[LCAP * 256];
+    bool row0 = true;                                          // the row being read is the list the walk wrote (global)
+    auto cand_load = [&](int depth) -> uint4 {
+        if (row0) return *entry(top - depth);
+        uint4 v = surv[(depth <= LCAP ? depth - 1 : 0) * 256 + threadIdx.x];
+        if (depth > LCAP) {
+            v = *entry(top - depth);
+            asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));      // (keeps the LDS and the global load apart)
+        }
+        return v;
+    };
 
     for (;;) {
         while (state != B_EXT && state != B_DONE) {            // `break` = yield
@@ -392,7 +406,7 @@ k_bwd(DevIndex ix, SeedParams sp, int pass, const uint8_t *__restrict__ enc, con
                 q = enc + h.rd_off;
                 lst = ents + slot * CAPF;
                 lpool = pool + (int64_t)(h.pool_id >= 0 && h.pool_id < pool_slots ? h.pool_id : 0) * pool_cap;
-                top = n_prev - 1; j = x - 1; m_row = x;
+                top = n_prev - 1; j = x - 1; m_row = x; row0 = true;
                 nxt_raw4 = *entry(top);
                 if (j >= 0) w.start(q, j, -1);
                 state = B_FIRST; break;
@@ -404,7 +418,7 @@ k_bwd(DevIndex ix, SeedParams sp, int pass, const uint8_t *__restrict__ enc, con
             if (state == B_ROWEND) {                            // :650-655
                 n_prev = n_curr;
                 if (n_curr == 0) state = B_FIN;
-                else { m_row = j; j--; state = B_ROW; }
+                else { m_row = j; j--; row0 = false; state = B_ROW; }
             }
             if (state == B_ROW) {                               // :596-606
                 if (j < 0) state = B_FIN;
@@ -413,7 +427,7 @@ k_bwd(DevIndex ix, SeedParams sp, int pass, const uint8_t *__restrict__ enc, con
                 else {
                     n_curr = 0; curr_s = -1; p = 0; first_done = false;
                     ck = fk; cl = fl; cs = fs; cn = fn;
-                    if (n_prev > 1) nxt_raw4 = *entry(top - 1);
+                    if (n_prev > 1) nxt_raw4 = cand_load(1);
                     state = B_EXT;
                 }
             }
@@ -438,6 +452,7 @@ k_bwd(DevIndex ix, SeedParams sp, int pass, const uint8_t *__restrict__ enc, con
             } else if (o.s >= (int64_t)min_intv && o.s != (int64_t)curr_s) {
                 curr_s = (int32_t)o.s;
                 if (n_curr == 0) { fk = o.k; fl = o.l; fs = o.s; fn = cn; }
+                else if (n_curr <= LCAP) surv[(n_curr - 1) * 256 + threadIdx.x] = pv_pack(o.k, o.l, o.s, cn);
                 else *entry(top - n_curr) = pv_pack(o.k, o.l, o.s, cn);
                 n_curr++;
                 first_done = true;
@@ -463,7 +478,7 @@ k_bwd(DevIndex ix, SeedParams sp, int pass, const uint8_t *__restrict__ enc, con
             p++;
             if (p < n_prev) {
                 pv_unpack(nxt_raw4, ck, cl, cs, cn);
-                if (p + 1 < n_prev) nxt_raw4 = *entry(top - (p + 1));
+                if (p + 1 < n_prev) nxt_raw4 = cand_load(p + 1);
             } else state = B_ROWEND;
         }
     }
