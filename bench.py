@@ -31,6 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "bwa-mem2_amd"))
 
+RANDOM_LINE_GBS = 3500.0      # measured: ~55 G independent 64-B lines/s (tools/ubench/randline.hip)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -177,19 +178,29 @@ def main():
     if rank == 0:
         steps = max(a.steps, 1)
         value = world * n_reads * a.steps / dt
-        stage_ms = {k: v / steps for k, v in kms.items()}
-        fm_bytes = 128.0 * st["n_ext"]                       # two 64-B CP_OCC lines per backwardExt
+        kern_ms = {k: v / steps for k, v in kms.items()}     # every timed interval of the library's stream (HIP events)
+        stage_ms = {}
+        for k, v in kern_ms.items():                         # "smem.walk1" ... -> stage "smem"
+            stage_ms[k.split(".")[0]] = stage_ms.get(k.split(".")[0], 0.0) + v
+        # the FM-index seeding kernels: two 64-B CP_OCC lines per backwardExt; the dominant one is k_bwd
+        # (two launches per step: the backward phases of pass 1 and of pass 2)
+        sc = ctx.batch_fetch("seed_counters", np.uint64)
+        ext_of = {"walk1": int(sc[12]), "walk2": int(sc[13]), "walk3": int(sc[14]), "bwd1": int(sc[15]), "bwd2": int(sc[16])}
         smem_ms = stage_ms.get("smem", 0.0)
-        ach = fm_bytes / (smem_ms * 1e-3) / 1e9 if smem_ms > 0 else 0.0
+        bwd_ms = (kern_ms.get("smem.bwd1", 0.0) + kern_ms.get("smem.bwd2", 0.0)) / 2.0          # average launch duration
+        bwd_bytes = 128.0 * (ext_of["bwd1"] + ext_of["bwd2"]) / 2.0                              # algorithmic bytes per launch
+        ach = bwd_bytes / (bwd_ms * 1e-3) / 1e9 if bwd_ms > 0 else 0.0
+        fm_bytes = 128.0 * st["n_ext"]
+        stage_ach = fm_bytes / (smem_ms * 1e-3) / 1e9 if smem_ms > 0 else 0.0
         cells = st["n_sw_cells"]
         ext_ms = stage_ms.get("extend", 0.0)
         dominant = max(stage_ms, key=stage_ms.get) if stage_ms else None
-        traffic = None                                       # HBM bytes per k_smem launch from the committed PMC pass, same workload only
+        traffic = None                                       # HBM bytes per k_bwd launch from the committed PMC passes, same workload only
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_k_smem_pmc.json")))
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_k_bwd_pmc.json")))
             wl = pm["workload"]
             if wl["genome_mbp"] == a.genome_mbp and wl["reads_per_gpu_per_step"] == n_reads and wl["read_len"] == a.read_len:
-                traffic = pm["fetch_size_kb_per_launch"] * 1024.0
+                traffic = pm["hbm_bytes_per_launch"]
         except Exception:
             pass
         out = {
@@ -208,9 +219,18 @@ def main():
             "work_per_read": {"backwardExt": st["n_ext"] / n_reads, "lf_steps": st["n_lf"] / n_reads,
                               "sa_lookups": st["n_sa"] / n_reads, "sw_tasks": st["n_sw_tasks"] / n_reads,
                               "sw_cells": cells / n_reads, "regs": st["n_reg"] / n_reads},
-            "roofline": {"kernel": "k_smem", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"kernel": "k_bwd", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": fm_bytes, "avg_launch_ms": smem_ms},
+                         "algorithmic_bytes_per_launch": bwd_bytes, "avg_launch_ms": bwd_ms, "launches_per_step": 2,
+                         "random_line_ceiling": RANDOM_LINE_GBS,
+                         "frac_of_random_line_ceiling": ach / RANDOM_LINE_GBS,
+                         "note": "k_bwd fetches isolated 64-byte lines; the measured ceiling of this GPU for that access pattern is "
+                                 "~55 G lines/s = 3.5 TB/s (tools/ubench/randline.hip, DESIGN.md section 5)",
+                         "seeding_stage": {"kernels": "k_walk<1> + k_bwd + k_walk<2> + k_bwd (+ k_walk<3> on a second stream)",
+                                           "ms": smem_ms, "algorithmic_bytes": fm_bytes, "achieved": stage_ach,
+                                           "frac": stage_ach / HBM_PEAK_GBS,
+                                           "kernel_ms": {k: v for k, v in kern_ms.items() if k.startswith("smem.")},
+                                           "backwardExt_per_kernel": ext_of}},
             "extend_kernel": {"kernel": "k_extend", "gcups": cells / (ext_ms * 1e-3) / 1e9 if ext_ms > 0 else 0.0,
                               "avg_launch_ms": ext_ms, "cells_per_launch": cells},
         }

@@ -32,10 +32,13 @@ struct SeedBufs {                                   // workspace of the seeding 
     uint4 *pool; int pool_cap, pool_slots;
     bm2_smem_t *recs; int64_t rec_cap;
     P2Task *tasks; int64_t task_cap;
+    int32_t *heavy1, *heavy2; int64_t heavy_cap;     // slot ids of the long-list tasks of pass 1 / pass 2
 };
-enum { BM2_SC_SLOT1 = 1, BM2_SC_REC = 3, BM2_SC_TASK = 4, BM2_SC_SLOT2 = 6, BM2_SC_NEXT = 9, BM2_SC_OVF = 10, BM2_SC_POOL = 11 };   // = the SC_* of smem.hip
+enum { BM2_SC_SLOT1 = 1, BM2_SC_REC = 3, BM2_SC_TASK = 4, BM2_SC_SLOT2 = 6, BM2_SC_NEXT = 9, BM2_SC_OVF = 10, BM2_SC_POOL = 11,
+       BM2_SC_NEXT_W1 = 12 /* then W2, W3, B1, B2 */ };   // = the SC_* of smem.hip
 int bm2_launch_seeding(bm2_ctx *c, const SeedParams &sp, int n_reads, const uint8_t *enc, const int64_t *off, const int32_t *len,
-                       const SeedBufs &sb, int grid_walk, int grid_bwd, int32_t *smem_cnt, unsigned long long *sc);
+                       const SeedBufs &sb, int grid_walk, int grid_bwd, int32_t *smem_cnt, unsigned long long *sc,
+                       void (*tick)(bm2_ctx *, const char *));
 int bm2_launch_smem_finish(bm2_ctx *c, int n_reads, const SeedBufs &sb, const unsigned long long *sc, const int32_t *smem_cnt,
                            const int64_t *smem_off, int32_t *fill, bm2_smem_t *tmp, int32_t max_occ, bm2_smem_t *out, int32_t *occ_cnt);
 int bm2_seed_sizes(size_t *head, size_t *ent, size_t *task, int *n_sc);      // returns CAPF

@@ -50,7 +50,7 @@ struct Batch {
     bm2_stats stats{};
     std::vector<int32_t> h_len;              // host copy of the read lengths (per-read filter thresholds)
     DevBuf min_hsp, seed_owner, seed_keep, mat25;
-    DevBuf heads1, ents1, heads2, ents2, pool, recs, tasks, seedc, fill, smem_tmp;     // seeding task kernels
+    DevBuf heads1, ents1, heads2, ents2, pool, recs, tasks, seedc, fill, smem_tmp, heavy1, heavy2;     // seeding task kernels
     int64_t seed_cap[5] = { 0, 0, 0, 0, 0 };   // learned workspace sizes: slots pass 1/2, records, pass-2 tasks, pool lists
 };
 
@@ -61,7 +61,8 @@ void bm2_batch_destroy(bm2_ctx *c) {
                       &b->counters, &b->sa_off, &b->sa_coord, &b->scan_tmp, &b->read_base, &b->wchain, &b->wseed, &b->nodes,
                       &b->order, &b->chn, &b->seeds, &b->srt, &b->reg_seed, &b->reg_chain, &b->regs, &b->slot_base, &b->n_chain,
                       &b->n_reg, &b->n_chain0, &b->n_out, &b->out_off, &b->out_regs, &b->smem_sorted, &b->smem_sorted_off, &b->ext_tmp, &b->cursor, &b->n_sa_read, &b->perm, &b->perm_hist, &b->part_tmp, &b->min_hsp, &b->seed_owner, &b->seed_keep, &b->mat25,
-                      &b->heads1, &b->ents1, &b->heads2, &b->ents2, &b->pool, &b->recs, &b->tasks, &b->seedc, &b->fill, &b->smem_tmp };
+                      &b->heads1, &b->ents1, &b->heads2, &b->ents2, &b->pool, &b->recs, &b->tasks, &b->seedc, &b->fill, &b->smem_tmp,
+                      &b->heavy1, &b->heavy2 };
     for (DevBuf *d : all) bm2_release(*d);
     delete b;
     c->batch = nullptr;
@@ -201,12 +202,17 @@ static int run_seeding(bm2_ctx *c, Batch *b, const bm2_opt *opt, bool with_sal) 
         sb.heads2 = (BHead *)b->heads2.p; sb.ents2 = (uint4 *)b->ents2.p; sb.slot2_cap = slot2_cap;
         sb.pool = (uint4 *)b->pool.p; sb.pool_slots = (int)pool_slots;
         sb.recs = (bm2_smem_t *)b->recs.p; sb.rec_cap = rec_cap; sb.tasks = (P2Task *)b->tasks.p; sb.task_cap = task_cap;
+        sb.heavy_cap = (int64_t)n / 4 + lanes + 4096;           // (a full list only means the task stays lane-per-task)
+        if ((rc = bm2_reserve(b->heavy1, (size_t)sb.heavy_cap * 4))) return rc;
+        if ((rc = bm2_reserve(b->heavy2, (size_t)sb.heavy_cap * 4))) return rc;
+        sb.heavy1 = (int32_t *)b->heavy1.p; sb.heavy2 = (int32_t *)b->heavy2.p;
         if ((rc = bm2_check(hipMemsetAsync(b->seedc.p, 0, (size_t)n_sc * 8, s), "memset seed cursors"))) return rc;
         if ((rc = bm2_check(hipMemsetAsync(b->smem_cnt.p, 0, (size_t)(n + 1) * 4, s), "memset smem_cnt"))) return rc;
         if ((rc = bm2_check(hipMemsetAsync(b->fill.p, 0, (size_t)(n + 1) * 4, s), "memset fill"))) return rc;
         if (verbose) { (void)hipStreamSynchronize(s); fprintf(stderr, "[seeding] reserve+memset %.1f ms\n", now_ms() - t0); t0 = now_ms(); }
+        c->n_ev = 0;                                                // (a repeated attempt restarts the stage clock)
         if ((rc = bm2_launch_seeding(c, sp, n, (const uint8_t *)b->enc.p, (const int64_t *)b->off.p, (const int32_t *)b->len.p, sb,
-                                     grid_w, grid_b, (int32_t *)b->smem_cnt.p, (unsigned long long *)b->seedc.p))) return rc;
+                                     grid_w, grid_b, (int32_t *)b->smem_cnt.p, (unsigned long long *)b->seedc.p, tick))) return rc;
         if ((rc = bm2_scan_i32(c, (const int32_t *)b->smem_cnt.p, n, (int64_t *)b->smem_off.p, b->scan_tmp))) return rc;
         if ((rc = bm2_check(hipMemcpyAsync(&n_smem_tot, (int64_t *)b->smem_off.p + n, 8, hipMemcpyDeviceToHost, s), "D2H n_smem"))) return rc;
         if ((rc = bm2_check(hipMemcpyAsync(h_sc.data(), b->seedc.p, (size_t)n_sc * 8, hipMemcpyDeviceToHost, s), "D2H seed cursors"))) return rc;
@@ -234,6 +240,7 @@ static int run_seeding(bm2_ctx *c, Batch *b, const bm2_opt *opt, bool with_sal) 
                 h_sc[BM2_SC_SLOT2], h_sc[BM2_SC_REC], h_sc[BM2_SC_TASK], h_sc[BM2_SC_POOL]);
     }
     unsigned long long h_cnt[3] = { (unsigned long long)n_smem_tot, h_sc[BM2_SC_NEXT], 0 };
+    static_assert(BM2_SC_NEXT_W1 + 5 == 17, "bm2_batch_fetch(\"seed_counters\") exposes 17 counters");
     if ((rc = bm2_reserve(b->smem, (size_t)(n_smem_tot + 1) * sizeof(bm2_smem_t)))) return rc;
     if ((rc = bm2_reserve(b->smem_tmp, (size_t)(n_smem_tot + 1) * sizeof(bm2_smem_t)))) return rc;
     if ((rc = bm2_reserve(b->occ_cnt, (size_t)(n_smem_tot + 2) * 4))) return rc;
@@ -241,7 +248,7 @@ static int run_seeding(bm2_ctx *c, Batch *b, const bm2_opt *opt, bool with_sal) 
     if ((rc = bm2_launch_smem_finish(c, n, sb, (const unsigned long long *)b->seedc.p, (const int32_t *)b->smem_cnt.p,
                                      (const int64_t *)b->smem_off.p, (int32_t *)b->fill.p, (bm2_smem_t *)b->smem_tmp.p, sp.max_occ,
                                      (bm2_smem_t *)b->smem.p, (int32_t *)b->occ_cnt.p))) return rc;
-    tick(c, "smem");
+    tick(c, "smem.finish");
     b->n_smem = (int64_t)h_cnt[0];
     b->stats.n_smem = b->n_smem; b->stats.n_ext = (int64_t)h_cnt[1];
     if (!with_sal) return BM2_OK;
@@ -603,7 +610,7 @@ extern "C" int bm2_batch_fetch(bm2_ctx *c, const char *what, void *out, int64_t 
         { "sa_coord", &b->sa_coord, ns * 8 }, { "read_base", &b->read_base, (size_t)n * 8 },
         { "n_chain", &b->n_chain, (size_t)n * 4 }, { "n_chain0", &b->n_chain0, (size_t)n * 4 }, { "n_reg", &b->n_reg, (size_t)n * 4 },
         { "n_out", &b->n_out, (size_t)n * 4 }, { "chn", &b->chn, ns * sizeof(DevChain) }, { "seeds", &b->seeds, ns * sizeof(DevSeed) },
-        { "regs_raw", &b->regs, ns * sizeof(DevReg) }, { "reg_seed", &b->reg_seed, ns * 4 }, { "wchain", &b->wchain, ns * sizeof(WChain) },
+        { "seed_counters", &b->seedc, (size_t)17 * 8 }, { "regs_raw", &b->regs, ns * sizeof(DevReg) }, { "reg_seed", &b->reg_seed, ns * 4 }, { "wchain", &b->wchain, ns * sizeof(WChain) },
     };
     for (auto &t : tab) if (!strcmp(t.name, what)) {
         *n_bytes = (int64_t)t.bytes;

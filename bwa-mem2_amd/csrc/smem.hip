@@ -117,7 +117,7 @@ static __device__ __forceinline__ Bi init_bi(const DevIndex &ix, int a) {     //
 
 enum { W_P1 = 1, W_P2 = 2, W_P3 = 3 };
 enum { SC_P1_ITEM = 0, SC_SLOT1, SC_B1_ITEM, SC_REC, SC_TASK, SC_P2_ITEM, SC_SLOT2, SC_B2_ITEM, SC_P3_ITEM, SC_NEXT, SC_OVF_FLAG,
-       SC_POOL, SC_N };           // cursors / counters of the seeding kernels (unsigned long long each)
+       SC_POOL, SC_NEXT_W1, SC_NEXT_W2, SC_NEXT_W3, SC_NEXT_B1, SC_NEXT_B2, SC_HEAVY1, SC_HEAVY2, SC_H1_ITEM, SC_H2_ITEM, SC_N };   // SC_NEXT_*: backwardExt calls per kernel           // cursors / counters of the seeding kernels (unsigned long long each)
 enum { OVF_SLOT1 = 1, OVF_SLOT2 = 2, OVF_REC = 4, OVF_TASK = 8, OVF_POOL = 16 };
 
 struct __attribute__((aligned(16))) BHead {       // header of a backward-phase task (32 bytes)
@@ -158,6 +158,9 @@ static __device__ __forceinline__ int64_t wave_alloc(LdsPool *wp, unsigned long 
     return lt < rem ? pos + lt : nbase + (lt - rem);
 }
 #define LCAP 12                   // survivors of a backward row kept in LDS per lane (48 KB per 256-thread block)
+#define HEAVY_T 40                // backward tasks with longer candidate lists go to the wave-per-task kernel ...
+#define HCAP 256                  // ... if the list fits its LDS row (else they stay lane-per-task)
+#define HEAVY_BATCH 64
 #define ITEM_BATCH 64
 #define SLOT_BATCH 256
 #define REC_BATCH 256
@@ -214,15 +217,16 @@ __global__ void __launch_bounds__(256)
 k_walk(DevIndex ix, SeedParams sp, int n_reads, const uint8_t *__restrict__ enc, const int64_t *__restrict__ off,
        const int32_t *__restrict__ len, const P2Task *__restrict__ tasks, int64_t task_cap,
        BHead *__restrict__ heads, uint4 *__restrict__ ents, int64_t slot_cap, uint4 *__restrict__ pool, int pool_cap, int pool_slots,
-       bm2_smem_t *__restrict__ recs, int64_t rec_cap, int32_t *__restrict__ smem_cnt, unsigned long long *sc) {
+       bm2_smem_t *__restrict__ recs, int64_t rec_cap, int32_t *__restrict__ smem_cnt, unsigned long long *sc,
+       int32_t *__restrict__ heavy_ids, int64_t heavy_cap) {
     int64_t n_ext = 0;
     unsigned ovf = 0;
     int64_t n_items;
     if (MODE == W_P2) { n_items = (int64_t)sc[SC_TASK]; if (n_items > task_cap) n_items = task_cap; }
     else n_items = n_reads;
-    __shared__ WavePool pools[4][2];                           // per wave: [0] work items, [1] task slots or records
-    LdsPool *ip = (LdsPool *)&pools[threadIdx.x >> 6][0], *op = (LdsPool *)&pools[threadIdx.x >> 6][1];
-    if ((threadIdx.x & 63) == 0) { ip->pos = ip->end = 0; op->pos = op->end = 0; }
+    __shared__ WavePool pools[4][3];                           // per wave: [0] work items, [1] task slots or records, [2] heavy-task ids
+    LdsPool *ip = (LdsPool *)&pools[threadIdx.x >> 6][0], *op = (LdsPool *)&pools[threadIdx.x >> 6][1], *hp = (LdsPool *)&pools[threadIdx.x >> 6][2];
+    if ((threadIdx.x & 63) == 0) { ip->pos = ip->end = 0; op->pos = op->end = 0; hp->pos = hp->end = 0; }
     unsigned long long *item_cur = sc + (MODE == W_P1 ? SC_P1_ITEM : MODE == W_P2 ? SC_P2_ITEM : SC_P3_ITEM);
     unsigned long long *out_cur = sc + (MODE == W_P1 ? SC_SLOT1 : MODE == W_P2 ? SC_SLOT2 : SC_REC);
     // work items: it_a = the next item of this lane; its payload is already loaded
@@ -293,8 +297,13 @@ k_walk(DevIndex ix, SeedParams sp, int n_reads, const uint8_t *__restrict__ enc,
                 if (MODE == W_P3) { x = next_x; state = F_NEWPOS; continue; }
                 if (sms >= min_intv) push(pv_pack(smk, sml, sms, smn));                      // :576-580
                 if (slot < slot_cap) {
+                    bool heavy = n_prev > HEAVY_T && n_prev <= HCAP;              // long list: a whole wave will take this task
+                    if (heavy) {
+                        const int64_t hid = wave_alloc<HEAVY_BATCH>(hp, sc + (MODE == W_P1 ? SC_HEAVY1 : SC_HEAVY2));
+                        if (hid < heavy_cap) heavy_ids[hid] = (int32_t)slot; else heavy = false;
+                    }
                     BHead h; h.rd_off = rd_off; h.r = r; h.L = L; h.x_np = (uint32_t)x | (uint32_t)n_prev << 16;
-                    h.mi_pass = (uint32_t)min_intv | (uint32_t)(MODE == W_P1 ? 1 : 2) << 16; h.pool_id = pool_id; h.pad = 0;
+                    h.mi_pass = (uint32_t)min_intv | (uint32_t)(MODE == W_P1 ? 1 : 2) << 16 | (heavy ? 1u << 24 : 0u); h.pool_id = pool_id; h.pad = 0;
                     heads[slot] = h;
                 } else ovf |= (MODE == W_P1 ? OVF_SLOT1 : OVF_SLOT2);
                 if (MODE == W_P1) { x = next_x; state = F_NEWPOS; } else state = F_NEWITEM;
@@ -334,7 +343,9 @@ k_walk(DevIndex ix, SeedParams sp, int n_reads, const uint8_t *__restrict__ enc,
         if (MODE != W_P3) { if (at < slot_cap) { BHead h = {}; h.r = -1; h.pool_id = -1; heads[at] = h; } }
         else if (at < rec_cap) recs[at].rid = 0xffffffffu;
     }
+    if (MODE != W_P3) for (int64_t at = hp->pos + (threadIdx.x & 63); at < hp->end; at += 64) if (at < heavy_cap) heavy_ids[at] = -1;
     atomicAdd(&sc[SC_NEXT], (unsigned long long)n_ext);
+    atomicAdd(&sc[SC_NEXT_W1 + (MODE - 1)], (unsigned long long)n_ext);
     if (ovf) atomicOr(&sc[SC_OVF_FLAG], (unsigned long long)ovf);
 #ifdef BM2_SMEM_PROF
     atomicAdd(&sc[SC_N + 2 * (MODE - 1)], prof_rounds); atomicAdd(&sc[SC_N + 2 * (MODE - 1) + 1], prof_active);
@@ -401,7 +412,7 @@ k_bwd(DevIndex ix, SeedParams sp, int pass, const uint8_t *__restrict__ enc, con
                 it_a = wave_alloc<ITEM_BATCH>(ip, item_cur);
                 if (it_a < n_items) pl = heads[it_a];
                 n_prev = (int)(h.x_np >> 16);
-                if (h.r < 0 || n_prev == 0) break;             // unused slot / empty list: take the next item
+                if (h.r < 0 || n_prev == 0 || ((h.mi_pass >> 24) & 1)) break;      // unused slot / empty list / a heavy task (k_bwd_heavy): next item
                 r = h.r; L = h.L; x = (int)(h.x_np & 0xffff); min_intv = (int32_t)(h.mi_pass & 0xffff);
                 q = enc + h.rd_off;
                 lst = ents + slot * CAPF;
@@ -485,10 +496,141 @@ k_bwd(DevIndex ix, SeedParams sp, int pass, const uint8_t *__restrict__ enc, con
     for (int64_t at = rp->pos + (threadIdx.x & 63); at < rp->end; at += 64) if (at < rec_cap) recs[at].rid = 0xffffffffu;
     for (int64_t at = tp->pos + (threadIdx.x & 63); at < tp->end; at += 64) if (at < task_cap) tasks[at].r = -1;
     atomicAdd(&sc[SC_NEXT], (unsigned long long)n_ext);
+    atomicAdd(&sc[SC_NEXT_B1 + (pass - 1)], (unsigned long long)n_ext);
     if (ovf) atomicOr(&sc[SC_OVF_FLAG], (unsigned long long)ovf);
 #ifdef BM2_SMEM_PROF
     atomicAdd(&sc[SC_N + 6 + 2 * (pass - 1)], prof_rounds); atomicAdd(&sc[SC_N + 6 + 2 * (pass - 1) + 1], prof_active);
 #endif
+}
+
+// lanes of one wavefront handing data to each other through LDS: order the accesses (the hardware runs them in lockstep)
+static __device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ---- backward phases of LONG candidate lists: one task per WAVEFRONT ----------------------------------------------------
+// A lane-per-task kernel cannot end before its longest task does, and a list of n candidates costs ~n * rows extensions in
+// a row: repeat-rich positions would set the length of the whole stage.  Within a row the candidates are independent
+// (FMI_search.cpp:607-649 only filters them in order), so here the 64 lanes extend 64 candidates of the row at once and the
+// in-order rules become ballots: the first candidate that either dies long enough or survives decides `first_done`
+// (-> at most one SMEM per row, and only if that first one died), and a live candidate is kept iff its interval size
+// differs from the previous LIVE candidate's (equal to the reference's compare with the last kept size, truncated to
+// int32 as there: a dropped candidate has the size of the last kept one).  The list sits in LDS, compacted in place.
+__global__ void __launch_bounds__(256)
+k_bwd_heavy(DevIndex ix, SeedParams sp, int pass, const uint8_t *__restrict__ enc, const BHead *__restrict__ heads,
+            const uint4 *__restrict__ ents, int64_t slot_cap, const uint4 *__restrict__ pool, int pool_cap, int pool_slots,
+            const int32_t *__restrict__ heavy_ids, int64_t heavy_cap,
+            bm2_smem_t *__restrict__ recs, int64_t rec_cap, P2Task *__restrict__ tasks, int64_t task_cap,
+            int32_t *__restrict__ smem_cnt, unsigned long long *sc) {
+    __shared__ uint4 lists[4][HCAP];
+    __shared__ int32_t alive_s[4][64];
+    __shared__ WavePool pools[4][2];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    LdsPool *rp = (LdsPool *)&pools[wv][0], *tp = (LdsPool *)&pools[wv][1];
+    if (lane == 0) { rp->pos = rp->end = 0; tp->pos = tp->end = 0; }
+    uint4 *lst = lists[wv];
+    int32_t *as = alive_s[wv];
+    int64_t n_items = (int64_t)sc[pass == 1 ? SC_HEAVY1 : SC_HEAVY2];
+    if (n_items > heavy_cap) n_items = heavy_cap;
+    unsigned long long *item_cur = sc + (pass == 1 ? SC_H1_ITEM : SC_H2_ITEM);
+    int64_t n_ext = 0;
+    unsigned ovf = 0;
+    const unsigned long long lt_mask = lane ? (~0ULL >> (64 - lane)) : 0ULL;
+    for (;;) {
+        unsigned long long it = 0;
+        if (lane == 0) it = atomicAdd(item_cur, 1ULL);
+        const int64_t hid = (int64_t)(((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(it >> 32)) << 32) |
+                                      (unsigned)__builtin_amdgcn_readfirstlane((unsigned)it));
+        if (hid >= n_items) break;
+        const int slot = heavy_ids[hid];
+        if (slot < 0 || slot >= slot_cap) continue;
+        const BHead h = heads[slot];
+        int n_prev = (int)(h.x_np >> 16);
+        const int x = (int)(h.x_np & 0xffff), r = h.r, L = h.L;
+        const int64_t min_intv = (int64_t)(h.mi_pass & 0xffff);
+        const uint8_t *q = enc + h.rd_off;
+        const uint4 *src = ents + (int64_t)slot * CAPF;
+        const uint4 *psrc = pool + (int64_t)(h.pool_id >= 0 && h.pool_id < pool_slots ? h.pool_id : 0) * pool_cap;
+        const int top = n_prev - 1;
+        for (int d = lane; d < n_prev; d += 64) {                // longest first (:586-592) = the walk's list read top-down
+            const int idx = top - d;
+            lst[d] = idx < CAPF ? src[idx] : psrc[idx - CAPF];
+        }
+        wave_sync();
+        int m_row = x;
+        for (int j = x - 1; j >= 0 && n_prev > 0; j--) {          // :596-655
+            const int a = q[j];
+            if (a > 3) break;
+            int n_curr = 0; bool first_done = false; int32_t curr_s = -1;
+            for (int c0 = 0; c0 < n_prev; c0 += 64) {
+                const int d = c0 + lane;
+                const bool valid = d < n_prev;
+                int64_t ck = 0, cl = 0, cs = 0; int cn = 0;
+                if (valid) pv_unpack(lst[d], ck, cl, cs, cn);
+                const Bi in = { ck, cl, cs };
+                const Bi o = backward_ext(ix, in, a, valid);
+                if (valid) n_ext++;
+                const bool alive = valid && o.s >= min_intv;
+                const bool deadlen = valid && o.s < min_intv && (cn - m_row + 1) >= sp.min_seed_len;
+                const unsigned long long am = __ballot(alive), dm = __ballot(deadlen);
+                if (!first_done && (am | dm)) {
+                    const int f = __ffsll((long long)(am | dm)) - 1;
+                    if (((dm >> f) & 1) && lane == f) {          // the first to trigger died long enough: one SMEM, FMI_search.cpp:611-621
+                        const int64_t at = wave_alloc<REC_BATCH>(rp, sc + SC_REC);
+                        if (at < rec_cap) {
+                            bm2_smem_t v; v.rid = (uint32_t)r; v.m = (uint32_t)m_row; v.n = (uint32_t)cn; v.pad = 0; v.k = ck; v.l = cl; v.s = cs;
+                            recs[at] = v;
+                            atomicAdd(&smem_cnt[r], 1);
+                        } else ovf |= OVF_REC;
+                        if (pass == 1 && (cn + 1 - m_row) >= sp.split_len && cs <= (int64_t)sp.split_width) {
+                            const int64_t ta = wave_alloc<TASK_BATCH>(tp, sc + SC_TASK);
+                            if (ta < task_cap) { P2Task t; t.rd_off = h.rd_off; t.r = r; t.L = L; t.x = (cn + 1 + m_row) >> 1; t.s = (int32_t)cs; t.pad = 0; tasks[ta] = t; }
+                            else ovf |= OVF_TASK;
+                        }
+                    }
+                    first_done = true;
+                }
+                // keep a live candidate iff its size differs from the previous live one's (int32, :625 / :640)
+                const int arank = __popcll(am & lt_mask);
+                if (alive) as[arank] = (int32_t)o.s;
+                wave_sync();
+                const int32_t prev_s = alive ? (arank ? as[arank - 1] : curr_s) : 0;
+                const bool keep = alive && o.s != (int64_t)prev_s;
+                const unsigned long long km = __ballot(keep);
+                if (keep) lst[n_curr + __popcll(km & lt_mask)] = pv_pack(o.k, o.l, o.s, cn);
+                n_curr += __popcll(km);
+                if (am) curr_s = as[__popcll(am) - 1];
+                wave_sync();
+            }
+            n_prev = n_curr;
+            m_row = j;
+        }
+        wave_sync();
+        if (n_prev > 0 && lane == 0) {                            // :656-665
+            int64_t ck, cl, cs; int cn;
+            pv_unpack(lst[0], ck, cl, cs, cn);
+            if ((cn - m_row + 1) >= sp.min_seed_len) {
+                const int64_t at = wave_alloc<REC_BATCH>(rp, sc + SC_REC);
+                if (at < rec_cap) {
+                    bm2_smem_t v; v.rid = (uint32_t)r; v.m = (uint32_t)m_row; v.n = (uint32_t)cn; v.pad = 0; v.k = ck; v.l = cl; v.s = cs;
+                    recs[at] = v;
+                    atomicAdd(&smem_cnt[r], 1);
+                } else ovf |= OVF_REC;
+                if (pass == 1 && (cn + 1 - m_row) >= sp.split_len && cs <= (int64_t)sp.split_width) {
+                    const int64_t ta = wave_alloc<TASK_BATCH>(tp, sc + SC_TASK);
+                    if (ta < task_cap) { P2Task t; t.rd_off = h.rd_off; t.r = r; t.L = L; t.x = (cn + 1 + m_row) >> 1; t.s = (int32_t)cs; t.pad = 0; tasks[ta] = t; }
+                    else ovf |= OVF_TASK;
+                }
+            }
+        }
+    }
+    for (int64_t at = rp->pos + lane; at < rp->end; at += 64) if (at < rec_cap) recs[at].rid = 0xffffffffu;
+    for (int64_t at = tp->pos + lane; at < tp->end; at += 64) if (at < task_cap) tasks[at].r = -1;
+    atomicAdd(&sc[SC_NEXT], (unsigned long long)n_ext);
+    atomicAdd(&sc[SC_NEXT_B1 + (pass - 1)], (unsigned long long)n_ext);
+    if (ovf) atomicOr(&sc[SC_OVF_FLAG], (unsigned long long)ovf);
 }
 
 // records (any order, with padding) -> the reads' segments of `tmp`
@@ -584,22 +726,40 @@ k_smem_gather(int n_reads, const bm2_smem_t *__restrict__ in, const int64_t *__r
 }
 
 int bm2_launch_seeding(bm2_ctx *c, const SeedParams &sp, int n_reads, const uint8_t *enc, const int64_t *off, const int32_t *len,
-                       const SeedBufs &sb, int grid_walk, int grid_bwd, int32_t *smem_cnt, unsigned long long *sc) {
-    hipStream_t s = c->stream, s3 = c->side_stream[0];
+                       const SeedBufs &sb, int grid_walk, int grid_bwd, int32_t *smem_cnt, unsigned long long *sc,
+                       void (*tick)(bm2_ctx *, const char *)) {
+    hipStream_t s = c->stream, s3 = c->side_stream[0], sh = c->side_stream[1];
+    const int grid_heavy = c->n_cu * 4;
     // pass 3 is independent of passes 1 and 2: it runs beside them
     (void)hipEventRecord(c->ev_fork, s);
     (void)hipStreamWaitEvent(s3, c->ev_fork, 0);
     hipLaunchKernelGGL(k_walk<W_P3>, dim3(grid_walk), dim3(256), 0, s3, c->ix, sp, n_reads, enc, off, len, (const P2Task *)nullptr, (int64_t)0,
-                       (BHead *)nullptr, (uint4 *)nullptr, (int64_t)0, (uint4 *)nullptr, 0, 0, sb.recs, sb.rec_cap, smem_cnt, sc);
+                       (BHead *)nullptr, (uint4 *)nullptr, (int64_t)0, (uint4 *)nullptr, 0, 0, sb.recs, sb.rec_cap, smem_cnt, sc,
+                       (int32_t *)nullptr, (int64_t)0);
     (void)hipEventRecord(c->ev_join[0], s3);
-    hipLaunchKernelGGL(k_walk<W_P1>, dim3(grid_walk), dim3(256), 0, s, c->ix, sp, n_reads, enc, off, len, (const P2Task *)nullptr, (int64_t)0,
-                       sb.heads1, sb.ents1, sb.slot1_cap, sb.pool, sb.pool_cap, sb.pool_slots, sb.recs, sb.rec_cap, smem_cnt, sc);
-    hipLaunchKernelGGL(k_bwd, dim3(grid_bwd), dim3(256), 0, s, c->ix, sp, 1, enc, sb.heads1, sb.ents1, sb.slot1_cap, sb.pool, sb.pool_cap,
-                       sb.pool_slots, sb.recs, sb.rec_cap, sb.tasks, sb.task_cap, smem_cnt, sc);
-    hipLaunchKernelGGL(k_walk<W_P2>, dim3(grid_walk), dim3(256), 0, s, c->ix, sp, n_reads, enc, off, len, sb.tasks, sb.task_cap,
-                       sb.heads2, sb.ents2, sb.slot2_cap, sb.pool, sb.pool_cap, sb.pool_slots, sb.recs, sb.rec_cap, smem_cnt, sc);
-    hipLaunchKernelGGL(k_bwd, dim3(grid_bwd), dim3(256), 0, s, c->ix, sp, 2, enc, sb.heads2, sb.ents2, sb.slot2_cap, sb.pool, sb.pool_cap,
-                       sb.pool_slots, sb.recs, sb.rec_cap, sb.tasks, sb.task_cap, smem_cnt, sc);
+    for (int pass = 1; pass <= 2; pass++) {
+        BHead *heads = pass == 1 ? sb.heads1 : sb.heads2;
+        uint4 *ents = pass == 1 ? sb.ents1 : sb.ents2;
+        const int64_t slot_cap = pass == 1 ? sb.slot1_cap : sb.slot2_cap;
+        int32_t *heavy = pass == 1 ? sb.heavy1 : sb.heavy2;
+        if (pass == 1)
+            hipLaunchKernelGGL(k_walk<W_P1>, dim3(grid_walk), dim3(256), 0, s, c->ix, sp, n_reads, enc, off, len, (const P2Task *)nullptr, (int64_t)0,
+                               heads, ents, slot_cap, sb.pool, sb.pool_cap, sb.pool_slots, sb.recs, sb.rec_cap, smem_cnt, sc, heavy, sb.heavy_cap);
+        else
+            hipLaunchKernelGGL(k_walk<W_P2>, dim3(grid_walk), dim3(256), 0, s, c->ix, sp, n_reads, enc, off, len, sb.tasks, sb.task_cap,
+                               heads, ents, slot_cap, sb.pool, sb.pool_cap, sb.pool_slots, sb.recs, sb.rec_cap, smem_cnt, sc, heavy, sb.heavy_cap);
+        tick(c, pass == 1 ? "smem.walk1" : "smem.walk2");
+        // the long lists go to one wavefront each, beside the lane-per-task kernel
+        (void)hipEventRecord(c->ev_join[2], s);
+        (void)hipStreamWaitEvent(sh, c->ev_join[2], 0);
+        hipLaunchKernelGGL(k_bwd_heavy, dim3(grid_heavy), dim3(256), 0, sh, c->ix, sp, pass, enc, heads, ents, slot_cap, sb.pool, sb.pool_cap,
+                           sb.pool_slots, heavy, sb.heavy_cap, sb.recs, sb.rec_cap, sb.tasks, sb.task_cap, smem_cnt, sc);
+        (void)hipEventRecord(c->ev_join[1], sh);
+        hipLaunchKernelGGL(k_bwd, dim3(grid_bwd), dim3(256), 0, s, c->ix, sp, pass, enc, heads, ents, slot_cap, sb.pool, sb.pool_cap,
+                           sb.pool_slots, sb.recs, sb.rec_cap, sb.tasks, sb.task_cap, smem_cnt, sc);
+        (void)hipStreamWaitEvent(s, c->ev_join[1], 0);
+        tick(c, pass == 1 ? "smem.bwd1" : "smem.bwd2");
+    }
     (void)hipStreamWaitEvent(s, c->ev_join[0], 0);
     return bm2_check(hipGetLastError(), "seeding launch");
 }

@@ -117,7 +117,11 @@ def test_split_api_is_idempotent(gpu_ctx_factory, golden_dir):
     ctx.batch_run(opt)
     r2, o2 = ctx.batch_download()
     assert r1.tobytes() == r2.tobytes() and o1.tobytes() == o2.tobytes()
-    assert [n for n, _ in ctx.batch_kernel_ms()] == ["smem", "sal", "chain", "extend", "postfilter"]
+    stages = []
+    for n, _ in ctx.batch_kernel_ms():                  # timed intervals are "stage" or "stage.kernel"
+        if n.split(".")[0] not in stages:
+            stages.append(n.split(".")[0])
+    assert stages == ["smem", "sal", "chain", "extend", "postfilter"]
 
 
 def test_sub_batch_pipelining_matches_single_part(tmp_path):
@@ -139,7 +143,7 @@ def test_sub_batch_pipelining_matches_single_part(tmp_path):
     finally:
         c4.close()
     assert o1.tobytes() == o4.tobytes() and r1.tobytes() == r4.tobytes()
-    assert s1 == s4 and len(kms) == 5
+    assert s1 == s4 and len({n.split(".")[0] for n, _ in kms}) == 5
     ix = oracle.Index(fa)
     try:
         exp = ix.run(enc, off, ln)
