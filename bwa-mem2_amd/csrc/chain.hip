@@ -264,7 +264,7 @@ static __device__ int chain_weight(const WChain &c, const WSeed *seeds) {
     return w < 1 << 30 ? w : (1 << 30) - 1;
 }
 
-__global__ void __launch_bounds__(128)
+__global__ void __launch_bounds__(128, 6)
 k_chain(DevIndex ix, ChainParams o, int n_reads, const int32_t *__restrict__ len, const bm2_smem_t *__restrict__ smems,
         const int32_t *__restrict__ smem_cnt, const int64_t *__restrict__ smem_off, const int64_t *__restrict__ sa_off,
         const int64_t *__restrict__ sa_coord, WChain *wchain, WSeed *wseed, BtNode *nodes, int32_t *order,

@@ -330,10 +330,10 @@ static int batch_run_one(bm2_ctx *c, const bm2_opt *opt) {
     }
     hipLaunchKernelGGL(k_read_base, dim3((n + 255) / 256), dim3(256), 0, s, n, (const int32_t *)b->smem_cnt.p,
                        (const int64_t *)b->smem_off.p, (const int64_t *)b->sa_off.p, (int64_t *)b->read_base.p, (int32_t *)b->n_sa_read.p);
-    static const int perm_mode = getenv("BM2_PERM_MODE") ? atoi(getenv("BM2_PERM_MODE")) : 3;      // chaining: light reads first, stable
+    static const int perm_mode = getenv("BM2_PERM_MODE") ? atoi(getenv("BM2_PERM_MODE")) : 4;      // chaining: heavy reads (> 40 seeds) first, stable
     static const int perm_mode_pf = getenv("BM2_PERM_MODE_PF") ? atoi(getenv("BM2_PERM_MODE_PF")) : 0;   // post-filter: read order
     static const int thr_sa = getenv("BM2_HEAVY_SA") ? atoi(getenv("BM2_HEAVY_SA")) : 40;
-    if (perm_mode == 3) { if ((rc = bm2_partition_by_work(c, n, (const int32_t *)b->n_sa_read.p, thr_sa, (int32_t *)b->perm.p, b->part_tmp, b->scan_tmp))) return rc; }
+    if (perm_mode == 3 || perm_mode == 4) { if ((rc = bm2_partition_by_work(c, n, (const int32_t *)b->n_sa_read.p, thr_sa, (int32_t *)b->perm.p, b->part_tmp, b->scan_tmp, perm_mode == 4))) return rc; }
     else if ((rc = bm2_perm_by_work(c, n, (const int32_t *)b->n_sa_read.p, (int32_t *)b->perm.p, (uint32_t *)b->perm_hist.p, perm_mode))) return rc;
     if ((rc = bm2_launch_chain(c, cp, n, (const int32_t *)b->len.p, (const bm2_smem_t *)b->smem.p, (const int32_t *)b->smem_cnt.p,
                                (const int64_t *)b->smem_off.p, (const int64_t *)b->sa_off.p, (const int64_t *)b->sa_coord.p,
@@ -359,7 +359,7 @@ static int batch_run_one(bm2_ctx *c, const bm2_opt *opt) {
                                 (unsigned long long *)b->counters.p + 5, b->ext_tmp, (int32_t *)b->cursor.p, b->max_len))) return rc;
     tick(c, "extend");
     static const int thr_reg = getenv("BM2_HEAVY_REG") ? atoi(getenv("BM2_HEAVY_REG")) : 12;
-    if (perm_mode_pf == 3) { if ((rc = bm2_partition_by_work(c, n, (const int32_t *)b->n_reg.p, thr_reg, (int32_t *)b->perm.p, b->part_tmp, b->scan_tmp))) return rc; }
+    if (perm_mode_pf == 3 || perm_mode_pf == 4) { if ((rc = bm2_partition_by_work(c, n, (const int32_t *)b->n_reg.p, thr_reg, (int32_t *)b->perm.p, b->part_tmp, b->scan_tmp, perm_mode_pf == 4))) return rc; }
     else if ((rc = bm2_perm_by_work(c, n, (const int32_t *)b->n_reg.p, (int32_t *)b->perm.p, (uint32_t *)b->perm_hist.p, perm_mode_pf))) return rc;
     if ((rc = bm2_launch_postfilter(c, cp, n, (const int32_t *)b->len.p, (const int64_t *)b->read_base.p, (const int32_t *)b->n_chain.p,
                                     (const int32_t *)b->n_reg.p, (const DevChain *)b->chn.p, (const DevSeed *)b->seeds.p,

@@ -126,14 +126,20 @@ __global__ void __launch_bounds__(256) k_part_flag(int n, const int32_t *__restr
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) flag[i] = key[i] > thr ? 1 : 0;
 }
-__global__ void __launch_bounds__(256) k_part_scatter(int n, const int32_t *__restrict__ flag, const int64_t *__restrict__ hpos, int32_t *perm) {
+__global__ void __launch_bounds__(256) k_part_scatter(int n, const int32_t *__restrict__ flag, const int64_t *__restrict__ hpos, int32_t *perm,
+                                                      int heavy_first) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int64_t n_heavy = hpos[n], h = hpos[i];
-    if (flag[i]) perm[(n - n_heavy) + h] = i;
-    else perm[i - h] = i;
+    if (heavy_first) {               // the long-running reads start first and the light ones fill in behind them
+        if (flag[i]) perm[h] = i;
+        else perm[n_heavy + (i - h)] = i;
+    } else {
+        if (flag[i]) perm[(n - n_heavy) + h] = i;
+        else perm[i - h] = i;
+    }
 }
-int bm2_partition_by_work(bm2_ctx *c, int n, const int32_t *key, int thr, int32_t *perm, DevBuf &tmp, DevBuf &scan_tmp) {
+int bm2_partition_by_work(bm2_ctx *c, int n, const int32_t *key, int thr, int32_t *perm, DevBuf &tmp, DevBuf &scan_tmp, int heavy_first) {
     if (n <= 0) return BM2_OK;
     int rc = bm2_reserve(tmp, (size_t)(n + 1) * 4 + (size_t)(n + 2) * 8 + 64);
     if (rc) return rc;
@@ -141,6 +147,6 @@ int bm2_partition_by_work(bm2_ctx *c, int n, const int32_t *key, int thr, int32_
     int64_t *hpos = (int64_t *)((char *)tmp.p + (((size_t)(n + 1) * 4 + 15) & ~(size_t)15));
     hipLaunchKernelGGL(k_part_flag, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, key, thr, flag);
     if ((rc = bm2_scan_i32(c, flag, n, hpos, scan_tmp))) return rc;
-    hipLaunchKernelGGL(k_part_scatter, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, flag, hpos, perm);
+    hipLaunchKernelGGL(k_part_scatter, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, flag, hpos, perm, heavy_first);
     return bm2_check(hipGetLastError(), "partition launch");
 }
