@@ -51,6 +51,7 @@ struct Batch {
     std::vector<int32_t> h_len;              // host copy of the read lengths (per-read filter thresholds)
     DevBuf min_hsp, seed_owner, seed_keep, mat25;
     DevBuf heads1, ents1, heads2, ents2, pool, recs, tasks, seedc, fill, smem_tmp, heavy1, heavy2;     // seeding task kernels
+    int seed_attempts = 0;                      // runs of the seeding kernels the last batch needed (> 1: a workspace grew)
     int64_t seed_cap[5] = { 0, 0, 0, 0, 0 };   // learned workspace sizes: slots pass 1/2, records, pass-2 tasks, pool lists
 };
 
@@ -177,11 +178,13 @@ static int run_seeding(bm2_ctx *c, Batch *b, const bm2_opt *opt, bool with_sal) 
     //  the slack of the others)
     int64_t &slot1_cap = b->seed_cap[0], &slot2_cap = b->seed_cap[1], &rec_cap = b->seed_cap[2], &task_cap = b->seed_cap[3],
             &pool_slots = b->seed_cap[4];
-    if (slot1_cap < (int64_t)n * 6 + lanes * 4 + 4096) slot1_cap = (int64_t)n * 6 + lanes * 4 + 4096;
-    if (slot2_cap < (int64_t)n * 6 + lanes * 4 + 4096) slot2_cap = (int64_t)n * 6 + lanes * 4 + 4096;
-    if (rec_cap < (int64_t)n * 24 + lanes * 12 + 4096) rec_cap = (int64_t)n * 24 + lanes * 12 + 4096;      // + the pool tails: 3 kernels x 256 / wave
-    if (task_cap < (int64_t)n * 6 + lanes + 4096) task_cap = (int64_t)n * 6 + lanes + 4096;
-    if (pool_slots < n / 8 + 1024) pool_slots = n / 8 + 1024;
+    const int64_t per_read = getenv("BM2_SEED_TINY") ? 0 : 1;   // test hook: start from workspaces that only hold the pool tails
+    if (!per_read) { slot1_cap = slot2_cap = rec_cap = task_cap = pool_slots = 0; }
+    if (slot1_cap < (int64_t)n * 6 * per_read + lanes * 4 + 4096) slot1_cap = (int64_t)n * 6 * per_read + lanes * 4 + 4096;
+    if (slot2_cap < (int64_t)n * 6 * per_read + lanes * 4 + 4096) slot2_cap = (int64_t)n * 6 * per_read + lanes * 4 + 4096;
+    if (rec_cap < (int64_t)n * 24 * per_read + lanes * 12 + 4096) rec_cap = (int64_t)n * 24 * per_read + lanes * 12 + 4096;      // + the pool tails: 3 kernels x 256 / wave
+    if (task_cap < (int64_t)n * 6 * per_read + lanes + 4096) task_cap = (int64_t)n * 6 * per_read + lanes + 4096;
+    if (pool_slots < (n / 8 + 1024) * per_read + 1) pool_slots = (n / 8 + 1024) * per_read + 1;
     if ((rc = bm2_reserve(b->seedc, (size_t)n_sc * 8))) return rc;
     if ((rc = bm2_reserve(b->fill, (size_t)(n + 1) * 4))) return rc;
     std::vector<unsigned long long> h_sc((size_t)n_sc);
@@ -218,6 +221,7 @@ static int run_seeding(bm2_ctx *c, Batch *b, const bm2_opt *opt, bool with_sal) 
         if ((rc = bm2_check(hipMemcpyAsync(h_sc.data(), b->seedc.p, (size_t)n_sc * 8, hipMemcpyDeviceToHost, s), "D2H seed cursors"))) return rc;
         if ((rc = bm2_check(hipStreamSynchronize(s), "seeding kernels"))) return rc;
         if (verbose) { fprintf(stderr, "[seeding] kernels+scan %.1f ms\n", now_ms() - t0); t0 = now_ms(); }
+        b->seed_attempts = attempt + 1;
         if (!h_sc[BM2_SC_OVF]) break;
         if (getenv("BM2_VERBOSE") || getenv("BM2_WARN_RETRY"))
             fprintf(stderr, "[seeding] attempt %d overflowed (flags %llu): slots %llu/%lld + %llu/%lld, records %llu/%lld, tasks %llu/%lld, pool %llu/%lld\n",
@@ -240,7 +244,7 @@ static int run_seeding(bm2_ctx *c, Batch *b, const bm2_opt *opt, bool with_sal) 
                 h_sc[BM2_SC_SLOT2], h_sc[BM2_SC_REC], h_sc[BM2_SC_TASK], h_sc[BM2_SC_POOL]);
     }
     unsigned long long h_cnt[3] = { (unsigned long long)n_smem_tot, h_sc[BM2_SC_NEXT], 0 };
-    static_assert(BM2_SC_NEXT_W1 + 5 == 17, "bm2_batch_fetch(\"seed_counters\") exposes 17 counters");
+    static_assert(BM2_SC_NEXT_W1 + 9 == 21, "bm2_batch_fetch(\"seed_counters\") exposes 21 counters");
     if ((rc = bm2_reserve(b->smem, (size_t)(n_smem_tot + 1) * sizeof(bm2_smem_t)))) return rc;
     if ((rc = bm2_reserve(b->smem_tmp, (size_t)(n_smem_tot + 1) * sizeof(bm2_smem_t)))) return rc;
     if ((rc = bm2_reserve(b->occ_cnt, (size_t)(n_smem_tot + 2) * 4))) return rc;
@@ -610,8 +614,15 @@ extern "C" int bm2_batch_fetch(bm2_ctx *c, const char *what, void *out, int64_t 
         { "sa_coord", &b->sa_coord, ns * 8 }, { "read_base", &b->read_base, (size_t)n * 8 },
         { "n_chain", &b->n_chain, (size_t)n * 4 }, { "n_chain0", &b->n_chain0, (size_t)n * 4 }, { "n_reg", &b->n_reg, (size_t)n * 4 },
         { "n_out", &b->n_out, (size_t)n * 4 }, { "chn", &b->chn, ns * sizeof(DevChain) }, { "seeds", &b->seeds, ns * sizeof(DevSeed) },
-        { "seed_counters", &b->seedc, (size_t)17 * 8 }, { "regs_raw", &b->regs, ns * sizeof(DevReg) }, { "reg_seed", &b->reg_seed, ns * 4 }, { "wchain", &b->wchain, ns * sizeof(WChain) },
+        { "seed_counters", &b->seedc, (size_t)21 * 8 }, { "regs_raw", &b->regs, ns * sizeof(DevReg) }, { "reg_seed", &b->reg_seed, ns * 4 }, { "wchain", &b->wchain, ns * sizeof(WChain) },
     };
+    if (!strcmp(what, "seed_attempts")) {
+        *n_bytes = 4;
+        if (cap_bytes < 4) return BM2_ECAP;
+        if (!out) return BM2_EINVAL;
+        *(int32_t *)out = b->seed_attempts;
+        return BM2_OK;
+    }
     for (auto &t : tab) if (!strcmp(t.name, what)) {
         *n_bytes = (int64_t)t.bytes;
         if ((int64_t)t.bytes > cap_bytes) return BM2_ECAP;

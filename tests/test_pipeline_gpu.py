@@ -106,6 +106,52 @@ def test_non_default_options_vs_oracle(gpu_ctx_factory, tmp_path):
     _same(exp["REGPRG"], regs_to_records(regs, reg_off), "REGPRG")
 
 
+def _repeat_case(tmp_path, seed, n_reads):
+    # a few high-copy, low-divergence repeat families: candidate lists of the backward phases run to > 100 entries
+    names, ctg, alts = synth.make_genome(seed, [400000, 200000], alt_contigs=0, n_repeat_families=4, repeat_len=(1500, 4000),
+                                         copies=(150, 300), divergence=(0.005, 0.04))
+    fa = str(tmp_path / "rep.fa")
+    synth.write_fasta(fa, names, ctg)
+    if not build_index(fa):
+        pytest.skip("oracle/_ref reference binary not present (build it with `make -C oracle ref`)")
+    return fa, refio.pack_reads(synth.make_reads_se(seed + 1, ctg, n_reads, L=150))
+
+
+def test_repeat_rich_lists_vs_oracle(gpu_ctx_factory, tmp_path):
+    # exercises what ordinary reads rarely do: lists beyond the 32-entry slot (pool), beyond the 12 LDS survivors, and the
+    # wave-per-task kernel for lists > 40
+    fa, (enc, off, ln) = _repeat_case(tmp_path, 21, 5000)
+    ix = oracle.Index(fa)
+    try:
+        exp = ix.run(enc, off, ln)
+    finally:
+        ix.close()
+    ctx = gpu_ctx_factory(fa)
+    regs, reg_off, st = ctx.seed_chain_extend(enc, off, ln, bm2.default_opt())
+    sc = ctx.batch_fetch("seed_counters", np.uint64)
+    assert sc[11] > 0 and sc[17] > 0 and sc[18] > 0, "the case must reach the pool and the heavy-task kernel (%s)" % sc
+    _same(exp["REGPRG"], regs_to_records(regs, reg_off), "REGPRG")
+    assert st["n_ext"] == exp["counters"]["n_ext"]
+    sm = ctx.smem(enc, off, ln, bm2.default_opt())
+    got = np.zeros(len(sm), refio.SMEM_DT)
+    for a, b in (("read", "rid"), ("m", "m"), ("n", "n"), ("k", "k"), ("l", "l"), ("s", "s")):
+        got[a] = sm[b]
+    _same(exp["SMEM"], got, "SMEM")
+
+
+def test_seeding_workspace_growth(gpu_ctx_factory, tmp_path, monkeypatch):
+    # start from workspaces that hold nothing but the pool tails: the run must report what it needs, grow, and repeat
+    fa, (enc, off, ln) = _fresh_case(tmp_path, 31, [200000, 80000], 40000, 150)
+    ctx = gpu_ctx_factory(fa)
+    r0, o0, _ = ctx.seed_chain_extend(enc, off, ln, bm2.default_opt())
+    assert ctx.batch_fetch("seed_attempts", np.int32)[0] == 1
+    monkeypatch.setenv("BM2_SEED_TINY", "1")
+    ctx2 = gpu_ctx_factory(fa)
+    r1, o1, _ = ctx2.seed_chain_extend(enc, off, ln, bm2.default_opt())
+    assert ctx2.batch_fetch("seed_attempts", np.int32)[0] > 1
+    assert r0.tobytes() == r1.tobytes() and o0.tobytes() == o1.tobytes()
+
+
 def test_split_api_is_idempotent(gpu_ctx_factory, golden_dir):
     # upload once, run twice: identical regs (no state leaks between runs of a resident batch)
     pre, enc, off, ln, d = load_golden(golden_dir, "g60k")
