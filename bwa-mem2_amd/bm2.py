@@ -38,7 +38,8 @@ class IndexDesc(C.Structure):
     _fields_ = [("ref_len", C.c_int64), ("count", C.c_int64 * 5), ("sentinel_index", C.c_int64),
                 ("cp_occ", C.c_void_p), ("sa_ms_byte", C.c_void_p), ("sa_ls_word", C.c_void_p),
                 ("ref_string", C.c_void_p), ("l_pac", C.c_int64), ("n_seqs", C.c_int32),
-                ("ann_offset", C.c_void_p), ("ann_len", C.c_void_p), ("ann_is_alt", C.c_void_p)]
+                ("ann_offset", C.c_void_p), ("ann_len", C.c_void_p), ("ann_is_alt", C.c_void_p),
+                ("ann_name", C.c_void_p), ("ann_anno", C.c_void_p)]
 
 
 class Opt(C.Structure):
@@ -48,6 +49,16 @@ class Opt(C.Structure):
                [("max_mem_intv", C.c_int64), ("split_factor", C.c_float), ("mask_level", C.c_float),
                 ("drop_ratio", C.c_float), ("mask_level_redun", C.c_float), ("mat", C.c_int8 * 25),
                 ("pad", C.c_int8 * 3)]
+
+
+class SamOpt(C.Structure):
+    _fields_ = [("T", C.c_int32), ("flag", C.c_int32), ("max_XA_hits", C.c_int32), ("max_XA_hits_alt", C.c_int32),
+                ("XA_drop_ratio", C.c_float), ("mapQ_coef_len", C.c_float), ("mapQ_coef_fac", C.c_int32), ("pad", C.c_int32),
+                ("rg_id", C.c_char_p)]
+
+
+class ReadText(C.Structure):
+    _fields_ = [("name", C.POINTER(C.c_char_p)), ("comment", C.POINTER(C.c_char_p)), ("qual", C.POINTER(C.c_char_p))]
 
 
 class SwParams(C.Structure):
@@ -70,7 +81,7 @@ class Stats(C.Structure):
 EXPORTS = ["bm2_index_load", "bm2_index_free", "bm2_opt_init", "bm2_opt_fill_scmat", "bm2_create", "bm2_destroy",
            "bm2_last_error", "bm2_device_count", "bm2_bsw", "bm2_smem", "bm2_sal", "bm2_seed_chain_extend",
            "bm2_batch_upload", "bm2_batch_run", "bm2_batch_stats", "bm2_batch_download", "bm2_batch_kernel_ms",
-           "bm2_batch_fetch", "bm2_finish_regs", "bm2_index_build"]
+           "bm2_batch_fetch", "bm2_finish_regs", "bm2_index_build", "bm2_sam_opt_init", "bm2_sam_se"]
 
 _lib = None
 
@@ -109,6 +120,10 @@ def lib():
         L.bm2_finish_regs.argtypes = [C.POINTER(IndexDesc), C.POINTER(Opt), C.POINTER(Reads), C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_int64, C.c_void_p, C.POINTER(C.c_int64)]
         L.bm2_index_build.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
+        L.bm2_sam_opt_init.argtypes = [C.POINTER(SamOpt)]
+        L.bm2_sam_opt_init.restype = None
+        L.bm2_sam_se.argtypes = [C.POINTER(IndexDesc), C.POINTER(Opt), C.POINTER(SamOpt), C.POINTER(Reads), C.POINTER(ReadText),
+                                 C.c_void_p, C.c_void_p, C.c_int64, C.c_char_p, C.c_int64, C.POINTER(C.c_int64)]
         _lib = L
     return _lib
 
@@ -277,6 +292,51 @@ class Context:
         n = C.c_int32(0)
         _chk(lib().bm2_batch_kernel_ms(self.h, ms, 32, C.byref(n), names), "bm2_batch_kernel_ms")
         return [(names[i].decode(), float(ms[i])) for i in range(n.value)]
+
+
+def default_sam_opt(**kw):
+    o = SamOpt()
+    lib().bm2_sam_opt_init(C.byref(o))
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+def sam_se(index_prefix, enc, off, ln, opt, alnregs, reg_off, names, quals=None, comments=None, sam_opt=None, n_processed=0):
+    """Single-end SAM alignment lines (host only, no GPU) from the alnregs of finish_regs -> bytes."""
+    L = lib()
+    d = IndexDesc()
+    _chk(L.bm2_index_load(index_prefix.encode(), C.byref(d)), "bm2_index_load")
+    try:
+        r, keep = _reads_struct(enc, off, ln)
+        n = len(keep[2])
+        so = sam_opt if sam_opt is not None else default_sam_opt()
+
+        def arr(v):
+            if v is None:
+                return None
+            a = (C.c_char_p * n)()
+            for i, x in enumerate(v):
+                a[i] = None if x is None else (x if isinstance(x, bytes) else x.encode())
+            return a
+        nm, ql, cm = arr(names), arr(quals), arr(comments)
+        t = ReadText(C.cast(nm, C.POINTER(C.c_char_p)), C.cast(cm, C.POINTER(C.c_char_p)) if cm is not None else None,
+                     C.cast(ql, C.POINTER(C.c_char_p)) if ql is not None else None)
+        reg_off = np.ascontiguousarray(reg_off, np.int64)
+        need = C.c_int64(0)
+        cap = 1 << 20
+        while True:
+            a = np.ascontiguousarray(alnregs, ALNREG_DT).copy()          # reordered in place: every call gets fresh regs
+            buf = C.create_string_buffer(cap)
+            rc = L.bm2_sam_se(C.byref(d), C.byref(opt), C.byref(so), C.byref(r), C.byref(t), a.ctypes.data, reg_off.ctypes.data,
+                              C.c_int64(n_processed), buf, C.c_int64(cap), C.byref(need))
+            if rc == BM2_ECAP:
+                cap = need.value + 16
+                continue
+            _chk(rc, "bm2_sam_se")
+            return buf.raw[:need.value]
+    finally:
+        L.bm2_index_free(C.byref(d))
 
 
 def finish_regs(index_prefix, enc, off, ln, opt, regs, reg_off):

@@ -17,6 +17,8 @@ extern "C" void bm2_index_free(bm2_index_desc *d) {
     if (!d) return;
     free((void *)d->cp_occ); free((void *)d->sa_ms_byte); free((void *)d->sa_ls_word); free((void *)d->ref_string);
     free((void *)d->ann_offset); free((void *)d->ann_len); free((void *)d->ann_is_alt);
+    if (d->ann_name) { for (int i = 0; i < d->n_seqs; i++) { free((void *)d->ann_name[i]); if (d->ann_anno) free((void *)d->ann_anno[i]); } }
+    free((void *)d->ann_name); free((void *)d->ann_anno);
     memset(d, 0, sizeof *d);
 }
 
@@ -48,11 +50,16 @@ extern "C" int bm2_index_load(const char *prefix, bm2_index_desc *d) {
     int32_t *len = (int32_t *)calloc((size_t)n_seqs + 1, 4), *alt = (int32_t *)calloc((size_t)n_seqs + 1, 4);
     d->ann_offset = off; d->ann_len = len; d->ann_is_alt = alt;
     std::vector<std::string> names;
+    char **nm = (char **)calloc((size_t)n_seqs + 1, sizeof(char *)), **an = (char **)calloc((size_t)n_seqs + 1, sizeof(char *));
+    d->ann_name = nm; d->ann_anno = an;
     for (int i = 0; i < n_seqs; i++) {
         unsigned gi; char name[8193]; int c, namb; long long o;
         if (fscanf(f, "%u%8192s", &gi, name) != 2) { fclose(f); bm2_index_free(d); return BM2_EIO; }
         names.push_back(name);
-        while ((c = fgetc(f)) != '\n' && c != EOF) {}
+        nm[i] = strdup(name);
+        std::string rest;                                      // the comment up to the end of the line (bntseq.cpp:135-140)
+        while ((c = fgetc(f)) != '\n' && c != EOF) if (rest.size() < 8191) rest.push_back((char)c);
+        an[i] = strdup(rest.size() > 1 && rest != " (null)" ? rest.c_str() + 1 : "");
         if (fscanf(f, "%lld%d%d", &o, &len[i], &namb) != 3) { fclose(f); bm2_index_free(d); return BM2_EIO; }
         off[i] = o;
     }

@@ -44,6 +44,8 @@ typedef struct {
     const int64_t *ann_offset;      /* bntann1_t.offset, .len, .is_alt (bntseq.h:42-49) */
     const int32_t *ann_len;
     const int32_t *ann_is_alt;
+    const char *const *ann_name;    /* bntann1_t.name / .anno: only the SAM writer reads them (may be NULL otherwise) */
+    const char *const *ann_anno;
 } bm2_index_desc;
 
 /* Read the reference's index files into malloc'd host arrays (stands in for
@@ -153,6 +155,36 @@ int bm2_seed_chain_extend(bm2_ctx *c, const bm2_reads *reads, const bm2_opt *opt
  * worker_sam.  Pure host code (no GPU needed); idx must carry ref_string. */
 int bm2_finish_regs(const bm2_index_desc *idx, const bm2_opt *opt, const bm2_reads *reads, const bm2_reg_t *regs,
                     const int64_t *reg_off, bm2_alnreg_t *out, int64_t cap, int64_t *out_off, int64_t *n_out);
+
+/* ---- host side, next row of SURVEY.md 8(f): single-end records of worker_sam (bwamem.cpp:1320-1335) =
+ * mem_mark_primary_se (:1420-1465) + mem_reorder_primary5 (:1496-1519) + mem_reg2sam (:1521-1577) with mem_gen_alt
+ * (bwamem_extra.cpp:130-183), mem_reg2aln (:1732-1805: mem_approx_mapq_se, bwa_gen_cigar2 -> ksw_global2 with backtrack,
+ * NM / MD) and mem_aln2sam (:1592-1730).  Text is byte-identical to the alignment lines `bwa-mem2 mem` prints for
+ * single-end input (header lines are the caller's).  Pure host code. */
+typedef struct {                    /* the fields of mem_opt_t (bwamem.h:74-110) this tail reads beyond bm2_opt */
+    int32_t T;                      /* -T: minimum score to output (30) */
+    int32_t flag;                   /* MEM_F_ALL 0x8, MEM_F_NO_MULTI 0x10, MEM_F_REF_HDR 0x100, MEM_F_SOFTCLIP 0x200,
+                                     * MEM_F_PRIMARY5 0x800, MEM_F_KEEP_SUPP_MAPQ 0x1000 */
+    int32_t max_XA_hits, max_XA_hits_alt;   /* 5, 200 */
+    float   XA_drop_ratio;          /* 0.80 */
+    float   mapQ_coef_len;          /* 50 */
+    int32_t mapQ_coef_fac;          /* (int)log(50) = 3: an int in the reference */
+    int32_t pad;
+    const char *rg_id;              /* bwa_rg_id: RG:Z: value, NULL or "" = none */
+} bm2_sam_opt;
+void bm2_sam_opt_init(bm2_sam_opt *o);                  /* the defaults of mem_opt_init, bwamem.cpp:107-143 */
+
+typedef struct {                    /* what bseq1_t carries besides the bases (kseq) */
+    const char *const *name;        /* [n_reads] */
+    const char *const *comment;     /* [n_reads] or NULL; an entry may be NULL (only printed with `mem -C`) */
+    const char *const *qual;        /* [n_reads] or NULL; an entry may be NULL */
+} bm2_read_text;
+
+/* alnregs: the output of bm2_finish_regs, regs of read i = [reg_off[i], reg_off[i+1]); they are reordered and annotated in
+ * place exactly as mem_mark_primary_se does.  n_processed = reads of earlier chunks (it seeds the tie-breaking hash).
+ * out/cap: caller's buffer; *n_out = bytes needed (BM2_ECAP if cap is too small: grow and call again with FRESH alnregs). */
+int bm2_sam_se(const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt *so, const bm2_reads *reads, const bm2_read_text *txt,
+               bm2_alnreg_t *alnregs, const int64_t *reg_off, int64_t n_processed, char *out, int64_t cap, int64_t *n_out);
 
 /* ---- the same path split so that a caller can keep inputs resident in HBM and time only the device work */
 int bm2_batch_upload(bm2_ctx *c, const bm2_reads *reads);                 /* H2D (pinned staging) */

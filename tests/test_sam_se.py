@@ -1,0 +1,110 @@
+"""Single-end SAM tail (bm2_sam_se = mem_mark_primary_se + mem_reg2sam + mem_gen_alt + mem_reg2aln + mem_aln2sam) against the
+text the compiled reference prints for the same reads.  The regs come from the oracle (bit-identical to the device path,
+tests/test_pipeline_gpu.py) through bm2_finish_regs, so the whole chain runs without a GPU."""
+import subprocess
+
+import numpy as np
+import pytest
+
+import bm2
+from helpers import ONT2D, ref_binary
+from tools import oracle, refio, synth
+
+
+def _prg_to_regs(prg, n_reads):
+    regs = np.zeros(len(prg), bm2.REG_DT)
+    for f in ("rb", "re", "qb", "qe", "rid", "score", "truesc", "w", "seedcov", "seedlen0", "frac_rep"):
+        regs[f] = prg[f]
+    reg_off = np.zeros(n_reads + 1, np.int64)
+    np.add.at(reg_off, prg["read"] + 1, 1)
+    return regs, np.cumsum(reg_off)
+
+
+def _reference_sam(fa, fq, extra=()):
+    p = subprocess.run([ref_binary(), "mem", "-t", "1"] + list(extra) + [fa, fq], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True)
+    return b"".join(l for l in p.stdout.splitlines(keepends=True) if not l.startswith(b"@"))
+
+
+def _ours(fa, reads, names, quals, okw=None, sam_opt=None, comments=None):
+    enc, off, ln = refio.pack_reads(reads)
+    ix = oracle.Index(fa)
+    try:
+        exp = ix.run(enc, off, ln, oracle.default_opt(**(okw or {})))
+    finally:
+        ix.close()
+    opt = bm2.default_opt(**(okw or {}))
+    regs, reg_off = _prg_to_regs(exp["REGPRG"], len(ln))
+    aln, aln_off = bm2.finish_regs(fa, enc, off, ln, opt, regs, reg_off)
+    return bm2.sam_se(fa, enc, off, ln, opt, aln, aln_off, names, quals, comments, sam_opt)
+
+
+def _diff(a, b):
+    la, lb = a.splitlines(), b.splitlines()
+    for i, (x, y) in enumerate(zip(la, lb)):
+        if x != y:
+            return "line %d\n  ref : %s\n  ours: %s" % (i, x.decode()[:600], y.decode()[:600])
+    return "line counts %d vs %d" % (len(la), len(lb))
+
+
+def _case(tmp_path, seed, n_reads, L=150, **genome_kw):
+    if ref_binary() is None:
+        pytest.skip("oracle/_ref reference binary not present (build it with `make -C oracle ref`)")
+    kw = dict(alt_contigs=1, alt_len=4000, n_repeat_families=8, repeat_len=(200, 2500), copies=(3, 30), divergence=(0.0, 0.06))
+    kw.update(genome_kw)
+    names, ctg, alts = synth.make_genome(seed, [250000, 120000, 40000], **kw)
+    fa = str(tmp_path / "g.fa")
+    synth.write_fasta(fa, names, ctg)
+    if alts:
+        synth.write_alt(fa + ".alt", alts)
+    subprocess.check_call([ref_binary(), "index", fa], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    reads = synth.make_reads_se(seed + 1, ctg, n_reads, L=L, sub_rate=0.01, indel_frac=0.15, random_frac=0.01)
+    return fa, reads
+
+
+def _write_fastq(path, reads, quals):
+    with open(path, "wb") as f:
+        for i, r in enumerate(reads):
+            f.write(b"@q%d\n" % i + b"ACGTN"[0:0] + bytes(b"ACGTN"[c] for c in r) + b"\n+\n" + quals[i] + b"\n")
+
+
+def test_sam_se_matches_reference_text(tmp_path):
+    fa, reads = _case(tmp_path, 41, 4000)
+    rng = np.random.default_rng(3)
+    quals = [bytes(rng.integers(35, 74, size=len(r), dtype=np.uint8)) for r in reads]
+    fq = str(tmp_path / "r.fq")
+    _write_fastq(fq, reads, quals)
+    ref = _reference_sam(fa, fq)
+    got = _ours(fa, reads, ["q%d" % i for i in range(len(reads))], quals)
+    assert ref == got, _diff(ref, got)
+    assert ref.count(b"SA:Z:") > 0 and ref.count(b"XA:Z:") > 0 and ref.count(b"\t4\t*\t0\t0\t*") > 0      # the case has all record kinds
+
+
+def test_sam_se_options(tmp_path):
+    # -a (all alignments), -Y (soft clips), -M (secondary flag for split hits), -T, -5, non-default scoring
+    fa, reads = _case(tmp_path, 43, 1500, L=120)
+    quals = [b"F" * len(r) for r in reads]
+    fq = str(tmp_path / "r.fq")
+    _write_fastq(fq, reads, quals)
+    names = ["q%d" % i for i in range(len(reads))]
+    for extra, okw, flag, T in ((["-a"], {}, 0x8, 30), (["-Y", "-M"], {}, 0x200 | 0x10, 30), (["-T", "50", "-5"], {}, 0x800 | 0x1000, 50),
+                                (["-B", "3", "-O", "5,7", "-E", "2,1", "-L", "4,6"], dict(b=3, o_del=5, o_ins=7, e_del=2, e_ins=1, pen_clip5=4, pen_clip3=6), 0, 30)):
+        ref = _reference_sam(fa, fq, extra)
+        got = _ours(fa, reads, names, quals, okw, bm2.default_sam_opt(flag=flag, T=T))
+        assert ref == got, "%s: %s" % (" ".join(extra), _diff(ref, got))
+
+
+def test_sam_se_long_reads_ont2d(tmp_path):
+    if ref_binary() is None:
+        pytest.skip("oracle/_ref reference binary not present")
+    names, ctg, alts = synth.make_genome(47, [180000, 90000], alt_contigs=0, n_repeat_families=3, repeat_len=(300, 2000), copies=(3, 8),
+                                         divergence=(0.0, 0.05))
+    fa = str(tmp_path / "g.fa")
+    synth.write_fasta(fa, names, ctg)
+    subprocess.check_call([ref_binary(), "index", fa], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    reads = synth.make_reads_long(48, ctg, 60, mean_len=2500, max_len=6000, err=0.08)
+    quals = [b"5" * len(r) for r in reads]
+    fq = str(tmp_path / "r.fq")
+    _write_fastq(fq, reads, quals)
+    ref = _reference_sam(fa, fq, ["-x", "ont2d"])
+    got = _ours(fa, reads, ["q%d" % i for i in range(len(reads))], quals, ONT2D, bm2.default_sam_opt(T=ONT2D.get("T", 30)))
+    assert ref == got, _diff(ref, got)
