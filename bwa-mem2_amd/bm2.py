@@ -53,8 +53,12 @@ class Opt(C.Structure):
 
 class SamOpt(C.Structure):
     _fields_ = [("T", C.c_int32), ("flag", C.c_int32), ("max_XA_hits", C.c_int32), ("max_XA_hits_alt", C.c_int32),
-                ("XA_drop_ratio", C.c_float), ("mapQ_coef_len", C.c_float), ("mapQ_coef_fac", C.c_int32), ("pad", C.c_int32),
-                ("rg_id", C.c_char_p)]
+                ("XA_drop_ratio", C.c_float), ("mapQ_coef_len", C.c_float), ("mapQ_coef_fac", C.c_int32),
+                ("pen_unpaired", C.c_int32), ("max_ins", C.c_int32), ("max_matesw", C.c_int32), ("rg_id", C.c_char_p)]
+
+
+class PeStat(C.Structure):
+    _fields_ = [("low", C.c_int32), ("high", C.c_int32), ("failed", C.c_int32), ("pad", C.c_int32), ("avg", C.c_double), ("std", C.c_double)]
 
 
 class ReadText(C.Structure):
@@ -81,7 +85,7 @@ class Stats(C.Structure):
 EXPORTS = ["bm2_index_load", "bm2_index_free", "bm2_opt_init", "bm2_opt_fill_scmat", "bm2_create", "bm2_destroy",
            "bm2_last_error", "bm2_device_count", "bm2_bsw", "bm2_smem", "bm2_sal", "bm2_seed_chain_extend",
            "bm2_batch_upload", "bm2_batch_run", "bm2_batch_stats", "bm2_batch_download", "bm2_batch_kernel_ms",
-           "bm2_batch_fetch", "bm2_finish_regs", "bm2_index_build", "bm2_sam_opt_init", "bm2_sam_se"]
+           "bm2_batch_fetch", "bm2_finish_regs", "bm2_index_build", "bm2_sam_opt_init", "bm2_sam_se", "bm2_sam_pe"]
 
 _lib = None
 
@@ -124,6 +128,8 @@ def lib():
         L.bm2_sam_opt_init.restype = None
         L.bm2_sam_se.argtypes = [C.POINTER(IndexDesc), C.POINTER(Opt), C.POINTER(SamOpt), C.POINTER(Reads), C.POINTER(ReadText),
                                  C.c_void_p, C.c_void_p, C.c_int64, C.c_char_p, C.c_int64, C.POINTER(C.c_int64)]
+        L.bm2_sam_pe.argtypes = [C.POINTER(IndexDesc), C.POINTER(Opt), C.POINTER(SamOpt), C.POINTER(Reads), C.POINTER(ReadText),
+                                 C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_char_p, C.c_int64, C.POINTER(C.c_int64)]
         _lib = L
     return _lib
 
@@ -302,7 +308,12 @@ def default_sam_opt(**kw):
     return o
 
 
-def sam_se(index_prefix, enc, off, ln, opt, alnregs, reg_off, names, quals=None, comments=None, sam_opt=None, n_processed=0):
+def sam_pe(index_prefix, enc, off, ln, opt, alnregs, reg_off, names, quals=None, comments=None, sam_opt=None, n_processed=0):
+    """Paired-end SAM alignment lines (reads interleaved) -> (bytes, [4 PeStat])."""
+    return sam_se(index_prefix, enc, off, ln, opt, alnregs, reg_off, names, quals, comments, sam_opt, n_processed, paired=True)
+
+
+def sam_se(index_prefix, enc, off, ln, opt, alnregs, reg_off, names, quals=None, comments=None, sam_opt=None, n_processed=0, paired=False):
     """Single-end SAM alignment lines (host only, no GPU) from the alnregs of finish_regs -> bytes."""
     L = lib()
     d = IndexDesc()
@@ -328,13 +339,18 @@ def sam_se(index_prefix, enc, off, ln, opt, alnregs, reg_off, names, quals=None,
         while True:
             a = np.ascontiguousarray(alnregs, ALNREG_DT).copy()          # reordered in place: every call gets fresh regs
             buf = C.create_string_buffer(cap)
-            rc = L.bm2_sam_se(C.byref(d), C.byref(opt), C.byref(so), C.byref(r), C.byref(t), a.ctypes.data, reg_off.ctypes.data,
-                              C.c_int64(n_processed), buf, C.c_int64(cap), C.byref(need))
+            if paired:
+                pes = (PeStat * 4)()
+                rc = L.bm2_sam_pe(C.byref(d), C.byref(opt), C.byref(so), C.byref(r), C.byref(t), a.ctypes.data, reg_off.ctypes.data,
+                                  C.c_int64(n_processed), None, pes, buf, C.c_int64(cap), C.byref(need))
+            else:
+                rc = L.bm2_sam_se(C.byref(d), C.byref(opt), C.byref(so), C.byref(r), C.byref(t), a.ctypes.data, reg_off.ctypes.data,
+                                  C.c_int64(n_processed), buf, C.c_int64(cap), C.byref(need))
             if rc == BM2_ECAP:
                 cap = need.value + 16
                 continue
-            _chk(rc, "bm2_sam_se")
-            return buf.raw[:need.value]
+            _chk(rc, "bm2_sam_pe" if paired else "bm2_sam_se")
+            return (buf.raw[:need.value], list(pes)) if paired else buf.raw[:need.value]
     finally:
         L.bm2_index_free(C.byref(d))
 

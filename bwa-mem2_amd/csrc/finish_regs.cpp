@@ -8,6 +8,7 @@
 #include <vector>
 #include "../../include/bm2.h"
 #include "ksort_host.h"
+#include "host_tail.h"
 
 void bm2_set_error(const char *fmt, ...);
 
@@ -83,6 +84,7 @@ bool gen_score(const int8_t mat[25], int o_del, int e_del, int o_ins, int e_ins,
 // mem_patch_reg, bwamem.cpp:175-225
 int patch_reg(const bm2_opt *opt, int64_t l_pac, const uint8_t *ref_string, const uint8_t *query, const bm2_alnreg_t *a,
               const bm2_alnreg_t *b, int *_w) {
+    if (!ref_string || !query) return 0;                   // bwamem.cpp:181
     int w, score = 0, q_s, r_s;
     double r;
     if (a->rb < l_pac && b->rb >= l_pac) return 0;
@@ -150,6 +152,10 @@ int sort_dedup_patch(const bm2_opt *opt, int64_t l_pac, const uint8_t *ref_strin
 }
 
 }  // namespace
+
+int bm2h_sort_dedup_patch(const bm2_opt *opt, int64_t l_pac, const uint8_t *ref_string, const uint8_t *query, int n, bm2_alnreg_t *a) {
+    return sort_dedup_patch(opt, l_pac, ref_string, query, n, a);
+}
 
 // The tail of mem_kernel2_core for a whole chunk: regs of the device boundary in, final mem_alnreg_v contents out.
 extern "C" int bm2_finish_regs(const bm2_index_desc *idx, const bm2_opt *opt, const bm2_reads *reads, const bm2_reg_t *regs,

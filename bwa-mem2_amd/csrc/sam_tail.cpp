@@ -1,0 +1,1008 @@
+// sam_tail.cpp -- host side, rows 1-3 of SURVEY.md 8(f): worker_sam (bwamem.cpp:1216-1337) for single-end and paired-end
+// chunks.  Input: the mem_alnreg_v contents of every read (bm2_finish_regs).  Output: the SAM alignment lines, byte for
+// byte what `bwa-mem2 mem` prints.  Plain C++ on the host: per read a sort, a few banded global alignments with backtrack
+// (one per output record and per XA alternative), for pairs the insert-size statistics of the chunk (mem_pestat), mate
+// rescue (mem_matesw: a local Smith-Waterman in the shape of the reference's SSE2 kernel, whose quirks are observable) and
+// pairing (mem_pair) -- branchy and order-sensitive.  The mate-rescue SW is the next device kernel; this is its oracle.
+#include <limits.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include "../../include/bm2.h"
+#include <algorithm>
+#include "ksort_host.h"
+#include "host_tail.h"
+
+void bm2_set_error(const char *fmt, ...);
+
+namespace {
+
+enum { F_NOPAIRING = 0x4, F_ALL = 0x8, F_NO_MULTI = 0x10, F_NO_RESCUE = 0x20, F_REF_HDR = 0x100, F_SOFTCLIP = 0x200, F_PRIMARY5 = 0x800, F_KEEP_SUPP_MAPQ = 0x1000 };
+const int MINUS_INF = -0x40000000;
+
+struct Ref {                        // what bntseq_t + pac give this code
+    int64_t l_pac; const uint8_t *ref_string; int n_seqs; const int64_t *off; const char *const *name; const char *const *anno;
+    int64_t depos(int64_t pos, int *is_rev) const { return (*is_rev = (pos >= l_pac)) ? (l_pac << 1) - 1 - pos : pos; }   // bntseq.h:87-90
+    int pos2rid(int64_t pos_f) const {                         // bntseq.cpp:378-392
+        if (pos_f >= l_pac) return -1;
+        int left = 0, mid = 0, right = n_seqs;
+        while (left < right) {
+            mid = (left + right) >> 1;
+            if (pos_f >= off[mid]) {
+                if (mid == n_seqs - 1) break;
+                if (pos_f < off[mid + 1]) break;
+                left = mid + 1;
+            } else right = mid;
+        }
+        return mid;
+    }
+};
+
+void put_int(std::string &s, long long v) { char b[32]; snprintf(b, sizeof b, "%lld", v); s += b; }       // kputw / kputl
+
+// ---- ksw_global2 with backtrack (ksw.cpp:558-668): direction byte per cell = f<<4 | e<<2 | h ---------------------------
+int global_align(int qlen, const uint8_t *query, int tlen, const uint8_t *target, const int8_t *mat, int o_del, int e_del, int o_ins,
+                 int e_ins, int w, std::vector<uint32_t> &cigar) {
+    struct EH { int32_t h, e; };
+    const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
+    const int n_col = qlen < 2 * w + 1 ? qlen : 2 * w + 1;
+    std::vector<uint8_t> z((size_t)n_col * (size_t)tlen);
+    std::vector<EH> eh((size_t)qlen + 1);
+    int i, j, k;
+    eh[0].h = 0; eh[0].e = MINUS_INF;
+    for (j = 1; j <= qlen && j <= w; ++j) { eh[j].h = -(o_ins + e_ins * j); eh[j].e = MINUS_INF; }
+    for (; j <= qlen; ++j) eh[j].h = eh[j].e = MINUS_INF;
+    for (i = 0; i < tlen; ++i) {
+        int32_t f = MINUS_INF, h1, beg, end, t;
+        const int8_t *q = &mat[target[i] * 5];
+        beg = i > w ? i - w : 0;
+        end = i + w + 1 < qlen ? i + w + 1 : qlen;
+        h1 = beg == 0 ? -(o_del + e_del * (i + 1)) : MINUS_INF;
+        uint8_t *zi = &z[(size_t)i * n_col];
+        for (j = beg; j < end; ++j) {
+            EH *p = &eh[j];
+            int32_t h, m = p->h, e = p->e;
+            uint8_t d;
+            p->h = h1;
+            m += q[query[j]];
+            d = m >= e ? 0 : 1;
+            h = m >= e ? m : e;
+            d = h >= f ? d : 2;
+            h = h >= f ? h : f;
+            h1 = h;
+            t = m - oe_del; e -= e_del;
+            d |= e > t ? 1 << 2 : 0;
+            e = e > t ? e : t;
+            p->e = e;
+            t = m - oe_ins; f -= e_ins;
+            d |= f > t ? 2 << 4 : 0;
+            f = f > t ? f : t;
+            zi[j - beg] = d;
+        }
+        eh[end].h = h1; eh[end].e = MINUS_INF;
+    }
+    const int score = eh[qlen].h;
+    cigar.clear();
+    auto push = [&](int op, int len) {                         // push_cigar, ksw.cpp:546-556
+        if (cigar.empty() || op != (int)(cigar.back() & 0xf)) cigar.push_back((uint32_t)len << 4 | (uint32_t)op);
+        else cigar.back() += (uint32_t)len << 4;
+    };
+    int which = 0;
+    i = tlen - 1; k = (i + w + 1 < qlen ? i + w + 1 : qlen) - 1;
+    while (i >= 0 && k >= 0) {
+        which = z[(size_t)i * n_col + (k - (i > w ? i - w : 0))] >> (which << 1) & 3;
+        if (which == 0) { push(0, 1); --i; --k; }
+        else if (which == 1) { push(2, 1); --i; }
+        else { push(1, 1); --k; }
+    }
+    if (i >= 0) push(2, i + 1);
+    if (k >= 0) push(1, k + 1);
+    for (size_t a = 0, b = cigar.size(); a + 1 < b; ++a, --b) { uint32_t t = cigar[a]; cigar[a] = cigar[b - 1]; cigar[b - 1] = t; }
+    return score;
+}
+
+// ---- bwa_gen_cigar2 (bwa.cpp:260-347): CIGAR, score, NM and MD of query vs [rb, re).  false = the NULL return ----------
+bool gen_cigar(const int8_t mat[25], int o_del, int e_del, int o_ins, int e_ins, int w_, const Ref &R, int l_query, const uint8_t *query,
+               int64_t rb, int64_t re, int *score, std::vector<uint32_t> &cigar, int *NM, std::string &MD) {
+    cigar.clear(); MD.clear(); *NM = -1;
+    const int64_t l_pac = R.l_pac;
+    if (l_query <= 0 || rb >= re || (rb < l_pac && re > l_pac)) return false;
+    int64_t b = rb, e = re;                                     // bns_get_seq clamps (bntseq.cpp:320-345); a clamped range bails out
+    if (e > (l_pac << 1)) e = l_pac << 1;
+    if (b < 0) b = 0;
+    if (e - b != re - rb) return false;
+    const int64_t rlen = re - rb;
+    std::vector<uint8_t> rseq(R.ref_string + rb, R.ref_string + re), q(query, query + l_query);
+    if (rb >= l_pac) {                                          // reverse both: indels end up leftmost on the forward strand
+        for (int i = 0; i < l_query >> 1; ++i) { uint8_t t = q[i]; q[i] = q[l_query - 1 - i]; q[l_query - 1 - i] = t; }
+        for (int64_t i = 0; i < rlen >> 1; ++i) { uint8_t t = rseq[i]; rseq[i] = rseq[rlen - 1 - i]; rseq[rlen - 1 - i] = t; }
+    }
+    if (l_query == rlen && w_ == 0) {
+        cigar.push_back((uint32_t)l_query << 4 | 0);
+        int sc = 0;
+        for (int i = 0; i < l_query; ++i) sc += mat[rseq[i] * 5 + q[i]];
+        *score = sc;
+    } else {
+        int max_ins = (int)((double)(((l_query + 1) >> 1) * mat[0] - o_ins) / e_ins + 1.);
+        int max_del = (int)((double)(((l_query + 1) >> 1) * mat[0] - o_del) / e_del + 1.);
+        int max_gap = max_ins > max_del ? max_ins : max_del;
+        max_gap = max_gap > 1 ? max_gap : 1;
+        int w = (max_gap + abs((int)rlen - l_query) + 1) >> 1;
+        w = w < w_ ? w : w_;
+        const int min_w = abs((int)rlen - l_query) + 3;
+        w = w > min_w ? w : min_w;
+        *score = global_align(l_query, q.data(), (int)rlen, rseq.data(), mat, o_del, e_del, o_ins, e_ins, w, cigar);
+    }
+    {   // NM and MD (:311-340)
+        int x = 0, y = 0, u = 0, n_mm = 0, n_gap = 0;
+        const char *int2base = rb < l_pac ? "ACGTN" : "TGCAN";
+        const int n = (int)cigar.size();
+        for (int k = 0; k < n; ++k) {
+            const int op = cigar[k] & 0xf, len = (int)(cigar[k] >> 4);
+            if (op == 0) {
+                for (int i = 0; i < len; ++i) {
+                    if (q[x + i] != rseq[y + i]) { put_int(MD, u); MD.push_back(int2base[rseq[y + i]]); ++n_mm; u = 0; }
+                    else ++u;
+                }
+                x += len; y += len;
+            } else if (op == 2) {
+                if (k > 0 && k < n - 1) {
+                    put_int(MD, u); MD.push_back('^');
+                    for (int i = 0; i < len; ++i) MD.push_back(int2base[rseq[y + i]]);
+                    u = 0; n_gap += len;
+                }
+                y += len;
+            } else if (op == 1) { x += len; n_gap += len; }
+        }
+        put_int(MD, u);
+        *NM = n_mm + n_gap;
+    }
+    return true;
+}
+
+struct Aln {                        // mem_aln_t (bwamem.h:168-178)
+    int64_t pos = -1; int rid = -1, flag = 0, is_rev = 0, is_alt = 0, mapq = 0, NM = 0;
+    std::vector<uint32_t> cigar; std::string MD; const std::string *XA = nullptr;
+    int score = 0, sub = 0, alt_sc = 0;
+};
+
+int infer_bw(int l1, int l2, int score, int a, int q, int r) {  // bwamem.cpp:1811-1818
+    if (l1 == l2 && l1 * a - score < (q + r - a) << 1) return 0;
+    int w = (int)((double)((l1 < l2 ? l1 : l2) * a - score - q) / r + 2.);
+    if (w < abs(l1 - l2)) w = abs(l1 - l2);
+    return w;
+}
+
+int approx_mapq_se(const bm2_opt *opt, const bm2_sam_opt *so, const bm2_alnreg_t *a) {          // bwamem.cpp:1470-1494
+    int mapq, l, sub = a->sub ? a->sub : opt->min_seed_len * opt->a;
+    double identity;
+    sub = a->csub > sub ? a->csub : sub;
+    if (sub >= a->score) return 0;
+    l = a->qe - a->qb > a->re - a->rb ? a->qe - a->qb : (int)(a->re - a->rb);
+    identity = 1. - (double)(l * opt->a - a->score) / (opt->a + opt->b) / l;
+    if (a->score == 0) mapq = 0;
+    else if (so->mapQ_coef_len > 0) {
+        double tmp = l < so->mapQ_coef_len ? 1. : so->mapQ_coef_fac / log(l);
+        tmp *= identity * identity;
+        mapq = (int)(6.02 * (a->score - sub) / opt->a * tmp * tmp + .499);
+    } else {
+        mapq = (int)(30.0 * (1. - (double)sub / a->score) * log(a->seedcov) + .499);
+        mapq = identity < 0.95 ? (int)(mapq * identity * identity + .499) : mapq;
+    }
+    if (a->sub_n > 0) mapq -= (int)(4.343 * log(a->sub_n + 1) + .499);
+    if (mapq > 60) mapq = 60;
+    if (mapq < 0) mapq = 0;
+    mapq = (int)(mapq * (1. - a->frac_rep) + .499);
+    return mapq;
+}
+
+// mem_reg2aln, bwamem.cpp:1732-1805; ar == NULL -> the unmapped record
+bool reg2aln(const bm2_opt *opt, const bm2_sam_opt *so, const Ref &R, int l_query, const uint8_t *query, const bm2_alnreg_t *ar, Aln &a) {
+    a = Aln();
+    if (ar == 0 || ar->rb < 0 || ar->re < 0) { a.rid = -1; a.pos = -1; a.flag |= 0x4; return true; }
+    const int qb = ar->qb, qe = ar->qe;
+    const int64_t rb = ar->rb, re = ar->re;
+    a.mapq = ar->secondary < 0 ? approx_mapq_se(opt, so, ar) : 0;
+    if (ar->secondary >= 0) a.flag |= 0x100;
+    int tmp = infer_bw(qe - qb, (int)(re - rb), ar->truesc, opt->a, opt->o_del, opt->e_del);
+    int w2 = infer_bw(qe - qb, (int)(re - rb), ar->truesc, opt->a, opt->o_ins, opt->e_ins);
+    w2 = w2 > tmp ? w2 : tmp;
+    if (w2 > opt->w) w2 = w2 < ar->w ? w2 : ar->w;
+    int i = 0, score = 0, NM = 0, last_sc = -(1 << 30);
+    bool ok;
+    do {
+        w2 = w2 < opt->w << 2 ? w2 : opt->w << 2;
+        ok = gen_cigar(opt->mat, opt->o_del, opt->e_del, opt->o_ins, opt->e_ins, w2, R, qe - qb, query + qb, rb, re, &score, a.cigar, &NM, a.MD);
+        if (!ok) break;
+        if (score == last_sc || w2 == opt->w << 2) break;
+        last_sc = score;
+        w2 <<= 1;
+    } while (++i < 3 && score < ar->truesc - opt->a);
+    if (!ok) return false;                                      // the reference asserts a.cigar != NULL here
+    a.NM = NM;
+    int is_rev;
+    int64_t pos = R.depos(rb < R.l_pac ? rb : re - 1, &is_rev);
+    a.is_rev = is_rev;
+    if (!a.cigar.empty()) {                                     // squeeze out a leading or a trailing deletion
+        if ((a.cigar[0] & 0xf) == 2) { pos += a.cigar[0] >> 4; a.cigar.erase(a.cigar.begin()); }
+        else if ((a.cigar.back() & 0xf) == 2) a.cigar.pop_back();
+    }
+    if (qb != 0 || qe != l_query) {                             // clipping
+        const int clip5 = is_rev ? l_query - qe : qb, clip3 = is_rev ? qb : l_query - qe;
+        if (clip5) a.cigar.insert(a.cigar.begin(), (uint32_t)clip5 << 4 | 3);
+        if (clip3) a.cigar.push_back((uint32_t)clip3 << 4 | 3);
+    }
+    a.rid = R.pos2rid(pos);
+    if (a.rid < 0) return false;
+    a.pos = pos - R.off[a.rid];
+    a.score = ar->score; a.sub = ar->sub > ar->csub ? ar->sub : ar->csub;
+    a.is_alt = ar->is_alt; a.alt_sc = ar->alt_sc;
+    return true;
+}
+
+uint64_t hash_64(uint64_t key) {                                // utils.h:117-128
+    key += ~(key << 32); key ^= (key >> 22); key += ~(key << 13); key ^= (key >> 8);
+    key += (key << 3); key ^= (key >> 15); key += ~(key << 27); key ^= (key >> 31);
+    return key;
+}
+
+// mem_mark_primary_se_core, bwamem.cpp:1392-1418
+void mark_primary_core(const bm2_opt *opt, int n, bm2_alnreg_t *a, std::vector<int> &z) {
+    int tmp = opt->a + opt->b;
+    tmp = opt->o_del + opt->e_del > tmp ? opt->o_del + opt->e_del : tmp;
+    tmp = opt->o_ins + opt->e_ins > tmp ? opt->o_ins + opt->e_ins : tmp;
+    z.clear(); z.push_back(0);
+    for (int i = 1; i < n; ++i) {
+        size_t k;
+        for (k = 0; k < z.size(); ++k) {
+            const int j = z[k];
+            const int b_max = a[j].qb > a[i].qb ? a[j].qb : a[i].qb, e_min = a[j].qe < a[i].qe ? a[j].qe : a[i].qe;
+            if (e_min > b_max) {
+                const int min_l = a[i].qe - a[i].qb < a[j].qe - a[j].qb ? a[i].qe - a[i].qb : a[j].qe - a[j].qb;
+                if (e_min - b_max >= min_l * opt->mask_level) {
+                    if (a[j].sub == 0) a[j].sub = a[i].score;
+                    if (a[j].score - a[i].score <= tmp && (a[j].is_alt || !a[i].is_alt)) ++a[j].sub_n;
+                    break;
+                }
+            }
+        }
+        if (k == z.size()) z.push_back(i);
+        else a[i].secondary = z[k];
+    }
+}
+
+// mem_mark_primary_se, bwamem.cpp:1420-1465
+int mark_primary_se(const bm2_opt *opt, int n, bm2_alnreg_t *a, int64_t id) {
+    if (n == 0) return 0;
+    int n_pri = 0;
+    std::vector<int> z;
+    for (int i = 0; i < n; ++i) {
+        a[i].sub = a[i].alt_sc = 0; a[i].secondary = a[i].secondary_all = -1; a[i].hash = hash_64((uint64_t)(id + i));
+        if (!a[i].is_alt) ++n_pri;
+    }
+    k_introsort((size_t)n, a, [](const bm2_alnreg_t &x, const bm2_alnreg_t &y) {          // alnreg_hlt, bwamem.cpp:155
+        return x.score > y.score || (x.score == y.score && (x.is_alt < y.is_alt || (x.is_alt == y.is_alt && x.hash < y.hash)));
+    });
+    mark_primary_core(opt, n, a, z);
+    for (int i = 0; i < n; ++i) {
+        bm2_alnreg_t *p = &a[i];
+        p->secondary_all = i;
+        if (!p->is_alt && p->secondary >= 0 && a[p->secondary].is_alt) p->alt_sc = a[p->secondary].score;
+    }
+    if (n_pri >= 0 && n_pri < n) {
+        z.assign((size_t)n, 0);
+        if (n_pri > 0)
+            k_introsort((size_t)n, a, [](const bm2_alnreg_t &x, const bm2_alnreg_t &y) {  // alnreg_hlt2, bwamem.cpp:158
+                return x.is_alt < y.is_alt || (x.is_alt == y.is_alt && (x.score > y.score || (x.score == y.score && x.hash < y.hash)));
+            });
+        for (int i = 0; i < n; ++i) z[a[i].secondary_all] = i;
+        for (int i = 0; i < n; ++i) {
+            if (a[i].secondary >= 0) {
+                a[i].secondary_all = z[a[i].secondary];
+                if (a[i].is_alt) a[i].secondary = INT_MAX;
+            } else a[i].secondary_all = -1;
+        }
+        if (n_pri > 0) {
+            for (int i = 0; i < n_pri; ++i) { a[i].sub = 0; a[i].secondary = -1; }
+            mark_primary_core(opt, n_pri, a, z);
+        }
+    } else {
+        for (int i = 0; i < n; ++i) a[i].secondary_all = a[i].secondary;
+    }
+    return n_pri;
+}
+
+// mem_reorder_primary5, bwamem.cpp:1496-1519
+void reorder_primary5(int T, int n, bm2_alnreg_t *a) {
+    int n_pri = 0, left_st = INT_MAX, left_k = -1;
+    for (int k = 0; k < n; ++k) if (a[k].secondary < 0 && !a[k].is_alt && a[k].score >= T) ++n_pri;
+    if (n_pri <= 1) return;
+    for (int k = 0; k < n; ++k) {
+        const bm2_alnreg_t *p = &a[k];
+        if (p->secondary >= 0 || p->is_alt || p->score < T) continue;
+        if (p->qb < left_st) { left_st = p->qb; left_k = k; }
+    }
+    if (left_k == 0) return;
+    bm2_alnreg_t t = a[0]; a[0] = a[left_k]; a[left_k] = t;
+    for (int k = 1; k < n; ++k) {
+        bm2_alnreg_t *p = &a[k];
+        if (p->secondary == 0) p->secondary = left_k;
+        else if (p->secondary == left_k) p->secondary = 0;
+        if (p->secondary_all == 0) p->secondary_all = left_k;
+        else if (p->secondary_all == left_k) p->secondary_all = 0;
+    }
+}
+
+void put_cigar(std::string &s, const std::vector<uint32_t> &cg, const char *ops) {
+    for (uint32_t c : cg) { put_int(s, c >> 4); s.push_back(ops[c & 0xf]); }
+}
+
+// mem_gen_alt, bwamem_extra.cpp:118-183: the XA:Z value of every primary hit ("" = none)
+bool gen_alt(const bm2_opt *opt, const bm2_sam_opt *so, const Ref &R, int n, const bm2_alnreg_t *a, int l_query, const uint8_t *query,
+             std::vector<std::string> &XA, bool &any) {
+    auto pri_idx = [&](int i) {
+        const int k = a[i].secondary_all;
+        return (k >= 0 && a[i].score >= a[k].score * (double)so->XA_drop_ratio) ? k : -1;      // (a double parameter in the reference)
+    };
+    std::vector<int> cnt((size_t)n, 0); std::vector<char> has_alt((size_t)n, 0);
+    int tot = 0;
+    any = false;
+    for (int i = 0; i < n; ++i) {
+        const int r = pri_idx(i);
+        if (r >= 0) { ++cnt[r]; ++tot; if (a[i].is_alt) has_alt[r] = 1; }
+    }
+    if (tot == 0) return true;
+    any = true;
+    XA.assign((size_t)n, std::string());
+    for (int i = 0; i < n; ++i) {
+        const int r = pri_idx(i);
+        if (r < 0) continue;
+        if (cnt[r] > so->max_XA_hits_alt || (!has_alt[r] && cnt[r] > so->max_XA_hits)) continue;
+        Aln t;
+        if (!reg2aln(opt, so, R, l_query, query, &a[i], t)) return false;
+        std::string &s = XA[r];
+        s += R.name[t.rid]; s.push_back(','); s.push_back("+-"[t.is_rev]); put_int(s, t.pos + 1); s.push_back(',');
+        put_cigar(s, t.cigar, "MIDSHN");
+        s.push_back(','); put_int(s, t.NM); s.push_back(';');
+    }
+    return true;
+}
+
+// add_cigar, bwamem.cpp:1579-1590
+void add_cigar(const bm2_sam_opt *so, const Aln &p, std::string &s, int which) {
+    if (p.cigar.empty()) { s.push_back('*'); return; }
+    for (uint32_t cg : p.cigar) {
+        int c = cg & 0xf;
+        if (!(so->flag & F_SOFTCLIP) && !p.is_alt && (c == 3 || c == 4)) c = which ? 4 : 3;
+        put_int(s, cg >> 4); s.push_back("MIDSH"[c]);
+    }
+}
+
+int get_rlen(const std::vector<uint32_t> &cg) {                // bwamem.cpp:1820-1829
+    int l = 0;
+    for (uint32_t c : cg) { const int op = c & 0xf; if (op == 0 || op == 2) l += (int)(c >> 4); }
+    return l;
+}
+
+// mem_aln2sam (bwamem.cpp:1592-1730); m_ = the mate's alignment or NULL
+void aln2sam(const bm2_sam_opt *so, const Ref &R, std::string &s, const char *name, const char *comment, const char *qual, int l_seq,
+             const uint8_t *seq, const std::vector<Aln> &list, int which, const Aln *m_) {
+    Aln p = list[which], mtmp; Aln *m = 0;
+    const int n = (int)list.size();
+    if (m_) { mtmp = *m_; m = &mtmp; }
+    p.flag |= m ? 0x1 : 0;
+    p.flag |= p.rid < 0 ? 0x4 : 0;
+    p.flag |= m && m->rid < 0 ? 0x8 : 0;
+    if (p.rid < 0 && m && m->rid >= 0) { p.rid = m->rid; p.pos = m->pos; p.is_rev = m->is_rev; p.cigar.clear(); }      // copy mate to alignment
+    if (m && m->rid < 0 && p.rid >= 0) { m->rid = p.rid; m->pos = p.pos; m->is_rev = p.is_rev; m->cigar.clear(); }     // copy alignment to mate
+    p.flag |= p.is_rev ? 0x10 : 0;
+    p.flag |= m && m->is_rev ? 0x20 : 0;
+    s += name; s.push_back('\t');
+    put_int(s, (p.flag & 0xffff) | (p.flag & 0x10000 ? 0x100 : 0)); s.push_back('\t');
+    if (p.rid >= 0) {
+        s += R.name[p.rid]; s.push_back('\t');
+        put_int(s, p.pos + 1); s.push_back('\t');
+        put_int(s, p.mapq); s.push_back('\t');
+        add_cigar(so, p, s, which);
+    } else s += "*\t0\t0\t*";
+    s.push_back('\t');
+    if (m && m->rid >= 0) {                                     // mate position and template length
+        if (p.rid == m->rid) s.push_back('='); else s += R.name[m->rid];
+        s.push_back('\t');
+        put_int(s, m->pos + 1); s.push_back('\t');
+        if (p.rid == m->rid) {
+            const int64_t p0 = p.pos + (p.is_rev ? get_rlen(p.cigar) - 1 : 0), p1 = m->pos + (m->is_rev ? get_rlen(m->cigar) - 1 : 0);
+            if (m->cigar.empty() || p.cigar.empty()) s.push_back('0');
+            else put_int(s, -(p0 - p1 + (p0 > p1 ? 1 : p0 < p1 ? -1 : 0)));
+        } else s.push_back('0');
+    } else s += "*\t0\t0";
+    s.push_back('\t');
+    if (p.flag & 0x100) s += "*\t*";
+    else {
+        int qb = 0, qe = l_seq;
+        if (!p.cigar.empty() && which && !(so->flag & F_SOFTCLIP) && !p.is_alt) {
+            const uint32_t c0 = p.cigar[0], c1 = p.cigar.back();
+            if (!p.is_rev) {
+                if ((c0 & 0xf) == 4 || (c0 & 0xf) == 3) qb += c0 >> 4;
+                if ((c1 & 0xf) == 4 || (c1 & 0xf) == 3) qe -= c1 >> 4;
+            } else {
+                if ((c0 & 0xf) == 4 || (c0 & 0xf) == 3) qe -= c0 >> 4;
+                if ((c1 & 0xf) == 4 || (c1 & 0xf) == 3) qb += c1 >> 4;
+            }
+        }
+        if (!p.is_rev) {
+            for (int i = qb; i < qe; ++i) s.push_back("ACGTN"[seq[i]]);
+            s.push_back('\t');
+            if (qual) s.append(qual + qb, (size_t)(qe - qb)); else s.push_back('*');
+        } else {
+            for (int i = qe - 1; i >= qb; --i) s.push_back("TGCAN"[seq[i]]);
+            s.push_back('\t');
+            if (qual) { for (int i = qe - 1; i >= qb; --i) s.push_back(qual[i]); } else s.push_back('*');
+        }
+    }
+    if (!p.cigar.empty()) { s += "\tNM:i:"; put_int(s, p.NM); s += "\tMD:Z:"; s += p.MD; }
+    if (m && !m->cigar.empty()) { s += "\tMC:Z:"; add_cigar(so, *m, s, which); }
+    if (p.score >= 0) { s += "\tAS:i:"; put_int(s, p.score); }
+    if (p.sub >= 0) { s += "\tXS:i:"; put_int(s, p.sub); }
+    if (so->rg_id && so->rg_id[0]) { s += "\tRG:Z:"; s += so->rg_id; }
+    if (!(p.flag & 0x100)) {
+        int i;
+        for (i = 0; i < n; ++i) if (i != which && !(list[i].flag & 0x100)) break;
+        if (i < n) {
+            s += "\tSA:Z:";
+            for (i = 0; i < n; ++i) {
+                const Aln &r = list[i];
+                if (i == which || (r.flag & 0x100)) continue;
+                s += R.name[r.rid]; s.push_back(','); put_int(s, r.pos + 1); s.push_back(','); s.push_back("+-"[r.is_rev]); s.push_back(',');
+                put_cigar(s, r.cigar, "MIDSH");
+                s.push_back(','); put_int(s, r.mapq); s.push_back(','); put_int(s, r.NM); s.push_back(';');
+            }
+        }
+        if (p.alt_sc > 0) { char b[64]; snprintf(b, sizeof b, "\tpa:f:%.3f", (double)p.score / p.alt_sc); s += b; }
+    }
+    if (p.XA) { s += "\tXA:Z:"; s += *p.XA; }
+    if (comment) { s.push_back('\t'); s += comment; }
+    if ((so->flag & F_REF_HDR) && p.rid >= 0 && R.anno && R.anno[p.rid] && R.anno[p.rid][0]) {
+        s += "\tXR:Z:";
+        for (const char *c = R.anno[p.rid]; *c; ++c) s.push_back(*c == '\t' ? ' ' : *c);
+    }
+    s.push_back('\n');
+}
+
+// mem_reg2sam (bwamem.cpp:1521-1577)
+bool reg2sam(const bm2_opt *opt, const bm2_sam_opt *so, const Ref &R, std::string &out, const char *name, const char *comment,
+             const char *qual, int l_seq, const uint8_t *seq, int n, const bm2_alnreg_t *a, int extra_flag, const Aln *m) {
+    std::vector<std::string> XA; bool any_xa = false;
+    if (!(so->flag & F_ALL)) { if (!gen_alt(opt, so, R, n, a, l_seq, seq, XA, any_xa)) return false; }
+    std::vector<Aln> aa;
+    int l = 0;
+    for (int k = 0; k < n; ++k) {
+        const bm2_alnreg_t *p = &a[k];
+        if (p->score < so->T) continue;
+        if (p->secondary >= 0 && (p->is_alt || !(so->flag & F_ALL))) continue;
+        if (p->secondary >= 0 && p->secondary < INT_MAX && p->score < a[p->secondary].score * opt->drop_ratio) continue;
+        aa.emplace_back();
+        Aln &q = aa.back();
+        if (!reg2aln(opt, so, R, l_seq, seq, p, q)) return false;
+        q.XA = (any_xa && !XA[k].empty()) ? &XA[k] : nullptr;   // XA[k] is a NULL pointer in the reference when nothing was appended
+        q.flag |= extra_flag;
+        if (p->secondary >= 0) q.sub = -1;
+        if (l && p->secondary < 0) q.flag |= (so->flag & F_NO_MULTI) ? 0x10000 : 0x800;
+        if (!(so->flag & F_KEEP_SUPP_MAPQ) && l && !p->is_alt && q.mapq > aa[0].mapq) q.mapq = aa[0].mapq;
+        ++l;
+    }
+    if (aa.empty()) {
+        aa.emplace_back();
+        reg2aln(opt, so, R, l_seq, seq, 0, aa[0]);
+        aa[0].flag |= extra_flag;
+        aln2sam(so, R, out, name, comment, qual, l_seq, seq, aa, 0, m);
+    } else {
+        for (int k = 0; k < (int)aa.size(); ++k) aln2sam(so, R, out, name, comment, qual, l_seq, seq, aa, k, m);
+    }
+    return true;
+}
+
+// ================================================================================================== paired-end reads
+// ---- the local SW of ksw.cpp:111-381 (ksw_u8 / ksw_i16 / ksw_align2), restated lane by lane.  The SSE2 kernel is striped
+// (Farrar): vector j holds query positions j, j+slen, j+2*slen, ...; E(i+1,j) is taken from H before the lazy-F pass, so an
+// insertion followed by a deletion is possible inside a stripe segment but not across one -- the result depends on the
+// striping, hence the vectors are kept (P = 16 byte lanes or 8 word lanes) instead of a textbook recurrence.
+struct KswResult { int score = 0, te = -1, qe = -1, score2 = -1, te2 = -1, tb = -1, qb = -1; };
+enum { KSW_XBYTE = 0x10000, KSW_XSTOP = 0x20000, KSW_XSUBO = 0x40000, KSW_XSTART = 0x80000 };
+
+template <int P> struct KswProfile {                            // ksw_qinit, ksw.cpp:62-109
+    int qlen, slen, shift, max;
+    std::vector<int> qp;                                        // [m = 5][slen][P]
+    KswProfile(int qlen_, const uint8_t *query, const int8_t *mat) : qlen(qlen_) {
+        slen = (qlen + P - 1) / P;
+        int lo = 127, hi = 0;
+        for (int a = 0; a < 25; ++a) { if (mat[a] < lo) lo = mat[a]; if (mat[a] > hi) hi = mat[a]; }
+        max = hi;
+        shift = (256 - (lo & 0xff)) & 0xff;                     // uint8_t arithmetic of the reference
+        qp.assign((size_t)5 * slen * P, 0);
+        size_t t = 0;
+        for (int a = 0; a < 5; ++a) {
+            const int8_t *ma = mat + a * 5;
+            const int nlen = slen * P;
+            for (int i = 0; i < slen; ++i)
+                for (int k = i; k < nlen; k += slen) qp[t++] = (k >= qlen ? 0 : ma[query[k]]) + (P == 16 ? shift : 0);
+        }
+    }
+};
+
+template <int P>
+KswResult ksw_striped(const KswProfile<P> &q, int tlen, const uint8_t *target, int o_del, int e_del, int o_ins, int e_ins, int xtra) {
+    const bool U8 = P == 16;
+    const int slen = q.slen, oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
+    const int minsc = (xtra & KSW_XSUBO) ? xtra & 0xffff : 0x10000, endsc = (xtra & KSW_XSTOP) ? xtra & 0xffff : 0x10000;
+    auto ssub = [](int a, int b) { return a > b ? a - b : 0; };    // _mm_subs_epu8 / _mm_subs_epu16 on non-negative values
+    struct V { int v[P]; };
+    std::vector<V> Ha((size_t)slen), Hb((size_t)slen), E((size_t)slen), Hmax((size_t)slen);
+    for (int j = 0; j < slen; ++j) for (int k = 0; k < P; ++k) Ha[j].v[k] = Hb[j].v[k] = E[j].v[k] = Hmax[j].v[k] = 0;
+    V *H0 = Ha.data(), *H1 = Hb.data();
+    std::vector<uint64_t> b;
+    int te = -1, gmax = 0;
+    KswResult r;
+    for (int i = 0; i < tlen; ++i) {
+        const int *S = &q.qp[(size_t)target[i] * slen * P];
+        V h, f, mx;
+        for (int k = 0; k < P; ++k) { h.v[k] = k ? H0[slen - 1].v[k - 1] : 0; f.v[k] = 0; mx.v[k] = 0; }
+        for (int j = 0; j < slen; ++j) {
+            for (int k = 0; k < P; ++k) {
+                int hv = h.v[k];
+                if (U8) { hv += S[j * P + k]; if (hv > 255) hv = 255; hv = ssub(hv, q.shift); }      // adds_epu8, subs_epu8
+                else { hv += S[j * P + k]; if (hv > 32767) hv = 32767; if (hv < -32768) hv = -32768; } // adds_epi16
+                int e = E[j].v[k];
+                if (hv < e) hv = e;
+                if (hv < f.v[k]) hv = f.v[k];
+                if (mx.v[k] < hv) mx.v[k] = hv;
+                H1[j].v[k] = hv;
+                e = ssub(e, e_del);
+                int t = ssub(hv, oe_del);
+                E[j].v[k] = e > t ? e : t;
+                int fv = ssub(f.v[k], e_ins);
+                t = ssub(hv, oe_ins);
+                f.v[k] = fv > t ? fv : t;
+                h.v[k] = H0[j].v[k];
+            }
+        }
+        bool done = false;                                      // the lazy-F pass (16 rounds at most, as in both kernels)
+        for (int k16 = 0; k16 < 16 && !done; ++k16) {
+            for (int k = P - 1; k > 0; --k) f.v[k] = f.v[k - 1];
+            f.v[0] = 0;
+            for (int j = 0; j < slen; ++j) {
+                bool all_le = true;
+                for (int k = 0; k < P; ++k) {
+                    int hv = H1[j].v[k];
+                    if (hv < f.v[k]) hv = f.v[k];
+                    H1[j].v[k] = hv;
+                    hv = ssub(hv, oe_ins);
+                    f.v[k] = ssub(f.v[k], e_ins);
+                    if (f.v[k] > hv) all_le = false;
+                }
+                if (all_le) { done = true; break; }
+            }
+        }
+        int imax = 0;
+        for (int k = 0; k < P; ++k) if (mx.v[k] > imax) imax = mx.v[k];
+        if (imax >= minsc) {
+            if (b.empty() || (int32_t)b.back() + 1 != i) b.push_back((uint64_t)imax << 32 | (uint32_t)i);
+            else if ((int)(b.back() >> 32) < imax) b.back() = (uint64_t)imax << 32 | (uint32_t)i;
+        }
+        if (imax > gmax) {
+            gmax = imax; te = i;
+            for (int j = 0; j < slen; ++j) Hmax[j] = H1[j];
+            if (U8 ? (gmax + q.shift >= 255 || gmax >= endsc) : (gmax >= endsc)) break;
+        }
+        V *t = H1; H1 = H0; H0 = t;
+    }
+    r.score = U8 ? (gmax + q.shift < 255 ? gmax : 255) : gmax;
+    r.te = te;
+    if (!U8 || r.score != 255) {
+        int mxv = -1;
+        const int qlen = slen * P;
+        for (int i = 0; i < qlen; ++i) {
+            const int t = Hmax[i / P].v[i % P], pos = i / P + i % P * slen;
+            if (t > mxv) { mxv = t; r.qe = pos; }
+            else if (t == mxv && pos < r.qe) r.qe = pos;
+        }
+        if (!b.empty()) {
+            const int d = (r.score + q.max - 1) / q.max, low = te - d, high = te + d;
+            for (uint64_t x : b) {
+                const int e = (int32_t)x;
+                if ((e < low || e > high) && (int)(x >> 32) > r.score2) { r.score2 = (int)(x >> 32); r.te2 = e; }
+            }
+        }
+    }
+    return r;
+}
+
+// ksw_align2, ksw.cpp:340-381 (query and target are private copies here; the reference reverses them in place and back)
+KswResult ksw_align2(int qlen, const uint8_t *query, int tlen, const uint8_t *target, const int8_t *mat, int o_del, int e_del, int o_ins,
+                     int e_ins, int xtra) {
+    const bool byte = (xtra & KSW_XBYTE) != 0;
+    KswResult r = byte ? ksw_striped<16>(KswProfile<16>(qlen, query, mat), tlen, target, o_del, e_del, o_ins, e_ins, xtra)
+                       : ksw_striped<8>(KswProfile<8>(qlen, query, mat), tlen, target, o_del, e_del, o_ins, e_ins, xtra);
+    if ((xtra & KSW_XSTART) == 0 || ((xtra & KSW_XSUBO) && r.score < (xtra & 0xffff))) return r;
+    std::vector<uint8_t> rq(query, query + r.qe + 1), rt(target, target + tlen);
+    std::reverse(rq.begin(), rq.end());
+    std::reverse(rt.begin(), rt.begin() + r.te + 1);            // only the first te+1 bases are reversed; the rest of the target stays
+    const int x2 = KSW_XSTOP | r.score;
+    const KswResult rr = byte ? ksw_striped<16>(KswProfile<16>(r.qe + 1, rq.data(), mat), tlen, rt.data(), o_del, e_del, o_ins, e_ins, x2)
+                              : ksw_striped<8>(KswProfile<8>(r.qe + 1, rq.data(), mat), tlen, rt.data(), o_del, e_del, o_ins, e_ins, x2);
+    if (r.score == rr.score) { r.tb = r.te - rr.te; r.qb = r.qe - rr.qe; }
+    return r;
+}
+
+struct PeStat { int low = 0, high = 0, failed = 0; double avg = 0, std = 0; };   // mem_pestat_t
+
+int infer_dir(int64_t l_pac, int64_t b1, int64_t b2, int64_t *dist) {            // bwamem_pair.cpp:58-65
+    const int r1 = (b1 >= l_pac), r2 = (b2 >= l_pac);
+    const int64_t p2 = r1 == r2 ? b2 : (l_pac << 1) - 1 - b2;
+    *dist = p2 > b1 ? p2 - b1 : b1 - p2;
+    return (r1 == r2 ? 0 : 1) ^ (p2 > b1 ? 0 : 3);
+}
+
+int cal_sub(const bm2_opt *opt, const std::vector<bm2_alnreg_t> &r) {            // bwamem_pair.cpp:67-79
+    size_t j;
+    for (j = 1; j < r.size(); ++j) {
+        const int b_max = r[j].qb > r[0].qb ? r[j].qb : r[0].qb, e_min = r[j].qe < r[0].qe ? r[j].qe : r[0].qe;
+        if (e_min > b_max) {
+            const int min_l = r[j].qe - r[j].qb < r[0].qe - r[0].qb ? r[j].qe - r[j].qb : r[0].qe - r[0].qb;
+            if (e_min - b_max >= min_l * opt->mask_level) break;
+        }
+    }
+    return j < r.size() ? r[j].score : opt->min_seed_len * opt->a;
+}
+
+// mem_pestat, bwamem_pair.cpp:81-148 (without the log lines)
+void pestat(const bm2_opt *opt, const bm2_sam_opt *so, int64_t l_pac, const std::vector<std::vector<bm2_alnreg_t>> &regs, PeStat pes[4]) {
+    std::vector<uint64_t> isize[4];
+    const int n = (int)regs.size();
+    for (int d = 0; d < 4; ++d) pes[d] = PeStat();
+    for (int i = 0; i < n >> 1; ++i) {
+        const std::vector<bm2_alnreg_t> &r0 = regs[i << 1 | 0], &r1 = regs[i << 1 | 1];
+        if (r0.empty() || r1.empty()) continue;
+        if (cal_sub(opt, r0) > 0.8 * r0[0].score) continue;
+        if (cal_sub(opt, r1) > 0.8 * r1[0].score) continue;
+        if (r0[0].rid != r1[0].rid) continue;
+        int64_t is;
+        const int dir = infer_dir(l_pac, r0[0].rb, r1[0].rb, &is);
+        if (is && is <= so->max_ins) isize[dir].push_back((uint64_t)is);
+    }
+    for (int d = 0; d < 4; ++d) {
+        PeStat *r = &pes[d];
+        std::vector<uint64_t> &q = isize[d];
+        if (q.size() < 10) { r->failed = 1; continue; }
+        std::sort(q.begin(), q.end());
+        const int p25 = (int)q[(int)(.25 * q.size() + .499)], p50 = (int)q[(int)(.50 * q.size() + .499)], p75 = (int)q[(int)(.75 * q.size() + .499)];
+        (void)p50;
+        r->low = (int)(p25 - 2.0 * (p75 - p25) + .499);
+        if (r->low < 1) r->low = 1;
+        r->high = (int)(p75 + 2.0 * (p75 - p25) + .499);
+        size_t x = 0;
+        r->avg = 0;
+        for (uint64_t v : q) if (v >= (uint64_t)r->low && v <= (uint64_t)r->high) { r->avg += v; ++x; }
+        r->avg /= x;
+        r->std = 0;
+        for (uint64_t v : q) if (v >= (uint64_t)r->low && v <= (uint64_t)r->high) r->std += (v - r->avg) * (v - r->avg);
+        r->std = sqrt(r->std / x);
+        r->low = (int)(p25 - 3.0 * (p75 - p25) + .499);
+        r->high = (int)(p75 + 3.0 * (p75 - p25) + .499);
+        if (r->low > r->avg - 4.0 * r->std) r->low = (int)(r->avg - 4.0 * r->std + .499);
+        if (r->high < r->avg + 4.0 * r->std) r->high = (int)(r->avg + 4.0 * r->std + .499);
+        if (r->low < 1) r->low = 1;
+    }
+    size_t mx = 0;
+    for (int d = 0; d < 4; ++d) mx = mx > isize[d].size() ? mx : isize[d].size();
+    for (int d = 0; d < 4; ++d) if (pes[d].failed == 0 && isize[d].size() < mx * 0.05) pes[d].failed = 1;
+}
+
+// bns_fetch_seq (bntseq.cpp:453-482) on the unpacked reference: [*beg, *end) clamped to the contig (strand-aware) that holds mid
+bool fetch_seq(const Ref &R, const int32_t *ann_len, int64_t *beg, int64_t mid, int64_t *end, int *rid, std::vector<uint8_t> &seq) {
+    if (*end < *beg) { const int64_t t = *beg; *beg = *end; *end = t; }
+    int is_rev;
+    *rid = R.pos2rid(R.depos(mid, &is_rev));
+    if (*rid < 0) return false;
+    int64_t far_beg = R.off[*rid], far_end = far_beg + ann_len[*rid];
+    if (is_rev) { const int64_t t = far_beg; far_beg = (R.l_pac << 1) - far_end; far_end = (R.l_pac << 1) - t; }
+    *beg = *beg > far_beg ? *beg : far_beg;
+    *end = *end < far_end ? *end : far_end;
+    seq.assign(R.ref_string + *beg, R.ref_string + *end);       // .0123 = what bns_get_seq unpacks (forward, then reverse complement)
+    return true;
+}
+
+// mem_matesw, bwamem_pair.cpp:150-283 (MATE_SORT == 0): rescue the mate of hit `a` near where the insert-size model expects it
+int matesw(const bm2_opt *opt, const bm2_sam_opt *so, const Ref &R, const int32_t *ann_len, const PeStat pes[4], const bm2_alnreg_t *a,
+           int l_ms, const uint8_t *ms, std::vector<bm2_alnreg_t> &ma) {
+    const int64_t l_pac = R.l_pac;
+    int skip[4], n = 0, rid = -1;
+    for (int r = 0; r < 4; ++r) skip[r] = pes[r].failed ? 1 : 0;
+    for (size_t i = 0; i < ma.size(); ++i) {
+        int64_t dist;
+        const int r = infer_dir(l_pac, a->rb, ma[i].rb, &dist);
+        if (dist >= pes[r].low && dist <= pes[r].high) skip[r] = 1;
+    }
+    if (skip[0] + skip[1] + skip[2] + skip[3] == 4) return 0;
+    for (int r = 0; r < 4; ++r) {
+        if (skip[r]) continue;
+        const int is_rev = (r >> 1 != (r & 1)), is_larger = !(r >> 1);
+        std::vector<uint8_t> rev, ref;
+        const uint8_t *seq = ms;
+        if (is_rev) {
+            rev.resize((size_t)l_ms);
+            for (int i = 0; i < l_ms; ++i) rev[l_ms - 1 - i] = ms[i] < 4 ? 3 - ms[i] : 4;
+            seq = rev.data();
+        }
+        int64_t rb, re;
+        if (!is_rev) {
+            rb = is_larger ? a->rb + pes[r].low : a->rb - pes[r].high;
+            re = (is_larger ? a->rb + pes[r].high : a->rb - pes[r].low) + l_ms;
+        } else {
+            rb = (is_larger ? a->rb + pes[r].low : a->rb - pes[r].high) - l_ms;
+            re = is_larger ? a->rb + pes[r].high : a->rb - pes[r].low;
+        }
+        if (rb < 0) rb = 0;
+        if (re > l_pac << 1) re = l_pac << 1;
+        bool have = false;
+        if (rb < re) have = fetch_seq(R, ann_len, &rb, (rb + re) >> 1, &re, &rid, ref);
+        if (have && a->rid == rid && re - rb >= opt->min_seed_len) {
+            const int xtra = KSW_XSUBO | KSW_XSTART | (l_ms * opt->a < 250 ? KSW_XBYTE : 0) | (opt->min_seed_len * opt->a);
+            const KswResult aln = ksw_align2(l_ms, seq, (int)(re - rb), ref.data(), opt->mat, opt->o_del, opt->e_del, opt->o_ins, opt->e_ins, xtra);
+            if (aln.score >= opt->min_seed_len && aln.qb >= 0) {
+                bm2_alnreg_t b; memset(&b, 0, sizeof b);
+                b.rid = a->rid; b.is_alt = a->is_alt;
+                b.qb = is_rev ? l_ms - (aln.qe + 1) : aln.qb;
+                b.qe = is_rev ? l_ms - aln.qb : aln.qe + 1;
+                b.rb = is_rev ? (l_pac << 1) - (rb + aln.te + 1) : rb + aln.tb;
+                b.re = is_rev ? (l_pac << 1) - (rb + aln.tb) : rb + aln.te + 1;
+                b.score = aln.score; b.csub = aln.score2; b.secondary = -1;
+                b.seedcov = (int)((b.re - b.rb < b.qe - b.qb ? b.re - b.rb : b.qe - b.qb) >> 1);
+                size_t i;
+                for (i = 0; i < ma.size(); ++i) if (ma[i].score < b.score) break;      // keep ma sorted by score
+                ma.insert(ma.begin() + (long)i, b);
+            }
+            ++n;
+        }
+        if (n) ma.resize((size_t)bm2h_sort_dedup_patch(opt, 0, 0, 0, (int)ma.size(), ma.data()));
+    }
+    return n;
+}
+
+// mem_pair, bwamem_pair.cpp:285-346
+int pair_hits(const bm2_opt *opt, const Ref &R, const PeStat pes[4], const std::vector<bm2_alnreg_t> a[2], int id, int *sub, int *n_sub,
+              int z[2], const int n_pri[2]) {
+    struct P64 { uint64_t x, y; };
+    auto lt = [](const P64 &p, const P64 &q) { return p.x < q.x || (p.x == q.x && p.y < q.y); };
+    std::vector<P64> v, u;
+    const int64_t l_pac = R.l_pac;
+    for (int r = 0; r < 2; ++r)
+        for (int i = 0; i < n_pri[r]; ++i) {
+            const bm2_alnreg_t *e = &a[r][i];
+            P64 key;
+            key.x = (uint64_t)(e->rb < l_pac ? e->rb : (l_pac << 1) - 1 - e->rb);
+            key.x = (uint64_t)e->rid << 32 | (key.x - (uint64_t)R.off[e->rid]);
+            key.y = (uint64_t)e->score << 32 | (uint64_t)(int64_t)(i << 2 | (e->rb >= l_pac) << 1 | r);
+            v.push_back(key);
+        }
+    std::sort(v.begin(), v.end(), lt);
+    int y[4] = { -1, -1, -1, -1 };
+    for (int i = 0; i < (int)v.size(); ++i) {
+        for (int r = 0; r < 2; ++r) {
+            const int dir = r << 1 | (int)(v[i].y >> 1 & 1);
+            if (pes[dir].failed) continue;
+            const int which = r << 1 | (int)((v[i].y & 1) ^ 1);
+            if (y[which] < 0) continue;
+            for (int k = y[which]; k >= 0; --k) {
+                if ((int)(v[k].y & 3) != which) continue;
+                const int64_t dist = (int64_t)v[i].x - (int64_t)v[k].x;
+                if (dist > pes[dir].high) break;
+                if (dist < pes[dir].low) continue;
+                const double ns = (dist - pes[dir].avg) / pes[dir].std;
+                int q = (int)((v[i].y >> 32) + (v[k].y >> 32) + .721 * log(2. * erfc(fabs(ns) * M_SQRT1_2)) * opt->a + .499);
+                if (q < 0) q = 0;
+                P64 p;
+                p.y = (uint64_t)k << 32 | (uint64_t)i;
+                p.x = (uint64_t)q << 32 | (hash_64(p.y ^ (uint64_t)(int64_t)(id << 8)) & 0xffffffffU);
+                u.push_back(p);
+            }
+        }
+        y[v[i].y & 3] = i;
+    }
+    int ret;
+    if (!u.empty()) {
+        int tmp = opt->a + opt->b;
+        tmp = tmp > opt->o_del + opt->e_del ? tmp : opt->o_del + opt->e_del;
+        tmp = tmp > opt->o_ins + opt->e_ins ? tmp : opt->o_ins + opt->e_ins;
+        std::sort(u.begin(), u.end(), lt);
+        const int i = (int)(u.back().y >> 32), k = (int)(u.back().y << 32 >> 32);
+        z[v[i].y & 1] = (int)(v[i].y << 32 >> 34);
+        z[v[k].y & 1] = (int)(v[k].y << 32 >> 34);
+        ret = (int)(u.back().x >> 32);
+        *sub = u.size() > 1 ? (int)(u[u.size() - 2].x >> 32) : 0;
+        *n_sub = 0;
+        for (long t = (long)u.size() - 2; t >= 0; --t) if (*sub - (int)(u[(size_t)t].x >> 32) <= tmp) ++*n_sub;
+    } else { ret = 0; *sub = 0; *n_sub = 0; }
+    return ret;
+}
+
+int raw_mapq(int diff, int a) { return (int)(6.02 * diff / a + .499); }
+
+struct ReadIO { const char *name, *comment, *qual; int l_seq; const uint8_t *seq; };
+
+// mem_sam_pe, bwamem_pair.cpp:353-551
+bool sam_pe(const bm2_opt *opt, const bm2_sam_opt *so, const Ref &R, const int32_t *ann_len, const PeStat pes[4], uint64_t id,
+            const ReadIO s[2], std::vector<bm2_alnreg_t> a[2], std::string &out) {
+    int z[2] = { 0, 0 }, o, subo, n_sub, extra_flag = 1, n_pri[2];
+    Aln h[2];
+    if (!(so->flag & F_NO_RESCUE)) {
+        std::vector<bm2_alnreg_t> b[2];
+        for (int i = 0; i < 2; ++i)
+            for (size_t j = 0; j < a[i].size(); ++j)
+                if (a[i][j].score >= a[i][0].score - so->pen_unpaired) b[i].push_back(a[i][j]);
+        for (int i = 0; i < 2; ++i)
+            for (size_t j = 0; j < b[i].size() && (int)j < so->max_matesw; ++j)
+                matesw(opt, so, R, ann_len, pes, &b[i][j], s[!i].l_seq, s[!i].seq, a[!i]);
+    }
+    n_pri[0] = mark_primary_se(opt, (int)a[0].size(), a[0].data(), (int64_t)(id << 1 | 0));
+    n_pri[1] = mark_primary_se(opt, (int)a[1].size(), a[1].data(), (int64_t)(id << 1 | 1));
+    if (so->flag & F_PRIMARY5) { reorder_primary5(so->T, (int)a[0].size(), a[0].data()); reorder_primary5(so->T, (int)a[1].size(), a[1].data()); }
+    bool paired = false;
+    if (!(so->flag & F_NOPAIRING) && n_pri[0] && n_pri[1] && (o = pair_hits(opt, R, pes, a, (int)id, &subo, &n_sub, z, n_pri)) > 0) {
+        int is_multi[2], q_pe, score_un, q_se[2];
+        for (int i = 0; i < 2; ++i) {
+            int j;
+            for (j = 1; j < n_pri[i]; ++j) if (a[i][j].secondary < 0 && a[i][j].score >= so->T) break;
+            is_multi[i] = j < n_pri[i] ? 1 : 0;
+        }
+        if (!(is_multi[0] || is_multi[1])) {
+            paired = true;
+            score_un = a[0][0].score + a[1][0].score - so->pen_unpaired;
+            subo = subo > score_un ? subo : score_un;
+            q_pe = raw_mapq(o - subo, opt->a);
+            if (n_sub > 0) q_pe -= (int)(4.343 * log(n_sub + 1) + .499);
+            if (q_pe < 0) q_pe = 0;
+            if (q_pe > 60) q_pe = 60;
+            q_pe = (int)(q_pe * (1. - .5 * (a[0][0].frac_rep + a[1][0].frac_rep)) + .499);
+            if (o > score_un) {
+                bm2_alnreg_t *c[2] = { &a[0][z[0]], &a[1][z[1]] };
+                for (int i = 0; i < 2; ++i) {
+                    if (c[i]->secondary >= 0) { c[i]->sub = a[i][c[i]->secondary].score; c[i]->secondary = -2; }
+                    q_se[i] = approx_mapq_se(opt, so, c[i]);
+                }
+                q_se[0] = q_se[0] > q_pe ? q_se[0] : q_pe < q_se[0] + 40 ? q_pe : q_se[0] + 40;
+                q_se[1] = q_se[1] > q_pe ? q_se[1] : q_pe < q_se[1] + 40 ? q_pe : q_se[1] + 40;
+                extra_flag |= 2;
+                q_se[0] = q_se[0] < raw_mapq(c[0]->score - c[0]->csub, opt->a) ? q_se[0] : raw_mapq(c[0]->score - c[0]->csub, opt->a);
+                q_se[1] = q_se[1] < raw_mapq(c[1]->score - c[1]->csub, opt->a) ? q_se[1] : raw_mapq(c[1]->score - c[1]->csub, opt->a);
+            } else {
+                z[0] = z[1] = 0;
+                q_se[0] = approx_mapq_se(opt, so, &a[0][0]);
+                q_se[1] = approx_mapq_se(opt, so, &a[1][0]);
+            }
+            for (int i = 0; i < 2; ++i) {
+                const int k = a[i][z[i]].secondary_all;
+                if (k >= 0 && k < n_pri[i]) {                  // switch secondary and primary if both are non-ALT
+                    for (size_t j = 0; j < a[i].size(); ++j)
+                        if (a[i][j].secondary_all == k || (int)j == k) a[i][j].secondary_all = z[i];
+                    a[i][z[i]].secondary_all = -1;
+                }
+            }
+            std::vector<std::string> XA[2]; bool any_xa[2] = { false, false };
+            if (!(so->flag & F_ALL))
+                for (int i = 0; i < 2; ++i)
+                    if (!gen_alt(opt, so, R, (int)a[i].size(), a[i].data(), s[i].l_seq, s[i].seq, XA[i], any_xa[i])) return false;
+            std::vector<Aln> aa[2];
+            for (int i = 0; i < 2; ++i) {
+                if (!reg2aln(opt, so, R, s[i].l_seq, s[i].seq, &a[i][z[i]], h[i])) return false;
+                h[i].mapq = q_se[i];
+                h[i].flag |= 0x40 << i | extra_flag;
+                h[i].XA = (any_xa[i] && !XA[i][z[i]].empty()) ? &XA[i][z[i]] : nullptr;
+                aa[i].push_back(h[i]);
+                if (n_pri[i] < (int)a[i].size()) {             // the read has ALT hits
+                    const bm2_alnreg_t *p = &a[i][n_pri[i]];
+                    if (p->score < so->T || p->secondary >= 0 || !p->is_alt) continue;
+                    Aln g;
+                    if (!reg2aln(opt, so, R, s[i].l_seq, s[i].seq, p, g)) return false;
+                    g.flag |= 0x800 | 0x40 << i | extra_flag;
+                    g.XA = (any_xa[i] && !XA[i][n_pri[i]].empty()) ? &XA[i][n_pri[i]] : nullptr;
+                    aa[i].push_back(g);
+                }
+            }
+            for (int i = 0; i < (int)aa[0].size(); ++i) aln2sam(so, R, out, s[0].name, s[0].comment, s[0].qual, s[0].l_seq, s[0].seq, aa[0], i, &h[1]);
+            for (int i = 0; i < (int)aa[1].size(); ++i) aln2sam(so, R, out, s[1].name, s[1].comment, s[1].qual, s[1].l_seq, s[1].seq, aa[1], i, &h[0]);
+        }
+    }
+    if (paired) return true;
+    // no_pairing:
+    for (int i = 0; i < 2; ++i) {
+        int which = -1;
+        if (!a[i].empty()) {
+            if (a[i][0].score >= so->T) which = 0;
+            else if (n_pri[i] < (int)a[i].size() && a[i][n_pri[i]].score >= so->T) which = n_pri[i];
+        }
+        if (!reg2aln(opt, so, R, s[i].l_seq, s[i].seq, which >= 0 ? &a[i][which] : 0, h[i])) return false;
+    }
+    if (!(so->flag & F_NOPAIRING) && h[0].rid == h[1].rid && h[0].rid >= 0) {
+        int64_t dist;
+        const int d = infer_dir(R.l_pac, a[0][0].rb, a[1][0].rb, &dist);
+        if (!pes[d].failed && dist >= pes[d].low && dist <= pes[d].high) extra_flag |= 2;
+    }
+    if (!reg2sam(opt, so, R, out, s[0].name, s[0].comment, s[0].qual, s[0].l_seq, s[0].seq, (int)a[0].size(), a[0].data(), 0x41 | extra_flag, &h[1])) return false;
+    if (!reg2sam(opt, so, R, out, s[1].name, s[1].comment, s[1].qual, s[1].l_seq, s[1].seq, (int)a[1].size(), a[1].data(), 0x81 | extra_flag, &h[0])) return false;
+    return true;
+}
+
+}  // namespace
+
+extern "C" void bm2_sam_opt_init(bm2_sam_opt *o) {
+    if (!o) return;
+    memset(o, 0, sizeof *o);
+    o->T = 30; o->flag = 0; o->max_XA_hits = 5; o->max_XA_hits_alt = 200; o->XA_drop_ratio = 0.80f;
+    o->mapQ_coef_len = 50; o->mapQ_coef_fac = (int32_t)log(o->mapQ_coef_len);     // an int in mem_opt_t: 3
+    o->pen_unpaired = 17; o->max_ins = 10000; o->max_matesw = 50;
+    o->rg_id = 0;
+}
+
+extern "C" int bm2_sam_pe(const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt *so, const bm2_reads *reads,
+                          const bm2_read_text *txt, const bm2_alnreg_t *alnregs, const int64_t *reg_off, int64_t n_processed,
+                          const bm2_pestat *pes_in, bm2_pestat *pes_out, char *out, int64_t cap, int64_t *n_out) {
+    if (!idx || !opt || !so || !reads || !txt || !txt->name || !reg_off || !n_out || (reads->n_reads & 1) || (!alnregs && reg_off[reads->n_reads] > 0)) {
+        bm2_set_error("bm2_sam_pe: bad argument (reads must be interleaved pairs)"); return BM2_EINVAL;
+    }
+    if (!idx->ref_string || !idx->ann_offset || !idx->ann_len || !idx->ann_name) { bm2_set_error("bm2_sam_pe: the index descriptor needs ref_string, contig lengths and names"); return BM2_EINVAL; }
+    Ref R = { idx->l_pac, idx->ref_string, idx->n_seqs, idx->ann_offset, idx->ann_name, idx->ann_anno };
+    const int n = reads->n_reads;
+    std::vector<std::vector<bm2_alnreg_t>> regs((size_t)n);
+    for (int i = 0; i < n; ++i) regs[(size_t)i].assign(alnregs + reg_off[i], alnregs + reg_off[i + 1]);
+    PeStat pes[4];
+    if (pes_in) for (int d = 0; d < 4; ++d) { pes[d].low = pes_in[d].low; pes[d].high = pes_in[d].high; pes[d].failed = pes_in[d].failed; pes[d].avg = pes_in[d].avg; pes[d].std = pes_in[d].std; }
+    else pestat(opt, so, idx->l_pac, regs, pes);                 // per chunk, as mem_process_seqs does (bwamem.cpp:1366-1370)
+    if (pes_out) for (int d = 0; d < 4; ++d) { pes_out[d].low = pes[d].low; pes_out[d].high = pes[d].high; pes_out[d].failed = pes[d].failed; pes_out[d].pad = 0; pes_out[d].avg = pes[d].avg; pes_out[d].std = pes[d].std; }
+    std::string s;
+    for (int i = 0; i < n; i += 2) {
+        ReadIO io[2];
+        for (int k = 0; k < 2; ++k) {
+            io[k].name = txt->name[i + k]; io[k].comment = txt->comment ? txt->comment[i + k] : 0; io[k].qual = txt->qual ? txt->qual[i + k] : 0;
+            io[k].l_seq = reads->len[i + k]; io[k].seq = reads->enc + reads->off[i + k];
+        }
+        if (strcmp(io[0].name, io[1].name) != 0) { bm2_set_error("paired reads have different names: \"%s\", \"%s\"", io[0].name, io[1].name); return BM2_EINVAL; }
+        if (!sam_pe(opt, so, R, idx->ann_len, pes, (uint64_t)((n_processed >> 1) + (i >> 1)), io, &regs[(size_t)i], s)) {
+            bm2_set_error("bm2_sam_pe: pair %d has a hit whose CIGAR cannot be generated (range outside the reference)", i >> 1);
+            return BM2_EINVAL;
+        }
+    }
+    *n_out = (int64_t)s.size();
+    if ((int64_t)s.size() > cap) return BM2_ECAP;
+    if (out && !s.empty()) memcpy(out, s.data(), s.size());
+    return BM2_OK;
+}
+
+extern "C" int bm2_sam_se(const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt *so, const bm2_reads *reads,
+                          const bm2_read_text *txt, bm2_alnreg_t *alnregs, const int64_t *reg_off, int64_t n_processed, char *out,
+                          int64_t cap, int64_t *n_out) {
+    if (!idx || !opt || !so || !reads || !txt || !txt->name || !reg_off || !n_out || (!alnregs && reg_off[reads->n_reads] > 0)) {
+        bm2_set_error("bm2_sam_se: bad argument"); return BM2_EINVAL;
+    }
+    if (!idx->ref_string || !idx->ann_offset || !idx->ann_name) { bm2_set_error("bm2_sam_se: the index descriptor needs ref_string and contig names"); return BM2_EINVAL; }
+    Ref R = { idx->l_pac, idx->ref_string, idx->n_seqs, idx->ann_offset, idx->ann_name, idx->ann_anno };
+    std::string s;
+    for (int i = 0; i < reads->n_reads; ++i) {
+        bm2_alnreg_t *a = alnregs + reg_off[i];
+        const int n = (int)(reg_off[i + 1] - reg_off[i]);
+        mark_primary_se(opt, n, a, n_processed + i);
+        if (so->flag & F_PRIMARY5) reorder_primary5(so->T, n, a);
+        if (!reg2sam(opt, so, R, s, txt->name[i], txt->comment ? txt->comment[i] : 0, txt->qual ? txt->qual[i] : 0, reads->len[i],
+                     reads->enc + reads->off[i], n, a, 0, 0)) {
+            bm2_set_error("bm2_sam_se: read %d has a hit whose CIGAR cannot be generated (range outside the reference)", i);
+            return BM2_EINVAL;
+        }
+    }
+    *n_out = (int64_t)s.size();
+    if ((int64_t)s.size() > cap) return BM2_ECAP;
+    if (out && !s.empty()) memcpy(out, s.data(), s.size());
+    return BM2_OK;
+}

@@ -164,12 +164,14 @@ int bm2_finish_regs(const bm2_index_desc *idx, const bm2_opt *opt, const bm2_rea
 typedef struct {                    /* the fields of mem_opt_t (bwamem.h:74-110) this tail reads beyond bm2_opt */
     int32_t T;                      /* -T: minimum score to output (30) */
     int32_t flag;                   /* MEM_F_ALL 0x8, MEM_F_NO_MULTI 0x10, MEM_F_REF_HDR 0x100, MEM_F_SOFTCLIP 0x200,
-                                     * MEM_F_PRIMARY5 0x800, MEM_F_KEEP_SUPP_MAPQ 0x1000 */
+                                     * MEM_F_PRIMARY5 0x800, MEM_F_KEEP_SUPP_MAPQ 0x1000; pairs: MEM_F_NOPAIRING 0x4, MEM_F_NO_RESCUE 0x20 */
     int32_t max_XA_hits, max_XA_hits_alt;   /* 5, 200 */
     float   XA_drop_ratio;          /* 0.80 */
     float   mapQ_coef_len;          /* 50 */
     int32_t mapQ_coef_fac;          /* (int)log(50) = 3: an int in the reference */
-    int32_t pad;
+    int32_t pen_unpaired;           /* -U, 17 */
+    int32_t max_ins;                /* 10000: pairs further apart are ignored by the insert-size statistics */
+    int32_t max_matesw;             /* -m, 50: mate-rescue rounds per end */
     const char *rg_id;              /* bwa_rg_id: RG:Z: value, NULL or "" = none */
 } bm2_sam_opt;
 void bm2_sam_opt_init(bm2_sam_opt *o);                  /* the defaults of mem_opt_init, bwamem.cpp:107-143 */
@@ -185,6 +187,15 @@ typedef struct {                    /* what bseq1_t carries besides the bases (k
  * out/cap: caller's buffer; *n_out = bytes needed (BM2_ECAP if cap is too small: grow and call again with FRESH alnregs). */
 int bm2_sam_se(const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt *so, const bm2_reads *reads, const bm2_read_text *txt,
                bm2_alnreg_t *alnregs, const int64_t *reg_off, int64_t n_processed, char *out, int64_t cap, int64_t *n_out);
+
+/* Paired-end chunks (reads interleaved: 2i, 2i+1): mem_pestat over the chunk (bwamem_pair.cpp:81-148) unless pes_in is
+ * given, then per pair mem_sam_pe (:353-551): mate rescue (mem_matesw :150-283 -> ksw_align2, ksw.cpp:340-381), mem_pair
+ * (:285-346), mapping qualities, the records of both ends.  alnregs are not modified.  pes_out (optional) receives the four
+ * orientation models (FF, FR, RF, RR). */
+typedef struct { int32_t low, high, failed, pad; double avg, std; } bm2_pestat;      /* mem_pestat_t, bwamem.h:162-166 */
+int bm2_sam_pe(const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt *so, const bm2_reads *reads, const bm2_read_text *txt,
+               const bm2_alnreg_t *alnregs, const int64_t *reg_off, int64_t n_processed, const bm2_pestat *pes_in, bm2_pestat *pes_out,
+               char *out, int64_t cap, int64_t *n_out);
 
 /* ---- the same path split so that a caller can keep inputs resident in HBM and time only the device work */
 int bm2_batch_upload(bm2_ctx *c, const bm2_reads *reads);                 /* H2D (pinned staging) */

@@ -752,10 +752,14 @@ int ora_band_clamp(int w, int qlen, int max_sc, int end_bonus, int o_ins, int e_
 }
 
 /* ksw_extend2 (ksw.cpp:432-533) == BandedPairWiseSW::scalarBandedSWA (bandedSWA.cpp:116-237).
- * `w` must already be clamped by ora_band_clamp. */
-int ora_ksw_extend(int qlen, const uint8_t *query, int tlen, const uint8_t *target, const int8_t *mat,
-                   int o_del, int e_del, int o_ins, int e_ins, int w, int end_bonus, int zdrop, int h0,
-                   int *_qle, int *_tle, int *_gtle, int *_gscore, int *_max_off, int64_t *cells) {
+ * `w` must already be clamped by ora_band_clamp.  cls = 8 / 16: the pair runs in the reference's int8 / int16 SIMD kernel,
+ * whose Z-drop test (ZSCORE8 / ZSCORE16, bandedSWA.cpp:268-281, 309-322) is NOT the scalar one: it is evaluated on every
+ * row (also the row that raised the maximum, and also when zdrop <= 0), in wrapping lane arithmetic with zdrop itself
+ * truncated to the lane width (-d 200 is -56 in the int8 kernel), and the diagonal offset is not multiplied by the gap
+ * extension penalty.  With e_del = e_ins = 1 and 0 < zdrop < 128 the two tests agree. */
+int ora_ksw_extend_cls(int qlen, const uint8_t *query, int tlen, const uint8_t *target, const int8_t *mat,
+                       int o_del, int e_del, int o_ins, int e_ins, int w, int end_bonus, int zdrop, int h0,
+                       int *_qle, int *_tle, int *_gtle, int *_gscore, int *_max_off, int64_t *cells, int cls) {
     typedef struct { int32_t h, e; } eh_t;
     const int m = 5;
     int i, j, oe_del = o_del + e_del, oe_ins = o_ins + e_ins, beg, end, max, max_i, max_j, max_ie, gscore, max_off;
@@ -800,12 +804,20 @@ int ora_ksw_extend(int qlen, const uint8_t *query, int tlen, const uint8_t *targ
         if (mm > max) {
             max = mm; max_i = i; max_j = mj;
             max_off = max_off > abs(mj - i) ? max_off : abs(mj - i);
-        } else if (zdrop > 0) {
+        } else if (cls == 32 && zdrop > 0) {
             if (i - max_i > mj - max_j) {
                 if (max - mm - ((i - max_i) - (mj - max_j)) * e_del > zdrop) break;
             } else {
                 if (max - mm - ((mj - max_j) - (i - max_i)) * e_ins > zdrop) break;
             }
+        }
+        if (cls != 32) {
+#define ORA_WR(v) (cls == 8 ? (int)(int8_t)(v) : (int)(int16_t)(v))
+            const int ti = ORA_WR(i - max_i), tj = ORA_WR(mj - max_j);
+            const int diff = ti > tj ? ORA_WR(ti - tj) : ORA_WR(tj - ti);
+            const int t2 = ORA_WR(ORA_WR(max - mm) - diff);
+            if (t2 > ORA_WR(zdrop)) break;
+#undef ORA_WR
         }
         for (j = beg; j < end && eh[j].h == 0 && eh[j].e == 0; ++j) {}
         beg = j;
@@ -820,6 +832,13 @@ int ora_ksw_extend(int qlen, const uint8_t *query, int tlen, const uint8_t *targ
     if (_max_off) *_max_off = max_off;
     if (cells) *cells += nc;
     return max;
+}
+
+int ora_ksw_extend(int qlen, const uint8_t *query, int tlen, const uint8_t *target, const int8_t *mat,
+                   int o_del, int e_del, int o_ins, int e_ins, int w, int end_bonus, int zdrop, int h0,
+                   int *_qle, int *_tle, int *_gtle, int *_gscore, int *_max_off, int64_t *cells) {
+    return ora_ksw_extend_cls(qlen, query, tlen, target, mat, o_del, e_del, o_ins, e_ins, w, end_bonus, zdrop, h0, _qle, _tle, _gtle,
+                              _gscore, _max_off, cells, 32);
 }
 
 /* cal_max_gap, bwamem.cpp:66-76 */
@@ -858,8 +877,8 @@ static void extend_task(const ora_opt *opt, const uint8_t *qs, int len2, const u
     for (int i = 0; i < ORA_MAX_BAND_TRY; i++) {
         int w = opt->w << i, qle, tle, gtle, gscore, max_off;
         int wc = ora_band_clamp(w, len2, opt->a, end_bonus, opt->o_ins, opt->e_ins, opt->o_del, opt->e_del, cls);
-        int sc = ora_ksw_extend(len2, qs, len1, rs, opt->mat, opt->o_del, opt->e_del, opt->o_ins, opt->e_ins, wc,
-                                end_bonus, opt->zdrop, h0, &qle, &tle, &gtle, &gscore, &max_off, cells);
+        int sc = ora_ksw_extend_cls(len2, qs, len1, rs, opt->mat, opt->o_del, opt->e_del, opt->o_ins, opt->e_ins, wc,
+                                    end_bonus, opt->zdrop, h0, &qle, &tle, &gtle, &gscore, &max_off, cells, cls);
         pr->score = sc; pr->qle = qle; pr->tle = tle; pr->gtle = gtle; pr->gscore = gscore; pr->max_off = max_off;
         pr->w_used = w;
         if (sc == prev || max_off < (w >> 1) + (w >> 2) || i + 1 == ORA_MAX_BAND_TRY) break;

@@ -80,6 +80,9 @@ int ora_ksw_extend(int qlen, const uint8_t *query, int tlen, const uint8_t *targ
                    int o_del, int e_del, int o_ins, int e_ins, int w, int end_bonus, int zdrop, int h0,
                    int *qle, int *tle, int *gtle, int *gscore, int *max_off, int64_t *cells);
 /* band clamp as the caller's class computes it (A.3 item 15 of SURVEY.md): cls 8/16 = wrapping, 32 = signed */
+int ora_ksw_extend_cls(int qlen, const uint8_t *query, int tlen, const uint8_t *target, const int8_t *mat,
+                       int o_del, int e_del, int o_ins, int e_ins, int w, int end_bonus, int zdrop, int h0,
+                       int *_qle, int *_tle, int *_gtle, int *_gscore, int *_max_off, int64_t *cells, int cls);
 int ora_band_clamp(int w, int qlen, int max_sc, int end_bonus, int o_ins, int e_ins, int o_del, int e_del, int cls);
 int ora_pair_class(int len1, int len2, int h0, int a);
 

@@ -24,6 +24,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <cstdint>
+#include <ctype.h>
 #include <string>
 #include <vector>
 #include <unistd.h>
@@ -154,9 +155,14 @@ int main(int argc, char **argv) {
         else if (c == 'w') opt->w = atoi(optarg);
         else if (c == 'A') opt->a = atoi(optarg), set_a = 1;
         else if (c == 'B') opt->b = atoi(optarg), set_b = 1;
-        else if (c == 'O') opt->o_del = opt->o_ins = atoi(optarg), set_od = set_oi = 1;
-        else if (c == 'E') opt->e_del = opt->e_ins = atoi(optarg), set_ed = set_ei = 1;
-        else if (c == 'L') opt->pen_clip5 = opt->pen_clip3 = atoi(optarg), set_l5 = set_l3 = 1;
+        else if (c == 'O' || c == 'E' || c == 'L') {           // INT[,INT] as fastmap.cpp:681-700 parses them
+            char *p;
+            const int v1 = (int)strtol(optarg, &p, 10);
+            const int v2 = (*p != 0 && ispunct(*p) && isdigit(p[1])) ? (int)strtol(p + 1, &p, 10) : v1;
+            if (c == 'O') opt->o_del = v1, opt->o_ins = v2, set_od = set_oi = 1;
+            else if (c == 'E') opt->e_del = v1, opt->e_ins = v2, set_ed = set_ei = 1;
+            else opt->pen_clip5 = v1, opt->pen_clip3 = v2, set_l5 = set_l3 = 1;
+        }
         else if (c == 'd') opt->zdrop = atoi(optarg), set_z = 1;
         else if (c == 'r') opt->split_factor = atof(optarg), set_r = 1;
         else if (c == 'y') opt->max_mem_intv = atol(optarg);

@@ -108,3 +108,71 @@ def test_sam_se_long_reads_ont2d(tmp_path):
     ref = _reference_sam(fa, fq, ["-x", "ont2d"])
     got = _ours(fa, reads, ["q%d" % i for i in range(len(reads))], quals, ONT2D, bm2.default_sam_opt(T=ONT2D.get("T", 30)))
     assert ref == got, _diff(ref, got)
+
+
+# ---- paired-end ------------------------------------------------------------------------------------------------------
+def _pe_case(tmp_path, seed, n_pairs, L=150, **rkw):
+    if ref_binary() is None:
+        pytest.skip("oracle/_ref reference binary not present (build it with `make -C oracle ref`)")
+    names, ctg, alts = synth.make_genome(seed, [300000, 150000, 60000], alt_contigs=1, alt_len=4000, n_repeat_families=8,
+                                         repeat_len=(200, 2500), copies=(3, 30), divergence=(0.0, 0.06))
+    fa = str(tmp_path / "g.fa")
+    synth.write_fasta(fa, names, ctg)
+    synth.write_alt(fa + ".alt", alts)
+    subprocess.check_call([ref_binary(), "index", fa], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    r1, r2 = synth.make_reads_pe(seed + 1, ctg, n_pairs, L=L, **rkw)
+    return fa, r1, r2
+
+
+def _pe_run(tmp_path, fa, r1, r2, extra, flag=0, okw=None, **skw):
+    rng = np.random.default_rng(9)
+    reads, quals, names = [], [], []
+    for i in range(len(r1)):
+        for r in (r1[i], r2[i]):
+            reads.append(r); quals.append(bytes(rng.integers(40, 74, size=len(r), dtype=np.uint8))); names.append("p%d" % i)
+    f1, f2 = str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq")
+    for path, sel in ((f1, 0), (f2, 1)):
+        with open(path, "wb") as f:
+            for i in range(sel, len(reads), 2):
+                f.write(b"@" + names[i].encode() + b"\n" + bytes(b"ACGTN"[c] for c in reads[i]) + b"\n+\n" + quals[i] + b"\n")
+    p = subprocess.run([ref_binary(), "mem", "-t", "1"] + list(extra) + [fa, f1, f2], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True)
+    ref = b"".join(l for l in p.stdout.splitlines(keepends=True) if not l.startswith(b"@"))
+    enc, off, ln = refio.pack_reads(reads)
+    ix = oracle.Index(fa)
+    try:
+        exp = ix.run(enc, off, ln, oracle.default_opt(**(okw or {})))
+    finally:
+        ix.close()
+    opt = bm2.default_opt(**(okw or {}))
+    regs, reg_off = _prg_to_regs(exp["REGPRG"], len(ln))
+    aln, aln_off = bm2.finish_regs(fa, enc, off, ln, opt, regs, reg_off)
+    got, pes = bm2.sam_pe(fa, enc, off, ln, opt, aln, aln_off, names, quals, None, bm2.default_sam_opt(flag=flag, **skw))
+    return ref, got, pes
+
+
+def test_sam_pe_without_rescue_matches_reference_text(tmp_path):
+    # -S: no mate rescue -> mem_pestat, mem_pair, mapping qualities and the paired record layout alone
+    fa, r1, r2 = _pe_case(tmp_path, 51, 3000)
+    ref, got, pes = _pe_run(tmp_path, fa, r1, r2, ["-S"], flag=0x20)
+    assert not pes[1].failed and pes[1].low > 0
+    assert ref == got, _diff(ref, got)
+
+
+def test_sam_pe_matches_reference_text(tmp_path):
+    # the default: mate rescue (local SW of the mate near the expected position), pairing, proper-pair flags, MC/TLEN
+    fa, r1, r2 = _pe_case(tmp_path, 53, 3000)
+    ref, got, pes = _pe_run(tmp_path, fa, r1, r2, [])
+    assert ref == got, _diff(ref, got)
+
+
+def test_sam_pe_noisy_mates_and_options(tmp_path):
+    # noisy, shorter reads: many mates seed badly or not at all, so the records depend on the rescue SW (score, sub-optimal
+    # score, start found by the reverse pass); then the option paths: -a, -Y, -P (no pairing), -U / -m, non-default scoring
+    fa, r1, r2 = _pe_case(tmp_path, 57, 1500, L=100, sub_rate=0.04, indel_frac=0.3, ins_mean=300, ins_sd=60, random_frac=0.02)
+    for extra, flag, okw, skw in (([], 0, None, {}), (["-a"], 0x8, None, {}), (["-Y"], 0x200, None, {}), (["-P"], 0x4, None, {}),
+                                  (["-U", "9", "-m", "2"], 0, None, dict(pen_unpaired=9, max_matesw=2)),
+                                  # (-A scales the options that are not given: zdrop, clipping penalties, -T and -U, fastmap.cpp:547-561)
+                                  (["-A", "2", "-B", "5", "-O", "7,8", "-E", "2,2"], 0,
+                                   dict(a=2, b=5, o_del=7, o_ins=8, e_del=2, e_ins=2, zdrop=200, pen_clip5=10, pen_clip3=10), dict(T=60, pen_unpaired=34))):
+        ref, got, pes = _pe_run(tmp_path, fa, r1, r2, extra, flag=flag, okw=okw, **skw)
+        assert ref == got, "%s: %s" % (" ".join(extra), _diff(ref, got))
