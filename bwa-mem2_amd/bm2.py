@@ -54,7 +54,8 @@ class Opt(C.Structure):
 class SamOpt(C.Structure):
     _fields_ = [("T", C.c_int32), ("flag", C.c_int32), ("max_XA_hits", C.c_int32), ("max_XA_hits_alt", C.c_int32),
                 ("XA_drop_ratio", C.c_float), ("mapQ_coef_len", C.c_float), ("mapQ_coef_fac", C.c_int32),
-                ("pen_unpaired", C.c_int32), ("max_ins", C.c_int32), ("max_matesw", C.c_int32), ("rg_id", C.c_char_p)]
+                ("pen_unpaired", C.c_int32), ("max_ins", C.c_int32), ("max_matesw", C.c_int32), ("n_threads", C.c_int32),
+                ("pad", C.c_int32), ("rg_id", C.c_char_p)]
 
 
 class PeStat(C.Structure):

@@ -13,6 +13,8 @@
 #include <vector>
 #include "../../include/bm2.h"
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include "ksort_host.h"
 #include "host_tail.h"
 
@@ -936,6 +938,38 @@ bool sam_pe(const bm2_opt *opt, const bm2_sam_opt *so, const Ref &R, const int32
     return true;
 }
 
+// items [0, n) in blocks over n_threads host threads; f(i, out) appends the text of item i; the blocks are joined in order
+template <class F> bool run_blocks(int n, int n_threads, std::string &out, F f) {
+    if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency();
+    if (n_threads < 1) n_threads = 1;
+    const int block = 256;
+    const int n_blocks = (n + block - 1) / block;
+    if (n_threads > n_blocks) n_threads = n_blocks > 0 ? n_blocks : 1;
+    std::vector<std::string> parts((size_t)n_blocks);
+    std::atomic<int> next(0), failed(-1);
+    auto work = [&]() {
+        for (;;) {
+            const int b = next.fetch_add(1);
+            if (b >= n_blocks || failed.load() >= 0) return;
+            const int hi = (b + 1) * block < n ? (b + 1) * block : n;
+            for (int i = b * block; i < hi; ++i)
+                if (!f(i, parts[(size_t)b])) { int e = -1; failed.compare_exchange_strong(e, i); return; }
+        }
+    };
+    if (n_threads == 1) work();
+    else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < n_threads; ++t) th.emplace_back(work);
+        for (auto &t : th) t.join();
+    }
+    if (failed.load() >= 0) { out.clear(); out = std::to_string(failed.load()); return false; }
+    size_t tot = 0;
+    for (auto &p : parts) tot += p.size();
+    out.clear(); out.reserve(tot);
+    for (auto &p : parts) out += p;
+    return true;
+}
+
 }  // namespace
 
 extern "C" void bm2_sam_opt_init(bm2_sam_opt *o) {
@@ -962,19 +996,19 @@ extern "C" int bm2_sam_pe(const bm2_index_desc *idx, const bm2_opt *opt, const b
     if (pes_in) for (int d = 0; d < 4; ++d) { pes[d].low = pes_in[d].low; pes[d].high = pes_in[d].high; pes[d].failed = pes_in[d].failed; pes[d].avg = pes_in[d].avg; pes[d].std = pes_in[d].std; }
     else pestat(opt, so, idx->l_pac, regs, pes);                 // per chunk, as mem_process_seqs does (bwamem.cpp:1366-1370)
     if (pes_out) for (int d = 0; d < 4; ++d) { pes_out[d].low = pes[d].low; pes_out[d].high = pes[d].high; pes_out[d].failed = pes[d].failed; pes_out[d].pad = 0; pes_out[d].avg = pes[d].avg; pes_out[d].std = pes[d].std; }
+    for (int i = 0; i < n; i += 2)
+        if (strcmp(txt->name[i], txt->name[i + 1]) != 0) { bm2_set_error("paired reads have different names: \"%s\", \"%s\"", txt->name[i], txt->name[i + 1]); return BM2_EINVAL; }
     std::string s;
-    for (int i = 0; i < n; i += 2) {
+    const bool ok = run_blocks(n >> 1, so->n_threads, s, [&](int pi, std::string &part) {
+        const int i = pi << 1;
         ReadIO io[2];
         for (int k = 0; k < 2; ++k) {
             io[k].name = txt->name[i + k]; io[k].comment = txt->comment ? txt->comment[i + k] : 0; io[k].qual = txt->qual ? txt->qual[i + k] : 0;
             io[k].l_seq = reads->len[i + k]; io[k].seq = reads->enc + reads->off[i + k];
         }
-        if (strcmp(io[0].name, io[1].name) != 0) { bm2_set_error("paired reads have different names: \"%s\", \"%s\"", io[0].name, io[1].name); return BM2_EINVAL; }
-        if (!sam_pe(opt, so, R, idx->ann_len, pes, (uint64_t)((n_processed >> 1) + (i >> 1)), io, &regs[(size_t)i], s)) {
-            bm2_set_error("bm2_sam_pe: pair %d has a hit whose CIGAR cannot be generated (range outside the reference)", i >> 1);
-            return BM2_EINVAL;
-        }
-    }
+        return sam_pe(opt, so, R, idx->ann_len, pes, (uint64_t)((n_processed >> 1) + pi), io, &regs[(size_t)i], part);
+    });
+    if (!ok) { bm2_set_error("bm2_sam_pe: pair %s has a hit whose CIGAR cannot be generated (range outside the reference)", s.c_str()); return BM2_EINVAL; }
     *n_out = (int64_t)s.size();
     if ((int64_t)s.size() > cap) return BM2_ECAP;
     if (out && !s.empty()) memcpy(out, s.data(), s.size());
@@ -990,17 +1024,15 @@ extern "C" int bm2_sam_se(const bm2_index_desc *idx, const bm2_opt *opt, const b
     if (!idx->ref_string || !idx->ann_offset || !idx->ann_name) { bm2_set_error("bm2_sam_se: the index descriptor needs ref_string and contig names"); return BM2_EINVAL; }
     Ref R = { idx->l_pac, idx->ref_string, idx->n_seqs, idx->ann_offset, idx->ann_name, idx->ann_anno };
     std::string s;
-    for (int i = 0; i < reads->n_reads; ++i) {
+    const bool ok = run_blocks(reads->n_reads, so->n_threads, s, [&](int i, std::string &part) {
         bm2_alnreg_t *a = alnregs + reg_off[i];
         const int n = (int)(reg_off[i + 1] - reg_off[i]);
         mark_primary_se(opt, n, a, n_processed + i);
         if (so->flag & F_PRIMARY5) reorder_primary5(so->T, n, a);
-        if (!reg2sam(opt, so, R, s, txt->name[i], txt->comment ? txt->comment[i] : 0, txt->qual ? txt->qual[i] : 0, reads->len[i],
-                     reads->enc + reads->off[i], n, a, 0, 0)) {
-            bm2_set_error("bm2_sam_se: read %d has a hit whose CIGAR cannot be generated (range outside the reference)", i);
-            return BM2_EINVAL;
-        }
-    }
+        return reg2sam(opt, so, R, part, txt->name[i], txt->comment ? txt->comment[i] : 0, txt->qual ? txt->qual[i] : 0, reads->len[i],
+                       reads->enc + reads->off[i], n, a, 0, 0);
+    });
+    if (!ok) { bm2_set_error("bm2_sam_se: read %s has a hit whose CIGAR cannot be generated (range outside the reference)", s.c_str()); return BM2_EINVAL; }
     *n_out = (int64_t)s.size();
     if ((int64_t)s.size() > cap) return BM2_ECAP;
     if (out && !s.empty()) memcpy(out, s.data(), s.size());

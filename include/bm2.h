@@ -172,6 +172,8 @@ typedef struct {                    /* the fields of mem_opt_t (bwamem.h:74-110)
     int32_t pen_unpaired;           /* -U, 17 */
     int32_t max_ins;                /* 10000: pairs further apart are ignored by the insert-size statistics */
     int32_t max_matesw;             /* -m, 50: mate-rescue rounds per end */
+    int32_t n_threads;              /* host threads for this tail; 0 = all hardware threads (the text does not depend on it) */
+    int32_t pad;
     const char *rg_id;              /* bwa_rg_id: RG:Z: value, NULL or "" = none */
 } bm2_sam_opt;
 void bm2_sam_opt_init(bm2_sam_opt *o);                  /* the defaults of mem_opt_init, bwamem.cpp:107-143 */
