@@ -58,6 +58,12 @@ class SamOpt(C.Structure):
                 ("pad", C.c_int32), ("rg_id", C.c_char_p)]
 
 
+class Fastq(C.Structure):
+    _fields_ = [("n_reads", C.c_int32), ("pad", C.c_int32), ("n_bases", C.c_int64), ("enc", C.POINTER(C.c_uint8)),
+                ("off", C.POINTER(C.c_int64)), ("len", C.POINTER(C.c_int32)), ("name", C.POINTER(C.c_char_p)),
+                ("comment", C.POINTER(C.c_char_p)), ("qual", C.POINTER(C.c_char_p))]
+
+
 class PeStat(C.Structure):
     _fields_ = [("low", C.c_int32), ("high", C.c_int32), ("failed", C.c_int32), ("pad", C.c_int32), ("avg", C.c_double), ("std", C.c_double)]
 
@@ -86,7 +92,7 @@ class Stats(C.Structure):
 EXPORTS = ["bm2_index_load", "bm2_index_free", "bm2_opt_init", "bm2_opt_fill_scmat", "bm2_create", "bm2_destroy",
            "bm2_last_error", "bm2_device_count", "bm2_bsw", "bm2_smem", "bm2_sal", "bm2_seed_chain_extend",
            "bm2_batch_upload", "bm2_batch_run", "bm2_batch_stats", "bm2_batch_download", "bm2_batch_kernel_ms",
-           "bm2_batch_fetch", "bm2_finish_regs", "bm2_index_build", "bm2_sam_opt_init", "bm2_sam_se", "bm2_sam_pe"]
+           "bm2_batch_fetch", "bm2_finish_regs", "bm2_index_build", "bm2_sam_opt_init", "bm2_sam_se", "bm2_sam_pe", "bm2_fastq_parse", "bm2_fastq_free"]
 
 _lib = None
 
@@ -299,6 +305,27 @@ class Context:
         n = C.c_int32(0)
         _chk(lib().bm2_batch_kernel_ms(self.h, ms, 32, C.byref(n), names), "bm2_batch_kernel_ms")
         return [(names[i].decode(), float(ms[i])) for i in range(n.value)]
+
+
+def fastq_parse(text):
+    """FASTA/FASTQ bytes -> (enc, off, len, names, comments, quals) with kseq / bseq_read semantics."""
+    L = lib()
+    f = Fastq()
+    L.bm2_fastq_parse.argtypes = [C.c_char_p, C.c_int64, C.POINTER(Fastq)]
+    L.bm2_fastq_free.argtypes = [C.POINTER(Fastq)]
+    L.bm2_fastq_free.restype = None
+    _chk(L.bm2_fastq_parse(text, len(text), C.byref(f)), "bm2_fastq_parse")
+    try:
+        n = f.n_reads
+        enc = np.ctypeslib.as_array(f.enc, shape=(max(f.n_bases, 1),))[:f.n_bases].copy()
+        off = np.ctypeslib.as_array(f.off, shape=(max(n, 1),))[:n].copy()
+        ln = np.ctypeslib.as_array(f.len, shape=(max(n, 1),))[:n].copy()
+        names = [f.name[i] for i in range(n)]
+        comments = [f.comment[i] for i in range(n)]
+        quals = [f.qual[i] for i in range(n)]
+        return enc, off, ln, names, comments, quals
+    finally:
+        L.bm2_fastq_free(C.byref(f))
 
 
 def default_sam_opt(**kw):

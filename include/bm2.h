@@ -190,6 +190,17 @@ typedef struct {                    /* what bseq1_t carries besides the bases (k
 int bm2_sam_se(const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt *so, const bm2_reads *reads, const bm2_read_text *txt,
                bm2_alnreg_t *alnregs, const int64_t *reg_off, int64_t n_processed, char *out, int64_t cap, int64_t *n_out);
 
+/* FASTA / FASTQ text -> packed reads + names / comments / qualities: kseq's record grammar (kseq.h:185-227), trim_readno
+ * (bwa.cpp:62-66: a trailing "/<digit>" is cut off the name) and the nst_nt4_table base codes (bwamem.cpp:992-1000).  The
+ * arrays are owned by the library until bm2_fastq_free; comment[i] / qual[i] are NULL when the record has none. */
+typedef struct {
+    int32_t n_reads; int32_t pad; int64_t n_bases;
+    uint8_t *enc; int64_t *off; int32_t *len;       /* what bm2_reads points at */
+    char **name, **comment, **qual;                  /* what bm2_read_text points at */
+} bm2_fastq;
+int  bm2_fastq_parse(const char *text, int64_t n_bytes, bm2_fastq *out);
+void bm2_fastq_free(bm2_fastq *f);
+
 /* Paired-end chunks (reads interleaved: 2i, 2i+1): mem_pestat over the chunk (bwamem_pair.cpp:81-148) unless pes_in is
  * given, then per pair mem_sam_pe (:353-551): mate rescue (mem_matesw :150-283 -> ksw_align2, ksw.cpp:340-381), mem_pair
  * (:285-346), mapping qualities, the records of both ends.  alnregs are not modified.  pes_out (optional) receives the four

@@ -176,3 +176,34 @@ def test_sam_pe_noisy_mates_and_options(tmp_path):
                                    dict(a=2, b=5, o_del=7, o_ins=8, e_del=2, e_ins=2, zdrop=200, pen_clip5=10, pen_clip3=10), dict(T=60, pen_unpaired=34))):
         ref, got, pes = _pe_run(tmp_path, fa, r1, r2, extra, flag=flag, okw=okw, **skw)
         assert ref == got, "%s: %s" % (" ".join(extra), _diff(ref, got))
+
+
+def test_fastq_text_to_sam_text(tmp_path):
+    # the host I/O row end to end: FASTQ text (names with /1, comments, lower case, multi-line FASTA records mixed in)
+    # -> bm2_fastq_parse -> regs -> bm2_sam_se == `bwa-mem2 mem -C` on the same file
+    fa, reads = _case(tmp_path, 61, 600)
+    rng = np.random.default_rng(4)
+    fq = str(tmp_path / "r.fq")
+    with open(fq, "wb") as f:
+        for i, r in enumerate(reads):
+            s = bytes(b"ACGTN"[c] for c in r)
+            if i % 7 == 3:
+                s = s.lower()
+            if i % 11 == 5:                                      # a FASTA record, sequence on two lines
+                f.write(b">fa%d/2 XY:i:%d\n" % (i, i) + s[:70] + b"\n" + s[70:] + b"\n")
+            else:
+                q = bytes(rng.integers(35, 74, size=len(r), dtype=np.uint8))
+                f.write(b"@rd%d/1 BC:Z:AC%dGT\tRX:Z:x\n" % (i, i) + s + b"\n+\n" + q + b"\n")
+    ref = _reference_sam(fa, fq, ["-C"])
+    enc, off, ln, names, comments, quals = bm2.fastq_parse(open(fq, "rb").read())
+    assert len(ln) == len(reads) and names[0] == b"rd0" and comments[0] == b"BC:Z:AC0GT\tRX:Z:x"
+    ix = oracle.Index(fa)
+    try:
+        exp = ix.run(enc, off, ln)
+    finally:
+        ix.close()
+    opt = bm2.default_opt()
+    regs, reg_off = _prg_to_regs(exp["REGPRG"], len(ln))
+    aln, aln_off = bm2.finish_regs(fa, enc, off, ln, opt, regs, reg_off)
+    got = bm2.sam_se(fa, enc, off, ln, opt, aln, aln_off, names, quals, comments)
+    assert ref == got, _diff(ref, got)
