@@ -538,58 +538,55 @@ template <int P> struct KswProfile {                            // ksw_qinit, ks
 template <int P>
 KswResult ksw_striped(const KswProfile<P> &q, int tlen, const uint8_t *target, int o_del, int e_del, int o_ins, int e_ins, int xtra) {
     const bool U8 = P == 16;
-    const int slen = q.slen, oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
+    typedef int16_t L;                                          // every value of either kernel fits a signed 16-bit lane
+    const int slen = q.slen;
+    const L oe_del = (L)(o_del + e_del), oe_ins = (L)(o_ins + e_ins), ed = (L)e_del, ei = (L)e_ins, shift = (L)q.shift;
     const int minsc = (xtra & KSW_XSUBO) ? xtra & 0xffff : 0x10000, endsc = (xtra & KSW_XSTOP) ? xtra & 0xffff : 0x10000;
-    auto ssub = [](int a, int b) { return a > b ? a - b : 0; };    // _mm_subs_epu8 / _mm_subs_epu16 on non-negative values
-    struct V { int v[P]; };
-    std::vector<V> Ha((size_t)slen), Hb((size_t)slen), E((size_t)slen), Hmax((size_t)slen);
+    struct alignas(32) V { L v[P]; };
+    std::vector<V> Ha((size_t)slen), Hb((size_t)slen), E((size_t)slen), Hmax((size_t)slen), QP((size_t)5 * slen);
     for (int j = 0; j < slen; ++j) for (int k = 0; k < P; ++k) Ha[j].v[k] = Hb[j].v[k] = E[j].v[k] = Hmax[j].v[k] = 0;
+    for (size_t t = 0; t < (size_t)5 * slen; ++t) for (int k = 0; k < P; ++k) QP[t].v[k] = (L)q.qp[t * P + k];
     V *H0 = Ha.data(), *H1 = Hb.data();
     std::vector<uint64_t> b;
     int te = -1, gmax = 0;
     KswResult r;
     for (int i = 0; i < tlen; ++i) {
-        const int *S = &q.qp[(size_t)target[i] * slen * P];
+        const V *S = &QP[(size_t)target[i] * slen];
         V h, f, mx;
-        for (int k = 0; k < P; ++k) { h.v[k] = k ? H0[slen - 1].v[k - 1] : 0; f.v[k] = 0; mx.v[k] = 0; }
+        for (int k = 0; k < P; ++k) { h.v[k] = k ? H0[slen - 1].v[k - 1] : (L)0; f.v[k] = 0; mx.v[k] = 0; }
         for (int j = 0; j < slen; ++j) {
-            for (int k = 0; k < P; ++k) {
-                int hv = h.v[k];
-                if (U8) { hv += S[j * P + k]; if (hv > 255) hv = 255; hv = ssub(hv, q.shift); }      // adds_epu8, subs_epu8
-                else { hv += S[j * P + k]; if (hv > 32767) hv = 32767; if (hv < -32768) hv = -32768; } // adds_epi16
-                int e = E[j].v[k];
-                if (hv < e) hv = e;
-                if (hv < f.v[k]) hv = f.v[k];
-                if (mx.v[k] < hv) mx.v[k] = hv;
-                H1[j].v[k] = hv;
-                e = ssub(e, e_del);
-                int t = ssub(hv, oe_del);
-                E[j].v[k] = e > t ? e : t;
-                int fv = ssub(f.v[k], e_ins);
-                t = ssub(hv, oe_ins);
-                f.v[k] = fv > t ? fv : t;
-                h.v[k] = H0[j].v[k];
+            V hn, e = E[j];
+            for (int k = 0; k < P; ++k) {                       // branch-free: the compiler turns these into 16-bit SIMD min / max
+                L hv;
+                if (U8) { hv = (L)std::min<int>(h.v[k] + S[j].v[k], 255); hv = (L)std::max<int>(hv - shift, 0); }   // adds_epu8, subs_epu8
+                else hv = (L)std::min<int>(std::max<int>(h.v[k] + S[j].v[k], -32768), 32767);                          // adds_epi16
+                hv = std::max(hv, e.v[k]);
+                hv = std::max(hv, f.v[k]);
+                mx.v[k] = std::max(mx.v[k], hv);
+                hn.v[k] = hv;
+                e.v[k] = std::max((L)std::max<int>(e.v[k] - ed, 0), (L)std::max<int>(hv - oe_del, 0));
+                f.v[k] = std::max((L)std::max<int>(f.v[k] - ei, 0), (L)std::max<int>(hv - oe_ins, 0));
             }
+            h = H0[j];
+            H1[j] = hn; E[j] = e;
         }
         bool done = false;                                      // the lazy-F pass (16 rounds at most, as in both kernels)
         for (int k16 = 0; k16 < 16 && !done; ++k16) {
             for (int k = P - 1; k > 0; --k) f.v[k] = f.v[k - 1];
             f.v[0] = 0;
             for (int j = 0; j < slen; ++j) {
-                bool all_le = true;
+                int any_gt = 0;
                 for (int k = 0; k < P; ++k) {
-                    int hv = H1[j].v[k];
-                    if (hv < f.v[k]) hv = f.v[k];
+                    const L hv = std::max(H1[j].v[k], f.v[k]);
                     H1[j].v[k] = hv;
-                    hv = ssub(hv, oe_ins);
-                    f.v[k] = ssub(f.v[k], e_ins);
-                    if (f.v[k] > hv) all_le = false;
+                    f.v[k] = (L)std::max<int>(f.v[k] - ei, 0);
+                    any_gt |= f.v[k] > (L)std::max<int>(hv - oe_ins, 0);
                 }
-                if (all_le) { done = true; break; }
+                if (!any_gt) { done = true; break; }
             }
         }
         int imax = 0;
-        for (int k = 0; k < P; ++k) if (mx.v[k] > imax) imax = mx.v[k];
+        for (int k = 0; k < P; ++k) imax = std::max<int>(imax, mx.v[k]);
         if (imax >= minsc) {
             if (b.empty() || (int32_t)b.back() + 1 != i) b.push_back((uint64_t)imax << 32 | (uint32_t)i);
             else if ((int)(b.back() >> 32) < imax) b.back() = (uint64_t)imax << 32 | (uint32_t)i;

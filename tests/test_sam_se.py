@@ -207,3 +207,39 @@ def test_fastq_text_to_sam_text(tmp_path):
     aln, aln_off = bm2.finish_regs(fa, enc, off, ln, opt, regs, reg_off)
     got = bm2.sam_se(fa, enc, off, ln, opt, aln, aln_off, names, quals, comments)
     assert ref == got, _diff(ref, got)
+
+
+def test_sam_pe_chunked_like_the_reference(tmp_path):
+    # -K: the reference cuts the input into chunks; the insert-size model is re-estimated per chunk and the hash / pair ids keep
+    # counting (n_processed).  Calling bm2_sam_pe once per chunk with n_processed must give the same text.
+    fa, r1, r2 = _pe_case(tmp_path, 67, 1600, L=100, sub_rate=0.02, indel_frac=0.2, ins_mean=280, ins_sd=50)
+    K = 60000
+    reads, quals, names = [], [], []
+    for i in range(len(r1)):
+        for r in (r1[i], r2[i]):
+            reads.append(r); quals.append(b"G" * len(r)); names.append("p%d" % i)
+    f1, f2 = str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq")
+    for path, sel in ((f1, 0), (f2, 1)):
+        with open(path, "wb") as f:
+            for i in range(sel, len(reads), 2):
+                f.write(b"@" + names[i].encode() + b"\n" + bytes(b"ACGTN"[c] for c in reads[i]) + b"\n+\n" + quals[i] + b"\n")
+    p = subprocess.run([ref_binary(), "mem", "-t", "1", "-K", str(K), fa, f1, f2], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True)
+    ref = b"".join(l for l in p.stdout.splitlines(keepends=True) if not l.startswith(b"@"))
+    opt = bm2.default_opt()
+    ix = oracle.Index(fa)
+    got, lo, n_chunks = b"", 0, 0
+    try:
+        while lo < len(reads):
+            hi, size = lo, 0
+            while hi < len(reads) and size < K:                  # bseq_read: whole pairs until the chunk holds >= K bases
+                size += len(reads[hi]) + len(reads[hi + 1]); hi += 2
+            enc, off, ln = refio.pack_reads(reads[lo:hi])
+            exp = ix.run(enc, off, ln)
+            regs, reg_off = _prg_to_regs(exp["REGPRG"], len(ln))
+            aln, aln_off = bm2.finish_regs(fa, enc, off, ln, opt, regs, reg_off)
+            txt, pes = bm2.sam_pe(fa, enc, off, ln, opt, aln, aln_off, names[lo:hi], quals[lo:hi], None, None, n_processed=lo)
+            got += txt; lo = hi; n_chunks += 1
+    finally:
+        ix.close()
+    assert n_chunks > 3
+    assert ref == got, _diff(ref, got)
