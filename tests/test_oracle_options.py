@@ -47,3 +47,38 @@ def test_oracle_matches_reference_under_non_default_scoring(tmp_path, L):
                 assert d[t].tobytes() == exp[t].tobytes(), "%s: stage %s differs" % (" ".join(args), t)
     finally:
         ix.close()
+
+
+@pytest.mark.parametrize("case", ["L36", "L600_noisy", "long_pacbio"])
+def test_oracle_matches_reference_across_read_shapes(tmp_path, case):
+    from helpers import ONT2D
+    exe, dump = ref_binary(), ref_binary("refdump")
+    if exe is None or dump is None:
+        pytest.skip("oracle/_ref not built (make -C oracle ref)")
+    names, ctg, alts = synth.make_genome(101, [300000, 120000, 30000], alt_contigs=2, alt_len=5000, n_repeat_families=10, repeat_len=(100, 4000),
+                                         copies=(2, 80), divergence=(0.0, 0.1), n_gaps=6, gap_len=(20, 800))
+    fa = str(tmp_path / "g.fa")
+    synth.write_fasta(fa, names, ctg)
+    synth.write_alt(fa + ".alt", alts)
+    subprocess.check_call([exe, "index", fa], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    if case == "L36":
+        reads, args, kw = synth.make_reads_se(236, ctg, 2500, L=36, n_frac=0.03), ["-x", "intractg"], dict(b=9, o_del=16, o_ins=16, pen_clip5=5, pen_clip3=5)
+    elif case == "L600_noisy":
+        reads, args, kw = synth.make_reads_se(800, ctg, 500, L=600, sub_rate=0.06, indel_frac=0.5), [], {}
+    else:
+        reads, args, kw = synth.make_reads_long(333, ctg, 60, mean_len=3000, max_len=9000, err=0.1), ["-x", "pacbio"], dict(ONT2D, min_seed_len=17, min_chain_weight=40)
+    rt = str(tmp_path / "reads.txt")
+    with open(rt, "w") as f:
+        for r in reads:
+            f.write("".join("ACGTN"[c] for c in r) + "\n")
+    out = str(tmp_path / "dump")
+    subprocess.check_call([dump] + args + [fa, rt, out], stderr=subprocess.DEVNULL)
+    d = refio.read_dump(out)
+    enc, off, ln = refio.pack_reads(list(reads))
+    ix = oracle.Index(fa)
+    try:
+        exp = ix.run(enc, off, ln, oracle.default_opt(**kw))
+    finally:
+        ix.close()
+    for t in ("SMEM", "SACOORD", "CHN1", "SEED1", "REGRAW", "REGPRG"):
+        assert d[t].tobytes() == exp[t].tobytes(), "%s: stage %s differs" % (case, t)
