@@ -336,12 +336,13 @@ def default_sam_opt(**kw):
     return o
 
 
-def sam_pe(index_prefix, enc, off, ln, opt, alnregs, reg_off, names, quals=None, comments=None, sam_opt=None, n_processed=0):
-    """Paired-end SAM alignment lines (reads interleaved) -> (bytes, [4 PeStat])."""
-    return sam_se(index_prefix, enc, off, ln, opt, alnregs, reg_off, names, quals, comments, sam_opt, n_processed, paired=True)
+def sam_pe(index_prefix, enc, off, ln, opt, alnregs, reg_off, names, quals=None, comments=None, sam_opt=None, n_processed=0, pes_in=None):
+    """Paired-end SAM alignment lines (reads interleaved) -> (bytes, [4 PeStat]); pes_in = 4 PeStat to use instead of mem_pestat."""
+    return sam_se(index_prefix, enc, off, ln, opt, alnregs, reg_off, names, quals, comments, sam_opt, n_processed, paired=True, pes_in=pes_in)
 
 
-def sam_se(index_prefix, enc, off, ln, opt, alnregs, reg_off, names, quals=None, comments=None, sam_opt=None, n_processed=0, paired=False):
+def sam_se(index_prefix, enc, off, ln, opt, alnregs, reg_off, names, quals=None, comments=None, sam_opt=None, n_processed=0, paired=False,
+           pes_in=None):
     """Single-end SAM alignment lines (host only, no GPU) from the alnregs of finish_regs -> bytes."""
     L = lib()
     d = IndexDesc()
@@ -370,7 +371,8 @@ def sam_se(index_prefix, enc, off, ln, opt, alnregs, reg_off, names, quals=None,
             if paired:
                 pes = (PeStat * 4)()
                 rc = L.bm2_sam_pe(C.byref(d), C.byref(opt), C.byref(so), C.byref(r), C.byref(t), a.ctypes.data, reg_off.ctypes.data,
-                                  C.c_int64(n_processed), None, pes, buf, C.c_int64(cap), C.byref(need))
+                                  C.c_int64(n_processed), (PeStat * 4)(*pes_in) if pes_in is not None else None, pes, buf, C.c_int64(cap),
+                                  C.byref(need))
             else:
                 rc = L.bm2_sam_se(C.byref(d), C.byref(opt), C.byref(so), C.byref(r), C.byref(t), a.ctypes.data, reg_off.ctypes.data,
                                   C.c_int64(n_processed), buf, C.c_int64(cap), C.byref(need))

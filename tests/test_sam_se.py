@@ -243,3 +243,32 @@ def test_sam_pe_chunked_like_the_reference(tmp_path):
         ix.close()
     assert n_chunks > 3
     assert ref == got, _diff(ref, got)
+
+
+def test_sam_pe_given_insert_size_model(tmp_path):
+    # -I mean,std: the caller fixes the FR model (fastmap.cpp:703-718); the other orientations are off
+    fa, r1, r2 = _pe_case(tmp_path, 71, 1200, L=120, ins_mean=260, ins_sd=20, random_frac=0.1)
+    reads, quals, names = [], [], []
+    for i in range(len(r1)):
+        for r in (r1[i], r2[i]):
+            reads.append(r); quals.append(b"E" * len(r)); names.append("p%d" % i)
+    f1, f2 = str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq")
+    for path, sel in ((f1, 0), (f2, 1)):
+        with open(path, "wb") as f:
+            for i in range(sel, len(reads), 2):
+                f.write(b"@" + names[i].encode() + b"\n" + bytes(b"ACGTN"[c] for c in reads[i]) + b"\n+\n" + quals[i] + b"\n")
+    p = subprocess.run([ref_binary(), "mem", "-t", "1", "-I", "260,20", fa, f1, f2], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True)
+    ref = b"".join(l for l in p.stdout.splitlines(keepends=True) if not l.startswith(b"@"))
+    enc, off, ln = refio.pack_reads(reads)
+    ix = oracle.Index(fa)
+    try:
+        exp = ix.run(enc, off, ln)
+    finally:
+        ix.close()
+    opt = bm2.default_opt()
+    regs, reg_off = _prg_to_regs(exp["REGPRG"], len(ln))
+    aln, aln_off = bm2.finish_regs(fa, enc, off, ln, opt, regs, reg_off)
+    pin = [bm2.PeStat(0, 0, 1, 0, 0., 0.) for _ in range(4)]
+    pin[1] = bm2.PeStat(max(int(260. - 4. * 20. + .499), 1), int(260. + 4. * 20. + .499), 0, 0, 260., 20.)
+    got, pes = bm2.sam_pe(fa, enc, off, ln, opt, aln, aln_off, names, quals, pes_in=pin)
+    assert ref == got, _diff(ref, got)
