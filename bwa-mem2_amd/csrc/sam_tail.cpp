@@ -538,55 +538,49 @@ template <int P> struct KswProfile {                            // ksw_qinit, ks
 template <int P>
 KswResult ksw_striped(const KswProfile<P> &q, int tlen, const uint8_t *target, int o_del, int e_del, int o_ins, int e_ins, int xtra) {
     const bool U8 = P == 16;
-    typedef int16_t L;                                          // every value of either kernel fits a signed 16-bit lane
+    // P lanes of signed 16 bits (every value of either kernel fits) as one compiler vector: element-wise +, -, min, max
+    typedef int16_t V __attribute__((vector_size(P * 2)));
     const int slen = q.slen;
-    const L oe_del = (L)(o_del + e_del), oe_ins = (L)(o_ins + e_ins), ed = (L)e_del, ei = (L)e_ins, shift = (L)q.shift;
+    auto splat = [](int x) { V v; for (int k = 0; k < P; ++k) v[k] = (int16_t)x; return v; };
+    const V zero = splat(0), oe_del = splat(o_del + e_del), oe_ins = splat(o_ins + e_ins), ed = splat(e_del), ei = splat(e_ins),
+            shift = splat(q.shift), c255 = splat(255);
+    auto vmax = [](V a, V b) { return __builtin_elementwise_max(a, b); };
+    auto vmin = [](V a, V b) { return __builtin_elementwise_min(a, b); };
+    auto ssub = [&](V a, V b) { return vmax(a - b, zero); };                    // subs_epu8 / subs_epu16 on non-negative lanes
+    auto up1 = [&](V v) { V r; r[0] = 0; for (int k = 1; k < P; ++k) r[k] = v[k - 1]; return r; };   // _mm_slli_si128 by one lane
     const int minsc = (xtra & KSW_XSUBO) ? xtra & 0xffff : 0x10000, endsc = (xtra & KSW_XSTOP) ? xtra & 0xffff : 0x10000;
-    struct alignas(32) V { L v[P]; };
-    std::vector<V> Ha((size_t)slen), Hb((size_t)slen), E((size_t)slen), Hmax((size_t)slen), QP((size_t)5 * slen);
-    for (int j = 0; j < slen; ++j) for (int k = 0; k < P; ++k) Ha[j].v[k] = Hb[j].v[k] = E[j].v[k] = Hmax[j].v[k] = 0;
-    for (size_t t = 0; t < (size_t)5 * slen; ++t) for (int k = 0; k < P; ++k) QP[t].v[k] = (L)q.qp[t * P + k];
+    std::vector<V> Ha((size_t)slen, zero), Hb((size_t)slen, zero), E((size_t)slen, zero), Hmax((size_t)slen, zero), QP((size_t)5 * slen);
+    for (size_t t = 0; t < (size_t)5 * slen; ++t) for (int k = 0; k < P; ++k) QP[t][k] = (int16_t)q.qp[t * P + k];
     V *H0 = Ha.data(), *H1 = Hb.data();
     std::vector<uint64_t> b;
     int te = -1, gmax = 0;
     KswResult r;
     for (int i = 0; i < tlen; ++i) {
         const V *S = &QP[(size_t)target[i] * slen];
-        V h, f, mx;
-        for (int k = 0; k < P; ++k) { h.v[k] = k ? H0[slen - 1].v[k - 1] : (L)0; f.v[k] = 0; mx.v[k] = 0; }
+        V h = up1(H0[slen - 1]), f = zero, mx = zero;
         for (int j = 0; j < slen; ++j) {
-            V hn, e = E[j];
-            for (int k = 0; k < P; ++k) {                       // branch-free: the compiler turns these into 16-bit SIMD min / max
-                L hv;
-                if (U8) { hv = (L)std::min<int>(h.v[k] + S[j].v[k], 255); hv = (L)std::max<int>(hv - shift, 0); }   // adds_epu8, subs_epu8
-                else hv = (L)std::min<int>(std::max<int>(h.v[k] + S[j].v[k], -32768), 32767);                          // adds_epi16
-                hv = std::max(hv, e.v[k]);
-                hv = std::max(hv, f.v[k]);
-                mx.v[k] = std::max(mx.v[k], hv);
-                hn.v[k] = hv;
-                e.v[k] = std::max((L)std::max<int>(e.v[k] - ed, 0), (L)std::max<int>(hv - oe_del, 0));
-                f.v[k] = std::max((L)std::max<int>(f.v[k] - ei, 0), (L)std::max<int>(hv - oe_ins, 0));
-            }
+            if (U8) h = ssub(vmin(h + S[j], c255), shift);                       // adds_epu8, subs_epu8
+            else h = __builtin_elementwise_add_sat(h, S[j]);                     // adds_epi16
+            V e = E[j];
+            h = vmax(vmax(h, e), f);
+            mx = vmax(mx, h);
+            H1[j] = h;
+            E[j] = vmax(ssub(e, ed), ssub(h, oe_del));
+            f = vmax(ssub(f, ei), ssub(h, oe_ins));
             h = H0[j];
-            H1[j] = hn; E[j] = e;
         }
         bool done = false;                                      // the lazy-F pass (16 rounds at most, as in both kernels)
         for (int k16 = 0; k16 < 16 && !done; ++k16) {
-            for (int k = P - 1; k > 0; --k) f.v[k] = f.v[k - 1];
-            f.v[0] = 0;
+            f = up1(f);
             for (int j = 0; j < slen; ++j) {
-                int any_gt = 0;
-                for (int k = 0; k < P; ++k) {
-                    const L hv = std::max(H1[j].v[k], f.v[k]);
-                    H1[j].v[k] = hv;
-                    f.v[k] = (L)std::max<int>(f.v[k] - ei, 0);
-                    any_gt |= f.v[k] > (L)std::max<int>(hv - oe_ins, 0);
-                }
-                if (!any_gt) { done = true; break; }
+                const V hv = vmax(H1[j], f);
+                H1[j] = hv;
+                f = ssub(f, ei);
+                const V gt = f > ssub(hv, oe_ins);              // lanes: -1 where f still beats what H would start
+                if (!__builtin_reduce_or(gt)) { done = true; break; }
             }
         }
-        int imax = 0;
-        for (int k = 0; k < P; ++k) imax = std::max<int>(imax, mx.v[k]);
+        const int imax = __builtin_reduce_max(mx);
         if (imax >= minsc) {
             if (b.empty() || (int32_t)b.back() + 1 != i) b.push_back((uint64_t)imax << 32 | (uint32_t)i);
             else if ((int)(b.back() >> 32) < imax) b.back() = (uint64_t)imax << 32 | (uint32_t)i;
@@ -604,7 +598,7 @@ KswResult ksw_striped(const KswProfile<P> &q, int tlen, const uint8_t *target, i
         int mxv = -1;
         const int qlen = slen * P;
         for (int i = 0; i < qlen; ++i) {
-            const int t = Hmax[i / P].v[i % P], pos = i / P + i % P * slen;
+            const int t = Hmax[i / P][i % P], pos = i / P + i % P * slen;
             if (t > mxv) { mxv = t; r.qe = pos; }
             else if (t == mxv && pos < r.qe) r.qe = pos;
         }
