@@ -989,6 +989,8 @@ static void chain2aln_read(const ora_index *ix, const ora_opt *opt, int read_id,
         free(srt);
     }
     /* redundant-seed post-filter, :2895-2989 */
+    static int check_chunked = -1;                 /* ORA_CHECK_CHUNKED=1: cross-check the 64-regs-at-a-time form of the walk */
+    if (check_chunked < 0) check_chunked = getenv("ORA_CHECK_CHUNKED") ? 1 : 0;
     int lim = 0, s_start = 0;
     for (int j = 0; j < n_chains; j++) {
         chain_t *c = &chains[j];
@@ -1012,6 +1014,40 @@ static void chain2aln_read(const ora_index *ix, const ora_opt *opt, int read_id,
                 w = max_gap < p->w ? max_gap : p->w;
                 if (qd - rd < w && rd - qd < w) break;
                 v++;
+            }
+            if (check_chunked) {
+                /* the form a wavefront would use (notes/postfilter_heavy_wip.patch): judge 64 regs at once, restore the order
+                 * of the walk with masks: v = non-purged regs seen; a reg is looked at only while v < lim; the first
+                 * looked-at reg that passes one of the two band tests ends the walk */
+                int v2 = 0, stopped = 0;
+                for (int i0 = 0; i0 < (int)av->n && v2 < lim && !stopped; i0 += 64) {
+                    uint64_t lm = 0, bk = 0;
+                    for (int lane = 0; lane < 64 && i0 + lane < (int)av->n; lane++) {
+                        const reg_t *p = &av->a[i0 + lane];
+                        if (p->qb == -1 && p->qe == -1) continue;
+                        lm |= 1ULL << lane;
+                        if (s->rbeg < p->rb || s->rbeg + s->len > p->re || s->qbeg < p->qb || s->qbeg + s->len > p->qe) continue;
+                        if (s->len - p->seedlen0 > .1 * l_query) continue;
+                        int qd = s->qbeg - p->qb; int64_t rd = s->rbeg - p->rb;
+                        int max_gap = cal_max_gap(opt, qd < rd ? qd : (int)rd), w = max_gap < p->w ? max_gap : p->w;
+                        if (qd - rd < w && rd - qd < w) { bk |= 1ULL << lane; continue; }
+                        qd = p->qe - (s->qbeg + s->len); rd = p->re - (s->rbeg + s->len);
+                        max_gap = cal_max_gap(opt, qd < rd ? qd : (int)rd); w = max_gap < p->w ? max_gap : p->w;
+                        if (qd - rd < w && rd - qd < w) bk |= 1ULL << lane;
+                    }
+                    uint64_t looked_brk = 0;
+                    for (int lane = 0; lane < 64; lane++)
+                        if ((bk >> lane & 1) && v2 + __builtin_popcountll(lm & (lane ? ~0ULL >> (64 - lane) : 0ULL)) < lim) looked_brk |= 1ULL << lane;
+                    if (looked_brk) {
+                        const int ib = __builtin_ctzll(looked_brk);
+                        v2 += __builtin_popcountll(lm & (ib ? ~0ULL >> (64 - ib) : 0ULL));
+                        stopped = 1;
+                    } else v2 += __builtin_popcountll(lm);
+                }
+                if ((stopped || v2 < lim) != (v < lim)) {
+                    fprintf(stderr, "ORA_CHECK_CHUNKED: the chunked walk disagrees (v %d lim %d, chunked v %d stopped %d)\n", v, lim, v2, stopped);
+                    abort();
+                }
             }
             if (v < lim) {
                 for (v = k + 1; v < c->n; ++v) {
