@@ -92,7 +92,7 @@ class Stats(C.Structure):
 EXPORTS = ["bm2_index_load", "bm2_index_free", "bm2_opt_init", "bm2_opt_fill_scmat", "bm2_create", "bm2_destroy",
            "bm2_last_error", "bm2_device_count", "bm2_bsw", "bm2_smem", "bm2_sal", "bm2_seed_chain_extend",
            "bm2_batch_upload", "bm2_batch_run", "bm2_batch_stats", "bm2_batch_download", "bm2_batch_kernel_ms",
-           "bm2_batch_fetch", "bm2_finish_regs", "bm2_index_build", "bm2_sam_opt_init", "bm2_sam_se", "bm2_sam_pe", "bm2_fastq_parse", "bm2_fastq_free"]
+           "bm2_batch_fetch", "bm2_finish_regs", "bm2_index_build", "bm2_sam_opt_init", "bm2_sam_se", "bm2_sam_pe", "bm2_fastq_parse", "bm2_fastq_free", "bm2_ksw_align2"]
 
 _lib = None
 
@@ -305,6 +305,27 @@ class Context:
         n = C.c_int32(0)
         _chk(lib().bm2_batch_kernel_ms(self.h, ms, 32, C.byref(n), names), "bm2_batch_kernel_ms")
         return [(names[i].decode(), float(ms[i])) for i in range(n.value)]
+
+
+def ksw_align2(pairs, xtra, opt):
+    """pairs: list of (query codes, target codes); xtra: list of ints -> int32 array [n, 7] (score, te, qe, score2, te2, tb, qb)."""
+    n = len(pairs)
+    buf, q_off, q_len, t_off, t_len = [], [], [], [], []
+    p = 0
+    for q, t in pairs:
+        q = np.ascontiguousarray(q, np.uint8); t = np.ascontiguousarray(t, np.uint8)
+        q_off.append(p); q_len.append(len(q)); buf.append(q); p += len(q)
+        t_off.append(p); t_len.append(len(t)); buf.append(t); p += len(t)
+    seqs = np.concatenate(buf) if buf else np.zeros(1, np.uint8)
+    q_off = np.array(q_off, np.int64); t_off = np.array(t_off, np.int64)
+    q_len = np.array(q_len, np.int32); t_len = np.array(t_len, np.int32); xt = np.array(xtra, np.int32)
+    out = np.zeros((max(n, 1), 7), np.int32)
+    L = lib()
+    L.bm2_ksw_align2.argtypes = [C.c_int32] + [C.c_void_p] * 6 + [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    mat = (C.c_int8 * 25)(*opt.mat)
+    _chk(L.bm2_ksw_align2(n, seqs.ctypes.data, q_off.ctypes.data, q_len.ctypes.data, t_off.ctypes.data, t_len.ctypes.data, xt.ctypes.data,
+                          C.cast(mat, C.c_void_p), opt.o_del, opt.e_del, opt.o_ins, opt.e_ins, out.ctypes.data), "bm2_ksw_align2")
+    return out[:n]
 
 
 def fastq_parse(text):

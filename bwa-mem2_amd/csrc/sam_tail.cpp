@@ -972,6 +972,20 @@ extern "C" void bm2_sam_opt_init(bm2_sam_opt *o) {
     o->rg_id = 0;
 }
 
+extern "C" int bm2_ksw_align2(int32_t n, const uint8_t *seqs, const int64_t *q_off, const int32_t *q_len, const int64_t *t_off,
+                              const int32_t *t_len, const int32_t *xtra, const int8_t mat[25], int o_del, int e_del, int o_ins, int e_ins,
+                              bm2_ksw_result *out) {
+    if (n < 0 || (n > 0 && (!seqs || !q_off || !q_len || !t_off || !t_len || !xtra || !mat || !out)) || e_del <= 0 || e_ins <= 0) {
+        bm2_set_error("bm2_ksw_align2: bad argument"); return BM2_EINVAL;
+    }
+    for (int i = 0; i < n; ++i) {
+        if (q_len[i] <= 0 || t_len[i] < 0) { bm2_set_error("bm2_ksw_align2: pair %d has an empty query", i); return BM2_EINVAL; }
+        const KswResult r = ksw_align2(q_len[i], seqs + q_off[i], t_len[i], seqs + t_off[i], mat, o_del, e_del, o_ins, e_ins, xtra[i]);
+        out[i].score = r.score; out[i].te = r.te; out[i].qe = r.qe; out[i].score2 = r.score2; out[i].te2 = r.te2; out[i].tb = r.tb; out[i].qb = r.qb;
+    }
+    return BM2_OK;
+}
+
 extern "C" int bm2_sam_pe(const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt *so, const bm2_reads *reads,
                           const bm2_read_text *txt, const bm2_alnreg_t *alnregs, const int64_t *reg_off, int64_t n_processed,
                           const bm2_pestat *pes_in, bm2_pestat *pes_out, char *out, int64_t cap, int64_t *n_out) {

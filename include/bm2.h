@@ -190,6 +190,15 @@ typedef struct {                    /* what bseq1_t carries besides the bases (k
 int bm2_sam_se(const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt *so, const bm2_reads *reads, const bm2_read_text *txt,
                bm2_alnreg_t *alnregs, const int64_t *reg_off, int64_t n_processed, char *out, int64_t cap, int64_t *n_out);
 
+/* The local Smith-Waterman of mate rescue for a batch of (query, target) pairs: ksw_align2 (ksw.cpp:340-381) = a forward pass
+ * (score, target end, query end, second-best score / its target end outside the best's neighbourhood) and, with KSW_XSTART, a
+ * reverse pass for the start.  Host implementation today (the SSE2 kernel's striping is observable and kept); this is the
+ * seam the device kernel of SURVEY.md 8(f)1 will sit behind.  xtra = KSW_X* flags | minimum score, as mem_matesw builds it
+ * (bwamem_pair.cpp:205).  out[i] = { score, te, qe, score2, te2, tb, qb }. */
+typedef struct { int32_t score, te, qe, score2, te2, tb, qb; } bm2_ksw_result;
+int bm2_ksw_align2(int32_t n, const uint8_t *seqs, const int64_t *q_off, const int32_t *q_len, const int64_t *t_off, const int32_t *t_len,
+                   const int32_t *xtra, const int8_t mat[25], int o_del, int e_del, int o_ins, int e_ins, bm2_ksw_result *out);
+
 /* FASTA / FASTQ text -> packed reads + names / comments / qualities: kseq's record grammar (kseq.h:185-227), trim_readno
  * (bwa.cpp:62-66: a trailing "/<digit>" is cut off the name) and the nst_nt4_table base codes (bwamem.cpp:992-1000).  The
  * arrays are owned by the library until bm2_fastq_free; comment[i] / qual[i] are NULL when the record has none. */

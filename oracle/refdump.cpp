@@ -30,6 +30,7 @@
 #include <unistd.h>
 
 #include "bwamem.h"
+#include "ksw.h"
 #include "FMI_search.h"
 #include "fastmap.h"
 
@@ -195,8 +196,30 @@ int main(int argc, char **argv) {
         opt->pen_unpaired *= opt->a;
     }
     bwa_fill_scmat(opt->a, opt->b, opt->mat);
+    if (argc - optind == 3 && !strcmp(argv[optind], "ksw")) {
+        // known answers for the mate-rescue SW: every line of <pairs.txt> is "<xtra> <query> <target>" (ACGTN text);
+        // out = 7 int32 per line (score, te, qe, score2, te2, tb, qb) from the reference's ksw_align2 (ksw.cpp:340-381)
+        FILE *fi = fopen(argv[optind + 1], "r"), *fo = fopen(argv[optind + 2], "wb");
+        if (!fi || !fo) { fprintf(stderr, "cannot open the --ksw files\n"); return 1; }
+        char *line = 0; size_t cap = 0; ssize_t len;
+        while ((len = getline(&line, &cap, fi)) > 0) {
+            int xtra = 0, pos = 0;
+            if (sscanf(line, "%d %n", &xtra, &pos) < 1) continue;
+            std::vector<uint8_t> q, t; std::vector<uint8_t> *cur = &q;
+            for (char *c = line + pos; *c && *c != '\n'; ++c) {
+                if (*c == ' ') { cur = &t; continue; }
+                cur->push_back(*c == 'A' ? 0 : *c == 'C' ? 1 : *c == 'G' ? 2 : *c == 'T' ? 3 : 4);
+            }
+            kswr_t r = ksw_align2((int)q.size(), q.data(), (int)t.size(), t.data(), 5, opt->mat, opt->o_del, opt->e_del, opt->o_ins, opt->e_ins, xtra, 0);
+            int32_t o[7] = { r.score, r.te, r.qe, r.score2, r.te2, r.tb, r.qb };
+            fwrite(o, 4, 7, fo);
+        }
+        fclose(fi); fclose(fo);
+        return 0;
+    }
     if (argc - optind < 3) {
-        fprintf(stderr, "usage: refdump [mem options] <idx_prefix> <reads.fq|reads.txt> <out.bin>\n");
+        fprintf(stderr, "usage: refdump [mem options] <idx_prefix> <reads.fq|reads.txt> <out.bin>\n"
+                        "       refdump [scoring options] ksw <pairs.txt> <out.bin>\n");
         return 1;
     }
     const char *prefix = argv[optind], *reads_fn = argv[optind + 1], *out_fn = argv[optind + 2];
