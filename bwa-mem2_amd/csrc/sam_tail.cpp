@@ -43,7 +43,13 @@ struct Ref {                        // what bntseq_t + pac give this code
     }
 };
 
-void put_int(std::string &s, long long v) { char b[32]; snprintf(b, sizeof b, "%lld", v); s += b; }       // kputw / kputl
+void put_int(std::string &s, long long v) {                    // kputw / kputl (kstring.h:92-141): plain decimal
+    char b[24]; int l = 0;
+    unsigned long long x = v < 0 ? 0ULL - (unsigned long long)v : (unsigned long long)v;
+    do { b[l++] = (char)('0' + x % 10); x /= 10; } while (x);
+    if (v < 0) b[l++] = '-';
+    while (l) s.push_back(b[--l]);
+}
 
 // ---- ksw_global2 with backtrack (ksw.cpp:558-668): direction byte per cell = f<<4 | e<<2 | h ---------------------------
 int global_align(int qlen, const uint8_t *query, int tlen, const uint8_t *target, const int8_t *mat, int o_del, int e_del, int o_ins,
