@@ -272,3 +272,30 @@ def test_sam_pe_given_insert_size_model(tmp_path):
     pin[1] = bm2.PeStat(max(int(260. - 4. * 20. + .499), 1), int(260. + 4. * 20. + .499), 0, 0, 260., 20.)
     got, pes = bm2.sam_pe(fa, enc, off, ln, opt, aln, aln_off, names, quals, pes_in=pin)
     assert ref == got, _diff(ref, got)
+
+
+def test_sam_se_reference_header_tags(tmp_path):
+    # -V (XR:Z: = the contig's FASTA comment, tabs turned into spaces), -R (RG:Z:), -h (XA limits)
+    if ref_binary() is None:
+        pytest.skip("oracle/_ref reference binary not present")
+    names, ctg, alts = synth.make_genome(91, [200000, 90000], alt_contigs=1, alt_len=4000, n_repeat_families=5, repeat_len=(200, 2000),
+                                         copies=(3, 20), divergence=(0.0, 0.05))
+    fa = str(tmp_path / "g.fa")
+    with open(fa, "w") as f:
+        for i, (n, c) in enumerate(zip(names, ctg)):
+            f.write(">%s assembly=test%d\tnote with tab\n" % (n, i) if i != 1 else ">%s\n" % n)
+            s = "".join("ACGTN"[x] for x in c)
+            for k in range(0, len(s), 80):
+                f.write(s[k:k + 80] + "\n")
+    synth.write_alt(fa + ".alt", alts)
+    subprocess.check_call([ref_binary(), "index", fa], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    reads = synth.make_reads_se(92, ctg, 1200, L=120, sub_rate=0.02, indel_frac=0.2)
+    quals = [b"I" * len(r) for r in reads]
+    fq = str(tmp_path / "r.fq")
+    _write_fastq(fq, reads, quals)
+    names_ = ["q%d" % i for i in range(len(reads))]
+    for extra, so in ((["-V"], dict(flag=0x100)), (["-R", "@RG\\tID:grp1\\tSM:x"], dict(rg_id=b"grp1")), (["-h", "2,3"], dict(max_XA_hits=2, max_XA_hits_alt=3))):
+        ref = _reference_sam(fa, fq, extra)
+        got = _ours(fa, reads, names_, quals, None, bm2.default_sam_opt(**so))
+        assert ref == got, "%s: %s" % (" ".join(extra), _diff(ref, got))
+    assert b"XR:Z:assembly=test0 note with tab" in _reference_sam(fa, fq, ["-V"])
