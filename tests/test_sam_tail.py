@@ -299,3 +299,22 @@ def test_sam_se_reference_header_tags(tmp_path):
         got = _ours(fa, reads, names_, quals, None, bm2.default_sam_opt(**so))
         assert ref == got, "%s: %s" % (" ".join(extra), _diff(ref, got))
     assert b"XR:Z:assembly=test0 note with tab" in _reference_sam(fa, fq, ["-V"])
+
+
+def test_sam_pe_chimeric_mates(tmp_path):
+    # mates whose tail comes from another locus: split hits -> supplementary records, the no_pairing branch with a mate,
+    # SA:Z: lists; with -M (secondary flag instead), -Y -a, -5
+    fa, r1, r2 = _pe_case(tmp_path, 121, 1400)
+    rng = np.random.default_rng(8)
+    names_g, ctg, _ = synth.make_genome(121, [300000, 150000, 60000], alt_contigs=1, alt_len=4000, n_repeat_families=8, repeat_len=(200, 2500),
+                                        copies=(3, 30), divergence=(0.0, 0.06))
+    genome = np.concatenate(ctg)
+    for i in range(0, len(r1), 7):
+        p = int(rng.integers(0, len(genome) - 100)); k = int(rng.integers(50, 100))
+        piece = genome[p:p + (150 - k)].copy(); piece[piece > 3] = 0
+        (r1 if i % 2 else r2)[i][k:] = piece
+    for extra, flag in (([], 0), (["-M"], 0x10), (["-Y", "-a"], 0x208), (["-5"], 0x1800)):
+        ref, got, pes = _pe_run(tmp_path, fa, r1, r2, extra, flag=flag)
+        assert ref == got, "%s: %s" % (" ".join(extra), _diff(ref, got))
+        if not extra:
+            assert sum(1 for l in ref.splitlines() if int(l.split(b"\t")[1]) & 0x800) > 50
