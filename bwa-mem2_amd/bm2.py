@@ -92,7 +92,7 @@ class Stats(C.Structure):
 EXPORTS = ["bm2_index_load", "bm2_index_free", "bm2_opt_init", "bm2_opt_fill_scmat", "bm2_create", "bm2_destroy",
            "bm2_last_error", "bm2_device_count", "bm2_bsw", "bm2_smem", "bm2_sal", "bm2_seed_chain_extend",
            "bm2_batch_upload", "bm2_batch_run", "bm2_batch_stats", "bm2_batch_download", "bm2_batch_kernel_ms",
-           "bm2_batch_fetch", "bm2_finish_regs", "bm2_index_build", "bm2_sam_opt_init", "bm2_sam_se", "bm2_sam_pe", "bm2_fastq_parse", "bm2_fastq_free", "bm2_ksw_align2"]
+           "bm2_batch_fetch", "bm2_finish_regs", "bm2_index_build", "bm2_sam_opt_init", "bm2_sam_se", "bm2_sam_pe", "bm2_fastq_parse", "bm2_fastq_free", "bm2_ksw_align2", "bm2_gen_cigar"]
 
 _lib = None
 
@@ -326,6 +326,47 @@ def ksw_align2(pairs, xtra, opt):
     _chk(L.bm2_ksw_align2(n, seqs.ctypes.data, q_off.ctypes.data, q_len.ctypes.data, t_off.ctypes.data, t_len.ctypes.data, xt.ctypes.data,
                           C.cast(mat, C.c_void_p), opt.o_del, opt.e_del, opt.o_ins, opt.e_ins, out.ctypes.data), "bm2_ksw_align2")
     return out[:n]
+
+
+def gen_cigar(index_prefix, opt, tasks):
+    """tasks: list of (query codes, rb, re, w) -> list of (score, NM, [cigar ops] or None, MD bytes)."""
+    L = lib()
+    d = IndexDesc()
+    _chk(L.bm2_index_load(index_prefix.encode(), C.byref(d)), "bm2_index_load")
+    try:
+        n = len(tasks)
+        qs = [np.ascontiguousarray(t[0], np.uint8) for t in tasks]
+        q_len = np.array([len(q) for q in qs], np.int32)
+        q_off = np.concatenate([[0], np.cumsum(q_len[:-1])]).astype(np.int64) if n else np.zeros(0, np.int64)
+        seqs = np.concatenate(qs) if n else np.zeros(1, np.uint8)
+        rb = np.array([t[1] for t in tasks], np.int64); re_ = np.array([t[2] for t in tasks], np.int64); w = np.array([t[3] for t in tasks], np.int32)
+        score = np.zeros(max(n, 1), np.int32); nm = np.zeros(max(n, 1), np.int32); nc = np.zeros(max(n, 1), np.int32)
+        c_off = np.zeros(max(n, 1), np.int64); m_off = np.zeros(max(n, 1), np.int64)
+        cneed, mneed = C.c_int64(0), C.c_int64(0)
+        ccap, mcap = 16 * max(n, 1), 64 * max(n, 1)
+        L.bm2_gen_cigar.argtypes = [C.POINTER(IndexDesc), C.POINTER(Opt), C.c_int32] + [C.c_void_p] * 11 + [C.c_int64, C.POINTER(C.c_int64),
+                                    C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+        while True:
+            cig = np.zeros(ccap, np.uint32); md = C.create_string_buffer(mcap)
+            rc = L.bm2_gen_cigar(C.byref(d), C.byref(opt), n, seqs.ctypes.data, q_off.ctypes.data, q_len.ctypes.data, rb.ctypes.data,
+                                 re_.ctypes.data, w.ctypes.data, score.ctypes.data, nm.ctypes.data, nc.ctypes.data, c_off.ctypes.data,
+                                 cig.ctypes.data, ccap, C.byref(cneed), m_off.ctypes.data, C.cast(md, C.c_void_p), mcap, C.byref(mneed))
+            if rc == BM2_ECAP:
+                ccap, mcap = max(ccap, cneed.value + 1), max(mcap, mneed.value + 1)
+                continue
+            _chk(rc, "bm2_gen_cigar")
+            break
+        out = []
+        raw = md.raw
+        for i in range(n):
+            if nc[i] < 0:
+                out.append((int(score[i]), int(nm[i]), None, b""))
+            else:
+                m = raw[m_off[i]:raw.index(b"\0", m_off[i])]
+                out.append((int(score[i]), int(nm[i]), [int(x) for x in cig[c_off[i]:c_off[i] + nc[i]]], m))
+        return out
+    finally:
+        L.bm2_index_free(C.byref(d))
 
 
 def fastq_parse(text):

@@ -978,6 +978,33 @@ extern "C" void bm2_sam_opt_init(bm2_sam_opt *o) {
     o->rg_id = 0;
 }
 
+extern "C" int bm2_gen_cigar(const bm2_index_desc *idx, const bm2_opt *opt, int32_t n, const uint8_t *seqs, const int64_t *q_off,
+                             const int32_t *q_len, const int64_t *rb, const int64_t *re, const int32_t *w, int32_t *score, int32_t *nm,
+                             int32_t *n_cigar, int64_t *cigar_off, uint32_t *cigar, int64_t cigar_cap, int64_t *cigar_need, int64_t *md_off,
+                             char *md, int64_t md_cap, int64_t *md_need) {
+    if (!idx || !opt || n < 0 || !idx->ref_string || (n > 0 && (!seqs || !q_off || !q_len || !rb || !re || !w || !score || !nm || !n_cigar ||
+                                                                !cigar_off || !md_off)) || !cigar_need || !md_need) {
+        bm2_set_error("bm2_gen_cigar: bad argument"); return BM2_EINVAL;
+    }
+    Ref R = { idx->l_pac, idx->ref_string, idx->n_seqs, idx->ann_offset, idx->ann_name, idx->ann_anno };
+    int64_t co = 0, mo = 0;
+    std::vector<uint32_t> cg; std::string mds;
+    for (int i = 0; i < n; ++i) {
+        int sc = 0, NM = -1;
+        const bool ok = gen_cigar(opt->mat, opt->o_del, opt->e_del, opt->o_ins, opt->e_ins, w[i], R, q_len[i], seqs + q_off[i], rb[i], re[i], &sc, cg, &NM, mds);
+        score[i] = sc; nm[i] = NM; n_cigar[i] = ok ? (int32_t)cg.size() : -1;
+        cigar_off[i] = co; md_off[i] = mo;
+        if (ok) {
+            if (cigar && co + (int64_t)cg.size() <= cigar_cap) memcpy(cigar + co, cg.data(), cg.size() * 4);
+            if (md && mo + (int64_t)mds.size() + 1 <= md_cap) memcpy(md + mo, mds.c_str(), mds.size() + 1);
+            co += (int64_t)cg.size(); mo += (int64_t)mds.size() + 1;
+        }
+    }
+    *cigar_need = co; *md_need = mo;
+    if (co > cigar_cap || mo > md_cap || (co && !cigar) || (mo && !md)) return BM2_ECAP;
+    return BM2_OK;
+}
+
 extern "C" int bm2_ksw_align2(int32_t n, const uint8_t *seqs, const int64_t *q_off, const int32_t *q_len, const int64_t *t_off,
                               const int32_t *t_len, const int32_t *xtra, const int8_t mat[25], int o_del, int e_del, int o_ins, int e_ins,
                               bm2_ksw_result *out) {

@@ -199,6 +199,18 @@ typedef struct { int32_t score, te, qe, score2, te2, tb, qb; } bm2_ksw_result;
 int bm2_ksw_align2(int32_t n, const uint8_t *seqs, const int64_t *q_off, const int32_t *q_len, const int64_t *t_off, const int32_t *t_len,
                    const int32_t *xtra, const int8_t mat[25], int o_del, int e_del, int o_ins, int e_ins, bm2_ksw_result *out);
 
+/* CIGAR generation for a batch of hits: bwa_gen_cigar2 (bwa.cpp:260-347) = banded global alignment with backtrack of the
+ * query against reference [rb, re) (ksw_global2, ksw.cpp:558-668; both reversed first for hits on the reverse strand so that
+ * gaps end up leftmost on the forward strand), NM and the MD string.  Host implementation today; the seam of the device
+ * kernel of SURVEY.md 8(f)2.  Task i: query codes seqs[q_off[i] .. +q_len[i]), reference range [rb[i], re[i]), band w[i].
+ * Out: score[i], nm[i], n_cigar[i] (-1 = the reference returns NULL: empty or strand-bridging range), its ops at
+ * cigar[cigar_off[i] ..] (BAM encoding len<<4|op) and the NUL-terminated MD at md[md_off[i] ..].  cigar_cap / md_cap are the
+ * callers' capacities; BM2_ECAP with the needed sizes in *cigar_need / *md_need otherwise. */
+int bm2_gen_cigar(const bm2_index_desc *idx, const bm2_opt *opt, int32_t n, const uint8_t *seqs, const int64_t *q_off, const int32_t *q_len,
+                  const int64_t *rb, const int64_t *re, const int32_t *w, int32_t *score, int32_t *nm, int32_t *n_cigar,
+                  int64_t *cigar_off, uint32_t *cigar, int64_t cigar_cap, int64_t *cigar_need,
+                  int64_t *md_off, char *md, int64_t md_cap, int64_t *md_need);
+
 /* FASTA / FASTQ text -> packed reads + names / comments / qualities: kseq's record grammar (kseq.h:185-227), trim_readno
  * (bwa.cpp:62-66: a trailing "/<digit>" is cut off the name) and the nst_nt4_table base codes (bwamem.cpp:992-1000).  The
  * arrays are owned by the library until bm2_fastq_free; comment[i] / qual[i] are NULL when the record has none. */

@@ -30,6 +30,9 @@
 #include <unistd.h>
 
 #include "bwamem.h"
+#include "bwa.h"
+#include "bntseq.h"
+#include "utils.h"
 #include "ksw.h"
 #include "FMI_search.h"
 #include "fastmap.h"
@@ -217,8 +220,40 @@ int main(int argc, char **argv) {
         fclose(fi); fclose(fo);
         return 0;
     }
+    if (argc - optind == 4 && !strcmp(argv[optind], "cigar")) {
+        // known answers for CIGAR generation: every line of <tasks.txt> is "<w> <rb> <re> <query>" (query = ACGTN text of the
+        // aligned part of the read); out per line: int32 score, n_cigar, NM, then n_cigar uint32 ops, then the MD string + NUL
+        // padded to 4 bytes -- from the reference's bwa_gen_cigar2 (bwa.cpp:260-347); a NULL return is written as n_cigar = -1
+        bntseq_t *bns = bns_restore(argv[optind + 1]);
+        uint8_t *pac = (uint8_t *)calloc(bns->l_pac / 4 + 1, 1);
+        err_fread_noeof(pac, 1, bns->l_pac / 4 + 1, bns->fp_pac);
+        FILE *fi = fopen(argv[optind + 2], "r"), *fo = fopen(argv[optind + 3], "wb");
+        if (!fi || !fo) { fprintf(stderr, "cannot open the cigar files\n"); return 1; }
+        char *line = 0; size_t cap = 0; ssize_t len;
+        while ((len = getline(&line, &cap, fi)) > 0) {
+            int w = 0, pos = 0; long long rb = 0, re = 0;
+            if (sscanf(line, "%d %lld %lld %n", &w, &rb, &re, &pos) < 3) continue;
+            std::vector<uint8_t> q;
+            for (char *c = line + pos; *c && *c != '\n'; ++c) q.push_back(*c == 'A' ? 0 : *c == 'C' ? 1 : *c == 'G' ? 2 : *c == 'T' ? 3 : 4);
+            int score = 0, n_cigar = 0, NM = 0;
+            uint32_t *cg = bwa_gen_cigar2(opt->mat, opt->o_del, opt->e_del, opt->o_ins, opt->e_ins, w, bns->l_pac, pac, (int)q.size(), q.data(), rb, re, &score, &n_cigar, &NM);
+            int32_t hd[3] = { score, cg ? n_cigar : -1, NM };
+            fwrite(hd, 4, 3, fo);
+            if (cg) {
+                fwrite(cg, 4, n_cigar, fo);
+                const char *md = (const char *)(cg + n_cigar);
+                size_t l = strlen(md) + 1, padded = (l + 3) & ~(size_t)3;
+                std::vector<char> buf(padded, 0); memcpy(buf.data(), md, l);
+                fwrite(buf.data(), 1, padded, fo);
+                free(cg);
+            }
+        }
+        fclose(fi); fclose(fo);
+        return 0;
+    }
     if (argc - optind < 3) {
         fprintf(stderr, "usage: refdump [mem options] <idx_prefix> <reads.fq|reads.txt> <out.bin>\n"
+                        "       refdump [scoring options] cigar <idx_prefix> <tasks.txt> <out.bin>\n"
                         "       refdump [scoring options] ksw <pairs.txt> <out.bin>\n");
         return 1;
     }
