@@ -92,7 +92,7 @@ class Stats(C.Structure):
 EXPORTS = ["bm2_index_load", "bm2_index_free", "bm2_opt_init", "bm2_opt_fill_scmat", "bm2_create", "bm2_destroy",
            "bm2_last_error", "bm2_device_count", "bm2_bsw", "bm2_smem", "bm2_sal", "bm2_seed_chain_extend",
            "bm2_batch_upload", "bm2_batch_run", "bm2_batch_stats", "bm2_batch_download", "bm2_batch_kernel_ms",
-           "bm2_batch_fetch", "bm2_finish_regs", "bm2_index_build", "bm2_sam_opt_init", "bm2_sam_se", "bm2_sam_pe", "bm2_fastq_parse", "bm2_fastq_free", "bm2_ksw_align2", "bm2_gen_cigar"]
+           "bm2_batch_fetch", "bm2_finish_regs", "bm2_index_build", "bm2_sam_opt_init", "bm2_sam_se", "bm2_sam_pe", "bm2_fastq_parse", "bm2_fastq_free", "bm2_ksw_align2", "bm2_gen_cigar", "bm2_sam_header"]
 
 _lib = None
 
@@ -326,6 +326,22 @@ def ksw_align2(pairs, xtra, opt):
     _chk(L.bm2_ksw_align2(n, seqs.ctypes.data, q_off.ctypes.data, q_len.ctypes.data, t_off.ctypes.data, t_len.ctypes.data, xt.ctypes.data,
                           C.cast(mat, C.c_void_p), opt.o_del, opt.e_del, opt.o_ins, opt.e_ins, out.ctypes.data), "bm2_ksw_align2")
     return out[:n]
+
+
+def sam_header(index_prefix, hdr_line=None):
+    """@SQ lines (+ the caller's header lines) as bwa_print_sam_hdr prints them -> bytes."""
+    L = lib()
+    d = IndexDesc()
+    _chk(L.bm2_index_load(index_prefix.encode(), C.byref(d)), "bm2_index_load")
+    try:
+        L.bm2_sam_header.argtypes = [C.POINTER(IndexDesc), C.c_char_p, C.c_char_p, C.c_int64, C.POINTER(C.c_int64)]
+        need = C.c_int64(0)
+        L.bm2_sam_header(C.byref(d), hdr_line, None, 0, C.byref(need))
+        buf = C.create_string_buffer(need.value + 1)
+        _chk(L.bm2_sam_header(C.byref(d), hdr_line, buf, need.value, C.byref(need)), "bm2_sam_header")
+        return buf.raw[:need.value]
+    finally:
+        L.bm2_index_free(C.byref(d))
 
 
 def gen_cigar(index_prefix, opt, tasks):

@@ -978,6 +978,24 @@ extern "C" void bm2_sam_opt_init(bm2_sam_opt *o) {
     o->rg_id = 0;
 }
 
+extern "C" int bm2_sam_header(const bm2_index_desc *idx, const char *hdr_line, char *out, int64_t cap, int64_t *n_out) {
+    if (!idx || !n_out || !idx->ann_name || !idx->ann_len) { bm2_set_error("bm2_sam_header: the index descriptor needs contig names and lengths"); return BM2_EINVAL; }
+    int n_SQ = 0;
+    if (hdr_line)                                               // @SQ lines supplied by the caller replace ours (bwa.cpp:527-533)
+        for (const char *p = hdr_line; (p = strstr(p, "@SQ\t")) != 0; p += 4) if (p == hdr_line || *(p - 1) == '\n') ++n_SQ;
+    std::string s;
+    if (n_SQ == 0)
+        for (int i = 0; i < idx->n_seqs; ++i) {
+            s += "@SQ\tSN:"; s += idx->ann_name[i]; s += "\tLN:"; put_int(s, idx->ann_len[i]);
+            s += (idx->ann_is_alt && idx->ann_is_alt[i]) ? "\tAH:*\n" : "\n";
+        }
+    if (hdr_line) { s += hdr_line; s.push_back('\n'); }
+    *n_out = (int64_t)s.size();
+    if ((int64_t)s.size() > cap) return BM2_ECAP;
+    if (out && !s.empty()) memcpy(out, s.data(), s.size());
+    return BM2_OK;
+}
+
 extern "C" int bm2_gen_cigar(const bm2_index_desc *idx, const bm2_opt *opt, int32_t n, const uint8_t *seqs, const int64_t *q_off,
                              const int32_t *q_len, const int64_t *rb, const int64_t *re, const int32_t *w, int32_t *score, int32_t *nm,
                              int32_t *n_cigar, int64_t *cigar_off, uint32_t *cigar, int64_t cigar_cap, int64_t *cigar_need, int64_t *md_off,

@@ -199,6 +199,11 @@ typedef struct { int32_t score, te, qe, score2, te2, tb, qb; } bm2_ksw_result;
 int bm2_ksw_align2(int32_t n, const uint8_t *seqs, const int64_t *q_off, const int32_t *q_len, const int64_t *t_off, const int32_t *t_len,
                    const int32_t *xtra, const int8_t mat[25], int o_del, int e_del, int o_ins, int e_ins, bm2_ksw_result *out);
 
+/* The @SQ lines of bwa_print_sam_hdr (bwa.cpp:523-556): one per contig, "\tAH:*" for ALT contigs; followed by hdr_line (the
+ * caller's @RG / extra header lines, may be NULL) and a newline, as the reference prints them.  The @PG line carries the
+ * command line and stays with the caller.  *n_out = bytes needed (BM2_ECAP when cap is smaller). */
+int bm2_sam_header(const bm2_index_desc *idx, const char *hdr_line, char *out, int64_t cap, int64_t *n_out);
+
 /* CIGAR generation for a batch of hits: bwa_gen_cigar2 (bwa.cpp:260-347) = banded global alignment with backtrack of the
  * query against reference [rb, re) (ksw_global2, ksw.cpp:558-668; both reversed first for hits on the reverse strand so that
  * gaps end up leftmost on the forward strand), NM and the MD string.  Host implementation today; the seam of the device

@@ -299,6 +299,10 @@ def test_sam_se_reference_header_tags(tmp_path):
         got = _ours(fa, reads, names_, quals, None, bm2.default_sam_opt(**so))
         assert ref == got, "%s: %s" % (" ".join(extra), _diff(ref, got))
     assert b"XR:Z:assembly=test0 note with tab" in _reference_sam(fa, fq, ["-V"])
+    # the header: @SQ lines (AH:* on the ALT contig), then the caller's @RG line; @PG (the command line) is the caller's
+    p = subprocess.run([ref_binary(), "mem", "-t", "1", "-R", "@RG\\tID:grp1\\tSM:x", fa, fq], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True)
+    hdr = b"".join(l for l in p.stdout.splitlines(keepends=True) if l.startswith(b"@") and not l.startswith(b"@PG"))
+    assert hdr == bm2.sam_header(fa, b"@RG\tID:grp1\tSM:x") and b"\tAH:*\n" in hdr
 
 
 def test_sam_pe_chimeric_mates(tmp_path):
