@@ -322,3 +322,23 @@ def test_sam_pe_chimeric_mates(tmp_path):
         assert ref == got, "%s: %s" % (" ".join(extra), _diff(ref, got))
         if not extra:
             assert sum(1 for l in ref.splitlines() if int(l.split(b"\t")[1]) & 0x800) > 50
+
+
+def test_end_to_end_harness_with_the_oracle_backend(tmp_path):
+    # tools/bm2_mem.py: FASTQ files -> chunks as `mem -K` cuts them -> SAM incl. @SQ header; the oracle stands in for the device
+    # (the same harness with --backend gpu is what tests/test_end_to_end_gpu.py exercises piece by piece)
+    fa, r1, r2 = _pe_case(tmp_path, 131, 900, L=100, ins_mean=280, ins_sd=40)
+    f1, f2 = str(tmp_path / "a_1.fq"), str(tmp_path / "a_2.fq")
+    for path, rr, sfx in ((f1, r1, b"/1"), (f2, r2, b"/2")):
+        with open(path, "wb") as f:
+            for i, r in enumerate(rr):
+                f.write(b"@frag%d" % i + sfx + b"\n" + bytes(b"ACGTN"[c] for c in r) + b"\n+\n" + b"F" * len(r) + b"\n")
+    K = 40000
+    p = subprocess.run([ref_binary(), "mem", "-t", "1", "-K", str(K), fa, f1, f2], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True)
+    ref = b"".join(l for l in p.stdout.splitlines(keepends=True) if not l.startswith(b"@PG"))
+    import os, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "out.sam")
+    subprocess.check_call([sys.executable, os.path.join(root, "tools", "bm2_mem.py"), "--backend", "oracle", "-K", str(K), "-o", out, fa, f1, f2])
+    got = open(out, "rb").read()
+    assert ref == got, _diff(ref, got)
