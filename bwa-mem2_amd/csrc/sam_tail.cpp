@@ -521,51 +521,74 @@ bool reg2sam(const bm2_opt *opt, const bm2_sam_opt *so, const Ref &R, std::strin
 struct KswResult { int score = 0, te = -1, qe = -1, score2 = -1, te2 = -1, tb = -1, qb = -1; };
 enum { KSW_XBYTE = 0x10000, KSW_XSTOP = 0x20000, KSW_XSUBO = 0x40000, KSW_XSTART = 0x80000 };
 
+// Lane types: the byte kernel works on 16 unsigned bytes with saturating +/- (paddusb / psubusb), the word kernel on 8 signed
+// words; both are one 16-byte compiler vector, so the code below maps one to one onto SSE2 (or NEON) registers.
+template <int P> struct KswLane;
+template <> struct KswLane<16> { typedef uint8_t T; };
+template <> struct KswLane<8> { typedef int16_t T; };
+
 template <int P> struct KswProfile {                            // ksw_qinit, ksw.cpp:62-109
+    typedef typename KswLane<P>::T T;
+    typedef T V __attribute__((vector_size(16)));
     int qlen, slen, shift, max;
-    std::vector<int> qp;                                        // [m = 5][slen][P]
-    KswProfile(int qlen_, const uint8_t *query, const int8_t *mat) : qlen(qlen_) {
+    V *qp;                                                      // [m = 5][slen] vectors, lane k of segment i = query position i + k*slen
+    KswProfile(int qlen_, const uint8_t *query, const int8_t *mat, std::vector<V> &store) : qlen(qlen_) {
         slen = (qlen + P - 1) / P;
         int lo = 127, hi = 0;
         for (int a = 0; a < 25; ++a) { if (mat[a] < lo) lo = mat[a]; if (mat[a] > hi) hi = mat[a]; }
         max = hi;
         shift = (256 - (lo & 0xff)) & 0xff;                     // uint8_t arithmetic of the reference
-        qp.assign((size_t)5 * slen * P, 0);
-        size_t t = 0;
+        store.resize((size_t)5 * slen);
+        qp = store.data();
+        const int add = P == 16 ? shift : 0;
         for (int a = 0; a < 5; ++a) {
             const int8_t *ma = mat + a * 5;
-            const int nlen = slen * P;
-            for (int i = 0; i < slen; ++i)
-                for (int k = i; k < nlen; k += slen) qp[t++] = (k >= qlen ? 0 : ma[query[k]]) + (P == 16 ? shift : 0);
+            T row[5];
+            for (int c = 0; c < 5; ++c) row[c] = (T)(ma[c] + add);
+            for (int i = 0; i < slen; ++i) {
+                V v;
+                for (int k = 0; k < P; ++k) { const int pos = i + k * slen; v[k] = pos >= qlen ? (T)add : row[query[pos]]; }
+                qp[(size_t)a * slen + i] = v;
+            }
         }
     }
 };
 
-template <int P>
-KswResult ksw_striped(const KswProfile<P> &q, int tlen, const uint8_t *target, int o_del, int e_del, int o_ins, int e_ins, int xtra) {
-    const bool U8 = P == 16;
-    // P lanes of signed 16 bits (every value of either kernel fits) as one compiler vector: element-wise +, -, min, max
-    typedef int16_t V __attribute__((vector_size(P * 2)));
-    const int slen = q.slen;
-    auto splat = [](int x) { V v; for (int k = 0; k < P; ++k) v[k] = (int16_t)x; return v; };
-    const V zero = splat(0), oe_del = splat(o_del + e_del), oe_ins = splat(o_ins + e_ins), ed = splat(e_del), ei = splat(e_ins),
-            shift = splat(q.shift), c255 = splat(255);
-    auto vmax = [](V a, V b) { return __builtin_elementwise_max(a, b); };
-    auto vmin = [](V a, V b) { return __builtin_elementwise_min(a, b); };
-    auto ssub = [&](V a, V b) { return vmax(a - b, zero); };                    // subs_epu8 / subs_epu16 on non-negative lanes
-    auto up1 = [&](V v) { V r; r[0] = 0; for (int k = 1; k < P; ++k) r[k] = v[k - 1]; return r; };   // _mm_slli_si128 by one lane
-    const int minsc = (xtra & KSW_XSUBO) ? xtra & 0xffff : 0x10000, endsc = (xtra & KSW_XSTOP) ? xtra & 0xffff : 0x10000;
-    std::vector<V> Ha((size_t)slen, zero), Hb((size_t)slen, zero), E((size_t)slen, zero), Hmax((size_t)slen, zero), QP((size_t)5 * slen);
-    for (size_t t = 0; t < (size_t)5 * slen; ++t) for (int k = 0; k < P; ++k) QP[t][k] = (int16_t)q.qp[t * P + k];
-    V *H0 = Ha.data(), *H1 = Hb.data();
+template <int P> struct KswScratch {                            // per-thread buffers, reused from call to call
+    typedef typename KswProfile<P>::V V;
+    std::vector<V> prof, rows;
     std::vector<uint64_t> b;
+};
+
+template <int P>
+KswResult ksw_striped(const KswProfile<P> &q, KswScratch<P> &ws, int tlen, const uint8_t *target, int o_del, int e_del, int o_ins, int e_ins, int xtra) {
+    constexpr bool U8 = P == 16;
+    typedef typename KswProfile<P>::T T;
+    typedef typename KswProfile<P>::V V;
+    const int slen = q.slen;
+    auto splat = [](int x) { V v; for (int k = 0; k < P; ++k) v[k] = (T)x; return v; };
+    const V zero = splat(0), oe_del = splat(o_del + e_del), oe_ins = splat(o_ins + e_ins), ed = splat(e_del), ei = splat(e_ins),
+            shift = splat(q.shift);
+    auto vmax = [](V a, V b) { return __builtin_elementwise_max(a, b); };
+    auto ssub = [&](V a, V b) {                                                  // subs_epu8 / subs_epu16 (word lanes are never negative here)
+        if constexpr (U8) return __builtin_elementwise_sub_sat(a, b); else return __builtin_elementwise_max(a - b, zero);
+    };
+    auto up1 = [&](V v) {                                                        // _mm_slli_si128 by one lane
+        if constexpr (U8) return __builtin_shufflevector(zero, v, 0, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30);
+        else return __builtin_shufflevector(zero, v, 0, 8, 9, 10, 11, 12, 13, 14);
+    };
+    const int minsc = (xtra & KSW_XSUBO) ? xtra & 0xffff : 0x10000, endsc = (xtra & KSW_XSTOP) ? xtra & 0xffff : 0x10000;
+    ws.rows.assign((size_t)4 * slen, zero);
+    V *H0 = ws.rows.data(), *H1 = H0 + slen, *E = H1 + slen, *Hmax = E + slen;
+    std::vector<uint64_t> &b = ws.b;
+    b.clear();
     int te = -1, gmax = 0;
     KswResult r;
     for (int i = 0; i < tlen; ++i) {
-        const V *S = &QP[(size_t)target[i] * slen];
+        const V *S = q.qp + (size_t)target[i] * slen;
         V h = up1(H0[slen - 1]), f = zero, mx = zero;
         for (int j = 0; j < slen; ++j) {
-            if (U8) h = ssub(vmin(h + S[j], c255), shift);                       // adds_epu8, subs_epu8
+            if constexpr (U8) h = __builtin_elementwise_sub_sat(__builtin_elementwise_add_sat(h, S[j]), shift);   // adds_epu8, subs_epu8
             else h = __builtin_elementwise_add_sat(h, S[j]);                     // adds_epi16
             V e = E[j];
             h = vmax(vmax(h, e), f);
@@ -582,8 +605,9 @@ KswResult ksw_striped(const KswProfile<P> &q, int tlen, const uint8_t *target, i
                 const V hv = vmax(H1[j], f);
                 H1[j] = hv;
                 f = ssub(f, ei);
-                const V gt = f > ssub(hv, oe_ins);              // lanes: -1 where f still beats what H would start
-                if (!__builtin_reduce_or(gt)) { done = true; break; }
+                // stop once no lane of f beats what H would start: f <= H - oe_ins everywhere  <=>  subs(f, H - oe_ins) == 0
+                const V over = ssub(f, ssub(hv, oe_ins));
+                if (!__builtin_reduce_or(over)) { done = true; break; }
             }
         }
         const int imax = __builtin_reduce_max(mx);
@@ -593,7 +617,7 @@ KswResult ksw_striped(const KswProfile<P> &q, int tlen, const uint8_t *target, i
         }
         if (imax > gmax) {
             gmax = imax; te = i;
-            for (int j = 0; j < slen; ++j) Hmax[j] = H1[j];
+            memcpy(Hmax, H1, (size_t)slen * sizeof(V));
             if (U8 ? (gmax + q.shift >= 255 || gmax >= endsc) : (gmax >= endsc)) break;
         }
         V *t = H1; H1 = H0; H0 = t;
@@ -602,12 +626,11 @@ KswResult ksw_striped(const KswProfile<P> &q, int tlen, const uint8_t *target, i
     r.te = te;
     if (!U8 || r.score != 255) {
         int mxv = -1;
-        const int qlen = slen * P;
-        for (int i = 0; i < qlen; ++i) {
-            const int t = Hmax[i / P][i % P], pos = i / P + i % P * slen;
-            if (t > mxv) { mxv = t; r.qe = pos; }
-            else if (t == mxv && pos < r.qe) r.qe = pos;
-        }
+        for (int k = 0; k < P; ++k)                             // ascending query position within a lane, so ties keep the smallest
+            for (int i = 0; i < slen; ++i) {
+                const int t = Hmax[i][k], pos = i + k * slen;
+                if (t > mxv) { mxv = t; r.qe = pos; }
+            }
         if (!b.empty()) {
             const int d = (r.score + q.max - 1) / q.max, low = te - d, high = te + d;
             for (uint64_t x : b) {
@@ -619,19 +642,27 @@ KswResult ksw_striped(const KswProfile<P> &q, int tlen, const uint8_t *target, i
     return r;
 }
 
+template <int P>
+KswResult ksw_pass(int qlen, const uint8_t *query, int tlen, const uint8_t *target, const int8_t *mat, int o_del, int e_del, int o_ins,
+                   int e_ins, int xtra) {
+    static thread_local KswScratch<P> ws;
+    const KswProfile<P> prof(qlen, query, mat, ws.prof);
+    return ksw_striped<P>(prof, ws, tlen, target, o_del, e_del, o_ins, e_ins, xtra);
+}
+
 // ksw_align2, ksw.cpp:340-381 (query and target are private copies here; the reference reverses them in place and back)
 KswResult ksw_align2(int qlen, const uint8_t *query, int tlen, const uint8_t *target, const int8_t *mat, int o_del, int e_del, int o_ins,
                      int e_ins, int xtra) {
     const bool byte = (xtra & KSW_XBYTE) != 0;
-    KswResult r = byte ? ksw_striped<16>(KswProfile<16>(qlen, query, mat), tlen, target, o_del, e_del, o_ins, e_ins, xtra)
-                       : ksw_striped<8>(KswProfile<8>(qlen, query, mat), tlen, target, o_del, e_del, o_ins, e_ins, xtra);
+    KswResult r = byte ? ksw_pass<16>(qlen, query, tlen, target, mat, o_del, e_del, o_ins, e_ins, xtra)
+                       : ksw_pass<8>(qlen, query, tlen, target, mat, o_del, e_del, o_ins, e_ins, xtra);
     if ((xtra & KSW_XSTART) == 0 || ((xtra & KSW_XSUBO) && r.score < (xtra & 0xffff))) return r;
     std::vector<uint8_t> rq(query, query + r.qe + 1), rt(target, target + tlen);
     std::reverse(rq.begin(), rq.end());
     std::reverse(rt.begin(), rt.begin() + r.te + 1);            // only the first te+1 bases are reversed; the rest of the target stays
     const int x2 = KSW_XSTOP | r.score;
-    const KswResult rr = byte ? ksw_striped<16>(KswProfile<16>(r.qe + 1, rq.data(), mat), tlen, rt.data(), o_del, e_del, o_ins, e_ins, x2)
-                              : ksw_striped<8>(KswProfile<8>(r.qe + 1, rq.data(), mat), tlen, rt.data(), o_del, e_del, o_ins, e_ins, x2);
+    const KswResult rr = byte ? ksw_pass<16>(r.qe + 1, rq.data(), tlen, rt.data(), mat, o_del, e_del, o_ins, e_ins, x2)
+                              : ksw_pass<8>(r.qe + 1, rq.data(), tlen, rt.data(), mat, o_del, e_del, o_ins, e_ins, x2);
     if (r.score == rr.score) { r.tb = r.te - rr.te; r.qb = r.qe - rr.qe; }
     return r;
 }
