@@ -58,6 +58,8 @@ def lib():
         _lib.ora_ksw_extend.restype = C.c_int
         _lib.ora_ksw_extend.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p] + [C.c_int] * 8 + \
                                        [C.POINTER(C.c_int)] * 5 + [C.c_void_p]
+        _lib.ora_ksw_extend_cls.restype = C.c_int
+        _lib.ora_ksw_extend_cls.argtypes = _lib.ora_ksw_extend.argtypes + [C.c_int]
         _lib.ora_band_clamp.restype = C.c_int
         _lib.ora_band_clamp.argtypes = [C.c_int] * 9
         _lib.ora_pair_class.restype = C.c_int
@@ -116,7 +118,7 @@ class Index:
 
 
 def ksw_extend(query, target, opt, w, end_bonus, h0, cls=None):
-    """-> (score, qle, tle, gtle, gscore, max_off); band clamped as the pair's class would."""
+    """-> (score, qle, tle, gtle, gscore, max_off); band clamp and Z-drop rule of the kernel class the pair runs in."""
     L = lib()
     q = np.ascontiguousarray(query, np.uint8)
     t = np.ascontiguousarray(target, np.uint8)
@@ -125,6 +127,6 @@ def ksw_extend(query, target, opt, w, end_bonus, h0, cls=None):
     wc = L.ora_band_clamp(w, len(q), opt.a, end_bonus, opt.o_ins, opt.e_ins, opt.o_del, opt.e_del, cls)
     outs = [C.c_int() for _ in range(5)]
     mat = (C.c_int8 * 25)(*opt.mat)
-    sc = L.ora_ksw_extend(len(q), q.ctypes.data, len(t), t.ctypes.data, C.addressof(mat), opt.o_del, opt.e_del,
-                          opt.o_ins, opt.e_ins, wc, end_bonus, opt.zdrop, h0, *[C.byref(x) for x in outs], None)
+    sc = L.ora_ksw_extend_cls(len(q), q.ctypes.data, len(t), t.ctypes.data, C.addressof(mat), opt.o_del, opt.e_del,
+                              opt.o_ins, opt.e_ins, wc, end_bonus, opt.zdrop, h0, *[C.byref(x) for x in outs], None, cls)
     return (sc,) + tuple(x.value for x in outs)
