@@ -44,7 +44,14 @@ extern "C" int bm2_index_load(const char *prefix, bm2_index_desc *d) {
     f = fopen((pre + ".ann").c_str(), "r");
     if (!f) { bm2_set_error("cannot open %s.ann", prefix); bm2_index_free(d); return BM2_EIO; }
     long long l_pac; int n_seqs; unsigned seed;
-    if (fscanf(f, "%lld%d%u", &l_pac, &n_seqs, &seed) != 3 || n_seqs < 0) { fclose(f); bm2_index_free(d); return BM2_EIO; }
+    auto bad_ann = [&](const char *what) {
+        bm2_set_error("%s.ann is malformed (%s)", prefix, what);
+        fclose(f); bm2_index_free(d);
+        return BM2_EIO;
+    };
+    if (fscanf(f, "%lld%d%u", &l_pac, &n_seqs, &seed) != 3) return bad_ann("first line is not `l_pac n_seqs seed`");
+    if (n_seqs <= 0 || n_seqs > 100000000 || l_pac <= 0) return bad_ann("sequence count or packed length out of range");
+    if (d->ref_len != 2 * l_pac + 1) return bad_ann("its packed length does not match .bwt.2bit.64: ref_len != 2*l_pac+1");
     d->l_pac = l_pac; d->n_seqs = n_seqs;
     int64_t *off = (int64_t *)calloc((size_t)n_seqs + 1, 8);
     int32_t *len = (int32_t *)calloc((size_t)n_seqs + 1, 4), *alt = (int32_t *)calloc((size_t)n_seqs + 1, 4);
@@ -52,17 +59,22 @@ extern "C" int bm2_index_load(const char *prefix, bm2_index_desc *d) {
     std::vector<std::string> names;
     char **nm = (char **)calloc((size_t)n_seqs + 1, sizeof(char *)), **an = (char **)calloc((size_t)n_seqs + 1, sizeof(char *));
     d->ann_name = nm; d->ann_anno = an;
+    if (!off || !len || !alt || !nm || !an) return bad_ann("out of memory");
+    long long expect = 0;
     for (int i = 0; i < n_seqs; i++) {
         unsigned gi; char name[8193]; int c, namb; long long o;
-        if (fscanf(f, "%u%8192s", &gi, name) != 2) { fclose(f); bm2_index_free(d); return BM2_EIO; }
+        if (fscanf(f, "%u%8192s", &gi, name) != 2) return bad_ann("sequence name line missing");
         names.push_back(name);
         nm[i] = strdup(name);
         std::string rest;                                      // the comment up to the end of the line (bntseq.cpp:135-140)
         while ((c = fgetc(f)) != '\n' && c != EOF) if (rest.size() < 8191) rest.push_back((char)c);
         an[i] = strdup(rest.size() > 1 && rest != " (null)" ? rest.c_str() + 1 : "");
-        if (fscanf(f, "%lld%d%d", &o, &len[i], &namb) != 3) { fclose(f); bm2_index_free(d); return BM2_EIO; }
+        if (fscanf(f, "%lld%d%d", &o, &len[i], &namb) != 3) return bad_ann("`offset len n_ambs` line missing");
+        if (o != expect || len[i] < 0) return bad_ann("sequence offsets are not contiguous");
         off[i] = o;
+        expect += len[i];
     }
+    if (expect != l_pac) return bad_ann("sequence lengths do not add up to l_pac");
     fclose(f);
     if ((f = fopen((pre + ".alt").c_str(), "r")) != 0) {     // bntseq.cpp:201-226
         char line[8192];
@@ -73,7 +85,6 @@ extern "C" int bm2_index_load(const char *prefix, bm2_index_desc *d) {
         }
         fclose(f);
     }
-    if (d->ref_len != 2 * d->l_pac + 1) { bm2_set_error("index inconsistent: ref_len != 2*l_pac+1"); bm2_index_free(d); return BM2_EIO; }
     f = fopen((pre + ".0123").c_str(), "rb");
     if (!f) { bm2_set_error("cannot open %s.0123", prefix); bm2_index_free(d); return BM2_EIO; }
     uint8_t *ref = (uint8_t *)malloc((size_t)(2 * d->l_pac) + 64);
