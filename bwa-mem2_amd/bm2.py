@@ -55,7 +55,7 @@ class SamOpt(C.Structure):
     _fields_ = [("T", C.c_int32), ("flag", C.c_int32), ("max_XA_hits", C.c_int32), ("max_XA_hits_alt", C.c_int32),
                 ("XA_drop_ratio", C.c_float), ("mapQ_coef_len", C.c_float), ("mapQ_coef_fac", C.c_int32),
                 ("pen_unpaired", C.c_int32), ("max_ins", C.c_int32), ("max_matesw", C.c_int32), ("n_threads", C.c_int32),
-                ("pad", C.c_int32), ("rg_id", C.c_char_p)]
+                ("rescue_inline", C.c_int32), ("rg_id", C.c_char_p)]
 
 
 class Fastq(C.Structure):
@@ -92,7 +92,7 @@ class Stats(C.Structure):
 EXPORTS = ["bm2_index_load", "bm2_index_free", "bm2_opt_init", "bm2_opt_fill_scmat", "bm2_create", "bm2_destroy",
            "bm2_last_error", "bm2_device_count", "bm2_bsw", "bm2_smem", "bm2_sal", "bm2_seed_chain_extend",
            "bm2_batch_upload", "bm2_batch_run", "bm2_batch_stats", "bm2_batch_download", "bm2_batch_kernel_ms",
-           "bm2_batch_fetch", "bm2_finish_regs", "bm2_index_build", "bm2_sam_opt_init", "bm2_sam_se", "bm2_sam_pe", "bm2_fastq_parse", "bm2_fastq_free", "bm2_ksw_align2", "bm2_gen_cigar", "bm2_sam_header"]
+           "bm2_batch_fetch", "bm2_finish_regs", "bm2_index_build", "bm2_sam_opt_init", "bm2_sam_se", "bm2_sam_pe", "bm2_fastq_parse", "bm2_fastq_free", "bm2_ksw_align2", "bm2_gen_cigar", "bm2_sam_header", "bm2_sam_rescue_stats"]
 
 _lib = None
 
@@ -328,6 +328,13 @@ def ksw_align2(pairs, xtra, opt):
     return out[:n]
 
 
+def sam_rescue_stats():
+    """(planned, used, missed) mate-rescue alignments of the last sam_pe call."""
+    v = [C.c_int64(0) for _ in range(3)]
+    lib().bm2_sam_rescue_stats(*[C.byref(x) for x in v])
+    return tuple(x.value for x in v)
+
+
 def sam_header(index_prefix, hdr_line=None):
     """@SQ lines (+ the caller's header lines) as bwa_print_sam_hdr prints them -> bytes."""
     L = lib()
@@ -442,7 +449,7 @@ def sam_se(index_prefix, enc, off, ln, opt, alnregs, reg_off, names, quals=None,
                      C.cast(ql, C.POINTER(C.c_char_p)) if ql is not None else None)
         reg_off = np.ascontiguousarray(reg_off, np.int64)
         need = C.c_int64(0)
-        cap = 1 << 20
+        cap = max(1 << 20, int(3 * (np.asarray(ln, np.int64).sum() + 200 * n)))       # a generous first guess: ECAP means running the chunk again
         while True:
             a = np.ascontiguousarray(alnregs, ALNREG_DT).copy()          # reordered in place: every call gets fresh regs
             buf = C.create_string_buffer(cap)

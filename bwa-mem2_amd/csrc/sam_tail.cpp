@@ -732,7 +732,7 @@ void pestat(const bm2_opt *opt, const bm2_sam_opt *so, int64_t l_pac, const std:
 }
 
 // bns_fetch_seq (bntseq.cpp:453-482) on the unpacked reference: [*beg, *end) clamped to the contig (strand-aware) that holds mid
-bool fetch_seq(const Ref &R, const int32_t *ann_len, int64_t *beg, int64_t mid, int64_t *end, int *rid, std::vector<uint8_t> &seq) {
+bool fetch_range(const Ref &R, const int32_t *ann_len, int64_t *beg, int64_t mid, int64_t *end, int *rid) {
     if (*end < *beg) { const int64_t t = *beg; *beg = *end; *end = t; }
     int is_rev;
     *rid = R.pos2rid(R.depos(mid, &is_rev));
@@ -741,65 +741,134 @@ bool fetch_seq(const Ref &R, const int32_t *ann_len, int64_t *beg, int64_t mid, 
     if (is_rev) { const int64_t t = far_beg; far_beg = (R.l_pac << 1) - far_end; far_end = (R.l_pac << 1) - t; }
     *beg = *beg > far_beg ? *beg : far_beg;
     *end = *end < far_end ? *end : far_end;
-    seq.assign(R.ref_string + *beg, R.ref_string + *end);       // .0123 = what bns_get_seq unpacks (forward, then reverse complement)
+    return true;                                                 // the bases are R.ref_string[*beg, *end): .0123 = what bns_get_seq unpacks
+}
+
+// ---- mate rescue (mem_matesw, bwamem_pair.cpp:150-283, MATE_SORT == 0), split so that the alignments of a whole chunk can run as
+// one batch: rescue_window = where direction r of anchor `a` would look for the mate; rescue_align = the local SW there;
+// rescue_apply = what the result does to the mate's hit list.  matesw() strings them together per anchor as the reference does.
+struct RescueTask {                 // one (anchor, direction) alignment of a pair, enumerated before the pair is processed
+    int32_t pair, j;                // j = rank of the anchor in b[end] (mem_sam_pe's candidate list)
+    uint8_t end, r;                 // end = which read the ANCHOR belongs to (the mate is !end); r = direction 0..3
+    int64_t rb, re;                 // the window, already clamped to the contig
+    KswResult res;
+};
+struct RescueStats { std::atomic<long long> planned{0}, used{0}, missed{0}; };
+
+bool rescue_window(const bm2_opt *opt, const Ref &R, const int32_t *ann_len, const PeStat pes[4], const bm2_alnreg_t *a, int l_ms, int r,
+                   int64_t *rb_, int64_t *re_) {
+    const int64_t l_pac = R.l_pac;
+    const int is_rev = (r >> 1 != (r & 1)), is_larger = !(r >> 1);
+    int64_t rb, re;
+    if (!is_rev) {
+        rb = is_larger ? a->rb + pes[r].low : a->rb - pes[r].high;
+        re = (is_larger ? a->rb + pes[r].high : a->rb - pes[r].low) + l_ms;
+    } else {
+        rb = (is_larger ? a->rb + pes[r].low : a->rb - pes[r].high) - l_ms;
+        re = is_larger ? a->rb + pes[r].high : a->rb - pes[r].low;
+    }
+    if (rb < 0) rb = 0;
+    if (re > l_pac << 1) re = l_pac << 1;
+    if (rb >= re) return false;
+    int rid = -1;
+    if (!fetch_range(R, ann_len, &rb, (rb + re) >> 1, &re, &rid)) return false;
+    if (a->rid != rid || re - rb < opt->min_seed_len) return false;
+    *rb_ = rb; *re_ = re;
     return true;
 }
 
-// mem_matesw, bwamem_pair.cpp:150-283 (MATE_SORT == 0): rescue the mate of hit `a` near where the insert-size model expects it
-int matesw(const bm2_opt *opt, const bm2_sam_opt *so, const Ref &R, const int32_t *ann_len, const PeStat pes[4], const bm2_alnreg_t *a,
-           int l_ms, const uint8_t *ms, std::vector<bm2_alnreg_t> &ma) {
+int rescue_xtra(const bm2_opt *opt, int l_ms) { return KSW_XSUBO | KSW_XSTART | (l_ms * opt->a < 250 ? KSW_XBYTE : 0) | (opt->min_seed_len * opt->a); }
+
+void rescue_query(int l_ms, const uint8_t *ms, int r, std::vector<uint8_t> &q) {       // the mate as direction r reads it
+    const int is_rev = (r >> 1 != (r & 1));
+    q.resize((size_t)l_ms);
+    if (!is_rev) memcpy(q.data(), ms, (size_t)l_ms);
+    else for (int i = 0; i < l_ms; ++i) q[(size_t)(l_ms - 1 - i)] = ms[i] < 4 ? 3 - ms[i] : 4;
+}
+
+KswResult rescue_align(const bm2_opt *opt, const Ref &R, int l_ms, const uint8_t *ms, int r, int64_t rb, int64_t re) {
+    static thread_local std::vector<uint8_t> q;
+    rescue_query(l_ms, ms, r, q);
+    return ksw_align2(l_ms, q.data(), (int)(re - rb), R.ref_string + rb, opt->mat, opt->o_del, opt->e_del, opt->o_ins, opt->e_ins, rescue_xtra(opt, l_ms));
+}
+
+void rescue_apply(const bm2_opt *opt, const Ref &R, const bm2_alnreg_t *a, int l_ms, int r, int64_t rb, const KswResult &aln,
+                  std::vector<bm2_alnreg_t> &ma) {
     const int64_t l_pac = R.l_pac;
-    int skip[4], n = 0, rid = -1;
+    const int is_rev = (r >> 1 != (r & 1));
+    if (aln.score < opt->min_seed_len || aln.qb < 0) return;
+    bm2_alnreg_t b; memset(&b, 0, sizeof b);
+    b.rid = a->rid; b.is_alt = a->is_alt;
+    b.qb = is_rev ? l_ms - (aln.qe + 1) : aln.qb;
+    b.qe = is_rev ? l_ms - aln.qb : aln.qe + 1;
+    b.rb = is_rev ? (l_pac << 1) - (rb + aln.te + 1) : rb + aln.tb;
+    b.re = is_rev ? (l_pac << 1) - (rb + aln.tb) : rb + aln.te + 1;
+    b.score = aln.score; b.csub = aln.score2; b.secondary = -1;
+    b.seedcov = (int)((b.re - b.rb < b.qe - b.qb ? b.re - b.rb : b.qe - b.qb) >> 1);
+    size_t i;
+    for (i = 0; i < ma.size(); ++i) if (ma[i].score < b.score) break;                  // keep ma sorted by score
+    ma.insert(ma.begin() + (long)i, b);
+}
+
+void rescue_skip(const Ref &R, const PeStat pes[4], const bm2_alnreg_t *a, const std::vector<bm2_alnreg_t> &ma, int skip[4]) {
     for (int r = 0; r < 4; ++r) skip[r] = pes[r].failed ? 1 : 0;
-    for (size_t i = 0; i < ma.size(); ++i) {
+    for (size_t i = 0; i < ma.size(); ++i) {                     // a direction that already has a hit at a plausible distance needs no rescue
         int64_t dist;
-        const int r = infer_dir(l_pac, a->rb, ma[i].rb, &dist);
+        const int r = infer_dir(R.l_pac, a->rb, ma[i].rb, &dist);
         if (dist >= pes[r].low && dist <= pes[r].high) skip[r] = 1;
     }
+}
+
+// pre[0, n_pre): the alignments planned for this anchor (end, j) and already computed, or none (then they are computed here)
+int matesw(const bm2_opt *opt, const bm2_sam_opt *so, const Ref &R, const int32_t *ann_len, const PeStat pes[4], const bm2_alnreg_t *a,
+           int l_ms, const uint8_t *ms, std::vector<bm2_alnreg_t> &ma, const RescueTask *pre, int n_pre, RescueStats *st) {
+    int skip[4], n = 0;
+    rescue_skip(R, pes, a, ma, skip);
     if (skip[0] + skip[1] + skip[2] + skip[3] == 4) return 0;
     for (int r = 0; r < 4; ++r) {
         if (skip[r]) continue;
-        const int is_rev = (r >> 1 != (r & 1)), is_larger = !(r >> 1);
-        std::vector<uint8_t> rev, ref;
-        const uint8_t *seq = ms;
-        if (is_rev) {
-            rev.resize((size_t)l_ms);
-            for (int i = 0; i < l_ms; ++i) rev[l_ms - 1 - i] = ms[i] < 4 ? 3 - ms[i] : 4;
-            seq = rev.data();
-        }
         int64_t rb, re;
-        if (!is_rev) {
-            rb = is_larger ? a->rb + pes[r].low : a->rb - pes[r].high;
-            re = (is_larger ? a->rb + pes[r].high : a->rb - pes[r].low) + l_ms;
-        } else {
-            rb = (is_larger ? a->rb + pes[r].low : a->rb - pes[r].high) - l_ms;
-            re = is_larger ? a->rb + pes[r].high : a->rb - pes[r].low;
-        }
-        if (rb < 0) rb = 0;
-        if (re > l_pac << 1) re = l_pac << 1;
-        bool have = false;
-        if (rb < re) have = fetch_seq(R, ann_len, &rb, (rb + re) >> 1, &re, &rid, ref);
-        if (have && a->rid == rid && re - rb >= opt->min_seed_len) {
-            const int xtra = KSW_XSUBO | KSW_XSTART | (l_ms * opt->a < 250 ? KSW_XBYTE : 0) | (opt->min_seed_len * opt->a);
-            const KswResult aln = ksw_align2(l_ms, seq, (int)(re - rb), ref.data(), opt->mat, opt->o_del, opt->e_del, opt->o_ins, opt->e_ins, xtra);
-            if (aln.score >= opt->min_seed_len && aln.qb >= 0) {
-                bm2_alnreg_t b; memset(&b, 0, sizeof b);
-                b.rid = a->rid; b.is_alt = a->is_alt;
-                b.qb = is_rev ? l_ms - (aln.qe + 1) : aln.qb;
-                b.qe = is_rev ? l_ms - aln.qb : aln.qe + 1;
-                b.rb = is_rev ? (l_pac << 1) - (rb + aln.te + 1) : rb + aln.tb;
-                b.re = is_rev ? (l_pac << 1) - (rb + aln.tb) : rb + aln.te + 1;
-                b.score = aln.score; b.csub = aln.score2; b.secondary = -1;
-                b.seedcov = (int)((b.re - b.rb < b.qe - b.qb ? b.re - b.rb : b.qe - b.qb) >> 1);
-                size_t i;
-                for (i = 0; i < ma.size(); ++i) if (ma[i].score < b.score) break;      // keep ma sorted by score
-                ma.insert(ma.begin() + (long)i, b);
+        if (rescue_window(opt, R, ann_len, pes, a, l_ms, r, &rb, &re)) {
+            const RescueTask *hit = nullptr;
+            for (int t = 0; t < n_pre; ++t) if (pre[t].r == r) { hit = &pre[t]; break; }
+            if (hit) { if (st) st->used++; rescue_apply(opt, R, a, l_ms, r, rb, hit->res, ma); }
+            else {
+                if (st && pre) st->missed++;                     // planned before the mate's list changed: rare, computed in place
+                rescue_apply(opt, R, a, l_ms, r, rb, rescue_align(opt, R, l_ms, ms, r, rb, re), ma);
             }
             ++n;
         }
         if (n) ma.resize((size_t)bm2h_sort_dedup_patch(opt, 0, 0, 0, (int)ma.size(), ma.data()));
     }
     return n;
+}
+
+// The candidate anchors of mem_sam_pe (bwamem_pair.cpp:371-376): hits within pen_unpaired of the best, at most max_matesw used
+void rescue_anchors(const bm2_sam_opt *so, const std::vector<bm2_alnreg_t> &a, std::vector<bm2_alnreg_t> &b) {
+    b.clear();
+    for (size_t j = 0; j < a.size(); ++j) if (a[j].score >= a[0].score - so->pen_unpaired) b.push_back(a[j]);
+}
+
+// All alignments mate rescue may ask for in one pair, judged on the hit lists as they are BEFORE any rescue.  While the pair is
+// processed the mate's list only grows (each insertion is followed by a de-duplication that keeps the better of two overlapping
+// hits), so a direction skipped here stays skipped and what is planned is, but for freak cases, a superset of what is used.
+void rescue_plan(const bm2_opt *opt, const bm2_sam_opt *so, const Ref &R, const int32_t *ann_len, const PeStat pes[4], int pair,
+                 const int l_seq[2], const std::vector<bm2_alnreg_t> a[2], std::vector<RescueTask> &out) {
+    std::vector<bm2_alnreg_t> b;
+    for (int i = 0; i < 2; ++i) {
+        rescue_anchors(so, a[i], b);
+        for (size_t j = 0; j < b.size() && (int)j < so->max_matesw; ++j) {
+            int skip[4];
+            rescue_skip(R, pes, &b[j], a[!i], skip);
+            for (int r = 0; r < 4; ++r) {
+                if (skip[r]) continue;
+                RescueTask t;
+                if (!rescue_window(opt, R, ann_len, pes, &b[j], l_seq[!i], r, &t.rb, &t.re)) continue;
+                t.pair = pair; t.end = (uint8_t)i; t.r = (uint8_t)r; t.j = (int32_t)j;
+                out.push_back(t);
+            }
+        }
+    }
 }
 
 // mem_pair, bwamem_pair.cpp:285-346
@@ -865,17 +934,20 @@ struct ReadIO { const char *name, *comment, *qual; int l_seq; const uint8_t *seq
 
 // mem_sam_pe, bwamem_pair.cpp:353-551
 bool sam_pe(const bm2_opt *opt, const bm2_sam_opt *so, const Ref &R, const int32_t *ann_len, const PeStat pes[4], uint64_t id,
-            const ReadIO s[2], std::vector<bm2_alnreg_t> a[2], std::string &out) {
+            const ReadIO s[2], std::vector<bm2_alnreg_t> a[2], std::string &out, const RescueTask *pre, int n_pre, RescueStats *st) {
     int z[2] = { 0, 0 }, o, subo, n_sub, extra_flag = 1, n_pri[2];
     Aln h[2];
     if (!(so->flag & F_NO_RESCUE)) {
         std::vector<bm2_alnreg_t> b[2];
+        for (int i = 0; i < 2; ++i) rescue_anchors(so, a[i], b[i]);
+        int t = 0;                                               // pre[] is ordered by (end, j, r), as rescue_plan emits it
         for (int i = 0; i < 2; ++i)
-            for (size_t j = 0; j < a[i].size(); ++j)
-                if (a[i][j].score >= a[i][0].score - so->pen_unpaired) b[i].push_back(a[i][j]);
-        for (int i = 0; i < 2; ++i)
-            for (size_t j = 0; j < b[i].size() && (int)j < so->max_matesw; ++j)
-                matesw(opt, so, R, ann_len, pes, &b[i][j], s[!i].l_seq, s[!i].seq, a[!i]);
+            for (size_t j = 0; j < b[i].size() && (int)j < so->max_matesw; ++j) {
+                while (t < n_pre && (pre[t].end < i || (pre[t].end == i && pre[t].j < (int)j))) ++t;
+                int t1 = t;
+                while (t1 < n_pre && pre[t1].end == i && pre[t1].j == (int)j) ++t1;
+                matesw(opt, so, R, ann_len, pes, &b[i][j], s[!i].l_seq, s[!i].seq, a[!i], pre ? pre + t : nullptr, t1 - t, st);
+            }
     }
     n_pri[0] = mark_primary_se(opt, (int)a[0].size(), a[0].data(), (int64_t)(id << 1 | 0));
     n_pri[1] = mark_primary_se(opt, (int)a[1].size(), a[1].data(), (int64_t)(id << 1 | 1));
@@ -965,6 +1037,15 @@ bool sam_pe(const bm2_opt *opt, const bm2_sam_opt *so, const Ref &R, const int32
     if (!reg2sam(opt, so, R, out, s[1].name, s[1].comment, s[1].qual, s[1].l_seq, s[1].seq, (int)a[1].size(), a[1].data(), 0x81 | extra_flag, &h[0])) return false;
     return true;
 }
+
+template <class F> void run_threads(int n_threads, F f) {
+    if (n_threads <= 1) { f(); return; }
+    std::vector<std::thread> th;
+    for (int t = 0; t < n_threads; ++t) th.emplace_back(f);
+    for (auto &t : th) t.join();
+}
+
+RescueStats g_rescue;               // counters of the last bm2_sam_pe call (diagnostic; bm2_sam_rescue_stats)
 
 // items [0, n) in blocks over n_threads host threads; f(i, out) appends the text of item i; the blocks are joined in order
 template <class F> bool run_blocks(int n, int n_threads, std::string &out, F f) {
@@ -1068,6 +1149,12 @@ extern "C" int bm2_ksw_align2(int32_t n, const uint8_t *seqs, const int64_t *q_o
     return BM2_OK;
 }
 
+extern "C" void bm2_sam_rescue_stats(int64_t *planned, int64_t *used, int64_t *missed) {
+    if (planned) *planned = g_rescue.planned;
+    if (used) *used = g_rescue.used;
+    if (missed) *missed = g_rescue.missed;
+}
+
 extern "C" int bm2_sam_pe(const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt *so, const bm2_reads *reads,
                           const bm2_read_text *txt, const bm2_alnreg_t *alnregs, const int64_t *reg_off, int64_t n_processed,
                           const bm2_pestat *pes_in, bm2_pestat *pes_out, char *out, int64_t cap, int64_t *n_out) {
@@ -1085,15 +1172,55 @@ extern "C" int bm2_sam_pe(const bm2_index_desc *idx, const bm2_opt *opt, const b
     if (pes_out) for (int d = 0; d < 4; ++d) { pes_out[d].low = pes[d].low; pes_out[d].high = pes[d].high; pes_out[d].failed = pes[d].failed; pes_out[d].pad = 0; pes_out[d].avg = pes[d].avg; pes_out[d].std = pes[d].std; }
     for (int i = 0; i < n; i += 2)
         if (strcmp(txt->name[i], txt->name[i + 1]) != 0) { bm2_set_error("paired reads have different names: \"%s\", \"%s\"", txt->name[i], txt->name[i + 1]); return BM2_EINVAL; }
+    // Mate rescue in three steps, the shape a device kernel needs: plan every pair's alignments on the hit lists as they stand,
+    // run them all as one batch (here: host threads over single tasks), then process the pairs with the results at hand.
+    // so->rescue_inline = 1 aligns inside the pair loop as mem_sam_pe does; the output is the same.
+    const int n_pairs = n >> 1;
+    std::vector<RescueTask> tasks;
+    std::vector<int64_t> task_off;
+    const bool batch = !(so->flag & F_NO_RESCUE) && !so->rescue_inline;
+    g_rescue.planned = 0; g_rescue.used = 0; g_rescue.missed = 0;
+    if (batch) {
+        int n_threads = so->n_threads > 0 ? so->n_threads : (int)std::thread::hardware_concurrency();
+        if (n_threads < 1) n_threads = 1;
+        const int blk = 256, n_blk = (n_pairs + blk - 1) / blk;
+        std::vector<std::vector<RescueTask>> part((size_t)n_blk);
+        std::atomic<int> next(0);
+        auto plan = [&]() {
+            for (int b; (b = next.fetch_add(1)) < n_blk;)
+                for (int pi = b * blk; pi < n_pairs && pi < (b + 1) * blk; ++pi) {
+                    const int l_seq[2] = { reads->len[2 * pi], reads->len[2 * pi + 1] };
+                    rescue_plan(opt, so, R, idx->ann_len, pes, pi, l_seq, &regs[(size_t)2 * pi], part[(size_t)b]);
+                }
+        };
+        run_threads(n_threads < n_blk ? n_threads : n_blk, plan);
+        task_off.assign((size_t)n_pairs + 1, 0);
+        for (auto &v : part) { for (auto &t : v) task_off[(size_t)t.pair + 1]++; tasks.insert(tasks.end(), v.begin(), v.end()); }
+        for (int pi = 0; pi < n_pairs; ++pi) task_off[(size_t)pi + 1] += task_off[(size_t)pi];
+        g_rescue.planned = (long long)tasks.size();
+        std::atomic<long long> nt(0);
+        const long long step = 32, tot = (long long)tasks.size();
+        auto align = [&]() {
+            for (long long t0; (t0 = nt.fetch_add(step)) < tot;)
+                for (long long t = t0; t < tot && t < t0 + step; ++t) {
+                    RescueTask &T = tasks[(size_t)t];
+                    const int m = 2 * T.pair + !T.end;           // the mate is the read that is aligned
+                    T.res = rescue_align(opt, R, reads->len[m], reads->enc + reads->off[m], T.r, T.rb, T.re);
+                }
+        };
+        run_threads((long long)n_threads < (tot + step - 1) / step ? n_threads : (int)((tot + step - 1) / step), align);
+    }
     std::string s;
-    const bool ok = run_blocks(n >> 1, so->n_threads, s, [&](int pi, std::string &part) {
+    const bool ok = run_blocks(n_pairs, so->n_threads, s, [&](int pi, std::string &part) {
         const int i = pi << 1;
         ReadIO io[2];
         for (int k = 0; k < 2; ++k) {
             io[k].name = txt->name[i + k]; io[k].comment = txt->comment ? txt->comment[i + k] : 0; io[k].qual = txt->qual ? txt->qual[i + k] : 0;
             io[k].l_seq = reads->len[i + k]; io[k].seq = reads->enc + reads->off[i + k];
         }
-        return sam_pe(opt, so, R, idx->ann_len, pes, (uint64_t)((n_processed >> 1) + pi), io, &regs[(size_t)i], part);
+        const RescueTask *pre = batch ? tasks.data() + task_off[(size_t)pi] : nullptr;
+        const int n_pre = batch ? (int)(task_off[(size_t)pi + 1] - task_off[(size_t)pi]) : 0;
+        return sam_pe(opt, so, R, idx->ann_len, pes, (uint64_t)((n_processed >> 1) + pi), io, &regs[(size_t)i], part, pre, n_pre, batch ? &g_rescue : nullptr);
     });
     if (!ok) { bm2_set_error("bm2_sam_pe: pair %s has a hit whose CIGAR cannot be generated (range outside the reference)", s.c_str()); return BM2_EINVAL; }
     *n_out = (int64_t)s.size();

@@ -173,7 +173,8 @@ typedef struct {                    /* the fields of mem_opt_t (bwamem.h:74-110)
     int32_t max_ins;                /* 10000: pairs further apart are ignored by the insert-size statistics */
     int32_t max_matesw;             /* -m, 50: mate-rescue rounds per end */
     int32_t n_threads;              /* host threads for this tail; 0 = all hardware threads (the text does not depend on it) */
-    int32_t pad;
+    int32_t rescue_inline;          /* 0: the mate-rescue alignments of a chunk are planned up front and run as one batch (the shape the
+                                     * device kernel needs); 1: aligned inside the pair loop as mem_sam_pe does.  Same output. */
     const char *rg_id;              /* bwa_rg_id: RG:Z: value, NULL or "" = none */
 } bm2_sam_opt;
 void bm2_sam_opt_init(bm2_sam_opt *o);                  /* the defaults of mem_opt_init, bwamem.cpp:107-143 */
@@ -189,6 +190,10 @@ typedef struct {                    /* what bseq1_t carries besides the bases (k
  * out/cap: caller's buffer; *n_out = bytes needed (BM2_ECAP if cap is too small: grow and call again with FRESH alnregs). */
 int bm2_sam_se(const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt *so, const bm2_reads *reads, const bm2_read_text *txt,
                bm2_alnreg_t *alnregs, const int64_t *reg_off, int64_t n_processed, char *out, int64_t cap, int64_t *n_out);
+
+/* Counters of the last bm2_sam_pe call on this process (diagnostic, not synchronised between concurrent calls): rescue alignments
+ * planned up front, those the pairs then used, and those a pair asked for that had not been planned (computed in place). */
+void bm2_sam_rescue_stats(int64_t *planned, int64_t *used, int64_t *missed);
 
 /* The local Smith-Waterman of mate rescue for a batch of (query, target) pairs: ksw_align2 (ksw.cpp:340-381) = a forward pass
  * (score, target end, query end, second-best score / its target end outside the best's neighbourhood) and, with KSW_XSTART, a

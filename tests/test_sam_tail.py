@@ -165,6 +165,19 @@ def test_sam_pe_matches_reference_text(tmp_path):
     assert ref == got, _diff(ref, got)
 
 
+def test_sam_pe_rescue_batched_equals_inline(tmp_path):
+    # mate rescue planned up front and run as one batch (the default: the shape the device kernel needs) against the alignments made
+    # inside the pair loop as mem_sam_pe makes them; the plan must cover what the pairs ask for
+    fa, r1, r2 = _pe_case(tmp_path, 57, 2500, sub_rate=0.03, indel_frac=0.3, random_frac=0.05)
+    ref, got, pes = _pe_run(tmp_path, fa, r1, r2, [])
+    planned, used, missed = bm2.sam_rescue_stats()
+    assert ref == got, _diff(ref, got)
+    assert planned > 500 and used <= planned and missed <= planned // 100, (planned, used, missed)
+    ref2, got2, pes2 = _pe_run(tmp_path, fa, r1, r2, [], rescue_inline=1)
+    assert bm2.sam_rescue_stats() == (0, 0, 0)
+    assert got2 == got
+
+
 def test_sam_pe_noisy_mates_and_options(tmp_path):
     # noisy, shorter reads: many mates seed badly or not at all, so the records depend on the rescue SW (score, sub-optimal
     # score, start found by the reverse pass); then the option paths: -a, -Y, -P (no pairing), -U / -m, non-default scoring
