@@ -6,3 +6,14 @@
 // mem_sort_dedup_patch (bwamem.cpp:292-353); query == NULL: no hit merging (mem_patch_reg returns 0, bwamem.cpp:181), the
 // form mem_matesw calls it in (bwamem_pair.cpp:274)
 int bm2h_sort_dedup_patch(const bm2_opt *opt, int64_t l_pac, const uint8_t *ref_string, const uint8_t *query, int n, bm2_alnreg_t *a);
+
+// The batch of mate-rescue alignments of one chunk, flat: query i = qbuf[q_off[i], +q_len[i]) (the mate, already oriented), target i
+// = ref_string[t_pos[i], +t_len[i]), xtra[i] as mem_matesw builds it.  A hook of this type runs the batch (bm2_ksw_align2
+// semantics, out[i] = 7 result fields); 0 = success.  The device kernel plugs in here with ref_string resident in HBM.
+typedef int (*bm2h_ksw_batch_fn)(void *user, int32_t n, const uint8_t *qbuf, int64_t qbuf_bytes, const int64_t *q_off, const int32_t *q_len,
+                                 const int64_t *t_pos, const int32_t *t_len, const int32_t *xtra, const bm2_opt *opt,
+                                 const uint8_t *ref_string, bm2_ksw_result *out);
+// bm2_sam_pe with the rescue batch routed through `fn` (NULL: host threads, one task at a time)
+int bm2h_sam_pe(const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt *so, const bm2_reads *reads, const bm2_read_text *txt,
+                const bm2_alnreg_t *alnregs, const int64_t *reg_off, int64_t n_processed, const bm2_pestat *pes_in, bm2_pestat *pes_out,
+                char *out, int64_t cap, int64_t *n_out, bm2h_ksw_batch_fn fn, void *user);

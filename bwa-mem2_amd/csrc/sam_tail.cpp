@@ -1155,9 +1155,35 @@ extern "C" void bm2_sam_rescue_stats(int64_t *planned, int64_t *used, int64_t *m
     if (missed) *missed = g_rescue.missed;
 }
 
+// the batch hook on the host: the same flat arrays the device kernel takes, aligned by the host kernel (BM2_RESCUE_FLAT=1 routes
+// bm2_sam_pe through it, so that the flattening is tested without a GPU)
+static int host_flat_batch(void *user, int32_t n, const uint8_t *qbuf, int64_t, const int64_t *q_off, const int32_t *q_len, const int64_t *t_pos,
+                           const int32_t *t_len, const int32_t *xtra, const bm2_opt *opt, const uint8_t *ref_string, bm2_ksw_result *out) {
+    const int n_threads = *(const int *)user;
+    std::atomic<int> next(0);
+    run_threads(n_threads, [&]() {
+        for (int i; (i = next.fetch_add(1)) < n;) {
+            const KswResult r = ksw_align2(q_len[i], qbuf + q_off[i], t_len[i], ref_string + t_pos[i], opt->mat, opt->o_del, opt->e_del, opt->o_ins,
+                                           opt->e_ins, xtra[i]);
+            out[i].score = r.score; out[i].te = r.te; out[i].qe = r.qe; out[i].score2 = r.score2; out[i].te2 = r.te2; out[i].tb = r.tb; out[i].qb = r.qb;
+        }
+    });
+    return 0;
+}
+
 extern "C" int bm2_sam_pe(const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt *so, const bm2_reads *reads,
                           const bm2_read_text *txt, const bm2_alnreg_t *alnregs, const int64_t *reg_off, int64_t n_processed,
                           const bm2_pestat *pes_in, bm2_pestat *pes_out, char *out, int64_t cap, int64_t *n_out) {
+    int n_threads = so && so->n_threads > 0 ? so->n_threads : (int)std::thread::hardware_concurrency();
+    if (n_threads < 1) n_threads = 1;
+    const char *flat = getenv("BM2_RESCUE_FLAT");
+    return bm2h_sam_pe(idx, opt, so, reads, txt, alnregs, reg_off, n_processed, pes_in, pes_out, out, cap, n_out,
+                       flat && flat[0] == '1' ? host_flat_batch : nullptr, &n_threads);
+}
+
+int bm2h_sam_pe(const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt *so, const bm2_reads *reads, const bm2_read_text *txt,
+                const bm2_alnreg_t *alnregs, const int64_t *reg_off, int64_t n_processed, const bm2_pestat *pes_in, bm2_pestat *pes_out,
+                char *out, int64_t cap, int64_t *n_out, bm2h_ksw_batch_fn fn, void *user) {
     if (!idx || !opt || !so || !reads || !txt || !txt->name || !reg_off || !n_out || (reads->n_reads & 1) || (!alnregs && reg_off[reads->n_reads] > 0)) {
         bm2_set_error("bm2_sam_pe: bad argument (reads must be interleaved pairs)"); return BM2_EINVAL;
     }
@@ -1198,17 +1224,51 @@ extern "C" int bm2_sam_pe(const bm2_index_desc *idx, const bm2_opt *opt, const b
         for (auto &v : part) { for (auto &t : v) task_off[(size_t)t.pair + 1]++; tasks.insert(tasks.end(), v.begin(), v.end()); }
         for (int pi = 0; pi < n_pairs; ++pi) task_off[(size_t)pi + 1] += task_off[(size_t)pi];
         g_rescue.planned = (long long)tasks.size();
-        std::atomic<long long> nt(0);
-        const long long step = 32, tot = (long long)tasks.size();
-        auto align = [&]() {
-            for (long long t0; (t0 = nt.fetch_add(step)) < tot;)
-                for (long long t = t0; t < tot && t < t0 + step; ++t) {
-                    RescueTask &T = tasks[(size_t)t];
-                    const int m = 2 * T.pair + !T.end;           // the mate is the read that is aligned
-                    T.res = rescue_align(opt, R, reads->len[m], reads->enc + reads->off[m], T.r, T.rb, T.re);
+        const long long tot = (long long)tasks.size();
+        if (fn && tot > 0) {                                     // flat arrays -> one call of the hook
+            if (tot > 0x7fffffff) { bm2_set_error("bm2_sam_pe: too many rescue alignments in one chunk"); return BM2_EINVAL; }
+            std::vector<int64_t> q_off((size_t)tot), t_pos((size_t)tot);
+            std::vector<int32_t> q_len((size_t)tot), t_len((size_t)tot), xtra((size_t)tot);
+            int64_t qb = 0;
+            for (long long t = 0; t < tot; ++t) {
+                const RescueTask &T = tasks[(size_t)t];
+                const int m = 2 * T.pair + !T.end;               // the mate is the read that is aligned
+                q_off[(size_t)t] = qb; q_len[(size_t)t] = reads->len[m]; qb += reads->len[m];
+                t_pos[(size_t)t] = T.rb; t_len[(size_t)t] = (int32_t)(T.re - T.rb); xtra[(size_t)t] = rescue_xtra(opt, reads->len[m]);
+            }
+            std::vector<uint8_t> qbuf((size_t)qb + 1);
+            std::atomic<long long> nq(0);
+            run_threads(n_threads, [&]() {
+                std::vector<uint8_t> q;
+                for (long long t; (t = nq.fetch_add(1)) < tot;) {
+                    const RescueTask &T = tasks[(size_t)t];
+                    const int m = 2 * T.pair + !T.end;
+                    rescue_query(reads->len[m], reads->enc + reads->off[m], T.r, q);
+                    if (!q.empty()) memcpy(qbuf.data() + q_off[(size_t)t], q.data(), q.size());
                 }
-        };
-        run_threads((long long)n_threads < (tot + step - 1) / step ? n_threads : (int)((tot + step - 1) / step), align);
+            });
+            std::vector<bm2_ksw_result> res((size_t)tot);
+            const int rc = fn(user, (int32_t)tot, qbuf.data(), qb, q_off.data(), q_len.data(), t_pos.data(), t_len.data(), xtra.data(), opt,
+                              idx->ref_string, res.data());
+            if (rc) return rc;
+            for (long long t = 0; t < tot; ++t) {
+                const bm2_ksw_result &r = res[(size_t)t];
+                KswResult &o = tasks[(size_t)t].res;
+                o.score = r.score; o.te = r.te; o.qe = r.qe; o.score2 = r.score2; o.te2 = r.te2; o.tb = r.tb; o.qb = r.qb;
+            }
+        } else {
+            std::atomic<long long> nt(0);
+            const long long step = 32;
+            auto align = [&]() {
+                for (long long t0; (t0 = nt.fetch_add(step)) < tot;)
+                    for (long long t = t0; t < tot && t < t0 + step; ++t) {
+                        RescueTask &T = tasks[(size_t)t];
+                        const int m = 2 * T.pair + !T.end;       // the mate is the read that is aligned
+                        T.res = rescue_align(opt, R, reads->len[m], reads->enc + reads->off[m], T.r, T.rb, T.re);
+                    }
+            };
+            run_threads((long long)n_threads < (tot + step - 1) / step ? n_threads : (int)((tot + step - 1) / step), align);
+        }
     }
     std::string s;
     const bool ok = run_blocks(n_pairs, so->n_threads, s, [&](int pi, std::string &part) {

@@ -165,7 +165,7 @@ def test_sam_pe_matches_reference_text(tmp_path):
     assert ref == got, _diff(ref, got)
 
 
-def test_sam_pe_rescue_batched_equals_inline(tmp_path):
+def test_sam_pe_rescue_batched_equals_inline(tmp_path, monkeypatch):
     # mate rescue planned up front and run as one batch (the default: the shape the device kernel needs) against the alignments made
     # inside the pair loop as mem_sam_pe makes them; the plan must cover what the pairs ask for
     fa, r1, r2 = _pe_case(tmp_path, 57, 2500, sub_rate=0.03, indel_frac=0.3, random_frac=0.05)
@@ -176,6 +176,10 @@ def test_sam_pe_rescue_batched_equals_inline(tmp_path):
     ref2, got2, pes2 = _pe_run(tmp_path, fa, r1, r2, [], rescue_inline=1)
     assert bm2.sam_rescue_stats() == (0, 0, 0)
     assert got2 == got
+    # the batch as the flat arrays a device kernel takes (oriented mates in one buffer, targets as positions in ref_string)
+    monkeypatch.setenv("BM2_RESCUE_FLAT", "1")
+    ref3, got3, pes3 = _pe_run(tmp_path, fa, r1, r2, [])
+    assert got3 == got and bm2.sam_rescue_stats() == (planned, used, missed)
 
 
 def test_sam_pe_noisy_mates_and_options(tmp_path):
