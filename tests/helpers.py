@@ -138,3 +138,21 @@ def first_diff(a, b):
 
 ONT2D = dict(a=1, b=1, o_del=1, e_del=1, o_ins=1, e_ins=1, pen_clip5=0, pen_clip3=0, min_seed_len=14, min_chain_weight=20,
              split_factor=10.0)      # `-x ont2d`, fastmap.cpp:812-826
+
+
+def oracle_regs_fn(prefix):
+    """Stand-in for the device stage, built on the CPU oracle: f(enc, off, ln) -> (regs, reg_off) as bm2_seed_chain_extend returns
+    them.  For checking host-side code (the SAM tail, tools/bm2_mem.py) without a GPU."""
+    import bm2
+    from tools import oracle
+    ix = oracle.Index(prefix)
+
+    def f(enc, off, ln):
+        prg = ix.run(enc, off, ln)["REGPRG"]
+        regs = np.zeros(len(prg), bm2.REG_DT)
+        for k in ("rb", "re", "qb", "qe", "rid", "score", "truesc", "w", "seedcov", "seedlen0", "frac_rep"):
+            regs[k] = prg[k]
+        ro = np.zeros(len(ln) + 1, np.int64)
+        np.add.at(ro, prg["read"] + 1, 1)
+        return regs, np.cumsum(ro)
+    return f

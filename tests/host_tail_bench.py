@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Times the host tail (bm2_finish_regs, bm2_sam_se, bm2_sam_pe) on a synthetic paired-end batch whose regs come from the
-CPU oracle (cached under /tmp), so the tail can be tuned without a GPU.  python tools/host_tail_bench.py [pairs] [threads...]"""
+CPU oracle (cached under /tmp), so the tail can be tuned without a GPU.  python tests/host_tail_bench.py [pairs] [threads...]"""
 import os
 import subprocess
 import sys
@@ -8,7 +8,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))          # tests/ -> repo root
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "bwa-mem2_amd"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))

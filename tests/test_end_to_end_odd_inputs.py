@@ -10,8 +10,8 @@ import sys
 import numpy as np
 import pytest
 
-from helpers import ref_binary
-from tools import synth
+from helpers import oracle_regs_fn, ref_binary
+from tools import bm2_mem, synth
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -97,7 +97,7 @@ def test_odd_inputs_fastq_to_sam(tmp_path, seed, paired):
     p = subprocess.run([exe, "mem", "-t", "1", "-K", K, fa] + files, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True)
     ref = b"".join(l for l in p.stdout.splitlines(keepends=True) if not l.startswith(b"@PG"))
     out = str(tmp_path / "o.sam")
-    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "bm2_mem.py"), "--backend", "oracle", "-K", K, "-o", out, fa] + files)
+    bm2_mem.run(fa, files, int(K), out, regs_of=oracle_regs_fn(fa))
     got = open(out, "rb").read()
     if ref != got:
         la, lb = ref.splitlines(), got.splitlines()

@@ -356,6 +356,8 @@ def test_end_to_end_harness_with_the_oracle_backend(tmp_path):
     import os, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = str(tmp_path / "out.sam")
-    subprocess.check_call([sys.executable, os.path.join(root, "tools", "bm2_mem.py"), "--backend", "oracle", "-K", str(K), "-o", out, fa, f1, f2])
+    from helpers import oracle_regs_fn
+    from tools import bm2_mem
+    bm2_mem.run(fa, [f1, f2], K, out, regs_of=oracle_regs_fn(fa))
     got = open(out, "rb").read()
     assert ref == got, _diff(ref, got)

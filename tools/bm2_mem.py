@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
-"""End-to-end harness: FASTQ in, SAM out, through the library -- the device hot path (`--backend gpu`) or, for checking the
-harness itself without a GPU, the CPU oracle in its place (`--backend oracle`; test infrastructure, ~1 k reads/s).
+"""End-to-end harness: FASTQ in, SAM out, through the library: bm2_fastq_parse -> bm2_seed_chain_extend (device; there is no
+CPU path, the script fails without a GPU) -> bm2_finish_regs -> bm2_sam_se / bm2_sam_pe.
 Chunks the input as `bwa-mem2 mem -K` does (whole reads / pairs until the chunk holds >= K bases, fastmap.cpp:943-949,
 bwa.cpp:62-216), so insert-size models, tie-breaking hashes and pair ids match the reference run with the same -K.
 Output = @SQ header lines + alignment lines (no @PG: that line is the caller's command line).
 
-    python tools/bm2_mem.py [-K bases] [--backend gpu|oracle] <idx_prefix> <in1.fq> [in2.fq] > out.sam
-"""
+    python tools/bm2_mem.py [-K bases] <idx_prefix> <in1.fq> [in2.fq] > out.sam
+
+run(..., regs_of=f) lets the tests put a stand-in for the device stage (tests/helpers.py does, to check the harness on a CPU)."""
 import argparse
 import os
 import sys
@@ -30,18 +31,11 @@ def chunks(n_reads, lens, K, paired):
         lo = hi
 
 
-def main(argv=None):
-    ap = argparse.ArgumentParser()
-    ap.add_argument("-K", type=int, default=10000000)
-    ap.add_argument("--backend", choices=("gpu", "oracle"), default="gpu")
-    ap.add_argument("--threads", type=int, default=0, help="host threads of the SAM tail (0 = all)")
-    ap.add_argument("-o", default="-")
-    ap.add_argument("prefix")
-    ap.add_argument("fq", nargs="+")
-    a = ap.parse_args(argv)
+def run(prefix, fq, K=10000000, out_path="-", threads=0, regs_of=None):
+    """regs_of(enc, off, ln) -> (regs REG_DT, reg_off): the device stage; None = a Context on GPU 0."""
     import bm2
-    paired = len(a.fq) == 2
-    parts = [bm2.fastq_parse(open(f, "rb").read()) for f in a.fq]
+    paired = len(fq) == 2
+    parts = [bm2.fastq_parse(open(f, "rb").read()) for f in fq]
     if paired:
         p, q = parts
         if len(p[2]) != len(q[2]):
@@ -55,37 +49,36 @@ def main(argv=None):
         seqs = [e[0][e[1][i]:e[1][i] + e[2][i]] for i in range(len(e[2]))]
         names, quals = e[3], e[5]
     lens = np.array([len(s) for s in seqs], np.int64)
-    opt, so = bm2.default_opt(), bm2.default_sam_opt(n_threads=a.threads)
-    if a.backend == "gpu":
-        ctx = bm2.Context(0, a.prefix)
+    opt, so = bm2.default_opt(), bm2.default_sam_opt(n_threads=threads)
+    if regs_of is None:
+        ctx = bm2.Context(0, prefix)
         regs_of = lambda enc, off, ln: ctx.seed_chain_extend(enc, off, ln, opt)[:2]
-    else:
-        from tools import oracle
-        ix = oracle.Index(a.prefix)
-
-        def regs_of(enc, off, ln):
-            prg = ix.run(enc, off, ln)["REGPRG"]
-            regs = np.zeros(len(prg), bm2.REG_DT)
-            for f in ("rb", "re", "qb", "qe", "rid", "score", "truesc", "w", "seedcov", "seedlen0", "frac_rep"):
-                regs[f] = prg[f]
-            ro = np.zeros(len(ln) + 1, np.int64)
-            np.add.at(ro, prg["read"] + 1, 1)
-            return regs, np.cumsum(ro)
-    out = sys.stdout.buffer if a.o == "-" else open(a.o, "wb")
-    out.write(bm2.sam_header(a.prefix))
-    for lo, hi in chunks(len(seqs), lens, a.K, paired):
+    out = sys.stdout.buffer if out_path == "-" else open(out_path, "wb")
+    out.write(bm2.sam_header(prefix))
+    for lo, hi in chunks(len(seqs), lens, K, paired):
         enc = np.concatenate(seqs[lo:hi]) if hi > lo else np.zeros(0, np.uint8)
         ln = lens[lo:hi].astype(np.int32)
         off = np.concatenate([[0], np.cumsum(ln[:-1])]).astype(np.int64)
         regs, reg_off = regs_of(enc, off, ln)
-        aln, aln_off = bm2.finish_regs(a.prefix, enc, off, ln, opt, regs, reg_off)
+        aln, aln_off = bm2.finish_regs(prefix, enc, off, ln, opt, regs, reg_off)
         if paired:
-            txt, _ = bm2.sam_pe(a.prefix, enc, off, ln, opt, aln, aln_off, names[lo:hi], quals[lo:hi], None, so, n_processed=lo)
+            txt, _ = bm2.sam_pe(prefix, enc, off, ln, opt, aln, aln_off, names[lo:hi], quals[lo:hi], None, so, n_processed=lo)
         else:
-            txt = bm2.sam_se(a.prefix, enc, off, ln, opt, aln, aln_off, names[lo:hi], quals[lo:hi], None, so, n_processed=lo)
+            txt = bm2.sam_se(prefix, enc, off, ln, opt, aln, aln_off, names[lo:hi], quals[lo:hi], None, so, n_processed=lo)
         out.write(txt)
     if out is not sys.stdout.buffer:
         out.close()
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("-K", type=int, default=10000000)
+    ap.add_argument("--threads", type=int, default=0, help="host threads of the SAM tail (0 = all)")
+    ap.add_argument("-o", default="-")
+    ap.add_argument("prefix")
+    ap.add_argument("fq", nargs="+")
+    a = ap.parse_args(argv)
+    run(a.prefix, a.fq, a.K, a.o, a.threads)
 
 
 if __name__ == "__main__":
