@@ -234,11 +234,13 @@ def main():
             "extend_kernel": {"kernel": "k_extend", "gcups": cells / (ext_ms * 1e-3) / 1e9 if ext_ms > 0 else 0.0,
                               "avg_launch_ms": ext_ms, "cells_per_launch": cells},
         }
-        if not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline:             # the reference on this host's cores: at N=1 only (the other ranks would idle)
             t = time.time()
             cb = cpu_baseline(prefix, contigs, a.cpu_pairs, a.read_len, a.workdir, seed + 5)
             log("cpu baseline took %.1fs" % (time.time() - t))
             out["cpu_baseline"] = cb
+        else:
+            out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
     ctx.close()
     dist_util.finish(world)
