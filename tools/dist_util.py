@@ -13,7 +13,8 @@ def env_rank():
 def init(backend, world, device_id=None):
     import torch.distributed as dist
     if world > 1 and not dist.is_initialized():
-        kw = {}
+        import datetime
+        kw = {"timeout": datetime.timedelta(minutes=60)}     # rank 0 may spend minutes building the synthetic index behind a barrier
         if device_id is not None:
             kw["device_id"] = device_id
         dist.init_process_group(backend, **kw)
