@@ -57,8 +57,10 @@ int global_align(int qlen, const uint8_t *query, int tlen, const uint8_t *target
     struct EH { int32_t h, e; };
     const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
     const int n_col = qlen < 2 * w + 1 ? qlen : 2 * w + 1;
-    std::vector<uint8_t> z((size_t)n_col * (size_t)tlen);
-    std::vector<EH> eh((size_t)qlen + 1);
+    static thread_local std::vector<uint8_t> z;                // scratch kept per thread: this runs once or more per output record
+    static thread_local std::vector<EH> eh;
+    if (z.size() < (size_t)n_col * (size_t)tlen) z.resize((size_t)n_col * (size_t)tlen);
+    if (eh.size() < (size_t)qlen + 1) eh.resize((size_t)qlen + 1);
     int i, j, k;
     eh[0].h = 0; eh[0].e = MINUS_INF;
     for (j = 1; j <= qlen && j <= w; ++j) { eh[j].h = -(o_ins + e_ins * j); eh[j].e = MINUS_INF; }
@@ -123,7 +125,8 @@ bool gen_cigar(const int8_t mat[25], int o_del, int e_del, int o_ins, int e_ins,
     if (b < 0) b = 0;
     if (e - b != re - rb) return false;
     const int64_t rlen = re - rb;
-    std::vector<uint8_t> rseq(R.ref_string + rb, R.ref_string + re), q(query, query + l_query);
+    static thread_local std::vector<uint8_t> rseq, q;
+    rseq.assign(R.ref_string + rb, R.ref_string + re); q.assign(query, query + l_query);
     if (rb >= l_pac) {                                          // reverse both: indels end up leftmost on the forward strand
         for (int i = 0; i < l_query >> 1; ++i) { uint8_t t = q[i]; q[i] = q[l_query - 1 - i]; q[l_query - 1 - i] = t; }
         for (int64_t i = 0; i < rlen >> 1; ++i) { uint8_t t = rseq[i]; rseq[i] = rseq[rlen - 1 - i]; rseq[rlen - 1 - i] = t; }
