@@ -17,10 +17,13 @@ CSRC = os.path.join(ROOT, "bwa-mem2_amd", "csrc")
 
 
 def build(tmp, src_name, harness, macro):
-    """The emu build of one device source: `extern __shared__` -> a harness-defined array, then g++ against the fake HIP header."""
+    """One device source + a harness with its own main(), against the fake HIP header."""
+    import sys
+    sys.path.insert(0, EMU)
+    import build_emu
     src = os.path.join(tmp, src_name + ".cpp")
     with open(os.path.join(CSRC, src_name)) as f, open(src, "w") as g:
-        g.write(f.read().replace("extern __shared__", "EMU_EXTERN_SHARED"))
+        g.write(build_emu.rewrite(f.read()))
     exe = os.path.join(tmp, harness.replace(".cpp", ""))
     subprocess.check_call(["g++", "-O1", "-std=c++17", "-pthread", "-w", "-I", os.path.join(EMU, "fakehip"), "-I", CSRC,
                            "-D%s=\"%s\"" % (macro, src), os.path.join(EMU, harness), os.path.join(EMU, "emu_runtime.cpp"), "-o", exe])
@@ -44,3 +47,35 @@ def test_k_bsw_pairs_on_the_emulator(bsw_emu, tmp_path, seed, n, max_len, w):
     got = np.fromfile(of, "<i4").reshape(-1, 6)
     for i, (q, t, h0) in enumerate(tr):
         assert tuple(got[i]) == tuple(oracle.ksw_extend(q, t, opt, w, 5, h0)), (i, len(q), len(t), h0)
+
+
+@pytest.fixture(scope="module")
+def emu_lib(tmp_path_factory):
+    import sys
+    sys.path.insert(0, EMU)
+    import build_emu
+    return build_emu.build(str(tmp_path_factory.mktemp("emulib")))
+
+
+def test_whole_device_pipeline_on_the_emulator(emu_lib, golden_dir):
+    # every kernel of bm2_seed_chain_extend (seeding task kernels with their quad-cooperative Occ loads, SA lookup, chaining, the
+    # lane-per-task extension rounds, the purge) executed by OS threads, against the oracle: 3 reads take about a minute
+    script = r'''
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np, bm2
+bm2.LIB_PATH = %r
+from helpers import load_golden, regs_to_records
+from tools import oracle
+pre, enc, off, ln, d = load_golden(%r, "g20k_l76")
+n = 3
+ln = ln[:n]; off = off[:n]; enc = enc[:int(off[-1] + ln[-1])]
+ctx = bm2.Context(0, pre)
+regs, reg_off, st = ctx.seed_chain_extend(enc, off, ln, bm2.default_opt())
+ix = oracle.Index(pre); exp = ix.run(enc, off, ln); ix.close()
+assert st["n_smem"] == len(exp["SMEM"]) and st["n_sa"] == len(exp["SACOORD"]), st
+assert regs_to_records(regs, reg_off).tobytes() == exp["REGPRG"].tobytes()
+print("ok", len(regs))
+''' % (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "bwa-mem2_amd"), emu_lib, golden_dir)
+    p = subprocess.run(["python", "-c", script], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)   # own process: bm2 binds one library
+    assert p.returncode == 0 and p.stdout.startswith(b"ok"), p.stderr.decode()[-2000:]

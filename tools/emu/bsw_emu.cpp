@@ -4,9 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <string>
-#include BSW_SRC                      /* bsw.hip with `extern __shared__` rewritten to EMU_EXTERN_SHARED */
-
-__attribute__((aligned(16))) int lds[48 * 1024];               // the dynamic LDS of k_bsw_pairs
+#include BSW_SRC                      /* bsw.hip as rewritten by build_emu.rewrite() */
 
 void bm2_set_error(const char *fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fputc('\n', stderr); }
 int bm2_check(hipError_t e, const char *) { return e == hipSuccess ? BM2_OK : BM2_ENODEV; }

@@ -3,7 +3,9 @@
 #include <memory>
 
 thread_local EmuThread emu_t;
+thread_local int emu_site = 0;
 size_t emu_dyn_lds_bytes = 0;
+__attribute__((aligned(64))) char emu_dyn_lds[160 * 1024];
 
 namespace {
 struct Arg { unsigned idx; emu_dim3 bid, bdim, gdim; EmuWave *wave; pthread_barrier_t *bb; const std::function<void()> *body; };
@@ -27,6 +29,7 @@ void emu_run_block(unsigned n_threads, emu_dim3 bid, emu_dim3 bdim, emu_dim3 gdi
         const unsigned lanes = w + 1 < n_waves || n_threads % 64 == 0 ? 64 : n_threads % 64;
         if (lanes != 64) { fprintf(stderr, "emu: block size %u is not a multiple of 64 (partial wavefronts are not modelled)\n", n_threads); abort(); }
         pthread_barrier_init(&waves[w].bar, 0, lanes);
+        pthread_mutex_init(&waves[w].mu, 0);
     }
     pthread_barrier_t bb; pthread_barrier_init(&bb, 0, n_threads);
     std::vector<pthread_t> th(n_threads); std::vector<Arg> args(n_threads);

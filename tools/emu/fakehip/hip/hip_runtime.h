@@ -23,11 +23,24 @@
 #define __forceinline__ inline
 #define __launch_bounds__(...)
 #define __shared__ static                 /* blocks run one at a time: one static copy IS the block's LDS */
-#define EMU_EXTERN_SHARED extern          /* `extern __shared__ T name[]` (rewritten by the emu build) -> defined by the harness */
+
+struct uint2 { unsigned x, y; }; struct uint4 { unsigned x, y, z, w; }; struct int2 { int x, y; }; struct int4 { int x, y, z, w; };
+static inline uint4 make_uint4(unsigned a, unsigned b, unsigned c, unsigned d) { uint4 v = { a, b, c, d }; return v; }
+static inline uint2 make_uint2(unsigned a, unsigned b) { uint2 v = { a, b }; return v; }
+struct ulonglong2 { unsigned long long x, y; };
+static inline ulonglong2 make_ulonglong2(unsigned long long a, unsigned long long b) { ulonglong2 v = { a, b }; return v; }
+static inline int max(int a, int b) { return a > b ? a : b; }
+static inline int min(int a, int b) { return a < b ? a : b; }
+static inline long long max(long long a, long long b) { return a > b ? a : b; }
+static inline long long min(long long a, long long b) { return a < b ? a : b; }
+static inline long max(long a, long b) { return a > b ? a : b; }
+static inline long min(long a, long b) { return a < b ? a : b; }
+static inline unsigned max(unsigned a, unsigned b) { return a > b ? a : b; }
+static inline unsigned min(unsigned a, unsigned b) { return a < b ? a : b; }
 
 struct emu_dim3 { unsigned x, y, z; emu_dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };
 typedef emu_dim3 dim3;
-struct EmuWave { pthread_barrier_t bar; int alive; long long slot[64]; };
+struct EmuWave { pthread_barrier_t bar; pthread_mutex_t mu; long long slot[64]; int site[64]; };
 struct EmuThread { emu_dim3 tid, bid, bdim, gdim; EmuWave *wave; pthread_barrier_t *block_bar; int lane; };
 extern thread_local EmuThread emu_t;
 #define threadIdx (emu_t.tid)
@@ -37,9 +50,17 @@ extern thread_local EmuThread emu_t;
 
 // ---- rendezvous of a wavefront: publish, wait, read, wait ----
 static inline void emu_wsync() { pthread_barrier_wait(&emu_t.wave->bar); }
+extern thread_local int emu_site;         // source line of the primitive being executed (set by the macros below)
 template <class F> static inline auto emu_exchange(long long v, F read) -> decltype(read((const long long *)0)) {
-    emu_t.wave->slot[emu_t.lane] = v; emu_wsync();
-    auto r = read((const long long *)emu_t.wave->slot); emu_wsync();
+    EmuWave *w = emu_t.wave;
+    w->slot[emu_t.lane] = v; w->site[emu_t.lane] = emu_site; emu_wsync();
+    for (int i = 0; i < 64; ++i)
+        if (w->site[i] != emu_site) {         // lanes met at different primitives: the code is not wave-uniform here
+            fprintf(stderr, "emu: lanes %d and %d of a wavefront met at different primitives (source lines %d and %d): a collective is "
+                            "called from divergent lanes\n", emu_t.lane, i, emu_site, w->site[i]);
+            abort();
+        }
+    auto r = read((const long long *)w->slot); emu_wsync();
     return r;
 }
 static inline unsigned long long emu_ballot(bool p) {
@@ -75,19 +96,24 @@ static inline int emu_dpp(int old, int v, int ctrl, int row_mask, int bank_mask,
         return (int)s[src];
     });
 }
-#define __ballot(p) emu_ballot(p)
-#define __shfl(...) emu_shfl(__VA_ARGS__)
-#define __shfl_xor(...) emu_shfl_xor(__VA_ARGS__)
-#define __builtin_amdgcn_readlane(v, l) emu_readlane((int)(v), (int)(l))
-#define __builtin_amdgcn_readfirstlane(v) emu_readfirstlane((int)(v))
-#define __builtin_amdgcn_update_dpp(old, v, ctrl, rm, bm, bc) emu_dpp((int)(old), (int)(v), (ctrl), (rm), (bm), (bc))
-#define __builtin_amdgcn_mov_dpp(v, ctrl, rm, bm, bc) emu_dpp(0, (int)(v), (ctrl), (rm), (bm), (bc))
+#define EMU_AT(expr) (emu_site = __LINE__, (expr))
+#define __ballot(p) EMU_AT(emu_ballot(p))
+#define __shfl(...) EMU_AT(emu_shfl(__VA_ARGS__))
+#define __shfl_xor(...) EMU_AT(emu_shfl_xor(__VA_ARGS__))
+#define __builtin_amdgcn_readlane(v, l) EMU_AT(emu_readlane((int)(v), (int)(l)))
+#define __builtin_amdgcn_readfirstlane(v) EMU_AT(emu_readfirstlane((int)(v)))
+#define __builtin_amdgcn_update_dpp(old, v, ctrl, rm, bm, bc) EMU_AT(emu_dpp((int)(old), (int)(v), (ctrl), (rm), (bm), (bc)))
+#define __builtin_amdgcn_mov_dpp(v, ctrl, rm, bm, bc) EMU_AT(emu_dpp(0, (int)(v), (ctrl), (rm), (bm), (bc)))
 #define __builtin_amdgcn_wave_barrier() emu_wsync()
 #define __builtin_amdgcn_fence(...) std::atomic_thread_fence(std::memory_order_seq_cst)
 #define __builtin_amdgcn_mbcnt_lo(m, c) ((int)(c) + __builtin_popcount((unsigned)(m) & (emu_t.lane >= 32 ? 0xffffffffu : ((1u << emu_t.lane) - 1u))))
 #define __builtin_amdgcn_mbcnt_hi(m, c) ((int)(c) + (emu_t.lane > 32 ? __builtin_popcount((unsigned)(m) & ((1u << (emu_t.lane - 32)) - 1u)) : 0))
 #define __builtin_amdgcn_inverse_ballot_w64(m) ((((unsigned long long)(m)) >> emu_t.lane) & 1ull)
 #define __popcll(x) __builtin_popcountll(x)
+#define __popc(x) __builtin_popcount(x)
+static inline int __clz(int x) { return x ? __builtin_clz((unsigned)x) : 32; }
+#define __any(p) (EMU_AT(emu_ballot(p)) != 0)
+#define __all(p) (EMU_AT(emu_ballot(!(p))) == 0)
 #define __ffsll(x) __builtin_ffsll(x)
 #define __clzll(x) __builtin_clzll(x)
 #define __threadfence() std::atomic_thread_fence(std::memory_order_seq_cst)
@@ -98,6 +124,18 @@ template <class T> static inline T atomicAdd(T *p, T v) { return __atomic_fetch_
 static inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
 template <class T> static inline T atomicOr(T *p, T v) { return __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST); }
 template <class T> static inline T atomicMax(T *p, T v) { T o = __atomic_load_n(p, __ATOMIC_SEQ_CST); while (o < v && !__atomic_compare_exchange_n(p, &o, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) {} return o; }
+
+// A collective that the device code calls from DIVERGENT lanes (smem.hip: wave_alloc -- ballot(1) there means "whoever is here with
+// me") has no fixed set of participants to wait for.  Any grouping of the callers is a legal execution on the GPU, so the emu build
+// routes such functions to a one-lane-at-a-time version: every caller is its own group, serialised per wavefront.
+template <int BATCH, class Pool> static inline int64_t emu_wave_alloc(Pool *wp, unsigned long long *cursor) {
+    pthread_mutex_lock(&emu_t.wave->mu);
+    int64_t id;
+    if (wp->pos < wp->end) { id = wp->pos; wp->pos = id + 1; }
+    else { id = (int64_t)__atomic_fetch_add(cursor, (unsigned long long)BATCH, __ATOMIC_SEQ_CST); wp->pos = id + 1; wp->end = id + BATCH; }
+    pthread_mutex_unlock(&emu_t.wave->mu);
+    return id;
+}
 
 // ---- just enough of the runtime API for the launchers to compile ----
 typedef int hipError_t; typedef void *hipStream_t; typedef void *hipEvent_t;
@@ -114,13 +152,28 @@ static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; 
 static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t = 0) { return hipSuccess; }
 static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 
+static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
+enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2 };
+static inline hipError_t hipStreamCreate(hipStream_t *s) { *s = (hipStream_t)1; return hipSuccess; }
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = (hipStream_t)1; return hipSuccess; }
+static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = (hipEvent_t)1; return hipSuccess; }
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = (hipEvent_t)1; return hipSuccess; }
+static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
+static inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
+struct hipDeviceProp_t { int multiProcessorCount; };
+static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) { p->multiProcessorCount = 2; return hipSuccess; }   // few blocks per launch
+extern char emu_dyn_lds[];                /* dynamic LDS of the running block (160 KB) */
+
 // ---- launch: blocks in sequence, the threads of a block as OS threads ----
 void emu_run_block(unsigned n_threads, emu_dim3 bid, emu_dim3 bdim, emu_dim3 gdim, const std::function<void()> &body);
 extern size_t emu_dyn_lds_bytes;          // what the launch asked for (the harness's definition of the extern array must be that big)
-template <class K, class... A> static inline void emu_launch(K kernel, emu_dim3 grid, emu_dim3 block, size_t lds, hipStream_t, A... args) {
+template <class K, class... A> static inline void emu_launch(const char *name, K kernel, emu_dim3 grid, emu_dim3 block, size_t lds, hipStream_t, A... args) {
     emu_dyn_lds_bytes = lds;
+    if (getenv("EMU_TRACE")) fprintf(stderr, "[emu] %s <<<%u, %u, %zu>>>\n", name, grid.x * grid.y * grid.z, block.x * block.y * block.z, lds);
     const unsigned nt = block.x * block.y * block.z;
     for (unsigned bz = 0; bz < grid.z; ++bz) for (unsigned by = 0; by < grid.y; ++by) for (unsigned bx = 0; bx < grid.x; ++bx)
         emu_run_block(nt, emu_dim3(bx, by, bz), block, grid, [&]() { kernel(args...); });
 }
-#define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) emu_launch(kernel, grid, block, lds, stream, ##__VA_ARGS__)
+#define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) emu_launch(#kernel, kernel, grid, block, lds, stream, ##__VA_ARGS__)
