@@ -174,11 +174,6 @@ extern "C" int bm2_bsw(bm2_ctx *c, bm2_seqpair_t *pairs, const uint8_t *ref, int
     if (!c || !pairs || !p || n < 0 || w < 0 || (n > 0 && (!ref || !qer))) { bm2_set_error("bm2_bsw: bad argument"); return BM2_EINVAL; }
     if (n == 0) return BM2_OK;
     if (p->e_del <= 0 || p->e_ins <= 0) { bm2_set_error("bm2_bsw: gap extension penalties must be > 0"); return BM2_EINVAL; }
-    if (p->e_del != 1 || p->e_ins != 1 || p->zdrop < 1 || p->zdrop > 127) {      // see check_opt in pipeline.hip
-        bm2_set_error("bm2_bsw: gap extension penalties other than 1 or a Z-drop outside [1, 127] are not supported yet "
-                      "(Z-drop rule of the reference's int8/int16 kernels, bandedSWA.cpp:268-281)");
-        return BM2_EUNSUP;
-    }
     int rc = bm2_check(hipSetDevice(c->device), "hipSetDevice");
     if (rc) return rc;
     if ((rc = bm2_reserve(c->b_pairs, (size_t)n * sizeof(bm2_seqpair_t)))) return rc;

@@ -77,6 +77,23 @@ static __device__ __forceinline__ int band_clamp(int w, int qlen, const SwParams
     return w;
 }
 
+// Z-drop test of one row, after its maximum m (column mj) was folded into (maxv, max_i, max_j); di = i - max_i, dj = mj - max_j.
+// Class 32 is ksw_extend2's test (bandedSWA.cpp:210-216).  The int8 / int16 SIMD kernels have their own (ZSCORE8 / ZSCORE16,
+// bandedSWA.cpp:268-281, 309-322): evaluated on EVERY row, also the one that raised the maximum and also for zdrop <= 0, in
+// arithmetic that wraps at the lane width (zdrop itself is truncated: 200 is -56 in an int8 lane), and the diagonal offset is
+// not multiplied by the gap extension penalty.  oracle/bm2_oracle.c: ora_ksw_extend_cls.
+static __device__ __forceinline__ bool zdrop_stop(int cls, bool new_max, int maxv, int m, int di, int dj, int e_del, int e_ins, int zdrop) {
+    if (cls == 32) {
+        if (new_max || zdrop <= 0) return false;
+        return (di > dj ? maxv - m - (di - dj) * e_del : maxv - m - (dj - di) * e_ins) > zdrop;
+    }
+    const int sh = 32 - cls;
+    auto wr = [sh](int x) { return (int)((unsigned)x << sh) >> sh; };              // truncate to a signed cls-bit lane
+    const int ti = wr(di), tj = wr(dj);
+    const int diff = ti > tj ? wr(ti - tj) : wr(tj - ti);
+    return wr(wr(maxv - m) - diff) > wr(zdrop);
+}
+
 // One extension on one wavefront.  All arguments wave-uniform.  RH/RE: this wave's LDS rings (RM = R-1, R a
 // power of two >= 2*w+4).  q/t are read with strides qs/ts (-1 walks a left extension backwards through the
 // read and through ref_string, so no reversed copies are ever materialised, cf. bwamem.cpp:2268-2290).
@@ -87,6 +104,7 @@ static __device__ int bsw_extend_wave(const uint8_t *__restrict__ qp, int qs, in
     const int lane = threadIdx.x & 63;
     const int oe_del = P.o_del + P.e_del, oe_ins = P.o_ins + P.e_ins, e_del = P.e_del, e_ins = P.e_ins;
     const int e1 = h0 > oe_ins ? h0 - oe_ins : 0;                  // first row, bandedSWA.cpp:143-145
+    const int cls = pair_class(tlen, qlen, h0, P.max_sc);
     int beg = 0, end = qlen, maxv = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0;
     int maxEnd = -1;                                               // columns <= maxEnd have been stored in the ring
     int cells = 0;
@@ -144,17 +162,13 @@ static __device__ int bsw_extend_wave(const uint8_t *__restrict__ qp, int qs, in
             gscore = gscore > h1 ? gscore : h1;
         }
         if (m == 0) break;                                          // :206
-        if (m > maxv) {
+        const bool new_max = m > maxv;
+        if (new_max) {
             maxv = m; max_i = i; max_j = mj;
             const int d = mj - i;
             max_off = imax(max_off, d < 0 ? -d : d);
-        } else if (P.zdrop > 0) {                                   // :210-216
-            if (i - max_i > mj - max_j) {
-                if (maxv - m - ((i - max_i) - (mj - max_j)) * e_del > P.zdrop) break;
-            } else {
-                if (maxv - m - ((mj - max_j) - (i - max_i)) * e_ins > P.zdrop) break;
-            }
         }
+        if (zdrop_stop(cls, new_max, maxv, m, i - max_i, mj - max_j, e_del, e_ins, P.zdrop)) break;     // :210-216 / ZSCORE8/16
         const int nb = firstnz >= 0 ? firstnz : end;                // :218-221
         const int jl = imax(lastnz, nb - 1);
         beg = nb;
@@ -188,6 +202,7 @@ static __device__ int bsw_extend_reg(const uint8_t *__restrict__ qp, int qs, int
     const int oe_del = o_del + e_del, oe_ins = uni(P.o_ins) + e_ins;
     const int sc_match = uni(P.mat[0]), sc_mis = uni(P.mat[1]), sc_amb = uni(P.mat[4]);
     const int e1 = h0 > oe_ins ? h0 - oe_ins : 0;
+    const int cls = pair_class(tlen, qlen, h0, uni(P.max_sc));
     const int le = lane * e_ins, le1 = le - e_ins;
     int H[NCH], E[NCH], Q[NCH], X[NCH];
 #pragma unroll
@@ -266,17 +281,13 @@ static __device__ int bsw_extend_reg(const uint8_t *__restrict__ qp, int qs, int
             gscore = gscore > h1 ? gscore : h1;
         }
         if (m == 0) break;
-        if (m > maxv) {
+        const bool new_max = m > maxv;
+        if (new_max) {
             maxv = m; max_i = i; max_j = mj;
             const int d = mj - i;
             max_off = imax(max_off, d < 0 ? -d : d);
-        } else if (zdrop > 0) {
-            if (i - max_i > mj - max_j) {
-                if (maxv - m - ((i - max_i) - (mj - max_j)) * e_del > zdrop) break;
-            } else {
-                if (maxv - m - ((mj - max_j) - (i - max_i)) * e_ins > zdrop) break;
-            }
         }
+        if (zdrop_stop(cls, new_max, maxv, m, i - max_i, mj - max_j, e_del, e_ins, zdrop)) break;
         const int nb = firstnz >= 0 ? firstnz : end;
         const int jl = imax(lastnz, nb - 1);
         beg = nb;

@@ -132,6 +132,7 @@ static __device__ void lane_dp(bool run, int qlen, int tlen, int w, int h0, cons
     const int sc_match = P.mat[0], sc_mis = P.mat[1], sc_amb = P.mat[4];
     // first row, bandedSWA.cpp:143-145
     const int e1 = h0 > oe_ins ? h0 - oe_ins : 0;
+    const int cls = pair_class(tlen, qlen, h0, P.max_sc);        // which of the reference's kernels runs this pair: its Z-drop rule
     const int maxq = __builtin_amdgcn_readlane(wave_scan_max(run ? qlen : 0, 0), 63);
     for (int j = 0; j <= maxq; j++)
         if (run && j <= qlen) EH[j * 64 + lane] = (uint32_t)(j == 0 ? h0 : imax(e1 - (j - 1) * e_ins, 0));
@@ -182,14 +183,13 @@ static __device__ void lane_dp(bool run, int qlen, int tlen, int w, int h0, cons
             if (jfin == qlen) { max_ie = gscore > h1 ? max_ie : i; gscore = gscore > h1 ? gscore : h1; }
             if (m == 0) alive = false;
             else {
-                if (m > maxv) {
+                const bool new_max = m > maxv;
+                if (new_max) {
                     maxv = m; max_i = i; max_j = mj;
                     const int d = mj - i;
                     max_off = imax(max_off, d < 0 ? -d : d);
-                } else if (P.zdrop > 0) {
-                    if (i - max_i > mj - max_j) { if (maxv - m - ((i - max_i) - (mj - max_j)) * e_del > P.zdrop) alive = false; }
-                    else { if (maxv - m - ((mj - max_j) - (i - max_i)) * e_ins > P.zdrop) alive = false; }
                 }
+                if (zdrop_stop(cls, new_max, maxv, m, i - max_i, mj - max_j, e_del, e_ins, P.zdrop)) alive = false;
                 const int nb = fnz >= 0 ? fnz : end;
                 const int jl = imax(lnz, nb - 1);
                 beg = nb;
@@ -210,6 +210,7 @@ static __device__ void lane_dp8(bool run, int qlen, int tlen, int w, int h0, con
     const int o_del = P.o_del, e_del = P.e_del, o_ins = P.o_ins, e_ins = P.e_ins, oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
     const int sc_match = P.mat[0], sc_mis = P.mat[1], sc_amb = P.mat[4];
     const int e1 = h0 > oe_ins ? h0 - oe_ins : 0;                // first row, bandedSWA.cpp:143-145
+    const int cls = pair_class(tlen, qlen, h0, P.max_sc);
     const int maxq = __builtin_amdgcn_readlane(wave_scan_max(run ? qlen : 0, 0), 63);
     for (int jp = 0; jp <= maxq; jp += 2) {
         if (run && jp <= qlen) {
@@ -276,14 +277,13 @@ static __device__ void lane_dp8(bool run, int qlen, int tlen, int w, int h0, con
             if (jfin == qlen) { max_ie = gscore > h1 ? max_ie : i; gscore = gscore > h1 ? gscore : h1; }
             if (m == 0) alive = false;
             else {
-                if (m > maxv) {
+                const bool new_max = m > maxv;
+                if (new_max) {
                     maxv = m; max_i = i; max_j = mj;
                     const int d = mj - i;
                     max_off = imax(max_off, d < 0 ? -d : d);
-                } else if (P.zdrop > 0) {
-                    if (i - max_i > mj - max_j) { if (maxv - m - ((i - max_i) - (mj - max_j)) * e_del > P.zdrop) alive = false; }
-                    else { if (maxv - m - ((mj - max_j) - (i - max_i)) * e_ins > P.zdrop) alive = false; }
                 }
+                if (zdrop_stop(cls, new_max, maxv, m, i - max_i, mj - max_j, e_del, e_ins, P.zdrop)) alive = false;
                 const int nb = fnz >= 0 ? fnz : end;
                 const int jl = imax(lnz, nb - 1);
                 beg = nb;

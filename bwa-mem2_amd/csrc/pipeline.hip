@@ -144,16 +144,6 @@ static int check_opt(const bm2_opt *opt) {
         bm2_set_error("bm2: option out of range (a, w, max_occ, min_seed_len, e_del, e_ins must be > 0)");
         return BM2_EINVAL;
     }
-    // The reference's int8 / int16 SIMD kernels have their own Z-drop test (ZSCORE8 / ZSCORE16, bandedSWA.cpp:268-281, 309-322):
-    // evaluated on every row in wrapping lane arithmetic, with zdrop truncated to the lane width, and without multiplying the
-    // diagonal offset by the gap extension penalty.  It coincides with the scalar test the device kernels implement exactly
-    // when e_del = e_ins = 1 and 0 < zdrop < 128 (pinned by oracle/ against the reference for other settings, tests/
-    // test_oracle_options.py); anything else is refused rather than answered differently from the reference.
-    if (opt->e_del != 1 || opt->e_ins != 1 || opt->zdrop < 1 || opt->zdrop > 127) {
-        bm2_set_error("bm2: gap extension penalties other than 1 (e_del %d, e_ins %d) or a Z-drop outside [1, 127] (%d) are not supported yet: "
-                      "the Z-drop rule of the reference's int8/int16 kernels is not reproduced on the device", opt->e_del, opt->e_ins, opt->zdrop);
-        return BM2_EUNSUP;
-    }
     // the kernels score with (match, mismatch, ambiguous) = (mat[0], mat[1], mat[4]), the structure bwa_fill_scmat builds
     // (bwa.cpp:248-257) and the only one the reference's SIMD kernels implement (bandedSWA.cpp:286-290)
     for (int i = 0; i < 5; i++) for (int j = 0; j < 5; j++) {

@@ -56,6 +56,18 @@ def test_bsw_intractg_band_wrap(gpu_ctx_factory):
     _check(ctx, tr, oracle.default_opt(**kw), bm2.default_opt(**kw), 100, 5)
 
 
+def test_bsw_zdrop_rule_of_each_kernel_class(gpu_ctx_factory):
+    # e_del / e_ins != 1, zdrop <= 0, zdrop >= 128: the int8 / int16 kernels of the reference stop on a different rule than its
+    # scalar kernel (ZSCORE8/16, bandedSWA.cpp:268-281, 309-322); pairs of all three classes, both sides of the 128 / 32768 limits
+    ctx = gpu_ctx_factory()
+    for seed, kw in ((41, dict(e_del=2, e_ins=3, zdrop=30)), (42, dict(zdrop=0)), (43, dict(zdrop=200)), (44, dict(zdrop=-5, e_ins=2)),
+                     (45, dict(a=2, b=8, o_del=12, o_ins=12, e_del=2, e_ins=2, zdrop=200, pen_clip5=10, pen_clip3=10))):
+        tr = random_pairs(seed, 1500, max_len=200, h0_max=150)
+        _check(ctx, tr, oracle.default_opt(**kw), bm2.default_opt(**kw), 100, 5)
+        tr = random_pairs(seed + 100, 40, max_len=1200, h0_max=600)
+        _check(ctx, tr, oracle.default_opt(**kw), bm2.default_opt(**kw), 100, 0)
+
+
 def test_bsw_empty_batch(gpu_ctx_factory):
     ctx = gpu_ctx_factory()
     out = ctx.bsw(np.zeros(0, bm2.SEQPAIR_DT), np.zeros(1, np.uint8), np.zeros(1, np.uint8), 100,

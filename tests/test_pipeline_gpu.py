@@ -94,7 +94,7 @@ def test_fresh_inputs_vs_oracle(gpu_ctx_factory, tmp_path, seed, L, n):
 
 def test_non_default_options_vs_oracle(gpu_ctx_factory, tmp_path):
     fa, (enc, off, ln) = _fresh_case(tmp_path, 9, [120000, 60000], 2500, 150, sub_rate=0.03, indel_frac=0.3)
-    kw = dict(min_seed_len=15, w=30, max_occ=50, zdrop=40, b=3, o_del=4, o_ins=5, e_del=1, e_ins=1, pen_clip5=3, pen_clip3=7,
+    kw = dict(min_seed_len=15, w=30, max_occ=50, zdrop=150, b=3, o_del=4, o_ins=5, e_del=2, e_ins=1, pen_clip5=3, pen_clip3=7,
               max_mem_intv=0, split_width=5, drop_ratio=0.3, max_chain_gap=500)
     ix = oracle.Index(fa)
     try:
@@ -230,13 +230,19 @@ def test_long_reads_fresh_vs_oracle(gpu_ctx_factory, tmp_path):
     _same(exp["REGPRG"], regs_to_records(regs, reg_off), "REGPRG")
 
 
-def test_zdrop_rule_outside_the_pinned_range_is_refused(gpu_ctx_factory, golden_dir):
-    # e_del / e_ins != 1, zdrop <= 0 or > 127: the reference's SIMD kernels use a Z-drop rule the device does not reproduce
-    pre, enc, off, ln, d = load_golden(golden_dir, "g20k_l76")
-    ctx = gpu_ctx_factory(pre)
-    for kw in (dict(e_del=2), dict(e_ins=3), dict(zdrop=0), dict(zdrop=200)):
-        with pytest.raises(bm2.Bm2Error):
-            ctx.seed_chain_extend(enc, off, ln, bm2.default_opt(**kw))
+@pytest.mark.parametrize("kw", [dict(e_del=2, e_ins=3), dict(zdrop=0), dict(zdrop=200),
+                                dict(a=2, b=8, o_del=12, o_ins=12, e_del=2, e_ins=2, zdrop=200, pen_clip5=10, pen_clip3=10)])
+def test_zdrop_rule_of_the_simd_kernels(gpu_ctx_factory, tmp_path, kw):
+    # option sets where the Z-drop test of the reference's int8 / int16 kernels differs from the scalar one (the last = `-A 2`)
+    fa, (enc, off, ln) = _fresh_case(tmp_path, 19, [100000, 40000], 2000, 150, sub_rate=0.03, indel_frac=0.3)
+    ix = oracle.Index(fa)
+    try:
+        exp = ix.run(enc, off, ln, oracle.default_opt(**kw))
+    finally:
+        ix.close()
+    ctx = gpu_ctx_factory(fa)
+    regs, reg_off, st = ctx.seed_chain_extend(enc, off, ln, bm2.default_opt(**kw))
+    _same(exp["REGPRG"], regs_to_records(regs, reg_off), "REGPRG")
 
 
 def test_non_bwa_scoring_matrix_is_refused(gpu_ctx_factory, golden_dir):
