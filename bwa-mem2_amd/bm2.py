@@ -92,7 +92,7 @@ class Stats(C.Structure):
 EXPORTS = ["bm2_index_load", "bm2_index_free", "bm2_opt_init", "bm2_opt_fill_scmat", "bm2_create", "bm2_destroy",
            "bm2_last_error", "bm2_device_count", "bm2_bsw", "bm2_smem", "bm2_sal", "bm2_seed_chain_extend",
            "bm2_batch_upload", "bm2_batch_run", "bm2_batch_stats", "bm2_batch_download", "bm2_batch_kernel_ms",
-           "bm2_batch_fetch", "bm2_finish_regs", "bm2_index_build", "bm2_sam_opt_init", "bm2_sam_se", "bm2_sam_pe", "bm2_fastq_parse", "bm2_fastq_free", "bm2_ksw_align2", "bm2_gen_cigar", "bm2_sam_header", "bm2_sam_rescue_stats"]
+           "bm2_batch_fetch", "bm2_finish_regs", "bm2_index_build", "bm2_sam_opt_init", "bm2_sam_se", "bm2_sam_pe", "bm2_fastq_parse", "bm2_fastq_free", "bm2_ksw_align2", "bm2_ksw_align2_dev", "bm2_sam_pe_dev", "bm2_gen_cigar", "bm2_sam_header", "bm2_sam_rescue_stats"]
 
 _lib = None
 
@@ -307,8 +307,9 @@ class Context:
         return [(names[i].decode(), float(ms[i])) for i in range(n.value)]
 
 
-def ksw_align2(pairs, xtra, opt):
-    """pairs: list of (query codes, target codes); xtra: list of ints -> int32 array [n, 7] (score, te, qe, score2, te2, tb, qb)."""
+def ksw_align2(pairs, xtra, opt, ctx=None):
+    """pairs: list of (query codes, target codes); xtra: list of ints -> int32 array [n, 7] (score, te, qe, score2, te2, tb, qb).
+    ctx = a Context: run the device kernel (bm2_ksw_align2_dev) instead of the host one."""
     n = len(pairs)
     buf, q_off, q_len, t_off, t_len = [], [], [], [], []
     p = 0
@@ -321,6 +322,12 @@ def ksw_align2(pairs, xtra, opt):
     q_len = np.array(q_len, np.int32); t_len = np.array(t_len, np.int32); xt = np.array(xtra, np.int32)
     out = np.zeros((max(n, 1), 7), np.int32)
     L = lib()
+    if ctx is not None:
+        L.bm2_ksw_align2_dev.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64] + [C.c_void_p] * 5 + [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        mat = (C.c_int8 * 25)(*opt.mat)
+        _chk(L.bm2_ksw_align2_dev(ctx.h, n, seqs.ctypes.data, len(seqs), q_off.ctypes.data, q_len.ctypes.data, t_off.ctypes.data, t_len.ctypes.data,
+                                  xt.ctypes.data, C.cast(mat, C.c_void_p), opt.o_del, opt.e_del, opt.o_ins, opt.e_ins, out.ctypes.data), "bm2_ksw_align2_dev")
+        return out[:n]
     L.bm2_ksw_align2.argtypes = [C.c_int32] + [C.c_void_p] * 6 + [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
     mat = (C.c_int8 * 25)(*opt.mat)
     _chk(L.bm2_ksw_align2(n, seqs.ctypes.data, q_off.ctypes.data, q_len.ctypes.data, t_off.ctypes.data, t_len.ctypes.data, xt.ctypes.data,
@@ -421,13 +428,14 @@ def default_sam_opt(**kw):
     return o
 
 
-def sam_pe(index_prefix, enc, off, ln, opt, alnregs, reg_off, names, quals=None, comments=None, sam_opt=None, n_processed=0, pes_in=None):
-    """Paired-end SAM alignment lines (reads interleaved) -> (bytes, [4 PeStat]); pes_in = 4 PeStat to use instead of mem_pestat."""
-    return sam_se(index_prefix, enc, off, ln, opt, alnregs, reg_off, names, quals, comments, sam_opt, n_processed, paired=True, pes_in=pes_in)
+def sam_pe(index_prefix, enc, off, ln, opt, alnregs, reg_off, names, quals=None, comments=None, sam_opt=None, n_processed=0, pes_in=None, ctx=None):
+    """Paired-end SAM alignment lines (reads interleaved) -> (bytes, [4 PeStat]); pes_in = 4 PeStat to use instead of mem_pestat;
+    ctx = a Context created with this index: the mate-rescue alignments run on the device (bm2_sam_pe_dev)."""
+    return sam_se(index_prefix, enc, off, ln, opt, alnregs, reg_off, names, quals, comments, sam_opt, n_processed, paired=True, pes_in=pes_in, ctx=ctx)
 
 
 def sam_se(index_prefix, enc, off, ln, opt, alnregs, reg_off, names, quals=None, comments=None, sam_opt=None, n_processed=0, paired=False,
-           pes_in=None):
+           pes_in=None, ctx=None):
     """Single-end SAM alignment lines (host only, no GPU) from the alnregs of finish_regs -> bytes."""
     L = lib()
     d = IndexDesc()
@@ -455,9 +463,9 @@ def sam_se(index_prefix, enc, off, ln, opt, alnregs, reg_off, names, quals=None,
             buf = C.create_string_buffer(cap)
             if paired:
                 pes = (PeStat * 4)()
-                rc = L.bm2_sam_pe(C.byref(d), C.byref(opt), C.byref(so), C.byref(r), C.byref(t), a.ctypes.data, reg_off.ctypes.data,
-                                  C.c_int64(n_processed), (PeStat * 4)(*pes_in) if pes_in is not None else None, pes, buf, C.c_int64(cap),
-                                  C.byref(need))
+                args = (C.byref(d), C.byref(opt), C.byref(so), C.byref(r), C.byref(t), C.c_void_p(a.ctypes.data), C.c_void_p(reg_off.ctypes.data),
+                        C.c_int64(n_processed), (PeStat * 4)(*pes_in) if pes_in is not None else None, pes, buf, C.c_int64(cap), C.byref(need))
+                rc = L.bm2_sam_pe_dev(C.c_void_p(ctx.h), *args) if ctx is not None else L.bm2_sam_pe(*args)
             else:
                 rc = L.bm2_sam_se(C.byref(d), C.byref(opt), C.byref(so), C.byref(r), C.byref(t), a.ctypes.data, reg_off.ctypes.data,
                                   C.c_int64(n_processed), buf, C.c_int64(cap), C.byref(need))

@@ -1,0 +1,125 @@
+// matesw.hip -- the local Smith-Waterman of mate rescue on the device: ksw_align2 (ksw.cpp:340-381) for a batch of
+// (mate, reference window) pairs, SURVEY.md 8(f) row 1.  The reference runs Farrar's striped kernel on one SSE2 register
+// (ksw_u8: 16 byte lanes, ksw_i16: 8 word lanes) and its results depend on that striping: query position p lives in lane
+// p / slen, the lazy-F pass gives up after 16 rounds, an insertion cannot be followed by a deletion across a segment border,
+// byte lanes saturate.  So the register IS the unit of work here: ONE TASK PER 16-LANE DPP ROW, lane k of the row = SIMD lane k
+// of the reference's register, `_mm_slli_si128(x, 1 lane)` = DPP row_shr:1, `_mm_movemask` tests = a ballot masked to the row;
+// four tasks per wavefront, each with its own control flow (rows diverge; the hardware serialises them).  A lane only ever reads
+// LDS words it wrote itself, so there is no barrier in the DP.  Host oracle: ksw_align2 in sam_tail.cpp (bm2_ksw_align2).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <algorithm>
+#include <numeric>
+#include <vector>
+#include "../../include/bm2.h"
+#include "bm2_ctx.h"
+#include "matesw_dev.h"
+
+__global__ void __launch_bounds__(256)
+k_ksw_align2(const uint8_t *__restrict__ qbase, const uint8_t *__restrict__ tbase, const KswTask *__restrict__ tasks, const int *__restrict__ order, int n, KswPrm prm,
+             int slen_max, bm2_ksw_result *__restrict__ out, unsigned long long *__restrict__ blists) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
+    int8_t *smat = (int8_t *)lds;                                // 32 bytes, then the rows' areas
+    if (threadIdx.x < 25) smat[threadIdx.x] = prm.mat[threadIdx.x];
+    __syncthreads();
+    const int rows = blockDim.x >> 4, row = threadIdx.x >> 4, k = threadIdx.x & 15;
+    const int slot = blockIdx.x * rows + row;
+    if (slot >= n) return;                                       // a whole row leaves; nothing below synchronises across rows
+    const int id = order[slot];
+    const KswTask T = tasks[id];
+    ksw_row_task(qbase, tbase, T, prm, smat, lds + 16 + (size_t)row * 9 * slen_max * 16, slen_max, k, blists + T.b_off, out + id);
+}
+
+#include "host_tail.h"
+
+// Runs n tasks: queries at qbase_host[q_off[i]] (uploaded here), targets at t_off[i] either in the same uploaded buffer
+// (d_tbase == NULL) or in a device-resident array (d_tbase, e.g. the context's ref_string replica).
+static int ksw_batch_run(bm2_ctx *c, int32_t n, const uint8_t *qbuf, int64_t qbuf_bytes, const uint8_t *d_tbase, const int64_t *q_off,
+                         const int32_t *q_len, const int64_t *t_off, const int32_t *t_len, const int32_t *xtra, const int8_t mat[25], int o_del,
+                         int e_del, int o_ins, int e_ins, bm2_ksw_result *out) {
+    if (n == 0) return BM2_OK;
+    int rc = bm2_check(hipSetDevice(c->device), "hipSetDevice");
+    if (rc) return rc;
+    KswPrm prm;
+    int lo = 127, hi = 0;
+    for (int a = 0; a < 25; ++a) { prm.mat[a] = mat[a]; if (mat[a] < lo) lo = mat[a]; if (mat[a] > hi) hi = mat[a]; }
+    prm.o_del = o_del; prm.e_del = e_del; prm.o_ins = o_ins; prm.e_ins = e_ins;
+    prm.shift = (256 - (lo & 0xff)) & 0xff; prm.maxsc = hi;
+    if (hi <= 0) { bm2_set_error("ksw batch: the scoring matrix has no positive entry"); return BM2_EINVAL; }
+    std::vector<KswTask> tasks((size_t)n);
+    std::vector<int> order((size_t)n);
+    int64_t nb = 0;
+    int slen_max = 1;
+    for (int i = 0; i < n; ++i) {
+        if (q_len[i] < 0 || t_len[i] < 0) { bm2_set_error("ksw batch: negative length"); return BM2_EINVAL; }
+        KswTask &T = tasks[(size_t)i];
+        T.q_off = q_off[i]; T.t_off = t_off[i]; T.qlen = q_len[i]; T.tlen = t_len[i]; T.xtra = xtra[i]; T.pad = 0;
+        T.b_off = nb; nb += (t_len[i] + 1) / 2 + 1;
+        const int P = (xtra[i] & KSW_XBYTE) ? 16 : 8;
+        slen_max = std::max(slen_max, (q_len[i] + P - 1) / P);
+    }
+    // rows of a wavefront diverge: neighbours should be alike (same lane width, same segment count, similar target length)
+    std::iota(order.begin(), order.end(), 0);
+    auto key = [&](int i) {
+        const KswTask &T = tasks[(size_t)i];
+        const int P = (T.xtra & KSW_XBYTE) ? 16 : 8;
+        return ((uint64_t)(P == 8) << 62) | ((uint64_t)((T.qlen + P - 1) / P) << 40) | (uint64_t)(uint32_t)T.tlen;
+    };
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return key(a) > key(b); });
+    // rows (tasks) per block: as many as fit 64 KB of LDS, the per-workgroup amount every launch may ask for without further ado
+    int rows = 16;
+    size_t lds = 32 + (size_t)rows * 9 * slen_max * 16 * 2;
+    while (lds > 64 * 1024 && rows > 4) { rows >>= 1; lds = 32 + (size_t)rows * 9 * slen_max * 16 * 2; }
+    if (lds > 64 * 1024) {
+        bm2_set_error("ksw batch: a query of %d stripe segments does not fit the LDS layout (mates longer than 448 bases: use bm2_sam_pe)", slen_max);
+        return BM2_EUNSUP;
+    }
+    DevBuf &b_seq = c->b_ref, &b_task = c->b_qer, &b_out = c->b_pairs, &b_misc = c->b_misc;
+    const size_t task_bytes = (size_t)n * sizeof(KswTask), ord_bytes = (size_t)n * sizeof(int);
+    if ((rc = bm2_reserve(b_seq, (size_t)qbuf_bytes + 64))) return rc;
+    if ((rc = bm2_reserve(b_task, task_bytes + ord_bytes + 64))) return rc;
+    if ((rc = bm2_reserve(b_out, (size_t)n * sizeof(bm2_ksw_result)))) return rc;
+    if ((rc = bm2_reserve(b_misc, (size_t)nb * 8))) return rc;
+    hipStream_t s = c->stream;
+    KswTask *d_task = (KswTask *)b_task.p;
+    int *d_order = (int *)((char *)b_task.p + ((task_bytes + 15) & ~(size_t)15));
+    rc = bm2_check(hipMemcpyAsync(b_seq.p, qbuf, (size_t)qbuf_bytes, hipMemcpyHostToDevice, s), "H2D queries");
+    if (!rc) rc = bm2_check(hipMemcpyAsync(d_task, tasks.data(), task_bytes, hipMemcpyHostToDevice, s), "H2D tasks");
+    if (!rc) rc = bm2_check(hipMemcpyAsync(d_order, order.data(), ord_bytes, hipMemcpyHostToDevice, s), "H2D order");
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_ksw_align2, dim3((n + rows - 1) / rows), dim3(rows * 16), lds, s, (const uint8_t *)b_seq.p,
+                       d_tbase ? d_tbase : (const uint8_t *)b_seq.p, d_task, d_order, n, prm, slen_max, (bm2_ksw_result *)b_out.p,
+                       (unsigned long long *)b_misc.p);
+    rc = bm2_check(hipGetLastError(), "k_ksw_align2 launch");
+    if (!rc) rc = bm2_check(hipMemcpyAsync(out, b_out.p, (size_t)n * sizeof(bm2_ksw_result), hipMemcpyDeviceToHost, s), "D2H results");
+    if (!rc) rc = bm2_check(hipStreamSynchronize(s), "ksw batch sync");
+    return rc;
+}
+
+// Device twin of bm2_ksw_align2 (same arguments after the context, same results).
+extern "C" int bm2_ksw_align2_dev(bm2_ctx *c, int32_t n, const uint8_t *seqs, int64_t seq_bytes, const int64_t *q_off, const int32_t *q_len,
+                                  const int64_t *t_off, const int32_t *t_len, const int32_t *xtra, const int8_t mat[25], int o_del, int e_del,
+                                  int o_ins, int e_ins, bm2_ksw_result *out) {
+    if (!c || n < 0 || (n > 0 && (!seqs || !q_off || !q_len || !t_off || !t_len || !xtra || !mat || !out))) {
+        bm2_set_error("bm2_ksw_align2_dev: bad argument");
+        return BM2_EINVAL;
+    }
+    return ksw_batch_run(c, n, seqs, seq_bytes, nullptr, q_off, q_len, t_off, t_len, xtra, mat, o_del, e_del, o_ins, e_ins, out);
+}
+
+// bm2_sam_pe with the mate-rescue alignments of the chunk on the device: the host plans them, this hook runs them against the
+// context's resident ref_string, the host replays the pairs (sam_tail.cpp: bm2h_sam_pe).
+static int dev_rescue_batch(void *user, int32_t n, const uint8_t *qbuf, int64_t qbuf_bytes, const int64_t *q_off, const int32_t *q_len,
+                            const int64_t *t_pos, const int32_t *t_len, const int32_t *xtra, const bm2_opt *opt, const uint8_t *,
+                            bm2_ksw_result *out) {
+    bm2_ctx *c = (bm2_ctx *)user;
+    return ksw_batch_run(c, n, qbuf, qbuf_bytes, (const uint8_t *)c->d_ref, q_off, q_len, t_pos, t_len, xtra, opt->mat, opt->o_del, opt->e_del,
+                         opt->o_ins, opt->e_ins, out);
+}
+
+extern "C" int bm2_sam_pe_dev(bm2_ctx *c, const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt *so, const bm2_reads *reads,
+                              const bm2_read_text *txt, const bm2_alnreg_t *alnregs, const int64_t *reg_off, int64_t n_processed,
+                              const bm2_pestat *pes_in, bm2_pestat *pes_out, char *out, int64_t cap, int64_t *n_out) {
+    if (!c || !c->has_index || !c->d_ref) { bm2_set_error("bm2_sam_pe_dev: the context holds no index"); return BM2_EINVAL; }
+    return bm2h_sam_pe(idx, opt, so, reads, txt, alnregs, reg_off, n_processed, pes_in, pes_out, out, cap, n_out, dev_rescue_batch, c);
+}

@@ -1,0 +1,147 @@
+// matesw_dev.h -- device code of the mate-rescue SW (see matesw.hip), kept free of anything but per-lane C++ and four
+// cross-lane primitives (row_shr1, row_any, row_xor, row_first), so that tools/emu can run the very same source on the host, one
+// thread per lane with a rendezvous of the row at every cross-lane step (matesw_emu.cpp: one task at a time; the fake hip_runtime.h:
+// the real launcher and bm2_sam_pe_dev), against the host oracle.
+#pragma once
+#include <stdint.h>
+#include "../../include/bm2.h"
+
+#if defined(BM2_EMU) || defined(BM2_EMU_ROW_PRIMS)      /* the includer supplies the four row primitives (tools/emu) */
+#ifndef BM2_DEV
+#define BM2_DEV inline
+#endif
+#else
+#define BM2_DEV __device__ __forceinline__
+static BM2_DEV int row_shr1(int v) {                            // lane k <- lane k-1 of the same 16-lane row, lane 0 <- 0
+    return __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);
+}
+static BM2_DEV bool row_any(bool p) {                           // p on any lane of this row (the row executes this together)
+    const unsigned long long b = __ballot(p);
+    return ((b >> (threadIdx.x & 48)) & 0xffffull) != 0;
+}
+static BM2_DEV int row_xor(int v, int m) { return __shfl_xor(v, m, 16); }
+static BM2_DEV int row_first(int v) { return __shfl(v, 0, 16); }
+#endif
+
+enum { KSW_XBYTE = 0x10000, KSW_XSTOP = 0x20000, KSW_XSUBO = 0x40000, KSW_XSTART = 0x80000 };
+
+struct KswTask { int64_t q_off, t_off, b_off; int32_t qlen, tlen, xtra, pad; };
+struct KswPrm { int8_t mat[25]; int8_t pad[3]; int32_t o_del, e_del, o_ins, e_ins, shift, maxsc; };
+struct KswRes { int score, te, qe, score2, te2; };
+
+static BM2_DEV int imx(int a, int b) { return a > b ? a : b; }
+static BM2_DEV int imn(int a, int b) { return a < b ? a : b; }
+
+// One pass of the striped kernel over one task, executed by the 16 lanes of a row (lanes k >= P idle along).
+//   rev = false: query[0, qlen) against target[0, tlen)
+//   rev = true : the reversed query prefix [0, qe0] against the target whose first te0+1 bases are reversed (ksw.cpp:366-371)
+template <int P>
+static BM2_DEV KswRes ksw_pass(bool rev, const uint8_t *__restrict__ q, int qlen, int qe0, const uint8_t *__restrict__ t, int tlen, int te0,
+                           const KswPrm &prm, const int8_t *smat, int minsc, int endsc, uint16_t *L, int slen_max, int k,
+                           unsigned long long *blist) {
+    constexpr bool U8 = P == 16;
+    const bool on = k < P;
+    const int slen = (qlen + P - 1) / P;
+    const int shift = prm.shift, ed = prm.e_del, ei = prm.e_ins, oe_del = prm.o_del + prm.e_del, oe_ins = prm.o_ins + prm.e_ins;
+    int16_t *prof = (int16_t *)L;                                // [5][slen][16]
+    const int H0 = 5 * slen_max * 16, SZ = slen_max * 16;       // then H0, H1, E, Hmax: [slen][16] each
+    int h0o = H0, h1o = H0 + SZ;
+    const int eo = H0 + 2 * SZ, hmo = H0 + 3 * SZ;
+    for (int j = 0; j < slen; ++j) {                             // ksw_qinit, ksw.cpp:62-109
+        const int pos = j + k * slen;
+        int qc = -1;
+        if (on && pos < qlen) qc = rev ? q[qe0 - pos] : q[pos];
+        for (int a = 0; a < 5; ++a) prof[(a * slen + j) * 16 + k] = (int16_t)((qc < 0 ? 0 : smat[a * 5 + qc]) + (U8 ? shift : 0));
+        L[h0o + j * 16 + k] = 0; L[h1o + j * 16 + k] = 0; L[eo + j * 16 + k] = 0; L[hmo + j * 16 + k] = 0;
+    }
+    int te = -1, gmax = 0, nb = 0, last_sc = 0, last_pos = -2;
+    for (int i = 0; i < tlen; ++i) {
+        const int tb = rev ? (i <= te0 ? t[te0 - i] : t[i]) : t[i];
+        const int16_t *S = prof + tb * slen * 16 + k;
+        int h = row_shr1((int)L[h0o + (slen - 1) * 16 + k]), f = 0, mx = 0;
+        for (int j = 0; j < slen; ++j) {
+            const int s = S[j * 16];
+            if (U8) h = imx(imn(h + s, 255) - shift, 0);                                   // adds_epu8, subs_epu8
+            else h = imx(imn(h + s, 32767), -32768);                                       // adds_epi16
+            const int e = L[eo + j * 16 + k];
+            h = imx(imx(h, e), f);
+            mx = imx(mx, h);
+            L[h1o + j * 16 + k] = (uint16_t)h;
+            L[eo + j * 16 + k] = (uint16_t)imx(imx(e - ed, 0), imx(h - oe_del, 0));
+            f = imx(imx(f - ei, 0), imx(h - oe_ins, 0));
+            h = L[h0o + j * 16 + k];
+        }
+        bool done = false;                                       // lazy F: 16 rounds at most, as in both kernels
+        for (int r = 0; r < 16 && !done; ++r) {
+            f = row_shr1(f);
+            for (int j = 0; j < slen; ++j) {
+                const int hv = imx((int)L[h1o + j * 16 + k], f);
+                L[h1o + j * 16 + k] = (uint16_t)hv;
+                f = imx(f - ei, 0);
+                if (!row_any(on && f > imx(hv - oe_ins, 0))) { done = true; break; }
+            }
+        }
+        if (!on) mx = 0;
+        for (int m = 8; m >= 1; m >>= 1) mx = imx(mx, row_xor(mx, m));
+        const int imax = mx;
+        if (imax >= minsc) {                                     // the list of local maxima for the second-best score, ksw.cpp:179-188
+            if (nb == 0 || last_pos + 1 != i) { ++nb; last_sc = imax; last_pos = i; if (k == 0) blist[nb - 1] = (unsigned long long)imax << 32 | (unsigned)i; }
+            else if (last_sc < imax) { last_sc = imax; last_pos = i; if (k == 0) blist[nb - 1] = (unsigned long long)imax << 32 | (unsigned)i; }
+        }
+        if (imax > gmax) {
+            gmax = imax; te = i;
+            for (int j = 0; j < slen; ++j) L[hmo + j * 16 + k] = L[h1o + j * 16 + k];
+            if (U8 ? (gmax + shift >= 255 || gmax >= endsc) : (gmax >= endsc)) break;
+        }
+        const int sw = h0o; h0o = h1o; h1o = sw;
+    }
+    KswRes r;
+    r.score = U8 ? (gmax + shift < 255 ? gmax : 255) : gmax;
+    r.te = te; r.qe = -1; r.score2 = -1; r.te2 = -1;
+    if (!U8 || r.score != 255) {
+        int bv = -2, bp = 0x7fffffff;
+        if (on) {
+            bv = -1;
+            for (int j = 0; j < slen; ++j) { const int v = L[hmo + j * 16 + k]; if (v > bv) { bv = v; bp = j + k * slen; } }
+        }
+        for (int m = 8; m >= 1; m >>= 1) {                       // largest value, smallest query position among equals
+            const int ov = row_xor(bv, m), op = row_xor(bp, m);
+            if (ov > bv || (ov == bv && op < bp)) { bv = ov; bp = op; }
+        }
+        r.qe = bv < 0 ? -1 : bp;                                 // an empty query has no end
+        if (nb > 0) {
+            int s2 = -1, t2 = -1;
+            if (k == 0) {
+                const int d = (r.score + prm.maxsc - 1) / prm.maxsc, low = te - d, high = te + d;
+                for (int x = 0; x < nb; ++x) {
+                    const unsigned long long v = blist[x];
+                    const int e = (int)(unsigned)v, sc = (int)(v >> 32);
+                    if ((e < low || e > high) && sc > s2) { s2 = sc; t2 = e; }
+                }
+            }
+            r.score2 = row_first(s2); r.te2 = row_first(t2);
+        }
+    }
+    return r;
+}
+
+// One task on the 16 lanes of a row: ksw_align2, ksw.cpp:340-381.  L = this row's LDS area (9 * slen_max * 16 halfwords).
+static BM2_DEV void ksw_row_task(const uint8_t *__restrict__ qbase, const uint8_t *__restrict__ tbase, const KswTask &T, const KswPrm &prm, const int8_t *smat, uint16_t *L,
+                                 int slen_max, int k, unsigned long long *bl, bm2_ksw_result *out) {
+    const uint8_t *q = qbase + T.q_off, *t = tbase + T.t_off;
+    const bool byte = (T.xtra & KSW_XBYTE) != 0;
+    const int minsc = (T.xtra & KSW_XSUBO) ? T.xtra & 0xffff : 0x10000, endsc = (T.xtra & KSW_XSTOP) ? T.xtra & 0xffff : 0x10000;
+    KswRes r = byte ? ksw_pass<16>(false, q, T.qlen, 0, t, T.tlen, 0, prm, smat, minsc, endsc, L, slen_max, k, bl)
+                    : ksw_pass<8>(false, q, T.qlen, 0, t, T.tlen, 0, prm, smat, minsc, endsc, L, slen_max, k, bl);
+    int tb = -1, qb = -1;
+    if ((T.xtra & KSW_XSTART) && !((T.xtra & KSW_XSUBO) && r.score < (T.xtra & 0xffff)) && r.qe >= 0) {
+        const KswRes rr = byte ? ksw_pass<16>(true, q, r.qe + 1, r.qe, t, T.tlen, r.te, prm, smat, 0x10000, r.score, L, slen_max, k, bl)
+                               : ksw_pass<8>(true, q, r.qe + 1, r.qe, t, T.tlen, r.te, prm, smat, 0x10000, r.score, L, slen_max, k, bl);
+        if (r.score == rr.score) { tb = r.te - rr.te; qb = r.qe - rr.qe; }
+    }
+    if (k == 0) {
+        bm2_ksw_result o;
+        o.score = r.score; o.te = r.te; o.qe = r.qe; o.score2 = r.score2; o.te2 = r.te2; o.tb = tb; o.qb = qb;
+        *out = o;
+    }
+}

@@ -204,6 +204,12 @@ typedef struct { int32_t score, te, qe, score2, te2, tb, qb; } bm2_ksw_result;
 int bm2_ksw_align2(int32_t n, const uint8_t *seqs, const int64_t *q_off, const int32_t *q_len, const int64_t *t_off, const int32_t *t_len,
                    const int32_t *xtra, const int8_t mat[25], int o_del, int e_del, int o_ins, int e_ins, bm2_ksw_result *out);
 
+/* The same on the device (matesw.hip: one task per 16-lane row, the lanes of the reference's SSE2 register).  seq_bytes = size of
+ * seqs.  Results identical to bm2_ksw_align2. */
+int bm2_ksw_align2_dev(bm2_ctx *c, int32_t n, const uint8_t *seqs, int64_t seq_bytes, const int64_t *q_off, const int32_t *q_len,
+                       const int64_t *t_off, const int32_t *t_len, const int32_t *xtra, const int8_t mat[25], int o_del, int e_del,
+                       int o_ins, int e_ins, bm2_ksw_result *out);
+
 /* The @SQ lines of bwa_print_sam_hdr (bwa.cpp:523-556): one per contig, "\tAH:*" for ALT contigs; followed by hdr_line (the
  * caller's @RG / extra header lines, may be NULL) and a newline, as the reference prints them.  The @PG line carries the
  * command line and stays with the caller.  *n_out = bytes needed (BM2_ECAP when cap is smaller). */
@@ -240,6 +246,13 @@ typedef struct { int32_t low, high, failed, pad; double avg, std; } bm2_pestat; 
 int bm2_sam_pe(const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt *so, const bm2_reads *reads, const bm2_read_text *txt,
                const bm2_alnreg_t *alnregs, const int64_t *reg_off, int64_t n_processed, const bm2_pestat *pes_in, bm2_pestat *pes_out,
                char *out, int64_t cap, int64_t *n_out);
+
+/* bm2_sam_pe with the chunk's mate-rescue alignments run by the device kernel against the context's resident reference (the
+ * context must have been created with this index).  Same output. */
+int bm2_sam_pe_dev(bm2_ctx *c, const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt *so, const bm2_reads *reads,
+                   const bm2_read_text *txt, const bm2_alnreg_t *alnregs, const int64_t *reg_off, int64_t n_processed,
+                   const bm2_pestat *pes_in, bm2_pestat *pes_out, char *out, int64_t cap, int64_t *n_out);
+
 
 /* ---- the same path split so that a caller can keep inputs resident in HBM and time only the device work */
 int bm2_batch_upload(bm2_ctx *c, const bm2_reads *reads);                 /* H2D (pinned staging) */

@@ -79,3 +79,34 @@ print("ok", len(regs))
 ''' % (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "bwa-mem2_amd"), emu_lib, golden_dir)
     p = subprocess.run(["python", "-c", script], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)   # own process: bm2 binds one library
     assert p.returncode == 0 and p.stdout.startswith(b"ok"), p.stderr.decode()[-2000:]
+
+
+def test_rescue_kernel_and_sam_pe_dev_on_the_emulator(emu_lib, tmp_path):
+    # k_ksw_align2 through its real launcher (task records, size-sorted order, LDS layout, list offsets) and bm2_sam_pe_dev end to end
+    # (the host plans, the emulated device aligns against its reference replica, the host replays): same results as the host kernel,
+    # same SAM text as the all-host path and the compiled reference.  The four row primitives are rendezvous of 16 threads here.
+    script = r'''
+import sys, pathlib
+sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np, bm2
+bm2.LIB_PATH = %r
+from test_ksw_align2 import _pairs, KSW_XBYTE, KSW_XSTART, KSW_XSUBO
+import test_sam_tail as T
+ctx = bm2.Context(0, None)
+for kw in ({}, dict(a=2, b=5, o_del=7, o_ins=8, e_del=2, e_ins=1)):
+    opt = bm2.default_opt(**kw)
+    rng = np.random.default_rng(5)
+    pairs = _pairs(41, 12) + [(rng.integers(0, 4, ql).astype(np.uint8), rng.integers(0, 4, tl).astype(np.uint8)) for ql, tl in ((1, 1), (16, 16), (17, 40), (8, 5), (33, 1))]
+    xtra = [(9 * opt.a) | (KSW_XSUBO if i %% 5 else 0) | (KSW_XSTART if i %% 7 else 0) | (KSW_XBYTE if len(q) * opt.a < 250 and i %% 3 else 0) for i, (q, t) in enumerate(pairs)]
+    assert (bm2.ksw_align2(pairs, xtra, opt) == bm2.ksw_align2(pairs, xtra, opt, ctx=ctx)).all()
+d = pathlib.Path(%r)
+fa, r1, r2 = T._pe_case(d, 61, 40, L=100, sub_rate=0.02, indel_frac=0.2, random_frac=0.05)
+ref, got, pes = T._pe_run(d, fa, r1, r2, [])
+stats = bm2.sam_rescue_stats()
+assert ref == got and stats[0] > 20, stats
+ref2, got2, pes2 = T._pe_run(d, fa, r1, r2, [], ctx=bm2.Context(0, fa))
+assert got2 == got and bm2.sam_rescue_stats() == stats
+print("ok", stats)
+''' % (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "bwa-mem2_amd"), emu_lib, str(tmp_path))
+    p = subprocess.run(["python", "-c", script], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
+    assert p.returncode == 0 and p.stdout.startswith(b"ok"), p.stderr.decode()[-2000:]

@@ -124,7 +124,7 @@ def _pe_case(tmp_path, seed, n_pairs, L=150, **rkw):
     return fa, r1, r2
 
 
-def _pe_run(tmp_path, fa, r1, r2, extra, flag=0, okw=None, **skw):
+def _pe_run(tmp_path, fa, r1, r2, extra, flag=0, okw=None, ctx=None, **skw):
     rng = np.random.default_rng(9)
     reads, quals, names = [], [], []
     for i in range(len(r1)):
@@ -146,7 +146,7 @@ def _pe_run(tmp_path, fa, r1, r2, extra, flag=0, okw=None, **skw):
     opt = bm2.default_opt(**(okw or {}))
     regs, reg_off = _prg_to_regs(exp["REGPRG"], len(ln))
     aln, aln_off = bm2.finish_regs(fa, enc, off, ln, opt, regs, reg_off)
-    got, pes = bm2.sam_pe(fa, enc, off, ln, opt, aln, aln_off, names, quals, None, bm2.default_sam_opt(flag=flag, **skw))
+    got, pes = bm2.sam_pe(fa, enc, off, ln, opt, aln, aln_off, names, quals, None, bm2.default_sam_opt(flag=flag, **skw), ctx=ctx)
     return ref, got, pes
 
 

@@ -1,0 +1,76 @@
+"""Mate-rescue SW on the device (bm2_ksw_align2_dev, matesw.hip) against the host kernel that is pinned to the reference's
+ksw_align2 (tests/test_ksw_align2.py): all seven result fields, byte and word lanes, with / without the start pass and the
+minimum score, degenerate lengths, several scorings."""
+import numpy as np
+import pytest
+
+import bm2
+from test_ksw_align2 import KSW_XBYTE, KSW_XSTART, KSW_XSUBO, _pairs
+
+pytestmark = pytest.mark.gpu
+
+
+def _xtra(pairs, opt, rng):
+    out = []
+    for q, t in pairs:
+        x = 19 * opt.a
+        if rng.random() < 0.9:
+            x |= KSW_XSUBO
+        if rng.random() < 0.9:
+            x |= KSW_XSTART
+        if len(q) * opt.a < 250 and rng.random() < 0.9:
+            x |= KSW_XBYTE
+        out.append(x)
+    return out
+
+
+@pytest.mark.parametrize("kw", [{}, dict(a=2, b=5, o_del=7, o_ins=8, e_del=2, e_ins=1), dict(b=1, o_del=1, o_ins=1)])
+def test_device_ksw_align2_equals_host(gpu_ctx_factory, kw):
+    ctx = gpu_ctx_factory()
+    opt = bm2.default_opt(**kw)
+    rng = np.random.default_rng(11)
+    pairs = _pairs(23 + len(kw), 3000)
+    for ql, tl in ((1, 1), (1, 40), (16, 16), (17, 300), (8, 5), (150, 0), (33, 1)):        # edges of the striping
+        pairs.append((rng.integers(0, 4, ql).astype(np.uint8), rng.integers(0, 4, tl).astype(np.uint8)))
+    xtra = _xtra(pairs, opt, rng)
+    exp = bm2.ksw_align2(pairs, xtra, opt)
+    got = bm2.ksw_align2(pairs, xtra, opt, ctx=ctx)
+    bad = np.nonzero((exp != got).any(axis=1))[0]
+    assert len(bad) == 0, "%d of %d differ; first: task %d (qlen %d, tlen %d, xtra %#x) host %s device %s" % (
+        len(bad), len(pairs), bad[0], len(pairs[bad[0]][0]), len(pairs[bad[0]][1]), xtra[bad[0]], exp[bad[0]].tolist(), got[bad[0]].tolist())
+
+
+def test_device_ksw_align2_paired_end_shape(gpu_ctx_factory):
+    # the shape mate rescue produces: 150 bp mates against ~600 bp windows, most with the mate inside
+    ctx = gpu_ctx_factory()
+    opt = bm2.default_opt()
+    rng = np.random.default_rng(12)
+    pairs = []
+    for i in range(20000):
+        t = rng.integers(0, 4, int(rng.integers(400, 800)), dtype=np.uint8)
+        if i % 4:
+            s = int(rng.integers(0, len(t) - 150))
+            q = t[s:s + 150].copy()
+            m = rng.random(150) < 0.02
+            q[m] = (q[m] + 1) % 4
+        else:
+            q = rng.integers(0, 4, 150, dtype=np.uint8)
+        pairs.append((q, t))
+    xtra = [KSW_XSUBO | KSW_XSTART | KSW_XBYTE | 19] * len(pairs)
+    exp = bm2.ksw_align2(pairs, xtra, opt)
+    got = bm2.ksw_align2(pairs, xtra, opt, ctx=ctx)
+    assert (exp == got).all()
+
+
+def test_sam_pe_with_the_rescue_alignments_on_the_device(gpu_ctx_factory, tmp_path):
+    # bm2_sam_pe_dev: the host plans the chunk's rescue alignments, the device runs them against its resident reference, the host
+    # replays the pairs -- against the text of the compiled reference and against the all-host path
+    import test_sam_tail as T
+    fa, r1, r2 = T._pe_case(tmp_path, 61, 3000, sub_rate=0.02, indel_frac=0.2, random_frac=0.03)
+    ref, got, pes = T._pe_run(tmp_path, fa, r1, r2, [])
+    assert ref == got, T._diff(ref, got)
+    host_stats = bm2.sam_rescue_stats()
+    ctx = gpu_ctx_factory(fa)
+    ref2, got2, pes2 = T._pe_run(tmp_path, fa, r1, r2, [], ctx=ctx)
+    assert got2 == got, T._diff(got, got2)
+    assert bm2.sam_rescue_stats() == host_stats and host_stats[0] > 500

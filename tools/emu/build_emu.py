@@ -32,7 +32,8 @@ def build(out_dir, csrc=None, only=None):
     csrc = csrc or os.path.join(ROOT, "bwa-mem2_amd", "csrc")
     os.makedirs(out_dir, exist_ok=True)
     srcs = []
-    for f in only or HIP:
+    extra = [f for f in ("matesw.hip",) if os.path.exists(os.path.join(csrc, f))]      # kernels that exist only in a patched tree
+    for f in only or HIP + extra:
         dst = os.path.join(out_dir, f.replace(".hip", "_emu.cpp"))
         with open(os.path.join(csrc, f)) as g:
             open(dst, "w").write(rewrite(g.read()))

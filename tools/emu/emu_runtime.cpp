@@ -30,6 +30,7 @@ void emu_run_block(unsigned n_threads, emu_dim3 bid, emu_dim3 bdim, emu_dim3 gdi
         if (lanes != 64) { fprintf(stderr, "emu: block size %u is not a multiple of 64 (partial wavefronts are not modelled)\n", n_threads); abort(); }
         pthread_barrier_init(&waves[w].bar, 0, lanes);
         pthread_mutex_init(&waves[w].mu, 0);
+        for (int r = 0; r < 4; ++r) pthread_barrier_init(&waves[w].rowbar[r], 0, 16);
     }
     pthread_barrier_t bb; pthread_barrier_init(&bb, 0, n_threads);
     std::vector<pthread_t> th(n_threads); std::vector<Arg> args(n_threads);

@@ -40,7 +40,7 @@ static inline unsigned min(unsigned a, unsigned b) { return a < b ? a : b; }
 
 struct emu_dim3 { unsigned x, y, z; emu_dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };
 typedef emu_dim3 dim3;
-struct EmuWave { pthread_barrier_t bar; pthread_mutex_t mu; long long slot[64]; int site[64]; };
+struct EmuWave { pthread_barrier_t bar, rowbar[4]; pthread_mutex_t mu; long long slot[64]; int site[64]; long long rslot[64]; };
 struct EmuThread { emu_dim3 tid, bid, bdim, gdim; EmuWave *wave; pthread_barrier_t *block_bar; int lane; };
 extern thread_local EmuThread emu_t;
 #define threadIdx (emu_t.tid)
@@ -137,6 +137,22 @@ template <int BATCH, class Pool> static inline int64_t emu_wave_alloc(Pool *wp, 
     return id;
 }
 
+// Primitives scoped to a 16-lane DPP row (matesw_dev.h: one task per row, the four rows of a wavefront each in their own control flow --
+// divergent as a wavefront, uniform as a row).  On the GPU they are DPP row_shr / a ballot masked to the row / shuffles of width 16,
+// which only ever involve the lanes of the row that is executing; here they rendezvous the 16 threads of the row.
+#define BM2_EMU_ROW_PRIMS 1
+static inline void emu_rsync() { pthread_barrier_wait(&emu_t.wave->rowbar[emu_t.lane >> 4]); }
+template <class F> static inline int emu_row_exchange(long long v, F read) {
+    EmuWave *w = emu_t.wave;
+    w->rslot[emu_t.lane] = v; emu_rsync();
+    const int r = read((const long long *)(w->rslot + (emu_t.lane & 48)), emu_t.lane & 15); emu_rsync();
+    return r;
+}
+static inline int row_shr1(int v) { return emu_row_exchange(v, [](const long long *s, int k) { return k ? (int)s[k - 1] : 0; }); }
+static inline bool row_any(bool p) { return emu_row_exchange(p, [](const long long *s, int) { int a = 0; for (int i = 0; i < 16; ++i) a |= (int)s[i]; return a; }) != 0; }
+static inline int row_xor(int v, int m) { return emu_row_exchange(v, [m](const long long *s, int k) { return (int)s[(k ^ m) & 15]; }); }
+static inline int row_first(int v) { return emu_row_exchange(v, [](const long long *s, int) { return (int)s[0]; }); }
+
 // ---- just enough of the runtime API for the launchers to compile ----
 typedef int hipError_t; typedef void *hipStream_t; typedef void *hipEvent_t;
 enum { hipSuccess = 0, hipErrorOutOfMemory = 2 };
@@ -162,6 +178,8 @@ static inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e =
 static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
 static inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+static inline hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int) { return hipSuccess; }
 struct hipDeviceProp_t { int multiProcessorCount; };
 static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) { p->multiProcessorCount = 2; return hipSuccess; }   // few blocks per launch
 extern char emu_dyn_lds[];                /* dynamic LDS of the running block (160 KB) */
