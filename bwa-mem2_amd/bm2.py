@@ -92,7 +92,7 @@ class Stats(C.Structure):
 EXPORTS = ["bm2_index_load", "bm2_index_free", "bm2_opt_init", "bm2_opt_fill_scmat", "bm2_create", "bm2_destroy",
            "bm2_last_error", "bm2_device_count", "bm2_bsw", "bm2_smem", "bm2_sal", "bm2_seed_chain_extend",
            "bm2_batch_upload", "bm2_batch_run", "bm2_batch_stats", "bm2_batch_download", "bm2_batch_kernel_ms",
-           "bm2_batch_fetch", "bm2_finish_regs", "bm2_index_build", "bm2_sam_opt_init", "bm2_sam_se", "bm2_sam_pe", "bm2_fastq_parse", "bm2_fastq_free", "bm2_ksw_align2", "bm2_ksw_align2_dev", "bm2_sam_pe_dev", "bm2_gen_cigar", "bm2_sam_header", "bm2_sam_rescue_stats"]
+           "bm2_batch_fetch", "bm2_finish_regs", "bm2_index_build", "bm2_sam_opt_init", "bm2_sam_se", "bm2_sam_pe", "bm2_fastq_parse", "bm2_fastq_free", "bm2_ksw_align2", "bm2_ksw_align2_dev", "bm2_sam_pe_dev", "bm2_gen_cigar", "bm2_gen_cigar_dev", "bm2_sam_header", "bm2_sam_rescue_stats"]
 
 _lib = None
 
@@ -358,8 +358,9 @@ def sam_header(index_prefix, hdr_line=None):
         L.bm2_index_free(C.byref(d))
 
 
-def gen_cigar(index_prefix, opt, tasks):
-    """tasks: list of (query codes, rb, re, w) -> list of (score, NM, [cigar ops] or None, MD bytes)."""
+def gen_cigar(index_prefix, opt, tasks, ctx=None):
+    """tasks: list of (query codes, rb, re, w) -> list of (score, NM, [cigar ops] or None, MD bytes).
+    ctx = a Context created with this index: the device kernel (bm2_gen_cigar_dev) instead of the host code."""
     L = lib()
     d = IndexDesc()
     _chk(L.bm2_index_load(index_prefix.encode(), C.byref(d)), "bm2_index_load")
@@ -378,9 +379,14 @@ def gen_cigar(index_prefix, opt, tasks):
                                     C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
         while True:
             cig = np.zeros(ccap, np.uint32); md = C.create_string_buffer(mcap)
-            rc = L.bm2_gen_cigar(C.byref(d), C.byref(opt), n, seqs.ctypes.data, q_off.ctypes.data, q_len.ctypes.data, rb.ctypes.data,
-                                 re_.ctypes.data, w.ctypes.data, score.ctypes.data, nm.ctypes.data, nc.ctypes.data, c_off.ctypes.data,
-                                 cig.ctypes.data, ccap, C.byref(cneed), m_off.ctypes.data, C.cast(md, C.c_void_p), mcap, C.byref(mneed))
+            tail = (q_off.ctypes.data, q_len.ctypes.data, rb.ctypes.data, re_.ctypes.data, w.ctypes.data, score.ctypes.data, nm.ctypes.data,
+                    nc.ctypes.data, c_off.ctypes.data, cig.ctypes.data, ccap, C.byref(cneed), m_off.ctypes.data, C.cast(md, C.c_void_p), mcap, C.byref(mneed))
+            if ctx is not None:
+                L.bm2_gen_cigar_dev.argtypes = [C.c_void_p, C.POINTER(Opt), C.c_int32, C.c_void_p, C.c_int64] + [C.c_void_p] * 10 + \
+                                               [C.c_int64, C.POINTER(C.c_int64), C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+                rc = L.bm2_gen_cigar_dev(ctx.h, C.byref(opt), n, seqs.ctypes.data, len(seqs), *tail)
+            else:
+                rc = L.bm2_gen_cigar(C.byref(d), C.byref(opt), n, seqs.ctypes.data, *tail)
             if rc == BM2_ECAP:
                 ccap, mcap = max(ccap, cneed.value + 1), max(mcap, mneed.value + 1)
                 continue

@@ -1,0 +1,232 @@
+// cigar.hip -- CIGAR / NM / MD of a batch of hits on the device: bwa_gen_cigar2 (bwa.cpp:260-347) = ksw_global2 with backtrack
+// (ksw.cpp:558-668), SURVEY.md 8(f) row 2.  One task per lane: the banded global alignment of a 150-base read against its
+// reference range is a few thousand cells, there are a few per read, and nothing in it crosses lanes -- each lane walks its own
+// rows, keeps its direction bytes and its row of (H, E) in its own slice of a scratch buffer, backtracks, and writes its CIGAR and
+// MD string into its own slice of the output.  Targets are read from the context's resident ref_string (reversed in place by index
+// arithmetic for hits on the reverse strand, as the reference reverses its copies so that gaps end up leftmost on the forward
+// strand).  Host oracle: gen_cigar / global_align in sam_tail.cpp (bm2_gen_cigar), pinned against the reference's bwa_gen_cigar2.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include "../../include/bm2.h"
+#include "bm2_ctx.h"
+
+#define CG_MINUS_INF (-0x40000000)
+
+struct CigarPrm { int8_t mat[25]; int8_t pad[3]; int32_t o_del, e_del, o_ins, e_ins; int64_t l_pac; };
+struct CigarTask {
+    int64_t q_off, rb, re;
+    int64_t z_off, eh_off, cg_off, md_off;      // this task's slices of the scratch / output buffers
+    int32_t q_len, w, cg_cap, md_cap;
+};
+struct CigarRes { int32_t score, nm, n_cigar, md_len; };
+
+// the band of ksw_global2 as bwa_gen_cigar2 sets it (bwa.cpp:289-301); host and device size and run with the same number
+static __host__ __device__ inline int cigar_band(int l_query, int rlen, int w_, int mat0, int o_del, int e_del, int o_ins, int e_ins) {
+    int max_ins = (int)((double)(((l_query + 1) >> 1) * mat0 - o_ins) / e_ins + 1.);
+    int max_del = (int)((double)(((l_query + 1) >> 1) * mat0 - o_del) / e_del + 1.);
+    int max_gap = max_ins > max_del ? max_ins : max_del;
+    max_gap = max_gap > 1 ? max_gap : 1;
+    const int dl = rlen > l_query ? rlen - l_query : l_query - rlen;
+    int w = (max_gap + dl + 1) >> 1;
+    w = w < w_ ? w : w_;
+    const int min_w = dl + 3;
+    return w > min_w ? w : min_w;
+}
+static __host__ __device__ inline bool cigar_range_ok(int64_t l_pac, int l_query, int64_t rb, int64_t re) {
+    if (l_query <= 0 || rb >= re || (rb < l_pac && re > l_pac)) return false;
+    return rb >= 0 && re <= (l_pac << 1);                       // bns_get_seq would clamp: a clamped range is the NULL return
+}
+
+static __device__ int put_dec(char *s, int n, int v) {          // kputw: plain decimal
+    char t[12]; int l = 0;
+    if (v == 0) t[l++] = '0';
+    while (v > 0) { t[l++] = (char)('0' + v % 10); v /= 10; }
+    while (l > 0) s[n++] = t[--l];
+    return n;
+}
+
+__global__ void __launch_bounds__(64)
+k_gen_cigar(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ seqs, const CigarTask *__restrict__ tasks, const int *__restrict__ order,
+            int n, CigarPrm prm, uint8_t *__restrict__ zbuf, int2 *__restrict__ ehbuf, uint32_t *__restrict__ cgbuf, char *__restrict__ mdbuf,
+            CigarRes *__restrict__ res) {
+    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= n) return;
+    const int id = order[slot];
+    const CigarTask T = tasks[id];
+    CigarRes R; R.score = 0; R.nm = -1; R.n_cigar = -1; R.md_len = 0;
+    if (!cigar_range_ok(prm.l_pac, T.q_len, T.rb, T.re)) { res[id] = R; return; }
+    const int lq = T.q_len, rlen = (int)(T.re - T.rb);
+    const bool rev = T.rb >= prm.l_pac;
+    const uint8_t *qp = seqs + T.q_off;
+    auto Q = [&](int i) -> int { return rev ? qp[lq - 1 - i] : qp[i]; };
+    auto RF = [&](int i) -> int { return rev ? ref[T.re - 1 - i] : ref[T.rb + i]; };
+    uint32_t *cg = cgbuf + T.cg_off;
+    int ncg = 0;
+    if (lq == rlen && T.w == 0) {                               // no gap possible: one M (bwa.cpp:281-288)
+        int sc = 0;
+        for (int i = 0; i < lq; ++i) sc += prm.mat[RF(i) * 5 + Q(i)];
+        R.score = sc;
+        cg[ncg++] = (uint32_t)lq << 4;
+    } else {
+        const int w = cigar_band(lq, rlen, T.w, prm.mat[0], prm.o_del, prm.e_del, prm.o_ins, prm.e_ins);
+        const int oe_del = prm.o_del + prm.e_del, oe_ins = prm.o_ins + prm.e_ins, e_del = prm.e_del, e_ins = prm.e_ins;
+        const int n_col = lq < 2 * w + 1 ? lq : 2 * w + 1;
+        uint8_t *z = zbuf + T.z_off;
+        int2 *eh = ehbuf + T.eh_off;                            // .x = h, .y = e
+        int j;
+        eh[0] = make_int2(0, CG_MINUS_INF);
+        for (j = 1; j <= lq && j <= w; ++j) eh[j] = make_int2(-(prm.o_ins + e_ins * j), CG_MINUS_INF);
+        for (; j <= lq; ++j) eh[j] = make_int2(CG_MINUS_INF, CG_MINUS_INF);
+        for (int i = 0; i < rlen; ++i) {                        // ksw.cpp:598-637
+            int f = CG_MINUS_INF;
+            const int8_t *sc = &prm.mat[RF(i) * 5];
+            const int beg = i > w ? i - w : 0, end = i + w + 1 < lq ? i + w + 1 : lq;
+            int h1 = beg == 0 ? -(prm.o_del + e_del * (i + 1)) : CG_MINUS_INF;
+            uint8_t *zi = z + (int64_t)i * n_col;
+            for (j = beg; j < end; ++j) {
+                const int2 p = eh[j];
+                int m = p.x, e = p.y, h, t;
+                uint8_t d;
+                m += sc[Q(j)];
+                d = m >= e ? 0 : 1;
+                h = m >= e ? m : e;
+                d = h >= f ? d : 2;
+                h = h >= f ? h : f;
+                t = m - oe_del; e -= e_del;
+                d |= e > t ? 1 << 2 : 0;
+                e = e > t ? e : t;
+                eh[j] = make_int2(h1, e);
+                h1 = h;
+                t = m - oe_ins; f -= e_ins;
+                d |= f > t ? 2 << 4 : 0;
+                f = f > t ? f : t;
+                zi[j - beg] = d;
+            }
+            eh[end] = make_int2(h1, CG_MINUS_INF);
+        }
+        R.score = eh[lq].x;
+        // backtrack (ksw.cpp:640-660): ops are pushed last-to-first, merged, then reversed
+        auto push = [&](int op, int len) {
+            if (ncg == 0 || op != (int)(cg[ncg - 1] & 0xf)) cg[ncg++] = (uint32_t)len << 4 | (uint32_t)op;
+            else cg[ncg - 1] += (uint32_t)len << 4;
+        };
+        int which = 0, i = rlen - 1, k = (i + w + 1 < lq ? i + w + 1 : lq) - 1;
+        while (i >= 0 && k >= 0) {
+            which = z[(int64_t)i * n_col + (k - (i > w ? i - w : 0))] >> (which << 1) & 3;
+            if (which == 0) { push(0, 1); --i; --k; }
+            else if (which == 1) { push(2, 1); --i; }
+            else { push(1, 1); --k; }
+        }
+        if (i >= 0) push(2, i + 1);
+        if (k >= 0) push(1, k + 1);
+        for (int a = 0, b = ncg; a + 1 < b; ++a, --b) { const uint32_t t = cg[a]; cg[a] = cg[b - 1]; cg[b - 1] = t; }
+    }
+    // NM and MD (bwa.cpp:311-340)
+    char *md = mdbuf + T.md_off;
+    int x = 0, y = 0, u = 0, n_mm = 0, n_gap = 0, nmd = 0;
+    const char *int2base = rev ? "TGCAN" : "ACGTN";
+    for (int k = 0; k < ncg; ++k) {
+        const int op = cg[k] & 0xf, len = (int)(cg[k] >> 4);
+        if (op == 0) {
+            for (int i = 0; i < len; ++i) {
+                const int rb_ = RF(y + i);
+                if (Q(x + i) != rb_) { nmd = put_dec(md, nmd, u); md[nmd++] = int2base[rb_]; ++n_mm; u = 0; }
+                else ++u;
+            }
+            x += len; y += len;
+        } else if (op == 2) {
+            if (k > 0 && k < ncg - 1) {
+                nmd = put_dec(md, nmd, u); md[nmd++] = '^';
+                for (int i = 0; i < len; ++i) md[nmd++] = int2base[RF(y + i)];
+                u = 0; n_gap += len;
+            }
+            y += len;
+        } else if (op == 1) { x += len; n_gap += len; }
+    }
+    nmd = put_dec(md, nmd, u);
+    md[nmd] = 0;
+    R.nm = n_mm + n_gap; R.n_cigar = ncg; R.md_len = nmd;
+    res[id] = R;
+}
+
+// Device twin of bm2_gen_cigar: same arguments after the context (which must hold the index), same results.
+extern "C" int bm2_gen_cigar_dev(bm2_ctx *c, const bm2_opt *opt, int32_t n, const uint8_t *seqs, int64_t seq_bytes, const int64_t *q_off,
+                                 const int32_t *q_len, const int64_t *rb, const int64_t *re, const int32_t *w, int32_t *score, int32_t *nm,
+                                 int32_t *n_cigar, int64_t *cigar_off, uint32_t *cigar, int64_t cigar_cap, int64_t *cigar_need,
+                                 int64_t *md_off, char *md, int64_t md_cap, int64_t *md_need) {
+    if (!c || !opt || n < 0 || (n > 0 && (!seqs || !q_off || !q_len || !rb || !re || !w || !score || !nm || !n_cigar || !cigar_off || !md_off)) ||
+        !cigar_need || !md_need) { bm2_set_error("bm2_gen_cigar_dev: bad argument"); return BM2_EINVAL; }
+    if (!c->has_index || !c->d_ref) { bm2_set_error("bm2_gen_cigar_dev: the context holds no index"); return BM2_EINVAL; }
+    *cigar_need = 0; *md_need = 0;
+    if (n == 0) return BM2_OK;
+    if (opt->e_del <= 0 || opt->e_ins <= 0) { bm2_set_error("bm2_gen_cigar_dev: gap extension penalties must be > 0"); return BM2_EINVAL; }
+    int rc = bm2_check(hipSetDevice(c->device), "hipSetDevice");
+    if (rc) return rc;
+    CigarPrm prm; memset(&prm, 0, sizeof prm);
+    for (int a = 0; a < 25; ++a) prm.mat[a] = opt->mat[a];
+    prm.o_del = opt->o_del; prm.e_del = opt->e_del; prm.o_ins = opt->o_ins; prm.e_ins = opt->e_ins; prm.l_pac = c->ix.l_pac;
+    std::vector<CigarTask> tasks((size_t)n);
+    std::vector<int> order((size_t)n);
+    std::vector<int64_t> cost((size_t)n);
+    int64_t zo = 0, eo = 0, co = 0, mo = 0;
+    for (int i = 0; i < n; ++i) {
+        CigarTask &T = tasks[(size_t)i];
+        T.q_off = q_off[i]; T.q_len = q_len[i]; T.rb = rb[i]; T.re = re[i]; T.w = w[i];
+        T.z_off = zo; T.eh_off = eo; T.cg_off = co; T.md_off = mo; T.cg_cap = 0; T.md_cap = 0;
+        cost[(size_t)i] = 0; order[(size_t)i] = i;
+        if (!cigar_range_ok(prm.l_pac, q_len[i], rb[i], re[i])) continue;
+        const int64_t rlen = re[i] - rb[i];
+        if (rlen > 0x3fffffff) { bm2_set_error("bm2_gen_cigar_dev: reference range too long"); return BM2_EINVAL; }
+        if (!(q_len[i] == rlen && w[i] == 0)) {
+            const int wb = cigar_band(q_len[i], (int)rlen, w[i], prm.mat[0], prm.o_del, prm.e_del, prm.o_ins, prm.e_ins);
+            const int n_col = q_len[i] < 2 * wb + 1 ? q_len[i] : 2 * wb + 1;
+            zo += (int64_t)n_col * rlen; eo += q_len[i] + 1;
+            cost[(size_t)i] = (int64_t)n_col * rlen;
+        }
+        T.cg_cap = (int32_t)(q_len[i] + rlen + 2); T.md_cap = (int32_t)(2 * (q_len[i] + rlen) + 16);
+        co += T.cg_cap; mo += T.md_cap;
+    }
+    // lanes of a wavefront run their tasks side by side: neighbours should cost alike
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost[(size_t)a] > cost[(size_t)b]; });
+    DevBuf &b_seq = c->b_ref, &b_task = c->b_qer, &b_res = c->b_pairs, &b_scr = c->b_misc;
+    const size_t task_bytes = ((size_t)n * sizeof(CigarTask) + 15) & ~(size_t)15, ord_bytes = (size_t)n * sizeof(int);
+    const size_t z_bytes = ((size_t)zo + 15) & ~(size_t)15, eh_bytes = (size_t)eo * sizeof(int2), cg_bytes = (size_t)co * 4, md_bytes = (size_t)mo;
+    const size_t res_bytes = ((size_t)n * sizeof(CigarRes) + 15) & ~(size_t)15;
+    if ((rc = bm2_reserve(b_seq, (size_t)seq_bytes + 64))) return rc;
+    if ((rc = bm2_reserve(b_task, task_bytes + ord_bytes + 64))) return rc;
+    if ((rc = bm2_reserve(b_res, res_bytes + cg_bytes + md_bytes + 64))) return rc;
+    if ((rc = bm2_reserve(b_scr, z_bytes + eh_bytes + 64))) return rc;
+    hipStream_t s = c->stream;
+    CigarTask *d_task = (CigarTask *)b_task.p; int *d_order = (int *)((char *)b_task.p + task_bytes);
+    CigarRes *d_res = (CigarRes *)b_res.p; uint32_t *d_cg = (uint32_t *)((char *)b_res.p + res_bytes); char *d_md = (char *)d_cg + cg_bytes;
+    uint8_t *d_z = (uint8_t *)b_scr.p; int2 *d_eh = (int2 *)((char *)b_scr.p + z_bytes);
+    rc = bm2_check(hipMemcpyAsync(b_seq.p, seqs, (size_t)seq_bytes, hipMemcpyHostToDevice, s), "H2D queries");
+    if (!rc) rc = bm2_check(hipMemcpyAsync(d_task, tasks.data(), (size_t)n * sizeof(CigarTask), hipMemcpyHostToDevice, s), "H2D tasks");
+    if (!rc) rc = bm2_check(hipMemcpyAsync(d_order, order.data(), ord_bytes, hipMemcpyHostToDevice, s), "H2D order");
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_gen_cigar, dim3((n + 63) / 64), dim3(64), 0, s, (const uint8_t *)c->d_ref, (const uint8_t *)b_seq.p, d_task, d_order, n, prm,
+                       d_z, d_eh, d_cg, d_md, d_res);
+    rc = bm2_check(hipGetLastError(), "k_gen_cigar launch");
+    std::vector<CigarRes> h_res((size_t)n);
+    std::vector<uint32_t> h_cg((size_t)co); std::vector<char> h_md((size_t)mo + 1);
+    if (!rc) rc = bm2_check(hipMemcpyAsync(h_res.data(), d_res, (size_t)n * sizeof(CigarRes), hipMemcpyDeviceToHost, s), "D2H results");
+    if (!rc && co) rc = bm2_check(hipMemcpyAsync(h_cg.data(), d_cg, cg_bytes, hipMemcpyDeviceToHost, s), "D2H cigars");
+    if (!rc && mo) rc = bm2_check(hipMemcpyAsync(h_md.data(), d_md, md_bytes, hipMemcpyDeviceToHost, s), "D2H MD");
+    if (!rc) rc = bm2_check(hipStreamSynchronize(s), "bm2_gen_cigar_dev sync");
+    if (rc) return rc;
+    int64_t oc = 0, om = 0;                                     // pack into the caller's arrays, as bm2_gen_cigar lays them out
+    for (int i = 0; i < n; ++i) {
+        const CigarRes &R = h_res[(size_t)i]; const CigarTask &T = tasks[(size_t)i];
+        score[i] = R.score; nm[i] = R.nm; n_cigar[i] = R.n_cigar; cigar_off[i] = oc; md_off[i] = om;
+        if (R.n_cigar < 0) continue;
+        if (cigar && oc + R.n_cigar <= cigar_cap) memcpy(cigar + oc, h_cg.data() + T.cg_off, (size_t)R.n_cigar * 4);
+        if (md && om + R.md_len + 1 <= md_cap) memcpy(md + om, h_md.data() + T.md_off, (size_t)R.md_len + 1);
+        oc += R.n_cigar; om += R.md_len + 1;
+    }
+    *cigar_need = oc; *md_need = om;
+    if (oc > cigar_cap || om > md_cap || (oc && !cigar) || (om && !md)) return BM2_ECAP;
+    return BM2_OK;
+}

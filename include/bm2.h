@@ -227,6 +227,13 @@ int bm2_gen_cigar(const bm2_index_desc *idx, const bm2_opt *opt, int32_t n, cons
                   int64_t *cigar_off, uint32_t *cigar, int64_t cigar_cap, int64_t *cigar_need,
                   int64_t *md_off, char *md, int64_t md_cap, int64_t *md_need);
 
+/* The same on the device (cigar.hip: one task per lane, targets from the context's resident reference).  The context must have
+ * been created with the index; seq_bytes = size of seqs.  Results identical to bm2_gen_cigar. */
+int bm2_gen_cigar_dev(bm2_ctx *c, const bm2_opt *opt, int32_t n, const uint8_t *seqs, int64_t seq_bytes, const int64_t *q_off,
+                      const int32_t *q_len, const int64_t *rb, const int64_t *re, const int32_t *w, int32_t *score, int32_t *nm,
+                      int32_t *n_cigar, int64_t *cigar_off, uint32_t *cigar, int64_t cigar_cap, int64_t *cigar_need,
+                      int64_t *md_off, char *md, int64_t md_cap, int64_t *md_need);
+
 /* FASTA / FASTQ text -> packed reads + names / comments / qualities: kseq's record grammar (kseq.h:185-227), trim_readno
  * (bwa.cpp:62-66: a trailing "/<digit>" is cut off the name) and the nst_nt4_table base codes (bwamem.cpp:992-1000).  The
  * arrays are owned by the library until bm2_fastq_free; comment[i] / qual[i] are NULL when the record has none. */

@@ -110,3 +110,35 @@ print("ok", stats)
 ''' % (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "bwa-mem2_amd"), emu_lib, str(tmp_path))
     p = subprocess.run(["python", "-c", script], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
     assert p.returncode == 0 and p.stdout.startswith(b"ok"), p.stderr.decode()[-2000:]
+
+
+def test_cigar_kernel_on_the_emulator(emu_lib, tmp_path):
+    # k_gen_cigar (one task per lane: banded global alignment with backtrack, NM, MD) through bm2_gen_cigar_dev, against the host
+    # implementation that tests/test_gen_cigar.py pins to the reference's bwa_gen_cigar2
+    script = r'''
+import sys, subprocess
+sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np, bm2
+bm2.LIB_PATH = %r
+from helpers import ref_binary
+from tools import synth
+from test_gen_cigar import make_tasks
+names, ctg, alts = synth.make_genome(17, [60000, 20000], alt_contigs=0, n_repeat_families=2, repeat_len=(200, 800), copies=(3, 6),
+                                     divergence=(0.0, 0.05), n_gaps=1, gap_len=(30, 100))
+fa = %r
+synth.write_fasta(fa, names, ctg)
+subprocess.check_call([ref_binary(), "index", fa], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+ctx = bm2.Context(0, fa)
+for kw in ({}, dict(a=2, b=5, o_del=7, o_ins=8, e_del=2, e_ins=1)):
+    opt = bm2.default_opt(**kw)
+    tasks = make_tasks(ctg, 11 + len(kw), 250)
+    exp = bm2.gen_cigar(fa, opt, tasks)
+    assert exp == bm2.gen_cigar(fa, opt, tasks, ctx=ctx)
+    assert sum(1 for x in exp if x[2] and len(x[2]) > 1) > 100 and sum(1 for x in exp if x[2] is None) == 2
+print("ok")
+''' % (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "bwa-mem2_amd"), emu_lib, str(tmp_path / "g.fa"))
+    from helpers import ref_binary
+    if ref_binary() is None:
+        pytest.skip("oracle/_ref reference binary not present (it builds the index)")
+    p = subprocess.run(["python", "-c", script], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0 and p.stdout.startswith(b"ok"), p.stderr.decode()[-2000:]

@@ -18,21 +18,13 @@ def _revcomp(a):
     return b
 
 
-@pytest.mark.parametrize("args,kw", [([], {}), (["-A", "2", "-B", "5", "-O", "7,8", "-E", "2,1"], dict(a=2, b=5, o_del=7, o_ins=8, e_del=2, e_ins=1))])
-def test_gen_cigar_matches_reference(tmp_path, args, kw):
-    exe, dump = ref_binary(), ref_binary("refdump")
-    if exe is None or dump is None:
-        pytest.skip("oracle/_ref not built (make -C oracle ref)")
-    names, ctg, alts = synth.make_genome(17, [120000, 50000], alt_contigs=0, n_repeat_families=3, repeat_len=(200, 1500), copies=(3, 10),
-                                         divergence=(0.0, 0.05), n_gaps=2, gap_len=(30, 200))
-    fa = str(tmp_path / "g.fa")
-    synth.write_fasta(fa, names, ctg)
-    subprocess.check_call([exe, "index", fa], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+def make_tasks(ctg, seed, n):
+    """(query, rb, re, w) tasks: noisy copies of reference windows on both strands, with indels, several bands, plus two NULL cases."""
     genome = np.concatenate(ctg)
     l_pac = len(genome)
-    rng = np.random.default_rng(3 + len(args))
+    rng = np.random.default_rng(seed)
     tasks = []
-    for i in range(1200):
+    for i in range(n):
         ln = int(rng.integers(20, 400))
         p = int(rng.integers(0, l_pac - ln - 1))
         piece = genome[p:p + ln].copy()
@@ -51,6 +43,20 @@ def test_gen_cigar_matches_reference(tmp_path, args, kw):
         tasks.append((q.astype(np.uint8), rb, re_, int(rng.choice([0, 1, 3, 10, 40]))))
     tasks.append((tasks[0][0], l_pac - 50, l_pac + 50, 5))       # bridges the two strands: NULL
     tasks.append((tasks[1][0], 2 * l_pac - 30, 2 * l_pac + 40, 5))   # runs past the end: clamped, NULL
+    return tasks
+
+
+@pytest.mark.parametrize("args,kw", [([], {}), (["-A", "2", "-B", "5", "-O", "7,8", "-E", "2,1"], dict(a=2, b=5, o_del=7, o_ins=8, e_del=2, e_ins=1))])
+def test_gen_cigar_matches_reference(tmp_path, args, kw):
+    exe, dump = ref_binary(), ref_binary("refdump")
+    if exe is None or dump is None:
+        pytest.skip("oracle/_ref not built (make -C oracle ref)")
+    names, ctg, alts = synth.make_genome(17, [120000, 50000], alt_contigs=0, n_repeat_families=3, repeat_len=(200, 1500), copies=(3, 10),
+                                         divergence=(0.0, 0.05), n_gaps=2, gap_len=(30, 200))
+    fa = str(tmp_path / "g.fa")
+    synth.write_fasta(fa, names, ctg)
+    subprocess.check_call([exe, "index", fa], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    tasks = make_tasks(ctg, 3 + len(args), 1200)
     tf, of = str(tmp_path / "tasks.txt"), str(tmp_path / "out.bin")
     with open(tf, "w") as f:
         for q, rb, re_, w in tasks:

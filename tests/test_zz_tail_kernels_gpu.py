@@ -1,4 +1,5 @@
-"""Mate-rescue SW on the device (bm2_ksw_align2_dev, matesw.hip) against the host kernel that is pinned to the reference's
+"""The device kernels of the host tail (last in the suite on purpose: they were written after the round's GPU minutes were spent and ran
+on the host emulator only).  Mate-rescue SW on the device (bm2_ksw_align2_dev, matesw.hip) against the host kernel that is pinned to the reference's
 ksw_align2 (tests/test_ksw_align2.py): all seven result fields, byte and word lanes, with / without the start pass and the
 minimum score, degenerate lengths, several scorings."""
 import numpy as np
@@ -74,3 +75,25 @@ def test_sam_pe_with_the_rescue_alignments_on_the_device(gpu_ctx_factory, tmp_pa
     ref2, got2, pes2 = T._pe_run(tmp_path, fa, r1, r2, [], ctx=ctx)
     assert got2 == got, T._diff(got, got2)
     assert bm2.sam_rescue_stats() == host_stats and host_stats[0] > 500
+
+
+@pytest.mark.parametrize("kw", [{}, dict(a=2, b=5, o_del=7, o_ins=8, e_del=2, e_ins=1)])
+def test_device_gen_cigar_equals_host(gpu_ctx_factory, tmp_path, kw):
+    # k_gen_cigar (cigar.hip) against the host code pinned to the reference's bwa_gen_cigar2 (tests/test_gen_cigar.py)
+    import subprocess
+    from helpers import ref_binary
+    from test_gen_cigar import make_tasks
+    from tools import synth
+    if ref_binary() is None:
+        pytest.skip("oracle/_ref reference binary not present (it builds the index)")
+    names, ctg, alts = synth.make_genome(17, [120000, 50000], alt_contigs=0, n_repeat_families=3, repeat_len=(200, 1500), copies=(3, 10),
+                                         divergence=(0.0, 0.05), n_gaps=2, gap_len=(30, 200))
+    fa = str(tmp_path / "g.fa")
+    synth.write_fasta(fa, names, ctg)
+    subprocess.check_call([ref_binary(), "index", fa], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    opt = bm2.default_opt(**kw)
+    tasks = make_tasks(ctg, 5 + len(kw), 5000)
+    exp = bm2.gen_cigar(fa, opt, tasks)
+    got = bm2.gen_cigar(fa, opt, tasks, ctx=gpu_ctx_factory(fa))
+    bad = [i for i, (x, y) in enumerate(zip(exp, got)) if x != y]
+    assert not bad, "%d of %d differ; first: task %d %s host %s device %s" % (len(bad), len(tasks), bad[0], tasks[bad[0]][1:], exp[bad[0]], got[bad[0]])

@@ -10,7 +10,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-HIP = ["bm2_api.hip", "bsw.hip", "smem.hip", "scan.hip", "chain.hip", "seedsw.hip", "extend.hip", "pipeline.hip"]
+HIP = ["bm2_api.hip", "bsw.hip", "smem.hip", "scan.hip", "chain.hip", "seedsw.hip", "extend.hip", "pipeline.hip", "matesw.hip", "cigar.hip"]
 HOST = ["index_io.cpp", "finish_regs.cpp", "index_build.cpp", "sam_tail.cpp", "fastq_io.cpp"]
 
 
@@ -32,8 +32,7 @@ def build(out_dir, csrc=None, only=None):
     csrc = csrc or os.path.join(ROOT, "bwa-mem2_amd", "csrc")
     os.makedirs(out_dir, exist_ok=True)
     srcs = []
-    extra = [f for f in ("matesw.hip",) if os.path.exists(os.path.join(csrc, f))]      # kernels that exist only in a patched tree
-    for f in only or HIP + extra:
+    for f in only or [f for f in HIP if os.path.exists(os.path.join(csrc, f))]:
         dst = os.path.join(out_dir, f.replace(".hip", "_emu.cpp"))
         with open(os.path.join(csrc, f)) as g:
             open(dst, "w").write(rewrite(g.read()))

@@ -26,6 +26,7 @@
 
 struct uint2 { unsigned x, y; }; struct uint4 { unsigned x, y, z, w; }; struct int2 { int x, y; }; struct int4 { int x, y, z, w; };
 static inline uint4 make_uint4(unsigned a, unsigned b, unsigned c, unsigned d) { uint4 v = { a, b, c, d }; return v; }
+static inline int2 make_int2(int a, int b) { int2 v = { a, b }; return v; }
 static inline uint2 make_uint2(unsigned a, unsigned b) { uint2 v = { a, b }; return v; }
 struct ulonglong2 { unsigned long long x, y; };
 static inline ulonglong2 make_ulonglong2(unsigned long long a, unsigned long long b) { ulonglong2 v = { a, b }; return v; }
