@@ -92,7 +92,7 @@ class Stats(C.Structure):
 EXPORTS = ["bm2_index_load", "bm2_index_free", "bm2_opt_init", "bm2_opt_fill_scmat", "bm2_create", "bm2_destroy",
            "bm2_last_error", "bm2_device_count", "bm2_bsw", "bm2_smem", "bm2_sal", "bm2_seed_chain_extend",
            "bm2_batch_upload", "bm2_batch_run", "bm2_batch_stats", "bm2_batch_download", "bm2_batch_kernel_ms",
-           "bm2_batch_fetch", "bm2_finish_regs", "bm2_index_build", "bm2_sam_opt_init", "bm2_sam_se", "bm2_sam_pe", "bm2_fastq_parse", "bm2_fastq_free", "bm2_ksw_align2", "bm2_ksw_align2_dev", "bm2_sam_pe_dev", "bm2_gen_cigar", "bm2_gen_cigar_dev", "bm2_sam_header", "bm2_sam_rescue_stats"]
+           "bm2_batch_fetch", "bm2_finish_regs", "bm2_index_build", "bm2_sam_opt_init", "bm2_sam_se", "bm2_sam_pe", "bm2_fastq_parse", "bm2_fastq_free", "bm2_ksw_align2", "bm2_ksw_align2_dev", "bm2_sam_pe_dev", "bm2_sam_se_dev", "bm2_sam_cigar_stats", "bm2_gen_cigar", "bm2_gen_cigar_dev", "bm2_sam_header", "bm2_sam_rescue_stats"]
 
 _lib = None
 
@@ -335,6 +335,13 @@ def ksw_align2(pairs, xtra, opt, ctx=None):
     return out[:n]
 
 
+def sam_cigar_stats():
+    """(planned, used, missed) CIGAR alignments of the last sam_se / sam_pe call that ran them as a batch."""
+    v = [C.c_int64(0) for _ in range(3)]
+    lib().bm2_sam_cigar_stats(*[C.byref(x) for x in v])
+    return tuple(x.value for x in v)
+
+
 def sam_rescue_stats():
     """(planned, used, missed) mate-rescue alignments of the last sam_pe call."""
     v = [C.c_int64(0) for _ in range(3)]
@@ -473,8 +480,9 @@ def sam_se(index_prefix, enc, off, ln, opt, alnregs, reg_off, names, quals=None,
                         C.c_int64(n_processed), (PeStat * 4)(*pes_in) if pes_in is not None else None, pes, buf, C.c_int64(cap), C.byref(need))
                 rc = L.bm2_sam_pe_dev(C.c_void_p(ctx.h), *args) if ctx is not None else L.bm2_sam_pe(*args)
             else:
-                rc = L.bm2_sam_se(C.byref(d), C.byref(opt), C.byref(so), C.byref(r), C.byref(t), a.ctypes.data, reg_off.ctypes.data,
-                                  C.c_int64(n_processed), buf, C.c_int64(cap), C.byref(need))
+                args = (C.byref(d), C.byref(opt), C.byref(so), C.byref(r), C.byref(t), C.c_void_p(a.ctypes.data), C.c_void_p(reg_off.ctypes.data),
+                        C.c_int64(n_processed), buf, C.c_int64(cap), C.byref(need))
+                rc = L.bm2_sam_se_dev(C.c_void_p(ctx.h), *args) if ctx is not None else L.bm2_sam_se(*args)
             if rc == BM2_ECAP:
                 cap = need.value + 16
                 continue

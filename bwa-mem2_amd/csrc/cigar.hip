@@ -12,6 +12,7 @@
 #include <vector>
 #include "../../include/bm2.h"
 #include "bm2_ctx.h"
+#include "host_tail.h"
 
 #define CG_MINUS_INF (-0x40000000)
 
@@ -229,4 +230,21 @@ extern "C" int bm2_gen_cigar_dev(bm2_ctx *c, const bm2_opt *opt, int32_t n, cons
     *cigar_need = oc; *md_need = om;
     if (oc > cigar_cap || om > md_cap || (oc && !cigar) || (om && !md)) return BM2_ECAP;
     return BM2_OK;
+}
+
+// The CIGAR batch of a SAM chunk on the device (hook of bm2h_sam_pe / bm2h_sam_se: user = the context).  The capacities are upper
+// bounds computed by the caller, so this cannot come back with BM2_ECAP.
+int bm2_dev_cigar_batch(void *user, const bm2_opt *opt, int32_t n, const uint8_t *seqs, int64_t seq_bytes, const int64_t *q_off, const int32_t *q_len,
+                        const int64_t *rb, const int64_t *re, const int32_t *w, int32_t *score, int32_t *nm, int32_t *n_cigar, int64_t *cigar_off,
+                        uint32_t *cigar, int64_t cigar_cap, int64_t *md_off, char *md, int64_t md_cap) {
+    int64_t cn = 0, mn = 0;
+    return bm2_gen_cigar_dev((bm2_ctx *)user, opt, n, seqs, seq_bytes, q_off, q_len, rb, re, w, score, nm, n_cigar, cigar_off, cigar, cigar_cap, &cn,
+                             md_off, md, md_cap, &mn);
+}
+
+extern "C" int bm2_sam_se_dev(bm2_ctx *c, const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt *so, const bm2_reads *reads,
+                              const bm2_read_text *txt, bm2_alnreg_t *alnregs, const int64_t *reg_off, int64_t n_processed, char *out,
+                              int64_t cap, int64_t *n_out) {
+    if (!c || !c->has_index || !c->d_ref) { bm2_set_error("bm2_sam_se_dev: the context holds no index"); return BM2_EINVAL; }
+    return bm2h_sam_se(idx, opt, so, reads, txt, alnregs, reg_off, n_processed, out, cap, n_out, bm2_dev_cigar_batch, c);
 }

@@ -107,7 +107,11 @@ extern "C" int bm2_ksw_align2_dev(bm2_ctx *c, int32_t n, const uint8_t *seqs, in
     return ksw_batch_run(c, n, seqs, seq_bytes, nullptr, q_off, q_len, t_off, t_len, xtra, mat, o_del, e_del, o_ins, e_ins, out);
 }
 
-// bm2_sam_pe with the mate-rescue alignments of the chunk on the device: the host plans them, this hook runs them against the
+int bm2_dev_cigar_batch(void *user, const bm2_opt *opt, int32_t n, const uint8_t *seqs, int64_t seq_bytes, const int64_t *q_off, const int32_t *q_len,
+                        const int64_t *rb, const int64_t *re, const int32_t *w, int32_t *score, int32_t *nm, int32_t *n_cigar, int64_t *cigar_off,
+                        uint32_t *cigar, int64_t cigar_cap, int64_t *md_off, char *md, int64_t md_cap);      // cigar.hip
+
+// bm2_sam_pe with the mate-rescue alignments AND the CIGAR alignments of the chunk on the device: the host plans them, this hook runs them against the
 // context's resident ref_string, the host replays the pairs (sam_tail.cpp: bm2h_sam_pe).
 static int dev_rescue_batch(void *user, int32_t n, const uint8_t *qbuf, int64_t qbuf_bytes, const int64_t *q_off, const int32_t *q_len,
                             const int64_t *t_pos, const int32_t *t_len, const int32_t *xtra, const bm2_opt *opt, const uint8_t *,
@@ -121,5 +125,6 @@ extern "C" int bm2_sam_pe_dev(bm2_ctx *c, const bm2_index_desc *idx, const bm2_o
                               const bm2_read_text *txt, const bm2_alnreg_t *alnregs, const int64_t *reg_off, int64_t n_processed,
                               const bm2_pestat *pes_in, bm2_pestat *pes_out, char *out, int64_t cap, int64_t *n_out) {
     if (!c || !c->has_index || !c->d_ref) { bm2_set_error("bm2_sam_pe_dev: the context holds no index"); return BM2_EINVAL; }
-    return bm2h_sam_pe(idx, opt, so, reads, txt, alnregs, reg_off, n_processed, pes_in, pes_out, out, cap, n_out, dev_rescue_batch, c);
+    return bm2h_sam_pe(idx, opt, so, reads, txt, alnregs, reg_off, n_processed, pes_in, pes_out, out, cap, n_out, dev_rescue_batch, c,
+                       bm2_dev_cigar_batch, c);
 }

@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <atomic>
 #include <thread>
+#include <unordered_map>
 #include "ksort_host.h"
 #include "host_tail.h"
 
@@ -211,6 +212,32 @@ int approx_mapq_se(const bm2_opt *opt, const bm2_sam_opt *so, const bm2_alnreg_t
 }
 
 // mem_reg2aln, bwamem.cpp:1732-1805; ar == NULL -> the unmapped record
+// ---- CIGAR generation as a batch.  A hit's alignment depends on (read, qb, qe, rb, re, band) only, so the SAM flow can be run twice: a
+// dry pass in which reg2aln merely RECORDS what it would align (every band its retry loop could ask for), one batch of all recorded
+// tasks (the device kernel's shape), and the real pass in which reg2aln looks the results up.  Nothing else in the flow looks at a
+// CIGAR before the text is written, so the dry pass takes the same decisions.
+struct CgTask {
+    const uint8_t *q; int32_t qb, qe, w2; int64_t rb, re;
+    bool operator==(const CgTask &o) const { return q == o.q && qb == o.qb && qe == o.qe && w2 == o.w2 && rb == o.rb && re == o.re; }
+};
+struct CgTaskHash {
+    size_t operator()(const CgTask &t) const {
+        uint64_t h = (uint64_t)(uintptr_t)t.q * 0x9E3779B97F4A7C15ull;
+        h ^= ((uint64_t)(uint32_t)t.qb << 32 | (uint32_t)t.qe) + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
+        h ^= (uint64_t)t.rb + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
+        h ^= ((uint64_t)t.re << 8 | (uint32_t)t.w2) + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
+        return (size_t)h;
+    }
+};
+struct CgMemo {                      // results of the batch, indexed through `at`
+    std::unordered_map<CgTask, int, CgTaskHash> at;
+    std::vector<int32_t> score, nm, n_cigar; std::vector<int64_t> cigar_off, md_off;
+    std::vector<uint32_t> cigar; std::vector<char> md;
+};
+struct CgStats { std::atomic<long long> planned{0}, used{0}, missed{0}; };
+struct CgSession { int mode = 0; std::vector<CgTask> *rec = nullptr; const CgMemo *memo = nullptr; CgStats *st = nullptr; };   // mode 1 = record, 2 = replay
+thread_local CgSession t_cg;
+
 bool reg2aln(const bm2_opt *opt, const bm2_sam_opt *so, const Ref &R, int l_query, const uint8_t *query, const bm2_alnreg_t *ar, Aln &a) {
     a = Aln();
     if (ar == 0 || ar->rb < 0 || ar->re < 0) { a.rid = -1; a.pos = -1; a.flag |= 0x4; return true; }
@@ -224,8 +251,40 @@ bool reg2aln(const bm2_opt *opt, const bm2_sam_opt *so, const Ref &R, int l_quer
     if (w2 > opt->w) w2 = w2 < ar->w ? w2 : ar->w;
     int i = 0, score = 0, NM = 0, last_sc = -(1 << 30);
     bool ok;
+    if (t_cg.mode == 1) {                                        // dry pass: note the bands the loop below could ask for; no alignment
+        int w = w2;
+        for (int t = 0; t < 3; ++t) {
+            w = w < opt->w << 2 ? w : opt->w << 2;
+            const CgTask k = { query, qb, qe, w, rb, re };
+            if (t == 0 || !(t_cg.rec->back() == k)) t_cg.rec->push_back(k);
+            if (w == opt->w << 2) break;
+            w <<= 1;
+        }
+        int is_rev;
+        const int64_t pos = R.depos(rb < R.l_pac ? rb : re - 1, &is_rev);
+        a.is_rev = is_rev; a.rid = R.pos2rid(pos); if (a.rid < 0) a.rid = 0;
+        a.pos = pos - R.off[a.rid]; a.cigar.assign(1, (uint32_t)(qe - qb) << 4); a.score = ar->score; a.is_alt = ar->is_alt;
+        return true;
+    }
     do {
         w2 = w2 < opt->w << 2 ? w2 : opt->w << 2;
+        int at = -1;
+        if (t_cg.mode == 2) {
+            const CgTask k = { query, qb, qe, w2, rb, re };
+            const auto it = t_cg.memo->at.find(k);
+            if (it != t_cg.memo->at.end()) at = it->second;
+            if (at >= 0) t_cg.st->used++; else t_cg.st->missed++;
+        }
+        if (at >= 0) {                                           // the batch has it
+            const CgMemo &M = *t_cg.memo;
+            ok = M.n_cigar[(size_t)at] >= 0;
+            score = M.score[(size_t)at]; NM = M.nm[(size_t)at];
+            a.cigar.clear(); a.MD.clear();
+            if (ok) {
+                a.cigar.assign(M.cigar.begin() + M.cigar_off[(size_t)at], M.cigar.begin() + M.cigar_off[(size_t)at] + M.n_cigar[(size_t)at]);
+                a.MD = M.md.data() + M.md_off[(size_t)at];
+            }
+        } else
         ok = gen_cigar(opt->mat, opt->o_del, opt->e_del, opt->o_ins, opt->e_ins, w2, R, qe - qb, query + qb, rb, re, &score, a.cigar, &NM, a.MD);
         if (!ok) break;
         if (score == last_sc || w2 == opt->w << 2) break;
@@ -401,6 +460,7 @@ int get_rlen(const std::vector<uint32_t> &cg) {                // bwamem.cpp:182
 // mem_aln2sam (bwamem.cpp:1592-1730); m_ = the mate's alignment or NULL
 void aln2sam(const bm2_sam_opt *so, const Ref &R, std::string &s, const char *name, const char *comment, const char *qual, int l_seq,
              const uint8_t *seq, const std::vector<Aln> &list, int which, const Aln *m_) {
+    if (t_cg.mode == 1) return;                                  // dry pass of a CIGAR session: decisions only
     Aln p = list[which], mtmp; Aln *m = 0;
     const int n = (int)list.size();
     if (m_) { mtmp = *m_; m = &mtmp; }
@@ -1048,6 +1108,32 @@ template <class F> void run_threads(int n_threads, F f) {
     for (auto &t : th) t.join();
 }
 
+CgStats g_cigar;                    // counters of the last bm2_sam_pe / bm2_sam_se call that ran a CIGAR session (bm2_sam_cigar_stats)
+
+// the recorded tasks of a dry pass -> unique tasks -> one call of the hook -> memo
+int cigar_session_batch(const bm2_index_desc *idx, const bm2_opt *opt, const bm2_reads *reads, int64_t enc_bytes,
+                        std::vector<std::vector<CgTask>> &recs, bm2h_cigar_batch_fn cfn, void *cuser, CgMemo &M) {
+    std::vector<CgTask> tasks;
+    for (auto &v : recs) for (const CgTask &t : v) if (M.at.emplace(t, (int)tasks.size()).second) tasks.push_back(t);
+    const size_t n = tasks.size();
+    g_cigar.planned = (long long)n;
+    if (n == 0) return BM2_OK;
+    if (n > 0x7fffffff) { bm2_set_error("too many CIGAR alignments in one chunk"); return BM2_EINVAL; }
+    std::vector<int64_t> q_off(n), rb(n), re(n);
+    std::vector<int32_t> q_len(n), w(n);
+    int64_t ccap = 0, mcap = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const CgTask &t = tasks[i];
+        q_off[i] = (t.q - reads->enc) + t.qb; q_len[i] = t.qe - t.qb; rb[i] = t.rb; re[i] = t.re; w[i] = t.w2;
+        const bool ok = q_len[i] > 0 && t.rb < t.re && !(t.rb < idx->l_pac && t.re > idx->l_pac) && t.rb >= 0 && t.re <= (idx->l_pac << 1);
+        if (ok) { ccap += q_len[i] + (t.re - t.rb) + 2; mcap += 2 * (q_len[i] + (t.re - t.rb)) + 16; }
+    }
+    M.score.resize(n); M.nm.resize(n); M.n_cigar.resize(n); M.cigar_off.resize(n); M.md_off.resize(n);
+    M.cigar.resize((size_t)ccap + 1); M.md.resize((size_t)mcap + 1);
+    return cfn(cuser, opt, (int32_t)n, reads->enc, enc_bytes, q_off.data(), q_len.data(), rb.data(), re.data(), w.data(), M.score.data(),
+               M.nm.data(), M.n_cigar.data(), M.cigar_off.data(), M.cigar.data(), ccap + 1, M.md_off.data(), M.md.data(), mcap + 1);
+}
+
 RescueStats g_rescue;               // counters of the last bm2_sam_pe call (diagnostic; bm2_sam_rescue_stats)
 
 // items [0, n) in blocks over n_threads host threads; f(i, out) appends the text of item i; the blocks are joined in order
@@ -1158,6 +1244,21 @@ extern "C" void bm2_sam_rescue_stats(int64_t *planned, int64_t *used, int64_t *m
     if (missed) *missed = g_rescue.missed;
 }
 
+// the CIGAR batch hook on the host (BM2_CIGAR_FLAT=1): the session machinery tested without a GPU
+static int host_cigar_batch(void *user, const bm2_opt *opt, int32_t n, const uint8_t *seqs, int64_t, const int64_t *q_off, const int32_t *q_len,
+                            const int64_t *rb, const int64_t *re, const int32_t *w, int32_t *score, int32_t *nm, int32_t *n_cigar,
+                            int64_t *cigar_off, uint32_t *cigar, int64_t cigar_cap, int64_t *md_off, char *md, int64_t md_cap) {
+    int64_t cn = 0, mn = 0;
+    return bm2_gen_cigar((const bm2_index_desc *)user, opt, n, seqs, q_off, q_len, rb, re, w, score, nm, n_cigar, cigar_off, cigar, cigar_cap, &cn,
+                         md_off, md, md_cap, &mn);
+}
+
+extern "C" void bm2_sam_cigar_stats(int64_t *planned, int64_t *used, int64_t *missed) {
+    if (planned) *planned = g_cigar.planned;
+    if (used) *used = g_cigar.used;
+    if (missed) *missed = g_cigar.missed;
+}
+
 // the batch hook on the host: the same flat arrays the device kernel takes, aligned by the host kernel (BM2_RESCUE_FLAT=1 routes
 // bm2_sam_pe through it, so that the flattening is tested without a GPU)
 static int host_flat_batch(void *user, int32_t n, const uint8_t *qbuf, int64_t, const int64_t *q_off, const int32_t *q_len, const int64_t *t_pos,
@@ -1180,13 +1281,15 @@ extern "C" int bm2_sam_pe(const bm2_index_desc *idx, const bm2_opt *opt, const b
     int n_threads = so && so->n_threads > 0 ? so->n_threads : (int)std::thread::hardware_concurrency();
     if (n_threads < 1) n_threads = 1;
     const char *flat = getenv("BM2_RESCUE_FLAT");
+    const char *cflat = getenv("BM2_CIGAR_FLAT");
     return bm2h_sam_pe(idx, opt, so, reads, txt, alnregs, reg_off, n_processed, pes_in, pes_out, out, cap, n_out,
-                       flat && flat[0] == '1' ? host_flat_batch : nullptr, &n_threads);
+                       flat && flat[0] == '1' ? host_flat_batch : nullptr, &n_threads,
+                       cflat && cflat[0] == '1' ? host_cigar_batch : nullptr, (void *)idx);
 }
 
 int bm2h_sam_pe(const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt *so, const bm2_reads *reads, const bm2_read_text *txt,
                 const bm2_alnreg_t *alnregs, const int64_t *reg_off, int64_t n_processed, const bm2_pestat *pes_in, bm2_pestat *pes_out,
-                char *out, int64_t cap, int64_t *n_out, bm2h_ksw_batch_fn fn, void *user) {
+                char *out, int64_t cap, int64_t *n_out, bm2h_ksw_batch_fn fn, void *user, bm2h_cigar_batch_fn cfn, void *cuser) {
     if (!idx || !opt || !so || !reads || !txt || !txt->name || !reg_off || !n_out || (reads->n_reads & 1) || (!alnregs && reg_off[reads->n_reads] > 0)) {
         bm2_set_error("bm2_sam_pe: bad argument (reads must be interleaved pairs)"); return BM2_EINVAL;
     }
@@ -1273,8 +1376,7 @@ int bm2h_sam_pe(const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt
             run_threads((long long)n_threads < (tot + step - 1) / step ? n_threads : (int)((tot + step - 1) / step), align);
         }
     }
-    std::string s;
-    const bool ok = run_blocks(n_pairs, so->n_threads, s, [&](int pi, std::string &part) {
+    auto one_pair = [&](int pi, std::vector<bm2_alnreg_t> *a2, std::string &part, RescueStats *st) {
         const int i = pi << 1;
         ReadIO io[2];
         for (int k = 0; k < 2; ++k) {
@@ -1283,7 +1385,39 @@ int bm2h_sam_pe(const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt
         }
         const RescueTask *pre = batch ? tasks.data() + task_off[(size_t)pi] : nullptr;
         const int n_pre = batch ? (int)(task_off[(size_t)pi + 1] - task_off[(size_t)pi]) : 0;
-        return sam_pe(opt, so, R, idx->ann_len, pes, (uint64_t)((n_processed >> 1) + pi), io, &regs[(size_t)i], part, pre, n_pre, batch ? &g_rescue : nullptr);
+        return sam_pe(opt, so, R, idx->ann_len, pes, (uint64_t)((n_processed >> 1) + pi), io, a2, part, pre, n_pre, st);
+    };
+    CgMemo memo;
+    g_cigar.planned = 0; g_cigar.used = 0; g_cigar.missed = 0;
+    if (cfn) {                                                   // CIGAR session: dry pass on copies of the hit lists, batch, then the real pass
+        int n_threads = so->n_threads > 0 ? so->n_threads : (int)std::thread::hardware_concurrency();
+        if (n_threads < 1) n_threads = 1;
+        const int blk = 256, n_blk = (n_pairs + blk - 1) / blk;
+        std::vector<std::vector<CgTask>> recs((size_t)n_blk);
+        std::atomic<int> next(0), failed(-1);
+        run_threads(n_threads < n_blk ? n_threads : n_blk, [&]() {
+            std::string sink;
+            for (int b; (b = next.fetch_add(1)) < n_blk;) {
+                t_cg.mode = 1; t_cg.rec = &recs[(size_t)b];
+                for (int pi = b * blk; pi < n_pairs && pi < (b + 1) * blk; ++pi) {
+                    std::vector<bm2_alnreg_t> a2[2] = { regs[(size_t)2 * pi], regs[(size_t)2 * pi + 1] };
+                    if (!one_pair(pi, a2, sink, nullptr)) { int e = -1; failed.compare_exchange_strong(e, pi); }
+                    sink.clear();
+                }
+                t_cg = CgSession();
+            }
+        });
+        int64_t enc_bytes = 0;
+        for (int i = 0; i < n; ++i) if (reads->off[i] + reads->len[i] > enc_bytes) enc_bytes = reads->off[i] + reads->len[i];
+        const int rc = cigar_session_batch(idx, opt, reads, enc_bytes, recs, cfn, cuser, memo);
+        if (rc) return rc;
+    }
+    std::string s;
+    const bool ok = run_blocks(n_pairs, so->n_threads, s, [&](int pi, std::string &part) {
+        if (cfn) { t_cg.mode = 2; t_cg.memo = &memo; t_cg.st = &g_cigar; }
+        const bool r = one_pair(pi, &regs[(size_t)2 * pi], part, batch ? &g_rescue : nullptr);
+        t_cg = CgSession();
+        return r;
     });
     if (!ok) { bm2_set_error("bm2_sam_pe: pair %s has a hit whose CIGAR cannot be generated (range outside the reference)", s.c_str()); return BM2_EINVAL; }
     *n_out = (int64_t)s.size();
@@ -1295,19 +1429,58 @@ int bm2h_sam_pe(const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt
 extern "C" int bm2_sam_se(const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt *so, const bm2_reads *reads,
                           const bm2_read_text *txt, bm2_alnreg_t *alnregs, const int64_t *reg_off, int64_t n_processed, char *out,
                           int64_t cap, int64_t *n_out) {
+    const char *cflat = getenv("BM2_CIGAR_FLAT");
+    return bm2h_sam_se(idx, opt, so, reads, txt, alnregs, reg_off, n_processed, out, cap, n_out,
+                       cflat && cflat[0] == '1' ? host_cigar_batch : nullptr, (void *)idx);
+}
+
+int bm2h_sam_se(const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt *so, const bm2_reads *reads, const bm2_read_text *txt,
+                bm2_alnreg_t *alnregs, const int64_t *reg_off, int64_t n_processed, char *out, int64_t cap, int64_t *n_out,
+                bm2h_cigar_batch_fn cfn, void *cuser) {
     if (!idx || !opt || !so || !reads || !txt || !txt->name || !reg_off || !n_out || (!alnregs && reg_off[reads->n_reads] > 0)) {
         bm2_set_error("bm2_sam_se: bad argument"); return BM2_EINVAL;
     }
     if (!idx->ref_string || !idx->ann_offset || !idx->ann_name) { bm2_set_error("bm2_sam_se: the index descriptor needs ref_string and contig names"); return BM2_EINVAL; }
     Ref R = { idx->l_pac, idx->ref_string, idx->n_seqs, idx->ann_offset, idx->ann_name, idx->ann_anno };
-    std::string s;
-    const bool ok = run_blocks(reads->n_reads, so->n_threads, s, [&](int i, std::string &part) {
-        bm2_alnreg_t *a = alnregs + reg_off[i];
+    const int n_reads = reads->n_reads;
+    auto one_read = [&](int i, bm2_alnreg_t *a, std::string &part) {
         const int n = (int)(reg_off[i + 1] - reg_off[i]);
         mark_primary_se(opt, n, a, n_processed + i);
         if (so->flag & F_PRIMARY5) reorder_primary5(so->T, n, a);
         return reg2sam(opt, so, R, part, txt->name[i], txt->comment ? txt->comment[i] : 0, txt->qual ? txt->qual[i] : 0, reads->len[i],
                        reads->enc + reads->off[i], n, a, 0, 0);
+    };
+    CgMemo memo;
+    g_cigar.planned = 0; g_cigar.used = 0; g_cigar.missed = 0;
+    if (cfn) {                                                   // CIGAR session (see reg2aln): dry pass on copies, batch, real pass
+        int n_threads = so->n_threads > 0 ? so->n_threads : (int)std::thread::hardware_concurrency();
+        if (n_threads < 1) n_threads = 1;
+        const int blk = 512, n_blk = (n_reads + blk - 1) / blk;
+        std::vector<std::vector<CgTask>> recs((size_t)n_blk);
+        std::atomic<int> next(0);
+        run_threads(n_threads < n_blk ? n_threads : n_blk, [&]() {
+            std::string sink; std::vector<bm2_alnreg_t> tmp;
+            for (int b; (b = next.fetch_add(1)) < n_blk;) {
+                t_cg.mode = 1; t_cg.rec = &recs[(size_t)b];
+                for (int i = b * blk; i < n_reads && i < (b + 1) * blk; ++i) {
+                    tmp.assign(alnregs + reg_off[i], alnregs + reg_off[i + 1]);
+                    one_read(i, tmp.data(), sink);
+                    sink.clear();
+                }
+                t_cg = CgSession();
+            }
+        });
+        int64_t enc_bytes = 0;
+        for (int i = 0; i < n_reads; ++i) if (reads->off[i] + reads->len[i] > enc_bytes) enc_bytes = reads->off[i] + reads->len[i];
+        const int rc = cigar_session_batch(idx, opt, reads, enc_bytes, recs, cfn, cuser, memo);
+        if (rc) return rc;
+    }
+    std::string s;
+    const bool ok = run_blocks(n_reads, so->n_threads, s, [&](int i, std::string &part) {
+        if (cfn) { t_cg.mode = 2; t_cg.memo = &memo; t_cg.st = &g_cigar; }
+        const bool r = one_read(i, alnregs + reg_off[i], part);
+        t_cg = CgSession();
+        return r;
     });
     if (!ok) { bm2_set_error("bm2_sam_se: read %s has a hit whose CIGAR cannot be generated (range outside the reference)", s.c_str()); return BM2_EINVAL; }
     *n_out = (int64_t)s.size();

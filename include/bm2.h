@@ -254,8 +254,13 @@ int bm2_sam_pe(const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt 
                const bm2_alnreg_t *alnregs, const int64_t *reg_off, int64_t n_processed, const bm2_pestat *pes_in, bm2_pestat *pes_out,
                char *out, int64_t cap, int64_t *n_out);
 
-/* bm2_sam_pe with the chunk's mate-rescue alignments run by the device kernel against the context's resident reference (the
- * context must have been created with this index).  Same output. */
+/* bm2_sam_pe / bm2_sam_se with the chunk's mate-rescue alignments (PE) and CIGAR alignments run as device batches against the
+ * context's resident reference (the context must have been created with this index).  Same output.  bm2_sam_cigar_stats: CIGAR
+ * alignments planned by the dry pass / looked up / computed in place by the last call. */
+int bm2_sam_se_dev(bm2_ctx *c, const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt *so, const bm2_reads *reads,
+                   const bm2_read_text *txt, bm2_alnreg_t *alnregs, const int64_t *reg_off, int64_t n_processed, char *out, int64_t cap,
+                   int64_t *n_out);
+void bm2_sam_cigar_stats(int64_t *planned, int64_t *used, int64_t *missed);
 int bm2_sam_pe_dev(bm2_ctx *c, const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt *so, const bm2_reads *reads,
                    const bm2_read_text *txt, const bm2_alnreg_t *alnregs, const int64_t *reg_off, int64_t n_processed,
                    const bm2_pestat *pes_in, bm2_pestat *pes_out, char *out, int64_t cap, int64_t *n_out);

@@ -104,9 +104,12 @@ fa, r1, r2 = T._pe_case(d, 61, 40, L=100, sub_rate=0.02, indel_frac=0.2, random_
 ref, got, pes = T._pe_run(d, fa, r1, r2, [])
 stats = bm2.sam_rescue_stats()
 assert ref == got and stats[0] > 20, stats
-ref2, got2, pes2 = T._pe_run(d, fa, r1, r2, [], ctx=bm2.Context(0, fa))
+ctx2 = bm2.Context(0, fa)
+ref2, got2, pes2 = T._pe_run(d, fa, r1, r2, [], ctx=ctx2)              # rescue AND CIGAR batches on the (emulated) device
 assert got2 == got and bm2.sam_rescue_stats() == stats
-print("ok", stats)
+cg = bm2.sam_cigar_stats()
+assert cg[0] >= cg[1] > 40 and cg[2] == 0, cg
+print("ok", stats, cg)
 ''' % (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "bwa-mem2_amd"), emu_lib, str(tmp_path))
     p = subprocess.run(["python", "-c", script], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
     assert p.returncode == 0 and p.stdout.startswith(b"ok"), p.stderr.decode()[-2000:]

@@ -67,7 +67,7 @@ def _write_fastq(path, reads, quals):
             f.write(b"@q%d\n" % i + b"ACGTN"[0:0] + bytes(b"ACGTN"[c] for c in r) + b"\n+\n" + quals[i] + b"\n")
 
 
-def test_sam_se_matches_reference_text(tmp_path):
+def test_sam_se_matches_reference_text(tmp_path, monkeypatch):
     fa, reads = _case(tmp_path, 41, 4000)
     rng = np.random.default_rng(3)
     quals = [bytes(rng.integers(35, 74, size=len(r), dtype=np.uint8)) for r in reads]
@@ -77,6 +77,10 @@ def test_sam_se_matches_reference_text(tmp_path):
     got = _ours(fa, reads, ["q%d" % i for i in range(len(reads))], quals)
     assert ref == got, _diff(ref, got)
     assert ref.count(b"SA:Z:") > 0 and ref.count(b"XA:Z:") > 0 and ref.count(b"\t4\t*\t0\t0\t*") > 0      # the case has all record kinds
+    monkeypatch.setenv("BM2_CIGAR_FLAT", "1")                   # the same with CIGAR generation as a session (dry pass, batch, real pass)
+    assert _ours(fa, reads, ["q%d" % i for i in range(len(reads))], quals) == got
+    cp, cu, cm = bm2.sam_cigar_stats()
+    assert cp >= cu > 3000 and cm == 0, (cp, cu, cm)
 
 
 def test_sam_se_options(tmp_path):
@@ -180,6 +184,11 @@ def test_sam_pe_rescue_batched_equals_inline(tmp_path, monkeypatch):
     monkeypatch.setenv("BM2_RESCUE_FLAT", "1")
     ref3, got3, pes3 = _pe_run(tmp_path, fa, r1, r2, [])
     assert got3 == got and bm2.sam_rescue_stats() == (planned, used, missed)
+    # CIGAR generation as a session: a dry pass records every alignment the flow could ask for, one batch, the real pass looks them up
+    monkeypatch.setenv("BM2_CIGAR_FLAT", "1")
+    ref4, got4, pes4 = _pe_run(tmp_path, fa, r1, r2, [])
+    cp, cu, cm = bm2.sam_cigar_stats()
+    assert got4 == got and cp >= cu > 2000 and cm == 0, (cp, cu, cm)
 
 
 def test_sam_pe_noisy_mates_and_options(tmp_path):
