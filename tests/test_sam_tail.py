@@ -25,7 +25,7 @@ def _reference_sam(fa, fq, extra=()):
     return b"".join(l for l in p.stdout.splitlines(keepends=True) if not l.startswith(b"@"))
 
 
-def _ours(fa, reads, names, quals, okw=None, sam_opt=None, comments=None):
+def _ours(fa, reads, names, quals, okw=None, sam_opt=None, comments=None, ctx=None):
     enc, off, ln = refio.pack_reads(reads)
     ix = oracle.Index(fa)
     try:
@@ -35,7 +35,7 @@ def _ours(fa, reads, names, quals, okw=None, sam_opt=None, comments=None):
     opt = bm2.default_opt(**(okw or {}))
     regs, reg_off = _prg_to_regs(exp["REGPRG"], len(ln))
     aln, aln_off = bm2.finish_regs(fa, enc, off, ln, opt, regs, reg_off)
-    return bm2.sam_se(fa, enc, off, ln, opt, aln, aln_off, names, quals, comments, sam_opt)
+    return bm2.sam_se(fa, enc, off, ln, opt, aln, aln_off, names, quals, comments, sam_opt, ctx=ctx)
 
 
 def _diff(a, b):

@@ -72,9 +72,28 @@ def test_sam_pe_with_the_rescue_alignments_on_the_device(gpu_ctx_factory, tmp_pa
     assert ref == got, T._diff(ref, got)
     host_stats = bm2.sam_rescue_stats()
     ctx = gpu_ctx_factory(fa)
-    ref2, got2, pes2 = T._pe_run(tmp_path, fa, r1, r2, [], ctx=ctx)
+    ref2, got2, pes2 = T._pe_run(tmp_path, fa, r1, r2, [], ctx=ctx)                 # rescue AND CIGAR batches on the device
     assert got2 == got, T._diff(got, got2)
     assert bm2.sam_rescue_stats() == host_stats and host_stats[0] > 500
+    planned, used, missed = bm2.sam_cigar_stats()
+    assert planned >= used > 3000 and missed == 0, (planned, used, missed)
+
+
+def test_sam_se_with_the_cigar_alignments_on_the_device(gpu_ctx_factory, tmp_path):
+    # bm2_sam_se_dev: dry pass on the host, k_gen_cigar for every alignment the flow could ask for, real pass -- against the text of
+    # the compiled reference (all record kinds: supplementary, XA, unmapped)
+    import test_sam_tail as T
+    fa, reads = T._case(tmp_path, 41, 4000)
+    rng = np.random.default_rng(3)
+    quals = [bytes(rng.integers(35, 74, size=len(r), dtype=np.uint8)) for r in reads]
+    fq = str(tmp_path / "r.fq")
+    T._write_fastq(fq, reads, quals)
+    ref = T._reference_sam(fa, fq)
+    names = ["q%d" % i for i in range(len(reads))]
+    got = T._ours(fa, reads, names, quals, ctx=gpu_ctx_factory(fa))
+    assert ref == got, T._diff(ref, got)
+    planned, used, missed = bm2.sam_cigar_stats()
+    assert planned >= used > 3000 and missed == 0, (planned, used, missed)
 
 
 @pytest.mark.parametrize("kw", [{}, dict(a=2, b=5, o_del=7, o_ins=8, e_del=2, e_ins=1)])

@@ -31,8 +31,9 @@ def chunks(n_reads, lens, K, paired):
         lo = hi
 
 
-def run(prefix, fq, K=10000000, out_path="-", threads=0, regs_of=None):
-    """regs_of(enc, off, ln) -> (regs REG_DT, reg_off): the device stage; None = a Context on GPU 0."""
+def run(prefix, fq, K=10000000, out_path="-", threads=0, regs_of=None, device_tail=False):
+    """regs_of(enc, off, ln) -> (regs REG_DT, reg_off): the device stage; None = a Context on GPU 0.
+    device_tail: the mate-rescue and CIGAR alignments of the SAM tail run as device batches too (bm2_sam_pe_dev / bm2_sam_se_dev)."""
     import bm2
     paired = len(fq) == 2
     parts = [bm2.fastq_parse(open(f, "rb").read()) for f in fq]
@@ -50,8 +51,10 @@ def run(prefix, fq, K=10000000, out_path="-", threads=0, regs_of=None):
         names, quals = e[3], e[5]
     lens = np.array([len(s) for s in seqs], np.int64)
     opt, so = bm2.default_opt(), bm2.default_sam_opt(n_threads=threads)
-    if regs_of is None:
+    ctx = None
+    if regs_of is None or device_tail:
         ctx = bm2.Context(0, prefix)
+    if regs_of is None:
         regs_of = lambda enc, off, ln: ctx.seed_chain_extend(enc, off, ln, opt)[:2]
     out = sys.stdout.buffer if out_path == "-" else open(out_path, "wb")
     out.write(bm2.sam_header(prefix))
@@ -62,9 +65,9 @@ def run(prefix, fq, K=10000000, out_path="-", threads=0, regs_of=None):
         regs, reg_off = regs_of(enc, off, ln)
         aln, aln_off = bm2.finish_regs(prefix, enc, off, ln, opt, regs, reg_off)
         if paired:
-            txt, _ = bm2.sam_pe(prefix, enc, off, ln, opt, aln, aln_off, names[lo:hi], quals[lo:hi], None, so, n_processed=lo)
+            txt, _ = bm2.sam_pe(prefix, enc, off, ln, opt, aln, aln_off, names[lo:hi], quals[lo:hi], None, so, n_processed=lo, ctx=ctx if device_tail else None)
         else:
-            txt = bm2.sam_se(prefix, enc, off, ln, opt, aln, aln_off, names[lo:hi], quals[lo:hi], None, so, n_processed=lo)
+            txt = bm2.sam_se(prefix, enc, off, ln, opt, aln, aln_off, names[lo:hi], quals[lo:hi], None, so, n_processed=lo, ctx=ctx if device_tail else None)
         out.write(txt)
     if out is not sys.stdout.buffer:
         out.close()
@@ -74,11 +77,12 @@ def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("-K", type=int, default=10000000)
     ap.add_argument("--threads", type=int, default=0, help="host threads of the SAM tail (0 = all)")
+    ap.add_argument("--device-tail", action="store_true", help="rescue and CIGAR alignments of the SAM tail on the device as well")
     ap.add_argument("-o", default="-")
     ap.add_argument("prefix")
     ap.add_argument("fq", nargs="+")
     a = ap.parse_args(argv)
-    run(a.prefix, a.fq, a.K, a.o, a.threads)
+    run(a.prefix, a.fq, a.K, a.o, a.threads, device_tail=a.device_tail)
 
 
 if __name__ == "__main__":
