@@ -14,6 +14,13 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# BM2_EMU_LIB=<libbm2_emu.so built by tools/emu/build_emu.py>: the `gpu` tests run against the host emulator of the device sources
+# (a logic check without a GPU; sizes are what they are, so pick tests with -k).
+if os.environ.get("BM2_EMU_LIB"):
+    import bm2 as _bm2
+    _bm2.LIB_PATH = os.environ["BM2_EMU_LIB"]
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN

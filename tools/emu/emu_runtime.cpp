@@ -8,7 +8,7 @@ size_t emu_dyn_lds_bytes = 0;
 __attribute__((aligned(64))) char emu_dyn_lds[160 * 1024];
 
 namespace {
-struct Arg { unsigned idx; emu_dim3 bid, bdim, gdim; EmuWave *wave; pthread_barrier_t *bb; const std::function<void()> *body; };
+struct Arg { unsigned idx; emu_dim3 bid, bdim, gdim; EmuWave *wave; EmuBarrier *bb; const std::function<void()> *body; };
 void *thread_main(void *p) {
     Arg *a = (Arg *)p;
     emu_t.tid = emu_dim3(a->idx % a->bdim.x, (a->idx / a->bdim.x) % a->bdim.y, a->idx / (a->bdim.x * a->bdim.y));
@@ -28,11 +28,11 @@ void emu_run_block(unsigned n_threads, emu_dim3 bid, emu_dim3 bdim, emu_dim3 gdi
     for (unsigned w = 0; w < n_waves; ++w) {
         const unsigned lanes = w + 1 < n_waves || n_threads % 64 == 0 ? 64 : n_threads % 64;
         if (lanes != 64) { fprintf(stderr, "emu: block size %u is not a multiple of 64 (partial wavefronts are not modelled)\n", n_threads); abort(); }
-        pthread_barrier_init(&waves[w].bar, 0, lanes);
+        waves[w].bar.init((int)lanes);
         pthread_mutex_init(&waves[w].mu, 0);
-        for (int r = 0; r < 4; ++r) pthread_barrier_init(&waves[w].rowbar[r], 0, 16);
+        for (int r = 0; r < 4; ++r) waves[w].rowbar[r].init(16);
     }
-    pthread_barrier_t bb; pthread_barrier_init(&bb, 0, n_threads);
+    EmuBarrier bb; bb.init((int)n_threads);
     std::vector<pthread_t> th(n_threads); std::vector<Arg> args(n_threads);
     pthread_attr_t at; pthread_attr_init(&at); pthread_attr_setstacksize(&at, 1 << 20);
     for (unsigned i = 0; i < n_threads; ++i) {
@@ -40,6 +40,5 @@ void emu_run_block(unsigned n_threads, emu_dim3 bid, emu_dim3 bdim, emu_dim3 gdi
         if (pthread_create(&th[i], &at, thread_main, &args[i]) != 0) { perror("pthread_create"); abort(); }
     }
     for (unsigned i = 0; i < n_threads; ++i) pthread_join(th[i], 0);
-    for (unsigned w = 0; w < n_waves; ++w) pthread_barrier_destroy(&waves[w].bar);
-    pthread_barrier_destroy(&bb); pthread_attr_destroy(&at);
+    pthread_attr_destroy(&at);
 }

@@ -9,6 +9,7 @@
 // structurisation of loops, visibility without fences, timing).
 #pragma once
 #include <pthread.h>
+#include <sched.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -41,8 +42,18 @@ static inline unsigned min(unsigned a, unsigned b) { return a < b ? a : b; }
 
 struct emu_dim3 { unsigned x, y, z; emu_dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };
 typedef emu_dim3 dim3;
-struct EmuWave { pthread_barrier_t bar, rowbar[4]; pthread_mutex_t mu; long long slot[64]; int site[64]; long long rslot[64]; };
-struct EmuThread { emu_dim3 tid, bid, bdim, gdim; EmuWave *wave; pthread_barrier_t *block_bar; int lane; };
+// A barrier that spins with sched_yield: rendezvous are so frequent that sleeping in a futex (pthread_barrier) dominates the run time.
+struct EmuBarrier {
+    std::atomic<int> count{0}, gen{0}; int n = 0;
+    void init(int n_) { n = n_; count = 0; gen = 0; }
+    void wait() {
+        const int g = gen.load(std::memory_order_acquire);
+        if (count.fetch_add(1, std::memory_order_acq_rel) + 1 == n) { count.store(0, std::memory_order_relaxed); gen.fetch_add(1, std::memory_order_acq_rel); }
+        else { int spins = 0; while (gen.load(std::memory_order_acquire) == g) { if (++spins > 64) sched_yield(); } }
+    }
+};
+struct EmuWave { EmuBarrier bar, rowbar[4]; pthread_mutex_t mu; long long slot[64]; int site[64]; long long rslot[64]; };
+struct EmuThread { emu_dim3 tid, bid, bdim, gdim; EmuWave *wave; EmuBarrier *block_bar; int lane; };
 extern thread_local EmuThread emu_t;
 #define threadIdx (emu_t.tid)
 #define blockIdx  (emu_t.bid)
@@ -50,7 +61,7 @@ extern thread_local EmuThread emu_t;
 #define gridDim   (emu_t.gdim)
 
 // ---- rendezvous of a wavefront: publish, wait, read, wait ----
-static inline void emu_wsync() { pthread_barrier_wait(&emu_t.wave->bar); }
+static inline void emu_wsync() { emu_t.wave->bar.wait(); }
 extern thread_local int emu_site;         // source line of the primitive being executed (set by the macros below)
 template <class F> static inline auto emu_exchange(long long v, F read) -> decltype(read((const long long *)0)) {
     EmuWave *w = emu_t.wave;
@@ -119,7 +130,7 @@ static inline int __clz(int x) { return x ? __builtin_clz((unsigned)x) : 32; }
 #define __clzll(x) __builtin_clzll(x)
 #define __threadfence() std::atomic_thread_fence(std::memory_order_seq_cst)
 #define __threadfence_block() std::atomic_thread_fence(std::memory_order_seq_cst)
-static inline void __syncthreads() { pthread_barrier_wait(emu_t.block_bar); }
+static inline void __syncthreads() { emu_t.block_bar->wait(); }
 
 template <class T> static inline T atomicAdd(T *p, T v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
 static inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
@@ -142,7 +153,7 @@ template <int BATCH, class Pool> static inline int64_t emu_wave_alloc(Pool *wp, 
 // divergent as a wavefront, uniform as a row).  On the GPU they are DPP row_shr / a ballot masked to the row / shuffles of width 16,
 // which only ever involve the lanes of the row that is executing; here they rendezvous the 16 threads of the row.
 #define BM2_EMU_ROW_PRIMS 1
-static inline void emu_rsync() { pthread_barrier_wait(&emu_t.wave->rowbar[emu_t.lane >> 4]); }
+static inline void emu_rsync() { emu_t.wave->rowbar[emu_t.lane >> 4].wait(); }
 template <class F> static inline int emu_row_exchange(long long v, F read) {
     EmuWave *w = emu_t.wave;
     w->rslot[emu_t.lane] = v; emu_rsync();
