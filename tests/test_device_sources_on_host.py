@@ -59,7 +59,7 @@ def emu_lib(tmp_path_factory):
 
 def test_whole_device_pipeline_on_the_emulator(emu_lib, golden_dir):
     # every kernel of bm2_seed_chain_extend (seeding task kernels with their quad-cooperative Occ loads, SA lookup, chaining, the
-    # lane-per-task extension rounds, the purge) executed by OS threads, against the oracle: 3 reads take about a minute
+    # lane-per-task extension rounds, the purge) executed by OS threads, against the oracle: 48 reads take a few seconds
     script = r'''
 import sys
 sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r)
@@ -68,7 +68,7 @@ bm2.LIB_PATH = %r
 from helpers import load_golden, regs_to_records
 from tools import oracle
 pre, enc, off, ln, d = load_golden(%r, "g20k_l76")
-n = 3
+n = 48
 ln = ln[:n]; off = off[:n]; enc = enc[:int(off[-1] + ln[-1])]
 ctx = bm2.Context(0, pre)
 regs, reg_off, st = ctx.seed_chain_extend(enc, off, ln, bm2.default_opt())
