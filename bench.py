@@ -1,26 +1,34 @@
 #!/usr/bin/env python3
-"""bench.py -- hot-path throughput of libbm2 on MI355X (one process per GPU).
+"""bench.py -- throughput of libbm2 on MI355X (one process per GPU).
 
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
 A "step" = one pass of the device pipeline (SMEM seeding -> SA lookup -> chaining -> banded extension -> regs,
-i.e. mem_kernel1_core + mem_kernel2_core up to bwamem.cpp:1152) over one chunk of synthetic 150 bp paired-end reads
-that is already resident in HBM.  Reads shard across GPUs (per-GPU index replica, no collective on the data path;
+i.e. mem_kernel1_core + mem_kernel2_core up to bwamem.cpp:1152) over one chunk of synthetic reads that is already
+resident in HBM: `value`.  Reads shard across GPUs (per-GPU index replica, no collective on the data path;
 torch.distributed is used only for the barrier and the max-over-ranks of the timed region) => weak scaling.
 
-Prints ONE JSON line on rank 0 (see the driver contract in the task statement) with two extra objects:
+Prints ONE JSON line on rank 0 (see the driver contract in the task statement) with these extra objects:
   roofline     -- the FM-index seeding kernel against the HBM peak, from ALGORITHMIC bytes (128 B per backwardExt,
-                  SURVEY.md section 8(d)) over its HIP-event-timed launches inside the timed region
-  cpu_baseline -- the compiled reference (oracle/_ref/bwa-mem2.<isa> mem) on this host's cores, bounded sample.
+                  SURVEY.md section 8(d)) over its HIP-event-timed launches inside the timed region; `achieved_counter` is the
+                  same with the HBM bytes the PMC passes measured (profiles/)
+  cpu_baseline -- the compiled reference (oracle/_ref/bwa-mem2.<isa> mem) on this host's cores, bounded sample
+  parity       -- the gate: a 512-aligned PREFIX of the timed chunk (the block rule of bwamem.cpp:834 makes a prefix the only valid
+                  sample) through the reference on the same index: regs before / after mem_sort_dedup_patch byte for byte against
+                  oracle/_ref/refdump, SAM text against `bwa-mem2 mem`.  A mismatch makes the run fail (exit code 3).
+  end_to_end   -- the metric as stated: FASTQ text in host memory -> SAM text in host memory over several distinct chunks, the
+                  host tail of chunk n overlapping the device work of chunk n+1 (reported beside `value`, never instead of it)
 """
 import argparse
 import json
 import os
+import queue
 import re
 import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -31,18 +39,20 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "bwa-mem2_amd"))
 
-RANDOM_LINE_GBS = 3500.0      # measured: ~55 G independent 64-B lines/s (tools/ubench/randline.hip)
+RANDOM_LINE_GLPS = 55.0        # measured: ~55 G independent 64-B lines/s delivered (tools/ubench/randline.hip)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+ONT2D = dict(a=1, b=1, o_del=1, e_del=1, o_ins=1, e_ins=1, pen_clip5=0, pen_clip3=0, min_seed_len=14, min_chain_weight=20,
+             split_factor=10.0)      # `-x ont2d`, fastmap.cpp:812-826
 
 
 def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
 
 
-def ref_binary():
+def ref_binary(kind="bwa-mem2"):
     flags = open("/proc/cpuinfo").read()
     for a in (["avx512bw"] if "avx512bw" in flags else []) + (["avx2"] if "avx2" in flags else []) + ["sse41"]:
-        p = os.path.join(ROOT, "oracle", "_ref", "bwa-mem2." + a)
+        p = os.path.join(ROOT, "oracle", "_ref", "%s.%s" % (kind, a))
         if os.path.exists(p):
             return p, a
     return None, None
@@ -80,40 +90,194 @@ def prepare_genome(workdir, mbp, seed):
     return pre, ctg
 
 
-def cpu_baseline(prefix, contigs, n_pairs, read_len, workdir, seed):
-    """Time the compiled reference on a bounded sample of the same workload, all host cores."""
-    from tools import synth
+def host_threads():
+    return min(os.cpu_count() or 1, 128)
+
+
+def run_reference_mem(prefix, fq, extra=(), threads=None, out="/dev/null"):
+    """`bwa-mem2 mem` of the compiled reference -> (stderr text, wall seconds) or (None, 0)."""
     exe, isa = ref_binary()
     if exe is None:
-        return None
-    r1, r2 = synth.make_reads_pe(seed, contigs, n_pairs, L=read_len)
-    f1, f2 = os.path.join(workdir, "cpu_1.fq"), os.path.join(workdir, "cpu_2.fq")
-    synth.write_fastq(f1, r1, suffix="/1")
-    synth.write_fastq(f2, r2, suffix="/2")
-    cores = os.cpu_count() or 1
-    threads = min(cores, 128)
+        return None, 0.0, None
+    threads = threads or host_threads()
     t = time.time()
-    p = subprocess.run([exe, "mem", "-t", str(threads), "-K", "100000000", "-o", "/dev/null", prefix, f1, f2],
+    p = subprocess.run([exe, "mem", "-t", str(threads), "-K", "100000000", "-o", out] + list(extra) + [prefix] + list(fq),
                        stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
-    wall = time.time() - t
     if p.returncode != 0:
         log("reference mem failed:", p.stderr[-500:])
+        return None, 0.0, isa
+    return p.stderr, time.time() - t, isa
+
+
+def cpu_baseline(prefix, fq, n_reads_desc, extra=()):
+    """Time the compiled reference on a bounded sample of the same workload, all host cores."""
+    err, wall, isa = run_reference_mem(prefix, fq, extra)
+    if err is None:
         return None
+    threads = host_threads()
     n_proc, real = 0, 0.0
-    for m in re.finditer(r"Processed (\d+) reads in [\d.]+ CPU sec, ([\d.]+) real sec", p.stderr):
+    for m in re.finditer(r"Processed (\d+) reads in [\d.]+ CPU sec, ([\d.]+) real sec", err):
         n_proc += int(m.group(1)); real += float(m.group(2))
-    kern = re.search(r"Total kernel \(smem\+sal\+bsw\) time avg: ([\d.]+)", p.stderr)
+    kern = re.search(r"Total kernel \(smem\+sal\+bsw\) time avg: ([\d.]+)", err)
     kern_s = float(kern.group(1)) if kern else None
     if n_proc == 0 or real <= 0:
         return None
     out = {"value": n_proc / real, "unit": "reads/s", "cores": threads, "kind": "reference",
-           "sample": "%d x %d bp PE reads, same index; bwa-mem2 v2.2.1 %s build, `mem -t %d`; whole `mem` chunk time "
+           "sample": "%s, same index; bwa-mem2 v2.2.1 %s build, `mem -t %d %s`; whole `mem` chunk time "
                      "(seed+chain+extend+pairing+SAM) from its own 'Processed N reads' lines; wall %.1fs"
-                     % (n_proc, read_len, isa, threads, wall)}
+                     % (n_reads_desc, isa, threads, " ".join(extra), wall)}
     if kern_s:
         out["hot_path_value"] = n_proc / kern_s
-        out["hot_path_note"] = "reads / reference's own per-thread-average SMEM+SAL+BSW kernel time (same scope as `value`)"
+        out["hot_path_note"] = "reads / reference's own per-thread-average SMEM+SAL+BSW kernel time (the scope of the top-level `value`)"
     return out
+
+
+def regs_records(regs, reg_off, lo, hi):
+    """device regs of reads [lo, hi) in the record layout of refdump's REGPRG section"""
+    from tools import refio
+    a, b = int(reg_off[lo]), int(reg_off[hi])
+    out = np.zeros(b - a, refio.REG_DT)
+    out["read"] = np.repeat(np.arange(hi - lo), np.diff(reg_off[lo:hi + 1]))
+    for f in ("rb", "re", "qb", "qe", "rid", "score", "truesc", "w", "seedcov", "seedlen0", "frac_rep"):
+        out[f] = regs[f][a:b]
+    return out
+
+
+def alnregs_records(aln, aln_off):
+    from tools import refio
+    out = np.zeros(len(aln), refio.REG_DT)
+    out["read"] = np.repeat(np.arange(len(aln_off) - 1), np.diff(aln_off))
+    for f in ("rb", "re", "qb", "qe", "rid", "score", "truesc", "sub", "alt_sc", "csub", "sub_n", "w", "seedcov", "secondary",
+              "secondary_all", "seedlen0", "n_comp", "is_alt", "frac_rep"):
+        out[f] = aln[f]
+    return out
+
+
+def sam_lines(text):
+    return [l for l in text.split(b"\n") if l and not l.startswith(b"@")]
+
+
+def parity_gate(ctx, bm2, prefix, workdir, seqs, regs, reg_off, opt, opt_args, paired, n_sample, tag):
+    """The reference on the first n_sample reads of the timed chunk, same index: regs (refdump) and SAM text (bwa-mem2 mem)."""
+    from tools import refio, synth
+    refdump, isa = ref_binary("refdump")
+    exe, _ = ref_binary()
+    if refdump is None or exe is None:
+        return {"reads": 0, "regs_equal": None, "fin_equal": None, "sam_equal": None, "note": "oracle/_ref is not built on this box"}
+    n = n_sample
+    res = {"reads": n, "sample": "first %d reads of the timed chunk (a 512-aligned prefix), reference %s build" % (n, isa)}
+    # --- regs: REGPRG (device boundary) and REGFIN (after mem_sort_dedup_patch)
+    t = time.time()
+    rtxt = os.path.join(workdir, "parity_%s.txt" % tag)
+    acgtn = np.frombuffer(b"ACGTN", np.uint8)
+    with open(rtxt, "wb") as f:
+        for s in seqs[:n]:
+            f.write(acgtn[s].tobytes() + b"\n")
+    dump = os.path.join(workdir, "parity_%s.bin" % tag)
+    p = subprocess.run([refdump] + list(opt_args) + [prefix, rtxt, dump], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+    if p.returncode != 0:
+        res.update(regs_equal=False, note="refdump failed: " + p.stderr[-300:])
+        return res
+    d = refio.read_dump(dump)
+    got = regs_records(regs, reg_off, 0, n)
+    res["regs"] = int(len(got))
+    res["regs_equal"] = bool(len(got) == len(d["REGPRG"]) and got.tobytes() == d["REGPRG"].tobytes())
+    res["max_coord"] = int(d["REGPRG"]["re"].max()) if len(d["REGPRG"]) else 0
+    res["regs_over_2p32"] = int((d["REGPRG"]["re"] >= (1 << 32)).sum())
+    log("parity[%s]: refdump on %d reads in %.1fs: REGPRG equal = %s (%d regs, %d beyond 2^32)"
+        % (tag, n, time.time() - t, res["regs_equal"], len(got), res["regs_over_2p32"]))
+    # --- the tail: a19 + pairing + SAM on the same prefix, from FASTQ text as the reference reads it
+    t = time.time()
+    if paired:
+        f1, f2 = os.path.join(workdir, "parity_%s_1.fq" % tag), os.path.join(workdir, "parity_%s_2.fq" % tag)
+        synth.write_fastq(f1, seqs[0:n:2], suffix="/1"); synth.write_fastq(f2, seqs[1:n:2], suffix="/2")
+        fq = [f1, f2]
+    else:
+        f1 = os.path.join(workdir, "parity_%s.fq" % tag)
+        synth.write_fastq(f1, seqs[:n])
+        fq = [f1]
+    ref_sam = os.path.join(workdir, "parity_%s.ref.sam" % tag)
+    err, wall, _ = run_reference_mem(prefix, fq, opt_args, out=ref_sam)
+    if err is None:
+        res.update(sam_equal=False, note="reference mem failed")
+        return res
+    chunk = bm2.FastqChunk(open(fq[0], "rb").read(), open(fq[1], "rb").read() if paired else None, 0)
+    try:
+        sub_off = (reg_off[:n + 1] - reg_off[0]).astype(np.int64)
+        sub_regs = regs[int(reg_off[0]):int(reg_off[n])]
+        aln, aln_off = ctx.finish_regs(chunk, opt, sub_regs, sub_off)
+        fin = alnregs_records(aln, aln_off)
+        res["fin_equal"] = bool(len(fin) == len(d["REGFIN"]) and fin.tobytes() == d["REGFIN"].tobytes())
+        so = bm2.default_sam_opt(n_threads=0)
+        txt = ctx.sam(chunk, opt, so, aln, aln_off, 0, paired)
+    finally:
+        chunk.close()
+    mine, ref = sam_lines(txt), sam_lines(open(ref_sam, "rb").read())
+    res["sam_records"] = len(ref)
+    res["sam_equal"] = bool(mine == ref)
+    if not res["sam_equal"]:
+        for i, (x, y) in enumerate(zip(mine, ref)):
+            if x != y:
+                res["first_sam_diff"] = {"line": i, "got": x[:300].decode("latin1"), "exp": y[:300].decode("latin1")}
+                break
+    log("parity[%s]: a19 equal = %s, SAM equal = %s (%d records; reference mem %.1fs, total %.1fs)"
+        % (tag, res["fin_equal"], res["sam_equal"], len(ref), wall, time.time() - t))
+    return res
+
+
+def end_to_end(ctx, bm2, texts, opt, paired, n_threads):
+    """FASTQ text -> SAM text over the chunks `texts` = [(bytes1, bytes2 | None)], two stages on two host threads: the front
+    (parse, upload, device pipeline, a19, download) of chunk n+1 runs while the tail (pairing, rescue + CIGAR batches on the device
+    through a second context that shares the index replica, SAM text) of chunk n does."""
+    ctx2 = bm2.Context(share=ctx)
+    so = bm2.default_sam_opt(n_threads=n_threads)
+    q = queue.Queue(maxsize=2)
+    stage = {}
+    err = []
+
+    def add(k, dt):
+        stage[k] = stage.get(k, 0.0) + dt
+
+    def front():
+        try:
+            n_done = 0
+            for t1, t2 in texts:
+                t = time.perf_counter(); ch = bm2.FastqChunk(t1, t2, n_threads); add("parse", time.perf_counter() - t)
+                t = time.perf_counter(); ctx.batch_upload_chunk(ch); add("h2d", time.perf_counter() - t)
+                t = time.perf_counter(); ctx.batch_run(opt); add("device", time.perf_counter() - t)
+                t = time.perf_counter(); regs, reg_off = ctx.batch_download(); add("d2h", time.perf_counter() - t)
+                t = time.perf_counter(); aln, aln_off = ctx.finish_regs(ch, opt, regs, reg_off); add("a19", time.perf_counter() - t)
+                q.put((ch, aln, aln_off, n_done))
+                n_done += ch.n_reads
+        except Exception as e:                                    # noqa
+            err.append(e)
+        q.put(None)
+
+    out_bytes, n_reads = 0, 0
+    th = threading.Thread(target=front)
+    t0 = time.perf_counter()
+    th.start()
+    while True:
+        it = q.get()
+        if it is None:
+            break
+        ch, aln, aln_off, n_done = it
+        t = time.perf_counter()
+        txt = ctx2.sam(ch, opt, so, aln, aln_off, n_done, paired)
+        add("tail", time.perf_counter() - t)
+        out_bytes += len(txt); n_reads += ch.n_reads
+        ch.close()
+    th.join()
+    dt = time.perf_counter() - t0
+    ctx2.close()
+    if err:
+        raise err[0]
+    nch = max(len(texts), 1)
+    return {"value": n_reads / dt, "unit": "reads/s", "reads": n_reads, "chunks": len(texts), "wall_s": dt, "sam_bytes": out_bytes,
+            "host_threads": n_threads or (os.cpu_count() or 1),
+            "stage_ms_per_chunk": {k: v / nch * 1e3 for k, v in stage.items()},
+            "scope": "FASTQ text in host memory -> bm2_fastq_parse_mt -> H2D -> device pipeline -> D2H -> a19 -> pairing / mate rescue / "
+                     "CIGAR (device batches) / SAM text in host memory; front and tail of consecutive chunks overlap; file I/O excluded"}
 
 
 def main():
@@ -121,23 +285,34 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="pe150", choices=["pe150", "ont2d"],
+                    help="pe150: BASELINE config 3 shape (the metric); ont2d: config 5 shape (10 kb reads, -x ont2d)")
     ap.add_argument("--genome-mbp", type=int, default=int(os.environ.get("BM2_BENCH_GENOME_MBP", 3100)))
-    ap.add_argument("--reads", type=int, default=int(os.environ.get("BM2_BENCH_READS", 1000000)),
-                    help="reads per GPU per step (both mates counted)")
+    ap.add_argument("--reads", type=int, default=int(os.environ.get("BM2_BENCH_READS", 0)),
+                    help="reads per GPU per step (both mates counted); default 1000000 (pe150) / 2000 (ont2d)")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--cpu-pairs", type=int, default=int(os.environ.get("BM2_BENCH_CPU_PAIRS", 250000)))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--parity-reads", type=int, default=int(os.environ.get("BM2_BENCH_PARITY_READS", 20480)))
+    ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--e2e-chunks", type=int, default=int(os.environ.get("BM2_BENCH_E2E_CHUNKS", 4)))
     ap.add_argument("--workdir", default=os.environ.get("BM2_BENCH_WORKDIR", "/tmp/bm2_bench"))
     a = ap.parse_args()
 
     from tools import dist_util, synth
     rank, world, local = dist_util.env_rank()
     import torch
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (libbm2 has no CPU fallback)")
-    torch.cuda.set_device(local)
-    dist_util.init("nccl", world, torch.device("cuda", local))     # "nccl" is RCCL on ROCm
     import bm2
+    emu = os.environ.get("BM2_EMU_LIB")                  # test hook: the host emulator of the device sources (tools/emu) stands in for the
+    if emu:                                              # GPU so that this script's own logic can be checked on a CPU box; never a result
+        bm2.LIB_PATH = emu
+        torch.cuda.synchronize = lambda *x: None
+    elif not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (libbm2 has no CPU fallback)")
+    else:
+        torch.cuda.set_device(local)
+    dist_util.init("gloo" if emu else "nccl", world, None if emu else torch.device("cuda", local))     # "nccl" is RCCL on ROCm
 
     os.makedirs(a.workdir, exist_ok=True)
     seed = 20260924
@@ -150,14 +325,25 @@ def main():
     t = time.time()
     ctx = bm2.Context(local, prefix)
     log("rank %d: index replica in HBM after %.1fs" % (rank, time.time() - t))
-    r1, r2 = synth.make_reads_pe(dist_util.shard_seed(seed, rank), contigs, a.reads // 2, L=a.read_len)
-    reads = np.empty((2 * len(r1), a.read_len), np.uint8)
-    reads[0::2] = r1; reads[1::2] = r2                      # mates interleaved, as bseq_read_orig delivers PE chunks
-    n_reads = len(reads)
-    enc = reads.reshape(-1)
-    off = np.arange(n_reads, dtype=np.int64) * a.read_len
-    ln = np.full(n_reads, a.read_len, np.int32)
-    opt = bm2.default_opt()
+    ont = a.workload == "ont2d"
+    paired = not ont
+    if ont:
+        n_reads = a.reads or 2000
+        opt, opt_args = bm2.default_opt(**ONT2D), ["-x", "ont2d"]
+        seqs = synth.make_reads_long(dist_util.shard_seed(seed, rank), contigs, n_reads, mean_len=10000, max_len=30000)
+        from tools import refio
+        enc, off, ln = refio.pack_reads(seqs)
+    else:
+        n_reads = a.reads or 1000000
+        opt, opt_args = bm2.default_opt(), []
+        r1, r2 = synth.make_reads_pe(dist_util.shard_seed(seed, rank), contigs, n_reads // 2, L=a.read_len)
+        seqs = np.empty((2 * len(r1), a.read_len), np.uint8)
+        seqs[0::2] = r1; seqs[1::2] = r2                    # mates interleaved, as bseq_read_orig delivers PE chunks
+        n_reads = len(seqs)
+        enc = seqs.reshape(-1)
+        off = np.arange(n_reads, dtype=np.int64) * a.read_len
+        ln = np.full(n_reads, a.read_len, np.int32)
+    n_bases = int(np.asarray(ln, np.int64).sum())
     ctx.batch_upload(enc, off, ln)
 
     for _ in range(a.warmup):
@@ -172,9 +358,10 @@ def main():
             kms[name] = kms.get(name, 0.0) + ms
     torch.cuda.synchronize()
     dist_util.barrier(world)
-    dt = dist_util.max_over_ranks(time.perf_counter() - t0, world, "cuda")
+    dt = dist_util.max_over_ranks(time.perf_counter() - t0, world, "cpu" if emu else "cuda")
     st = ctx.batch_stats()
 
+    rc = 0
     if rank == 0:
         steps = max(a.steps, 1)
         value = world * n_reads * a.steps / dt
@@ -195,55 +382,112 @@ def main():
         cells = st["n_sw_cells"]
         ext_ms = stage_ms.get("extend", 0.0)
         dominant = max(stage_ms, key=stage_ms.get) if stage_ms else None
-        traffic = None                                       # HBM bytes per k_bwd launch from the committed PMC passes, same workload only
+        traffic, pmc_src = None, None                        # HBM bytes per k_bwd launch from the committed PMC passes, same workload only
+        ext_pmc = None
+        for fn in ("r02_k_bwd_pmc.json", "r01_k_bwd_pmc.json"):
+            try:
+                pm = json.load(open(os.path.join(ROOT, "profiles", fn)))
+                wl = pm["workload"]
+                if wl["genome_mbp"] == a.genome_mbp and wl["reads_per_gpu_per_step"] == n_reads and wl["read_len"] == a.read_len and not ont:
+                    traffic, pmc_src = pm["hbm_bytes_per_launch"], "profiles/" + fn
+                    break
+            except Exception:
+                pass
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_k_bwd_pmc.json")))
-            wl = pm["workload"]
-            if wl["genome_mbp"] == a.genome_mbp and wl["reads_per_gpu_per_step"] == n_reads and wl["read_len"] == a.read_len:
-                traffic = pm["hbm_bytes_per_launch"]
+            ext_pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_ext_pmc_sq.json")))
         except Exception:
             pass
+        ach_counter = traffic / (bwd_ms * 1e-3) / 1e9 if traffic and bwd_ms > 0 else None
+        lines_counter = traffic / 64.0 / (bwd_ms * 1e-3) / 1e9 if traffic and bwd_ms > 0 else None
+        wl_name = ("config 5 shape: %d ONT-like reads (mean 10 kb, cap 30 kb, ~10%% error) per GPU per step, `-x ont2d`" % n_reads) if ont else \
+                  ("config 3 shape: %d x %d bp PE reads per GPU per step" % (n_reads, a.read_len))
         out = {
             "metric": "aligned reads/s (150bp PE vs GRCh38) at 1/2/4/8 GPU; SAM bit-exact vs ref",
             "value": value, "unit": "reads/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "int32", "data": "synthetic",
-            "config": {"workload": "config 3 shape (SMEM+SAL+chain+banded-SW all on device), %d x %d bp PE reads per GPU "
-                                   "per step, synthetic %d Mbp genome with planted repeats/ALT/N-gaps, indexed in-run by bm2_index_build "
-                                   "(3100 Mbp = GRCh38 size; the index alone takes ~2 min of the set-up on 256 host threads); "
-                                   "output = mem_alnreg_t regs at bwamem.cpp:1152 (pairing/SAM formatting not included)"
-                                   % (n_reads, a.read_len, a.genome_mbp),
-                       "reads_per_gpu_per_step": n_reads, "read_len": a.read_len, "genome_mbp": a.genome_mbp,
+            "dtype": "int32", "data": "synthetic" if not emu else "synthetic; HOST EMULATOR RUN (not a measurement)",
+            "config": {"workload": wl_name + " (SMEM+SAL+chain+banded-SW all on device), synthetic %d Mbp genome with planted repeats/ALT/"
+                                   "N-gaps, indexed in-run by bm2_index_build (3100 Mbp = GRCh38 size); `value` = device hot path "
+                                   "with the reads resident in HBM, output = mem_alnreg_t regs at bwamem.cpp:1152; the FASTQ -> SAM "
+                                   "rate of the same library is `end_to_end.value`" % a.genome_mbp,
+                       "reads_per_gpu_per_step": n_reads, "bases_per_gpu_per_step": n_bases, "read_len": a.read_len if not ont else None,
+                       "genome_mbp": a.genome_mbp,
                        "parallelism": "reads sharded over %d GPU(s), index replica per GPU, no collectives" % world},
             "stage_ms_per_step": stage_ms, "dominant_stage": dominant,
             "work_per_read": {"backwardExt": st["n_ext"] / n_reads, "lf_steps": st["n_lf"] / n_reads,
                               "sa_lookups": st["n_sa"] / n_reads, "sw_tasks": st["n_sw_tasks"] / n_reads,
                               "sw_cells": cells / n_reads, "regs": st["n_reg"] / n_reads},
             "roofline": {"kernel": "k_bwd", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": pmc_src,
+                         "achieved_counter": ach_counter,
+                         "frac_counter": ach_counter / HBM_PEAK_GBS if ach_counter else None,
                          "algorithmic_bytes_per_launch": bwd_bytes, "avg_launch_ms": bwd_ms, "launches_per_step": 2,
-                         "random_line_ceiling": RANDOM_LINE_GBS,
-                         "frac_of_random_line_ceiling": ach / RANDOM_LINE_GBS,
-                         "note": "k_bwd fetches isolated 64-byte lines; the measured ceiling of this GPU for that access pattern is "
-                                 "~55 G lines/s = 3.5 TB/s (tools/ubench/randline.hip, DESIGN.md section 5)",
+                         "random_line_ceiling_glines": RANDOM_LINE_GLPS,
+                         "delivered_glines": lines_counter,
+                         "frac_of_random_line_ceiling": lines_counter / RANDOM_LINE_GLPS if lines_counter else None,
+                         "note": "k_bwd fetches isolated 64-byte lines; this GPU delivers ~55 G such lines/s (tools/ubench/randline.hip). "
+                                 "`achieved` counts 128 algorithmic bytes per backwardExt; `achieved_counter` / `delivered_glines` count "
+                                 "the bytes / lines HBM actually delivered (FETCH_SIZE + WRITE_SIZE of the committed PMC passes): two "
+                                 "ends of an interval in one CP_OCC block and L2-resident first steps make them smaller",
                          "seeding_stage": {"kernels": "k_walk<1> + k_bwd + k_walk<2> + k_bwd (+ k_walk<3> on a second stream)",
                                            "ms": smem_ms, "algorithmic_bytes": fm_bytes, "achieved": stage_ach,
                                            "frac": stage_ach / HBM_PEAK_GBS,
                                            "kernel_ms": {k: v for k, v in kern_ms.items() if k.startswith("smem.")},
                                            "backwardExt_per_kernel": ext_of}},
-            "extend_kernel": {"kernel": "k_extend", "gcups": cells / (ext_ms * 1e-3) / 1e9 if ext_ms > 0 else 0.0,
-                              "avg_launch_ms": ext_ms, "cells_per_launch": cells},
+            "extend_kernel": {"kernel": "k_ext_lanes", "gcups": cells / (ext_ms * 1e-3) / 1e9 if ext_ms > 0 else 0.0,
+                              "avg_launch_ms": ext_ms, "cells_per_launch": cells,
+                              "valu_frac": ext_pmc.get("valu_frac") if ext_pmc else None,
+                              "lds_conflict_frac": ext_pmc.get("lds_conflict_frac") if ext_pmc else None,
+                              "pmc_source": "profiles/r02_ext_pmc_sq.json" if ext_pmc else None},
         }
+        if world == 1 and not a.no_parity:
+            regs, reg_off = ctx.batch_download()
+            n_s = min(a.parity_reads, n_reads) if not ont else min(256, n_reads)
+            if not ont:
+                n_s -= n_s % 512
+            out["parity"] = parity_gate(ctx, bm2, prefix, a.workdir, seqs, regs, reg_off, opt, opt_args, paired, max(n_s, 2), a.workload)
+            if not (out["parity"].get("regs_equal") and out["parity"].get("sam_equal") and out["parity"].get("fin_equal")):
+                rc = 3
+        else:
+            out["parity"] = None
         if world == 1 and not a.no_cpu_baseline:             # the reference on this host's cores: at N=1 only (the other ranks would idle)
             t = time.time()
-            cb = cpu_baseline(prefix, contigs, a.cpu_pairs, a.read_len, a.workdir, seed + 5)
+            if ont:
+                nb = min(len(seqs), 300)
+                f1 = os.path.join(a.workdir, "cpu_ont.fq")
+                synth.write_fastq(f1, seqs[:nb])
+                cb = cpu_baseline(prefix, [f1], "%d ONT-like reads (the first of the timed chunk)" % nb, opt_args)
+            else:
+                c1, c2 = synth.make_reads_pe(seed + 5, contigs, a.cpu_pairs, L=a.read_len)
+                f1, f2 = os.path.join(a.workdir, "cpu_1.fq"), os.path.join(a.workdir, "cpu_2.fq")
+                synth.write_fastq(f1, c1, suffix="/1"); synth.write_fastq(f2, c2, suffix="/2")
+                cb = cpu_baseline(prefix, [f1, f2], "%d x %d bp PE reads" % (2 * a.cpu_pairs, a.read_len))
             log("cpu baseline took %.1fs" % (time.time() - t))
             out["cpu_baseline"] = cb
         else:
             out["cpu_baseline"] = None
+        if world == 1 and not a.no_e2e and not ont:
+            t = time.time()
+            texts = []
+            for i in range(a.e2e_chunks):                    # distinct chunks of the same shape as the timed one
+                e1, e2 = synth.make_reads_pe(seed + 100 + i, contigs, n_reads // 2, L=a.read_len)
+                fa, fb = os.path.join(a.workdir, "e2e_1.fq"), os.path.join(a.workdir, "e2e_2.fq")
+                synth.write_fastq(fa, e1, prefix="c%d_" % i, suffix="/1"); synth.write_fastq(fb, e2, prefix="c%d_" % i, suffix="/2")
+                texts.append((open(fa, "rb").read(), open(fb, "rb").read()))
+            log("end-to-end input: %d chunks generated in %.1fs" % (len(texts), time.time() - t))
+            try:
+                end_to_end(ctx, bm2, texts[:1], opt, True, 0)                       # warm-up (workspaces, thread pools)
+                out["end_to_end"] = end_to_end(ctx, bm2, texts, opt, True, 0)
+                out["end_to_end"]["frac_of_hot_path"] = out["end_to_end"]["value"] / value
+            except Exception as e:                                                    # noqa
+                out["end_to_end"] = {"error": str(e)}
+        else:
+            out["end_to_end"] = None
         print(json.dumps(out), flush=True)
     ctx.close()
     dist_util.finish(world)
+    if rc:
+        sys.exit(rc)
 
 
 if __name__ == "__main__":

@@ -61,7 +61,7 @@ class SamOpt(C.Structure):
 class Fastq(C.Structure):
     _fields_ = [("n_reads", C.c_int32), ("pad", C.c_int32), ("n_bases", C.c_int64), ("enc", C.POINTER(C.c_uint8)),
                 ("off", C.POINTER(C.c_int64)), ("len", C.POINTER(C.c_int32)), ("name", C.POINTER(C.c_char_p)),
-                ("comment", C.POINTER(C.c_char_p)), ("qual", C.POINTER(C.c_char_p))]
+                ("comment", C.POINTER(C.c_char_p)), ("qual", C.POINTER(C.c_char_p)), ("arena", C.c_void_p)]
 
 
 class PeStat(C.Structure):
@@ -89,10 +89,10 @@ class Stats(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
-EXPORTS = ["bm2_index_load", "bm2_index_free", "bm2_opt_init", "bm2_opt_fill_scmat", "bm2_create", "bm2_destroy",
+EXPORTS = ["bm2_index_load", "bm2_index_free", "bm2_opt_init", "bm2_opt_fill_scmat", "bm2_create", "bm2_create_shared", "bm2_destroy",
            "bm2_last_error", "bm2_device_count", "bm2_bsw", "bm2_smem", "bm2_sal", "bm2_seed_chain_extend",
            "bm2_batch_upload", "bm2_batch_run", "bm2_batch_stats", "bm2_batch_download", "bm2_batch_kernel_ms",
-           "bm2_batch_fetch", "bm2_finish_regs", "bm2_index_build", "bm2_sam_opt_init", "bm2_sam_se", "bm2_sam_pe", "bm2_fastq_parse", "bm2_fastq_free", "bm2_ksw_align2", "bm2_ksw_align2_dev", "bm2_sam_pe_dev", "bm2_sam_se_dev", "bm2_sam_cigar_stats", "bm2_gen_cigar", "bm2_gen_cigar_dev", "bm2_sam_header", "bm2_sam_rescue_stats"]
+           "bm2_batch_fetch", "bm2_finish_regs", "bm2_index_build", "bm2_sam_opt_init", "bm2_sam_se", "bm2_sam_pe", "bm2_fastq_parse", "bm2_fastq_parse_mt", "bm2_fastq_free", "bm2_ksw_align2", "bm2_ksw_align2_dev", "bm2_sam_pe_dev", "bm2_sam_se_dev", "bm2_sam_cigar_stats", "bm2_gen_cigar", "bm2_gen_cigar_dev", "bm2_sam_header", "bm2_sam_rescue_stats"]
 
 _lib = None
 
@@ -176,13 +176,74 @@ def _reads_struct(enc, off, ln):
     return r, (enc, off, ln)
 
 
+class Index:
+    """The host arrays of one index (bm2_index_load), loaded once and shared by the host-side entry points: every function below
+    that takes `index_prefix` also accepts an Index or a Context (then nothing is read from disk again)."""
+
+    def __init__(self, prefix):
+        self.prefix = prefix
+        self._desc = IndexDesc()
+        _chk(lib().bm2_index_load(prefix.encode(), C.byref(self._desc)), "bm2_index_load")
+
+    @property
+    def l_pac(self):
+        return self._desc.l_pac
+
+    def close(self):
+        if self._desc is not None:
+            lib().bm2_index_free(C.byref(self._desc))
+            self._desc = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+class _DescOf:
+    """with _DescOf(prefix | Index | Context) as d: ...   (loads and frees only when given a path)"""
+
+    def __init__(self, x):
+        self.x, self.own = x, None
+
+    def __enter__(self):
+        if isinstance(self.x, (str, bytes)):
+            self.own = Index(self.x if isinstance(self.x, str) else self.x.decode())
+            return self.own._desc
+        if getattr(self.x, "_desc", None) is None:
+            raise Bm2Error("this Context / Index holds no index")
+        return self.x._desc
+
+    def __exit__(self, *a):
+        if self.own is not None:
+            self.own.close()
+
+
 class Context:
     """One per GPU; mirrors the lifetime of the reference's FMI_search + ref_string (fastmap.cpp:848-888)."""
 
-    def __init__(self, device=0, index_prefix=None):
+    def __init__(self, device=0, index_prefix=None, share=None):
+        """index_prefix: path (loaded here), or an Index (kept by the caller); share=<Context>: a second context on the same
+        device that uses that context's index replica (bm2_create_shared)."""
         L = lib()
         self._desc = None
+        self._own_desc = True
         self.h = None
+        if share is not None:
+            L.bm2_create_shared.restype = C.c_void_p
+            L.bm2_create_shared.argtypes = [C.c_void_p]
+            self._desc, self._own_desc = share._desc, False
+            self.h = L.bm2_create_shared(share.h)
+            if not self.h:
+                raise Bm2Error("bm2_create_shared failed: " + L.bm2_last_error().decode())
+            return
+        if isinstance(index_prefix, Index):
+            self._desc, self._own_desc = index_prefix._desc, False
+            self.h = L.bm2_create(device, C.byref(self._desc))
+            if not self.h:
+                raise Bm2Error("bm2_create failed: " + L.bm2_last_error().decode())
+            return
         if index_prefix is not None:
             self._desc = IndexDesc()
             _chk(L.bm2_index_load(index_prefix.encode(), C.byref(self._desc)), "bm2_index_load")
@@ -202,7 +263,8 @@ class Context:
             lib().bm2_destroy(self.h)
             self.h = None
         if self._desc is not None:
-            lib().bm2_index_free(C.byref(self._desc))
+            if self._own_desc:
+                lib().bm2_index_free(C.byref(self._desc))
             self._desc = None
 
     def __enter__(self):
@@ -265,6 +327,47 @@ class Context:
         r, keep = _reads_struct(enc, off, ln)
         _chk(lib().bm2_batch_upload(self.h, C.byref(r)), "bm2_batch_upload")
         self._n_reads = len(keep[2])
+
+    def batch_upload_chunk(self, chunk):
+        """H2D of a FastqChunk (its arrays stay in the library's buffers)."""
+        _chk(lib().bm2_batch_upload(self.h, C.byref(chunk.reads)), "bm2_batch_upload")
+        self._n_reads = chunk.n_reads
+
+    def finish_regs(self, chunk, opt, regs, reg_off):
+        """The tail of mem_kernel2_core (mem_sort_dedup_patch + ALT flag, bwamem.cpp:1154-1169) for the regs of a chunk
+        -> (alnregs ALNREG_DT, aln_off)."""
+        regs = np.ascontiguousarray(regs, REG_DT)
+        reg_off = np.ascontiguousarray(reg_off, np.int64)
+        out = np.zeros(max(len(regs), 1), ALNREG_DT)
+        out_off = np.zeros(chunk.n_reads + 1, np.int64)
+        n = C.c_int64(0)
+        _chk(lib().bm2_finish_regs(C.byref(self._desc), C.byref(opt), C.byref(chunk.reads), regs.ctypes.data, reg_off.ctypes.data,
+                                   out.ctypes.data, len(out), out_off.ctypes.data, C.byref(n)), "bm2_finish_regs")
+        return out[:n.value], out_off
+
+    def sam(self, chunk, opt, so, alnregs, aln_off, n_processed=0, paired=True):
+        """SAM alignment lines of a chunk (bm2_sam_pe_dev / bm2_sam_se_dev: rescue and CIGAR alignments as device batches) -> bytes."""
+        L = lib()
+        alnregs = np.ascontiguousarray(alnregs, ALNREG_DT)
+        aln_off = np.ascontiguousarray(aln_off, np.int64)
+        need = C.c_int64(0)
+        cap = max(1 << 20, int(3 * (int(chunk.f.n_bases) + 200 * chunk.n_reads)))
+        while True:
+            buf = np.empty(cap, np.uint8)
+            if paired:
+                rc = L.bm2_sam_pe_dev(C.c_void_p(self.h), C.byref(self._desc), C.byref(opt), C.byref(so), C.byref(chunk.reads), C.byref(chunk.text),
+                                      C.c_void_p(alnregs.ctypes.data), C.c_void_p(aln_off.ctypes.data), C.c_int64(n_processed), None, None,
+                                      C.c_void_p(buf.ctypes.data), C.c_int64(cap), C.byref(need))
+            else:
+                a = alnregs.copy()                                  # reordered in place
+                rc = L.bm2_sam_se_dev(C.c_void_p(self.h), C.byref(self._desc), C.byref(opt), C.byref(so), C.byref(chunk.reads), C.byref(chunk.text),
+                                      C.c_void_p(a.ctypes.data), C.c_void_p(aln_off.ctypes.data), C.c_int64(n_processed),
+                                      C.c_void_p(buf.ctypes.data), C.c_int64(cap), C.byref(need))
+            if rc == BM2_ECAP:
+                cap = need.value + 16
+                continue
+            _chk(rc, "bm2_sam_pe_dev" if paired else "bm2_sam_se_dev")
+            return buf[:need.value].tobytes()
 
     def batch_run(self, opt):
         _chk(lib().bm2_batch_run(self.h, C.byref(opt)), "bm2_batch_run")
@@ -352,26 +455,20 @@ def sam_rescue_stats():
 def sam_header(index_prefix, hdr_line=None):
     """@SQ lines (+ the caller's header lines) as bwa_print_sam_hdr prints them -> bytes."""
     L = lib()
-    d = IndexDesc()
-    _chk(L.bm2_index_load(index_prefix.encode(), C.byref(d)), "bm2_index_load")
-    try:
+    with _DescOf(index_prefix) as d:
         L.bm2_sam_header.argtypes = [C.POINTER(IndexDesc), C.c_char_p, C.c_char_p, C.c_int64, C.POINTER(C.c_int64)]
         need = C.c_int64(0)
         L.bm2_sam_header(C.byref(d), hdr_line, None, 0, C.byref(need))
         buf = C.create_string_buffer(need.value + 1)
         _chk(L.bm2_sam_header(C.byref(d), hdr_line, buf, need.value, C.byref(need)), "bm2_sam_header")
         return buf.raw[:need.value]
-    finally:
-        L.bm2_index_free(C.byref(d))
 
 
 def gen_cigar(index_prefix, opt, tasks, ctx=None):
     """tasks: list of (query codes, rb, re, w) -> list of (score, NM, [cigar ops] or None, MD bytes).
     ctx = a Context created with this index: the device kernel (bm2_gen_cigar_dev) instead of the host code."""
     L = lib()
-    d = IndexDesc()
-    _chk(L.bm2_index_load(index_prefix.encode(), C.byref(d)), "bm2_index_load")
-    try:
+    with _DescOf(index_prefix) as d:
         n = len(tasks)
         qs = [np.ascontiguousarray(t[0], np.uint8) for t in tasks]
         q_len = np.array([len(q) for q in qs], np.int32)
@@ -408,8 +505,6 @@ def gen_cigar(index_prefix, opt, tasks, ctx=None):
                 m = raw[m_off[i]:raw.index(b"\0", m_off[i])]
                 out.append((int(score[i]), int(nm[i]), [int(x) for x in cig[c_off[i]:c_off[i] + nc[i]]], m))
         return out
-    finally:
-        L.bm2_index_free(C.byref(d))
 
 
 def fastq_parse(text):
@@ -433,6 +528,42 @@ def fastq_parse(text):
         L.bm2_fastq_free(C.byref(f))
 
 
+class FastqChunk:
+    """A parsed chunk that stays in the library's arrays (bm2_fastq_parse_mt): numpy views of enc / off / len and the bm2_read_text
+    pointers the SAM writer takes -- no per-read Python objects.  close() frees it."""
+
+    def __init__(self, text1, text2=None, n_threads=0):
+        L = lib()
+        L.bm2_fastq_parse_mt.argtypes = [C.c_char_p, C.c_int64, C.c_char_p, C.c_int64, C.c_int, C.POINTER(Fastq)]
+        L.bm2_fastq_free.argtypes = [C.POINTER(Fastq)]
+        L.bm2_fastq_free.restype = None
+        self.f = Fastq()
+        _chk(L.bm2_fastq_parse_mt(text1, len(text1), text2, len(text2) if text2 is not None else 0, n_threads, C.byref(self.f)), "bm2_fastq_parse_mt")
+        f = self.f
+        n = f.n_reads
+        self.n_reads = n
+        self.enc = np.ctypeslib.as_array(f.enc, shape=(max(f.n_bases, 1),))[:f.n_bases]
+        self.off = np.ctypeslib.as_array(f.off, shape=(max(n, 1),))[:n]
+        self.len = np.ctypeslib.as_array(f.len, shape=(max(n, 1),))[:n]
+        self.reads = Reads(n, C.cast(f.enc, C.c_void_p), C.cast(f.off, C.c_void_p), C.cast(f.len, C.c_void_p))
+        self.text = ReadText(f.name, f.comment, f.qual)
+
+    def names(self):
+        return [self.f.name[i] for i in range(self.n_reads)]
+
+    def close(self):
+        if self.f is not None:
+            self.enc = self.off = self.len = None
+            lib().bm2_fastq_free(C.byref(self.f))
+            self.f = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
 def default_sam_opt(**kw):
     o = SamOpt()
     lib().bm2_sam_opt_init(C.byref(o))
@@ -451,9 +582,7 @@ def sam_se(index_prefix, enc, off, ln, opt, alnregs, reg_off, names, quals=None,
            pes_in=None, ctx=None):
     """Single-end SAM alignment lines (host only, no GPU) from the alnregs of finish_regs -> bytes."""
     L = lib()
-    d = IndexDesc()
-    _chk(L.bm2_index_load(index_prefix.encode(), C.byref(d)), "bm2_index_load")
-    try:
+    with _DescOf(index_prefix) as d:
         r, keep = _reads_struct(enc, off, ln)
         n = len(keep[2])
         so = sam_opt if sam_opt is not None else default_sam_opt()
@@ -488,16 +617,12 @@ def sam_se(index_prefix, enc, off, ln, opt, alnregs, reg_off, names, quals=None,
                 continue
             _chk(rc, "bm2_sam_pe" if paired else "bm2_sam_se")
             return (buf.raw[:need.value], list(pes)) if paired else buf.raw[:need.value]
-    finally:
-        L.bm2_index_free(C.byref(d))
 
 
 def finish_regs(index_prefix, enc, off, ln, opt, regs, reg_off):
     """Tail of mem_kernel2_core on the host (no GPU): -> (alnregs ALNREG_DT, out_off)."""
     L = lib()
-    d = IndexDesc()
-    _chk(L.bm2_index_load(index_prefix.encode(), C.byref(d)), "bm2_index_load")
-    try:
+    with _DescOf(index_prefix) as d:
         r, keep = _reads_struct(enc, off, ln)
         regs = np.ascontiguousarray(regs, REG_DT)
         reg_off = np.ascontiguousarray(reg_off, np.int64)
@@ -507,8 +632,6 @@ def finish_regs(index_prefix, enc, off, ln, opt, regs, reg_off):
         _chk(L.bm2_finish_regs(C.byref(d), C.byref(opt), C.byref(r), regs.ctypes.data, reg_off.ctypes.data, out.ctypes.data,
                                len(out), out_off.ctypes.data, C.byref(n)), "bm2_finish_regs")
         return out[:n.value], out_off
-    finally:
-        L.bm2_index_free(C.byref(d))
 
 
 def index_build(fasta, prefix=None, n_threads=0):

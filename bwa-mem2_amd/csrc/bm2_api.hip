@@ -149,6 +149,19 @@ extern "C" bm2_ctx *bm2_create(int device, const bm2_index_desc *idx) {
     return c;
 }
 
+// A second context on the same device that SHARES the parent's index replica (its own streams and workspaces): lets a caller
+// overlap two chunks on one GPU -- the device stages of chunk n+1 beside the device batches of chunk n's SAM tail -- or split one
+// chunk over several contexts without a second 17 GB upload.  Valid while the parent lives; destroy it first.
+extern "C" bm2_ctx *bm2_create_shared(bm2_ctx *parent) {
+    if (!parent || parent->is_child) { bm2_set_error("bm2_create_shared: needs a context made by bm2_create"); return nullptr; }
+    if (bm2_check(hipSetDevice(parent->device), "hipSetDevice")) return nullptr;
+    bm2_ctx *k = new (std::nothrow) bm2_ctx();
+    if (!k) return nullptr;
+    k->device = parent->device; k->n_cu = parent->n_cu; k->ix = parent->ix; k->has_index = parent->has_index; k->is_child = true;
+    if (make_streams(k)) { delete k; return nullptr; }
+    return k;
+}
+
 extern "C" void bm2_destroy(bm2_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
@@ -162,7 +175,7 @@ extern "C" void bm2_destroy(bm2_ctx *c) {
     c->subs.clear();
     bm2_batch_destroy(c);
     void *ps[] = { c->d_cp_occ, c->d_sa_ms, c->d_sa_ls, c->d_ref, c->d_ann_off, c->d_ann_len, c->d_ann_alt };
-    for (void *p : ps) if (p) (void)hipFree(p);
+    if (!c->is_child) for (void *p : ps) if (p) (void)hipFree(p);          // a shared context does not own the replica
     bm2_release(c->b_pairs); bm2_release(c->b_ref); bm2_release(c->b_qer); bm2_release(c->b_misc);
     free_streams(c);
     delete c;

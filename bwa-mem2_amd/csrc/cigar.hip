@@ -160,7 +160,7 @@ extern "C" int bm2_gen_cigar_dev(bm2_ctx *c, const bm2_opt *opt, int32_t n, cons
                                  int64_t *md_off, char *md, int64_t md_cap, int64_t *md_need) {
     if (!c || !opt || n < 0 || (n > 0 && (!seqs || !q_off || !q_len || !rb || !re || !w || !score || !nm || !n_cigar || !cigar_off || !md_off)) ||
         !cigar_need || !md_need) { bm2_set_error("bm2_gen_cigar_dev: bad argument"); return BM2_EINVAL; }
-    if (!c->has_index || !c->d_ref) { bm2_set_error("bm2_gen_cigar_dev: the context holds no index"); return BM2_EINVAL; }
+    if (!c->has_index || !c->ix.ref_string) { bm2_set_error("bm2_gen_cigar_dev: the context holds no index"); return BM2_EINVAL; }
     *cigar_need = 0; *md_need = 0;
     if (n == 0) return BM2_OK;
     if (opt->e_del <= 0 || opt->e_ins <= 0) { bm2_set_error("bm2_gen_cigar_dev: gap extension penalties must be > 0"); return BM2_EINVAL; }
@@ -208,7 +208,7 @@ extern "C" int bm2_gen_cigar_dev(bm2_ctx *c, const bm2_opt *opt, int32_t n, cons
     if (!rc) rc = bm2_check(hipMemcpyAsync(d_task, tasks.data(), (size_t)n * sizeof(CigarTask), hipMemcpyHostToDevice, s), "H2D tasks");
     if (!rc) rc = bm2_check(hipMemcpyAsync(d_order, order.data(), ord_bytes, hipMemcpyHostToDevice, s), "H2D order");
     if (rc) return rc;
-    hipLaunchKernelGGL(k_gen_cigar, dim3((n + 63) / 64), dim3(64), 0, s, (const uint8_t *)c->d_ref, (const uint8_t *)b_seq.p, d_task, d_order, n, prm,
+    hipLaunchKernelGGL(k_gen_cigar, dim3((n + 63) / 64), dim3(64), 0, s, c->ix.ref_string, (const uint8_t *)b_seq.p, d_task, d_order, n, prm,
                        d_z, d_eh, d_cg, d_md, d_res);
     rc = bm2_check(hipGetLastError(), "k_gen_cigar launch");
     std::vector<CigarRes> h_res((size_t)n);
@@ -245,6 +245,6 @@ int bm2_dev_cigar_batch(void *user, const bm2_opt *opt, int32_t n, const uint8_t
 extern "C" int bm2_sam_se_dev(bm2_ctx *c, const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt *so, const bm2_reads *reads,
                               const bm2_read_text *txt, bm2_alnreg_t *alnregs, const int64_t *reg_off, int64_t n_processed, char *out,
                               int64_t cap, int64_t *n_out) {
-    if (!c || !c->has_index || !c->d_ref) { bm2_set_error("bm2_sam_se_dev: the context holds no index"); return BM2_EINVAL; }
+    if (!c || !c->has_index || !c->ix.ref_string) { bm2_set_error("bm2_sam_se_dev: the context holds no index"); return BM2_EINVAL; }
     return bm2h_sam_se(idx, opt, so, reads, txt, alnregs, reg_off, n_processed, out, cap, n_out, bm2_dev_cigar_batch, c);
 }

@@ -481,6 +481,8 @@ static __device__ bool seed_redundant(const ChainParams &o, int l_query, const D
     return false;
 }
 
+#define PF_HEAVY 24                 // reads with more regs than this are purged by a whole wavefront (k_postfilter_heavy)
+
 // Redundant-seed post-filter, bwamem.cpp:2895-2989 (one read per lane): replays the original bwa-mem rule "skip a seed
 // already contained in an earlier alignment unless an overlapping seed lies on another diagonal" and purges those regs.
 // Seeds already decided by the lazy rounds (k_decide_round) get the same verdict again, so replaying them is harmless.
@@ -494,6 +496,7 @@ k_postfilter(ChainParams o, int n_reads, const int32_t *__restrict__ len, const 
     const int r = perm[tix];
     const int nc = n_chain[r], nr = n_reg[r];
     if (nc == 0) { n_out[r] = 0; return; }
+    if (nr > PF_HEAVY) return;                               // k_postfilter_heavy takes these: one read per wavefront
     const int first_idx = cursor[r];
     const int64_t base = read_base[r];
     const int l_query = len[r];
@@ -521,6 +524,116 @@ k_postfilter(ChainParams o, int n_reads, const int32_t *__restrict__ len, const 
     int m = 0;
     for (int i = 0; i < nr; i++) if (av[i].qe > av[i].qb) m++;       // bwamem.cpp:1141-1152
     n_out[r] = m;
+}
+
+// The same filter for reads with many regs, one read per wavefront.  The test of one seed walks the read's regs in order
+// (O(regs) per seed, O(regs^2) per read: a repeat read with 400 regs kept one lane busy for the whole 14 ms of the
+// lane-per-read kernel while the other million reads took 2 ms).  The walk only counts and looks for the first reg that
+// stops it, so 64 regs are judged at once and the order is restored with ballots: `v` = non-purged regs seen so far; a reg
+// is looked at only while v < lim; the first looked-at reg that satisfies one of the two band tests ends the walk.
+__global__ void __launch_bounds__(256)
+k_postfilter_heavy(ChainParams o, const int32_t *__restrict__ heavy /* read ids, heavy ones first */, const int64_t *__restrict__ n_heavy_p,
+                   const int32_t *__restrict__ len, const int64_t *__restrict__ read_base, const int32_t *__restrict__ n_chain,
+                   const int32_t *__restrict__ n_reg, const DevChain *__restrict__ chn, const DevSeed *__restrict__ seeds,
+                   int32_t *srt_all, DevReg *regs, int32_t *n_out, const int32_t *__restrict__ cursor, unsigned long long *item_cur) {
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lt_mask = lane ? (~0ULL >> (64 - lane)) : 0ULL;
+    const int64_t n_heavy = *n_heavy_p;
+    for (;;) {
+        // one item per wavefront: every lane takes part in the atomic (lane 0 adds 1, the others 0), so there is no divergent
+        // branch around it and the compiler cannot split lane 0 from the rest (see notes/NEXT.md)
+        const unsigned long long it = atomicAdd(item_cur, lane == 0 ? 1ULL : 0ULL);
+        const int64_t hid = (int64_t)(((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(it >> 32)) << 32) |
+                                      (unsigned)__builtin_amdgcn_readfirstlane((unsigned)it));
+        if (hid >= n_heavy) break;
+        const int r = heavy[hid];
+        const int nc = n_chain[r], nr = n_reg[r];
+        if (nc != 0 && nr > PF_HEAVY) {                          // (no `continue` in this loop: see notes/NEXT.md)
+        const int first_idx = cursor[r];
+        const int64_t base = read_base[r];
+        const int l_query = len[r];
+        DevReg *av = regs + base;
+        int lim = 0;
+        for (int i0 = 0; i0 < first_idx && i0 < nr; i0 += 64) {
+            const int i = i0 + lane;
+            const bool kept = i < first_idx && i < nr && !(av[i].qb == -1 && av[i].qe == -1);
+            lim += __popcll(__ballot(kept));
+        }
+        if (nr > first_idx) {
+            for (int j = 0; j < nc; j++) {
+                const DevChain c = chn[base + j];
+                if (c.reg0 + c.n <= first_idx) continue;
+                const DevSeed *cs = seeds + c.seed_off;
+                int32_t *srt2 = srt_all + c.seed_off;
+                for (int k = c.n - 1; k >= 0; k--) {
+                    const int idx = c.reg0 + (c.n - 1 - k);
+                    if (idx < first_idx) continue;
+                    // ---- seed_redundant, bwamem.cpp:2922-2983, 64 regs at a time
+                    const DevSeed s = cs[srt2[k]];
+                    int v = 0; bool stopped = false;
+                    for (int i0 = 0; i0 < nr && v < lim && !stopped; i0 += 64) {
+                        const int i = i0 + lane;
+                        bool live = false, brk = false;
+                        if (i < nr) {
+                            const DevReg p = av[i];
+                            live = !(p.qb == -1 && p.qe == -1);
+                            if (live && !(s.rbeg < p.rb || s.rbeg + s.len > p.re || s.qbeg < p.qb || s.qbeg + s.len > p.qe) &&
+                                !(s.len - p.seedlen0 > .1 * l_query)) {
+                                int qd = s.qbeg - p.qb; int64_t rd = s.rbeg - p.rb;
+                                int max_gap = cal_max_gap2(o, qd < rd ? qd : (int)rd);
+                                int w = max_gap < p.w ? max_gap : p.w;
+                                if (qd - rd < w && rd - qd < w) brk = true;
+                                else {
+                                    qd = p.qe - (s.qbeg + s.len); rd = p.re - (s.rbeg + s.len);
+                                    max_gap = cal_max_gap2(o, qd < rd ? qd : (int)rd);
+                                    w = max_gap < p.w ? max_gap : p.w;
+                                    if (qd - rd < w && rd - qd < w) brk = true;
+                                }
+                            }
+                        }
+                        const unsigned long long lm = __ballot(live);
+                        const bool looked = live && v + __popcll(lm & lt_mask) < lim;     // the walk reaches this reg with v < lim
+                        const unsigned long long bm = __ballot(looked && brk);
+                        if (bm) {
+                            const int ib = __ffsll((long long)bm) - 1;
+                            v += __popcll(lm & (ib ? (~0ULL >> (64 - ib)) : 0ULL));          // regs counted before the stopping one
+                            stopped = true;
+                        } else v += __popcll(lm);                                            // (>= lim ends the walk: v is only compared with lim)
+                    }
+                    bool red = false;
+                    if (stopped || v < lim) {                 // the walk ended early: purge unless an overlapping seed lies on another diagonal
+                        bool other = false;
+                        for (int v0 = k + 1; v0 < c.n && !other; v0 += 64) {
+                            const int vv = v0 + lane;
+                            bool b2 = false;
+                            if (vv < c.n && srt2[vv] >= 0) {
+                                const DevSeed t = cs[srt2[vv]];
+                                if (!(t.len < s.len * .95)) {
+                                    if (s.qbeg <= t.qbeg && s.qbeg + s.len - t.qbeg >= s.len >> 2 && t.qbeg - s.qbeg != t.rbeg - s.rbeg) b2 = true;
+                                    if (t.qbeg <= s.qbeg && t.qbeg + t.len - s.qbeg >= s.len >> 2 && s.qbeg - t.qbeg != s.rbeg - t.rbeg) b2 = true;
+                                }
+                            }
+                            other = __ballot(b2) != 0;
+                        }
+                        red = !other;
+                    }
+                    if (red) {
+                        if (lane == 0) { av[idx].qb = -1; av[idx].qe = -1; srt2[k] = -1; }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");      // the next seed's walk re-reads av[] / srt2[] through other lanes
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    } else lim++;
+                }
+            }
+        }
+        int m = 0;
+        for (int i0 = 0; i0 < nr; i0 += 64) {                // bwamem.cpp:1141-1152
+            const int i = i0 + lane;
+            m += __popcll(__ballot(i < nr && av[i].qe > av[i].qb));
+        }
+        if (lane == 0) n_out[r] = m;
+        }
+    }
 }
 
 // Lazy rounds: BEFORE extending, decide whether the next seeds of each read are redundant given the regs kept so far (the
@@ -783,12 +896,19 @@ int bm2_launch_slot_base(bm2_ctx *c, int n_reads, const int64_t *read_base, cons
     return bm2_check(hipGetLastError(), "k_slot_base launch");
 }
 
+int bm2_pf_heavy_threshold() { return PF_HEAVY; }
+
 int bm2_launch_postfilter(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_t *len, const int64_t *read_base,
                           const int32_t *n_chain, const int32_t *n_reg, const DevChain *chn, const DevSeed *seeds,
-                          int32_t *srt_all, DevReg *regs, int32_t *n_out, const int32_t *cursor, const int32_t *perm) {
+                          int32_t *srt_all, DevReg *regs, int32_t *n_out, const int32_t *cursor, const int32_t *perm,
+                          const int32_t *heavy, const int64_t *n_heavy, unsigned long long *item_cur) {
     if (n_reads <= 0) return BM2_OK;
     hipLaunchKernelGGL(k_postfilter, dim3((n_reads + 127) / 128), dim3(128), 0, c->stream, o, n_reads, len, read_base, n_chain,
                        n_reg, chn, seeds, srt_all, regs, n_out, cursor, perm);
+    if (heavy) {                                             // (different reads: order between the two kernels does not matter)
+        hipLaunchKernelGGL(k_postfilter_heavy, dim3(c->n_cu * 4), dim3(256), 0, c->stream, o, heavy, n_heavy, len, read_base, n_chain,
+                           n_reg, chn, seeds, srt_all, regs, n_out, cursor, item_cur);
+    }
     return bm2_check(hipGetLastError(), "k_postfilter launch");
 }
 

@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <string>
+#include <thread>
 #include <vector>
 #include "../../include/bm2.h"
 
@@ -34,7 +35,8 @@ char *dup(const std::string &s) { char *d = (char *)malloc(s.size() + 1); if (d)
 
 extern "C" void bm2_fastq_free(bm2_fastq *f) {
     if (!f) return;
-    for (int i = 0; i < f->n_reads; i++) {
+    if (f->arena) free(f->arena);                              // bm2_fastq_parse_mt: every string lives in one arena
+    else for (int i = 0; i < f->n_reads; i++) {
         if (f->name) free(f->name[i]);
         if (f->comment) free(f->comment[i]);
         if (f->qual) free(f->qual[i]);
@@ -107,3 +109,182 @@ extern "C" int bm2_fastq_parse(const char *text, int64_t n_bytes, bm2_fastq *out
     }
     return BM2_OK;
 }
+
+// ---- the same for the common case at full speed: strict four-line FASTQ records, one or two files, on n_threads host threads.
+// Each file is cut into byte ranges at record starts (a line that begins with '@' whose second-next line begins with '+': a
+// quality line may begin with '@' too, but then the line two below it is a sequence line); every range is scanned for
+// (name, comment, sequence, quality) spans; two files are interleaved record by record as bseq_read_orig does (bwa.cpp:170-216;
+// the shorter file ends the input).  All strings go into ONE arena (three million mallocs per million reads cost more than the
+// scan).  Anything that is not a strict four-line record (FASTA, wrapped sequence lines, stray blank lines) makes the function
+// fall back to the sequential parser above, whose grammar is kseq's; the result is the same either way.
+namespace {
+struct Span { const char *name; int name_len; const char *comment; int comment_len; const char *seq; int len; const char *qual; };
+
+// records of [b, e) where b is a record start; false = not four-line FASTQ
+bool scan_range(const char *b, const char *e, std::vector<Span> &out) {
+    const char *p = b;
+    while (p < e) {
+        if (*p != '@') return false;
+        const char *l1 = (const char *)memchr(p, '\n', (size_t)(e - p));
+        if (!l1) return false;
+        const char *l2 = (const char *)memchr(l1 + 1, '\n', (size_t)(e - l1 - 1));
+        if (!l2 || l2 + 1 >= e || l2[1] != '+') return false;
+        const char *l3 = (const char *)memchr(l2 + 1, '\n', (size_t)(e - l2 - 1));
+        if (!l3) return false;
+        const char *l4 = (const char *)memchr(l3 + 1, '\n', (size_t)(e - l3 - 1));
+        const char *qe = l4 ? l4 : e;
+        Span s;
+        const char *he = l1; if (he > p + 1 && he[-1] == '\r') --he;
+        const char *n0 = p + 1, *n1 = n0;
+        while (n1 < he && !isspace((unsigned char)*n1)) ++n1;
+        if (n1 == n0) return false;                             // an empty name: leave it to kseq's grammar
+        s.name = n0; s.name_len = (int)(n1 - n0);
+        s.comment = n1 < he ? n1 + 1 : he; s.comment_len = (int)(he - s.comment);
+        const char *se = l2; if (se > l1 + 1 && se[-1] == '\r') --se;
+        s.seq = l1 + 1;
+        if (se - s.seq > 0x7fffffff || se == s.seq) return false;
+        s.len = (int)(se - s.seq);
+        for (const char *c = s.seq; c < se; ++c) if (*c == '>' || *c == '+' || *c == '@' || *c == '\r') return false;
+        const char *q1 = qe; if (q1 > l3 + 1 && q1[-1] == '\r') --q1;
+        s.qual = l3 + 1;
+        if (q1 - s.qual != s.len) return false;
+        if (s.name_len > 2 && s.name[s.name_len - 2] == '/' && isdigit((unsigned char)s.name[s.name_len - 1])) s.name_len -= 2;   // trim_readno
+        out.push_back(s);
+        p = l4 ? l4 + 1 : e;
+    }
+    return true;
+}
+
+// first record start at or after p (p itself if it is one)
+const char *next_record(const char *b, const char *p, const char *e) {
+    if (p <= b) return b;
+    const char *q = (const char *)memchr(p - 1, '\n', (size_t)(e - p + 1));
+    while (q && q + 1 < e) {
+        const char *h = q + 1;
+        if (*h == '@') {
+            const char *l1 = (const char *)memchr(h, '\n', (size_t)(e - h));
+            const char *l2 = l1 ? (const char *)memchr(l1 + 1, '\n', (size_t)(e - l1 - 1)) : nullptr;
+            if (l2 && l2 + 1 < e && l2[1] == '+') return h;
+        }
+        q = (const char *)memchr(h, '\n', (size_t)(e - h));
+    }
+    return e;
+}
+
+bool scan_file(const char *text, int64_t n, int n_threads, std::vector<std::vector<Span>> &parts) {
+    const char *b = text, *e = text + n;
+    while (b < e && *b != '@') { if (*b == '>' || !isspace((unsigned char)*b)) return false; ++b; }     // leading blank lines only
+    int P = n_threads;
+    if ((int64_t)P > n / 65536 + 1) P = (int)(n / 65536 + 1);
+    std::vector<const char *> cut((size_t)P + 1);
+    cut[0] = b; cut[(size_t)P] = e;
+    for (int i = 1; i < P; ++i) cut[(size_t)i] = next_record(b, b + (e - b) * i / P, e);
+    for (int i = 1; i <= P; ++i) if (cut[(size_t)i] < cut[(size_t)i - 1]) cut[(size_t)i] = cut[(size_t)i - 1];
+    parts.assign((size_t)P, {});
+    std::vector<char> ok((size_t)P, 1);
+    std::vector<std::thread> th;
+    for (int i = 0; i < P; ++i) th.emplace_back([&, i]() {
+        parts[(size_t)i].reserve((size_t)((cut[(size_t)i + 1] - cut[(size_t)i]) / 200 + 16));
+        ok[(size_t)i] = scan_range(cut[(size_t)i], cut[(size_t)i + 1], parts[(size_t)i]);
+    });
+    for (auto &t : th) t.join();
+    for (char c : ok) if (!c) return false;
+    return true;
+}
+
+int seq_fallback(const char *t1, int64_t n1, const char *t2, int64_t n2, bm2_fastq *out);
+}  // namespace
+
+extern "C" int bm2_fastq_parse_mt(const char *text1, int64_t n1, const char *text2, int64_t n2, int n_threads, bm2_fastq *out) {
+    if (!out || n1 < 0 || (n1 > 0 && !text1) || n2 < 0 || (n2 > 0 && !text2)) { bm2_set_error("bm2_fastq_parse_mt: bad argument"); return BM2_EINVAL; }
+    if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency();
+    if (n_threads < 1) n_threads = 1;
+    const bool paired = text2 != nullptr;
+    std::vector<std::vector<Span>> pa, pb;
+    if (!scan_file(text1, n1, n_threads, pa) || (paired && !scan_file(text2, n2, n_threads, pb))) return seq_fallback(text1, n1, text2, n2, out);
+    // flat record tables per file (pointers only), then the output arrays are filled in parallel
+    auto flat = [](std::vector<std::vector<Span>> &parts, std::vector<const Span *> &first, std::vector<int64_t> &base) {
+        int64_t tot = 0;
+        for (auto &v : parts) { first.push_back(v.data()); base.push_back(tot); tot += (int64_t)v.size(); }
+        base.push_back(tot);
+        return tot;
+    };
+    std::vector<const Span *> fa, fb; std::vector<int64_t> ba, bb;
+    const int64_t ra = flat(pa, fa, ba), rb = paired ? flat(pb, fb, bb) : 0;
+    const int64_t n_rec = paired ? (ra < rb ? ra : rb) : ra;    // bseq_read_orig stops at the shorter file
+    const int64_t n = paired ? 2 * n_rec : n_rec;
+    if (n > 0x7fffffff) { bm2_set_error("bm2_fastq_parse_mt: too many records for one call"); return BM2_EINVAL; }
+    auto rec = [](const std::vector<const Span *> &first, const std::vector<int64_t> &base, int64_t i, size_t &part) -> const Span & {
+        while (i >= base[part + 1]) ++part;
+        return first[part][i - base[part]];
+    };
+    memset(out, 0, sizeof *out);
+    out->n_reads = (int32_t)n;
+    out->off = (int64_t *)malloc((size_t)(n + 1) * 8); out->len = (int32_t *)malloc((size_t)(n + 1) * 4);
+    out->name = (char **)calloc((size_t)n + 1, sizeof(char *)); out->comment = (char **)calloc((size_t)n + 1, sizeof(char *));
+    out->qual = (char **)calloc((size_t)n + 1, sizeof(char *));
+    std::vector<int64_t> soff((size_t)n + 1);                   // offsets of record i's strings in the arena
+    if (!out->off || !out->len || !out->name || !out->comment || !out->qual) { bm2_fastq_free(out); return BM2_ENOMEM; }
+    {   // sizes (sequential: two additions per record)
+        int64_t nb = 0, sb = 0; size_t qa = 0, qb = 0;
+        for (int64_t i = 0; i < n; ++i) {
+            const Span &s = paired ? ((i & 1) ? rec(fb, bb, i >> 1, qb) : rec(fa, ba, i >> 1, qa)) : rec(fa, ba, i, qa);
+            out->off[i] = nb; out->len[i] = s.len; nb += s.len;
+            soff[(size_t)i] = sb; sb += s.name_len + 1 + (s.comment_len ? s.comment_len + 1 : 0) + s.len + 1;
+        }
+        soff[(size_t)n] = sb; out->n_bases = nb;
+        out->enc = (uint8_t *)malloc((size_t)nb + 64); out->arena = (char *)malloc((size_t)sb + 1);
+        if (!out->enc || !out->arena) { bm2_fastq_free(out); return BM2_ENOMEM; }
+    }
+    static uint8_t nt4[256]; static bool nt4_ready = false;
+    if (!nt4_ready) { for (int i = 0; i < 256; ++i) nt4[i] = 4; nt4[(int)'A'] = nt4[(int)'a'] = 0; nt4[(int)'C'] = nt4[(int)'c'] = 1; nt4[(int)'G'] = nt4[(int)'g'] = 2; nt4[(int)'T'] = nt4[(int)'t'] = 3; nt4_ready = true; }
+    int T = n_threads; if ((int64_t)T > n / 4096 + 1) T = (int)(n / 4096 + 1);
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; ++t) th.emplace_back([&, t]() {
+        const int64_t lo = n * t / T, hi = n * (t + 1) / T;
+        size_t qa = 0, qb = 0;
+        for (int64_t i = lo; i < hi; ++i) {
+            const Span &s = paired ? ((i & 1) ? rec(fb, bb, i >> 1, qb) : rec(fa, ba, i >> 1, qa)) : rec(fa, ba, i, qa);
+            uint8_t *d = out->enc + out->off[i];
+            for (int k = 0; k < s.len; ++k) d[k] = nt4[(unsigned char)s.seq[k]];
+            char *a = out->arena + soff[(size_t)i];
+            out->name[i] = a; memcpy(a, s.name, (size_t)s.name_len); a[s.name_len] = 0; a += s.name_len + 1;
+            if (s.comment_len) { out->comment[i] = a; memcpy(a, s.comment, (size_t)s.comment_len); a[s.comment_len] = 0; a += s.comment_len + 1; }
+            out->qual[i] = a; memcpy(a, s.qual, (size_t)s.len); a[s.len] = 0;
+        }
+    });
+    for (auto &t : th) t.join();
+    return BM2_OK;
+}
+
+namespace {
+// the sequential parser on both files, interleaved
+int seq_fallback(const char *t1, int64_t n1, const char *t2, int64_t n2, bm2_fastq *out) {
+    if (!t2) return bm2_fastq_parse(t1, n1, out);
+    bm2_fastq a, b;
+    int rc = bm2_fastq_parse(t1, n1, &a);
+    if (rc) return rc;
+    if ((rc = bm2_fastq_parse(t2, n2, &b))) { bm2_fastq_free(&a); return rc; }
+    const int64_t np = a.n_reads < b.n_reads ? a.n_reads : b.n_reads, n = 2 * np;
+    memset(out, 0, sizeof *out);
+    out->n_reads = (int32_t)n;
+    int64_t nb = 0;
+    for (int64_t i = 0; i < np; ++i) nb += a.len[i] + b.len[i];
+    out->n_bases = nb;
+    out->enc = (uint8_t *)malloc((size_t)nb + 64); out->off = (int64_t *)malloc((size_t)(n + 1) * 8); out->len = (int32_t *)malloc((size_t)(n + 1) * 4);
+    out->name = (char **)calloc((size_t)n + 1, sizeof(char *)); out->comment = (char **)calloc((size_t)n + 1, sizeof(char *));
+    out->qual = (char **)calloc((size_t)n + 1, sizeof(char *));
+    if (!out->enc || !out->off || !out->len || !out->name || !out->comment || !out->qual) { bm2_fastq_free(&a); bm2_fastq_free(&b); bm2_fastq_free(out); return BM2_ENOMEM; }
+    int64_t o = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        bm2_fastq &f = (i & 1) ? b : a; const int64_t k = i >> 1;
+        out->off[i] = o; out->len[i] = f.len[k];
+        memcpy(out->enc + o, f.enc + f.off[k], (size_t)f.len[k]); o += f.len[k];
+        out->name[i] = f.name[k]; f.name[k] = nullptr;          // strings move over
+        out->comment[i] = f.comment[k]; f.comment[k] = nullptr;
+        out->qual[i] = f.qual[k]; f.qual[k] = nullptr;
+    }
+    bm2_fastq_free(&a); bm2_fastq_free(&b);
+    return BM2_OK;
+}
+}  // namespace

@@ -117,14 +117,14 @@ static int dev_rescue_batch(void *user, int32_t n, const uint8_t *qbuf, int64_t 
                             const int64_t *t_pos, const int32_t *t_len, const int32_t *xtra, const bm2_opt *opt, const uint8_t *,
                             bm2_ksw_result *out) {
     bm2_ctx *c = (bm2_ctx *)user;
-    return ksw_batch_run(c, n, qbuf, qbuf_bytes, (const uint8_t *)c->d_ref, q_off, q_len, t_pos, t_len, xtra, opt->mat, opt->o_del, opt->e_del,
+    return ksw_batch_run(c, n, qbuf, qbuf_bytes, c->ix.ref_string, q_off, q_len, t_pos, t_len, xtra, opt->mat, opt->o_del, opt->e_del,
                          opt->o_ins, opt->e_ins, out);
 }
 
 extern "C" int bm2_sam_pe_dev(bm2_ctx *c, const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt *so, const bm2_reads *reads,
                               const bm2_read_text *txt, const bm2_alnreg_t *alnregs, const int64_t *reg_off, int64_t n_processed,
                               const bm2_pestat *pes_in, bm2_pestat *pes_out, char *out, int64_t cap, int64_t *n_out) {
-    if (!c || !c->has_index || !c->d_ref) { bm2_set_error("bm2_sam_pe_dev: the context holds no index"); return BM2_EINVAL; }
+    if (!c || !c->has_index || !c->ix.ref_string) { bm2_set_error("bm2_sam_pe_dev: the context holds no index"); return BM2_EINVAL; }
     return bm2h_sam_pe(idx, opt, so, reads, txt, alnregs, reg_off, n_processed, pes_in, pes_out, out, cap, n_out, dev_rescue_batch, c,
                        bm2_dev_cigar_batch, c);
 }

@@ -23,7 +23,9 @@ int bm2_scan_i32(bm2_ctx *c, const int32_t *in, int64_t n, int64_t *out_excl /* 
 
 int bm2_perm_by_work(bm2_ctx *c, int n, const int32_t *key, int32_t *perm, uint32_t *hist32, int mode);
 
-int bm2_partition_by_work(bm2_ctx *c, int n, const int32_t *key, int thr, int32_t *perm, DevBuf &tmp, DevBuf &scan_tmp, int heavy_first = 0);
+int bm2_partition_by_work(bm2_ctx *c, int n, const int32_t *key, int thr, int32_t *perm, DevBuf &tmp, DevBuf &scan_tmp, int heavy_first = 0,
+                          const int64_t **n_heavy_dev = nullptr);
+int bm2_pf_heavy_threshold();
 
 // smem.hip
 struct BHead; struct P2Task;

@@ -31,7 +31,8 @@ int bm2_launch_extend(bm2_ctx *c, const bm2_opt &opt, const ChainParams &cp, int
 int bm2_launch_slot_base(bm2_ctx *c, int n_reads, const int64_t *read_base, const int32_t *n_reg, int64_t *slot_base);
 int bm2_launch_postfilter(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_t *len, const int64_t *read_base,
                           const int32_t *n_chain, const int32_t *n_reg, const DevChain *chn, const DevSeed *seeds,
-                          int32_t *srt_all, DevReg *regs, int32_t *n_out, const int32_t *cursor, const int32_t *perm);
+                          int32_t *srt_all, DevReg *regs, int32_t *n_out, const int32_t *cursor, const int32_t *perm,
+                          const int32_t *heavy, const int64_t *n_heavy, unsigned long long *item_cur);
 int bm2_launch_reg_gather(bm2_ctx *c, int n_reads, const int64_t *read_base, const int32_t *n_reg, const DevReg *regs,
                           const int64_t *out_off, bm2_reg_t *out, int64_t out_cap);
 
@@ -50,6 +51,7 @@ struct Batch {
     bm2_stats stats{};
     std::vector<int32_t> h_len;              // host copy of the read lengths (per-read filter thresholds)
     DevBuf min_hsp, seed_owner, seed_keep, mat25;
+    DevBuf perm2, part_tmp2;
     DevBuf heads1, ents1, heads2, ents2, pool, recs, tasks, seedc, fill, smem_tmp, heavy1, heavy2;     // seeding task kernels
     int seed_attempts = 0;                      // runs of the seeding kernels the last batch needed (> 1: a workspace grew)
     int64_t seed_cap[5] = { 0, 0, 0, 0, 0 };   // learned workspace sizes: slots pass 1/2, records, pass-2 tasks, pool lists
@@ -63,7 +65,7 @@ void bm2_batch_destroy(bm2_ctx *c) {
                       &b->order, &b->chn, &b->seeds, &b->srt, &b->reg_seed, &b->reg_chain, &b->regs, &b->slot_base, &b->n_chain,
                       &b->n_reg, &b->n_chain0, &b->n_out, &b->out_off, &b->out_regs, &b->smem_sorted, &b->smem_sorted_off, &b->ext_tmp, &b->cursor, &b->n_sa_read, &b->perm, &b->perm_hist, &b->part_tmp, &b->min_hsp, &b->seed_owner, &b->seed_keep, &b->mat25,
                       &b->heads1, &b->ents1, &b->heads2, &b->ents2, &b->pool, &b->recs, &b->tasks, &b->seedc, &b->fill, &b->smem_tmp,
-                      &b->heavy1, &b->heavy2 };
+                      &b->heavy1, &b->heavy2, &b->perm2, &b->part_tmp2 };
     for (DevBuf *d : all) bm2_release(*d);
     delete b;
     c->batch = nullptr;
@@ -365,9 +367,14 @@ static int batch_run_one(bm2_ctx *c, const bm2_opt *opt) {
     static const int thr_reg = getenv("BM2_HEAVY_REG") ? atoi(getenv("BM2_HEAVY_REG")) : 12;
     if (perm_mode_pf == 3 || perm_mode_pf == 4) { if ((rc = bm2_partition_by_work(c, n, (const int32_t *)b->n_reg.p, thr_reg, (int32_t *)b->perm.p, b->part_tmp, b->scan_tmp, perm_mode_pf == 4))) return rc; }
     else if ((rc = bm2_perm_by_work(c, n, (const int32_t *)b->n_reg.p, (int32_t *)b->perm.p, (uint32_t *)b->perm_hist.p, perm_mode_pf))) return rc;
+    // reads with many regs: listed (heavy first) for the wave-per-read purge; counters[9] is its work cursor
+    const int64_t *n_heavy_dev = nullptr;
+    if ((rc = bm2_reserve(b->perm2, (size_t)(n + 1) * 4))) return rc;
+    if ((rc = bm2_partition_by_work(c, n, (const int32_t *)b->n_reg.p, bm2_pf_heavy_threshold(), (int32_t *)b->perm2.p, b->part_tmp2, b->scan_tmp, 1, &n_heavy_dev))) return rc;
     if ((rc = bm2_launch_postfilter(c, cp, n, (const int32_t *)b->len.p, (const int64_t *)b->read_base.p, (const int32_t *)b->n_chain.p,
                                     (const int32_t *)b->n_reg.p, (const DevChain *)b->chn.p, (const DevSeed *)b->seeds.p,
-                                    (int32_t *)b->srt.p, (DevReg *)b->regs.p, (int32_t *)b->n_out.p, (const int32_t *)b->cursor.p, (const int32_t *)b->perm.p))) return rc;
+                                    (int32_t *)b->srt.p, (DevReg *)b->regs.p, (int32_t *)b->n_out.p, (const int32_t *)b->cursor.p, (const int32_t *)b->perm.p,
+                                    (const int32_t *)b->perm2.p, n_heavy_dev, (unsigned long long *)b->counters.p + 9))) return rc;
     if ((rc = bm2_scan_i32(c, (const int32_t *)b->n_out.p, n, (int64_t *)b->out_off.p, b->scan_tmp))) return rc;
     int64_t n_out = 0;
     unsigned long long h_cnt[8];

@@ -139,12 +139,14 @@ __global__ void __launch_bounds__(256) k_part_scatter(int n, const int32_t *__re
         else perm[i - h] = i;
     }
 }
-int bm2_partition_by_work(bm2_ctx *c, int n, const int32_t *key, int thr, int32_t *perm, DevBuf &tmp, DevBuf &scan_tmp, int heavy_first) {
+int bm2_partition_by_work(bm2_ctx *c, int n, const int32_t *key, int thr, int32_t *perm, DevBuf &tmp, DevBuf &scan_tmp, int heavy_first,
+                          const int64_t **n_heavy_dev) {
     if (n <= 0) return BM2_OK;
     int rc = bm2_reserve(tmp, (size_t)(n + 1) * 4 + (size_t)(n + 2) * 8 + 64);
     if (rc) return rc;
     int32_t *flag = (int32_t *)tmp.p;
     int64_t *hpos = (int64_t *)((char *)tmp.p + (((size_t)(n + 1) * 4 + 15) & ~(size_t)15));
+    if (n_heavy_dev) *n_heavy_dev = hpos + n;
     hipLaunchKernelGGL(k_part_flag, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, key, thr, flag);
     if ((rc = bm2_scan_i32(c, flag, n, hpos, scan_tmp))) return rc;
     hipLaunchKernelGGL(k_part_scatter, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, flag, hpos, perm, heavy_first);

@@ -2,11 +2,11 @@
 // suffix-array lookup (get_sa_entries_prefetch, FMI_search.cpp:1257-1375).
 //
 // Reference shape: one thread walks 512 reads round-robin, one backwardExt at a time, prefetching the next CP_OCC
-// blocks (FMI_search.cpp:693-721).  Here: ONE READ PER LANE, tens of thousands of reads in flight per GPU, so the
-// dependent chain of random 64-byte CP_OCC loads (two per backwardExt, FMI_search.cpp:1025-1052) is hidden by
-// occupancy instead of software prefetch.  CP_OCC blocks are 64-byte aligned = one HBM line each; every lane fetches
-// its two lines with four 16-byte loads each.  Memory-bound on random 64-B HBM transactions; no LDS reuse exists
-// between reads (the index is ~10^8 lines, the working set of a wave is 128 unrelated lines per step).
+// blocks (FMI_search.cpp:693-721).  Here the passes are cut into TASK KERNELS with persistent lanes (see below: forward
+// walks per read, backward phases per start position), every backwardExt is QUAD-COOPERATIVE (the four lanes of a quad
+// fetch one 64-byte CP_OCC entry with one coalesced request, 16 bytes each, on the per-base layout CpOccDev), and the
+// dependent chain of random 64-byte loads is hidden by tens of thousands of lanes in flight instead of software
+// prefetch.  Memory-bound on random 64-B HBM transactions; no LDS reuse exists between reads (the index is ~10^8 lines).
 #include "bm2_ctx.h"
 #include "pipeline.h"
 
@@ -539,13 +539,15 @@ k_bwd_heavy(DevIndex ix, SeedParams sp, int pass, const uint8_t *__restrict__ en
     unsigned ovf = 0;
     const unsigned long long lt_mask = lane ? (~0ULL >> (64 - lane)) : 0ULL;
     for (;;) {
-        unsigned long long it = 0;
-        if (lane == 0) it = atomicAdd(item_cur, 1ULL);
+        // one item per wavefront.  EVERY lane executes the atomic (lane 0 adds 1, the others 0) and the body sits in an `if`, not
+        // behind a `continue`: with `if (lane == 0) it = atomicAdd(...)` + `continue` the compiler may structurise the loop so
+        // that lanes 1..63 go round again without the atomic and read item 0 for ever (seen in the purge kernel, notes/NEXT.md)
+        const unsigned long long it = atomicAdd(item_cur, lane == 0 ? 1ULL : 0ULL);
         const int64_t hid = (int64_t)(((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(it >> 32)) << 32) |
                                       (unsigned)__builtin_amdgcn_readfirstlane((unsigned)it));
         if (hid >= n_items) break;
         const int slot = heavy_ids[hid];
-        if (slot < 0 || slot >= slot_cap) continue;
+        if (slot >= 0 && slot < slot_cap) {
         const BHead h = heads[slot];
         int n_prev = (int)(h.x_np >> 16);
         const int x = (int)(h.x_np & 0xffff), r = h.r, L = h.L;
@@ -624,6 +626,7 @@ k_bwd_heavy(DevIndex ix, SeedParams sp, int pass, const uint8_t *__restrict__ en
                     else ovf |= OVF_TASK;
                 }
             }
+        }
         }
     }
     for (int64_t at = rp->pos + lane; at < rp->end; at += 64) if (at < rec_cap) recs[at].rid = 0xffffffffu;

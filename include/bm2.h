@@ -122,6 +122,9 @@ typedef struct {                    /* work counters measured by the kernels the
 
 /* ---- lifetime ---------------------------------------------------------------------------- */
 bm2_ctx *bm2_create(int device, const bm2_index_desc *idx);     /* uploads the index replica to HBM */
+/* a second context on the same device sharing the parent's index replica (own streams / workspaces): overlap two chunks on one
+ * GPU, or split one chunk over several contexts, without another upload.  Valid while the parent lives. */
+bm2_ctx *bm2_create_shared(bm2_ctx *parent);
 void     bm2_destroy(bm2_ctx *c);
 const char *bm2_last_error(void);
 int      bm2_device_count(void);
@@ -241,8 +244,13 @@ typedef struct {
     int32_t n_reads; int32_t pad; int64_t n_bases;
     uint8_t *enc; int64_t *off; int32_t *len;       /* what bm2_reads points at */
     char **name, **comment, **qual;                  /* what bm2_read_text points at */
+    char *arena;                                     /* internal: non-NULL when the strings share one allocation */
 } bm2_fastq;
 int  bm2_fastq_parse(const char *text, int64_t n_bytes, bm2_fastq *out);
+/* The reader of a whole chunk on n_threads host threads (<= 0: all): one file (text2 == NULL) or two files whose records are
+ * interleaved 2i, 2i+1 as bseq_read_orig delivers paired input (bwa.cpp:170-216; the shorter file ends the input).  Same result as
+ * bm2_fastq_parse on each file; strict four-line FASTQ is scanned in parallel, anything else falls back to the sequential parser. */
+int  bm2_fastq_parse_mt(const char *text1, int64_t n1, const char *text2, int64_t n2, int n_threads, bm2_fastq *out);
 void bm2_fastq_free(bm2_fastq *f);
 
 /* Paired-end chunks (reads interleaved: 2i, 2i+1): mem_pestat over the chunk (bwamem_pair.cpp:81-148) unless pes_in is

@@ -145,3 +145,56 @@ print("ok")
         pytest.skip("oracle/_ref reference binary not present (it builds the index)")
     p = subprocess.run(["python", "-c", script], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert p.returncode == 0 and p.stdout.startswith(b"ok"), p.stderr.decode()[-2000:]
+
+
+def test_heavy_read_kernels_on_the_emulator(emu_lib, tmp_path):
+    # the wave-per-item kernels that keep one repeat-rich read or start position from setting the length of a stage:
+    # k_postfilter_heavy (reads with > 24 regs: the purge walk 64 regs at a time) and k_bwd_heavy (candidate lists of > 40 entries).
+    # Reads from high-copy repeat families; regs / SMEMs and the backwardExt count against the oracle.
+    script = r'''
+import sys, os
+sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np, bm2
+bm2.LIB_PATH = %r
+from helpers import build_index, regs_to_records
+from tools import oracle, refio, synth
+d = %r
+
+def case(seed, contigs, fam, n_pick, weight):
+    names, ctg, alts = synth.make_genome(seed, contigs, alt_contigs=0, n_gaps=0, **fam)
+    fa = os.path.join(d, "rep%%d.fa" %% seed)
+    synth.write_fasta(fa, names, ctg)
+    assert build_index(fa)
+    reads = synth.make_reads_se(seed + 1, ctg, 400, L=150)
+    enc, off, ln = refio.pack_reads(reads)
+    ix = oracle.Index(fa)
+    w = weight(ix.run(enc, off, ln), len(ln))
+    sel = [reads[i] for i in sorted(np.argsort(-w)[:n_pick])]
+    enc, off, ln = refio.pack_reads(sel)
+    exp = ix.run(enc, off, ln); ix.close()
+    return fa, enc, off, ln, exp
+
+# 1. many regs per read -> k_postfilter_heavy
+fa, enc, off, ln, exp = case(77, [60000, 30000], dict(n_repeat_families=2, repeat_len=(600, 900), copies=(70, 90), divergence=(0.004, 0.02)), 6,
+                             lambda e, n: np.bincount(e["REGRAW"]["read"], minlength=n).astype(float))
+assert np.bincount(exp["REGRAW"]["read"]).max() > 100
+ctx = bm2.Context(0, fa)
+regs, reg_off, st = ctx.seed_chain_extend(enc, off, ln, bm2.default_opt())
+assert regs_to_records(regs, reg_off).tobytes() == exp["REGPRG"].tobytes() and st["n_ext"] == exp["counters"]["n_ext"]
+ctx.close()
+# 2. long candidate lists -> k_bwd_heavy
+def w2(e, n):
+    w = np.zeros(n); np.add.at(w, e["SMEM"]["read"], e["SMEM"]["s"]); return w
+fa, enc, off, ln, exp = case(91, [200000], dict(n_repeat_families=1, repeat_len=(400, 500), copies=(280, 300), divergence=(0.03, 0.05)), 6, w2)
+ctx = bm2.Context(0, fa)
+sm = ctx.smem(enc, off, ln, bm2.default_opt())
+sc = ctx.batch_fetch("seed_counters", np.uint64)
+assert int(sc[17]) + int(sc[18]) > 0, "no candidate list was long enough for k_bwd_heavy"
+got = np.zeros(len(sm), refio.SMEM_DT)
+for a, b in (("read", "rid"), ("m", "m"), ("n", "n"), ("k", "k"), ("l", "l"), ("s", "s")):
+    got[a] = sm[b]
+assert got.tobytes() == exp["SMEM"].tobytes() and int(sc[9]) == exp["counters"]["n_ext"]
+print("ok")
+''' % (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "bwa-mem2_amd"), emu_lib, str(tmp_path))
+    p = subprocess.run(["python", "-c", script], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
+    assert p.returncode == 0 and p.stdout.startswith(b"ok"), p.stderr.decode()[-2000:]
