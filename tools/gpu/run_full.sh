@@ -20,10 +20,12 @@ if [ -z "$SKIP_PROF" ]; then
   python $R/tools/rocpd_summary.py $(find /tmp/p_f -name "*.db" | head -1) $O/pmc_fetch.md > /dev/null
   timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/p_w -o w -- $B --steps 1 --warmup 1 > /dev/null 2> $O/pmc_w.err
   python $R/tools/rocpd_summary.py $(find /tmp/p_w -name "*.db" | head -1) $O/pmc_write.md > /dev/null
-  for C in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY" "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES" "SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM SQ_WAVES"; do
-    T=$(echo $C | tr ' ' '_' | cut -c1-40)
-    timeout 300 rocprofv3 --pmc $C --kernel-trace -d /tmp/p_$T -o s -- $B --steps 1 --warmup 1 > /dev/null 2> $O/pmc_$T.err
-    python $R/tools/rocpd_summary.py $(find /tmp/p_$T -name "*.db" | head -1) $O/pmc_sq_$T.md > /dev/null
+  rocprofv3 -L > $O/counters_avail.txt 2>&1
+  i=0
+  for C in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS" "SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS"; do
+    i=$((i+1))
+    timeout 300 rocprofv3 --pmc $C --kernel-trace -d /tmp/p_sq$i -o s -- $B --steps 1 --warmup 1 > /dev/null 2> $O/pmc_sq$i.err
+    python $R/tools/rocpd_summary.py $(find /tmp/p_sq$i -name "*.db" | head -1) $O/pmc_sq$i.md > /dev/null
   done
   head -30 $O/kernel_trace.md
 fi
