@@ -245,8 +245,8 @@ def end_to_end(ctx, bm2, texts, opt, paired, n_threads):
                 t = time.perf_counter(); ch = bm2.FastqChunk(t1, t2, n_threads); add("parse", time.perf_counter() - t)
                 t = time.perf_counter(); ctx.batch_upload_chunk(ch); add("h2d", time.perf_counter() - t)
                 t = time.perf_counter(); ctx.batch_run(opt); add("device", time.perf_counter() - t)
-                t = time.perf_counter(); regs, reg_off = ctx.batch_download(); add("d2h", time.perf_counter() - t)
-                t = time.perf_counter(); aln, aln_off = ctx.finish_regs(ch, opt, regs, reg_off); add("a19", time.perf_counter() - t)
+                t = time.perf_counter(); ctx.batch_finish(opt); add("a19", time.perf_counter() - t)
+                t = time.perf_counter(); aln, aln_off = ctx.batch_download_alnregs(); add("d2h", time.perf_counter() - t)
                 q.put((ch, aln, aln_off, n_done))
                 n_done += ch.n_reads
         except Exception as e:                                    # noqa
@@ -276,7 +276,7 @@ def end_to_end(ctx, bm2, texts, opt, paired, n_threads):
     return {"value": n_reads / dt, "unit": "reads/s", "reads": n_reads, "chunks": len(texts), "wall_s": dt, "sam_bytes": out_bytes,
             "host_threads": n_threads or (os.cpu_count() or 1),
             "stage_ms_per_chunk": {k: v / nch * 1e3 for k, v in stage.items()},
-            "scope": "FASTQ text in host memory -> bm2_fastq_parse_mt -> H2D -> device pipeline -> D2H -> a19 -> pairing / mate rescue / "
+            "scope": "FASTQ text in host memory -> bm2_fastq_parse_mt -> H2D -> device pipeline incl. mem_sort_dedup_patch (a19) -> D2H -> pairing / mate rescue / "
                      "CIGAR (device batches) / SAM text in host memory; front and tail of consecutive chunks overlap; file I/O excluded"}
 
 

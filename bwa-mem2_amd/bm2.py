@@ -92,7 +92,7 @@ class Stats(C.Structure):
 EXPORTS = ["bm2_index_load", "bm2_index_free", "bm2_opt_init", "bm2_opt_fill_scmat", "bm2_create", "bm2_create_shared", "bm2_destroy",
            "bm2_last_error", "bm2_device_count", "bm2_bsw", "bm2_smem", "bm2_sal", "bm2_seed_chain_extend",
            "bm2_batch_upload", "bm2_batch_run", "bm2_batch_stats", "bm2_batch_download", "bm2_batch_kernel_ms",
-           "bm2_batch_fetch", "bm2_finish_regs", "bm2_index_build", "bm2_sam_opt_init", "bm2_sam_se", "bm2_sam_pe", "bm2_fastq_parse", "bm2_fastq_parse_mt", "bm2_fastq_free", "bm2_ksw_align2", "bm2_ksw_align2_dev", "bm2_sam_pe_dev", "bm2_sam_se_dev", "bm2_sam_cigar_stats", "bm2_gen_cigar", "bm2_gen_cigar_dev", "bm2_sam_header", "bm2_sam_rescue_stats"]
+           "bm2_batch_fetch", "bm2_batch_finish", "bm2_batch_download_alnregs", "bm2_finish_regs_dev", "bm2_index_build", "bm2_sam_opt_init", "bm2_sam_se", "bm2_sam_pe", "bm2_fastq_parse", "bm2_fastq_parse_mt", "bm2_fastq_free", "bm2_ksw_align2", "bm2_ksw_align2_dev", "bm2_sam_pe_dev", "bm2_sam_se_dev", "bm2_sam_cigar_stats", "bm2_gen_cigar", "bm2_gen_cigar_dev", "bm2_sam_header", "bm2_sam_rescue_stats"]
 
 _lib = None
 
@@ -128,8 +128,6 @@ def lib():
         L.bm2_batch_download.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_int64)]
         L.bm2_batch_kernel_ms.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.c_void_p]
         L.bm2_batch_fetch.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
-        L.bm2_finish_regs.argtypes = [C.POINTER(IndexDesc), C.POINTER(Opt), C.POINTER(Reads), C.c_void_p, C.c_void_p, C.c_void_p,
-                                      C.c_int64, C.c_void_p, C.POINTER(C.c_int64)]
         L.bm2_index_build.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
         L.bm2_sam_opt_init.argtypes = [C.POINTER(SamOpt)]
         L.bm2_sam_opt_init.restype = None
@@ -333,17 +331,47 @@ class Context:
         _chk(lib().bm2_batch_upload(self.h, C.byref(chunk.reads)), "bm2_batch_upload")
         self._n_reads = chunk.n_reads
 
-    def finish_regs(self, chunk, opt, regs, reg_off):
-        """The tail of mem_kernel2_core (mem_sort_dedup_patch + ALT flag, bwamem.cpp:1154-1169) for the regs of a chunk
-        -> (alnregs ALNREG_DT, aln_off)."""
+    def finish_regs(self, reads, opt, regs, reg_off):
+        """The tail of mem_kernel2_core (mem_sort_dedup_patch + ALT flag, bwamem.cpp:1154-1169) on the device for hits given as host
+        arrays (bm2_finish_regs_dev).  reads: a FastqChunk or (enc, off, len) -> (alnregs ALNREG_DT, aln_off)."""
+        if isinstance(reads, FastqChunk):
+            r, n_reads = reads.reads, reads.n_reads
+        else:
+            r, keep = _reads_struct(*reads)
+            n_reads = len(keep[2])
         regs = np.ascontiguousarray(regs, REG_DT)
         reg_off = np.ascontiguousarray(reg_off, np.int64)
         out = np.zeros(max(len(regs), 1), ALNREG_DT)
-        out_off = np.zeros(chunk.n_reads + 1, np.int64)
+        out_off = np.zeros(n_reads + 1, np.int64)
         n = C.c_int64(0)
-        _chk(lib().bm2_finish_regs(C.byref(self._desc), C.byref(opt), C.byref(chunk.reads), regs.ctypes.data, reg_off.ctypes.data,
-                                   out.ctypes.data, len(out), out_off.ctypes.data, C.byref(n)), "bm2_finish_regs")
+        L = lib()
+        L.bm2_finish_regs_dev.argtypes = [C.c_void_p, C.POINTER(Opt), C.POINTER(Reads), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                          C.POINTER(C.c_int64)]
+        _chk(L.bm2_finish_regs_dev(self.h, C.byref(opt), C.byref(r), regs.ctypes.data, reg_off.ctypes.data, out.ctypes.data, len(out),
+                                   out_off.ctypes.data, C.byref(n)), "bm2_finish_regs_dev")
         return out[:n.value], out_off
+
+    def batch_finish(self, opt):
+        """mem_sort_dedup_patch + ALT flag on the regs of the last batch_run, in HBM (bm2_batch_finish)."""
+        L = lib()
+        L.bm2_batch_finish.argtypes = [C.c_void_p, C.POINTER(Opt)]
+        _chk(L.bm2_batch_finish(self.h, C.byref(opt)), "bm2_batch_finish")
+
+    def batch_download_alnregs(self, cap=None):
+        nr = self._n_reads
+        cap = cap or max(1024, 4 * nr)
+        aln_off = np.zeros(nr + 1, np.int64)
+        L = lib()
+        L.bm2_batch_download_alnregs.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_int64)]
+        while True:
+            out = np.zeros(cap, ALNREG_DT)
+            n = C.c_int64(0)
+            rc = L.bm2_batch_download_alnregs(self.h, out.ctypes.data, cap, aln_off.ctypes.data, C.byref(n))
+            if rc == BM2_ECAP:
+                cap = int(n.value)
+                continue
+            _chk(rc, "bm2_batch_download_alnregs")
+            return out[:n.value], aln_off
 
     def sam(self, chunk, opt, so, alnregs, aln_off, n_processed=0, paired=True):
         """SAM alignment lines of a chunk (bm2_sam_pe_dev / bm2_sam_se_dev: rescue and CIGAR alignments as device batches) -> bytes."""
@@ -617,21 +645,6 @@ def sam_se(index_prefix, enc, off, ln, opt, alnregs, reg_off, names, quals=None,
                 continue
             _chk(rc, "bm2_sam_pe" if paired else "bm2_sam_se")
             return (buf.raw[:need.value], list(pes)) if paired else buf.raw[:need.value]
-
-
-def finish_regs(index_prefix, enc, off, ln, opt, regs, reg_off):
-    """Tail of mem_kernel2_core on the host (no GPU): -> (alnregs ALNREG_DT, out_off)."""
-    L = lib()
-    with _DescOf(index_prefix) as d:
-        r, keep = _reads_struct(enc, off, ln)
-        regs = np.ascontiguousarray(regs, REG_DT)
-        reg_off = np.ascontiguousarray(reg_off, np.int64)
-        out = np.zeros(max(len(regs), 1), ALNREG_DT)
-        out_off = np.zeros(len(keep[2]) + 1, np.int64)
-        n = C.c_int64(0)
-        _chk(L.bm2_finish_regs(C.byref(d), C.byref(opt), C.byref(r), regs.ctypes.data, reg_off.ctypes.data, out.ctypes.data,
-                               len(out), out_off.ctypes.data, C.byref(n)), "bm2_finish_regs")
-        return out[:n.value], out_off
 
 
 def index_build(fasta, prefix=None, n_threads=0):

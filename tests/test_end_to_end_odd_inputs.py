@@ -97,7 +97,7 @@ def test_odd_inputs_fastq_to_sam(tmp_path, seed, paired):
     p = subprocess.run([exe, "mem", "-t", "1", "-K", K, fa] + files, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True)
     ref = b"".join(l for l in p.stdout.splitlines(keepends=True) if not l.startswith(b"@PG"))
     out = str(tmp_path / "o.sam")
-    bm2_mem.run(fa, files, int(K), out, regs_of=oracle_regs_fn(fa))
+    bm2_mem.run(fa, files, int(K), out, hits_of=oracle_regs_fn(fa))
     got = open(out, "rb").read()
     if ref != got:
         la, lb = ref.splitlines(), got.splitlines()

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import bm2
-from helpers import ONT2D, ref_binary
+from helpers import ONT2D, oracle_finish_regs, ref_binary
 from tools import oracle, refio, synth
 
 
@@ -34,7 +34,7 @@ def _ours(fa, reads, names, quals, okw=None, sam_opt=None, comments=None, ctx=No
         ix.close()
     opt = bm2.default_opt(**(okw or {}))
     regs, reg_off = _prg_to_regs(exp["REGPRG"], len(ln))
-    aln, aln_off = bm2.finish_regs(fa, enc, off, ln, opt, regs, reg_off)
+    aln, aln_off = oracle_finish_regs(fa, enc, off, ln, opt, regs, reg_off)
     return bm2.sam_se(fa, enc, off, ln, opt, aln, aln_off, names, quals, comments, sam_opt, ctx=ctx)
 
 
@@ -149,7 +149,7 @@ def _pe_run(tmp_path, fa, r1, r2, extra, flag=0, okw=None, ctx=None, **skw):
         ix.close()
     opt = bm2.default_opt(**(okw or {}))
     regs, reg_off = _prg_to_regs(exp["REGPRG"], len(ln))
-    aln, aln_off = bm2.finish_regs(fa, enc, off, ln, opt, regs, reg_off)
+    aln, aln_off = oracle_finish_regs(fa, enc, off, ln, opt, regs, reg_off)
     got, pes = bm2.sam_pe(fa, enc, off, ln, opt, aln, aln_off, names, quals, None, bm2.default_sam_opt(flag=flag, **skw), ctx=ctx)
     return ref, got, pes
 
@@ -230,7 +230,7 @@ def test_fastq_text_to_sam_text(tmp_path):
         ix.close()
     opt = bm2.default_opt()
     regs, reg_off = _prg_to_regs(exp["REGPRG"], len(ln))
-    aln, aln_off = bm2.finish_regs(fa, enc, off, ln, opt, regs, reg_off)
+    aln, aln_off = oracle_finish_regs(fa, enc, off, ln, opt, regs, reg_off)
     got = bm2.sam_se(fa, enc, off, ln, opt, aln, aln_off, names, quals, comments)
     assert ref == got, _diff(ref, got)
 
@@ -262,7 +262,7 @@ def test_sam_pe_chunked_like_the_reference(tmp_path):
             enc, off, ln = refio.pack_reads(reads[lo:hi])
             exp = ix.run(enc, off, ln)
             regs, reg_off = _prg_to_regs(exp["REGPRG"], len(ln))
-            aln, aln_off = bm2.finish_regs(fa, enc, off, ln, opt, regs, reg_off)
+            aln, aln_off = oracle_finish_regs(fa, enc, off, ln, opt, regs, reg_off)
             txt, pes = bm2.sam_pe(fa, enc, off, ln, opt, aln, aln_off, names[lo:hi], quals[lo:hi], None, None, n_processed=lo)
             got += txt; lo = hi; n_chunks += 1
     finally:
@@ -293,7 +293,7 @@ def test_sam_pe_given_insert_size_model(tmp_path):
         ix.close()
     opt = bm2.default_opt()
     regs, reg_off = _prg_to_regs(exp["REGPRG"], len(ln))
-    aln, aln_off = bm2.finish_regs(fa, enc, off, ln, opt, regs, reg_off)
+    aln, aln_off = oracle_finish_regs(fa, enc, off, ln, opt, regs, reg_off)
     pin = [bm2.PeStat(0, 0, 1, 0, 0., 0.) for _ in range(4)]
     pin[1] = bm2.PeStat(max(int(260. - 4. * 20. + .499), 1), int(260. + 4. * 20. + .499), 0, 0, 260., 20.)
     got, pes = bm2.sam_pe(fa, enc, off, ln, opt, aln, aln_off, names, quals, pes_in=pin)
@@ -367,6 +367,6 @@ def test_end_to_end_harness_with_the_oracle_backend(tmp_path):
     out = str(tmp_path / "out.sam")
     from helpers import oracle_regs_fn
     from tools import bm2_mem
-    bm2_mem.run(fa, [f1, f2], K, out, regs_of=oracle_regs_fn(fa))
+    bm2_mem.run(fa, [f1, f2], K, out, hits_of=oracle_regs_fn(fa))
     got = open(out, "rb").read()
     assert ref == got, _diff(ref, got)

@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
-"""End-to-end harness: FASTQ in, SAM out, through the library: bm2_fastq_parse -> bm2_seed_chain_extend (device; there is no
-CPU path, the script fails without a GPU) -> bm2_finish_regs -> bm2_sam_se / bm2_sam_pe.
+"""End-to-end harness: FASTQ in, SAM out, through the library: bm2_fastq_parse -> bm2_batch_upload / run / finish (device: seeding,
+chaining, extension, mem_sort_dedup_patch; there is no CPU path, the script fails without a GPU) -> bm2_sam_se / bm2_sam_pe.
 Chunks the input as `bwa-mem2 mem -K` does (whole reads / pairs until the chunk holds >= K bases, fastmap.cpp:943-949,
 bwa.cpp:62-216), so insert-size models, tie-breaking hashes and pair ids match the reference run with the same -K.
 Output = @SQ header lines + alignment lines (no @PG: that line is the caller's command line).
 
     python tools/bm2_mem.py [-K bases] <idx_prefix> <in1.fq> [in2.fq] > out.sam
 
-run(..., regs_of=f) lets the tests put a stand-in for the device stage (tests/helpers.py does, to check the harness on a CPU)."""
+run(..., hits_of=f) lets the tests put a stand-in for the device stage (tests/helpers.py does, to check the harness on a CPU)."""
 import argparse
 import os
 import sys
@@ -31,8 +31,9 @@ def chunks(n_reads, lens, K, paired):
         lo = hi
 
 
-def run(prefix, fq, K=10000000, out_path="-", threads=0, regs_of=None, device_tail=False):
-    """regs_of(enc, off, ln) -> (regs REG_DT, reg_off): the device stage; None = a Context on GPU 0.
+def run(prefix, fq, K=10000000, out_path="-", threads=0, hits_of=None, device_tail=False):
+    """hits_of(enc, off, ln) -> (alnregs ALNREG_DT, aln_off): the device stage (up to and including mem_sort_dedup_patch); None = a
+    Context on GPU 0.
     device_tail: the mate-rescue and CIGAR alignments of the SAM tail run as device batches too (bm2_sam_pe_dev / bm2_sam_se_dev)."""
     import bm2
     paired = len(fq) == 2
@@ -52,18 +53,19 @@ def run(prefix, fq, K=10000000, out_path="-", threads=0, regs_of=None, device_ta
     lens = np.array([len(s) for s in seqs], np.int64)
     opt, so = bm2.default_opt(), bm2.default_sam_opt(n_threads=threads)
     ctx = None
-    if regs_of is None or device_tail:
+    if hits_of is None or device_tail:
         ctx = bm2.Context(0, prefix)
-    if regs_of is None:
-        regs_of = lambda enc, off, ln: ctx.seed_chain_extend(enc, off, ln, opt)[:2]
+    if hits_of is None:
+        def hits_of(enc, off, ln):
+            ctx.batch_upload(enc, off, ln); ctx.batch_run(opt); ctx.batch_finish(opt)
+            return ctx.batch_download_alnregs()
     out = sys.stdout.buffer if out_path == "-" else open(out_path, "wb")
     out.write(bm2.sam_header(prefix))
     for lo, hi in chunks(len(seqs), lens, K, paired):
         enc = np.concatenate(seqs[lo:hi]) if hi > lo else np.zeros(0, np.uint8)
         ln = lens[lo:hi].astype(np.int32)
         off = np.concatenate([[0], np.cumsum(ln[:-1])]).astype(np.int64)
-        regs, reg_off = regs_of(enc, off, ln)
-        aln, aln_off = bm2.finish_regs(prefix, enc, off, ln, opt, regs, reg_off)
+        aln, aln_off = hits_of(enc, off, ln)
         if paired:
             txt, _ = bm2.sam_pe(prefix, enc, off, ln, opt, aln, aln_off, names[lo:hi], quals[lo:hi], None, so, n_processed=lo, ctx=ctx if device_tail else None)
         else:

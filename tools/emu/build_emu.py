@@ -10,8 +10,8 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-HIP = ["bm2_api.hip", "bsw.hip", "smem.hip", "scan.hip", "chain.hip", "seedsw.hip", "extend.hip", "pipeline.hip", "matesw.hip", "cigar.hip"]
-HOST = ["index_io.cpp", "finish_regs.cpp", "index_build.cpp", "sam_tail.cpp", "fastq_io.cpp"]
+HIP = ["bm2_api.hip", "bsw.hip", "smem.hip", "scan.hip", "chain.hip", "seedsw.hip", "extend.hip", "pipeline.hip", "matesw.hip", "cigar.hip", "finish.hip"]
+HOST = ["index_io.cpp", "index_build.cpp", "sam_tail.cpp", "fastq_io.cpp"]
 
 
 def rewrite(text):

@@ -30,7 +30,7 @@ class OraResult(C.Structure):
                 ("n_regraw", C.c_int64), ("regraw", C.c_void_p), ("n_regprg", C.c_int64), ("regprg", C.c_void_p),
                 ("n_pair", C.c_int64), ("pair", C.c_void_p),
                 ("n_ext", C.c_int64), ("n_ext_sameblk", C.c_int64), ("n_lf", C.c_int64), ("n_sa_lookup", C.c_int64),
-                ("n_sw_cells", C.c_int64)]
+                ("n_sw_cells", C.c_int64), ("n_regfin", C.c_int64), ("regfin", C.c_void_p)]
 
 
 _lib = None
@@ -64,6 +64,8 @@ def lib():
         _lib.ora_band_clamp.argtypes = [C.c_int] * 9
         _lib.ora_pair_class.restype = C.c_int
         _lib.ora_pair_class.argtypes = [C.c_int] * 4
+        _lib.ora_finish_regs.restype = C.c_int64
+        _lib.ora_finish_regs.argtypes = [C.c_void_p, C.POINTER(OraOpt), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     return _lib
 
 
@@ -110,11 +112,26 @@ class Index:
                "CHN0": _arr(r.chn0, r.n_chn0, refio.CHAIN_DT), "SEED0": _arr(r.seed0, r.n_seed0, refio.SEED_DT),
                "CHN1": _arr(r.chn1, r.n_chn1, refio.CHAIN_DT), "SEED1": _arr(r.seed1, r.n_seed1, refio.SEED_DT),
                "REGRAW": _arr(r.regraw, r.n_regraw, refio.REG_DT), "REGPRG": _arr(r.regprg, r.n_regprg, refio.REG_DT),
+               "REGFIN": _arr(r.regfin, r.n_regfin, refio.REG_DT),
                "PAIR": _arr(r.pair, r.n_pair, refio.PAIR_DT),
                "counters": dict(n_ext=r.n_ext, n_ext_sameblk=r.n_ext_sameblk, n_lf=r.n_lf,
                                 n_sa_lookup=r.n_sa_lookup, n_sw_cells=r.n_sw_cells)}
         lib().ora_result_free(C.byref(r))
         return out
+
+
+def _finish(self, enc, off, ln, regs, opt=None):
+    """Tail of mem_kernel2_core (mem_sort_dedup_patch + ALT flag) on REG_DT records grouped by read -> REG_DT records."""
+    opt = opt or default_opt()
+    enc = np.ascontiguousarray(enc, np.uint8)
+    off = np.ascontiguousarray(off, np.int64)
+    regs = np.ascontiguousarray(regs, refio.REG_DT)
+    out = np.zeros(max(len(regs), 1), refio.REG_DT)
+    n = lib().ora_finish_regs(self.h, C.byref(opt), len(ln), enc.ctypes.data, off.ctypes.data, regs.ctypes.data, len(regs), out.ctypes.data)
+    return out[:n]
+
+
+Index.finish_regs = _finish
 
 
 def ksw_extend(query, target, opt, w, end_bonus, h0, cls=None):
