@@ -12,6 +12,8 @@
 #include "chain_dev.h"
 #include "ksort_dev.h"
 
+#define BM2_CHAIN_TIERS 5
+
 // ---------------------------------------------------------------- bntseq helpers (bntseq.cpp:378-402, bntseq.h:87-90)
 static __device__ __forceinline__ int64_t depos(const DevIndex &ix, int64_t pos, int &is_rev) {
     is_rev = pos >= ix.l_pac;
@@ -205,17 +207,21 @@ static __device__ int chain_weight(const WChain &c, const WSeed *seeds) {
     return w < 1 << 30 ? w : (1 << 30) - 1;
 }
 
-__global__ void __launch_bounds__(128, 6)
-k_chain(DevIndex ix, ChainParams o, int n_reads, const int32_t *__restrict__ len, const bm2_smem_t *__restrict__ smems,
-        const int32_t *__restrict__ smem_cnt, const int64_t *__restrict__ smem_off, const int64_t *__restrict__ sa_off,
-        const int64_t *__restrict__ sa_coord, WChain *wchain, WSeed *wseed, BtNode *nodes, int32_t *order,
-        DevChain *chn, DevSeed *seeds_out, int32_t *seed_owner,
-        int32_t *n_chain_out, int32_t *n_reg_out, int32_t *n_chain0_out, const int32_t *__restrict__ perm) {
-    const int tix = blockIdx.x * blockDim.x + threadIdx.x;
-    if (tix >= n_reads) return;
-    const int r = perm[tix];
+// The working set of one read while it is chained: chains, seeds, B-tree nodes, an order array.  The lane-per-read kernel keeps
+// them in the read's slices of global arrays; the wave-per-read kernel of seed-rich reads keeps them in LDS (k_chain_heavy).
+struct ChainWork { WChain *ch; WSeed *sd; BtNode *nodes; int32_t *ord; };
+
+// mem_chain_seeds + mem_chain_flt for read r.  LIGHT: the lane-per-read kernel (global slices); otherwise the caller offers LDS
+// for up to lds_cap seeds in `lw`.
+template <bool LIGHT>
+static __device__ void chain_one_read(const DevIndex &ix, const ChainParams &o, int r, int n_reads, const int32_t *__restrict__ len,
+                                      const bm2_smem_t *__restrict__ smems, const int32_t *__restrict__ smem_cnt,
+                                      const int64_t *__restrict__ smem_off, const int64_t *__restrict__ sa_off,
+                                      const int64_t *__restrict__ sa_coord, WChain *wchain, WSeed *wseed, BtNode *nodes_g, int32_t *order,
+                                      DevChain *chn, DevSeed *seeds_out, int32_t *seed_owner, int32_t *n_chain_out, int32_t *n_reg_out,
+                                      int32_t *n_chain0_out, int heavy_thr, const ChainWork *lw, int lds_cap) {
     const int n_sm = smem_cnt[r];
-    n_chain_out[r] = 0; n_reg_out[r] = 0;
+    n_chain_out[r] = 0; n_reg_out[r] = 0;          // (k_chain never gets here with a read it leaves to k_chain_heavy: one writer per read)
     if (n_chain0_out) n_chain0_out[r] = 0;
     if (n_sm == 0 || len[r] < o.min_seed_len) return;
     if (n_sm <= 1) {                                    // the `pos < num_smem - 1` loop bound of mem_chain_seeds (bwamem.cpp:834):
@@ -229,10 +235,12 @@ k_chain(DevIndex ix, ChainParams o, int n_reads, const int32_t *__restrict__ len
     const int64_t base = sa_off[so];
     const int n_sa = (int)(sa_off[so + n_sm] - base);
     if (n_sa == 0) return;
-    WChain *ch = wchain + base;
-    WSeed *sd = wseed + base;
-    int32_t *ord = order + base;
-    BTree bt; bt.nodes = nodes + base; bt.n_nodes = 0; bt.n_keys = 0; bt.ch = ch;     // <= n_sa/4 + 1 nodes are ever needed
+    const bool in_lds = !LIGHT && n_sa <= lds_cap;
+    WChain *ch = in_lds ? lw->ch : wchain + base;
+    WSeed *sd = in_lds ? lw->sd : wseed + base;
+    int32_t *ord = in_lds ? lw->ord : order + base;
+    BtNode *nodes = in_lds ? lw->nodes : nodes_g + base;
+    BTree bt; bt.nodes = nodes; bt.n_nodes = 0; bt.n_keys = 0; bt.ch = ch;     // <= n_sa/4 + 1 nodes are ever needed
     bt.root = bt_new(bt, 0);
     int n_ch = 0, n_sd = 0;
     RidCache ridc; ridc.lo = 1; ridc.hi = 0; ridc.rid = -1;
@@ -296,7 +304,7 @@ k_chain(DevIndex ix, ChainParams o, int n_reads, const int32_t *__restrict__ len
     if (n > 0) {
         k_introsort(n, ord, [&](int32_t x, int32_t y) { return ch[x].w > ch[y].w; });     // flt_lt, bwamem.cpp:61
         // `kept chain list` reuses the tail of the order array's sibling: indices into ord
-        int32_t *kept_list = (int32_t *)(nodes + base);          // the B-tree is no longer needed
+        int32_t *kept_list = (int32_t *)nodes;                   // the B-tree is no longer needed
         int n_kept = 0;
         ch[ord[0]].kept = 3;
         kept_list[n_kept++] = 0;
@@ -356,6 +364,60 @@ k_chain(DevIndex ix, ChainParams o, int n_reads, const int32_t *__restrict__ len
     }
     n_chain_out[r] = n;
     n_reg_out[r] = 0;              // set by k_chain_finish
+}
+
+__global__ void __launch_bounds__(128, 6)
+k_chain(DevIndex ix, ChainParams o, int n_reads, const int32_t *__restrict__ len, const bm2_smem_t *__restrict__ smems,
+        const int32_t *__restrict__ smem_cnt, const int64_t *__restrict__ smem_off, const int64_t *__restrict__ sa_off,
+        const int64_t *__restrict__ sa_coord, WChain *wchain, WSeed *wseed, BtNode *nodes, int32_t *order,
+        DevChain *chn, DevSeed *seeds_out, int32_t *seed_owner,
+        int32_t *n_chain_out, int32_t *n_reg_out, int32_t *n_chain0_out, const int32_t *__restrict__ perm, int heavy_thr,
+        const int32_t *__restrict__ n_sa_read) {
+    const int tix = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tix >= n_reads) return;
+    if (heavy_thr >= 0 && n_sa_read[perm[tix]] > heavy_thr) return;          // a whole wavefront takes this read (k_chain_heavy)
+    chain_one_read<true>(ix, o, perm[tix], n_reads, len, smems, smem_cnt, smem_off, sa_off, sa_coord, wchain, wseed, nodes, order, chn, seeds_out,
+                         seed_owner, n_chain_out, n_reg_out, n_chain0_out, heavy_thr, nullptr, 0);
+}
+
+// Seed-rich reads, ONE READ PER WAVEFRONT.  Chaining is sequential per read by definition (every seed meets the B-tree the earlier
+// ones built) and costs ~25 dependent memory accesses per seed: in the lane-per-read kernel a read with 600 seeds kept one lane busy
+// for 12 ms at global-memory latency while the other million reads took 2 ms.  Here lane 0 runs the same code with the read's
+// chains, seeds, B-tree nodes and order array in LDS (~130 bytes per seed), where a dependent access costs ~60 ns; the launch is
+// tiered by seed count so that a block claims only the LDS its reads need (tier capacity `cap`: reads with lo < seeds <= cap; the
+// last tier also takes the reads beyond its capacity and works on their global slices).  Items come from the heavy-first list of
+// the partition; every tier scans it and skips what is not its own.
+__global__ void __launch_bounds__(64)
+k_chain_heavy(DevIndex ix, ChainParams o, int n_reads, const int32_t *__restrict__ len, const bm2_smem_t *__restrict__ smems,
+              const int32_t *__restrict__ smem_cnt, const int64_t *__restrict__ smem_off, const int64_t *__restrict__ sa_off,
+              const int64_t *__restrict__ sa_coord, WChain *wchain, WSeed *wseed, BtNode *nodes, int32_t *order,
+              DevChain *chn, DevSeed *seeds_out, int32_t *seed_owner, int32_t *n_chain_out, int32_t *n_reg_out, int32_t *n_chain0_out,
+              const int32_t *__restrict__ heavy /* read ids, heavy ones first */, const int64_t *__restrict__ n_heavy_p,
+              const int32_t *__restrict__ n_sa_read, int lo, int cap, int last_tier, unsigned long long *item_cur) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t chain_lds[];
+    const int lane = threadIdx.x;
+    ChainWork lw;
+    {
+        size_t at = 0;
+        lw.ch = (WChain *)(chain_lds + at); at += (size_t)cap * sizeof(WChain);
+        lw.nodes = (BtNode *)(chain_lds + at); at += (size_t)(cap / 4 + 2) * sizeof(BtNode);
+        lw.sd = (WSeed *)(chain_lds + at); at += (size_t)cap * sizeof(WSeed);
+        lw.ord = (int32_t *)(chain_lds + at);
+    }
+    const int64_t n_heavy = *n_heavy_p;
+    for (;;) {
+        // (every lane takes part in the atomic and the body sits in an `if`: see the note on work loops in smem.hip)
+        const unsigned long long it = atomicAdd(item_cur, lane == 0 ? 1ULL : 0ULL);
+        const int64_t hid = (int64_t)(((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(it >> 32)) << 32) |
+                                      (unsigned)__builtin_amdgcn_readfirstlane((unsigned)it));
+        if (hid >= n_heavy) break;
+        const int r = heavy[hid];
+        const int ns = n_sa_read[r];
+        const bool mine = ns > lo && (ns <= cap || last_tier);
+        if (mine && lane == 0)
+            chain_one_read<false>(ix, o, r, n_reads, len, smems, smem_cnt, smem_off, sa_off, sa_coord, wchain, wseed, nodes, order, chn, seeds_out,
+                                  seed_owner, n_chain_out, n_reg_out, n_chain0_out, -1, &lw, cap);
+    }
 }
 
 // After the (optional) short-seed filter: reference window, extension order and reg slots of every kept chain
@@ -429,14 +491,40 @@ int bm2_launch_chain_finish(bm2_ctx *c, const ChainParams &o, int n_reads, const
     return bm2_check(hipGetLastError(), "k_chain_finish launch");
 }
 
+size_t bm2_chain_lds_bytes(int cap) { return (size_t)cap * (sizeof(WChain) + sizeof(WSeed) + 4) + (size_t)(cap / 4 + 2) * sizeof(BtNode) + 16; }
+
 int bm2_launch_chain(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_t *len, const bm2_smem_t *smems,
                      const int32_t *smem_cnt, const int64_t *smem_off, const int64_t *sa_off, const int64_t *sa_coord,
                      WChain *wchain, WSeed *wseed, BtNode *nodes, int32_t *order, DevChain *chn, DevSeed *seeds_out,
                      int32_t *seed_owner,
-                     int32_t *n_chain_out, int32_t *n_reg_out, int32_t *n_chain0_out, const int32_t *perm) {
+                     int32_t *n_chain_out, int32_t *n_reg_out, int32_t *n_chain0_out, const int32_t *perm,
+                     int heavy_thr, const int64_t *n_heavy_dev, const int32_t *n_sa_read, unsigned long long *item_cur /* one per tier */) {
     if (n_reads <= 0) return BM2_OK;
-    hipLaunchKernelGGL(k_chain, dim3((n_reads + 127) / 128), dim3(128), 0, c->stream, c->ix, o, n_reads, len, smems, smem_cnt,
+    hipStream_t s = c->stream;
+    const bool heavy = heavy_thr >= 0 && n_heavy_dev != nullptr;
+    if (heavy) (void)hipEventRecord(c->ev_fork, s);
+    hipLaunchKernelGGL(k_chain, dim3((n_reads + 127) / 128), dim3(128), 0, s, c->ix, o, n_reads, len, smems, smem_cnt,
                        smem_off, sa_off, sa_coord, wchain, wseed, nodes, order, chn, seeds_out, seed_owner,
-                       n_chain_out, n_reg_out, n_chain0_out, perm);
+                       n_chain_out, n_reg_out, n_chain0_out, perm, heavy ? heavy_thr : -1, n_sa_read);
+    if (heavy) {
+        // tiers by seed count (LDS per block follows the tier): the launches run beside the lane-per-read kernel and each other
+        static const int caps[BM2_CHAIN_TIERS] = { 64, 128, 256, 512, 1184 };
+        static bool attr_set = false;
+        if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_chain_heavy, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bm2_chain_lds_bytes(caps[BM2_CHAIN_TIERS - 1])); attr_set = true; }
+        int lo = heavy_thr;
+        for (int t = 0; t < BM2_CHAIN_TIERS; t++) {
+            if (caps[t] <= lo) continue;
+            hipStream_t sk = c->side_stream[2 + t];
+            const size_t lds = bm2_chain_lds_bytes(caps[t]);
+            int per_cu = (int)(160 * 1024 / lds); if (per_cu < 1) per_cu = 1; if (per_cu > 16) per_cu = 16;
+            (void)hipStreamWaitEvent(sk, c->ev_fork, 0);
+            hipLaunchKernelGGL(k_chain_heavy, dim3(c->n_cu * per_cu), dim3(64), lds, sk, c->ix, o, n_reads, len, smems, smem_cnt, smem_off, sa_off,
+                               sa_coord, wchain, wseed, nodes, order, chn, seeds_out, seed_owner, n_chain_out, n_reg_out, n_chain0_out, perm,
+                               n_heavy_dev, n_sa_read, lo, caps[t], t == BM2_CHAIN_TIERS - 1 ? 1 : 0, item_cur + t);
+            (void)hipEventRecord(c->ev_join[2 + t], sk);
+            (void)hipStreamWaitEvent(s, c->ev_join[2 + t], 0);
+            lo = caps[t];
+        }
+    }
     return bm2_check(hipGetLastError(), "k_chain launch");
 }

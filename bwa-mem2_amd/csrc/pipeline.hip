@@ -16,7 +16,8 @@ int bm2_launch_chain(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_
                      const int32_t *smem_cnt, const int64_t *smem_off, const int64_t *sa_off, const int64_t *sa_coord,
                      WChain *wchain, WSeed *wseed, BtNode *nodes, int32_t *order, DevChain *chn, DevSeed *seeds_out,
                      int32_t *seed_owner,
-                     int32_t *n_chain_out, int32_t *n_reg_out, int32_t *n_chain0_out, const int32_t *perm);
+                     int32_t *n_chain_out, int32_t *n_reg_out, int32_t *n_chain0_out, const int32_t *perm,
+                     int heavy_thr, const int64_t *n_heavy_dev, const int32_t *n_sa_read, unsigned long long *item_cur);
 int bm2_launch_chain_finish(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_t *len, const int64_t *read_base,
                             const int32_t *n_chain, DevChain *chn, DevSeed *seeds_out, int32_t *srt_out, int32_t *reg_seed,
                             int32_t *reg_chain, int32_t *n_reg_out);
@@ -346,13 +347,17 @@ static int batch_run_one(bm2_ctx *c, const bm2_opt *opt) {
     static const int perm_mode = getenv("BM2_PERM_MODE") ? atoi(getenv("BM2_PERM_MODE")) : 4;      // chaining: heavy reads (> 40 seeds) first, stable
     static const int perm_mode_pf = getenv("BM2_PERM_MODE_PF") ? atoi(getenv("BM2_PERM_MODE_PF")) : 0;   // post-filter: read order
     static const int thr_sa = getenv("BM2_HEAVY_SA") ? atoi(getenv("BM2_HEAVY_SA")) : 40;
-    if (perm_mode == 3 || perm_mode == 4) { if ((rc = bm2_partition_by_work(c, n, (const int32_t *)b->n_sa_read.p, thr_sa, (int32_t *)b->perm.p, b->part_tmp, b->scan_tmp, perm_mode == 4))) return rc; }
+    const int64_t *n_heavy_chain = nullptr;                      // set when the permutation lists the seed-rich reads first: k_chain_heavy takes them
+    static const int chain_heavy = getenv("BM2_CHAIN_HEAVY") ? atoi(getenv("BM2_CHAIN_HEAVY")) : 1;
+    if (perm_mode == 3 || perm_mode == 4) { if ((rc = bm2_partition_by_work(c, n, (const int32_t *)b->n_sa_read.p, thr_sa, (int32_t *)b->perm.p, b->part_tmp, b->scan_tmp, perm_mode == 4, perm_mode == 4 && chain_heavy ? &n_heavy_chain : nullptr))) return rc; }
     else if ((rc = bm2_perm_by_work(c, n, (const int32_t *)b->n_sa_read.p, (int32_t *)b->perm.p, (uint32_t *)b->perm_hist.p, perm_mode))) return rc;
     if ((rc = bm2_launch_chain(c, cp, n, (const int32_t *)b->len.p, (const bm2_smem_t *)b->smem.p, (const int32_t *)b->smem_cnt.p,
                                (const int64_t *)b->smem_off.p, (const int64_t *)b->sa_off.p, (const int64_t *)b->sa_coord.p,
                                (WChain *)b->wchain.p, (WSeed *)b->wseed.p, (BtNode *)b->nodes.p, (int32_t *)b->order.p,
                                (DevChain *)b->chn.p, (DevSeed *)b->seeds.p, (int32_t *)b->seed_owner.p,
-                               (int32_t *)b->n_chain.p, (int32_t *)b->n_reg.p, (int32_t *)b->n_chain0.p, (const int32_t *)b->perm.p))) return rc;
+                               (int32_t *)b->n_chain.p, (int32_t *)b->n_reg.p, (int32_t *)b->n_chain0.p, (const int32_t *)b->perm.p,
+                               n_heavy_chain ? thr_sa : -1, n_heavy_chain, (const int32_t *)b->n_sa_read.p,
+                               (unsigned long long *)b->counters.p + 10))) return rc;      // counters[10..14]: work cursors of the tiers
     if (any_flt) {
         if ((rc = bm2_launch_seed_filter(c, cp, (const int8_t *)b->mat25.p, n, n_sa, (const uint8_t *)b->enc.p, (const int64_t *)b->off.p,
                                          (const int32_t *)b->len.p, (const int32_t *)b->min_hsp.p, (const int64_t *)b->read_base.p,
