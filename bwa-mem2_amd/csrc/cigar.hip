@@ -166,6 +166,7 @@ extern "C" int bm2_gen_cigar_dev(bm2_ctx *c, const bm2_opt *opt, int32_t n, cons
     if (opt->e_del <= 0 || opt->e_ins <= 0) { bm2_set_error("bm2_gen_cigar_dev: gap extension penalties must be > 0"); return BM2_EINVAL; }
     int rc = bm2_check(hipSetDevice(c->device), "hipSetDevice");
     if (rc) return rc;
+    TailProf prof("gen_cigar_dev");
     CigarPrm prm; memset(&prm, 0, sizeof prm);
     for (int a = 0; a < 25; ++a) prm.mat[a] = opt->mat[a];
     prm.o_del = opt->o_del; prm.e_del = opt->e_del; prm.o_ins = opt->o_ins; prm.e_ins = opt->e_ins; prm.l_pac = c->ix.l_pac;
@@ -191,7 +192,9 @@ extern "C" int bm2_gen_cigar_dev(bm2_ctx *c, const bm2_opt *opt, int32_t n, cons
         co += T.cg_cap; mo += T.md_cap;
     }
     // lanes of a wavefront run their tasks side by side: neighbours should cost alike
+    prof.mark("tasks");
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost[(size_t)a] > cost[(size_t)b]; });
+    prof.mark("sort");
     DevBuf &b_seq = c->b_ref, &b_task = c->b_qer, &b_res = c->b_pairs, &b_scr = c->b_misc;
     const size_t task_bytes = ((size_t)n * sizeof(CigarTask) + 15) & ~(size_t)15, ord_bytes = (size_t)n * sizeof(int);
     const size_t z_bytes = ((size_t)zo + 15) & ~(size_t)15, eh_bytes = (size_t)eo * sizeof(int2), cg_bytes = (size_t)co * 4, md_bytes = (size_t)mo;
@@ -204,6 +207,7 @@ extern "C" int bm2_gen_cigar_dev(bm2_ctx *c, const bm2_opt *opt, int32_t n, cons
     CigarTask *d_task = (CigarTask *)b_task.p; int *d_order = (int *)((char *)b_task.p + task_bytes);
     CigarRes *d_res = (CigarRes *)b_res.p; uint32_t *d_cg = (uint32_t *)((char *)b_res.p + res_bytes); char *d_md = (char *)d_cg + cg_bytes;
     uint8_t *d_z = (uint8_t *)b_scr.p; int2 *d_eh = (int2 *)((char *)b_scr.p + z_bytes);
+    prof.mark("reserve");
     rc = bm2_check(hipMemcpyAsync(b_seq.p, seqs, (size_t)seq_bytes, hipMemcpyHostToDevice, s), "H2D queries");
     if (!rc) rc = bm2_check(hipMemcpyAsync(d_task, tasks.data(), (size_t)n * sizeof(CigarTask), hipMemcpyHostToDevice, s), "H2D tasks");
     if (!rc) rc = bm2_check(hipMemcpyAsync(d_order, order.data(), ord_bytes, hipMemcpyHostToDevice, s), "H2D order");
@@ -211,13 +215,16 @@ extern "C" int bm2_gen_cigar_dev(bm2_ctx *c, const bm2_opt *opt, int32_t n, cons
     hipLaunchKernelGGL(k_gen_cigar, dim3((n + 63) / 64), dim3(64), 0, s, c->ix.ref_string, (const uint8_t *)b_seq.p, d_task, d_order, n, prm,
                        d_z, d_eh, d_cg, d_md, d_res);
     rc = bm2_check(hipGetLastError(), "k_gen_cigar launch");
+    if (prof.on) { (void)hipStreamSynchronize(s); prof.mark("H2D + kernel"); }
     std::vector<CigarRes> h_res((size_t)n);
     std::vector<uint32_t> h_cg((size_t)co); std::vector<char> h_md((size_t)mo + 1);
+    prof.mark("host buffers");
     if (!rc) rc = bm2_check(hipMemcpyAsync(h_res.data(), d_res, (size_t)n * sizeof(CigarRes), hipMemcpyDeviceToHost, s), "D2H results");
     if (!rc && co) rc = bm2_check(hipMemcpyAsync(h_cg.data(), d_cg, cg_bytes, hipMemcpyDeviceToHost, s), "D2H cigars");
     if (!rc && mo) rc = bm2_check(hipMemcpyAsync(h_md.data(), d_md, md_bytes, hipMemcpyDeviceToHost, s), "D2H MD");
     if (!rc) rc = bm2_check(hipStreamSynchronize(s), "bm2_gen_cigar_dev sync");
     if (rc) return rc;
+    prof.mark("D2H");
     int64_t oc = 0, om = 0;                                     // pack into the caller's arrays, as bm2_gen_cigar lays them out
     for (int i = 0; i < n; ++i) {
         const CigarRes &R = h_res[(size_t)i]; const CigarTask &T = tasks[(size_t)i];
@@ -227,6 +234,7 @@ extern "C" int bm2_gen_cigar_dev(bm2_ctx *c, const bm2_opt *opt, int32_t n, cons
         if (md && om + R.md_len + 1 <= md_cap) memcpy(md + om, h_md.data() + T.md_off, (size_t)R.md_len + 1);
         oc += R.n_cigar; om += R.md_len + 1;
     }
+    prof.mark("pack");
     *cigar_need = oc; *md_need = om;
     if (oc > cigar_cap || om > md_cap || (oc && !cigar) || (om && !md)) return BM2_ECAP;
     return BM2_OK;

@@ -22,3 +22,19 @@ int bm2h_sam_pe(const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt
 int bm2h_sam_se(const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt *so, const bm2_reads *reads, const bm2_read_text *txt,
                 bm2_alnreg_t *alnregs, const int64_t *reg_off, int64_t n_processed, char *out, int64_t cap, int64_t *n_out,
                 bm2h_cigar_batch_fn cfn, void *cuser);
+
+// Phase clock of the tail (BM2_TAIL_PROF=1 prints the phases of every call to stderr): where the host time of a chunk goes.
+#include <chrono>
+#include <stdio.h>
+#include <stdlib.h>
+struct TailProf {
+    bool on; const char *who; std::chrono::steady_clock::time_point t0, t;
+    explicit TailProf(const char *w) : on(getenv("BM2_TAIL_PROF") != nullptr), who(w) { t0 = t = std::chrono::steady_clock::now(); }
+    void mark(const char *what) {
+        if (!on) return;
+        const auto n = std::chrono::steady_clock::now();
+        fprintf(stderr, "[tail] %-14s %-22s %8.1f ms\n", who, what, std::chrono::duration<double, std::milli>(n - t).count());
+        t = n;
+    }
+    ~TailProf() { if (on) fprintf(stderr, "[tail] %-14s %-22s %8.1f ms\n", who, "TOTAL", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); }
+};

@@ -40,6 +40,7 @@ static int ksw_batch_run(bm2_ctx *c, int32_t n, const uint8_t *qbuf, int64_t qbu
     if (n == 0) return BM2_OK;
     int rc = bm2_check(hipSetDevice(c->device), "hipSetDevice");
     if (rc) return rc;
+    TailProf prof("ksw_batch");
     KswPrm prm;
     int lo = 127, hi = 0;
     for (int a = 0; a < 25; ++a) { prm.mat[a] = mat[a]; if (mat[a] < lo) lo = mat[a]; if (mat[a] > hi) hi = mat[a]; }
@@ -65,7 +66,9 @@ static int ksw_batch_run(bm2_ctx *c, int32_t n, const uint8_t *qbuf, int64_t qbu
         const int P = (T.xtra & KSW_XBYTE) ? 16 : 8;
         return ((uint64_t)(P == 8) << 62) | ((uint64_t)((T.qlen + P - 1) / P) << 40) | (uint64_t)(uint32_t)T.tlen;
     };
+    prof.mark("tasks");
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return key(a) > key(b); });
+    prof.mark("sort");
     // rows (tasks) per block: as many as fit 64 KB of LDS, the per-workgroup amount every launch may ask for without further ado
     int rows = 16;
     size_t lds = 32 + (size_t)rows * 9 * slen_max * 16 * 2;
@@ -91,6 +94,7 @@ static int ksw_batch_run(bm2_ctx *c, int32_t n, const uint8_t *qbuf, int64_t qbu
                        d_tbase ? d_tbase : (const uint8_t *)b_seq.p, d_task, d_order, n, prm, slen_max, (bm2_ksw_result *)b_out.p,
                        (unsigned long long *)b_misc.p);
     rc = bm2_check(hipGetLastError(), "k_ksw_align2 launch");
+    if (prof.on) { (void)hipStreamSynchronize(s); prof.mark("H2D + kernel"); }
     if (!rc) rc = bm2_check(hipMemcpyAsync(out, b_out.p, (size_t)n * sizeof(bm2_ksw_result), hipMemcpyDeviceToHost, s), "D2H results");
     if (!rc) rc = bm2_check(hipStreamSynchronize(s), "ksw batch sync");
     return rc;

@@ -1156,8 +1156,10 @@ CgStats g_cigar;                    // counters of the last bm2_sam_pe / bm2_sam
 // the recorded tasks of a dry pass -> unique tasks -> one call of the hook -> memo
 int cigar_session_batch(const bm2_index_desc *idx, const bm2_opt *opt, const bm2_reads *reads, int64_t enc_bytes,
                         std::vector<std::vector<CgTask>> &recs, bm2h_cigar_batch_fn cfn, void *cuser, CgMemo &M) {
+    TailProf prof("cigar_session");
     std::vector<CgTask> tasks;
     for (auto &v : recs) for (const CgTask &t : v) if (M.at.emplace(t, (int)tasks.size()).second) tasks.push_back(t);
+    prof.mark("dedup (hash)");
     const size_t n = tasks.size();
     g_cigar.planned = (long long)n;
     if (n == 0) return BM2_OK;
@@ -1173,6 +1175,7 @@ int cigar_session_batch(const bm2_index_desc *idx, const bm2_opt *opt, const bm2
     }
     M.score.resize(n); M.nm.resize(n); M.n_cigar.resize(n); M.cigar_off.resize(n); M.md_off.resize(n);
     M.cigar.resize((size_t)ccap + 1); M.md.resize((size_t)mcap + 1);
+    prof.mark("marshal");
     return cfn(cuser, opt, (int32_t)n, reads->enc, enc_bytes, q_off.data(), q_len.data(), rb.data(), re.data(), w.data(), M.score.data(),
                M.nm.data(), M.n_cigar.data(), M.cigar_off.data(), M.cigar.data(), ccap + 1, M.md_off.data(), M.md.data(), mcap + 1);
 }
@@ -1338,9 +1341,11 @@ int bm2h_sam_pe(const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt
     }
     if (!idx->ref_string || !idx->ann_offset || !idx->ann_len || !idx->ann_name) { bm2_set_error("bm2_sam_pe: the index descriptor needs ref_string, contig lengths and names"); return BM2_EINVAL; }
     Ref R = { idx->l_pac, idx->ref_string, idx->n_seqs, idx->ann_offset, idx->ann_name, idx->ann_anno };
+    TailProf prof("sam_pe");
     const int n = reads->n_reads;
     std::vector<std::vector<bm2_alnreg_t>> regs((size_t)n);
     for (int i = 0; i < n; ++i) regs[(size_t)i].assign(alnregs + reg_off[i], alnregs + reg_off[i + 1]);
+    prof.mark("hit lists");
     PeStat pes[4];
     if (pes_in) for (int d = 0; d < 4; ++d) { pes[d].low = pes_in[d].low; pes[d].high = pes_in[d].high; pes[d].failed = pes_in[d].failed; pes[d].avg = pes_in[d].avg; pes[d].std = pes_in[d].std; }
     else pestat(opt, so, idx->l_pac, regs, pes);                 // per chunk, as mem_process_seqs does (bwamem.cpp:1366-1370)
@@ -1351,6 +1356,7 @@ int bm2h_sam_pe(const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt
     // run them all as one batch (here: host threads over single tasks), then process the pairs with the results at hand.
     // so->rescue_inline = 1 aligns inside the pair loop as mem_sam_pe does; the output is the same.
     const int n_pairs = n >> 1;
+    prof.mark("pestat + names");
     std::vector<RescueTask> tasks;
     std::vector<int64_t> task_off;
     const bool batch = !(so->flag & F_NO_RESCUE) && !so->rescue_inline;
@@ -1369,6 +1375,7 @@ int bm2h_sam_pe(const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt
                 }
         };
         run_threads(n_threads < n_blk ? n_threads : n_blk, plan);
+        prof.mark("rescue plan");
         task_off.assign((size_t)n_pairs + 1, 0);
         for (auto &v : part) { for (auto &t : v) task_off[(size_t)t.pair + 1]++; tasks.insert(tasks.end(), v.begin(), v.end()); }
         for (int pi = 0; pi < n_pairs; ++pi) task_off[(size_t)pi + 1] += task_off[(size_t)pi];
@@ -1397,9 +1404,11 @@ int bm2h_sam_pe(const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt
                 }
             });
             std::vector<bm2_ksw_result> res((size_t)tot);
+            prof.mark("rescue flatten");
             const int rc = fn(user, (int32_t)tot, qbuf.data(), qb, q_off.data(), q_len.data(), t_pos.data(), t_len.data(), xtra.data(), opt,
                               idx->ref_string, res.data());
             if (rc) return rc;
+            prof.mark("rescue batch");
             for (long long t = 0; t < tot; ++t) {
                 const bm2_ksw_result &r = res[(size_t)t];
                 KswResult &o = tasks[(size_t)t].res;
@@ -1431,6 +1440,7 @@ int bm2h_sam_pe(const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt
         return sam_pe(opt, so, R, idx->ann_len, pes, (uint64_t)((n_processed >> 1) + pi), io, a2, part, pre, n_pre, st);
     };
     CgMemo memo;
+    prof.mark("rescue results");
     g_cigar.planned = 0; g_cigar.used = 0; g_cigar.missed = 0;
     if (cfn) {                                                   // CIGAR session: dry pass on copies of the hit lists, batch, then the real pass
         int n_threads = so->n_threads > 0 ? so->n_threads : (int)std::thread::hardware_concurrency();
@@ -1450,10 +1460,12 @@ int bm2h_sam_pe(const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt
                 t_cg = CgSession();
             }
         });
+        prof.mark("dry pass");
         int64_t enc_bytes = 0;
         for (int i = 0; i < n; ++i) if (reads->off[i] + reads->len[i] > enc_bytes) enc_bytes = reads->off[i] + reads->len[i];
         const int rc = cigar_session_batch(idx, opt, reads, enc_bytes, recs, cfn, cuser, memo);
         if (rc) return rc;
+        prof.mark("cigar session");
     }
     std::string s;
     const bool ok = run_blocks(n_pairs, so->n_threads, s, [&](int pi, std::string &part) {
@@ -1463,6 +1475,7 @@ int bm2h_sam_pe(const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt
         return r;
     });
     if (!ok) { bm2_set_error("bm2_sam_pe: pair %s has a hit whose CIGAR cannot be generated (range outside the reference)", s.c_str()); return BM2_EINVAL; }
+    prof.mark("real pass + join");
     *n_out = (int64_t)s.size();
     if ((int64_t)s.size() > cap) return BM2_ECAP;
     if (out && !s.empty()) memcpy(out, s.data(), s.size());
