@@ -92,7 +92,7 @@ class Stats(C.Structure):
 EXPORTS = ["bm2_index_load", "bm2_index_free", "bm2_opt_init", "bm2_opt_fill_scmat", "bm2_create", "bm2_create_shared", "bm2_destroy",
            "bm2_last_error", "bm2_device_count", "bm2_bsw", "bm2_smem", "bm2_sal", "bm2_seed_chain_extend",
            "bm2_batch_upload", "bm2_batch_run", "bm2_batch_stats", "bm2_batch_download", "bm2_batch_kernel_ms",
-           "bm2_batch_fetch", "bm2_batch_finish", "bm2_batch_download_alnregs", "bm2_finish_regs_dev", "bm2_index_build", "bm2_sam_opt_init", "bm2_sam_se", "bm2_sam_pe", "bm2_fastq_parse", "bm2_fastq_parse_mt", "bm2_fastq_free", "bm2_ksw_align2", "bm2_ksw_align2_dev", "bm2_sam_pe_dev", "bm2_sam_se_dev", "bm2_sam_cigar_stats", "bm2_gen_cigar", "bm2_gen_cigar_dev", "bm2_sam_header", "bm2_sam_rescue_stats"]
+           "bm2_batch_fetch", "bm2_batch_finish", "bm2_batch_download_alnregs", "bm2_finish_regs_dev", "bm2_chunk_hits_sharded", "bm2_index_build", "bm2_sam_opt_init", "bm2_sam_se", "bm2_sam_pe", "bm2_fastq_parse", "bm2_fastq_parse_mt", "bm2_fastq_free", "bm2_ksw_align2", "bm2_ksw_align2_dev", "bm2_sam_pe_dev", "bm2_sam_se_dev", "bm2_sam_cigar_stats", "bm2_gen_cigar", "bm2_gen_cigar_dev", "bm2_sam_header", "bm2_sam_rescue_stats"]
 
 _lib = None
 
@@ -436,6 +436,29 @@ class Context:
         n = C.c_int32(0)
         _chk(lib().bm2_batch_kernel_ms(self.h, ms, 32, C.byref(n), names), "bm2_batch_kernel_ms")
         return [(names[i].decode(), float(ms[i])) for i in range(n.value)]
+
+
+def chunk_hits_sharded(ctxs, reads, opt):
+    """One chunk over several contexts (bm2_chunk_hits_sharded): reads = FastqChunk or (enc, off, len) -> (alnregs, aln_off)."""
+    if isinstance(reads, FastqChunk):
+        r, n_reads = reads.reads, reads.n_reads
+    else:
+        r, keep = _reads_struct(*reads)
+        n_reads = len(keep[2])
+    L = lib()
+    L.bm2_chunk_hits_sharded.argtypes = [C.c_void_p, C.c_int, C.POINTER(Reads), C.POINTER(Opt), C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_int64)]
+    hs = (C.c_void_p * len(ctxs))(*[c.h for c in ctxs])
+    aln_off = np.zeros(n_reads + 1, np.int64)
+    cap = max(1024, 4 * n_reads)
+    while True:
+        out = np.zeros(cap, ALNREG_DT)
+        n = C.c_int64(0)
+        rc = L.bm2_chunk_hits_sharded(hs, len(ctxs), C.byref(r), C.byref(opt), out.ctypes.data, cap, aln_off.ctypes.data, C.byref(n))
+        if rc == BM2_ECAP:
+            cap = int(n.value)                                  # (the parts run again: size generously)
+            continue
+        _chk(rc, "bm2_chunk_hits_sharded")
+        return out[:n.value], aln_off
 
 
 def ksw_align2(pairs, xtra, opt, ctx=None):

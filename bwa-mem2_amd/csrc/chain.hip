@@ -302,7 +302,7 @@ static __device__ void chain_one_read(const DevIndex &ix, const ChainParams &o, 
     if (k == 0 && n > 0) k = 1;      // quirk: an empty survivor list still processes the untouched a_[0] (bwamem.cpp:529-546)
     n = k;
     if (n > 0) {
-        k_introsort(n, ord, [&](int32_t x, int32_t y) { return ch[x].w > ch[y].w; });     // flt_lt, bwamem.cpp:61
+        k_introsort_flat(n, ord, [&](int32_t x, int32_t y) { return ch[x].w > ch[y].w; });     // flt_lt, bwamem.cpp:61
         // `kept chain list` reuses the tail of the order array's sibling: indices into ord
         int32_t *kept_list = (int32_t *)nodes;                   // the B-tree is no longer needed
         int n_kept = 0;
@@ -469,7 +469,7 @@ k_chain_finish(DevIndex ix, ChainParams o, int n_reads, const int32_t *__restric
         for (int t = 0; t < c.n; t++) srt[t] = t;
         if (c.n > 1) {
             const DevSeed *cs = os + s0;
-            k_introsort(c.n, srt, [&](int32_t x, int32_t y) { return cs[x].score < cs[y].score || (cs[x].score == cs[y].score && x < y); });
+            k_introsort_flat(c.n, srt, [&](int32_t x, int32_t y) { return cs[x].score < cs[y].score || (cs[x].score == cs[y].score && x < y); });
         }
         for (int kk = c.n - 1; kk >= 0; kk--) {
             const int reg = n_reg++;

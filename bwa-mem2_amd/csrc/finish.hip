@@ -17,6 +17,7 @@
 //   * the host alternates the two until no request is left (150-base reads: one or two rounds), then a scan and k_fin_gather lay
 //     the survivors out densely in read order.
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
@@ -50,109 +51,156 @@ static __device__ __forceinline__ int fin_band(int l_query, int rlen, int w_, co
     return w > min_w ? w : min_w;
 }
 
+// the two orders of the stage as out-of-line functions (one copy of klib's introsort each, called, not inlined into the kernels)
+struct FinByEnd { const bm2_alnreg_t *A; __device__ bool operator()(int32_t x, int32_t y) const { return A[x].re < A[y].re; } };
+struct FinByScore {
+    const bm2_alnreg_t *A;
+    __device__ bool operator()(int32_t x, int32_t y) const {
+        const bm2_alnreg_t &a = A[x], &b = A[y];
+        return a.score > b.score || (a.score == b.score && (a.rb < b.rb || (a.rb == b.rb && a.qb < b.qb)));
+    }
+};
+#ifdef BM2_FIN_NOINLINE
+#define FIN_SORT_ATTR __noinline__
+#else
+#define FIN_SORT_ATTR
+#endif
+static __device__ FIN_SORT_ATTR void fin_sort_by_end(int n, int32_t *ord, const bm2_alnreg_t *A) { FinByEnd lt = { A }; k_introsort_flat(n, ord, lt); }
+static __device__ FIN_SORT_ATTR void fin_sort_by_score(int n, int32_t *ord, const bm2_alnreg_t *A) { FinByScore lt = { A }; k_introsort_flat(n, ord, lt); }
+
+// first kernel of the stage: the hits as mem_kernel2_core holds them at bwamem.cpp:1152 (calloc'd: every other field is 0), ordered
+// by reference end ("sort by the END position", :299)
 __global__ void __launch_bounds__(128)
-k_fin_walk(DevIndex ix, FinParams P, int n_reads, int first_round, const bm2_reg_t *__restrict__ regs, const int64_t *__restrict__ reg_off,
-           bm2_alnreg_t *work, int32_t *ordbuf, FinState *state, int32_t *n_fin, FinReq *reqs, unsigned long long *cnt /* [0] requests, [1] widest band */) {
+k_fin_init(int n_reads, const bm2_reg_t *__restrict__ regs, const int64_t *__restrict__ reg_off, bm2_alnreg_t *work, int32_t *ordbuf,
+           FinState *state, int32_t *n_fin) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_reads) return;
     const int64_t base = reg_off[r];
     const int n = (int)(reg_off[r + 1] - base);
     bm2_alnreg_t *A = work + base;
     int32_t *ord = ordbuf + base;
-    FinState st;
-    if (first_round) {                                          // the hits as mem_kernel2_core holds them at bwamem.cpp:1152 (calloc'd: the rest is 0)
-        for (int i = 0; i < n; i++) {
-            const bm2_reg_t s = regs[base + i];
-            bm2_alnreg_t d; memset(&d, 0, sizeof d);
-            d.rb = s.rb; d.re = s.re; d.qb = s.qb; d.qe = s.qe; d.rid = s.rid; d.score = s.score; d.truesc = s.truesc; d.w = s.w;
-            d.seedcov = s.seedcov; d.seedlen0 = s.seedlen0; d.frac_rep = s.frac_rep;
-            A[i] = d; ord[i] = i;
-        }
-        st.i = 1; st.j = -2; st.phase = 1; st.dp_score = 0;
-        if (n <= 1) { n_fin[r] = n; st.phase = 3; state[r] = st; return; }       // bwamem.cpp:298 (n_comp stays 0)
-        k_introsort(n, ord, [&](int32_t x, int32_t y) { return A[x].re < A[y].re; });   // "sort by the END position", :299
-        for (int i = 0; i < n; i++) A[i].n_comp = 1;
-    } else {
-        st = state[r];
-        if (st.phase == 3) return;
+    for (int i = 0; i < n; i++) {
+        const bm2_reg_t s = regs[base + i];
+        bm2_alnreg_t d; memset(&d, 0, sizeof d);
+        d.rb = s.rb; d.re = s.re; d.qb = s.qb; d.qe = s.qe; d.rid = s.rid; d.score = s.score; d.truesc = s.truesc; d.w = s.w;
+        d.seedcov = s.seedcov; d.seedlen0 = s.seedlen0; d.frac_rep = s.frac_rep;
+        d.n_comp = n > 1 ? 1 : 0;                                // bwamem.cpp:298-300 (a single hit returns before n_comp is set)
+        A[i] = d; ord[i] = i;
     }
-    // ---- the walk, bwamem.cpp:302-335.  st.j == -2: hit i has not been looked at yet; otherwise (i, j) is the pair whose score
-    // has just arrived (phase 2).
+    FinState st; st.i = 1; st.j = -2; st.phase = n <= 1 ? 3 : 1; st.dp_score = 0;
+    state[r] = st;
+    n_fin[r] = n <= 1 ? n : 0;
+    if (n > 1) fin_sort_by_end(n, ord, A);
+}
+
+// the walk, resumable (phase 1 = walking, 2 = a score has arrived, 3 = through, 4 = walk done, final ordering pending)
+__global__ void __launch_bounds__(128)
+k_fin_walk(DevIndex ix, FinParams P, int n_reads, const int64_t *__restrict__ reg_off, bm2_alnreg_t *work, const int32_t *__restrict__ ordbuf,
+           FinState *state, FinReq *reqs, unsigned long long *cnt /* [0] requests, [1] widest band */) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    FinState st = state[r];
+    if (st.phase >= 3) return;
+    const int64_t base = reg_off[r];
+    const int n = (int)(reg_off[r + 1] - base);
+    bm2_alnreg_t *A = work + base;
+    const int32_t *ord = ordbuf + base;
+    // ---- the walk, bwamem.cpp:302-335, as ONE loop over (i, j) pairs (no nested loops, no early exits: a lane that must wait for
+    // an alignment score parks and falls through to the end of the kernel).  j == -2: hit i has not been looked at yet; on entry
+    // with phase 2, (i, j) is the pair whose score has just arrived.
     int i = st.i, j = st.j;
-    bool have_score = st.phase == 2;
-    for (; i < n; ++i, j = -2) {
+    bool have_score = st.phase == 2, parked = false;
+    while (i < n && !parked) {
         bm2_alnreg_t *p = &A[ord[i]];
-        if (j == -2) {
+        bool next_i = false;
+        if (j == -2) {                                          // first look at hit i: anything before it close enough?
             const bm2_alnreg_t *pr = &A[ord[i - 1]];
-            if (p->rid != pr->rid || p->rb >= pr->re + P.max_chain_gap) continue;
-            j = i - 1;
+            if (p->rid != pr->rid || p->rb >= pr->re + P.max_chain_gap) next_i = true;
+            else j = i - 1;
         }
-        for (; j >= 0; --j) {
-            bm2_alnreg_t *q = &A[ord[j]];
-            if (!(p->rid == q->rid && p->rb < q->re + P.max_chain_gap)) break;
-            if (!have_score) {
-                if (q->qe == q->qb) continue;                   // excluded earlier
+        if (!next_i) {
+            bm2_alnreg_t *q = &A[ord[j >= 0 ? j : 0]];
+            if (j < 0 || !(p->rid == q->rid && p->rb < q->re + P.max_chain_gap)) next_i = true;
+            else if (have_score) {
+                // ---- back with the score: the rest of mem_patch_reg (:214-224) and the merge (:320-332)
+                have_score = false;
+                int wq = (int)((q->re - p->rb) - (q->qe - p->qb));
+                wq = wq > 0 ? wq : -wq;
+                wq += q->w + p->w;
+                wq = wq < P.w << 2 ? wq : P.w << 2;
+                const int score = st.dp_score;
+                // (the reference's AVX-512 / AVX2 builds contract x / y * z + .499 into one fused multiply-add; so does this)
+                const int q_s = (int)fma((double)(p->qe - q->qb) / (double)((p->qe - p->qb) + (q->qe - q->qb)), (double)(p->score + q->score), .499);
+                const int r_s = (int)fma((double)(p->re - q->rb) / (double)((p->re - p->rb) + (q->re - q->rb)), (double)(p->score + q->score), .499);
+                if (!((double)score / (double)(q_s > r_s ? q_s : r_s) < PATCH_MIN_SC_RATIO) && score > 0) {
+                    p->n_comp += q->n_comp + 1;
+                    p->seedcov = p->seedcov > q->seedcov ? p->seedcov : q->seedcov;
+                    p->sub = p->sub > q->sub ? p->sub : q->sub;
+                    p->csub = p->csub > q->csub ? p->csub : q->csub;
+                    p->qb = q->qb; p->rb = q->rb;
+                    p->truesc = p->score = score;
+                    p->w = wq;
+                    q->qb = q->qe;
+                }
+                --j;
+            } else if (q->qe == q->qb) --j;                     // excluded earlier
+            else {
                 const int64_t orr = q->re - p->rb;
                 const int64_t oq = q->qb < p->qb ? q->qe - p->qb : p->qe - q->qb;
                 const int64_t mr = q->re - q->rb < p->re - p->rb ? q->re - q->rb : p->re - p->rb;
                 const int64_t mq = q->qe - q->qb < p->qe - p->qb ? q->qe - q->qb : p->qe - p->qb;
                 if (orr > P.mask_level_redun * mr && oq > P.mask_level_redun * mq) {          // one of the two is redundant
-                    if (p->score < q->score) { p->qe = p->qb; break; }
-                    q->qe = q->qb;
-                    continue;
+                    if (p->score < q->score) { p->qe = p->qb; next_i = true; }
+                    else { q->qe = q->qb; --j; }
+                } else {
+                    // mem_patch_reg(a = q, b = p) up to the alignment, bwamem.cpp:186-205
+                    bool cand = q->rb < p->rb && !(q->rb < ix.l_pac && p->rb >= ix.l_pac) && !(q->qb >= p->qb || q->qe >= p->qe || q->re >= p->re);
+                    int w = 0;
+                    if (cand) {
+                        w = (int)((q->re - p->rb) - (q->qe - p->qb));
+                        w = w > 0 ? w : -w;
+                        double rr = (double)(q->re - p->rb) / (double)(p->re - q->rb) - (double)(q->qe - p->qb) / (double)(p->qe - q->qb);
+                        rr = rr > 0. ? rr : -rr;
+                        if (q->re < p->rb || q->qe < p->qb) { if (w > P.w << 1 || rr >= PATCH_MAX_R_BW) cand = false; }
+                        else if (w > P.w << 2 || rr >= PATCH_MAX_R_BW * 2) cand = false;
+                    }
+                    if (!cand) --j;
+                    else {                                      // the score of the global alignment decides: file the request and park
+                        w += q->w + p->w;
+                        w = w < P.w << 2 ? w : P.w << 2;
+                        const unsigned long long at = atomicAdd(&cnt[0], 1ULL);
+                        FinReq rq; rq.read = r; rq.a = ord[j]; rq.b = ord[i]; rq.w = w;
+                        reqs[at] = rq;                          // (at most one per read and round: the queue holds n_reads)
+                        const int lq = p->qe - q->qb; const int64_t rl = p->re - q->rb;
+                        const int band = rl <= 0x3fffffff ? fin_band(lq, (int)rl, w, P) : 0x3fffffff;
+                        atomicMax(&cnt[1], (unsigned long long)band);
+                        st.i = i; st.j = j; st.phase = 2; st.dp_score = 0;
+                        parked = true;
+                    }
                 }
-                if (!(q->rb < p->rb)) continue;
-                // mem_patch_reg(a = q, b = p) up to the alignment, bwamem.cpp:186-205
-                if (q->rb < ix.l_pac && p->rb >= ix.l_pac) continue;
-                if (q->qb >= p->qb || q->qe >= p->qe || q->re >= p->re) continue;
-                int w = (int)((q->re - p->rb) - (q->qe - p->qb));
-                w = w > 0 ? w : -w;
-                double rr = (double)(q->re - p->rb) / (double)(p->re - q->rb) - (double)(q->qe - p->qb) / (double)(p->qe - q->qb);
-                rr = rr > 0. ? rr : -rr;
-                if (q->re < p->rb || q->qe < p->qb) { if (w > P.w << 1 || rr >= PATCH_MAX_R_BW) continue; }
-                else if (w > P.w << 2 || rr >= PATCH_MAX_R_BW * 2) continue;
-                w += q->w + p->w;
-                w = w < P.w << 2 ? w : P.w << 2;
-                // the score of the global alignment decides: file the request and leave
-                const unsigned long long at = atomicAdd(&cnt[0], 1ULL);
-                FinReq rq; rq.read = r; rq.a = ord[j]; rq.b = ord[i]; rq.w = w;
-                reqs[at] = rq;                                  // (at most one per read and round: the queue holds n_reads)
-                const int lq = p->qe - q->qb; const int64_t rl = p->re - q->rb;
-                const int band = rl <= 0x3fffffff ? fin_band(lq, (int)rl, w, P) : 0x3fffffff;
-                atomicMax(&cnt[1], (unsigned long long)band);
-                st.i = i; st.j = j; st.phase = 2; st.dp_score = 0;
-                state[r] = st;
-                return;
             }
-            // ---- back with the score: the rest of mem_patch_reg (:214-224) and the merge (:320-332)
-            have_score = false;
-            int wq = (int)((q->re - p->rb) - (q->qe - p->qb));
-            wq = wq > 0 ? wq : -wq;
-            wq += q->w + p->w;
-            wq = wq < P.w << 2 ? wq : P.w << 2;
-            const int score = st.dp_score;
-            // (the reference's AVX-512 / AVX2 builds contract x / y * z + .499 into one fused multiply-add; so does this)
-            const int q_s = (int)fma((double)(p->qe - q->qb) / (double)((p->qe - p->qb) + (q->qe - q->qb)), (double)(p->score + q->score), .499);
-            const int r_s = (int)fma((double)(p->re - q->rb) / (double)((p->re - p->rb) + (q->re - q->rb)), (double)(p->score + q->score), .499);
-            if ((double)score / (double)(q_s > r_s ? q_s : r_s) < PATCH_MIN_SC_RATIO) continue;
-            if (score <= 0) continue;
-            p->n_comp += q->n_comp + 1;
-            p->seedcov = p->seedcov > q->seedcov ? p->seedcov : q->seedcov;
-            p->sub = p->sub > q->sub ? p->sub : q->sub;
-            p->csub = p->csub > q->csub ? p->csub : q->csub;
-            p->qb = q->qb; p->rb = q->rb;
-            p->truesc = p->score = score;
-            p->w = wq;
-            q->qb = q->qe;
         }
+        if (next_i) { ++i; j = -2; }
     }
+    if (!parked) st.phase = 4;
+    state[r] = st;
+}
+
+// last kernel: bwamem.cpp:336-352
+__global__ void __launch_bounds__(128)
+k_fin_order(int n_reads, const int64_t *__restrict__ reg_off, bm2_alnreg_t *work, int32_t *ordbuf, FinState *state, int32_t *n_fin) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    FinState st = state[r];
+    if (st.phase != 4) return;
+    const int64_t base = reg_off[r];
+    const int n = (int)(reg_off[r + 1] - base);
+    bm2_alnreg_t *A = work + base;
+    int32_t *ord = ordbuf + base;
     // ---- bwamem.cpp:336-352: drop the excluded, order by (score desc, rb, qb), drop identical hits
     int m = 0;
     for (int k = 0; k < n; k++) if (A[ord[k]].qe > A[ord[k]].qb) ord[m++] = ord[k];
-    k_introsort(m, ord, [&](int32_t x, int32_t y) {
-        const bm2_alnreg_t &a = A[x], &b = A[y];
-        return a.score > b.score || (a.score == b.score && (a.rb < b.rb || (a.rb == b.rb && a.qb < b.qb)));
-    });
+    fin_sort_by_score(m, ord, A);
     for (int k = 1; k < m; k++) {
         bm2_alnreg_t &a = A[ord[k]]; const bm2_alnreg_t &b = A[ord[k - 1]];
         if (a.score == b.score && a.rb == b.rb && a.qb == b.qb) a.qe = a.qb;
@@ -282,14 +330,19 @@ int bm2_run_finish(bm2_ctx *c, const bm2_opt *opt, int n_reads, const uint8_t *e
     P.mat0 = opt->mat[0]; P.mask_level_redun = opt->mask_level_redun;
     for (int i = 0; i < 25; i++) P.mat[i] = opt->mat[i];
     const unsigned nb = (unsigned)((n_reads + 127) / 128);
+    const bool verbose = getenv("BM2_FIN_VERBOSE") != nullptr;
+    hipLaunchKernelGGL(k_fin_init, dim3(nb), dim3(128), 0, s, n_reads, regs, reg_off, (bm2_alnreg_t *)work.p, (int32_t *)ordb.p, (FinState *)stateb.p,
+                       (int32_t *)nfin.p);
+    if (verbose) { rc = bm2_check(hipStreamSynchronize(s), "k_fin_init"); fprintf(stderr, "[finish] init + sort by end: rc %d\n", rc); if (rc) return rc; }
     for (int round = 0; ; round++) {
         if ((rc = bm2_check(hipMemsetAsync(cntb.p, 0, 16, s), "memset fin counters"))) return rc;
-        hipLaunchKernelGGL(k_fin_walk, dim3(nb), dim3(128), 0, s, c->ix, P, n_reads, round == 0 ? 1 : 0, regs, reg_off, (bm2_alnreg_t *)work.p,
-                           (int32_t *)ordb.p, (FinState *)stateb.p, (int32_t *)nfin.p, (FinReq *)reqb.p, (unsigned long long *)cntb.p);
+        hipLaunchKernelGGL(k_fin_walk, dim3(nb), dim3(128), 0, s, c->ix, P, n_reads, reg_off, (bm2_alnreg_t *)work.p, (const int32_t *)ordb.p,
+                           (FinState *)stateb.p, (FinReq *)reqb.p, (unsigned long long *)cntb.p);
         unsigned long long h_cnt[2] = { 0, 0 };
         if ((rc = bm2_check(hipMemcpyAsync(h_cnt, cntb.p, 16, hipMemcpyDeviceToHost, s), "D2H fin counters"))) return rc;
         if ((rc = bm2_check(hipStreamSynchronize(s), "k_fin_walk"))) return rc;
         if (rounds) *rounds = round + 1;
+        if (verbose) fprintf(stderr, "[finish] round %d: %llu alignment requests, widest band %llu\n", round, h_cnt[0], h_cnt[1]);
         if (h_cnt[0] == 0) break;
         // the alignments of this round: one per wavefront, LDS ring of R slots per wave for the widest band
         int R = 64;
@@ -304,6 +357,9 @@ int bm2_run_finish(bm2_ctx *c, const bm2_opt *opt, int n_reads, const uint8_t *e
                            reg_off, (const bm2_alnreg_t *)work.p, (FinState *)stateb.p, R);
         if ((rc = bm2_check(hipGetLastError(), "k_fin_dp launch"))) return rc;
     }
+    hipLaunchKernelGGL(k_fin_order, dim3(nb), dim3(128), 0, s, n_reads, reg_off, (bm2_alnreg_t *)work.p, (int32_t *)ordb.p, (FinState *)stateb.p,
+                       (int32_t *)nfin.p);
+    if (verbose) { rc = bm2_check(hipStreamSynchronize(s), "k_fin_order"); fprintf(stderr, "[finish] final order: rc %d\n", rc); if (rc) return rc; }
     if ((rc = bm2_scan_i32(c, (const int32_t *)nfin.p, n_reads, (int64_t *)finoff.p, scan_tmp))) return rc;
     int64_t tot = 0;
     if ((rc = bm2_check(hipMemcpyAsync(&tot, (int64_t *)finoff.p + n_reads, 8, hipMemcpyDeviceToHost, s), "D2H n_fin"))) return rc;

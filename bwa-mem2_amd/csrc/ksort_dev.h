@@ -64,3 +64,56 @@ static __device__ void k_introsort(int n, int32_t *a, LT lt) {
     }
 }
 
+
+// The same algorithm as ONE loop over an explicit state (no loops nested in loops; indices, not pointers, so the array keeps its
+// address space): the form the hit-finishing kernels use.  Same comparisons in the same order as k_introsort above, hence the same
+// permutation.
+template <class LT>
+static __device__ void k_introsort_flat(int n, int32_t *a, LT lt) {
+    if (n < 1) return;
+    if (n == 2) { if (lt(a[1], a[0])) { const int32_t t = a[0]; a[0] = a[1]; a[1] = t; } return; }
+    int d = 2;
+    while ((1 << d) < n) ++d;
+    d <<= 1;
+    int stk_s[72], stk_t[72], stk_d[72], top = 0;
+    int s = 0, t = n - 1, i = 0, j = 0;
+    int32_t rp = 0;
+    enum { ST_TOP, ST_I, ST_J, ST_DONE };
+    int st = ST_TOP;
+    while (st != ST_DONE) {
+        if (st == ST_TOP) {
+            if (s < t) {
+                if (--d == 0) { k_combsort(t - s + 1, a + s, lt); t = s; }
+                else {
+                    i = s; j = t;
+                    int k = i + ((j - i) >> 1) + 1;
+                    if (lt(a[k], a[i])) { if (lt(a[k], a[j])) k = j; }
+                    else k = lt(a[j], a[i]) ? i : j;
+                    rp = a[k];
+                    if (k != t) { const int32_t tmp = a[k]; a[k] = a[t]; a[t] = tmp; }
+                    st = ST_I;
+                }
+            } else if (top == 0) st = ST_DONE;
+            else { --top; s = stk_s[top]; t = stk_t[top]; d = stk_d[top]; }
+        } else if (st == ST_I) {                                  // do ++i; while (lt(*i, rp));
+            ++i;
+            if (!lt(a[i], rp)) st = ST_J;
+        } else {                                                  // do --j; while (i <= j && lt(rp, *j));
+            --j;
+            if (!(i <= j && lt(rp, a[j]))) {
+                if (j <= i) {                                     // the partition is through
+                    { const int32_t tmp = a[i]; a[i] = a[t]; a[t] = tmp; }
+                    if (i - s > t - i) {
+                        if (i - s > 16) { stk_s[top] = s; stk_t[top] = i - 1; stk_d[top] = d; ++top; }
+                        s = t - i > 16 ? i + 1 : t;
+                    } else {
+                        if (t - i > 16) { stk_s[top] = i + 1; stk_t[top] = t; stk_d[top] = d; ++top; }
+                        t = i - s > 16 ? i - 1 : s;
+                    }
+                    st = ST_TOP;
+                } else { const int32_t tmp = a[i]; a[i] = a[j]; a[j] = tmp; st = ST_I; }
+            }
+        }
+    }
+    k_insertsort(a, a + n, lt);
+}

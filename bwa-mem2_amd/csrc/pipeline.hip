@@ -633,6 +633,72 @@ extern "C" int bm2_finish_regs_dev(bm2_ctx *c, const bm2_opt *opt, const bm2_rea
     return bm2_batch_download_alnregs(c, out, cap, out_off, n_out);
 }
 
+// ---- one chunk over several contexts ----------------------------------------------------------------------
+// kernel1 / kernel2 have no cross-read state except the 512-read block rule of mem_chain_seeds (bwamem.cpp:834), so a chunk may be
+// cut at multiples of 512 reads (even: mates stay together) and its parts run on different contexts -- different GPUs of a node,
+// each with its index replica, or contexts sharing one replica -- on one host thread each.  The hits come back in read order; the
+// caller then runs the pairing ONCE over the whole chunk (mem_pestat is chunk-wide, bwamem.cpp:1375), so the SAM does not depend
+// on how many contexts took part.  No collective: every part is independent until the gather.
+extern "C" int bm2_chunk_hits_sharded(bm2_ctx *const *ctxs, int n_ctx, const bm2_reads *reads, const bm2_opt *opt, bm2_alnreg_t *out, int64_t cap,
+                                      int64_t *aln_off, int64_t *n_out) {
+    if (!ctxs || n_ctx < 1 || !reads || !opt || !aln_off || !n_out || reads->n_reads < 0) { bm2_set_error("bm2_chunk_hits_sharded: bad argument"); return BM2_EINVAL; }
+    const int n = reads->n_reads;
+    const int blocks = (n + BM2_BLOCK_READS - 1) / BM2_BLOCK_READS;
+    std::vector<int> first((size_t)n_ctx + 1);
+    for (int i = 0; i <= n_ctx; i++) { const int64_t b = (int64_t)blocks * i / n_ctx * BM2_BLOCK_READS; first[(size_t)i] = (int)(b < n ? b : n); }
+    first[(size_t)n_ctx] = n;
+    std::vector<int> rcs((size_t)n_ctx, 0);
+    std::vector<std::string> msgs((size_t)n_ctx);
+    std::vector<std::vector<int64_t>> offs((size_t)n_ctx);
+    auto device_part = [&](int i) {
+        const int lo = first[(size_t)i], hi = first[(size_t)i + 1];
+        bm2_reads r; r.n_reads = hi - lo; r.enc = reads->enc; r.off = reads->off + lo; r.len = reads->len + lo;
+        std::vector<int64_t> off2;
+        if (r.n_reads > 0) {                                    // upload only the part's bases: rebase the offsets
+            int64_t mn = r.off[0];
+            for (int k = 0; k < r.n_reads; k++) if (r.off[k] < mn) mn = r.off[k];
+            off2.resize((size_t)r.n_reads);
+            for (int k = 0; k < r.n_reads; k++) off2[(size_t)k] = r.off[k] - mn;
+            r.enc = reads->enc + mn; r.off = off2.data();
+        }
+        int rc = bm2_batch_upload(ctxs[i], &r);
+        if (!rc) rc = bm2_batch_run(ctxs[i], opt);
+        if (!rc) rc = bm2_batch_finish(ctxs[i], opt);
+        rcs[(size_t)i] = rc;
+        if (rc) msgs[(size_t)i] = bm2_last_error();
+    };
+    {
+        std::vector<std::thread> th;
+        for (int i = 1; i < n_ctx; i++) th.emplace_back(device_part, i);
+        device_part(0);
+        for (auto &t : th) t.join();
+    }
+    for (int i = 0; i < n_ctx; i++) if (rcs[(size_t)i]) { bm2_set_error("context %d: %s", i, msgs[(size_t)i].c_str()); return rcs[(size_t)i]; }
+    // gather in read order
+    int64_t tot = 0;
+    std::vector<int64_t> cnt((size_t)n_ctx);
+    for (int i = 0; i < n_ctx; i++) {
+        Batch *b = ctxs[i]->batch;
+        int64_t t = 0;
+        for (int k = 0; k < (ctxs[i]->n_parts < 1 ? 1 : ctxs[i]->n_parts); k++) t += part_ctx(ctxs[i], k)->batch->n_fin;
+        (void)b; cnt[(size_t)i] = t; tot += t;
+    }
+    *n_out = tot;
+    if (tot > cap) { bm2_set_error("alnregs capacity %ld < %ld", (long)cap, (long)tot); return BM2_ECAP; }
+    int64_t base = 0;
+    for (int i = 0; i < n_ctx; i++) {
+        const int lo = first[(size_t)i], hi = first[(size_t)i + 1];
+        int64_t n1 = 0;
+        offs[(size_t)i].assign((size_t)(hi - lo) + 1, 0);
+        const int rc = bm2_batch_download_alnregs(ctxs[i], out ? out + base : nullptr, cap - base, offs[(size_t)i].data(), &n1);
+        if (rc) return rc;
+        for (int k = 0; k <= hi - lo; k++) aln_off[lo + k] = offs[(size_t)i][(size_t)k] + base;
+        base += n1;
+    }
+    aln_off[n] = tot;
+    return BM2_OK;
+}
+
 // ---- S2 --------------------------------------------------------------------------------------------------------
 extern "C" int bm2_smem(bm2_ctx *c, const bm2_reads *reads, const bm2_opt *opt, bm2_smem_t *out, int64_t cap, int64_t *n_out) {
     if (!n_out) return BM2_EINVAL;

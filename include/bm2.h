@@ -162,6 +162,14 @@ int bm2_batch_download_alnregs(bm2_ctx *c, bm2_alnreg_t *out, int64_t cap, int64
 int bm2_finish_regs_dev(bm2_ctx *c, const bm2_opt *opt, const bm2_reads *reads, const bm2_reg_t *regs, const int64_t *reg_off,
                         bm2_alnreg_t *out, int64_t cap, int64_t *out_off, int64_t *n_out);
 
+/* ---- one chunk over several contexts (several GPUs of a node with a replica each, or contexts sharing one replica): the chunk is
+ * cut at multiples of 512 reads (the kt_for block, the only cross-read rule of the path: bwamem.cpp:834), the parts run through
+ * bm2_batch_upload / run / finish on one host thread per context, and the hits come back in read order -- ready for ONE
+ * bm2_sam_pe[_dev] over the whole chunk (mem_pestat is chunk-wide, bwamem.cpp:1375).  No collective.  The result does not depend on
+ * n_ctx. */
+int bm2_chunk_hits_sharded(bm2_ctx *const *ctxs, int n_ctx, const bm2_reads *reads, const bm2_opt *opt, bm2_alnreg_t *out, int64_t cap,
+                           int64_t *aln_off, int64_t *n_out);
+
 /* ---- host side, next row of SURVEY.md 8(f): single-end records of worker_sam (bwamem.cpp:1320-1335) =
  * mem_mark_primary_se (:1420-1465) + mem_reorder_primary5 (:1496-1519) + mem_reg2sam (:1521-1577) with mem_gen_alt
  * (bwamem_extra.cpp:130-183), mem_reg2aln (:1732-1805: mem_approx_mapq_se, bwa_gen_cigar2 -> ksw_global2 with backtrack,

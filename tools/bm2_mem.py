@@ -31,9 +31,10 @@ def chunks(n_reads, lens, K, paired):
         lo = hi
 
 
-def run(prefix, fq, K=10000000, out_path="-", threads=0, hits_of=None, device_tail=False):
+def run(prefix, fq, K=10000000, out_path="-", threads=0, hits_of=None, device_tail=False, contexts=1):
     """hits_of(enc, off, ln) -> (alnregs ALNREG_DT, aln_off): the device stage (up to and including mem_sort_dedup_patch); None = a
-    Context on GPU 0.
+    Context on GPU 0.  contexts = G > 1: every chunk is split at multiples of 512 reads over G contexts -- one per GPU while there
+    are GPUs, further ones share a replica -- and paired ONCE (bm2_chunk_hits_sharded): same SAM for every G.
     device_tail: the mate-rescue and CIGAR alignments of the SAM tail run as device batches too (bm2_sam_pe_dev / bm2_sam_se_dev)."""
     import bm2
     paired = len(fq) == 2
@@ -55,6 +56,17 @@ def run(prefix, fq, K=10000000, out_path="-", threads=0, hits_of=None, device_ta
     ctx = None
     if hits_of is None or device_tail:
         ctx = bm2.Context(0, prefix)
+    extra = []
+    if hits_of is None and contexts > 1:
+        ndev = max(bm2.lib().bm2_device_count(), 1)
+        idx = bm2.Index(prefix)
+        per_dev = {0: ctx}
+        ctxs = [ctx]
+        for k in range(1, contexts):
+            d = k % ndev
+            c = bm2.Context(share=per_dev[d]) if d in per_dev else bm2.Context(d, idx)
+            per_dev.setdefault(d, c); ctxs.append(c); extra.append(c)
+        hits_of = lambda enc, off, ln: bm2.chunk_hits_sharded(ctxs, (enc, off, ln), opt)
     if hits_of is None:
         def hits_of(enc, off, ln):
             ctx.batch_upload(enc, off, ln); ctx.batch_run(opt); ctx.batch_finish(opt)
@@ -73,6 +85,10 @@ def run(prefix, fq, K=10000000, out_path="-", threads=0, hits_of=None, device_ta
         out.write(txt)
     if out is not sys.stdout.buffer:
         out.close()
+    for c in reversed(extra):
+        c.close()
+    if ctx is not None:
+        ctx.close()
 
 
 def main(argv=None):
@@ -80,11 +96,12 @@ def main(argv=None):
     ap.add_argument("-K", type=int, default=10000000)
     ap.add_argument("--threads", type=int, default=0, help="host threads of the SAM tail (0 = all)")
     ap.add_argument("--device-tail", action="store_true", help="rescue and CIGAR alignments of the SAM tail on the device as well")
+    ap.add_argument("--contexts", type=int, default=1, help="split every chunk over this many contexts (GPUs first); one pairing per chunk")
     ap.add_argument("-o", default="-")
     ap.add_argument("prefix")
     ap.add_argument("fq", nargs="+")
     a = ap.parse_args(argv)
-    run(a.prefix, a.fq, a.K, a.o, a.threads, device_tail=a.device_tail)
+    run(a.prefix, a.fq, a.K, a.o, a.threads, device_tail=a.device_tail, contexts=a.contexts)
 
 
 if __name__ == "__main__":

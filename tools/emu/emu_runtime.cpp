@@ -42,3 +42,6 @@ void emu_run_block(unsigned n_threads, emu_dim3 bid, emu_dim3 bdim, emu_dim3 gdi
     for (unsigned i = 0; i < n_threads; ++i) pthread_join(th[i], 0);
     pthread_attr_destroy(&at);
 }
+
+#include <mutex>
+std::mutex &emu_launch_mutex() { static std::mutex m; return m; }

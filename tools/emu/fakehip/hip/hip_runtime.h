@@ -199,7 +199,10 @@ extern char emu_dyn_lds[];                /* dynamic LDS of the running block (1
 // ---- launch: blocks in sequence, the threads of a block as OS threads ----
 void emu_run_block(unsigned n_threads, emu_dim3 bid, emu_dim3 bdim, emu_dim3 gdim, const std::function<void()> &body);
 extern size_t emu_dyn_lds_bytes;          // what the launch asked for (the harness's definition of the extern array must be that big)
+#include <mutex>
+std::mutex &emu_launch_mutex();           // one launch at a time: the static __shared__ copies and the dynamic LDS buffer are per process
 template <class K, class... A> static inline void emu_launch(const char *name, K kernel, emu_dim3 grid, emu_dim3 block, size_t lds, hipStream_t, A... args) {
+    std::lock_guard<std::mutex> one_launch(emu_launch_mutex());       // (host threads driving different contexts launch concurrently)
     emu_dyn_lds_bytes = lds;
     if (getenv("EMU_TRACE")) fprintf(stderr, "[emu] %s <<<%u, %u, %zu>>>\n", name, grid.x * grid.y * grid.z, block.x * block.y * block.z, lds);
     const unsigned nt = block.x * block.y * block.z;
