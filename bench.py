@@ -209,7 +209,7 @@ def parity_gate(ctx, bm2, prefix, workdir, seqs, regs, reg_off, opt, opt_args, p
         fin = alnregs_records(aln, aln_off)
         res["fin_equal"] = bool(len(fin) == len(d["REGFIN"]) and fin.tobytes() == d["REGFIN"].tobytes())
         so = bm2.default_sam_opt(n_threads=0)
-        txt = ctx.sam(chunk, opt, so, aln, aln_off, 0, paired)
+        txt = ctx.sam(chunk, opt, so, aln, aln_off, 0, paired).tobytes()
     finally:
         chunk.close()
     mine, ref = sam_lines(txt), sam_lines(open(ref_sam, "rb").read())

@@ -374,7 +374,7 @@ class Context:
             return out[:n.value], aln_off
 
     def sam(self, chunk, opt, so, alnregs, aln_off, n_processed=0, paired=True):
-        """SAM alignment lines of a chunk (bm2_sam_pe_dev / bm2_sam_se_dev: rescue and CIGAR alignments as device batches) -> bytes."""
+        """SAM alignment lines of a chunk (bm2_sam_pe_dev / bm2_sam_se_dev: rescue and CIGAR alignments as device batches) -> uint8 array."""
         L = lib()
         alnregs = np.ascontiguousarray(alnregs, ALNREG_DT)
         aln_off = np.ascontiguousarray(aln_off, np.int64)
@@ -395,7 +395,7 @@ class Context:
                 cap = need.value + 16
                 continue
             _chk(rc, "bm2_sam_pe_dev" if paired else "bm2_sam_se_dev")
-            return buf[:need.value].tobytes()
+            return buf[:need.value]                              # a uint8 view of the buffer the library wrote into (no copy); bytes(x) / x.tobytes() for text
 
     def batch_run(self, opt):
         _chk(lib().bm2_batch_run(self.h, C.byref(opt)), "bm2_batch_run")

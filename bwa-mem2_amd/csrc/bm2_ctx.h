@@ -22,7 +22,7 @@ struct bm2_ctx {
     void *d_cp_occ = nullptr, *d_sa_ms = nullptr, *d_sa_ls = nullptr, *d_ref = nullptr;
     void *d_ann_off = nullptr, *d_ann_len = nullptr, *d_ann_alt = nullptr;
     // scratch for the S1/S2 entry points
-    DevBuf b_pairs, b_ref, b_qer, b_misc;
+    DevBuf b_pairs, b_pairs2, b_ref, b_qer, b_misc;
     // batch state of the S3 path (see pipeline.hip)
     struct Batch *batch = nullptr;
     // per-kernel timers of the last bm2_batch_run

@@ -13,14 +13,15 @@
 #include "../../include/bm2.h"
 #include "bm2_ctx.h"
 #include "host_tail.h"
+#include "pipeline.h"
 
 #define CG_MINUS_INF (-0x40000000)
 
-struct CigarPrm { int8_t mat[25]; int8_t pad[3]; int32_t o_del, e_del, o_ins, e_ins; int64_t l_pac; };
+struct CigarPrm { int8_t mat[25]; int8_t pad[3]; int32_t o_del, e_del, o_ins, e_ins, a, w; int64_t l_pac; };
 struct CigarTask {
     int64_t q_off, rb, re;
-    int64_t z_off, eh_off, cg_off, md_off;      // this task's slices of the scratch / output buffers
-    int32_t q_len, w, cg_cap, md_cap;
+    int64_t z_off, eh_off, cg_off, md_off;      // this task's slices of the scratch buffers
+    int32_t q_len, w, truesc, retry;            // retry = 1: w is the hit's band and the kernel runs mem_reg2aln's retry loop around the alignment
 };
 struct CigarRes { int32_t score, nm, n_cigar, md_len; };
 
@@ -39,6 +40,20 @@ static __host__ __device__ inline int cigar_band(int l_query, int rlen, int w_, 
 static __host__ __device__ inline bool cigar_range_ok(int64_t l_pac, int l_query, int64_t rb, int64_t re) {
     if (l_query <= 0 || rb >= re || (rb < l_pac && re > l_pac)) return false;
     return rb >= 0 && re <= (l_pac << 1);                       // bns_get_seq would clamp: a clamped range is the NULL return
+}
+// infer_bw, bwamem.cpp:1811-1818, and the band of mem_reg2aln's first try (:1743-1747)
+static __host__ __device__ inline int cigar_infer_bw(int l1, int l2, int score, int a, int q, int r) {
+    if (l1 == l2 && l1 * a - score < (q + r - a) << 1) return 0;
+    int w = (int)((double)((l1 < l2 ? l1 : l2) * a - score - q) / r + 2.);
+    const int d = l1 > l2 ? l1 - l2 : l2 - l1;
+    return w < d ? d : w;
+}
+static __host__ __device__ inline int cigar_first_band(int lq, int rlen, int truesc, int w_hit, int a, int w_opt, int o_del, int e_del, int o_ins, int e_ins) {
+    const int t = cigar_infer_bw(lq, rlen, truesc, a, o_del, e_del);
+    int w2 = cigar_infer_bw(lq, rlen, truesc, a, o_ins, e_ins);
+    w2 = w2 > t ? w2 : t;
+    if (w2 > w_opt) w2 = w2 < w_hit ? w2 : w_hit;
+    return w2;
 }
 
 static __device__ int put_dec(char *s, int n, int v) {          // kputw: plain decimal
@@ -66,64 +81,81 @@ k_gen_cigar(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ seqs, c
     auto RF = [&](int i) -> int { return rev ? ref[T.re - 1 - i] : ref[T.rb + i]; };
     uint32_t *cg = cgbuf + T.cg_off;
     int ncg = 0;
-    if (lq == rlen && T.w == 0) {                               // no gap possible: one M (bwa.cpp:281-288)
-        int sc = 0;
-        for (int i = 0; i < lq; ++i) sc += prm.mat[RF(i) * 5 + Q(i)];
-        R.score = sc;
-        cg[ncg++] = (uint32_t)lq << 4;
-    } else {
-        const int w = cigar_band(lq, rlen, T.w, prm.mat[0], prm.o_del, prm.e_del, prm.o_ins, prm.e_ins);
-        const int oe_del = prm.o_del + prm.e_del, oe_ins = prm.o_ins + prm.e_ins, e_del = prm.e_del, e_ins = prm.e_ins;
-        const int n_col = lq < 2 * w + 1 ? lq : 2 * w + 1;
-        uint8_t *z = zbuf + T.z_off;
-        int2 *eh = ehbuf + T.eh_off;                            // .x = h, .y = e
-        int j;
-        eh[0] = make_int2(0, CG_MINUS_INF);
-        for (j = 1; j <= lq && j <= w; ++j) eh[j] = make_int2(-(prm.o_ins + e_ins * j), CG_MINUS_INF);
-        for (; j <= lq; ++j) eh[j] = make_int2(CG_MINUS_INF, CG_MINUS_INF);
-        for (int i = 0; i < rlen; ++i) {                        // ksw.cpp:598-637
-            int f = CG_MINUS_INF;
-            const int8_t *sc = &prm.mat[RF(i) * 5];
-            const int beg = i > w ? i - w : 0, end = i + w + 1 < lq ? i + w + 1 : lq;
-            int h1 = beg == 0 ? -(prm.o_del + e_del * (i + 1)) : CG_MINUS_INF;
-            uint8_t *zi = z + (int64_t)i * n_col;
-            for (j = beg; j < end; ++j) {
-                const int2 p = eh[j];
-                int m = p.x, e = p.y, h, t;
-                uint8_t d;
-                m += sc[Q(j)];
-                d = m >= e ? 0 : 1;
-                h = m >= e ? m : e;
-                d = h >= f ? d : 2;
-                h = h >= f ? h : f;
-                t = m - oe_del; e -= e_del;
-                d |= e > t ? 1 << 2 : 0;
-                e = e > t ? e : t;
-                eh[j] = make_int2(h1, e);
-                h1 = h;
-                t = m - oe_ins; f -= e_ins;
-                d |= f > t ? 2 << 4 : 0;
-                f = f > t ? f : t;
-                zi[j - beg] = d;
+    // one alignment (bwa_gen_cigar2, bwa.cpp:281-310), or mem_reg2aln's loop around it (bwamem.cpp:1748-1766): retry with twice the band
+    // while the score keeps changing, stays more than a match below the hit's score, and the band has not reached 4 w
+    int w_try = T.retry ? cigar_first_band(lq, rlen, T.truesc, T.w, prm.a, prm.w, prm.o_del, prm.e_del, prm.o_ins, prm.e_ins) : T.w;
+    int last_sc = -(1 << 30);
+    for (int attempt = 0; ; ) {
+        if (T.retry) w_try = w_try < prm.w << 2 ? w_try : prm.w << 2;
+        ncg = 0;
+        if (lq == rlen && w_try == 0) {                         // no gap possible: one M (bwa.cpp:281-288)
+            int sc = 0;
+            for (int i = 0; i < lq; ++i) sc += prm.mat[RF(i) * 5 + Q(i)];
+            R.score = sc;
+            cg[ncg++] = (uint32_t)lq << 4;
+        } else {
+            const int w = cigar_band(lq, rlen, w_try, prm.mat[0], prm.o_del, prm.e_del, prm.o_ins, prm.e_ins);
+            const int oe_del = prm.o_del + prm.e_del, oe_ins = prm.o_ins + prm.e_ins, e_del = prm.e_del, e_ins = prm.e_ins;
+            const int n_col = ((lq < 2 * w + 1 ? lq : 2 * w + 1) + 3) & ~3;       // row stride: whole dwords (the directions are stored four cells at a time)
+            uint8_t *z = zbuf + T.z_off;
+            int2 *eh = ehbuf + T.eh_off;                        // .x = h, .y = e
+            int j;
+            eh[0] = make_int2(0, CG_MINUS_INF);
+            for (j = 1; j <= lq && j <= w; ++j) eh[j] = make_int2(-(prm.o_ins + e_ins * j), CG_MINUS_INF);
+            for (; j <= lq; ++j) eh[j] = make_int2(CG_MINUS_INF, CG_MINUS_INF);
+            for (int i = 0; i < rlen; ++i) {                    // ksw.cpp:598-637
+                int f = CG_MINUS_INF;
+                const int8_t *sc = &prm.mat[RF(i) * 5];
+                const int beg = i > w ? i - w : 0, end = i + w + 1 < lq ? i + w + 1 : lq;
+                int h1 = beg == 0 ? -(prm.o_del + e_del * (i + 1)) : CG_MINUS_INF;
+                uint32_t *zi = (uint32_t *)(z + (int64_t)i * n_col);
+                uint32_t zacc = 0;
+                for (j = beg; j < end; ++j) {
+                    const int2 p = eh[j];
+                    int m = p.x, e = p.y, h, t;
+                    uint8_t d;
+                    m += sc[Q(j)];
+                    d = m >= e ? 0 : 1;
+                    h = m >= e ? m : e;
+                    d = h >= f ? d : 2;
+                    h = h >= f ? h : f;
+                    t = m - oe_del; e -= e_del;
+                    d |= e > t ? 1 << 2 : 0;
+                    e = e > t ? e : t;
+                    eh[j] = make_int2(h1, e);
+                    h1 = h;
+                    t = m - oe_ins; f -= e_ins;
+                    d |= f > t ? 2 << 4 : 0;
+                    f = f > t ? f : t;
+                    const int c = j - beg;
+                    zacc |= (uint32_t)d << (8 * (c & 3));
+                    if ((c & 3) == 3) { zi[c >> 2] = zacc; zacc = 0; }
+                }
+                if ((end - beg) & 3) zi[(end - beg) >> 2] = zacc;
+                eh[end] = make_int2(h1, CG_MINUS_INF);
             }
-            eh[end] = make_int2(h1, CG_MINUS_INF);
+            R.score = eh[lq].x;
+            // backtrack (ksw.cpp:640-660): ops are pushed last-to-first, merged, then reversed
+            auto push = [&](int op, int len) {
+                if (ncg == 0 || op != (int)(cg[ncg - 1] & 0xf)) cg[ncg++] = (uint32_t)len << 4 | (uint32_t)op;
+                else cg[ncg - 1] += (uint32_t)len << 4;
+            };
+            int which = 0, i = rlen - 1, k = (i + w + 1 < lq ? i + w + 1 : lq) - 1;
+            while (i >= 0 && k >= 0) {
+                which = z[(int64_t)i * n_col + (k - (i > w ? i - w : 0))] >> (which << 1) & 3;
+                if (which == 0) { push(0, 1); --i; --k; }
+                else if (which == 1) { push(2, 1); --i; }
+                else { push(1, 1); --k; }
+            }
+            if (i >= 0) push(2, i + 1);
+            if (k >= 0) push(1, k + 1);
+            for (int a = 0, b = ncg; a + 1 < b; ++a, --b) { const uint32_t t = cg[a]; cg[a] = cg[b - 1]; cg[b - 1] = t; }
         }
-        R.score = eh[lq].x;
-        // backtrack (ksw.cpp:640-660): ops are pushed last-to-first, merged, then reversed
-        auto push = [&](int op, int len) {
-            if (ncg == 0 || op != (int)(cg[ncg - 1] & 0xf)) cg[ncg++] = (uint32_t)len << 4 | (uint32_t)op;
-            else cg[ncg - 1] += (uint32_t)len << 4;
-        };
-        int which = 0, i = rlen - 1, k = (i + w + 1 < lq ? i + w + 1 : lq) - 1;
-        while (i >= 0 && k >= 0) {
-            which = z[(int64_t)i * n_col + (k - (i > w ? i - w : 0))] >> (which << 1) & 3;
-            if (which == 0) { push(0, 1); --i; --k; }
-            else if (which == 1) { push(2, 1); --i; }
-            else { push(1, 1); --k; }
-        }
-        if (i >= 0) push(2, i + 1);
-        if (k >= 0) push(1, k + 1);
-        for (int a = 0, b = ncg; a + 1 < b; ++a, --b) { const uint32_t t = cg[a]; cg[a] = cg[b - 1]; cg[b - 1] = t; }
+        if (!T.retry) break;
+        if (R.score == last_sc || w_try == prm.w << 2) break;
+        last_sc = R.score;
+        w_try <<= 1;
+        if (!(++attempt < 3 && R.score < T.truesc - prm.a)) break;
     }
     // NM and MD (bwa.cpp:311-340)
     char *md = mdbuf + T.md_off;
@@ -153,6 +185,119 @@ k_gen_cigar(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ seqs, c
     res[id] = R;
 }
 
+// per-task slices -> dense arrays: ops of task i at cg_out[cg_pos[i] ..], its MD (with the NUL) at md_out[md_pos[i] ..]
+__global__ void __launch_bounds__(256)
+k_cigar_sizes(int n, const CigarRes *__restrict__ res, int32_t *n_ops, int32_t *n_md) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    n_ops[i] = res[i].n_cigar > 0 ? res[i].n_cigar : 0;
+    n_md[i] = res[i].n_cigar >= 0 ? res[i].md_len + 1 : 1;
+}
+__global__ void __launch_bounds__(256)
+k_cigar_compact(int n, const CigarTask *__restrict__ tasks, const CigarRes *__restrict__ res, const uint32_t *__restrict__ cgbuf,
+                const char *__restrict__ mdbuf, const int64_t *__restrict__ cg_pos, const int64_t *__restrict__ md_pos, uint32_t *cg_out, char *md_out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const CigarRes R = res[i];
+    const CigarTask T = tasks[i];
+    for (int k = 0; k < R.n_cigar; ++k) cg_out[cg_pos[i] + k] = cgbuf[T.cg_off + k];
+    if (R.n_cigar >= 0) for (int k = 0; k <= R.md_len; ++k) md_out[md_pos[i] + k] = mdbuf[T.md_off + k];
+    else md_out[md_pos[i]] = 0;
+}
+
+// Runs the tasks (slices not yet assigned) against the context's resident reference; queries are ranges of `seqs` (uploaded here).
+// Results: res[i] and the dense arrays (offsets cg_pos / md_pos have n + 1 entries).
+static int cigar_run(bm2_ctx *c, const bm2_opt *opt, std::vector<CigarTask> &tasks, const uint8_t *seqs, int64_t seq_bytes,
+                     std::vector<CigarRes> &h_res, std::vector<int64_t> &cg_pos, std::vector<int64_t> &md_pos, std::vector<uint32_t> &cg, std::vector<char> &md) {
+    TailProf prof("gen_cigar_dev");
+    const int n = (int)tasks.size();
+    int rc = bm2_check(hipSetDevice(c->device), "hipSetDevice");
+    if (rc) return rc;
+    CigarPrm prm; memset(&prm, 0, sizeof prm);
+    for (int a = 0; a < 25; ++a) prm.mat[a] = opt->mat[a];
+    prm.o_del = opt->o_del; prm.e_del = opt->e_del; prm.o_ins = opt->o_ins; prm.e_ins = opt->e_ins; prm.a = opt->a; prm.w = opt->w; prm.l_pac = c->ix.l_pac;
+    // slices of the scratch buffers (sized for the widest band a task can come to) and the cost class of every task
+    std::vector<int> order((size_t)n);
+    std::vector<int64_t> cost((size_t)n);
+    int64_t zo = 0, eo = 0, co = 0, mo = 0;
+    for (int i = 0; i < n; ++i) {
+        CigarTask &T = tasks[(size_t)i];
+        T.z_off = zo; T.eh_off = eo; T.cg_off = co; T.md_off = mo;
+        cost[(size_t)i] = 0;
+        if (!cigar_range_ok(prm.l_pac, T.q_len, T.rb, T.re)) continue;
+        const int64_t rlen = T.re - T.rb;
+        if (rlen > 0x3fffffff) { bm2_set_error("bm2_gen_cigar_dev: reference range too long"); return BM2_EINVAL; }
+        const int w_first = T.retry ? cigar_first_band(T.q_len, (int)rlen, T.truesc, T.w, prm.a, prm.w, prm.o_del, prm.e_del, prm.o_ins, prm.e_ins) : T.w;
+        if (!(T.q_len == rlen && w_first == 0)) {               // (a retried task never starts from band 0: the first score ends its loop)
+            const int w_cap = T.retry ? (w_first < prm.w << 2 ? prm.w << 2 : w_first) : T.w;
+            const int wb = cigar_band(T.q_len, (int)rlen, w_cap, prm.mat[0], prm.o_del, prm.e_del, prm.o_ins, prm.e_ins);
+            const int n_col = ((T.q_len < 2 * wb + 1 ? T.q_len : 2 * wb + 1) + 3) & ~3;
+            zo = (zo + 3) & ~(int64_t)3; T.z_off = zo;
+            zo += (int64_t)n_col * rlen; eo += T.q_len + 1;
+            cost[(size_t)i] = (int64_t)n_col * rlen;
+        }
+        co += T.q_len + rlen + 2; mo += 2 * (T.q_len + rlen) + 16;
+    }
+    prof.mark("slices");
+    {   // lanes of a wavefront run their tasks side by side: neighbours should cost alike.  Counting sort by cost class (log scale).
+        auto cls = [](int64_t v) { int k = 0; while (v > 0) { v >>= 1; ++k; } return 63 - k; };   // expensive first
+        int64_t cnt[65] = { 0 };
+        for (int i = 0; i < n; ++i) cnt[cls(cost[(size_t)i]) + 1]++;
+        for (int k = 0; k < 64; ++k) cnt[k + 1] += cnt[k];
+        for (int i = 0; i < n; ++i) order[(size_t)cnt[cls(cost[(size_t)i])]++] = i;
+    }
+    prof.mark("order");
+    DevBuf &b_seq = c->b_ref, &b_task = c->b_qer, &b_res = c->b_pairs, &b_scr = c->b_misc;
+    const size_t task_bytes = ((size_t)n * sizeof(CigarTask) + 15) & ~(size_t)15, ord_bytes = ((size_t)n * sizeof(int) + 15) & ~(size_t)15;
+    const size_t z_bytes = ((size_t)zo + 15) & ~(size_t)15, eh_bytes = (size_t)eo * sizeof(int2), cg_bytes = ((size_t)co * 4 + 15) & ~(size_t)15, md_bytes = ((size_t)mo + 15) & ~(size_t)15;
+    const size_t res_bytes = ((size_t)n * sizeof(CigarRes) + 15) & ~(size_t)15, cnt_bytes = ((size_t)(n + 2) * 4 + 15) & ~(size_t)15, pos_bytes = (size_t)(n + 2) * 8;
+    if ((rc = bm2_reserve(b_seq, (size_t)seq_bytes + 64))) return rc;
+    if ((rc = bm2_reserve(b_task, task_bytes + ord_bytes + 64))) return rc;
+    if ((rc = bm2_reserve(b_res, res_bytes + 2 * cnt_bytes + 2 * pos_bytes + 64))) return rc;
+    if ((rc = bm2_reserve(b_scr, z_bytes + eh_bytes + cg_bytes + md_bytes + 64))) return rc;
+    hipStream_t s = c->stream;
+    CigarTask *d_task = (CigarTask *)b_task.p; int *d_order = (int *)((char *)b_task.p + task_bytes);
+    CigarRes *d_res = (CigarRes *)b_res.p;
+    int32_t *d_nops = (int32_t *)((char *)b_res.p + res_bytes), *d_nmd = (int32_t *)((char *)d_nops + cnt_bytes);
+    int64_t *d_cgpos = (int64_t *)((char *)d_nmd + cnt_bytes), *d_mdpos = (int64_t *)((char *)d_cgpos + pos_bytes);
+    uint8_t *d_z = (uint8_t *)b_scr.p; int2 *d_eh = (int2 *)((char *)b_scr.p + z_bytes);
+    uint32_t *d_cg = (uint32_t *)((char *)d_eh + eh_bytes); char *d_md = (char *)d_cg + cg_bytes;
+    prof.mark("reserve");
+    rc = bm2_check(hipMemcpyAsync(b_seq.p, seqs, (size_t)seq_bytes, hipMemcpyHostToDevice, s), "H2D queries");
+    if (!rc) rc = bm2_check(hipMemcpyAsync(d_task, tasks.data(), (size_t)n * sizeof(CigarTask), hipMemcpyHostToDevice, s), "H2D tasks");
+    if (!rc) rc = bm2_check(hipMemcpyAsync(d_order, order.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, s), "H2D order");
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_gen_cigar, dim3((n + 63) / 64), dim3(64), 0, s, c->ix.ref_string, (const uint8_t *)b_seq.p, d_task, d_order, n, prm,
+                       d_z, d_eh, d_cg, d_md, d_res);
+    if ((rc = bm2_check(hipGetLastError(), "k_gen_cigar launch"))) return rc;
+    if (prof.on) { (void)hipStreamSynchronize(s); prof.mark("H2D + kernel"); }
+    // dense output: sizes -> offsets (scan) -> gather, all on the device; then one small copy back
+    hipLaunchKernelGGL(k_cigar_sizes, dim3((n + 255) / 256), dim3(256), 0, s, n, d_res, d_nops, d_nmd);
+    DevBuf scan_tmp;                                            // (scratch of the scans; small)
+    if ((rc = bm2_scan_i32(c, d_nops, n, d_cgpos, scan_tmp))) { bm2_release(scan_tmp); return rc; }
+    if ((rc = bm2_scan_i32(c, d_nmd, n, d_mdpos, scan_tmp))) { bm2_release(scan_tmp); return rc; }
+    cg_pos.resize((size_t)n + 1); md_pos.resize((size_t)n + 1); h_res.resize((size_t)n);
+    rc = bm2_check(hipMemcpyAsync(cg_pos.data(), d_cgpos, (size_t)(n + 1) * 8, hipMemcpyDeviceToHost, s), "D2H cigar offsets");
+    if (!rc) rc = bm2_check(hipMemcpyAsync(md_pos.data(), d_mdpos, (size_t)(n + 1) * 8, hipMemcpyDeviceToHost, s), "D2H MD offsets");
+    if (!rc) rc = bm2_check(hipMemcpyAsync(h_res.data(), d_res, (size_t)n * sizeof(CigarRes), hipMemcpyDeviceToHost, s), "D2H results");
+    if (!rc) rc = bm2_check(hipStreamSynchronize(s), "cigar offsets");
+    bm2_release(scan_tmp);
+    if (rc) return rc;
+    const int64_t n_cg = cg_pos[(size_t)n], n_md = md_pos[(size_t)n];
+    DevBuf &b_out = c->b_pairs2;
+    const size_t ocg_bytes = ((size_t)n_cg * 4 + 15) & ~(size_t)15;
+    if ((rc = bm2_reserve(b_out, ocg_bytes + (size_t)n_md + 64))) return rc;
+    uint32_t *o_cg = (uint32_t *)b_out.p; char *o_md = (char *)b_out.p + ocg_bytes;
+    hipLaunchKernelGGL(k_cigar_compact, dim3((n + 255) / 256), dim3(256), 0, s, n, d_task, d_res, d_cg, d_md, d_cgpos, d_mdpos, o_cg, o_md);
+    if ((rc = bm2_check(hipGetLastError(), "k_cigar_compact launch"))) return rc;
+    cg.resize((size_t)n_cg + 1); md.resize((size_t)n_md + 1);
+    if (n_cg) rc = bm2_check(hipMemcpyAsync(cg.data(), o_cg, (size_t)n_cg * 4, hipMemcpyDeviceToHost, s), "D2H cigars");
+    if (!rc && n_md) rc = bm2_check(hipMemcpyAsync(md.data(), o_md, (size_t)n_md, hipMemcpyDeviceToHost, s), "D2H MD");
+    if (!rc) rc = bm2_check(hipStreamSynchronize(s), "bm2_gen_cigar_dev sync");
+    prof.mark("compact + D2H");
+    return rc;
+}
+
 // Device twin of bm2_gen_cigar: same arguments after the context (which must hold the index), same results.
 extern "C" int bm2_gen_cigar_dev(bm2_ctx *c, const bm2_opt *opt, int32_t n, const uint8_t *seqs, int64_t seq_bytes, const int64_t *q_off,
                                  const int32_t *q_len, const int64_t *rb, const int64_t *re, const int32_t *w, int32_t *score, int32_t *nm,
@@ -164,90 +309,44 @@ extern "C" int bm2_gen_cigar_dev(bm2_ctx *c, const bm2_opt *opt, int32_t n, cons
     *cigar_need = 0; *md_need = 0;
     if (n == 0) return BM2_OK;
     if (opt->e_del <= 0 || opt->e_ins <= 0) { bm2_set_error("bm2_gen_cigar_dev: gap extension penalties must be > 0"); return BM2_EINVAL; }
-    int rc = bm2_check(hipSetDevice(c->device), "hipSetDevice");
-    if (rc) return rc;
-    TailProf prof("gen_cigar_dev");
-    CigarPrm prm; memset(&prm, 0, sizeof prm);
-    for (int a = 0; a < 25; ++a) prm.mat[a] = opt->mat[a];
-    prm.o_del = opt->o_del; prm.e_del = opt->e_del; prm.o_ins = opt->o_ins; prm.e_ins = opt->e_ins; prm.l_pac = c->ix.l_pac;
     std::vector<CigarTask> tasks((size_t)n);
-    std::vector<int> order((size_t)n);
-    std::vector<int64_t> cost((size_t)n);
-    int64_t zo = 0, eo = 0, co = 0, mo = 0;
     for (int i = 0; i < n; ++i) {
-        CigarTask &T = tasks[(size_t)i];
+        CigarTask &T = tasks[(size_t)i]; memset(&T, 0, sizeof T);
         T.q_off = q_off[i]; T.q_len = q_len[i]; T.rb = rb[i]; T.re = re[i]; T.w = w[i];
-        T.z_off = zo; T.eh_off = eo; T.cg_off = co; T.md_off = mo; T.cg_cap = 0; T.md_cap = 0;
-        cost[(size_t)i] = 0; order[(size_t)i] = i;
-        if (!cigar_range_ok(prm.l_pac, q_len[i], rb[i], re[i])) continue;
-        const int64_t rlen = re[i] - rb[i];
-        if (rlen > 0x3fffffff) { bm2_set_error("bm2_gen_cigar_dev: reference range too long"); return BM2_EINVAL; }
-        if (!(q_len[i] == rlen && w[i] == 0)) {
-            const int wb = cigar_band(q_len[i], (int)rlen, w[i], prm.mat[0], prm.o_del, prm.e_del, prm.o_ins, prm.e_ins);
-            const int n_col = q_len[i] < 2 * wb + 1 ? q_len[i] : 2 * wb + 1;
-            zo += (int64_t)n_col * rlen; eo += q_len[i] + 1;
-            cost[(size_t)i] = (int64_t)n_col * rlen;
-        }
-        T.cg_cap = (int32_t)(q_len[i] + rlen + 2); T.md_cap = (int32_t)(2 * (q_len[i] + rlen) + 16);
-        co += T.cg_cap; mo += T.md_cap;
     }
-    // lanes of a wavefront run their tasks side by side: neighbours should cost alike
-    prof.mark("tasks");
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost[(size_t)a] > cost[(size_t)b]; });
-    prof.mark("sort");
-    DevBuf &b_seq = c->b_ref, &b_task = c->b_qer, &b_res = c->b_pairs, &b_scr = c->b_misc;
-    const size_t task_bytes = ((size_t)n * sizeof(CigarTask) + 15) & ~(size_t)15, ord_bytes = (size_t)n * sizeof(int);
-    const size_t z_bytes = ((size_t)zo + 15) & ~(size_t)15, eh_bytes = (size_t)eo * sizeof(int2), cg_bytes = (size_t)co * 4, md_bytes = (size_t)mo;
-    const size_t res_bytes = ((size_t)n * sizeof(CigarRes) + 15) & ~(size_t)15;
-    if ((rc = bm2_reserve(b_seq, (size_t)seq_bytes + 64))) return rc;
-    if ((rc = bm2_reserve(b_task, task_bytes + ord_bytes + 64))) return rc;
-    if ((rc = bm2_reserve(b_res, res_bytes + cg_bytes + md_bytes + 64))) return rc;
-    if ((rc = bm2_reserve(b_scr, z_bytes + eh_bytes + 64))) return rc;
-    hipStream_t s = c->stream;
-    CigarTask *d_task = (CigarTask *)b_task.p; int *d_order = (int *)((char *)b_task.p + task_bytes);
-    CigarRes *d_res = (CigarRes *)b_res.p; uint32_t *d_cg = (uint32_t *)((char *)b_res.p + res_bytes); char *d_md = (char *)d_cg + cg_bytes;
-    uint8_t *d_z = (uint8_t *)b_scr.p; int2 *d_eh = (int2 *)((char *)b_scr.p + z_bytes);
-    prof.mark("reserve");
-    rc = bm2_check(hipMemcpyAsync(b_seq.p, seqs, (size_t)seq_bytes, hipMemcpyHostToDevice, s), "H2D queries");
-    if (!rc) rc = bm2_check(hipMemcpyAsync(d_task, tasks.data(), (size_t)n * sizeof(CigarTask), hipMemcpyHostToDevice, s), "H2D tasks");
-    if (!rc) rc = bm2_check(hipMemcpyAsync(d_order, order.data(), ord_bytes, hipMemcpyHostToDevice, s), "H2D order");
+    std::vector<CigarRes> res; std::vector<int64_t> cg_pos, md_pos; std::vector<uint32_t> cg; std::vector<char> mdv;
+    const int rc = cigar_run(c, opt, tasks, seqs, seq_bytes, res, cg_pos, md_pos, cg, mdv);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_gen_cigar, dim3((n + 63) / 64), dim3(64), 0, s, c->ix.ref_string, (const uint8_t *)b_seq.p, d_task, d_order, n, prm,
-                       d_z, d_eh, d_cg, d_md, d_res);
-    rc = bm2_check(hipGetLastError(), "k_gen_cigar launch");
-    if (prof.on) { (void)hipStreamSynchronize(s); prof.mark("H2D + kernel"); }
-    std::vector<CigarRes> h_res((size_t)n);
-    std::vector<uint32_t> h_cg((size_t)co); std::vector<char> h_md((size_t)mo + 1);
-    prof.mark("host buffers");
-    if (!rc) rc = bm2_check(hipMemcpyAsync(h_res.data(), d_res, (size_t)n * sizeof(CigarRes), hipMemcpyDeviceToHost, s), "D2H results");
-    if (!rc && co) rc = bm2_check(hipMemcpyAsync(h_cg.data(), d_cg, cg_bytes, hipMemcpyDeviceToHost, s), "D2H cigars");
-    if (!rc && mo) rc = bm2_check(hipMemcpyAsync(h_md.data(), d_md, md_bytes, hipMemcpyDeviceToHost, s), "D2H MD");
-    if (!rc) rc = bm2_check(hipStreamSynchronize(s), "bm2_gen_cigar_dev sync");
-    if (rc) return rc;
-    prof.mark("D2H");
-    int64_t oc = 0, om = 0;                                     // pack into the caller's arrays, as bm2_gen_cigar lays them out
+    int64_t oc = 0, om = 0;                                     // the caller's layout: NULL results take no space at all
     for (int i = 0; i < n; ++i) {
-        const CigarRes &R = h_res[(size_t)i]; const CigarTask &T = tasks[(size_t)i];
+        const CigarRes &R = res[(size_t)i];
         score[i] = R.score; nm[i] = R.nm; n_cigar[i] = R.n_cigar; cigar_off[i] = oc; md_off[i] = om;
         if (R.n_cigar < 0) continue;
-        if (cigar && oc + R.n_cigar <= cigar_cap) memcpy(cigar + oc, h_cg.data() + T.cg_off, (size_t)R.n_cigar * 4);
-        if (md && om + R.md_len + 1 <= md_cap) memcpy(md + om, h_md.data() + T.md_off, (size_t)R.md_len + 1);
+        if (cigar && oc + R.n_cigar <= cigar_cap) memcpy(cigar + oc, cg.data() + cg_pos[(size_t)i], (size_t)R.n_cigar * 4);
+        if (md && om + R.md_len + 1 <= md_cap) memcpy(md + om, mdv.data() + md_pos[(size_t)i], (size_t)R.md_len + 1);
         oc += R.n_cigar; om += R.md_len + 1;
     }
-    prof.mark("pack");
     *cigar_need = oc; *md_need = om;
     if (oc > cigar_cap || om > md_cap || (oc && !cigar) || (om && !md)) return BM2_ECAP;
     return BM2_OK;
 }
 
-// The CIGAR batch of a SAM chunk on the device (hook of bm2h_sam_pe / bm2h_sam_se: user = the context).  The capacities are upper
-// bounds computed by the caller, so this cannot come back with BM2_ECAP.
-int bm2_dev_cigar_batch(void *user, const bm2_opt *opt, int32_t n, const uint8_t *seqs, int64_t seq_bytes, const int64_t *q_off, const int32_t *q_len,
-                        const int64_t *rb, const int64_t *re, const int32_t *w, int32_t *score, int32_t *nm, int32_t *n_cigar, int64_t *cigar_off,
-                        uint32_t *cigar, int64_t cigar_cap, int64_t *md_off, char *md, int64_t md_cap) {
-    int64_t cn = 0, mn = 0;
-    return bm2_gen_cigar_dev((bm2_ctx *)user, opt, n, seqs, seq_bytes, q_off, q_len, rb, re, w, score, nm, n_cigar, cigar_off, cigar, cigar_cap, &cn,
-                             md_off, md, md_cap, &mn);
+// The CIGAR batch of a SAM chunk on the device (hook of bm2h_sam_pe / bm2h_sam_se: user = the context): every hit with the retry loop
+// of mem_reg2aln run by the kernel, results compacted on the device.
+int bm2_dev_cigar_batch(void *user, const bm2_opt *opt, const bm2_reads *reads, int64_t enc_bytes, int32_t n, const bm2h_cg_hit *hits, bm2h_cg_out *out) {
+    bm2_ctx *c = (bm2_ctx *)user;
+    std::vector<CigarTask> tasks((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        CigarTask &T = tasks[(size_t)i]; memset(&T, 0, sizeof T);
+        const bm2h_cg_hit &h = hits[i];
+        T.q_off = reads->off[h.read] + h.qb; T.q_len = h.qe - h.qb; T.rb = h.rb; T.re = h.re; T.w = h.w; T.truesc = h.truesc; T.retry = 1;
+    }
+    std::vector<CigarRes> res;
+    const int rc = cigar_run(c, opt, tasks, reads->enc, enc_bytes, res, out->cigar_off, out->md_off, out->cigar, out->md);
+    if (rc) return rc;
+    out->score.resize((size_t)n); out->nm.resize((size_t)n); out->n_cigar.resize((size_t)n);
+    for (int i = 0; i < n; ++i) { out->score[(size_t)i] = res[(size_t)i].score; out->nm[(size_t)i] = res[(size_t)i].nm; out->n_cigar[(size_t)i] = res[(size_t)i].n_cigar; }
+    return BM2_OK;
 }
 
 extern "C" int bm2_sam_se_dev(bm2_ctx *c, const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt *so, const bm2_reads *reads,

@@ -9,12 +9,21 @@
 typedef int (*bm2h_ksw_batch_fn)(void *user, int32_t n, const uint8_t *qbuf, int64_t qbuf_bytes, const int64_t *q_off, const int32_t *q_len,
                                  const int64_t *t_pos, const int32_t *t_len, const int32_t *xtra, const bm2_opt *opt,
                                  const uint8_t *ref_string, bm2_ksw_result *out);
-// The batch of CIGAR alignments of one chunk (bm2_gen_cigar semantics; queries are ranges of the chunk's read buffer `seqs`).  The
-// capacities are upper bounds, so one call always fits.  0 = success.
-typedef int (*bm2h_cigar_batch_fn)(void *user, const bm2_opt *opt, int32_t n, const uint8_t *seqs, int64_t seq_bytes, const int64_t *q_off,
-                                   const int32_t *q_len, const int64_t *rb, const int64_t *re, const int32_t *w, int32_t *score, int32_t *nm,
-                                   int32_t *n_cigar, int64_t *cigar_off, uint32_t *cigar, int64_t cigar_cap, int64_t *md_off, char *md,
-                                   int64_t md_cap);
+// The batch of CIGAR alignments of one chunk.  An alignment is a function of the HIT alone -- mem_reg2aln (bwamem.cpp:1732-1766) reads
+// qb, qe, rb, re, truesc and w of the hit and the read's bases, derives its band, and retries with doubled bands while the score keeps
+// improving -- so the tail numbers the chunk's hits, finds out in a dry run of the pairing flow WHICH hits get printed, and hands
+// those to a hook of this type in one call; the hook runs the whole retry loop per hit (the device kernel of cigar.hip, or the host
+// code for tests) and returns compact arrays: CIGAR ops of hit i at cigar[cigar_off[i] .. +n_cigar[i]) (n_cigar < 0: the reference
+// returns NULL), its MD string NUL-terminated at md[md_off[i]].  0 = success.
+#include <vector>
+struct bm2h_cg_hit { int64_t rb, re; int32_t read, qb, qe, truesc, w, pad; };
+struct bm2h_cg_out {
+    std::vector<int32_t> score, nm, n_cigar;
+    std::vector<int64_t> cigar_off, md_off;
+    std::vector<uint32_t> cigar; std::vector<char> md;
+};
+typedef int (*bm2h_cigar_batch_fn)(void *user, const bm2_opt *opt, const bm2_reads *reads, int64_t enc_bytes, int32_t n, const bm2h_cg_hit *hits,
+                                   bm2h_cg_out *out);
 // bm2_sam_pe / bm2_sam_se with the rescue batch routed through `fn` and the CIGAR batch through `cfn` (NULL: host code in place)
 int bm2h_sam_pe(const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt *so, const bm2_reads *reads, const bm2_read_text *txt,
                 const bm2_alnreg_t *alnregs, const int64_t *reg_off, int64_t n_processed, const bm2_pestat *pes_in, bm2_pestat *pes_out,

@@ -111,9 +111,7 @@ extern "C" int bm2_ksw_align2_dev(bm2_ctx *c, int32_t n, const uint8_t *seqs, in
     return ksw_batch_run(c, n, seqs, seq_bytes, nullptr, q_off, q_len, t_off, t_len, xtra, mat, o_del, e_del, o_ins, e_ins, out);
 }
 
-int bm2_dev_cigar_batch(void *user, const bm2_opt *opt, int32_t n, const uint8_t *seqs, int64_t seq_bytes, const int64_t *q_off, const int32_t *q_len,
-                        const int64_t *rb, const int64_t *re, const int32_t *w, int32_t *score, int32_t *nm, int32_t *n_cigar, int64_t *cigar_off,
-                        uint32_t *cigar, int64_t cigar_cap, int64_t *md_off, char *md, int64_t md_cap);      // cigar.hip
+int bm2_dev_cigar_batch(void *user, const bm2_opt *opt, const bm2_reads *reads, int64_t enc_bytes, int32_t n, const bm2h_cg_hit *hits, bm2h_cg_out *out);      // cigar.hip
 
 // bm2_sam_pe with the mate-rescue alignments AND the CIGAR alignments of the chunk on the device: the host plans them, this hook runs them against the
 // context's resident ref_string, the host replays the pairs (sam_tail.cpp: bm2h_sam_pe).

@@ -211,33 +211,42 @@ int approx_mapq_se(const bm2_opt *opt, const bm2_sam_opt *so, const bm2_alnreg_t
     return mapq;
 }
 
-// mem_reg2aln, bwamem.cpp:1732-1805; ar == NULL -> the unmapped record
-// ---- CIGAR generation as a batch.  A hit's alignment depends on (read, qb, qe, rb, re, band) only, so the SAM flow can be run twice: a
-// dry pass in which reg2aln merely RECORDS what it would align (every band its retry loop could ask for), one batch of all recorded
-// tasks (the device kernel's shape), and the real pass in which reg2aln looks the results up.  Nothing else in the flow looks at a
-// CIGAR before the text is written, so the dry pass takes the same decisions.
-struct CgTask {
-    const uint8_t *q; int32_t qb, qe, w2; int64_t rb, re;
-    bool operator==(const CgTask &o) const { return q == o.q && qb == o.qb && qe == o.qe && w2 == o.w2 && rb == o.rb && re == o.re; }
-};
-struct CgTaskHash {
-    size_t operator()(const CgTask &t) const {
-        uint64_t h = (uint64_t)(uintptr_t)t.q * 0x9E3779B97F4A7C15ull;
-        h ^= ((uint64_t)(uint32_t)t.qb << 32 | (uint32_t)t.qe) + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
-        h ^= (uint64_t)t.rb + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
-        h ^= ((uint64_t)t.re << 8 | (uint32_t)t.w2) + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
-        return (size_t)h;
-    }
-};
-struct CgMemo {                      // results of the batch, indexed through `at`
-    std::unordered_map<CgTask, int, CgTaskHash> at;
-    std::vector<int32_t> score, nm, n_cigar; std::vector<int64_t> cigar_off, md_off;
-    std::vector<uint32_t> cigar; std::vector<char> md;
+// ---- CIGAR generation as a batch.  A hit's alignment depends on the hit alone (qb, qe, rb, re, truesc, w and the read), and nothing in
+// the flow looks at a CIGAR before the text is written.  So the tail numbers the chunk's hits (bm2_alnreg_t::pad = index + 1; hits
+// that mate rescue creates later carry 0), runs the flow once DRY -- reg2aln only notes which hits it is asked for -- sends those
+// through one hook call (bm2h_cigar_batch_fn: the device kernel's shape), and runs the flow again with the results at hand.  Hits
+// without a number (rescued ones) are aligned in place.
+struct CgMemo {                      // results of the batch; task_of[hit number] = position in the batch or -1
+    std::vector<int32_t> task_of;
+    std::vector<bm2h_cg_hit> hits;
+    bm2h_cg_out out;
 };
 struct CgStats { std::atomic<long long> planned{0}, used{0}, missed{0}; };
-struct CgSession { int mode = 0; std::vector<CgTask> *rec = nullptr; const CgMemo *memo = nullptr; CgStats *st = nullptr; };   // mode 1 = record, 2 = replay
+struct CgSession { int mode = 0; std::vector<int32_t> *rec = nullptr; const CgMemo *memo = nullptr; CgStats *st = nullptr; };   // mode 1 = record, 2 = replay
 thread_local CgSession t_cg;
 
+// the band of the first try (bwamem.cpp:1743-1747) and the retry loop (:1748-1766) of mem_reg2aln around bwa_gen_cigar2
+int reg2aln_band(const bm2_opt *opt, int qb, int qe, int64_t rb, int64_t re, int truesc, int w_hit) {
+    const int tmp = infer_bw(qe - qb, (int)(re - rb), truesc, opt->a, opt->o_del, opt->e_del);
+    int w2 = infer_bw(qe - qb, (int)(re - rb), truesc, opt->a, opt->o_ins, opt->e_ins);
+    w2 = w2 > tmp ? w2 : tmp;
+    if (w2 > opt->w) w2 = w2 < w_hit ? w2 : w_hit;
+    return w2;
+}
+bool cigar_with_retries(const bm2_opt *opt, const Ref &R, const uint8_t *query, int qb, int qe, int64_t rb, int64_t re, int truesc, int w_hit,
+                        int *score, std::vector<uint32_t> &cigar, int *NM, std::string &MD) {
+    int w2 = reg2aln_band(opt, qb, qe, rb, re, truesc, w_hit), i = 0, last_sc = -(1 << 30);
+    do {
+        w2 = w2 < opt->w << 2 ? w2 : opt->w << 2;
+        if (!gen_cigar(opt->mat, opt->o_del, opt->e_del, opt->o_ins, opt->e_ins, w2, R, qe - qb, query + qb, rb, re, score, cigar, NM, MD)) return false;
+        if (*score == last_sc || w2 == opt->w << 2) break;
+        last_sc = *score;
+        w2 <<= 1;
+    } while (++i < 3 && *score < truesc - opt->a);
+    return true;
+}
+
+// mem_reg2aln, bwamem.cpp:1732-1805; ar == NULL -> the unmapped record
 bool reg2aln(const bm2_opt *opt, const bm2_sam_opt *so, const Ref &R, int l_query, const uint8_t *query, const bm2_alnreg_t *ar, Aln &a) {
     a = Aln();
     if (ar == 0 || ar->rb < 0 || ar->re < 0) { a.rid = -1; a.pos = -1; a.flag |= 0x4; return true; }
@@ -245,52 +254,36 @@ bool reg2aln(const bm2_opt *opt, const bm2_sam_opt *so, const Ref &R, int l_quer
     const int64_t rb = ar->rb, re = ar->re;
     a.mapq = ar->secondary < 0 ? approx_mapq_se(opt, so, ar) : 0;
     if (ar->secondary >= 0) a.flag |= 0x100;
-    int tmp = infer_bw(qe - qb, (int)(re - rb), ar->truesc, opt->a, opt->o_del, opt->e_del);
-    int w2 = infer_bw(qe - qb, (int)(re - rb), ar->truesc, opt->a, opt->o_ins, opt->e_ins);
-    w2 = w2 > tmp ? w2 : tmp;
-    if (w2 > opt->w) w2 = w2 < ar->w ? w2 : ar->w;
-    int i = 0, score = 0, NM = 0, last_sc = -(1 << 30);
-    bool ok;
-    if (t_cg.mode == 1) {                                        // dry pass: note the bands the loop below could ask for; no alignment
-        int w = w2;
-        for (int t = 0; t < 3; ++t) {
-            w = w < opt->w << 2 ? w : opt->w << 2;
-            const CgTask k = { query, qb, qe, w, rb, re };
-            if (t == 0 || !(t_cg.rec->back() == k)) t_cg.rec->push_back(k);
-            if (w == opt->w << 2) break;
-            w <<= 1;
-        }
+    int score = 0, NM = 0;
+    if (t_cg.mode == 1) {                                        // dry pass: note that this hit is asked for; no alignment
+        if (ar->pad > 0) t_cg.rec->push_back(ar->pad - 1);
         int is_rev;
         const int64_t pos = R.depos(rb < R.l_pac ? rb : re - 1, &is_rev);
         a.is_rev = is_rev; a.rid = R.pos2rid(pos); if (a.rid < 0) a.rid = 0;
         a.pos = pos - R.off[a.rid]; a.cigar.assign(1, (uint32_t)(qe - qb) << 4); a.score = ar->score; a.is_alt = ar->is_alt;
         return true;
     }
-    do {
-        w2 = w2 < opt->w << 2 ? w2 : opt->w << 2;
-        int at = -1;
-        if (t_cg.mode == 2) {
-            const CgTask k = { query, qb, qe, w2, rb, re };
-            const auto it = t_cg.memo->at.find(k);
-            if (it != t_cg.memo->at.end()) at = it->second;
-            if (at >= 0) t_cg.st->used++; else t_cg.st->missed++;
+    int at = -1;
+    if (t_cg.mode == 2 && ar->pad > 0) {
+        const CgMemo &M = *t_cg.memo;
+        if ((size_t)(ar->pad - 1) < M.task_of.size()) at = M.task_of[(size_t)(ar->pad - 1)];
+        if (at >= 0) {                                           // (the hit must still be the one the batch aligned)
+            const bm2h_cg_hit &h = M.hits[(size_t)at];
+            if (h.qb != qb || h.qe != qe || h.rb != rb || h.re != re || h.truesc != ar->truesc || h.w != ar->w) at = -1;
         }
-        if (at >= 0) {                                           // the batch has it
-            const CgMemo &M = *t_cg.memo;
-            ok = M.n_cigar[(size_t)at] >= 0;
-            score = M.score[(size_t)at]; NM = M.nm[(size_t)at];
-            a.cigar.clear(); a.MD.clear();
-            if (ok) {
-                a.cigar.assign(M.cigar.begin() + M.cigar_off[(size_t)at], M.cigar.begin() + M.cigar_off[(size_t)at] + M.n_cigar[(size_t)at]);
-                a.MD = M.md.data() + M.md_off[(size_t)at];
-            }
-        } else
-        ok = gen_cigar(opt->mat, opt->o_del, opt->e_del, opt->o_ins, opt->e_ins, w2, R, qe - qb, query + qb, rb, re, &score, a.cigar, &NM, a.MD);
-        if (!ok) break;
-        if (score == last_sc || w2 == opt->w << 2) break;
-        last_sc = score;
-        w2 <<= 1;
-    } while (++i < 3 && score < ar->truesc - opt->a);
+        if (at >= 0) t_cg.st->used++; else t_cg.st->missed++;
+    }
+    bool ok;
+    if (at >= 0) {                                               // the batch has it
+        const bm2h_cg_out &O = t_cg.memo->out;
+        ok = O.n_cigar[(size_t)at] >= 0;
+        score = O.score[(size_t)at]; NM = O.nm[(size_t)at];
+        a.cigar.clear(); a.MD.clear();
+        if (ok) {
+            a.cigar.assign(O.cigar.begin() + O.cigar_off[(size_t)at], O.cigar.begin() + O.cigar_off[(size_t)at] + O.n_cigar[(size_t)at]);
+            a.MD = O.md.data() + O.md_off[(size_t)at];
+        }
+    } else ok = cigar_with_retries(opt, R, query, qb, qe, rb, re, ar->truesc, ar->w, &score, a.cigar, &NM, a.MD);
     if (!ok) return false;                                      // the reference asserts a.cigar != NULL here
     a.NM = NM;
     int is_rev;
@@ -1153,37 +1146,40 @@ template <class F> void run_threads(int n_threads, F f) {
 
 CgStats g_cigar;                    // counters of the last bm2_sam_pe / bm2_sam_se call that ran a CIGAR session (bm2_sam_cigar_stats)
 
-// the recorded tasks of a dry pass -> unique tasks -> one call of the hook -> memo
-int cigar_session_batch(const bm2_index_desc *idx, const bm2_opt *opt, const bm2_reads *reads, int64_t enc_bytes,
-                        std::vector<std::vector<CgTask>> &recs, bm2h_cigar_batch_fn cfn, void *cuser, CgMemo &M) {
+// the hit numbers a dry pass recorded -> the batch (every hit once, in hit order) -> one call of the hook -> memo
+int cigar_session_batch(const bm2_opt *opt, const bm2_reads *reads, int64_t enc_bytes, const bm2_alnreg_t *alnregs, const int64_t *reg_off,
+                        std::vector<std::vector<int32_t>> &recs, bm2h_cigar_batch_fn cfn, void *cuser, CgMemo &M) {
     TailProf prof("cigar_session");
-    std::vector<CgTask> tasks;
-    for (auto &v : recs) for (const CgTask &t : v) if (M.at.emplace(t, (int)tasks.size()).second) tasks.push_back(t);
-    prof.mark("dedup (hash)");
-    const size_t n = tasks.size();
+    const int n_reads = reads->n_reads;
+    const int64_t n_hits = reg_off[n_reads];
+    M.task_of.assign((size_t)n_hits, -1);
+    for (auto &v : recs) for (int32_t id : v) if (id >= 0 && id < n_hits) M.task_of[(size_t)id] = 0;
+    int32_t n = 0;
+    for (int64_t i = 0; i < n_hits; ++i) if (M.task_of[(size_t)i] == 0) M.task_of[(size_t)i] = n++;
     g_cigar.planned = (long long)n;
     if (n == 0) return BM2_OK;
-    if (n > 0x7fffffff) { bm2_set_error("too many CIGAR alignments in one chunk"); return BM2_EINVAL; }
-    std::vector<int64_t> q_off(n), rb(n), re(n);
-    std::vector<int32_t> q_len(n), w(n);
-    int64_t ccap = 0, mcap = 0;
-    for (size_t i = 0; i < n; ++i) {
-        const CgTask &t = tasks[i];
-        q_off[i] = (t.q - reads->enc) + t.qb; q_len[i] = t.qe - t.qb; rb[i] = t.rb; re[i] = t.re; w[i] = t.w2;
-        const bool ok = q_len[i] > 0 && t.rb < t.re && !(t.rb < idx->l_pac && t.re > idx->l_pac) && t.rb >= 0 && t.re <= (idx->l_pac << 1);
-        if (ok) { ccap += q_len[i] + (t.re - t.rb) + 2; mcap += 2 * (q_len[i] + (t.re - t.rb)) + 16; }
-    }
-    M.score.resize(n); M.nm.resize(n); M.n_cigar.resize(n); M.cigar_off.resize(n); M.md_off.resize(n);
-    M.cigar.resize((size_t)ccap + 1); M.md.resize((size_t)mcap + 1);
-    prof.mark("marshal");
-    return cfn(cuser, opt, (int32_t)n, reads->enc, enc_bytes, q_off.data(), q_len.data(), rb.data(), re.data(), w.data(), M.score.data(),
-               M.nm.data(), M.n_cigar.data(), M.cigar_off.data(), M.cigar.data(), ccap + 1, M.md_off.data(), M.md.data(), mcap + 1);
+    M.hits.resize((size_t)n);
+    int64_t h = 0;
+    for (int r = 0; r < n_reads; ++r)
+        for (; h < reg_off[r + 1]; ++h) {
+            const int32_t t = M.task_of[(size_t)h];
+            if (t < 0) continue;
+            const bm2_alnreg_t &a = alnregs[h];
+            bm2h_cg_hit &k = M.hits[(size_t)t];
+            k.rb = a.rb; k.re = a.re; k.read = r; k.qb = a.qb; k.qe = a.qe; k.truesc = a.truesc; k.w = a.w; k.pad = 0;
+        }
+    prof.mark("batch list");
+    const int rc = cfn(cuser, opt, reads, enc_bytes, n, M.hits.data(), &M.out);
+    prof.mark("hook");
+    return rc;
 }
 
 RescueStats g_rescue;               // counters of the last bm2_sam_pe call (diagnostic; bm2_sam_rescue_stats)
 
-// items [0, n) in blocks over n_threads host threads; f(i, out) appends the text of item i; the blocks are joined in order
-template <class F> bool run_blocks(int n, int n_threads, std::string &out, F f) {
+// items [0, n) in blocks over n_threads host threads; f(i, part) appends the text of item i to its block's string; the blocks are
+// then copied -- in parallel, at their prefix-sum offsets -- straight into the caller's buffer.  *n_out = bytes needed; BM2_ECAP when
+// cap is smaller; a failing item makes the call return BM2_EINVAL with the item's number in `bad`.
+template <class F> int run_blocks(int n, int n_threads, char *out, int64_t cap, int64_t *n_out, int *bad, F f) {
     if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency();
     if (n_threads < 1) n_threads = 1;
     const int block = 256;
@@ -1196,22 +1192,24 @@ template <class F> bool run_blocks(int n, int n_threads, std::string &out, F f) 
             const int b = next.fetch_add(1);
             if (b >= n_blocks || failed.load() >= 0) return;
             const int hi = (b + 1) * block < n ? (b + 1) * block : n;
+            parts[(size_t)b].reserve((size_t)(hi - b * block) * 420);
             for (int i = b * block; i < hi; ++i)
                 if (!f(i, parts[(size_t)b])) { int e = -1; failed.compare_exchange_strong(e, i); return; }
         }
     };
-    if (n_threads == 1) work();
-    else {
-        std::vector<std::thread> th;
-        for (int t = 0; t < n_threads; ++t) th.emplace_back(work);
-        for (auto &t : th) t.join();
-    }
-    if (failed.load() >= 0) { out.clear(); out = std::to_string(failed.load()); return false; }
-    size_t tot = 0;
-    for (auto &p : parts) tot += p.size();
-    out.clear(); out.reserve(tot);
-    for (auto &p : parts) out += p;
-    return true;
+    run_threads(n_threads, work);
+    if (failed.load() >= 0) { *bad = failed.load(); *n_out = 0; return BM2_EINVAL; }
+    std::vector<int64_t> at((size_t)n_blocks + 1, 0);
+    for (int b = 0; b < n_blocks; ++b) at[(size_t)b + 1] = at[(size_t)b] + (int64_t)parts[(size_t)b].size();
+    *n_out = at[(size_t)n_blocks];
+    if (*n_out > cap) return BM2_ECAP;
+    if (!out) return *n_out ? BM2_EINVAL : BM2_OK;
+    next = 0;
+    run_threads(n_threads, [&]() {
+        for (int b; (b = next.fetch_add(1)) < n_blocks;)
+            if (!parts[(size_t)b].empty()) memcpy(out + at[(size_t)b], parts[(size_t)b].data(), parts[(size_t)b].size());
+    });
+    return BM2_OK;
 }
 
 }  // namespace
@@ -1291,12 +1289,22 @@ extern "C" void bm2_sam_rescue_stats(int64_t *planned, int64_t *used, int64_t *m
 }
 
 // the CIGAR batch hook on the host (BM2_CIGAR_FLAT=1): the session machinery tested without a GPU
-static int host_cigar_batch(void *user, const bm2_opt *opt, int32_t n, const uint8_t *seqs, int64_t, const int64_t *q_off, const int32_t *q_len,
-                            const int64_t *rb, const int64_t *re, const int32_t *w, int32_t *score, int32_t *nm, int32_t *n_cigar,
-                            int64_t *cigar_off, uint32_t *cigar, int64_t cigar_cap, int64_t *md_off, char *md, int64_t md_cap) {
-    int64_t cn = 0, mn = 0;
-    return bm2_gen_cigar((const bm2_index_desc *)user, opt, n, seqs, q_off, q_len, rb, re, w, score, nm, n_cigar, cigar_off, cigar, cigar_cap, &cn,
-                         md_off, md, md_cap, &mn);
+static int host_cigar_batch(void *user, const bm2_opt *opt, const bm2_reads *reads, int64_t, int32_t n, const bm2h_cg_hit *hits, bm2h_cg_out *out) {
+    const bm2_index_desc *idx = (const bm2_index_desc *)user;
+    Ref R = { idx->l_pac, idx->ref_string, idx->n_seqs, idx->ann_offset, idx->ann_name, idx->ann_anno };
+    out->score.assign((size_t)n, 0); out->nm.assign((size_t)n, -1); out->n_cigar.assign((size_t)n, -1);
+    out->cigar_off.assign((size_t)n, 0); out->md_off.assign((size_t)n, 0); out->cigar.clear(); out->md.clear();
+    std::vector<uint32_t> cg; std::string md;
+    for (int32_t i = 0; i < n; ++i) {
+        const bm2h_cg_hit &h = hits[i];
+        int score = 0, nm = -1;
+        const bool ok = cigar_with_retries(opt, R, reads->enc + reads->off[h.read], h.qb, h.qe, h.rb, h.re, h.truesc, h.w, &score, cg, &nm, md);
+        out->score[(size_t)i] = score; out->nm[(size_t)i] = nm;
+        out->cigar_off[(size_t)i] = (int64_t)out->cigar.size(); out->md_off[(size_t)i] = (int64_t)out->md.size();
+        if (ok) { out->n_cigar[(size_t)i] = (int32_t)cg.size(); out->cigar.insert(out->cigar.end(), cg.begin(), cg.end()); out->md.insert(out->md.end(), md.begin(), md.end()); }
+        out->md.push_back(0);
+    }
+    return 0;
 }
 
 extern "C" void bm2_sam_cigar_stats(int64_t *planned, int64_t *used, int64_t *missed) {
@@ -1344,14 +1352,27 @@ int bm2h_sam_pe(const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt
     TailProf prof("sam_pe");
     const int n = reads->n_reads;
     std::vector<std::vector<bm2_alnreg_t>> regs((size_t)n);
-    for (int i = 0; i < n; ++i) regs[(size_t)i].assign(alnregs + reg_off[i], alnregs + reg_off[i + 1]);
+    std::atomic<int> name_clash(-1);
+    {
+        int nt = so->n_threads > 0 ? so->n_threads : (int)std::thread::hardware_concurrency();
+        if (nt < 1) nt = 1;
+        if (nt > n / 4096 + 1) nt = n / 4096 + 1;
+        std::atomic<int> nx(0);
+        run_threads(nt, [&]() {
+            for (int lo; (lo = nx.fetch_add(4096)) < n;)
+                for (int i = lo; i < n && i < lo + 4096; ++i) {
+                    regs[(size_t)i].assign(alnregs + reg_off[i], alnregs + reg_off[i + 1]);
+                    for (int64_t k = reg_off[i]; k < reg_off[i + 1]; ++k) regs[(size_t)i][(size_t)(k - reg_off[i])].pad = (int32_t)(k + 1);   // the hit's number (CIGAR batch)
+                    if (!(i & 1) && strcmp(txt->name[i], txt->name[i + 1]) != 0) { int e = -1; name_clash.compare_exchange_strong(e, i); }
+                }
+        });
+    }
+    if (name_clash.load() >= 0) { const int i = name_clash.load(); bm2_set_error("paired reads have different names: \"%s\", \"%s\"", txt->name[i], txt->name[i + 1]); return BM2_EINVAL; }
     prof.mark("hit lists");
     PeStat pes[4];
     if (pes_in) for (int d = 0; d < 4; ++d) { pes[d].low = pes_in[d].low; pes[d].high = pes_in[d].high; pes[d].failed = pes_in[d].failed; pes[d].avg = pes_in[d].avg; pes[d].std = pes_in[d].std; }
     else pestat(opt, so, idx->l_pac, regs, pes);                 // per chunk, as mem_process_seqs does (bwamem.cpp:1366-1370)
     if (pes_out) for (int d = 0; d < 4; ++d) { pes_out[d].low = pes[d].low; pes_out[d].high = pes[d].high; pes_out[d].failed = pes[d].failed; pes_out[d].pad = 0; pes_out[d].avg = pes[d].avg; pes_out[d].std = pes[d].std; }
-    for (int i = 0; i < n; i += 2)
-        if (strcmp(txt->name[i], txt->name[i + 1]) != 0) { bm2_set_error("paired reads have different names: \"%s\", \"%s\"", txt->name[i], txt->name[i + 1]); return BM2_EINVAL; }
     // Mate rescue in three steps, the shape a device kernel needs: plan every pair's alignments on the hit lists as they stand,
     // run them all as one batch (here: host threads over single tasks), then process the pairs with the results at hand.
     // so->rescue_inline = 1 aligns inside the pair loop as mem_sam_pe does; the output is the same.
@@ -1446,7 +1467,7 @@ int bm2h_sam_pe(const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt
         int n_threads = so->n_threads > 0 ? so->n_threads : (int)std::thread::hardware_concurrency();
         if (n_threads < 1) n_threads = 1;
         const int blk = 256, n_blk = (n_pairs + blk - 1) / blk;
-        std::vector<std::vector<CgTask>> recs((size_t)n_blk);
+        std::vector<std::vector<int32_t>> recs((size_t)n_blk);
         std::atomic<int> next(0), failed(-1);
         run_threads(n_threads < n_blk ? n_threads : n_blk, [&]() {
             std::string sink;
@@ -1463,23 +1484,20 @@ int bm2h_sam_pe(const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt
         prof.mark("dry pass");
         int64_t enc_bytes = 0;
         for (int i = 0; i < n; ++i) if (reads->off[i] + reads->len[i] > enc_bytes) enc_bytes = reads->off[i] + reads->len[i];
-        const int rc = cigar_session_batch(idx, opt, reads, enc_bytes, recs, cfn, cuser, memo);
+        const int rc = cigar_session_batch(opt, reads, enc_bytes, alnregs, reg_off, recs, cfn, cuser, memo);
         if (rc) return rc;
         prof.mark("cigar session");
     }
-    std::string s;
-    const bool ok = run_blocks(n_pairs, so->n_threads, s, [&](int pi, std::string &part) {
+    int bad = -1;
+    const int rc_out = run_blocks(n_pairs, so->n_threads, out, cap, n_out, &bad, [&](int pi, std::string &part) {
         if (cfn) { t_cg.mode = 2; t_cg.memo = &memo; t_cg.st = &g_cigar; }
         const bool r = one_pair(pi, &regs[(size_t)2 * pi], part, batch ? &g_rescue : nullptr);
         t_cg = CgSession();
         return r;
     });
-    if (!ok) { bm2_set_error("bm2_sam_pe: pair %s has a hit whose CIGAR cannot be generated (range outside the reference)", s.c_str()); return BM2_EINVAL; }
-    prof.mark("real pass + join");
-    *n_out = (int64_t)s.size();
-    if ((int64_t)s.size() > cap) return BM2_ECAP;
-    if (out && !s.empty()) memcpy(out, s.data(), s.size());
-    return BM2_OK;
+    if (bad >= 0) { bm2_set_error("bm2_sam_pe: pair %d has a hit whose CIGAR cannot be generated (range outside the reference)", bad); return BM2_EINVAL; }
+    prof.mark("real pass + copy");
+    return rc_out;
 }
 
 extern "C" int bm2_sam_se(const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt *so, const bm2_reads *reads,
@@ -1508,11 +1526,12 @@ int bm2h_sam_se(const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt
     };
     CgMemo memo;
     g_cigar.planned = 0; g_cigar.used = 0; g_cigar.missed = 0;
+    for (int64_t k = 0; k < reg_off[n_reads]; ++k) alnregs[k].pad = (int32_t)(k + 1);     // the hit's number (CIGAR batch); the lists are reordered in place
     if (cfn) {                                                   // CIGAR session (see reg2aln): dry pass on copies, batch, real pass
         int n_threads = so->n_threads > 0 ? so->n_threads : (int)std::thread::hardware_concurrency();
         if (n_threads < 1) n_threads = 1;
         const int blk = 512, n_blk = (n_reads + blk - 1) / blk;
-        std::vector<std::vector<CgTask>> recs((size_t)n_blk);
+        std::vector<std::vector<int32_t>> recs((size_t)n_blk);
         std::atomic<int> next(0);
         run_threads(n_threads < n_blk ? n_threads : n_blk, [&]() {
             std::string sink; std::vector<bm2_alnreg_t> tmp;
@@ -1528,19 +1547,16 @@ int bm2h_sam_se(const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt
         });
         int64_t enc_bytes = 0;
         for (int i = 0; i < n_reads; ++i) if (reads->off[i] + reads->len[i] > enc_bytes) enc_bytes = reads->off[i] + reads->len[i];
-        const int rc = cigar_session_batch(idx, opt, reads, enc_bytes, recs, cfn, cuser, memo);
+        const int rc = cigar_session_batch(opt, reads, enc_bytes, alnregs, reg_off, recs, cfn, cuser, memo);
         if (rc) return rc;
     }
-    std::string s;
-    const bool ok = run_blocks(n_reads, so->n_threads, s, [&](int i, std::string &part) {
+    int bad = -1;
+    const int rc_out = run_blocks(n_reads, so->n_threads, out, cap, n_out, &bad, [&](int i, std::string &part) {
         if (cfn) { t_cg.mode = 2; t_cg.memo = &memo; t_cg.st = &g_cigar; }
         const bool r = one_read(i, alnregs + reg_off[i], part);
         t_cg = CgSession();
         return r;
     });
-    if (!ok) { bm2_set_error("bm2_sam_se: read %s has a hit whose CIGAR cannot be generated (range outside the reference)", s.c_str()); return BM2_EINVAL; }
-    *n_out = (int64_t)s.size();
-    if ((int64_t)s.size() > cap) return BM2_ECAP;
-    if (out && !s.empty()) memcpy(out, s.data(), s.size());
-    return BM2_OK;
+    if (bad >= 0) { bm2_set_error("bm2_sam_se: read %d has a hit whose CIGAR cannot be generated (range outside the reference)", bad); return BM2_EINVAL; }
+    return rc_out;
 }

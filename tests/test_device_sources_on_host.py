@@ -108,7 +108,7 @@ ctx2 = bm2.Context(0, fa)
 ref2, got2, pes2 = T._pe_run(d, fa, r1, r2, [], ctx=ctx2)              # rescue AND CIGAR batches on the (emulated) device
 assert got2 == got and bm2.sam_rescue_stats() == stats
 cg = bm2.sam_cigar_stats()
-assert cg[0] >= cg[1] > 40 and cg[2] == 0, cg
+assert cg[0] > 40 and cg[1] >= cg[0] and cg[2] == 0, cg      # hits in the batch, lookups it served (a hit can be printed twice), numbered hits it lacked
 print("ok", stats, cg)
 ''' % (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "bwa-mem2_amd"), emu_lib, str(tmp_path))
     p = subprocess.run(["python", "-c", script], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)

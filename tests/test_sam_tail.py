@@ -80,7 +80,7 @@ def test_sam_se_matches_reference_text(tmp_path, monkeypatch):
     monkeypatch.setenv("BM2_CIGAR_FLAT", "1")                   # the same with CIGAR generation as a session (dry pass, batch, real pass)
     assert _ours(fa, reads, ["q%d" % i for i in range(len(reads))], quals) == got
     cp, cu, cm = bm2.sam_cigar_stats()
-    assert cp >= cu > 3000 and cm == 0, (cp, cu, cm)
+    assert cu >= cp > 3000 and cm == 0, (cp, cu, cm)       # hits in the batch, lookups it served, numbered hits it lacked
 
 
 def test_sam_se_options(tmp_path):
@@ -188,7 +188,7 @@ def test_sam_pe_rescue_batched_equals_inline(tmp_path, monkeypatch):
     monkeypatch.setenv("BM2_CIGAR_FLAT", "1")
     ref4, got4, pes4 = _pe_run(tmp_path, fa, r1, r2, [])
     cp, cu, cm = bm2.sam_cigar_stats()
-    assert got4 == got and cp >= cu > 2000 and cm == 0, (cp, cu, cm)
+    assert got4 == got and cu >= cp > 2000 and cm == 0, (cp, cu, cm)
 
 
 def test_sam_pe_noisy_mates_and_options(tmp_path):

@@ -76,11 +76,11 @@ def test_sam_pe_with_the_rescue_alignments_on_the_device(gpu_ctx_factory, tmp_pa
     assert got2 == got, T._diff(got, got2)
     assert bm2.sam_rescue_stats() == host_stats and host_stats[0] > 500
     planned, used, missed = bm2.sam_cigar_stats()
-    assert planned >= used > 3000 and missed == 0, (planned, used, missed)
+    assert used >= planned > 3000 and missed == 0, (planned, used, missed)     # hits in the batch, lookups served, numbered hits it lacked
 
 
 def test_sam_se_with_the_cigar_alignments_on_the_device(gpu_ctx_factory, tmp_path):
-    # bm2_sam_se_dev: dry pass on the host, k_gen_cigar for every alignment the flow could ask for, real pass -- against the text of
+    # bm2_sam_se_dev: dry pass on the host, k_gen_cigar (with the retry loop of mem_reg2aln) for every hit the flow asks for, real pass -- against the text of
     # the compiled reference (all record kinds: supplementary, XA, unmapped)
     import test_sam_tail as T
     fa, reads = T._case(tmp_path, 41, 4000)
@@ -93,7 +93,7 @@ def test_sam_se_with_the_cigar_alignments_on_the_device(gpu_ctx_factory, tmp_pat
     got = T._ours(fa, reads, names, quals, ctx=gpu_ctx_factory(fa))
     assert ref == got, T._diff(ref, got)
     planned, used, missed = bm2.sam_cigar_stats()
-    assert planned >= used > 3000 and missed == 0, (planned, used, missed)
+    assert used >= planned > 3000 and missed == 0, (planned, used, missed)     # hits in the batch, lookups served, numbered hits it lacked
 
 
 @pytest.mark.parametrize("kw", [{}, dict(a=2, b=5, o_del=7, o_ins=8, e_del=2, e_ins=1)])
