@@ -59,16 +59,22 @@ static int ksw_batch_run(bm2_ctx *c, int32_t n, const uint8_t *qbuf, int64_t qbu
         const int P = (xtra[i] & KSW_XBYTE) ? 16 : 8;
         slen_max = std::max(slen_max, (q_len[i] + P - 1) / P);
     }
-    // rows of a wavefront diverge: neighbours should be alike (same lane width, same segment count, similar target length)
-    std::iota(order.begin(), order.end(), 0);
-    auto key = [&](int i) {
-        const KswTask &T = tasks[(size_t)i];
-        const int P = (T.xtra & KSW_XBYTE) ? 16 : 8;
-        return ((uint64_t)(P == 8) << 62) | ((uint64_t)((T.qlen + P - 1) / P) << 40) | (uint64_t)(uint32_t)T.tlen;
-    };
-    prof.mark("tasks");
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return key(a) > key(b); });
-    prof.mark("sort");
+    // rows of a wavefront diverge: neighbours should be alike (same lane width, same segment count, similar target length): a
+    // counting sort on (lane width, segments, target length / 8), largest first (which of two equal tasks comes first changes nothing)
+    {
+        auto key = [&](int i) {
+            const KswTask &T = tasks[(size_t)i];
+            const int P = (T.xtra & KSW_XBYTE) ? 16 : 8;
+            const int sl = std::min((T.qlen + P - 1) / P, 63), tl = std::min(T.tlen >> 3, 511);
+            return (((P == 8) ? 64 : 0) + sl) * 512 + tl;
+        };
+        const int NB = 128 * 512;
+        std::vector<int> cnt((size_t)NB + 1, 0);
+        for (int i = 0; i < n; ++i) cnt[(size_t)(NB - 1 - key(i)) + 1]++;
+        for (int k = 0; k < NB; ++k) cnt[(size_t)k + 1] += cnt[(size_t)k];
+        for (int i = 0; i < n; ++i) order[(size_t)cnt[(size_t)(NB - 1 - key(i))]++] = i;
+    }
+    prof.mark("order");
     // rows (tasks) per block: as many as fit 64 KB of LDS, the per-workgroup amount every launch may ask for without further ado
     int rows = 16;
     size_t lds = 32 + (size_t)rows * 9 * slen_max * 16 * 2;

@@ -22,6 +22,13 @@
 void bm2_set_error(const char *fmt, ...);
 
 namespace {
+template <class F> void run_threads(int n_threads, F f) {
+    if (n_threads <= 1) { f(); return; }
+    std::vector<std::thread> th;
+    for (int t = 0; t < n_threads; ++t) th.emplace_back(f);
+    for (auto &t : th) t.join();
+}
+
 
 enum { F_NOPAIRING = 0x4, F_ALL = 0x8, F_NO_MULTI = 0x10, F_NO_RESCUE = 0x20, F_REF_HDR = 0x100, F_SOFTCLIP = 0x200, F_PRIMARY5 = 0x800, F_KEEP_SUPP_MAPQ = 0x1000 };
 const int MINUS_INF = -0x40000000;
@@ -222,6 +229,9 @@ struct CgMemo {                      // results of the batch; task_of[hit number
     bm2h_cg_out out;
 };
 struct CgStats { std::atomic<long long> planned{0}, used{0}, missed{0}; };
+// (the per-lookup counts are tallied per thread and added to the shared counters when the thread is through with its blocks: a
+//  shared atomic per lookup, hit by a few hundred threads, took longer than the rest of the pass)
+thread_local long long t_cg_used = 0, t_cg_missed = 0, t_rs_used = 0, t_rs_missed = 0;
 struct CgSession { int mode = 0; std::vector<int32_t> *rec = nullptr; const CgMemo *memo = nullptr; CgStats *st = nullptr; };   // mode 1 = record, 2 = replay
 thread_local CgSession t_cg;
 
@@ -271,7 +281,7 @@ bool reg2aln(const bm2_opt *opt, const bm2_sam_opt *so, const Ref &R, int l_quer
             const bm2h_cg_hit &h = M.hits[(size_t)at];
             if (h.qb != qb || h.qe != qe || h.rb != rb || h.re != re || h.truesc != ar->truesc || h.w != ar->w) at = -1;
         }
-        if (at >= 0) t_cg.st->used++; else t_cg.st->missed++;
+        if (at >= 0) ++t_cg_used; else ++t_cg_missed;
     }
     bool ok;
     if (at >= 0) {                                               // the batch has it
@@ -749,15 +759,27 @@ void pestat(const bm2_opt *opt, const bm2_sam_opt *so, int64_t l_pac, const std:
     std::vector<uint64_t> isize[4];
     const int n = (int)regs.size();
     for (int d = 0; d < 4; ++d) pes[d] = PeStat();
-    for (int i = 0; i < n >> 1; ++i) {
-        const std::vector<bm2_alnreg_t> &r0 = regs[i << 1 | 0], &r1 = regs[i << 1 | 1];
-        if (r0.empty() || r1.empty()) continue;
-        if (cal_sub(opt, r0) > 0.8 * r0[0].score) continue;
-        if (cal_sub(opt, r1) > 0.8 * r1[0].score) continue;
-        if (r0[0].rid != r1[0].rid) continue;
-        int64_t is;
-        const int dir = infer_dir(l_pac, r0[0].rb, r1[0].rb, &is);
-        if (is && is <= so->max_ins) isize[dir].push_back((uint64_t)is);
+    {   // the insert sizes of the pairs whose ends are both unique (collected on several threads: they are sorted before use)
+        int nt = so->n_threads > 0 ? so->n_threads : (int)std::thread::hardware_concurrency();
+        if (nt > (n >> 1) / 8192 + 1) nt = (n >> 1) / 8192 + 1;
+        if (nt < 1) nt = 1;
+        std::vector<std::vector<uint64_t>> loc((size_t)nt * 4);
+        std::atomic<int> nx(0), tid(0);
+        run_threads(nt, [&]() {
+            const int me = tid.fetch_add(1);
+            for (int lo; (lo = nx.fetch_add(8192)) < n >> 1;)
+                for (int i = lo; i < n >> 1 && i < lo + 8192; ++i) {
+                    const std::vector<bm2_alnreg_t> &r0 = regs[i << 1 | 0], &r1 = regs[i << 1 | 1];
+                    if (r0.empty() || r1.empty()) continue;
+                    if (cal_sub(opt, r0) > 0.8 * r0[0].score) continue;
+                    if (cal_sub(opt, r1) > 0.8 * r1[0].score) continue;
+                    if (r0[0].rid != r1[0].rid) continue;
+                    int64_t is;
+                    const int dir = infer_dir(l_pac, r0[0].rb, r1[0].rb, &is);
+                    if (is && is <= so->max_ins) loc[(size_t)me * 4 + dir].push_back((uint64_t)is);
+                }
+        });
+        for (int t = 0; t < nt; ++t) for (int d = 0; d < 4; ++d) isize[d].insert(isize[d].end(), loc[(size_t)t * 4 + d].begin(), loc[(size_t)t * 4 + d].end());
     }
     for (int d = 0; d < 4; ++d) {
         PeStat *r = &pes[d];
@@ -930,9 +952,9 @@ int matesw(const bm2_opt *opt, const bm2_sam_opt *so, const Ref &R, const int32_
         if (rescue_window(opt, R, ann_len, pes, a, l_ms, r, &rb, &re)) {
             const RescueTask *hit = nullptr;
             for (int t = 0; t < n_pre; ++t) if (pre[t].r == r) { hit = &pre[t]; break; }
-            if (hit) { if (st) st->used++; rescue_apply(opt, R, a, l_ms, r, rb, hit->res, ma); }
+            if (hit) { if (st) ++t_rs_used; rescue_apply(opt, R, a, l_ms, r, rb, hit->res, ma); }
             else {
-                if (st && pre) st->missed++;                     // planned before the mate's list changed: rare, computed in place
+                if (st && pre) ++t_rs_missed;                    // planned before the mate's list changed: rare, computed in place
                 rescue_apply(opt, R, a, l_ms, r, rb, rescue_align(opt, R, l_ms, ms, r, rb, re), ma);
             }
             ++n;
@@ -1137,12 +1159,6 @@ bool sam_pe(const bm2_opt *opt, const bm2_sam_opt *so, const Ref &R, const int32
     return true;
 }
 
-template <class F> void run_threads(int n_threads, F f) {
-    if (n_threads <= 1) { f(); return; }
-    std::vector<std::thread> th;
-    for (int t = 0; t < n_threads; ++t) th.emplace_back(f);
-    for (auto &t : th) t.join();
-}
 
 CgStats g_cigar;                    // counters of the last bm2_sam_pe / bm2_sam_se call that ran a CIGAR session (bm2_sam_cigar_stats)
 
@@ -1176,6 +1192,14 @@ int cigar_session_batch(const bm2_opt *opt, const bm2_reads *reads, int64_t enc_
 
 RescueStats g_rescue;               // counters of the last bm2_sam_pe call (diagnostic; bm2_sam_rescue_stats)
 
+void flush_tallies() {
+    if (t_cg_used) g_cigar.used += t_cg_used;
+    if (t_cg_missed) g_cigar.missed += t_cg_missed;
+    if (t_rs_used) g_rescue.used += t_rs_used;
+    if (t_rs_missed) g_rescue.missed += t_rs_missed;
+    t_cg_used = t_cg_missed = t_rs_used = t_rs_missed = 0;
+}
+
 // items [0, n) in blocks over n_threads host threads; f(i, part) appends the text of item i to its block's string; the blocks are
 // then copied -- in parallel, at their prefix-sum offsets -- straight into the caller's buffer.  *n_out = bytes needed; BM2_ECAP when
 // cap is smaller; a failing item makes the call return BM2_EINVAL with the item's number in `bad`.
@@ -1190,14 +1214,19 @@ template <class F> int run_blocks(int n, int n_threads, char *out, int64_t cap, 
     auto work = [&]() {
         for (;;) {
             const int b = next.fetch_add(1);
-            if (b >= n_blocks || failed.load() >= 0) return;
+            if (b >= n_blocks || failed.load() >= 0) break;
             const int hi = (b + 1) * block < n ? (b + 1) * block : n;
             parts[(size_t)b].reserve((size_t)(hi - b * block) * 420);
-            for (int i = b * block; i < hi; ++i)
-                if (!f(i, parts[(size_t)b])) { int e = -1; failed.compare_exchange_strong(e, i); return; }
+            bool ok = true;
+            for (int i = b * block; i < hi && ok; ++i)
+                if (!f(i, parts[(size_t)b])) { int e = -1; failed.compare_exchange_strong(e, i); ok = false; }
+            if (!ok) break;
         }
+        flush_tallies();
     };
+    TailProf prof("run_blocks");
     run_threads(n_threads, work);
+    prof.mark("items");
     if (failed.load() >= 0) { *bad = failed.load(); *n_out = 0; return BM2_EINVAL; }
     std::vector<int64_t> at((size_t)n_blocks + 1, 0);
     for (int b = 0; b < n_blocks; ++b) at[(size_t)b + 1] = at[(size_t)b] + (int64_t)parts[(size_t)b].size();

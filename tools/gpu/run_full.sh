@@ -7,24 +7,24 @@ R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O
 cd $R
 export TMPDIR=/tmp
 if [ -z "$SKIP_TESTS" ]; then
-  timeout 900 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log; tail -4 $O/pytest.log
+  timeout 300 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log; tail -4 $O/pytest.log
 fi
-timeout 1200 python bench.py --steps $STEPS --warmup 3 > $O/bench.json 2> $O/bench.err; echo "bench rc=$?" >> $O/bench.err; tail -12 $O/bench.err
+BM2_TAIL_PROF=1 timeout 700 python bench.py --steps $STEPS --warmup 3 > $O/bench.json 2> $O/bench.err; echo "bench rc=$?" >> $O/bench.err; tail -12 $O/bench.err
 head -c 1500 $O/bench.json; echo
 if [ -z "$SKIP_PROF" ]; then
   cd /tmp
   B="python $R/bench.py --no-cpu-baseline --no-parity --no-e2e"
-  timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/p_kt -o kt -- $B --steps 4 --warmup 1 > $O/bench_kt.json 2> $O/kt.err
+  timeout 250 rocprofv3 --kernel-trace --stats -d /tmp/p_kt -o kt -- $B --steps 4 --warmup 1 > $O/bench_kt.json 2> $O/kt.err
   python $R/tools/rocpd_summary.py $(find /tmp/p_kt -name "*.db" | head -1) $O/kernel_trace.md > /dev/null
-  timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/p_f -o f -- $B --steps 1 --warmup 1 > /dev/null 2> $O/pmc_f.err
+  timeout 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/p_f -o f -- $B --steps 1 --warmup 1 > /dev/null 2> $O/pmc_f.err
   python $R/tools/rocpd_summary.py $(find /tmp/p_f -name "*.db" | head -1) $O/pmc_fetch.md > /dev/null
-  timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/p_w -o w -- $B --steps 1 --warmup 1 > /dev/null 2> $O/pmc_w.err
+  timeout 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/p_w -o w -- $B --steps 1 --warmup 1 > /dev/null 2> $O/pmc_w.err
   python $R/tools/rocpd_summary.py $(find /tmp/p_w -name "*.db" | head -1) $O/pmc_write.md > /dev/null
   rocprofv3 -L > $O/counters_avail.txt 2>&1
   i=0
   for C in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS" "SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS"; do
     i=$((i+1))
-    timeout 300 rocprofv3 --pmc $C --kernel-trace -d /tmp/p_sq$i -o s -- $B --steps 1 --warmup 1 > /dev/null 2> $O/pmc_sq$i.err
+    timeout 200 rocprofv3 --pmc $C --kernel-trace -d /tmp/p_sq$i -o s -- $B --steps 1 --warmup 1 > /dev/null 2> $O/pmc_sq$i.err
     python $R/tools/rocpd_summary.py $(find /tmp/p_sq$i -name "*.db" | head -1) $O/pmc_sq$i.md > /dev/null
   done
   head -30 $O/kernel_trace.md
