@@ -225,59 +225,86 @@ def parity_gate(ctx, bm2, prefix, workdir, seqs, regs, reg_off, opt, opt_args, p
     return res
 
 
-def end_to_end(ctx, bm2, texts, opt, paired, n_threads):
-    """FASTQ text -> SAM text over the chunks `texts` = [(bytes1, bytes2 | None)], two stages on two host threads: the front
-    (parse, upload, device pipeline, a19, download) of chunk n+1 runs while the tail (pairing, rescue + CIGAR batches on the device
-    through a second context that shares the index replica, SAM text) of chunk n does."""
-    ctx2 = bm2.Context(share=ctx)
+def end_to_end(ctx, bm2, texts, opt, paired, n_threads, n_tail=2):
+    """FASTQ text -> SAM text over the chunks `texts` = [(bytes1, bytes2 | None)] as a pipeline of host threads, one stage each:
+    the reader (bm2_fastq_parse_mt), the device stage (H2D, seeding .. extension, mem_sort_dedup_patch, D2H) and n_tail tail workers
+    (pairing, rescue + CIGAR batches on the device through contexts that share the index replica, SAM text).  Chunks leave in order
+    (a chunk's text is complete before it is counted)."""
+    tails = [bm2.Context(share=ctx) for _ in range(n_tail)]
     so = bm2.default_sam_opt(n_threads=n_threads)
-    q = queue.Queue(maxsize=2)
-    stage = {}
-    err = []
+    q_parsed, q_hits = queue.Queue(maxsize=2), queue.Queue(maxsize=2)
+    stage, err, lock = {}, [], threading.Lock()
+    done = [0] * len(texts)
 
     def add(k, dt):
-        stage[k] = stage.get(k, 0.0) + dt
+        with lock:
+            stage[k] = stage.get(k, 0.0) + dt
 
-    def front():
+    def reader():
+        try:
+            for i, (t1, t2) in enumerate(texts):
+                t = time.perf_counter(); ch = bm2.FastqChunk(t1, t2, n_threads); add("parse", time.perf_counter() - t)
+                q_parsed.put((i, ch))
+        except Exception as e:                                    # noqa
+            err.append(e)
+        q_parsed.put(None)
+
+    def device():
         try:
             n_done = 0
-            for t1, t2 in texts:
-                t = time.perf_counter(); ch = bm2.FastqChunk(t1, t2, n_threads); add("parse", time.perf_counter() - t)
+            while True:
+                it = q_parsed.get()
+                if it is None:
+                    break
+                i, ch = it
                 t = time.perf_counter(); ctx.batch_upload_chunk(ch); add("h2d", time.perf_counter() - t)
                 t = time.perf_counter(); ctx.batch_run(opt); add("device", time.perf_counter() - t)
                 t = time.perf_counter(); ctx.batch_finish(opt); add("a19", time.perf_counter() - t)
                 t = time.perf_counter(); aln, aln_off = ctx.batch_download_alnregs(); add("d2h", time.perf_counter() - t)
-                q.put((ch, aln, aln_off, n_done))
+                q_hits.put((i, ch, aln, aln_off, n_done))
                 n_done += ch.n_reads
         except Exception as e:                                    # noqa
             err.append(e)
-        q.put(None)
+        for _ in tails:
+            q_hits.put(None)
 
-    out_bytes, n_reads = 0, 0
-    th = threading.Thread(target=front)
+    def tail(k):
+        buf = None
+        try:
+            while True:
+                it = q_hits.get()
+                if it is None:
+                    break
+                i, ch, aln, aln_off, n_done = it
+                if buf is None:
+                    buf = np.empty(max(1 << 20, int(3 * (int(ch.f.n_bases) + 200 * ch.n_reads))), np.uint8)
+                t = time.perf_counter()
+                txt = tails[k].sam(ch, opt, so, aln, aln_off, n_done, paired, out=buf)
+                add("tail", time.perf_counter() - t)
+                done[i] = (len(txt), ch.n_reads)
+                ch.close()
+        except Exception as e:                                    # noqa
+            err.append(e)
+
+    th = [threading.Thread(target=reader), threading.Thread(target=device)] + [threading.Thread(target=tail, args=(k,)) for k in range(n_tail)]
     t0 = time.perf_counter()
-    th.start()
-    while True:
-        it = q.get()
-        if it is None:
-            break
-        ch, aln, aln_off, n_done = it
-        t = time.perf_counter()
-        txt = ctx2.sam(ch, opt, so, aln, aln_off, n_done, paired)
-        add("tail", time.perf_counter() - t)
-        out_bytes += len(txt); n_reads += ch.n_reads
-        ch.close()
-    th.join()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
     dt = time.perf_counter() - t0
-    ctx2.close()
+    for c in tails:
+        c.close()
     if err:
         raise err[0]
+    out_bytes = sum(d[0] for d in done); n_reads = sum(d[1] for d in done)
     nch = max(len(texts), 1)
     return {"value": n_reads / dt, "unit": "reads/s", "reads": n_reads, "chunks": len(texts), "wall_s": dt, "sam_bytes": out_bytes,
-            "host_threads": n_threads or (os.cpu_count() or 1),
+            "host_threads": n_threads or (os.cpu_count() or 1), "tail_workers": n_tail,
             "stage_ms_per_chunk": {k: v / nch * 1e3 for k, v in stage.items()},
-            "scope": "FASTQ text in host memory -> bm2_fastq_parse_mt -> H2D -> device pipeline incl. mem_sort_dedup_patch (a19) -> D2H -> pairing / mate rescue / "
-                     "CIGAR (device batches) / SAM text in host memory; front and tail of consecutive chunks overlap; file I/O excluded"}
+            "scope": "FASTQ text in host memory -> bm2_fastq_parse_mt | H2D -> device pipeline incl. mem_sort_dedup_patch (a19) -> D2H | pairing / "
+                     "mate rescue / CIGAR (device batches) / SAM text in host memory; one host thread per stage (two tail workers), stages of "
+                     "consecutive chunks overlap; file I/O excluded"}
 
 
 def main():
@@ -296,7 +323,9 @@ def main():
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--parity-reads", type=int, default=int(os.environ.get("BM2_BENCH_PARITY_READS", 20480)))
     ap.add_argument("--no-e2e", action="store_true")
-    ap.add_argument("--e2e-chunks", type=int, default=int(os.environ.get("BM2_BENCH_E2E_CHUNKS", 4)))
+    ap.add_argument("--e2e-chunks", type=int, default=int(os.environ.get("BM2_BENCH_E2E_CHUNKS", 10)))
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling: ONE chunk of --reads reads is cut at multiples of 512 over the ranks (SURVEY.md 8(e)) instead of one chunk per rank")
     ap.add_argument("--workdir", default=os.environ.get("BM2_BENCH_WORKDIR", "/tmp/bm2_bench"))
     a = ap.parse_args()
 
@@ -336,9 +365,12 @@ def main():
     else:
         n_reads = a.reads or 1000000
         opt, opt_args = bm2.default_opt(), []
-        r1, r2 = synth.make_reads_pe(dist_util.shard_seed(seed, rank), contigs, n_reads // 2, L=a.read_len)
+        r1, r2 = synth.make_reads_pe(dist_util.shard_seed(seed, 0 if a.strong else rank), contigs, n_reads // 2, L=a.read_len)
         seqs = np.empty((2 * len(r1), a.read_len), np.uint8)
         seqs[0::2] = r1; seqs[1::2] = r2                    # mates interleaved, as bseq_read_orig delivers PE chunks
+        if a.strong and world > 1:                          # this rank's part of the one chunk: [lo, hi) at multiples of 512 reads
+            b = dist_util.shard_bounds(len(seqs), world)
+            seqs = seqs[b[rank]:b[rank + 1]]
         n_reads = len(seqs)
         enc = seqs.reshape(-1)
         off = np.arange(n_reads, dtype=np.int64) * a.read_len
@@ -364,7 +396,8 @@ def main():
     rc = 0
     if rank == 0:
         steps = max(a.steps, 1)
-        value = world * n_reads * a.steps / dt
+        n_total = (a.reads or 1000000) if (a.strong and not ont) else world * n_reads
+        value = n_total * a.steps / dt
         kern_ms = {k: v / steps for k, v in kms.items()}     # every timed interval of the library's stream (HIP events)
         stage_ms = {}
         for k, v in kern_ms.items():                         # "smem.walk1" ... -> stage "smem"
@@ -404,7 +437,7 @@ def main():
         out = {
             "metric": "aligned reads/s (150bp PE vs GRCh38) at 1/2/4/8 GPU; SAM bit-exact vs ref",
             "value": value, "unit": "reads/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "strong" if a.strong else "weak", "vs_baseline": None,
             "dtype": "int32", "data": "synthetic" if not emu else "synthetic; HOST EMULATOR RUN (not a measurement)",
             "config": {"workload": wl_name + " (SMEM+SAL+chain+banded-SW all on device), synthetic %d Mbp genome with planted repeats/ALT/"
                                    "N-gaps, indexed in-run by bm2_index_build (3100 Mbp = GRCh38 size); `value` = device hot path "
@@ -412,7 +445,8 @@ def main():
                                    "rate of the same library is `end_to_end.value`" % a.genome_mbp,
                        "reads_per_gpu_per_step": n_reads, "bases_per_gpu_per_step": n_bases, "read_len": a.read_len if not ont else None,
                        "genome_mbp": a.genome_mbp,
-                       "parallelism": "reads sharded over %d GPU(s), index replica per GPU, no collectives" % world},
+                       "parallelism": ("ONE chunk cut at multiples of 512 reads over %d GPU(s) (strong scaling), " if a.strong else "one chunk per GPU over %d GPU(s), ") % world
+                                      + "index replica per GPU, no collectives"},
             "stage_ms_per_step": stage_ms, "dominant_stage": dominant,
             "work_per_read": {"backwardExt": st["n_ext"] / n_reads, "lf_steps": st["n_lf"] / n_reads,
                               "sa_lookups": st["n_sa"] / n_reads, "sw_tasks": st["n_sw_tasks"] / n_reads,
@@ -442,7 +476,7 @@ def main():
         }
         if world == 1 and not a.no_parity:
             regs, reg_off = ctx.batch_download()
-            n_s = min(a.parity_reads, n_reads) if not ont else min(256, n_reads)
+            n_s = min(a.parity_reads, n_reads) if not ont else min(a.parity_reads, 256, n_reads)
             if not ont:
                 n_s -= n_s % 512
             out["parity"] = parity_gate(ctx, bm2, prefix, a.workdir, seqs, regs, reg_off, opt, opt_args, paired, max(n_s, 2), a.workload)

@@ -373,15 +373,17 @@ class Context:
             _chk(rc, "bm2_batch_download_alnregs")
             return out[:n.value], aln_off
 
-    def sam(self, chunk, opt, so, alnregs, aln_off, n_processed=0, paired=True):
+    def sam(self, chunk, opt, so, alnregs, aln_off, n_processed=0, paired=True, out=None):
         """SAM alignment lines of a chunk (bm2_sam_pe_dev / bm2_sam_se_dev: rescue and CIGAR alignments as device batches) -> uint8 array."""
         L = lib()
         alnregs = np.ascontiguousarray(alnregs, ALNREG_DT)
         aln_off = np.ascontiguousarray(aln_off, np.int64)
         need = C.c_int64(0)
         cap = max(1 << 20, int(3 * (int(chunk.f.n_bases) + 200 * chunk.n_reads)))
+        if out is not None and len(out) >= 1 << 20:
+            cap = len(out)                                      # a caller's buffer, reused from chunk to chunk (no fresh pages to fault in)
         while True:
-            buf = np.empty(cap, np.uint8)
+            buf = out if out is not None and len(out) == cap else np.empty(cap, np.uint8)
             if paired:
                 rc = L.bm2_sam_pe_dev(C.c_void_p(self.h), C.byref(self._desc), C.byref(opt), C.byref(so), C.byref(chunk.reads), C.byref(chunk.text),
                                       C.c_void_p(alnregs.ctypes.data), C.c_void_p(aln_off.ctypes.data), C.c_int64(n_processed), None, None,

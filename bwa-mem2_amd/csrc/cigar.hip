@@ -9,6 +9,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
 #include <vector>
 #include "../../include/bm2.h"
 #include "bm2_ctx.h"
@@ -64,10 +65,22 @@ static __device__ int put_dec(char *s, int n, int v) {          // kputw: plain 
     return n;
 }
 
+// LDS = true: the row of (H, E) and the query live in LDS, [column][lane], 16 + 16 bits per column and 4 bits per base -- for tasks
+// whose scores stay small (the host checks (l_query + rlen) * largest penalty < CG_SMALL): then "minus infinity" can be -22768 instead of
+// -2^30 without changing a single comparison (every DP value is either a real score or ONE sentinel plus an offset the reference has
+// too; the two families never meet), and a cell costs one LDS read and write instead of four scattered global accesses per lane.
+#define CG_SMALL 10000
+#define CG_MINF16 (-32768 + CG_SMALL)
+template <bool LDS>
 __global__ void __launch_bounds__(64)
 k_gen_cigar(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ seqs, const CigarTask *__restrict__ tasks, const int *__restrict__ order,
             int n, CigarPrm prm, uint8_t *__restrict__ zbuf, int2 *__restrict__ ehbuf, uint32_t *__restrict__ cgbuf, char *__restrict__ mdbuf,
-            CigarRes *__restrict__ res) {
+            CigarRes *__restrict__ res, int qmax) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t cg_lds[];
+    uint32_t *EH = cg_lds;                                      // [(qmax + 1)][64]
+    uint32_t *Q4 = cg_lds + (size_t)(qmax + 1) * 64;            // [(qmax + 7) / 8][64]: 8 bases of 4 bits
+    const int lane = threadIdx.x;
+    constexpr int MINF = LDS ? CG_MINF16 : CG_MINUS_INF;
     const int slot = blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= n) return;
     const int id = order[slot];
@@ -77,8 +90,25 @@ k_gen_cigar(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ seqs, c
     const int lq = T.q_len, rlen = (int)(T.re - T.rb);
     const bool rev = T.rb >= prm.l_pac;
     const uint8_t *qp = seqs + T.q_off;
-    auto Q = [&](int i) -> int { return rev ? qp[lq - 1 - i] : qp[i]; };
+    if (LDS) {                                                  // the query in alignment order (reversed for reverse-strand hits)
+        for (int j0 = 0; j0 < lq; j0 += 8) {
+            uint32_t wq = 0;
+            for (int u = 0; u < 8 && j0 + u < lq; u++) wq |= (uint32_t)((rev ? qp[lq - 1 - (j0 + u)] : qp[j0 + u]) & 15) << (4 * u);
+            Q4[(j0 >> 3) * 64 + lane] = wq;
+        }
+    }
+    auto Q = [&](int i) -> int { return LDS ? (int)((Q4[(i >> 3) * 64 + lane] >> (4 * (i & 7))) & 15u) : (rev ? qp[lq - 1 - i] : qp[i]); };
     auto RF = [&](int i) -> int { return rev ? ref[T.re - 1 - i] : ref[T.rb + i]; };
+    int2 *ehg = ehbuf + T.eh_off;                               // .x = h, .y = e (global version)
+    auto eh_get = [&](int j) -> int2 {
+        if (!LDS) return ehg[j];
+        const uint32_t w = EH[j * 64 + lane];
+        return make_int2((int)(int16_t)(w & 0xffffu), (int)w >> 16);
+    };
+    auto eh_set = [&](int j, int h, int e) {
+        if (!LDS) ehg[j] = make_int2(h, e);
+        else EH[j * 64 + lane] = ((uint32_t)h & 0xffffu) | (uint32_t)e << 16;
+    };
     uint32_t *cg = cgbuf + T.cg_off;
     int ncg = 0;
     // one alignment (bwa_gen_cigar2, bwa.cpp:281-310), or mem_reg2aln's loop around it (bwamem.cpp:1748-1766): retry with twice the band
@@ -98,20 +128,19 @@ k_gen_cigar(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ seqs, c
             const int oe_del = prm.o_del + prm.e_del, oe_ins = prm.o_ins + prm.e_ins, e_del = prm.e_del, e_ins = prm.e_ins;
             const int n_col = ((lq < 2 * w + 1 ? lq : 2 * w + 1) + 3) & ~3;       // row stride: whole dwords (the directions are stored four cells at a time)
             uint8_t *z = zbuf + T.z_off;
-            int2 *eh = ehbuf + T.eh_off;                        // .x = h, .y = e
             int j;
-            eh[0] = make_int2(0, CG_MINUS_INF);
-            for (j = 1; j <= lq && j <= w; ++j) eh[j] = make_int2(-(prm.o_ins + e_ins * j), CG_MINUS_INF);
-            for (; j <= lq; ++j) eh[j] = make_int2(CG_MINUS_INF, CG_MINUS_INF);
+            eh_set(0, 0, MINF);
+            for (j = 1; j <= lq && j <= w; ++j) eh_set(j, -(prm.o_ins + e_ins * j), MINF);
+            for (; j <= lq; ++j) eh_set(j, MINF, MINF);
             for (int i = 0; i < rlen; ++i) {                    // ksw.cpp:598-637
-                int f = CG_MINUS_INF;
+                int f = MINF;
                 const int8_t *sc = &prm.mat[RF(i) * 5];
                 const int beg = i > w ? i - w : 0, end = i + w + 1 < lq ? i + w + 1 : lq;
-                int h1 = beg == 0 ? -(prm.o_del + e_del * (i + 1)) : CG_MINUS_INF;
+                int h1 = beg == 0 ? -(prm.o_del + e_del * (i + 1)) : MINF;
                 uint32_t *zi = (uint32_t *)(z + (int64_t)i * n_col);
                 uint32_t zacc = 0;
                 for (j = beg; j < end; ++j) {
-                    const int2 p = eh[j];
+                    const int2 p = eh_get(j);
                     int m = p.x, e = p.y, h, t;
                     uint8_t d;
                     m += sc[Q(j)];
@@ -122,7 +151,7 @@ k_gen_cigar(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ seqs, c
                     t = m - oe_del; e -= e_del;
                     d |= e > t ? 1 << 2 : 0;
                     e = e > t ? e : t;
-                    eh[j] = make_int2(h1, e);
+                    eh_set(j, h1, e);
                     h1 = h;
                     t = m - oe_ins; f -= e_ins;
                     d |= f > t ? 2 << 4 : 0;
@@ -132,9 +161,9 @@ k_gen_cigar(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ seqs, c
                     if ((c & 3) == 3) { zi[c >> 2] = zacc; zacc = 0; }
                 }
                 if ((end - beg) & 3) zi[(end - beg) >> 2] = zacc;
-                eh[end] = make_int2(h1, CG_MINUS_INF);
+                eh_set(end, h1, MINF);
             }
-            R.score = eh[lq].x;
+            R.score = eh_get(lq).x;
             // backtrack (ksw.cpp:640-660): ops are pushed last-to-first, merged, then reversed
             auto push = [&](int op, int len) {
                 if (ncg == 0 || op != (int)(cg[ncg - 1] & 0xf)) cg[ncg++] = (uint32_t)len << 4 | (uint32_t)op;
@@ -239,12 +268,20 @@ static int cigar_run(bm2_ctx *c, const bm2_opt *opt, std::vector<CigarTask> &tas
         co += T.q_len + rlen + 2; mo += 2 * (T.q_len + rlen) + 16;
     }
     prof.mark("slices");
-    {   // lanes of a wavefront run their tasks side by side: neighbours should cost alike.  Counting sort by cost class (log scale).
-        auto cls = [](int64_t v) { int k = 0; while (v > 0) { v >>= 1; ++k; } return 63 - k; };   // expensive first
-        int64_t cnt[65] = { 0 };
-        for (int i = 0; i < n; ++i) cnt[cls(cost[(size_t)i]) + 1]++;
-        for (int k = 0; k < 64; ++k) cnt[k + 1] += cnt[k];
-        for (int i = 0; i < n; ++i) order[(size_t)cnt[cls(cost[(size_t)i])]++] = i;
+    int n_small = 0, qmax = 0;
+    {   // lanes of a wavefront run their tasks side by side: neighbours should cost alike.  Counting sort by (small-score class first,
+        // then cost on a log scale, expensive first).  "Small": the LDS kernel's condition, see k_gen_cigar.
+        int pen = 1;
+        for (int a = 0; a < 25; ++a) pen = std::max(pen, abs((int)opt->mat[a]));
+        pen = std::max(pen, std::max(opt->o_del + opt->e_del, opt->o_ins + opt->e_ins));
+        static const int no_lds = getenv("BM2_CIGAR_NO_LDS") ? atoi(getenv("BM2_CIGAR_NO_LDS")) : 0;
+        auto small = [&](int i) { const CigarTask &T = tasks[(size_t)i]; return !no_lds && T.q_len <= 220 && (int64_t)(T.q_len + (T.re - T.rb)) * pen < CG_SMALL; };
+        auto cls = [&](int i) { int64_t v = cost[(size_t)i]; int k = 0; while (v > 0) { v >>= 1; ++k; } return (small(i) ? 0 : 64) + 63 - k; };
+        int64_t cnt[129] = { 0 };
+        for (int i = 0; i < n; ++i) cnt[cls(i) + 1]++;
+        for (int k = 0; k < 128; ++k) cnt[k + 1] += cnt[k];
+        n_small = (int)cnt[64];
+        for (int i = 0; i < n; ++i) { order[(size_t)cnt[cls(i)]++] = i; if (small(i)) qmax = std::max(qmax, tasks[(size_t)i].q_len); }
     }
     prof.mark("order");
     DevBuf &b_seq = c->b_ref, &b_task = c->b_qer, &b_res = c->b_pairs, &b_scr = c->b_misc;
@@ -267,8 +304,15 @@ static int cigar_run(bm2_ctx *c, const bm2_opt *opt, std::vector<CigarTask> &tas
     if (!rc) rc = bm2_check(hipMemcpyAsync(d_task, tasks.data(), (size_t)n * sizeof(CigarTask), hipMemcpyHostToDevice, s), "H2D tasks");
     if (!rc) rc = bm2_check(hipMemcpyAsync(d_order, order.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, s), "H2D order");
     if (rc) return rc;
-    hipLaunchKernelGGL(k_gen_cigar, dim3((n + 63) / 64), dim3(64), 0, s, c->ix.ref_string, (const uint8_t *)b_seq.p, d_task, d_order, n, prm,
-                       d_z, d_eh, d_cg, d_md, d_res);
+    if (n_small) {
+        const size_t lds = (size_t)(qmax + 1) * 256 + (size_t)((qmax + 7) / 8) * 256;
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_gen_cigar<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_gen_cigar<true>, dim3((n_small + 63) / 64), dim3(64), lds, s, c->ix.ref_string, (const uint8_t *)b_seq.p, d_task, d_order, n_small,
+                           prm, d_z, d_eh, d_cg, d_md, d_res, qmax);
+    }
+    if (n > n_small)
+        hipLaunchKernelGGL(k_gen_cigar<false>, dim3((n - n_small + 63) / 64), dim3(64), 0, s, c->ix.ref_string, (const uint8_t *)b_seq.p, d_task,
+                           d_order + n_small, n - n_small, prm, d_z, d_eh, d_cg, d_md, d_res, 0);
     if ((rc = bm2_check(hipGetLastError(), "k_gen_cigar launch"))) return rc;
     if (prof.on) { (void)hipStreamSynchronize(s); prof.mark("H2D + kernel"); }
     // dense output: sizes -> offsets (scan) -> gather, all on the device; then one small copy back

@@ -1175,15 +1175,23 @@ int cigar_session_batch(const bm2_opt *opt, const bm2_reads *reads, int64_t enc_
     g_cigar.planned = (long long)n;
     if (n == 0) return BM2_OK;
     M.hits.resize((size_t)n);
-    int64_t h = 0;
-    for (int r = 0; r < n_reads; ++r)
-        for (; h < reg_off[r + 1]; ++h) {
-            const int32_t t = M.task_of[(size_t)h];
-            if (t < 0) continue;
-            const bm2_alnreg_t &a = alnregs[h];
-            bm2h_cg_hit &k = M.hits[(size_t)t];
-            k.rb = a.rb; k.re = a.re; k.read = r; k.qb = a.qb; k.qe = a.qe; k.truesc = a.truesc; k.w = a.w; k.pad = 0;
-        }
+    {
+        int nt = (int)std::thread::hardware_concurrency();
+        if (nt > n_reads / 16384 + 1) nt = n_reads / 16384 + 1;
+        if (nt < 1) nt = 1;
+        std::atomic<int> nx(0);
+        run_threads(nt, [&]() {
+            for (int lo; (lo = nx.fetch_add(16384)) < n_reads;)
+                for (int r = lo; r < n_reads && r < lo + 16384; ++r)
+                    for (int64_t h = reg_off[r]; h < reg_off[r + 1]; ++h) {
+                        const int32_t t = M.task_of[(size_t)h];
+                        if (t < 0) continue;
+                        const bm2_alnreg_t &a = alnregs[h];
+                        bm2h_cg_hit &k = M.hits[(size_t)t];
+                        k.rb = a.rb; k.re = a.re; k.read = r; k.qb = a.qb; k.qe = a.qe; k.truesc = a.truesc; k.w = a.w; k.pad = 0;
+                    }
+        });
+    }
     prof.mark("batch list");
     const int rc = cfn(cuser, opt, reads, enc_bytes, n, M.hits.data(), &M.out);
     prof.mark("hook");

@@ -60,3 +60,75 @@ def test_shard_bounds_are_block_aligned_and_cover():
             b = dist_util.shard_bounds(n, w)
             assert b[0] == 0 and b[-1] == n and all(x <= y for x, y in zip(b, b[1:]))
             assert all(x % 512 == 0 for x in b[:-1])
+
+
+def _align_worker(rank, world, port, lib, fa, npz, out):
+    """one rank of the strong-scaling scheme: its part of ONE chunk through the (emulated) device pipeline, hits gathered on rank 0"""
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "bwa-mem2_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    import bm2
+    from tools import dist_util
+    bm2.LIB_PATH = lib
+    dist_util.init("gloo", world)
+    z = np.load(npz)
+    enc, off, ln = z["enc"], z["off"], z["ln"]
+    b = dist_util.shard_bounds(len(ln), world)
+    lo, hi = b[rank], b[rank + 1]
+    e0 = int(off[lo]); e1 = int(off[hi - 1] + ln[hi - 1]) if hi > lo else e0
+    ctx = bm2.Context(0, fa)
+    opt = bm2.default_opt()
+    ctx.batch_upload(enc[e0:e1], off[lo:hi] - e0, ln[lo:hi]); ctx.batch_run(opt); ctx.batch_finish(opt)
+    aln, aln_off = ctx.batch_download_alnregs()
+    ctx.close()
+    parts = [None] * world if rank == 0 else None
+    dist.gather_object((lo, hi, aln.tobytes(), aln_off.tobytes()), parts, dst=0)          # no collective on the data path: results only
+    if rank == 0:
+        out.put(parts)
+    dist_util.finish(world)
+
+
+def test_two_ranks_align_one_chunk(tmp_path):
+    # SURVEY.md 8(e) with processes: ONE chunk cut at a multiple of 512 reads over two ranks (gloo), every rank runs the device
+    # pipeline (host emulator of the device sources) on its part, rank 0 gathers the hits in read order: equal to the oracle's
+    # mem_alnreg_v contents of the whole chunk, i.e. independent of the sharding
+    import subprocess
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools", "emu")); sys.path.insert(0, os.path.join(ROOT, "bwa-mem2_amd"))
+    import build_emu
+    import bm2
+    from helpers import alnregs_to_recs, ref_binary
+    from tools import oracle, refio, synth
+    if ref_binary() is None:
+        import pytest
+        pytest.skip("oracle/_ref reference binary not present")
+    lib = build_emu.build(str(tmp_path / "emu"))
+    names, ctg, _ = synth.make_genome(5, [60000, 30000], alt_contigs=0, n_repeat_families=2, repeat_len=(200, 800), copies=(3, 8))
+    fa = str(tmp_path / "g.fa")
+    synth.write_fasta(fa, names, ctg)
+    subprocess.check_call([ref_binary(), "index", fa], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    r1, r2 = synth.make_reads_pe(9, ctg, 300, L=100)                    # 600 reads: parts of 512 and 88
+    reads = np.empty((600, 100), np.uint8); reads[0::2] = r1; reads[1::2] = r2
+    enc, off, ln = refio.pack_reads(reads)
+    npz = str(tmp_path / "chunk.npz")
+    np.savez(npz, enc=enc, off=off, ln=ln)
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_align_worker, args=(r, world, port, lib, fa, npz, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    parts = q.get(timeout=1200)
+    for p in ps:
+        p.join(120)
+        assert p.exitcode == 0
+    parts.sort()
+    assert [(lo, hi) for lo, hi, _, _ in parts] == [(0, 512), (512, 600)]
+    aln = np.concatenate([np.frombuffer(a, bm2.ALNREG_DT) for _, _, a, _ in parts])
+    aln_off, base = [0], 0
+    for lo, hi, a, o in parts:
+        o = np.frombuffer(o, np.int64)
+        aln_off += list(o[1:] + base); base += int(o[-1])
+    ix = oracle.Index(fa); exp = ix.run(enc, off, ln)["REGFIN"]; ix.close()
+    got = alnregs_to_recs(aln, np.array(aln_off, np.int64))
+    assert len(got) == len(exp) and got.tobytes() == exp.tobytes()
