@@ -230,8 +230,10 @@ def end_to_end(ctx, bm2, texts, opt, paired, n_threads, n_tail=2):
     the reader (bm2_fastq_parse_mt), the device stage (H2D, seeding .. extension, mem_sort_dedup_patch, D2H) and n_tail tail workers
     (pairing, rescue + CIGAR batches on the device through contexts that share the index replica, SAM text).  Chunks leave in order
     (a chunk's text is complete before it is counted)."""
+    n_tail = int(os.environ.get("BM2_E2E_TAILS", n_tail))
     tails = [bm2.Context(share=ctx) for _ in range(n_tail)]
-    so = bm2.default_sam_opt(n_threads=n_threads)
+    hw = os.cpu_count() or 1
+    so = bm2.default_sam_opt(n_threads=int(os.environ.get("BM2_E2E_TAIL_THREADS", n_threads or max(hw // n_tail, 1))))
     q_parsed, q_hits = queue.Queue(maxsize=2), queue.Queue(maxsize=2)
     stage, err, lock = {}, [], threading.Lock()
     done = [0] * len(texts)
@@ -300,7 +302,7 @@ def end_to_end(ctx, bm2, texts, opt, paired, n_threads, n_tail=2):
     out_bytes = sum(d[0] for d in done); n_reads = sum(d[1] for d in done)
     nch = max(len(texts), 1)
     return {"value": n_reads / dt, "unit": "reads/s", "reads": n_reads, "chunks": len(texts), "wall_s": dt, "sam_bytes": out_bytes,
-            "host_threads": n_threads or (os.cpu_count() or 1), "tail_workers": n_tail,
+            "host_threads": hw, "tail_workers": n_tail, "threads_per_tail_worker": so.n_threads,
             "stage_ms_per_chunk": {k: v / nch * 1e3 for k, v in stage.items()},
             "scope": "FASTQ text in host memory -> bm2_fastq_parse_mt | H2D -> device pipeline incl. mem_sort_dedup_patch (a19) -> D2H | pairing / "
                      "mate rescue / CIGAR (device batches) / SAM text in host memory; one host thread per stage (two tail workers), stages of "

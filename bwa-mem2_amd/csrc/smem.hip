@@ -9,6 +9,7 @@
 // prefetch.  Memory-bound on random 64-B HBM transactions; no LDS reuse exists between reads (the index is ~10^8 lines).
 #include "bm2_ctx.h"
 #include "pipeline.h"
+#include "ksort_dev.h"
 
 // (forcing 8 waves/SIMD with __launch_bounds__(256, 8) spills 88 B/lane and measured 25 % slower: left at the natural 84 VGPRs)
 
@@ -659,6 +660,14 @@ k_smem_finish(int n_reads, const bm2_smem_t *__restrict__ tmp, const int32_t *__
     const int n = smem_cnt[r];
     const int64_t o = smem_off[r];
     const bm2_smem_t *row = tmp + o;
+    if (n > 48) {                                               // long reads own thousands of SMEMs: n log n instead of the n^2 ranking below
+        int32_t *idx = occ_cnt + o;                             // (this read's slice of occ_cnt is free until the loop at the end fills it)
+        for (int i = 0; i < n; i++) idx[i] = i;
+        k_introsort_flat(n, idx, [&](int32_t x, int32_t y) { return row[x].m < row[y].m || (row[x].m == row[y].m && row[x].n < row[y].n); });
+        for (int i = 0; i < n; i++) out[o + i] = row[idx[i]];
+        for (int i = 0; i < n; i++) { const int64_t sv = out[o + i].s; occ_cnt[o + i] = (int32_t)(sv < max_occ ? sv : max_occ); }
+        return;
+    }
     for (int i = 0; i < n; i++) {
         const bm2_smem_t v = row[i];
         int rank = 0;
