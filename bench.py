@@ -245,7 +245,7 @@ def end_to_end(ctx, bm2, texts, opt, paired, n_threads, n_tail=2):
     def reader():
         try:
             for i, (t1, t2) in enumerate(texts):
-                t = time.perf_counter(); ch = bm2.FastqChunk(t1, t2, n_threads); add("parse", time.perf_counter() - t)
+                t = time.perf_counter(); ch = bm2.FastqChunk(t1, t2, min(hw, 48)); add("parse", time.perf_counter() - t)    # a memory-bound scan: a few dozen threads saturate it
                 q_parsed.put((i, ch))
         except Exception as e:                                    # noqa
             err.append(e)

@@ -359,19 +359,16 @@ class Context:
 
     def batch_download_alnregs(self, cap=None):
         nr = self._n_reads
-        cap = cap or max(1024, 4 * nr)
-        aln_off = np.zeros(nr + 1, np.int64)
+        aln_off = np.empty(nr + 1, np.int64)
         L = lib()
         L.bm2_batch_download_alnregs.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_int64)]
-        while True:
-            out = np.zeros(cap, ALNREG_DT)
-            n = C.c_int64(0)
-            rc = L.bm2_batch_download_alnregs(self.h, out.ctypes.data, cap, aln_off.ctypes.data, C.byref(n))
-            if rc == BM2_ECAP:
-                cap = int(n.value)
-                continue
+        n = C.c_int64(0)
+        rc = L.bm2_batch_download_alnregs(self.h, None, 0, aln_off.ctypes.data, C.byref(n))       # the count first: an exact, untouched buffer
+        if rc not in (BM2_OK, BM2_ECAP):
             _chk(rc, "bm2_batch_download_alnregs")
-            return out[:n.value], aln_off
+        out = np.empty(max(int(n.value), 1), ALNREG_DT)
+        _chk(L.bm2_batch_download_alnregs(self.h, out.ctypes.data, len(out), aln_off.ctypes.data, C.byref(n)), "bm2_batch_download_alnregs")
+        return out[:n.value], aln_off
 
     def sam(self, chunk, opt, so, alnregs, aln_off, n_processed=0, paired=True, out=None):
         """SAM alignment lines of a chunk (bm2_sam_pe_dev / bm2_sam_se_dev: rescue and CIGAR alignments as device batches) -> uint8 array."""

@@ -97,7 +97,7 @@ extern "C" int bm2_index_build(const char *fasta, const char *prefix, int n_thre
     int64_t tw = 0;                                     // write cursor into T
     uint8_t tbl[256];
     for (int c = 0; c < 256; c++) tbl[c] = (uint8_t)nt4(c);
-    tbl['\r'] = tbl[' '] = tbl['\t'] = 255;
+    // (kseq keeps every character of a sequence line but the '\r' of a CR-LF line end: a blank inside a line is an ambiguous base)
     srand48(11);
     {
         int64_t p = 0; int lasts = 0; Hole *q = nullptr;
@@ -118,7 +118,8 @@ extern "C" int bm2_index_build(const char *fasta, const char *prefix, int n_thre
                 if (ctg.empty()) { p = e + 1; continue; }
                 Contig &c = ctg.back();
                 const int64_t tw0 = tw;
-                for (int64_t k = p; k < e; k++) {
+                const int64_t le = (e > p && buf[e - 1] == '\r') ? e - 1 : e;
+                for (int64_t k = p; k < le; k++) {
                     const int ch = (uint8_t)buf[k];
                     int v = tbl[ch];
                     if (v < 4) { T[tw++] = (uint8_t)v; lasts = ch; continue; }
@@ -149,22 +150,24 @@ extern "C" int bm2_index_build(const char *fasta, const char *prefix, int n_thre
         for (int64_t i = 0; i < l_pac; i++) pac[i >> 2] |= T[i] << ((~i & 3) << 1);
         FILE *o = fopen((pre + ".pac").c_str(), "wb");
         if (!o) { bm2_set_error("cannot write %s.pac", prefix); return BM2_EIO; }
-        fwrite(pac.data(), 1, (size_t)((l_pac >> 2) + ((l_pac & 3) == 0 ? 0 : 1)), o);
-        if (l_pac % 4 == 0) { uint8_t z = 0; fwrite(&z, 1, 1, o); }
-        uint8_t ct = (uint8_t)(l_pac % 4); fwrite(&ct, 1, 1, o);
-        fclose(o);
+        bool wrote = fwrite(pac.data(), 1, (size_t)((l_pac >> 2) + ((l_pac & 3) == 0 ? 0 : 1)), o) == (size_t)((l_pac >> 2) + ((l_pac & 3) == 0 ? 0 : 1));
+        if (l_pac % 4 == 0) { uint8_t z = 0; wrote = wrote && fwrite(&z, 1, 1, o) == 1; }
+        uint8_t ct = (uint8_t)(l_pac % 4); wrote = wrote && fwrite(&ct, 1, 1, o) == 1;
+        if (fclose(o) != 0 || !wrote) { bm2_set_error("cannot write %s.pac (disk full?)", prefix); return BM2_EIO; }
         o = fopen((pre + ".ann").c_str(), "w");
+        if (!o) { bm2_set_error("cannot write %s.ann", prefix); return BM2_EIO; }
         fprintf(o, "%lld %d %u\n", (long long)l_pac, (int)ctg.size(), 11u);
         for (auto &c : ctg) {
             fprintf(o, "%d %s", 0, c.name.c_str());
             if (!c.anno.empty()) fprintf(o, " %s\n", c.anno.c_str()); else fprintf(o, "\n");
             fprintf(o, "%lld %d %d\n", (long long)c.offset, c.len, c.n_ambs);
         }
-        fclose(o);
+        if (fclose(o) != 0) { bm2_set_error("cannot write %s.ann", prefix); return BM2_EIO; }
         o = fopen((pre + ".amb").c_str(), "w");
+        if (!o) { bm2_set_error("cannot write %s.amb", prefix); return BM2_EIO; }
         fprintf(o, "%lld %d %u\n", (long long)l_pac, (int)ctg.size(), (unsigned)holes.size());
         for (auto &h : holes) fprintf(o, "%lld %d %c\n", (long long)h.offset, h.len, h.amb);
-        fclose(o);
+        if (fclose(o) != 0) { bm2_set_error("cannot write %s.amb", prefix); return BM2_EIO; }
     }
     lap("pac/ann/amb");
     // ---- 3. text = forward + reverse complement (pac2nt, FMI_search.cpp:83-142); .0123

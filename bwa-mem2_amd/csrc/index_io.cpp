@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <string>
+#include <unordered_map>
 #include <vector>
 #include "../../include/bm2.h"
 
@@ -76,12 +77,16 @@ extern "C" int bm2_index_load(const char *prefix, bm2_index_desc *d) {
     }
     if (expect != l_pac) return bad_ann("sequence lengths do not add up to l_pac");
     fclose(f);
-    if ((f = fopen((pre + ".alt").c_str(), "r")) != 0) {     // bntseq.cpp:201-226
-        char line[8192];
-        while (fgets(line, sizeof line, f)) {
-            line[strcspn(line, "\t\r\n")] = 0;
-            if (line[0] == '@') continue;
-            for (int i = 0; i < n_seqs; i++) if (names[i] == line) alt[i] = 1;
+    if ((f = fopen((pre + ".alt").c_str(), "r")) != 0) {     // bntseq.cpp:201-226: the first field of every line that does not start with
+        std::unordered_map<std::string, int> by_name;          // '@' names an ALT contig; the rest of the line (a whole SAM record in
+        for (int i = 0; i < n_seqs; i++) by_name.emplace(names[i], i);     // hs38DH.fa.alt, far longer than any line buffer) is skipped
+        std::string tok;
+        for (int c = fgetc(f); c != EOF; c = fgetc(f)) {
+            if (c == '\t' || c == '\n' || c == '\r') {
+                if (!tok.empty() && tok[0] != '@') { const auto it = by_name.find(tok); if (it != by_name.end()) alt[it->second] = 1; }
+                while (c != '\n' && c != EOF) c = fgetc(f);
+                tok.clear();
+            } else tok.push_back((char)c);
         }
         fclose(f);
     }

@@ -14,6 +14,9 @@
 #include "../../include/bm2.h"
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <unordered_map>
 #include "ksort_host.h"
@@ -22,11 +25,55 @@
 void bm2_set_error(const char *fmt, ...);
 
 namespace {
+// A process-wide pool of worker threads for the tail's parallel phases.  A chunk goes through a dozen short phases; spawning a few
+// hundred threads for each of them cost more than the phases themselves.  run_threads(n, f) runs n copies of f (the caller is one
+// of them) and returns when all are through; several callers (tail workers of different chunks) may be inside at once.
+class TailPool {
+    struct Job { std::function<void()> *f; std::atomic<int> *left; std::mutex *m; std::condition_variable *cv; };
+    std::mutex mu; std::condition_variable cv;
+    std::vector<Job> queue; std::vector<std::thread> workers; bool stop = false;
+    void loop() {
+        for (;;) {
+            Job j;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&]() { return stop || !queue.empty(); });
+                if (stop && queue.empty()) return;
+                j = queue.back(); queue.pop_back();
+            }
+            (*j.f)();
+            if (j.left->fetch_sub(1) == 1) { std::lock_guard<std::mutex> lk(*j.m); j.cv->notify_all(); }
+        }
+    }
+public:
+    TailPool() {
+        int n = (int)std::thread::hardware_concurrency();
+        if (n < 1) n = 1;
+        for (int i = 0; i < n; ++i) workers.emplace_back([this]() { loop(); });
+    }
+    ~TailPool() {
+        { std::lock_guard<std::mutex> lk(mu); stop = true; }
+        cv.notify_all();
+        for (auto &t : workers) t.join();
+    }
+    void run(int n, std::function<void()> f) {
+        if (n <= 1) { f(); return; }
+        std::atomic<int> left(n - 1);
+        std::mutex m; std::condition_variable done;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            for (int i = 0; i < n - 1; ++i) queue.push_back(Job{ &f, &left, &m, &done });
+        }
+        cv.notify_all();
+        f();                                                    // the caller takes part
+        std::unique_lock<std::mutex> lk(m);
+        done.wait(lk, [&]() { return left.load() == 0; });
+    }
+};
+TailPool &tail_pool() { static TailPool p; return p; }
 template <class F> void run_threads(int n_threads, F f) {
     if (n_threads <= 1) { f(); return; }
-    std::vector<std::thread> th;
-    for (int t = 0; t < n_threads; ++t) th.emplace_back(f);
-    for (auto &t : th) t.join();
+    tail_pool().run(n_threads, std::function<void()>(f));
 }
 
 

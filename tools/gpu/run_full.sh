@@ -11,6 +11,13 @@ if [ -z "$SKIP_TESTS" ]; then
 fi
 BM2_TAIL_PROF=1 timeout 700 python bench.py --steps $STEPS --warmup 3 > $O/bench.json 2> $O/bench.err; echo "bench rc=$?" >> $O/bench.err; tail -12 $O/bench.err
 head -c 1500 $O/bench.json; echo
+if [ -z "$SKIP_ONT" ]; then     # config 5 shape on the same index: its own bench line (parity on a sample, CPU baseline on a sample)
+  timeout 500 python bench.py --workload ont2d --steps 3 --warmup 1 --parity-reads 48 > $O/bench_ont2d.json 2> $O/bench_ont2d.err; echo "ont2d rc=$?" >> $O/bench_ont2d.err; tail -6 $O/bench_ont2d.err
+  head -c 600 $O/bench_ont2d.json; echo
+fi
+if [ -n "$TRY_NSUB" ]; then     # experiment: the chunk as two sub-batches on two sets of streams
+  for NS in 1 2; do BM2_N_SUB=$NS timeout 200 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-parity --no-e2e 2> /dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('N_SUB=$NS', d['value'], d['ms_per_step'], d['stage_ms_per_step'])"; done | tee $O/nsub.txt
+fi
 if [ -z "$SKIP_PROF" ]; then
   cd /tmp
   B="python $R/bench.py --no-cpu-baseline --no-parity --no-e2e"
