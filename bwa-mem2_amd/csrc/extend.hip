@@ -238,58 +238,36 @@ static __device__ void lane_dp8(bool run, int qlen, int tlen, int w, int h0, con
         const int s_eq = tb > 3 ? sc_amb : sc_match;
         const int jlo = (1 << 20) - __builtin_amdgcn_readlane(wave_scan_max(alive ? (1 << 20) - beg : 0, 0), 63);
         const int jhi = __builtin_amdgcn_readlane(wave_scan_max(alive ? end : 0, 0), 63);
-        // one cell of the recurrence (bandedSWA.cpp:181-199) on the packed word
-        auto cell = [&](uint32_t &word, int u, int j, uint32_t qw) {
-            const int qb = (int)((qw >> (4 * u)) & 15u);
-            const int e = (int)((word >> (16 * u + 8)) & 0xffu);
-            int M = (int)((word >> (16 * u)) & 0xffu);
-            const int sc = (qb == tb && tb < 4) ? s_eq : ((qb > 3 || tb > 3) ? sc_amb : sc_mis);
-            M = M ? M + sc : 0;
-            int h = M > e ? M : e;
-            h = h > f ? h : f;
-            mj = m > h ? mj : j;
-            m = m > h ? m : h;
-            const int en = imax(imax(e - e_del, M - oe_del), 0);
-            f = imax(imax(f - e_ins, M - oe_ins), 0);
-            const uint32_t nw = (uint32_t)h1 | ((uint32_t)en << 8);
-            word = (word & ~(0xffffu << (16 * u))) | nw << (16 * u);
-            if (nw) { lnz = j; if (fnz < 0) fnz = j; }
-            h1 = h;
-        };
-        // The columns [ilo, ihi) lie inside the band of EVERY live lane of the wavefront (tasks arrive sorted by query length and
-        // their bands move alike): there the pair loop needs no per-cell band test.  The columns of the union outside it keep them.
-        const int ilo_r = __builtin_amdgcn_readlane(wave_scan_max(alive ? beg : 0, 0), 63);
-        const int ihi_r = (1 << 20) - __builtin_amdgcn_readlane(wave_scan_max(alive ? (1 << 20) - end : 0, 0), 63);
-        const int j0 = jlo & ~1;
-        int ilo = (ilo_r + 1) & ~1, ihi = ihi_r & ~1;
-        if (ilo < j0) ilo = j0;
-        if (ihi <= ilo) { ilo = jhi; ihi = jhi; }                 // no common interior: everything goes through the tested loop
-        auto tested = [&](int ja, int jb) {
-            uint32_t qw = 0;
-            for (int jp = ja; jp < jb; jp += 2) {
-                if ((jp & 7) == 0 || jp == ja) qw = QL[(jp >> 3) * 64 + lane] >> (4 * (jp & 7));
-                if (alive && jp + 1 >= beg && jp < end) {
-                    uint32_t word = EH[(jp >> 1) * 64 + lane];
-                    if (jp >= beg && jp < end) cell(word, 0, jp, qw);
-                    if (jp + 1 >= beg && jp + 1 < end) cell(word, 1, jp + 1, qw);
-                    EH[(jp >> 1) * 64 + lane] = word;
-                }
-                qw >>= 8;
-            }
-        };
-        tested(j0, ilo < jhi ? ilo : jhi);
-        if (alive) {
-            uint32_t qw = 0;
-            for (int jp = ilo; jp < ihi; jp += 2) {
-                if ((jp & 7) == 0 || jp == ilo) qw = QL[(jp >> 3) * 64 + lane] >> (4 * (jp & 7));
+        uint32_t qw = 0;
+        for (int jp = jlo & ~1; jp < jhi; jp += 2) {
+            if ((jp & 7) == 0 || jp == (jlo & ~1)) qw = QL[(jp >> 3) * 64 + lane] >> (4 * (jp & 7));
+            if (alive && jp + 1 >= beg && jp < end) {
                 uint32_t word = EH[(jp >> 1) * 64 + lane];
-                cell(word, 0, jp, qw);
-                cell(word, 1, jp + 1, qw);
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const int j = jp + u;
+                    if (j >= beg && j < end) {
+                        const int qb = (int)((qw >> (4 * u)) & 15u);
+                        const int e = (int)((word >> (16 * u + 8)) & 0xffu);
+                        int M = (int)((word >> (16 * u)) & 0xffu);
+                        const int sc = (qb == tb && tb < 4) ? s_eq : ((qb > 3 || tb > 3) ? sc_amb : sc_mis);
+                        M = M ? M + sc : 0;
+                        int h = M > e ? M : e;
+                        h = h > f ? h : f;
+                        mj = m > h ? mj : j;
+                        m = m > h ? m : h;
+                        const int en = imax(imax(e - e_del, M - oe_del), 0);
+                        f = imax(imax(f - e_ins, M - oe_ins), 0);
+                        const uint32_t nw = (uint32_t)h1 | ((uint32_t)en << 8);
+                        word = (word & ~(0xffffu << (16 * u))) | nw << (16 * u);
+                        if (nw) { lnz = j; if (fnz < 0) fnz = j; }
+                        h1 = h;
+                    }
+                }
                 EH[(jp >> 1) * 64 + lane] = word;
-                qw >>= 8;
             }
+            qw >>= 8;
         }
-        tested(ihi, jhi);
         if (alive) {
             uint32_t word = EH[(end >> 1) * 64 + lane];                // eh[end] = {h1, 0}, bandedSWA.cpp:201
             word = (word & ~(0xffffu << (16 * (end & 1)))) | (uint32_t)h1 << (16 * (end & 1));
