@@ -67,6 +67,56 @@ static int upload(void **dst, const T *src, size_t n, hipStream_t s) {
 
 void bm2_batch_destroy(bm2_ctx *c);     // pipeline.hip
 
+#define BM2_PIN_CAP ((size_t)16 << 20)
+// (BM2_PIN_PIECE / BM2_PIN_MIN: test hooks that make small copies go through the staged path in small pieces)
+static const size_t BM2_PIN_BYTES = getenv("BM2_PIN_PIECE") ? (size_t)atol(getenv("BM2_PIN_PIECE")) : BM2_PIN_CAP;
+static const size_t BM2_PIN_MIN = getenv("BM2_PIN_MIN") ? (size_t)atol(getenv("BM2_PIN_MIN")) : (size_t)1 << 20;
+static int pin_ready(bm2_ctx *c) {
+    for (int i = 0; i < 2; i++) {
+        if (!c->pin[i] && bm2_check(hipHostMalloc(&c->pin[i], BM2_PIN_CAP, 0), "hipHostMalloc")) { c->pin[i] = nullptr; return BM2_ENOMEM; }
+        if (!c->pin_ev[i]) (void)hipEventCreateWithFlags(&c->pin_ev[i], hipEventDisableTiming);
+    }
+    return BM2_OK;
+}
+int bm2_copy_h2d(bm2_ctx *c, void *dst_dev, const void *src_host, size_t bytes) {
+    if (bytes < BM2_PIN_MIN || pin_ready(c)) {
+        int rc = bm2_check(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, c->stream), "H2D");
+        return rc ? rc : bm2_check(hipStreamSynchronize(c->stream), "H2D sync");
+    }
+    int k = 0;
+    for (size_t at = 0; at < bytes; at += BM2_PIN_BYTES, k ^= 1) {
+        const size_t n = bytes - at < BM2_PIN_BYTES ? bytes - at : BM2_PIN_BYTES;
+        if (at >= 2 * BM2_PIN_BYTES) { int rc = bm2_check(hipEventSynchronize(c->pin_ev[k]), "H2D staging"); if (rc) return rc; }   // buffer k is free again
+        memcpy(c->pin[k], (const char *)src_host + at, n);
+        int rc = bm2_check(hipMemcpyAsync((char *)dst_dev + at, c->pin[k], n, hipMemcpyHostToDevice, c->stream), "H2D");
+        if (rc) return rc;
+        (void)hipEventRecord(c->pin_ev[k], c->stream);
+    }
+    return bm2_check(hipStreamSynchronize(c->stream), "H2D sync");
+}
+int bm2_copy_d2h(bm2_ctx *c, void *dst_host, const void *src_dev, size_t bytes) {
+    if (bytes < BM2_PIN_MIN || pin_ready(c)) {
+        int rc = bm2_check(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, c->stream), "D2H");
+        return rc ? rc : bm2_check(hipStreamSynchronize(c->stream), "D2H sync");
+    }
+    // piece i travels into buffer i & 1 while piece i - 1 is copied out of the other
+    size_t prev_at = 0, prev_n = 0; int k = 0;
+    for (size_t at = 0; at < bytes; at += BM2_PIN_BYTES, k ^= 1) {
+        const size_t n = bytes - at < BM2_PIN_BYTES ? bytes - at : BM2_PIN_BYTES;
+        int rc = bm2_check(hipMemcpyAsync(c->pin[k], (const char *)src_dev + at, n, hipMemcpyDeviceToHost, c->stream), "D2H");
+        if (rc) return rc;
+        (void)hipEventRecord(c->pin_ev[k], c->stream);
+        if (prev_n) {
+            if ((rc = bm2_check(hipEventSynchronize(c->pin_ev[k ^ 1]), "D2H staging"))) return rc;
+            memcpy((char *)dst_host + prev_at, c->pin[k ^ 1], prev_n);
+        }
+        prev_at = at; prev_n = n;
+    }
+    int rc = bm2_check(hipStreamSynchronize(c->stream), "D2H sync");
+    if (!rc && prev_n) memcpy((char *)dst_host + prev_at, c->pin[k ^ 1], prev_n);
+    return rc;
+}
+
 static int make_streams(bm2_ctx *c) {
     if (bm2_check(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "hipStreamCreate")) return BM2_ENODEV;
     for (int i = 0; i <= BM2_MAX_TIMERS; i++) (void)hipEventCreate(&c->ev[i]);
@@ -78,6 +128,7 @@ static int make_streams(bm2_ctx *c) {
     return BM2_OK;
 }
 static void free_streams(bm2_ctx *c) {
+    for (int i = 0; i < 2; i++) { if (c->pin[i]) (void)hipHostFree(c->pin[i]); if (c->pin_ev[i]) (void)hipEventDestroy(c->pin_ev[i]); c->pin[i] = nullptr; c->pin_ev[i] = nullptr; }
     for (int i = 0; i <= BM2_MAX_TIMERS; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     for (int i = 0; i < 12; i++) {
         if (c->side_stream[i]) (void)hipStreamDestroy(c->side_stream[i]);

@@ -39,6 +39,9 @@ struct bm2_ctx {
     bool is_child = false;
     int n_parts = 1;
     std::vector<int> part_first;
+    // two pinned staging buffers for the large host <-> device copies of a chunk (bm2_copy_h2d / bm2_copy_d2h)
+    void *pin[2] = { nullptr, nullptr };
+    hipEvent_t pin_ev[2] = { nullptr, nullptr };
 };
 #define BM2_N_SUB 1     // sub-batch pipelining is implemented and parity-tested, but did not pay on one GPU (profiles/)
 
@@ -46,6 +49,11 @@ int  bm2_check(hipError_t e, const char *what);            // -> BM2_OK or BM2_E
 void bm2_set_error(const char *fmt, ...);
 int  bm2_reserve(DevBuf &b, size_t bytes);                  // grow-only device allocation
 void bm2_release(DevBuf &b);
+// Large copies between PAGEABLE host memory (the caller's arrays) and the device, staged through the context's pinned buffers in
+// 16 MB pieces: the DMA of one piece overlaps the host memcpy of the next (a plain hipMemcpy of pageable memory runs at a few GB/s).
+// Both return after the data has arrived.
+int bm2_copy_h2d(bm2_ctx *c, void *dst_dev, const void *src_host, size_t bytes);
+int bm2_copy_d2h(bm2_ctx *c, void *dst_host, const void *src_dev, size_t bytes);
 
 struct SwParams;
 int bm2_launch_bsw_pairs(bm2_ctx *c, bm2_seqpair_t *d_pairs, const uint8_t *d_ref, const uint8_t *d_qer, int n, int w,

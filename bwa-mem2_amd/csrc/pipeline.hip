@@ -122,7 +122,7 @@ static int batch_upload_one(bm2_ctx *c, const bm2_reads *reads) {
     if ((rc = bm2_reserve(b->off, (size_t)(n + 1) * 8))) return rc;
     if ((rc = bm2_reserve(b->len, (size_t)(n + 1) * 4))) return rc;
     if (n) {
-        rc = bm2_check(hipMemcpyAsync(b->enc.p, reads->enc, (size_t)nb, hipMemcpyHostToDevice, c->stream), "H2D reads");
+        rc = bm2_copy_h2d(c, b->enc.p, reads->enc, (size_t)nb);
         if (!rc) rc = bm2_check(hipMemcpyAsync(b->off.p, reads->off, (size_t)n * 8, hipMemcpyHostToDevice, c->stream), "H2D off");
         if (!rc) rc = bm2_check(hipMemcpyAsync(b->len.p, reads->len, (size_t)n * 4, hipMemcpyHostToDevice, c->stream), "H2D len");
         if (!rc) rc = bm2_check(hipStreamSynchronize(c->stream), "upload sync");
@@ -428,7 +428,7 @@ static int batch_download_one(bm2_ctx *c, bm2_reg_t *regs, int64_t cap, int64_t 
     if (rc) return rc;
     if (b->n_out_regs > cap) { bm2_set_error("regs capacity %ld < %ld", (long)cap, (long)b->n_out_regs); return BM2_ECAP; }
     if (b->n_out_regs && !regs) return BM2_EINVAL;
-    if (b->n_out_regs) rc = bm2_check(hipMemcpy(regs, b->out_regs.p, (size_t)b->n_out_regs * sizeof(bm2_reg_t), hipMemcpyDeviceToHost), "D2H regs");
+    if (b->n_out_regs) rc = bm2_copy_d2h(c, regs, b->out_regs.p, (size_t)b->n_out_regs * sizeof(bm2_reg_t));
     return rc;
 }
 
@@ -605,7 +605,7 @@ extern "C" int bm2_batch_download_alnregs(bm2_ctx *c, bm2_alnreg_t *out, int64_t
         for (int k = lo; k <= lo + b->n_reads; k++) aln_off[k] += base;
         if (tot <= cap && b->n_fin) {
             if (!out) return BM2_EINVAL;
-            if ((rc = bm2_check(hipMemcpy(out + base, b->fin_out.p, (size_t)b->n_fin * sizeof(bm2_alnreg_t), hipMemcpyDeviceToHost), "D2H alnregs"))) return rc;
+            if ((rc = bm2_copy_d2h(p, out + base, b->fin_out.p, (size_t)b->n_fin * sizeof(bm2_alnreg_t)))) return rc;
         }
         base += b->n_fin;
     }
