@@ -70,9 +70,15 @@ def prepare_genome(workdir, mbp, seed):
     from tools import synth
     pre = os.path.join(workdir, "genome_%dmbp_s%d.fa" % (mbp, seed))
     meta = pre + ".contigs.npz"
+    memo = []
+
+    def contigs():                                            # loaded on demand: 3 GB that a run with a cached chunk never touches
+        if not memo:
+            z = np.load(meta, allow_pickle=True)
+            memo.append([z["c%d" % i] for i in range(int(z["n"]))])
+        return memo[0]
     if os.path.exists(pre + ".bwt.2bit.64") and os.path.exists(meta):
-        z = np.load(meta, allow_pickle=True)
-        return pre, [z["c%d" % i] for i in range(int(z["n"]))]
+        return pre, contigs
     import bm2
     t = time.time()
     total = int(mbp * 1e6)
@@ -87,7 +93,26 @@ def prepare_genome(workdir, mbp, seed):
     bm2.index_build(pre, None, 0)
     log("index built in %.1fs" % (time.time() - t))
     np.savez(meta, n=len(ctg), **{"c%d" % i: c for i, c in enumerate(ctg)})
-    return pre, ctg
+    memo.append(ctg)
+    return pre, contigs
+
+
+def pe_chunk(workdir, contigs_fn, seed, n_reads, read_len, tag=""):
+    """The timed chunk: n_reads/2 synthetic pairs, mates interleaved as bseq_read_orig delivers PE chunks.  Deterministic in (seed,
+    n_reads, read_len), so the array is kept beside the index (the profiling passes of one box re-run this script several times)."""
+    from tools import synth
+    fn = os.path.join(workdir, "chunk_pe_s%d_n%d_l%d%s.npy" % (seed, n_reads, read_len, tag))
+    if os.path.exists(fn):
+        return np.load(fn)
+    r1, r2 = synth.make_reads_pe(seed, contigs_fn(), n_reads // 2, L=read_len)
+    seqs = np.empty((2 * len(r1), read_len), np.uint8)
+    seqs[0::2] = r1; seqs[1::2] = r2
+    try:
+        tmp = "%s.%d.tmp.npy" % (fn, os.getpid())
+        np.save(tmp, seqs); os.replace(tmp, fn)
+    except OSError:
+        pass
+    return seqs
 
 
 def host_threads():
@@ -361,15 +386,13 @@ def main():
     if ont:
         n_reads = a.reads or 2000
         opt, opt_args = bm2.default_opt(**ONT2D), ["-x", "ont2d"]
-        seqs = synth.make_reads_long(dist_util.shard_seed(seed, rank), contigs, n_reads, mean_len=10000, max_len=30000)
+        seqs = synth.make_reads_long(dist_util.shard_seed(seed, rank), contigs(), n_reads, mean_len=10000, max_len=30000)
         from tools import refio
         enc, off, ln = refio.pack_reads(seqs)
     else:
         n_reads = a.reads or 1000000
         opt, opt_args = bm2.default_opt(), []
-        r1, r2 = synth.make_reads_pe(dist_util.shard_seed(seed, 0 if a.strong else rank), contigs, n_reads // 2, L=a.read_len)
-        seqs = np.empty((2 * len(r1), a.read_len), np.uint8)
-        seqs[0::2] = r1; seqs[1::2] = r2                    # mates interleaved, as bseq_read_orig delivers PE chunks
+        seqs = pe_chunk(a.workdir, contigs, dist_util.shard_seed(seed, 0 if a.strong else rank), n_reads, a.read_len)
         if a.strong and world > 1:                          # this rank's part of the one chunk: [lo, hi) at multiples of 512 reads
             b = dist_util.shard_bounds(len(seqs), world)
             seqs = seqs[b[rank]:b[rank + 1]]
@@ -494,7 +517,7 @@ def main():
                 synth.write_fastq(f1, seqs[:nb])
                 cb = cpu_baseline(prefix, [f1], "%d ONT-like reads (the first of the timed chunk)" % nb, opt_args)
             else:
-                c1, c2 = synth.make_reads_pe(seed + 5, contigs, a.cpu_pairs, L=a.read_len)
+                c1, c2 = synth.make_reads_pe(seed + 5, contigs(), a.cpu_pairs, L=a.read_len)
                 f1, f2 = os.path.join(a.workdir, "cpu_1.fq"), os.path.join(a.workdir, "cpu_2.fq")
                 synth.write_fastq(f1, c1, suffix="/1"); synth.write_fastq(f2, c2, suffix="/2")
                 cb = cpu_baseline(prefix, [f1, f2], "%d x %d bp PE reads" % (2 * a.cpu_pairs, a.read_len))
@@ -506,7 +529,7 @@ def main():
             t = time.time()
             texts = []
             for i in range(a.e2e_chunks):                    # distinct chunks of the same shape as the timed one
-                e1, e2 = synth.make_reads_pe(seed + 100 + i, contigs, n_reads // 2, L=a.read_len)
+                e1, e2 = synth.make_reads_pe(seed + 100 + i, contigs(), n_reads // 2, L=a.read_len)
                 fa, fb = os.path.join(a.workdir, "e2e_1.fq"), os.path.join(a.workdir, "e2e_2.fq")
                 synth.write_fastq(fa, e1, prefix="c%d_" % i, suffix="/1"); synth.write_fastq(fb, e2, prefix="c%d_" % i, suffix="/2")
                 texts.append((open(fa, "rb").read(), open(fb, "rb").read()))

@@ -45,6 +45,11 @@ struct bm2_ctx {
 };
 #define BM2_N_SUB 1     // sub-batch pipelining is implemented and parity-tested, but did not pay on one GPU (profiles/)
 
+// Launch-policy knobs (grid sizes, class routing, thresholds): none of them changes a result.  Read from the environment on every
+// use so that tools/gpu/sweep.py can compare settings inside one process; the defaults are the measured best (profiles/).
+#include <stdlib.h>
+static inline int bm2_knob(const char *name, int dflt) { const char *v = getenv(name); return v && *v ? atoi(v) : dflt; }
+
 int  bm2_check(hipError_t e, const char *what);            // -> BM2_OK or BM2_ENODEV (+ message)
 void bm2_set_error(const char *fmt, ...);
 int  bm2_reserve(DevBuf &b, size_t bytes);                  // grow-only device allocation

@@ -205,6 +205,10 @@ static __device__ void lane_dp(bool run, int qlen, int tlen, int w, int h0, cons
 // i.e. every short-read run with the default scoring).  Two columns share one LDS dword -- {H[j], E[j], H[j+1], E[j+1]}
 // -- and the query sits 8 bases to a dword, so a cell costs half an LDS read and half an LDS write instead of two reads
 // and a write, and a wave's rows take 2.6x less LDS: 6 instead of 3 wavefronts per CU for 150-base queries.
+// PF: the row word of the NEXT column pair is requested (unconditionally: one row past the band still lies inside the block's
+// LDS) before the current pair is computed, so the LDS round trip overlaps the ~80 VALU instructions of a pair instead of
+// preceding them; what it buys depends on how many wavefronts share the SIMD (few, for the long classes).
+template <bool PF>
 static __device__ void lane_dp8(bool run, int qlen, int tlen, int w, int h0, const uint8_t *tp, int ts, const SwParams &P,
                                 uint32_t *EH, const uint32_t *QL, int lane, LaneOut &out, long long &cells) {
     const int o_del = P.o_del, e_del = P.e_del, o_ins = P.o_ins, e_ins = P.e_ins, oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
@@ -239,10 +243,13 @@ static __device__ void lane_dp8(bool run, int qlen, int tlen, int w, int h0, con
         const int jlo = (1 << 20) - __builtin_amdgcn_readlane(wave_scan_max(alive ? (1 << 20) - beg : 0, 0), 63);
         const int jhi = __builtin_amdgcn_readlane(wave_scan_max(alive ? end : 0, 0), 63);
         uint32_t qw = 0;
+        uint32_t wnext = PF ? EH[((jlo & ~1) >> 1) * 64 + lane] : 0u;
         for (int jp = jlo & ~1; jp < jhi; jp += 2) {
             if ((jp & 7) == 0 || jp == (jlo & ~1)) qw = QL[(jp >> 3) * 64 + lane] >> (4 * (jp & 7));
+            const uint32_t wcur = wnext;
+            if (PF) wnext = EH[((jp >> 1) + 1) * 64 + lane];
             if (alive && jp + 1 >= beg && jp < end) {
-                uint32_t word = EH[(jp >> 1) * 64 + lane];
+                uint32_t word = PF ? wcur : EH[(jp >> 1) * 64 + lane];
 #pragma unroll
                 for (int u = 0; u < 2; u++) {
                     const int j = jp + u;
@@ -295,18 +302,19 @@ static __device__ void lane_dp8(bool run, int qlen, int tlen, int w, int h0, con
     if (run) { out.score = maxv; out.qle = max_j + 1; out.tle = max_i + 1; out.gtle = max_ie + 1; out.gscore = gscore; out.max_off = max_off; }
 }
 
-template <int SIDE, bool P8>
+template <int SIDE, bool P8, bool PF>
 __global__ void __launch_bounds__(64)
 k_ext_lanes(DevIndex ix, ExtParams xp, const int32_t *__restrict__ tasks, int n_tasks, int qmax,
             const uint8_t *__restrict__ enc, const int64_t *__restrict__ off, const int32_t *__restrict__ len,
             const int64_t *__restrict__ slot_base, const int32_t *__restrict__ reg_seed, const int32_t *__restrict__ reg_chain,
-            const DevChain *__restrict__ chn, const DevSeed *__restrict__ seeds, DevReg *regs, unsigned long long *counters) {
+            const DevChain *__restrict__ chn, const DevSeed *__restrict__ seeds, DevReg *regs, unsigned long long *counters, int rev) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_l[];
     uint32_t *EH = lds_l;                                       // [(qmax+1)][64]           (P8: [(qmax+2)/2][64])
     uint8_t *QL = (uint8_t *)(lds_l + (size_t)(qmax + 1) * 64); // [qmax][64] bytes
     uint32_t *QL8 = lds_l + (size_t)((qmax + 2) / 2) * 64;      // P8: [(qmax+7)/8][64] dwords, 8 bases of 4 bits each
     const int lane = threadIdx.x;
-    const int idx = blockIdx.x * 64 + lane;
+    // (rev: the task list ascends in query length; the blocks with the longest queries -- the slowest wavefronts -- are dispatched first)
+    const int idx = (rev ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x) * 64 + lane;
     const bool valid = idx < n_tasks;
     const SwParams &P = SIDE == 0 ? xp.left : xp.right;
     int g = 0, l_query = 0, h0 = 0, prev = -1;
@@ -345,7 +353,7 @@ k_ext_lanes(DevIndex ix, ExtParams xp, const int32_t *__restrict__ tasks, int n_
         if (!__ballot(run)) break;
         const int w = xp.w << t;
         const int wc = band_clamp(w, tg.len2, P, cls);
-        if (P8) lane_dp8(run, tg.len2, tg.len1, wc, h0, tg.t, tg.ts, P, EH, QL8, lane, o, cells);
+        if (P8) lane_dp8<PF>(run, tg.len2, tg.len1, wc, h0, tg.t, tg.ts, P, EH, QL8, lane, o, cells);
         else lane_dp(run, tg.len2, tg.len1, wc, h0, tg.t, tg.ts, P, EH, QL, lane, o, cells);
         if (run) {
             w_used = w;
@@ -388,7 +396,7 @@ __global__ void __launch_bounds__(256)
 k_ext_wave(DevIndex ix, ExtParams xp, const int32_t *__restrict__ tasks, int n_tasks,
            const uint8_t *__restrict__ enc, const int64_t *__restrict__ off, const int32_t *__restrict__ len,
            const int64_t *__restrict__ slot_base, const int32_t *__restrict__ reg_seed, const int32_t *__restrict__ reg_chain,
-           const DevChain *__restrict__ chn, const DevSeed *__restrict__ seeds, DevReg *regs, int R, unsigned long long *counters) {
+           const DevChain *__restrict__ chn, const DevSeed *__restrict__ seeds, DevReg *regs, int R, unsigned long long *counters, int rev) {
     extern __shared__ __attribute__((aligned(16))) int lds[];
     ExtParams *sP = (ExtParams *)lds;
     int *rings = lds + (sizeof(ExtParams) + 3) / 4;
@@ -398,7 +406,7 @@ k_ext_wave(DevIndex ix, ExtParams xp, const int32_t *__restrict__ tasks, int n_t
     int *RH = rings + (size_t)wv * 2 * R, *RE = RH + R;
     const int idx = blockIdx.x * (blockDim.x >> 6) + wv;
     if (idx >= n_tasks) return;
-    const int g = tasks[idx];
+    const int g = tasks[rev ? n_tasks - 1 - idx : idx];
     const int64_t base = slot_base[g];
     const DevChain c = chn[base + reg_chain[g]];
     const DevSeed s = seeds[base + reg_seed[g]];
@@ -481,7 +489,7 @@ static __device__ bool seed_redundant(const ChainParams &o, int l_query, const D
     return false;
 }
 
-#define PF_HEAVY 24                 // reads with more regs than this are purged by a whole wavefront (k_postfilter_heavy)
+#define PF_HEAVY 24                 // reads with more regs than this are purged by a whole wavefront (k_postfilter_heavy); knob BM2_PF_HEAVY
 
 // Redundant-seed post-filter, bwamem.cpp:2895-2989 (one read per lane): replays the original bwa-mem rule "skip a seed
 // already contained in an earlier alignment unless an overlapping seed lies on another diagonal" and purges those regs.
@@ -490,13 +498,13 @@ __global__ void __launch_bounds__(128)
 k_postfilter(ChainParams o, int n_reads, const int32_t *__restrict__ len, const int64_t *__restrict__ read_base,
              const int32_t *__restrict__ n_chain, const int32_t *__restrict__ n_reg, const DevChain *__restrict__ chn,
              const DevSeed *__restrict__ seeds, int32_t *srt_all, DevReg *regs, int32_t *n_out, const int32_t *__restrict__ cursor,
-             const int32_t *__restrict__ perm) {
+             const int32_t *__restrict__ perm, int pf_heavy) {
     const int tix = blockIdx.x * blockDim.x + threadIdx.x;
     if (tix >= n_reads) return;
     const int r = perm[tix];
     const int nc = n_chain[r], nr = n_reg[r];
     if (nc == 0) { n_out[r] = 0; return; }
-    if (nr > PF_HEAVY) return;                               // k_postfilter_heavy takes these: one read per wavefront
+    if (nr > pf_heavy) return;                               // k_postfilter_heavy takes these: one read per wavefront
     const int first_idx = cursor[r];
     const int64_t base = read_base[r];
     const int l_query = len[r];
@@ -535,7 +543,8 @@ __global__ void __launch_bounds__(256)
 k_postfilter_heavy(ChainParams o, const int32_t *__restrict__ heavy /* read ids, heavy ones first */, const int64_t *__restrict__ n_heavy_p,
                    const int32_t *__restrict__ len, const int64_t *__restrict__ read_base, const int32_t *__restrict__ n_chain,
                    const int32_t *__restrict__ n_reg, const DevChain *__restrict__ chn, const DevSeed *__restrict__ seeds,
-                   int32_t *srt_all, DevReg *regs, int32_t *n_out, const int32_t *__restrict__ cursor, unsigned long long *item_cur) {
+                   int32_t *srt_all, DevReg *regs, int32_t *n_out, const int32_t *__restrict__ cursor, unsigned long long *item_cur,
+                   int pf_heavy) {
     const int lane = threadIdx.x & 63;
     const unsigned long long lt_mask = lane ? (~0ULL >> (64 - lane)) : 0ULL;
     const int64_t n_heavy = *n_heavy_p;
@@ -548,7 +557,7 @@ k_postfilter_heavy(ChainParams o, const int32_t *__restrict__ heavy /* read ids,
         if (hid >= n_heavy) break;
         const int r = heavy[hid];
         const int nc = n_chain[r], nr = n_reg[r];
-        if (nc != 0 && nr > PF_HEAVY) {                          // (no `continue` in this loop: see notes/NEXT.md)
+        if (nc != 0 && nr > pf_heavy) {                          // (no `continue` in this loop: see notes/NEXT.md)
         const int first_idx = cursor[r];
         const int64_t base = read_base[r];
         const int l_query = len[r];
@@ -762,10 +771,14 @@ struct ExtLaunch {
     bm2_ctx *c; hipStream_t s; ExtParams xp; const uint8_t *enc; const int64_t *off; const int32_t *len; const int64_t *slot_base;
     const int32_t *reg_seed, *reg_chain; const DevChain *chn; const DevSeed *seeds; DevReg *regs; unsigned long long *counters;
     int R; size_t lds_w; bool pack8;
+    // launch policy (bm2_knob): which kernel takes a query-length class.  Every launch of a side lasts about as long as its slowest
+    // wavefront, and a lane-per-task wavefront of 150-base queries walks ~30 k cells one after the other (milliseconds), so the
+    // classes with few tasks or long queries go one task per WAVEFRONT (k_ext_wave: ~0.1 ms per task) beside the lane kernels.
+    int wave_qmin, wave_nmax, prefetch, rev;
 };
 
 // Left side, then right side (whose h0 is the left score).  Lane-per-task kernels per query-length class (each class needs
-// a different LDS footprint) plus the wavefront-per-task fallback; the launches of one side run concurrently on the
+// a different LDS footprint) plus the wavefront-per-task kernel; the launches of one side run concurrently on the
 // context's side streams, joined by events before the other side starts.
 static int run_sides(const ExtLaunch &L, const uint32_t *h_hist, const uint32_t *h_start, const int32_t *taskL, const int32_t *taskR) {
     static const int cls_hi[N_CLS] = { 16, 32, 48, 64, 80, 96, 112, 128, 144, 160 };
@@ -774,35 +787,41 @@ static int run_sides(const ExtLaunch &L, const uint32_t *h_hist, const uint32_t 
         const int32_t *tasks = side == 0 ? taskL : taskR;
         const uint32_t *st = h_start + side * N_BINS, *hc = h_hist + side * N_BINS;
         (void)hipEventRecord(c->ev_fork, L.s);
-        int used = 0;
+        auto wave_launch = [&](hipStream_t sk, uint32_t first, uint32_t n) {
+            if (side == 0) hipLaunchKernelGGL(k_ext_wave<0>, dim3((n + 3) / 4), dim3(256), L.lds_w, sk, c->ix, L.xp, tasks + first, (int)n, L.enc, L.off, L.len, L.slot_base, L.reg_seed, L.reg_chain, L.chn, L.seeds, L.regs, L.R, L.counters, L.rev);
+            else hipLaunchKernelGGL(k_ext_wave<1>, dim3((n + 3) / 4), dim3(256), L.lds_w, sk, c->ix, L.xp, tasks + first, (int)n, L.enc, L.off, L.len, L.slot_base, L.reg_seed, L.reg_chain, L.chn, L.seeds, L.regs, L.R, L.counters, L.rev);
+        };
+        // the classes from k_wave up (long queries) and the fallback bin are adjacent in the task list: one wavefront-per-task launch
+        int k_wave = N_CLS;
+        while (k_wave > 0 && (k_wave >= 2 ? cls_hi[k_wave - 2] : 0) + 1 >= L.wave_qmin) k_wave--;
         for (int kk = 0; kk <= N_CLS; kk++) {                  // longest queries first: their tails overlap the short classes
             const int k = kk == 0 ? N_CLS : N_CLS - kk;
             hipStream_t sk = c->side_stream[k];
             uint32_t n = 0, first = 0; int hi = 0;
             if (k < N_CLS) {
+                if (k >= k_wave) continue;                      // part of the launch of k == N_CLS
                 hi = cls_hi[k];
                 const int lo = k ? cls_hi[k - 1] : 0;
                 first = st[lo + 1];
                 for (int b = lo + 1; b <= hi; b++) n += hc[b];
-            } else { n = hc[BIN_FALLBACK]; first = st[BIN_FALLBACK]; }
+            } else {
+                const int lo = k_wave ? cls_hi[k_wave - 1] : 0;
+                first = st[lo + 1];
+                for (int b = lo + 1; b <= BIN_FALLBACK; b++) n += hc[b];
+            }
             if (!n) continue;
             (void)hipStreamWaitEvent(sk, c->ev_fork, 0);
-            if (k < N_CLS) {
+            if (k < N_CLS && (int64_t)n > (int64_t)L.wave_nmax) {
                 const size_t lds = L.pack8 ? (size_t)((hi + 2) / 2) * 64 * 4 + (size_t)((hi + 7) / 8) * 64 * 4
                                            : (size_t)(hi + 1) * 64 * 4 + (size_t)hi * 64;
-                auto kern = side == 0 ? (L.pack8 ? k_ext_lanes<0, true> : k_ext_lanes<0, false>)
-                                      : (L.pack8 ? k_ext_lanes<1, true> : k_ext_lanes<1, false>);
+                auto kern = side == 0 ? (L.pack8 ? (L.prefetch ? k_ext_lanes<0, true, true> : k_ext_lanes<0, true, false>) : k_ext_lanes<0, false, false>)
+                                      : (L.pack8 ? (L.prefetch ? k_ext_lanes<1, true, true> : k_ext_lanes<1, true, false>) : k_ext_lanes<1, false, false>);
                 hipLaunchKernelGGL(kern, dim3((n + 63) / 64), dim3(64), lds, sk, c->ix, L.xp, tasks + first, (int)n, hi, L.enc, L.off, L.len,
-                                   L.slot_base, L.reg_seed, L.reg_chain, L.chn, L.seeds, L.regs, L.counters);
-            } else {
-                if (side == 0) hipLaunchKernelGGL(k_ext_wave<0>, dim3((n + 3) / 4), dim3(256), L.lds_w, sk, c->ix, L.xp, tasks + first, (int)n, L.enc, L.off, L.len, L.slot_base, L.reg_seed, L.reg_chain, L.chn, L.seeds, L.regs, L.R, L.counters);
-                else hipLaunchKernelGGL(k_ext_wave<1>, dim3((n + 3) / 4), dim3(256), L.lds_w, sk, c->ix, L.xp, tasks + first, (int)n, L.enc, L.off, L.len, L.slot_base, L.reg_seed, L.reg_chain, L.chn, L.seeds, L.regs, L.R, L.counters);
-            }
+                                   L.slot_base, L.reg_seed, L.reg_chain, L.chn, L.seeds, L.regs, L.counters, L.rev);
+            } else wave_launch(sk, first, n);
             (void)hipEventRecord(c->ev_join[k], sk);
             (void)hipStreamWaitEvent(L.s, c->ev_join[k], 0);
-            used++;
         }
-        (void)used;
     }
     return bm2_check(hipGetLastError(), "extension launches");
 }
@@ -830,8 +849,12 @@ int bm2_launch_extend(bm2_ctx *c, const bm2_opt &opt, const ChainParams &cp, int
     P.end_bonus = opt.pen_clip5; xp.left = P;
     P.end_bonus = opt.pen_clip3; xp.right = P;
     // no H / E of the batch can exceed l_query * a (a full-length perfect match): 8-bit rows when that fits
-    static const int no_p8 = getenv("BM2_NO_PACK8") ? atoi(getenv("BM2_NO_PACK8")) : 0;
-    L.pack8 = !no_p8 && (int64_t)max_len * opt.a <= 255 && opt.a > 0;
+    L.pack8 = !bm2_knob("BM2_NO_PACK8", 0) && (int64_t)max_len * opt.a <= 255 && opt.a > 0;
+    L.wave_qmin = bm2_knob("BM2_EXT_WAVE_QMIN", LANE_QMAX + 1);     // classes of queries at least this long: one task per wavefront
+    L.wave_nmax = bm2_knob("BM2_EXT_WAVE_NMAX", 0);                 // classes with at most this many tasks in a round: likewise
+    L.prefetch = bm2_knob("BM2_EXT_PREFETCH", 0);
+    L.rev = bm2_knob("BM2_EXT_REVERSE", 0);
+    const int lazy_rounds = bm2_knob("BM2_EXT_ROUNDS", LAZY_ROUNDS), pend_div = bm2_knob("BM2_EXT_PEND_DIV", 12);
     L.R = ring_size2(opt.w << (MAX_BAND_TRY - 1));
     L.lds_w = ((sizeof(ExtParams) + 3) / 4) * 4 + (size_t)4 * 2 * L.R * 4;
     if (L.lds_w > 160 * 1024) { bm2_set_error("band width %d needs more LDS than a CU has", opt.w); return BM2_EUNSUP; }
@@ -854,7 +877,7 @@ int bm2_launch_extend(bm2_ctx *c, const bm2_opt &opt, const ChainParams &cp, int
     };
     const unsigned nbr = (unsigned)((n_reads + 127) / 128), nbr2 = (unsigned)((n_reads + 255) / 256);
     uint32_t pending = 1;
-    for (int round = 0; round < LAZY_ROUNDS && pending && (round < 1 || pending * 12u >= (uint32_t)n_reads); round++) {
+    for (int round = 0; round < lazy_rounds && pending && (round < 1 || (uint64_t)pending * (uint32_t)pend_div >= (uint32_t)n_reads); round++) {
         if ((rc = bm2_check(hipMemsetAsync(hist, 0, (2 * N_BINS + 1) * 4, s), "memset hist"))) return rc;
         hipLaunchKernelGGL(k_advance, dim3(nbr), dim3(128), 0, s, cp, xp, n_reads, len, read_base, n_reg, reg_chain, chn, seeds, srt_all,
                            regs, cursor, cur_slot, bins, hist);
@@ -896,18 +919,18 @@ int bm2_launch_slot_base(bm2_ctx *c, int n_reads, const int64_t *read_base, cons
     return bm2_check(hipGetLastError(), "k_slot_base launch");
 }
 
-int bm2_pf_heavy_threshold() { return PF_HEAVY; }
+int bm2_pf_heavy_threshold() { const int t = bm2_knob("BM2_PF_HEAVY", PF_HEAVY); return t > 0 ? t : PF_HEAVY; }
 
 int bm2_launch_postfilter(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_t *len, const int64_t *read_base,
                           const int32_t *n_chain, const int32_t *n_reg, const DevChain *chn, const DevSeed *seeds,
                           int32_t *srt_all, DevReg *regs, int32_t *n_out, const int32_t *cursor, const int32_t *perm,
-                          const int32_t *heavy, const int64_t *n_heavy, unsigned long long *item_cur) {
+                          const int32_t *heavy, const int64_t *n_heavy, unsigned long long *item_cur, int pf_heavy) {
     if (n_reads <= 0) return BM2_OK;
     hipLaunchKernelGGL(k_postfilter, dim3((n_reads + 127) / 128), dim3(128), 0, c->stream, o, n_reads, len, read_base, n_chain,
-                       n_reg, chn, seeds, srt_all, regs, n_out, cursor, perm);
+                       n_reg, chn, seeds, srt_all, regs, n_out, cursor, perm, heavy ? pf_heavy : 0x7fffffff);
     if (heavy) {                                             // (different reads: order between the two kernels does not matter)
         hipLaunchKernelGGL(k_postfilter_heavy, dim3(c->n_cu * 4), dim3(256), 0, c->stream, o, heavy, n_heavy, len, read_base, n_chain,
-                           n_reg, chn, seeds, srt_all, regs, n_out, cursor, item_cur);
+                           n_reg, chn, seeds, srt_all, regs, n_out, cursor, item_cur, pf_heavy);
     }
     return bm2_check(hipGetLastError(), "k_postfilter launch");
 }

@@ -33,7 +33,7 @@ int bm2_launch_slot_base(bm2_ctx *c, int n_reads, const int64_t *read_base, cons
 int bm2_launch_postfilter(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_t *len, const int64_t *read_base,
                           const int32_t *n_chain, const int32_t *n_reg, const DevChain *chn, const DevSeed *seeds,
                           int32_t *srt_all, DevReg *regs, int32_t *n_out, const int32_t *cursor, const int32_t *perm,
-                          const int32_t *heavy, const int64_t *n_heavy, unsigned long long *item_cur);
+                          const int32_t *heavy, const int64_t *n_heavy, unsigned long long *item_cur, int pf_heavy);
 int bm2_launch_reg_gather(bm2_ctx *c, int n_reads, const int64_t *read_base, const int32_t *n_reg, const DevReg *regs,
                           const int64_t *out_off, bm2_reg_t *out, int64_t out_cap);
 
@@ -175,8 +175,8 @@ static int run_seeding(bm2_ctx *c, Batch *b, const bm2_opt *opt, bool with_sal) 
     if ((rc = bm2_reserve(b->smem_off, (size_t)(n + 1) * 8))) return rc;
     // task kernels with persistent lanes (smem.hip); workspace sizes are learned: a run that overflows one of them reports
     // what it needed and is repeated
-    static const int bpc_w = getenv("BM2_WALK_BLOCKS_PER_CU") ? atoi(getenv("BM2_WALK_BLOCKS_PER_CU")) : 4;
-    static const int bpc_b = getenv("BM2_BWD_BLOCKS_PER_CU") ? atoi(getenv("BM2_BWD_BLOCKS_PER_CU")) : 3;
+    const int bpc_w = bm2_knob("BM2_WALK_BLOCKS_PER_CU", 4);
+    const int bpc_b = bm2_knob("BM2_BWD_BLOCKS_PER_CU", 3);
     const int grid_w = c->n_cu * bpc_w, grid_b = c->n_cu * bpc_b;
     const int64_t lanes = (int64_t)(grid_w > grid_b ? grid_w : grid_b) * 256;
     if (opt->split_width > 65534) { bm2_set_error("split_width %d > 65534 is not supported", opt->split_width); return BM2_EUNSUP; }
@@ -344,11 +344,11 @@ static int batch_run_one(bm2_ctx *c, const bm2_opt *opt) {
     }
     hipLaunchKernelGGL(k_read_base, dim3((n + 255) / 256), dim3(256), 0, s, n, (const int32_t *)b->smem_cnt.p,
                        (const int64_t *)b->smem_off.p, (const int64_t *)b->sa_off.p, (int64_t *)b->read_base.p, (int32_t *)b->n_sa_read.p);
-    static const int perm_mode = getenv("BM2_PERM_MODE") ? atoi(getenv("BM2_PERM_MODE")) : 4;      // chaining: heavy reads (> 40 seeds) first, stable
-    static const int perm_mode_pf = getenv("BM2_PERM_MODE_PF") ? atoi(getenv("BM2_PERM_MODE_PF")) : 0;   // post-filter: read order
-    static const int thr_sa = getenv("BM2_HEAVY_SA") ? atoi(getenv("BM2_HEAVY_SA")) : 40;
+    const int perm_mode = bm2_knob("BM2_PERM_MODE", 4);      // chaining: heavy reads (> 40 seeds) first, stable
+    const int perm_mode_pf = bm2_knob("BM2_PERM_MODE_PF", 0);   // post-filter: read order
+    const int thr_sa = bm2_knob("BM2_HEAVY_SA", 40);
     const int64_t *n_heavy_chain = nullptr;                      // set when the permutation lists the seed-rich reads first: k_chain_heavy takes them
-    static const int chain_heavy = getenv("BM2_CHAIN_HEAVY") ? atoi(getenv("BM2_CHAIN_HEAVY")) : 1;
+    const int chain_heavy = bm2_knob("BM2_CHAIN_HEAVY", 1);
     if (perm_mode == 3 || perm_mode == 4) { if ((rc = bm2_partition_by_work(c, n, (const int32_t *)b->n_sa_read.p, thr_sa, (int32_t *)b->perm.p, b->part_tmp, b->scan_tmp, perm_mode == 4, perm_mode == 4 && chain_heavy ? &n_heavy_chain : nullptr))) return rc; }
     else if ((rc = bm2_perm_by_work(c, n, (const int32_t *)b->n_sa_read.p, (int32_t *)b->perm.p, (uint32_t *)b->perm_hist.p, perm_mode))) return rc;
     if ((rc = bm2_launch_chain(c, cp, n, (const int32_t *)b->len.p, (const bm2_smem_t *)b->smem.p, (const int32_t *)b->smem_cnt.p,
@@ -376,17 +376,18 @@ static int batch_run_one(bm2_ctx *c, const bm2_opt *opt) {
                                 (const DevChain *)b->chn.p, (const DevSeed *)b->seeds.p, (int32_t *)b->srt.p, (DevReg *)b->regs.p,
                                 (unsigned long long *)b->counters.p + 5, b->ext_tmp, (int32_t *)b->cursor.p, b->max_len))) return rc;
     tick(c, "extend");
-    static const int thr_reg = getenv("BM2_HEAVY_REG") ? atoi(getenv("BM2_HEAVY_REG")) : 12;
+    const int thr_reg = bm2_knob("BM2_HEAVY_REG", 12);
     if (perm_mode_pf == 3 || perm_mode_pf == 4) { if ((rc = bm2_partition_by_work(c, n, (const int32_t *)b->n_reg.p, thr_reg, (int32_t *)b->perm.p, b->part_tmp, b->scan_tmp, perm_mode_pf == 4))) return rc; }
     else if ((rc = bm2_perm_by_work(c, n, (const int32_t *)b->n_reg.p, (int32_t *)b->perm.p, (uint32_t *)b->perm_hist.p, perm_mode_pf))) return rc;
     // reads with many regs: listed (heavy first) for the wave-per-read purge; counters[9] is its work cursor
     const int64_t *n_heavy_dev = nullptr;
     if ((rc = bm2_reserve(b->perm2, (size_t)(n + 1) * 4))) return rc;
-    if ((rc = bm2_partition_by_work(c, n, (const int32_t *)b->n_reg.p, bm2_pf_heavy_threshold(), (int32_t *)b->perm2.p, b->part_tmp2, b->scan_tmp, 1, &n_heavy_dev))) return rc;
+    const int pf_heavy = bm2_pf_heavy_threshold();
+    if ((rc = bm2_partition_by_work(c, n, (const int32_t *)b->n_reg.p, pf_heavy, (int32_t *)b->perm2.p, b->part_tmp2, b->scan_tmp, 1, &n_heavy_dev))) return rc;
     if ((rc = bm2_launch_postfilter(c, cp, n, (const int32_t *)b->len.p, (const int64_t *)b->read_base.p, (const int32_t *)b->n_chain.p,
                                     (const int32_t *)b->n_reg.p, (const DevChain *)b->chn.p, (const DevSeed *)b->seeds.p,
                                     (int32_t *)b->srt.p, (DevReg *)b->regs.p, (int32_t *)b->n_out.p, (const int32_t *)b->cursor.p, (const int32_t *)b->perm.p,
-                                    (const int32_t *)b->perm2.p, n_heavy_dev, (unsigned long long *)b->counters.p + 9))) return rc;
+                                    (const int32_t *)b->perm2.p, n_heavy_dev, (unsigned long long *)b->counters.p + 9, pf_heavy))) return rc;
     if ((rc = bm2_scan_i32(c, (const int32_t *)b->n_out.p, n, (int64_t *)b->out_off.p, b->scan_tmp))) return rc;
     int64_t n_out = 0;
     unsigned long long h_cnt[8];

@@ -1,0 +1,134 @@
+#!/usr/bin/env python3
+"""Launch-policy sweep on the bench workload, in ONE process (no torch): every knob of bm2_knob() (bm2_ctx.h) is a launch-policy
+setting that cannot change a result, so each candidate is timed on the resident chunk and its regs are checksummed against the
+default's.  Coordinate descent: one knob at a time, the best value is kept.  Writes <out>/sweep.json (every candidate: ms per step,
+stage ms, checksum) and <out>/best_env.sh (export lines for the profiling passes that follow in tools/gpu/run_prof.sh).
+
+    python tools/gpu/sweep.py <out_dir> [--steps 3] [--genome-mbp 3100] [--reads 1000000]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import zlib
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "bwa-mem2_amd"))
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+GRID = [   # (knob, candidates): the first candidate of each list is the library's default
+    ("BM2_EXT_WAVE_QMIN", [161, 145, 129, 113, 97, 81, 65, 49, 33]),
+    ("BM2_EXT_WAVE_NMAX", [0, 500, 2000, 8000, 32000, 128000]),
+    ("BM2_EXT_PREFETCH", [0, 1]),
+    ("BM2_EXT_REVERSE", [0, 1]),
+    ("BM2_EXT_ROUNDS", [6, 3, 4, 8, 12]),
+    ("BM2_EXT_PEND_DIV", [12, 4, 30, 100]),
+    ("BM2_EXT_WAVE_QMIN", [161, 145, 129, 113, 97, 81, 65, 49, 33]),      # again, now that the other extension knobs are set
+    ("BM2_PF_HEAVY", [24, 12, 48, 96]),
+    ("BM2_HEAVY_SA", [40, 24, 64, 100]),
+    ("BM2_CHAIN_HEAVY", [1, 0]),
+    ("BM2_BWD_BLOCKS_PER_CU", [3, 2, 4, 6]),
+    ("BM2_WALK_BLOCKS_PER_CU", [4, 2, 3, 6]),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("out")
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--genome-mbp", type=int, default=3100)
+    ap.add_argument("--reads", type=int, default=1000000)
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--workdir", default=os.environ.get("BM2_BENCH_WORKDIR", "/tmp/bm2_bench"))
+    ap.add_argument("--quick", action="store_true", help="two candidates per knob (a test of this script on the emulator)")
+    ap.add_argument("--budget-s", type=float, default=90.0, help="stop sweeping (keep what is best so far) after this many seconds")
+    a = ap.parse_args()
+    os.makedirs(a.out, exist_ok=True)
+    import bench
+    import bm2
+    emu = os.environ.get("BM2_EMU_LIB")
+    if emu:
+        bm2.LIB_PATH = emu
+    seed = 20260924
+    os.makedirs(a.workdir, exist_ok=True)
+    t = time.time()
+    prefix, contigs = bench.prepare_genome(a.workdir, a.genome_mbp, seed)
+    seqs = bench.pe_chunk(a.workdir, contigs, seed, a.reads, a.read_len)
+    n = len(seqs)
+    print("[sweep] workload ready in %.1fs" % (time.time() - t), file=sys.stderr, flush=True)
+    t = time.time()
+    ctx = bm2.Context(0, prefix)
+    ctx.batch_upload(seqs.reshape(-1), np.arange(n, dtype=np.int64) * a.read_len, np.full(n, a.read_len, np.int32))
+    opt = bm2.default_opt()
+    print("[sweep] index + chunk resident after %.1fs" % (time.time() - t), file=sys.stderr, flush=True)
+
+    def measure(env):
+        for k in [k for k in os.environ if k.startswith("BM2_")
+                  and k not in ("BM2_EMU_LIB", "BM2_BENCH_WORKDIR", "BM2_N_SUB")]:
+            del os.environ[k]
+        for k, v in env.items():
+            os.environ[k] = str(v)
+        ctx.batch_run(opt)                                   # warm-up (workspace sizes of this setting)
+        kms = {}
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            ctx.batch_run(opt)
+            for name, ms in ctx.batch_kernel_ms():
+                kms[name.split(".")[0]] = kms.get(name.split(".")[0], 0.0) + ms / a.steps
+        ms = (time.perf_counter() - t0) / a.steps * 1e3
+        regs, reg_off = ctx.batch_download()
+        crc = zlib.crc32(reg_off.tobytes(), zlib.crc32(regs.tobytes()))
+        return ms, kms, crc
+
+    log = []
+    best_env = {}
+    t_start = time.time()
+    base_ms, base_k, base_crc = measure(best_env)
+    log.append({"env": {}, "ms": base_ms, "stages": base_k, "crc": base_crc})
+    best_ms = base_ms
+    print("[sweep] default: %.2f ms/step %s" % (base_ms, {k: round(v, 2) for k, v in base_k.items()}), file=sys.stderr, flush=True)
+    for knob, cands in GRID:
+        if a.quick:
+            cands = cands[:2]
+        if time.time() - t_start > a.budget_s:
+            print("[sweep] time budget used; stopping at", knob, file=sys.stderr, flush=True)
+            break
+        cur = best_env.get(knob, cands[0])
+        for v in cands:
+            if v == cur:
+                continue
+            env = dict(best_env); env[knob] = v
+            try:
+                ms, k, crc = measure(env)
+            except Exception as e:                                        # noqa
+                log.append({"env": env, "error": str(e)})
+                continue
+            ok = crc == base_crc
+            log.append({"env": env, "ms": ms, "stages": k, "crc": crc, "same_regs": ok})
+            print("[sweep] %s=%s: %.2f ms/step %s%s" % (knob, v, ms, {x: round(y, 2) for x, y in k.items()}, "" if ok else "  REGS DIFFER"),
+                  file=sys.stderr, flush=True)
+            if ok and ms < best_ms * 0.985:                               # keep a change only if it buys more than the noise
+                best_ms, cur = ms, v
+        if cur != cands[0]:
+            best_env[knob] = cur
+        else:
+            best_env.pop(knob, None)
+    final_ms, final_k, final_crc = measure(best_env)
+    out = {"workload": {"genome_mbp": a.genome_mbp, "reads": n, "read_len": a.read_len, "steps": a.steps},
+           "default": {"ms": base_ms, "stages": base_k}, "best_env": best_env, "best": {"ms": final_ms, "stages": final_k},
+           "same_regs": final_crc == base_crc, "log": log}
+    json.dump(out, open(os.path.join(a.out, "sweep.json"), "w"), indent=1)
+    with open(os.path.join(a.out, "best_env.sh"), "w") as f:
+        if final_crc == base_crc:
+            for k, v in best_env.items():
+                f.write("export %s=%s\n" % (k, v))
+    print("[sweep] best %s: %.2f ms/step (default %.2f)" % (best_env, final_ms, base_ms), file=sys.stderr, flush=True)
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
