@@ -850,9 +850,11 @@ int bm2_launch_extend(bm2_ctx *c, const bm2_opt &opt, const ChainParams &cp, int
     P.end_bonus = opt.pen_clip3; xp.right = P;
     // no H / E of the batch can exceed l_query * a (a full-length perfect match): 8-bit rows when that fits
     L.pack8 = !bm2_knob("BM2_NO_PACK8", 0) && (int64_t)max_len * opt.a <= 255 && opt.a > 0;
-    L.wave_qmin = bm2_knob("BM2_EXT_WAVE_QMIN", LANE_QMAX + 1);     // classes of queries at least this long: one task per wavefront
-    L.wave_nmax = bm2_knob("BM2_EXT_WAVE_NMAX", 0);                 // classes with at most this many tasks in a round: likewise
-    L.prefetch = bm2_knob("BM2_EXT_PREFETCH", 0);
+    // defaults = the best of tools/gpu/sweep.py on the GRCh38-sized bench workload (profiles/r02_sweep.json): extension stage
+    // 36.8 -> 30.4 ms with the classes from 113 bases up on k_ext_wave (97: 34 ms, 129: 34.7 ms, 65: 51 ms), -0.2 ms with the prefetch
+    L.wave_qmin = bm2_knob("BM2_EXT_WAVE_QMIN", 113);               // classes of queries at least this long: one task per wavefront
+    L.wave_nmax = bm2_knob("BM2_EXT_WAVE_NMAX", 0);                 // classes with at most this many tasks in a round: likewise (no gain measured)
+    L.prefetch = bm2_knob("BM2_EXT_PREFETCH", 1);
     L.rev = bm2_knob("BM2_EXT_REVERSE", 0);
     const int lazy_rounds = bm2_knob("BM2_EXT_ROUNDS", LAZY_ROUNDS), pend_div = bm2_knob("BM2_EXT_PEND_DIV", 12);
     L.R = ring_size2(opt.w << (MAX_BAND_TRY - 1));

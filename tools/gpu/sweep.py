@@ -21,15 +21,14 @@ sys.path.insert(0, os.path.join(ROOT, "bwa-mem2_amd"))
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 GRID = [   # (knob, candidates): the first candidate of each list is the library's default
-    ("BM2_EXT_WAVE_QMIN", [161, 145, 129, 113, 97, 81, 65, 49, 33]),
+    ("BM2_EXT_WAVE_QMIN", [113, 161, 145, 129, 97, 81, 65, 49, 33]),
     ("BM2_EXT_WAVE_NMAX", [0, 500, 2000, 8000, 32000, 128000]),
-    ("BM2_EXT_PREFETCH", [0, 1]),
+    ("BM2_EXT_PREFETCH", [1, 0]),
     ("BM2_EXT_REVERSE", [0, 1]),
     ("BM2_EXT_ROUNDS", [6, 3, 4, 8, 12]),
     ("BM2_EXT_PEND_DIV", [12, 4, 30, 100]),
-    ("BM2_EXT_WAVE_QMIN", [161, 145, 129, 113, 97, 81, 65, 49, 33]),      # again, now that the other extension knobs are set
     ("BM2_PF_HEAVY", [24, 12, 48, 96]),
-    ("BM2_HEAVY_SA", [40, 24, 64, 100]),
+    ("BM2_HEAVY_SA", [100, 40, 64, 160, 250]),
     ("BM2_CHAIN_HEAVY", [1, 0]),
     ("BM2_BWD_BLOCKS_PER_CU", [3, 2, 4, 6]),
     ("BM2_WALK_BLOCKS_PER_CU", [4, 2, 3, 6]),

@@ -40,7 +40,8 @@ def main():
     pre = sys.argv[2] if len(sys.argv) > 2 else "r02"
     dst = os.path.join(ROOT, "profiles")
     for a, b in (("kernel_trace.md", "kernel_trace.md"), ("pmc_fetch.md", "pmc_fetch.md"), ("pmc_write.md", "pmc_write.md"),
-                 ("pmc_sq1.md", "pmc_sq1.md"), ("pmc_sq2.md", "pmc_sq2.md"), ("bench.json", "bench.json"), ("bench_ont2d.json", "bench_ont2d.json")):
+                 ("pmc_sq1.md", "pmc_sq1.md"), ("pmc_sq2.md", "pmc_sq2.md"), ("bench.json", "bench.json"), ("bench_ont2d.json", "bench_ont2d.json"),
+                 ("bench_parity.json", "bench_parity.json"), ("sweep.json", "sweep.json"), ("pytest.log", "pytest_subset.log")):
         if os.path.exists(os.path.join(src, a)):
             shutil.copy(os.path.join(src, a), os.path.join(dst, "%s_%s" % (pre, b)))
     bench = json.load(open(os.path.join(src, "bench.json")))
@@ -59,17 +60,23 @@ def main():
     json.dump(out, open(os.path.join(dst, "%s_k_bwd_pmc.json" % pre), "w"), indent=1)
     s1, c1 = counters(os.path.join(src, "pmc_sq1.md"))
     tot = {}
+    per = {}
     for k, v in s1.items():
-        if "k_ext_lanes" in k:
+        if "k_ext_lanes" in k or "k_ext_wave" in k:             # both kernels of the stage: lane-per-task classes and wavefront-per-task classes
+            fam = "k_ext_lanes" if "k_ext_lanes" in k else "k_ext_wave"
             for cn, (val, _) in v.items():
                 tot[cn] = tot.get(cn, 0.0) + val
+                per.setdefault(fam, {})[cn] = per.setdefault(fam, {}).get(cn, 0.0) + val
     steps = 2.0                                                  # the PMC passes run `--steps 1 --warmup 1`
     stage_ms = bench["stage_ms_per_step"]["extend"]
     # VALU issue: wave-instructions per second against 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction (and, as the
     # verdict of round 1 computed it, / 2 cycles)
     insts = tot["SQ_INSTS_VALU"] / steps
     peak4 = 256 * 4 * 2.4e9 / 4.0
-    ext = {"kernel": "k_ext_lanes<side, P8>", "workload": wl,
+    ext = {"kernel": "k_ext_lanes<side, P8, PF> + k_ext_wave<side> (the extension stage)", "workload": wl,
+           "per_kernel": {f: {"valu_wave_insts_per_step": c["SQ_INSTS_VALU"] / steps, "valu_busy_of_wave_cycles": c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"],
+                              "wait_any_of_wave_cycles": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], "lds_insts_per_step": c["SQ_INSTS_LDS"] / steps,
+                              "lds_bank_conflict_cycles": c["SQ_LDS_BANK_CONFLICT"]} for f, c in per.items()},
            "valu_wave_insts_per_step": insts, "extend_stage_ms": stage_ms,
            "valu_frac": insts / (stage_ms * 1e-3) / peak4,
            "valu_frac_at_2_cycles_per_inst": insts / (stage_ms * 1e-3) / (peak4 * 2),
@@ -79,7 +86,7 @@ def main():
            "lds_conflict_frac": tot["SQ_LDS_BANK_CONFLICT"] / tot["SQ_LDS_IDX_ACTIVE"] if tot.get("SQ_LDS_IDX_ACTIVE") else None,
            "lane_slots_per_cell": insts * 64.0 / bench["extend_kernel"]["cells_per_launch"],
            "source": "rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE "
-                     "SQ_WAIT_INST_LDS (profiles/%s_pmc_sq1.md), sums over both k_ext_lanes instantiations and both steps of the pass; the "
+                     "SQ_WAIT_INST_LDS (profiles/%s_pmc_sq1.md), sums over the k_ext_lanes / k_ext_wave instantiations and both steps of the pass; the "
                      "launches of a stage overlap on side streams, so the issue fraction is taken over the stage's wall time of the bench run "
                      "(%.1f ms), not over the summed kernel durations" % (pre, stage_ms)}
     json.dump(ext, open(os.path.join(dst, "%s_ext_pmc_sq.json" % pre), "w"), indent=1)
