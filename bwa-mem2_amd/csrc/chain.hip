@@ -209,7 +209,12 @@ static __device__ int chain_weight(const WChain &c, const WSeed *seeds) {
 
 // The working set of one read while it is chained: chains, seeds, B-tree nodes, an order array.  The lane-per-read kernel keeps
 // them in the read's slices of global arrays; the wave-per-read kernel of seed-rich reads keeps them in LDS (k_chain_heavy).
-struct ChainWork { WChain *ch; WSeed *sd; BtNode *nodes; int32_t *ord; };
+struct ChainWork {
+    WChain *ch; WSeed *sd; BtNode *nodes; int32_t *ord;
+    // inputs of the read staged by the whole wavefront before lane 0 walks them (k_chain_heavy, `staged`): per seed the reference
+    // position, (qbeg | len << 15 | is_alt << 31) and the contig id bns_intv2rid gives; per SMEM (m | (n + 1) << 15 | repetitive << 31)
+    int64_t *st_rbeg; uint32_t *st_ql; int32_t *st_rid; uint32_t *st_sm; bool staged;
+};
 
 // mem_chain_seeds + mem_chain_flt for read r.  LIGHT: the lane-per-read kernel (global slices); otherwise the caller offers LDS
 // for up to lds_cap seeds in `lw`.
@@ -245,9 +250,12 @@ static __device__ void chain_one_read(const DevIndex &ix, const ChainParams &o, 
     int n_ch = 0, n_sd = 0;
     RidCache ridc; ridc.lo = 1; ridc.hi = 0; ridc.rid = -1;
     int b = 0, e = 0, l_rep = 0;
+    const bool staged = !LIGHT && in_lds && lw->staged;
     for (int i = 0; i < n_sm; i++) {                     // l_rep, bwamem.cpp:849-861
-        const int sb = (int)smems[so + i].m, se = (int)smems[so + i].n + 1;
-        if (smems[so + i].s <= o.max_occ) continue;
+        int sb, se; bool rep;
+        if (staged) { const uint32_t v = lw->st_sm[i]; sb = (int)(v & 0x7fffu); se = (int)((v >> 15) & 0xffffu); rep = (v >> 31) != 0; }
+        else { sb = (int)smems[so + i].m; se = (int)smems[so + i].n + 1; rep = smems[so + i].s > o.max_occ; }
+        if (!rep) continue;
         if (sb > e) { l_rep += e - b; b = sb; e = se; }
         else e = e > se ? e : se;
     }
@@ -257,14 +265,21 @@ static __device__ void chain_one_read(const DevIndex &ix, const ChainParams &o, 
     {
         int si = -1, left = 0, qbeg = 0, slen = 0;
         for (int t = 0; t < n_sa; t++) {
-            while (left == 0) {                          // next SMEM with at least one sampled occurrence
-                ++si;
-                left = (int)(sa_off[so + si + 1] - sa_off[so + si]);
-                qbeg = (int)smems[so + si].m; slen = (int)(smems[so + si].n + 1 - smems[so + si].m);
+            WSeed s; int rid, alt_staged = 0;
+            if (staged) {
+                const uint32_t ql = lw->st_ql[t];
+                s.rbeg = lw->st_rbeg[t]; s.qbeg = (int)(ql & 0x7fffu); s.len = (int)((ql >> 15) & 0xffffu); s.next = -1;
+                rid = lw->st_rid[t]; alt_staged = (int)(ql >> 31);
+            } else {
+                while (left == 0) {                      // next SMEM with at least one sampled occurrence
+                    ++si;
+                    left = (int)(sa_off[so + si + 1] - sa_off[so + si]);
+                    qbeg = (int)smems[so + si].m; slen = (int)(smems[so + si].n + 1 - smems[so + si].m);
+                }
+                --left;
+                s.rbeg = sa_coord[base + t]; s.qbeg = qbeg; s.len = slen; s.next = -1;
+                rid = intv2rid_cached(ix, s.rbeg, s.rbeg + s.len, ridc);
             }
-            --left;
-            WSeed s; s.rbeg = sa_coord[base + t]; s.qbeg = qbeg; s.len = slen; s.next = -1;
-            const int rid = intv2rid_cached(ix, s.rbeg, s.rbeg + s.len, ridc);
             if (rid < 0) continue;                       // bwamem.cpp:915-919
             int to_add = 0;
             if (bt.n_keys) {
@@ -279,7 +294,7 @@ static __device__ void chain_one_read(const DevIndex &ix, const ChainParams &o, 
             if (to_add) {                                // bwamem.cpp:930-951
                 WChain c2;
                 c2.pos = s.rbeg; c2.last_rbeg = s.rbeg; c2.first_qbeg = s.qbeg; c2.last_qbeg = s.qbeg; c2.last_len = s.len;
-                c2.n = 1; c2.rid = rid; c2.is_alt = ix.ann_is_alt[rid] ? 1 : 0; c2.head = c2.tail = n_sd;
+                c2.n = 1; c2.rid = rid; c2.is_alt = staged ? alt_staged : (ix.ann_is_alt[rid] ? 1 : 0); c2.head = c2.tail = n_sd;
                 c2.w = 0; c2.kept = 0; c2.first = -1;
                 sd[n_sd] = s; n_sd++;
                 ch[n_ch] = c2;
@@ -380,6 +395,12 @@ k_chain(DevIndex ix, ChainParams o, int n_reads, const int32_t *__restrict__ len
                          seed_owner, n_chain_out, n_reg_out, n_chain0_out, heavy_thr, nullptr, 0);
 }
 
+static __device__ __forceinline__ void chain_wave_sync() {      // lanes of one wavefront handing data to each other through LDS
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // Seed-rich reads, ONE READ PER WAVEFRONT.  Chaining is sequential per read by definition (every seed meets the B-tree the earlier
 // ones built) and costs ~25 dependent memory accesses per seed: in the lane-per-read kernel a read with 600 seeds kept one lane busy
 // for 12 ms at global-memory latency while the other million reads took 2 ms.  Here lane 0 runs the same code with the read's
@@ -393,16 +414,24 @@ k_chain_heavy(DevIndex ix, ChainParams o, int n_reads, const int32_t *__restrict
               const int64_t *__restrict__ sa_coord, WChain *wchain, WSeed *wseed, BtNode *nodes, int32_t *order,
               DevChain *chn, DevSeed *seeds_out, int32_t *seed_owner, int32_t *n_chain_out, int32_t *n_reg_out, int32_t *n_chain0_out,
               const int32_t *__restrict__ heavy /* read ids, heavy ones first */, const int64_t *__restrict__ n_heavy_p,
-              const int32_t *__restrict__ n_sa_read, int lo, int cap, int last_tier, unsigned long long *item_cur) {
+              const int32_t *__restrict__ n_sa_read, int lo, int cap, int last_tier, unsigned long long *item_cur, int stage) {
     extern __shared__ __attribute__((aligned(16))) uint8_t chain_lds[];
     const int lane = threadIdx.x;
     ChainWork lw;
+    int32_t *st_cut = nullptr;
     {
         size_t at = 0;
         lw.ch = (WChain *)(chain_lds + at); at += (size_t)cap * sizeof(WChain);
         lw.nodes = (BtNode *)(chain_lds + at); at += (size_t)(cap / 4 + 2) * sizeof(BtNode);
         lw.sd = (WSeed *)(chain_lds + at); at += (size_t)cap * sizeof(WSeed);
-        lw.ord = (int32_t *)(chain_lds + at);
+        lw.ord = (int32_t *)(chain_lds + at); at += (size_t)cap * 4;
+        at = (at + 7) & ~(size_t)7;                               // (the staged arrays exist only when the launch asked for them)
+        lw.st_rbeg = (int64_t *)(chain_lds + at); at += (size_t)cap * 8;
+        lw.st_ql = (uint32_t *)(chain_lds + at); at += (size_t)cap * 4;
+        lw.st_rid = (int32_t *)(chain_lds + at); at += (size_t)cap * 4;
+        lw.st_sm = (uint32_t *)(chain_lds + at); at += (size_t)cap * 4;
+        st_cut = (int32_t *)(chain_lds + at);
+        lw.staged = false;
     }
     const int64_t n_heavy = *n_heavy_p;
     for (;;) {
@@ -414,6 +443,38 @@ k_chain_heavy(DevIndex ix, ChainParams o, int n_reads, const int32_t *__restrict
         const int r = heavy[hid];
         const int ns = n_sa_read[r];
         const bool mine = ns > lo && (ns <= cap || last_tier);
+        // The serial walk of lane 0 pays a global round trip (~1 us) for every seed's position and, for a repeat read whose seeds lie
+        // in many contigs, ~10 more for the two binary searches of bns_intv2rid -- the bulk of this kernel's time.  Those inputs do
+        // not depend on the walk: the 64 lanes fetch them for 64 seeds at a time into LDS first.
+        lw.staged = false;
+        if (mine && stage && ns <= cap) {
+            const int n_sm = smem_cnt[r];
+            if (n_sm > 0) {
+                const int64_t so = smem_off[r];
+                const int64_t base = sa_off[so];
+                const int n_sa = (int)(sa_off[so + n_sm] - base);
+                if (n_sa > 0 && n_sa <= cap) {
+                    for (int i = lane; i < n_sm; i += 64) {
+                        const uint32_t m = smems[so + i].m, n1 = smems[so + i].n + 1;
+                        lw.st_sm[i] = (m & 0x7fffu) | (n1 & 0xffffu) << 15 | (smems[so + i].s > o.max_occ ? 1u << 31 : 0u);
+                        st_cut[i] = (int32_t)(sa_off[so + i + 1] - base);          // seeds of SMEM i end here
+                    }
+                    chain_wave_sync();
+                    for (int t = lane; t < n_sa; t += 64) {
+                        int a = 0, b = n_sm - 1;                                  // the seed's SMEM: first i with st_cut[i] > t
+                        while (a < b) { const int mid = (a + b) >> 1; if (st_cut[mid] > t) b = mid; else a = mid + 1; }
+                        const uint32_t sm = lw.st_sm[a];
+                        const int qbeg = (int)(sm & 0x7fffu), slen = (int)((sm >> 15) & 0xffffu) - qbeg;
+                        const int64_t rbeg = sa_coord[base + t];
+                        const int rid = intv2rid(ix, rbeg, rbeg + slen);
+                        const uint32_t alt = rid >= 0 && ix.ann_is_alt[rid] ? 1u : 0u;
+                        lw.st_rbeg[t] = rbeg; lw.st_ql[t] = (uint32_t)qbeg | (uint32_t)slen << 15 | alt << 31; lw.st_rid[t] = rid;
+                    }
+                    chain_wave_sync();
+                    lw.staged = true;
+                }
+            }
+        }
         if (mine && lane == 0)
             chain_one_read<false>(ix, o, r, n_reads, len, smems, smem_cnt, smem_off, sa_off, sa_coord, wchain, wseed, nodes, order, chn, seeds_out,
                                   seed_owner, n_chain_out, n_reg_out, n_chain0_out, -1, &lw, cap);
@@ -491,7 +552,9 @@ int bm2_launch_chain_finish(bm2_ctx *c, const ChainParams &o, int n_reads, const
     return bm2_check(hipGetLastError(), "k_chain_finish launch");
 }
 
-size_t bm2_chain_lds_bytes(int cap) { return (size_t)cap * (sizeof(WChain) + sizeof(WSeed) + 4) + (size_t)(cap / 4 + 2) * sizeof(BtNode) + 16; }
+size_t bm2_chain_lds_bytes(int cap, int stage) {      // working set (chains, seeds, order, B-tree nodes) + staged inputs (24 bytes per seed)
+    return (size_t)cap * (sizeof(WChain) + sizeof(WSeed) + 4) + (size_t)(cap / 4 + 2) * sizeof(BtNode) + 16 + (stage ? (size_t)cap * 24 + 8 : 0);
+}
 
 int bm2_launch_chain(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_t *len, const bm2_smem_t *smems,
                      const int32_t *smem_cnt, const int64_t *smem_off, const int64_t *sa_off, const int64_t *sa_coord,
@@ -508,19 +571,21 @@ int bm2_launch_chain(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_
                        n_chain_out, n_reg_out, n_chain0_out, perm, heavy ? heavy_thr : -1, n_sa_read);
     if (heavy) {
         // tiers by seed count (LDS per block follows the tier): the launches run beside the lane-per-read kernel and each other
-        static const int caps[BM2_CHAIN_TIERS] = { 64, 128, 256, 512, 1184 };
+        const int stage = bm2_knob("BM2_CHAIN_STAGE", 0);
+        const int caps[BM2_CHAIN_TIERS] = { 64, 128, 256, 512, stage ? 1000 : 1184 };       // (the last tier fills a CU's 160 KB of LDS)
         static bool attr_set = false;
-        if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_chain_heavy, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bm2_chain_lds_bytes(caps[BM2_CHAIN_TIERS - 1])); attr_set = true; }
+        if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_chain_heavy, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
         int lo = heavy_thr;
         for (int t = 0; t < BM2_CHAIN_TIERS; t++) {
             if (caps[t] <= lo) continue;
             hipStream_t sk = c->side_stream[2 + t];
-            const size_t lds = bm2_chain_lds_bytes(caps[t]);
-            int per_cu = (int)(160 * 1024 / lds); if (per_cu < 1) per_cu = 1; if (per_cu > 16) per_cu = 16;
+            const size_t lds = bm2_chain_lds_bytes(caps[t], stage);
+            const int per_cu_max = bm2_knob("BM2_CHAIN_WAVES_PER_CU", 16);
+            int per_cu = (int)(160 * 1024 / lds); if (per_cu < 1) per_cu = 1; if (per_cu > per_cu_max) per_cu = per_cu_max;
             (void)hipStreamWaitEvent(sk, c->ev_fork, 0);
             hipLaunchKernelGGL(k_chain_heavy, dim3(c->n_cu * per_cu), dim3(64), lds, sk, c->ix, o, n_reads, len, smems, smem_cnt, smem_off, sa_off,
                                sa_coord, wchain, wseed, nodes, order, chn, seeds_out, seed_owner, n_chain_out, n_reg_out, n_chain0_out, perm,
-                               n_heavy_dev, n_sa_read, lo, caps[t], t == BM2_CHAIN_TIERS - 1 ? 1 : 0, item_cur + t);
+                               n_heavy_dev, n_sa_read, lo, caps[t], t == BM2_CHAIN_TIERS - 1 ? 1 : 0, item_cur + t, stage);
             (void)hipEventRecord(c->ev_join[2 + t], sk);
             (void)hipStreamWaitEvent(s, c->ev_join[2 + t], 0);
             lo = caps[t];

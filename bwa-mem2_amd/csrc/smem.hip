@@ -360,6 +360,7 @@ k_walk(DevIndex ix, SeedParams sp, int n_reads, const uint8_t *__restrict__ enc,
 // and the first survivor of a row -- the first candidate of the next row -- never leaves the registers.
 enum { B_EXT = 0, B_NEWITEM, B_FIRST, B_ROWEND, B_ROW, B_FIN, B_DONE };
 
+template <int LC>       // survivors of a row kept in LDS per lane: 16 B x LC x 256 lanes per block decides how many blocks share a CU
 __global__ void __launch_bounds__(256)
 k_bwd(DevIndex ix, SeedParams sp, int pass, const uint8_t *__restrict__ enc, const BHead *__restrict__ heads,
       uint4 *__restrict__ ents, int64_t slot_cap, uint4 *__restrict__ pool, int pool_cap, int pool_slots,
@@ -391,13 +392,13 @@ k_bwd(DevIndex ix, SeedParams sp, int pass, const uint8_t *__restrict__ enc, con
     int em = 0;                                                // an SMEM to write out: 1 = the candidate, 2 = the first survivor
     QWin w; w.cur = w.nxt = 0; w.curb = w.nxtb = -64;
     auto entry = [&](int idx) -> uint4 * { return idx < CAPF ? lst + idx : lpool + (idx - CAPF); };
-    // survivors at depth 1..LCAP below the top of the list live in LDS ([depth][lane]); deeper ones go back to the slot
-    __shared__ uint4 surv[LCAP * 256];
+    // survivors at depth 1..LC below the top of the list live in LDS ([depth][lane]); deeper ones go back to the slot
+    __shared__ uint4 surv[LC * 256];
     bool row0 = true;                                          // the row being read is the list the walk wrote (global)
     auto cand_load = [&](int depth) -> uint4 {
         if (row0) return *entry(top - depth);
-        uint4 v = surv[(depth <= LCAP ? depth - 1 : 0) * 256 + threadIdx.x];
-        if (depth > LCAP) {
+        uint4 v = surv[(depth <= LC ? depth - 1 : 0) * 256 + threadIdx.x];
+        if (depth > LC) {
             v = *entry(top - depth);
             asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));      // (keeps the LDS and the global load apart)
         }
@@ -464,7 +465,7 @@ k_bwd(DevIndex ix, SeedParams sp, int pass, const uint8_t *__restrict__ enc, con
             } else if (o.s >= (int64_t)min_intv && o.s != (int64_t)curr_s) {
                 curr_s = (int32_t)o.s;
                 if (n_curr == 0) { fk = o.k; fl = o.l; fs = o.s; fn = cn; }
-                else if (n_curr <= LCAP) surv[(n_curr - 1) * 256 + threadIdx.x] = pv_pack(o.k, o.l, o.s, cn);
+                else if (n_curr <= LC) surv[(n_curr - 1) * 256 + threadIdx.x] = pv_pack(o.k, o.l, o.s, cn);
                 else *entry(top - n_curr) = pv_pack(o.k, o.l, o.s, cn);
                 n_curr++;
                 first_done = true;
@@ -767,7 +768,9 @@ int bm2_launch_seeding(bm2_ctx *c, const SeedParams &sp, int n_reads, const uint
         hipLaunchKernelGGL(k_bwd_heavy, dim3(grid_heavy), dim3(256), 0, sh, c->ix, sp, pass, enc, heads, ents, slot_cap, sb.pool, sb.pool_cap,
                            sb.pool_slots, heavy, sb.heavy_cap, sb.recs, sb.rec_cap, sb.tasks, sb.task_cap, smem_cnt, sc);
         (void)hipEventRecord(c->ev_join[1], sh);
-        hipLaunchKernelGGL(k_bwd, dim3(grid_bwd), dim3(256), 0, s, c->ix, sp, pass, enc, heads, ents, slot_cap, sb.pool, sb.pool_cap,
+        const int lc = bm2_knob("BM2_BWD_LCAP", LCAP);
+        auto kb = lc <= 4 ? k_bwd<4> : lc <= 6 ? k_bwd<6> : lc <= 8 ? k_bwd<8> : k_bwd<LCAP>;
+        hipLaunchKernelGGL(kb, dim3(grid_bwd), dim3(256), 0, s, c->ix, sp, pass, enc, heads, ents, slot_cap, sb.pool, sb.pool_cap,
                            sb.pool_slots, sb.recs, sb.rec_cap, sb.tasks, sb.task_cap, smem_cnt, sc);
         (void)hipStreamWaitEvent(s, c->ev_join[1], 0);
         tick(c, pass == 1 ? "smem.bwd1" : "smem.bwd2");

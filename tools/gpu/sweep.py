@@ -20,18 +20,18 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "bwa-mem2_amd"))
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
-GRID = [   # (knob, candidates): the first candidate of each list is the library's default
-    ("BM2_EXT_WAVE_QMIN", [113, 161, 145, 129, 97, 81, 65, 49, 33]),
-    ("BM2_EXT_WAVE_NMAX", [0, 500, 2000, 8000, 32000, 128000]),
-    ("BM2_EXT_PREFETCH", [1, 0]),
-    ("BM2_EXT_REVERSE", [0, 1]),
-    ("BM2_EXT_ROUNDS", [6, 3, 4, 8, 12]),
-    ("BM2_EXT_PEND_DIV", [12, 4, 30, 100]),
-    ("BM2_PF_HEAVY", [24, 12, 48, 96]),
-    ("BM2_HEAVY_SA", [100, 40, 64, 160, 250]),
-    ("BM2_CHAIN_HEAVY", [1, 0]),
-    ("BM2_BWD_BLOCKS_PER_CU", [3, 2, 4, 6]),
-    ("BM2_WALK_BLOCKS_PER_CU", [4, 2, 3, 6]),
+GRID = [   # (name, candidates): a candidate is a dict of knobs set together; the first one ({} = the library's defaults) is the incumbent
+    ("chain staging", [{}, {"BM2_CHAIN_STAGE": 1}]),
+    ("chain heavy threshold", [{}, {"BM2_HEAVY_SA": 64}, {"BM2_HEAVY_SA": 40}, {"BM2_HEAVY_SA": 24}, {"BM2_HEAVY_SA": 160}]),
+    ("chain waves per CU", [{}, {"BM2_CHAIN_WAVES_PER_CU": 32}, {"BM2_CHAIN_WAVES_PER_CU": 8}]),
+    ("k_bwd LDS survivors / blocks per CU", [{}, {"BM2_BWD_LCAP": 8, "BM2_BWD_BLOCKS_PER_CU": 5}, {"BM2_BWD_LCAP": 8, "BM2_BWD_BLOCKS_PER_CU": 4},
+                                             {"BM2_BWD_LCAP": 6, "BM2_BWD_BLOCKS_PER_CU": 6}, {"BM2_BWD_LCAP": 4, "BM2_BWD_BLOCKS_PER_CU": 6}]),
+    ("extension kernel", [{}, {"BM2_EXT_LANE_V2": 1}]),
+    ("extension wave classes", [{}, {"BM2_EXT_WAVE_QMIN": 129}, {"BM2_EXT_WAVE_QMIN": 97}, {"BM2_EXT_WAVE_QMIN": 161}]),
+    ("extension dispatch order", [{}, {"BM2_EXT_REVERSE": 1}]),
+    ("extension prefetch", [{}, {"BM2_EXT_PREFETCH": 0}]),
+    ("walk blocks per CU", [{}, {"BM2_WALK_BLOCKS_PER_CU": 6}, {"BM2_WALK_BLOCKS_PER_CU": 3}]),
+    ("purge threshold", [{}, {"BM2_PF_HEAVY": 48}, {"BM2_PF_HEAVY": 12}]),
 ]
 
 
@@ -90,32 +90,28 @@ def main():
     log.append({"env": {}, "ms": base_ms, "stages": base_k, "crc": base_crc})
     best_ms = base_ms
     print("[sweep] default: %.2f ms/step %s" % (base_ms, {k: round(v, 2) for k, v in base_k.items()}), file=sys.stderr, flush=True)
-    for knob, cands in GRID:
+    for name, cands in GRID:
         if a.quick:
             cands = cands[:2]
         if time.time() - t_start > a.budget_s:
-            print("[sweep] time budget used; stopping at", knob, file=sys.stderr, flush=True)
+            print("[sweep] time budget used; stopping at", name, file=sys.stderr, flush=True)
             break
-        cur = best_env.get(knob, cands[0])
-        for v in cands:
-            if v == cur:
-                continue
-            env = dict(best_env); env[knob] = v
+        pick = {}
+        for cand in cands[1:]:
+            env = dict(best_env); env.update(cand)
             try:
                 ms, k, crc = measure(env)
             except Exception as e:                                        # noqa
                 log.append({"env": env, "error": str(e)})
+                print("[sweep] %s %s: %s" % (name, cand, e), file=sys.stderr, flush=True)
                 continue
             ok = crc == base_crc
             log.append({"env": env, "ms": ms, "stages": k, "crc": crc, "same_regs": ok})
-            print("[sweep] %s=%s: %.2f ms/step %s%s" % (knob, v, ms, {x: round(y, 2) for x, y in k.items()}, "" if ok else "  REGS DIFFER"),
+            print("[sweep] %s %s: %.2f ms/step %s%s" % (name, cand, ms, {x: round(y, 2) for x, y in k.items()}, "" if ok else "  REGS DIFFER"),
                   file=sys.stderr, flush=True)
             if ok and ms < best_ms * 0.985:                               # keep a change only if it buys more than the noise
-                best_ms, cur = ms, v
-        if cur != cands[0]:
-            best_env[knob] = cur
-        else:
-            best_env.pop(knob, None)
+                best_ms, pick = ms, cand
+        best_env.update(pick)
     final_ms, final_k, final_crc = measure(best_env)
     out = {"workload": {"genome_mbp": a.genome_mbp, "reads": n, "read_len": a.read_len, "steps": a.steps},
            "default": {"ms": base_ms, "stages": base_k}, "best_env": best_env, "best": {"ms": final_ms, "stages": final_k},
