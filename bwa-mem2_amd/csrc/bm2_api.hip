@@ -187,17 +187,23 @@ extern "C" bm2_ctx *bm2_create(int device, const bm2_index_desc *idx) {
         for (int i = 0; i < 5; i++) ix.count[i] = idx->count[i] + 1;      // FMI_search.cpp:433-436
         ix.n_seqs = idx->n_seqs;
         c->has_index = true;
-        const char *ns = getenv("BM2_N_SUB");
-        const int n_sub = ns ? atoi(ns) : BM2_N_SUB;
-        for (int i = 1; i < n_sub; i++) {               // extra contexts for sub-batch pipelining: same index replica
-            bm2_ctx *k = new (std::nothrow) bm2_ctx();
-            if (!k) break;
-            k->device = c->device; k->n_cu = c->n_cu; k->ix = c->ix; k->has_index = true; k->is_child = true;
-            if (make_streams(k)) { delete k; break; }
-            c->subs.push_back(k);
-        }
+        bm2_ensure_subs(c, bm2_knob("BM2_N_SUB", BM2_N_SUB));
     }
     return c;
+}
+
+// extra contexts for sub-batch pipelining (pipeline.hip): same index replica, own streams and workspaces; made on demand
+int bm2_ensure_subs(bm2_ctx *c, int n_sub) {
+    if (!c || c->is_child || !c->has_index) return 1;
+    if (n_sub > 8) n_sub = 8;
+    while ((int)c->subs.size() + 1 < n_sub) {
+        bm2_ctx *k = new (std::nothrow) bm2_ctx();
+        if (!k) break;
+        k->device = c->device; k->n_cu = c->n_cu; k->ix = c->ix; k->has_index = true; k->is_child = true;
+        if (make_streams(k)) { delete k; break; }
+        c->subs.push_back(k);
+    }
+    return 1 + (int)c->subs.size();
 }
 
 // A second context on the same device that SHARES the parent's index replica (its own streams and workspaces): lets a caller

@@ -43,7 +43,8 @@ struct bm2_ctx {
     void *pin[2] = { nullptr, nullptr };
     hipEvent_t pin_ev[2] = { nullptr, nullptr };
 };
-#define BM2_N_SUB 1     // sub-batch pipelining is implemented and parity-tested, but did not pay on one GPU (profiles/)
+#define BM2_N_SUB 1     // sub-batch pipelining is implemented and parity-tested, but did not pay on one GPU (profiles/); knob BM2_N_SUB
+int bm2_ensure_subs(bm2_ctx *c, int n_sub);      // -> parts available (1 + sub-contexts)
 
 // Launch-policy knobs (grid sizes, class routing, thresholds): none of them changes a result.  Read from the environment on every
 // use so that tools/gpu/sweep.py can compare settings inside one process; the defaults are the measured best (profiles/).

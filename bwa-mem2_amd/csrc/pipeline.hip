@@ -460,7 +460,9 @@ static bm2_ctx *part_ctx(bm2_ctx *c, int i) { return i == 0 ? c : c->subs[i - 1]
 extern "C" int bm2_batch_upload(bm2_ctx *c, const bm2_reads *reads) {
     if (!c || !reads || reads->n_reads < 0) { bm2_set_error("bm2_batch_upload: bad argument"); return BM2_EINVAL; }
     const int n = reads->n_reads;
-    int parts = 1 + (int)c->subs.size();
+    int parts = bm2_knob("BM2_N_SUB", 1 + (int)c->subs.size());          // (the knob is read per chunk: tools/gpu/sweep.py compares in one process)
+    if (parts > 1) { const int have = bm2_ensure_subs(c, parts); if (parts > have) parts = have; }
+    if (parts < 1) parts = 1;
     const int blocks = (n + BM2_BLOCK_READS - 1) / BM2_BLOCK_READS;
     if (blocks < 64 * parts) parts = 1;                    // small chunk: one part
     c->n_parts = parts;

@@ -360,12 +360,13 @@ k_walk(DevIndex ix, SeedParams sp, int n_reads, const uint8_t *__restrict__ enc,
 // and the first survivor of a row -- the first candidate of the next row -- never leaves the registers.
 enum { B_EXT = 0, B_NEWITEM, B_FIRST, B_ROWEND, B_ROW, B_FIN, B_DONE };
 
-template <int LC>       // survivors of a row kept in LDS per lane: 16 B x LC x 256 lanes per block decides how many blocks share a CU
-__global__ void __launch_bounds__(256)
-k_bwd(DevIndex ix, SeedParams sp, int pass, const uint8_t *__restrict__ enc, const BHead *__restrict__ heads,
-      uint4 *__restrict__ ents, int64_t slot_cap, uint4 *__restrict__ pool, int pool_cap, int pool_slots,
-      bm2_smem_t *__restrict__ recs, int64_t rec_cap, P2Task *__restrict__ tasks, int64_t task_cap,
-      int32_t *__restrict__ smem_cnt, unsigned long long *sc) {
+// LC: survivors of a row kept in LDS per lane (16 B x LC x 256 lanes per block decides how many blocks share a CU's 160 KB)
+template <int LC>
+static __device__ __forceinline__ void
+bwd_body(const DevIndex &ix, const SeedParams &sp, int pass, const uint8_t *__restrict__ enc, const BHead *__restrict__ heads,
+         uint4 *__restrict__ ents, int64_t slot_cap, uint4 *__restrict__ pool, int pool_cap, int pool_slots,
+         bm2_smem_t *__restrict__ recs, int64_t rec_cap, P2Task *__restrict__ tasks, int64_t task_cap,
+         int32_t *__restrict__ smem_cnt, unsigned long long *sc) {
     int64_t n_ext = 0;
     unsigned ovf = 0;
     int64_t n_items = (int64_t)sc[pass == 1 ? SC_SLOT1 : SC_SLOT2];
@@ -504,6 +505,14 @@ k_bwd(DevIndex ix, SeedParams sp, int pass, const uint8_t *__restrict__ enc, con
     atomicAdd(&sc[SC_N + 6 + 2 * (pass - 1)], prof_rounds); atomicAdd(&sc[SC_N + 6 + 2 * (pass - 1) + 1], prof_active);
 #endif
 }
+
+#define BWD_ARGS DevIndex ix, SeedParams sp, int pass, const uint8_t *__restrict__ enc, const BHead *__restrict__ heads, uint4 *__restrict__ ents, \
+                 int64_t slot_cap, uint4 *__restrict__ pool, int pool_cap, int pool_slots, bm2_smem_t *__restrict__ recs, int64_t rec_cap, \
+                 P2Task *__restrict__ tasks, int64_t task_cap, int32_t *__restrict__ smem_cnt, unsigned long long *sc
+#define BWD_PASS ix, sp, pass, enc, heads, ents, slot_cap, pool, pool_cap, pool_slots, recs, rec_cap, tasks, task_cap, smem_cnt, sc
+template <int LC> __global__ void __launch_bounds__(256) k_bwd(BWD_ARGS) { bwd_body<LC>(BWD_PASS); }     // 117 VGPRs: 4 waves per SIMD
+// the same with the register allocation told to leave room for 5 waves per SIMD (96 VGPRs, 100 bytes per lane spilled)
+template <int LC> __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) k_bwd5(BWD_ARGS) { bwd_body<LC>(BWD_PASS); }
 
 // lanes of one wavefront handing data to each other through LDS: order the accesses (the hardware runs them in lockstep)
 static __device__ __forceinline__ void wave_sync() {
@@ -768,8 +777,9 @@ int bm2_launch_seeding(bm2_ctx *c, const SeedParams &sp, int n_reads, const uint
         hipLaunchKernelGGL(k_bwd_heavy, dim3(grid_heavy), dim3(256), 0, sh, c->ix, sp, pass, enc, heads, ents, slot_cap, sb.pool, sb.pool_cap,
                            sb.pool_slots, heavy, sb.heavy_cap, sb.recs, sb.rec_cap, sb.tasks, sb.task_cap, smem_cnt, sc);
         (void)hipEventRecord(c->ev_join[1], sh);
-        const int lc = bm2_knob("BM2_BWD_LCAP", LCAP);
-        auto kb = lc <= 4 ? k_bwd<4> : lc <= 6 ? k_bwd<6> : lc <= 8 ? k_bwd<8> : k_bwd<LCAP>;
+        const int lc = bm2_knob("BM2_BWD_LCAP", LCAP), wpe = bm2_knob("BM2_BWD_WAVES", 4);
+        auto kb = wpe >= 5 ? (lc <= 4 ? k_bwd5<4> : k_bwd5<6>)
+                           : (lc <= 4 ? k_bwd<4> : lc <= 6 ? k_bwd<6> : lc <= 8 ? k_bwd<8> : k_bwd<LCAP>);
         hipLaunchKernelGGL(kb, dim3(grid_bwd), dim3(256), 0, s, c->ix, sp, pass, enc, heads, ents, slot_cap, sb.pool, sb.pool_cap,
                            sb.pool_slots, sb.recs, sb.rec_cap, sb.tasks, sb.task_cap, smem_cnt, sc);
         (void)hipStreamWaitEvent(s, c->ev_join[1], 0);

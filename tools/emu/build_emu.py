@@ -19,6 +19,7 @@ def rewrite(text):
                   r"\1 *\2 = (\1 *)emu_dyn_lds;", text)
     text = text.replace("__attribute__((address_space(3)))", "")
     text = text.replace('"+v"', '"+r"')
+    text = re.sub(r"__attribute__\(\(amdgpu_waves_per_eu\([^)]*\)\)\)", "", text)       # a register-allocation hint
     # collectives called from divergent lanes -> their one-lane-at-a-time versions (see the fake hip_runtime.h); the definition stays
     text = re.sub(r"(?<![A-Za-z_])wave_alloc<(\w+)>\(", r"emu_wave_alloc<\1>(", text)
     text = text.replace("static __device__ __forceinline__ int64_t emu_wave_alloc(", "static __device__ __forceinline__ int64_t wave_alloc(")

@@ -24,12 +24,14 @@ GRID = [   # (name, candidates): a candidate is a dict of knobs set together; th
     ("chain staging", [{}, {"BM2_CHAIN_STAGE": 1}]),
     ("chain heavy threshold", [{}, {"BM2_HEAVY_SA": 64}, {"BM2_HEAVY_SA": 40}, {"BM2_HEAVY_SA": 24}, {"BM2_HEAVY_SA": 160}]),
     ("chain waves per CU", [{}, {"BM2_CHAIN_WAVES_PER_CU": 32}, {"BM2_CHAIN_WAVES_PER_CU": 8}]),
-    ("k_bwd LDS survivors / blocks per CU", [{}, {"BM2_BWD_LCAP": 8, "BM2_BWD_BLOCKS_PER_CU": 5}, {"BM2_BWD_LCAP": 8, "BM2_BWD_BLOCKS_PER_CU": 4},
-                                             {"BM2_BWD_LCAP": 6, "BM2_BWD_BLOCKS_PER_CU": 6}, {"BM2_BWD_LCAP": 4, "BM2_BWD_BLOCKS_PER_CU": 6}]),
-    ("extension kernel", [{}, {"BM2_EXT_LANE_V2": 1}]),
+    ("k_bwd LDS survivors / blocks per CU / waves per SIMD", [{}, {"BM2_BWD_LCAP": 8, "BM2_BWD_BLOCKS_PER_CU": 4}, {"BM2_BWD_LCAP": 6, "BM2_BWD_BLOCKS_PER_CU": 4},
+                                                              {"BM2_BWD_LCAP": 4, "BM2_BWD_BLOCKS_PER_CU": 4},
+                                                              {"BM2_BWD_LCAP": 6, "BM2_BWD_BLOCKS_PER_CU": 5, "BM2_BWD_WAVES": 5},
+                                                              {"BM2_BWD_LCAP": 4, "BM2_BWD_BLOCKS_PER_CU": 5, "BM2_BWD_WAVES": 5}]),
     ("extension wave classes", [{}, {"BM2_EXT_WAVE_QMIN": 129}, {"BM2_EXT_WAVE_QMIN": 97}, {"BM2_EXT_WAVE_QMIN": 161}]),
     ("extension dispatch order", [{}, {"BM2_EXT_REVERSE": 1}]),
     ("extension prefetch", [{}, {"BM2_EXT_PREFETCH": 0}]),
+    ("sub-batches of the chunk on their own streams", [{}, {"BM2_N_SUB": 2}, {"BM2_N_SUB": 3}]),
     ("walk blocks per CU", [{}, {"BM2_WALK_BLOCKS_PER_CU": 6}, {"BM2_WALK_BLOCKS_PER_CU": 3}]),
     ("purge threshold", [{}, {"BM2_PF_HEAVY": 48}, {"BM2_PF_HEAVY": 12}]),
 ]
@@ -65,12 +67,16 @@ def main():
     opt = bm2.default_opt()
     print("[sweep] index + chunk resident after %.1fs" % (time.time() - t), file=sys.stderr, flush=True)
 
+    state = {"nsub": None}
+
     def measure(env):
-        for k in [k for k in os.environ if k.startswith("BM2_")
-                  and k not in ("BM2_EMU_LIB", "BM2_BENCH_WORKDIR", "BM2_N_SUB")]:
+        for k in [k for k in os.environ if k.startswith("BM2_") and k not in ("BM2_EMU_LIB", "BM2_BENCH_WORKDIR")]:
             del os.environ[k]
         for k, v in env.items():
             os.environ[k] = str(v)
+        if env.get("BM2_N_SUB") != state["nsub"]:                  # the chunk is cut into sub-batches when it is uploaded
+            ctx.batch_upload(seqs.reshape(-1), np.arange(n, dtype=np.int64) * a.read_len, np.full(n, a.read_len, np.int32))
+            state["nsub"] = env.get("BM2_N_SUB")
         ctx.batch_run(opt)                                   # warm-up (workspace sizes of this setting)
         kms = {}
         t0 = time.perf_counter()
