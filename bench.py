@@ -527,12 +527,18 @@ def main():
             out["cpu_baseline"] = None
         if world == 1 and not a.no_e2e and not ont:
             t = time.time()
-            texts = []
-            for i in range(a.e2e_chunks):                    # distinct chunks of the same shape as the timed one
-                e1, e2 = synth.make_reads_pe(seed + 100 + i, contigs(), n_reads // 2, L=a.read_len)
-                fa, fb = os.path.join(a.workdir, "e2e_1.fq"), os.path.join(a.workdir, "e2e_2.fq")
-                synth.write_fastq(fa, e1, prefix="c%d_" % i, suffix="/1"); synth.write_fastq(fb, e2, prefix="c%d_" % i, suffix="/2")
+            texts = []                                       # distinct chunks of the same shape as the timed one, generated side by side
+            meta = prefix + ".contigs.npz"
+            procs = []
+            for i in range(a.e2e_chunks):
+                fa, fb = os.path.join(a.workdir, "e2e_%d_1.fq" % i), os.path.join(a.workdir, "e2e_%d_2.fq" % i)
+                procs.append((fa, fb, subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "gen_chunk.py"), meta, str(seed + 100 + i),
+                                                        str(n_reads // 2), str(a.read_len), fa, fb, "c%d_" % i])))
+            for fa, fb, pr in procs:
+                if pr.wait() != 0:
+                    raise SystemExit("bench.py: generating an end-to-end chunk failed")
                 texts.append((open(fa, "rb").read(), open(fb, "rb").read()))
+                os.remove(fa); os.remove(fb)
             log("end-to-end input: %d chunks generated in %.1fs" % (len(texts), time.time() - t))
             try:
                 end_to_end(ctx, bm2, texts[:1], opt, True, 0)                       # warm-up (workspaces, thread pools)

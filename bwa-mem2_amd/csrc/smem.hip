@@ -737,6 +737,53 @@ k_sal(DevIndex ix, int64_t n, int64_t *pos_coord, unsigned long long *n_lf_out) 
     if (n_lf_out) atomicAdd(n_lf_out, (unsigned long long)n_lf);
 }
 
+// The same walk, QUAD-COOPERATIVE like backward_ext: each lane still owns one lookup, but the CP_OCC entry a lane needs is fetched
+// by its quad -- lane b loads quarter b = {count[b], bwt[b]} -- so one load instruction touches 16 lines per wave instead of 64
+// (the address-translation rate, not HBM, caps one-line-per-lane access on an index of this size: tools/ubench/randline.hip).
+// The lane whose quarter has the position's bit set knows the base and ranks it; a quad sum hands the result to the owner.
+// All 64 lanes stay in the loop until the whole wavefront is done (the exchange needs every lane of a quad).
+template <int T>
+static __device__ __forceinline__ void sal_turn(const DevIndex &ix, int sub, int64_t my_sp, bool my_walk, int64_t &new_sp, int &hit) {
+    const int64_t sp = qbcast64<T>(my_sp);
+    const int want = qbcast32<T>(my_walk ? 1 : 0);
+    ulonglong2 e = make_ulonglong2(0, 0);
+    if (want) e = ((const ulonglong2 *)&ix.cp_occ[sp >> 6])[sub];             // {count[sub], bwt[sub]}
+    const int y = 63 - (int)(sp & 63);
+    const bool mine = want && ((e.y >> y) & 1);                                // the symbol at sp is base `sub`
+    const int yy = (int)(sp & 63);
+    const uint64_t msk = yy ? (~0ULL << (64 - yy)) : 0ULL;
+    const int64_t nxt = mine ? pick4(sub, ix.count[0], ix.count[1], ix.count[2], ix.count[3]) + (int64_t)e.x + __popcll(e.y & msk) : 0;
+    const int64_t sum = qsum64(nxt);
+    const int any = (int)qsum64(mine ? 1 : 0);
+    if (sub == T) { new_sp = sum; hit = any; }
+}
+__global__ void __launch_bounds__(256)
+k_sal_quad(DevIndex ix, int64_t n, int64_t *pos_coord, unsigned long long *n_lf_out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int sub = (int)(threadIdx.x & 3);
+    int64_t n_lf = 0, sp = 0, offset = 0, res = 0;
+    bool walk = false;
+    if (t < n) {
+        sp = pos_coord[t];
+        if ((sp & 7) == 0) res = ((int64_t)ix.sa_ms_byte[sp >> 3] << 32) + ix.sa_ls_word[sp >> 3];
+        else walk = true;
+    }
+    while (__any(walk)) {
+        int64_t nsp = 0; int hit = 0;
+        sal_turn<0>(ix, sub, sp, walk, nsp, hit); sal_turn<1>(ix, sub, sp, walk, nsp, hit);
+        sal_turn<2>(ix, sub, sp, walk, nsp, hit); sal_turn<3>(ix, sub, sp, walk, nsp, hit);
+        if (walk) {
+            if (!hit) { res = 0; walk = false; }                                // sentinel: 0 whatever the offset (:1230-1233)
+            else {
+                n_lf++; sp = nsp; offset++;
+                if ((sp & 7) == 0) { res = ((int64_t)ix.sa_ms_byte[sp >> 3] << 32) + ix.sa_ls_word[sp >> 3] + offset; walk = false; }
+            }
+        }
+    }
+    if (t < n) pos_coord[t] = res;
+    if (n_lf_out) atomicAdd(n_lf_out, (unsigned long long)n_lf);
+}
+
 // gather SMEMs from the bump-allocated order into read order (for the S2 entry point only)
 __global__ void __launch_bounds__(256)
 k_smem_gather(int n_reads, const bm2_smem_t *__restrict__ in, const int64_t *__restrict__ in_off,
@@ -806,7 +853,8 @@ int bm2_launch_sal_expand(bm2_ctx *c, const bm2_smem_t *smems, int64_t n_smem, c
 }
 int bm2_launch_sal(bm2_ctx *c, int64_t n, int64_t *pos_coord, unsigned long long *n_lf) {
     if (n <= 0) return BM2_OK;
-    hipLaunchKernelGGL(k_sal, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->ix, n, pos_coord, n_lf);
+    if (bm2_knob("BM2_SAL_QUAD", 0)) hipLaunchKernelGGL(k_sal_quad, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->ix, n, pos_coord, n_lf);
+    else hipLaunchKernelGGL(k_sal, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->ix, n, pos_coord, n_lf);
     return bm2_check(hipGetLastError(), "k_sal launch");
 }
 int bm2_launch_smem_gather(bm2_ctx *c, int n_reads, const bm2_smem_t *in, const int64_t *in_off, const int32_t *cnt,

@@ -31,6 +31,7 @@ GRID = [   # (name, candidates): a candidate is a dict of knobs set together; th
     ("extension wave classes", [{}, {"BM2_EXT_WAVE_QMIN": 129}, {"BM2_EXT_WAVE_QMIN": 97}, {"BM2_EXT_WAVE_QMIN": 161}]),
     ("extension dispatch order", [{}, {"BM2_EXT_REVERSE": 1}]),
     ("extension prefetch", [{}, {"BM2_EXT_PREFETCH": 0}]),
+    ("SA lookup by quads", [{}, {"BM2_SAL_QUAD": 1}]),
     ("sub-batches of the chunk on their own streams", [{}, {"BM2_N_SUB": 2}, {"BM2_N_SUB": 3}]),
     ("walk blocks per CU", [{}, {"BM2_WALK_BLOCKS_PER_CU": 6}, {"BM2_WALK_BLOCKS_PER_CU": 3}]),
     ("purge threshold", [{}, {"BM2_PF_HEAVY": 48}, {"BM2_PF_HEAVY": 12}]),

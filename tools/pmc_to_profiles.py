@@ -49,8 +49,14 @@ def main():
           "read_len": bench["config"]["read_len"]}
     f, fc = counters(os.path.join(src, "pmc_fetch.md"))
     w, _ = counters(os.path.join(src, "pmc_write.md"))
-    fs, nd = f["k_bwd"]["FETCH_SIZE"]
-    ws, _ = w["k_bwd"]["WRITE_SIZE"]
+    def bwd(d, counter):                                          # k_bwd is a template since round 2: "void k_bwd<12>", "void k_bwd5<6>"
+        tot, nd = 0.0, 0
+        for k, v in d.items():
+            if "k_bwd" in k and "heavy" not in k and counter in v:
+                tot += v[counter][0]; nd += v[counter][1]
+        return tot, nd
+    fs, nd = bwd(f, "FETCH_SIZE")
+    ws, _ = bwd(w, "WRITE_SIZE")
     out = {"kernel": "k_bwd", "workload": wl, "fetch_size_kib_per_launch": fs / nd, "write_size_kib_per_launch": ws / nd,
            "hbm_bytes_per_launch": (fs + ws) / nd * 1024.0,
            "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (profiles/%s_pmc_fetch.md, %s_pmc_write.md): sums over %d "
