@@ -81,6 +81,38 @@ print("ok", len(regs))
     assert p.returncode == 0 and p.stdout.startswith(b"ok"), p.stderr.decode()[-2000:]
 
 
+def test_launch_policy_knobs_do_not_change_results(emu_lib, golden_dir):
+    # bm2_knob settings select kernels and code paths (wavefront-per-task extension for a query-length class, staged heavy chaining,
+    # k_bwd's LDS depth / register budget, quad-cooperative SA lookup, wave-per-read purge threshold, dispatch order, round limits):
+    # the regs must not depend on any of them.  tools/gpu/sweep.py relies on this when it compares settings by checksum on the GPU.
+    script = r'''
+import sys, os
+sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np, bm2
+bm2.LIB_PATH = %r
+from helpers import load_golden, regs_to_records
+from tools import oracle
+pre, enc, off, ln, d = load_golden(%r, "g60k")
+n = 48
+ln = ln[:n]; off = off[:n]; enc = enc[:int(off[-1] + ln[-1])]
+ix = oracle.Index(pre); exp = ix.run(enc, off, ln)["REGPRG"].tobytes(); ix.close()
+ctx = bm2.Context(0, pre)
+sets = [{}, {"BM2_EXT_WAVE_QMIN": 33, "BM2_EXT_REVERSE": 1, "BM2_EXT_PREFETCH": 0}, {"BM2_EXT_WAVE_QMIN": 161, "BM2_EXT_WAVE_NMAX": 20, "BM2_EXT_ROUNDS": 2},
+        {"BM2_HEAVY_SA": 2, "BM2_CHAIN_STAGE": 1, "BM2_CHAIN_WAVES_PER_CU": 32, "BM2_PF_HEAVY": 2},
+        {"BM2_BWD_LCAP": 4, "BM2_BWD_BLOCKS_PER_CU": 5, "BM2_BWD_WAVES": 5, "BM2_SAL_QUAD": 1}, {"BM2_BWD_LCAP": 8, "BM2_HEAVY_SA": 5, "BM2_CHAIN_STAGE": 0}]
+for kn in sets:
+    for k in [k for k in os.environ if k.startswith("BM2_")]:
+        del os.environ[k]
+    for k, v in kn.items():
+        os.environ[k] = str(v)
+    regs, reg_off, st = ctx.seed_chain_extend(enc, off, ln, bm2.default_opt())
+    assert regs_to_records(regs, reg_off).tobytes() == exp, kn
+print("ok", len(sets))
+''' % (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "bwa-mem2_amd"), emu_lib, golden_dir)
+    p = subprocess.run(["python", "-c", script], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
+    assert p.returncode == 0 and p.stdout.startswith(b"ok"), p.stderr.decode()[-2000:]
+
+
 def test_rescue_kernel_and_sam_pe_dev_on_the_emulator(emu_lib, tmp_path):
     # k_ksw_align2 through its real launcher (task records, size-sorted order, LDS layout, list offsets) and bm2_sam_pe_dev end to end
     # (the host plans, the emulated device aligns against its reference replica, the host replays): same results as the host kernel,
