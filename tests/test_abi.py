@@ -3,6 +3,8 @@ import ctypes
 import os
 import re
 
+import pytest
+
 import bm2
 from conftest import ROOT
 
@@ -41,7 +43,7 @@ def test_opt_defaults_are_mem_opt_init():
 
 def test_no_device_fails_loudly():
     if bm2.lib().bm2_device_count() > 0:
-        return
+        pytest.skip("a HIP device is visible here: the no-device error path cannot be reached")
     try:
         bm2.Context(0)
     except bm2.Bm2Error as e:

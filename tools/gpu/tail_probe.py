@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""End-to-end leg (FASTQ text -> SAM text) of bench.py on a SMALL genome, without torch: where the time of the host tail and of its two
+device batches (mate-rescue SW, CIGAR) goes.  Run it under `rocprofv3 --kernel-trace` with BM2_TAIL_PROF=1 for the per-kernel and
+per-phase clocks.   python tools/gpu/tail_probe.py <out_dir> [genome_mbp] [chunks]"""
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "bwa-mem2_amd"))
+
+
+def main():
+    out = sys.argv[1]
+    mbp = int(sys.argv[2]) if len(sys.argv) > 2 else 128
+    n_chunks = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+    os.makedirs(out, exist_ok=True)
+    import bench
+    import bm2
+    wd = "/tmp/bm2_tail_probe"
+    os.makedirs(wd, exist_ok=True)
+    t = time.time()
+    prefix, contigs = bench.prepare_genome(wd, mbp, 777)
+    procs = []
+    for i in range(n_chunks + 1):
+        fa, fb = os.path.join(wd, "c%d_1.fq" % i), os.path.join(wd, "c%d_2.fq" % i)
+        procs.append((fa, fb, subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "gen_chunk.py"), prefix + ".contigs.npz", str(900 + i),
+                                                str(int(sys.argv[4]) if len(sys.argv) > 4 else 500000), "150", fa, fb, "c%d_" % i])))
+    texts = []
+    for fa, fb, pr in procs:
+        assert pr.wait() == 0
+        texts.append((open(fa, "rb").read(), open(fb, "rb").read()))
+    print("[probe] inputs ready in %.1fs" % (time.time() - t), file=sys.stderr, flush=True)
+    ctx = bm2.Context(0, prefix)
+    opt = bm2.default_opt()
+    bench.end_to_end(ctx, bm2, texts[:1], opt, True, 0)
+    print("[probe] ---- warm-up done ----", file=sys.stderr, flush=True)
+    r = bench.end_to_end(ctx, bm2, texts[1:], opt, True, 0)
+    r["genome_mbp"] = mbp
+    print("[probe] rescue stats (planned, used, missed):", bm2.sam_rescue_stats(), "cigar stats:", bm2.sam_cigar_stats(), file=sys.stderr, flush=True)
+    json.dump(r, open(os.path.join(out, "tail_probe.json"), "w"), indent=1)
+    print(json.dumps(r), flush=True)
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
