@@ -40,6 +40,13 @@ def main():
     print("[probe] ---- warm-up done ----", file=sys.stderr, flush=True)
     r = bench.end_to_end(ctx, bm2, texts[1:], opt, True, 0)
     r["genome_mbp"] = mbp
+    r["splits"] = []                                        # tail workers x host threads per worker: which split feeds the device best
+    for tails, threads in [(s_.split("x")) for s_ in os.environ.get("PROBE_SPLITS", "").split()]:
+        os.environ["BM2_E2E_TAILS"] = tails; os.environ["BM2_E2E_TAIL_THREADS"] = threads
+        os.environ.pop("BM2_TAIL_PROF", None)
+        q = bench.end_to_end(ctx, bm2, texts[1:], opt, True, 0)
+        r["splits"].append({"tail_workers": int(tails), "threads_per_worker": int(threads), "value": q["value"], "stage_ms_per_chunk": q["stage_ms_per_chunk"]})
+        print("[probe] %s workers x %s threads: %.2f M reads/s %s" % (tails, threads, q["value"] / 1e6, {k: round(v) for k, v in q["stage_ms_per_chunk"].items()}), file=sys.stderr, flush=True)
     print("[probe] rescue stats (planned, used, missed):", bm2.sam_rescue_stats(), "cigar stats:", bm2.sam_cigar_stats(), file=sys.stderr, flush=True)
     json.dump(r, open(os.path.join(out, "tail_probe.json"), "w"), indent=1)
     print(json.dumps(r), flush=True)
