@@ -5,6 +5,12 @@
 // rescue (mem_matesw: a local Smith-Waterman in the shape of the reference's SSE2 kernel, whose quirks are observable) and
 // pairing (mem_pair) -- branchy and order-sensitive.  The mate-rescue SW is the next device kernel; this is its oracle.
 #include <limits.h>
+#include <linux/futex.h>
+#include <pthread.h>
+#include <sched.h>
+#include <sys/syscall.h>
+#include <unistd.h>
+#include <memory>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -25,52 +31,79 @@
 void bm2_set_error(const char *fmt, ...);
 
 namespace {
-// A process-wide pool of worker threads for the tail's parallel phases.  A chunk goes through a dozen short phases; spawning a few
-// hundred threads for each of them cost more than the phases themselves.  run_threads(n, f) runs n copies of f (the caller is one
-// of them) and returns when all are through; several callers (tail workers of different chunks) may be inside at once.
+// Worker threads for the tail's parallel phases.  A chunk goes through a dozen short phases, so what counts is how fast ALL workers get
+// going: a queue behind one mutex hands the lock from one woken thread to the next (each hand-over costs a scheduler wake-up: milliseconds
+// for a few hundred threads), and spawning threads per phase cost more than the phases themselves.  Here every calling thread (a tail
+// worker of the pipeline) owns its workers; a phase is published by bumping a generation word and waking every sleeper with ONE futex
+// call; a worker that finished spins briefly before it sleeps, so back-to-back phases find the workers awake; completion is a counter
+// the caller spins / sleeps on.  No lock anywhere.  run(n, f) runs n copies of f (the caller is one of them) and returns when all are through.
 class TailPool {
-    struct Job { std::function<void()> *f; std::atomic<int> *left; std::mutex *m; std::condition_variable *cv; };
-    std::mutex mu; std::condition_variable cv;
-    std::vector<Job> queue; std::vector<std::thread> workers; bool stop = false;
-    void loop() {
+    std::vector<std::thread> workers;
+    std::function<void()> *job = nullptr;
+    alignas(64) std::atomic<uint32_t> gen{0};                   // futex word: one increment per phase
+    alignas(64) std::atomic<int32_t> want{0};                   // workers [0, want) take part in the current phase
+    alignas(64) std::atomic<uint32_t> left{0};                  // futex word: participants still inside f
+    std::atomic<bool> stop{false};
+    static void pause() {
+#if defined(__x86_64__) || defined(__i386__)
+        __builtin_ia32_pause();
+#endif
+    }
+    static void futex_wait(std::atomic<uint32_t> *w, uint32_t seen) { syscall(SYS_futex, (uint32_t *)w, FUTEX_WAIT_PRIVATE, seen, nullptr, nullptr, 0); }
+    static void futex_wake_all(std::atomic<uint32_t> *w) { syscall(SYS_futex, (uint32_t *)w, FUTEX_WAKE_PRIVATE, INT_MAX, nullptr, nullptr, 0); }
+    // A worker stays on one CPU of the process's affinity mask, handed out round-robin over all pools: a freshly woken thread then
+    // starts where it slept instead of queueing on the waker's CPU until the load balancer gets to it (milliseconds on virtualised
+    // hosts; a phase lasts a few).  BM2_TAIL_PIN=0 leaves the placement to the scheduler.
+    static void pin_self() {
+        static const bool on = []() { const char *e = getenv("BM2_TAIL_PIN"); return !(e && e[0] == '0'); }();
+        if (!on) return;
+        static std::atomic<unsigned> next_cpu{1};
+        cpu_set_t all;
+        if (sched_getaffinity(0, sizeof all, &all) != 0) return;
+        const int n = CPU_COUNT(&all);
+        if (n < 2) return;
+        int k = (int)(next_cpu.fetch_add(1) % (unsigned)n);
+        for (int c = 0; c < CPU_SETSIZE; ++c)
+            if (CPU_ISSET(c, &all) && k-- == 0) { cpu_set_t one; CPU_ZERO(&one); CPU_SET(c, &one); pthread_setaffinity_np(pthread_self(), sizeof one, &one); return; }
+    }
+    void loop(int idx, uint32_t seen) {
+        pin_self();
         for (;;) {
-            Job j;
-            {
-                std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&]() { return stop || !queue.empty(); });
-                if (stop && queue.empty()) return;
-                j = queue.back(); queue.pop_back();
+            uint32_t g;
+            for (int spins = 0; (g = gen.load(std::memory_order_acquire)) == seen;) { if (++spins < 4000) pause(); else futex_wait(&gen, seen); }
+            seen = g;
+            if (stop.load(std::memory_order_acquire)) return;
+            if (idx < want.load(std::memory_order_relaxed)) {
+                (*job)();
+                if (left.fetch_sub(1, std::memory_order_acq_rel) == 1) futex_wake_all(&left);
             }
-            (*j.f)();
-            if (j.left->fetch_sub(1) == 1) { std::lock_guard<std::mutex> lk(*j.m); j.cv->notify_all(); }
         }
     }
 public:
-    TailPool() {
-        int n = (int)std::thread::hardware_concurrency();
-        if (n < 1) n = 1;
-        for (int i = 0; i < n; ++i) workers.emplace_back([this]() { loop(); });
-    }
+    TailPool() {}
     ~TailPool() {
-        { std::lock_guard<std::mutex> lk(mu); stop = true; }
-        cv.notify_all();
+        stop.store(true, std::memory_order_release);
+        gen.fetch_add(1, std::memory_order_release);
+        futex_wake_all(&gen);
         for (auto &t : workers) t.join();
     }
     void run(int n, std::function<void()> f) {
         if (n <= 1) { f(); return; }
-        std::atomic<int> left(n - 1);
-        std::mutex m; std::condition_variable done;
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            for (int i = 0; i < n - 1; ++i) queue.push_back(Job{ &f, &left, &m, &done });
+        while ((int)workers.size() < n - 1) {                     // (a worker starts out having "seen" the current generation)
+            const int idx = (int)workers.size(); const uint32_t g = gen.load(std::memory_order_relaxed);
+            workers.emplace_back([this, idx, g]() { loop(idx, g); });
         }
-        cv.notify_all();
-        f();                                                    // the caller takes part
-        std::unique_lock<std::mutex> lk(m);
-        done.wait(lk, [&]() { return left.load() == 0; });
+        job = &f;
+        want.store(n - 1, std::memory_order_relaxed);
+        left.store((uint32_t)(n - 1), std::memory_order_relaxed);
+        gen.fetch_add(1, std::memory_order_release);
+        futex_wake_all(&gen);
+        f();                                                      // the caller takes part
+        uint32_t l;
+        for (int spins = 0; (l = left.load(std::memory_order_acquire)) != 0;) { if (++spins < 4000) pause(); else futex_wait(&left, l); }
     }
 };
-TailPool &tail_pool() { static TailPool p; return p; }
+TailPool &tail_pool() { static thread_local TailPool p; return p; }
 template <class F> void run_threads(int n_threads, F f) {
     if (n_threads <= 1) { f(); return; }
     tail_pool().run(n_threads, std::function<void()>(f));
@@ -954,10 +987,13 @@ void rescue_skip(const Ref &R, const PeStat pes[4], const bm2_alnreg_t *a, const
 void dedup_rescued(const bm2_opt *opt, std::vector<bm2_alnreg_t> &hits) {
     const int n = (int)hits.size();
     if (n <= 1) return;
-    std::vector<int> ord((size_t)n);
+    static thread_local std::vector<int> ord, keep;              // (scratch kept per thread: this runs after every rescued direction)
+    static thread_local std::vector<char> gone;
+    static thread_local std::vector<bm2_alnreg_t> out;
+    ord.resize((size_t)n);
     for (int i = 0; i < n; ++i) ord[(size_t)i] = i;
     k_introsort((size_t)n, ord.data(), [&](int x, int y) { return hits[(size_t)x].re < hits[(size_t)y].re; });
-    std::vector<char> gone((size_t)n, 0);
+    gone.assign((size_t)n, 0);
     for (auto &h : hits) h.n_comp = 1;
     auto span = [](int64_t b, int64_t e) { return e - b; };
     for (int i = 1; i < n; ++i) {
@@ -972,20 +1008,19 @@ void dedup_rescued(const bm2_opt *opt, std::vector<bm2_alnreg_t> &hits) {
                 gone[(size_t)ord[(size_t)(p.score < q.score ? i : j)]] = 1;
         }
     }
-    std::vector<int> keep;
+    keep.clear();
     for (int i = 0; i < n; ++i) if (!gone[(size_t)ord[(size_t)i]]) keep.push_back(ord[(size_t)i]);
     k_introsort(keep.size(), keep.data(), [&](int x, int y) {
         const bm2_alnreg_t &a = hits[(size_t)x], &b = hits[(size_t)y];
         return a.score > b.score || (a.score == b.score && (a.rb < b.rb || (a.rb == b.rb && a.qb < b.qb)));
     });
-    std::vector<bm2_alnreg_t> out;
-    out.reserve(keep.size());
+    out.clear();
     for (size_t k = 0; k < keep.size(); ++k) {
         const bm2_alnreg_t &a = hits[(size_t)keep[k]];
         if (k > 0) { const bm2_alnreg_t &b = hits[(size_t)keep[k - 1]]; if (a.score == b.score && a.rb == b.rb && a.qb == b.qb) continue; }
         out.push_back(a);
     }
-    hits.swap(out);
+    hits.assign(out.begin(), out.end());
 }
 
 int matesw(const bm2_opt *opt, const bm2_sam_opt *so, const Ref &R, const int32_t *ann_len, const PeStat pes[4], const bm2_alnreg_t *a,
@@ -1100,13 +1135,18 @@ int raw_mapq(int diff, int a) { return (int)(6.02 * diff / a + .499); }
 
 struct ReadIO { const char *name, *comment, *qual; int l_seq; const uint8_t *seq; };
 
-// mem_sam_pe, bwamem_pair.cpp:353-551
-bool sam_pe(const bm2_opt *opt, const bm2_sam_opt *so, const Ref &R, const int32_t *ann_len, const PeStat pes[4], uint64_t id,
-            const ReadIO s[2], std::vector<bm2_alnreg_t> a[2], std::string &out, const RescueTask *pre, int n_pre, RescueStats *st) {
-    int z[2] = { 0, 0 }, o, subo, n_sub, extra_flag = 1, n_pri[2];
-    Aln h[2];
+// mem_sam_pe (bwamem_pair.cpp:353-551) in two halves.  pe_decide is everything that CHANGES the pair's hit lists: mate rescue (with the
+// batch's results at hand), primary marking, pairing, the MAPQs of a proper pair.  pe_emit is what follows -- XA strings, CIGARs, text --
+// and only reads the lists, so a CIGAR session can run it twice (once to note the hits it asks for, once to print) on the same state.
+struct PairPlan { int z[2] = { 0, 0 }, n_pri[2] = { 0, 0 }, q_se[2] = { 0, 0 }, extra_flag = 1; bool paired = false; };
+
+void pe_decide(const bm2_opt *opt, const bm2_sam_opt *so, const Ref &R, const int32_t *ann_len, const PeStat pes[4], uint64_t id,
+               const ReadIO s[2], std::vector<bm2_alnreg_t> a[2], const RescueTask *pre, int n_pre, RescueStats *st, PairPlan &P) {
+    int o, subo, n_sub;
+    P = PairPlan();
+    int *z = P.z, *n_pri = P.n_pri, *q_se = P.q_se;
     if (!(so->flag & F_NO_RESCUE)) {
-        std::vector<bm2_alnreg_t> b[2];
+        static thread_local std::vector<bm2_alnreg_t> b[2];
         for (int i = 0; i < 2; ++i) rescue_anchors(so, a[i], b[i]);
         int t = 0;                                               // pre[] is ordered by (end, j, r), as rescue_plan emits it
         for (int i = 0; i < 2; ++i)
@@ -1120,73 +1160,74 @@ bool sam_pe(const bm2_opt *opt, const bm2_sam_opt *so, const Ref &R, const int32
     n_pri[0] = mark_primary_se(opt, (int)a[0].size(), a[0].data(), (int64_t)(id << 1 | 0));
     n_pri[1] = mark_primary_se(opt, (int)a[1].size(), a[1].data(), (int64_t)(id << 1 | 1));
     if (so->flag & F_PRIMARY5) { reorder_primary5(so->T, (int)a[0].size(), a[0].data()); reorder_primary5(so->T, (int)a[1].size(), a[1].data()); }
-    bool paired = false;
-    if (!(so->flag & F_NOPAIRING) && n_pri[0] && n_pri[1] && (o = pair_hits(opt, R, pes, a, (int)id, &subo, &n_sub, z, n_pri)) > 0) {
-        int is_multi[2], q_pe, score_un, q_se[2];
+    if ((so->flag & F_NOPAIRING) || !n_pri[0] || !n_pri[1] || (o = pair_hits(opt, R, pes, a, (int)id, &subo, &n_sub, z, n_pri)) <= 0) return;
+    for (int i = 0; i < 2; ++i)                                  // a second primary hit above the threshold: the reads go out one by one
+        for (int j = 1; j < n_pri[i]; ++j) if (a[i][j].secondary < 0 && a[i][j].score >= so->T) return;
+    P.paired = true;
+    int score_un = a[0][0].score + a[1][0].score - so->pen_unpaired;
+    subo = subo > score_un ? subo : score_un;
+    int q_pe = raw_mapq(o - subo, opt->a);
+    if (n_sub > 0) q_pe -= (int)(4.343 * log(n_sub + 1) + .499);
+    if (q_pe < 0) q_pe = 0;
+    if (q_pe > 60) q_pe = 60;
+    q_pe = (int)(q_pe * (1. - .5 * (a[0][0].frac_rep + a[1][0].frac_rep)) + .499);
+    if (o > score_un) {
+        bm2_alnreg_t *c[2] = { &a[0][z[0]], &a[1][z[1]] };
         for (int i = 0; i < 2; ++i) {
-            int j;
-            for (j = 1; j < n_pri[i]; ++j) if (a[i][j].secondary < 0 && a[i][j].score >= so->T) break;
-            is_multi[i] = j < n_pri[i] ? 1 : 0;
+            if (c[i]->secondary >= 0) { c[i]->sub = a[i][c[i]->secondary].score; c[i]->secondary = -2; }
+            q_se[i] = approx_mapq_se(opt, so, c[i]);
         }
-        if (!(is_multi[0] || is_multi[1])) {
-            paired = true;
-            score_un = a[0][0].score + a[1][0].score - so->pen_unpaired;
-            subo = subo > score_un ? subo : score_un;
-            q_pe = raw_mapq(o - subo, opt->a);
-            if (n_sub > 0) q_pe -= (int)(4.343 * log(n_sub + 1) + .499);
-            if (q_pe < 0) q_pe = 0;
-            if (q_pe > 60) q_pe = 60;
-            q_pe = (int)(q_pe * (1. - .5 * (a[0][0].frac_rep + a[1][0].frac_rep)) + .499);
-            if (o > score_un) {
-                bm2_alnreg_t *c[2] = { &a[0][z[0]], &a[1][z[1]] };
-                for (int i = 0; i < 2; ++i) {
-                    if (c[i]->secondary >= 0) { c[i]->sub = a[i][c[i]->secondary].score; c[i]->secondary = -2; }
-                    q_se[i] = approx_mapq_se(opt, so, c[i]);
-                }
-                q_se[0] = q_se[0] > q_pe ? q_se[0] : q_pe < q_se[0] + 40 ? q_pe : q_se[0] + 40;
-                q_se[1] = q_se[1] > q_pe ? q_se[1] : q_pe < q_se[1] + 40 ? q_pe : q_se[1] + 40;
-                extra_flag |= 2;
-                q_se[0] = q_se[0] < raw_mapq(c[0]->score - c[0]->csub, opt->a) ? q_se[0] : raw_mapq(c[0]->score - c[0]->csub, opt->a);
-                q_se[1] = q_se[1] < raw_mapq(c[1]->score - c[1]->csub, opt->a) ? q_se[1] : raw_mapq(c[1]->score - c[1]->csub, opt->a);
-            } else {
-                z[0] = z[1] = 0;
-                q_se[0] = approx_mapq_se(opt, so, &a[0][0]);
-                q_se[1] = approx_mapq_se(opt, so, &a[1][0]);
-            }
-            for (int i = 0; i < 2; ++i) {
-                const int k = a[i][z[i]].secondary_all;
-                if (k >= 0 && k < n_pri[i]) {                  // switch secondary and primary if both are non-ALT
-                    for (size_t j = 0; j < a[i].size(); ++j)
-                        if (a[i][j].secondary_all == k || (int)j == k) a[i][j].secondary_all = z[i];
-                    a[i][z[i]].secondary_all = -1;
-                }
-            }
-            std::vector<std::string> XA[2]; bool any_xa[2] = { false, false };
-            if (!(so->flag & F_ALL))
-                for (int i = 0; i < 2; ++i)
-                    if (!gen_alt(opt, so, R, (int)a[i].size(), a[i].data(), s[i].l_seq, s[i].seq, XA[i], any_xa[i])) return false;
-            std::vector<Aln> aa[2];
-            for (int i = 0; i < 2; ++i) {
-                if (!reg2aln(opt, so, R, s[i].l_seq, s[i].seq, &a[i][z[i]], h[i])) return false;
-                h[i].mapq = q_se[i];
-                h[i].flag |= 0x40 << i | extra_flag;
-                h[i].XA = (any_xa[i] && !XA[i][z[i]].empty()) ? &XA[i][z[i]] : nullptr;
-                aa[i].push_back(h[i]);
-                if (n_pri[i] < (int)a[i].size()) {             // the read has ALT hits
-                    const bm2_alnreg_t *p = &a[i][n_pri[i]];
-                    if (p->score < so->T || p->secondary >= 0 || !p->is_alt) continue;
-                    Aln g;
-                    if (!reg2aln(opt, so, R, s[i].l_seq, s[i].seq, p, g)) return false;
-                    g.flag |= 0x800 | 0x40 << i | extra_flag;
-                    g.XA = (any_xa[i] && !XA[i][n_pri[i]].empty()) ? &XA[i][n_pri[i]] : nullptr;
-                    aa[i].push_back(g);
-                }
-            }
-            for (int i = 0; i < (int)aa[0].size(); ++i) aln2sam(so, R, out, s[0].name, s[0].comment, s[0].qual, s[0].l_seq, s[0].seq, aa[0], i, &h[1]);
-            for (int i = 0; i < (int)aa[1].size(); ++i) aln2sam(so, R, out, s[1].name, s[1].comment, s[1].qual, s[1].l_seq, s[1].seq, aa[1], i, &h[0]);
+        q_se[0] = q_se[0] > q_pe ? q_se[0] : q_pe < q_se[0] + 40 ? q_pe : q_se[0] + 40;
+        q_se[1] = q_se[1] > q_pe ? q_se[1] : q_pe < q_se[1] + 40 ? q_pe : q_se[1] + 40;
+        P.extra_flag |= 2;
+        q_se[0] = q_se[0] < raw_mapq(c[0]->score - c[0]->csub, opt->a) ? q_se[0] : raw_mapq(c[0]->score - c[0]->csub, opt->a);
+        q_se[1] = q_se[1] < raw_mapq(c[1]->score - c[1]->csub, opt->a) ? q_se[1] : raw_mapq(c[1]->score - c[1]->csub, opt->a);
+    } else {
+        z[0] = z[1] = 0;
+        q_se[0] = approx_mapq_se(opt, so, &a[0][0]);
+        q_se[1] = approx_mapq_se(opt, so, &a[1][0]);
+    }
+    for (int i = 0; i < 2; ++i) {
+        const int k = a[i][z[i]].secondary_all;
+        if (k >= 0 && k < n_pri[i]) {                            // switch secondary and primary if both are non-ALT
+            for (size_t j = 0; j < a[i].size(); ++j)
+                if (a[i][j].secondary_all == k || (int)j == k) a[i][j].secondary_all = z[i];
+            a[i][z[i]].secondary_all = -1;
         }
     }
-    if (paired) return true;
+}
+
+bool pe_emit(const bm2_opt *opt, const bm2_sam_opt *so, const Ref &R, const PeStat pes[4], const ReadIO s[2],
+             const std::vector<bm2_alnreg_t> a[2], const PairPlan &P, std::string &out) {
+    const int *z = P.z, *n_pri = P.n_pri;
+    int extra_flag = P.extra_flag;
+    Aln h[2];
+    if (P.paired) {
+        std::vector<std::string> XA[2]; bool any_xa[2] = { false, false };
+        if (!(so->flag & F_ALL))
+            for (int i = 0; i < 2; ++i)
+                if (!gen_alt(opt, so, R, (int)a[i].size(), a[i].data(), s[i].l_seq, s[i].seq, XA[i], any_xa[i])) return false;
+        std::vector<Aln> aa[2];
+        for (int i = 0; i < 2; ++i) {
+            if (!reg2aln(opt, so, R, s[i].l_seq, s[i].seq, &a[i][z[i]], h[i])) return false;
+            h[i].mapq = P.q_se[i];
+            h[i].flag |= 0x40 << i | extra_flag;
+            h[i].XA = (any_xa[i] && !XA[i][z[i]].empty()) ? &XA[i][z[i]] : nullptr;
+            aa[i].push_back(h[i]);
+            if (n_pri[i] < (int)a[i].size()) {                   // the read has ALT hits
+                const bm2_alnreg_t *p = &a[i][n_pri[i]];
+                if (p->score < so->T || p->secondary >= 0 || !p->is_alt) continue;
+                Aln g;
+                if (!reg2aln(opt, so, R, s[i].l_seq, s[i].seq, p, g)) return false;
+                g.flag |= 0x800 | 0x40 << i | extra_flag;
+                g.XA = (any_xa[i] && !XA[i][n_pri[i]].empty()) ? &XA[i][n_pri[i]] : nullptr;
+                aa[i].push_back(g);
+            }
+        }
+        for (int i = 0; i < (int)aa[0].size(); ++i) aln2sam(so, R, out, s[0].name, s[0].comment, s[0].qual, s[0].l_seq, s[0].seq, aa[0], i, &h[1]);
+        for (int i = 0; i < (int)aa[1].size(); ++i) aln2sam(so, R, out, s[1].name, s[1].comment, s[1].qual, s[1].l_seq, s[1].seq, aa[1], i, &h[0]);
+        return true;
+    }
     // no_pairing:
     for (int i = 0; i < 2; ++i) {
         int which = -1;
@@ -1211,7 +1252,7 @@ CgStats g_cigar;                    // counters of the last bm2_sam_pe / bm2_sam
 
 // the hit numbers a dry pass recorded -> the batch (every hit once, in hit order) -> one call of the hook -> memo
 int cigar_session_batch(const bm2_opt *opt, const bm2_reads *reads, int64_t enc_bytes, const bm2_alnreg_t *alnregs, const int64_t *reg_off,
-                        std::vector<std::vector<int32_t>> &recs, bm2h_cigar_batch_fn cfn, void *cuser, CgMemo &M) {
+                        std::vector<std::vector<int32_t>> &recs, bm2h_cigar_batch_fn cfn, void *cuser, CgMemo &M, bool by_pad) {
     TailProf prof("cigar_session");
     const int n_reads = reads->n_reads;
     const int64_t n_hits = reg_off[n_reads];
@@ -1231,9 +1272,9 @@ int cigar_session_batch(const bm2_opt *opt, const bm2_reads *reads, int64_t enc_
             for (int lo; (lo = nx.fetch_add(16384)) < n_reads;)
                 for (int r = lo; r < n_reads && r < lo + 16384; ++r)
                     for (int64_t h = reg_off[r]; h < reg_off[r + 1]; ++h) {
-                        const int32_t t = M.task_of[(size_t)h];
+                        const bm2_alnreg_t &a = alnregs[h];          // (by_pad: the lists were reordered in place; a hit carries its number)
+                        const int32_t t = M.task_of[(size_t)(by_pad ? a.pad - 1 : h)];
                         if (t < 0) continue;
-                        const bm2_alnreg_t &a = alnregs[h];
                         bm2h_cg_hit &k = M.hits[(size_t)t];
                         k.rb = a.rb; k.re = a.re; k.read = r; k.qb = a.qb; k.qe = a.qe; k.truesc = a.truesc; k.w = a.w; k.pad = 0;
                     }
@@ -1255,44 +1296,45 @@ void flush_tallies() {
     t_cg_used = t_cg_missed = t_rs_used = t_rs_missed = 0;
 }
 
-// items [0, n) in blocks over n_threads host threads; f(i, part) appends the text of item i to its block's string; the blocks are
-// then copied -- in parallel, at their prefix-sum offsets -- straight into the caller's buffer.  *n_out = bytes needed; BM2_ECAP when
-// cap is smaller; a failing item makes the call return BM2_EINVAL with the item's number in `bad`.
+// items [0, n) in blocks of 256 over n_threads host threads; f(i, text) appends the text of item i.  A thread formats a block into its
+// own buffer (kept from call to call: it stays in the cache), learns where the block starts from the end of the block before it --
+// blocks are taken in order, so that one is finished or about to be -- publishes its own end at once and copies the block straight into
+// the caller's buffer: the chunk's text never exists a second time.  *n_out = bytes needed; BM2_ECAP when cap is smaller (what fitted
+// was written); a failing item makes the call return BM2_EINVAL with the item's number in `bad`.
 template <class F> int run_blocks(int n, int n_threads, char *out, int64_t cap, int64_t *n_out, int *bad, F f) {
     if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency();
     if (n_threads < 1) n_threads = 1;
     const int block = 256;
     const int n_blocks = (n + block - 1) / block;
     if (n_threads > n_blocks) n_threads = n_blocks > 0 ? n_blocks : 1;
-    std::vector<std::string> parts((size_t)n_blocks);
+    std::unique_ptr<std::atomic<int64_t>[]> end_of(new std::atomic<int64_t>[(size_t)n_blocks + 1]);
+    for (int b = 0; b <= n_blocks; ++b) end_of[(size_t)b].store(b == 0 ? 0 : -1, std::memory_order_relaxed);      // end_of[b] = where block b starts
     std::atomic<int> next(0), failed(-1);
     auto work = [&]() {
+        static thread_local std::string text;
         for (;;) {
             const int b = next.fetch_add(1);
-            if (b >= n_blocks || failed.load() >= 0) break;
-            const int hi = (b + 1) * block < n ? (b + 1) * block : n;
-            parts[(size_t)b].reserve((size_t)(hi - b * block) * 420);
-            bool ok = true;
-            for (int i = b * block; i < hi && ok; ++i)
-                if (!f(i, parts[(size_t)b])) { int e = -1; failed.compare_exchange_strong(e, i); ok = false; }
-            if (!ok) break;
+            if (b >= n_blocks) break;
+            text.clear();
+            if (failed.load(std::memory_order_relaxed) < 0) {
+                const int hi = (b + 1) * block < n ? (b + 1) * block : n;
+                for (int i = b * block; i < hi; ++i)
+                    if (!f(i, text)) { int e = -1; failed.compare_exchange_strong(e, i); break; }
+            }
+            int64_t at;
+            for (int spins = 0; (at = end_of[(size_t)b].load(std::memory_order_acquire)) < 0;) { if (++spins < 2000) __builtin_ia32_pause(); else std::this_thread::yield(); }
+            end_of[(size_t)b + 1].store(at + (int64_t)text.size(), std::memory_order_release);
+            if (out && at + (int64_t)text.size() <= cap && !text.empty()) memcpy(out + at, text.data(), text.size());
         }
         flush_tallies();
     };
     TailProf prof("run_blocks");
     run_threads(n_threads, work);
-    prof.mark("items");
+    prof.mark("items + copy");
     if (failed.load() >= 0) { *bad = failed.load(); *n_out = 0; return BM2_EINVAL; }
-    std::vector<int64_t> at((size_t)n_blocks + 1, 0);
-    for (int b = 0; b < n_blocks; ++b) at[(size_t)b + 1] = at[(size_t)b] + (int64_t)parts[(size_t)b].size();
-    *n_out = at[(size_t)n_blocks];
+    *n_out = n_blocks > 0 ? end_of[(size_t)n_blocks].load() : 0;
     if (*n_out > cap) return BM2_ECAP;
     if (!out) return *n_out ? BM2_EINVAL : BM2_OK;
-    next = 0;
-    run_threads(n_threads, [&]() {
-        for (int b; (b = next.fetch_add(1)) < n_blocks;)
-            if (!parts[(size_t)b].empty()) memcpy(out + at[(size_t)b], parts[(size_t)b].data(), parts[(size_t)b].size());
-    });
     return BM2_OK;
 }
 
@@ -1533,23 +1575,31 @@ int bm2h_sam_pe(const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt
             run_threads((long long)n_threads < (tot + step - 1) / step ? n_threads : (int)((tot + step - 1) / step), align);
         }
     }
-    auto one_pair = [&](int pi, std::vector<bm2_alnreg_t> *a2, std::string &part, RescueStats *st) {
+    auto io_of = [&](int pi, ReadIO io[2]) {
         const int i = pi << 1;
-        ReadIO io[2];
         for (int k = 0; k < 2; ++k) {
             io[k].name = txt->name[i + k]; io[k].comment = txt->comment ? txt->comment[i + k] : 0; io[k].qual = txt->qual ? txt->qual[i + k] : 0;
             io[k].l_seq = reads->len[i + k]; io[k].seq = reads->enc + reads->off[i + k];
         }
+    };
+    auto decide = [&](int pi, PairPlan &P) {
+        ReadIO io[2]; io_of(pi, io);
         const RescueTask *pre = batch ? tasks.data() + task_off[(size_t)pi] : nullptr;
         const int n_pre = batch ? (int)(task_off[(size_t)pi + 1] - task_off[(size_t)pi]) : 0;
-        return sam_pe(opt, so, R, idx->ann_len, pes, (uint64_t)((n_processed >> 1) + pi), io, a2, part, pre, n_pre, st);
+        pe_decide(opt, so, R, idx->ann_len, pes, (uint64_t)((n_processed >> 1) + pi), io, &regs[(size_t)2 * pi], pre, n_pre, batch ? &g_rescue : nullptr, P);
+    };
+    auto emit = [&](int pi, const PairPlan &P, std::string &part) {
+        ReadIO io[2]; io_of(pi, io);
+        return pe_emit(opt, so, R, pes, io, &regs[(size_t)2 * pi], P, part);
     };
     CgMemo memo;
     prof.mark("rescue results");
     g_cigar.planned = 0; g_cigar.used = 0; g_cigar.missed = 0;
-    if (cfn) {                                                   // CIGAR session: dry pass on copies of the hit lists, batch, then the real pass
+    std::vector<PairPlan> plans;
+    if (cfn) {                                                   // CIGAR session: decide every pair, note the hits its text will ask for, batch; then print
         int n_threads = so->n_threads > 0 ? so->n_threads : (int)std::thread::hardware_concurrency();
         if (n_threads < 1) n_threads = 1;
+        plans.resize((size_t)n_pairs);
         const int blk = 256, n_blk = (n_pairs + blk - 1) / blk;
         std::vector<std::vector<int32_t>> recs((size_t)n_blk);
         std::atomic<int> next(0), failed(-1);
@@ -1558,24 +1608,26 @@ int bm2h_sam_pe(const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt
             for (int b; (b = next.fetch_add(1)) < n_blk;) {
                 t_cg.mode = 1; t_cg.rec = &recs[(size_t)b];
                 for (int pi = b * blk; pi < n_pairs && pi < (b + 1) * blk; ++pi) {
-                    std::vector<bm2_alnreg_t> a2[2] = { regs[(size_t)2 * pi], regs[(size_t)2 * pi + 1] };
-                    if (!one_pair(pi, a2, sink, nullptr)) { int e = -1; failed.compare_exchange_strong(e, pi); }
+                    decide(pi, plans[(size_t)pi]);
+                    if (!emit(pi, plans[(size_t)pi], sink)) { int e = -1; failed.compare_exchange_strong(e, pi); }
                     sink.clear();
                 }
                 t_cg = CgSession();
             }
+            flush_tallies();
         });
-        prof.mark("dry pass");
+        prof.mark("decide + dry emit");
         int64_t enc_bytes = 0;
         for (int i = 0; i < n; ++i) if (reads->off[i] + reads->len[i] > enc_bytes) enc_bytes = reads->off[i] + reads->len[i];
-        const int rc = cigar_session_batch(opt, reads, enc_bytes, alnregs, reg_off, recs, cfn, cuser, memo);
+        const int rc = cigar_session_batch(opt, reads, enc_bytes, alnregs, reg_off, recs, cfn, cuser, memo, false);
         if (rc) return rc;
         prof.mark("cigar session");
     }
     int bad = -1;
     const int rc_out = run_blocks(n_pairs, so->n_threads, out, cap, n_out, &bad, [&](int pi, std::string &part) {
-        if (cfn) { t_cg.mode = 2; t_cg.memo = &memo; t_cg.st = &g_cigar; }
-        const bool r = one_pair(pi, &regs[(size_t)2 * pi], part, batch ? &g_rescue : nullptr);
+        if (!cfn) { PairPlan P; decide(pi, P); return emit(pi, P, part); }
+        t_cg.mode = 2; t_cg.memo = &memo; t_cg.st = &g_cigar;
+        const bool r = emit(pi, plans[(size_t)pi], part);
         t_cg = CgSession();
         return r;
     });
@@ -1601,29 +1653,32 @@ int bm2h_sam_se(const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt
     if (!idx->ref_string || !idx->ann_offset || !idx->ann_name) { bm2_set_error("bm2_sam_se: the index descriptor needs ref_string and contig names"); return BM2_EINVAL; }
     Ref R = { idx->l_pac, idx->ref_string, idx->n_seqs, idx->ann_offset, idx->ann_name, idx->ann_anno };
     const int n_reads = reads->n_reads;
-    auto one_read = [&](int i, bm2_alnreg_t *a, std::string &part) {
+    auto decide = [&](int i) {                                   // what changes the read's hit list (mem_reg2sam's caller, bwamem.cpp:1240-1243)
+        bm2_alnreg_t *a = alnregs + reg_off[i];
         const int n = (int)(reg_off[i + 1] - reg_off[i]);
         mark_primary_se(opt, n, a, n_processed + i);
         if (so->flag & F_PRIMARY5) reorder_primary5(so->T, n, a);
+    };
+    auto emit = [&](int i, std::string &part) {                  // reads the list only: a CIGAR session runs it twice
         return reg2sam(opt, so, R, part, txt->name[i], txt->comment ? txt->comment[i] : 0, txt->qual ? txt->qual[i] : 0, reads->len[i],
-                       reads->enc + reads->off[i], n, a, 0, 0);
+                       reads->enc + reads->off[i], (int)(reg_off[i + 1] - reg_off[i]), alnregs + reg_off[i], 0, 0);
     };
     CgMemo memo;
     g_cigar.planned = 0; g_cigar.used = 0; g_cigar.missed = 0;
     for (int64_t k = 0; k < reg_off[n_reads]; ++k) alnregs[k].pad = (int32_t)(k + 1);     // the hit's number (CIGAR batch); the lists are reordered in place
-    if (cfn) {                                                   // CIGAR session (see reg2aln): dry pass on copies, batch, real pass
+    if (cfn) {                                                   // CIGAR session (see reg2aln): decide, note the hits the text will ask for, batch; then print
         int n_threads = so->n_threads > 0 ? so->n_threads : (int)std::thread::hardware_concurrency();
         if (n_threads < 1) n_threads = 1;
         const int blk = 512, n_blk = (n_reads + blk - 1) / blk;
         std::vector<std::vector<int32_t>> recs((size_t)n_blk);
         std::atomic<int> next(0);
         run_threads(n_threads < n_blk ? n_threads : n_blk, [&]() {
-            std::string sink; std::vector<bm2_alnreg_t> tmp;
+            std::string sink;
             for (int b; (b = next.fetch_add(1)) < n_blk;) {
                 t_cg.mode = 1; t_cg.rec = &recs[(size_t)b];
                 for (int i = b * blk; i < n_reads && i < (b + 1) * blk; ++i) {
-                    tmp.assign(alnregs + reg_off[i], alnregs + reg_off[i + 1]);
-                    one_read(i, tmp.data(), sink);
+                    decide(i);
+                    emit(i, sink);
                     sink.clear();
                 }
                 t_cg = CgSession();
@@ -1631,13 +1686,14 @@ int bm2h_sam_se(const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt
         });
         int64_t enc_bytes = 0;
         for (int i = 0; i < n_reads; ++i) if (reads->off[i] + reads->len[i] > enc_bytes) enc_bytes = reads->off[i] + reads->len[i];
-        const int rc = cigar_session_batch(opt, reads, enc_bytes, alnregs, reg_off, recs, cfn, cuser, memo);
+        const int rc = cigar_session_batch(opt, reads, enc_bytes, alnregs, reg_off, recs, cfn, cuser, memo, true);
         if (rc) return rc;
     }
     int bad = -1;
     const int rc_out = run_blocks(n_reads, so->n_threads, out, cap, n_out, &bad, [&](int i, std::string &part) {
-        if (cfn) { t_cg.mode = 2; t_cg.memo = &memo; t_cg.st = &g_cigar; }
-        const bool r = one_read(i, alnregs + reg_off[i], part);
+        if (!cfn) { decide(i); return emit(i, part); }
+        t_cg.mode = 2; t_cg.memo = &memo; t_cg.st = &g_cigar;
+        const bool r = emit(i, part);
         t_cg = CgSession();
         return r;
     });
