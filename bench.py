@@ -250,7 +250,7 @@ def parity_gate(ctx, bm2, prefix, workdir, seqs, regs, reg_off, opt, opt_args, p
     return res
 
 
-def end_to_end(ctx, bm2, texts, opt, paired, n_threads, n_tail=2):
+def end_to_end(ctx, bm2, texts, opt, paired, n_threads, n_tail=2, limit_s=None):
     """FASTQ text -> SAM text over the chunks `texts` = [(bytes1, bytes2 | None)] as a pipeline of host threads, one stage each:
     the reader (bm2_fastq_parse_mt), the device stage (H2D, seeding .. extension, mem_sort_dedup_patch, D2H) and n_tail tail workers
     (pairing, rescue + CIGAR batches on the device through contexts that share the index replica, SAM text).  Chunks leave in order
@@ -258,7 +258,10 @@ def end_to_end(ctx, bm2, texts, opt, paired, n_threads, n_tail=2):
     n_tail = int(os.environ.get("BM2_E2E_TAILS", n_tail))
     tails = [bm2.Context(share=ctx) for _ in range(n_tail)]
     hw = os.cpu_count() or 1
-    so = bm2.default_sam_opt(n_threads=int(os.environ.get("BM2_E2E_TAIL_THREADS", n_threads or max(hw // n_tail, 1))))
+    # the library's host workers stay on their CPUs (host_pool.h): the stages' thread counts are chosen not to overlap -- the parser's,
+    # the tail workers', and a few CPUs left to the pipeline's own threads
+    n_parse = int(os.environ.get("BM2_E2E_PARSE_THREADS", max(1, min(hw // 8, 32))))
+    so = bm2.default_sam_opt(n_threads=int(os.environ.get("BM2_E2E_TAIL_THREADS", n_threads or max((hw - n_parse - min(8, hw // 4)) // n_tail, 1))))
     q_parsed, q_hits = queue.Queue(maxsize=2), queue.Queue(maxsize=2)
     stage, err, lock = {}, [], threading.Lock()
     done = [0] * len(texts)
@@ -270,7 +273,7 @@ def end_to_end(ctx, bm2, texts, opt, paired, n_threads, n_tail=2):
     def reader():
         try:
             for i, (t1, t2) in enumerate(texts):
-                t = time.perf_counter(); ch = bm2.FastqChunk(t1, t2, min(hw, 48)); add("parse", time.perf_counter() - t)    # a memory-bound scan: a few dozen threads saturate it
+                t = time.perf_counter(); ch = bm2.FastqChunk(t1, t2, n_parse); add("parse", time.perf_counter() - t)    # a memory-bound scan: a few dozen threads saturate it
                 q_parsed.put((i, ch))
         except Exception as e:                                    # noqa
             err.append(e)
@@ -313,12 +316,15 @@ def end_to_end(ctx, bm2, texts, opt, paired, n_threads, n_tail=2):
         except Exception as e:                                    # noqa
             err.append(e)
 
-    th = [threading.Thread(target=reader), threading.Thread(target=device)] + [threading.Thread(target=tail, args=(k,)) for k in range(n_tail)]
+    th = [threading.Thread(target=reader, daemon=True), threading.Thread(target=device, daemon=True)] + \
+         [threading.Thread(target=tail, args=(k,), daemon=True) for k in range(n_tail)]
     t0 = time.perf_counter()
     for t in th:
         t.start()
     for t in th:
-        t.join()
+        t.join(max(0.0, limit_s - (time.perf_counter() - t0)) if limit_s else None)
+        if t.is_alive():
+            raise TimeoutError("end-to-end leg not finished after %.0f s (stages so far: %s)" % (limit_s, {k: round(v, 1) for k, v in stage.items()}))
     dt = time.perf_counter() - t0
     for c in tails:
         c.close()
@@ -327,7 +333,7 @@ def end_to_end(ctx, bm2, texts, opt, paired, n_threads, n_tail=2):
     out_bytes = sum(d[0] for d in done); n_reads = sum(d[1] for d in done)
     nch = max(len(texts), 1)
     return {"value": n_reads / dt, "unit": "reads/s", "reads": n_reads, "chunks": len(texts), "wall_s": dt, "sam_bytes": out_bytes,
-            "host_threads": hw, "tail_workers": n_tail, "threads_per_tail_worker": so.n_threads,
+            "host_threads": hw, "parse_threads": n_parse, "tail_workers": n_tail, "threads_per_tail_worker": so.n_threads,
             "stage_ms_per_chunk": {k: v / nch * 1e3 for k, v in stage.items()},
             "scope": "FASTQ text in host memory -> bm2_fastq_parse_mt | H2D -> device pipeline incl. mem_sort_dedup_patch (a19) -> D2H | pairing / "
                      "mate rescue / CIGAR (device batches) / SAM text in host memory; one host thread per stage (two tail workers), stages of "
@@ -354,7 +360,15 @@ def main():
     ap.add_argument("--strong", action="store_true",
                     help="strong scaling: ONE chunk of --reads reads is cut at multiples of 512 over the ranks (SURVEY.md 8(e)) instead of one chunk per rank")
     ap.add_argument("--workdir", default=os.environ.get("BM2_BENCH_WORKDIR", "/tmp/bm2_bench"))
+    ap.add_argument("--budget-s", type=float, default=float(os.environ.get("BM2_BENCH_BUDGET_S", 1500)),
+                    help="wall-clock budget of the whole run: an optional leg (parity gate, CPU baseline, end-to-end) that could not finish inside it is "
+                         "skipped and says so in the JSON line; the end-to-end leg also runs under a watchdog")
     a = ap.parse_args()
+    t_start = time.time()
+    hung = False
+
+    def time_left():
+        return a.budget_s - (time.time() - t_start)
 
     from tools import dist_util, synth
     rank, world, local = dist_util.env_rank()
@@ -499,7 +513,9 @@ def main():
                               "lds_conflict_frac": ext_pmc.get("lds_conflict_frac") if ext_pmc else None,
                               "pmc_source": "profiles/r02_ext_pmc_sq.json" if ext_pmc else None},
         }
-        if world == 1 and not a.no_parity:
+        if world == 1 and not a.no_parity and time_left() < 150:
+            out["parity"] = {"skipped": "time budget (%.0f s of %.0f s left)" % (time_left(), a.budget_s)}
+        elif world == 1 and not a.no_parity:
             regs, reg_off = ctx.batch_download()
             n_s = min(a.parity_reads, n_reads) if not ont else min(a.parity_reads, 256, n_reads)
             if not ont:
@@ -509,7 +525,9 @@ def main():
                 rc = 3
         else:
             out["parity"] = None
-        if world == 1 and not a.no_cpu_baseline:             # the reference on this host's cores: at N=1 only (the other ranks would idle)
+        if world == 1 and not a.no_cpu_baseline and time_left() < 120:
+            out["cpu_baseline"] = {"skipped": "time budget (%.0f s of %.0f s left)" % (time_left(), a.budget_s)}
+        elif world == 1 and not a.no_cpu_baseline:           # the reference on this host's cores: at N=1 only (the other ranks would idle)
             t = time.time()
             if ont:
                 nb = min(len(seqs), 300)
@@ -525,7 +543,9 @@ def main():
             out["cpu_baseline"] = cb
         else:
             out["cpu_baseline"] = None
-        if world == 1 and not a.no_e2e and not ont:
+        if world == 1 and not a.no_e2e and not ont and time_left() < 180:
+            out["end_to_end"] = {"skipped": "time budget (%.0f s of %.0f s left)" % (time_left(), a.budget_s)}
+        elif world == 1 and not a.no_e2e and not ont:
             t = time.time()
             texts = []                                       # distinct chunks of the same shape as the timed one, generated side by side
             meta = prefix + ".contigs.npz"
@@ -541,14 +561,19 @@ def main():
                 os.remove(fa); os.remove(fb)
             log("end-to-end input: %d chunks generated in %.1fs" % (len(texts), time.time() - t))
             try:
-                end_to_end(ctx, bm2, texts[:1], opt, True, 0)                       # warm-up (workspaces, thread pools)
-                out["end_to_end"] = end_to_end(ctx, bm2, texts, opt, True, 0)
+                end_to_end(ctx, bm2, texts[:1], opt, True, 0, limit_s=max(30.0, min(120.0, time_left() - 90)))      # warm-up (workspaces, thread pools)
+                out["end_to_end"] = end_to_end(ctx, bm2, texts, opt, True, 0, limit_s=max(30.0, min(300.0, time_left() - 30)))
                 out["end_to_end"]["frac_of_hot_path"] = out["end_to_end"]["value"] / value
+            except TimeoutError as e:                                                 # a stage is stuck: report, then leave without joining it
+                out["end_to_end"] = {"error": str(e)}
+                hung = True
             except Exception as e:                                                    # noqa
                 out["end_to_end"] = {"error": str(e)}
         else:
             out["end_to_end"] = None
         print(json.dumps(out), flush=True)
+    if hung:
+        os._exit(rc or 4)
     ctx.close()
     dist_util.finish(world)
     if rc:

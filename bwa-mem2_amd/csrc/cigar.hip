@@ -14,6 +14,7 @@
 #include "../../include/bm2.h"
 #include "bm2_ctx.h"
 #include "host_tail.h"
+#include "host_pool.h"
 #include "pipeline.h"
 
 #define CG_MINUS_INF (-0x40000000)
@@ -245,28 +246,47 @@ static int cigar_run(bm2_ctx *c, const bm2_opt *opt, std::vector<CigarTask> &tas
     CigarPrm prm; memset(&prm, 0, sizeof prm);
     for (int a = 0; a < 25; ++a) prm.mat[a] = opt->mat[a];
     prm.o_del = opt->o_del; prm.e_del = opt->e_del; prm.o_ins = opt->o_ins; prm.e_ins = opt->e_ins; prm.a = opt->a; prm.w = opt->w; prm.l_pac = c->ix.l_pac;
-    // slices of the scratch buffers (sized for the widest band a task can come to) and the cost class of every task
-    std::vector<int> order((size_t)n);
-    std::vector<int64_t> cost((size_t)n);
-    int64_t zo = 0, eo = 0, co = 0, mo = 0;
-    for (int i = 0; i < n; ++i) {
-        CigarTask &T = tasks[(size_t)i];
-        T.z_off = zo; T.eh_off = eo; T.cg_off = co; T.md_off = mo;
-        cost[(size_t)i] = 0;
-        if (!cigar_range_ok(prm.l_pac, T.q_len, T.rb, T.re)) continue;
+    // slices of the scratch buffers (sized for the widest band a task can come to) and the cost class of every task: sizes per piece
+    // of the task list on the host's worker threads, offsets by a scan over the pieces, then the tasks' slices
+    static thread_local std::vector<int> order_tl; static thread_local std::vector<int64_t> cost_tl;
+    std::vector<int> &order = order_tl; std::vector<int64_t> &cost = cost_tl;
+    if (order.size() < (size_t)n) { order.resize((size_t)n); cost.resize((size_t)n); }
+    const int host_threads = bm2_host_threads();
+    const int64_t grain = 16384, pieces = ((int64_t)n + grain - 1) / grain;
+    struct Sz { int64_t z, e, c, m; };
+    std::vector<Sz> at((size_t)pieces + 1, Sz{ 0, 0, 0, 0 });
+    std::atomic<int> too_long(0);
+    auto sizes = [&](const CigarTask &T, Sz &s) {               // what the task takes of the four buffers; s.z = its DP area = its cost
+        s = Sz{ 0, 0, 0, 0 };
+        if (!cigar_range_ok(prm.l_pac, T.q_len, T.rb, T.re)) return;
         const int64_t rlen = T.re - T.rb;
-        if (rlen > 0x3fffffff) { bm2_set_error("bm2_gen_cigar_dev: reference range too long"); return BM2_EINVAL; }
+        if (rlen > 0x3fffffff) { too_long = 1; return; }
         const int w_first = T.retry ? cigar_first_band(T.q_len, (int)rlen, T.truesc, T.w, prm.a, prm.w, prm.o_del, prm.e_del, prm.o_ins, prm.e_ins) : T.w;
         if (!(T.q_len == rlen && w_first == 0)) {               // (a retried task never starts from band 0: the first score ends its loop)
             const int w_cap = T.retry ? (w_first < prm.w << 2 ? prm.w << 2 : w_first) : T.w;
             const int wb = cigar_band(T.q_len, (int)rlen, w_cap, prm.mat[0], prm.o_del, prm.e_del, prm.o_ins, prm.e_ins);
-            const int n_col = ((T.q_len < 2 * wb + 1 ? T.q_len : 2 * wb + 1) + 3) & ~3;
-            zo = (zo + 3) & ~(int64_t)3; T.z_off = zo;
-            zo += (int64_t)n_col * rlen; eo += T.q_len + 1;
-            cost[(size_t)i] = (int64_t)n_col * rlen;
+            const int n_col = ((T.q_len < 2 * wb + 1 ? T.q_len : 2 * wb + 1) + 3) & ~3;      // a multiple of 4: every z slice starts 4-aligned
+            s.z = (int64_t)n_col * rlen; s.e = T.q_len + 1;
         }
-        co += T.q_len + rlen + 2; mo += 2 * (T.q_len + rlen) + 16;
-    }
+        s.c = T.q_len + rlen + 2; s.m = 2 * (T.q_len + rlen) + 16;
+    };
+    bm2_parallel_ranges(n, grain, host_threads, [&](int64_t lo, int64_t hi) {
+        Sz sum{ 0, 0, 0, 0 }, s;
+        for (int64_t i = lo; i < hi; ++i) { sizes(tasks[(size_t)i], s); cost[(size_t)i] = s.z; sum.z += s.z; sum.e += s.e; sum.c += s.c; sum.m += s.m; }
+        at[(size_t)(lo / grain) + 1] = sum;
+    });
+    if (too_long.load()) { bm2_set_error("bm2_gen_cigar_dev: reference range too long"); return BM2_EINVAL; }
+    for (int64_t p = 0; p < pieces; ++p) { Sz &x = at[(size_t)p + 1]; const Sz &y = at[(size_t)p]; x.z += y.z; x.e += y.e; x.c += y.c; x.m += y.m; }
+    const int64_t zo = at[(size_t)pieces].z, eo = at[(size_t)pieces].e, co = at[(size_t)pieces].c, mo = at[(size_t)pieces].m;
+    bm2_parallel_ranges(n, grain, host_threads, [&](int64_t lo, int64_t hi) {
+        Sz o = at[(size_t)(lo / grain)], s;
+        for (int64_t i = lo; i < hi; ++i) {
+            CigarTask &T = tasks[(size_t)i];
+            T.z_off = o.z; T.eh_off = o.e; T.cg_off = o.c; T.md_off = o.m;
+            sizes(T, s);
+            o.z += s.z; o.e += s.e; o.c += s.c; o.m += s.m;
+        }
+    });
     prof.mark("slices");
     int n_small = 0, qmax = 0;
     {   // lanes of a wavefront run their tasks side by side: neighbours should cost alike.  Counting sort by (small-score class first,
@@ -276,12 +296,16 @@ static int cigar_run(bm2_ctx *c, const bm2_opt *opt, std::vector<CigarTask> &tas
         pen = std::max(pen, std::max(opt->o_del + opt->e_del, opt->o_ins + opt->e_ins));
         static const int no_lds = getenv("BM2_CIGAR_NO_LDS") ? atoi(getenv("BM2_CIGAR_NO_LDS")) : 0;
         auto small = [&](int i) { const CigarTask &T = tasks[(size_t)i]; return !no_lds && T.q_len <= 220 && (int64_t)(T.q_len + (T.re - T.rb)) * pen < CG_SMALL; };
-        auto cls = [&](int i) { int64_t v = cost[(size_t)i]; int k = 0; while (v > 0) { v >>= 1; ++k; } return (small(i) ? 0 : 64) + 63 - k; };
-        int64_t cnt[129] = { 0 };
-        for (int i = 0; i < n; ++i) cnt[cls(i) + 1]++;
-        for (int k = 0; k < 128; ++k) cnt[k + 1] += cnt[k];
-        n_small = (int)cnt[64];
-        for (int i = 0; i < n; ++i) { order[(size_t)cnt[cls(i)]++] = i; if (small(i)) qmax = std::max(qmax, tasks[(size_t)i].q_len); }
+        auto cls = [&](int i) { const int64_t v = cost[(size_t)i]; const int k = v > 0 ? 64 - __builtin_clzll((unsigned long long)v) : 0; return (small(i) ? 0 : 64) + 63 - k; };
+        bm2_counting_order(n, 128, host_threads, cls, order.data());
+        std::atomic<int> ns(0), qm(0);
+        bm2_parallel_ranges(n, grain, host_threads, [&](int64_t lo, int64_t hi) {
+            int c = 0, q = 0;
+            for (int64_t i = lo; i < hi; ++i) if (small((int)i)) { ++c; q = std::max(q, tasks[(size_t)i].q_len); }
+            ns += c;
+            for (int cur = qm.load(); q > cur && !qm.compare_exchange_weak(cur, q);) {}
+        });
+        n_small = ns.load(); qmax = qm.load();
     }
     prof.mark("order");
     DevBuf &b_seq = c->b_ref, &b_task = c->b_qer, &b_res = c->b_pairs, &b_scr = c->b_misc;
@@ -379,17 +403,25 @@ extern "C" int bm2_gen_cigar_dev(bm2_ctx *c, const bm2_opt *opt, int32_t n, cons
 // of mem_reg2aln run by the kernel, results compacted on the device.
 int bm2_dev_cigar_batch(void *user, const bm2_opt *opt, const bm2_reads *reads, int64_t enc_bytes, int32_t n, const bm2h_cg_hit *hits, bm2h_cg_out *out) {
     bm2_ctx *c = (bm2_ctx *)user;
-    std::vector<CigarTask> tasks((size_t)n);
-    for (int i = 0; i < n; ++i) {
-        CigarTask &T = tasks[(size_t)i]; memset(&T, 0, sizeof T);
-        const bm2h_cg_hit &h = hits[i];
-        T.q_off = reads->off[h.read] + h.qb; T.q_len = h.qe - h.qb; T.rb = h.rb; T.re = h.re; T.w = h.w; T.truesc = h.truesc; T.retry = 1;
-    }
-    std::vector<CigarRes> res;
+    static thread_local std::vector<CigarTask> tasks_tl;
+    std::vector<CigarTask> &tasks = tasks_tl;
+    tasks.resize((size_t)n);                                     // (cigar_run takes the list's size as the task count)
+    const int host_threads = bm2_host_threads();
+    bm2_parallel_ranges(n, 16384, host_threads, [&](int64_t lo, int64_t hi) {
+        for (int64_t i = lo; i < hi; ++i) {
+            CigarTask &T = tasks[(size_t)i]; memset(&T, 0, sizeof T);
+            const bm2h_cg_hit &h = hits[i];
+            T.q_off = reads->off[h.read] + h.qb; T.q_len = h.qe - h.qb; T.rb = h.rb; T.re = h.re; T.w = h.w; T.truesc = h.truesc; T.retry = 1;
+        }
+    });
+    static thread_local std::vector<CigarRes> res_tl;
+    std::vector<CigarRes> &res = res_tl;
     const int rc = cigar_run(c, opt, tasks, reads->enc, enc_bytes, res, out->cigar_off, out->md_off, out->cigar, out->md);
     if (rc) return rc;
     out->score.resize((size_t)n); out->nm.resize((size_t)n); out->n_cigar.resize((size_t)n);
-    for (int i = 0; i < n; ++i) { out->score[(size_t)i] = res[(size_t)i].score; out->nm[(size_t)i] = res[(size_t)i].nm; out->n_cigar[(size_t)i] = res[(size_t)i].n_cigar; }
+    bm2_parallel_ranges(n, 16384, host_threads, [&](int64_t lo, int64_t hi) {
+        for (int64_t i = lo; i < hi; ++i) { out->score[(size_t)i] = res[(size_t)i].score; out->nm[(size_t)i] = res[(size_t)i].nm; out->n_cigar[(size_t)i] = res[(size_t)i].n_cigar; }
+    });
     return BM2_OK;
 }
 

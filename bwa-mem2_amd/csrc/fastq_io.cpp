@@ -9,6 +9,7 @@
 #include <string.h>
 #include <string>
 #include <thread>
+#include "host_pool.h"
 #include <vector>
 #include "../../include/bm2.h"
 
@@ -182,12 +183,13 @@ bool scan_file(const char *text, int64_t n, int n_threads, std::vector<std::vect
     for (int i = 1; i <= P; ++i) if (cut[(size_t)i] < cut[(size_t)i - 1]) cut[(size_t)i] = cut[(size_t)i - 1];
     parts.assign((size_t)P, {});
     std::vector<char> ok((size_t)P, 1);
-    std::vector<std::thread> th;
-    for (int i = 0; i < P; ++i) th.emplace_back([&, i]() {
-        parts[(size_t)i].reserve((size_t)((cut[(size_t)i + 1] - cut[(size_t)i]) / 200 + 16));
-        ok[(size_t)i] = scan_range(cut[(size_t)i], cut[(size_t)i + 1], parts[(size_t)i]);
+    std::atomic<int> nx(0);
+    bm2_run_threads(P, [&]() {
+        for (int i; (i = nx.fetch_add(1)) < P;) {
+            parts[(size_t)i].reserve((size_t)((cut[(size_t)i + 1] - cut[(size_t)i]) / 200 + 16));
+            ok[(size_t)i] = scan_range(cut[(size_t)i], cut[(size_t)i + 1], parts[(size_t)i]);
+        }
     });
-    for (auto &t : th) t.join();
     for (char c : ok) if (!c) return false;
     return true;
 }
@@ -239,8 +241,9 @@ extern "C" int bm2_fastq_parse_mt(const char *text1, int64_t n1, const char *tex
     static uint8_t nt4[256]; static bool nt4_ready = false;
     if (!nt4_ready) { for (int i = 0; i < 256; ++i) nt4[i] = 4; nt4[(int)'A'] = nt4[(int)'a'] = 0; nt4[(int)'C'] = nt4[(int)'c'] = 1; nt4[(int)'G'] = nt4[(int)'g'] = 2; nt4[(int)'T'] = nt4[(int)'t'] = 3; nt4_ready = true; }
     int T = n_threads; if ((int64_t)T > n / 4096 + 1) T = (int)(n / 4096 + 1);
-    std::vector<std::thread> th;
-    for (int t = 0; t < T; ++t) th.emplace_back([&, t]() {
+    std::atomic<int> nx(0);
+    bm2_run_threads(T, [&]() {
+      for (int t; (t = nx.fetch_add(1)) < T;) {
         const int64_t lo = n * t / T, hi = n * (t + 1) / T;
         size_t qa = 0, qb = 0;
         for (int64_t i = lo; i < hi; ++i) {
@@ -252,8 +255,8 @@ extern "C" int bm2_fastq_parse_mt(const char *text1, int64_t n1, const char *tex
             if (s.comment_len) { out->comment[i] = a; memcpy(a, s.comment, (size_t)s.comment_len); a[s.comment_len] = 0; a += s.comment_len + 1; }
             out->qual[i] = a; memcpy(a, s.qual, (size_t)s.len); a[s.len] = 0;
         }
+      }
     });
-    for (auto &t : th) t.join();
     return BM2_OK;
 }
 

@@ -1,0 +1,141 @@
+// host_pool.h -- the host side's worker threads (sam_tail.cpp, fastq_io.cpp): bm2_run_threads(n, f) runs n copies of f.
+#pragma once
+#include <limits.h>
+#include <linux/futex.h>
+#include <pthread.h>
+#include <sched.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <sys/syscall.h>
+#include <unistd.h>
+#include <atomic>
+#include <functional>
+#include <thread>
+#include <vector>
+
+// Worker threads for the host side's short parallel phases (SAM tail, FASTQ parser).  A chunk goes through a dozen short phases, so what counts is how fast ALL workers get
+// going: a queue behind one mutex hands the lock from one woken thread to the next (each hand-over costs a scheduler wake-up: milliseconds
+// for a few hundred threads), and spawning threads per phase cost more than the phases themselves.  Here every calling thread (a tail
+// worker of the pipeline) owns its workers; a phase is published by bumping a generation word and waking every sleeper with ONE futex
+// call; a worker that finished spins briefly before it sleeps, so back-to-back phases find the workers awake; completion is a counter
+// the caller spins / sleeps on.  No lock anywhere.  run(n, f) runs n copies of f (the caller is one of them) and returns when all are through.
+class TailPool {
+    std::vector<std::thread> workers;
+    std::function<void()> *job = nullptr;
+    alignas(64) std::atomic<uint32_t> gen{0};                   // futex word: phase number << 12 | workers taking part in it
+    alignas(64) std::atomic<uint32_t> left{0};                  // futex word: participants still inside f
+    std::atomic<bool> stop{false};
+    static void pause() {
+#if defined(__x86_64__) || defined(__i386__)
+        __builtin_ia32_pause();
+#endif
+    }
+    static void futex_wait(std::atomic<uint32_t> *w, uint32_t seen) { syscall(SYS_futex, (uint32_t *)w, FUTEX_WAIT_PRIVATE, seen, nullptr, nullptr, 0); }
+    static void futex_wake_all(std::atomic<uint32_t> *w) { syscall(SYS_futex, (uint32_t *)w, FUTEX_WAKE_PRIVATE, INT_MAX, nullptr, nullptr, 0); }
+    // A worker stays on one CPU of the process's affinity mask, handed out round-robin over all pools: a freshly woken thread then
+    // starts where it slept instead of queueing on the waker's CPU until the load balancer gets to it (milliseconds on virtualised
+    // hosts; a phase lasts a few).  BM2_TAIL_PIN=0 leaves the placement to the scheduler.
+    static void pin_self() {
+        static const bool on = []() { const char *e = getenv("BM2_TAIL_PIN"); return !(e && e[0] == '0'); }();
+        if (!on) return;
+        static std::atomic<unsigned> next_cpu{1};
+        cpu_set_t all;
+        if (sched_getaffinity(0, sizeof all, &all) != 0) return;
+        const int n = CPU_COUNT(&all);
+        if (n < 2) return;
+        int k = (int)(next_cpu.fetch_add(1) % (unsigned)n);
+        for (int c = 0; c < CPU_SETSIZE; ++c)
+            if (CPU_ISSET(c, &all) && k-- == 0) { cpu_set_t one; CPU_ZERO(&one); CPU_SET(c, &one); pthread_setaffinity_np(pthread_self(), sizeof one, &one); return; }
+    }
+    // The generation word carries the phase's participant count in its low bits: a worker decides from ONE load whether the phase it
+    // saw is its business (a separate `want` could already belong to the next phase by the time a slow non-participant reads it).
+    enum { WANT_BITS = 12, WANT_MASK = (1 << WANT_BITS) - 1 };
+    void loop(int idx, uint32_t seen) {
+        pin_self();
+        for (;;) {
+            uint32_t g;
+            for (int spins = 0; (g = gen.load(std::memory_order_acquire)) == seen;) { if (++spins < 4000) pause(); else futex_wait(&gen, seen); }
+            seen = g;
+            if (stop.load(std::memory_order_acquire)) return;
+            if (idx < (int)(g & WANT_MASK)) {
+                (*job)();
+                if (left.fetch_sub(1, std::memory_order_acq_rel) == 1) futex_wake_all(&left);
+            }
+        }
+    }
+public:
+    TailPool() {}
+    ~TailPool() {
+        stop.store(true, std::memory_order_release);
+        gen.store((((gen.load(std::memory_order_relaxed) >> WANT_BITS) + 1) << WANT_BITS), std::memory_order_release);
+        futex_wake_all(&gen);
+        for (auto &t : workers) t.join();
+    }
+    void run(int n, std::function<void()> f) {
+        if (n <= 1) { f(); return; }
+        if (n - 1 > WANT_MASK) n = WANT_MASK + 1;
+        while ((int)workers.size() < n - 1) {                     // (a worker starts out having "seen" the current generation)
+            const int idx = (int)workers.size(); const uint32_t g = gen.load(std::memory_order_relaxed);
+            workers.emplace_back([this, idx, g]() { loop(idx, g); });
+        }
+        job = &f;
+        left.store((uint32_t)(n - 1), std::memory_order_relaxed);
+        gen.store((((gen.load(std::memory_order_relaxed) >> WANT_BITS) + 1) << WANT_BITS) | (uint32_t)(n - 1), std::memory_order_release);
+        futex_wake_all(&gen);
+        f();                                                      // the caller takes part
+        uint32_t l;
+        for (int spins = 0; (l = left.load(std::memory_order_acquire)) != 0;) { if (++spins < 4000) pause(); else futex_wait(&left, l); }
+    }
+};
+// How many host threads the call in progress on THIS thread may use (bm2_sam_pe / bm2_sam_se set it from bm2_sam_opt::n_threads for
+// the batch hooks they call, which have no such argument); 0 = all hardware threads.
+inline int &bm2_host_thread_budget() { static thread_local int v = 0; return v; }
+inline int bm2_host_threads() {
+    const int b = bm2_host_thread_budget();
+    if (b > 0) return b;
+    const int h = (int)std::thread::hardware_concurrency();
+    return h > 0 ? h : 1;
+}
+
+inline void bm2_run_threads(int n_threads, std::function<void()> f) {
+    if (n_threads <= 1) { f(); return; }
+    static thread_local TailPool pool;                            // one set of workers per calling thread
+    pool.run(n_threads, std::move(f));
+}
+
+// order[0, n) = the items 0 .. n-1 by ascending key(i) in [0, n_keys), items of one key in index order (a counting sort on up to
+// n_threads threads over static ranges, so the result does not depend on the thread count)
+template <class K> void bm2_counting_order(int n, int n_keys, int n_threads, K key, int *order) {
+    if (n <= 0) return;
+    int T = n_threads < 1 ? 1 : n_threads;
+    if (T > n / 16384 + 1) T = n / 16384 + 1;
+    if ((int64_t)T * n_keys > (1 << 22)) T = (1 << 22) / n_keys > 1 ? (1 << 22) / n_keys : 1;
+    std::vector<uint32_t> keys((size_t)n), cnt((size_t)T * (size_t)n_keys, 0);
+    std::atomic<int> nx(0);
+    bm2_run_threads(T, [&]() {
+        for (int t; (t = nx.fetch_add(1)) < T;) {
+            uint32_t *c = cnt.data() + (size_t)t * (size_t)n_keys;
+            for (int64_t i = (int64_t)n * t / T, hi = (int64_t)n * (t + 1) / T; i < hi; ++i) { const uint32_t k = (uint32_t)key((int)i); keys[(size_t)i] = k; ++c[k]; }
+        }
+    });
+    uint32_t pos = 0;
+    for (int k = 0; k < n_keys; ++k)
+        for (int t = 0; t < T; ++t) { uint32_t &c = cnt[(size_t)t * (size_t)n_keys + (size_t)k]; const uint32_t v = c; c = pos; pos += v; }
+    nx = 0;
+    bm2_run_threads(T, [&]() {
+        for (int t; (t = nx.fetch_add(1)) < T;) {
+            uint32_t *c = cnt.data() + (size_t)t * (size_t)n_keys;
+            for (int64_t i = (int64_t)n * t / T, hi = (int64_t)n * (t + 1) / T; i < hi; ++i) order[c[keys[(size_t)i]]++] = (int)i;
+        }
+    });
+}
+
+// f(lo, hi) over [0, n) in pieces of `grain` items on up to n_threads threads
+template <class F> void bm2_parallel_ranges(int64_t n, int64_t grain, int n_threads, F f) {
+    if (n <= 0) return;
+    const int64_t pieces = (n + grain - 1) / grain;
+    int T = n_threads < 1 ? 1 : n_threads;
+    if ((int64_t)T > pieces) T = (int)pieces;
+    std::atomic<int64_t> nx(0);
+    bm2_run_threads(T, [&]() { for (int64_t p; (p = nx.fetch_add(1)) < pieces;) f(p * grain, (p + 1) * grain < n ? (p + 1) * grain : n); });
+}

@@ -14,6 +14,7 @@
 #include "../../include/bm2.h"
 #include "bm2_ctx.h"
 #include "matesw_dev.h"
+#include "host_pool.h"
 
 __global__ void __launch_bounds__(256)
 k_ksw_align2(const uint8_t *__restrict__ qbase, const uint8_t *__restrict__ tbase, const KswTask *__restrict__ tasks, const int *__restrict__ order, int n, KswPrm prm,
@@ -47,32 +48,47 @@ static int ksw_batch_run(bm2_ctx *c, int32_t n, const uint8_t *qbuf, int64_t qbu
     prm.o_del = o_del; prm.e_del = e_del; prm.o_ins = o_ins; prm.e_ins = e_ins;
     prm.shift = (256 - (lo & 0xff)) & 0xff; prm.maxsc = hi;
     if (hi <= 0) { bm2_set_error("ksw batch: the scoring matrix has no positive entry"); return BM2_EINVAL; }
-    std::vector<KswTask> tasks((size_t)n);
-    std::vector<int> order((size_t)n);
-    int64_t nb = 0;
-    int slen_max = 1;
-    for (int i = 0; i < n; ++i) {
-        if (q_len[i] < 0 || t_len[i] < 0) { bm2_set_error("ksw batch: negative length"); return BM2_EINVAL; }
-        KswTask &T = tasks[(size_t)i];
-        T.q_off = q_off[i]; T.t_off = t_off[i]; T.qlen = q_len[i]; T.tlen = t_len[i]; T.xtra = xtra[i]; T.pad = 0;
-        T.b_off = nb; nb += (t_len[i] + 1) / 2 + 1;
-        const int P = (xtra[i] & KSW_XBYTE) ? 16 : 8;
-        slen_max = std::max(slen_max, (q_len[i] + P - 1) / P);
-    }
+    // (host-side staging kept per calling thread from batch to batch; every loop over the tasks runs on the host's worker threads)
+    static thread_local std::vector<KswTask> tasks_tl; static thread_local std::vector<int> order_tl; static thread_local std::vector<int64_t> nb_tl;
+    std::vector<KswTask> &tasks = tasks_tl; std::vector<int> &order = order_tl; std::vector<int64_t> &nb_of = nb_tl;
+    if (tasks.size() < (size_t)n) { tasks.resize((size_t)n); order.resize((size_t)n); }
+    const int host_threads = bm2_host_threads();
+    const int64_t grain = 16384, pieces = ((int64_t)n + grain - 1) / grain;
+    nb_of.assign((size_t)pieces + 1, 0);
+    std::atomic<int> bad(0), slen_all(1);
+    bm2_parallel_ranges(n, grain, host_threads, [&](int64_t lo, int64_t hi) {
+        int64_t nbp = 0; int sl = 1;
+        for (int64_t i = lo; i < hi; ++i) {
+            if (q_len[i] < 0 || t_len[i] < 0) { bad = 1; continue; }
+            nbp += (t_len[i] + 1) / 2 + 1;
+            const int P = (xtra[i] & KSW_XBYTE) ? 16 : 8;
+            sl = std::max(sl, (q_len[i] + P - 1) / P);
+        }
+        nb_of[(size_t)(lo / grain) + 1] = nbp;
+        for (int cur = slen_all.load(); sl > cur && !slen_all.compare_exchange_weak(cur, sl);) {}
+    });
+    if (bad.load()) { bm2_set_error("ksw batch: negative length"); return BM2_EINVAL; }
+    for (int64_t p = 0; p < pieces; ++p) nb_of[(size_t)p + 1] += nb_of[(size_t)p];
+    const int64_t nb = nb_of[(size_t)pieces];
+    const int slen_max = slen_all.load();
+    bm2_parallel_ranges(n, grain, host_threads, [&](int64_t lo, int64_t hi) {
+        int64_t at = nb_of[(size_t)(lo / grain)];
+        for (int64_t i = lo; i < hi; ++i) {
+            KswTask &T = tasks[(size_t)i];
+            T.q_off = q_off[i]; T.t_off = t_off[i]; T.qlen = q_len[i]; T.tlen = t_len[i]; T.xtra = xtra[i]; T.pad = 0;
+            T.b_off = at; at += (t_len[i] + 1) / 2 + 1;
+        }
+    });
     // rows of a wavefront diverge: neighbours should be alike (same lane width, same segment count, similar target length): a
     // counting sort on (lane width, segments, target length / 8), largest first (which of two equal tasks comes first changes nothing)
     {
-        auto key = [&](int i) {
+        const int NB = 128 * 512;
+        bm2_counting_order(n, NB, host_threads, [&](int i) {
             const KswTask &T = tasks[(size_t)i];
             const int P = (T.xtra & KSW_XBYTE) ? 16 : 8;
             const int sl = std::min((T.qlen + P - 1) / P, 63), tl = std::min(T.tlen >> 3, 511);
-            return (((P == 8) ? 64 : 0) + sl) * 512 + tl;
-        };
-        const int NB = 128 * 512;
-        std::vector<int> cnt((size_t)NB + 1, 0);
-        for (int i = 0; i < n; ++i) cnt[(size_t)(NB - 1 - key(i)) + 1]++;
-        for (int k = 0; k < NB; ++k) cnt[(size_t)k + 1] += cnt[(size_t)k];
-        for (int i = 0; i < n; ++i) order[(size_t)cnt[(size_t)(NB - 1 - key(i))]++] = i;
+            return NB - 1 - ((((P == 8) ? 64 : 0) + sl) * 512 + tl);
+        }, order.data());
     }
     prof.mark("order");
     // rows (tasks) per block: as many as fit 64 KB of LDS, the per-workgroup amount every launch may ask for without further ado

@@ -5,11 +5,6 @@
 // rescue (mem_matesw: a local Smith-Waterman in the shape of the reference's SSE2 kernel, whose quirks are observable) and
 // pairing (mem_pair) -- branchy and order-sensitive.  The mate-rescue SW is the next device kernel; this is its oracle.
 #include <limits.h>
-#include <linux/futex.h>
-#include <pthread.h>
-#include <sched.h>
-#include <sys/syscall.h>
-#include <unistd.h>
 #include <memory>
 #include <math.h>
 #include <stdio.h>
@@ -27,88 +22,12 @@
 #include <unordered_map>
 #include "ksort_host.h"
 #include "host_tail.h"
+#include "host_pool.h"
 
 void bm2_set_error(const char *fmt, ...);
 
 namespace {
-// Worker threads for the tail's parallel phases.  A chunk goes through a dozen short phases, so what counts is how fast ALL workers get
-// going: a queue behind one mutex hands the lock from one woken thread to the next (each hand-over costs a scheduler wake-up: milliseconds
-// for a few hundred threads), and spawning threads per phase cost more than the phases themselves.  Here every calling thread (a tail
-// worker of the pipeline) owns its workers; a phase is published by bumping a generation word and waking every sleeper with ONE futex
-// call; a worker that finished spins briefly before it sleeps, so back-to-back phases find the workers awake; completion is a counter
-// the caller spins / sleeps on.  No lock anywhere.  run(n, f) runs n copies of f (the caller is one of them) and returns when all are through.
-class TailPool {
-    std::vector<std::thread> workers;
-    std::function<void()> *job = nullptr;
-    alignas(64) std::atomic<uint32_t> gen{0};                   // futex word: one increment per phase
-    alignas(64) std::atomic<int32_t> want{0};                   // workers [0, want) take part in the current phase
-    alignas(64) std::atomic<uint32_t> left{0};                  // futex word: participants still inside f
-    std::atomic<bool> stop{false};
-    static void pause() {
-#if defined(__x86_64__) || defined(__i386__)
-        __builtin_ia32_pause();
-#endif
-    }
-    static void futex_wait(std::atomic<uint32_t> *w, uint32_t seen) { syscall(SYS_futex, (uint32_t *)w, FUTEX_WAIT_PRIVATE, seen, nullptr, nullptr, 0); }
-    static void futex_wake_all(std::atomic<uint32_t> *w) { syscall(SYS_futex, (uint32_t *)w, FUTEX_WAKE_PRIVATE, INT_MAX, nullptr, nullptr, 0); }
-    // A worker stays on one CPU of the process's affinity mask, handed out round-robin over all pools: a freshly woken thread then
-    // starts where it slept instead of queueing on the waker's CPU until the load balancer gets to it (milliseconds on virtualised
-    // hosts; a phase lasts a few).  BM2_TAIL_PIN=0 leaves the placement to the scheduler.
-    static void pin_self() {
-        static const bool on = []() { const char *e = getenv("BM2_TAIL_PIN"); return !(e && e[0] == '0'); }();
-        if (!on) return;
-        static std::atomic<unsigned> next_cpu{1};
-        cpu_set_t all;
-        if (sched_getaffinity(0, sizeof all, &all) != 0) return;
-        const int n = CPU_COUNT(&all);
-        if (n < 2) return;
-        int k = (int)(next_cpu.fetch_add(1) % (unsigned)n);
-        for (int c = 0; c < CPU_SETSIZE; ++c)
-            if (CPU_ISSET(c, &all) && k-- == 0) { cpu_set_t one; CPU_ZERO(&one); CPU_SET(c, &one); pthread_setaffinity_np(pthread_self(), sizeof one, &one); return; }
-    }
-    void loop(int idx, uint32_t seen) {
-        pin_self();
-        for (;;) {
-            uint32_t g;
-            for (int spins = 0; (g = gen.load(std::memory_order_acquire)) == seen;) { if (++spins < 4000) pause(); else futex_wait(&gen, seen); }
-            seen = g;
-            if (stop.load(std::memory_order_acquire)) return;
-            if (idx < want.load(std::memory_order_relaxed)) {
-                (*job)();
-                if (left.fetch_sub(1, std::memory_order_acq_rel) == 1) futex_wake_all(&left);
-            }
-        }
-    }
-public:
-    TailPool() {}
-    ~TailPool() {
-        stop.store(true, std::memory_order_release);
-        gen.fetch_add(1, std::memory_order_release);
-        futex_wake_all(&gen);
-        for (auto &t : workers) t.join();
-    }
-    void run(int n, std::function<void()> f) {
-        if (n <= 1) { f(); return; }
-        while ((int)workers.size() < n - 1) {                     // (a worker starts out having "seen" the current generation)
-            const int idx = (int)workers.size(); const uint32_t g = gen.load(std::memory_order_relaxed);
-            workers.emplace_back([this, idx, g]() { loop(idx, g); });
-        }
-        job = &f;
-        want.store(n - 1, std::memory_order_relaxed);
-        left.store((uint32_t)(n - 1), std::memory_order_relaxed);
-        gen.fetch_add(1, std::memory_order_release);
-        futex_wake_all(&gen);
-        f();                                                      // the caller takes part
-        uint32_t l;
-        for (int spins = 0; (l = left.load(std::memory_order_acquire)) != 0;) { if (++spins < 4000) pause(); else futex_wait(&left, l); }
-    }
-};
-TailPool &tail_pool() { static thread_local TailPool p; return p; }
-template <class F> void run_threads(int n_threads, F f) {
-    if (n_threads <= 1) { f(); return; }
-    tail_pool().run(n_threads, std::function<void()>(f));
-}
-
+template <class F> void run_threads(int n_threads, F f) { bm2_run_threads(n_threads, std::function<void()>(f)); }
 
 enum { F_NOPAIRING = 0x4, F_ALL = 0x8, F_NO_MULTI = 0x10, F_NO_RESCUE = 0x20, F_REF_HDR = 0x100, F_SOFTCLIP = 0x200, F_PRIMARY5 = 0x800, F_KEEP_SUPP_MAPQ = 0x1000 };
 const int MINUS_INF = -0x40000000;
@@ -835,48 +754,60 @@ int cal_sub(const bm2_opt *opt, const std::vector<bm2_alnreg_t> &r) {           
 }
 
 // mem_pestat, bwamem_pair.cpp:81-148 (without the log lines)
+// The insert-size model of a chunk (mem_pestat, bwamem_pair.cpp:81-148).  The reference collects the insert sizes of the pairs whose ends
+// are both unique into four arrays, sorts them and reads quartiles, a trimmed mean and a trimmed deviation off the sorted arrays.  An
+// insert size is an integer in [1, max_ins], so here the chunk's pairs are counted into four HISTOGRAMS on all threads (integer adds:
+// any order), and everything else is read off the counts: a quartile is a rank in the cumulative counts; the mean sums integers (exact
+// in a double whatever the order); the deviation adds (v - mean)^2 once per pair in ascending order of v, which is the order -- and
+// therefore the rounding -- of the reference's loop over its sorted array.
 void pestat(const bm2_opt *opt, const bm2_sam_opt *so, int64_t l_pac, const std::vector<std::vector<bm2_alnreg_t>> &regs, PeStat pes[4]) {
-    std::vector<uint64_t> isize[4];
-    const int n = (int)regs.size();
+    const int n_pairs = (int)(regs.size() >> 1);
+    const int64_t top = so->max_ins > 0 ? so->max_ins : 0;       // bins 1 .. max_ins
     for (int d = 0; d < 4; ++d) pes[d] = PeStat();
-    {   // the insert sizes of the pairs whose ends are both unique (collected on several threads: they are sorted before use)
-        int nt = so->n_threads > 0 ? so->n_threads : (int)std::thread::hardware_concurrency();
-        if (nt > (n >> 1) / 8192 + 1) nt = (n >> 1) / 8192 + 1;
-        if (nt < 1) nt = 1;
-        std::vector<std::vector<uint64_t>> loc((size_t)nt * 4);
-        std::atomic<int> nx(0), tid(0);
-        run_threads(nt, [&]() {
-            const int me = tid.fetch_add(1);
-            for (int lo; (lo = nx.fetch_add(8192)) < n >> 1;)
-                for (int i = lo; i < n >> 1 && i < lo + 8192; ++i) {
-                    const std::vector<bm2_alnreg_t> &r0 = regs[i << 1 | 0], &r1 = regs[i << 1 | 1];
-                    if (r0.empty() || r1.empty()) continue;
-                    if (cal_sub(opt, r0) > 0.8 * r0[0].score) continue;
-                    if (cal_sub(opt, r1) > 0.8 * r1[0].score) continue;
-                    if (r0[0].rid != r1[0].rid) continue;
-                    int64_t is;
-                    const int dir = infer_dir(l_pac, r0[0].rb, r1[0].rb, &is);
-                    if (is && is <= so->max_ins) loc[(size_t)me * 4 + dir].push_back((uint64_t)is);
-                }
-        });
-        for (int t = 0; t < nt; ++t) for (int d = 0; d < 4; ++d) isize[d].insert(isize[d].end(), loc[(size_t)t * 4 + d].begin(), loc[(size_t)t * 4 + d].end());
-    }
+    int nt = so->n_threads > 0 ? so->n_threads : (int)std::thread::hardware_concurrency();
+    if (nt > n_pairs / 8192 + 1) nt = n_pairs / 8192 + 1;
+    if (nt < 1) nt = 1;
+    const size_t bins = (size_t)top + 1;
+    std::vector<uint32_t> hist((size_t)nt * 4 * bins, 0);
+    std::atomic<int> nx(0), tid(0);
+    run_threads(nt, [&]() {
+        uint32_t *mine = hist.data() + (size_t)tid.fetch_add(1) * 4 * bins;
+        for (int lo; (lo = nx.fetch_add(8192)) < n_pairs;)
+            for (int i = lo; i < n_pairs && i < lo + 8192; ++i) {
+                const std::vector<bm2_alnreg_t> &r0 = regs[(size_t)i << 1 | 0], &r1 = regs[(size_t)i << 1 | 1];
+                if (r0.empty() || r1.empty()) continue;
+                if (cal_sub(opt, r0) > 0.8 * r0[0].score) continue;
+                if (cal_sub(opt, r1) > 0.8 * r1[0].score) continue;
+                if (r0[0].rid != r1[0].rid) continue;
+                int64_t is;
+                const int dir = infer_dir(l_pac, r0[0].rb, r1[0].rb, &is);
+                if (is && is <= top) ++mine[(size_t)dir * bins + (size_t)is];
+            }
+    });
+    uint64_t count[4] = { 0, 0, 0, 0 };
     for (int d = 0; d < 4; ++d) {
+        uint32_t *h = hist.data() + (size_t)d * bins;            // thread 0's histogram becomes the total
+        for (int t = 1; t < nt; ++t) { const uint32_t *o = hist.data() + ((size_t)t * 4 + d) * bins; for (size_t v = 0; v < bins; ++v) h[v] += o[v]; }
+        uint64_t tot = 0;
+        for (size_t v = 0; v < bins; ++v) tot += h[v];
+        count[d] = tot;
         PeStat *r = &pes[d];
-        std::vector<uint64_t> &q = isize[d];
-        if (q.size() < 10) { r->failed = 1; continue; }
-        std::sort(q.begin(), q.end());
-        const int p25 = (int)q[(int)(.25 * q.size() + .499)], p50 = (int)q[(int)(.50 * q.size() + .499)], p75 = (int)q[(int)(.75 * q.size() + .499)];
-        (void)p50;
+        if (tot < 10) { r->failed = 1; continue; }
+        auto at_rank = [&](uint64_t k) {                         // the k-th smallest insert size (k counted from 0)
+            uint64_t c = 0;
+            for (size_t v = 0; v < bins; ++v) { c += h[v]; if (c > k) return (int)v; }
+            return (int)top;
+        };
+        const int p25 = at_rank((uint64_t)(int)(.25 * tot + .499)), p75 = at_rank((uint64_t)(int)(.75 * tot + .499));
         r->low = (int)(p25 - 2.0 * (p75 - p25) + .499);
         if (r->low < 1) r->low = 1;
         r->high = (int)(p75 + 2.0 * (p75 - p25) + .499);
-        size_t x = 0;
-        r->avg = 0;
-        for (uint64_t v : q) if (v >= (uint64_t)r->low && v <= (uint64_t)r->high) { r->avg += v; ++x; }
-        r->avg /= x;
+        const size_t v_lo = (size_t)r->low, v_hi = r->high < 0 ? 0 : std::min((size_t)r->high, bins - 1);
+        uint64_t x = 0; double sum = 0;
+        for (size_t v = v_lo; v <= v_hi && r->high >= r->low; ++v) { x += h[v]; sum += (double)v * h[v]; }
+        r->avg = sum / x;
         r->std = 0;
-        for (uint64_t v : q) if (v >= (uint64_t)r->low && v <= (uint64_t)r->high) r->std += (v - r->avg) * (v - r->avg);
+        for (size_t v = v_lo; v <= v_hi && r->high >= r->low; ++v) { const double dv = ((double)v - r->avg) * ((double)v - r->avg); for (uint32_t c = 0; c < h[v]; ++c) r->std += dv; }
         r->std = sqrt(r->std / x);
         r->low = (int)(p25 - 3.0 * (p75 - p25) + .499);
         r->high = (int)(p75 + 3.0 * (p75 - p25) + .499);
@@ -884,9 +815,9 @@ void pestat(const bm2_opt *opt, const bm2_sam_opt *so, int64_t l_pac, const std:
         if (r->high < r->avg + 4.0 * r->std) r->high = (int)(r->avg + 4.0 * r->std + .499);
         if (r->low < 1) r->low = 1;
     }
-    size_t mx = 0;
-    for (int d = 0; d < 4; ++d) mx = mx > isize[d].size() ? mx : isize[d].size();
-    for (int d = 0; d < 4; ++d) if (pes[d].failed == 0 && isize[d].size() < mx * 0.05) pes[d].failed = 1;
+    uint64_t mx = 0;
+    for (int d = 0; d < 4; ++d) mx = mx > count[d] ? mx : count[d];
+    for (int d = 0; d < 4; ++d) if (pes[d].failed == 0 && count[d] < mx * 0.05) pes[d].failed = 1;
 }
 
 // bns_fetch_seq (bntseq.cpp:453-482) on the unpacked reference: [*beg, *end) clamped to the contig (strand-aware) that holds mid
@@ -1264,7 +1195,7 @@ int cigar_session_batch(const bm2_opt *opt, const bm2_reads *reads, int64_t enc_
     if (n == 0) return BM2_OK;
     M.hits.resize((size_t)n);
     {
-        int nt = (int)std::thread::hardware_concurrency();
+        int nt = bm2_host_threads();
         if (nt > n_reads / 16384 + 1) nt = n_reads / 16384 + 1;
         if (nt < 1) nt = 1;
         std::atomic<int> nx(0);
@@ -1287,6 +1218,11 @@ int cigar_session_batch(const bm2_opt *opt, const bm2_reads *reads, int64_t enc_
 }
 
 RescueStats g_rescue;               // counters of the last bm2_sam_pe call (diagnostic; bm2_sam_rescue_stats)
+
+struct PeWork {                     // the rescue batch of a chunk: tasks in pair order, their flat arrays, the results
+    std::vector<RescueTask> tasks; std::vector<int64_t> task_off, q_off, t_pos; std::vector<int32_t> q_len, t_len, xtra;
+    std::vector<uint8_t> qbuf; std::vector<bm2_ksw_result> res;
+};
 
 void flush_tallies() {
     if (t_cg_used) g_cigar.used += t_cg_used;
@@ -1474,7 +1410,9 @@ int bm2h_sam_pe(const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt
         bm2_set_error("bm2_sam_pe: bad argument (reads must be interleaved pairs)"); return BM2_EINVAL;
     }
     if (!idx->ref_string || !idx->ann_offset || !idx->ann_len || !idx->ann_name) { bm2_set_error("bm2_sam_pe: the index descriptor needs ref_string, contig lengths and names"); return BM2_EINVAL; }
+    if (so->max_ins > (1 << 24)) { bm2_set_error("bm2_sam_pe: max_ins above 2^24 is not supported (the insert sizes are counted in a histogram)"); return BM2_EUNSUP; }
     Ref R = { idx->l_pac, idx->ref_string, idx->n_seqs, idx->ann_offset, idx->ann_name, idx->ann_anno };
+    struct Budget { int was; explicit Budget(int n) : was(bm2_host_thread_budget()) { bm2_host_thread_budget() = n; } ~Budget() { bm2_host_thread_budget() = was; } } budget(so->n_threads);
     TailProf prof("sam_pe");
     const int n = reads->n_reads;
     std::vector<std::vector<bm2_alnreg_t>> regs((size_t)n);
@@ -1504,63 +1442,86 @@ int bm2h_sam_pe(const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt
     // so->rescue_inline = 1 aligns inside the pair loop as mem_sam_pe does; the output is the same.
     const int n_pairs = n >> 1;
     prof.mark("pestat + names");
-    std::vector<RescueTask> tasks;
-    std::vector<int64_t> task_off;
+    // (the flat arrays of the batch live in buffers the calling thread keeps from chunk to chunk: no fresh pages per chunk)
+    static thread_local PeWork W_of_this_thread;
+    PeWork &W = W_of_this_thread;                                // (a reference: the lambdas below run on the workers, whose own thread_local objects are other objects)
+    std::vector<RescueTask> &tasks = W.tasks;
+    std::vector<int64_t> &task_off = W.task_off;
     const bool batch = !(so->flag & F_NO_RESCUE) && !so->rescue_inline;
     g_rescue.planned = 0; g_rescue.used = 0; g_rescue.missed = 0;
     if (batch) {
         int n_threads = so->n_threads > 0 ? so->n_threads : (int)std::thread::hardware_concurrency();
         if (n_threads < 1) n_threads = 1;
         const int blk = 256, n_blk = (n_pairs + blk - 1) / blk;
+        const int nt_blk = n_threads < n_blk ? n_threads : n_blk;
         std::vector<std::vector<RescueTask>> part((size_t)n_blk);
+        std::vector<int64_t> base((size_t)n_blk + 1, 0), qbase((size_t)n_blk + 1, 0);      // tasks / query bytes before block b
         std::atomic<int> next(0);
-        auto plan = [&]() {
-            for (int b; (b = next.fetch_add(1)) < n_blk;)
+        run_threads(nt_blk, [&]() {                              // plan: every block lists its pairs' alignments, in pair order
+            for (int b; (b = next.fetch_add(1)) < n_blk;) {
+                std::vector<RescueTask> &v = part[(size_t)b];
                 for (int pi = b * blk; pi < n_pairs && pi < (b + 1) * blk; ++pi) {
                     const int l_seq[2] = { reads->len[2 * pi], reads->len[2 * pi + 1] };
-                    rescue_plan(opt, so, R, idx->ann_len, pes, pi, l_seq, &regs[(size_t)2 * pi], part[(size_t)b]);
+                    rescue_plan(opt, so, R, idx->ann_len, pes, pi, l_seq, &regs[(size_t)2 * pi], v);
                 }
-        };
-        run_threads(n_threads < n_blk ? n_threads : n_blk, plan);
-        prof.mark("rescue plan");
-        task_off.assign((size_t)n_pairs + 1, 0);
-        for (auto &v : part) { for (auto &t : v) task_off[(size_t)t.pair + 1]++; tasks.insert(tasks.end(), v.begin(), v.end()); }
-        for (int pi = 0; pi < n_pairs; ++pi) task_off[(size_t)pi + 1] += task_off[(size_t)pi];
-        g_rescue.planned = (long long)tasks.size();
-        const long long tot = (long long)tasks.size();
-        if (fn && tot > 0) {                                     // flat arrays -> one call of the hook
-            if (tot > 0x7fffffff) { bm2_set_error("bm2_sam_pe: too many rescue alignments in one chunk"); return BM2_EINVAL; }
-            std::vector<int64_t> q_off((size_t)tot), t_pos((size_t)tot);
-            std::vector<int32_t> q_len((size_t)tot), t_len((size_t)tot), xtra((size_t)tot);
-            int64_t qb = 0;
-            for (long long t = 0; t < tot; ++t) {
-                const RescueTask &T = tasks[(size_t)t];
-                const int m = 2 * T.pair + !T.end;               // the mate is the read that is aligned
-                q_off[(size_t)t] = qb; q_len[(size_t)t] = reads->len[m]; qb += reads->len[m];
-                t_pos[(size_t)t] = T.rb; t_len[(size_t)t] = (int32_t)(T.re - T.rb); xtra[(size_t)t] = rescue_xtra(opt, reads->len[m]);
+                int64_t q = 0;
+                for (const RescueTask &T : v) q += reads->len[2 * T.pair + !T.end];           // the mate is the read that is aligned
+                base[(size_t)b + 1] = (int64_t)v.size(); qbase[(size_t)b + 1] = q;
             }
-            std::vector<uint8_t> qbuf((size_t)qb + 1);
-            std::atomic<long long> nq(0);
-            run_threads(n_threads, [&]() {
-                std::vector<uint8_t> q;
-                for (long long t; (t = nq.fetch_add(1)) < tot;) {
-                    const RescueTask &T = tasks[(size_t)t];
-                    const int m = 2 * T.pair + !T.end;
-                    rescue_query(reads->len[m], reads->enc + reads->off[m], T.r, q);
-                    if (!q.empty()) memcpy(qbuf.data() + q_off[(size_t)t], q.data(), q.size());
+        });
+        for (int b = 0; b < n_blk; ++b) { base[(size_t)b + 1] += base[(size_t)b]; qbase[(size_t)b + 1] += qbase[(size_t)b]; }
+        const long long tot = (long long)base[(size_t)n_blk];
+        const int64_t qb_tot = qbase[(size_t)n_blk];
+        prof.mark("rescue plan");
+        if (tot > 0x7fffffff) { bm2_set_error("bm2_sam_pe: too many rescue alignments in one chunk"); return BM2_EINVAL; }
+        g_rescue.planned = tot;
+        const bool flat = fn && tot > 0;
+        if (tasks.size() < (size_t)tot) tasks.resize((size_t)tot);
+        if (task_off.size() < (size_t)n_pairs + 1) task_off.resize((size_t)n_pairs + 1);
+        if (flat) {
+            if (W.q_off.size() < (size_t)tot) { W.q_off.resize((size_t)tot); W.t_pos.resize((size_t)tot); W.q_len.resize((size_t)tot); W.t_len.resize((size_t)tot); W.xtra.resize((size_t)tot); W.res.resize((size_t)tot); }
+            if (W.qbuf.size() < (size_t)qb_tot + 1) W.qbuf.resize((size_t)qb_tot + 1);
+        }
+        next = 0;
+        run_threads(nt_blk, [&]() {                              // place: the blocks' lists at their offsets, the batch's flat arrays beside them
+            for (int b; (b = next.fetch_add(1)) < n_blk;) {
+                const std::vector<RescueTask> &v = part[(size_t)b];
+                int64_t g = base[(size_t)b], qb = qbase[(size_t)b];
+                size_t k = 0;
+                for (int pi = b * blk; pi < n_pairs && pi < (b + 1) * blk; ++pi) {
+                    task_off[(size_t)pi] = g;
+                    for (; k < v.size() && v[k].pair == pi; ++k, ++g) {
+                        const RescueTask &T = v[k];
+                        tasks[(size_t)g] = T;
+                        if (!flat) continue;
+                        const int m = 2 * pi + !T.end, l_ms = reads->len[m];
+                        W.q_off[(size_t)g] = qb; W.q_len[(size_t)g] = l_ms;
+                        W.t_pos[(size_t)g] = T.rb; W.t_len[(size_t)g] = (int32_t)(T.re - T.rb); W.xtra[(size_t)g] = rescue_xtra(opt, l_ms);
+                        const uint8_t *ms = reads->enc + reads->off[m];
+                        uint8_t *q = W.qbuf.data() + qb;         // the mate as direction r reads it (rescue_query)
+                        if (!(T.r >> 1 != (T.r & 1))) memcpy(q, ms, (size_t)l_ms);
+                        else for (int i = 0; i < l_ms; ++i) q[l_ms - 1 - i] = ms[i] < 4 ? 3 - ms[i] : 4;
+                        qb += l_ms;
+                    }
                 }
-            });
-            std::vector<bm2_ksw_result> res((size_t)tot);
+            }
+        });
+        task_off[(size_t)n_pairs] = tot;
+        if (flat) {                                              // one call of the hook
             prof.mark("rescue flatten");
-            const int rc = fn(user, (int32_t)tot, qbuf.data(), qb, q_off.data(), q_len.data(), t_pos.data(), t_len.data(), xtra.data(), opt,
-                              idx->ref_string, res.data());
+            const int rc = fn(user, (int32_t)tot, W.qbuf.data(), qb_tot, W.q_off.data(), W.q_len.data(), W.t_pos.data(), W.t_len.data(), W.xtra.data(), opt,
+                              idx->ref_string, W.res.data());
             if (rc) return rc;
             prof.mark("rescue batch");
-            for (long long t = 0; t < tot; ++t) {
-                const bm2_ksw_result &r = res[(size_t)t];
-                KswResult &o = tasks[(size_t)t].res;
-                o.score = r.score; o.te = r.te; o.qe = r.qe; o.score2 = r.score2; o.te2 = r.te2; o.tb = r.tb; o.qb = r.qb;
-            }
+            std::atomic<long long> nr(0);
+            run_threads((long long)n_threads < tot / 8192 + 1 ? n_threads : (int)(tot / 8192 + 1), [&]() {
+                for (long long t0; (t0 = nr.fetch_add(8192)) < tot;)
+                    for (long long t = t0; t < tot && t < t0 + 8192; ++t) {
+                        const bm2_ksw_result &r = W.res[(size_t)t];
+                        KswResult &o = tasks[(size_t)t].res;
+                        o.score = r.score; o.te = r.te; o.qe = r.qe; o.score2 = r.score2; o.te2 = r.te2; o.tb = r.tb; o.qb = r.qb;
+                    }
+            });
         } else {
             std::atomic<long long> nt(0);
             const long long step = 32;
@@ -1592,7 +1553,8 @@ int bm2h_sam_pe(const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt
         ReadIO io[2]; io_of(pi, io);
         return pe_emit(opt, so, R, pes, io, &regs[(size_t)2 * pi], P, part);
     };
-    CgMemo memo;
+    static thread_local CgMemo memo_of_this_thread;              // (kept from chunk to chunk, like W)
+    CgMemo &memo = memo_of_this_thread;
     prof.mark("rescue results");
     g_cigar.planned = 0; g_cigar.used = 0; g_cigar.missed = 0;
     std::vector<PairPlan> plans;
@@ -1631,8 +1593,18 @@ int bm2h_sam_pe(const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt
         t_cg = CgSession();
         return r;
     });
-    if (bad >= 0) { bm2_set_error("bm2_sam_pe: pair %d has a hit whose CIGAR cannot be generated (range outside the reference)", bad); return BM2_EINVAL; }
     prof.mark("real pass + copy");
+    {   // a million small hit lists: released by the threads, not one by one on the way out
+        std::atomic<int> nx(0);
+        int nt = so->n_threads > 0 ? so->n_threads : (int)std::thread::hardware_concurrency();
+        if (nt > n / 4096 + 1) nt = n / 4096 + 1;
+        run_threads(nt < 1 ? 1 : nt, [&]() {
+            for (int lo; (lo = nx.fetch_add(4096)) < n;)
+                for (int i = lo; i < n && i < lo + 4096; ++i) std::vector<bm2_alnreg_t>().swap(regs[(size_t)i]);
+        });
+        prof.mark("release");
+    }
+    if (bad >= 0) { bm2_set_error("bm2_sam_pe: pair %d has a hit whose CIGAR cannot be generated (range outside the reference)", bad); return BM2_EINVAL; }
     return rc_out;
 }
 
@@ -1652,6 +1624,7 @@ int bm2h_sam_se(const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt
     }
     if (!idx->ref_string || !idx->ann_offset || !idx->ann_name) { bm2_set_error("bm2_sam_se: the index descriptor needs ref_string and contig names"); return BM2_EINVAL; }
     Ref R = { idx->l_pac, idx->ref_string, idx->n_seqs, idx->ann_offset, idx->ann_name, idx->ann_anno };
+    struct Budget { int was; explicit Budget(int n) : was(bm2_host_thread_budget()) { bm2_host_thread_budget() = n; } ~Budget() { bm2_host_thread_budget() = was; } } budget(so->n_threads);
     const int n_reads = reads->n_reads;
     auto decide = [&](int i) {                                   // what changes the read's hit list (mem_reg2sam's caller, bwamem.cpp:1240-1243)
         bm2_alnreg_t *a = alnregs + reg_off[i];
