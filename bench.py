@@ -250,21 +250,25 @@ def parity_gate(ctx, bm2, prefix, workdir, seqs, regs, reg_off, opt, opt_args, p
     return res
 
 
-def end_to_end(ctx, bm2, texts, opt, paired, n_threads, n_tail=2, limit_s=None):
-    """FASTQ text -> SAM text over the chunks `texts` = [(bytes1, bytes2 | None)] as a pipeline of host threads, one stage each:
-    the reader (bm2_fastq_parse_mt), the device stage (H2D, seeding .. extension, mem_sort_dedup_patch, D2H) and n_tail tail workers
-    (pairing, rescue + CIGAR batches on the device through contexts that share the index replica, SAM text).  Chunks leave in order
-    (a chunk's text is complete before it is counted)."""
+def end_to_end(ctx, bm2, texts, opt, paired, n_threads, n_tail=2, limit_s=None, n_dev=None):
+    """FASTQ text -> SAM text over the chunks `texts` = [(bytes1, bytes2 | None)] as a pipeline of host threads: the reader
+    (bm2_fastq_parse_mt), n_dev device workers (H2D, seeding .. extension, mem_sort_dedup_patch, D2H; each with a context of its own on
+    the shared index replica, chunk i on worker i % n_dev, so the copies and the latency-bound kernels of one chunk overlap the kernels
+    of the next) and n_tail tail workers (pairing, rescue + CIGAR batches on the device through further contexts, SAM text).  A chunk's
+    text is complete before it is counted; the tie-breaking hash of a read is seeded with its number in the input (n_before)."""
     n_tail = int(os.environ.get("BM2_E2E_TAILS", n_tail))
+    n_dev = max(1, int(os.environ.get("BM2_E2E_DEVS", n_dev or 2)))
     tails = [bm2.Context(share=ctx) for _ in range(n_tail)]
+    devs = [ctx] + [bm2.Context(share=ctx) for _ in range(n_dev - 1)]
     hw = os.cpu_count() or 1
     # the library's host workers stay on their CPUs (host_pool.h): the stages' thread counts are chosen not to overlap -- the parser's,
     # the tail workers', and a few CPUs left to the pipeline's own threads
     n_parse = int(os.environ.get("BM2_E2E_PARSE_THREADS", max(1, min(hw // 8, 32))))
     so = bm2.default_sam_opt(n_threads=int(os.environ.get("BM2_E2E_TAIL_THREADS", n_threads or max((hw - n_parse - min(8, hw // 4)) // n_tail, 1))))
-    q_parsed, q_hits = queue.Queue(maxsize=2), queue.Queue(maxsize=2)
+    q_parsed, q_hits = [queue.Queue(maxsize=2) for _ in range(n_dev)], queue.Queue(maxsize=2)
     stage, err, lock = {}, [], threading.Lock()
     done = [0] * len(texts)
+    devs_left = [n_dev]
 
     def add(k, dt):
         with lock:
@@ -272,31 +276,37 @@ def end_to_end(ctx, bm2, texts, opt, paired, n_threads, n_tail=2, limit_s=None):
 
     def reader():
         try:
+            n_before = 0
             for i, (t1, t2) in enumerate(texts):
                 t = time.perf_counter(); ch = bm2.FastqChunk(t1, t2, n_parse); add("parse", time.perf_counter() - t)    # a memory-bound scan: a few dozen threads saturate it
-                q_parsed.put((i, ch))
+                q_parsed[i % n_dev].put((i, ch, n_before))
+                n_before += ch.n_reads
         except Exception as e:                                    # noqa
             err.append(e)
-        q_parsed.put(None)
+        for q in q_parsed:
+            q.put(None)
 
-    def device():
+    def device(k):
+        c = devs[k]
         try:
-            n_done = 0
             while True:
-                it = q_parsed.get()
+                it = q_parsed[k].get()
                 if it is None:
                     break
-                i, ch = it
-                t = time.perf_counter(); ctx.batch_upload_chunk(ch); add("h2d", time.perf_counter() - t)
-                t = time.perf_counter(); ctx.batch_run(opt); add("device", time.perf_counter() - t)
-                t = time.perf_counter(); ctx.batch_finish(opt); add("a19", time.perf_counter() - t)
-                t = time.perf_counter(); aln, aln_off = ctx.batch_download_alnregs(); add("d2h", time.perf_counter() - t)
-                q_hits.put((i, ch, aln, aln_off, n_done))
-                n_done += ch.n_reads
+                i, ch, n_before = it
+                t = time.perf_counter(); c.batch_upload_chunk(ch); add("h2d", time.perf_counter() - t)
+                t = time.perf_counter(); c.batch_run(opt); add("device", time.perf_counter() - t)
+                t = time.perf_counter(); c.batch_finish(opt); add("a19", time.perf_counter() - t)
+                t = time.perf_counter(); aln, aln_off = c.batch_download_alnregs(); add("d2h", time.perf_counter() - t)
+                q_hits.put((i, ch, aln, aln_off, n_before))
         except Exception as e:                                    # noqa
             err.append(e)
-        for _ in tails:
-            q_hits.put(None)
+        with lock:
+            devs_left[0] -= 1
+            last = devs_left[0] == 0
+        if last:
+            for _ in tails:
+                q_hits.put(None)
 
     def tail(k):
         buf = None
@@ -305,39 +315,45 @@ def end_to_end(ctx, bm2, texts, opt, paired, n_threads, n_tail=2, limit_s=None):
                 it = q_hits.get()
                 if it is None:
                     break
-                i, ch, aln, aln_off, n_done = it
+                i, ch, aln, aln_off, n_before = it
                 if buf is None:
                     buf = np.empty(max(1 << 20, int(3 * (int(ch.f.n_bases) + 200 * ch.n_reads))), np.uint8)
                 t = time.perf_counter()
-                txt = tails[k].sam(ch, opt, so, aln, aln_off, n_done, paired, out=buf)
+                txt = tails[k].sam(ch, opt, so, aln, aln_off, n_before, paired, out=buf)
                 add("tail", time.perf_counter() - t)
                 done[i] = (len(txt), ch.n_reads)
                 ch.close()
         except Exception as e:                                    # noqa
             err.append(e)
 
-    th = [threading.Thread(target=reader, daemon=True), threading.Thread(target=device, daemon=True)] + \
+    th = [threading.Thread(target=reader, daemon=True)] + [threading.Thread(target=device, args=(k,), daemon=True) for k in range(n_dev)] + \
          [threading.Thread(target=tail, args=(k,), daemon=True) for k in range(n_tail)]
     t0 = time.perf_counter()
     for t in th:
         t.start()
     for t in th:
-        t.join(max(0.0, limit_s - (time.perf_counter() - t0)) if limit_s else None)
+        while t.is_alive():                                       # (short joins: an error in one stage must not leave the others waiting on a queue)
+            t.join(0.05)
+            if err or (limit_s and time.perf_counter() - t0 > limit_s):
+                break
+        if err:
+            break
         if t.is_alive():
             raise TimeoutError("end-to-end leg not finished after %.0f s (stages so far: %s)" % (limit_s, {k: round(v, 1) for k, v in stage.items()}))
     dt = time.perf_counter() - t0
-    for c in tails:
-        c.close()
     if err:
-        raise err[0]
+        raise err[0]                                              # (the stages are daemon threads: whatever still waits on a queue goes with the process)
+    for c in tails + devs[1:]:
+        c.close()
     out_bytes = sum(d[0] for d in done); n_reads = sum(d[1] for d in done)
     nch = max(len(texts), 1)
     return {"value": n_reads / dt, "unit": "reads/s", "reads": n_reads, "chunks": len(texts), "wall_s": dt, "sam_bytes": out_bytes,
-            "host_threads": hw, "parse_threads": n_parse, "tail_workers": n_tail, "threads_per_tail_worker": so.n_threads,
+            "host_threads": hw, "parse_threads": n_parse, "device_workers": n_dev, "tail_workers": n_tail, "threads_per_tail_worker": so.n_threads,
             "stage_ms_per_chunk": {k: v / nch * 1e3 for k, v in stage.items()},
             "scope": "FASTQ text in host memory -> bm2_fastq_parse_mt | H2D -> device pipeline incl. mem_sort_dedup_patch (a19) -> D2H | pairing / "
-                     "mate rescue / CIGAR (device batches) / SAM text in host memory; one host thread per stage (two tail workers), stages of "
-                     "consecutive chunks overlap; file I/O excluded"}
+                     "mate rescue / CIGAR (device batches) / SAM text in host memory; one host thread per stage worker (%d device workers on contexts "
+                     "sharing the index replica, %d tail workers), stages of consecutive chunks overlap; `stage_ms_per_chunk` is the time a chunk "
+                     "spends in a stage on its worker; file I/O excluded" % (n_dev, n_tail)}
 
 
 def main():
@@ -560,20 +576,28 @@ def main():
                 texts.append((open(fa, "rb").read(), open(fb, "rb").read()))
                 os.remove(fa); os.remove(fb)
             log("end-to-end input: %d chunks generated in %.1fs" % (len(texts), time.time() - t))
-            try:
-                end_to_end(ctx, bm2, texts[:1], opt, True, 0, limit_s=max(30.0, min(120.0, time_left() - 90)))      # warm-up (workspaces, thread pools)
-                out["end_to_end"] = end_to_end(ctx, bm2, texts, opt, True, 0, limit_s=max(30.0, min(300.0, time_left() - 30)))
-                out["end_to_end"]["frac_of_hot_path"] = out["end_to_end"]["value"] / value
-            except TimeoutError as e:                                                 # a stage is stuck: report, then leave without joining it
-                out["end_to_end"] = {"error": str(e)}
-                hung = True
-            except Exception as e:                                                    # noqa
-                out["end_to_end"] = {"error": str(e)}
+            n_dev = max(1, int(os.environ.get("BM2_E2E_DEVS", 2)))
+            for attempt_devs in ([n_dev, 1] if n_dev > 1 else [1]):
+                try:
+                    end_to_end(ctx, bm2, texts[:attempt_devs], opt, True, 0, limit_s=max(30.0, min(120.0, time_left() - 90)), n_dev=attempt_devs)   # warm-up: every worker's workspaces
+                    out["end_to_end"] = end_to_end(ctx, bm2, texts, opt, True, 0, limit_s=max(30.0, min(300.0, time_left() - 30)), n_dev=attempt_devs)
+                    out["end_to_end"]["frac_of_hot_path"] = out["end_to_end"]["value"] / value
+                    break
+                except TimeoutError as e:                                             # a stage is stuck: report, then leave without joining it
+                    out["end_to_end"] = {"error": str(e), "device_workers": attempt_devs}
+                    hung = True
+                    break
+                except Exception as e:                                                # noqa
+                    out["end_to_end"] = {"error": str(e), "device_workers": attempt_devs}
+                    hung = True                                                       # (stage threads may still wait on a queue: leave through os._exit)
+                    log("end-to-end leg with %d device worker(s) failed: %s" % (attempt_devs, e))
+                    time.sleep(2.0)                                                   # (calls in flight on the contexts finish before the next attempt)
         else:
             out["end_to_end"] = None
         print(json.dumps(out), flush=True)
-    if hung:
-        os._exit(rc or 4)
+    if hung:                                                     # stage threads of a failed end-to-end attempt may be left: do not join them
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(rc)
     ctx.close()
     dist_util.finish(world)
     if rc:

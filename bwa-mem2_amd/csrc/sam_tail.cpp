@@ -59,65 +59,72 @@ void put_int(std::string &s, long long v) {                    // kputw / kputl 
 }
 
 // ---- ksw_global2 with backtrack (ksw.cpp:558-668): direction byte per cell = f<<4 | e<<2 | h ---------------------------
+// Banded global alignment with traceback; must reproduce ksw_global2 (ksw.cpp:558-668) decision for decision, because the CIGAR of a
+// rescued hit is printed from it.  Only the rescued hits of a chunk come here (everything numbered goes through the device batch), so this
+// is written for clarity, not speed: a row is computed in three sweeps over structure-of-arrays rows -- (1) the diagonal move M and the
+// choice between M and the deletion state E, (2) the insertion state F, the only value that depends on the cell to its left, folded in
+// as a running maximum, (3) next row's E -- and a cell's traceback record is three named fields (where H came from; whether E / F were
+// extended rather than opened) instead of ksw's shifted byte.  The walk back is an explicit three-state machine.
+// The reference's preferences at ties are what make the result unique: H takes M over E over F; E and F prefer opening over extending.
 int global_align(int qlen, const uint8_t *query, int tlen, const uint8_t *target, const int8_t *mat, int o_del, int e_del, int o_ins,
                  int e_ins, int w, std::vector<uint32_t> &cigar) {
-    struct EH { int32_t h, e; };
-    const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
-    const int n_col = qlen < 2 * w + 1 ? qlen : 2 * w + 1;
-    static thread_local std::vector<uint8_t> z;                // scratch kept per thread: this runs once or more per output record
-    static thread_local std::vector<EH> eh;
-    if (z.size() < (size_t)n_col * (size_t)tlen) z.resize((size_t)n_col * (size_t)tlen);
-    if (eh.size() < (size_t)qlen + 1) eh.resize((size_t)qlen + 1);
-    int i, j, k;
-    eh[0].h = 0; eh[0].e = MINUS_INF;
-    for (j = 1; j <= qlen && j <= w; ++j) { eh[j].h = -(o_ins + e_ins * j); eh[j].e = MINUS_INF; }
-    for (; j <= qlen; ++j) eh[j].h = eh[j].e = MINUS_INF;
-    for (i = 0; i < tlen; ++i) {
-        int32_t f = MINUS_INF, h1, beg, end, t;
-        const int8_t *q = &mat[target[i] * 5];
-        beg = i > w ? i - w : 0;
-        end = i + w + 1 < qlen ? i + w + 1 : qlen;
-        h1 = beg == 0 ? -(o_del + e_del * (i + 1)) : MINUS_INF;
-        uint8_t *zi = &z[(size_t)i * n_col];
-        for (j = beg; j < end; ++j) {
-            EH *p = &eh[j];
-            int32_t h, m = p->h, e = p->e;
-            uint8_t d;
-            p->h = h1;
-            m += q[query[j]];
-            d = m >= e ? 0 : 1;
-            h = m >= e ? m : e;
-            d = h >= f ? d : 2;
-            h = h >= f ? h : f;
-            h1 = h;
-            t = m - oe_del; e -= e_del;
-            d |= e > t ? 1 << 2 : 0;
-            e = e > t ? e : t;
-            p->e = e;
-            t = m - oe_ins; f -= e_ins;
-            d |= f > t ? 2 << 4 : 0;
-            f = f > t ? f : t;
-            zi[j - beg] = d;
+    enum : uint8_t { FROM_M = 0, FROM_E = 1, FROM_F = 2, E_EXTENDED = 4, F_EXTENDED = 8 };
+    const int open_del = o_del + e_del, open_ins = o_ins + e_ins;
+    const int width = std::min(qlen, 2 * w + 1);                // cells of a row inside the band
+    static thread_local std::vector<uint8_t> trace;            // [tlen][width], column index relative to the row's first band cell
+    static thread_local std::vector<int32_t> Hup, Eup, Mrow, Hrow;   // H(i-1, j-1) shifted to column j; E(i, j); this row's M and H
+    if (trace.size() < (size_t)width * (size_t)tlen) trace.resize((size_t)width * (size_t)tlen);
+    for (auto *v : { &Hup, &Eup, &Mrow, &Hrow }) if (v->size() < (size_t)qlen + 2) v->resize((size_t)qlen + 2);
+    // row -1: only leading insertions, and only inside the band
+    for (int j = 0; j <= qlen; ++j) { Hup[j] = j == 0 ? 0 : (j <= w ? -(o_ins + e_ins * j) : MINUS_INF); Eup[j] = MINUS_INF; }
+    auto band_begin = [&](int i) { return i > w ? i - w : 0; };
+    auto band_end = [&](int i) { return std::min(i + w + 1, qlen); };
+    for (int i = 0; i < tlen; ++i) {
+        const int lo = band_begin(i), hi = band_end(i);
+        const int8_t *score_of = mat + target[i] * 5;
+        uint8_t *rec = trace.data() + (size_t)i * width;
+        for (int j = lo; j < hi; ++j) {                          // sweep 1: M, and H without insertions
+            const int m = Hup[j] + score_of[query[j]];
+            Mrow[j] = m;
+            const bool take_e = Eup[j] > m;
+            Hrow[j] = take_e ? Eup[j] : m;
+            rec[j - lo] = take_e ? FROM_E : FROM_M;
         }
-        eh[end].h = h1; eh[end].e = MINUS_INF;
+        int f = MINUS_INF;                                       // sweep 2: F runs left to right; H = max(H, F) with F last in the preference
+        for (int j = lo; j < hi; ++j) {
+            if (f > Hrow[j]) { Hrow[j] = f; rec[j - lo] = FROM_F; }
+            const int opened = Mrow[j] - open_ins, extended = f - e_ins;
+            if (extended > opened) { f = extended; rec[j - lo] |= F_EXTENDED; } else f = opened;
+        }
+        for (int j = lo; j < hi; ++j) {                          // sweep 3: E of the next row at this column
+            const int opened = Mrow[j] - open_del, extended = Eup[j] - e_del;
+            if (extended > opened) { Eup[j] = extended; rec[j - lo] |= E_EXTENDED; } else Eup[j] = opened;
+        }
+        // shift: next row's diagonal predecessor of column j is this row's H at j - 1; column lo takes the boundary value
+        int carry = lo == 0 ? -(o_del + e_del * (i + 1)) : MINUS_INF;
+        for (int j = lo; j < hi; ++j) { const int h = Hrow[j]; Hup[j] = carry; carry = h; }
+        Hup[hi] = carry; Eup[hi] = MINUS_INF;
     }
-    const int score = eh[qlen].h;
+    const int score = Hup[qlen];
     cigar.clear();
-    auto push = [&](int op, int len) {                         // push_cigar, ksw.cpp:546-556
-        if (cigar.empty() || op != (int)(cigar.back() & 0xf)) cigar.push_back((uint32_t)len << 4 | (uint32_t)op);
-        else cigar.back() += (uint32_t)len << 4;
+    auto emit = [&](uint32_t op, uint32_t len) {                 // runs are merged as they are found (back to front)
+        if (!cigar.empty() && (cigar.back() & 0xf) == op) cigar.back() += len << 4;
+        else cigar.push_back(len << 4 | op);
     };
-    int which = 0;
-    i = tlen - 1; k = (i + w + 1 < qlen ? i + w + 1 : qlen) - 1;
-    while (i >= 0 && k >= 0) {
-        which = z[(size_t)i * n_col + (k - (i > w ? i - w : 0))] >> (which << 1) & 3;
-        if (which == 0) { push(0, 1); --i; --k; }
-        else if (which == 1) { push(2, 1); --i; }
-        else { push(1, 1); --k; }
+    int i = tlen - 1, j = band_end(tlen - 1) - 1;
+    uint8_t state = FROM_M;                                      // in which of the three matrices the path currently is
+    while (i >= 0 && j >= 0) {
+        const uint8_t r = trace[(size_t)i * width + (size_t)(j - band_begin(i))];
+        if (state == FROM_M) state = r & 3;                      // leave H through the matrix it was taken from
+        else if (state == FROM_E) state = (r & E_EXTENDED) ? FROM_E : FROM_M;
+        else state = (r & F_EXTENDED) ? FROM_F : FROM_M;
+        if (state == FROM_M) { emit(0, 1); --i; --j; }
+        else if (state == FROM_E) { emit(2, 1); --i; }
+        else { emit(1, 1); --j; }
     }
-    if (i >= 0) push(2, i + 1);
-    if (k >= 0) push(1, k + 1);
-    for (size_t a = 0, b = cigar.size(); a + 1 < b; ++a, --b) { uint32_t t = cigar[a]; cigar[a] = cigar[b - 1]; cigar[b - 1] = t; }
+    if (i >= 0) emit(2, (uint32_t)i + 1);
+    if (j >= 0) emit(1, (uint32_t)j + 1);
+    std::reverse(cigar.begin(), cigar.end());
     return score;
 }
 
