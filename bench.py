@@ -258,6 +258,8 @@ def end_to_end(ctx, bm2, texts, opt, paired, n_threads, n_tail=2, limit_s=None, 
     text is complete before it is counted; the tie-breaking hash of a read is seeded with its number in the input (n_before)."""
     n_tail = int(os.environ.get("BM2_E2E_TAILS", n_tail))
     n_dev = max(1, int(os.environ.get("BM2_E2E_DEVS", n_dev or 2)))
+    if os.environ.get("BM2_E2E_LIMIT_S"):                        # (the host emulator needs minutes where the GPU needs milliseconds)
+        limit_s = float(os.environ["BM2_E2E_LIMIT_S"])
     tails = [bm2.Context(share=ctx) for _ in range(n_tail)]
     devs = [ctx] + [bm2.Context(share=ctx) for _ in range(n_dev - 1)]
     hw = os.cpu_count() or 1

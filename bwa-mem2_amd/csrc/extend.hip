@@ -212,7 +212,10 @@ template <bool PF>
 static __device__ void lane_dp8(bool run, int qlen, int tlen, int w, int h0, const uint8_t *tp, int ts, const SwParams &P,
                                 uint32_t *EH, const uint32_t *QL, int lane, LaneOut &out, long long &cells) {
     const int o_del = P.o_del, e_del = P.e_del, o_ins = P.o_ins, e_ins = P.e_ins, oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
-    const int sc_match = P.mat[0], sc_mis = P.mat[1], sc_amb = P.mat[4];
+    int sc_match = P.mat[0], sc_mis = P.mat[1], sc_amb = P.mat[4];
+    // (the three scores are operands of v_cndmask in every cell, which takes both sources from VGPRs: kept there, or the compiler
+    //  re-materialises them from SGPRs with a v_mov per use -- 3 of a cell's 33 VALU instructions)
+    asm volatile("" : "+v"(sc_match), "+v"(sc_mis), "+v"(sc_amb));
     const int e1 = h0 > oe_ins ? h0 - oe_ins : 0;                // first row, bandedSWA.cpp:143-145
     const int cls = pair_class(tlen, qlen, h0, P.max_sc);
     const int maxq = __builtin_amdgcn_readlane(wave_scan_max(run ? qlen : 0, 0), 63);
@@ -231,7 +234,11 @@ static __device__ void lane_dp8(bool run, int qlen, int tlen, int w, int h0, con
         if (!__ballot(alive)) break;
         const int tb = t_next;
         if (alive && i + 1 < tlen) t_next = (int)tp[(int64_t)(i + 1) * ts];
-        int h1 = 0, f = 0, m = 0, mj = -1, fnz = -1, lnz = -1;
+        // The row's maximum and the LAST column holding it (bandedSWA.cpp:188-189) as one running maximum over h << 8 | j (h and j are
+        // below 256 in this class); the first / last column with a non-zero stored cell as an unsigned minimum / a signed maximum over
+        // (cell != 0 ? j : -1): -1 is "none" in both.
+        int h1 = 0, f = 0, lnz = -1;
+        unsigned key = 0, fnz_u = 0xffffffffu;
         if (alive) {
             if (beg < i - w) beg = i - w;
             if (end > i + w + 1) end = i + w + 1;
@@ -239,13 +246,14 @@ static __device__ void lane_dp8(bool run, int qlen, int tlen, int w, int h0, con
             if (beg == 0) { h1 = h0 - (o_del + e_del * (i + 1)); if (h1 < 0) h1 = 0; }
             cells += imax(end - beg, 0);
         }
-        const int s_eq = tb > 3 ? sc_amb : sc_match;
+        const int s_eq = tb > 3 ? sc_amb : sc_match;         // against an equal query code (both N: ambiguous)
+        const int s_ne = tb > 3 ? sc_amb : sc_mis;           // against a different base
         const int jlo = (1 << 20) - __builtin_amdgcn_readlane(wave_scan_max(alive ? (1 << 20) - beg : 0, 0), 63);
         const int jhi = __builtin_amdgcn_readlane(wave_scan_max(alive ? end : 0, 0), 63);
-        uint32_t qw = 0;
-        uint32_t wnext = PF ? EH[((jlo & ~1) >> 1) * 64 + lane] : 0u;
-        for (int jp = jlo & ~1; jp < jhi; jp += 2) {
-            if ((jp & 7) == 0 || jp == (jlo & ~1)) qw = QL[(jp >> 3) * 64 + lane] >> (4 * (jp & 7));
+        const int jp0 = jlo & ~1;
+        uint32_t qw = jp0 < jhi ? QL[(jp0 >> 3) * 64 + lane] >> (4 * (jp0 & 7)) : 0u;     // 8 query bases per word; the next word when a pair starts one
+        uint32_t wnext = PF ? EH[(jp0 >> 1) * 64 + lane] : 0u;
+        for (int jp = jp0; jp < jhi; jp += 2) {
             const uint32_t wcur = wnext;
             if (PF) wnext = EH[((jp >> 1) + 1) * 64 + lane];
             if (alive && jp + 1 >= beg && jp < end) {
@@ -257,24 +265,28 @@ static __device__ void lane_dp8(bool run, int qlen, int tlen, int w, int h0, con
                         const int qb = (int)((qw >> (4 * u)) & 15u);
                         const int e = (int)((word >> (16 * u + 8)) & 0xffu);
                         int M = (int)((word >> (16 * u)) & 0xffu);
-                        const int sc = (qb == tb && tb < 4) ? s_eq : ((qb > 3 || tb > 3) ? sc_amb : sc_mis);
+                        const int sc = qb == tb ? s_eq : (qb > 3 ? sc_amb : s_ne);
                         M = M ? M + sc : 0;
                         int h = M > e ? M : e;
                         h = h > f ? h : f;
-                        mj = m > h ? mj : j;
-                        m = m > h ? m : h;
+                        const unsigned kj = (unsigned)h << 8 | (unsigned)j;
+                        key = key > kj ? key : kj;
                         const int en = imax(imax(e - e_del, M - oe_del), 0);
                         f = imax(imax(f - e_ins, M - oe_ins), 0);
                         const uint32_t nw = (uint32_t)h1 | ((uint32_t)en << 8);
                         word = (word & ~(0xffffu << (16 * u))) | nw << (16 * u);
-                        if (nw) { lnz = j; if (fnz < 0) fnz = j; }
+                        const int jj = nw ? j : -1;
+                        lnz = lnz > jj ? lnz : jj;
+                        fnz_u = fnz_u < (unsigned)jj ? fnz_u : (unsigned)jj;
                         h1 = h;
                     }
                 }
                 EH[(jp >> 1) * 64 + lane] = word;
             }
             qw >>= 8;
+            if (((jp + 2) & 7) == 0 && jp + 2 < jhi) qw = QL[((jp + 2) >> 3) * 64 + lane];
         }
+        const int m = (int)(key >> 8), mj = (int)(key & 255u), fnz = (int)fnz_u;
         if (alive) {
             uint32_t word = EH[(end >> 1) * 64 + lane];                // eh[end] = {h1, 0}, bandedSWA.cpp:201
             word = (word & ~(0xffffu << (16 * (end & 1)))) | (uint32_t)h1 << (16 * (end & 1));
