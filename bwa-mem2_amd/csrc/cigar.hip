@@ -324,9 +324,9 @@ static int cigar_run(bm2_ctx *c, const bm2_opt *opt, std::vector<CigarTask> &tas
     uint8_t *d_z = (uint8_t *)b_scr.p; int2 *d_eh = (int2 *)((char *)b_scr.p + z_bytes);
     uint32_t *d_cg = (uint32_t *)((char *)d_eh + eh_bytes); char *d_md = (char *)d_cg + cg_bytes;
     prof.mark("reserve");
-    rc = bm2_check(hipMemcpyAsync(b_seq.p, seqs, (size_t)seq_bytes, hipMemcpyHostToDevice, s), "H2D queries");
-    if (!rc) rc = bm2_check(hipMemcpyAsync(d_task, tasks.data(), (size_t)n * sizeof(CigarTask), hipMemcpyHostToDevice, s), "H2D tasks");
-    if (!rc) rc = bm2_check(hipMemcpyAsync(d_order, order.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, s), "H2D order");
+    rc = bm2_copy_h2d(c, b_seq.p, seqs, (size_t)seq_bytes);        // (pageable memory: through the context's pinned staging buffers)
+    if (!rc) rc = bm2_copy_h2d(c, d_task, tasks.data(), (size_t)n * sizeof(CigarTask));
+    if (!rc) rc = bm2_copy_h2d(c, d_order, order.data(), (size_t)n * sizeof(int));
     if (rc) return rc;
     if (n_small) {
         const size_t lds = (size_t)(qmax + 1) * 256 + (size_t)((qmax + 7) / 8) * 256;
@@ -345,10 +345,9 @@ static int cigar_run(bm2_ctx *c, const bm2_opt *opt, std::vector<CigarTask> &tas
     if ((rc = bm2_scan_i32(c, d_nops, n, d_cgpos, scan_tmp))) { bm2_release(scan_tmp); return rc; }
     if ((rc = bm2_scan_i32(c, d_nmd, n, d_mdpos, scan_tmp))) { bm2_release(scan_tmp); return rc; }
     cg_pos.resize((size_t)n + 1); md_pos.resize((size_t)n + 1); h_res.resize((size_t)n);
-    rc = bm2_check(hipMemcpyAsync(cg_pos.data(), d_cgpos, (size_t)(n + 1) * 8, hipMemcpyDeviceToHost, s), "D2H cigar offsets");
-    if (!rc) rc = bm2_check(hipMemcpyAsync(md_pos.data(), d_mdpos, (size_t)(n + 1) * 8, hipMemcpyDeviceToHost, s), "D2H MD offsets");
-    if (!rc) rc = bm2_check(hipMemcpyAsync(h_res.data(), d_res, (size_t)n * sizeof(CigarRes), hipMemcpyDeviceToHost, s), "D2H results");
-    if (!rc) rc = bm2_check(hipStreamSynchronize(s), "cigar offsets");
+    rc = bm2_copy_d2h(c, cg_pos.data(), d_cgpos, (size_t)(n + 1) * 8);
+    if (!rc) rc = bm2_copy_d2h(c, md_pos.data(), d_mdpos, (size_t)(n + 1) * 8);
+    if (!rc) rc = bm2_copy_d2h(c, h_res.data(), d_res, (size_t)n * sizeof(CigarRes));
     bm2_release(scan_tmp);
     if (rc) return rc;
     const int64_t n_cg = cg_pos[(size_t)n], n_md = md_pos[(size_t)n];
@@ -359,8 +358,8 @@ static int cigar_run(bm2_ctx *c, const bm2_opt *opt, std::vector<CigarTask> &tas
     hipLaunchKernelGGL(k_cigar_compact, dim3((n + 255) / 256), dim3(256), 0, s, n, d_task, d_res, d_cg, d_md, d_cgpos, d_mdpos, o_cg, o_md);
     if ((rc = bm2_check(hipGetLastError(), "k_cigar_compact launch"))) return rc;
     cg.resize((size_t)n_cg + 1); md.resize((size_t)n_md + 1);
-    if (n_cg) rc = bm2_check(hipMemcpyAsync(cg.data(), o_cg, (size_t)n_cg * 4, hipMemcpyDeviceToHost, s), "D2H cigars");
-    if (!rc && n_md) rc = bm2_check(hipMemcpyAsync(md.data(), o_md, (size_t)n_md, hipMemcpyDeviceToHost, s), "D2H MD");
+    if (n_cg) rc = bm2_copy_d2h(c, cg.data(), o_cg, (size_t)n_cg * 4);
+    if (!rc && n_md) rc = bm2_copy_d2h(c, md.data(), o_md, (size_t)n_md);
     if (!rc) rc = bm2_check(hipStreamSynchronize(s), "bm2_gen_cigar_dev sync");
     prof.mark("compact + D2H");
     return rc;

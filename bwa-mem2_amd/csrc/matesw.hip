@@ -108,17 +108,16 @@ static int ksw_batch_run(bm2_ctx *c, int32_t n, const uint8_t *qbuf, int64_t qbu
     hipStream_t s = c->stream;
     KswTask *d_task = (KswTask *)b_task.p;
     int *d_order = (int *)((char *)b_task.p + ((task_bytes + 15) & ~(size_t)15));
-    rc = bm2_check(hipMemcpyAsync(b_seq.p, qbuf, (size_t)qbuf_bytes, hipMemcpyHostToDevice, s), "H2D queries");
-    if (!rc) rc = bm2_check(hipMemcpyAsync(d_task, tasks.data(), task_bytes, hipMemcpyHostToDevice, s), "H2D tasks");
-    if (!rc) rc = bm2_check(hipMemcpyAsync(d_order, order.data(), ord_bytes, hipMemcpyHostToDevice, s), "H2D order");
+    rc = bm2_copy_h2d(c, b_seq.p, qbuf, (size_t)qbuf_bytes);       // (pageable memory: through the context's pinned staging buffers)
+    if (!rc) rc = bm2_copy_h2d(c, d_task, tasks.data(), task_bytes);
+    if (!rc) rc = bm2_copy_h2d(c, d_order, order.data(), ord_bytes);
     if (rc) return rc;
     hipLaunchKernelGGL(k_ksw_align2, dim3((n + rows - 1) / rows), dim3(rows * 16), lds, s, (const uint8_t *)b_seq.p,
                        d_tbase ? d_tbase : (const uint8_t *)b_seq.p, d_task, d_order, n, prm, slen_max, (bm2_ksw_result *)b_out.p,
                        (unsigned long long *)b_misc.p);
     rc = bm2_check(hipGetLastError(), "k_ksw_align2 launch");
     if (prof.on) { (void)hipStreamSynchronize(s); prof.mark("H2D + kernel"); }
-    if (!rc) rc = bm2_check(hipMemcpyAsync(out, b_out.p, (size_t)n * sizeof(bm2_ksw_result), hipMemcpyDeviceToHost, s), "D2H results");
-    if (!rc) rc = bm2_check(hipStreamSynchronize(s), "ksw batch sync");
+    if (!rc) rc = bm2_copy_d2h(c, out, b_out.p, (size_t)n * sizeof(bm2_ksw_result));     // (waits for the kernel: same stream)
     return rc;
 }
 
