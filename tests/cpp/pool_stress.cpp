@@ -12,8 +12,7 @@ static int caller(unsigned seed, int phases, int max_n) {
         x = x * 1664525u + 1013904223u;
         const int n = 1 + (int)((x >> 16) % (unsigned)max_n);
         std::atomic<int> copies(0);
-        volatile int sink = 0;
-        bm2_run_threads(n, [&]() { copies.fetch_add(1); if ((x >> 8) & 1) for (int i = 0; i < 2000; ++i) sink = sink + i; });
+        bm2_run_threads(n, [&]() { copies.fetch_add(1); volatile int sink = 0; if ((x >> 8) & 1) for (int i = 0; i < 2000; ++i) sink = sink + i; });
         if (copies.load() != n) { fprintf(stderr, "phase %d: %d copies ran, %d wanted\n", p, copies.load(), n); return 1; }
     }
     return 0;
