@@ -250,7 +250,7 @@ def parity_gate(ctx, bm2, prefix, workdir, seqs, regs, reg_off, opt, opt_args, p
     return res
 
 
-def end_to_end(ctx, bm2, texts, opt, paired, n_threads, n_tail=2, limit_s=None, n_dev=None):
+def end_to_end(ctx, bm2, texts, opt, paired, n_threads, n_tail=3, limit_s=None, n_dev=None):
     """FASTQ text -> SAM text over the chunks `texts` = [(bytes1, bytes2 | None)] as a pipeline of host threads: the reader
     (bm2_fastq_parse_mt), n_dev device workers (H2D, seeding .. extension, mem_sort_dedup_patch, D2H; each with a context of its own on
     the shared index replica, chunk i on worker i % n_dev, so the copies and the latency-bound kernels of one chunk overlap the kernels
