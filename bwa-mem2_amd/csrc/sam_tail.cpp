@@ -58,7 +58,7 @@ void put_int(std::string &s, long long v) {                    // kputw / kputl 
     while (l) s.push_back(b[--l]);
 }
 
-// ---- ksw_global2 with backtrack (ksw.cpp:558-668): direction byte per cell = f<<4 | e<<2 | h ---------------------------
+// ---- banded global alignment with traceback ---------------------------------------------------------------------------
 // Banded global alignment with traceback; must reproduce ksw_global2 (ksw.cpp:558-668) decision for decision, because the CIGAR of a
 // rescued hit is printed from it.  Only the rescued hits of a chunk come here (everything numbered goes through the device batch), so this
 // is written for clarity, not speed: a row is computed in three sweeps over structure-of-arrays rows -- (1) the diagonal move M and the
@@ -450,62 +450,69 @@ bool gen_alt(const bm2_opt *opt, const bm2_sam_opt *so, const Ref &R, int n, con
     return true;
 }
 
-// add_cigar, bwamem.cpp:1579-1590
-void add_cigar(const bm2_sam_opt *so, const Aln &p, std::string &s, int which) {
-    if (p.cigar.empty()) { s.push_back('*'); return; }
-    for (uint32_t cg : p.cigar) {
-        int c = cg & 0xf;
-        if (!(so->flag & F_SOFTCLIP) && !p.is_alt && (c == 3 || c == 4)) c = which ? 4 : 3;
-        put_int(s, cg >> 4); s.push_back("MIDSH"[c]);
-    }
-}
-
 int get_rlen(const std::vector<uint32_t> &cg) {                // bwamem.cpp:1820-1829
     int l = 0;
     for (uint32_t c : cg) { const int op = c & 0xf; if (op == 0 || op == 2) l += (int)(c >> 4); }
     return l;
 }
 
-// mem_aln2sam (bwamem.cpp:1592-1730); m_ = the mate's alignment or NULL
+// mem_aln2sam (bwamem.cpp:1592-1730); m_ = the mate's alignment or NULL.  The reference edits copies of the two records (an unmapped
+// read borrows its mate's position and loses its CIGAR, and the other way round); here the few fields that can change are locals and
+// the records themselves are only read -- no copies of CIGAR vectors and MD strings per printed line.
 void aln2sam(const bm2_sam_opt *so, const Ref &R, std::string &s, const char *name, const char *comment, const char *qual, int l_seq,
              const uint8_t *seq, const std::vector<Aln> &list, int which, const Aln *m_) {
     if (t_cg.mode == 1) return;                                  // dry pass of a CIGAR session: decisions only
-    Aln p = list[which], mtmp; Aln *m = 0;
+    static const std::vector<uint32_t> no_cigar;
+    const Aln &P = list[which];
     const int n = (int)list.size();
-    if (m_) { mtmp = *m_; m = &mtmp; }
-    p.flag |= m ? 0x1 : 0;
-    p.flag |= p.rid < 0 ? 0x4 : 0;
-    p.flag |= m && m->rid < 0 ? 0x8 : 0;
-    if (p.rid < 0 && m && m->rid >= 0) { p.rid = m->rid; p.pos = m->pos; p.is_rev = m->is_rev; p.cigar.clear(); }      // copy mate to alignment
-    if (m && m->rid < 0 && p.rid >= 0) { m->rid = p.rid; m->pos = p.pos; m->is_rev = p.is_rev; m->cigar.clear(); }     // copy alignment to mate
-    p.flag |= p.is_rev ? 0x10 : 0;
-    p.flag |= m && m->is_rev ? 0x20 : 0;
+    const bool has_mate = m_ != nullptr;
+    int p_rid = P.rid, p_rev = P.is_rev, p_flag = P.flag;
+    int64_t p_pos = P.pos;
+    const std::vector<uint32_t> *p_cg = &P.cigar;
+    int m_rid = has_mate ? m_->rid : -1, m_rev = has_mate ? m_->is_rev : 0;
+    int64_t m_pos = has_mate ? m_->pos : -1;
+    const std::vector<uint32_t> *m_cg = has_mate ? &m_->cigar : &no_cigar;
+    p_flag |= has_mate ? 0x1 : 0;
+    p_flag |= p_rid < 0 ? 0x4 : 0;
+    p_flag |= has_mate && m_rid < 0 ? 0x8 : 0;
+    if (p_rid < 0 && has_mate && m_rid >= 0) { p_rid = m_rid; p_pos = m_pos; p_rev = m_rev; p_cg = &no_cigar; }         // copy mate to alignment
+    if (has_mate && m_rid < 0 && p_rid >= 0) { m_rid = p_rid; m_pos = p_pos; m_rev = p_rev; m_cg = &no_cigar; }         // copy alignment to mate
+    p_flag |= p_rev ? 0x10 : 0;
+    p_flag |= has_mate && m_rev ? 0x20 : 0;
+    auto put_cigar_of = [&](const std::vector<uint32_t> &cg, int is_alt) {     // add_cigar, bwamem.cpp:1579-1590
+        if (cg.empty()) { s.push_back('*'); return; }
+        for (uint32_t c0 : cg) {
+            int c = c0 & 0xf;
+            if (!(so->flag & F_SOFTCLIP) && !is_alt && (c == 3 || c == 4)) c = which ? 4 : 3;
+            put_int(s, c0 >> 4); s.push_back("MIDSH"[c]);
+        }
+    };
     s += name; s.push_back('\t');
-    put_int(s, (p.flag & 0xffff) | (p.flag & 0x10000 ? 0x100 : 0)); s.push_back('\t');
-    if (p.rid >= 0) {
-        s += R.name[p.rid]; s.push_back('\t');
-        put_int(s, p.pos + 1); s.push_back('\t');
-        put_int(s, p.mapq); s.push_back('\t');
-        add_cigar(so, p, s, which);
+    put_int(s, (p_flag & 0xffff) | (p_flag & 0x10000 ? 0x100 : 0)); s.push_back('\t');
+    if (p_rid >= 0) {
+        s += R.name[p_rid]; s.push_back('\t');
+        put_int(s, p_pos + 1); s.push_back('\t');
+        put_int(s, P.mapq); s.push_back('\t');
+        put_cigar_of(*p_cg, P.is_alt);
     } else s += "*\t0\t0\t*";
     s.push_back('\t');
-    if (m && m->rid >= 0) {                                     // mate position and template length
-        if (p.rid == m->rid) s.push_back('='); else s += R.name[m->rid];
+    if (has_mate && m_rid >= 0) {                                // mate position and template length
+        if (p_rid == m_rid) s.push_back('='); else s += R.name[m_rid];
         s.push_back('\t');
-        put_int(s, m->pos + 1); s.push_back('\t');
-        if (p.rid == m->rid) {
-            const int64_t p0 = p.pos + (p.is_rev ? get_rlen(p.cigar) - 1 : 0), p1 = m->pos + (m->is_rev ? get_rlen(m->cigar) - 1 : 0);
-            if (m->cigar.empty() || p.cigar.empty()) s.push_back('0');
+        put_int(s, m_pos + 1); s.push_back('\t');
+        if (p_rid == m_rid) {
+            const int64_t p0 = p_pos + (p_rev ? get_rlen(*p_cg) - 1 : 0), p1 = m_pos + (m_rev ? get_rlen(*m_cg) - 1 : 0);
+            if (m_cg->empty() || p_cg->empty()) s.push_back('0');
             else put_int(s, -(p0 - p1 + (p0 > p1 ? 1 : p0 < p1 ? -1 : 0)));
         } else s.push_back('0');
     } else s += "*\t0\t0";
     s.push_back('\t');
-    if (p.flag & 0x100) s += "*\t*";
+    if (p_flag & 0x100) s += "*\t*";
     else {
         int qb = 0, qe = l_seq;
-        if (!p.cigar.empty() && which && !(so->flag & F_SOFTCLIP) && !p.is_alt) {
-            const uint32_t c0 = p.cigar[0], c1 = p.cigar.back();
-            if (!p.is_rev) {
+        if (!p_cg->empty() && which && !(so->flag & F_SOFTCLIP) && !P.is_alt) {
+            const uint32_t c0 = (*p_cg)[0], c1 = p_cg->back();
+            if (!p_rev) {
                 if ((c0 & 0xf) == 4 || (c0 & 0xf) == 3) qb += c0 >> 4;
                 if ((c1 & 0xf) == 4 || (c1 & 0xf) == 3) qe -= c1 >> 4;
             } else {
@@ -513,22 +520,26 @@ void aln2sam(const bm2_sam_opt *so, const Ref &R, std::string &s, const char *na
                 if ((c1 & 0xf) == 4 || (c1 & 0xf) == 3) qb += c1 >> 4;
             }
         }
-        if (!p.is_rev) {
-            for (int i = qb; i < qe; ++i) s.push_back("ACGTN"[seq[i]]);
-            s.push_back('\t');
-            if (qual) s.append(qual + qb, (size_t)(qe - qb)); else s.push_back('*');
+        const size_t len = qe > qb ? (size_t)(qe - qb) : 0, at = s.size();
+        s.resize(at + 2 * len + 1 + (qual ? 0 : 1));             // bases, tab, qualities (or '*') written in place
+        char *d = &s[at];
+        if (!p_rev) {
+            for (size_t i = 0; i < len; ++i) d[i] = "ACGTN"[seq[qb + (int)i]];
+            d[len] = '\t';
+            if (qual) memcpy(d + len + 1, qual + qb, len); else d[len + 1] = '*';
         } else {
-            for (int i = qe - 1; i >= qb; --i) s.push_back("TGCAN"[seq[i]]);
-            s.push_back('\t');
-            if (qual) { for (int i = qe - 1; i >= qb; --i) s.push_back(qual[i]); } else s.push_back('*');
+            for (size_t i = 0; i < len; ++i) d[i] = "TGCAN"[seq[qe - 1 - (int)i]];
+            d[len] = '\t';
+            if (qual) { for (size_t i = 0; i < len; ++i) d[len + 1 + i] = qual[qe - 1 - (int)i]; } else d[len + 1] = '*';
         }
+        if (!qual) s.resize(at + len + 2);
     }
-    if (!p.cigar.empty()) { s += "\tNM:i:"; put_int(s, p.NM); s += "\tMD:Z:"; s += p.MD; }
-    if (m && !m->cigar.empty()) { s += "\tMC:Z:"; add_cigar(so, *m, s, which); }
-    if (p.score >= 0) { s += "\tAS:i:"; put_int(s, p.score); }
-    if (p.sub >= 0) { s += "\tXS:i:"; put_int(s, p.sub); }
+    if (!p_cg->empty()) { s += "\tNM:i:"; put_int(s, P.NM); s += "\tMD:Z:"; s += P.MD; }
+    if (has_mate && !m_cg->empty()) { s += "\tMC:Z:"; put_cigar_of(*m_cg, m_->is_alt); }
+    if (P.score >= 0) { s += "\tAS:i:"; put_int(s, P.score); }
+    if (P.sub >= 0) { s += "\tXS:i:"; put_int(s, P.sub); }
     if (so->rg_id && so->rg_id[0]) { s += "\tRG:Z:"; s += so->rg_id; }
-    if (!(p.flag & 0x100)) {
+    if (!(p_flag & 0x100)) {
         int i;
         for (i = 0; i < n; ++i) if (i != which && !(list[i].flag & 0x100)) break;
         if (i < n) {
@@ -541,13 +552,13 @@ void aln2sam(const bm2_sam_opt *so, const Ref &R, std::string &s, const char *na
                 s.push_back(','); put_int(s, r.mapq); s.push_back(','); put_int(s, r.NM); s.push_back(';');
             }
         }
-        if (p.alt_sc > 0) { char b[64]; snprintf(b, sizeof b, "\tpa:f:%.3f", (double)p.score / p.alt_sc); s += b; }
+        if (P.alt_sc > 0) { char b[64]; snprintf(b, sizeof b, "\tpa:f:%.3f", (double)P.score / P.alt_sc); s += b; }
     }
-    if (p.XA) { s += "\tXA:Z:"; s += *p.XA; }
+    if (P.XA) { s += "\tXA:Z:"; s += *P.XA; }
     if (comment) { s.push_back('\t'); s += comment; }
-    if ((so->flag & F_REF_HDR) && p.rid >= 0 && R.anno && R.anno[p.rid] && R.anno[p.rid][0]) {
+    if ((so->flag & F_REF_HDR) && p_rid >= 0 && R.anno && R.anno[p_rid] && R.anno[p_rid][0]) {
         s += "\tXR:Z:";
-        for (const char *c = R.anno[p.rid]; *c; ++c) s.push_back(*c == '\t' ? ' ' : *c);
+        for (const char *c = R.anno[p_rid]; *c; ++c) s.push_back(*c == '\t' ? ' ' : *c);
     }
     s.push_back('\n');
 }
