@@ -45,6 +45,25 @@ def main():
         q = bench.end_to_end(ctx, bm2, texts[1:], opt, True, 0)
         r["splits"].append({"tail_workers": int(tails), "threads_per_worker": int(threads), "value": q["value"], "stage_ms_per_chunk": q["stage_ms_per_chunk"]})
         print("[probe] %s workers x %s threads: %.2f M reads/s %s" % (tails, threads, q["value"] / 1e6, {k: round(v) for k, v in q["stage_ms_per_chunk"].items()}), file=sys.stderr, flush=True)
+    r["variants"] = []                                      # PROBE_ENVS="BM2_E2E_DEVS=1 BM2_TAIL_PIN=0,BM2_E2E_DEVS=1 ...": the leg again under each setting
+    for spec in os.environ.get("PROBE_ENVS", "").split():
+        kv = dict(x.split("=", 1) for x in spec.split(","))
+        old = {k: os.environ.get(k) for k in kv}
+        os.environ.update(kv)
+        os.environ.pop("BM2_TAIL_PROF", None); os.environ.pop("BM2_E2E_TAILS", None); os.environ.pop("BM2_E2E_TAIL_THREADS", None)
+        os.environ.update(kv)
+        try:
+            q = bench.end_to_end(ctx, bm2, texts[1:], opt, True, 0, limit_s=120)
+            r["variants"].append({"env": kv, "value": q["value"], "stage_ms_per_chunk": q["stage_ms_per_chunk"]})
+            print("[probe] %s: %.2f M reads/s %s" % (spec, q["value"] / 1e6, {k: round(v) for k, v in q["stage_ms_per_chunk"].items()}), file=sys.stderr, flush=True)
+        except Exception as e:                                # noqa
+            print("[probe] %s: FAILED %s" % (spec, e), file=sys.stderr, flush=True)
+            break
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
     print("[probe] rescue stats (planned, used, missed):", bm2.sam_rescue_stats(), "cigar stats:", bm2.sam_cigar_stats(), file=sys.stderr, flush=True)
     json.dump(r, open(os.path.join(out, "tail_probe.json"), "w"), indent=1)
     print(json.dumps(r), flush=True)
