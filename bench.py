@@ -389,13 +389,108 @@ def end_to_end(ctx, bm2, texts, opt, paired, n_threads, n_tail=3, limit_s=None, 
                      % (n_dev, n_tail)}
 
 
+TASKS_PER_READ = 2.874          # extension tasks per 150 bp read of the pe150 workload (work_per_read.sw_tasks of its bench line)
+
+
+def make_extension_pairs(seed, n, max_q=131, sub_rate=0.012):
+    """n synthetic (query, target, h0) extension tasks shaped like those mem_chain2aln builds for 150 bp reads (bwamem.cpp:2229-2418): the
+    query is what is left of the read beside a seed (1 .. 131 bases), the target the reference beside the seed's hit plus the room the
+    band allows, h0 the seed's score; the query is the target's head with substitutions, one task in seven diverges half way (Z-drop).
+    Vectorised: -> (len2[n], len1[n], h0[n], qer flat, ref flat) with pair i's bases at the prefix sums of the lengths."""
+    rng = np.random.default_rng(seed)
+    len2 = rng.integers(1, max_q + 1, size=n).astype(np.int32)
+    len1 = (len2 + rng.integers(0, 45, size=n)).astype(np.int32)
+    h0 = (150 - len2 - rng.integers(0, np.maximum(150 - len2 - 18, 1))).clip(19, 150).astype(np.int32)
+    roff = np.concatenate([[0], np.cumsum(len1, dtype=np.int64)]); qoff = np.concatenate([[0], np.cumsum(len2, dtype=np.int64)])
+    ref = rng.integers(0, 4, size=int(roff[-1]), dtype=np.uint8)
+    src = np.arange(int(qoff[-1]), dtype=np.int64) - np.repeat(qoff[:-1], len2) + np.repeat(roff[:-1], len2)      # query base k of pair i = target base k
+    qer = ref[src]
+    flip = rng.random(len(qer)) < sub_rate
+    qer[flip] = (qer[flip] + rng.integers(1, 4, size=int(flip.sum()), dtype=np.uint8)) & 3
+    div = np.flatnonzero(rng.random(n) < 1.0 / 7)                 # divergent tails: random bases from the middle of the query on
+    if len(div):
+        pos = np.arange(int(qoff[-1]), dtype=np.int64) - np.repeat(qoff[:-1], len2)
+        tail = np.zeros(n, bool); tail[div] = True
+        m = np.repeat(tail, len2) & (pos >= np.repeat(len2 // 2, len2))
+        qer[m] = rng.integers(0, 4, size=int(m.sum()), dtype=np.uint8)
+    return len2, len1, h0, qer, ref, qoff, roff
+
+
+def bench_bsw(a, bm2, torch, dist_util, rank, world, local, emu, seed):
+    """BASELINE.json config 2: the banded-SW kernel alone (S1, one SeqPair per wavefront), the batch resident in HBM."""
+    from tools import oracle
+    n = a.bsw_pairs
+    len2, len1, h0, qer, ref, qoff, roff = make_extension_pairs(dist_util.shard_seed(seed, rank), n)
+    pairs = np.zeros(n, bm2.SEQPAIR_DT)
+    pairs["idr"], pairs["idq"], pairs["id"] = roff[:-1], qoff[:-1], np.arange(n)
+    pairs["len1"], pairs["len2"], pairs["h0"] = len1, len2, h0
+    opt = bm2.default_opt()
+    w, end_bonus = 100, 5
+    prm = bm2.sw_params(opt, end_bonus)
+    ctx = bm2.Context(local)
+    ctx.bsw_upload(pairs, ref, qer)
+    _, cells = ctx.bsw_run(w, prm, count_cells=True)             # untimed: the cell counter costs an atomic per pair
+    for _ in range(a.warmup):
+        ctx.bsw_run(w, prm)
+    torch.cuda.synchronize()
+    dist_util.barrier(world)
+    t0 = time.perf_counter()
+    k_ms = 0.0
+    for _ in range(a.steps):
+        ms, _ = ctx.bsw_run(w, prm)                              # returns after the stream has drained
+        k_ms += ms
+    torch.cuda.synchronize()
+    dist_util.barrier(world)
+    dt = dist_util.max_over_ranks(time.perf_counter() - t0, world, "cpu" if emu else "cuda")
+    got = ctx.bsw_download()
+    ctx.close()
+    if rank != 0:
+        return 0
+    steps = max(a.steps, 1)
+    k_ms /= steps
+    n_s = min(n, 3000)                                           # parity + CPU baseline: the oracle's ksw_extend2 restatement on a sample, one host thread
+    oopt = oracle.default_opt()
+    t = time.time(); bad = 0
+    for i in range(n_s):
+        exp = oracle.ksw_extend(qer[qoff[i]:qoff[i + 1]], ref[roff[i]:roff[i + 1]], oopt, w, end_bonus, int(h0[i]))
+        if tuple(int(got[i][f]) for f in ("score", "qle", "tle", "gtle", "gscore", "max_off")) != exp:
+            bad += 1
+    cpu_s = time.time() - t
+    algo_bytes = float(int(roff[-1]) + int(qoff[-1]) + 2 * n * pairs.dtype.itemsize)     # every base once, every SeqPair read and written
+    out = {
+        "metric": "aligned reads/s (150bp PE vs GRCh38) at 1/2/4/8 GPU; SAM bit-exact vs ref",
+        "value": world * n / TASKS_PER_READ * a.steps / dt, "unit": "reads/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32",
+        "data": "synthetic" if not emu else "synthetic; HOST EMULATOR RUN (not a measurement)",
+        "config": {"workload": "config 2 shape: the banded-SW kernel alone (S1: bm2_bsw_upload / bm2_bsw_run, one SeqPair per wavefront, band %d) on %d "
+                               "synthetic extension tasks per GPU per step shaped like those of 150 bp reads, batch resident in HBM; `value` = tasks/s "
+                               "divided by the %.3f tasks per read the pe150 workload measures" % (w, n, TASKS_PER_READ),
+                   "pairs_per_gpu_per_step": n, "tasks_per_read": TASKS_PER_READ, "parallelism": "one batch per GPU over %d GPU(s), no collectives" % world},
+        "pairs_per_s": world * n * a.steps / dt,
+        "roofline": {"kernel": "k_bsw_pairs", "bound": "hbm", "achieved": algo_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": algo_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if k_ms > 0 else 0.0, "traffic": None,
+                     "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": k_ms, "launches_per_step": 1,
+                     "note": "integer DP: the kernel is bound by VALU / LDS issue, not by HBM (each base is read once); `extend_kernel.gcups` is its rate"},
+        "extend_kernel": {"kernel": "k_bsw_pairs", "gcups": cells / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0, "avg_launch_ms": k_ms, "cells_per_launch": cells},
+        "parity": {"pairs": n_s, "sample": "the first %d pairs against the oracle's ksw_extend2 restatement (all six outputs)" % n_s, "pairs_equal": bad == 0,
+                   "mismatches": bad},
+        "cpu_baseline": {"value": n_s / cpu_s / TASKS_PER_READ if cpu_s > 0 else None, "unit": "reads/s", "cores": 1, "kind": "port",
+                         "sample": "%d pairs through oracle/bm2_oracle.c (ora_ksw_extend_cls) from Python, one thread, %.1f s" % (n_s, cpu_s)},
+    }
+    print(json.dumps(out), flush=True)
+    return 0 if bad == 0 else 3
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="pe150", choices=["pe150", "ont2d"],
-                    help="pe150: BASELINE config 3 shape (the metric); ont2d: config 5 shape (10 kb reads, -x ont2d)")
+    ap.add_argument("--workload", default="pe150", choices=["pe150", "ont2d", "bsw"],
+                    help="pe150: BASELINE config 3 shape (the metric); ont2d: config 5 shape (10 kb reads, -x ont2d); bsw: config 2 shape "
+                         "(the banded-SW kernel alone on the extension tasks of 150 bp reads, batch resident: S1 = bm2_bsw_upload / _run / _download)")
+    ap.add_argument("--bsw-pairs", type=int, default=int(os.environ.get("BM2_BENCH_BSW_PAIRS", 2874000)),
+                    help="bsw: extension tasks per step (default = the 2.874 tasks per read the pe150 workload measures x 1 M reads)")
     ap.add_argument("--genome-mbp", type=int, default=int(os.environ.get("BM2_BENCH_GENOME_MBP", 3100)))
     ap.add_argument("--reads", type=int, default=int(os.environ.get("BM2_BENCH_READS", 0)),
                     help="reads per GPU per step (both mates counted); default 1000000 (pe150) / 2000 (ont2d)")
@@ -435,6 +530,10 @@ def main():
 
     os.makedirs(a.workdir, exist_ok=True)
     seed = 20260924
+    if a.workload == "bsw":
+        rc = bench_bsw(a, bm2, torch, dist_util, rank, world, local, emu, seed)
+        dist_util.finish(world)
+        sys.exit(rc)
     if rank == 0:
         prefix, contigs = prepare_genome(a.workdir, a.genome_mbp, seed)
     dist_util.barrier(world)

@@ -90,7 +90,7 @@ class Stats(C.Structure):
 
 
 EXPORTS = ["bm2_index_load", "bm2_index_free", "bm2_opt_init", "bm2_opt_fill_scmat", "bm2_create", "bm2_create_shared", "bm2_destroy",
-           "bm2_last_error", "bm2_device_count", "bm2_bsw", "bm2_smem", "bm2_sal", "bm2_seed_chain_extend",
+           "bm2_last_error", "bm2_device_count", "bm2_bsw", "bm2_bsw_upload", "bm2_bsw_run", "bm2_bsw_download", "bm2_smem", "bm2_sal", "bm2_seed_chain_extend",
            "bm2_batch_upload", "bm2_batch_run", "bm2_batch_stats", "bm2_batch_download", "bm2_batch_kernel_ms",
            "bm2_batch_fetch", "bm2_batch_finish", "bm2_batch_download_alnregs", "bm2_finish_regs_dev", "bm2_chunk_hits_sharded", "bm2_index_build", "bm2_sam_opt_init", "bm2_sam_se", "bm2_sam_pe", "bm2_fastq_parse", "bm2_fastq_parse_mt", "bm2_fastq_free", "bm2_ksw_align2", "bm2_ksw_align2_dev", "bm2_sam_pe_dev", "bm2_sam_se_dev", "bm2_sam_cigar_stats", "bm2_gen_cigar", "bm2_gen_cigar_dev", "bm2_sam_header", "bm2_sam_rescue_stats"]
 
@@ -279,6 +279,31 @@ class Context:
         _chk(lib().bm2_bsw(self.h, pairs.ctypes.data, ref.ctypes.data, len(ref), qer.ctypes.data, len(qer), len(pairs), w,
                            C.byref(params)), "bm2_bsw")
         return pairs
+
+    def bsw_upload(self, pairs, ref, qer):
+        """S1 with the batch resident: upload once (bm2_bsw_upload), bsw_run any number of times, bsw_download."""
+        pairs = np.ascontiguousarray(pairs, SEQPAIR_DT)
+        ref = np.ascontiguousarray(ref, np.uint8)
+        qer = np.ascontiguousarray(qer, np.uint8)
+        L = lib()
+        L.bm2_bsw_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32]
+        _chk(L.bm2_bsw_upload(self.h, pairs.ctypes.data, ref.ctypes.data, len(ref), qer.ctypes.data, len(qer), len(pairs)), "bm2_bsw_upload")
+        self._n_bsw = len(pairs)
+
+    def bsw_run(self, w, params, count_cells=False):
+        """-> (kernel ms from HIP events, DP cells or None); counting the cells costs an atomic per pair: not in a timed run."""
+        L = lib()
+        L.bm2_bsw_run.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int64)]
+        ms, cells = C.c_float(0), C.c_int64(0)
+        _chk(L.bm2_bsw_run(self.h, w, C.byref(params), C.byref(ms), C.byref(cells) if count_cells else None), "bm2_bsw_run")
+        return ms.value, (cells.value if count_cells else None)
+
+    def bsw_download(self):
+        out = np.zeros(self._n_bsw, SEQPAIR_DT)
+        L = lib()
+        L.bm2_bsw_download.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+        _chk(L.bm2_bsw_download(self.h, out.ctypes.data, len(out)), "bm2_bsw_download")
+        return out
 
     # S2
     def smem(self, enc, off, ln, opt, cap=None):

@@ -253,6 +253,7 @@ extern "C" int bm2_bsw(bm2_ctx *c, bm2_seqpair_t *pairs, const uint8_t *ref, int
     P.o_del = p->o_del; P.e_del = p->e_del; P.o_ins = p->o_ins; P.e_ins = p->e_ins; P.zdrop = p->zdrop;
     P.end_bonus = p->end_bonus; P.max_sc = p->w_match;
     for (int i = 0; i < 25; i++) P.mat[i] = p->mat[i];
+    c->n_bsw = 0;                                               // (the scratch buffers are shared with the resident variant)
     hipStream_t s = c->stream;
     rc = bm2_check(hipMemcpyAsync(c->b_pairs.p, pairs, (size_t)n * sizeof(bm2_seqpair_t), hipMemcpyHostToDevice, s), "H2D pairs");
     if (!rc) rc = bm2_check(hipMemcpyAsync(c->b_ref.p, ref, (size_t)ref_bytes, hipMemcpyHostToDevice, s), "H2D ref");
@@ -261,4 +262,66 @@ extern "C" int bm2_bsw(bm2_ctx *c, bm2_seqpair_t *pairs, const uint8_t *ref, int
     if (!rc) rc = bm2_check(hipMemcpyAsync(pairs, c->b_pairs.p, (size_t)n * sizeof(bm2_seqpair_t), hipMemcpyDeviceToHost, s), "D2H pairs");
     if (!rc) rc = bm2_check(hipStreamSynchronize(s), "bm2_bsw sync");
     return rc;
+}
+
+// S1 with the batch RESIDENT (config 2 of BASELINE.json = the banded-SW kernel alone, timed without the PCIe copies): upload once, run
+// any number of times -- the kernel only writes the six output fields of a pair -- download when done.  bm2_bsw_run reports the kernel's
+// duration from HIP events on the launch stream and, if asked, the DP cells it computed (its own counter: one same-address atomic per
+// pair, which a timed run should not pay -- ask for the cells in a run of their own).
+static SwParams sw_params_of(const bm2_sw_params *p) {
+    SwParams P;
+    P.o_del = p->o_del; P.e_del = p->e_del; P.o_ins = p->o_ins; P.e_ins = p->e_ins; P.zdrop = p->zdrop;
+    P.end_bonus = p->end_bonus; P.max_sc = p->w_match;
+    for (int i = 0; i < 25; i++) P.mat[i] = p->mat[i];
+    return P;
+}
+extern "C" int bm2_bsw_upload(bm2_ctx *c, const bm2_seqpair_t *pairs, const uint8_t *ref, int64_t ref_bytes, const uint8_t *qer,
+                              int64_t qer_bytes, int32_t n) {
+    if (!c || n < 0 || (n > 0 && (!pairs || !ref || !qer)) || ref_bytes < 0 || qer_bytes < 0) { bm2_set_error("bm2_bsw_upload: bad argument"); return BM2_EINVAL; }
+    int rc = bm2_check(hipSetDevice(c->device), "hipSetDevice");
+    if (rc) return rc;
+    c->n_bsw = 0;
+    if (n == 0) return BM2_OK;
+    if ((rc = bm2_reserve(c->b_pairs, (size_t)n * sizeof(bm2_seqpair_t)))) return rc;
+    if ((rc = bm2_reserve(c->b_ref, (size_t)ref_bytes + 64))) return rc;
+    if ((rc = bm2_reserve(c->b_qer, (size_t)qer_bytes + 64))) return rc;
+    if ((rc = bm2_reserve(c->b_misc, 64))) return rc;
+    if ((rc = bm2_copy_h2d(c, c->b_pairs.p, pairs, (size_t)n * sizeof(bm2_seqpair_t)))) return rc;
+    if ((rc = bm2_copy_h2d(c, c->b_ref.p, ref, (size_t)ref_bytes))) return rc;
+    if ((rc = bm2_copy_h2d(c, c->b_qer.p, qer, (size_t)qer_bytes))) return rc;
+    c->n_bsw = n;
+    return BM2_OK;
+}
+extern "C" int bm2_bsw_run(bm2_ctx *c, int32_t w, const bm2_sw_params *p, float *kernel_ms, int64_t *cells) {
+    if (!c || !p || w < 0) { bm2_set_error("bm2_bsw_run: bad argument"); return BM2_EINVAL; }
+    if (p->e_del <= 0 || p->e_ins <= 0) { bm2_set_error("bm2_bsw_run: gap extension penalties must be > 0"); return BM2_EINVAL; }
+    if (kernel_ms) *kernel_ms = 0.f;
+    if (cells) *cells = 0;
+    if (c->n_bsw == 0) return BM2_OK;
+    int rc = bm2_check(hipSetDevice(c->device), "hipSetDevice");
+    if (rc) return rc;
+    hipStream_t s = c->stream;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if ((rc = bm2_check(hipEventCreate(&e0), "hipEventCreate")) || (rc = bm2_check(hipEventCreate(&e1), "hipEventCreate"))) { if (e0) (void)hipEventDestroy(e0); return rc; }
+    unsigned long long *d_cells = (unsigned long long *)c->b_misc.p;
+    rc = bm2_check(hipMemsetAsync(d_cells, 0, sizeof(unsigned long long), s), "memset cells");
+    if (!rc) rc = bm2_check(hipEventRecord(e0, s), "hipEventRecord");
+    if (!rc) rc = bm2_launch_bsw_pairs(c, (bm2_seqpair_t *)c->b_pairs.p, (const uint8_t *)c->b_ref.p, (const uint8_t *)c->b_qer.p, c->n_bsw, w, sw_params_of(p), cells ? d_cells : nullptr);
+    if (!rc) rc = bm2_check(hipEventRecord(e1, s), "hipEventRecord");
+    unsigned long long h_cells = 0;
+    if (!rc) rc = bm2_check(hipMemcpyAsync(&h_cells, d_cells, sizeof h_cells, hipMemcpyDeviceToHost, s), "D2H cells");
+    if (!rc) rc = bm2_check(hipStreamSynchronize(s), "bm2_bsw_run sync");
+    float ms = 0.f;
+    if (!rc) rc = bm2_check(hipEventElapsedTime(&ms, e0, e1), "hipEventElapsedTime");
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (!rc) { if (kernel_ms) *kernel_ms = ms; if (cells) *cells = (int64_t)h_cells; }
+    return rc;
+}
+extern "C" int bm2_bsw_download(bm2_ctx *c, bm2_seqpair_t *pairs, int32_t n) {
+    if (!c || n < 0 || (n > 0 && !pairs)) { bm2_set_error("bm2_bsw_download: bad argument"); return BM2_EINVAL; }
+    if (n != c->n_bsw) { bm2_set_error("bm2_bsw_download: %d pairs asked for, %d are resident", n, c->n_bsw); return BM2_EINVAL; }
+    if (n == 0) return BM2_OK;
+    int rc = bm2_check(hipSetDevice(c->device), "hipSetDevice");
+    if (rc) return rc;
+    return bm2_copy_d2h(c, pairs, c->b_pairs.p, (size_t)n * sizeof(bm2_seqpair_t));
 }

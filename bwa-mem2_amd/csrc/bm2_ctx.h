@@ -23,6 +23,7 @@ struct bm2_ctx {
     void *d_ann_off = nullptr, *d_ann_len = nullptr, *d_ann_alt = nullptr;
     // scratch for the S1/S2 entry points
     DevBuf b_pairs, b_pairs2, b_ref, b_qer, b_misc;
+    int n_bsw = 0;                 // pairs of the resident S1 batch (bm2_bsw_upload)
     // batch state of the S3 path (see pipeline.hip)
     struct Batch *batch = nullptr;
     // per-kernel timers of the last bm2_batch_run

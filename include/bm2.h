@@ -135,6 +135,13 @@ int      bm2_device_count(void);
  * three entry points do.  ref/qer are the flat seqBuf arrays indexed by idr/idq. */
 int bm2_bsw(bm2_ctx *c, bm2_seqpair_t *pairs, const uint8_t *ref, int64_t ref_bytes, const uint8_t *qer,
             int64_t qer_bytes, int32_t n, int32_t w, const bm2_sw_params *p);
+/* The same with the batch resident in HBM (BASELINE.json config 2: the banded-SW kernel alone, timed without the copies): upload once,
+ * run any number of times (the kernel writes only the six output fields), download.  kernel_ms = duration of the kernel from HIP
+ * events on its stream, cells = DP cells computed (either may be NULL; counting costs an atomic per pair: ask for it in an untimed run). */
+int bm2_bsw_upload(bm2_ctx *c, const bm2_seqpair_t *pairs, const uint8_t *ref, int64_t ref_bytes, const uint8_t *qer,
+                   int64_t qer_bytes, int32_t n);
+int bm2_bsw_run(bm2_ctx *c, int32_t w, const bm2_sw_params *p, float *kernel_ms, int64_t *cells);
+int bm2_bsw_download(bm2_ctx *c, bm2_seqpair_t *pairs, int32_t n);
 
 /* ---- S2: mem_collect_smem (bwamem.cpp:626-803) = getSMEMsAllPosOneThread + the pass-2 selection +
  * getSMEMsOnePosOneThread + bwtSeedStrategyAllPosOneThread + sortSMEMs (FMI_search.h:106-165).

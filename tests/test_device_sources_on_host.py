@@ -113,6 +113,35 @@ print("ok", len(sets))
     assert p.returncode == 0 and p.stdout.startswith(b"ok"), p.stderr.decode()[-2000:]
 
 
+def test_resident_s1_batch_on_the_emulator(emu_lib):
+    # bm2_bsw_upload / bm2_bsw_run / bm2_bsw_download (config 2 of bench.py: the batch stays in HBM between runs): the results of bm2_bsw,
+    # the same again on a second run (the kernel writes only the output fields), the cell count of the kernel's own counter
+    script = r'''
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np, bm2
+bm2.LIB_PATH = %r
+from helpers import pack_pairs, random_pairs
+ctx = bm2.Context(0, None)
+opt = bm2.default_opt()
+pairs, ref, qer = pack_pairs(bm2, random_pairs(77, 60, max_len=60))
+prm = bm2.sw_params(opt, 5)
+exp = ctx.bsw(pairs.copy(), ref, qer, 100, prm)
+ctx.bsw_upload(pairs, ref, qer)
+ms, cells = ctx.bsw_run(100, prm, count_cells=True)
+a = ctx.bsw_download()
+ctx.bsw_run(100, prm)
+b = ctx.bsw_download()
+assert a.tobytes() == exp.tobytes() and b.tobytes() == exp.tobytes() and cells > 0
+import bench
+l2, l1, h0, q, r, qo, ro = bench.make_extension_pairs(3, 500)
+assert len(q) == qo[-1] == l2.sum() and len(r) == ro[-1] == l1.sum() and (l1 >= l2).all() and h0.min() >= 19 and q.max() < 4
+print("ok", cells)
+''' % (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "bwa-mem2_amd"), emu_lib)
+    p = subprocess.run(["python", "-c", script], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
+    assert p.returncode == 0 and p.stdout.startswith(b"ok"), p.stderr.decode()[-2000:]
+
+
 def test_rescue_kernel_and_sam_pe_dev_on_the_emulator(emu_lib, tmp_path):
     # k_ksw_align2 through its real launcher (task records, size-sorted order, LDS layout, list offsets) and bm2_sam_pe_dev end to end
     # (the host plans, the emulated device aligns against its reference replica, the host replays): same results as the host kernel,

@@ -30,6 +30,11 @@ if [ $(left) -gt 120 ]; then
   timeout $(( $(left) - 60 )) python tools/gpu/sweep.py $O --steps 4 --budget-s 60 > $O/sweep.out 2> $O/sweep.err; echo "sweep rc=$? at $(( $(date +%s) - T0 ))s"
   grep "\[sweep\]" $O/sweep.err | tail -30
 fi
+# 3b. config 2 (the S1 kernel alone, batch resident)
+cd $R
+if [ $(left) -gt 60 ]; then
+  timeout 50 python bench.py --workload bsw --steps 5 --warmup 2 > $O/bench_bsw.json 2> $O/bench_bsw.err; echo "bsw rc=$? at $(( $(date +%s) - T0 ))s"; head -c 600 $O/bench_bsw.json; echo
+fi
 # 4. kernel trace of the defaults (k_ext_lanes: did the shorter DP cell pay?)
 cd /tmp
 if [ $(left) -gt 45 ]; then
