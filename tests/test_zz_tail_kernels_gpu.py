@@ -116,3 +116,34 @@ def test_device_gen_cigar_equals_host(gpu_ctx_factory, tmp_path, kw):
     got = bm2.gen_cigar(fa, opt, tasks, ctx=gpu_ctx_factory(fa))
     bad = [i for i, (x, y) in enumerate(zip(exp, got)) if x != y]
     assert not bad, "%d of %d differ; first: task %d %s host %s device %s" % (len(bad), len(tasks), bad[0], tasks[bad[0]][1:], exp[bad[0]], got[bad[0]])
+
+
+def test_s1_batch_resident_between_runs(gpu_ctx_factory):
+    # bm2_bsw_upload / bm2_bsw_run / bm2_bsw_download (what `bench.py --workload bsw` times): the results of bm2_bsw, unchanged by a second
+    # run over the resident batch, the kernel's own cell counter, and bench.py's synthetic extension tasks against the oracle
+    # (last in the suite: the entry points are new)
+    from helpers import pack_pairs, random_pairs
+    from tools import oracle
+    ctx = gpu_ctx_factory()
+    opt = bm2.default_opt()
+    prm = bm2.sw_params(opt, 5)
+    pairs, ref, qer = pack_pairs(bm2, random_pairs(91, 2000))
+    exp = ctx.bsw(pairs.copy(), ref, qer, 100, prm)
+    ctx.bsw_upload(pairs, ref, qer)
+    ms, cells = ctx.bsw_run(100, prm, count_cells=True)
+    first = ctx.bsw_download()
+    ms2, _ = ctx.bsw_run(100, prm)
+    second = ctx.bsw_download()
+    assert first.tobytes() == exp.tobytes() and second.tobytes() == exp.tobytes()
+    assert cells > 0 and ms2 >= 0.0
+    import bench
+    l2, l1, h0, q, r, qo, ro = bench.make_extension_pairs(5, 1500)
+    sp = np.zeros(len(l2), bm2.SEQPAIR_DT)
+    sp["idr"], sp["idq"], sp["id"], sp["len1"], sp["len2"], sp["h0"] = ro[:-1], qo[:-1], np.arange(len(l2)), l1, l2, h0
+    ctx.bsw_upload(sp, r, q)
+    ctx.bsw_run(100, prm)
+    got = ctx.bsw_download()
+    oopt = oracle.default_opt()
+    for i in range(len(l2)):
+        e = oracle.ksw_extend(q[qo[i]:qo[i + 1]], r[ro[i]:ro[i + 1]], oopt, 100, 5, int(h0[i]))
+        assert tuple(int(got[i][f]) for f in ("score", "qle", "tle", "gtle", "gscore", "max_off")) == e, i
