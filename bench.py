@@ -18,8 +18,10 @@ Prints ONE JSON line on rank 0 (see the driver contract in the task statement) w
   parity       -- the gate: a 512-aligned PREFIX of the timed chunk (the block rule of bwamem.cpp:834 makes a prefix the only valid
                   sample) through the reference on the same index: regs before / after mem_sort_dedup_patch byte for byte against
                   oracle/_ref/refdump, SAM text against `bwa-mem2 mem`.  A mismatch makes the run fail (exit code 3).
-  end_to_end   -- the metric as stated: FASTQ text in host memory -> SAM text in host memory over several distinct chunks, the
-                  host tail of chunk n overlapping the device work of chunk n+1 (reported beside `value`, never instead of it)
+  end_to_end   -- the metric as stated: FASTQ text in host memory -> SAM text in host memory over several distinct chunks through a
+                  pipeline of host threads (reader | device workers | tail workers), the stages of consecutive chunks overlapping
+                  (reported beside `value`, never instead of it); under a watchdog, inside the run's time budget (--budget-s)
+--workload ont2d / bsw: BASELINE configs 5 and 2 as workloads of their own (same JSON shape).
 """
 import argparse
 import json
