@@ -191,6 +191,20 @@ def test_sam_pe_rescue_batched_equals_inline(tmp_path, monkeypatch):
     assert got4 == got and cu >= cp > 2000 and cm == 0, (cp, cu, cm)
 
 
+def test_sam_pe_text_does_not_depend_on_threads_or_batching(tmp_path, monkeypatch):
+    # the worker pool, the in-order text commit and the scanned placement of the rescue batch: the same bytes with 1, 3 and 16 threads
+    # (more than this machine has), with the alignments in place, as host batches and with the CIGAR session
+    fa, r1, r2 = _pe_case(tmp_path, 59, 1800, sub_rate=0.03, indel_frac=0.3, random_frac=0.04)
+    ref, base, pes = _pe_run(tmp_path, fa, r1, r2, [], n_threads=1)
+    assert ref == base, _diff(ref, base)
+    for env in ({}, {"BM2_RESCUE_FLAT": "1", "BM2_CIGAR_FLAT": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        for nt in (1, 3, 16):
+            _, got, _ = _pe_run(tmp_path, fa, r1, r2, [], n_threads=nt)
+            assert got == base, (env, nt)
+
+
 def test_sam_pe_noisy_mates_and_options(tmp_path):
     # noisy, shorter reads: many mates seed badly or not at all, so the records depend on the rescue SW (score, sub-optimal
     # score, start found by the reverse pass); then the option paths: -a, -Y, -P (no pairing), -U / -m, non-default scoring
