@@ -30,6 +30,21 @@ class TailPool {
         __builtin_ia32_pause();
 #endif
     }
+    // How long a thread polls a word before it sleeps on it: ~1 ms by default (BM2_POOL_SPIN_US).  The gaps between the phases of a chunk
+    // are mostly shorter (prefix sums, a scan over blocks), and a sleeper's wake-up costs a scheduler round trip -- milliseconds where the
+    // CPUs are virtual and halt when idle -- while a poller on an otherwise idle CPU costs nothing that anybody wanted.
+    static int spin_rounds() {
+        static const int r = []() { const char *e = getenv("BM2_POOL_SPIN_US"); const long us = e && *e ? atol(e) : 1000; return (int)(us < 0 ? 0 : us > 100000 ? 100000 : us); }();
+        return r;                                                 // rounds of ~1 us (16 pauses)
+    }
+    template <class W> static void wait_while_equal(std::atomic<uint32_t> *w, uint32_t seen, W still) {
+        const int rounds = spin_rounds();
+        for (int r = 0; r < rounds; ++r) {
+            for (int k = 0; k < 16; ++k) pause();
+            if (!still()) return;
+        }
+        while (still()) futex_wait(w, seen);
+    }
     static void futex_wait(std::atomic<uint32_t> *w, uint32_t seen) { syscall(SYS_futex, (uint32_t *)w, FUTEX_WAIT_PRIVATE, seen, nullptr, nullptr, 0); }
     static void futex_wake_all(std::atomic<uint32_t> *w) { syscall(SYS_futex, (uint32_t *)w, FUTEX_WAKE_PRIVATE, INT_MAX, nullptr, nullptr, 0); }
     // A worker stays on one CPU of the process's affinity mask, handed out round-robin over all pools: a freshly woken thread then
@@ -53,8 +68,8 @@ class TailPool {
     void loop(int idx, uint32_t seen) {
         pin_self();
         for (;;) {
-            uint32_t g;
-            for (int spins = 0; (g = gen.load(std::memory_order_acquire)) == seen;) { if (++spins < 4000) pause(); else futex_wait(&gen, seen); }
+            wait_while_equal(&gen, seen, [&]() { return gen.load(std::memory_order_acquire) == seen; });
+            const uint32_t g = gen.load(std::memory_order_acquire);      // (ONE load decides: see above)
             seen = g;
             if (stop.load(std::memory_order_acquire)) return;
             if (idx < (int)(g & WANT_MASK)) {
@@ -83,8 +98,8 @@ public:
         gen.store((((gen.load(std::memory_order_relaxed) >> WANT_BITS) + 1) << WANT_BITS) | (uint32_t)(n - 1), std::memory_order_release);
         futex_wake_all(&gen);
         f();                                                      // the caller takes part
-        uint32_t l;
-        for (int spins = 0; (l = left.load(std::memory_order_acquire)) != 0;) { if (++spins < 4000) pause(); else futex_wait(&left, l); }
+        for (uint32_t l; (l = left.load(std::memory_order_acquire)) != 0;)
+            wait_while_equal(&left, l, [&]() { return left.load(std::memory_order_acquire) == l; });
     }
 };
 // How many host threads the call in progress on THIS thread may use (bm2_sam_pe / bm2_sam_se set it from bm2_sam_opt::n_threads for

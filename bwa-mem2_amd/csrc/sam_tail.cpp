@@ -61,20 +61,22 @@ void put_int(std::string &s, long long v) {                    // kputw / kputl 
 // ---- banded global alignment with traceback ---------------------------------------------------------------------------
 // Banded global alignment with traceback; must reproduce ksw_global2 (ksw.cpp:558-668) decision for decision, because the CIGAR of a
 // rescued hit is printed from it.  Only the rescued hits of a chunk come here (everything numbered goes through the device batch), so this
-// is written for clarity, not speed: a row is computed in three sweeps over structure-of-arrays rows -- (1) the diagonal move M and the
-// choice between M and the deletion state E, (2) the insertion state F, the only value that depends on the cell to its left, folded in
-// as a running maximum, (3) next row's E -- and a cell's traceback record is three named fields (where H came from; whether E / F were
-// extended rather than opened) instead of ksw's shifted byte.  The walk back is an explicit three-state machine.
+// is written for clarity: the row state lives in two plain arrays (H of the row above, shifted to the column it is the diagonal
+// predecessor of; E of the row being entered) instead of an array of structs, a cell's traceback record is three named fields (where H
+// came from; whether E / F were extended rather than opened) instead of ksw's shifted byte, and the walk back is an explicit
+// three-state machine.
 // The reference's preferences at ties are what make the result unique: H takes M over E over F; E and F prefer opening over extending.
 int global_align(int qlen, const uint8_t *query, int tlen, const uint8_t *target, const int8_t *mat, int o_del, int e_del, int o_ins,
                  int e_ins, int w, std::vector<uint32_t> &cigar) {
     enum : uint8_t { FROM_M = 0, FROM_E = 1, FROM_F = 2, E_EXTENDED = 4, F_EXTENDED = 8 };
     const int open_del = o_del + e_del, open_ins = o_ins + e_ins;
     const int width = std::min(qlen, 2 * w + 1);                // cells of a row inside the band
-    static thread_local std::vector<uint8_t> trace;            // [tlen][width], column index relative to the row's first band cell
-    static thread_local std::vector<int32_t> Hup, Eup, Mrow, Hrow;   // H(i-1, j-1) shifted to column j; E(i, j); this row's M and H
-    if (trace.size() < (size_t)width * (size_t)tlen) trace.resize((size_t)width * (size_t)tlen);
-    for (auto *v : { &Hup, &Eup, &Mrow, &Hrow }) if (v->size() < (size_t)qlen + 2) v->resize((size_t)qlen + 2);
+    static thread_local std::vector<uint8_t> trace_tl;         // [tlen][width], column index relative to the row's first band cell
+    static thread_local std::vector<int32_t> rows_tl;          // two rows of qlen + 2: H(i-1, j-1) shifted to column j; E(i, j)
+    if (trace_tl.size() < (size_t)width * (size_t)tlen) trace_tl.resize((size_t)width * (size_t)tlen);
+    if (rows_tl.size() < 2 * ((size_t)qlen + 2)) rows_tl.resize(2 * ((size_t)qlen + 2));
+    uint8_t *const trace = trace_tl.data();
+    int32_t *const __restrict Hup = rows_tl.data(), *const __restrict Eup = Hup + qlen + 2;
     // row -1: only leading insertions, and only inside the band
     for (int j = 0; j <= qlen; ++j) { Hup[j] = j == 0 ? 0 : (j <= w ? -(o_ins + e_ins * j) : MINUS_INF); Eup[j] = MINUS_INF; }
     auto band_begin = [&](int i) { return i > w ? i - w : 0; };
@@ -82,27 +84,22 @@ int global_align(int qlen, const uint8_t *query, int tlen, const uint8_t *target
     for (int i = 0; i < tlen; ++i) {
         const int lo = band_begin(i), hi = band_end(i);
         const int8_t *score_of = mat + target[i] * 5;
-        uint8_t *rec = trace.data() + (size_t)i * width;
-        for (int j = lo; j < hi; ++j) {                          // sweep 1: M, and H without insertions
-            const int m = Hup[j] + score_of[query[j]];
-            Mrow[j] = m;
-            const bool take_e = Eup[j] > m;
-            Hrow[j] = take_e ? Eup[j] : m;
-            rec[j - lo] = take_e ? FROM_E : FROM_M;
-        }
-        int f = MINUS_INF;                                       // sweep 2: F runs left to right; H = max(H, F) with F last in the preference
+        uint8_t *const __restrict rec = trace + (size_t)i * width;
+        int f = MINUS_INF;                                       // F(i, j): the only state that travels along the row
+        int carry = lo == 0 ? -(o_del + e_del * (i + 1)) : MINUS_INF;     // H(i, lo - 1): becomes column lo's diagonal predecessor in the next row
         for (int j = lo; j < hi; ++j) {
-            if (f > Hrow[j]) { Hrow[j] = f; rec[j - lo] = FROM_F; }
-            const int opened = Mrow[j] - open_ins, extended = f - e_ins;
-            if (extended > opened) { f = extended; rec[j - lo] |= F_EXTENDED; } else f = opened;
+            const int m = Hup[j] + score_of[query[j]], e = Eup[j];
+            uint8_t r = FROM_M;
+            int h = m;
+            if (e > h) { h = e; r = FROM_E; }                    // H prefers M, then E, then F
+            if (f > h) { h = f; r = FROM_F; }
+            Hup[j] = carry; carry = h;                           // (the row shifts by one: next row's diagonal predecessor of column j + 1)
+            const int e_open = m - open_del, e_ext = e - e_del;  // E(i + 1, j): opening wins a tie
+            if (e_ext > e_open) { Eup[j] = e_ext; r |= E_EXTENDED; } else Eup[j] = e_open;
+            const int f_open = m - open_ins, f_ext = f - e_ins;  // F(i, j + 1)
+            if (f_ext > f_open) { f = f_ext; r |= F_EXTENDED; } else f = f_open;
+            rec[j - lo] = r;
         }
-        for (int j = lo; j < hi; ++j) {                          // sweep 3: E of the next row at this column
-            const int opened = Mrow[j] - open_del, extended = Eup[j] - e_del;
-            if (extended > opened) { Eup[j] = extended; rec[j - lo] |= E_EXTENDED; } else Eup[j] = opened;
-        }
-        // shift: next row's diagonal predecessor of column j is this row's H at j - 1; column lo takes the boundary value
-        int carry = lo == 0 ? -(o_del + e_del * (i + 1)) : MINUS_INF;
-        for (int j = lo; j < hi; ++j) { const int h = Hrow[j]; Hup[j] = carry; carry = h; }
         Hup[hi] = carry; Eup[hi] = MINUS_INF;
     }
     const int score = Hup[qlen];
