@@ -636,6 +636,7 @@ def main():
                        "genome_mbp": a.genome_mbp,
                        "parallelism": ("ONE chunk cut at multiples of 512 reads over %d GPU(s) (strong scaling), " if a.strong else "one chunk per GPU over %d GPU(s), ") % world
                                       + "index replica per GPU, no collectives"},
+            "knobs": {k: v for k, v in sorted(os.environ.items()) if k.startswith("BM2_") and k != "BM2_EMU_LIB"},      # launch-policy / pipeline settings in force ({} = defaults)
             "stage_ms_per_step": stage_ms, "dominant_stage": dominant,
             "work_per_read": {"backwardExt": st["n_ext"] / n_reads, "lf_steps": st["n_lf"] / n_reads,
                               "sa_lookups": st["n_sa"] / n_reads, "sw_tasks": st["n_sw_tasks"] / n_reads,
