@@ -79,7 +79,10 @@ def prepare_genome(workdir, mbp, seed):
             z = np.load(meta, allow_pickle=True)
             memo.append([z["c%d" % i] for i in range(int(z["n"]))])
         return memo[0]
+    lens_fn = pre + ".contig_lens.npy"                        # (tools/gen_chunk.py samples reads from the mapped .0123 with these)
     if os.path.exists(pre + ".bwt.2bit.64") and os.path.exists(meta):
+        if not os.path.exists(lens_fn):
+            np.save(lens_fn, np.array([len(c) for c in contigs()], np.int64))
         return pre, contigs
     import bm2
     t = time.time()
@@ -95,6 +98,7 @@ def prepare_genome(workdir, mbp, seed):
     bm2.index_build(pre, None, 0)
     log("index built in %.1fs" % (time.time() - t))
     np.savez(meta, n=len(ctg), **{"c%d" % i: c for i, c in enumerate(ctg)})
+    np.save(lens_fn, np.array([len(c) for c in ctg], np.int64))
     memo.append(ctg)
     return pre, contigs
 

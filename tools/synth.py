@@ -179,7 +179,9 @@ def make_reads_pe(seed, contigs, n_pairs, L=150, ins_mean=400, ins_sd=40, **kw):
     random_frac = kw.get("random_frac", 0.002)
     n_frac = kw.get("n_frac", 0.001)
     rng = np.random.default_rng(seed)
-    genome, offs = _concat(contigs)
+    # contigs: a list of code arrays, or (genome, offsets) already concatenated -- e.g. a memory map of the index's .0123 file, which
+    # several generator processes then share through the page cache instead of holding a copy of the genome each
+    genome, offs = contigs if isinstance(contigs, tuple) else _concat(contigs)
     isz = np.maximum(np.rint(rng.normal(ins_mean, ins_sd, size=n_pairs)).astype(np.int64), L + 20)
     span = int(isz.max()) + 16
     start = _sample_windows(rng, offs, n_pairs, span)
