@@ -69,7 +69,12 @@ void bm2_batch_destroy(bm2_ctx *c);     // pipeline.hip
 
 #define BM2_PIN_CAP ((size_t)16 << 20)
 // (BM2_PIN_PIECE / BM2_PIN_MIN: test hooks that make small copies go through the staged path in small pieces)
-static const size_t BM2_PIN_BYTES = getenv("BM2_PIN_PIECE") ? (size_t)atol(getenv("BM2_PIN_PIECE")) : BM2_PIN_CAP;
+static size_t pin_piece() {
+    const char *e = getenv("BM2_PIN_PIECE");
+    long v = e && *e ? atol(e) : (long)BM2_PIN_CAP;
+    return v < 4096 ? (size_t)4096 : (size_t)v > BM2_PIN_CAP ? BM2_PIN_CAP : (size_t)v;     // (0 would never advance, more than the buffers hold would overrun them)
+}
+static const size_t BM2_PIN_BYTES = pin_piece();
 static const size_t BM2_PIN_MIN = getenv("BM2_PIN_MIN") ? (size_t)atol(getenv("BM2_PIN_MIN")) : (size_t)1 << 20;
 static int pin_ready(bm2_ctx *c) {
     for (int i = 0; i < 2; i++) {

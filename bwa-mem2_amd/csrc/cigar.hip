@@ -308,6 +308,7 @@ static int cigar_run(bm2_ctx *c, const bm2_opt *opt, std::vector<CigarTask> &tas
         n_small = ns.load(); qmax = qm.load();
     }
     prof.mark("order");
+    c->n_bsw = 0;                                               // (these scratch buffers held the resident S1 batch, if any: it is gone)
     DevBuf &b_seq = c->b_ref, &b_task = c->b_qer, &b_res = c->b_pairs, &b_scr = c->b_misc;
     const size_t task_bytes = ((size_t)n * sizeof(CigarTask) + 15) & ~(size_t)15, ord_bytes = ((size_t)n * sizeof(int) + 15) & ~(size_t)15;
     const size_t z_bytes = ((size_t)zo + 15) & ~(size_t)15, eh_bytes = (size_t)eo * sizeof(int2), cg_bytes = ((size_t)co * 4 + 15) & ~(size_t)15, md_bytes = ((size_t)mo + 15) & ~(size_t)15;

@@ -47,20 +47,35 @@ class TailPool {
     }
     static void futex_wait(std::atomic<uint32_t> *w, uint32_t seen) { syscall(SYS_futex, (uint32_t *)w, FUTEX_WAIT_PRIVATE, seen, nullptr, nullptr, 0); }
     static void futex_wake_all(std::atomic<uint32_t> *w) { syscall(SYS_futex, (uint32_t *)w, FUTEX_WAKE_PRIVATE, INT_MAX, nullptr, nullptr, 0); }
-    // A worker stays on one CPU of the process's affinity mask, handed out round-robin over all pools: a freshly woken thread then
-    // starts where it slept instead of queueing on the waker's CPU until the load balancer gets to it (milliseconds on virtualised
-    // hosts; a phase lasts a few).  BM2_TAIL_PIN=0 leaves the placement to the scheduler.
+    // A worker stays on one CPU of the PROCESS's affinity mask (read once, from the main thread: a pool made by an already pinned thread
+    // must not inherit that thread's one-CPU mask): a freshly woken thread then starts where it slept instead of queueing on the
+    // waker's CPU until the load balancer gets to it (milliseconds on virtualised hosts; a phase lasts a few).  One process per GPU is
+    // the deployment: rank r of w (LOCAL_RANK / LOCAL_WORLD_SIZE, as torchrun exports them) hands out only the r-th of w equal slices of
+    // the mask, so the ranks of a node never stack their workers on the same CPUs; without a launcher the start is hashed from the pid.
+    // BM2_TAIL_PIN=0 leaves the placement to the scheduler.
+    struct PinPlan { cpu_set_t all; int n = 0, base = 0, span = 0; };
+    static const PinPlan &pin_plan() {
+        static const PinPlan plan = []() {
+            PinPlan p; CPU_ZERO(&p.all);
+            if (sched_getaffinity(getpid(), sizeof p.all, &p.all) != 0) return p;      // (pid = the main thread: the process's own mask)
+            p.n = CPU_COUNT(&p.all);
+            const char *r = getenv("LOCAL_RANK"), *w = getenv("LOCAL_WORLD_SIZE");
+            const int world = w && *w ? atoi(w) : 1, rank = r && *r ? atoi(r) : 0;
+            if (world > 1 && rank >= 0 && rank < world && p.n >= 2 * world) { p.span = p.n / world; p.base = rank * p.span; }
+            else { p.span = p.n; p.base = p.n > 1 ? (int)(((unsigned)getpid() * 2654435761u >> 8) % (unsigned)p.n) : 0; }
+            return p;
+        }();
+        return plan;
+    }
     static void pin_self() {
         static const bool on = []() { const char *e = getenv("BM2_TAIL_PIN"); return !(e && e[0] == '0'); }();
         if (!on) return;
+        const PinPlan &p = pin_plan();
+        if (p.n < 2 || p.span < 1) return;
         static std::atomic<unsigned> next_cpu{1};
-        cpu_set_t all;
-        if (sched_getaffinity(0, sizeof all, &all) != 0) return;
-        const int n = CPU_COUNT(&all);
-        if (n < 2) return;
-        int k = (int)(next_cpu.fetch_add(1) % (unsigned)n);
+        int k = (p.base + (int)(next_cpu.fetch_add(1) % (unsigned)p.span)) % p.n;
         for (int c = 0; c < CPU_SETSIZE; ++c)
-            if (CPU_ISSET(c, &all) && k-- == 0) { cpu_set_t one; CPU_ZERO(&one); CPU_SET(c, &one); pthread_setaffinity_np(pthread_self(), sizeof one, &one); return; }
+            if (CPU_ISSET(c, &p.all) && k-- == 0) { cpu_set_t one; CPU_ZERO(&one); CPU_SET(c, &one); pthread_setaffinity_np(pthread_self(), sizeof one, &one); return; }
     }
     // The generation word carries the phase's participant count in its low bits: a worker decides from ONE load whether the phase it
     // saw is its business (a separate `want` could already belong to the next phase by the time a slow non-participant reads it).

@@ -99,6 +99,7 @@ static int ksw_batch_run(bm2_ctx *c, int32_t n, const uint8_t *qbuf, int64_t qbu
         bm2_set_error("ksw batch: a query of %d stripe segments does not fit the LDS layout (mates longer than 448 bases: use bm2_sam_pe)", slen_max);
         return BM2_EUNSUP;
     }
+    c->n_bsw = 0;                                               // (these scratch buffers held the resident S1 batch, if any: it is gone)
     DevBuf &b_seq = c->b_ref, &b_task = c->b_qer, &b_out = c->b_pairs, &b_misc = c->b_misc;
     const size_t task_bytes = (size_t)n * sizeof(KswTask), ord_bytes = (size_t)n * sizeof(int);
     if ((rc = bm2_reserve(b_seq, (size_t)qbuf_bytes + 64))) return rc;

@@ -568,7 +568,12 @@ static int batch_finish_one(bm2_ctx *c, const bm2_opt *opt) {
     if (rc) return rc;
     if ((rc = bm2_check(hipSetDevice(c->device), "hipSetDevice"))) return rc;
     Batch *b = c->batch;
-    if (b->n_reads == 0) { b->n_fin = 0; return bm2_reserve(b->fin_off, 16) ? BM2_ENOMEM : bm2_check(hipMemsetAsync(b->fin_off.p, 0, 16, c->stream), "memset"); }
+    if (b->n_reads == 0) {                                       // (the stream is non-blocking: the memset has landed when this returns)
+        b->n_fin = 0;
+        if (bm2_reserve(b->fin_off, 16)) return BM2_ENOMEM;
+        if ((rc = bm2_check(hipMemsetAsync(b->fin_off.p, 0, 16, c->stream), "memset"))) return rc;
+        return bm2_check(hipStreamSynchronize(c->stream), "hit finishing (empty chunk)");
+    }
     int64_t n_out = 0;
     rc = bm2_run_finish(c, opt, b->n_reads, (const uint8_t *)b->enc.p, (const int64_t *)b->off.p, (const bm2_reg_t *)b->out_regs.p,
                         (const int64_t *)b->out_off.p, b->n_out_regs, b->fin_work, b->fin_ord, b->fin_state, b->fin_n, b->fin_off, b->fin_req,

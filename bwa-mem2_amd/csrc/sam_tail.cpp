@@ -1247,6 +1247,12 @@ void flush_tallies() {
     t_cg_used = t_cg_missed = t_rs_used = t_rs_missed = 0;
 }
 
+inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#endif
+}
+
 // items [0, n) in blocks of 256 over n_threads host threads; f(i, text) appends the text of item i.  A thread formats a block into its
 // own buffer (kept from call to call: it stays in the cache), learns where the block starts from the end of the block before it --
 // blocks are taken in order, so that one is finished or about to be -- publishes its own end at once and copies the block straight into
@@ -1273,7 +1279,7 @@ template <class F> int run_blocks(int n, int n_threads, char *out, int64_t cap, 
                     if (!f(i, text)) { int e = -1; failed.compare_exchange_strong(e, i); break; }
             }
             int64_t at;
-            for (int spins = 0; (at = end_of[(size_t)b].load(std::memory_order_acquire)) < 0;) { if (++spins < 2000) __builtin_ia32_pause(); else std::this_thread::yield(); }
+            for (int spins = 0; (at = end_of[(size_t)b].load(std::memory_order_acquire)) < 0;) { if (++spins < 2000) cpu_relax(); else std::this_thread::yield(); }
             end_of[(size_t)b + 1].store(at + (int64_t)text.size(), std::memory_order_release);
             if (out && at + (int64_t)text.size() <= cap && !text.empty()) memcpy(out + at, text.data(), text.size());
         }

@@ -13,6 +13,7 @@ from tools import synth
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BM2_EXE = os.path.join(ROOT, "oracle", "_ref", "bwa-mem2.bm2")
+S1_EXE = os.path.join(ROOT, "oracle", "_ref", "bwa-mem2.bm2s1")         # only seam S1 replaced (integration/bm2_bsw_binding.cpp; BASELINE config 2)
 
 
 def _inputs(d, n_pairs, n_se):
@@ -29,12 +30,12 @@ def _inputs(d, n_pairs, n_se):
     return fa
 
 
-def _compare(d, fa, env, K):
+def _compare(d, fa, env, K, exe=BM2_EXE, marker=b"libbm2"):
     pe = [os.path.join(d, "r1.fq"), os.path.join(d, "r2.fq")]
     for tag, args in (("pe", ["-K", str(K), fa] + pe), ("se", [fa, os.path.join(d, "se.fq")]),
                       ("pe_opts", ["-R", "@RG\\tID:x\\tSM:y", "-Y", "-M", "-a", fa] + pe)):
         a = subprocess.run([ref_binary(), "mem", "-t", "4"] + args, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
-        p = subprocess.run([BM2_EXE, "mem", "-t", "4"] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+        p = subprocess.run([exe, "mem", "-t", "4"] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
         assert p.returncode == 0, p.stderr.decode()[-1500:]
         la = [l for l in a.split(b"\n") if not l.startswith(b"@PG")]
         lb = [l for l in p.stdout.split(b"\n") if not l.startswith(b"@PG")]
@@ -42,12 +43,12 @@ def _compare(d, fa, env, K):
         for i, (x, y) in enumerate(zip(la, lb)):
             assert x == y, "%s line %d\n  ref : %s\n  bm2 : %s" % (tag, i, x[:300], y[:300])
         assert len(la) == len(lb), tag
-        assert b"libbm2" in p.stderr            # the chunk really went through the replacement
+        assert marker in p.stderr               # the chunk really went through the replacement
 
 
-def _need():
-    if ref_binary() is None or not os.path.exists(BM2_EXE):
-        pytest.skip("oracle/_ref (reference + bwa-mem2.bm2) not built: make -C oracle ref bm2")
+def _need(exe=BM2_EXE):
+    if ref_binary() is None or not os.path.exists(exe):
+        pytest.skip("oracle/_ref (reference + %s) not built: make -C oracle ref bm2 bm2s1" % os.path.basename(exe))
 
 
 def test_binding_against_the_emulator(tmp_path):
@@ -66,3 +67,23 @@ def test_binding_on_the_gpu(tmp_path):
     _need()
     fa = _inputs(str(tmp_path), 3000, 2000)
     _compare(str(tmp_path), fa, dict(os.environ), 300000)
+
+
+def test_s1_binding_against_the_emulator(tmp_path):
+    """bwa-mem2.bm2s1: the reference with ONLY its banded extension (getScores8 / getScores16 / scalarBandedSWAWrapper) routed to bm2_bsw;
+    seeding, chaining, the band retry rule, pairing and SAM are the reference's host code."""
+    _need(S1_EXE)
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools", "emu"))
+    import build_emu
+    lib = build_emu.build(str(tmp_path / "emu"))
+    os.symlink(lib, str(tmp_path / "emu" / "libbm2.so"))
+    fa = _inputs(str(tmp_path), 100, 60)
+    _compare(str(tmp_path), fa, dict(os.environ, LD_LIBRARY_PATH=str(tmp_path / "emu"), BM2_S1_CONTEXTS="2"), 20000, S1_EXE, b"[bm2s1]")
+
+
+@pytest.mark.gpu
+def test_s1_binding_on_the_gpu(tmp_path):
+    _need(S1_EXE)
+    fa = _inputs(str(tmp_path), 3000, 2000)
+    _compare(str(tmp_path), fa, dict(os.environ), 300000, S1_EXE, b"[bm2s1]")

@@ -20,10 +20,10 @@ def main():
     os.makedirs(out, exist_ok=True)
     import bench
     import bm2
-    wd = "/tmp/bm2_tail_probe"
+    wd = os.environ.get("PROBE_WORKDIR", "/tmp/bm2_tail_probe")          # PROBE_WORKDIR=/tmp/bm2_bench PROBE_SEED=20260924: bench.py's own index
     os.makedirs(wd, exist_ok=True)
     t = time.time()
-    prefix, contigs = bench.prepare_genome(wd, mbp, 777)
+    prefix, contigs = bench.prepare_genome(wd, mbp, int(os.environ.get("PROBE_SEED", 777)))
     procs = []
     for i in range(n_chunks + 1):
         fa, fb = os.path.join(wd, "c%d_1.fq" % i), os.path.join(wd, "c%d_2.fq" % i)
@@ -36,7 +36,8 @@ def main():
     print("[probe] inputs ready in %.1fs" % (time.time() - t), file=sys.stderr, flush=True)
     ctx = bm2.Context(0, prefix)
     opt = bm2.default_opt()
-    r = bench.end_to_end(ctx, bm2, texts[1:], opt, True, 0)         # (its warm-up chunks pass through the same threads before the clock starts)
+    r = bench.end_to_end(ctx, bm2, texts[1:], opt, True, 0, limit_s=float(os.environ.get("PROBE_LIMIT_S", 150)))     # (its warm-up chunks pass through the same threads before the clock starts)
+    print("[probe] defaults: %.2f M reads/s %s" % (r["value"] / 1e6, {k: round(v) for k, v in r["stage_ms_per_chunk"].items()}), file=sys.stderr, flush=True)
     r["genome_mbp"] = mbp
     r["splits"] = []                                        # tail workers x host threads per worker: which split feeds the device best
     for tails, threads in [(s_.split("x")) for s_ in os.environ.get("PROBE_SPLITS", "").split()]:
