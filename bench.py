@@ -140,9 +140,10 @@ def run_reference_mem(prefix, fq, extra=(), threads=None, out="/dev/null"):
     return p.stderr, time.time() - t, isa
 
 
-def cpu_baseline(prefix, fq, n_reads_desc, extra=()):
-    """Time the compiled reference on a bounded sample of the same workload, all host cores."""
-    err, wall, isa = run_reference_mem(prefix, fq, extra)
+def cpu_baseline(prefix, fq, n_reads_desc, extra=(), out="/dev/null"):
+    """Time the compiled reference on a bounded sample of the same workload, all host cores (its SAM goes to `out`: the wide parity gate
+    compares it with the library's text for the same reads)."""
+    err, wall, isa = run_reference_mem(prefix, fq, extra, out=out)
     if err is None:
         return None
     threads = host_threads()
@@ -153,10 +154,10 @@ def cpu_baseline(prefix, fq, n_reads_desc, extra=()):
     kern_s = float(kern.group(1)) if kern else None
     if n_proc == 0 or real <= 0:
         return None
-    out = {"value": n_proc / real, "unit": "reads/s", "cores": threads, "kind": "reference",
-           "sample": "%s, same index; bwa-mem2 v2.2.1 %s build, `mem -t %d %s`; whole `mem` chunk time "
+    out = {"value": n_proc / real, "unit": "reads/s", "cores": threads, "threads_present": os.cpu_count(), "kind": "reference",
+           "sample": "%s, same index; bwa-mem2 v2.2.1 %s build, `mem -t %d %s` (%d of the host's %d hardware threads); whole `mem` chunk time "
                      "(seed+chain+extend+pairing+SAM) from its own 'Processed N reads' lines; wall %.1fs"
-                     % (n_reads_desc, isa, threads, " ".join(extra), wall)}
+                     % (n_reads_desc, isa, threads, " ".join(extra), threads, os.cpu_count() or 0, wall)}
     if kern_s:
         out["hot_path_value"] = n_proc / kern_s
         out["hot_path_note"] = "reads / reference's own per-thread-average SMEM+SAL+BSW kernel time (the scope of the top-level `value`)"
@@ -253,6 +254,30 @@ def parity_gate(ctx, bm2, prefix, workdir, seqs, regs, reg_off, opt, opt_args, p
                 break
     log("parity[%s]: a19 equal = %s, SAM equal = %s (%d records; reference mem %.1fs, total %.1fs)"
         % (tag, res["fin_equal"], res["sam_equal"], len(ref), wall, time.time() - t))
+    return res
+
+
+def sam_gate(ctx, bm2, fq, ref_sam, opt, paired, tag):
+    """The wide gate: the reads of the FASTQ files `fq` (one chunk) through the library -- parse, device pipeline incl. a19, tail -- against the
+    SAM text the compiled reference wrote for the same files (`ref_sam`: the CPU-baseline run's output, or a single-end run of it)."""
+    t = time.time()
+    chunk = bm2.FastqChunk(open(fq[0], "rb").read(), open(fq[1], "rb").read() if paired else None, 0)
+    try:
+        ctx.batch_upload_chunk(chunk); ctx.batch_run(opt); ctx.batch_finish(opt)
+        aln, aln_off = ctx.batch_download_alnregs()
+        txt = ctx.sam(chunk, opt, bm2.default_sam_opt(n_threads=0), aln, aln_off, 0, paired).tobytes()
+        n_reads = chunk.n_reads
+    finally:
+        chunk.close()
+    mine, ref = sam_lines(txt), sam_lines(open(ref_sam, "rb").read())
+    res = {"reads": n_reads, "sam_records": len(ref), "sam_equal": bool(mine == ref)}
+    if not res["sam_equal"]:
+        res["got_records"] = len(mine)
+        for i, (x, y) in enumerate(zip(mine, ref)):
+            if x != y:
+                res["first_sam_diff"] = {"line": i, "got": x[:300].decode("latin1"), "exp": y[:300].decode("latin1")}
+                break
+    log("parity[%s]: %d reads through the library vs the reference's SAM: equal = %s (%d records, %.1fs)" % (tag, n_reads, res["sam_equal"], len(ref), time.time() - t))
     return res
 
 
@@ -504,7 +529,8 @@ def main():
     ap.add_argument("--cpu-pairs", type=int, default=int(os.environ.get("BM2_BENCH_CPU_PAIRS", 250000)))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
-    ap.add_argument("--parity-reads", type=int, default=int(os.environ.get("BM2_BENCH_PARITY_READS", 20480)))
+    ap.add_argument("--parity-reads", type=int, default=int(os.environ.get("BM2_BENCH_PARITY_READS", 204800)),
+                    help="reads of the timed chunk's prefix that go through refdump (REGPRG / REGFIN byte for byte) and `bwa-mem2 mem` (SAM)")
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--e2e-chunks", type=int, default=int(os.environ.get("BM2_BENCH_E2E_CHUNKS", 10)))
     ap.add_argument("--strong", action="store_true",
@@ -663,7 +689,7 @@ def main():
                                            "kernel_ms": {k: v for k, v in kern_ms.items() if k.startswith("smem.")},
                                            "backwardExt_per_kernel": ext_of}},
             "extend_kernel": {"kernel": "k_ext_lanes", "gcups": cells / (ext_ms * 1e-3) / 1e9 if ext_ms > 0 else 0.0,
-                              "avg_launch_ms": ext_ms, "cells_per_launch": cells,
+                              "stage_ms": ext_ms, "cells_per_step": cells,
                               "valu_frac": ext_pmc.get("valu_frac") if ext_pmc else None,
                               "lds_conflict_frac": ext_pmc.get("lds_conflict_frac") if ext_pmc else None,
                               "pmc_source": "profiles/r02_ext_pmc_sq.json" if ext_pmc else None},
@@ -698,8 +724,35 @@ def main():
                     c1, c2 = synth.make_reads_pe(seed + 5, contigs(), a.cpu_pairs, L=a.read_len)
                     f1, f2 = os.path.join(a.workdir, "cpu_1.fq"), os.path.join(a.workdir, "cpu_2.fq")
                     synth.write_fastq(f1, c1, suffix="/1"); synth.write_fastq(f2, c2, suffix="/2")
-                    cb = cpu_baseline(prefix, [f1, f2], "%d x %d bp PE reads" % (2 * a.cpu_pairs, a.read_len))
-                log("cpu baseline took %.1fs" % (time.time() - t))
+                    ref_sam = os.path.join(a.workdir, "cpu_ref.sam") if not a.no_parity else "/dev/null"
+                    cb = cpu_baseline(prefix, [f1, f2], "%d x %d bp PE reads" % (2 * a.cpu_pairs, a.read_len), out=ref_sam)
+                    log("cpu baseline took %.1fs" % (time.time() - t))
+                    if cb and not a.no_parity and isinstance(out.get("parity"), dict) and "regs_equal" in out["parity"]:
+                        # the wide gate: what the baseline run already paid for (all its records), then the same first mates as single-end reads
+                        try:
+                            g = sam_gate(ctx, bm2, [f1, f2], ref_sam, opt, True, "pe-wide")
+                            out["parity"]["wide_pe"] = g
+                            out["parity"]["sam_records"] = out["parity"].get("sam_records", 0) + g["sam_records"]
+                            ok = g["sam_equal"]
+                            if time_left() > 200:
+                                se_sam = os.path.join(a.workdir, "cpu_ref_se.sam")
+                                n_se = min(a.cpu_pairs, 100000)
+                                f_se = os.path.join(a.workdir, "cpu_se.fq")
+                                synth.write_fastq(f_se, c1[:n_se])
+                                err_se, _, _ = run_reference_mem(prefix, [f_se], out=se_sam)
+                                if err_se is not None:
+                                    g2 = sam_gate(ctx, bm2, [f_se], se_sam, opt, False, "se-wide")
+                                    out["parity"]["wide_se"] = g2
+                                    out["parity"]["sam_records"] += g2["sam_records"]
+                                    ok = ok and g2["sam_equal"]
+                            out["parity"]["sam_equal"] = bool(out["parity"].get("sam_equal") and ok)
+                            if not ok:
+                                rc = 3
+                        except Exception as e:                                        # noqa
+                            out["parity"]["wide_error"] = str(e)
+                            rc = 3
+                if ont:
+                    log("cpu baseline took %.1fs" % (time.time() - t))
             except Exception as e:                                                    # noqa
                 cb = {"error": str(e)}
             out["cpu_baseline"] = cb

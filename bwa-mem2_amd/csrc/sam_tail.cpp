@@ -23,8 +23,25 @@
 #include "ksort_host.h"
 #include "host_tail.h"
 #include "host_pool.h"
+#include <malloc.h>
 
 void bm2_set_error(const char *fmt, ...);
+
+// A chunk's tail runs on a few hundred threads that allocate and release small blocks all the time.  glibc gives every thread an arena and
+// by default hands the top of an arena back to the kernel (madvise / munmap) whenever 128 KB of it are free, and takes blocks above 128 KB
+// straight from mmap: on a 256-thread host every such call is a TLB shootdown across the process and a turn on its address-space lock, and
+// the phases of a chunk were seen to take 5 ms or 800 ms depending on what the other threads were doing.  So: never trim, big blocks from
+// the arenas too (up to glibc's cap of 32 MB).  Process-wide and once; BM2_MALLOC_TUNE=0 leaves the allocator alone.
+void bm2_tune_malloc_once() {
+    static std::once_flag once;
+    std::call_once(once, []() {
+        const char *e = getenv("BM2_MALLOC_TUNE");
+        if (e && e[0] == '0') return;
+        mallopt(M_TRIM_THRESHOLD, 1 << 30);
+        mallopt(M_MMAP_THRESHOLD, 32 << 20);
+        mallopt(M_TOP_PAD, 64 << 20);
+    });
+}
 
 namespace {
 template <class F> void run_threads(int n_threads, F f) { bm2_run_threads(n_threads, std::function<void()>(f)); }
@@ -1267,26 +1284,41 @@ template <class F> int run_blocks(int n, int n_threads, char *out, int64_t cap, 
     std::unique_ptr<std::atomic<int64_t>[]> end_of(new std::atomic<int64_t>[(size_t)n_blocks + 1]);
     for (int b = 0; b <= n_blocks; ++b) end_of[(size_t)b].store(b == 0 ? 0 : -1, std::memory_order_relaxed);      // end_of[b] = where block b starts
     std::atomic<int> next(0), failed(-1);
+    TailProf prof("run_blocks");
+    std::atomic<long long> ns_fmt(0), ns_wait(0), ns_copy(0), ns_max(0);     // (BM2_TAIL_PROF: where the threads' time goes)
     auto work = [&]() {
         static thread_local std::string text;
+        long long t_fmt = 0, t_wait = 0, t_copy = 0;
+        auto now = [&]() { return prof.on ? std::chrono::steady_clock::now().time_since_epoch().count() : 0LL; };
         for (;;) {
             const int b = next.fetch_add(1);
             if (b >= n_blocks) break;
+            const long long c0 = now();
             text.clear();
             if (failed.load(std::memory_order_relaxed) < 0) {
                 const int hi = (b + 1) * block < n ? (b + 1) * block : n;
                 for (int i = b * block; i < hi; ++i)
                     if (!f(i, text)) { int e = -1; failed.compare_exchange_strong(e, i); break; }
             }
+            const long long c1 = now();
             int64_t at;
             for (int spins = 0; (at = end_of[(size_t)b].load(std::memory_order_acquire)) < 0;) { if (++spins < 2000) cpu_relax(); else std::this_thread::yield(); }
             end_of[(size_t)b + 1].store(at + (int64_t)text.size(), std::memory_order_release);
+            const long long c2 = now();
             if (out && at + (int64_t)text.size() <= cap && !text.empty()) memcpy(out + at, text.data(), text.size());
+            const long long c3 = now();
+            t_fmt += c1 - c0; t_wait += c2 - c1; t_copy += c3 - c2;
         }
         flush_tallies();
+        if (prof.on) {
+            ns_fmt += t_fmt; ns_wait += t_wait; ns_copy += t_copy;
+            const long long tot = t_fmt + t_wait + t_copy;
+            for (long long m = ns_max.load(); tot > m && !ns_max.compare_exchange_weak(m, tot);) {}
+        }
     };
-    TailProf prof("run_blocks");
     run_threads(n_threads, work);
+    if (prof.on) fprintf(stderr, "[tail] run_blocks     %d threads: format %.1f, wait-for-predecessor %.1f, copy %.1f ms summed over threads; busiest thread %.1f ms\n",
+                         n_threads, ns_fmt.load() / 1e6, ns_wait.load() / 1e6, ns_copy.load() / 1e6, ns_max.load() / 1e6);
     prof.mark("items + copy");
     if (failed.load() >= 0) { *bad = failed.load(); *n_out = 0; return BM2_EINVAL; }
     *n_out = n_blocks > 0 ? end_of[(size_t)n_blocks].load() : 0;
@@ -1434,6 +1466,7 @@ int bm2h_sam_pe(const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt
     if (so->max_ins > (1 << 24)) { bm2_set_error("bm2_sam_pe: max_ins above 2^24 is not supported (the insert sizes are counted in a histogram)"); return BM2_EUNSUP; }
     Ref R = { idx->l_pac, idx->ref_string, idx->n_seqs, idx->ann_offset, idx->ann_name, idx->ann_anno };
     struct Budget { int was; explicit Budget(int n) : was(bm2_host_thread_budget()) { bm2_host_thread_budget() = n; } ~Budget() { bm2_host_thread_budget() = was; } } budget(so->n_threads);
+    bm2_tune_malloc_once();
     TailProf prof("sam_pe");
     const int n = reads->n_reads;
     std::vector<std::vector<bm2_alnreg_t>> regs((size_t)n);
@@ -1646,6 +1679,7 @@ int bm2h_sam_se(const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt
     if (!idx->ref_string || !idx->ann_offset || !idx->ann_name) { bm2_set_error("bm2_sam_se: the index descriptor needs ref_string and contig names"); return BM2_EINVAL; }
     Ref R = { idx->l_pac, idx->ref_string, idx->n_seqs, idx->ann_offset, idx->ann_name, idx->ann_anno };
     struct Budget { int was; explicit Budget(int n) : was(bm2_host_thread_budget()) { bm2_host_thread_budget() = n; } ~Budget() { bm2_host_thread_budget() = was; } } budget(so->n_threads);
+    bm2_tune_malloc_once();
     const int n_reads = reads->n_reads;
     auto decide = [&](int i) {                                   // what changes the read's hit list (mem_reg2sam's caller, bwamem.cpp:1240-1243)
         bm2_alnreg_t *a = alnregs + reg_off[i];
