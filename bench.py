@@ -122,7 +122,12 @@ def pe_chunk(workdir, contigs_fn, seed, n_reads, read_len, tag=""):
 
 
 def host_threads():
-    return min(os.cpu_count() or 1, 128)
+    """threads for the compiled reference: the CPUs this process can really use (cgroup quota), not the hardware threads it can see"""
+    try:
+        import bm2
+        return max(1, min(bm2.host_cpus(), 128))
+    except Exception:                                             # noqa
+        return min(os.cpu_count() or 1, 128)
 
 
 def run_reference_mem(prefix, fq, extra=(), threads=None, out="/dev/null"):
@@ -155,7 +160,7 @@ def cpu_baseline(prefix, fq, n_reads_desc, extra=(), out="/dev/null"):
     if n_proc == 0 or real <= 0:
         return None
     out = {"value": n_proc / real, "unit": "reads/s", "cores": threads, "threads_present": os.cpu_count(), "kind": "reference",
-           "sample": "%s, same index; bwa-mem2 v2.2.1 %s build, `mem -t %d %s` (%d of the host's %d hardware threads); whole `mem` chunk time "
+           "sample": "%s, same index; bwa-mem2 v2.2.1 %s build, `mem -t %d %s` (%d = the CPUs this process may use: cgroup quota; the host shows %d hardware threads); whole `mem` chunk time "
                      "(seed+chain+extend+pairing+SAM) from its own 'Processed N reads' lines; wall %.1fs"
                      % (n_reads_desc, isa, threads, " ".join(extra), threads, os.cpu_count() or 0, wall)}
     if kern_s:
@@ -281,7 +286,7 @@ def sam_gate(ctx, bm2, fq, ref_sam, opt, paired, tag):
     return res
 
 
-def end_to_end(ctx, bm2, texts, opt, paired, n_threads, n_tail=3, limit_s=None, n_dev=None, n_warm=None):
+def end_to_end(ctx, bm2, texts, opt, paired, n_threads, n_tail=None, limit_s=None, n_dev=None, n_warm=None):
     """FASTQ text -> SAM text over the chunks `texts` = [(bytes1, bytes2 | None)] as a pipeline of host threads: the reader
     (bm2_fastq_parse_mt), n_dev device workers (H2D, seeding .. extension, mem_sort_dedup_patch, D2H; each with a context of its own on
     the shared index replica, chunk i on worker i % n_dev, so the copies and the latency-bound kernels of one chunk overlap the kernels
@@ -289,7 +294,8 @@ def end_to_end(ctx, bm2, texts, opt, paired, n_threads, n_tail=3, limit_s=None, 
     worker i % n_tail).  The first n_warm chunks go through the SAME threads untimed (workspaces, the library's per-thread worker pools
     and buffers, the output buffers' pages); the pipeline drains, then the clock starts and all of `texts` follow.  A chunk's text is
     complete before it is counted; the tie-breaking hash of a read is seeded with its number in the input (n_before)."""
-    n_tail = int(os.environ.get("BM2_E2E_TAILS", n_tail))
+    hw = bm2.host_cpus()                                         # CPUs this process can really use (cgroup quota), not the hardware threads it sees
+    n_tail = int(os.environ.get("BM2_E2E_TAILS", n_tail if n_tail is not None else (2 if hw <= 32 else 3)))
     n_dev = max(1, int(os.environ.get("BM2_E2E_DEVS", n_dev or 2)))
     if os.environ.get("BM2_E2E_LIMIT_S"):                        # (the host emulator needs minutes where the GPU needs milliseconds)
         limit_s = float(os.environ["BM2_E2E_LIMIT_S"])
@@ -297,12 +303,14 @@ def end_to_end(ctx, bm2, texts, opt, paired, n_threads, n_tail=3, limit_s=None, 
     work = list(texts[:n_warm]) + list(texts)                    # (warm-up chunks are the first timed ones again: another pass)
     tails = [bm2.Context(share=ctx) for _ in range(n_tail)]
     devs = [ctx] + [bm2.Context(share=ctx) for _ in range(n_dev - 1)]
-    hw = os.cpu_count() or 1
-    # the library's host workers stay on their CPUs (host_pool.h): the stages' thread counts are chosen not to overlap -- the parser's,
-    # the tail workers', and a few CPUs left to the pipeline's own threads
-    n_parse = int(os.environ.get("BM2_E2E_PARSE_THREADS", max(1, min(hw // 8, 32))))
-    so = bm2.default_sam_opt(n_threads=int(os.environ.get("BM2_E2E_TAIL_THREADS", n_threads or max((hw - n_parse - min(8, hw // 4)) // n_tail, 1))))
-    q_parsed, q_hits = [queue.Queue(maxsize=2) for _ in range(n_dev)], [queue.Queue(maxsize=2) for _ in range(n_tail)]
+    # the stages' thread counts add up to the CPUs the process may use: beyond that the threads do not run in parallel, they get the process
+    # throttled (measured on the MI355X box: 256 hardware threads visible, quota 16 -- profiles/r03c_cgroup.txt)
+    n_parse = int(os.environ.get("BM2_E2E_PARSE_THREADS", max(1, min(hw // 4, 32))))
+    so = bm2.default_sam_opt(n_threads=int(os.environ.get("BM2_E2E_TAIL_THREADS", n_threads or max((hw - n_parse) // n_tail, 1))))
+    q_parsed, q_hits = [queue.Queue(maxsize=2) for _ in range(n_dev)], [queue.Queue(maxsize=1) for _ in range(n_tail)]
+    free_pins = queue.Queue()
+    for _ in range(n_dev + 2 * n_tail):
+        free_pins.put([None])
     stage, err, lock = {}, [], threading.Lock()
     done = [0] * len(work)
     devs_left, n_done = [n_dev], [0]
@@ -340,8 +348,15 @@ def end_to_end(ctx, bm2, texts, opt, paired, n_threads, n_tail=3, limit_s=None, 
                 t = time.perf_counter(); c.batch_upload_chunk(ch); add("h2d", time.perf_counter() - t)
                 t = time.perf_counter(); c.batch_run(opt); add("device", time.perf_counter() - t)
                 t = time.perf_counter(); c.batch_finish(opt); add("a19", time.perf_counter() - t)
-                t = time.perf_counter(); aln, aln_off = c.batch_download_alnregs(); add("d2h", time.perf_counter() - t)
-                q_hits[i % n_tail].put((i, ch, aln, aln_off, n_before))
+                pin = free_pins.get()                             # a page-locked hit buffer from the pool (its last reader, a tail worker, has returned it)
+                t = time.perf_counter()
+                if pin[0] is None or len(pin[0].a) < 3 * ch.n_reads:
+                    if pin[0] is not None:
+                        pin[0].close()
+                    pin[0] = bm2.Pinned(max(3 * ch.n_reads, 1 << 16), bm2.ALNREG_DT)
+                aln, aln_off = c.batch_download_alnregs(out=pin[0].a)
+                add("d2h", time.perf_counter() - t)
+                q_hits[i % n_tail].put((i, ch, aln, aln_off, n_before, pin))
         except Exception as e:                                    # noqa
             err.append(e)
         with lock:
@@ -358,13 +373,15 @@ def end_to_end(ctx, bm2, texts, opt, paired, n_threads, n_tail=3, limit_s=None, 
                 it = q_hits[k].get()
                 if it is None:
                     break
-                i, ch, aln, aln_off, n_before = it
+                i, ch, aln, aln_off, n_before, pin = it
                 if buf is None:
                     buf = np.empty(max(1 << 20, int(3 * (int(ch.f.n_bases) + 200 * ch.n_reads))), np.uint8)
                 t = time.perf_counter()
                 txt = tails[k].sam(ch, opt, so, aln, aln_off, n_before, paired, out=buf)
                 add("tail", time.perf_counter() - t)
                 done[i] = (len(txt), ch.n_reads)
+                aln = None
+                free_pins.put(pin)
                 ch.close()
                 with lock:
                     n_done[0] += 1
@@ -407,11 +424,15 @@ def end_to_end(ctx, bm2, texts, opt, paired, n_threads, n_tail=3, limit_s=None, 
         raise err[0]
     for c in tails + devs[1:]:
         c.close()
+    while not free_pins.empty():
+        pin = free_pins.get()
+        if pin[0] is not None:
+            pin[0].close()
     timed = done[n_warm:]
     out_bytes = sum(d[0] for d in timed); n_reads = sum(d[1] for d in timed)
     nch = max(len(texts), 1)
     return {"value": n_reads / dt, "unit": "reads/s", "reads": n_reads, "chunks": len(texts), "warmup_chunks": n_warm, "wall_s": dt, "sam_bytes": out_bytes,
-            "host_threads": hw, "parse_threads": n_parse, "device_workers": n_dev, "tail_workers": n_tail, "threads_per_tail_worker": so.n_threads,
+            "host_cpus": hw, "host_threads_visible": os.cpu_count(), "parse_threads": n_parse, "device_workers": n_dev, "tail_workers": n_tail, "threads_per_tail_worker": so.n_threads,
             "stage_ms_per_chunk": {k: v / nch * 1e3 for k, v in stage.items()},
             "scope": "FASTQ text in host memory -> bm2_fastq_parse_mt | H2D -> device pipeline incl. mem_sort_dedup_patch (a19) -> D2H | pairing / "
                      "mate rescue / CIGAR (device batches) / SAM text in host memory; one host thread per stage worker (%d device workers on contexts "

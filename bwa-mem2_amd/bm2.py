@@ -90,11 +90,39 @@ class Stats(C.Structure):
 
 
 EXPORTS = ["bm2_index_load", "bm2_index_free", "bm2_opt_init", "bm2_opt_fill_scmat", "bm2_create", "bm2_create_shared", "bm2_destroy",
-           "bm2_last_error", "bm2_device_count", "bm2_bsw", "bm2_bsw_upload", "bm2_bsw_run", "bm2_bsw_download", "bm2_smem", "bm2_sal", "bm2_seed_chain_extend",
+           "bm2_last_error", "bm2_device_count", "bm2_host_cpus", "bm2_host_alloc", "bm2_host_free", "bm2_bsw", "bm2_bsw_upload", "bm2_bsw_run", "bm2_bsw_download", "bm2_smem", "bm2_sal", "bm2_seed_chain_extend",
            "bm2_batch_upload", "bm2_batch_run", "bm2_batch_stats", "bm2_batch_download", "bm2_batch_kernel_ms",
            "bm2_batch_fetch", "bm2_batch_finish", "bm2_batch_download_alnregs", "bm2_finish_regs_dev", "bm2_chunk_hits_sharded", "bm2_index_build", "bm2_sam_opt_init", "bm2_sam_se", "bm2_sam_pe", "bm2_fastq_parse", "bm2_fastq_parse_mt", "bm2_fastq_free", "bm2_ksw_align2", "bm2_ksw_align2_dev", "bm2_sam_pe_dev", "bm2_sam_se_dev", "bm2_sam_cigar_stats", "bm2_gen_cigar", "bm2_gen_cigar_dev", "bm2_sam_header", "bm2_sam_rescue_stats"]
 
 _lib = None
+
+
+def host_cpus():
+    """CPUs this process can really use (hardware threads capped by the cgroup CPU-time quota): bm2_host_cpus"""
+    return int(lib().bm2_host_cpus())
+
+
+class Pinned:
+    """A page-locked host array (bm2_host_alloc): .a is a numpy view; close() frees it."""
+
+    def __init__(self, n, dtype=np.uint8):
+        L = lib()
+        L.bm2_host_alloc.restype = C.c_void_p
+        L.bm2_host_alloc.argtypes = [C.c_int64]
+        L.bm2_host_free.argtypes = [C.c_void_p]
+        L.bm2_host_free.restype = None
+        dt = np.dtype(dtype)
+        self.nbytes = max(int(n), 1) * dt.itemsize
+        self.p = L.bm2_host_alloc(self.nbytes)
+        if not self.p:
+            raise MemoryError("bm2_host_alloc(%d): %s" % (self.nbytes, L.bm2_last_error()))
+        self.a = np.frombuffer((C.c_uint8 * self.nbytes).from_address(self.p), dtype=dt)
+
+    def close(self):
+        if self.p:
+            self.a = None
+            lib().bm2_host_free(C.c_void_p(self.p))
+            self.p = None
 
 
 def build():
@@ -382,7 +410,8 @@ class Context:
         L.bm2_batch_finish.argtypes = [C.c_void_p, C.POINTER(Opt)]
         _chk(L.bm2_batch_finish(self.h, C.byref(opt)), "bm2_batch_finish")
 
-    def batch_download_alnregs(self, cap=None):
+    def batch_download_alnregs(self, cap=None, out=None):
+        """-> (alnregs, aln_off); out = a caller's ALNREG_DT array to fill when it is large enough (e.g. pinned_empty: no staging copy)"""
         nr = self._n_reads
         aln_off = np.empty(nr + 1, np.int64)
         L = lib()
@@ -391,7 +420,8 @@ class Context:
         rc = L.bm2_batch_download_alnregs(self.h, None, 0, aln_off.ctypes.data, C.byref(n))       # the count first: an exact, untouched buffer
         if rc not in (BM2_OK, BM2_ECAP):
             _chk(rc, "bm2_batch_download_alnregs")
-        out = np.empty(max(int(n.value), 1), ALNREG_DT)
+        if out is None or len(out) < max(int(n.value), 1):
+            out = np.empty(max(int(n.value), 1), ALNREG_DT)
         _chk(L.bm2_batch_download_alnregs(self.h, out.ctypes.data, len(out), aln_off.ctypes.data, C.byref(n)), "bm2_batch_download_alnregs")
         return out[:n.value], aln_off
 

@@ -83,8 +83,22 @@ static int pin_ready(bm2_ctx *c) {
     }
     return BM2_OK;
 }
+// Page-locked host memory for the caller's big per-chunk arrays (reads in, hits and text out): copies from / to such memory go straight
+// over the DMA engines at PCIe speed and cost the host no memcpy into the staging buffers (bm2_copy_* notice it by themselves).
+extern "C" void *bm2_host_alloc(int64_t bytes) {
+    void *p = nullptr;
+    if (bytes <= 0 || bm2_check(hipHostMalloc(&p, (size_t)bytes, hipHostMallocPortable), "hipHostMalloc")) return nullptr;
+    return p;
+}
+extern "C" void bm2_host_free(void *p) { if (p) (void)hipHostFree(p); }
+static bool is_pinned(const void *host) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, host) != hipSuccess) { (void)hipGetLastError(); return false; }   // (plain malloc'd memory: "invalid value")
+    return a.type == hipMemoryTypeHost;
+}
+
 int bm2_copy_h2d(bm2_ctx *c, void *dst_dev, const void *src_host, size_t bytes) {
-    if (bytes < BM2_PIN_MIN || pin_ready(c)) {
+    if (bytes < BM2_PIN_MIN || is_pinned(src_host) || pin_ready(c)) {
         int rc = bm2_check(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, c->stream), "H2D");
         return rc ? rc : bm2_check(hipStreamSynchronize(c->stream), "H2D sync");
     }
@@ -100,7 +114,7 @@ int bm2_copy_h2d(bm2_ctx *c, void *dst_dev, const void *src_host, size_t bytes) 
     return bm2_check(hipStreamSynchronize(c->stream), "H2D sync");
 }
 int bm2_copy_d2h(bm2_ctx *c, void *dst_host, const void *src_dev, size_t bytes) {
-    if (bytes < BM2_PIN_MIN || pin_ready(c)) {
+    if (bytes < BM2_PIN_MIN || is_pinned(dst_host) || pin_ready(c)) {
         int rc = bm2_check(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, c->stream), "D2H");
         return rc ? rc : bm2_check(hipStreamSynchronize(c->stream), "D2H sync");
     }

@@ -199,7 +199,7 @@ int seq_fallback(const char *t1, int64_t n1, const char *t2, int64_t n2, bm2_fas
 
 extern "C" int bm2_fastq_parse_mt(const char *text1, int64_t n1, const char *text2, int64_t n2, int n_threads, bm2_fastq *out) {
     if (!out || n1 < 0 || (n1 > 0 && !text1) || n2 < 0 || (n2 > 0 && !text2)) { bm2_set_error("bm2_fastq_parse_mt: bad argument"); return BM2_EINVAL; }
-    if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency();
+    if (n_threads <= 0) n_threads = bm2_effective_cpus();
     if (n_threads < 1) n_threads = 1;
     const bool paired = text2 != nullptr;
     std::vector<std::vector<Span>> pa, pb;
@@ -291,3 +291,5 @@ int seq_fallback(const char *t1, int64_t n1, const char *t2, int64_t n2, bm2_fas
     return BM2_OK;
 }
 }  // namespace
+
+extern "C" int bm2_host_cpus(void) { return bm2_effective_cpus(); }

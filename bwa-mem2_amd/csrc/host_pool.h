@@ -5,6 +5,7 @@
 #include <pthread.h>
 #include <sched.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <sys/syscall.h>
 #include <unistd.h>
@@ -30,11 +31,11 @@ class TailPool {
         __builtin_ia32_pause();
 #endif
     }
-    // How long a thread polls a word before it sleeps on it: ~1 ms by default (BM2_POOL_SPIN_US).  The gaps between the phases of a chunk
+    // How long a thread polls a word before it sleeps on it: ~100 us by default (BM2_POOL_SPIN_US; polling burns CPU-time quota where there is one).  The gaps between the phases of a chunk
     // are mostly shorter (prefix sums, a scan over blocks), and a sleeper's wake-up costs a scheduler round trip -- milliseconds where the
     // CPUs are virtual and halt when idle -- while a poller on an otherwise idle CPU costs nothing that anybody wanted.
     static int spin_rounds() {
-        static const int r = []() { const char *e = getenv("BM2_POOL_SPIN_US"); const long us = e && *e ? atol(e) : 1000; return (int)(us < 0 ? 0 : us > 100000 ? 100000 : us); }();
+        static const int r = []() { const char *e = getenv("BM2_POOL_SPIN_US"); const long us = e && *e ? atol(e) : 100; return (int)(us < 0 ? 0 : us > 100000 ? 100000 : us); }();
         return r;                                                 // rounds of ~1 us (16 pauses)
     }
     template <class W> static void wait_while_equal(std::atomic<uint32_t> *w, uint32_t seen, W still) {
@@ -117,14 +118,40 @@ public:
             wait_while_equal(&left, l, [&]() { return left.load(std::memory_order_acquire) == l; });
     }
 };
+// The CPUs this process can really use: the hardware threads it may run on, capped by its cgroup's CPU-time quota (cgroup v2 cpu.max,
+// v1 cpu.cfs_quota_us / cpu.cfs_period_us).  A GPU slice of a shared node typically sees every hardware thread of the host but is given
+// the time of a few (measured on the MI355X box of this project: 256 visible, quota 16): threads beyond the quota do not run in
+// parallel, they get the whole process throttled for the rest of the scheduler period -- and spinning burns the quota too.
+inline int bm2_effective_cpus() {
+    static const int n = []() {
+        int hw = (int)std::thread::hardware_concurrency();
+        cpu_set_t all;
+        if (sched_getaffinity(getpid(), sizeof all, &all) == 0 && CPU_COUNT(&all) > 0 && CPU_COUNT(&all) < hw) hw = CPU_COUNT(&all);
+        if (hw < 1) hw = 1;
+        long long quota = -1, period = 100000;
+        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char q[64] = "";
+            if (fscanf(f, "%63s %lld", q, &period) >= 1 && q[0] != 'm') quota = atoll(q);
+            fclose(f);
+        } else {
+            if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(g, "%lld", &quota) != 1) quota = -1; fclose(g); }
+            if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(g, "%lld", &period) != 1) period = 100000; fclose(g); }
+        }
+        if (quota > 0 && period > 0) { const int c = (int)((quota + period - 1) / period); if (c >= 1 && c < hw) hw = c; }
+        const char *e = getenv("BM2_HOST_CPUS");                  // (override)
+        if (e && atoi(e) > 0) hw = atoi(e);
+        return hw;
+    }();
+    return n;
+}
+
 // How many host threads the call in progress on THIS thread may use (bm2_sam_pe / bm2_sam_se set it from bm2_sam_opt::n_threads for
 // the batch hooks they call, which have no such argument); 0 = all hardware threads.
 inline int &bm2_host_thread_budget() { static thread_local int v = 0; return v; }
 inline int bm2_host_threads() {
     const int b = bm2_host_thread_budget();
     if (b > 0) return b;
-    const int h = (int)std::thread::hardware_concurrency();
-    return h > 0 ? h : 1;
+    return bm2_effective_cpus();
 }
 
 inline void bm2_run_threads(int n_threads, std::function<void()> f) {

@@ -6,6 +6,7 @@
 // human genome); here suffixes are bucketed by their first 11 bases and every bucket is sorted independently on all host
 // cores with word-wise comparisons on a 2-bit packed text -- what lets a GRCh38-size synthetic genome be indexed inside a
 // benchmark run.  Host code; no GPU involved.
+#include "host_pool.h"
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -80,7 +81,7 @@ extern "C" int bm2_index_build(const char *fasta, const char *prefix, int n_thre
         if (verbose) fprintf(stderr, "[bm2_index_build] %-28s %.2f s\n", what, std::chrono::duration<double>(now - t_last).count());
         t_last = now;
     };
-    if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency();
+    if (n_threads <= 0) n_threads = bm2_effective_cpus();
     if (n_threads <= 0) n_threads = 1;
     // ---- 1. FASTA -> contigs, holes, forward bases (N -> lrand48()&3 after srand48(11): bntseq.cpp:284,314-315)
     FILE *f = fopen(fasta, "rb");

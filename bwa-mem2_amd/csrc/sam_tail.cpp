@@ -796,7 +796,7 @@ void pestat(const bm2_opt *opt, const bm2_sam_opt *so, int64_t l_pac, const std:
     const int n_pairs = (int)(regs.size() >> 1);
     const int64_t top = so->max_ins > 0 ? so->max_ins : 0;       // bins 1 .. max_ins
     for (int d = 0; d < 4; ++d) pes[d] = PeStat();
-    int nt = so->n_threads > 0 ? so->n_threads : (int)std::thread::hardware_concurrency();
+    int nt = so->n_threads > 0 ? so->n_threads : bm2_effective_cpus();
     if (nt > n_pairs / 8192 + 1) nt = n_pairs / 8192 + 1;
     if (nt < 1) nt = 1;
     const size_t bins = (size_t)top + 1;
@@ -1276,7 +1276,7 @@ inline void cpu_relax() {
 // the caller's buffer: the chunk's text never exists a second time.  *n_out = bytes needed; BM2_ECAP when cap is smaller (what fitted
 // was written); a failing item makes the call return BM2_EINVAL with the item's number in `bad`.
 template <class F> int run_blocks(int n, int n_threads, char *out, int64_t cap, int64_t *n_out, int *bad, F f) {
-    if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency();
+    if (n_threads <= 0) n_threads = bm2_effective_cpus();
     if (n_threads < 1) n_threads = 1;
     const int block = 256;
     const int n_blocks = (n + block - 1) / block;
@@ -1447,7 +1447,7 @@ static int host_flat_batch(void *user, int32_t n, const uint8_t *qbuf, int64_t, 
 extern "C" int bm2_sam_pe(const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt *so, const bm2_reads *reads,
                           const bm2_read_text *txt, const bm2_alnreg_t *alnregs, const int64_t *reg_off, int64_t n_processed,
                           const bm2_pestat *pes_in, bm2_pestat *pes_out, char *out, int64_t cap, int64_t *n_out) {
-    int n_threads = so && so->n_threads > 0 ? so->n_threads : (int)std::thread::hardware_concurrency();
+    int n_threads = so && so->n_threads > 0 ? so->n_threads : bm2_effective_cpus();
     if (n_threads < 1) n_threads = 1;
     const char *flat = getenv("BM2_RESCUE_FLAT");
     const char *cflat = getenv("BM2_CIGAR_FLAT");
@@ -1472,7 +1472,7 @@ int bm2h_sam_pe(const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt
     std::vector<std::vector<bm2_alnreg_t>> regs((size_t)n);
     std::atomic<int> name_clash(-1);
     {
-        int nt = so->n_threads > 0 ? so->n_threads : (int)std::thread::hardware_concurrency();
+        int nt = so->n_threads > 0 ? so->n_threads : bm2_effective_cpus();
         if (nt < 1) nt = 1;
         if (nt > n / 4096 + 1) nt = n / 4096 + 1;
         std::atomic<int> nx(0);
@@ -1504,7 +1504,7 @@ int bm2h_sam_pe(const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt
     const bool batch = !(so->flag & F_NO_RESCUE) && !so->rescue_inline;
     g_rescue.planned = 0; g_rescue.used = 0; g_rescue.missed = 0;
     if (batch) {
-        int n_threads = so->n_threads > 0 ? so->n_threads : (int)std::thread::hardware_concurrency();
+        int n_threads = so->n_threads > 0 ? so->n_threads : bm2_effective_cpus();
         if (n_threads < 1) n_threads = 1;
         const int blk = 256, n_blk = (n_pairs + blk - 1) / blk;
         const int nt_blk = n_threads < n_blk ? n_threads : n_blk;
@@ -1613,7 +1613,7 @@ int bm2h_sam_pe(const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt
     g_cigar.planned = 0; g_cigar.used = 0; g_cigar.missed = 0;
     std::vector<PairPlan> plans;
     if (cfn) {                                                   // CIGAR session: decide every pair, note the hits its text will ask for, batch; then print
-        int n_threads = so->n_threads > 0 ? so->n_threads : (int)std::thread::hardware_concurrency();
+        int n_threads = so->n_threads > 0 ? so->n_threads : bm2_effective_cpus();
         if (n_threads < 1) n_threads = 1;
         plans.resize((size_t)n_pairs);
         const int blk = 256, n_blk = (n_pairs + blk - 1) / blk;
@@ -1650,7 +1650,7 @@ int bm2h_sam_pe(const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt
     prof.mark("real pass + copy");
     {   // a million small hit lists: released by the threads, not one by one on the way out
         std::atomic<int> nx(0);
-        int nt = so->n_threads > 0 ? so->n_threads : (int)std::thread::hardware_concurrency();
+        int nt = so->n_threads > 0 ? so->n_threads : bm2_effective_cpus();
         if (nt > n / 4096 + 1) nt = n / 4096 + 1;
         run_threads(nt < 1 ? 1 : nt, [&]() {
             for (int lo; (lo = nx.fetch_add(4096)) < n;)
@@ -1695,7 +1695,7 @@ int bm2h_sam_se(const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt
     g_cigar.planned = 0; g_cigar.used = 0; g_cigar.missed = 0;
     for (int64_t k = 0; k < reg_off[n_reads]; ++k) alnregs[k].pad = (int32_t)(k + 1);     // the hit's number (CIGAR batch); the lists are reordered in place
     if (cfn) {                                                   // CIGAR session (see reg2aln): decide, note the hits the text will ask for, batch; then print
-        int n_threads = so->n_threads > 0 ? so->n_threads : (int)std::thread::hardware_concurrency();
+        int n_threads = so->n_threads > 0 ? so->n_threads : bm2_effective_cpus();
         if (n_threads < 1) n_threads = 1;
         const int blk = 512, n_blk = (n_reads + blk - 1) / blk;
         std::vector<std::vector<int32_t>> recs((size_t)n_blk);

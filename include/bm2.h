@@ -128,6 +128,13 @@ bm2_ctx *bm2_create_shared(bm2_ctx *parent);
 void     bm2_destroy(bm2_ctx *c);
 const char *bm2_last_error(void);
 int      bm2_device_count(void);
+/* the CPUs this process can really use: hardware threads it may run on, capped by its cgroup CPU-time quota (a GPU slice of a shared node
+ * sees every hardware thread of the host but is given the time of a few); the default of every n_threads <= 0 in this library */
+int      bm2_host_cpus(void);
+/* page-locked host memory for a caller's large per-chunk arrays (reads, hits, text): the library's copies from / to it are plain DMA at
+ * PCIe speed instead of a staged copy through 16 MB bounce buffers; anything else the caller passes is staged, as before */
+void    *bm2_host_alloc(int64_t bytes);
+void     bm2_host_free(void *p);
 
 /* ---- S1: BandedPairWiseSW::getScores8 / getScores16 / scalarBandedSWAWrapper (bandedSWA.h:126-135,
  * 199-211; call sites bwamem.cpp:2476,2544,2613,2692,2757,2828).  Fills score,tle,gtle,qle,gscore,max_off

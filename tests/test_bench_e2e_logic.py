@@ -42,8 +42,9 @@ class _Ctx:
     def batch_finish(self, opt):
         pass
 
-    def batch_download_alnregs(self):
-        return np.zeros(1), np.zeros(2, np.int64)
+    def batch_download_alnregs(self, out=None):
+        assert out is not None and len(out) >= 3 * self.cur.n_reads      # the pool's page-locked buffer
+        return out[:1], np.zeros(2, np.int64)
 
     def sam(self, ch, opt, so, aln, aln_off, n_before, paired, out=None):
         time.sleep(self.tail_sleep)
@@ -54,8 +55,19 @@ class _Ctx:
         pass
 
 
+class _Pinned:
+    live = 0
+
+    def __init__(self, n, dtype=np.uint8):
+        self.a = np.zeros(n, dtype)
+        _Pinned.live += 1
+
+    def close(self):
+        _Pinned.live -= 1
+
+
 def _fake_bm2(**kw):
-    return types.SimpleNamespace(Context=lambda share=None: _Ctx(share=share), FastqChunk=_Chunk,
+    return types.SimpleNamespace(Context=lambda share=None: _Ctx(share=share), FastqChunk=_Chunk, host_cpus=lambda: 64, Pinned=_Pinned, ALNREG_DT=np.uint8,
                                  default_sam_opt=lambda n_threads=0: types.SimpleNamespace(n_threads=n_threads))
 
 
@@ -68,6 +80,7 @@ def test_pipeline_counts_only_the_timed_chunks_and_seeds_the_read_numbers():
     timed = [x for x in _Ctx.log][-7:]                            # the warm-up chunks come first, then every chunk once more
     before = {tag[0]: nb for tag, nb in timed}
     assert before == {i: sum(100 + j for j in range(i)) for i in range(7)}
+    assert _Pinned.live == 0                                       # every pool buffer was released
 
 
 def test_an_error_in_a_stage_is_raised_not_waited_for():
