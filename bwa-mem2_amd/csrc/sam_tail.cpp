@@ -67,13 +67,94 @@ struct Ref {                        // what bntseq_t + pac give this code
     }
 };
 
-void put_int(std::string &s, long long v) {                    // kputw / kputl (kstring.h:92-141): plain decimal
-    char b[24]; int l = 0;
+template <class S> void put_int(S &s, long long v) {           // kputw / kputl (kstring.h:92-141): plain decimal
+    char b[24]; int l = 24;
     unsigned long long x = v < 0 ? 0ULL - (unsigned long long)v : (unsigned long long)v;
-    do { b[l++] = (char)('0' + x % 10); x /= 10; } while (x);
-    if (v < 0) b[l++] = '-';
-    while (l) s.push_back(b[--l]);
+    do { b[--l] = (char)('0' + x % 10); x /= 10; } while (x);
+    if (v < 0) b[--l] = '-';
+    s.append(b + l, (size_t)(24 - l));
 }
+
+// ---- memory of the text pass.  A pair's records are built from a dozen small arrays (CIGARs with their clips, XA strings, the list of
+// printed alignments); from the general-purpose allocator they were the largest single cost of the pass on a many-core host.  They
+// live in a per-thread bump arena that is reset per pair (nothing is freed one by one), and the text itself goes into a plain
+// growing buffer whose appends do not maintain a terminator.
+struct Arena {
+    std::vector<std::pair<char *, size_t>> blocks; size_t cur = 0, at = 0;
+    Arena() {}
+    Arena(const Arena &) = delete;
+    ~Arena() { for (auto &b : blocks) free(b.first); }
+    void *get(size_t bytes) {
+        bytes = (bytes + 15) & ~(size_t)15;
+        while (cur < blocks.size() && at + bytes > blocks[cur].second) { ++cur; at = 0; }
+        if (cur == blocks.size()) {
+            size_t sz = blocks.empty() ? (size_t)1 << 16 : blocks.back().second * 2;
+            if (sz < bytes) sz = bytes;
+            char *m = (char *)malloc(sz);
+            if (!m) throw std::bad_alloc();
+            blocks.emplace_back(m, sz); at = 0;
+        }
+        void *r = blocks[cur].first + at; at += bytes;
+        return r;
+    }
+    void reset() { cur = 0; at = 0; }
+};
+thread_local Arena t_scratch;
+
+template <class T> struct AVec {    // a vector of trivially copyable T in the thread's arena (valid until the arena is reset)
+    T *p = nullptr; int n = 0, cap = 0;
+    void reserve(int c) {
+        if (c <= cap) return;
+        int nc = cap * 2 > c ? cap * 2 : c; if (nc < 4) nc = 4;
+        T *q = (T *)t_scratch.get(sizeof(T) * (size_t)nc);
+        if (n) memcpy((void *)q, (const void *)p, sizeof(T) * (size_t)n);
+        p = q; cap = nc;
+    }
+    void push_back(const T &v) { reserve(n + 1); p[n++] = v; }
+    void append(const T *b, size_t k) { reserve(n + (int)k); if (k) memcpy((void *)(p + n), (const void *)b, sizeof(T) * k); n += (int)k; }
+    void assign(const T *b, const T *e) { n = 0; append(b, (size_t)(e - b)); }
+    void fill(int count, const T &v) { n = 0; reserve(count); for (int i = 0; i < count; ++i) p[i] = v; n = count; }
+    void clear() { n = 0; }
+    void erase_front() { if (n > 1) memmove((void *)p, (const void *)(p + 1), sizeof(T) * (size_t)(n - 1)); --n; }
+    void insert_front(const T &v) { reserve(n + 1); if (n) memmove((void *)(p + 1), (const void *)p, sizeof(T) * (size_t)n); p[0] = v; ++n; }
+    void pop_back() { --n; }
+    T &back() { return p[n - 1]; }
+    const T &back() const { return p[n - 1]; }
+    bool empty() const { return n == 0; }
+    int size() const { return n; }
+    T &operator[](int i) { return p[i]; }
+    const T &operator[](int i) const { return p[i]; }
+    const T *begin() const { return p; }
+    const T *end() const { return p + n; }
+    void operator+=(const char *z) { append((const T *)z, strlen(z)); }       // (T = char)
+};
+
+struct Text {                       // the output of a thread: appends only, no terminator
+    char *b = nullptr; size_t n = 0, cap = 0;
+    Text() {}
+    Text(const Text &) = delete;
+    ~Text() { free(b); }
+    void grow(size_t k) {
+        size_t nc = cap * 2 > n + k ? cap * 2 : n + k; if (nc < 4096) nc = 4096;
+        char *q = (char *)realloc(b, nc);
+        if (!q) throw std::bad_alloc();
+        b = q; cap = nc;
+    }
+    void need(size_t k) { if (n + k > cap) grow(k); }
+    void push_back(char c) { need(1); b[n++] = c; }
+    void append(const char *p, size_t k) { need(k); memcpy(b + n, p, k); n += k; }
+    void operator+=(const char *z) { append(z, strlen(z)); }
+    char *extend(size_t k) { need(k); char *r = b + n; n += k; return r; }    // k bytes to be written in place
+    void clear() { n = 0; }
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+    const char *data() const { return b; }
+};
+struct MdOut {                      // gen_cigar's MD sink: appends like Text, on a std::string (the C ABI's bm2_gen_cigar hands the string out)
+    std::string &s;
+    void push_back(char c) { s.push_back(c); }
+    void append(const char *p, size_t k) { s.append(p, k); }
+};
 
 // ---- banded global alignment with traceback ---------------------------------------------------------------------------
 // Banded global alignment with traceback; must reproduce ksw_global2 (ksw.cpp:558-668) decision for decision, because the CIGAR of a
@@ -176,6 +257,7 @@ bool gen_cigar(const int8_t mat[25], int o_del, int e_del, int o_ins, int e_ins,
         *score = global_align(l_query, q.data(), (int)rlen, rseq.data(), mat, o_del, e_del, o_ins, e_ins, w, cigar);
     }
     {   // NM and MD (:311-340)
+        MdOut MDo{MD};
         int x = 0, y = 0, u = 0, n_mm = 0, n_gap = 0;
         const char *int2base = rb < l_pac ? "ACGTN" : "TGCAN";
         const int n = (int)cigar.size();
@@ -183,28 +265,28 @@ bool gen_cigar(const int8_t mat[25], int o_del, int e_del, int o_ins, int e_ins,
             const int op = cigar[k] & 0xf, len = (int)(cigar[k] >> 4);
             if (op == 0) {
                 for (int i = 0; i < len; ++i) {
-                    if (q[x + i] != rseq[y + i]) { put_int(MD, u); MD.push_back(int2base[rseq[y + i]]); ++n_mm; u = 0; }
+                    if (q[x + i] != rseq[y + i]) { put_int(MDo, u); MD.push_back(int2base[rseq[y + i]]); ++n_mm; u = 0; }
                     else ++u;
                 }
                 x += len; y += len;
             } else if (op == 2) {
                 if (k > 0 && k < n - 1) {
-                    put_int(MD, u); MD.push_back('^');
+                    put_int(MDo, u); MD.push_back('^');
                     for (int i = 0; i < len; ++i) MD.push_back(int2base[rseq[y + i]]);
                     u = 0; n_gap += len;
                 }
                 y += len;
             } else if (op == 1) { x += len; n_gap += len; }
         }
-        put_int(MD, u);
+        put_int(MDo, u);
         *NM = n_mm + n_gap;
     }
     return true;
 }
 
-struct Aln {                        // mem_aln_t (bwamem.h:168-178)
+struct Aln {                        // mem_aln_t (bwamem.h:168-178); CIGAR, MD and XA live in the thread's arena or in the batch's results
     int64_t pos = -1; int rid = -1, flag = 0, is_rev = 0, is_alt = 0, mapq = 0, NM = 0;
-    std::vector<uint32_t> cigar; std::string MD; const std::string *XA = nullptr;
+    AVec<uint32_t> cigar; const char *MD = ""; const AVec<char> *XA = nullptr;
     int score = 0, sub = 0, alt_sc = 0;
 };
 
@@ -290,7 +372,7 @@ bool reg2aln(const bm2_opt *opt, const bm2_sam_opt *so, const Ref &R, int l_quer
         int is_rev;
         const int64_t pos = R.depos(rb < R.l_pac ? rb : re - 1, &is_rev);
         a.is_rev = is_rev; a.rid = R.pos2rid(pos); if (a.rid < 0) a.rid = 0;
-        a.pos = pos - R.off[a.rid]; a.cigar.assign(1, (uint32_t)(qe - qb) << 4); a.score = ar->score; a.is_alt = ar->is_alt;
+        a.pos = pos - R.off[a.rid]; a.cigar.fill(1, (uint32_t)(qe - qb) << 4); a.score = ar->score; a.is_alt = ar->is_alt;
         return true;
     }
     int at = -1;
@@ -308,24 +390,33 @@ bool reg2aln(const bm2_opt *opt, const bm2_sam_opt *so, const Ref &R, int l_quer
         const bm2h_cg_out &O = t_cg.memo->out;
         ok = O.n_cigar[(size_t)at] >= 0;
         score = O.score[(size_t)at]; NM = O.nm[(size_t)at];
-        a.cigar.clear(); a.MD.clear();
-        if (ok) {
-            a.cigar.assign(O.cigar.begin() + O.cigar_off[(size_t)at], O.cigar.begin() + O.cigar_off[(size_t)at] + O.n_cigar[(size_t)at]);
+        a.cigar.clear(); a.MD = "";
+        if (ok) {                                                // (the ops are copied: clips are added below; the MD string is read where it lies)
+            a.cigar.assign(O.cigar.data() + O.cigar_off[(size_t)at], O.cigar.data() + O.cigar_off[(size_t)at] + O.n_cigar[(size_t)at]);
             a.MD = O.md.data() + O.md_off[(size_t)at];
         }
-    } else ok = cigar_with_retries(opt, R, query, qb, qe, rb, re, ar->truesc, ar->w, &score, a.cigar, &NM, a.MD);
+    } else {                                                     // a rescued hit (or a hit the batch does not know): aligned here
+        static thread_local std::vector<uint32_t> cg_tl; static thread_local std::string md_tl;
+        ok = cigar_with_retries(opt, R, query, qb, qe, rb, re, ar->truesc, ar->w, &score, cg_tl, &NM, md_tl);
+        if (ok) {
+            a.cigar.assign(cg_tl.data(), cg_tl.data() + cg_tl.size());
+            char *m = (char *)t_scratch.get(md_tl.size() + 1);
+            memcpy(m, md_tl.c_str(), md_tl.size() + 1);
+            a.MD = m;
+        }
+    }
     if (!ok) return false;                                      // the reference asserts a.cigar != NULL here
     a.NM = NM;
     int is_rev;
     int64_t pos = R.depos(rb < R.l_pac ? rb : re - 1, &is_rev);
     a.is_rev = is_rev;
     if (!a.cigar.empty()) {                                     // squeeze out a leading or a trailing deletion
-        if ((a.cigar[0] & 0xf) == 2) { pos += a.cigar[0] >> 4; a.cigar.erase(a.cigar.begin()); }
+        if ((a.cigar[0] & 0xf) == 2) { pos += a.cigar[0] >> 4; a.cigar.erase_front(); }
         else if ((a.cigar.back() & 0xf) == 2) a.cigar.pop_back();
     }
     if (qb != 0 || qe != l_query) {                             // clipping
         const int clip5 = is_rev ? l_query - qe : qb, clip3 = is_rev ? qb : l_query - qe;
-        if (clip5) a.cigar.insert(a.cigar.begin(), (uint32_t)clip5 << 4 | 3);
+        if (clip5) a.cigar.insert_front((uint32_t)clip5 << 4 | 3);
         if (clip3) a.cigar.push_back((uint32_t)clip3 << 4 | 3);
     }
     a.rid = R.pos2rid(pos);
@@ -343,13 +434,13 @@ uint64_t hash_64(uint64_t key) {                                // utils.h:117-1
 }
 
 // mem_mark_primary_se_core, bwamem.cpp:1392-1418
-void mark_primary_core(const bm2_opt *opt, int n, bm2_alnreg_t *a, std::vector<int> &z) {
+void mark_primary_core(const bm2_opt *opt, int n, bm2_alnreg_t *a, AVec<int> &z) {
     int tmp = opt->a + opt->b;
     tmp = opt->o_del + opt->e_del > tmp ? opt->o_del + opt->e_del : tmp;
     tmp = opt->o_ins + opt->e_ins > tmp ? opt->o_ins + opt->e_ins : tmp;
     z.clear(); z.push_back(0);
     for (int i = 1; i < n; ++i) {
-        size_t k;
+        int k;
         for (k = 0; k < z.size(); ++k) {
             const int j = z[k];
             const int b_max = a[j].qb > a[i].qb ? a[j].qb : a[i].qb, e_min = a[j].qe < a[i].qe ? a[j].qe : a[i].qe;
@@ -371,7 +462,7 @@ void mark_primary_core(const bm2_opt *opt, int n, bm2_alnreg_t *a, std::vector<i
 int mark_primary_se(const bm2_opt *opt, int n, bm2_alnreg_t *a, int64_t id) {
     if (n == 0) return 0;
     int n_pri = 0;
-    std::vector<int> z;
+    AVec<int> z;                                                 // (scratch arena: reset per pair / read by the caller)
     for (int i = 0; i < n; ++i) {
         a[i].sub = a[i].alt_sc = 0; a[i].secondary = a[i].secondary_all = -1; a[i].hash = hash_64((uint64_t)(id + i));
         if (!a[i].is_alt) ++n_pri;
@@ -386,7 +477,7 @@ int mark_primary_se(const bm2_opt *opt, int n, bm2_alnreg_t *a, int64_t id) {
         if (!p->is_alt && p->secondary >= 0 && a[p->secondary].is_alt) p->alt_sc = a[p->secondary].score;
     }
     if (n_pri >= 0 && n_pri < n) {
-        z.assign((size_t)n, 0);
+        z.fill(n, 0);
         if (n_pri > 0)
             k_introsort((size_t)n, a, [](const bm2_alnreg_t &x, const bm2_alnreg_t &y) {  // alnreg_hlt2, bwamem.cpp:158
                 return x.is_alt < y.is_alt || (x.is_alt == y.is_alt && (x.score > y.score || (x.score == y.score && x.hash < y.hash)));
@@ -429,18 +520,19 @@ void reorder_primary5(int T, int n, bm2_alnreg_t *a) {
     }
 }
 
-void put_cigar(std::string &s, const std::vector<uint32_t> &cg, const char *ops) {
+template <class S> void put_cigar(S &s, const AVec<uint32_t> &cg, const char *ops) {
     for (uint32_t c : cg) { put_int(s, c >> 4); s.push_back(ops[c & 0xf]); }
 }
 
 // mem_gen_alt, bwamem_extra.cpp:118-183: the XA:Z value of every primary hit ("" = none)
 bool gen_alt(const bm2_opt *opt, const bm2_sam_opt *so, const Ref &R, int n, const bm2_alnreg_t *a, int l_query, const uint8_t *query,
-             std::vector<std::string> &XA, bool &any) {
+             AVec<AVec<char>> &XA, bool &any) {
     auto pri_idx = [&](int i) {
         const int k = a[i].secondary_all;
         return (k >= 0 && a[i].score >= a[k].score * (double)so->XA_drop_ratio) ? k : -1;      // (a double parameter in the reference)
     };
-    std::vector<int> cnt((size_t)n, 0); std::vector<char> has_alt((size_t)n, 0);
+    AVec<int> cnt; cnt.fill(n, 0);
+    AVec<char> has_alt; has_alt.fill(n, 0);
     int tot = 0;
     any = false;
     for (int i = 0; i < n; ++i) {
@@ -449,14 +541,14 @@ bool gen_alt(const bm2_opt *opt, const bm2_sam_opt *so, const Ref &R, int n, con
     }
     if (tot == 0) return true;
     any = true;
-    XA.assign((size_t)n, std::string());
+    XA.fill(n, AVec<char>());
     for (int i = 0; i < n; ++i) {
         const int r = pri_idx(i);
         if (r < 0) continue;
         if (cnt[r] > so->max_XA_hits_alt || (!has_alt[r] && cnt[r] > so->max_XA_hits)) continue;
         Aln t;
         if (!reg2aln(opt, so, R, l_query, query, &a[i], t)) return false;
-        std::string &s = XA[r];
+        AVec<char> &s = XA[r];
         s += R.name[t.rid]; s.push_back(','); s.push_back("+-"[t.is_rev]); put_int(s, t.pos + 1); s.push_back(',');
         put_cigar(s, t.cigar, "MIDSHN");
         s.push_back(','); put_int(s, t.NM); s.push_back(';');
@@ -464,7 +556,7 @@ bool gen_alt(const bm2_opt *opt, const bm2_sam_opt *so, const Ref &R, int n, con
     return true;
 }
 
-int get_rlen(const std::vector<uint32_t> &cg) {                // bwamem.cpp:1820-1829
+int get_rlen(const AVec<uint32_t> &cg) {                // bwamem.cpp:1820-1829
     int l = 0;
     for (uint32_t c : cg) { const int op = c & 0xf; if (op == 0 || op == 2) l += (int)(c >> 4); }
     return l;
@@ -473,19 +565,19 @@ int get_rlen(const std::vector<uint32_t> &cg) {                // bwamem.cpp:182
 // mem_aln2sam (bwamem.cpp:1592-1730); m_ = the mate's alignment or NULL.  The reference edits copies of the two records (an unmapped
 // read borrows its mate's position and loses its CIGAR, and the other way round); here the few fields that can change are locals and
 // the records themselves are only read -- no copies of CIGAR vectors and MD strings per printed line.
-void aln2sam(const bm2_sam_opt *so, const Ref &R, std::string &s, const char *name, const char *comment, const char *qual, int l_seq,
-             const uint8_t *seq, const std::vector<Aln> &list, int which, const Aln *m_) {
+void aln2sam(const bm2_sam_opt *so, const Ref &R, Text &s, const char *name, const char *comment, const char *qual, int l_seq,
+             const uint8_t *seq, const AVec<Aln> &list, int which, const Aln *m_) {
     if (t_cg.mode == 1) return;                                  // dry pass of a CIGAR session: decisions only
-    static const std::vector<uint32_t> no_cigar;
+    static const AVec<uint32_t> no_cigar = AVec<uint32_t>();
     const Aln &P = list[which];
     const int n = (int)list.size();
     const bool has_mate = m_ != nullptr;
     int p_rid = P.rid, p_rev = P.is_rev, p_flag = P.flag;
     int64_t p_pos = P.pos;
-    const std::vector<uint32_t> *p_cg = &P.cigar;
+    const AVec<uint32_t> *p_cg = &P.cigar;
     int m_rid = has_mate ? m_->rid : -1, m_rev = has_mate ? m_->is_rev : 0;
     int64_t m_pos = has_mate ? m_->pos : -1;
-    const std::vector<uint32_t> *m_cg = has_mate ? &m_->cigar : &no_cigar;
+    const AVec<uint32_t> *m_cg = has_mate ? &m_->cigar : &no_cigar;
     p_flag |= has_mate ? 0x1 : 0;
     p_flag |= p_rid < 0 ? 0x4 : 0;
     p_flag |= has_mate && m_rid < 0 ? 0x8 : 0;
@@ -493,7 +585,7 @@ void aln2sam(const bm2_sam_opt *so, const Ref &R, std::string &s, const char *na
     if (has_mate && m_rid < 0 && p_rid >= 0) { m_rid = p_rid; m_pos = p_pos; m_rev = p_rev; m_cg = &no_cigar; }         // copy alignment to mate
     p_flag |= p_rev ? 0x10 : 0;
     p_flag |= has_mate && m_rev ? 0x20 : 0;
-    auto put_cigar_of = [&](const std::vector<uint32_t> &cg, int is_alt) {     // add_cigar, bwamem.cpp:1579-1590
+    auto put_cigar_of = [&](const AVec<uint32_t> &cg, int is_alt) {     // add_cigar, bwamem.cpp:1579-1590
         if (cg.empty()) { s.push_back('*'); return; }
         for (uint32_t c0 : cg) {
             int c = c0 & 0xf;
@@ -534,9 +626,8 @@ void aln2sam(const bm2_sam_opt *so, const Ref &R, std::string &s, const char *na
                 if ((c1 & 0xf) == 4 || (c1 & 0xf) == 3) qb += c1 >> 4;
             }
         }
-        const size_t len = qe > qb ? (size_t)(qe - qb) : 0, at = s.size();
-        s.resize(at + 2 * len + 1 + (qual ? 0 : 1));             // bases, tab, qualities (or '*') written in place
-        char *d = &s[at];
+        const size_t len = qe > qb ? (size_t)(qe - qb) : 0;
+        char *d = s.extend(len + 1 + (qual ? len : 1));          // bases, tab, qualities (or '*') written in place
         if (!p_rev) {
             for (size_t i = 0; i < len; ++i) d[i] = "ACGTN"[seq[qb + (int)i]];
             d[len] = '\t';
@@ -546,7 +637,6 @@ void aln2sam(const bm2_sam_opt *so, const Ref &R, std::string &s, const char *na
             d[len] = '\t';
             if (qual) { for (size_t i = 0; i < len; ++i) d[len + 1 + i] = qual[qe - 1 - (int)i]; } else d[len + 1] = '*';
         }
-        if (!qual) s.resize(at + len + 2);
     }
     if (!p_cg->empty()) { s += "\tNM:i:"; put_int(s, P.NM); s += "\tMD:Z:"; s += P.MD; }
     if (has_mate && !m_cg->empty()) { s += "\tMC:Z:"; put_cigar_of(*m_cg, m_->is_alt); }
@@ -568,7 +658,7 @@ void aln2sam(const bm2_sam_opt *so, const Ref &R, std::string &s, const char *na
         }
         if (P.alt_sc > 0) { char b[64]; snprintf(b, sizeof b, "\tpa:f:%.3f", (double)P.score / P.alt_sc); s += b; }
     }
-    if (P.XA) { s += "\tXA:Z:"; s += *P.XA; }
+    if (P.XA) { s += "\tXA:Z:"; s.append(P.XA->p, (size_t)P.XA->n); }
     if (comment) { s.push_back('\t'); s += comment; }
     if ((so->flag & F_REF_HDR) && p_rid >= 0 && R.anno && R.anno[p_rid] && R.anno[p_rid][0]) {
         s += "\tXR:Z:";
@@ -578,29 +668,29 @@ void aln2sam(const bm2_sam_opt *so, const Ref &R, std::string &s, const char *na
 }
 
 // mem_reg2sam (bwamem.cpp:1521-1577)
-bool reg2sam(const bm2_opt *opt, const bm2_sam_opt *so, const Ref &R, std::string &out, const char *name, const char *comment,
+bool reg2sam(const bm2_opt *opt, const bm2_sam_opt *so, const Ref &R, Text &out, const char *name, const char *comment,
              const char *qual, int l_seq, const uint8_t *seq, int n, const bm2_alnreg_t *a, int extra_flag, const Aln *m) {
-    std::vector<std::string> XA; bool any_xa = false;
+    AVec<AVec<char>> XA; bool any_xa = false;
     if (!(so->flag & F_ALL)) { if (!gen_alt(opt, so, R, n, a, l_seq, seq, XA, any_xa)) return false; }
-    std::vector<Aln> aa;
+    AVec<Aln> aa;
     int l = 0;
     for (int k = 0; k < n; ++k) {
         const bm2_alnreg_t *p = &a[k];
         if (p->score < so->T) continue;
         if (p->secondary >= 0 && (p->is_alt || !(so->flag & F_ALL))) continue;
         if (p->secondary >= 0 && p->secondary < INT_MAX && p->score < a[p->secondary].score * opt->drop_ratio) continue;
-        aa.emplace_back();
-        Aln &q = aa.back();
+        Aln q;                                                   // (filled, then stored: the list may move when it grows)
         if (!reg2aln(opt, so, R, l_seq, seq, p, q)) return false;
         q.XA = (any_xa && !XA[k].empty()) ? &XA[k] : nullptr;   // XA[k] is a NULL pointer in the reference when nothing was appended
         q.flag |= extra_flag;
         if (p->secondary >= 0) q.sub = -1;
         if (l && p->secondary < 0) q.flag |= (so->flag & F_NO_MULTI) ? 0x10000 : 0x800;
         if (!(so->flag & F_KEEP_SUPP_MAPQ) && l && !p->is_alt && q.mapq > aa[0].mapq) q.mapq = aa[0].mapq;
+        aa.push_back(q);
         ++l;
     }
     if (aa.empty()) {
-        aa.emplace_back();
+        aa.push_back(Aln());
         reg2aln(opt, so, R, l_seq, seq, 0, aa[0]);
         aa[0].flag |= extra_flag;
         aln2sam(so, R, out, name, comment, qual, l_seq, seq, aa, 0, m);
@@ -766,6 +856,39 @@ KswResult ksw_align2(int qlen, const uint8_t *query, int tlen, const uint8_t *ta
 
 struct PeStat { int low = 0, high = 0, failed = 0; double avg = 0, std = 0; };   // mem_pestat_t
 
+// A read's hits (mem_alnreg_v): a slice of the chunk's flat store with room for what mate rescue may add (one hit per planned alignment);
+// a list that outgrows its slice all the same moves to the spill arena of the thread that grows it.  No allocation per read, nothing to
+// release one by one.
+thread_local Arena t_spill;
+thread_local uint64_t t_spill_epoch = 0;
+std::atomic<uint64_t> g_call_epoch{0};
+inline void spill_sync(uint64_t epoch) { if (t_spill_epoch != epoch) { t_spill.reset(); t_spill_epoch = epoch; } }   // (spilled lists of the call before are gone)
+struct HitList {
+    bm2_alnreg_t *p = nullptr; int n = 0, cap = 0;
+    size_t size() const { return (size_t)n; }
+    bool empty() const { return n == 0; }
+    bm2_alnreg_t &operator[](size_t i) { return p[i]; }
+    const bm2_alnreg_t &operator[](size_t i) const { return p[i]; }
+    bm2_alnreg_t *data() { return p; }
+    const bm2_alnreg_t *data() const { return p; }
+    void room(int want) {
+        if (want <= cap) return;
+        int nc = cap * 2 > want ? cap * 2 : want; if (nc < 8) nc = 8;
+        bm2_alnreg_t *q = (bm2_alnreg_t *)t_spill.get(sizeof(bm2_alnreg_t) * (size_t)nc);
+        if (n) memcpy(q, p, sizeof(bm2_alnreg_t) * (size_t)n);
+        p = q; cap = nc;
+    }
+    void insert_at(size_t i, const bm2_alnreg_t &b) {
+        room(n + 1);
+        if ((size_t)n > i) memmove(p + i + 1, p + i, sizeof(bm2_alnreg_t) * ((size_t)n - i));
+        p[i] = b; ++n;
+    }
+    void assign(const bm2_alnreg_t *first, const bm2_alnreg_t *last) { const int k = (int)(last - first); room(k); if (k) memmove(p, first, sizeof(bm2_alnreg_t) * (size_t)k); n = k; }
+};
+inline HitList view_of(const bm2_alnreg_t *alnregs, const int64_t *reg_off, int i) {       // the input's list of read i, for reading only
+    HitList v; v.p = const_cast<bm2_alnreg_t *>(alnregs) + reg_off[i]; v.n = v.cap = (int)(reg_off[i + 1] - reg_off[i]); return v;
+}
+
 int infer_dir(int64_t l_pac, int64_t b1, int64_t b2, int64_t *dist) {            // bwamem_pair.cpp:58-65
     const int r1 = (b1 >= l_pac), r2 = (b2 >= l_pac);
     const int64_t p2 = r1 == r2 ? b2 : (l_pac << 1) - 1 - b2;
@@ -773,7 +896,7 @@ int infer_dir(int64_t l_pac, int64_t b1, int64_t b2, int64_t *dist) {           
     return (r1 == r2 ? 0 : 1) ^ (p2 > b1 ? 0 : 3);
 }
 
-int cal_sub(const bm2_opt *opt, const std::vector<bm2_alnreg_t> &r) {            // bwamem_pair.cpp:67-79
+int cal_sub(const bm2_opt *opt, const HitList &r) {            // bwamem_pair.cpp:67-79
     size_t j;
     for (j = 1; j < r.size(); ++j) {
         const int b_max = r[j].qb > r[0].qb ? r[j].qb : r[0].qb, e_min = r[j].qe < r[0].qe ? r[j].qe : r[0].qe;
@@ -792,8 +915,8 @@ int cal_sub(const bm2_opt *opt, const std::vector<bm2_alnreg_t> &r) {           
 // any order), and everything else is read off the counts: a quartile is a rank in the cumulative counts; the mean sums integers (exact
 // in a double whatever the order); the deviation adds (v - mean)^2 once per pair in ascending order of v, which is the order -- and
 // therefore the rounding -- of the reference's loop over its sorted array.
-void pestat(const bm2_opt *opt, const bm2_sam_opt *so, int64_t l_pac, const std::vector<std::vector<bm2_alnreg_t>> &regs, PeStat pes[4]) {
-    const int n_pairs = (int)(regs.size() >> 1);
+void pestat(const bm2_opt *opt, const bm2_sam_opt *so, int64_t l_pac, int n_reads, const bm2_alnreg_t *alnregs, const int64_t *reg_off, PeStat pes[4]) {
+    const int n_pairs = n_reads >> 1;
     const int64_t top = so->max_ins > 0 ? so->max_ins : 0;       // bins 1 .. max_ins
     for (int d = 0; d < 4; ++d) pes[d] = PeStat();
     int nt = so->n_threads > 0 ? so->n_threads : bm2_effective_cpus();
@@ -806,7 +929,7 @@ void pestat(const bm2_opt *opt, const bm2_sam_opt *so, int64_t l_pac, const std:
         uint32_t *mine = hist.data() + (size_t)tid.fetch_add(1) * 4 * bins;
         for (int lo; (lo = nx.fetch_add(8192)) < n_pairs;)
             for (int i = lo; i < n_pairs && i < lo + 8192; ++i) {
-                const std::vector<bm2_alnreg_t> &r0 = regs[(size_t)i << 1 | 0], &r1 = regs[(size_t)i << 1 | 1];
+                const HitList r0 = view_of(alnregs, reg_off, i << 1 | 0), r1 = view_of(alnregs, reg_off, i << 1 | 1);
                 if (r0.empty() || r1.empty()) continue;
                 if (cal_sub(opt, r0) > 0.8 * r0[0].score) continue;
                 if (cal_sub(opt, r1) > 0.8 * r1[0].score) continue;
@@ -914,7 +1037,7 @@ KswResult rescue_align(const bm2_opt *opt, const Ref &R, int l_ms, const uint8_t
 }
 
 void rescue_apply(const bm2_opt *opt, const Ref &R, const bm2_alnreg_t *a, int l_ms, int r, int64_t rb, const KswResult &aln,
-                  std::vector<bm2_alnreg_t> &ma) {
+                  HitList &ma) {
     const int64_t l_pac = R.l_pac;
     const int is_rev = (r >> 1 != (r & 1));
     if (aln.score < opt->min_seed_len || aln.qb < 0) return;
@@ -928,10 +1051,10 @@ void rescue_apply(const bm2_opt *opt, const Ref &R, const bm2_alnreg_t *a, int l
     b.seedcov = (int)((b.re - b.rb < b.qe - b.qb ? b.re - b.rb : b.qe - b.qb) >> 1);
     size_t i;
     for (i = 0; i < ma.size(); ++i) if (ma[i].score < b.score) break;                  // keep ma sorted by score
-    ma.insert(ma.begin() + (long)i, b);
+    ma.insert_at(i, b);
 }
 
-void rescue_skip(const Ref &R, const PeStat pes[4], const bm2_alnreg_t *a, const std::vector<bm2_alnreg_t> &ma, int skip[4]) {
+void rescue_skip(const Ref &R, const PeStat pes[4], const bm2_alnreg_t *a, const HitList &ma, int skip[4]) {
     for (int r = 0; r < 4; ++r) skip[r] = pes[r].failed ? 1 : 0;
     for (size_t i = 0; i < ma.size(); ++i) {                     // a direction that already has a hit at a plausible distance needs no rescue
         int64_t dist;
@@ -947,7 +1070,7 @@ void rescue_skip(const Ref &R, const PeStat pes[4], const bm2_alnreg_t *a, const
 // that overlap by more than mask_level_redun on the reference AND on the read the lower-scoring one goes (the later one on a tie),
 // looking back only while the earlier hit ends within max_chain_gap before the later one begins; (2) survivors by (score desc, rb,
 // qb); (3) of hits equal in all three the first stays.  The full procedure, with merging, is the device's (finish.hip).
-void dedup_rescued(const bm2_opt *opt, std::vector<bm2_alnreg_t> &hits) {
+void dedup_rescued(const bm2_opt *opt, HitList &hits) {
     const int n = (int)hits.size();
     if (n <= 1) return;
     static thread_local std::vector<int> ord, keep;              // (scratch kept per thread: this runs after every rescued direction)
@@ -957,7 +1080,7 @@ void dedup_rescued(const bm2_opt *opt, std::vector<bm2_alnreg_t> &hits) {
     for (int i = 0; i < n; ++i) ord[(size_t)i] = i;
     k_introsort((size_t)n, ord.data(), [&](int x, int y) { return hits[(size_t)x].re < hits[(size_t)y].re; });
     gone.assign((size_t)n, 0);
-    for (auto &h : hits) h.n_comp = 1;
+    for (int i = 0; i < n; ++i) hits[(size_t)i].n_comp = 1;
     auto span = [](int64_t b, int64_t e) { return e - b; };
     for (int i = 1; i < n; ++i) {
         const bm2_alnreg_t &p = hits[(size_t)ord[(size_t)i]];
@@ -983,11 +1106,11 @@ void dedup_rescued(const bm2_opt *opt, std::vector<bm2_alnreg_t> &hits) {
         if (k > 0) { const bm2_alnreg_t &b = hits[(size_t)keep[k - 1]]; if (a.score == b.score && a.rb == b.rb && a.qb == b.qb) continue; }
         out.push_back(a);
     }
-    hits.assign(out.begin(), out.end());
+    hits.assign(out.data(), out.data() + out.size());
 }
 
 int matesw(const bm2_opt *opt, const bm2_sam_opt *so, const Ref &R, const int32_t *ann_len, const PeStat pes[4], const bm2_alnreg_t *a,
-           int l_ms, const uint8_t *ms, std::vector<bm2_alnreg_t> &ma, const RescueTask *pre, int n_pre, RescueStats *st) {
+           int l_ms, const uint8_t *ms, HitList &ma, const RescueTask *pre, int n_pre, RescueStats *st) {
     int skip[4], n = 0;
     rescue_skip(R, pes, a, ma, skip);
     if (skip[0] + skip[1] + skip[2] + skip[3] == 4) return 0;
@@ -1010,7 +1133,7 @@ int matesw(const bm2_opt *opt, const bm2_sam_opt *so, const Ref &R, const int32_
 }
 
 // The candidate anchors of mem_sam_pe (bwamem_pair.cpp:371-376): hits within pen_unpaired of the best, at most max_matesw used
-void rescue_anchors(const bm2_sam_opt *so, const std::vector<bm2_alnreg_t> &a, std::vector<bm2_alnreg_t> &b) {
+void rescue_anchors(const bm2_sam_opt *so, const HitList &a, std::vector<bm2_alnreg_t> &b) {
     b.clear();
     for (size_t j = 0; j < a.size(); ++j) if (a[j].score >= a[0].score - so->pen_unpaired) b.push_back(a[j]);
 }
@@ -1019,8 +1142,8 @@ void rescue_anchors(const bm2_sam_opt *so, const std::vector<bm2_alnreg_t> &a, s
 // processed the mate's list only grows (each insertion is followed by a de-duplication that keeps the better of two overlapping
 // hits), so a direction skipped here stays skipped and what is planned is, but for freak cases, a superset of what is used.
 void rescue_plan(const bm2_opt *opt, const bm2_sam_opt *so, const Ref &R, const int32_t *ann_len, const PeStat pes[4], int pair,
-                 const int l_seq[2], const std::vector<bm2_alnreg_t> a[2], std::vector<RescueTask> &out) {
-    std::vector<bm2_alnreg_t> b;
+                 const int l_seq[2], const HitList a[2], std::vector<RescueTask> &out) {
+    static thread_local std::vector<bm2_alnreg_t> b;
     for (int i = 0; i < 2; ++i) {
         rescue_anchors(so, a[i], b);
         for (size_t j = 0; j < b.size() && (int)j < so->max_matesw; ++j) {
@@ -1038,11 +1161,11 @@ void rescue_plan(const bm2_opt *opt, const bm2_sam_opt *so, const Ref &R, const 
 }
 
 // mem_pair, bwamem_pair.cpp:285-346
-int pair_hits(const bm2_opt *opt, const Ref &R, const PeStat pes[4], const std::vector<bm2_alnreg_t> a[2], int id, int *sub, int *n_sub,
+struct P64 { uint64_t x, y; };
+int pair_hits(const bm2_opt *opt, const Ref &R, const PeStat pes[4], const HitList a[2], int id, int *sub, int *n_sub,
               int z[2], const int n_pri[2]) {
-    struct P64 { uint64_t x, y; };
     auto lt = [](const P64 &p, const P64 &q) { return p.x < q.x || (p.x == q.x && p.y < q.y); };
-    std::vector<P64> v, u;
+    AVec<P64> v, u;                                              // (in the thread's scratch arena: the caller resets it per pair)
     const int64_t l_pac = R.l_pac;
     for (int r = 0; r < 2; ++r)
         for (int i = 0; i < n_pri[r]; ++i) {
@@ -1053,7 +1176,7 @@ int pair_hits(const bm2_opt *opt, const Ref &R, const PeStat pes[4], const std::
             key.y = (uint64_t)e->score << 32 | (uint64_t)(int64_t)(i << 2 | (e->rb >= l_pac) << 1 | r);
             v.push_back(key);
         }
-    std::sort(v.begin(), v.end(), lt);
+    std::sort(v.p, v.p + v.n, lt);
     int y[4] = { -1, -1, -1, -1 };
     for (int i = 0; i < (int)v.size(); ++i) {
         for (int r = 0; r < 2; ++r) {
@@ -1082,14 +1205,14 @@ int pair_hits(const bm2_opt *opt, const Ref &R, const PeStat pes[4], const std::
         int tmp = opt->a + opt->b;
         tmp = tmp > opt->o_del + opt->e_del ? tmp : opt->o_del + opt->e_del;
         tmp = tmp > opt->o_ins + opt->e_ins ? tmp : opt->o_ins + opt->e_ins;
-        std::sort(u.begin(), u.end(), lt);
+        std::sort(u.p, u.p + u.n, lt);
         const int i = (int)(u.back().y >> 32), k = (int)(u.back().y << 32 >> 32);
         z[v[i].y & 1] = (int)(v[i].y << 32 >> 34);
         z[v[k].y & 1] = (int)(v[k].y << 32 >> 34);
         ret = (int)(u.back().x >> 32);
         *sub = u.size() > 1 ? (int)(u[u.size() - 2].x >> 32) : 0;
         *n_sub = 0;
-        for (long t = (long)u.size() - 2; t >= 0; --t) if (*sub - (int)(u[(size_t)t].x >> 32) <= tmp) ++*n_sub;
+        for (int t = u.size() - 2; t >= 0; --t) if (*sub - (int)(u[t].x >> 32) <= tmp) ++*n_sub;
     } else { ret = 0; *sub = 0; *n_sub = 0; }
     return ret;
 }
@@ -1104,7 +1227,7 @@ struct ReadIO { const char *name, *comment, *qual; int l_seq; const uint8_t *seq
 struct PairPlan { int z[2] = { 0, 0 }, n_pri[2] = { 0, 0 }, q_se[2] = { 0, 0 }, extra_flag = 1; bool paired = false; };
 
 void pe_decide(const bm2_opt *opt, const bm2_sam_opt *so, const Ref &R, const int32_t *ann_len, const PeStat pes[4], uint64_t id,
-               const ReadIO s[2], std::vector<bm2_alnreg_t> a[2], const RescueTask *pre, int n_pre, RescueStats *st, PairPlan &P) {
+               const ReadIO s[2], HitList a[2], const RescueTask *pre, int n_pre, RescueStats *st, PairPlan &P) {
     int o, subo, n_sub;
     P = PairPlan();
     int *z = P.z, *n_pri = P.n_pri, *q_se = P.q_se;
@@ -1161,16 +1284,16 @@ void pe_decide(const bm2_opt *opt, const bm2_sam_opt *so, const Ref &R, const in
 }
 
 bool pe_emit(const bm2_opt *opt, const bm2_sam_opt *so, const Ref &R, const PeStat pes[4], const ReadIO s[2],
-             const std::vector<bm2_alnreg_t> a[2], const PairPlan &P, std::string &out) {
+             const HitList a[2], const PairPlan &P, Text &out) {
     const int *z = P.z, *n_pri = P.n_pri;
     int extra_flag = P.extra_flag;
     Aln h[2];
     if (P.paired) {
-        std::vector<std::string> XA[2]; bool any_xa[2] = { false, false };
+        AVec<AVec<char>> XA[2]; bool any_xa[2] = { false, false };
         if (!(so->flag & F_ALL))
             for (int i = 0; i < 2; ++i)
                 if (!gen_alt(opt, so, R, (int)a[i].size(), a[i].data(), s[i].l_seq, s[i].seq, XA[i], any_xa[i])) return false;
-        std::vector<Aln> aa[2];
+        AVec<Aln> aa[2];
         for (int i = 0; i < 2; ++i) {
             if (!reg2aln(opt, so, R, s[i].l_seq, s[i].seq, &a[i][z[i]], h[i])) return false;
             h[i].mapq = P.q_se[i];
@@ -1251,7 +1374,9 @@ int cigar_session_batch(const bm2_opt *opt, const bm2_reads *reads, int64_t enc_
 
 RescueStats g_rescue;               // counters of the last bm2_sam_pe call (diagnostic; bm2_sam_rescue_stats)
 
-struct PeWork {                     // the rescue batch of a chunk: tasks in pair order, their flat arrays, the results
+struct PeWork {                     // a chunk's working set, kept per calling thread from chunk to chunk: the hit lists (flat store + one
+                                    // HitList per read), the rescue batch (tasks in pair order, their flat arrays, the results), the pairs' plans
+    std::vector<bm2_alnreg_t> store; std::vector<HitList> lists; std::vector<int32_t> extra;
     std::vector<RescueTask> tasks; std::vector<int64_t> task_off, q_off, t_pos; std::vector<int32_t> q_len, t_len, xtra;
     std::vector<uint8_t> qbuf; std::vector<bm2_ksw_result> res;
 };
@@ -1270,60 +1395,50 @@ inline void cpu_relax() {
 #endif
 }
 
-// items [0, n) in blocks of 256 over n_threads host threads; f(i, text) appends the text of item i.  A thread formats a block into its
-// own buffer (kept from call to call: it stays in the cache), learns where the block starts from the end of the block before it --
-// blocks are taken in order, so that one is finished or about to be -- publishes its own end at once and copies the block straight into
-// the caller's buffer: the chunk's text never exists a second time.  *n_out = bytes needed; BM2_ECAP when cap is smaller (what fitted
-// was written); a failing item makes the call return BM2_EINVAL with the item's number in `bad`.
+// items [0, n) in blocks of 256 over n_threads host threads; f(i, text) appends the text of item i.  Two passes without a wait in either:
+// first every thread formats the blocks it draws, one after the other, into its own buffer (kept from call to call) and notes their sizes;
+// the blocks' places in the output are a prefix sum over ~n / 256 numbers; then every thread copies ITS blocks to their places.  (One pass
+// with an in-order hand-over of the offset from block to block was the earlier form: a third of the threads' time went into waiting for
+// the block before, and on a host whose CPU time is capped a descheduled thread stalled everybody behind it.)
+// *n_out = bytes needed; BM2_ECAP when cap is smaller (nothing useful was written); a failing item makes the call return BM2_EINVAL with the
+// item's number in `bad`.
+struct BlockNote { int block; size_t at, size; };
 template <class F> int run_blocks(int n, int n_threads, char *out, int64_t cap, int64_t *n_out, int *bad, F f) {
     if (n_threads <= 0) n_threads = bm2_effective_cpus();
     if (n_threads < 1) n_threads = 1;
     const int block = 256;
     const int n_blocks = (n + block - 1) / block;
     if (n_threads > n_blocks) n_threads = n_blocks > 0 ? n_blocks : 1;
-    std::unique_ptr<std::atomic<int64_t>[]> end_of(new std::atomic<int64_t>[(size_t)n_blocks + 1]);
-    for (int b = 0; b <= n_blocks; ++b) end_of[(size_t)b].store(b == 0 ? 0 : -1, std::memory_order_relaxed);      // end_of[b] = where block b starts
+    std::vector<int64_t> start_of((size_t)n_blocks + 1, 0);     // sizes, then offsets
     std::atomic<int> next(0), failed(-1);
     TailProf prof("run_blocks");
-    std::atomic<long long> ns_fmt(0), ns_wait(0), ns_copy(0), ns_max(0);     // (BM2_TAIL_PROF: where the threads' time goes)
-    auto work = [&]() {
-        static thread_local std::string text;
-        long long t_fmt = 0, t_wait = 0, t_copy = 0;
-        auto now = [&]() { return prof.on ? std::chrono::steady_clock::now().time_since_epoch().count() : 0LL; };
+    static thread_local Text text;                               // (a worker thread's own; the two passes below run on the same threads)
+    static thread_local std::vector<BlockNote> notes;
+    auto format = [&]() {
+        text.clear(); notes.clear();
         for (;;) {
             const int b = next.fetch_add(1);
             if (b >= n_blocks) break;
-            const long long c0 = now();
-            text.clear();
+            const size_t at = text.size();
             if (failed.load(std::memory_order_relaxed) < 0) {
                 const int hi = (b + 1) * block < n ? (b + 1) * block : n;
                 for (int i = b * block; i < hi; ++i)
                     if (!f(i, text)) { int e = -1; failed.compare_exchange_strong(e, i); break; }
             }
-            const long long c1 = now();
-            int64_t at;
-            for (int spins = 0; (at = end_of[(size_t)b].load(std::memory_order_acquire)) < 0;) { if (++spins < 2000) cpu_relax(); else std::this_thread::yield(); }
-            end_of[(size_t)b + 1].store(at + (int64_t)text.size(), std::memory_order_release);
-            const long long c2 = now();
-            if (out && at + (int64_t)text.size() <= cap && !text.empty()) memcpy(out + at, text.data(), text.size());
-            const long long c3 = now();
-            t_fmt += c1 - c0; t_wait += c2 - c1; t_copy += c3 - c2;
+            notes.push_back({ b, at, text.size() - at });
+            start_of[(size_t)b + 1] = (int64_t)(text.size() - at);
         }
         flush_tallies();
-        if (prof.on) {
-            ns_fmt += t_fmt; ns_wait += t_wait; ns_copy += t_copy;
-            const long long tot = t_fmt + t_wait + t_copy;
-            for (long long m = ns_max.load(); tot > m && !ns_max.compare_exchange_weak(m, tot);) {}
-        }
     };
-    run_threads(n_threads, work);
-    if (prof.on) fprintf(stderr, "[tail] run_blocks     %d threads: format %.1f, wait-for-predecessor %.1f, copy %.1f ms summed over threads; busiest thread %.1f ms\n",
-                         n_threads, ns_fmt.load() / 1e6, ns_wait.load() / 1e6, ns_copy.load() / 1e6, ns_max.load() / 1e6);
-    prof.mark("items + copy");
+    run_threads(n_threads, format);
+    prof.mark("format");
     if (failed.load() >= 0) { *bad = failed.load(); *n_out = 0; return BM2_EINVAL; }
-    *n_out = n_blocks > 0 ? end_of[(size_t)n_blocks].load() : 0;
+    for (int b = 0; b < n_blocks; ++b) start_of[(size_t)b + 1] += start_of[(size_t)b];
+    *n_out = start_of[(size_t)n_blocks];
     if (*n_out > cap) return BM2_ECAP;
     if (!out) return *n_out ? BM2_EINVAL : BM2_OK;
+    run_threads(n_threads, [&]() { for (const BlockNote &k : notes) if (k.size) memcpy(out + start_of[(size_t)k.block], text.data() + k.at, k.size); notes.clear(); });
+    prof.mark("copy");
     return BM2_OK;
 }
 
@@ -1469,36 +1584,54 @@ int bm2h_sam_pe(const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt
     bm2_tune_malloc_once();
     TailProf prof("sam_pe");
     const int n = reads->n_reads;
-    std::vector<std::vector<bm2_alnreg_t>> regs((size_t)n);
     std::atomic<int> name_clash(-1);
     {
         int nt = so->n_threads > 0 ? so->n_threads : bm2_effective_cpus();
         if (nt < 1) nt = 1;
-        if (nt > n / 4096 + 1) nt = n / 4096 + 1;
+        if (nt > n / 16384 + 1) nt = n / 16384 + 1;
         std::atomic<int> nx(0);
         run_threads(nt, [&]() {
-            for (int lo; (lo = nx.fetch_add(4096)) < n;)
-                for (int i = lo; i < n && i < lo + 4096; ++i) {
-                    regs[(size_t)i].assign(alnregs + reg_off[i], alnregs + reg_off[i + 1]);
-                    for (int64_t k = reg_off[i]; k < reg_off[i + 1]; ++k) regs[(size_t)i][(size_t)(k - reg_off[i])].pad = (int32_t)(k + 1);   // the hit's number (CIGAR batch)
-                    if (!(i & 1) && strcmp(txt->name[i], txt->name[i + 1]) != 0) { int e = -1; name_clash.compare_exchange_strong(e, i); }
-                }
+            for (int lo; (lo = nx.fetch_add(16384)) < n;)
+                for (int i = lo; i < n && i < lo + 16384; i += 2)
+                    if (strcmp(txt->name[i], txt->name[i + 1]) != 0) { int e = -1; name_clash.compare_exchange_strong(e, i); }
         });
     }
     if (name_clash.load() >= 0) { const int i = name_clash.load(); bm2_set_error("paired reads have different names: \"%s\", \"%s\"", txt->name[i], txt->name[i + 1]); return BM2_EINVAL; }
-    prof.mark("hit lists");
+    prof.mark("names");
     PeStat pes[4];
     if (pes_in) for (int d = 0; d < 4; ++d) { pes[d].low = pes_in[d].low; pes[d].high = pes_in[d].high; pes[d].failed = pes_in[d].failed; pes[d].avg = pes_in[d].avg; pes[d].std = pes_in[d].std; }
-    else pestat(opt, so, idx->l_pac, regs, pes);                 // per chunk, as mem_process_seqs does (bwamem.cpp:1366-1370)
+    else pestat(opt, so, idx->l_pac, n, alnregs, reg_off, pes);  // per chunk, as mem_process_seqs does (bwamem.cpp:1366-1370)
     if (pes_out) for (int d = 0; d < 4; ++d) { pes_out[d].low = pes[d].low; pes_out[d].high = pes[d].high; pes_out[d].failed = pes[d].failed; pes_out[d].pad = 0; pes_out[d].avg = pes[d].avg; pes_out[d].std = pes[d].std; }
     // Mate rescue in three steps, the shape a device kernel needs: plan every pair's alignments on the hit lists as they stand,
     // run them all as one batch (here: host threads over single tasks), then process the pairs with the results at hand.
     // so->rescue_inline = 1 aligns inside the pair loop as mem_sam_pe does; the output is the same.
     const int n_pairs = n >> 1;
-    prof.mark("pestat + names");
+    prof.mark("pestat");
     // (the flat arrays of the batch live in buffers the calling thread keeps from chunk to chunk: no fresh pages per chunk)
     static thread_local PeWork W_of_this_thread;
     PeWork &W = W_of_this_thread;                                // (a reference: the lambdas below run on the workers, whose own thread_local objects are other objects)
+    const uint64_t epoch = ++g_call_epoch;                       // (a list that outgrows its slice moves to its thread's spill arena: valid until that thread's next call)
+    if (W.lists.size() < (size_t)n) W.lists.resize((size_t)n);
+    if (W.extra.size() < (size_t)n) W.extra.resize((size_t)n);
+    HitList *const lists = W.lists.data();
+    int32_t *const extra = W.extra.data();                       // hits mate rescue may add to read i = alignments planned with read i as the mate
+    const int slack = 2;
+    auto fill_store = [&](const std::vector<int64_t> &cap_base, int blk_pairs, int n_blk, int n_threads_) {   // lists[i] <- the input's hits of read i
+        std::atomic<int> nb(0);
+        run_threads(n_threads_ < n_blk ? n_threads_ : n_blk, [&]() {
+            for (int b; (b = nb.fetch_add(1)) < n_blk;) {
+                int64_t at = cap_base[(size_t)b];
+                for (int i = 2 * b * blk_pairs; i < n && i < 2 * (b + 1) * blk_pairs; ++i) {
+                    HitList &L = lists[i];
+                    const int k = (int)(reg_off[i + 1] - reg_off[i]);
+                    L.p = W.store.data() + at; L.n = k; L.cap = k + extra[i] + slack;
+                    if (k) memcpy(L.p, alnregs + reg_off[i], sizeof(bm2_alnreg_t) * (size_t)k);
+                    for (int h = 0; h < k; ++h) L.p[h].pad = (int32_t)(reg_off[i] + h + 1);      // the hit's number (CIGAR batch)
+                    at += L.cap;
+                }
+            }
+        });
+    };
     std::vector<RescueTask> &tasks = W.tasks;
     std::vector<int64_t> &task_off = W.task_off;
     const bool batch = !(so->flag & F_NO_RESCUE) && !so->rescue_inline;
@@ -1509,21 +1642,26 @@ int bm2h_sam_pe(const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt
         const int blk = 256, n_blk = (n_pairs + blk - 1) / blk;
         const int nt_blk = n_threads < n_blk ? n_threads : n_blk;
         std::vector<std::vector<RescueTask>> part((size_t)n_blk);
-        std::vector<int64_t> base((size_t)n_blk + 1, 0), qbase((size_t)n_blk + 1, 0);      // tasks / query bytes before block b
+        std::vector<int64_t> base((size_t)n_blk + 1, 0), qbase((size_t)n_blk + 1, 0), cbase((size_t)n_blk + 1, 0);   // tasks / query bytes / hit slots before block b
         std::atomic<int> next(0);
-        run_threads(nt_blk, [&]() {                              // plan: every block lists its pairs' alignments, in pair order
+        run_threads(nt_blk, [&]() {                              // plan: every block lists its pairs' alignments, in pair order (on the input's lists, read only)
             for (int b; (b = next.fetch_add(1)) < n_blk;) {
                 std::vector<RescueTask> &v = part[(size_t)b];
                 for (int pi = b * blk; pi < n_pairs && pi < (b + 1) * blk; ++pi) {
                     const int l_seq[2] = { reads->len[2 * pi], reads->len[2 * pi + 1] };
-                    rescue_plan(opt, so, R, idx->ann_len, pes, pi, l_seq, &regs[(size_t)2 * pi], v);
+                    const HitList a[2] = { view_of(alnregs, reg_off, 2 * pi), view_of(alnregs, reg_off, 2 * pi + 1) };
+                    extra[2 * pi] = extra[2 * pi + 1] = 0;
+                    rescue_plan(opt, so, R, idx->ann_len, pes, pi, l_seq, a, v);
                 }
-                int64_t q = 0;
-                for (const RescueTask &T : v) q += reads->len[2 * T.pair + !T.end];           // the mate is the read that is aligned
-                base[(size_t)b + 1] = (int64_t)v.size(); qbase[(size_t)b + 1] = q;
+                int64_t q = 0, slots = 0;
+                for (const RescueTask &T : v) { q += reads->len[2 * T.pair + !T.end]; ++extra[2 * T.pair + !T.end]; }      // the mate is the read that is aligned
+                for (int i = 2 * b * blk; i < n && i < 2 * (b + 1) * blk; ++i) slots += (reg_off[i + 1] - reg_off[i]) + extra[i] + slack;
+                base[(size_t)b + 1] = (int64_t)v.size(); qbase[(size_t)b + 1] = q; cbase[(size_t)b + 1] = slots;
             }
         });
-        for (int b = 0; b < n_blk; ++b) { base[(size_t)b + 1] += base[(size_t)b]; qbase[(size_t)b + 1] += qbase[(size_t)b]; }
+        for (int b = 0; b < n_blk; ++b) { base[(size_t)b + 1] += base[(size_t)b]; qbase[(size_t)b + 1] += qbase[(size_t)b]; cbase[(size_t)b + 1] += cbase[(size_t)b]; }
+        if (W.store.size() < (size_t)cbase[(size_t)n_blk] + 1) W.store.resize((size_t)cbase[(size_t)n_blk] + 1);
+        fill_store(cbase, blk, n_blk, n_threads);
         const long long tot = (long long)base[(size_t)n_blk];
         const int64_t qb_tot = qbase[(size_t)n_blk];
         prof.mark("rescue plan");
@@ -1590,6 +1728,18 @@ int bm2h_sam_pe(const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt
             run_threads((long long)n_threads < (tot + step - 1) / step ? n_threads : (int)((tot + step - 1) / step), align);
         }
     }
+    if (!batch) {                                                // no plan: the lists with the slack only (inline rescue grows them through the spill arena)
+        int n_threads = so->n_threads > 0 ? so->n_threads : bm2_effective_cpus();
+        const int blk = 4096, n_blk = (n_pairs + blk - 1) / blk;
+        std::vector<int64_t> cbase((size_t)n_blk + 1, 0);
+        for (int b = 0; b < n_blk; ++b) {
+            const int lo = 2 * b * blk, hi = 2 * (b + 1) * blk < n ? 2 * (b + 1) * blk : n;
+            cbase[(size_t)b + 1] = cbase[(size_t)b] + (reg_off[hi] - reg_off[lo]) + (int64_t)slack * (hi - lo);
+        }
+        for (int i = 0; i < n; ++i) extra[i] = 0;
+        if (W.store.size() < (size_t)cbase[(size_t)n_blk] + 1) W.store.resize((size_t)cbase[(size_t)n_blk] + 1);
+        fill_store(cbase, blk, n_blk, n_threads < 1 ? 1 : n_threads);
+    }
     auto io_of = [&](int pi, ReadIO io[2]) {
         const int i = pi << 1;
         for (int k = 0; k < 2; ++k) {
@@ -1601,26 +1751,29 @@ int bm2h_sam_pe(const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt
         ReadIO io[2]; io_of(pi, io);
         const RescueTask *pre = batch ? tasks.data() + task_off[(size_t)pi] : nullptr;
         const int n_pre = batch ? (int)(task_off[(size_t)pi + 1] - task_off[(size_t)pi]) : 0;
-        pe_decide(opt, so, R, idx->ann_len, pes, (uint64_t)((n_processed >> 1) + pi), io, &regs[(size_t)2 * pi], pre, n_pre, batch ? &g_rescue : nullptr, P);
+        t_scratch.reset(); spill_sync(epoch);
+        pe_decide(opt, so, R, idx->ann_len, pes, (uint64_t)((n_processed >> 1) + pi), io, lists + 2 * pi, pre, n_pre, batch ? &g_rescue : nullptr, P);
     };
-    auto emit = [&](int pi, const PairPlan &P, std::string &part) {
+    auto emit = [&](int pi, const PairPlan &P, Text &part) {
         ReadIO io[2]; io_of(pi, io);
-        return pe_emit(opt, so, R, pes, io, &regs[(size_t)2 * pi], P, part);
+        t_scratch.reset();                                       // (the pair's CIGARs, XA strings and record lists: gone with the next pair)
+        return pe_emit(opt, so, R, pes, io, lists + 2 * pi, P, part);
     };
     static thread_local CgMemo memo_of_this_thread;              // (kept from chunk to chunk, like W)
     CgMemo &memo = memo_of_this_thread;
     prof.mark("rescue results");
     g_cigar.planned = 0; g_cigar.used = 0; g_cigar.missed = 0;
-    std::vector<PairPlan> plans;
+    static thread_local std::vector<PairPlan> plans_of_this_thread;      // (kept from chunk to chunk)
+    std::vector<PairPlan> &plans = plans_of_this_thread;
     if (cfn) {                                                   // CIGAR session: decide every pair, note the hits its text will ask for, batch; then print
         int n_threads = so->n_threads > 0 ? so->n_threads : bm2_effective_cpus();
         if (n_threads < 1) n_threads = 1;
-        plans.resize((size_t)n_pairs);
+        if (plans.size() < (size_t)n_pairs) plans.resize((size_t)n_pairs);
         const int blk = 256, n_blk = (n_pairs + blk - 1) / blk;
         std::vector<std::vector<int32_t>> recs((size_t)n_blk);
         std::atomic<int> next(0), failed(-1);
         run_threads(n_threads < n_blk ? n_threads : n_blk, [&]() {
-            std::string sink;
+            Text sink;
             for (int b; (b = next.fetch_add(1)) < n_blk;) {
                 t_cg.mode = 1; t_cg.rec = &recs[(size_t)b];
                 for (int pi = b * blk; pi < n_pairs && pi < (b + 1) * blk; ++pi) {
@@ -1640,7 +1793,7 @@ int bm2h_sam_pe(const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt
         prof.mark("cigar session");
     }
     int bad = -1;
-    const int rc_out = run_blocks(n_pairs, so->n_threads, out, cap, n_out, &bad, [&](int pi, std::string &part) {
+    const int rc_out = run_blocks(n_pairs, so->n_threads, out, cap, n_out, &bad, [&](int pi, Text &part) {
         if (!cfn) { PairPlan P; decide(pi, P); return emit(pi, P, part); }
         t_cg.mode = 2; t_cg.memo = &memo; t_cg.st = &g_cigar;
         const bool r = emit(pi, plans[(size_t)pi], part);
@@ -1648,16 +1801,6 @@ int bm2h_sam_pe(const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt
         return r;
     });
     prof.mark("real pass + copy");
-    {   // a million small hit lists: released by the threads, not one by one on the way out
-        std::atomic<int> nx(0);
-        int nt = so->n_threads > 0 ? so->n_threads : bm2_effective_cpus();
-        if (nt > n / 4096 + 1) nt = n / 4096 + 1;
-        run_threads(nt < 1 ? 1 : nt, [&]() {
-            for (int lo; (lo = nx.fetch_add(4096)) < n;)
-                for (int i = lo; i < n && i < lo + 4096; ++i) std::vector<bm2_alnreg_t>().swap(regs[(size_t)i]);
-        });
-        prof.mark("release");
-    }
     if (bad >= 0) { bm2_set_error("bm2_sam_pe: pair %d has a hit whose CIGAR cannot be generated (range outside the reference)", bad); return BM2_EINVAL; }
     return rc_out;
 }
@@ -1682,12 +1825,14 @@ int bm2h_sam_se(const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt
     bm2_tune_malloc_once();
     const int n_reads = reads->n_reads;
     auto decide = [&](int i) {                                   // what changes the read's hit list (mem_reg2sam's caller, bwamem.cpp:1240-1243)
+        t_scratch.reset();
         bm2_alnreg_t *a = alnregs + reg_off[i];
         const int n = (int)(reg_off[i + 1] - reg_off[i]);
         mark_primary_se(opt, n, a, n_processed + i);
         if (so->flag & F_PRIMARY5) reorder_primary5(so->T, n, a);
     };
-    auto emit = [&](int i, std::string &part) {                  // reads the list only: a CIGAR session runs it twice
+    auto emit = [&](int i, Text &part) {                         // reads the list only: a CIGAR session runs it twice
+        t_scratch.reset();
         return reg2sam(opt, so, R, part, txt->name[i], txt->comment ? txt->comment[i] : 0, txt->qual ? txt->qual[i] : 0, reads->len[i],
                        reads->enc + reads->off[i], (int)(reg_off[i + 1] - reg_off[i]), alnregs + reg_off[i], 0, 0);
     };
@@ -1701,7 +1846,7 @@ int bm2h_sam_se(const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt
         std::vector<std::vector<int32_t>> recs((size_t)n_blk);
         std::atomic<int> next(0);
         run_threads(n_threads < n_blk ? n_threads : n_blk, [&]() {
-            std::string sink;
+            Text sink;
             for (int b; (b = next.fetch_add(1)) < n_blk;) {
                 t_cg.mode = 1; t_cg.rec = &recs[(size_t)b];
                 for (int i = b * blk; i < n_reads && i < (b + 1) * blk; ++i) {
@@ -1718,7 +1863,7 @@ int bm2h_sam_se(const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt
         if (rc) return rc;
     }
     int bad = -1;
-    const int rc_out = run_blocks(n_reads, so->n_threads, out, cap, n_out, &bad, [&](int i, std::string &part) {
+    const int rc_out = run_blocks(n_reads, so->n_threads, out, cap, n_out, &bad, [&](int i, Text &part) {
         if (!cfn) { decide(i); return emit(i, part); }
         t_cg.mode = 2; t_cg.memo = &memo; t_cg.st = &g_cigar;
         const bool r = emit(i, part);
