@@ -571,7 +571,7 @@ int bm2_launch_chain(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_
                        n_chain_out, n_reg_out, n_chain0_out, perm, heavy ? heavy_thr : -1, n_sa_read);
     if (heavy) {
         // tiers by seed count (LDS per block follows the tier): the launches run beside the lane-per-read kernel and each other
-        const int stage = bm2_knob("BM2_CHAIN_STAGE", 0);
+        const int stage = bm2_knob("BM2_CHAIN_STAGE", 1);     // (sweep of round 3, profiles/r03a_sweep.json: chaining 12.4 -> 10.3 ms)
         const int caps[BM2_CHAIN_TIERS] = { 64, 128, 256, 512, stage ? 1000 : 1184 };       // (the last tier fills a CU's 160 KB of LDS)
         static bool attr_set = false;
         if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_chain_heavy, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }

@@ -867,7 +867,7 @@ int bm2_launch_extend(bm2_ctx *c, const bm2_opt &opt, const ChainParams &cp, int
     L.wave_qmin = bm2_knob("BM2_EXT_WAVE_QMIN", 113);               // classes of queries at least this long: one task per wavefront
     L.wave_nmax = bm2_knob("BM2_EXT_WAVE_NMAX", 0);                 // classes with at most this many tasks in a round: likewise (no gain measured)
     L.prefetch = bm2_knob("BM2_EXT_PREFETCH", 1);
-    L.rev = bm2_knob("BM2_EXT_REVERSE", 0);
+    L.rev = bm2_knob("BM2_EXT_REVERSE", 1);      // (sweep of round 3: -0.6 ms)
     const int lazy_rounds = bm2_knob("BM2_EXT_ROUNDS", LAZY_ROUNDS), pend_div = bm2_knob("BM2_EXT_PEND_DIV", 12);
     L.R = ring_size2(opt.w << (MAX_BAND_TRY - 1));
     L.lds_w = ((sizeof(ExtParams) + 3) / 4) * 4 + (size_t)4 * 2 * L.R * 4;
