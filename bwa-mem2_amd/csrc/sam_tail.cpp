@@ -3,7 +3,8 @@
 // byte what `bwa-mem2 mem` prints.  Plain C++ on the host: per read a sort, a few banded global alignments with backtrack
 // (one per output record and per XA alternative), for pairs the insert-size statistics of the chunk (mem_pestat), mate
 // rescue (mem_matesw: a local Smith-Waterman in the shape of the reference's SSE2 kernel, whose quirks are observable) and
-// pairing (mem_pair) -- branchy and order-sensitive.  The mate-rescue SW is the next device kernel; this is its oracle.
+// pairing (mem_pair) -- branchy and order-sensitive.  The two heavy parts run as device batches through the hooks of host_tail.h (the
+// mate-rescue SW: matesw.hip; CIGAR / NM / MD: cigar.hip); their host twins here are the kernels' oracles and the no-GPU entry points.
 #include <limits.h>
 #include <memory>
 #include <math.h>
@@ -433,91 +434,94 @@ uint64_t hash_64(uint64_t key) {                                // utils.h:117-1
     return key;
 }
 
-// mem_mark_primary_se_core, bwamem.cpp:1392-1418
-void mark_primary_core(const bm2_opt *opt, int n, bm2_alnreg_t *a, AVec<int> &z) {
-    int tmp = opt->a + opt->b;
-    tmp = opt->o_del + opt->e_del > tmp ? opt->o_del + opt->e_del : tmp;
-    tmp = opt->o_ins + opt->e_ins > tmp ? opt->o_ins + opt->e_ins : tmp;
-    z.clear(); z.push_back(0);
-    for (int i = 1; i < n; ++i) {
-        int k;
-        for (k = 0; k < z.size(); ++k) {
-            const int j = z[k];
-            const int b_max = a[j].qb > a[i].qb ? a[j].qb : a[i].qb, e_min = a[j].qe < a[i].qe ? a[j].qe : a[i].qe;
-            if (e_min > b_max) {
-                const int min_l = a[i].qe - a[i].qb < a[j].qe - a[j].qb ? a[i].qe - a[i].qb : a[j].qe - a[j].qb;
-                if (e_min - b_max >= min_l * opt->mask_level) {
-                    if (a[j].sub == 0) a[j].sub = a[i].score;
-                    if (a[j].score - a[i].score <= tmp && (a[j].is_alt || !a[i].is_alt)) ++a[j].sub_n;
-                    break;
-                }
-            }
-        }
-        if (k == z.size()) z.push_back(i);
-        else a[i].secondary = z[k];
+// ---- which hits of a read are primary (mem_mark_primary_se, bwamem.cpp:1392-1465).  The rule, in this file's words: hits are RANKED
+// (score, then non-ALT first, then a hash of the read's number: ties must not depend on the input order); going down the ranking, a hit
+// whose stretch of the read is mostly covered (mask_level of the shorter stretch) by a higher-ranked LEADER becomes that leader's
+// follower (`secondary` = the leader's rank); the first follower's score is the leader's `sub`, followers scoring within one
+// mismatch / gap of the leader count in `sub_n`.  With ALT contigs the ranking is done twice: over all hits (which gives `secondary_all`
+// and the ALT score of a primary hit shadowed by an ALT hit), then with the primary-assembly hits moved to the front and judged among
+// themselves.
+struct QSpan { int b, e; int len() const { return e - b; } };
+inline QSpan span_of(const bm2_alnreg_t &h) { return QSpan{ h.qb, h.qe }; }
+inline bool mostly_covered(const QSpan &x, const QSpan &y, float mask_level) {         // the shared stretch against mask_level of the shorter one
+    const int from = std::max(x.b, y.b), to = std::min(x.e, y.e);
+    return to > from && to - from >= std::min(x.len(), y.len()) * mask_level;
+}
+void follow_leaders(const bm2_opt *opt, int n, bm2_alnreg_t *a, AVec<int> &leaders) {  // mem_mark_primary_se_core, bwamem.cpp:1392-1418
+    const int close = std::max(opt->a + opt->b, std::max(opt->o_del + opt->e_del, opt->o_ins + opt->e_ins));
+    leaders.clear();
+    for (int i = 0; i < n; ++i) {
+        const QSpan mine = span_of(a[i]);
+        const int *lead = std::find_if(leaders.begin(), leaders.end(), [&](int j) { return mostly_covered(span_of(a[j]), mine, opt->mask_level); });
+        if (lead == leaders.end()) { leaders.push_back(i); continue; }                  // (rank 0 always leads: the list is empty then)
+        bm2_alnreg_t &L = a[*lead];
+        if (L.sub == 0) L.sub = a[i].score;
+        if (L.score - a[i].score <= close && (L.is_alt || !a[i].is_alt)) ++L.sub_n;
+        a[i].secondary = *lead;
     }
 }
 
-// mem_mark_primary_se, bwamem.cpp:1420-1465
 int mark_primary_se(const bm2_opt *opt, int n, bm2_alnreg_t *a, int64_t id) {
     if (n == 0) return 0;
-    int n_pri = 0;
-    AVec<int> z;                                                 // (scratch arena: reset per pair / read by the caller)
+    AVec<int> scratch;                                           // (the thread's scratch arena: reset per pair / read by the caller)
+    int n_assembly = 0;                                          // hits on the primary assembly (not on an ALT contig)
     for (int i = 0; i < n; ++i) {
-        a[i].sub = a[i].alt_sc = 0; a[i].secondary = a[i].secondary_all = -1; a[i].hash = hash_64((uint64_t)(id + i));
-        if (!a[i].is_alt) ++n_pri;
+        bm2_alnreg_t &h = a[i];
+        h.sub = h.alt_sc = 0; h.secondary = h.secondary_all = -1; h.hash = hash_64((uint64_t)(id + i));
+        n_assembly += !h.is_alt;
     }
-    k_introsort((size_t)n, a, [](const bm2_alnreg_t &x, const bm2_alnreg_t &y) {          // alnreg_hlt, bwamem.cpp:155
-        return x.score > y.score || (x.score == y.score && (x.is_alt < y.is_alt || (x.is_alt == y.is_alt && x.hash < y.hash)));
-    });
-    mark_primary_core(opt, n, a, z);
+    auto by_score = [](const bm2_alnreg_t &x, const bm2_alnreg_t &y) {                  // alnreg_hlt, bwamem.cpp:155
+        if (x.score != y.score) return x.score > y.score;
+        if (x.is_alt != y.is_alt) return x.is_alt < y.is_alt;
+        return x.hash < y.hash;
+    };
+    auto assembly_first = [](const bm2_alnreg_t &x, const bm2_alnreg_t &y) {            // alnreg_hlt2, bwamem.cpp:158
+        if (x.is_alt != y.is_alt) return x.is_alt < y.is_alt;
+        if (x.score != y.score) return x.score > y.score;
+        return x.hash < y.hash;
+    };
+    k_introsort((size_t)n, a, by_score);
+    follow_leaders(opt, n, a, scratch);
     for (int i = 0; i < n; ++i) {
-        bm2_alnreg_t *p = &a[i];
-        p->secondary_all = i;
-        if (!p->is_alt && p->secondary >= 0 && a[p->secondary].is_alt) p->alt_sc = a[p->secondary].score;
+        a[i].secondary_all = i;                                  // (for now: the hit's rank in the all-hits ranking)
+        const int lead = a[i].secondary;
+        if (!a[i].is_alt && lead >= 0 && a[lead].is_alt) a[i].alt_sc = a[lead].score;
     }
-    if (n_pri >= 0 && n_pri < n) {
-        z.fill(n, 0);
-        if (n_pri > 0)
-            k_introsort((size_t)n, a, [](const bm2_alnreg_t &x, const bm2_alnreg_t &y) {  // alnreg_hlt2, bwamem.cpp:158
-                return x.is_alt < y.is_alt || (x.is_alt == y.is_alt && (x.score > y.score || (x.score == y.score && x.hash < y.hash)));
-            });
-        for (int i = 0; i < n; ++i) z[a[i].secondary_all] = i;
-        for (int i = 0; i < n; ++i) {
-            if (a[i].secondary >= 0) {
-                a[i].secondary_all = z[a[i].secondary];
-                if (a[i].is_alt) a[i].secondary = INT_MAX;
-            } else a[i].secondary_all = -1;
-        }
-        if (n_pri > 0) {
-            for (int i = 0; i < n_pri; ++i) { a[i].sub = 0; a[i].secondary = -1; }
-            mark_primary_core(opt, n_pri, a, z);
-        }
-    } else {
+    if (n_assembly == n) {                                       // no ALT hit: one ranking serves both purposes
         for (int i = 0; i < n; ++i) a[i].secondary_all = a[i].secondary;
+        return n_assembly;
     }
-    return n_pri;
+    if (n_assembly > 0) k_introsort((size_t)n, a, assembly_first);
+    AVec<int> &now_at = scratch;                                 // rank in the all-hits ranking -> position after the second sort
+    now_at.fill(n, 0);
+    for (int i = 0; i < n; ++i) now_at[a[i].secondary_all] = i;
+    for (int i = 0; i < n; ++i) {
+        bm2_alnreg_t &h = a[i];
+        if (h.secondary < 0) { h.secondary_all = -1; continue; }
+        h.secondary_all = now_at[h.secondary];
+        if (h.is_alt) h.secondary = INT_MAX;
+    }
+    if (n_assembly > 0) {                                        // the assembly hits among themselves
+        for (int i = 0; i < n_assembly; ++i) { a[i].sub = 0; a[i].secondary = -1; }
+        follow_leaders(opt, n_assembly, a, scratch);
+    }
+    return n_assembly;
 }
 
-// mem_reorder_primary5, bwamem.cpp:1496-1519
+// `-5` (mem_reorder_primary5, bwamem.cpp:1496-1519): of the reportable primary hits (leading, on the assembly, score >= T) the one that
+// starts leftmost on the read goes first; every reference to the two positions that trade places is renamed.
 void reorder_primary5(int T, int n, bm2_alnreg_t *a) {
-    int n_pri = 0, left_st = INT_MAX, left_k = -1;
-    for (int k = 0; k < n; ++k) if (a[k].secondary < 0 && !a[k].is_alt && a[k].score >= T) ++n_pri;
-    if (n_pri <= 1) return;
+    auto reportable = [&](const bm2_alnreg_t &h) { return h.secondary < 0 && !h.is_alt && h.score >= T; };
+    int count = 0, leftmost = -1;
     for (int k = 0; k < n; ++k) {
-        const bm2_alnreg_t *p = &a[k];
-        if (p->secondary >= 0 || p->is_alt || p->score < T) continue;
-        if (p->qb < left_st) { left_st = p->qb; left_k = k; }
+        if (!reportable(a[k])) continue;
+        ++count;
+        if (leftmost < 0 || a[k].qb < a[leftmost].qb) leftmost = k;                    // (the first of equally left hits stays the choice)
     }
-    if (left_k == 0) return;
-    bm2_alnreg_t t = a[0]; a[0] = a[left_k]; a[left_k] = t;
-    for (int k = 1; k < n; ++k) {
-        bm2_alnreg_t *p = &a[k];
-        if (p->secondary == 0) p->secondary = left_k;
-        else if (p->secondary == left_k) p->secondary = 0;
-        if (p->secondary_all == 0) p->secondary_all = left_k;
-        else if (p->secondary_all == left_k) p->secondary_all = 0;
-    }
+    if (count <= 1 || leftmost == 0) return;
+    std::swap(a[0], a[leftmost]);
+    auto renamed = [&](int ref) { return ref == 0 ? leftmost : ref == leftmost ? 0 : ref; };
+    for (int k = 1; k < n; ++k) { a[k].secondary = renamed(a[k].secondary); a[k].secondary_all = renamed(a[k].secondary_all); }
 }
 
 template <class S> void put_cigar(S &s, const AVec<uint32_t> &cg, const char *ops) {

@@ -225,8 +225,8 @@ void bm2_sam_rescue_stats(int64_t *planned, int64_t *used, int64_t *missed);
 
 /* The local Smith-Waterman of mate rescue for a batch of (query, target) pairs: ksw_align2 (ksw.cpp:340-381) = a forward pass
  * (score, target end, query end, second-best score / its target end outside the best's neighbourhood) and, with KSW_XSTART, a
- * reverse pass for the start.  Host implementation today (the SSE2 kernel's striping is observable and kept); this is the
- * seam the device kernel of SURVEY.md 8(f)1 will sit behind.  xtra = KSW_X* flags | minimum score, as mem_matesw builds it
+ * reverse pass for the start.  This is the HOST implementation (the SSE2 kernel's striping is observable and kept): the oracle of the
+ * device kernel below and the code that aligns the few rescues a pair asks for outside its chunk's batch.  xtra = KSW_X* flags | minimum score, as mem_matesw builds it
  * (bwamem_pair.cpp:205).  out[i] = { score, te, qe, score2, te2, tb, qb }. */
 typedef struct { int32_t score, te, qe, score2, te2, tb, qb; } bm2_ksw_result;
 int bm2_ksw_align2(int32_t n, const uint8_t *seqs, const int64_t *q_off, const int32_t *q_len, const int64_t *t_off, const int32_t *t_len,
@@ -245,8 +245,8 @@ int bm2_sam_header(const bm2_index_desc *idx, const char *hdr_line, char *out, i
 
 /* CIGAR generation for a batch of hits: bwa_gen_cigar2 (bwa.cpp:260-347) = banded global alignment with backtrack of the
  * query against reference [rb, re) (ksw_global2, ksw.cpp:558-668; both reversed first for hits on the reverse strand so that
- * gaps end up leftmost on the forward strand), NM and the MD string.  Host implementation today; the seam of the device
- * kernel of SURVEY.md 8(f)2.  Task i: query codes seqs[q_off[i] .. +q_len[i]), reference range [rb[i], re[i]), band w[i].
+ * gaps end up leftmost on the forward strand), NM and the MD string.  This is the HOST implementation: the oracle of the device
+ * kernel below and the code behind bm2_sam_se / bm2_sam_pe (no GPU) and behind the CIGARs of rescued hits.  Task i: query codes seqs[q_off[i] .. +q_len[i]), reference range [rb[i], re[i]), band w[i].
  * Out: score[i], nm[i], n_cigar[i] (-1 = the reference returns NULL: empty or strand-bridging range), its ops at
  * cigar[cigar_off[i] ..] (BAM encoding len<<4|op) and the NUL-terminated MD at md[md_off[i] ..].  cigar_cap / md_cap are the
  * callers' capacities; BM2_ECAP with the needed sizes in *cigar_need / *md_need otherwise. */
