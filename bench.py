@@ -295,7 +295,7 @@ def end_to_end(ctx, bm2, texts, opt, paired, n_threads, n_tail=None, limit_s=Non
     and buffers, the output buffers' pages); the pipeline drains, then the clock starts and all of `texts` follow.  A chunk's text is
     complete before it is counted; the tie-breaking hash of a read is seeded with its number in the input (n_before)."""
     hw = bm2.host_cpus()                                         # CPUs this process can really use (cgroup quota), not the hardware threads it sees
-    n_tail = int(os.environ.get("BM2_E2E_TAILS", n_tail if n_tail is not None else (2 if hw <= 32 else 3)))
+    n_tail = int(os.environ.get("BM2_E2E_TAILS", n_tail if n_tail is not None else (3 if hw >= 12 else 2)))
     n_dev = max(1, int(os.environ.get("BM2_E2E_DEVS", n_dev or 2)))
     if os.environ.get("BM2_E2E_LIMIT_S"):                        # (the host emulator needs minutes where the GPU needs milliseconds)
         limit_s = float(os.environ["BM2_E2E_LIMIT_S"])
@@ -305,13 +305,15 @@ def end_to_end(ctx, bm2, texts, opt, paired, n_threads, n_tail=None, limit_s=Non
     devs = [ctx] + [bm2.Context(share=ctx) for _ in range(n_dev - 1)]
     # the stages' thread counts add up to the CPUs the process may use: beyond that the threads do not run in parallel, they get the process
     # throttled (measured on the MI355X box: 256 hardware threads visible, quota 16 -- profiles/r03c_cgroup.txt)
-    n_parse = int(os.environ.get("BM2_E2E_PARSE_THREADS", max(1, min(hw // 4, 32))))
-    so = bm2.default_sam_opt(n_threads=int(os.environ.get("BM2_E2E_TAIL_THREADS", n_threads or max((hw - n_parse) // n_tail, 1))))
+    # (the stages do not all compute at once -- a tail worker waits for its device batches, the reader for a free queue slot -- so the
+    #  counts add up to somewhat more than the CPUs: the split below is the best of profiles/r03f's variants)
+    n_parse = int(os.environ.get("BM2_E2E_PARSE_THREADS", max(1, min((3 * hw) // 8, 32))))
+    so = bm2.default_sam_opt(n_threads=int(os.environ.get("BM2_E2E_TAIL_THREADS", n_threads or max((hw - 1) // n_tail, 1))))
     q_parsed, q_hits = [queue.Queue(maxsize=2) for _ in range(n_dev)], [queue.Queue(maxsize=1) for _ in range(n_tail)]
     free_pins = queue.Queue()
     for _ in range(n_dev + 2 * n_tail):
         free_pins.put([None])
-    stage, err, lock = {}, [], threading.Lock()
+    stage, err, lock, compute = {}, [], threading.Lock(), threading.Lock()
     done = [0] * len(work)
     devs_left, n_done = [n_dev], [0]
     warm_done, go = threading.Event(), threading.Event()
@@ -346,8 +348,9 @@ def end_to_end(ctx, bm2, texts, opt, paired, n_threads, n_tail=None, limit_s=Non
                     break
                 i, ch, n_before = it
                 t = time.perf_counter(); c.batch_upload_chunk(ch); add("h2d", time.perf_counter() - t)
-                t = time.perf_counter(); c.batch_run(opt); add("device", time.perf_counter() - t)
-                t = time.perf_counter(); c.batch_finish(opt); add("a19", time.perf_counter() - t)
+                with compute:                                     # one chunk's seeding .. extension at a time: two of them side by side only slow each other
+                    t = time.perf_counter(); c.batch_run(opt); add("device", time.perf_counter() - t)      # down (measured); the workers overlap copies with kernels
+                    t = time.perf_counter(); c.batch_finish(opt); add("a19", time.perf_counter() - t)
                 pin = free_pins.get()                             # a page-locked hit buffer from the pool (its last reader, a tail worker, has returned it)
                 t = time.perf_counter()
                 if pin[0] is None or len(pin[0].a) < 3 * ch.n_reads:

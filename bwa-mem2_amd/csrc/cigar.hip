@@ -66,129 +66,30 @@ static __device__ int put_dec(char *s, int n, int v) {          // kputw: plain 
     return n;
 }
 
-// LDS = true: the row of (H, E) and the query live in LDS, [column][lane], 16 + 16 bits per column and 4 bits per base -- for tasks
-// whose scores stay small (the host checks (l_query + rlen) * largest penalty < CG_SMALL): then "minus infinity" can be -22768 instead of
-// -2^30 without changing a single comparison (every DP value is either a real score or ONE sentinel plus an offset the reference has
-// too; the two families never meet), and a cell costs one LDS read and write instead of four scattered global accesses per lane.
+// Four shapes of a task, four launches (the host sorts the batch by shape, then by cost):
+//   FLAT   the query and its range are equally long and the band is 0 (bwa.cpp:281-288: no gap possible; three reads in four of a
+//          short-read run): one pass over the bases gives score, NM and MD, the CIGAR is one M.  No DP state at all.
+//   RING   banded DP whose band fits 64 columns and whose scores stay small (see CG_SMALL): the row of (H, E) lives in LDS as a RING of 64
+//          columns, [column & 63][lane] -- row i only ever touches columns i - w .. i + w + 1, and every column is written (by the row
+//          before: its band's last cell, or its closing store) before it is read -- so a wavefront takes 16 KB of LDS instead of the
+//          (query length + 1) x 256 bytes of a full row, and twice as many wavefronts share a CU.  Only the FIRST try of mem_reg2aln's
+//          retry loop runs here; a task that has to try a wider band (rare) is put on a list and goes through the ROW kernel afterwards.
+//   ROW    the full row in LDS, 16 + 16 bits per column (small scores, any band); also the later tries of deferred tasks.
+//   GLOBAL the row in the task's slice of a global scratch buffer, 32 + 32 bits (anything else).
+// In the LDS shapes "minus infinity" is -22768 instead of -2^30 without changing a single comparison (every DP value is either a real
+// score or ONE sentinel plus an offset the reference has too; the two families never meet).  The query sits in LDS 4 bits per base.
+// Scores are computed, not looked up: (match, mismatch, ambiguous) = (mat[0], mat[1], mat[4]) -- the bwa_fill_scmat form the host checks.
 #define CG_SMALL 10000
 #define CG_MINF16 (-32768 + CG_SMALL)
-template <bool LDS>
-__global__ void __launch_bounds__(64)
-k_gen_cigar(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ seqs, const CigarTask *__restrict__ tasks, const int *__restrict__ order,
-            int n, CigarPrm prm, uint8_t *__restrict__ zbuf, int2 *__restrict__ ehbuf, uint32_t *__restrict__ cgbuf, char *__restrict__ mdbuf,
-            CigarRes *__restrict__ res, int qmax) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t cg_lds[];
-    uint32_t *EH = cg_lds;                                      // [(qmax + 1)][64]
-    uint32_t *Q4 = cg_lds + (size_t)(qmax + 1) * 64;            // [(qmax + 7) / 8][64]: 8 bases of 4 bits
-    const int lane = threadIdx.x;
-    constexpr int MINF = LDS ? CG_MINF16 : CG_MINUS_INF;
-    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
-    if (slot >= n) return;
-    const int id = order[slot];
-    const CigarTask T = tasks[id];
-    CigarRes R; R.score = 0; R.nm = -1; R.n_cigar = -1; R.md_len = 0;
-    if (!cigar_range_ok(prm.l_pac, T.q_len, T.rb, T.re)) { res[id] = R; return; }
-    const int lq = T.q_len, rlen = (int)(T.re - T.rb);
-    const bool rev = T.rb >= prm.l_pac;
-    const uint8_t *qp = seqs + T.q_off;
-    if (LDS) {                                                  // the query in alignment order (reversed for reverse-strand hits)
-        for (int j0 = 0; j0 < lq; j0 += 8) {
-            uint32_t wq = 0;
-            for (int u = 0; u < 8 && j0 + u < lq; u++) wq |= (uint32_t)((rev ? qp[lq - 1 - (j0 + u)] : qp[j0 + u]) & 15) << (4 * u);
-            Q4[(j0 >> 3) * 64 + lane] = wq;
-        }
-    }
-    auto Q = [&](int i) -> int { return LDS ? (int)((Q4[(i >> 3) * 64 + lane] >> (4 * (i & 7))) & 15u) : (rev ? qp[lq - 1 - i] : qp[i]); };
-    auto RF = [&](int i) -> int { return rev ? ref[T.re - 1 - i] : ref[T.rb + i]; };
-    int2 *ehg = ehbuf + T.eh_off;                               // .x = h, .y = e (global version)
-    auto eh_get = [&](int j) -> int2 {
-        if (!LDS) return ehg[j];
-        const uint32_t w = EH[j * 64 + lane];
-        return make_int2((int)(int16_t)(w & 0xffffu), (int)w >> 16);
-    };
-    auto eh_set = [&](int j, int h, int e) {
-        if (!LDS) ehg[j] = make_int2(h, e);
-        else EH[j * 64 + lane] = ((uint32_t)h & 0xffffu) | (uint32_t)e << 16;
-    };
-    uint32_t *cg = cgbuf + T.cg_off;
-    int ncg = 0;
-    // one alignment (bwa_gen_cigar2, bwa.cpp:281-310), or mem_reg2aln's loop around it (bwamem.cpp:1748-1766): retry with twice the band
-    // while the score keeps changing, stays more than a match below the hit's score, and the band has not reached 4 w
-    int w_try = T.retry ? cigar_first_band(lq, rlen, T.truesc, T.w, prm.a, prm.w, prm.o_del, prm.e_del, prm.o_ins, prm.e_ins) : T.w;
-    int last_sc = -(1 << 30);
-    for (int attempt = 0; ; ) {
-        if (T.retry) w_try = w_try < prm.w << 2 ? w_try : prm.w << 2;
-        ncg = 0;
-        if (lq == rlen && w_try == 0) {                         // no gap possible: one M (bwa.cpp:281-288)
-            int sc = 0;
-            for (int i = 0; i < lq; ++i) sc += prm.mat[RF(i) * 5 + Q(i)];
-            R.score = sc;
-            cg[ncg++] = (uint32_t)lq << 4;
-        } else {
-            const int w = cigar_band(lq, rlen, w_try, prm.mat[0], prm.o_del, prm.e_del, prm.o_ins, prm.e_ins);
-            const int oe_del = prm.o_del + prm.e_del, oe_ins = prm.o_ins + prm.e_ins, e_del = prm.e_del, e_ins = prm.e_ins;
-            const int n_col = ((lq < 2 * w + 1 ? lq : 2 * w + 1) + 3) & ~3;       // row stride: whole dwords (the directions are stored four cells at a time)
-            uint8_t *z = zbuf + T.z_off;
-            int j;
-            eh_set(0, 0, MINF);
-            for (j = 1; j <= lq && j <= w; ++j) eh_set(j, -(prm.o_ins + e_ins * j), MINF);
-            for (; j <= lq; ++j) eh_set(j, MINF, MINF);
-            for (int i = 0; i < rlen; ++i) {                    // ksw.cpp:598-637
-                int f = MINF;
-                const int8_t *sc = &prm.mat[RF(i) * 5];
-                const int beg = i > w ? i - w : 0, end = i + w + 1 < lq ? i + w + 1 : lq;
-                int h1 = beg == 0 ? -(prm.o_del + e_del * (i + 1)) : MINF;
-                uint32_t *zi = (uint32_t *)(z + (int64_t)i * n_col);
-                uint32_t zacc = 0;
-                for (j = beg; j < end; ++j) {
-                    const int2 p = eh_get(j);
-                    int m = p.x, e = p.y, h, t;
-                    uint8_t d;
-                    m += sc[Q(j)];
-                    d = m >= e ? 0 : 1;
-                    h = m >= e ? m : e;
-                    d = h >= f ? d : 2;
-                    h = h >= f ? h : f;
-                    t = m - oe_del; e -= e_del;
-                    d |= e > t ? 1 << 2 : 0;
-                    e = e > t ? e : t;
-                    eh_set(j, h1, e);
-                    h1 = h;
-                    t = m - oe_ins; f -= e_ins;
-                    d |= f > t ? 2 << 4 : 0;
-                    f = f > t ? f : t;
-                    const int c = j - beg;
-                    zacc |= (uint32_t)d << (8 * (c & 3));
-                    if ((c & 3) == 3) { zi[c >> 2] = zacc; zacc = 0; }
-                }
-                if ((end - beg) & 3) zi[(end - beg) >> 2] = zacc;
-                eh_set(end, h1, MINF);
-            }
-            R.score = eh_get(lq).x;
-            // backtrack (ksw.cpp:640-660): ops are pushed last-to-first, merged, then reversed
-            auto push = [&](int op, int len) {
-                if (ncg == 0 || op != (int)(cg[ncg - 1] & 0xf)) cg[ncg++] = (uint32_t)len << 4 | (uint32_t)op;
-                else cg[ncg - 1] += (uint32_t)len << 4;
-            };
-            int which = 0, i = rlen - 1, k = (i + w + 1 < lq ? i + w + 1 : lq) - 1;
-            while (i >= 0 && k >= 0) {
-                which = z[(int64_t)i * n_col + (k - (i > w ? i - w : 0))] >> (which << 1) & 3;
-                if (which == 0) { push(0, 1); --i; --k; }
-                else if (which == 1) { push(2, 1); --i; }
-                else { push(1, 1); --k; }
-            }
-            if (i >= 0) push(2, i + 1);
-            if (k >= 0) push(1, k + 1);
-            for (int a = 0, b = ncg; a + 1 < b; ++a, --b) { const uint32_t t = cg[a]; cg[a] = cg[b - 1]; cg[b - 1] = t; }
-        }
-        if (!T.retry) break;
-        if (R.score == last_sc || w_try == prm.w << 2) break;
-        last_sc = R.score;
-        w_try <<= 1;
-        if (!(++attempt < 3 && R.score < T.truesc - prm.a)) break;
-    }
-    // NM and MD (bwa.cpp:311-340)
-    char *md = mdbuf + T.md_off;
+#define CG_RING 64
+enum { CG_GLOBAL = 0, CG_ROW = 1, CG_RINGED = 2 };
+enum { CG_NULL = -1, CG_DEFERRED = -3 };                          // CigarRes::n_cigar: the reference's NULL return; "try the next band in the ROW kernel"
+
+static __device__ __forceinline__ int cg_score(int t, int q, int s_match, int s_mis, int s_amb) { return (t == q && t < 4) ? s_match : ((t > 3 || q > 3) ? s_amb : s_mis); }
+
+// NM and MD of a finished CIGAR (bwa.cpp:311-340)
+template <class QF, class RFn>
+static __device__ __forceinline__ void cg_nm_md(const uint32_t *cg, int ncg, QF Q, RFn RF, bool rev, char *md, CigarRes &R) {
     int x = 0, y = 0, u = 0, n_mm = 0, n_gap = 0, nmd = 0;
     const char *int2base = rev ? "TGCAN" : "ACGTN";
     for (int k = 0; k < ncg; ++k) {
@@ -212,6 +113,168 @@ k_gen_cigar(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ seqs, c
     nmd = put_dec(md, nmd, u);
     md[nmd] = 0;
     R.nm = n_mm + n_gap; R.n_cigar = ncg; R.md_len = nmd;
+}
+
+__global__ void __launch_bounds__(256)
+k_cigar_flat(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ seqs, const CigarTask *__restrict__ tasks, const int *__restrict__ order,
+             int n, CigarPrm prm, uint32_t *__restrict__ cgbuf, char *__restrict__ mdbuf, CigarRes *__restrict__ res) {
+    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= n) return;
+    const int id = order[slot];
+    const CigarTask T = tasks[id];
+    CigarRes R; R.score = 0; R.nm = -1; R.n_cigar = CG_NULL; R.md_len = 0;
+    if (!cigar_range_ok(prm.l_pac, T.q_len, T.rb, T.re)) { res[id] = R; return; }     // (the NULL returns of the batch are filed under this shape)
+    const int lq = T.q_len;
+    const bool rev = T.rb >= prm.l_pac;
+    const uint8_t *qp = seqs + T.q_off;
+    const int s_match = prm.mat[0], s_mis = prm.mat[1], s_amb = prm.mat[4];
+    char *md = mdbuf + T.md_off;
+    const char *int2base = rev ? "TGCAN" : "ACGTN";
+    int sc = 0, u = 0, n_mm = 0, nmd = 0;
+    for (int i = 0; i < lq; ++i) {                              // both in alignment order (reversed for a hit on the reverse strand)
+        const int t = rev ? ref[T.re - 1 - i] : ref[T.rb + i], q = (rev ? qp[lq - 1 - i] : qp[i]) & 15;
+        sc += cg_score(t, q, s_match, s_mis, s_amb);
+        if (q != t) { nmd = put_dec(md, nmd, u); md[nmd++] = int2base[t]; ++n_mm; u = 0; }
+        else ++u;
+    }
+    nmd = put_dec(md, nmd, u);
+    md[nmd] = 0;
+    cgbuf[T.cg_off] = (uint32_t)lq << 4;
+    R.score = sc; R.nm = n_mm; R.n_cigar = 1; R.md_len = nmd;
+    res[id] = R;
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(64)
+k_gen_cigar(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ seqs, const CigarTask *__restrict__ tasks, const int *__restrict__ order,
+            int n, CigarPrm prm, uint8_t *__restrict__ zbuf, int2 *__restrict__ ehbuf, uint32_t *__restrict__ cgbuf, char *__restrict__ mdbuf,
+            CigarRes *__restrict__ res, int qmax, int resume, int *__restrict__ defer_list, int *__restrict__ defer_count) {
+    constexpr bool LDS = MODE != CG_GLOBAL, RING = MODE == CG_RINGED;
+    extern __shared__ __attribute__((aligned(16))) uint32_t cg_lds[];
+    uint32_t *EH = cg_lds;                                      // ROW: [(qmax + 1)][64]; RING: [64][64]
+    uint32_t *Q4 = cg_lds + (size_t)(RING ? CG_RING : qmax + 1) * 64;        // [(qmax + 7) / 8][64]: 8 bases of 4 bits
+    const int lane = threadIdx.x;
+    constexpr int MINF = LDS ? CG_MINF16 : CG_MINUS_INF;
+    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= n) return;
+    const int id = order[slot];
+    const CigarTask T = tasks[id];
+    CigarRes R; R.score = 0; R.nm = -1; R.n_cigar = CG_NULL; R.md_len = 0;
+    if (!cigar_range_ok(prm.l_pac, T.q_len, T.rb, T.re)) { res[id] = R; return; }
+    const int lq = T.q_len, rlen = (int)(T.re - T.rb);
+    const bool rev = T.rb >= prm.l_pac;
+    const uint8_t *qp = seqs + T.q_off;
+    const int s_match = prm.mat[0], s_mis = prm.mat[1], s_amb = prm.mat[4];
+    if (LDS) {                                                  // the query in alignment order (reversed for reverse-strand hits)
+        for (int j0 = 0; j0 < lq; j0 += 8) {
+            uint32_t wq = 0;
+            for (int u = 0; u < 8 && j0 + u < lq; u++) wq |= (uint32_t)((rev ? qp[lq - 1 - (j0 + u)] : qp[j0 + u]) & 15) << (4 * u);
+            Q4[(j0 >> 3) * 64 + lane] = wq;
+        }
+    }
+    auto Q = [&](int i) -> int { return LDS ? (int)((Q4[(i >> 3) * 64 + lane] >> (4 * (i & 7))) & 15u) : (rev ? qp[lq - 1 - i] : qp[i]); };
+    auto RF = [&](int i) -> int { return rev ? ref[T.re - 1 - i] : ref[T.rb + i]; };
+    int2 *ehg = ehbuf + T.eh_off;                               // .x = h, .y = e (global version)
+    auto eh_get = [&](int j) -> int2 {
+        if (!LDS) return ehg[j];
+        const uint32_t w = EH[(RING ? (j & (CG_RING - 1)) : j) * 64 + lane];
+        return make_int2((int)(int16_t)(w & 0xffffu), (int)w >> 16);
+    };
+    auto eh_set = [&](int j, int h, int e) {
+        if (!LDS) ehg[j] = make_int2(h, e);
+        else EH[(RING ? (j & (CG_RING - 1)) : j) * 64 + lane] = ((uint32_t)h & 0xffffu) | (uint32_t)e << 16;
+    };
+    uint32_t *cg = cgbuf + T.cg_off;
+    int ncg = 0;
+    // one alignment (bwa_gen_cigar2, bwa.cpp:281-310), or mem_reg2aln's loop around it (bwamem.cpp:1748-1766): retry with twice the band
+    // while the score keeps changing, stays more than a match below the hit's score, and the band has not reached 4 w
+    int w_try = T.retry ? cigar_first_band(lq, rlen, T.truesc, T.w, prm.a, prm.w, prm.o_del, prm.e_del, prm.o_ins, prm.e_ins) : T.w;
+    int last_sc = -(1 << 30), attempt = 0;
+    if (resume) { const CigarRes P = res[id]; last_sc = P.score; w_try = P.nm; attempt = P.md_len; }      // (a deferred task: where the RING kernel left its loop)
+    for (;;) {
+        if (T.retry) w_try = w_try < prm.w << 2 ? w_try : prm.w << 2;
+        ncg = 0;
+        if (lq == rlen && w_try == 0) {                         // no gap possible: one M (bwa.cpp:281-288)
+            int sc = 0;
+            for (int i = 0; i < lq; ++i) sc += cg_score(RF(i), Q(i), s_match, s_mis, s_amb);
+            R.score = sc;
+            cg[ncg++] = (uint32_t)lq << 4;
+        } else {
+            const int w = cigar_band(lq, rlen, w_try, prm.mat[0], prm.o_del, prm.e_del, prm.o_ins, prm.e_ins);
+            const int oe_del = prm.o_del + prm.e_del, oe_ins = prm.o_ins + prm.e_ins, e_del = prm.e_del, e_ins = prm.e_ins;
+            const int n_col = ((lq < 2 * w + 1 ? lq : 2 * w + 1) + 3) & ~3;       // row stride: whole dwords (the directions are stored four cells at a time)
+            uint8_t *z = zbuf + T.z_off;
+            int j;
+            // row -1.  Only the columns 0 .. w are ever read from it: a column further right is first read by the row whose band reaches it,
+            // and the row before that one has stored it (its closing store).  H of the LAST column travels in a register beside the row.
+            int h_lq = lq <= w ? -(prm.o_ins + e_ins * lq) : MINF;
+            eh_set(0, 0, MINF);
+            for (j = 1; j <= lq && j <= w; ++j) eh_set(j, -(prm.o_ins + e_ins * j), MINF);
+            if (!RING) for (; j <= lq; ++j) eh_set(j, MINF, MINF);
+            int t_next = RF(0);
+            for (int i = 0; i < rlen; ++i) {                    // ksw.cpp:598-637
+                int f = MINF;
+                const int tb = t_next;
+                if (i + 1 < rlen) t_next = RF(i + 1);           // (requested a row ahead)
+                const int beg = i > w ? i - w : 0, end = i + w + 1 < lq ? i + w + 1 : lq;
+                int h1 = beg == 0 ? -(prm.o_del + e_del * (i + 1)) : MINF;
+                uint32_t *zi = (uint32_t *)(z + (int64_t)i * n_col);
+                uint32_t zacc = 0;
+                for (j = beg; j < end; ++j) {
+                    const int2 p = eh_get(j);
+                    int m = p.x, e = p.y, h, t;
+                    uint8_t d;
+                    m += cg_score(tb, Q(j), s_match, s_mis, s_amb);
+                    d = m >= e ? 0 : 1;
+                    h = m >= e ? m : e;
+                    d = h >= f ? d : 2;
+                    h = h >= f ? h : f;
+                    t = m - oe_del; e -= e_del;
+                    d |= e > t ? 1 << 2 : 0;
+                    e = e > t ? e : t;
+                    eh_set(j, h1, e);
+                    h1 = h;
+                    t = m - oe_ins; f -= e_ins;
+                    d |= f > t ? 2 << 4 : 0;
+                    f = f > t ? f : t;
+                    const int c = j - beg;
+                    zacc |= (uint32_t)d << (8 * (c & 3));
+                    if ((c & 3) == 3) { zi[c >> 2] = zacc; zacc = 0; }
+                }
+                if ((end - beg) & 3) zi[(end - beg) >> 2] = zacc;
+                eh_set(end, h1, MINF);
+                if (end == lq) h_lq = h1;
+            }
+            R.score = h_lq;
+            // backtrack (ksw.cpp:640-660): ops are pushed last-to-first, merged, then reversed
+            auto push = [&](int op, int len) {
+                if (ncg == 0 || op != (int)(cg[ncg - 1] & 0xf)) cg[ncg++] = (uint32_t)len << 4 | (uint32_t)op;
+                else cg[ncg - 1] += (uint32_t)len << 4;
+            };
+            int which = 0, i = rlen - 1, k = (i + w + 1 < lq ? i + w + 1 : lq) - 1;
+            while (i >= 0 && k >= 0) {
+                which = z[(int64_t)i * n_col + (k - (i > w ? i - w : 0))] >> (which << 1) & 3;
+                if (which == 0) { push(0, 1); --i; --k; }
+                else if (which == 1) { push(2, 1); --i; }
+                else { push(1, 1); --k; }
+            }
+            if (i >= 0) push(2, i + 1);
+            if (k >= 0) push(1, k + 1);
+            for (int a = 0, b = ncg; a + 1 < b; ++a, --b) { const uint32_t t = cg[a]; cg[a] = cg[b - 1]; cg[b - 1] = t; }
+        }
+        if (!T.retry) break;
+        if (R.score == last_sc || w_try == prm.w << 2) break;
+        last_sc = R.score;
+        w_try <<= 1;
+        if (!(++attempt < 3 && R.score < T.truesc - prm.a)) break;
+        if (RING) {                                             // another try, with a wider band: the ROW kernel's (rare)
+            R.score = last_sc; R.nm = w_try; R.md_len = attempt; R.n_cigar = CG_DEFERRED;
+            res[id] = R;
+            defer_list[atomicAdd(defer_count, 1)] = id;
+            return;
+        }
+    }
+    cg_nm_md(cg, ncg, Q, RF, rev, mdbuf + T.md_off, R);
     res[id] = R;
 }
 
@@ -248,16 +311,20 @@ static int cigar_run(bm2_ctx *c, const bm2_opt *opt, std::vector<CigarTask> &tas
     prm.o_del = opt->o_del; prm.e_del = opt->e_del; prm.o_ins = opt->o_ins; prm.e_ins = opt->e_ins; prm.a = opt->a; prm.w = opt->w; prm.l_pac = c->ix.l_pac;
     // slices of the scratch buffers (sized for the widest band a task can come to) and the cost class of every task: sizes per piece
     // of the task list on the host's worker threads, offsets by a scan over the pieces, then the tasks' slices
-    static thread_local std::vector<int> order_tl; static thread_local std::vector<int64_t> cost_tl;
-    std::vector<int> &order = order_tl; std::vector<int64_t> &cost = cost_tl;
-    if (order.size() < (size_t)n) { order.resize((size_t)n); cost.resize((size_t)n); }
+    static thread_local std::vector<int> order_tl; static thread_local std::vector<int64_t> cost_tl; static thread_local std::vector<int16_t> wb_tl;
+    std::vector<int> &order = order_tl; std::vector<int64_t> &cost = cost_tl; std::vector<int16_t> &wb1 = wb_tl;
+    if (order.size() < (size_t)n) { order.resize((size_t)n); cost.resize((size_t)n); wb1.resize((size_t)n); }
+    for (int i = 0; i < 5; i++) for (int j = 0; j < 5; j++) {       // the kernels compute scores from (match, mismatch, ambiguous), as the hot path does
+        const int want = (i == 4 || j == 4) ? opt->mat[4] : (i == j ? opt->mat[0] : opt->mat[1]);
+        if (opt->mat[i * 5 + j] != want) { bm2_set_error("bm2_gen_cigar_dev: scoring matrix is not of the bwa_fill_scmat form"); return BM2_EUNSUP; }
+    }
     const int host_threads = bm2_host_threads();
     const int64_t grain = 16384, pieces = ((int64_t)n + grain - 1) / grain;
-    struct Sz { int64_t z, e, c, m; };
-    std::vector<Sz> at((size_t)pieces + 1, Sz{ 0, 0, 0, 0 });
+    struct Sz { int64_t z, e, c, m; int wb_first; };          // wb_first: the band of the first (or only) alignment, -1 = none (flat / NULL)
+    std::vector<Sz> at((size_t)pieces + 1, Sz{ 0, 0, 0, 0, -1 });
     std::atomic<int> too_long(0);
     auto sizes = [&](const CigarTask &T, Sz &s) {               // what the task takes of the four buffers; s.z = its DP area = its cost
-        s = Sz{ 0, 0, 0, 0 };
+        s = Sz{ 0, 0, 0, 0, -1 };
         if (!cigar_range_ok(prm.l_pac, T.q_len, T.rb, T.re)) return;
         const int64_t rlen = T.re - T.rb;
         if (rlen > 0x3fffffff) { too_long = 1; return; }
@@ -267,12 +334,18 @@ static int cigar_run(bm2_ctx *c, const bm2_opt *opt, std::vector<CigarTask> &tas
             const int wb = cigar_band(T.q_len, (int)rlen, w_cap, prm.mat[0], prm.o_del, prm.e_del, prm.o_ins, prm.e_ins);
             const int n_col = ((T.q_len < 2 * wb + 1 ? T.q_len : 2 * wb + 1) + 3) & ~3;      // a multiple of 4: every z slice starts 4-aligned
             s.z = (int64_t)n_col * rlen; s.e = T.q_len + 1;
+            const int w0 = T.retry ? (w_first < prm.w << 2 ? w_first : prm.w << 2) : T.w;      // (the kernel's clamp of the first try)
+            s.wb_first = cigar_band(T.q_len, (int)rlen, w0, prm.mat[0], prm.o_del, prm.e_del, prm.o_ins, prm.e_ins);
         }
         s.c = T.q_len + rlen + 2; s.m = 2 * (T.q_len + rlen) + 16;
     };
     bm2_parallel_ranges(n, grain, host_threads, [&](int64_t lo, int64_t hi) {
-        Sz sum{ 0, 0, 0, 0 }, s;
-        for (int64_t i = lo; i < hi; ++i) { sizes(tasks[(size_t)i], s); cost[(size_t)i] = s.z; sum.z += s.z; sum.e += s.e; sum.c += s.c; sum.m += s.m; }
+        Sz sum{ 0, 0, 0, 0, -1 }, s;
+        for (int64_t i = lo; i < hi; ++i) {
+            sizes(tasks[(size_t)i], s);
+            cost[(size_t)i] = s.z; wb1[(size_t)i] = (int16_t)(s.wb_first > 32000 ? 32000 : s.wb_first);
+            sum.z += s.z; sum.e += s.e; sum.c += s.c; sum.m += s.m;
+        }
         at[(size_t)(lo / grain) + 1] = sum;
     });
     if (too_long.load()) { bm2_set_error("bm2_gen_cigar_dev: reference range too long"); return BM2_EINVAL; }
@@ -288,24 +361,34 @@ static int cigar_run(bm2_ctx *c, const bm2_opt *opt, std::vector<CigarTask> &tas
         }
     });
     prof.mark("slices");
-    int n_small = 0, qmax = 0;
-    {   // lanes of a wavefront run their tasks side by side: neighbours should cost alike.  Counting sort by (small-score class first,
-        // then cost on a log scale, expensive first).  "Small": the LDS kernel's condition, see k_gen_cigar.
+    // lanes of a wavefront run their tasks side by side: neighbours should be of one shape (see k_gen_cigar) and cost alike.  Counting sort by
+    // (shape, cost on a log scale, expensive first); the order array is the four shapes' task lists one after the other.
+    enum { SH_RING = 0, SH_ROW = 1, SH_GLOBAL = 2, SH_FLAT = 3 };
+    int n_shape[4] = { 0, 0, 0, 0 }, qmax = 0;
+    {
         int pen = 1;
         for (int a = 0; a < 25; ++a) pen = std::max(pen, abs((int)opt->mat[a]));
         pen = std::max(pen, std::max(opt->o_del + opt->e_del, opt->o_ins + opt->e_ins));
         static const int no_lds = getenv("BM2_CIGAR_NO_LDS") ? atoi(getenv("BM2_CIGAR_NO_LDS")) : 0;
+        static const int no_ring = getenv("BM2_CIGAR_NO_RING") ? atoi(getenv("BM2_CIGAR_NO_RING")) : 0;
         auto small = [&](int i) { const CigarTask &T = tasks[(size_t)i]; return !no_lds && T.q_len <= 220 && (int64_t)(T.q_len + (T.re - T.rb)) * pen < CG_SMALL; };
-        auto cls = [&](int i) { const int64_t v = cost[(size_t)i]; const int k = v > 0 ? 64 - __builtin_clzll((unsigned long long)v) : 0; return (small(i) ? 0 : 64) + 63 - k; };
-        bm2_counting_order(n, 128, host_threads, cls, order.data());
-        std::atomic<int> ns(0), qm(0);
+        auto shape = [&](int i) {
+            if (cost[(size_t)i] == 0) return (int)SH_FLAT;       // (no DP area: the one-M case, or a NULL return)
+            if (!small(i)) return (int)SH_GLOBAL;
+            return (!no_ring && 2 * (int)wb1[(size_t)i] + 2 <= CG_RING) ? (int)SH_RING : (int)SH_ROW;
+        };
+        auto cls = [&](int i) { const int64_t v = cost[(size_t)i]; const int k = v > 0 ? 64 - __builtin_clzll((unsigned long long)v) : 0; return shape(i) * 64 + 63 - k; };
+        bm2_counting_order(n, 256, host_threads, cls, order.data());
+        std::atomic<int> ns[4], qm(0);
+        for (auto &x : ns) x = 0;
         bm2_parallel_ranges(n, grain, host_threads, [&](int64_t lo, int64_t hi) {
-            int c = 0, q = 0;
-            for (int64_t i = lo; i < hi; ++i) if (small((int)i)) { ++c; q = std::max(q, tasks[(size_t)i].q_len); }
-            ns += c;
+            int c[4] = { 0, 0, 0, 0 }, q = 0;
+            for (int64_t i = lo; i < hi; ++i) { const int sh = shape((int)i); ++c[sh]; if (sh == SH_RING || sh == SH_ROW) q = std::max(q, tasks[(size_t)i].q_len); }
+            for (int k = 0; k < 4; ++k) ns[k] += c[k];
             for (int cur = qm.load(); q > cur && !qm.compare_exchange_weak(cur, q);) {}
         });
-        n_small = ns.load(); qmax = qm.load();
+        for (int k = 0; k < 4; ++k) n_shape[k] = ns[k].load();
+        qmax = qm.load();
     }
     prof.mark("order");
     c->n_bsw = 0;                                               // (these scratch buffers held the resident S1 batch, if any: it is gone)
@@ -313,15 +396,17 @@ static int cigar_run(bm2_ctx *c, const bm2_opt *opt, std::vector<CigarTask> &tas
     const size_t task_bytes = ((size_t)n * sizeof(CigarTask) + 15) & ~(size_t)15, ord_bytes = ((size_t)n * sizeof(int) + 15) & ~(size_t)15;
     const size_t z_bytes = ((size_t)zo + 15) & ~(size_t)15, eh_bytes = (size_t)eo * sizeof(int2), cg_bytes = ((size_t)co * 4 + 15) & ~(size_t)15, md_bytes = ((size_t)mo + 15) & ~(size_t)15;
     const size_t res_bytes = ((size_t)n * sizeof(CigarRes) + 15) & ~(size_t)15, cnt_bytes = ((size_t)(n + 2) * 4 + 15) & ~(size_t)15, pos_bytes = (size_t)(n + 2) * 8;
+    const size_t defer_bytes = ((size_t)(n_shape[SH_RING] + 4) * 4 + 15) & ~(size_t)15;      // [0] = count, then the list
     if ((rc = bm2_reserve(b_seq, (size_t)seq_bytes + 64))) return rc;
     if ((rc = bm2_reserve(b_task, task_bytes + ord_bytes + 64))) return rc;
-    if ((rc = bm2_reserve(b_res, res_bytes + 2 * cnt_bytes + 2 * pos_bytes + 64))) return rc;
+    if ((rc = bm2_reserve(b_res, res_bytes + 2 * cnt_bytes + 2 * pos_bytes + defer_bytes + 64))) return rc;
     if ((rc = bm2_reserve(b_scr, z_bytes + eh_bytes + cg_bytes + md_bytes + 64))) return rc;
     hipStream_t s = c->stream;
     CigarTask *d_task = (CigarTask *)b_task.p; int *d_order = (int *)((char *)b_task.p + task_bytes);
     CigarRes *d_res = (CigarRes *)b_res.p;
     int32_t *d_nops = (int32_t *)((char *)b_res.p + res_bytes), *d_nmd = (int32_t *)((char *)d_nops + cnt_bytes);
     int64_t *d_cgpos = (int64_t *)((char *)d_nmd + cnt_bytes), *d_mdpos = (int64_t *)((char *)d_cgpos + pos_bytes);
+    int *d_defer = (int *)((char *)d_mdpos + pos_bytes);
     uint8_t *d_z = (uint8_t *)b_scr.p; int2 *d_eh = (int2 *)((char *)b_scr.p + z_bytes);
     uint32_t *d_cg = (uint32_t *)((char *)d_eh + eh_bytes); char *d_md = (char *)d_cg + cg_bytes;
     prof.mark("reserve");
@@ -329,17 +414,38 @@ static int cigar_run(bm2_ctx *c, const bm2_opt *opt, std::vector<CigarTask> &tas
     if (!rc) rc = bm2_copy_h2d(c, d_task, tasks.data(), (size_t)n * sizeof(CigarTask));
     if (!rc) rc = bm2_copy_h2d(c, d_order, order.data(), (size_t)n * sizeof(int));
     if (rc) return rc;
-    if (n_small) {
-        const size_t lds = (size_t)(qmax + 1) * 256 + (size_t)((qmax + 7) / 8) * 256;
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_gen_cigar<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k_gen_cigar<true>, dim3((n_small + 63) / 64), dim3(64), lds, s, c->ix.ref_string, (const uint8_t *)b_seq.p, d_task, d_order, n_small,
-                           prm, d_z, d_eh, d_cg, d_md, d_res, qmax);
+    const size_t lds_q = (size_t)((qmax + 7) / 8) * 256, lds_row = (size_t)(qmax + 1) * 256 + lds_q, lds_ring = (size_t)CG_RING * 256 + lds_q;
+    if (lds_row > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_gen_cigar<CG_ROW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_row);
+    const int *o_ring = d_order, *o_row = o_ring + n_shape[SH_RING], *o_glob = o_row + n_shape[SH_ROW], *o_flat = o_glob + n_shape[SH_GLOBAL];
+    if ((rc = bm2_check(hipMemsetAsync(d_defer, 0, 4, s), "memset"))) return rc;
+    // (the costliest tasks lead every list; the four launches follow each other on the stream, the cheap flat tasks last)
+    if (n_shape[SH_RING])
+        hipLaunchKernelGGL(k_gen_cigar<CG_RINGED>, dim3((n_shape[SH_RING] + 63) / 64), dim3(64), lds_ring, s, c->ix.ref_string, (const uint8_t *)b_seq.p, d_task, o_ring,
+                           n_shape[SH_RING], prm, d_z, d_eh, d_cg, d_md, d_res, qmax, 0, d_defer + 1, d_defer);
+    if (n_shape[SH_ROW])
+        hipLaunchKernelGGL(k_gen_cigar<CG_ROW>, dim3((n_shape[SH_ROW] + 63) / 64), dim3(64), lds_row, s, c->ix.ref_string, (const uint8_t *)b_seq.p, d_task, o_row,
+                           n_shape[SH_ROW], prm, d_z, d_eh, d_cg, d_md, d_res, qmax, 0, (int *)nullptr, (int *)nullptr);
+    if (n_shape[SH_GLOBAL])
+        hipLaunchKernelGGL(k_gen_cigar<CG_GLOBAL>, dim3((n_shape[SH_GLOBAL] + 63) / 64), dim3(64), 0, s, c->ix.ref_string, (const uint8_t *)b_seq.p, d_task, o_glob,
+                           n_shape[SH_GLOBAL], prm, d_z, d_eh, d_cg, d_md, d_res, 0, 0, (int *)nullptr, (int *)nullptr);
+    if (n_shape[SH_FLAT])
+        hipLaunchKernelGGL(k_cigar_flat, dim3((n_shape[SH_FLAT] + 255) / 256), dim3(256), 0, s, c->ix.ref_string, (const uint8_t *)b_seq.p, d_task, o_flat,
+                           n_shape[SH_FLAT], prm, d_cg, d_md, d_res);
+    int n_defer = 0;
+    if (n_shape[SH_RING]) {                                      // tasks whose first try asked for a wider band: their later tries in the ROW kernel
+        if ((rc = bm2_check(hipMemcpyAsync(&n_defer, d_defer, 4, hipMemcpyDeviceToHost, s), "D2H deferred"))) return rc;
+        if ((rc = bm2_check(hipStreamSynchronize(s), "k_gen_cigar"))) return rc;
+        if (n_defer > 0)
+            hipLaunchKernelGGL(k_gen_cigar<CG_ROW>, dim3((n_defer + 63) / 64), dim3(64), lds_row, s, c->ix.ref_string, (const uint8_t *)b_seq.p, d_task, d_defer + 1,
+                               n_defer, prm, d_z, d_eh, d_cg, d_md, d_res, qmax, 1, (int *)nullptr, (int *)nullptr);
     }
-    if (n > n_small)
-        hipLaunchKernelGGL(k_gen_cigar<false>, dim3((n - n_small + 63) / 64), dim3(64), 0, s, c->ix.ref_string, (const uint8_t *)b_seq.p, d_task,
-                           d_order + n_small, n - n_small, prm, d_z, d_eh, d_cg, d_md, d_res, 0);
     if ((rc = bm2_check(hipGetLastError(), "k_gen_cigar launch"))) return rc;
-    if (prof.on) { (void)hipStreamSynchronize(s); prof.mark("H2D + kernel"); }
+    if (prof.on) {
+        (void)hipStreamSynchronize(s);
+        fprintf(stderr, "[tail] gen_cigar_dev  tasks by shape: ring %d (%d of them deferred to a wider band), row %d, global %d, flat %d\n", n_shape[SH_RING], n_defer,
+                n_shape[SH_ROW], n_shape[SH_GLOBAL], n_shape[SH_FLAT]);
+        prof.mark("H2D + kernel");
+    }
     // dense output: sizes -> offsets (scan) -> gather, all on the device; then one small copy back
     hipLaunchKernelGGL(k_cigar_sizes, dim3((n + 255) / 256), dim3(256), 0, s, n, d_res, d_nops, d_nmd);
     DevBuf scan_tmp;                                            // (scratch of the scans; small)

@@ -118,6 +118,41 @@ def test_device_gen_cigar_equals_host(gpu_ctx_factory, tmp_path, kw):
     assert not bad, "%d of %d differ; first: task %d %s host %s device %s" % (len(bad), len(tasks), bad[0], tasks[bad[0]][1:], exp[bad[0]], got[bad[0]])
 
 
+def test_cigar_retry_loop_beyond_the_first_band(gpu_ctx_factory, tmp_path, capfd):
+    # mem_reg2aln's retry loop (bwamem.cpp:1748-1766) on the device: the RING kernel runs a task's first try only and hands a task that asks
+    # for a wider band to the ROW kernel.  Real hits hardly ever ask; hits whose truesc is raised by hand do (the first band is inferred
+    # from truesc, and the alignment's score stays below it): the device text must equal the host twin's (cigar_with_retries).
+    import os
+    import test_sam_tail as T
+    from helpers import oracle_finish_regs
+    from tools import oracle, refio
+    fa, reads = T._case(tmp_path, 43, 1500)
+    enc, off, ln = refio.pack_reads(reads)
+    ix = oracle.Index(fa)
+    try:
+        exp = ix.run(enc, off, ln, oracle.default_opt())
+    finally:
+        ix.close()
+    opt = bm2.default_opt()
+    regs, reg_off = T._prg_to_regs(exp["REGPRG"], len(ln))
+    aln, aln_off = oracle_finish_regs(fa, enc, off, ln, opt, regs, reg_off)
+    aln = aln.copy()
+    aln["truesc"] += 14                                             # every alignment now looks 14 short of its hit's score
+    names = ["q%d" % i for i in range(len(reads))]
+    quals = [b"I" * len(r) for r in reads]
+    host = bm2.sam_se(fa, enc, off, ln, opt, aln, aln_off, names, quals, None, None)
+    os.environ["BM2_TAIL_PROF"] = "1"
+    try:
+        dev = bm2.sam_se(fa, enc, off, ln, opt, aln, aln_off, names, quals, None, None, ctx=gpu_ctx_factory(fa))
+    finally:
+        del os.environ["BM2_TAIL_PROF"]
+    assert host == dev, T._diff(host, dev)
+    err = capfd.readouterr().err
+    import re
+    m = re.search(r"ring (\d+) \((\d+) of them deferred", err)
+    assert m and int(m.group(2)) > 50, err[-600:]                  # the hand-over really happened
+
+
 def test_s1_batch_resident_between_runs(gpu_ctx_factory):
     # bm2_bsw_upload / bm2_bsw_run / bm2_bsw_download (what `bench.py --workload bsw` times): the results of bm2_bsw, unchanged by a second
     # run over the resident batch, the kernel's own cell counter, and bench.py's synthetic extension tasks against the oracle
