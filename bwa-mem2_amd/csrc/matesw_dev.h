@@ -21,6 +21,20 @@ static BM2_DEV bool row_any(bool p) {                           // p on any lane
 }
 static BM2_DEV int row_xor(int v, int m) { return __shfl_xor(v, m, 16); }
 static BM2_DEV int row_first(int v) { return __shfl(v, 0, 16); }
+// the maximum over the row, in every lane of it: four rotations of the 16-lane DPP row (row_ror:8, 4, 2, 1) -- one VALU instruction each,
+// where a butterfly of __shfl_xor costs a trip through the LDS crossbar per step (this runs once per target row of every task)
+#define BM2_HAVE_ROW_MAX 1
+template <int N> static BM2_DEV int row_ror(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x120 + N, 0xf, 0xf, false); }
+static BM2_DEV int row_max(int v) {
+    int o = row_ror<8>(v); v = v > o ? v : o;
+    o = row_ror<4>(v); v = v > o ? v : o;
+    o = row_ror<2>(v); v = v > o ? v : o;
+    o = row_ror<1>(v); v = v > o ? v : o;
+    return v;
+}
+#endif
+#ifndef BM2_HAVE_ROW_MAX                                          /* (the emulator: from the butterfly it already has) */
+static BM2_DEV int row_max(int v) { for (int m = 8; m >= 1; m >>= 1) { const int o = row_xor(v, m); v = v > o ? v : o; } return v; }
 #endif
 
 enum { KSW_XBYTE = 0x10000, KSW_XSTOP = 0x20000, KSW_XSUBO = 0x40000, KSW_XSTART = 0x80000 };
@@ -55,8 +69,11 @@ static BM2_DEV KswRes ksw_pass(bool rev, const uint8_t *__restrict__ q, int qlen
         L[h0o + j * 16 + k] = 0; L[h1o + j * 16 + k] = 0; L[eo + j * 16 + k] = 0; L[hmo + j * 16 + k] = 0;
     }
     int te = -1, gmax = 0, nb = 0, last_sc = 0, last_pos = -2;
+    auto target = [&](int i) -> int { return rev ? (i <= te0 ? t[te0 - i] : t[i]) : t[i]; };
+    int tb_next = tlen > 0 ? target(0) : 0;
     for (int i = 0; i < tlen; ++i) {
-        const int tb = rev ? (i <= te0 ? t[te0 - i] : t[i]) : t[i];
+        const int tb = tb_next;                                  // (requested a row ahead: the row's profile address hangs on it)
+        if (i + 1 < tlen) tb_next = target(i + 1);
         const int16_t *S = prof + tb * slen * 16 + k;
         int h = row_shr1((int)L[h0o + (slen - 1) * 16 + k]), f = 0, mx = 0;
         for (int j = 0; j < slen; ++j) {
@@ -82,8 +99,7 @@ static BM2_DEV KswRes ksw_pass(bool rev, const uint8_t *__restrict__ q, int qlen
             }
         }
         if (!on) mx = 0;
-        for (int m = 8; m >= 1; m >>= 1) mx = imx(mx, row_xor(mx, m));
-        const int imax = mx;
+        const int imax = row_max(mx);
         if (imax >= minsc) {                                     // the list of local maxima for the second-best score, ksw.cpp:179-188
             if (nb == 0 || last_pos + 1 != i) { ++nb; last_sc = imax; last_pos = i; if (k == 0) blist[nb - 1] = (unsigned long long)imax << 32 | (unsigned)i; }
             else if (last_sc < imax) { last_sc = imax; last_pos = i; if (k == 0) blist[nb - 1] = (unsigned long long)imax << 32 | (unsigned)i; }
