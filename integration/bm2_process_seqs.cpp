@@ -7,12 +7,16 @@
 // `bwa-mem2.bm2 mem ...` -- the reference's CLI, option parser, FASTQ reader (kseq), chunking, @HD/@SQ/@PG header and writer --
 // aligns on the GPU.  Nothing of the reference is modified or copied; its headers are included from where they lie.
 //
-// What happens to a chunk here: bases -> 2-bit codes (bwamem.cpp:992-1000), bm2_batch_upload / run (mem_kernel1_core +
-// mem_kernel2_core up to :1152) / finish (mem_sort_dedup_patch), bm2_batch_download_alnregs, then bm2_sam_pe_dev / bm2_sam_se_dev
-// (mem_pestat + worker_sam with the rescue and CIGAR alignments as device batches).  The index is NOT loaded twice: the
+// What happens to a chunk here: bases -> 2-bit codes (bwamem.cpp:992-1000) on opt->n_threads host threads, then bm2_chunk_hits_sharded --
+// the chunk cut at multiples of 512 reads over every visible GPU (BM2_DEVICES=n caps the number, BM2_DEVICE picks the first), each part
+// through bm2_batch_upload / run (mem_kernel1_core + mem_kernel2_core up to :1152) / finish (mem_sort_dedup_patch) on its GPU's replica,
+// the hits gathered in read order -- then ONE bm2_sam_pe_dev / bm2_sam_se_dev over the whole chunk (mem_pestat is chunk-wide; the rescue
+// and CIGAR alignments run as device batches on the first GPU), so the text does not depend on the number of GPUs.  The index is NOT loaded twice: the
 // descriptor points at the arrays FMI_search::load_index and main_mem already hold (FMI_search keeps them private; a maintainer
 // would add accessors -- this file opens the class with the preprocessor instead, to leave the reference's sources alone).
+#include <atomic>
 #include <mutex>
+#include <thread>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -31,7 +35,7 @@ extern unsigned char nst_nt4_table[256];            // bntseq.cpp:38-55
 
 namespace {
 struct Gpu {
-    bm2_ctx *ctx = nullptr;
+    std::vector<bm2_ctx *> ctx;                      // one per GPU, each with its index replica
     bm2_index_desc desc;
     std::vector<int64_t> ann_offset; std::vector<int32_t> ann_len, ann_is_alt; std::vector<const char *> ann_name, ann_anno;
     std::mutex mu;
@@ -55,16 +59,23 @@ void attach(const worker_t &w) {                    // once: the loaded index as
     }
     g.desc.ann_offset = g.ann_offset.data(); g.desc.ann_len = g.ann_len.data(); g.desc.ann_is_alt = g.ann_is_alt.data();
     g.desc.ann_name = g.ann_name.data(); g.desc.ann_anno = g.ann_anno.data();
-    const char *dev = getenv("BM2_DEVICE");
-    g.ctx = bm2_create(dev ? atoi(dev) : 0, &g.desc);
-    if (!g.ctx) die("bm2_create");
-    fprintf(stderr, "[bm2] index replica on the GPU (%ld bases); seed -> chain -> extend -> pair runs in libbm2\n", (long)bns->l_pac);
+    const char *dev = getenv("BM2_DEVICE"), *cap = getenv("BM2_DEVICES");
+    const int first = dev ? atoi(dev) : 0, visible = bm2_device_count();
+    int n_gpu = visible - first;
+    if (cap && atoi(cap) > 0 && atoi(cap) < n_gpu) n_gpu = atoi(cap);
+    if (n_gpu < 1) n_gpu = 1;
+    g.ctx.assign((size_t)n_gpu, nullptr);
+    std::vector<std::thread> up;                                 // the replicas go up side by side
+    for (int i = 0; i < n_gpu; i++) up.emplace_back([i, first]() { g.ctx[(size_t)i] = bm2_create(first + i, &g.desc); });
+    for (auto &t : up) t.join();
+    for (int i = 0; i < n_gpu; i++) if (!g.ctx[(size_t)i]) die("bm2_create");
+    fprintf(stderr, "[bm2] index replica on %d GPU(s) (%ld bases); seed -> chain -> extend -> pair runs in libbm2\n", n_gpu, (long)bns->l_pac);
 }
 }  // namespace
 
 void mem_process_seqs(mem_opt_t *opt, int64_t n_processed, int n, bseq1_t *seqs, const mem_pestat_t *pes0, worker_t &w) {
     std::lock_guard<std::mutex> lock(g.mu);
-    if (!g.ctx) attach(w);
+    if (g.ctx.empty()) attach(w);
     const double t0 = realtime();
     // ---- options: mem_opt_t -> the two structs of include/bm2.h (same names, same meaning)
     bm2_opt o; bm2_opt_init(&o);
@@ -85,34 +96,48 @@ void mem_process_seqs(mem_opt_t *opt, int64_t n_processed, int n, bseq1_t *seqs,
     for (int i = 0; i < n; i++) { off[(size_t)i] = nb; len[(size_t)i] = seqs[i].l_seq; nb += seqs[i].l_seq; }
     std::vector<uint8_t> enc((size_t)nb + 1);
     std::vector<const char *> name((size_t)n + 1), comment((size_t)n + 1), qual((size_t)n + 1);
-    for (int i = 0; i < n; i++) {
-        uint8_t *d = enc.data() + off[(size_t)i];
-        const char *s = seqs[i].seq;
-        for (int k = 0; k < seqs[i].l_seq; k++) d[k] = (unsigned char)s[k] < 4 ? (uint8_t)s[k] : nst_nt4_table[(unsigned char)s[k]];
-        name[(size_t)i] = seqs[i].name; comment[(size_t)i] = seqs[i].comment; qual[(size_t)i] = seqs[i].qual;
-        seqs[i].sam = nullptr;
+    {
+        int nt = opt->n_threads > 0 ? opt->n_threads : 1;
+        if (nt > n / 4096 + 1) nt = n / 4096 + 1;
+        std::atomic<int> next(0);
+        auto convert = [&]() {
+            for (int lo; (lo = next.fetch_add(4096)) < n;)
+                for (int i = lo; i < n && i < lo + 4096; i++) {
+                    uint8_t *d = enc.data() + off[(size_t)i];
+                    const char *s = seqs[i].seq;
+                    for (int k = 0; k < seqs[i].l_seq; k++) d[k] = (unsigned char)s[k] < 4 ? (uint8_t)s[k] : nst_nt4_table[(unsigned char)s[k]];
+                    name[(size_t)i] = seqs[i].name; comment[(size_t)i] = seqs[i].comment; qual[(size_t)i] = seqs[i].qual;
+                    seqs[i].sam = nullptr;
+                }
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < nt; t++) th.emplace_back(convert);
+        convert();
+        for (auto &t : th) t.join();
     }
     bm2_reads reads = { n, enc.data(), off.data(), len.data() };
     bm2_read_text txt = { name.data(), comment.data(), qual.data() };
-    // ---- device: mem_kernel1_core + mem_kernel2_core, then the hits worker_sam receives
-    if (bm2_batch_upload(g.ctx, &reads) || bm2_batch_run(g.ctx, &o) || bm2_batch_finish(g.ctx, &o)) die("device stage");
+    // ---- device: mem_kernel1_core + mem_kernel2_core over the chunk's parts, then the hits worker_sam receives, in read order
     std::vector<int64_t> aln_off((size_t)n + 1);
     int64_t n_aln = 0;
-    std::vector<bm2_alnreg_t> aln(1);
-    int rc = bm2_batch_download_alnregs(g.ctx, aln.data(), 0, aln_off.data(), &n_aln);
-    if (rc == BM2_ECAP || rc == BM2_OK) { aln.resize((size_t)n_aln + 1); rc = bm2_batch_download_alnregs(g.ctx, aln.data(), n_aln + 1, aln_off.data(), &n_aln); }
-    if (rc) die("bm2_batch_download_alnregs");
+    std::vector<bm2_alnreg_t> aln((size_t)(4 * (int64_t)n + 1024));
+    int rc = bm2_chunk_hits_sharded(g.ctx.data(), (int)g.ctx.size(), &reads, &o, aln.data(), (int64_t)aln.size(), aln_off.data(), &n_aln);
+    if (rc == BM2_ECAP) { aln.resize((size_t)n_aln + 1); rc = bm2_chunk_hits_sharded(g.ctx.data(), (int)g.ctx.size(), &reads, &o, aln.data(), (int64_t)aln.size(), aln_off.data(), &n_aln); }
+    if (rc) die("device stage");
     // ---- pairing / SAM text: mem_pestat + worker_sam
     int64_t cap = 3 * (nb + 200 * (int64_t)n) + (1 << 20), need = 0;
     char *text = nullptr;
     bm2_pestat pin[4];
     if (pes0) for (int d = 0; d < 4; d++) { pin[d].low = pes0[d].low; pin[d].high = pes0[d].high; pin[d].failed = pes0[d].failed; pin[d].pad = 0; pin[d].avg = pes0[d].avg; pin[d].std = pes0[d].std; }
-    for (;;) {
+    const bool pe = (opt->flag & MEM_F_PE) != 0;
+    for (int attempt = 0;; ++attempt) {
         text = (char *)realloc(text, (size_t)cap + 1);
         if (!text) { fprintf(stderr, "[bm2] out of memory\n"); exit(EXIT_FAILURE); }
-        std::vector<bm2_alnreg_t> a2(aln);          // (the single-end tail reorders the hits in place: every attempt gets fresh ones)
-        rc = (opt->flag & MEM_F_PE) ? bm2_sam_pe_dev(g.ctx, &g.desc, &o, &so, &reads, &txt, a2.data(), aln_off.data(), n_processed, pes0 ? pin : nullptr, nullptr, text, cap, &need)
-                                    : bm2_sam_se_dev(g.ctx, &g.desc, &o, &so, &reads, &txt, a2.data(), aln_off.data(), n_processed, text, cap, &need);
+        // (the single-end tail reorders the hits in place: should the text not fit -- the capacity above is generous, so hardly ever -- the
+        //  second attempt fetches the hits again instead of every chunk paying for a spare copy)
+        if (attempt > 0 && !pe && bm2_chunk_hits_sharded(g.ctx.data(), (int)g.ctx.size(), &reads, &o, aln.data(), (int64_t)aln.size(), aln_off.data(), &n_aln)) die("device stage");
+        rc = pe ? bm2_sam_pe_dev(g.ctx[0], &g.desc, &o, &so, &reads, &txt, aln.data(), aln_off.data(), n_processed, pes0 ? pin : nullptr, nullptr, text, cap, &need)
+                : bm2_sam_se_dev(g.ctx[0], &g.desc, &o, &so, &reads, &txt, aln.data(), aln_off.data(), n_processed, text, cap, &need);
         if (rc != BM2_ECAP) break;
         cap = need + 16;
     }
