@@ -303,6 +303,9 @@ def end_to_end(ctx, bm2, texts, opt, paired, n_threads, n_tail=None, limit_s=Non
     work = list(texts[:n_warm]) + list(texts)                    # (warm-up chunks are the first timed ones again: another pass)
     tails = [bm2.Context(share=ctx) for _ in range(n_tail)]
     devs = [ctx] + [bm2.Context(share=ctx) for _ in range(n_dev - 1)]
+    if os.environ.get("BM2_E2E_TAIL_PRIO", "1") != "0" and hasattr(tails[0], "set_stream_priority"):
+        for c in tails:                                           # the tail's short batches go first: their chunk leaves the pipeline sooner
+            c.set_stream_priority(1)
     # the stages' thread counts add up to the CPUs the process may use: beyond that the threads do not run in parallel, they get the process
     # throttled (measured on the MI355X box: 256 hardware threads visible, quota 16 -- profiles/r03c_cgroup.txt)
     # (the stages do not all compute at once -- a tail worker waits for its device batches, the reader for a free queue slot -- so the
@@ -310,6 +313,8 @@ def end_to_end(ctx, bm2, texts, opt, paired, n_threads, n_tail=None, limit_s=Non
     n_parse = int(os.environ.get("BM2_E2E_PARSE_THREADS", max(1, min((3 * hw) // 8, 32))))
     so = bm2.default_sam_opt(n_threads=int(os.environ.get("BM2_E2E_TAIL_THREADS", n_threads or max((hw - 1) // n_tail, 1))))
     q_parsed, q_hits = [queue.Queue(maxsize=2) for _ in range(n_dev)], [queue.Queue(maxsize=1) for _ in range(n_tail)]
+    busy, dyn_threads = [0], os.environ.get("BM2_E2E_DYN_THREADS", "1") != "0"
+    last = [None] * n_tail
     free_pins = queue.Queue()
     for _ in range(n_dev + 2 * n_tail):
         free_pins.put([None])
@@ -331,7 +336,8 @@ def end_to_end(ctx, bm2, texts, opt, paired, n_threads, n_tail=None, limit_s=Non
                 if i == n_warm:
                     go.wait()                                     # the warm-up chunks have left the pipeline; the clock runs from here
                     n_before = 0
-                t = time.perf_counter(); ch = bm2.FastqChunk(t1, t2, n_parse); add("parse", time.perf_counter() - t)    # a memory-bound scan: a few dozen threads saturate it
+                # (a memory-bound scan.  The first chunk of a run has the host to itself: it is parsed on every CPU)
+                t = time.perf_counter(); ch = bm2.FastqChunk(t1, t2, hw if i in (0, n_warm) else n_parse); add("parse", time.perf_counter() - t)
                 q_parsed[i % n_dev].put((i, ch, n_before))
                 n_before += ch.n_reads
         except Exception as e:                                    # noqa
@@ -379,10 +385,20 @@ def end_to_end(ctx, bm2, texts, opt, paired, n_threads, n_tail=None, limit_s=Non
                 i, ch, aln, aln_off, n_before, pin = it
                 if buf is None:
                     buf = np.empty(max(1 << 20, int(3 * (int(ch.f.n_bases) + 200 * ch.n_reads))), np.uint8)
+                # threads of this call: the CPUs divided by the tail workers busy right now (all three in the steady state; the last chunks of a
+                # run, with the other workers idle, take the whole host and leave the pipeline sooner)
+                with lock:
+                    busy[0] += 1
+                    mine = max(so.n_threads, hw // busy[0]) if dyn_threads else so.n_threads
                 t = time.perf_counter()
-                txt = tails[k].sam(ch, opt, so, aln, aln_off, n_before, paired, out=buf)
+                try:
+                    txt = tails[k].sam(ch, opt, bm2.default_sam_opt(n_threads=mine), aln, aln_off, n_before, paired, out=buf)
+                finally:
+                    with lock:
+                        busy[0] -= 1
                 add("tail", time.perf_counter() - t)
                 done[i] = (len(txt), ch.n_reads)
+                last[k] = (i, len(txt), n_before, buf)            # (this worker's latest chunk: its text stays in `buf` until the next one)
                 aln = None
                 free_pins.put(pin)
                 ch.close()
@@ -431,12 +447,26 @@ def end_to_end(ctx, bm2, texts, opt, paired, n_threads, n_tail=None, limit_s=Non
         pin = free_pins.get()
         if pin[0] is not None:
             pin[0].close()
+    # the text of the run's LAST chunk (still in its worker's buffer) against the same chunk put through ONE context, stage after stage, on
+    # this thread: the pipeline (several contexts on one replica, worker threads, pinned buffers in rotation) must not change a byte
+    check = None
+    if os.environ.get("BM2_E2E_CHECK", "1") != "0" and any(x is not None for x in last):
+        i, n_txt, n_before, buf = max((x for x in last if x is not None), key=lambda x: x[0])
+        t1, t2 = work[i]
+        ch = bm2.FastqChunk(t1, t2, 0)
+        try:
+            ctx.batch_upload_chunk(ch); ctx.batch_run(opt); ctx.batch_finish(opt)
+            aln, aln_off = ctx.batch_download_alnregs()
+            ref_txt = ctx.sam(ch, opt, bm2.default_sam_opt(n_threads=0), aln, aln_off, n_before, paired)
+            check = {"chunk": int(i - n_warm), "bytes": int(n_txt), "equal_to_serial_run": bool(n_txt == len(ref_txt) and np.array_equal(buf[:n_txt], ref_txt))}
+        finally:
+            ch.close()
     timed = done[n_warm:]
     out_bytes = sum(d[0] for d in timed); n_reads = sum(d[1] for d in timed)
     nch = max(len(texts), 1)
     return {"value": n_reads / dt, "unit": "reads/s", "reads": n_reads, "chunks": len(texts), "warmup_chunks": n_warm, "wall_s": dt, "sam_bytes": out_bytes,
             "host_cpus": hw, "host_threads_visible": os.cpu_count(), "parse_threads": n_parse, "device_workers": n_dev, "tail_workers": n_tail, "threads_per_tail_worker": so.n_threads,
-            "stage_ms_per_chunk": {k: v / nch * 1e3 for k, v in stage.items()},
+            "stage_ms_per_chunk": {k: v / nch * 1e3 for k, v in stage.items()}, "chunk_check": check,
             "scope": "FASTQ text in host memory -> bm2_fastq_parse_mt | H2D -> device pipeline incl. mem_sort_dedup_patch (a19) -> D2H | pairing / "
                      "mate rescue / CIGAR (device batches) / SAM text in host memory; one host thread per stage worker (%d device workers on contexts "
                      "sharing the index replica, %d tail workers), stages of consecutive chunks overlap; the warm-up chunks pass through the same "
@@ -813,6 +843,9 @@ def main():
                 try:
                     out["end_to_end"] = end_to_end(ctx, bm2, texts, opt, True, 0, limit_s=max(60.0, min(420.0, time_left() - 30)), n_dev=attempt_devs)
                     out["end_to_end"]["frac_of_hot_path"] = out["end_to_end"]["value"] / value
+                    if (out["end_to_end"].get("chunk_check") or {}).get("equal_to_serial_run") is False:
+                        log("end-to-end leg: the text of chunk %d differs from the serial run's" % out["end_to_end"]["chunk_check"]["chunk"])
+                        rc = 3
                     break
                 except TimeoutError as e:                                             # a stage is stuck: report, then leave without joining it
                     out["end_to_end"] = {"error": str(e), "device_workers": attempt_devs}

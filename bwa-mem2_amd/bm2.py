@@ -11,7 +11,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbm2.so")
+LIB_PATH = os.environ.get("BM2_LIB") or os.path.join(_HERE, "libbm2.so")      # (BM2_LIB: another build of the same sources, e.g. an A/B variant)
 
 BM2_OK, BM2_ENODEV, BM2_ENOMEM, BM2_EINVAL, BM2_ECAP, BM2_EUNSUP, BM2_EIO = 0, -1, -2, -3, -4, -5, -6
 
@@ -90,7 +90,7 @@ class Stats(C.Structure):
 
 
 EXPORTS = ["bm2_index_load", "bm2_index_free", "bm2_opt_init", "bm2_opt_fill_scmat", "bm2_create", "bm2_create_shared", "bm2_destroy",
-           "bm2_last_error", "bm2_device_count", "bm2_host_cpus", "bm2_host_alloc", "bm2_host_free", "bm2_bsw", "bm2_bsw_upload", "bm2_bsw_run", "bm2_bsw_download", "bm2_smem", "bm2_sal", "bm2_seed_chain_extend",
+           "bm2_last_error", "bm2_device_count", "bm2_set_stream_priority", "bm2_host_cpus", "bm2_host_alloc", "bm2_host_free", "bm2_bsw", "bm2_bsw_upload", "bm2_bsw_run", "bm2_bsw_download", "bm2_smem", "bm2_sal", "bm2_seed_chain_extend",
            "bm2_batch_upload", "bm2_batch_run", "bm2_batch_stats", "bm2_batch_download", "bm2_batch_kernel_ms",
            "bm2_batch_fetch", "bm2_batch_finish", "bm2_batch_download_alnregs", "bm2_finish_regs_dev", "bm2_chunk_hits_sharded", "bm2_index_build", "bm2_sam_opt_init", "bm2_sam_se", "bm2_sam_pe", "bm2_fastq_parse", "bm2_fastq_parse_mt", "bm2_fastq_free", "bm2_ksw_align2", "bm2_ksw_align2_dev", "bm2_sam_pe_dev", "bm2_sam_se_dev", "bm2_sam_cigar_stats", "bm2_gen_cigar", "bm2_gen_cigar_dev", "bm2_sam_header", "bm2_sam_rescue_stats"]
 
@@ -378,6 +378,12 @@ class Context:
         r, keep = _reads_struct(enc, off, ln)
         _chk(lib().bm2_batch_upload(self.h, C.byref(r)), "bm2_batch_upload")
         self._n_reads = len(keep[2])
+
+    def set_stream_priority(self, level):
+        """main stream at the highest (level > 0) / lowest (< 0) / default hardware queue priority"""
+        L = lib()
+        L.bm2_set_stream_priority.argtypes = [C.c_void_p, C.c_int]
+        _chk(L.bm2_set_stream_priority(self.h, level), "bm2_set_stream_priority")
 
     def batch_upload_chunk(self, chunk):
         """H2D of a FastqChunk (its arrays stay in the library's buffers)."""

@@ -238,6 +238,23 @@ extern "C" bm2_ctx *bm2_create_shared(bm2_ctx *parent) {
     return k;
 }
 
+// The context's main stream at a hardware queue priority (level > 0: highest, < 0: lowest, 0: default).  A pipeline that runs the short
+// device batches of the SAM tail (mate rescue, CIGAR) beside the seeding .. extension of the next chunk gives the tail's contexts the
+// higher priority: their workgroups are dispatched first, the chunk they belong to leaves the pipeline sooner.
+extern "C" int bm2_set_stream_priority(bm2_ctx *c, int level) {
+    if (!c) { bm2_set_error("bm2_set_stream_priority: no context"); return BM2_EINVAL; }
+    int rc = bm2_check(hipSetDevice(c->device), "hipSetDevice");
+    if (rc) return rc;
+    int least = 0, greatest = 0;
+    if ((rc = bm2_check(hipDeviceGetStreamPriorityRange(&least, &greatest), "hipDeviceGetStreamPriorityRange"))) return rc;
+    const int prio = level > 0 ? greatest : level < 0 ? least : 0;
+    hipStream_t fresh = nullptr;
+    if ((rc = bm2_check(hipStreamCreateWithPriority(&fresh, hipStreamNonBlocking, prio), "hipStreamCreateWithPriority"))) return rc;
+    if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+    c->stream = fresh;
+    return BM2_OK;
+}
+
 extern "C" void bm2_destroy(bm2_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);

@@ -126,6 +126,9 @@ bm2_ctx *bm2_create(int device, const bm2_index_desc *idx);     /* uploads the i
  * GPU, or split one chunk over several contexts, without another upload.  Valid while the parent lives. */
 bm2_ctx *bm2_create_shared(bm2_ctx *parent);
 void     bm2_destroy(bm2_ctx *c);
+/* the context's main stream at a hardware queue priority (level > 0: highest, < 0: lowest, 0: default): e.g. high for the contexts that
+ * run the short device batches of the SAM tail beside another context's seeding .. extension */
+int      bm2_set_stream_priority(bm2_ctx *c, int level);
 const char *bm2_last_error(void);
 int      bm2_device_count(void);
 /* the CPUs this process can really use: hardware threads it may run on, capped by its cgroup CPU-time quota (a GPU slice of a shared node

@@ -192,6 +192,8 @@ enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2 };
 static inline hipError_t hipStreamCreate(hipStream_t *s) { *s = (hipStream_t)1; return hipSuccess; }
 static inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = (hipStream_t)1; return hipSuccess; }
 static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipDeviceGetStreamPriorityRange(int *l, int *g) { *l = 0; *g = 0; return hipSuccess; }
+static inline hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned, int) { *s = (hipStream_t)1; return hipSuccess; }
 static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = (hipEvent_t)1; return hipSuccess; }
 static inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = (hipEvent_t)1; return hipSuccess; }
 static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
