@@ -286,6 +286,53 @@ def sam_gate(ctx, bm2, fq, ref_sam, opt, paired, tag):
     return res
 
 
+def binding_leg(workdir, prefix, n_chunks=2):
+    """`bwa-mem2.bm2 mem` (the reference's CLI, reader and writer around libbm2) and `bwa-mem2.<isa> mem` on the same FASTQ files, same -t / -K:
+    wall seconds from process start to exit (index load included in both), SAM compared without the @PG line."""
+    import hashlib
+    exe, isa = ref_binary()
+    bm2_exe = os.path.join(ROOT, "oracle", "_ref", "bwa-mem2.bm2")
+    f1 = [os.path.join(workdir, "e2e_%d_1.fq" % i) for i in range(n_chunks)]
+    f2 = [os.path.join(workdir, "e2e_%d_2.fq" % i) for i in range(n_chunks)]
+    if exe is None or not os.path.exists(bm2_exe) or not all(os.path.exists(f) for f in f1 + f2):
+        return {"skipped": "oracle/_ref/bwa-mem2.bm2 or the chunk files are not there"}
+    r1, r2 = os.path.join(workdir, "bind_1.fq"), os.path.join(workdir, "bind_2.fq")
+    for dst, srcs in ((r1, f1), (r2, f2)):
+        with open(dst, "wb") as o:
+            for f in srcs:
+                o.write(open(f, "rb").read())
+                os.remove(f)
+    n_reads = 2 * sum(1 for _ in open(r1, "rb")) // 4
+    threads = host_threads()
+
+    def run(binary, out_sam):
+        t = time.time()
+        p = subprocess.run([binary, "mem", "-t", str(threads), "-K", "150000000", "-o", out_sam, prefix, r1, r2], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+        if p.returncode != 0:
+            raise RuntimeError("%s failed: %s" % (os.path.basename(binary), p.stderr[-400:]))
+        wall = time.time() - t
+        h = hashlib.md5()
+        n = 0
+        with open(out_sam, "rb") as f:
+            for line in f:
+                if not line.startswith(b"@PG"):
+                    h.update(line); n += not line.startswith(b"@")
+        os.remove(out_sam)
+        return wall, h.hexdigest(), n
+
+    w_ref, md_ref, n_ref = run(exe, os.path.join(workdir, "bind_ref.sam"))
+    w_bm2, md_bm2, n_bm2 = run(bm2_exe, os.path.join(workdir, "bind_bm2.sam"))
+    for f in (r1, r2):
+        os.remove(f)
+    res = {"reads": n_reads, "threads": threads, "chunk_bases": 150000000, "reference": "bwa-mem2.%s mem" % isa, "reference_wall_s": w_ref, "bm2_wall_s": w_bm2,
+           "speedup": w_ref / w_bm2 if w_bm2 > 0 else None, "reads_per_s_bm2": n_reads / w_bm2, "reads_per_s_reference": n_reads / w_ref,
+           "sam_records": n_ref, "sam_equal": bool(md_ref == md_bm2 and n_ref == n_bm2),
+           "scope": "process start to exit, index load (and the replica's upload) included in both; the binding is single-chunk-at-a-time "
+                    "(mem_process_seqs is called per chunk; the reference's reader and writer run around it)"}
+    log("binding: %d reads, reference %.1f s, bwa-mem2.bm2 %.1f s (x%.1f), SAM equal = %s" % (n_reads, w_ref, w_bm2, w_ref / w_bm2, res["sam_equal"]))
+    return res
+
+
 def end_to_end(ctx, bm2, texts, opt, paired, n_threads, n_tail=None, limit_s=None, n_dev=None, n_warm=None):
     """FASTQ text -> SAM text over the chunks `texts` = [(bytes1, bytes2 | None)] as a pipeline of host threads: the reader
     (bm2_fastq_parse_mt), n_dev device workers (H2D, seeding .. extension, mem_sort_dedup_patch, D2H; each with a context of its own on
@@ -586,6 +633,7 @@ def main():
     ap.add_argument("--parity-reads", type=int, default=int(os.environ.get("BM2_BENCH_PARITY_READS", 204800)),
                     help="reads of the timed chunk's prefix that go through refdump (REGPRG / REGFIN byte for byte) and `bwa-mem2 mem` (SAM)")
     ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--no-binding", action="store_true", help="skip the drop-in timing (`bwa-mem2.bm2 mem` beside `bwa-mem2.<isa> mem` on the first two end-to-end chunks' files)")
     ap.add_argument("--e2e-chunks", type=int, default=int(os.environ.get("BM2_BENCH_E2E_CHUNKS", 10)))
     ap.add_argument("--strong", action="store_true",
                     help="strong scaling: ONE chunk of --reads reads is cut at multiples of 512 over the ranks (SURVEY.md 8(e)) instead of one chunk per rank")
@@ -829,7 +877,8 @@ def main():
                     if pr.wait(timeout=max(30.0, time_left() - 120)) != 0:
                         raise RuntimeError("generator exit code %d" % pr.returncode)
                     texts.append((open(fa, "rb").read(), open(fb, "rb").read()))
-                    os.remove(fa); os.remove(fb)
+                    if len(texts) > 2 or a.no_binding:               # (the first two chunks' files stay for the drop-in timing below)
+                        os.remove(fa); os.remove(fb)
                 except Exception as e:                                                    # noqa  (the leg runs on the chunks that exist)
                     gen_failed += 1
                     log("end-to-end input: a chunk was not generated: %s" % e)
@@ -858,6 +907,13 @@ def main():
                     time.sleep(2.0)                                                   # (calls in flight on the contexts finish before the next attempt)
         else:
             out["end_to_end"] = None
+        # the literal drop-in: the reference's own binary with libbm2 linked in place of mem_process_seqs (oracle/_ref/bwa-mem2.bm2), from FASTQ
+        # files to a SAM file, beside the unmodified binary on the same files and threads
+        if world == 1 and not ont and not a.no_e2e and not a.no_binding and not hung and time_left() > 240:
+            try:
+                out["binding"] = binding_leg(a.workdir, prefix)
+            except Exception as e:                                                    # noqa
+                out["binding"] = {"error": str(e)}
         print(json.dumps(out), flush=True)
     if hung:                                                     # stage threads of a failed end-to-end attempt may be left: do not join them
         sys.stdout.flush(); sys.stderr.flush()

@@ -69,6 +69,12 @@ struct DevTask {
 };
 
 static __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
+// max(a - b, 0) for a, b >= 0 in ONE VALU instruction (v_sub_u32 ... clamp) instead of a subtraction and a maximum
+#if defined(__HIP_DEVICE_COMPILE__)
+static __device__ __forceinline__ int isub0(int a, int b) { return (int)__builtin_elementwise_sub_sat((unsigned)a, (unsigned)b); }
+#else
+static __device__ __forceinline__ int isub0(int a, int b) { return a > b ? a - b : 0; }
+#endif
 static __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
 static __device__ __forceinline__ int64_t lmax(int64_t a, int64_t b) { return a > b ? a : b; }
 static __device__ __forceinline__ int64_t lmin(int64_t a, int64_t b) { return a < b ? a : b; }

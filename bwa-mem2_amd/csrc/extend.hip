@@ -168,8 +168,8 @@ static __device__ void lane_dp(bool run, int qlen, int tlen, int w, int h0, cons
                 h = h > f ? h : f;
                 mj = m > h ? mj : j;
                 m = m > h ? m : h;
-                const int en = imax(imax(e - e_del, M - oe_del), 0);
-                f = imax(imax(f - e_ins, M - oe_ins), 0);
+                const int en = imax(isub0(e, e_del), M - oe_del);
+                f = imax(isub0(f, e_ins), M - oe_ins);
                 const uint32_t nw = (uint32_t)h1 | ((uint32_t)en << 16);
                 EH[j * 64 + lane] = nw;
                 if (nw) { lnz = j; if (fnz < 0) fnz = j; }
@@ -271,8 +271,8 @@ static __device__ void lane_dp8(bool run, int qlen, int tlen, int w, int h0, con
                         h = h > f ? h : f;
                         const unsigned kj = (unsigned)h << 8 | (unsigned)j;
                         key = key > kj ? key : kj;
-                        const int en = imax(imax(e - e_del, M - oe_del), 0);
-                        f = imax(imax(f - e_ins, M - oe_ins), 0);
+                        const int en = imax(isub0(e, e_del), M - oe_del);     // = max(e - e_del, M - oe_del, 0): e, f >= 0; a negative M loses anyway
+                        f = imax(isub0(f, e_ins), M - oe_ins);
                         const uint32_t nw = (uint32_t)h1 | ((uint32_t)en << 8);
                         word = (word & ~(0xffffu << (16 * u))) | nw << (16 * u);
                         const int jj = nw ? j : -1;

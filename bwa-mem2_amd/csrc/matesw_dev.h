@@ -45,6 +45,13 @@ struct KswRes { int score, te, qe, score2, te2; };
 
 static BM2_DEV int imx(int a, int b) { return a > b ? a : b; }
 static BM2_DEV int imn(int a, int b) { return a < b ? a : b; }
+// max(a - b, 0) for a, b >= 0: the saturating subtractions of the SSE2 kernels (psubusb / psubusw).  On the device ONE instruction
+// (v_sub_u32 ... clamp) instead of a subtraction and a maximum: the kernel is bound by VALU issue (profiles/r03h_tail_kernels_pmc_sq.md)
+#if defined(__HIP_DEVICE_COMPILE__)
+static BM2_DEV int sub0(int a, int b) { return (int)__builtin_elementwise_sub_sat((unsigned)a, (unsigned)b); }
+#else
+static BM2_DEV int sub0(int a, int b) { return a > b ? a - b : 0; }
+#endif
 
 // One pass of the striped kernel over one task, executed by the 16 lanes of a row (lanes k >= P idle along).
 //   rev = false: query[0, qlen) against target[0, tlen)
@@ -78,14 +85,14 @@ static BM2_DEV KswRes ksw_pass(bool rev, const uint8_t *__restrict__ q, int qlen
         int h = row_shr1((int)L[h0o + (slen - 1) * 16 + k]), f = 0, mx = 0;
         for (int j = 0; j < slen; ++j) {
             const int s = S[j * 16];
-            if (U8) h = imx(imn(h + s, 255) - shift, 0);                                   // adds_epu8, subs_epu8
+            if (U8) h = sub0(imn(h + s, 255), shift);                                      // adds_epu8, subs_epu8
             else h = imx(imn(h + s, 32767), -32768);                                       // adds_epi16
             const int e = L[eo + j * 16 + k];
             h = imx(imx(h, e), f);
             mx = imx(mx, h);
             L[h1o + j * 16 + k] = (uint16_t)h;
-            L[eo + j * 16 + k] = (uint16_t)imx(imx(e - ed, 0), imx(h - oe_del, 0));
-            f = imx(imx(f - ei, 0), imx(h - oe_ins, 0));
+            L[eo + j * 16 + k] = (uint16_t)imx(sub0(e, ed), sub0(h, oe_del));
+            f = imx(sub0(f, ei), sub0(h, oe_ins));
             h = L[h0o + j * 16 + k];
         }
         bool done = false;                                       // lazy F: 16 rounds at most, as in both kernels
@@ -94,8 +101,8 @@ static BM2_DEV KswRes ksw_pass(bool rev, const uint8_t *__restrict__ q, int qlen
             for (int j = 0; j < slen; ++j) {
                 const int hv = imx((int)L[h1o + j * 16 + k], f);
                 L[h1o + j * 16 + k] = (uint16_t)hv;
-                f = imx(f - ei, 0);
-                if (!row_any(on && f > imx(hv - oe_ins, 0))) { done = true; break; }
+                f = sub0(f, ei);
+                if (!row_any(on && f > sub0(hv, oe_ins))) { done = true; break; }
             }
         }
         if (!on) mx = 0;

@@ -56,11 +56,8 @@ static __device__ __forceinline__ void coop_issue(const DevIndex &ix, int64_t k,
     e1 = make_ulonglong2(0, 0); e2 = e1;
     if (qbcast32<T>(want)) {         // (a quad whose lane T has nothing pending loads nothing: idle lanes must not all hit one line)
         e1 = ((const ulonglong2 *)&ix.cp_occ[sp >> 6])[sub];
-#ifdef BM2_BWD_SAME_BLOCK
-        if ((sp >> 6) == (ep >> 6)) e2 = e1;                     // both ends of the interval in one CP_OCC block (4 of 10 calls): one request
-        else
-#endif
-        e2 = ((const ulonglong2 *)&ix.cp_occ[ep >> 6])[sub];
+        e2 = ((const ulonglong2 *)&ix.cp_occ[ep >> 6])[sub];     // (also when both ends lie in one block, 4 of 10 calls: skipping the second request
+                                                                 //  under a per-quad branch measured 18 % SLOWER, profiles/r03i_bench.json vs bench_sb)
     }
 }
 template <int T>
