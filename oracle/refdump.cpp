@@ -20,6 +20,7 @@
 // Blocks are BATCH_SIZE(512) reads, exactly as kt_for hands them out (kthread.cpp:53-78).
 //
 // Output: a sequence of sections  [8-byte tag][int64 nbytes][payload]  (little endian).
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -36,6 +37,7 @@
 #include "ksw.h"
 #include "FMI_search.h"
 #include "fastmap.h"
+#include "bandedSWA.h"
 
 uint64_t proc_freq, tprof[LIM_R][LIM_C], prof[LIM_R];
 
@@ -220,6 +222,73 @@ int main(int argc, char **argv) {
         fclose(fi); fclose(fo);
         return 0;
     }
+    if (argc - optind == 5 && !strcmp(argv[optind], "bsw")) {
+        // known answers for the banded extension (seam S1): every line of <pairs.txt> is "<h0> <query> <target>" (ACGTN text); the pairs are
+        // filed under the reference's three kernels exactly as sortPairsLenExt files them (bwamem.cpp:1924-1950) and run through
+        // BandedPairWiseSW::getScores8 / getScores16 / scalarBandedSWAWrapper of THIS build's ISA with band <w> and end bonus <end_bonus>.
+        // out = 8 int32 per line: score, qle, tle, gtle, gscore, max_off, class (8 / 16 / 32), and 1 if the pair's result in INPUT order differs
+        // from its result in the order the reference runs a class in -- sorted by target length, sortPairsLen (bwamem.cpp:2025-2064, called
+        // before every getScores8 / getScores16): the vector kernels work on SIMD-wide groups whose row / column counts are the group's
+        // maxima, and a pair grouped with much longer ones is not always left alone.  The sorted run is the answer.
+        const int w = atoi(argv[optind + 1]), end_bonus = atoi(argv[optind + 2]);
+        FILE *fi = fopen(argv[optind + 3], "r"), *fo = fopen(argv[optind + 4], "wb");
+        if (!fi || !fo) { fprintf(stderr, "cannot open the bsw files\n"); return 1; }
+        std::vector<SeqPair> all; std::vector<uint8_t> ref, qer;
+        char *line = 0; size_t cap = 0; ssize_t len;
+        while ((len = getline(&line, &cap, fi)) > 0) {
+            int h0 = 0, pos = 0;
+            if (sscanf(line, "%d %n", &h0, &pos) < 1) continue;
+            SeqPair sp; memset(&sp, 0, sizeof sp);
+            sp.idq = (int32_t)qer.size(); sp.idr = (int32_t)ref.size(); sp.h0 = h0; sp.id = (int32_t)all.size();
+            std::vector<uint8_t> *cur = &qer;
+            for (char *c = line + pos; *c && *c != '\n'; ++c) {
+                if (*c == ' ') { cur = &ref; continue; }
+                cur->push_back(*c == 'A' ? 0 : *c == 'C' ? 1 : *c == 'G' ? 2 : *c == 'T' ? 3 : 4);
+            }
+            sp.len2 = (int32_t)qer.size() - sp.idq; sp.len1 = (int32_t)ref.size() - sp.idr;
+            all.push_back(sp);
+        }
+        ref.resize(ref.size() + 65536, 0); qer.resize(qer.size() + 65536, 0);        // (the vector kernels gather whole SIMD groups)
+        std::vector<int32_t> cls(all.size());
+        std::vector<SeqPair> by[3];
+        for (size_t i = 0; i < all.size(); i++) {
+            const SeqPair &sp = all[i];
+            const int minval = sp.h0 + (sp.len1 < sp.len2 ? sp.len1 : sp.len2) * opt->a;
+            const int k = (sp.len1 < MAX_SEQ_LEN8 && sp.len2 < MAX_SEQ_LEN8 && minval < MAX_SEQ_LEN8) ? 0 : (sp.len1 < MAX_SEQ_LEN16 && sp.len2 < MAX_SEQ_LEN16 && minval < MAX_SEQ_LEN16) ? 1 : 2;
+            cls[i] = k == 0 ? 8 : k == 1 ? 16 : 32;
+            by[k].push_back(sp);
+        }
+        BandedPairWiseSW bsw(opt->o_del, opt->e_del, opt->o_ins, opt->e_ins, opt->zdrop, end_bonus, opt->mat, opt->a, opt->b, 1);
+        auto run = [&](int k, std::vector<SeqPair> &v) {
+            if (v.empty()) return;
+            const int n = (int)v.size();
+            v.resize(v.size() + 2 * SIMD_WIDTH8);               // (the vector wrappers pad the array to a whole SIMD group in place, bandedSWA.cpp:447-455)
+            if (k == 0) bsw.getScores8(v.data(), ref.data(), qer.data(), n, 1, w);
+            else if (k == 1) bsw.getScores16(v.data(), ref.data(), qer.data(), n, 1, w);
+            else bsw.scalarBandedSWAWrapper(v.data(), ref.data(), qer.data(), n, 1, w);
+            v.resize((size_t)n);
+        };
+        std::vector<int32_t> out(all.size() * 8, 0);
+        long order_dependent = 0;
+        for (int k = 0; k < 3; k++) {
+            std::vector<SeqPair> a = by[k], b = by[k];
+            std::stable_sort(b.begin(), b.end(), [](const SeqPair &x, const SeqPair &y) { return x.len1 < y.len1; });
+            run(k, a); run(k, b);
+            std::vector<SeqPair> unsorted(all.size());
+            for (const SeqPair &sp : a) unsorted[(size_t)sp.id] = sp;
+            for (const SeqPair &sp : b) {
+                const SeqPair &o = unsorted[(size_t)sp.id];
+                const bool dep = sp.score != o.score || sp.qle != o.qle || sp.tle != o.tle || sp.gtle != o.gtle || sp.gscore != o.gscore || sp.max_off != o.max_off;
+                order_dependent += dep;
+                int32_t *r = &out[(size_t)sp.id * 8];
+                r[0] = sp.score; r[1] = sp.qle; r[2] = sp.tle; r[3] = sp.gtle; r[4] = sp.gscore; r[5] = sp.max_off; r[6] = cls[(size_t)sp.id]; r[7] = dep;
+            }
+        }
+        if (order_dependent) fprintf(stderr, "bsw: %ld of %zu pairs give other numbers in input order than in the reference's (target-length) order\n", order_dependent, all.size());
+        fwrite(out.data(), 4, out.size(), fo);
+        fclose(fi); fclose(fo);
+        return 0;
+    }
     if (argc - optind == 4 && !strcmp(argv[optind], "cigar")) {
         // known answers for CIGAR generation: every line of <tasks.txt> is "<w> <rb> <re> <query>" (query = ACGTN text of the
         // aligned part of the read); out per line: int32 score, n_cigar, NM, then n_cigar uint32 ops, then the MD string + NUL
@@ -254,7 +323,8 @@ int main(int argc, char **argv) {
     if (argc - optind < 3) {
         fprintf(stderr, "usage: refdump [mem options] <idx_prefix> <reads.fq|reads.txt> <out.bin>\n"
                         "       refdump [scoring options] cigar <idx_prefix> <tasks.txt> <out.bin>\n"
-                        "       refdump [scoring options] ksw <pairs.txt> <out.bin>\n");
+                        "       refdump [scoring options] ksw <pairs.txt> <out.bin>\n"
+                        "       refdump [scoring options] bsw <w> <end_bonus> <pairs.txt> <out.bin>\n");
         return 1;
     }
     const char *prefix = argv[optind], *reads_fn = argv[optind + 1], *out_fn = argv[optind + 2];
