@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stddef.h>
+#include <condition_variable>
+#include <mutex>
 #include <vector>
 #include "bm2_dev.h"
 
@@ -12,6 +14,17 @@ struct DevBuf {
 };
 
 #define BM2_MAX_TIMERS 24
+
+// The two halves of a chunk's device path lean on different parts of the GPU: seeding .. chaining waits for random HBM lines, extension ..
+// purge keeps the integer VALUs busy.  When a chunk runs as several parts (sub-batches), the gate lets exactly one part be in each half at a
+// time, in part order: part i + 1 seeds while part i extends.
+struct StageGate {
+    std::mutex m; std::condition_variable cv;
+    int turn[2] = { 0, 0 };                                       // next part to enter the front / the back half
+    void reset() { std::lock_guard<std::mutex> l(m); turn[0] = turn[1] = 0; }
+    void enter(int half, int part) { std::unique_lock<std::mutex> l(m); cv.wait(l, [&]() { return turn[half] == part; }); }
+    void leave(int half, int part) { { std::lock_guard<std::mutex> l(m); if (turn[half] == part) turn[half] = part + 1; } cv.notify_all(); }
+};
 
 struct bm2_ctx {
     int device = -1;
@@ -37,6 +50,7 @@ struct bm2_ctx {
     hipEvent_t ev_fork = nullptr, ev_join[12] = {};
     // sub-batch pipelining (pipeline.hip): extra contexts sharing this one's index replica
     std::vector<bm2_ctx *> subs;
+    StageGate gate;                                               // (of the parent: the schedule of its parts)
     bool is_child = false;
     int n_parts = 1;
     std::vector<int> part_first;

@@ -281,8 +281,17 @@ static int run_seeding(bm2_ctx *c, Batch *b, const bm2_opt *opt, bool with_sal) 
     return BM2_OK;
 }
 
-static int batch_run_one(bm2_ctx *c, const bm2_opt *opt) {
+// (gate / part: the chunk runs as several parts and this is part `part` of them -- see StageGate; nullptr: the whole chunk, no schedule)
+struct HalfPass {                   // a part's turn in one half of the path; given up when the half is through -- or, on an error path, by the destructor
+    StageGate *g; int half, part, state = 0;                     // 0 = not yet in, 1 = in, 2 = through
+    HalfPass(StageGate *g_, int half_, int part_) : g(g_), half(half_), part(part_) {}
+    void enter() { if (g && state == 0) { g->enter(half, part); state = 1; } }
+    void leave() { if (g && state == 1) { g->leave(half, part); state = 2; } }
+    ~HalfPass() { enter(); leave(); }                            // (a part that never got in still takes and passes its turn: the parts behind it must not wait for ever)
+};
+static int batch_run_one(bm2_ctx *c, const bm2_opt *opt, StageGate *gate = nullptr, int part = 0) {
     if (!c || !c->batch || !c->batch->uploaded) { bm2_set_error("bm2_batch_run: no batch uploaded"); return BM2_EINVAL; }
+    HalfPass front(gate, 0, part), back(gate, 1, part);
     int rc = check_opt(opt);
     if (rc) return rc;
     if ((rc = bm2_check(hipSetDevice(c->device), "hipSetDevice"))) return rc;
@@ -296,6 +305,7 @@ static int batch_run_one(bm2_ctx *c, const bm2_opt *opt) {
     b->n_out_regs = 0; b->n_fin = -1;
     if ((rc = bm2_reserve(b->out_off, (size_t)(n + 2) * 8))) return rc;
     if (n == 0) { b->ran = true; return bm2_check(hipMemsetAsync(b->out_off.p, 0, 16, s), "memset"); }
+    front.enter();
     if ((rc = run_seeding(c, b, opt, true))) return rc;
     const int64_t n_sa = b->n_sa;
     const ChainParams cp = chain_params(opt);
@@ -368,6 +378,11 @@ static int batch_run_one(bm2_ctx *c, const bm2_opt *opt) {
                                       (DevChain *)b->chn.p, (DevSeed *)b->seeds.p, (int32_t *)b->srt.p, (int32_t *)b->reg_seed.p,
                                       (int32_t *)b->reg_chain.p, (int32_t *)b->n_reg.p))) return rc;
     tick(c, "chain");
+    if (gate) {                                                  // the front half has left the GPU before the next part's seeding is let in
+        if ((rc = bm2_check(hipStreamSynchronize(s), "chaining"))) return rc;
+        front.leave();
+        back.enter();
+    }
     if ((rc = bm2_launch_slot_base(c, n, (const int64_t *)b->read_base.p, (const int32_t *)b->n_reg.p, (int64_t *)b->slot_base.p))) return rc;
     if ((rc = bm2_reserve(b->cursor, (size_t)(n + 1) * 4))) return rc;
     if ((rc = bm2_launch_extend(c, *opt, cp, n, n_sa, (const uint8_t *)b->enc.p, (const int64_t *)b->off.p, (const int32_t *)b->len.p,
@@ -497,8 +512,12 @@ extern "C" int bm2_batch_run(bm2_ctx *c, const bm2_opt *opt) {
     std::vector<int> rcs(c->n_parts, 0);
     std::vector<std::string> msgs(c->n_parts);
     std::vector<std::thread> th;
+    // the parts on their own host threads, streams and workspaces; staggered by the gate (BM2_SUB_STAGGER=0: all at once, the round-2 form,
+    // in which the parts sat in the same stage at the same time and gained nothing from each other)
+    StageGate *gate = bm2_knob("BM2_SUB_STAGGER", 1) ? &c->gate : nullptr;
+    c->gate.reset();
     for (int i = 0; i < c->n_parts; i++)
-        th.emplace_back([&, i]() { rcs[i] = batch_run_one(part_ctx(c, i), opt); if (rcs[i]) msgs[i] = bm2_last_error(); });
+        th.emplace_back([&, i]() { rcs[i] = batch_run_one(part_ctx(c, i), opt, gate, i); if (rcs[i]) msgs[i] = bm2_last_error(); });
     for (auto &t : th) t.join();
     for (int i = 0; i < c->n_parts; i++) if (rcs[i]) { bm2_set_error("part %d: %s", i, msgs[i].c_str()); return rcs[i]; }
     return BM2_OK;
@@ -537,7 +556,8 @@ extern "C" int bm2_batch_download(bm2_ctx *c, bm2_reg_t *regs, int64_t cap, int6
     return BM2_OK;
 }
 
-// per-stage time of the last run: mean over the parts (their stages overlap each other on the device)
+// per-stage time of the last run: SUMMED over the parts (the time the chunk as a whole spent in a stage; where the parts' stages overlap on
+// the device -- see StageGate -- the stages add up to more than the run's wall time)
 extern "C" int bm2_batch_kernel_ms(bm2_ctx *c, float *ms, int32_t cap, int32_t *n_out, const char **names) {
     if (!c || !ms || !n_out) return BM2_EINVAL;
     int rc = batch_kernel_ms_one(c, ms, cap, n_out, names);
@@ -548,7 +568,6 @@ extern "C" int bm2_batch_kernel_ms(bm2_ctx *c, float *ms, int32_t cap, int32_t *
         if ((rc = batch_kernel_ms_one(part_ctx(c, i), t.data(), cap, &n1, nullptr))) return rc;
         for (int k = 0; k < *n_out && k < n1; k++) ms[k] += t[k];
     }
-    for (int k = 0; k < *n_out; k++) ms[k] /= c->n_parts;
     return BM2_OK;
 }
 

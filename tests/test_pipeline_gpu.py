@@ -182,12 +182,16 @@ def test_sub_batch_pipelining_matches_single_part(tmp_path):
         r1, o1, s1 = c1.seed_chain_extend(enc, off, ln, bm2.default_opt())
     finally:
         c1.close()
-    c4 = bm2.Context(0, fa)
+    os.environ["BM2_N_SUB"] = "4"                                 # staggered by the stage gate: part i + 1 seeds while part i extends
     try:
-        r4, o4, s4 = c4.seed_chain_extend(enc, off, ln, bm2.default_opt())
-        kms = c4.batch_kernel_ms()
+        c4 = bm2.Context(0, fa)
+        try:
+            r4, o4, s4 = c4.seed_chain_extend(enc, off, ln, bm2.default_opt())
+            kms = c4.batch_kernel_ms()
+        finally:
+            c4.close()
     finally:
-        c4.close()
+        del os.environ["BM2_N_SUB"]
     assert o1.tobytes() == o4.tobytes() and r1.tobytes() == r4.tobytes()
     assert s1 == s4 and len({n.split(".")[0] for n, _ in kms}) == 5
     ix = oracle.Index(fa)
