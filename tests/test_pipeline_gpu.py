@@ -177,12 +177,12 @@ def test_sub_batch_pipelining_matches_single_part(tmp_path):
     try:
         c1 = bm2.Context(0, fa)
     finally:
-        del os.environ["BM2_N_SUB"]
+        del os.environ["BM2_N_SUB"]; os.environ.pop("BM2_SUB_STAGGER", None)
     try:
         r1, o1, s1 = c1.seed_chain_extend(enc, off, ln, bm2.default_opt())
     finally:
         c1.close()
-    os.environ["BM2_N_SUB"] = "4"                                 # staggered by the stage gate: part i + 1 seeds while part i extends
+    os.environ["BM2_N_SUB"] = "4"; os.environ["BM2_SUB_STAGGER"] = "1"      # staggered by the stage gate: part i + 1 seeds while part i extends
     try:
         c4 = bm2.Context(0, fa)
         try:
@@ -191,7 +191,7 @@ def test_sub_batch_pipelining_matches_single_part(tmp_path):
         finally:
             c4.close()
     finally:
-        del os.environ["BM2_N_SUB"]
+        del os.environ["BM2_N_SUB"]; os.environ.pop("BM2_SUB_STAGGER", None)
     assert o1.tobytes() == o4.tobytes() and r1.tobytes() == r4.tobytes()
     assert s1 == s4 and len({n.split(".")[0] for n, _ in kms}) == 5
     ix = oracle.Index(fa)
