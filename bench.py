@@ -738,7 +738,7 @@ def main():
         dominant = max(stage_ms, key=stage_ms.get) if stage_ms else None
         traffic, pmc_src = None, None                        # HBM bytes per k_bwd launch from the committed PMC passes, same workload only
         ext_pmc = None
-        for fn in ("r02_k_bwd_pmc.json", "r01_k_bwd_pmc.json"):
+        for fn in ("r03_k_bwd_pmc.json", "r02_k_bwd_pmc.json", "r01_k_bwd_pmc.json"):
             try:
                 pm = json.load(open(os.path.join(ROOT, "profiles", fn)))
                 wl = pm["workload"]
@@ -747,10 +747,14 @@ def main():
                     break
             except Exception:
                 pass
-        try:
-            ext_pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_ext_pmc_sq.json")))
-        except Exception:
-            pass
+        ext_src = None
+        for fn in ("r03_ext_pmc_sq.json", "r02_ext_pmc_sq.json"):      # SQ counter passes of the extension stage (tools/pmc_to_profiles.py): the newest committed
+            try:
+                ext_pmc = json.load(open(os.path.join(ROOT, "profiles", fn)))
+                ext_src = "profiles/" + fn
+                break
+            except Exception:
+                pass
         ach_counter = traffic / (bwd_ms * 1e-3) / 1e9 if traffic and bwd_ms > 0 else None
         lines_counter = traffic / 64.0 / (bwd_ms * 1e-3) / 1e9 if traffic and bwd_ms > 0 else None
         wl_name = ("config 5 shape: %d ONT-like reads (mean 10 kb, cap 30 kb, ~10%% error) per GPU per step, `-x ont2d`" % n_reads) if ont else \
@@ -793,8 +797,12 @@ def main():
             "extend_kernel": {"kernel": "k_ext_lanes", "gcups": cells / (ext_ms * 1e-3) / 1e9 if ext_ms > 0 else 0.0,
                               "stage_ms": ext_ms, "cells_per_step": cells,
                               "valu_frac": ext_pmc.get("valu_frac") if ext_pmc else None,
+                              "valu_peak_wave_insts_per_s": ext_pmc.get("valu_peak_wave_insts_per_s") if ext_pmc else None,
+                              "valu_peak_source": ext_pmc.get("valu_peak_source") if ext_pmc else None,
+                              "pmc_stage_ms": ext_pmc.get("extend_stage_ms") if ext_pmc else None,
                               "lds_conflict_frac": ext_pmc.get("lds_conflict_frac") if ext_pmc else None,
-                              "pmc_source": "profiles/r02_ext_pmc_sq.json" if ext_pmc else None},
+                              "pmc_source": ext_src,
+                              "note": "valu_frac / lds_conflict_frac are of the committed counter pass (its own stage time: pmc_stage_ms), the rest is of this run"},
         }
         if world == 1 and not a.no_parity and time_left() < 150:
             out["parity"] = {"skipped": "time budget (%.0f s of %.0f s left)" % (time_left(), a.budget_s)}
