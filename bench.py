@@ -632,6 +632,8 @@ def main():
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--parity-reads", type=int, default=int(os.environ.get("BM2_BENCH_PARITY_READS", 204800)),
                     help="reads of the timed chunk's prefix that go through refdump (REGPRG / REGFIN byte for byte) and `bwa-mem2 mem` (SAM)")
+    ap.add_argument("--resident-chunks", type=int, default=int(os.environ.get("BM2_BENCH_RESIDENT", 4)),
+                    help="distinct chunks the timed steps go round (all resident before the clock starts; capped by --warmup and --steps)")
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--no-binding", action="store_true", help="skip the drop-in timing (`bwa-mem2.bm2 mem` beside `bwa-mem2.<isa> mem` on the first two end-to-end chunks' files)")
     ap.add_argument("--e2e-chunks", type=int, default=int(os.environ.get("BM2_BENCH_E2E_CHUNKS", 10)))
@@ -698,21 +700,53 @@ def main():
         ln = np.full(n_reads, a.read_len, np.int32)
     n_bases = int(np.asarray(ln, np.int64).sum())
     ctx.batch_upload(enc, off, ln)
+    # The timed steps go round SEVERAL distinct chunks, all resident in HBM before the clock starts (each on a context of its own that shares
+    # the index replica): a step does not find the L2 / MALL / TLB state and the learned workspace sizes of the same reads it just aligned.
+    # As many chunks as warm-up steps allow (every chunk runs once untimed: its workspaces are sized by then), at most --resident-chunks.
+    n_res = 1 if (ont or a.strong) else max(1, min(a.resident_chunks, a.warmup, a.steps))
+    run_ctx, res_chunks = [ctx], []
+    if n_res > 1:
+        t = time.time()
+        meta = prefix + ".contigs.npz"
+        procs = []
+        for k in range(1, n_res):
+            fa, fb = os.path.join(a.workdir, "res_r%d_%d_1.fq" % (rank, k)), os.path.join(a.workdir, "res_r%d_%d_2.fq" % (rank, k))
+            procs.append((fa, fb, subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "gen_chunk.py"), meta, str(dist_util.shard_seed(seed, rank) + 7000 + k),
+                                                    str(n_reads // 2), str(a.read_len), fa, fb, "r%d_" % k])))
+        for fa, fb, pr in procs:
+            if pr.wait() != 0:
+                raise SystemExit("resident chunk generator failed")
+            ch = bm2.FastqChunk(open(fa, "rb").read(), open(fb, "rb").read(), 0)
+            os.remove(fa); os.remove(fb)
+            c2 = bm2.Context(share=ctx)
+            c2.batch_upload_chunk(ch)
+            run_ctx.append(c2); res_chunks.append(ch)
+        log("rank %d: %d distinct chunks resident after %.1fs" % (rank, n_res, time.time() - t))
 
-    for _ in range(a.warmup):
-        ctx.batch_run(opt)
+    for i in range(a.warmup):
+        run_ctx[i % n_res].batch_run(opt)
     kms = {}
+    sc_sum = None
     torch.cuda.synchronize()
     dist_util.barrier(world)
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        ctx.batch_run(opt)                                   # returns after the library's stream has drained
-        for name, ms in ctx.batch_kernel_ms():
+    for i in range(a.steps):
+        c = run_ctx[i % n_res]
+        c.batch_run(opt)                                     # returns after the library's stream has drained
+        for name, ms in c.batch_kernel_ms():
             kms[name] = kms.get(name, 0.0) + ms
     torch.cuda.synchronize()
     dist_util.barrier(world)
     dt = dist_util.max_over_ranks(time.perf_counter() - t0, world, "cpu" if emu else "cuda")
     st = ctx.batch_stats()
+    if n_res > 1:                                            # work counters: the mean over the chunks that ran (they differ by a fraction of a per cent)
+        sts = [c.batch_stats() for c in run_ctx[:min(n_res, a.steps)]]
+        st = {k: sum(x[k] for x in sts) / len(sts) for k in st}
+        sc_sum = sum(np.asarray(c.batch_fetch("seed_counters", np.uint64), np.float64) for c in run_ctx[:min(n_res, a.steps)]) / min(n_res, a.steps)
+    for c in run_ctx[1:]:                                    # (their workspaces are not needed by the legs that follow)
+        c.close()
+    for ch in res_chunks:
+        ch.close()
 
     rc = 0
     if rank == 0:
@@ -725,7 +759,7 @@ def main():
             stage_ms[k.split(".")[0]] = stage_ms.get(k.split(".")[0], 0.0) + v
         # the FM-index seeding kernels: two 64-B CP_OCC lines per backwardExt; the dominant one is k_bwd
         # (two launches per step: the backward phases of pass 1 and of pass 2)
-        sc = ctx.batch_fetch("seed_counters", np.uint64)
+        sc = sc_sum if sc_sum is not None else ctx.batch_fetch("seed_counters", np.uint64)
         ext_of = {"walk1": int(sc[12]), "walk2": int(sc[13]), "walk3": int(sc[14]), "bwd1": int(sc[15]), "bwd2": int(sc[16])}
         smem_ms = stage_ms.get("smem", 0.0)
         bwd_ms = (kern_ms.get("smem.bwd1", 0.0) + kern_ms.get("smem.bwd2", 0.0)) / 2.0          # average launch duration
@@ -766,8 +800,9 @@ def main():
             "dtype": "int32", "data": "synthetic" if not emu else "synthetic; HOST EMULATOR RUN (not a measurement)",
             "config": {"workload": wl_name + " (SMEM+SAL+chain+banded-SW all on device), synthetic %d Mbp genome with planted repeats/ALT/"
                                    "N-gaps, indexed in-run by bm2_index_build (3100 Mbp = GRCh38 size); `value` = device hot path "
-                                   "with the reads resident in HBM, output = mem_alnreg_t regs at bwamem.cpp:1152; the FASTQ -> SAM "
-                                   "rate of the same library is `end_to_end.value`" % a.genome_mbp,
+                                   "with the reads resident in HBM (the steps go round %d distinct chunks), output = mem_alnreg_t regs at bwamem.cpp:1152; the FASTQ -> SAM "
+                                   "rate of the same library is `end_to_end.value`" % (a.genome_mbp, n_res),
+                       "resident_chunks": n_res,
                        "reads_per_gpu_per_step": n_reads, "bases_per_gpu_per_step": n_bases, "read_len": a.read_len if not ont else None,
                        "genome_mbp": a.genome_mbp,
                        "parallelism": ("ONE chunk cut at multiples of 512 reads over %d GPU(s) (strong scaling), " if a.strong else "one chunk per GPU over %d GPU(s), ") % world
