@@ -22,6 +22,7 @@ struct ChainParams {                                // what mem_chain_seeds / me
 int bm2_scan_i32(bm2_ctx *c, const int32_t *in, int64_t n, int64_t *out_excl /* n+1 */, DevBuf &tmp);
 
 int bm2_perm_by_work(bm2_ctx *c, int n, const int32_t *key, int32_t *perm, uint32_t *hist32, int mode);
+int bm2_partition_by_class(bm2_ctx *c, int n, const int32_t *key, int thr, int32_t *perm, DevBuf &tmp, DevBuf &scan_tmp, const int64_t **n_heavy_dev);
 
 int bm2_partition_by_work(bm2_ctx *c, int n, const int32_t *key, int thr, int32_t *perm, DevBuf &tmp, DevBuf &scan_tmp, int heavy_first = 0,
                           const int64_t **n_heavy_dev = nullptr);

@@ -359,7 +359,8 @@ static int batch_run_one(bm2_ctx *c, const bm2_opt *opt, StageGate *gate = nullp
     const int thr_sa = bm2_knob("BM2_HEAVY_SA", 100);           // reads with more SA coordinates go to k_chain_heavy (sweep: 40 -> 13.6 ms, 100 -> 12.1 ms)
     const int64_t *n_heavy_chain = nullptr;                      // set when the permutation lists the seed-rich reads first: k_chain_heavy takes them
     const int chain_heavy = bm2_knob("BM2_CHAIN_HEAVY", 1);
-    if (perm_mode == 3 || perm_mode == 4) { if ((rc = bm2_partition_by_work(c, n, (const int32_t *)b->n_sa_read.p, thr_sa, (int32_t *)b->perm.p, b->part_tmp, b->scan_tmp, perm_mode == 4, perm_mode == 4 && chain_heavy ? &n_heavy_chain : nullptr))) return rc; }
+    if (perm_mode == 5) { if ((rc = bm2_partition_by_class(c, n, (const int32_t *)b->n_sa_read.p, thr_sa, (int32_t *)b->perm.p, b->part_tmp, b->scan_tmp, chain_heavy ? &n_heavy_chain : nullptr))) return rc; }
+    else if (perm_mode == 3 || perm_mode == 4) { if ((rc = bm2_partition_by_work(c, n, (const int32_t *)b->n_sa_read.p, thr_sa, (int32_t *)b->perm.p, b->part_tmp, b->scan_tmp, perm_mode == 4, perm_mode == 4 && chain_heavy ? &n_heavy_chain : nullptr))) return rc; }
     else if ((rc = bm2_perm_by_work(c, n, (const int32_t *)b->n_sa_read.p, (int32_t *)b->perm.p, (uint32_t *)b->perm_hist.p, perm_mode))) return rc;
     if ((rc = bm2_launch_chain(c, cp, n, (const int32_t *)b->len.p, (const bm2_smem_t *)b->smem.p, (const int32_t *)b->smem_cnt.p,
                                (const int64_t *)b->smem_off.p, (const int64_t *)b->sa_off.p, (const int64_t *)b->sa_coord.p,

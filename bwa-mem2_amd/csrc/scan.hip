@@ -152,3 +152,37 @@ int bm2_partition_by_work(bm2_ctx *c, int n, const int32_t *key, int thr, int32_
     hipLaunchKernelGGL(k_part_scatter, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, flag, hpos, perm, heavy_first);
     return bm2_check(hipGetLastError(), "partition launch");
 }
+
+// ---- stable partition of reads into work classes: heavy reads (key > thr) first, then the light reads by falling class of key (> 64, > 32, > 16,
+// > 8, > 4, the rest), every class in the reads' original order.  A lane-per-read kernel is as slow as the busiest lane of each wavefront:
+// with the light reads in plain order nearly every wavefront holds a read with 50+ seeds among reads with ten (k_chain: 7.2 ms); with classes a
+// wavefront's reads cost alike, and because a class keeps the original order its lanes still own nearby memory (a full sort by key loses that and
+// measured slower in round 1).  One flag per (class, read), ONE scan over the class-major flags, one scatter.
+#define BM2_WORK_CLASSES 7
+static __device__ __forceinline__ int work_class(int key, int thr) {
+    return key > thr ? 0 : key > 64 ? 1 : key > 32 ? 2 : key > 16 ? 3 : key > 8 ? 4 : key > 4 ? 5 : 6;
+}
+__global__ void __launch_bounds__(256) k_class_flag(int n, const int32_t *__restrict__ key, int thr, int32_t *flag) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int b = work_class(key[i], thr);
+    for (int k = 0; k < BM2_WORK_CLASSES; k++) flag[(int64_t)k * n + i] = k == b;
+}
+__global__ void __launch_bounds__(256) k_class_scatter(int n, const int32_t *__restrict__ key, int thr, const int64_t *__restrict__ pos, int32_t *perm) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    perm[pos[(int64_t)work_class(key[i], thr) * n + i]] = i;
+}
+int bm2_partition_by_class(bm2_ctx *c, int n, const int32_t *key, int thr, int32_t *perm, DevBuf &tmp, DevBuf &scan_tmp, const int64_t **n_heavy_dev) {
+    if (n <= 0) return BM2_OK;
+    const size_t m = (size_t)BM2_WORK_CLASSES * (size_t)n;
+    int rc = bm2_reserve(tmp, (m + 1) * 4 + (m + 2) * 8 + 64);
+    if (rc) return rc;
+    int32_t *flag = (int32_t *)tmp.p;
+    int64_t *pos = (int64_t *)((char *)tmp.p + (((m + 1) * 4 + 15) & ~(size_t)15));
+    if (n_heavy_dev) *n_heavy_dev = pos + n;                   // where class 1 starts = how many heavy reads there are
+    hipLaunchKernelGGL(k_class_flag, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, key, thr, flag);
+    if ((rc = bm2_scan_i32(c, flag, (int64_t)m, pos, scan_tmp))) return rc;
+    hipLaunchKernelGGL(k_class_scatter, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, key, thr, pos, perm);
+    return bm2_check(hipGetLastError(), "class partition launch");
+}
