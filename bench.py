@@ -928,26 +928,21 @@ def main():
                     if pr.poll() is None:
                         pr.kill()
             log("end-to-end input: %d chunks generated in %.1fs" % (len(texts), time.time() - t))
-            n_dev = max(1, int(os.environ.get("BM2_E2E_DEVS", 2)))
             if not texts:
                 out["end_to_end"] = {"error": "no input chunk could be generated"}
-            for attempt_devs in ([n_dev, 1] if n_dev > 1 else [1]) if texts else []:
+            else:
+                # ONE attempt: a stage that fails or hangs leaves its threads behind (they may still be inside a library call on a context, which is
+                # not thread-safe), so nothing else is run on these contexts afterwards -- the line is printed and the process leaves through os._exit
                 try:
-                    out["end_to_end"] = end_to_end(ctx, bm2, texts, opt, True, 0, limit_s=max(60.0, min(420.0, time_left() - 30)), n_dev=attempt_devs)
+                    out["end_to_end"] = end_to_end(ctx, bm2, texts, opt, True, 0, limit_s=max(60.0, min(420.0, time_left() - 30)))
                     out["end_to_end"]["frac_of_hot_path"] = out["end_to_end"]["value"] / value
                     if (out["end_to_end"].get("chunk_check") or {}).get("equal_to_serial_run") is False:
                         log("end-to-end leg: the text of chunk %d differs from the serial run's" % out["end_to_end"]["chunk_check"]["chunk"])
                         rc = 3
-                    break
-                except TimeoutError as e:                                             # a stage is stuck: report, then leave without joining it
-                    out["end_to_end"] = {"error": str(e), "device_workers": attempt_devs}
+                except Exception as e:                                                # noqa  (TimeoutError: a stage is stuck)
+                    out["end_to_end"] = {"error": str(e)}
                     hung = True
-                    break
-                except Exception as e:                                                # noqa
-                    out["end_to_end"] = {"error": str(e), "device_workers": attempt_devs}
-                    hung = True                                                       # (stage threads may still wait on a queue: leave through os._exit)
-                    log("end-to-end leg with %d device worker(s) failed: %s" % (attempt_devs, e))
-                    time.sleep(2.0)                                                   # (calls in flight on the contexts finish before the next attempt)
+                    log("end-to-end leg failed: %s" % e)
         else:
             out["end_to_end"] = None
         # the literal drop-in: the reference's own binary with libbm2 linked in place of mem_process_seqs (oracle/_ref/bwa-mem2.bm2), from FASTQ
