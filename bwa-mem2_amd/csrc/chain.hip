@@ -561,7 +561,7 @@ int bm2_launch_chain(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_
                      WChain *wchain, WSeed *wseed, BtNode *nodes, int32_t *order, DevChain *chn, DevSeed *seeds_out,
                      int32_t *seed_owner,
                      int32_t *n_chain_out, int32_t *n_reg_out, int32_t *n_chain0_out, const int32_t *perm,
-                     int heavy_thr, const int64_t *n_heavy_dev, const int32_t *n_sa_read, unsigned long long *item_cur /* one per tier */) {
+                     int heavy_thr, const int64_t *n_heavy_dev, const int32_t *n_sa_read, unsigned long long *item_cur /* one per tier + 1 */, int max_len) {
     if (n_reads <= 0) return BM2_OK;
     hipStream_t s = c->stream;
     const bool heavy = heavy_thr >= 0 && n_heavy_dev != nullptr;
@@ -575,6 +575,8 @@ int bm2_launch_chain(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_
         const int caps[BM2_CHAIN_TIERS] = { 64, 128, 256, 512, stage ? 1000 : 1184 };       // (the last tier fills a CU's 160 KB of LDS)
         static bool attr_set = false;
         if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_chain_heavy, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+        // reads with more seeds than the largest tier holds: a launch of their own where they are the norm (long reads), otherwise the last tier's
+        const bool own_overflow = max_len >= bm2_knob("BM2_CHAIN_OVF_MIN_LEN", 1000);
         int lo = heavy_thr;
         for (int t = 0; t < BM2_CHAIN_TIERS; t++) {
             if (caps[t] <= lo) continue;
@@ -585,10 +587,24 @@ int bm2_launch_chain(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_
             (void)hipStreamWaitEvent(sk, c->ev_fork, 0);
             hipLaunchKernelGGL(k_chain_heavy, dim3(c->n_cu * per_cu), dim3(64), lds, sk, c->ix, o, n_reads, len, smems, smem_cnt, smem_off, sa_off,
                                sa_coord, wchain, wseed, nodes, order, chn, seeds_out, seed_owner, n_chain_out, n_reg_out, n_chain0_out, perm,
-                               n_heavy_dev, n_sa_read, lo, caps[t], t == BM2_CHAIN_TIERS - 1 ? 1 : 0, item_cur + t, stage);
+                               n_heavy_dev, n_sa_read, lo, caps[t], (t == BM2_CHAIN_TIERS - 1 && !own_overflow) ? 1 : 0, item_cur + t, stage);
             (void)hipEventRecord(c->ev_join[2 + t], sk);
             (void)hipStreamWaitEvent(s, c->ev_join[2 + t], 0);
             lo = caps[t];
+        }
+        // Reads with more seeds than the largest tier holds in LDS (long reads: ~12 k seeds per 10 kb read) walk their GLOBAL slices.  They
+        // used to ride in the last tier -- whose blocks reserve a CU's whole LDS, so only one such walk ran per CU: 256 at a time, 5.1 s for
+        // a chunk of 10 000 ONT-like reads.  A launch of their own with (almost) no LDS: as many walks in flight as the CUs hold wavefronts.
+        // (Short-read chunks keep the old routing: a read of theirs beyond 1000 seeds is a rarity, and one more launch scanning the heavy list is not free.)
+        if (own_overflow) {
+            hipStream_t sk = c->side_stream[2 + BM2_CHAIN_TIERS];
+            const int per_cu = bm2_knob("BM2_CHAIN_OVF_WAVES_PER_CU", 32);
+            (void)hipStreamWaitEvent(sk, c->ev_fork, 0);
+            hipLaunchKernelGGL(k_chain_heavy, dim3(c->n_cu * per_cu), dim3(64), bm2_chain_lds_bytes(0, 0), sk, c->ix, o, n_reads, len, smems, smem_cnt, smem_off, sa_off,
+                               sa_coord, wchain, wseed, nodes, order, chn, seeds_out, seed_owner, n_chain_out, n_reg_out, n_chain0_out, perm,
+                               n_heavy_dev, n_sa_read, lo, 0, 1, item_cur + BM2_CHAIN_TIERS, 0);
+            (void)hipEventRecord(c->ev_join[2 + BM2_CHAIN_TIERS], sk);
+            (void)hipStreamWaitEvent(s, c->ev_join[2 + BM2_CHAIN_TIERS], 0);
         }
     }
     return bm2_check(hipGetLastError(), "k_chain launch");
