@@ -625,7 +625,7 @@ def main():
                     help="bsw: extension tasks per step (default = the 2.874 tasks per read the pe150 workload measures x 1 M reads)")
     ap.add_argument("--genome-mbp", type=int, default=int(os.environ.get("BM2_BENCH_GENOME_MBP", 3100)))
     ap.add_argument("--reads", type=int, default=int(os.environ.get("BM2_BENCH_READS", 0)),
-                    help="reads per GPU per step (both mates counted); default 1000000 (pe150) / 2000 (ont2d)")
+                    help="reads per GPU per step (both mates counted); default 1000000 (pe150) / 10000 (ont2d)")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--cpu-pairs", type=int, default=int(os.environ.get("BM2_BENCH_CPU_PAIRS", 250000)))
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -682,7 +682,7 @@ def main():
     ont = a.workload == "ont2d"
     paired = not ont
     if ont:
-        n_reads = a.reads or 2000
+        n_reads = a.reads or 10000                           # ~100 Mbases: the chunk of `bwa-mem2 mem -K 100000000`
         opt, opt_args = bm2.default_opt(**ONT2D), ["-x", "ont2d"]
         seqs = synth.make_reads_long(dist_util.shard_seed(seed, rank), contigs(), n_reads, mean_len=10000, max_len=30000)
         from tools import refio
