@@ -196,7 +196,7 @@ static int run_seeding(bm2_ctx *c, Batch *b, const bm2_opt *opt, bool with_sal) 
     if (task_cap < (int64_t)n * 6 * per_read + lanes + 4096) task_cap = (int64_t)n * 6 * per_read + lanes + 4096;
     if (pool_slots < (n / 8 + 1024) * per_read + 1) pool_slots = (n / 8 + 1024) * per_read + 1;
     if ((rc = bm2_reserve(b->seedc, (size_t)n_sc * 8))) return rc;
-    if ((rc = bm2_reserve(b->fill, (size_t)(n + 1) * 4))) return rc;
+    if ((rc = bm2_reserve(b->fill, (size_t)(2 * (size_t)n + 8) * 4))) return rc;      // per-read fill counters | list of SMEM-rich reads | its count, cursor
     std::vector<unsigned long long> h_sc((size_t)n_sc);
     int64_t n_smem_tot = 0;
     const bool verbose = getenv("BM2_VERBOSE") != nullptr;
@@ -221,7 +221,7 @@ static int run_seeding(bm2_ctx *c, Batch *b, const bm2_opt *opt, bool with_sal) 
         sb.heavy1 = (int32_t *)b->heavy1.p; sb.heavy2 = (int32_t *)b->heavy2.p;
         if ((rc = bm2_check(hipMemsetAsync(b->seedc.p, 0, (size_t)n_sc * 8, s), "memset seed cursors"))) return rc;
         if ((rc = bm2_check(hipMemsetAsync(b->smem_cnt.p, 0, (size_t)(n + 1) * 4, s), "memset smem_cnt"))) return rc;
-        if ((rc = bm2_check(hipMemsetAsync(b->fill.p, 0, (size_t)(n + 1) * 4, s), "memset fill"))) return rc;
+        if ((rc = bm2_check(hipMemsetAsync(b->fill.p, 0, (size_t)(2 * (size_t)n + 8) * 4, s), "memset fill"))) return rc;
         if (verbose) { (void)hipStreamSynchronize(s); fprintf(stderr, "[seeding] reserve+memset %.1f ms\n", now_ms() - t0); t0 = now_ms(); }
         c->n_ev = 0;                                                // (a repeated attempt restarts the stage clock)
         if ((rc = bm2_launch_seeding(c, sp, n, (const uint8_t *)b->enc.p, (const int64_t *)b->off.p, (const int32_t *)b->len.p, sb,

@@ -661,24 +661,73 @@ k_rec_scatter(const bm2_smem_t *__restrict__ recs, int64_t rec_cap, const unsign
     }
 }
 
+// Reads with many SMEMs (a 10 kb read owns thousands): ONE WORKGROUP PER READ.  One lane sorting 3000 records in global memory took 0.4 s --
+// four fifths of the seeding stage of a long-read chunk.  Here the keys (m << 40 | n << 20 | index: m, n < 2^15) are sorted by a bitonic
+// network in LDS (up to 16 k keys = 128 KB), then the records are gathered by all lanes.  Equal (m, n) are field-identical, so the index in
+// the key only makes the order total.  A read with more SMEMs than the LDS holds is sorted by lane 0 as before.
+#define SMEM_FINISH_BIG 48
+#define SMEM_FINISH_LDS_KEYS 16384
+__global__ void __launch_bounds__(256)
+k_smem_finish_big(const bm2_smem_t *__restrict__ tmp, const int32_t *__restrict__ smem_cnt, const int64_t *__restrict__ smem_off, int32_t max_occ,
+                  bm2_smem_t *out, int32_t *occ_cnt, const int32_t *__restrict__ big_list, const int32_t *__restrict__ big_cnt, int32_t *cursor) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t fin_keys[];
+    __shared__ int item_s;
+    const int n_big = *big_cnt;
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) item_s = atomicAdd(cursor, 1);
+        __syncthreads();
+        const int item = item_s;
+        if (item >= n_big) break;
+        const int r = big_list[item];
+        const int n = smem_cnt[r];
+        const int64_t o = smem_off[r];
+        const bm2_smem_t *row = tmp + o;
+        if (n > SMEM_FINISH_LDS_KEYS) {                         // (beyond the LDS: one lane, index array in the read's slice of occ_cnt)
+            if (threadIdx.x == 0) {
+                int32_t *idx = occ_cnt + o;
+                for (int i = 0; i < n; i++) idx[i] = i;
+                k_introsort_flat(n, idx, [&](int32_t x, int32_t y) { return row[x].m < row[y].m || (row[x].m == row[y].m && row[x].n < row[y].n); });
+                for (int i = 0; i < n; i++) out[o + i] = row[idx[i]];
+                for (int i = 0; i < n; i++) { const int64_t sv = out[o + i].s; occ_cnt[o + i] = (int32_t)(sv < max_occ ? sv : max_occ); }
+            }
+            continue;
+        }
+        int N = 64; while (N < n) N <<= 1;
+        for (int i = threadIdx.x; i < N; i += blockDim.x)
+            fin_keys[i] = i < n ? ((uint64_t)row[i].m << 40 | (uint64_t)row[i].n << 20 | (uint64_t)i) : ~(uint64_t)0;
+        __syncthreads();
+        for (int k = 2; k <= N; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int t = threadIdx.x; t < N; t += blockDim.x) {
+                    const int p = t ^ j;
+                    if (p > t) {
+                        const uint64_t a = fin_keys[t], b = fin_keys[p];
+                        const bool up = (t & k) == 0;
+                        if ((a > b) == up) { fin_keys[t] = b; fin_keys[p] = a; }
+                    }
+                }
+                __syncthreads();
+            }
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            const bm2_smem_t v = row[(int)(fin_keys[i] & 0xfffffULL)];
+            out[o + i] = v;
+            occ_cnt[o + i] = (int32_t)(v.s < max_occ ? v.s : max_occ);                     // FMI_search.cpp:1280-1290
+        }
+    }
+}
+
 // Order one read's SMEMs by (m, n) (sortSMEMs + ks_introsort(mem_intv1), bwamem.cpp:785-799; equal (m, n) are
 // field-identical, so any order among them gives the same array); `out` is dense and in read order.
 __global__ void __launch_bounds__(256)
 k_smem_finish(int n_reads, const bm2_smem_t *__restrict__ tmp, const int32_t *__restrict__ smem_cnt,
-              const int64_t *__restrict__ smem_off, int32_t max_occ, bm2_smem_t *out, int32_t *occ_cnt) {
+              const int64_t *__restrict__ smem_off, int32_t max_occ, bm2_smem_t *out, int32_t *occ_cnt, int32_t *big_list, int32_t *big_cnt) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_reads) return;
     const int n = smem_cnt[r];
     const int64_t o = smem_off[r];
     const bm2_smem_t *row = tmp + o;
-    if (n > 48) {                                               // long reads own thousands of SMEMs: n log n instead of the n^2 ranking below
-        int32_t *idx = occ_cnt + o;                             // (this read's slice of occ_cnt is free until the loop at the end fills it)
-        for (int i = 0; i < n; i++) idx[i] = i;
-        k_introsort_flat(n, idx, [&](int32_t x, int32_t y) { return row[x].m < row[y].m || (row[x].m == row[y].m && row[x].n < row[y].n); });
-        for (int i = 0; i < n; i++) out[o + i] = row[idx[i]];
-        for (int i = 0; i < n; i++) { const int64_t sv = out[o + i].s; occ_cnt[o + i] = (int32_t)(sv < max_occ ? sv : max_occ); }
-        return;
-    }
+    if (n > SMEM_FINISH_BIG) { big_list[atomicAdd(big_cnt, 1)] = (int32_t)r; return; }      // a whole workgroup sorts this read's SMEMs (k_smem_finish_big)
     for (int i = 0; i < n; i++) {
         const bm2_smem_t v = row[i];
         int rank = 0;
@@ -840,7 +889,13 @@ int bm2_launch_smem_finish(bm2_ctx *c, int n_reads, const SeedBufs &sb, const un
                            const int64_t *smem_off, int32_t *fill, bm2_smem_t *tmp, int32_t max_occ, bm2_smem_t *out, int32_t *occ_cnt) {
     if (n_reads <= 0) return BM2_OK;
     hipLaunchKernelGGL(k_rec_scatter, dim3(c->n_cu * 8), dim3(256), 0, c->stream, sb.recs, sb.rec_cap, sc, smem_off, fill, tmp);
-    hipLaunchKernelGGL(k_smem_finish, dim3((n_reads + 255) / 256), dim3(256), 0, c->stream, n_reads, tmp, smem_cnt, smem_off, max_occ, out, occ_cnt);
+    // (`fill` is through after the scatter: its second half lists the reads that go to the workgroup-per-read sort; [2 n + 2], [2 n + 3] = count, cursor)
+    int32_t *big_list = fill + n_reads + 1, *big_cnt = fill + 2 * (int64_t)n_reads + 2, *big_cur = big_cnt + 1;
+    hipLaunchKernelGGL(k_smem_finish, dim3((n_reads + 255) / 256), dim3(256), 0, c->stream, n_reads, tmp, smem_cnt, smem_off, max_occ, out, occ_cnt, big_list, big_cnt);
+    static bool attr_set = false;
+    const size_t lds = (size_t)SMEM_FINISH_LDS_KEYS * 8;
+    if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_smem_finish_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+    hipLaunchKernelGGL(k_smem_finish_big, dim3(c->n_cu), dim3(256), lds, c->stream, tmp, smem_cnt, smem_off, max_occ, out, occ_cnt, big_list, big_cnt, big_cur);
     return bm2_check(hipGetLastError(), "k_smem_finish launch");
 }
 int bm2_seed_sizes(size_t *head, size_t *ent, size_t *task, int *n_sc) {
