@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 3, call Q: reads beyond the LDS tiers of k_chain_heavy on a launch of their own (long reads): long-read GPU tests, config 5 at 2000 / 10 000 reads per step
+# Round 3, call Q (re-run as R with the workgroup-per-read SMEM sort): long-read GPU tests, config 5 at 2000 / 10 000 reads per step, pe150 check
 TAG=${1:-r03q}; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O
 cd $R; export TMPDIR=/tmp
 T0=$(date +%s)
