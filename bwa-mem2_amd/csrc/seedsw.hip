@@ -27,12 +27,16 @@ static __device__ int pos2rid2(const DevIndex &ix, int64_t pos_f) {
     return mid;
 }
 
+// P8: no score of the window can exceed 255 (199 columns x a): the row as 8 + 8 bits per column and the query 4 bits per base -- 32 KB of
+// LDS per wavefront instead of 64 KB (5 wavefronts per CU instead of 2).  Scores are computed from (match, mismatch, ambiguous), the form
+// check_opt guarantees, instead of a global-memory lookup per cell.
+template <bool P8>
 __global__ void __launch_bounds__(64)
 k_seed_sw(DevIndex ix, ChainParams o, const int8_t *__restrict__ mat25, int64_t n_slots, const uint8_t *__restrict__ enc,
           const int64_t *__restrict__ off, const int32_t *__restrict__ len, const int32_t *__restrict__ min_hsp /* per read, <0 = filter inactive */,
           const int32_t *__restrict__ seed_owner, DevSeed *seeds, uint8_t *seed_keep) {
-    __shared__ uint32_t HE[SSW_QMAX * 64];
-    __shared__ uint8_t QL[SSW_QMAX * 64];
+    __shared__ uint32_t HE[(P8 ? SSW_QMAX / 2 : SSW_QMAX) * 64];     // P8: two columns per dword {h, e, h, e}
+    __shared__ uint32_t QL[(SSW_QMAX + 7) / 8 * 64];                 // 8 bases of 4 bits per dword
     const int lane = threadIdx.x;
     const int64_t g = (int64_t)blockIdx.x * 64 + lane;
     int r = -1;
@@ -63,33 +67,66 @@ k_seed_sw(DevIndex ix, ChainParams o, const int8_t *__restrict__ mat25, int64_t 
                 qlen = qe - qb; tlen = (int)(re - rb);
                 tp = ix.ref_string + rb;
                 const uint8_t *qp = enc + off[r] + qb;
-                for (int j = 0; j < qlen; j++) { QL[j * 64 + lane] = qp[j]; HE[j * 64 + lane] = 0; }
+                for (int j0 = 0; j0 < qlen; j0 += 8) {
+                    uint32_t wq = 0;
+                    for (int u = 0; u < 8 && j0 + u < qlen; u++) wq |= (uint32_t)(qp[j0 + u] & 15) << (4 * u);
+                    QL[(j0 >> 3) * 64 + lane] = wq;
+                }
+                for (int j = 0; j < (P8 ? (qlen + 1) / 2 : qlen); j++) HE[j * 64 + lane] = 0;
                 run = true;
             }
         }
     }
     // local SW, ksw_i16 recurrence (ksw.cpp:275-291): gaps open from H, everything clamped at 0
     const int oe_del = o.o_del + o.e_del, oe_ins = o.o_ins + o.e_ins;
+    const int s_match = mat25[0], s_mis = mat25[1], s_amb = mat25[4];            // (uniform loads: once per wavefront)
     int maxq = run ? qlen : 0, maxt = run ? tlen : 0;
     for (int d = 32; d > 0; d >>= 1) { maxq = max(maxq, __shfl_xor(maxq, d)); maxt = max(maxt, __shfl_xor(maxt, d)); }
     int gmax = 0;
+    int t_next = run && tlen > 0 ? (int)tp[0] : 4;
     for (int i = 0; i < maxt; i++) {
         const bool rowon = run && i < tlen;
-        const int tb = rowon ? (int)tp[i] : 4;
+        const int tb = rowon ? t_next : 4;
+        if (run && i + 1 < tlen) t_next = (int)tp[i + 1];                           // (requested a row ahead)
         int hdiag = 0, f = 0;
-        for (int j = 0; j < maxq; j++) {
-            if (rowon && j < qlen) {
-                const uint32_t p = HE[j * 64 + lane];
-                const int qb = QL[j * 64 + lane];
-                int e = (int)(p >> 16);
-                int h = hdiag + mat25[tb * 5 + qb];
-                hdiag = (int)(p & 0xffffu);
-                h = h > e ? h : e;
-                h = h > f ? h : f;
-                gmax = gmax > h ? gmax : h;
-                e = max(max(e - o.e_del, h - oe_del), 0);
-                f = max(max(f - o.e_ins, h - oe_ins), 0);
-                HE[j * 64 + lane] = (uint32_t)h | ((uint32_t)e << 16);
+        if (P8) {
+            for (int jp = 0; jp < maxq; jp += 2) {
+                if (rowon && jp < qlen) {
+                    uint32_t word = HE[(jp >> 1) * 64 + lane];
+                    const uint32_t qw = QL[(jp >> 3) * 64 + lane] >> (4 * (jp & 7));
+#pragma unroll
+                    for (int u = 0; u < 2; u++) {
+                        if (jp + u < qlen) {
+                            const int qb = (int)((qw >> (4 * u)) & 15u);
+                            int e = (int)((word >> (16 * u + 8)) & 0xffu);
+                            int h = hdiag + ((qb == tb && tb < 4) ? s_match : ((qb > 3 || tb > 3) ? s_amb : s_mis));
+                            hdiag = (int)((word >> (16 * u)) & 0xffu);
+                            h = h > e ? h : e;
+                            h = h > f ? h : f;
+                            gmax = gmax > h ? gmax : h;
+                            e = max(isub0(e, o.e_del), h - oe_del);
+                            f = max(isub0(f, o.e_ins), h - oe_ins);
+                            word = (word & ~(0xffffu << (16 * u))) | ((uint32_t)h | (uint32_t)e << 8) << (16 * u);
+                        }
+                    }
+                    HE[(jp >> 1) * 64 + lane] = word;
+                }
+            }
+        } else {
+            for (int j = 0; j < maxq; j++) {
+                if (rowon && j < qlen) {
+                    const uint32_t p = HE[j * 64 + lane];
+                    const int qb = (int)((QL[(j >> 3) * 64 + lane] >> (4 * (j & 7))) & 15u);
+                    int e = (int)(p >> 16);
+                    int h = hdiag + ((qb == tb && tb < 4) ? s_match : ((qb > 3 || tb > 3) ? s_amb : s_mis));
+                    hdiag = (int)(p & 0xffffu);
+                    h = h > e ? h : e;
+                    h = h > f ? h : f;
+                    gmax = gmax > h ? gmax : h;
+                    e = max(isub0(e, o.e_del), h - oe_del);
+                    f = max(isub0(f, o.e_ins), h - oe_ins);
+                    HE[j * 64 + lane] = (uint32_t)h | ((uint32_t)e << 16);
+                }
             }
         }
     }
@@ -121,8 +158,12 @@ int bm2_launch_seed_filter(bm2_ctx *c, const ChainParams &o, const int8_t *d_mat
                            const int64_t *off, const int32_t *len, const int32_t *min_hsp, const int64_t *read_base, const int32_t *n_chain,
                            const int32_t *seed_owner, DevChain *chn, DevSeed *seeds, uint8_t *seed_keep) {
     if (n_slots <= 0) return BM2_OK;
-    hipLaunchKernelGGL(k_seed_sw, dim3((unsigned)((n_slots + 63) / 64)), dim3(64), 0, c->stream, c->ix, o, d_mat25, n_slots, enc, off, len, min_hsp,
-                       seed_owner, seeds, seed_keep);
+    if ((SSW_QMAX - 1) * o.a <= 255)                            // (a window has < 200 columns: no score above 199 a)
+        hipLaunchKernelGGL(k_seed_sw<true>, dim3((unsigned)((n_slots + 63) / 64)), dim3(64), 0, c->stream, c->ix, o, d_mat25, n_slots, enc, off, len, min_hsp,
+                           seed_owner, seeds, seed_keep);
+    else
+        hipLaunchKernelGGL(k_seed_sw<false>, dim3((unsigned)((n_slots + 63) / 64)), dim3(64), 0, c->stream, c->ix, o, d_mat25, n_slots, enc, off, len, min_hsp,
+                           seed_owner, seeds, seed_keep);
     hipLaunchKernelGGL(k_seed_flt_apply, dim3((n_reads + 127) / 128), dim3(128), 0, c->stream, n_reads, read_base, n_chain, min_hsp, chn, seeds, seed_keep);
     return bm2_check(hipGetLastError(), "seed filter launch");
 }

@@ -669,7 +669,7 @@ k_rec_scatter(const bm2_smem_t *__restrict__ recs, int64_t rec_cap, const unsign
 #define SMEM_FINISH_LDS_KEYS 16384
 __global__ void __launch_bounds__(256)
 k_smem_finish_big(const bm2_smem_t *__restrict__ tmp, const int32_t *__restrict__ smem_cnt, const int64_t *__restrict__ smem_off, int32_t max_occ,
-                  bm2_smem_t *out, int32_t *occ_cnt, const int32_t *__restrict__ big_list, const int32_t *__restrict__ big_cnt, int32_t *cursor) {
+                  bm2_smem_t *out, int32_t *occ_cnt, const int32_t *__restrict__ big_list, const int32_t *__restrict__ big_cnt, int32_t *cursor, int lds_keys) {
     extern __shared__ __attribute__((aligned(16))) uint64_t fin_keys[];
     __shared__ int item_s;
     const int n_big = *big_cnt;
@@ -683,13 +683,65 @@ k_smem_finish_big(const bm2_smem_t *__restrict__ tmp, const int32_t *__restrict_
         const int n = smem_cnt[r];
         const int64_t o = smem_off[r];
         const bm2_smem_t *row = tmp + o;
-        if (n > SMEM_FINISH_LDS_KEYS) {                         // (beyond the LDS: one lane, index array in the read's slice of occ_cnt)
-            if (threadIdx.x == 0) {
-                int32_t *idx = occ_cnt + o;
-                for (int i = 0; i < n; i++) idx[i] = i;
-                k_introsort_flat(n, idx, [&](int32_t x, int32_t y) { return row[x].m < row[y].m || (row[x].m == row[y].m && row[x].n < row[y].n); });
-                for (int i = 0; i < n; i++) out[o + i] = row[idx[i]];
-                for (int i = 0; i < n; i++) { const int64_t sv = out[o + i].s; occ_cnt[o + i] = (int32_t)(sv < max_occ ? sv : max_occ); }
+        if (n > lds_keys) {
+            // More SMEMs than the LDS holds keys (a 30 kb read): m is the major key, so the read's SMEMs are cut into runs of m-classes (m >> 6:
+            // 512 classes) that fit, each run collected into LDS, sorted there and written behind the run before it.
+            __shared__ int cls_cnt[513];
+            __shared__ int run_lo, run_hi, run_base, run_n, fits;
+            for (int i = threadIdx.x; i < 513; i += blockDim.x) cls_cnt[i] = 0;
+            __syncthreads();
+            for (int i = threadIdx.x; i < n; i += blockDim.x) atomicAdd(&cls_cnt[row[i].m >> 6 < 512 ? row[i].m >> 6 : 511], 1);
+            __syncthreads();
+            if (threadIdx.x == 0) { fits = 1; for (int k = 0; k < 512; k++) if (cls_cnt[k] > lds_keys) fits = 0; run_lo = 0; run_base = 0; }
+            __syncthreads();
+            if (!fits) {                                        // (one m-class alone overflows the LDS: one lane, index array in the read's slice of occ_cnt)
+                if (threadIdx.x == 0) {
+                    int32_t *idx = occ_cnt + o;
+                    for (int i = 0; i < n; i++) idx[i] = i;
+                    k_introsort_flat(n, idx, [&](int32_t x, int32_t y) { return row[x].m < row[y].m || (row[x].m == row[y].m && row[x].n < row[y].n); });
+                    for (int i = 0; i < n; i++) out[o + i] = row[idx[i]];
+                    for (int i = 0; i < n; i++) { const int64_t sv = out[o + i].s; occ_cnt[o + i] = (int32_t)(sv < max_occ ? sv : max_occ); }
+                }
+                continue;
+            }
+            for (;;) {
+                __syncthreads();
+                if (threadIdx.x == 0) {                          // the next run: classes [run_lo, run_hi) with at most LDS_KEYS records
+                    int k = run_lo, tot = 0;
+                    while (k < 512 && tot + cls_cnt[k] <= lds_keys) tot += cls_cnt[k++];
+                    run_hi = k; run_n = 0;
+                }
+                __syncthreads();
+                const int lo = run_lo, hi = run_hi, base = run_base;
+                if (lo >= 512) break;
+                for (int i = threadIdx.x; i < n; i += blockDim.x) {
+                    const int k = row[i].m >> 6 < 512 ? (int)(row[i].m >> 6) : 511;
+                    if (k >= lo && k < hi) fin_keys[atomicAdd(&run_n, 1)] = (uint64_t)row[i].m << 40 | (uint64_t)row[i].n << 20 | (uint64_t)i;
+                }
+                __syncthreads();
+                const int cnt = run_n;
+                int N2 = 64; while (N2 < cnt) N2 <<= 1;
+                for (int i = cnt + threadIdx.x; i < N2; i += blockDim.x) fin_keys[i] = ~(uint64_t)0;
+                __syncthreads();
+                for (int k = 2; k <= N2; k <<= 1)
+                    for (int j = k >> 1; j > 0; j >>= 1) {
+                        for (int t = threadIdx.x; t < N2; t += blockDim.x) {
+                            const int p = t ^ j;
+                            if (p > t) {
+                                const uint64_t a = fin_keys[t], b = fin_keys[p];
+                                const bool up = (t & k) == 0;
+                                if ((a > b) == up) { fin_keys[t] = b; fin_keys[p] = a; }
+                            }
+                        }
+                        __syncthreads();
+                    }
+                for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
+                    const bm2_smem_t v = row[(int)(fin_keys[i] & 0xfffffULL)];
+                    out[o + base + i] = v;
+                    occ_cnt[o + base + i] = (int32_t)(v.s < max_occ ? v.s : max_occ);
+                }
+                __syncthreads();
+                if (threadIdx.x == 0) { run_lo = hi; run_base = base + cnt; }
             }
             continue;
         }
@@ -893,9 +945,12 @@ int bm2_launch_smem_finish(bm2_ctx *c, int n_reads, const SeedBufs &sb, const un
     int32_t *big_list = fill + n_reads + 1, *big_cnt = fill + 2 * (int64_t)n_reads + 2, *big_cur = big_cnt + 1;
     hipLaunchKernelGGL(k_smem_finish, dim3((n_reads + 255) / 256), dim3(256), 0, c->stream, n_reads, tmp, smem_cnt, smem_off, max_occ, out, occ_cnt, big_list, big_cnt);
     static bool attr_set = false;
+    int lds_keys = bm2_knob("BM2_SMEM_SORT_KEYS", SMEM_FINISH_LDS_KEYS);     // (a test hook: small values force the m-class runs on ordinary reads)
+    if (lds_keys < 64) lds_keys = 64;
+    if (lds_keys > SMEM_FINISH_LDS_KEYS) lds_keys = SMEM_FINISH_LDS_KEYS;
     const size_t lds = (size_t)SMEM_FINISH_LDS_KEYS * 8;
     if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_smem_finish_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
-    hipLaunchKernelGGL(k_smem_finish_big, dim3(c->n_cu), dim3(256), lds, c->stream, tmp, smem_cnt, smem_off, max_occ, out, occ_cnt, big_list, big_cnt, big_cur);
+    hipLaunchKernelGGL(k_smem_finish_big, dim3(c->n_cu), dim3(256), lds, c->stream, tmp, smem_cnt, smem_off, max_occ, out, occ_cnt, big_list, big_cnt, big_cur, lds_keys);
     return bm2_check(hipGetLastError(), "k_smem_finish launch");
 }
 int bm2_seed_sizes(size_t *head, size_t *ent, size_t *task, int *n_sc) {

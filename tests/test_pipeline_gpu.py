@@ -214,6 +214,27 @@ def test_long_reads_ont2d_golden(gpu_ctx_factory, golden_dir):
     _same(d["REGPRG"], regs_to_records(regs, reg_off), "REGPRG")
 
 
+def test_long_reads_smem_order_in_runs_of_start_classes(golden_dir):
+    # k_smem_finish_big with its LDS capacity cut to 128 keys: the SMEM-rich reads of the fixture are ordered in runs of m-classes (the path a 30 kb
+    # read takes at the real capacity), a class that alone exceeds the capacity falls back to the one-lane sort
+    pre, enc, off, ln, d = load_golden(golden_dir, "g40k_ont")
+    os.environ["BM2_SMEM_SORT_KEYS"] = "128"
+    try:
+        ctx = bm2.Context(0, pre)
+        try:
+            regs, reg_off, st = ctx.seed_chain_extend(enc, off, ln, bm2.default_opt(**ONT2D))
+            sm = ctx.smem(enc, off, ln, bm2.default_opt(**ONT2D))
+        finally:
+            ctx.close()
+    finally:
+        del os.environ["BM2_SMEM_SORT_KEYS"]
+    got = np.zeros(len(sm), refio.SMEM_DT)
+    for a, b in (("read", "rid"), ("m", "m"), ("n", "n"), ("k", "k"), ("l", "l"), ("s", "s")):
+        got[a] = sm[b]
+    _same(d["SMEM"], got, "SMEM")
+    _same(d["REGPRG"], regs_to_records(regs, reg_off), "REGPRG")
+
+
 def test_long_reads_fresh_vs_oracle(gpu_ctx_factory, tmp_path):
     names, ctg, alts = synth.make_genome(41, [200000, 90000], alt_contigs=1, alt_len=4000, n_repeat_families=5,
                                          repeat_len=(300, 4000), copies=(3, 20), divergence=(0.0, 0.08))
