@@ -31,15 +31,21 @@ static __device__ __forceinline__ Blk load_blk(const CpOccDev *p) {             
 template <int CTRL> static __device__ __forceinline__ int32_t qperm32(int32_t v) {
     return __builtin_amdgcn_mov_dpp(v, CTRL, 0xf, 0xf, false);
 }
+typedef int32_t bm2_i32x2 __attribute__((ext_vector_type(2)));
 template <int CTRL> static __device__ __forceinline__ int64_t qperm64(int64_t v) {
-    const int32_t lo = qperm32<CTRL>((int32_t)(uint32_t)v), hi = qperm32<CTRL>((int32_t)(v >> 32));
-    return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+    const bm2_i32x2 r = { qperm32<CTRL>((int32_t)(uint32_t)v), qperm32<CTRL>((int32_t)(v >> 32)) };
+    return __builtin_bit_cast(int64_t, r);           // (a register pair: shifting and or-ing the halves together costs two 64-bit adds)
 }
 template <int T> static __device__ __forceinline__ int64_t qbcast64(int64_t v) { return qperm64<T | T << 2 | T << 4 | T << 6>(v); }
 template <int T> static __device__ __forceinline__ int32_t qbcast32(int32_t v) { return qperm32<T | T << 2 | T << 4 | T << 6>(v); }
 static __device__ __forceinline__ int64_t qsum64(int64_t v) {                     // sum over the quad, in every lane
     v += qperm64<0xB1>(v);           // [1,0,3,2]
     v += qperm64<0x4E>(v);           // [2,3,0,1]
+    return v;
+}
+static __device__ __forceinline__ uint32_t qsum32(uint32_t v) {                  // sum over the quad, in every lane
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int32_t)v, 0xB1, 0xf, 0xf, true);        // [1,0,3,2]  (bound_ctrl: lets the exchange fold into the add)
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int32_t)v, 0x4E, 0xf, 0xf, true);        // [2,3,0,1]
     return v;
 }
 
@@ -53,24 +59,35 @@ static __device__ __forceinline__ int64_t qsum64(int64_t v) {                   
 template <int T>
 static __device__ __forceinline__ void coop_issue(const DevIndex &ix, int64_t k, int64_t s, int want, int sub, ulonglong2 &e1, ulonglong2 &e2) {
     const int64_t sp = qbcast64<T>(k), ep = sp + qbcast64<T>(s);
+#if defined(__HIP_DEVICE_COMPILE__)
+    // (a quad that loads nothing ranks whatever the registers hold and nobody reads the result: "defined" without 32 v_mov per call)
+    asm volatile("" : "=v"(e1.x), "=v"(e1.y), "=v"(e2.x), "=v"(e2.y));
+#else
     e1 = make_ulonglong2(0, 0); e2 = e1;
+#endif
     if (qbcast32<T>(want)) {         // (a quad whose lane T has nothing pending loads nothing: idle lanes must not all hit one line)
         e1 = ((const ulonglong2 *)&ix.cp_occ[sp >> 6])[sub];
         e2 = ((const ulonglong2 *)&ix.cp_occ[ep >> 6])[sub];     // (also when both ends lie in one block, 4 of 10 calls: skipping the second request
                                                                  //  under a per-quad branch measured 18 % SLOWER, profiles/r03i_bench.json vs bench_sb)
     }
 }
+// What lane T gets back travels as four 32-bit quad sums (a 64-bit sum is three instructions per step, a 32-bit one can fold its
+// exchange into the add): occ and size of base a -- one lane contributes, so the halves add without carries -- and the sizes above a
+// as a 31-bit part (three of them stay below 2^32) and a high part, the three high parts sharing one word.  All counts are below 2^40.
+struct QuadOut { uint32_t xl, yl, zl, hw; };
 template <int T>
-static __device__ __forceinline__ void coop_rank(int64_t k, int64_t s, int a, int sub, const ulonglong2 e1, const ulonglong2 e2,
-                                                 int64_t &X, int64_t &Y, int64_t &Z) {
-    const int64_t sp = qbcast64<T>(k), ep = sp + qbcast64<T>(s);
+static __device__ __forceinline__ void coop_rank(int64_t k, int64_t s, int a, int sub, const ulonglong2 e1, const ulonglong2 e2, QuadOut &out) {
+    const int32_t spl = qbcast32<T>((int32_t)k), epl = spl + qbcast32<T>((int32_t)s);
     const int at = qbcast32<T>(a);
-    const int y1 = (int)(sp & 63), y2 = (int)(ep & 63);
-    const uint64_t m1 = y1 ? (~0ULL << (64 - y1)) : 0ULL, m2 = y2 ? (~0ULL << (64 - y2)) : 0ULL;   // one_hot_mask_array[y]
-    const int64_t o1 = (int64_t)e1.x + __popcll(e1.y & m1);
-    const int64_t d = (int64_t)e2.x + __popcll(e2.y & m2) - o1;
-    const int64_t x = qsum64(sub == at ? o1 : 0), y = qsum64(sub == at ? d : 0), z = qsum64(sub > at ? d : 0);
-    if (sub == T) { X = x; Y = y; Z = z; }
+    // the top y bits of the word (one_hot_mask_array[y], y = position in the block): (w >> 1) >> (63 - y) is 0 for y = 0 without a select
+    const int y1 = spl & 63, y2 = epl & 63;
+    const int64_t o1 = (int64_t)e1.x + __popcll((e1.y >> 1) >> (y1 ^ 63));
+    const int64_t d = (int64_t)e2.x + __popcll((e2.y >> 1) >> (y2 ^ 63)) - o1;
+    const bool is_at = sub == at, above = sub > at;
+    const uint32_t xl = qsum32(is_at ? (uint32_t)o1 : 0u), yl = qsum32(is_at ? (uint32_t)d : 0u);
+    const uint32_t zl = qsum32(above ? (uint32_t)d & 0x7fffffffu : 0u);
+    const uint32_t hw = qsum32(is_at ? (uint32_t)(o1 >> 32) | (uint32_t)(d >> 32) << 8 : above ? (uint32_t)(d >> 31) << 16 : 0u);
+    if (sub == T) { out.xl = xl; out.yl = yl; out.zl = zl; out.hw = hw; }
 }
 static __device__ __forceinline__ Bi backward_ext(const DevIndex &ix, Bi in, int a, bool want) {
     const int sub = (int)(threadIdx.x & 3);
@@ -79,9 +96,11 @@ static __device__ __forceinline__ Bi backward_ext(const DevIndex &ix, Bi in, int
     const int w = want ? 1 : 0;
     coop_issue<0>(ix, k, s, w, sub, e1[0], e2[0]); coop_issue<1>(ix, k, s, w, sub, e1[1], e2[1]);
     coop_issue<2>(ix, k, s, w, sub, e1[2], e2[2]); coop_issue<3>(ix, k, s, w, sub, e1[3], e2[3]);
-    int64_t X = 0, Y = 0, Z = 0;
-    coop_rank<0>(k, s, a, sub, e1[0], e2[0], X, Y, Z); coop_rank<1>(k, s, a, sub, e1[1], e2[1], X, Y, Z);
-    coop_rank<2>(k, s, a, sub, e1[2], e2[2], X, Y, Z); coop_rank<3>(k, s, a, sub, e1[3], e2[3], X, Y, Z);
+    QuadOut q = { 0, 0, 0, 0 };
+    coop_rank<0>(k, s, a, sub, e1[0], e2[0], q); coop_rank<1>(k, s, a, sub, e1[1], e2[1], q);
+    coop_rank<2>(k, s, a, sub, e1[2], e2[2], q); coop_rank<3>(k, s, a, sub, e1[3], e2[3], q);
+    const int64_t X = (int64_t)q.xl | (int64_t)(q.hw & 0xffu) << 32, Y = (int64_t)q.yl | (int64_t)((q.hw >> 8) & 0xffu) << 32;
+    const int64_t Z = (int64_t)q.zl + ((int64_t)(q.hw >> 16) << 31);
     const int64_t sent = (k <= ix.sentinel_index && k + s > ix.sentinel_index) ? 1 : 0;
     Bi out;
     out.k = pick4(a, ix.count[0], ix.count[1], ix.count[2], ix.count[3]) + X;

@@ -202,6 +202,35 @@ def test_sub_batch_pipelining_matches_single_part(tmp_path):
     _same(exp["REGPRG"], regs_to_records(r4, o4), "REGPRG")
 
 
+@pytest.mark.parametrize("name,L", [("g60k", 150), ("g20k_l76", 76)])
+def test_extension_rows_in_registers(golden_dir, name, L, tmp_path):
+    # the lane kernels with the row in a register array indexed by the wave-uniform column pair (BM2_EXT_REG_ROWS): the goldens' regs,
+    # and a fresh chunk of reads whose query-length classes fill whole wavefronts, against the LDS-row kernels
+    pre, enc, off, ln, d = load_golden(golden_dir, name)
+    os.environ["BM2_EXT_REG_ROWS"] = "1"
+    try:
+        ctx = bm2.Context(0, pre)
+        try:
+            regs, reg_off, st = ctx.seed_chain_extend(enc, off, ln, bm2.default_opt())
+        finally:
+            ctx.close()
+        _same(d["REGPRG"], regs_to_records(regs, reg_off), "REGPRG")
+        fa, (enc2, off2, ln2) = _fresh_case(tmp_path, 31, [200000, 100000], 3000, L)
+        c1 = bm2.Context(0, fa)
+        try:
+            r1, o1, s1 = c1.seed_chain_extend(enc2, off2, ln2, bm2.default_opt())
+        finally:
+            c1.close()
+    finally:
+        del os.environ["BM2_EXT_REG_ROWS"]
+    c0 = bm2.Context(0, fa)
+    try:
+        r0, o0, s0 = c0.seed_chain_extend(enc2, off2, ln2, bm2.default_opt())
+    finally:
+        c0.close()
+    assert o0.tobytes() == o1.tobytes() and r0.tobytes() == r1.tobytes() and s0 == s1
+
+
 def test_long_reads_ont2d_golden(gpu_ctx_factory, golden_dir):
     # config-5 shape: the seed filter (local SW per short seed), chains emptied by it, kb-long int16/int32-class extensions
     pre, enc, off, ln, d = load_golden(golden_dir, "g40k_ont")

@@ -116,6 +116,21 @@ static inline int emu_dpp(int old, int v, int ctrl, int row_mask, int bank_mask,
 #define __builtin_amdgcn_readfirstlane(v) EMU_AT(emu_readfirstlane((int)(v)))
 #define __builtin_amdgcn_update_dpp(old, v, ctrl, rm, bm, bc) EMU_AT(emu_dpp((int)(old), (int)(v), (ctrl), (rm), (bm), (bc)))
 #define __builtin_amdgcn_mov_dpp(v, ctrl, rm, bm, bc) EMU_AT(emu_dpp(0, (int)(v), (ctrl), (rm), (bm), (bc)))
+// v_perm_b32: byte i of the result = byte sel[i] of {s0 (bytes 4..7), s1 (bytes 0..3)}; 8..11 -> sign fill of 16-bit word sel - 8, 12 -> 0x00, 13.. -> 0xff
+static inline unsigned emu_perm(unsigned s0, unsigned s1, unsigned sel) {
+    const unsigned long long src = ((unsigned long long)s0 << 32) | s1;
+    unsigned r = 0;
+    for (int i = 0; i < 4; i++) {
+        const unsigned v = (sel >> (8 * i)) & 0xffu;
+        unsigned b;
+        if (v < 8) b = (unsigned)(src >> (8 * v)) & 0xffu;
+        else if (v < 12) b = ((src >> (16 * (v - 8) + 15)) & 1) ? 0xffu : 0u;       // sign fill of word v - 8
+        else b = v == 12 ? 0u : 0xffu;
+        r |= b << (8 * i);
+    }
+    return r;
+}
+#define __builtin_amdgcn_perm(s0, s1, sel) emu_perm((unsigned)(s0), (unsigned)(s1), (unsigned)(sel))
 #define __builtin_amdgcn_wave_barrier() emu_wsync()
 #define __builtin_amdgcn_fence(...) std::atomic_thread_fence(std::memory_order_seq_cst)
 #define __builtin_amdgcn_mbcnt_lo(m, c) ((int)(c) + __builtin_popcount((unsigned)(m) & (emu_t.lane >= 32 ? 0xffffffffu : ((1u << emu_t.lane) - 1u))))

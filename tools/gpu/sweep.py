@@ -22,12 +22,14 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 GRID = [   # (name, candidates): a candidate is a dict of knobs set together; the first one ({} = the library's defaults) is the incumbent
     ("chain staging", [{}, {"BM2_CHAIN_STAGE": 1}]),
-    ("chain heavy threshold", [{}, {"BM2_HEAVY_SA": 64}, {"BM2_HEAVY_SA": 40}, {"BM2_HEAVY_SA": 24}, {"BM2_HEAVY_SA": 160}]),
+    ("chain heavy threshold", [{}, {"BM2_HEAVY_SA": 64}, {"BM2_HEAVY_SA": 40}, {"BM2_HEAVY_SA": 24}, {"BM2_HEAVY_SA": 160}, {"BM2_HEAVY_SA": 256}, {"BM2_HEAVY_SA": 512}]),
     ("chain waves per CU", [{}, {"BM2_CHAIN_WAVES_PER_CU": 32}, {"BM2_CHAIN_WAVES_PER_CU": 8}]),
     ("k_bwd LDS survivors / blocks per CU / waves per SIMD", [{}, {"BM2_BWD_LCAP": 8, "BM2_BWD_BLOCKS_PER_CU": 4}, {"BM2_BWD_LCAP": 6, "BM2_BWD_BLOCKS_PER_CU": 4},
                                                               {"BM2_BWD_LCAP": 4, "BM2_BWD_BLOCKS_PER_CU": 4},
                                                               {"BM2_BWD_LCAP": 6, "BM2_BWD_BLOCKS_PER_CU": 5, "BM2_BWD_WAVES": 5},
                                                               {"BM2_BWD_LCAP": 4, "BM2_BWD_BLOCKS_PER_CU": 5, "BM2_BWD_WAVES": 5}]),
+    ("extension rows in registers", [{}, {"BM2_EXT_REG_ROWS": 1}, {"BM2_EXT_REG_ROWS": 1, "BM2_EXT_WAVE_QMIN": 129}, {"BM2_EXT_REG_ROWS": 1, "BM2_EXT_WAVE_QMIN": 97},
+                                     {"BM2_EXT_REG_ROWS": 1, "BM2_EXT_WAVE_QMIN": 161}]),
     ("extension wave classes", [{}, {"BM2_EXT_WAVE_QMIN": 129}, {"BM2_EXT_WAVE_QMIN": 97}, {"BM2_EXT_WAVE_QMIN": 161}]),
     ("extension dispatch order", [{}, {"BM2_EXT_REVERSE": 1}]),
     ("extension prefetch", [{}, {"BM2_EXT_PREFETCH": 0}]),
@@ -48,6 +50,7 @@ def main():
     ap.add_argument("--workdir", default=os.environ.get("BM2_BENCH_WORKDIR", "/tmp/bm2_bench"))
     ap.add_argument("--quick", action="store_true", help="two candidates per knob (a test of this script on the emulator)")
     ap.add_argument("--budget-s", type=float, default=90.0, help="stop sweeping (keep what is best so far) after this many seconds")
+    ap.add_argument("--only", default="", help="comma-separated substrings: sweep only the knobs whose name contains one of them")
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
     import bench
@@ -97,7 +100,10 @@ def main():
     log.append({"env": {}, "ms": base_ms, "stages": base_k, "crc": base_crc})
     best_ms = base_ms
     print("[sweep] default: %.2f ms/step %s" % (base_ms, {k: round(v, 2) for k, v in base_k.items()}), file=sys.stderr, flush=True)
+    only = [x for x in a.only.split(",") if x]
     for name, cands in GRID:
+        if only and not any(x in name for x in only):
+            continue
         if a.quick:
             cands = cands[:2]
         if time.time() - t_start > a.budget_s:
