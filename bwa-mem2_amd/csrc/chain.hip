@@ -433,7 +433,7 @@ static __device__ void chain_one_read(const DevIndex &ix, const ChainParams &o, 
     n_reg_out[r] = 0;              // set by k_chain_finish
 }
 
-__global__ void __launch_bounds__(128, 3)      // (room for two register copies of a B-tree node: 160 bytes each)
+__global__ void __launch_bounds__(128, 4)      // (127 VGPRs: room for two register copies of a B-tree node, 160 bytes each; 9 dwords spilled)
 k_chain(DevIndex ix, ChainParams o, int n_reads, const int32_t *__restrict__ len, const bm2_smem_t *__restrict__ smems,
         const int32_t *__restrict__ smem_cnt, const int64_t *__restrict__ smem_off, const int64_t *__restrict__ sa_off,
         const int64_t *__restrict__ sa_coord, WChain *wchain, WSeed *wseed, BtNode *nodes, int32_t *order,
