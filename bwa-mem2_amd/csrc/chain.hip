@@ -68,113 +68,80 @@ static __device__ __forceinline__ int cal_max_gap(const ChainParams &o, int qlen
 }
 
 // ---------------------------------------------------------------- klib B-tree, t = 5 (kbtree.h; kb_init(chn, 512+8), 48-byte keys)
-// A node is worked on as a REGISTER COPY: one wide load brings the whole node (160 bytes), the probes of __kb_getp_aux and the key
-// shifts of an insertion run on registers, one wide store puts it back.  The serial walk of a read pays a memory round trip per tree
-// LEVEL instead of one per probe and per shifted key (a leaf insertion was ~20 dependent accesses; reads of ~100 seeds set the
-// length of k_chain, reads of ~10^5 seeds that of a long-read chunk).
 #define BT_T 5
-#define BT_KEYS (2 * BT_T - 1)
 struct BTree { BtNode *nodes; int n_nodes, root, n_keys; const WChain *ch; };
 
-template <typename T, int N> static __device__ __forceinline__ T reg_get(const T (&v)[N], int i) {      // v[i], v in registers
-    T r = v[0];
-#pragma unroll
-    for (int t = 1; t < N; t++) r = i == t ? v[t] : r;
-    return r;
+static __device__ __forceinline__ int bt_new(BTree &b, int internal) {
+    BtNode &z = b.nodes[b.n_nodes];
+    z.n = 0; z.is_internal = internal;
+    return b.n_nodes++;
 }
-template <typename T, int N> static __device__ __forceinline__ void reg_set(T (&v)[N], int i, T x) {
-#pragma unroll
-    for (int t = 0; t < N; t++) v[t] = i == t ? x : v[t];
-}
-// v[t + 1] = v[t] for t = last down to first (the shifts of kbtree.h:188-191 and :208-209)
-template <typename T, int N> static __device__ __forceinline__ void reg_shift_up(T (&v)[N], int first, int last) {
-#pragma unroll
-    for (int t = N - 2; t >= 0; t--) v[t + 1] = (t >= first && t <= last) ? v[t] : v[t + 1];
-}
-
-static __device__ __forceinline__ int bt_new_id(BTree &b) { return b.n_nodes++; }
-// __kb_getp_aux, kbtree.h:124-138, on a register copy: its binary search ends at the first key that is not below k, i.e. at the number
-// of keys below k; the comparison with that key gives r
-static __device__ __forceinline__ int bt_getp_aux(const BtNode &x, int64_t k, int &r) {
+// __kb_getp_aux, kbtree.h:124-138
+static __device__ int bt_getp_aux(const BTree &b, const BtNode &x, int64_t k, int &r) {
+    int begin = 0, end = x.n;
     if (x.n == 0) return -1;
-    int below = 0, equal = 0;
-#pragma unroll
-    for (int t = 0; t < BT_KEYS; t++) {
-        below += (t < x.n && x.kpos[t] < k) ? 1 : 0;
-        equal |= (t < x.n && x.kpos[t] == k) ? 1 : 0;
+    while (begin < end) {
+        const int mid = (begin + end) >> 1;
+        if (x.kpos[mid] < k) begin = mid + 1; else end = mid;
     }
-    if (below == x.n) { r = 1; return x.n - 1; }
-    r = equal ? 0 : -1;
-    return equal ? below : below - 1;
+    if (begin == x.n) { r = 1; return x.n - 1; }
+    const int64_t kp = x.kpos[begin];
+    r = (kp < k) - (k < kp);
+    if (r < 0) --begin;
+    return begin;
 }
 // kb_intervalp, lower bound only (kbtree.h:158-175)
 static __device__ int bt_lower(const BTree &b, int64_t k) {
     int lower = -1, x = b.root, r = 0;
     while (x >= 0) {
-        const BtNode nd = b.nodes[x];
-        const int i = bt_getp_aux(nd, k, r);
-        if (i >= 0) lower = reg_get(nd.key, i);
-        if ((i >= 0 && r == 0) || !nd.is_internal) return lower;
-        x = reg_get(nd.ptr, i + 1);
+        const BtNode &nd = b.nodes[x];
+        const int i = bt_getp_aux(b, nd, k, r);
+        if (i >= 0 && r == 0) return nd.key[i];
+        if (i >= 0) lower = nd.key[i];
+        if (!nd.is_internal) return lower;
+        x = nd.ptr[i + 1];
     }
     return lower;
 }
-// __kb_split, kbtree.h:179-196: child yi of x (x = the register copy of node xi, not full; y = that of the child) is full; its
-// upper half moves to a new node
-static __device__ void bt_split(BTree &b, int xi, BtNode &x, int i, int yi, const BtNode &y) {
-    const int zi = bt_new_id(b);
-    BtNode z;
-#pragma unroll
-    for (int t = 0; t < BT_KEYS; t++) { z.key[t] = t < BT_T - 1 ? y.key[BT_T + t] : 0; z.kpos[t] = t < BT_T - 1 ? y.kpos[BT_T + t] : 0; }
-#pragma unroll
-    for (int t = 0; t < 2 * BT_T; t++) z.ptr[t] = (t < BT_T && y.is_internal) ? y.ptr[BT_T + t] : 0;
-    z.is_internal = y.is_internal; z.n = BT_T - 1; z.pad = 0;
-    b.nodes[zi] = z;
-    b.nodes[yi].n = BT_T - 1;
-    reg_shift_up(x.ptr, i + 1, x.n);
-    reg_set(x.ptr, i + 1, (int32_t)zi);
-    reg_shift_up(x.key, i, x.n - 1); reg_shift_up(x.kpos, i, x.n - 1);
-    reg_set(x.key, i, y.key[BT_T - 1]); reg_set(x.kpos, i, y.kpos[BT_T - 1]);
+// __kb_split, kbtree.h:179-196
+static __device__ void bt_split(BTree &b, int xi, int i, int yi) {
+    const int zi = bt_new(b, b.nodes[yi].is_internal);
+    BtNode &x = b.nodes[xi], &y = b.nodes[yi], &z = b.nodes[zi];
+    z.n = BT_T - 1;
+    for (int t = 0; t < BT_T - 1; t++) { z.key[t] = y.key[BT_T + t]; z.kpos[t] = y.kpos[BT_T + t]; }
+    if (y.is_internal) for (int t = 0; t < BT_T; t++) z.ptr[t] = y.ptr[BT_T + t];
+    y.n = BT_T - 1;
+    for (int t = x.n; t > i; t--) x.ptr[t + 1] = x.ptr[t];
+    x.ptr[i + 1] = zi;
+    for (int t = x.n - 1; t >= i; t--) { x.key[t + 1] = x.key[t]; x.kpos[t + 1] = x.kpos[t]; }
+    x.key[i] = y.key[BT_T - 1]; x.kpos[i] = y.kpos[BT_T - 1];
     ++x.n;
-    b.nodes[xi] = x;
 }
-// kb_putp + __kb_putp_aux, kbtree.h:197-231 (the recursion is a plain descent; the child is loaded once: its fill decides about the
-// split and it is the next node of the descent)
+// kb_putp + __kb_putp_aux, kbtree.h:197-231 (the recursion is a plain descent)
 static __device__ void bt_put(BTree &b, int key) {
     const int64_t k = b.ch[key].pos;
     ++b.n_keys;
-    int xi = b.root, r;
-    BtNode x = b.nodes[xi];
-    if (x.n == BT_KEYS) {
-        const int s = bt_new_id(b);
-        BtNode top;
-#pragma unroll
-        for (int t = 0; t < BT_KEYS; t++) { top.key[t] = 0; top.kpos[t] = 0; }
-#pragma unroll
-        for (int t = 0; t < 2 * BT_T; t++) top.ptr[t] = 0;
-        top.n = 0; top.is_internal = 1; top.pad = 0; top.ptr[0] = xi;
-        b.root = s;
-        bt_split(b, s, top, 0, xi, x);
-        xi = s; x = top;
+    if (b.nodes[b.root].n == 2 * BT_T - 1) {
+        const int s = bt_new(b, 1), r = b.root;
+        b.root = s; b.nodes[s].ptr[0] = r;
+        bt_split(b, s, 0, r);
     }
+    int xi = b.root, r;
     for (;;) {
+        BtNode &x = b.nodes[xi];
         if (!x.is_internal) {
-            const int i = bt_getp_aux(x, k, r);
-            reg_shift_up(x.key, i + 1, x.n - 1); reg_shift_up(x.kpos, i + 1, x.n - 1);
-            reg_set(x.key, i + 1, (int32_t)key); reg_set(x.kpos, i + 1, k);
+            const int i = bt_getp_aux(b, x, k, r);
+            for (int t = x.n - 1; t > i; t--) { x.key[t + 1] = x.key[t]; x.kpos[t + 1] = x.kpos[t]; }
+            x.key[i + 1] = key; x.kpos[i + 1] = k;
             ++x.n;
-            b.nodes[xi] = x;
             return;
         }
-        int i = bt_getp_aux(x, k, r) + 1;
-        int child = reg_get(x.ptr, i);
-        BtNode y = b.nodes[child];
-        if (y.n == BT_KEYS) {
-            bt_split(b, xi, x, i, child, y);
-            if (k > reg_get(x.kpos, i)) { ++i; child = reg_get(x.ptr, i); y = b.nodes[child]; }
-            else y.n = BT_T - 1;                         // (the lower half stays in this child: the copy follows the store)
+        int i = bt_getp_aux(b, x, k, r) + 1;
+        if (b.nodes[x.ptr[i]].n == 2 * BT_T - 1) {
+            bt_split(b, xi, i, x.ptr[i]);
+            if (k > x.kpos[i]) ++i;
         }
-        xi = child; x = y;
+        xi = x.ptr[i];
     }
 }
 // __kb_traverse (in-order), kbtree.h:343-366
@@ -203,9 +170,8 @@ static __device__ int bt_traverse(const BTree &b, int32_t *out) {
 
 // ---------------------------------------------------------------- chaining of one read
 // test_and_merge, bwamem.cpp:357-399
-static __device__ int test_and_merge(const ChainParams &o, int64_t l_pac, WChain *cp, const WSeed &p, int seed_rid,
+static __device__ int test_and_merge(const ChainParams &o, int64_t l_pac, WChain &c, const WSeed &p, int seed_rid,
                                      WSeed *seeds, int si) {
-    const WChain c = *cp;                          // (one wide load: the tests below would fetch the fields one after the other)
     const int64_t qend = c.last_qbeg + c.last_len, rend = c.last_rbeg + c.last_len;
     if (seed_rid != c.rid) return 0;
     if (p.qbeg >= c.first_qbeg && p.qbeg + p.len <= qend && p.rbeg >= c.pos && p.rbeg + p.len <= rend) return 1;
@@ -214,28 +180,30 @@ static __device__ int test_and_merge(const ChainParams &o, int64_t l_pac, WChain
     if (y >= 0 && x - y <= o.w && y - x <= o.w && x - c.last_len < o.max_chain_gap && y - c.last_len < o.max_chain_gap) {
         seeds[si] = p; seeds[si].next = -1;
         seeds[c.tail].next = si;
-        cp->tail = si; cp->n = c.n + 1;
-        cp->last_rbeg = p.rbeg; cp->last_qbeg = p.qbeg; cp->last_len = p.len;
+        c.tail = si; c.n++;
+        c.last_rbeg = p.rbeg; c.last_qbeg = p.qbeg; c.last_len = p.len;
         return 2;      // merged and consumed the seed slot
     }
     return 0;
 }
 
-// mem_chain_weight, bwamem.cpp:429-448: the query and the reference coverage in ONE walk of the seed list (every step of the walk is a
-// dependent load; the two sums do not depend on each other)
+// mem_chain_weight, bwamem.cpp:429-448
 static __device__ int chain_weight(const WChain &c, const WSeed *seeds) {
-    int64_t qe = 0, re = 0; int wq = 0, wr = 0;
-    for (int si = c.head; si >= 0; ) {
-        const WSeed s = seeds[si];
-        if (s.qbeg >= qe) wq += s.len;
-        else if (s.qbeg + s.len > qe) wq += (int)(s.qbeg + s.len - qe);
-        qe = qe > s.qbeg + s.len ? qe : s.qbeg + s.len;
-        if (s.rbeg >= re) wr += s.len;
-        else if (s.rbeg + s.len > re) wr += (int)(s.rbeg + s.len - re);
-        re = re > s.rbeg + s.len ? re : s.rbeg + s.len;
-        si = s.next;
+    int64_t end = 0; int w = 0, tmp;
+    for (int si = c.head; si >= 0; si = seeds[si].next) {
+        const WSeed &s = seeds[si];
+        if (s.qbeg >= end) w += s.len;
+        else if (s.qbeg + s.len > end) w += (int)(s.qbeg + s.len - end);
+        end = end > s.qbeg + s.len ? end : s.qbeg + s.len;
     }
-    const int w = wr < wq ? wr : wq;
+    tmp = w; w = 0; end = 0;
+    for (int si = c.head; si >= 0; si = seeds[si].next) {
+        const WSeed &s = seeds[si];
+        if (s.rbeg >= end) w += s.len;
+        else if (s.rbeg + s.len > end) w += (int)(s.rbeg + s.len - end);
+        end = end > s.rbeg + s.len ? end : s.rbeg + s.len;
+    }
+    w = w < tmp ? w : tmp;
     return w < 1 << 30 ? w : (1 << 30) - 1;
 }
 
@@ -278,8 +246,7 @@ static __device__ void chain_one_read(const DevIndex &ix, const ChainParams &o, 
     int32_t *ord = in_lds ? lw->ord : order + base;
     BtNode *nodes = in_lds ? lw->nodes : nodes_g + base;
     BTree bt; bt.nodes = nodes; bt.n_nodes = 0; bt.n_keys = 0; bt.ch = ch;     // <= n_sa/4 + 1 nodes are ever needed
-    bt.root = bt_new_id(bt);
-    nodes[bt.root].n = 0; nodes[bt.root].is_internal = 0;
+    bt.root = bt_new(bt, 0);
     int n_ch = 0, n_sd = 0;
     RidCache ridc; ridc.lo = 1; ridc.hi = 0; ridc.rid = -1;
     int b = 0, e = 0, l_rep = 0;
@@ -297,7 +264,6 @@ static __device__ void chain_one_read(const DevIndex &ix, const ChainParams &o, 
     // a wavefront then run max(seeds per read) iterations instead of the sum over SMEM ranks of the per-rank maxima
     {
         int si = -1, left = 0, qbeg = 0, slen = 0;
-        int64_t rbeg_next = staged ? 0 : sa_coord[base];          // (requested a seed ahead: the walk never waits for a coordinate)
         for (int t = 0; t < n_sa; t++) {
             WSeed s; int rid, alt_staged = 0;
             if (staged) {
@@ -311,8 +277,7 @@ static __device__ void chain_one_read(const DevIndex &ix, const ChainParams &o, 
                     qbeg = (int)smems[so + si].m; slen = (int)(smems[so + si].n + 1 - smems[so + si].m);
                 }
                 --left;
-                s.rbeg = rbeg_next; s.qbeg = qbeg; s.len = slen; s.next = -1;
-                if (t + 1 < n_sa) rbeg_next = sa_coord[base + t + 1];
+                s.rbeg = sa_coord[base + t]; s.qbeg = qbeg; s.len = slen; s.next = -1;
                 rid = intv2rid_cached(ix, s.rbeg, s.rbeg + s.len, ridc);
             }
             if (rid < 0) continue;                       // bwamem.cpp:915-919
@@ -321,7 +286,7 @@ static __device__ void chain_one_read(const DevIndex &ix, const ChainParams &o, 
                 const int lower = bt_lower(bt, s.rbeg);
                 if (lower < 0) to_add = 1;
                 else {
-                    const int m = test_and_merge(o, ix.l_pac, &ch[lower], s, rid, sd, n_sd);
+                    const int m = test_and_merge(o, ix.l_pac, ch[lower], s, rid, sd, n_sd);
                     if (m == 2) n_sd++;
                     else if (m == 0) to_add = 1;
                 }
@@ -353,53 +318,36 @@ static __device__ void chain_one_read(const DevIndex &ix, const ChainParams &o, 
     n = k;
     if (n > 0) {
         k_introsort_flat(n, ord, [&](int32_t x, int32_t y) { return ch[x].w > ch[y].w; });     // flt_lt, bwamem.cpp:61
-        // The kept chains, in the B-tree's space (no longer needed): what the overlap test reads of a kept chain sits in ONE 16-byte
-        // record per chain, consecutive -- the reference's loop costs three dependent loads per (chain, kept chain) pair
-        // (kept_list -> ord -> chain), here four records are requested at once and tested in order.
-        KeptInfo *ki = (KeptInfo *)nodes;
-        int32_t *kept_list = (int32_t *)(ki + n);                // indices into ord
+        // `kept chain list` reuses the tail of the order array's sibling: indices into ord
+        int32_t *kept_list = (int32_t *)nodes;                   // the B-tree is no longer needed
         int n_kept = 0;
-        {
-            WChain &c0 = ch[ord[0]];
-            c0.kept = 3;
-            KeptInfo e; e.beg = c0.first_qbeg; e.end = c0.last_qbeg + c0.last_len; e.w_alt = (uint32_t)c0.w | (c0.is_alt ? 1u << 31 : 0u); e.first = -1;
-            ki[0] = e; kept_list[0] = 0; n_kept = 1;
-        }
+        ch[ord[0]].kept = 3;
+        kept_list[n_kept++] = 0;
         for (int i = 1; i < n; ++i) {
             WChain &ci = ch[ord[i]];
-            const int beg_i = ci.first_qbeg, end_i = ci.last_qbeg + ci.last_len, w_i = ci.w, alt_i = ci.is_alt;
-            int large_ovlp = 0;
-            bool stop = false;
-            for (int kk = 0; kk < n_kept && !stop; kk += 4) {
-                KeptInfo e[4];
-#pragma unroll
-                for (int u = 0; u < 4; u++) e[u] = ki[kk + u < n_kept ? kk + u : n_kept - 1];
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    if (stop || kk + u >= n_kept) continue;
-                    const int beg_j = e[u].beg, end_j = e[u].end, w_j = (int)(e[u].w_alt & 0x7fffffffu), alt_j = (int)(e[u].w_alt >> 31);
-                    const int b_max = beg_j > beg_i ? beg_j : beg_i;
-                    const int e_min = end_j < end_i ? end_j : end_i;
-                    if (e_min > b_max && (!alt_j || alt_i)) {
-                        const int li = end_i - beg_i, lj = end_j - beg_j;
-                        const int min_l = li < lj ? li : lj;
-                        if (e_min - b_max >= min_l * o.mask_level && min_l < o.max_chain_gap) {
-                            large_ovlp = 1;
-                            if (e[u].first < 0) ki[kk + u].first = i;
-                            if (w_i < w_j * o.drop_ratio && w_j - w_i >= o.min_seed_len << 1) stop = true;
-                        }
+            const int beg_i = ci.first_qbeg, end_i = ci.last_qbeg + ci.last_len;
+            int large_ovlp = 0, kk;
+            for (kk = 0; kk < n_kept; ++kk) {
+                const int j = kept_list[kk];
+                WChain &cj = ch[ord[j]];
+                const int beg_j = cj.first_qbeg, end_j = cj.last_qbeg + cj.last_len;
+                const int b_max = beg_j > beg_i ? beg_j : beg_i;
+                const int e_min = end_j < end_i ? end_j : end_i;
+                if (e_min > b_max && (!cj.is_alt || ci.is_alt)) {
+                    const int li = end_i - beg_i, lj = end_j - beg_j;
+                    const int min_l = li < lj ? li : lj;
+                    if (e_min - b_max >= min_l * o.mask_level && min_l < o.max_chain_gap) {
+                        large_ovlp = 1;
+                        if (cj.first < 0) cj.first = i;
+                        if (ci.w < cj.w * o.drop_ratio && cj.w - ci.w >= o.min_seed_len << 1) break;
                     }
                 }
             }
-            if (!stop) {
-                KeptInfo e; e.beg = beg_i; e.end = end_i; e.w_alt = (uint32_t)w_i | (alt_i ? 1u << 31 : 0u); e.first = -1;
-                ki[n_kept] = e; kept_list[n_kept] = i; n_kept++;
-                ci.kept = large_ovlp ? 2 : 3;
-            }
+            if (kk == n_kept) { kept_list[n_kept++] = i; ci.kept = large_ovlp ? 2 : 3; }
         }
         for (int i = 0; i < n_kept; ++i) {
-            const int first = ki[i].first;
-            if (first >= 0) { ch[ord[kept_list[i]]].first = first; ch[ord[first]].kept = 1; }
+            const WChain &c = ch[ord[kept_list[i]]];
+            if (c.first >= 0) ch[ord[c.first]].kept = 1;
         }
         int i2;
         for (i2 = k = 0; i2 < n; ++i2) {
@@ -433,7 +381,7 @@ static __device__ void chain_one_read(const DevIndex &ix, const ChainParams &o, 
     n_reg_out[r] = 0;              // set by k_chain_finish
 }
 
-__global__ void __launch_bounds__(128, 4)      // (127 VGPRs: room for two register copies of a B-tree node, 160 bytes each; 9 dwords spilled)
+__global__ void __launch_bounds__(128, 6)
 k_chain(DevIndex ix, ChainParams o, int n_reads, const int32_t *__restrict__ len, const bm2_smem_t *__restrict__ smems,
         const int32_t *__restrict__ smem_cnt, const int64_t *__restrict__ smem_off, const int64_t *__restrict__ sa_off,
         const int64_t *__restrict__ sa_coord, WChain *wchain, WSeed *wseed, BtNode *nodes, int32_t *order,
@@ -460,11 +408,7 @@ static __device__ __forceinline__ void chain_wave_sync() {      // lanes of one 
 // tiered by seed count so that a block claims only the LDS its reads need (tier capacity `cap`: reads with lo < seeds <= cap; the
 // last tier also takes the reads beyond its capacity and works on their global slices).  Items come from the heavy-first list of
 // the partition; every tier scans it and skips what is not its own.
-// WPE: wavefronts per SIMD the register allocation leaves room for (4: 126 VGPRs, both register copies of a node stay in registers;
-// 5: 96, 6: 80 with 28 / 68 dwords spilled).  The tiers are bound by their LDS; the overflow launch -- reads that walk global memory,
-// a chunk of long reads has thousands of them -- by how many walks are in flight.
-template <int WPE>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE)))
+__global__ void __launch_bounds__(64)
 k_chain_heavy(DevIndex ix, ChainParams o, int n_reads, const int32_t *__restrict__ len, const bm2_smem_t *__restrict__ smems,
               const int32_t *__restrict__ smem_cnt, const int64_t *__restrict__ smem_off, const int64_t *__restrict__ sa_off,
               const int64_t *__restrict__ sa_coord, WChain *wchain, WSeed *wseed, BtNode *nodes, int32_t *order,
@@ -630,7 +574,7 @@ int bm2_launch_chain(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_
         const int stage = bm2_knob("BM2_CHAIN_STAGE", 1);     // (sweep of round 3, profiles/r03a_sweep.json: chaining 12.4 -> 10.3 ms)
         const int caps[BM2_CHAIN_TIERS] = { 64, 128, 256, 512, stage ? 1000 : 1184 };       // (the last tier fills a CU's 160 KB of LDS)
         static bool attr_set = false;
-        if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_chain_heavy<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+        if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_chain_heavy, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
         // reads with more seeds than the largest tier holds: a launch of their own where they are the norm (long reads), otherwise the last tier's
         const bool own_overflow = max_len >= bm2_knob("BM2_CHAIN_OVF_MIN_LEN", 1000);
         int lo = heavy_thr;
@@ -641,7 +585,7 @@ int bm2_launch_chain(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_
             const int per_cu_max = bm2_knob("BM2_CHAIN_WAVES_PER_CU", 16);
             int per_cu = (int)(160 * 1024 / lds); if (per_cu < 1) per_cu = 1; if (per_cu > per_cu_max) per_cu = per_cu_max;
             (void)hipStreamWaitEvent(sk, c->ev_fork, 0);
-            hipLaunchKernelGGL(k_chain_heavy<4>, dim3(c->n_cu * per_cu), dim3(64), lds, sk, c->ix, o, n_reads, len, smems, smem_cnt, smem_off, sa_off,
+            hipLaunchKernelGGL(k_chain_heavy, dim3(c->n_cu * per_cu), dim3(64), lds, sk, c->ix, o, n_reads, len, smems, smem_cnt, smem_off, sa_off,
                                sa_coord, wchain, wseed, nodes, order, chn, seeds_out, seed_owner, n_chain_out, n_reg_out, n_chain0_out, perm,
                                n_heavy_dev, n_sa_read, lo, caps[t], (t == BM2_CHAIN_TIERS - 1 && !own_overflow) ? 1 : 0, item_cur + t, stage);
             (void)hipEventRecord(c->ev_join[2 + t], sk);
@@ -654,10 +598,9 @@ int bm2_launch_chain(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_
         // (Short-read chunks keep the old routing: a read of theirs beyond 1000 seeds is a rarity, and one more launch scanning the heavy list is not free.)
         if (own_overflow) {
             hipStream_t sk = c->side_stream[2 + BM2_CHAIN_TIERS];
-            const int per_cu = bm2_knob("BM2_CHAIN_OVF_WAVES_PER_CU", 32), wpe = bm2_knob("BM2_CHAIN_OVF_WAVES_PER_EU", 4);
+            const int per_cu = bm2_knob("BM2_CHAIN_OVF_WAVES_PER_CU", 32);
             (void)hipStreamWaitEvent(sk, c->ev_fork, 0);
-            auto kern = wpe >= 6 ? k_chain_heavy<6> : wpe == 5 ? k_chain_heavy<5> : k_chain_heavy<4>;
-            hipLaunchKernelGGL(kern, dim3(c->n_cu * per_cu), dim3(64), bm2_chain_lds_bytes(0, 0), sk, c->ix, o, n_reads, len, smems, smem_cnt, smem_off, sa_off,
+            hipLaunchKernelGGL(k_chain_heavy, dim3(c->n_cu * per_cu), dim3(64), bm2_chain_lds_bytes(0, 0), sk, c->ix, o, n_reads, len, smems, smem_cnt, smem_off, sa_off,
                                sa_coord, wchain, wseed, nodes, order, chn, seeds_out, seed_owner, n_chain_out, n_reg_out, n_chain0_out, perm,
                                n_heavy_dev, n_sa_read, lo, 0, 1, item_cur + BM2_CHAIN_TIERS, 0);
             (void)hipEventRecord(c->ev_join[2 + BM2_CHAIN_TIERS], sk);

@@ -14,12 +14,6 @@ struct WChain {                      // mem_chain_t while it is in the B-tree; f
     int32_t n, rid, is_alt, head, tail, w, kept, first, pad;
 };
 
-struct __attribute__((aligned(16))) KeptInfo {     // a kept chain as mem_chain_flt's overlap test sees it
-    int32_t beg, end;                // query span
-    uint32_t w_alt;                  // weight (< 2^30) | is_alt << 31
-    int32_t first;                   // the first chain it shadows, -1 = none
-};
-
 struct BtNode {                      // kbnode_t with t = 5: up to 9 keys (chain indices) and 10 children (node indices).
     int64_t kpos[9];                 // the key's sort field (chain.pos) is kept next to the index so that a search touches the
     int32_t key[9];                  // node only (one memory round trip per level instead of one per probe)

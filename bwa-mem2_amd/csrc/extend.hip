@@ -935,7 +935,7 @@ struct ExtLaunch {
     // launch policy (bm2_knob): which kernel takes a query-length class.  Every launch of a side lasts about as long as its slowest
     // wavefront, and a lane-per-task wavefront of 150-base queries walks ~30 k cells one after the other (milliseconds), so the
     // classes with few tasks or long queries go one task per WAVEFRONT (k_ext_wave: ~0.1 ms per task) beside the lane kernels.
-    int wave_qmin, wave_nmax, prefetch, rev, reg_rows;
+    int wave_qmin, wave_nmax, prefetch, rev, reg_rows, reg_rows_max;
 };
 
 // Left side, then right side (whose h0 is the left score).  Lane-per-task kernels per query-length class (each class needs
@@ -943,7 +943,7 @@ struct ExtLaunch {
 // context's side streams, joined by events before the other side starts.
 static int run_sides(const ExtLaunch &L, const uint32_t *h_hist, const uint32_t *h_start, const int32_t *taskL, const int32_t *taskR) {
     static const int cls_lds[N_CLS] = { 16, 32, 48, 64, 80, 96, 112, 128, 144, 160 };
-    static const int cls_reg[N_CLS] = { 14, 30, 46, 62, 78, 94, 110, 126, 142, 160 };     // (a register block holds 64 columns, the one past the query included)
+    static const int cls_reg[N_CLS] = { 14, 30, 46, 62, 78, 94, 112, 128, 144, 160 };     // (a register block holds 64 columns, the one past the query included)
     const int *cls_hi = L.reg_rows && L.pack8 ? cls_reg : cls_lds;
     bm2_ctx *c = L.c;
     for (int side = 0; side < 2; side++) {
@@ -980,7 +980,7 @@ static int run_sides(const ExtLaunch &L, const uint32_t *h_hist, const uint32_t 
                 auto kern = side == 0 ? (L.pack8 ? (L.prefetch ? k_ext_lanes<0, true, true> : k_ext_lanes<0, true, false>) : k_ext_lanes<0, false, false>)
                                       : (L.pack8 ? (L.prefetch ? k_ext_lanes<1, true, true> : k_ext_lanes<1, true, false>) : k_ext_lanes<1, false, false>);
                 size_t lds_k = lds;
-                if (L.pack8 && L.reg_rows && hi <= 190) {           // the class's row in registers: 64 columns per block, column `hi` included
+                if (L.pack8 && L.reg_rows && hi <= L.reg_rows_max && hi <= 190) {      // the class's row in registers: 64 columns per block, column `hi` included
                     const int rb = hi <= 62 ? 1 : hi <= 126 ? 2 : 3;
                     kern = side == 0 ? (rb == 1 ? k_ext_lanes<0, true, false, 1> : rb == 2 ? k_ext_lanes<0, true, false, 2> : k_ext_lanes<0, true, false, 3>)
                                      : (rb == 1 ? k_ext_lanes<1, true, false, 1> : rb == 2 ? k_ext_lanes<1, true, false, 2> : k_ext_lanes<1, true, false, 3>);
@@ -1027,6 +1027,7 @@ int bm2_launch_extend(bm2_ctx *c, const bm2_opt &opt, const ChainParams &cp, int
     L.prefetch = bm2_knob("BM2_EXT_PREFETCH", 1);
     L.rev = bm2_knob("BM2_EXT_REVERSE", 1);      // (sweep of round 3: -0.6 ms)
     L.reg_rows = bm2_knob("BM2_EXT_REG_ROWS", 0);
+    L.reg_rows_max = bm2_knob("BM2_EXT_REG_ROWS_MAX", 94);           // classes of longer queries keep their rows in LDS
     for (int k : { 0, 1, 4 }) if (opt.mat[k] < -128 || opt.mat[k] > 127) L.reg_rows = 0;     // (its score table holds signed bytes)
     const int lazy_rounds = bm2_knob("BM2_EXT_ROUNDS", LAZY_ROUNDS), pend_div = bm2_knob("BM2_EXT_PEND_DIV", 12);
     L.R = ring_size2(opt.w << (MAX_BAND_TRY - 1));
