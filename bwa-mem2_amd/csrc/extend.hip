@@ -208,7 +208,11 @@ static __device__ void lane_dp(bool run, int qlen, int tlen, int w, int h0, cons
 // PF: the row word of the NEXT column pair is requested (unconditionally: one row past the band still lies inside the block's
 // LDS) before the current pair is computed, so the LDS round trip overlaps the ~80 VALU instructions of a pair instead of
 // preceding them; what it buys depends on how many wavefronts share the SIMD (few, for the long classes).
-template <bool PF>
+// PT: the query sits one base per BYTE (4 to a dword) and the cell's score comes from a byte permute: the row's five scores (against
+// A, C, G, T, N) are five bytes of a register pair, ONE v_perm_b32 with the query word as its selector turns four query bases into
+// their four scores -- the two compares and two selects per cell of the 4-bit layout are gone (27 -> 22 VALU per cell).
+static __device__ __forceinline__ uint32_t rep4(int x) { return ((uint32_t)x & 0xffu) * 0x01010101u; }
+template <bool PF, bool PT = false>
 static __device__ void lane_dp8(bool run, int qlen, int tlen, int w, int h0, const uint8_t *tp, int ts, const SwParams &P,
                                 uint32_t *EH, const uint32_t *QL, int lane, LaneOut &out, long long &cells) {
     const int o_del = P.o_del, e_del = P.e_del, o_ins = P.o_ins, e_ins = P.e_ins, oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
@@ -216,6 +220,7 @@ static __device__ void lane_dp8(bool run, int qlen, int tlen, int w, int h0, con
     // (the three scores are operands of v_cndmask in every cell, which takes both sources from VGPRs: kept there, or the compiler
     //  re-materialises them from SGPRs with a v_mov per use -- 3 of a cell's 33 VALU instructions)
     asm volatile("" : "+v"(sc_match), "+v"(sc_mis), "+v"(sc_amb));
+    const uint32_t rep_mis = rep4(sc_mis), rep_amb = rep4(sc_amb);
     const int e1 = h0 > oe_ins ? h0 - oe_ins : 0;                // first row, bandedSWA.cpp:143-145
     const int cls = pair_class(tlen, qlen, h0, P.max_sc);
     const int maxq = __builtin_amdgcn_readlane(wave_scan_max(run ? qlen : 0, 0), 63);
@@ -251,7 +256,13 @@ static __device__ void lane_dp8(bool run, int qlen, int tlen, int w, int h0, con
         const int jlo = (1 << 20) - __builtin_amdgcn_readlane(wave_scan_max(alive ? (1 << 20) - beg : 0, 0), 63);
         const int jhi = __builtin_amdgcn_readlane(wave_scan_max(alive ? end : 0, 0), 63);
         const int jp0 = jlo & ~1;
-        uint32_t qw = jp0 < jhi ? QL[(jp0 >> 3) * 64 + lane] >> (4 * (jp0 & 7)) : 0u;     // 8 query bases per word; the next word when a pair starts one
+        // PT: scores of this row against the query codes 0..4: bytes 0..3 of t_lo (the target's own base: match; target N: ambiguous), byte 0 of t_hi
+        const uint32_t t_lo = tb > 3 ? rep_amb : rep_mis ^ ((uint32_t)((sc_mis ^ sc_match) & 0xff) << (8 * tb)), t_hi = rep_amb;
+        uint32_t qw, qnext = 0u;
+        if (PT) {                                                                          // 4 score bytes per word; `qw` holds the current pair's in its low half
+            qw = jp0 < jhi ? __builtin_amdgcn_perm(t_hi, t_lo, QL[(jp0 >> 2) * 64 + lane]) >> (8 * (jp0 & 3)) : 0u;
+            qnext = ((jp0 | 3) + 1) < jhi ? QL[((jp0 >> 2) + 1) * 64 + lane] : 0u;
+        } else qw = jp0 < jhi ? QL[(jp0 >> 3) * 64 + lane] >> (4 * (jp0 & 7)) : 0u;       // 8 query bases per word; the next word when a pair starts one
         uint32_t wnext = PF ? EH[(jp0 >> 1) * 64 + lane] : 0u;
         for (int jp = jp0; jp < jhi; jp += 2) {
             const uint32_t wcur = wnext;
@@ -265,7 +276,7 @@ static __device__ void lane_dp8(bool run, int qlen, int tlen, int w, int h0, con
                         const int qb = (int)((qw >> (4 * u)) & 15u);
                         const int e = (int)((word >> (16 * u + 8)) & 0xffu);
                         int M = (int)((word >> (16 * u)) & 0xffu);
-                        const int sc = qb == tb ? s_eq : (qb > 3 ? sc_amb : s_ne);
+                        const int sc = PT ? (int)(int8_t)(qw >> (8 * u)) : qb == tb ? s_eq : (qb > 3 ? sc_amb : s_ne);
                         M = M ? M + sc : 0;
                         int h = M > e ? M : e;
                         h = h > f ? h : f;
@@ -283,8 +294,13 @@ static __device__ void lane_dp8(bool run, int qlen, int tlen, int w, int h0, con
                 }
                 EH[(jp >> 1) * 64 + lane] = word;
             }
-            qw >>= 8;
-            if (((jp + 2) & 7) == 0 && jp + 2 < jhi) qw = QL[((jp + 2) >> 3) * 64 + lane];
+            if (PT) {
+                qw >>= 16;
+                if (((jp + 2) & 3) == 0) { qw = __builtin_amdgcn_perm(t_hi, t_lo, qnext); if (jp + 6 < jhi) qnext = QL[((jp + 2) >> 2) * 64 + 64 + lane]; }
+            } else {
+                qw >>= 8;
+                if (((jp + 2) & 7) == 0 && jp + 2 < jhi) qw = QL[((jp + 2) >> 3) * 64 + lane];
+            }
         }
         const int m = (int)(key >> 8), mj = (int)(key & 255u), fnz = (int)fnz_u;
         if (alive) {
@@ -323,7 +339,6 @@ static __device__ void lane_dp8(bool run, int qlen, int tlen, int w, int h0, con
 // register pair, and ONE v_perm_b32 with the query word as its selector turns four query bases into their four scores (the cell's
 // two compares and two selects of the 4-bit layout are gone); the next word is requested four columns ahead.
 typedef uint32_t bm2_u32x32 __attribute__((ext_vector_type(32)));
-static __device__ __forceinline__ uint32_t rep4(int x) { return ((uint32_t)x & 0xffu) * 0x01010101u; }
 
 template <int NB>
 static __device__ void lane_dp8r(bool run, int qlen, int tlen, int w, int h0, const uint8_t *tp, int ts, const SwParams &P,
@@ -454,7 +469,7 @@ static __device__ void lane_dp8r(bool run, int qlen, int tlen, int w, int h0, co
     if (run) { out.score = maxv; out.qle = max_j + 1; out.tle = max_i + 1; out.gtle = max_ie + 1; out.gscore = gscore; out.max_off = max_off; }
 }
 
-template <int SIDE, bool P8, bool PF, int RB = 0>      // RB > 0: rows in registers, RB blocks of 64 columns (lane_dp8r)
+template <int SIDE, bool P8, bool PF, int RB = 0, bool PT = false>      // RB > 0: rows in registers, RB blocks of 64 columns (lane_dp8r); PT: scores by byte permute
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RB == 2 ? 4 : 1)))       // (RB == 2: 132 VGPRs without the hint)
 k_ext_lanes(DevIndex ix, ExtParams xp, const int32_t *__restrict__ tasks, int n_tasks, int qmax,
             const uint8_t *__restrict__ enc, const int64_t *__restrict__ off, const int32_t *__restrict__ len,
@@ -485,7 +500,7 @@ k_ext_lanes(DevIndex ix, ExtParams xp, const int32_t *__restrict__ tasks, int n_
     }
     // stage the query bases
     const int maxq = __builtin_amdgcn_readlane(wave_scan_max(valid ? tg.len2 : 0, 0), 63);
-    if (RB) {                                                   // one base per byte, 4 to a dword: the selector words of lane_dp8r
+    if (RB || PT) {                                             // one base per byte, 4 to a dword: the selector words of the byte permute
         for (int j0 = 0; j0 < maxq; j0 += 4) {
             if (valid && j0 < tg.len2) {
                 uint32_t wq = 0;
@@ -514,7 +529,7 @@ k_ext_lanes(DevIndex ix, ExtParams xp, const int32_t *__restrict__ tasks, int n_
         const int w = xp.w << t;
         const int wc = band_clamp(w, tg.len2, P, cls);
         if constexpr (RB > 0) lane_dp8r<RB>(run, tg.len2, tg.len1, wc, h0, tg.t, tg.ts, P, QL8, lane, o, cells);
-        else if (P8) lane_dp8<PF>(run, tg.len2, tg.len1, wc, h0, tg.t, tg.ts, P, EH, QL8, lane, o, cells);
+        else if (P8) lane_dp8<PF, PT>(run, tg.len2, tg.len1, wc, h0, tg.t, tg.ts, P, EH, QL8, lane, o, cells);
         else lane_dp(run, tg.len2, tg.len1, wc, h0, tg.t, tg.ts, P, EH, QL, lane, o, cells);
         if (run) {
             w_used = w;
@@ -935,7 +950,7 @@ struct ExtLaunch {
     // launch policy (bm2_knob): which kernel takes a query-length class.  Every launch of a side lasts about as long as its slowest
     // wavefront, and a lane-per-task wavefront of 150-base queries walks ~30 k cells one after the other (milliseconds), so the
     // classes with few tasks or long queries go one task per WAVEFRONT (k_ext_wave: ~0.1 ms per task) beside the lane kernels.
-    int wave_qmin, wave_nmax, prefetch, rev, reg_rows, reg_rows_max;
+    int wave_qmin, wave_nmax, prefetch, rev, reg_rows, reg_rows_max, perm_scores;
 };
 
 // Left side, then right side (whose h0 is the left score).  Lane-per-task kernels per query-length class (each class needs
@@ -980,6 +995,10 @@ static int run_sides(const ExtLaunch &L, const uint32_t *h_hist, const uint32_t 
                 auto kern = side == 0 ? (L.pack8 ? (L.prefetch ? k_ext_lanes<0, true, true> : k_ext_lanes<0, true, false>) : k_ext_lanes<0, false, false>)
                                       : (L.pack8 ? (L.prefetch ? k_ext_lanes<1, true, true> : k_ext_lanes<1, true, false>) : k_ext_lanes<1, false, false>);
                 size_t lds_k = lds;
+                if (L.pack8 && L.perm_scores && L.prefetch) {       // the LDS-row kernel with the byte-permute score table (query one base per byte)
+                    kern = side == 0 ? k_ext_lanes<0, true, true, 0, true> : k_ext_lanes<1, true, true, 0, true>;
+                    lds_k = (size_t)((hi + 2) / 2) * 64 * 4 + (size_t)((hi + 3) / 4 + 1) * 64 * 4;
+                }
                 if (L.pack8 && L.reg_rows && hi <= L.reg_rows_max && hi <= 190) {      // the class's row in registers: 64 columns per block, column `hi` included
                     const int rb = hi <= 62 ? 1 : hi <= 126 ? 2 : 3;
                     kern = side == 0 ? (rb == 1 ? k_ext_lanes<0, true, false, 1> : rb == 2 ? k_ext_lanes<0, true, false, 2> : k_ext_lanes<0, true, false, 3>)
@@ -1028,7 +1047,8 @@ int bm2_launch_extend(bm2_ctx *c, const bm2_opt &opt, const ChainParams &cp, int
     L.rev = bm2_knob("BM2_EXT_REVERSE", 1);      // (sweep of round 3: -0.6 ms)
     L.reg_rows = bm2_knob("BM2_EXT_REG_ROWS", 0);
     L.reg_rows_max = bm2_knob("BM2_EXT_REG_ROWS_MAX", 94);           // classes of longer queries keep their rows in LDS
-    for (int k : { 0, 1, 4 }) if (opt.mat[k] < -128 || opt.mat[k] > 127) L.reg_rows = 0;     // (its score table holds signed bytes)
+    L.perm_scores = bm2_knob("BM2_EXT_PERM_SCORES", 0);
+    for (int k : { 0, 1, 4 }) if (opt.mat[k] < -128 || opt.mat[k] > 127) L.reg_rows = L.perm_scores = 0;     // (the score table holds signed bytes)
     const int lazy_rounds = bm2_knob("BM2_EXT_ROUNDS", LAZY_ROUNDS), pend_div = bm2_knob("BM2_EXT_PEND_DIV", 12);
     L.R = ring_size2(opt.w << (MAX_BAND_TRY - 1));
     L.lds_w = ((sizeof(ExtParams) + 3) / 4) * 4 + (size_t)4 * 2 * L.R * 4;

@@ -202,12 +202,14 @@ def test_sub_batch_pipelining_matches_single_part(tmp_path):
     _same(exp["REGPRG"], regs_to_records(r4, o4), "REGPRG")
 
 
+@pytest.mark.parametrize("knob", ["BM2_EXT_REG_ROWS", "BM2_EXT_PERM_SCORES"])
 @pytest.mark.parametrize("name,L", [("g60k", 150), ("g20k_l76", 76)])
-def test_extension_rows_in_registers(golden_dir, name, L, tmp_path):
-    # the lane kernels with the row in a register array indexed by the wave-uniform column pair (BM2_EXT_REG_ROWS): the goldens' regs,
-    # and a fresh chunk of reads whose query-length classes fill whole wavefronts, against the LDS-row kernels
+def test_extension_lane_kernel_variants(golden_dir, name, L, knob, tmp_path):
+    # the lane kernels with the row in a register array indexed by the wave-uniform column pair (BM2_EXT_REG_ROWS) / with the cell's
+    # score from a byte permute over the row's score table (BM2_EXT_PERM_SCORES): the goldens' regs, and a fresh chunk of reads whose
+    # query-length classes fill whole wavefronts, against the default kernels
     pre, enc, off, ln, d = load_golden(golden_dir, name)
-    os.environ["BM2_EXT_REG_ROWS"] = "1"
+    os.environ[knob] = "1"
     try:
         ctx = bm2.Context(0, pre)
         try:
@@ -222,7 +224,7 @@ def test_extension_rows_in_registers(golden_dir, name, L, tmp_path):
         finally:
             c1.close()
     finally:
-        del os.environ["BM2_EXT_REG_ROWS"]
+        del os.environ[knob]
     c0 = bm2.Context(0, fa)
     try:
         r0, o0, s0 = c0.seed_chain_extend(enc2, off2, ln2, bm2.default_opt())
