@@ -24,6 +24,7 @@ GRID = [   # (name, candidates): a candidate is a dict of knobs set together; th
     ("chain staging", [{}, {"BM2_CHAIN_STAGE": 1}]),
     ("chain heavy threshold", [{}, {"BM2_HEAVY_SA": 64}, {"BM2_HEAVY_SA": 40}, {"BM2_HEAVY_SA": 24}, {"BM2_HEAVY_SA": 160}, {"BM2_HEAVY_SA": 256}, {"BM2_HEAVY_SA": 512}]),
     ("chain waves per CU", [{}, {"BM2_CHAIN_WAVES_PER_CU": 32}, {"BM2_CHAIN_WAVES_PER_CU": 8}]),
+    ("k_bwd non-temporal loads", [{}, {"BM2_BWD_NT": 1}]),
     ("k_bwd LDS survivors / blocks per CU / waves per SIMD", [{}, {"BM2_BWD_LCAP": 8, "BM2_BWD_BLOCKS_PER_CU": 4}, {"BM2_BWD_LCAP": 6, "BM2_BWD_BLOCKS_PER_CU": 4},
                                                               {"BM2_BWD_LCAP": 4, "BM2_BWD_BLOCKS_PER_CU": 4},
                                                               {"BM2_BWD_LCAP": 6, "BM2_BWD_BLOCKS_PER_CU": 5, "BM2_BWD_WAVES": 5},

@@ -32,7 +32,7 @@ __global__ void __launch_bounds__(256) k_rand(const ulonglong2 *__restrict__ buf
 
 // quad-cooperative variant: the four lanes of a quad fetch the four 16-byte quarters of ONE line with one instruction
 // (one coalesced 64-byte request); each lane still consumes LPL lines of its own per step (4 * LPL instructions)
-template <int LPL>
+template <int LPL, bool NT = false>       // NT: the same with non-temporal loads (`global_load ... nt`: a line nobody will touch again)
 __global__ void __launch_bounds__(256) k_rand_quad(const ulonglong2 *__restrict__ buf, uint64_t n_lines, int steps, uint64_t *out) {
     uint64_t x = (uint64_t)(blockIdx.x * blockDim.x + threadIdx.x) * 0x9E3779B97F4A7C15ULL + 12345;
     uint64_t acc = 0;
@@ -46,7 +46,9 @@ __global__ void __launch_bounds__(256) k_rand_quad(const ulonglong2 *__restrict_
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const uint64_t line = __shfl(mine, qb + u);
-                const ulonglong2 a = buf[line * 4 + sub];
+                ulonglong2 a;
+                if (NT) { const uint64_t *q = (const uint64_t *)&buf[line * 4 + sub]; a.x = __builtin_nontemporal_load(q); a.y = __builtin_nontemporal_load(q + 1); }
+                else a = buf[line * 4 + sub];
                 part[u] = a.x ^ a.y;
             }
             // every lane needs the xor over the four quarters of ITS line: quad all-to-all
@@ -82,13 +84,14 @@ int main(int argc, char **argv) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int rep = 0; rep < 2; rep++) {
         hipEventRecord(e0);
-        if (quad) hipLaunchKernelGGL(k_rand_quad<2>, dim3(grid), dim3(256), 0, 0, (const ulonglong2 *)buf, n_lines, steps, out);
+        if (quad == 2) hipLaunchKernelGGL((k_rand_quad<2, true>), dim3(grid), dim3(256), 0, 0, (const ulonglong2 *)buf, n_lines, steps, out);
+        else if (quad) hipLaunchKernelGGL(k_rand_quad<2>, dim3(grid), dim3(256), 0, 0, (const ulonglong2 *)buf, n_lines, steps, out);
         else if (lpl == 1) hipLaunchKernelGGL(k_rand<1>, dim3(grid), dim3(256), 0, 0, (const ulonglong2 *)buf, n_lines, steps, out);
         else hipLaunchKernelGGL(k_rand<2>, dim3(grid), dim3(256), 0, 0, (const ulonglong2 *)buf, n_lines, steps, out);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         const double lines = (double)grid * 256 * steps * lpl;
-        if (rep) printf("%s footprint %6zu MB  blocks/CU %2d  lines/lane %d : %7.2f ms  %6.1f G lines/s  %7.1f GB/s  (%.2f us per step)\n", quad ? "quad" : "lane", mb, bpc, lpl, ms,
+        if (rep) printf("%s footprint %6zu MB  blocks/CU %2d  lines/lane %d : %7.2f ms  %6.1f G lines/s  %7.1f GB/s  (%.2f us per step)\n", quad == 2 ? "quad-nt" : quad ? "quad" : "lane", mb, bpc, lpl, ms,
                         lines / ms / 1e6, lines * 64 / ms / 1e6, ms * 1e3 / steps);
     }
     return 0;
