@@ -1045,9 +1045,9 @@ int bm2_launch_extend(bm2_ctx *c, const bm2_opt &opt, const ChainParams &cp, int
     L.wave_nmax = bm2_knob("BM2_EXT_WAVE_NMAX", 0);                 // classes with at most this many tasks in a round: likewise (no gain measured)
     L.prefetch = bm2_knob("BM2_EXT_PREFETCH", 1);
     L.rev = bm2_knob("BM2_EXT_REVERSE", 1);      // (sweep of round 3: -0.6 ms)
-    L.reg_rows = bm2_knob("BM2_EXT_REG_ROWS", 0);
+    L.reg_rows = bm2_knob("BM2_EXT_REG_ROWS", 0);                   // (same sweep: no gain at any class bound, +8 ms with every class)
     L.reg_rows_max = bm2_knob("BM2_EXT_REG_ROWS_MAX", 94);           // classes of longer queries keep their rows in LDS
-    L.perm_scores = bm2_knob("BM2_EXT_PERM_SCORES", 0);
+    L.perm_scores = bm2_knob("BM2_EXT_PERM_SCORES", 1);            // (sweep of round 3, profiles/r03v_sweep_lane_variants.json: extension 28.0 -> 26.5 ms)
     for (int k : { 0, 1, 4 }) if (opt.mat[k] < -128 || opt.mat[k] > 127) L.reg_rows = L.perm_scores = 0;     // (the score table holds signed bytes)
     const int lazy_rounds = bm2_knob("BM2_EXT_ROUNDS", LAZY_ROUNDS), pend_div = bm2_knob("BM2_EXT_PEND_DIV", 12);
     L.R = ring_size2(opt.w << (MAX_BAND_TRY - 1));

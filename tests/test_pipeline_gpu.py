@@ -209,7 +209,8 @@ def test_extension_lane_kernel_variants(golden_dir, name, L, knob, tmp_path):
     # score from a byte permute over the row's score table (BM2_EXT_PERM_SCORES): the goldens' regs, and a fresh chunk of reads whose
     # query-length classes fill whole wavefronts, against the default kernels
     pre, enc, off, ln, d = load_golden(golden_dir, name)
-    os.environ[knob] = "1"
+    val = "0" if knob == "BM2_EXT_PERM_SCORES" else "1"          # (the permute table is the default: its variant is the 4-bit query with compares)
+    os.environ[knob] = val
     try:
         ctx = bm2.Context(0, pre)
         try:
