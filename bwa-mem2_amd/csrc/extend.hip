@@ -950,7 +950,7 @@ struct ExtLaunch {
     // launch policy (bm2_knob): which kernel takes a query-length class.  Every launch of a side lasts about as long as its slowest
     // wavefront, and a lane-per-task wavefront of 150-base queries walks ~30 k cells one after the other (milliseconds), so the
     // classes with few tasks or long queries go one task per WAVEFRONT (k_ext_wave: ~0.1 ms per task) beside the lane kernels.
-    int wave_qmin, wave_nmax, prefetch, rev, reg_rows, reg_rows_max, perm_scores;
+    int wave_qmin, wave_nmax, prefetch, rev, reg_rows, reg_rows_max, perm_scores, qmap;
 };
 
 // Left side, then right side (whose h0 is the left score).  Lane-per-task kernels per query-length class (each class needs
@@ -972,9 +972,15 @@ static int run_sides(const ExtLaunch &L, const uint32_t *h_hist, const uint32_t 
         // the classes from k_wave up (long queries) and the fallback bin are adjacent in the task list: one wavefront-per-task launch
         int k_wave = N_CLS;
         while (k_wave > 0 && (k_wave >= 2 ? cls_hi[k_wave - 2] : 0) + 1 >= L.wave_qmin) k_wave--;
+        // Streams sit on HARDWARE QUEUES round-robin (GPU_MAX_HW_QUEUES = 8: the context's main stream and its first seven side streams are
+        // eight different queues, side stream 10 shares the queue of side stream 3), and two launches on one queue run one after the other
+        // (profiles/r03x_timeline.tsv: the 49..64-column class started when the wavefront kernel ended, 0.8-1.1 ms later than its peers, in every
+        // phase).  The eight launches of a side -- seven lane classes and the wavefront kernel -- get eight queues: the shortest class rides the
+        // main stream (idle while the side runs), the wavefront kernel takes that class's side stream.
         for (int kk = 0; kk <= N_CLS; kk++) {                  // longest queries first: their tails overlap the short classes
-            const int k = kk == 0 ? N_CLS : N_CLS - kk;
-            hipStream_t sk = c->side_stream[k];
+            const int k = L.qmap ? (kk == 0 ? N_CLS : kk == 1 ? 0 : N_CLS + 1 - kk) : (kk == 0 ? N_CLS : N_CLS - kk);
+            const bool on_main = L.qmap && k == 0;
+            hipStream_t sk = !L.qmap ? c->side_stream[k] : k == N_CLS ? c->side_stream[0] : on_main ? L.s : c->side_stream[k];
             uint32_t n = 0, first = 0; int hi = 0;
             if (k < N_CLS) {
                 if (k >= k_wave) continue;                      // part of the launch of k == N_CLS
@@ -988,7 +994,7 @@ static int run_sides(const ExtLaunch &L, const uint32_t *h_hist, const uint32_t 
                 for (int b = lo + 1; b <= BIN_FALLBACK; b++) n += hc[b];
             }
             if (!n) continue;
-            (void)hipStreamWaitEvent(sk, c->ev_fork, 0);
+            if (!on_main) (void)hipStreamWaitEvent(sk, c->ev_fork, 0);
             if (k < N_CLS && (int64_t)n > (int64_t)L.wave_nmax) {
                 const size_t lds = L.pack8 ? (size_t)((hi + 2) / 2) * 64 * 4 + (size_t)((hi + 7) / 8) * 64 * 4
                                            : (size_t)(hi + 1) * 64 * 4 + (size_t)hi * 64;
@@ -1008,6 +1014,7 @@ static int run_sides(const ExtLaunch &L, const uint32_t *h_hist, const uint32_t 
                 hipLaunchKernelGGL(kern, dim3((n + 63) / 64), dim3(64), lds_k, sk, c->ix, L.xp, tasks + first, (int)n, hi, L.enc, L.off, L.len,
                                    L.slot_base, L.reg_seed, L.reg_chain, L.chn, L.seeds, L.regs, L.counters, L.rev);
             } else wave_launch(sk, first, n);
+            if (on_main) continue;
             (void)hipEventRecord(c->ev_join[k], sk);
             (void)hipStreamWaitEvent(L.s, c->ev_join[k], 0);
         }
@@ -1047,6 +1054,7 @@ int bm2_launch_extend(bm2_ctx *c, const bm2_opt &opt, const ChainParams &cp, int
     L.rev = bm2_knob("BM2_EXT_REVERSE", 1);      // (sweep of round 3: -0.6 ms)
     L.reg_rows = bm2_knob("BM2_EXT_REG_ROWS", 0);                   // (same sweep: no gain at any class bound, +8 ms with every class)
     L.reg_rows_max = bm2_knob("BM2_EXT_REG_ROWS_MAX", 94);           // classes of longer queries keep their rows in LDS
+    L.qmap = bm2_knob("BM2_EXT_QUEUE_MAP", 1);
     L.perm_scores = bm2_knob("BM2_EXT_PERM_SCORES", 1);            // (sweep of round 3, profiles/r03v_sweep_lane_variants.json: extension 28.0 -> 26.5 ms)
     for (int k : { 0, 1, 4 }) if (opt.mat[k] < -128 || opt.mat[k] > 127) L.reg_rows = L.perm_scores = 0;     // (the score table holds signed bytes)
     const int lazy_rounds = bm2_knob("BM2_EXT_ROUNDS", LAZY_ROUNDS), pend_div = bm2_knob("BM2_EXT_PEND_DIV", 12);

@@ -32,6 +32,7 @@ GRID = [   # (name, candidates): a candidate is a dict of knobs set together; th
     ("extension rows in registers", [{}, {"BM2_EXT_REG_ROWS": 1, "BM2_EXT_REG_ROWS_MAX": 94}, {"BM2_EXT_REG_ROWS": 1, "BM2_EXT_REG_ROWS_MAX": 62},
                                      {"BM2_EXT_REG_ROWS": 1, "BM2_EXT_REG_ROWS_MAX": 78}, {"BM2_EXT_REG_ROWS": 1, "BM2_EXT_REG_ROWS_MAX": 112},
                                      {"BM2_EXT_REG_ROWS": 1, "BM2_EXT_REG_ROWS_MAX": 46}, {"BM2_EXT_REG_ROWS": 1, "BM2_EXT_REG_ROWS_MAX": 30}]),
+    ("extension launches on distinct hardware queues", [{}, {"BM2_EXT_QUEUE_MAP": 0}]),
     ("extension scores by byte permute", [{}, {"BM2_EXT_PERM_SCORES": 0}]),
     ("extension wave classes", [{}, {"BM2_EXT_WAVE_QMIN": 129}, {"BM2_EXT_WAVE_QMIN": 97}, {"BM2_EXT_WAVE_QMIN": 161}]),
     ("extension dispatch order", [{}, {"BM2_EXT_REVERSE": 1}]),
