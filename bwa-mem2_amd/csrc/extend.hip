@@ -126,6 +126,15 @@ k_task_scatter(int64_t n_slots, const uint8_t *__restrict__ bins, uint32_t *curs
 // band or past its own exit is masked off.
 struct LaneOut { int score, qle, tle, gtle, gscore, max_off; };
 
+// Instruction-issue priority of this wavefront among those sharing its SIMD (s_setprio).  A phase of the extension stage lasts as long as
+// its slowest launch, and that is always a class of long queries whose few wavefronts share their SIMDs with the short classes': they
+// are the critical path, so they issue first.  The level rides in bits 1.. of the kernels' `rev` argument.
+static __device__ __forceinline__ void wave_priority(int level) {
+    if (level == 1) __builtin_amdgcn_s_setprio(1);
+    else if (level == 2) __builtin_amdgcn_s_setprio(2);
+    else if (level >= 3) __builtin_amdgcn_s_setprio(3);
+}
+
 static __device__ void lane_dp(bool run, int qlen, int tlen, int w, int h0, const uint8_t *tp, int ts, const SwParams &P,
                                uint32_t *EH, const uint8_t *QL, int lane, LaneOut &out, long long &cells) {
     const int o_del = P.o_del, e_del = P.e_del, o_ins = P.o_ins, e_ins = P.e_ins, oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
@@ -480,8 +489,9 @@ k_ext_lanes(DevIndex ix, ExtParams xp, const int32_t *__restrict__ tasks, int n_
     uint8_t *QL = (uint8_t *)(lds_l + (size_t)(qmax + 1) * 64); // [qmax][64] bytes
     uint32_t *QL8 = RB ? lds_l : lds_l + (size_t)((qmax + 2) / 2) * 64;      // P8: [(qmax+7)/8][64] dwords, 8 bases of 4 bits each
     const int lane = threadIdx.x;
+    wave_priority(rev >> 1);
     // (rev: the task list ascends in query length; the blocks with the longest queries -- the slowest wavefronts -- are dispatched first)
-    const int idx = (rev ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x) * 64 + lane;
+    const int idx = ((rev & 1) ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x) * 64 + lane;
     const bool valid = idx < n_tasks;
     const SwParams &P = SIDE == 0 ? xp.left : xp.right;
     int g = 0, l_query = 0, h0 = 0, prev = -1;
@@ -582,7 +592,8 @@ k_ext_wave(DevIndex ix, ExtParams xp, const int32_t *__restrict__ tasks, int n_t
     int *RH = rings + (size_t)wv * 2 * R, *RE = RH + R;
     const int idx = blockIdx.x * (blockDim.x >> 6) + wv;
     if (idx >= n_tasks) return;
-    const int g = tasks[rev ? n_tasks - 1 - idx : idx];
+    wave_priority(rev >> 1);
+    const int g = tasks[(rev & 1) ? n_tasks - 1 - idx : idx];
     const int64_t base = slot_base[g];
     const DevChain c = chn[base + reg_chain[g]];
     const DevSeed s = seeds[base + reg_seed[g]];
@@ -950,7 +961,7 @@ struct ExtLaunch {
     // launch policy (bm2_knob): which kernel takes a query-length class.  Every launch of a side lasts about as long as its slowest
     // wavefront, and a lane-per-task wavefront of 150-base queries walks ~30 k cells one after the other (milliseconds), so the
     // classes with few tasks or long queries go one task per WAVEFRONT (k_ext_wave: ~0.1 ms per task) beside the lane kernels.
-    int wave_qmin, wave_nmax, prefetch, rev, reg_rows, reg_rows_max, perm_scores, qmap;
+    int wave_qmin, wave_nmax, prefetch, rev, reg_rows, reg_rows_max, perm_scores, qmap, prio, prio_min, wave_prio;
 };
 
 // Left side, then right side (whose h0 is the left score).  Lane-per-task kernels per query-length class (each class needs
@@ -966,8 +977,8 @@ static int run_sides(const ExtLaunch &L, const uint32_t *h_hist, const uint32_t 
         const uint32_t *st = h_start + side * N_BINS, *hc = h_hist + side * N_BINS;
         (void)hipEventRecord(c->ev_fork, L.s);
         auto wave_launch = [&](hipStream_t sk, uint32_t first, uint32_t n) {
-            if (side == 0) hipLaunchKernelGGL(k_ext_wave<0>, dim3((n + 3) / 4), dim3(256), L.lds_w, sk, c->ix, L.xp, tasks + first, (int)n, L.enc, L.off, L.len, L.slot_base, L.reg_seed, L.reg_chain, L.chn, L.seeds, L.regs, L.R, L.counters, L.rev);
-            else hipLaunchKernelGGL(k_ext_wave<1>, dim3((n + 3) / 4), dim3(256), L.lds_w, sk, c->ix, L.xp, tasks + first, (int)n, L.enc, L.off, L.len, L.slot_base, L.reg_seed, L.reg_chain, L.chn, L.seeds, L.regs, L.R, L.counters, L.rev);
+            if (side == 0) hipLaunchKernelGGL(k_ext_wave<0>, dim3((n + 3) / 4), dim3(256), L.lds_w, sk, c->ix, L.xp, tasks + first, (int)n, L.enc, L.off, L.len, L.slot_base, L.reg_seed, L.reg_chain, L.chn, L.seeds, L.regs, L.R, L.counters, L.rev | L.wave_prio << 1);
+            else hipLaunchKernelGGL(k_ext_wave<1>, dim3((n + 3) / 4), dim3(256), L.lds_w, sk, c->ix, L.xp, tasks + first, (int)n, L.enc, L.off, L.len, L.slot_base, L.reg_seed, L.reg_chain, L.chn, L.seeds, L.regs, L.R, L.counters, L.rev | L.wave_prio << 1);
         };
         // the classes from k_wave up (long queries) and the fallback bin are adjacent in the task list: one wavefront-per-task launch
         int k_wave = N_CLS;
@@ -978,9 +989,9 @@ static int run_sides(const ExtLaunch &L, const uint32_t *h_hist, const uint32_t 
         // phase).  The eight launches of a side -- seven lane classes and the wavefront kernel -- get eight queues: the shortest class rides the
         // main stream (idle while the side runs), the wavefront kernel takes that class's side stream.
         for (int kk = 0; kk <= N_CLS; kk++) {                  // longest queries first: their tails overlap the short classes
-            const int k = L.qmap ? (kk == 0 ? N_CLS : kk == 1 ? 0 : N_CLS + 1 - kk) : (kk == 0 ? N_CLS : N_CLS - kk);
-            const bool on_main = L.qmap && k == 0;
-            hipStream_t sk = !L.qmap ? c->side_stream[k] : k == N_CLS ? c->side_stream[0] : on_main ? L.s : c->side_stream[k];
+            const int k = L.qmap == 1 ? (kk == 0 ? N_CLS : kk == 1 ? 0 : N_CLS + 1 - kk) : (kk == 0 ? N_CLS : N_CLS - kk);
+            const bool on_main = L.qmap == 1 && k == 0;                        // (qmap 2: the shortest class behind the second shortest on ITS stream)
+            hipStream_t sk = !L.qmap ? c->side_stream[k] : k == N_CLS ? c->side_stream[0] : on_main ? L.s : c->side_stream[k ? k : 1];
             uint32_t n = 0, first = 0; int hi = 0;
             if (k < N_CLS) {
                 if (k >= k_wave) continue;                      // part of the launch of k == N_CLS
@@ -1012,7 +1023,7 @@ static int run_sides(const ExtLaunch &L, const uint32_t *h_hist, const uint32_t 
                     lds_k = (size_t)((hi + 3) / 4 + 1) * 64 * 4;
                 }
                 hipLaunchKernelGGL(kern, dim3((n + 63) / 64), dim3(64), lds_k, sk, c->ix, L.xp, tasks + first, (int)n, hi, L.enc, L.off, L.len,
-                                   L.slot_base, L.reg_seed, L.reg_chain, L.chn, L.seeds, L.regs, L.counters, L.rev);
+                                   L.slot_base, L.reg_seed, L.reg_chain, L.chn, L.seeds, L.regs, L.counters, L.rev | (hi >= L.prio_min ? L.prio << 1 : 0));
             } else wave_launch(sk, first, n);
             if (on_main) continue;
             (void)hipEventRecord(c->ev_join[k], sk);
@@ -1055,6 +1066,8 @@ int bm2_launch_extend(bm2_ctx *c, const bm2_opt &opt, const ChainParams &cp, int
     L.reg_rows = bm2_knob("BM2_EXT_REG_ROWS", 0);                   // (same sweep: no gain at any class bound, +8 ms with every class)
     L.reg_rows_max = bm2_knob("BM2_EXT_REG_ROWS_MAX", 94);           // classes of longer queries keep their rows in LDS
     L.qmap = bm2_knob("BM2_EXT_QUEUE_MAP", 1);
+    L.prio = bm2_knob("BM2_EXT_PRIO", 0) & 3; L.prio_min = bm2_knob("BM2_EXT_PRIO_MIN", 80); L.wave_prio = bm2_knob("BM2_EXT_WAVE_PRIO", 0) & 3;
+    L.rev = L.rev ? 1 : 0;
     L.perm_scores = bm2_knob("BM2_EXT_PERM_SCORES", 1);            // (sweep of round 3, profiles/r03v_sweep_lane_variants.json: extension 28.0 -> 26.5 ms)
     for (int k : { 0, 1, 4 }) if (opt.mat[k] < -128 || opt.mat[k] > 127) L.reg_rows = L.perm_scores = 0;     // (the score table holds signed bytes)
     const int lazy_rounds = bm2_knob("BM2_EXT_ROUNDS", LAZY_ROUNDS), pend_div = bm2_knob("BM2_EXT_PEND_DIV", 12);

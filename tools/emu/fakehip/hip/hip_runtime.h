@@ -131,6 +131,7 @@ static inline unsigned emu_perm(unsigned s0, unsigned s1, unsigned sel) {
     return r;
 }
 #define __builtin_amdgcn_perm(s0, s1, sel) emu_perm((unsigned)(s0), (unsigned)(s1), (unsigned)(sel))
+#define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_wave_barrier() emu_wsync()
 #define __builtin_amdgcn_fence(...) std::atomic_thread_fence(std::memory_order_seq_cst)
 #define __builtin_amdgcn_mbcnt_lo(m, c) ((int)(c) + __builtin_popcount((unsigned)(m) & (emu_t.lane >= 32 ? 0xffffffffu : ((1u << emu_t.lane) - 1u))))

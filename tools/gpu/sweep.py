@@ -32,7 +32,10 @@ GRID = [   # (name, candidates): a candidate is a dict of knobs set together; th
     ("extension rows in registers", [{}, {"BM2_EXT_REG_ROWS": 1, "BM2_EXT_REG_ROWS_MAX": 94}, {"BM2_EXT_REG_ROWS": 1, "BM2_EXT_REG_ROWS_MAX": 62},
                                      {"BM2_EXT_REG_ROWS": 1, "BM2_EXT_REG_ROWS_MAX": 78}, {"BM2_EXT_REG_ROWS": 1, "BM2_EXT_REG_ROWS_MAX": 112},
                                      {"BM2_EXT_REG_ROWS": 1, "BM2_EXT_REG_ROWS_MAX": 46}, {"BM2_EXT_REG_ROWS": 1, "BM2_EXT_REG_ROWS_MAX": 30}]),
-    ("extension launches on distinct hardware queues", [{}, {"BM2_EXT_QUEUE_MAP": 0}]),
+    ("extension launches on distinct hardware queues", [{}, {"BM2_EXT_QUEUE_MAP": 2}, {"BM2_EXT_QUEUE_MAP": 0}]),
+    ("extension issue priority of the long classes", [{}, {"BM2_EXT_PRIO": 3, "BM2_EXT_PRIO_MIN": 80, "BM2_EXT_WAVE_PRIO": 3}, {"BM2_EXT_PRIO": 3, "BM2_EXT_PRIO_MIN": 96, "BM2_EXT_WAVE_PRIO": 3},
+                                                      {"BM2_EXT_PRIO": 2, "BM2_EXT_PRIO_MIN": 64, "BM2_EXT_WAVE_PRIO": 3}, {"BM2_EXT_PRIO": 3, "BM2_EXT_PRIO_MIN": 80, "BM2_EXT_WAVE_PRIO": 0},
+                                                      {"BM2_EXT_PRIO": 0, "BM2_EXT_WAVE_PRIO": 3}, {"BM2_EXT_PRIO": 3, "BM2_EXT_PRIO_MIN": 112, "BM2_EXT_WAVE_PRIO": 2}]),
     ("extension scores by byte permute", [{}, {"BM2_EXT_PERM_SCORES": 0}]),
     ("extension wave classes", [{}, {"BM2_EXT_WAVE_QMIN": 129}, {"BM2_EXT_WAVE_QMIN": 97}, {"BM2_EXT_WAVE_QMIN": 161}]),
     ("extension dispatch order", [{}, {"BM2_EXT_REVERSE": 1}]),
