@@ -986,8 +986,10 @@ static int run_sides(const ExtLaunch &L, const uint32_t *h_hist, const uint32_t 
         // Streams sit on HARDWARE QUEUES round-robin (GPU_MAX_HW_QUEUES = 8: the context's main stream and its first seven side streams are
         // eight different queues, side stream 10 shares the queue of side stream 3), and two launches on one queue run one after the other
         // (profiles/r03x_timeline.tsv: the 49..64-column class started when the wavefront kernel ended, 0.8-1.1 ms later than its peers, in every
-        // phase).  The eight launches of a side -- seven lane classes and the wavefront kernel -- get eight queues: the shortest class rides the
-        // main stream (idle while the side runs), the wavefront kernel takes that class's side stream.
+        // phase).  The eight launches of a side -- seven lane classes and the wavefront kernel -- get seven queues of their own: the shortest class rides the
+        // stream of the second shortest (both end long before the side does; on the main stream -- qmap 1 -- it was dispatched last and became
+        // the side's tail), the wavefront kernel takes that class's side stream.  (Issue priority -- s_setprio -- for the long classes'
+        // wavefronts, the critical path of every side, measured no gain: BM2_EXT_PRIO, profiles/r03z_sweep_priority.json.)
         for (int kk = 0; kk <= N_CLS; kk++) {                  // longest queries first: their tails overlap the short classes
             const int k = L.qmap == 1 ? (kk == 0 ? N_CLS : kk == 1 ? 0 : N_CLS + 1 - kk) : (kk == 0 ? N_CLS : N_CLS - kk);
             const bool on_main = L.qmap == 1 && k == 0;                        // (qmap 2: the shortest class behind the second shortest on ITS stream)
@@ -1065,7 +1067,7 @@ int bm2_launch_extend(bm2_ctx *c, const bm2_opt &opt, const ChainParams &cp, int
     L.rev = bm2_knob("BM2_EXT_REVERSE", 1);      // (sweep of round 3: -0.6 ms)
     L.reg_rows = bm2_knob("BM2_EXT_REG_ROWS", 0);                   // (same sweep: no gain at any class bound, +8 ms with every class)
     L.reg_rows_max = bm2_knob("BM2_EXT_REG_ROWS_MAX", 94);           // classes of longer queries keep their rows in LDS
-    L.qmap = bm2_knob("BM2_EXT_QUEUE_MAP", 1);
+    L.qmap = bm2_knob("BM2_EXT_QUEUE_MAP", 2);      // (profiles/r03y_*, r03z_*: extension 26.5 ms with the old assignment, 25.0 with 1, 24.6 with 2)
     L.prio = bm2_knob("BM2_EXT_PRIO", 0) & 3; L.prio_min = bm2_knob("BM2_EXT_PRIO_MIN", 80); L.wave_prio = bm2_knob("BM2_EXT_WAVE_PRIO", 0) & 3;
     L.rev = L.rev ? 1 : 0;
     L.perm_scores = bm2_knob("BM2_EXT_PERM_SCORES", 1);            // (sweep of round 3, profiles/r03v_sweep_lane_variants.json: extension 28.0 -> 26.5 ms)
