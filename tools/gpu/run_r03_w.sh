@@ -21,8 +21,10 @@ B="python $R/bench.py --no-cpu-baseline --no-parity --no-e2e --no-binding"
 timeout 250 rocprofv3 --kernel-trace --stats -d /tmp/p_kt -o kt -- $B --steps 4 --warmup 1 > $O/bench.json 2> $O/kt.err; at trace $?
 python $R/tools/rocpd_summary.py $(find /tmp/p_kt -name "*.db" | head -1) $O/kernel_trace.md > /dev/null 2>> $O/kt.err
 head -14 $O/kernel_trace.md
+timeout 150 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/p_f -o f -- $B --steps 1 --warmup 1 > /dev/null 2> $O/pmc_f.err; at fetch $?
+python $R/tools/rocpd_summary.py $(find /tmp/p_f -name "*.db" | head -1) $O/pmc_fetch.md > /dev/null 2>> $O/pmc_f.err
 SQ1="SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS"
 timeout 150 rocprofv3 --pmc WRITE_SIZE $SQ1 --kernel-trace -d /tmp/p_ws -o s -- $B --steps 1 --warmup 1 > /dev/null 2> $O/pmc_ws.err; at write_sq1 $?
-python $R/tools/rocpd_summary.py $(find /tmp/p_ws -name "*.db" | head -1) $O/pmc_sq1.md > /dev/null 2>> $O/pmc_ws.err
+python $R/tools/rocpd_summary.py $(find /tmp/p_ws -name "*.db" | head -1) $O/pmc_sq1.md > /dev/null 2>> $O/pmc_ws.err; cp $O/pmc_sq1.md $O/pmc_write.md
 grep -E "k_bwd|k_ext_lanes" $O/pmc_sq1.md | head -24
 echo "finished at $(( $(date +%s) - T0 ))s"
