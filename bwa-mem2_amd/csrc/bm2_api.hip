@@ -168,6 +168,10 @@ __global__ void __launch_bounds__(256) k_cp_occ_relayout(CpOcc *occ, int64_t n) 
 }
 
 extern "C" bm2_ctx *bm2_create(int device, const bm2_index_desc *idx) {
+    // The extension stage forks eight concurrent launches per side, each on a stream of its own; streams share the process's hardware
+    // queues round-robin and the runtime's default is four.  Eight, unless the caller chose (read when the runtime starts: a process that
+    // has already used HIP keeps what it had).
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
         bm2_set_error("no HIP device visible: libbm2 has no CPU fallback");

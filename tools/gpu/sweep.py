@@ -38,6 +38,7 @@ GRID = [   # (name, candidates): a candidate is a dict of knobs set together; th
                                                       {"BM2_EXT_PRIO": 0, "BM2_EXT_WAVE_PRIO": 3}, {"BM2_EXT_PRIO": 3, "BM2_EXT_PRIO_MIN": 112, "BM2_EXT_WAVE_PRIO": 2}]),
     ("extension scores by byte permute", [{}, {"BM2_EXT_PERM_SCORES": 0}]),
     ("extension wave classes", [{}, {"BM2_EXT_WAVE_QMIN": 129}, {"BM2_EXT_WAVE_QMIN": 97}, {"BM2_EXT_WAVE_QMIN": 161}]),
+    ("extension rounds", [{}, {"BM2_EXT_ROUNDS": 2}, {"BM2_EXT_ROUNDS": 1}, {"BM2_EXT_PEND_DIV": 6}, {"BM2_EXT_PEND_DIV": 24}]),
     ("extension dispatch order", [{}, {"BM2_EXT_REVERSE": 1}]),
     ("extension prefetch", [{}, {"BM2_EXT_PREFETCH": 0}]),
     ("SA lookup by quads", [{}, {"BM2_SAL_QUAD": 1}]),
