@@ -126,14 +126,6 @@ k_task_scatter(int64_t n_slots, const uint8_t *__restrict__ bins, uint32_t *curs
 // band or past its own exit is masked off.
 struct LaneOut { int score, qle, tle, gtle, gscore, max_off; };
 
-// Instruction-issue priority of this wavefront among those sharing its SIMD (s_setprio).  A phase of the extension stage lasts as long as
-// its slowest launch, and that is always a class of long queries whose few wavefronts share their SIMDs with the short classes': they
-// are the critical path, so they issue first.  The level rides in bits 1.. of the kernels' `rev` argument.
-static __device__ __forceinline__ void wave_priority(int level) {
-    if (level == 1) __builtin_amdgcn_s_setprio(1);
-    else if (level == 2) __builtin_amdgcn_s_setprio(2);
-    else if (level >= 3) __builtin_amdgcn_s_setprio(3);
-}
 
 static __device__ void lane_dp(bool run, int qlen, int tlen, int w, int h0, const uint8_t *tp, int ts, const SwParams &P,
                                uint32_t *EH, const uint8_t *QL, int lane, LaneOut &out, long long &cells) {
@@ -339,147 +331,8 @@ static __device__ void lane_dp8(bool run, int qlen, int tlen, int w, int h0, con
     if (run) { out.score = maxv; out.qle = max_j + 1; out.tle = max_i + 1; out.gtle = max_ie + 1; out.gscore = gscore; out.max_off = max_off; }
 }
 
-// The 8+8-bit rows in REGISTERS.  Every lane of the wavefront steps the same column pair, so the row word of a pair is the same
-// register in every lane: the row is a register array indexed by a wave-uniform pair number (s_set_gpr_idx + v_mov), NB blocks of 32
-// dwords = 64 columns each.  No LDS round trip sits in the recurrence, and a wavefront's footprint is ~64 VGPRs per 128 columns
-// instead of 18 KB of LDS: 4 wavefronts per SIMD for the 65..126-column classes where the LDS rows allowed 2.  What is NOT uniform
-// is the column one past a lane's band, eh[end] (bandedSWA.cpp:201): it is written by a short uniform walk over the pairs that
-// hold some lane's `end`.  The query stays in LDS, one base per BYTE: the row's five scores (against A, C, G, T, N) are five bytes of a
-// register pair, and ONE v_perm_b32 with the query word as its selector turns four query bases into their four scores (the cell's
-// two compares and two selects of the 4-bit layout are gone); the next word is requested four columns ahead.
-typedef uint32_t bm2_u32x32 __attribute__((ext_vector_type(32)));
-
-template <int NB>
-static __device__ void lane_dp8r(bool run, int qlen, int tlen, int w, int h0, const uint8_t *tp, int ts, const SwParams &P,
-                                 const uint32_t *QL, int lane, LaneOut &out, long long &cells) {
-    const int o_del = P.o_del, e_del = P.e_del, o_ins = P.o_ins, e_ins = P.e_ins, oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
-    const int sc_match = P.mat[0], sc_mis = P.mat[1], sc_amb = P.mat[4];         // (each fits a signed byte: the host checks)
-    const uint32_t rep_mis = rep4(sc_mis), rep_amb = rep4(sc_amb);
-    const int e1 = h0 > oe_ins ? h0 - oe_ins : 0;                // first row, bandedSWA.cpp:143-145
-    const int cls = pair_class(tlen, qlen, h0, P.max_sc);
-    const int maxq = __builtin_amdgcn_readlane(wave_scan_max(run ? qlen : 0, 0), 63);
-    bm2_u32x32 R[NB];
-#pragma unroll
-    for (int b = 0; b < NB; b++)
-#pragma unroll
-        for (int t = 0; t < 32; t++) R[b][t] = 0u;
-#pragma unroll
-    for (int b = 0; b < NB; b++) {
-        const int pe = imin(maxq >> 1, b * 32 + 31);
-        for (int pp = b * 32; pp <= pe; pp++) {
-            const int jp = pp << 1;
-            if (run && jp <= qlen) {
-                const uint32_t v0 = (uint32_t)(jp == 0 ? h0 : imax(e1 - (jp - 1) * e_ins, 0));
-                const uint32_t v1 = jp + 1 <= qlen ? (uint32_t)imax(e1 - jp * e_ins, 0) : 0u;
-                R[b][pp & 31] = v0 | v1 << 16;
-            }
-        }
-    }
-    int beg = 0, end = qlen, maxv = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0;
-    bool alive = run && tlen > 0;
-    const int maxt = __builtin_amdgcn_readlane(wave_scan_max(alive ? tlen : 0, 0), 63);
-    int t_next = alive ? (int)tp[0] : 4;
-    for (int i = 0; i < maxt; ++i) {
-        if (!__ballot(alive)) break;
-        const int tb = t_next;
-        if (alive && i + 1 < tlen) t_next = (int)tp[(int64_t)(i + 1) * ts];
-        int h1 = 0, f = 0, lnz = -1;
-        unsigned key = 0, fnz_u = 0xffffffffu;
-        if (alive) {
-            if (beg < i - w) beg = i - w;
-            if (end > i + w + 1) end = i + w + 1;
-            if (end > qlen) end = qlen;
-            if (beg == 0) { h1 = h0 - (o_del + e_del * (i + 1)); if (h1 < 0) h1 = 0; }
-            cells += imax(end - beg, 0);
-        }
-        // scores of this row against the query codes 0..4: bytes 0..3 of t_lo (the target's own base: match; both N or target N: ambiguous),
-        // byte 0 of t_hi (query N)
-        const uint32_t t_lo = tb > 3 ? rep_amb : rep_mis ^ ((uint32_t)((sc_mis ^ sc_match) & 0xff) << (8 * tb));
-        const uint32_t t_hi = rep_amb;
-        const int jlo = (1 << 20) - __builtin_amdgcn_readlane(wave_scan_max(alive ? (1 << 20) - beg : 0, 0), 63);
-        const int jhi = __builtin_amdgcn_readlane(wave_scan_max(alive ? end : 0, 0), 63);
-        const int elo = (1 << 20) - __builtin_amdgcn_readlane(wave_scan_max(alive ? (1 << 20) - end : 0, 0), 63);     // smallest `end` of a live lane
-        const int jp0 = jlo & ~1;
-        // 4 query bases per word -> 4 score bytes; `sq` holds the bytes of the current pair in its low half
-        uint32_t sq = jp0 < jhi ? __builtin_amdgcn_perm(t_hi, t_lo, QL[(jp0 >> 2) * 64 + lane]) >> (8 * (jp0 & 3)) : 0u;
-        uint32_t qnext = ((jp0 | 3) + 1) < jhi ? QL[((jp0 >> 2) + 1) * 64 + lane] : 0u;
-        const int p_lo = jp0 >> 1, p_hi = (jhi + 1) >> 1;                                  // pairs [p_lo, p_hi)
-#pragma unroll
-        for (int b = 0; b < NB; b++) {
-            const int pa = imax(p_lo, b * 32), pb = imin(p_hi, b * 32 + 32);
-            for (int pp = pa; pp < pb; pp++) {
-                const int jp = pp << 1;
-                if (alive && jp + 1 >= beg && jp < end) {
-                    uint32_t word = R[b][pp & 31];
-#pragma unroll
-                    for (int u = 0; u < 2; u++) {
-                        const int j = jp + u;
-                        if (j >= beg && j < end) {
-                            const int e = (int)((word >> (16 * u + 8)) & 0xffu);
-                            int M = (int)((word >> (16 * u)) & 0xffu);
-                            const int sc = (int)(int8_t)(sq >> (8 * u));
-                            M = M ? M + sc : 0;
-                            int h = M > e ? M : e;
-                            h = h > f ? h : f;
-                            const unsigned kj = (unsigned)h << 8 | (unsigned)j;
-                            key = key > kj ? key : kj;
-                            const int en = imax(isub0(e, e_del), M - oe_del);     // = max(e - e_del, M - oe_del, 0): e, f >= 0; a negative M loses anyway
-                            f = imax(isub0(f, e_ins), M - oe_ins);
-                            const uint32_t nw = (uint32_t)h1 | ((uint32_t)en << 8);
-                            word = (word & ~(0xffffu << (16 * u))) | nw << (16 * u);
-                            const int jj = nw ? j : -1;
-                            lnz = lnz > jj ? lnz : jj;
-                            fnz_u = fnz_u < (unsigned)jj ? fnz_u : (unsigned)jj;
-                            h1 = h;
-                        }
-                    }
-                    R[b][pp & 31] = word;
-                }
-                sq >>= 16;
-                if (((jp + 2) & 3) == 0) { sq = __builtin_amdgcn_perm(t_hi, t_lo, qnext); if (jp + 6 < jhi) qnext = QL[((jp + 2) >> 2) * 64 + 64 + lane]; }
-            }
-        }
-        const int m = (int)(key >> 8), mj = (int)(key & 255u), fnz = (int)fnz_u;
-        // eh[end] = {h1, 0}, bandedSWA.cpp:201: the pairs holding the `end` column of some live lane, walked uniformly
-        if (__ballot(alive)) {
-#pragma unroll
-            for (int b = 0; b < NB; b++) {
-                const int pa = imax(elo >> 1, b * 32), pb = imin((jhi >> 1) + 1, b * 32 + 32);
-                for (int pp = pa; pp < pb; pp++) {
-                    if (alive && (end >> 1) == pp) {
-                        uint32_t word = R[b][pp & 31];
-                        word = (word & ~(0xffffu << (16 * (end & 1)))) | (uint32_t)h1 << (16 * (end & 1));
-                        R[b][pp & 31] = word;
-                    }
-                }
-            }
-        }
-        if (alive) {
-            if (h1) lnz = end;
-            const int jfin = beg < end ? end : beg;
-            if (jfin == qlen) { max_ie = gscore > h1 ? max_ie : i; gscore = gscore > h1 ? gscore : h1; }
-            if (m == 0) alive = false;
-            else {
-                const bool new_max = m > maxv;
-                if (new_max) {
-                    maxv = m; max_i = i; max_j = mj;
-                    const int d = mj - i;
-                    max_off = imax(max_off, d < 0 ? -d : d);
-                }
-                if (zdrop_stop(cls, new_max, maxv, m, i - max_i, mj - max_j, e_del, e_ins, P.zdrop)) alive = false;
-                const int nb = fnz >= 0 ? fnz : end;
-                const int jl = imax(lnz, nb - 1);
-                beg = nb;
-                end = jl + 2 < qlen ? jl + 2 : qlen;
-                if (i + 1 >= tlen) alive = false;
-            }
-        }
-    }
-    if (run) { out.score = maxv; out.qle = max_j + 1; out.tle = max_i + 1; out.gtle = max_ie + 1; out.gscore = gscore; out.max_off = max_off; }
-}
-
-template <int SIDE, bool P8, bool PF, int RB = 0, bool PT = false>      // RB > 0: rows in registers, RB blocks of 64 columns (lane_dp8r); PT: scores by byte permute
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RB == 2 ? 4 : 1)))       // (RB == 2: 132 VGPRs without the hint)
+template <int SIDE, bool P8, bool PF, bool PT = false>      // PT: scores by byte permute (lane_dp8)
+__global__ void __launch_bounds__(64)
 k_ext_lanes(DevIndex ix, ExtParams xp, const int32_t *__restrict__ tasks, int n_tasks, int qmax,
             const uint8_t *__restrict__ enc, const int64_t *__restrict__ off, const int32_t *__restrict__ len,
             const int64_t *__restrict__ slot_base, const int32_t *__restrict__ reg_seed, const int32_t *__restrict__ reg_chain,
@@ -487,11 +340,10 @@ k_ext_lanes(DevIndex ix, ExtParams xp, const int32_t *__restrict__ tasks, int n_
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_l[];
     uint32_t *EH = lds_l;                                       // [(qmax+1)][64]           (P8: [(qmax+2)/2][64])
     uint8_t *QL = (uint8_t *)(lds_l + (size_t)(qmax + 1) * 64); // [qmax][64] bytes
-    uint32_t *QL8 = RB ? lds_l : lds_l + (size_t)((qmax + 2) / 2) * 64;      // P8: [(qmax+7)/8][64] dwords, 8 bases of 4 bits each
+    uint32_t *QL8 = lds_l + (size_t)((qmax + 2) / 2) * 64;      // P8: [(qmax+7)/8][64] dwords, 8 bases of 4 bits each (PT: [(qmax+3)/4 + 1][64], one per byte)
     const int lane = threadIdx.x;
-    wave_priority(rev >> 1);
     // (rev: the task list ascends in query length; the blocks with the longest queries -- the slowest wavefronts -- are dispatched first)
-    const int idx = ((rev & 1) ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x) * 64 + lane;
+    const int idx = (rev ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x) * 64 + lane;
     const bool valid = idx < n_tasks;
     const SwParams &P = SIDE == 0 ? xp.left : xp.right;
     int g = 0, l_query = 0, h0 = 0, prev = -1;
@@ -510,7 +362,7 @@ k_ext_lanes(DevIndex ix, ExtParams xp, const int32_t *__restrict__ tasks, int n_
     }
     // stage the query bases
     const int maxq = __builtin_amdgcn_readlane(wave_scan_max(valid ? tg.len2 : 0, 0), 63);
-    if (RB || PT) {                                             // one base per byte, 4 to a dword: the selector words of the byte permute
+    if (PT) {                                                   // one base per byte, 4 to a dword: the selector words of the byte permute
         for (int j0 = 0; j0 < maxq; j0 += 4) {
             if (valid && j0 < tg.len2) {
                 uint32_t wq = 0;
@@ -538,8 +390,7 @@ k_ext_lanes(DevIndex ix, ExtParams xp, const int32_t *__restrict__ tasks, int n_
         if (!__ballot(run)) break;
         const int w = xp.w << t;
         const int wc = band_clamp(w, tg.len2, P, cls);
-        if constexpr (RB > 0) lane_dp8r<RB>(run, tg.len2, tg.len1, wc, h0, tg.t, tg.ts, P, QL8, lane, o, cells);
-        else if (P8) lane_dp8<PF, PT>(run, tg.len2, tg.len1, wc, h0, tg.t, tg.ts, P, EH, QL8, lane, o, cells);
+        if (P8) lane_dp8<PF, PT>(run, tg.len2, tg.len1, wc, h0, tg.t, tg.ts, P, EH, QL8, lane, o, cells);
         else lane_dp(run, tg.len2, tg.len1, wc, h0, tg.t, tg.ts, P, EH, QL, lane, o, cells);
         if (run) {
             w_used = w;
@@ -592,8 +443,7 @@ k_ext_wave(DevIndex ix, ExtParams xp, const int32_t *__restrict__ tasks, int n_t
     int *RH = rings + (size_t)wv * 2 * R, *RE = RH + R;
     const int idx = blockIdx.x * (blockDim.x >> 6) + wv;
     if (idx >= n_tasks) return;
-    wave_priority(rev >> 1);
-    const int g = tasks[(rev & 1) ? n_tasks - 1 - idx : idx];
+    const int g = tasks[rev ? n_tasks - 1 - idx : idx];
     const int64_t base = slot_base[g];
     const DevChain c = chn[base + reg_chain[g]];
     const DevSeed s = seeds[base + reg_seed[g]];
@@ -961,24 +811,22 @@ struct ExtLaunch {
     // launch policy (bm2_knob): which kernel takes a query-length class.  Every launch of a side lasts about as long as its slowest
     // wavefront, and a lane-per-task wavefront of 150-base queries walks ~30 k cells one after the other (milliseconds), so the
     // classes with few tasks or long queries go one task per WAVEFRONT (k_ext_wave: ~0.1 ms per task) beside the lane kernels.
-    int wave_qmin, wave_nmax, prefetch, rev, reg_rows, reg_rows_max, perm_scores, qmap, prio, prio_min, wave_prio;
+    int wave_qmin, wave_nmax, prefetch, rev, perm_scores, qmap;
 };
 
 // Left side, then right side (whose h0 is the left score).  Lane-per-task kernels per query-length class (each class needs
 // a different LDS footprint) plus the wavefront-per-task kernel; the launches of one side run concurrently on the
 // context's side streams, joined by events before the other side starts.
 static int run_sides(const ExtLaunch &L, const uint32_t *h_hist, const uint32_t *h_start, const int32_t *taskL, const int32_t *taskR) {
-    static const int cls_lds[N_CLS] = { 16, 32, 48, 64, 80, 96, 112, 128, 144, 160 };
-    static const int cls_reg[N_CLS] = { 14, 30, 46, 62, 78, 94, 112, 128, 144, 160 };     // (a register block holds 64 columns, the one past the query included)
-    const int *cls_hi = L.reg_rows && L.pack8 ? cls_reg : cls_lds;
+    static const int cls_hi[N_CLS] = { 16, 32, 48, 64, 80, 96, 112, 128, 144, 160 };
     bm2_ctx *c = L.c;
     for (int side = 0; side < 2; side++) {
         const int32_t *tasks = side == 0 ? taskL : taskR;
         const uint32_t *st = h_start + side * N_BINS, *hc = h_hist + side * N_BINS;
         (void)hipEventRecord(c->ev_fork, L.s);
         auto wave_launch = [&](hipStream_t sk, uint32_t first, uint32_t n) {
-            if (side == 0) hipLaunchKernelGGL(k_ext_wave<0>, dim3((n + 3) / 4), dim3(256), L.lds_w, sk, c->ix, L.xp, tasks + first, (int)n, L.enc, L.off, L.len, L.slot_base, L.reg_seed, L.reg_chain, L.chn, L.seeds, L.regs, L.R, L.counters, L.rev | L.wave_prio << 1);
-            else hipLaunchKernelGGL(k_ext_wave<1>, dim3((n + 3) / 4), dim3(256), L.lds_w, sk, c->ix, L.xp, tasks + first, (int)n, L.enc, L.off, L.len, L.slot_base, L.reg_seed, L.reg_chain, L.chn, L.seeds, L.regs, L.R, L.counters, L.rev | L.wave_prio << 1);
+            if (side == 0) hipLaunchKernelGGL(k_ext_wave<0>, dim3((n + 3) / 4), dim3(256), L.lds_w, sk, c->ix, L.xp, tasks + first, (int)n, L.enc, L.off, L.len, L.slot_base, L.reg_seed, L.reg_chain, L.chn, L.seeds, L.regs, L.R, L.counters, L.rev);
+            else hipLaunchKernelGGL(k_ext_wave<1>, dim3((n + 3) / 4), dim3(256), L.lds_w, sk, c->ix, L.xp, tasks + first, (int)n, L.enc, L.off, L.len, L.slot_base, L.reg_seed, L.reg_chain, L.chn, L.seeds, L.regs, L.R, L.counters, L.rev);
         };
         // the classes from k_wave up (long queries) and the fallback bin are adjacent in the task list: one wavefront-per-task launch
         int k_wave = N_CLS;
@@ -989,7 +837,7 @@ static int run_sides(const ExtLaunch &L, const uint32_t *h_hist, const uint32_t 
         // phase).  The eight launches of a side -- seven lane classes and the wavefront kernel -- get seven queues of their own: the shortest class rides the
         // stream of the second shortest (both end long before the side does; on the main stream -- qmap 1 -- it was dispatched last and became
         // the side's tail), the wavefront kernel takes that class's side stream.  (Issue priority -- s_setprio -- for the long classes'
-        // wavefronts, the critical path of every side, measured no gain: BM2_EXT_PRIO, profiles/r03z_sweep_priority.json.)
+        // wavefronts, the critical path of every side, was tried and measured no gain: profiles/r03z_sweep_priority.json.)
         for (int kk = 0; kk <= N_CLS; kk++) {                  // longest queries first: their tails overlap the short classes
             const int k = L.qmap == 1 ? (kk == 0 ? N_CLS : kk == 1 ? 0 : N_CLS + 1 - kk) : (kk == 0 ? N_CLS : N_CLS - kk);
             const bool on_main = L.qmap == 1 && k == 0;                        // (qmap 2: the shortest class behind the second shortest on ITS stream)
@@ -1015,17 +863,11 @@ static int run_sides(const ExtLaunch &L, const uint32_t *h_hist, const uint32_t 
                                       : (L.pack8 ? (L.prefetch ? k_ext_lanes<1, true, true> : k_ext_lanes<1, true, false>) : k_ext_lanes<1, false, false>);
                 size_t lds_k = lds;
                 if (L.pack8 && L.perm_scores && L.prefetch) {       // the LDS-row kernel with the byte-permute score table (query one base per byte)
-                    kern = side == 0 ? k_ext_lanes<0, true, true, 0, true> : k_ext_lanes<1, true, true, 0, true>;
+                    kern = side == 0 ? k_ext_lanes<0, true, true, true> : k_ext_lanes<1, true, true, true>;
                     lds_k = (size_t)((hi + 2) / 2) * 64 * 4 + (size_t)((hi + 3) / 4 + 1) * 64 * 4;
                 }
-                if (L.pack8 && L.reg_rows && hi <= L.reg_rows_max && hi <= 190) {      // the class's row in registers: 64 columns per block, column `hi` included
-                    const int rb = hi <= 62 ? 1 : hi <= 126 ? 2 : 3;
-                    kern = side == 0 ? (rb == 1 ? k_ext_lanes<0, true, false, 1> : rb == 2 ? k_ext_lanes<0, true, false, 2> : k_ext_lanes<0, true, false, 3>)
-                                     : (rb == 1 ? k_ext_lanes<1, true, false, 1> : rb == 2 ? k_ext_lanes<1, true, false, 2> : k_ext_lanes<1, true, false, 3>);
-                    lds_k = (size_t)((hi + 3) / 4 + 1) * 64 * 4;
-                }
                 hipLaunchKernelGGL(kern, dim3((n + 63) / 64), dim3(64), lds_k, sk, c->ix, L.xp, tasks + first, (int)n, hi, L.enc, L.off, L.len,
-                                   L.slot_base, L.reg_seed, L.reg_chain, L.chn, L.seeds, L.regs, L.counters, L.rev | (hi >= L.prio_min ? L.prio << 1 : 0));
+                                   L.slot_base, L.reg_seed, L.reg_chain, L.chn, L.seeds, L.regs, L.counters, L.rev);
             } else wave_launch(sk, first, n);
             if (on_main) continue;
             (void)hipEventRecord(c->ev_join[k], sk);
@@ -1065,13 +907,9 @@ int bm2_launch_extend(bm2_ctx *c, const bm2_opt &opt, const ChainParams &cp, int
     L.wave_nmax = bm2_knob("BM2_EXT_WAVE_NMAX", 0);                 // classes with at most this many tasks in a round: likewise (no gain measured)
     L.prefetch = bm2_knob("BM2_EXT_PREFETCH", 1);
     L.rev = bm2_knob("BM2_EXT_REVERSE", 1);      // (sweep of round 3: -0.6 ms)
-    L.reg_rows = bm2_knob("BM2_EXT_REG_ROWS", 0);                   // (same sweep: no gain at any class bound, +8 ms with every class)
-    L.reg_rows_max = bm2_knob("BM2_EXT_REG_ROWS_MAX", 94);           // classes of longer queries keep their rows in LDS
     L.qmap = bm2_knob("BM2_EXT_QUEUE_MAP", 2);      // (profiles/r03y_*, r03z_*: extension 26.5 ms with the old assignment, 25.0 with 1, 24.6 with 2)
-    L.prio = bm2_knob("BM2_EXT_PRIO", 0) & 3; L.prio_min = bm2_knob("BM2_EXT_PRIO_MIN", 80); L.wave_prio = bm2_knob("BM2_EXT_WAVE_PRIO", 0) & 3;
-    L.rev = L.rev ? 1 : 0;
     L.perm_scores = bm2_knob("BM2_EXT_PERM_SCORES", 1);            // (sweep of round 3, profiles/r03v_sweep_lane_variants.json: extension 28.0 -> 26.5 ms)
-    for (int k : { 0, 1, 4 }) if (opt.mat[k] < -128 || opt.mat[k] > 127) L.reg_rows = L.perm_scores = 0;     // (the score table holds signed bytes)
+    for (int k : { 0, 1, 4 }) if (opt.mat[k] < -128 || opt.mat[k] > 127) L.perm_scores = 0;     // (the score table holds signed bytes)
     const int lazy_rounds = bm2_knob("BM2_EXT_ROUNDS", LAZY_ROUNDS), pend_div = bm2_knob("BM2_EXT_PEND_DIV", 12);
     L.R = ring_size2(opt.w << (MAX_BAND_TRY - 1));
     L.lds_w = ((sizeof(ExtParams) + 3) / 4) * 4 + (size_t)4 * 2 * L.R * 4;

@@ -56,12 +56,7 @@ static __device__ __forceinline__ uint32_t qsum32(uint32_t v) {                 
 // the address-translation rate caps the kernel at ~22 G lines/s once the index exceeds ~3 GB; fetched by quads the same
 // hardware delivers ~50 G lines/s (tools/ubench/randline.hip).  Lane b then ranks base b at both ends of the interval,
 // and three quad sums hand lane t what it needs: occ(a, k), the size d[a], and the sizes of the bases above a.
-static __device__ __forceinline__ ulonglong2 load_nt16(const ulonglong2 *p) {      // global_load_dwordx4 ... nt: a line this wave will not touch again
-    const uint64_t *q = (const uint64_t *)p;
-    ulonglong2 r; r.x = __builtin_nontemporal_load(q); r.y = __builtin_nontemporal_load(q + 1);
-    return r;
-}
-template <int T, bool NT = false>
+template <int T>
 static __device__ __forceinline__ void coop_issue(const DevIndex &ix, int64_t k, int64_t s, int want, int sub, ulonglong2 &e1, ulonglong2 &e2) {
     const int64_t sp = qbcast64<T>(k), ep = sp + qbcast64<T>(s);
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -71,10 +66,11 @@ static __device__ __forceinline__ void coop_issue(const DevIndex &ix, int64_t k,
     e1 = make_ulonglong2(0, 0); e2 = e1;
 #endif
     if (qbcast32<T>(want)) {         // (a quad whose lane T has nothing pending loads nothing: idle lanes must not all hit one line)
-        if (NT) { e1 = load_nt16(&((const ulonglong2 *)&ix.cp_occ[sp >> 6])[sub]); e2 = load_nt16(&((const ulonglong2 *)&ix.cp_occ[ep >> 6])[sub]); }
-        else { e1 = ((const ulonglong2 *)&ix.cp_occ[sp >> 6])[sub]; e2 = ((const ulonglong2 *)&ix.cp_occ[ep >> 6])[sub]; }
+        e1 = ((const ulonglong2 *)&ix.cp_occ[sp >> 6])[sub];
+        e2 = ((const ulonglong2 *)&ix.cp_occ[ep >> 6])[sub];
         // (the second request also when both ends lie in one block, 4 of 10 calls: skipping it under a per-quad branch measured 18 % SLOWER,
-        //  profiles/r03i_bench.json vs bench_sb)
+        //  profiles/r03i_bench.json vs bench_sb; with non-temporal loads -- lines nobody touches again, +8 % in the random-line micro-benchmark --
+        //  the kernel is 17 % SLOWER: the first steps of every walk hit the same few thousand lines, profiles/r03v_sweep_lane_variants.json)
     }
 }
 // What lane T gets back travels as four 32-bit quad sums (a 64-bit sum is three instructions per step, a 32-bit one can fold its
@@ -95,14 +91,13 @@ static __device__ __forceinline__ void coop_rank(int64_t k, int64_t s, int a, in
     const uint32_t hw = qsum32(is_at ? (uint32_t)(o1 >> 32) | (uint32_t)(d >> 32) << 8 : above ? (uint32_t)(d >> 31) << 16 : 0u);
     if (sub == T) { out.xl = xl; out.yl = yl; out.zl = zl; out.hw = hw; }
 }
-template <bool NT = false>
 static __device__ __forceinline__ Bi backward_ext(const DevIndex &ix, Bi in, int a, bool want) {
     const int sub = (int)(threadIdx.x & 3);
     const int64_t k = want ? in.k : 0, s = want ? in.s : 0;
     ulonglong2 e1[4], e2[4];
     const int w = want ? 1 : 0;
-    coop_issue<0, NT>(ix, k, s, w, sub, e1[0], e2[0]); coop_issue<1, NT>(ix, k, s, w, sub, e1[1], e2[1]);
-    coop_issue<2, NT>(ix, k, s, w, sub, e1[2], e2[2]); coop_issue<3, NT>(ix, k, s, w, sub, e1[3], e2[3]);
+    coop_issue<0>(ix, k, s, w, sub, e1[0], e2[0]); coop_issue<1>(ix, k, s, w, sub, e1[1], e2[1]);
+    coop_issue<2>(ix, k, s, w, sub, e1[2], e2[2]); coop_issue<3>(ix, k, s, w, sub, e1[3], e2[3]);
     QuadOut q = { 0, 0, 0, 0 };
     coop_rank<0>(k, s, a, sub, e1[0], e2[0], q); coop_rank<1>(k, s, a, sub, e1[1], e2[1], q);
     coop_rank<2>(k, s, a, sub, e1[2], e2[2], q); coop_rank<3>(k, s, a, sub, e1[3], e2[3], q);
@@ -388,7 +383,7 @@ k_walk(DevIndex ix, SeedParams sp, int n_reads, const uint8_t *__restrict__ enc,
 enum { B_EXT = 0, B_NEWITEM, B_FIRST, B_ROWEND, B_ROW, B_FIN, B_DONE };
 
 // LC: survivors of a row kept in LDS per lane (16 B x LC x 256 lanes per block decides how many blocks share a CU's 160 KB)
-template <int LC, bool NT = false>
+template <int LC>
 static __device__ __forceinline__ void
 bwd_body(const DevIndex &ix, const SeedParams &sp, int pass, const uint8_t *__restrict__ enc, const BHead *__restrict__ heads,
          uint4 *__restrict__ ents, int64_t slot_cap, uint4 *__restrict__ pool, int pool_cap, int pool_slots,
@@ -484,7 +479,7 @@ bwd_body(const DevIndex &ix, const SeedParams &sp, int pass, const uint8_t *__re
         if (state == B_EXT) prof_active++;
 #endif
         const Bi ein = { ck, cl, cs };
-        const Bi o = backward_ext<NT>(ix, ein, a, state == B_EXT);    // (all lanes: quad-cooperative)
+        const Bi o = backward_ext(ix, ein, a, state == B_EXT);    // (all lanes: quad-cooperative)
         if (state == B_EXT) {                                   // :607-649
             n_ext++;
             if (!first_done && o.s < (int64_t)min_intv && (cn - m_row + 1) >= sp.min_seed_len) {
@@ -537,7 +532,7 @@ bwd_body(const DevIndex &ix, const SeedParams &sp, int pass, const uint8_t *__re
                  int64_t slot_cap, uint4 *__restrict__ pool, int pool_cap, int pool_slots, bm2_smem_t *__restrict__ recs, int64_t rec_cap, \
                  P2Task *__restrict__ tasks, int64_t task_cap, int32_t *__restrict__ smem_cnt, unsigned long long *sc
 #define BWD_PASS ix, sp, pass, enc, heads, ents, slot_cap, pool, pool_cap, pool_slots, recs, rec_cap, tasks, task_cap, smem_cnt, sc
-template <int LC, bool NT = false> __global__ void __launch_bounds__(256) k_bwd(BWD_ARGS) { bwd_body<LC, NT>(BWD_PASS); }     // 111 VGPRs: 4 waves per SIMD
+template <int LC> __global__ void __launch_bounds__(256) k_bwd(BWD_ARGS) { bwd_body<LC>(BWD_PASS); }     // 111 VGPRs: 4 waves per SIMD
 // the same with the register allocation told to leave room for 5 waves per SIMD (96 VGPRs, 100 bytes per lane spilled)
 template <int LC> __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) k_bwd5(BWD_ARGS) { bwd_body<LC>(BWD_PASS); }
 
@@ -955,7 +950,6 @@ int bm2_launch_seeding(bm2_ctx *c, const SeedParams &sp, int n_reads, const uint
         const int lc = bm2_knob("BM2_BWD_LCAP", LCAP), wpe = bm2_knob("BM2_BWD_WAVES", 4);
         auto kb = wpe >= 5 ? (lc <= 4 ? k_bwd5<4> : k_bwd5<6>)
                            : (lc <= 4 ? k_bwd<4> : lc <= 6 ? k_bwd<6> : lc <= 8 ? k_bwd<8> : k_bwd<LCAP>);
-        if (bm2_knob("BM2_BWD_NT", 0) && wpe < 5 && lc > 8) kb = k_bwd<LCAP, true>;       // non-temporal CP_OCC loads
         hipLaunchKernelGGL(kb, dim3(grid_bwd), dim3(256), 0, s, c->ix, sp, pass, enc, heads, ents, slot_cap, sb.pool, sb.pool_cap,
                            sb.pool_slots, sb.recs, sb.rec_cap, sb.tasks, sb.task_cap, smem_cnt, sc);
         (void)hipStreamWaitEvent(s, c->ev_join[1], 0);

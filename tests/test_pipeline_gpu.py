@@ -202,15 +202,13 @@ def test_sub_batch_pipelining_matches_single_part(tmp_path):
     _same(exp["REGPRG"], regs_to_records(r4, o4), "REGPRG")
 
 
-@pytest.mark.parametrize("knob", ["BM2_EXT_REG_ROWS", "BM2_EXT_PERM_SCORES"])
 @pytest.mark.parametrize("name,L", [("g60k", 150), ("g20k_l76", 76)])
-def test_extension_lane_kernel_variants(golden_dir, name, L, knob, tmp_path):
-    # the lane kernels with the row in a register array indexed by the wave-uniform column pair (BM2_EXT_REG_ROWS) / with the cell's
-    # score from a byte permute over the row's score table (BM2_EXT_PERM_SCORES): the goldens' regs, and a fresh chunk of reads whose
-    # query-length classes fill whole wavefronts, against the default kernels
+def test_extension_lane_kernel_without_the_score_table(golden_dir, name, L, tmp_path):
+    # the lane kernels take a cell's score from a byte permute over the row's score table (the default when the three scores fit a
+    # signed byte); BM2_EXT_PERM_SCORES=0 is the kernel they fall back to -- 4-bit query, two compares per cell: the goldens' regs
+    # through it, and a fresh chunk of reads whose query-length classes fill whole wavefronts through both
     pre, enc, off, ln, d = load_golden(golden_dir, name)
-    val = "0" if knob == "BM2_EXT_PERM_SCORES" else "1"          # (the permute table is the default: its variant is the 4-bit query with compares)
-    os.environ[knob] = val
+    os.environ["BM2_EXT_PERM_SCORES"] = "0"
     try:
         ctx = bm2.Context(0, pre)
         try:
@@ -225,7 +223,7 @@ def test_extension_lane_kernel_variants(golden_dir, name, L, knob, tmp_path):
         finally:
             c1.close()
     finally:
-        del os.environ[knob]
+        del os.environ["BM2_EXT_PERM_SCORES"]
     c0 = bm2.Context(0, fa)
     try:
         r0, o0, s0 = c0.seed_chain_extend(enc2, off2, ln2, bm2.default_opt())

@@ -24,18 +24,11 @@ GRID = [   # (name, candidates): a candidate is a dict of knobs set together; th
     ("chain staging", [{}, {"BM2_CHAIN_STAGE": 1}]),
     ("chain heavy threshold", [{}, {"BM2_HEAVY_SA": 64}, {"BM2_HEAVY_SA": 40}, {"BM2_HEAVY_SA": 24}, {"BM2_HEAVY_SA": 160}, {"BM2_HEAVY_SA": 256}, {"BM2_HEAVY_SA": 512}]),
     ("chain waves per CU", [{}, {"BM2_CHAIN_WAVES_PER_CU": 32}, {"BM2_CHAIN_WAVES_PER_CU": 8}]),
-    ("k_bwd non-temporal loads", [{}, {"BM2_BWD_NT": 1}]),
     ("k_bwd LDS survivors / blocks per CU / waves per SIMD", [{}, {"BM2_BWD_LCAP": 8, "BM2_BWD_BLOCKS_PER_CU": 4}, {"BM2_BWD_LCAP": 6, "BM2_BWD_BLOCKS_PER_CU": 4},
                                                               {"BM2_BWD_LCAP": 4, "BM2_BWD_BLOCKS_PER_CU": 4},
                                                               {"BM2_BWD_LCAP": 6, "BM2_BWD_BLOCKS_PER_CU": 5, "BM2_BWD_WAVES": 5},
                                                               {"BM2_BWD_LCAP": 4, "BM2_BWD_BLOCKS_PER_CU": 5, "BM2_BWD_WAVES": 5}]),
-    ("extension rows in registers", [{}, {"BM2_EXT_REG_ROWS": 1, "BM2_EXT_REG_ROWS_MAX": 94}, {"BM2_EXT_REG_ROWS": 1, "BM2_EXT_REG_ROWS_MAX": 62},
-                                     {"BM2_EXT_REG_ROWS": 1, "BM2_EXT_REG_ROWS_MAX": 78}, {"BM2_EXT_REG_ROWS": 1, "BM2_EXT_REG_ROWS_MAX": 112},
-                                     {"BM2_EXT_REG_ROWS": 1, "BM2_EXT_REG_ROWS_MAX": 46}, {"BM2_EXT_REG_ROWS": 1, "BM2_EXT_REG_ROWS_MAX": 30}]),
     ("extension launches on distinct hardware queues", [{}, {"BM2_EXT_QUEUE_MAP": 2}, {"BM2_EXT_QUEUE_MAP": 0}]),
-    ("extension issue priority of the long classes", [{}, {"BM2_EXT_PRIO": 3, "BM2_EXT_PRIO_MIN": 80, "BM2_EXT_WAVE_PRIO": 3}, {"BM2_EXT_PRIO": 3, "BM2_EXT_PRIO_MIN": 96, "BM2_EXT_WAVE_PRIO": 3},
-                                                      {"BM2_EXT_PRIO": 2, "BM2_EXT_PRIO_MIN": 64, "BM2_EXT_WAVE_PRIO": 3}, {"BM2_EXT_PRIO": 3, "BM2_EXT_PRIO_MIN": 80, "BM2_EXT_WAVE_PRIO": 0},
-                                                      {"BM2_EXT_PRIO": 0, "BM2_EXT_WAVE_PRIO": 3}, {"BM2_EXT_PRIO": 3, "BM2_EXT_PRIO_MIN": 112, "BM2_EXT_WAVE_PRIO": 2}]),
     ("extension scores by byte permute", [{}, {"BM2_EXT_PERM_SCORES": 0}]),
     ("extension wave classes", [{}, {"BM2_EXT_WAVE_QMIN": 129}, {"BM2_EXT_WAVE_QMIN": 97}, {"BM2_EXT_WAVE_QMIN": 161}]),
     ("extension rounds", [{}, {"BM2_EXT_ROUNDS": 2}, {"BM2_EXT_ROUNDS": 1}, {"BM2_EXT_PEND_DIV": 6}, {"BM2_EXT_PEND_DIV": 24}]),
