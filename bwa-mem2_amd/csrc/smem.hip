@@ -55,7 +55,7 @@ static __device__ __forceinline__ uint32_t qsum32(uint32_t v) {                 
 // quarter b -- so that one load instruction touches 16 lines (and 16 pages) per wave, not 64: with one entry per lane
 // the address-translation rate caps the kernel at ~22 G lines/s once the index exceeds ~3 GB; fetched by quads the same
 // hardware delivers ~50 G lines/s (tools/ubench/randline.hip).  Lane b then ranks base b at both ends of the interval,
-// and three quad sums hand lane t what it needs: occ(a, k), the size d[a], and the sizes of the bases above a.
+// and four 32-bit quad sums (coop_rank) hand lane t what it needs: occ(a, k), the size d[a], and the sizes of the bases above a.
 template <int T>
 static __device__ __forceinline__ void coop_issue(const DevIndex &ix, int64_t k, int64_t s, int want, int sub, ulonglong2 &e1, ulonglong2 &e2) {
     const int64_t sp = qbcast64<T>(k), ep = sp + qbcast64<T>(s);
