@@ -11,10 +11,13 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
+#include <new>
 #include <algorithm>
 #include <atomic>
 #include <string>
 #include <thread>
+#include <utility>
 #include <vector>
 #include <chrono>
 #include "../../include/bm2.h"
@@ -41,10 +44,36 @@ template <class F> void parallel_for(int nthr, int64_t n, F f) {       // f(tid,
     for (auto &x : th) x.join();
 }
 
+// The text, its packed copy and the suffix array are gigabytes that the bucket scatter, the bucket sorts and the BWT pass touch at RANDOM:
+// on 4 KB pages every such access is a TLB miss on top of the cache miss.  2 MB pages where the kernel gives them out on request
+// (transparent_hugepage = madvise); a plain allocation otherwise.
+inline void *huge_alloc(size_t bytes) {
+    void *p = nullptr;
+    const size_t al = (size_t)2 << 20;
+    if (posix_memalign(&p, al, (bytes + al - 1) / al * al) != 0) return nullptr;
+#ifdef MADV_HUGEPAGE
+    (void)madvise(p, (bytes + al - 1) / al * al, MADV_HUGEPAGE);
+#endif
+    return p;
+}
+template <class U> struct HugeAlloc {
+    typedef U value_type;
+    HugeAlloc() {}
+    template <class V> HugeAlloc(const HugeAlloc<V> &) {}
+    U *allocate(size_t n) { U *p = (U *)huge_alloc(n * sizeof(U)); if (!p) throw std::bad_alloc(); return p; }
+    void deallocate(U *p, size_t) { free(p); }
+    // resize() leaves new elements uninitialised (every one is written by the loop that follows it -- in parallel, which is also who should
+    // take the page faults); assign(n, v) / resize(n, v) still fill
+    template <class V> void construct(V *p) { ::new ((void *)p) V; }
+    template <class V, class A0, class... A> void construct(V *p, A0 &&a0, A &&...a) { ::new ((void *)p) V(std::forward<A0>(a0), std::forward<A>(a)...); }
+    template <class V> bool operator==(const HugeAlloc<V> &) const { return true; }
+    template <class V> bool operator!=(const HugeAlloc<V> &) const { return false; }
+};
+
 struct Text {
     int64_t N = 0;                  // 2 * l_pac
-    std::vector<uint8_t> T;         // one base per byte (.0123)
-    std::vector<uint64_t> P;        // 2-bit packed, 32 bases per word, first base in the top bits
+    std::vector<uint8_t, HugeAlloc<uint8_t>> T;         // one base per byte (.0123)
+    std::vector<uint64_t, HugeAlloc<uint64_t>> P;       // 2-bit packed, 32 bases per word, first base in the top bits
     inline uint64_t get32(int64_t i) const {
         const int64_t w = i >> 5; const int s = (int)(i & 31) * 2;
         return s ? (P[w] << s) | (P[w + 1] >> (64 - s)) : P[w];
@@ -87,13 +116,14 @@ extern "C" int bm2_index_build(const char *fasta, const char *prefix, int n_thre
     FILE *f = fopen(fasta, "rb");
     if (!f) { bm2_set_error("cannot open %s", fasta); return BM2_EIO; }
     fseek(f, 0, SEEK_END); const int64_t fsz = ftell(f); fseek(f, 0, SEEK_SET);
-    std::vector<char> buf((size_t)fsz + 1);
+    std::vector<char, HugeAlloc<char>> buf((size_t)fsz + 1);      // (uninitialised: fread fills it)
+    buf[(size_t)fsz] = 0;
     if (fsz > 0 && (int64_t)fread(buf.data(), 1, (size_t)fsz, f) != fsz) { fclose(f); bm2_set_error("short read on %s", fasta); return BM2_EIO; }
     fclose(f);
     if (fsz >= 2 && (uint8_t)buf[0] == 0x1f && (uint8_t)buf[1] == 0x8b) { bm2_set_error("%s is gzip-compressed: give plain FASTA", fasta); return BM2_EUNSUP; }
     std::vector<Contig> ctg; std::vector<Hole> holes;
     Text tx;
-    std::vector<uint8_t> &T = tx.T;
+    std::vector<uint8_t, HugeAlloc<uint8_t>> &T = tx.T;
     T.resize((size_t)fsz + 64);                        // bases <= file size; shrunk below
     int64_t tw = 0;                                     // write cursor into T
     uint8_t tbl[256];
@@ -139,7 +169,7 @@ extern "C" int bm2_index_build(const char *fasta, const char *prefix, int n_thre
             }
         }
     }
-    std::vector<char>().swap(buf);
+    std::vector<char, HugeAlloc<char>>().swap(buf);
     T.resize((size_t)tw);
     lap("read + parse FASTA");
     const int64_t l_pac = tw;
@@ -176,12 +206,21 @@ extern "C" int bm2_index_build(const char *fasta, const char *prefix, int n_thre
     tx.N = N;
     T.resize((size_t)N);
     parallel_for(n_threads, l_pac, [&](int, int64_t b, int64_t e) { for (int64_t i = b; i < e; i++) T[N - 1 - i] = 3 - T[i]; });
+    // (the text is final from here on: its file -- N bytes -- is written by a thread of its own beside the suffix sort)
+    struct TextWriter {
+        std::thread th; bool ok = true;
+        ~TextWriter() { if (th.joinable()) th.join(); }
+    } tw0123;
     {
-        FILE *o = fopen((pre + ".0123").c_str(), "wb");
-        if (!o || (int64_t)fwrite(T.data(), 1, (size_t)N, o) != N) { if (o) fclose(o); bm2_set_error("cannot write %s.0123", prefix); return BM2_EIO; }
-        fclose(o);
+        const uint8_t *tp = T.data(); const std::string fn = pre + ".0123";
+        tw0123.th = std::thread([tp, N, fn, &tw0123]() {
+            FILE *o = fopen(fn.c_str(), "wb");
+            if (!o || (int64_t)fwrite(tp, 1, (size_t)N, o) != N) tw0123.ok = false;
+            if (o && fclose(o) != 0) tw0123.ok = false;
+        });
     }
-    tx.P.assign((size_t)(N >> 5) + 3, 0);
+    tx.P.resize((size_t)(N >> 5) + 3);
+    for (int64_t w = (N >> 5) + 1; w < (N >> 5) + 3; w++) tx.P[(size_t)w] = 0;      // (the words past the text that get32 may read)
     parallel_for(n_threads, (N >> 5) + 1, [&](int, int64_t b, int64_t e) {
         for (int64_t w = b; w < e; w++) {
             uint64_t v = 0;
@@ -203,8 +242,13 @@ extern "C" int bm2_index_build(const char *fasta, const char *prefix, int n_thre
     auto key_of = [&](int64_t i) -> int64_t {              // first KPRE bases, zero-padded past the end (a short suffix then
         return (int64_t)(tx.get32(i) >> (64 - 2 * KPRE));  // sorts first inside the bucket it is padded into)
     };
-    std::vector<int64_t> SA((size_t)N + 2);
-    SA[0] = N;
+    lap("base counts");
+    // (not a std::vector: value-initialising 8 N bytes -- 50 GB for a human genome -- on one thread took longer than sorting them; every entry
+    //  is written by the scatter below, whose threads also take the page faults)
+    struct RawI64 { int64_t *p; explicit RawI64(size_t n) : p((int64_t *)huge_alloc(n * sizeof(int64_t))) {} ~RawI64() { free(p); } } sa_mem((size_t)N + 2);
+    if (!sa_mem.p) { bm2_set_error("bm2_index_build: cannot allocate %lld bytes for the suffix array", (long long)((N + 2) * 8)); return BM2_ENOMEM; }
+    int64_t *const SA = sa_mem.p;
+    SA[0] = N; SA[N + 1] = 0;
     std::vector<int64_t> bstart((size_t)NB + 1, 0);
     {
         // text chunks: enough for all cores, few enough that the per-chunk histograms (16 MB each) stay cheap to combine
@@ -246,7 +290,7 @@ extern "C" int bm2_index_build(const char *fasta, const char *prefix, int n_thre
                     if (b0 >= NB) break;
                     for (int64_t b = b0; b < b0 + 256 && b < NB; b++) {
                         const int64_t lo = bstart[b], hi = bstart[b + 1];
-                        if (hi - lo > 1) std::sort(SA.begin() + lo, SA.begin() + hi, [&](int64_t x, int64_t y) { return tx.less(x, y); });
+                        if (hi - lo > 1) std::sort(SA + lo, SA + hi, [&](int64_t x, int64_t y) { return tx.less(x, y); });
                     }
                 }
             });
@@ -262,6 +306,8 @@ extern "C" int bm2_index_build(const char *fasta, const char *prefix, int n_thre
     parallel_for(n_threads, n_occ, [&](int t, int64_t b, int64_t e) {
         for (int64_t blk = b; blk < e; blk++) {
             CpOcc c; memset(&c, 0, sizeof c);
+            if ((blk + 2) * 64 + 63 < ref_seq_len)                  // (T[SA[i] - 1] is a cache miss per suffix: asked for two blocks ahead)
+                for (int j = 0; j < 64; j++) { const int64_t s2 = SA[(blk + 2) * 64 + j]; if (s2 > 0) __builtin_prefetch(&T[s2 - 1], 0, 0); }
             for (int j = 0; j < 64; j++) {
                 const int64_t i = blk * 64 + j;
                 for (int k = 0; k < 4; k++) c.bwt[k] <<= 1;
@@ -299,6 +345,8 @@ extern "C" int bm2_index_build(const char *fasta, const char *prefix, int n_thre
         fclose(o);
         if (!ok) { bm2_set_error("short write on %s.bwt.2bit.64", prefix); return BM2_EIO; }
     }
+    tw0123.th.join();
+    if (!tw0123.ok) { bm2_set_error("cannot write %s.0123", prefix); return BM2_EIO; }
     lap("write .bwt.2bit.64");
     return BM2_OK;
 }
