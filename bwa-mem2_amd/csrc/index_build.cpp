@@ -70,6 +70,13 @@ template <class U> struct HugeAlloc {
     template <class V> bool operator!=(const HugeAlloc<V> &) const { return false; }
 };
 
+// first touch of a fresh allocation by all threads at once (one write per 4 KB page): page faults -- and the zeroing of 2 MB pages -- cost
+// seconds per GB on one thread
+inline void prefault(void *p, size_t bytes, int n_threads) {
+    volatile uint8_t *q = (volatile uint8_t *)p;
+    parallel_for(n_threads, (int64_t)((bytes + 4095) / 4096), [&](int, int64_t b, int64_t e) { for (int64_t i = b; i < e; i++) q[(size_t)i * 4096] = 0; });
+}
+
 struct Text {
     int64_t N = 0;                  // 2 * l_pac
     std::vector<uint8_t, HugeAlloc<uint8_t>> T;         // one base per byte (.0123)
@@ -79,8 +86,7 @@ struct Text {
         return s ? (P[w] << s) | (P[w + 1] >> (64 - s)) : P[w];
     }
     // suffix i < suffix j (i != j); the end of the text sorts before every base (implicit sentinel, as SA-IS does)
-    inline bool less(int64_t i, int64_t j) const {
-        int64_t off = 0;
+    inline bool less(int64_t i, int64_t j, int64_t off = 0) const {      // (off: bases already known to be equal)
         for (;;) {
             if (i + off + 32 <= N && j + off + 32 <= N) {
                 const uint64_t a = get32(i + off), b = get32(j + off);
@@ -117,6 +123,7 @@ extern "C" int bm2_index_build(const char *fasta, const char *prefix, int n_thre
     if (!f) { bm2_set_error("cannot open %s", fasta); return BM2_EIO; }
     fseek(f, 0, SEEK_END); const int64_t fsz = ftell(f); fseek(f, 0, SEEK_SET);
     std::vector<char, HugeAlloc<char>> buf((size_t)fsz + 1);      // (uninitialised: fread fills it)
+    prefault(buf.data(), buf.size(), n_threads);
     buf[(size_t)fsz] = 0;
     if (fsz > 0 && (int64_t)fread(buf.data(), 1, (size_t)fsz, f) != fsz) { fclose(f); bm2_set_error("short read on %s", fasta); return BM2_EIO; }
     fclose(f);
@@ -124,7 +131,9 @@ extern "C" int bm2_index_build(const char *fasta, const char *prefix, int n_thre
     std::vector<Contig> ctg; std::vector<Hole> holes;
     Text tx;
     std::vector<uint8_t, HugeAlloc<uint8_t>> &T = tx.T;
+    T.reserve((size_t)2 * (size_t)fsz + 64);           // (forward + reverse complement: no reallocation when the text doubles below)
     T.resize((size_t)fsz + 64);                        // bases <= file size; shrunk below
+    prefault(T.data(), T.capacity(), n_threads);
     int64_t tw = 0;                                     // write cursor into T
     uint8_t tbl[256];
     for (int c = 0; c < 256; c++) tbl[c] = (uint8_t)nt4(c);
@@ -220,6 +229,7 @@ extern "C" int bm2_index_build(const char *fasta, const char *prefix, int n_thre
         });
     }
     tx.P.resize((size_t)(N >> 5) + 3);
+    prefault(tx.P.data(), tx.P.size() * 8, n_threads);
     for (int64_t w = (N >> 5) + 1; w < (N >> 5) + 3; w++) tx.P[(size_t)w] = 0;      // (the words past the text that get32 may read)
     parallel_for(n_threads, (N >> 5) + 1, [&](int, int64_t b, int64_t e) {
         for (int64_t w = b; w < e; w++) {
@@ -285,12 +295,30 @@ extern "C" int bm2_index_build(const char *fasta, const char *prefix, int n_thre
         std::vector<std::thread> th;
         for (int t = 0; t < n_threads; t++)
             th.emplace_back([&]() {
+                std::vector<std::pair<uint64_t, int64_t>> kv;
                 for (;;) {
                     const int64_t b0 = next.fetch_add(256);
                     if (b0 >= NB) break;
                     for (int64_t b = b0; b < b0 + 256 && b < NB; b++) {
-                        const int64_t lo = bstart[b], hi = bstart[b + 1];
-                        if (hi - lo > 1) std::sort(SA + lo, SA + hi, [&](int64_t x, int64_t y) { return tx.less(x, y); });
+                        const int64_t lo = bstart[b], hi = bstart[b + 1], n = hi - lo;
+                        if (n <= 1) continue;
+                        if (n < 8) { std::sort(SA + lo, SA + hi, [&](int64_t x, int64_t y) { return tx.less(x, y, 0); }); continue; }
+                        // The bucket's suffixes agree in their first KPRE bases.  Their next 32 bases as ONE integer key each, fetched once
+                        // (a random read of the packed text per suffix instead of one per comparison), the (key, suffix) pairs sorted as
+                        // integers, and only the runs of equal keys -- repeats longer than KPRE + 32 bases -- compared base by base.  A
+                        // bucket with a suffix that ends inside the key window sorts by the full comparison (the end of the text sorts first).
+                        kv.resize((size_t)n);
+                        bool near_end = false;
+                        for (int64_t t = 0; t < n; t++) {
+                            const int64_t s = SA[lo + t];
+                            if (s + KPRE + 32 > N) { near_end = true; break; }
+                            kv[(size_t)t].first = tx.get32(s + KPRE); kv[(size_t)t].second = s;
+                        }
+                        if (near_end) { std::sort(SA + lo, SA + hi, [&](int64_t x, int64_t y) { return tx.less(x, y, 0); }); continue; }
+                        std::sort(kv.begin(), kv.end(), [&](const std::pair<uint64_t, int64_t> &x, const std::pair<uint64_t, int64_t> &y) {
+                            return x.first != y.first ? x.first < y.first : tx.less(x.second, y.second, KPRE + 32);
+                        });
+                        for (int64_t t = 0; t < n; t++) SA[lo + t] = kv[(size_t)t].second;
                     }
                 }
             });
