@@ -126,7 +126,6 @@ k_task_scatter(int64_t n_slots, const uint8_t *__restrict__ bins, uint32_t *curs
 // band or past its own exit is masked off.
 struct LaneOut { int score, qle, tle, gtle, gscore, max_off; };
 
-
 static __device__ void lane_dp(bool run, int qlen, int tlen, int w, int h0, const uint8_t *tp, int ts, const SwParams &P,
                                uint32_t *EH, const uint8_t *QL, int lane, LaneOut &out, long long &cells) {
     const int o_del = P.o_del, e_del = P.e_del, o_ins = P.o_ins, e_ins = P.e_ins, oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
@@ -834,14 +833,14 @@ static int run_sides(const ExtLaunch &L, const uint32_t *h_hist, const uint32_t 
         // Streams sit on HARDWARE QUEUES round-robin (GPU_MAX_HW_QUEUES = 8: the context's main stream and its first seven side streams are
         // eight different queues, side stream 10 shares the queue of side stream 3), and two launches on one queue run one after the other
         // (profiles/r03x_timeline.tsv: the 49..64-column class started when the wavefront kernel ended, 0.8-1.1 ms later than its peers, in every
-        // phase).  The eight launches of a side -- seven lane classes and the wavefront kernel -- get seven queues of their own: the shortest class rides the
-        // stream of the second shortest (both end long before the side does; on the main stream -- qmap 1 -- it was dispatched last and became
-        // the side's tail), the wavefront kernel takes that class's side stream.  (Issue priority -- s_setprio -- for the long classes'
-        // wavefronts, the critical path of every side, was tried and measured no gain: profiles/r03z_sweep_priority.json.)
+        // phase).  The eight launches of a side -- seven lane classes and the wavefront kernel -- get seven queues: the wavefront kernel takes the
+        // shortest class's side stream, the shortest class queues behind the second shortest (both end long before the side does; on the main
+        // stream it was dispatched last and became the side's tail: 25.0 instead of 24.6 ms).  BM2_EXT_QUEUE_MAP=0: one side stream per class
+        // index, as before (26.5 ms).  (Issue priority -- s_setprio -- for the long classes' wavefronts, the critical path of every side, was
+        // tried and measured no gain: profiles/r03z_sweep_priority.json.)
         for (int kk = 0; kk <= N_CLS; kk++) {                  // longest queries first: their tails overlap the short classes
-            const int k = L.qmap == 1 ? (kk == 0 ? N_CLS : kk == 1 ? 0 : N_CLS + 1 - kk) : (kk == 0 ? N_CLS : N_CLS - kk);
-            const bool on_main = L.qmap == 1 && k == 0;                        // (qmap 2: the shortest class behind the second shortest on ITS stream)
-            hipStream_t sk = !L.qmap ? c->side_stream[k] : k == N_CLS ? c->side_stream[0] : on_main ? L.s : c->side_stream[k ? k : 1];
+            const int k = kk == 0 ? N_CLS : N_CLS - kk;
+            hipStream_t sk = !L.qmap ? c->side_stream[k] : k == N_CLS ? c->side_stream[0] : c->side_stream[k ? k : 1];
             uint32_t n = 0, first = 0; int hi = 0;
             if (k < N_CLS) {
                 if (k >= k_wave) continue;                      // part of the launch of k == N_CLS
@@ -855,7 +854,7 @@ static int run_sides(const ExtLaunch &L, const uint32_t *h_hist, const uint32_t 
                 for (int b = lo + 1; b <= BIN_FALLBACK; b++) n += hc[b];
             }
             if (!n) continue;
-            if (!on_main) (void)hipStreamWaitEvent(sk, c->ev_fork, 0);
+            (void)hipStreamWaitEvent(sk, c->ev_fork, 0);
             if (k < N_CLS && (int64_t)n > (int64_t)L.wave_nmax) {
                 const size_t lds = L.pack8 ? (size_t)((hi + 2) / 2) * 64 * 4 + (size_t)((hi + 7) / 8) * 64 * 4
                                            : (size_t)(hi + 1) * 64 * 4 + (size_t)hi * 64;
@@ -869,7 +868,6 @@ static int run_sides(const ExtLaunch &L, const uint32_t *h_hist, const uint32_t 
                 hipLaunchKernelGGL(kern, dim3((n + 63) / 64), dim3(64), lds_k, sk, c->ix, L.xp, tasks + first, (int)n, hi, L.enc, L.off, L.len,
                                    L.slot_base, L.reg_seed, L.reg_chain, L.chn, L.seeds, L.regs, L.counters, L.rev);
             } else wave_launch(sk, first, n);
-            if (on_main) continue;
             (void)hipEventRecord(c->ev_join[k], sk);
             (void)hipStreamWaitEvent(L.s, c->ev_join[k], 0);
         }
@@ -907,7 +905,7 @@ int bm2_launch_extend(bm2_ctx *c, const bm2_opt &opt, const ChainParams &cp, int
     L.wave_nmax = bm2_knob("BM2_EXT_WAVE_NMAX", 0);                 // classes with at most this many tasks in a round: likewise (no gain measured)
     L.prefetch = bm2_knob("BM2_EXT_PREFETCH", 1);
     L.rev = bm2_knob("BM2_EXT_REVERSE", 1);      // (sweep of round 3: -0.6 ms)
-    L.qmap = bm2_knob("BM2_EXT_QUEUE_MAP", 2);      // (profiles/r03y_*, r03z_*: extension 26.5 ms with the old assignment, 25.0 with 1, 24.6 with 2)
+    L.qmap = bm2_knob("BM2_EXT_QUEUE_MAP", 1);      // (profiles/r03y_*, r03z_*: extension 26.5 -> 24.6 ms)
     L.perm_scores = bm2_knob("BM2_EXT_PERM_SCORES", 1);            // (sweep of round 3, profiles/r03v_sweep_lane_variants.json: extension 28.0 -> 26.5 ms)
     for (int k : { 0, 1, 4 }) if (opt.mat[k] < -128 || opt.mat[k] > 127) L.perm_scores = 0;     // (the score table holds signed bytes)
     const int lazy_rounds = bm2_knob("BM2_EXT_ROUNDS", LAZY_ROUNDS), pend_div = bm2_knob("BM2_EXT_PEND_DIV", 12);

@@ -261,7 +261,7 @@ static int run_seeding(bm2_ctx *c, Batch *b, const bm2_opt *opt, bool with_sal) 
     if (verbose) { fprintf(stderr, "[seeding] output reserve %.1f ms (n_smem %lld, caps %zu %zu %zu)\n", now_ms() - t0, (long long)n_smem_tot, b->smem.cap, b->smem_tmp.cap, b->occ_cnt.cap); t0 = now_ms(); }
     if ((rc = bm2_launch_smem_finish(c, n, sb, (const unsigned long long *)b->seedc.p, (const int32_t *)b->smem_cnt.p,
                                      (const int64_t *)b->smem_off.p, (int32_t *)b->fill.p, (bm2_smem_t *)b->smem_tmp.p, sp.max_occ,
-                                     (bm2_smem_t *)b->smem.p, (int32_t *)b->occ_cnt.p))) return rc;
+                                     (bm2_smem_t *)b->smem.p, (int32_t *)b->occ_cnt.p, b->max_len))) return rc;
     tick(c, "smem.finish");
     b->n_smem = (int64_t)h_cnt[0];
     b->stats.n_smem = b->n_smem; b->stats.n_ext = (int64_t)h_cnt[1];

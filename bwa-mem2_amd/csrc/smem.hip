@@ -959,7 +959,7 @@ int bm2_launch_seeding(bm2_ctx *c, const SeedParams &sp, int n_reads, const uint
     return bm2_check(hipGetLastError(), "seeding launch");
 }
 int bm2_launch_smem_finish(bm2_ctx *c, int n_reads, const SeedBufs &sb, const unsigned long long *sc, const int32_t *smem_cnt,
-                           const int64_t *smem_off, int32_t *fill, bm2_smem_t *tmp, int32_t max_occ, bm2_smem_t *out, int32_t *occ_cnt) {
+                           const int64_t *smem_off, int32_t *fill, bm2_smem_t *tmp, int32_t max_occ, bm2_smem_t *out, int32_t *occ_cnt, int max_len) {
     if (n_reads <= 0) return BM2_OK;
     hipLaunchKernelGGL(k_rec_scatter, dim3(c->n_cu * 8), dim3(256), 0, c->stream, sb.recs, sb.rec_cap, sc, smem_off, fill, tmp);
     // (`fill` is through after the scatter: its second half lists the reads that go to the workgroup-per-read sort; [2 n + 2], [2 n + 3] = count, cursor)
@@ -969,9 +969,12 @@ int bm2_launch_smem_finish(bm2_ctx *c, int n_reads, const SeedBufs &sb, const un
     int lds_keys = bm2_knob("BM2_SMEM_SORT_KEYS", SMEM_FINISH_LDS_KEYS);     // (a test hook: small values force the m-class runs on ordinary reads)
     if (lds_keys < 64) lds_keys = 64;
     if (lds_keys > SMEM_FINISH_LDS_KEYS) lds_keys = SMEM_FINISH_LDS_KEYS;
+    // (the sort key packs m, n and the record's index into 20 bits each: reads of 2^18 bases and more -- up to 3 SMEMs per base -- take the
+    //  kernel's one-lane path, which compares the fields themselves)
+    const int keys_arg = max_len < (1 << 18) ? lds_keys : 0;
     const size_t lds = (size_t)SMEM_FINISH_LDS_KEYS * 8;
     if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_smem_finish_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
-    hipLaunchKernelGGL(k_smem_finish_big, dim3(c->n_cu), dim3(256), lds, c->stream, tmp, smem_cnt, smem_off, max_occ, out, occ_cnt, big_list, big_cnt, big_cur, lds_keys);
+    hipLaunchKernelGGL(k_smem_finish_big, dim3(c->n_cu), dim3(256), lds, c->stream, tmp, smem_cnt, smem_off, max_occ, out, occ_cnt, big_list, big_cnt, big_cur, keys_arg);
     return bm2_check(hipGetLastError(), "k_smem_finish launch");
 }
 int bm2_seed_sizes(size_t *head, size_t *ent, size_t *task, int *n_sc) {
