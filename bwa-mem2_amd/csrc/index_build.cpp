@@ -260,6 +260,9 @@ extern "C" int bm2_index_build(const char *fasta, const char *prefix, int n_thre
     int64_t *const SA = sa_mem.p;
     SA[0] = N; SA[N + 1] = 0;
     std::vector<int64_t> bstart((size_t)NB + 1, 0);
+    const int PBASES = 4, PSHIFT = 2 * (KPRE - PBASES);           // partition = first 4 bases: 256 partitions of 4^7 buckets
+    const int64_t NPART = 1LL << (2 * PBASES);
+    std::vector<std::vector<int64_t>> pcur;                       // [chunk][partition]: where the chunk's next suffix of the partition goes
     {
         // text chunks: enough for all cores, few enough that the per-chunk histograms (16 MB each) stay cheap to combine
         const int n_chunks = n_threads < 64 ? n_threads : 64;
@@ -269,7 +272,7 @@ extern "C" int bm2_index_build(const char *fasta, const char *prefix, int n_thre
             for (int64_t i = b; i < e; i++) hist[t][key_of(i)]++;
         });
         lap("bucket histogram");
-        // offsets: bucket-major, chunk-minor => suffixes enter a bucket in text order
+        // bucket starts; and, per text chunk, how many of its suffixes fall into each PARTITION (= the buckets sharing their first PBASES bases)
         std::vector<int64_t> tot((size_t)NB);
         parallel_for(n_threads, NB, [&](int, int64_t b0, int64_t b1) {
             for (int64_t b = b0; b < b1; b++) { int64_t c = 0; for (int t = 0; t < n_chunks; t++) c += hist[t][b]; tot[b] = c; }
@@ -277,29 +280,45 @@ extern "C" int bm2_index_build(const char *fasta, const char *prefix, int n_thre
         int64_t acc = 1;
         for (int64_t b = 0; b < NB; b++) { bstart[b] = acc; acc += tot[b]; }
         bstart[NB] = acc;
-        parallel_for(n_threads, NB, [&](int, int64_t b0, int64_t b1) {
-            for (int64_t b = b0; b < b1; b++) {
-                uint32_t run = 0;
-                for (int t = 0; t < n_chunks; t++) { const uint32_t c = hist[t][b]; hist[t][b] = run; run += c; }
+        pcur.assign((size_t)n_chunks, std::vector<int64_t>((size_t)NPART, 0));
+        parallel_for(n_threads, NPART, [&](int, int64_t p0, int64_t p1) {
+            for (int64_t p = p0; p < p1; p++) {
+                int64_t run = bstart[p << PSHIFT];               // chunk-minor inside the partition: its suffixes arrive in text order
+                for (int t = 0; t < n_chunks; t++) {
+                    int64_t c = 0;
+                    for (int64_t b = p << PSHIFT; b < (p + 1) << PSHIFT; b++) c += hist[t][b];
+                    pcur[(size_t)t][(size_t)p] = run; run += c;
+                }
             }
         });
         lap("bucket offsets");
+        // Scatter in two steps.  Straight into 4^KPRE buckets, every suffix is a random write somewhere in the 8 N bytes of the array and a
+        // random read-modify-write of a 16 MB counter table.  First into the NPART partitions -- NPART sequential write streams per thread --,
+        // then, partition by partition (below, together with the sorting), from a copy of the partition into its buckets: counters and targets
+        // of that step are a few hundred KB and a few MB.
         parallel_for(n_chunks, N, [&](int t, int64_t b, int64_t e) {
-            std::vector<uint32_t> &h = hist[t];
-            for (int64_t i = b; i < e; i++) { const int64_t k = key_of(i); SA[bstart[k] + h[k]++] = i; }
+            int64_t *cur = pcur[(size_t)t].data();
+            for (int64_t i = b; i < e; i++) SA[cur[key_of(i) >> PSHIFT]++] = i;
         });
     }
-    lap("bucket scatter");
+    lap("partition scatter");
     {
         std::atomic<int64_t> next(0);
         std::vector<std::thread> th;
         for (int t = 0; t < n_threads; t++)
             th.emplace_back([&]() {
                 std::vector<std::pair<uint64_t, int64_t>> kv;
+                std::vector<int64_t> part, cur((size_t)1 << PSHIFT);
                 for (;;) {
-                    const int64_t b0 = next.fetch_add(256);
-                    if (b0 >= NB) break;
-                    for (int64_t b = b0; b < b0 + 256 && b < NB; b++) {
+                    const int64_t p = next.fetch_add(1);
+                    if (p >= NPART) break;
+                    const int64_t kb = p << PSHIFT, ke = (p + 1) << PSHIFT, plo = bstart[kb], phi = bstart[ke];
+                    if (phi - plo > 1) {                          // the partition's suffixes (text order) into its buckets
+                        part.assign(SA + plo, SA + phi);
+                        for (int64_t k = kb; k < ke; k++) cur[(size_t)(k - kb)] = bstart[k];
+                        for (int64_t x : part) SA[cur[(size_t)(key_of(x) - kb)]++] = x;
+                    }
+                    for (int64_t b = kb; b < ke; b++) {
                         const int64_t lo = bstart[b], hi = bstart[b + 1], n = hi - lo;
                         if (n <= 1) continue;
                         if (n < 8) { std::sort(SA + lo, SA + hi, [&](int64_t x, int64_t y) { return tx.less(x, y, 0); }); continue; }
@@ -324,7 +343,7 @@ extern "C" int bm2_index_build(const char *fasta, const char *prefix, int n_thre
             });
         for (auto &x : th) x.join();
     }
-    lap("bucket sort");
+    lap("bucket scatter + sort");
     // ---- 5. BWT -> CP_OCC blocks, sampled SA (build_fm_index, FMI_search.cpp:144-304)
     const int64_t ref_seq_len = N + 1;
     const int64_t n_occ = (ref_seq_len >> 6) + 1, n_sa = (ref_seq_len >> 3) + 1;
