@@ -258,7 +258,11 @@ extern "C" int bm2_index_build(const char *fasta, const char *prefix, int n_thre
     struct RawI64 { int64_t *p; explicit RawI64(size_t n) : p((int64_t *)huge_alloc(n * sizeof(int64_t))) {} ~RawI64() { free(p); } } sa_mem((size_t)N + 2);
     if (!sa_mem.p) { bm2_set_error("bm2_index_build: cannot allocate %lld bytes for the suffix array", (long long)((N + 2) * 8)); return BM2_ENOMEM; }
     int64_t *const SA = sa_mem.p;
-    SA[0] = N; SA[N + 1] = 0;
+    // An entry carries the base BEFORE its suffix in its top bits (bit 62: there is one; bits 61..60: which): it is read where the suffix is
+    // filed -- in text order, for nothing -- and saves the BWT pass a cache miss per suffix into the text (positions stay below 2^40).
+    const int64_t SMASK = ((int64_t)1 << 60) - 1;
+    auto tagged = [&](int64_t i) -> int64_t { return i > 0 ? i | (int64_t)(4 | T[i - 1]) << 60 : i; };
+    SA[0] = tagged(N); SA[N + 1] = 0;
     std::vector<int64_t> bstart((size_t)NB + 1, 0);
     const int PBASES = 4, PSHIFT = 2 * (KPRE - PBASES);           // partition = first 4 bases: 256 partitions of 4^7 buckets
     const int64_t NPART = 1LL << (2 * PBASES);
@@ -298,7 +302,7 @@ extern "C" int bm2_index_build(const char *fasta, const char *prefix, int n_thre
         // of that step are a few hundred KB and a few MB.
         parallel_for(n_chunks, N, [&](int t, int64_t b, int64_t e) {
             int64_t *cur = pcur[(size_t)t].data();
-            for (int64_t i = b; i < e; i++) SA[cur[key_of(i) >> PSHIFT]++] = i;
+            for (int64_t i = b; i < e; i++) SA[cur[key_of(i) >> PSHIFT]++] = tagged(i);
         });
     }
     lap("partition scatter");
@@ -316,12 +320,12 @@ extern "C" int bm2_index_build(const char *fasta, const char *prefix, int n_thre
                     if (phi - plo > 1) {                          // the partition's suffixes (text order) into its buckets
                         part.assign(SA + plo, SA + phi);
                         for (int64_t k = kb; k < ke; k++) cur[(size_t)(k - kb)] = bstart[k];
-                        for (int64_t x : part) SA[cur[(size_t)(key_of(x) - kb)]++] = x;
+                        for (int64_t x : part) SA[cur[(size_t)(key_of(x & SMASK) - kb)]++] = x;
                     }
                     for (int64_t b = kb; b < ke; b++) {
                         const int64_t lo = bstart[b], hi = bstart[b + 1], n = hi - lo;
                         if (n <= 1) continue;
-                        if (n < 8) { std::sort(SA + lo, SA + hi, [&](int64_t x, int64_t y) { return tx.less(x, y, 0); }); continue; }
+                        if (n < 8) { std::sort(SA + lo, SA + hi, [&](int64_t x, int64_t y) { return tx.less(x & SMASK, y & SMASK, 0); }); continue; }
                         // The bucket's suffixes agree in their first KPRE bases.  Their next 32 bases as ONE integer key each, fetched once
                         // (a random read of the packed text per suffix instead of one per comparison), the (key, suffix) pairs sorted as
                         // integers, and only the runs of equal keys -- repeats longer than KPRE + 32 bases -- compared base by base.  A
@@ -329,13 +333,13 @@ extern "C" int bm2_index_build(const char *fasta, const char *prefix, int n_thre
                         kv.resize((size_t)n);
                         bool near_end = false;
                         for (int64_t t = 0; t < n; t++) {
-                            const int64_t s = SA[lo + t];
+                            const int64_t s = SA[lo + t] & SMASK;
                             if (s + KPRE + 32 > N) { near_end = true; break; }
-                            kv[(size_t)t].first = tx.get32(s + KPRE); kv[(size_t)t].second = s;
+                            kv[(size_t)t].first = tx.get32(s + KPRE); kv[(size_t)t].second = SA[lo + t];
                         }
-                        if (near_end) { std::sort(SA + lo, SA + hi, [&](int64_t x, int64_t y) { return tx.less(x, y, 0); }); continue; }
+                        if (near_end) { std::sort(SA + lo, SA + hi, [&](int64_t x, int64_t y) { return tx.less(x & SMASK, y & SMASK, 0); }); continue; }
                         std::sort(kv.begin(), kv.end(), [&](const std::pair<uint64_t, int64_t> &x, const std::pair<uint64_t, int64_t> &y) {
-                            return x.first != y.first ? x.first < y.first : tx.less(x.second, y.second, KPRE + 32);
+                            return x.first != y.first ? x.first < y.first : tx.less(x.second & SMASK, y.second & SMASK, KPRE + 32);
                         });
                         for (int64_t t = 0; t < n; t++) SA[lo + t] = kv[(size_t)t].second;
                     }
@@ -348,20 +352,23 @@ extern "C" int bm2_index_build(const char *fasta, const char *prefix, int n_thre
     const int64_t ref_seq_len = N + 1;
     const int64_t n_occ = (ref_seq_len >> 6) + 1, n_sa = (ref_seq_len >> 3) + 1;
     struct CpOcc { int64_t cp_count[4]; uint64_t bwt[4]; };
-    std::vector<CpOcc> occ((size_t)n_occ);
+    std::vector<CpOcc, HugeAlloc<CpOcc>> occ((size_t)n_occ);     // (uninitialised: every block is written below, as is every sampled entry)
+    std::vector<int8_t, HugeAlloc<int8_t>> ms((size_t)n_sa); std::vector<uint32_t, HugeAlloc<uint32_t>> ls((size_t)n_sa);
     std::vector<int64_t> sent((size_t)n_threads, -1);
     parallel_for(n_threads, n_occ, [&](int t, int64_t b, int64_t e) {
         for (int64_t blk = b; blk < e; blk++) {
             CpOcc c; memset(&c, 0, sizeof c);
-            if ((blk + 2) * 64 + 63 < ref_seq_len)                  // (T[SA[i] - 1] is a cache miss per suffix: asked for two blocks ahead)
-                for (int j = 0; j < 64; j++) { const int64_t s2 = SA[(blk + 2) * 64 + j]; if (s2 > 0) __builtin_prefetch(&T[s2 - 1], 0, 0); }
             for (int j = 0; j < 64; j++) {
                 const int64_t i = blk * 64 + j;
                 for (int k = 0; k < 4; k++) c.bwt[k] <<= 1;
+                if ((j & 7) == 0 && (i >> 3) < n_sa) {           // the sampled suffix array (every 8th entry: low word + high byte) in the same pass
+                    const int64_t sv = i < ref_seq_len ? SA[i] & SMASK : 0;
+                    ls[(size_t)(i >> 3)] = (uint32_t)(sv & 0xffffffff); ms[(size_t)(i >> 3)] = (int8_t)((sv >> 32) & 0xff);
+                }
                 if (i < ref_seq_len) {
-                    const int64_t s = SA[i];
-                    if (s == 0) sent[t] = i;
-                    else { const int ch = T[s - 1]; c.bwt[ch] += 1; c.cp_count[ch]++; }       // cp_count holds the block's own counts for now
+                    const int64_t v = SA[i];
+                    if ((v & SMASK) == 0) sent[t] = i;
+                    else { const int ch = (int)(v >> 60) & 3; c.bwt[ch] += 1; c.cp_count[ch]++; }       // (the base before the suffix rides in the entry) cp_count holds the block's own counts for now
                 }
             }
             occ[blk] = c;
@@ -374,13 +381,6 @@ extern "C" int bm2_index_build(const char *fasta, const char *prefix, int n_thre
         for (int64_t blk = 0; blk < n_occ; blk++)
             for (int k = 0; k < 4; k++) { const int64_t c = occ[blk].cp_count[k]; occ[blk].cp_count[k] = run[k]; run[k] += c; }
     }
-    std::vector<int8_t> ms((size_t)n_sa, 0); std::vector<uint32_t> ls((size_t)n_sa, 0);
-    parallel_for(n_threads, n_sa, [&](int, int64_t b, int64_t e) {
-        for (int64_t p = b; p < e; p++) {
-            const int64_t i = p << 3;
-            if (i < ref_seq_len) { ls[p] = (uint32_t)(SA[i] & 0xffffffff); ms[p] = (int8_t)((SA[i] >> 32) & 0xff); }
-        }
-    });
     lap("BWT / Occ / sampled SA");
     {
         FILE *o = fopen((pre + ".bwt.2bit.64").c_str(), "wb");
