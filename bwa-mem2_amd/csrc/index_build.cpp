@@ -3,9 +3,11 @@
 // `bwa-mem2 index` (bns_fasta2bntseq bntseq.cpp:249-357, bns_dump :73-105, FMI_search::build_index / build_fm_index
 // FMI_search.cpp:144-382), so either program can load either index.  The FM-index of a text is unique, so only the
 // construction differs: the reference runs single-threaded SA-IS (28N bytes of RAM, ~0.25-0.5 us per base: an hour for a
-// human genome); here suffixes are bucketed by their first 11 bases and every bucket is sorted independently on all host
-// cores with word-wise comparisons on a 2-bit packed text -- what lets a GRCh38-size synthetic genome be indexed inside a
-// benchmark run.  Host code; no GPU involved.
+// human genome); here suffixes are bucketed by their first 11 bases (filed in two steps: 256 partitions, then each partition's
+// buckets) and every bucket is sorted independently on all host cores -- by the 32 bases after the bucket prefix as one integer
+// key per suffix, ties by word-wise comparison of the 2-bit packed text; a suffix array entry carries the base before its suffix,
+// so the BWT falls out of one sequential pass -- what lets a GRCh38-size synthetic genome be indexed inside a benchmark run.
+// The big arrays sit on 2 MB pages where the kernel grants them and are first touched by all threads.  Host code; no GPU involved.
 #include "host_pool.h"
 #include <stdint.h>
 #include <stdio.h>
