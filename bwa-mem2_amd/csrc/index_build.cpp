@@ -313,7 +313,7 @@ extern "C" int bm2_index_build(const char *fasta, const char *prefix, int n_thre
         std::vector<std::thread> th;
         for (int t = 0; t < n_threads; t++)
             th.emplace_back([&]() {
-                std::vector<std::pair<uint64_t, int64_t>> kv;
+                std::vector<std::pair<uint64_t, int64_t>> kv, kv2;
                 std::vector<int64_t> part, cur((size_t)1 << PSHIFT);
                 for (;;) {
                     const int64_t p = next.fetch_add(1);
@@ -340,10 +340,33 @@ extern "C" int bm2_index_build(const char *fasta, const char *prefix, int n_thre
                             kv[(size_t)t].first = tx.get32(s + KPRE); kv[(size_t)t].second = SA[lo + t];
                         }
                         if (near_end) { std::sort(SA + lo, SA + hi, [&](int64_t x, int64_t y) { return tx.less(x & SMASK, y & SMASK, 0); }); continue; }
-                        std::sort(kv.begin(), kv.end(), [&](const std::pair<uint64_t, int64_t> &x, const std::pair<uint64_t, int64_t> &y) {
+                        auto kv_less = [&](const std::pair<uint64_t, int64_t> &x, const std::pair<uint64_t, int64_t> &y) {
                             return x.first != y.first ? x.first < y.first : tx.less(x.second & SMASK, y.second & SMASK, KPRE + 32);
-                        });
-                        for (int64_t t = 0; t < n; t++) SA[lo + t] = kv[(size_t)t].second;
+                        };
+                        // one counting pass over the key's top byte (the 4 bases after the bucket prefix) leaves runs of a handful of pairs:
+                        // insertion sort for those, std::sort for what a repeat makes long
+                        uint32_t cnt[257];
+                        memset(cnt, 0, sizeof cnt);
+                        for (int64_t t = 0; t < n; t++) cnt[(kv[(size_t)t].first >> 56) + 1]++;
+                        for (int d = 0; d < 256; d++) cnt[d + 1] += cnt[d];
+                        kv2.resize((size_t)n);
+                        {
+                            uint32_t at[256];
+                            memcpy(at, cnt, sizeof at);
+                            for (int64_t t = 0; t < n; t++) kv2[at[kv[(size_t)t].first >> 56]++] = kv[(size_t)t];
+                        }
+                        for (int d = 0; d < 256; d++) {
+                            const uint32_t r0 = cnt[d], r1 = cnt[d + 1];
+                            if (r1 - r0 < 2) continue;
+                            if (r1 - r0 > 24) { std::sort(kv2.begin() + r0, kv2.begin() + r1, kv_less); continue; }
+                            for (uint32_t a = r0 + 1; a < r1; a++) {
+                                const std::pair<uint64_t, int64_t> v = kv2[a];
+                                uint32_t c = a;
+                                while (c > r0 && kv_less(v, kv2[c - 1])) { kv2[c] = kv2[c - 1]; --c; }
+                                kv2[c] = v;
+                            }
+                        }
+                        for (int64_t t = 0; t < n; t++) SA[lo + t] = kv2[(size_t)t].second;
                     }
                 }
             });
