@@ -27,6 +27,22 @@ def golden_dir():
 
 
 @pytest.fixture(scope="session")
+def emu_lib(tmp_path_factory):
+    """The device sources compiled for the host (tools/emu/build_emu.py): built ONCE per test session (a build takes ~20 s)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools", "emu"))
+    import build_emu
+    return build_emu.build(str(tmp_path_factory.mktemp("emulib")))
+
+
+def emu_dir_as_libbm2(emu_lib, tmp_path):
+    """A directory holding the emulator library under the name the bindings link against (for LD_LIBRARY_PATH)."""
+    d = os.path.join(str(tmp_path), "emu")
+    os.makedirs(d, exist_ok=True)
+    os.symlink(emu_lib, os.path.join(d, "libbm2.so"))
+    return d
+
+
+@pytest.fixture(scope="session")
 def gpu_ctx_factory():
     """Creates bm2 contexts on cuda:0; fails loudly (no CPU fallback) if the library or device is missing."""
     import bm2

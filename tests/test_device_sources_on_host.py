@@ -49,14 +49,6 @@ def test_k_bsw_pairs_on_the_emulator(bsw_emu, tmp_path, seed, n, max_len, w):
         assert tuple(got[i]) == tuple(oracle.ksw_extend(q, t, opt, w, 5, h0)), (i, len(q), len(t), h0)
 
 
-@pytest.fixture(scope="module")
-def emu_lib(tmp_path_factory):
-    import sys
-    sys.path.insert(0, EMU)
-    import build_emu
-    return build_emu.build(str(tmp_path_factory.mktemp("emulib")))
-
-
 def test_whole_device_pipeline_on_the_emulator(emu_lib, golden_dir):
     # every kernel of bm2_seed_chain_extend (seeding task kernels with their quad-cooperative Occ loads, SA lookup, chaining, the
     # lane-per-task extension rounds, the purge) executed by OS threads, against the oracle: 48 reads take a few seconds
@@ -83,7 +75,8 @@ print("ok", len(regs))
 
 def test_launch_policy_knobs_do_not_change_results(emu_lib, golden_dir):
     # bm2_knob settings select kernels and code paths (wavefront-per-task extension for a query-length class, staged heavy chaining,
-    # k_bwd's LDS depth / register budget, quad-cooperative SA lookup, wave-per-read purge threshold, dispatch order, round limits):
+    # k_bwd's LDS depth / register budget, quad-cooperative SA lookup, wave-per-read purge threshold, dispatch order, round limits, the lane
+    # kernel without its score table, the old stream assignment of an extension side):
     # the regs must not depend on any of them.  tools/gpu/sweep.py relies on this when it compares settings by checksum on the GPU.
     script = r'''
 import sys, os
@@ -97,7 +90,7 @@ n = 48
 ln = ln[:n]; off = off[:n]; enc = enc[:int(off[-1] + ln[-1])]
 ix = oracle.Index(pre); exp = ix.run(enc, off, ln)["REGPRG"].tobytes(); ix.close()
 ctx = bm2.Context(0, pre)
-sets = [{}, {"BM2_EXT_WAVE_QMIN": 33, "BM2_EXT_REVERSE": 1, "BM2_EXT_PREFETCH": 0}, {"BM2_EXT_WAVE_QMIN": 161, "BM2_EXT_WAVE_NMAX": 20, "BM2_EXT_ROUNDS": 2},
+sets = [{}, {"BM2_EXT_WAVE_QMIN": 33, "BM2_EXT_REVERSE": 1, "BM2_EXT_PREFETCH": 0}, {"BM2_EXT_WAVE_QMIN": 161, "BM2_EXT_WAVE_NMAX": 20, "BM2_EXT_ROUNDS": 2, "BM2_EXT_PERM_SCORES": 0, "BM2_EXT_QUEUE_MAP": 0},
         {"BM2_HEAVY_SA": 2, "BM2_CHAIN_STAGE": 1, "BM2_CHAIN_WAVES_PER_CU": 32, "BM2_PF_HEAVY": 2},
         {"BM2_BWD_LCAP": 4, "BM2_BWD_BLOCKS_PER_CU": 5, "BM2_BWD_WAVES": 5, "BM2_SAL_QUAD": 1}, {"BM2_BWD_LCAP": 8, "BM2_HEAVY_SA": 5, "BM2_CHAIN_STAGE": 0}]
 for kn in sets:

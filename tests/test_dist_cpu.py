@@ -88,20 +88,19 @@ def _align_worker(rank, world, port, lib, fa, npz, out):
     dist_util.finish(world)
 
 
-def test_two_ranks_align_one_chunk(tmp_path):
+def test_two_ranks_align_one_chunk(tmp_path, emu_lib):
     # SURVEY.md 8(e) with processes: ONE chunk cut at a multiple of 512 reads over two ranks (gloo), every rank runs the device
     # pipeline (host emulator of the device sources) on its part, rank 0 gathers the hits in read order: equal to the oracle's
     # mem_alnreg_v contents of the whole chunk, i.e. independent of the sharding
     import subprocess
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools", "emu")); sys.path.insert(0, os.path.join(ROOT, "bwa-mem2_amd"))
-    import build_emu
     import bm2
     from helpers import alnregs_to_recs, ref_binary
     from tools import oracle, refio, synth
     if ref_binary() is None:
         import pytest
         pytest.skip("oracle/_ref reference binary not present")
-    lib = build_emu.build(str(tmp_path / "emu"))
+    lib = emu_lib
     names, ctg, _ = synth.make_genome(5, [60000, 30000], alt_contigs=0, n_repeat_families=2, repeat_len=(200, 800), copies=(3, 8))
     fa = str(tmp_path / "g.fa")
     synth.write_fasta(fa, names, ctg)

@@ -72,11 +72,8 @@ def _run(lib, pre, golden_dir, n):
     assert p.returncode == 0 and p.stdout.startswith(b"ok"), p.stderr.decode()[-2000:]
 
 
-def test_sa_high_byte_on_the_emulator(golden_dir, tmp_path, tmp_path_factory):
-    sys.path.insert(0, os.path.join(ROOT, "tools", "emu"))
-    import build_emu
-    lib = build_emu.build(str(tmp_path_factory.mktemp("emulib_sa")))
-    _run(lib, patched_index(golden_dir, "g20k_l76", str(tmp_path)), golden_dir, 24)
+def test_sa_high_byte_on_the_emulator(golden_dir, tmp_path, emu_lib):
+    _run(emu_lib, patched_index(golden_dir, "g20k_l76", str(tmp_path)), golden_dir, 24)
 
 
 @pytest.mark.gpu

@@ -59,10 +59,8 @@ def _run(d, lib, n_pairs, gs, K):
     assert p.returncode == 0 and p.stdout.startswith(b"ok"), p.stderr.decode()[-2000:]
 
 
-def test_sharded_chunk_on_the_emulator(tmp_path):
-    sys.path.insert(0, os.path.join(ROOT, "tools", "emu"))
-    import build_emu
-    lib = build_emu.build(str(tmp_path / "emu"))
+def test_sharded_chunk_on_the_emulator(tmp_path, emu_lib):
+    lib = emu_lib
     # 2 x 600 reads in one chunk: 3 blocks of 512 -> parts of 512 / 688 reads (2 contexts)
     _run(str(tmp_path), lib, 600, [1, 2], 10 ** 9)
 
