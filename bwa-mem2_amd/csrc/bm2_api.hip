@@ -144,6 +144,7 @@ static int make_streams(bm2_ctx *c) {
         (void)hipStreamCreateWithFlags(&c->side_stream[i], hipStreamNonBlocking);
         (void)hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming);
     }
+    if (hipHostMalloc((void **)&c->ext_stat, sizeof(uint32_t) * BM2_EXT_PHASES * BM2_EXT_STATW, hipHostMallocPortable) != hipSuccess) c->ext_stat = nullptr;
     return BM2_OK;
 }
 static void free_streams(bm2_ctx *c) {
@@ -154,6 +155,7 @@ static void free_streams(bm2_ctx *c) {
         if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
     }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ext_stat) { (void)hipHostFree(c->ext_stat); c->ext_stat = nullptr; }
     if (c->stream) (void)hipStreamDestroy(c->stream);
 }
 

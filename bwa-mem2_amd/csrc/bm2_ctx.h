@@ -48,6 +48,12 @@ struct bm2_ctx {
     // fork/join of the per-class extension launches (extend.hip)
     hipStream_t side_stream[12] = {};
     hipEvent_t ev_fork = nullptr, ev_join[12] = {};
+    // what the extension stage of the last batch saw (page-locked; written by an asynchronous copy at the end of the stage): per phase the
+    // seeds of every LDS class and the reads left pending.  The next batch sizes its launches and picks its number of lazy rounds with it.
+#define BM2_EXT_PHASES 8
+#define BM2_EXT_STATW 16
+    uint32_t *ext_stat = nullptr;
+    int ext_stat_reads = 0, ext_stat_rounds = 0;
     // sub-batch pipelining (pipeline.hip): extra contexts sharing this one's index replica
     std::vector<bm2_ctx *> subs;
     StageGate gate;                                               // (of the parent: the schedule of its parts)

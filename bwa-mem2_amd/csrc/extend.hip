@@ -4,12 +4,17 @@
 // inter-task SIMD kernels with band w, compacts the tasks that must be retried and runs them again with 2w, and then
 // does the same for the right tasks (whose h0 is the left score) -- six sort/run/compact rounds per side
 // (bwamem.cpp:2472-2880).  None of that batching is semantic: each seed's outcome depends only on its own two tasks.
-// Here ONE WAVEFRONT OWNS ONE SEED (= one mem_alnreg_t): it runs the left extension (retrying with 2w in place when
-// the reference would), feeds the score into the right extension, applies the clip/extend decision, and computes
-// seedcov -- no SeqPair arrays, no reversed sequence copies, no host round trip between the two sides.
+// Here ONE LANE OWNS ONE SEED (= one mem_alnreg_t): it runs the left extension (retrying with 2w in place when the
+// reference would), feeds the score into the right extension, applies the clip/extend decision -- no SeqPair arrays, no
+// reversed sequence copies, no launch boundary between the two sides.  The seeds of a round are counting-sorted by
+// (class of max(left, right) query length, left length, right length): the 64 seeds of a wavefront have the same
+// geometry on BOTH sides (with reads of one length also the same seed length, i.e. the same h0), so the lanes walk the
+// same rows and nearly the same bands (tools/ext_sim.py: 0.88 of the lane slots of the column loop hold a cell).
+// The sort, its prefix sums and the launch sizes all stay on the device: a round makes no trip to the host.
 #include "bsw_dev.h"
 #include "pipeline.h"
 #include "chain_dev.h"
+#include <string.h>
 
 #define MAX_BAND_TRY 2            // bwamem.cpp:51
 
@@ -18,9 +23,13 @@ struct ExtParams {
     SwParams left, right;         // end_bonus = pen_clip5 / pen_clip3 (bwamem.cpp:2457-2463)
 };
 
-#define LANE_QMAX 160             // longest query the lane-per-task kernel takes; longer tasks go one-per-wavefront
-#define BIN_FALLBACK (LANE_QMAX + 1)
-#define N_BINS (LANE_QMAX + 2)
+#define LANE_QMAX 160             // longest query the lane-per-seed kernel takes; longer ones go one seed per wavefront
+#define N_CLS 10                  // LDS classes of the lane kernel: max(left, right) query length in steps of 16
+#define EB_L (LANE_QMAX + 1)
+#define EB_2D (EB_L * EB_L)       // bins of one class: (left length, right length)
+#define EBIN_FALLBACK (N_CLS * EB_2D)          // seeds of the wavefront kernel, ordered by (left + right) >> 3
+#define N_EBINS ((N_CLS + 1) * EB_2D)
+#define EBIN_NONE 0xffffffffu     // nothing to extend
 
 // geometry of the two extension tasks of a seed (what a SeqPair + its seqBuf slices describe, bwamem.cpp:2229-2418)
 struct TaskGeom { const uint8_t *q, *t; int qs, ts, len2, len1; };
@@ -53,69 +62,68 @@ static __device__ __forceinline__ void apply_side(int side, DevReg &a, const Dev
     a.w = imax(a.w, w_used);
 }
 
-// ---- per-seed initialisation (mem_alnreg_t set-up of bwamem.cpp:2212-2223, 2318-2322, 2419-2437) and task binning
+// Sort key of a seed: which kernel / LDS class extends it and where it sits among that class's seeds.
+static __device__ __forceinline__ uint32_t seed_bin(const ExtParams &xp, const DevSeed &s, const DevChain &c, int l_query) {
+    const bool hl = s.qbeg != 0, hr = s.qbeg + s.len != l_query;
+    if (!hl && !hr) return EBIN_NONE;
+    int ll = 0, lr = 0; bool ok = true;
+    for (int side = 0; side < 2; side++) {
+        if (!(side == 0 ? hl : hr)) continue;
+        const TaskGeom tg = task_geom(side, s, c, nullptr, l_query, nullptr);
+        ok = ok && tg.len2 <= LANE_QMAX && tg.len1 < 32768 && (l_query + tg.len1 + 1) * xp.a < 32768;
+        if (side == 0) ll = tg.len2; else lr = tg.len2;
+    }
+    if (!ok) return (uint32_t)(EBIN_FALLBACK + imin((ll + lr) >> 3, EB_2D - 1));
+    return (uint32_t)(((imax(ll, lr) - 1) >> 4) * EB_2D + ll * EB_L + lr);
+}
+
+// ---- per-seed initialisation (mem_alnreg_t set-up of bwamem.cpp:2212-2223, 2318-2322, 2419-2437) and sort key, eager phase:
+// every seed at or beyond its read's cursor
 __global__ void __launch_bounds__(256)
 k_reg_init(ExtParams xp, int64_t n_slots, const int32_t *__restrict__ len, const int64_t *__restrict__ slot_base,
            const int32_t *__restrict__ reg_seed, const int32_t *__restrict__ reg_chain, const DevChain *__restrict__ chn,
-           const DevSeed *__restrict__ seeds, DevReg *regs, uint8_t *bins /* [2][n_slots] */, uint32_t *hist /* [2][N_BINS] */,
+           const DevSeed *__restrict__ seeds, DevReg *regs, uint32_t *ebin /* [n_slots] */, int32_t *hist /* [N_EBINS] */,
            const int32_t *__restrict__ cursor /* per read: regs below this index were handled by the lazy rounds */) {
-    __shared__ uint32_t sh[2 * N_BINS];
-    for (int i = threadIdx.x; i < 2 * N_BINS; i += blockDim.x) sh[i] = 0;
-    __syncthreads();
     const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g < n_slots) {
-        const int sidx = reg_seed[g];
-        int bl = 255, br = 255;                              // 255 = no task
-        if (sidx >= 0 && g - slot_base[g] >= cursor[chn[slot_base[g] + reg_chain[g]].read]) {
-            const int64_t base = slot_base[g];
-            const DevChain c = chn[base + reg_chain[g]];
-            const DevSeed s = seeds[base + sidx];
-            const int l_query = len[c.read];
-            DevReg a;
-            a.w = xp.w; a.rid = c.rid; a.frac_rep = c.frac_rep; a.seedlen0 = s.len; a.chain = reg_chain[g]; a.seedcov = 0;
-            a.rb = s.rbeg; a.re = s.rbeg + s.len;
-            if (s.qbeg) { a.score = a.truesc = -1; a.qb = s.qbeg; }
-            else { a.score = a.truesc = s.len * xp.a; a.qb = 0; }
-            a.qe = (s.qbeg + s.len != l_query) ? s.qbeg + s.len : l_query;
-            regs[g] = a;
-            for (int side = 0; side < 2; side++) {
-                const bool has = side == 0 ? s.qbeg != 0 : s.qbeg + s.len != l_query;
-                if (!has) continue;
-                const TaskGeom tg = task_geom(side, s, c, nullptr, l_query, nullptr);
-                const bool lane_ok = tg.len2 <= LANE_QMAX && tg.len1 < 32768 && (l_query + tg.len1 + 1) * xp.a < 32768;
-                const int b = lane_ok ? tg.len2 : BIN_FALLBACK;
-                if (side == 0) bl = b; else br = b;
-                atomicAdd(&sh[side * N_BINS + b], 1u);
-            }
-        }
-        bins[g] = (uint8_t)bl; bins[n_slots + g] = (uint8_t)br;
+    if (g >= n_slots) return;
+    const int sidx = reg_seed[g];
+    uint32_t b = EBIN_NONE;
+    if (sidx >= 0 && g - slot_base[g] >= cursor[chn[slot_base[g] + reg_chain[g]].read]) {
+        const int64_t base = slot_base[g];
+        const DevChain c = chn[base + reg_chain[g]];
+        const DevSeed s = seeds[base + sidx];
+        const int l_query = len[c.read];
+        DevReg a;
+        a.w = xp.w; a.rid = c.rid; a.frac_rep = c.frac_rep; a.seedlen0 = s.len; a.chain = reg_chain[g]; a.seedcov = 0;
+        a.rb = s.rbeg; a.re = s.rbeg + s.len;
+        if (s.qbeg) { a.score = a.truesc = -1; a.qb = s.qbeg; }
+        else { a.score = a.truesc = s.len * xp.a; a.qb = 0; }
+        a.qe = (s.qbeg + s.len != l_query) ? s.qbeg + s.len : l_query;
+        regs[g] = a;
+        b = seed_bin(xp, s, c, l_query);
+        if (b != EBIN_NONE) atomicAdd(&hist[b], 1);
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < 2 * N_BINS; i += blockDim.x) if (sh[i]) atomicAdd(&hist[i], sh[i]);
+    ebin[g] = b;
 }
 
-// scatter slot ids into per-side task lists ordered by bin (= query length): a counting sort.  Each block first counts
-// its own tasks per bin in LDS and reserves its ranges with one global atomic per non-empty bin.
+// Counting sort of the round's seeds by their key: `start` = exclusive prefix sums of the histogram (bm2_scan_i32), and the histogram
+// itself counts back down to zero as the slots are handed out -- it is clean for the next round without a memset.
 __global__ void __launch_bounds__(256)
-k_task_scatter(int64_t n_slots, const uint8_t *__restrict__ bins, uint32_t *cursor /* [2][N_BINS] start offsets, bumped */,
-               int32_t *taskL, int32_t *taskR, const int64_t *__restrict__ read_base /* round mode: item = read */,
-               const int32_t *__restrict__ cur_slot) {
-    __shared__ uint32_t cnt[2 * N_BINS], basep[2 * N_BINS];
-    for (int i = threadIdx.x; i < 2 * N_BINS; i += blockDim.x) cnt[i] = 0;
-    __syncthreads();
+k_task_scatter(int64_t n_items, const uint32_t *__restrict__ ebin, int32_t *hist, const int64_t *__restrict__ start, int32_t *tasks,
+               const int64_t *__restrict__ read_base /* round mode: item = read */, const int32_t *__restrict__ cur_slot) {
     const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int bl = 255, br = 255; uint32_t pl = 0, pr = 0;
-    if (g < n_slots) {
-        bl = bins[g]; br = bins[n_slots + g];
-        if (bl != 255) pl = atomicAdd(&cnt[bl], 1u);
-        if (br != 255) pr = atomicAdd(&cnt[N_BINS + br], 1u);
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < 2 * N_BINS; i += blockDim.x) if (cnt[i]) basep[i] = atomicAdd(&cursor[i], cnt[i]);
-    __syncthreads();
-    const int32_t slot = read_base ? (int32_t)(read_base[g < n_slots ? g : 0] + cur_slot[g < n_slots ? g : 0]) : (int32_t)g;
-    if (bl != 255) taskL[basep[bl] + pl] = slot;
-    if (br != 255) taskR[basep[N_BINS + br] + pr] = slot;
+    if (g >= n_items) return;
+    const uint32_t b = ebin[g];
+    if (b == EBIN_NONE) return;
+    const int k = atomicAdd(&hist[b], -1) - 1;
+    tasks[start[b] + k] = read_base ? (int32_t)(read_base[g] + cur_slot[g]) : (int32_t)g;
+}
+
+// what the host wants to know about a phase AFTER the batch (it sizes the next batch's launches with it): seeds per class, reads still pending
+__global__ void k_phase_stats(const int64_t *__restrict__ start, const uint32_t *__restrict__ pend, uint32_t *out /* [N_CLS + 2] */) {
+    const int t = threadIdx.x;
+    if (t <= N_CLS) out[t] = (uint32_t)(start[(int64_t)(t + 1) * EB_2D] - start[(int64_t)t * EB_2D]);
+    if (t == N_CLS + 1) out[t] = pend ? *pend : 0u;
 }
 
 // ---- lane-per-task extension: the inter-task SIMD shape of the reference (one pair per lane, bandedSWA.cpp:436-1113)
@@ -330,9 +338,12 @@ static __device__ void lane_dp8(bool run, int qlen, int tlen, int w, int h0, con
     if (run) { out.score = maxv; out.qle = max_j + 1; out.tle = max_i + 1; out.gtle = max_ie + 1; out.gscore = gscore; out.max_off = max_off; }
 }
 
-template <int SIDE, bool P8, bool PF, bool PT = false>      // PT: scores by byte permute (lane_dp8)
+// One seed per lane: left side, then right side (h0 = the score after the left side, bwamem.cpp:2672-2677), each with the two-try
+// band rule.  A wavefront takes tiles of 64 consecutive seeds of its class's sorted list (grid-stride: the host sizes the grid from the
+// previous batch's counts, the kernel reads the real range from the device).
+template <bool P8, bool PF, bool PT = false>      // PT: scores by byte permute (lane_dp8)
 __global__ void __launch_bounds__(64)
-k_ext_lanes(DevIndex ix, ExtParams xp, const int32_t *__restrict__ tasks, int n_tasks, int qmax,
+k_ext_seeds(DevIndex ix, ExtParams xp, const int32_t *__restrict__ tasks_all, const int64_t *__restrict__ start, int bin_lo, int bin_hi, int qmax,
             const uint8_t *__restrict__ enc, const int64_t *__restrict__ off, const int32_t *__restrict__ len,
             const int64_t *__restrict__ slot_base, const int32_t *__restrict__ reg_seed, const int32_t *__restrict__ reg_chain,
             const DevChain *__restrict__ chn, const DevSeed *__restrict__ seeds, DevReg *regs, unsigned long long *counters, int rev) {
@@ -341,69 +352,87 @@ k_ext_lanes(DevIndex ix, ExtParams xp, const int32_t *__restrict__ tasks, int n_
     uint8_t *QL = (uint8_t *)(lds_l + (size_t)(qmax + 1) * 64); // [qmax][64] bytes
     uint32_t *QL8 = lds_l + (size_t)((qmax + 2) / 2) * 64;      // P8: [(qmax+7)/8][64] dwords, 8 bases of 4 bits each (PT: [(qmax+3)/4 + 1][64], one per byte)
     const int lane = threadIdx.x;
-    // (rev: the task list ascends in query length; the blocks with the longest queries -- the slowest wavefronts -- are dispatched first)
-    const int idx = (rev ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x) * 64 + lane;
-    const bool valid = idx < n_tasks;
-    const SwParams &P = SIDE == 0 ? xp.left : xp.right;
-    int g = 0, l_query = 0, h0 = 0, prev = -1;
-    DevSeed s; DevReg a; TaskGeom tg;
-    tg.len1 = tg.len2 = 0; tg.q = tg.t = ix.ref_string; tg.qs = tg.ts = 1;
-    if (valid) {
-        g = tasks[idx];
-        const int64_t base = slot_base[g];
-        const DevChain c = chn[base + reg_chain[g]];
-        s = seeds[base + reg_seed[g]];
-        a = regs[g];
-        l_query = len[c.read];
-        tg = task_geom(SIDE, s, c, enc + off[c.read], l_query, ix.ref_string);
-        if (SIDE == 0) { h0 = s.len * xp.a; prev = -1; }
-        else { h0 = a.score; prev = a.score; }                  // right h0 = score after the left side, bwamem.cpp:2672-2677
-    }
-    // stage the query bases
-    const int maxq = __builtin_amdgcn_readlane(wave_scan_max(valid ? tg.len2 : 0, 0), 63);
-    if (PT) {                                                   // one base per byte, 4 to a dword: the selector words of the byte permute
-        for (int j0 = 0; j0 < maxq; j0 += 4) {
-            if (valid && j0 < tg.len2) {
-                uint32_t wq = 0;
-                for (int u = 0; u < 4 && j0 + u < tg.len2; u++) { const uint32_t qv = tg.q[(int64_t)(j0 + u) * tg.qs]; wq |= (qv > 3 ? 4u : qv) << (8 * u); }
-                QL8[(j0 >> 2) * 64 + lane] = wq;
-            }
-        }
-    } else if (!P8) {
-        for (int j = 0; j < maxq; j++) if (valid && j < tg.len2) QL[j * 64 + lane] = tg.q[(int64_t)j * tg.qs];
-    } else {
-        for (int j0 = 0; j0 < maxq; j0 += 8) {
-            if (valid && j0 < tg.len2) {
-                uint32_t wq = 0;
-                for (int u = 0; u < 8 && j0 + u < tg.len2; u++) wq |= (uint32_t)(tg.q[(int64_t)(j0 + u) * tg.qs] & 15) << (4 * u);
-                QL8[(j0 >> 3) * 64 + lane] = wq;
-            }
-        }
-    }
-    const int cls = pair_class(tg.len1, tg.len2, h0, P.max_sc);
-    LaneOut o; o.score = h0; o.qle = o.tle = o.gtle = 0; o.gscore = -1; o.max_off = 0;
+    const int64_t first = start[bin_lo];
+    const int n_tasks = (int)(start[bin_hi] - first);
+    const int32_t *tasks = tasks_all + first;
+    const int n_tiles = (n_tasks + 63) >> 6;
     long long cells = 0;
-    bool run = valid;
-    int w_used = xp.w;
-    for (int t = 0; t < MAX_BAND_TRY; t++) {                    // two-try band rule, bwamem.cpp:2495-2496
-        if (!__ballot(run)) break;
-        const int w = xp.w << t;
-        const int wc = band_clamp(w, tg.len2, P, cls);
-        if (P8) lane_dp8<PF, PT>(run, tg.len2, tg.len1, wc, h0, tg.t, tg.ts, P, EH, QL8, lane, o, cells);
-        else lane_dp(run, tg.len2, tg.len1, wc, h0, tg.t, tg.ts, P, EH, QL, lane, o, cells);
-        if (run) {
-            w_used = w;
-            if (o.score == prev || o.max_off < (w >> 1) + (w >> 2) || t + 1 == MAX_BAND_TRY) run = false;
-            else prev = o.score;
+    unsigned long long n_done = 0;
+    // (rev: the list ascends in query length; the tiles with the longest queries -- the slowest wavefronts -- are taken first)
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int idx = (rev ? n_tiles - 1 - tile : tile) * 64 + lane;
+        const bool valid = idx < n_tasks;
+        int g = 0, l_query = 0;
+        DevSeed s; DevReg a; DevChain c;
+        s.qbeg = 0; s.len = 0; s.rbeg = 0; c.rmax0 = c.rmax1 = 0; c.read = 0; a.score = 0;
+        if (valid) {
+            g = tasks[idx];
+            const int64_t base = slot_base[g];
+            c = chn[base + reg_chain[g]];
+            s = seeds[base + reg_seed[g]];
+            a = regs[g];
+            l_query = len[c.read];
         }
-    }
-    if (valid) {
-        SwOut so; so.score = o.score; so.qle = o.qle; so.tle = o.tle; so.gtle = o.gtle; so.gscore = o.gscore; so.max_off = o.max_off;
-        apply_side(SIDE, a, s, l_query, so, h0, w_used, SIDE == 0 ? xp.pen_clip5 : xp.pen_clip3);
-        regs[g] = a;
+#pragma nounroll
+        for (int side = 0; side < 2; side++) {
+            const bool has = valid && (side == 0 ? s.qbeg != 0 : s.qbeg + s.len != l_query);
+            if (!__ballot(has)) continue;
+            const SwParams &P = side == 0 ? xp.left : xp.right;
+            TaskGeom tg;
+            tg.len1 = tg.len2 = 0; tg.q = tg.t = ix.ref_string; tg.qs = tg.ts = 1;
+            int h0 = 0, prev = -1;
+            if (has) {
+                tg = task_geom(side, s, c, enc + off[c.read], l_query, ix.ref_string);
+                if (side == 0) h0 = s.len * xp.a;
+                else { h0 = a.score; prev = a.score; }
+            }
+            // stage the query bases
+            const int maxq = __builtin_amdgcn_readlane(wave_scan_max(has ? tg.len2 : 0, 0), 63);
+            if (PT) {                                               // one base per byte, 4 to a dword: the selector words of the byte permute
+                for (int j0 = 0; j0 < maxq; j0 += 4) {
+                    if (has && j0 < tg.len2) {
+                        uint32_t wq = 0;
+                        for (int u = 0; u < 4 && j0 + u < tg.len2; u++) { const uint32_t qv = tg.q[(int64_t)(j0 + u) * tg.qs]; wq |= (qv > 3 ? 4u : qv) << (8 * u); }
+                        QL8[(j0 >> 2) * 64 + lane] = wq;
+                    }
+                }
+            } else if (!P8) {
+                for (int j = 0; j < maxq; j++) if (has && j < tg.len2) QL[j * 64 + lane] = tg.q[(int64_t)j * tg.qs];
+            } else {
+                for (int j0 = 0; j0 < maxq; j0 += 8) {
+                    if (has && j0 < tg.len2) {
+                        uint32_t wq = 0;
+                        for (int u = 0; u < 8 && j0 + u < tg.len2; u++) wq |= (uint32_t)(tg.q[(int64_t)(j0 + u) * tg.qs] & 15) << (4 * u);
+                        QL8[(j0 >> 3) * 64 + lane] = wq;
+                    }
+                }
+            }
+            const int cls = pair_class(tg.len1, tg.len2, h0, P.max_sc);
+            LaneOut o; o.score = h0; o.qle = o.tle = o.gtle = 0; o.gscore = -1; o.max_off = 0;
+            bool run = has;
+            int w_used = xp.w;
+            for (int t = 0; t < MAX_BAND_TRY; t++) {                // two-try band rule, bwamem.cpp:2495-2496
+                if (!__ballot(run)) break;
+                const int w = xp.w << t;
+                const int wc = band_clamp(w, tg.len2, P, cls);
+                if (P8) lane_dp8<PF, PT>(run, tg.len2, tg.len1, wc, h0, tg.t, tg.ts, P, EH, QL8, lane, o, cells);
+                else lane_dp(run, tg.len2, tg.len1, wc, h0, tg.t, tg.ts, P, EH, QL, lane, o, cells);
+                if (run) {
+                    w_used = w;
+                    if (o.score == prev || o.max_off < (w >> 1) + (w >> 2) || t + 1 == MAX_BAND_TRY) run = false;
+                    else prev = o.score;
+                }
+            }
+            if (has) {
+                SwOut so; so.score = o.score; so.qle = o.qle; so.tle = o.tle; so.gtle = o.gtle; so.gscore = o.gscore; so.max_off = o.max_off;
+                apply_side(side, a, s, l_query, so, h0, w_used, side == 0 ? xp.pen_clip5 : xp.pen_clip3);
+                n_done++;
+            }
+        }
+        if (valid) regs[g] = a;
     }
     atomicAdd(&counters[0], (unsigned long long)cells);
-    atomicAdd(&counters[1], valid ? 1ULL : 0ULL);
+    atomicAdd(&counters[1], n_done);
 }
 
 // one side on one wavefront, with the accept/retry rule of bwamem.cpp:2495-2496: stop when the score did not change, or
@@ -417,19 +446,19 @@ static __device__ __forceinline__ int extend_side(const uint8_t *q, int qs, int 
         const int wc = band_clamp(w, len2, P, cls);
         cells += bsw_extend(q, qs, len2, t, ts, len1, wc, h0, P, RH, RE, RM, o);
         w_used = w;
-        if (o.score == prev || o.max_off < (w >> 1) + (w >> 2) || i + 1 == MAX_BAND_TRY) break;
-        prev = o.score;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // (the next try, or the other side, reuses the LDS rings)
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (o.score == prev || o.max_off < (w >> 1) + (w >> 2) || i + 1 == MAX_BAND_TRY) break;
+        prev = o.score;
     }
     return o.score;
 }
 
-// ---- one task per wavefront: long queries, int32-class scores (the scalar fallback of the reference, bwamem.cpp:2472)
-template <int SIDE>
+// ---- one seed per wavefront: long queries, int32-class scores (the scalar fallback of the reference, bwamem.cpp:2472), and the query-length
+// classes the launch policy sends here; left side, then right side
 __global__ void __launch_bounds__(256)
-k_ext_wave(DevIndex ix, ExtParams xp, const int32_t *__restrict__ tasks, int n_tasks,
+k_ext_wave(DevIndex ix, ExtParams xp, const int32_t *__restrict__ tasks_all, const int64_t *__restrict__ start, int bin_lo, int bin_hi,
            const uint8_t *__restrict__ enc, const int64_t *__restrict__ off, const int32_t *__restrict__ len,
            const int64_t *__restrict__ slot_base, const int32_t *__restrict__ reg_seed, const int32_t *__restrict__ reg_chain,
            const DevChain *__restrict__ chn, const DevSeed *__restrict__ seeds, DevReg *regs, int R, unsigned long long *counters, int rev) {
@@ -438,26 +467,36 @@ k_ext_wave(DevIndex ix, ExtParams xp, const int32_t *__restrict__ tasks, int n_t
     int *rings = lds + (sizeof(ExtParams) + 3) / 4;
     if (threadIdx.x < sizeof(ExtParams) / 4) ((int *)sP)[threadIdx.x] = ((const int *)&xp)[threadIdx.x];
     __syncthreads();
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
     int *RH = rings + (size_t)wv * 2 * R, *RE = RH + R;
-    const int idx = blockIdx.x * (blockDim.x >> 6) + wv;
-    if (idx >= n_tasks) return;
-    const int g = tasks[rev ? n_tasks - 1 - idx : idx];
-    const int64_t base = slot_base[g];
-    const DevChain c = chn[base + reg_chain[g]];
-    const DevSeed s = seeds[base + reg_seed[g]];
-    DevReg a = regs[g];
-    const int l_query = len[c.read];
-    const TaskGeom tg = task_geom(SIDE, s, c, enc + off[c.read], l_query, ix.ref_string);
-    const int h0 = SIDE == 0 ? s.len * sP->a : a.score;
-    const int prev = SIDE == 0 ? -1 : a.score;
-    SwOut o; int w_used; long long cells = 0;
-    extend_side(tg.q, tg.qs, tg.len2, tg.t, tg.ts, tg.len1, h0, prev, sP->w, SIDE == 0 ? sP->left : sP->right, RH, RE, R - 1, o, w_used, cells);
+    const int64_t first = start[bin_lo];
+    const int n_tasks = (int)(start[bin_hi] - first);
+    const int32_t *tasks = tasks_all + first;
+    long long cells = 0;
+    unsigned long long n_done = 0;
+    for (int idx = blockIdx.x * wpb + wv; idx < n_tasks; idx += gridDim.x * wpb) {
+        const int g = uni(tasks[rev ? n_tasks - 1 - idx : idx]);
+        const int64_t base = slot_base[g];
+        const DevChain c = chn[base + reg_chain[g]];
+        const DevSeed s = seeds[base + reg_seed[g]];
+        DevReg a = regs[g];
+        const int l_query = len[c.read];
+#pragma nounroll
+        for (int side = 0; side < 2; side++) {
+            if (!(side == 0 ? s.qbeg != 0 : s.qbeg + s.len != l_query)) continue;
+            const TaskGeom tg = task_geom(side, s, c, enc + off[c.read], l_query, ix.ref_string);
+            const int h0 = side == 0 ? s.len * sP->a : a.score;
+            const int prev = side == 0 ? -1 : a.score;
+            SwOut o; int w_used;
+            extend_side(tg.q, tg.qs, tg.len2, tg.t, tg.ts, tg.len1, h0, prev, sP->w, side == 0 ? sP->left : sP->right, RH, RE, R - 1, o, w_used, cells);
+            apply_side(side, a, s, l_query, o, h0, w_used, side == 0 ? sP->pen_clip5 : sP->pen_clip3);     // (wave-uniform: every lane holds the same reg)
+            n_done++;
+        }
+        if (lane == 0) regs[g] = a;
+    }
     if (lane == 0) {
-        apply_side(SIDE, a, s, l_query, o, h0, w_used, SIDE == 0 ? sP->pen_clip5 : sP->pen_clip3);
-        regs[g] = a;
         atomicAdd(&counters[0], (unsigned long long)cells);
-        atomicAdd(&counters[1], 1ULL);
+        atomicAdd(&counters[1], n_done);
     }
 }
 
@@ -691,13 +730,14 @@ k_advance(ChainParams o, ExtParams xp, int n_reads, const int32_t *__restrict__ 
           const int64_t *__restrict__ read_base, const int32_t *__restrict__ n_reg,
           const int32_t *__restrict__ reg_chain, const DevChain *__restrict__ chn,
           const DevSeed *__restrict__ seeds, int32_t *srt_all, DevReg *regs, int32_t *cursor, int32_t *cur_slot /* [n_reads] reg idx to extend or -1 */,
-          uint8_t *bins /* [2][n_reads] */, uint32_t *hist /* [2*N_BINS] + [1] pending reads */) {
-    __shared__ uint32_t sh[2 * N_BINS + 1];
-    for (int i = threadIdx.x; i < 2 * N_BINS + 1; i += blockDim.x) sh[i] = 0;
+          uint32_t *ebin /* [n_reads] sort key of the picked seed */, int32_t *hist /* [N_EBINS] */, uint32_t *pend /* reads with undecided seeds left */) {
+    __shared__ uint32_t sh_pend;
+    if (threadIdx.x == 0) sh_pend = 0;
     __syncthreads();
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r < n_reads) {
-        int bl = 255, br = 255, pick = -1;
+        int pick = -1;
+        uint32_t b = EBIN_NONE;
         const int nr = n_reg[r];
         int cur = cursor[r];
         if (cur < nr) {
@@ -725,28 +765,21 @@ k_advance(ChainParams o, ExtParams xp, int n_reads, const int32_t *__restrict__ 
                 if (s.qbeg) { a.qb = s.qbeg; }
                 else { a.score = a.truesc = s.len * xp.a; a.qb = 0; }
                 a.qe = (s.qbeg + s.len != l_query) ? s.qbeg + s.len : l_query;
-                for (int side = 0; side < 2; side++) {
-                    const bool has = side == 0 ? s.qbeg != 0 : s.qbeg + s.len != l_query;
-                    if (!has) continue;
-                    const TaskGeom tg = task_geom(side, s, c, nullptr, l_query, nullptr);
-                    const bool lane_ok = tg.len2 <= LANE_QMAX && tg.len1 < 32768 && (l_query + tg.len1 + 1) * xp.a < 32768;
-                    const int b = lane_ok ? tg.len2 : BIN_FALLBACK;
-                    if (side == 0) bl = b; else br = b;
-                    atomicAdd(&sh[side * N_BINS + b], 1u);
-                }
+                b = seed_bin(xp, s, c, l_query);
+                if (b != EBIN_NONE) atomicAdd(&hist[b], 1);
                 av[cur] = a;
                 pick = cur;
                 cur++;
                 break;
             }
             cursor[r] = cur;
-            if (cur < nr) atomicAdd(&sh[2 * N_BINS], 1u);    // this read still has undecided seeds
+            if (cur < nr) atomicAdd(&sh_pend, 1u);           // this read still has undecided seeds
         }
         cur_slot[r] = pick;
-        bins[r] = (uint8_t)bl; bins[n_reads + r] = (uint8_t)br;
+        ebin[r] = b;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 2 * N_BINS + 1; i += blockDim.x) if (sh[i]) atomicAdd(&hist[i], sh[i]);
+    if (threadIdx.x == 0 && sh_pend) atomicAdd(pend, sh_pend);
 }
 
 // seedcov for the regs extended in one lazy round (one read per lane)
@@ -801,88 +834,84 @@ k_slot_base(int n_reads, const int64_t *__restrict__ read_base, const int32_t *_
 static int ring_size2(int w) { int R = 64; while (R < 2 * w + 4) R <<= 1; return R; }
 
 #define LAZY_ROUNDS 6
-#define N_CLS 10
+#define EXT_EAGER_PHASE (BM2_EXT_PHASES - 1)      // the eager remainder's row of the per-phase statistics
 
 struct ExtLaunch {
     bm2_ctx *c; hipStream_t s; ExtParams xp; const uint8_t *enc; const int64_t *off; const int32_t *len; const int64_t *slot_base;
     const int32_t *reg_seed, *reg_chain; const DevChain *chn; const DevSeed *seeds; DevReg *regs; unsigned long long *counters;
     int R; size_t lds_w; bool pack8;
-    // launch policy (bm2_knob): which kernel takes a query-length class.  Every launch of a side lasts about as long as its slowest
-    // wavefront, and a lane-per-task wavefront of 150-base queries walks ~30 k cells one after the other (milliseconds), so the
-    // classes with few tasks or long queries go one task per WAVEFRONT (k_ext_wave: ~0.1 ms per task) beside the lane kernels.
-    int wave_qmin, wave_nmax, prefetch, rev, perm_scores, qmap;
+    // launch policy (bm2_knob): which kernel takes a query-length class.  A lane-per-seed wavefront of long queries walks tens of thousands
+    // of cells one after the other (milliseconds) and a phase lasts as long as its slowest wavefront, so the classes from wave_qmin up can go
+    // one seed per WAVEFRONT (k_ext_wave) beside the lane kernels.
+    int wave_qmin, prefetch, rev, perm_scores, qmap;
+    // the sorted seed list of the phase and where it lives
+    const int32_t *tasks; const int64_t *start;
 };
 
-// Left side, then right side (whose h0 is the left score).  Lane-per-task kernels per query-length class (each class needs
-// a different LDS footprint) plus the wavefront-per-task kernel; the launches of one side run concurrently on the
-// context's side streams, joined by events before the other side starts.
-static int run_sides(const ExtLaunch &L, const uint32_t *h_hist, const uint32_t *h_start, const int32_t *taskL, const int32_t *taskR) {
+// The launches of one phase: a lane-per-seed launch per LDS class (each class needs a different LDS footprint) plus the wavefront-per-seed
+// kernel; they run concurrently on the context's side streams, joined by events.  Every kernel reads its range of the sorted list from the
+// device (`start`); the host only chooses grid sizes, from `hint` = the class counts of this phase in the previous batch (nullptr: unknown,
+// `ub` seeds at most) -- a grid that is too small costs time (the kernels stride), never correctness.
+static int run_phase(const ExtLaunch &L, const uint32_t *hint, int64_t ub) {
     static const int cls_hi[N_CLS] = { 16, 32, 48, 64, 80, 96, 112, 128, 144, 160 };
     bm2_ctx *c = L.c;
-    for (int side = 0; side < 2; side++) {
-        const int32_t *tasks = side == 0 ? taskL : taskR;
-        const uint32_t *st = h_start + side * N_BINS, *hc = h_hist + side * N_BINS;
-        (void)hipEventRecord(c->ev_fork, L.s);
-        auto wave_launch = [&](hipStream_t sk, uint32_t first, uint32_t n) {
-            if (side == 0) hipLaunchKernelGGL(k_ext_wave<0>, dim3((n + 3) / 4), dim3(256), L.lds_w, sk, c->ix, L.xp, tasks + first, (int)n, L.enc, L.off, L.len, L.slot_base, L.reg_seed, L.reg_chain, L.chn, L.seeds, L.regs, L.R, L.counters, L.rev);
-            else hipLaunchKernelGGL(k_ext_wave<1>, dim3((n + 3) / 4), dim3(256), L.lds_w, sk, c->ix, L.xp, tasks + first, (int)n, L.enc, L.off, L.len, L.slot_base, L.reg_seed, L.reg_chain, L.chn, L.seeds, L.regs, L.R, L.counters, L.rev);
-        };
-        // the classes from k_wave up (long queries) and the fallback bin are adjacent in the task list: one wavefront-per-task launch
-        int k_wave = N_CLS;
-        while (k_wave > 0 && (k_wave >= 2 ? cls_hi[k_wave - 2] : 0) + 1 >= L.wave_qmin) k_wave--;
-        // Streams sit on HARDWARE QUEUES round-robin (GPU_MAX_HW_QUEUES = 8: the context's main stream and its first seven side streams are
-        // eight different queues, side stream 10 shares the queue of side stream 3), and two launches on one queue run one after the other
-        // (profiles/r03x_timeline.tsv: the 49..64-column class started when the wavefront kernel ended, 0.8-1.1 ms later than its peers, in every
-        // phase).  The eight launches of a side -- seven lane classes and the wavefront kernel -- get seven queues: the wavefront kernel takes the
-        // shortest class's side stream, the shortest class queues behind the second shortest (both end long before the side does; on the main
-        // stream it was dispatched last and became the side's tail: 25.0 instead of 24.6 ms).  BM2_EXT_QUEUE_MAP=0: one side stream per class
-        // index, as before (26.5 ms).  (Issue priority -- s_setprio -- for the long classes' wavefronts, the critical path of every side, was
-        // tried and measured no gain: profiles/r03z_sweep_priority.json.)
-        for (int kk = 0; kk <= N_CLS; kk++) {                  // longest queries first: their tails overlap the short classes
-            const int k = kk == 0 ? N_CLS : N_CLS - kk;
-            hipStream_t sk = !L.qmap ? c->side_stream[k] : k == N_CLS ? c->side_stream[0] : c->side_stream[k ? k : 1];
-            uint32_t n = 0, first = 0; int hi = 0;
-            if (k < N_CLS) {
-                if (k >= k_wave) continue;                      // part of the launch of k == N_CLS
-                hi = cls_hi[k];
-                const int lo = k ? cls_hi[k - 1] : 0;
-                first = st[lo + 1];
-                for (int b = lo + 1; b <= hi; b++) n += hc[b];
-            } else {
-                const int lo = k_wave ? cls_hi[k_wave - 1] : 0;
-                first = st[lo + 1];
-                for (int b = lo + 1; b <= BIN_FALLBACK; b++) n += hc[b];
+    (void)hipEventRecord(c->ev_fork, L.s);
+    // the classes from k_wave up (long queries) and the fallback bins are adjacent in the list: one wavefront-per-seed launch
+    int k_wave = N_CLS;
+    while (k_wave > 0 && (k_wave >= 2 ? cls_hi[k_wave - 2] : 0) + 1 >= L.wave_qmin) k_wave--;
+    auto grid_for = [&](int k_lo, int k_hi, int per_block) -> unsigned {
+        int64_t n = 0;
+        if (hint) { for (int k = k_lo; k < k_hi; k++) n += hint[k]; n += n / 4 + 64; }
+        else n = ub;
+        if (n > ub) n = ub;
+        int64_t g = (n + per_block - 1) / per_block;
+        if (g < 1) g = 1;
+        if (g > (1 << 16)) g = 1 << 16;                 // (the kernels stride)
+        return (unsigned)g;
+    };
+    // Streams sit on HARDWARE QUEUES round-robin (GPU_MAX_HW_QUEUES = 8: the context's main stream and its first seven side streams are
+    // eight different queues, side stream 10 shares the queue of side stream 3), and two launches on one queue run one after the other
+    // (profiles/r03x_timeline.tsv).  The eight launches of a phase -- seven lane classes and the wavefront kernel for 150 bp reads -- get
+    // seven queues: the wavefront kernel takes the shortest class's side stream, the shortest class queues behind the second shortest.
+    // BM2_EXT_QUEUE_MAP=0: one side stream per class index.
+    for (int kk = 0; kk <= N_CLS; kk++) {                  // longest queries first: their tails overlap the short classes
+        const int k = kk == 0 ? N_CLS : N_CLS - kk;
+        hipStream_t sk = !L.qmap ? c->side_stream[k] : k == N_CLS ? c->side_stream[0] : c->side_stream[k ? k : 1];
+        if (k < N_CLS && k >= k_wave) continue;            // part of the launch of k == N_CLS
+        (void)hipStreamWaitEvent(sk, c->ev_fork, 0);
+        if (k < N_CLS) {
+            const int hi = cls_hi[k];
+            const size_t lds = L.pack8 ? (size_t)((hi + 2) / 2) * 64 * 4 + (size_t)((hi + 7) / 8) * 64 * 4
+                                       : (size_t)(hi + 1) * 64 * 4 + (size_t)hi * 64;
+            auto kern = L.pack8 ? (L.prefetch ? k_ext_seeds<true, true> : k_ext_seeds<true, false>) : k_ext_seeds<false, false>;
+            size_t lds_k = lds;
+            if (L.pack8 && L.perm_scores && L.prefetch) {       // the LDS-row kernel with the byte-permute score table (query one base per byte)
+                kern = k_ext_seeds<true, true, true>;
+                lds_k = (size_t)((hi + 2) / 2) * 64 * 4 + (size_t)((hi + 3) / 4 + 1) * 64 * 4;
             }
-            if (!n) continue;
-            (void)hipStreamWaitEvent(sk, c->ev_fork, 0);
-            if (k < N_CLS && (int64_t)n > (int64_t)L.wave_nmax) {
-                const size_t lds = L.pack8 ? (size_t)((hi + 2) / 2) * 64 * 4 + (size_t)((hi + 7) / 8) * 64 * 4
-                                           : (size_t)(hi + 1) * 64 * 4 + (size_t)hi * 64;
-                auto kern = side == 0 ? (L.pack8 ? (L.prefetch ? k_ext_lanes<0, true, true> : k_ext_lanes<0, true, false>) : k_ext_lanes<0, false, false>)
-                                      : (L.pack8 ? (L.prefetch ? k_ext_lanes<1, true, true> : k_ext_lanes<1, true, false>) : k_ext_lanes<1, false, false>);
-                size_t lds_k = lds;
-                if (L.pack8 && L.perm_scores && L.prefetch) {       // the LDS-row kernel with the byte-permute score table (query one base per byte)
-                    kern = side == 0 ? k_ext_lanes<0, true, true, true> : k_ext_lanes<1, true, true, true>;
-                    lds_k = (size_t)((hi + 2) / 2) * 64 * 4 + (size_t)((hi + 3) / 4 + 1) * 64 * 4;
-                }
-                hipLaunchKernelGGL(kern, dim3((n + 63) / 64), dim3(64), lds_k, sk, c->ix, L.xp, tasks + first, (int)n, hi, L.enc, L.off, L.len,
-                                   L.slot_base, L.reg_seed, L.reg_chain, L.chn, L.seeds, L.regs, L.counters, L.rev);
-            } else wave_launch(sk, first, n);
-            (void)hipEventRecord(c->ev_join[k], sk);
-            (void)hipStreamWaitEvent(L.s, c->ev_join[k], 0);
+            hipLaunchKernelGGL(kern, dim3(grid_for(k, k + 1, 64)), dim3(64), lds_k, sk, c->ix, L.xp, L.tasks, L.start, k * EB_2D, (k + 1) * EB_2D, hi,
+                               L.enc, L.off, L.len, L.slot_base, L.reg_seed, L.reg_chain, L.chn, L.seeds, L.regs, L.counters, L.rev);
+        } else {
+            hipLaunchKernelGGL(k_ext_wave, dim3(grid_for(k_wave, N_CLS + 1, 4)), dim3(256), L.lds_w, sk, c->ix, L.xp, L.tasks, L.start, k_wave * EB_2D,
+                               (int)N_EBINS, L.enc, L.off, L.len, L.slot_base, L.reg_seed, L.reg_chain, L.chn, L.seeds, L.regs, L.R, L.counters, L.rev);
         }
+        (void)hipEventRecord(c->ev_join[k], sk);
+        (void)hipStreamWaitEvent(L.s, c->ev_join[k], 0);
     }
     return bm2_check(hipGetLastError(), "extension launches");
 }
 
 // Extension stage: lazy rounds (k_advance + extension of the picked seeds), then -- for reads that still have undecided
-// seeds after LAZY_ROUNDS kept alignments (repeat-rich reads) -- eager extension of the rest, purged by k_postfilter exactly
+// seeds after the lazy rounds (repeat-rich reads) -- eager extension of the rest, purged by k_postfilter exactly
 // as the reference does for every seed.  cursor[r] tells the post-filter where its replay starts.
+// Nothing here waits for the device: the number of lazy rounds and the grid sizes come from the statistics the PREVIOUS batch left in
+// the context's page-locked `ext_stat` (they arrive before bm2_batch_run returns); neither can change a result -- a lazy round that finds
+// nothing to do, or an eager phase with nothing left, launches kernels that exit.
 int bm2_launch_extend(bm2_ctx *c, const bm2_opt &opt, const ChainParams &cp, int n_reads, int64_t n_slots, const uint8_t *enc,
                       const int64_t *off, const int32_t *len, const int64_t *read_base, const int32_t *n_chain, const int32_t *n_reg,
                       const int64_t *slot_base, const int32_t *reg_seed, const int32_t *reg_chain, const DevChain *chn,
-                      const DevSeed *seeds, int32_t *srt_all, DevReg *regs, unsigned long long *counters, DevBuf &tmp, int32_t *cursor,
-                      int max_len) {
+                      const DevSeed *seeds, int32_t *srt_all, DevReg *regs, unsigned long long *counters, DevBuf &tmp, DevBuf &scan_tmp,
+                      int32_t *cursor, int max_len) {
     hipStream_t s = c->stream;
     int rc;
     if ((rc = bm2_check(hipMemsetAsync(cursor, 0, (size_t)(n_reads + 1) * 4, s), "memset cursor"))) return rc;
@@ -899,70 +928,70 @@ int bm2_launch_extend(bm2_ctx *c, const bm2_opt &opt, const ChainParams &cp, int
     P.end_bonus = opt.pen_clip3; xp.right = P;
     // no H / E of the batch can exceed l_query * a (a full-length perfect match): 8-bit rows when that fits
     L.pack8 = !bm2_knob("BM2_NO_PACK8", 0) && (int64_t)max_len * opt.a <= 255 && opt.a > 0;
-    // defaults = the best of tools/gpu/sweep.py on the GRCh38-sized bench workload (profiles/r02_sweep.json): extension stage
-    // 36.8 -> 30.4 ms with the classes from 113 bases up on k_ext_wave (97: 34 ms, 129: 34.7 ms, 65: 51 ms), -0.2 ms with the prefetch
-    L.wave_qmin = bm2_knob("BM2_EXT_WAVE_QMIN", 113);               // classes of queries at least this long: one task per wavefront
-    L.wave_nmax = bm2_knob("BM2_EXT_WAVE_NMAX", 0);                 // classes with at most this many tasks in a round: likewise (no gain measured)
+    L.wave_qmin = bm2_knob("BM2_EXT_WAVE_QMIN", 113);               // classes of queries at least this long: one seed per wavefront
     L.prefetch = bm2_knob("BM2_EXT_PREFETCH", 1);
-    L.rev = bm2_knob("BM2_EXT_REVERSE", 1);      // (sweep of round 3: -0.6 ms)
-    L.qmap = bm2_knob("BM2_EXT_QUEUE_MAP", 1);      // (profiles/r03y_*, r03z_*: extension 26.5 -> 24.6 ms)
-    L.perm_scores = bm2_knob("BM2_EXT_PERM_SCORES", 1);            // (sweep of round 3, profiles/r03v_sweep_lane_variants.json: extension 28.0 -> 26.5 ms)
+    L.rev = bm2_knob("BM2_EXT_REVERSE", 1);
+    L.qmap = bm2_knob("BM2_EXT_QUEUE_MAP", 1);
+    L.perm_scores = bm2_knob("BM2_EXT_PERM_SCORES", 1);
     for (int k : { 0, 1, 4 }) if (opt.mat[k] < -128 || opt.mat[k] > 127) L.perm_scores = 0;     // (the score table holds signed bytes)
-    const int lazy_rounds = bm2_knob("BM2_EXT_ROUNDS", LAZY_ROUNDS), pend_div = bm2_knob("BM2_EXT_PEND_DIV", 12);
+    const int lazy_max = bm2_knob("BM2_EXT_ROUNDS", LAZY_ROUNDS), pend_div = bm2_knob("BM2_EXT_PEND_DIV", 12);
     L.R = ring_size2(opt.w << (MAX_BAND_TRY - 1));
     L.lds_w = ((sizeof(ExtParams) + 3) / 4) * 4 + (size_t)4 * 2 * L.R * 4;
     if (L.lds_w > 160 * 1024) { bm2_set_error("band width %d needs more LDS than a CU has", opt.w); return BM2_EUNSUP; }
-    // scratch: bins[2*max(n_slots,n_reads)] | hist[2*N_BINS+1] | start[2*N_BINS] | cur_slot[n_reads] | taskL[n_slots] | taskR[n_slots]
-    const size_t n_items = (size_t)(n_slots > n_reads ? n_slots : n_reads);
-    const size_t o_hist = (2 * n_items + 255) & ~(size_t)255, o_cur = o_hist + (2 * N_BINS + 2) * 4;
-    const size_t o_cs = (o_cur + 2 * N_BINS * 4 + 255) & ~(size_t)255;
-    const size_t o_tl = (o_cs + (size_t)n_reads * 4 + 255) & ~(size_t)255, o_tr = o_tl + (size_t)n_slots * 4;
-    if ((rc = bm2_reserve(tmp, o_tr + (size_t)n_slots * 4 + 256))) return rc;
-    uint8_t *bins = (uint8_t *)tmp.p;
-    uint32_t *hist = (uint32_t *)((char *)tmp.p + o_hist), *start = (uint32_t *)((char *)tmp.p + o_cur);
-    int32_t *cur_slot = (int32_t *)((char *)tmp.p + o_cs);
-    int32_t *taskL = (int32_t *)((char *)tmp.p + o_tl), *taskR = (int32_t *)((char *)tmp.p + o_tr);
-    uint32_t h_hist[2 * N_BINS + 1], h_start[2 * N_BINS];
-    auto prefix = [&]() {
-        for (int side = 0; side < 2; side++) {
-            uint32_t acc = 0;
-            for (int b = 0; b < N_BINS; b++) { h_start[side * N_BINS + b] = acc; acc += h_hist[side * N_BINS + b]; }
+    // what the previous batch of this context saw: seeds per class and phase (grid sizes), reads pending after each lazy round (how many
+    // lazy rounds pay: a round for a twelfth of the reads costs more in launches than it saves in cells)
+    uint32_t hint[BM2_EXT_PHASES][BM2_EXT_STATW];
+    const bool have_hint = c->ext_stat && c->ext_stat_reads > 0;
+    int n_lazy = 2;
+    if (have_hint) {
+        memcpy(hint, c->ext_stat, sizeof hint);
+        if (c->ext_stat_reads != n_reads)                           // another batch size: the class counts scale with it
+            for (int p = 0; p < BM2_EXT_PHASES; p++)
+                for (int k = 0; k <= N_CLS; k++) hint[p][k] = (uint32_t)((uint64_t)hint[p][k] * (uint32_t)n_reads / (uint32_t)c->ext_stat_reads) + 64;
+        n_lazy = 1;
+        for (int r = 0; r < c->ext_stat_rounds && r + 1 < EXT_EAGER_PHASE; r++) {
+            const uint32_t pend = hint[r][N_CLS + 1];
+            if (pend && (uint64_t)pend * (uint32_t)pend_div >= (uint32_t)c->ext_stat_reads) n_lazy = r + 2; else break;
         }
+    }
+    if (n_lazy > lazy_max) n_lazy = lazy_max;
+    if (n_lazy > EXT_EAGER_PHASE) n_lazy = EXT_EAGER_PHASE;
+    // scratch: ebin[n_items] | hist[N_EBINS] | pend[PHASES] | stat[PHASES][STATW] | start[N_EBINS + 1] | cur_slot[n_reads] | tasks[n_items]
+    const size_t n_items = (size_t)(n_slots > n_reads ? n_slots : n_reads);
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t o_hist = up(n_items * 4), o_pend = up(o_hist + (size_t)N_EBINS * 4), o_stat = o_pend + 256;
+    const size_t o_start = up(o_stat + sizeof hint), o_cs = up(o_start + (size_t)(N_EBINS + 2) * 8), o_task = up(o_cs + (size_t)n_reads * 4);
+    if ((rc = bm2_reserve(tmp, o_task + n_items * 4 + 256))) return rc;
+    char *base = (char *)tmp.p;
+    uint32_t *ebin = (uint32_t *)base, *pend = (uint32_t *)(base + o_pend), *stat = (uint32_t *)(base + o_stat);
+    int32_t *hist = (int32_t *)(base + o_hist), *cur_slot = (int32_t *)(base + o_cs), *tasks = (int32_t *)(base + o_task);
+    int64_t *start = (int64_t *)(base + o_start);
+    L.tasks = tasks; L.start = start;
+    if ((rc = bm2_check(hipMemsetAsync(hist, 0, o_start - o_hist, s), "memset hist"))) return rc;      // histogram, pending counters, statistics
+    auto sort_and_run = [&](int phase, int64_t n_sort, bool by_read) -> int {
+        int rc2;
+        if ((rc2 = bm2_scan_i32(c, hist, N_EBINS, start, scan_tmp))) return rc2;
+        hipLaunchKernelGGL(k_task_scatter, dim3((unsigned)((n_sort + 255) / 256)), dim3(256), 0, s, n_sort, ebin, hist, start, tasks,
+                           by_read ? read_base : (const int64_t *)nullptr, by_read ? cur_slot : (const int32_t *)nullptr);
+        hipLaunchKernelGGL(k_phase_stats, dim3(1), dim3(64), 0, s, start, by_read ? pend + phase : (const uint32_t *)nullptr, stat + (size_t)phase * BM2_EXT_STATW);
+        return run_phase(L, have_hint ? hint[phase] : nullptr, n_sort);
     };
     const unsigned nbr = (unsigned)((n_reads + 127) / 128), nbr2 = (unsigned)((n_reads + 255) / 256);
-    uint32_t pending = 1;
-    for (int round = 0; round < lazy_rounds && pending && (round < 1 || (uint64_t)pending * (uint32_t)pend_div >= (uint32_t)n_reads); round++) {
-        if ((rc = bm2_check(hipMemsetAsync(hist, 0, (2 * N_BINS + 1) * 4, s), "memset hist"))) return rc;
+    for (int round = 0; round < n_lazy; round++) {
         hipLaunchKernelGGL(k_advance, dim3(nbr), dim3(128), 0, s, cp, xp, n_reads, len, read_base, n_reg, reg_chain, chn, seeds, srt_all,
-                           regs, cursor, cur_slot, bins, hist);
-        if ((rc = bm2_check(hipMemcpyAsync(h_hist, hist, sizeof h_hist, hipMemcpyDeviceToHost, s), "D2H hist"))) return rc;
-        if ((rc = bm2_check(hipStreamSynchronize(s), "k_advance"))) return rc;
-        pending = h_hist[2 * N_BINS];
-        uint32_t tot = 0;
-        for (int b = 0; b < 2 * N_BINS; b++) tot += h_hist[b];
-        if (tot) {
-            prefix();
-            if ((rc = bm2_check(hipMemcpyAsync(start, h_start, sizeof h_start, hipMemcpyHostToDevice, s), "H2D start"))) return rc;
-            hipLaunchKernelGGL(k_task_scatter, dim3(nbr2), dim3(256), 0, s, (int64_t)n_reads, bins, start, taskL, taskR, read_base, cur_slot);
-            if ((rc = run_sides(L, h_hist, h_start, taskL, taskR))) return rc;
-        }
+                           regs, cursor, cur_slot, ebin, hist, pend + round);
+        if ((rc = sort_and_run(round, n_reads, true))) return rc;
         hipLaunchKernelGGL(k_seedcov_round, dim3(nbr2), dim3(256), 0, s, n_reads, read_base, cur_slot, reg_chain, chn, seeds, regs);
     }
-    if (pending) {      // eager remainder: every seed at or beyond its read's cursor
-        if ((rc = bm2_check(hipMemsetAsync(hist, 0, (2 * N_BINS + 1) * 4, s), "memset hist"))) return rc;
+    {       // eager remainder: every seed at or beyond its read's cursor
         const unsigned nb = (unsigned)((n_slots + 255) / 256);
-        hipLaunchKernelGGL(k_reg_init, dim3(nb), dim3(256), 0, s, xp, n_slots, len, slot_base, reg_seed, reg_chain, chn, seeds, regs, bins, hist, cursor);
-        if ((rc = bm2_check(hipMemcpyAsync(h_hist, hist, sizeof h_hist, hipMemcpyDeviceToHost, s), "D2H hist"))) return rc;
-        if ((rc = bm2_check(hipStreamSynchronize(s), "k_reg_init"))) return rc;
-        uint32_t tot = 0;
-        for (int b = 0; b < 2 * N_BINS; b++) tot += h_hist[b];
-        if (tot) {
-            prefix();
-            if ((rc = bm2_check(hipMemcpyAsync(start, h_start, sizeof h_start, hipMemcpyHostToDevice, s), "H2D start"))) return rc;
-            hipLaunchKernelGGL(k_task_scatter, dim3(nb), dim3(256), 0, s, n_slots, bins, start, taskL, taskR, (const int64_t *)nullptr, (const int32_t *)nullptr);
-            if ((rc = run_sides(L, h_hist, h_start, taskL, taskR))) return rc;
-        }
+        hipLaunchKernelGGL(k_reg_init, dim3(nb), dim3(256), 0, s, xp, n_slots, len, slot_base, reg_seed, reg_chain, chn, seeds, regs, ebin, hist, cursor);
+        if ((rc = sort_and_run(EXT_EAGER_PHASE, n_slots, false))) return rc;
         hipLaunchKernelGGL(k_seedcov, dim3(nb), dim3(256), 0, s, n_slots, slot_base, reg_seed, reg_chain, chn, seeds, regs, cursor);
+    }
+    if (c->ext_stat) {      // (arrives before the caller's end-of-batch synchronisation; read by the next batch)
+        if ((rc = bm2_check(hipMemcpyAsync(c->ext_stat, stat, sizeof hint, hipMemcpyDeviceToHost, s), "D2H extension statistics"))) return rc;
+        c->ext_stat_reads = n_reads; c->ext_stat_rounds = n_lazy;
     }
     return bm2_check(hipGetLastError(), "extension launches");
 }

@@ -27,7 +27,7 @@ int bm2_launch_seed_filter(bm2_ctx *c, const ChainParams &o, const int8_t *d_mat
 int bm2_launch_extend(bm2_ctx *c, const bm2_opt &opt, const ChainParams &cp, int n_reads, int64_t n_slots, const uint8_t *enc,
                       const int64_t *off, const int32_t *len, const int64_t *read_base, const int32_t *n_chain, const int32_t *n_reg,
                       const int64_t *slot_base, const int32_t *reg_seed, const int32_t *reg_chain, const DevChain *chn,
-                      const DevSeed *seeds, int32_t *srt_all, DevReg *regs, unsigned long long *counters, DevBuf &tmp, int32_t *cursor,
+                      const DevSeed *seeds, int32_t *srt_all, DevReg *regs, unsigned long long *counters, DevBuf &tmp, DevBuf &scan_tmp, int32_t *cursor,
                       int max_len);
 int bm2_launch_slot_base(bm2_ctx *c, int n_reads, const int64_t *read_base, const int32_t *n_reg, int64_t *slot_base);
 int bm2_launch_postfilter(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_t *len, const int64_t *read_base,
@@ -390,7 +390,7 @@ static int batch_run_one(bm2_ctx *c, const bm2_opt *opt, StageGate *gate = nullp
                                 (const int64_t *)b->read_base.p, (const int32_t *)b->n_chain.p, (const int32_t *)b->n_reg.p,
                                 (const int64_t *)b->slot_base.p, (const int32_t *)b->reg_seed.p, (const int32_t *)b->reg_chain.p,
                                 (const DevChain *)b->chn.p, (const DevSeed *)b->seeds.p, (int32_t *)b->srt.p, (DevReg *)b->regs.p,
-                                (unsigned long long *)b->counters.p + 5, b->ext_tmp, (int32_t *)b->cursor.p, b->max_len))) return rc;
+                                (unsigned long long *)b->counters.p + 5, b->ext_tmp, b->scan_tmp, (int32_t *)b->cursor.p, b->max_len))) return rc;
     tick(c, "extend");
     const int thr_reg = bm2_knob("BM2_HEAVY_REG", 12);
     if (perm_mode_pf == 3 || perm_mode_pf == 4) { if ((rc = bm2_partition_by_work(c, n, (const int32_t *)b->n_reg.p, thr_reg, (int32_t *)b->perm.p, b->part_tmp, b->scan_tmp, perm_mode_pf == 4))) return rc; }

@@ -766,6 +766,11 @@ int ora_ksw_extend_cls(int qlen, const uint8_t *query, int tlen, const uint8_t *
     eh_t *eh = (eh_t *)calloc((size_t)qlen + 1, sizeof(eh_t));
     int64_t nc = 0;
     (void)end_bonus;
+    /* ORA_TRACE_ROWS=<file>: the band [beg, end) of every row of every call, for tools/ext_sim.py (how the lanes of a
+     * wavefront would be used by a given task-to-lane mapping); int32 header {qlen, tlen, h0, w, rows} then rows x {beg, end} int16 */
+    static FILE *trace_f = NULL; static int trace_on = -1;
+    if (trace_on < 0) { const char *fn = getenv("ORA_TRACE_ROWS"); trace_on = fn && *fn; if (trace_on) trace_f = fopen(fn, "wb"); if (!trace_f) trace_on = 0; }
+    int16_t *trace_rows = trace_on ? (int16_t *)malloc((size_t)(tlen + 1) * 4) : NULL; int trace_n = 0;
     eh[0].h = h0; eh[1].h = h0 > oe_ins ? h0 - oe_ins : 0;
     for (j = 2; j <= qlen && eh[j - 1].h > e_ins; ++j) eh[j].h = eh[j - 1].h - e_ins;
     max = h0; max_i = max_j = -1; max_ie = -1; gscore = -1; max_off = 0;
@@ -778,6 +783,7 @@ int ora_ksw_extend_cls(int qlen, const uint8_t *query, int tlen, const uint8_t *
         if (end > qlen) end = qlen;
         if (beg == 0) { h1 = h0 - (o_del + e_del * (i + 1)); if (h1 < 0) h1 = 0; }
         else h1 = 0;
+        if (trace_rows) { trace_rows[2 * trace_n] = (int16_t)beg; trace_rows[2 * trace_n + 1] = (int16_t)end; trace_n++; }
         for (j = beg; j < end; ++j) {
             eh_t *p = &eh[j];
             int h, M = p->h, e = p->e;
@@ -825,6 +831,11 @@ int ora_ksw_extend_cls(int qlen, const uint8_t *query, int tlen, const uint8_t *
         end = j + 2 < qlen ? j + 2 : qlen;
     }
     free(eh);
+    if (trace_rows) {
+        int32_t hdr[5] = { qlen, tlen, h0, w, trace_n };
+        fwrite(hdr, 4, 5, trace_f); fwrite(trace_rows, 4, (size_t)trace_n, trace_f); fflush(trace_f);
+        free(trace_rows);
+    }
     if (_qle) *_qle = max_j + 1;
     if (_tle) *_tle = max_i + 1;
     if (_gtle) *_gtle = max_ie + 1;
