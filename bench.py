@@ -333,6 +333,43 @@ def binding_leg(workdir, prefix, n_chunks=2):
     return res
 
 
+def s1_binding_leg(workdir, prefix):
+    """BASELINE config 2 as it is worded -- seeding and chaining on the host, only the banded SW (seam S1) on the GPU, inside the reference's own
+    program: `bwa-mem2.bm2s1 mem` (oracle/_ref, integration/bm2_bsw_binding.cpp) beside `bwa-mem2.<isa> mem` on the same single-end reads,
+    same -t: chunk rates from their own 'Processed N reads' lines (index load excluded), wall from start to exit, SAM compared."""
+    import hashlib
+    exe, isa = ref_binary()
+    s1 = os.path.join(ROOT, "oracle", "_ref", "bwa-mem2.bm2s1")
+    fq = os.path.join(workdir, "cpu_1.fq")
+    if exe is None or not os.path.exists(s1) or not os.path.exists(fq) or not os.path.exists(prefix + ".bwt.2bit.64"):
+        return {"skipped": "oracle/_ref/bwa-mem2.bm2s1, the index or the reads of the main run (cpu_1.fq) are not there"}
+    threads = host_threads()
+    res = {"reads_file": "cpu_1.fq (the first mates of the CPU baseline's pairs, as single-end reads)", "threads": threads}
+    md = {}
+    for tag, binary in (("reference", exe), ("bm2s1", s1)):
+        out_sam = os.path.join(workdir, "s1_%s.sam" % tag)
+        t = time.time()
+        p = subprocess.run([binary, "mem", "-t", str(threads), "-K", "100000000", "-o", out_sam, prefix, fq], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+        wall = time.time() - t
+        if p.returncode != 0:
+            return {"error": "%s failed: %s" % (os.path.basename(binary), p.stderr[-300:])}
+        n_proc, real = 0, 0.0
+        for m in re.finditer(r"Processed (\d+) reads in [\d.]+ CPU sec, ([\d.]+) real sec", p.stderr):
+            n_proc += int(m.group(1)); real += float(m.group(2))
+        h = hashlib.md5(); n = 0
+        with open(out_sam, "rb") as f:
+            for line in f:
+                if not line.startswith(b"@PG"):
+                    h.update(line); n += not line.startswith(b"@")
+        os.remove(out_sam)
+        md[tag] = (h.hexdigest(), n)
+        res[tag] = {"wall_s": wall, "reads": n_proc, "chunk_real_s": real, "reads_per_s_chunks": n_proc / real if real > 0 else None}
+    res["sam_equal"] = bool(md["reference"] == md["bm2s1"])
+    res["sam_records"] = md["reference"][1]
+    log("S1 binding: reference %.1f s, bwa-mem2.bm2s1 %.1f s, SAM equal = %s" % (res["reference"]["wall_s"], res["bm2s1"]["wall_s"], res["sam_equal"]))
+    return res
+
+
 def end_to_end(ctx, bm2, texts, opt, paired, n_threads, n_tail=None, limit_s=None, n_dev=None, n_warm=None):
     """FASTQ text -> SAM text over the chunks `texts` = [(bytes1, bytes2 | None)] as a pipeline of host threads: the reader
     (bm2_fastq_parse_mt), n_dev device workers (H2D, seeding .. extension, mem_sort_dedup_patch, D2H; each with a context of its own on
@@ -521,6 +558,31 @@ def end_to_end(ctx, bm2, texts, opt, paired, n_threads, n_tail=None, limit_s=Non
                      % (n_dev, n_tail)}
 
 
+def side_workload(a, name, extra, limit_s):
+    """BASELINE configs 5 / 2 inside the default run: the same script with --workload <name> as a process of its own on the same index
+    files (a failure or a hang there cannot take the main line with it) -> the fields of its JSON line that describe that workload."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--workload", name, "--gpus", "1", "--genome-mbp", str(a.genome_mbp), "--workdir", a.workdir,
+           "--no-e2e", "--no-binding", "--no-side-workloads", "--budget-s", str(int(limit_s))] + [str(x) for x in extra]
+    t = time.time()
+    try:
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=limit_s + 30)
+    except subprocess.TimeoutExpired:
+        return {"error": "not finished after %.0f s" % (limit_s + 30)}
+    for l in p.stderr.split("\n"):
+        if l.startswith("[bench]"):
+            log("[%s]" % name, l[8:])
+    line = [l for l in p.stdout.split("\n") if l.startswith("{")]
+    if not line:
+        return {"error": "exit code %d, no JSON line; stderr tail: %s" % (p.returncode, p.stderr[-300:])}
+    d = json.loads(line[-1])
+    keep = ("value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "stage_ms_per_step", "dominant_stage", "work_per_read", "roofline", "extend_kernel",
+            "chain_kernel", "parity", "cpu_baseline", "pairs_per_s", "s1_binding")
+    out = {k: d[k] for k in keep if k in d}
+    out["exit_code"] = p.returncode
+    out["wall_s"] = time.time() - t
+    return out
+
+
 TASKS_PER_READ = 2.874          # extension tasks per 150 bp read of the pe150 workload (work_per_read.sw_tasks of its bench line)
 
 
@@ -580,14 +642,63 @@ def bench_bsw(a, bm2, torch, dist_util, rank, world, local, emu, seed):
         return 0
     steps = max(a.steps, 1)
     k_ms /= steps
-    n_s = min(n, 3000)                                           # parity + CPU baseline: the oracle's ksw_extend2 restatement on a sample, one host thread
-    oopt = oracle.default_opt()
-    t = time.time(); bad = 0
-    for i in range(n_s):
-        exp = oracle.ksw_extend(qer[qoff[i]:qoff[i + 1]], ref[roff[i]:roff[i + 1]], oopt, w, end_bonus, int(h0[i]))
-        if tuple(int(got[i][f]) for f in ("score", "qle", "tle", "gtle", "gscore", "max_off")) != exp:
-            bad += 1
-    cpu_s = time.time() - t
+    # parity + CPU baseline: the REFERENCE's own kernels (oracle/_ref/refdump.<isa> bswtime: BandedPairWiseSW::getScores8 / getScores16 /
+    # scalarBandedSWAWrapper, pairs filed and ordered as the reference files and orders them, one BandedPairWiseSW object and one slice per
+    # thread) on ALL pairs of the step, on the CPUs this process may use; every pair's six outputs are compared
+    refdump, isa = ref_binary("refdump")
+    threads = host_threads()
+    cb, par = None, None
+    fields = ("score", "qle", "tle", "gtle", "gscore", "max_off")
+    if refdump is not None:
+        fn_in, fn_out = os.path.join(a.workdir, "bsw_pairs_r%d.bin" % rank), os.path.join(a.workdir, "bsw_ref_r%d.bin" % rank)
+        with open(fn_in, "wb") as f:
+            np.array([n], np.int32).tofile(f); len2.astype(np.int32).tofile(f); len1.astype(np.int32).tofile(f); h0.astype(np.int32).tofile(f)
+            qer.tofile(f); ref.tofile(f)
+        best = None
+        for _ in range(2):                                       # (the first run also pages the files in)
+            p = subprocess.run([refdump, "bswtime", str(w), str(end_bonus), str(threads), fn_in, fn_out], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+            if p.returncode != 0:
+                log("refdump bswtime failed:", p.stderr[-300:])
+                best = None
+                break
+            r = json.loads(p.stdout.strip().split("\n")[-1])
+            if best is None or r["seconds"] < best["seconds"]:
+                best = r
+        if best is not None:
+            exp = np.fromfile(fn_out, np.int32).reshape(-1, 8)
+            g = np.stack([np.asarray(got[f], np.int64) for f in fields], axis=1)
+            e = exp[:, :6].astype(np.int64)
+            # gtle means something only while gscore > 0: the reference's vector kernels keep stepping a finished pair (tests/test_bsw_reference.py)
+            cmp_cols = np.ones((len(e), 6), bool); cmp_cols[e[:, 4] <= 0, 3] = False
+            bad_rows = np.flatnonzero(((g != e) & cmp_cols).any(axis=1))
+            par = {"pairs": int(n), "sample": "ALL pairs of the step against the reference's getScores8 / getScores16 / scalarBandedSWAWrapper (%s build, refdump bswtime); six outputs, "
+                                               "gtle where gscore > 0" % isa, "pairs_equal": len(bad_rows) == 0, "mismatches": int(len(bad_rows)),
+                   "class8": best["class8"], "class16": best["class16"], "class32": best["class32"]}
+            if len(bad_rows):
+                i = int(bad_rows[0])
+                par["first_diff"] = {"pair": i, "got": [int(x) for x in g[i]], "exp": [int(x) for x in e[i]], "len2": int(len2[i]), "len1": int(len1[i]), "h0": int(h0[i])}
+            cb = {"value": n / best["seconds"] / TASKS_PER_READ, "unit": "reads/s", "cores": threads, "kind": "reference", "pairs_per_s": n / best["seconds"],
+                  "gcups": cells / best["seconds"] / 1e9,
+                  "sample": "the step's %d pairs through the reference's own BSW kernels (bwa-mem2 v2.2.1 %s build) on %d threads, each with its own BandedPairWiseSW object "
+                            "and slice: %.3f s wall for the kernel calls (best of 2; slowest thread %.3f s)" % (n, isa, threads, best["seconds"], best["slowest_thread_s"])}
+        for fn in (fn_in, fn_out):
+            try:
+                os.remove(fn)
+            except OSError:
+                pass
+    if par is None:                                              # no compiled reference on this box: the oracle's restatement on a sample, one thread
+        n_s = min(n, 3000)
+        oopt = oracle.default_opt()
+        t = time.time(); bad = 0
+        for i in range(n_s):
+            exp1 = oracle.ksw_extend(qer[qoff[i]:qoff[i + 1]], ref[roff[i]:roff[i + 1]], oopt, w, end_bonus, int(h0[i]))
+            if tuple(int(got[i][f]) for f in fields) != exp1:
+                bad += 1
+        cpu_s = time.time() - t
+        par = {"pairs": n_s, "sample": "the first %d pairs against the oracle's ksw_extend2 restatement (oracle/_ref is not built here)" % n_s, "pairs_equal": bad == 0, "mismatches": bad}
+        cb = {"value": n_s / cpu_s / TASKS_PER_READ if cpu_s > 0 else None, "unit": "reads/s", "cores": 1, "kind": "port",
+              "sample": "%d pairs through oracle/bm2_oracle.c (ora_ksw_extend_cls) from Python, one thread, %.1f s" % (n_s, cpu_s)}
+    bad = par["mismatches"]
     algo_bytes = float(int(roff[-1]) + int(qoff[-1]) + 2 * n * pairs.dtype.itemsize)     # every base once, every SeqPair read and written
     out = {
         "metric": "aligned reads/s (150bp PE vs GRCh38) at 1/2/4/8 GPU; SAM bit-exact vs ref",
@@ -604,11 +715,16 @@ def bench_bsw(a, bm2, torch, dist_util, rank, world, local, emu, seed):
                      "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": k_ms, "launches_per_step": 1,
                      "note": "integer DP: the kernel is bound by VALU / LDS issue, not by HBM (each base is read once); `extend_kernel.gcups` is its rate"},
         "extend_kernel": {"kernel": "k_bsw_pairs", "gcups": cells / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0, "avg_launch_ms": k_ms, "cells_per_launch": cells},
-        "parity": {"pairs": n_s, "sample": "the first %d pairs against the oracle's ksw_extend2 restatement (all six outputs)" % n_s, "pairs_equal": bad == 0,
-                   "mismatches": bad},
-        "cpu_baseline": {"value": n_s / cpu_s / TASKS_PER_READ if cpu_s > 0 else None, "unit": "reads/s", "cores": 1, "kind": "port",
-                         "sample": "%d pairs through oracle/bm2_oracle.c (ora_ksw_extend_cls) from Python, one thread, %.1f s" % (n_s, cpu_s)},
+        "parity": par,
+        "cpu_baseline": cb,
     }
+    if world == 1 and not a.no_binding_s1:
+        try:
+            out["s1_binding"] = s1_binding_leg(a.workdir, os.path.join(a.workdir, "genome_%dmbp_s%d.fa" % (a.genome_mbp, seed)))
+            if out["s1_binding"].get("sam_equal") is False:
+                bad += 1
+        except Exception as e:                                                        # noqa
+            out["s1_binding"] = {"error": str(e)}
     print(json.dumps(out), flush=True)
     return 0 if bad == 0 else 3
 
@@ -635,6 +751,8 @@ def main():
     ap.add_argument("--resident-chunks", type=int, default=int(os.environ.get("BM2_BENCH_RESIDENT", 4)),
                     help="distinct chunks the timed steps go round (all resident before the clock starts; capped by --warmup and --steps)")
     ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--no-binding-s1", action="store_true", help="bsw: skip the timing of `bwa-mem2.bm2s1 mem` (S1 on the GPU inside the reference's program) beside `bwa-mem2.<isa> mem`")
+    ap.add_argument("--no-side-workloads", action="store_true", help="skip configs 5 and 2 (objects `config5` / `config2` of the pe150 line: --workload ont2d / bsw as processes of their own)")
     ap.add_argument("--no-binding", action="store_true", help="skip the drop-in timing (`bwa-mem2.bm2 mem` beside `bwa-mem2.<isa> mem` on the first two end-to-end chunks' files)")
     ap.add_argument("--e2e-chunks", type=int, default=int(os.environ.get("BM2_BENCH_E2E_CHUNKS", 10)))
     ap.add_argument("--strong", action="store_true",
@@ -685,6 +803,8 @@ def main():
         n_reads = a.reads or 10000                           # ~100 Mbases: the chunk of `bwa-mem2 mem -K 100000000`
         opt, opt_args = bm2.default_opt(**ONT2D), ["-x", "ont2d"]
         seqs = synth.make_reads_long(dist_util.shard_seed(seed, rank), contigs(), n_reads, mean_len=10000, max_len=30000)
+        longest = int(np.argmax([len(x) for x in seqs]))      # the parity gate takes the first reads of the chunk: the chunk's longest read (the
+        seqs[0], seqs[longest] = seqs[longest], seqs[0]       # 30 kb cap is reached in any chunk of thousands) is one of them
         from tools import refio
         enc, off, ln = refio.pack_reads(seqs)
     else:
@@ -772,7 +892,7 @@ def main():
         dominant = max(stage_ms, key=stage_ms.get) if stage_ms else None
         traffic, pmc_src = None, None                        # HBM bytes per k_bwd launch from the committed PMC passes, same workload only
         ext_pmc = None
-        for fn in ("r03_k_bwd_pmc.json", "r02_k_bwd_pmc.json", "r01_k_bwd_pmc.json"):
+        for fn in ("r04_k_bwd_pmc.json", "r03_k_bwd_pmc.json", "r02_k_bwd_pmc.json", "r01_k_bwd_pmc.json"):
             try:
                 pm = json.load(open(os.path.join(ROOT, "profiles", fn)))
                 wl = pm["workload"]
@@ -782,7 +902,9 @@ def main():
             except Exception:
                 pass
         ext_src = None
-        for fn in ("r03_ext_pmc_sq.json", "r02_ext_pmc_sq.json"):      # SQ counter passes of the extension stage (tools/pmc_to_profiles.py): the newest committed
+        # SQ counter passes of the extension stage (tools/pmc_to_profiles.py), the newest committed one OF THIS WORKLOAD (a pass of the 150 bp
+        # workload says nothing about the kernels a 10 kb chunk runs)
+        for fn in (("r04_ont2d_ext_pmc_sq.json",) if ont else ("r04_ext_pmc_sq.json", "r03_ext_pmc_sq.json", "r02_ext_pmc_sq.json")):
             try:
                 ext_pmc = json.load(open(os.path.join(ROOT, "profiles", fn)))
                 ext_src = "profiles/" + fn
@@ -829,7 +951,7 @@ def main():
                                            "frac": stage_ach / HBM_PEAK_GBS,
                                            "kernel_ms": {k: v for k, v in kern_ms.items() if k.startswith("smem.")},
                                            "backwardExt_per_kernel": ext_of}},
-            "extend_kernel": {"kernel": "k_ext_lanes", "gcups": cells / (ext_ms * 1e-3) / 1e9 if ext_ms > 0 else 0.0,
+            "extend_kernel": {"kernel": "k_ext_seeds + k_ext_wave", "gcups": cells / (ext_ms * 1e-3) / 1e9 if ext_ms > 0 else 0.0,
                               "stage_ms": ext_ms, "cells_per_step": cells,
                               "valu_frac": ext_pmc.get("valu_frac") if ext_pmc else None,
                               "valu_peak_wave_insts_per_s": ext_pmc.get("valu_peak_wave_insts_per_s") if ext_pmc else None,
@@ -952,6 +1074,20 @@ def main():
                 out["binding"] = binding_leg(a.workdir, prefix)
             except Exception as e:                                                    # noqa
                 out["binding"] = {"error": str(e)}
+        # BASELINE configs 5 and 2 as workloads of their own, in the same line: each with its parity gate, its kernels' figures and the compiled
+        # reference timed beside it on this host
+        if world == 1 and not ont and not a.no_side_workloads and not hung:
+            for key, name, extra, need_s in (("config5", "ont2d", ["--steps", 2, "--warmup", 1, "--parity-reads", 200], 240),
+                                             ("config2", "bsw", ["--steps", 5, "--warmup", 2], 90)):
+                if time_left() < need_s:
+                    out[key] = {"skipped": "time budget (%.0f s of %.0f s left)" % (time_left(), a.budget_s)}
+                    continue
+                try:
+                    out[key] = side_workload(a, name, extra, min(need_s * 2, time_left() - 20))
+                    if out[key].get("exit_code") not in (0, None):
+                        rc = rc or 3
+                except Exception as e:                                                # noqa
+                    out[key] = {"error": str(e)}
         print(json.dumps(out), flush=True)
     if hung:                                                     # stage threads of a failed end-to-end attempt may be left: do not join them
         sys.stdout.flush(); sys.stderr.flush()

@@ -28,6 +28,8 @@
 #include <ctype.h>
 #include <string>
 #include <vector>
+#include <thread>
+#include <time.h>
 #include <unistd.h>
 
 #include "bwamem.h"
@@ -289,6 +291,74 @@ int main(int argc, char **argv) {
         fclose(fi); fclose(fo);
         return 0;
     }
+    if (argc - optind == 6 && !strcmp(argv[optind], "bswtime")) {
+        // The reference's banded-extension kernels TIMED on <threads> host threads over a batch in the binary layout bench.py writes
+        // (int32 n, then len2[n], len1[n], h0[n], then the query bases and the target bases back to back): config 2's CPU baseline and,
+        // since the results are written out (8 int32 per pair as in `bsw`), its parity gate.  As the reference does it: the pairs are filed
+        // under the three kernels (sortPairsLenExt), every class runs sorted by target length (sortPairsLen), every thread has its own
+        // BandedPairWiseSW object and a contiguous slice (a multiple of 64 pairs) -- kt_for hands each worker its own SeqPair arrays.
+        const int w = atoi(argv[optind + 1]), end_bonus = atoi(argv[optind + 2]);
+        int T = atoi(argv[optind + 3]); if (T < 1) T = 1;
+        FILE *fi = fopen(argv[optind + 4], "rb"), *fo = fopen(argv[optind + 5], "wb");
+        if (!fi || !fo) { fprintf(stderr, "cannot open the bswtime files\n"); return 1; }
+        int32_t n = 0;
+        if (fread(&n, 4, 1, fi) != 1 || n < 0) { fprintf(stderr, "bswtime: bad header\n"); return 1; }
+        std::vector<int32_t> l2((size_t)n), l1((size_t)n), h0((size_t)n);
+        if (fread(l2.data(), 4, (size_t)n, fi) != (size_t)n || fread(l1.data(), 4, (size_t)n, fi) != (size_t)n || fread(h0.data(), 4, (size_t)n, fi) != (size_t)n) return 1;
+        int64_t nq = 0, nr = 0;
+        for (int32_t i = 0; i < n; i++) { nq += l2[(size_t)i]; nr += l1[(size_t)i]; }
+        if (nq + 65536 >= (1LL << 31) || nr + 65536 >= (1LL << 31)) { fprintf(stderr, "bswtime: batch too large for SeqPair's int32 offsets\n"); return 1; }
+        std::vector<uint8_t> qer((size_t)nq + 65536, 0), ref((size_t)nr + 65536, 0);
+        if (fread(qer.data(), 1, (size_t)nq, fi) != (size_t)nq || fread(ref.data(), 1, (size_t)nr, fi) != (size_t)nr) return 1;
+        fclose(fi);
+        std::vector<SeqPair> by[3];
+        std::vector<int32_t> cls((size_t)n);
+        int64_t oq = 0, orf = 0;
+        for (int32_t i = 0; i < n; i++) {
+            SeqPair sp; memset(&sp, 0, sizeof sp);
+            sp.idq = (int32_t)oq; sp.idr = (int32_t)orf; sp.len2 = l2[(size_t)i]; sp.len1 = l1[(size_t)i]; sp.h0 = h0[(size_t)i]; sp.id = i;
+            oq += sp.len2; orf += sp.len1;
+            const int minval = sp.h0 + (sp.len1 < sp.len2 ? sp.len1 : sp.len2) * opt->a;
+            const int k = (sp.len1 < MAX_SEQ_LEN8 && sp.len2 < MAX_SEQ_LEN8 && minval < MAX_SEQ_LEN8) ? 0 : (sp.len1 < MAX_SEQ_LEN16 && sp.len2 < MAX_SEQ_LEN16 && minval < MAX_SEQ_LEN16) ? 1 : 2;
+            cls[(size_t)i] = k == 0 ? 8 : k == 1 ? 16 : 32;
+            by[k].push_back(sp);
+        }
+        for (int k = 0; k < 3; k++) std::stable_sort(by[k].begin(), by[k].end(), [](const SeqPair &x, const SeqPair &y) { return x.len1 < y.len1; });
+        std::vector<int32_t> out((size_t)n * 8, 0);
+        std::vector<double> busy((size_t)T, 0.0);
+        auto now = []() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; };
+        const double t_begin = now();
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; t++) th.emplace_back([&, t]() {
+            BandedPairWiseSW bsw(opt->o_del, opt->e_del, opt->o_ins, opt->e_ins, opt->zdrop, end_bonus, opt->mat, opt->a, opt->b, 1);
+            const double t0 = now();
+            for (int k = 0; k < 3; k++) {
+                const size_t tot = by[k].size(), per = ((tot + (size_t)T - 1) / (size_t)T + 63) / 64 * 64;
+                const size_t lo = std::min(tot, per * (size_t)t), hi = std::min(tot, lo + per);
+                if (hi <= lo) continue;
+                std::vector<SeqPair> v(by[k].begin() + (long)lo, by[k].begin() + (long)hi);
+                const int m = (int)v.size();
+                v.resize(v.size() + 2 * SIMD_WIDTH8);
+                if (k == 0) bsw.getScores8(v.data(), ref.data(), qer.data(), m, 1, w);
+                else if (k == 1) bsw.getScores16(v.data(), ref.data(), qer.data(), m, 1, w);
+                else bsw.scalarBandedSWAWrapper(v.data(), ref.data(), qer.data(), m, 1, w);
+                for (int i = 0; i < m; i++) {
+                    const SeqPair &sp = v[(size_t)i];
+                    int32_t *r = &out[(size_t)sp.id * 8];
+                    r[0] = sp.score; r[1] = sp.qle; r[2] = sp.tle; r[3] = sp.gtle; r[4] = sp.gscore; r[5] = sp.max_off; r[6] = cls[(size_t)sp.id]; r[7] = 0;
+                }
+            }
+            busy[(size_t)t] = now() - t0;
+        });
+        for (auto &x : th) x.join();
+        const double wall = now() - t_begin;
+        double mx = 0; for (double b : busy) mx = b > mx ? b : mx;
+        fwrite(out.data(), 4, out.size(), fo);
+        fclose(fo);
+        printf("{\"pairs\": %d, \"threads\": %d, \"seconds\": %.6f, \"slowest_thread_s\": %.6f, \"class8\": %zu, \"class16\": %zu, \"class32\": %zu}\n",
+               n, T, wall, mx, by[0].size(), by[1].size(), by[2].size());
+        return 0;
+    }
     if (argc - optind == 4 && !strcmp(argv[optind], "cigar")) {
         // known answers for CIGAR generation: every line of <tasks.txt> is "<w> <rb> <re> <query>" (query = ACGTN text of the
         // aligned part of the read); out per line: int32 score, n_cigar, NM, then n_cigar uint32 ops, then the MD string + NUL
@@ -324,7 +394,8 @@ int main(int argc, char **argv) {
         fprintf(stderr, "usage: refdump [mem options] <idx_prefix> <reads.fq|reads.txt> <out.bin>\n"
                         "       refdump [scoring options] cigar <idx_prefix> <tasks.txt> <out.bin>\n"
                         "       refdump [scoring options] ksw <pairs.txt> <out.bin>\n"
-                        "       refdump [scoring options] bsw <w> <end_bonus> <pairs.txt> <out.bin>\n");
+                        "       refdump [scoring options] bsw <w> <end_bonus> <pairs.txt> <out.bin>\n"
+                        "       refdump [scoring options] bswtime <w> <end_bonus> <threads> <pairs.bin> <out.bin>\n");
         return 1;
     }
     const char *prefix = argv[optind], *reads_fn = argv[optind + 1], *out_fn = argv[optind + 2];
