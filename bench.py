@@ -889,6 +889,13 @@ def main():
         stage_ach = fm_bytes / (smem_ms * 1e-3) / 1e9 if smem_ms > 0 else 0.0
         cells = st["n_sw_cells"]
         ext_ms = stage_ms.get("extend", 0.0)
+        lane_use = wave_cell_share = None
+        try:                                                 # the lane kernel's own count of its column-pair trips (128 lane slots each) and the wavefront kernel's cells
+            cn = np.asarray(ctx.batch_fetch("counters", np.uint64), np.float64)
+            if cn[7] > 0:
+                lane_use, wave_cell_share = float((cn[5] - cn[8]) / (128.0 * cn[7])), float(cn[8] / max(cn[5], 1.0))
+        except Exception:                                                             # noqa
+            pass
         dominant = max(stage_ms, key=stage_ms.get) if stage_ms else None
         traffic, pmc_src = None, None                        # HBM bytes per k_bwd launch from the committed PMC passes, same workload only
         ext_pmc = None
@@ -953,6 +960,7 @@ def main():
                                            "backwardExt_per_kernel": ext_of}},
             "extend_kernel": {"kernel": "k_ext_seeds + k_ext_wave", "gcups": cells / (ext_ms * 1e-3) / 1e9 if ext_ms > 0 else 0.0,
                               "stage_ms": ext_ms, "cells_per_step": cells,
+                              "lane_use_of_the_column_loop": lane_use, "cell_share_of_the_wavefront_kernel": wave_cell_share,
                               "valu_frac": ext_pmc.get("valu_frac") if ext_pmc else None,
                               "valu_peak_wave_insts_per_s": ext_pmc.get("valu_peak_wave_insts_per_s") if ext_pmc else None,
                               "valu_peak_source": ext_pmc.get("valu_peak_source") if ext_pmc else None,

@@ -135,7 +135,7 @@ __global__ void k_phase_stats(const int64_t *__restrict__ start, const uint32_t 
 struct LaneOut { int score, qle, tle, gtle, gscore, max_off; };
 
 static __device__ void lane_dp(bool run, int qlen, int tlen, int w, int h0, const uint8_t *tp, int ts, const SwParams &P,
-                               uint32_t *EH, const uint8_t *QL, int lane, LaneOut &out, long long &cells) {
+                               uint32_t *EH, const uint8_t *QL, int lane, LaneOut &out, long long &cells, long long &iters) {
     const int o_del = P.o_del, e_del = P.e_del, o_ins = P.o_ins, e_ins = P.e_ins, oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
     const int sc_match = P.mat[0], sc_mis = P.mat[1], sc_amb = P.mat[4];
     // first row, bandedSWA.cpp:143-145
@@ -163,6 +163,7 @@ static __device__ void lane_dp(bool run, int qlen, int tlen, int w, int h0, cons
         const int s_eq = tb > 3 ? sc_amb : sc_match;
         const int jlo = (1 << 20) - __builtin_amdgcn_readlane(wave_scan_max(alive ? (1 << 20) - beg : 0, 0), 63);
         const int jhi = __builtin_amdgcn_readlane(wave_scan_max(alive ? end : 0, 0), 63);
+        iters += jhi > jlo ? (jhi - jlo + 1) >> 1 : 0;           // (wave-uniform: trips of the column loop, in column pairs)
 #pragma unroll 2
         for (int j = jlo; j < jhi; ++j) {
             if (alive && j >= beg && j < end) {
@@ -222,7 +223,7 @@ static __device__ void lane_dp(bool run, int qlen, int tlen, int w, int h0, cons
 static __device__ __forceinline__ uint32_t rep4(int x) { return ((uint32_t)x & 0xffu) * 0x01010101u; }
 template <bool PF, bool PT = false>
 static __device__ void lane_dp8(bool run, int qlen, int tlen, int w, int h0, const uint8_t *tp, int ts, const SwParams &P,
-                                uint32_t *EH, const uint32_t *QL, int lane, LaneOut &out, long long &cells) {
+                                uint32_t *EH, const uint32_t *QL, int lane, LaneOut &out, long long &cells, long long &iters) {
     const int o_del = P.o_del, e_del = P.e_del, o_ins = P.o_ins, e_ins = P.e_ins, oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
     int sc_match = P.mat[0], sc_mis = P.mat[1], sc_amb = P.mat[4];
     // (the three scores are operands of v_cndmask in every cell, which takes both sources from VGPRs: kept there, or the compiler
@@ -264,6 +265,7 @@ static __device__ void lane_dp8(bool run, int qlen, int tlen, int w, int h0, con
         const int jlo = (1 << 20) - __builtin_amdgcn_readlane(wave_scan_max(alive ? (1 << 20) - beg : 0, 0), 63);
         const int jhi = __builtin_amdgcn_readlane(wave_scan_max(alive ? end : 0, 0), 63);
         const int jp0 = jlo & ~1;
+        iters += jhi > jp0 ? (jhi - jp0 + 1) >> 1 : 0;           // (wave-uniform: trips of the column-pair loop)
         // PT: scores of this row against the query codes 0..4: bytes 0..3 of t_lo (the target's own base: match; target N: ambiguous), byte 0 of t_hi
         const uint32_t t_lo = tb > 3 ? rep_amb : rep_mis ^ ((uint32_t)((sc_mis ^ sc_match) & 0xff) << (8 * tb)), t_hi = rep_amb;
         uint32_t qw, qnext = 0u;
@@ -356,7 +358,7 @@ k_ext_seeds(DevIndex ix, ExtParams xp, const int32_t *__restrict__ tasks_all, co
     const int n_tasks = (int)(start[bin_hi] - first);
     const int32_t *tasks = tasks_all + first;
     const int n_tiles = (n_tasks + 63) >> 6;
-    long long cells = 0;
+    long long cells = 0, iters = 0;
     unsigned long long n_done = 0;
     // (rev: the list ascends in query length; the tiles with the longest queries -- the slowest wavefronts -- are taken first)
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -415,8 +417,8 @@ k_ext_seeds(DevIndex ix, ExtParams xp, const int32_t *__restrict__ tasks_all, co
                 if (!__ballot(run)) break;
                 const int w = xp.w << t;
                 const int wc = band_clamp(w, tg.len2, P, cls);
-                if (P8) lane_dp8<PF, PT>(run, tg.len2, tg.len1, wc, h0, tg.t, tg.ts, P, EH, QL8, lane, o, cells);
-                else lane_dp(run, tg.len2, tg.len1, wc, h0, tg.t, tg.ts, P, EH, QL, lane, o, cells);
+                if (P8) lane_dp8<PF, PT>(run, tg.len2, tg.len1, wc, h0, tg.t, tg.ts, P, EH, QL8, lane, o, cells, iters);
+                else lane_dp(run, tg.len2, tg.len1, wc, h0, tg.t, tg.ts, P, EH, QL, lane, o, cells, iters);
                 if (run) {
                     w_used = w;
                     if (o.score == prev || o.max_off < (w >> 1) + (w >> 2) || t + 1 == MAX_BAND_TRY) run = false;
@@ -433,6 +435,7 @@ k_ext_seeds(DevIndex ix, ExtParams xp, const int32_t *__restrict__ tasks_all, co
     }
     atomicAdd(&counters[0], (unsigned long long)cells);
     atomicAdd(&counters[1], n_done);
+    if (lane == 0) atomicAdd(&counters[2], (unsigned long long)iters);      // column-pair trips of this wavefront: 128 lane slots each (lane use = cells / that)
 }
 
 // one side on one wavefront, with the accept/retry rule of bwamem.cpp:2495-2496: stop when the score did not change, or
@@ -497,6 +500,7 @@ k_ext_wave(DevIndex ix, ExtParams xp, const int32_t *__restrict__ tasks_all, con
     if (lane == 0) {
         atomicAdd(&counters[0], (unsigned long long)cells);
         atomicAdd(&counters[1], n_done);
+        atomicAdd(&counters[3], (unsigned long long)cells);      // the wavefront kernel's share of the cells
     }
 }
 

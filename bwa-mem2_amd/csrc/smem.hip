@@ -922,13 +922,19 @@ int bm2_launch_seeding(bm2_ctx *c, const SeedParams &sp, int n_reads, const uint
                        void (*tick)(bm2_ctx *, const char *)) {
     hipStream_t s = c->stream, s3 = c->side_stream[0], sh = c->side_stream[1];
     const int grid_heavy = c->n_cu * 4;
-    // pass 3 is independent of passes 1 and 2: it runs beside them
-    (void)hipEventRecord(c->ev_fork, s);
-    (void)hipStreamWaitEvent(s3, c->ev_fork, 0);
-    hipLaunchKernelGGL(k_walk<W_P3>, dim3(grid_walk), dim3(256), 0, s3, c->ix, sp, n_reads, enc, off, len, (const P2Task *)nullptr, (int64_t)0,
-                       (BHead *)nullptr, (uint4 *)nullptr, (int64_t)0, (uint4 *)nullptr, 0, 0, sb.recs, sb.rec_cap, smem_cnt, sc,
-                       (int32_t *)nullptr, (int64_t)0);
-    (void)hipEventRecord(c->ev_join[0], s3);
+    // pass 3 is independent of passes 1 and 2: it runs beside them.  WHERE is launch policy (BM2_P3_AT): 0 = beside the forward walks of
+    // pass 1 (both are forward-only kernels without LDS lists: they compete for the same wave slots), 1 / 2 = beside the backward kernel of
+    // pass 1 / 2, whose blocks hold 48 KB of LDS survivors and leave wave slots empty that a kernel without LDS can use
+    const int p3_at = bm2_knob("BM2_P3_AT", 0);
+    auto launch_p3 = [&]() {
+        (void)hipEventRecord(c->ev_fork, s);
+        (void)hipStreamWaitEvent(s3, c->ev_fork, 0);
+        hipLaunchKernelGGL(k_walk<W_P3>, dim3(grid_walk), dim3(256), 0, s3, c->ix, sp, n_reads, enc, off, len, (const P2Task *)nullptr, (int64_t)0,
+                           (BHead *)nullptr, (uint4 *)nullptr, (int64_t)0, (uint4 *)nullptr, 0, 0, sb.recs, sb.rec_cap, smem_cnt, sc,
+                           (int32_t *)nullptr, (int64_t)0);
+        (void)hipEventRecord(c->ev_join[0], s3);
+    };
+    if (p3_at <= 0 || p3_at > 2) launch_p3();
     for (int pass = 1; pass <= 2; pass++) {
         BHead *heads = pass == 1 ? sb.heads1 : sb.heads2;
         uint4 *ents = pass == 1 ? sb.ents1 : sb.ents2;
@@ -941,6 +947,7 @@ int bm2_launch_seeding(bm2_ctx *c, const SeedParams &sp, int n_reads, const uint
             hipLaunchKernelGGL(k_walk<W_P2>, dim3(grid_walk), dim3(256), 0, s, c->ix, sp, n_reads, enc, off, len, sb.tasks, sb.task_cap,
                                heads, ents, slot_cap, sb.pool, sb.pool_cap, sb.pool_slots, sb.recs, sb.rec_cap, smem_cnt, sc, heavy, sb.heavy_cap);
         tick(c, pass == 1 ? "smem.walk1" : "smem.walk2");
+        if (p3_at == pass) launch_p3();
         // the long lists go to one wavefront each, beside the lane-per-task kernel
         (void)hipEventRecord(c->ev_join[2], s);
         (void)hipStreamWaitEvent(sh, c->ev_join[2], 0);
