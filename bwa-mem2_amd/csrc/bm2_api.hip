@@ -5,6 +5,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <new>
+#include <mutex>
+#include <vector>
 #include "bm2_ctx.h"
 
 static thread_local char g_err[512] = "";
@@ -91,6 +93,52 @@ extern "C" void *bm2_host_alloc(int64_t bytes) {
     return p;
 }
 extern "C" void bm2_host_free(void *p) { if (p) (void)hipHostFree(p); }
+// ---- page-locked blocks for the chunk-sized arrays the LIBRARY hands out (the parser's enc / off / len): locking 160 MB of pages costs tens of
+// milliseconds, so blocks go back to a pool when their chunk is freed and the next chunk's parse takes them again.  Small requests and hosts
+// without a device get plain malloc.  A block is reused for a request it fits without wasting more than half of it; free blocks beyond
+// BM2_PIN_POOL_MB (default 3072) are unlocked and released.
+namespace {
+struct PoolBlock { void *p; size_t cap; bool used, pinned; };
+std::mutex pool_mu;
+std::vector<PoolBlock> pool_blocks;
+}
+void *bm2_chunk_mem_get(size_t bytes) {
+    if (bytes < ((size_t)1 << 20)) return malloc(bytes ? bytes : 1);
+    {
+        std::lock_guard<std::mutex> l(pool_mu);
+        PoolBlock *best = nullptr;
+        for (PoolBlock &b : pool_blocks)
+            if (!b.used && b.cap >= bytes && b.cap <= 2 * bytes + ((size_t)8 << 20) && (!best || b.cap < best->cap)) best = &b;
+        if (best) { best->used = true; return best->p; }
+    }
+    const size_t cap = (bytes + bytes / 8 + ((size_t)4 << 20) - 1) & ~(((size_t)4 << 20) - 1);
+    void *p = nullptr; bool pinned = true;
+    if (hipHostMalloc(&p, cap, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); p = malloc(cap); pinned = false; }
+    if (!p) return nullptr;
+    std::lock_guard<std::mutex> l(pool_mu);
+    pool_blocks.push_back(PoolBlock{ p, cap, true, pinned });
+    return p;
+}
+void bm2_chunk_mem_put(void *p) {
+    if (!p) return;
+    std::vector<PoolBlock> drop;
+    {
+        std::lock_guard<std::mutex> l(pool_mu);
+        bool mine = false;
+        for (PoolBlock &b : pool_blocks) if (b.p == p) { b.used = false; mine = true; break; }
+        if (!mine) { free(p); return; }
+        const char *e = getenv("BM2_PIN_POOL_MB");
+        const size_t limit = (size_t)(e && *e ? atol(e) : 3072) << 20;
+        size_t idle = 0;
+        for (const PoolBlock &b : pool_blocks) if (!b.used) idle += b.cap;
+        for (size_t i = 0; i < pool_blocks.size() && idle > limit;) {
+            if (!pool_blocks[i].used) { idle -= pool_blocks[i].cap; drop.push_back(pool_blocks[i]); pool_blocks.erase(pool_blocks.begin() + (long)i); }
+            else ++i;
+        }
+    }
+    for (const PoolBlock &b : drop) { if (b.pinned) (void)hipHostFree(b.p); else free(b.p); }
+}
+
 static bool is_pinned(const void *host) {
     hipPointerAttribute_t a;
     if (hipPointerGetAttributes(&a, host) != hipSuccess) { (void)hipGetLastError(); return false; }   // (plain malloc'd memory: "invalid value")
@@ -139,12 +187,19 @@ int bm2_copy_d2h(bm2_ctx *c, void *dst_host, const void *src_dev, size_t bytes) 
 static int make_streams(bm2_ctx *c) {
     if (bm2_check(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "hipStreamCreate")) return BM2_ENODEV;
     for (int i = 0; i <= BM2_MAX_TIMERS; i++) (void)hipEventCreate(&c->ev[i]);
-    (void)hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+    if (hipHostMalloc((void **)&c->ext_stat, sizeof(uint32_t) * BM2_EXT_PHASES * BM2_EXT_STATW, hipHostMallocPortable) != hipSuccess) c->ext_stat = nullptr;
+    return BM2_OK;
+}
+// The side streams of the fork / join launches (seeding, chaining, extension) exist only in contexts that run those stages: a process has
+// GPU_MAX_HW_QUEUES hardware queues, its streams share them round-robin, and whatever is queued behind a long kernel on its queue waits for
+// it -- a context that only runs the SAM tail's batches (one stream) must not dilute the queues of the contexts that run the hot path.
+int bm2_side_streams(bm2_ctx *c) {
+    if (c->ev_fork) return BM2_OK;
+    if (bm2_check(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming), "hipEventCreate")) return BM2_ENODEV;
     for (int i = 0; i < 12; i++) {
-        (void)hipStreamCreateWithFlags(&c->side_stream[i], hipStreamNonBlocking);
+        if (bm2_check(hipStreamCreateWithFlags(&c->side_stream[i], hipStreamNonBlocking), "hipStreamCreate")) return BM2_ENODEV;
         (void)hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming);
     }
-    if (hipHostMalloc((void **)&c->ext_stat, sizeof(uint32_t) * BM2_EXT_PHASES * BM2_EXT_STATW, hipHostMallocPortable) != hipSuccess) c->ext_stat = nullptr;
     return BM2_OK;
 }
 static void free_streams(bm2_ctx *c) {
@@ -169,11 +224,22 @@ __global__ void __launch_bounds__(256) k_cp_occ_relayout(CpOcc *occ, int64_t n) 
     ((CpOccDev *)occ)[i] = d;
 }
 
+// The runtime reads GPU_MAX_HW_QUEUES when it STARTS (default: four hardware queues per process).  The earliest moment this library can speak
+// is when it is loaded: it asks for eight unless the host chose.  A host that has initialised HIP before loading libbm2 keeps what it had
+// -- nothing in the HIP API tells (include/bm2.h says so; bm2_create notes a smaller explicit setting on stderr).
+__attribute__((constructor)) static void bm2_ask_for_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+
 extern "C" bm2_ctx *bm2_create(int device, const bm2_index_desc *idx) {
     // The extension stage forks eight concurrent launches per side, each on a stream of its own; streams share the process's hardware
     // queues round-robin and the runtime's default is four.  Eight, unless the caller chose (read when the runtime starts: a process that
     // has already used HIP keeps what it had).
-    setenv("GPU_MAX_HW_QUEUES", "8", 0);
+    static std::once_flag queues_once;
+    std::call_once(queues_once, []() {
+        const char *have = getenv("GPU_MAX_HW_QUEUES");
+        if (have && *have && atoi(have) < 8)
+            fprintf(stderr, "[libbm2] note: GPU_MAX_HW_QUEUES=%s -- the extension stage forks eight concurrent launches; with fewer hardware queues they "
+                            "run partly one after the other (about 2 ms per million-read chunk)\n", have);
+    });
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
         bm2_set_error("no HIP device visible: libbm2 has no CPU fallback");

@@ -72,6 +72,7 @@ int bm2_ensure_subs(bm2_ctx *c, int n_sub);      // -> parts available (1 + sub-
 #include <stdlib.h>
 static inline int bm2_knob(const char *name, int dflt) { const char *v = getenv(name); return v && *v ? atoi(v) : dflt; }
 
+int  bm2_side_streams(bm2_ctx *c);                         // creates the fork / join streams of this context on first use
 int  bm2_check(hipError_t e, const char *what);            // -> BM2_OK or BM2_ENODEV (+ message)
 void bm2_set_error(const char *fmt, ...);
 int  bm2_reserve(DevBuf &b, size_t bytes);                  // grow-only device allocation

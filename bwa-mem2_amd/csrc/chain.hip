@@ -565,6 +565,7 @@ int bm2_launch_chain(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_
     if (n_reads <= 0) return BM2_OK;
     hipStream_t s = c->stream;
     const bool heavy = heavy_thr >= 0 && n_heavy_dev != nullptr;
+    if (heavy && bm2_side_streams(c)) return BM2_ENODEV;
     if (heavy) (void)hipEventRecord(c->ev_fork, s);
     hipLaunchKernelGGL(k_chain, dim3((n_reads + 127) / 128), dim3(128), 0, s, c->ix, o, n_reads, len, smems, smem_cnt,
                        smem_off, sa_off, sa_coord, wchain, wseed, nodes, order, chn, seeds_out, seed_owner,

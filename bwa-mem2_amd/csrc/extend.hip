@@ -920,6 +920,7 @@ int bm2_launch_extend(bm2_ctx *c, const bm2_opt &opt, const ChainParams &cp, int
     int rc;
     if ((rc = bm2_check(hipMemsetAsync(cursor, 0, (size_t)(n_reads + 1) * 4, s), "memset cursor"))) return rc;
     if (n_slots <= 0) return BM2_OK;
+    if ((rc = bm2_side_streams(c))) return rc;
     ExtLaunch L;
     L.c = c; L.s = s; L.enc = enc; L.off = off; L.len = len; L.slot_base = slot_base; L.reg_seed = reg_seed; L.reg_chain = reg_chain;
     L.chn = chn; L.seeds = seeds; L.regs = regs; L.counters = counters;

@@ -14,6 +14,9 @@
 #include "../../include/bm2.h"
 
 void bm2_set_error(const char *fmt, ...);
+// bm2_api.hip: chunk-sized arrays come page-locked from a pool (plain DMA to the device, no staging copy); small ones are malloc'd
+void *bm2_chunk_mem_get(size_t bytes);
+void bm2_chunk_mem_put(void *p);
 
 namespace {
 struct Cur {
@@ -42,7 +45,7 @@ extern "C" void bm2_fastq_free(bm2_fastq *f) {
         if (f->comment) free(f->comment[i]);
         if (f->qual) free(f->qual[i]);
     }
-    free(f->name); free(f->comment); free(f->qual); free(f->enc); free(f->off); free(f->len);
+    free(f->name); free(f->comment); free(f->qual); bm2_chunk_mem_put(f->enc); bm2_chunk_mem_put(f->off); bm2_chunk_mem_put(f->len);
     memset(f, 0, sizeof *f);
 }
 
@@ -98,7 +101,7 @@ extern "C" int bm2_fastq_parse(const char *text, int64_t n_bytes, bm2_fastq *out
     }
     const size_t n = names.size();
     out->n_reads = (int32_t)n; out->n_bases = (int64_t)enc.size();
-    out->enc = (uint8_t *)malloc(enc.size() + 64); out->off = (int64_t *)malloc((n + 1) * 8); out->len = (int32_t *)malloc((n + 1) * 4);
+    out->enc = (uint8_t *)bm2_chunk_mem_get(enc.size() + 64); out->off = (int64_t *)bm2_chunk_mem_get((n + 1) * 8); out->len = (int32_t *)bm2_chunk_mem_get((n + 1) * 4);
     out->name = (char **)calloc(n + 1, sizeof(char *)); out->comment = (char **)calloc(n + 1, sizeof(char *)); out->qual = (char **)calloc(n + 1, sizeof(char *));
     if (!out->enc || !out->off || !out->len || !out->name || !out->comment || !out->qual) { bm2_fastq_free(out); return BM2_ENOMEM; }
     if (!enc.empty()) memcpy(out->enc, enc.data(), enc.size());
@@ -222,7 +225,7 @@ extern "C" int bm2_fastq_parse_mt(const char *text1, int64_t n1, const char *tex
     };
     memset(out, 0, sizeof *out);
     out->n_reads = (int32_t)n;
-    out->off = (int64_t *)malloc((size_t)(n + 1) * 8); out->len = (int32_t *)malloc((size_t)(n + 1) * 4);
+    out->off = (int64_t *)bm2_chunk_mem_get((size_t)(n + 1) * 8); out->len = (int32_t *)bm2_chunk_mem_get((size_t)(n + 1) * 4);
     out->name = (char **)calloc((size_t)n + 1, sizeof(char *)); out->comment = (char **)calloc((size_t)n + 1, sizeof(char *));
     out->qual = (char **)calloc((size_t)n + 1, sizeof(char *));
     std::vector<int64_t> soff((size_t)n + 1);                   // offsets of record i's strings in the arena
@@ -235,7 +238,7 @@ extern "C" int bm2_fastq_parse_mt(const char *text1, int64_t n1, const char *tex
             soff[(size_t)i] = sb; sb += s.name_len + 1 + (s.comment_len ? s.comment_len + 1 : 0) + s.len + 1;
         }
         soff[(size_t)n] = sb; out->n_bases = nb;
-        out->enc = (uint8_t *)malloc((size_t)nb + 64); out->arena = (char *)malloc((size_t)sb + 1);
+        out->enc = (uint8_t *)bm2_chunk_mem_get((size_t)nb + 64); out->arena = (char *)malloc((size_t)sb + 1);
         if (!out->enc || !out->arena) { bm2_fastq_free(out); return BM2_ENOMEM; }
     }
     static uint8_t nt4[256]; static bool nt4_ready = false;
@@ -274,7 +277,7 @@ int seq_fallback(const char *t1, int64_t n1, const char *t2, int64_t n2, bm2_fas
     int64_t nb = 0;
     for (int64_t i = 0; i < np; ++i) nb += a.len[i] + b.len[i];
     out->n_bases = nb;
-    out->enc = (uint8_t *)malloc((size_t)nb + 64); out->off = (int64_t *)malloc((size_t)(n + 1) * 8); out->len = (int32_t *)malloc((size_t)(n + 1) * 4);
+    out->enc = (uint8_t *)bm2_chunk_mem_get((size_t)nb + 64); out->off = (int64_t *)bm2_chunk_mem_get((size_t)(n + 1) * 8); out->len = (int32_t *)bm2_chunk_mem_get((size_t)(n + 1) * 4);
     out->name = (char **)calloc((size_t)n + 1, sizeof(char *)); out->comment = (char **)calloc((size_t)n + 1, sizeof(char *));
     out->qual = (char **)calloc((size_t)n + 1, sizeof(char *));
     if (!out->enc || !out->off || !out->len || !out->name || !out->comment || !out->qual) { bm2_fastq_free(&a); bm2_fastq_free(&b); bm2_fastq_free(out); return BM2_ENOMEM; }

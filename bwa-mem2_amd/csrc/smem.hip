@@ -920,6 +920,7 @@ k_smem_gather(int n_reads, const bm2_smem_t *__restrict__ in, const int64_t *__r
 int bm2_launch_seeding(bm2_ctx *c, const SeedParams &sp, int n_reads, const uint8_t *enc, const int64_t *off, const int32_t *len,
                        const SeedBufs &sb, int grid_walk, int grid_bwd, int32_t *smem_cnt, unsigned long long *sc,
                        void (*tick)(bm2_ctx *, const char *)) {
+    if (bm2_side_streams(c)) return BM2_ENODEV;
     hipStream_t s = c->stream, s3 = c->side_stream[0], sh = c->side_stream[1];
     const int grid_heavy = c->n_cu * 4;
     // pass 3 is independent of passes 1 and 2: it runs beside them.  WHERE is launch policy (BM2_P3_AT): 0 = beside the forward walks of
