@@ -36,6 +36,7 @@ import time
 import numpy as np
 
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # the extension stage forks ~10 concurrent launches per side
+os.environ.setdefault("BM2_MALLOC_TUNE", "1")        # this process is the library's host: it opts in to the allocator settings of sam_tail.cpp
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -121,12 +122,19 @@ def pe_chunk(workdir, contigs_fn, seed, n_reads, read_len, tag=""):
     return seqs
 
 
+THREADS_SOURCE = [None]
+
+
 def host_threads():
-    """threads for the compiled reference: the CPUs this process can really use (cgroup quota), not the hardware threads it can see"""
+    """threads for the compiled reference: the CPUs this process can really use (cgroup quota), not the hardware threads it can see.  Which of
+    the two counts was taken is recorded (THREADS_SOURCE -> cpu_baseline.threads_source): rounds 1-2 ran the baseline on min(cpu_count, 128)
+    threads, so their baselines are not comparable with the quota-sized ones since round 3."""
     try:
         import bm2
+        THREADS_SOURCE[0] = "cgroup CPU quota (bm2_host_cpus)"
         return max(1, min(bm2.host_cpus(), 128))
     except Exception:                                             # noqa
+        THREADS_SOURCE[0] = "os.cpu_count() -- libbm2 could not be loaded: NOT the quota-sized count of the other runs"
         return min(os.cpu_count() or 1, 128)
 
 
@@ -159,7 +167,7 @@ def cpu_baseline(prefix, fq, n_reads_desc, extra=(), out="/dev/null"):
     kern_s = float(kern.group(1)) if kern else None
     if n_proc == 0 or real <= 0:
         return None
-    out = {"value": n_proc / real, "unit": "reads/s", "cores": threads, "threads_present": os.cpu_count(), "kind": "reference",
+    out = {"value": n_proc / real, "unit": "reads/s", "cores": threads, "threads_present": os.cpu_count(), "threads_source": THREADS_SOURCE[0], "kind": "reference",
            "sample": "%s, same index; bwa-mem2 v2.2.1 %s build, `mem -t %d %s` (%d = the CPUs this process may use: cgroup quota; the host shows %d hardware threads); whole `mem` chunk time "
                      "(seed+chain+extend+pairing+SAM) from its own 'Processed N reads' lines; wall %.1fs"
                      % (n_reads_desc, isa, threads, " ".join(extra), threads, os.cpu_count() or 0, wall)}

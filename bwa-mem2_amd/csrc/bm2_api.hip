@@ -202,6 +202,14 @@ int bm2_side_streams(bm2_ctx *c) {
     }
     return BM2_OK;
 }
+// The dynamic-LDS limit of a kernel is a property of the loaded code object on ONE device: raised once per context (contexts of several
+// devices live in one process since the binding drives every visible GPU), and a refusal is an error, not a silent 64 KB launch.
+int bm2_raise_lds_limit(bm2_ctx *c, int which, const void *kernel, size_t bytes) {
+    if (c->lds_attr_done & (1u << which)) return BM2_OK;
+    int rc = bm2_check(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes), "hipFuncSetAttribute(max dynamic LDS)");
+    if (!rc) c->lds_attr_done |= 1u << which;
+    return rc;
+}
 static void free_streams(bm2_ctx *c) {
     for (int i = 0; i < 2; i++) { if (c->pin[i]) (void)hipHostFree(c->pin[i]); if (c->pin_ev[i]) (void)hipEventDestroy(c->pin_ev[i]); c->pin[i] = nullptr; c->pin_ev[i] = nullptr; }
     for (int i = 0; i <= BM2_MAX_TIMERS; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);

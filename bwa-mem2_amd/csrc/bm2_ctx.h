@@ -53,6 +53,8 @@ struct bm2_ctx {
 #define BM2_EXT_PHASES 8
 #define BM2_EXT_STATW 16
     uint32_t *ext_stat = nullptr;
+    // kernels whose dynamic LDS limit has been raised for this context's device (hipFuncSetAttribute: once per context, result checked)
+    unsigned lds_attr_done = 0;
     int ext_stat_reads = 0, ext_stat_rounds = 0;
     // sub-batch pipelining (pipeline.hip): extra contexts sharing this one's index replica
     std::vector<bm2_ctx *> subs;
@@ -72,6 +74,7 @@ int bm2_ensure_subs(bm2_ctx *c, int n_sub);      // -> parts available (1 + sub-
 #include <stdlib.h>
 static inline int bm2_knob(const char *name, int dflt) { const char *v = getenv(name); return v && *v ? atoi(v) : dflt; }
 
+int  bm2_raise_lds_limit(bm2_ctx *c, int which, const void *kernel, size_t bytes);      // which: a bit number of bm2_ctx::lds_attr_done
 int  bm2_side_streams(bm2_ctx *c);                         // creates the fork / join streams of this context on first use
 int  bm2_check(hipError_t e, const char *what);            // -> BM2_OK or BM2_ENODEV (+ message)
 void bm2_set_error(const char *fmt, ...);

@@ -298,7 +298,130 @@ static __device__ int bsw_extend_reg(const uint8_t *__restrict__ qp, int qs, int
     return cells;
 }
 
-// dispatch: registers when the query fits 4 chunks, the LDS ring otherwise
+// ---------------------------------------------------------------------------------------------------------------
+// Register-resident variant for LONG queries (10 kb reads): a window of NCH 64-column chunks that SLIDES along the band.
+// The live columns of row i lie in [i - w, i + w + 1] (the band clamp, and every column stored by an earlier row was inside that
+// row's band), and `beg` never decreases, so chunk c0 = beg >> 6 and the NCH - 1 = ((2w + 1) >> 6) + 1 chunks after it hold every
+// column that can still be read; lane l of slot k owns column 64 (c0 + k) + l.  When c0 moves on the slots shift down by one
+// (3 x NCH v_mov, once per ~64 rows) and the chunk that enters is initialised with the first-row values -- it was never stored:
+// a chunk outside the previous window cannot have been.  Its query bases were requested one shift earlier.  No LDS, no
+// per-row global loads: the ring variant below pays a dependent global load for the query and four LDS round trips per chunk.
+template <int NCH>
+static __device__ int bsw_extend_slide(const uint8_t *__restrict__ qp, int qs, int qlen_,
+                                       const uint8_t *__restrict__ tp, int ts, int tlen_,
+                                       int w_, int h0_, const SwParams &P, SwOut &out) {
+    const int lane = threadIdx.x & 63;
+    const int qlen = uni(qlen_), tlen = uni(tlen_), w = uni(w_), h0 = uni(h0_);
+    const int o_del = uni(P.o_del), e_del = uni(P.e_del), e_ins = uni(P.e_ins), zdrop = uni(P.zdrop);
+    const int oe_del = o_del + e_del, oe_ins = uni(P.o_ins) + e_ins;
+    const int sc_match = uni(P.mat[0]), sc_mis = uni(P.mat[1]), sc_amb = uni(P.mat[4]);
+    const int e1 = h0 > oe_ins ? h0 - oe_ins : 0;
+    const int cls = pair_class(tlen, qlen, h0, uni(P.max_sc));
+    const int le = lane * e_ins, le1 = le - e_ins;
+    int H[NCH], E[NCH], Q[NCH], X[NCH];
+    auto fresh_h = [&](int j) { return j == 0 ? h0 : (j <= qlen ? imax(e1 - (j - 1) * e_ins, 0) : 0); };      // first row, bandedSWA.cpp:143-145
+    auto load_q = [&](int c) { const int j = c * 64 + lane; return j < qlen ? (int)qp[(int64_t)j * qs] : 4; };
+    int c0 = 0;                                                     // chunk of slot 0
+#pragma unroll
+    for (int k = 0; k < NCH; k++) {
+        const int qv = load_q(k);
+        Q[k] = qv > 3 ? 5 : qv; X[k] = qv > 3 ? sc_amb : sc_mis;    // 5 never equals a target code
+        H[k] = fresh_h(k * 64 + lane); E[k] = 0;
+    }
+    int qnext = load_q(NCH);                                        // bases of the chunk that enters next
+    int beg = 0, end = qlen, maxv = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0;
+    int cells = 0;
+    int tchunk = 4;
+    for (int i = 0; i < tlen; ++i) {
+        if ((i & 63) == 0) { const int ti = i + lane; tchunk = ti < tlen ? (int)tp[(int64_t)ti * ts] : 4; }
+        const int tb = __builtin_amdgcn_readlane(tchunk, i & 63);
+        const bool t_amb = tb > 3;
+        const int s_eq = t_amb ? sc_amb : sc_match;
+        beg = beg < i - w ? i - w : beg;
+        end = end > i + w + 1 ? i + w + 1 : end;
+        end = end > qlen ? qlen : end;
+        while ((beg >> 6) > c0) {                                   // slide: slot k <- slot k + 1, a fresh chunk enters at the top
+#pragma unroll
+            for (int k = 0; k + 1 < NCH; k++) { H[k] = H[k + 1]; E[k] = E[k + 1]; Q[k] = Q[k + 1]; X[k] = X[k + 1]; }
+            ++c0;
+            Q[NCH - 1] = qnext > 3 ? 5 : qnext; X[NCH - 1] = qnext > 3 ? sc_amb : sc_mis;
+            H[NCH - 1] = fresh_h((c0 + NCH - 1) * 64 + lane); E[NCH - 1] = 0;
+            qnext = load_q(c0 + NCH);
+        }
+        int h1 = 0;
+        if (beg == 0) { h1 = h0 - (o_del + e_del * (i + 1)); h1 = h1 < 0 ? 0 : h1; }
+        int fc = 0, m = 0, mj = -1, firstnz = -1, lastnz = -1;
+        cells += end > beg ? end - beg : 0;
+        const int cb = beg >> 6, ce = end >> 6;
+        int hcarry = h1;
+        if (beg <= end) {
+#pragma unroll
+            for (int k = 0; k < NCH; k++) {
+                const int c = c0 + k;
+                if (c >= cb && c <= ce) {                                           // wave-uniform
+                    const int jb = c * 64;
+                    const int lo = beg > jb ? beg - jb : 0;
+                    const int hi = end - jb < 64 ? end - jb : 64;                   // active lanes [lo, hi)
+                    const int hi2 = end - jb + 1 < 64 ? end - jb + 1 : 64;          // stored lanes  [lo, hi2)
+                    const unsigned long long mlo = (1ULL << lo) - 1ULL;
+                    const unsigned long long mhi = hi >= 64 ? ~0ULL : ((1ULL << hi) - 1ULL);
+                    const unsigned long long mhi2 = hi2 >= 64 ? ~0ULL : ((1ULL << hi2) - 1ULL);
+                    const unsigned long long actm = mhi & ~mlo, stm = mhi2 & ~mlo;
+                    const bool act = __builtin_amdgcn_inverse_ballot_w64(actm);
+                    const bool st = __builtin_amdgcn_inverse_ballot_w64(stm);
+                    const int Hd = H[k], Ec = E[k];
+                    int sc = Q[k] == tb ? s_eq : X[k];
+                    if (t_amb) sc = sc_amb;
+                    const int M = (act && Hd != 0) ? Hd + sc : 0;
+                    const int Pm = wave_scan_max(imax(M - oe_ins, 0) + le, 0);
+                    const int Pprev = wave_shr1(Pm, NEG_BIG);
+                    const int F = imax(fc - le, Pprev - le1);
+                    const int h = act ? imax(imax(M, Ec), F) : 0;
+                    const int hs = wave_shr1(h, hcarry);
+                    const int en = act ? imax(imax(Ec - e_del, M - oe_del), 0) : 0;
+                    H[k] = st ? hs : Hd;
+                    E[k] = st ? en : Ec;
+                    if (actm) {
+                        // row maximum and the LAST column holding it (bandedSWA.cpp:188-189): max over (h << 6 | lane) + 1
+                        const int key = act ? (((h << 6) | lane) + 1) : 0;
+                        const int kmax = __builtin_amdgcn_readlane(wave_scan_max(key, 0), 63) - 1;
+                        const int cm = kmax >> 6;
+                        if (cm >= m) { m = cm; mj = jb + (kmax & 63); }
+                        h1 = __builtin_amdgcn_readlane(h, hi - 1);
+                    }
+                    hcarry = __builtin_amdgcn_readlane(h, 63);
+                    fc = imax(fc - 64 * e_ins, __builtin_amdgcn_readlane(Pm, 63) - 63 * e_ins);
+                    const unsigned long long nz = __ballot((hs | en) != 0);
+                    const unsigned long long nzb = nz & actm, nze = nz & stm;
+                    if (firstnz < 0 && nzb) firstnz = jb + __builtin_ctzll(nzb);
+                    if (nze) lastnz = jb + 63 - __builtin_clzll(nze);
+                }
+            }
+        }
+        const int jfin = beg < end ? end : beg;
+        if (jfin == qlen) {
+            max_ie = gscore > h1 ? max_ie : i;
+            gscore = gscore > h1 ? gscore : h1;
+        }
+        if (m == 0) break;
+        const bool new_max = m > maxv;
+        if (new_max) {
+            maxv = m; max_i = i; max_j = mj;
+            const int d = mj - i;
+            max_off = imax(max_off, d < 0 ? -d : d);
+        }
+        if (zdrop_stop(cls, new_max, maxv, m, i - max_i, mj - max_j, e_del, e_ins, zdrop)) break;
+        const int nb = firstnz >= 0 ? firstnz : end;
+        const int jl = imax(lastnz, nb - 1);
+        beg = nb;
+        end = jl + 2 < qlen ? jl + 2 : qlen;
+    }
+    out.score = maxv; out.qle = max_j + 1; out.tle = max_i + 1; out.gtle = max_ie + 1;
+    out.gscore = gscore; out.max_off = max_off;
+    return cells;
+}
+
+// dispatch: registers when the query fits 4 chunks, a sliding register window when the band fits 8, the LDS ring otherwise
 static __device__ __forceinline__ int bsw_extend(const uint8_t *__restrict__ qp, int qs, int qlen,
                                                  const uint8_t *__restrict__ tp, int ts, int tlen,
                                                  int w, int h0, const SwParams &P, int *RH, int *RE, int RM, SwOut &out) {
@@ -307,5 +430,8 @@ static __device__ __forceinline__ int bsw_extend(const uint8_t *__restrict__ qp,
     if (nch == 2) return bsw_extend_reg<2>(qp, qs, qlen, tp, ts, tlen, w, h0, P, out);
     if (nch == 3) return bsw_extend_reg<3>(qp, qs, qlen, tp, ts, tlen, w, h0, P, out);
     if (nch == 4) return bsw_extend_reg<4>(qp, qs, qlen, tp, ts, tlen, w, h0, P, out);
+    const int nsl = ((2 * w + 1) >> 6) + 2;                          // chunks a sliding register window needs for this band
+    if (nsl <= 5) return bsw_extend_slide<5>(qp, qs, qlen, tp, ts, tlen, w, h0, P, out);
+    if (nsl <= 8) return bsw_extend_slide<8>(qp, qs, qlen, tp, ts, tlen, w, h0, P, out);
     return bsw_extend_wave(qp, qs, qlen, tp, ts, tlen, w, h0, P, RH, RE, RM, out);
 }

@@ -574,8 +574,7 @@ int bm2_launch_chain(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_
         // tiers by seed count (LDS per block follows the tier): the launches run beside the lane-per-read kernel and each other
         const int stage = bm2_knob("BM2_CHAIN_STAGE", 1);     // (sweep of round 3, profiles/r03a_sweep.json: chaining 12.4 -> 10.3 ms)
         const int caps[BM2_CHAIN_TIERS] = { 64, 128, 256, 512, stage ? 1000 : 1184 };       // (the last tier fills a CU's 160 KB of LDS)
-        static bool attr_set = false;
-        if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_chain_heavy, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+        { const int rc_a = bm2_raise_lds_limit(c, 0, (const void *)k_chain_heavy, 160 * 1024); if (rc_a) return rc_a; }
         // reads with more seeds than the largest tier holds: a launch of their own where they are the norm (long reads), otherwise the last tier's
         const bool own_overflow = max_len >= bm2_knob("BM2_CHAIN_OVF_MIN_LEN", 1000);
         int lo = heavy_thr;

@@ -415,7 +415,7 @@ static int cigar_run(bm2_ctx *c, const bm2_opt *opt, std::vector<CigarTask> &tas
     if (!rc) rc = bm2_copy_h2d(c, d_order, order.data(), (size_t)n * sizeof(int));
     if (rc) return rc;
     const size_t lds_q = (size_t)((qmax + 7) / 8) * 256, lds_row = (size_t)(qmax + 1) * 256 + lds_q, lds_ring = (size_t)CG_RING * 256 + lds_q;
-    if (lds_row > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_gen_cigar<CG_ROW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_row);
+    if (lds_row > 64 * 1024 && (rc = bm2_check(hipFuncSetAttribute((const void *)k_gen_cigar<CG_ROW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_row), "hipFuncSetAttribute(k_gen_cigar)"))) return rc;
     const int *o_ring = d_order, *o_row = o_ring + n_shape[SH_RING], *o_glob = o_row + n_shape[SH_ROW], *o_flat = o_glob + n_shape[SH_GLOBAL];
     if ((rc = bm2_check(hipMemsetAsync(d_defer, 0, 4, s), "memset"))) return rc;
     // (the costliest tasks lead every list; the four launches follow each other on the stream, the cheap flat tasks last)

@@ -340,10 +340,130 @@ static __device__ void lane_dp8(bool run, int qlen, int tlen, int w, int h0, con
     if (run) { out.score = maxv; out.qle = max_j + 1; out.tle = max_i + 1; out.gtle = max_ie + 1; out.gscore = gscore; out.max_off = max_off; }
 }
 
+// The same rows again, the column loop in GROUPS OF FOUR columns -- one query word (four bases, one v_perm_b32 for their four scores) and two
+// row words per trip -- with the next group's three LDS words requested into a SECOND set of registers before the current group is computed
+// (two copies of the group body that hand the sets to each other: no register copy, and so no wait, between a request and its use one trip
+// later).  What that removes (profiles/r04c_pmc_sq1_lanes_only.md: a wavefront of the pair loop above issued VALU in 14 % of its cycles and
+// waited in 72 %): the compiler ended every trip of the pair loop with `s_waitcnt lgkmcnt(0)` + `v_mov` for the carried row word -- a wait for
+// the store it had just issued -- and every second trip with the same for the query word requested one instruction earlier.
+// LDS: rows [2 NG + 2][64] words, query [NG + 1][64] words, NG = (qmax + 3) / 4 (one group of slack for the request beyond the last group).
+struct Dp8Row { int h1, f, lnz; unsigned key, fnz_u; };
+static __device__ __forceinline__ void dp8_group(int g, uint32_t w0, uint32_t w1, uint32_t q, bool alive, int beg, int end, uint32_t t_lo, uint32_t t_hi,
+                                                 int e_del, int e_ins, int oe_del, int oe_ins, uint32_t *EH, int lane, Dp8Row &r) {
+    const int j0 = g << 2;
+    if (alive && j0 + 3 >= beg && j0 < end) {
+        const uint32_t sc4 = __builtin_amdgcn_perm(t_hi, t_lo, q);
+        uint32_t word[2] = { w0, w1 };
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int j = j0 + u;
+            if (j >= beg && j < end) {
+                uint32_t &wd = word[u >> 1];
+                const int sh = 16 * (u & 1);
+                const int e = (int)((wd >> (sh + 8)) & 0xffu);
+                int M = (int)((wd >> sh) & 0xffu);
+                const int sc = (int)(int8_t)(sc4 >> (8 * u));
+                M = M ? M + sc : 0;
+                int h = M > e ? M : e;
+                h = h > r.f ? h : r.f;
+                const unsigned kj = (unsigned)h << 8 | (unsigned)j;
+                r.key = r.key > kj ? r.key : kj;
+                const int en = imax(isub0(e, e_del), M - oe_del);
+                r.f = imax(isub0(r.f, e_ins), M - oe_ins);
+                const uint32_t nw = (uint32_t)r.h1 | ((uint32_t)en << 8);
+                wd = (wd & ~(0xffffu << sh)) | nw << sh;
+                const int jj = nw ? j : -1;
+                r.lnz = r.lnz > jj ? r.lnz : jj;
+                r.fnz_u = r.fnz_u < (unsigned)jj ? r.fnz_u : (unsigned)jj;
+                r.h1 = h;
+            }
+        }
+        EH[(2 * g) * 64 + lane] = word[0];                         // (a word none of whose columns lay in the band goes back unchanged)
+        EH[(2 * g + 1) * 64 + lane] = word[1];
+    }
+}
+
+static __device__ void lane_dp8g(bool run, int qlen, int tlen, int w, int h0, const uint8_t *tp, int ts, const SwParams &P,
+                                 uint32_t *EH, const uint32_t *QL, int lane, LaneOut &out, long long &cells, long long &iters) {
+    const int o_del = P.o_del, e_del = P.e_del, o_ins = P.o_ins, e_ins = P.e_ins, oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
+    const int sc_match = P.mat[0], sc_mis = P.mat[1], sc_amb = P.mat[4];
+    const uint32_t rep_mis = rep4(sc_mis), rep_amb = rep4(sc_amb);
+    const int e1 = h0 > oe_ins ? h0 - oe_ins : 0;                // first row, bandedSWA.cpp:143-145
+    const int cls = pair_class(tlen, qlen, h0, P.max_sc);
+    const int maxq = __builtin_amdgcn_readlane(wave_scan_max(run ? qlen : 0, 0), 63);
+    for (int jp = 0; jp <= maxq; jp += 2) {
+        if (run && jp <= qlen) {
+            const uint32_t v0 = (uint32_t)(jp == 0 ? h0 : imax(e1 - (jp - 1) * e_ins, 0));
+            const uint32_t v1 = jp + 1 <= qlen ? (uint32_t)imax(e1 - jp * e_ins, 0) : 0u;
+            EH[(jp >> 1) * 64 + lane] = v0 | v1 << 16;
+        }
+    }
+    int beg = 0, end = qlen, maxv = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0;
+    bool alive = run && tlen > 0;
+    const int maxt = __builtin_amdgcn_readlane(wave_scan_max(alive ? tlen : 0, 0), 63);
+    int t_next = alive ? (int)tp[0] : 4;
+    for (int i = 0; i < maxt; ++i) {
+        if (!__ballot(alive)) break;
+        const int tb = t_next;
+        if (alive && i + 1 < tlen) t_next = (int)tp[(int64_t)(i + 1) * ts];
+        Dp8Row r; r.h1 = 0; r.f = 0; r.lnz = -1; r.key = 0; r.fnz_u = 0xffffffffu;
+        if (alive) {
+            if (beg < i - w) beg = i - w;
+            if (end > i + w + 1) end = i + w + 1;
+            if (end > qlen) end = qlen;
+            if (beg == 0) { r.h1 = h0 - (o_del + e_del * (i + 1)); if (r.h1 < 0) r.h1 = 0; }
+            cells += imax(end - beg, 0);
+        }
+        const int jlo = (1 << 20) - __builtin_amdgcn_readlane(wave_scan_max(alive ? (1 << 20) - beg : 0, 0), 63);
+        const int jhi = __builtin_amdgcn_readlane(wave_scan_max(alive ? end : 0, 0), 63);
+        const int g0 = jlo >> 2, g1 = (jhi + 3) >> 2;                // groups [g0, g1)
+        iters += g1 > g0 ? 2 * (g1 - g0) : 0;                        // (wave-uniform; in column pairs, like the pair loop's count)
+        // scores of this row against the query codes 0..4: bytes 0..3 of t_lo (the target's own base: match; target N: ambiguous), byte 0 of t_hi
+        const uint32_t t_lo = tb > 3 ? rep_amb : rep_mis ^ ((uint32_t)((sc_mis ^ sc_match) & 0xff) << (8 * tb)), t_hi = rep_amb;
+        if (g0 < g1) {
+            uint32_t a0 = EH[(2 * g0) * 64 + lane], a1 = EH[(2 * g0 + 1) * 64 + lane], aq = QL[g0 * 64 + lane], b0, b1, bq;
+            for (int g = g0;; g += 2) {
+                b0 = EH[(2 * g + 2) * 64 + lane]; b1 = EH[(2 * g + 3) * 64 + lane]; bq = QL[(g + 1) * 64 + lane];
+                dp8_group(g, a0, a1, aq, alive, beg, end, t_lo, t_hi, e_del, e_ins, oe_del, oe_ins, EH, lane, r);
+                if (g + 1 >= g1) break;
+                a0 = EH[(2 * g + 4) * 64 + lane]; a1 = EH[(2 * g + 5) * 64 + lane]; aq = QL[(g + 2) * 64 + lane];
+                dp8_group(g + 1, b0, b1, bq, alive, beg, end, t_lo, t_hi, e_del, e_ins, oe_del, oe_ins, EH, lane, r);
+                if (g + 2 >= g1) break;
+            }
+        }
+        const int m = (int)(r.key >> 8), mj = (int)(r.key & 255u), fnz = (int)r.fnz_u, h1 = r.h1;
+        int lnz = r.lnz;
+        if (alive) {
+            uint32_t word = EH[(end >> 1) * 64 + lane];                // eh[end] = {h1, 0}, bandedSWA.cpp:201
+            word = (word & ~(0xffffu << (16 * (end & 1)))) | (uint32_t)h1 << (16 * (end & 1));
+            EH[(end >> 1) * 64 + lane] = word;
+            if (h1) lnz = end;
+            const int jfin = beg < end ? end : beg;
+            if (jfin == qlen) { max_ie = gscore > h1 ? max_ie : i; gscore = gscore > h1 ? gscore : h1; }
+            if (m == 0) alive = false;
+            else {
+                const bool new_max = m > maxv;
+                if (new_max) {
+                    maxv = m; max_i = i; max_j = mj;
+                    const int d = mj - i;
+                    max_off = imax(max_off, d < 0 ? -d : d);
+                }
+                if (zdrop_stop(cls, new_max, maxv, m, i - max_i, mj - max_j, e_del, e_ins, P.zdrop)) alive = false;
+                const int nb = fnz >= 0 ? fnz : end;
+                const int jl = imax(lnz, nb - 1);
+                beg = nb;
+                end = jl + 2 < qlen ? jl + 2 : qlen;
+                if (i + 1 >= tlen) alive = false;
+            }
+        }
+    }
+    if (run) { out.score = maxv; out.qle = max_j + 1; out.tle = max_i + 1; out.gtle = max_ie + 1; out.gscore = gscore; out.max_off = max_off; }
+}
+
 // One seed per lane: left side, then right side (h0 = the score after the left side, bwamem.cpp:2672-2677), each with the two-try
 // band rule.  A wavefront takes tiles of 64 consecutive seeds of its class's sorted list (grid-stride: the host sizes the grid from the
 // previous batch's counts, the kernel reads the real range from the device).
-template <bool P8, bool PF, bool PT = false>      // PT: scores by byte permute (lane_dp8)
+template <bool P8, bool PF, bool PT = false, bool G4 = false>      // PT: scores by byte permute (lane_dp8); G4: columns in groups of four (lane_dp8g)
 __global__ void __launch_bounds__(64)
 k_ext_seeds(DevIndex ix, ExtParams xp, const int32_t *__restrict__ tasks_all, const int64_t *__restrict__ start, int bin_lo, int bin_hi, int qmax,
             const uint8_t *__restrict__ enc, const int64_t *__restrict__ off, const int32_t *__restrict__ len,
@@ -352,7 +472,7 @@ k_ext_seeds(DevIndex ix, ExtParams xp, const int32_t *__restrict__ tasks_all, co
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_l[];
     uint32_t *EH = lds_l;                                       // [(qmax+1)][64]           (P8: [(qmax+2)/2][64])
     uint8_t *QL = (uint8_t *)(lds_l + (size_t)(qmax + 1) * 64); // [qmax][64] bytes
-    uint32_t *QL8 = lds_l + (size_t)((qmax + 2) / 2) * 64;      // P8: [(qmax+7)/8][64] dwords, 8 bases of 4 bits each (PT: [(qmax+3)/4 + 1][64], one per byte)
+    uint32_t *QL8 = lds_l + (G4 ? (size_t)(2 * ((qmax + 3) / 4) + 2) : (size_t)((qmax + 2) / 2)) * 64;      // P8: [(qmax+7)/8][64] dwords, 8 bases of 4 bits each (PT: [(qmax+3)/4 + 1][64], one per byte)
     const int lane = threadIdx.x;
     const int64_t first = start[bin_lo];
     const int n_tasks = (int)(start[bin_hi] - first);
@@ -417,7 +537,8 @@ k_ext_seeds(DevIndex ix, ExtParams xp, const int32_t *__restrict__ tasks_all, co
                 if (!__ballot(run)) break;
                 const int w = xp.w << t;
                 const int wc = band_clamp(w, tg.len2, P, cls);
-                if (P8) lane_dp8<PF, PT>(run, tg.len2, tg.len1, wc, h0, tg.t, tg.ts, P, EH, QL8, lane, o, cells, iters);
+                if (G4) lane_dp8g(run, tg.len2, tg.len1, wc, h0, tg.t, tg.ts, P, EH, QL8, lane, o, cells, iters);
+                else if (P8) lane_dp8<PF, PT>(run, tg.len2, tg.len1, wc, h0, tg.t, tg.ts, P, EH, QL8, lane, o, cells, iters);
                 else lane_dp(run, tg.len2, tg.len1, wc, h0, tg.t, tg.ts, P, EH, QL, lane, o, cells, iters);
                 if (run) {
                     w_used = w;
@@ -847,7 +968,7 @@ struct ExtLaunch {
     // launch policy (bm2_knob): which kernel takes a query-length class.  A lane-per-seed wavefront of long queries walks tens of thousands
     // of cells one after the other (milliseconds) and a phase lasts as long as its slowest wavefront, so the classes from wave_qmin up can go
     // one seed per WAVEFRONT (k_ext_wave) beside the lane kernels.
-    int wave_qmin, prefetch, rev, perm_scores, qmap;
+    int wave_qmin, prefetch, rev, perm_scores, qmap, group4;
     // the sorted seed list of the phase and where it lives
     const int32_t *tasks; const int64_t *start;
 };
@@ -892,6 +1013,10 @@ static int run_phase(const ExtLaunch &L, const uint32_t *hint, int64_t ub) {
             if (L.pack8 && L.perm_scores && L.prefetch) {       // the LDS-row kernel with the byte-permute score table (query one base per byte)
                 kern = k_ext_seeds<true, true, true>;
                 lds_k = (size_t)((hi + 2) / 2) * 64 * 4 + (size_t)((hi + 3) / 4 + 1) * 64 * 4;
+                if (L.group4) {                                     // ... its column loop in groups of four with two register sets for the LDS words
+                    kern = k_ext_seeds<true, true, true, true>;
+                    lds_k = (size_t)(2 * ((hi + 3) / 4) + 2) * 64 * 4 + (size_t)((hi + 3) / 4 + 1) * 64 * 4;
+                }
             }
             hipLaunchKernelGGL(kern, dim3(grid_for(k, k + 1, 64)), dim3(64), lds_k, sk, c->ix, L.xp, L.tasks, L.start, k * EB_2D, (k + 1) * EB_2D, hi,
                                L.enc, L.off, L.len, L.slot_base, L.reg_seed, L.reg_chain, L.chn, L.seeds, L.regs, L.counters, L.rev);
@@ -938,6 +1063,7 @@ int bm2_launch_extend(bm2_ctx *c, const bm2_opt &opt, const ChainParams &cp, int
     L.rev = bm2_knob("BM2_EXT_REVERSE", 1);
     L.qmap = bm2_knob("BM2_EXT_QUEUE_MAP", 1);
     L.perm_scores = bm2_knob("BM2_EXT_PERM_SCORES", 1);
+    L.group4 = bm2_knob("BM2_EXT_GROUP4", 1);
     for (int k : { 0, 1, 4 }) if (opt.mat[k] < -128 || opt.mat[k] > 127) L.perm_scores = 0;     // (the score table holds signed bytes)
     const int lazy_max = bm2_knob("BM2_EXT_ROUNDS", LAZY_ROUNDS), pend_div = bm2_knob("BM2_EXT_PEND_DIV", 12);
     L.R = ring_size2(opt.w << (MAX_BAND_TRY - 1));

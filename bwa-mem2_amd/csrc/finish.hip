@@ -351,7 +351,7 @@ int bm2_run_finish(bm2_ctx *c, const bm2_opt *opt, int n_reads, const uint8_t *e
         while (waves > 1 && (size_t)waves * 2 * R * 4 > 64 * 1024) waves >>= 1;
         const size_t lds = (size_t)waves * 2 * R * 4;
         if (lds > 160 * 1024) { bm2_set_error("hit merging: a band of %llu columns needs more LDS than a CU has", h_cnt[1]); return BM2_EUNSUP; }
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_fin_dp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (lds > 64 * 1024 && (rc = bm2_check(hipFuncSetAttribute((const void *)k_fin_dp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute(k_fin_dp)"))) return rc;
         const unsigned nbd = (unsigned)((h_cnt[0] + waves - 1) / waves);
         hipLaunchKernelGGL(k_fin_dp, dim3(nbd), dim3(64 * waves), lds, s, c->ix, P, (const FinReq *)reqb.p, (const unsigned long long *)cntb.p, enc, off,
                            reg_off, (const bm2_alnreg_t *)work.p, (FinState *)stateb.p, R);

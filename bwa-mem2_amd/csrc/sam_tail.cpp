@@ -32,12 +32,15 @@ void bm2_set_error(const char *fmt, ...);
 // by default hands the top of an arena back to the kernel (madvise / munmap) whenever 128 KB of it are free, and takes blocks above 128 KB
 // straight from mmap: on a 256-thread host every such call is a TLB shootdown across the process and a turn on its address-space lock, and
 // the phases of a chunk were seen to take 5 ms or 800 ms depending on what the other threads were doing.  So: never trim, big blocks from
-// the arenas too (up to glibc's cap of 32 MB).  Process-wide and once; BM2_MALLOC_TUNE=0 leaves the allocator alone.
+// the arenas too (up to glibc's cap of 32 MB).  That is a PROCESS-WIDE setting -- the host's own allocations stop returning memory to
+// the kernel too -- so it is the host's decision: it happens (once) only when the host asks for it, with BM2_MALLOC_TUNE=1 in the environment
+// (bench.py and the compiled binding do; include/bm2.h).  Since round 3 the tail allocates from per-thread arenas and append buffers and
+// needs the setting far less than it did.
 void bm2_tune_malloc_once() {
     static std::once_flag once;
     std::call_once(once, []() {
         const char *e = getenv("BM2_MALLOC_TUNE");
-        if (e && e[0] == '0') return;
+        if (!e || e[0] != '1') return;
         mallopt(M_TRIM_THRESHOLD, 1 << 30);
         mallopt(M_MMAP_THRESHOLD, 32 << 20);
         mallopt(M_TOP_PAD, 64 << 20);
@@ -148,6 +151,8 @@ struct Text {                       // the output of a thread: appends only, no 
     char *extend(size_t k) { need(k); char *r = b + n; n += k; return r; }    // k bytes to be written in place
     void clear() { n = 0; }
     size_t size() const { return n; }
+    size_t capacity() const { return cap; }
+    void release() { free(b); b = nullptr; n = cap = 0; }
     bool empty() const { return n == 0; }
     const char *data() const { return b; }
 };
@@ -1441,7 +1446,14 @@ template <class F> int run_blocks(int n, int n_threads, char *out, int64_t cap, 
     *n_out = start_of[(size_t)n_blocks];
     if (*n_out > cap) return BM2_ECAP;
     if (!out) return *n_out ? BM2_EINVAL : BM2_OK;
-    run_threads(n_threads, [&]() { for (const BlockNote &k : notes) if (k.size) memcpy(out + start_of[(size_t)k.block], text.data() + k.at, k.size); notes.clear(); });
+    // (a thread keeps its buffer for the next chunk -- but not more than RETAIN bytes of it: a caller that formats one huge chunk and then
+    //  small ones does not hold the huge chunk's text for the life of its threads)
+    const size_t RETAIN = (size_t)64 << 20;
+    run_threads(n_threads, [&]() {
+        for (const BlockNote &k : notes) if (k.size) memcpy(out + start_of[(size_t)k.block], text.data() + k.at, k.size);
+        notes.clear();
+        if (text.capacity() > RETAIN) text.release();
+    });
     prof.mark("copy");
     return BM2_OK;
 }

@@ -926,7 +926,7 @@ int bm2_launch_seeding(bm2_ctx *c, const SeedParams &sp, int n_reads, const uint
     // pass 3 is independent of passes 1 and 2: it runs beside them.  WHERE is launch policy (BM2_P3_AT): 0 = beside the forward walks of
     // pass 1 (both are forward-only kernels without LDS lists: they compete for the same wave slots), 1 / 2 = beside the backward kernel of
     // pass 1 / 2, whose blocks hold 48 KB of LDS survivors and leave wave slots empty that a kernel without LDS can use
-    const int p3_at = bm2_knob("BM2_P3_AT", 0);
+    const int p3_at = bm2_knob("BM2_P3_AT", 1);      // (profiles/r04c: beside bwd1 the seeding stage takes 34.9 instead of 36.1 ms)
     auto launch_p3 = [&]() {
         (void)hipEventRecord(c->ev_fork, s);
         (void)hipStreamWaitEvent(s3, c->ev_fork, 0);
@@ -973,7 +973,6 @@ int bm2_launch_smem_finish(bm2_ctx *c, int n_reads, const SeedBufs &sb, const un
     // (`fill` is through after the scatter: its second half lists the reads that go to the workgroup-per-read sort; [2 n + 2], [2 n + 3] = count, cursor)
     int32_t *big_list = fill + n_reads + 1, *big_cnt = fill + 2 * (int64_t)n_reads + 2, *big_cur = big_cnt + 1;
     hipLaunchKernelGGL(k_smem_finish, dim3((n_reads + 255) / 256), dim3(256), 0, c->stream, n_reads, tmp, smem_cnt, smem_off, max_occ, out, occ_cnt, big_list, big_cnt);
-    static bool attr_set = false;
     int lds_keys = bm2_knob("BM2_SMEM_SORT_KEYS", SMEM_FINISH_LDS_KEYS);     // (a test hook: small values force the m-class runs on ordinary reads)
     if (lds_keys < 64) lds_keys = 64;
     if (lds_keys > SMEM_FINISH_LDS_KEYS) lds_keys = SMEM_FINISH_LDS_KEYS;
@@ -981,7 +980,7 @@ int bm2_launch_smem_finish(bm2_ctx *c, int n_reads, const SeedBufs &sb, const un
     //  kernel's one-lane path, which compares the fields themselves)
     const int keys_arg = max_len < (1 << 18) ? lds_keys : 0;
     const size_t lds = (size_t)SMEM_FINISH_LDS_KEYS * 8;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_smem_finish_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+    { const int rc_a = bm2_raise_lds_limit(c, 1, (const void *)k_smem_finish_big, lds); if (rc_a) return rc_a; }
     hipLaunchKernelGGL(k_smem_finish_big, dim3(c->n_cu), dim3(256), lds, c->stream, tmp, smem_cnt, smem_off, max_occ, out, occ_cnt, big_list, big_cnt, big_cur, keys_arg);
     return bm2_check(hipGetLastError(), "k_smem_finish launch");
 }

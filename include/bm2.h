@@ -136,6 +136,9 @@ int      bm2_device_count(void);
 int      bm2_host_cpus(void);
 /* page-locked host memory for a caller's large per-chunk arrays (reads, hits, text): the library's copies from / to it are plain DMA at
  * PCIe speed instead of a staged copy through 16 MB bounce buffers; anything else the caller passes is staged, as before */
+/* (hardware queues: the HIP runtime reads GPU_MAX_HW_QUEUES when it starts; libbm2 asks for 8 when it is loaded unless the variable is set.
+ * A host that initialises HIP BEFORE loading libbm2 must export GPU_MAX_HW_QUEUES=8 itself, or the concurrent launches of the extension stage
+ * share four queues -- about 2 ms per million-read chunk.) */
 void    *bm2_host_alloc(int64_t bytes);
 void     bm2_host_free(void *p);
 
@@ -218,7 +221,11 @@ typedef struct {                    /* what bseq1_t carries besides the bases (k
 
 /* alnregs: the output of bm2_batch_finish / bm2_finish_regs_dev, regs of read i = [reg_off[i], reg_off[i+1]); they are reordered and annotated in
  * place exactly as mem_mark_primary_se does.  n_processed = reads of earlier chunks (it seeds the tie-breaking hash).
- * out/cap: caller's buffer; *n_out = bytes needed (BM2_ECAP if cap is too small: grow and call again with FRESH alnregs). */
+ * out/cap: caller's buffer; *n_out = bytes needed.  BM2_ECAP if cap is too small: NOTHING has been written to `out` then (the text is
+ * formatted into per-thread buffers first and copied once every block's place is known) -- grow and call again with FRESH alnregs.
+ * Process-wide settings: none unless the host asks.  BM2_MALLOC_TUNE=1 in the environment makes the first bm2_sam_* call set glibc's
+ * M_TRIM_THRESHOLD / M_MMAP_THRESHOLD / M_TOP_PAD for the whole process (the tail's threads allocate small blocks at a high rate; see
+ * sam_tail.cpp) -- the host's own allocations then stop returning memory to the OS as well, which is why it is the host's choice. */
 int bm2_sam_se(const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt *so, const bm2_reads *reads, const bm2_read_text *txt,
                bm2_alnreg_t *alnregs, const int64_t *reg_off, int64_t n_processed, char *out, int64_t cap, int64_t *n_out);
 

@@ -59,6 +59,7 @@ void attach(const worker_t &w) {                    // once: the loaded index as
     }
     g.desc.ann_offset = g.ann_offset.data(); g.desc.ann_len = g.ann_len.data(); g.desc.ann_is_alt = g.ann_is_alt.data();
     g.desc.ann_name = g.ann_name.data(); g.desc.ann_anno = g.ann_anno.data();
+    setenv("BM2_MALLOC_TUNE", "1", 0);                          // this program is the library's host: it opts in to the allocator settings of the SAM tail
     const char *dev = getenv("BM2_DEVICE"), *cap = getenv("BM2_DEVICES");
     const int first = dev ? atoi(dev) : 0, visible = bm2_device_count();
     int n_gpu = visible - first;

@@ -73,3 +73,14 @@ def test_bsw_empty_batch(gpu_ctx_factory):
     out = ctx.bsw(np.zeros(0, bm2.SEQPAIR_DT), np.zeros(1, np.uint8), np.zeros(1, np.uint8), 100,
                   bm2.sw_params(bm2.default_opt(), 5))
     assert len(out) == 0
+
+
+def test_bsw_long_queries_in_the_sliding_register_window(gpu_ctx_factory):
+    # queries beyond 255 columns whose band fits 5 (w = 100) or 8 (w = 200) chunks of 64 columns: bsw_extend_slide (bsw_dev.h); a band of
+    # 300 goes to the LDS ring.  Few pairs: the host emulator of the device sources runs this test too.
+    ctx = gpu_ctx_factory()
+    kw = dict(a=1, b=1, o_del=1, e_del=1, o_ins=1, e_ins=1, pen_clip5=0, pen_clip3=0)
+    for seed, n, max_len, w, opts in ((51, 24, 1400, 100, kw), (52, 10, 2500, 200, kw), (53, 16, 900, 100, dict()), (54, 6, 1200, 300, kw)):
+        tr = [t for t in random_pairs(seed, 4 * n, max_len=max_len, h0_max=300) if len(t[0]) > 256][:n]
+        assert len(tr) >= n // 2
+        _check(ctx, tr, oracle.default_opt(**opts), bm2.default_opt(**opts), w, 0 if opts else 5)

@@ -34,7 +34,8 @@ GRID = [   # (name, candidates): a candidate is a dict of knobs set together; th
     ("extension rounds", [{}, {"BM2_EXT_ROUNDS": 2}, {"BM2_EXT_ROUNDS": 1}, {"BM2_EXT_PEND_DIV": 6}, {"BM2_EXT_PEND_DIV": 24}]),
     ("extension dispatch order", [{}, {"BM2_EXT_REVERSE": 1}]),
     ("extension prefetch", [{}, {"BM2_EXT_PREFETCH": 0}]),
-    ("seeding pass 3 placement", [{}, {"BM2_P3_AT": 1}, {"BM2_P3_AT": 2}]),
+    ("seeding pass 3 placement", [{}, {"BM2_P3_AT": 0}, {"BM2_P3_AT": 2}]),
+    ("extension column loop in groups of four", [{}, {"BM2_EXT_GROUP4": 0}]),
     ("SA lookup by quads", [{}, {"BM2_SAL_QUAD": 1}]),
     ("sub-batches of the chunk on their own streams", [{}, {"BM2_N_SUB": 2}, {"BM2_N_SUB": 3}]),
     ("walk blocks per CU", [{}, {"BM2_WALK_BLOCKS_PER_CU": 6}, {"BM2_WALK_BLOCKS_PER_CU": 3}]),
