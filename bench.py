@@ -35,7 +35,7 @@ import time
 
 import numpy as np
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # the extension stage forks ~10 concurrent launches per side
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")    # the extension stage forks 8 concurrent launches per phase, chaining 5; 8 / 16 / 24 measured (profiles/r04c, r04d)
 os.environ.setdefault("BM2_MALLOC_TUNE", "1")        # this process is the library's host: it opts in to the allocator settings of sam_tail.cpp
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

@@ -92,7 +92,7 @@ class Stats(C.Structure):
 EXPORTS = ["bm2_index_load", "bm2_index_free", "bm2_opt_init", "bm2_opt_fill_scmat", "bm2_create", "bm2_create_shared", "bm2_destroy",
            "bm2_last_error", "bm2_device_count", "bm2_set_stream_priority", "bm2_host_cpus", "bm2_host_alloc", "bm2_host_free", "bm2_bsw", "bm2_bsw_upload", "bm2_bsw_run", "bm2_bsw_download", "bm2_smem", "bm2_sal", "bm2_seed_chain_extend",
            "bm2_batch_upload", "bm2_batch_run", "bm2_batch_stats", "bm2_batch_download", "bm2_batch_kernel_ms",
-           "bm2_batch_fetch", "bm2_batch_finish", "bm2_batch_download_alnregs", "bm2_finish_regs_dev", "bm2_chunk_hits_sharded", "bm2_index_build", "bm2_sam_opt_init", "bm2_sam_se", "bm2_sam_pe", "bm2_fastq_parse", "bm2_fastq_parse_mt", "bm2_fastq_free", "bm2_ksw_align2", "bm2_ksw_align2_dev", "bm2_sam_pe_dev", "bm2_sam_se_dev", "bm2_sam_cigar_stats", "bm2_gen_cigar", "bm2_gen_cigar_dev", "bm2_sam_header", "bm2_sam_rescue_stats"]
+           "bm2_batch_fetch", "bm2_batch_finish", "bm2_batch_download_alnregs", "bm2_finish_regs_dev", "bm2_chunk_hits_sharded", "bm2_index_build", "bm2_sam_opt_init", "bm2_sam_se", "bm2_sam_pe", "bm2_fastq_parse", "bm2_fastq_parse_mt", "bm2_fastq_free", "bm2_ksw_align2", "bm2_ksw_align2_dev", "bm2_sam_pe_dev", "bm2_sam_se_dev", "bm2_sam_pe_dev_multi", "bm2_sam_se_dev_multi", "bm2_sam_cigar_stats", "bm2_gen_cigar", "bm2_gen_cigar_dev", "bm2_sam_header", "bm2_sam_rescue_stats"]
 
 _lib = None
 
@@ -718,11 +718,19 @@ def sam_se(index_prefix, enc, off, ln, opt, alnregs, reg_off, names, quals=None,
                 pes = (PeStat * 4)()
                 args = (C.byref(d), C.byref(opt), C.byref(so), C.byref(r), C.byref(t), C.c_void_p(a.ctypes.data), C.c_void_p(reg_off.ctypes.data),
                         C.c_int64(n_processed), (PeStat * 4)(*pes_in) if pes_in is not None else None, pes, buf, C.c_int64(cap), C.byref(need))
-                rc = L.bm2_sam_pe_dev(C.c_void_p(ctx.h), *args) if ctx is not None else L.bm2_sam_pe(*args)
+                if isinstance(ctx, (list, tuple)):              # several contexts: the tail's device batches are cut over them (bm2_sam_pe_dev_multi)
+                    hs = (C.c_void_p * len(ctx))(*[c.h for c in ctx])
+                    rc = L.bm2_sam_pe_dev_multi(hs, C.c_int(len(ctx)), *args)
+                else:
+                    rc = L.bm2_sam_pe_dev(C.c_void_p(ctx.h), *args) if ctx is not None else L.bm2_sam_pe(*args)
             else:
                 args = (C.byref(d), C.byref(opt), C.byref(so), C.byref(r), C.byref(t), C.c_void_p(a.ctypes.data), C.c_void_p(reg_off.ctypes.data),
                         C.c_int64(n_processed), buf, C.c_int64(cap), C.byref(need))
-                rc = L.bm2_sam_se_dev(C.c_void_p(ctx.h), *args) if ctx is not None else L.bm2_sam_se(*args)
+                if isinstance(ctx, (list, tuple)):
+                    hs = (C.c_void_p * len(ctx))(*[c.h for c in ctx])
+                    rc = L.bm2_sam_se_dev_multi(hs, C.c_int(len(ctx)), *args)
+                else:
+                    rc = L.bm2_sam_se_dev(C.c_void_p(ctx.h), *args) if ctx is not None else L.bm2_sam_se(*args)
             if rc == BM2_ECAP:
                 cap = need.value + 16
                 continue

@@ -233,9 +233,10 @@ __global__ void __launch_bounds__(256) k_cp_occ_relayout(CpOcc *occ, int64_t n) 
 }
 
 // The runtime reads GPU_MAX_HW_QUEUES when it STARTS (default: four hardware queues per process).  The earliest moment this library can speak
-// is when it is loaded: it asks for eight unless the host chose.  A host that has initialised HIP before loading libbm2 keeps what it had
+// is when it is loaded: it asks for sixteen unless the host chose (eight launches of an extension phase, five of the chaining stage, the
+// copies of the neighbouring chunk: with 16 queues the hot path takes 74.8 ms instead of 76.7 and the FASTQ -> SAM leg gains 7 %; with 24 the hot path collapses to 101 ms).  A host that has initialised HIP before loading libbm2 keeps what it had
 // -- nothing in the HIP API tells (include/bm2.h says so; bm2_create notes a smaller explicit setting on stderr).
-__attribute__((constructor)) static void bm2_ask_for_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+__attribute__((constructor)) static void bm2_ask_for_queues() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }     // (8 / 16 / 24 measured: profiles/r04c, r04d)
 
 extern "C" bm2_ctx *bm2_create(int device, const bm2_index_desc *idx) {
     // The extension stage forks eight concurrent launches per side, each on a stream of its own; streams share the process's hardware

@@ -10,6 +10,9 @@
 #include <stdint.h>
 #include <algorithm>
 #include <numeric>
+#include <string>
+#include <string.h>
+#include <thread>
 #include <vector>
 #include "../../include/bm2.h"
 #include "bm2_ctx.h"
@@ -151,4 +154,91 @@ extern "C" int bm2_sam_pe_dev(bm2_ctx *c, const bm2_index_desc *idx, const bm2_o
     if (!c || !c->has_index || !c->ix.ref_string) { bm2_set_error("bm2_sam_pe_dev: the context holds no index"); return BM2_EINVAL; }
     return bm2h_sam_pe(idx, opt, so, reads, txt, alnregs, reg_off, n_processed, pes_in, pes_out, out, cap, n_out, dev_rescue_batch, c,
                        bm2_dev_cigar_batch, c);
+}
+
+// ---- the tail's two device batches over SEVERAL contexts (one per GPU, or contexts sharing a replica): once mem_pestat has run the rescue
+// alignments and the CIGAR alignments of a chunk are independent per task, so each batch is cut into contiguous parts, one host thread and one
+// context per part, and the results are put back in task order -- the text cannot depend on the number of contexts.  (bwamem.cpp:1366-1381 runs
+// them inside worker_sam on every host thread; with G GPUs the hot path of a chunk shrinks G-fold and the tail's batches have to follow.)
+namespace {
+struct MultiCtx { bm2_ctx *const *ctx; int n; };
+template <class F> int run_parts(int parts, int budget, F f) {          // f(part) on a thread of its own; first error wins
+    std::vector<int> rcs((size_t)parts, 0);
+    std::vector<std::string> msgs((size_t)parts);
+    auto one = [&](int g) {
+        bm2_host_thread_budget() = budget;                                  // (a fresh thread would size its host loops to the whole machine)
+        rcs[(size_t)g] = f(g);
+        if (rcs[(size_t)g]) msgs[(size_t)g] = bm2_last_error();
+    };
+    std::vector<std::thread> th;
+    for (int g = 1; g < parts; g++) th.emplace_back(one, g);
+    const int mine = bm2_host_thread_budget();
+    one(0);
+    bm2_host_thread_budget() = mine;
+    for (auto &t : th) t.join();
+    for (int g = 0; g < parts; g++) if (rcs[(size_t)g]) { bm2_set_error("context %d: %s", g, msgs[(size_t)g].c_str()); return rcs[(size_t)g]; }
+    return BM2_OK;
+}
+int parts_of(const MultiCtx *m, int64_t n, int64_t grain) { int64_t p = n / grain + 1; return (int)(p < m->n ? p : m->n); }
+
+int multi_rescue_batch(void *user, int32_t n, const uint8_t *qbuf, int64_t qbuf_bytes, const int64_t *q_off, const int32_t *q_len,
+                       const int64_t *t_pos, const int32_t *t_len, const int32_t *xtra, const bm2_opt *opt, const uint8_t *unused, bm2_ksw_result *out) {
+    const MultiCtx *m = (const MultiCtx *)user;
+    const int G = parts_of(m, n, 8192);
+    if (G <= 1) return dev_rescue_batch(m->ctx[0], n, qbuf, qbuf_bytes, q_off, q_len, t_pos, t_len, xtra, opt, unused, out);
+    const int budget = bm2_host_threads() / G > 0 ? bm2_host_threads() / G : 1;
+    return run_parts(G, budget, [&](int g) {
+        const int64_t lo = (int64_t)n * g / G, hi = (int64_t)n * (g + 1) / G;
+        return dev_rescue_batch(m->ctx[g], (int32_t)(hi - lo), qbuf, qbuf_bytes, q_off + lo, q_len + lo, t_pos + lo, t_len + lo, xtra + lo, opt, unused, out + lo);
+    });
+}
+int multi_cigar_batch(void *user, const bm2_opt *opt, const bm2_reads *reads, int64_t enc_bytes, int32_t n, const bm2h_cg_hit *hits, bm2h_cg_out *out) {
+    const MultiCtx *m = (const MultiCtx *)user;
+    const int G = parts_of(m, n, 16384);
+    if (G <= 1) return bm2_dev_cigar_batch(m->ctx[0], opt, reads, enc_bytes, n, hits, out);
+    std::vector<bm2h_cg_out> part((size_t)G);
+    const int budget = bm2_host_threads() / G > 0 ? bm2_host_threads() / G : 1;
+    int rc = run_parts(G, budget, [&](int g) {
+        const int64_t lo = (int64_t)n * g / G, hi = (int64_t)n * (g + 1) / G;
+        return bm2_dev_cigar_batch(m->ctx[g], opt, reads, enc_bytes, (int32_t)(hi - lo), hits + lo, &part[(size_t)g]);
+    });
+    if (rc) return rc;
+    // task order again: the per-task arrays are concatenated, the offsets into the CIGAR / MD pools move by what the parts before hold
+    size_t nt = 0, nc = 0, nm = 0;
+    for (const bm2h_cg_out &p : part) { nt += p.score.size(); nc += p.cigar.size(); nm += p.md.size(); }
+    out->score.resize(nt); out->nm.resize(nt); out->n_cigar.resize(nt); out->cigar_off.resize(nt); out->md_off.resize(nt);
+    out->cigar.resize(nc); out->md.resize(nm);
+    size_t at = 0, ac = 0, am = 0;
+    for (const bm2h_cg_out &p : part) {
+        const size_t k = p.score.size();
+        for (size_t i = 0; i < k; i++) {
+            out->score[at + i] = p.score[i]; out->nm[at + i] = p.nm[i]; out->n_cigar[at + i] = p.n_cigar[i];
+            out->cigar_off[at + i] = p.cigar_off[i] + (int64_t)ac; out->md_off[at + i] = p.md_off[i] + (int64_t)am;
+        }
+        if (!p.cigar.empty()) memcpy(out->cigar.data() + ac, p.cigar.data(), p.cigar.size() * sizeof(uint32_t));
+        if (!p.md.empty()) memcpy(out->md.data() + am, p.md.data(), p.md.size());
+        at += k; ac += p.cigar.size(); am += p.md.size();
+    }
+    return BM2_OK;
+}
+bool all_hold_index(bm2_ctx *const *ctxs, int n_ctx) {
+    if (!ctxs || n_ctx < 1) return false;
+    for (int i = 0; i < n_ctx; i++) if (!ctxs[i] || !ctxs[i]->has_index || !ctxs[i]->ix.ref_string) return false;
+    return true;
+}
+}  // namespace
+
+extern "C" int bm2_sam_pe_dev_multi(bm2_ctx *const *ctxs, int n_ctx, const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt *so, const bm2_reads *reads,
+                                    const bm2_read_text *txt, const bm2_alnreg_t *alnregs, const int64_t *reg_off, int64_t n_processed,
+                                    const bm2_pestat *pes_in, bm2_pestat *pes_out, char *out, int64_t cap, int64_t *n_out) {
+    if (!all_hold_index(ctxs, n_ctx)) { bm2_set_error("bm2_sam_pe_dev_multi: every context must hold the index"); return BM2_EINVAL; }
+    MultiCtx m = { ctxs, n_ctx };
+    return bm2h_sam_pe(idx, opt, so, reads, txt, alnregs, reg_off, n_processed, pes_in, pes_out, out, cap, n_out, multi_rescue_batch, &m, multi_cigar_batch, &m);
+}
+extern "C" int bm2_sam_se_dev_multi(bm2_ctx *const *ctxs, int n_ctx, const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt *so, const bm2_reads *reads,
+                                    const bm2_read_text *txt, bm2_alnreg_t *alnregs, const int64_t *reg_off, int64_t n_processed, char *out,
+                                    int64_t cap, int64_t *n_out) {
+    if (!all_hold_index(ctxs, n_ctx)) { bm2_set_error("bm2_sam_se_dev_multi: every context must hold the index"); return BM2_EINVAL; }
+    MultiCtx m = { ctxs, n_ctx };
+    return bm2h_sam_se(idx, opt, so, reads, txt, alnregs, reg_off, n_processed, out, cap, n_out, multi_cigar_batch, &m);
 }

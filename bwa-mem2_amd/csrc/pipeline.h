@@ -41,7 +41,7 @@ enum { BM2_SC_SLOT1 = 1, BM2_SC_REC = 3, BM2_SC_TASK = 4, BM2_SC_SLOT2 = 6, BM2_
        BM2_SC_NEXT_W1 = 12 /* then W2, W3, B1, B2 */ };   // = the SC_* of smem.hip
 int bm2_launch_seeding(bm2_ctx *c, const SeedParams &sp, int n_reads, const uint8_t *enc, const int64_t *off, const int32_t *len,
                        const SeedBufs &sb, int grid_walk, int grid_bwd, int32_t *smem_cnt, unsigned long long *sc,
-                       void (*tick)(bm2_ctx *, const char *));
+                       void (*tick)(bm2_ctx *, const char *), int max_len);
 int bm2_launch_smem_finish(bm2_ctx *c, int n_reads, const SeedBufs &sb, const unsigned long long *sc, const int32_t *smem_cnt,
                            const int64_t *smem_off, int32_t *fill, bm2_smem_t *tmp, int32_t max_occ, bm2_smem_t *out, int32_t *occ_cnt, int max_len);
 int bm2_seed_sizes(size_t *head, size_t *ent, size_t *task, int *n_sc);      // returns CAPF

@@ -225,7 +225,7 @@ static int run_seeding(bm2_ctx *c, Batch *b, const bm2_opt *opt, bool with_sal) 
         if (verbose) { (void)hipStreamSynchronize(s); fprintf(stderr, "[seeding] reserve+memset %.1f ms\n", now_ms() - t0); t0 = now_ms(); }
         c->n_ev = 0;                                                // (a repeated attempt restarts the stage clock)
         if ((rc = bm2_launch_seeding(c, sp, n, (const uint8_t *)b->enc.p, (const int64_t *)b->off.p, (const int32_t *)b->len.p, sb,
-                                     grid_w, grid_b, (int32_t *)b->smem_cnt.p, (unsigned long long *)b->seedc.p, tick))) return rc;
+                                     grid_w, grid_b, (int32_t *)b->smem_cnt.p, (unsigned long long *)b->seedc.p, tick, b->max_len))) return rc;
         if ((rc = bm2_scan_i32(c, (const int32_t *)b->smem_cnt.p, n, (int64_t *)b->smem_off.p, b->scan_tmp))) return rc;
         if ((rc = bm2_check(hipMemcpyAsync(&n_smem_tot, (int64_t *)b->smem_off.p + n, 8, hipMemcpyDeviceToHost, s), "D2H n_smem"))) return rc;
         if ((rc = bm2_check(hipMemcpyAsync(h_sc.data(), b->seedc.p, (size_t)n_sc * 8, hipMemcpyDeviceToHost, s), "D2H seed cursors"))) return rc;
@@ -713,16 +713,26 @@ extern "C" int bm2_chunk_hits_sharded(bm2_ctx *const *ctxs, int n_ctx, const bm2
     }
     *n_out = tot;
     if (tot > cap) { bm2_set_error("alnregs capacity %ld < %ld", (long)cap, (long)tot); return BM2_ECAP; }
-    int64_t base = 0;
-    for (int i = 0; i < n_ctx; i++) {
+    // every part comes down on its own host thread, straight into its place of the caller's arrays (the places are the prefix sums of the
+    // parts' hit counts; G copies over G links instead of one after the other)
+    std::vector<int64_t> base((size_t)n_ctx + 1, 0);
+    for (int i = 0; i < n_ctx; i++) base[(size_t)i + 1] = base[(size_t)i] + cnt[(size_t)i];
+    auto download_part = [&](int i) {
         const int lo = first[(size_t)i], hi = first[(size_t)i + 1];
         int64_t n1 = 0;
         offs[(size_t)i].assign((size_t)(hi - lo) + 1, 0);
-        const int rc = bm2_batch_download_alnregs(ctxs[i], out ? out + base : nullptr, cap - base, offs[(size_t)i].data(), &n1);
-        if (rc) return rc;
-        for (int k = 0; k <= hi - lo; k++) aln_off[lo + k] = offs[(size_t)i][(size_t)k] + base;
-        base += n1;
+        const int rc = bm2_batch_download_alnregs(ctxs[i], out ? out + base[(size_t)i] : nullptr, cap - base[(size_t)i], offs[(size_t)i].data(), &n1);
+        rcs[(size_t)i] = rc;
+        if (rc) { msgs[(size_t)i] = bm2_last_error(); return; }
+        for (int k = 0; k <= hi - lo; k++) aln_off[lo + k] = offs[(size_t)i][(size_t)k] + base[(size_t)i];
+    };
+    {
+        std::vector<std::thread> th;
+        for (int i = 1; i < n_ctx; i++) th.emplace_back(download_part, i);
+        download_part(0);
+        for (auto &t : th) t.join();
     }
+    for (int i = 0; i < n_ctx; i++) if (rcs[(size_t)i]) { bm2_set_error("context %d: %s", i, msgs[(size_t)i].c_str()); return rcs[(size_t)i]; }
     aln_off[n] = tot;
     return BM2_OK;
 }

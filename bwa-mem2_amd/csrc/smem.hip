@@ -919,14 +919,15 @@ k_smem_gather(int n_reads, const bm2_smem_t *__restrict__ in, const int64_t *__r
 
 int bm2_launch_seeding(bm2_ctx *c, const SeedParams &sp, int n_reads, const uint8_t *enc, const int64_t *off, const int32_t *len,
                        const SeedBufs &sb, int grid_walk, int grid_bwd, int32_t *smem_cnt, unsigned long long *sc,
-                       void (*tick)(bm2_ctx *, const char *)) {
+                       void (*tick)(bm2_ctx *, const char *), int max_len) {
     if (bm2_side_streams(c)) return BM2_ENODEV;
     hipStream_t s = c->stream, s3 = c->side_stream[0], sh = c->side_stream[1];
     const int grid_heavy = c->n_cu * 4;
     // pass 3 is independent of passes 1 and 2: it runs beside them.  WHERE is launch policy (BM2_P3_AT): 0 = beside the forward walks of
     // pass 1 (both are forward-only kernels without LDS lists: they compete for the same wave slots), 1 / 2 = beside the backward kernel of
     // pass 1 / 2, whose blocks hold 48 KB of LDS survivors and leave wave slots empty that a kernel without LDS can use
-    const int p3_at = bm2_knob("BM2_P3_AT", 1);      // (profiles/r04c: beside bwd1 the seeding stage takes 34.9 instead of 36.1 ms)
+    const int p3_at = bm2_knob("BM2_P3_AT", max_len >= 1000 ? 0 : 1);      // (150 bp reads, profiles/r04c: beside bwd1 34.9 instead of 36.1 ms; 10 kb reads, whose walks are
+                                                                               //  ten times as long as their backward phases, r04d: 180 instead of 138 ms there)
     auto launch_p3 = [&]() {
         (void)hipEventRecord(c->ev_fork, s);
         (void)hipStreamWaitEvent(s3, c->ev_fork, 0);

@@ -136,8 +136,8 @@ int      bm2_device_count(void);
 int      bm2_host_cpus(void);
 /* page-locked host memory for a caller's large per-chunk arrays (reads, hits, text): the library's copies from / to it are plain DMA at
  * PCIe speed instead of a staged copy through 16 MB bounce buffers; anything else the caller passes is staged, as before */
-/* (hardware queues: the HIP runtime reads GPU_MAX_HW_QUEUES when it starts; libbm2 asks for 8 when it is loaded unless the variable is set.
- * A host that initialises HIP BEFORE loading libbm2 must export GPU_MAX_HW_QUEUES=8 itself, or the concurrent launches of the extension stage
+/* (hardware queues: the HIP runtime reads GPU_MAX_HW_QUEUES when it starts; libbm2 asks for 16 when it is loaded unless the variable is set.
+ * A host that initialises HIP BEFORE loading libbm2 must export GPU_MAX_HW_QUEUES=16 itself, or the concurrent launches of the extension stage
  * share four queues -- about 2 ms per million-read chunk.) */
 void    *bm2_host_alloc(int64_t bytes);
 void     bm2_host_free(void *p);
@@ -307,6 +307,16 @@ void bm2_sam_cigar_stats(int64_t *planned, int64_t *used, int64_t *missed);
 int bm2_sam_pe_dev(bm2_ctx *c, const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt *so, const bm2_reads *reads,
                    const bm2_read_text *txt, const bm2_alnreg_t *alnregs, const int64_t *reg_off, int64_t n_processed,
                    const bm2_pestat *pes_in, bm2_pestat *pes_out, char *out, int64_t cap, int64_t *n_out);
+/* The same over SEVERAL contexts (one per GPU, or contexts sharing one replica): the chunk's rescue batch and CIGAR batch are cut into
+ * contiguous parts, one context and one host thread per part, results back in task order -- same text whatever n_ctx is.  What a host that
+ * shards the hot path with bm2_chunk_hits_sharded calls afterwards, so that the tail's device work shrinks with the number of GPUs too
+ * (worker_sam, bwamem.cpp:1366-1381; mem_matesw, bwamem_pair.cpp:150-283). */
+int bm2_sam_se_dev_multi(bm2_ctx *const *ctxs, int n_ctx, const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt *so, const bm2_reads *reads,
+                         const bm2_read_text *txt, bm2_alnreg_t *alnregs, const int64_t *reg_off, int64_t n_processed, char *out, int64_t cap,
+                         int64_t *n_out);
+int bm2_sam_pe_dev_multi(bm2_ctx *const *ctxs, int n_ctx, const bm2_index_desc *idx, const bm2_opt *opt, const bm2_sam_opt *so, const bm2_reads *reads,
+                         const bm2_read_text *txt, const bm2_alnreg_t *alnregs, const int64_t *reg_off, int64_t n_processed,
+                         const bm2_pestat *pes_in, bm2_pestat *pes_out, char *out, int64_t cap, int64_t *n_out);
 
 
 /* ---- the same path split so that a caller can keep inputs resident in HBM and time only the device work */

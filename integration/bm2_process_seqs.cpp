@@ -10,8 +10,8 @@
 // What happens to a chunk here: bases -> 2-bit codes (bwamem.cpp:992-1000) on opt->n_threads host threads, then bm2_chunk_hits_sharded --
 // the chunk cut at multiples of 512 reads over every visible GPU (BM2_DEVICES=n caps the number, BM2_DEVICE picks the first), each part
 // through bm2_batch_upload / run (mem_kernel1_core + mem_kernel2_core up to :1152) / finish (mem_sort_dedup_patch) on its GPU's replica,
-// the hits gathered in read order -- then ONE bm2_sam_pe_dev / bm2_sam_se_dev over the whole chunk (mem_pestat is chunk-wide; the rescue
-// and CIGAR alignments run as device batches on the first GPU), so the text does not depend on the number of GPUs.  The index is NOT loaded twice: the
+// the hits gathered in read order -- then ONE bm2_sam_pe_dev_multi / bm2_sam_se_dev_multi over the whole chunk (mem_pestat is chunk-wide; the rescue
+// and CIGAR alignments run as device batches cut over the same GPUs, results back in task order), so the text does not depend on the number of GPUs.  The index is NOT loaded twice: the
 // descriptor points at the arrays FMI_search::load_index and main_mem already hold (FMI_search keeps them private; a maintainer
 // would add accessors -- this file opens the class with the preprocessor instead, to leave the reference's sources alone).
 #include <atomic>
@@ -137,8 +137,8 @@ void mem_process_seqs(mem_opt_t *opt, int64_t n_processed, int n, bseq1_t *seqs,
         // (the single-end tail reorders the hits in place: should the text not fit -- the capacity above is generous, so hardly ever -- the
         //  second attempt fetches the hits again instead of every chunk paying for a spare copy)
         if (attempt > 0 && !pe && bm2_chunk_hits_sharded(g.ctx.data(), (int)g.ctx.size(), &reads, &o, aln.data(), (int64_t)aln.size(), aln_off.data(), &n_aln)) die("device stage");
-        rc = pe ? bm2_sam_pe_dev(g.ctx[0], &g.desc, &o, &so, &reads, &txt, aln.data(), aln_off.data(), n_processed, pes0 ? pin : nullptr, nullptr, text, cap, &need)
-                : bm2_sam_se_dev(g.ctx[0], &g.desc, &o, &so, &reads, &txt, aln.data(), aln_off.data(), n_processed, text, cap, &need);
+        rc = pe ? bm2_sam_pe_dev_multi(g.ctx.data(), (int)g.ctx.size(), &g.desc, &o, &so, &reads, &txt, aln.data(), aln_off.data(), n_processed, pes0 ? pin : nullptr, nullptr, text, cap, &need)
+                : bm2_sam_se_dev_multi(g.ctx.data(), (int)g.ctx.size(), &g.desc, &o, &so, &reads, &txt, aln.data(), aln_off.data(), n_processed, text, cap, &need);
         if (rc != BM2_ECAP) break;
         cap = need + 16;
     }

@@ -57,6 +57,7 @@ def run(prefix, fq, K=10000000, out_path="-", threads=0, hits_of=None, device_ta
     if hits_of is None or device_tail:
         ctx = bm2.Context(0, prefix)
     extra = []
+    tail_ctx = ctx
     if hits_of is None and contexts > 1:
         ndev = max(bm2.lib().bm2_device_count(), 1)
         idx = bm2.Index(prefix)
@@ -67,6 +68,7 @@ def run(prefix, fq, K=10000000, out_path="-", threads=0, hits_of=None, device_ta
             c = bm2.Context(share=per_dev[d]) if d in per_dev else bm2.Context(d, idx)
             per_dev.setdefault(d, c); ctxs.append(c); extra.append(c)
         hits_of = lambda enc, off, ln: bm2.chunk_hits_sharded(ctxs, (enc, off, ln), opt)
+        tail_ctx = ctxs                                      # the tail's rescue / CIGAR batches over the same contexts (bm2_sam_*_dev_multi)
     if hits_of is None:
         def hits_of(enc, off, ln):
             ctx.batch_upload(enc, off, ln); ctx.batch_run(opt); ctx.batch_finish(opt)
@@ -79,9 +81,9 @@ def run(prefix, fq, K=10000000, out_path="-", threads=0, hits_of=None, device_ta
         off = np.concatenate([[0], np.cumsum(ln[:-1])]).astype(np.int64)
         aln, aln_off = hits_of(enc, off, ln)
         if paired:
-            txt, _ = bm2.sam_pe(prefix, enc, off, ln, opt, aln, aln_off, names[lo:hi], quals[lo:hi], None, so, n_processed=lo, ctx=ctx if device_tail else None)
+            txt, _ = bm2.sam_pe(prefix, enc, off, ln, opt, aln, aln_off, names[lo:hi], quals[lo:hi], None, so, n_processed=lo, ctx=tail_ctx if device_tail else None)
         else:
-            txt = bm2.sam_se(prefix, enc, off, ln, opt, aln, aln_off, names[lo:hi], quals[lo:hi], None, so, n_processed=lo, ctx=ctx if device_tail else None)
+            txt = bm2.sam_se(prefix, enc, off, ln, opt, aln, aln_off, names[lo:hi], quals[lo:hi], None, so, n_processed=lo, ctx=tail_ctx if device_tail else None)
         out.write(txt)
     if out is not sys.stdout.buffer:
         out.close()

@@ -18,7 +18,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "bwa-mem2_amd"))
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 GRID = [   # (name, candidates): a candidate is a dict of knobs set together; the first one ({} = the library's defaults) is the incumbent
     ("chain staging", [{}, {"BM2_CHAIN_STAGE": 1}]),
