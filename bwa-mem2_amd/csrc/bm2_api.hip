@@ -350,7 +350,7 @@ extern "C" void bm2_destroy(bm2_ctx *c) {
     bm2_batch_destroy(c);
     void *ps[] = { c->d_cp_occ, c->d_sa_ms, c->d_sa_ls, c->d_ref, c->d_ann_off, c->d_ann_len, c->d_ann_alt };
     if (!c->is_child) for (void *p : ps) if (p) (void)hipFree(p);          // a shared context does not own the replica
-    bm2_release(c->b_pairs); bm2_release(c->b_pairs2); bm2_release(c->b_ref); bm2_release(c->b_qer); bm2_release(c->b_misc);
+    bm2_release(c->b_pairs); bm2_release(c->b_pairs2); bm2_release(c->b_ref); bm2_release(c->b_qer); bm2_release(c->b_misc); bm2_release(c->b_scan);
     free_streams(c);
     delete c;
 }

@@ -56,6 +56,8 @@ struct bm2_ctx {
     // kernels whose dynamic LDS limit has been raised for this context's device (hipFuncSetAttribute: once per context, result checked)
     unsigned lds_attr_done = 0;
     int ext_stat_reads = 0, ext_stat_rounds = 0;
+    int bsw_stat_n = 0;                                           // pairs of the S1 batch whose class counts row BSW_STAT_ROW holds
+    DevBuf b_scan;                                                // prefix-sum scratch of the S1 path
     // sub-batch pipelining (pipeline.hip): extra contexts sharing this one's index replica
     std::vector<bm2_ctx *> subs;
     StageGate gate;                                               // (of the parent: the schedule of its parts)
@@ -87,5 +89,7 @@ int bm2_copy_h2d(bm2_ctx *c, void *dst_dev, const void *src_host, size_t bytes);
 int bm2_copy_d2h(bm2_ctx *c, void *dst_host, const void *src_dev, size_t bytes);
 
 struct SwParams;
+int bm2_launch_bsw_sorted(bm2_ctx *c, bm2_seqpair_t *d_pairs, const uint8_t *d_ref, const uint8_t *d_qer, int n, int w, const SwParams &P,
+                          unsigned long long *d_cells, bool *done);      // extend.hip: S1 through the lane kernel where the pairs allow it
 int bm2_launch_bsw_pairs(bm2_ctx *c, bm2_seqpair_t *d_pairs, const uint8_t *d_ref, const uint8_t *d_qer, int n, int w,
                          const SwParams &P, unsigned long long *d_cells);

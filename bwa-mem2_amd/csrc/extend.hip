@@ -1127,6 +1127,121 @@ int bm2_launch_extend(bm2_ctx *c, const bm2_opt &opt, const ChainParams &cp, int
     return bm2_check(hipGetLastError(), "extension launches");
 }
 
+// ---- seam S1 on the lane kernel: BandedPairWiseSW::getScores8 / getScores16 (bandedSWA.h:126-135) are inter-task SIMD kernels -- one pair per
+// SIMD lane -- and so is this: the pairs of a batch whose query fits the lane kernel's LDS rows and whose scores fit its 8-bit cells are
+// counting-sorted on the device by (query length, target length / 4) and run one per lane through the same row code as the pipeline's
+// extension stage (lane_dp8g); the others -- long queries, int16 / int32-class scores -- stay on the pair-per-wavefront kernel (bsw.hip).
+#define BSW_STAT_ROW (BM2_EXT_PHASES - 2)       // the row of bm2_ctx::ext_stat the S1 batches keep their class counts in (no lazy round ever has it)
+__global__ void __launch_bounds__(256)
+k_bsw_bin(const bm2_seqpair_t *__restrict__ pairs, int n, int a_match, int lanes_ok, uint32_t *ebin, int32_t *hist) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int len1 = pairs[i].len1, len2 = pairs[i].len2, h0 = pairs[i].h0;
+    uint32_t b = (uint32_t)EBIN_FALLBACK;
+    if (lanes_ok && len2 >= 1 && len2 <= LANE_QMAX && len1 >= 1 && len1 < 32768 && h0 >= 0 && h0 + len2 * a_match <= 255)
+        b = (uint32_t)(((len2 - 1) >> 4) * EB_2D + len2 * EB_L + imin(len1 >> 2, LANE_QMAX));
+    ebin[i] = b;
+    atomicAdd(&hist[b], 1);
+}
+
+__global__ void __launch_bounds__(64)
+k_bsw_lanes(bm2_seqpair_t *pairs, const uint8_t *__restrict__ ref, const uint8_t *__restrict__ qer, const int32_t *__restrict__ tasks_all,
+            const int64_t *__restrict__ start, int bin_lo, int bin_hi, int qmax, int w, SwParams P, unsigned long long *cells_out, int rev) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_l[];
+    uint32_t *EH = lds_l;
+    uint32_t *QL8 = lds_l + (size_t)(2 * ((qmax + 3) / 4) + 2) * 64;
+    const int lane = threadIdx.x;
+    const int64_t first = start[bin_lo];
+    const int n_tasks = (int)(start[bin_hi] - first);
+    const int32_t *tasks = tasks_all + first;
+    const int n_tiles = (n_tasks + 63) >> 6;
+    long long cells = 0, iters = 0;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int idx = (rev ? n_tiles - 1 - tile : tile) * 64 + lane;
+        const bool valid = idx < n_tasks;
+        int id = 0, len1 = 0, len2 = 0, h0 = 0;
+        const uint8_t *q = qer, *t = ref;
+        if (valid) { id = tasks[idx]; len1 = pairs[id].len1; len2 = pairs[id].len2; h0 = pairs[id].h0; q = qer + pairs[id].idq; t = ref + pairs[id].idr; }
+        const int maxq = __builtin_amdgcn_readlane(wave_scan_max(valid ? len2 : 0, 0), 63);
+        for (int j0 = 0; j0 < maxq; j0 += 4) {
+            if (valid && j0 < len2) {
+                uint32_t wq = 0;
+                for (int u = 0; u < 4 && j0 + u < len2; u++) { const uint32_t qv = q[j0 + u]; wq |= (qv > 3 ? 4u : qv) << (8 * u); }
+                QL8[(j0 >> 2) * 64 + lane] = wq;
+            }
+        }
+        const int cls = pair_class(len1, len2, h0, P.max_sc);
+        const int wc = band_clamp(w, len2, P, cls);
+        LaneOut o; o.score = h0; o.qle = o.tle = o.gtle = 0; o.gscore = -1; o.max_off = 0;
+        lane_dp8g(valid, len2, len1, wc, h0, t, 1, P, EH, QL8, lane, o, cells, iters);
+        if (valid) {
+            bm2_seqpair_t *d = &pairs[id];
+            d->score = o.score; d->tle = o.tle; d->gtle = o.gtle; d->qle = o.qle; d->gscore = o.gscore; d->max_off = o.max_off;
+        }
+    }
+    if (cells_out) atomicAdd(cells_out, (unsigned long long)cells);
+}
+
+int bm2_launch_bsw_list(bm2_ctx *c, bm2_seqpair_t *d_pairs, const uint8_t *d_ref, const uint8_t *d_qer, const int32_t *list, const int64_t *start,
+                        int bin_lo, int bin_hi, unsigned grid, int w, const SwParams &P, unsigned long long *d_cells, hipStream_t s);      // bsw.hip
+
+// -> BM2_OK and *done = true when the batch went through the sorted path; *done = false: the caller launches the plain pair-per-wavefront kernel
+int bm2_launch_bsw_sorted(bm2_ctx *c, bm2_seqpair_t *d_pairs, const uint8_t *d_ref, const uint8_t *d_qer, int n, int w, const SwParams &P,
+                          unsigned long long *d_cells, bool *done) {
+    *done = false;
+    if (!bm2_knob("BM2_BSW_LANES", 1) || n < bm2_knob("BM2_BSW_LANES_MIN", 4096)) return BM2_OK;      // (small batches: the sort's fixed cost is not worth it)
+    for (int i = 0; i < 5; i++)
+        for (int j = 0; j < 5; j++) {                                   // the lane kernel scores by (match, mismatch, ambiguous) bytes: bwa_fill_scmat's form only
+            const int want = (i == 4 || j == 4) ? P.mat[4] : i == j ? P.mat[0] : P.mat[1];
+            if (P.mat[i * 5 + j] != want || want < -128 || want > 127) return BM2_OK;
+        }
+    if (P.max_sc <= 0) return BM2_OK;
+    int rc;
+    if ((rc = bm2_side_streams(c))) return rc;
+    hipStream_t s = c->stream;
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t o_hist = up((size_t)n * 4), o_stat = up(o_hist + (size_t)N_EBINS * 4), o_start = up(o_stat + BM2_EXT_STATW * 4);
+    const size_t o_task = up(o_start + (size_t)(N_EBINS + 2) * 8);
+    if ((rc = bm2_reserve(c->b_pairs2, o_task + (size_t)n * 4 + 256))) return rc;
+    char *base = (char *)c->b_pairs2.p;
+    uint32_t *ebin = (uint32_t *)base, *stat = (uint32_t *)(base + o_stat);
+    int32_t *hist = (int32_t *)(base + o_hist), *tasks = (int32_t *)(base + o_task);
+    int64_t *start = (int64_t *)(base + o_start);
+    if ((rc = bm2_check(hipMemsetAsync(hist, 0, o_start - o_hist, s), "memset hist"))) return rc;
+    hipLaunchKernelGGL(k_bsw_bin, dim3((n + 255) / 256), dim3(256), 0, s, (const bm2_seqpair_t *)d_pairs, n, (int)P.max_sc, 1, ebin, hist);
+    if ((rc = bm2_scan_i32(c, hist, N_EBINS, start, c->b_scan))) return rc;
+    hipLaunchKernelGGL(k_task_scatter, dim3((n + 255) / 256), dim3(256), 0, s, (int64_t)n, ebin, hist, start, tasks, (const int64_t *)nullptr, (const int32_t *)nullptr);
+    hipLaunchKernelGGL(k_phase_stats, dim3(1), dim3(64), 0, s, start, (const uint32_t *)nullptr, stat);
+    static const int cls_hi[N_CLS] = { 16, 32, 48, 64, 80, 96, 112, 128, 144, 160 };
+    const uint32_t *hint = c->ext_stat && c->bsw_stat_n == n ? c->ext_stat + (size_t)BSW_STAT_ROW * BM2_EXT_STATW : nullptr;
+    uint32_t hcopy[BM2_EXT_STATW];
+    if (hint) { memcpy(hcopy, hint, sizeof hcopy); hint = hcopy; }
+    (void)hipEventRecord(c->ev_fork, s);
+    for (int k = N_CLS; k >= 0; k--) {                                   // long queries first
+        hipStream_t sk = c->side_stream[k];
+        int64_t cnt = hint ? (int64_t)hint[k] + hint[k] / 4 + 64 : n;
+        if (cnt > n) cnt = n;
+        (void)hipStreamWaitEvent(sk, c->ev_fork, 0);
+        if (k < N_CLS) {
+            const int hi = cls_hi[k];
+            const size_t lds = (size_t)(2 * ((hi + 3) / 4) + 2) * 64 * 4 + (size_t)((hi + 3) / 4 + 1) * 64 * 4;
+            int64_t g = (cnt + 63) / 64; if (g < 1) g = 1; if (g > (1 << 16)) g = 1 << 16;
+            hipLaunchKernelGGL(k_bsw_lanes, dim3((unsigned)g), dim3(64), lds, sk, d_pairs, d_ref, d_qer, tasks, start, k * EB_2D, (k + 1) * EB_2D, hi, w, P, d_cells, 1);
+        } else {
+            int64_t g = (cnt + 3) / 4; if (g < 1) g = 1; if (g > (1 << 20)) g = 1 << 20;
+            if ((rc = bm2_launch_bsw_list(c, d_pairs, d_ref, d_qer, tasks, start, N_CLS * EB_2D, (int)N_EBINS, (unsigned)g, w, P, d_cells, sk))) return rc;
+        }
+        (void)hipEventRecord(c->ev_join[k], sk);
+        (void)hipStreamWaitEvent(s, c->ev_join[k], 0);
+    }
+    if (c->ext_stat) {
+        if ((rc = bm2_check(hipMemcpyAsync(c->ext_stat + (size_t)BSW_STAT_ROW * BM2_EXT_STATW, stat, BM2_EXT_STATW * 4, hipMemcpyDeviceToHost, s), "D2H S1 class counts"))) return rc;
+        c->bsw_stat_n = n;
+    }
+    *done = true;
+    return bm2_check(hipGetLastError(), "S1 lane launches");
+}
+
 int bm2_launch_slot_base(bm2_ctx *c, int n_reads, const int64_t *read_base, const int32_t *n_reg, int64_t *slot_base) {
     if (n_reads <= 0) return BM2_OK;
     hipLaunchKernelGGL(k_slot_base, dim3((n_reads + 255) / 256), dim3(256), 0, c->stream, n_reads, read_base, n_reg, slot_base);
