@@ -196,8 +196,16 @@ static int make_streams(bm2_ctx *c) {
 int bm2_side_streams(bm2_ctx *c) {
     if (c->ev_fork) return BM2_OK;
     if (bm2_check(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming), "hipEventCreate")) return BM2_ENODEV;
+    // BM2_SIDE_PRIO_MASK: the side streams whose bit is set -- e.g. those of the extension launches of the long query classes, whose wavefronts
+    // are a phase's critical path -- are created with the highest queue priority: when a phase holds more workgroups than the GPU, theirs are placed first
+    // and the short classes fill in behind them (longest job first)
+    const int prio_mask = bm2_knob("BM2_SIDE_PRIO_MASK", 0);
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
     for (int i = 0; i < 12; i++) {
-        if (bm2_check(hipStreamCreateWithFlags(&c->side_stream[i], hipStreamNonBlocking), "hipStreamCreate")) return BM2_ENODEV;
+        const hipError_t e = (prio_mask >> i & 1) ? hipStreamCreateWithPriority(&c->side_stream[i], hipStreamNonBlocking, greatest)
+                                            : hipStreamCreateWithFlags(&c->side_stream[i], hipStreamNonBlocking);
+        if (bm2_check(e, "hipStreamCreate")) return BM2_ENODEV;
         (void)hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming);
     }
     return BM2_OK;
