@@ -207,6 +207,75 @@ static __device__ int chain_weight(const WChain &c, const WSeed *seeds) {
     return w < 1 << 30 ? w : (1 << 30) - 1;
 }
 
+// The rest of mem_chain_flt (bwamem.cpp:548-624) and the hand-over to the extension stage, for the n chains ord[0..n) -- the chains that
+// passed the weight test, in key order -- of read r: introsort by weight, overlap filter, kept chains with their seeds made contiguous.
+// kept_list: scratch for n ints (the B-tree's nodes are no longer needed when this runs).
+static __device__ void chain_finish_read(const ChainParams &o, int r, WChain *ch, WSeed *sd, int32_t *ord, int32_t *kept_list, int n, int64_t base,
+                                         float frac_rep, DevChain *chn, DevSeed *seeds_out, int32_t *seed_owner, int32_t *n_chain_out, int32_t *n_reg_out) {
+    int k;
+    if (n > 0) {
+        k_introsort_flat(n, ord, [&](int32_t x, int32_t y) { return ch[x].w > ch[y].w; });     // flt_lt, bwamem.cpp:61
+        int n_kept = 0;
+        ch[ord[0]].kept = 3;
+        kept_list[n_kept++] = 0;
+        for (int i = 1; i < n; ++i) {
+            WChain &ci = ch[ord[i]];
+            const int beg_i = ci.first_qbeg, end_i = ci.last_qbeg + ci.last_len;
+            int large_ovlp = 0, kk;
+            for (kk = 0; kk < n_kept; ++kk) {
+                const int j = kept_list[kk];
+                WChain &cj = ch[ord[j]];
+                const int beg_j = cj.first_qbeg, end_j = cj.last_qbeg + cj.last_len;
+                const int b_max = beg_j > beg_i ? beg_j : beg_i;
+                const int e_min = end_j < end_i ? end_j : end_i;
+                if (e_min > b_max && (!cj.is_alt || ci.is_alt)) {
+                    const int li = end_i - beg_i, lj = end_j - beg_j;
+                    const int min_l = li < lj ? li : lj;
+                    if (e_min - b_max >= min_l * o.mask_level && min_l < o.max_chain_gap) {
+                        large_ovlp = 1;
+                        if (cj.first < 0) cj.first = i;
+                        if (ci.w < cj.w * o.drop_ratio && cj.w - ci.w >= o.min_seed_len << 1) break;
+                    }
+                }
+            }
+            if (kk == n_kept) { kept_list[n_kept++] = i; ci.kept = large_ovlp ? 2 : 3; }
+        }
+        for (int i = 0; i < n_kept; ++i) {
+            const WChain &c = ch[ord[kept_list[i]]];
+            if (c.first >= 0) ch[ord[c.first]].kept = 1;
+        }
+        int i2;
+        for (i2 = k = 0; i2 < n; ++i2) {
+            const int kp = ch[ord[i2]].kept;
+            if (kp == 0 || kp == 3) continue;
+            if (++k >= o.max_chain_extend) break;
+        }
+        for (; i2 < n; ++i2) if (ch[ord[i2]].kept < 3) ch[ord[i2]].kept = 0;
+        for (i2 = k = 0; i2 < n; ++i2) if (ch[ord[i2]].kept != 0) ord[k++] = ord[i2];
+        n = k;
+    }
+    // ---- emit kept chains with contiguous seeds
+    DevChain *oc = chn + base;
+    DevSeed *os = seeds_out + base;
+    int n_seed = 0;
+    for (int i = 0; i < n; i++) {
+        const WChain &c = ch[ord[i]];
+        DevChain d;
+        d.pos = c.pos; d.seed_off = base + n_seed; d.n = c.n; d.rid = c.rid; d.w = c.w; d.kept = c.kept; d.first = c.first;
+        d.is_alt = c.is_alt; d.read = r; d.frac_rep = frac_rep; d.rmax0 = 0; d.rmax1 = 0;
+        const int s0 = n_seed;
+        for (int si = c.head; si >= 0; si = sd[si].next) {
+            DevSeed s; s.rbeg = sd[si].rbeg; s.qbeg = sd[si].qbeg; s.len = sd[si].len; s.score = sd[si].len; s.aln = -1;
+            os[n_seed++] = s;
+        }
+        d.reg0 = 0; d.pad = 0;
+        for (int t = s0; t < n_seed; t++) seed_owner[base + t] = r;
+        oc[i] = d;
+    }
+    n_chain_out[r] = n;
+    n_reg_out[r] = 0;              // set by k_chain_finish
+}
+
 // The working set of one read while it is chained: chains, seeds, B-tree nodes, an order array.  The lane-per-read kernel keeps
 // them in the read's slices of global arrays; the wave-per-read kernel of seed-rich reads keeps them in LDS (k_chain_heavy).
 struct ChainWork {
@@ -315,70 +384,7 @@ static __device__ void chain_one_read(const DevIndex &ix, const ChainParams &o, 
         if (c.w >= o.min_chain_weight) ord[k++] = ord[i];
     }
     if (k == 0 && n > 0) k = 1;      // quirk: an empty survivor list still processes the untouched a_[0] (bwamem.cpp:529-546)
-    n = k;
-    if (n > 0) {
-        k_introsort_flat(n, ord, [&](int32_t x, int32_t y) { return ch[x].w > ch[y].w; });     // flt_lt, bwamem.cpp:61
-        // `kept chain list` reuses the tail of the order array's sibling: indices into ord
-        int32_t *kept_list = (int32_t *)nodes;                   // the B-tree is no longer needed
-        int n_kept = 0;
-        ch[ord[0]].kept = 3;
-        kept_list[n_kept++] = 0;
-        for (int i = 1; i < n; ++i) {
-            WChain &ci = ch[ord[i]];
-            const int beg_i = ci.first_qbeg, end_i = ci.last_qbeg + ci.last_len;
-            int large_ovlp = 0, kk;
-            for (kk = 0; kk < n_kept; ++kk) {
-                const int j = kept_list[kk];
-                WChain &cj = ch[ord[j]];
-                const int beg_j = cj.first_qbeg, end_j = cj.last_qbeg + cj.last_len;
-                const int b_max = beg_j > beg_i ? beg_j : beg_i;
-                const int e_min = end_j < end_i ? end_j : end_i;
-                if (e_min > b_max && (!cj.is_alt || ci.is_alt)) {
-                    const int li = end_i - beg_i, lj = end_j - beg_j;
-                    const int min_l = li < lj ? li : lj;
-                    if (e_min - b_max >= min_l * o.mask_level && min_l < o.max_chain_gap) {
-                        large_ovlp = 1;
-                        if (cj.first < 0) cj.first = i;
-                        if (ci.w < cj.w * o.drop_ratio && cj.w - ci.w >= o.min_seed_len << 1) break;
-                    }
-                }
-            }
-            if (kk == n_kept) { kept_list[n_kept++] = i; ci.kept = large_ovlp ? 2 : 3; }
-        }
-        for (int i = 0; i < n_kept; ++i) {
-            const WChain &c = ch[ord[kept_list[i]]];
-            if (c.first >= 0) ch[ord[c.first]].kept = 1;
-        }
-        int i2;
-        for (i2 = k = 0; i2 < n; ++i2) {
-            const int kp = ch[ord[i2]].kept;
-            if (kp == 0 || kp == 3) continue;
-            if (++k >= o.max_chain_extend) break;
-        }
-        for (; i2 < n; ++i2) if (ch[ord[i2]].kept < 3) ch[ord[i2]].kept = 0;
-        for (i2 = k = 0; i2 < n; ++i2) if (ch[ord[i2]].kept != 0) ord[k++] = ord[i2];
-        n = k;
-    }
-    // ---- emit kept chains with contiguous seeds
-    DevChain *oc = chn + base;
-    DevSeed *os = seeds_out + base;
-    int n_seed = 0;
-    for (int i = 0; i < n; i++) {
-        const WChain &c = ch[ord[i]];
-        DevChain d;
-        d.pos = c.pos; d.seed_off = base + n_seed; d.n = c.n; d.rid = c.rid; d.w = c.w; d.kept = c.kept; d.first = c.first;
-        d.is_alt = c.is_alt; d.read = r; d.frac_rep = frac_rep; d.rmax0 = 0; d.rmax1 = 0;
-        const int s0 = n_seed;
-        for (int si = c.head; si >= 0; si = sd[si].next) {
-            DevSeed s; s.rbeg = sd[si].rbeg; s.qbeg = sd[si].qbeg; s.len = sd[si].len; s.score = sd[si].len; s.aln = -1;
-            os[n_seed++] = s;
-        }
-        d.reg0 = 0; d.pad = 0;
-        for (int t = s0; t < n_seed; t++) seed_owner[base + t] = r;
-        oc[i] = d;
-    }
-    n_chain_out[r] = n;
-    n_reg_out[r] = 0;              // set by k_chain_finish
+    chain_finish_read(o, r, ch, sd, ord, (int32_t *)nodes, k, base, frac_rep, chn, seeds_out, seed_owner, n_chain_out, n_reg_out);
 }
 
 __global__ void __launch_bounds__(128, 6)
@@ -481,6 +487,254 @@ k_chain_heavy(DevIndex ix, ChainParams o, int n_reads, const int32_t *__restrict
     }
 }
 
+// ---------------------------------------------------------------- long reads: chaining by ISLANDS
+// A 10 kb read brings ~12 000 seeds (a 30 kb read 35 000), and mem_chain_seeds is sequential by definition: every seed meets the B-tree the
+// earlier ones built.  Walked by one lane through the read's global slices that is ~31 us per seed -- one second for the chunk's longest
+// read, which is what the chaining of a long-read chunk took (profiles/r04b_kernel_trace_ont2d.md: 1.07 s of a 1.68 s step).
+// But the seeds of a read interact only NEAR each other: test_and_merge (bwamem.cpp:357-399) lets a seed p join or be swallowed by the chain c
+// below it only if p.rbeg - (c's last seed's end) < max_chain_gap, so once the seeds are filed in buckets of 2^S >= max_chain_gap + (longest
+// seed) reference bases, seeds of buckets that are not adjacent can never meet: for a seed whose `lower` chain (kb_intervalp) lies in another
+// run of occupied buckets the test fails exactly as it does when there is no lower chain at all -- a new chain either way.  So every maximal
+// run of occupied buckets -- an island -- is chained on its own, in the read's seed order, with a B-tree of its own: the ~10 000 stray hits of
+// a read are islands of one or two seeds (no tree at all), the true locus is one island of a few thousand seeds whose tree stays a handful of
+// nodes.  What the rest of the path reads of mem_chain_seeds' result is the chains that pass the weight test IN KEY ORDER (plus their number
+// and, when none passes, the chain with the smallest key: the a_[0] quirk): the islands' survivors are sorted by position afterwards.
+// One thing a private tree cannot reproduce: chains with EQUAL keys -- where a later equal key lands, and which of them kb_intervalp returns,
+// depends on the shape of the whole tree.  An island that is about to create one raises a flag and the read is chained again by the serial code.
+// One wavefront per read: all lanes stage the seeds (position, query span, contig: the two binary searches of bns_intv2rid leave the serial
+// part), file them, number the islands, put the seeds of every island together in seed order (a stable counting sort); then every lane
+// chains islands of its own; then lane 0 finishes the read.  Scratch: the read's slices of the OUTPUT arrays, which nothing has written yet.
+struct IslHash { unsigned long long key; int32_t cnt, start; };        // key = bucket + 1 (0: free); seeds in the island that STARTS at this bucket; its place in `perm`
+struct IslSeed { int64_t rbeg; uint32_t ql; int32_t rid; };           // ql = qbeg | len << 15 | is_alt << 31 (as ChainWork::st_ql)
+static_assert(sizeof(IslHash) == 16 && sizeof(IslSeed) == 16 && sizeof(DevChain) >= 68 && sizeof(DevSeed) >= 24, "island scratch is carved from the output slices");
+
+static __device__ __forceinline__ unsigned isl_slot0(unsigned long long key, int log_h) { return (unsigned)((key * 0x9E3779B97F4A7C15ULL) >> (64 - log_h)); }
+static __device__ int isl_insert(IslHash *h, int log_h, unsigned long long key) {
+    const unsigned mask = (1u << log_h) - 1u;
+    for (unsigned i = isl_slot0(key, log_h);; i = (i + 1) & mask) {
+        const unsigned long long prev = atomicCAS(&h[i].key, 0ULL, key);
+        if (prev == 0ULL || prev == key) return (int)i;
+    }
+}
+static __device__ int isl_find(const IslHash *h, int log_h, unsigned long long key) {
+    const unsigned mask = (1u << log_h) - 1u;
+    for (unsigned i = isl_slot0(key, log_h);; i = (i + 1) & mask) {
+        const unsigned long long k = h[i].key;
+        if (k == key) return (int)i;
+        if (k == 0ULL) return -1;
+    }
+}
+static __device__ __forceinline__ void isl_sync() {              // lanes of one wavefront handing GLOBAL data to each other
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
+// one island: the seeds perm[start .. start + tot) in seed order; chains / seeds get the ids start, start + 1, ... of the read's slices
+static __device__ void isl_build(const DevIndex &ix, const ChainParams &o, const IslSeed *st, const int32_t *perm, int start, int tot,
+                                 WChain *ch, WSeed *sd, BtNode *nd, int32_t *ord, int *s_nsurv, int *s_ntot, int *s_dup, unsigned long long *s_min) {
+    int n_ch = start, n_sd = start;
+    bool dup = false;
+    if (tot == 1) {                                              // a stray hit: a chain of one seed, no tree
+        const IslSeed q = st[perm[start]];
+        WSeed s; s.rbeg = q.rbeg; s.qbeg = (int)(q.ql & 0x7fffu); s.len = (int)((q.ql >> 15) & 0xffffu); s.next = -1; s.pad = 0;
+        WChain c2;
+        c2.pos = s.rbeg; c2.last_rbeg = s.rbeg; c2.first_qbeg = s.qbeg; c2.last_qbeg = s.qbeg; c2.last_len = s.len;
+        c2.n = 1; c2.rid = q.rid; c2.is_alt = (int)(q.ql >> 31); c2.head = c2.tail = start; c2.w = 0; c2.kept = 0; c2.first = -1; c2.pad = 0;
+        sd[start] = s; ch[start] = c2;
+        n_ch = start + 1;
+    } else {
+        BTree bt; bt.nodes = nd + start; bt.n_nodes = 0; bt.n_keys = 0; bt.ch = ch;
+        bt.root = bt_new(bt, 0);
+        for (int idx = start; idx < start + tot; idx++) {
+            const IslSeed q = st[perm[idx]];
+            WSeed s; s.rbeg = q.rbeg; s.qbeg = (int)(q.ql & 0x7fffu); s.len = (int)((q.ql >> 15) & 0xffffu); s.next = -1; s.pad = 0;
+            int to_add = 0;
+            if (bt.n_keys) {
+                const int lower = bt_lower(bt, s.rbeg);
+                if (lower < 0) to_add = 1;
+                else {
+                    const int m = test_and_merge(o, ix.l_pac, ch[lower], s, q.rid, sd, n_sd);
+                    if (m == 2) n_sd++;
+                    else if (m == 0) { to_add = 1; if (ch[lower].pos == s.rbeg) dup = true; }      // an equal key: the private tree cannot say where it goes
+                }
+            } else to_add = 1;
+            if (to_add) {
+                WChain c2;
+                c2.pos = s.rbeg; c2.last_rbeg = s.rbeg; c2.first_qbeg = s.qbeg; c2.last_qbeg = s.qbeg; c2.last_len = s.len;
+                c2.n = 1; c2.rid = q.rid; c2.is_alt = (int)(q.ql >> 31); c2.head = c2.tail = n_sd; c2.w = 0; c2.kept = 0; c2.first = -1; c2.pad = 0;
+                sd[n_sd] = s; n_sd++;
+                ch[n_ch] = c2;
+                bt_put(bt, n_ch);
+                n_ch++;
+            }
+        }
+    }
+    unsigned long long mn = ~0ULL;
+    for (int i = start; i < n_ch; i++) {                         // the weight test of mem_chain_flt (bwamem.cpp:516-528), island by island
+        WChain &c = ch[i];
+        c.first = -1; c.kept = 0;
+        c.w = chain_weight(c, sd);
+        if (c.w >= o.min_chain_weight) ord[atomicAdd(s_nsurv, 1)] = i;
+        const unsigned long long key = (unsigned long long)c.pos << 24 | (unsigned)i;
+        mn = mn < key ? mn : key;
+    }
+    atomicAdd(s_ntot, n_ch - start);
+    atomicMin(s_min, mn);
+    if (dup) atomicAdd(s_dup, 1);
+}
+
+__global__ void __launch_bounds__(64)
+k_chain_islands(DevIndex ix, ChainParams o, int n_reads, const int32_t *__restrict__ len, const bm2_smem_t *__restrict__ smems,
+                const int32_t *__restrict__ smem_cnt, const int64_t *__restrict__ smem_off, const int64_t *__restrict__ sa_off,
+                const int64_t *__restrict__ sa_coord, WChain *wchain, WSeed *wseed, BtNode *nodes, int32_t *order,
+                DevChain *chn, DevSeed *seeds_out, int32_t *seed_owner, int32_t *cut_all, int32_t *n_chain_out, int32_t *n_reg_out, int32_t *n_chain0_out,
+                const int32_t *__restrict__ heavy /* read ids, heavy ones first */, const int64_t *__restrict__ n_heavy_p,
+                const int32_t *__restrict__ n_sa_read, int lo, unsigned long long *item_cur, unsigned long long *n_fallback) {
+    __shared__ int s_nsurv, s_ntot, s_dup;
+    __shared__ unsigned long long s_min;
+    const int lane = threadIdx.x;
+    const unsigned long long lt_mask = lane ? (~0ULL >> (64 - lane)) : 0ULL;
+    const int64_t n_heavy = *n_heavy_p;
+    for (;;) {
+        // (every lane takes part in the atomic and the body sits in an `if`: see the note on work loops in smem.hip)
+        const unsigned long long it = atomicAdd(item_cur, lane == 0 ? 1ULL : 0ULL);
+        const int64_t hid = (int64_t)(((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(it >> 32)) << 32) |
+                                      (unsigned)__builtin_amdgcn_readfirstlane((unsigned)it));
+        if (hid >= n_heavy) break;
+        const int r = __builtin_amdgcn_readfirstlane(heavy[hid]);
+        const int ns = __builtin_amdgcn_readfirstlane(n_sa_read[r]);
+        if (ns > lo) {
+        const int n_sm = __builtin_amdgcn_readfirstlane(smem_cnt[r]);
+        if (lane == 0) { n_chain_out[r] = 0; n_reg_out[r] = 0; if (n_chain0_out) n_chain0_out[r] = 0; }
+        const int64_t so = smem_off[r];
+        const int64_t base = sa_off[so];
+        const int n_sa = n_sm > 0 ? (int)(sa_off[so + n_sm] - base) : 0;
+        if (n_sm > 1 && n_sa >= 64 && len[r] >= o.min_seed_len) {     // (a read that comes here has more than `lo` seeds: the block rule of one-SMEM reads cannot apply)
+        WChain *ch = wchain + base; WSeed *sd = wseed + base; BtNode *nd = nodes + base; int32_t *ord = order + base;
+        IslHash *hash = (IslHash *)(chn + base);
+        IslSeed *st = (IslSeed *)(seeds_out + base);
+        // (chn slice, 72 B per seed: the table, < 64 B per seed, then the island list; seeds_out slice, 24 B per seed: staged seed, its island, the permutation)
+        int32_t *cslot = (int32_t *)(st + n_sa), *perm = cslot + n_sa, *clist = (int32_t *)((char *)(chn + base) + (size_t)64 * n_sa), *cut = cut_all + base;
+        int log_h = 7;
+        while ((1 << log_h) < 2 * n_sa) log_h++;
+        const int H = 1 << log_h;                                    // < 4 n_sa entries of 16 bytes: inside the read's slice of chn
+        // ---- stage: SMEM cuts, the bucket width, the table
+        for (int i = lane; i < H; i += 64) { IslHash e; e.key = 0ULL; e.cnt = 0; e.start = 0; hash[i] = e; }
+        int mx = 0;
+        for (int i = lane; i < n_sm; i += 64) {
+            cut[i] = (int32_t)(sa_off[so + i + 1] - base);           // seeds of SMEM i end here
+            const int l = (int)(smems[so + i].n + 1 - smems[so + i].m);
+            mx = mx > l ? mx : l;
+        }
+        for (int d = 32; d > 0; d >>= 1) { const int y = __shfl_xor(mx, d); mx = mx > y ? mx : y; }
+        int S = 1;
+        while ((1LL << S) < (long long)o.max_chain_gap + mx + 1) S++;
+        isl_sync();
+        // ---- every seed: position, query span, contig; its bucket goes into the table
+        for (int t = lane; t < n_sa; t += 64) {
+            int a = 0, b = n_sm - 1;                                  // the seed's SMEM: first i with cut[i] > t
+            while (a < b) { const int mid = (a + b) >> 1; if (cut[mid] > t) b = mid; else a = mid + 1; }
+            const int qbeg = (int)smems[so + a].m, slen = (int)(smems[so + a].n + 1 - smems[so + a].m);
+            const int64_t rbeg = sa_coord[base + t];
+            const int rid = intv2rid(ix, rbeg, rbeg + slen);
+            const uint32_t alt = rid >= 0 && ix.ann_is_alt[rid] ? 1u : 0u;
+            IslSeed q; q.rbeg = rbeg; q.ql = (uint32_t)qbeg | (uint32_t)slen << 15 | alt << 31; q.rid = rid;
+            st[t] = q;
+            if (rid >= 0) (void)isl_insert(hash, log_h, (unsigned long long)(rbeg >> S) + 1ULL);      // (rid < 0: the seed is skipped, bwamem.cpp:915-919)
+        }
+        isl_sync();
+        // ---- the island of every seed = the first bucket of its run of occupied buckets
+        for (int t = lane; t < n_sa; t += 64) {
+            int slot = -1;
+            if (st[t].rid >= 0) {
+                long long b = st[t].rbeg >> S;
+                while (b > 0 && isl_find(hash, log_h, (unsigned long long)b) >= 0) b--;      // key of bucket b - 1 is b
+                slot = isl_find(hash, log_h, (unsigned long long)b + 1ULL);
+                atomicAdd(&hash[slot].cnt, 1);
+            }
+            cslot[t] = slot;
+        }
+        isl_sync();
+        // ---- places: prefix sums of the island sizes over the table, the list of islands
+        int run = 0, n_comp = 0;
+        for (int h0 = 0; h0 < H; h0 += 64) {
+            const int c = hash[h0 + lane].cnt;
+            int x = c;
+            for (int d = 1; d < 64; d <<= 1) { const int y = __shfl(x, lane >= d ? lane - d : lane); if (lane >= d) x += y; }
+            hash[h0 + lane].start = run + x - c;
+            const unsigned long long m = __ballot(c > 0);
+            if (c > 0) clist[n_comp + __popcll(m & lt_mask)] = h0 + lane;
+            n_comp += __popcll(m);
+            run += __shfl(x, 63);
+        }
+        isl_sync();
+        // ---- the seeds of an island together, in seed order: blocks of 64 seeds in order, inside a block the lanes of one island ranked by lane
+        // (`start` of an island with several seeds moves on as its seeds are placed: it ends at start + cnt)
+        for (int t0 = 0; t0 < n_sa; t0 += 64) {
+            const int t = t0 + lane;
+            const int slot = t < n_sa ? cslot[t] : -1;
+            int tot = 0, stt = 0;
+            if (slot >= 0) { tot = hash[slot].cnt; stt = hash[slot].start; }
+            const bool multi = slot >= 0 && tot > 1;
+            if (slot >= 0 && tot == 1) perm[stt] = t;
+            unsigned long long rem = __ballot(multi);
+            const bool any_multi = rem != 0ULL;
+            while (rem) {
+                const int leader = __ffsll((long long)rem) - 1;
+                const int key = __shfl(slot, leader);
+                const bool mine = multi && slot == key;
+                const unsigned long long m = __ballot(mine);
+                if (mine) perm[stt + __popcll(m & lt_mask)] = t;
+                if (lane == leader) hash[key].start = stt + __popcll(m);
+                rem &= ~m;
+            }
+            if (any_multi) isl_sync();
+        }
+        if (lane == 0) { s_nsurv = 0; s_ntot = 0; s_dup = 0; s_min = ~0ULL; }
+        isl_sync();
+        // ---- the islands, one per lane at a time (lanes diverge from here to the next rendezvous: no wavefront primitive inside)
+        for (int k = lane; k < n_comp; k += 64) {
+            const int slot = clist[k];
+            const int tot = hash[slot].cnt;
+            const int start = hash[slot].start - (tot > 1 ? tot : 0);
+            isl_build(ix, o, st, perm, start, tot, ch, sd, nd, ord, &s_nsurv, &s_ntot, &s_dup, &s_min);
+        }
+        isl_sync();
+        // ---- the read
+        if (lane == 0) {
+            if (s_dup) {                                             // chains with equal keys: the serial code on the read's slices
+                atomicAdd(n_fallback, 1ULL);
+                chain_one_read<false>(ix, o, r, n_reads, len, smems, smem_cnt, smem_off, sa_off, sa_coord, wchain, wseed, nodes, order, chn, seeds_out,
+                                      seed_owner, n_chain_out, n_reg_out, n_chain0_out, -1, nullptr, 0);
+            } else {
+                const int n_all = s_ntot;
+                if (n_chain0_out) n_chain0_out[r] = n_all;
+                int b = 0, e = 0, l_rep = 0;
+                for (int i = 0; i < n_sm; i++) {                     // l_rep, bwamem.cpp:849-861
+                    if (!(smems[so + i].s > o.max_occ)) continue;
+                    const int sb = (int)smems[so + i].m, se = (int)smems[so + i].n + 1;
+                    if (sb > e) { l_rep += e - b; b = sb; e = se; }
+                    else e = e > se ? e : se;
+                }
+                l_rep += e - b;
+                int k = s_nsurv;
+                if (k == 0 && n_all > 0) { ord[0] = (int32_t)(s_min & 0xffffffULL); k = 1; }       // the a_[0] quirk: the chain with the smallest key
+                else if (k > 1) k_introsort_flat(k, ord, [&](int32_t x, int32_t y) { return ch[x].pos < ch[y].pos; });     // key order (keys are distinct here)
+                chain_finish_read(o, r, ch, sd, ord, (int32_t *)nd, k, base, (float)l_rep / len[r], chn, seeds_out, seed_owner, n_chain_out, n_reg_out);
+                atomicAdd(n_fallback + 1, 1ULL);                     // reads chained by islands
+                atomicAdd(n_fallback + 2, (unsigned long long)n_comp);      // islands
+            }
+        }
+        isl_sync();
+        } else if (lane == 0) {                                      // (too few seeds for the table's place in the slices -- cannot happen above `lo` >= 64 -- or nothing to chain)
+            chain_one_read<false>(ix, o, r, n_reads, len, smems, smem_cnt, smem_off, sa_off, sa_coord, wchain, wseed, nodes, order, chn, seeds_out,
+                                  seed_owner, n_chain_out, n_reg_out, n_chain0_out, -1, nullptr, 0);
+        }
+        }
+    }
+}
+
 // After the (optional) short-seed filter: reference window, extension order and reg slots of every kept chain
 // (the task-building part of mem_chain2aln_across_reads_V2, bwamem.cpp:2127-2223).  One read per lane.
 __global__ void __launch_bounds__(128)
@@ -561,7 +815,8 @@ int bm2_launch_chain(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_
                      WChain *wchain, WSeed *wseed, BtNode *nodes, int32_t *order, DevChain *chn, DevSeed *seeds_out,
                      int32_t *seed_owner,
                      int32_t *n_chain_out, int32_t *n_reg_out, int32_t *n_chain0_out, const int32_t *perm,
-                     int heavy_thr, const int64_t *n_heavy_dev, const int32_t *n_sa_read, unsigned long long *item_cur /* one per tier + 1 */, int max_len) {
+                     int heavy_thr, const int64_t *n_heavy_dev, const int32_t *n_sa_read, unsigned long long *item_cur /* one per tier + 2 */, int max_len,
+                     int32_t *isl_cut /* scratch of the island kernel: one int per SA coordinate */) {
     if (n_reads <= 0) return BM2_OK;
     hipStream_t s = c->stream;
     const bool heavy = heavy_thr >= 0 && n_heavy_dev != nullptr;
@@ -578,8 +833,9 @@ int bm2_launch_chain(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_
         // reads with more seeds than the largest tier holds: a launch of their own where they are the norm (long reads), otherwise the last tier's
         const bool own_overflow = max_len >= bm2_knob("BM2_CHAIN_OVF_MIN_LEN", 1000);
         int lo = heavy_thr;
+        const int tier_max = own_overflow ? bm2_knob("BM2_CHAIN_TIER_MAX", 1 << 30) : 1 << 30;     // (a test hook: tiers beyond it are left out, their reads go to the launch for long reads)
         for (int t = 0; t < BM2_CHAIN_TIERS; t++) {
-            if (caps[t] <= lo) continue;
+            if (caps[t] <= lo || caps[t] > tier_max) continue;
             hipStream_t sk = c->side_stream[2 + t];
             const size_t lds = bm2_chain_lds_bytes(caps[t], stage);
             const int per_cu_max = bm2_knob("BM2_CHAIN_WAVES_PER_CU", 16);
@@ -598,11 +854,18 @@ int bm2_launch_chain(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_
         // (Short-read chunks keep the old routing: a read of theirs beyond 1000 seeds is a rarity, and one more launch scanning the heavy list is not free.)
         if (own_overflow) {
             hipStream_t sk = c->side_stream[2 + BM2_CHAIN_TIERS];
-            const int per_cu = bm2_knob("BM2_CHAIN_OVF_WAVES_PER_CU", 32);
             (void)hipStreamWaitEvent(sk, c->ev_fork, 0);
-            hipLaunchKernelGGL(k_chain_heavy, dim3(c->n_cu * per_cu), dim3(64), bm2_chain_lds_bytes(0, 0), sk, c->ix, o, n_reads, len, smems, smem_cnt, smem_off, sa_off,
-                               sa_coord, wchain, wseed, nodes, order, chn, seeds_out, seed_owner, n_chain_out, n_reg_out, n_chain0_out, perm,
-                               n_heavy_dev, n_sa_read, lo, 0, 1, item_cur + BM2_CHAIN_TIERS, 0);
+            if (bm2_knob("BM2_CHAIN_ISLANDS", 1)) {                 // chaining by islands (k_chain_islands): one wavefront per read, every lane at work
+                const int per_cu = bm2_knob("BM2_CHAIN_ISL_WAVES_PER_CU", 32);
+                hipLaunchKernelGGL(k_chain_islands, dim3(c->n_cu * per_cu), dim3(64), 0, sk, c->ix, o, n_reads, len, smems, smem_cnt, smem_off, sa_off,
+                                   sa_coord, wchain, wseed, nodes, order, chn, seeds_out, seed_owner, isl_cut, n_chain_out, n_reg_out, n_chain0_out, perm,
+                                   n_heavy_dev, n_sa_read, lo, item_cur + BM2_CHAIN_TIERS, item_cur + BM2_CHAIN_TIERS + 1);
+            } else {
+                const int per_cu = bm2_knob("BM2_CHAIN_OVF_WAVES_PER_CU", 32);
+                hipLaunchKernelGGL(k_chain_heavy, dim3(c->n_cu * per_cu), dim3(64), bm2_chain_lds_bytes(0, 0), sk, c->ix, o, n_reads, len, smems, smem_cnt, smem_off, sa_off,
+                                   sa_coord, wchain, wseed, nodes, order, chn, seeds_out, seed_owner, n_chain_out, n_reg_out, n_chain0_out, perm,
+                                   n_heavy_dev, n_sa_read, lo, 0, 1, item_cur + BM2_CHAIN_TIERS, 0);
+            }
             (void)hipEventRecord(c->ev_join[2 + BM2_CHAIN_TIERS], sk);
             (void)hipStreamWaitEvent(s, c->ev_join[2 + BM2_CHAIN_TIERS], 0);
         }

@@ -17,7 +17,7 @@ int bm2_launch_chain(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_
                      WChain *wchain, WSeed *wseed, BtNode *nodes, int32_t *order, DevChain *chn, DevSeed *seeds_out,
                      int32_t *seed_owner,
                      int32_t *n_chain_out, int32_t *n_reg_out, int32_t *n_chain0_out, const int32_t *perm,
-                     int heavy_thr, const int64_t *n_heavy_dev, const int32_t *n_sa_read, unsigned long long *item_cur, int max_len);
+                     int heavy_thr, const int64_t *n_heavy_dev, const int32_t *n_sa_read, unsigned long long *item_cur, int max_len, int32_t *isl_cut);
 int bm2_launch_chain_finish(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_t *len, const int64_t *read_base,
                             const int32_t *n_chain, DevChain *chn, DevSeed *seeds_out, int32_t *srt_out, int32_t *reg_seed,
                             int32_t *reg_chain, int32_t *n_reg_out);
@@ -169,8 +169,8 @@ static int run_seeding(bm2_ctx *c, Batch *b, const bm2_opt *opt, bool with_sal) 
     int rc;
     hipStream_t s = c->stream;
     const SeedParams sp = seed_params(opt);
-    if ((rc = bm2_reserve(b->counters, 16 * 8))) return rc;
-    if ((rc = bm2_check(hipMemsetAsync(b->counters.p, 0, 16 * 8, s), "memset counters"))) return rc;
+    if ((rc = bm2_reserve(b->counters, 24 * 8))) return rc;
+    if ((rc = bm2_check(hipMemsetAsync(b->counters.p, 0, 24 * 8, s), "memset counters"))) return rc;
     if ((rc = bm2_reserve(b->smem_cnt, (size_t)(n + 1) * 4))) return rc;
     if ((rc = bm2_reserve(b->smem_off, (size_t)(n + 1) * 8))) return rc;
     // task kernels with persistent lanes (smem.hip); workspace sizes are learned: a run that overflows one of them reports
@@ -368,7 +368,7 @@ static int batch_run_one(bm2_ctx *c, const bm2_opt *opt, StageGate *gate = nullp
                                (DevChain *)b->chn.p, (DevSeed *)b->seeds.p, (int32_t *)b->seed_owner.p,
                                (int32_t *)b->n_chain.p, (int32_t *)b->n_reg.p, (int32_t *)b->n_chain0.p, (const int32_t *)b->perm.p,
                                n_heavy_chain ? thr_sa : -1, n_heavy_chain, (const int32_t *)b->n_sa_read.p,
-                               (unsigned long long *)b->counters.p + 10, b->max_len))) return rc;      // counters[10..15]: work cursors of the tiers and of the overflow launch
+                               (unsigned long long *)b->counters.p + 10, b->max_len, (int32_t *)b->srt.p))) return rc;      // counters[10..15]: work cursors of the tiers and of the overflow launch, [16]: reads the island kernel chained serially
     if (any_flt) {
         if ((rc = bm2_launch_seed_filter(c, cp, (const int8_t *)b->mat25.p, n, n_sa, (const uint8_t *)b->enc.p, (const int64_t *)b->off.p,
                                          (const int32_t *)b->len.p, (const int32_t *)b->min_hsp.p, (const int64_t *)b->read_base.p,
@@ -812,7 +812,7 @@ extern "C" int bm2_batch_fetch(bm2_ctx *c, const char *what, void *out, int64_t 
         { "sa_coord", &b->sa_coord, ns * 8 }, { "read_base", &b->read_base, (size_t)n * 8 },
         { "n_chain", &b->n_chain, (size_t)n * 4 }, { "n_chain0", &b->n_chain0, (size_t)n * 4 }, { "n_reg", &b->n_reg, (size_t)n * 4 },
         { "n_out", &b->n_out, (size_t)n * 4 }, { "chn", &b->chn, ns * sizeof(DevChain) }, { "seeds", &b->seeds, ns * sizeof(DevSeed) },
-        { "seed_counters", &b->seedc, (size_t)21 * 8 }, { "counters", &b->counters, (size_t)16 * 8 }, { "regs_raw", &b->regs, ns * sizeof(DevReg) }, { "reg_seed", &b->reg_seed, ns * 4 }, { "wchain", &b->wchain, ns * sizeof(WChain) },
+        { "seed_counters", &b->seedc, (size_t)21 * 8 }, { "counters", &b->counters, (size_t)24 * 8 }, { "regs_raw", &b->regs, ns * sizeof(DevReg) }, { "reg_seed", &b->reg_seed, ns * 4 }, { "wchain", &b->wchain, ns * sizeof(WChain) },
     };
     if (!strcmp(what, "seed_attempts")) {
         *n_bytes = 4;

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import bm2
-from helpers import (ONT2D, build_index, first_diff, gpu_stage_records, load_golden, regs_to_records)
+from helpers import (ONT2D, build_index, chain_mask, first_diff, gpu_stage_records, load_golden, regs_to_records)
 from tools import oracle, refio, synth
 
 pytestmark = pytest.mark.gpu
@@ -283,6 +283,37 @@ def test_long_reads_fresh_vs_oracle(gpu_ctx_factory, tmp_path):
     ctx = gpu_ctx_factory(fa)
     regs, reg_off, st = ctx.seed_chain_extend(enc, off, ln, bm2.default_opt(**ONT2D))
     _same(exp["REGPRG"], regs_to_records(regs, reg_off), "REGPRG")
+
+
+def test_long_reads_chained_by_islands(gpu_ctx_factory, tmp_path, monkeypatch):
+    # mem_chain_seeds of seed-rich reads cut into islands of reference buckets (k_chain_islands, chain.hip): a repeat-rich genome, so that a read
+    # brings hundreds of stray hits -- islands of one seed -- beside its locus; the tiers of the wavefront-per-read kernel are switched off so
+    # that every read beyond 100 seeds takes the island path.  Chains, seeds and regs must equal the oracle's; the kernel says how many reads it
+    # chained by islands and how many it handed to the serial code (equal chain keys).
+    monkeypatch.setenv("BM2_CHAIN_TIER_MAX", "64")
+    names, ctg, alts = synth.make_genome(43, [400000, 150000], alt_contigs=1, alt_len=5000, n_repeat_families=40, repeat_len=(100, 2000),
+                                         copies=(3, 80), divergence=(0.0, 0.03))
+    fa = str(tmp_path / "g.fa")
+    synth.write_fasta(fa, names, ctg)
+    synth.write_alt(fa + ".alt", alts)
+    if not build_index(fa):
+        pytest.skip("oracle/_ref reference binary not present")
+    reads = synth.make_reads_long(44, ctg, 40, mean_len=5000, max_len=20000)
+    enc, off, ln = refio.pack_reads(reads)
+    ix = oracle.Index(fa)
+    try:
+        exp = ix.run(enc, off, ln, oracle.default_opt(**ONT2D))
+    finally:
+        ix.close()
+    ctx = gpu_ctx_factory(fa)
+    regs, reg_off, st = ctx.seed_chain_extend(enc, off, ln, bm2.default_opt(**ONT2D))
+    cn = ctx.batch_fetch("counters", np.uint64)
+    C, S, R = gpu_stage_records(ctx, bm2, len(ln))
+    _same(chain_mask(exp["CHN1"]), chain_mask(C), "CHN1")
+    _same(exp["SEED1"], S, "SEED1")
+    _same(exp["REGPRG"], regs_to_records(regs, reg_off), "REGPRG")
+    assert int(cn[17]) + int(cn[16]) >= 30 and int(cn[18]) > 10 * int(cn[17]), (int(cn[16]), int(cn[17]), int(cn[18]))
+    print("island path: %d reads, %d islands, %d reads chained serially (equal keys)" % (int(cn[17]), int(cn[18]), int(cn[16])))
 
 
 @pytest.mark.parametrize("kw", [dict(e_del=2, e_ins=3), dict(zdrop=0), dict(zdrop=200),
