@@ -713,16 +713,16 @@ def bench_bsw(a, bm2, torch, dist_util, rank, world, local, emu, seed):
         "value": world * n / TASKS_PER_READ * a.steps / dt, "unit": "reads/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32",
         "data": "synthetic" if not emu else "synthetic; HOST EMULATOR RUN (not a measurement)",
-        "config": {"workload": "config 2 shape: the banded-SW kernel alone (S1: bm2_bsw_upload / bm2_bsw_run, one SeqPair per wavefront, band %d) on %d "
+        "config": {"workload": "config 2 shape: the banded-SW kernel alone (S1: bm2_bsw_upload / bm2_bsw_run: the pairs sorted on the device, one per LANE where query and scores fit the lane kernel, one per wavefront otherwise; band %d) on %d "
                                "synthetic extension tasks per GPU per step shaped like those of 150 bp reads, batch resident in HBM; `value` = tasks/s "
                                "divided by the %.3f tasks per read the pe150 workload measures" % (w, n, TASKS_PER_READ),
                    "pairs_per_gpu_per_step": n, "tasks_per_read": TASKS_PER_READ, "parallelism": "one batch per GPU over %d GPU(s), no collectives" % world},
         "pairs_per_s": world * n * a.steps / dt,
-        "roofline": {"kernel": "k_bsw_pairs", "bound": "hbm", "achieved": algo_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0, "peak": HBM_PEAK_GBS,
+        "roofline": {"kernel": "k_bsw_lanes (+ k_bsw_list)", "bound": "hbm", "achieved": algo_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": algo_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if k_ms > 0 else 0.0, "traffic": None,
                      "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": k_ms, "launches_per_step": 1,
                      "note": "integer DP: the kernel is bound by VALU / LDS issue, not by HBM (each base is read once); `extend_kernel.gcups` is its rate"},
-        "extend_kernel": {"kernel": "k_bsw_pairs", "gcups": cells / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0, "avg_launch_ms": k_ms, "cells_per_launch": cells},
+        "extend_kernel": {"kernel": "k_bsw_lanes (+ k_bsw_list)", "gcups": cells / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0, "avg_launch_ms": k_ms, "cells_per_launch": cells},
         "parity": par,
         "cpu_baseline": cb,
     }
@@ -893,15 +893,32 @@ def main():
         bwd_ms = (kern_ms.get("smem.bwd1", 0.0) + kern_ms.get("smem.bwd2", 0.0)) / 2.0          # average launch duration
         bwd_bytes = 128.0 * (ext_of["bwd1"] + ext_of["bwd2"]) / 2.0                              # algorithmic bytes per launch
         ach = bwd_bytes / (bwd_ms * 1e-3) / 1e9 if bwd_ms > 0 else 0.0
+        roof_kernel, roof_launches = "k_bwd", 2
+        fm_kernels = {}                                       # every FM-index kernel of the step against the same peak: 128 algorithmic bytes per backwardExt
+        for kn, ev in (("k_walk<1>", "walk1"), ("k_bwd (pass 1)", "bwd1"), ("k_walk<2>", "walk2"), ("k_bwd (pass 2)", "bwd2")):
+            ms_k = kern_ms.get("smem." + ev, 0.0)
+            if ms_k > 0:
+                gbs = 128.0 * ext_of[ev] / (ms_k * 1e-3) / 1e9
+                fm_kernels[kn] = {"ms": ms_k, "backwardExt": ext_of[ev], "achieved": gbs, "frac": gbs / HBM_PEAK_GBS}
+        w1 = fm_kernels.get("k_walk<1>")
+        if w1 and w1["ms"] > 2.0 * bwd_ms:                    # long reads: the forward walks, not the backward phases, are the seeding stage
+            roof_kernel, roof_launches = "k_walk<1>", 1
+            bwd_ms, bwd_bytes, ach = w1["ms"], 128.0 * w1["backwardExt"], w1["achieved"]
         fm_bytes = 128.0 * st["n_ext"]
         stage_ach = fm_bytes / (smem_ms * 1e-3) / 1e9 if smem_ms > 0 else 0.0
         cells = st["n_sw_cells"]
         ext_ms = stage_ms.get("extend", 0.0)
-        lane_use = wave_cell_share = None
+        lane_use = wave_cell_share = chain_kernel = None
         try:                                                 # the lane kernel's own count of its column-pair trips (128 lane slots each) and the wavefront kernel's cells
             cn = np.asarray(ctx.batch_fetch("counters", np.uint64), np.float64)
             if cn[7] > 0:
                 lane_use, wave_cell_share = float((cn[5] - cn[8]) / (128.0 * cn[7])), float(cn[8] / max(cn[5], 1.0))
+            if cn[17] + cn[16] > 0:                           # the island kernel of long-read chaining (chain.hip): its own counts and phase clock (100 MHz ticks summed over its reads)
+                nr = max(cn[17], 1.0)
+                names = ("table + SMEM cuts", "stage seeds + file buckets", "island of every seed", "places (scan)", "seeds of an island together", "islands chained", "read finished")
+                chain_kernel = {"kernel": "k_chain_islands", "reads_by_islands": int(cn[17]), "reads_chained_serially_equal_keys": int(cn[16]), "islands_per_read": float(cn[18] / nr),
+                                "chains_per_read": float(cn[27] / nr), "chains_past_the_weight_test_per_read": float(cn[26] / nr),
+                                "phase_ms_per_read": {nm: float(cn[19 + i] * 1e-5 / (cn[17] + cn[16])) for i, nm in enumerate(names)}}
         except Exception:                                                             # noqa
             pass
         dominant = max(stage_ms, key=stage_ms.get) if stage_ms else None
@@ -949,11 +966,12 @@ def main():
             "work_per_read": {"backwardExt": st["n_ext"] / n_reads, "lf_steps": st["n_lf"] / n_reads,
                               "sa_lookups": st["n_sa"] / n_reads, "sw_tasks": st["n_sw_tasks"] / n_reads,
                               "sw_cells": cells / n_reads, "regs": st["n_reg"] / n_reads},
-            "roofline": {"kernel": "k_bwd", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"kernel": roof_kernel, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": pmc_src,
                          "achieved_counter": ach_counter,
                          "frac_counter": ach_counter / HBM_PEAK_GBS if ach_counter else None,
-                         "algorithmic_bytes_per_launch": bwd_bytes, "avg_launch_ms": bwd_ms, "launches_per_step": 2,
+                         "algorithmic_bytes_per_launch": bwd_bytes, "avg_launch_ms": bwd_ms, "launches_per_step": roof_launches,
+                         "fm_index_kernels": fm_kernels,
                          "random_line_ceiling_glines": RANDOM_LINE_GLPS,
                          "delivered_glines": lines_counter,
                          "frac_of_random_line_ceiling": lines_counter / RANDOM_LINE_GLPS if lines_counter else None,
@@ -977,6 +995,8 @@ def main():
                               "pmc_source": ext_src,
                               "note": "valu_frac / lds_conflict_frac are of the committed counter pass (its own stage time: pmc_stage_ms), the rest is of this run"},
         }
+        if chain_kernel:
+            out["chain_kernel"] = chain_kernel
         if world == 1 and not a.no_parity and time_left() < 150:
             out["parity"] = {"skipped": "time budget (%.0f s of %.0f s left)" % (time_left(), a.budget_s)}
         elif world == 1 and not a.no_parity:

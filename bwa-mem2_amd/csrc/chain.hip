@@ -276,6 +276,8 @@ static __device__ void chain_finish_read(const ChainParams &o, int r, WChain *ch
     n_reg_out[r] = 0;              // set by k_chain_finish
 }
 
+struct IslSeed { int64_t rbeg; uint32_t ql; int32_t rid; };           // a seed staged in global memory (k_chain_islands): ql = qbeg | len << 15 | is_alt << 31
+
 // The working set of one read while it is chained: chains, seeds, B-tree nodes, an order array.  The lane-per-read kernel keeps
 // them in the read's slices of global arrays; the wave-per-read kernel of seed-rich reads keeps them in LDS (k_chain_heavy).
 struct ChainWork {
@@ -293,7 +295,7 @@ static __device__ void chain_one_read(const DevIndex &ix, const ChainParams &o, 
                                       const int64_t *__restrict__ smem_off, const int64_t *__restrict__ sa_off,
                                       const int64_t *__restrict__ sa_coord, WChain *wchain, WSeed *wseed, BtNode *nodes_g, int32_t *order,
                                       DevChain *chn, DevSeed *seeds_out, int32_t *seed_owner, int32_t *n_chain_out, int32_t *n_reg_out,
-                                      int32_t *n_chain0_out, int heavy_thr, const ChainWork *lw, int lds_cap) {
+                                      int32_t *n_chain0_out, int heavy_thr, const ChainWork *lw, int lds_cap, const IslSeed *ist = nullptr) {
     const int n_sm = smem_cnt[r];
     n_chain_out[r] = 0; n_reg_out[r] = 0;          // (k_chain never gets here with a read it leaves to k_chain_heavy: one writer per read)
     if (n_chain0_out) n_chain0_out[r] = 0;
@@ -335,7 +337,11 @@ static __device__ void chain_one_read(const DevIndex &ix, const ChainParams &o, 
         int si = -1, left = 0, qbeg = 0, slen = 0;
         for (int t = 0; t < n_sa; t++) {
             WSeed s; int rid, alt_staged = 0;
-            if (staged) {
+            if (ist) {                                   // every seed staged in global memory by the island kernel's wavefront
+                const IslSeed q = ist[t];
+                s.rbeg = q.rbeg; s.qbeg = (int)(q.ql & 0x7fffu); s.len = (int)((q.ql >> 15) & 0xffffu); s.next = -1;
+                rid = q.rid; alt_staged = (int)(q.ql >> 31);
+            } else if (staged) {
                 const uint32_t ql = lw->st_ql[t];
                 s.rbeg = lw->st_rbeg[t]; s.qbeg = (int)(ql & 0x7fffu); s.len = (int)((ql >> 15) & 0xffffu); s.next = -1;
                 rid = lw->st_rid[t]; alt_staged = (int)(ql >> 31);
@@ -363,7 +369,7 @@ static __device__ void chain_one_read(const DevIndex &ix, const ChainParams &o, 
             if (to_add) {                                // bwamem.cpp:930-951
                 WChain c2;
                 c2.pos = s.rbeg; c2.last_rbeg = s.rbeg; c2.first_qbeg = s.qbeg; c2.last_qbeg = s.qbeg; c2.last_len = s.len;
-                c2.n = 1; c2.rid = rid; c2.is_alt = staged ? alt_staged : (ix.ann_is_alt[rid] ? 1 : 0); c2.head = c2.tail = n_sd;
+                c2.n = 1; c2.rid = rid; c2.is_alt = (staged || ist) ? alt_staged : (ix.ann_is_alt[rid] ? 1 : 0); c2.head = c2.tail = n_sd;
                 c2.w = 0; c2.kept = 0; c2.first = -1;
                 sd[n_sd] = s; n_sd++;
                 ch[n_ch] = c2;
@@ -499,13 +505,13 @@ k_chain_heavy(DevIndex ix, ChainParams o, int n_reads, const int32_t *__restrict
 // a read are islands of one or two seeds (no tree at all), the true locus is one island of a few thousand seeds whose tree stays a handful of
 // nodes.  What the rest of the path reads of mem_chain_seeds' result is the chains that pass the weight test IN KEY ORDER (plus their number
 // and, when none passes, the chain with the smallest key: the a_[0] quirk): the islands' survivors are sorted by position afterwards.
-// One thing a private tree cannot reproduce: chains with EQUAL keys -- where a later equal key lands, and which of them kb_intervalp returns,
-// depends on the shape of the whole tree.  An island that is about to create one raises a flag and the read is chained again by the serial code.
+// One thing a private tree cannot reproduce: chains with EQUAL keys -- where the later one lands and which of them kb_intervalp returns depend on
+// the shape of the whole tree (isl_build).  An island that is about to create one raises a flag and the read is chained again by the serial code
+// -- on the inputs the wavefront has already staged, so that even that walk makes no look-up of its own besides the tree's.
 // One wavefront per read: all lanes stage the seeds (position, query span, contig: the two binary searches of bns_intv2rid leave the serial
 // part), file them, number the islands, put the seeds of every island together in seed order (a stable counting sort); then every lane
 // chains islands of its own; then lane 0 finishes the read.  Scratch: the read's slices of the OUTPUT arrays, which nothing has written yet.
 struct IslHash { unsigned long long key; int32_t cnt, start; };        // key = bucket + 1 (0: free); seeds in the island that STARTS at this bucket; its place in `perm`
-struct IslSeed { int64_t rbeg; uint32_t ql; int32_t rid; };           // ql = qbeg | len << 15 | is_alt << 31 (as ChainWork::st_ql)
 static_assert(sizeof(IslHash) == 16 && sizeof(IslSeed) == 16 && sizeof(DevChain) >= 68 && sizeof(DevSeed) >= 24, "island scratch is carved from the output slices");
 
 static __device__ __forceinline__ unsigned isl_slot0(unsigned long long key, int log_h) { return (unsigned)((key * 0x9E3779B97F4A7C15ULL) >> (64 - log_h)); }
@@ -546,6 +552,9 @@ static __device__ void isl_build(const DevIndex &ix, const ChainParams &o, const
     } else {
         BTree bt; bt.nodes = nd + start; bt.n_nodes = 0; bt.n_keys = 0; bt.ch = ch;
         bt.root = bt_new(bt, 0);
+        // Equal keys: where a chain lands whose key another chain already has -- after it, or BEFORE it when that chain happens to be the median of
+        // a full node that kb_putp splits on its way down (`if (k > median) ++i`) -- and which of the two a later look-up finds depend on the
+        // shape of the WHOLE tree.  A private tree cannot know: the island raises `dup`, the read is chained again by the serial code.
         for (int idx = start; idx < start + tot; idx++) {
             const IslSeed q = st[perm[idx]];
             WSeed s; s.rbeg = q.rbeg; s.qbeg = (int)(q.ql & 0x7fffu); s.len = (int)((q.ql >> 15) & 0xffffu); s.next = -1; s.pad = 0;
@@ -556,7 +565,7 @@ static __device__ void isl_build(const DevIndex &ix, const ChainParams &o, const
                 else {
                     const int m = test_and_merge(o, ix.l_pac, ch[lower], s, q.rid, sd, n_sd);
                     if (m == 2) n_sd++;
-                    else if (m == 0) { to_add = 1; if (ch[lower].pos == s.rbeg) dup = true; }      // an equal key: the private tree cannot say where it goes
+                    else if (m == 0) { to_add = 1; if (ch[lower].pos == s.rbeg) dup = true; }
                 }
             } else to_add = 1;
             if (to_add) {
@@ -616,6 +625,8 @@ k_chain_islands(DevIndex ix, ChainParams o, int n_reads, const int32_t *__restri
         IslSeed *st = (IslSeed *)(seeds_out + base);
         // (chn slice, 72 B per seed: the table, < 64 B per seed, then the island list; seeds_out slice, 24 B per seed: staged seed, its island, the permutation)
         int32_t *cslot = (int32_t *)(st + n_sa), *perm = cslot + n_sa, *clist = (int32_t *)((char *)(chn + base) + (size_t)64 * n_sa), *cut = cut_all + base;
+        long long tck = wall_clock64();                              // phase clock (lane 0 adds every phase's ticks to the counters behind n_fallback: bm2_batch_fetch("counters"))
+#define ISL_TICK(ph) do { const long long t_now = wall_clock64(); if (lane == 0) atomicAdd(n_fallback + 3 + (ph), (unsigned long long)(t_now - tck)); tck = t_now; } while (0)
         int log_h = 7;
         while ((1 << log_h) < 2 * n_sa) log_h++;
         const int H = 1 << log_h;                                    // < 4 n_sa entries of 16 bytes: inside the read's slice of chn
@@ -631,6 +642,7 @@ k_chain_islands(DevIndex ix, ChainParams o, int n_reads, const int32_t *__restri
         int S = 1;
         while ((1LL << S) < (long long)o.max_chain_gap + mx + 1) S++;
         isl_sync();
+        ISL_TICK(0);
         // ---- every seed: position, query span, contig; its bucket goes into the table
         for (int t = lane; t < n_sa; t += 64) {
             int a = 0, b = n_sm - 1;                                  // the seed's SMEM: first i with cut[i] > t
@@ -644,6 +656,7 @@ k_chain_islands(DevIndex ix, ChainParams o, int n_reads, const int32_t *__restri
             if (rid >= 0) (void)isl_insert(hash, log_h, (unsigned long long)(rbeg >> S) + 1ULL);      // (rid < 0: the seed is skipped, bwamem.cpp:915-919)
         }
         isl_sync();
+        ISL_TICK(1);
         // ---- the island of every seed = the first bucket of its run of occupied buckets
         for (int t = lane; t < n_sa; t += 64) {
             int slot = -1;
@@ -656,6 +669,7 @@ k_chain_islands(DevIndex ix, ChainParams o, int n_reads, const int32_t *__restri
             cslot[t] = slot;
         }
         isl_sync();
+        ISL_TICK(2);
         // ---- places: prefix sums of the island sizes over the table, the list of islands
         int run = 0, n_comp = 0;
         for (int h0 = 0; h0 < H; h0 += 64) {
@@ -669,6 +683,7 @@ k_chain_islands(DevIndex ix, ChainParams o, int n_reads, const int32_t *__restri
             run += __shfl(x, 63);
         }
         isl_sync();
+        ISL_TICK(3);
         // ---- the seeds of an island together, in seed order: blocks of 64 seeds in order, inside a block the lanes of one island ranked by lane
         // (`start` of an island with several seeds moves on as its seeds are placed: it ends at start + cnt)
         for (int t0 = 0; t0 < n_sa; t0 += 64) {
@@ -693,6 +708,7 @@ k_chain_islands(DevIndex ix, ChainParams o, int n_reads, const int32_t *__restri
         }
         if (lane == 0) { s_nsurv = 0; s_ntot = 0; s_dup = 0; s_min = ~0ULL; }
         isl_sync();
+        ISL_TICK(4);
         // ---- the islands, one per lane at a time (lanes diverge from here to the next rendezvous: no wavefront primitive inside)
         for (int k = lane; k < n_comp; k += 64) {
             const int slot = clist[k];
@@ -701,12 +717,13 @@ k_chain_islands(DevIndex ix, ChainParams o, int n_reads, const int32_t *__restri
             isl_build(ix, o, st, perm, start, tot, ch, sd, nd, ord, &s_nsurv, &s_ntot, &s_dup, &s_min);
         }
         isl_sync();
+        ISL_TICK(5);
         // ---- the read
         if (lane == 0) {
             if (s_dup) {                                             // chains with equal keys: the serial code on the read's slices
                 atomicAdd(n_fallback, 1ULL);
                 chain_one_read<false>(ix, o, r, n_reads, len, smems, smem_cnt, smem_off, sa_off, sa_coord, wchain, wseed, nodes, order, chn, seeds_out,
-                                      seed_owner, n_chain_out, n_reg_out, n_chain0_out, -1, nullptr, 0);
+                                      seed_owner, n_chain_out, n_reg_out, n_chain0_out, -1, nullptr, 0, st);
             } else {
                 const int n_all = s_ntot;
                 if (n_chain0_out) n_chain0_out[r] = n_all;
@@ -720,13 +737,16 @@ k_chain_islands(DevIndex ix, ChainParams o, int n_reads, const int32_t *__restri
                 l_rep += e - b;
                 int k = s_nsurv;
                 if (k == 0 && n_all > 0) { ord[0] = (int32_t)(s_min & 0xffffffULL); k = 1; }       // the a_[0] quirk: the chain with the smallest key
-                else if (k > 1) k_introsort_flat(k, ord, [&](int32_t x, int32_t y) { return ch[x].pos < ch[y].pos; });     // key order (keys are distinct here)
+                else if (k > 1) k_introsort_flat(k, ord, [&](int32_t x, int32_t y) { return ch[x].pos < ch[y].pos; });     // key order (the keys are distinct here)
                 chain_finish_read(o, r, ch, sd, ord, (int32_t *)nd, k, base, (float)l_rep / len[r], chn, seeds_out, seed_owner, n_chain_out, n_reg_out);
                 atomicAdd(n_fallback + 1, 1ULL);                     // reads chained by islands
                 atomicAdd(n_fallback + 2, (unsigned long long)n_comp);      // islands
+                atomicAdd(n_fallback + 10, (unsigned long long)k);           // chains that passed the weight test
+                atomicAdd(n_fallback + 11, (unsigned long long)n_all);       // chains
             }
         }
         isl_sync();
+        ISL_TICK(6);
         } else if (lane == 0) {                                      // (too few seeds for the table's place in the slices -- cannot happen above `lo` >= 64 -- or nothing to chain)
             chain_one_read<false>(ix, o, r, n_reads, len, smems, smem_cnt, smem_off, sa_off, sa_coord, wchain, wseed, nodes, order, chn, seeds_out,
                                   seed_owner, n_chain_out, n_reg_out, n_chain0_out, -1, nullptr, 0);
