@@ -69,7 +69,7 @@ static __device__ __forceinline__ int cal_max_gap(const ChainParams &o, int qlen
 
 // ---------------------------------------------------------------- klib B-tree, t = 5 (kbtree.h; kb_init(chn, 512+8), 48-byte keys)
 #define BT_T 5
-struct BTree { BtNode *nodes; int n_nodes, root, n_keys; const WChain *ch; };
+struct BTree { BtNode *nodes; int n_nodes, root, n_keys; const WChain *ch; bool reg = false; };     // reg: nodes in GLOBAL memory, visited through registers (below)
 
 static __device__ __forceinline__ int bt_new(BTree &b, int internal) {
     BtNode &z = b.nodes[b.n_nodes];
@@ -90,8 +90,120 @@ static __device__ int bt_getp_aux(const BTree &b, const BtNode &x, int64_t k, in
     if (r < 0) --begin;
     return begin;
 }
+// ---- a node visited through REGISTERS.  In global memory every probe of a node is a dependent load: the binary search of __kb_getp_aux makes
+// three or four per level, kb_putp two more for the child's fill and pointer -- sixty-odd dependent loads per seed over five levels, a third of
+// them misses.  Here a node comes in with TEN 16-byte loads issued back to back (one latency), the search is nine compares on registers, the
+// fields it then needs are picked by select chains; an insertion into a leaf shifts the keys in registers and stores the node whole.
+// (The ten quads are pinned by an empty asm over every component right after the loads: without it the compiler keeps the 160-byte copy in
+// SCRATCH and turns every constant-index read back into a memory access -- round 3's attempt at this, profiles/r03u_*.)
+struct RNode { uint4 q[10]; };
+static_assert(sizeof(BtNode) == 160, "RNode mirrors BtNode: kpos[9] at dwords 0..17, key[9] at 18..26, ptr[10] at 27..36, is_internal 37, n 38");
+static __device__ __forceinline__ void rn_load(RNode &nd, const BtNode *p) {
+    const uint4 *s = (const uint4 *)p;
+#pragma unroll
+    for (int i = 0; i < 10; i++) nd.q[i] = s[i];
+#pragma unroll
+    for (int i = 0; i < 10; i++) asm volatile("" : "+v"(nd.q[i].x), "+v"(nd.q[i].y), "+v"(nd.q[i].z), "+v"(nd.q[i].w));
+}
+static __device__ __forceinline__ void rn_store(const RNode &nd, BtNode *p) {
+    uint4 *d = (uint4 *)p;
+#pragma unroll
+    for (int i = 0; i < 10; i++) d[i] = nd.q[i];
+}
+template <int D> static __device__ __forceinline__ uint32_t &rn_dw(RNode &nd) {
+    return (D & 3) == 0 ? nd.q[D >> 2].x : (D & 3) == 1 ? nd.q[D >> 2].y : (D & 3) == 2 ? nd.q[D >> 2].z : nd.q[D >> 2].w;
+}
+template <int T> static __device__ __forceinline__ int64_t rn_kpos(RNode &nd) { return (int64_t)((uint64_t)rn_dw<2 * T + 1>(nd) << 32 | rn_dw<2 * T>(nd)); }
+template <int T> static __device__ __forceinline__ void rn_set_kpos(RNode &nd, int64_t v) { rn_dw<2 * T>(nd) = (uint32_t)v; rn_dw<2 * T + 1>(nd) = (uint32_t)((uint64_t)v >> 32); }
+#define RN_FOR9(F) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(8)
+#define RN_FOR10(F) RN_FOR9(F) F(9)
+static __device__ __forceinline__ int rn_n(RNode &nd) { return (int)rn_dw<38>(nd); }
+static __device__ __forceinline__ int rn_internal(RNode &nd) { return (int)rn_dw<37>(nd); }
+static __device__ __forceinline__ int rn_key(RNode &nd, int i) {                 // key[i], 0 <= i < 9
+    int v = 0;
+#define RN_PICK(T) v = i == T ? (int)rn_dw<18 + T>(nd) : v;
+    RN_FOR9(RN_PICK)
+#undef RN_PICK
+    return v;
+}
+static __device__ __forceinline__ int rn_ptr(RNode &nd, int i) {                 // ptr[i], 0 <= i < 10
+    int v = 0;
+#define RN_PICK(T) v = i == T ? (int)rn_dw<27 + T>(nd) : v;
+    RN_FOR10(RN_PICK)
+#undef RN_PICK
+    return v;
+}
+static __device__ __forceinline__ int64_t rn_kpos_at(RNode &nd, int i) {
+    int64_t v = 0;
+#define RN_PICK(T) v = i == T ? rn_kpos<T>(nd) : v;
+    RN_FOR9(RN_PICK)
+#undef RN_PICK
+    return v;
+}
+// __kb_getp_aux on a register node: the first key >= k is at index `begin` = the number of keys below k (the keys of a node ascend)
+static __device__ __forceinline__ int rn_getp(RNode &nd, int64_t k, int &r) {
+    const int n = rn_n(nd);
+    if (n == 0) return -1;
+    int begin = 0;
+#define RN_CNT(T) begin += (T < n && rn_kpos<T>(nd) < k) ? 1 : 0;
+    RN_FOR9(RN_CNT)
+#undef RN_CNT
+    if (begin == n) { r = 1; return n - 1; }
+    const int64_t kp = rn_kpos_at(nd, begin);
+    r = (kp < k) - (k < kp);
+    if (r < 0) --begin;
+    return begin;
+}
+static __device__ int bt_lower_reg(const BTree &b, int64_t k) {
+    int lower = -1, x = b.root, r = 0;
+    while (x >= 0) {
+        RNode nd; rn_load(nd, b.nodes + x);
+        const int i = rn_getp(nd, k, r);
+        if (i >= 0 && r == 0) return rn_key(nd, i);
+        if (i >= 0) lower = rn_key(nd, i);
+        if (!rn_internal(nd)) return lower;
+        x = rn_ptr(nd, i + 1);
+    }
+    return lower;
+}
+static __device__ void bt_split(BTree &b, int xi, int i, int yi);
+static __device__ void bt_put_reg(BTree &b, int key) {
+    const int64_t k = b.ch[key].pos;
+    ++b.n_keys;
+    if (b.nodes[b.root].n == 2 * BT_T - 1) {
+        const int s = bt_new(b, 1), r = b.root;
+        b.root = s; b.nodes[s].ptr[0] = r;
+        bt_split(b, s, 0, r);
+    }
+    int xi = b.root, r;
+    for (;;) {
+        RNode x; rn_load(x, b.nodes + xi);
+        if (!rn_internal(x)) {                               // leaf: keys above i move up by one, the new key goes to i + 1
+            const int i = rn_getp(x, k, r), at = i + 1;
+#define RN_SHIFT(T) if (8 - T > at) { rn_set_kpos<8 - T>(x, rn_kpos<(8 - T > 0 ? 8 - T - 1 : 0)>(x)); rn_dw<18 + 8 - T>(x) = rn_dw<18 + (8 - T > 0 ? 8 - T - 1 : 0)>(x); }
+            RN_FOR9(RN_SHIFT)                                // t = 8 .. 0, descending: every entry takes its lower neighbour's OLD value
+#undef RN_SHIFT
+#define RN_PUT(T) if (at == T) { rn_set_kpos<T>(x, k); rn_dw<18 + T>(x) = (uint32_t)key; }
+            RN_FOR9(RN_PUT)
+#undef RN_PUT
+            rn_dw<38>(x) = (uint32_t)(rn_n(x) + 1);
+            rn_store(x, b.nodes + xi);
+            return;
+        }
+        int i = rn_getp(x, k, r) + 1;
+        int child = rn_ptr(x, i);
+        if (b.nodes[child].n == 2 * BT_T - 1) {              // (once per ~5 insertions: the split works on memory, the parent is read again)
+            bt_split(b, xi, i, child);
+            if (k > b.nodes[xi].kpos[i]) ++i;
+            child = b.nodes[xi].ptr[i];
+        }
+        xi = child;
+    }
+}
+
 // kb_intervalp, lower bound only (kbtree.h:158-175)
 static __device__ int bt_lower(const BTree &b, int64_t k) {
+    if (b.reg) return bt_lower_reg(b, k);
     int lower = -1, x = b.root, r = 0;
     while (x >= 0) {
         const BtNode &nd = b.nodes[x];
@@ -119,6 +231,7 @@ static __device__ void bt_split(BTree &b, int xi, int i, int yi) {
 }
 // kb_putp + __kb_putp_aux, kbtree.h:197-231 (the recursion is a plain descent)
 static __device__ void bt_put(BTree &b, int key) {
+    if (b.reg) { bt_put_reg(b, key); return; }
     const int64_t k = b.ch[key].pos;
     ++b.n_keys;
     if (b.nodes[b.root].n == 2 * BT_T - 1) {
@@ -317,6 +430,7 @@ static __device__ void chain_one_read(const DevIndex &ix, const ChainParams &o, 
     int32_t *ord = in_lds ? lw->ord : order + base;
     BtNode *nodes = in_lds ? lw->nodes : nodes_g + base;
     BTree bt; bt.nodes = nodes; bt.n_nodes = 0; bt.n_keys = 0; bt.ch = ch;     // <= n_sa/4 + 1 nodes are ever needed
+    bt.reg = !in_lds && o.reg_nodes;
     bt.root = bt_new(bt, 0);
     int n_ch = 0, n_sd = 0;
     RidCache ridc; ridc.lo = 1; ridc.hi = 0; ridc.rid = -1;
@@ -550,7 +664,7 @@ static __device__ void isl_build(const DevIndex &ix, const ChainParams &o, const
         sd[start] = s; ch[start] = c2;
         n_ch = start + 1;
     } else {
-        BTree bt; bt.nodes = nd + start; bt.n_nodes = 0; bt.n_keys = 0; bt.ch = ch;
+        BTree bt; bt.nodes = nd + start; bt.n_nodes = 0; bt.n_keys = 0; bt.ch = ch; bt.reg = o.reg_nodes != 0;
         bt.root = bt_new(bt, 0);
         // Equal keys: where a chain lands whose key another chain already has -- after it, or BEFORE it when that chain happens to be the median of
         // a full node that kb_putp splits on its way down (`if (k > median) ++i`) -- and which of the two a later look-up finds depend on the

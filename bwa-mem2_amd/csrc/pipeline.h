@@ -16,6 +16,7 @@ struct ChainParams {                                // what mem_chain_seeds / me
     int32_t a, o_del, e_del, o_ins, e_ins, w, max_chain_gap, max_occ, min_seed_len, min_chain_weight, max_chain_extend;
     int32_t pen_clip5, pen_clip3, zdrop;
     float mask_level, drop_ratio;
+    int32_t reg_nodes;                              // launch policy, not an option: B-tree nodes in global memory are visited through registers (chain.hip)
 };
 
 // scan.hip

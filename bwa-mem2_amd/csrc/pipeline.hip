@@ -145,6 +145,7 @@ static ChainParams chain_params(const bm2_opt *opt) {
     o.min_chain_weight = opt->min_chain_weight; o.max_chain_extend = opt->max_chain_extend;
     o.pen_clip5 = opt->pen_clip5; o.pen_clip3 = opt->pen_clip3; o.zdrop = opt->zdrop;
     o.mask_level = opt->mask_level; o.drop_ratio = opt->drop_ratio;
+    o.reg_nodes = bm2_knob("BM2_CHAIN_REGNODES", 1);
     return o;
 }
 

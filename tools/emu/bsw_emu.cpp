@@ -8,6 +8,8 @@
 
 void bm2_set_error(const char *fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fputc('\n', stderr); }
 int bm2_check(hipError_t e, const char *) { return e == hipSuccess ? BM2_OK : BM2_ENODEV; }
+// (the sorted S1 path lives in extend.hip, which this single-source harness does not link: every pair goes to the pair-per-wavefront kernel)
+int bm2_launch_bsw_sorted(bm2_ctx *, bm2_seqpair_t *, const uint8_t *, const uint8_t *, int, int, const SwParams &, unsigned long long *, bool *done) { *done = false; return BM2_OK; }
 
 static int env_int(const char *n, int d) { const char *v = getenv(n); return v ? atoi(v) : d; }
 
