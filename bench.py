@@ -918,7 +918,9 @@ def main():
                 names = ("table + SMEM cuts", "stage seeds + file buckets", "island of every seed", "places (scan)", "seeds of an island together", "islands chained", "read finished")
                 chain_kernel = {"kernel": "k_chain_islands", "reads_by_islands": int(cn[17]), "reads_chained_serially_equal_keys": int(cn[16]), "islands_per_read": float(cn[18] / nr),
                                 "chains_per_read": float(cn[27] / nr), "chains_past_the_weight_test_per_read": float(cn[26] / nr),
-                                "phase_ms_per_read": {nm: float(cn[19 + i] * 1e-5 / (cn[17] + cn[16])) for i, nm in enumerate(names)}}
+                                "phase_ms_per_read": {nm: float(cn[19 + i] * 1e-5 / (cn[17] + cn[16])) for i, nm in enumerate(names)},
+                                "phase_ms_slowest_read": {nm: float(cn[31 + i] * 1e-5) for i, nm in enumerate(names)},
+                                "serial_reads": {"ms_per_read": float(cn[28] * 1e-5 / max(cn[16], 1.0)), "seeds_per_read": float(cn[29] / max(cn[16], 1.0)), "slowest_ms": float(cn[30] * 1e-5)}}
         except Exception:                                                             # noqa
             pass
         dominant = max(stage_ms, key=stage_ms.get) if stage_ms else None

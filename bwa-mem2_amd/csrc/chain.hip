@@ -390,6 +390,7 @@ static __device__ void chain_finish_read(const ChainParams &o, int r, WChain *ch
 }
 
 struct IslSeed { int64_t rbeg; uint32_t ql; int32_t rid; };           // a seed staged in global memory (k_chain_islands): ql = qbeg | len << 15 | is_alt << 31
+struct IslHash { unsigned long long key; int32_t cnt, start; };        // key = bucket + 1 (0: free); seeds in the island that STARTS at this bucket; its place in `perm`
 
 // The working set of one read while it is chained: chains, seeds, B-tree nodes, an order array.  The lane-per-read kernel keeps
 // them in the read's slices of global arrays; the wave-per-read kernel of seed-rich reads keeps them in LDS (k_chain_heavy).
@@ -408,7 +409,8 @@ static __device__ void chain_one_read(const DevIndex &ix, const ChainParams &o, 
                                       const int64_t *__restrict__ smem_off, const int64_t *__restrict__ sa_off,
                                       const int64_t *__restrict__ sa_coord, WChain *wchain, WSeed *wseed, BtNode *nodes_g, int32_t *order,
                                       DevChain *chn, DevSeed *seeds_out, int32_t *seed_owner, int32_t *n_chain_out, int32_t *n_reg_out,
-                                      int32_t *n_chain0_out, int heavy_thr, const ChainWork *lw, int lds_cap, const IslSeed *ist = nullptr) {
+                                      int32_t *n_chain0_out, int heavy_thr, const ChainWork *lw, int lds_cap, const IslSeed *ist = nullptr,
+                                      const IslHash *isl_hash = nullptr, const int32_t *isl_slot = nullptr) {
     const int n_sm = smem_cnt[r];
     n_chain_out[r] = 0; n_reg_out[r] = 0;          // (k_chain never gets here with a read it leaves to k_chain_heavy: one writer per read)
     if (n_chain0_out) n_chain0_out[r] = 0;
@@ -471,7 +473,10 @@ static __device__ void chain_one_read(const DevIndex &ix, const ChainParams &o, 
             }
             if (rid < 0) continue;                       // bwamem.cpp:915-919
             int to_add = 0;
-            if (bt.n_keys) {
+            // (a seed that is alone in its island of reference buckets can meet no chain: whatever kb_intervalp returned, test_and_merge
+            //  would fail -- see k_chain_islands -- so the look-up is skipped and only the tree's shape is kept exact)
+            if (isl_hash && isl_hash[isl_slot[t]].cnt == 1) to_add = 1;
+            else if (bt.n_keys) {
                 const int lower = bt_lower(bt, s.rbeg);
                 if (lower < 0) to_add = 1;
                 else {
@@ -625,7 +630,6 @@ k_chain_heavy(DevIndex ix, ChainParams o, int n_reads, const int32_t *__restrict
 // One wavefront per read: all lanes stage the seeds (position, query span, contig: the two binary searches of bns_intv2rid leave the serial
 // part), file them, number the islands, put the seeds of every island together in seed order (a stable counting sort); then every lane
 // chains islands of its own; then lane 0 finishes the read.  Scratch: the read's slices of the OUTPUT arrays, which nothing has written yet.
-struct IslHash { unsigned long long key; int32_t cnt, start; };        // key = bucket + 1 (0: free); seeds in the island that STARTS at this bucket; its place in `perm`
 static_assert(sizeof(IslHash) == 16 && sizeof(IslSeed) == 16 && sizeof(DevChain) >= 68 && sizeof(DevSeed) >= 24, "island scratch is carved from the output slices");
 
 static __device__ __forceinline__ unsigned isl_slot0(unsigned long long key, int log_h) { return (unsigned)((key * 0x9E3779B97F4A7C15ULL) >> (64 - log_h)); }
@@ -713,12 +717,12 @@ k_chain_islands(DevIndex ix, ChainParams o, int n_reads, const int32_t *__restri
                 const int64_t *__restrict__ sa_coord, WChain *wchain, WSeed *wseed, BtNode *nodes, int32_t *order,
                 DevChain *chn, DevSeed *seeds_out, int32_t *seed_owner, int32_t *cut_all, int32_t *n_chain_out, int32_t *n_reg_out, int32_t *n_chain0_out,
                 const int32_t *__restrict__ heavy /* read ids, heavy ones first */, const int64_t *__restrict__ n_heavy_p,
-                const int32_t *__restrict__ n_sa_read, int lo, unsigned long long *item_cur, unsigned long long *n_fallback) {
+                const int32_t *__restrict__ n_sa_read, int lo, unsigned long long *item_cur, unsigned long long *n_fallback, int n_items) {
     __shared__ int s_nsurv, s_ntot, s_dup;
     __shared__ unsigned long long s_min;
     const int lane = threadIdx.x;
     const unsigned long long lt_mask = lane ? (~0ULL >> (64 - lane)) : 0ULL;
-    const int64_t n_heavy = *n_heavy_p;
+    const int64_t n_heavy = n_items >= 0 ? (int64_t)n_items : *n_heavy_p;     // (n_items: `heavy` lists EVERY read, the seed-richest first)
     for (;;) {
         // (every lane takes part in the atomic and the body sits in an `if`: see the note on work loops in smem.hip)
         const unsigned long long it = atomicAdd(item_cur, lane == 0 ? 1ULL : 0ULL);
@@ -740,7 +744,7 @@ k_chain_islands(DevIndex ix, ChainParams o, int n_reads, const int32_t *__restri
         // (chn slice, 72 B per seed: the table, < 64 B per seed, then the island list; seeds_out slice, 24 B per seed: staged seed, its island, the permutation)
         int32_t *cslot = (int32_t *)(st + n_sa), *perm = cslot + n_sa, *clist = (int32_t *)((char *)(chn + base) + (size_t)64 * n_sa), *cut = cut_all + base;
         long long tck = wall_clock64();                              // phase clock (lane 0 adds every phase's ticks to the counters behind n_fallback: bm2_batch_fetch("counters"))
-#define ISL_TICK(ph) do { const long long t_now = wall_clock64(); if (lane == 0) atomicAdd(n_fallback + 3 + (ph), (unsigned long long)(t_now - tck)); tck = t_now; } while (0)
+#define ISL_TICK(ph) do { const long long t_now = wall_clock64(); if (lane == 0) { atomicAdd(n_fallback + 3 + (ph), (unsigned long long)(t_now - tck)); atomicMax(n_fallback + 15 + (ph), (unsigned long long)(t_now - tck)); } tck = t_now; } while (0)
         int log_h = 7;
         while ((1 << log_h) < 2 * n_sa) log_h++;
         const int H = 1 << log_h;                                    // < 4 n_sa entries of 16 bytes: inside the read's slice of chn
@@ -836,8 +840,11 @@ k_chain_islands(DevIndex ix, ChainParams o, int n_reads, const int32_t *__restri
         if (lane == 0) {
             if (s_dup) {                                             // chains with equal keys: the serial code on the read's slices
                 atomicAdd(n_fallback, 1ULL);
+                const long long t_fb = wall_clock64();
                 chain_one_read<false>(ix, o, r, n_reads, len, smems, smem_cnt, smem_off, sa_off, sa_coord, wchain, wseed, nodes, order, chn, seeds_out,
-                                      seed_owner, n_chain_out, n_reg_out, n_chain0_out, -1, nullptr, 0, st);
+                                      seed_owner, n_chain_out, n_reg_out, n_chain0_out, -1, nullptr, 0, st, hash, cslot);
+                const unsigned long long dt_fb = (unsigned long long)(wall_clock64() - t_fb);
+                atomicAdd(n_fallback + 12, dt_fb); atomicAdd(n_fallback + 13, (unsigned long long)n_sa); atomicMax(n_fallback + 14, dt_fb);
             } else {
                 const int n_all = s_ntot;
                 if (n_chain0_out) n_chain0_out[r] = n_all;
@@ -950,7 +957,8 @@ int bm2_launch_chain(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_
                      int32_t *seed_owner,
                      int32_t *n_chain_out, int32_t *n_reg_out, int32_t *n_chain0_out, const int32_t *perm,
                      int heavy_thr, const int64_t *n_heavy_dev, const int32_t *n_sa_read, unsigned long long *item_cur /* one per tier + 2 */, int max_len,
-                     int32_t *isl_cut /* scratch of the island kernel: one int per SA coordinate */) {
+                     int32_t *isl_cut /* scratch of the island kernel: one int per SA coordinate */,
+                     const int32_t *isl_order /* or NULL: every read, the seed-richest first -- the island kernel's longest reads start first */) {
     if (n_reads <= 0) return BM2_OK;
     hipStream_t s = c->stream;
     const bool heavy = heavy_thr >= 0 && n_heavy_dev != nullptr;
@@ -967,7 +975,9 @@ int bm2_launch_chain(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_
         // reads with more seeds than the largest tier holds: a launch of their own where they are the norm (long reads), otherwise the last tier's
         const bool own_overflow = max_len >= bm2_knob("BM2_CHAIN_OVF_MIN_LEN", 1000);
         int lo = heavy_thr;
-        const int tier_max = own_overflow ? bm2_knob("BM2_CHAIN_TIER_MAX", 1 << 30) : 1 << 30;     // (a test hook: tiers beyond it are left out, their reads go to the launch for long reads)
+        // BM2_CHAIN_TIER_MAX: tiers beyond it are left out and their reads -- the seed-richest -- go to the island kernel with the long reads
+        const int tier_max = bm2_knob("BM2_CHAIN_TIER_MAX", 1 << 30);
+        const bool use_islands = own_overflow || caps[BM2_CHAIN_TIERS - 1] > tier_max;
         for (int t = 0; t < BM2_CHAIN_TIERS; t++) {
             if (caps[t] <= lo || caps[t] > tier_max) continue;
             hipStream_t sk = c->side_stream[2 + t];
@@ -977,7 +987,7 @@ int bm2_launch_chain(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_
             (void)hipStreamWaitEvent(sk, c->ev_fork, 0);
             hipLaunchKernelGGL(k_chain_heavy, dim3(c->n_cu * per_cu), dim3(64), lds, sk, c->ix, o, n_reads, len, smems, smem_cnt, smem_off, sa_off,
                                sa_coord, wchain, wseed, nodes, order, chn, seeds_out, seed_owner, n_chain_out, n_reg_out, n_chain0_out, perm,
-                               n_heavy_dev, n_sa_read, lo, caps[t], (t == BM2_CHAIN_TIERS - 1 && !own_overflow) ? 1 : 0, item_cur + t, stage);
+                               n_heavy_dev, n_sa_read, lo, caps[t], (t == BM2_CHAIN_TIERS - 1 && !use_islands) ? 1 : 0, item_cur + t, stage);
             (void)hipEventRecord(c->ev_join[2 + t], sk);
             (void)hipStreamWaitEvent(s, c->ev_join[2 + t], 0);
             lo = caps[t];
@@ -986,14 +996,15 @@ int bm2_launch_chain(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_
         // used to ride in the last tier -- whose blocks reserve a CU's whole LDS, so only one such walk ran per CU: 256 at a time, 5.1 s for
         // a chunk of 10 000 ONT-like reads.  A launch of their own with (almost) no LDS: as many walks in flight as the CUs hold wavefronts.
         // (Short-read chunks keep the old routing: a read of theirs beyond 1000 seeds is a rarity, and one more launch scanning the heavy list is not free.)
-        if (own_overflow) {
+        if (use_islands) {
             hipStream_t sk = c->side_stream[2 + BM2_CHAIN_TIERS];
             (void)hipStreamWaitEvent(sk, c->ev_fork, 0);
             if (bm2_knob("BM2_CHAIN_ISLANDS", 1)) {                 // chaining by islands (k_chain_islands): one wavefront per read, every lane at work
                 const int per_cu = bm2_knob("BM2_CHAIN_ISL_WAVES_PER_CU", 32);
                 hipLaunchKernelGGL(k_chain_islands, dim3(c->n_cu * per_cu), dim3(64), 0, sk, c->ix, o, n_reads, len, smems, smem_cnt, smem_off, sa_off,
-                                   sa_coord, wchain, wseed, nodes, order, chn, seeds_out, seed_owner, isl_cut, n_chain_out, n_reg_out, n_chain0_out, perm,
-                                   n_heavy_dev, n_sa_read, lo, item_cur + BM2_CHAIN_TIERS, item_cur + BM2_CHAIN_TIERS + 1);
+                                   sa_coord, wchain, wseed, nodes, order, chn, seeds_out, seed_owner, isl_cut, n_chain_out, n_reg_out, n_chain0_out,
+                                   isl_order ? isl_order : perm, n_heavy_dev, n_sa_read, lo, item_cur + BM2_CHAIN_TIERS, item_cur + BM2_CHAIN_TIERS + 1,
+                                   isl_order ? n_reads : -1);
             } else {
                 const int per_cu = bm2_knob("BM2_CHAIN_OVF_WAVES_PER_CU", 32);
                 hipLaunchKernelGGL(k_chain_heavy, dim3(c->n_cu * per_cu), dim3(64), bm2_chain_lds_bytes(0, 0), sk, c->ix, o, n_reads, len, smems, smem_cnt, smem_off, sa_off,

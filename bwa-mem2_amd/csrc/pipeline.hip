@@ -17,7 +17,8 @@ int bm2_launch_chain(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_
                      WChain *wchain, WSeed *wseed, BtNode *nodes, int32_t *order, DevChain *chn, DevSeed *seeds_out,
                      int32_t *seed_owner,
                      int32_t *n_chain_out, int32_t *n_reg_out, int32_t *n_chain0_out, const int32_t *perm,
-                     int heavy_thr, const int64_t *n_heavy_dev, const int32_t *n_sa_read, unsigned long long *item_cur, int max_len, int32_t *isl_cut);
+                     int heavy_thr, const int64_t *n_heavy_dev, const int32_t *n_sa_read, unsigned long long *item_cur, int max_len, int32_t *isl_cut,
+                     const int32_t *isl_order);
 int bm2_launch_chain_finish(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_t *len, const int64_t *read_base,
                             const int32_t *n_chain, DevChain *chn, DevSeed *seeds_out, int32_t *srt_out, int32_t *reg_seed,
                             int32_t *reg_chain, int32_t *n_reg_out);
@@ -170,8 +171,8 @@ static int run_seeding(bm2_ctx *c, Batch *b, const bm2_opt *opt, bool with_sal) 
     int rc;
     hipStream_t s = c->stream;
     const SeedParams sp = seed_params(opt);
-    if ((rc = bm2_reserve(b->counters, 32 * 8))) return rc;
-    if ((rc = bm2_check(hipMemsetAsync(b->counters.p, 0, 32 * 8, s), "memset counters"))) return rc;
+    if ((rc = bm2_reserve(b->counters, 40 * 8))) return rc;
+    if ((rc = bm2_check(hipMemsetAsync(b->counters.p, 0, 40 * 8, s), "memset counters"))) return rc;
     if ((rc = bm2_reserve(b->smem_cnt, (size_t)(n + 1) * 4))) return rc;
     if ((rc = bm2_reserve(b->smem_off, (size_t)(n + 1) * 8))) return rc;
     // task kernels with persistent lanes (smem.hip); workspace sizes are learned: a run that overflows one of them reports
@@ -363,13 +364,21 @@ static int batch_run_one(bm2_ctx *c, const bm2_opt *opt, StageGate *gate = nullp
     if (perm_mode == 5) { if ((rc = bm2_partition_by_class(c, n, (const int32_t *)b->n_sa_read.p, thr_sa, (int32_t *)b->perm.p, b->part_tmp, b->scan_tmp, chain_heavy ? &n_heavy_chain : nullptr))) return rc; }
     else if (perm_mode == 3 || perm_mode == 4) { if ((rc = bm2_partition_by_work(c, n, (const int32_t *)b->n_sa_read.p, thr_sa, (int32_t *)b->perm.p, b->part_tmp, b->scan_tmp, perm_mode == 4, perm_mode == 4 && chain_heavy ? &n_heavy_chain : nullptr))) return rc; }
     else if ((rc = bm2_perm_by_work(c, n, (const int32_t *)b->n_sa_read.p, (int32_t *)b->perm.p, (uint32_t *)b->perm_hist.p, perm_mode))) return rc;
+    // long reads: the island kernel takes its reads by falling seed count (log2 classes), so that the few reads it has to chain serially --
+    // hundreds of milliseconds each -- start at once instead of behind a first round of ordinary reads
+    const int32_t *isl_order = nullptr;
+    if (b->max_len >= 1000 && bm2_knob("BM2_CHAIN_ISL_ORDER", 1)) {
+        if ((rc = bm2_reserve(b->perm2, (size_t)(n + 1) * 4))) return rc;
+        if ((rc = bm2_perm_by_work(c, n, (const int32_t *)b->n_sa_read.p, (int32_t *)b->perm2.p, (uint32_t *)b->perm_hist.p, 1))) return rc;
+        isl_order = (const int32_t *)b->perm2.p;
+    }
     if ((rc = bm2_launch_chain(c, cp, n, (const int32_t *)b->len.p, (const bm2_smem_t *)b->smem.p, (const int32_t *)b->smem_cnt.p,
                                (const int64_t *)b->smem_off.p, (const int64_t *)b->sa_off.p, (const int64_t *)b->sa_coord.p,
                                (WChain *)b->wchain.p, (WSeed *)b->wseed.p, (BtNode *)b->nodes.p, (int32_t *)b->order.p,
                                (DevChain *)b->chn.p, (DevSeed *)b->seeds.p, (int32_t *)b->seed_owner.p,
                                (int32_t *)b->n_chain.p, (int32_t *)b->n_reg.p, (int32_t *)b->n_chain0.p, (const int32_t *)b->perm.p,
                                n_heavy_chain ? thr_sa : -1, n_heavy_chain, (const int32_t *)b->n_sa_read.p,
-                               (unsigned long long *)b->counters.p + 10, b->max_len, (int32_t *)b->srt.p))) return rc;      // counters[10..15]: work cursors of the tiers and of the overflow launch, [16]: reads the island kernel chained serially
+                               (unsigned long long *)b->counters.p + 10, b->max_len, (int32_t *)b->srt.p, isl_order))) return rc;      // counters[10..15]: work cursors of the tiers and of the overflow launch, [16]: reads the island kernel chained serially
     if (any_flt) {
         if ((rc = bm2_launch_seed_filter(c, cp, (const int8_t *)b->mat25.p, n, n_sa, (const uint8_t *)b->enc.p, (const int64_t *)b->off.p,
                                          (const int32_t *)b->len.p, (const int32_t *)b->min_hsp.p, (const int64_t *)b->read_base.p,
@@ -813,7 +822,7 @@ extern "C" int bm2_batch_fetch(bm2_ctx *c, const char *what, void *out, int64_t 
         { "sa_coord", &b->sa_coord, ns * 8 }, { "read_base", &b->read_base, (size_t)n * 8 },
         { "n_chain", &b->n_chain, (size_t)n * 4 }, { "n_chain0", &b->n_chain0, (size_t)n * 4 }, { "n_reg", &b->n_reg, (size_t)n * 4 },
         { "n_out", &b->n_out, (size_t)n * 4 }, { "chn", &b->chn, ns * sizeof(DevChain) }, { "seeds", &b->seeds, ns * sizeof(DevSeed) },
-        { "seed_counters", &b->seedc, (size_t)21 * 8 }, { "counters", &b->counters, (size_t)32 * 8 }, { "regs_raw", &b->regs, ns * sizeof(DevReg) }, { "reg_seed", &b->reg_seed, ns * 4 }, { "wchain", &b->wchain, ns * sizeof(WChain) },
+        { "seed_counters", &b->seedc, (size_t)21 * 8 }, { "counters", &b->counters, (size_t)40 * 8 }, { "regs_raw", &b->regs, ns * sizeof(DevReg) }, { "reg_seed", &b->reg_seed, ns * 4 }, { "wchain", &b->wchain, ns * sizeof(WChain) },
     };
     if (!strcmp(what, "seed_attempts")) {
         *n_bytes = 4;

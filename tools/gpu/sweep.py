@@ -23,6 +23,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 GRID = [   # (name, candidates): a candidate is a dict of knobs set together; the first one ({} = the library's defaults) is the incumbent
     ("chain staging", [{}, {"BM2_CHAIN_STAGE": 1}]),
     ("chain heavy threshold", [{}, {"BM2_HEAVY_SA": 64}, {"BM2_HEAVY_SA": 40}, {"BM2_HEAVY_SA": 24}, {"BM2_HEAVY_SA": 160}, {"BM2_HEAVY_SA": 256}, {"BM2_HEAVY_SA": 512}]),
+    ("chain: seed-rich reads to the island kernel", [{}, {"BM2_CHAIN_TIER_MAX": 512}, {"BM2_CHAIN_TIER_MAX": 256}, {"BM2_CHAIN_TIER_MAX": 128}, {"BM2_CHAIN_TIER_MAX": 256, "BM2_HEAVY_SA": 160}]),
     ("chain waves per CU", [{}, {"BM2_CHAIN_WAVES_PER_CU": 32}, {"BM2_CHAIN_WAVES_PER_CU": 8}]),
     ("k_bwd LDS survivors / blocks per CU / waves per SIMD", [{}, {"BM2_BWD_LCAP": 8, "BM2_BWD_BLOCKS_PER_CU": 4}, {"BM2_BWD_LCAP": 6, "BM2_BWD_BLOCKS_PER_CU": 4},
                                                               {"BM2_BWD_LCAP": 4, "BM2_BWD_BLOCKS_PER_CU": 4},
