@@ -170,14 +170,15 @@ static __device__ void bt_split(BTree &b, int xi, int i, int yi);
 static __device__ void bt_put_reg(BTree &b, int key) {
     const int64_t k = b.ch[key].pos;
     ++b.n_keys;
-    if (b.nodes[b.root].n == 2 * BT_T - 1) {
+    RNode x; rn_load(x, b.nodes + b.root);                    // (the node's own fill comes with it: no separate load for the "is it full" test)
+    if (rn_n(x) == 2 * BT_T - 1) {
         const int s = bt_new(b, 1), r = b.root;
         b.root = s; b.nodes[s].ptr[0] = r;
         bt_split(b, s, 0, r);
+        rn_load(x, b.nodes + b.root);
     }
     int xi = b.root, r;
     for (;;) {
-        RNode x; rn_load(x, b.nodes + xi);
         if (!rn_internal(x)) {                               // leaf: keys above i move up by one, the new key goes to i + 1
             const int i = rn_getp(x, k, r), at = i + 1;
 #define RN_SHIFT(T) if (8 - T > at) { rn_set_kpos<8 - T>(x, rn_kpos<(8 - T > 0 ? 8 - T - 1 : 0)>(x)); rn_dw<18 + 8 - T>(x) = rn_dw<18 + (8 - T > 0 ? 8 - T - 1 : 0)>(x); }
@@ -192,12 +193,14 @@ static __device__ void bt_put_reg(BTree &b, int key) {
         }
         int i = rn_getp(x, k, r) + 1;
         int child = rn_ptr(x, i);
-        if (b.nodes[child].n == 2 * BT_T - 1) {              // (once per ~5 insertions: the split works on memory, the parent is read again)
+        RNode y; rn_load(y, b.nodes + child);
+        if (rn_n(y) == 2 * BT_T - 1) {                       // (once per ~5 insertions: the split works on memory, parent and child are read again)
             bt_split(b, xi, i, child);
             if (k > b.nodes[xi].kpos[i]) ++i;
             child = b.nodes[xi].ptr[i];
+            rn_load(y, b.nodes + child);
         }
-        xi = child;
+        x = y; xi = child;
     }
 }
 

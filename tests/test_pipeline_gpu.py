@@ -285,6 +285,40 @@ def test_long_reads_fresh_vs_oracle(gpu_ctx_factory, tmp_path):
     _same(exp["REGPRG"], regs_to_records(regs, reg_off), "REGPRG")
 
 
+def test_long_reads_at_scale_against_the_reference(gpu_ctx_factory, tmp_path):
+    # config-5 shape at its real sizes: 200 reads of mean 10 kb, one of them at the 30 kb cap (> 16 k SMEMs: the workgroup sort of k_smem_finish_big at
+    # its real LDS capacity, runs of start classes; > 30 k seeds: the island kernel and the sliding register window on their longest inputs), against
+    # the dump of the COMPILED REFERENCE (oracle/_ref/refdump: the reference's own mem_kernel1_core / mem_kernel2_core) -- the oracle's single
+    # thread would need minutes for these reads
+    import subprocess
+    from helpers import ref_binary
+    refdump = ref_binary("refdump")
+    if refdump is None:
+        pytest.skip("oracle/_ref not built")
+    names, ctg, alts = synth.make_genome(45, [1800000, 900000, 300000], alt_contigs=1, alt_len=20000, n_repeat_families=30, repeat_len=(300, 5000),
+                                         copies=(5, 60), divergence=(0.01, 0.12))
+    fa = str(tmp_path / "g.fa")
+    synth.write_fasta(fa, names, ctg)
+    synth.write_alt(fa + ".alt", alts)
+    if not build_index(fa):
+        pytest.skip("oracle/_ref reference binary not present")
+    reads = synth.make_reads_long(46, ctg, 200, mean_len=10000, max_len=30000)
+    assert max(len(r) for r in reads) >= 25000 and np.mean([len(r) for r in reads]) > 8000
+    enc, off, ln = refio.pack_reads(reads)
+    rtxt, dump = str(tmp_path / "reads.txt"), str(tmp_path / "dump.bin")
+    acgtn = np.frombuffer(b"ACGTN", np.uint8)
+    with open(rtxt, "wb") as f:
+        for r in reads:
+            f.write(acgtn[r].tobytes() + b"\n")
+    p = subprocess.run([refdump, "-x", "ont2d", fa, rtxt, dump], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+    assert p.returncode == 0, p.stderr[-400:]
+    exp = refio.read_dump(dump)
+    ctx = gpu_ctx_factory(fa)
+    regs, reg_off, st = ctx.seed_chain_extend(enc, off, ln, bm2.default_opt(**ONT2D))
+    _same(exp["REGPRG"], regs_to_records(regs, reg_off), "REGPRG")
+    assert st["n_sa"] / len(reads) > 1000          # the reads are seed-rich enough for the long-read kernels
+
+
 def test_long_reads_chained_by_islands(gpu_ctx_factory, tmp_path, monkeypatch):
     # mem_chain_seeds of seed-rich reads cut into islands of reference buckets (k_chain_islands, chain.hip): a repeat-rich genome, so that a read
     # brings hundreds of stray hits -- islands of one seed -- beside its locus; the tiers of the wavefront-per-read kernel are switched off so

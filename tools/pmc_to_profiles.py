@@ -35,7 +35,43 @@ def counters(path):
     return pmc, calls
 
 
+def ont2d(src, pre):
+    """config 5's own counter pass: gpurun_out/<tag>/bench_ont2d.json (the pass's own bench line) + pmc_sq1_ont2d.md -> profiles/<pre>_ont2d_pmc_sq.md and
+    profiles/<pre>_ont2d_ext_pmc_sq.json (what bench.py --workload ont2d reports as extend_kernel.valu_frac) with the chaining kernels' counters beside."""
+    dst = os.path.join(ROOT, "profiles")
+    bench = json.load(open(os.path.join(src, "bench_ont2d_pmc.json")))
+    shutil.copy(os.path.join(src, "pmc_sq1_ont2d.md"), os.path.join(dst, "%s_ont2d_pmc_sq.md" % pre))
+    s1, calls = counters(os.path.join(src, "pmc_sq1_ont2d.md"))
+    steps = float(os.environ.get("PMC_STEPS", 2))
+    fam = {}
+    for k, v in s1.items():
+        name = "k_ext_wave" if "k_ext_wave" in k else "k_ext_seeds" if "k_ext_seeds" in k else "k_chain_islands" if "k_chain_islands" in k else \
+               "k_chain_heavy" if "k_chain_heavy" in k else "k_seed_sw" if "k_seed_sw" in k else "k_walk" if "k_walk" in k else None
+        if name:
+            for cn, (val, _) in v.items():
+                fam.setdefault(name, {})[cn] = fam.setdefault(name, {}).get(cn, 0.0) + val
+    peak, src_peak = 256 * 4 * 2.4e9 / 4.0, "nominal: 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction"
+    for fn in sorted(os.listdir(dst), reverse=True):
+        if fn.endswith("valu_int_ubench.txt"):
+            rates = [float(m.group(1)) for m in re.finditer(r"([\d.]+) G wave-instr/s", open(os.path.join(dst, fn)).read())]
+            if rates:
+                peak, src_peak = max(rates) * 1e9, "profiles/" + fn
+                break
+    stage_ms = bench["stage_ms_per_step"]["extend"]
+    ext_insts = sum(fam.get(k, {}).get("SQ_INSTS_VALU", 0.0) for k in ("k_ext_wave", "k_ext_seeds")) / steps
+    out = {"kernel": "k_ext_wave (sliding register window) + k_ext_seeds, config 5", "workload": {"reads_per_gpu_per_step": bench["config"]["reads_per_gpu_per_step"], "genome_mbp": bench["config"]["genome_mbp"], "read_len": None},
+           "extend_stage_ms": stage_ms, "valu_wave_insts_per_step": ext_insts, "valu_frac": ext_insts / (stage_ms * 1e-3) / peak, "valu_peak_wave_insts_per_s": peak, "valu_peak_source": src_peak,
+           "lds_conflict_frac": 0.0,
+           "per_kernel": {k: {"valu_wave_insts_per_step": c.get("SQ_INSTS_VALU", 0.0) / steps, "valu_busy_of_wave_cycles": c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"] if c.get("SQ_WAVE_CYCLES") else None,
+                              "wait_any_of_wave_cycles": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"] if c.get("SQ_WAVE_CYCLES") else None} for k, c in fam.items()},
+           "source": "rocprofv3 --pmc SQ_* --kernel-trace on `bench.py --workload ont2d` (profiles/%s_ont2d_pmc_sq.md); the issue fraction over the stage's wall time of that run" % pre}
+    json.dump(out, open(os.path.join(dst, "%s_ont2d_ext_pmc_sq.json" % pre), "w"), indent=1)
+    print(json.dumps(out, indent=1))
+
+
 def main():
+    if sys.argv[1] == "--ont2d":
+        return ont2d(sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else "r04")
     src = sys.argv[1]
     pre = sys.argv[2] if len(sys.argv) > 2 else "r02"
     dst = os.path.join(ROOT, "profiles")
@@ -68,12 +104,12 @@ def main():
     tot = {}
     per = {}
     for k, v in s1.items():
-        if "k_ext_lanes" in k or "k_ext_wave" in k:             # both kernels of the stage: lane-per-task classes and wavefront-per-task classes
-            fam = "k_ext_lanes" if "k_ext_lanes" in k else "k_ext_wave"
+        if "k_ext_lanes" in k or "k_ext_seeds" in k or "k_ext_wave" in k:             # both kernels of the stage: lane-per-seed classes and wavefront-per-seed classes
+            fam = "k_ext_wave" if "k_ext_wave" in k else "k_ext_seeds"
             for cn, (val, _) in v.items():
                 tot[cn] = tot.get(cn, 0.0) + val
                 per.setdefault(fam, {})[cn] = per.setdefault(fam, {}).get(cn, 0.0) + val
-    steps = 2.0                                                  # the PMC passes run `--steps 1 --warmup 1`
+    steps = float(os.environ.get("PMC_STEPS", 2))                # the PMC passes run `--steps 1 --warmup 1`
     stage_ms = bench["stage_ms_per_step"]["extend"]
     # VALU issue: wave-instructions per second against the rate MEASURED on this GPU by tools/ubench/valu_int.hip (the best line of the
     # committed run: independent v_add_u32 + v_max_i32 chains), and against the nominal 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction
@@ -86,7 +122,7 @@ def main():
             if rates:
                 measured_peak, measured_src = max(rates) * 1e9, "profiles/" + fn
                 break
-    ext = {"kernel": "k_ext_lanes<side, P8, PF> + k_ext_wave<side> (the extension stage)", "workload": wl,
+    ext = {"kernel": "k_ext_seeds<P8, PF, PT, G4> + k_ext_wave (the extension stage)", "workload": wl,
            "per_kernel": {f: {"valu_wave_insts_per_step": c["SQ_INSTS_VALU"] / steps, "valu_busy_of_wave_cycles": c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"],
                               "wait_any_of_wave_cycles": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], "lds_insts_per_step": c["SQ_INSTS_LDS"] / steps,
                               "lds_bank_conflict_cycles": c["SQ_LDS_BANK_CONFLICT"]} for f, c in per.items()},
