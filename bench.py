@@ -1025,7 +1025,10 @@ def main():
                          "random_line_ceiling_glines": RANDOM_LINE_GLPS,
                          "delivered_glines": lines_counter,
                          "frac_of_random_line_ceiling": lines_counter / RANDOM_LINE_GLPS if lines_counter else None,
-                         "note": "k_bwd fetches isolated 64-byte lines; this GPU delivers ~55 G such lines/s (tools/ubench/randline.hip). "
+                         "note": "since round 4 pass 3 of the seeding (k_walk<3>, forward-only, no LDS) runs BESIDE k_bwd of pass 1 instead of beside k_walk<1>: the stage is "
+                                 "shorter (walk1 8.4 -> 5.4 ms, stage 36.3 -> ~35 ms) while k_bwd's own pass-1 interval now shares the GPU -- its launches are "
+                                 "averaged all the same; `seeding_stage.frac` is the stage-wide figure, `fm_index_kernels` every kernel's own.  "
+                                 "k_bwd fetches isolated 64-byte lines; this GPU delivers ~55 G such lines/s (tools/ubench/randline.hip). "
                                  "`achieved` counts 128 algorithmic bytes per backwardExt; `achieved_counter` / `delivered_glines` count "
                                  "the bytes / lines HBM actually delivered (FETCH_SIZE + WRITE_SIZE of the committed PMC passes): two "
                                  "ends of an interval in one CP_OCC block and L2-resident first steps make them smaller",

@@ -401,11 +401,28 @@ static __device__ void lane_dp8g(bool run, int qlen, int tlen, int w, int h0, co
     int beg = 0, end = qlen, maxv = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0;
     bool alive = run && tlen > 0;
     const int maxt = __builtin_amdgcn_readlane(wave_scan_max(alive ? tlen : 0, 0), 63);
-    int t_next = alive ? (int)tp[0] : 4;
+    // The target bases FOUR ROWS AT A TIME, one (unaligned) 32-bit load per four rows requested four rows before its first use: a byte load per
+    // row was consumed one row later, and a row of a short query lasts about as long as a global load takes on a 6 GB reference (a TLB miss
+    // more often than not) -- the short classes, which hold most seeds, waited for it in every row.
+    typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+    auto bases4 = [&](int i0) -> uint32_t {                      // byte k = base of row i0 + k (4 beyond the target's end)
+        uint32_t wv = 0x04040404u;
+        if (run && i0 < tlen) {
+            if (i0 + 3 < tlen) {
+                if (ts > 0) wv = *(const u32_unaligned *)(tp + i0);
+                else wv = __builtin_bswap32(*(const u32_unaligned *)(tp - i0 - 3));
+            } else {
+                wv = 0;
+                for (int k = 0; k < 4; k++) wv |= (uint32_t)(i0 + k < tlen ? tp[(int64_t)(i0 + k) * ts] : 4) << (8 * k);
+            }
+        }
+        return wv;
+    };
+    uint32_t tw_cur = bases4(0), tw_next = bases4(4);
     for (int i = 0; i < maxt; ++i) {
         if (!__ballot(alive)) break;
-        const int tb = t_next;
-        if (alive && i + 1 < tlen) t_next = (int)tp[(int64_t)(i + 1) * ts];
+        const int tb = (int)((tw_cur >> (8 * (i & 3))) & 0xffu);
+        if ((i & 3) == 3) { tw_cur = tw_next; tw_next = bases4(i + 5); }
         Dp8Row r; r.h1 = 0; r.f = 0; r.lnz = -1; r.key = 0; r.fnz_u = 0xffffffffu;
         if (alive) {
             if (beg < i - w) beg = i - w;
@@ -511,10 +528,19 @@ k_ext_seeds(DevIndex ix, ExtParams xp, const int32_t *__restrict__ tasks_all, co
             // stage the query bases
             const int maxq = __builtin_amdgcn_readlane(wave_scan_max(has ? tg.len2 : 0, 0), 63);
             if (PT) {                                               // one base per byte, 4 to a dword: the selector words of the byte permute
+                typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
                 for (int j0 = 0; j0 < maxq; j0 += 4) {
                     if (has && j0 < tg.len2) {
                         uint32_t wq = 0;
-                        for (int u = 0; u < 4 && j0 + u < tg.len2; u++) { const uint32_t qv = tg.q[(int64_t)(j0 + u) * tg.qs]; wq |= (qv > 3 ? 4u : qv) << (8 * u); }
+                        bool bytewise = j0 + 3 >= tg.len2;
+                        if (!bytewise) {                            // four bases with one (unaligned) load; a word with an N in it (rare) goes the byte way
+                            wq = tg.qs > 0 ? *(const u32_unaligned *)(tg.q + j0) : __builtin_bswap32(*(const u32_unaligned *)(tg.q - j0 - 3));
+                            bytewise = (wq & 0xfcfcfcfcu) != 0u;
+                        }
+                        if (bytewise) {
+                            wq = 0;
+                            for (int u = 0; u < 4 && j0 + u < tg.len2; u++) { const uint32_t qv = tg.q[(int64_t)(j0 + u) * tg.qs]; wq |= (qv > 3 ? 4u : qv) << (8 * u); }
+                        }
                         QL8[(j0 >> 2) * 64 + lane] = wq;
                     }
                 }
