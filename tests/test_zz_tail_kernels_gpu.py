@@ -182,3 +182,64 @@ def test_s1_batch_resident_between_runs(gpu_ctx_factory):
     for i in range(len(l2)):
         e = oracle.ksw_extend(q[qo[i]:qo[i + 1]], r[ro[i]:ro[i + 1]], oopt, 100, 5, int(h0[i]))
         assert tuple(int(got[i][f]) for f in ("score", "qle", "tle", "gtle", "gscore", "max_off")) == e, i
+
+
+# ---- the two tail kernels against the REFERENCE itself (oracle/_ref/refdump ksw / cigar: the reference's own ksw_align2 and bwa_gen_cigar2), not
+# through the library's host twins
+
+@pytest.mark.parametrize("args,kw", [([], {}), (["-A", "2", "-B", "5", "-O", "7,8", "-E", "2,1"], dict(a=2, b=5, o_del=7, o_ins=8, e_del=2, e_ins=1))])
+def test_device_ksw_align2_equals_the_reference(gpu_ctx_factory, tmp_path, args, kw):
+    import subprocess
+    from helpers import ref_binary
+    dump = ref_binary("refdump")
+    if dump is None:
+        pytest.skip("oracle/_ref not built (make -C oracle ref)")
+    opt = bm2.default_opt(**kw)
+    pairs = _pairs(31 + len(args), 2500)
+    xtra = [KSW_XSUBO | KSW_XSTART | (19 * opt.a) | (KSW_XBYTE if len(q) * opt.a < 250 else 0) for q, t in pairs]
+    pf, of = str(tmp_path / "pairs.txt"), str(tmp_path / "out.bin")
+    with open(pf, "w") as f:
+        for (q, t), x in zip(pairs, xtra):
+            f.write("%d %s %s\n" % (x, "".join("ACGTN"[c] for c in q), "".join("ACGTN"[c] for c in t)))
+    subprocess.check_call([dump] + args + ["ksw", pf, of], stderr=subprocess.DEVNULL)
+    exp = np.fromfile(of, "<i4").reshape(-1, 7)
+    got = bm2.ksw_align2(pairs, xtra, opt, ctx=gpu_ctx_factory())
+    bad = np.nonzero((exp != got).any(axis=1))[0]
+    assert len(bad) == 0, "%d of %d differ; first: pair %d reference %s device %s" % (len(bad), len(pairs), bad[0], exp[bad[0]].tolist(), got[bad[0]].tolist())
+
+
+def test_device_gen_cigar_equals_the_reference(gpu_ctx_factory, tmp_path):
+    import subprocess
+    from helpers import ref_binary
+    from test_gen_cigar import make_tasks
+    from tools import synth
+    exe, dump = ref_binary(), ref_binary("refdump")
+    if exe is None or dump is None:
+        pytest.skip("oracle/_ref not built (make -C oracle ref)")
+    names, ctg, alts = synth.make_genome(19, [150000, 60000], alt_contigs=0, n_repeat_families=3, repeat_len=(200, 1500), copies=(3, 10),
+                                         divergence=(0.0, 0.05), n_gaps=2, gap_len=(30, 200))
+    fa = str(tmp_path / "g.fa")
+    synth.write_fasta(fa, names, ctg)
+    subprocess.check_call([exe, "index", fa], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    tasks = make_tasks(ctg, 9, 3000)
+    tf, of = str(tmp_path / "tasks.txt"), str(tmp_path / "out.bin")
+    with open(tf, "w") as f:
+        for q, rb, re_, w in tasks:
+            f.write("%d %d %d %s\n" % (w, rb, re_, "".join("ACGTN"[c] for c in q)))
+    subprocess.check_call([dump, "cigar", fa, tf, of], stderr=subprocess.DEVNULL)
+    raw = open(of, "rb").read()
+    exp, p = [], 0
+    while p < len(raw):
+        sc, nc, nm = np.frombuffer(raw, "<i4", 3, p); p += 12
+        if nc < 0:
+            exp.append((int(sc), int(nm), None, b"")); continue
+        ops = [int(x) for x in np.frombuffer(raw, "<u4", nc, p)]; p += 4 * nc
+        e = raw.index(b"\0", p); md = raw[p:e]; p += (e - p + 1 + 3) & ~3
+        exp.append((int(sc), int(nm), ops, md))
+    got = bm2.gen_cigar(fa, bm2.default_opt(), tasks, ctx=gpu_ctx_factory(fa))
+    assert len(exp) == len(got) == len(tasks)
+    for i, (x, y) in enumerate(zip(exp, got)):
+        if x[2] is None:
+            assert y[2] is None, "task %d: the reference returns NULL" % i
+        else:
+            assert x == y, "task %d (w %d, %d..%d): reference %s device %s" % (i, tasks[i][3], tasks[i][1], tasks[i][2], x, y)
