@@ -846,8 +846,10 @@ def main():
         prefix, contigs = prepare_genome(a.workdir, a.genome_mbp, seed)
 
     t = time.time()
+    free0 = torch.cuda.mem_get_info(local)[0] if not emu else 0
     ctx = bm2.Context(local, prefix)
-    log("rank %d: index replica in HBM after %.1fs" % (rank, time.time() - t))
+    replica_gb = (free0 - torch.cuda.mem_get_info(local)[0]) / 1e9 if not emu else None       # (what the device's free memory dropped by)
+    log("rank %d: index replica in HBM after %.1fs (%s GB)" % (rank, time.time() - t, "%.2f" % replica_gb if replica_gb is not None else "-"))
     ont = a.workload == "ont2d"
     paired = not ont
     if ont:
@@ -1002,6 +1004,9 @@ def main():
             "value_end_to_end": None,
             "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "strong" if a.strong else "weak", "vs_baseline": None,
             "dtype": "int32", "data": "synthetic" if not emu else "synthetic; HOST EMULATOR RUN (not a measurement)",
+            "index_replica_gb": round(replica_gb, 2) if replica_gb is not None else None,
+            "index_replica_layout": "Occ checkpoints 64 B per 64 symbols, suffix array 5 B per 8 positions, reference string "
+                                    + ("1 byte per base (BM2_REF_BYTES=1)" if os.environ.get("BM2_REF_BYTES", "0") not in ("", "0") else "2 bits per base (refseq.h)"),
             "config": {"workload": wl_name + " (SMEM+SAL+chain+banded-SW all on device), synthetic %d Mbp genome with planted repeats/ALT/"
                                    "N-gaps, indexed in-run by bm2_index_build (3100 Mbp = GRCh38 size); `value` = device hot path "
                                    "with the reads resident in HBM (the steps go round %d distinct chunks), output = mem_alnreg_t regs at bwamem.cpp:1152; the FASTQ -> SAM "

@@ -240,6 +240,71 @@ __global__ void __launch_bounds__(256) k_cp_occ_relayout(CpOcc *occ, int64_t n) 
     ((CpOccDev *)occ)[i] = d;
 }
 
+// The reference string on the device: four codes per byte (refseq.h).  The host's image -- one code per byte, as fastmap.cpp:873-881 reads the
+// .0123 file -- goes through a staging buffer in pieces and is packed by a kernel, 64 codes per thread.  A code above 3 cannot be packed (the
+// .0123 file holds none: bntseq.cpp:284 draws a random base for every ambiguous one): the kernel reports it and the caller keeps bytes.
+#define REF_PIECE ((size_t)64 << 20)
+__global__ void __launch_bounds__(256) k_pack_ref(const uint8_t *__restrict__ src, int64_t n_codes, uint8_t *__restrict__ dst, int *bad) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, c0 = t * 64;
+    if (c0 >= n_codes) return;
+    uint32_t over = 0;
+    if (c0 + 64 <= n_codes) {
+        uint32_t o[4];
+        for (int k = 0; k < 4; k++) {
+            const uint4 v = ((const uint4 *)(src + c0))[k];
+            const uint32_t w[4] = { v.x, v.y, v.z, v.w };
+            uint32_t acc = 0;
+            for (int u = 0; u < 4; u++) {
+                over |= w[u] & 0xfcfcfcfcu;
+                const uint32_t x = w[u] & 0x03030303u;
+                acc |= ((x | x >> 6 | x >> 12 | x >> 18) & 0xffu) << (8 * u);
+            }
+            o[k] = acc;
+        }
+        *(uint4 *)(dst + (c0 >> 2)) = make_uint4(o[0], o[1], o[2], o[3]);
+    } else {
+        for (int64_t b = c0; b < n_codes; b += 4) {
+            uint32_t acc = 0;
+            for (int u = 0; u < 4 && b + u < n_codes; u++) { over |= src[b + u] & 0xfcu; acc |= (uint32_t)(src[b + u] & 3) << (2 * u); }
+            dst[b >> 2] = (uint8_t)acc;
+        }
+    }
+    if (over) *bad = 1;
+}
+static int upload_ref(bm2_ctx *c, const uint8_t *src, size_t n_codes) {
+    int rc;
+    if (bm2_knob("BM2_REF_BYTES", 0)) return upload(&c->d_ref, src, n_codes, c->stream);        // (one code per byte: for A/B measurements)
+    const size_t packed = (n_codes + 3) / 4 + 16;               // (RefPtr::load4 reads one byte beyond the last code's)
+    void *stage = nullptr; int *bad = nullptr;
+    if ((rc = bm2_check(hipMalloc(&c->d_ref, packed), "hipMalloc(reference, packed)"))) return rc;
+    rc = bm2_check(hipMalloc(&stage, REF_PIECE + 64), "hipMalloc(reference staging)");
+    if (!rc) rc = bm2_check(hipMalloc((void **)&bad, 64), "hipMalloc(flag)");
+    if (!rc) rc = bm2_check(hipMemsetAsync(bad, 0, 4, c->stream), "memset");
+    if (!rc) rc = bm2_check(hipMemsetAsync((char *)c->d_ref + (packed - 32), 0, 32, c->stream), "memset");
+    for (size_t off = 0; !rc && off < n_codes; off += REF_PIECE) {
+        const size_t n = n_codes - off < REF_PIECE ? n_codes - off : REF_PIECE;
+        rc = bm2_check(hipMemcpyAsync(stage, src + off, n, hipMemcpyHostToDevice, c->stream), "hipMemcpy(reference piece)");
+        if (rc) break;
+        const size_t thr = (n + 63) / 64;
+        hipLaunchKernelGGL(k_pack_ref, dim3((unsigned)((thr + 255) / 256)), dim3(256), 0, c->stream, (const uint8_t *)stage, (int64_t)n,
+                           (uint8_t *)c->d_ref + off / 4, bad);
+        rc = bm2_check(hipGetLastError(), "k_pack_ref");
+    }
+    int h_bad = 0;
+    if (!rc) rc = bm2_check(hipMemcpyAsync(&h_bad, bad, 4, hipMemcpyDeviceToHost, c->stream), "D2H flag");
+    if (!rc) rc = bm2_check(hipStreamSynchronize(c->stream), "reference upload");
+    if (stage) (void)hipFree(stage);
+    if (bad) (void)hipFree(bad);
+    if (rc) return rc;
+    if (h_bad) {        // not a .0123 image: keep what the caller gave
+        fprintf(stderr, "[libbm2] note: the reference string holds codes above 3; kept one code per byte on the device\n");
+        (void)hipFree(c->d_ref); c->d_ref = nullptr;
+        return upload(&c->d_ref, src, n_codes, c->stream);
+    }
+    c->ix.ref_pk = 1;
+    return BM2_OK;
+}
+
 // The runtime reads GPU_MAX_HW_QUEUES when it STARTS (default: four hardware queues per process).  The earliest moment this library can speak
 // is when it is loaded: it asks for sixteen unless the host chose (eight launches of an extension phase, five of the chaining stage, the
 // copies of the neighbouring chunk: with 16 queues the hot path takes 74.8 ms instead of 76.7 and the FASTQ -> SAM leg gains 7 %; with 24 the hot path collapses to 101 ms).  A host that has initialised HIP before loading libbm2 keeps what it had
@@ -280,7 +345,7 @@ extern "C" bm2_ctx *bm2_create(int device, const bm2_index_desc *idx) {
         }
         rc = rc ? rc : upload(&c->d_sa_ms, idx->sa_ms_byte, (size_t)nsa, c->stream);
         rc = rc ? rc : upload(&c->d_sa_ls, idx->sa_ls_word, (size_t)nsa, c->stream);
-        rc = rc ? rc : upload(&c->d_ref, idx->ref_string, (size_t)(2 * idx->l_pac), c->stream);
+        rc = rc ? rc : upload_ref(c, idx->ref_string, (size_t)(2 * idx->l_pac));
         rc = rc ? rc : upload(&c->d_ann_off, idx->ann_offset, (size_t)idx->n_seqs, c->stream);
         rc = rc ? rc : upload(&c->d_ann_len, idx->ann_len, (size_t)idx->n_seqs, c->stream);
         rc = rc ? rc : upload(&c->d_ann_alt, idx->ann_is_alt, (size_t)idx->n_seqs, c->stream);

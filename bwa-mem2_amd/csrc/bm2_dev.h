@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/bm2.h"
+#include "refseq.h"
 
 #define BM2_WAVE 64
 #define BM2_BLOCK_READS 512          // BATCH_SIZE of the reference (macro.h:48): the kt_for block (kthread.cpp:53-78)
@@ -24,13 +25,15 @@ struct DevIndex {
     const CpOccDev *cp_occ;
     const int8_t   *sa_ms_byte;
     const uint32_t *sa_ls_word;
-    const uint8_t  *ref_string;      // .0123: forward then reverse complement, one base per byte
+    const uint8_t  *ref_string;      // .0123: forward then reverse complement; four bases per byte when ref_pk (refseq.h), else one
     const int64_t  *ann_offset;
     const int32_t  *ann_len;
     const int32_t  *ann_is_alt;
     int64_t ref_len, l_pac, sentinel_index;
     int64_t count[5];                // already +1 (FMI_search.cpp:433-436)
     int32_t n_seqs;
+    int32_t ref_pk;
+    __host__ __device__ RefPtr ref(int64_t pos) const { return RefPtr{ref_string, pos, ref_pk}; }
 };
 
 struct SwParams {                    // scoring for one extension side

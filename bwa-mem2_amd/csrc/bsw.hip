@@ -27,7 +27,7 @@ k_bsw_pairs(bm2_seqpair_t *__restrict__ pairs, const uint8_t *__restrict__ ref, 
     const int cls = pair_class(sp.len1, sp.len2, sp.h0, sP->max_sc);
     const int wc = band_clamp(w, sp.len2, *sP, cls);
     SwOut o;
-    int cells = bsw_extend(qer + sp.idq, 1, sp.len2, ref + sp.idr, 1, sp.len1, wc, sp.h0, *sP, RH, RE, R - 1, o);
+    int cells = bsw_extend(qer + sp.idq, 1, sp.len2, RefPtr::bytes(ref + sp.idr), 1, sp.len1, wc, sp.h0, *sP, RH, RE, R - 1, o);
     if ((threadIdx.x & 63) == 0) {
         bm2_seqpair_t *d = &pairs[wid];
         d->score = o.score; d->tle = o.tle; d->gtle = o.gtle; d->qle = o.qle; d->gscore = o.gscore; d->max_off = o.max_off;
@@ -60,7 +60,7 @@ k_bsw_list(bm2_seqpair_t *__restrict__ pairs, const uint8_t *__restrict__ ref, c
         const int cls = pair_class(sp.len1, sp.len2, sp.h0, sP->max_sc);
         const int wc = band_clamp(w, sp.len2, *sP, cls);
         SwOut o;
-        cells += bsw_extend(qer + sp.idq, 1, sp.len2, ref + sp.idr, 1, sp.len1, wc, sp.h0, *sP, RH, RE, R - 1, o);
+        cells += bsw_extend(qer + sp.idq, 1, sp.len2, RefPtr::bytes(ref + sp.idr), 1, sp.len1, wc, sp.h0, *sP, RH, RE, R - 1, o);
         if ((threadIdx.x & 63) == 0) {
             bm2_seqpair_t *d = &pairs[id];
             d->score = o.score; d->tle = o.tle; d->gtle = o.gtle; d->qle = o.qle; d->gscore = o.gscore; d->max_off = o.max_off;

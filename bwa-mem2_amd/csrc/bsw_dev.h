@@ -99,7 +99,7 @@ static __device__ __forceinline__ bool zdrop_stop(int cls, bool new_max, int max
 // read and through ref_string, so no reversed copies are ever materialised, cf. bwamem.cpp:2268-2290).
 // `w` must already be clamped.  Returns the number of DP cells computed.
 static __device__ int bsw_extend_wave(const uint8_t *__restrict__ qp, int qs, int qlen,
-                                      const uint8_t *__restrict__ tp, int ts, int tlen,
+                                      RefPtr tp, int ts, int tlen,
                                       int w, int h0, const SwParams &P, int *RH, int *RE, int RM, SwOut &out) {
     const int lane = threadIdx.x & 63;
     const int oe_del = P.o_del + P.e_del, oe_ins = P.o_ins + P.e_ins, e_del = P.e_del, e_ins = P.e_ins;
@@ -194,7 +194,7 @@ static __device__ int bsw_extend_wave(const uint8_t *__restrict__ qp, int qs, in
 // reference's SIMD kernels implement (bandedSWA.cpp:286-290): P.mat[0] / P.mat[1] / P.mat[4].
 template <int NCH>
 static __device__ int bsw_extend_reg(const uint8_t *__restrict__ qp, int qs, int qlen_,
-                                     const uint8_t *__restrict__ tp, int ts, int tlen_,
+                                     RefPtr tp, int ts, int tlen_,
                                      int w_, int h0_, const SwParams &P, SwOut &out) {
     const int lane = threadIdx.x & 63;
     const int qlen = uni(qlen_), tlen = uni(tlen_), w = uni(w_), h0 = uni(h0_);
@@ -308,7 +308,7 @@ static __device__ int bsw_extend_reg(const uint8_t *__restrict__ qp, int qs, int
 // per-row global loads: the ring variant below pays a dependent global load for the query and four LDS round trips per chunk.
 template <int NCH>
 static __device__ int bsw_extend_slide(const uint8_t *__restrict__ qp, int qs, int qlen_,
-                                       const uint8_t *__restrict__ tp, int ts, int tlen_,
+                                       RefPtr tp, int ts, int tlen_,
                                        int w_, int h0_, const SwParams &P, SwOut &out) {
     const int lane = threadIdx.x & 63;
     const int qlen = uni(qlen_), tlen = uni(tlen_), w = uni(w_), h0 = uni(h0_);
@@ -423,7 +423,7 @@ static __device__ int bsw_extend_slide(const uint8_t *__restrict__ qp, int qs, i
 
 // dispatch: registers when the query fits 4 chunks, a sliding register window when the band fits 8, the LDS ring otherwise
 static __device__ __forceinline__ int bsw_extend(const uint8_t *__restrict__ qp, int qs, int qlen,
-                                                 const uint8_t *__restrict__ tp, int ts, int tlen,
+                                                 RefPtr tp, int ts, int tlen,
                                                  int w, int h0, const SwParams &P, int *RH, int *RE, int RM, SwOut &out) {
     const int nch = (qlen >> 6) + 1;
     if (nch == 1) return bsw_extend_reg<1>(qp, qs, qlen, tp, ts, tlen, w, h0, P, out);

@@ -116,7 +116,7 @@ static __device__ __forceinline__ void cg_nm_md(const uint32_t *cg, int ncg, QF 
 }
 
 __global__ void __launch_bounds__(256)
-k_cigar_flat(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ seqs, const CigarTask *__restrict__ tasks, const int *__restrict__ order,
+k_cigar_flat(RefPtr ref, const uint8_t *__restrict__ seqs, const CigarTask *__restrict__ tasks, const int *__restrict__ order,
              int n, CigarPrm prm, uint32_t *__restrict__ cgbuf, char *__restrict__ mdbuf, CigarRes *__restrict__ res) {
     const int slot = blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= n) return;
@@ -146,7 +146,7 @@ k_cigar_flat(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ seqs, 
 
 template <int MODE>
 __global__ void __launch_bounds__(64)
-k_gen_cigar(const uint8_t *__restrict__ ref, const uint8_t *__restrict__ seqs, const CigarTask *__restrict__ tasks, const int *__restrict__ order,
+k_gen_cigar(RefPtr ref, const uint8_t *__restrict__ seqs, const CigarTask *__restrict__ tasks, const int *__restrict__ order,
             int n, CigarPrm prm, uint8_t *__restrict__ zbuf, int2 *__restrict__ ehbuf, uint32_t *__restrict__ cgbuf, char *__restrict__ mdbuf,
             CigarRes *__restrict__ res, int qmax, int resume, int *__restrict__ defer_list, int *__restrict__ defer_count) {
     constexpr bool LDS = MODE != CG_GLOBAL, RING = MODE == CG_RINGED;
@@ -420,23 +420,23 @@ static int cigar_run(bm2_ctx *c, const bm2_opt *opt, std::vector<CigarTask> &tas
     if ((rc = bm2_check(hipMemsetAsync(d_defer, 0, 4, s), "memset"))) return rc;
     // (the costliest tasks lead every list; the four launches follow each other on the stream, the cheap flat tasks last)
     if (n_shape[SH_RING])
-        hipLaunchKernelGGL(k_gen_cigar<CG_RINGED>, dim3((n_shape[SH_RING] + 63) / 64), dim3(64), lds_ring, s, c->ix.ref_string, (const uint8_t *)b_seq.p, d_task, o_ring,
+        hipLaunchKernelGGL(k_gen_cigar<CG_RINGED>, dim3((n_shape[SH_RING] + 63) / 64), dim3(64), lds_ring, s, c->ix.ref(0), (const uint8_t *)b_seq.p, d_task, o_ring,
                            n_shape[SH_RING], prm, d_z, d_eh, d_cg, d_md, d_res, qmax, 0, d_defer + 1, d_defer);
     if (n_shape[SH_ROW])
-        hipLaunchKernelGGL(k_gen_cigar<CG_ROW>, dim3((n_shape[SH_ROW] + 63) / 64), dim3(64), lds_row, s, c->ix.ref_string, (const uint8_t *)b_seq.p, d_task, o_row,
+        hipLaunchKernelGGL(k_gen_cigar<CG_ROW>, dim3((n_shape[SH_ROW] + 63) / 64), dim3(64), lds_row, s, c->ix.ref(0), (const uint8_t *)b_seq.p, d_task, o_row,
                            n_shape[SH_ROW], prm, d_z, d_eh, d_cg, d_md, d_res, qmax, 0, (int *)nullptr, (int *)nullptr);
     if (n_shape[SH_GLOBAL])
-        hipLaunchKernelGGL(k_gen_cigar<CG_GLOBAL>, dim3((n_shape[SH_GLOBAL] + 63) / 64), dim3(64), 0, s, c->ix.ref_string, (const uint8_t *)b_seq.p, d_task, o_glob,
+        hipLaunchKernelGGL(k_gen_cigar<CG_GLOBAL>, dim3((n_shape[SH_GLOBAL] + 63) / 64), dim3(64), 0, s, c->ix.ref(0), (const uint8_t *)b_seq.p, d_task, o_glob,
                            n_shape[SH_GLOBAL], prm, d_z, d_eh, d_cg, d_md, d_res, 0, 0, (int *)nullptr, (int *)nullptr);
     if (n_shape[SH_FLAT])
-        hipLaunchKernelGGL(k_cigar_flat, dim3((n_shape[SH_FLAT] + 255) / 256), dim3(256), 0, s, c->ix.ref_string, (const uint8_t *)b_seq.p, d_task, o_flat,
+        hipLaunchKernelGGL(k_cigar_flat, dim3((n_shape[SH_FLAT] + 255) / 256), dim3(256), 0, s, c->ix.ref(0), (const uint8_t *)b_seq.p, d_task, o_flat,
                            n_shape[SH_FLAT], prm, d_cg, d_md, d_res);
     int n_defer = 0;
     if (n_shape[SH_RING]) {                                      // tasks whose first try asked for a wider band: their later tries in the ROW kernel
         if ((rc = bm2_check(hipMemcpyAsync(&n_defer, d_defer, 4, hipMemcpyDeviceToHost, s), "D2H deferred"))) return rc;
         if ((rc = bm2_check(hipStreamSynchronize(s), "k_gen_cigar"))) return rc;
         if (n_defer > 0)
-            hipLaunchKernelGGL(k_gen_cigar<CG_ROW>, dim3((n_defer + 63) / 64), dim3(64), lds_row, s, c->ix.ref_string, (const uint8_t *)b_seq.p, d_task, d_defer + 1,
+            hipLaunchKernelGGL(k_gen_cigar<CG_ROW>, dim3((n_defer + 63) / 64), dim3(64), lds_row, s, c->ix.ref(0), (const uint8_t *)b_seq.p, d_task, d_defer + 1,
                                n_defer, prm, d_z, d_eh, d_cg, d_md, d_res, qmax, 1, (int *)nullptr, (int *)nullptr);
     }
     if ((rc = bm2_check(hipGetLastError(), "k_gen_cigar launch"))) return rc;

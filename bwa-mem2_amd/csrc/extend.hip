@@ -32,18 +32,18 @@ struct ExtParams {
 #define EBIN_NONE 0xffffffffu     // nothing to extend
 
 // geometry of the two extension tasks of a seed (what a SeqPair + its seqBuf slices describe, bwamem.cpp:2229-2418)
-struct TaskGeom { const uint8_t *q, *t; int qs, ts, len2, len1; };
+struct TaskGeom { const uint8_t *q; RefPtr t; int qs, ts, len2, len1; };
 static __device__ __forceinline__ TaskGeom task_geom(int side, const DevSeed &s, const DevChain &c, const uint8_t *query,
-                                                     int l_query, const uint8_t *ref) {
+                                                     int l_query, RefPtr ref) {
     TaskGeom g;
     if (side == 0) {            // left: query prefix and reference prefix, both walked backwards
         g.len2 = s.qbeg; g.len1 = (int)(s.rbeg - c.rmax0);
-        g.q = query + s.qbeg - 1; g.qs = -1; g.t = ref + s.rbeg - 1; g.ts = -1;
+        g.q = query + s.qbeg - 1; g.qs = -1; g.t = ref + (s.rbeg - 1); g.ts = -1;
     } else {
         const int qe0 = s.qbeg + s.len;
         const int64_t re0 = s.rbeg + s.len - c.rmax0;
         g.len2 = l_query - qe0; g.len1 = (int)(c.rmax1 - c.rmax0 - re0);
-        g.q = query + qe0; g.qs = 1; g.t = ref + c.rmax0 + re0; g.ts = 1;
+        g.q = query + qe0; g.qs = 1; g.t = ref + (c.rmax0 + re0); g.ts = 1;
     }
     return g;
 }
@@ -69,7 +69,7 @@ static __device__ __forceinline__ uint32_t seed_bin(const ExtParams &xp, const D
     int ll = 0, lr = 0; bool ok = true;
     for (int side = 0; side < 2; side++) {
         if (!(side == 0 ? hl : hr)) continue;
-        const TaskGeom tg = task_geom(side, s, c, nullptr, l_query, nullptr);
+        const TaskGeom tg = task_geom(side, s, c, nullptr, l_query, RefPtr::bytes(nullptr));
         ok = ok && tg.len2 <= LANE_QMAX && tg.len1 < 32768 && (l_query + tg.len1 + 1) * xp.a < 32768;
         if (side == 0) ll = tg.len2; else lr = tg.len2;
     }
@@ -134,7 +134,7 @@ __global__ void k_phase_stats(const int64_t *__restrict__ start, const uint32_t 
 // band or past its own exit is masked off.
 struct LaneOut { int score, qle, tle, gtle, gscore, max_off; };
 
-static __device__ void lane_dp(bool run, int qlen, int tlen, int w, int h0, const uint8_t *tp, int ts, const SwParams &P,
+static __device__ void lane_dp(bool run, int qlen, int tlen, int w, int h0, RefPtr tp, int ts, const SwParams &P,
                                uint32_t *EH, const uint8_t *QL, int lane, LaneOut &out, long long &cells, long long &iters) {
     const int o_del = P.o_del, e_del = P.e_del, o_ins = P.o_ins, e_ins = P.e_ins, oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
     const int sc_match = P.mat[0], sc_mis = P.mat[1], sc_amb = P.mat[4];
@@ -222,7 +222,7 @@ static __device__ void lane_dp(bool run, int qlen, int tlen, int w, int h0, cons
 // their four scores -- the two compares and two selects per cell of the 4-bit layout are gone (27 -> 22 VALU per cell).
 static __device__ __forceinline__ uint32_t rep4(int x) { return ((uint32_t)x & 0xffu) * 0x01010101u; }
 template <bool PF, bool PT = false>
-static __device__ void lane_dp8(bool run, int qlen, int tlen, int w, int h0, const uint8_t *tp, int ts, const SwParams &P,
+static __device__ void lane_dp8(bool run, int qlen, int tlen, int w, int h0, RefPtr tp, int ts, const SwParams &P,
                                 uint32_t *EH, const uint32_t *QL, int lane, LaneOut &out, long long &cells, long long &iters) {
     const int o_del = P.o_del, e_del = P.e_del, o_ins = P.o_ins, e_ins = P.e_ins, oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
     int sc_match = P.mat[0], sc_mis = P.mat[1], sc_amb = P.mat[4];
@@ -383,7 +383,7 @@ static __device__ __forceinline__ void dp8_group(int g, uint32_t w0, uint32_t w1
     }
 }
 
-static __device__ void lane_dp8g(bool run, int qlen, int tlen, int w, int h0, const uint8_t *tp, int ts, const SwParams &P,
+static __device__ void lane_dp8g(bool run, int qlen, int tlen, int w, int h0, RefPtr tp, int ts, const SwParams &P,
                                  uint32_t *EH, const uint32_t *QL, int lane, LaneOut &out, long long &cells, long long &iters) {
     const int o_del = P.o_del, e_del = P.e_del, o_ins = P.o_ins, e_ins = P.e_ins, oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
     const int sc_match = P.mat[0], sc_mis = P.mat[1], sc_amb = P.mat[4];
@@ -404,14 +404,11 @@ static __device__ void lane_dp8g(bool run, int qlen, int tlen, int w, int h0, co
     // The target bases FOUR ROWS AT A TIME, one (unaligned) 32-bit load per four rows requested four rows before its first use: a byte load per
     // row was consumed one row later, and a row of a short query lasts about as long as a global load takes on a 6 GB reference (a TLB miss
     // more often than not) -- the short classes, which hold most seeds, waited for it in every row.
-    typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
     auto bases4 = [&](int i0) -> uint32_t {                      // byte k = base of row i0 + k (4 beyond the target's end)
         uint32_t wv = 0x04040404u;
         if (run && i0 < tlen) {
-            if (i0 + 3 < tlen) {
-                if (ts > 0) wv = *(const u32_unaligned *)(tp + i0);
-                else wv = __builtin_bswap32(*(const u32_unaligned *)(tp - i0 - 3));
-            } else {
+            if (i0 + 3 < tlen) wv = tp.load4(i0, ts);
+            else {
                 wv = 0;
                 for (int k = 0; k < 4; k++) wv |= (uint32_t)(i0 + k < tlen ? tp[(int64_t)(i0 + k) * ts] : 4) << (8 * k);
             }
@@ -518,10 +515,10 @@ k_ext_seeds(DevIndex ix, ExtParams xp, const int32_t *__restrict__ tasks_all, co
             if (!__ballot(has)) continue;
             const SwParams &P = side == 0 ? xp.left : xp.right;
             TaskGeom tg;
-            tg.len1 = tg.len2 = 0; tg.q = tg.t = ix.ref_string; tg.qs = tg.ts = 1;
+            tg.len1 = tg.len2 = 0; tg.q = enc; tg.t = ix.ref(0); tg.qs = tg.ts = 1;
             int h0 = 0, prev = -1;
             if (has) {
-                tg = task_geom(side, s, c, enc + off[c.read], l_query, ix.ref_string);
+                tg = task_geom(side, s, c, enc + off[c.read], l_query, ix.ref(0));
                 if (side == 0) h0 = s.len * xp.a;
                 else { h0 = a.score; prev = a.score; }
             }
@@ -587,7 +584,7 @@ k_ext_seeds(DevIndex ix, ExtParams xp, const int32_t *__restrict__ tasks_all, co
 
 // one side on one wavefront, with the accept/retry rule of bwamem.cpp:2495-2496: stop when the score did not change, or
 // the best cell stayed within 3/4 of the band, or this was the last try.
-static __device__ __forceinline__ int extend_side(const uint8_t *q, int qs, int len2, const uint8_t *t, int ts, int len1, int h0,
+static __device__ __forceinline__ int extend_side(const uint8_t *q, int qs, int len2, RefPtr t, int ts, int len1, int h0,
                                                   int prev, int w0, const SwParams &P, int *RH, int *RE, int RM, SwOut &o,
                                                   int &w_used, long long &cells) {
     const int cls = pair_class(len1, len2, h0, P.max_sc);
@@ -634,7 +631,7 @@ k_ext_wave(DevIndex ix, ExtParams xp, const int32_t *__restrict__ tasks_all, con
 #pragma nounroll
         for (int side = 0; side < 2; side++) {
             if (!(side == 0 ? s.qbeg != 0 : s.qbeg + s.len != l_query)) continue;
-            const TaskGeom tg = task_geom(side, s, c, enc + off[c.read], l_query, ix.ref_string);
+            const TaskGeom tg = task_geom(side, s, c, enc + off[c.read], l_query, ix.ref(0));
             const int h0 = side == 0 ? s.len * sP->a : a.score;
             const int prev = side == 0 ? -1 : a.score;
             SwOut o; int w_used;
@@ -701,6 +698,41 @@ static __device__ bool seed_redundant(const ChainParams &o, int l_query, const D
         w = max_gap < p.w ? max_gap : p.w;
         if (qd - rd < w && rd - qd < w) break;
         v++;
+    }
+    if (v < lim) {
+        for (v = k + 1; v < c.n; ++v) {
+            if (srt2[v] < 0) continue;                      // UINT_MAX marker of the reference
+            const DevSeed t = cs[srt2[v]];
+            if (t.len < s.len * .95) continue;
+            if (s.qbeg <= t.qbeg && s.qbeg + s.len - t.qbeg >= s.len >> 2 && t.qbeg - s.qbeg != t.rbeg - s.rbeg) break;
+            if (t.qbeg <= s.qbeg && t.qbeg + t.len - s.qbeg >= s.len >> 2 && s.qbeg - t.qbeg != s.rbeg - t.rbeg) break;
+        }
+        if (v == c.n) return true;
+    }
+    return false;
+}
+
+// The same test for the lazy rounds, over the LIST of the read's kept regs instead of all its regs: in a lazy round every reg before the cursor is
+// either purged (never extended) or was picked and extended -- the kept ones are exactly the picks, in order -- so `lim` is the list's length and
+// the walk visits av[kept[0]], av[kept[1]], ... where the walk above skips over the purged regs between them one by one (quadratic in the regs of a
+// long read's chain: k_advance took 38 ms per 10 000 reads of 10 kb).
+static __device__ bool seed_redundant_kept(const ChainParams &o, int l_query, const DevReg *av, const int32_t *kept, int lim, const DevChain &c,
+                                           const DevSeed *cs, const int32_t *srt2, int k) {
+    const DevSeed s = cs[srt2[k]];
+    int v = 0;
+    for (; v < lim; ++v) {
+        const DevReg p = av[kept[v]];
+        int64_t rd; int qd, w, max_gap;
+        if (s.rbeg < p.rb || s.rbeg + s.len > p.re || s.qbeg < p.qb || s.qbeg + s.len > p.qe) continue;
+        if (s.len - p.seedlen0 > .1 * l_query) continue;
+        qd = s.qbeg - p.qb; rd = s.rbeg - p.rb;
+        max_gap = cal_max_gap2(o, qd < rd ? qd : (int)rd);
+        w = max_gap < p.w ? max_gap : p.w;
+        if (qd - rd < w && rd - qd < w) break;
+        qd = p.qe - (s.qbeg + s.len); rd = p.re - (s.rbeg + s.len);
+        max_gap = cal_max_gap2(o, qd < rd ? qd : (int)rd);
+        w = max_gap < p.w ? max_gap : p.w;
+        if (qd - rd < w && rd - qd < w) break;
     }
     if (v < lim) {
         for (v = k + 1; v < c.n; ++v) {
@@ -881,7 +913,8 @@ k_advance(ChainParams o, ExtParams xp, int n_reads, const int32_t *__restrict__ 
           const int64_t *__restrict__ read_base, const int32_t *__restrict__ n_reg,
           const int32_t *__restrict__ reg_chain, const DevChain *__restrict__ chn,
           const DevSeed *__restrict__ seeds, int32_t *srt_all, DevReg *regs, int32_t *cursor, int32_t *cur_slot /* [n_reads] reg idx to extend or -1 */,
-          uint32_t *ebin /* [n_reads] sort key of the picked seed */, int32_t *hist /* [N_EBINS] */, uint32_t *pend /* reads with undecided seeds left */) {
+          uint32_t *ebin /* [n_reads] sort key of the picked seed */, int32_t *hist /* [N_EBINS] */, uint32_t *pend /* reads with undecided seeds left */,
+          int32_t *kept /* [n_slots]: per read the reg indices picked so far, in order */, int32_t *n_kept /* [n_reads] */) {
     __shared__ uint32_t sh_pend;
     if (threadIdx.x == 0) sh_pend = 0;
     __syncthreads();
@@ -895,8 +928,7 @@ k_advance(ChainParams o, ExtParams xp, int n_reads, const int32_t *__restrict__ 
             const int64_t base = read_base[r];
             const int l_query = len[r];
             DevReg *av = regs + base;
-            int lim = 0;
-            for (int i = 0; i < cur; i++) if (!(av[i].qb == -1 && av[i].qe == -1)) lim++;
+            const int lim = n_kept[r];                       // (= the regs before the cursor that are not purged: the picks of the rounds before)
             while (cur < nr) {
                 const int ci = reg_chain[base + cur];
                 const DevChain c = chn[base + ci];
@@ -907,7 +939,7 @@ k_advance(ChainParams o, ExtParams xp, int n_reads, const int32_t *__restrict__ 
                 DevReg a;
                 a.w = xp.w; a.rid = c.rid; a.frac_rep = c.frac_rep; a.seedlen0 = s.len; a.chain = ci; a.seedcov = 0;
                 a.rb = s.rbeg; a.re = s.rbeg + s.len; a.score = a.truesc = -1; a.qb = a.qe = -1;
-                if (lim > 0 && seed_redundant(o, l_query, av, cur, lim, c, cs, srt2, k)) {
+                if (lim > 0 && seed_redundant_kept(o, l_query, av, kept + base, lim, c, cs, srt2, k)) {
                     srt2[k] = -1;                            // purged: never extended
                     av[cur] = a;
                     cur++;
@@ -920,6 +952,7 @@ k_advance(ChainParams o, ExtParams xp, int n_reads, const int32_t *__restrict__ 
                 if (b != EBIN_NONE) atomicAdd(&hist[b], 1);
                 av[cur] = a;
                 pick = cur;
+                kept[base + lim] = cur; n_kept[r] = lim + 1;
                 cur++;
                 break;
             }
@@ -1113,13 +1146,16 @@ int bm2_launch_extend(bm2_ctx *c, const bm2_opt &opt, const ChainParams &cp, int
     }
     if (n_lazy > lazy_max) n_lazy = lazy_max;
     if (n_lazy > EXT_EAGER_PHASE) n_lazy = EXT_EAGER_PHASE;
-    // scratch: ebin[n_items] | hist[N_EBINS] | pend[PHASES] | stat[PHASES][STATW] | start[N_EBINS + 1] | cur_slot[n_reads] | tasks[n_items]
+    // scratch: ebin[n_items] | hist[N_EBINS] | pend[PHASES] | stat[PHASES][STATW] | start[N_EBINS + 1] | cur_slot[n_reads] | tasks[n_items] | kept[n_slots] | n_kept[n_reads]
     const size_t n_items = (size_t)(n_slots > n_reads ? n_slots : n_reads);
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t o_hist = up(n_items * 4), o_pend = up(o_hist + (size_t)N_EBINS * 4), o_stat = o_pend + 256;
     const size_t o_start = up(o_stat + sizeof hint), o_cs = up(o_start + (size_t)(N_EBINS + 2) * 8), o_task = up(o_cs + (size_t)n_reads * 4);
-    if ((rc = bm2_reserve(tmp, o_task + n_items * 4 + 256))) return rc;
+    const size_t o_kept = up(o_task + n_items * 4), o_nk = up(o_kept + (size_t)n_slots * 4);
+    if ((rc = bm2_reserve(tmp, o_nk + (size_t)n_reads * 4 + 256))) return rc;
     char *base = (char *)tmp.p;
+    int32_t *kept = (int32_t *)(base + o_kept), *n_kept = (int32_t *)(base + o_nk);
+    if ((rc = bm2_check(hipMemsetAsync(n_kept, 0, (size_t)n_reads * 4, s), "memset n_kept"))) return rc;
     uint32_t *ebin = (uint32_t *)base, *pend = (uint32_t *)(base + o_pend), *stat = (uint32_t *)(base + o_stat);
     int32_t *hist = (int32_t *)(base + o_hist), *cur_slot = (int32_t *)(base + o_cs), *tasks = (int32_t *)(base + o_task);
     int64_t *start = (int64_t *)(base + o_start);
@@ -1136,7 +1172,7 @@ int bm2_launch_extend(bm2_ctx *c, const bm2_opt &opt, const ChainParams &cp, int
     const unsigned nbr = (unsigned)((n_reads + 127) / 128), nbr2 = (unsigned)((n_reads + 255) / 256);
     for (int round = 0; round < n_lazy; round++) {
         hipLaunchKernelGGL(k_advance, dim3(nbr), dim3(128), 0, s, cp, xp, n_reads, len, read_base, n_reg, reg_chain, chn, seeds, srt_all,
-                           regs, cursor, cur_slot, ebin, hist, pend + round);
+                           regs, cursor, cur_slot, ebin, hist, pend + round, kept, n_kept);
         if ((rc = sort_and_run(round, n_reads, true))) return rc;
         hipLaunchKernelGGL(k_seedcov_round, dim3(nbr2), dim3(256), 0, s, n_reads, read_base, cur_slot, reg_chain, chn, seeds, regs);
     }
@@ -1199,7 +1235,7 @@ k_bsw_lanes(bm2_seqpair_t *pairs, const uint8_t *__restrict__ ref, const uint8_t
         const int cls = pair_class(len1, len2, h0, P.max_sc);
         const int wc = band_clamp(w, len2, P, cls);
         LaneOut o; o.score = h0; o.qle = o.tle = o.gtle = 0; o.gscore = -1; o.max_off = 0;
-        lane_dp8g(valid, len2, len1, wc, h0, t, 1, P, EH, QL8, lane, o, cells, iters);
+        lane_dp8g(valid, len2, len1, wc, h0, RefPtr::bytes(t), 1, P, EH, QL8, lane, o, cells, iters);
         if (valid) {
             bm2_seqpair_t *d = &pairs[id];
             d->score = o.score; d->tle = o.tle; d->gtle = o.gtle; d->qle = o.qle; d->gscore = o.gscore; d->max_off = o.max_off;

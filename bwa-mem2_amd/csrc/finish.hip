@@ -213,7 +213,7 @@ k_fin_order(int n_reads, const int64_t *__restrict__ reg_off, bm2_alnreg_t *work
 }
 
 // ---- ksw_global2 without backtrack (ksw.cpp:558-668) for one request on one wavefront.  q / t are walked with strides qs / ts.
-static __device__ int fin_global_score(const uint8_t *qp, int qs, int qlen, const uint8_t *tp, int ts, int tlen, int w, const FinParams &P,
+static __device__ int fin_global_score(const uint8_t *qp, int qs, int qlen, RefPtr tp, int ts, int tlen, int w, const FinParams &P,
                                        int *RH, int *RE, int RM) {
     const int lane = threadIdx.x & 63;
     const int o_del = P.o_del, e_del = P.e_del, o_ins = P.o_ins, e_ins = P.e_ins, oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
@@ -281,7 +281,8 @@ k_fin_dp(DevIndex ix, FinParams P, const FinReq *__restrict__ reqs, const unsign
         const int rlen = (int)(re - rb);
         const bool rev = rb >= ix.l_pac;                        // then both are walked back to front (:277-282)
         const uint8_t *q0 = enc + off[rq.read] + a.qb;
-        const uint8_t *qp = rev ? q0 + lq - 1 : q0, *tp = rev ? ix.ref_string + re - 1 : ix.ref_string + rb;
+        const uint8_t *qp = rev ? q0 + lq - 1 : q0;
+        const RefPtr tp = ix.ref(rev ? re - 1 : rb);
         const int sd = rev ? -1 : 1;
         if (lq == rlen && rq.w == 0) {                          // no gap possible (:283-293)
             int sc = 0;

@@ -20,7 +20,7 @@
 #include "host_pool.h"
 
 __global__ void __launch_bounds__(256)
-k_ksw_align2(const uint8_t *__restrict__ qbase, const uint8_t *__restrict__ tbase, const KswTask *__restrict__ tasks, const int *__restrict__ order, int n, KswPrm prm,
+k_ksw_align2(const uint8_t *__restrict__ qbase, RefPtr tbase, const KswTask *__restrict__ tasks, const int *__restrict__ order, int n, KswPrm prm,
              int slen_max, bm2_ksw_result *__restrict__ out, unsigned long long *__restrict__ blists) {
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
     int8_t *smat = (int8_t *)lds;                                // 32 bytes, then the rows' areas
@@ -38,7 +38,7 @@ k_ksw_align2(const uint8_t *__restrict__ qbase, const uint8_t *__restrict__ tbas
 
 // Runs n tasks: queries at qbase_host[q_off[i]] (uploaded here), targets at t_off[i] either in the same uploaded buffer
 // (d_tbase == NULL) or in a device-resident array (d_tbase, e.g. the context's ref_string replica).
-static int ksw_batch_run(bm2_ctx *c, int32_t n, const uint8_t *qbuf, int64_t qbuf_bytes, const uint8_t *d_tbase, const int64_t *q_off,
+static int ksw_batch_run(bm2_ctx *c, int32_t n, const uint8_t *qbuf, int64_t qbuf_bytes, const RefPtr *d_tbase, const int64_t *q_off,
                          const int32_t *q_len, const int64_t *t_off, const int32_t *t_len, const int32_t *xtra, const int8_t mat[25], int o_del,
                          int e_del, int o_ins, int e_ins, bm2_ksw_result *out) {
     if (n == 0) return BM2_OK;
@@ -117,7 +117,7 @@ static int ksw_batch_run(bm2_ctx *c, int32_t n, const uint8_t *qbuf, int64_t qbu
     if (!rc) rc = bm2_copy_h2d(c, d_order, order.data(), ord_bytes);
     if (rc) return rc;
     hipLaunchKernelGGL(k_ksw_align2, dim3((n + rows - 1) / rows), dim3(rows * 16), lds, s, (const uint8_t *)b_seq.p,
-                       d_tbase ? d_tbase : (const uint8_t *)b_seq.p, d_task, d_order, n, prm, slen_max, (bm2_ksw_result *)b_out.p,
+                       d_tbase ? *d_tbase : RefPtr::bytes((const uint8_t *)b_seq.p), d_task, d_order, n, prm, slen_max, (bm2_ksw_result *)b_out.p,
                        (unsigned long long *)b_misc.p);
     rc = bm2_check(hipGetLastError(), "k_ksw_align2 launch");
     if (prof.on) { (void)hipStreamSynchronize(s); prof.mark("H2D + kernel"); }
@@ -144,7 +144,8 @@ static int dev_rescue_batch(void *user, int32_t n, const uint8_t *qbuf, int64_t 
                             const int64_t *t_pos, const int32_t *t_len, const int32_t *xtra, const bm2_opt *opt, const uint8_t *,
                             bm2_ksw_result *out) {
     bm2_ctx *c = (bm2_ctx *)user;
-    return ksw_batch_run(c, n, qbuf, qbuf_bytes, c->ix.ref_string, q_off, q_len, t_pos, t_len, xtra, opt->mat, opt->o_del, opt->e_del,
+    const RefPtr ref = c->ix.ref(0);
+    return ksw_batch_run(c, n, qbuf, qbuf_bytes, &ref, q_off, q_len, t_pos, t_len, xtra, opt->mat, opt->o_del, opt->e_del,
                          opt->o_ins, opt->e_ins, out);
 }
 

@@ -5,6 +5,7 @@
 #pragma once
 #include <stdint.h>
 #include "../../include/bm2.h"
+#include "refseq.h"
 
 #if defined(BM2_EMU) || defined(BM2_EMU_ROW_PRIMS)      /* the includer supplies the four row primitives (tools/emu) */
 #ifndef BM2_DEV
@@ -57,7 +58,7 @@ static BM2_DEV int sub0(int a, int b) { return a > b ? a - b : 0; }
 //   rev = false: query[0, qlen) against target[0, tlen)
 //   rev = true : the reversed query prefix [0, qe0] against the target whose first te0+1 bases are reversed (ksw.cpp:366-371)
 template <int P>
-static BM2_DEV KswRes ksw_pass(bool rev, const uint8_t *__restrict__ q, int qlen, int qe0, const uint8_t *__restrict__ t, int tlen, int te0,
+static BM2_DEV KswRes ksw_pass(bool rev, const uint8_t *__restrict__ q, int qlen, int qe0, RefPtr t, int tlen, int te0,
                            const KswPrm &prm, const int8_t *smat, int minsc, int endsc, uint16_t *L, int slen_max, int k,
                            unsigned long long *blist) {
     constexpr bool U8 = P == 16;
@@ -149,9 +150,10 @@ static BM2_DEV KswRes ksw_pass(bool rev, const uint8_t *__restrict__ q, int qlen
 }
 
 // One task on the 16 lanes of a row: ksw_align2, ksw.cpp:340-381.  L = this row's LDS area (9 * slen_max * 16 halfwords).
-static BM2_DEV void ksw_row_task(const uint8_t *__restrict__ qbase, const uint8_t *__restrict__ tbase, const KswTask &T, const KswPrm &prm, const int8_t *smat, uint16_t *L,
+static BM2_DEV void ksw_row_task(const uint8_t *__restrict__ qbase, RefPtr tbase, const KswTask &T, const KswPrm &prm, const int8_t *smat, uint16_t *L,
                                  int slen_max, int k, unsigned long long *bl, bm2_ksw_result *out) {
-    const uint8_t *q = qbase + T.q_off, *t = tbase + T.t_off;
+    const uint8_t *q = qbase + T.q_off;
+    const RefPtr t = tbase + T.t_off;
     const bool byte = (T.xtra & KSW_XBYTE) != 0;
     const int minsc = (T.xtra & KSW_XSUBO) ? T.xtra & 0xffff : 0x10000, endsc = (T.xtra & KSW_XSTOP) ? T.xtra & 0xffff : 0x10000;
     KswRes r = byte ? ksw_pass<16>(false, q, T.qlen, 0, t, T.tlen, 0, prm, smat, minsc, endsc, L, slen_max, k, bl)

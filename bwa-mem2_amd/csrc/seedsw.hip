@@ -43,7 +43,7 @@ k_seed_sw(DevIndex ix, ChainParams o, const int8_t *__restrict__ mat25, int64_t 
     if (g < n_slots) r = seed_owner[g];
     bool run = r >= 0 && min_hsp[r] >= 0;
     int qlen = 0, tlen = 0;
-    const uint8_t *tp = ix.ref_string;
+    RefPtr tp = ix.ref(0);
     DevSeed s;
     if (run) {
         s = seeds[g];
@@ -65,7 +65,7 @@ k_seed_sw(DevIndex ix, ChainParams o, const int8_t *__restrict__ mat25, int64_t 
                 rb = rb > far_beg ? rb : far_beg;
                 re = re < far_end ? re : far_end;
                 qlen = qe - qb; tlen = (int)(re - rb);
-                tp = ix.ref_string + rb;
+                tp = ix.ref(rb);
                 const uint8_t *qp = enc + off[r] + qb;
                 for (int j0 = 0; j0 < qlen; j0 += 8) {
                     uint32_t wq = 0;

@@ -38,7 +38,7 @@ typedef struct {
     const void     *cp_occ;         /* (ref_len>>6)+1 CP_OCC blocks of 64 B (FMI_search.h:54-58) */
     const int8_t   *sa_ms_byte;     /* (ref_len>>3)+1 */
     const uint32_t *sa_ls_word;     /* (ref_len>>3)+1 */
-    const uint8_t  *ref_string;     /* 2*l_pac bytes, values 0..3 (.0123) */
+    const uint8_t  *ref_string;     /* 2*l_pac bytes, values 0..3 (.0123); the device copy holds four per byte (a value above 3 anywhere keeps bytes) */
     int64_t l_pac;
     int32_t n_seqs;
     const int64_t *ann_offset;      /* bntann1_t.offset, .len, .is_alt (bntseq.h:42-49) */

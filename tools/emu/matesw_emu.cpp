@@ -21,7 +21,7 @@ static void *lane_main(void *p) {
     LaneArg *a = (LaneArg *)p;
     emu_row = &a->job->row; emu_lane = a->lane;
     Job *j = a->job;
-    ksw_row_task(j->seqs, j->seqs, *j->T, *j->prm, j->smat, j->L, j->slen_max, a->lane, j->bl, j->out);
+    ksw_row_task(j->seqs, RefPtr::bytes(j->seqs), *j->T, *j->prm, j->smat, j->L, j->slen_max, a->lane, j->bl, j->out);
     return 0;
 }
 
