@@ -244,6 +244,7 @@ __global__ void __launch_bounds__(256) k_cp_occ_relayout(CpOcc *occ, int64_t n) 
 // .0123 file -- goes through a staging buffer in pieces and is packed by a kernel, 64 codes per thread.  A code above 3 cannot be packed (the
 // .0123 file holds none: bntseq.cpp:284 draws a random base for every ambiguous one): the kernel reports it and the caller keeps bytes.
 #define REF_PIECE ((size_t)64 << 20)
+#define REF_PAD 64
 __global__ void __launch_bounds__(256) k_pack_ref(const uint8_t *__restrict__ src, int64_t n_codes, uint8_t *__restrict__ dst, int *bad) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, c0 = t * 64;
     if (c0 >= n_codes) return;
@@ -274,20 +275,23 @@ __global__ void __launch_bounds__(256) k_pack_ref(const uint8_t *__restrict__ sr
 static int upload_ref(bm2_ctx *c, const uint8_t *src, size_t n_codes) {
     int rc;
     if (bm2_knob("BM2_REF_BYTES", 0)) return upload(&c->d_ref, src, n_codes, c->stream);        // (one code per byte: for A/B measurements)
-    const size_t packed = (n_codes + 3) / 4 + 16;               // (RefPtr::load4 reads one byte beyond the last code's)
+    // (REF_PAD bytes of zeros on either side: the lane kernel's 64-bit windows start up to 27 bases before a target's first base and end up to
+    //  31 beyond its last, RefPtr::load4 reads one byte beyond the last code's; c->d_ref is the allocation, the codes start REF_PAD bytes in)
+    const size_t packed = (n_codes + 3) / 4 + 2 * REF_PAD;
     void *stage = nullptr; int *bad = nullptr;
     if ((rc = bm2_check(hipMalloc(&c->d_ref, packed), "hipMalloc(reference, packed)"))) return rc;
     rc = bm2_check(hipMalloc(&stage, REF_PIECE + 64), "hipMalloc(reference staging)");
     if (!rc) rc = bm2_check(hipMalloc((void **)&bad, 64), "hipMalloc(flag)");
     if (!rc) rc = bm2_check(hipMemsetAsync(bad, 0, 4, c->stream), "memset");
-    if (!rc) rc = bm2_check(hipMemsetAsync((char *)c->d_ref + (packed - 32), 0, 32, c->stream), "memset");
+    if (!rc) rc = bm2_check(hipMemsetAsync(c->d_ref, 0, REF_PAD, c->stream), "memset");
+    if (!rc) rc = bm2_check(hipMemsetAsync((char *)c->d_ref + (packed - REF_PAD - 16), 0, REF_PAD + 16, c->stream), "memset");
     for (size_t off = 0; !rc && off < n_codes; off += REF_PIECE) {
         const size_t n = n_codes - off < REF_PIECE ? n_codes - off : REF_PIECE;
         rc = bm2_check(hipMemcpyAsync(stage, src + off, n, hipMemcpyHostToDevice, c->stream), "hipMemcpy(reference piece)");
         if (rc) break;
         const size_t thr = (n + 63) / 64;
         hipLaunchKernelGGL(k_pack_ref, dim3((unsigned)((thr + 255) / 256)), dim3(256), 0, c->stream, (const uint8_t *)stage, (int64_t)n,
-                           (uint8_t *)c->d_ref + off / 4, bad);
+                           (uint8_t *)c->d_ref + REF_PAD + off / 4, bad);
         rc = bm2_check(hipGetLastError(), "k_pack_ref");
     }
     int h_bad = 0;
@@ -353,7 +357,7 @@ extern "C" bm2_ctx *bm2_create(int device, const bm2_index_desc *idx) {
         if (rc) { bm2_destroy(c); return nullptr; }
         DevIndex &ix = c->ix;
         ix.cp_occ = (const CpOccDev *)c->d_cp_occ; ix.sa_ms_byte = (const int8_t *)c->d_sa_ms;
-        ix.sa_ls_word = (const uint32_t *)c->d_sa_ls; ix.ref_string = (const uint8_t *)c->d_ref;
+        ix.sa_ls_word = (const uint32_t *)c->d_sa_ls; ix.ref_string = (const uint8_t *)c->d_ref + (ix.ref_pk ? REF_PAD : 0);
         ix.ann_offset = (const int64_t *)c->d_ann_off; ix.ann_len = (const int32_t *)c->d_ann_len;
         ix.ann_is_alt = (const int32_t *)c->d_ann_alt;
         ix.ref_len = idx->ref_len; ix.l_pac = idx->l_pac; ix.sentinel_index = idx->sentinel_index;

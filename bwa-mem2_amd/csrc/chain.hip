@@ -967,9 +967,18 @@ int bm2_launch_chain(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_
     const bool heavy = heavy_thr >= 0 && n_heavy_dev != nullptr;
     if (heavy && bm2_side_streams(c)) return BM2_ENODEV;
     if (heavy) (void)hipEventRecord(c->ev_fork, s);
-    hipLaunchKernelGGL(k_chain, dim3((n_reads + 127) / 128), dim3(128), 0, s, c->ix, o, n_reads, len, smems, smem_cnt,
+    // With the wavefront-per-read launches beside it, the lane-per-read kernel goes to a side stream of its own and the main stream only
+    // waits, and waits for all of them AFTER the last is queued: streams share hardware queues, nothing tells which, and a launch whose
+    // stream sits on the main stream's queue starts behind whatever the main stream queued before it -- the fourth tier started when
+    // k_chain had ended, 7.6 ms late (profiles/r04_timeline.tsv).  BM2_CHAIN_MAIN_SIDE=0: k_chain on the main stream, as before.
+    const bool main_side = heavy && bm2_knob("BM2_CHAIN_MAIN_SIDE", 1);
+    hipStream_t s_main = main_side ? c->side_stream[1] : s;
+    if (main_side) (void)hipStreamWaitEvent(s_main, c->ev_fork, 0);
+    hipLaunchKernelGGL(k_chain, dim3((n_reads + 127) / 128), dim3(128), 0, s_main, c->ix, o, n_reads, len, smems, smem_cnt,
                        smem_off, sa_off, sa_coord, wchain, wseed, nodes, order, chn, seeds_out, seed_owner,
                        n_chain_out, n_reg_out, n_chain0_out, perm, heavy ? heavy_thr : -1, n_sa_read);
+    int joined[BM2_CHAIN_TIERS + 3], n_joined = 0;
+    if (main_side) { (void)hipEventRecord(c->ev_join[1], s_main); joined[n_joined++] = 1; }
     if (heavy) {
         // tiers by seed count (LDS per block follows the tier): the launches run beside the lane-per-read kernel and each other
         const int stage = bm2_knob("BM2_CHAIN_STAGE", 1);     // (sweep of round 3, profiles/r03a_sweep.json: chaining 12.4 -> 10.3 ms)
@@ -992,7 +1001,7 @@ int bm2_launch_chain(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_
                                sa_coord, wchain, wseed, nodes, order, chn, seeds_out, seed_owner, n_chain_out, n_reg_out, n_chain0_out, perm,
                                n_heavy_dev, n_sa_read, lo, caps[t], (t == BM2_CHAIN_TIERS - 1 && !use_islands) ? 1 : 0, item_cur + t, stage);
             (void)hipEventRecord(c->ev_join[2 + t], sk);
-            (void)hipStreamWaitEvent(s, c->ev_join[2 + t], 0);
+            joined[n_joined++] = 2 + t;
             lo = caps[t];
         }
         // Reads with more seeds than the largest tier holds in LDS (long reads: ~12 k seeds per 10 kb read) walk their GLOBAL slices.  They
@@ -1015,8 +1024,9 @@ int bm2_launch_chain(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_
                                    n_heavy_dev, n_sa_read, lo, 0, 1, item_cur + BM2_CHAIN_TIERS, 0);
             }
             (void)hipEventRecord(c->ev_join[2 + BM2_CHAIN_TIERS], sk);
-            (void)hipStreamWaitEvent(s, c->ev_join[2 + BM2_CHAIN_TIERS], 0);
+            joined[n_joined++] = 2 + BM2_CHAIN_TIERS;
         }
     }
+    for (int i = 0; i < n_joined; i++) (void)hipStreamWaitEvent(s, c->ev_join[joined[i]], 0);
     return bm2_check(hipGetLastError(), "k_chain launch");
 }

@@ -401,9 +401,23 @@ static __device__ void lane_dp8g(bool run, int qlen, int tlen, int w, int h0, Re
     int beg = 0, end = qlen, maxv = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0;
     bool alive = run && tlen > 0;
     const int maxt = __builtin_amdgcn_readlane(wave_scan_max(alive ? tlen : 0, 0), 63);
-    // The target bases FOUR ROWS AT A TIME, one (unaligned) 32-bit load per four rows requested four rows before its first use: a byte load per
-    // row was consumed one row later, and a row of a short query lasts about as long as a global load takes on a 6 GB reference (a TLB miss
-    // more often than not) -- the short classes, which hold most seeds, waited for it in every row.
+    // The target bases.  From a byte buffer (seam S1, BM2_REF_BYTES): FOUR ROWS AT A TIME, one (unaligned) 32-bit load per four rows requested
+    // four rows before its first use.  From the packed reference: TWENTY-EIGHT rows per (unaligned) 64-bit load -- 56 bits of bases and up to
+    // 6 bits of misalignment -- requested a whole window (28 rows) before its first use.  A lane's target is a stream of its own somewhere in
+    // the genome: every load instruction is 64 different lines, most of them TLB misses, microseconds; a wavefront of a short class passes
+    // four rows in less than that and there is hardly a second wavefront on the SIMD to cover for it (rows in LDS: 1-2 wavefronts per SIMD).
+    const bool pk = tp.pk != 0;
+    constexpr int TW = 28;
+    typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
+    const int64_t pa0 = ts > 0 ? tp.at : tp.at - (TW - 1);      // lowest position of window 0 (before the reference's start by < 28 at most: padded)
+    const int psh = (int)(pa0 & 3) << 1, pstep = ts > 0 ? TW / 4 : -(TW / 4);
+    const uint8_t *pbyte = tp.p + (pa0 >> 2);
+    uint64_t pw_cur = 0, pw_next = 0;
+    int pr = 0;
+    if (pk && run && tlen > 0) {
+        pw_cur = *(const u64_unaligned *)pbyte;
+        if (TW < tlen) pw_next = *(const u64_unaligned *)(pbyte + pstep);
+    }
     auto bases4 = [&](int i0) -> uint32_t {                      // byte k = base of row i0 + k (4 beyond the target's end)
         uint32_t wv = 0x04040404u;
         if (run && i0 < tlen) {
@@ -415,11 +429,21 @@ static __device__ void lane_dp8g(bool run, int qlen, int tlen, int w, int h0, Re
         }
         return wv;
     };
-    uint32_t tw_cur = bases4(0), tw_next = bases4(4);
+    uint32_t tw_cur = 0, tw_next = 0;
+    if (!pk) { tw_cur = bases4(0); tw_next = bases4(4); }
     for (int i = 0; i < maxt; ++i) {
         if (!__ballot(alive)) break;
-        const int tb = (int)((tw_cur >> (8 * (i & 3))) & 0xffu);
-        if ((i & 3) == 3) { tw_cur = tw_next; tw_next = bases4(i + 5); }
+        int tb;
+        if (pk) {
+            tb = (int)(pw_cur >> (psh + 2 * (ts > 0 ? pr : TW - 1 - pr))) & 3;
+            if (++pr == TW) {
+                pr = 0; pw_cur = pw_next;
+                if (run && i + 1 + TW < tlen) pw_next = *(const u64_unaligned *)(pbyte + (int64_t)((i + 1) / TW + 1) * pstep);
+            }
+        } else {
+            tb = (int)((tw_cur >> (8 * (i & 3))) & 0xffu);
+            if ((i & 3) == 3) { tw_cur = tw_next; tw_next = bases4(i + 5); }
+        }
         Dp8Row r; r.h1 = 0; r.f = 0; r.lnz = -1; r.key = 0; r.fnz_u = 0xffffffffu;
         if (alive) {
             if (beg < i - w) beg = i - w;
@@ -526,19 +550,26 @@ k_ext_seeds(DevIndex ix, ExtParams xp, const int32_t *__restrict__ tasks_all, co
             const int maxq = __builtin_amdgcn_readlane(wave_scan_max(has ? tg.len2 : 0, 0), 63);
             if (PT) {                                               // one base per byte, 4 to a dword: the selector words of the byte permute
                 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
-                for (int j0 = 0; j0 < maxq; j0 += 4) {
-                    if (has && j0 < tg.len2) {
-                        uint32_t wq = 0;
-                        bool bytewise = j0 + 3 >= tg.len2;
-                        if (!bytewise) {                            // four bases with one (unaligned) load; a word with an N in it (rare) goes the byte way
-                            wq = tg.qs > 0 ? *(const u32_unaligned *)(tg.q + j0) : __builtin_bswap32(*(const u32_unaligned *)(tg.q - j0 - 3));
-                            bytewise = (wq & 0xfcfcfcfcu) != 0u;
+                for (int jb = 0; jb < maxq; jb += 16) {             // four words requested before the first is looked at: one wait per 16 bases
+                    uint32_t wq4[4];
+#pragma unroll
+                    for (int v = 0; v < 4; v++) {
+                        const int j0 = jb + 4 * v;
+                        wq4[v] = 0xffffffffu;                       // (the tail of a query, or a word with an N in it -- rare --, goes the byte way)
+                        if (has && j0 + 3 < tg.len2)
+                            wq4[v] = tg.qs > 0 ? *(const u32_unaligned *)(tg.q + j0) : __builtin_bswap32(*(const u32_unaligned *)(tg.q - j0 - 3));
+                    }
+#pragma unroll
+                    for (int v = 0; v < 4; v++) {
+                        const int j0 = jb + 4 * v;
+                        if (has && j0 < tg.len2) {
+                            uint32_t wq = wq4[v];
+                            if ((wq & 0xfcfcfcfcu) != 0u) {
+                                wq = 0;
+                                for (int u = 0; u < 4 && j0 + u < tg.len2; u++) { const uint32_t qv = tg.q[(int64_t)(j0 + u) * tg.qs]; wq |= (qv > 3 ? 4u : qv) << (8 * u); }
+                            }
+                            QL8[(j0 >> 2) * 64 + lane] = wq;
                         }
-                        if (bytewise) {
-                            wq = 0;
-                            for (int u = 0; u < 4 && j0 + u < tg.len2; u++) { const uint32_t qv = tg.q[(int64_t)(j0 + u) * tg.qs]; wq |= (qv > 3 ? 4u : qv) << (8 * u); }
-                        }
-                        QL8[(j0 >> 2) * 64 + lane] = wq;
                     }
                 }
             } else if (!P8) {
@@ -1058,6 +1089,7 @@ static int run_phase(const ExtLaunch &L, const uint32_t *hint, int64_t ub) {
     // (profiles/r03x_timeline.tsv).  The eight launches of a phase -- seven lane classes and the wavefront kernel for 150 bp reads -- get
     // seven queues: the wavefront kernel takes the shortest class's side stream, the shortest class queues behind the second shortest.
     // BM2_EXT_QUEUE_MAP=0: one side stream per class index.
+    int joined[N_CLS + 1], n_joined = 0;
     for (int kk = 0; kk <= N_CLS; kk++) {                  // longest queries first: their tails overlap the short classes
         const int k = kk == 0 ? N_CLS : N_CLS - kk;
         hipStream_t sk = !L.qmap ? c->side_stream[k] : k == N_CLS ? c->side_stream[0] : c->side_stream[k ? k : 1];
@@ -1084,8 +1116,13 @@ static int run_phase(const ExtLaunch &L, const uint32_t *hint, int64_t ub) {
                                (int)N_EBINS, L.enc, L.off, L.len, L.slot_base, L.reg_seed, L.reg_chain, L.chn, L.seeds, L.regs, L.R, L.counters, L.rev);
         }
         (void)hipEventRecord(c->ev_join[k], sk);
-        (void)hipStreamWaitEvent(L.s, c->ev_join[k], 0);
+        joined[n_joined++] = k;
     }
+    // The main stream waits for the launches only AFTER the last of them is queued.  A wait is a barrier packet in the main stream's hardware
+    // queue, streams share the process's hardware queues, and nothing tells which share one: a side stream that sits on the main stream's
+    // queue had its launch queued BEHIND the waits for the launches before it -- profiles/r04_timeline.tsv: the class of 65..80-base
+    // queries started when every other launch of its phase had ended and ran 1.4-1.8 ms alone, three times per batch.
+    for (int i = 0; i < n_joined; i++) (void)hipStreamWaitEvent(L.s, c->ev_join[joined[i]], 0);
     return bm2_check(hipGetLastError(), "extension launches");
 }
 
@@ -1294,8 +1331,8 @@ int bm2_launch_bsw_sorted(bm2_ctx *c, bm2_seqpair_t *d_pairs, const uint8_t *d_r
             if ((rc = bm2_launch_bsw_list(c, d_pairs, d_ref, d_qer, tasks, start, N_CLS * EB_2D, (int)N_EBINS, (unsigned)g, w, P, d_cells, sk))) return rc;
         }
         (void)hipEventRecord(c->ev_join[k], sk);
-        (void)hipStreamWaitEvent(s, c->ev_join[k], 0);
     }
+    for (int k = N_CLS; k >= 0; k--) (void)hipStreamWaitEvent(s, c->ev_join[k], 0);        // (after the last launch is queued: see run_phase)
     if (c->ext_stat) {
         if ((rc = bm2_check(hipMemcpyAsync(c->ext_stat + (size_t)BSW_STAT_ROW * BM2_EXT_STATW, stat, BM2_EXT_STATW * 4, hipMemcpyDeviceToHost, s), "D2H S1 class counts"))) return rc;
         c->bsw_stat_n = n;

@@ -31,7 +31,7 @@ GRID = [   # (name, candidates): a candidate is a dict of knobs set together; th
                                                               {"BM2_BWD_LCAP": 4, "BM2_BWD_BLOCKS_PER_CU": 5, "BM2_BWD_WAVES": 5}]),
     ("extension launches on distinct hardware queues", [{}, {"BM2_EXT_QUEUE_MAP": 0}]),
     ("extension scores by byte permute", [{}, {"BM2_EXT_PERM_SCORES": 0}]),
-    ("extension wave classes", [{}, {"BM2_EXT_WAVE_QMIN": 129}, {"BM2_EXT_WAVE_QMIN": 97}, {"BM2_EXT_WAVE_QMIN": 161}]),
+    ("extension wave classes", [{}, {"BM2_EXT_WAVE_QMIN": 129}, {"BM2_EXT_WAVE_QMIN": 145}, {"BM2_EXT_WAVE_QMIN": 161}, {"BM2_EXT_WAVE_QMIN": 97}]),
     ("extension rounds", [{}, {"BM2_EXT_ROUNDS": 2}, {"BM2_EXT_ROUNDS": 1}, {"BM2_EXT_PEND_DIV": 6}, {"BM2_EXT_PEND_DIV": 24}]),
     ("extension dispatch order", [{}, {"BM2_EXT_REVERSE": 1}]),
     ("extension prefetch", [{}, {"BM2_EXT_PREFETCH": 0}]),

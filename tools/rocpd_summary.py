@@ -30,6 +30,21 @@ def main():
                 lines.append("|---|---|---|---|")
                 for k, cn, v, c in prow:
                     lines.append("| %s | %s | %.6g | %d |" % (k.split("(")[0][:50], cn, v, c))
+            # The SECOND HALF of each kernel's dispatches on their own: a bench run of 2n steps whose first steps size their grids without the
+            # previous batch's statistics (the extension stage's hints) or learn workspace sizes is not the steady state the bench line times.
+            key = next((k for k in ("dispatch_id", "id", "start") if k in ccols), None)
+            if prow and key:
+                lines.append("\n## PMC counters, second half of each kernel's dispatches (by %s; columns: %s)\n" % (key, ", ".join(ccols)))
+                lines.append("| kernel | counter | sum | dispatches*dims |")
+                lines.append("|---|---|---|---|")
+                for (k,) in cur.execute("select distinct kernel_name from counters_collection order by kernel_name").fetchall():
+                    ids = sorted(r[0] for r in cur.execute("select distinct %s from counters_collection where kernel_name = ?" % key, (k,)))
+                    if len(ids) < 2:
+                        continue
+                    cut = ids[len(ids) // 2]
+                    for cn, v, c in cur.execute("select counter_name, sum(value), count(*) from counters_collection where kernel_name = ? and %s >= ? "
+                                                "group by counter_name order by counter_name" % key, (k, cut)).fetchall():
+                        lines.append("| %s | %s | %.6g | %d |" % (k.split("(")[0][:50], cn, v, c))
     except sqlite3.Error as e:
         lines.append("(no counters: %s)" % e)
     out = "\n".join(lines) + "\n"
