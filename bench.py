@@ -563,6 +563,7 @@ def end_to_end(ctx, bm2, texts, opt, paired, n_threads, n_tail=None, limit_s=Non
     with lock:
         stage.clear()
     t0 = time.perf_counter()
+    cpu0 = time.process_time()                                   # CPU seconds of every thread of this process (the stages' workers and the library's pools)
     go.set()
     for t in th:
         while t.is_alive():
@@ -574,6 +575,7 @@ def end_to_end(ctx, bm2, texts, opt, paired, n_threads, n_tail=None, limit_s=Non
         if t.is_alive():
             raise TimeoutError("end-to-end leg not finished after %.0f s (stages so far: %s)" % (limit_s, {k: round(v, 1) for k, v in stage.items()}))
     dt = time.perf_counter() - t0
+    cpu_s = time.process_time() - cpu0
     if err:
         raise err[0]
     for c in tails + devs[1:]:
@@ -602,6 +604,8 @@ def end_to_end(ctx, bm2, texts, opt, paired, n_threads, n_tail=None, limit_s=Non
     return {"value": n_reads / dt, "unit": "reads/s", "reads": n_reads, "chunks": len(texts), "warmup_chunks": n_warm, "wall_s": dt, "sam_bytes": out_bytes,
             "host_cpus": hw, "host_threads_visible": os.cpu_count(), "parse_threads": n_parse, "device_workers": n_dev, "tail_workers": n_tail, "threads_per_tail_worker": so.n_threads,
             "stage_ms_per_chunk": {k: v / nch * 1e3 for k, v in stage.items()}, "chunk_check": check,
+            # what the host side costs: CPU seconds of the whole process per timed chunk, and the chunk time that alone would allow on this host's cores
+            "host_cpu_s_per_chunk": cpu_s / nch, "host_cpu_bound_ms_per_chunk": cpu_s / nch / max(hw, 1) * 1e3, "ms_per_chunk": dt / nch * 1e3,
             "scope": "FASTQ text in host memory -> bm2_fastq_parse_mt | H2D -> device pipeline incl. mem_sort_dedup_patch (a19) -> D2H | pairing / "
                      "mate rescue / CIGAR (device batches) / SAM text in host memory; one host thread per stage worker (%d device workers on contexts "
                      "sharing the index replica, %d tail workers), stages of consecutive chunks overlap; the warm-up chunks pass through the same "
@@ -912,6 +916,7 @@ def main():
     dist_util.barrier(world)
     dt = dist_util.max_over_ranks(time.perf_counter() - t0, world, "cpu" if emu else "cuda")
     st = ctx.batch_stats()
+    parts = ctx.batch_parts() if hasattr(ctx, "batch_parts") else 1      # (a chunk runs as `parts` parts beside each other: the per-kernel times are summed over them)
     if n_res > 1:                                            # work counters: the mean over the chunks that ran (they differ by a fraction of a per cent)
         sts = [c.batch_stats() for c in run_ctx[:min(n_res, a.steps)]]
         st = {k: sum(x[k] for x in sts) / len(sts) for k in st}
@@ -935,21 +940,22 @@ def main():
         sc = sc_sum if sc_sum is not None else ctx.batch_fetch("seed_counters", np.uint64)
         ext_of = {"walk1": int(sc[12]), "walk2": int(sc[13]), "walk3": int(sc[14]), "bwd1": int(sc[15]), "bwd2": int(sc[16])}
         smem_ms = stage_ms.get("smem", 0.0)
-        bwd_ms = (kern_ms.get("smem.bwd1", 0.0) + kern_ms.get("smem.bwd2", 0.0)) / 2.0          # average launch duration
-        bwd_bytes = 128.0 * (ext_of["bwd1"] + ext_of["bwd2"]) / 2.0                              # algorithmic bytes per launch
+        bwd_ms = (kern_ms.get("smem.bwd1", 0.0) + kern_ms.get("smem.bwd2", 0.0)) / (2.0 * parts)          # average launch duration (every part launches its own two)
+        bwd_bytes = 128.0 * (ext_of["bwd1"] + ext_of["bwd2"]) / (2.0 * parts)                              # algorithmic bytes per launch
         ach = bwd_bytes / (bwd_ms * 1e-3) / 1e9 if bwd_ms > 0 else 0.0
-        roof_kernel, roof_launches = "k_bwd", 2
+        roof_kernel, roof_launches = "k_bwd", 2 * parts
         fm_kernels = {}                                       # every FM-index kernel of the step against the same peak: 128 algorithmic bytes per backwardExt
         for kn, ev in (("k_walk<1>", "walk1"), ("k_bwd (pass 1)", "bwd1"), ("k_walk<2>", "walk2"), ("k_bwd (pass 2)", "bwd2")):
-            ms_k = kern_ms.get("smem." + ev, 0.0)
+            ms_k = kern_ms.get("smem." + ev, 0.0) / parts    # (per launch: one per part)
             if ms_k > 0:
-                gbs = 128.0 * ext_of[ev] / (ms_k * 1e-3) / 1e9
-                fm_kernels[kn] = {"ms": ms_k, "backwardExt": ext_of[ev], "achieved": gbs, "frac": gbs / HBM_PEAK_GBS}
+                gbs = 128.0 * ext_of[ev] / parts / (ms_k * 1e-3) / 1e9
+                fm_kernels[kn] = {"ms": ms_k, "backwardExt": ext_of[ev] / parts, "achieved": gbs, "frac": gbs / HBM_PEAK_GBS}
         w1 = fm_kernels.get("k_walk<1>")
         if w1 and w1["ms"] > 2.0 * bwd_ms:                    # long reads: the forward walks, not the backward phases, are the seeding stage
-            roof_kernel, roof_launches = "k_walk<1>", 1
+            roof_kernel, roof_launches = "k_walk<1>", parts
             bwd_ms, bwd_bytes, ach = w1["ms"], 128.0 * w1["backwardExt"], w1["achieved"]
         fm_bytes = 128.0 * st["n_ext"]
+        # (in parts the stage intervals of the parts overlap and `smem_ms` is their sum: per part the stage moved fm_bytes / parts in smem_ms / parts)
         stage_ach = fm_bytes / (smem_ms * 1e-3) / 1e9 if smem_ms > 0 else 0.0
         cells = st["n_sw_cells"]
         ext_ms = stage_ms.get("extend", 0.0)
@@ -1004,6 +1010,10 @@ def main():
             "value_end_to_end": None,
             "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "strong" if a.strong else "weak", "vs_baseline": None,
             "dtype": "int32", "data": "synthetic" if not emu else "synthetic; HOST EMULATOR RUN (not a measurement)",
+            "parts_per_chunk": parts,
+            "parts_note": None if parts <= 1 else ("the chunk runs as %d parts (cut at multiples of 512 reads) on streams and workspaces of their own, beside each other: "
+                                                   "`stage_ms_per_step` and every per-kernel time are SUMS over the parts' intervals, which overlap -- they add up to more "
+                                                   "than `ms_per_step`; the roofline's launch is one part's (BM2_N_SUB=1: one part, stages in sequence)" % parts),
             "index_replica_gb": round(replica_gb, 2) if replica_gb is not None else None,
             "index_replica_layout": "Occ checkpoints 64 B per 64 symbols, suffix array 5 B per 8 positions, reference string "
                                     + ("1 byte per base (BM2_REF_BYTES=1)" if os.environ.get("BM2_REF_BYTES", "0") not in ("", "0") else "2 bits per base (refseq.h)"),

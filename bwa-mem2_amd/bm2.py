@@ -91,7 +91,7 @@ class Stats(C.Structure):
 
 EXPORTS = ["bm2_index_load", "bm2_index_free", "bm2_opt_init", "bm2_opt_fill_scmat", "bm2_create", "bm2_create_shared", "bm2_destroy",
            "bm2_last_error", "bm2_device_count", "bm2_set_stream_priority", "bm2_host_cpus", "bm2_host_alloc", "bm2_host_free", "bm2_bsw", "bm2_bsw_upload", "bm2_bsw_run", "bm2_bsw_download", "bm2_smem", "bm2_sal", "bm2_seed_chain_extend",
-           "bm2_batch_upload", "bm2_batch_run", "bm2_batch_stats", "bm2_batch_download", "bm2_batch_kernel_ms",
+           "bm2_batch_upload", "bm2_batch_run", "bm2_batch_stats", "bm2_batch_download", "bm2_batch_kernel_ms", "bm2_batch_parts",
            "bm2_batch_fetch", "bm2_batch_finish", "bm2_batch_download_alnregs", "bm2_finish_regs_dev", "bm2_chunk_hits_sharded", "bm2_index_build", "bm2_sam_opt_init", "bm2_sam_se", "bm2_sam_pe", "bm2_fastq_parse", "bm2_fastq_parse_mt", "bm2_fastq_free", "bm2_ksw_align2", "bm2_ksw_align2_dev", "bm2_sam_pe_dev", "bm2_sam_se_dev", "bm2_sam_pe_dev_multi", "bm2_sam_se_dev_multi", "bm2_sam_cigar_stats", "bm2_gen_cigar", "bm2_gen_cigar_dev", "bm2_sam_header", "bm2_sam_rescue_stats"]
 
 _lib = None
@@ -155,6 +155,7 @@ def lib():
         L.bm2_batch_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
         L.bm2_batch_download.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_int64)]
         L.bm2_batch_kernel_ms.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.c_void_p]
+        L.bm2_batch_parts.argtypes = [C.c_void_p]
         L.bm2_batch_fetch.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
         L.bm2_index_build.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
         L.bm2_sam_opt_init.argtypes = [C.POINTER(SamOpt)]
@@ -496,6 +497,10 @@ class Context:
         n = C.c_int32(0)
         _chk(lib().bm2_batch_kernel_ms(self.h, ms, 32, C.byref(n), names), "bm2_batch_kernel_ms")
         return [(names[i].decode(), float(ms[i])) for i in range(n.value)]
+
+    def batch_parts(self):
+        """Parts the last uploaded chunk was cut into (each runs beside the others on streams of its own)."""
+        return int(lib().bm2_batch_parts(self.h))
 
 
 def chunk_hits_sharded(ctxs, reads, opt):

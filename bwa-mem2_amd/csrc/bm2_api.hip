@@ -371,12 +371,12 @@ extern "C" bm2_ctx *bm2_create(int device, const bm2_index_desc *idx) {
 
 // extra contexts for sub-batch pipelining (pipeline.hip): same index replica, own streams and workspaces; made on demand
 int bm2_ensure_subs(bm2_ctx *c, int n_sub) {
-    if (!c || c->is_child || !c->has_index) return 1;
+    if (!c || c->is_sub || !c->has_index) return 1;
     if (n_sub > 8) n_sub = 8;
     while ((int)c->subs.size() + 1 < n_sub) {
         bm2_ctx *k = new (std::nothrow) bm2_ctx();
         if (!k) break;
-        k->device = c->device; k->n_cu = c->n_cu; k->ix = c->ix; k->has_index = true; k->is_child = true;
+        k->device = c->device; k->n_cu = c->n_cu; k->ix = c->ix; k->has_index = true; k->is_child = true; k->is_sub = true;
         if (make_streams(k)) { delete k; break; }
         c->subs.push_back(k);
     }
@@ -393,6 +393,7 @@ extern "C" bm2_ctx *bm2_create_shared(bm2_ctx *parent) {
     if (!k) return nullptr;
     k->device = parent->device; k->n_cu = parent->n_cu; k->ix = parent->ix; k->has_index = parent->has_index; k->is_child = true;
     if (make_streams(k)) { delete k; return nullptr; }
+    if (k->has_index) bm2_ensure_subs(k, bm2_knob("BM2_N_SUB", BM2_N_SUB));
     return k;
 }
 

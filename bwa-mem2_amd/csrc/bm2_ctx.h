@@ -61,14 +61,20 @@ struct bm2_ctx {
     // sub-batch pipelining (pipeline.hip): extra contexts sharing this one's index replica
     std::vector<bm2_ctx *> subs;
     StageGate gate;                                               // (of the parent: the schedule of its parts)
-    bool is_child = false;
+    bool is_child = false;     // shares another context's index replica (bm2_create_shared, sub-contexts)
+    bool is_sub = false;       // a sub-context of bm2_ensure_subs: takes a part of its owner's chunk, has no sub-contexts of its own
     int n_parts = 1;
     std::vector<int> part_first;
     // two pinned staging buffers for the large host <-> device copies of a chunk (bm2_copy_h2d / bm2_copy_d2h)
     void *pin[2] = { nullptr, nullptr };
     hipEvent_t pin_ev[2] = { nullptr, nullptr };
 };
-#define BM2_N_SUB 1     // sub-batch pipelining is implemented and parity-tested, but did not pay on one GPU (profiles/); knob BM2_N_SUB
+// Parts a chunk is cut into, each on a context (streams, workspace, host thread) of its own: the latency-bound kernels of one part run beside
+// the other's.  Launch policy, knob BM2_N_SUB, read per chunk.  ONE by default: two parts on a lone context take 63.7 ms per million-read
+// chunk instead of 69.7 (profiles/r04q_sweep.json), but two parts are 24 streams on the process's 16 hardware queues, and beside the
+// contexts of the other resident chunks (the bench's rotation, a pipeline's second device worker) the same chunk takes 74.0 ms instead of
+// 69.0 (profiles/r04r_*.json; with 24 hardware queues 86 ms, with 32 116 ms: more queues than the hardware schedules well).
+#define BM2_N_SUB 1
 int bm2_ensure_subs(bm2_ctx *c, int n_sub);      // -> parts available (1 + sub-contexts)
 
 // Launch-policy knobs (grid sizes, class routing, thresholds): none of them changes a result.  Read from the environment on every

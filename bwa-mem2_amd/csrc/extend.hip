@@ -1154,7 +1154,10 @@ int bm2_launch_extend(bm2_ctx *c, const bm2_opt &opt, const ChainParams &cp, int
     P.end_bonus = opt.pen_clip3; xp.right = P;
     // no H / E of the batch can exceed l_query * a (a full-length perfect match): 8-bit rows when that fits
     L.pack8 = !bm2_knob("BM2_NO_PACK8", 0) && (int64_t)max_len * opt.a <= 255 && opt.a > 0;
-    L.wave_qmin = bm2_knob("BM2_EXT_WAVE_QMIN", 113);               // classes of queries at least this long: one seed per wavefront
+    L.wave_qmin = bm2_knob("BM2_EXT_WAVE_QMIN", 129);               // classes of queries at least this long: one seed per wavefront
+    // (113 until the launches of a phase really ran beside each other, see run_phase: the wavefront kernel then took 200 000 seeds of the second
+    //  round -- short seeds at a read's end, the whole rest of the read to extend -- and was the last launch of its phase to end by 2 ms;
+    //  profiles/r04q_sweep.json: extension 20.1 ms at 113, 16.0 ms at 129 / 145 / 161, 25.0 ms at 97)
     L.prefetch = bm2_knob("BM2_EXT_PREFETCH", 1);
     L.rev = bm2_knob("BM2_EXT_REVERSE", 1);
     L.qmap = bm2_knob("BM2_EXT_QUEUE_MAP", 1);

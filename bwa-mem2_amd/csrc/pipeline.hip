@@ -534,6 +534,8 @@ extern "C" int bm2_batch_run(bm2_ctx *c, const bm2_opt *opt) {
     return BM2_OK;
 }
 
+extern "C" int bm2_batch_parts(const bm2_ctx *c) { return !c ? 0 : c->n_parts < 1 ? 1 : c->n_parts; }
+
 extern "C" int bm2_batch_stats(bm2_ctx *c, bm2_stats *st) {
     if (!c || !st) return BM2_EINVAL;
     memset(st, 0, sizeof *st);
@@ -824,6 +826,24 @@ extern "C" int bm2_batch_fetch(bm2_ctx *c, const char *what, void *out, int64_t 
         { "n_out", &b->n_out, (size_t)n * 4 }, { "chn", &b->chn, ns * sizeof(DevChain) }, { "seeds", &b->seeds, ns * sizeof(DevSeed) },
         { "seed_counters", &b->seedc, (size_t)21 * 8 }, { "counters", &b->counters, (size_t)40 * 8 }, { "regs_raw", &b->regs, ns * sizeof(DevReg) }, { "reg_seed", &b->reg_seed, ns * 4 }, { "wchain", &b->wchain, ns * sizeof(WChain) },
     };
+    if (c->n_parts > 1 && (!strcmp(what, "seed_counters") || !strcmp(what, "counters"))) {       // work counters of a chunk in parts: the parts' sums
+        const size_t nb = !strcmp(what, "counters") ? (size_t)40 * 8 : (size_t)21 * 8;
+        *n_bytes = (int64_t)nb;
+        if ((size_t)cap_bytes < nb) return BM2_ECAP;
+        if (!out) return BM2_EINVAL;
+        unsigned long long acc[40] = { 0 }, one[40];
+        for (int i = 0; i < c->n_parts; i++) {
+            bm2_ctx *p = part_ctx(c, i);
+            if (!p->batch) return BM2_EINVAL;
+            DevBuf &src = !strcmp(what, "counters") ? p->batch->counters : p->batch->seedc;
+            int rc = bm2_check(hipSetDevice(p->device), "hipSetDevice");
+            if (!rc) rc = bm2_check(hipMemcpy(one, src.p, nb, hipMemcpyDeviceToHost), "fetch counters");
+            if (rc) return rc;
+            for (size_t k = 0; k < nb / 8; k++) acc[k] += one[k];
+        }
+        memcpy(out, acc, nb);
+        return BM2_OK;
+    }
     if (!strcmp(what, "seed_attempts")) {
         *n_bytes = 4;
         if (cap_bytes < 4) return BM2_ECAP;
