@@ -327,7 +327,7 @@ int bm2_batch_download(bm2_ctx *c, bm2_reg_t *regs, int64_t cap, int64_t *reg_of
 /* wall time of the last bm2_batch_run measured with hipEvents on the library's stream, per kernel: SUMMED over the parts of the chunk */
 int bm2_batch_kernel_ms(bm2_ctx *c, float *ms, int32_t cap, int32_t *n_out, const char **names);
 /* parts the last uploaded chunk was cut into (at multiples of 512 reads, the one cross-read rule of the path: bwamem.cpp:834): each part
- * runs on streams and a workspace of its own, beside the others (launch policy BM2_N_SUB, default 2; a chunk below 64 blocks per part: 1) */
+ * runs on streams and a workspace of its own, beside the others (launch policy BM2_N_SUB, default 1; a chunk below 64 blocks per part: 1) */
 int bm2_batch_parts(const bm2_ctx *c);
 /* diagnostic: copy a raw device array of the last bm2_batch_run to the host ("smem", "sa_coord", "chn", "seeds",
  * "regs_raw", ... see pipeline.hip); lets tests pin every stage against the oracle (level ii) */

@@ -38,19 +38,19 @@ if [ $(left) -gt 120 ]; then
   python $R/tools/rocpd_timeline.py $DB $O/timeline_all.tsv >> $O/kt.err 2>&1; tail -240 $O/timeline_all.tsv > $O/timeline.tsv; rm -f $O/timeline_all.tsv
 fi
 if [ $(left) -gt 100 ]; then
-  timeout 120 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/p_f -o f -- $B --steps 1 --warmup 1 > /dev/null 2> $O/pmc_f.err; at fetch $?
+  timeout 120 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/p_f -o f -- $B --steps 2 --warmup 2 > /dev/null 2> $O/pmc_f.err; at fetch $?
   python $R/tools/rocpd_summary.py $(find /tmp/p_f -name "*.db" | head -1) $O/pmc_fetch.md > /dev/null 2>> $O/pmc_f.err
 fi
 if [ $(left) -gt 100 ]; then
-  timeout 120 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/p_w -o w -- $B --steps 1 --warmup 1 > /dev/null 2> $O/pmc_w.err; at write $?
+  timeout 120 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/p_w -o w -- $B --steps 2 --warmup 2 > /dev/null 2> $O/pmc_w.err; at write $?
   python $R/tools/rocpd_summary.py $(find /tmp/p_w -name "*.db" | head -1) $O/pmc_write.md > /dev/null 2>> $O/pmc_w.err
 fi
 if [ $(left) -gt 100 ]; then
-  timeout 120 rocprofv3 --pmc $SQ1 --kernel-trace -d /tmp/p_sq1 -o s -- $B --steps 1 --warmup 1 > /dev/null 2> $O/pmc_sq1.err; at sq1 $?
+  timeout 120 rocprofv3 --pmc $SQ1 --kernel-trace -d /tmp/p_sq1 -o s -- $B --steps 2 --warmup 2 > /dev/null 2> $O/pmc_sq1.err; at sq1 $?
   python $R/tools/rocpd_summary.py $(find /tmp/p_sq1 -name "*.db" | head -1) $O/pmc_sq1.md > /dev/null 2>> $O/pmc_sq1.err
 fi
 if [ $(left) -gt 100 ]; then
-  timeout 150 rocprofv3 --pmc $SQ1 --kernel-trace -d /tmp/p_ont -o s -- python $R/bench.py --workload ont2d --no-cpu-baseline --no-parity --steps 1 --warmup 1 > $O/bench_ont2d_pmc.json 2> $O/pmc_ont.err; at ont_sq $?
+  timeout 150 rocprofv3 --pmc $SQ1 --kernel-trace -d /tmp/p_ont -o s -- python $R/bench.py --workload ont2d --no-cpu-baseline --no-parity --steps 2 --warmup 2 > $O/bench_ont2d_pmc.json 2> $O/pmc_ont.err; at ont_sq $?
   python $R/tools/rocpd_summary.py $(find /tmp/p_ont -name "*.db" | head -1) $O/pmc_sq1_ont2d.md > /dev/null 2>> $O/pmc_ont.err
 fi
 echo "finished at $(( $(date +%s) - T0 ))s"
