@@ -532,7 +532,7 @@ def end_to_end(ctx, bm2, texts, opt, paired, n_threads, n_tail=None, limit_s=Non
                     with lock:
                         busy[0] -= 1
                 add("tail", time.perf_counter() - t)
-                done[i] = (len(txt), ch.n_reads)
+                done[i] = (len(txt), ch.n_reads, time.perf_counter())
                 last[k] = (i, len(txt), n_before, buf)            # (this worker's latest chunk: its text stays in `buf` until the next one)
                 aln = None
                 free_pins.put(pin)
@@ -601,7 +601,15 @@ def end_to_end(ctx, bm2, texts, opt, paired, n_threads, n_tail=None, limit_s=Non
     timed = done[n_warm:]
     out_bytes = sum(d[0] for d in timed); n_reads = sum(d[1] for d in timed)
     nch = max(len(texts), 1)
-    return {"value": n_reads / dt, "unit": "reads/s", "reads": n_reads, "chunks": len(texts), "warmup_chunks": n_warm, "wall_s": dt, "sam_bytes": out_bytes,
+    # the rate between the completion of the timed region's 4th chunk and its last one: what a long run converges to (`value` holds the
+    # fill of the empty pipeline -- the first chunk's parse, copies, device stages and tail, ~0.45 s -- and its drain, spread over nch chunks)
+    steady = None
+    fin = sorted(d[2] for d in timed if isinstance(d, tuple) and len(d) > 2)
+    if len(fin) >= 8:
+        steady = {"chunks": len(fin) - 4, "ms_per_chunk": (fin[-1] - fin[3]) / (len(fin) - 4) * 1e3,
+                  "reads_per_s": (n_reads / len(fin)) * (len(fin) - 4) / (fin[-1] - fin[3]) if fin[-1] > fin[3] else None}
+    return {"value": n_reads / dt, "unit": "reads/s", "reads": n_reads, "chunks": len(texts), "distinct_chunks": len(set(id(t[0]) for t in texts)),
+            "steady_state": steady, "warmup_chunks": n_warm, "wall_s": dt, "sam_bytes": out_bytes,
             "host_cpus": hw, "host_threads_visible": os.cpu_count(), "parse_threads": n_parse, "device_workers": n_dev, "tail_workers": n_tail, "threads_per_tail_worker": so.n_threads,
             "stage_ms_per_chunk": {k: v / nch * 1e3 for k, v in stage.items()}, "chunk_check": check,
             # what the host side costs: CPU seconds of the whole process per timed chunk, and the chunk time that alone would allow on this host's cores
@@ -810,6 +818,8 @@ def main():
     ap.add_argument("--no-side-workloads", action="store_true", help="skip configs 5 and 2 (objects `config5` / `config2` of the pe150 line: --workload ont2d / bsw as processes of their own)")
     ap.add_argument("--no-binding", action="store_true", help="skip the drop-in timing (`bwa-mem2.bm2 mem` beside `bwa-mem2.<isa> mem` on the first two end-to-end chunks' files)")
     ap.add_argument("--e2e-chunks", type=int, default=int(os.environ.get("BM2_BENCH_E2E_CHUNKS", 10)))
+    ap.add_argument("--e2e-rounds", type=int, default=int(os.environ.get("BM2_BENCH_E2E_ROUNDS", 3)),
+                    help="the end-to-end leg goes this many times round its distinct chunks (a run of 10 chunks is one third fill and drain of the pipeline)")
     ap.add_argument("--strong", action="store_true",
                     help="strong scaling: ONE chunk of --reads reads is cut at multiples of 512 over the ranks (SURVEY.md 8(e)) instead of one chunk per rank")
     ap.add_argument("--workdir", default=os.environ.get("BM2_BENCH_WORKDIR", "/tmp/bm2_bench"))
@@ -1160,7 +1170,7 @@ def main():
                 # ONE attempt: a stage that fails or hangs leaves its threads behind (they may still be inside a library call on a context, which is
                 # not thread-safe), so nothing else is run on these contexts afterwards -- the line is printed and the process leaves through os._exit
                 try:
-                    out["end_to_end"] = end_to_end(ctx, bm2, texts, opt, True, 0, limit_s=max(60.0, min(420.0, time_left() - 30)))
+                    out["end_to_end"] = end_to_end(ctx, bm2, texts * max(a.e2e_rounds, 1), opt, True, 0, limit_s=max(60.0, min(420.0, time_left() - 30)))
                     out["end_to_end"]["frac_of_hot_path"] = out["end_to_end"]["value"] / value
                     out["value_end_to_end"] = out["end_to_end"]["value"]
                     if (out["end_to_end"].get("chunk_check") or {}).get("equal_to_serial_run") is False:
