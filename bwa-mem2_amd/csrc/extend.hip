@@ -608,6 +608,9 @@ k_ext_seeds(DevIndex ix, ExtParams xp, const int32_t *__restrict__ tasks_all, co
         }
         if (valid) regs[g] = a;
     }
+    // (a wavefront that found no tile -- the first batch of a process sizes its grids without the previous batch's statistics: ten times the
+    //  wavefronts -- leaves without queueing three atomics on one cache line)
+    if (!__ballot(n_done != 0 || cells != 0)) return;
     atomicAdd(&counters[0], (unsigned long long)cells);
     atomicAdd(&counters[1], n_done);
     if (lane == 0) atomicAdd(&counters[2], (unsigned long long)iters);      // column-pair trips of this wavefront: 128 lane slots each (lane use = cells / that)
@@ -672,7 +675,7 @@ k_ext_wave(DevIndex ix, ExtParams xp, const int32_t *__restrict__ tasks_all, con
         }
         if (lane == 0) regs[g] = a;
     }
-    if (lane == 0) {
+    if (lane == 0 && (n_done != 0 || cells != 0)) {
         atomicAdd(&counters[0], (unsigned long long)cells);
         atomicAdd(&counters[1], n_done);
         atomicAdd(&counters[3], (unsigned long long)cells);      // the wavefront kernel's share of the cells
