@@ -92,7 +92,8 @@ ix = oracle.Index(pre); exp = ix.run(enc, off, ln)["REGPRG"].tobytes(); ix.close
 ctx = bm2.Context(0, pre)
 sets = [{}, {"BM2_EXT_WAVE_QMIN": 33, "BM2_EXT_REVERSE": 1, "BM2_EXT_PREFETCH": 0}, {"BM2_EXT_WAVE_QMIN": 161, "BM2_EXT_WAVE_NMAX": 20, "BM2_EXT_ROUNDS": 2, "BM2_EXT_PERM_SCORES": 0, "BM2_EXT_QUEUE_MAP": 0}, {"BM2_EXT_GROUP4": 0, "BM2_P3_AT": 2},
         {"BM2_HEAVY_SA": 2, "BM2_CHAIN_STAGE": 1, "BM2_CHAIN_WAVES_PER_CU": 32, "BM2_PF_HEAVY": 2},
-        {"BM2_BWD_LCAP": 4, "BM2_BWD_BLOCKS_PER_CU": 5, "BM2_BWD_WAVES": 5, "BM2_SAL_QUAD": 1}, {"BM2_BWD_LCAP": 8, "BM2_HEAVY_SA": 5, "BM2_CHAIN_STAGE": 0}]
+        {"BM2_BWD_LCAP": 4, "BM2_BWD_BLOCKS_PER_CU": 5, "BM2_BWD_WAVES": 5, "BM2_SAL_QUAD": 1}, {"BM2_BWD_LCAP": 8, "BM2_HEAVY_SA": 5, "BM2_CHAIN_STAGE": 0},
+        {"BM2_EXT_WAVE_QMIN": 113, "BM2_CHAIN_MAIN_SIDE": 0, "BM2_HEAVY_SA": 3}]
 for kn in sets:
     for k in [k for k in os.environ if k.startswith("BM2_")]:
         del os.environ[k]
@@ -100,6 +101,13 @@ for kn in sets:
         os.environ[k] = str(v)
     regs, reg_off, st = ctx.seed_chain_extend(enc, off, ln, bm2.default_opt())
     assert regs_to_records(regs, reg_off).tobytes() == exp, kn
+for k in [k for k in os.environ if k.startswith("BM2_")]:
+    del os.environ[k]
+os.environ["BM2_REF_BYTES"] = "1"                            # the reference string one base per byte on the device (read at bm2_create): the same RefPtr code, pk = 0
+ctx_b = bm2.Context(0, pre)
+del os.environ["BM2_REF_BYTES"]
+regs, reg_off, st = ctx_b.seed_chain_extend(enc, off, ln, bm2.default_opt())
+assert regs_to_records(regs, reg_off).tobytes() == exp, "BM2_REF_BYTES=1"
 print("ok", len(sets))
 ''' % (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "bwa-mem2_amd"), emu_lib, golden_dir)
     p = subprocess.run(["python", "-c", script], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
