@@ -11,6 +11,9 @@
 #include <vector>
 #include "bm2.h"
 
+// (the parser's chunk arrays come from the library's page-locked pool, bm2_api.hip: plain memory here)
+void *bm2_chunk_mem_get(size_t bytes) { return malloc(bytes); }
+void bm2_chunk_mem_put(void *p) { free(p); }
 void bm2_set_error(const char *fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fputc('\n', stderr); }
 extern "C" void bm2_opt_fill_scmat(bm2_opt *o) {
     int k = 0;
