@@ -12,7 +12,9 @@
 #include "chain_dev.h"
 #include "ksort_dev.h"
 
-#define BM2_CHAIN_TIERS 5
+#define BM2_CHAIN_TIERS 8          // at most (BM2_CHAIN_FINE_TIERS); five by default
+#define CHAIN_CUR_SLOTS 5           // work cursors item_cur[0..4]: the first five tiers; [5], [6]: the overflow / island launch; further tiers: item_cur[CHAIN_CUR_EXTRA ..]
+#define CHAIN_CUR_EXTRA 30          // (= counters[40..42] of the batch: pipeline.hip)
 
 // ---------------------------------------------------------------- bntseq helpers (bntseq.cpp:378-402, bntseq.h:87-90)
 static __device__ __forceinline__ int64_t depos(const DevIndex &ix, int64_t pos, int &is_rev) {
@@ -982,15 +984,22 @@ int bm2_launch_chain(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_
     if (heavy) {
         // tiers by seed count (LDS per block follows the tier): the launches run beside the lane-per-read kernel and each other
         const int stage = bm2_knob("BM2_CHAIN_STAGE", 1);     // (sweep of round 3, profiles/r03a_sweep.json: chaining 12.4 -> 10.3 ms)
-        const int caps[BM2_CHAIN_TIERS] = { 64, 128, 256, 512, stage ? 1000 : 1184 };       // (the last tier fills a CU's 160 KB of LDS)
+        // The tiers' launches share the CUs' LDS (together they ask for four times what there is) and a block reserves its tier's cap whatever its
+        // read holds: with caps a factor 2 apart a read uses 60-70 % of its block's LDS on average.  BM2_CHAIN_FINE_TIERS=1: eight tiers, caps
+        // chosen where the number of blocks per CU changes (10, 15, 20, 30, 40, 53, 80, 156 KB: 16, 10, 8, 5, 4, 3, 2, 1 per CU).
+        const int fine = bm2_knob("BM2_CHAIN_FINE_TIERS", 0);
+        const int last_cap = stage ? 1000 : 1184;                 // (the last tier fills a CU's 160 KB of LDS)
+        const int caps_coarse[5] = { 64, 128, 256, 512, last_cap }, caps_fine[8] = { 64, 96, 128, 192, 256, 340, 512, last_cap };
+        const int n_tiers = fine ? 8 : 5;
+        const int *caps = fine ? caps_fine : caps_coarse;
         { const int rc_a = bm2_raise_lds_limit(c, 0, (const void *)k_chain_heavy, 160 * 1024); if (rc_a) return rc_a; }
         // reads with more seeds than the largest tier holds: a launch of their own where they are the norm (long reads), otherwise the last tier's
         const bool own_overflow = max_len >= bm2_knob("BM2_CHAIN_OVF_MIN_LEN", 1000);
         int lo = heavy_thr;
         // BM2_CHAIN_TIER_MAX: tiers beyond it are left out and their reads -- the seed-richest -- go to the island kernel with the long reads
         const int tier_max = bm2_knob("BM2_CHAIN_TIER_MAX", 1 << 30);
-        const bool use_islands = own_overflow || caps[BM2_CHAIN_TIERS - 1] > tier_max;
-        for (int t = 0; t < BM2_CHAIN_TIERS; t++) {
+        const bool use_islands = own_overflow || caps[n_tiers - 1] > tier_max;
+        for (int t = 0; t < n_tiers; t++) {
             if (caps[t] <= lo || caps[t] > tier_max) continue;
             hipStream_t sk = c->side_stream[2 + t];
             const size_t lds = bm2_chain_lds_bytes(caps[t], stage);
@@ -999,7 +1008,8 @@ int bm2_launch_chain(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_
             (void)hipStreamWaitEvent(sk, c->ev_fork, 0);
             hipLaunchKernelGGL(k_chain_heavy, dim3(c->n_cu * per_cu), dim3(64), lds, sk, c->ix, o, n_reads, len, smems, smem_cnt, smem_off, sa_off,
                                sa_coord, wchain, wseed, nodes, order, chn, seeds_out, seed_owner, n_chain_out, n_reg_out, n_chain0_out, perm,
-                               n_heavy_dev, n_sa_read, lo, caps[t], (t == BM2_CHAIN_TIERS - 1 && !use_islands) ? 1 : 0, item_cur + t, stage);
+                               n_heavy_dev, n_sa_read, lo, caps[t], (t == n_tiers - 1 && !use_islands) ? 1 : 0,
+                               item_cur + (t < CHAIN_CUR_SLOTS ? t : CHAIN_CUR_EXTRA + t - CHAIN_CUR_SLOTS), stage);
             (void)hipEventRecord(c->ev_join[2 + t], sk);
             joined[n_joined++] = 2 + t;
             lo = caps[t];
@@ -1015,13 +1025,13 @@ int bm2_launch_chain(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_
                 const int per_cu = bm2_knob("BM2_CHAIN_ISL_WAVES_PER_CU", 32);
                 hipLaunchKernelGGL(k_chain_islands, dim3(c->n_cu * per_cu), dim3(64), 0, sk, c->ix, o, n_reads, len, smems, smem_cnt, smem_off, sa_off,
                                    sa_coord, wchain, wseed, nodes, order, chn, seeds_out, seed_owner, isl_cut, n_chain_out, n_reg_out, n_chain0_out,
-                                   isl_order ? isl_order : perm, n_heavy_dev, n_sa_read, lo, item_cur + BM2_CHAIN_TIERS, item_cur + BM2_CHAIN_TIERS + 1,
+                                   isl_order ? isl_order : perm, n_heavy_dev, n_sa_read, lo, item_cur + CHAIN_CUR_SLOTS, item_cur + CHAIN_CUR_SLOTS + 1,
                                    isl_order ? n_reads : -1);
             } else {
                 const int per_cu = bm2_knob("BM2_CHAIN_OVF_WAVES_PER_CU", 32);
                 hipLaunchKernelGGL(k_chain_heavy, dim3(c->n_cu * per_cu), dim3(64), bm2_chain_lds_bytes(0, 0), sk, c->ix, o, n_reads, len, smems, smem_cnt, smem_off, sa_off,
                                    sa_coord, wchain, wseed, nodes, order, chn, seeds_out, seed_owner, n_chain_out, n_reg_out, n_chain0_out, perm,
-                                   n_heavy_dev, n_sa_read, lo, 0, 1, item_cur + BM2_CHAIN_TIERS, 0);
+                                   n_heavy_dev, n_sa_read, lo, 0, 1, item_cur + CHAIN_CUR_SLOTS, 0);
             }
             (void)hipEventRecord(c->ev_join[2 + BM2_CHAIN_TIERS], sk);
             joined[n_joined++] = 2 + BM2_CHAIN_TIERS;

@@ -171,8 +171,8 @@ static int run_seeding(bm2_ctx *c, Batch *b, const bm2_opt *opt, bool with_sal) 
     int rc;
     hipStream_t s = c->stream;
     const SeedParams sp = seed_params(opt);
-    if ((rc = bm2_reserve(b->counters, 40 * 8))) return rc;
-    if ((rc = bm2_check(hipMemsetAsync(b->counters.p, 0, 40 * 8, s), "memset counters"))) return rc;
+    if ((rc = bm2_reserve(b->counters, 48 * 8))) return rc;      // ([40..42]: work cursors of the chain stage's tiers beyond the fifth)
+    if ((rc = bm2_check(hipMemsetAsync(b->counters.p, 0, 48 * 8, s), "memset counters"))) return rc;
     if ((rc = bm2_reserve(b->smem_cnt, (size_t)(n + 1) * 4))) return rc;
     if ((rc = bm2_reserve(b->smem_off, (size_t)(n + 1) * 8))) return rc;
     // task kernels with persistent lanes (smem.hip); workspace sizes are learned: a run that overflows one of them reports

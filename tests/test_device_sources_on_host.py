@@ -93,7 +93,7 @@ ctx = bm2.Context(0, pre)
 sets = [{}, {"BM2_EXT_WAVE_QMIN": 33, "BM2_EXT_REVERSE": 1, "BM2_EXT_PREFETCH": 0}, {"BM2_EXT_WAVE_QMIN": 161, "BM2_EXT_WAVE_NMAX": 20, "BM2_EXT_ROUNDS": 2, "BM2_EXT_PERM_SCORES": 0, "BM2_EXT_QUEUE_MAP": 0}, {"BM2_EXT_GROUP4": 0, "BM2_P3_AT": 2},
         {"BM2_HEAVY_SA": 2, "BM2_CHAIN_STAGE": 1, "BM2_CHAIN_WAVES_PER_CU": 32, "BM2_PF_HEAVY": 2},
         {"BM2_BWD_LCAP": 4, "BM2_BWD_BLOCKS_PER_CU": 5, "BM2_BWD_WAVES": 5, "BM2_SAL_QUAD": 1}, {"BM2_BWD_LCAP": 8, "BM2_HEAVY_SA": 5, "BM2_CHAIN_STAGE": 0},
-        {"BM2_EXT_WAVE_QMIN": 113, "BM2_CHAIN_MAIN_SIDE": 0, "BM2_HEAVY_SA": 3}]
+        {"BM2_EXT_WAVE_QMIN": 113, "BM2_CHAIN_MAIN_SIDE": 0, "BM2_HEAVY_SA": 3}, {"BM2_CHAIN_FINE_TIERS": 1, "BM2_HEAVY_SA": 2}]
 for kn in sets:
     for k in [k for k in os.environ if k.startswith("BM2_")]:
         del os.environ[k]
@@ -243,6 +243,10 @@ assert np.bincount(exp["REGRAW"]["read"]).max() > 100
 ctx = bm2.Context(0, fa)
 regs, reg_off, st = ctx.seed_chain_extend(enc, off, ln, bm2.default_opt())
 assert regs_to_records(regs, reg_off).tobytes() == exp["REGPRG"].tobytes() and st["n_ext"] == exp["counters"]["n_ext"]
+os.environ["BM2_CHAIN_FINE_TIERS"] = "1"                     # eight k_chain_heavy tiers instead of five (these reads hold hundreds of seeds: the tiers beyond the fifth)
+regs, reg_off, st = ctx.seed_chain_extend(enc, off, ln, bm2.default_opt())
+del os.environ["BM2_CHAIN_FINE_TIERS"]
+assert regs_to_records(regs, reg_off).tobytes() == exp["REGPRG"].tobytes(), "BM2_CHAIN_FINE_TIERS=1"
 ctx.close()
 # 2. long candidate lists -> k_bwd_heavy
 def w2(e, n):
