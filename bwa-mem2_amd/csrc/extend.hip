@@ -1061,7 +1061,7 @@ struct ExtLaunch {
     // launch policy (bm2_knob): which kernel takes a query-length class.  A lane-per-seed wavefront of long queries walks tens of thousands
     // of cells one after the other (milliseconds) and a phase lasts as long as its slowest wavefront, so the classes from wave_qmin up can go
     // one seed per WAVEFRONT (k_ext_wave) beside the lane kernels.
-    int wave_qmin, prefetch, rev, perm_scores, qmap, group4;
+    int wave_qmin, wave_budget, prefetch, rev, perm_scores, qmap, group4;
     // the sorted seed list of the phase and where it lives
     const int32_t *tasks; const int64_t *start;
 };
@@ -1077,6 +1077,16 @@ static int run_phase(const ExtLaunch &L, const uint32_t *hint, int64_t ub) {
     // the classes from k_wave up (long queries) and the fallback bins are adjacent in the list: one wavefront-per-seed launch
     int k_wave = N_CLS;
     while (k_wave > 0 && (k_wave >= 2 ? cls_hi[k_wave - 2] : 0) + 1 >= L.wave_qmin) k_wave--;
+    // BM2_EXT_WAVE_BUDGET = B > 0 (launch policy, off by default; not yet measured): the bound moves PER PHASE with the previous batch's class
+    // counts -- the wavefront kernel takes the longest classes as long as they hold at most B seeds together (never a class below 49 bases).
+    // A long class with few seeds is a handful of lane tiles, each as long as its slowest lane's two sides -- milliseconds on a mostly idle
+    // GPU --, where the wavefront kernel spends ~30 us of one wavefront per seed; with many seeds it is the other way round (section 6 of DESIGN.md).
+    if (hint && L.wave_budget > 0) {
+        int64_t acc = hint[N_CLS];                                  // (the fallback bins are the wavefront kernel's in any case)
+        int k = N_CLS;
+        while (k > 3 && acc + (int64_t)hint[k - 1] <= (int64_t)L.wave_budget) { acc += hint[k - 1]; k--; }
+        k_wave = k;
+    }
     auto grid_for = [&](int k_lo, int k_hi, int per_block) -> unsigned {
         int64_t n = 0;
         if (hint) { for (int k = k_lo; k < k_hi; k++) n += hint[k]; n += n / 4 + 64; }
@@ -1161,6 +1171,7 @@ int bm2_launch_extend(bm2_ctx *c, const bm2_opt &opt, const ChainParams &cp, int
     // (113 until the launches of a phase really ran beside each other, see run_phase: the wavefront kernel then took 200 000 seeds of the second
     //  round -- short seeds at a read's end, the whole rest of the read to extend -- and was the last launch of its phase to end by 2 ms;
     //  profiles/r04q_sweep.json: extension 20.1 ms at 113, 16.0 ms at 129 / 145 / 161, 25.0 ms at 97)
+    L.wave_budget = bm2_knob("BM2_EXT_WAVE_BUDGET", 0);
     L.prefetch = bm2_knob("BM2_EXT_PREFETCH", 1);
     L.rev = bm2_knob("BM2_EXT_REVERSE", 1);
     L.qmap = bm2_knob("BM2_EXT_QUEUE_MAP", 1);
