@@ -982,6 +982,11 @@ def main():
                                 "phase_ms_per_read": {nm: float(cn[19 + i] * 1e-5 / (cn[17] + cn[16])) for i, nm in enumerate(names)},
                                 "phase_ms_slowest_read": {nm: float(cn[31 + i] * 1e-5) for i, nm in enumerate(names)},
                                 "serial_reads": {"ms_per_read": float(cn[28] * 1e-5 / max(cn[16], 1.0)), "seeds_per_read": float(cn[29] / max(cn[16], 1.0)), "slowest_ms": float(cn[30] * 1e-5)}}
+            if len(cn) >= 48 and cn[46] > 0:                   # BM2_CHAIN_CLOCK=1: lane 0's walk of the wavefront-per-read chain launches, clocked (100 MHz ticks)
+                heavy_clock = {"reads": int(cn[46]), "seeds_per_read": float(cn[47] / cn[46]),
+                               "ms_per_read": {"staging by the 64 lanes": float(cn[43] * 1e-5 / cn[46]), "mem_chain_seeds (lane 0)": float(cn[44] * 1e-5 / cn[46]),
+                                               "traversal + mem_chain_flt + output (lane 0)": float(cn[45] * 1e-5 / cn[46])}}
+                chain_kernel = dict(chain_kernel or {}, k_chain_heavy_clock=heavy_clock)
         except Exception:                                                             # noqa
             pass
         dominant = max(stage_ms, key=stage_ms.get) if stage_ms else None

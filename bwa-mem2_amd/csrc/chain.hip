@@ -404,6 +404,8 @@ struct ChainWork {
     // inputs of the read staged by the whole wavefront before lane 0 walks them (k_chain_heavy, `staged`): per seed the reference
     // position, (qbeg | len << 15 | is_alt << 31) and the contig id bns_intv2rid gives; per SMEM (m | (n + 1) << 15 | repetitive << 31)
     int64_t *st_rbeg; uint32_t *st_ql; int32_t *st_rid; uint32_t *st_sm; bool staged;
+    // BM2_CHAIN_CLOCK=1: 100 MHz ticks of lane 0's walk, [1] mem_chain_seeds, [2] traversal + mem_chain_flt + the read's output (k_chain_heavy adds [0] staging, [3] reads, [4] seeds)
+    unsigned long long *clk = nullptr;
 };
 
 // mem_chain_seeds + mem_chain_flt for read r.  LIGHT: the lane-per-read kernel (global slices); otherwise the caller offers LDS
@@ -417,6 +419,7 @@ static __device__ void chain_one_read(const DevIndex &ix, const ChainParams &o, 
                                       int32_t *n_chain0_out, int heavy_thr, const ChainWork *lw, int lds_cap, const IslSeed *ist = nullptr,
                                       const IslHash *isl_hash = nullptr, const int32_t *isl_slot = nullptr) {
     const int n_sm = smem_cnt[r];
+    const long long t_enter = (!LIGHT && lw && lw->clk) ? wall_clock64() : 0;
     n_chain_out[r] = 0; n_reg_out[r] = 0;          // (k_chain never gets here with a read it leaves to k_chain_heavy: one writer per read)
     if (n_chain0_out) n_chain0_out[r] = 0;
     if (n_sm == 0 || len[r] < o.min_seed_len) return;
@@ -502,6 +505,8 @@ static __device__ void chain_one_read(const DevIndex &ix, const ChainParams &o, 
             }
         }
     }
+    long long t_walk = 0;
+    if (!LIGHT && lw && lw->clk) { t_walk = wall_clock64(); atomicAdd(lw->clk + 1, (unsigned long long)(t_walk - t_enter)); }
     int n = bt_traverse(bt, ord);                        // chains in key order (bwamem.cpp:958-962)
     if (n_chain0_out) n_chain0_out[r] = n;
     const float frac_rep = (float)l_rep / len[r];        // bwamem.cpp:965-966
@@ -515,6 +520,7 @@ static __device__ void chain_one_read(const DevIndex &ix, const ChainParams &o, 
     }
     if (k == 0 && n > 0) k = 1;      // quirk: an empty survivor list still processes the untouched a_[0] (bwamem.cpp:529-546)
     chain_finish_read(o, r, ch, sd, ord, (int32_t *)nodes, k, base, frac_rep, chn, seeds_out, seed_owner, n_chain_out, n_reg_out);
+    if (!LIGHT && lw && lw->clk) atomicAdd(lw->clk + 2, (unsigned long long)(wall_clock64() - t_walk));
 }
 
 __global__ void __launch_bounds__(128, 6)
@@ -550,10 +556,12 @@ k_chain_heavy(DevIndex ix, ChainParams o, int n_reads, const int32_t *__restrict
               const int64_t *__restrict__ sa_coord, WChain *wchain, WSeed *wseed, BtNode *nodes, int32_t *order,
               DevChain *chn, DevSeed *seeds_out, int32_t *seed_owner, int32_t *n_chain_out, int32_t *n_reg_out, int32_t *n_chain0_out,
               const int32_t *__restrict__ heavy /* read ids, heavy ones first */, const int64_t *__restrict__ n_heavy_p,
-              const int32_t *__restrict__ n_sa_read, int lo, int cap, int last_tier, unsigned long long *item_cur, int stage) {
+              const int32_t *__restrict__ n_sa_read, int lo, int cap, int last_tier, unsigned long long *item_cur, int stage,
+              unsigned long long *clk /* or NULL: BM2_CHAIN_CLOCK */) {
     extern __shared__ __attribute__((aligned(16))) uint8_t chain_lds[];
     const int lane = threadIdx.x;
     ChainWork lw;
+    lw.clk = clk;
     int32_t *st_cut = nullptr;
     {
         size_t at = 0;
@@ -583,6 +591,7 @@ k_chain_heavy(DevIndex ix, ChainParams o, int n_reads, const int32_t *__restrict
         // in many contigs, ~10 more for the two binary searches of bns_intv2rid -- the bulk of this kernel's time.  Those inputs do
         // not depend on the walk: the 64 lanes fetch them for 64 seeds at a time into LDS first.
         lw.staged = false;
+        const long long t_stage = clk && mine ? wall_clock64() : 0;
         if (mine && stage && ns <= cap) {
             const int n_sm = smem_cnt[r];
             if (n_sm > 0) {
@@ -611,6 +620,7 @@ k_chain_heavy(DevIndex ix, ChainParams o, int n_reads, const int32_t *__restrict
                 }
             }
         }
+        if (clk && mine && lane == 0) { atomicAdd(clk, (unsigned long long)(wall_clock64() - t_stage)); atomicAdd(clk + 3, 1ULL); atomicAdd(clk + 4, (unsigned long long)ns); }
         if (mine && lane == 0)
             chain_one_read<false>(ix, o, r, n_reads, len, smems, smem_cnt, smem_off, sa_off, sa_coord, wchain, wseed, nodes, order, chn, seeds_out,
                                   seed_owner, n_chain_out, n_reg_out, n_chain0_out, -1, &lw, cap);
@@ -987,6 +997,8 @@ int bm2_launch_chain(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_
         // The tiers' launches share the CUs' LDS (together they ask for four times what there is) and a block reserves its tier's cap whatever its
         // read holds: with caps a factor 2 apart a read uses 60-70 % of its block's LDS on average.  BM2_CHAIN_FINE_TIERS=1: eight tiers, caps
         // chosen where the number of blocks per CU changes (10, 15, 20, 30, 40, 53, 80, 156 KB: 16, 10, 8, 5, 4, 3, 2, 1 per CU).
+        // BM2_CHAIN_CLOCK=1: the wavefront-per-read launches clock their reads (counters[43..47] of the batch: staging, mem_chain_seeds, the rest, reads, seeds)
+        unsigned long long *clk = bm2_knob("BM2_CHAIN_CLOCK", 0) ? item_cur + CHAIN_CUR_EXTRA + 3 : (unsigned long long *)nullptr;
         const int fine = bm2_knob("BM2_CHAIN_FINE_TIERS", 0);
         const int last_cap = stage ? 1000 : 1184;                 // (the last tier fills a CU's 160 KB of LDS)
         const int caps_coarse[5] = { 64, 128, 256, 512, last_cap }, caps_fine[8] = { 64, 96, 128, 192, 256, 340, 512, last_cap };
@@ -1009,7 +1021,7 @@ int bm2_launch_chain(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_
             hipLaunchKernelGGL(k_chain_heavy, dim3(c->n_cu * per_cu), dim3(64), lds, sk, c->ix, o, n_reads, len, smems, smem_cnt, smem_off, sa_off,
                                sa_coord, wchain, wseed, nodes, order, chn, seeds_out, seed_owner, n_chain_out, n_reg_out, n_chain0_out, perm,
                                n_heavy_dev, n_sa_read, lo, caps[t], (t == n_tiers - 1 && !use_islands) ? 1 : 0,
-                               item_cur + (t < CHAIN_CUR_SLOTS ? t : CHAIN_CUR_EXTRA + t - CHAIN_CUR_SLOTS), stage);
+                               item_cur + (t < CHAIN_CUR_SLOTS ? t : CHAIN_CUR_EXTRA + t - CHAIN_CUR_SLOTS), stage, clk);
             (void)hipEventRecord(c->ev_join[2 + t], sk);
             joined[n_joined++] = 2 + t;
             lo = caps[t];
@@ -1031,7 +1043,7 @@ int bm2_launch_chain(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_
                 const int per_cu = bm2_knob("BM2_CHAIN_OVF_WAVES_PER_CU", 32);
                 hipLaunchKernelGGL(k_chain_heavy, dim3(c->n_cu * per_cu), dim3(64), bm2_chain_lds_bytes(0, 0), sk, c->ix, o, n_reads, len, smems, smem_cnt, smem_off, sa_off,
                                    sa_coord, wchain, wseed, nodes, order, chn, seeds_out, seed_owner, n_chain_out, n_reg_out, n_chain0_out, perm,
-                                   n_heavy_dev, n_sa_read, lo, 0, 1, item_cur + CHAIN_CUR_SLOTS, 0);
+                                   n_heavy_dev, n_sa_read, lo, 0, 1, item_cur + CHAIN_CUR_SLOTS, 0, clk);
             }
             (void)hipEventRecord(c->ev_join[2 + BM2_CHAIN_TIERS], sk);
             joined[n_joined++] = 2 + BM2_CHAIN_TIERS;

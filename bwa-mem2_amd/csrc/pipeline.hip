@@ -824,14 +824,14 @@ extern "C" int bm2_batch_fetch(bm2_ctx *c, const char *what, void *out, int64_t 
         { "sa_coord", &b->sa_coord, ns * 8 }, { "read_base", &b->read_base, (size_t)n * 8 },
         { "n_chain", &b->n_chain, (size_t)n * 4 }, { "n_chain0", &b->n_chain0, (size_t)n * 4 }, { "n_reg", &b->n_reg, (size_t)n * 4 },
         { "n_out", &b->n_out, (size_t)n * 4 }, { "chn", &b->chn, ns * sizeof(DevChain) }, { "seeds", &b->seeds, ns * sizeof(DevSeed) },
-        { "seed_counters", &b->seedc, (size_t)21 * 8 }, { "counters", &b->counters, (size_t)40 * 8 }, { "regs_raw", &b->regs, ns * sizeof(DevReg) }, { "reg_seed", &b->reg_seed, ns * 4 }, { "wchain", &b->wchain, ns * sizeof(WChain) },
+        { "seed_counters", &b->seedc, (size_t)21 * 8 }, { "counters", &b->counters, (size_t)48 * 8 }, { "regs_raw", &b->regs, ns * sizeof(DevReg) }, { "reg_seed", &b->reg_seed, ns * 4 }, { "wchain", &b->wchain, ns * sizeof(WChain) },
     };
     if (c->n_parts > 1 && (!strcmp(what, "seed_counters") || !strcmp(what, "counters"))) {       // work counters of a chunk in parts: the parts' sums
-        const size_t nb = !strcmp(what, "counters") ? (size_t)40 * 8 : (size_t)21 * 8;
+        const size_t nb = !strcmp(what, "counters") ? (size_t)48 * 8 : (size_t)21 * 8;
         *n_bytes = (int64_t)nb;
         if ((size_t)cap_bytes < nb) return BM2_ECAP;
         if (!out) return BM2_EINVAL;
-        unsigned long long acc[40] = { 0 }, one[40];
+        unsigned long long acc[48] = { 0 }, one[48];
         for (int i = 0; i < c->n_parts; i++) {
             bm2_ctx *p = part_ctx(c, i);
             if (!p->batch) return BM2_EINVAL;

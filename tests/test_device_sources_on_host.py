@@ -95,7 +95,7 @@ sets = [{}, {"BM2_EXT_WAVE_QMIN": 33, "BM2_EXT_REVERSE": 1, "BM2_EXT_PREFETCH": 
         {"BM2_HEAVY_SA": 2, "BM2_CHAIN_STAGE": 1, "BM2_CHAIN_WAVES_PER_CU": 32, "BM2_PF_HEAVY": 2},
         {"BM2_BWD_LCAP": 4, "BM2_BWD_BLOCKS_PER_CU": 5, "BM2_BWD_WAVES": 5, "BM2_SAL_QUAD": 1},
         {"BM2_BWD_LCAP": 8, "BM2_HEAVY_SA": 5, "BM2_CHAIN_STAGE": 0, "BM2_EXT_WAVE_BUDGET": 1000000},
-        {"BM2_EXT_WAVE_QMIN": 113, "BM2_CHAIN_MAIN_SIDE": 0, "BM2_CHAIN_FINE_TIERS": 1, "BM2_HEAVY_SA": 2}]
+        {"BM2_EXT_WAVE_QMIN": 113, "BM2_CHAIN_MAIN_SIDE": 0, "BM2_CHAIN_FINE_TIERS": 1, "BM2_HEAVY_SA": 2, "BM2_CHAIN_CLOCK": 1}]
 for kn in sets:
     for k in [k for k in os.environ if k.startswith("BM2_")]:
         del os.environ[k]
@@ -103,6 +103,9 @@ for kn in sets:
         os.environ[k] = str(v)
     regs, reg_off, st = ctx.seed_chain_extend(enc, off, ln, bm2.default_opt())
     assert regs_to_records(regs, reg_off).tobytes() == exp, kn
+    if kn.get("BM2_CHAIN_CLOCK"):                              # the wavefront-per-read launches clocked their reads: counters[43..47]
+        cn = ctx.batch_fetch("counters", np.uint64)
+        assert len(cn) >= 48 and cn[46] > 0 and cn[47] >= cn[46], cn[40:48]       # (reads, seeds; the ticks need a real clock)
 for k in [k for k in os.environ if k.startswith("BM2_")]:
     del os.environ[k]
 os.environ["BM2_REF_BYTES"] = "1"                            # the reference string one base per byte on the device (read at bm2_create): the same RefPtr code, pk = 0
