@@ -394,6 +394,118 @@ static __device__ void chain_finish_read(const ChainParams &o, int r, WChain *ch
     n_reg_out[r] = 0;              // set by k_chain_finish
 }
 
+// ---- mem_chain_flt again, for a WHOLE WAVEFRONT (BM2_CHAIN_COOP_FLT; chain_finish_read above is what one lane runs and stays as it is): the walk over
+// the kept chains is quadratic in the chains of a repeat-rich read -- 64 kept chains at a time, one per lane (flt_kept_coop); the weight sort before it
+// and the rest + the read's output after it (flt_rest_emit: the same statements as in chain_finish_read) are lane 0's.
+static __device__ __forceinline__ void flt_sort(const WChain *ch, int32_t *ord, int n) {
+    k_introsort_flat(n, ord, [&](int32_t x, int32_t y) { return ch[x].w > ch[y].w; });     // flt_lt, bwamem.cpp:61
+}
+// the overlap test of chain i (span [beg_i, end_i), weight w_i) against the kept chain cj: bit 0 = large overlap, bit 1 = ... and i is dropped (bwamem.cpp:570-584)
+static __device__ __forceinline__ int flt_ovlp(const ChainParams &o, const WChain &cj, int beg_i, int end_i, int w_i, int alt_i) {
+    const int beg_j = cj.first_qbeg, end_j = cj.last_qbeg + cj.last_len;
+    const int b_max = beg_j > beg_i ? beg_j : beg_i;
+    const int e_min = end_j < end_i ? end_j : end_i;
+    if (e_min > b_max && (!cj.is_alt || alt_i)) {
+        const int li = end_i - beg_i, lj = end_j - beg_j;
+        const int min_l = li < lj ? li : lj;
+        if (e_min - b_max >= min_l * o.mask_level && min_l < o.max_chain_gap)
+            return (w_i < cj.w * o.drop_ratio && cj.w - w_i >= o.min_seed_len << 1) ? 3 : 1;
+    }
+    return 0;
+}
+static __device__ __forceinline__ void flt_sync() {              // lanes of one wavefront handing LDS or GLOBAL data to each other
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+// The same walk by the 64 lanes of a (converged) wavefront: chain i meets 64 kept chains at a time, one per lane.  The serial walk stops at
+// the FIRST kept chain that drops i, and every kept chain up to and including that one which overlaps i largely gets `first` (if it has none):
+// a ballot of the drop test gives the stopping lane, the lanes up to it apply their own chain's side effect -- no two lanes touch one chain.
+static __device__ int flt_kept_coop(const ChainParams &o, WChain *ch, const int32_t *ord, int32_t *kept_list, int n, int lane) {
+    if (lane == 0) { ch[ord[0]].kept = 3; kept_list[0] = 0; }
+    int n_kept = 1;
+    flt_sync();
+    for (int i = 1; i < n; ++i) {
+        const int ci_idx = ord[i];
+        const int beg_i = ch[ci_idx].first_qbeg, end_i = ch[ci_idx].last_qbeg + ch[ci_idx].last_len, w_i = ch[ci_idx].w, alt_i = ch[ci_idx].is_alt;
+        int large_ovlp = 0;
+        bool stopped = false;
+        for (int k0 = 0; k0 < n_kept && !stopped; k0 += 64) {
+            const int kk = k0 + lane;
+            int v = 0, j = -1;
+            if (kk < n_kept) { j = ord[kept_list[kk]]; v = flt_ovlp(o, ch[j], beg_i, end_i, w_i, alt_i); }
+            const unsigned long long bm = __ballot((v & 2) != 0);
+            unsigned long long am = __ballot(v != 0);
+            if (bm) {
+                const int fb = __ffsll((long long)bm) - 1;
+                am &= fb >= 63 ? ~0ULL : ((1ULL << (fb + 1)) - 1ULL);
+                stopped = true;
+            }
+            if ((am >> lane) & 1ULL) { if (ch[j].first < 0) ch[j].first = i; }
+            if (am) large_ovlp = 1;
+        }
+        if (!stopped) {
+            if (lane == 0) { kept_list[n_kept] = i; ch[ci_idx].kept = large_ovlp ? 2 : 3; }
+            n_kept++;
+        }
+        flt_sync();
+    }
+    return n_kept;
+}
+// the rest of mem_chain_flt and the read's chains with contiguous seeds
+static __device__ void flt_rest_emit(const ChainParams &o, int r, WChain *ch, WSeed *sd, int32_t *ord, const int32_t *kept_list, int n, int n_kept, int64_t base,
+                                     float frac_rep, DevChain *chn, DevSeed *seeds_out, int32_t *seed_owner, int32_t *n_chain_out, int32_t *n_reg_out) {
+    int k;
+    if (n > 0) {
+        for (int i = 0; i < n_kept; ++i) {
+            const WChain &c = ch[ord[kept_list[i]]];
+            if (c.first >= 0) ch[ord[c.first]].kept = 1;
+        }
+        int i2;
+        for (i2 = k = 0; i2 < n; ++i2) {
+            const int kp = ch[ord[i2]].kept;
+            if (kp == 0 || kp == 3) continue;
+            if (++k >= o.max_chain_extend) break;
+        }
+        for (; i2 < n; ++i2) if (ch[ord[i2]].kept < 3) ch[ord[i2]].kept = 0;
+        for (i2 = k = 0; i2 < n; ++i2) if (ch[ord[i2]].kept != 0) ord[k++] = ord[i2];
+        n = k;
+    }
+    // ---- emit kept chains with contiguous seeds
+    DevChain *oc = chn + base;
+    DevSeed *os = seeds_out + base;
+    int n_seed = 0;
+    for (int i = 0; i < n; i++) {
+        const WChain &c = ch[ord[i]];
+        DevChain d;
+        d.pos = c.pos; d.seed_off = base + n_seed; d.n = c.n; d.rid = c.rid; d.w = c.w; d.kept = c.kept; d.first = c.first;
+        d.is_alt = c.is_alt; d.read = r; d.frac_rep = frac_rep; d.rmax0 = 0; d.rmax1 = 0;
+        const int s0 = n_seed;
+        for (int si = c.head; si >= 0; si = sd[si].next) {
+            DevSeed s; s.rbeg = sd[si].rbeg; s.qbeg = sd[si].qbeg; s.len = sd[si].len; s.score = sd[si].len; s.aln = -1;
+            os[n_seed++] = s;
+        }
+        d.reg0 = 0; d.pad = 0;
+        for (int t = s0; t < n_seed; t++) seed_owner[base + t] = r;
+        oc[i] = d;
+    }
+    n_chain_out[r] = n;
+    n_reg_out[r] = 0;              // set by k_chain_finish
+}
+// A read whose finish the caller runs itself (with all its lanes: chain_finish_coop): what chain_one_read would have passed to chain_finish_read
+struct DeferFinish { int valid, r, n; int64_t base; float frac_rep; WChain *ch; WSeed *sd; int32_t *ord; int32_t *kept; };
+static __device__ void chain_finish_coop(const ChainParams &o, const DeferFinish &d, int lane, DevChain *chn, DevSeed *seeds_out, int32_t *seed_owner,
+                                         int32_t *n_chain_out, int32_t *n_reg_out) {      // (every lane of the wavefront, converged; `d` is the same in all of them)
+    int n_kept = 0;
+    if (d.n > 0) {
+        if (lane == 0) flt_sort(d.ch, d.ord, d.n);
+        flt_sync();
+        n_kept = flt_kept_coop(o, d.ch, d.ord, d.kept, d.n, lane);
+    }
+    if (lane == 0) flt_rest_emit(o, d.r, d.ch, d.sd, d.ord, d.kept, d.n, n_kept, d.base, d.frac_rep, chn, seeds_out, seed_owner, n_chain_out, n_reg_out);
+    flt_sync();
+}
+
 struct IslSeed { int64_t rbeg; uint32_t ql; int32_t rid; };           // a seed staged in global memory (k_chain_islands): ql = qbeg | len << 15 | is_alt << 31
 struct IslHash { unsigned long long key; int32_t cnt, start; };        // key = bucket + 1 (0: free); seeds in the island that STARTS at this bucket; its place in `perm`
 
@@ -417,7 +529,8 @@ static __device__ void chain_one_read(const DevIndex &ix, const ChainParams &o, 
                                       const int64_t *__restrict__ sa_coord, WChain *wchain, WSeed *wseed, BtNode *nodes_g, int32_t *order,
                                       DevChain *chn, DevSeed *seeds_out, int32_t *seed_owner, int32_t *n_chain_out, int32_t *n_reg_out,
                                       int32_t *n_chain0_out, int heavy_thr, const ChainWork *lw, int lds_cap, const IslSeed *ist = nullptr,
-                                      const IslHash *isl_hash = nullptr, const int32_t *isl_slot = nullptr) {
+                                      const IslHash *isl_hash = nullptr, const int32_t *isl_slot = nullptr,
+                                      DeferFinish *defer = nullptr /* !LIGHT: leave mem_chain_flt's walk and the output to the caller's wavefront */) {
     const int n_sm = smem_cnt[r];
     const long long t_enter = (!LIGHT && lw && lw->clk) ? wall_clock64() : 0;
     n_chain_out[r] = 0; n_reg_out[r] = 0;          // (k_chain never gets here with a read it leaves to k_chain_heavy: one writer per read)
@@ -519,6 +632,11 @@ static __device__ void chain_one_read(const DevIndex &ix, const ChainParams &o, 
         if (c.w >= o.min_chain_weight) ord[k++] = ord[i];
     }
     if (k == 0 && n > 0) k = 1;      // quirk: an empty survivor list still processes the untouched a_[0] (bwamem.cpp:529-546)
+    if (!LIGHT && defer) {
+        defer->r = r; defer->n = k; defer->base = base; defer->frac_rep = frac_rep; defer->ch = ch; defer->sd = sd; defer->ord = ord; defer->kept = (int32_t *)nodes;
+        defer->valid = 1;
+        return;
+    }
     chain_finish_read(o, r, ch, sd, ord, (int32_t *)nodes, k, base, frac_rep, chn, seeds_out, seed_owner, n_chain_out, n_reg_out);
     if (!LIGHT && lw && lw->clk) atomicAdd(lw->clk + 2, (unsigned long long)(wall_clock64() - t_walk));
 }
@@ -550,6 +668,7 @@ static __device__ __forceinline__ void chain_wave_sync() {      // lanes of one 
 // tiered by seed count so that a block claims only the LDS its reads need (tier capacity `cap`: reads with lo < seeds <= cap; the
 // last tier also takes the reads beyond its capacity and works on their global slices).  Items come from the heavy-first list of
 // the partition; every tier scans it and skips what is not its own.
+template <bool COOP>      // COOP (BM2_CHAIN_COOP_FLT): mem_chain_flt's walk over the kept chains by all 64 lanes; a launch of its own so that the default one keeps its registers
 __global__ void __launch_bounds__(64)
 k_chain_heavy(DevIndex ix, ChainParams o, int n_reads, const int32_t *__restrict__ len, const bm2_smem_t *__restrict__ smems,
               const int32_t *__restrict__ smem_cnt, const int64_t *__restrict__ smem_off, const int64_t *__restrict__ sa_off,
@@ -621,7 +740,22 @@ k_chain_heavy(DevIndex ix, ChainParams o, int n_reads, const int32_t *__restrict
             }
         }
         if (clk && mine && lane == 0) { atomicAdd(clk, (unsigned long long)(wall_clock64() - t_stage)); atomicAdd(clk + 3, 1ULL); atomicAdd(clk + 4, (unsigned long long)ns); }
-        if (mine && lane == 0)
+        if constexpr (COOP) {
+          if (mine) {                                              // (`mine` is the same in every lane)
+            __shared__ DeferFinish df;
+            if (lane == 0) {
+                df.valid = 0;
+                chain_one_read<false>(ix, o, r, n_reads, len, smems, smem_cnt, smem_off, sa_off, sa_coord, wchain, wseed, nodes, order, chn, seeds_out,
+                                      seed_owner, n_chain_out, n_reg_out, n_chain0_out, -1, &lw, cap, nullptr, nullptr, nullptr, &df);
+            }
+            flt_sync();
+            if (df.valid) {
+                const DeferFinish d = df;
+                chain_finish_coop(o, d, lane, chn, seeds_out, seed_owner, n_chain_out, n_reg_out);
+            }
+            flt_sync();
+          }
+        } else if (mine && lane == 0)
             chain_one_read<false>(ix, o, r, n_reads, len, smems, smem_cnt, smem_off, sa_off, sa_coord, wchain, wseed, nodes, order, chn, seeds_out,
                                   seed_owner, n_chain_out, n_reg_out, n_chain0_out, -1, &lw, cap);
     }
@@ -726,6 +860,7 @@ static __device__ void isl_build(const DevIndex &ix, const ChainParams &o, const
     if (dup) atomicAdd(s_dup, 1);
 }
 
+template <bool COOP>      // COOP (BM2_CHAIN_COOP_FLT): see k_chain_heavy
 __global__ void __launch_bounds__(64)
 k_chain_islands(DevIndex ix, ChainParams o, int n_reads, const int32_t *__restrict__ len, const bm2_smem_t *__restrict__ smems,
                 const int32_t *__restrict__ smem_cnt, const int64_t *__restrict__ smem_off, const int64_t *__restrict__ sa_off,
@@ -735,6 +870,7 @@ k_chain_islands(DevIndex ix, ChainParams o, int n_reads, const int32_t *__restri
                 const int32_t *__restrict__ n_sa_read, int lo, unsigned long long *item_cur, unsigned long long *n_fallback, int n_items) {
     __shared__ int s_nsurv, s_ntot, s_dup;
     __shared__ unsigned long long s_min;
+    __shared__ DeferFinish df;                                     // (only the COOP launch touches it)
     const int lane = threadIdx.x;
     const unsigned long long lt_mask = lane ? (~0ULL >> (64 - lane)) : 0ULL;
     const int64_t n_heavy = n_items >= 0 ? (int64_t)n_items : *n_heavy_p;     // (n_items: `heavy` lists EVERY read, the seed-richest first)
@@ -853,11 +989,12 @@ k_chain_islands(DevIndex ix, ChainParams o, int n_reads, const int32_t *__restri
         ISL_TICK(5);
         // ---- the read
         if (lane == 0) {
+            if constexpr (COOP) df.valid = 0;
             if (s_dup) {                                             // chains with equal keys: the serial code on the read's slices
                 atomicAdd(n_fallback, 1ULL);
                 const long long t_fb = wall_clock64();
                 chain_one_read<false>(ix, o, r, n_reads, len, smems, smem_cnt, smem_off, sa_off, sa_coord, wchain, wseed, nodes, order, chn, seeds_out,
-                                      seed_owner, n_chain_out, n_reg_out, n_chain0_out, -1, nullptr, 0, st, hash, cslot);
+                                      seed_owner, n_chain_out, n_reg_out, n_chain0_out, -1, nullptr, 0, st, hash, cslot, COOP ? &df : (DeferFinish *)nullptr);
                 const unsigned long long dt_fb = (unsigned long long)(wall_clock64() - t_fb);
                 atomicAdd(n_fallback + 12, dt_fb); atomicAdd(n_fallback + 13, (unsigned long long)n_sa); atomicMax(n_fallback + 14, dt_fb);
             } else {
@@ -874,7 +1011,10 @@ k_chain_islands(DevIndex ix, ChainParams o, int n_reads, const int32_t *__restri
                 int k = s_nsurv;
                 if (k == 0 && n_all > 0) { ord[0] = (int32_t)(s_min & 0xffffffULL); k = 1; }       // the a_[0] quirk: the chain with the smallest key
                 else if (k > 1) k_introsort_flat(k, ord, [&](int32_t x, int32_t y) { return ch[x].pos < ch[y].pos; });     // key order (the keys are distinct here)
-                chain_finish_read(o, r, ch, sd, ord, (int32_t *)nd, k, base, (float)l_rep / len[r], chn, seeds_out, seed_owner, n_chain_out, n_reg_out);
+                if constexpr (COOP) {
+                    df.r = r; df.n = k; df.base = base; df.frac_rep = (float)l_rep / len[r]; df.ch = ch; df.sd = sd; df.ord = ord; df.kept = (int32_t *)nd;
+                    df.valid = 1;
+                } else chain_finish_read(o, r, ch, sd, ord, (int32_t *)nd, k, base, (float)l_rep / len[r], chn, seeds_out, seed_owner, n_chain_out, n_reg_out);
                 atomicAdd(n_fallback + 1, 1ULL);                     // reads chained by islands
                 atomicAdd(n_fallback + 2, (unsigned long long)n_comp);      // islands
                 atomicAdd(n_fallback + 10, (unsigned long long)k);           // chains that passed the weight test
@@ -882,6 +1022,13 @@ k_chain_islands(DevIndex ix, ChainParams o, int n_reads, const int32_t *__restri
             }
         }
         isl_sync();
+        if constexpr (COOP) {                                        // mem_chain_flt's walk over the kept chains and the read's output, by the whole wavefront
+            if (df.valid) {
+                const DeferFinish d = df;
+                chain_finish_coop(o, d, lane, chn, seeds_out, seed_owner, n_chain_out, n_reg_out);
+            }
+            isl_sync();
+        }
         ISL_TICK(6);
         } else if (lane == 0) {                                      // (too few seeds for the table's place in the slices -- cannot happen above `lo` >= 64 -- or nothing to chain)
             chain_one_read<false>(ix, o, r, n_reads, len, smems, smem_cnt, smem_off, sa_off, sa_coord, wchain, wseed, nodes, order, chn, seeds_out,
@@ -999,12 +1146,15 @@ int bm2_launch_chain(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_
         // chosen where the number of blocks per CU changes (10, 15, 20, 30, 40, 53, 80, 156 KB: 16, 10, 8, 5, 4, 3, 2, 1 per CU).
         // BM2_CHAIN_CLOCK=1: the wavefront-per-read launches clock their reads (counters[43..47] of the batch: staging, mem_chain_seeds, the rest, reads, seeds)
         unsigned long long *clk = bm2_knob("BM2_CHAIN_CLOCK", 0) ? item_cur + CHAIN_CUR_EXTRA + 3 : (unsigned long long *)nullptr;
+        // BM2_CHAIN_COOP_FLT=1 (off; not yet measured on the GPU): the wavefront-per-read launches run mem_chain_flt's walk over the kept chains with all 64 lanes
+        const int coop = bm2_knob("BM2_CHAIN_COOP_FLT", 0);
         const int fine = bm2_knob("BM2_CHAIN_FINE_TIERS", 0);
         const int last_cap = stage ? 1000 : 1184;                 // (the last tier fills a CU's 160 KB of LDS)
         const int caps_coarse[5] = { 64, 128, 256, 512, last_cap }, caps_fine[8] = { 64, 96, 128, 192, 256, 340, 512, last_cap };
         const int n_tiers = fine ? 8 : 5;
         const int *caps = fine ? caps_fine : caps_coarse;
-        { const int rc_a = bm2_raise_lds_limit(c, 0, (const void *)k_chain_heavy, 160 * 1024); if (rc_a) return rc_a; }
+        { const int rc_a = coop ? bm2_raise_lds_limit(c, 2, (const void *)k_chain_heavy<true>, 160 * 1024 - 256)        // (its static record rides on top of the dynamic LDS)
+                                : bm2_raise_lds_limit(c, 0, (const void *)k_chain_heavy<false>, 160 * 1024); if (rc_a) return rc_a; }
         // reads with more seeds than the largest tier holds: a launch of their own where they are the norm (long reads), otherwise the last tier's
         const bool own_overflow = max_len >= bm2_knob("BM2_CHAIN_OVF_MIN_LEN", 1000);
         int lo = heavy_thr;
@@ -1018,7 +1168,7 @@ int bm2_launch_chain(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_
             const int per_cu_max = bm2_knob("BM2_CHAIN_WAVES_PER_CU", 16);
             int per_cu = (int)(160 * 1024 / lds); if (per_cu < 1) per_cu = 1; if (per_cu > per_cu_max) per_cu = per_cu_max;
             (void)hipStreamWaitEvent(sk, c->ev_fork, 0);
-            hipLaunchKernelGGL(k_chain_heavy, dim3(c->n_cu * per_cu), dim3(64), lds, sk, c->ix, o, n_reads, len, smems, smem_cnt, smem_off, sa_off,
+            hipLaunchKernelGGL(coop ? k_chain_heavy<true> : k_chain_heavy<false>, dim3(c->n_cu * per_cu), dim3(64), lds, sk, c->ix, o, n_reads, len, smems, smem_cnt, smem_off, sa_off,
                                sa_coord, wchain, wseed, nodes, order, chn, seeds_out, seed_owner, n_chain_out, n_reg_out, n_chain0_out, perm,
                                n_heavy_dev, n_sa_read, lo, caps[t], (t == n_tiers - 1 && !use_islands) ? 1 : 0,
                                item_cur + (t < CHAIN_CUR_SLOTS ? t : CHAIN_CUR_EXTRA + t - CHAIN_CUR_SLOTS), stage, clk);
@@ -1035,13 +1185,13 @@ int bm2_launch_chain(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_
             (void)hipStreamWaitEvent(sk, c->ev_fork, 0);
             if (bm2_knob("BM2_CHAIN_ISLANDS", 1)) {                 // chaining by islands (k_chain_islands): one wavefront per read, every lane at work
                 const int per_cu = bm2_knob("BM2_CHAIN_ISL_WAVES_PER_CU", 32);
-                hipLaunchKernelGGL(k_chain_islands, dim3(c->n_cu * per_cu), dim3(64), 0, sk, c->ix, o, n_reads, len, smems, smem_cnt, smem_off, sa_off,
+                hipLaunchKernelGGL(coop ? k_chain_islands<true> : k_chain_islands<false>, dim3(c->n_cu * per_cu), dim3(64), 0, sk, c->ix, o, n_reads, len, smems, smem_cnt, smem_off, sa_off,
                                    sa_coord, wchain, wseed, nodes, order, chn, seeds_out, seed_owner, isl_cut, n_chain_out, n_reg_out, n_chain0_out,
                                    isl_order ? isl_order : perm, n_heavy_dev, n_sa_read, lo, item_cur + CHAIN_CUR_SLOTS, item_cur + CHAIN_CUR_SLOTS + 1,
                                    isl_order ? n_reads : -1);
             } else {
                 const int per_cu = bm2_knob("BM2_CHAIN_OVF_WAVES_PER_CU", 32);
-                hipLaunchKernelGGL(k_chain_heavy, dim3(c->n_cu * per_cu), dim3(64), bm2_chain_lds_bytes(0, 0), sk, c->ix, o, n_reads, len, smems, smem_cnt, smem_off, sa_off,
+                hipLaunchKernelGGL(coop ? k_chain_heavy<true> : k_chain_heavy<false>, dim3(c->n_cu * per_cu), dim3(64), bm2_chain_lds_bytes(0, 0), sk, c->ix, o, n_reads, len, smems, smem_cnt, smem_off, sa_off,
                                    sa_coord, wchain, wseed, nodes, order, chn, seeds_out, seed_owner, n_chain_out, n_reg_out, n_chain0_out, perm,
                                    n_heavy_dev, n_sa_read, lo, 0, 1, item_cur + CHAIN_CUR_SLOTS, 0, clk);
             }

@@ -86,7 +86,7 @@ bm2.LIB_PATH = %r
 from helpers import load_golden, regs_to_records
 from tools import oracle
 pre, enc, off, ln, d = load_golden(%r, "g60k")
-n = 48
+n = 28                                                       # (every set runs the whole device path on the emulator: seconds per read)
 ln = ln[:n]; off = off[:n]; enc = enc[:int(off[-1] + ln[-1])]
 ix = oracle.Index(pre); exp = ix.run(enc, off, ln)["REGPRG"].tobytes(); ix.close()
 ctx = bm2.Context(0, pre)
@@ -95,7 +95,8 @@ sets = [{}, {"BM2_EXT_WAVE_QMIN": 33, "BM2_EXT_REVERSE": 1, "BM2_EXT_PREFETCH": 
         {"BM2_HEAVY_SA": 2, "BM2_CHAIN_STAGE": 1, "BM2_CHAIN_WAVES_PER_CU": 32, "BM2_PF_HEAVY": 2},
         {"BM2_BWD_LCAP": 4, "BM2_BWD_BLOCKS_PER_CU": 5, "BM2_BWD_WAVES": 5, "BM2_SAL_QUAD": 1},
         {"BM2_BWD_LCAP": 8, "BM2_HEAVY_SA": 5, "BM2_CHAIN_STAGE": 0, "BM2_EXT_WAVE_BUDGET": 1000000},
-        {"BM2_EXT_WAVE_QMIN": 113, "BM2_CHAIN_MAIN_SIDE": 0, "BM2_CHAIN_FINE_TIERS": 1, "BM2_HEAVY_SA": 2, "BM2_CHAIN_CLOCK": 1}]
+        {"BM2_EXT_WAVE_QMIN": 113, "BM2_CHAIN_MAIN_SIDE": 0, "BM2_CHAIN_FINE_TIERS": 1, "BM2_HEAVY_SA": 2, "BM2_CHAIN_CLOCK": 1},
+        {"BM2_CHAIN_COOP_FLT": 1, "BM2_HEAVY_SA": 2}]
 for kn in sets:
     for k in [k for k in os.environ if k.startswith("BM2_")]:
         del os.environ[k]
@@ -248,10 +249,12 @@ assert np.bincount(exp["REGRAW"]["read"]).max() > 100
 ctx = bm2.Context(0, fa)
 regs, reg_off, st = ctx.seed_chain_extend(enc, off, ln, bm2.default_opt())
 assert regs_to_records(regs, reg_off).tobytes() == exp["REGPRG"].tobytes() and st["n_ext"] == exp["counters"]["n_ext"]
-os.environ["BM2_CHAIN_FINE_TIERS"] = "1"                     # eight k_chain_heavy tiers instead of five (these reads hold hundreds of seeds: the tiers beyond the fifth)
+# eight k_chain_heavy tiers instead of five (these reads hold hundreds of seeds: the tiers beyond the fifth) and mem_chain_flt's walk over the
+# kept chains by the 64 lanes (they keep hundreds of chains)
+os.environ["BM2_CHAIN_FINE_TIERS"] = "1"; os.environ["BM2_CHAIN_COOP_FLT"] = "1"
 regs, reg_off, st = ctx.seed_chain_extend(enc, off, ln, bm2.default_opt())
-del os.environ["BM2_CHAIN_FINE_TIERS"]
-assert regs_to_records(regs, reg_off).tobytes() == exp["REGPRG"].tobytes(), "BM2_CHAIN_FINE_TIERS=1"
+del os.environ["BM2_CHAIN_FINE_TIERS"]; del os.environ["BM2_CHAIN_COOP_FLT"]
+assert regs_to_records(regs, reg_off).tobytes() == exp["REGPRG"].tobytes(), "BM2_CHAIN_FINE_TIERS=1 BM2_CHAIN_COOP_FLT=1"
 ctx.close()
 # 2. long candidate lists -> k_bwd_heavy
 def w2(e, n):
