@@ -86,7 +86,7 @@ bm2.LIB_PATH = %r
 from helpers import load_golden, regs_to_records
 from tools import oracle
 pre, enc, off, ln, d = load_golden(%r, "g60k")
-n = 28                                                       # (every set runs the whole device path on the emulator: seconds per read)
+n = 20                                                       # (every set runs the whole device path on the emulator: seconds per read)
 ln = ln[:n]; off = off[:n]; enc = enc[:int(off[-1] + ln[-1])]
 ix = oracle.Index(pre); exp = ix.run(enc, off, ln)["REGPRG"].tobytes(); ix.close()
 ctx = bm2.Context(0, pre)
