@@ -37,6 +37,7 @@ struct SeedBufs {                                   // workspace of the seeding 
     bm2_smem_t *recs; int64_t rec_cap;
     P2Task *tasks; int64_t task_cap;
     int32_t *heavy1, *heavy2; int64_t heavy_cap;     // slot ids of the long-list tasks of pass 1 / pass 2
+    int32_t *cont1, *cont2; int64_t cont_cap;        // slot ids of the tasks k_bwd handed over at a row boundary (BM2_BWD_EXPORT_AGE)
 };
 enum { BM2_SC_SLOT1 = 1, BM2_SC_REC = 3, BM2_SC_TASK = 4, BM2_SC_SLOT2 = 6, BM2_SC_NEXT = 9, BM2_SC_OVF = 10, BM2_SC_POOL = 11,
        BM2_SC_NEXT_W1 = 12 /* then W2, W3, B1, B2 */ };   // = the SC_* of smem.hip

@@ -58,7 +58,7 @@ struct Batch {
     std::vector<int32_t> h_len;              // host copy of the read lengths (per-read filter thresholds)
     DevBuf min_hsp, seed_owner, seed_keep, mat25;
     DevBuf perm2, part_tmp2;
-    DevBuf heads1, ents1, heads2, ents2, pool, recs, tasks, seedc, fill, smem_tmp, heavy1, heavy2;     // seeding task kernels
+    DevBuf heads1, ents1, heads2, ents2, pool, recs, tasks, seedc, fill, smem_tmp, heavy1, heavy2, cont1, cont2;     // seeding task kernels
     DevBuf fin_work, fin_ord, fin_state, fin_n, fin_off, fin_req, fin_cnt, fin_out;                     // hit finishing (finish.hip)
     int64_t n_fin = -1; int fin_rounds = 0;     // -1: bm2_batch_finish has not run on the current regs
     int seed_attempts = 0;                      // runs of the seeding kernels the last batch needed (> 1: a workspace grew)
@@ -73,7 +73,7 @@ void bm2_batch_destroy(bm2_ctx *c) {
                       &b->order, &b->chn, &b->seeds, &b->srt, &b->reg_seed, &b->reg_chain, &b->regs, &b->slot_base, &b->n_chain,
                       &b->n_reg, &b->n_chain0, &b->n_out, &b->out_off, &b->out_regs, &b->smem_sorted, &b->smem_sorted_off, &b->ext_tmp, &b->cursor, &b->n_sa_read, &b->perm, &b->perm_hist, &b->part_tmp, &b->min_hsp, &b->seed_owner, &b->seed_keep, &b->mat25,
                       &b->heads1, &b->ents1, &b->heads2, &b->ents2, &b->pool, &b->recs, &b->tasks, &b->seedc, &b->fill, &b->smem_tmp,
-                      &b->heavy1, &b->heavy2, &b->perm2, &b->part_tmp2,
+                      &b->heavy1, &b->heavy2, &b->cont1, &b->cont2, &b->perm2, &b->part_tmp2,
                       &b->fin_work, &b->fin_ord, &b->fin_state, &b->fin_n, &b->fin_off, &b->fin_req, &b->fin_cnt, &b->fin_out };
     for (DevBuf *d : all) bm2_release(*d);
     delete b;
@@ -221,6 +221,10 @@ static int run_seeding(bm2_ctx *c, Batch *b, const bm2_opt *opt, bool with_sal) 
         if ((rc = bm2_reserve(b->heavy1, (size_t)sb.heavy_cap * 4))) return rc;
         if ((rc = bm2_reserve(b->heavy2, (size_t)sb.heavy_cap * 4))) return rc;
         sb.heavy1 = (int32_t *)b->heavy1.p; sb.heavy2 = (int32_t *)b->heavy2.p;
+        sb.cont_cap = (int64_t)n / 2 + lanes + 4096;            // (a full list only means the task stays with its lane)
+        if ((rc = bm2_reserve(b->cont1, (size_t)sb.cont_cap * 4))) return rc;
+        if ((rc = bm2_reserve(b->cont2, (size_t)sb.cont_cap * 4))) return rc;
+        sb.cont1 = (int32_t *)b->cont1.p; sb.cont2 = (int32_t *)b->cont2.p;
         if ((rc = bm2_check(hipMemsetAsync(b->seedc.p, 0, (size_t)n_sc * 8, s), "memset seed cursors"))) return rc;
         if ((rc = bm2_check(hipMemsetAsync(b->smem_cnt.p, 0, (size_t)(n + 1) * 4, s), "memset smem_cnt"))) return rc;
         if ((rc = bm2_check(hipMemsetAsync(b->fill.p, 0, (size_t)(2 * (size_t)n + 8) * 4, s), "memset fill"))) return rc;
@@ -256,7 +260,7 @@ static int run_seeding(bm2_ctx *c, Batch *b, const bm2_opt *opt, bool with_sal) 
                 h_sc[BM2_SC_SLOT2], h_sc[BM2_SC_REC], h_sc[BM2_SC_TASK], h_sc[BM2_SC_POOL]);
     }
     unsigned long long h_cnt[3] = { (unsigned long long)n_smem_tot, h_sc[BM2_SC_NEXT], 0 };
-    static_assert(BM2_SC_NEXT_W1 + 9 == 21, "bm2_batch_fetch(\"seed_counters\") exposes 21 counters");
+    static_assert(BM2_SC_NEXT_W1 + 13 == 25, "bm2_batch_fetch(\"seed_counters\") exposes 25 counters ([21], [22]: tasks handed over in pass 1 / 2)");
     if ((rc = bm2_reserve(b->smem, (size_t)(n_smem_tot + 1) * sizeof(bm2_smem_t)))) return rc;
     if ((rc = bm2_reserve(b->smem_tmp, (size_t)(n_smem_tot + 1) * sizeof(bm2_smem_t)))) return rc;
     if ((rc = bm2_reserve(b->occ_cnt, (size_t)(n_smem_tot + 2) * 4))) return rc;
@@ -824,7 +828,7 @@ extern "C" int bm2_batch_fetch(bm2_ctx *c, const char *what, void *out, int64_t 
         { "sa_coord", &b->sa_coord, ns * 8 }, { "read_base", &b->read_base, (size_t)n * 8 },
         { "n_chain", &b->n_chain, (size_t)n * 4 }, { "n_chain0", &b->n_chain0, (size_t)n * 4 }, { "n_reg", &b->n_reg, (size_t)n * 4 },
         { "n_out", &b->n_out, (size_t)n * 4 }, { "chn", &b->chn, ns * sizeof(DevChain) }, { "seeds", &b->seeds, ns * sizeof(DevSeed) },
-        { "seed_counters", &b->seedc, (size_t)21 * 8 }, { "counters", &b->counters, (size_t)48 * 8 }, { "regs_raw", &b->regs, ns * sizeof(DevReg) }, { "reg_seed", &b->reg_seed, ns * 4 }, { "wchain", &b->wchain, ns * sizeof(WChain) },
+        { "seed_counters", &b->seedc, (size_t)25 * 8 }, { "counters", &b->counters, (size_t)48 * 8 }, { "regs_raw", &b->regs, ns * sizeof(DevReg) }, { "reg_seed", &b->reg_seed, ns * 4 }, { "wchain", &b->wchain, ns * sizeof(WChain) },
     };
     if (c->n_parts > 1 && (!strcmp(what, "seed_counters") || !strcmp(what, "counters"))) {       // work counters of a chunk in parts: the parts' sums
         const size_t nb = !strcmp(what, "counters") ? (size_t)48 * 8 : (size_t)21 * 8;

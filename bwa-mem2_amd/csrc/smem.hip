@@ -140,7 +140,8 @@ static __device__ __forceinline__ Bi init_bi(const DevIndex &ix, int a) {     //
 
 enum { W_P1 = 1, W_P2 = 2, W_P3 = 3 };
 enum { SC_P1_ITEM = 0, SC_SLOT1, SC_B1_ITEM, SC_REC, SC_TASK, SC_P2_ITEM, SC_SLOT2, SC_B2_ITEM, SC_P3_ITEM, SC_NEXT, SC_OVF_FLAG,
-       SC_POOL, SC_NEXT_W1, SC_NEXT_W2, SC_NEXT_W3, SC_NEXT_B1, SC_NEXT_B2, SC_HEAVY1, SC_HEAVY2, SC_H1_ITEM, SC_H2_ITEM, SC_N };   // SC_NEXT_*: backwardExt calls per kernel           // cursors / counters of the seeding kernels (unsigned long long each)
+       SC_POOL, SC_NEXT_W1, SC_NEXT_W2, SC_NEXT_W3, SC_NEXT_B1, SC_NEXT_B2, SC_HEAVY1, SC_HEAVY2, SC_H1_ITEM, SC_H2_ITEM,
+       SC_CONT1, SC_CONT2, SC_C1_ITEM, SC_C2_ITEM, SC_N };   // SC_CONT*: backward tasks k_bwd handed over at a row boundary (their slot ids: SeedBufs::cont1 / cont2)   // SC_NEXT_*: backwardExt calls per kernel           // cursors / counters of the seeding kernels (unsigned long long each)
 enum { OVF_SLOT1 = 1, OVF_SLOT2 = 2, OVF_REC = 4, OVF_TASK = 8, OVF_POOL = 16 };
 
 struct __attribute__((aligned(16))) BHead {       // header of a backward-phase task (32 bytes)
@@ -184,6 +185,7 @@ static __device__ __forceinline__ int64_t wave_alloc(LdsPool *wp, unsigned long 
 #define HEAVY_T 40                // backward tasks with longer candidate lists go to the wave-per-task kernel ...
 #define HCAP 256                  // ... if the list fits its LDS row (else they stay lane-per-task)
 #define HEAVY_BATCH 64
+#define BWD_EXPORT_AGE 0              // (default of BM2_BWD_EXPORT_AGE)
 #define ITEM_BATCH 64
 #define SLOT_BATCH 256
 #define REC_BATCH 256
@@ -385,17 +387,18 @@ enum { B_EXT = 0, B_NEWITEM, B_FIRST, B_ROWEND, B_ROW, B_FIN, B_DONE };
 // LC: survivors of a row kept in LDS per lane (16 B x LC x 256 lanes per block decides how many blocks share a CU's 160 KB)
 template <int LC>
 static __device__ __forceinline__ void
-bwd_body(const DevIndex &ix, const SeedParams &sp, int pass, const uint8_t *__restrict__ enc, const BHead *__restrict__ heads,
+bwd_body(const DevIndex &ix, const SeedParams &sp, int pass, const uint8_t *__restrict__ enc, BHead *heads,
          uint4 *__restrict__ ents, int64_t slot_cap, uint4 *__restrict__ pool, int pool_cap, int pool_slots,
          bm2_smem_t *__restrict__ recs, int64_t rec_cap, P2Task *__restrict__ tasks, int64_t task_cap,
-         int32_t *__restrict__ smem_cnt, unsigned long long *sc) {
+         int32_t *__restrict__ smem_cnt, unsigned long long *sc, int32_t *__restrict__ cont_ids, int64_t cont_cap, int export_age) {
     int64_t n_ext = 0;
     unsigned ovf = 0;
     int64_t n_items = (int64_t)sc[pass == 1 ? SC_SLOT1 : SC_SLOT2];
     if (n_items > slot_cap) n_items = slot_cap;
-    __shared__ WavePool pools[4][3];                           // per wave: [0] work items, [1] records, [2] pass-2 tasks
+    __shared__ WavePool pools[4][4];                           // per wave: [0] work items, [1] records, [2] pass-2 tasks, [3] ids of handed-over tasks
     LdsPool *ip = (LdsPool *)&pools[threadIdx.x >> 6][0], *rp = (LdsPool *)&pools[threadIdx.x >> 6][1], *tp = (LdsPool *)&pools[threadIdx.x >> 6][2];
-    if ((threadIdx.x & 63) == 0) { ip->pos = ip->end = 0; rp->pos = rp->end = 0; tp->pos = tp->end = 0; }
+    LdsPool *cp = (LdsPool *)&pools[threadIdx.x >> 6][3];
+    if ((threadIdx.x & 63) == 0) { ip->pos = ip->end = 0; rp->pos = rp->end = 0; tp->pos = tp->end = 0; cp->pos = cp->end = 0; }
     unsigned long long *item_cur = sc + (pass == 1 ? SC_B1_ITEM : SC_B2_ITEM);
     int64_t it_a = wave_alloc<ITEM_BATCH>(ip, item_cur);
     BHead pl = {};
@@ -408,6 +411,7 @@ bwd_body(const DevIndex &ix, const SeedParams &sp, int pass, const uint8_t *__re
     int32_t r = 0; const uint8_t *q = enc; int L = 0;
     int x = 0, j = 0, a = 0, n_prev = 0, top = 0, n_curr = 0, p = 0, m_row = 0; int32_t curr_s = -1; bool first_done = false;
     int32_t min_intv = 1;                                      // <= 65535 (pass 2: s + 1 with s <= split_width)
+    int age = 0;                                               // extensions this task has had so far (hand-over: see B_ROWEND)
     uint4 *lst = ents; uint4 *lpool = pool;                   // this task's list: entries [0, CAPF) and [CAPF, ...)
     int64_t ck = 0, cl = 0, cs = 0; int cn = 0;                // the candidate being extended
     int64_t fk = 0, fl = 0, fs = 0; int fn = 0;                // first survivor of the current row
@@ -442,7 +446,7 @@ bwd_body(const DevIndex &ix, const SeedParams &sp, int pass, const uint8_t *__re
                 q = enc + h.rd_off;
                 lst = ents + slot * CAPF;
                 lpool = pool + (int64_t)(h.pool_id >= 0 && h.pool_id < pool_slots ? h.pool_id : 0) * pool_cap;
-                top = n_prev - 1; j = x - 1; m_row = x; row0 = true;
+                top = n_prev - 1; j = x - 1; m_row = x; row0 = true; age = 0;
                 nxt_raw4 = *entry(top);
                 if (j >= 0) w.start(q, j, -1);
                 state = B_FIRST; break;
@@ -454,6 +458,28 @@ bwd_body(const DevIndex &ix, const SeedParams &sp, int pass, const uint8_t *__re
             if (state == B_ROWEND) {                            // :650-655
                 n_prev = n_curr;
                 if (n_curr == 0) state = B_FIN;
+                else if (export_age > 0 && age >= export_age && j > 0 && n_curr <= HCAP) {
+                    // HAND-OVER.  A lane-per-task kernel cannot end before its oldest task does, and the task sizes have a long tail (mean ~100
+                    // extensions, one in a thousand beyond 1000: tools/seed_sim): the last third of this kernel used to be a few lanes finishing
+                    // repeat-rich positions on an otherwise empty GPU.  A task that has had `export_age` extensions stops at the end of its row:
+                    // the row's survivors go back into the task's slot where the reader of a walk's list expects them (entry(top - depth)), the
+                    // header says row j is done, and k_bwd_heavy -- a wavefront per task, the candidates of a row side by side -- finishes it in a
+                    // launch of its own after this one (a kernel boundary: no hand-off between running workgroups).
+                    const int64_t cid = wave_alloc<HEAVY_BATCH>(cp, sc + (pass == 1 ? SC_CONT1 : SC_CONT2));
+                    if (cid < cont_cap) {
+                        const int64_t slot = (int64_t)(lst - ents) / CAPF;
+                        *entry(top) = pv_pack(fk, fl, fs, fn);
+                        const int nl = n_curr - 1 < LC ? n_curr - 1 : LC;
+                        for (int d = 1; d <= nl; d++) *entry(top - d) = surv[(d - 1) * 256 + threadIdx.x];
+                        BHead h = heads[slot];
+                        h.x_np = (uint32_t)j | (uint32_t)n_curr << 16;          // "start position" j: the continuation sets m_row = j and goes on with row j - 1
+                        h.mi_pass |= 1u << 24;
+                        h.pad = top + 1;                                        // where the list's first entry is (a walk's list: n_prev - 1)
+                        heads[slot] = h;
+                        cont_ids[cid] = (int32_t)slot;
+                        state = B_NEWITEM;
+                    } else { m_row = j; j--; row0 = false; state = B_ROW; }
+                }
                 else { m_row = j; j--; row0 = false; state = B_ROW; }
             }
             if (state == B_ROW) {                               // :596-606
@@ -481,7 +507,7 @@ bwd_body(const DevIndex &ix, const SeedParams &sp, int pass, const uint8_t *__re
         const Bi ein = { ck, cl, cs };
         const Bi o = backward_ext(ix, ein, a, state == B_EXT);    // (all lanes: quad-cooperative)
         if (state == B_EXT) {                                   // :607-649
-            n_ext++;
+            n_ext++; age++;
             if (!first_done && o.s < (int64_t)min_intv && (cn - m_row + 1) >= sp.min_seed_len) {
                 em = 1;
                 first_done = true;
@@ -520,6 +546,7 @@ bwd_body(const DevIndex &ix, const SeedParams &sp, int pass, const uint8_t *__re
     }
     for (int64_t at = rp->pos + (threadIdx.x & 63); at < rp->end; at += 64) if (at < rec_cap) recs[at].rid = 0xffffffffu;
     for (int64_t at = tp->pos + (threadIdx.x & 63); at < tp->end; at += 64) if (at < task_cap) tasks[at].r = -1;
+    for (int64_t at = cp->pos + (threadIdx.x & 63); at < cp->end; at += 64) if (at < cont_cap) cont_ids[at] = -1;
     atomicAdd(&sc[SC_NEXT], (unsigned long long)n_ext);
     atomicAdd(&sc[SC_NEXT_B1 + (pass - 1)], (unsigned long long)n_ext);
     if (ovf) atomicOr(&sc[SC_OVF_FLAG], (unsigned long long)ovf);
@@ -528,10 +555,11 @@ bwd_body(const DevIndex &ix, const SeedParams &sp, int pass, const uint8_t *__re
 #endif
 }
 
-#define BWD_ARGS DevIndex ix, SeedParams sp, int pass, const uint8_t *__restrict__ enc, const BHead *__restrict__ heads, uint4 *__restrict__ ents, \
+#define BWD_ARGS DevIndex ix, SeedParams sp, int pass, const uint8_t *__restrict__ enc, BHead *heads, uint4 *__restrict__ ents, \
                  int64_t slot_cap, uint4 *__restrict__ pool, int pool_cap, int pool_slots, bm2_smem_t *__restrict__ recs, int64_t rec_cap, \
-                 P2Task *__restrict__ tasks, int64_t task_cap, int32_t *__restrict__ smem_cnt, unsigned long long *sc
-#define BWD_PASS ix, sp, pass, enc, heads, ents, slot_cap, pool, pool_cap, pool_slots, recs, rec_cap, tasks, task_cap, smem_cnt, sc
+                 P2Task *__restrict__ tasks, int64_t task_cap, int32_t *__restrict__ smem_cnt, unsigned long long *sc, \
+                 int32_t *__restrict__ cont_ids, int64_t cont_cap, int export_age
+#define BWD_PASS ix, sp, pass, enc, heads, ents, slot_cap, pool, pool_cap, pool_slots, recs, rec_cap, tasks, task_cap, smem_cnt, sc, cont_ids, cont_cap, export_age
 template <int LC> __global__ void __launch_bounds__(256) k_bwd(BWD_ARGS) { bwd_body<LC>(BWD_PASS); }     // 111 VGPRs: 4 waves per SIMD
 // the same with the register allocation told to leave room for 5 waves per SIMD (96 VGPRs, 100 bytes per lane spilled)
 template <int LC> __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) k_bwd5(BWD_ARGS) { bwd_body<LC>(BWD_PASS); }
@@ -556,7 +584,7 @@ k_bwd_heavy(DevIndex ix, SeedParams sp, int pass, const uint8_t *__restrict__ en
             const uint4 *__restrict__ ents, int64_t slot_cap, const uint4 *__restrict__ pool, int pool_cap, int pool_slots,
             const int32_t *__restrict__ heavy_ids, int64_t heavy_cap,
             bm2_smem_t *__restrict__ recs, int64_t rec_cap, P2Task *__restrict__ tasks, int64_t task_cap,
-            int32_t *__restrict__ smem_cnt, unsigned long long *sc) {
+            int32_t *__restrict__ smem_cnt, unsigned long long *sc, int cont) {          // cont: the items are the tasks k_bwd handed over (SC_CONT*), not the walks' long lists
     __shared__ uint4 lists[4][HCAP];
     __shared__ int32_t alive_s[4][64];
     __shared__ WavePool pools[4][2];
@@ -565,9 +593,9 @@ k_bwd_heavy(DevIndex ix, SeedParams sp, int pass, const uint8_t *__restrict__ en
     if (lane == 0) { rp->pos = rp->end = 0; tp->pos = tp->end = 0; }
     uint4 *lst = lists[wv];
     int32_t *as = alive_s[wv];
-    int64_t n_items = (int64_t)sc[pass == 1 ? SC_HEAVY1 : SC_HEAVY2];
+    int64_t n_items = (int64_t)sc[cont ? (pass == 1 ? SC_CONT1 : SC_CONT2) : (pass == 1 ? SC_HEAVY1 : SC_HEAVY2)];
     if (n_items > heavy_cap) n_items = heavy_cap;
-    unsigned long long *item_cur = sc + (pass == 1 ? SC_H1_ITEM : SC_H2_ITEM);
+    unsigned long long *item_cur = sc + (cont ? (pass == 1 ? SC_C1_ITEM : SC_C2_ITEM) : (pass == 1 ? SC_H1_ITEM : SC_H2_ITEM));
     int64_t n_ext = 0;
     unsigned ovf = 0;
     const unsigned long long lt_mask = lane ? (~0ULL >> (64 - lane)) : 0ULL;
@@ -588,7 +616,7 @@ k_bwd_heavy(DevIndex ix, SeedParams sp, int pass, const uint8_t *__restrict__ en
         const uint8_t *q = enc + h.rd_off;
         const uint4 *src = ents + (int64_t)slot * CAPF;
         const uint4 *psrc = pool + (int64_t)(h.pool_id >= 0 && h.pool_id < pool_slots ? h.pool_id : 0) * pool_cap;
-        const int top = n_prev - 1;
+        const int top = h.pad > 0 ? h.pad - 1 : n_prev - 1;         // (a handed-over task: the survivors of its last row lie where the walk's list began)
         for (int d = lane; d < n_prev; d += 64) {                // longest first (:586-592) = the walk's list read top-down
             const int idx = top - d;
             lst[d] = idx < CAPF ? src[idx] : psrc[idx - CAPF];
@@ -923,15 +951,20 @@ int bm2_launch_seeding(bm2_ctx *c, const SeedParams &sp, int n_reads, const uint
     if (bm2_side_streams(c)) return BM2_ENODEV;
     hipStream_t s = c->stream, s3 = c->side_stream[0], sh = c->side_stream[1];
     const int grid_heavy = c->n_cu * 4;
+    // k_bwd hands a task that has had this many extensions over to the wavefront-per-task kernel at its next row boundary (0 = never)
+    const int export_age = bm2_knob("BM2_BWD_EXPORT_AGE", BWD_EXPORT_AGE);
     // pass 3 is independent of passes 1 and 2: it runs beside them.  WHERE is launch policy (BM2_P3_AT): 0 = beside the forward walks of
     // pass 1 (both are forward-only kernels without LDS lists: they compete for the same wave slots), 1 / 2 = beside the backward kernel of
     // pass 1 / 2, whose blocks hold 48 KB of LDS survivors and leave wave slots empty that a kernel without LDS can use
     const int p3_at = bm2_knob("BM2_P3_AT", max_len >= 1000 ? 0 : 1);      // (150 bp reads, profiles/r04c: beside bwd1 34.9 instead of 36.1 ms; 10 kb reads, whose walks are
                                                                                //  ten times as long as their backward phases, r04d: 180 instead of 138 ms there)
+    const int p3_bpc = bm2_knob("BM2_P3_BPC", 0);                            // workgroups per CU of pass 3 (0: as many as the other walks)
+    const int grid_p3 = p3_bpc > 0 ? c->n_cu * p3_bpc : grid_walk;
+    const int heavy_after = bm2_knob("BM2_BWD_HEAVY_AFTER", 0);              // the long lists' wavefront-per-task kernel after k_bwd instead of beside it
     auto launch_p3 = [&]() {
         (void)hipEventRecord(c->ev_fork, s);
         (void)hipStreamWaitEvent(s3, c->ev_fork, 0);
-        hipLaunchKernelGGL(k_walk<W_P3>, dim3(grid_walk), dim3(256), 0, s3, c->ix, sp, n_reads, enc, off, len, (const P2Task *)nullptr, (int64_t)0,
+        hipLaunchKernelGGL(k_walk<W_P3>, dim3(grid_p3), dim3(256), 0, s3, c->ix, sp, n_reads, enc, off, len, (const P2Task *)nullptr, (int64_t)0,
                            (BHead *)nullptr, (uint4 *)nullptr, (int64_t)0, (uint4 *)nullptr, 0, 0, sb.recs, sb.rec_cap, smem_cnt, sc,
                            (int32_t *)nullptr, (int64_t)0);
         (void)hipEventRecord(c->ev_join[0], s3);
@@ -951,18 +984,28 @@ int bm2_launch_seeding(bm2_ctx *c, const SeedParams &sp, int n_reads, const uint
         tick(c, pass == 1 ? "smem.walk1" : "smem.walk2");
         if (p3_at == pass) launch_p3();
         // the long lists go to one wavefront each, beside the lane-per-task kernel
-        (void)hipEventRecord(c->ev_join[2], s);
-        (void)hipStreamWaitEvent(sh, c->ev_join[2], 0);
-        hipLaunchKernelGGL(k_bwd_heavy, dim3(grid_heavy), dim3(256), 0, sh, c->ix, sp, pass, enc, heads, ents, slot_cap, sb.pool, sb.pool_cap,
-                           sb.pool_slots, heavy, sb.heavy_cap, sb.recs, sb.rec_cap, sb.tasks, sb.task_cap, smem_cnt, sc);
-        (void)hipEventRecord(c->ev_join[1], sh);
+        if (!heavy_after) {
+            (void)hipEventRecord(c->ev_join[2], s);
+            (void)hipStreamWaitEvent(sh, c->ev_join[2], 0);
+            hipLaunchKernelGGL(k_bwd_heavy, dim3(grid_heavy), dim3(256), 0, sh, c->ix, sp, pass, enc, heads, ents, slot_cap, sb.pool, sb.pool_cap,
+                               sb.pool_slots, heavy, sb.heavy_cap, sb.recs, sb.rec_cap, sb.tasks, sb.task_cap, smem_cnt, sc, 0);
+            (void)hipEventRecord(c->ev_join[1], sh);
+        }
         const int lc = bm2_knob("BM2_BWD_LCAP", LCAP), wpe = bm2_knob("BM2_BWD_WAVES", 4);
         auto kb = wpe >= 5 ? (lc <= 4 ? k_bwd5<4> : k_bwd5<6>)
                            : (lc <= 4 ? k_bwd<4> : lc <= 6 ? k_bwd<6> : lc <= 8 ? k_bwd<8> : k_bwd<LCAP>);
+        int32_t *cont = pass == 1 ? sb.cont1 : sb.cont2;
         hipLaunchKernelGGL(kb, dim3(grid_bwd), dim3(256), 0, s, c->ix, sp, pass, enc, heads, ents, slot_cap, sb.pool, sb.pool_cap,
-                           sb.pool_slots, sb.recs, sb.rec_cap, sb.tasks, sb.task_cap, smem_cnt, sc);
-        (void)hipStreamWaitEvent(s, c->ev_join[1], 0);
+                           sb.pool_slots, sb.recs, sb.rec_cap, sb.tasks, sb.task_cap, smem_cnt, sc, cont, sb.cont_cap, export_age);
+        if (!heavy_after) (void)hipStreamWaitEvent(s, c->ev_join[1], 0);
+        else hipLaunchKernelGGL(k_bwd_heavy, dim3(grid_heavy * 2), dim3(256), 0, s, c->ix, sp, pass, enc, heads, ents, slot_cap, sb.pool, sb.pool_cap,
+                                sb.pool_slots, heavy, sb.heavy_cap, sb.recs, sb.rec_cap, sb.tasks, sb.task_cap, smem_cnt, sc, 0);
         tick(c, pass == 1 ? "smem.bwd1" : "smem.bwd2");
+        if (export_age > 0) {                                   // the tasks k_bwd handed over, a wavefront each (they may file pass-2 tasks: before k_walk<P2>)
+            hipLaunchKernelGGL(k_bwd_heavy, dim3(grid_heavy * 2), dim3(256), 0, s, c->ix, sp, pass, enc, heads, ents, slot_cap, sb.pool, sb.pool_cap,
+                               sb.pool_slots, cont, sb.cont_cap, sb.recs, sb.rec_cap, sb.tasks, sb.task_cap, smem_cnt, sc, 1);
+            tick(c, pass == 1 ? "smem.cont1" : "smem.cont2");
+        }
     }
     (void)hipStreamWaitEvent(s, c->ev_join[0], 0);
     return bm2_check(hipGetLastError(), "seeding launch");

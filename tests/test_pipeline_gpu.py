@@ -139,6 +139,61 @@ def test_repeat_rich_lists_vs_oracle(gpu_ctx_factory, tmp_path):
     _same(exp["SMEM"], got, "SMEM")
 
 
+# Launch-policy knobs that are OFF by default (bm2_knob, bm2_ctx.h): none may change a result, and none may sit in the tree without having met a GPU.
+# Every setting below runs the repeat-rich short reads (pool lists, wavefront-per-task seeding, the heavy chaining tiers, wave / lane extension
+# classes) and a set of long ONT-like reads (island chaining, serial equal-key reads, the sliding-window extension) against the oracle.
+KNOB_SETTINGS = [
+    {"BM2_BWD_EXPORT_AGE": "256"}, {"BM2_BWD_EXPORT_AGE": "24"}, {"BM2_BWD_EXPORT_AGE": "128", "BM2_BWD_HEAVY_AFTER": "1"},
+    {"BM2_P3_BPC": "1"}, {"BM2_P3_BPC": "2", "BM2_P3_AT": "2"},
+    {"BM2_CHAIN_COOP_FLT": "1"}, {"BM2_CHAIN_COOP_FLT": "1", "BM2_CHAIN_FINE_TIERS": "1"}, {"BM2_CHAIN_CLOCK": "1"},
+    {"BM2_EXT_WAVE_BUDGET": "2000"}, {"BM2_EXT_WAVE_BUDGET": "100000"},
+]
+
+
+@pytest.fixture(scope="module")
+def knob_cases(tmp_path_factory):
+    tmp = tmp_path_factory.mktemp("knobs")
+    fa, (enc, off, ln) = _repeat_case(tmp, 23, 4000)
+    ix = oracle.Index(fa)
+    try:
+        exp_short = ix.run(enc, off, ln)
+    finally:
+        ix.close()
+    (tmp / "long").mkdir()
+    names, ctg, alts = synth.make_genome(47, [400000, 150000], alt_contigs=1, alt_len=5000, n_repeat_families=40, repeat_len=(100, 2000),
+                                         copies=(3, 80), divergence=(0.0, 0.03))
+    fl = str(tmp / "long" / "g.fa")
+    synth.write_fasta(fl, names, ctg)
+    synth.write_alt(fl + ".alt", alts)
+    assert build_index(fl)
+    lenc, loff, lln = refio.pack_reads(synth.make_reads_long(48, ctg, 48, mean_len=5000, max_len=20000))
+    ix = oracle.Index(fl)
+    try:
+        exp_long = ix.run(lenc, loff, lln, oracle.default_opt(**ONT2D))
+    finally:
+        ix.close()
+    return (fa, enc, off, ln, exp_short), (fl, lenc, loff, lln, exp_long)
+
+
+@pytest.mark.parametrize("env", KNOB_SETTINGS, ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
+def test_off_by_default_knobs_keep_every_result(gpu_ctx_factory, knob_cases, monkeypatch, env):
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    (fa, enc, off, ln, exp), (fl, lenc, loff, lln, lexp) = knob_cases
+    ctx = gpu_ctx_factory(fa)
+    for rep in range(2):                                     # (twice: the second batch runs with the first one's launch statistics)
+        regs, reg_off, st = ctx.seed_chain_extend(enc, off, ln, bm2.default_opt())
+        _same(exp["REGPRG"], regs_to_records(regs, reg_off), "REGPRG (short reads, batch %d)" % rep)
+        assert st["n_ext"] == exp["counters"]["n_ext"]
+    sc = ctx.batch_fetch("seed_counters", np.uint64)
+    if "BM2_BWD_EXPORT_AGE" in env:
+        assert int(sc[21]) > 0 and int(sc[22]) > 0, "no backward task was handed over (%s)" % sc
+    ctx = gpu_ctx_factory(fl)
+    regs, reg_off, st = ctx.seed_chain_extend(lenc, loff, lln, bm2.default_opt(**ONT2D))
+    _same(lexp["REGPRG"], regs_to_records(regs, reg_off), "REGPRG (long reads)")
+    assert st["n_ext"] == lexp["counters"]["n_ext"]
+
+
 def test_seeding_workspace_growth(gpu_ctx_factory, tmp_path, monkeypatch):
     # start from workspaces that hold nothing but the pool tails: the run must report what it needs, grow, and repeat
     fa, (enc, off, ln) = _fresh_case(tmp_path, 31, [200000, 80000], 40000, 150)

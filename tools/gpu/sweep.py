@@ -21,6 +21,11 @@ sys.path.insert(0, os.path.join(ROOT, "bwa-mem2_amd"))
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 GRID = [   # (name, candidates): a candidate is a dict of knobs set together; the first one ({} = the library's defaults) is the incumbent
+    ("seeding: k_bwd hands old tasks over to the wavefront kernel", [{}, {"BM2_BWD_EXPORT_AGE": 512}, {"BM2_BWD_EXPORT_AGE": 384}, {"BM2_BWD_EXPORT_AGE": 256},
+                                                                      {"BM2_BWD_EXPORT_AGE": 192}, {"BM2_BWD_EXPORT_AGE": 128}, {"BM2_BWD_EXPORT_AGE": 96}]),
+    ("seeding: the long lists' kernel after k_bwd", [{}, {"BM2_BWD_HEAVY_AFTER": 1}]),
+    ("seeding: pass 3 workgroups per CU", [{}, {"BM2_P3_BPC": 2}, {"BM2_P3_BPC": 1}, {"BM2_P3_BPC": 2, "BM2_P3_AT": 2}]),
+    ("chain clock", [{}, {"BM2_CHAIN_CLOCK": 1}]),
     ("chain staging", [{}, {"BM2_CHAIN_STAGE": 1}]),
     ("chain heavy threshold", [{}, {"BM2_HEAVY_SA": 64}, {"BM2_HEAVY_SA": 40}, {"BM2_HEAVY_SA": 24}, {"BM2_HEAVY_SA": 160}, {"BM2_HEAVY_SA": 256}, {"BM2_HEAVY_SA": 512}]),
     ("chain: seed-rich reads to the island kernel", [{}, {"BM2_CHAIN_TIER_MAX": 512}, {"BM2_CHAIN_TIER_MAX": 256}, {"BM2_CHAIN_TIER_MAX": 128}, {"BM2_CHAIN_TIER_MAX": 256, "BM2_HEAVY_SA": 160}]),
@@ -95,6 +100,8 @@ def main():
             ctx.batch_run(opt)
             for name, ms in ctx.batch_kernel_ms():
                 kms[name.split(".")[0]] = kms.get(name.split(".")[0], 0.0) + ms / a.steps
+                if "." in name:
+                    kms[name] = kms.get(name, 0.0) + ms / a.steps
         ms = (time.perf_counter() - t0) / a.steps * 1e3
         regs, reg_off = ctx.batch_download()
         crc = zlib.crc32(reg_off.tobytes(), zlib.crc32(regs.tobytes()))
