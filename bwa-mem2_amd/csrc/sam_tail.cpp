@@ -1045,31 +1045,36 @@ KswResult rescue_align(const bm2_opt *opt, const Ref &R, int l_ms, const uint8_t
     return ksw_align2(l_ms, q.data(), (int)(re - rb), R.ref_string + rb, opt->mat, opt->o_del, opt->e_del, opt->o_ins, opt->e_ins, rescue_xtra(opt, l_ms));
 }
 
+// A rescued alignment becomes a hit of the mate (mem_matesw, bwamem_pair.cpp:205-222): the aligner saw the mate as direction r reads it and
+// the window [rb, ...) of the doubled reference, so both spans are mirrored back when that view was the reverse strand's.
+struct Span { int64_t b, e; };
+static inline Span mirrored(Span s, int64_t len, bool flip) { return flip ? Span{ len - s.e, len - s.b } : s; }
 void rescue_apply(const bm2_opt *opt, const Ref &R, const bm2_alnreg_t *a, int l_ms, int r, int64_t rb, const KswResult &aln,
                   HitList &ma) {
-    const int64_t l_pac = R.l_pac;
-    const int is_rev = (r >> 1 != (r & 1));
     if (aln.score < opt->min_seed_len || aln.qb < 0) return;
+    const bool flip = (r >> 1) != (r & 1);
+    const Span on_read = mirrored(Span{ aln.qb, (int64_t)aln.qe + 1 }, l_ms, flip);
+    const Span on_ref = mirrored(Span{ rb + aln.tb, rb + aln.te + 1 }, R.l_pac << 1, flip);
     bm2_alnreg_t b; memset(&b, 0, sizeof b);
     b.rid = a->rid; b.is_alt = a->is_alt;
-    b.qb = is_rev ? l_ms - (aln.qe + 1) : aln.qb;
-    b.qe = is_rev ? l_ms - aln.qb : aln.qe + 1;
-    b.rb = is_rev ? (l_pac << 1) - (rb + aln.te + 1) : rb + aln.tb;
-    b.re = is_rev ? (l_pac << 1) - (rb + aln.tb) : rb + aln.te + 1;
+    b.qb = (int)on_read.b; b.qe = (int)on_read.e; b.rb = on_ref.b; b.re = on_ref.e;
     b.score = aln.score; b.csub = aln.score2; b.secondary = -1;
-    b.seedcov = (int)((b.re - b.rb < b.qe - b.qb ? b.re - b.rb : b.qe - b.qb) >> 1);
-    size_t i;
-    for (i = 0; i < ma.size(); ++i) if (ma[i].score < b.score) break;                  // keep ma sorted by score
-    ma.insert_at(i, b);
+    b.seedcov = (int)(std::min<int64_t>(on_ref.e - on_ref.b, on_read.e - on_read.b) >> 1);
+    size_t at = 0;                                               // in front of the first hit that scores less
+    while (at < ma.size() && !(ma[at].score < b.score)) ++at;
+    ma.insert_at(at, b);
 }
 
+// Which of the four directions of an anchor need no rescue: those whose insert-size model failed, and those in which the mate already has
+// a hit at a plausible distance (bwamem_pair.cpp:165-174)
 void rescue_skip(const Ref &R, const PeStat pes[4], const bm2_alnreg_t *a, const HitList &ma, int skip[4]) {
-    for (int r = 0; r < 4; ++r) skip[r] = pes[r].failed ? 1 : 0;
-    for (size_t i = 0; i < ma.size(); ++i) {                     // a direction that already has a hit at a plausible distance needs no rescue
+    unsigned served = 0;
+    for (size_t i = 0; i < ma.size(); ++i) {
         int64_t dist;
         const int r = infer_dir(R.l_pac, a->rb, ma[i].rb, &dist);
-        if (dist >= pes[r].low && dist <= pes[r].high) skip[r] = 1;
+        served |= (unsigned)(dist >= pes[r].low && dist <= pes[r].high) << r;
     }
+    for (int r = 0; r < 4; ++r) skip[r] = pes[r].failed || (served >> r & 1) ? 1 : 0;
 }
 
 // pre[0, n_pre): the alignments planned for this anchor (end, j) and already computed, or none (then they are computed here)
@@ -1169,61 +1174,83 @@ void rescue_plan(const bm2_opt *opt, const bm2_sam_opt *so, const Ref &R, const 
     }
 }
 
-// mem_pair, bwamem_pair.cpp:285-346
-struct P64 { uint64_t x, y; };
+// The best pairing of the two reads' primary hits: what mem_pair (bwamem_pair.cpp:285-346) answers, computed this file's way.
+// A pairing is a hit k of one read and a hit i of the other whose forward-strand coordinates on one contig lie `dist` apart with k first,
+// low <= dist <= high of the orientation (strand of k, strand of i) in the chunk's insert-size model; it scores
+// score_k + score_i + 0.721 ln(2 erfc(|dist - avg| / std / sqrt 2)) * a (rounded, floored at 0).  The answer is the best pairing, the score
+// of the runner-up and how many others come within one mismatch / gap of that.
+// Form: the ends are ranked in reference order once; each (strand, read) class keeps its ends in that order, so the partners of an end are a
+// WINDOW of the class of the other read on each strand, and as the ends of a class are visited in order the window only moves forward (two
+// cursors per class and partner strand) -- no back-scan over the mixed list, no second sort: the best and the runner-up are picked in one
+// pass over the pairings' scores.  What the output can see of the reference's procedure is kept to the letter: the rank of an end in the
+// order (position, score, index in its read's list, strand, read) -- the tie-breaking hash of a pairing is taken of the two ranks and the
+// pair's number --, the floating-point expression of the score, and the order (score, hash, ranks) among pairings.
+struct PairEnd { uint64_t pos; int32_t score, idx; uint8_t strand, read; };
 int pair_hits(const bm2_opt *opt, const Ref &R, const PeStat pes[4], const HitList a[2], int id, int *sub, int *n_sub,
               int z[2], const int n_pri[2]) {
-    auto lt = [](const P64 &p, const P64 &q) { return p.x < q.x || (p.x == q.x && p.y < q.y); };
-    AVec<P64> v, u;                                              // (in the thread's scratch arena: the caller resets it per pair)
+    AVec<PairEnd> ends;                                          // (in the thread's scratch arena: the caller resets it per pair)
     const int64_t l_pac = R.l_pac;
-    for (int r = 0; r < 2; ++r)
-        for (int i = 0; i < n_pri[r]; ++i) {
-            const bm2_alnreg_t *e = &a[r][i];
-            P64 key;
-            key.x = (uint64_t)(e->rb < l_pac ? e->rb : (l_pac << 1) - 1 - e->rb);
-            key.x = (uint64_t)e->rid << 32 | (key.x - (uint64_t)R.off[e->rid]);
-            key.y = (uint64_t)e->score << 32 | (uint64_t)(int64_t)(i << 2 | (e->rb >= l_pac) << 1 | r);
-            v.push_back(key);
+    ends.reserve(n_pri[0] + n_pri[1]);
+    for (int rd = 0; rd < 2; ++rd)
+        for (int i = 0; i < n_pri[rd]; ++i) {
+            const bm2_alnreg_t &h = a[rd][i];
+            PairEnd e;
+            e.strand = h.rb >= l_pac; e.read = (uint8_t)rd; e.idx = i; e.score = h.score;
+            const uint64_t fwd = (uint64_t)(e.strand ? (l_pac << 1) - 1 - h.rb : h.rb);
+            e.pos = (uint64_t)h.rid << 32 | (fwd - (uint64_t)R.off[h.rid]);          // contig in the high word: ends of two contigs are never `high` apart
+            ends.push_back(e);
         }
-    std::sort(v.p, v.p + v.n, lt);
-    int y[4] = { -1, -1, -1, -1 };
-    for (int i = 0; i < (int)v.size(); ++i) {
-        for (int r = 0; r < 2; ++r) {
-            const int dir = r << 1 | (int)(v[i].y >> 1 & 1);
-            if (pes[dir].failed) continue;
-            const int which = r << 1 | (int)((v[i].y & 1) ^ 1);
-            if (y[which] < 0) continue;
-            for (int k = y[which]; k >= 0; --k) {
-                if ((int)(v[k].y & 3) != which) continue;
-                const int64_t dist = (int64_t)v[i].x - (int64_t)v[k].x;
-                if (dist > pes[dir].high) break;
-                if (dist < pes[dir].low) continue;
-                const double ns = (dist - pes[dir].avg) / pes[dir].std;
-                int q = (int)((v[i].y >> 32) + (v[k].y >> 32) + .721 * log(2. * erfc(fabs(ns) * M_SQRT1_2)) * opt->a + .499);
-                if (q < 0) q = 0;
-                P64 p;
-                p.y = (uint64_t)k << 32 | (uint64_t)i;
-                p.x = (uint64_t)q << 32 | (hash_64(p.y ^ (uint64_t)(int64_t)(id << 8)) & 0xffffffffU);
-                u.push_back(p);
+    std::sort(ends.p, ends.p + ends.n, [](const PairEnd &p, const PairEnd &q) {
+        if (p.pos != q.pos) return p.pos < q.pos;
+        if (p.score != q.score) return (uint32_t)p.score < (uint32_t)q.score;
+        if (p.idx != q.idx) return p.idx < q.idx;
+        if (p.strand != q.strand) return p.strand < q.strand;
+        return p.read < q.read;
+    });
+    AVec<int> cls[4];                                            // ranks of the ends of class strand << 1 | read, ascending
+    for (int k = 0; k < ends.n; ++k) cls[ends[k].strand << 1 | ends[k].read].push_back(k);
+    int gap = opt->a + opt->b;                                   // "within one mismatch or gap" of the runner-up
+    if (gap < opt->o_del + opt->e_del) gap = opt->o_del + opt->e_del;
+    if (gap < opt->o_ins + opt->e_ins) gap = opt->o_ins + opt->e_ins;
+    AVec<int> scores;                                            // one per pairing
+    uint64_t best_key = 0, best_ranks = 0; int best_at = -1;
+    for (int c = 0; c < 4; ++c) {                                // the later end i of a pairing, class by class
+        const int strand_i = c >> 1, read_i = c & 1;
+        for (int r = 0; r < 2; ++r) {                            // its partner's strand
+            const PeStat &m = pes[r << 1 | strand_i];
+            if (m.failed) continue;
+            const AVec<int> &part = cls[r << 1 | (read_i ^ 1)];
+            int lo = 0, hi = 0;                                  // partners [lo, hi): high >= pos_i - pos_k >= low
+            for (int t = 0; t < cls[c].n; ++t) {
+                const int i = cls[c][t];
+                const uint64_t pi = ends[i].pos;
+                while (hi < part.n && part[hi] < i && (int64_t)(pi - ends[part[hi]].pos) >= (int64_t)m.low) ++hi;      // (an earlier rank: its position is not beyond pi)
+                while (lo < hi && (int64_t)(pi - ends[part[lo]].pos) > (int64_t)m.high) ++lo;
+                for (int w = lo; w < hi; ++w) {
+                    const int k = part[w];
+                    const int64_t dist = (int64_t)(pi - ends[k].pos);
+                    const double ns = (dist - m.avg) / m.std;
+                    int q = (int)((uint64_t)(uint32_t)ends[i].score + (uint64_t)(uint32_t)ends[k].score + .721 * log(2. * erfc(fabs(ns) * M_SQRT1_2)) * opt->a + .499);
+                    if (q < 0) q = 0;
+                    const uint64_t ranks = (uint64_t)k << 32 | (uint64_t)i;
+                    const uint64_t key = (uint64_t)q << 32 | (hash_64(ranks ^ (uint64_t)(int64_t)(id << 8)) & 0xffffffffU);
+                    if (best_at < 0 || key > best_key || (key == best_key && ranks > best_ranks)) { best_key = key; best_ranks = ranks; best_at = scores.n; }
+                    scores.push_back(q);
+                }
             }
         }
-        y[v[i].y & 3] = i;
     }
-    int ret;
-    if (!u.empty()) {
-        int tmp = opt->a + opt->b;
-        tmp = tmp > opt->o_del + opt->e_del ? tmp : opt->o_del + opt->e_del;
-        tmp = tmp > opt->o_ins + opt->e_ins ? tmp : opt->o_ins + opt->e_ins;
-        std::sort(u.p, u.p + u.n, lt);
-        const int i = (int)(u.back().y >> 32), k = (int)(u.back().y << 32 >> 32);
-        z[v[i].y & 1] = (int)(v[i].y << 32 >> 34);
-        z[v[k].y & 1] = (int)(v[k].y << 32 >> 34);
-        ret = (int)(u.back().x >> 32);
-        *sub = u.size() > 1 ? (int)(u[u.size() - 2].x >> 32) : 0;
-        *n_sub = 0;
-        for (int t = u.size() - 2; t >= 0; --t) if (*sub - (int)(u[t].x >> 32) <= tmp) ++*n_sub;
-    } else { ret = 0; *sub = 0; *n_sub = 0; }
-    return ret;
+    *sub = 0; *n_sub = 0;
+    if (best_at < 0) return 0;
+    const PairEnd &ek = ends[(int)(best_ranks >> 32)], &ei = ends[(int)(best_ranks & 0xffffffffU)];
+    z[ei.read] = ei.idx; z[ek.read] = ek.idx;
+    if (scores.n > 1) {
+        int second = -1;
+        for (int t = 0; t < scores.n; ++t) if (t != best_at && scores[t] > second) second = scores[t];
+        *sub = second;
+        for (int t = 0; t < scores.n; ++t) if (t != best_at && second - scores[t] <= gap) ++*n_sub;
+    }
+    return (int)(best_key >> 32);
 }
 
 int raw_mapq(int diff, int a) { return (int)(6.02 * diff / a + .499); }
