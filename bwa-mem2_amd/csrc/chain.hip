@@ -413,10 +413,10 @@ static __device__ __forceinline__ int flt_ovlp(const ChainParams &o, const WChai
     }
     return 0;
 }
-static __device__ __forceinline__ void flt_sync() {              // lanes of one wavefront handing LDS or GLOBAL data to each other
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+static __device__ __forceinline__ void flt_sync() {              // lanes of ONE wavefront handing LDS or global data to each other: wavefront scope (the lanes share
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       //  the CU's L1; agent scope -- an L2 write-back and an L1 invalidate per call -- made the heavy tiers take
+    __builtin_amdgcn_wave_barrier();                             //  26 ms instead of 11, profiles/r05a_sweep.json)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 // The same walk by the 64 lanes of a (converged) wavefront: chain i meets 64 kept chains at a time, one per lane.  The serial walk stops at
 // the FIRST kept chain that drops i, and every kept chain up to and including that one which overlaps i largely gets `first` (if it has none):

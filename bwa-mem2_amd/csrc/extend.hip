@@ -1053,6 +1053,7 @@ static int ring_size2(int w) { int R = 64; while (R < 2 * w + 4) R <<= 1; return
 
 #define LAZY_ROUNDS 6
 #define EXT_EAGER_PHASE (BM2_EXT_PHASES - 1)      // the eager remainder's row of the per-phase statistics
+#define BSW_STAT_ROW (BM2_EXT_PHASES - 2)         // the row of bm2_ctx::ext_stat the S1 batches keep their class counts in (no lazy round ever has it: n_lazy <= BSW_STAT_ROW)
 
 struct ExtLaunch {
     bm2_ctx *c; hipStream_t s; ExtParams xp; const uint8_t *enc; const int64_t *off; const int32_t *len; const int64_t *slot_base;
@@ -1061,7 +1062,7 @@ struct ExtLaunch {
     // launch policy (bm2_knob): which kernel takes a query-length class.  A lane-per-seed wavefront of long queries walks tens of thousands
     // of cells one after the other (milliseconds) and a phase lasts as long as its slowest wavefront, so the classes from wave_qmin up can go
     // one seed per WAVEFRONT (k_ext_wave) beside the lane kernels.
-    int wave_qmin, wave_budget, prefetch, rev, perm_scores, qmap, group4;
+    int wave_qmin, prefetch, rev, perm_scores, qmap, group4;
     // the sorted seed list of the phase and where it lives
     const int32_t *tasks; const int64_t *start;
 };
@@ -1077,22 +1078,19 @@ static int run_phase(const ExtLaunch &L, const uint32_t *hint, int64_t ub) {
     // the classes from k_wave up (long queries) and the fallback bins are adjacent in the list: one wavefront-per-seed launch
     int k_wave = N_CLS;
     while (k_wave > 0 && (k_wave >= 2 ? cls_hi[k_wave - 2] : 0) + 1 >= L.wave_qmin) k_wave--;
-    // BM2_EXT_WAVE_BUDGET = B > 0 (launch policy, off by default; not yet measured): the bound moves PER PHASE with the previous batch's class
-    // counts -- the wavefront kernel takes the longest classes as long as they hold at most B seeds together (never a class below 49 bases).
-    // A long class with few seeds is a handful of lane tiles, each as long as its slowest lane's two sides -- milliseconds on a mostly idle
-    // GPU --, where the wavefront kernel spends ~30 us of one wavefront per seed; with many seeds it is the other way round (section 6 of DESIGN.md).
-    if (hint && L.wave_budget > 0) {
-        int64_t acc = hint[N_CLS];                                  // (the fallback bins are the wavefront kernel's in any case)
-        int k = N_CLS;
-        while (k > 3 && acc + (int64_t)hint[k - 1] <= (int64_t)L.wave_budget) { acc += hint[k - 1]; k--; }
-        k_wave = k;
-    }
+    // (BM2_EXT_WAVE_BUDGET -- the bound moved per phase by the previous batch's class counts -- was measured in round 5 and bought nothing:
+    //  16.3-16.4 ms against 16.1 at 30 000 / 60 000 seeds, 21-24 ms beyond, profiles/r05a_sweep.json; removed)
     auto grid_for = [&](int k_lo, int k_hi, int per_block) -> unsigned {
         int64_t n = 0;
         if (hint) { for (int k = k_lo; k < k_hi; k++) n += hint[k]; n += n / 4 + 64; }
         else n = ub;
         if (n > ub) n = ub;
         int64_t g = (n + per_block - 1) / per_block;
+        // a floor: the hint is the PREVIOUS batch's count, and a class that was empty then (another read length after a file boundary, trimmed
+        // reads) would get one workgroup to stride through whatever the class holds now -- the phase's critical path.  A workgroup that finds
+        // no tile leaves after two loads.
+        const int64_t floor_g = per_block == 64 ? c->n_cu : c->n_cu / 4, ub_g = (ub + per_block - 1) / per_block;
+        if (g < floor_g) g = floor_g < ub_g ? floor_g : ub_g;
         if (g < 1) g = 1;
         if (g > (1 << 16)) g = 1 << 16;                 // (the kernels stride)
         return (unsigned)g;
@@ -1171,7 +1169,6 @@ int bm2_launch_extend(bm2_ctx *c, const bm2_opt &opt, const ChainParams &cp, int
     // (113 until the launches of a phase really ran beside each other, see run_phase: the wavefront kernel then took 200 000 seeds of the second
     //  round -- short seeds at a read's end, the whole rest of the read to extend -- and was the last launch of its phase to end by 2 ms;
     //  profiles/r04q_sweep.json: extension 20.1 ms at 113, 16.0 ms at 129 / 145 / 161, 25.0 ms at 97)
-    L.wave_budget = bm2_knob("BM2_EXT_WAVE_BUDGET", 0);
     L.prefetch = bm2_knob("BM2_EXT_PREFETCH", 1);
     L.rev = bm2_knob("BM2_EXT_REVERSE", 1);
     L.qmap = bm2_knob("BM2_EXT_QUEUE_MAP", 1);
@@ -1199,7 +1196,7 @@ int bm2_launch_extend(bm2_ctx *c, const bm2_opt &opt, const ChainParams &cp, int
         }
     }
     if (n_lazy > lazy_max) n_lazy = lazy_max;
-    if (n_lazy > EXT_EAGER_PHASE) n_lazy = EXT_EAGER_PHASE;
+    if (n_lazy > BSW_STAT_ROW) n_lazy = BSW_STAT_ROW;              // (rows [0, BSW_STAT_ROW) are the lazy rounds')
     // scratch: ebin[n_items] | hist[N_EBINS] | pend[PHASES] | stat[PHASES][STATW] | start[N_EBINS + 1] | cur_slot[n_reads] | tasks[n_items] | kept[n_slots] | n_kept[n_reads]
     const size_t n_items = (size_t)(n_slots > n_reads ? n_slots : n_reads);
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
@@ -1237,7 +1234,12 @@ int bm2_launch_extend(bm2_ctx *c, const bm2_opt &opt, const ChainParams &cp, int
         hipLaunchKernelGGL(k_seedcov, dim3(nb), dim3(256), 0, s, n_slots, slot_base, reg_seed, reg_chain, chn, seeds, regs, cursor);
     }
     if (c->ext_stat) {      // (arrives before the caller's end-of-batch synchronisation; read by the next batch)
-        if ((rc = bm2_check(hipMemcpyAsync(c->ext_stat, stat, sizeof hint, hipMemcpyDeviceToHost, s), "D2H extension statistics"))) return rc;
+        // only the rows this stage wrote -- the lazy rounds and the eager phase: the row between them belongs to the S1 batches (BSW_STAT_ROW),
+        // whose class counts a copy of the whole table would overwrite with zeros
+        const size_t row = sizeof(uint32_t) * BM2_EXT_STATW;
+        if ((rc = bm2_check(hipMemcpyAsync(c->ext_stat, stat, row * (size_t)n_lazy, hipMemcpyDeviceToHost, s), "D2H extension statistics"))) return rc;
+        if ((rc = bm2_check(hipMemcpyAsync((char *)c->ext_stat + row * EXT_EAGER_PHASE, (const char *)stat + row * EXT_EAGER_PHASE, row, hipMemcpyDeviceToHost, s),
+                            "D2H extension statistics (eager phase)"))) return rc;
         c->ext_stat_reads = n_reads; c->ext_stat_rounds = n_lazy;
     }
     return bm2_check(hipGetLastError(), "extension launches");
@@ -1247,7 +1249,6 @@ int bm2_launch_extend(bm2_ctx *c, const bm2_opt &opt, const ChainParams &cp, int
 // SIMD lane -- and so is this: the pairs of a batch whose query fits the lane kernel's LDS rows and whose scores fit its 8-bit cells are
 // counting-sorted on the device by (query length, target length / 4) and run one per lane through the same row code as the pipeline's
 // extension stage (lane_dp8g); the others -- long queries, int16 / int32-class scores -- stay on the pair-per-wavefront kernel (bsw.hip).
-#define BSW_STAT_ROW (BM2_EXT_PHASES - 2)       // the row of bm2_ctx::ext_stat the S1 batches keep their class counts in (no lazy round ever has it)
 __global__ void __launch_bounds__(256)
 k_bsw_bin(const bm2_seqpair_t *__restrict__ pairs, int n, int a_match, int lanes_ok, uint32_t *ebin, int32_t *hist) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

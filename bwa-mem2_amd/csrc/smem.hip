@@ -91,6 +91,16 @@ static __device__ __forceinline__ void coop_rank(int64_t k, int64_t s, int a, in
     const uint32_t hw = qsum32(is_at ? (uint32_t)(o1 >> 32) | (uint32_t)(d >> 32) << 8 : above ? (uint32_t)(d >> 31) << 16 : 0u);
     if (sub == T) { out.xl = xl; out.yl = yl; out.zl = zl; out.hw = hw; }
 }
+static __device__ __forceinline__ Bi ext_result(const DevIndex &ix, const Bi &in, int64_t k, int64_t s, int a, const QuadOut &q) {
+    const int64_t X = (int64_t)q.xl | (int64_t)(q.hw & 0xffu) << 32, Y = (int64_t)q.yl | (int64_t)((q.hw >> 8) & 0xffu) << 32;
+    const int64_t Z = (int64_t)q.zl + ((int64_t)(q.hw >> 16) << 31);
+    const int64_t sent = (k <= ix.sentinel_index && k + s > ix.sentinel_index) ? 1 : 0;
+    Bi out;
+    out.k = pick4(a, ix.count[0], ix.count[1], ix.count[2], ix.count[3]) + X;
+    out.l = in.l + sent + Z;
+    out.s = Y;
+    return out;
+}
 static __device__ __forceinline__ Bi backward_ext(const DevIndex &ix, Bi in, int a, bool want) {
     const int sub = (int)(threadIdx.x & 3);
     const int64_t k = want ? in.k : 0, s = want ? in.s : 0;
@@ -101,14 +111,26 @@ static __device__ __forceinline__ Bi backward_ext(const DevIndex &ix, Bi in, int
     QuadOut q = { 0, 0, 0, 0 };
     coop_rank<0>(k, s, a, sub, e1[0], e2[0], q); coop_rank<1>(k, s, a, sub, e1[1], e2[1], q);
     coop_rank<2>(k, s, a, sub, e1[2], e2[2], q); coop_rank<3>(k, s, a, sub, e1[3], e2[3], q);
-    const int64_t X = (int64_t)q.xl | (int64_t)(q.hw & 0xffu) << 32, Y = (int64_t)q.yl | (int64_t)((q.hw >> 8) & 0xffu) << 32;
-    const int64_t Z = (int64_t)q.zl + ((int64_t)(q.hw >> 16) << 31);
-    const int64_t sent = (k <= ix.sentinel_index && k + s > ix.sentinel_index) ? 1 : 0;
-    Bi out;
-    out.k = pick4(a, ix.count[0], ix.count[1], ix.count[2], ix.count[3]) + X;
-    out.l = in.l + sent + Z;
-    out.s = Y;
-    return out;
+    return ext_result(ix, in, k, s, a, q);
+}
+// Two intervals of one lane extended by the same base in one round (k_bwd with two candidates of a row per round): all sixteen requests of
+// the quad are issued before the first rank waits, so a wavefront has up to 256 lines in flight instead of 128.
+static __device__ __forceinline__ void backward_ext2(const DevIndex &ix, Bi inA, Bi inB, int a, bool wantA, bool wantB, Bi &outA, Bi &outB) {
+    const int sub = (int)(threadIdx.x & 3);
+    const int64_t kA = wantA ? inA.k : 0, sA = wantA ? inA.s : 0, kB = wantB ? inB.k : 0, sB = wantB ? inB.s : 0;
+    ulonglong2 a1[4], a2[4], b1[4], b2[4];
+    const int wA = wantA ? 1 : 0, wB = wantB ? 1 : 0;
+    coop_issue<0>(ix, kA, sA, wA, sub, a1[0], a2[0]); coop_issue<1>(ix, kA, sA, wA, sub, a1[1], a2[1]);
+    coop_issue<2>(ix, kA, sA, wA, sub, a1[2], a2[2]); coop_issue<3>(ix, kA, sA, wA, sub, a1[3], a2[3]);
+    coop_issue<0>(ix, kB, sB, wB, sub, b1[0], b2[0]); coop_issue<1>(ix, kB, sB, wB, sub, b1[1], b2[1]);
+    coop_issue<2>(ix, kB, sB, wB, sub, b1[2], b2[2]); coop_issue<3>(ix, kB, sB, wB, sub, b1[3], b2[3]);
+    QuadOut qa = { 0, 0, 0, 0 }, qb = { 0, 0, 0, 0 };
+    coop_rank<0>(kA, sA, a, sub, a1[0], a2[0], qa); coop_rank<1>(kA, sA, a, sub, a1[1], a2[1], qa);
+    coop_rank<2>(kA, sA, a, sub, a1[2], a2[2], qa); coop_rank<3>(kA, sA, a, sub, a1[3], a2[3], qa);
+    coop_rank<0>(kB, sB, a, sub, b1[0], b2[0], qb); coop_rank<1>(kB, sB, a, sub, b1[1], b2[1], qb);
+    coop_rank<2>(kB, sB, a, sub, b1[2], b2[2], qb); coop_rank<3>(kB, sB, a, sub, b1[3], b2[3], qb);
+    outA = ext_result(ix, inA, kA, sA, a, qa);
+    outB = ext_result(ix, inB, kB, sB, a, qb);
 }
 
 static __device__ __forceinline__ Bi init_bi(const DevIndex &ix, int a) {     // FMI_search.cpp:531-533
@@ -186,6 +208,7 @@ static __device__ __forceinline__ int64_t wave_alloc(LdsPool *wp, unsigned long 
 #define HCAP 256                  // ... if the list fits its LDS row (else they stay lane-per-task)
 #define HEAVY_BATCH 64
 #define BWD_EXPORT_AGE 0              // (default of BM2_BWD_EXPORT_AGE)
+#define BWD_ILP 1                     // (default of BM2_BWD_ILP)
 #define ITEM_BATCH 64
 #define SLOT_BATCH 256
 #define REC_BATCH 256
@@ -385,7 +408,9 @@ k_walk(DevIndex ix, SeedParams sp, int n_reads, const uint8_t *__restrict__ enc,
 enum { B_EXT = 0, B_NEWITEM, B_FIRST, B_ROWEND, B_ROW, B_FIN, B_DONE };
 
 // LC: survivors of a row kept in LDS per lane (16 B x LC x 256 lanes per block decides how many blocks share a CU's 160 KB)
-template <int LC>
+// ILP: candidates of a row a lane extends per round (2: the candidates of a row do not depend on each other -- FMI_search.cpp:607-649 only filters
+// them in order -- so the lane issues the requests of candidates p and p + 1 together and judges the two results one after the other)
+template <int LC, int ILP>
 static __device__ __forceinline__ void
 bwd_body(const DevIndex &ix, const SeedParams &sp, int pass, const uint8_t *__restrict__ enc, BHead *heads,
          uint4 *__restrict__ ents, int64_t slot_cap, uint4 *__restrict__ pool, int pool_cap, int pool_slots,
@@ -416,7 +441,8 @@ bwd_body(const DevIndex &ix, const SeedParams &sp, int pass, const uint8_t *__re
     int64_t ck = 0, cl = 0, cs = 0; int cn = 0;                // the candidate being extended
     int64_t fk = 0, fl = 0, fs = 0; int fn = 0;                // first survivor of the current row
     uint4 nxt_raw4 = {};                                       // the candidate after the current one, requested one round ahead
-    int em = 0;                                                // an SMEM to write out: 1 = the candidate, 2 = the first survivor
+    int64_t dk = 0, dl = 0, ds = 0; int dn = 0; bool have_b = false; uint4 nxt_rawb = {};     // ILP 2: the second candidate of the round, and the one after next
+    int em = 0;                                                // an SMEM to write out: 1 = the candidate, 2 = the first survivor, 3 = the round's second candidate
     QWin w; w.cur = w.nxt = 0; w.curb = w.nxtb = -64;
     auto entry = [&](int idx) -> uint4 * { return idx < CAPF ? lst + idx : lpool + (idx - CAPF); };
     // survivors at depth 1..LC below the top of the list live in LDS ([depth][lane]); deeper ones go back to the slot
@@ -489,7 +515,19 @@ bwd_body(const DevIndex &ix, const SeedParams &sp, int pass, const uint8_t *__re
                 else {
                     n_curr = 0; curr_s = -1; p = 0; first_done = false;
                     ck = fk; cl = fl; cs = fs; cn = fn;
-                    if (n_prev > 1) nxt_raw4 = cand_load(1);
+                    if constexpr (ILP == 2) {
+                        have_b = false;
+                        if (n_prev > 1) {
+                            if (!row0) {                        // the previous row's survivors are in LDS: the second candidate is at hand
+                                pv_unpack(cand_load(1), dk, dl, ds, dn); have_b = true;
+                                if (n_prev > 2) nxt_raw4 = cand_load(2);
+                                if (n_prev > 3) nxt_rawb = cand_load(3);
+                            } else {                            // the walk's list is in global memory: the row's first round takes one candidate
+                                nxt_raw4 = cand_load(1);
+                                if (n_prev > 2) nxt_rawb = cand_load(2);
+                            }
+                        }
+                    } else if (n_prev > 1) nxt_raw4 = cand_load(1);
                     state = B_EXT;
                 }
             }
@@ -505,24 +543,31 @@ bwd_body(const DevIndex &ix, const SeedParams &sp, int pass, const uint8_t *__re
         if (state == B_EXT) prof_active++;
 #endif
         const Bi ein = { ck, cl, cs };
-        const Bi o = backward_ext(ix, ein, a, state == B_EXT);    // (all lanes: quad-cooperative)
-        if (state == B_EXT) {                                   // :607-649
+        Bi o, ob = { 0, 0, 0 };
+        if constexpr (ILP == 2) { const Bi einb = { dk, dl, ds }; backward_ext2(ix, ein, einb, a, state == B_EXT, state == B_EXT && have_b, o, ob); }
+        else o = backward_ext(ix, ein, a, state == B_EXT);        // (all lanes: quad-cooperative)
+        auto judge = [&](const Bi &o_, int cn_, int em_code) {   // :607-649 for one candidate
             n_ext++; age++;
-            if (!first_done && o.s < (int64_t)min_intv && (cn - m_row + 1) >= sp.min_seed_len) {
-                em = 1;
+            if (!first_done && o_.s < (int64_t)min_intv && (cn_ - m_row + 1) >= sp.min_seed_len) {
+                em = em_code;
                 first_done = true;
-            } else if (o.s >= (int64_t)min_intv && o.s != (int64_t)curr_s) {
-                curr_s = (int32_t)o.s;
-                if (n_curr == 0) { fk = o.k; fl = o.l; fs = o.s; fn = cn; }
-                else if (n_curr <= LC) surv[(n_curr - 1) * 256 + threadIdx.x] = pv_pack(o.k, o.l, o.s, cn);
-                else *entry(top - n_curr) = pv_pack(o.k, o.l, o.s, cn);
+            } else if (o_.s >= (int64_t)min_intv && o_.s != (int64_t)curr_s) {
+                curr_s = (int32_t)o_.s;
+                if (n_curr == 0) { fk = o_.k; fl = o_.l; fs = o_.s; fn = cn_; }
+                else if (n_curr <= LC) surv[(n_curr - 1) * 256 + threadIdx.x] = pv_pack(o_.k, o_.l, o_.s, cn_);
+                else *entry(top - n_curr) = pv_pack(o_.k, o_.l, o_.s, cn_);
                 n_curr++;
                 first_done = true;
             }
+        };
+        if (state == B_EXT) {
+            judge(o, cn, 1);
+            if constexpr (ILP == 2) if (have_b) judge(ob, dn, 3);
         }
         if (em) {                                               // one SMEM: record, per-read count, pass-2 task
-            const int64_t ek = em == 1 ? ck : fk, el = em == 1 ? cl : fl, es = em == 1 ? cs : fs;
-            const int en = em == 1 ? cn : fn;
+            int64_t ek = em == 1 ? ck : fk, el = em == 1 ? cl : fl, es = em == 1 ? cs : fs;
+            int en = em == 1 ? cn : fn;
+            if constexpr (ILP == 2) if (em == 3) { ek = dk; el = dl; es = ds; en = dn; }
             em = 0;
             const int64_t at = wave_alloc<REC_BATCH>(rp, sc + SC_REC);
             if (at < rec_cap) {
@@ -536,12 +581,23 @@ bwd_body(const DevIndex &ix, const SeedParams &sp, int pass, const uint8_t *__re
                 else ovf |= OVF_TASK;
             }
         }
-        if (state == B_EXT) {                                   // on to the next candidate of the row
-            p++;
-            if (p < n_prev) {
-                pv_unpack(nxt_raw4, ck, cl, cs, cn);
-                if (p + 1 < n_prev) nxt_raw4 = cand_load(p + 1);
-            } else state = B_ROWEND;
+        if (state == B_EXT) {                                   // on to the next candidate(s) of the row
+            if constexpr (ILP == 2) {
+                p += have_b ? 2 : 1;
+                if (p < n_prev) {
+                    pv_unpack(nxt_raw4, ck, cl, cs, cn);
+                    have_b = p + 1 < n_prev;
+                    if (have_b) pv_unpack(nxt_rawb, dk, dl, ds, dn);
+                    if (p + 2 < n_prev) nxt_raw4 = cand_load(p + 2);
+                    if (p + 3 < n_prev) nxt_rawb = cand_load(p + 3);
+                } else state = B_ROWEND;
+            } else {
+                p++;
+                if (p < n_prev) {
+                    pv_unpack(nxt_raw4, ck, cl, cs, cn);
+                    if (p + 1 < n_prev) nxt_raw4 = cand_load(p + 1);
+                } else state = B_ROWEND;
+            }
         }
     }
     for (int64_t at = rp->pos + (threadIdx.x & 63); at < rp->end; at += 64) if (at < rec_cap) recs[at].rid = 0xffffffffu;
@@ -560,9 +616,11 @@ bwd_body(const DevIndex &ix, const SeedParams &sp, int pass, const uint8_t *__re
                  P2Task *__restrict__ tasks, int64_t task_cap, int32_t *__restrict__ smem_cnt, unsigned long long *sc, \
                  int32_t *__restrict__ cont_ids, int64_t cont_cap, int export_age
 #define BWD_PASS ix, sp, pass, enc, heads, ents, slot_cap, pool, pool_cap, pool_slots, recs, rec_cap, tasks, task_cap, smem_cnt, sc, cont_ids, cont_cap, export_age
-template <int LC> __global__ void __launch_bounds__(256) k_bwd(BWD_ARGS) { bwd_body<LC>(BWD_PASS); }     // 111 VGPRs: 4 waves per SIMD
+template <int LC> __global__ void __launch_bounds__(256) k_bwd(BWD_ARGS) { bwd_body<LC, 1>(BWD_PASS); }     // 111 VGPRs: 4 waves per SIMD
 // the same with the register allocation told to leave room for 5 waves per SIMD (96 VGPRs, 100 bytes per lane spilled)
-template <int LC> __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) k_bwd5(BWD_ARGS) { bwd_body<LC>(BWD_PASS); }
+template <int LC> __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) k_bwd5(BWD_ARGS) { bwd_body<LC, 1>(BWD_PASS); }
+// two candidates of a row per round (BM2_BWD_ILP=2)
+template <int LC> __global__ void __launch_bounds__(256) k_bwd_ilp2(BWD_ARGS) { bwd_body<LC, 2>(BWD_PASS); }
 
 // lanes of one wavefront handing data to each other through LDS: order the accesses (the hardware runs them in lockstep)
 static __device__ __forceinline__ void wave_sync() {
@@ -994,6 +1052,7 @@ int bm2_launch_seeding(bm2_ctx *c, const SeedParams &sp, int n_reads, const uint
         const int lc = bm2_knob("BM2_BWD_LCAP", LCAP), wpe = bm2_knob("BM2_BWD_WAVES", 4);
         auto kb = wpe >= 5 ? (lc <= 4 ? k_bwd5<4> : k_bwd5<6>)
                            : (lc <= 4 ? k_bwd<4> : lc <= 6 ? k_bwd<6> : lc <= 8 ? k_bwd<8> : k_bwd<LCAP>);
+        if (bm2_knob("BM2_BWD_ILP", BWD_ILP) == 2) kb = lc <= 8 ? k_bwd_ilp2<8> : k_bwd_ilp2<LCAP>;
         int32_t *cont = pass == 1 ? sb.cont1 : sb.cont2;
         hipLaunchKernelGGL(kb, dim3(grid_bwd), dim3(256), 0, s, c->ix, sp, pass, enc, heads, ents, slot_cap, sb.pool, sb.pool_cap,
                            sb.pool_slots, sb.recs, sb.rec_cap, sb.tasks, sb.task_cap, smem_cnt, sc, cont, sb.cont_cap, export_age);
