@@ -37,7 +37,7 @@ struct SeedBufs {                                   // workspace of the seeding 
     bm2_smem_t *recs; int64_t rec_cap;
     P2Task *tasks; int64_t task_cap;
     int32_t *heavy1, *heavy2; int64_t heavy_cap;     // slot ids of the long-list tasks of pass 1 / pass 2
-    int32_t *cont1, *cont2; int64_t cont_cap;        // slot ids of the tasks k_bwd handed over at a row boundary (BM2_BWD_EXPORT_AGE)
+    void *cont1, *cont2; int64_t cont_cap;           // the tasks k_bwd handed over at a row boundary (CTask records, BM2_BWD_EXPORT_AGE)
 };
 enum { BM2_SC_SLOT1 = 1, BM2_SC_REC = 3, BM2_SC_TASK = 4, BM2_SC_SLOT2 = 6, BM2_SC_NEXT = 9, BM2_SC_OVF = 10, BM2_SC_POOL = 11,
        BM2_SC_NEXT_W1 = 12 /* then W2, W3, B1, B2 */ };   // = the SC_* of smem.hip
@@ -46,7 +46,7 @@ int bm2_launch_seeding(bm2_ctx *c, const SeedParams &sp, int n_reads, const uint
                        void (*tick)(bm2_ctx *, const char *), int max_len);
 int bm2_launch_smem_finish(bm2_ctx *c, int n_reads, const SeedBufs &sb, const unsigned long long *sc, const int32_t *smem_cnt,
                            const int64_t *smem_off, int32_t *fill, bm2_smem_t *tmp, int32_t max_occ, bm2_smem_t *out, int32_t *occ_cnt, int max_len);
-int bm2_seed_sizes(size_t *head, size_t *ent, size_t *task, int *n_sc);      // returns CAPF
+int bm2_seed_sizes(size_t *head, size_t *ent, size_t *task, int *n_sc, size_t *ctask);      // returns CAPF
 int bm2_launch_sal_expand(bm2_ctx *c, const bm2_smem_t *smems, int64_t n_smem, const int64_t *sa_off, int32_t max_occ, int64_t *pos);
 int bm2_launch_sal(bm2_ctx *c, int64_t n, int64_t *pos_coord, unsigned long long *n_lf);
 int bm2_launch_smem_gather(bm2_ctx *c, int n_reads, const bm2_smem_t *in, const int64_t *in_off, const int32_t *cnt,

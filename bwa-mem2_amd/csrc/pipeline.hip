@@ -182,8 +182,8 @@ static int run_seeding(bm2_ctx *c, Batch *b, const bm2_opt *opt, bool with_sal) 
     const int grid_w = c->n_cu * bpc_w, grid_b = c->n_cu * bpc_b;
     const int64_t lanes = (int64_t)(grid_w > grid_b ? grid_w : grid_b) * 256;
     if (opt->split_width > 65534) { bm2_set_error("split_width %d > 65534 is not supported", opt->split_width); return BM2_EUNSUP; }
-    size_t head_sz, ent_sz, task_sz; int n_sc;
-    const int capf = bm2_seed_sizes(&head_sz, &ent_sz, &task_sz, &n_sc);
+    size_t head_sz, ent_sz, task_sz, ctask_sz; int n_sc;
+    const int capf = bm2_seed_sizes(&head_sz, &ent_sz, &task_sz, &n_sc, &ctask_sz);
     SeedBufs sb;
     sb.pool_cap = b->max_len + 2 > capf ? b->max_len + 2 - capf : 1;
     // (the learned sizes are kept as counts: deriving them from the buffers' byte capacities would make every buffer chase
@@ -222,9 +222,9 @@ static int run_seeding(bm2_ctx *c, Batch *b, const bm2_opt *opt, bool with_sal) 
         if ((rc = bm2_reserve(b->heavy2, (size_t)sb.heavy_cap * 4))) return rc;
         sb.heavy1 = (int32_t *)b->heavy1.p; sb.heavy2 = (int32_t *)b->heavy2.p;
         sb.cont_cap = (int64_t)n / 2 + lanes + 4096;            // (a full list only means the task stays with its lane)
-        if ((rc = bm2_reserve(b->cont1, (size_t)sb.cont_cap * 4))) return rc;
-        if ((rc = bm2_reserve(b->cont2, (size_t)sb.cont_cap * 4))) return rc;
-        sb.cont1 = (int32_t *)b->cont1.p; sb.cont2 = (int32_t *)b->cont2.p;
+        if ((rc = bm2_reserve(b->cont1, (size_t)sb.cont_cap * ctask_sz))) return rc;
+        if ((rc = bm2_reserve(b->cont2, (size_t)sb.cont_cap * ctask_sz))) return rc;
+        sb.cont1 = b->cont1.p; sb.cont2 = b->cont2.p;
         if ((rc = bm2_check(hipMemsetAsync(b->seedc.p, 0, (size_t)n_sc * 8, s), "memset seed cursors"))) return rc;
         if ((rc = bm2_check(hipMemsetAsync(b->smem_cnt.p, 0, (size_t)(n + 1) * 4, s), "memset smem_cnt"))) return rc;
         if ((rc = bm2_check(hipMemsetAsync(b->fill.p, 0, (size_t)(2 * (size_t)n + 8) * 4, s), "memset fill"))) return rc;
@@ -260,7 +260,7 @@ static int run_seeding(bm2_ctx *c, Batch *b, const bm2_opt *opt, bool with_sal) 
                 h_sc[BM2_SC_SLOT2], h_sc[BM2_SC_REC], h_sc[BM2_SC_TASK], h_sc[BM2_SC_POOL]);
     }
     unsigned long long h_cnt[3] = { (unsigned long long)n_smem_tot, h_sc[BM2_SC_NEXT], 0 };
-    static_assert(BM2_SC_NEXT_W1 + 13 == 25, "bm2_batch_fetch(\"seed_counters\") exposes 25 counters ([21], [22]: tasks handed over in pass 1 / 2)");
+    static_assert(BM2_SC_NEXT_W1 + 15 == 27, "bm2_batch_fetch(\"seed_counters\") exposes 27 counters ([21], [22]: tasks handed over in pass 1 / 2 (in sixteens), [25], [26]: rows their continuations walked)");
     if ((rc = bm2_reserve(b->smem, (size_t)(n_smem_tot + 1) * sizeof(bm2_smem_t)))) return rc;
     if ((rc = bm2_reserve(b->smem_tmp, (size_t)(n_smem_tot + 1) * sizeof(bm2_smem_t)))) return rc;
     if ((rc = bm2_reserve(b->occ_cnt, (size_t)(n_smem_tot + 2) * 4))) return rc;
@@ -828,7 +828,7 @@ extern "C" int bm2_batch_fetch(bm2_ctx *c, const char *what, void *out, int64_t 
         { "sa_coord", &b->sa_coord, ns * 8 }, { "read_base", &b->read_base, (size_t)n * 8 },
         { "n_chain", &b->n_chain, (size_t)n * 4 }, { "n_chain0", &b->n_chain0, (size_t)n * 4 }, { "n_reg", &b->n_reg, (size_t)n * 4 },
         { "n_out", &b->n_out, (size_t)n * 4 }, { "chn", &b->chn, ns * sizeof(DevChain) }, { "seeds", &b->seeds, ns * sizeof(DevSeed) },
-        { "seed_counters", &b->seedc, (size_t)25 * 8 }, { "counters", &b->counters, (size_t)48 * 8 }, { "regs_raw", &b->regs, ns * sizeof(DevReg) }, { "reg_seed", &b->reg_seed, ns * 4 }, { "wchain", &b->wchain, ns * sizeof(WChain) },
+        { "seed_counters", &b->seedc, (size_t)27 * 8 }, { "counters", &b->counters, (size_t)48 * 8 }, { "regs_raw", &b->regs, ns * sizeof(DevReg) }, { "reg_seed", &b->reg_seed, ns * 4 }, { "wchain", &b->wchain, ns * sizeof(WChain) },
     };
     if (c->n_parts > 1 && (!strcmp(what, "seed_counters") || !strcmp(what, "counters"))) {       // work counters of a chunk in parts: the parts' sums
         const size_t nb = !strcmp(what, "counters") ? (size_t)48 * 8 : (size_t)21 * 8;

@@ -163,7 +163,7 @@ static __device__ __forceinline__ Bi init_bi(const DevIndex &ix, int a) {     //
 enum { W_P1 = 1, W_P2 = 2, W_P3 = 3 };
 enum { SC_P1_ITEM = 0, SC_SLOT1, SC_B1_ITEM, SC_REC, SC_TASK, SC_P2_ITEM, SC_SLOT2, SC_B2_ITEM, SC_P3_ITEM, SC_NEXT, SC_OVF_FLAG,
        SC_POOL, SC_NEXT_W1, SC_NEXT_W2, SC_NEXT_W3, SC_NEXT_B1, SC_NEXT_B2, SC_HEAVY1, SC_HEAVY2, SC_H1_ITEM, SC_H2_ITEM,
-       SC_CONT1, SC_CONT2, SC_C1_ITEM, SC_C2_ITEM, SC_N };   // SC_CONT*: backward tasks k_bwd handed over at a row boundary (their slot ids: SeedBufs::cont1 / cont2)   // SC_NEXT_*: backwardExt calls per kernel           // cursors / counters of the seeding kernels (unsigned long long each)
+       SC_CONT1, SC_CONT2, SC_C1_ITEM, SC_C2_ITEM, SC_CROWS1, SC_CROWS2, SC_N };   // SC_CONT*: backward tasks k_bwd handed over at a row boundary (SeedBufs::cont1 / cont2), SC_CROWS*: rows k_bwd_cont walked   // SC_NEXT_*: backwardExt calls per kernel           // cursors / counters of the seeding kernels (unsigned long long each)
 enum { OVF_SLOT1 = 1, OVF_SLOT2 = 2, OVF_REC = 4, OVF_TASK = 8, OVF_POOL = 16 };
 
 struct __attribute__((aligned(16))) BHead {       // header of a backward-phase task (32 bytes)
@@ -179,6 +179,11 @@ struct __attribute__((aligned(16))) P2Task {      // pass-2 forward walk (32 byt
     int32_t r, L, x, s;
     int64_t pad;
 };
+struct __attribute__((aligned(16))) CTask {       // a backward task k_bwd handed over at a row boundary (48 bytes): its header as the continuation reads it + its slot
+    BHead h;                      // x_np: the row just finished | the survivors' count << 16; pad: index of the list's first entry + 1
+    int32_t slot, pad0, pad1, pad2;
+};
+#define CCAP 64                   // survivors a handed-over task may have (k_bwd_cont keeps a task's row in 64 LDS entries)
 // Ids (work items, task slots, record / task indices) are handed out from per-wave pools: the lanes that need one at
 // the same point take consecutive ids from the wave's pool with a ballot; a pool is refilled with ONE atomic on the
 // global cursor per BATCH ids (a same-address atomic per lane and id would serialise in L2: ~10 ns each, measured).
@@ -207,6 +212,7 @@ static __device__ __forceinline__ int64_t wave_alloc(LdsPool *wp, unsigned long 
 #define HEAVY_T 40                // backward tasks with longer candidate lists go to the wave-per-task kernel ...
 #define HCAP 256                  // ... if the list fits its LDS row (else they stay lane-per-task)
 #define HEAVY_BATCH 64
+#define CONT_BATCH 16                 // ids of handed-over tasks a wave of k_bwd takes at a time
 #define BWD_EXPORT_AGE 0              // (default of BM2_BWD_EXPORT_AGE)
 #define BWD_ILP 1                     // (default of BM2_BWD_ILP)
 #define ITEM_BATCH 64
@@ -412,10 +418,10 @@ enum { B_EXT = 0, B_NEWITEM, B_FIRST, B_ROWEND, B_ROW, B_FIN, B_DONE };
 // them in order -- so the lane issues the requests of candidates p and p + 1 together and judges the two results one after the other)
 template <int LC, int ILP>
 static __device__ __forceinline__ void
-bwd_body(const DevIndex &ix, const SeedParams &sp, int pass, const uint8_t *__restrict__ enc, BHead *heads,
+bwd_body(const DevIndex &ix, const SeedParams &sp, int pass, const uint8_t *__restrict__ enc, const BHead *__restrict__ heads,
          uint4 *__restrict__ ents, int64_t slot_cap, uint4 *__restrict__ pool, int pool_cap, int pool_slots,
          bm2_smem_t *__restrict__ recs, int64_t rec_cap, P2Task *__restrict__ tasks, int64_t task_cap,
-         int32_t *__restrict__ smem_cnt, unsigned long long *sc, int32_t *__restrict__ cont_ids, int64_t cont_cap, int export_age) {
+         int32_t *__restrict__ smem_cnt, unsigned long long *sc, CTask *__restrict__ ctasks, int64_t cont_cap, int export_age) {
     int64_t n_ext = 0;
     unsigned ovf = 0;
     int64_t n_items = (int64_t)sc[pass == 1 ? SC_SLOT1 : SC_SLOT2];
@@ -484,25 +490,27 @@ bwd_body(const DevIndex &ix, const SeedParams &sp, int pass, const uint8_t *__re
             if (state == B_ROWEND) {                            // :650-655
                 n_prev = n_curr;
                 if (n_curr == 0) state = B_FIN;
-                else if (export_age > 0 && age >= export_age && j > 0 && n_curr <= HCAP) {
+                else if (export_age > 0 && age >= export_age && j > 0 && n_curr <= CCAP) {
                     // HAND-OVER.  A lane-per-task kernel cannot end before its oldest task does, and the task sizes have a long tail (mean ~100
                     // extensions, one in a thousand beyond 1000: tools/seed_sim): the last third of this kernel used to be a few lanes finishing
                     // repeat-rich positions on an otherwise empty GPU.  A task that has had `export_age` extensions stops at the end of its row:
-                    // the row's survivors go back into the task's slot where the reader of a walk's list expects them (entry(top - depth)), the
-                    // header says row j is done, and k_bwd_heavy -- a wavefront per task, the candidates of a row side by side -- finishes it in a
+                    // the row's survivors go back into the task's slot where the reader of a walk's list expects them (entry(top - depth)), a
+                    // CTask says row j is done, and k_bwd_cont -- sixteen lanes per task, the candidates of a row side by side -- finishes it in a
                     // launch of its own after this one (a kernel boundary: no hand-off between running workgroups).
-                    const int64_t cid = wave_alloc<HEAVY_BATCH>(cp, sc + (pass == 1 ? SC_CONT1 : SC_CONT2));
+                    const int64_t cid = wave_alloc<CONT_BATCH>(cp, sc + (pass == 1 ? SC_CONT1 : SC_CONT2));
                     if (cid < cont_cap) {
                         const int64_t slot = (int64_t)(lst - ents) / CAPF;
                         *entry(top) = pv_pack(fk, fl, fs, fn);
                         const int nl = n_curr - 1 < LC ? n_curr - 1 : LC;
                         for (int d = 1; d <= nl; d++) *entry(top - d) = surv[(d - 1) * 256 + threadIdx.x];
-                        BHead h = heads[slot];
-                        h.x_np = (uint32_t)j | (uint32_t)n_curr << 16;          // "start position" j: the continuation sets m_row = j and goes on with row j - 1
-                        h.mi_pass |= 1u << 24;
-                        h.pad = top + 1;                                        // where the list's first entry is (a walk's list: n_prev - 1)
-                        heads[slot] = h;
-                        cont_ids[cid] = (int32_t)slot;
+                        CTask t;
+                        t.h.rd_off = (int64_t)(q - enc); t.h.r = r; t.h.L = L;
+                        t.h.x_np = (uint32_t)j | (uint32_t)n_curr << 16;        // "start position" j: the continuation sets m_row = j and goes on with row j - 1
+                        t.h.mi_pass = (uint32_t)min_intv | (uint32_t)pass << 16;
+                        t.h.pool_id = (int32_t)((lpool - pool) / pool_cap);     // (0 for a list without a pool part: then nothing beyond CAPF is ever read)
+                        t.h.pad = top + 1;                                      // where the list's first entry is
+                        t.slot = (int32_t)slot; t.pad0 = t.pad1 = t.pad2 = 0;
+                        ctasks[cid] = t;
                         state = B_NEWITEM;
                     } else { m_row = j; j--; row0 = false; state = B_ROW; }
                 }
@@ -602,7 +610,7 @@ bwd_body(const DevIndex &ix, const SeedParams &sp, int pass, const uint8_t *__re
     }
     for (int64_t at = rp->pos + (threadIdx.x & 63); at < rp->end; at += 64) if (at < rec_cap) recs[at].rid = 0xffffffffu;
     for (int64_t at = tp->pos + (threadIdx.x & 63); at < tp->end; at += 64) if (at < task_cap) tasks[at].r = -1;
-    for (int64_t at = cp->pos + (threadIdx.x & 63); at < cp->end; at += 64) if (at < cont_cap) cont_ids[at] = -1;
+    for (int64_t at = cp->pos + (threadIdx.x & 63); at < cp->end; at += 64) if (at < cont_cap) ctasks[at].h.r = -1;
     atomicAdd(&sc[SC_NEXT], (unsigned long long)n_ext);
     atomicAdd(&sc[SC_NEXT_B1 + (pass - 1)], (unsigned long long)n_ext);
     if (ovf) atomicOr(&sc[SC_OVF_FLAG], (unsigned long long)ovf);
@@ -611,11 +619,11 @@ bwd_body(const DevIndex &ix, const SeedParams &sp, int pass, const uint8_t *__re
 #endif
 }
 
-#define BWD_ARGS DevIndex ix, SeedParams sp, int pass, const uint8_t *__restrict__ enc, BHead *heads, uint4 *__restrict__ ents, \
+#define BWD_ARGS DevIndex ix, SeedParams sp, int pass, const uint8_t *__restrict__ enc, const BHead *__restrict__ heads, uint4 *__restrict__ ents, \
                  int64_t slot_cap, uint4 *__restrict__ pool, int pool_cap, int pool_slots, bm2_smem_t *__restrict__ recs, int64_t rec_cap, \
                  P2Task *__restrict__ tasks, int64_t task_cap, int32_t *__restrict__ smem_cnt, unsigned long long *sc, \
-                 int32_t *__restrict__ cont_ids, int64_t cont_cap, int export_age
-#define BWD_PASS ix, sp, pass, enc, heads, ents, slot_cap, pool, pool_cap, pool_slots, recs, rec_cap, tasks, task_cap, smem_cnt, sc, cont_ids, cont_cap, export_age
+                 CTask *__restrict__ ctasks, int64_t cont_cap, int export_age
+#define BWD_PASS ix, sp, pass, enc, heads, ents, slot_cap, pool, pool_cap, pool_slots, recs, rec_cap, tasks, task_cap, smem_cnt, sc, ctasks, cont_cap, export_age
 template <int LC> __global__ void __launch_bounds__(256) k_bwd(BWD_ARGS) { bwd_body<LC, 1>(BWD_PASS); }     // 111 VGPRs: 4 waves per SIMD
 // the same with the register allocation told to leave room for 5 waves per SIMD (96 VGPRs, 100 bytes per lane spilled)
 template <int LC> __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) k_bwd5(BWD_ARGS) { bwd_body<LC, 1>(BWD_PASS); }
@@ -642,7 +650,7 @@ k_bwd_heavy(DevIndex ix, SeedParams sp, int pass, const uint8_t *__restrict__ en
             const uint4 *__restrict__ ents, int64_t slot_cap, const uint4 *__restrict__ pool, int pool_cap, int pool_slots,
             const int32_t *__restrict__ heavy_ids, int64_t heavy_cap,
             bm2_smem_t *__restrict__ recs, int64_t rec_cap, P2Task *__restrict__ tasks, int64_t task_cap,
-            int32_t *__restrict__ smem_cnt, unsigned long long *sc, int cont) {          // cont: the items are the tasks k_bwd handed over (SC_CONT*), not the walks' long lists
+            int32_t *__restrict__ smem_cnt, unsigned long long *sc) {
     __shared__ uint4 lists[4][HCAP];
     __shared__ int32_t alive_s[4][64];
     __shared__ WavePool pools[4][2];
@@ -651,9 +659,9 @@ k_bwd_heavy(DevIndex ix, SeedParams sp, int pass, const uint8_t *__restrict__ en
     if (lane == 0) { rp->pos = rp->end = 0; tp->pos = tp->end = 0; }
     uint4 *lst = lists[wv];
     int32_t *as = alive_s[wv];
-    int64_t n_items = (int64_t)sc[cont ? (pass == 1 ? SC_CONT1 : SC_CONT2) : (pass == 1 ? SC_HEAVY1 : SC_HEAVY2)];
+    int64_t n_items = (int64_t)sc[pass == 1 ? SC_HEAVY1 : SC_HEAVY2];
     if (n_items > heavy_cap) n_items = heavy_cap;
-    unsigned long long *item_cur = sc + (cont ? (pass == 1 ? SC_C1_ITEM : SC_C2_ITEM) : (pass == 1 ? SC_H1_ITEM : SC_H2_ITEM));
+    unsigned long long *item_cur = sc + (pass == 1 ? SC_H1_ITEM : SC_H2_ITEM);
     int64_t n_ext = 0;
     unsigned ovf = 0;
     const unsigned long long lt_mask = lane ? (~0ULL >> (64 - lane)) : 0ULL;
@@ -674,7 +682,7 @@ k_bwd_heavy(DevIndex ix, SeedParams sp, int pass, const uint8_t *__restrict__ en
         const uint8_t *q = enc + h.rd_off;
         const uint4 *src = ents + (int64_t)slot * CAPF;
         const uint4 *psrc = pool + (int64_t)(h.pool_id >= 0 && h.pool_id < pool_slots ? h.pool_id : 0) * pool_cap;
-        const int top = h.pad > 0 ? h.pad - 1 : n_prev - 1;         // (a handed-over task: the survivors of its last row lie where the walk's list began)
+        const int top = n_prev - 1;
         for (int d = lane; d < n_prev; d += 64) {                // longest first (:586-592) = the walk's list read top-down
             const int idx = top - d;
             lst[d] = idx < CAPF ? src[idx] : psrc[idx - CAPF];
@@ -752,6 +760,147 @@ k_bwd_heavy(DevIndex ix, SeedParams sp, int pass, const uint8_t *__restrict__ en
     for (int64_t at = tp->pos + lane; at < tp->end; at += 64) if (at < task_cap) tasks[at].r = -1;
     atomicAdd(&sc[SC_NEXT], (unsigned long long)n_ext);
     atomicAdd(&sc[SC_NEXT_B1 + (pass - 1)], (unsigned long long)n_ext);
+    if (ovf) atomicOr(&sc[SC_OVF_FLAG], (unsigned long long)ovf);
+}
+
+// ---- the tasks k_bwd handed over: SIXTEEN LANES per task, four tasks per wavefront ---------------------------------------------
+// A handed-over task has had its share of a lane (BM2_BWD_EXPORT_AGE extensions) and still has rows to go -- a few candidates over tens of rows,
+// or tens of candidates over a few.  Its rows are sequential, its candidates are not: a group of sixteen lanes extends sixteen candidates of
+// the row at once (the in-order rules as ballots over the group, as in k_bwd_heavy), so a task lasts (rows x chunks) rounds instead of (rows x
+// candidates).  Four groups share a wavefront's converged backwardExt; what a group needs between two rounds -- its next task's record, the
+// query bases eight rows ahead -- is requested a task / a window ahead.
+enum { C_EXT = 0, C_NEWITEM, C_LIST, C_ROW, C_FIN, C_DONE };
+#if !defined(BM2_EMU_ROW_PRIMS)                                /* (tools/emu supplies the row primitives: a rendezvous of the sixteen threads of a row) */
+static __device__ __forceinline__ int row_first(int v) { return __shfl(v, 0, 16); }     // lane 0 of this 16-lane row; the row executes this together
+#endif
+__global__ void __launch_bounds__(256)
+k_bwd_cont(DevIndex ix, SeedParams sp, int pass, const uint8_t *__restrict__ enc, const uint4 *__restrict__ ents, int64_t slot_cap,
+           const uint4 *__restrict__ pool, int pool_cap, int pool_slots, const CTask *__restrict__ ctasks, int64_t cont_cap,
+           bm2_smem_t *__restrict__ recs, int64_t rec_cap, P2Task *__restrict__ tasks, int64_t task_cap,
+           int32_t *__restrict__ smem_cnt, unsigned long long *sc) {
+    __shared__ uint4 lists[4][4][CCAP];
+    __shared__ int32_t alive_s[4][4][16];
+    __shared__ WavePool pools[4][3];                           // per wave: [0] work items, [1] records, [2] pass-2 tasks
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, gl = lane & 15;
+    LdsPool *ip = (LdsPool *)&pools[wv][0], *rp = (LdsPool *)&pools[wv][1], *tp = (LdsPool *)&pools[wv][2];
+    if (lane == 0) { ip->pos = ip->end = 0; rp->pos = rp->end = 0; tp->pos = tp->end = 0; }
+    uint4 *lst = lists[wv][g];
+    int32_t *as = alive_s[wv][g];
+    int64_t n_items = (int64_t)sc[pass == 1 ? SC_CONT1 : SC_CONT2];
+    if (n_items > cont_cap) n_items = cont_cap;
+    unsigned long long *item_cur = sc + (pass == 1 ? SC_C1_ITEM : SC_C2_ITEM);
+    const unsigned glt = (1u << gl) - 1u;                        // the group's lanes below this one
+    auto gballot = [&](bool v) -> unsigned { return (unsigned)(__ballot(v) >> (16 * g)) & 0xffffu; };
+    // the group's next work item (its first lane draws, the others copy) with the item's record already requested
+    auto draw = [&]() -> int64_t {
+        int64_t id = 0;
+        if (gl == 0) id = wave_alloc<4>(ip, item_cur);
+        const unsigned lo = (unsigned)row_first((int)(unsigned)id), hi = (unsigned)row_first((int)(unsigned)(id >> 32));
+        return (int64_t)(((unsigned long long)hi << 32) | lo);
+    };
+    int64_t it_a = draw();
+    CTask pl = {};
+    if (it_a < n_items) pl = ctasks[it_a];
+    int64_t n_ext = 0, n_rows = 0;
+    unsigned ovf = 0;
+    int state = C_NEWITEM;
+    int32_t r = 0; const uint8_t *q = enc; int L = 0; int64_t rd_off = 0;
+    int j = 0, a = 0, n_prev = 0, n_curr = 0, c0 = 0, m_row = 0, top = 0; int32_t curr_s = -1; bool first_done = false;
+    int64_t min_intv = 1;
+    const uint4 *src = ents, *psrc = pool;
+    uint4 e4[CCAP / 16];
+    QWin w; w.cur = w.nxt = 0; w.curb = w.nxtb = -64;
+    auto emit = [&](int64_t ck, int64_t cl, int64_t cs, int cn) {   // one SMEM: record, per-read count, pass-2 task (FMI_search.cpp:611-621 / :656-665)
+        const int64_t at = wave_alloc<REC_BATCH>(rp, sc + SC_REC);
+        if (at < rec_cap) {
+            bm2_smem_t v; v.rid = (uint32_t)r; v.m = (uint32_t)m_row; v.n = (uint32_t)cn; v.pad = 0; v.k = ck; v.l = cl; v.s = cs;
+            recs[at] = v;
+            atomicAdd(&smem_cnt[r], 1);
+        } else ovf |= OVF_REC;
+        if (pass == 1 && (cn + 1 - m_row) >= sp.split_len && cs <= (int64_t)sp.split_width) {       // bwamem.cpp:701-703
+            const int64_t ta = wave_alloc<TASK_BATCH>(tp, sc + SC_TASK);
+            if (ta < task_cap) { P2Task t; t.rd_off = rd_off; t.r = r; t.L = L; t.x = (cn + 1 + m_row) >> 1; t.s = (int32_t)cs; t.pad = 0; tasks[ta] = t; }
+            else ovf |= OVF_TASK;
+        }
+    };
+    for (;;) {
+        while (state != C_EXT && state != C_DONE) {            // `break` = yield: the group sits out one extension round
+            if (state == C_NEWITEM) {
+                if (it_a >= n_items) { state = C_DONE; break; }
+                const CTask t = pl;
+                it_a = draw();
+                if (it_a < n_items) pl = ctasks[it_a];
+                n_prev = (int)(t.h.x_np >> 16);
+                if (t.h.r < 0 || n_prev <= 0 || n_prev > CCAP || t.slot < 0 || t.slot >= slot_cap) break;      // padding of a wave's id pool: next item
+                r = t.h.r; L = t.h.L; rd_off = t.h.rd_off; q = enc + rd_off; min_intv = (int64_t)(t.h.mi_pass & 0xffff);
+                m_row = (int)(t.h.x_np & 0xffff); j = m_row - 1; top = t.h.pad - 1;
+                src = ents + (int64_t)t.slot * CAPF;
+                psrc = pool + (int64_t)(t.h.pool_id >= 0 && t.h.pool_id < pool_slots ? t.h.pool_id : 0) * pool_cap;
+                for (int c = 0; c < CCAP / 16; c++) {            // longest first = the list read top-down
+                    const int d = gl + 16 * c, idx = top - d;
+                    if (d < n_prev) e4[c] = idx < CAPF ? src[idx] : psrc[idx - CAPF];
+                }
+                if (j >= 0) w.start(q, j, -1);
+                state = C_LIST; break;
+            }
+            if (state == C_LIST) {
+                for (int c = 0; c < CCAP / 16; c++) if (gl + 16 * c < n_prev) lst[gl + 16 * c] = e4[c];     // (a lane reads back what it wrote itself until the first row is compacted)
+                state = C_ROW;
+            }
+            if (state == C_ROW) {                               // :596-606
+                if (j < 0 || n_prev == 0) state = C_FIN;
+                else if (!w.get(q, j, -1, a)) break;
+                else if (a > 3) state = C_FIN;
+                else { n_curr = 0; curr_s = -1; first_done = false; c0 = 0; n_rows += gl == 0; state = C_EXT; }
+            }
+            if (state == C_FIN) {                               // :656-665
+                if (n_prev > 0 && gl == 0) {
+                    int64_t ck, cl, cs; int cn;
+                    pv_unpack(lst[0], ck, cl, cs, cn);
+                    if ((cn - m_row + 1) >= sp.min_seed_len) emit(ck, cl, cs, cn);
+                }
+                state = C_NEWITEM;
+            }
+        }
+        if (!__any(state != C_DONE)) break;
+        const int d = c0 + gl;
+        const bool valid = state == C_EXT && d < n_prev;
+        int64_t ck = 0, cl = 0, cs = 0; int cn = 0;
+        if (valid) pv_unpack(lst[d], ck, cl, cs, cn);
+        const Bi in = { ck, cl, cs };
+        const Bi o = backward_ext(ix, in, a, valid);            // (all lanes: quad-cooperative)
+        if (valid) n_ext++;
+        const bool alive = valid && o.s >= min_intv;
+        const bool deadlen = valid && o.s < min_intv && (cn - m_row + 1) >= sp.min_seed_len;
+        const unsigned am = gballot(alive), dm = gballot(deadlen);
+        if (state == C_EXT && !first_done && (am | dm)) {
+            const int f = __ffsll((long long)(am | dm)) - 1;
+            if (((dm >> f) & 1u) && gl == f) emit(ck, cl, cs, cn);      // the first to trigger died long enough: one SMEM
+            first_done = true;
+        }
+        // keep a live candidate iff its size differs from the previous live one's (int32, :625 / :640)
+        const int arank = __popc(am & glt);
+        if (alive) as[arank] = (int32_t)o.s;
+        wave_sync();
+        const int32_t prev_s = alive ? (arank ? as[arank - 1] : curr_s) : 0;
+        const bool keep = alive && o.s != (int64_t)prev_s;
+        const unsigned km = gballot(keep);
+        if (keep) lst[n_curr + __popc(km & glt)] = pv_pack(o.k, o.l, o.s, cn);
+        if (state == C_EXT) {
+            n_curr += __popc(km);
+            if (am) curr_s = as[__popc(am) - 1];
+        }
+        wave_sync();
+        if (state == C_EXT) {
+            c0 += 16;
+            if (c0 >= n_prev) { n_prev = n_curr; m_row = j; j--; state = C_ROW; }
+        }
+    }
+    for (int64_t at = rp->pos + lane; at < rp->end; at += 64) if (at < rec_cap) recs[at].rid = 0xffffffffu;
+    for (int64_t at = tp->pos + lane; at < tp->end; at += 64) if (at < task_cap) tasks[at].r = -1;
+    atomicAdd(&sc[SC_NEXT], (unsigned long long)n_ext);
+    atomicAdd(&sc[SC_NEXT_B1 + (pass - 1)], (unsigned long long)n_ext);
+    atomicAdd(&sc[SC_CROWS1 + (pass - 1)], (unsigned long long)n_rows);
     if (ovf) atomicOr(&sc[SC_OVF_FLAG], (unsigned long long)ovf);
 }
 
@@ -1046,23 +1195,23 @@ int bm2_launch_seeding(bm2_ctx *c, const SeedParams &sp, int n_reads, const uint
             (void)hipEventRecord(c->ev_join[2], s);
             (void)hipStreamWaitEvent(sh, c->ev_join[2], 0);
             hipLaunchKernelGGL(k_bwd_heavy, dim3(grid_heavy), dim3(256), 0, sh, c->ix, sp, pass, enc, heads, ents, slot_cap, sb.pool, sb.pool_cap,
-                               sb.pool_slots, heavy, sb.heavy_cap, sb.recs, sb.rec_cap, sb.tasks, sb.task_cap, smem_cnt, sc, 0);
+                               sb.pool_slots, heavy, sb.heavy_cap, sb.recs, sb.rec_cap, sb.tasks, sb.task_cap, smem_cnt, sc);
             (void)hipEventRecord(c->ev_join[1], sh);
         }
         const int lc = bm2_knob("BM2_BWD_LCAP", LCAP), wpe = bm2_knob("BM2_BWD_WAVES", 4);
         auto kb = wpe >= 5 ? (lc <= 4 ? k_bwd5<4> : k_bwd5<6>)
                            : (lc <= 4 ? k_bwd<4> : lc <= 6 ? k_bwd<6> : lc <= 8 ? k_bwd<8> : k_bwd<LCAP>);
         if (bm2_knob("BM2_BWD_ILP", BWD_ILP) == 2) kb = lc <= 8 ? k_bwd_ilp2<8> : k_bwd_ilp2<LCAP>;
-        int32_t *cont = pass == 1 ? sb.cont1 : sb.cont2;
+        CTask *cont = (CTask *)(pass == 1 ? sb.cont1 : sb.cont2);
         hipLaunchKernelGGL(kb, dim3(grid_bwd), dim3(256), 0, s, c->ix, sp, pass, enc, heads, ents, slot_cap, sb.pool, sb.pool_cap,
                            sb.pool_slots, sb.recs, sb.rec_cap, sb.tasks, sb.task_cap, smem_cnt, sc, cont, sb.cont_cap, export_age);
         if (!heavy_after) (void)hipStreamWaitEvent(s, c->ev_join[1], 0);
         else hipLaunchKernelGGL(k_bwd_heavy, dim3(grid_heavy * 2), dim3(256), 0, s, c->ix, sp, pass, enc, heads, ents, slot_cap, sb.pool, sb.pool_cap,
-                                sb.pool_slots, heavy, sb.heavy_cap, sb.recs, sb.rec_cap, sb.tasks, sb.task_cap, smem_cnt, sc, 0);
+                                sb.pool_slots, heavy, sb.heavy_cap, sb.recs, sb.rec_cap, sb.tasks, sb.task_cap, smem_cnt, sc);
         tick(c, pass == 1 ? "smem.bwd1" : "smem.bwd2");
-        if (export_age > 0) {                                   // the tasks k_bwd handed over, a wavefront each (they may file pass-2 tasks: before k_walk<P2>)
-            hipLaunchKernelGGL(k_bwd_heavy, dim3(grid_heavy * 2), dim3(256), 0, s, c->ix, sp, pass, enc, heads, ents, slot_cap, sb.pool, sb.pool_cap,
-                               sb.pool_slots, cont, sb.cont_cap, sb.recs, sb.rec_cap, sb.tasks, sb.task_cap, smem_cnt, sc, 1);
+        if (export_age > 0) {                                   // the tasks k_bwd handed over, sixteen lanes each (they may file pass-2 tasks: before k_walk<P2>)
+            hipLaunchKernelGGL(k_bwd_cont, dim3(c->n_cu * bm2_knob("BM2_BWD_CONT_BPC", 6)), dim3(256), 0, s, c->ix, sp, pass, enc, ents, slot_cap, sb.pool, sb.pool_cap,
+                               sb.pool_slots, cont, sb.cont_cap, sb.recs, sb.rec_cap, sb.tasks, sb.task_cap, smem_cnt, sc);
             tick(c, pass == 1 ? "smem.cont1" : "smem.cont2");
         }
     }
@@ -1087,8 +1236,8 @@ int bm2_launch_smem_finish(bm2_ctx *c, int n_reads, const SeedBufs &sb, const un
     hipLaunchKernelGGL(k_smem_finish_big, dim3(c->n_cu), dim3(256), lds, c->stream, tmp, smem_cnt, smem_off, max_occ, out, occ_cnt, big_list, big_cnt, big_cur, keys_arg);
     return bm2_check(hipGetLastError(), "k_smem_finish launch");
 }
-int bm2_seed_sizes(size_t *head, size_t *ent, size_t *task, int *n_sc) {
-    *head = sizeof(BHead); *ent = (size_t)CAPF * 16; *task = sizeof(P2Task); *n_sc = SC_N + 10;
+int bm2_seed_sizes(size_t *head, size_t *ent, size_t *task, int *n_sc, size_t *ctask) {
+    *head = sizeof(BHead); *ent = (size_t)CAPF * 16; *task = sizeof(P2Task); *n_sc = SC_N + 10; *ctask = sizeof(CTask);
     return CAPF;
 }
 int bm2_launch_sal_expand(bm2_ctx *c, const bm2_smem_t *smems, int64_t n_smem, const int64_t *sa_off, int32_t max_occ, int64_t *pos) {

@@ -21,10 +21,11 @@ sys.path.insert(0, os.path.join(ROOT, "bwa-mem2_amd"))
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 GRID = [   # (name, candidates): a candidate is a dict of knobs set together; the first one ({} = the library's defaults) is the incumbent
-    ("seeding: k_bwd hands old tasks over to the wavefront kernel", [{}, {"BM2_BWD_EXPORT_AGE": 512}, {"BM2_BWD_EXPORT_AGE": 384}, {"BM2_BWD_EXPORT_AGE": 256},
-                                                                      {"BM2_BWD_EXPORT_AGE": 192}, {"BM2_BWD_EXPORT_AGE": 128}, {"BM2_BWD_EXPORT_AGE": 96}]),
+    ("seeding: k_bwd hands old tasks over (k_bwd_cont: sixteen lanes per task)", [{}, {"BM2_BWD_EXPORT_AGE": 512}, {"BM2_BWD_EXPORT_AGE": 384}, {"BM2_BWD_EXPORT_AGE": 256},
+                                                                                     {"BM2_BWD_EXPORT_AGE": 192}, {"BM2_BWD_EXPORT_AGE": 128}, {"BM2_BWD_EXPORT_AGE": 96}]),
+    ("seeding: workgroups per CU of k_bwd_cont", [{}, {"BM2_BWD_CONT_BPC": 4}, {"BM2_BWD_CONT_BPC": 8}]),
+    ("seeding: two candidates of a row per round in k_bwd", [{}, {"BM2_BWD_ILP": 2}, {"BM2_BWD_ILP": 2, "BM2_BWD_LCAP": 8, "BM2_BWD_BLOCKS_PER_CU": 4}]),
     ("seeding: the long lists' kernel after k_bwd", [{}, {"BM2_BWD_HEAVY_AFTER": 1}]),
-    ("seeding: pass 3 workgroups per CU", [{}, {"BM2_P3_BPC": 2}, {"BM2_P3_BPC": 1}, {"BM2_P3_BPC": 2, "BM2_P3_AT": 2}]),
     ("chain clock", [{}, {"BM2_CHAIN_CLOCK": 1}]),
     ("chain staging", [{}, {"BM2_CHAIN_STAGE": 1}]),
     ("chain heavy threshold", [{}, {"BM2_HEAVY_SA": 64}, {"BM2_HEAVY_SA": 40}, {"BM2_HEAVY_SA": 24}, {"BM2_HEAVY_SA": 160}, {"BM2_HEAVY_SA": 256}, {"BM2_HEAVY_SA": 512}]),
@@ -104,6 +105,9 @@ def main():
         ms = (time.perf_counter() - t0) / a.steps * 1e3
         regs, reg_off = ctx.batch_download()
         crc = zlib.crc32(reg_off.tobytes(), zlib.crc32(regs.tobytes()))
+        sc = ctx.batch_fetch("seed_counters", np.uint64)
+        if len(sc) >= 27:                                        # tasks k_bwd handed over in pass 1 / 2 (drawn in sixteens) and the rows their continuations walked
+            kms["handed_over"] = [int(sc[21]), int(sc[22]), int(sc[25]), int(sc[26])]
         return ms, kms, crc
 
     log = []
@@ -112,7 +116,7 @@ def main():
     base_ms, base_k, base_crc = measure(best_env)
     log.append({"env": {}, "ms": base_ms, "stages": base_k, "crc": base_crc})
     best_ms = base_ms
-    print("[sweep] default: %.2f ms/step %s" % (base_ms, {k: round(v, 2) for k, v in base_k.items()}), file=sys.stderr, flush=True)
+    print("[sweep] default: %.2f ms/step %s" % (base_ms, {k: (round(v, 2) if isinstance(v, float) else v) for k, v in base_k.items()}), file=sys.stderr, flush=True)
     only = [x for x in a.only.split(",") if x]
     for name, cands in GRID:
         if only and not any(x in name for x in only):
@@ -133,7 +137,7 @@ def main():
                 continue
             ok = crc == base_crc
             log.append({"env": env, "ms": ms, "stages": k, "crc": crc, "same_regs": ok})
-            print("[sweep] %s %s: %.2f ms/step %s%s" % (name, cand, ms, {x: round(y, 2) for x, y in k.items()}, "" if ok else "  REGS DIFFER"),
+            print("[sweep] %s %s: %.2f ms/step %s%s" % (name, cand, ms, {x: (round(y, 2) if isinstance(y, float) else y) for x, y in k.items()}, "" if ok else "  REGS DIFFER"),
                   file=sys.stderr, flush=True)
             if ok and ms < best_ms * 0.985:                               # keep a change only if it buys more than the noise
                 best_ms, pick = ms, cand
