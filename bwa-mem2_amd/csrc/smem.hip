@@ -113,26 +113,6 @@ static __device__ __forceinline__ Bi backward_ext(const DevIndex &ix, Bi in, int
     coop_rank<2>(k, s, a, sub, e1[2], e2[2], q); coop_rank<3>(k, s, a, sub, e1[3], e2[3], q);
     return ext_result(ix, in, k, s, a, q);
 }
-// Two intervals of one lane extended by the same base in one round (k_bwd with two candidates of a row per round): all sixteen requests of
-// the quad are issued before the first rank waits, so a wavefront has up to 256 lines in flight instead of 128.
-static __device__ __forceinline__ void backward_ext2(const DevIndex &ix, Bi inA, Bi inB, int a, bool wantA, bool wantB, Bi &outA, Bi &outB) {
-    const int sub = (int)(threadIdx.x & 3);
-    const int64_t kA = wantA ? inA.k : 0, sA = wantA ? inA.s : 0, kB = wantB ? inB.k : 0, sB = wantB ? inB.s : 0;
-    ulonglong2 a1[4], a2[4], b1[4], b2[4];
-    const int wA = wantA ? 1 : 0, wB = wantB ? 1 : 0;
-    coop_issue<0>(ix, kA, sA, wA, sub, a1[0], a2[0]); coop_issue<1>(ix, kA, sA, wA, sub, a1[1], a2[1]);
-    coop_issue<2>(ix, kA, sA, wA, sub, a1[2], a2[2]); coop_issue<3>(ix, kA, sA, wA, sub, a1[3], a2[3]);
-    coop_issue<0>(ix, kB, sB, wB, sub, b1[0], b2[0]); coop_issue<1>(ix, kB, sB, wB, sub, b1[1], b2[1]);
-    coop_issue<2>(ix, kB, sB, wB, sub, b1[2], b2[2]); coop_issue<3>(ix, kB, sB, wB, sub, b1[3], b2[3]);
-    QuadOut qa = { 0, 0, 0, 0 }, qb = { 0, 0, 0, 0 };
-    coop_rank<0>(kA, sA, a, sub, a1[0], a2[0], qa); coop_rank<1>(kA, sA, a, sub, a1[1], a2[1], qa);
-    coop_rank<2>(kA, sA, a, sub, a1[2], a2[2], qa); coop_rank<3>(kA, sA, a, sub, a1[3], a2[3], qa);
-    coop_rank<0>(kB, sB, a, sub, b1[0], b2[0], qb); coop_rank<1>(kB, sB, a, sub, b1[1], b2[1], qb);
-    coop_rank<2>(kB, sB, a, sub, b1[2], b2[2], qb); coop_rank<3>(kB, sB, a, sub, b1[3], b2[3], qb);
-    outA = ext_result(ix, inA, kA, sA, a, qa);
-    outB = ext_result(ix, inB, kB, sB, a, qb);
-}
-
 static __device__ __forceinline__ Bi init_bi(const DevIndex &ix, int a) {     // FMI_search.cpp:531-533
     Bi b;
     b.k = pick4(a, ix.count[0], ix.count[1], ix.count[2], ix.count[3]);
@@ -212,9 +192,10 @@ static __device__ __forceinline__ int64_t wave_alloc(LdsPool *wp, unsigned long 
 #define HEAVY_T 40                // backward tasks with longer candidate lists go to the wave-per-task kernel ...
 #define HCAP 256                  // ... if the list fits its LDS row (else they stay lane-per-task)
 #define HEAVY_BATCH 64
-#define CONT_BATCH 16                 // ids of handed-over tasks a wave of k_bwd takes at a time
+#define CONT_BATCH 64                 // ids of handed-over tasks a wave of k_bwd takes at a time (wave_alloc: a batch must cover the 64 lanes that may ask at once)
 #define BWD_EXPORT_AGE 0              // (default of BM2_BWD_EXPORT_AGE)
-#define BWD_ILP 1                     // (default of BM2_BWD_ILP)
+#define WALK_SLOW_MASK 0              // (default of BM2_WALK_SLOW: the same for the forward walks)
+#define BWD_SLOW_MASK 0               // (default of BM2_BWD_SLOW: the rare steps of a k_bwd lane in every (mask + 1)-th round)
 #define ITEM_BATCH 64
 #define SLOT_BATCH 256
 #define REC_BATCH 256
@@ -264,7 +245,7 @@ struct QWin {
 // ---- forward walks ----------------------------------------------------------------------------------------------
 // MODE W_P1: item = read; chain of start positions, every walk leaves a backward task.  W_P2: item = P2Task, one walk.
 // W_P3: item = read; forward-only seeding, SMEM records written directly.
-enum { F_EXT = 0, F_NEWITEM, F_START, F_NEWPOS, F_CHK, F_END, F_DONE };
+enum { F_EXT = 0, F_NEWITEM, F_START, F_NEWPOS, F_CHK, F_END, F_REC, F_DONE };
 
 template <int MODE>
 __global__ void __launch_bounds__(256)
@@ -272,7 +253,7 @@ k_walk(DevIndex ix, SeedParams sp, int n_reads, const uint8_t *__restrict__ enc,
        const int32_t *__restrict__ len, const P2Task *__restrict__ tasks, int64_t task_cap,
        BHead *__restrict__ heads, uint4 *__restrict__ ents, int64_t slot_cap, uint4 *__restrict__ pool, int pool_cap, int pool_slots,
        bm2_smem_t *__restrict__ recs, int64_t rec_cap, int32_t *__restrict__ smem_cnt, unsigned long long *sc,
-       int32_t *__restrict__ heavy_ids, int64_t heavy_cap) {
+       int32_t *__restrict__ heavy_ids, int64_t heavy_cap, unsigned slow_mask) {      // slow_mask: see bwd_body
     int64_t n_ext = 0;
     unsigned ovf = 0;
     int64_t n_items;
@@ -311,9 +292,21 @@ k_walk(DevIndex ix, SeedParams sp, int n_reads, const uint8_t *__restrict__ enc,
         n_prev++;
     };
 
-    for (;;) {
+    for (unsigned rnd = 0;; rnd++) {
+        const bool slow = (rnd & slow_mask) == 0;             // the rare steps of a lane (a new item, closing a walk, a record) wait for such a round
         while (state != F_EXT && state != F_DONE) {            // `break` = yield: sit out one extension round
+            if (MODE == W_P3 && state == F_REC) {               // :771-808: the SMEM of this start position
+                if (!slow) break;
+                const int64_t at = wave_alloc<REC_BATCH>(op, out_cur);
+                if (at < rec_cap) {
+                    bm2_smem_t v; v.rid = (uint32_t)r; v.m = (uint32_t)x; v.n = (uint32_t)smn; v.pad = 0; v.k = smk; v.l = sml; v.s = sms;
+                    recs[at] = v;
+                    atomicAdd(&smem_cnt[r], 1);
+                } else ovf |= OVF_REC;
+                x = next_x; state = F_NEWPOS;
+            }
             if (state == F_NEWITEM) {
+                if (!slow) break;
                 if (it_a >= n_items) { state = F_DONE; break; }
                 if (MODE == W_P2) { r = pl_t.r; rd_off = pl_t.rd_off; L = pl_t.L; x = pl_t.x; min_intv = (int64_t)pl_t.s + 1; }
                 else { r = (int32_t)it_a; rd_off = pl_off; L = pl_len; x = 0; min_intv = 1; }
@@ -326,6 +319,7 @@ k_walk(DevIndex ix, SeedParams sp, int n_reads, const uint8_t *__restrict__ enc,
                 state = F_NEWPOS; break;
             }
             if (state == F_NEWPOS) {                            // FMI_search.cpp:514-535 / :746-755
+                if (MODE != W_P3 && !slow) break;               // (it draws a task slot)
                 if (MODE != W_P2 && x >= L) { state = F_NEWITEM; continue; }
                 if (!w.get(q, x, 1, a)) break;
                 next_x = x + 1;
@@ -349,6 +343,7 @@ k_walk(DevIndex ix, SeedParams sp, int n_reads, const uint8_t *__restrict__ enc,
             }
             if (state == F_END) {
                 if (MODE == W_P3) { x = next_x; state = F_NEWPOS; continue; }
+                if (!slow) break;
                 if (sms >= min_intv) push(pv_pack(smk, sml, sms, smn));                      // :576-580
                 if (slot < slot_cap) {
                     bool heavy = n_prev > HEAVY_T && n_prev <= HCAP;              // long list: a whole wave will take this task
@@ -375,15 +370,8 @@ k_walk(DevIndex ix, SeedParams sp, int n_reads, const uint8_t *__restrict__ enc,
             if (MODE == W_P3) {                                 // :771-808
                 smk = o.l; sml = o.k; sms = o.s; smn = j;
                 if (sms < sp.max_mem_intv && (smn - x + 1) >= sp.min_seed_len + 1) {
-                    if (sms > 0) {
-                        const int64_t at = wave_alloc<REC_BATCH>(op, out_cur);
-                        if (at < rec_cap) {
-                            bm2_smem_t v; v.rid = (uint32_t)r; v.m = (uint32_t)x; v.n = (uint32_t)smn; v.pad = 0; v.k = smk; v.l = sml; v.s = sms;
-                            recs[at] = v;
-                            atomicAdd(&smem_cnt[r], 1);
-                        } else ovf |= OVF_REC;
-                    }
-                    x = next_x; state = F_NEWPOS;
+                    if (sms > 0) state = F_REC;
+                    else { x = next_x; state = F_NEWPOS; }
                 } else { j++; state = F_CHK; }
             } else {
                 if (o.s != sms) push(pv_pack(smk, sml, sms, smn));
@@ -411,17 +399,21 @@ k_walk(DevIndex ix, SeedParams sp, int n_reads, const uint8_t *__restrict__ enc,
 // and is compacted in place: it is read top-down (longest candidate first = the reversal of :586-592), the survivors
 // of a row are written top-down behind the reader, the next candidate is requested while the current one is extended,
 // and the first survivor of a row -- the first candidate of the next row -- never leaves the registers.
-enum { B_EXT = 0, B_NEWITEM, B_FIRST, B_ROWEND, B_ROW, B_FIN, B_DONE };
+enum { B_EXT = 0, B_NEWITEM, B_FIRST, B_ROWEND, B_ROW, B_FIN, B_EM, B_DONE };
 
 // LC: survivors of a row kept in LDS per lane (16 B x LC x 256 lanes per block decides how many blocks share a CU's 160 KB)
-// ILP: candidates of a row a lane extends per round (2: the candidates of a row do not depend on each other -- FMI_search.cpp:607-649 only filters
-// them in order -- so the lane issues the requests of candidates p and p + 1 together and judges the two results one after the other)
-template <int LC, int ILP>
+// LC: survivors of a row kept in LDS per lane (16 B x LC x 256 lanes per block decides how many blocks share a CU's 160 KB).
+// slow_mask: the RARE steps of a lane -- taking a new task, writing an SMEM out -- are taken only in rounds whose number has no bit of the mask
+// set (0: every round).  A wavefront executes a block of the state machine whenever ONE of its lanes is in that state, and with 64 lanes "once
+// per task" is every other round: the kernel issues ~700 instructions per round of which the extension itself is 220 -- and its wavefronts issue
+// in 3/4 of all cycles (profiles/r04p_pmc_sq_steady.md: SQ_ACTIVE_INST_ANY).  Served every fourth round, the rare blocks cost a lane 1.5 rounds of
+// waiting per use and the wavefront three quarters of their instructions.
+template <int LC>
 static __device__ __forceinline__ void
 bwd_body(const DevIndex &ix, const SeedParams &sp, int pass, const uint8_t *__restrict__ enc, const BHead *__restrict__ heads,
          uint4 *__restrict__ ents, int64_t slot_cap, uint4 *__restrict__ pool, int pool_cap, int pool_slots,
          bm2_smem_t *__restrict__ recs, int64_t rec_cap, P2Task *__restrict__ tasks, int64_t task_cap,
-         int32_t *__restrict__ smem_cnt, unsigned long long *sc, CTask *__restrict__ ctasks, int64_t cont_cap, int export_age) {
+         int32_t *__restrict__ smem_cnt, unsigned long long *sc, CTask *__restrict__ ctasks, int64_t cont_cap, int export_age, unsigned slow_mask) {
     int64_t n_ext = 0;
     unsigned ovf = 0;
     int64_t n_items = (int64_t)sc[pass == 1 ? SC_SLOT1 : SC_SLOT2];
@@ -447,8 +439,8 @@ bwd_body(const DevIndex &ix, const SeedParams &sp, int pass, const uint8_t *__re
     int64_t ck = 0, cl = 0, cs = 0; int cn = 0;                // the candidate being extended
     int64_t fk = 0, fl = 0, fs = 0; int fn = 0;                // first survivor of the current row
     uint4 nxt_raw4 = {};                                       // the candidate after the current one, requested one round ahead
-    int64_t dk = 0, dl = 0, ds = 0; int dn = 0; bool have_b = false; uint4 nxt_rawb = {};     // ILP 2: the second candidate of the round, and the one after next
-    int em = 0;                                                // an SMEM to write out: 1 = the candidate, 2 = the first survivor, 3 = the round's second candidate
+    int em = 0;                                                // an SMEM to write out (state B_EM): 1 = the candidate, 2 = the first survivor
+    unsigned rnd = 0;                                          // (wave-uniform)
     QWin w; w.cur = w.nxt = 0; w.curb = w.nxtb = -64;
     auto entry = [&](int idx) -> uint4 * { return idx < CAPF ? lst + idx : lpool + (idx - CAPF); };
     // survivors at depth 1..LC below the top of the list live in LDS ([depth][lane]); deeper ones go back to the slot
@@ -463,10 +455,38 @@ bwd_body(const DevIndex &ix, const SeedParams &sp, int pass, const uint8_t *__re
         }
         return v;
     };
+    auto advance = [&]() {                                     // on to the next candidate of the row
+        p++;
+        if (p < n_prev) {
+            pv_unpack(nxt_raw4, ck, cl, cs, cn);
+            if (p + 1 < n_prev) nxt_raw4 = cand_load(p + 1);
+            state = B_EXT;
+        } else state = B_ROWEND;
+    };
 
-    for (;;) {
+    for (;; rnd++) {
+        const bool slow = (rnd & slow_mask) == 0;
         while (state != B_EXT && state != B_DONE) {            // `break` = yield
+            if (state == B_EM) {                                // one SMEM: record, per-read count, pass-2 task
+                if (!slow) break;
+                const int64_t ek = em == 1 ? ck : fk, el = em == 1 ? cl : fl, es = em == 1 ? cs : fs;
+                const int en = em == 1 ? cn : fn;
+                const int64_t at = wave_alloc<REC_BATCH>(rp, sc + SC_REC);
+                if (at < rec_cap) {
+                    bm2_smem_t v; v.rid = (uint32_t)r; v.m = (uint32_t)m_row; v.n = (uint32_t)en; v.pad = 0; v.k = ek; v.l = el; v.s = es;
+                    recs[at] = v;
+                    atomicAdd(&smem_cnt[r], 1);
+                } else ovf |= OVF_REC;
+                if (pass == 1 && (en + 1 - m_row) >= sp.split_len && es <= (int64_t)sp.split_width) {       // bwamem.cpp:701-703
+                    const int64_t ta = wave_alloc<TASK_BATCH>(tp, sc + SC_TASK);
+                    if (ta < task_cap) { P2Task t; t.rd_off = (int64_t)(q - enc); t.r = r; t.L = L; t.x = (en + 1 + m_row) >> 1; t.s = (int32_t)es; t.pad = 0; tasks[ta] = t; }
+                    else ovf |= OVF_TASK;
+                }
+                if (em == 1) { em = 0; advance(); if (state == B_EXT) break; }      // (B_EXT: straight into this round's extension)
+                else { em = 0; state = B_NEWITEM; }
+            }
             if (state == B_NEWITEM) {
+                if (!slow) break;
                 if (it_a >= n_items) { state = B_DONE; break; }
                 const BHead h = pl;
                 const int64_t slot = it_a;
@@ -512,6 +532,8 @@ bwd_body(const DevIndex &ix, const SeedParams &sp, int pass, const uint8_t *__re
                         t.slot = (int32_t)slot; t.pad0 = t.pad1 = t.pad2 = 0;
                         ctasks[cid] = t;
                         state = B_NEWITEM;
+                        if (!slow) break;
+                        continue;
                     } else { m_row = j; j--; row0 = false; state = B_ROW; }
                 }
                 else { m_row = j; j--; row0 = false; state = B_ROW; }
@@ -523,88 +545,38 @@ bwd_body(const DevIndex &ix, const SeedParams &sp, int pass, const uint8_t *__re
                 else {
                     n_curr = 0; curr_s = -1; p = 0; first_done = false;
                     ck = fk; cl = fl; cs = fs; cn = fn;
-                    if constexpr (ILP == 2) {
-                        have_b = false;
-                        if (n_prev > 1) {
-                            if (!row0) {                        // the previous row's survivors are in LDS: the second candidate is at hand
-                                pv_unpack(cand_load(1), dk, dl, ds, dn); have_b = true;
-                                if (n_prev > 2) nxt_raw4 = cand_load(2);
-                                if (n_prev > 3) nxt_rawb = cand_load(3);
-                            } else {                            // the walk's list is in global memory: the row's first round takes one candidate
-                                nxt_raw4 = cand_load(1);
-                                if (n_prev > 2) nxt_rawb = cand_load(2);
-                            }
-                        }
-                    } else if (n_prev > 1) nxt_raw4 = cand_load(1);
+                    if (n_prev > 1) nxt_raw4 = cand_load(1);
                     state = B_EXT;
                 }
             }
             if (state == B_FIN) {                               // :656-665
-                if (n_prev != 0 && (fn - m_row + 1) >= sp.min_seed_len) em = 2;
-                state = B_NEWITEM;
-                if (em) break;                                  // write it out below, then look for work
+                if (n_prev != 0 && (fn - m_row + 1) >= sp.min_seed_len) { em = 2; state = B_EM; }
+                else state = B_NEWITEM;
+                if (!slow) break;                               // (both are rare steps: next slow round)
             }
         }
-        if (!__any(state != B_DONE || em)) break;
+        if (!__any(state != B_DONE)) break;
 #ifdef BM2_SMEM_PROF
         if ((threadIdx.x & 63) == 0) prof_rounds++;
         if (state == B_EXT) prof_active++;
 #endif
         const Bi ein = { ck, cl, cs };
-        Bi o, ob = { 0, 0, 0 };
-        if constexpr (ILP == 2) { const Bi einb = { dk, dl, ds }; backward_ext2(ix, ein, einb, a, state == B_EXT, state == B_EXT && have_b, o, ob); }
-        else o = backward_ext(ix, ein, a, state == B_EXT);        // (all lanes: quad-cooperative)
-        auto judge = [&](const Bi &o_, int cn_, int em_code) {   // :607-649 for one candidate
+        const Bi o = backward_ext(ix, ein, a, state == B_EXT);    // (all lanes: quad-cooperative)
+        if (state == B_EXT) {                                   // :607-649
             n_ext++; age++;
-            if (!first_done && o_.s < (int64_t)min_intv && (cn_ - m_row + 1) >= sp.min_seed_len) {
-                em = em_code;
+            if (!first_done && o.s < (int64_t)min_intv && (cn - m_row + 1) >= sp.min_seed_len) {
+                em = 1; state = B_EM;                            // (written out in the next slow round; the lane goes on from there)
                 first_done = true;
-            } else if (o_.s >= (int64_t)min_intv && o_.s != (int64_t)curr_s) {
-                curr_s = (int32_t)o_.s;
-                if (n_curr == 0) { fk = o_.k; fl = o_.l; fs = o_.s; fn = cn_; }
-                else if (n_curr <= LC) surv[(n_curr - 1) * 256 + threadIdx.x] = pv_pack(o_.k, o_.l, o_.s, cn_);
-                else *entry(top - n_curr) = pv_pack(o_.k, o_.l, o_.s, cn_);
-                n_curr++;
-                first_done = true;
-            }
-        };
-        if (state == B_EXT) {
-            judge(o, cn, 1);
-            if constexpr (ILP == 2) if (have_b) judge(ob, dn, 3);
-        }
-        if (em) {                                               // one SMEM: record, per-read count, pass-2 task
-            int64_t ek = em == 1 ? ck : fk, el = em == 1 ? cl : fl, es = em == 1 ? cs : fs;
-            int en = em == 1 ? cn : fn;
-            if constexpr (ILP == 2) if (em == 3) { ek = dk; el = dl; es = ds; en = dn; }
-            em = 0;
-            const int64_t at = wave_alloc<REC_BATCH>(rp, sc + SC_REC);
-            if (at < rec_cap) {
-                bm2_smem_t v; v.rid = (uint32_t)r; v.m = (uint32_t)m_row; v.n = (uint32_t)en; v.pad = 0; v.k = ek; v.l = el; v.s = es;
-                recs[at] = v;
-                atomicAdd(&smem_cnt[r], 1);
-            } else ovf |= OVF_REC;
-            if (pass == 1 && (en + 1 - m_row) >= sp.split_len && es <= (int64_t)sp.split_width) {       // bwamem.cpp:701-703
-                const int64_t ta = wave_alloc<TASK_BATCH>(tp, sc + SC_TASK);
-                if (ta < task_cap) { P2Task t; t.rd_off = (int64_t)(q - enc); t.r = r; t.L = L; t.x = (en + 1 + m_row) >> 1; t.s = (int32_t)es; t.pad = 0; tasks[ta] = t; }
-                else ovf |= OVF_TASK;
-            }
-        }
-        if (state == B_EXT) {                                   // on to the next candidate(s) of the row
-            if constexpr (ILP == 2) {
-                p += have_b ? 2 : 1;
-                if (p < n_prev) {
-                    pv_unpack(nxt_raw4, ck, cl, cs, cn);
-                    have_b = p + 1 < n_prev;
-                    if (have_b) pv_unpack(nxt_rawb, dk, dl, ds, dn);
-                    if (p + 2 < n_prev) nxt_raw4 = cand_load(p + 2);
-                    if (p + 3 < n_prev) nxt_rawb = cand_load(p + 3);
-                } else state = B_ROWEND;
             } else {
-                p++;
-                if (p < n_prev) {
-                    pv_unpack(nxt_raw4, ck, cl, cs, cn);
-                    if (p + 1 < n_prev) nxt_raw4 = cand_load(p + 1);
-                } else state = B_ROWEND;
+                if (o.s >= (int64_t)min_intv && o.s != (int64_t)curr_s) {
+                    curr_s = (int32_t)o.s;
+                    if (n_curr == 0) { fk = o.k; fl = o.l; fs = o.s; fn = cn; }
+                    else if (n_curr <= LC) surv[(n_curr - 1) * 256 + threadIdx.x] = pv_pack(o.k, o.l, o.s, cn);
+                    else *entry(top - n_curr) = pv_pack(o.k, o.l, o.s, cn);
+                    n_curr++;
+                    first_done = true;
+                }
+                advance();
             }
         }
     }
@@ -622,13 +594,13 @@ bwd_body(const DevIndex &ix, const SeedParams &sp, int pass, const uint8_t *__re
 #define BWD_ARGS DevIndex ix, SeedParams sp, int pass, const uint8_t *__restrict__ enc, const BHead *__restrict__ heads, uint4 *__restrict__ ents, \
                  int64_t slot_cap, uint4 *__restrict__ pool, int pool_cap, int pool_slots, bm2_smem_t *__restrict__ recs, int64_t rec_cap, \
                  P2Task *__restrict__ tasks, int64_t task_cap, int32_t *__restrict__ smem_cnt, unsigned long long *sc, \
-                 CTask *__restrict__ ctasks, int64_t cont_cap, int export_age
-#define BWD_PASS ix, sp, pass, enc, heads, ents, slot_cap, pool, pool_cap, pool_slots, recs, rec_cap, tasks, task_cap, smem_cnt, sc, ctasks, cont_cap, export_age
-template <int LC> __global__ void __launch_bounds__(256) k_bwd(BWD_ARGS) { bwd_body<LC, 1>(BWD_PASS); }     // 111 VGPRs: 4 waves per SIMD
+                 CTask *__restrict__ ctasks, int64_t cont_cap, int export_age, unsigned slow_mask
+#define BWD_PASS ix, sp, pass, enc, heads, ents, slot_cap, pool, pool_cap, pool_slots, recs, rec_cap, tasks, task_cap, smem_cnt, sc, ctasks, cont_cap, export_age, slow_mask
+template <int LC> __global__ void __launch_bounds__(256) k_bwd(BWD_ARGS) { bwd_body<LC>(BWD_PASS); }
 // the same with the register allocation told to leave room for 5 waves per SIMD (96 VGPRs, 100 bytes per lane spilled)
-template <int LC> __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) k_bwd5(BWD_ARGS) { bwd_body<LC, 1>(BWD_PASS); }
-// two candidates of a row per round (BM2_BWD_ILP=2)
-template <int LC> __global__ void __launch_bounds__(256) k_bwd_ilp2(BWD_ARGS) { bwd_body<LC, 2>(BWD_PASS); }
+template <int LC> __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) k_bwd5(BWD_ARGS) { bwd_body<LC>(BWD_PASS); }
+// (k_bwd_ilp2 -- two candidates of a row per round, sixteen requests of a quad in flight, 161 VGPRs -- was bit-exact and bought nothing:
+//  bwd1 + bwd2 23.5 ms with it, 23.9 without, profiles/r05b_sweep.json: the kernel is bound by the instructions it issues, not by lines in flight; removed)
 
 // lanes of one wavefront handing data to each other through LDS: order the accesses (the hardware runs them in lockstep)
 static __device__ __forceinline__ void wave_sync() {
@@ -1160,6 +1132,7 @@ int bm2_launch_seeding(bm2_ctx *c, const SeedParams &sp, int n_reads, const uint
     const int grid_heavy = c->n_cu * 4;
     // k_bwd hands a task that has had this many extensions over to the wavefront-per-task kernel at its next row boundary (0 = never)
     const int export_age = bm2_knob("BM2_BWD_EXPORT_AGE", BWD_EXPORT_AGE);
+    const unsigned walk_slow = (unsigned)bm2_knob("BM2_WALK_SLOW", WALK_SLOW_MASK);
     // pass 3 is independent of passes 1 and 2: it runs beside them.  WHERE is launch policy (BM2_P3_AT): 0 = beside the forward walks of
     // pass 1 (both are forward-only kernels without LDS lists: they compete for the same wave slots), 1 / 2 = beside the backward kernel of
     // pass 1 / 2, whose blocks hold 48 KB of LDS survivors and leave wave slots empty that a kernel without LDS can use
@@ -1173,7 +1146,7 @@ int bm2_launch_seeding(bm2_ctx *c, const SeedParams &sp, int n_reads, const uint
         (void)hipStreamWaitEvent(s3, c->ev_fork, 0);
         hipLaunchKernelGGL(k_walk<W_P3>, dim3(grid_p3), dim3(256), 0, s3, c->ix, sp, n_reads, enc, off, len, (const P2Task *)nullptr, (int64_t)0,
                            (BHead *)nullptr, (uint4 *)nullptr, (int64_t)0, (uint4 *)nullptr, 0, 0, sb.recs, sb.rec_cap, smem_cnt, sc,
-                           (int32_t *)nullptr, (int64_t)0);
+                           (int32_t *)nullptr, (int64_t)0, walk_slow);
         (void)hipEventRecord(c->ev_join[0], s3);
     };
     if (p3_at <= 0 || p3_at > 2) launch_p3();
@@ -1184,10 +1157,10 @@ int bm2_launch_seeding(bm2_ctx *c, const SeedParams &sp, int n_reads, const uint
         int32_t *heavy = pass == 1 ? sb.heavy1 : sb.heavy2;
         if (pass == 1)
             hipLaunchKernelGGL(k_walk<W_P1>, dim3(grid_walk), dim3(256), 0, s, c->ix, sp, n_reads, enc, off, len, (const P2Task *)nullptr, (int64_t)0,
-                               heads, ents, slot_cap, sb.pool, sb.pool_cap, sb.pool_slots, sb.recs, sb.rec_cap, smem_cnt, sc, heavy, sb.heavy_cap);
+                               heads, ents, slot_cap, sb.pool, sb.pool_cap, sb.pool_slots, sb.recs, sb.rec_cap, smem_cnt, sc, heavy, sb.heavy_cap, walk_slow);
         else
             hipLaunchKernelGGL(k_walk<W_P2>, dim3(grid_walk), dim3(256), 0, s, c->ix, sp, n_reads, enc, off, len, sb.tasks, sb.task_cap,
-                               heads, ents, slot_cap, sb.pool, sb.pool_cap, sb.pool_slots, sb.recs, sb.rec_cap, smem_cnt, sc, heavy, sb.heavy_cap);
+                               heads, ents, slot_cap, sb.pool, sb.pool_cap, sb.pool_slots, sb.recs, sb.rec_cap, smem_cnt, sc, heavy, sb.heavy_cap, walk_slow);
         tick(c, pass == 1 ? "smem.walk1" : "smem.walk2");
         if (p3_at == pass) launch_p3();
         // the long lists go to one wavefront each, beside the lane-per-task kernel
@@ -1201,10 +1174,9 @@ int bm2_launch_seeding(bm2_ctx *c, const SeedParams &sp, int n_reads, const uint
         const int lc = bm2_knob("BM2_BWD_LCAP", LCAP), wpe = bm2_knob("BM2_BWD_WAVES", 4);
         auto kb = wpe >= 5 ? (lc <= 4 ? k_bwd5<4> : k_bwd5<6>)
                            : (lc <= 4 ? k_bwd<4> : lc <= 6 ? k_bwd<6> : lc <= 8 ? k_bwd<8> : k_bwd<LCAP>);
-        if (bm2_knob("BM2_BWD_ILP", BWD_ILP) == 2) kb = lc <= 8 ? k_bwd_ilp2<8> : k_bwd_ilp2<LCAP>;
         CTask *cont = (CTask *)(pass == 1 ? sb.cont1 : sb.cont2);
         hipLaunchKernelGGL(kb, dim3(grid_bwd), dim3(256), 0, s, c->ix, sp, pass, enc, heads, ents, slot_cap, sb.pool, sb.pool_cap,
-                           sb.pool_slots, sb.recs, sb.rec_cap, sb.tasks, sb.task_cap, smem_cnt, sc, cont, sb.cont_cap, export_age);
+                           sb.pool_slots, sb.recs, sb.rec_cap, sb.tasks, sb.task_cap, smem_cnt, sc, cont, sb.cont_cap, export_age, (unsigned)bm2_knob("BM2_BWD_SLOW", BWD_SLOW_MASK));
         if (!heavy_after) (void)hipStreamWaitEvent(s, c->ev_join[1], 0);
         else hipLaunchKernelGGL(k_bwd_heavy, dim3(grid_heavy * 2), dim3(256), 0, s, c->ix, sp, pass, enc, heads, ents, slot_cap, sb.pool, sb.pool_cap,
                                 sb.pool_slots, heavy, sb.heavy_cap, sb.recs, sb.rec_cap, sb.tasks, sb.task_cap, smem_cnt, sc);

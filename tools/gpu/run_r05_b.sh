@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 5, call B: the hand-over with its own continuation kernel (k_bwd_cont), two candidates per round in k_bwd (BM2_BWD_ILP=2), the cooperative
+# Round 5, calls B and C: the hand-over with its own continuation kernel (k_bwd_cont), the rare steps of the seeding lanes in every (mask + 1)-th round,
 # chain filter with wavefront-scope fences: parity test of every setting, then timed on the 3100 Mbp bench chunk in one process, then a kernel trace
 # of the bench with the sweep's best settings.
 #   gpurun --timeout 900 -- 'bash tools/gpu/run_r05_b.sh r05b'
@@ -8,7 +8,7 @@ cd $R; export TMPDIR=/tmp
 T0=$(date +%s); at() { echo "$1 rc=$2 at $(( $(date +%s) - T0 ))s"; }
 timeout 500 python -m pytest tests/test_pipeline_gpu.py -m gpu -x -q -k "off_by_default" > $O/pytest_knobs.log 2>&1; at pytest $?
 tail -5 $O/pytest_knobs.log
-timeout 420 python tools/gpu/sweep.py $O --steps 4 --budget-s 300 --only "seeding:,kept-chain walk" > $O/sweep.log 2>&1; at sweep $?
+timeout 420 python tools/gpu/sweep.py $O --steps 4 --budget-s 300 --only "seeding:" > $O/sweep.log 2>&1; at sweep $?
 grep "\[sweep\]" $O/sweep.log | tail -40
 cd /tmp
 set -a; [ -f $O/best_env.sh ] && . $O/best_env.sh; set +a
