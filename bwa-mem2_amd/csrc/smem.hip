@@ -159,7 +159,7 @@ struct __attribute__((aligned(16))) P2Task {      // pass-2 forward walk (32 byt
     int32_t r, L, x, s;
     int64_t pad;
 };
-struct __attribute__((aligned(16))) CTask {       // a backward task k_bwd handed over at a row boundary (48 bytes): its header as the continuation reads it + its slot
+struct __attribute__((aligned(16))) CTask {       // a backward task k_bwd handed over at a row boundary (48 bytes, read by k_bwd_cont as three 16-byte words): its header as the continuation reads it + its slot
     BHead h;                      // x_np: the row just finished | the survivors' count << 16; pad: index of the list's first entry + 1
     int32_t slot, pad0, pad1, pad2;
 };
@@ -193,9 +193,7 @@ static __device__ __forceinline__ int64_t wave_alloc(LdsPool *wp, unsigned long 
 #define HCAP 256                  // ... if the list fits its LDS row (else they stay lane-per-task)
 #define HEAVY_BATCH 64
 #define CONT_BATCH 64                 // ids of handed-over tasks a wave of k_bwd takes at a time (wave_alloc: a batch must cover the 64 lanes that may ask at once)
-#define BWD_EXPORT_AGE 0              // (default of BM2_BWD_EXPORT_AGE)
-#define WALK_SLOW_MASK 0              // (default of BM2_WALK_SLOW: the same for the forward walks)
-#define BWD_SLOW_MASK 0               // (default of BM2_BWD_SLOW: the rare steps of a k_bwd lane in every (mask + 1)-th round)
+#define BWD_EXPORT_AGE 256             // (default of BM2_BWD_EXPORT_AGE)
 #define ITEM_BATCH 64
 #define SLOT_BATCH 256
 #define REC_BATCH 256
@@ -245,7 +243,7 @@ struct QWin {
 // ---- forward walks ----------------------------------------------------------------------------------------------
 // MODE W_P1: item = read; chain of start positions, every walk leaves a backward task.  W_P2: item = P2Task, one walk.
 // W_P3: item = read; forward-only seeding, SMEM records written directly.
-enum { F_EXT = 0, F_NEWITEM, F_START, F_NEWPOS, F_CHK, F_END, F_REC, F_DONE };
+enum { F_EXT = 0, F_NEWITEM, F_START, F_NEWPOS, F_CHK, F_END, F_DONE };
 
 template <int MODE>
 __global__ void __launch_bounds__(256)
@@ -253,7 +251,7 @@ k_walk(DevIndex ix, SeedParams sp, int n_reads, const uint8_t *__restrict__ enc,
        const int32_t *__restrict__ len, const P2Task *__restrict__ tasks, int64_t task_cap,
        BHead *__restrict__ heads, uint4 *__restrict__ ents, int64_t slot_cap, uint4 *__restrict__ pool, int pool_cap, int pool_slots,
        bm2_smem_t *__restrict__ recs, int64_t rec_cap, int32_t *__restrict__ smem_cnt, unsigned long long *sc,
-       int32_t *__restrict__ heavy_ids, int64_t heavy_cap, unsigned slow_mask) {      // slow_mask: see bwd_body
+       int32_t *__restrict__ heavy_ids, int64_t heavy_cap) {
     int64_t n_ext = 0;
     unsigned ovf = 0;
     int64_t n_items;
@@ -292,21 +290,9 @@ k_walk(DevIndex ix, SeedParams sp, int n_reads, const uint8_t *__restrict__ enc,
         n_prev++;
     };
 
-    for (unsigned rnd = 0;; rnd++) {
-        const bool slow = (rnd & slow_mask) == 0;             // the rare steps of a lane (a new item, closing a walk, a record) wait for such a round
+    for (;;) {
         while (state != F_EXT && state != F_DONE) {            // `break` = yield: sit out one extension round
-            if (MODE == W_P3 && state == F_REC) {               // :771-808: the SMEM of this start position
-                if (!slow) break;
-                const int64_t at = wave_alloc<REC_BATCH>(op, out_cur);
-                if (at < rec_cap) {
-                    bm2_smem_t v; v.rid = (uint32_t)r; v.m = (uint32_t)x; v.n = (uint32_t)smn; v.pad = 0; v.k = smk; v.l = sml; v.s = sms;
-                    recs[at] = v;
-                    atomicAdd(&smem_cnt[r], 1);
-                } else ovf |= OVF_REC;
-                x = next_x; state = F_NEWPOS;
-            }
             if (state == F_NEWITEM) {
-                if (!slow) break;
                 if (it_a >= n_items) { state = F_DONE; break; }
                 if (MODE == W_P2) { r = pl_t.r; rd_off = pl_t.rd_off; L = pl_t.L; x = pl_t.x; min_intv = (int64_t)pl_t.s + 1; }
                 else { r = (int32_t)it_a; rd_off = pl_off; L = pl_len; x = 0; min_intv = 1; }
@@ -319,7 +305,6 @@ k_walk(DevIndex ix, SeedParams sp, int n_reads, const uint8_t *__restrict__ enc,
                 state = F_NEWPOS; break;
             }
             if (state == F_NEWPOS) {                            // FMI_search.cpp:514-535 / :746-755
-                if (MODE != W_P3 && !slow) break;               // (it draws a task slot)
                 if (MODE != W_P2 && x >= L) { state = F_NEWITEM; continue; }
                 if (!w.get(q, x, 1, a)) break;
                 next_x = x + 1;
@@ -343,7 +328,6 @@ k_walk(DevIndex ix, SeedParams sp, int n_reads, const uint8_t *__restrict__ enc,
             }
             if (state == F_END) {
                 if (MODE == W_P3) { x = next_x; state = F_NEWPOS; continue; }
-                if (!slow) break;
                 if (sms >= min_intv) push(pv_pack(smk, sml, sms, smn));                      // :576-580
                 if (slot < slot_cap) {
                     bool heavy = n_prev > HEAVY_T && n_prev <= HCAP;              // long list: a whole wave will take this task
@@ -370,8 +354,15 @@ k_walk(DevIndex ix, SeedParams sp, int n_reads, const uint8_t *__restrict__ enc,
             if (MODE == W_P3) {                                 // :771-808
                 smk = o.l; sml = o.k; sms = o.s; smn = j;
                 if (sms < sp.max_mem_intv && (smn - x + 1) >= sp.min_seed_len + 1) {
-                    if (sms > 0) state = F_REC;
-                    else { x = next_x; state = F_NEWPOS; }
+                    if (sms > 0) {
+                        const int64_t at = wave_alloc<REC_BATCH>(op, out_cur);
+                        if (at < rec_cap) {
+                            bm2_smem_t v; v.rid = (uint32_t)r; v.m = (uint32_t)x; v.n = (uint32_t)smn; v.pad = 0; v.k = smk; v.l = sml; v.s = sms;
+                            recs[at] = v;
+                            atomicAdd(&smem_cnt[r], 1);
+                        } else ovf |= OVF_REC;
+                    }
+                    x = next_x; state = F_NEWPOS;
                 } else { j++; state = F_CHK; }
             } else {
                 if (o.s != sms) push(pv_pack(smk, sml, sms, smn));
@@ -399,21 +390,15 @@ k_walk(DevIndex ix, SeedParams sp, int n_reads, const uint8_t *__restrict__ enc,
 // and is compacted in place: it is read top-down (longest candidate first = the reversal of :586-592), the survivors
 // of a row are written top-down behind the reader, the next candidate is requested while the current one is extended,
 // and the first survivor of a row -- the first candidate of the next row -- never leaves the registers.
-enum { B_EXT = 0, B_NEWITEM, B_FIRST, B_ROWEND, B_ROW, B_FIN, B_EM, B_DONE };
+enum { B_EXT = 0, B_NEWITEM, B_FIRST, B_ROWEND, B_ROW, B_FIN, B_DONE };
 
 // LC: survivors of a row kept in LDS per lane (16 B x LC x 256 lanes per block decides how many blocks share a CU's 160 KB)
-// LC: survivors of a row kept in LDS per lane (16 B x LC x 256 lanes per block decides how many blocks share a CU's 160 KB).
-// slow_mask: the RARE steps of a lane -- taking a new task, writing an SMEM out -- are taken only in rounds whose number has no bit of the mask
-// set (0: every round).  A wavefront executes a block of the state machine whenever ONE of its lanes is in that state, and with 64 lanes "once
-// per task" is every other round: the kernel issues ~700 instructions per round of which the extension itself is 220 -- and its wavefronts issue
-// in 3/4 of all cycles (profiles/r04p_pmc_sq_steady.md: SQ_ACTIVE_INST_ANY).  Served every fourth round, the rare blocks cost a lane 1.5 rounds of
-// waiting per use and the wavefront three quarters of their instructions.
 template <int LC>
 static __device__ __forceinline__ void
 bwd_body(const DevIndex &ix, const SeedParams &sp, int pass, const uint8_t *__restrict__ enc, const BHead *__restrict__ heads,
          uint4 *__restrict__ ents, int64_t slot_cap, uint4 *__restrict__ pool, int pool_cap, int pool_slots,
          bm2_smem_t *__restrict__ recs, int64_t rec_cap, P2Task *__restrict__ tasks, int64_t task_cap,
-         int32_t *__restrict__ smem_cnt, unsigned long long *sc, CTask *__restrict__ ctasks, int64_t cont_cap, int export_age, unsigned slow_mask) {
+         int32_t *__restrict__ smem_cnt, unsigned long long *sc, CTask *__restrict__ ctasks, int64_t cont_cap, int export_age) {
     int64_t n_ext = 0;
     unsigned ovf = 0;
     int64_t n_items = (int64_t)sc[pass == 1 ? SC_SLOT1 : SC_SLOT2];
@@ -439,8 +424,7 @@ bwd_body(const DevIndex &ix, const SeedParams &sp, int pass, const uint8_t *__re
     int64_t ck = 0, cl = 0, cs = 0; int cn = 0;                // the candidate being extended
     int64_t fk = 0, fl = 0, fs = 0; int fn = 0;                // first survivor of the current row
     uint4 nxt_raw4 = {};                                       // the candidate after the current one, requested one round ahead
-    int em = 0;                                                // an SMEM to write out (state B_EM): 1 = the candidate, 2 = the first survivor
-    unsigned rnd = 0;                                          // (wave-uniform)
+    int em = 0;                                                // an SMEM to write out: 1 = the candidate, 2 = the first survivor
     QWin w; w.cur = w.nxt = 0; w.curb = w.nxtb = -64;
     auto entry = [&](int idx) -> uint4 * { return idx < CAPF ? lst + idx : lpool + (idx - CAPF); };
     // survivors at depth 1..LC below the top of the list live in LDS ([depth][lane]); deeper ones go back to the slot
@@ -455,38 +439,10 @@ bwd_body(const DevIndex &ix, const SeedParams &sp, int pass, const uint8_t *__re
         }
         return v;
     };
-    auto advance = [&]() {                                     // on to the next candidate of the row
-        p++;
-        if (p < n_prev) {
-            pv_unpack(nxt_raw4, ck, cl, cs, cn);
-            if (p + 1 < n_prev) nxt_raw4 = cand_load(p + 1);
-            state = B_EXT;
-        } else state = B_ROWEND;
-    };
 
-    for (;; rnd++) {
-        const bool slow = (rnd & slow_mask) == 0;
+    for (;;) {
         while (state != B_EXT && state != B_DONE) {            // `break` = yield
-            if (state == B_EM) {                                // one SMEM: record, per-read count, pass-2 task
-                if (!slow) break;
-                const int64_t ek = em == 1 ? ck : fk, el = em == 1 ? cl : fl, es = em == 1 ? cs : fs;
-                const int en = em == 1 ? cn : fn;
-                const int64_t at = wave_alloc<REC_BATCH>(rp, sc + SC_REC);
-                if (at < rec_cap) {
-                    bm2_smem_t v; v.rid = (uint32_t)r; v.m = (uint32_t)m_row; v.n = (uint32_t)en; v.pad = 0; v.k = ek; v.l = el; v.s = es;
-                    recs[at] = v;
-                    atomicAdd(&smem_cnt[r], 1);
-                } else ovf |= OVF_REC;
-                if (pass == 1 && (en + 1 - m_row) >= sp.split_len && es <= (int64_t)sp.split_width) {       // bwamem.cpp:701-703
-                    const int64_t ta = wave_alloc<TASK_BATCH>(tp, sc + SC_TASK);
-                    if (ta < task_cap) { P2Task t; t.rd_off = (int64_t)(q - enc); t.r = r; t.L = L; t.x = (en + 1 + m_row) >> 1; t.s = (int32_t)es; t.pad = 0; tasks[ta] = t; }
-                    else ovf |= OVF_TASK;
-                }
-                if (em == 1) { em = 0; advance(); if (state == B_EXT) break; }      // (B_EXT: straight into this round's extension)
-                else { em = 0; state = B_NEWITEM; }
-            }
             if (state == B_NEWITEM) {
-                if (!slow) break;
                 if (it_a >= n_items) { state = B_DONE; break; }
                 const BHead h = pl;
                 const int64_t slot = it_a;
@@ -532,8 +488,6 @@ bwd_body(const DevIndex &ix, const SeedParams &sp, int pass, const uint8_t *__re
                         t.slot = (int32_t)slot; t.pad0 = t.pad1 = t.pad2 = 0;
                         ctasks[cid] = t;
                         state = B_NEWITEM;
-                        if (!slow) break;
-                        continue;
                     } else { m_row = j; j--; row0 = false; state = B_ROW; }
                 }
                 else { m_row = j; j--; row0 = false; state = B_ROW; }
@@ -550,12 +504,12 @@ bwd_body(const DevIndex &ix, const SeedParams &sp, int pass, const uint8_t *__re
                 }
             }
             if (state == B_FIN) {                               // :656-665
-                if (n_prev != 0 && (fn - m_row + 1) >= sp.min_seed_len) { em = 2; state = B_EM; }
-                else state = B_NEWITEM;
-                if (!slow) break;                               // (both are rare steps: next slow round)
+                if (n_prev != 0 && (fn - m_row + 1) >= sp.min_seed_len) em = 2;
+                state = B_NEWITEM;
+                if (em) break;                                  // write it out below, then look for work
             }
         }
-        if (!__any(state != B_DONE)) break;
+        if (!__any(state != B_DONE || em)) break;
 #ifdef BM2_SMEM_PROF
         if ((threadIdx.x & 63) == 0) prof_rounds++;
         if (state == B_EXT) prof_active++;
@@ -565,19 +519,39 @@ bwd_body(const DevIndex &ix, const SeedParams &sp, int pass, const uint8_t *__re
         if (state == B_EXT) {                                   // :607-649
             n_ext++; age++;
             if (!first_done && o.s < (int64_t)min_intv && (cn - m_row + 1) >= sp.min_seed_len) {
-                em = 1; state = B_EM;                            // (written out in the next slow round; the lane goes on from there)
+                em = 1;
                 first_done = true;
-            } else {
-                if (o.s >= (int64_t)min_intv && o.s != (int64_t)curr_s) {
-                    curr_s = (int32_t)o.s;
-                    if (n_curr == 0) { fk = o.k; fl = o.l; fs = o.s; fn = cn; }
-                    else if (n_curr <= LC) surv[(n_curr - 1) * 256 + threadIdx.x] = pv_pack(o.k, o.l, o.s, cn);
-                    else *entry(top - n_curr) = pv_pack(o.k, o.l, o.s, cn);
-                    n_curr++;
-                    first_done = true;
-                }
-                advance();
+            } else if (o.s >= (int64_t)min_intv && o.s != (int64_t)curr_s) {
+                curr_s = (int32_t)o.s;
+                if (n_curr == 0) { fk = o.k; fl = o.l; fs = o.s; fn = cn; }
+                else if (n_curr <= LC) surv[(n_curr - 1) * 256 + threadIdx.x] = pv_pack(o.k, o.l, o.s, cn);
+                else *entry(top - n_curr) = pv_pack(o.k, o.l, o.s, cn);
+                n_curr++;
+                first_done = true;
             }
+        }
+        if (em) {                                               // one SMEM: record, per-read count, pass-2 task
+            const int64_t ek = em == 1 ? ck : fk, el = em == 1 ? cl : fl, es = em == 1 ? cs : fs;
+            const int en = em == 1 ? cn : fn;
+            em = 0;
+            const int64_t at = wave_alloc<REC_BATCH>(rp, sc + SC_REC);
+            if (at < rec_cap) {
+                bm2_smem_t v; v.rid = (uint32_t)r; v.m = (uint32_t)m_row; v.n = (uint32_t)en; v.pad = 0; v.k = ek; v.l = el; v.s = es;
+                recs[at] = v;
+                atomicAdd(&smem_cnt[r], 1);
+            } else ovf |= OVF_REC;
+            if (pass == 1 && (en + 1 - m_row) >= sp.split_len && es <= (int64_t)sp.split_width) {       // bwamem.cpp:701-703
+                const int64_t ta = wave_alloc<TASK_BATCH>(tp, sc + SC_TASK);
+                if (ta < task_cap) { P2Task t; t.rd_off = (int64_t)(q - enc); t.r = r; t.L = L; t.x = (en + 1 + m_row) >> 1; t.s = (int32_t)es; t.pad = 0; tasks[ta] = t; }
+                else ovf |= OVF_TASK;
+            }
+        }
+        if (state == B_EXT) {                                   // on to the next candidate of the row
+            p++;
+            if (p < n_prev) {
+                pv_unpack(nxt_raw4, ck, cl, cs, cn);
+                if (p + 1 < n_prev) nxt_raw4 = cand_load(p + 1);
+            } else state = B_ROWEND;
         }
     }
     for (int64_t at = rp->pos + (threadIdx.x & 63); at < rp->end; at += 64) if (at < rec_cap) recs[at].rid = 0xffffffffu;
@@ -594,13 +568,16 @@ bwd_body(const DevIndex &ix, const SeedParams &sp, int pass, const uint8_t *__re
 #define BWD_ARGS DevIndex ix, SeedParams sp, int pass, const uint8_t *__restrict__ enc, const BHead *__restrict__ heads, uint4 *__restrict__ ents, \
                  int64_t slot_cap, uint4 *__restrict__ pool, int pool_cap, int pool_slots, bm2_smem_t *__restrict__ recs, int64_t rec_cap, \
                  P2Task *__restrict__ tasks, int64_t task_cap, int32_t *__restrict__ smem_cnt, unsigned long long *sc, \
-                 CTask *__restrict__ ctasks, int64_t cont_cap, int export_age, unsigned slow_mask
-#define BWD_PASS ix, sp, pass, enc, heads, ents, slot_cap, pool, pool_cap, pool_slots, recs, rec_cap, tasks, task_cap, smem_cnt, sc, ctasks, cont_cap, export_age, slow_mask
+                 CTask *__restrict__ ctasks, int64_t cont_cap, int export_age
+#define BWD_PASS ix, sp, pass, enc, heads, ents, slot_cap, pool, pool_cap, pool_slots, recs, rec_cap, tasks, task_cap, smem_cnt, sc, ctasks, cont_cap, export_age
 template <int LC> __global__ void __launch_bounds__(256) k_bwd(BWD_ARGS) { bwd_body<LC>(BWD_PASS); }
 // the same with the register allocation told to leave room for 5 waves per SIMD (96 VGPRs, 100 bytes per lane spilled)
 template <int LC> __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) k_bwd5(BWD_ARGS) { bwd_body<LC>(BWD_PASS); }
-// (k_bwd_ilp2 -- two candidates of a row per round, sixteen requests of a quad in flight, 161 VGPRs -- was bit-exact and bought nothing:
-//  bwd1 + bwd2 23.5 ms with it, 23.9 without, profiles/r05b_sweep.json: the kernel is bound by the instructions it issues, not by lines in flight; removed)
+// Measured in round 5 and removed (profiles/r05b_sweep.json, r05c_sweep_slow_rounds.json): (1) two candidates of a row per round (sixteen requests of a quad
+// in flight, 161 VGPRs): bwd1 + bwd2 23.5 ms with it, 23.9 without -- lines in flight are not what binds the kernel; (2) the rare steps of a lane (new
+// task, SMEM record) only in every 2nd / 4th / 8th round, so that a wavefront pays for those blocks of the state machine less often: -0.8 ms at every
+// 4th round, and the restructured loops cost more than that in default form (phi copies of prefetched registers at the loop header: a
+// `s_waitcnt vmcnt(0)` per round; k_walk<3> 3.3 -> 17 ms)
 
 // lanes of one wavefront handing data to each other through LDS: order the accesses (the hardware runs them in lockstep)
 static __device__ __forceinline__ void wave_sync() {
@@ -771,8 +748,10 @@ k_bwd_cont(DevIndex ix, SeedParams sp, int pass, const uint8_t *__restrict__ enc
         return (int64_t)(((unsigned long long)hi << 32) | lo);
     };
     int64_t it_a = draw();
-    CTask pl = {};
-    if (it_a < n_items) pl = ctasks[it_a];
+    // (the record as three 16-byte words picked apart by hand: a struct copied out of memory stays a scratch alloca with this compiler)
+    uint4 pl0 = {}, pl1 = {}, pl2 = {};                          // {rd_off, r, L} | {x_np, mi_pass, pool_id, pad} | {slot, -, -, -}
+    auto fetch = [&](int64_t id) { const uint4 *p = (const uint4 *)(ctasks + id); pl0 = p[0]; pl1 = p[1]; pl2 = p[2]; };
+    if (it_a < n_items) fetch(it_a);
     int64_t n_ext = 0, n_rows = 0;
     unsigned ovf = 0;
     int state = C_NEWITEM;
@@ -780,7 +759,8 @@ k_bwd_cont(DevIndex ix, SeedParams sp, int pass, const uint8_t *__restrict__ enc
     int j = 0, a = 0, n_prev = 0, n_curr = 0, c0 = 0, m_row = 0, top = 0; int32_t curr_s = -1; bool first_done = false;
     int64_t min_intv = 1;
     const uint4 *src = ents, *psrc = pool;
-    uint4 e4[CCAP / 16];
+    uint4 e4a = {}, e4b = {}, e4c = {}, e4d = {};             // (four named registers: an array indexed in an unrolled loop went to scratch)
+    static_assert(CCAP == 64, "k_bwd_cont stages a task's list as four entries per lane");
     QWin w; w.cur = w.nxt = 0; w.curb = w.nxtb = -64;
     auto emit = [&](int64_t ck, int64_t cl, int64_t cs, int cn) {   // one SMEM: record, per-read count, pass-2 task (FMI_search.cpp:611-621 / :656-665)
         const int64_t at = wave_alloc<REC_BATCH>(rp, sc + SC_REC);
@@ -799,24 +779,29 @@ k_bwd_cont(DevIndex ix, SeedParams sp, int pass, const uint8_t *__restrict__ enc
         while (state != C_EXT && state != C_DONE) {            // `break` = yield: the group sits out one extension round
             if (state == C_NEWITEM) {
                 if (it_a >= n_items) { state = C_DONE; break; }
-                const CTask t = pl;
+                const uint4 t0 = pl0, t1 = pl1, t2 = pl2;
                 it_a = draw();
-                if (it_a < n_items) pl = ctasks[it_a];
-                n_prev = (int)(t.h.x_np >> 16);
-                if (t.h.r < 0 || n_prev <= 0 || n_prev > CCAP || t.slot < 0 || t.slot >= slot_cap) break;      // padding of a wave's id pool: next item
-                r = t.h.r; L = t.h.L; rd_off = t.h.rd_off; q = enc + rd_off; min_intv = (int64_t)(t.h.mi_pass & 0xffff);
-                m_row = (int)(t.h.x_np & 0xffff); j = m_row - 1; top = t.h.pad - 1;
-                src = ents + (int64_t)t.slot * CAPF;
-                psrc = pool + (int64_t)(t.h.pool_id >= 0 && t.h.pool_id < pool_slots ? t.h.pool_id : 0) * pool_cap;
-                for (int c = 0; c < CCAP / 16; c++) {            // longest first = the list read top-down
-                    const int d = gl + 16 * c, idx = top - d;
-                    if (d < n_prev) e4[c] = idx < CAPF ? src[idx] : psrc[idx - CAPF];
-                }
+                if (it_a < n_items) fetch(it_a);
+                const int32_t t_r = (int32_t)t0.z, t_slot = (int32_t)t2.x, t_pool = (int32_t)t1.z;
+                n_prev = (int)(t1.x >> 16);
+                if (t_r < 0 || n_prev <= 0 || n_prev > CCAP || t_slot < 0 || t_slot >= slot_cap) break;      // padding of a wave's id pool: next item
+                r = t_r; L = (int)t0.w; rd_off = (int64_t)((uint64_t)t0.x | (uint64_t)t0.y << 32); q = enc + rd_off; min_intv = (int64_t)(t1.y & 0xffff);
+                m_row = (int)(t1.x & 0xffff); j = m_row - 1; top = (int)t1.w - 1;
+                src = ents + (int64_t)t_slot * CAPF;
+                psrc = pool + (int64_t)(t_pool >= 0 && t_pool < pool_slots ? t_pool : 0) * pool_cap;
+                auto list_entry = [&](int d) -> uint4 { const int idx = top - d; return idx < CAPF ? src[idx] : psrc[idx - CAPF]; };      // longest first = the list read top-down
+                if (gl < n_prev) e4a = list_entry(gl);
+                if (gl + 16 < n_prev) e4b = list_entry(gl + 16);
+                if (gl + 32 < n_prev) e4c = list_entry(gl + 32);
+                if (gl + 48 < n_prev) e4d = list_entry(gl + 48);
                 if (j >= 0) w.start(q, j, -1);
                 state = C_LIST; break;
             }
             if (state == C_LIST) {
-                for (int c = 0; c < CCAP / 16; c++) if (gl + 16 * c < n_prev) lst[gl + 16 * c] = e4[c];     // (a lane reads back what it wrote itself until the first row is compacted)
+                if (gl < n_prev) lst[gl] = e4a;                 // (a lane reads back what it wrote itself until the first row is compacted)
+                if (gl + 16 < n_prev) lst[gl + 16] = e4b;
+                if (gl + 32 < n_prev) lst[gl + 32] = e4c;
+                if (gl + 48 < n_prev) lst[gl + 48] = e4d;
                 state = C_ROW;
             }
             if (state == C_ROW) {                               // :596-606
@@ -1132,7 +1117,6 @@ int bm2_launch_seeding(bm2_ctx *c, const SeedParams &sp, int n_reads, const uint
     const int grid_heavy = c->n_cu * 4;
     // k_bwd hands a task that has had this many extensions over to the wavefront-per-task kernel at its next row boundary (0 = never)
     const int export_age = bm2_knob("BM2_BWD_EXPORT_AGE", BWD_EXPORT_AGE);
-    const unsigned walk_slow = (unsigned)bm2_knob("BM2_WALK_SLOW", WALK_SLOW_MASK);
     // pass 3 is independent of passes 1 and 2: it runs beside them.  WHERE is launch policy (BM2_P3_AT): 0 = beside the forward walks of
     // pass 1 (both are forward-only kernels without LDS lists: they compete for the same wave slots), 1 / 2 = beside the backward kernel of
     // pass 1 / 2, whose blocks hold 48 KB of LDS survivors and leave wave slots empty that a kernel without LDS can use
@@ -1146,7 +1130,7 @@ int bm2_launch_seeding(bm2_ctx *c, const SeedParams &sp, int n_reads, const uint
         (void)hipStreamWaitEvent(s3, c->ev_fork, 0);
         hipLaunchKernelGGL(k_walk<W_P3>, dim3(grid_p3), dim3(256), 0, s3, c->ix, sp, n_reads, enc, off, len, (const P2Task *)nullptr, (int64_t)0,
                            (BHead *)nullptr, (uint4 *)nullptr, (int64_t)0, (uint4 *)nullptr, 0, 0, sb.recs, sb.rec_cap, smem_cnt, sc,
-                           (int32_t *)nullptr, (int64_t)0, walk_slow);
+                           (int32_t *)nullptr, (int64_t)0);
         (void)hipEventRecord(c->ev_join[0], s3);
     };
     if (p3_at <= 0 || p3_at > 2) launch_p3();
@@ -1157,10 +1141,10 @@ int bm2_launch_seeding(bm2_ctx *c, const SeedParams &sp, int n_reads, const uint
         int32_t *heavy = pass == 1 ? sb.heavy1 : sb.heavy2;
         if (pass == 1)
             hipLaunchKernelGGL(k_walk<W_P1>, dim3(grid_walk), dim3(256), 0, s, c->ix, sp, n_reads, enc, off, len, (const P2Task *)nullptr, (int64_t)0,
-                               heads, ents, slot_cap, sb.pool, sb.pool_cap, sb.pool_slots, sb.recs, sb.rec_cap, smem_cnt, sc, heavy, sb.heavy_cap, walk_slow);
+                               heads, ents, slot_cap, sb.pool, sb.pool_cap, sb.pool_slots, sb.recs, sb.rec_cap, smem_cnt, sc, heavy, sb.heavy_cap);
         else
             hipLaunchKernelGGL(k_walk<W_P2>, dim3(grid_walk), dim3(256), 0, s, c->ix, sp, n_reads, enc, off, len, sb.tasks, sb.task_cap,
-                               heads, ents, slot_cap, sb.pool, sb.pool_cap, sb.pool_slots, sb.recs, sb.rec_cap, smem_cnt, sc, heavy, sb.heavy_cap, walk_slow);
+                               heads, ents, slot_cap, sb.pool, sb.pool_cap, sb.pool_slots, sb.recs, sb.rec_cap, smem_cnt, sc, heavy, sb.heavy_cap);
         tick(c, pass == 1 ? "smem.walk1" : "smem.walk2");
         if (p3_at == pass) launch_p3();
         // the long lists go to one wavefront each, beside the lane-per-task kernel
@@ -1176,7 +1160,7 @@ int bm2_launch_seeding(bm2_ctx *c, const SeedParams &sp, int n_reads, const uint
                            : (lc <= 4 ? k_bwd<4> : lc <= 6 ? k_bwd<6> : lc <= 8 ? k_bwd<8> : k_bwd<LCAP>);
         CTask *cont = (CTask *)(pass == 1 ? sb.cont1 : sb.cont2);
         hipLaunchKernelGGL(kb, dim3(grid_bwd), dim3(256), 0, s, c->ix, sp, pass, enc, heads, ents, slot_cap, sb.pool, sb.pool_cap,
-                           sb.pool_slots, sb.recs, sb.rec_cap, sb.tasks, sb.task_cap, smem_cnt, sc, cont, sb.cont_cap, export_age, (unsigned)bm2_knob("BM2_BWD_SLOW", BWD_SLOW_MASK));
+                           sb.pool_slots, sb.recs, sb.rec_cap, sb.tasks, sb.task_cap, smem_cnt, sc, cont, sb.cont_cap, export_age);
         if (!heavy_after) (void)hipStreamWaitEvent(s, c->ev_join[1], 0);
         else hipLaunchKernelGGL(k_bwd_heavy, dim3(grid_heavy * 2), dim3(256), 0, s, c->ix, sp, pass, enc, heads, ents, slot_cap, sb.pool, sb.pool_cap,
                                 sb.pool_slots, heavy, sb.heavy_cap, sb.recs, sb.rec_cap, sb.tasks, sb.task_cap, smem_cnt, sc);

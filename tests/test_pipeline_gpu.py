@@ -144,7 +144,7 @@ def test_repeat_rich_lists_vs_oracle(gpu_ctx_factory, tmp_path):
 # classes) and a set of long ONT-like reads (island chaining, serial equal-key reads, the sliding-window extension) against the oracle.
 KNOB_SETTINGS = [
     {"BM2_BWD_EXPORT_AGE": "256"}, {"BM2_BWD_EXPORT_AGE": "24"}, {"BM2_BWD_EXPORT_AGE": "128", "BM2_BWD_HEAVY_AFTER": "1"},
-    {"BM2_BWD_SLOW": "3"}, {"BM2_BWD_SLOW": "3", "BM2_WALK_SLOW": "3", "BM2_BWD_EXPORT_AGE": "64"}, {"BM2_BWD_SLOW": "1", "BM2_WALK_SLOW": "7", "BM2_BWD_LCAP": "8", "BM2_BWD_BLOCKS_PER_CU": "4"},
+    {"BM2_BWD_EXPORT_AGE": "0"}, {"BM2_BWD_EXPORT_AGE": "64", "BM2_BWD_LCAP": "8", "BM2_BWD_BLOCKS_PER_CU": "4"}, {"BM2_BWD_CONT_BPC": "2", "BM2_BWD_EXPORT_AGE": "100"},
     {"BM2_P3_BPC": "1"}, {"BM2_P3_BPC": "2", "BM2_P3_AT": "2"},
     {"BM2_CHAIN_COOP_FLT": "1"}, {"BM2_CHAIN_COOP_FLT": "1", "BM2_CHAIN_FINE_TIERS": "1"}, {"BM2_CHAIN_CLOCK": "1"},
 ]
@@ -186,7 +186,7 @@ def test_off_by_default_knobs_keep_every_result(gpu_ctx_factory, knob_cases, mon
         _same(exp["REGPRG"], regs_to_records(regs, reg_off), "REGPRG (short reads, batch %d)" % rep)
         assert st["n_ext"] == exp["counters"]["n_ext"]
     sc = ctx.batch_fetch("seed_counters", np.uint64)
-    if "BM2_BWD_EXPORT_AGE" in env:
+    if env.get("BM2_BWD_EXPORT_AGE", "256") != "0":
         assert int(sc[21]) > 0 and int(sc[22]) > 0, "no backward task was handed over (%s)" % sc
     ctx = gpu_ctx_factory(fl)
     regs, reg_off, st = ctx.seed_chain_extend(lenc, loff, lln, bm2.default_opt(**ONT2D))

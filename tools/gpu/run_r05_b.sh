@@ -8,7 +8,7 @@ cd $R; export TMPDIR=/tmp
 T0=$(date +%s); at() { echo "$1 rc=$2 at $(( $(date +%s) - T0 ))s"; }
 timeout 500 python -m pytest tests/test_pipeline_gpu.py -m gpu -x -q -k "off_by_default" > $O/pytest_knobs.log 2>&1; at pytest $?
 tail -5 $O/pytest_knobs.log
-timeout 420 python tools/gpu/sweep.py $O --steps 4 --budget-s 300 --only "seeding:" > $O/sweep.log 2>&1; at sweep $?
+timeout 420 python tools/gpu/sweep.py $O --steps 4 --budget-s 300 --only "seeding: k_bwd hands,kept-chain walk,chain clock" > $O/sweep.log 2>&1; at sweep $?
 grep "\[sweep\]" $O/sweep.log | tail -40
 cd /tmp
 set -a; [ -f $O/best_env.sh ] && . $O/best_env.sh; set +a
