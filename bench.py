@@ -44,6 +44,7 @@ sys.path.insert(0, os.path.join(ROOT, "bwa-mem2_amd"))
 
 RANDOM_LINE_GLPS = 55.0        # measured: ~55 G independent 64-B lines/s delivered (tools/ubench/randline.hip)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+CONFIG5_READS = ["--reads", "40000"]                       # config 5's chunk inside the default line (tools/gpu/ont_scaling.py: reads/s against chunk size)
 ONT2D = dict(a=1, b=1, o_del=1, e_del=1, o_ins=1, e_ins=1, pen_clip5=0, pen_clip3=0, min_seed_len=14, min_chain_weight=20,
              split_factor=10.0)      # `-x ont2d`, fastmap.cpp:812-826
 
@@ -157,6 +158,11 @@ def cpu_baseline(prefix, fq, n_reads_desc, extra=(), out="/dev/null"):
     """Time the compiled reference on a bounded sample of the same workload, all host cores (its SAM goes to `out`: the wide parity gate
     compares it with the library's text for the same reads)."""
     err, wall, isa = run_reference_mem(prefix, fq, extra, out=out)
+    return cpu_baseline_from(err, wall, isa, n_reads_desc, extra)
+
+
+def cpu_baseline_from(err, wall, isa, n_reads_desc, extra=()):
+    """The baseline figures from the stderr of a finished `bwa-mem2 mem` run (its own per-chunk and per-kernel clocks)."""
     if err is None:
         return None
     threads = host_threads()
@@ -202,21 +208,25 @@ def sam_lines(text):
     return [l for l in text.split(b"\n") if l and not l.startswith(b"@")]
 
 
-def parity_gate(ctx, bm2, prefix, workdir, seqs, regs, reg_off, opt, opt_args, paired, n_sample, tag):
-    """The reference on the first n_sample reads of the timed chunk, same index: regs (refdump) and SAM text (bwa-mem2 mem)."""
+def parity_gate(ctx, bm2, prefix, workdir, seqs, regs, reg_off, opt, opt_args, paired, n_sample, tag, n_regs=None):
+    """The reference on the first n_sample reads of the timed chunk, same index: regs (refdump) and SAM text (bwa-mem2 mem).  n_regs: the
+    stage dumps (refdump: ONE host thread) cover only the first n_regs of them -- long reads cost it a second each -- while `bwa-mem2 mem`
+    runs all n_sample on every CPU and every one of their SAM records is compared."""
     from tools import refio, synth
     refdump, isa = ref_binary("refdump")
     exe, _ = ref_binary()
     if refdump is None or exe is None:
         return {"reads": 0, "regs_equal": None, "fin_equal": None, "sam_equal": None, "note": "oracle/_ref is not built on this box"}
     n = n_sample
-    res = {"reads": n, "sample": "first %d reads of the timed chunk (a 512-aligned prefix), reference %s build" % (n, isa)}
+    nr = min(n_regs or n, n)
+    res = {"reads": n, "sample": "first %d reads of the timed chunk (a 512-aligned prefix), reference %s build" % (n, isa) +
+                                 ("" if nr == n else "; REGPRG / REGFIN dumps of the first %d, SAM records of all %d" % (nr, n)), "regs_reads": nr}
     # --- regs: REGPRG (device boundary) and REGFIN (after mem_sort_dedup_patch)
     t = time.time()
     rtxt = os.path.join(workdir, "parity_%s.txt" % tag)
     acgtn = np.frombuffer(b"ACGTN", np.uint8)
     with open(rtxt, "wb") as f:
-        for s in seqs[:n]:
+        for s in seqs[:nr]:
             f.write(acgtn[s].tobytes() + b"\n")
     dump = os.path.join(workdir, "parity_%s.bin" % tag)
     p = subprocess.run([refdump] + list(opt_args) + [prefix, rtxt, dump], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
@@ -224,13 +234,13 @@ def parity_gate(ctx, bm2, prefix, workdir, seqs, regs, reg_off, opt, opt_args, p
         res.update(regs_equal=False, note="refdump failed: " + p.stderr[-300:])
         return res
     d = refio.read_dump(dump)
-    got = regs_records(regs, reg_off, 0, n)
+    got = regs_records(regs, reg_off, 0, nr)
     res["regs"] = int(len(got))
     res["regs_equal"] = bool(len(got) == len(d["REGPRG"]) and got.tobytes() == d["REGPRG"].tobytes())
     res["max_coord"] = int(d["REGPRG"]["re"].max()) if len(d["REGPRG"]) else 0
     res["regs_over_2p32"] = int((d["REGPRG"]["re"] >= (1 << 32)).sum())
     log("parity[%s]: refdump on %d reads in %.1fs: REGPRG equal = %s (%d regs, %d beyond 2^32)"
-        % (tag, n, time.time() - t, res["regs_equal"], len(got), res["regs_over_2p32"]))
+        % (tag, nr, time.time() - t, res["regs_equal"], len(got), res["regs_over_2p32"]))
     # --- the tail: a19 + pairing + SAM on the same prefix, from FASTQ text as the reference reads it
     t = time.time()
     if paired:
@@ -242,16 +252,17 @@ def parity_gate(ctx, bm2, prefix, workdir, seqs, regs, reg_off, opt, opt_args, p
         synth.write_fastq(f1, seqs[:n])
         fq = [f1]
     ref_sam = os.path.join(workdir, "parity_%s.ref.sam" % tag)
-    err, wall, _ = run_reference_mem(prefix, fq, opt_args, out=ref_sam)
+    err, wall, isa_mem = run_reference_mem(prefix, fq, opt_args, out=ref_sam)
     if err is None:
         res.update(sam_equal=False, note="reference mem failed")
         return res
+    res["_reference_run"] = (err, wall, isa_mem)                 # (popped by the caller: the run doubles as the CPU baseline where it is long enough)
     chunk = bm2.FastqChunk(open(fq[0], "rb").read(), open(fq[1], "rb").read() if paired else None, 0)
     try:
         sub_off = (reg_off[:n + 1] - reg_off[0]).astype(np.int64)
         sub_regs = regs[int(reg_off[0]):int(reg_off[n])]
         aln, aln_off = ctx.finish_regs(chunk, opt, sub_regs, sub_off)
-        fin = alnregs_records(aln, aln_off)
+        fin = alnregs_records(aln[:int(aln_off[nr])], aln_off[:nr + 1])
         res["fin_equal"] = bool(len(fin) == len(d["REGFIN"]) and fin.tobytes() == d["REGFIN"].tobytes())
         so = bm2.default_sam_opt(n_threads=0)
         txt = ctx.sam(chunk, opt, so, aln, aln_off, 0, paired).tobytes()
@@ -302,7 +313,9 @@ def binding_leg(workdir, prefix, n_chunks=10, n_ref_chunks=2):
     own I/O clocks, and the SAM of the reference's chunks against the same records of the binding's output (a prefix: same -K, same chunks)."""
     import hashlib
     exe, isa = ref_binary()
-    bm2_exe = os.path.join(ROOT, "oracle", "_ref", "bwa-mem2.bm2")
+    bm2_exe = os.path.join(ROOT, "oracle", "_ref", "bwa-mem2.bm2.%s" % isa)       # the binding built with the ISA of the reference binary it is timed beside
+    if not os.path.exists(bm2_exe):
+        bm2_exe = os.path.join(ROOT, "oracle", "_ref", "bwa-mem2.bm2")
     f1 = [os.path.join(workdir, "e2e_%d_1.fq" % i) for i in range(n_chunks)]
     f2 = [os.path.join(workdir, "e2e_%d_2.fq" % i) for i in range(n_chunks)]
     have = [i for i in range(n_chunks) if os.path.exists(f1[i]) and os.path.exists(f2[i])]
@@ -373,7 +386,7 @@ def binding_leg(workdir, prefix, n_chunks=10, n_ref_chunks=2):
            "bm2_chunk_real_s": [c[1] for c in ch_bm2],
            "reads_per_s_bm2_steady_chunks": sum(c[0] for c in steady) / sum(c[1] for c in steady) if steady and sum(c[1] for c in steady) > 0 else None,
            "bm2_profile": prof_bm2,
-           "reference": "bwa-mem2.%s mem" % isa, "reference_reads": reads_ref, "reference_wall_s": w_ref, "reference_chunk_real_s": [c[1] for c in ch_ref],
+           "binding_binary": os.path.basename(bm2_exe), "reference": "bwa-mem2.%s mem" % isa, "reference_reads": reads_ref, "reference_wall_s": w_ref, "reference_chunk_real_s": [c[1] for c in ch_ref],
            "reads_per_s_reference_chunks": reads_ref / sum(c[1] for c in ch_ref) if ch_ref and sum(c[1] for c in ch_ref) > 0 else None, "reference_profile": prof_ref,
            "sam_records_compared": n_ref, "sam_records_bm2": n_all, "sam_equal": bool(md_ref == md_prefix and n == n_ref),
            "scope": "bm2: %d chunks from two FASTQ files to a SAM file, process start to exit (17 GB index load and the replica's upload included); per-chunk "
@@ -390,13 +403,29 @@ def s1_binding_leg(workdir, prefix):
     same -t: chunk rates from their own 'Processed N reads' lines (index load excluded), wall from start to exit, SAM compared."""
     import hashlib
     exe, isa = ref_binary()
-    s1 = os.path.join(ROOT, "oracle", "_ref", "bwa-mem2.bm2s1")
+    s1 = os.path.join(ROOT, "oracle", "_ref", "bwa-mem2.bm2s1.%s" % isa)
+    if not os.path.exists(s1):
+        s1 = os.path.join(ROOT, "oracle", "_ref", "bwa-mem2.bm2s1")
     fq = os.path.join(workdir, "cpu_1.fq")
     if exe is None or not os.path.exists(s1) or not os.path.exists(fq) or not os.path.exists(prefix + ".bwt.2bit.64"):
         return {"skipped": "oracle/_ref/bwa-mem2.bm2s1, the index or the reads of the main run (cpu_1.fq) are not there"}
     threads = host_threads()
-    res = {"reads_file": "cpu_1.fq (the first mates of the CPU baseline's pairs, as single-end reads)", "threads": threads}
+    # BASELINE config 2 names 1 M single-end reads: the CPU baseline's mates, both files, twice over (the records of a single-end run do not
+    # depend on each other beyond the chunk's 512-read blocks)
+    fq2 = os.path.join(workdir, "cpu_2.fq")
+    fq_all = os.path.join(workdir, "s1_reads.fq")
+    parts_in = [f for f in (fq, fq2) if os.path.exists(f)]
+    with open(fq_all, "wb") as o:
+        n_lines = 0
+        for rep in range(2):
+            for f in parts_in:
+                b = open(f, "rb").read()
+                o.write(b); n_lines += b.count(b"\n")
+    fq = fq_all
+    res = {"reads_file": "the CPU baseline's mates (%s) as single-end reads, twice over: %d reads" % (" + ".join(os.path.basename(f) for f in parts_in), n_lines // 4), "threads": threads}
     md = {}
+    prof_pat = (("mem_process_seqs_s", r"MEM_PROCESS_SEQ\(\)[^:]*: ([\d.]+)"), ("kernels_s", r"Total kernel \(smem\+sal\+bsw\) time avg: ([\d.]+)"),
+                ("smem_s", r"SMEM compute avg: ([\d.]+)"), ("sal_s", r"SAL compute avg: ([\d.]+)"), ("bsw_s", r"BSW time, avg: ([\d.]+)"), ("worker_sam_s", r"WORKER_SAM avg: ([\d.]+)"))
     for tag, binary in (("reference", exe), ("bm2s1", s1)):
         out_sam = os.path.join(workdir, "s1_%s.sam" % tag)
         t = time.time()
@@ -414,9 +443,29 @@ def s1_binding_leg(workdir, prefix):
                     h.update(line); n += not line.startswith(b"@")
         os.remove(out_sam)
         md[tag] = (h.hexdigest(), n)
-        res[tag] = {"wall_s": wall, "reads": n_proc, "chunk_real_s": real, "reads_per_s_chunks": n_proc / real if real > 0 else None}
+        prof = {}
+        for key, pat in prof_pat:                                   # the program's own clocks (per-thread averages), printed at exit
+            m = re.search(pat, p.stderr)
+            if m:
+                prof[key] = float(m.group(1))
+        res[tag] = {"wall_s": wall, "reads": n_proc, "chunk_real_s": real, "reads_per_s_chunks": n_proc / real if real > 0 else None, "own_clocks": prof}
+        m = re.search(r"\[bm2s1\] (\d+) SeqPairs in (\d+) device batches(?: from (\d+) calls)?", p.stderr)
+        if m:
+            res[tag]["seqpairs"], res[tag]["device_batches"] = int(m.group(1)), int(m.group(2))
+            if m.group(3):
+                res[tag]["calls"] = int(m.group(3))
+    try:
+        os.remove(fq_all)
+    except OSError:
+        pass
     res["sam_equal"] = bool(md["reference"] == md["bm2s1"])
     res["sam_records"] = md["reference"][1]
+    rp = res["reference"]["own_clocks"]
+    if rp.get("bsw_s") and rp.get("mem_process_seqs_s"):
+        share = rp["bsw_s"] / rp["mem_process_seqs_s"]
+        res["seam_share"] = {"bsw_share_of_the_reference_chunk_time": share, "floor_of_bm2s1_over_reference": 1.0 - share,
+                             "note": "seam S1 is this share of the reference's own chunk time (its per-thread clocks: the rest is SMEM + SAL on the host, chaining, "
+                                     "SAM); a drop-in for S1 alone cannot take the chunk below (1 - share) of the reference's time however fast the kernel is"}
     log("S1 binding: reference %.1f s, bwa-mem2.bm2s1 %.1f s, SAM equal = %s" % (res["reference"]["wall_s"], res["bm2s1"]["wall_s"], res["sam_equal"]))
     return res
 
@@ -783,6 +832,14 @@ def bench_bsw(a, bm2, torch, dist_util, rank, world, local, emu, seed):
     }
     if world == 1 and not a.no_binding_s1:
         try:
+            f1, f2 = os.path.join(a.workdir, "cpu_1.fq"), os.path.join(a.workdir, "cpu_2.fq")
+            meta = os.path.join(a.workdir, "genome_%dmbp_s%d.fa.contigs.npz" % (a.genome_mbp, seed))
+            if not os.path.exists(f1) and os.path.exists(meta):   # (a run of its own: the reads the main line's CPU baseline would have left)
+                from tools import synth
+                z = np.load(meta, allow_pickle=True)
+                c1, c2 = synth.make_reads_pe(seed + 5, [z["c%d" % i] for i in range(int(z["n"]))], a.cpu_pairs, L=150)
+                synth.write_fastq(f1, c1, suffix="/1"); synth.write_fastq(f2, c2, suffix="/2")
+                del z, c1, c2
             out["s1_binding"] = s1_binding_leg(a.workdir, os.path.join(a.workdir, "genome_%dmbp_s%d.fa" % (a.genome_mbp, seed)))
             if out["s1_binding"].get("sam_equal") is False:
                 bad += 1
@@ -814,6 +871,7 @@ def main():
     ap.add_argument("--resident-chunks", type=int, default=int(os.environ.get("BM2_BENCH_RESIDENT", 4)),
                     help="distinct chunks the timed steps go round (all resident before the clock starts; capped by --warmup and --steps)")
     ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--parity-regs-reads", type=int, default=256, help="ont2d: reads of the gate whose stage dumps (refdump, one host thread) are compared; all --parity-reads go through `bwa-mem2 mem` and the SAM comparison")
     ap.add_argument("--no-binding-s1", action="store_true", help="bsw: skip the timing of `bwa-mem2.bm2s1 mem` (S1 on the GPU inside the reference's program) beside `bwa-mem2.<isa> mem`")
     ap.add_argument("--no-side-workloads", action="store_true", help="skip configs 5 and 2 (objects `config5` / `config2` of the pe150 line: --workload ont2d / bsw as processes of their own)")
     ap.add_argument("--no-binding", action="store_true", help="skip the drop-in timing (`bwa-mem2.bm2 mem` beside `bwa-mem2.<isa> mem` on the first two end-to-end chunks' files)")
@@ -950,13 +1008,21 @@ def main():
         sc = sc_sum if sc_sum is not None else ctx.batch_fetch("seed_counters", np.uint64)
         ext_of = {"walk1": int(sc[12]), "walk2": int(sc[13]), "walk3": int(sc[14]), "bwd1": int(sc[15]), "bwd2": int(sc[16])}
         smem_ms = stage_ms.get("smem", 0.0)
-        bwd_ms = (kern_ms.get("smem.bwd1", 0.0) + kern_ms.get("smem.bwd2", 0.0)) / (2.0 * parts)          # average launch duration (every part launches its own two)
+        # Since round 5 k_bwd hands the tasks that have had BM2_BWD_EXPORT_AGE extensions over to k_bwd_cont, a launch right behind it (intervals
+        # smem.cont1 / smem.cont2): the backward phase of a pass is the two launches together -- the pass's backwardExt count covers both (and the
+        # wavefront-per-task kernel of the long lists, which runs beside k_bwd), so does the time it is divided by.
+        cont_ms = kern_ms.get("smem.cont1", 0.0) + kern_ms.get("smem.cont2", 0.0)
+        bwd_ms = (kern_ms.get("smem.bwd1", 0.0) + kern_ms.get("smem.bwd2", 0.0) + cont_ms) / (2.0 * parts)          # average duration of a pass's backward phase (every part launches its own two)
         bwd_bytes = 128.0 * (ext_of["bwd1"] + ext_of["bwd2"]) / (2.0 * parts)                              # algorithmic bytes per launch
         ach = bwd_bytes / (bwd_ms * 1e-3) / 1e9 if bwd_ms > 0 else 0.0
-        roof_kernel, roof_launches = "k_bwd", 2 * parts
+        roof_kernel, roof_launches = ("k_bwd (+ k_bwd_cont, the tasks it hands over)" if cont_ms > 0 else "k_bwd"), 2 * parts
+        handed = None
+        if len(sc) >= 27 and (sc[21] > 0 or sc[22] > 0):
+            handed = {"export_age": int(os.environ.get("BM2_BWD_EXPORT_AGE", "256") or 0), "tasks_pass1_in_64s": int(sc[21]), "tasks_pass2_in_64s": int(sc[22]),
+                      "rows_walked_by_k_bwd_cont": [int(sc[25]), int(sc[26])], "k_bwd_cont_ms": [kern_ms.get("smem.cont1", 0.0) / parts, kern_ms.get("smem.cont2", 0.0) / parts]}
         fm_kernels = {}                                       # every FM-index kernel of the step against the same peak: 128 algorithmic bytes per backwardExt
-        for kn, ev in (("k_walk<1>", "walk1"), ("k_bwd (pass 1)", "bwd1"), ("k_walk<2>", "walk2"), ("k_bwd (pass 2)", "bwd2")):
-            ms_k = kern_ms.get("smem." + ev, 0.0) / parts    # (per launch: one per part)
+        for kn, ev in (("k_walk<1>", "walk1"), ("k_bwd + k_bwd_cont (pass 1)", "bwd1"), ("k_walk<2>", "walk2"), ("k_bwd + k_bwd_cont (pass 2)", "bwd2")):
+            ms_k = (kern_ms.get("smem." + ev, 0.0) + kern_ms.get("smem." + ev.replace("bwd", "cont"), 0.0) * (ev.startswith("bwd"))) / parts    # (per launch: one per part)
             if ms_k > 0:
                 gbs = 128.0 * ext_of[ev] / parts / (ms_k * 1e-3) / 1e9
                 fm_kernels[kn] = {"ms": ms_k, "backwardExt": ext_of[ev] / parts, "achieved": gbs, "frac": gbs / HBM_PEAK_GBS}
@@ -992,7 +1058,7 @@ def main():
         dominant = max(stage_ms, key=stage_ms.get) if stage_ms else None
         traffic, pmc_src = None, None                        # HBM bytes per k_bwd launch from the committed PMC passes, same workload only
         ext_pmc = None
-        for fn in ("r04_k_bwd_pmc.json", "r03_k_bwd_pmc.json", "r02_k_bwd_pmc.json", "r01_k_bwd_pmc.json"):
+        for fn in ("r05_k_bwd_pmc.json", "r04_k_bwd_pmc.json", "r03_k_bwd_pmc.json", "r02_k_bwd_pmc.json", "r01_k_bwd_pmc.json"):
             try:
                 pm = json.load(open(os.path.join(ROOT, "profiles", fn)))
                 wl = pm["workload"]
@@ -1004,7 +1070,7 @@ def main():
         ext_src = None
         # SQ counter passes of the extension stage (tools/pmc_to_profiles.py), the newest committed one OF THIS WORKLOAD (a pass of the 150 bp
         # workload says nothing about the kernels a 10 kb chunk runs)
-        for fn in (("r04_ont2d_ext_pmc_sq.json",) if ont else ("r04_ext_pmc_sq.json", "r03_ext_pmc_sq.json", "r02_ext_pmc_sq.json")):
+        for fn in (("r05_ont2d_ext_pmc_sq.json", "r04_ont2d_ext_pmc_sq.json") if ont else ("r05_ext_pmc_sq.json", "r04_ext_pmc_sq.json", "r03_ext_pmc_sq.json", "r02_ext_pmc_sq.json")):
             try:
                 ext_pmc = json.load(open(os.path.join(ROOT, "profiles", fn)))
                 ext_src = "profiles/" + fn
@@ -1052,6 +1118,7 @@ def main():
                          "frac_counter": ach_counter / HBM_PEAK_GBS if ach_counter else None,
                          "algorithmic_bytes_per_launch": bwd_bytes, "avg_launch_ms": bwd_ms, "launches_per_step": roof_launches,
                          "fm_index_kernels": fm_kernels,
+                         "handed_over": handed,
                          "random_line_ceiling_glines": RANDOM_LINE_GLPS,
                          "delivered_glines": lines_counter,
                          "frac_of_random_line_ceiling": lines_counter / RANDOM_LINE_GLPS if lines_counter else None,
@@ -1080,15 +1147,39 @@ def main():
         }
         if chain_kernel:
             out["chain_kernel"] = chain_kernel
+        # (stderr: the driver keeps the tail of it; the JSON line on stdout is long enough to lose its head there)
+        log("hot path %.2f ms per step = %.2f M reads/s (%s); %s %.2f ms per launch = %.0f GB/s algorithmic = %.3f of the HBM peak"
+            % (dt / steps * 1e3, value / 1e6, " / ".join("%s %.1f" % (k, v) for k, v in stage_ms.items()), roof_kernel, bwd_ms, ach, ach / HBM_PEAK_GBS))
+        ref_run = None
         if world == 1 and not a.no_parity and time_left() < 150:
             out["parity"] = {"skipped": "time budget (%.0f s of %.0f s left)" % (time_left(), a.budget_s)}
         elif world == 1 and not a.no_parity:
             regs, reg_off = ctx.batch_download()
-            n_s = min(a.parity_reads, n_reads) if not ont else min(a.parity_reads, 256, n_reads)
-            if not ont:
+            n_s = min(a.parity_reads, n_reads)
+            if not ont or n_s >= 512:
                 n_s -= n_s % 512
             try:
-                out["parity"] = parity_gate(ctx, bm2, prefix, a.workdir, seqs, regs, reg_off, opt, opt_args, paired, max(n_s, 2), a.workload)
+                out["parity"] = parity_gate(ctx, bm2, prefix, a.workdir, seqs, regs, reg_off, opt, opt_args, paired, max(n_s, 2), a.workload,
+                                            n_regs=min(n_s, a.parity_regs_reads) if ont else None)
+                ref_run = out["parity"].pop("_reference_run", None)
+                if ont and "regs_equal" in out["parity"]:
+                    # which of the gated reads took the rare paths: the prefix once more as a chunk of its own (its regs must not depend on what else
+                    # is in the batch) -- the island kernel counts the reads it chained by islands and those it had to chain serially (equal chain keys)
+                    c3 = bm2.Context(share=ctx)
+                    try:
+                        from tools import refio as _refio
+                        e3, o3, l3 = _refio.pack_reads(seqs[:n_s])
+                        c3.batch_upload(e3, o3, l3); c3.batch_run(opt)
+                        r3, ro3 = c3.batch_download()
+                        cn3 = np.asarray(c3.batch_fetch("counters", np.uint64), np.float64)
+                        same = bool(regs_records(r3, ro3, 0, n_s).tobytes() == regs_records(regs, reg_off, 0, n_s).tobytes())
+                        out["parity"]["gated_reads_chained_serially_equal_keys"] = int(cn3[16])
+                        out["parity"]["gated_reads_chained_by_islands"] = int(cn3[17])
+                        out["parity"]["prefix_alone_equals_prefix_in_chunk"] = same
+                        if not same:
+                            rc = 3
+                    finally:
+                        c3.close()
                 if not (out["parity"].get("regs_equal") and out["parity"].get("sam_equal") and out["parity"].get("fin_equal")):
                     rc = 3
             except Exception as e:                                                    # noqa  (the line is still printed: the gate did not run to its end)
@@ -1101,7 +1192,10 @@ def main():
         elif world == 1 and not a.no_cpu_baseline:           # the reference on this host's cores: at N=1 only (the other ranks would idle)
             try:
                 t = time.time()
-                if ont:
+                if ont and ref_run is not None and (out.get("parity") or {}).get("reads", 0) >= 300:
+                    # the gate's `bwa-mem2 mem -x ont2d` run over its reads IS a timed run of the reference on this host's CPUs: no second one
+                    cb = cpu_baseline_from(ref_run[0], ref_run[1], ref_run[2], "%d ONT-like reads (the first of the timed chunk: the parity gate's reference run)" % out["parity"]["reads"], opt_args)
+                elif ont:
                     nb = min(len(seqs), 300)
                     f1 = os.path.join(a.workdir, "cpu_ont.fq")
                     synth.write_fastq(f1, seqs[:nb])
@@ -1203,7 +1297,7 @@ def main():
         # BASELINE configs 5 and 2 as workloads of their own, in the same line: each with its parity gate, its kernels' figures and the compiled
         # reference timed beside it on this host
         if world == 1 and not ont and not a.no_side_workloads and not hung:
-            for key, name, extra, need_s in (("config5", "ont2d", ["--steps", 2, "--warmup", 1, "--parity-reads", 200], 240),
+            for key, name, extra, need_s in (("config5", "ont2d", ["--steps", 2, "--warmup", 1, "--parity-reads", 2048, "--parity-regs-reads", 200] + CONFIG5_READS, 420),
                                              ("config2", "bsw", ["--steps", 5, "--warmup", 2], 90)):
                 if time_left() < need_s:
                     out[key] = {"skipped": "time budget (%.0f s of %.0f s left)" % (time_left(), a.budget_s)}
@@ -1214,6 +1308,39 @@ def main():
                         rc = rc or 3
                 except Exception as e:                                                # noqa
                     out[key] = {"error": str(e)}
+        try:                                                     # the legs once more, one line each, at the very end of stderr
+            pr = out.get("parity") or {}
+            if "regs_equal" in pr:
+                log("parity gate: regs %s, a19 %s, SAM %s (%s records; %s regs of the %d-read prefix, %s beyond 2^32)"
+                    % (pr.get("regs_equal"), pr.get("fin_equal"), pr.get("sam_equal"), pr.get("sam_records"), pr.get("regs"), pr.get("reads", 0), pr.get("regs_over_2p32")))
+            e2 = out.get("end_to_end") or {}
+            if e2.get("value"):
+                log("end_to_end (FASTQ text -> SAM text): %.2f M reads/s over %d chunks = %.2f of the hot path (steady state %s M reads/s); last chunk equal to a serial run: %s"
+                    % (e2["value"] / 1e6, e2.get("chunks", 0), e2.get("frac_of_hot_path", 0.0),
+                       ("%.2f" % (e2["steady_state"]["reads_per_s"] / 1e6)) if isinstance(e2.get("steady_state"), dict) and e2["steady_state"].get("reads_per_s") else "n/a",
+                       (e2.get("chunk_check") or {}).get("equal_to_serial_run")))
+            cbl = out.get("cpu_baseline") or {}
+            if cbl.get("value"):
+                log("cpu baseline (%s, %s threads): %.3f M reads/s whole mem, %s like-for-like" % (cbl.get("kind"), cbl.get("cores"), cbl["value"] / 1e6,
+                    ("%.3f M" % (cbl["hot_path_value"] / 1e6)) if cbl.get("hot_path_value") else "n/a"))
+            bd = out.get("binding") or {}
+            if bd.get("bm2_wall_s"):
+                log("binding (bwa-mem2.bm2 mem, %d reads from files): %.1f s wall, %.2f M reads/s in steady chunks; SAM equal to the reference's: %s (%s records compared)"
+                    % (bd.get("reads", 0), bd["bm2_wall_s"], (bd.get("reads_per_s_bm2_steady_chunks") or 0.0) / 1e6, bd.get("sam_equal"), bd.get("sam_records_compared")))
+            c5 = out.get("config5") or {}
+            if c5.get("value"):
+                log("config 5 (%s reads of mean 10 kb per step, -x ont2d): %.0f reads/s, %.0f ms per step (%s); gate %s; reference on this host %s reads/s"
+                    % ((c5.get("config") or {}).get("reads_per_gpu_per_step"), c5["value"], c5.get("ms_per_step", 0.0),
+                       " / ".join("%s %.0f" % (k, v) for k, v in (c5.get("stage_ms_per_step") or {}).items()),
+                       {k: (c5.get("parity") or {}).get(k) for k in ("regs_equal", "fin_equal", "sam_equal", "reads")}, (c5.get("cpu_baseline") or {}).get("value")))
+            c2 = out.get("config2") or {}
+            if c2.get("value"):
+                s1 = c2.get("s1_binding") or {}
+                log("config 2 (S1 alone, %s pairs resident): %s G cells/s; bwa-mem2.bm2s1 mem %s s per chunk against the unmodified binary's %s s, SAM equal: %s"
+                    % ((c2.get("config") or {}).get("pairs_per_gpu_per_step"), ("%.0f" % ((c2.get("extend_kernel") or {}).get("gcups") or 0.0)),
+                       (s1.get("bm2s1") or {}).get("chunk_real_s"), (s1.get("reference") or {}).get("chunk_real_s"), s1.get("sam_equal")))
+        except Exception as e:                                                        # noqa  (a summary must not cost the line)
+            log("summary lines: %s" % e)
         print(json.dumps(out), flush=True)
     if hung:                                                     # stage threads of a failed end-to-end attempt may be left: do not join them
         sys.stdout.flush(); sys.stderr.flush()

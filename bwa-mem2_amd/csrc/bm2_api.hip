@@ -99,40 +99,47 @@ extern "C" void bm2_host_free(void *p) { if (p) (void)hipHostFree(p); }
 // BM2_PIN_POOL_MB (default 3072) are unlocked and released.
 namespace {
 struct PoolBlock { void *p; size_t cap; bool used, pinned; };
-std::mutex pool_mu;
-std::vector<PoolBlock> pool_blocks;
+// (a heap singleton that is never destroyed: detached parser threads may still hand blocks back while the process's statics are being torn down)
+struct ChunkPool : std::mutex { std::vector<PoolBlock> blocks; };
+ChunkPool &pool() { static ChunkPool *p = new ChunkPool; return *p; }
 }
 void *bm2_chunk_mem_get(size_t bytes) {
     if (bytes < ((size_t)1 << 20)) return malloc(bytes ? bytes : 1);
     {
-        std::lock_guard<std::mutex> l(pool_mu);
+        std::lock_guard<std::mutex> l(pool());
         PoolBlock *best = nullptr;
-        for (PoolBlock &b : pool_blocks)
+        for (PoolBlock &b : pool().blocks)
             if (!b.used && b.cap >= bytes && b.cap <= 2 * bytes + ((size_t)8 << 20) && (!best || b.cap < best->cap)) best = &b;
         if (best) { best->used = true; return best->p; }
     }
     const size_t cap = (bytes + bytes / 8 + ((size_t)4 << 20) - 1) & ~(((size_t)4 << 20) - 1);
     void *p = nullptr; bool pinned = true;
-    if (hipHostMalloc(&p, cap, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); p = malloc(cap); pinned = false; }
+    // (a host without a device, or out of lockable memory: plain memory of the size asked for, NOT pooled -- bm2_chunk_mem_put frees it at once, a
+    //  parser-only process would otherwise sit on gigabytes of idle blocks)
+    if (hipHostMalloc(&p, cap, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return malloc(bytes); }
     if (!p) return nullptr;
-    std::lock_guard<std::mutex> l(pool_mu);
-    pool_blocks.push_back(PoolBlock{ p, cap, true, pinned });
+    std::lock_guard<std::mutex> l(pool());
+    pool().blocks.push_back(PoolBlock{ p, cap, true, pinned });
     return p;
 }
 void bm2_chunk_mem_put(void *p) {
     if (!p) return;
     std::vector<PoolBlock> drop;
     {
-        std::lock_guard<std::mutex> l(pool_mu);
+        std::lock_guard<std::mutex> l(pool());
+        std::vector<PoolBlock> &blocks = pool().blocks;
         bool mine = false;
-        for (PoolBlock &b : pool_blocks) if (b.p == p) { b.used = false; mine = true; break; }
-        if (!mine) { free(p); return; }
+        for (PoolBlock &b : blocks) if (b.p == p) { b.used = false; mine = true; break; }
+        if (!mine) { free(p); return; }                          // (a small request, or the plain memory of a host that cannot lock pages)
         const char *e = getenv("BM2_PIN_POOL_MB");
-        const size_t limit = (size_t)(e && *e ? atol(e) : 3072) << 20;
+        long mb = e && *e ? atol(e) : 3072;
+        if (mb < 0) mb = 0;                                      // (a negative or unreadable setting keeps nothing idle; it must not become a huge unsigned limit)
+        if (mb > (1L << 20)) mb = 1L << 20;
+        const size_t limit = (size_t)mb << 20;
         size_t idle = 0;
-        for (const PoolBlock &b : pool_blocks) if (!b.used) idle += b.cap;
-        for (size_t i = 0; i < pool_blocks.size() && idle > limit;) {
-            if (!pool_blocks[i].used) { idle -= pool_blocks[i].cap; drop.push_back(pool_blocks[i]); pool_blocks.erase(pool_blocks.begin() + (long)i); }
+        for (const PoolBlock &b : blocks) if (!b.used) idle += b.cap;
+        for (size_t i = 0; i < blocks.size() && idle > limit;) {
+            if (!blocks[i].used) { idle -= blocks[i].cap; drop.push_back(blocks[i]); blocks.erase(blocks.begin() + (long)i); }
             else ++i;
         }
     }
@@ -194,8 +201,8 @@ static int make_streams(bm2_ctx *c) {
 // GPU_MAX_HW_QUEUES hardware queues, its streams share them round-robin, and whatever is queued behind a long kernel on its queue waits for
 // it -- a context that only runs the SAM tail's batches (one stream) must not dilute the queues of the contexts that run the hot path.
 int bm2_side_streams(bm2_ctx *c) {
-    if (c->ev_fork) return BM2_OK;
-    if (bm2_check(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming), "hipEventCreate")) return BM2_ENODEV;
+    if (c->side_ready) return BM2_OK;                            // (set only when every stream and event below exists)
+    if (!c->ev_fork && bm2_check(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming), "hipEventCreate")) { c->ev_fork = nullptr; return BM2_ENODEV; }
     // BM2_SIDE_PRIO_MASK: the side streams whose bit is set -- e.g. those of the extension launches of the long query classes, whose wavefronts
     // are a phase's critical path -- are created with the highest queue priority: when a phase holds more workgroups than the GPU, theirs are placed first
     // and the short classes fill in behind them (longest job first)
@@ -203,11 +210,14 @@ int bm2_side_streams(bm2_ctx *c) {
     int least = 0, greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
     for (int i = 0; i < 12; i++) {
-        const hipError_t e = (prio_mask >> i & 1) ? hipStreamCreateWithPriority(&c->side_stream[i], hipStreamNonBlocking, greatest)
-                                            : hipStreamCreateWithFlags(&c->side_stream[i], hipStreamNonBlocking);
-        if (bm2_check(e, "hipStreamCreate")) return BM2_ENODEV;
-        (void)hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming);
+        if (!c->side_stream[i]) {
+            const hipError_t e = (prio_mask >> i & 1) ? hipStreamCreateWithPriority(&c->side_stream[i], hipStreamNonBlocking, greatest)
+                                                : hipStreamCreateWithFlags(&c->side_stream[i], hipStreamNonBlocking);
+            if (bm2_check(e, "hipStreamCreate")) { c->side_stream[i] = nullptr; return BM2_ENODEV; }      // (a later call tries again from here: nothing half-made is ever used)
+        }
+        if (!c->ev_join[i] && bm2_check(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming), "hipEventCreate")) { c->ev_join[i] = nullptr; return BM2_ENODEV; }
     }
+    c->side_ready = true;
     return BM2_OK;
 }
 // The dynamic-LDS limit of a kernel is a property of the loaded code object on ONE device: raised once per context (contexts of several

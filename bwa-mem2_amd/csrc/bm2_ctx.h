@@ -48,6 +48,7 @@ struct bm2_ctx {
     // fork/join of the per-class extension launches (extend.hip)
     hipStream_t side_stream[12] = {};
     hipEvent_t ev_fork = nullptr, ev_join[12] = {};
+    bool side_ready = false;                                      // every side stream and its events exist (bm2_side_streams)
     // what the extension stage of the last batch saw (page-locked; written by an asynchronous copy at the end of the stage): per phase the
     // seeds of every LDS class and the reads left pending.  The next batch sizes its launches and picks its number of lazy rounds with it.
 #define BM2_EXT_PHASES 8

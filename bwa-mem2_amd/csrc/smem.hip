@@ -188,11 +188,21 @@ static __device__ __forceinline__ int64_t wave_alloc(LdsPool *wp, unsigned long 
     if (lt == 0) { wp->pos = nbase + (cnt - rem); wp->end = nbase + BATCH; }
     return lt < rem ? pos + lt : nbase + (lt - rem);
 }
+// The same for ids that are drawn RARELY (a handed-over task: a few per wavefront and launch): exactly as many as lanes ask, one atomic per call
+// that the wavefront waits for -- a pool would leave most of every batch unused, and every unused id is an item the consumer has to skip.
+static __device__ __forceinline__ int64_t wave_alloc_exact(LdsPool *, unsigned long long *cursor) {
+    const unsigned long long mask = __ballot(1);
+    const int lt = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+    unsigned long long nb = 0;
+    if (lt == 0) nb = atomicAdd(cursor, (unsigned long long)__popcll(mask));
+    const int leader = __ffsll((long long)mask) - 1;
+    const unsigned lo = __builtin_amdgcn_readlane((unsigned)nb, leader), hi = __builtin_amdgcn_readlane((unsigned)(nb >> 32), leader);
+    return (int64_t)(((unsigned long long)hi << 32) | lo) + lt;
+}
 #define LCAP 12                   // survivors of a backward row kept in LDS per lane (48 KB per 256-thread block)
 #define HEAVY_T 40                // backward tasks with longer candidate lists go to the wave-per-task kernel ...
-#define HCAP 256                  // ... if the list fits its LDS row (else they stay lane-per-task)
+#define HCAP 192                  // ... if the list fits its LDS row (else they stay lane-per-task); 192: a workgroup of k_bwd_heavy (13 KB) fits beside three of k_bwd (3 x 48.5 KB of 160)
 #define HEAVY_BATCH 64
-#define CONT_BATCH 64                 // ids of handed-over tasks a wave of k_bwd takes at a time (wave_alloc: a batch must cover the 64 lanes that may ask at once)
 #define BWD_EXPORT_AGE 256             // (default of BM2_BWD_EXPORT_AGE)
 #define ITEM_BATCH 64
 #define SLOT_BATCH 256
@@ -473,7 +483,7 @@ bwd_body(const DevIndex &ix, const SeedParams &sp, int pass, const uint8_t *__re
                     // the row's survivors go back into the task's slot where the reader of a walk's list expects them (entry(top - depth)), a
                     // CTask says row j is done, and k_bwd_cont -- sixteen lanes per task, the candidates of a row side by side -- finishes it in a
                     // launch of its own after this one (a kernel boundary: no hand-off between running workgroups).
-                    const int64_t cid = wave_alloc<CONT_BATCH>(cp, sc + (pass == 1 ? SC_CONT1 : SC_CONT2));
+                    const int64_t cid = wave_alloc_exact(cp, sc + (pass == 1 ? SC_CONT1 : SC_CONT2));
                     if (cid < cont_cap) {
                         const int64_t slot = (int64_t)(lst - ents) / CAPF;
                         *entry(top) = pv_pack(fk, fl, fs, fn);
@@ -556,7 +566,6 @@ bwd_body(const DevIndex &ix, const SeedParams &sp, int pass, const uint8_t *__re
     }
     for (int64_t at = rp->pos + (threadIdx.x & 63); at < rp->end; at += 64) if (at < rec_cap) recs[at].rid = 0xffffffffu;
     for (int64_t at = tp->pos + (threadIdx.x & 63); at < tp->end; at += 64) if (at < task_cap) tasks[at].r = -1;
-    for (int64_t at = cp->pos + (threadIdx.x & 63); at < cp->end; at += 64) if (at < cont_cap) ctasks[at].h.r = -1;
     atomicAdd(&sc[SC_NEXT], (unsigned long long)n_ext);
     atomicAdd(&sc[SC_NEXT_B1 + (pass - 1)], (unsigned long long)n_ext);
     if (ovf) atomicOr(&sc[SC_OVF_FLAG], (unsigned long long)ovf);
@@ -1114,7 +1123,7 @@ int bm2_launch_seeding(bm2_ctx *c, const SeedParams &sp, int n_reads, const uint
                        void (*tick)(bm2_ctx *, const char *), int max_len) {
     if (bm2_side_streams(c)) return BM2_ENODEV;
     hipStream_t s = c->stream, s3 = c->side_stream[0], sh = c->side_stream[1];
-    const int grid_heavy = c->n_cu * 4;
+    const int grid_heavy = c->n_cu * bm2_knob("BM2_BWD_HEAVY_BPC", 4);        // workgroups per CU of the wavefront-per-task kernel beside k_bwd
     // k_bwd hands a task that has had this many extensions over to the wavefront-per-task kernel at its next row boundary (0 = never)
     const int export_age = bm2_knob("BM2_BWD_EXPORT_AGE", BWD_EXPORT_AGE);
     // pass 3 is independent of passes 1 and 2: it runs beside them.  WHERE is launch policy (BM2_P3_AT): 0 = beside the forward walks of

@@ -5,15 +5,21 @@
 // them to BandedPairWiseSW::getScores8 / getScores16 / scalarBandedSWAWrapper (bandedSWA.h:126-135,199-211; call sites bwamem.cpp:2476,2541,
 // 2544,2610,2613,2692,2754,2757,2825,2828).  This file IS those three member functions, with the reference's own signatures, for a build in
 // which bandedSWA.cpp is compiled with the three names renamed (-DgetScores8=getScores8_reference ...): every call in bwamem.cpp then lands
-// here and runs as one bm2_bsw batch on the GPU -- seeding, chaining, the band retry rule and everything after stay the reference's host code.
+// here and runs on the GPU -- seeding, chaining, the band retry rule and everything after stay the reference's host code.
 // Nothing of the reference is modified or copied; its header is included from where it lies (the class keeps its parameters private; a
 // maintainer would add accessors -- this file opens the class with the preprocessor instead).
 //
-// The reference calls these from every worker thread at once (one BandedPairWiseSW per call of mem_chain2aln_across_reads_V2); a bm2_ctx
-// serves one host thread at a time, so the calls are spread over BM2_S1_CONTEXTS contexts (default 4) on device BM2_DEVICE, each behind a
-// mutex: the copies of one thread's batch overlap the kernel of another's.
+// COMBINING (round 5).  The reference calls these from every worker thread at once, a few thousand pairs per call -- too few for the
+// pair-per-lane kernel, and a synchronous copy in, launch, copy out each (rounds 3-4: one bm2_bsw per call behind a mutex; the program was 8 %
+// SLOWER than the unmodified binary).  Now a call files a request and the first caller that finds a free device slot becomes the LEADER of a
+// batch: it takes every request filed so far (same band and scoring), lays their pairs and sequences end to end in page-locked buffers of
+// the slot (the pairs' offsets moved accordingly), runs ONE bm2_bsw, copies the six result fields back and wakes the callers.  While a batch
+// is on the device the next requests pile up: batches grow with the load by themselves (group commit), no timer involved.  BM2_S1_CONTEXTS
+// slots (default 2) so that the copies of one batch overlap the kernels of another.
 #include <atomic>
+#include <condition_variable>
 #include <mutex>
+#include <vector>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -24,48 +30,114 @@
 #include "../include/bm2.h"
 
 namespace {
-enum { MAX_CTX = 16 };
-struct Slot { bm2_ctx *ctx = nullptr; std::mutex mu; };
-Slot g_slot[MAX_CTX];
+enum { MAX_SLOT = 8 };
+struct Request {
+    SeqPair *pairs; const uint8_t *ref, *qer; int n, w; int64_t ref_bytes, qer_bytes; bm2_sw_params p; bool done;
+};
+struct Slot {                          // one device context with its staging buffers (page-locked: plain DMA, no second host copy inside the library)
+    bm2_ctx *ctx = nullptr; bool busy = false;
+    bm2_seqpair_t *pairs = nullptr; uint8_t *ref = nullptr, *qer = nullptr; size_t cap_pairs = 0, cap_ref = 0, cap_qer = 0;
+};
+Slot g_slot[MAX_SLOT];
 int g_n = 0;
 std::once_flag g_once;
-std::atomic<unsigned> g_next{0};
-std::atomic<long long> g_pairs{0}, g_calls{0};
+std::mutex g_mu;
+std::condition_variable g_cv;
+std::vector<Request *> g_pending;
+std::atomic<long long> g_pairs{0}, g_batches{0}, g_calls{0};
 
 void attach() {
     const char *e = getenv("BM2_S1_CONTEXTS"), *dev = getenv("BM2_DEVICE");
-    int n = e && *e ? atoi(e) : 4;
-    g_n = n < 1 ? 1 : n > MAX_CTX ? MAX_CTX : n;
+    int n = e && *e ? atoi(e) : 2;
+    g_n = n < 1 ? 1 : n > MAX_SLOT ? MAX_SLOT : n;
     for (int i = 0; i < g_n; i++) {
         g_slot[i].ctx = bm2_create(dev ? atoi(dev) : 0, nullptr);       // (no index: S1 needs none)
         if (!g_slot[i].ctx) { fprintf(stderr, "[bm2s1] bm2_create: %s\n", bm2_last_error()); exit(EXIT_FAILURE); }
     }
-    fprintf(stderr, "[bm2s1] banded extension (getScores8 / getScores16 / scalarBandedSWAWrapper) runs in libbm2 on %d context(s)\n", g_n);
-    atexit([]() { fprintf(stderr, "[bm2s1] %lld SeqPairs in %lld device batches\n", g_pairs.load(), g_calls.load()); });
+    fprintf(stderr, "[bm2s1] banded extension (getScores8 / getScores16 / scalarBandedSWAWrapper) runs in libbm2: the calls of all threads combined into batches on %d context(s)\n", g_n);
+    atexit([]() { fprintf(stderr, "[bm2s1] %lld SeqPairs in %lld device batches from %lld calls\n", g_pairs.load(), g_batches.load(), g_calls.load()); });
 }
 
-// one batch: the six output fields of every pair, by the rule of the pair's own kernel class (bm2_bsw derives the class from len1, len2
-// and h0 exactly as sortPairsLenExt does, bwamem.cpp:1924-1950 -- the class the reference filed the pair under)
+template <class T> void grow(T *&buf, size_t &cap, size_t need) {
+    if (need <= cap) return;
+    if (buf) bm2_host_free(buf);
+    cap = need + need / 2 + 4096;
+    buf = (T *)bm2_host_alloc(cap * sizeof(T));
+    if (!buf) { fprintf(stderr, "[bm2s1] out of page-locked memory (%zu bytes)\n", cap * sizeof(T)); exit(EXIT_FAILURE); }
+}
+
+// the leader's part: requests laid end to end, one device batch, results back (no lock held)
+void run_batch(Slot &s, const std::vector<Request *> &batch) {
+    size_t n = 0, rb = 0, qb = 0;
+    for (const Request *r : batch) { n += (size_t)r->n; rb += (size_t)r->ref_bytes; qb += (size_t)r->qer_bytes; }
+    grow(s.pairs, s.cap_pairs, n); grow(s.ref, s.cap_ref, rb + 8); grow(s.qer, s.cap_qer, qb + 8);
+    size_t at = 0, ro = 0, qo = 0;
+    for (const Request *r : batch) {
+        memcpy(s.ref + ro, r->ref, (size_t)r->ref_bytes); memcpy(s.qer + qo, r->qer, (size_t)r->qer_bytes);
+        static_assert(sizeof(SeqPair) == sizeof(bm2_seqpair_t), "SeqPair and bm2_seqpair_t are the same 56 bytes");
+        memcpy(s.pairs + at, r->pairs, (size_t)r->n * sizeof(SeqPair));
+        for (int i = 0; i < r->n; i++) { s.pairs[at + i].idr += (int64_t)ro; s.pairs[at + i].idq += (int64_t)qo; }
+        at += (size_t)r->n; ro += (size_t)r->ref_bytes; qo += (size_t)r->qer_bytes;
+    }
+    // one batch: the six output fields of every pair, by the rule of the pair's own kernel class (bm2_bsw derives the class from len1, len2
+    // and h0 exactly as sortPairsLenExt does, bwamem.cpp:1924-1950 -- the class the reference filed the pair under)
+    if (bm2_bsw(s.ctx, s.pairs, s.ref, (int64_t)rb, s.qer, (int64_t)qb, (int)n, batch[0]->w, &batch[0]->p)) {
+        fprintf(stderr, "[bm2s1] bm2_bsw: %s\n", bm2_last_error()); exit(EXIT_FAILURE);
+    }
+    at = 0;
+    for (const Request *r : batch) {
+        for (int i = 0; i < r->n; i++) {
+            const bm2_seqpair_t &o = s.pairs[at + i];
+            SeqPair &d = r->pairs[i];
+            d.score = o.score; d.tle = o.tle; d.gtle = o.gtle; d.qle = o.qle; d.gscore = o.gscore; d.max_off = o.max_off;
+        }
+        at += (size_t)r->n;
+    }
+    g_pairs += (long long)n; ++g_batches;
+}
+
 void run(const BandedPairWiseSW *self, SeqPair *pairs, uint8_t *ref, uint8_t *qer, int n, int w) {
     if (n <= 0) return;
     std::call_once(g_once, attach);
-    static_assert(sizeof(SeqPair) == sizeof(bm2_seqpair_t), "SeqPair and bm2_seqpair_t are the same 56 bytes");
-    bm2_sw_params p; memset(&p, 0, sizeof p);
-    p.o_del = self->o_del; p.e_del = self->e_del; p.o_ins = self->o_ins; p.e_ins = self->e_ins; p.zdrop = self->zdrop;
-    p.end_bonus = self->end_bonus; p.w_match = self->w_match; p.w_mismatch = self->w_mismatch;
-    memcpy(p.mat, self->mat, 25);
-    int64_t ref_bytes = 0, qer_bytes = 0;
+    Request me; memset(&me.p, 0, sizeof me.p);
+    me.pairs = pairs; me.ref = ref; me.qer = qer; me.n = n; me.w = w; me.done = false;
+    me.p.o_del = self->o_del; me.p.e_del = self->e_del; me.p.o_ins = self->o_ins; me.p.e_ins = self->e_ins; me.p.zdrop = self->zdrop;
+    me.p.end_bonus = self->end_bonus; me.p.w_match = self->w_match; me.p.w_mismatch = self->w_mismatch;
+    memcpy(me.p.mat, self->mat, 25);
+    me.ref_bytes = me.qer_bytes = 0;
     for (int i = 0; i < n; i++) {
         const int64_t r = (int64_t)pairs[i].idr + pairs[i].len1, q = (int64_t)pairs[i].idq + pairs[i].len2;
-        if (r > ref_bytes) ref_bytes = r;
-        if (q > qer_bytes) qer_bytes = q;
+        if (r > me.ref_bytes) me.ref_bytes = r;
+        if (q > me.qer_bytes) me.qer_bytes = q;
     }
-    Slot &s = g_slot[g_next.fetch_add(1) % (unsigned)g_n];
-    std::lock_guard<std::mutex> lock(s.mu);
-    if (bm2_bsw(s.ctx, (bm2_seqpair_t *)pairs, ref, ref_bytes, qer, qer_bytes, n, w, &p)) {
-        fprintf(stderr, "[bm2s1] bm2_bsw: %s\n", bm2_last_error()); exit(EXIT_FAILURE);
+    ++g_calls;
+    std::unique_lock<std::mutex> lock(g_mu);
+    g_pending.push_back(&me);
+    for (;;) {
+        if (me.done) return;
+        int free_slot = -1;
+        for (int i = 0; i < g_n; i++) if (!g_slot[i].busy) { free_slot = i; break; }
+        if (free_slot >= 0 && !g_pending.empty()) {              // lead a batch: everything filed so far that shares the first request's band and scoring
+            std::vector<Request *> batch, rest;
+            const Request *lead = g_pending[0];
+            size_t pairs_in = 0;
+            for (Request *r : g_pending) {
+                const bool same = r->w == lead->w && !memcmp(&r->p, &lead->p, sizeof r->p) && pairs_in + (size_t)r->n < ((size_t)1 << 30);
+                if (same) { batch.push_back(r); pairs_in += (size_t)r->n; } else rest.push_back(r);
+            }
+            g_pending.swap(rest);
+            Slot &s = g_slot[free_slot];
+            s.busy = true;
+            lock.unlock();
+            run_batch(s, batch);
+            lock.lock();
+            s.busy = false;
+            for (Request *r : batch) r->done = true;
+            g_cv.notify_all();
+            continue;                                            // (mine may have been in another leader's batch, or still be pending)
+        }
+        g_cv.wait(lock);
     }
-    g_pairs += n; ++g_calls;
 }
 }  // namespace
 

@@ -75,7 +75,14 @@ void attach(const worker_t &w) {                    // once: the loaded index as
 }  // namespace
 
 void mem_process_seqs(mem_opt_t *opt, int64_t n_processed, int n, bseq1_t *seqs, const mem_pestat_t *pes0, worker_t &w) {
-    std::lock_guard<std::mutex> lock(g.mu);
+    // One chunk at a time: the contexts serve one host thread each.  Under fastmap.cpp's kt_pipeline this never waits (klib lets chunk i + 1 into
+    // step 1 only when chunk i has left it); a caller that runs step 1 of two chunks side by side is serialised HERE, and is told so once.
+    std::unique_lock<std::mutex> lock(g.mu, std::try_to_lock);
+    if (!lock.owns_lock()) {
+        static std::atomic<bool> told{false};
+        if (!told.exchange(true)) fprintf(stderr, "[bm2] mem_process_seqs was entered by two threads at once: the chunks run one after the other (one device stage per process)\n");
+        lock.lock();
+    }
     if (g.ctx.empty()) attach(w);
     const double t0 = realtime();
     // ---- options: mem_opt_t -> the two structs of include/bm2.h (same names, same meaning)
@@ -144,6 +151,9 @@ void mem_process_seqs(mem_opt_t *opt, int64_t n_processed, int n, bseq1_t *seqs,
     }
     if (rc) die("SAM tail");
     text[need] = 0;
-    if (n > 0) seqs[0].sam = text; else free(text);     // step 2 prints the strings in read order and frees them (fastmap.cpp:307-316)
+    // The chunk's records are ONE string, handed over as read 0's: step 2 prints the non-null strings in read order and frees them
+    // (fastmap.cpp:307-316), so the output is the same bytes; a caller that wants one string per read has to cut it at the reads' QNAMEs.
+    for (int i = 1; i < n; i++) seqs[i].sam = nullptr;
+    if (n > 0) seqs[0].sam = text; else free(text);
     fprintf(stderr, "\t[0000][ M::%s] Processed %d reads in %.3f real sec (libbm2)\n", __func__, n, realtime() - t0);
 }

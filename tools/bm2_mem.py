@@ -10,6 +10,8 @@ Output = @SQ header lines + alignment lines (no @PG: that line is the caller's c
 run(..., hits_of=f) lets the tests put a stand-in for the device stage (tests/helpers.py does, to check the harness on a CPU)."""
 import argparse
 import os
+
+os.environ.setdefault("BM2_MALLOC_TUNE", "1")        # this program IS the host: the tail's threads run with glibc's trim / mmap thresholds set (sam_tail.cpp: the library touches them only on request)
 import sys
 
 import numpy as np

@@ -23,6 +23,8 @@ def rewrite(text):
     # collectives called from divergent lanes -> their one-lane-at-a-time versions (see the fake hip_runtime.h); the definition stays
     text = re.sub(r"(?<![A-Za-z_])wave_alloc<(\w+)>\(", r"emu_wave_alloc<\1>(", text)
     text = text.replace("static __device__ __forceinline__ int64_t emu_wave_alloc(", "static __device__ __forceinline__ int64_t wave_alloc(")
+    text = re.sub(r"(?<![A-Za-z_])wave_alloc_exact\(", "emu_wave_alloc<1>(", text)                      # (one id per calling lane, atomically: what the GPU's ballot + one atomic gives)
+    text = text.replace("static __device__ __forceinline__ int64_t emu_wave_alloc<1>(LdsPool *,", "static __device__ __forceinline__ int64_t wave_alloc_exact(LdsPool *,")
     # implicit lockstep: "lane 0 initialises the wave's LDS pool, then every lane uses it" needs no barrier on a GPU (one wavefront,
     # program order); OS threads need a rendezvous there.  (Sites are wave-uniform: the first statements of the kernels.)
     text = re.sub(r"(\n[ \t]*if \((?:\(threadIdx\.x & 63\) == 0|lane == 0)\) \{[^\n{}]*->pos = [^\n{}]*\}[ \t]*)(?=\n)", r"\1 emu_wsync();", text)

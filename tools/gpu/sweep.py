@@ -21,8 +21,9 @@ sys.path.insert(0, os.path.join(ROOT, "bwa-mem2_amd"))
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 GRID = [   # (name, candidates): a candidate is a dict of knobs set together; the first one ({} = the library's defaults) is the incumbent
-    ("seeding: k_bwd hands old tasks over (k_bwd_cont: sixteen lanes per task)", [{}, {"BM2_BWD_EXPORT_AGE": 0}, {"BM2_BWD_EXPORT_AGE": 384}, {"BM2_BWD_EXPORT_AGE": 192}, {"BM2_BWD_EXPORT_AGE": 160}]),
+    ("seeding: k_bwd hands old tasks over (k_bwd_cont: sixteen lanes per task)", [{}, {"BM2_BWD_EXPORT_AGE": 0}, {"BM2_BWD_EXPORT_AGE": 192}, {"BM2_BWD_EXPORT_AGE": 160}]),
     ("seeding: workgroups per CU of k_bwd_cont", [{}, {"BM2_BWD_CONT_BPC": 4}, {"BM2_BWD_CONT_BPC": 8}]),
+    ("seeding: workgroups per CU of k_bwd_heavy beside k_bwd", [{}, {"BM2_BWD_HEAVY_BPC": 1}, {"BM2_BWD_HEAVY_BPC": 2}]),
     ("seeding: the long lists' kernel after k_bwd", [{}, {"BM2_BWD_HEAVY_AFTER": 1}]),
     ("chain clock", [{}, {"BM2_CHAIN_CLOCK": 1}]),
     ("chain staging", [{}, {"BM2_CHAIN_STAGE": 1}]),
