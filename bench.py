@@ -44,7 +44,7 @@ sys.path.insert(0, os.path.join(ROOT, "bwa-mem2_amd"))
 
 RANDOM_LINE_GLPS = 55.0        # measured: ~55 G independent 64-B lines/s delivered (tools/ubench/randline.hip)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-CONFIG5_READS = ["--reads", "40000"]                       # config 5's chunk inside the default line (tools/gpu/ont_scaling.py: reads/s against chunk size)
+CONFIG5_READS = ["--reads", "20000"]                       # config 5's chunk inside the default line: what fits beside the index (9 GB of workspaces per 1000 reads; profiles/r05e_ont_scaling.log: 11.9 k reads/s at 10 000 reads, 16.6 k at 20 000)
 ONT2D = dict(a=1, b=1, o_del=1, e_del=1, o_ins=1, e_ins=1, pen_clip5=0, pen_clip3=0, min_seed_len=14, min_chain_weight=20,
              split_factor=10.0)      # `-x ont2d`, fastmap.cpp:812-826
 

@@ -1146,8 +1146,10 @@ int bm2_launch_chain(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_
         // chosen where the number of blocks per CU changes (10, 15, 20, 30, 40, 53, 80, 156 KB: 16, 10, 8, 5, 4, 3, 2, 1 per CU).
         // BM2_CHAIN_CLOCK=1: the wavefront-per-read launches clock their reads (counters[43..47] of the batch: staging, mem_chain_seeds, the rest, reads, seeds)
         unsigned long long *clk = bm2_knob("BM2_CHAIN_CLOCK", 0) ? item_cur + CHAIN_CUR_EXTRA + 3 : (unsigned long long *)nullptr;
-        // BM2_CHAIN_COOP_FLT=1 (off; not yet measured on the GPU): the wavefront-per-read launches run mem_chain_flt's walk over the kept chains with all 64 lanes
-        const int coop = bm2_knob("BM2_CHAIN_COOP_FLT", 0);
+        // BM2_CHAIN_COOP_FLT: the wavefront-per-read launches run mem_chain_flt's walk over the kept chains with all 64 lanes.  Measured in round 5 (with
+        // wavefront-scope fences: profiles/r05b / r05d / r05e_sweep.json): chaining of the 150 bp workload 11.5-12.4 -> 10.9-11.1 ms in three sweeps (ON for
+        // short reads); a chunk of 10 kb reads -- the island kernel, a handful of kept chains per read -- 454 -> 463 ms (OFF there)
+        const int coop = bm2_knob("BM2_CHAIN_COOP_FLT", max_len < 1000 ? 1 : 0);
         const int fine = bm2_knob("BM2_CHAIN_FINE_TIERS", 0);
         const int last_cap = stage ? 1000 : 1184;                 // (the last tier fills a CU's 160 KB of LDS)
         const int caps_coarse[5] = { 64, 128, 256, 512, last_cap }, caps_fine[8] = { 64, 96, 128, 192, 256, 340, 512, last_cap };

@@ -782,6 +782,7 @@ static __device__ bool seed_redundant_kept(const ChainParams &o, int l_query, co
 }
 
 #define PF_HEAVY 24                 // reads with more regs than this are purged by a whole wavefront (k_postfilter_heavy); knob BM2_PF_HEAVY
+#define PF_RCACHE 8                 // k_postfilter_heavy: regs per lane held in registers (the first 512 regs of a read)
 
 // Redundant-seed post-filter, bwamem.cpp:2895-2989 (one read per lane): replays the original bwa-mem rule "skip a seed
 // already contained in an earlier alignment unless an overlapping seed lies on another diagonal" and purges those regs.
@@ -860,6 +861,15 @@ k_postfilter_heavy(ChainParams o, const int32_t *__restrict__ heavy /* read ids,
             const bool kept = i < first_idx && i < nr && !(av[i].qb == -1 && av[i].qe == -1);
             lim += __popcll(__ballot(kept));
         }
+        // The walk of every seed reads the same six fields of the read's regs: the first PF_RCACHE * 64 regs live in REGISTERS (lane l holds regs
+        // l, l + 64, ...; a purge updates the owner's copy), so a walk is compares and ballots -- the heaviest read of a chunk (400+ regs, its seeds
+        // judged one after the other) set the length of this kernel with 7 dependent loads per seed (3.3 ms of a 67 ms step).
+        int64_t c_rb[PF_RCACHE], c_re[PF_RCACHE]; int32_t c_qb[PF_RCACHE], c_qe[PF_RCACHE], c_w[PF_RCACHE], c_sl[PF_RCACHE];
+        _Pragma("unroll") for (int cc = 0; cc < PF_RCACHE; cc++) {
+            const int i = cc * 64 + lane;
+            c_rb[cc] = c_re[cc] = 0; c_qb[cc] = c_qe[cc] = -1; c_w[cc] = c_sl[cc] = 0;
+            if (i < nr) { const DevReg p = av[i]; c_rb[cc] = p.rb; c_re[cc] = p.re; c_qb[cc] = p.qb; c_qe[cc] = p.qe; c_w[cc] = p.w; c_sl[cc] = p.seedlen0; }
+        }
         if (nr > first_idx) {
             for (int j = 0; j < nc; j++) {
                 const DevChain c = chn[base + j];
@@ -872,25 +882,46 @@ k_postfilter_heavy(ChainParams o, const int32_t *__restrict__ heavy /* read ids,
                     // ---- seed_redundant, bwamem.cpp:2922-2983, 64 regs at a time
                     const DevSeed s = cs[srt2[k]];
                     int v = 0; bool stopped = false;
-                    for (int i0 = 0; i0 < nr && v < lim && !stopped; i0 += 64) {
+                    // one reg against the seed: is it live, and does it end the walk (one of the two band tests)
+                    auto judge = [&](bool in_range, int64_t p_rb, int64_t p_re, int p_qb, int p_qe, int p_w, int p_sl, bool &live, bool &brk) {
+                        live = in_range && !(p_qb == -1 && p_qe == -1); brk = false;
+                        if (live && !(s.rbeg < p_rb || s.rbeg + s.len > p_re || s.qbeg < p_qb || s.qbeg + s.len > p_qe) &&
+                            !(s.len - p_sl > .1 * l_query)) {
+                            int qd = s.qbeg - p_qb; int64_t rd = s.rbeg - p_rb;
+                            int max_gap = cal_max_gap2(o, qd < rd ? qd : (int)rd);
+                            int w = max_gap < p_w ? max_gap : p_w;
+                            if (qd - rd < w && rd - qd < w) brk = true;
+                            else {
+                                qd = p_qe - (s.qbeg + s.len); rd = p_re - (s.rbeg + s.len);
+                                max_gap = cal_max_gap2(o, qd < rd ? qd : (int)rd);
+                                w = max_gap < p_w ? max_gap : p_w;
+                                if (qd - rd < w && rd - qd < w) brk = true;
+                            }
+                        }
+                    };
+                    auto tally = [&](bool live, bool brk) {     // the order of the 64 regs restored with ballots
+                        const unsigned long long lm = __ballot(live);
+                        const bool looked = live && v + __popcll(lm & lt_mask) < lim;     // the walk reaches this reg with v < lim
+                        const unsigned long long bm = __ballot(looked && brk);
+                        if (bm) {
+                            const int ib = __ffsll((long long)bm) - 1;
+                            v += __popcll(lm & (ib ? (~0ULL >> (64 - ib)) : 0ULL));          // regs counted before the stopping one
+                            stopped = true;
+                        } else v += __popcll(lm);                                            // (>= lim ends the walk: v is only compared with lim)
+                    };
+                    _Pragma("unroll") for (int cc = 0; cc < PF_RCACHE; cc++) {              // the regs held in registers
+                        if (cc * 64 < nr && v < lim && !stopped) {
+                            bool live, brk;
+                            judge(cc * 64 + lane < nr, c_rb[cc], c_re[cc], c_qb[cc], c_qe[cc], c_w[cc], c_sl[cc], live, brk);
+                            tally(live, brk);
+                        }
+                    }
+                    for (int i0 = PF_RCACHE * 64; i0 < nr && v < lim && !stopped; i0 += 64) {   // a read with more regs than that: the rest from memory
                         const int i = i0 + lane;
                         bool live = false, brk = false;
                         if (i < nr) {
                             const DevReg p = av[i];
-                            live = !(p.qb == -1 && p.qe == -1);
-                            if (live && !(s.rbeg < p.rb || s.rbeg + s.len > p.re || s.qbeg < p.qb || s.qbeg + s.len > p.qe) &&
-                                !(s.len - p.seedlen0 > .1 * l_query)) {
-                                int qd = s.qbeg - p.qb; int64_t rd = s.rbeg - p.rb;
-                                int max_gap = cal_max_gap2(o, qd < rd ? qd : (int)rd);
-                                int w = max_gap < p.w ? max_gap : p.w;
-                                if (qd - rd < w && rd - qd < w) brk = true;
-                                else {
-                                    qd = p.qe - (s.qbeg + s.len); rd = p.re - (s.rbeg + s.len);
-                                    max_gap = cal_max_gap2(o, qd < rd ? qd : (int)rd);
-                                    w = max_gap < p.w ? max_gap : p.w;
-                                    if (qd - rd < w && rd - qd < w) brk = true;
-                                }
-                            }
+                            judge(true, p.rb, p.re, p.qb, p.qe, p.w, p.seedlen0, live, brk);
                         }
                         const unsigned long long lm = __ballot(live);
                         const bool looked = live && v + __popcll(lm & lt_mask) < lim;     // the walk reaches this reg with v < lim
@@ -920,9 +951,12 @@ k_postfilter_heavy(ChainParams o, const int32_t *__restrict__ heavy /* read ids,
                     }
                     if (red) {
                         if (lane == 0) { av[idx].qb = -1; av[idx].qe = -1; srt2[k] = -1; }
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");      // the next seed's walk re-reads av[] / srt2[] through other lanes
+                        _Pragma("unroll") for (int cc = 0; cc < PF_RCACHE; cc++) if (idx == cc * 64 + lane) { c_qb[cc] = -1; c_qe[cc] = -1; }
+                        // the next seed's walk re-reads av[] / srt2[] through other lanes OF THIS WAVEFRONT: wavefront scope (the lanes share the CU's L1;
+                        // at agent scope every purged reg cost an L2 write-back and an L1 invalidate, ~3 us of a read whose walk is sequential anyway)
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                         __builtin_amdgcn_wave_barrier();
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                     } else lim++;
                 }
             }
