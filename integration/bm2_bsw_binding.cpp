@@ -50,6 +50,7 @@ void attach() {
     const char *e = getenv("BM2_S1_CONTEXTS"), *dev = getenv("BM2_DEVICE");
     int n = e && *e ? atoi(e) : 2;
     g_n = n < 1 ? 1 : n > MAX_SLOT ? MAX_SLOT : n;
+    setenv("BM2_BLOCKING_SYNC", "1", 0);                         // the leader of a batch sleeps while the device works: its CPU goes to the threads that are seeding
     for (int i = 0; i < g_n; i++) {
         g_slot[i].ctx = bm2_create(dev ? atoi(dev) : 0, nullptr);       // (no index: S1 needs none)
         if (!g_slot[i].ctx) { fprintf(stderr, "[bm2s1] bm2_create: %s\n", bm2_last_error()); exit(EXIT_FAILURE); }
@@ -120,10 +121,12 @@ void run(const BandedPairWiseSW *self, SeqPair *pairs, uint8_t *ref, uint8_t *qe
         if (free_slot >= 0 && !g_pending.empty()) {              // lead a batch: everything filed so far that shares the first request's band and scoring
             std::vector<Request *> batch, rest;
             const Request *lead = g_pending[0];
-            size_t pairs_in = 0;
+            size_t pairs_in = 0, ref_in = 0, qer_in = 0;          // (SeqPair's offsets are 32-bit: a batch stays below 2^30 bytes of either sequence buffer)
             for (Request *r : g_pending) {
-                const bool same = r->w == lead->w && !memcmp(&r->p, &lead->p, sizeof r->p) && pairs_in + (size_t)r->n < ((size_t)1 << 30);
-                if (same) { batch.push_back(r); pairs_in += (size_t)r->n; } else rest.push_back(r);
+                const bool same = r->w == lead->w && !memcmp(&r->p, &lead->p, sizeof r->p);
+                const bool fits = batch.empty() || (pairs_in + (size_t)r->n < ((size_t)1 << 28) && ref_in + (size_t)r->ref_bytes < ((size_t)1 << 30) &&
+                                                    qer_in + (size_t)r->qer_bytes < ((size_t)1 << 30));
+                if (same && fits) { batch.push_back(r); pairs_in += (size_t)r->n; ref_in += (size_t)r->ref_bytes; qer_in += (size_t)r->qer_bytes; } else rest.push_back(r);
             }
             g_pending.swap(rest);
             Slot &s = g_slot[free_slot];

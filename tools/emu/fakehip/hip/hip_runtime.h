@@ -191,6 +191,8 @@ enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDevi
 static inline const char *hipGetErrorString(hipError_t) { return "emulated"; }
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }
+enum { hipDeviceScheduleBlockingSync = 4 };
+static inline hipError_t hipSetDeviceFlags(unsigned) { return hipSuccess; }
 static inline hipError_t hipMalloc(void **p, size_t n) { *p = calloc(1, n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 static inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t = 0) { memcpy(d, s, n); return hipSuccess; }

@@ -86,14 +86,16 @@ def main():
     f, fc = counters(os.path.join(src, "pmc_fetch.md"))
     w, _ = counters(os.path.join(src, "pmc_write.md"))
     def bwd(d, counter):                                          # k_bwd is a template since round 2: "void k_bwd<12>", "void k_bwd5<6>"
-        tot, nd = 0.0, 0
+        tot, nd = 0.0, 0                                          # (k_bwd_cont -- the tasks k_bwd hands over, round 5 -- belongs to its k_bwd launch: its bytes count, its dispatches do not)
         for k, v in d.items():
             if "k_bwd" in k and "heavy" not in k and counter in v:
-                tot += v[counter][0]; nd += v[counter][1]
+                tot += v[counter][0]
+                if "k_bwd_cont" not in k:
+                    nd += v[counter][1]
         return tot, nd
     fs, nd = bwd(f, "FETCH_SIZE")
     ws, _ = bwd(w, "WRITE_SIZE")
-    out = {"kernel": "k_bwd", "workload": wl, "fetch_size_kib_per_launch": fs / nd, "write_size_kib_per_launch": ws / nd,
+    out = {"kernel": "k_bwd (+ k_bwd_cont)", "workload": wl, "fetch_size_kib_per_launch": fs / nd, "write_size_kib_per_launch": ws / nd,
            "hbm_bytes_per_launch": (fs + ws) / nd * 1024.0,
            "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (profiles/%s_pmc_fetch.md, %s_pmc_write.md): sums over %d "
                      "dispatches divided by %d.  FETCH_SIZE is in KiB and was calibrated at factor 1.00 on isolated 64-byte lines with "
@@ -111,6 +113,9 @@ def main():
                 per.setdefault(fam, {})[cn] = per.setdefault(fam, {}).get(cn, 0.0) + val
     steps = float(os.environ.get("PMC_STEPS", 2))                # the PMC passes run `--steps 1 --warmup 1`
     stage_ms = bench["stage_ms_per_step"]["extend"]
+    # (NOT the stage time of the counter pass itself: under --pmc the profiler runs one dispatch at a time, the eight concurrent launches of a phase one
+    #  after the other -- 43 ms instead of 16 in round 5's pass.  The instruction count of a step does not depend on that; the time it is divided by
+    #  is the stage time of the un-profiled bench run of the same call, src/bench.json.)
     # VALU issue: wave-instructions per second against the rate MEASURED on this GPU by tools/ubench/valu_int.hip (the best line of the
     # committed run: independent v_add_u32 + v_max_i32 chains), and against the nominal 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction
     insts = tot["SQ_INSTS_VALU"] / steps
