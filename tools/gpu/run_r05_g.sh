@@ -3,6 +3,7 @@
 TAG=${1:-r05g}; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O
 cd $R; export TMPDIR=/tmp
 T0=$(date +%s); at() { echo "$1 rc=$2 at $(( $(date +%s) - T0 ))s"; }
+timeout 300 python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-parity --no-e2e --no-side-workloads > $O/bench_min.json 2> $O/bench_min.err; at genome_and_index $?
 for k in 1 2; do
   timeout 300 python bench.py --workload bsw --steps 3 --warmup 1 > $O/bench_bsw_$k.json 2> $O/bench_bsw_$k.err; at bsw$k $?
   python - <<P
