@@ -426,10 +426,9 @@ def s1_binding_leg(workdir, prefix):
     md = {}
     prof_pat = (("mem_process_seqs_s", r"MEM_PROCESS_SEQ\(\)[^:]*: ([\d.]+)"), ("kernels_s", r"Total kernel \(smem\+sal\+bsw\) time avg: ([\d.]+)"),
                 ("smem_s", r"SMEM compute avg: ([\d.]+)"), ("sal_s", r"SAL compute avg: ([\d.]+)"), ("bsw_s", r"BSW time, avg: ([\d.]+)"), ("worker_sam_s", r"WORKER_SAM avg: ([\d.]+)"))
-    # Both programs get the same CPUs -- this process's quota -- but not the same -t: the HIP runtime brings service threads of its own (and a leader
-    # waiting for its batch), and a process with more runnable threads than its quota has CPUs is throttled for whole scheduler periods (section 6b
-    # of DESIGN.md: the same bm2s1 run measured 6.5 s and 8.7 s per chunk with -t 16).  The binding's run leaves two CPUs of the quota to them.
-    t_s1 = max(1, threads - 2)
+    # (Both programs with the same -t.  Measured in round 5, profiles/r05g_*: leaving two CPUs of the quota to the HIP runtime's threads -- the binding with
+    #  -t 14 -- is WORSE, 7.0-7.2 s per chunk against 6.45 with -t 16: the fourteen threads' seeding takes what the two would have done.)
+    t_s1 = threads
     res["threads_bm2s1"] = t_s1
     for tag, binary in (("reference", exe), ("bm2s1", s1)):
         out_sam = os.path.join(workdir, "s1_%s.sam" % tag)
