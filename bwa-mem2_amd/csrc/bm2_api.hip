@@ -68,7 +68,6 @@ static int upload(void **dst, const T *src, size_t n, hipStream_t s) {
 }
 
 void bm2_batch_destroy(bm2_ctx *c);     // pipeline.hip
-int bm2_build_ktab(bm2_ctx *c, int K, void **d_tab);      // smem.hip
 
 #define BM2_PIN_CAP ((size_t)16 << 20)
 // (BM2_PIN_PIECE / BM2_PIN_MIN: test hooks that make small copies go through the staged path in small pieces)
@@ -382,12 +381,6 @@ extern "C" bm2_ctx *bm2_create(int device, const bm2_index_desc *idx) {
         ix.ref_len = idx->ref_len; ix.l_pac = idx->l_pac; ix.sentinel_index = idx->sentinel_index;
         for (int i = 0; i < 5; i++) ix.count[i] = idx->count[i] + 1;      // FMI_search.cpp:433-436
         ix.n_seqs = idx->n_seqs;
-        ix.ktab = nullptr; ix.ktab_k = 0; ix.ktab_pad = 0;
-        const int ktab_k = bm2_knob("BM2_KTAB_K", BM2_KTAB_K);     // the k-mer table of the seeding's forward walks (bm2_dev.h): 2 * 4^K entries of 16 bytes (537 MB at 12); 0 = none
-        if (ktab_k > 0) {
-            if (bm2_build_ktab(c, ktab_k > 12 ? 12 : ktab_k, &c->d_ktab)) { bm2_destroy(c); return nullptr; }
-            ix.ktab = (const uint4 *)c->d_ktab; ix.ktab_k = ktab_k > 12 ? 12 : ktab_k;
-        }
         c->has_index = true;
         bm2_ensure_subs(c, bm2_knob("BM2_N_SUB", BM2_N_SUB));
     }
@@ -451,7 +444,7 @@ extern "C" void bm2_destroy(bm2_ctx *c) {
     }
     c->subs.clear();
     bm2_batch_destroy(c);
-    void *ps[] = { c->d_cp_occ, c->d_sa_ms, c->d_sa_ls, c->d_ref, c->d_ann_off, c->d_ann_len, c->d_ann_alt, c->d_ktab };
+    void *ps[] = { c->d_cp_occ, c->d_sa_ms, c->d_sa_ls, c->d_ref, c->d_ann_off, c->d_ann_len, c->d_ann_alt };
     if (!c->is_child) for (void *p : ps) if (p) (void)hipFree(p);          // a shared context does not own the replica
     bm2_release(c->b_pairs); bm2_release(c->b_pairs2); bm2_release(c->b_ref); bm2_release(c->b_qer); bm2_release(c->b_misc); bm2_release(c->b_scan);
     free_streams(c);

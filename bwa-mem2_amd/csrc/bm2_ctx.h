@@ -14,7 +14,6 @@ struct DevBuf {
 };
 
 #define BM2_MAX_TIMERS 24
-#define BM2_KTAB_K 0                   // default of BM2_KTAB_K (bases of the k-mer table; 0 = no table)
 
 // The two halves of a chunk's device path lean on different parts of the GPU: seeding .. chaining waits for random HBM lines, extension ..
 // purge keeps the integer VALUs busy.  When a chunk runs as several parts (sub-batches), the gate lets exactly one part be in each half at a
@@ -35,7 +34,6 @@ struct bm2_ctx {
     // device copies of the index arrays (owned)
     void *d_cp_occ = nullptr, *d_sa_ms = nullptr, *d_sa_ls = nullptr, *d_ref = nullptr;
     void *d_ann_off = nullptr, *d_ann_len = nullptr, *d_ann_alt = nullptr;
-    void *d_ktab = nullptr;                                       // the k-mer table of the forward walks (DevIndex::ktab), owned by the context that built it
     // scratch for the S1/S2 entry points
     DevBuf b_pairs, b_pairs2, b_ref, b_qer, b_misc;
     int n_bsw = 0;                 // pairs of the resident S1 batch (bm2_bsw_upload)

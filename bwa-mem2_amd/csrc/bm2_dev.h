@@ -33,11 +33,6 @@ struct DevIndex {
     int64_t count[5];                // already +1 (FMI_search.cpp:433-436)
     int32_t n_seqs;
     int32_t ref_pk;
-    // k-mer table (round 5, bm2_build_ktab): the bi-interval {k, l, s} (packed as a candidate-list entry) of EVERY string of 1..ktab_k bases, entry
-    // (1 << 2 len) | code with code = the bases as a big-endian base-4 number.  The interval of a string does not depend on the order it was extended in,
-    // so a forward walk may take its first ktab_k bases in one step where nothing between them is looked at (pass 3 of the seeding).  nullptr / 0: none.
-    const uint4 *ktab;
-    int32_t ktab_k, ktab_pad;
     __host__ __device__ RefPtr ref(int64_t pos) const { return RefPtr{ref_string, pos, ref_pk}; }
 };
 

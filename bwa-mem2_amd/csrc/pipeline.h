@@ -46,7 +46,6 @@ int bm2_launch_seeding(bm2_ctx *c, const SeedParams &sp, int n_reads, const uint
                        void (*tick)(bm2_ctx *, const char *), int max_len);
 int bm2_launch_smem_finish(bm2_ctx *c, int n_reads, const SeedBufs &sb, const unsigned long long *sc, const int32_t *smem_cnt,
                            const int64_t *smem_off, int32_t *fill, bm2_smem_t *tmp, int32_t max_occ, bm2_smem_t *out, int32_t *occ_cnt, int max_len);
-int bm2_build_ktab(bm2_ctx *c, int K, void **d_tab);
 int bm2_seed_sizes(size_t *head, size_t *ent, size_t *task, int *n_sc, size_t *ctask);      // returns CAPF
 int bm2_launch_sal_expand(bm2_ctx *c, const bm2_smem_t *smems, int64_t n_smem, const int64_t *sa_off, int32_t max_occ, int64_t *pos);
 int bm2_launch_sal(bm2_ctx *c, int64_t n, int64_t *pos_coord, unsigned long long *n_lf);

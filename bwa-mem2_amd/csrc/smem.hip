@@ -250,44 +250,10 @@ struct QWin {
     }
 };
 
-// ---- the k-mer table (DevIndex::ktab): level by level, a string of `level` bases from its prefix of level - 1 by one forward extension --------
-__global__ void __launch_bounds__(256)
-k_ktab_level(DevIndex ix, uint4 *tab, int level) {
-    const int64_t n = (int64_t)1 << (2 * level);
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool on = i < n;                                    // (the first levels hold fewer strings than a workgroup has lanes: the idle lanes stay for the quad exchanges)
-    const int a = (int)(i & 3);
-    Bi sm = init_bi(ix, a);
-    int64_t ek = 0, el = 0, es = 0;
-    if (on && level > 1) {
-        int nn;
-        int64_t pk, pl, ps;
-        pv_unpack(tab[((int64_t)1 << (2 * (level - 1))) | (i >> 2)], pk, pl, ps, nn);
-        ek = pl; el = pk; es = ps;                            // forward = backward on the swapped interval with the complement (FMI_search.cpp:546-570)
-    }
-    const Bi ein = { ek, el, es };
-    const Bi o = backward_ext(ix, ein, 3 - a, on && level > 1);
-    if (on && level > 1) { sm.k = o.l; sm.l = o.k; sm.s = o.s; }
-    if (on) tab[n | i] = pv_pack(sm.k, sm.l, sm.s, 0);
-}
-int bm2_build_ktab(bm2_ctx *c, int K, void **d_tab) {          // K in [1, 12]; *d_tab: 2 * 4^K entries of 16 bytes, owned by the caller
-    if (K < 1 || K > 12) { bm2_set_error("k-mer table: K = %d is out of range (1..12)", K); return BM2_EINVAL; }
-    const size_t bytes = ((size_t)2 << (2 * K)) * sizeof(uint4);
-    int rc = bm2_check(hipMalloc(d_tab, bytes), "hipMalloc(k-mer table)");
-    if (rc) return rc;
-    if ((rc = bm2_check(hipMemsetAsync(*d_tab, 0, bytes, c->stream), "memset k-mer table"))) return rc;
-    for (int level = 1; level <= K; level++) {
-        const int64_t n = (int64_t)1 << (2 * level);
-        hipLaunchKernelGGL(k_ktab_level, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->ix, (uint4 *)*d_tab, level);
-    }
-    if ((rc = bm2_check(hipGetLastError(), "k_ktab_level"))) return rc;
-    return bm2_check(hipStreamSynchronize(c->stream), "k-mer table");
-}
-
 // ---- forward walks ----------------------------------------------------------------------------------------------
 // MODE W_P1: item = read; chain of start positions, every walk leaves a backward task.  W_P2: item = P2Task, one walk.
 // W_P3: item = read; forward-only seeding, SMEM records written directly.
-enum { F_EXT = 0, F_NEWITEM, F_START, F_NEWPOS, F_CHK, F_END, F_KCODE, F_KWAIT, F_DONE };
+enum { F_EXT = 0, F_NEWITEM, F_START, F_NEWPOS, F_CHK, F_END, F_DONE };
 
 template <int MODE>
 __global__ void __launch_bounds__(256)
@@ -321,7 +287,6 @@ k_walk(DevIndex ix, SeedParams sp, int n_reads, const uint8_t *__restrict__ enc,
     int64_t smk = 0, sml = 0, sms = 0; int smn = 0;
     int64_t eik = 0, eil = 0, eis = 0; int ea = 0;
     QWin w; w.cur = w.nxt = 0; w.curb = w.nxtb = -64;
-    uint4 ktv = {}; int klen = 0; unsigned kcode = 0; bool ktry = true, kreq = false;      // pass 3: the table entry of a walk's first k-mer, the k-mer's length, the entry's index
 
     auto push = [&](const uint4 v) {                          // prev[n_prev++] = sm
         if (slot < slot_cap) {
@@ -337,7 +302,6 @@ k_walk(DevIndex ix, SeedParams sp, int n_reads, const uint8_t *__restrict__ enc,
 
     for (;;) {
         while (state != F_EXT && state != F_DONE) {            // `break` = yield: sit out one extension round
-            if constexpr (MODE == W_P3) { if (state == F_KCODE || state == F_KWAIT) break; }      // (the k-mer step goes on outside this loop: below)
             if (state == F_NEWITEM) {
                 if (it_a >= n_items) { state = F_DONE; break; }
                 if (MODE == W_P2) { r = pl_t.r; rd_off = pl_t.rd_off; L = pl_t.L; x = pl_t.x; min_intv = (int64_t)pl_t.s + 1; }
@@ -353,16 +317,6 @@ k_walk(DevIndex ix, SeedParams sp, int n_reads, const uint8_t *__restrict__ enc,
             if (state == F_NEWPOS) {                            // FMI_search.cpp:514-535 / :746-755
                 if (MODE != W_P2 && x >= L) { state = F_NEWITEM; continue; }
                 if (!w.get(q, x, 1, a)) break;
-                if constexpr (MODE == W_P3) {
-                    // Pass 3 looks at nothing between the start of a walk and its (min_seed_len + 1)-th base (:771-808: an SMEM needs that length), so
-                    // its first bases are ONE lookup in the k-mer table (bm2_dev.h) instead of an extension each: as many as the two query windows in
-                    // registers hold from x on (9..16), at most ktab_k and min_seed_len, all of them A, C, G, T.  Two rounds: the bases' code is worked
-                    // out BEHIND this round's extension (the windows are prefetches: behind the extension they have arrived), the entry is requested
-                    // before the next one and used behind it.  Nothing pending is looked at inside this loop or carried round it -- the compiler
-                    // answers that with a `s_waitcnt vmcnt(0)` at a loop header (notes/NEXT.md).
-                    if (ktry && ix.ktab_k > 1 && L - x > 1) { state = F_KCODE; break; }
-                    ktry = true;
-                }
                 next_x = x + 1;
                 if (a >= 4) {
                     if (MODE == W_P2) state = F_NEWITEM; else x = next_x;
@@ -403,16 +357,8 @@ k_walk(DevIndex ix, SeedParams sp, int n_reads, const uint8_t *__restrict__ enc,
         if ((threadIdx.x & 63) == 0) prof_rounds++;
         if (state == F_EXT) prof_active++;
 #endif
-        if constexpr (MODE == W_P3) { if (state == F_KWAIT) { ktv = ix.ktab[kcode]; kreq = true; } }      // (requested here -- not inside the state loop --, used behind the extension)
         const Bi ein = { eik, eil, eis };
         const Bi o = backward_ext(ix, ein, ea, state == F_EXT);   // (all lanes: quad-cooperative)
-        // What the lane requested before this extension -- the next query window, the next work item -- has arrived behind the CP_OCC lines: say so
-        // HERE, where waiting for it costs nothing.  Left pending round the loop, such a register may get copied at the loop header, and the copy
-        // brings a `s_waitcnt vmcnt(0)` per round with it (k_walk<3>: 3.3 -> 17 ms when a restructured loop did that, profiles/r05c_*).
-        asm volatile("" : "+v"(w.cur), "+v"(w.nxt));
-        if (MODE == W_P3) asm volatile("" : "+v"(ktv.x), "+v"(ktv.y), "+v"(ktv.z), "+v"(ktv.w));
-        if (MODE == W_P2) asm volatile("" : "+v"(pl_t.rd_off), "+v"(pl_t.r), "+v"(pl_t.L), "+v"(pl_t.x), "+v"(pl_t.s));
-        else asm volatile("" : "+v"(pl_off), "+v"(pl_len));
         if (state == F_EXT) {                                   // forward = swapped backward, :546-570
             n_ext++;
             if (MODE == W_P3) {                                 // :771-808
@@ -432,24 +378,6 @@ k_walk(DevIndex ix, SeedParams sp, int n_reads, const uint8_t *__restrict__ enc,
                 if (o.s != sms) push(pv_pack(smk, sml, sms, smn));
                 if (o.s < min_intv) { next_x = j; state = F_END; }
                 else { smk = o.l; sml = o.k; sms = o.s; smn = j; j++; state = F_CHK; }
-            }
-        }
-        if constexpr (MODE == W_P3) {                           // the k-mer step, behind the round's extension
-            if (state == F_KCODE) {
-                const int d0 = x - w.curb;                      // (0..7: w.get has found x in the current window; the next one starts at curb + 8)
-                int kl = 16 - d0; kl = kl < ix.ktab_k ? kl : ix.ktab_k; kl = kl < sp.min_seed_len ? kl : sp.min_seed_len; kl = kl < L - x ? kl : L - x;
-                bool ok = kl > 1 && w.nxtb == w.curb + 8 && d0 >= 0 && d0 < 8;
-                const uint64_t lo = d0 ? (w.cur >> (8 * d0)) | (w.nxt << (64 - 8 * d0)) : w.cur, hi = d0 ? w.nxt >> (8 * d0) : w.nxt;   // the bases from x on, one per byte
-                unsigned code = 0;
-                for (int t = 0; t < 12; t++) if (t < kl) { const unsigned b = (unsigned)((t < 8 ? lo >> (8 * t) : hi >> (8 * (t - 8))) & 0xff); ok = ok && b < 4; code = code << 2 | (b & 3); }
-                if (ok) { klen = kl; kcode = ((unsigned)1 << (2 * kl)) | code; state = F_KWAIT; }
-                else { ktry = false; state = F_NEWPOS; }       // (an ambiguous base, a window that does not follow: this start goes base by base)
-            } else if (state == F_KWAIT && kreq) {                             // the interval of q[x .. x + klen): the walk continues behind it, klen - 1 extensions taken in one step
-                int nn;
-                pv_unpack(ktv, smk, sml, sms, nn);
-                smn = x + klen - 1; j = x + klen; next_x = j; n_ext += klen - 1;
-                kreq = false;
-                state = F_CHK;
             }
         }
     }
@@ -654,7 +582,11 @@ bwd_body(const DevIndex &ix, const SeedParams &sp, int pass, const uint8_t *__re
 template <int LC> __global__ void __launch_bounds__(256) k_bwd(BWD_ARGS) { bwd_body<LC>(BWD_PASS); }
 // the same with the register allocation told to leave room for 5 waves per SIMD (96 VGPRs, 100 bytes per lane spilled)
 template <int LC> __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) k_bwd5(BWD_ARGS) { bwd_body<LC>(BWD_PASS); }
-// Measured in round 5 and removed (profiles/r05b_sweep.json, r05c_sweep_slow_rounds.json): (1) two candidates of a row per round (sixteen requests of a quad
+// Measured in round 5 and removed (profiles/r05b_sweep.json, r05c_sweep_slow_rounds.json, r05h_sweep_kmer_table_pass3.json): (0) a k-mer table (the
+// bi-interval of every string of up to 12 bases, 537 MB, built on the device at index upload -- the interval of a string does not depend on the order it was
+// extended in, checked with the oracle on 2 M strings) from which pass 3's walks took their first 9..12 bases in one lookup: bit-exact, 40 % fewer rounds in
+// k_walk<3> (beside k_walk<1>: 8.3 -> 7.1 ms), and the stage no faster: the reworked kernel beside k_bwd of pass 1 made that interval 17.0 ms with or without
+// the table (14.1 with the kernel as it is), beside k_walk<1> the stage took 32.5 ms against 31.5.  (1) two candidates of a row per round (sixteen requests of a quad
 // in flight, 161 VGPRs): bwd1 + bwd2 23.5 ms with it, 23.9 without -- lines in flight are not what binds the kernel; (2) the rare steps of a lane (new
 // task, SMEM record) only in every 2nd / 4th / 8th round, so that a wavefront pays for those blocks of the state machine less often: -0.8 ms at every
 // 4th round, and the restructured loops cost more than that in default form (phi copies of prefetched registers at the loop header: a
@@ -1206,12 +1138,10 @@ int bm2_launch_seeding(bm2_ctx *c, const SeedParams &sp, int n_reads, const uint
     const int p3_bpc = bm2_knob("BM2_P3_BPC", 0);                            // workgroups per CU of pass 3 (0: as many as the other walks)
     const int grid_p3 = p3_bpc > 0 ? c->n_cu * p3_bpc : grid_walk;
     const int heavy_after = bm2_knob("BM2_BWD_HEAVY_AFTER", 0);              // the long lists' wavefront-per-task kernel after k_bwd instead of beside it
-    DevIndex ix3 = c->ix;                                       // (BM2_KTAB_USE=0: pass 3 without the k-mer table although the context has one -- for A/B runs in one process)
-    if (!bm2_knob("BM2_KTAB_USE", 1)) ix3.ktab_k = 0;
     auto launch_p3 = [&]() {
         (void)hipEventRecord(c->ev_fork, s);
         (void)hipStreamWaitEvent(s3, c->ev_fork, 0);
-        hipLaunchKernelGGL(k_walk<W_P3>, dim3(grid_p3), dim3(256), 0, s3, ix3, sp, n_reads, enc, off, len, (const P2Task *)nullptr, (int64_t)0,
+        hipLaunchKernelGGL(k_walk<W_P3>, dim3(grid_p3), dim3(256), 0, s3, c->ix, sp, n_reads, enc, off, len, (const P2Task *)nullptr, (int64_t)0,
                            (BHead *)nullptr, (uint4 *)nullptr, (int64_t)0, (uint4 *)nullptr, 0, 0, sb.recs, sb.rec_cap, smem_cnt, sc,
                            (int32_t *)nullptr, (int64_t)0);
         (void)hipEventRecord(c->ev_join[0], s3);

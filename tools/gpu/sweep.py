@@ -19,10 +19,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "bwa-mem2_amd"))
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
-os.environ.setdefault("BM2_KTAB_K", "12")                     # (read when the context is made: the table is there, BM2_KTAB_USE switches its use per run)
 
 GRID = [   # (name, candidates): a candidate is a dict of knobs set together; the first one ({} = the library's defaults) is the incumbent
-    ("seeding: pass 3 takes its first bases from the k-mer table", [{}, {"BM2_KTAB_USE": 0}, {"BM2_KTAB_USE": 0, "BM2_P3_AT": 0}, {"BM2_P3_AT": 0}, {"BM2_P3_AT": 2}]),
     ("seeding: k_bwd hands old tasks over (k_bwd_cont: sixteen lanes per task)", [{}, {"BM2_BWD_EXPORT_AGE": 0}, {"BM2_BWD_EXPORT_AGE": 192}, {"BM2_BWD_EXPORT_AGE": 160}]),
     ("seeding: workgroups per CU of k_bwd_cont", [{}, {"BM2_BWD_CONT_BPC": 4}, {"BM2_BWD_CONT_BPC": 8}]),
     ("seeding: workgroups per CU of k_bwd_heavy beside k_bwd", [{}, {"BM2_BWD_HEAVY_BPC": 1}, {"BM2_BWD_HEAVY_BPC": 2}]),
@@ -87,7 +85,7 @@ def main():
     state = {"nsub": None}
 
     def measure(env):
-        for k in [k for k in os.environ if k.startswith("BM2_") and k not in ("BM2_EMU_LIB", "BM2_BENCH_WORKDIR", "BM2_KTAB_K")]:
+        for k in [k for k in os.environ if k.startswith("BM2_") and k not in ("BM2_EMU_LIB", "BM2_BENCH_WORKDIR")]:
             del os.environ[k]
         for k, v in env.items():
             os.environ[k] = str(v)
