@@ -43,6 +43,7 @@ GRID = [   # (name, candidates): a candidate is a dict of knobs set together; th
     ("extension dispatch order", [{}, {"BM2_EXT_REVERSE": 1}]),
     ("extension prefetch", [{}, {"BM2_EXT_PREFETCH": 0}]),
     ("seeding pass 3 placement", [{}, {"BM2_P3_AT": 0}, {"BM2_P3_AT": 2}]),
+    ("seeding: pass 3 workgroups per CU", [{}, {"BM2_P3_BPC": 2}, {"BM2_P3_BPC": 1}, {"BM2_P3_AT": 0, "BM2_P3_BPC": 1}, {"BM2_P3_AT": 0, "BM2_P3_BPC": 2}, {"BM2_P3_AT": 0, "BM2_P3_BPC": 3}]),
     ("extension column loop in groups of four", [{}, {"BM2_EXT_GROUP4": 0}]),
     ("SA lookup by quads", [{}, {"BM2_SAL_QUAD": 1}]),
     ("sub-batches of the chunk on their own streams", [{}, {"BM2_N_SUB": 2}, {"BM2_N_SUB": 3}]),
