@@ -1071,6 +1071,15 @@ def main():
                     break
             except Exception:
                 pass
+        if ont and traffic is None:                             # config 5: the forward walks are the seeding stage -- HBM bytes per k_walk<1> launch from the committed FETCH pass of the same chunk size
+            for fn in ("r05_ont2d_k_walk_pmc.json",):
+                try:
+                    pm = json.load(open(os.path.join(ROOT, "profiles", fn)))
+                    if pm["workload"]["genome_mbp"] == a.genome_mbp and pm["workload"]["reads_per_gpu_per_step"] == n_reads and roof_kernel.startswith("k_walk"):
+                        traffic, pmc_src = pm["hbm_bytes_per_launch"], "profiles/" + fn
+                        break
+                except Exception:
+                    pass
         ext_src = None
         # SQ counter passes of the extension stage (tools/pmc_to_profiles.py), the newest committed one OF THIS WORKLOAD (a pass of the 150 bp
         # workload says nothing about the kernels a 10 kb chunk runs)
@@ -1152,6 +1161,13 @@ def main():
                               "note": "valu_frac / lds_conflict_frac are of the committed counter pass (its own stage time: pmc_stage_ms), the rest is of this run"},
         }
         if chain_kernel:
+            if "serial_reads" in chain_kernel:                   # what bounds the chaining stage of a long-read chunk, from the kernel's own clock
+                sr = chain_kernel["serial_reads"]
+                chain_kernel["stage_bound"] = {"kind": "latency (one wavefront per read; a read with equal chain keys is chained again by ONE lane through global memory)",
+                                               "floor_ms": sr["slowest_ms"], "stage_ms": stage_ms.get("chain"),
+                                               "note": "k_chain_islands cannot end before its slowest serially chained read does (floor_ms; %d such reads of %.0f ms on average in this chunk); "
+                                                       "the seed filter's local SW (k_seed_sw, ~11 ms per 1000 reads, throughput-bound) and k_chain_finish follow it in the stage"
+                                                       % (chain_kernel["reads_chained_serially_equal_keys"], sr["ms_per_read"])}
             out["chain_kernel"] = chain_kernel
         # (stderr: the driver keeps the tail of it; the JSON line on stdout is long enough to lose its head there)
         log("hot path %.2f ms per step = %.2f M reads/s (%s); %s %.2f ms per launch = %.0f GB/s algorithmic = %.3f of the HBM peak"

@@ -69,7 +69,27 @@ def ont2d(src, pre):
     print(json.dumps(out, indent=1))
 
 
+def ont2d_fetch(src, pre):
+    """config 5's FETCH pass: gpurun_out/<tag>/pmc_fetch_ont2d.md + bench_ont2d_fetch.json -> profiles/<pre>_ont2d_k_walk_pmc.json (HBM bytes per k_walk<1> launch,
+    what `bench.py --workload ont2d` reports as roofline.traffic; FETCH_SIZE at face value: isolated 64-byte lines, profiles/r01_randline_ubench.txt)"""
+    dst = os.path.join(ROOT, "profiles")
+    bench = json.load(open(os.path.join(src, "bench_ont2d_fetch.json")))
+    shutil.copy(os.path.join(src, "pmc_fetch_ont2d.md"), os.path.join(dst, "%s_ont2d_pmc_fetch.md" % pre))
+    f, _ = counters(os.path.join(src, "pmc_fetch_ont2d.md"))
+    tot, nd = 0.0, 0
+    for k, v in f.items():
+        if "k_walk<1>" in k and "FETCH_SIZE" in v:
+            tot += v["FETCH_SIZE"][0]; nd += v["FETCH_SIZE"][1]
+    out = {"kernel": "k_walk<1>", "workload": {"genome_mbp": bench["config"]["genome_mbp"], "reads_per_gpu_per_step": bench["config"]["reads_per_gpu_per_step"], "read_len": None},
+           "fetch_size_kib_per_launch": tot / nd, "hbm_bytes_per_launch": tot / nd * 1024.0,
+           "source": "rocprofv3 --pmc FETCH_SIZE --kernel-trace on `bench.py --workload ont2d` (profiles/%s_ont2d_pmc_fetch.md): %d dispatches (the steady-state half)" % (pre, nd)}
+    json.dump(out, open(os.path.join(dst, "%s_ont2d_k_walk_pmc.json" % pre), "w"), indent=1)
+    print(json.dumps(out, indent=1))
+
+
 def main():
+    if sys.argv[1] == "--ont2d-fetch":
+        return ont2d_fetch(sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else "r05")
     if sys.argv[1] == "--ont2d":
         return ont2d(sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else "r04")
     src = sys.argv[1]
