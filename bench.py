@@ -1320,6 +1320,14 @@ def main():
         # BASELINE configs 5 and 2 as workloads of their own, in the same line: each with its parity gate, its kernels' figures and the compiled
         # reference timed beside it on this host
         if world == 1 and not ont and not a.no_side_workloads and not hung:
+            # The other configs run as processes of their own on this GPU: this process gives its contexts back first (the index replica and the chunk's
+            # workspaces: config 5's chunk needs the room) -- and its hardware queues: beside a process that merely HOLDS contexts the small device batches
+            # of `bwa-mem2.bm2s1` took 8.3-8.7 s per million reads in rounds 5's calls, 6.45 s with the GPU to itself (profiles/r05e, r05_, r05z_)
+            try:
+                ctx.close()
+                ctx = None
+            except Exception as e:                                                    # noqa
+                log("closing the main context before the side workloads: %s" % e)
             for key, name, extra, need_s in (("config5", "ont2d", ["--steps", 2, "--warmup", 1, "--parity-reads", 2048, "--parity-regs-reads", 200] + CONFIG5_READS, 420),
                                              ("config2", "bsw", ["--steps", 5, "--warmup", 2], 90)):
                 if time_left() < need_s:
@@ -1368,7 +1376,8 @@ def main():
     if hung:                                                     # stage threads of a failed end-to-end attempt may be left: do not join them
         sys.stdout.flush(); sys.stderr.flush()
         os._exit(rc)
-    ctx.close()
+    if ctx is not None:
+        ctx.close()
     dist_util.finish(world)
     if rc:
         sys.exit(rc)

@@ -1006,6 +1006,22 @@ k_smem_finish(int n_reads, const bm2_smem_t *__restrict__ tmp, const int32_t *__
     const int64_t o = smem_off[r];
     const bm2_smem_t *row = tmp + o;
     if (n > SMEM_FINISH_BIG) { big_list[atomicAdd(big_cnt, 1)] = (int32_t)r; return; }      // a whole workgroup sorts this read's SMEMs (k_smem_finish_big)
+    if (n <= 16) {
+        // The usual read (~12 SMEMs): the (m, n) keys in sixteen REGISTERS (m, n < 2^15: one word each; an unused place holds the largest word), every
+        // record's rank by sixteen compares on them -- the loop below reads every key again for every record (n^2 loads: 1.3 ms per million reads)
+        uint32_t key[16];
+        _Pragma("unroll") for (int i = 0; i < 16; i++) key[i] = i < n ? (row[i].m << 16 | row[i].n) : 0xffffffffu;
+        _Pragma("unroll") for (int i = 0; i < 16; i++) {
+            if (i < n) {
+                int rank = 0;
+                _Pragma("unroll") for (int t = 0; t < 16; t++) rank += (key[t] < key[i] || (key[t] == key[i] && t < i)) ? 1 : 0;
+                const bm2_smem_t v = row[i];
+                out[o + rank] = v;
+                occ_cnt[o + rank] = (int32_t)(v.s < max_occ ? v.s : max_occ);           // FMI_search.cpp:1280-1290
+            }
+        }
+        return;
+    }
     for (int i = 0; i < n; i++) {
         const bm2_smem_t v = row[i];
         int rank = 0;
