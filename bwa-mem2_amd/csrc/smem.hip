@@ -478,7 +478,7 @@ bwd_body(const DevIndex &ix, const SeedParams &sp, int pass, const uint8_t *__re
                 if (n_curr == 0) state = B_FIN;
                 else if (export_age > 0 && age >= export_age && j > 0 && n_curr <= CCAP) {
                     // HAND-OVER.  A lane-per-task kernel cannot end before its oldest task does, and the task sizes have a long tail (mean ~100
-                    // extensions, one in a thousand beyond 1000: tools/seed_sim): the last third of this kernel used to be a few lanes finishing
+                    // extensions, one in a thousand beyond 1000: tests/seed_sim): the last third of this kernel used to be a few lanes finishing
                     // repeat-rich positions on an otherwise empty GPU.  A task that has had `export_age` extensions stops at the end of its row:
                     // the row's survivors go back into the task's slot where the reader of a walk's list expects them (entry(top - depth)), a
                     // CTask says row j is done, and k_bwd_cont -- sixteen lanes per task, the candidates of a row side by side -- finishes it in a

@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""tools/seed_sim/sim_export.py -- analysis tool (not product): a lane-level model of k_bwd's persistent lanes (smem.hip) on the task
-sizes tools/seed_sim/task_trace.c writes, with and without the hand-over of old tasks to the wavefront-per-task kernel at a row
+"""tests/seed_sim/sim_export.py -- analysis tool (not product): a lane-level model of k_bwd's persistent lanes (smem.hip) on the task
+sizes tests/seed_sim/task_trace.c writes, with and without the hand-over of old tasks to the wavefront-per-task kernel at a row
 boundary (BM2_BWD_EXPORT_AGE).  One "round" = one converged backwardExt of a wavefront; all rounds cost the same here, which the GPU's
 do not (a wavefront alone on its SIMD goes round faster), so the model overstates the tail in time and is right about its cause.
 
-    python tools/seed_sim/sim_export.py tasks_rows.txt [scale]      (scale = 1 M reads / reads traced: the lanes are cut by it)
+    python tests/seed_sim/sim_export.py tasks_rows.txt [scale]      (scale = 1 M reads / reads traced: the lanes are cut by it)
 """
 import heapq
 import sys

@@ -1,7 +1,7 @@
-/* tools/seed_sim/task_trace.c -- analysis tool (test infrastructure, not product): the work items of the seeding kernels as the
+/* tests/seed_sim/task_trace.c -- analysis tool (TEST INFRASTRUCTURE like everything that touches oracle/, not product): the work items of the seeding kernels as the
  * device cuts them (smem.hip: one forward walk per start position, one backward task per candidate list), with their sizes, from the
  * oracle's restatement of getSMEMsOnePosOneThread.  Output: one line per task "pass rid x n_prev fwd_ext bwd_ext rows first_blk [candidates per row ...]".
- *   gcc -O2 -o /tmp/task_trace tools/seed_sim/task_trace.c -lm && /tmp/task_trace <index prefix> <reads.bin> <n_reads> <read_len> > tasks.txt */
+ *   gcc -O2 -o /tmp/task_trace tests/seed_sim/task_trace.c -lm && /tmp/task_trace <index prefix> <reads.bin> <n_reads> <read_len> > tasks.txt */
 #include "../../oracle/bm2_oracle.c"
 
 typedef struct { int fwd, n_prev, bwd, rows; int64_t blk; int rowc[512]; } trace_t;   /* rowc[i] = candidates extended in the i-th backward row */
