@@ -668,8 +668,12 @@ static __device__ __forceinline__ void chain_wave_sync() {      // lanes of one 
 // tiered by seed count so that a block claims only the LDS its reads need (tier capacity `cap`: reads with lo < seeds <= cap; the
 // last tier also takes the reads beyond its capacity and works on their global slices).  Items come from the heavy-first list of
 // the partition; every tier scans it and skips what is not its own.
-template <bool COOP>      // COOP (BM2_CHAIN_COOP_FLT): mem_chain_flt's walk over the kept chains by all 64 lanes; a launch of its own so that the default one keeps its registers
-__global__ void __launch_bounds__(64)
+// COOP (BM2_CHAIN_COOP_FLT): mem_chain_flt's walk over the kept chains by all 64 lanes; a launch of its own so that the default one keeps its registers.
+// WPE: wavefronts per SIMD the register allocation leaves room for (BM2_CHAIN_HEAVY_WPE).  Left alone the cooperative instantiation takes 171 registers --
+// 176 allocated, TWO wavefronts per SIMD, eight per CU, where the tiers of the seed-poorest heavy reads could hold sixteen by their LDS; 3: 139 registers,
+// nothing spilled; 4: 128 registers and 32-64 more bytes of scratch
+template <bool COOP, int WPE>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 k_chain_heavy(DevIndex ix, ChainParams o, int n_reads, const int32_t *__restrict__ len, const bm2_smem_t *__restrict__ smems,
               const int32_t *__restrict__ smem_cnt, const int64_t *__restrict__ smem_off, const int64_t *__restrict__ sa_off,
               const int64_t *__restrict__ sa_coord, WChain *wchain, WSeed *wseed, BtNode *nodes, int32_t *order,
@@ -1155,8 +1159,12 @@ int bm2_launch_chain(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_
         const int caps_coarse[5] = { 64, 128, 256, 512, last_cap }, caps_fine[8] = { 64, 96, 128, 192, 256, 340, 512, last_cap };
         const int n_tiers = fine ? 8 : 5;
         const int *caps = fine ? caps_fine : caps_coarse;
-        { const int rc_a = coop ? bm2_raise_lds_limit(c, 2, (const void *)k_chain_heavy<true>, 160 * 1024 - 256)        // (its static record rides on top of the dynamic LDS)
-                                : bm2_raise_lds_limit(c, 0, (const void *)k_chain_heavy<false>, 160 * 1024); if (rc_a) return rc_a; }
+        const int wpe = bm2_knob("BM2_CHAIN_HEAVY_WPE", 3);
+        auto k_heavy = coop ? (wpe >= 4 ? k_chain_heavy<true, 4> : wpe == 3 ? k_chain_heavy<true, 3> : k_chain_heavy<true, 2>)
+                            : (wpe >= 4 ? k_chain_heavy<false, 4> : wpe == 3 ? k_chain_heavy<false, 3> : k_chain_heavy<false, 2>);
+        { const int which = (coop ? 2 : 0) + 8 * (wpe >= 4 ? 2 : wpe == 3 ? 1 : 0);        // (one flag per instantiation: the limit is a property of the kernel)
+          const int rc_a = bm2_raise_lds_limit(c, which, (const void *)k_heavy, coop ? 160 * 1024 - 256 : 160 * 1024);       // (the cooperative one's static record rides on top of the dynamic LDS)
+          if (rc_a) return rc_a; }
         // reads with more seeds than the largest tier holds: a launch of their own where they are the norm (long reads), otherwise the last tier's
         const bool own_overflow = max_len >= bm2_knob("BM2_CHAIN_OVF_MIN_LEN", 1000);
         int lo = heavy_thr;
@@ -1170,7 +1178,7 @@ int bm2_launch_chain(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_
             const int per_cu_max = bm2_knob("BM2_CHAIN_WAVES_PER_CU", 16);
             int per_cu = (int)(160 * 1024 / lds); if (per_cu < 1) per_cu = 1; if (per_cu > per_cu_max) per_cu = per_cu_max;
             (void)hipStreamWaitEvent(sk, c->ev_fork, 0);
-            hipLaunchKernelGGL(coop ? k_chain_heavy<true> : k_chain_heavy<false>, dim3(c->n_cu * per_cu), dim3(64), lds, sk, c->ix, o, n_reads, len, smems, smem_cnt, smem_off, sa_off,
+            hipLaunchKernelGGL(k_heavy, dim3(c->n_cu * per_cu), dim3(64), lds, sk, c->ix, o, n_reads, len, smems, smem_cnt, smem_off, sa_off,
                                sa_coord, wchain, wseed, nodes, order, chn, seeds_out, seed_owner, n_chain_out, n_reg_out, n_chain0_out, perm,
                                n_heavy_dev, n_sa_read, lo, caps[t], (t == n_tiers - 1 && !use_islands) ? 1 : 0,
                                item_cur + (t < CHAIN_CUR_SLOTS ? t : CHAIN_CUR_EXTRA + t - CHAIN_CUR_SLOTS), stage, clk);
@@ -1193,7 +1201,7 @@ int bm2_launch_chain(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_
                                    isl_order ? n_reads : -1);
             } else {
                 const int per_cu = bm2_knob("BM2_CHAIN_OVF_WAVES_PER_CU", 32);
-                hipLaunchKernelGGL(coop ? k_chain_heavy<true> : k_chain_heavy<false>, dim3(c->n_cu * per_cu), dim3(64), bm2_chain_lds_bytes(0, 0), sk, c->ix, o, n_reads, len, smems, smem_cnt, smem_off, sa_off,
+                hipLaunchKernelGGL(k_heavy, dim3(c->n_cu * per_cu), dim3(64), bm2_chain_lds_bytes(0, 0), sk, c->ix, o, n_reads, len, smems, smem_cnt, smem_off, sa_off,
                                    sa_coord, wchain, wseed, nodes, order, chn, seeds_out, seed_owner, n_chain_out, n_reg_out, n_chain0_out, perm,
                                    n_heavy_dev, n_sa_read, lo, 0, 1, item_cur + CHAIN_CUR_SLOTS, 0, clk);
             }

@@ -39,6 +39,7 @@ GRID = [   # (name, candidates): a candidate is a dict of knobs set together; th
     ("extension wave classes", [{}, {"BM2_EXT_WAVE_QMIN": 129}, {"BM2_EXT_WAVE_QMIN": 145}, {"BM2_EXT_WAVE_QMIN": 161}, {"BM2_EXT_WAVE_QMIN": 97}]),
     ("chain tiers", [{}, {"BM2_CHAIN_FINE_TIERS": 1}]),
     ("chain: mem_chain_flt's kept-chain walk by the whole wavefront", [{}, {"BM2_CHAIN_COOP_FLT": 0}]),
+    ("chain: wavefronts per SIMD the heavy reads' kernel is allocated for", [{}, {"BM2_CHAIN_HEAVY_WPE": 2}, {"BM2_CHAIN_HEAVY_WPE": 4}]),
     ("extension rounds", [{}, {"BM2_EXT_ROUNDS": 2}, {"BM2_EXT_ROUNDS": 1}, {"BM2_EXT_PEND_DIV": 6}, {"BM2_EXT_PEND_DIV": 24}]),
     ("extension dispatch order", [{}, {"BM2_EXT_REVERSE": 1}]),
     ("extension prefetch", [{}, {"BM2_EXT_PREFETCH": 0}]),
