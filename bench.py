@@ -1047,11 +1047,12 @@ def main():
             if cn[17] + cn[16] > 0:                           # the island kernel of long-read chaining (chain.hip): its own counts and phase clock (100 MHz ticks summed over its reads)
                 nr = max(cn[17], 1.0)
                 names = ("table + SMEM cuts", "stage seeds + file buckets", "island of every seed", "places (scan)", "seeds of an island together", "islands chained", "read finished")
-                chain_kernel = {"kernel": "k_chain_islands", "reads_by_islands": int(cn[17]), "reads_chained_serially_equal_keys": int(cn[16]), "islands_per_read": float(cn[18] / nr),
+                chain_kernel = {"kernel": "k_chain_islands", "reads_by_islands": int(cn[17]), "reads_chained_serially_equal_keys": int(cn[16] - (cn[39] if len(cn) > 39 else 0)), "islands_per_read": float(cn[18] / nr),
                                 "chains_per_read": float(cn[27] / nr), "chains_past_the_weight_test_per_read": float(cn[26] / nr),
                                 "phase_ms_per_read": {nm: float(cn[19 + i] * 1e-5 / (cn[17] + cn[16])) for i, nm in enumerate(names)},
                                 "phase_ms_slowest_read": {nm: float(cn[31 + i] * 1e-5) for i, nm in enumerate(names)},
-                                "serial_reads": {"ms_per_read": float(cn[28] * 1e-5 / max(cn[16], 1.0)), "seeds_per_read": float(cn[29] / max(cn[16], 1.0)), "slowest_ms": float(cn[30] * 1e-5)}}
+                                "serial_reads": {"ms_per_read": float(cn[28] * 1e-5 / max(cn[16], 1.0)), "seeds_per_read": float(cn[29] / max(cn[16], 1.0)), "slowest_ms": float(cn[30] * 1e-5),
+                                                 "where": "k_chain_serial: a launch of its own beside the island kernel, the tree's internal nodes in LDS (BM2_CHAIN_SERIAL_OWN=0: inside k_chain_islands)"}}
             if len(cn) >= 48 and cn[46] > 0:                   # BM2_CHAIN_CLOCK=1: lane 0's walk of the wavefront-per-read chain launches, clocked (100 MHz ticks)
                 heavy_clock = {"reads": int(cn[46]), "seeds_per_read": float(cn[47] / cn[46]),
                                "ms_per_read": {"staging by the 64 lanes": float(cn[43] * 1e-5 / cn[46]), "mem_chain_seeds (lane 0)": float(cn[44] * 1e-5 / cn[46]),

@@ -71,9 +71,20 @@ static __device__ __forceinline__ int cal_max_gap(const ChainParams &o, int qlen
 
 // ---------------------------------------------------------------- klib B-tree, t = 5 (kbtree.h; kb_init(chn, 512+8), 48-byte keys)
 #define BT_T 5
-struct BTree { BtNode *nodes; int n_nodes, root, n_keys; const WChain *ch; bool reg = false; };     // reg: nodes in GLOBAL memory, visited through registers (below)
+// reg: nodes in GLOBAL memory, visited through registers (below).  lnodes (the SP = "split pool" instantiations, k_chain_serial): the INTERNAL nodes live in a
+// pool of their own in LDS while it has room -- a node's number then carries BT_LDS_FLAG -- and only the leaves in global memory: a descent of five levels is
+// one global round trip instead of five.  (Node numbers are this file's own; kbtree's results depend on the tree's shape only.)
+#define BT_LDS_FLAG 0x40000000
+struct BTree { BtNode *nodes; int n_nodes, root, n_keys; const WChain *ch; bool reg = false; BtNode *lnodes = nullptr; int l_cap = 0, n_l = 0; };
+template <bool SP> static __device__ __forceinline__ BtNode *bt_at(const BTree &b, int x) {
+    if constexpr (SP) { if (x & BT_LDS_FLAG) return b.lnodes + (x & ~BT_LDS_FLAG); }
+    return b.nodes + x;
+}
 
-static __device__ __forceinline__ int bt_new(BTree &b, int internal) {
+template <bool SP = false> static __device__ __forceinline__ int bt_new(BTree &b, int internal) {
+    if constexpr (SP) {
+        if (internal && b.n_l < b.l_cap) { BtNode &z = b.lnodes[b.n_l]; z.n = 0; z.is_internal = 1; return BT_LDS_FLAG | b.n_l++; }
+    }
     BtNode &z = b.nodes[b.n_nodes];
     z.n = 0; z.is_internal = internal;
     return b.n_nodes++;
@@ -156,10 +167,10 @@ static __device__ __forceinline__ int rn_getp(RNode &nd, int64_t k, int &r) {
     if (r < 0) --begin;
     return begin;
 }
-static __device__ int bt_lower_reg(const BTree &b, int64_t k) {
+template <bool SP = false> static __device__ int bt_lower_reg(const BTree &b, int64_t k) {
     int lower = -1, x = b.root, r = 0;
     while (x >= 0) {
-        RNode nd; rn_load(nd, b.nodes + x);
+        RNode nd; rn_load(nd, bt_at<SP>(b, x));
         const int i = rn_getp(nd, k, r);
         if (i >= 0 && r == 0) return rn_key(nd, i);
         if (i >= 0) lower = rn_key(nd, i);
@@ -168,16 +179,15 @@ static __device__ int bt_lower_reg(const BTree &b, int64_t k) {
     }
     return lower;
 }
-static __device__ void bt_split(BTree &b, int xi, int i, int yi);
-static __device__ void bt_put_reg(BTree &b, int key) {
-    const int64_t k = b.ch[key].pos;
+template <bool SP> static __device__ void bt_split(BTree &b, int xi, int i, int yi);
+template <bool SP = false> static __device__ void bt_put_reg(BTree &b, int key, int64_t k) {
     ++b.n_keys;
-    RNode x; rn_load(x, b.nodes + b.root);                    // (the node's own fill comes with it: no separate load for the "is it full" test)
+    RNode x; rn_load(x, bt_at<SP>(b, b.root));                // (the node's own fill comes with it: no separate load for the "is it full" test)
     if (rn_n(x) == 2 * BT_T - 1) {
-        const int s = bt_new(b, 1), r = b.root;
-        b.root = s; b.nodes[s].ptr[0] = r;
-        bt_split(b, s, 0, r);
-        rn_load(x, b.nodes + b.root);
+        const int s = bt_new<SP>(b, 1), r = b.root;
+        b.root = s; bt_at<SP>(b, s)->ptr[0] = r;
+        bt_split<SP>(b, s, 0, r);
+        rn_load(x, bt_at<SP>(b, b.root));
     }
     int xi = b.root, r;
     for (;;) {
@@ -190,28 +200,28 @@ static __device__ void bt_put_reg(BTree &b, int key) {
             RN_FOR9(RN_PUT)
 #undef RN_PUT
             rn_dw<38>(x) = (uint32_t)(rn_n(x) + 1);
-            rn_store(x, b.nodes + xi);
+            rn_store(x, bt_at<SP>(b, xi));
             return;
         }
         int i = rn_getp(x, k, r) + 1;
         int child = rn_ptr(x, i);
-        RNode y; rn_load(y, b.nodes + child);
+        RNode y; rn_load(y, bt_at<SP>(b, child));
         if (rn_n(y) == 2 * BT_T - 1) {                       // (once per ~5 insertions: the split works on memory, parent and child are read again)
-            bt_split(b, xi, i, child);
-            if (k > b.nodes[xi].kpos[i]) ++i;
-            child = b.nodes[xi].ptr[i];
-            rn_load(y, b.nodes + child);
+            bt_split<SP>(b, xi, i, child);
+            if (k > bt_at<SP>(b, xi)->kpos[i]) ++i;
+            child = bt_at<SP>(b, xi)->ptr[i];
+            rn_load(y, bt_at<SP>(b, child));
         }
         x = y; xi = child;
     }
 }
 
 // kb_intervalp, lower bound only (kbtree.h:158-175)
-static __device__ int bt_lower(const BTree &b, int64_t k) {
-    if (b.reg) return bt_lower_reg(b, k);
+template <bool SP = false> static __device__ int bt_lower(const BTree &b, int64_t k) {
+    if (b.reg) return bt_lower_reg<SP>(b, k);
     int lower = -1, x = b.root, r = 0;
     while (x >= 0) {
-        const BtNode &nd = b.nodes[x];
+        const BtNode &nd = *bt_at<SP>(b, x);
         const int i = bt_getp_aux(b, nd, k, r);
         if (i >= 0 && r == 0) return nd.key[i];
         if (i >= 0) lower = nd.key[i];
@@ -221,9 +231,9 @@ static __device__ int bt_lower(const BTree &b, int64_t k) {
     return lower;
 }
 // __kb_split, kbtree.h:179-196
-static __device__ void bt_split(BTree &b, int xi, int i, int yi) {
-    const int zi = bt_new(b, b.nodes[yi].is_internal);
-    BtNode &x = b.nodes[xi], &y = b.nodes[yi], &z = b.nodes[zi];
+template <bool SP = false> static __device__ void bt_split(BTree &b, int xi, int i, int yi) {
+    const int zi = bt_new<SP>(b, bt_at<SP>(b, yi)->is_internal);
+    BtNode &x = *bt_at<SP>(b, xi), &y = *bt_at<SP>(b, yi), &z = *bt_at<SP>(b, zi);
     z.n = BT_T - 1;
     for (int t = 0; t < BT_T - 1; t++) { z.key[t] = y.key[BT_T + t]; z.kpos[t] = y.kpos[BT_T + t]; }
     if (y.is_internal) for (int t = 0; t < BT_T; t++) z.ptr[t] = y.ptr[BT_T + t];
@@ -235,18 +245,18 @@ static __device__ void bt_split(BTree &b, int xi, int i, int yi) {
     ++x.n;
 }
 // kb_putp + __kb_putp_aux, kbtree.h:197-231 (the recursion is a plain descent)
-static __device__ void bt_put(BTree &b, int key) {
-    if (b.reg) { bt_put_reg(b, key); return; }
-    const int64_t k = b.ch[key].pos;
+// (k = the key's sort field, ch[key].pos: the caller has it in a register -- it has just written the chain)
+template <bool SP = false> static __device__ void bt_put(BTree &b, int key, int64_t k) {
+    if (b.reg) { bt_put_reg<SP>(b, key, k); return; }
     ++b.n_keys;
-    if (b.nodes[b.root].n == 2 * BT_T - 1) {
-        const int s = bt_new(b, 1), r = b.root;
-        b.root = s; b.nodes[s].ptr[0] = r;
-        bt_split(b, s, 0, r);
+    if (bt_at<SP>(b, b.root)->n == 2 * BT_T - 1) {
+        const int s = bt_new<SP>(b, 1), r = b.root;
+        b.root = s; bt_at<SP>(b, s)->ptr[0] = r;
+        bt_split<SP>(b, s, 0, r);
     }
     int xi = b.root, r;
     for (;;) {
-        BtNode &x = b.nodes[xi];
+        BtNode &x = *bt_at<SP>(b, xi);
         if (!x.is_internal) {
             const int i = bt_getp_aux(b, x, k, r);
             for (int t = x.n - 1; t > i; t--) { x.key[t + 1] = x.key[t]; x.kpos[t + 1] = x.kpos[t]; }
@@ -255,20 +265,20 @@ static __device__ void bt_put(BTree &b, int key) {
             return;
         }
         int i = bt_getp_aux(b, x, k, r) + 1;
-        if (b.nodes[x.ptr[i]].n == 2 * BT_T - 1) {
-            bt_split(b, xi, i, x.ptr[i]);
+        if (bt_at<SP>(b, x.ptr[i])->n == 2 * BT_T - 1) {
+            bt_split<SP>(b, xi, i, x.ptr[i]);
             if (k > x.kpos[i]) ++i;
         }
         xi = x.ptr[i];
     }
 }
 // __kb_traverse (in-order), kbtree.h:343-366
-static __device__ int bt_traverse(const BTree &b, int32_t *out) {
+template <bool SP = false> static __device__ int bt_traverse(const BTree &b, int32_t *out) {
     int n = 0, sp = 0;
     int stk_node[24], stk_i[24];
     stk_node[0] = b.root; stk_i[0] = 0;
     while (sp >= 0) {
-        const BtNode &nd = b.nodes[stk_node[sp]];
+        const BtNode &nd = *bt_at<SP>(b, stk_node[sp]);
         const int i = stk_i[sp];
         if (nd.is_internal) {
             if (i <= nd.n) {
@@ -613,7 +623,7 @@ static __device__ void chain_one_read(const DevIndex &ix, const ChainParams &o, 
                 c2.w = 0; c2.kept = 0; c2.first = -1;
                 sd[n_sd] = s; n_sd++;
                 ch[n_ch] = c2;
-                bt_put(bt, n_ch);
+                bt_put(bt, n_ch, c2.pos);
                 n_ch++;
             }
         }
@@ -809,7 +819,8 @@ static __device__ __forceinline__ void isl_sync() {              // lanes of one
 
 // one island: the seeds perm[start .. start + tot) in seed order; chains / seeds get the ids start, start + 1, ... of the read's slices
 static __device__ void isl_build(const DevIndex &ix, const ChainParams &o, const IslSeed *st, const int32_t *perm, int start, int tot,
-                                 WChain *ch, WSeed *sd, BtNode *nd, int32_t *ord, int *s_nsurv, int *s_ntot, int *s_dup, unsigned long long *s_min) {
+                                 WChain *ch, WSeed *sd, BtNode *nd, int32_t *ord, int *s_nsurv, int *s_ntot, int *s_dup, unsigned long long *s_min,
+                                 bool quit_on_dup /* the read goes to k_chain_serial when equal keys turn up: nothing of this pass is kept */) {
     int n_ch = start, n_sd = start;
     bool dup = false;
     if (tot == 1) {                                              // a stray hit: a chain of one seed, no tree
@@ -827,6 +838,9 @@ static __device__ void isl_build(const DevIndex &ix, const ChainParams &o, const
         // a full node that kb_putp splits on its way down (`if (k > median) ++i`) -- and which of the two a later look-up finds depend on the
         // shape of the WHOLE tree.  A private tree cannot know: the island raises `dup`, the read is chained again by the serial code.
         for (int idx = start; idx < start + tot; idx++) {
+            // (another island of the read has met equal keys: the read will be chained again whatever this island yields -- its long islands are what
+            //  stands between the read and k_chain_serial)
+            if (quit_on_dup && *(volatile int *)s_dup) return;
             const IslSeed q = st[perm[idx]];
             WSeed s; s.rbeg = q.rbeg; s.qbeg = (int)(q.ql & 0x7fffu); s.len = (int)((q.ql >> 15) & 0xffffu); s.next = -1; s.pad = 0;
             int to_add = 0;
@@ -836,7 +850,7 @@ static __device__ void isl_build(const DevIndex &ix, const ChainParams &o, const
                 else {
                     const int m = test_and_merge(o, ix.l_pac, ch[lower], s, q.rid, sd, n_sd);
                     if (m == 2) n_sd++;
-                    else if (m == 0) { to_add = 1; if (ch[lower].pos == s.rbeg) dup = true; }
+                    else if (m == 0) { to_add = 1; if (ch[lower].pos == s.rbeg) { dup = true; if (quit_on_dup) { atomicAdd(s_dup, 1); return; } } }
                 }
             } else to_add = 1;
             if (to_add) {
@@ -845,7 +859,7 @@ static __device__ void isl_build(const DevIndex &ix, const ChainParams &o, const
                 c2.n = 1; c2.rid = q.rid; c2.is_alt = (int)(q.ql >> 31); c2.head = c2.tail = n_sd; c2.w = 0; c2.kept = 0; c2.first = -1; c2.pad = 0;
                 sd[n_sd] = s; n_sd++;
                 ch[n_ch] = c2;
-                bt_put(bt, n_ch);
+                bt_put(bt, n_ch, c2.pos);
                 n_ch++;
             }
         }
@@ -864,14 +878,28 @@ static __device__ void isl_build(const DevIndex &ix, const ChainParams &o, const
     if (dup) atomicAdd(s_dup, 1);
 }
 
-template <bool COOP>      // COOP (BM2_CHAIN_COOP_FLT): see k_chain_heavy
-__global__ void __launch_bounds__(64)
+// The list k_chain_islands (producer, any of its wavefronts' lane 0) hands to k_chain_serial (consumer, running BESIDE it on a stream of its own): a place is
+// drawn with an atomic, the read's number stored with release semantics behind everything the wavefront staged for it (the caller's isl_sync); the list is
+// memset to -1 before the launch, a consumer that drew place i waits for list[i] to turn up or for the last producer to leave (n_fallback[SER_DONE]).
+#define SER_PLAIN 0x40000000         // a read the island kernel did not stage (plain chain_one_read)
+#define SER_DONE 32                  // n_fallback[32] = counters[48] of the batch: producers that have left
+static __device__ __forceinline__ void ser_publish(int32_t *list, unsigned long long *n_fallback, int v) {
+    const unsigned long long idx = atomicAdd(n_fallback, 1ULL);
+    __hip_atomic_store(list + idx, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+// COOP (BM2_CHAIN_COOP_FLT): see k_chain_heavy.  OWN: the reads this kernel cannot chain by islands are LISTED (serial_list) for k_chain_serial and the serial
+// code is not part of this kernel at all -- with it inlined the kernel needed 264 registers, ONE wavefront per SIMD, and a chunk of 20 000 long reads was
+// throughput-bound at four wavefronts per CU
+// (OWN = 3 or 4: the wavefronts per SIMD the registers are allocated for, BM2_CHAIN_ISL_WPE -- 145 registers, or 128 and four more dwords of scratch)
+template <bool COOP, int OWN>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OWN ? OWN : 1, OWN ? OWN : 8)))
 k_chain_islands(DevIndex ix, ChainParams o, int n_reads, const int32_t *__restrict__ len, const bm2_smem_t *__restrict__ smems,
                 const int32_t *__restrict__ smem_cnt, const int64_t *__restrict__ smem_off, const int64_t *__restrict__ sa_off,
                 const int64_t *__restrict__ sa_coord, WChain *wchain, WSeed *wseed, BtNode *nodes, int32_t *order,
                 DevChain *chn, DevSeed *seeds_out, int32_t *seed_owner, int32_t *cut_all, int32_t *n_chain_out, int32_t *n_reg_out, int32_t *n_chain0_out,
                 const int32_t *__restrict__ heavy /* read ids, heavy ones first */, const int64_t *__restrict__ n_heavy_p,
-                const int32_t *__restrict__ n_sa_read, int lo, unsigned long long *item_cur, unsigned long long *n_fallback, int n_items) {
+                const int32_t *__restrict__ n_sa_read, int lo, unsigned long long *item_cur, unsigned long long *n_fallback, int n_items,
+                int32_t *serial_list /* or NULL: reads with equal chain keys are listed for k_chain_serial instead of being chained again here */) {
     __shared__ int s_nsurv, s_ntot, s_dup;
     __shared__ unsigned long long s_min;
     __shared__ DeferFinish df;                                     // (only the COOP launch touches it)
@@ -987,7 +1015,8 @@ k_chain_islands(DevIndex ix, ChainParams o, int n_reads, const int32_t *__restri
             const int slot = clist[k];
             const int tot = hash[slot].cnt;
             const int start = hash[slot].start - (tot > 1 ? tot : 0);
-            isl_build(ix, o, st, perm, start, tot, ch, sd, nd, ord, &s_nsurv, &s_ntot, &s_dup, &s_min);
+            if (OWN != 0 && *(volatile int *)&s_dup) break;
+            isl_build(ix, o, st, perm, start, tot, ch, sd, nd, ord, &s_nsurv, &s_ntot, &s_dup, &s_min, OWN != 0);
         }
         isl_sync();
         ISL_TICK(5);
@@ -995,12 +1024,15 @@ k_chain_islands(DevIndex ix, ChainParams o, int n_reads, const int32_t *__restri
         if (lane == 0) {
             if constexpr (COOP) df.valid = 0;
             if (s_dup) {                                             // chains with equal keys: the serial code on the read's slices
-                atomicAdd(n_fallback, 1ULL);
-                const long long t_fb = wall_clock64();
-                chain_one_read<false>(ix, o, r, n_reads, len, smems, smem_cnt, smem_off, sa_off, sa_coord, wchain, wseed, nodes, order, chn, seeds_out,
-                                      seed_owner, n_chain_out, n_reg_out, n_chain0_out, -1, nullptr, 0, st, hash, cslot, COOP ? &df : (DeferFinish *)nullptr);
-                const unsigned long long dt_fb = (unsigned long long)(wall_clock64() - t_fb);
-                atomicAdd(n_fallback + 12, dt_fb); atomicAdd(n_fallback + 13, (unsigned long long)n_sa); atomicMax(n_fallback + 14, dt_fb);
+                if constexpr (OWN) ser_publish(serial_list, n_fallback, r);      // ... in k_chain_serial (the read's staged seeds, table and islands stay where they are)
+                else {
+                    atomicAdd(n_fallback, 1ULL);
+                    const long long t_fb = wall_clock64();
+                    chain_one_read<false>(ix, o, r, n_reads, len, smems, smem_cnt, smem_off, sa_off, sa_coord, wchain, wseed, nodes, order, chn, seeds_out,
+                                          seed_owner, n_chain_out, n_reg_out, n_chain0_out, -1, nullptr, 0, st, hash, cslot, COOP ? &df : (DeferFinish *)nullptr);
+                    const unsigned long long dt_fb = (unsigned long long)(wall_clock64() - t_fb);
+                    atomicAdd(n_fallback + 12, dt_fb); atomicAdd(n_fallback + 13, (unsigned long long)n_sa); atomicMax(n_fallback + 14, dt_fb);
+                }
             } else {
                 const int n_all = s_ntot;
                 if (n_chain0_out) n_chain0_out[r] = n_all;
@@ -1035,9 +1067,162 @@ k_chain_islands(DevIndex ix, ChainParams o, int n_reads, const int32_t *__restri
         }
         ISL_TICK(6);
         } else if (lane == 0) {                                      // (too few seeds for the table's place in the slices -- cannot happen above `lo` >= 64 -- or nothing to chain)
-            chain_one_read<false>(ix, o, r, n_reads, len, smems, smem_cnt, smem_off, sa_off, sa_coord, wchain, wseed, nodes, order, chn, seeds_out,
-                                  seed_owner, n_chain_out, n_reg_out, n_chain0_out, -1, nullptr, 0);
+            if constexpr (OWN) { atomicAdd(n_fallback + 23, 1ULL); ser_publish(serial_list, n_fallback, r | SER_PLAIN); }       // (flagged: plain chain_one_read there)
+            else chain_one_read<false>(ix, o, r, n_reads, len, smems, smem_cnt, smem_off, sa_off, sa_coord, wchain, wseed, nodes, order, chn, seeds_out,
+                                       seed_owner, n_chain_out, n_reg_out, n_chain0_out, -1, nullptr, 0);
         }
+        }
+    }
+    if constexpr (OWN != 0) {                                        // this wavefront lists nothing any more: k_chain_serial stops waiting when every one has said so
+        if (lane == 0) { __threadfence(); atomicAdd(n_fallback + SER_DONE, 1ULL); }
+    }
+}
+
+// The reads k_chain_islands could not chain by islands (two chains with EQUAL keys: their order depends on the shape of the whole tree), chained again by the
+// serial code -- the kbtree walk of mem_chain_seeds, bwamem.cpp:906-951, seed by seed on lane 0 -- in a launch of their own.  Inside the island kernel one such
+// read cost 12 us per seed (five dependent node loads from global memory per insertion; 200 ms per read, 390 ms the slowest of a chunk of 20 000, and the
+// kernel could not end before it did).  Here a workgroup is ONE wavefront with most of a CU's LDS: the tree's INTERNAL nodes live there (BTree::lnodes),
+// so that a descent ends with its only global round trip at the leaf; the other 63 lanes stage the next 64 seeds (staged record, "alone in its island")
+// into LDS while lane 0 walks, and all lanes share the weight test of mem_chain_flt (bwamem.cpp:516-528) at the end.
+struct SerStage { int64_t rbeg; uint32_t ql; int32_t rid, single, pad; };
+template <bool COOP>
+__global__ void __launch_bounds__(64)
+k_chain_serial(DevIndex ix, ChainParams o, int n_reads, const int32_t *__restrict__ len, const bm2_smem_t *__restrict__ smems, const int32_t *__restrict__ smem_cnt,
+               const int64_t *__restrict__ smem_off, const int64_t *__restrict__ sa_off, const int64_t *__restrict__ sa_coord, WChain *wchain, WSeed *wseed, BtNode *nodes, int32_t *order,
+               DevChain *chn, DevSeed *seeds_out, int32_t *seed_owner, int32_t *n_chain_out, int32_t *n_reg_out, int32_t *n_chain0_out,
+               const int32_t *serial_list /* n_reads places, -1 = not yet listed: reads with equal chain keys, staged by k_chain_islands; | SER_PLAIN: reads it did not touch */,
+               unsigned long long *n_fallback /* [0]: reads listed so far, [22]: this launch's work cursor, [SER_DONE]: producers that have left */, int l_cap,
+               int n_producers) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t ser_lds[];
+    BtNode *lnodes = (BtNode *)ser_lds;
+    SerStage *stg = (SerStage *)(ser_lds + (size_t)l_cap * sizeof(BtNode));
+    __shared__ DeferFinish df;
+    __shared__ int s_n;
+    const int lane = threadIdx.x;
+    const unsigned long long lt_mask = lane ? (~0ULL >> (64 - lane)) : 0ULL;
+    for (;;) {
+        const unsigned long long it = atomicAdd(n_fallback + 22, lane == 0 ? 1ULL : 0ULL);
+        const int item = __builtin_amdgcn_readfirstlane((int)it);
+        if (item >= n_reads) break;
+        int listed = -1;
+        if (lane == 0) {                                             // wait for place `item` to be filled, or for the producers to have left without filling it
+            const long long t_w = wall_clock64();
+            for (;;) {
+                listed = __hip_atomic_load(serial_list + item, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                if (listed != -1) break;
+                if (__hip_atomic_load(n_fallback + SER_DONE, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned long long)n_producers) {
+                    listed = __hip_atomic_load(serial_list + item, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+                if (wall_clock64() - t_w > 2000000000LL) __builtin_trap();      // (20 s at 100 MHz without a producer moving: fail loudly, do not hang the device)
+                __builtin_amdgcn_s_sleep(64);
+            }
+        }
+        listed = __builtin_amdgcn_readfirstlane(listed);
+        if (listed == -1) break;
+        isl_sync();                                                  // (every lane: what the producer staged is behind the list entry)
+        if (listed & SER_PLAIN) {                                    // a read the island kernel had no table for (or nothing to chain)
+            const int r = listed & ~SER_PLAIN;
+            if (lane == 0) chain_one_read<false>(ix, o, r, n_reads, len, smems, smem_cnt, smem_off, sa_off, sa_coord, wchain, wseed, nodes, order, chn, seeds_out,
+                                                 seed_owner, n_chain_out, n_reg_out, n_chain0_out, -1, nullptr, 0);
+            continue;
+        }
+        const long long t_fb = wall_clock64();
+        const int r = listed;
+        const int n_sm = __builtin_amdgcn_readfirstlane(smem_cnt[r]);
+        const int64_t so = smem_off[r];
+        const int64_t base = sa_off[so];
+        const int n_sa = (int)(sa_off[so + n_sm] - base);
+        WChain *ch = wchain + base; WSeed *sd = wseed + base; int32_t *ord = order + base;
+        const IslHash *hash = (const IslHash *)(chn + base);
+        const IslSeed *st = (const IslSeed *)(seeds_out + base);
+        const int32_t *cslot = (const int32_t *)(st + n_sa);
+        BTree bt; bt.nodes = nodes + base; bt.n_nodes = 0; bt.n_keys = 0; bt.ch = ch; bt.reg = o.reg_nodes != 0;
+        bt.lnodes = lnodes; bt.l_cap = l_cap; bt.n_l = 0;
+        bt.root = bt_new<true>(bt, 0);
+        int n_ch = 0, n_sd = 0;
+        for (int t0 = 0; t0 < n_sa; t0 += 64) {
+            if (t0 + lane < n_sa) {
+                const IslSeed q = st[t0 + lane];
+                SerStage e; e.rbeg = q.rbeg; e.ql = q.ql; e.rid = q.rid; e.pad = 0;
+                e.single = q.rid >= 0 && hash[cslot[t0 + lane]].cnt == 1 ? 1 : 0;
+                stg[lane] = e;
+            }
+            chain_wave_sync();
+            if (lane == 0) {
+                const int nb = n_sa - t0 < 64 ? n_sa - t0 : 64;
+                for (int j = 0; j < nb; j++) {
+                    const SerStage q = stg[j];
+                    if (q.rid < 0) continue;                         // bwamem.cpp:915-919
+                    WSeed sdd; sdd.rbeg = q.rbeg; sdd.qbeg = (int)(q.ql & 0x7fffu); sdd.len = (int)((q.ql >> 15) & 0xffffu); sdd.next = -1; sdd.pad = 0;
+                    int to_add = 0;
+                    // (a seed alone in its island can meet no chain -- see chain_one_read -- only the tree's shape is kept exact)
+                    if (q.single) to_add = 1;
+                    else if (bt.n_keys) {
+                        const int lower = bt_lower<true>(bt, sdd.rbeg);
+                        if (lower < 0) to_add = 1;
+                        else {
+                            const int m = test_and_merge(o, ix.l_pac, ch[lower], sdd, q.rid, sd, n_sd);
+                            if (m == 2) n_sd++;
+                            else if (m == 0) to_add = 1;
+                        }
+                    } else to_add = 1;
+                    if (to_add) {                                    // bwamem.cpp:930-951
+                        WChain c2;
+                        c2.pos = sdd.rbeg; c2.last_rbeg = sdd.rbeg; c2.first_qbeg = sdd.qbeg; c2.last_qbeg = sdd.qbeg; c2.last_len = sdd.len;
+                        c2.n = 1; c2.rid = q.rid; c2.is_alt = (int)(q.ql >> 31); c2.head = c2.tail = n_sd; c2.w = 0; c2.kept = 0; c2.first = -1; c2.pad = 0;
+                        sd[n_sd] = sdd; n_sd++;
+                        ch[n_ch] = c2;
+                        bt_put<true>(bt, n_ch, c2.pos);
+                        n_ch++;
+                    }
+                }
+            }
+            chain_wave_sync();
+        }
+        if (lane == 0) s_n = bt_traverse<true>(bt, ord);             // chains in key order (bwamem.cpp:958-962)
+        isl_sync();
+        const int n = s_n;
+        // the weight test, 64 chains at a time; the survivors keep their order (the serial loop's `ord[k++] = ord[i]`: a block writes below what it has read)
+        int k = 0;
+        for (int i0 = 0; i0 < n; i0 += 64) {
+            const int i = i0 + lane;
+            int id = 0; bool keep = false;
+            if (i < n) {
+                id = ord[i];
+                WChain &c = ch[id];
+                c.first = -1; c.kept = 0;
+                c.w = chain_weight(c, sd);
+                keep = c.w >= o.min_chain_weight;
+            }
+            const unsigned long long m = __ballot(keep);
+            if (keep) ord[k + __popcll(m & lt_mask)] = id;
+            k += __popcll(m);
+        }
+        if (k == 0 && n > 0) k = 1;      // quirk: an empty survivor list still processes the untouched a_[0] (bwamem.cpp:529-546)
+        if (lane == 0) {
+            if (n_chain0_out) n_chain0_out[r] = n;
+            int b = 0, e = 0, l_rep = 0;
+            for (int i = 0; i < n_sm; i++) {                         // l_rep, bwamem.cpp:849-861
+                if (!(smems[so + i].s > o.max_occ)) continue;
+                const int sb = (int)smems[so + i].m, se = (int)smems[so + i].n + 1;
+                if (sb > e) { l_rep += e - b; b = sb; e = se; }
+                else e = e > se ? e : se;
+            }
+            l_rep += e - b;
+            df.r = r; df.n = k; df.base = base; df.frac_rep = (float)l_rep / len[r]; df.ch = ch; df.sd = sd; df.ord = ord; df.kept = (int32_t *)(nodes + base);
+            df.valid = 1;
+        }
+        isl_sync();
+        {
+            const DeferFinish d = df;
+            if constexpr (COOP) chain_finish_coop(o, d, lane, chn, seeds_out, seed_owner, n_chain_out, n_reg_out);
+            else if (lane == 0) chain_finish_read(o, d.r, d.ch, d.sd, d.ord, d.kept, d.n, d.base, d.frac_rep, chn, seeds_out, seed_owner, n_chain_out, n_reg_out);
+        }
+        isl_sync();
+        if (lane == 0) {
+            const unsigned long long dt_fb = (unsigned long long)(wall_clock64() - t_fb);
+            atomicAdd(n_fallback + 12, dt_fb); atomicAdd(n_fallback + 13, (unsigned long long)n_sa); atomicMax(n_fallback + 14, dt_fb);
         }
     }
 }
@@ -1124,7 +1309,8 @@ int bm2_launch_chain(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_
                      int32_t *n_chain_out, int32_t *n_reg_out, int32_t *n_chain0_out, const int32_t *perm,
                      int heavy_thr, const int64_t *n_heavy_dev, const int32_t *n_sa_read, unsigned long long *item_cur /* one per tier + 2 */, int max_len,
                      int32_t *isl_cut /* scratch of the island kernel: one int per SA coordinate */,
-                     const int32_t *isl_order /* or NULL: every read, the seed-richest first -- the island kernel's longest reads start first */) {
+                     const int32_t *isl_order /* or NULL: every read, the seed-richest first -- the island kernel's longest reads start first */,
+                     int32_t *isl_serial /* or NULL: one int per read (all -1), the list of reads k_chain_islands leaves to k_chain_serial */) {
     if (n_reads <= 0) return BM2_OK;
     hipStream_t s = c->stream;
     const bool heavy = heavy_thr >= 0 && n_heavy_dev != nullptr;
@@ -1140,7 +1326,7 @@ int bm2_launch_chain(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_
     hipLaunchKernelGGL(k_chain, dim3((n_reads + 127) / 128), dim3(128), 0, s_main, c->ix, o, n_reads, len, smems, smem_cnt,
                        smem_off, sa_off, sa_coord, wchain, wseed, nodes, order, chn, seeds_out, seed_owner,
                        n_chain_out, n_reg_out, n_chain0_out, perm, heavy ? heavy_thr : -1, n_sa_read);
-    int joined[BM2_CHAIN_TIERS + 3], n_joined = 0;
+    int joined[BM2_CHAIN_TIERS + 4], n_joined = 0;
     if (main_side) { (void)hipEventRecord(c->ev_join[1], s_main); joined[n_joined++] = 1; }
     if (heavy) {
         // tiers by seed count (LDS per block follows the tier): the launches run beside the lane-per-read kernel and each other
@@ -1194,11 +1380,35 @@ int bm2_launch_chain(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_
             hipStream_t sk = c->side_stream[2 + BM2_CHAIN_TIERS];
             (void)hipStreamWaitEvent(sk, c->ev_fork, 0);
             if (bm2_knob("BM2_CHAIN_ISLANDS", 1)) {                 // chaining by islands (k_chain_islands): one wavefront per read, every lane at work
-                const int per_cu = bm2_knob("BM2_CHAIN_ISL_WAVES_PER_CU", 32);
-                hipLaunchKernelGGL(coop ? k_chain_islands<true> : k_chain_islands<false>, dim3(c->n_cu * per_cu), dim3(64), 0, sk, c->ix, o, n_reads, len, smems, smem_cnt, smem_off, sa_off,
+                // (wavefronts per CU: 32 asked for, 16 resident at 128 registers -- the kernel itself is shortest there, 298 ms for 20 000 long reads, but every read
+                //  is three times slower than at 4 per CU, and the stage ends when the seed-richest read with equal keys has gone through this kernel AND
+                //  k_chain_serial: 8 per CU gave the shortest stage, profiles/r05p_config5_variants.txt)
+                const int per_cu = bm2_knob("BM2_CHAIN_ISL_WAVES_PER_CU", isl_serial ? 8 : 32);
+                const int isl_wpe = bm2_knob("BM2_CHAIN_ISL_WPE", 4);
+                auto k_isl = !isl_serial ? (coop ? k_chain_islands<true, 0> : k_chain_islands<false, 0>)
+                           : isl_wpe >= 4 ? (coop ? k_chain_islands<true, 4> : k_chain_islands<false, 4>) : (coop ? k_chain_islands<true, 3> : k_chain_islands<false, 3>);
+                hipLaunchKernelGGL(k_isl, dim3(c->n_cu * per_cu), dim3(64), 0, sk, c->ix, o, n_reads, len, smems, smem_cnt, smem_off, sa_off,
                                    sa_coord, wchain, wseed, nodes, order, chn, seeds_out, seed_owner, isl_cut, n_chain_out, n_reg_out, n_chain0_out,
                                    isl_order ? isl_order : perm, n_heavy_dev, n_sa_read, lo, item_cur + CHAIN_CUR_SLOTS, item_cur + CHAIN_CUR_SLOTS + 1,
-                                   isl_order ? n_reads : -1);
+                                   isl_order ? n_reads : -1, isl_serial);
+                if (isl_serial) {
+                    // the reads with equal chain keys, one wavefront per CU each with the internal nodes of its tree in LDS (BM2_CHAIN_SERIAL_LNODES of 160 bytes),
+                    // on a stream of its own BEHIND the island kernel's launch (never before it: a consumer must not hold a queue its producer waits in): it takes a
+                    // read as soon as the island kernel lists it (BM2_CHAIN_SERIAL_BESIDE=0: after the island kernel, same stream)
+                    const bool beside = bm2_knob("BM2_CHAIN_SERIAL_BESIDE", 1) != 0;
+                    hipStream_t sc2 = beside ? c->side_stream[11] : sk;
+                    if (beside) (void)hipStreamWaitEvent(sc2, c->ev_fork, 0);
+                    int l_cap = bm2_knob("BM2_CHAIN_SERIAL_LNODES", 960);
+                    if (l_cap < 1) l_cap = 1; if (l_cap > 1000) l_cap = 1000;
+                    const size_t lds_s = (size_t)l_cap * sizeof(BtNode) + 64 * sizeof(SerStage);
+                    auto k_ser = coop ? k_chain_serial<true> : k_chain_serial<false>;
+                    { const int rc_a = bm2_raise_lds_limit(c, coop ? 3 : 4, (const void *)k_ser, 160 * 1024 - 512); if (rc_a) return rc_a; }
+                    const int per_cu_s = (int)((160 * 1024 - 512) / lds_s) < 1 ? 1 : (int)((160 * 1024 - 512) / lds_s);
+                    hipLaunchKernelGGL(k_ser, dim3(c->n_cu * (per_cu_s > 8 ? 8 : per_cu_s)), dim3(64), lds_s, sc2, c->ix, o, n_reads, len, smems, smem_cnt, smem_off, sa_off, sa_coord,
+                                       wchain, wseed, nodes, order, chn, seeds_out, seed_owner, n_chain_out, n_reg_out, n_chain0_out,
+                                       (const int32_t *)isl_serial, item_cur + CHAIN_CUR_SLOTS + 1, l_cap, c->n_cu * per_cu);
+                    if (beside) { (void)hipEventRecord(c->ev_join[11], sc2); joined[n_joined++] = 11; }
+                }
             } else {
                 const int per_cu = bm2_knob("BM2_CHAIN_OVF_WAVES_PER_CU", 32);
                 hipLaunchKernelGGL(k_heavy, dim3(c->n_cu * per_cu), dim3(64), bm2_chain_lds_bytes(0, 0), sk, c->ix, o, n_reads, len, smems, smem_cnt, smem_off, sa_off,

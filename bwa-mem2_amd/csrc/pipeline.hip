@@ -18,7 +18,7 @@ int bm2_launch_chain(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_
                      int32_t *seed_owner,
                      int32_t *n_chain_out, int32_t *n_reg_out, int32_t *n_chain0_out, const int32_t *perm,
                      int heavy_thr, const int64_t *n_heavy_dev, const int32_t *n_sa_read, unsigned long long *item_cur, int max_len, int32_t *isl_cut,
-                     const int32_t *isl_order);
+                     const int32_t *isl_order, int32_t *isl_serial);
 int bm2_launch_chain_finish(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_t *len, const int64_t *read_base,
                             const int32_t *n_chain, DevChain *chn, DevSeed *seeds_out, int32_t *srt_out, int32_t *reg_seed,
                             int32_t *reg_chain, int32_t *n_reg_out);
@@ -57,7 +57,7 @@ struct Batch {
     bm2_stats stats{};
     std::vector<int32_t> h_len;              // host copy of the read lengths (per-read filter thresholds)
     DevBuf min_hsp, seed_owner, seed_keep, mat25;
-    DevBuf perm2, part_tmp2;
+    DevBuf perm2, part_tmp2, isl_serial;
     DevBuf heads1, ents1, heads2, ents2, pool, recs, tasks, seedc, fill, smem_tmp, heavy1, heavy2, cont1, cont2;     // seeding task kernels
     DevBuf fin_work, fin_ord, fin_state, fin_n, fin_off, fin_req, fin_cnt, fin_out;                     // hit finishing (finish.hip)
     int64_t n_fin = -1; int fin_rounds = 0;     // -1: bm2_batch_finish has not run on the current regs
@@ -73,7 +73,7 @@ void bm2_batch_destroy(bm2_ctx *c) {
                       &b->order, &b->chn, &b->seeds, &b->srt, &b->reg_seed, &b->reg_chain, &b->regs, &b->slot_base, &b->n_chain,
                       &b->n_reg, &b->n_chain0, &b->n_out, &b->out_off, &b->out_regs, &b->smem_sorted, &b->smem_sorted_off, &b->ext_tmp, &b->cursor, &b->n_sa_read, &b->perm, &b->perm_hist, &b->part_tmp, &b->min_hsp, &b->seed_owner, &b->seed_keep, &b->mat25,
                       &b->heads1, &b->ents1, &b->heads2, &b->ents2, &b->pool, &b->recs, &b->tasks, &b->seedc, &b->fill, &b->smem_tmp,
-                      &b->heavy1, &b->heavy2, &b->cont1, &b->cont2, &b->perm2, &b->part_tmp2,
+                      &b->heavy1, &b->heavy2, &b->cont1, &b->cont2, &b->perm2, &b->part_tmp2, &b->isl_serial,
                       &b->fin_work, &b->fin_ord, &b->fin_state, &b->fin_n, &b->fin_off, &b->fin_req, &b->fin_cnt, &b->fin_out };
     for (DevBuf *d : all) bm2_release(*d);
     delete b;
@@ -171,8 +171,8 @@ static int run_seeding(bm2_ctx *c, Batch *b, const bm2_opt *opt, bool with_sal) 
     int rc;
     hipStream_t s = c->stream;
     const SeedParams sp = seed_params(opt);
-    if ((rc = bm2_reserve(b->counters, 48 * 8))) return rc;      // ([40..42]: work cursors of the chain stage's tiers beyond the fifth)
-    if ((rc = bm2_check(hipMemsetAsync(b->counters.p, 0, 48 * 8, s), "memset counters"))) return rc;
+    if ((rc = bm2_reserve(b->counters, 56 * 8))) return rc;      // ([40..42]: work cursors of the chain stage's tiers beyond the fifth; [48]: the island kernel's wavefronts that have left)
+    if ((rc = bm2_check(hipMemsetAsync(b->counters.p, 0, 56 * 8, s), "memset counters"))) return rc;
     if ((rc = bm2_reserve(b->smem_cnt, (size_t)(n + 1) * 4))) return rc;
     if ((rc = bm2_reserve(b->smem_off, (size_t)(n + 1) * 8))) return rc;
     // task kernels with persistent lanes (smem.hip); workspace sizes are learned: a run that overflows one of them reports
@@ -376,13 +376,21 @@ static int batch_run_one(bm2_ctx *c, const bm2_opt *opt, StageGate *gate = nullp
         if ((rc = bm2_perm_by_work(c, n, (const int32_t *)b->n_sa_read.p, (int32_t *)b->perm2.p, (uint32_t *)b->perm_hist.p, 1))) return rc;
         isl_order = (const int32_t *)b->perm2.p;
     }
+    // ... and the reads it cannot chain by islands (equal chain keys) go to a launch of their own behind it (k_chain_serial; BM2_CHAIN_SERIAL_OWN=0: chained
+    // again inside the island kernel, as before round 5)
+    int32_t *isl_serial = nullptr;
+    if (b->max_len >= 1000 && bm2_knob("BM2_CHAIN_SERIAL_OWN", 1)) {
+        if ((rc = bm2_reserve(b->isl_serial, (size_t)(n + 1) * 4))) return rc;
+        isl_serial = (int32_t *)b->isl_serial.p;
+        if ((rc = bm2_check(hipMemsetAsync(isl_serial, 0xff, (size_t)(n + 1) * 4, s), "memset isl_serial"))) return rc;      // -1: place not yet filled
+    }
     if ((rc = bm2_launch_chain(c, cp, n, (const int32_t *)b->len.p, (const bm2_smem_t *)b->smem.p, (const int32_t *)b->smem_cnt.p,
                                (const int64_t *)b->smem_off.p, (const int64_t *)b->sa_off.p, (const int64_t *)b->sa_coord.p,
                                (WChain *)b->wchain.p, (WSeed *)b->wseed.p, (BtNode *)b->nodes.p, (int32_t *)b->order.p,
                                (DevChain *)b->chn.p, (DevSeed *)b->seeds.p, (int32_t *)b->seed_owner.p,
                                (int32_t *)b->n_chain.p, (int32_t *)b->n_reg.p, (int32_t *)b->n_chain0.p, (const int32_t *)b->perm.p,
                                n_heavy_chain ? thr_sa : -1, n_heavy_chain, (const int32_t *)b->n_sa_read.p,
-                               (unsigned long long *)b->counters.p + 10, b->max_len, (int32_t *)b->srt.p, isl_order))) return rc;      // counters[10..15]: work cursors of the tiers and of the overflow launch, [16]: reads the island kernel chained serially
+                               (unsigned long long *)b->counters.p + 10, b->max_len, (int32_t *)b->srt.p, isl_order, isl_serial))) return rc;      // counters[10..15]: work cursors of the tiers and of the overflow launch, [16]: reads listed for k_chain_serial (equal chain keys; [39] of them not staged), [38]: its work cursor
     if (any_flt) {
         if ((rc = bm2_launch_seed_filter(c, cp, (const int8_t *)b->mat25.p, n, n_sa, (const uint8_t *)b->enc.p, (const int64_t *)b->off.p,
                                          (const int32_t *)b->len.p, (const int32_t *)b->min_hsp.p, (const int64_t *)b->read_base.p,
@@ -828,14 +836,14 @@ extern "C" int bm2_batch_fetch(bm2_ctx *c, const char *what, void *out, int64_t 
         { "sa_coord", &b->sa_coord, ns * 8 }, { "read_base", &b->read_base, (size_t)n * 8 },
         { "n_chain", &b->n_chain, (size_t)n * 4 }, { "n_chain0", &b->n_chain0, (size_t)n * 4 }, { "n_reg", &b->n_reg, (size_t)n * 4 },
         { "n_out", &b->n_out, (size_t)n * 4 }, { "chn", &b->chn, ns * sizeof(DevChain) }, { "seeds", &b->seeds, ns * sizeof(DevSeed) },
-        { "seed_counters", &b->seedc, (size_t)27 * 8 }, { "counters", &b->counters, (size_t)48 * 8 }, { "regs_raw", &b->regs, ns * sizeof(DevReg) }, { "reg_seed", &b->reg_seed, ns * 4 }, { "wchain", &b->wchain, ns * sizeof(WChain) },
+        { "seed_counters", &b->seedc, (size_t)27 * 8 }, { "counters", &b->counters, (size_t)56 * 8 }, { "regs_raw", &b->regs, ns * sizeof(DevReg) }, { "reg_seed", &b->reg_seed, ns * 4 }, { "wchain", &b->wchain, ns * sizeof(WChain) },
     };
     if (c->n_parts > 1 && (!strcmp(what, "seed_counters") || !strcmp(what, "counters"))) {       // work counters of a chunk in parts: the parts' sums
-        const size_t nb = !strcmp(what, "counters") ? (size_t)48 * 8 : (size_t)21 * 8;
+        const size_t nb = !strcmp(what, "counters") ? (size_t)56 * 8 : (size_t)21 * 8;
         *n_bytes = (int64_t)nb;
         if ((size_t)cap_bytes < nb) return BM2_ECAP;
         if (!out) return BM2_EINVAL;
-        unsigned long long acc[48] = { 0 }, one[48];
+        unsigned long long acc[56] = { 0 }, one[56];
         for (int i = 0; i < c->n_parts; i++) {
             bm2_ctx *p = part_ctx(c, i);
             if (!p->batch) return BM2_EINVAL;

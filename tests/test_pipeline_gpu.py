@@ -147,6 +147,7 @@ KNOB_SETTINGS = [
     {"BM2_BWD_EXPORT_AGE": "0"}, {"BM2_BWD_EXPORT_AGE": "64", "BM2_BWD_LCAP": "8", "BM2_BWD_BLOCKS_PER_CU": "4"}, {"BM2_BWD_CONT_BPC": "2", "BM2_BWD_EXPORT_AGE": "100"},
     {"BM2_P3_BPC": "1"}, {"BM2_P3_BPC": "2", "BM2_P3_AT": "2"},
     {"BM2_CHAIN_COOP_FLT": "0"}, {"BM2_CHAIN_COOP_FLT": "1", "BM2_CHAIN_FINE_TIERS": "1"}, {"BM2_CHAIN_CLOCK": "1"}, {"BM2_CHAIN_HEAVY_WPE": "2"}, {"BM2_CHAIN_HEAVY_WPE": "4", "BM2_CHAIN_COOP_FLT": "0"}, {"BM2_BWD_HEAVY_BPC": "1"},
+    {"BM2_CHAIN_SERIAL_OWN": "0"}, {"BM2_CHAIN_SERIAL_LNODES": "3", "BM2_CHAIN_ISL_WPE": "3"}, {"BM2_CHAIN_SERIAL_LNODES": "400", "BM2_CHAIN_COOP_FLT": "1"},
 ]
 
 
@@ -374,12 +375,17 @@ def test_long_reads_at_scale_against_the_reference(gpu_ctx_factory, tmp_path):
     assert st["n_sa"] / len(reads) > 1000          # the reads are seed-rich enough for the long-read kernels
 
 
-def test_long_reads_chained_by_islands(gpu_ctx_factory, tmp_path, monkeypatch):
+@pytest.mark.parametrize("env", [{}, {"BM2_CHAIN_SERIAL_OWN": "0"}, {"BM2_CHAIN_SERIAL_LNODES": "2"}, {"BM2_CHAIN_COOP_FLT": "1", "BM2_CHAIN_ISL_WPE": "3"}, {"BM2_CHAIN_SERIAL_BESIDE": "0"}],
+                         ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()) or "default")
+def test_long_reads_chained_by_islands(gpu_ctx_factory, tmp_path, monkeypatch, env):
     # mem_chain_seeds of seed-rich reads cut into islands of reference buckets (k_chain_islands, chain.hip): a repeat-rich genome, so that a read
     # brings hundreds of stray hits -- islands of one seed -- beside its locus; the tiers of the wavefront-per-read kernel are switched off so
     # that every read beyond 100 seeds takes the island path.  Chains, seeds and regs must equal the oracle's; the kernel says how many reads it
     # chained by islands and how many it handed to the serial code (equal chain keys).
+    # (the reads with equal chain keys: k_chain_serial -- the tree's internal nodes in LDS -- by default; inside the island kernel; with an LDS pool of two nodes)
     monkeypatch.setenv("BM2_CHAIN_TIER_MAX", "64")
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
     names, ctg, alts = synth.make_genome(43, [400000, 150000], alt_contigs=1, alt_len=5000, n_repeat_families=40, repeat_len=(100, 2000),
                                          copies=(3, 80), divergence=(0.0, 0.03))
     fa = str(tmp_path / "g.fa")

@@ -144,6 +144,10 @@ static inline int __clz(int x) { return x ? __builtin_clz((unsigned)x) : 32; }
 #define __all(p) (EMU_AT(emu_ballot(!(p))) == 0)
 #define __ffsll(x) __builtin_ffsll(x)
 #define __clzll(x) __builtin_clzll(x)
+#define __HIP_MEMORY_SCOPE_AGENT 0
+#define __hip_atomic_load(p, order, scope) __atomic_load_n(p, __ATOMIC_SEQ_CST)
+#define __hip_atomic_store(p, v, order, scope) __atomic_store_n(p, v, __ATOMIC_SEQ_CST)
+#define __builtin_amdgcn_s_sleep(n) ((void)0)
 #define __threadfence() std::atomic_thread_fence(std::memory_order_seq_cst)
 #define __threadfence_block() std::atomic_thread_fence(std::memory_order_seq_cst)
 static inline void __syncthreads() { emu_t.block_bar->wait(); }
