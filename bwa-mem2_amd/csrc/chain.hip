@@ -180,16 +180,9 @@ template <bool SP = false> static __device__ int bt_lower_reg(const BTree &b, in
     return lower;
 }
 template <bool SP> static __device__ void bt_split(BTree &b, int xi, int i, int yi);
-template <bool SP = false> static __device__ void bt_put_reg(BTree &b, int key, int64_t k) {
-    ++b.n_keys;
-    RNode x; rn_load(x, bt_at<SP>(b, b.root));                // (the node's own fill comes with it: no separate load for the "is it full" test)
-    if (rn_n(x) == 2 * BT_T - 1) {
-        const int s = bt_new<SP>(b, 1), r = b.root;
-        b.root = s; bt_at<SP>(b, s)->ptr[0] = r;
-        bt_split<SP>(b, s, 0, r);
-        rn_load(x, bt_at<SP>(b, b.root));
-    }
-    int xi = b.root, r;
+// the descent from node xi, already in registers (x), to the leaf the key goes into
+template <bool SP> static __device__ void bt_put_reg_tail(BTree &b, int key, int64_t k, RNode &x, int xi) {
+    int r;
     for (;;) {
         if (!rn_internal(x)) {                               // leaf: keys above i move up by one, the new key goes to i + 1
             const int i = rn_getp(x, k, r), at = i + 1;
@@ -214,6 +207,17 @@ template <bool SP = false> static __device__ void bt_put_reg(BTree &b, int key, 
         }
         x = y; xi = child;
     }
+}
+template <bool SP = false> static __device__ void bt_put_reg(BTree &b, int key, int64_t k) {
+    ++b.n_keys;
+    RNode x; rn_load(x, bt_at<SP>(b, b.root));                // (the node's own fill comes with it: no separate load for the "is it full" test)
+    if (rn_n(x) == 2 * BT_T - 1) {
+        const int s = bt_new<SP>(b, 1), r = b.root;
+        b.root = s; bt_at<SP>(b, s)->ptr[0] = r;
+        bt_split<SP>(b, s, 0, r);
+        rn_load(x, bt_at<SP>(b, b.root));
+    }
+    bt_put_reg_tail<SP>(b, key, k, x, b.root);
 }
 
 // kb_intervalp, lower bound only (kbtree.h:158-175)
@@ -271,6 +275,63 @@ template <bool SP = false> static __device__ void bt_put(BTree &b, int key, int6
         }
         xi = x.ptr[i];
     }
+}
+// The split pool's own descent (k_chain_serial): a node in LDS is probed IN PLACE -- the binary search of __kb_getp_aux is three or four LDS reads, where
+// the register form pays ten 16-byte loads and ~130 instructions of compares and select chains per level -- and the first node in global memory (the leaf,
+// as a rule) comes into registers once and the register form takes over.
+static __device__ void bt_put_hyb(BTree &b, int key, int64_t k) {
+    ++b.n_keys;
+    if (bt_at<true>(b, b.root)->n == 2 * BT_T - 1) {
+        const int s = bt_new<true>(b, 1), r = b.root;
+        b.root = s; bt_at<true>(b, s)->ptr[0] = r;
+        bt_split<true>(b, s, 0, r);
+    }
+    int xi = b.root, r;
+    while (xi & BT_LDS_FLAG) {                               // (a node of the LDS pool is internal)
+        BtNode &x = b.lnodes[xi & ~BT_LDS_FLAG];
+        int i = bt_getp_aux(b, x, k, r) + 1;
+        int child = x.ptr[i];
+        if (child & BT_LDS_FLAG) {
+            if (b.lnodes[child & ~BT_LDS_FLAG].n == 2 * BT_T - 1) {
+                bt_split<true>(b, xi, i, child);
+                if (k > x.kpos[i]) ++i;
+                child = x.ptr[i];
+            }
+            xi = child;
+        } else {
+            RNode y; rn_load(y, b.nodes + child);
+            if (rn_n(y) == 2 * BT_T - 1) {
+                bt_split<true>(b, xi, i, child);
+                if (k > x.kpos[i]) ++i;
+                child = x.ptr[i];
+                rn_load(y, bt_at<true>(b, child));
+            }
+            bt_put_reg_tail<true>(b, key, k, y, child);
+            return;
+        }
+    }
+    RNode x; rn_load(x, b.nodes + xi);                       // (the root is a leaf still, or the pool was full when it was made)
+    bt_put_reg_tail<true>(b, key, k, x, xi);
+}
+static __device__ int bt_lower_hyb(const BTree &b, int64_t k) {
+    int lower = -1, x = b.root, r = 0;
+    while (x >= 0) {
+        if (x & BT_LDS_FLAG) {
+            const BtNode &nd = b.lnodes[x & ~BT_LDS_FLAG];
+            const int i = bt_getp_aux(b, nd, k, r);
+            if (i >= 0 && r == 0) return nd.key[i];
+            if (i >= 0) lower = nd.key[i];
+            x = nd.ptr[i + 1];
+        } else {
+            RNode nd; rn_load(nd, b.nodes + x);
+            const int i = rn_getp(nd, k, r);
+            if (i >= 0 && r == 0) return rn_key(nd, i);
+            if (i >= 0) lower = rn_key(nd, i);
+            if (!rn_internal(nd)) return lower;
+            x = rn_ptr(nd, i + 1);
+        }
+    }
+    return lower;
 }
 // __kb_traverse (in-order), kbtree.h:343-366
 template <bool SP = false> static __device__ int bt_traverse(const BTree &b, int32_t *out) {
@@ -1092,7 +1153,7 @@ k_chain_serial(DevIndex ix, ChainParams o, int n_reads, const int32_t *__restric
                DevChain *chn, DevSeed *seeds_out, int32_t *seed_owner, int32_t *n_chain_out, int32_t *n_reg_out, int32_t *n_chain0_out,
                const int32_t *serial_list /* n_reads places, -1 = not yet listed: reads with equal chain keys, staged by k_chain_islands; | SER_PLAIN: reads it did not touch */,
                unsigned long long *n_fallback /* [0]: reads listed so far, [22]: this launch's work cursor, [SER_DONE]: producers that have left */, int l_cap,
-               int n_producers) {
+               int n_producers, int hyb /* nodes in LDS probed in place (BM2_CHAIN_SERIAL_HYB) */) {
     extern __shared__ __attribute__((aligned(16))) uint8_t ser_lds[];
     BtNode *lnodes = (BtNode *)ser_lds;
     SerStage *stg = (SerStage *)(ser_lds + (size_t)l_cap * sizeof(BtNode));
@@ -1148,6 +1209,8 @@ k_chain_serial(DevIndex ix, ChainParams o, int n_reads, const int32_t *__restric
                 e.single = q.rid >= 0 && hash[cslot[t0 + lane]].cnt == 1 ? 1 : 0;
                 stg[lane] = e;
             }
+            // (Tried and removed, profiles/r05p_config5_variants.txt: every lane walking the tree as it is down the LDS levels for its own seed and touching
+            //  the leaf it reaches, so that lane 0's sixty-four descents find their leaves in the cache: the stage 476-481 ms with it, 463 without.)
             chain_wave_sync();
             if (lane == 0) {
                 const int nb = n_sa - t0 < 64 ? n_sa - t0 : 64;
@@ -1159,7 +1222,7 @@ k_chain_serial(DevIndex ix, ChainParams o, int n_reads, const int32_t *__restric
                     // (a seed alone in its island can meet no chain -- see chain_one_read -- only the tree's shape is kept exact)
                     if (q.single) to_add = 1;
                     else if (bt.n_keys) {
-                        const int lower = bt_lower<true>(bt, sdd.rbeg);
+                        const int lower = hyb ? bt_lower_hyb(bt, sdd.rbeg) : bt_lower<true>(bt, sdd.rbeg);
                         if (lower < 0) to_add = 1;
                         else {
                             const int m = test_and_merge(o, ix.l_pac, ch[lower], sdd, q.rid, sd, n_sd);
@@ -1173,7 +1236,7 @@ k_chain_serial(DevIndex ix, ChainParams o, int n_reads, const int32_t *__restric
                         c2.n = 1; c2.rid = q.rid; c2.is_alt = (int)(q.ql >> 31); c2.head = c2.tail = n_sd; c2.w = 0; c2.kept = 0; c2.first = -1; c2.pad = 0;
                         sd[n_sd] = sdd; n_sd++;
                         ch[n_ch] = c2;
-                        bt_put<true>(bt, n_ch, c2.pos);
+                        if (hyb) bt_put_hyb(bt, n_ch, c2.pos); else bt_put<true>(bt, n_ch, c2.pos);
                         n_ch++;
                     }
                 }
@@ -1382,8 +1445,8 @@ int bm2_launch_chain(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_
             if (bm2_knob("BM2_CHAIN_ISLANDS", 1)) {                 // chaining by islands (k_chain_islands): one wavefront per read, every lane at work
                 // (wavefronts per CU: 32 asked for, 16 resident at 128 registers -- the kernel itself is shortest there, 298 ms for 20 000 long reads, but every read
                 //  is three times slower than at 4 per CU, and the stage ends when the seed-richest read with equal keys has gone through this kernel AND
-                //  k_chain_serial: 8 per CU gave the shortest stage, profiles/r05p_config5_variants.txt)
-                const int per_cu = bm2_knob("BM2_CHAIN_ISL_WAVES_PER_CU", isl_serial ? 8 : 32);
+                //  k_chain_serial: 6 per CU gave the shortest stage -- 4: 551 ms, 6: 474, 8: 542-557, 12: 574-589, 16: 594 -- profiles/r05p_config5_variants.txt)
+                const int per_cu = bm2_knob("BM2_CHAIN_ISL_WAVES_PER_CU", isl_serial ? 6 : 32);
                 const int isl_wpe = bm2_knob("BM2_CHAIN_ISL_WPE", 4);
                 auto k_isl = !isl_serial ? (coop ? k_chain_islands<true, 0> : k_chain_islands<false, 0>)
                            : isl_wpe >= 4 ? (coop ? k_chain_islands<true, 4> : k_chain_islands<false, 4>) : (coop ? k_chain_islands<true, 3> : k_chain_islands<false, 3>);
@@ -1406,7 +1469,8 @@ int bm2_launch_chain(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_
                     const int per_cu_s = (int)((160 * 1024 - 512) / lds_s) < 1 ? 1 : (int)((160 * 1024 - 512) / lds_s);
                     hipLaunchKernelGGL(k_ser, dim3(c->n_cu * (per_cu_s > 8 ? 8 : per_cu_s)), dim3(64), lds_s, sc2, c->ix, o, n_reads, len, smems, smem_cnt, smem_off, sa_off, sa_coord,
                                        wchain, wseed, nodes, order, chn, seeds_out, seed_owner, n_chain_out, n_reg_out, n_chain0_out,
-                                       (const int32_t *)isl_serial, item_cur + CHAIN_CUR_SLOTS + 1, l_cap, c->n_cu * per_cu);
+                                       (const int32_t *)isl_serial, item_cur + CHAIN_CUR_SLOTS + 1, l_cap, c->n_cu * per_cu,
+                                       o.reg_nodes ? bm2_knob("BM2_CHAIN_SERIAL_HYB", 1) : 0);
                     if (beside) { (void)hipEventRecord(c->ev_join[11], sc2); joined[n_joined++] = 11; }
                 }
             } else {

@@ -375,7 +375,7 @@ def test_long_reads_at_scale_against_the_reference(gpu_ctx_factory, tmp_path):
     assert st["n_sa"] / len(reads) > 1000          # the reads are seed-rich enough for the long-read kernels
 
 
-@pytest.mark.parametrize("env", [{}, {"BM2_CHAIN_SERIAL_OWN": "0"}, {"BM2_CHAIN_SERIAL_LNODES": "2"}, {"BM2_CHAIN_COOP_FLT": "1", "BM2_CHAIN_ISL_WPE": "3"}, {"BM2_CHAIN_SERIAL_BESIDE": "0"}],
+@pytest.mark.parametrize("env", [{}, {"BM2_CHAIN_SERIAL_OWN": "0"}, {"BM2_CHAIN_SERIAL_LNODES": "2"}, {"BM2_CHAIN_COOP_FLT": "1", "BM2_CHAIN_ISL_WPE": "3"}, {"BM2_CHAIN_SERIAL_BESIDE": "0", "BM2_CHAIN_SERIAL_HYB": "0"}],
                          ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()) or "default")
 def test_long_reads_chained_by_islands(gpu_ctx_factory, tmp_path, monkeypatch, env):
     # mem_chain_seeds of seed-rich reads cut into islands of reference buckets (k_chain_islands, chain.hip): a repeat-rich genome, so that a read
