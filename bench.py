@@ -853,6 +853,25 @@ def bench_bsw(a, bm2, torch, dist_util, rank, world, local, emu, seed):
     return 0 if bad == 0 else 3
 
 
+def run_side_workloads(a, early_s1, time_left):
+    """BASELINE configs 5 and 2 as workloads of their own (each a process of its own on this GPU, with its parity gate, its kernels' figures and the
+    compiled reference timed beside it): {"config5": line, "config2": line}."""
+    res = {}
+    for key, name, extra, need_s in (("config5", "ont2d", ["--steps", 2, "--warmup", 1, "--parity-reads", 2048, "--parity-regs-reads", 200] + CONFIG5_READS, 420),
+                                     ("config2", "bsw", ["--steps", 5, "--warmup", 2], 90)):
+        if time_left() < need_s:
+            res[key] = {"skipped": "time budget (%.0f s left)" % time_left()}
+            continue
+        s1_done = key == "config2" and isinstance(early_s1, dict) and "sam_equal" in early_s1
+        try:
+            res[key] = side_workload(a, name, extra + (["--no-binding-s1"] if s1_done else []), min(need_s * 2, time_left() - 20))
+            if s1_done:                                          # (timed at the start of the run, the GPU to itself)
+                res[key]["s1_binding"] = early_s1
+        except Exception as e:                                                        # noqa
+            res[key] = {"error": str(e)}
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -925,6 +944,18 @@ def main():
                 early_s1["when"] = "before this process opened the device (the GPU to the binding alone, as a user runs it)"
         except Exception as e:                                                        # noqa
             early_s1 = {"error": str(e)}
+    # ... and so are BASELINE configs 5 and 2 as workloads of their own (processes of their own, `side_workload`): beside this process's idle contexts the
+    # same config-5 chunk took 1196 ms per step (chain stage 685 ms: its persistent launches and the consumer kernel that waits beside its producer are what a
+    # second process's queues on the GPU disturb most), 965-980 ms with the GPU to itself (profiles/r05zzz_bench.json against r05t / r05s)
+    early_side = None
+    if world == 1 and not emu and a.workload == "pe150" and not a.no_side_workloads:
+        early_side = {}
+        try:
+            prepare_genome(a.workdir, a.genome_mbp, seed)
+            early_side = run_side_workloads(a, early_s1, time_left)
+        except Exception as e:                                                        # noqa
+            log("side workloads ahead of the main line: %s" % e)
+            early_side = None
     if not emu:
         torch.cuda.set_device(local)
     dist_util.init("gloo" if emu else "nccl", world, None if emu else torch.device("cuda", local))     # "nccl" is RCCL on ROCm
@@ -1182,10 +1213,13 @@ def main():
         if chain_kernel:
             if "serial_reads" in chain_kernel:                   # what bounds the chaining stage of a long-read chunk, from the kernel's own clock
                 sr = chain_kernel["serial_reads"]
-                chain_kernel["stage_bound"] = {"kind": "latency (one wavefront per read; a read with equal chain keys is chained again by ONE lane through global memory)",
+                chain_kernel["stage_bound"] = {"kind": "latency (k_chain_islands: one wavefront per read, six per CU; the reads with equal chain keys are chained again by ONE lane of "
+                                                       "k_chain_serial beside it, the kbtree's internal nodes in LDS)",
                                                "floor_ms": sr["slowest_ms"], "stage_ms": stage_ms.get("chain"),
-                                               "note": "k_chain_islands cannot end before its slowest serially chained read does (floor_ms; %d such reads of %.0f ms on average in this chunk); "
-                                                       "the seed filter's local SW (k_seed_sw, ~11 ms per 1000 reads, throughput-bound) and k_chain_finish follow it in the stage"
+                                               "note": "the stage = the island kernel (330 ms for 20 000 reads at six wavefronts per CU: more of them and k_chain_serial's wavefront, which needs half a "
+                                                       "SIMD's registers, cannot start beside it) + what k_chain_serial still has to do when it ends (the seed-richest read with equal keys has to go "
+                                                       "through both: floor_ms is its serial part; %d such reads of %.0f ms on average in this chunk) + the seed filter's local SW (k_seed_sw_reg, ~4.7 ms per "
+                                                       "1000 reads, VALU-bound) + k_chain_finish; profiles/r05zzz_timeline_ont2d.tsv"
                                                        % (chain_kernel["reads_chained_serially_equal_keys"], sr["ms_per_read"])}
             out["chain_kernel"] = chain_kernel
         # (stderr: the driver keeps the tail of it; the JSON line on stdout is long enough to lose its head there)
@@ -1347,22 +1381,18 @@ def main():
                 ctx = None
             except Exception as e:                                                    # noqa
                 log("closing the main context before the side workloads: %s" % e)
-            for key, name, extra, need_s in (("config5", "ont2d", ["--steps", 2, "--warmup", 1, "--parity-reads", 2048, "--parity-regs-reads", 200] + CONFIG5_READS, 420),
-                                             ("config2", "bsw", ["--steps", 5, "--warmup", 2], 90)):
-                if time_left() < need_s:
-                    out[key] = {"skipped": "time budget (%.0f s of %.0f s left)" % (time_left(), a.budget_s)}
-                    continue
-                s1_done = key == "config2" and isinstance(early_s1, dict) and "sam_equal" in early_s1
-                try:
-                    out[key] = side_workload(a, name, extra + (["--no-binding-s1"] if s1_done else []), min(need_s * 2, time_left() - 20))
-                    if s1_done:                                  # (timed at the start of this run, the GPU to itself)
-                        out[key]["s1_binding"] = early_s1
-                        if early_s1.get("sam_equal") is False:
-                            rc = rc or 3
-                    if out[key].get("exit_code") not in (0, None):
+            if early_side is not None:                           # (run at the start of this process, the GPU to themselves)
+                for key, val in early_side.items():
+                    out[key] = val
+                    if isinstance(val, dict) and val.get("exit_code") not in (0, None):
                         rc = rc or 3
-                except Exception as e:                                                # noqa
-                    out[key] = {"error": str(e)}
+                    if key == "config2" and isinstance(val, dict) and (val.get("s1_binding") or {}).get("sam_equal") is False:
+                        rc = rc or 3
+            else:
+                for key, val in run_side_workloads(a, early_s1, time_left).items():
+                    out[key] = val
+                    if isinstance(val, dict) and val.get("exit_code") not in (0, None):
+                        rc = rc or 3
         try:                                                     # the legs once more, one line each, at the very end of stderr
             pr = out.get("parity") or {}
             if "regs_equal" in pr:
