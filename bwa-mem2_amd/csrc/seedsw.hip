@@ -178,9 +178,9 @@ static __device__ __forceinline__ void ssw_cols(uint32_t (&he)[SSW_QMAX / 2], ui
 // unrolled over them (a register has no run-time index) and leaves at the wavefront's widest window; three wavefronts per SIMD, no LDS at all.
 // A column past the lane's own window is computed and thrown away (two selects per cell) instead of branched around.
 #define SSW_NP (SSW_QMAX / 2)
-// (WPE = wavefronts per SIMD the registers are allocated for: 2 -- everything fits -- or 3 -- a tenth of the row loop's instructions are spills)
-template <int WPE>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
+// (registers allocated for TWO wavefronts per SIMD: for three, a tenth of the row loop's instructions were spills and the kernel slower than the LDS form --
+//  chain stage of 20 000 long reads 696 ms against 594 and 723, profiles/r05p_config5_variants.txt; that instantiation is gone)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_seed_sw_reg(DevIndex ix, ChainParams o, const int8_t *__restrict__ mat25, int64_t n_slots, const uint8_t *__restrict__ enc,
               const int64_t *__restrict__ off, const int32_t *__restrict__ len, const int32_t *__restrict__ min_hsp /* per read, <0 = filter inactive */,
               const int32_t *__restrict__ seed_owner, DevSeed *seeds, uint8_t *seed_keep) {
@@ -282,9 +282,8 @@ int bm2_launch_seed_filter(bm2_ctx *c, const ChainParams &o, const int8_t *d_mat
                            const int64_t *off, const int32_t *len, const int32_t *min_hsp, const int64_t *read_base, const int32_t *n_chain,
                            const int32_t *seed_owner, DevChain *chn, DevSeed *seeds, uint8_t *seed_keep) {
     if (n_slots <= 0) return BM2_OK;
-    const int reg_wpe = bm2_knob("BM2_SEEDSW_REG", 2);                       // 0: the row in LDS (k_seed_sw), 2 / 3: in registers, allocated for two / three wavefronts per SIMD
-    if ((SSW_QMAX - 1) * o.a <= 255 && reg_wpe)                              // (a window has < 200 columns: no score above 199 a)
-        hipLaunchKernelGGL(reg_wpe >= 3 ? k_seed_sw_reg<3> : k_seed_sw_reg<2>, dim3((unsigned)((n_slots + 63) / 64)), dim3(64), 0, c->stream, c->ix, o, d_mat25, n_slots, enc, off, len, min_hsp,
+    if ((SSW_QMAX - 1) * o.a <= 255 && bm2_knob("BM2_SEEDSW_REG", 1))       // (a window has < 200 columns: no score above 199 a); BM2_SEEDSW_REG=0: the row in LDS (k_seed_sw)
+        hipLaunchKernelGGL(k_seed_sw_reg, dim3((unsigned)((n_slots + 63) / 64)), dim3(64), 0, c->stream, c->ix, o, d_mat25, n_slots, enc, off, len, min_hsp,
                            seed_owner, seeds, seed_keep);
     else if ((SSW_QMAX - 1) * o.a <= 255)
         hipLaunchKernelGGL(k_seed_sw<true>, dim3((unsigned)((n_slots + 63) / 64)), dim3(64), 0, c->stream, c->ix, o, d_mat25, n_slots, enc, off, len, min_hsp,
