@@ -273,6 +273,50 @@ print("ok")
     p = subprocess.run(["python", "-c", script], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
     assert p.returncode == 0 and p.stdout.startswith(b"ok"), p.stderr.decode()[-2000:]
 
+def test_long_read_chaining_kernels_on_the_emulator(emu_lib, tmp_path):
+    # The long-read chaining launches (chain.hip): k_chain_islands (one wavefront per read, chaining by islands of reference buckets), the list it hands to
+    # k_chain_serial (reads whose chains have EQUAL keys: chained again by the kbtree walk, internal nodes in the LDS pool -- also with a pool of two nodes, the
+    # rest overflowing to global memory) and the seed filter's SW with its row in registers (k_seed_sw_reg), against the oracle.  Reads of ~0.5-1.1 kb, ONT-like
+    # errors, `-x ont2d`, a repeat-rich genome; one read of the five is known (from the oracle's chains) to hold two chains with the same key.  Real long reads
+    # are beyond what the thread-per-lane emulator runs in minutes: tests/test_pipeline_gpu.py has them.
+    script = r"""
+import sys, os
+sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np, bm2
+bm2.LIB_PATH = %r
+from helpers import build_index, regs_to_records, ONT2D
+from tools import oracle, refio, synth
+d = %r
+names, ctg, alts = synth.make_genome(43, [400000, 150000], alt_contigs=1, alt_len=5000, n_repeat_families=40, repeat_len=(100, 2000), copies=(3, 80), divergence=(0.0, 0.03))
+fa = os.path.join(d, "g.fa")
+synth.write_fasta(fa, names, ctg); synth.write_alt(fa + ".alt", alts)
+assert build_index(fa)
+reads = synth.make_reads_long(7, ctg, 400, mean_len=1100, max_len=1400)
+ix = oracle.Index(fa)
+os.environ["BM2_CHAIN_TIER_MAX"] = "64"                     # no LDS tiers: every read beyond 100 seeds takes the island path
+ctx = bm2.Context(0, fa)
+for pick, env in (((198, 1, 3, 30, 19), {}), ((198, 1), {"BM2_CHAIN_SERIAL_LNODES": "2"})):
+    sel = [reads[i] for i in pick]
+    assert max(len(x) for x in sel) >= 1000                # (a chunk with a read of 1000 bases or more is a long-read chunk to the chaining stage)
+    enc, off, ln = refio.pack_reads(sel)
+    exp = ix.run(enc, off, ln, oracle.default_opt(**ONT2D))
+    c0 = exp["CHN0"]
+    dup = [r for r in range(len(ln)) if len(c0["pos"][c0["read"] == r]) != len(np.unique(c0["pos"][c0["read"] == r]))]
+    assert dup == [0], dup                                  # the oracle's own chains: read 198 holds two with the same key
+    for k, v in env.items(): os.environ[k] = v
+    regs, reg_off, st = ctx.seed_chain_extend(enc, off, ln, bm2.default_opt(**ONT2D))
+    for k in env: del os.environ[k]
+    cn = ctx.batch_fetch("counters", np.uint64)
+    assert regs_to_records(regs, reg_off).tobytes() == exp["REGPRG"].tobytes(), env
+    assert int(cn[16]) == 1 and int(cn[39]) == 0, (int(cn[16]), int(cn[39]))      # one read listed for k_chain_serial, none of them unstaged
+    if len(pick) > 2:
+        assert int(cn[17]) >= 1                             # ... and at least one chained by islands
+ix.close(); ctx.close()
+print("ok")
+""" % (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "bwa-mem2_amd"), emu_lib, str(tmp_path))
+    p = subprocess.run(["python", "-c", script], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
+    assert p.returncode == 0 and p.stdout.startswith(b"ok"), p.stderr.decode()[-2000:]
+
 
 def test_hit_finishing_kernels_on_the_emulator(emu_lib, golden_dir, tmp_path):
     # finish.hip (mem_sort_dedup_patch + ALT flag on the device): the resumable lane-per-read walk, the wave-per-request global
