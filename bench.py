@@ -253,7 +253,7 @@ def main():
         roof_kernel, roof_launches = ("k_bwd (+ k_bwd_cont, the tasks it hands over)" if cont_ms > 0 else "k_bwd"), 2 * parts
         handed = None
         if len(sc) >= 27 and (sc[21] > 0 or sc[22] > 0):
-            handed = {"export_age": int(os.environ.get("BM2_BWD_EXPORT_AGE", "256") or 0), "tasks_pass1_in_64s": int(sc[21]), "tasks_pass2_in_64s": int(sc[22]),
+            handed = {"export_age": int(os.environ.get("BM2_BWD_EXPORT_AGE", "256") or 0), "tasks_pass1": int(sc[21]), "tasks_pass2": int(sc[22]),
                       "rows_walked_by_k_bwd_cont": [int(sc[25]), int(sc[26])], "k_bwd_cont_ms": [kern_ms.get("smem.cont1", 0.0) / parts, kern_ms.get("smem.cont2", 0.0) / parts]}
         fm_kernels = {}                                       # every FM-index kernel of the step against the same peak: 128 algorithmic bytes per backwardExt
         for kn, ev in (("k_walk<1>", "walk1"), ("k_bwd + k_bwd_cont (pass 1)", "bwd1"), ("k_walk<2>", "walk2"), ("k_bwd + k_bwd_cont (pass 2)", "bwd2")):
@@ -283,7 +283,7 @@ def main():
                                 "phase_ms_per_read": {nm: float(cn[19 + i] * 1e-5 / (cn[17] + cn[16])) for i, nm in enumerate(names)},
                                 "phase_ms_slowest_read": {nm: float(cn[31 + i] * 1e-5) for i, nm in enumerate(names)},
                                 "serial_reads": {"ms_per_read": float(cn[28] * 1e-5 / max(cn[16], 1.0)), "seeds_per_read": float(cn[29] / max(cn[16], 1.0)), "slowest_ms": float(cn[30] * 1e-5),
-                                                 "where": "k_chain_serial: a launch of its own beside the island kernel, the tree's internal nodes in LDS (BM2_CHAIN_SERIAL_OWN=0: inside k_chain_islands)"}}
+                                                 "where": "k_chain_serial: a launch of its own beside the island kernel, the tree's internal nodes in LDS"}}
             if len(cn) >= 48 and cn[46] > 0:                   # BM2_CHAIN_CLOCK=1: lane 0's walk of the wavefront-per-read chain launches, clocked (100 MHz ticks)
                 heavy_clock = {"reads": int(cn[46]), "seeds_per_read": float(cn[47] / cn[46]),
                                "ms_per_read": {"staging by the 64 lanes": float(cn[43] * 1e-5 / cn[46]), "mem_chain_seeds (lane 0)": float(cn[44] * 1e-5 / cn[46]),

@@ -195,6 +195,7 @@ static int make_streams(bm2_ctx *c) {
     if (bm2_check(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "hipStreamCreate")) return BM2_ENODEV;
     for (int i = 0; i <= BM2_MAX_TIMERS; i++) (void)hipEventCreate(&c->ev[i]);
     if (hipHostMalloc((void **)&c->ext_stat, sizeof(uint32_t) * BM2_EXT_PHASES * BM2_EXT_STATW, hipHostMallocPortable) != hipSuccess) c->ext_stat = nullptr;
+    if (c->ext_stat) memset(c->ext_stat, 0, sizeof(uint32_t) * BM2_EXT_PHASES * BM2_EXT_STATW);      // (rows no round has written yet size grids as hints: zeros, not whatever the pool held)
     return BM2_OK;
 }
 // The side streams of the fork / join launches (seeding, chaining, extension) exist only in contexts that run those stages: a process has

@@ -12,7 +12,7 @@
 #include "chain_dev.h"
 #include "ksort_dev.h"
 
-#define BM2_CHAIN_TIERS 8          // at most (BM2_CHAIN_FINE_TIERS); five by default
+#define BM2_CHAIN_TIERS 8          // stream / event slots kept for the tier launches (five tiers are launched)
 #define CHAIN_CUR_SLOTS 5           // work cursors item_cur[0..4]: the first five tiers; [5], [6]: the overflow / island launch; further tiers: item_cur[CHAIN_CUR_EXTRA ..]
 #define CHAIN_CUR_EXTRA 30          // (= counters[40..42] of the batch: pipeline.hip)
 
@@ -1167,15 +1167,21 @@ k_chain_serial(DevIndex ix, ChainParams o, int n_reads, const int32_t *__restric
         if (item >= n_reads) break;
         int listed = -1;
         if (lane == 0) {                                             // wait for place `item` to be filled, or for the producers to have left without filling it
-            const long long t_w = wall_clock64();
+            long long t_w = wall_clock64();
+            unsigned long long seen = ~0ULL;                         // (producers that have left + reads listed when the clock was last reset)
             for (;;) {
                 listed = __hip_atomic_load(serial_list + item, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
                 if (listed != -1) break;
-                if (__hip_atomic_load(n_fallback + SER_DONE, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned long long)n_producers) {
+                const unsigned long long gone = __hip_atomic_load(n_fallback + SER_DONE, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                if (gone >= (unsigned long long)n_producers) {
                     listed = __hip_atomic_load(serial_list + item, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
                     break;
                 }
-                if (wall_clock64() - t_w > 2000000000LL) __builtin_trap();      // (20 s at 100 MHz without a producer moving: fail loudly, do not hang the device)
+                // the guard is against producers that do not MOVE (s_memrealtime ticks at 100 MHz: 20 s): any progress of theirs -- one more has left, one
+                // more read is listed -- starts the clock again, however long the whole island launch takes
+                const unsigned long long now = gone + __hip_atomic_load(n_fallback + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (now != seen) { seen = now; t_w = wall_clock64(); }
+                else if (wall_clock64() - t_w > 2000000000LL) __builtin_trap();      // fail loudly, do not hang the device
                 __builtin_amdgcn_s_sleep(64);
             }
         }
@@ -1395,19 +1401,17 @@ int bm2_launch_chain(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_
         // tiers by seed count (LDS per block follows the tier): the launches run beside the lane-per-read kernel and each other
         const int stage = bm2_knob("BM2_CHAIN_STAGE", 1);     // (sweep of round 3, profiles/r03a_sweep.json: chaining 12.4 -> 10.3 ms)
         // The tiers' launches share the CUs' LDS (together they ask for four times what there is) and a block reserves its tier's cap whatever its
-        // read holds: with caps a factor 2 apart a read uses 60-70 % of its block's LDS on average.  BM2_CHAIN_FINE_TIERS=1: eight tiers, caps
-        // chosen where the number of blocks per CU changes (10, 15, 20, 30, 40, 53, 80, 156 KB: 16, 10, 8, 5, 4, 3, 2, 1 per CU).
+        // read holds: with caps a factor 2 apart a read uses 60-70 % of its block's LDS on average.  (Eight tiers with caps where the number of blocks per
+        // CU changes bought 0.2 ms -- profiles/r04w_* -- and left the tree in round 6: the 257..512-seed reads are the pole whatever tier they sit in.)
         // BM2_CHAIN_CLOCK=1: the wavefront-per-read launches clock their reads (counters[43..47] of the batch: staging, mem_chain_seeds, the rest, reads, seeds)
         unsigned long long *clk = bm2_knob("BM2_CHAIN_CLOCK", 0) ? item_cur + CHAIN_CUR_EXTRA + 3 : (unsigned long long *)nullptr;
         // BM2_CHAIN_COOP_FLT: the wavefront-per-read launches run mem_chain_flt's walk over the kept chains with all 64 lanes.  Measured in round 5 (with
         // wavefront-scope fences: profiles/r05b / r05d / r05e_sweep.json): chaining of the 150 bp workload 11.5-12.4 -> 10.9-11.1 ms in three sweeps (ON for
         // short reads); a chunk of 10 kb reads -- the island kernel, a handful of kept chains per read -- 454 -> 463 ms (OFF there)
         const int coop = bm2_knob("BM2_CHAIN_COOP_FLT", max_len < 1000 ? 1 : 0);
-        const int fine = bm2_knob("BM2_CHAIN_FINE_TIERS", 0);
         const int last_cap = stage ? 1000 : 1184;                 // (the last tier fills a CU's 160 KB of LDS)
-        const int caps_coarse[5] = { 64, 128, 256, 512, last_cap }, caps_fine[8] = { 64, 96, 128, 192, 256, 340, 512, last_cap };
-        const int n_tiers = fine ? 8 : 5;
-        const int *caps = fine ? caps_fine : caps_coarse;
+        const int caps[5] = { 64, 128, 256, 512, last_cap };
+        const int n_tiers = 5;
         const int wpe = bm2_knob("BM2_CHAIN_HEAVY_WPE", 3);
         auto k_heavy = coop ? (wpe >= 4 ? k_chain_heavy<true, 4> : wpe == 3 ? k_chain_heavy<true, 3> : k_chain_heavy<true, 2>)
                             : (wpe >= 4 ? k_chain_heavy<false, 4> : wpe == 3 ? k_chain_heavy<false, 3> : k_chain_heavy<false, 2>);
@@ -1467,7 +1471,13 @@ int bm2_launch_chain(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_
                     auto k_ser = coop ? k_chain_serial<true> : k_chain_serial<false>;
                     { const int rc_a = bm2_raise_lds_limit(c, coop ? 3 : 4, (const void *)k_ser, 160 * 1024 - 512); if (rc_a) return rc_a; }
                     const int per_cu_s = (int)((160 * 1024 - 512) / lds_s) < 1 ? 1 : (int)((160 * 1024 - 512) / lds_s);
-                    hipLaunchKernelGGL(k_ser, dim3(c->n_cu * (per_cu_s > 8 ? 8 : per_cu_s)), dim3(64), lds_s, sc2, c->ix, o, n_reads, len, smems, smem_cnt, smem_off, sa_off, sa_coord,
+                    // A resident consumer must never be what keeps its producer from starting: its workgroups pin most of a CU's LDS each while they wait, and
+                    // the island launch may sit in a hardware queue behind a tier launch whose workgroups (10-156 KB of LDS) have not all been placed.  Beside
+                    // the producer the consumer's grid therefore covers THREE QUARTERS of the CUs at most: on the others anything queued ahead of the island
+                    // kernel keeps running, so the island kernel starts and the list fills (a chunk of 20 000 long reads lists ~150: no shorter for it).
+                    int grid_s = c->n_cu * (per_cu_s > 8 ? 8 : per_cu_s);
+                    if (beside) { const int cus = c->n_cu - (c->n_cu + 3) / 4; grid_s = (cus < 1 ? 1 : cus) * (per_cu_s > 8 ? 8 : per_cu_s); }
+                    hipLaunchKernelGGL(k_ser, dim3(grid_s), dim3(64), lds_s, sc2, c->ix, o, n_reads, len, smems, smem_cnt, smem_off, sa_off, sa_coord,
                                        wchain, wseed, nodes, order, chn, seeds_out, seed_owner, n_chain_out, n_reg_out, n_chain0_out,
                                        (const int32_t *)isl_serial, item_cur + CHAIN_CUR_SLOTS + 1, l_cap, c->n_cu * per_cu,
                                        o.reg_nodes ? bm2_knob("BM2_CHAIN_SERIAL_HYB", 1) : 0);

@@ -260,7 +260,7 @@ static int run_seeding(bm2_ctx *c, Batch *b, const bm2_opt *opt, bool with_sal) 
                 h_sc[BM2_SC_SLOT2], h_sc[BM2_SC_REC], h_sc[BM2_SC_TASK], h_sc[BM2_SC_POOL]);
     }
     unsigned long long h_cnt[3] = { (unsigned long long)n_smem_tot, h_sc[BM2_SC_NEXT], 0 };
-    static_assert(BM2_SC_NEXT_W1 + 15 == 27, "bm2_batch_fetch(\"seed_counters\") exposes 27 counters ([21], [22]: tasks handed over in pass 1 / 2 (in sixteens), [25], [26]: rows their continuations walked)");
+    static_assert(BM2_SC_NEXT_W1 + 15 == 27, "bm2_batch_fetch(\"seed_counters\") exposes 27 counters ([21], [22]: tasks handed over in pass 1 / 2 (counted exactly: wave_alloc_exact), [25], [26]: rows their continuations walked)");
     if ((rc = bm2_reserve(b->smem, (size_t)(n_smem_tot + 1) * sizeof(bm2_smem_t)))) return rc;
     if ((rc = bm2_reserve(b->smem_tmp, (size_t)(n_smem_tot + 1) * sizeof(bm2_smem_t)))) return rc;
     if ((rc = bm2_reserve(b->occ_cnt, (size_t)(n_smem_tot + 2) * 4))) return rc;
@@ -376,10 +376,11 @@ static int batch_run_one(bm2_ctx *c, const bm2_opt *opt, StageGate *gate = nullp
         if ((rc = bm2_perm_by_work(c, n, (const int32_t *)b->n_sa_read.p, (int32_t *)b->perm2.p, (uint32_t *)b->perm_hist.p, 1))) return rc;
         isl_order = (const int32_t *)b->perm2.p;
     }
-    // ... and the reads it cannot chain by islands (equal chain keys) go to a launch of their own behind it (k_chain_serial; BM2_CHAIN_SERIAL_OWN=0: chained
-    // again inside the island kernel, as before round 5)
+    // ... and the reads it cannot chain by islands (equal chain keys) go to a launch of their own (k_chain_serial).  (Chained again inside the island kernel,
+    // as before round 5, a chunk of 20 000 long reads took 551 instead of 474 ms -- profiles/r05p_config5_variants.txt; short-read chunks whose seed-richest
+    // reads are sent to the island kernel, BM2_CHAIN_TIER_MAX, still use that form: no list for them.)
     int32_t *isl_serial = nullptr;
-    if (b->max_len >= 1000 && bm2_knob("BM2_CHAIN_SERIAL_OWN", 1)) {
+    if (b->max_len >= 1000) {
         if ((rc = bm2_reserve(b->isl_serial, (size_t)(n + 1) * 4))) return rc;
         isl_serial = (int32_t *)b->isl_serial.p;
         if ((rc = bm2_check(hipMemsetAsync(isl_serial, 0xff, (size_t)(n + 1) * 4, s), "memset isl_serial"))) return rc;      // -1: place not yet filled
@@ -839,7 +840,7 @@ extern "C" int bm2_batch_fetch(bm2_ctx *c, const char *what, void *out, int64_t 
         { "seed_counters", &b->seedc, (size_t)27 * 8 }, { "counters", &b->counters, (size_t)56 * 8 }, { "regs_raw", &b->regs, ns * sizeof(DevReg) }, { "reg_seed", &b->reg_seed, ns * 4 }, { "wchain", &b->wchain, ns * sizeof(WChain) },
     };
     if (c->n_parts > 1 && (!strcmp(what, "seed_counters") || !strcmp(what, "counters"))) {       // work counters of a chunk in parts: the parts' sums
-        const size_t nb = !strcmp(what, "counters") ? (size_t)56 * 8 : (size_t)21 * 8;
+        const size_t nb = !strcmp(what, "counters") ? (size_t)56 * 8 : (size_t)27 * 8;       // (the same 27 words as the one-part table above)
         *n_bytes = (int64_t)nb;
         if ((size_t)cap_bytes < nb) return BM2_ECAP;
         if (!out) return BM2_EINVAL;

@@ -282,11 +282,8 @@ int bm2_launch_seed_filter(bm2_ctx *c, const ChainParams &o, const int8_t *d_mat
                            const int64_t *off, const int32_t *len, const int32_t *min_hsp, const int64_t *read_base, const int32_t *n_chain,
                            const int32_t *seed_owner, DevChain *chn, DevSeed *seeds, uint8_t *seed_keep) {
     if (n_slots <= 0) return BM2_OK;
-    if ((SSW_QMAX - 1) * o.a <= 255 && bm2_knob("BM2_SEEDSW_REG", 1))       // (a window has < 200 columns: no score above 199 a); BM2_SEEDSW_REG=0: the row in LDS (k_seed_sw)
+    if ((SSW_QMAX - 1) * o.a <= 255)       // (a window has < 200 columns: no score above 199 a; the row in LDS -- k_seed_sw<true>, 218 instead of 93 ms per 20 000 long reads -- left the tree in round 6)
         hipLaunchKernelGGL(k_seed_sw_reg, dim3((unsigned)((n_slots + 63) / 64)), dim3(64), 0, c->stream, c->ix, o, d_mat25, n_slots, enc, off, len, min_hsp,
-                           seed_owner, seeds, seed_keep);
-    else if ((SSW_QMAX - 1) * o.a <= 255)
-        hipLaunchKernelGGL(k_seed_sw<true>, dim3((unsigned)((n_slots + 63) / 64)), dim3(64), 0, c->stream, c->ix, o, d_mat25, n_slots, enc, off, len, min_hsp,
                            seed_owner, seeds, seed_keep);
     else
         hipLaunchKernelGGL(k_seed_sw<false>, dim3((unsigned)((n_slots + 63) / 64)), dim3(64), 0, c->stream, c->ix, o, d_mat25, n_slots, enc, off, len, min_hsp,

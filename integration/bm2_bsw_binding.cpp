@@ -46,11 +46,14 @@ std::condition_variable g_cv;
 std::vector<Request *> g_pending;
 std::atomic<long long> g_pairs{0}, g_batches{0}, g_calls{0};
 
+// The leader of a batch sleeps while the device works (its CPU goes to the threads that are seeding): the library reads BM2_BLOCKING_SYNC when a context
+// is made.  Set at load time, while the program has ONE thread -- inside attach() it raced with the getenv of leaders on other slots (setenv may move environ).
+const int g_env_set = (setenv("BM2_BLOCKING_SYNC", "1", 0), 0);
+
 void attach() {
     const char *e = getenv("BM2_S1_CONTEXTS"), *dev = getenv("BM2_DEVICE");
     int n = e && *e ? atoi(e) : 2;
     g_n = n < 1 ? 1 : n > MAX_SLOT ? MAX_SLOT : n;
-    setenv("BM2_BLOCKING_SYNC", "1", 0);                         // the leader of a batch sleeps while the device works: its CPU goes to the threads that are seeding
     for (int i = 0; i < g_n; i++) {
         g_slot[i].ctx = bm2_create(dev ? atoi(dev) : 0, nullptr);       // (no index: S1 needs none)
         if (!g_slot[i].ctx) { fprintf(stderr, "[bm2s1] bm2_create: %s\n", bm2_last_error()); exit(EXIT_FAILURE); }
@@ -124,6 +127,7 @@ void run(const BandedPairWiseSW *self, SeqPair *pairs, uint8_t *ref, uint8_t *qe
             size_t pairs_in = 0, ref_in = 0, qer_in = 0;          // (SeqPair's offsets are 32-bit: a batch stays below 2^30 bytes of either sequence buffer)
             for (Request *r : g_pending) {
                 const bool same = r->w == lead->w && !memcmp(&r->p, &lead->p, sizeof r->p);
+                // (the FIRST request of a batch is rebased by zero: its own 32-bit offsets hold whatever its size; only what joins it must stay below 2^30)
                 const bool fits = batch.empty() || (pairs_in + (size_t)r->n < ((size_t)1 << 28) && ref_in + (size_t)r->ref_bytes < ((size_t)1 << 30) &&
                                                     qer_in + (size_t)r->qer_bytes < ((size_t)1 << 30));
                 if (same && fits) { batch.push_back(r); pairs_in += (size_t)r->n; ref_in += (size_t)r->ref_bytes; qer_in += (size_t)r->qer_bytes; } else rest.push_back(r);

@@ -57,6 +57,26 @@ import os
 import subprocess
 
 
+def gpu_box():
+    """a HIP device is visible to this process (the GPU box; BM2_EMU_LIB runs of the gpu tests on the host emulator count as one)"""
+    if os.environ.get("BM2_EMU_LIB"):
+        return True
+    try:
+        import torch
+        return bool(torch.cuda.is_available())
+    except Exception:                                             # noqa
+        return os.path.exists("/dev/kfd")
+
+
+def no_checker(reason):
+    """The compiled reference (oracle/_ref) is not there.  On a box WITHOUT a GPU the test has nothing to say and is skipped; on the GPU box a missing
+    checker FAILS the test -- a parity suite that goes quiet when its checker did not travel is not green (hygiene)."""
+    import pytest
+    if gpu_box():
+        pytest.fail("checker missing on a GPU box: " + reason)
+    pytest.skip(reason)
+
+
 def load_golden(golden_dir, name):
     """-> (index_prefix, enc, off, len, dump dict)"""
     from tools import refio

@@ -5,9 +5,11 @@ import socket
 import sys
 
 import numpy as np
+import pytest
 import torch.multiprocessing as mp
 
 from conftest import ROOT
+import helpers  # noqa: E402
 
 
 def _free_port():
@@ -88,8 +90,9 @@ def _align_worker(rank, world, port, lib, fa, npz, out):
     dist_util.finish(world)
 
 
-def test_two_ranks_align_one_chunk(tmp_path, emu_lib):
-    # SURVEY.md 8(e) with processes: ONE chunk cut at a multiple of 512 reads over two ranks (gloo), every rank runs the device
+@pytest.mark.parametrize("world,n_pairs", [(2, 300), (8, 2100)], ids=["two_ranks", "eight_ranks"])
+def test_ranks_align_one_chunk(tmp_path, emu_lib, world, n_pairs):
+    # SURVEY.md 8(e) with processes: ONE chunk cut at multiples of 512 reads over two / EIGHT ranks (gloo), every rank runs the device
     # pipeline (host emulator of the device sources) on its part, rank 0 gathers the hits in read order: equal to the oracle's
     # mem_alnreg_v contents of the whole chunk, i.e. independent of the sharding
     import subprocess
@@ -98,19 +101,17 @@ def test_two_ranks_align_one_chunk(tmp_path, emu_lib):
     from helpers import alnregs_to_recs, ref_binary
     from tools import oracle, refio, synth
     if ref_binary() is None:
-        import pytest
-        pytest.skip("oracle/_ref reference binary not present")
+        helpers.no_checker("oracle/_ref reference binary not present")
     lib = emu_lib
     names, ctg, _ = synth.make_genome(5, [60000, 30000], alt_contigs=0, n_repeat_families=2, repeat_len=(200, 800), copies=(3, 8))
     fa = str(tmp_path / "g.fa")
     synth.write_fasta(fa, names, ctg)
     subprocess.check_call([ref_binary(), "index", fa], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-    r1, r2 = synth.make_reads_pe(9, ctg, 300, L=100)                    # 600 reads: parts of 512 and 88
-    reads = np.empty((600, 100), np.uint8); reads[0::2] = r1; reads[1::2] = r2
+    r1, r2 = synth.make_reads_pe(9, ctg, n_pairs, L=100)                # 600 reads: parts of 512 and 88; 4200 reads: seven parts of 512 and one of 616
+    reads = np.empty((2 * n_pairs, 100), np.uint8); reads[0::2] = r1; reads[1::2] = r2
     enc, off, ln = refio.pack_reads(reads)
     npz = str(tmp_path / "chunk.npz")
     np.savez(npz, enc=enc, off=off, ln=ln)
-    world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -122,7 +123,8 @@ def test_two_ranks_align_one_chunk(tmp_path, emu_lib):
         p.join(120)
         assert p.exitcode == 0
     parts.sort()
-    assert [(lo, hi) for lo, hi, _, _ in parts] == [(0, 512), (512, 600)]
+    n = 2 * n_pairs
+    assert [(lo, hi) for lo, hi, _, _ in parts] == ([(0, 512), (512, 600)] if world == 2 else [(512 * i, 512 * (i + 1)) for i in range(7)] + [(3584, n)])
     aln = np.concatenate([np.frombuffer(a, bm2.ALNREG_DT) for _, _, a, _ in parts])
     aln_off, base = [0], 0
     for lo, hi, a, o in parts:

@@ -10,6 +10,7 @@ import pytest
 import bm2
 from helpers import ref_binary
 from tools import synth
+import helpers  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -17,7 +18,7 @@ pytestmark = pytest.mark.gpu
 def test_fastq_to_sam_paired_end_through_the_device(gpu_ctx_factory, tmp_path):
     exe = ref_binary()
     if exe is None:
-        pytest.skip("oracle/_ref reference binary not present")
+        helpers.no_checker("oracle/_ref reference binary not present")
     names, ctg, alts = synth.make_genome(81, [300000, 150000, 60000], alt_contigs=1, alt_len=4000, n_repeat_families=8, repeat_len=(200, 2500),
                                          copies=(3, 30), divergence=(0.0, 0.06))
     fa = str(tmp_path / "g.fa")

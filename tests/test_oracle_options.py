@@ -9,6 +9,7 @@ import pytest
 
 from helpers import ref_binary
 from tools import oracle, refio, synth
+import helpers  # noqa: E402
 
 SETS = [
     (["-E", "3,1"], dict(e_del=3, e_ins=1)),
@@ -23,7 +24,7 @@ SETS = [
 def test_oracle_matches_reference_under_non_default_scoring(tmp_path, L):
     exe, dump = ref_binary(), ref_binary("refdump")
     if exe is None or dump is None:
-        pytest.skip("oracle/_ref not built (make -C oracle ref)")
+        helpers.no_checker("oracle/_ref not built (make -C oracle ref)")
     names, ctg, alts = synth.make_genome(77, [200000, 90000], alt_contigs=1, alt_len=4000, n_repeat_families=6, repeat_len=(200, 2500),
                                          copies=(3, 30), divergence=(0.0, 0.06))
     fa = str(tmp_path / "g.fa")
@@ -54,7 +55,7 @@ def test_oracle_matches_reference_across_read_shapes(tmp_path, case):
     from helpers import ONT2D
     exe, dump = ref_binary(), ref_binary("refdump")
     if exe is None or dump is None:
-        pytest.skip("oracle/_ref not built (make -C oracle ref)")
+        helpers.no_checker("oracle/_ref not built (make -C oracle ref)")
     names, ctg, alts = synth.make_genome(101, [300000, 120000, 30000], alt_contigs=2, alt_len=5000, n_repeat_families=10, repeat_len=(100, 4000),
                                          copies=(2, 80), divergence=(0.0, 0.1), n_gaps=6, gap_len=(20, 800))
     fa = str(tmp_path / "g.fa")

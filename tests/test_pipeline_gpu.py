@@ -9,6 +9,7 @@ import pytest
 import bm2
 from helpers import (ONT2D, build_index, chain_mask, first_diff, gpu_stage_records, load_golden, regs_to_records)
 from tools import oracle, refio, synth
+import helpers  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -70,7 +71,7 @@ def _fresh_case(tmp_path, seed, contigs, n_reads, L, **kw):
     if alts:
         synth.write_alt(fa + ".alt", alts)
     if not build_index(fa):
-        pytest.skip("oracle/_ref reference binary not present (build it with `make -C oracle ref`)")
+        helpers.no_checker("oracle/_ref reference binary not present (build it with `make -C oracle ref`)")
     reads = synth.make_reads_se(seed + 1, ctg, n_reads, L=L, **kw)
     return fa, refio.pack_reads(reads)
 
@@ -113,7 +114,7 @@ def _repeat_case(tmp_path, seed, n_reads):
     fa = str(tmp_path / "rep.fa")
     synth.write_fasta(fa, names, ctg)
     if not build_index(fa):
-        pytest.skip("oracle/_ref reference binary not present (build it with `make -C oracle ref`)")
+        helpers.no_checker("oracle/_ref reference binary not present (build it with `make -C oracle ref`)")
     return fa, refio.pack_reads(synth.make_reads_se(seed + 1, ctg, n_reads, L=150))
 
 
@@ -146,8 +147,8 @@ KNOB_SETTINGS = [
     {"BM2_BWD_EXPORT_AGE": "256"}, {"BM2_BWD_EXPORT_AGE": "24"}, {"BM2_BWD_EXPORT_AGE": "128", "BM2_BWD_HEAVY_AFTER": "1"},
     {"BM2_BWD_EXPORT_AGE": "0"}, {"BM2_BWD_EXPORT_AGE": "64", "BM2_BWD_LCAP": "8", "BM2_BWD_BLOCKS_PER_CU": "4"}, {"BM2_BWD_CONT_BPC": "2", "BM2_BWD_EXPORT_AGE": "100"},
     {"BM2_P3_BPC": "1"}, {"BM2_P3_BPC": "2", "BM2_P3_AT": "2"},
-    {"BM2_CHAIN_COOP_FLT": "0"}, {"BM2_CHAIN_COOP_FLT": "1", "BM2_CHAIN_FINE_TIERS": "1"}, {"BM2_CHAIN_CLOCK": "1"}, {"BM2_CHAIN_HEAVY_WPE": "2"}, {"BM2_CHAIN_HEAVY_WPE": "4", "BM2_CHAIN_COOP_FLT": "0"}, {"BM2_BWD_HEAVY_BPC": "1"},
-    {"BM2_CHAIN_SERIAL_OWN": "0"}, {"BM2_CHAIN_SERIAL_LNODES": "3", "BM2_CHAIN_ISL_WPE": "3"}, {"BM2_CHAIN_SERIAL_LNODES": "400", "BM2_CHAIN_COOP_FLT": "1"}, {"BM2_SEEDSW_REG": "0"},
+    {"BM2_CHAIN_COOP_FLT": "0"}, {"BM2_CHAIN_COOP_FLT": "1"}, {"BM2_CHAIN_CLOCK": "1"}, {"BM2_CHAIN_HEAVY_WPE": "2"}, {"BM2_CHAIN_HEAVY_WPE": "4", "BM2_CHAIN_COOP_FLT": "0"},
+    {"BM2_CHAIN_SERIAL_LNODES": "3", "BM2_CHAIN_ISL_WPE": "3"}, {"BM2_CHAIN_SERIAL_LNODES": "400", "BM2_CHAIN_COOP_FLT": "1"},
 ]
 
 
@@ -328,7 +329,7 @@ def test_long_reads_fresh_vs_oracle(gpu_ctx_factory, tmp_path):
     synth.write_fasta(fa, names, ctg)
     synth.write_alt(fa + ".alt", alts)
     if not build_index(fa):
-        pytest.skip("oracle/_ref reference binary not present")
+        helpers.no_checker("oracle/_ref reference binary not present")
     reads = synth.make_reads_long(42, ctg, 60, mean_len=3000, max_len=9000)
     enc, off, ln = refio.pack_reads(reads)
     ix = oracle.Index(fa)
@@ -350,14 +351,14 @@ def test_long_reads_at_scale_against_the_reference(gpu_ctx_factory, tmp_path):
     from helpers import ref_binary
     refdump = ref_binary("refdump")
     if refdump is None:
-        pytest.skip("oracle/_ref not built")
+        helpers.no_checker("oracle/_ref not built")
     names, ctg, alts = synth.make_genome(45, [1800000, 900000, 300000], alt_contigs=1, alt_len=20000, n_repeat_families=30, repeat_len=(300, 5000),
                                          copies=(5, 60), divergence=(0.01, 0.12))
     fa = str(tmp_path / "g.fa")
     synth.write_fasta(fa, names, ctg)
     synth.write_alt(fa + ".alt", alts)
     if not build_index(fa):
-        pytest.skip("oracle/_ref reference binary not present")
+        helpers.no_checker("oracle/_ref reference binary not present")
     reads = synth.make_reads_long(46, ctg, 200, mean_len=10000, max_len=30000)
     assert max(len(r) for r in reads) >= 25000 and np.mean([len(r) for r in reads]) > 8000
     enc, off, ln = refio.pack_reads(reads)
@@ -375,7 +376,7 @@ def test_long_reads_at_scale_against_the_reference(gpu_ctx_factory, tmp_path):
     assert st["n_sa"] / len(reads) > 1000          # the reads are seed-rich enough for the long-read kernels
 
 
-@pytest.mark.parametrize("env", [{}, {"BM2_CHAIN_SERIAL_OWN": "0"}, {"BM2_CHAIN_SERIAL_LNODES": "2"}, {"BM2_CHAIN_COOP_FLT": "1", "BM2_CHAIN_ISL_WPE": "3"}, {"BM2_CHAIN_SERIAL_BESIDE": "0", "BM2_CHAIN_SERIAL_HYB": "0"}],
+@pytest.mark.parametrize("env", [{}, {"BM2_CHAIN_SERIAL_LNODES": "2"}, {"BM2_CHAIN_COOP_FLT": "1", "BM2_CHAIN_ISL_WPE": "3"}, {"BM2_CHAIN_SERIAL_BESIDE": "0", "BM2_CHAIN_SERIAL_HYB": "0"}],
                          ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()) or "default")
 def test_long_reads_chained_by_islands(gpu_ctx_factory, tmp_path, monkeypatch, env):
     # mem_chain_seeds of seed-rich reads cut into islands of reference buckets (k_chain_islands, chain.hip): a repeat-rich genome, so that a read
@@ -392,7 +393,7 @@ def test_long_reads_chained_by_islands(gpu_ctx_factory, tmp_path, monkeypatch, e
     synth.write_fasta(fa, names, ctg)
     synth.write_alt(fa + ".alt", alts)
     if not build_index(fa):
-        pytest.skip("oracle/_ref reference binary not present")
+        helpers.no_checker("oracle/_ref reference binary not present")
     reads = synth.make_reads_long(44, ctg, 40, mean_len=5000, max_len=20000)
     enc, off, ln = refio.pack_reads(reads)
     ix = oracle.Index(fa)

@@ -9,6 +9,7 @@ import pytest
 import bm2
 from helpers import ONT2D, oracle_finish_regs, ref_binary
 from tools import oracle, refio, synth
+import helpers  # noqa: E402
 
 
 def _prg_to_regs(prg, n_reads):
@@ -48,7 +49,7 @@ def _diff(a, b):
 
 def _case(tmp_path, seed, n_reads, L=150, **genome_kw):
     if ref_binary() is None:
-        pytest.skip("oracle/_ref reference binary not present (build it with `make -C oracle ref`)")
+        helpers.no_checker("oracle/_ref reference binary not present (build it with `make -C oracle ref`)")
     kw = dict(alt_contigs=1, alt_len=4000, n_repeat_families=8, repeat_len=(200, 2500), copies=(3, 30), divergence=(0.0, 0.06))
     kw.update(genome_kw)
     names, ctg, alts = synth.make_genome(seed, [250000, 120000, 40000], **kw)
@@ -99,7 +100,7 @@ def test_sam_se_options(tmp_path):
 
 def test_sam_se_long_reads_ont2d(tmp_path):
     if ref_binary() is None:
-        pytest.skip("oracle/_ref reference binary not present")
+        helpers.no_checker("oracle/_ref reference binary not present")
     names, ctg, alts = synth.make_genome(47, [180000, 90000], alt_contigs=0, n_repeat_families=3, repeat_len=(300, 2000), copies=(3, 8),
                                          divergence=(0.0, 0.05))
     fa = str(tmp_path / "g.fa")
@@ -117,7 +118,7 @@ def test_sam_se_long_reads_ont2d(tmp_path):
 # ---- paired-end ------------------------------------------------------------------------------------------------------
 def _pe_case(tmp_path, seed, n_pairs, L=150, **rkw):
     if ref_binary() is None:
-        pytest.skip("oracle/_ref reference binary not present (build it with `make -C oracle ref`)")
+        helpers.no_checker("oracle/_ref reference binary not present (build it with `make -C oracle ref`)")
     names, ctg, alts = synth.make_genome(seed, [300000, 150000, 60000], alt_contigs=1, alt_len=4000, n_repeat_families=8,
                                          repeat_len=(200, 2500), copies=(3, 30), divergence=(0.0, 0.06))
     fa = str(tmp_path / "g.fa")
@@ -317,7 +318,7 @@ def test_sam_pe_given_insert_size_model(tmp_path):
 def test_sam_se_reference_header_tags(tmp_path):
     # -V (XR:Z: = the contig's FASTA comment, tabs turned into spaces), -R (RG:Z:), -h (XA limits)
     if ref_binary() is None:
-        pytest.skip("oracle/_ref reference binary not present")
+        helpers.no_checker("oracle/_ref reference binary not present")
     names, ctg, alts = synth.make_genome(91, [200000, 90000], alt_contigs=1, alt_len=4000, n_repeat_families=5, repeat_len=(200, 2000),
                                          copies=(3, 20), divergence=(0.0, 0.05))
     fa = str(tmp_path / "g.fa")

@@ -7,6 +7,7 @@ import pytest
 
 import bm2
 from test_ksw_align2 import KSW_XBYTE, KSW_XSTART, KSW_XSUBO, _pairs
+import helpers  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -104,7 +105,7 @@ def test_device_gen_cigar_equals_host(gpu_ctx_factory, tmp_path, kw):
     from test_gen_cigar import make_tasks
     from tools import synth
     if ref_binary() is None:
-        pytest.skip("oracle/_ref reference binary not present (it builds the index)")
+        helpers.no_checker("oracle/_ref reference binary not present (it builds the index)")
     names, ctg, alts = synth.make_genome(17, [120000, 50000], alt_contigs=0, n_repeat_families=3, repeat_len=(200, 1500), copies=(3, 10),
                                          divergence=(0.0, 0.05), n_gaps=2, gap_len=(30, 200))
     fa = str(tmp_path / "g.fa")
@@ -193,7 +194,7 @@ def test_device_ksw_align2_equals_the_reference(gpu_ctx_factory, tmp_path, args,
     from helpers import ref_binary
     dump = ref_binary("refdump")
     if dump is None:
-        pytest.skip("oracle/_ref not built (make -C oracle ref)")
+        helpers.no_checker("oracle/_ref not built (make -C oracle ref)")
     opt = bm2.default_opt(**kw)
     pairs = _pairs(31 + len(args), 2500)
     xtra = [KSW_XSUBO | KSW_XSTART | (19 * opt.a) | (KSW_XBYTE if len(q) * opt.a < 250 else 0) for q, t in pairs]
@@ -215,7 +216,7 @@ def test_device_gen_cigar_equals_the_reference(gpu_ctx_factory, tmp_path):
     from tools import synth
     exe, dump = ref_binary(), ref_binary("refdump")
     if exe is None or dump is None:
-        pytest.skip("oracle/_ref not built (make -C oracle ref)")
+        helpers.no_checker("oracle/_ref not built (make -C oracle ref)")
     names, ctg, alts = synth.make_genome(19, [150000, 60000], alt_contigs=0, n_repeat_families=3, repeat_len=(200, 1500), copies=(3, 10),
                                          divergence=(0.0, 0.05), n_gaps=2, gap_len=(30, 200))
     fa = str(tmp_path / "g.fa")

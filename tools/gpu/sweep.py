@@ -23,7 +23,6 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 GRID = [   # (name, candidates): a candidate is a dict of knobs set together; the first one ({} = the library's defaults) is the incumbent
     ("seeding: k_bwd hands old tasks over (k_bwd_cont: sixteen lanes per task)", [{}, {"BM2_BWD_EXPORT_AGE": 0}, {"BM2_BWD_EXPORT_AGE": 192}, {"BM2_BWD_EXPORT_AGE": 160}]),
     ("seeding: workgroups per CU of k_bwd_cont", [{}, {"BM2_BWD_CONT_BPC": 4}, {"BM2_BWD_CONT_BPC": 8}]),
-    ("seeding: workgroups per CU of k_bwd_heavy beside k_bwd", [{}, {"BM2_BWD_HEAVY_BPC": 1}, {"BM2_BWD_HEAVY_BPC": 2}]),
     ("seeding: the long lists' kernel after k_bwd", [{}, {"BM2_BWD_HEAVY_AFTER": 1}]),
     ("chain clock", [{}, {"BM2_CHAIN_CLOCK": 1}]),
     ("chain staging", [{}, {"BM2_CHAIN_STAGE": 1}]),
@@ -37,7 +36,6 @@ GRID = [   # (name, candidates): a candidate is a dict of knobs set together; th
     ("extension launches on distinct hardware queues", [{}, {"BM2_EXT_QUEUE_MAP": 0}]),
     ("extension scores by byte permute", [{}, {"BM2_EXT_PERM_SCORES": 0}]),
     ("extension wave classes", [{}, {"BM2_EXT_WAVE_QMIN": 129}, {"BM2_EXT_WAVE_QMIN": 145}, {"BM2_EXT_WAVE_QMIN": 161}, {"BM2_EXT_WAVE_QMIN": 97}]),
-    ("chain tiers", [{}, {"BM2_CHAIN_FINE_TIERS": 1}]),
     ("chain: mem_chain_flt's kept-chain walk by the whole wavefront", [{}, {"BM2_CHAIN_COOP_FLT": 0}]),
     ("chain: wavefronts per SIMD the heavy reads' kernel is allocated for", [{}, {"BM2_CHAIN_HEAVY_WPE": 2}, {"BM2_CHAIN_HEAVY_WPE": 4}]),
     ("extension rounds", [{}, {"BM2_EXT_ROUNDS": 2}, {"BM2_EXT_ROUNDS": 1}, {"BM2_EXT_PEND_DIV": 6}, {"BM2_EXT_PEND_DIV": 24}]),
@@ -107,7 +105,7 @@ def main():
         regs, reg_off = ctx.batch_download()
         crc = zlib.crc32(reg_off.tobytes(), zlib.crc32(regs.tobytes()))
         sc = ctx.batch_fetch("seed_counters", np.uint64)
-        if len(sc) >= 27:                                        # tasks k_bwd handed over in pass 1 / 2 (drawn in sixteens) and the rows their continuations walked
+        if len(sc) >= 27:                                        # tasks k_bwd handed over in pass 1 / 2 (exact counts) and the rows their continuations walked
             kms["handed_over"] = [int(sc[21]), int(sc[22]), int(sc[25]), int(sc[26])]
         return ms, kms, crc
 
