@@ -62,6 +62,18 @@ static __device__ __forceinline__ void apply_side(int side, DevReg &a, const Dev
     a.w = imax(a.w, w_used);
 }
 
+// seedcov of a finished reg: the bases of its chain's seeds that lie inside it, bwamem.cpp:2507-2516 (the H0_ guard there is always true for real
+// coordinates).  Computed where the reg becomes final -- by the lane / wavefront that extended its seed, or where it is set up when there is nothing to
+// extend -- since round 6 (k_seedcov / k_seedcov_round were launches of their own behind every phase: 0.35 ms and three launch gaps per chunk).
+static __device__ __forceinline__ int seed_cover(const DevChain &c, const DevSeed *__restrict__ seeds, const DevReg &a) {
+    int cov = 0;
+    for (int i = 0; i < c.n; i++) {
+        const DevSeed t = seeds[c.seed_off + i];
+        if (t.qbeg >= a.qb && t.qbeg + t.len <= a.qe && t.rbeg >= a.rb && t.rbeg + t.len <= a.re) cov += t.len;
+    }
+    return cov;
+}
+
 // Sort key of a seed: which kernel / LDS class extends it and where it sits among that class's seeds.
 static __device__ __forceinline__ uint32_t seed_bin(const ExtParams &xp, const DevSeed &s, const DevChain &c, int l_query) {
     const bool hl = s.qbeg != 0, hr = s.qbeg + s.len != l_query;
@@ -99,9 +111,10 @@ k_reg_init(ExtParams xp, int64_t n_slots, const int32_t *__restrict__ len, const
         if (s.qbeg) { a.score = a.truesc = -1; a.qb = s.qbeg; }
         else { a.score = a.truesc = s.len * xp.a; a.qb = 0; }
         a.qe = (s.qbeg + s.len != l_query) ? s.qbeg + s.len : l_query;
-        regs[g] = a;
         b = seed_bin(xp, s, c, l_query);
         if (b != EBIN_NONE) atomicAdd(&hist[b], 1);
+        else a.seedcov = seed_cover(c, seeds, a);                // nothing to extend: the reg is final
+        regs[g] = a;
     }
     ebin[g] = b;
 }
@@ -498,16 +511,201 @@ static __device__ void lane_dp8g(bool run, int qlen, int tlen, int w, int h0, Re
     if (run) { out.score = maxv; out.qle = max_j + 1; out.tle = max_i + 1; out.gtle = max_ie + 1; out.gscore = gscore; out.max_off = max_off; }
 }
 
+// The same rows once more, IN REGISTERS (round 6): the classes of 80..128-base queries are each phase's longest launches -- a tile of 64 seeds is a
+// dependent chain of ~10^5 instructions, and with 16-25 KB of LDS rows per wavefront only 6-10 wavefronts fit a CU (1.5-2.5 per SIMD), each waiting for
+// its own LDS round trips.  Here a lane's row lives in 2 NG + 2 registers (two columns of {H, E} bytes per half word, as in LDS) and its query in NG + 1
+// (one base per byte: the selector of the score permute): no LDS at all, so the register file alone bounds the wavefronts per SIMD (3 at 128 columns,
+// 4 at 80) and a cell is its ~22 VALU instructions with nothing to wait for.  Registers have no dynamic index: the column loop is UNROLLED over the
+// class's groups, each group behind a scalar test of the wavefront's band (groups outside [g0, g1) cost two scalar instructions), and the closing store
+// of a row -- eh[end] = {h1, 0}, bandedSWA.cpp:201, a per-lane index -- is folded into the walk: the column after a lane's last cell takes it
+// (the walk covers [min(beg, end), end] of every live lane).  Same recurrence, same masks, same order of the cells as lane_dp8g: bit-exact by construction,
+// checked on the host emulator against the oracle before it met a GPU (tests/test_device_sources_on_host.py, tests/test_bsw_gpu.py).
+struct TStream {                     // the target bases of one lane: 28 rows per 64-bit load from the 2-bit reference, 4 per 32-bit load from bytes (lane_dp8g's scheme)
+    static constexpr int TW = 28;
+    typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
+    RefPtr tp; int ts, tlen; bool run, pk;
+    int psh, pstep, pr; const uint8_t *pbyte; uint64_t pw_cur, pw_next; uint32_t tw_cur, tw_next;
+    __device__ __forceinline__ uint32_t bases4(int i0) const {   // byte k = base of row i0 + k (4 beyond the target's end)
+        uint32_t wv = 0x04040404u;
+        if (run && i0 < tlen) {
+            if (i0 + 3 < tlen) wv = tp.load4(i0, ts);
+            else {
+                wv = 0;
+                for (int k = 0; k < 4; k++) wv |= (uint32_t)(i0 + k < tlen ? tp[(int64_t)(i0 + k) * ts] : 4) << (8 * k);
+            }
+        }
+        return wv;
+    }
+    __device__ __forceinline__ void init(bool run_, RefPtr tp_, int ts_, int tlen_) {
+        run = run_; tp = tp_; ts = ts_; tlen = tlen_; pk = tp.pk != 0;
+        const int64_t pa0 = ts > 0 ? tp.at : tp.at - (TW - 1);
+        psh = (int)(pa0 & 3) << 1; pstep = ts > 0 ? TW / 4 : -(TW / 4);
+        pbyte = tp.p + (pa0 >> 2);
+        pw_cur = pw_next = 0; pr = 0; tw_cur = tw_next = 0;
+        if (pk && run && tlen > 0) {
+            pw_cur = *(const u64_unaligned *)pbyte;
+            if (TW < tlen) pw_next = *(const u64_unaligned *)(pbyte + pstep);
+        }
+        if (!pk) { tw_cur = bases4(0); tw_next = bases4(4); }
+    }
+    __device__ __forceinline__ int next(int i) {                 // the base of row i (rows are asked for in order)
+        int tb;
+        if (pk) {
+            tb = (int)(pw_cur >> (psh + 2 * (ts > 0 ? pr : TW - 1 - pr))) & 3;
+            if (++pr == TW) {
+                pr = 0; pw_cur = pw_next;
+                if (run && i + 1 + TW < tlen) pw_next = *(const u64_unaligned *)(pbyte + (int64_t)((i + 1) / TW + 1) * pstep);
+            }
+        } else {
+            tb = (int)((tw_cur >> (8 * (i & 3))) & 0xffu);
+            if ((i & 3) == 3) { tw_cur = tw_next; tw_next = bases4(i + 5); }
+        }
+        return tb;
+    }
+};
+
+// one group of four columns on registers: the cells inside the lane's band, and -- at column `end` -- the row's closing store
+static __device__ __forceinline__ void dp8_group_reg(int j0, uint32_t &w0, uint32_t &w1, uint32_t q, bool alive, int lo, int beg, int end, uint32_t t_lo, uint32_t t_hi,
+                                                     int e_del, int e_ins, int oe_del, int oe_ins, Dp8Row &r) {
+    if (alive && j0 + 3 >= lo && j0 <= end) {
+        const uint32_t sc4 = __builtin_amdgcn_perm(t_hi, t_lo, q);
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int j = j0 + u;
+            uint32_t &wd = u < 2 ? w0 : w1;
+            const int sh = 16 * (u & 1);
+            if (j >= beg && j < end) {
+                const int e = (int)((wd >> (sh + 8)) & 0xffu);
+                int M = (int)((wd >> sh) & 0xffu);
+                const int sc = (int)(int8_t)(sc4 >> (8 * u));
+                M = M ? M + sc : 0;
+                int h = M > e ? M : e;
+                h = h > r.f ? h : r.f;
+                const unsigned kj = (unsigned)h << 8 | (unsigned)j;
+                r.key = r.key > kj ? r.key : kj;
+                const int en = imax(isub0(e, e_del), M - oe_del);
+                r.f = imax(isub0(r.f, e_ins), M - oe_ins);
+                const uint32_t nw = (uint32_t)r.h1 | ((uint32_t)en << 8);
+                wd = (wd & ~(0xffffu << sh)) | nw << sh;
+                const int jj = nw ? j : -1;
+                r.lnz = r.lnz > jj ? r.lnz : jj;
+                r.fnz_u = r.fnz_u < (unsigned)jj ? r.fnz_u : (unsigned)jj;
+                r.h1 = h;
+            } else if (j == end) {                                  // eh[end] = {h1, 0}: every cell of the lane's band lies before this column
+                wd = (wd & ~(0xffffu << sh)) | (uint32_t)r.h1 << sh;
+                if (r.h1) r.lnz = j;
+            }
+        }
+    }
+}
+
+template <int NG>
+static __device__ void lane_dp8r(bool run, int qlen, int tlen, int w, int h0, RefPtr tp, int ts, const SwParams &P,
+                                 const uint32_t (&Q)[NG + 1], LaneOut &out, long long &cells, long long &iters) {
+    const int o_del = P.o_del, e_del = P.e_del, o_ins = P.o_ins, e_ins = P.e_ins, oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
+    const int sc_match = P.mat[0], sc_mis = P.mat[1], sc_amb = P.mat[4];
+    const uint32_t rep_mis = rep4(sc_mis), rep_amb = rep4(sc_amb);
+    const int e1 = h0 > oe_ins ? h0 - oe_ins : 0;                // first row, bandedSWA.cpp:143-145
+    const int cls = pair_class(tlen, qlen, h0, P.max_sc);
+    uint32_t W[2 * NG + 2];
+#pragma unroll
+    for (int k = 0; k < 2 * NG + 2; k++) {                       // (columns beyond a lane's query are never read)
+        const int jp = 2 * k;
+        const uint32_t v0 = (uint32_t)(jp == 0 ? h0 : imax(e1 - (jp - 1) * e_ins, 0));
+        const uint32_t v1 = (uint32_t)imax(e1 - jp * e_ins, 0);
+        W[k] = v0 | v1 << 16;
+    }
+    int beg = 0, end = qlen, maxv = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0;
+    bool alive = run && tlen > 0;
+    const int maxt = __builtin_amdgcn_readlane(wave_scan_max(alive ? tlen : 0, 0), 63);
+    TStream T; T.init(run, tp, ts, tlen);
+    for (int i = 0; i < maxt; ++i) {
+        if (!__ballot(alive)) break;
+        const int tb = T.next(i);
+        Dp8Row r; r.h1 = 0; r.f = 0; r.lnz = -1; r.key = 0; r.fnz_u = 0xffffffffu;
+        if (alive) {
+            if (beg < i - w) beg = i - w;
+            if (end > i + w + 1) end = i + w + 1;
+            if (end > qlen) end = qlen;
+            if (beg == 0) { r.h1 = h0 - (o_del + e_del * (i + 1)); if (r.h1 < 0) r.h1 = 0; }
+            cells += imax(end - beg, 0);
+        }
+        const int lo = beg < end ? beg : end;                    // the walk of a lane: its cells [beg, end) and the closing column `end`
+        const int jlo = (1 << 20) - __builtin_amdgcn_readlane(wave_scan_max(alive ? (1 << 20) - lo : 0, 0), 63);
+        const int jhi = __builtin_amdgcn_readlane(wave_scan_max(alive ? end + 1 : 0, 0), 63);
+        const int g0 = jlo >> 2, g1 = (jhi + 3) >> 2;                // groups [g0, g1)
+        iters += g1 > g0 ? 2 * (g1 - g0) : 0;
+        const uint32_t t_lo = tb > 3 ? rep_amb : rep_mis ^ ((uint32_t)((sc_mis ^ sc_match) & 0xff) << (8 * tb)), t_hi = rep_amb;
+#pragma unroll
+        for (int g = 0; g <= NG; g++)
+            if (g >= g0 && g < g1)                                   // (wave-uniform: a scalar branch)
+                dp8_group_reg(4 * g, W[2 * g], W[2 * g + 1], Q[g], alive, lo, beg, end, t_lo, t_hi, e_del, e_ins, oe_del, oe_ins, r);
+        const int m = (int)(r.key >> 8), mj = (int)(r.key & 255u), fnz = (int)r.fnz_u, h1 = r.h1, lnz = r.lnz;
+        if (alive) {
+            const int jfin = beg < end ? end : beg;
+            if (jfin == qlen) { max_ie = gscore > h1 ? max_ie : i; gscore = gscore > h1 ? gscore : h1; }
+            if (m == 0) alive = false;
+            else {
+                const bool new_max = m > maxv;
+                if (new_max) {
+                    maxv = m; max_i = i; max_j = mj;
+                    const int d = mj - i;
+                    max_off = imax(max_off, d < 0 ? -d : d);
+                }
+                if (zdrop_stop(cls, new_max, maxv, m, i - max_i, mj - max_j, e_del, e_ins, P.zdrop)) alive = false;
+                const int nb = fnz >= 0 ? fnz : end;
+                const int jl = imax(lnz, nb - 1);
+                beg = nb;
+                end = jl + 2 < qlen ? jl + 2 : qlen;
+                if (i + 1 >= tlen) alive = false;
+            }
+        }
+    }
+    if (run) { out.score = maxv; out.qle = max_j + 1; out.tle = max_i + 1; out.gtle = max_ie + 1; out.gscore = gscore; out.max_off = max_off; }
+}
+
+// the query of a lane as the selector words of the score permute, four bases per register (a base > 3 is 4); words beyond the query are never read
+template <int NG>
+static __device__ __forceinline__ void load_query_regs(bool has, const uint8_t *q, int qs, int len2, uint32_t (&Q)[NG + 1]) {
+    typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+#pragma unroll
+    for (int g = 0; g <= NG; g++) {
+        const int j0 = 4 * g;
+        uint32_t wq = 0xffffffffu;                                  // (the tail of a query, or a word with an N in it -- rare --, goes the byte way)
+        if (has && j0 + 3 < len2) wq = qs > 0 ? *(const u32_unaligned *)(q + j0) : __builtin_bswap32(*(const u32_unaligned *)(q - j0 - 3));
+        Q[g] = wq;
+    }
+#pragma unroll
+    for (int g = 0; g <= NG; g++) {
+        const int j0 = 4 * g;
+        if (has && j0 < len2 && (Q[g] & 0xfcfcfcfcu) != 0u) {
+            uint32_t wq = 0;
+            for (int u = 0; u < 4 && j0 + u < len2; u++) { const uint32_t qv = q[(int64_t)(j0 + u) * qs]; wq |= (qv > 3 ? 4u : qv) << (8 * u); }
+            Q[g] = wq;
+        }
+    }
+}
+
+// The instruction arbiter's priority of this wavefront (s_setprio takes an immediate).  The launches of a phase share the SIMDs, and the phase is as
+// long as ONE tile of its long classes -- 64 seeds walked row after row, two sides: a dependent chain of ~10^5 instructions -- while the short classes'
+// wavefronts beside it are many and independent: BM2_EXT_PRIO_QMIN lets the long classes issue first (launch policy: no result can change).
+static __device__ __forceinline__ void wave_prio(int p) {
+    if (p == 1) __builtin_amdgcn_s_setprio(1);
+    else if (p == 2) __builtin_amdgcn_s_setprio(2);
+    else if (p >= 3) __builtin_amdgcn_s_setprio(3);
+}
+
 // One seed per lane: left side, then right side (h0 = the score after the left side, bwamem.cpp:2672-2677), each with the two-try
 // band rule.  A wavefront takes tiles of 64 consecutive seeds of its class's sorted list (grid-stride: the host sizes the grid from the
 // previous batch's counts, the kernel reads the real range from the device).
-template <bool P8, bool PF, bool PT = false, bool G4 = false>      // PT: scores by byte permute (lane_dp8); G4: columns in groups of four (lane_dp8g)
+template <bool P8, bool PF, bool PT = false, bool G4 = false, int RG = 0>      // PT: scores by byte permute (lane_dp8); G4: columns in groups of four (lane_dp8g); RG > 0: rows of RG groups in registers (lane_dp8r), no LDS
 __global__ void __launch_bounds__(64)
 k_ext_seeds(DevIndex ix, ExtParams xp, const int32_t *__restrict__ tasks_all, const int64_t *__restrict__ start, int bin_lo, int bin_hi, int qmax,
             const uint8_t *__restrict__ enc, const int64_t *__restrict__ off, const int32_t *__restrict__ len,
             const int64_t *__restrict__ slot_base, const int32_t *__restrict__ reg_seed, const int32_t *__restrict__ reg_chain,
-            const DevChain *__restrict__ chn, const DevSeed *__restrict__ seeds, DevReg *regs, unsigned long long *counters, int rev) {
+            const DevChain *__restrict__ chn, const DevSeed *__restrict__ seeds, DevReg *regs, unsigned long long *counters, int rev, int prio) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_l[];
+    wave_prio(prio);
     uint32_t *EH = lds_l;                                       // [(qmax+1)][64]           (P8: [(qmax+2)/2][64])
     uint8_t *QL = (uint8_t *)(lds_l + (size_t)(qmax + 1) * 64); // [qmax][64] bytes
     uint32_t *QL8 = lds_l + (G4 ? (size_t)(2 * ((qmax + 3) / 4) + 2) : (size_t)((qmax + 2) / 2)) * 64;      // P8: [(qmax+7)/8][64] dwords, 8 bases of 4 bits each (PT: [(qmax+3)/4 + 1][64], one per byte)
@@ -548,7 +746,9 @@ k_ext_seeds(DevIndex ix, ExtParams xp, const int32_t *__restrict__ tasks_all, co
             }
             // stage the query bases
             const int maxq = __builtin_amdgcn_readlane(wave_scan_max(has ? tg.len2 : 0, 0), 63);
-            if (PT) {                                               // one base per byte, 4 to a dword: the selector words of the byte permute
+            uint32_t QR[RG + 1];
+            if constexpr (RG > 0) load_query_regs<RG>(has, tg.q, tg.qs, tg.len2, QR);
+            else if (PT) {                                               // one base per byte, 4 to a dword: the selector words of the byte permute
                 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
                 for (int jb = 0; jb < maxq; jb += 16) {             // four words requested before the first is looked at: one wait per 16 bases
                     uint32_t wq4[4];
@@ -591,7 +791,8 @@ k_ext_seeds(DevIndex ix, ExtParams xp, const int32_t *__restrict__ tasks_all, co
                 if (!__ballot(run)) break;
                 const int w = xp.w << t;
                 const int wc = band_clamp(w, tg.len2, P, cls);
-                if (G4) lane_dp8g(run, tg.len2, tg.len1, wc, h0, tg.t, tg.ts, P, EH, QL8, lane, o, cells, iters);
+                if constexpr (RG > 0) lane_dp8r<RG>(run, tg.len2, tg.len1, wc, h0, tg.t, tg.ts, P, QR, o, cells, iters);
+                else if (G4) lane_dp8g(run, tg.len2, tg.len1, wc, h0, tg.t, tg.ts, P, EH, QL8, lane, o, cells, iters);
                 else if (P8) lane_dp8<PF, PT>(run, tg.len2, tg.len1, wc, h0, tg.t, tg.ts, P, EH, QL8, lane, o, cells, iters);
                 else lane_dp(run, tg.len2, tg.len1, wc, h0, tg.t, tg.ts, P, EH, QL, lane, o, cells, iters);
                 if (run) {
@@ -606,7 +807,7 @@ k_ext_seeds(DevIndex ix, ExtParams xp, const int32_t *__restrict__ tasks_all, co
                 n_done++;
             }
         }
-        if (valid) regs[g] = a;
+        if (valid) { a.seedcov = seed_cover(c, seeds, a); regs[g] = a; }
     }
     // (a wavefront that found no tile -- the first batch of a process sizes its grids without the previous batch's statistics: ten times the
     //  wavefronts -- leaves without queueing three atomics on one cache line)
@@ -642,8 +843,9 @@ __global__ void __launch_bounds__(256)
 k_ext_wave(DevIndex ix, ExtParams xp, const int32_t *__restrict__ tasks_all, const int64_t *__restrict__ start, int bin_lo, int bin_hi,
            const uint8_t *__restrict__ enc, const int64_t *__restrict__ off, const int32_t *__restrict__ len,
            const int64_t *__restrict__ slot_base, const int32_t *__restrict__ reg_seed, const int32_t *__restrict__ reg_chain,
-           const DevChain *__restrict__ chn, const DevSeed *__restrict__ seeds, DevReg *regs, int R, unsigned long long *counters, int rev) {
+           const DevChain *__restrict__ chn, const DevSeed *__restrict__ seeds, DevReg *regs, int R, unsigned long long *counters, int rev, int prio) {
     extern __shared__ __attribute__((aligned(16))) int lds[];
+    wave_prio(prio);
     ExtParams *sP = (ExtParams *)lds;
     int *rings = lds + (sizeof(ExtParams) + 3) / 4;
     if (threadIdx.x < sizeof(ExtParams) / 4) ((int *)sP)[threadIdx.x] = ((const int *)&xp)[threadIdx.x];
@@ -673,6 +875,7 @@ k_ext_wave(DevIndex ix, ExtParams xp, const int32_t *__restrict__ tasks_all, con
             apply_side(side, a, s, l_query, o, h0, w_used, side == 0 ? sP->pen_clip5 : sP->pen_clip3);     // (wave-uniform: every lane holds the same reg)
             n_done++;
         }
+        a.seedcov = seed_cover(c, seeds, a);                     // (wave-uniform, like the reg itself)
         if (lane == 0) regs[g] = a;
     }
     if (lane == 0 && (n_done != 0 || cells != 0)) {
@@ -680,23 +883,6 @@ k_ext_wave(DevIndex ix, ExtParams xp, const int32_t *__restrict__ tasks_all, con
         atomicAdd(&counters[1], n_done);
         atomicAdd(&counters[3], (unsigned long long)cells);      // the wavefront kernel's share of the cells
     }
-}
-
-// seedcov over the chain's seeds, bwamem.cpp:2507-2516 (the H0_ guard there is always true for real coordinates)
-__global__ void __launch_bounds__(256)
-k_seedcov(int64_t n_slots, const int64_t *__restrict__ slot_base, const int32_t *__restrict__ reg_seed,
-          const int32_t *__restrict__ reg_chain, const DevChain *__restrict__ chn, const DevSeed *__restrict__ seeds, DevReg *regs, const int32_t *__restrict__ cursor) {
-    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= n_slots || reg_seed[g] < 0) return;
-    const DevChain c = chn[slot_base[g] + reg_chain[g]];
-    if (g - slot_base[g] < cursor[c.read]) return;
-    DevReg a = regs[g];
-    int cov = 0;
-    for (int i = 0; i < c.n; i++) {
-        const DevSeed t = seeds[c.seed_off + i];
-        if (t.qbeg >= a.qb && t.qbeg + t.len <= a.qe && t.rbeg >= a.rb && t.rbeg + t.len <= a.re) cov += t.len;
-    }
-    regs[g].seedcov = cov;
 }
 
 // cal_max_gap, bwamem.cpp:66-76
@@ -1018,6 +1204,7 @@ k_advance(ChainParams o, ExtParams xp, int n_reads, const int32_t *__restrict__ 
                 a.qe = (s.qbeg + s.len != l_query) ? s.qbeg + s.len : l_query;
                 b = seed_bin(xp, s, c, l_query);
                 if (b != EBIN_NONE) atomicAdd(&hist[b], 1);
+                else a.seedcov = seed_cover(c, seeds, a);        // nothing to extend: the reg is final
                 av[cur] = a;
                 pick = cur;
                 kept[base + lim] = cur; n_kept[r] = lim + 1;
@@ -1032,23 +1219,6 @@ k_advance(ChainParams o, ExtParams xp, int n_reads, const int32_t *__restrict__ 
     }
     __syncthreads();
     if (threadIdx.x == 0 && sh_pend) atomicAdd(pend, sh_pend);
-}
-
-// seedcov for the regs extended in one lazy round (one read per lane)
-__global__ void __launch_bounds__(256)
-k_seedcov_round(int n_reads, const int64_t *__restrict__ read_base, const int32_t *__restrict__ cur_slot,
-                const int32_t *__restrict__ reg_chain, const DevChain *__restrict__ chn, const DevSeed *__restrict__ seeds, DevReg *regs) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_reads || cur_slot[r] < 0) return;
-    const int64_t base = read_base[r], g = base + cur_slot[r];
-    DevReg a = regs[g];
-    const DevChain c = chn[base + reg_chain[g]];
-    int cov = 0;
-    for (int i = 0; i < c.n; i++) {
-        const DevSeed t = seeds[c.seed_off + i];
-        if (t.qbeg >= a.qb && t.qbeg + t.len <= a.qe && t.rbeg >= a.rb && t.rbeg + t.len <= a.re) cov += t.len;
-    }
-    regs[g].seedcov = cov;
 }
 
 // compact the surviving regs into read order
@@ -1097,6 +1267,8 @@ struct ExtLaunch {
     // of cells one after the other (milliseconds) and a phase lasts as long as its slowest wavefront, so the classes from wave_qmin up can go
     // one seed per WAVEFRONT (k_ext_wave) beside the lane kernels.
     int wave_qmin, prefetch, rev, perm_scores, qmap, group4;
+    int prio_qmin, prio, prio_wave;          // s_setprio of the long classes' wavefronts (wave_prio)
+    int reg_qmin;                            // classes of queries up to at least this many bases keep their rows in registers (0: none)
     // the sorted seed list of the phase and where it lives
     const int32_t *tasks; const int64_t *start;
 };
@@ -1154,11 +1326,23 @@ static int run_phase(const ExtLaunch &L, const uint32_t *hint, int64_t ub) {
                     lds_k = (size_t)(2 * ((hi + 3) / 4) + 2) * 64 * 4 + (size_t)((hi + 3) / 4 + 1) * 64 * 4;
                 }
             }
+            if (L.pack8 && L.perm_scores && L.reg_qmin > 0 && hi >= L.reg_qmin && hi >= 48 && hi <= 128) {       // rows in registers (lane_dp8r): no LDS
+                lds_k = 0;
+                switch (hi) {
+                    case 48: kern = k_ext_seeds<true, true, true, true, 12>; break;
+                    case 64: kern = k_ext_seeds<true, true, true, true, 16>; break;
+                    case 80: kern = k_ext_seeds<true, true, true, true, 20>; break;
+                    case 96: kern = k_ext_seeds<true, true, true, true, 24>; break;
+                    case 112: kern = k_ext_seeds<true, true, true, true, 28>; break;
+                    default: kern = k_ext_seeds<true, true, true, true, 32>; break;
+                }
+            }
             hipLaunchKernelGGL(kern, dim3(grid_for(k, k + 1, 64)), dim3(64), lds_k, sk, c->ix, L.xp, L.tasks, L.start, k * EB_2D, (k + 1) * EB_2D, hi,
-                               L.enc, L.off, L.len, L.slot_base, L.reg_seed, L.reg_chain, L.chn, L.seeds, L.regs, L.counters, L.rev);
+                               L.enc, L.off, L.len, L.slot_base, L.reg_seed, L.reg_chain, L.chn, L.seeds, L.regs, L.counters, L.rev,
+                               L.prio_qmin > 0 && hi >= L.prio_qmin ? L.prio : 0);
         } else {
             hipLaunchKernelGGL(k_ext_wave, dim3(grid_for(k_wave, N_CLS + 1, 4)), dim3(256), L.lds_w, sk, c->ix, L.xp, L.tasks, L.start, k_wave * EB_2D,
-                               (int)N_EBINS, L.enc, L.off, L.len, L.slot_base, L.reg_seed, L.reg_chain, L.chn, L.seeds, L.regs, L.R, L.counters, L.rev);
+                               (int)N_EBINS, L.enc, L.off, L.len, L.slot_base, L.reg_seed, L.reg_chain, L.chn, L.seeds, L.regs, L.R, L.counters, L.rev, L.prio_wave);
         }
         (void)hipEventRecord(c->ev_join[k], sk);
         joined[n_joined++] = k;
@@ -1208,6 +1392,8 @@ int bm2_launch_extend(bm2_ctx *c, const bm2_opt &opt, const ChainParams &cp, int
     L.qmap = bm2_knob("BM2_EXT_QUEUE_MAP", 1);
     L.perm_scores = bm2_knob("BM2_EXT_PERM_SCORES", 1);
     L.group4 = bm2_knob("BM2_EXT_GROUP4", 1);
+    L.reg_qmin = bm2_knob("BM2_EXT_REG_QMIN", 0);
+    L.prio_qmin = bm2_knob("BM2_EXT_PRIO_QMIN", 0); L.prio = bm2_knob("BM2_EXT_PRIO", 2); L.prio_wave = bm2_knob("BM2_EXT_WAVE_PRIO", 0);
     for (int k : { 0, 1, 4 }) if (opt.mat[k] < -128 || opt.mat[k] > 127) L.perm_scores = 0;     // (the score table holds signed bytes)
     const int lazy_max = bm2_knob("BM2_EXT_ROUNDS", LAZY_ROUNDS), pend_div = bm2_knob("BM2_EXT_PEND_DIV", 12);
     L.R = ring_size2(opt.w << (MAX_BAND_TRY - 1));
@@ -1254,18 +1440,16 @@ int bm2_launch_extend(bm2_ctx *c, const bm2_opt &opt, const ChainParams &cp, int
         hipLaunchKernelGGL(k_phase_stats, dim3(1), dim3(64), 0, s, start, by_read ? pend + phase : (const uint32_t *)nullptr, stat + (size_t)phase * BM2_EXT_STATW);
         return run_phase(L, have_hint ? hint[phase] : nullptr, n_sort);
     };
-    const unsigned nbr = (unsigned)((n_reads + 127) / 128), nbr2 = (unsigned)((n_reads + 255) / 256);
+    const unsigned nbr = (unsigned)((n_reads + 127) / 128);
     for (int round = 0; round < n_lazy; round++) {
         hipLaunchKernelGGL(k_advance, dim3(nbr), dim3(128), 0, s, cp, xp, n_reads, len, read_base, n_reg, reg_chain, chn, seeds, srt_all,
                            regs, cursor, cur_slot, ebin, hist, pend + round, kept, n_kept);
         if ((rc = sort_and_run(round, n_reads, true))) return rc;
-        hipLaunchKernelGGL(k_seedcov_round, dim3(nbr2), dim3(256), 0, s, n_reads, read_base, cur_slot, reg_chain, chn, seeds, regs);
     }
     {       // eager remainder: every seed at or beyond its read's cursor
         const unsigned nb = (unsigned)((n_slots + 255) / 256);
         hipLaunchKernelGGL(k_reg_init, dim3(nb), dim3(256), 0, s, xp, n_slots, len, slot_base, reg_seed, reg_chain, chn, seeds, regs, ebin, hist, cursor);
         if ((rc = sort_and_run(EXT_EAGER_PHASE, n_slots, false))) return rc;
-        hipLaunchKernelGGL(k_seedcov, dim3(nb), dim3(256), 0, s, n_slots, slot_base, reg_seed, reg_chain, chn, seeds, regs, cursor);
     }
     if (c->ext_stat) {      // (arrives before the caller's end-of-batch synchronisation; read by the next batch)
         // only the rows this stage wrote -- the lazy rounds and the eager phase: the row between them belongs to the S1 batches (BSW_STAT_ROW),
@@ -1295,6 +1479,7 @@ k_bsw_bin(const bm2_seqpair_t *__restrict__ pairs, int n, int a_match, int lanes
     atomicAdd(&hist[b], 1);
 }
 
+template <int RG>                                            // RG > 0: the rows of RG groups in registers (lane_dp8r), no LDS
 __global__ void __launch_bounds__(64)
 k_bsw_lanes(bm2_seqpair_t *pairs, const uint8_t *__restrict__ ref, const uint8_t *__restrict__ qer, const int32_t *__restrict__ tasks_all,
             const int64_t *__restrict__ start, int bin_lo, int bin_hi, int qmax, int w, SwParams P, unsigned long long *cells_out, int rev) {
@@ -1314,6 +1499,9 @@ k_bsw_lanes(bm2_seqpair_t *pairs, const uint8_t *__restrict__ ref, const uint8_t
         const uint8_t *q = qer, *t = ref;
         if (valid) { id = tasks[idx]; len1 = pairs[id].len1; len2 = pairs[id].len2; h0 = pairs[id].h0; q = qer + pairs[id].idq; t = ref + pairs[id].idr; }
         const int maxq = __builtin_amdgcn_readlane(wave_scan_max(valid ? len2 : 0, 0), 63);
+        uint32_t QR[RG + 1];
+        if constexpr (RG > 0) load_query_regs<RG>(valid, q, 1, len2, QR);
+        else
         for (int j0 = 0; j0 < maxq; j0 += 4) {
             if (valid && j0 < len2) {
                 uint32_t wq = 0;
@@ -1324,7 +1512,8 @@ k_bsw_lanes(bm2_seqpair_t *pairs, const uint8_t *__restrict__ ref, const uint8_t
         const int cls = pair_class(len1, len2, h0, P.max_sc);
         const int wc = band_clamp(w, len2, P, cls);
         LaneOut o; o.score = h0; o.qle = o.tle = o.gtle = 0; o.gscore = -1; o.max_off = 0;
-        lane_dp8g(valid, len2, len1, wc, h0, RefPtr::bytes(t), 1, P, EH, QL8, lane, o, cells, iters);
+        if constexpr (RG > 0) lane_dp8r<RG>(valid, len2, len1, wc, h0, RefPtr::bytes(t), 1, P, QR, o, cells, iters);
+        else lane_dp8g(valid, len2, len1, wc, h0, RefPtr::bytes(t), 1, P, EH, QL8, lane, o, cells, iters);
         if (valid) {
             bm2_seqpair_t *d = &pairs[id];
             d->score = o.score; d->tle = o.tle; d->gtle = o.gtle; d->qle = o.qle; d->gscore = o.gscore; d->max_off = o.max_off;
@@ -1377,7 +1566,14 @@ int bm2_launch_bsw_sorted(bm2_ctx *c, bm2_seqpair_t *d_pairs, const uint8_t *d_r
             const int hi = cls_hi[k];
             const size_t lds = (size_t)(2 * ((hi + 3) / 4) + 2) * 64 * 4 + (size_t)((hi + 3) / 4 + 1) * 64 * 4;
             int64_t g = (cnt + 63) / 64; if (g < 1) g = 1; if (g > (1 << 16)) g = 1 << 16;
-            hipLaunchKernelGGL(k_bsw_lanes, dim3((unsigned)g), dim3(64), lds, sk, d_pairs, d_ref, d_qer, tasks, start, k * EB_2D, (k + 1) * EB_2D, hi, w, P, d_cells, 1);
+            const int reg_qmin = bm2_knob("BM2_EXT_REG_QMIN", 0);
+            auto kb = k_bsw_lanes<0>;
+            size_t lds_k = lds;
+            if (reg_qmin > 0 && hi >= reg_qmin && hi >= 48 && hi <= 128) {
+                lds_k = 0;
+                kb = hi == 48 ? k_bsw_lanes<12> : hi == 64 ? k_bsw_lanes<16> : hi == 80 ? k_bsw_lanes<20> : hi == 96 ? k_bsw_lanes<24> : hi == 112 ? k_bsw_lanes<28> : k_bsw_lanes<32>;
+            }
+            hipLaunchKernelGGL(kb, dim3((unsigned)g), dim3(64), lds_k, sk, d_pairs, d_ref, d_qer, tasks, start, k * EB_2D, (k + 1) * EB_2D, hi, w, P, d_cells, 1);
         } else {
             int64_t g = (cnt + 3) / 4; if (g < 1) g = 1; if (g > (1 << 20)) g = 1 << 20;
             if ((rc = bm2_launch_bsw_list(c, d_pairs, d_ref, d_qer, tasks, start, N_CLS * EB_2D, (int)N_EBINS, (unsigned)g, w, P, d_cells, sk))) return rc;
