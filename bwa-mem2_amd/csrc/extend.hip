@@ -564,65 +564,83 @@ struct TStream {                     // the target bases of one lane: 28 rows pe
     }
 };
 
-// one group of four columns on registers: the cells inside the lane's band, and -- at column `end` -- the row's closing store
-static __device__ __forceinline__ void dp8_group_reg(int j0, uint32_t &w0, uint32_t &w1, uint32_t q, bool alive, int lo, int beg, int end, uint32_t t_lo, uint32_t t_hi,
-                                                     int e_del, int e_ins, int oe_del, int oe_ins, Dp8Row &r) {
+// One group of four columns on registers: the cells inside the lane's band, and -- at column `end` -- the row's closing store.  NO per-column constant may
+// appear in it: a literal cannot be an operand of the three-operand VALU encodings, so the compiler put every column number beyond 64 into a register of
+// its own, hoisted out of the row loop -- 68 registers at 128 columns (the first build: 358 / 328 registers, one wavefront per SIMD).  Hence: the group's
+// first column j0 arrives as a run-time SCALAR (an opaque zero plus 4 g), the band is taken relative to it so that a cell compares with 0..3, the row
+// maximum's column and the non-zero cells are kept per group (key | u, one mask bit per cell) and folded into the row's state once per group.
+struct Dp8RowR { int h1, f; unsigned key; };
+template <int NZW>
+static __device__ __forceinline__ void dp8_group_reg(int g, int j0, uint32_t &w0, uint32_t &w1, uint32_t q, bool alive, int lo, int beg, int end, uint32_t t_lo, uint32_t t_hi,
+                                                     int e_del, int e_ins, int oe_del, int oe_ins, Dp8RowR &r, uint32_t (&NZ)[NZW]) {
     if (alive && j0 + 3 >= lo && j0 <= end) {
         const uint32_t sc4 = __builtin_amdgcn_perm(t_hi, t_lo, q);
+        const int rb = beg - j0, re = end - j0;                     // the lane's band relative to this group
+        unsigned kg = 0, mg = 0;
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            const int j = j0 + u;
             uint32_t &wd = u < 2 ? w0 : w1;
             const int sh = 16 * (u & 1);
-            if (j >= beg && j < end) {
+            if (u >= rb && u < re) {
                 const int e = (int)((wd >> (sh + 8)) & 0xffu);
                 int M = (int)((wd >> sh) & 0xffu);
                 const int sc = (int)(int8_t)(sc4 >> (8 * u));
                 M = M ? M + sc : 0;
                 int h = M > e ? M : e;
                 h = h > r.f ? h : r.f;
-                const unsigned kj = (unsigned)h << 8 | (unsigned)j;
-                r.key = r.key > kj ? r.key : kj;
+                const unsigned kj = (unsigned)h << 8 | (unsigned)u;
+                kg = kg > kj ? kg : kj;
                 const int en = imax(isub0(e, e_del), M - oe_del);
                 r.f = imax(isub0(r.f, e_ins), M - oe_ins);
                 const uint32_t nw = (uint32_t)r.h1 | ((uint32_t)en << 8);
                 wd = (wd & ~(0xffffu << sh)) | nw << sh;
-                const int jj = nw ? j : -1;
-                r.lnz = r.lnz > jj ? r.lnz : jj;
-                r.fnz_u = r.fnz_u < (unsigned)jj ? r.fnz_u : (unsigned)jj;
+                mg |= (nw < 1u ? nw : 1u) << u;                      // a stored cell that is not zero
                 r.h1 = h;
-            } else if (j == end) {                                  // eh[end] = {h1, 0}: every cell of the lane's band lies before this column
+            } else if (u == re) {                                   // eh[end] = {h1, 0}: every cell of the lane's band lies before this column
                 wd = (wd & ~(0xffffu << sh)) | (uint32_t)r.h1 << sh;
-                if (r.h1) r.lnz = j;
+                mg |= ((uint32_t)r.h1 < 1u ? (uint32_t)r.h1 : 1u) << u;
             }
         }
+        // (a group none of whose cells scored leaves j0 in the key's low byte: harmless, the column of a zero maximum is never read)
+        const unsigned kgj = kg + (unsigned)j0;
+        r.key = r.key > kgj ? r.key : kgj;
+        NZ[g >> 3] |= mg << (4 * (g & 7));
     }
 }
 
 template <int NG>
 static __device__ void lane_dp8r(bool run, int qlen, int tlen, int w, int h0, RefPtr tp, int ts, const SwParams &P,
                                  const uint32_t (&Q)[NG + 1], LaneOut &out, long long &cells, long long &iters) {
+    constexpr int NZW = NG / 8 + 1;                              // one bit per column 0 .. 4 NG + 3: the stored cells that are not zero
     const int o_del = P.o_del, e_del = P.e_del, o_ins = P.o_ins, e_ins = P.e_ins, oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
     const int sc_match = P.mat[0], sc_mis = P.mat[1], sc_amb = P.mat[4];
     const uint32_t rep_mis = rep4(sc_mis), rep_amb = rep4(sc_amb);
     const int e1 = h0 > oe_ins ? h0 - oe_ins : 0;                // first row, bandedSWA.cpp:143-145
     const int cls = pair_class(tlen, qlen, h0, P.max_sc);
     uint32_t W[2 * NG + 2];
+    {
+        int v = e1 + e_ins;                                      // column 1 holds e1, column j > 0: max(e1 - (j - 1) e_ins, 0) -- a running value, no per-column constant
 #pragma unroll
-    for (int k = 0; k < 2 * NG + 2; k++) {                       // (columns beyond a lane's query are never read)
-        const int jp = 2 * k;
-        const uint32_t v0 = (uint32_t)(jp == 0 ? h0 : imax(e1 - (jp - 1) * e_ins, 0));
-        const uint32_t v1 = (uint32_t)imax(e1 - jp * e_ins, 0);
-        W[k] = v0 | v1 << 16;
+        for (int k = 0; k < 2 * NG + 2; k++) {                   // (columns beyond a lane's query are never read)
+            uint32_t v0, v1;
+            if (k == 0) v0 = (uint32_t)h0; else { v -= e_ins; v0 = (uint32_t)imax(v, 0); }
+            v -= e_ins; v1 = (uint32_t)imax(v, 0);
+            W[k] = v0 | v1 << 16;
+        }
     }
     int beg = 0, end = qlen, maxv = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0;
     bool alive = run && tlen > 0;
     const int maxt = __builtin_amdgcn_readlane(wave_scan_max(alive ? tlen : 0, 0), 63);
     TStream T; T.init(run, tp, ts, tlen);
+    int zero_s = 0;
+    asm volatile("" : "+s"(zero_s));                             // (a scalar the compiler cannot fold: the groups' first columns are zero_s + 4 g)
     for (int i = 0; i < maxt; ++i) {
         if (!__ballot(alive)) break;
         const int tb = T.next(i);
-        Dp8Row r; r.h1 = 0; r.f = 0; r.lnz = -1; r.key = 0; r.fnz_u = 0xffffffffu;
+        Dp8RowR r; r.h1 = 0; r.f = 0; r.key = 0;
+        uint32_t NZ[NZW];
+#pragma unroll
+        for (int d = 0; d < NZW; d++) NZ[d] = 0;
         if (alive) {
             if (beg < i - w) beg = i - w;
             if (end > i + w + 1) end = i + w + 1;
@@ -639,8 +657,16 @@ static __device__ void lane_dp8r(bool run, int qlen, int tlen, int w, int h0, Re
 #pragma unroll
         for (int g = 0; g <= NG; g++)
             if (g >= g0 && g < g1)                                   // (wave-uniform: a scalar branch)
-                dp8_group_reg(4 * g, W[2 * g], W[2 * g + 1], Q[g], alive, lo, beg, end, t_lo, t_hi, e_del, e_ins, oe_del, oe_ins, r);
-        const int m = (int)(r.key >> 8), mj = (int)(r.key & 255u), fnz = (int)r.fnz_u, h1 = r.h1, lnz = r.lnz;
+                dp8_group_reg<NZW>(g, zero_s + 4 * g, W[2 * g], W[2 * g + 1], Q[g], alive, lo, beg, end, t_lo, t_hi, e_del, e_ins, oe_del, oe_ins, r, NZ);
+        int fnz = -1, lnz = -1;                                      // first / last column whose stored cell is not zero
+#pragma unroll
+        for (int d = 0; d < NZW; d++) {
+            if (NZ[d]) {
+                if (fnz < 0) fnz = 32 * d + __builtin_ctz(NZ[d]);
+                lnz = 32 * d + 31 - __builtin_clz(NZ[d]);
+            }
+        }
+        const int m = (int)(r.key >> 8), mj = (int)(r.key & 255u), h1 = r.h1;
         if (alive) {
             const int jfin = beg < end ? end : beg;
             if (jfin == qlen) { max_ie = gscore > h1 ? max_ie : i; gscore = gscore > h1 ? gscore : h1; }
@@ -698,7 +724,7 @@ static __device__ __forceinline__ void wave_prio(int p) {
 // One seed per lane: left side, then right side (h0 = the score after the left side, bwamem.cpp:2672-2677), each with the two-try
 // band rule.  A wavefront takes tiles of 64 consecutive seeds of its class's sorted list (grid-stride: the host sizes the grid from the
 // previous batch's counts, the kernel reads the real range from the device).
-template <bool P8, bool PF, bool PT = false, bool G4 = false, int RG = 0>      // PT: scores by byte permute (lane_dp8); G4: columns in groups of four (lane_dp8g); RG > 0: rows of RG groups in registers (lane_dp8r), no LDS
+template <bool P8, bool PF, bool PT = false, bool G4 = false>      // PT: scores by byte permute (lane_dp8); G4: columns in groups of four (lane_dp8g)
 __global__ void __launch_bounds__(64)
 k_ext_seeds(DevIndex ix, ExtParams xp, const int32_t *__restrict__ tasks_all, const int64_t *__restrict__ start, int bin_lo, int bin_hi, int qmax,
             const uint8_t *__restrict__ enc, const int64_t *__restrict__ off, const int32_t *__restrict__ len,
@@ -746,9 +772,7 @@ k_ext_seeds(DevIndex ix, ExtParams xp, const int32_t *__restrict__ tasks_all, co
             }
             // stage the query bases
             const int maxq = __builtin_amdgcn_readlane(wave_scan_max(has ? tg.len2 : 0, 0), 63);
-            uint32_t QR[RG + 1];
-            if constexpr (RG > 0) load_query_regs<RG>(has, tg.q, tg.qs, tg.len2, QR);
-            else if (PT) {                                               // one base per byte, 4 to a dword: the selector words of the byte permute
+            if (PT) {                                               // one base per byte, 4 to a dword: the selector words of the byte permute
                 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
                 for (int jb = 0; jb < maxq; jb += 16) {             // four words requested before the first is looked at: one wait per 16 bases
                     uint32_t wq4[4];
@@ -791,8 +815,7 @@ k_ext_seeds(DevIndex ix, ExtParams xp, const int32_t *__restrict__ tasks_all, co
                 if (!__ballot(run)) break;
                 const int w = xp.w << t;
                 const int wc = band_clamp(w, tg.len2, P, cls);
-                if constexpr (RG > 0) lane_dp8r<RG>(run, tg.len2, tg.len1, wc, h0, tg.t, tg.ts, P, QR, o, cells, iters);
-                else if (G4) lane_dp8g(run, tg.len2, tg.len1, wc, h0, tg.t, tg.ts, P, EH, QL8, lane, o, cells, iters);
+                if (G4) lane_dp8g(run, tg.len2, tg.len1, wc, h0, tg.t, tg.ts, P, EH, QL8, lane, o, cells, iters);
                 else if (P8) lane_dp8<PF, PT>(run, tg.len2, tg.len1, wc, h0, tg.t, tg.ts, P, EH, QL8, lane, o, cells, iters);
                 else lane_dp(run, tg.len2, tg.len1, wc, h0, tg.t, tg.ts, P, EH, QL, lane, o, cells, iters);
                 if (run) {
@@ -815,6 +838,94 @@ k_ext_seeds(DevIndex ix, ExtParams xp, const int32_t *__restrict__ tasks_all, co
     atomicAdd(&counters[0], (unsigned long long)cells);
     atomicAdd(&counters[1], n_done);
     if (lane == 0) atomicAdd(&counters[2], (unsigned long long)iters);      // column-pair trips of this wavefront: 128 lane slots each (lane use = cells / that)
+}
+
+// One seed per lane with the rows in REGISTERS (lane_dp8r).  The row and the query of a 128-column class are 99 registers and a wavefront's share of the
+// register file is what bounds the wavefronts per SIMD here, so NOTHING else stays in registers across the DP: the seed, its chain and its reg are read where
+// a side needs them and read again (L1 / L2 hits) when the side is applied -- through an index the compiler cannot see through, or it would keep the first
+// copies alive -- and the reg goes back to memory after every side.  With that state held across the DP (the LDS kernel's shape) the 128-column
+// instantiation took 358 registers, one wavefront per SIMD, and the stage was slower than with LDS rows (profiles/r06b_sweep_ext_prio_regrows.json).
+static __device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+template <int RG>
+__global__ void __launch_bounds__(64)
+k_ext_seeds_reg(DevIndex ix, ExtParams xp, const int32_t *__restrict__ tasks_all, const int64_t *__restrict__ start, int bin_lo, int bin_hi,
+                const uint8_t *__restrict__ enc, const int64_t *__restrict__ off, const int32_t *__restrict__ len,
+                const int64_t *__restrict__ slot_base, const int32_t *__restrict__ reg_seed, const int32_t *__restrict__ reg_chain,
+                const DevChain *__restrict__ chn, const DevSeed *__restrict__ seeds, DevReg *regs, unsigned long long *counters, int rev, int prio) {
+    wave_prio(prio);
+    const int lane = threadIdx.x;
+    const int64_t first = start[bin_lo];
+    const int n_tasks = (int)(start[bin_hi] - first);
+    const int32_t *tasks = tasks_all + first;
+    const int n_tiles = (n_tasks + 63) >> 6;
+    long long cells = 0, iters = 0;
+    unsigned long long n_done = 0;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int idx = (rev ? n_tiles - 1 - tile : tile) * 64 + lane;
+        const bool valid = idx < n_tasks;
+        const int g = valid ? tasks[idx] : 0;
+#pragma nounroll
+        for (int side = 0; side < 2; side++) {
+            bool has = false;
+            TaskGeom tg;
+            tg.len1 = tg.len2 = 0; tg.q = enc; tg.t = ix.ref(0); tg.qs = tg.ts = 1;
+            int h0 = 0, prev = -1;
+            if (valid) {
+                const int ga = opaque(g);
+                const int64_t base = slot_base[ga];
+                const DevChain c = chn[base + reg_chain[ga]];
+                const DevSeed s = seeds[base + reg_seed[ga]];
+                const int l_query = len[c.read];
+                has = side == 0 ? s.qbeg != 0 : s.qbeg + s.len != l_query;
+                if (has) {
+                    tg = task_geom(side, s, c, enc + off[c.read], l_query, ix.ref(0));
+                    if (side == 0) h0 = s.len * xp.a;
+                    else { h0 = regs[ga].score; prev = h0; }
+                }
+            }
+            if (!__ballot(has)) continue;
+            const SwParams &P = side == 0 ? xp.left : xp.right;
+            uint32_t QR[RG + 1];
+            load_query_regs<RG>(has, tg.q, tg.qs, tg.len2, QR);
+            const int cls = pair_class(tg.len1, tg.len2, h0, P.max_sc);
+            LaneOut o; o.score = h0; o.qle = o.tle = o.gtle = 0; o.gscore = -1; o.max_off = 0;
+            bool run = has;
+            int w_used = xp.w;
+#pragma nounroll
+            for (int t = 0; t < MAX_BAND_TRY; t++) {                // two-try band rule, bwamem.cpp:2495-2496
+                if (!__ballot(run)) break;
+                const int w = xp.w << t;
+                const int wc = band_clamp(w, tg.len2, P, cls);
+                lane_dp8r<RG>(run, tg.len2, tg.len1, wc, opaque(h0), tg.t, tg.ts, P, QR, o, cells, iters);      // (opaque: or the first row's 2 RG + 2 words are computed once and KEPT for the second try)
+                if (run) {
+                    w_used = w;
+                    if (o.score == prev || o.max_off < (w >> 1) + (w >> 2) || t + 1 == MAX_BAND_TRY) run = false;
+                    else prev = o.score;
+                }
+            }
+            if (has) {
+                const int gb = opaque(g);
+                const int64_t base = slot_base[gb];
+                const DevChain c = chn[base + reg_chain[gb]];
+                const DevSeed s = seeds[base + reg_seed[gb]];
+                DevReg a = regs[gb];
+                SwOut so; so.score = o.score; so.qle = o.qle; so.tle = o.tle; so.gtle = o.gtle; so.gscore = o.gscore; so.max_off = o.max_off;
+                apply_side(side, a, s, len[c.read], so, h0, w_used, side == 0 ? xp.pen_clip5 : xp.pen_clip3);
+                regs[gb] = a;
+                n_done++;
+            }
+        }
+        if (valid) {
+            const int gc = opaque(g);
+            const DevChain c = chn[slot_base[gc] + reg_chain[gc]];
+            const DevReg a = regs[gc];
+            regs[gc].seedcov = seed_cover(c, seeds, a);
+        }
+    }
+    if (!__ballot(n_done != 0 || cells != 0)) return;
+    atomicAdd(&counters[0], (unsigned long long)cells);
+    atomicAdd(&counters[1], n_done);
+    if (lane == 0) atomicAdd(&counters[2], (unsigned long long)iters);
 }
 
 // one side on one wavefront, with the accept/retry rule of bwamem.cpp:2495-2496: stop when the score did not change, or
@@ -1327,16 +1438,12 @@ static int run_phase(const ExtLaunch &L, const uint32_t *hint, int64_t ub) {
                 }
             }
             if (L.pack8 && L.perm_scores && L.reg_qmin > 0 && hi >= L.reg_qmin && hi >= 48 && hi <= 128) {       // rows in registers (lane_dp8r): no LDS
-                lds_k = 0;
-                switch (hi) {
-                    case 48: kern = k_ext_seeds<true, true, true, true, 12>; break;
-                    case 64: kern = k_ext_seeds<true, true, true, true, 16>; break;
-                    case 80: kern = k_ext_seeds<true, true, true, true, 20>; break;
-                    case 96: kern = k_ext_seeds<true, true, true, true, 24>; break;
-                    case 112: kern = k_ext_seeds<true, true, true, true, 28>; break;
-                    default: kern = k_ext_seeds<true, true, true, true, 32>; break;
-                }
-            }
+                auto kr = hi == 48 ? k_ext_seeds_reg<12> : hi == 64 ? k_ext_seeds_reg<16> : hi == 80 ? k_ext_seeds_reg<20> : hi == 96 ? k_ext_seeds_reg<24>
+                        : hi == 112 ? k_ext_seeds_reg<28> : k_ext_seeds_reg<32>;
+                hipLaunchKernelGGL(kr, dim3(grid_for(k, k + 1, 64)), dim3(64), 0, sk, c->ix, L.xp, L.tasks, L.start, k * EB_2D, (k + 1) * EB_2D,
+                                   L.enc, L.off, L.len, L.slot_base, L.reg_seed, L.reg_chain, L.chn, L.seeds, L.regs, L.counters, L.rev,
+                                   L.prio_qmin > 0 && hi >= L.prio_qmin ? L.prio : 0);
+            } else
             hipLaunchKernelGGL(kern, dim3(grid_for(k, k + 1, 64)), dim3(64), lds_k, sk, c->ix, L.xp, L.tasks, L.start, k * EB_2D, (k + 1) * EB_2D, hi,
                                L.enc, L.off, L.len, L.slot_base, L.reg_seed, L.reg_chain, L.chn, L.seeds, L.regs, L.counters, L.rev,
                                L.prio_qmin > 0 && hi >= L.prio_qmin ? L.prio : 0);

@@ -34,6 +34,21 @@ k_ksw_align2(const uint8_t *__restrict__ qbase, RefPtr tbase, const KswTask *__r
     ksw_row_task(qbase, tbase, T, prm, smat, lds + 16 + (size_t)row * 9 * slen_max * 16, slen_max, k, blists + T.b_off, out + id);
 }
 
+// the byte-kernel tasks of up to KSW_REG_SL stripe segments (every rescue alignment of a 150 bp run): rows in registers, no LDS but the score matrix
+__global__ void __launch_bounds__(256)
+k_ksw_align2_reg(const uint8_t *__restrict__ qbase, RefPtr tbase, const KswTask *__restrict__ tasks, const int *__restrict__ order, int n, KswPrm prm,
+                 bm2_ksw_result *__restrict__ out, unsigned long long *__restrict__ blists) {
+    __shared__ int8_t smat[32];
+    if (threadIdx.x < 25) smat[threadIdx.x] = prm.mat[threadIdx.x];
+    __syncthreads();
+    const int rows = blockDim.x >> 4, row = threadIdx.x >> 4, k = threadIdx.x & 15;
+    const int slot = blockIdx.x * rows + row;
+    if (slot >= n) return;
+    const int id = order[slot];
+    const KswTask T = tasks[id];
+    ksw_row_task_reg(qbase, tbase, T, prm, smat, k, blists + T.b_off, out + id);
+}
+
 #include "host_tail.h"
 
 // Runs n tasks: queries at qbase_host[q_off[i]] (uploaded here), targets at t_off[i] either in the same uploaded buffer
@@ -116,9 +131,19 @@ static int ksw_batch_run(bm2_ctx *c, int32_t n, const uint8_t *qbuf, int64_t qbu
     if (!rc) rc = bm2_copy_h2d(c, d_task, tasks.data(), task_bytes);
     if (!rc) rc = bm2_copy_h2d(c, d_order, order.data(), ord_bytes);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_ksw_align2, dim3((n + rows - 1) / rows), dim3(rows * 16), lds, s, (const uint8_t *)b_seq.p,
-                       d_tbase ? *d_tbase : RefPtr::bytes((const uint8_t *)b_seq.p), d_task, d_order, n, prm, slen_max, (bm2_ksw_result *)b_out.p,
-                       (unsigned long long *)b_misc.p);
+    // The order is (word kernel first, then the byte kernel by falling segment count): the tasks whose rows fit registers are its TAIL (k_ksw_align2_reg;
+    // BM2_KSW_REG=0: every task on the LDS kernel).
+    int n_reg = 0;
+    if (bm2_knob("BM2_KSW_REG", 1))
+        while (n_reg < n && ksw_task_fits_regs(tasks[(size_t)order[(size_t)(n - 1 - n_reg)]])) n_reg++;
+    const RefPtr tb_arg = d_tbase ? *d_tbase : RefPtr::bytes((const uint8_t *)b_seq.p);
+    const int n_lds = n - n_reg;
+    if (n_lds > 0)
+        hipLaunchKernelGGL(k_ksw_align2, dim3((n_lds + rows - 1) / rows), dim3(rows * 16), lds, s, (const uint8_t *)b_seq.p, tb_arg, d_task, d_order, n_lds, prm,
+                           slen_max, (bm2_ksw_result *)b_out.p, (unsigned long long *)b_misc.p);
+    if (n_reg > 0)
+        hipLaunchKernelGGL(k_ksw_align2_reg, dim3((n_reg + 15) / 16), dim3(256), 0, s, (const uint8_t *)b_seq.p, tb_arg, d_task, d_order + n_lds, n_reg, prm,
+                           (bm2_ksw_result *)b_out.p, (unsigned long long *)b_misc.p);
     rc = bm2_check(hipGetLastError(), "k_ksw_align2 launch");
     if (prof.on) { (void)hipStreamSynchronize(s); prof.mark("H2D + kernel"); }
     if (!rc) rc = bm2_copy_d2h(c, out, b_out.p, (size_t)n * sizeof(bm2_ksw_result));     // (waits for the kernel: same stream)

@@ -18,7 +18,7 @@ def rewrite(text):
     text = re.sub(r"extern\s+__shared__\s+(?:__attribute__\(\(aligned\(\d+\)\)\)\s+)?([A-Za-z_][A-Za-z0-9_]*)\s+([A-Za-z_][A-Za-z0-9_]*)\[\];",
                   r"\1 *\2 = (\1 *)emu_dyn_lds;", text)
     text = text.replace("__attribute__((address_space(3)))", "")
-    text = text.replace('"+v"', '"+r"')
+    text = text.replace('"+v"', '"+r"').replace('"+s"', '"+r"')
     text = re.sub(r"__attribute__\(\(amdgpu_waves_per_eu\([^)]*\)\)\)", "", text)       # a register-allocation hint
     # collectives called from divergent lanes -> their one-lane-at-a-time versions (see the fake hip_runtime.h); the definition stays
     text = re.sub(r"(?<![A-Za-z_])wave_alloc<(\w+)>\(", r"emu_wave_alloc<\1>(", text)

@@ -1,6 +1,6 @@
 // matesw_emu.cpp -- runs bwa-mem2_amd/csrc/matesw_dev.h (the device code of the mate-rescue SW) on the host through lane_emu.h.
 //   matesw_emu <pairs.txt> <out.bin>      pairs.txt: "xtra QUERY TARGET" per line (ACGTN), as `refdump ksw` reads
-//   scoring: env A B O_DEL E_DEL O_INS E_INS (defaults 1 4 6 1 6 1)
+//   scoring: env A B O_DEL E_DEL O_INS E_INS (defaults 1 4 6 1 6 1); EMU_KSW_REG=1: byte-kernel tasks of up to 160 bases go through ksw_row_task_reg
 // out.bin: 7 int32 per task (score, te, qe, score2, te2, tb, qb).  Tasks run one after the other, each on 16 lane threads.
 #include <stdio.h>
 #include <stdlib.h>
@@ -21,6 +21,9 @@ static void *lane_main(void *p) {
     LaneArg *a = (LaneArg *)p;
     emu_row = &a->job->row; emu_lane = a->lane;
     Job *j = a->job;
+    if (getenv("EMU_KSW_REG") && ksw_task_fits_regs(*j->T))       // the register pass (k_ksw_align2_reg) for the tasks it takes
+        ksw_row_task_reg(j->seqs, RefPtr::bytes(j->seqs), *j->T, *j->prm, j->smat, a->lane, j->bl, j->out);
+    else
     ksw_row_task(j->seqs, RefPtr::bytes(j->seqs), *j->T, *j->prm, j->smat, j->L, j->slen_max, a->lane, j->bl, j->out);
     return 0;
 }

@@ -10,7 +10,7 @@ left() { echo $(( LIMIT - ($(date +%s) - T0) )); }
 at() { echo "$1 rc=$2 at $(( $(date +%s) - T0 ))s"; }
 cd $R; export TMPDIR=/tmp
 (python -c "import torch" > /dev/null 2>&1 &)
-timeout 500 python tools/gpu/sweep.py $O --steps 4 --budget-s 200 --only "extension: wave priority,extension: rows in registers" > $O/sweep.out 2> $O/sweep.err; at sweep $?
+timeout 500 python tools/gpu/sweep.py $O --steps 4 --budget-s 200 --only "extension: rows in registers" > $O/sweep.out 2> $O/sweep.err; at sweep $?
 grep "\[sweep\]" $O/sweep.err | tail -40 | cut -c1-330
 for q in 0 96 48; do
   if [ $(left) -gt 100 ]; then
