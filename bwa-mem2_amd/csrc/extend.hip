@@ -847,7 +847,7 @@ k_ext_seeds(DevIndex ix, ExtParams xp, const int32_t *__restrict__ tasks_all, co
 // instantiation took 358 registers, one wavefront per SIMD, and the stage was slower than with LDS rows (profiles/r06b_sweep_ext_prio_regrows.json).
 static __device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
 template <int RG>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RG <= 12 ? 4 : 3)))
 k_ext_seeds_reg(DevIndex ix, ExtParams xp, const int32_t *__restrict__ tasks_all, const int64_t *__restrict__ start, int bin_lo, int bin_hi,
                 const uint8_t *__restrict__ enc, const int64_t *__restrict__ off, const int32_t *__restrict__ len,
                 const int64_t *__restrict__ slot_base, const int32_t *__restrict__ reg_seed, const int32_t *__restrict__ reg_chain,

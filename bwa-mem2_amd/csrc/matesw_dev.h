@@ -275,6 +275,9 @@ static BM2_DEV KswRes ksw_pass_u8r(bool rev, const uint8_t *__restrict__ q, int 
     return r;
 }
 #define KSW_REG_SL 10                 // segments the register pass holds: byte-kernel tasks of up to 160 query bases
+#if defined(__HIPCC__) && !defined(BM2_EMU) && !defined(BM2_EMU_ROW_PRIMS)
+__host__
+#endif
 static BM2_DEV bool ksw_task_fits_regs(const KswTask &T) { return (T.xtra & KSW_XBYTE) != 0 && (T.qlen + 15) / 16 <= KSW_REG_SL; }
 // ksw_align2 of a task that fits (ksw_task_fits_regs), both passes on registers; no LDS beyond the score matrix
 static BM2_DEV void ksw_row_task_reg(const uint8_t *__restrict__ qbase, RefPtr tbase, const KswTask &T, const KswPrm &prm, const int8_t *smat, int k,
