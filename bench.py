@@ -70,14 +70,18 @@ def main():
                     help="reads of the timed chunk's prefix that go through refdump (REGPRG / REGFIN byte for byte) and `bwa-mem2 mem` (SAM)")
     ap.add_argument("--resident-chunks", type=int, default=int(os.environ.get("BM2_BENCH_RESIDENT", 4)),
                     help="distinct chunks the timed steps go round (all resident before the clock starts; capped by --warmup and --steps)")
+    ap.add_argument("--distinct-chunks", type=int, default=1,
+                    help="ont2d: the timed steps go through this many DISTINCT chunks of --reads reads (BASELINE config 5 names 100 000 reads; one chunk's workspaces fill the "
+                         "HBM beside the index, so the chunks take turns: every step is timed on its own, its chunk uploaded before its clock starts)")
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--parity-regs-reads", type=int, default=256, help="ont2d: reads of the gate whose stage dumps (refdump, one host thread) are compared; all --parity-reads go through `bwa-mem2 mem` and the SAM comparison")
     ap.add_argument("--no-binding-s1", action="store_true", help="bsw: skip the timing of `bwa-mem2.bm2s1 mem` (S1 on the GPU inside the reference's program) beside `bwa-mem2.<isa> mem`")
     ap.add_argument("--no-side-workloads", action="store_true", help="skip configs 5 and 2 (objects `config5` / `config2` of the pe150 line: --workload ont2d / bsw as processes of their own)")
     ap.add_argument("--no-binding", action="store_true", help="skip the drop-in timing (`bwa-mem2.bm2 mem` beside `bwa-mem2.<isa> mem` on the first two end-to-end chunks' files)")
     ap.add_argument("--e2e-chunks", type=int, default=int(os.environ.get("BM2_BENCH_E2E_CHUNKS", 10)))
-    ap.add_argument("--e2e-rounds", type=int, default=int(os.environ.get("BM2_BENCH_E2E_ROUNDS", 3)),
-                    help="the end-to-end leg goes this many times round its distinct chunks (a run of 10 chunks is one third fill and drain of the pipeline)")
+    ap.add_argument("--e2e-rounds", type=int, default=int(os.environ.get("BM2_BENCH_E2E_ROUNDS", 10)),
+                    help="the end-to-end leg goes this many times round its distinct chunks (a run of 10 chunks is one third fill and drain of the pipeline; the default, "
+                         "10 x 10 chunks of 1 M reads, is BASELINE config 4's read count -- 100 M reads -- through one GPU)")
     ap.add_argument("--strong", action="store_true",
                     help="strong scaling: ONE chunk of --reads reads is cut at multiples of 512 over the ranks (SURVEY.md 8(e)) instead of one chunk per rank")
     ap.add_argument("--workdir", default=os.environ.get("BM2_BENCH_WORKDIR", "/tmp/bm2_bench"))
@@ -207,17 +211,51 @@ def main():
         run_ctx[i % n_res].batch_run(opt)
     kms = {}
     sc_sum = None
-    torch.cuda.synchronize()
-    dist_util.barrier(world)
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        c = run_ctx[i % n_res]
-        c.batch_run(opt)                                     # returns after the library's stream has drained
-        for name, ms in c.batch_kernel_ms():
-            kms[name] = kms.get(name, 0.0) + ms
-    torch.cuda.synchronize()
-    dist_util.barrier(world)
-    dt = dist_util.max_over_ranks(time.perf_counter() - t0, world, "cpu" if emu else "cuda")
+    n_distinct = max(1, min(a.distinct_chunks, a.steps)) if ont else 1
+    reads_timed = None
+    if n_distinct > 1:
+        # BASELINE config 5 as worded -- 100 000 reads in one run -- on a GPU whose HBM holds ONE chunk's workspaces beside the index: the steps go through
+        # n_distinct different chunks that take turns on the one context.  Each step is timed on its own (barrier + synchronize on both sides) with its chunk
+        # uploaded BEFORE its clock starts -- `value` keeps its meaning, reads resident in HBM -- and the step times are added up.  The last step runs the
+        # chunk the parity gate samples (chunk 0), so the gate reads that chunk's regs.
+        from tools import refio as _refio
+        chunks = [(enc, off, ln)]
+        t = time.time()
+        for k in range(1, n_distinct):
+            sq = synth.make_reads_long(dist_util.shard_seed(seed, rank) + 31 * k, contigs(), n_reads, mean_len=10000, max_len=30000)
+            chunks.append(_refio.pack_reads(sq))
+            del sq
+        log("rank %d: %d distinct chunks of %d long reads generated in %.1fs" % (rank, n_distinct, n_reads, time.time() - t))
+        dt_local, reads_timed = 0.0, 0
+        for i in range(a.steps):
+            e_k, o_k, l_k = chunks[(i + 1) % n_distinct]
+            ctx.batch_upload(e_k, o_k, l_k)
+            torch.cuda.synchronize()
+            dist_util.barrier(world)
+            t0 = time.perf_counter()
+            ctx.batch_run(opt)
+            torch.cuda.synchronize()
+            dist_util.barrier(world)
+            dt_local += time.perf_counter() - t0
+            reads_timed += len(l_k)
+            for name, ms in ctx.batch_kernel_ms():
+                kms[name] = kms.get(name, 0.0) + ms
+        if a.steps % n_distinct:                              # (the gate below compares chunk 0's regs: make it the resident one)
+            ctx.batch_upload(enc, off, ln); ctx.batch_run(opt)
+        dt = dist_util.max_over_ranks(dt_local, world, "cpu" if emu else "cuda")
+        del chunks
+    else:
+        torch.cuda.synchronize()
+        dist_util.barrier(world)
+        t0 = time.perf_counter()
+        for i in range(a.steps):
+            c = run_ctx[i % n_res]
+            c.batch_run(opt)                                     # returns after the library's stream has drained
+            for name, ms in c.batch_kernel_ms():
+                kms[name] = kms.get(name, 0.0) + ms
+        torch.cuda.synchronize()
+        dist_util.barrier(world)
+        dt = dist_util.max_over_ranks(time.perf_counter() - t0, world, "cpu" if emu else "cuda")
     st = ctx.batch_stats()
     parts = ctx.batch_parts() if hasattr(ctx, "batch_parts") else 1      # (a chunk runs as `parts` parts beside each other: the per-kernel times are summed over them)
     if n_res > 1:                                            # work counters: the mean over the chunks that ran (they differ by a fraction of a per cent)
@@ -234,6 +272,8 @@ def main():
         steps = max(a.steps, 1)
         n_total = (a.reads or 1000000) if (a.strong and not ont) else world * n_reads
         value = n_total * a.steps / dt
+        if reads_timed is not None:
+            value = world * reads_timed / dt
         kern_ms = {k: v / steps for k, v in kms.items()}     # every timed interval of the library's stream (HIP events)
         stage_ms = {}
         for k, v in kern_ms.items():                         # "smem.walk1" ... -> stage "smem"
@@ -324,7 +364,8 @@ def main():
                 pass
         ach_counter = traffic / (bwd_ms * 1e-3) / 1e9 if traffic and bwd_ms > 0 else None
         lines_counter = traffic / 64.0 / (bwd_ms * 1e-3) / 1e9 if traffic and bwd_ms > 0 else None
-        wl_name = ("config 5 shape: %d ONT-like reads (mean 10 kb, cap 30 kb, ~10%% error) per GPU per step, `-x ont2d`" % n_reads) if ont else \
+        wl_name = ("config 5 shape: %d ONT-like reads (mean 10 kb, cap 30 kb, ~10%% error) per GPU per step, `-x ont2d`%s" % (n_reads,
+                   "" if n_distinct <= 1 else "; the %d steps go through %d DISTINCT chunks = %d reads in this run, every step timed on its own with its chunk resident" % (a.steps, n_distinct, reads_timed))) if ont else \
                   ("config 3 shape: %d x %d bp PE reads per GPU per step" % (n_reads, a.read_len))
         out = {
             "metric": "aligned reads/s (150bp PE vs GRCh38) at 1/2/4/8 GPU; SAM bit-exact vs ref",
@@ -348,11 +389,12 @@ def main():
                                    "N-gaps, indexed in-run by bm2_index_build (3100 Mbp = GRCh38 size); `value` = device hot path "
                                    "with the reads resident in HBM (the steps go round %d distinct chunks), output = mem_alnreg_t regs at bwamem.cpp:1152; the FASTQ -> SAM "
                                    "rate of the same library is `end_to_end.value`" % (a.genome_mbp, n_res),
-                       "workload_short": (("config 5 shape: %d ONT-like reads (mean 10 kb) per GPU per step, -x ont2d" % n_reads) if ont else
+                       "workload_short": (("config 5 shape: %d ONT-like reads (mean 10 kb) per GPU per step, -x ont2d%s" % (n_reads, "" if n_distinct <= 1 else " (%d distinct chunks = %d reads)" % (n_distinct, reads_timed))) if ont else
                                           ("config 3 shape: %d x %d bp PE reads per GPU per step" % (n_reads, a.read_len)))
                                          + ", synthetic %d Mbp genome; SMEM+SAL+chain+banded SW on device, reads resident in HBM" % a.genome_mbp,
                        "parallelism_short": ("1 chunk cut over %d GPU(s), " if a.strong else "1 chunk per GPU x %d GPU(s), ") % world + "index replica per GPU, no collectives",
                        "resident_chunks": n_res,
+                       "distinct_chunks": n_distinct, "steps_cover_reads": (reads_timed if reads_timed is not None else None),
                        "reads_per_gpu_per_step": n_reads, "bases_per_gpu_per_step": n_bases, "read_len": a.read_len if not ont else None,
                        "genome_mbp": a.genome_mbp,
                        "parallelism": ("ONE chunk cut at multiples of 512 reads over %d GPU(s) (strong scaling), " if a.strong else "one chunk per GPU over %d GPU(s), ") % world

@@ -712,15 +712,9 @@ static __device__ __forceinline__ void load_query_regs(bool has, const uint8_t *
     }
 }
 
-// The instruction arbiter's priority of this wavefront (s_setprio takes an immediate).  The launches of a phase share the SIMDs, and the phase is as
-// long as ONE tile of its long classes -- 64 seeds walked row after row, two sides: a dependent chain of ~10^5 instructions -- while the short classes'
-// wavefronts beside it are many and independent: BM2_EXT_PRIO_QMIN lets the long classes issue first (launch policy: no result can change).
-static __device__ __forceinline__ void wave_prio(int p) {
-    if (p == 1) __builtin_amdgcn_s_setprio(1);
-    else if (p == 2) __builtin_amdgcn_s_setprio(2);
-    else if (p >= 3) __builtin_amdgcn_s_setprio(3);
-}
-
+// (Measured in round 6 and removed, profiles/r06b_sweep_ext_prio_regrows.json: s_setprio 1..3 for the wavefronts of the long classes and / or of the wavefront
+//  kernel -- a phase is as long as one tile of its long classes, so they were let issue first: extension 15.7 -> 15.4-15.5 ms at best, 16.4 with the
+//  wavefront kernel raised: within the sweep's noise.)
 // One seed per lane: left side, then right side (h0 = the score after the left side, bwamem.cpp:2672-2677), each with the two-try
 // band rule.  A wavefront takes tiles of 64 consecutive seeds of its class's sorted list (grid-stride: the host sizes the grid from the
 // previous batch's counts, the kernel reads the real range from the device).
@@ -729,9 +723,8 @@ __global__ void __launch_bounds__(64)
 k_ext_seeds(DevIndex ix, ExtParams xp, const int32_t *__restrict__ tasks_all, const int64_t *__restrict__ start, int bin_lo, int bin_hi, int qmax,
             const uint8_t *__restrict__ enc, const int64_t *__restrict__ off, const int32_t *__restrict__ len,
             const int64_t *__restrict__ slot_base, const int32_t *__restrict__ reg_seed, const int32_t *__restrict__ reg_chain,
-            const DevChain *__restrict__ chn, const DevSeed *__restrict__ seeds, DevReg *regs, unsigned long long *counters, int rev, int prio) {
+            const DevChain *__restrict__ chn, const DevSeed *__restrict__ seeds, DevReg *regs, unsigned long long *counters, int rev) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_l[];
-    wave_prio(prio);
     uint32_t *EH = lds_l;                                       // [(qmax+1)][64]           (P8: [(qmax+2)/2][64])
     uint8_t *QL = (uint8_t *)(lds_l + (size_t)(qmax + 1) * 64); // [qmax][64] bytes
     uint32_t *QL8 = lds_l + (G4 ? (size_t)(2 * ((qmax + 3) / 4) + 2) : (size_t)((qmax + 2) / 2)) * 64;      // P8: [(qmax+7)/8][64] dwords, 8 bases of 4 bits each (PT: [(qmax+3)/4 + 1][64], one per byte)
@@ -847,12 +840,11 @@ k_ext_seeds(DevIndex ix, ExtParams xp, const int32_t *__restrict__ tasks_all, co
 // instantiation took 358 registers, one wavefront per SIMD, and the stage was slower than with LDS rows (profiles/r06b_sweep_ext_prio_regrows.json).
 static __device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
 template <int RG>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RG <= 12 ? 4 : 3)))
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3)))
 k_ext_seeds_reg(DevIndex ix, ExtParams xp, const int32_t *__restrict__ tasks_all, const int64_t *__restrict__ start, int bin_lo, int bin_hi,
                 const uint8_t *__restrict__ enc, const int64_t *__restrict__ off, const int32_t *__restrict__ len,
                 const int64_t *__restrict__ slot_base, const int32_t *__restrict__ reg_seed, const int32_t *__restrict__ reg_chain,
-                const DevChain *__restrict__ chn, const DevSeed *__restrict__ seeds, DevReg *regs, unsigned long long *counters, int rev, int prio) {
-    wave_prio(prio);
+                const DevChain *__restrict__ chn, const DevSeed *__restrict__ seeds, DevReg *regs, unsigned long long *counters, int rev) {
     const int lane = threadIdx.x;
     const int64_t first = start[bin_lo];
     const int n_tasks = (int)(start[bin_hi] - first);
@@ -954,9 +946,8 @@ __global__ void __launch_bounds__(256)
 k_ext_wave(DevIndex ix, ExtParams xp, const int32_t *__restrict__ tasks_all, const int64_t *__restrict__ start, int bin_lo, int bin_hi,
            const uint8_t *__restrict__ enc, const int64_t *__restrict__ off, const int32_t *__restrict__ len,
            const int64_t *__restrict__ slot_base, const int32_t *__restrict__ reg_seed, const int32_t *__restrict__ reg_chain,
-           const DevChain *__restrict__ chn, const DevSeed *__restrict__ seeds, DevReg *regs, int R, unsigned long long *counters, int rev, int prio) {
+           const DevChain *__restrict__ chn, const DevSeed *__restrict__ seeds, DevReg *regs, int R, unsigned long long *counters, int rev) {
     extern __shared__ __attribute__((aligned(16))) int lds[];
-    wave_prio(prio);
     ExtParams *sP = (ExtParams *)lds;
     int *rings = lds + (sizeof(ExtParams) + 3) / 4;
     if (threadIdx.x < sizeof(ExtParams) / 4) ((int *)sP)[threadIdx.x] = ((const int *)&xp)[threadIdx.x];
@@ -1378,7 +1369,6 @@ struct ExtLaunch {
     // of cells one after the other (milliseconds) and a phase lasts as long as its slowest wavefront, so the classes from wave_qmin up can go
     // one seed per WAVEFRONT (k_ext_wave) beside the lane kernels.
     int wave_qmin, prefetch, rev, perm_scores, qmap, group4;
-    int prio_qmin, prio, prio_wave;          // s_setprio of the long classes' wavefronts (wave_prio)
     int reg_qmin;                            // classes of queries up to at least this many bases keep their rows in registers (0: none)
     // the sorted seed list of the phase and where it lives
     const int32_t *tasks; const int64_t *start;
@@ -1437,19 +1427,17 @@ static int run_phase(const ExtLaunch &L, const uint32_t *hint, int64_t ub) {
                     lds_k = (size_t)(2 * ((hi + 3) / 4) + 2) * 64 * 4 + (size_t)((hi + 3) / 4 + 1) * 64 * 4;
                 }
             }
-            if (L.pack8 && L.perm_scores && L.reg_qmin > 0 && hi >= L.reg_qmin && hi >= 48 && hi <= 128) {       // rows in registers (lane_dp8r): no LDS
-                auto kr = hi == 48 ? k_ext_seeds_reg<12> : hi == 64 ? k_ext_seeds_reg<16> : hi == 80 ? k_ext_seeds_reg<20> : hi == 96 ? k_ext_seeds_reg<24>
-                        : hi == 112 ? k_ext_seeds_reg<28> : k_ext_seeds_reg<32>;
+            if (L.pack8 && L.perm_scores && L.reg_qmin > 0 && hi >= L.reg_qmin && hi >= 80 && hi <= 128) {       // rows in registers (lane_dp8r): no LDS
+                // (the 144- and 160-column instantiations are not in the tree: the compiler stops unrolling their 37 / 41 groups and the row lands in scratch)
+                auto kr = hi == 80 ? k_ext_seeds_reg<20> : hi == 96 ? k_ext_seeds_reg<24> : hi == 112 ? k_ext_seeds_reg<28> : k_ext_seeds_reg<32>;
                 hipLaunchKernelGGL(kr, dim3(grid_for(k, k + 1, 64)), dim3(64), 0, sk, c->ix, L.xp, L.tasks, L.start, k * EB_2D, (k + 1) * EB_2D,
-                                   L.enc, L.off, L.len, L.slot_base, L.reg_seed, L.reg_chain, L.chn, L.seeds, L.regs, L.counters, L.rev,
-                                   L.prio_qmin > 0 && hi >= L.prio_qmin ? L.prio : 0);
+                                   L.enc, L.off, L.len, L.slot_base, L.reg_seed, L.reg_chain, L.chn, L.seeds, L.regs, L.counters, L.rev);
             } else
             hipLaunchKernelGGL(kern, dim3(grid_for(k, k + 1, 64)), dim3(64), lds_k, sk, c->ix, L.xp, L.tasks, L.start, k * EB_2D, (k + 1) * EB_2D, hi,
-                               L.enc, L.off, L.len, L.slot_base, L.reg_seed, L.reg_chain, L.chn, L.seeds, L.regs, L.counters, L.rev,
-                               L.prio_qmin > 0 && hi >= L.prio_qmin ? L.prio : 0);
+                               L.enc, L.off, L.len, L.slot_base, L.reg_seed, L.reg_chain, L.chn, L.seeds, L.regs, L.counters, L.rev);
         } else {
             hipLaunchKernelGGL(k_ext_wave, dim3(grid_for(k_wave, N_CLS + 1, 4)), dim3(256), L.lds_w, sk, c->ix, L.xp, L.tasks, L.start, k_wave * EB_2D,
-                               (int)N_EBINS, L.enc, L.off, L.len, L.slot_base, L.reg_seed, L.reg_chain, L.chn, L.seeds, L.regs, L.R, L.counters, L.rev, L.prio_wave);
+                               (int)N_EBINS, L.enc, L.off, L.len, L.slot_base, L.reg_seed, L.reg_chain, L.chn, L.seeds, L.regs, L.R, L.counters, L.rev);
         }
         (void)hipEventRecord(c->ev_join[k], sk);
         joined[n_joined++] = k;
@@ -1499,8 +1487,12 @@ int bm2_launch_extend(bm2_ctx *c, const bm2_opt &opt, const ChainParams &cp, int
     L.qmap = bm2_knob("BM2_EXT_QUEUE_MAP", 1);
     L.perm_scores = bm2_knob("BM2_EXT_PERM_SCORES", 1);
     L.group4 = bm2_knob("BM2_EXT_GROUP4", 1);
-    L.reg_qmin = bm2_knob("BM2_EXT_REG_QMIN", 0);
-    L.prio_qmin = bm2_knob("BM2_EXT_PRIO_QMIN", 0); L.prio = bm2_knob("BM2_EXT_PRIO", 2); L.prio_wave = bm2_knob("BM2_EXT_WAVE_PRIO", 0);
+    // Rows in registers for the classes from this query length up (k_ext_seeds_reg; 0: none).  Measured on the 3100 Mbp chunk (profiles/r06c_*, r06d_*: two
+    // sweeps): the 113..128-base class alone -- each phase's longest launch, 6 wavefronts per CU on LDS rows -- extension 15.7-16.2 -> 14.5-14.8 ms; with
+    // the 97..112 class as well 14.8-15.0, from 81 bases 15.4-15.6, from 49 bases 16.0-16.1 (the shorter classes' LDS rows already fit 8-12 wavefronts per
+    // CU and the register kernel pays a scalar test per group of its class, not of its band).  On seam S1 (one phase, a leaner kernel around the same
+    // rows): 809 -> 1055 G cells/s from 96 bases up (r06c_bench_bsw_reg_qmin*.json).
+    L.reg_qmin = bm2_knob("BM2_EXT_REG_QMIN", 128);
     for (int k : { 0, 1, 4 }) if (opt.mat[k] < -128 || opt.mat[k] > 127) L.perm_scores = 0;     // (the score table holds signed bytes)
     const int lazy_max = bm2_knob("BM2_EXT_ROUNDS", LAZY_ROUNDS), pend_div = bm2_knob("BM2_EXT_PEND_DIV", 12);
     L.R = ring_size2(opt.w << (MAX_BAND_TRY - 1));
@@ -1673,12 +1665,12 @@ int bm2_launch_bsw_sorted(bm2_ctx *c, bm2_seqpair_t *d_pairs, const uint8_t *d_r
             const int hi = cls_hi[k];
             const size_t lds = (size_t)(2 * ((hi + 3) / 4) + 2) * 64 * 4 + (size_t)((hi + 3) / 4 + 1) * 64 * 4;
             int64_t g = (cnt + 63) / 64; if (g < 1) g = 1; if (g > (1 << 16)) g = 1 << 16;
-            const int reg_qmin = bm2_knob("BM2_EXT_REG_QMIN", 0);
+            const int reg_qmin = bm2_knob("BM2_BSW_REG_QMIN", 96);     // (S1's own knob: its kernel around the register rows is leaner than the pipeline's, profiles/r06c_bench_bsw_reg_qmin*.json)
             auto kb = k_bsw_lanes<0>;
             size_t lds_k = lds;
-            if (reg_qmin > 0 && hi >= reg_qmin && hi >= 48 && hi <= 128) {
+            if (reg_qmin > 0 && hi >= reg_qmin && hi >= 64 && hi <= 128) {
                 lds_k = 0;
-                kb = hi == 48 ? k_bsw_lanes<12> : hi == 64 ? k_bsw_lanes<16> : hi == 80 ? k_bsw_lanes<20> : hi == 96 ? k_bsw_lanes<24> : hi == 112 ? k_bsw_lanes<28> : k_bsw_lanes<32>;
+                kb = hi == 64 ? k_bsw_lanes<16> : hi == 80 ? k_bsw_lanes<20> : hi == 96 ? k_bsw_lanes<24> : hi == 112 ? k_bsw_lanes<28> : k_bsw_lanes<32>;
             }
             hipLaunchKernelGGL(kb, dim3((unsigned)g), dim3(64), lds_k, sk, d_pairs, d_ref, d_qer, tasks, start, k * EB_2D, (k + 1) * EB_2D, hi, w, P, d_cells, 1);
         } else {

@@ -17,6 +17,7 @@
 // is on the device the next requests pile up: batches grow with the load by themselves (group commit), no timer involved.  BM2_S1_CONTEXTS
 // slots (default 2) so that the copies of one batch overlap the kernels of another.
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <mutex>
 #include <vector>
@@ -45,6 +46,10 @@ std::mutex g_mu;
 std::condition_variable g_cv;
 std::vector<Request *> g_pending;
 std::atomic<long long> g_pairs{0}, g_batches{0}, g_calls{0};
+// where a call's time goes (nanoseconds summed over all calls / batches; printed at exit): a caller WAITS for a leader's batch or LEADS one, a leader
+// gathers the requests into its page-locked staging buffers, calls bm2_bsw (H2D, device sort + kernels, D2H, the leader asleep), scatters the results
+std::atomic<long long> g_ns_call{0}, g_ns_gather{0}, g_ns_bsw{0}, g_ns_scatter{0};
+inline long long now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // The leader of a batch sleeps while the device works (its CPU goes to the threads that are seeding): the library reads BM2_BLOCKING_SYNC when a context
 // is made.  Set at load time, while the program has ONE thread -- inside attach() it raced with the getenv of leaders on other slots (setenv may move environ).
@@ -59,7 +64,12 @@ void attach() {
         if (!g_slot[i].ctx) { fprintf(stderr, "[bm2s1] bm2_create: %s\n", bm2_last_error()); exit(EXIT_FAILURE); }
     }
     fprintf(stderr, "[bm2s1] banded extension (getScores8 / getScores16 / scalarBandedSWAWrapper) runs in libbm2: the calls of all threads combined into batches on %d context(s)\n", g_n);
-    atexit([]() { fprintf(stderr, "[bm2s1] %lld SeqPairs in %lld device batches from %lld calls\n", g_pairs.load(), g_batches.load(), g_calls.load()); });
+    atexit([]() {
+        fprintf(stderr, "[bm2s1] %lld SeqPairs in %lld device batches from %lld calls\n", g_pairs.load(), g_batches.load(), g_calls.load());
+        const double nb = (double)(g_batches.load() ? g_batches.load() : 1), nc = (double)(g_calls.load() ? g_calls.load() : 1);
+        fprintf(stderr, "[bm2s1] per call %.3f ms (all threads' calls: %.2f s); per device batch: gather %.3f ms, bm2_bsw %.3f ms, scatter %.3f ms\n",
+                g_ns_call.load() / nc * 1e-6, g_ns_call.load() * 1e-9, g_ns_gather.load() / nb * 1e-6, g_ns_bsw.load() / nb * 1e-6, g_ns_scatter.load() / nb * 1e-6);
+    });
 }
 
 template <class T> void grow(T *&buf, size_t &cap, size_t need) {
@@ -72,6 +82,7 @@ template <class T> void grow(T *&buf, size_t &cap, size_t need) {
 
 // the leader's part: requests laid end to end, one device batch, results back (no lock held)
 void run_batch(Slot &s, const std::vector<Request *> &batch) {
+    const long long t_0 = now_ns();
     size_t n = 0, rb = 0, qb = 0;
     for (const Request *r : batch) { n += (size_t)r->n; rb += (size_t)r->ref_bytes; qb += (size_t)r->qer_bytes; }
     grow(s.pairs, s.cap_pairs, n); grow(s.ref, s.cap_ref, rb + 8); grow(s.qer, s.cap_qer, qb + 8);
@@ -85,9 +96,11 @@ void run_batch(Slot &s, const std::vector<Request *> &batch) {
     }
     // one batch: the six output fields of every pair, by the rule of the pair's own kernel class (bm2_bsw derives the class from len1, len2
     // and h0 exactly as sortPairsLenExt does, bwamem.cpp:1924-1950 -- the class the reference filed the pair under)
+    const long long t_1 = now_ns();
     if (bm2_bsw(s.ctx, s.pairs, s.ref, (int64_t)rb, s.qer, (int64_t)qb, (int)n, batch[0]->w, &batch[0]->p)) {
         fprintf(stderr, "[bm2s1] bm2_bsw: %s\n", bm2_last_error()); exit(EXIT_FAILURE);
     }
+    const long long t_2 = now_ns();
     at = 0;
     for (const Request *r : batch) {
         for (int i = 0; i < r->n; i++) {
@@ -98,6 +111,7 @@ void run_batch(Slot &s, const std::vector<Request *> &batch) {
         at += (size_t)r->n;
     }
     g_pairs += (long long)n; ++g_batches;
+    g_ns_gather += t_1 - t_0; g_ns_bsw += t_2 - t_1; g_ns_scatter += now_ns() - t_2;
 }
 
 void run(const BandedPairWiseSW *self, SeqPair *pairs, uint8_t *ref, uint8_t *qer, int n, int w) {
@@ -115,10 +129,11 @@ void run(const BandedPairWiseSW *self, SeqPair *pairs, uint8_t *ref, uint8_t *qe
         if (q > me.qer_bytes) me.qer_bytes = q;
     }
     ++g_calls;
+    const long long t_call = now_ns();
     std::unique_lock<std::mutex> lock(g_mu);
     g_pending.push_back(&me);
     for (;;) {
-        if (me.done) return;
+        if (me.done) { g_ns_call += now_ns() - t_call; return; }
         int free_slot = -1;
         for (int i = 0; i < g_n; i++) if (!g_slot[i].busy) { free_slot = i; break; }
         if (free_slot >= 0 && !g_pending.empty()) {              // lead a batch: everything filed so far that shares the first request's band and scoring

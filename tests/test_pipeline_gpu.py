@@ -149,7 +149,7 @@ KNOB_SETTINGS = [
     {"BM2_P3_BPC": "1"}, {"BM2_P3_BPC": "2", "BM2_P3_AT": "2"},
     {"BM2_CHAIN_COOP_FLT": "0"}, {"BM2_CHAIN_COOP_FLT": "1"}, {"BM2_CHAIN_CLOCK": "1"}, {"BM2_CHAIN_HEAVY_WPE": "2"}, {"BM2_CHAIN_HEAVY_WPE": "4", "BM2_CHAIN_COOP_FLT": "0"},
     {"BM2_CHAIN_SERIAL_LNODES": "3", "BM2_CHAIN_ISL_WPE": "3"}, {"BM2_CHAIN_SERIAL_LNODES": "400", "BM2_CHAIN_COOP_FLT": "1"},
-    {"BM2_EXT_REG_QMIN": "48"}, {"BM2_EXT_REG_QMIN": "96", "BM2_EXT_PRIO_QMIN": "80", "BM2_EXT_PRIO": "3", "BM2_EXT_WAVE_PRIO": "1"},
+    {"BM2_EXT_REG_QMIN": "80"}, {"BM2_EXT_REG_QMIN": "0"}, {"BM2_KSW_REG": "0"},
 ]
 
 

@@ -431,6 +431,10 @@ def s1_binding_leg(workdir, prefix):
             res[tag]["seqpairs"], res[tag]["device_batches"] = int(m.group(1)), int(m.group(2))
             if m.group(3):
                 res[tag]["calls"] = int(m.group(3))
+        m = re.search(r"\[bm2s1\] per call ([\d.]+) ms \(all threads' calls: ([\d.]+) s\); per device batch: gather ([\d.]+) ms, bm2_bsw ([\d.]+) ms, scatter ([\d.]+) ms", p.stderr)
+        if m:                                                       # the binding's own clocks: where a call's time goes (integration/bm2_bsw_binding.cpp)
+            res[tag]["seam_clock"] = {"ms_per_call": float(m.group(1)), "calls_s_all_threads": float(m.group(2)), "gather_ms_per_batch": float(m.group(3)),
+                                      "bm2_bsw_ms_per_batch": float(m.group(4)), "scatter_ms_per_batch": float(m.group(5))}
     try:
         os.remove(fq_all)
     except OSError:
@@ -839,7 +843,7 @@ def run_side_workloads(a, early_s1, time_left):
     """BASELINE configs 5 and 2 as workloads of their own (each a process of its own on this GPU, with its parity gate, its kernels' figures and the
     compiled reference timed beside it): {"config5": line, "config2": line}."""
     res = {}
-    for key, name, extra, need_s in (("config5", "ont2d", ["--steps", 2, "--warmup", 1, "--parity-reads", 2048, "--parity-regs-reads", 200] + CONFIG5_READS, 420),
+    for key, name, extra, need_s in (("config5", "ont2d", ["--steps", 5, "--warmup", 1, "--distinct-chunks", 5, "--parity-reads", 2048, "--parity-regs-reads", 200] + CONFIG5_READS, 480),
                                      ("config2", "bsw", ["--steps", 5, "--warmup", 2], 90)):
         if time_left() < need_s:
             res[key] = {"skipped": "time budget (%.0f s left)" % time_left()}
