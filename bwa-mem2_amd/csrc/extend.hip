@@ -1701,12 +1701,22 @@ int bm2_launch_postfilter(bm2_ctx *c, const ChainParams &o, int n_reads, const i
                           int32_t *srt_all, DevReg *regs, int32_t *n_out, const int32_t *cursor, const int32_t *perm,
                           const int32_t *heavy, const int64_t *n_heavy, unsigned long long *item_cur, int pf_heavy) {
     if (n_reads <= 0) return BM2_OK;
-    hipLaunchKernelGGL(k_postfilter, dim3((n_reads + 127) / 128), dim3(128), 0, c->stream, o, n_reads, len, read_base, n_chain,
+    // (different reads: the two kernels run beside each other -- the lane-per-read one on a side stream whose hardware queue is not the main stream's)
+    hipStream_t sl = c->stream;
+    const bool beside = heavy && bm2_side_streams(c) == BM2_OK;
+    if (beside) {
+        sl = c->side_stream[2];
+        (void)hipEventRecord(c->ev_fork, c->stream);
+        (void)hipStreamWaitEvent(sl, c->ev_fork, 0);
+    }
+    hipLaunchKernelGGL(k_postfilter, dim3((n_reads + 127) / 128), dim3(128), 0, sl, o, n_reads, len, read_base, n_chain,
                        n_reg, chn, seeds, srt_all, regs, n_out, cursor, perm, heavy ? pf_heavy : 0x7fffffff);
-    if (heavy) {                                             // (different reads: order between the two kernels does not matter)
+    if (beside) (void)hipEventRecord(c->ev_join[2], sl);
+    if (heavy) {
         hipLaunchKernelGGL(k_postfilter_heavy, dim3(c->n_cu * 4), dim3(256), 0, c->stream, o, heavy, n_heavy, len, read_base, n_chain,
                            n_reg, chn, seeds, srt_all, regs, n_out, cursor, item_cur, pf_heavy);
     }
+    if (beside) (void)hipStreamWaitEvent(c->stream, c->ev_join[2], 0);
     return bm2_check(hipGetLastError(), "k_postfilter launch");
 }
 

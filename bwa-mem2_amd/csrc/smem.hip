@@ -1142,12 +1142,10 @@ int bm2_launch_seeding(bm2_ctx *c, const SeedParams &sp, int n_reads, const uint
                        const SeedBufs &sb, int grid_walk, int grid_bwd, int32_t *smem_cnt, unsigned long long *sc,
                        void (*tick)(bm2_ctx *, const char *), int max_len) {
     if (bm2_side_streams(c)) return BM2_ENODEV;
-    // The wavefront-per-task kernel is MEANT to run beside k_bwd -- but streams share hardware queues, and side stream 1 sits on the MAIN stream's queue
-    // (profiles/r05_timeline.tsv: k_bwd_heavy 2.8 ms, and k_bwd started the moment it ended; 1.5 ms more in pass 2): BM2_BWD_HEAVY_STREAM picks the side
-    // stream, i.e. the queue
-    const int hs = bm2_knob("BM2_BWD_HEAVY_STREAM", 1);
-    hipStream_t s = c->stream, s3 = c->side_stream[0], sh = c->side_stream[hs >= 0 && hs < 12 ? hs : 1];
-    const int grid_heavy = c->n_cu * bm2_knob("BM2_BWD_HEAVY_WG", 4);      // workgroups per CU of the wavefront-per-task kernel (1 / 2 per CU measured no better: profiles/r05b_sweep.json)
+    hipStream_t s = c->stream, s3 = c->side_stream[0], sh = c->side_stream[1];
+    // workgroups per CU of the wavefront-per-task kernel beside k_bwd: 12 (pass 1's backward phase 14.9 -> 14.2 ms, profiles/r06e_sweep_bwd_heavy_stream_grid.json;
+    // 1 / 2 / 4 / 8 per CU and a side stream on another hardware queue than the main stream's: all within 0.3 ms of each other)
+    const int grid_heavy = c->n_cu * bm2_knob("BM2_BWD_HEAVY_WG", 12);
     // k_bwd hands a task that has had this many extensions over to the wavefront-per-task kernel at its next row boundary (0 = never)
     const int export_age = bm2_knob("BM2_BWD_EXPORT_AGE", BWD_EXPORT_AGE);
     // pass 3 is independent of passes 1 and 2: it runs beside them.  WHERE is launch policy (BM2_P3_AT): 0 = beside the forward walks of
