@@ -6,6 +6,7 @@
 #include <string.h>
 #include <new>
 #include <mutex>
+#include <algorithm>
 #include <vector>
 #include "bm2_ctx.h"
 
@@ -198,6 +199,69 @@ static int make_streams(bm2_ctx *c) {
     if (c->ext_stat) memset(c->ext_stat, 0, sizeof(uint32_t) * BM2_EXT_PHASES * BM2_EXT_STATW);      // (rows no round has written yet size grids as hints: zeros, not whatever the pool held)
     return BM2_OK;
 }
+// One lane that spins for `ticks` of the 100 MHz clock and leaves its start and end: launched on every side stream at once, the intervals of two streams
+// overlap unless the streams share a hardware queue.
+__global__ void k_queue_probe(unsigned long long *out, int slot, long long ticks) {
+    const long long t0 = wall_clock64();
+    long long t1 = t0;
+    for (int i = 0; i < (1 << 20) && t1 - t0 < ticks; i++) { __builtin_amdgcn_s_sleep(16); t1 = wall_clock64(); }
+    out[2 * slot] = (unsigned long long)t0; out[2 * slot + 1] = (unsigned long long)t1;
+}
+// The runtime spreads a process's streams over its hardware queues as it sees fit (least-loaded queue first; the contexts of a process, torch's own streams
+// and streams long destroyed all count), so WHICH side streams share a queue differs from process to process: profiles/r05_timeline.tsv has the eight
+// launches of an extension phase on eight queues, profiles/r06f_timeline.tsv has two pairs of them on two -- the 64-column class ran alone for 1.1 ms
+// behind the wavefront kernel, after everything else of its phase had ended.  Nothing in HIP tells; so it is measured once per context (0.4 ms).
+static void probe_side_queues(bm2_ctx *c) {
+    c->n_side_groups = 0;
+    if (!bm2_knob("BM2_QUEUE_PROBE", 1)) return;
+#if !defined(BM2_EMU_ROW_PRIMS)                                   /* (the host emulator has no queues and no clock) */
+    enum { NS = 13 };                                             // the twelve side streams and the main stream (slot 12)
+    unsigned long long *d = nullptr, h[2 * NS];
+    if (hipMalloc((void **)&d, sizeof h) != hipSuccess) return;
+    bool ok = hipMemset(d, 0, sizeof h) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+    const long long ticks = 30000;                                // 300 us: an order of magnitude beyond the time it takes to queue the launches
+    auto stream_of = [&](int i) { return i < 12 ? c->side_stream[i] : c->stream; };
+    for (int i = 0; ok && i < NS; i++) hipLaunchKernelGGL(k_queue_probe, dim3(1), dim3(1), 0, stream_of(i), d, i, ticks);
+    for (int i = 0; ok && i < NS; i++) ok = hipStreamSynchronize(stream_of(i)) == hipSuccess;
+    ok = ok && hipGetLastError() == hipSuccess && hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost) == hipSuccess;
+    (void)hipFree(d);
+    if (!ok) return;
+    // streams in the order their kernels started; a stream joins the class whose last kernel ended just before its own began (same queue: back to back),
+    // otherwise it opens a class of its own (its kernel began while every class's last kernel was still running: another queue)
+    int order[NS], n_g = 0, grp_of[NS], rep[NS];
+    long long last_end[NS];
+    for (int i = 0; i < NS; i++) order[i] = i;
+    std::sort(order, order + NS, [&](int a, int b) { return h[2 * a] < h[2 * b]; });
+    for (int k = 0; k < NS; k++) {
+        const int i = order[k];
+        const long long st = (long long)h[2 * i], en = (long long)h[2 * i + 1];
+        if (en - st < ticks / 2) return;                          // (the clock did not run as expected: leave the classes unknown)
+        int g = -1;
+        for (int x = 0; x < n_g; x++) if (last_end[x] <= st && (g < 0 || last_end[x] > last_end[g])) g = x;
+        if (g < 0) { g = n_g++; rep[g] = -1; }
+        if (rep[g] < 0 && i < 12) rep[g] = i;                     // (the class's first SIDE stream)
+        grp_of[i] = g; last_end[g] = en;
+    }
+    if (bm2_knob("BM2_QUEUE_PROBE_LOG", 0)) {
+        fprintf(stderr, "[bm2] hardware-queue classes of the side streams as made (main stream: %d; %d classes):", grp_of[12], n_g);
+        for (int i = 0; i < 12; i++) fprintf(stderr, " %d", grp_of[i]);
+        fprintf(stderr, "\n");
+    }
+    // The launchers address the side streams by fixed small numbers (seeding 0-2, chaining 1-6 and 10-11, an extension phase 0-9) and count on different
+    // numbers meaning different queues, none of them the main stream's (k_bwd and k_postfilter_heavy run ON the main stream beside side launches): ONE
+    // stream of every queue class first -- the main stream's class last of those --, the streams that double a queue behind them.
+    hipStream_t st[12]; int grp[12], n = 0;
+    bool taken[12] = {};
+    for (int pass = 0; pass < 2; pass++)
+        for (int g = 0; g < n_g; g++) {
+            if ((g == grp_of[12]) != (pass == 1) || rep[g] < 0) continue;
+            st[n] = c->side_stream[rep[g]]; grp[n] = g; taken[rep[g]] = true; c->group_rep[g] = n; n++;
+        }
+    for (int i = 0; i < 12; i++) if (!taken[i]) { st[n] = c->side_stream[i]; grp[n] = grp_of[i]; n++; }
+    for (int i = 0; i < 12; i++) { c->side_stream[i] = st[i]; c->side_group[i] = grp[i]; }
+    c->n_side_groups = n_g;
+#endif
+}
 // The side streams of the fork / join launches (seeding, chaining, extension) exist only in contexts that run those stages: a process has
 // GPU_MAX_HW_QUEUES hardware queues, its streams share them round-robin, and whatever is queued behind a long kernel on its queue waits for
 // it -- a context that only runs the SAM tail's batches (one stream) must not dilute the queues of the contexts that run the hot path.
@@ -218,6 +282,7 @@ int bm2_side_streams(bm2_ctx *c) {
         }
         if (!c->ev_join[i] && bm2_check(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming), "hipEventCreate")) { c->ev_join[i] = nullptr; return BM2_ENODEV; }
     }
+    probe_side_queues(c);
     c->side_ready = true;
     return BM2_OK;
 }

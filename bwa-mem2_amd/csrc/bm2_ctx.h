@@ -49,6 +49,10 @@ struct bm2_ctx {
     hipStream_t side_stream[12] = {};
     hipEvent_t ev_fork = nullptr, ev_join[12] = {};
     bool side_ready = false;                                      // every side stream and its events exist (bm2_side_streams)
+    // Which side streams share a HARDWARE QUEUE (two launches on one queue run one after the other, whatever their streams): measured when the streams
+    // are made (bm2_side_streams: a spinning one-lane kernel on every stream at once, the ones whose intervals do not overlap sit on one queue).
+    // side_group[i] = the queue class of side stream i, group_rep[g] = the first stream of class g; n_side_groups = 0: not known (every stream its own).
+    int side_group[12] = {}, group_rep[12] = {}, n_side_groups = 0;
     // what the extension stage of the last batch saw (page-locked; written by an asynchronous copy at the end of the stage): per phase the
     // seeds of every LDS class and the reads left pending.  The next batch sizes its launches and picks its number of lazy rounds with it.
 #define BM2_EXT_PHASES 8
