@@ -334,7 +334,7 @@ def main():
         dominant = max(stage_ms, key=stage_ms.get) if stage_ms else None
         traffic, pmc_src = None, None                        # HBM bytes per k_bwd launch from the committed PMC passes, same workload only
         ext_pmc = None
-        for fn in ("r05_k_bwd_pmc.json", "r04_k_bwd_pmc.json", "r03_k_bwd_pmc.json", "r02_k_bwd_pmc.json", "r01_k_bwd_pmc.json"):
+        for fn in ("r06_k_bwd_pmc.json", "r05_k_bwd_pmc.json", "r04_k_bwd_pmc.json", "r03_k_bwd_pmc.json", "r02_k_bwd_pmc.json", "r01_k_bwd_pmc.json"):
             try:
                 pm = json.load(open(os.path.join(ROOT, "profiles", fn)))
                 wl = pm["workload"]
@@ -355,7 +355,7 @@ def main():
         ext_src = None
         # SQ counter passes of the extension stage (tools/pmc_to_profiles.py), the newest committed one OF THIS WORKLOAD (a pass of the 150 bp
         # workload says nothing about the kernels a 10 kb chunk runs)
-        for fn in (("r05_ont2d_ext_pmc_sq.json", "r04_ont2d_ext_pmc_sq.json") if ont else ("r05_ext_pmc_sq.json", "r04_ext_pmc_sq.json", "r03_ext_pmc_sq.json", "r02_ext_pmc_sq.json")):
+        for fn in (("r05_ont2d_ext_pmc_sq.json", "r04_ont2d_ext_pmc_sq.json") if ont else ("r06_ext_pmc_sq.json", "r05_ext_pmc_sq.json", "r04_ext_pmc_sq.json", "r03_ext_pmc_sq.json", "r02_ext_pmc_sq.json")):
             try:
                 ext_pmc = json.load(open(os.path.join(ROOT, "profiles", fn)))
                 ext_src = "profiles/" + fn
