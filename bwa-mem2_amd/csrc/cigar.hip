@@ -95,10 +95,18 @@ static __device__ __forceinline__ void cg_nm_md(const uint32_t *cg, int ncg, QF 
     for (int k = 0; k < ncg; ++k) {
         const int op = cg[k] & 0xf, len = (int)(cg[k] >> 4);
         if (op == 0) {
-            for (int i = 0; i < len; ++i) {
-                const int rb_ = RF(y + i);
-                if (Q(x + i) != rb_) { nmd = put_dec(md, nmd, u); md[nmd++] = int2base[rb_]; ++n_mm; u = 0; }
-                else ++u;
+            for (int i0 = 0; i0 < len; i0 += 8) {                  // (eight reference bases requested together: see k_cigar_flat)
+                int tv[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) tv[k] = RF(y + (i0 + k < len ? i0 + k : len - 1));
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    if (i0 + k < len) {
+                        const int rb_ = tv[k];
+                        if (Q(x + i0 + k) != rb_) { nmd = put_dec(md, nmd, u); md[nmd++] = int2base[rb_]; ++n_mm; u = 0; }
+                        else ++u;
+                    }
+                }
             }
             x += len; y += len;
         } else if (op == 2) {
@@ -131,11 +139,26 @@ k_cigar_flat(RefPtr ref, const uint8_t *__restrict__ seqs, const CigarTask *__re
     char *md = mdbuf + T.md_off;
     const char *int2base = rev ? "TGCAN" : "ACGTN";
     int sc = 0, u = 0, n_mm = 0, nmd = 0;
-    for (int i = 0; i < lq; ++i) {                              // both in alignment order (reversed for a hit on the reverse strand)
-        const int t = rev ? ref[T.re - 1 - i] : ref[T.rb + i], q = (rev ? qp[lq - 1 - i] : qp[i]) & 15;
-        sc += cg_score(t, q, s_match, s_mis, s_amb);
-        if (q != t) { nmd = put_dec(md, nmd, u); md[nmd++] = int2base[t]; ++n_mm; u = 0; }
-        else ++u;
+    // both in alignment order (reversed for a hit on the reverse strand).  EIGHT positions at a time: their sixteen loads are requested before the first is
+    // looked at -- the MD bytes a mismatch stores may alias anything a load reads, so the compiler keeps the one-position loop's loads in order, each a
+    // round trip of its own (the kernel waited in 69 % of its wave cycles and issued VALU in 2 %: profiles/r06f_tail_kernels_pmc_sq.md)
+    for (int i0 = 0; i0 < lq; i0 += 8) {
+        int tv[8], qv[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = i0 + k < lq ? i0 + k : lq - 1;
+            tv[k] = rev ? ref[T.re - 1 - i] : ref[T.rb + i];
+            qv[k] = (rev ? qp[lq - 1 - i] : qp[i]) & 15;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (i0 + k < lq) {
+                const int t = tv[k], q = qv[k];
+                sc += cg_score(t, q, s_match, s_mis, s_amb);
+                if (q != t) { nmd = put_dec(md, nmd, u); md[nmd++] = int2base[t]; ++n_mm; u = 0; }
+                else ++u;
+            }
+        }
     }
     nmd = put_dec(md, nmd, u);
     md[nmd] = 0;

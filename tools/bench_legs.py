@@ -476,7 +476,10 @@ def end_to_end(ctx, bm2, texts, opt, paired, n_threads, n_tail=None, limit_s=Non
     # (the stages do not all compute at once -- a tail worker waits for its device batches, the reader for a free queue slot -- so the
     #  counts add up to somewhat more than the CPUs: the split below is the best of profiles/r03f's variants)
     n_parse = int(os.environ.get("BM2_E2E_PARSE_THREADS", max(1, min((3 * hw) // 8, 32))))
-    so = bm2.default_sam_opt(n_threads=int(os.environ.get("BM2_E2E_TAIL_THREADS", n_threads or max((hw - 1) // n_tail, 1))))
+    # (threads per tail worker: a worker's threads sleep through its device batches -- rescue SW, CIGAR -- and while the writer copies, so the workers
+    #  together hold 4/3 of the CPUs: with three workers on the 16-CPU box 5 threads each gave 10.9-11.0 M reads/s over 100 chunks, 6: 12.0-12.3, 7: 12.7,
+    #  8: 12.5; four workers x 6: 12.3, two x 9: 10.5 -- profiles/r06j_*, r06k_*)
+    so = bm2.default_sam_opt(n_threads=int(os.environ.get("BM2_E2E_TAIL_THREADS", n_threads or max((hw * 4 // 3) // n_tail, 1))))
     q_parsed, q_hits = [queue.Queue(maxsize=2) for _ in range(n_dev)], [queue.Queue(maxsize=1) for _ in range(n_tail)]
     busy, dyn_threads = [0], os.environ.get("BM2_E2E_DYN_THREADS", "1") != "0"
     last = [None] * n_tail
