@@ -58,11 +58,16 @@ static __host__ __device__ inline int cigar_first_band(int lq, int rlen, int tru
     return w2;
 }
 
-static __device__ int put_dec(char *s, int n, int v) {          // kputw: plain decimal
-    char t[12]; int l = 0;
-    if (v == 0) t[l++] = '0';
-    while (v > 0) { t[l++] = (char)('0' + v % 10); v /= 10; }
-    while (l > 0) s[n++] = t[--l];
+// kputw: plain decimal of v >= 0.  Digits by CONSTANT divisors, most significant first (the digit buffer of the obvious form -- fill backwards, copy
+// forwards -- is a local array under a run-time index: the compiler kept its twelve bytes in registers behind a select chain, ~60 VALU instructions per
+// digit, in every inlined copy)
+static __device__ int put_dec(char *s, int n, int v) {
+    bool lead = false;
+#define PUT_DIGIT(P) { const int d = v / (P); if (lead || d) { s[n++] = (char)('0' + d); v -= d * (P); lead = true; } }
+    if (v >= 100000) { PUT_DIGIT(1000000000) PUT_DIGIT(100000000) PUT_DIGIT(10000000) PUT_DIGIT(1000000) PUT_DIGIT(100000) }      // (MD run lengths and CIGAR lengths of reads below 32768 bases never come here)
+    PUT_DIGIT(10000) PUT_DIGIT(1000) PUT_DIGIT(100) PUT_DIGIT(10)
+#undef PUT_DIGIT
+    s[n++] = (char)('0' + v);
     return n;
 }
 
@@ -96,16 +101,15 @@ static __device__ __forceinline__ void cg_nm_md(const uint32_t *cg, int ncg, QF 
         const int op = cg[k] & 0xf, len = (int)(cg[k] >> 4);
         if (op == 0) {
             for (int i0 = 0; i0 < len; i0 += 8) {                  // (eight reference bases requested together: see k_cigar_flat)
-                int tv[8];
+                uint32_t tw = 0;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) tv[k] = RF(y + (i0 + k < len ? i0 + k : len - 1));
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    if (i0 + k < len) {
-                        const int rb_ = tv[k];
-                        if (Q(x + i0 + k) != rb_) { nmd = put_dec(md, nmd, u); md[nmd++] = int2base[rb_]; ++n_mm; u = 0; }
-                        else ++u;
-                    }
+                for (int k = 0; k < 8; ++k) tw |= (uint32_t)RF(y + (i0 + k < len ? i0 + k : len - 1)) << (4 * k);
+                const int nk = len - i0 < 8 ? len - i0 : 8;
+#pragma nounroll
+                for (int k = 0; k < nk; ++k, tw >>= 4) {
+                    const int rb_ = (int)(tw & 15u);
+                    if (Q(x + i0 + k) != rb_) { nmd = put_dec(md, nmd, u); md[nmd++] = int2base[rb_]; ++n_mm; u = 0; }
+                    else ++u;
                 }
             }
             x += len; y += len;
@@ -143,21 +147,20 @@ k_cigar_flat(RefPtr ref, const uint8_t *__restrict__ seqs, const CigarTask *__re
     // looked at -- the MD bytes a mismatch stores may alias anything a load reads, so the compiler keeps the one-position loop's loads in order, each a
     // round trip of its own (the kernel waited in 69 % of its wave cycles and issued VALU in 2 %: profiles/r06f_tail_kernels_pmc_sq.md)
     for (int i0 = 0; i0 < lq; i0 += 8) {
-        int tv[8], qv[8];
+        uint32_t tw = 0, qw = 0;                                // four bits per position
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int i = i0 + k < lq ? i0 + k : lq - 1;
-            tv[k] = rev ? ref[T.re - 1 - i] : ref[T.rb + i];
-            qv[k] = (rev ? qp[lq - 1 - i] : qp[i]) & 15;
+            tw |= (uint32_t)(rev ? ref[T.re - 1 - i] : ref[T.rb + i]) << (4 * k);
+            qw |= (uint32_t)((rev ? qp[lq - 1 - i] : qp[i]) & 15) << (4 * k);
         }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            if (i0 + k < lq) {
-                const int t = tv[k], q = qv[k];
-                sc += cg_score(t, q, s_match, s_mis, s_amb);
-                if (q != t) { nmd = put_dec(md, nmd, u); md[nmd++] = int2base[t]; ++n_mm; u = 0; }
-                else ++u;
-            }
+        const int nk = lq - i0 < 8 ? lq - i0 : 8;
+#pragma nounroll
+        for (int k = 0; k < nk; ++k, tw >>= 4, qw >>= 4) {
+            const int t = (int)(tw & 15u), q = (int)(qw & 15u);
+            sc += cg_score(t, q, s_match, s_mis, s_amb);
+            if (q != t) { nmd = put_dec(md, nmd, u); md[nmd++] = int2base[t]; ++n_mm; u = 0; }
+            else ++u;
         }
     }
     nmd = put_dec(md, nmd, u);
@@ -243,11 +246,27 @@ k_gen_cigar(RefPtr ref, const uint8_t *__restrict__ seqs, const CigarTask *__res
                 int h1 = beg == 0 ? -(prm.o_del + e_del * (i + 1)) : MINF;
                 uint32_t *zi = (uint32_t *)(z + (int64_t)i * n_col);
                 uint32_t zacc = 0;
+                // LDS shapes: the row word of the NEXT column is requested before this column is computed (a column is written by its own cell only, so the
+                // request may pass the store), and the query's 4-bit codes come eight to a register, shifted along -- with both reads asked for and waited
+                // for inside every cell the ring kernel issued VALU in 31 % of its wave cycles and waited in 50 (profiles/r06f_tail_kernels_pmc_sq.md)
+                uint32_t w_next = 0, q_word = 0;
+                if (LDS && beg < end) {
+                    w_next = EH[(RING ? (beg & (CG_RING - 1)) : beg) * 64 + lane];
+                    q_word = Q4[(beg >> 3) * 64 + lane] >> (4 * (beg & 7));
+                }
                 for (j = beg; j < end; ++j) {
-                    const int2 p = eh_get(j);
+                    int2 p; int qj;
+                    if (LDS) {
+                        const uint32_t wv = w_next;
+                        w_next = EH[(RING ? ((j + 1) & (CG_RING - 1)) : j + 1) * 64 + lane];      // (column `end` exists in both shapes)
+                        p = make_int2((int)(int16_t)(wv & 0xffffu), (int)wv >> 16);
+                        qj = (int)(q_word & 15u);
+                        q_word >>= 4;
+                        if (((j + 1) & 7) == 0 && j + 1 < lq) q_word = Q4[((j + 1) >> 3) * 64 + lane];
+                    } else { p = eh_get(j); qj = Q(j); }
                     int m = p.x, e = p.y, h, t;
                     uint8_t d;
-                    m += cg_score(tb, Q(j), s_match, s_mis, s_amb);
+                    m += cg_score(tb, qj, s_match, s_mis, s_amb);
                     d = m >= e ? 0 : 1;
                     h = m >= e ? m : e;
                     d = h >= f ? d : 2;
