@@ -86,11 +86,14 @@ def test_bsw_long_queries_in_the_sliding_register_window(gpu_ctx_factory):
         _check(ctx, tr, oracle.default_opt(**opts), bm2.default_opt(**opts), w, 0 if opts else 5)
 
 
-def test_bsw_batch_sorted_onto_the_lane_kernel(gpu_ctx_factory, monkeypatch):
+@pytest.mark.parametrize("reg_qmin", [None, "0", "64"], ids=["rows_default", "rows_in_lds", "rows_in_registers_from_64"])
+def test_bsw_batch_sorted_onto_the_lane_kernel(gpu_ctx_factory, monkeypatch, reg_qmin):
     # S1 batches of >= BM2_BSW_LANES_MIN pairs are sorted on the device by (query length, target length): pairs whose query fits the lane
     # kernel's rows and whose scores fit 8-bit cells run one per LANE (the shape of getScores8 / getScores16), the others one per wavefront.
     # Same six numbers either way, in the caller's order.  (threshold lowered so that the host emulator can run it)
     monkeypatch.setenv("BM2_BSW_LANES_MIN", "64")
+    if reg_qmin is not None:                                     # the classes whose rows live in registers (k_bsw_lanes<NG>, lane_dp8r): default from 96 columns
+        monkeypatch.setenv("BM2_BSW_REG_QMIN", reg_qmin)
     ctx = gpu_ctx_factory()
     tr = random_pairs(61, 500, max_len=150, h0_max=100) + random_pairs(62, 60, max_len=400, h0_max=300) + random_pairs(63, 100, max_len=12, h0_max=250)
     _check(ctx, tr, oracle.default_opt(), bm2.default_opt(), 100, 5)
