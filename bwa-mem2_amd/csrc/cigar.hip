@@ -216,6 +216,8 @@ k_gen_cigar(RefPtr ref, const uint8_t *__restrict__ seqs, const CigarTask *__res
     // while the score keeps changing, stays more than a match below the hit's score, and the band has not reached 4 w
     int w_try = T.retry ? cigar_first_band(lq, rlen, T.truesc, T.w, prm.a, prm.w, prm.o_del, prm.e_del, prm.o_ins, prm.e_ins) : T.w;
     int last_sc = -(1 << 30), attempt = 0;
+    const bool dbg_no_z = (resume & 2) != 0;                   // BM2_CIGAR_DBG_NOZ=1: a TIMING EXPERIMENT (the direction stores left out: results are wrong)
+    resume &= 1;
     if (resume) { const CigarRes P = res[id]; last_sc = P.score; w_try = P.nm; attempt = P.md_len; }      // (a deferred task: where the RING kernel left its loop)
     for (;;) {
         if (T.retry) w_try = w_try < prm.w << 2 ? w_try : prm.w << 2;
@@ -281,9 +283,9 @@ k_gen_cigar(RefPtr ref, const uint8_t *__restrict__ seqs, const CigarTask *__res
                     f = f > t ? f : t;
                     const int c = j - beg;
                     zacc |= (uint32_t)d << (8 * (c & 3));
-                    if ((c & 3) == 3) { zi[c >> 2] = zacc; zacc = 0; }
+                    if ((c & 3) == 3) { if (!dbg_no_z) zi[c >> 2] = zacc; zacc = 0; }
                 }
-                if ((end - beg) & 3) zi[(end - beg) >> 2] = zacc;
+                if (((end - beg) & 3) && !dbg_no_z) zi[(end - beg) >> 2] = zacc;
                 eh_set(end, h1, MINF);
                 if (end == lq) h_lq = h1;
             }
@@ -463,7 +465,7 @@ static int cigar_run(bm2_ctx *c, const bm2_opt *opt, std::vector<CigarTask> &tas
     // (the costliest tasks lead every list; the four launches follow each other on the stream, the cheap flat tasks last)
     if (n_shape[SH_RING])
         hipLaunchKernelGGL(k_gen_cigar<CG_RINGED>, dim3((n_shape[SH_RING] + 63) / 64), dim3(64), lds_ring, s, c->ix.ref(0), (const uint8_t *)b_seq.p, d_task, o_ring,
-                           n_shape[SH_RING], prm, d_z, d_eh, d_cg, d_md, d_res, qmax, 0, d_defer + 1, d_defer);
+                           n_shape[SH_RING], prm, d_z, d_eh, d_cg, d_md, d_res, qmax, bm2_knob("BM2_CIGAR_DBG_NOZ", 0) ? 2 : 0, d_defer + 1, d_defer);
     if (n_shape[SH_ROW])
         hipLaunchKernelGGL(k_gen_cigar<CG_ROW>, dim3((n_shape[SH_ROW] + 63) / 64), dim3(64), lds_row, s, c->ix.ref(0), (const uint8_t *)b_seq.p, d_task, o_row,
                            n_shape[SH_ROW], prm, d_z, d_eh, d_cg, d_md, d_res, qmax, 0, (int *)nullptr, (int *)nullptr);
