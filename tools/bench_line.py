@@ -137,6 +137,7 @@ def compact(full, full_path=None):
         if c5.get("value"):
             p5 = c5.get("parity") or {}
             out["config5"] = {"value": c5["value"], "unit": c5.get("unit"), "reads_per_step": (c5.get("config") or {}).get("reads_per_gpu_per_step"), "steps": c5.get("steps"),
+                              "reads_in_run": (c5.get("config") or {}).get("steps_cover_reads"),
                               "ms_per_step": c5.get("ms_per_step"), "regs_equal": p5.get("regs_equal"), "fin_equal": p5.get("fin_equal"), "sam_equal": p5.get("sam_equal"),
                               "gate_reads": p5.get("reads"), "cpu_reads_per_s": (c5.get("cpu_baseline") or {}).get("value"), "exit_code": c5.get("exit_code")}
         else:
