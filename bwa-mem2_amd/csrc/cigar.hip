@@ -81,6 +81,9 @@ static __device__ int put_dec(char *s, int n, int v) {
 //          retry loop runs here; a task that has to try a wider band (rare) is put on a list and goes through the ROW kernel afterwards.
 //   ROW    the full row in LDS, 16 + 16 bits per column (small scores, any band); also the later tries of deferred tasks.
 //   GLOBAL the row in the task's slice of a global scratch buffer, 32 + 32 bits (anything else).
+// (Measured in round 6, profiles/r06n_*, r06o_*: the ring kernel -- 8 ms per million-read chunk, VALU issue in 31 % of its wave cycles -- is NOT waiting for its scattered
+//  direction stores (left out: 8.7 -> 8.3 ms), nor for the LDS round trip of a cell (the row word requested a column ahead: no change), nor for wavefronts per CU
+//  (rings of 16 / 32 / 64 columns by band, 9 / 13 / 21 KB per wavefront: 16.1 -> 17.4 ms per 2 M-read chunk, not kept): a lane's ~50 instructions per cell are one dependent chain.)
 // In the LDS shapes "minus infinity" is -22768 instead of -2^30 without changing a single comparison (every DP value is either a real
 // score or ONE sentinel plus an offset the reference has too; the two families never meet).  The query sits in LDS 4 bits per base.
 // Scores are computed, not looked up: (match, mismatch, ambiguous) = (mat[0], mat[1], mat[4]) -- the bwa_fill_scmat form the host checks.
@@ -174,12 +177,11 @@ template <int MODE>
 __global__ void __launch_bounds__(64)
 k_gen_cigar(RefPtr ref, const uint8_t *__restrict__ seqs, const CigarTask *__restrict__ tasks, const int *__restrict__ order,
             int n, CigarPrm prm, uint8_t *__restrict__ zbuf, int2 *__restrict__ ehbuf, uint32_t *__restrict__ cgbuf, char *__restrict__ mdbuf,
-            CigarRes *__restrict__ res, int qmax, int resume, int *__restrict__ defer_list, int *__restrict__ defer_count, int rcols) {
+            CigarRes *__restrict__ res, int qmax, int resume, int *__restrict__ defer_list, int *__restrict__ defer_count) {
     constexpr bool LDS = MODE != CG_GLOBAL, RING = MODE == CG_RINGED;
     extern __shared__ __attribute__((aligned(16))) uint32_t cg_lds[];
-    uint32_t *EH = cg_lds;                                      // ROW: [(qmax + 1)][64]; RING: [rcols][64], rcols = 16, 32 or 64 (the launch's band class)
-    uint32_t *Q4 = cg_lds + (size_t)(RING ? rcols : qmax + 1) * 64;        // [(qmax + 7) / 8][64]: 8 bases of 4 bits
-    const int rmask = rcols - 1;
+    uint32_t *EH = cg_lds;                                      // ROW: [(qmax + 1)][64]; RING: [64][64]
+    uint32_t *Q4 = cg_lds + (size_t)(RING ? CG_RING : qmax + 1) * 64;        // [(qmax + 7) / 8][64]: 8 bases of 4 bits
     const int lane = threadIdx.x;
     constexpr int MINF = LDS ? CG_MINF16 : CG_MINUS_INF;
     const int slot = blockIdx.x * blockDim.x + threadIdx.x;
@@ -204,12 +206,12 @@ k_gen_cigar(RefPtr ref, const uint8_t *__restrict__ seqs, const CigarTask *__res
     int2 *ehg = ehbuf + T.eh_off;                               // .x = h, .y = e (global version)
     auto eh_get = [&](int j) -> int2 {
         if (!LDS) return ehg[j];
-        const uint32_t w = EH[(RING ? (j & rmask) : j) * 64 + lane];
+        const uint32_t w = EH[(RING ? (j & (CG_RING - 1)) : j) * 64 + lane];
         return make_int2((int)(int16_t)(w & 0xffffu), (int)w >> 16);
     };
     auto eh_set = [&](int j, int h, int e) {
         if (!LDS) ehg[j] = make_int2(h, e);
-        else EH[(RING ? (j & rmask) : j) * 64 + lane] = ((uint32_t)h & 0xffffu) | (uint32_t)e << 16;
+        else EH[(RING ? (j & (CG_RING - 1)) : j) * 64 + lane] = ((uint32_t)h & 0xffffu) | (uint32_t)e << 16;
     };
     uint32_t *cg = cgbuf + T.cg_off;
     int ncg = 0;
@@ -217,8 +219,6 @@ k_gen_cigar(RefPtr ref, const uint8_t *__restrict__ seqs, const CigarTask *__res
     // while the score keeps changing, stays more than a match below the hit's score, and the band has not reached 4 w
     int w_try = T.retry ? cigar_first_band(lq, rlen, T.truesc, T.w, prm.a, prm.w, prm.o_del, prm.e_del, prm.o_ins, prm.e_ins) : T.w;
     int last_sc = -(1 << 30), attempt = 0;
-    const bool dbg_no_z = (resume & 2) != 0;                   // BM2_CIGAR_DBG_NOZ=1: a TIMING EXPERIMENT (the direction stores left out: results are wrong)
-    resume &= 1;
     if (resume) { const CigarRes P = res[id]; last_sc = P.score; w_try = P.nm; attempt = P.md_len; }      // (a deferred task: where the RING kernel left its loop)
     for (;;) {
         if (T.retry) w_try = w_try < prm.w << 2 ? w_try : prm.w << 2;
@@ -254,14 +254,14 @@ k_gen_cigar(RefPtr ref, const uint8_t *__restrict__ seqs, const CigarTask *__res
                 // for inside every cell the ring kernel issued VALU in 31 % of its wave cycles and waited in 50 (profiles/r06f_tail_kernels_pmc_sq.md)
                 uint32_t w_next = 0, q_word = 0;
                 if (LDS && beg < end) {
-                    w_next = EH[(RING ? (beg & rmask) : beg) * 64 + lane];
+                    w_next = EH[(RING ? (beg & (CG_RING - 1)) : beg) * 64 + lane];
                     q_word = Q4[(beg >> 3) * 64 + lane] >> (4 * (beg & 7));
                 }
                 for (j = beg; j < end; ++j) {
                     int2 p; int qj;
                     if (LDS) {
                         const uint32_t wv = w_next;
-                        w_next = EH[(RING ? ((j + 1) & rmask) : j + 1) * 64 + lane];      // (column `end` exists in both shapes)
+                        w_next = EH[(RING ? ((j + 1) & (CG_RING - 1)) : j + 1) * 64 + lane];      // (column `end` exists in both shapes)
                         p = make_int2((int)(int16_t)(wv & 0xffffu), (int)wv >> 16);
                         qj = (int)(q_word & 15u);
                         q_word >>= 4;
@@ -284,9 +284,9 @@ k_gen_cigar(RefPtr ref, const uint8_t *__restrict__ seqs, const CigarTask *__res
                     f = f > t ? f : t;
                     const int c = j - beg;
                     zacc |= (uint32_t)d << (8 * (c & 3));
-                    if ((c & 3) == 3) { if (!dbg_no_z) zi[c >> 2] = zacc; zacc = 0; }
+                    if ((c & 3) == 3) { zi[c >> 2] = zacc; zacc = 0; }
                 }
-                if (((end - beg) & 3) && !dbg_no_z) zi[(end - beg) >> 2] = zacc;
+                if ((end - beg) & 3) zi[(end - beg) >> 2] = zacc;
                 eh_set(end, h1, MINF);
                 if (end == lq) h_lq = h1;
             }
@@ -408,10 +408,8 @@ static int cigar_run(bm2_ctx *c, const bm2_opt *opt, std::vector<CigarTask> &tas
     prof.mark("slices");
     // lanes of a wavefront run their tasks side by side: neighbours should be of one shape (see k_gen_cigar) and cost alike.  Counting sort by
     // (shape, cost on a log scale, expensive first); the order array is the four shapes' task lists one after the other.
-    // (the ring comes in three sizes since round 6 -- bands that fit 16, 32 or 64 columns: most first tries of a 150 bp run have bands of 3..8, and with a
-    //  16-column ring a wavefront takes 9 KB of LDS instead of 21: the kernel is a dependent chain per lane, bound by the wavefronts a CU holds)
-    enum { SH_RING16 = 0, SH_RING32 = 1, SH_RING = 2, SH_ROW = 3, SH_GLOBAL = 4, SH_FLAT = 5, N_SH = 6 };
-    int n_shape[N_SH] = { 0, 0, 0, 0, 0, 0 }, qmax = 0;
+    enum { SH_RING = 0, SH_ROW = 1, SH_GLOBAL = 2, SH_FLAT = 3 };
+    int n_shape[4] = { 0, 0, 0, 0 }, qmax = 0;
     {
         int pen = 1;
         for (int a = 0; a < 25; ++a) pen = std::max(pen, abs((int)opt->mat[a]));
@@ -422,21 +420,19 @@ static int cigar_run(bm2_ctx *c, const bm2_opt *opt, std::vector<CigarTask> &tas
         auto shape = [&](int i) {
             if (cost[(size_t)i] == 0) return (int)SH_FLAT;       // (no DP area: the one-M case, or a NULL return)
             if (!small(i)) return (int)SH_GLOBAL;
-            const int need = 2 * (int)wb1[(size_t)i] + 2;
-            if (no_ring || need > CG_RING) return (int)SH_ROW;
-            return need <= 16 ? (int)SH_RING16 : need <= 32 ? (int)SH_RING32 : (int)SH_RING;
+            return (!no_ring && 2 * (int)wb1[(size_t)i] + 2 <= CG_RING) ? (int)SH_RING : (int)SH_ROW;
         };
         auto cls = [&](int i) { const int64_t v = cost[(size_t)i]; const int k = v > 0 ? 64 - __builtin_clzll((unsigned long long)v) : 0; return shape(i) * 64 + 63 - k; };
-        bm2_counting_order(n, N_SH * 64, host_threads, cls, order.data());
-        std::atomic<int> ns[N_SH], qm(0);
+        bm2_counting_order(n, 256, host_threads, cls, order.data());
+        std::atomic<int> ns[4], qm(0);
         for (auto &x : ns) x = 0;
         bm2_parallel_ranges(n, grain, host_threads, [&](int64_t lo, int64_t hi) {
-            int c[N_SH] = { 0, 0, 0, 0, 0, 0 }, q = 0;
-            for (int64_t i = lo; i < hi; ++i) { const int sh = shape((int)i); ++c[sh]; if (sh <= SH_ROW) q = std::max(q, tasks[(size_t)i].q_len); }
-            for (int k = 0; k < N_SH; ++k) ns[k] += c[k];
+            int c[4] = { 0, 0, 0, 0 }, q = 0;
+            for (int64_t i = lo; i < hi; ++i) { const int sh = shape((int)i); ++c[sh]; if (sh == SH_RING || sh == SH_ROW) q = std::max(q, tasks[(size_t)i].q_len); }
+            for (int k = 0; k < 4; ++k) ns[k] += c[k];
             for (int cur = qm.load(); q > cur && !qm.compare_exchange_weak(cur, q);) {}
         });
-        for (int k = 0; k < N_SH; ++k) n_shape[k] = ns[k].load();
+        for (int k = 0; k < 4; ++k) n_shape[k] = ns[k].load();
         qmax = qm.load();
     }
     prof.mark("order");
@@ -445,8 +441,7 @@ static int cigar_run(bm2_ctx *c, const bm2_opt *opt, std::vector<CigarTask> &tas
     const size_t task_bytes = ((size_t)n * sizeof(CigarTask) + 15) & ~(size_t)15, ord_bytes = ((size_t)n * sizeof(int) + 15) & ~(size_t)15;
     const size_t z_bytes = ((size_t)zo + 15) & ~(size_t)15, eh_bytes = (size_t)eo * sizeof(int2), cg_bytes = ((size_t)co * 4 + 15) & ~(size_t)15, md_bytes = ((size_t)mo + 15) & ~(size_t)15;
     const size_t res_bytes = ((size_t)n * sizeof(CigarRes) + 15) & ~(size_t)15, cnt_bytes = ((size_t)(n + 2) * 4 + 15) & ~(size_t)15, pos_bytes = (size_t)(n + 2) * 8;
-    const int n_ring_all = n_shape[SH_RING16] + n_shape[SH_RING32] + n_shape[SH_RING];
-    const size_t defer_bytes = ((size_t)(n_ring_all + 4) * 4 + 15) & ~(size_t)15;      // [0] = count, then the list
+    const size_t defer_bytes = ((size_t)(n_shape[SH_RING] + 4) * 4 + 15) & ~(size_t)15;      // [0] = count, then the list
     if ((rc = bm2_reserve(b_seq, (size_t)seq_bytes + 64))) return rc;
     if ((rc = bm2_reserve(b_task, task_bytes + ord_bytes + 64))) return rc;
     if ((rc = bm2_reserve(b_res, res_bytes + 2 * cnt_bytes + 2 * pos_bytes + defer_bytes + 64))) return rc;
@@ -464,39 +459,35 @@ static int cigar_run(bm2_ctx *c, const bm2_opt *opt, std::vector<CigarTask> &tas
     if (!rc) rc = bm2_copy_h2d(c, d_task, tasks.data(), (size_t)n * sizeof(CigarTask));
     if (!rc) rc = bm2_copy_h2d(c, d_order, order.data(), (size_t)n * sizeof(int));
     if (rc) return rc;
-    const size_t lds_q = (size_t)((qmax + 7) / 8) * 256, lds_row = (size_t)(qmax + 1) * 256 + lds_q;
+    const size_t lds_q = (size_t)((qmax + 7) / 8) * 256, lds_row = (size_t)(qmax + 1) * 256 + lds_q, lds_ring = (size_t)CG_RING * 256 + lds_q;
     if (lds_row > 64 * 1024 && (rc = bm2_check(hipFuncSetAttribute((const void *)k_gen_cigar<CG_ROW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_row), "hipFuncSetAttribute(k_gen_cigar)"))) return rc;
-    const int *o_ring16 = d_order, *o_ring32 = o_ring16 + n_shape[SH_RING16], *o_ring = o_ring32 + n_shape[SH_RING32], *o_row = o_ring + n_shape[SH_RING],
-              *o_glob = o_row + n_shape[SH_ROW], *o_flat = o_glob + n_shape[SH_GLOBAL];
+    const int *o_ring = d_order, *o_row = o_ring + n_shape[SH_RING], *o_glob = o_row + n_shape[SH_ROW], *o_flat = o_glob + n_shape[SH_GLOBAL];
     if ((rc = bm2_check(hipMemsetAsync(d_defer, 0, 4, s), "memset"))) return rc;
-    // (the costliest tasks lead every list; the launches follow each other on the stream, the widest rings first, the cheap flat tasks last)
-    const int dbg = bm2_knob("BM2_CIGAR_DBG_NOZ", 0) ? 2 : 0;
-    const struct { int n; const int *o; int cols; } rings[3] = { { n_shape[SH_RING], o_ring, 64 }, { n_shape[SH_RING32], o_ring32, 32 }, { n_shape[SH_RING16], o_ring16, 16 } };
-    for (const auto &rg : rings)
-        if (rg.n)
-            hipLaunchKernelGGL(k_gen_cigar<CG_RINGED>, dim3((rg.n + 63) / 64), dim3(64), (size_t)rg.cols * 256 + lds_q, s, c->ix.ref(0), (const uint8_t *)b_seq.p, d_task, rg.o,
-                               rg.n, prm, d_z, d_eh, d_cg, d_md, d_res, qmax, dbg, d_defer + 1, d_defer, rg.cols);
+    // (the costliest tasks lead every list; the four launches follow each other on the stream, the cheap flat tasks last)
+    if (n_shape[SH_RING])
+        hipLaunchKernelGGL(k_gen_cigar<CG_RINGED>, dim3((n_shape[SH_RING] + 63) / 64), dim3(64), lds_ring, s, c->ix.ref(0), (const uint8_t *)b_seq.p, d_task, o_ring,
+                           n_shape[SH_RING], prm, d_z, d_eh, d_cg, d_md, d_res, qmax, 0, d_defer + 1, d_defer);
     if (n_shape[SH_ROW])
         hipLaunchKernelGGL(k_gen_cigar<CG_ROW>, dim3((n_shape[SH_ROW] + 63) / 64), dim3(64), lds_row, s, c->ix.ref(0), (const uint8_t *)b_seq.p, d_task, o_row,
-                           n_shape[SH_ROW], prm, d_z, d_eh, d_cg, d_md, d_res, qmax, 0, (int *)nullptr, (int *)nullptr, 0);
+                           n_shape[SH_ROW], prm, d_z, d_eh, d_cg, d_md, d_res, qmax, 0, (int *)nullptr, (int *)nullptr);
     if (n_shape[SH_GLOBAL])
         hipLaunchKernelGGL(k_gen_cigar<CG_GLOBAL>, dim3((n_shape[SH_GLOBAL] + 63) / 64), dim3(64), 0, s, c->ix.ref(0), (const uint8_t *)b_seq.p, d_task, o_glob,
-                           n_shape[SH_GLOBAL], prm, d_z, d_eh, d_cg, d_md, d_res, 0, 0, (int *)nullptr, (int *)nullptr, 0);
+                           n_shape[SH_GLOBAL], prm, d_z, d_eh, d_cg, d_md, d_res, 0, 0, (int *)nullptr, (int *)nullptr);
     if (n_shape[SH_FLAT])
         hipLaunchKernelGGL(k_cigar_flat, dim3((n_shape[SH_FLAT] + 255) / 256), dim3(256), 0, s, c->ix.ref(0), (const uint8_t *)b_seq.p, d_task, o_flat,
                            n_shape[SH_FLAT], prm, d_cg, d_md, d_res);
     int n_defer = 0;
-    if (n_ring_all) {                                            // tasks whose first try asked for a wider band: their later tries in the ROW kernel
+    if (n_shape[SH_RING]) {                                      // tasks whose first try asked for a wider band: their later tries in the ROW kernel
         if ((rc = bm2_check(hipMemcpyAsync(&n_defer, d_defer, 4, hipMemcpyDeviceToHost, s), "D2H deferred"))) return rc;
         if ((rc = bm2_check(hipStreamSynchronize(s), "k_gen_cigar"))) return rc;
         if (n_defer > 0)
             hipLaunchKernelGGL(k_gen_cigar<CG_ROW>, dim3((n_defer + 63) / 64), dim3(64), lds_row, s, c->ix.ref(0), (const uint8_t *)b_seq.p, d_task, d_defer + 1,
-                               n_defer, prm, d_z, d_eh, d_cg, d_md, d_res, qmax, 1, (int *)nullptr, (int *)nullptr, 0);
+                               n_defer, prm, d_z, d_eh, d_cg, d_md, d_res, qmax, 1, (int *)nullptr, (int *)nullptr);
     }
     if ((rc = bm2_check(hipGetLastError(), "k_gen_cigar launch"))) return rc;
     if (prof.on) {
         (void)hipStreamSynchronize(s);
-        fprintf(stderr, "[tail] gen_cigar_dev  tasks by shape: ring %d / %d / %d of 16 / 32 / 64 columns (%d of them deferred to a wider band), row %d, global %d, flat %d\n", n_shape[SH_RING16], n_shape[SH_RING32], n_shape[SH_RING], n_defer,
+        fprintf(stderr, "[tail] gen_cigar_dev  tasks by shape: ring %d (%d of them deferred to a wider band), row %d, global %d, flat %d\n", n_shape[SH_RING], n_defer,
                 n_shape[SH_ROW], n_shape[SH_GLOBAL], n_shape[SH_FLAT]);
         prof.mark("H2D + kernel");
     }
