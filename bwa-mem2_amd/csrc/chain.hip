@@ -939,6 +939,28 @@ static __device__ void isl_build(const DevIndex &ix, const ChainParams &o, const
     if (dup) atomicAdd(s_dup, 1);
 }
 
+// l_rep of mem_chain_seeds (bwamem.cpp:849-861: the query bases covered by repetitive SMEMs, a union of intervals in SMEM order) by a converged wavefront:
+// 64 SMEMs are looked at per round, the repetitive ones -- a handful in a read, if any -- are merged in order from a ballot; every lane ends with the same sum.
+// (One lane walking the list paid a dependent load per SMEM: a long read has a thousand of them.  Written at the end of round 5 without a GPU, run in round 6:
+//  bit-exact -- the 1024-read gate and the long-read GPU tests -- and config 5's chaining stage 467 -> 463-477 ms, nothing either way: profiles/r06q_*.)
+static __device__ int lrep_coop(const bm2_smem_t *__restrict__ sm, int n_sm, int max_occ, int lane) {
+    int b = 0, e = 0, l_rep = 0;
+    for (int i0 = 0; i0 < n_sm; i0 += 64) {
+        const int i = i0 + lane;
+        int sb = 0, se = 0; bool rep = false;
+        if (i < n_sm) { rep = sm[i].s > max_occ; sb = (int)sm[i].m; se = (int)sm[i].n + 1; }
+        unsigned long long m = __ballot(rep);
+        while (m) {
+            const int src = __ffsll((long long)m) - 1;
+            m &= m - 1ULL;
+            const int xb = __shfl(sb, src), xe = __shfl(se, src);
+            if (xb > e) { l_rep += e - b; b = xb; e = xe; }
+            else e = e > xe ? e : xe;
+        }
+    }
+    return l_rep + (e - b);
+}
+
 // The list k_chain_islands (producer, any of its wavefronts' lane 0) hands to k_chain_serial (consumer, running BESIDE it on a stream of its own): a place is
 // drawn with an atomic, the read's number stored with release semantics behind everything the wavefront staged for it (the caller's isl_sync); the list is
 // memset to -1 before the launch, a consumer that drew place i waits for list[i] to turn up or for the last producer to leave (n_fallback[SER_DONE]).
@@ -1082,6 +1104,7 @@ k_chain_islands(DevIndex ix, ChainParams o, int n_reads, const int32_t *__restri
         isl_sync();
         ISL_TICK(5);
         // ---- the read
+        const int l_rep_all = lrep_coop(smems + so, n_sm, o.max_occ, lane);
         if (lane == 0) {
             if constexpr (COOP) df.valid = 0;
             if (s_dup) {                                             // chains with equal keys: the serial code on the read's slices
@@ -1097,14 +1120,7 @@ k_chain_islands(DevIndex ix, ChainParams o, int n_reads, const int32_t *__restri
             } else {
                 const int n_all = s_ntot;
                 if (n_chain0_out) n_chain0_out[r] = n_all;
-                int b = 0, e = 0, l_rep = 0;
-                for (int i = 0; i < n_sm; i++) {                     // l_rep, bwamem.cpp:849-861
-                    if (!(smems[so + i].s > o.max_occ)) continue;
-                    const int sb = (int)smems[so + i].m, se = (int)smems[so + i].n + 1;
-                    if (sb > e) { l_rep += e - b; b = sb; e = se; }
-                    else e = e > se ? e : se;
-                }
-                l_rep += e - b;
+                const int l_rep = l_rep_all;                         // l_rep, bwamem.cpp:849-861
                 int k = s_nsurv;
                 if (k == 0 && n_all > 0) { ord[0] = (int32_t)(s_min & 0xffffffULL); k = 1; }       // the a_[0] quirk: the chain with the smallest key
                 else if (k > 1) k_introsort_flat(k, ord, [&](int32_t x, int32_t y) { return ch[x].pos < ch[y].pos; });     // key order (the keys are distinct here)
@@ -1269,16 +1285,9 @@ k_chain_serial(DevIndex ix, ChainParams o, int n_reads, const int32_t *__restric
             k += __popcll(m);
         }
         if (k == 0 && n > 0) k = 1;      // quirk: an empty survivor list still processes the untouched a_[0] (bwamem.cpp:529-546)
+        const int l_rep = lrep_coop(smems + so, n_sm, o.max_occ, lane);      // l_rep, bwamem.cpp:849-861
         if (lane == 0) {
             if (n_chain0_out) n_chain0_out[r] = n;
-            int b = 0, e = 0, l_rep = 0;
-            for (int i = 0; i < n_sm; i++) {                         // l_rep, bwamem.cpp:849-861
-                if (!(smems[so + i].s > o.max_occ)) continue;
-                const int sb = (int)smems[so + i].m, se = (int)smems[so + i].n + 1;
-                if (sb > e) { l_rep += e - b; b = sb; e = se; }
-                else e = e > se ? e : se;
-            }
-            l_rep += e - b;
             df.r = r; df.n = k; df.base = base; df.frac_rep = (float)l_rep / len[r]; df.ch = ch; df.sd = sd; df.ord = ord; df.kept = (int32_t *)(nodes + base);
             df.valid = 1;
         }
