@@ -353,6 +353,9 @@ static __device__ void lane_dp8(bool run, int qlen, int tlen, int w, int h0, Ref
     if (run) { out.score = maxv; out.qle = max_j + 1; out.tle = max_i + 1; out.gtle = max_ie + 1; out.gscore = gscore; out.max_off = max_off; }
 }
 
+// (Measured in round 6 and removed, profiles/r06r_sweep_fast_groups.json: a ballot per group and UNTESTED cells for the groups that lie inside the band of every live lane of the
+//  wavefront -- bit-exact on the emulator, extension 14.46 -> 14.38 ms with the 128-column class on register rows, 15.21 -> 15.58 with every class on LDS rows, seam S1 805 -> 808
+//  G cells/s: the lane kernel does not wait for its band tests.)
 // The same rows again, the column loop in GROUPS OF FOUR columns -- one query word (four bases, one v_perm_b32 for their four scores) and two
 // row words per trip -- with the next group's three LDS words requested into a SECOND set of registers before the current group is computed
 // (two copies of the group body that hand the sets to each other: no register copy, and so no wait, between a request and its use one trip
@@ -361,42 +364,9 @@ static __device__ void lane_dp8(bool run, int qlen, int tlen, int w, int h0, Ref
 // the store it had just issued -- and every second trip with the same for the query word requested one instruction earlier.
 // LDS: rows [2 NG + 2][64] words, query [NG + 1][64] words, NG = (qmax + 3) / 4 (one group of slack for the request beyond the last group).
 struct Dp8Row { int h1, f, lnz; unsigned key, fnz_u; };
-// FAST: a group whose four columns lie inside the band of EVERY live lane of the wavefront (one ballot says so) runs its cells without the per-cell band
-// tests -- the lanes of a tile are sorted by geometry, most groups of a row are such -- and lanes that are not alive compute along on their own LDS columns
-// and registers, which nothing reads again.  The edges of the band's union keep the tested cells.
-template <bool FAST>
 static __device__ __forceinline__ void dp8_group(int g, uint32_t w0, uint32_t w1, uint32_t q, bool alive, int beg, int end, uint32_t t_lo, uint32_t t_hi,
                                                  int e_del, int e_ins, int oe_del, int oe_ins, uint32_t *EH, int lane, Dp8Row &r) {
     const int j0 = g << 2;
-    if (FAST && !__ballot(alive && !(j0 >= beg && j0 + 3 < end))) {
-        const uint32_t sc4 = __builtin_amdgcn_perm(t_hi, t_lo, q);
-        uint32_t word[2] = { w0, w1 };
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int j = j0 + u;
-            uint32_t &wd = word[u >> 1];
-            const int sh = 16 * (u & 1);
-            const int e = (int)((wd >> (sh + 8)) & 0xffu);
-            int M = (int)((wd >> sh) & 0xffu);
-            const int sc = (int)(int8_t)(sc4 >> (8 * u));
-            M = M ? M + sc : 0;
-            int h = M > e ? M : e;
-            h = h > r.f ? h : r.f;
-            const unsigned kj = (unsigned)h << 8 | (unsigned)j;
-            r.key = r.key > kj ? r.key : kj;
-            const int en = imax(isub0(e, e_del), M - oe_del);
-            r.f = imax(isub0(r.f, e_ins), M - oe_ins);
-            const uint32_t nw = (uint32_t)r.h1 | ((uint32_t)en << 8);
-            wd = (wd & ~(0xffffu << sh)) | nw << sh;
-            const int jj = nw ? j : -1;
-            r.lnz = r.lnz > jj ? r.lnz : jj;
-            r.fnz_u = r.fnz_u < (unsigned)jj ? r.fnz_u : (unsigned)jj;
-            r.h1 = h;
-        }
-        EH[(2 * g) * 64 + lane] = word[0];
-        EH[(2 * g + 1) * 64 + lane] = word[1];
-        return;
-    }
     if (alive && j0 + 3 >= beg && j0 < end) {
         const uint32_t sc4 = __builtin_amdgcn_perm(t_hi, t_lo, q);
         uint32_t word[2] = { w0, w1 };
@@ -429,7 +399,6 @@ static __device__ __forceinline__ void dp8_group(int g, uint32_t w0, uint32_t w1
     }
 }
 
-template <bool FAST>
 static __device__ void lane_dp8g(bool run, int qlen, int tlen, int w, int h0, RefPtr tp, int ts, const SwParams &P,
                                  uint32_t *EH, const uint32_t *QL, int lane, LaneOut &out, long long &cells, long long &iters) {
     const int o_del = P.o_del, e_del = P.e_del, o_ins = P.o_ins, e_ins = P.e_ins, oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
@@ -509,10 +478,10 @@ static __device__ void lane_dp8g(bool run, int qlen, int tlen, int w, int h0, Re
             uint32_t a0 = EH[(2 * g0) * 64 + lane], a1 = EH[(2 * g0 + 1) * 64 + lane], aq = QL[g0 * 64 + lane], b0, b1, bq;
             for (int g = g0;; g += 2) {
                 b0 = EH[(2 * g + 2) * 64 + lane]; b1 = EH[(2 * g + 3) * 64 + lane]; bq = QL[(g + 1) * 64 + lane];
-                dp8_group<FAST>(g, a0, a1, aq, alive, beg, end, t_lo, t_hi, e_del, e_ins, oe_del, oe_ins, EH, lane, r);
+                dp8_group(g, a0, a1, aq, alive, beg, end, t_lo, t_hi, e_del, e_ins, oe_del, oe_ins, EH, lane, r);
                 if (g + 1 >= g1) break;
                 a0 = EH[(2 * g + 4) * 64 + lane]; a1 = EH[(2 * g + 5) * 64 + lane]; aq = QL[(g + 2) * 64 + lane];
-                dp8_group<FAST>(g + 1, b0, b1, bq, alive, beg, end, t_lo, t_hi, e_del, e_ins, oe_del, oe_ins, EH, lane, r);
+                dp8_group(g + 1, b0, b1, bq, alive, beg, end, t_lo, t_hi, e_del, e_ins, oe_del, oe_ins, EH, lane, r);
                 if (g + 2 >= g1) break;
             }
         }
@@ -757,7 +726,7 @@ __global__ void __launch_bounds__(64)
 k_ext_seeds(DevIndex ix, ExtParams xp, const int32_t *__restrict__ tasks_all, const int64_t *__restrict__ start, int bin_lo, int bin_hi, int qmax,
             const uint8_t *__restrict__ enc, const int64_t *__restrict__ off, const int32_t *__restrict__ len,
             const int64_t *__restrict__ slot_base, const int32_t *__restrict__ reg_seed, const int32_t *__restrict__ reg_chain,
-            const DevChain *__restrict__ chn, const DevSeed *__restrict__ seeds, DevReg *regs, unsigned long long *counters, int rev, int fast) {
+            const DevChain *__restrict__ chn, const DevSeed *__restrict__ seeds, DevReg *regs, unsigned long long *counters, int rev) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_l[];
     uint32_t *EH = lds_l;                                       // [(qmax+1)][64]           (P8: [(qmax+2)/2][64])
     uint8_t *QL = (uint8_t *)(lds_l + (size_t)(qmax + 1) * 64); // [qmax][64] bytes
@@ -842,8 +811,7 @@ k_ext_seeds(DevIndex ix, ExtParams xp, const int32_t *__restrict__ tasks_all, co
                 if (!__ballot(run)) break;
                 const int w = xp.w << t;
                 const int wc = band_clamp(w, tg.len2, P, cls);
-                if (G4) { if (fast) lane_dp8g<true>(run, tg.len2, tg.len1, wc, h0, tg.t, tg.ts, P, EH, QL8, lane, o, cells, iters);
-                          else lane_dp8g<false>(run, tg.len2, tg.len1, wc, h0, tg.t, tg.ts, P, EH, QL8, lane, o, cells, iters); }
+                if (G4) lane_dp8g(run, tg.len2, tg.len1, wc, h0, tg.t, tg.ts, P, EH, QL8, lane, o, cells, iters);
                 else if (P8) lane_dp8<PF, PT>(run, tg.len2, tg.len1, wc, h0, tg.t, tg.ts, P, EH, QL8, lane, o, cells, iters);
                 else lane_dp(run, tg.len2, tg.len1, wc, h0, tg.t, tg.ts, P, EH, QL, lane, o, cells, iters);
                 if (run) {
@@ -1405,7 +1373,6 @@ struct ExtLaunch {
     // one seed per WAVEFRONT (k_ext_wave) beside the lane kernels.
     int wave_qmin, prefetch, rev, perm_scores, qmap, group4;
     int reg_qmin;                            // classes of queries up to at least this many bases keep their rows in registers (0: none)
-    int fast_groups;                         // lane_dp8g<FAST>: column groups inside every live lane's band run untested cells
     // the sorted seed list of the phase and where it lives
     const int32_t *tasks; const int64_t *start;
 };
@@ -1470,7 +1437,7 @@ static int run_phase(const ExtLaunch &L, const uint32_t *hint, int64_t ub) {
                                    L.enc, L.off, L.len, L.slot_base, L.reg_seed, L.reg_chain, L.chn, L.seeds, L.regs, L.counters, L.rev);
             } else
             hipLaunchKernelGGL(kern, dim3(grid_for(k, k + 1, 64)), dim3(64), lds_k, sk, c->ix, L.xp, L.tasks, L.start, k * EB_2D, (k + 1) * EB_2D, hi,
-                               L.enc, L.off, L.len, L.slot_base, L.reg_seed, L.reg_chain, L.chn, L.seeds, L.regs, L.counters, L.rev, L.fast_groups);
+                               L.enc, L.off, L.len, L.slot_base, L.reg_seed, L.reg_chain, L.chn, L.seeds, L.regs, L.counters, L.rev);
         } else {
             hipLaunchKernelGGL(k_ext_wave, dim3(grid_for(k_wave, N_CLS + 1, 4)), dim3(256), L.lds_w, sk, c->ix, L.xp, L.tasks, L.start, k_wave * EB_2D,
                                (int)N_EBINS, L.enc, L.off, L.len, L.slot_base, L.reg_seed, L.reg_chain, L.chn, L.seeds, L.regs, L.R, L.counters, L.rev);
@@ -1529,7 +1496,6 @@ int bm2_launch_extend(bm2_ctx *c, const bm2_opt &opt, const ChainParams &cp, int
     // CU and the register kernel pays a scalar test per group of its class, not of its band).  On seam S1 (one phase, a leaner kernel around the same
     // rows): 809 -> 1055 G cells/s from 96 bases up (r06c_bench_bsw_reg_qmin*.json).
     L.reg_qmin = bm2_knob("BM2_EXT_REG_QMIN", 128);
-    L.fast_groups = bm2_knob("BM2_EXT_FAST_GROUPS", 0);
     for (int k : { 0, 1, 4 }) if (opt.mat[k] < -128 || opt.mat[k] > 127) L.perm_scores = 0;     // (the score table holds signed bytes)
     const int lazy_max = bm2_knob("BM2_EXT_ROUNDS", LAZY_ROUNDS), pend_div = bm2_knob("BM2_EXT_PEND_DIV", 12);
     L.R = ring_size2(opt.w << (MAX_BAND_TRY - 1));
@@ -1629,7 +1595,7 @@ k_bsw_lanes(bm2_seqpair_t *pairs, const uint8_t *__restrict__ ref, const uint8_t
     const int n_tiles = (n_tasks + 63) >> 6;
     long long cells = 0, iters = 0;
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const int idx = ((rev & 1) ? n_tiles - 1 - tile : tile) * 64 + lane;
+        const int idx = (rev ? n_tiles - 1 - tile : tile) * 64 + lane;
         const bool valid = idx < n_tasks;
         int id = 0, len1 = 0, len2 = 0, h0 = 0;
         const uint8_t *q = qer, *t = ref;
@@ -1649,8 +1615,7 @@ k_bsw_lanes(bm2_seqpair_t *pairs, const uint8_t *__restrict__ ref, const uint8_t
         const int wc = band_clamp(w, len2, P, cls);
         LaneOut o; o.score = h0; o.qle = o.tle = o.gtle = 0; o.gscore = -1; o.max_off = 0;
         if constexpr (RG > 0) lane_dp8r<RG>(valid, len2, len1, wc, h0, RefPtr::bytes(t), 1, P, QR, o, cells, iters);
-        else if (rev & 2) lane_dp8g<true>(valid, len2, len1, wc, h0, RefPtr::bytes(t), 1, P, EH, QL8, lane, o, cells, iters);      // (bit 1 of `rev`: BM2_EXT_FAST_GROUPS)
-        else lane_dp8g<false>(valid, len2, len1, wc, h0, RefPtr::bytes(t), 1, P, EH, QL8, lane, o, cells, iters);
+        else lane_dp8g(valid, len2, len1, wc, h0, RefPtr::bytes(t), 1, P, EH, QL8, lane, o, cells, iters);
         if (valid) {
             bm2_seqpair_t *d = &pairs[id];
             d->score = o.score; d->tle = o.tle; d->gtle = o.gtle; d->qle = o.qle; d->gscore = o.gscore; d->max_off = o.max_off;
@@ -1710,7 +1675,7 @@ int bm2_launch_bsw_sorted(bm2_ctx *c, bm2_seqpair_t *d_pairs, const uint8_t *d_r
                 lds_k = 0;
                 kb = hi == 64 ? k_bsw_lanes<16> : hi == 80 ? k_bsw_lanes<20> : hi == 96 ? k_bsw_lanes<24> : hi == 112 ? k_bsw_lanes<28> : k_bsw_lanes<32>;
             }
-            hipLaunchKernelGGL(kb, dim3((unsigned)g), dim3(64), lds_k, sk, d_pairs, d_ref, d_qer, tasks, start, k * EB_2D, (k + 1) * EB_2D, hi, w, P, d_cells, 1 | (bm2_knob("BM2_EXT_FAST_GROUPS", 0) ? 2 : 0));
+            hipLaunchKernelGGL(kb, dim3((unsigned)g), dim3(64), lds_k, sk, d_pairs, d_ref, d_qer, tasks, start, k * EB_2D, (k + 1) * EB_2D, hi, w, P, d_cells, 1);
         } else {
             int64_t g = (cnt + 3) / 4; if (g < 1) g = 1; if (g > (1 << 20)) g = 1 << 20;
             if ((rc = bm2_launch_bsw_list(c, d_pairs, d_ref, d_qer, tasks, start, N_CLS * EB_2D, (int)N_EBINS, (unsigned)g, w, P, d_cells, sk))) return rc;

@@ -8,18 +8,7 @@ T0=$(date +%s)
 at() { echo "$1 rc=$2 at $(( $(date +%s) - T0 ))s"; }
 cd $R; export TMPDIR=/tmp
 timeout 400 python bench.py --steps 1 --warmup 1 --no-parity --no-cpu-baseline --no-e2e --no-side-workloads > /dev/null 2> $O/prep.err; at "genome + index" $?
-timeout 300 python tools/gpu/sweep.py $O --steps 4 --budget-s 100 --only "extension: untested cells" > $O/sweep.out 2> $O/sweep.err; at sweep $?
-grep "\[sweep\]" $O/sweep.err | python3 -c "
-import sys,re
-for l in sys.stdin:
-    m=re.search(r\"\[sweep\] (.*?): ([\d.]+) ms/step.*?'extend': ([\d.]+)\",l)
-    print((m.group(1)[-80:]+' '+m.group(2)+' extend '+m.group(3)) if m else l[:160].rstrip())
-"
-for f in 0 1; do
-  BM2_EXT_FAST_GROUPS=$f BM2_BSW_REG_QMIN=0 timeout 200 python bench.py --workload bsw --steps 5 --warmup 2 --no-binding-s1 --full-json $O/bench_bsw_fast$f.json > /dev/null 2> $O/bsw_fast$f.err; at "bsw fast=$f (LDS rows everywhere)" $?
-  python3 -c "import json; d=json.load(open('$O/bench_bsw_fast$f.json')); print('  FAST_GROUPS=$f', d['extend_kernel']['gcups'], d['parity']['pairs_equal'])"
-done
-for n in 2 4 8 3; do
+for n in ${SLOTS:-2 4 8 3}; do
   BM2_S1_CONTEXTS=$n timeout 400 python bench.py --workload bsw --steps 3 --warmup 1 --full-json $O/bench_bsw_slots$n.json > /dev/null 2> $O/bsw_slots$n.err; at "slots $n" $?
   python3 -c "
 import json; s=json.load(open('$O/bench_bsw_slots$n.json'))['s1_binding']

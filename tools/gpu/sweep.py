@@ -24,7 +24,6 @@ GRID = [   # (name, candidates): a candidate is a dict of knobs set together; th
     ("extension: wave priority (s_setprio) of the long classes' wavefronts", [{}, {"BM2_EXT_PRIO_QMIN": 96}, {"BM2_EXT_PRIO_QMIN": 80}, {"BM2_EXT_PRIO_QMIN": 64}, {"BM2_EXT_PRIO_QMIN": 80, "BM2_EXT_PRIO": 3},
                                                                                 {"BM2_EXT_PRIO_QMIN": 80, "BM2_EXT_PRIO": 1}, {"BM2_EXT_WAVE_PRIO": 2}, {"BM2_EXT_PRIO_QMIN": 80, "BM2_EXT_WAVE_PRIO": 2},
                                                                                 {"BM2_EXT_PRIO_QMIN": 80, "BM2_EXT_PRIO": 1, "BM2_EXT_WAVE_PRIO": 3}]),
-    ("extension: untested cells for the column groups inside every live lane's band", [{}, {"BM2_EXT_FAST_GROUPS": 1}, {"BM2_EXT_FAST_GROUPS": 1, "BM2_EXT_REG_QMIN": 0}, {"BM2_EXT_REG_QMIN": 0}]),
     ("extension: rows in registers (lane_dp8r) from this class up", [{}, {"BM2_EXT_REG_QMIN": 0}, {"BM2_EXT_REG_QMIN": 112}, {"BM2_EXT_REG_QMIN": 96}, {"BM2_EXT_REG_QMIN": 80}]),
     ("seeding: workgroups per CU of the wavefront-per-task kernel beside k_bwd", [{}, {"BM2_BWD_HEAVY_WG": 4}, {"BM2_BWD_HEAVY_WG": 8}, {"BM2_BWD_HEAVY_WG": 16}]),
     ("seeding: k_bwd hands old tasks over (k_bwd_cont: sixteen lanes per task)", [{}, {"BM2_BWD_EXPORT_AGE": 0}, {"BM2_BWD_EXPORT_AGE": 192}, {"BM2_BWD_EXPORT_AGE": 160}]),
