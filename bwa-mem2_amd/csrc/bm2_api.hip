@@ -268,16 +268,10 @@ static void probe_side_queues(bm2_ctx *c) {
 int bm2_side_streams(bm2_ctx *c) {
     if (c->side_ready) return BM2_OK;                            // (set only when every stream and event below exists)
     if (!c->ev_fork && bm2_check(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming), "hipEventCreate")) { c->ev_fork = nullptr; return BM2_ENODEV; }
-    // BM2_SIDE_PRIO_MASK: the side streams whose bit is set -- e.g. those of the extension launches of the long query classes, whose wavefronts
-    // are a phase's critical path -- are created with the highest queue priority: when a phase holds more workgroups than the GPU, theirs are placed first
-    // and the short classes fill in behind them (longest job first)
-    const int prio_mask = bm2_knob("BM2_SIDE_PRIO_MASK", 0);
-    int least = 0, greatest = 0;
-    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    // (Side streams of the long query classes at the highest queue priority, BM2_SIDE_PRIO_MASK: the hot path 74.7 -> 105-139 ms, profiles/r04f_*: removed in round 6.)
     for (int i = 0; i < 12; i++) {
         if (!c->side_stream[i]) {
-            const hipError_t e = (prio_mask >> i & 1) ? hipStreamCreateWithPriority(&c->side_stream[i], hipStreamNonBlocking, greatest)
-                                                : hipStreamCreateWithFlags(&c->side_stream[i], hipStreamNonBlocking);
+            const hipError_t e = hipStreamCreateWithFlags(&c->side_stream[i], hipStreamNonBlocking);
             if (bm2_check(e, "hipStreamCreate")) { c->side_stream[i] = nullptr; return BM2_ENODEV; }      // (a later call tries again from here: nothing half-made is ever used)
         }
         if (!c->ev_join[i] && bm2_check(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming), "hipEventCreate")) { c->ev_join[i] = nullptr; return BM2_ENODEV; }

@@ -1371,7 +1371,7 @@ struct ExtLaunch {
     // launch policy (bm2_knob): which kernel takes a query-length class.  A lane-per-seed wavefront of long queries walks tens of thousands
     // of cells one after the other (milliseconds) and a phase lasts as long as its slowest wavefront, so the classes from wave_qmin up can go
     // one seed per WAVEFRONT (k_ext_wave) beside the lane kernels.
-    int wave_qmin, prefetch, rev, perm_scores, qmap, group4;
+    int wave_qmin, rev, perm_scores, qmap;
     int reg_qmin;                            // classes of queries up to at least this many bases keep their rows in registers (0: none)
     // the sorted seed list of the phase and where it lives
     const int32_t *tasks; const int64_t *start;
@@ -1420,15 +1420,11 @@ static int run_phase(const ExtLaunch &L, const uint32_t *hint, int64_t ub) {
             const int hi = cls_hi[k];
             const size_t lds = L.pack8 ? (size_t)((hi + 2) / 2) * 64 * 4 + (size_t)((hi + 7) / 8) * 64 * 4
                                        : (size_t)(hi + 1) * 64 * 4 + (size_t)hi * 64;
-            auto kern = L.pack8 ? (L.prefetch ? k_ext_seeds<true, true> : k_ext_seeds<true, false>) : k_ext_seeds<false, false>;
+            auto kern = L.pack8 ? k_ext_seeds<true, true> : k_ext_seeds<false, false>;
             size_t lds_k = lds;
-            if (L.pack8 && L.perm_scores && L.prefetch) {       // the LDS-row kernel with the byte-permute score table (query one base per byte)
-                kern = k_ext_seeds<true, true, true>;
-                lds_k = (size_t)((hi + 2) / 2) * 64 * 4 + (size_t)((hi + 3) / 4 + 1) * 64 * 4;
-                if (L.group4) {                                     // ... its column loop in groups of four with two register sets for the LDS words
-                    kern = k_ext_seeds<true, true, true, true>;
-                    lds_k = (size_t)(2 * ((hi + 3) / 4) + 2) * 64 * 4 + (size_t)((hi + 3) / 4 + 1) * 64 * 4;
-                }
+            if (L.pack8 && L.perm_scores) {                      // the byte-permute score table (query one base per byte), the column loop in groups of four with two register sets for the LDS words
+                kern = k_ext_seeds<true, true, true, true>;      // (without the next pair's LDS word requested ahead, BM2_EXT_PREFETCH=0, and with the column loop in pairs, BM2_EXT_GROUP4=0:
+                lds_k = (size_t)(2 * ((hi + 3) / 4) + 2) * 64 * 4 + (size_t)((hi + 3) / 4 + 1) * 64 * 4;      //  both slower in every sweep since round 4, profiles/r04d_sweep.json, r05k_sweep.json -- those instantiations left the tree in round 6)
             }
             if (L.pack8 && L.perm_scores && L.reg_qmin > 0 && hi >= L.reg_qmin && hi >= 80 && hi <= 128) {       // rows in registers (lane_dp8r): no LDS
                 // (the 144- and 160-column instantiations are not in the tree: the compiler stops unrolling their 37 / 41 groups and the row lands in scratch)
@@ -1485,11 +1481,9 @@ int bm2_launch_extend(bm2_ctx *c, const bm2_opt &opt, const ChainParams &cp, int
     // (113 until the launches of a phase really ran beside each other, see run_phase: the wavefront kernel then took 200 000 seeds of the second
     //  round -- short seeds at a read's end, the whole rest of the read to extend -- and was the last launch of its phase to end by 2 ms;
     //  profiles/r04q_sweep.json: extension 20.1 ms at 113, 16.0 ms at 129 / 145 / 161, 25.0 ms at 97)
-    L.prefetch = bm2_knob("BM2_EXT_PREFETCH", 1);
     L.rev = bm2_knob("BM2_EXT_REVERSE", 1);
     L.qmap = bm2_knob("BM2_EXT_QUEUE_MAP", 1);
     L.perm_scores = bm2_knob("BM2_EXT_PERM_SCORES", 1);
-    L.group4 = bm2_knob("BM2_EXT_GROUP4", 1);
     // Rows in registers for the classes from this query length up (k_ext_seeds_reg; 0: none).  Measured on the 3100 Mbp chunk (profiles/r06c_*, r06d_*: two
     // sweeps): the 113..128-base class alone -- each phase's longest launch, 6 wavefronts per CU on LDS rows -- extension 15.7-16.2 -> 14.5-14.8 ms; with
     // the 97..112 class as well 14.8-15.0, from 81 bases 15.4-15.6, from 49 bases 16.0-16.1 (the shorter classes' LDS rows already fit 8-12 wavefronts per

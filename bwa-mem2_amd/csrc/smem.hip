@@ -1155,7 +1155,6 @@ int bm2_launch_seeding(bm2_ctx *c, const SeedParams &sp, int n_reads, const uint
                                                                                //  ten times as long as their backward phases, r04d: 180 instead of 138 ms there)
     const int p3_bpc = bm2_knob("BM2_P3_BPC", 0);                            // workgroups per CU of pass 3 (0: as many as the other walks)
     const int grid_p3 = p3_bpc > 0 ? c->n_cu * p3_bpc : grid_walk;
-    const int heavy_after = bm2_knob("BM2_BWD_HEAVY_AFTER", 0);              // the long lists' wavefront-per-task kernel after k_bwd instead of beside it
     auto launch_p3 = [&]() {
         (void)hipEventRecord(c->ev_fork, s);
         (void)hipStreamWaitEvent(s3, c->ev_fork, 0);
@@ -1179,7 +1178,7 @@ int bm2_launch_seeding(bm2_ctx *c, const SeedParams &sp, int n_reads, const uint
         tick(c, pass == 1 ? "smem.walk1" : "smem.walk2");
         if (p3_at == pass) launch_p3();
         // the long lists go to one wavefront each, beside the lane-per-task kernel
-        if (!heavy_after) {
+        {       // (after k_bwd instead of beside it: +1 ms per pass, profiles/r05b_sweep.json)
             (void)hipEventRecord(c->ev_join[2], s);
             (void)hipStreamWaitEvent(sh, c->ev_join[2], 0);
             hipLaunchKernelGGL(k_bwd_heavy, dim3(grid_heavy), dim3(256), 0, sh, c->ix, sp, pass, enc, heads, ents, slot_cap, sb.pool, sb.pool_cap,
@@ -1192,9 +1191,7 @@ int bm2_launch_seeding(bm2_ctx *c, const SeedParams &sp, int n_reads, const uint
         CTask *cont = (CTask *)(pass == 1 ? sb.cont1 : sb.cont2);
         hipLaunchKernelGGL(kb, dim3(grid_bwd), dim3(256), 0, s, c->ix, sp, pass, enc, heads, ents, slot_cap, sb.pool, sb.pool_cap,
                            sb.pool_slots, sb.recs, sb.rec_cap, sb.tasks, sb.task_cap, smem_cnt, sc, cont, sb.cont_cap, export_age);
-        if (!heavy_after) (void)hipStreamWaitEvent(s, c->ev_join[1], 0);
-        else hipLaunchKernelGGL(k_bwd_heavy, dim3(grid_heavy * 2), dim3(256), 0, s, c->ix, sp, pass, enc, heads, ents, slot_cap, sb.pool, sb.pool_cap,
-                                sb.pool_slots, heavy, sb.heavy_cap, sb.recs, sb.rec_cap, sb.tasks, sb.task_cap, smem_cnt, sc);
+        (void)hipStreamWaitEvent(s, c->ev_join[1], 0);
         tick(c, pass == 1 ? "smem.bwd1" : "smem.bwd2");
         if (export_age > 0) {                                   // the tasks k_bwd handed over, sixteen lanes each (they may file pass-2 tasks: before k_walk<P2>)
             hipLaunchKernelGGL(k_bwd_cont, dim3(c->n_cu * bm2_knob("BM2_BWD_CONT_BPC", 6)), dim3(256), 0, s, c->ix, sp, pass, enc, ents, slot_cap, sb.pool, sb.pool_cap,

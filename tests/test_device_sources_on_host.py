@@ -91,11 +91,11 @@ n = 20                                                       # (every set runs t
 ln = ln[:n]; off = off[:n]; enc = enc[:int(off[-1] + ln[-1])]
 ix = oracle.Index(pre); exp = ix.run(enc, off, ln)["REGPRG"].tobytes(); ix.close()
 ctx = bm2.Context(0, pre)
-sets = [{}, {"BM2_EXT_WAVE_QMIN": 33, "BM2_EXT_REVERSE": 1, "BM2_EXT_PREFETCH": 0}, {"BM2_EXT_WAVE_QMIN": 161, "BM2_EXT_WAVE_NMAX": 20, "BM2_EXT_ROUNDS": 2, "BM2_EXT_PERM_SCORES": 0, "BM2_EXT_QUEUE_MAP": 0},
-        {"BM2_EXT_GROUP4": 0, "BM2_P3_AT": 2, "BM2_BWD_EXPORT_AGE": 40},
+sets = [{}, {"BM2_EXT_WAVE_QMIN": 33, "BM2_EXT_REVERSE": 1}, {"BM2_EXT_WAVE_QMIN": 161, "BM2_EXT_WAVE_NMAX": 20, "BM2_EXT_ROUNDS": 2, "BM2_EXT_PERM_SCORES": 0, "BM2_EXT_QUEUE_MAP": 0},
+        {"BM2_P3_AT": 2, "BM2_BWD_EXPORT_AGE": 40},
         {"BM2_HEAVY_SA": 2, "BM2_CHAIN_STAGE": 1, "BM2_CHAIN_WAVES_PER_CU": 32, "BM2_PF_HEAVY": 2},
         {"BM2_BWD_LCAP": 4, "BM2_BWD_BLOCKS_PER_CU": 5, "BM2_BWD_WAVES": 5, "BM2_SAL_QUAD": 1},
-        {"BM2_BWD_LCAP": 8, "BM2_HEAVY_SA": 5, "BM2_CHAIN_STAGE": 0, "BM2_BWD_EXPORT_AGE": 5, "BM2_BWD_HEAVY_AFTER": 1},
+        {"BM2_BWD_LCAP": 8, "BM2_HEAVY_SA": 5, "BM2_CHAIN_STAGE": 0, "BM2_BWD_EXPORT_AGE": 5},
         {"BM2_EXT_WAVE_QMIN": 113, "BM2_CHAIN_MAIN_SIDE": 0, "BM2_HEAVY_SA": 2, "BM2_CHAIN_CLOCK": 1},
         {"BM2_CHAIN_COOP_FLT": 1, "BM2_HEAVY_SA": 2},
         {"BM2_EXT_REG_QMIN": 80}, {"BM2_EXT_REG_QMIN": 0}]       # rows in registers (lane_dp8r) for every class that has the kernel / for none (default: the 128-column class)

@@ -144,7 +144,7 @@ def test_repeat_rich_lists_vs_oracle(gpu_ctx_factory, tmp_path):
 # Every setting below runs the repeat-rich short reads (pool lists, wavefront-per-task seeding, the heavy chaining tiers, wave / lane extension
 # classes) and a set of long ONT-like reads (island chaining, serial equal-key reads, the sliding-window extension) against the oracle.
 KNOB_SETTINGS = [
-    {"BM2_BWD_EXPORT_AGE": "256"}, {"BM2_BWD_EXPORT_AGE": "24"}, {"BM2_BWD_EXPORT_AGE": "128", "BM2_BWD_HEAVY_AFTER": "1"},
+    {"BM2_BWD_EXPORT_AGE": "256"}, {"BM2_BWD_EXPORT_AGE": "24"}, {"BM2_BWD_EXPORT_AGE": "128"},
     {"BM2_BWD_EXPORT_AGE": "0"}, {"BM2_BWD_EXPORT_AGE": "64", "BM2_BWD_LCAP": "8", "BM2_BWD_BLOCKS_PER_CU": "4"}, {"BM2_BWD_CONT_BPC": "2", "BM2_BWD_EXPORT_AGE": "100"},
     {"BM2_P3_BPC": "1"}, {"BM2_P3_BPC": "2", "BM2_P3_AT": "2"},
     {"BM2_CHAIN_COOP_FLT": "0"}, {"BM2_CHAIN_COOP_FLT": "1"}, {"BM2_CHAIN_CLOCK": "1"}, {"BM2_CHAIN_HEAVY_WPE": "2"}, {"BM2_CHAIN_HEAVY_WPE": "4", "BM2_CHAIN_COOP_FLT": "0"},

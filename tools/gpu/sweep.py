@@ -28,7 +28,6 @@ GRID = [   # (name, candidates): a candidate is a dict of knobs set together; th
     ("seeding: workgroups per CU of the wavefront-per-task kernel beside k_bwd", [{}, {"BM2_BWD_HEAVY_WG": 4}, {"BM2_BWD_HEAVY_WG": 8}, {"BM2_BWD_HEAVY_WG": 16}]),
     ("seeding: k_bwd hands old tasks over (k_bwd_cont: sixteen lanes per task)", [{}, {"BM2_BWD_EXPORT_AGE": 0}, {"BM2_BWD_EXPORT_AGE": 192}, {"BM2_BWD_EXPORT_AGE": 160}]),
     ("seeding: workgroups per CU of k_bwd_cont", [{}, {"BM2_BWD_CONT_BPC": 4}, {"BM2_BWD_CONT_BPC": 8}]),
-    ("seeding: the long lists' kernel after k_bwd", [{}, {"BM2_BWD_HEAVY_AFTER": 1}]),
     ("chain clock", [{}, {"BM2_CHAIN_CLOCK": 1}]),
     ("chain staging", [{}, {"BM2_CHAIN_STAGE": 1}]),
     ("chain heavy threshold", [{}, {"BM2_HEAVY_SA": 64}, {"BM2_HEAVY_SA": 40}, {"BM2_HEAVY_SA": 24}, {"BM2_HEAVY_SA": 160}, {"BM2_HEAVY_SA": 256}, {"BM2_HEAVY_SA": 512}]),
@@ -45,10 +44,8 @@ GRID = [   # (name, candidates): a candidate is a dict of knobs set together; th
     ("chain: wavefronts per SIMD the heavy reads' kernel is allocated for", [{}, {"BM2_CHAIN_HEAVY_WPE": 2}, {"BM2_CHAIN_HEAVY_WPE": 4}]),
     ("extension rounds", [{}, {"BM2_EXT_ROUNDS": 2}, {"BM2_EXT_ROUNDS": 1}, {"BM2_EXT_PEND_DIV": 6}, {"BM2_EXT_PEND_DIV": 24}]),
     ("extension dispatch order", [{}, {"BM2_EXT_REVERSE": 1}]),
-    ("extension prefetch", [{}, {"BM2_EXT_PREFETCH": 0}]),
     ("seeding pass 3 placement", [{}, {"BM2_P3_AT": 0}, {"BM2_P3_AT": 2}]),
     ("seeding: pass 3 workgroups per CU", [{}, {"BM2_P3_BPC": 2}, {"BM2_P3_BPC": 1}, {"BM2_P3_AT": 0, "BM2_P3_BPC": 1}, {"BM2_P3_AT": 0, "BM2_P3_BPC": 2}, {"BM2_P3_AT": 0, "BM2_P3_BPC": 3}]),
-    ("extension column loop in groups of four", [{}, {"BM2_EXT_GROUP4": 0}]),
     ("SA lookup by quads", [{}, {"BM2_SAL_QUAD": 1}]),
     ("sub-batches of the chunk on their own streams", [{}, {"BM2_N_SUB": 2}, {"BM2_N_SUB": 3}]),
     ("walk blocks per CU", [{}, {"BM2_WALK_BLOCKS_PER_CU": 6}, {"BM2_WALK_BLOCKS_PER_CU": 3}]),
