@@ -360,7 +360,10 @@ static int batch_run_one(bm2_ctx *c, const bm2_opt *opt, StageGate *gate = nullp
     }
     hipLaunchKernelGGL(k_read_base, dim3((n + 255) / 256), dim3(256), 0, s, n, (const int32_t *)b->smem_cnt.p,
                        (const int64_t *)b->smem_off.p, (const int64_t *)b->sa_off.p, (int64_t *)b->read_base.p, (int32_t *)b->n_sa_read.p);
-    const int perm_mode = bm2_knob("BM2_PERM_MODE", 4);      // chaining: heavy reads (> 40 seeds) first, stable
+    // chaining's read order: 5 = seed-rich reads first, then the light reads in 2x classes of seed count, every class in the reads' own order
+    // (profiles/r06u_, r06v_sweep_chain_classes.json: chain 10.5-10.7 -> 9.9 ms against 4 = heavy first and the rest in plain order; classes in
+    //  1.4x steps measured no better, 10.0, and were not kept)
+    const int perm_mode = bm2_knob("BM2_PERM_MODE", 5);
     const int perm_mode_pf = bm2_knob("BM2_PERM_MODE_PF", 0);   // post-filter: read order
     const int thr_sa = bm2_knob("BM2_HEAVY_SA", 100);           // reads with more SA coordinates go to k_chain_heavy (sweep: 40 -> 13.6 ms, 100 -> 12.1 ms)
     const int64_t *n_heavy_chain = nullptr;                      // set when the permutation lists the seed-rich reads first: k_chain_heavy takes them

@@ -21,13 +21,11 @@ sys.path.insert(0, os.path.join(ROOT, "bwa-mem2_amd"))
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 GRID = [   # (name, candidates): a candidate is a dict of knobs set together; the first one ({} = the library's defaults) is the incumbent
-    ("extension: wave priority (s_setprio) of the long classes' wavefronts", [{}, {"BM2_EXT_PRIO_QMIN": 96}, {"BM2_EXT_PRIO_QMIN": 80}, {"BM2_EXT_PRIO_QMIN": 64}, {"BM2_EXT_PRIO_QMIN": 80, "BM2_EXT_PRIO": 3},
-                                                                                {"BM2_EXT_PRIO_QMIN": 80, "BM2_EXT_PRIO": 1}, {"BM2_EXT_WAVE_PRIO": 2}, {"BM2_EXT_PRIO_QMIN": 80, "BM2_EXT_WAVE_PRIO": 2},
-                                                                                {"BM2_EXT_PRIO_QMIN": 80, "BM2_EXT_PRIO": 1, "BM2_EXT_WAVE_PRIO": 3}]),
     ("extension: rows in registers (lane_dp8r) from this class up", [{}, {"BM2_EXT_REG_QMIN": 0}, {"BM2_EXT_REG_QMIN": 112}, {"BM2_EXT_REG_QMIN": 96}, {"BM2_EXT_REG_QMIN": 80}]),
     ("seeding: workgroups per CU of the wavefront-per-task kernel beside k_bwd", [{}, {"BM2_BWD_HEAVY_WG": 4}, {"BM2_BWD_HEAVY_WG": 8}, {"BM2_BWD_HEAVY_WG": 16}]),
     ("seeding: k_bwd hands old tasks over (k_bwd_cont: sixteen lanes per task)", [{}, {"BM2_BWD_EXPORT_AGE": 0}, {"BM2_BWD_EXPORT_AGE": 192}, {"BM2_BWD_EXPORT_AGE": 160}]),
     ("seeding: workgroups per CU of k_bwd_cont", [{}, {"BM2_BWD_CONT_BPC": 4}, {"BM2_BWD_CONT_BPC": 8}]),
+    ("chaining: the light reads in plain order (4) instead of 2x classes of seed count (5, the default)", [{}, {"BM2_PERM_MODE": 4}]),
     ("chain clock", [{}, {"BM2_CHAIN_CLOCK": 1}]),
     ("chain staging", [{}, {"BM2_CHAIN_STAGE": 1}]),
     ("chain heavy threshold", [{}, {"BM2_HEAVY_SA": 64}, {"BM2_HEAVY_SA": 40}, {"BM2_HEAVY_SA": 24}, {"BM2_HEAVY_SA": 160}, {"BM2_HEAVY_SA": 256}, {"BM2_HEAVY_SA": 512}]),
