@@ -403,10 +403,12 @@ extern "C" bm2_ctx *bm2_create(int device, const bm2_index_desc *idx) {
     }
     if (device < 0 || device >= ndev) { bm2_set_error("device %d out of range (%d visible)", device, ndev); return nullptr; }
     if (bm2_check(hipSetDevice(device), "hipSetDevice")) return nullptr;
-    // BM2_BLOCKING_SYNC=1 (the host's decision, read once per device): a thread that waits for the device sleeps instead of spinning.  For a host
-    // whose CPUs are all busy with its own work (the S1 binding: every worker thread of the reference computes while one of them waits for a batch)
-    // a spinning waiter is a CPU taken from the work -- and under a CPU-time quota it is what gets the whole process throttled.
-    if (bm2_knob("BM2_BLOCKING_SYNC", 0)) {
+    // BM2_BLOCKING_SYNC (the host's decision, read once per device; default 1): a thread that waits for the device sleeps instead of spinning.  For a host
+    // whose CPUs are all busy with its own work (the S1 binding: every worker thread of the reference computes while one of them waits for a batch; the
+    // FASTQ -> SAM leg: parsers and tail workers beside the device workers) a spinning waiter is a CPU taken from the work -- and under a CPU-time quota it
+    // is what gets the whole process throttled.  profiles/r06w_e2e_blocking_sync_ab.txt: the leg's host CPU 1.19-1.20 -> 1.03-1.13 s per chunk, its rate
+    // and the hot path's step (59.4-59.7 ms both ways) unchanged.  0: HIP's default (spin).
+    if (bm2_knob("BM2_BLOCKING_SYNC", 1)) {
         static std::mutex flag_mu; static unsigned long long flagged = 0;
         std::lock_guard<std::mutex> l(flag_mu);
         if (device < 64 && !(flagged >> device & 1)) { flagged |= 1ULL << device; if (hipSetDeviceFlags(hipDeviceScheduleBlockingSync) != hipSuccess) (void)hipGetLastError(); }

@@ -396,11 +396,58 @@ static __device__ int chain_weight(const WChain &c, const WSeed *seeds) {
     return w < 1 << 30 ? w : (1 << 30) - 1;
 }
 
+// The task-building part of mem_chain2aln_across_reads_V2 (bwamem.cpp:2127-2223) for ONE kept chain whose seeds [s0, s0 + d.n) of the read's slice `os`
+// are final: reference window, extension order (srt keeps the ascending one), reg slots from n_reg on.  Used by k_chain_finish and -- for reads no seed
+// filter can touch -- by the lane that has just emitted the chain (chain_finish_read: the chain and its seeds are still in its registers / L1).
+static __device__ __forceinline__ void chain_finish_one(const DevIndex &ix, const ChainParams &o, int l_query, int64_t base, int i, DevChain &d, DevSeed *os,
+                                                        int s0, int32_t *srt_out, int32_t *reg_seed, int32_t *reg_chain, int &n_reg) {
+    const int n_seed = s0 + d.n;
+    d.reg0 = n_reg;
+    if (d.n == 0) return;                               // bwamem.cpp:2140 (a chain emptied by the seed filter)
+    // reference window of the chain, bwamem.cpp:2145-2172 (rmax, strand clip, bns_fetch_seq_v2 contig clip)
+    int64_t rmax0 = ix.l_pac << 1, rmax1 = 0;
+    for (int t = s0; t < n_seed; t++) {
+        const DevSeed &sx = os[t];
+        const int64_t bb = sx.rbeg - (sx.qbeg + cal_max_gap(o, sx.qbeg));
+        const int64_t ee = sx.rbeg + sx.len + ((l_query - sx.qbeg - sx.len) + cal_max_gap(o, l_query - sx.qbeg - sx.len));
+        rmax0 = rmax0 < bb ? rmax0 : bb;
+        rmax1 = rmax1 > ee ? rmax1 : ee;
+    }
+    rmax0 = rmax0 > 0 ? rmax0 : 0;
+    rmax1 = rmax1 < ix.l_pac << 1 ? rmax1 : ix.l_pac << 1;
+    if (rmax0 < ix.l_pac && ix.l_pac < rmax1) {
+        if (os[s0].rbeg < ix.l_pac) rmax1 = ix.l_pac; else rmax0 = ix.l_pac;
+    }
+    {
+        int is_rev;
+        const int rid = pos2rid(ix, depos(ix, os[s0].rbeg, is_rev));
+        int64_t far_beg = ix.ann_offset[rid], far_end = far_beg + ix.ann_len[rid];
+        if (is_rev) { const int64_t tmp = far_beg; far_beg = (ix.l_pac << 1) - far_end; far_end = (ix.l_pac << 1) - tmp; }
+        rmax0 = rmax0 > far_beg ? rmax0 : far_beg;
+        rmax1 = rmax1 < far_end ? rmax1 : far_end;
+    }
+    d.rmax0 = rmax0; d.rmax1 = rmax1;
+    // seeds are extended in descending (score<<32 | index) order, bwamem.cpp:2188-2206; srt keeps the ascending order
+    int32_t *srt = srt_out + base + s0;
+    for (int t = 0; t < d.n; t++) srt[t] = t;
+    if (d.n > 1) {
+        const DevSeed *cs = os + s0;
+        k_introsort_flat(d.n, srt, [&](int32_t x, int32_t y) { return cs[x].score < cs[y].score || (cs[x].score == cs[y].score && x < y); });
+    }
+    for (int kk = d.n - 1; kk >= 0; kk--) {
+        const int reg = n_reg++;
+        os[s0 + srt[kk]].aln = reg;
+        reg_seed[base + reg] = (int32_t)(s0 + srt[kk]);       // seed index relative to the read's base
+        reg_chain[base + reg] = i;                             // chain index relative to the read's base
+    }
+}
+
 // The rest of mem_chain_flt (bwamem.cpp:548-624) and the hand-over to the extension stage, for the n chains ord[0..n) -- the chains that
 // passed the weight test, in key order -- of read r: introsort by weight, overlap filter, kept chains with their seeds made contiguous.
 // kept_list: scratch for n ints (the B-tree's nodes are no longer needed when this runs).
 static __device__ void chain_finish_read(const ChainParams &o, int r, WChain *ch, WSeed *sd, int32_t *ord, int32_t *kept_list, int n, int64_t base,
-                                         float frac_rep, DevChain *chn, DevSeed *seeds_out, int32_t *seed_owner, int32_t *n_chain_out, int32_t *n_reg_out) {
+                                         float frac_rep, DevChain *chn, DevSeed *seeds_out, int32_t *seed_owner, int32_t *n_chain_out, int32_t *n_reg_out,
+                                         const DevIndex *fix = nullptr, const FinishOut *fo = nullptr /* both set: this lane does k_chain_finish's part too */) {
     int k;
     if (n > 0) {
         k_introsort_flat(n, ord, [&](int32_t x, int32_t y) { return ch[x].w > ch[y].w; });     // flt_lt, bwamem.cpp:61
@@ -446,7 +493,7 @@ static __device__ void chain_finish_read(const ChainParams &o, int r, WChain *ch
     // ---- emit kept chains with contiguous seeds
     DevChain *oc = chn + base;
     DevSeed *os = seeds_out + base;
-    int n_seed = 0;
+    int n_seed = 0, n_reg = 0;
     for (int i = 0; i < n; i++) {
         const WChain &c = ch[ord[i]];
         DevChain d;
@@ -459,10 +506,11 @@ static __device__ void chain_finish_read(const ChainParams &o, int r, WChain *ch
         }
         d.reg0 = 0; d.pad = 0;
         for (int t = s0; t < n_seed; t++) seed_owner[base + t] = r;
+        if (fo) chain_finish_one(*fix, o, fo->len[r], base, i, d, os, s0, fo->srt_out, fo->reg_seed, fo->reg_chain, n_reg);
         oc[i] = d;
     }
     n_chain_out[r] = n;
-    n_reg_out[r] = 0;              // set by k_chain_finish
+    n_reg_out[r] = n_reg;          // (without `fo`: 0, set by k_chain_finish)
 }
 
 // ---- mem_chain_flt again, for a WHOLE WAVEFRONT (BM2_CHAIN_COOP_FLT; chain_finish_read above is what one lane runs and stays as it is): the walk over
@@ -601,7 +649,8 @@ static __device__ void chain_one_read(const DevIndex &ix, const ChainParams &o, 
                                       DevChain *chn, DevSeed *seeds_out, int32_t *seed_owner, int32_t *n_chain_out, int32_t *n_reg_out,
                                       int32_t *n_chain0_out, int heavy_thr, const ChainWork *lw, int lds_cap, const IslSeed *ist = nullptr,
                                       const IslHash *isl_hash = nullptr, const int32_t *isl_slot = nullptr,
-                                      DeferFinish *defer = nullptr /* !LIGHT: leave mem_chain_flt's walk and the output to the caller's wavefront */) {
+                                      DeferFinish *defer = nullptr /* !LIGHT: leave mem_chain_flt's walk and the output to the caller's wavefront */,
+                                      const FinishOut *fo = nullptr /* LIGHT: the lane also builds the read's extension tasks (k_chain_finish's part) */) {
     const int n_sm = smem_cnt[r];
     const long long t_enter = (!LIGHT && lw && lw->clk) ? wall_clock64() : 0;
     n_chain_out[r] = 0; n_reg_out[r] = 0;          // (k_chain never gets here with a read it leaves to k_chain_heavy: one writer per read)
@@ -708,7 +757,7 @@ static __device__ void chain_one_read(const DevIndex &ix, const ChainParams &o, 
         defer->valid = 1;
         return;
     }
-    chain_finish_read(o, r, ch, sd, ord, (int32_t *)nodes, k, base, frac_rep, chn, seeds_out, seed_owner, n_chain_out, n_reg_out);
+    chain_finish_read(o, r, ch, sd, ord, (int32_t *)nodes, k, base, frac_rep, chn, seeds_out, seed_owner, n_chain_out, n_reg_out, &ix, LIGHT ? fo : nullptr);
     if (!LIGHT && lw && lw->clk) atomicAdd(lw->clk + 2, (unsigned long long)(wall_clock64() - t_walk));
 }
 
@@ -718,12 +767,12 @@ k_chain(DevIndex ix, ChainParams o, int n_reads, const int32_t *__restrict__ len
         const int64_t *__restrict__ sa_coord, WChain *wchain, WSeed *wseed, BtNode *nodes, int32_t *order,
         DevChain *chn, DevSeed *seeds_out, int32_t *seed_owner,
         int32_t *n_chain_out, int32_t *n_reg_out, int32_t *n_chain0_out, const int32_t *__restrict__ perm, int heavy_thr,
-        const int32_t *__restrict__ n_sa_read) {
+        const int32_t *__restrict__ n_sa_read, FinishOut fo /* srt_out == nullptr: k_chain_finish does every read */) {
     const int tix = blockIdx.x * blockDim.x + threadIdx.x;
     if (tix >= n_reads) return;
     if (heavy_thr >= 0 && n_sa_read[perm[tix]] > heavy_thr) return;          // a whole wavefront takes this read (k_chain_heavy)
     chain_one_read<true>(ix, o, perm[tix], n_reads, len, smems, smem_cnt, smem_off, sa_off, sa_coord, wchain, wseed, nodes, order, chn, seeds_out,
-                         seed_owner, n_chain_out, n_reg_out, n_chain0_out, heavy_thr, nullptr, 0);
+                         seed_owner, n_chain_out, n_reg_out, n_chain0_out, heavy_thr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, fo.srt_out ? &fo : nullptr);
 }
 
 static __device__ __forceinline__ void chain_wave_sync() {      // lanes of one wavefront handing data to each other through LDS
@@ -1306,62 +1355,27 @@ k_chain_serial(DevIndex ix, ChainParams o, int n_reads, const int32_t *__restric
 }
 
 // After the (optional) short-seed filter: reference window, extension order and reg slots of every kept chain
-// (the task-building part of mem_chain2aln_across_reads_V2, bwamem.cpp:2127-2223).  One read per lane.
+// (the task-building part of mem_chain2aln_across_reads_V2, bwamem.cpp:2127-2223: chain_finish_one).  One read per lane, in the order of the chaining's
+// permutation (reads with alike seed counts share a wavefront); with `done_thr` >= 0 the reads with at most that many SA coordinates have had
+// this done by k_chain's lane (chain_finish_read) and only the seed-rich ones -- the wavefront-per-read launches' -- are left.
 __global__ void __launch_bounds__(128)
 k_chain_finish(DevIndex ix, ChainParams o, int n_reads, const int32_t *__restrict__ len, const int64_t *__restrict__ read_base,
                const int32_t *__restrict__ n_chain, DevChain *chn, DevSeed *seeds_out, int32_t *srt_out, int32_t *reg_seed,
-               int32_t *reg_chain, int32_t *n_reg_out) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_reads) return;
+               int32_t *reg_chain, int32_t *n_reg_out, const int32_t *__restrict__ perm, const int32_t *__restrict__ n_sa_read, int done_thr) {
+    const int tix = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tix >= n_reads) return;
+    const int r = perm ? perm[tix] : tix;
+    if (done_thr >= 0 && n_sa_read[r] <= done_thr) return;
     const int n = n_chain[r];
     if (n == 0) { n_reg_out[r] = 0; return; }
     const int64_t base = read_base[r];
     DevChain *oc = chn + base;
+    DevSeed *os = seeds_out + base;
+    const int l_query = len[r];
     int n_reg = 0;
     for (int i = 0; i < n; i++) {
         DevChain d = oc[i];
-        DevSeed *os = seeds_out + base;
-        const int s0 = (int)(d.seed_off - base), n_seed = s0 + d.n;
-        d.reg0 = n_reg;
-        if (d.n == 0) { oc[i] = d; continue; }          // bwamem.cpp:2140 (a chain emptied by the seed filter)
-        struct { int n; } c; c.n = d.n;
-        // reference window of the chain, bwamem.cpp:2145-2172 (rmax, strand clip, bns_fetch_seq_v2 contig clip)
-        const int l_query = len[r];
-        int64_t rmax0 = ix.l_pac << 1, rmax1 = 0;
-        for (int t = s0; t < n_seed; t++) {
-            const DevSeed &sx = os[t];
-            const int64_t bb = sx.rbeg - (sx.qbeg + cal_max_gap(o, sx.qbeg));
-            const int64_t ee = sx.rbeg + sx.len + ((l_query - sx.qbeg - sx.len) + cal_max_gap(o, l_query - sx.qbeg - sx.len));
-            rmax0 = rmax0 < bb ? rmax0 : bb;
-            rmax1 = rmax1 > ee ? rmax1 : ee;
-        }
-        rmax0 = rmax0 > 0 ? rmax0 : 0;
-        rmax1 = rmax1 < ix.l_pac << 1 ? rmax1 : ix.l_pac << 1;
-        if (rmax0 < ix.l_pac && ix.l_pac < rmax1) {
-            if (os[s0].rbeg < ix.l_pac) rmax1 = ix.l_pac; else rmax0 = ix.l_pac;
-        }
-        {
-            int is_rev;
-            const int rid = pos2rid(ix, depos(ix, os[s0].rbeg, is_rev));
-            int64_t far_beg = ix.ann_offset[rid], far_end = far_beg + ix.ann_len[rid];
-            if (is_rev) { const int64_t tmp = far_beg; far_beg = (ix.l_pac << 1) - far_end; far_end = (ix.l_pac << 1) - tmp; }
-            rmax0 = rmax0 > far_beg ? rmax0 : far_beg;
-            rmax1 = rmax1 < far_end ? rmax1 : far_end;
-        }
-        d.rmax0 = rmax0; d.rmax1 = rmax1;
-        // seeds are extended in descending (score<<32 | index) order, bwamem.cpp:2188-2206; srt keeps the ascending order
-        int32_t *srt = srt_out + base + s0;
-        for (int t = 0; t < c.n; t++) srt[t] = t;
-        if (c.n > 1) {
-            const DevSeed *cs = os + s0;
-            k_introsort_flat(c.n, srt, [&](int32_t x, int32_t y) { return cs[x].score < cs[y].score || (cs[x].score == cs[y].score && x < y); });
-        }
-        for (int kk = c.n - 1; kk >= 0; kk--) {
-            const int reg = n_reg++;
-            os[s0 + srt[kk]].aln = reg;
-            reg_seed[base + reg] = (int32_t)(s0 + srt[kk]);       // seed index relative to the read's base
-            reg_chain[base + reg] = i;                             // chain index relative to the read's base
-        }
+        chain_finish_one(ix, o, l_query, base, i, d, os, (int)(d.seed_off - base), srt_out, reg_seed, reg_chain, n_reg);
         oc[i] = d;
     }
     n_reg_out[r] = n_reg;
@@ -1369,10 +1383,10 @@ k_chain_finish(DevIndex ix, ChainParams o, int n_reads, const int32_t *__restric
 
 int bm2_launch_chain_finish(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_t *len, const int64_t *read_base,
                             const int32_t *n_chain, DevChain *chn, DevSeed *seeds_out, int32_t *srt_out, int32_t *reg_seed,
-                            int32_t *reg_chain, int32_t *n_reg_out) {
+                            int32_t *reg_chain, int32_t *n_reg_out, const int32_t *perm, const int32_t *n_sa_read, int done_thr) {
     if (n_reads <= 0) return BM2_OK;
     hipLaunchKernelGGL(k_chain_finish, dim3((n_reads + 127) / 128), dim3(128), 0, c->stream, c->ix, o, n_reads, len, read_base, n_chain,
-                       chn, seeds_out, srt_out, reg_seed, reg_chain, n_reg_out);
+                       chn, seeds_out, srt_out, reg_seed, reg_chain, n_reg_out, perm, n_sa_read, done_thr);
     return bm2_check(hipGetLastError(), "k_chain_finish launch");
 }
 
@@ -1388,7 +1402,8 @@ int bm2_launch_chain(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_
                      int heavy_thr, const int64_t *n_heavy_dev, const int32_t *n_sa_read, unsigned long long *item_cur /* one per tier + 2 */, int max_len,
                      int32_t *isl_cut /* scratch of the island kernel: one int per SA coordinate */,
                      const int32_t *isl_order /* or NULL: every read, the seed-richest first -- the island kernel's longest reads start first */,
-                     int32_t *isl_serial /* or NULL: one int per read (all -1), the list of reads k_chain_islands leaves to k_chain_serial */) {
+                     int32_t *isl_serial /* or NULL: one int per read (all -1), the list of reads k_chain_islands leaves to k_chain_serial */,
+                     const FinishOut *fuse /* or NULL.  Set (no read of the batch can meet the seed filter): k_chain's lanes do k_chain_finish's part for their reads */) {
     if (n_reads <= 0) return BM2_OK;
     hipStream_t s = c->stream;
     const bool heavy = heavy_thr >= 0 && n_heavy_dev != nullptr;
@@ -1403,7 +1418,7 @@ int bm2_launch_chain(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_
     if (main_side) (void)hipStreamWaitEvent(s_main, c->ev_fork, 0);
     hipLaunchKernelGGL(k_chain, dim3((n_reads + 127) / 128), dim3(128), 0, s_main, c->ix, o, n_reads, len, smems, smem_cnt,
                        smem_off, sa_off, sa_coord, wchain, wseed, nodes, order, chn, seeds_out, seed_owner,
-                       n_chain_out, n_reg_out, n_chain0_out, perm, heavy ? heavy_thr : -1, n_sa_read);
+                       n_chain_out, n_reg_out, n_chain0_out, perm, heavy ? heavy_thr : -1, n_sa_read, fuse ? *fuse : FinishOut{ nullptr, nullptr, nullptr, nullptr });
     int joined[BM2_CHAIN_TIERS + 4], n_joined = 0;
     if (main_side) { (void)hipEventRecord(c->ev_join[1], s_main); joined[n_joined++] = 1; }
     if (heavy) {

@@ -20,3 +20,6 @@ struct BtNode {                      // kbnode_t with t = 5: up to 9 keys (chain
     int32_t ptr[10];
     int32_t is_internal, n, pad;
 };
+
+// where k_chain_finish's outputs go when the chaining kernel's lane writes them itself (chain.hip: chain_finish_one)
+struct FinishOut { const int32_t *len; int32_t *srt_out, *reg_seed, *reg_chain; };

@@ -18,10 +18,10 @@ int bm2_launch_chain(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_
                      int32_t *seed_owner,
                      int32_t *n_chain_out, int32_t *n_reg_out, int32_t *n_chain0_out, const int32_t *perm,
                      int heavy_thr, const int64_t *n_heavy_dev, const int32_t *n_sa_read, unsigned long long *item_cur, int max_len, int32_t *isl_cut,
-                     const int32_t *isl_order, int32_t *isl_serial);
+                     const int32_t *isl_order, int32_t *isl_serial, const FinishOut *fuse);
 int bm2_launch_chain_finish(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_t *len, const int64_t *read_base,
                             const int32_t *n_chain, DevChain *chn, DevSeed *seeds_out, int32_t *srt_out, int32_t *reg_seed,
-                            int32_t *reg_chain, int32_t *n_reg_out);
+                            int32_t *reg_chain, int32_t *n_reg_out, const int32_t *perm, const int32_t *n_sa_read, int done_thr);
 int bm2_launch_seed_filter(bm2_ctx *c, const ChainParams &o, const int8_t *d_mat25, int n_reads, int64_t n_slots, const uint8_t *enc,
                            const int64_t *off, const int32_t *len, const int32_t *min_hsp, const int64_t *read_base, const int32_t *n_chain,
                            const int32_t *seed_owner, DevChain *chn, DevSeed *seeds, uint8_t *seed_keep);
@@ -388,13 +388,20 @@ static int batch_run_one(bm2_ctx *c, const bm2_opt *opt, StageGate *gate = nullp
         isl_serial = (int32_t *)b->isl_serial.p;
         if ((rc = bm2_check(hipMemsetAsync(isl_serial, 0xff, (size_t)(n + 1) * 4, s), "memset isl_serial"))) return rc;      // -1: place not yet filled
     }
+    // k_chain_finish's part (reference window, extension order, reg slots of every kept chain) by the lane of k_chain that has just written the chain, when
+    // nothing can come between the two -- no read of the batch long enough for the seed filter (any_flt), no island kernel borrowing `srt` as scratch --;
+    // k_chain_finish is then left with the reads of the wavefront-per-read launches.  BM2_CHAIN_FUSE_FINISH=0: every read by k_chain_finish.
+    // BM2_CHAIN_FINISH_PERM=0: k_chain_finish takes the reads in plain order (a wavefront then waits for its seed-richest read).
+    const bool fuse_finish = !any_flt && b->max_len < 1000 && bm2_knob("BM2_CHAIN_FUSE_FINISH", 1);
+    const bool finish_perm = bm2_knob("BM2_CHAIN_FINISH_PERM", 1);
+    const FinishOut fin_out = { (const int32_t *)b->len.p, (int32_t *)b->srt.p, (int32_t *)b->reg_seed.p, (int32_t *)b->reg_chain.p };
     if ((rc = bm2_launch_chain(c, cp, n, (const int32_t *)b->len.p, (const bm2_smem_t *)b->smem.p, (const int32_t *)b->smem_cnt.p,
                                (const int64_t *)b->smem_off.p, (const int64_t *)b->sa_off.p, (const int64_t *)b->sa_coord.p,
                                (WChain *)b->wchain.p, (WSeed *)b->wseed.p, (BtNode *)b->nodes.p, (int32_t *)b->order.p,
                                (DevChain *)b->chn.p, (DevSeed *)b->seeds.p, (int32_t *)b->seed_owner.p,
                                (int32_t *)b->n_chain.p, (int32_t *)b->n_reg.p, (int32_t *)b->n_chain0.p, (const int32_t *)b->perm.p,
                                n_heavy_chain ? thr_sa : -1, n_heavy_chain, (const int32_t *)b->n_sa_read.p,
-                               (unsigned long long *)b->counters.p + 10, b->max_len, (int32_t *)b->srt.p, isl_order, isl_serial))) return rc;      // counters[10..15]: work cursors of the tiers and of the overflow launch, [16]: reads listed for k_chain_serial (equal chain keys; [39] of them not staged), [38]: its work cursor
+                               (unsigned long long *)b->counters.p + 10, b->max_len, (int32_t *)b->srt.p, isl_order, isl_serial, fuse_finish ? &fin_out : nullptr))) return rc;      // counters[10..15]: work cursors of the tiers and of the overflow launch, [16]: reads listed for k_chain_serial (equal chain keys; [39] of them not staged), [38]: its work cursor
     if (any_flt) {
         if ((rc = bm2_launch_seed_filter(c, cp, (const int8_t *)b->mat25.p, n, n_sa, (const uint8_t *)b->enc.p, (const int64_t *)b->off.p,
                                          (const int32_t *)b->len.p, (const int32_t *)b->min_hsp.p, (const int64_t *)b->read_base.p,
@@ -403,7 +410,8 @@ static int batch_run_one(bm2_ctx *c, const bm2_opt *opt, StageGate *gate = nullp
     }
     if ((rc = bm2_launch_chain_finish(c, cp, n, (const int32_t *)b->len.p, (const int64_t *)b->read_base.p, (const int32_t *)b->n_chain.p,
                                       (DevChain *)b->chn.p, (DevSeed *)b->seeds.p, (int32_t *)b->srt.p, (int32_t *)b->reg_seed.p,
-                                      (int32_t *)b->reg_chain.p, (int32_t *)b->n_reg.p))) return rc;
+                                      (int32_t *)b->reg_chain.p, (int32_t *)b->n_reg.p, finish_perm ? (const int32_t *)b->perm.p : (const int32_t *)nullptr,
+                                      (const int32_t *)b->n_sa_read.p, fuse_finish ? (n_heavy_chain ? thr_sa : 0x7fffffff) : -1))) return rc;
     tick(c, "chain");
     if (gate) {                                                  // the front half has left the GPU before the next part's seeding is let in
         if ((rc = bm2_check(hipStreamSynchronize(s), "chaining"))) return rc;
