@@ -1361,11 +1361,12 @@ k_chain_serial(DevIndex ix, ChainParams o, int n_reads, const int32_t *__restric
 __global__ void __launch_bounds__(128)
 k_chain_finish(DevIndex ix, ChainParams o, int n_reads, const int32_t *__restrict__ len, const int64_t *__restrict__ read_base,
                const int32_t *__restrict__ n_chain, DevChain *chn, DevSeed *seeds_out, int32_t *srt_out, int32_t *reg_seed,
-               int32_t *reg_chain, int32_t *n_reg_out, const int32_t *__restrict__ perm, const int32_t *__restrict__ n_sa_read, int done_thr) {
+               int32_t *reg_chain, int32_t *n_reg_out, const int32_t *__restrict__ perm, const int32_t *__restrict__ n_sa_read, int done_thr, int wave_thr) {
     const int tix = blockIdx.x * blockDim.x + threadIdx.x;
     if (tix >= n_reads) return;
     const int r = perm ? perm[tix] : tix;
     if (done_thr >= 0 && n_sa_read[r] <= done_thr) return;
+    if (wave_thr >= 0 && n_sa_read[r] > wave_thr) return;       // k_chain_finish_wave's
     const int n = n_chain[r];
     if (n == 0) { n_reg_out[r] = 0; return; }
     const int64_t base = read_base[r];
@@ -1381,12 +1382,56 @@ k_chain_finish(DevIndex ix, ChainParams o, int n_reads, const int32_t *__restric
     n_reg_out[r] = n_reg;
 }
 
+// The same for the seed-rich reads -- the first *n_heavy entries of the chaining's permutation, the reads of the wavefront-per-read launches --, one read
+// per WAVEFRONT and one chain per lane: a read with hundreds of chains kept one lane of k_chain_finish busy for a millisecond (the kernel with only these
+// reads left: 1.04 of its 1.51 ms per million-read chunk, profiles/r06ab_*).  A chain's first reg slot is the number of seeds in the chains before it: a
+// prefix sum over the wavefront per 64 chains.
+__global__ void __launch_bounds__(256)
+k_chain_finish_wave(DevIndex ix, ChainParams o, const int32_t *__restrict__ perm, const int64_t *__restrict__ n_heavy_dev, const int32_t *__restrict__ len,
+                    const int64_t *__restrict__ read_base, const int32_t *__restrict__ n_chain, DevChain *chn, DevSeed *seeds_out, int32_t *srt_out,
+                    int32_t *reg_seed, int32_t *reg_chain, int32_t *n_reg_out) {
+    const int lane = (int)(threadIdx.x & 63);
+    const int64_t n_heavy = *n_heavy_dev, n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t wv = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; wv < n_heavy; wv += n_waves) {
+        const int r = perm[wv];
+        const int n = n_chain[r];
+        const int64_t base = read_base[r];
+        DevChain *oc = chn + base;
+        DevSeed *os = seeds_out + base;
+        const int l_query = len[r];
+        int before = 0;                                         // seeds in the chains before this group of 64
+        for (int i0 = 0; i0 < n; i0 += 64) {
+            const int i = i0 + lane;
+            DevChain d = {};
+            if (i < n) d = oc[i];
+            int inc = i < n ? d.n : 0;
+            const int own = inc;
+            for (int dd = 1; dd < 64; dd <<= 1) { const int v = __shfl(inc, (lane - dd) & 63); if (lane >= dd) inc += v; }
+            int n_reg = before + inc - own;
+            if (i < n) {
+                chain_finish_one(ix, o, l_query, base, i, d, os, (int)(d.seed_off - base), srt_out, reg_seed, reg_chain, n_reg);
+                oc[i] = d;
+            }
+            before += __shfl(inc, 63);
+        }
+        if (lane == 0) n_reg_out[r] = before;
+    }
+}
+
 int bm2_launch_chain_finish(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_t *len, const int64_t *read_base,
                             const int32_t *n_chain, DevChain *chn, DevSeed *seeds_out, int32_t *srt_out, int32_t *reg_seed,
-                            int32_t *reg_chain, int32_t *n_reg_out, const int32_t *perm, const int32_t *n_sa_read, int done_thr) {
+                            int32_t *reg_chain, int32_t *n_reg_out, const int32_t *perm, bool lanes_by_perm, const int32_t *n_sa_read, int done_thr,
+                            const int64_t *n_heavy_dev /* or NULL.  Set: the permutation's first *n_heavy_dev reads (more than wave_thr SA coordinates) by k_chain_finish_wave */, int wave_thr) {
     if (n_reads <= 0) return BM2_OK;
-    hipLaunchKernelGGL(k_chain_finish, dim3((n_reads + 127) / 128), dim3(128), 0, c->stream, c->ix, o, n_reads, len, read_base, n_chain,
-                       chn, seeds_out, srt_out, reg_seed, reg_chain, n_reg_out, perm, n_sa_read, done_thr);
+    const bool lanes = !(n_heavy_dev && done_thr >= wave_thr);      // (nothing left for the lane kernel when k_chain has done the reads below the bound)
+    if (lanes) hipLaunchKernelGGL(k_chain_finish, dim3((n_reads + 127) / 128), dim3(128), 0, c->stream, c->ix, o, n_reads, len, read_base, n_chain,
+                                  chn, seeds_out, srt_out, reg_seed, reg_chain, n_reg_out, lanes_by_perm ? perm : (const int32_t *)nullptr, n_sa_read, done_thr,
+                                  n_heavy_dev ? wave_thr : -1);
+    if (n_heavy_dev) {
+        const int64_t waves = (int64_t)(n_reads < 64 * 1024 ? n_reads : 64 * 1024);
+        hipLaunchKernelGGL(k_chain_finish_wave, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, c->stream, c->ix, o, perm, n_heavy_dev, len, read_base, n_chain,
+                           chn, seeds_out, srt_out, reg_seed, reg_chain, n_reg_out);
+    }
     return bm2_check(hipGetLastError(), "k_chain_finish launch");
 }
 

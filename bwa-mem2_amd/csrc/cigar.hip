@@ -96,18 +96,16 @@ enum { CG_NULL = -1, CG_DEFERRED = -3 };                          // CigarRes::n
 static __device__ __forceinline__ int cg_score(int t, int q, int s_match, int s_mis, int s_amb) { return (t == q && t < 4) ? s_match : ((t > 3 || q > 3) ? s_amb : s_mis); }
 
 // NM and MD of a finished CIGAR (bwa.cpp:311-340)
-template <class QF, class RFn>
-static __device__ __forceinline__ void cg_nm_md(const uint32_t *cg, int ncg, QF Q, RFn RF, bool rev, char *md, CigarRes &R) {
+template <class QF, class RFn, class RF8n>
+static __device__ __forceinline__ void cg_nm_md(const uint32_t *cg, int ncg, QF Q, RFn RF, RF8n RF8 /* (i, n): reference bases i .. i + n - 1, n <= 8, four bits each */, bool rev, char *md, CigarRes &R) {
     int x = 0, y = 0, u = 0, n_mm = 0, n_gap = 0, nmd = 0;
     const char *int2base = rev ? "TGCAN" : "ACGTN";
     for (int k = 0; k < ncg; ++k) {
         const int op = cg[k] & 0xf, len = (int)(cg[k] >> 4);
         if (op == 0) {
-            for (int i0 = 0; i0 < len; i0 += 8) {                  // (eight reference bases requested together: see k_cigar_flat)
-                uint32_t tw = 0;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) tw |= (uint32_t)RF(y + (i0 + k < len ? i0 + k : len - 1)) << (4 * k);
+            for (int i0 = 0; i0 < len; i0 += 8) {                  // (eight reference bases in one load: see k_cigar_flat)
                 const int nk = len - i0 < 8 ? len - i0 : 8;
+                uint32_t tw = RF8(y + i0, nk);
 #pragma nounroll
                 for (int k = 0; k < nk; ++k, tw >>= 4) {
                     const int rb_ = (int)(tw & 15u);
@@ -146,18 +144,22 @@ k_cigar_flat(RefPtr ref, const uint8_t *__restrict__ seqs, const CigarTask *__re
     char *md = mdbuf + T.md_off;
     const char *int2base = rev ? "TGCAN" : "ACGTN";
     int sc = 0, u = 0, n_mm = 0, nmd = 0;
-    // both in alignment order (reversed for a hit on the reverse strand).  EIGHT positions at a time: their sixteen loads are requested before the first is
-    // looked at -- the MD bytes a mismatch stores may alias anything a load reads, so the compiler keeps the one-position loop's loads in order, each a
-    // round trip of its own (the kernel waited in 69 % of its wave cycles and issued VALU in 2 %: profiles/r06f_tail_kernels_pmc_sq.md)
+    // both in alignment order (reversed for a hit on the reverse strand).  EIGHT positions at a time, by TWO loads (RefPtr::nib8): a lane that walks its
+    // read and its reference range byte by byte fetches every line of them 64 (16) times, each a round trip of its own -- the MD bytes a mismatch stores may
+    // alias anything a load reads, so the compiler keeps the loads in order -- and the lanes of a CU hold far more lines than its L1: the kernel waited in 69 %
+    // of its wave cycles and issued VALU in 2 % (profiles/r06f_tail_kernels_pmc_sq.md).  The last, partial group goes position by position.
+    const RefPtr qr = RefPtr::bytes(qp);
     for (int i0 = 0; i0 < lq; i0 += 8) {
         uint32_t tw = 0, qw = 0;                                // four bits per position
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int i = i0 + k < lq ? i0 + k : lq - 1;
+        const int nk = lq - i0 < 8 ? lq - i0 : 8;
+        if (nk == 8) {
+            tw = rev ? ref.nib8(T.re - 1 - i0, -1) : ref.nib8(T.rb + i0, 1);
+            qw = rev ? qr.nib8(lq - 1 - i0, -1) : qr.nib8(i0, 1);
+        } else for (int k = 0; k < nk; ++k) {
+            const int i = i0 + k;
             tw |= (uint32_t)(rev ? ref[T.re - 1 - i] : ref[T.rb + i]) << (4 * k);
             qw |= (uint32_t)((rev ? qp[lq - 1 - i] : qp[i]) & 15) << (4 * k);
         }
-        const int nk = lq - i0 < 8 ? lq - i0 : 8;
 #pragma nounroll
         for (int k = 0; k < nk; ++k, tw >>= 4, qw >>= 4) {
             const int t = (int)(tw & 15u), q = (int)(qw & 15u);
@@ -195,14 +197,22 @@ k_gen_cigar(RefPtr ref, const uint8_t *__restrict__ seqs, const CigarTask *__res
     const uint8_t *qp = seqs + T.q_off;
     const int s_match = prm.mat[0], s_mis = prm.mat[1], s_amb = prm.mat[4];
     if (LDS) {                                                  // the query in alignment order (reversed for reverse-strand hits)
+        const RefPtr qr = RefPtr::bytes(qp);
         for (int j0 = 0; j0 < lq; j0 += 8) {
             uint32_t wq = 0;
-            for (int u = 0; u < 8 && j0 + u < lq; u++) wq |= (uint32_t)((rev ? qp[lq - 1 - (j0 + u)] : qp[j0 + u]) & 15) << (4 * u);
+            if (j0 + 8 <= lq) wq = rev ? qr.nib8(lq - 1 - j0, -1) : qr.nib8(j0, 1);      // (one load: see k_cigar_flat)
+            else for (int u = 0; j0 + u < lq; u++) wq |= (uint32_t)((rev ? qp[lq - 1 - (j0 + u)] : qp[j0 + u]) & 15) << (4 * u);
             Q4[(j0 >> 3) * 64 + lane] = wq;
         }
     }
     auto Q = [&](int i) -> int { return LDS ? (int)((Q4[(i >> 3) * 64 + lane] >> (4 * (i & 7))) & 15u) : (rev ? qp[lq - 1 - i] : qp[i]); };
     auto RF = [&](int i) -> int { return rev ? ref[T.re - 1 - i] : ref[T.rb + i]; };
+    auto RF8 = [&](int i, int n) -> uint32_t {                   // reference bases i .. i + n - 1 (n <= 8) of the range, four bits each
+        if (n == 8) return rev ? ref.nib8(T.re - 1 - i, -1) : ref.nib8(T.rb + i, 1);
+        uint32_t tw = 0;
+        for (int k = 0; k < n; ++k) tw |= (uint32_t)RF(i + k) << (4 * k);
+        return tw;
+    };
     int2 *ehg = ehbuf + T.eh_off;                               // .x = h, .y = e (global version)
     auto eh_get = [&](int j) -> int2 {
         if (!LDS) return ehg[j];
@@ -240,11 +250,15 @@ k_gen_cigar(RefPtr ref, const uint8_t *__restrict__ seqs, const CigarTask *__res
             eh_set(0, 0, MINF);
             for (j = 1; j <= lq && j <= w; ++j) eh_set(j, -(prm.o_ins + e_ins * j), MINF);
             if (!RING) for (; j <= lq; ++j) eh_set(j, MINF, MINF);
-            int t_next = RF(0);
+            uint32_t t_word = 0, t_ahead = RF8(0, rlen < 8 ? rlen : 8);
             for (int i = 0; i < rlen; ++i) {                    // ksw.cpp:598-637
                 int f = MINF;
-                const int tb = t_next;
-                if (i + 1 < rlen) t_next = RF(i + 1);           // (requested a row ahead)
+                if ((i & 7) == 0) {                             // the rows' reference bases eight to a load, the next eight requested eight rows ahead
+                    t_word = t_ahead;
+                    if (i + 8 < rlen) t_ahead = RF8(i + 8, rlen - (i + 8) < 8 ? rlen - (i + 8) : 8);
+                }
+                const int tb = (int)(t_word & 15u);
+                t_word >>= 4;
                 const int beg = i > w ? i - w : 0, end = i + w + 1 < lq ? i + w + 1 : lq;
                 int h1 = beg == 0 ? -(prm.o_del + e_del * (i + 1)) : MINF;
                 uint32_t *zi = (uint32_t *)(z + (int64_t)i * n_col);
@@ -319,7 +333,7 @@ k_gen_cigar(RefPtr ref, const uint8_t *__restrict__ seqs, const CigarTask *__res
             return;
         }
     }
-    cg_nm_md(cg, ncg, Q, RF, rev, mdbuf + T.md_off, R);
+    cg_nm_md(cg, ncg, Q, RF, RF8, rev, mdbuf + T.md_off, R);
     res[id] = R;
 }
 

@@ -21,7 +21,7 @@ int bm2_launch_chain(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_
                      const int32_t *isl_order, int32_t *isl_serial, const FinishOut *fuse);
 int bm2_launch_chain_finish(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_t *len, const int64_t *read_base,
                             const int32_t *n_chain, DevChain *chn, DevSeed *seeds_out, int32_t *srt_out, int32_t *reg_seed,
-                            int32_t *reg_chain, int32_t *n_reg_out, const int32_t *perm, const int32_t *n_sa_read, int done_thr);
+                            int32_t *reg_chain, int32_t *n_reg_out, const int32_t *perm, bool lanes_by_perm, const int32_t *n_sa_read, int done_thr, const int64_t *n_heavy_dev, int wave_thr);
 int bm2_launch_seed_filter(bm2_ctx *c, const ChainParams &o, const int8_t *d_mat25, int n_reads, int64_t n_slots, const uint8_t *enc,
                            const int64_t *off, const int32_t *len, const int32_t *min_hsp, const int64_t *read_base, const int32_t *n_chain,
                            const int32_t *seed_owner, DevChain *chn, DevSeed *seeds, uint8_t *seed_keep);
@@ -394,6 +394,7 @@ static int batch_run_one(bm2_ctx *c, const bm2_opt *opt, StageGate *gate = nullp
     // BM2_CHAIN_FINISH_PERM=0: k_chain_finish takes the reads in plain order (a wavefront then waits for its seed-richest read).
     const bool fuse_finish = !any_flt && b->max_len < 1000 && bm2_knob("BM2_CHAIN_FUSE_FINISH", 1);
     const bool finish_perm = bm2_knob("BM2_CHAIN_FINISH_PERM", 1);
+    const bool finish_wave = bm2_knob("BM2_CHAIN_FINISH_WAVE", 1);     // the seed-rich reads' part by k_chain_finish_wave (one read per wavefront, one chain per lane); 0: by k_chain_finish
     const FinishOut fin_out = { (const int32_t *)b->len.p, (int32_t *)b->srt.p, (int32_t *)b->reg_seed.p, (int32_t *)b->reg_chain.p };
     if ((rc = bm2_launch_chain(c, cp, n, (const int32_t *)b->len.p, (const bm2_smem_t *)b->smem.p, (const int32_t *)b->smem_cnt.p,
                                (const int64_t *)b->smem_off.p, (const int64_t *)b->sa_off.p, (const int64_t *)b->sa_coord.p,
@@ -410,8 +411,9 @@ static int batch_run_one(bm2_ctx *c, const bm2_opt *opt, StageGate *gate = nullp
     }
     if ((rc = bm2_launch_chain_finish(c, cp, n, (const int32_t *)b->len.p, (const int64_t *)b->read_base.p, (const int32_t *)b->n_chain.p,
                                       (DevChain *)b->chn.p, (DevSeed *)b->seeds.p, (int32_t *)b->srt.p, (int32_t *)b->reg_seed.p,
-                                      (int32_t *)b->reg_chain.p, (int32_t *)b->n_reg.p, finish_perm ? (const int32_t *)b->perm.p : (const int32_t *)nullptr,
-                                      (const int32_t *)b->n_sa_read.p, fuse_finish ? (n_heavy_chain ? thr_sa : 0x7fffffff) : -1))) return rc;
+                                      (int32_t *)b->reg_chain.p, (int32_t *)b->n_reg.p, (const int32_t *)b->perm.p, finish_perm,
+                                      (const int32_t *)b->n_sa_read.p, fuse_finish ? (n_heavy_chain ? thr_sa : 0x7fffffff) : -1,
+                                      finish_wave ? n_heavy_chain : (const int64_t *)nullptr, thr_sa))) return rc;
     tick(c, "chain");
     if (gate) {                                                  // the front half has left the GPU before the next part's seeding is let in
         if ((rc = bm2_check(hipStreamSynchronize(s), "chaining"))) return rc;

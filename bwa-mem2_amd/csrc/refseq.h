@@ -34,5 +34,28 @@ struct RefPtr {
         } else w = *(const u32u *)(p + a);
         return s > 0 ? w : __builtin_bswap32(w);
     }
+    // elements k, k + s, ..., k + 7s (s = +1 or -1) as the eight 4-bit fields of a word, the first in the lowest: ONE unaligned load instead of eight
+    // byte loads (a lane that walks its own sequence byte by byte fetches every 64-byte line 64 times -- 16 times when packed -- and the lanes of a CU
+    // together hold far more lines than its L1 does).  All eight elements must exist: the caller takes the tail of a sequence one by one.
+    BM2_REFSEQ_FN uint32_t nib8(int64_t k, int s) const {
+        typedef uint32_t __attribute__((aligned(1))) u32u;
+        typedef uint64_t __attribute__((aligned(1))) u64u;
+        const int64_t a = at + (s > 0 ? k : k - 7);             // the lowest of the eight positions
+        uint32_t x;
+        if (pk) {
+            x = (*(const u32u *)(p + (a >> 2)) >> ((int)(a & 3) << 1)) & 0xffffu;      // (22 bits of the word at most)
+            x = (x | x << 8) & 0x00ff00ffu; x = (x | x << 4) & 0x0f0f0f0fu; x = (x | x << 2) & 0x33333333u;
+        } else x = nib8_of_bytes(*(const u64u *)(p + a));
+        return s > 0 ? x : nib8_reverse(x);
+    }
+    static BM2_REFSEQ_FN uint32_t nib8_of_bytes(uint64_t w) {   // the low 4 bits of byte i -> field i
+        w &= 0x0f0f0f0f0f0f0f0full;
+        w = (w | w >> 4) & 0x00ff00ff00ff00ffull; w = (w | w >> 8) & 0x0000ffff0000ffffull;
+        return (uint32_t)(w | w >> 16);
+    }
+    static BM2_REFSEQ_FN uint32_t nib8_reverse(uint32_t x) {     // field i <-> field 7 - i
+        x = __builtin_bswap32(x);
+        return (x & 0x0f0f0f0fu) << 4 | ((x >> 4) & 0x0f0f0f0fu);
+    }
     static BM2_REFSEQ_FN RefPtr bytes(const uint8_t *q) { return RefPtr{q, 0, 0}; }
 };

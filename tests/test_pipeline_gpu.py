@@ -151,7 +151,8 @@ KNOB_SETTINGS = [
     {"BM2_CHAIN_SERIAL_LNODES": "3", "BM2_CHAIN_ISL_WPE": "3"}, {"BM2_CHAIN_SERIAL_LNODES": "400", "BM2_CHAIN_COOP_FLT": "1"},
     {"BM2_EXT_REG_QMIN": "80"}, {"BM2_EXT_REG_QMIN": "0"}, {"BM2_KSW_REG": "0"},
     {"BM2_PERM_MODE": "4"}, {"BM2_PERM_MODE": "2"}, {"BM2_PERM_MODE": "5", "BM2_HEAVY_SA": "64"},
-    {"BM2_CHAIN_FUSE_FINISH": "0"}, {"BM2_CHAIN_FUSE_FINISH": "0", "BM2_CHAIN_FINISH_PERM": "0"}, {"BM2_CHAIN_FINISH_PERM": "0", "BM2_HEAVY_SA": "8"},
+    {"BM2_CHAIN_FUSE_FINISH": "0"}, {"BM2_CHAIN_FUSE_FINISH": "0", "BM2_CHAIN_FINISH_PERM": "0", "BM2_CHAIN_FINISH_WAVE": "0"}, {"BM2_CHAIN_FINISH_PERM": "0", "BM2_HEAVY_SA": "8"},
+    {"BM2_CHAIN_FINISH_WAVE": "0"},
 ]
 
 

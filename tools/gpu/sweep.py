@@ -26,7 +26,7 @@ GRID = [   # (name, candidates): a candidate is a dict of knobs set together; th
     ("seeding: k_bwd hands old tasks over (k_bwd_cont: sixteen lanes per task)", [{}, {"BM2_BWD_EXPORT_AGE": 0}, {"BM2_BWD_EXPORT_AGE": 192}, {"BM2_BWD_EXPORT_AGE": 160}]),
     ("seeding: workgroups per CU of k_bwd_cont", [{}, {"BM2_BWD_CONT_BPC": 4}, {"BM2_BWD_CONT_BPC": 8}]),
     ("chaining: the light reads in plain order (4) instead of 2x classes of seed count (5, the default)", [{}, {"BM2_PERM_MODE": 4}]),
-    ("chaining: k_chain_finish's part by k_chain's lanes (default) / by the kernel, in the chaining's read order or in plain order", [{}, {"BM2_CHAIN_FUSE_FINISH": 0}, {"BM2_CHAIN_FUSE_FINISH": 0, "BM2_CHAIN_FINISH_PERM": 0}, {"BM2_CHAIN_FINISH_PERM": 0}]),
+    ("chaining: k_chain_finish's part by k_chain's lanes + one wavefront per seed-rich read (default) / by the lane-per-read kernel", [{}, {"BM2_CHAIN_FUSE_FINISH": 0}, {"BM2_CHAIN_FINISH_WAVE": 0}, {"BM2_CHAIN_FUSE_FINISH": 0, "BM2_CHAIN_FINISH_WAVE": 0}, {"BM2_CHAIN_FUSE_FINISH": 0, "BM2_CHAIN_FINISH_WAVE": 0, "BM2_CHAIN_FINISH_PERM": 0}]),
     ("chain clock", [{}, {"BM2_CHAIN_CLOCK": 1}]),
     ("chain staging", [{}, {"BM2_CHAIN_STAGE": 1}]),
     ("chain heavy threshold", [{}, {"BM2_HEAVY_SA": 64}, {"BM2_HEAVY_SA": 40}, {"BM2_HEAVY_SA": 24}, {"BM2_HEAVY_SA": 160}, {"BM2_HEAVY_SA": 256}, {"BM2_HEAVY_SA": 512}]),
