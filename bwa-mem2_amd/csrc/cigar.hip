@@ -430,13 +430,20 @@ static int cigar_run(bm2_ctx *c, const bm2_opt *opt, std::vector<CigarTask> &tas
         pen = std::max(pen, std::max(opt->o_del + opt->e_del, opt->o_ins + opt->e_ins));
         static const int no_lds = getenv("BM2_CIGAR_NO_LDS") ? atoi(getenv("BM2_CIGAR_NO_LDS")) : 0;
         static const int no_ring = getenv("BM2_CIGAR_NO_RING") ? atoi(getenv("BM2_CIGAR_NO_RING")) : 0;
+        const int ring_by_band = bm2_knob("BM2_CIGAR_RING_BY_BAND", 1);
         auto small = [&](int i) { const CigarTask &T = tasks[(size_t)i]; return !no_lds && T.q_len <= 220 && (int64_t)(T.q_len + (T.re - T.rb)) * pen < CG_SMALL; };
         auto shape = [&](int i) {
             if (cost[(size_t)i] == 0) return (int)SH_FLAT;       // (no DP area: the one-M case, or a NULL return)
             if (!small(i)) return (int)SH_GLOBAL;
             return (!no_ring && 2 * (int)wb1[(size_t)i] + 2 <= CG_RING) ? (int)SH_RING : (int)SH_ROW;
         };
-        auto cls = [&](int i) { const int64_t v = cost[(size_t)i]; const int k = v > 0 ? 64 - __builtin_clzll((unsigned long long)v) : 0; return shape(i) * 64 + 63 - k; };
+        // (the RING tasks by the band of their FIRST try, exactly: a wavefront steps through the widest band among its 64 tasks, and `cost` -- the DP area
+        //  the task's slices are sized for, i.e. of the widest band its retry loop can come to -- is the same for nearly all of them)
+        auto cls = [&](int i) {
+            const int sh = shape(i);
+            if (sh == SH_RING && ring_by_band) return sh * 64 + 31 - std::min(std::max((int)wb1[(size_t)i], 0), 31);
+            const int64_t v = cost[(size_t)i]; const int k = v > 0 ? 64 - __builtin_clzll((unsigned long long)v) : 0; return sh * 64 + 63 - k;
+        };
         bm2_counting_order(n, 256, host_threads, cls, order.data());
         std::atomic<int> ns[4], qm(0);
         for (auto &x : ns) x = 0;
