@@ -72,11 +72,9 @@ static __device__ FIN_SORT_ATTR void fin_sort_by_score(int n, int32_t *ord, cons
 // by reference end ("sort by the END position", :299)
 __global__ void __launch_bounds__(128)
 k_fin_init(int n_reads, const bm2_reg_t *__restrict__ regs, const int64_t *__restrict__ reg_off, bm2_alnreg_t *work, int32_t *ordbuf,
-           FinState *state, int32_t *n_fin,
-            const int32_t *__restrict__ perm /* or NULL: the reads in classes of hit count, so that the lanes of a wavefront have alike work */) {
-    const int tix = blockIdx.x * blockDim.x + threadIdx.x;
-    if (tix >= n_reads) return;
-    const int r = perm ? perm[tix] : tix;
+           FinState *state, int32_t *n_fin) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
     const int64_t base = reg_off[r];
     const int n = (int)(reg_off[r + 1] - base);
     bm2_alnreg_t *A = work + base;
@@ -98,11 +96,9 @@ k_fin_init(int n_reads, const bm2_reg_t *__restrict__ regs, const int64_t *__res
 // the walk, resumable (phase 1 = walking, 2 = a score has arrived, 3 = through, 4 = walk done, final ordering pending)
 __global__ void __launch_bounds__(128)
 k_fin_walk(DevIndex ix, FinParams P, int n_reads, const int64_t *__restrict__ reg_off, bm2_alnreg_t *work, const int32_t *__restrict__ ordbuf,
-           FinState *state, FinReq *reqs, unsigned long long *cnt /* [0] requests, [1] widest band */,
-            const int32_t *__restrict__ perm /* or NULL: the reads in classes of hit count, so that the lanes of a wavefront have alike work */) {
-    const int tix = blockIdx.x * blockDim.x + threadIdx.x;
-    if (tix >= n_reads) return;
-    const int r = perm ? perm[tix] : tix;
+           FinState *state, FinReq *reqs, unsigned long long *cnt /* [0] requests, [1] widest band */) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
     FinState st = state[r];
     if (st.phase >= 3) return;
     const int64_t base = reg_off[r];
@@ -192,11 +188,9 @@ k_fin_walk(DevIndex ix, FinParams P, int n_reads, const int64_t *__restrict__ re
 
 // last kernel: bwamem.cpp:336-352
 __global__ void __launch_bounds__(128)
-k_fin_order(int n_reads, const int64_t *__restrict__ reg_off, bm2_alnreg_t *work, int32_t *ordbuf, FinState *state, int32_t *n_fin,
-            const int32_t *__restrict__ perm /* or NULL: the reads in classes of hit count, so that the lanes of a wavefront have alike work */) {
-    const int tix = blockIdx.x * blockDim.x + threadIdx.x;
-    if (tix >= n_reads) return;
-    const int r = perm ? perm[tix] : tix;
+k_fin_order(int n_reads, const int64_t *__restrict__ reg_off, bm2_alnreg_t *work, int32_t *ordbuf, FinState *state, int32_t *n_fin) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
     FinState st = state[r];
     if (st.phase != 4) return;
     const int64_t base = reg_off[r];
@@ -320,8 +314,7 @@ k_fin_gather(DevIndex ix, int n_reads, const int64_t *__restrict__ reg_off, cons
 // device buffers of the stage (owned by the batch, pipeline.hip)
 int bm2_run_finish(bm2_ctx *c, const bm2_opt *opt, int n_reads, const uint8_t *enc, const int64_t *off, const bm2_reg_t *regs,
                    const int64_t *reg_off, int64_t n_regs, DevBuf &work, DevBuf &ordb, DevBuf &stateb, DevBuf &nfin, DevBuf &finoff, DevBuf &reqb,
-                   DevBuf &cntb, DevBuf &out, DevBuf &scan_tmp, int64_t *n_out, int *rounds,
-                   const int32_t *n_hits /* or NULL: hits per read (device) */, DevBuf &permb, DevBuf &part_tmp) {
+                   DevBuf &cntb, DevBuf &out, DevBuf &scan_tmp, int64_t *n_out, int *rounds) {
     hipStream_t s = c->stream;
     int rc;
     *n_out = 0; if (rounds) *rounds = 0;
@@ -339,21 +332,15 @@ int bm2_run_finish(bm2_ctx *c, const bm2_opt *opt, int n_reads, const uint8_t *e
     for (int i = 0; i < 25; i++) P.mat[i] = opt->mat[i];
     const unsigned nb = (unsigned)((n_reads + 127) / 128);
     const bool verbose = getenv("BM2_FIN_VERBOSE") != nullptr;
-    // The lane-per-read kernels take the reads in classes of hit count (> 64, > 32, ... hits, every class in the reads' own order: scan.hip): a read of a
-    // repeat has a hundred hits to sort and walk where its neighbours have two, and a wavefront lasts as long as its busiest lane.  BM2_FIN_PERM=0: plain order.
-    const int32_t *perm = nullptr;
-    if (n_hits && bm2_knob("BM2_FIN_PERM", 1)) {
-        if ((rc = bm2_reserve(permb, (size_t)(n_reads + 1) * 4))) return rc;
-        if ((rc = bm2_partition_by_class(c, n_reads, n_hits, 0x7fffffff, (int32_t *)permb.p, part_tmp, scan_tmp, nullptr))) return rc;
-        perm = (const int32_t *)permb.p;
-    }
+    // (the lane-per-read kernels below with the reads in classes of hit count, as the chaining takes them: 4.7 instead of 2.5 ms per chunk of the FASTQ -> SAM
+    //  leg, profiles/r06ah_* -- a read's hits are two or three records next to its neighbours'; not kept)
     hipLaunchKernelGGL(k_fin_init, dim3(nb), dim3(128), 0, s, n_reads, regs, reg_off, (bm2_alnreg_t *)work.p, (int32_t *)ordb.p, (FinState *)stateb.p,
-                       (int32_t *)nfin.p, perm);
+                       (int32_t *)nfin.p);
     if (verbose) { rc = bm2_check(hipStreamSynchronize(s), "k_fin_init"); fprintf(stderr, "[finish] init + sort by end: rc %d\n", rc); if (rc) return rc; }
     for (int round = 0; ; round++) {
         if ((rc = bm2_check(hipMemsetAsync(cntb.p, 0, 16, s), "memset fin counters"))) return rc;
         hipLaunchKernelGGL(k_fin_walk, dim3(nb), dim3(128), 0, s, c->ix, P, n_reads, reg_off, (bm2_alnreg_t *)work.p, (const int32_t *)ordb.p,
-                           (FinState *)stateb.p, (FinReq *)reqb.p, (unsigned long long *)cntb.p, perm);
+                           (FinState *)stateb.p, (FinReq *)reqb.p, (unsigned long long *)cntb.p);
         unsigned long long h_cnt[2] = { 0, 0 };
         if ((rc = bm2_check(hipMemcpyAsync(h_cnt, cntb.p, 16, hipMemcpyDeviceToHost, s), "D2H fin counters"))) return rc;
         if ((rc = bm2_check(hipStreamSynchronize(s), "k_fin_walk"))) return rc;
@@ -374,7 +361,7 @@ int bm2_run_finish(bm2_ctx *c, const bm2_opt *opt, int n_reads, const uint8_t *e
         if ((rc = bm2_check(hipGetLastError(), "k_fin_dp launch"))) return rc;
     }
     hipLaunchKernelGGL(k_fin_order, dim3(nb), dim3(128), 0, s, n_reads, reg_off, (bm2_alnreg_t *)work.p, (int32_t *)ordb.p, (FinState *)stateb.p,
-                       (int32_t *)nfin.p, perm);
+                       (int32_t *)nfin.p);
     if (verbose) { rc = bm2_check(hipStreamSynchronize(s), "k_fin_order"); fprintf(stderr, "[finish] final order: rc %d\n", rc); if (rc) return rc; }
     if ((rc = bm2_scan_i32(c, (const int32_t *)nfin.p, n_reads, (int64_t *)finoff.p, scan_tmp))) return rc;
     int64_t tot = 0;

@@ -40,7 +40,7 @@ int bm2_launch_reg_gather(bm2_ctx *c, int n_reads, const int64_t *read_base, con
 
 int bm2_run_finish(bm2_ctx *c, const bm2_opt *opt, int n_reads, const uint8_t *enc, const int64_t *off, const bm2_reg_t *regs,
                    const int64_t *reg_off, int64_t n_regs, DevBuf &work, DevBuf &ordb, DevBuf &stateb, DevBuf &nfin, DevBuf &finoff, DevBuf &reqb,
-                   DevBuf &cntb, DevBuf &out, DevBuf &scan_tmp, int64_t *n_out, int *rounds, const int32_t *n_hits, DevBuf &permb, DevBuf &part_tmp);     // finish.hip
+                   DevBuf &cntb, DevBuf &out, DevBuf &scan_tmp, int64_t *n_out, int *rounds);     // finish.hip
 
 struct Batch {
     int n_reads = 0, max_len = 0;
@@ -635,7 +635,7 @@ static int batch_finish_one(bm2_ctx *c, const bm2_opt *opt) {
     int64_t n_out = 0;
     rc = bm2_run_finish(c, opt, b->n_reads, (const uint8_t *)b->enc.p, (const int64_t *)b->off.p, (const bm2_reg_t *)b->out_regs.p,
                         (const int64_t *)b->out_off.p, b->n_out_regs, b->fin_work, b->fin_ord, b->fin_state, b->fin_n, b->fin_off, b->fin_req,
-                        b->fin_cnt, b->fin_out, b->scan_tmp, &n_out, &b->fin_rounds, (const int32_t *)b->n_out.p, b->perm, b->part_tmp);
+                        b->fin_cnt, b->fin_out, b->scan_tmp, &n_out, &b->fin_rounds);
     if (rc) return rc;
     if ((rc = bm2_check(hipStreamSynchronize(c->stream), "hit finishing"))) return rc;
     b->n_fin = n_out;

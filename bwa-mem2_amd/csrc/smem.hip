@@ -1081,54 +1081,9 @@ k_sal(DevIndex ix, int64_t n, int64_t *pos_coord, unsigned long long *n_lf_out) 
     if (n_lf_out) atomicAdd(n_lf_out, (unsigned long long)n_lf);
 }
 
-// The same walk with the lanes REFILLED: a lookup is a walk of 0, 1, 2, ... LF steps until it meets a sampled position (one in eight: seven steps on
-// average, forty for the unluckiest of a workgroup), and with one lookup per lane a wavefront spends most of its life with a handful of lanes walking -- a
-// handful of lines in flight.  Here a wavefront owns a contiguous range of the lookups and a lane that has finished one takes the range's next (ranked among
-// the lanes that ask in the same round by a ballot), so that all 64 lanes walk until the range runs dry.  In place as before: a position is read by the one
-// lane that later writes its coordinate.
-__global__ void __launch_bounds__(256)
-k_sal_refill(DevIndex ix, int64_t n, int64_t *pos_coord, unsigned long long *n_lf_out) {
-    const int lane = (int)(threadIdx.x & 63);
-    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6, wv = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int64_t per = (n + n_waves - 1) / n_waves;
-    int64_t cur = wv * per, end = cur + per < n ? cur + per : n;
-    int64_t n_lf = 0, sp = 0, offset = 0, mine = -1;
-    bool walk = false;
-    for (;;) {
-        const unsigned long long ask = __ballot(!walk);
-        if (cur < end) {
-            const int64_t t = cur + __popcll(ask & ((1ULL << lane) - 1ULL));
-            if (!walk && t < end) {
-                sp = pos_coord[t]; offset = 0; mine = t;
-                if ((sp & 7) == 0) { pos_coord[t] = ((int64_t)ix.sa_ms_byte[sp >> 3] << 32) + ix.sa_ls_word[sp >> 3]; mine = -1; }      // (asks again next round)
-                else walk = true;
-            }
-            cur += __popcll(ask);
-        } else if (!__any(walk)) break;
-        if (walk) {
-            const Blk b = load_blk(&ix.cp_occ[sp >> 6]);
-            const int y = 63 - (int)(sp & 63);
-            int c = -1;
-            if ((b.w[4] >> y) & 1) c = 0;
-            else if ((b.w[5] >> y) & 1) c = 1;
-            else if ((b.w[6] >> y) & 1) c = 2;
-            else if ((b.w[7] >> y) & 1) c = 3;
-            if (c < 0) { pos_coord[mine] = 0; walk = false; }           // sentinel: 0 whatever the offset (:1230-1233)
-            else {
-                n_lf++;
-                const int yy = (int)(sp & 63);
-                const uint64_t msk = yy ? (~0ULL << (64 - yy)) : 0ULL;
-                const int64_t occ = (int64_t)pick4(c, b.w[0], b.w[1], b.w[2], b.w[3]) +
-                                    __popcll((uint64_t)pick4(c, b.w[4], b.w[5], b.w[6], b.w[7]) & msk);
-                sp = pick4(c, ix.count[0], ix.count[1], ix.count[2], ix.count[3]) + occ;
-                offset++;
-                if ((sp & 7) == 0) { pos_coord[mine] = ((int64_t)ix.sa_ms_byte[sp >> 3] << 32) + ix.sa_ls_word[sp >> 3] + offset; walk = false; }
-            }
-        }
-    }
-    if (n_lf_out) atomicAdd(n_lf_out, (unsigned long long)n_lf);
-}
-
+// (Measured in round 6 and not kept, profiles/r06ah_*: the lanes REFILLED from their wavefront's range of lookups -- a lookup is seven LF steps on average and
+//  forty for the unluckiest of a workgroup, so most of a wavefront's life a handful of its lanes walk -- 3.2-3.4 ms at 4..16 workgroups per CU against this
+//  kernel's 2.8: with one line per LANE the address translations bound the fetch, and 64 walking lanes per wavefront ask for more of them at once.)
 // The same walk, QUAD-COOPERATIVE like backward_ext: each lane still owns one lookup, but the CP_OCC entry a lane needs is fetched
 // by its quad -- lane b loads quarter b = {count[b], bwt[b]} -- so one load instruction touches 16 lines per wave instead of 64
 // (the address-translation rate, not HBM, caps one-line-per-lane access on an index of this size: tools/ubench/randline.hip).
@@ -1279,12 +1234,7 @@ int bm2_launch_sal_expand(bm2_ctx *c, const bm2_smem_t *smems, int64_t n_smem, c
 }
 int bm2_launch_sal(bm2_ctx *c, int64_t n, int64_t *pos_coord, unsigned long long *n_lf) {
     if (n <= 0) return BM2_OK;
-    // BM2_SAL_REFILL: lanes take the next lookup of their wavefront's range when theirs is done (k_sal_refill); BM2_SAL_BPC: its workgroups per CU
-    if (bm2_knob("BM2_SAL_REFILL", 1)) {
-        int64_t blocks = (int64_t)c->n_cu * bm2_knob("BM2_SAL_BPC", 8);
-        if (blocks > (n + 255) / 256) blocks = (n + 255) / 256;
-        hipLaunchKernelGGL(k_sal_refill, dim3((unsigned)blocks), dim3(256), 0, c->stream, c->ix, n, pos_coord, n_lf);
-    } else if (bm2_knob("BM2_SAL_QUAD", 0)) hipLaunchKernelGGL(k_sal_quad, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->ix, n, pos_coord, n_lf);
+    if (bm2_knob("BM2_SAL_QUAD", 0)) hipLaunchKernelGGL(k_sal_quad, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->ix, n, pos_coord, n_lf);
     else hipLaunchKernelGGL(k_sal, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->ix, n, pos_coord, n_lf);
     return bm2_check(hipGetLastError(), "k_sal launch");
 }
