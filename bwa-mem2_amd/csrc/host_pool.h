@@ -13,6 +13,7 @@
 #include <functional>
 #include <thread>
 #include <vector>
+#include <string>
 
 // Worker threads for the host side's short parallel phases (SAM tail, FASTQ parser).  A chunk goes through a dozen short phases, so what counts is how fast ALL workers get
 // going: a queue behind one mutex hands the lock from one woken thread to the next (each hand-over costs a scheduler wake-up: milliseconds
@@ -107,7 +108,12 @@ public:
         if (n - 1 > WANT_MASK) n = WANT_MASK + 1;
         while ((int)workers.size() < n - 1) {                     // (a worker starts out having "seen" the current generation)
             const int idx = (int)workers.size(); const uint32_t g = gen.load(std::memory_order_relaxed);
-            workers.emplace_back([this, idx, g]() { loop(idx, g); });
+            // (a worker is named after the thread it works for -- "<owner>-w": bench.py's per-thread CPU table of the FASTQ -> SAM leg tells the parser's pool from the tail workers' by it)
+            char nm[16] = "bm2";
+            if (pthread_getname_np(pthread_self(), nm, sizeof nm) != 0) { nm[0] = 'b'; nm[1] = 'm'; nm[2] = '2'; nm[3] = 0; }
+            nm[13] = 0;
+            const std::string wname = std::string(nm) + "-w";
+            workers.emplace_back([this, idx, g, wname]() { pthread_setname_np(pthread_self(), wname.c_str()); loop(idx, g); });
         }
         job = &f;
         left.store((uint32_t)(n - 1), std::memory_order_relaxed);

@@ -497,7 +497,35 @@ def end_to_end(ctx, bm2, texts, opt, paired, n_threads, n_tail=None, limit_s=Non
         with lock:
             stage[k] = stage.get(k, 0.0) + dt
 
+    roles = {}                                                    # native thread id -> stage worker (for the per-thread CPU table)
+
+    def name_thread(role, comm):
+        roles[threading.get_native_id()] = role
+        try:                                                      # (the library's pool workers are named after the thread they work for: host_pool.h)
+            import ctypes
+            ctypes.CDLL(None).prctl(15, comm.encode()[:15], 0, 0, 0)      # PR_SET_NAME
+        except Exception:                                         # noqa
+            pass
+
+    def thread_cpu():
+        """{tid: (comm, CPU seconds)} of every thread of this process (Linux: /proc/self/task/*/stat)"""
+        out, tck = {}, os.sysconf("SC_CLK_TCK")
+        try:
+            for tid in os.listdir("/proc/self/task"):
+                try:
+                    with open("/proc/self/task/%s/stat" % tid) as f:
+                        st = f.read()
+                    comm = st[st.index("(") + 1:st.rindex(")")]
+                    fld = st[st.rindex(")") + 2:].split()
+                    out[int(tid)] = (comm, (int(fld[11]) + int(fld[12])) / tck)
+                except (OSError, ValueError, IndexError):
+                    pass
+        except OSError:
+            pass
+        return out
+
     def reader():
+        name_thread("reader (parse calls)", "bm2-parse")
         try:
             n_before = 0
             for i, (t1, t2) in enumerate(work):
@@ -514,6 +542,7 @@ def end_to_end(ctx, bm2, texts, opt, paired, n_threads, n_tail=None, limit_s=Non
             q.put(None)
 
     def device(k):
+        name_thread("device worker", "bm2-device")
         c = devs[k]
         try:
             while True:
@@ -544,6 +573,7 @@ def end_to_end(ctx, bm2, texts, opt, paired, n_threads, n_tail=None, limit_s=Non
                 q.put(None)
 
     def tail(k):
+        name_thread("tail worker", "bm2-tail")
         buf = None
         try:
             while True:
@@ -597,10 +627,14 @@ def end_to_end(ctx, bm2, texts, opt, paired, n_threads, n_tail=None, limit_s=Non
         stage.clear()
     t0 = time.perf_counter()
     cpu0 = time.process_time()                                   # CPU seconds of every thread of this process (the stages' workers and the library's pools)
+    tc0 = thread_cpu()
+    tc_seen, tc_next = dict(tc0), [time.perf_counter() + 0.5]     # (threads leave with their stage: the table keeps the last reading of every thread, taken twice a second)
     go.set()
     for t in th:
         while t.is_alive():
             t.join(0.05)
+            if time.perf_counter() >= tc_next[0]:
+                tc_seen.update(thread_cpu()); tc_next[0] = time.perf_counter() + 0.5
             if err or expired():
                 break
         if err:
@@ -609,6 +643,13 @@ def end_to_end(ctx, bm2, texts, opt, paired, n_threads, n_tail=None, limit_s=Non
             raise TimeoutError("end-to-end leg not finished after %.0f s (stages so far: %s)" % (limit_s, {k: round(v, 1) for k, v in stage.items()}))
     dt = time.perf_counter() - t0
     cpu_s = time.process_time() - cpu0
+    tc_seen.update(thread_cpu())
+    tc1 = tc_seen
+    by_role = {}                                                  # CPU seconds per chunk by kind of thread: stage workers by role, the library's pools ("bm2-pool"), the rest by name
+    for tid, (comm, sec) in tc1.items():
+        d_sec = sec - tc0.get(tid, (comm, 0.0))[1]
+        role = roles.get(tid) or ("main thread" if tid == os.getpid() else comm)
+        r = by_role.setdefault(role, [0, 0.0]); r[0] += 1; r[1] += d_sec
     if err:
         raise err[0]
     for c in tails + devs[1:]:
@@ -646,6 +687,7 @@ def end_to_end(ctx, bm2, texts, opt, paired, n_threads, n_tail=None, limit_s=Non
             "host_cpus": hw, "host_threads_visible": os.cpu_count(), "parse_threads": n_parse, "device_workers": n_dev, "tail_workers": n_tail, "threads_per_tail_worker": so.n_threads,
             "stage_ms_per_chunk": {k: v / nch * 1e3 for k, v in stage.items()}, "chunk_check": check,
             # what the host side costs: CPU seconds of the whole process per timed chunk, and the chunk time that alone would allow on this host's cores
+            "host_cpu_s_per_chunk_by_thread_kind": {k: {"threads": v[0], "cpu_s_per_chunk": round(v[1] / nch, 4)} for k, v in sorted(by_role.items(), key=lambda kv: -kv[1][1]) if v[1] / nch >= 0.0005},
             "host_cpu_s_per_chunk": cpu_s / nch, "host_cpu_bound_ms_per_chunk": cpu_s / nch / max(hw, 1) * 1e3, "ms_per_chunk": dt / nch * 1e3,
             "scope": "FASTQ text in host memory -> bm2_fastq_parse_mt | H2D -> device pipeline incl. mem_sort_dedup_patch (a19) -> D2H | pairing / "
                      "mate rescue / CIGAR (device batches) / SAM text in host memory; one host thread per stage worker (%d device workers on contexts "
