@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 6: the FASTQ -> SAM leg with the process bound to the hardware threads next to its GPU (bench.py's default now) and not (--no-numa-bind), alternating processes.
+# Round 6 (a TRIAL build with bm2_device_local_cpus and --no-numa-bind, not kept: profiles/r06al_*): the FASTQ -> SAM leg with the process bound to the hardware threads next to its GPU (bench.py's default now) and not (--no-numa-bind), alternating processes.
 #   gpurun --timeout 1200 -- 'bash tools/gpu/run_r06_al.sh r06al 1150'
 TAG=${1:-r06al}; LIMIT=${2:-1150}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O
