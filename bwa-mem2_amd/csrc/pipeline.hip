@@ -365,7 +365,10 @@ static int batch_run_one(bm2_ctx *c, const bm2_opt *opt, StageGate *gate = nullp
     //  1.4x steps measured no better, 10.0, and were not kept)
     const int perm_mode = bm2_knob("BM2_PERM_MODE", 5);
     const int perm_mode_pf = bm2_knob("BM2_PERM_MODE_PF", 0);   // post-filter: read order
-    const int thr_sa = bm2_knob("BM2_HEAVY_SA", 100);           // reads with more SA coordinates go to k_chain_heavy (sweep: 40 -> 13.6 ms, 100 -> 12.1 ms)
+    // reads with more SA coordinates go to k_chain_heavy (round 3's sweep: 40 -> 13.6 ms, 100 -> 12.1 ms; with the lane kernel's reads in classes and the chains'
+    // extension tasks built by its lanes -- round 6 -- the two sides of the stage end together at 72..80: 100 -> 9.0-9.1 ms, 90 -> 8.7, 80 -> 7.9-8.6, 72 -> 8.3,
+    // 64 -> 8.5, 56 -> 8.8, 48 -> 9.1, 120 -> 9.3; profiles/r06ao_*, r06ap_*)
+    const int thr_sa = bm2_knob("BM2_HEAVY_SA", 80);
     const int64_t *n_heavy_chain = nullptr;                      // set when the permutation lists the seed-rich reads first: k_chain_heavy takes them
     const int chain_heavy = bm2_knob("BM2_CHAIN_HEAVY", 1);
     if (perm_mode == 5) { if ((rc = bm2_partition_by_class(c, n, (const int32_t *)b->n_sa_read.p, thr_sa, (int32_t *)b->perm.p, b->part_tmp, b->scan_tmp, chain_heavy ? &n_heavy_chain : nullptr))) return rc; }

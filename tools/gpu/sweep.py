@@ -27,9 +27,11 @@ GRID = [   # (name, candidates): a candidate is a dict of knobs set together; th
     ("seeding: workgroups per CU of k_bwd_cont", [{}, {"BM2_BWD_CONT_BPC": 4}, {"BM2_BWD_CONT_BPC": 8}]),
     ("chaining: the light reads in plain order (4) instead of 2x classes of seed count (5, the default)", [{}, {"BM2_PERM_MODE": 4}]),
     ("chaining: k_chain_finish's part by k_chain's lanes + one wavefront per seed-rich read (default) / by the lane-per-read kernel", [{}, {"BM2_CHAIN_FUSE_FINISH": 0}, {"BM2_CHAIN_FINISH_WAVE": 0}, {"BM2_CHAIN_FUSE_FINISH": 0, "BM2_CHAIN_FINISH_WAVE": 0}, {"BM2_CHAIN_FUSE_FINISH": 0, "BM2_CHAIN_FINISH_WAVE": 0, "BM2_CHAIN_FINISH_PERM": 0}]),
+    ("chaining: k_chain on the main stream (0) instead of a side stream of its own (1, the default)", [{}, {"BM2_CHAIN_MAIN_SIDE": 0}, {"BM2_CHAIN_MAIN_SIDE": 0, "BM2_HEAVY_SA": 80}, {"BM2_HEAVY_SA": 80}, {"BM2_HEAVY_SA": 120}]),
+    ("chaining AB: the tiers' knobs, the default measured between the candidates", [{}, {"BM2_CHAIN_HEAVY_WPE": 2}, {"BM2_PERM_MODE": 5}, {"BM2_CHAIN_WAVES_PER_CU": 8}, {"BM2_HEAVY_SA": 80}, {"BM2_CHAIN_TIER_MAX": 512}, {"BM2_CHAIN_COOP_FLT": 1}, {"BM2_PERM_MODE": 4}, {"BM2_CHAIN_MAIN_SIDE": 1}, {"BM2_CHAIN_HEAVY_WPE": 2, "BM2_CHAIN_WAVES_PER_CU": 8}, {"BM2_CHAIN_STAGE": 1}, {"BM2_CHAIN_HEAVY_WPE": 2, "BM2_CHAIN_TIER_MAX": 512}, {"BM2_CHAIN_FUSE_FINISH": 1}, {"BM2_CHAIN_HEAVY_WPE": 2, "BM2_PERM_MODE": 4}]),
     ("chain clock", [{}, {"BM2_CHAIN_CLOCK": 1}]),
     ("chain staging", [{}, {"BM2_CHAIN_STAGE": 1}]),
-    ("chain heavy threshold", [{}, {"BM2_HEAVY_SA": 64}, {"BM2_HEAVY_SA": 40}, {"BM2_HEAVY_SA": 24}, {"BM2_HEAVY_SA": 160}, {"BM2_HEAVY_SA": 256}, {"BM2_HEAVY_SA": 512}]),
+    ("chain heavy threshold", [{}, {"BM2_HEAVY_SA": 100}, {"BM2_HEAVY_SA": 72}, {"BM2_HEAVY_SA": 64}]),
     ("chain: seed-rich reads to the island kernel", [{}, {"BM2_CHAIN_TIER_MAX": 512}, {"BM2_CHAIN_TIER_MAX": 256}, {"BM2_CHAIN_TIER_MAX": 128}, {"BM2_CHAIN_TIER_MAX": 256, "BM2_HEAVY_SA": 160}]),
     ("chain waves per CU", [{}, {"BM2_CHAIN_WAVES_PER_CU": 32}, {"BM2_CHAIN_WAVES_PER_CU": 8}]),
     ("k_bwd LDS survivors / blocks per CU / waves per SIMD", [{}, {"BM2_BWD_LCAP": 8, "BM2_BWD_BLOCKS_PER_CU": 4}, {"BM2_BWD_LCAP": 6, "BM2_BWD_BLOCKS_PER_CU": 4},
