@@ -48,9 +48,9 @@ GRID = [   # (name, candidates): a candidate is a dict of knobs set together; th
     ("seeding pass 3 placement", [{}, {"BM2_P3_AT": 0}, {"BM2_P3_AT": 2}]),
     ("seeding: pass 3 workgroups per CU", [{}, {"BM2_P3_BPC": 2}, {"BM2_P3_BPC": 1}, {"BM2_P3_AT": 0, "BM2_P3_BPC": 1}, {"BM2_P3_AT": 0, "BM2_P3_BPC": 2}, {"BM2_P3_AT": 0, "BM2_P3_BPC": 3}]),
     ("SA lookup by quads", [{}, {"BM2_SAL_QUAD": 1}]),
-    ("sub-batches of the chunk on their own streams", [{}, {"BM2_N_SUB": 2}, {"BM2_N_SUB": 3}]),
     ("walk blocks per CU", [{}, {"BM2_WALK_BLOCKS_PER_CU": 6}, {"BM2_WALK_BLOCKS_PER_CU": 3}]),
     ("purge threshold", [{}, {"BM2_PF_HEAVY": 48}, {"BM2_PF_HEAVY": 12}]),
+    ("sub-batches of the chunk on their own streams", [{}, {"BM2_N_SUB": 2}, {"BM2_N_SUB": 3}]),      # (last: the parts stay in place once made)
 ]
 
 
