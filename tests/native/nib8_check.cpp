@@ -21,15 +21,15 @@ int main() {
                     if (((y >> (4 * i)) & 15) != (uint32_t)B[k + s * i]) bad++;
                 }
             }
-    // load4 on the same data (the extension kernels' loader)
-    for (int k = 0; k + 4 <= N; k++)
+    // load4 on the same data (the extension kernels' loader: elements (k + i) * s of the view, i = 0..3 -- a view that walks down starts at its last position)
+    for (int k = 0; k + 4 <= N - 8; k++)
         for (int s = -1; s <= 1; s += 2) {
-            if (s < 0 && k < 3) continue;
-            const RefPtr P{packed.data(), 0, 1}, B{bytes.data(), 0, 0};
+            const int at = s > 0 ? 0 : N - 9;
+            const RefPtr P{packed.data(), at, 1}, B{bytes.data(), at, 0};
             const uint32_t x = P.load4(k, s), y = B.load4(k, s);
             for (int i = 0; i < 4; i++, n += 2) {
-                if (((x >> (8 * i)) & 255) != (uint32_t)P[k + s * i]) bad++;
-                if (((y >> (8 * i)) & 255) != (uint32_t)B[k + s * i]) bad++;
+                if (((x >> (8 * i)) & 255) != (uint32_t)P[(int64_t)(k + i) * s]) bad++;
+                if (((y >> (8 * i)) & 255) != (uint32_t)B[(int64_t)(k + i) * s]) bad++;
             }
         }
     printf("checked %ld fields, %ld differ\n", n, bad);
