@@ -1490,8 +1490,11 @@ int bm2_launch_chain(bm2_ctx *c, const ChainParams &o, int n_reads, const int32_
         // reads with more seeds than the largest tier holds: a launch of their own where they are the norm (long reads), otherwise the last tier's
         const bool own_overflow = max_len >= bm2_knob("BM2_CHAIN_OVF_MIN_LEN", 1000);
         int lo = heavy_thr;
-        // BM2_CHAIN_TIER_MAX: tiers beyond it are left out and their reads -- the seed-richest -- go to the island kernel with the long reads
-        const int tier_max = bm2_knob("BM2_CHAIN_TIER_MAX", 1 << 30);
+        // BM2_CHAIN_TIER_MAX: tiers beyond it are left out and their reads -- the seed-richest -- go to the island kernel with the long reads.  Short-read chunks
+        // leave out the last tier (513..1000 seeds: a workgroup of it reserves a CU's whole LDS for one read) since the end of round 6: chaining 8.2 -> 7.8 ms in
+        // four adjacent pairs of one process and in three earlier sweeps (profiles/r06au_*, r06aq_*, r06ar_*); without the 257..512 tier as well: 8.4-8.6 (and
+        // 12.7-15.9 ms in round 4, r04j_sweep.json).  Long-read chunks keep all five (their reads are the island kernel's anyway, by `own_overflow`).
+        const int tier_max = bm2_knob("BM2_CHAIN_TIER_MAX", max_len < 1000 ? 512 : 1 << 30);
         const bool use_islands = own_overflow || caps[n_tiers - 1] > tier_max;
         for (int t = 0; t < n_tiers; t++) {
             if (caps[t] <= lo || caps[t] > tier_max) continue;

@@ -101,6 +101,7 @@ sets = [{}, {"BM2_EXT_WAVE_QMIN": 33, "BM2_EXT_REVERSE": 1}, {"BM2_EXT_WAVE_QMIN
         {"BM2_PERM_MODE": 4}, {"BM2_PERM_MODE": 5, "BM2_HEAVY_SA": 6}, {"BM2_PERM_MODE": 2, "BM2_HEAVY_SA": 30},      # chaining's read order: heavy first and plain / classes of seed count (default) / by histogram
         {"BM2_CHAIN_FUSE_FINISH": 0}, {"BM2_CHAIN_FUSE_FINISH": 0, "BM2_CHAIN_FINISH_PERM": 0, "BM2_CHAIN_FINISH_WAVE": 0}, {"BM2_CHAIN_FUSE_FINISH": 1, "BM2_HEAVY_SA": 4, "BM2_CHAIN_FINISH_PERM": 0},
         {"BM2_CHAIN_FINISH_WAVE": 0, "BM2_HEAVY_SA": 6}, {"BM2_CHAIN_FUSE_FINISH": 0, "BM2_HEAVY_SA": 3},   # k_chain_finish's part by k_chain's lanes (default) / by the kernel
+        {"BM2_CHAIN_TIER_MAX": 1000000, "BM2_HEAVY_SA": 3}, {"BM2_CHAIN_TIER_MAX": 64, "BM2_HEAVY_SA": 3},      # every LDS tier (the routing until round 6) / the seed-rich reads to the island kernel
         {"BM2_EXT_REG_QMIN": 80}, {"BM2_EXT_REG_QMIN": 0}]       # rows in registers (lane_dp8r) for every class that has the kernel / for none (default: the 128-column class)
 for kn in sets:
     for k in [k for k in os.environ if k.startswith("BM2_")]:

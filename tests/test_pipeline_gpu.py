@@ -152,7 +152,7 @@ KNOB_SETTINGS = [
     {"BM2_EXT_REG_QMIN": "80"}, {"BM2_EXT_REG_QMIN": "0"}, {"BM2_KSW_REG": "0"},
     {"BM2_PERM_MODE": "4"}, {"BM2_PERM_MODE": "2"}, {"BM2_PERM_MODE": "5", "BM2_HEAVY_SA": "64"},
     {"BM2_CHAIN_FUSE_FINISH": "0"}, {"BM2_CHAIN_FUSE_FINISH": "0", "BM2_CHAIN_FINISH_PERM": "0", "BM2_CHAIN_FINISH_WAVE": "0"}, {"BM2_CHAIN_FINISH_PERM": "0", "BM2_HEAVY_SA": "8"},
-    {"BM2_CHAIN_FINISH_WAVE": "0"},
+    {"BM2_CHAIN_FINISH_WAVE": "0"}, {"BM2_CHAIN_TIER_MAX": "1000000"}, {"BM2_CHAIN_TIER_MAX": "128", "BM2_HEAVY_SA": "100"},
 ]
 
 
