@@ -30,6 +30,7 @@ GRID = [   # (name, candidates): a candidate is a dict of knobs set together; th
     ("chaining: k_chain on the main stream (0) instead of a side stream of its own (1, the default)", [{}, {"BM2_CHAIN_MAIN_SIDE": 0}, {"BM2_CHAIN_MAIN_SIDE": 0, "BM2_HEAVY_SA": 80}, {"BM2_HEAVY_SA": 80}, {"BM2_HEAVY_SA": 120}]),
     ("chaining AB: the tiers' knobs, the default measured between the candidates", [{}, {"BM2_CHAIN_HEAVY_WPE": 2}, {"BM2_PERM_MODE": 5}, {"BM2_CHAIN_WAVES_PER_CU": 8}, {"BM2_HEAVY_SA": 80}, {"BM2_CHAIN_TIER_MAX": 512}, {"BM2_CHAIN_COOP_FLT": 1}, {"BM2_PERM_MODE": 4}, {"BM2_CHAIN_MAIN_SIDE": 1}, {"BM2_CHAIN_HEAVY_WPE": 2, "BM2_CHAIN_WAVES_PER_CU": 8}, {"BM2_CHAIN_STAGE": 1}, {"BM2_CHAIN_HEAVY_WPE": 2, "BM2_CHAIN_TIER_MAX": 512}, {"BM2_CHAIN_FUSE_FINISH": 1}, {"BM2_CHAIN_HEAVY_WPE": 2, "BM2_PERM_MODE": 4}]),
     ("chaining AB2: reads beyond 512 seeds to the island kernel, the default measured between", [{}, {"BM2_CHAIN_TIER_MAX": 512}, {"BM2_CHAIN_COOP_FLT": 1}, {"BM2_CHAIN_TIER_MAX": 512}, {"BM2_CHAIN_STAGE": 1}, {"BM2_CHAIN_TIER_MAX": 512}, {"BM2_PERM_MODE": 5}, {"BM2_CHAIN_TIER_MAX": 512}, {"BM2_HEAVY_SA": 80}, {"BM2_CHAIN_TIER_MAX": 512}, {"BM2_CHAIN_MAIN_SIDE": 1}, {"BM2_CHAIN_TIER_MAX": 256}, {"BM2_CHAIN_FUSE_FINISH": 1}, {"BM2_CHAIN_TIER_MAX": 256}]),
+    ("AB3: seeding / extension knobs, the default measured between", [{}, {"BM2_BWD_HEAVY_WG": 8}, {"BM2_PERM_MODE": 5}, {"BM2_BWD_EXPORT_AGE": 160}, {"BM2_HEAVY_SA": 80}, {"BM2_BWD_HEAVY_WG": 8}, {"BM2_CHAIN_STAGE": 1}, {"BM2_BWD_EXPORT_AGE": 160}, {"BM2_CHAIN_COOP_FLT": 1}, {"BM2_EXT_PEND_DIV": 6}, {"BM2_CHAIN_MAIN_SIDE": 1}, {"BM2_EXT_PEND_DIV": 6}, {"BM2_CHAIN_FUSE_FINISH": 1}, {"BM2_BWD_HEAVY_WG": 8, "BM2_BWD_EXPORT_AGE": 160}, {"BM2_CHAIN_FINISH_WAVE": 1}, {"BM2_BWD_HEAVY_WG": 8, "BM2_BWD_EXPORT_AGE": 160}]),
     ("chain clock", [{}, {"BM2_CHAIN_CLOCK": 1}]),
     ("chain staging", [{}, {"BM2_CHAIN_STAGE": 1}]),
     ("chain heavy threshold", [{}, {"BM2_HEAVY_SA": 100}, {"BM2_HEAVY_SA": 72}, {"BM2_HEAVY_SA": 64}]),
